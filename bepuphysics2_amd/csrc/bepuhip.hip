@@ -1,0 +1,791 @@
+// libbepuhip — MI355X (gfx950) native constraint solver + pose integrator behind the C ABI of include/bepuhip.h.
+//
+// Data layout in HBM
+//   bodies        : the reference's BodyDynamics AoS, 128 B per body = 8 x float4 (BodyProperties.cs:318-338):
+//                   [0] orientation xyzw  [1] position xyz  [2] linear xyz  [3] angular xyz
+//                   [4..5] local inverse inertia {xx,yx,yy,zx | zy,zz,invMass}  [6..7] world inverse inertia.
+//                   One 128-byte line per gathered body; every access is a 16-byte vector load/store.
+//   type batches  : per (batch, type) SoA slabs — refs[slot][stride], prestep[field][stride], accumulated[field][stride],
+//                   stride = count rounded up to 64 lanes, so lane i of a wavefront reads consecutive dwords (coalesced 256 B/wave/field).
+//                   Converted from the host's AOSOA (BundleIndexing.cs:50-60) on upload and back on download.
+// Schedule (no host sync inside a frame; replayed from a hipGraph):
+//   per substep: [incremental contact update, all batches, one launch] -> [integrate constrained bodies, one launch]
+//                -> warm start: one launch per batch (all constraint types of the batch in one grid)
+//                -> velocity iterations: one launch per batch per iteration
+//   then one final pose-integration launch over all bodies.
+// Integration is hoisted out of the first-touching constraint's warm start into the per-substep body kernel; SURVEY.md A.2
+// gives the argument that this is value-identical (nothing reads a body between its integration and its first constraint).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bepuhip.h"
+#include "bepu_device_constraints.h"
+
+#pragma clang fp contract(off)
+
+using namespace bd;
+
+// ------------------------------------------------------------------------------------------------
+// Device side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr unsigned kDynamicLimit = 1u << 30;  // Bodies_GatherScatter.cs:107-118
+constexpr int kRefMask = 0x3FFFFFFF;
+constexpr int kBlock = 64;  // one wavefront per workgroup: a batch rarely fills the chip, so spread waves over as many CUs as possible
+
+struct DevTypeBatch {
+    int type_id, count, stride, block_begin;
+    int* refs;
+    float* prestep;
+    float* accum;
+};
+
+struct StepParams {
+    float dt, inv_dt;
+    float gx, gy, gz;  // gravity * dt
+    float lin_damp, ang_damp;
+};
+
+struct DBody {
+    V3 pos; Q ori; BodyVel vel; Inertia inertia;
+    float linw, angw;  // padding lanes of the velocity float4s, preserved on store
+};
+
+template <int ACCESS>
+__device__ __forceinline__ void load_body(const float4* __restrict__ bodies, int ref, DBody& b) {
+    const float4* base = bodies + (size_t)(ref & kRefMask) * 8;
+    if (ACCESS & kOri) { float4 q = base[0]; b.ori = {q.x, q.y, q.z, q.w}; } else b.ori = {0, 0, 0, 0};
+    if (ACCESS & kPos) { float4 p = base[1]; b.pos = {p.x, p.y, p.z}; } else b.pos = {0, 0, 0};
+    if (ACCESS & kLin) { float4 l = base[2]; b.vel.lin = {l.x, l.y, l.z}; b.linw = l.w; } else { b.vel.lin = {0, 0, 0}; b.linw = 0; }
+    if (ACCESS & kAng) { float4 a = base[3]; b.vel.ang = {a.x, a.y, a.z}; b.angw = a.w; } else { b.vel.ang = {0, 0, 0}; b.angw = 0; }
+    if (ACCESS & kInertia) {
+        float4 i0 = base[6], i1 = base[7];
+        b.inertia.t = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+        b.inertia.invMass = i1.z;
+    } else { b.inertia.t = {0, 0, 0, 0, 0, 0}; b.inertia.invMass = 0; }
+}
+// ScatterVelocities: kinematic / empty references are never written (Bodies_GatherScatter.cs:675-682,717-724).
+template <int ACCESS>
+__device__ __forceinline__ void store_velocity(float4* bodies, int ref, const DBody& b) {
+    if ((unsigned)ref >= kDynamicLimit) return;
+    float4* base = bodies + (size_t)ref * 8;
+    if (ACCESS & kLin) base[2] = make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, b.linw);
+    if (ACCESS & kAng) base[3] = make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, b.angw);
+}
+
+enum { kStageWarmStart = 0, kStageSolve = 1, kStageIncremental = 2 };
+
+template <class F, int STAGE>
+__device__ __forceinline__ void run_constraint(const DevTypeBatch& tb, int i, float4* bodies, float dt, float inv_dt) {
+    const int stride = tb.stride;
+    const int refA = tb.refs[i];
+    const int refB = (F::bodies == 2) ? tb.refs[stride + i] : -1;
+    float p[F::prestepFloats];
+    _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = tb.prestep[(size_t)f * stride + i];
+    DBody A, B;
+    if (STAGE == kStageIncremental) {
+        load_body<kAccessOnlyVelocity>(bodies, refA, A);
+        if (F::bodies == 2) load_body<kAccessOnlyVelocity>(bodies, refB, B); else load_body<0>(bodies, 0, B);
+        F::incrementalUpdate(dt, A.vel, B.vel, p);
+        // Only the contact depths change (PenetrationLimit.cs:42): prestep rows 4*c+3, c < contact count.
+        if constexpr (F::incremental) {
+            _Pragma("unroll") for (int cidx = 0; cidx < F::impulseFloats - 3; ++cidx) tb.prestep[(size_t)(4 * cidx + 3) * stride + i] = p[4 * cidx + 3];
+        }
+        return;
+    }
+    float a[F::impulseFloats];
+    _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = tb.accum[(size_t)f * stride + i];
+    constexpr int accA = (STAGE == kStageWarmStart) ? F::wsA : F::svA;
+    constexpr int accB = (STAGE == kStageWarmStart) ? F::wsB : F::svB;
+    load_body<accA>(bodies, refA, A);
+    if (F::bodies == 2) load_body<accB>(bodies, refB, B); else load_body<0>(bodies, 0, B);
+    if (STAGE == kStageWarmStart) {
+        F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel);
+    } else {
+        F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel);
+        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) tb.accum[(size_t)f * stride + i] = a[f];
+    }
+    store_velocity<accA>(bodies, refA, A);
+    if (F::bodies == 2) store_velocity<accB>(bodies, refB, B);
+}
+
+// One grid per (batch, stage): the block index selects the type batch, the type id (wave-uniform) selects the function.
+// Graph colouring guarantees that no dynamic body is referenced twice inside a batch (Solver.cs:1046-1051), so no two lanes of
+// the grid write the same body and results do not depend on lane order.
+template <int STAGE>
+__global__ __launch_bounds__(kBlock) void batch_kernel(const DevTypeBatch* __restrict__ tbs, int tb_begin, int tb_count, float4* bodies, float dt, float inv_dt) {
+    const int b = blockIdx.x;
+    int t = tb_begin;
+    for (int k = 1; k < tb_count; ++k)
+        if (b >= tbs[tb_begin + k].block_begin) t = tb_begin + k;
+    const DevTypeBatch tb = tbs[t];
+    const int i = (b - tb.block_begin) * kBlock + threadIdx.x;
+    if (i >= tb.count) return;
+    switch (tb.type_id) {
+        case kContact1OneBody: run_constraint<Contact<1, false>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact2OneBody: run_constraint<Contact<2, false>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact3OneBody: run_constraint<Contact<3, false>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact4OneBody: run_constraint<Contact<4, false>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact1: run_constraint<Contact<1, true>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact2: run_constraint<Contact<2, true>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact3: run_constraint<Contact<3, true>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact4: run_constraint<Contact<4, true>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        default: break;
+    }
+    if (STAGE == kStageIncremental) return;  // only contacts need incremental updates (RequiresIncrementalSubstepUpdates)
+    switch (tb.type_id) {
+        case kBallSocket: run_constraint<BallSocket, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kAngularHinge: run_constraint<AngularHinge, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kSwingLimit: run_constraint<SwingLimit, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kTwistServo: run_constraint<TwistServo, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kTwistLimit: run_constraint<TwistLimit, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kAngularMotor: run_constraint<AngularMotor, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kSwivelHinge: run_constraint<SwivelHinge, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kHinge: run_constraint<Hinge, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        default: break;
+    }
+}
+
+// Body flag bits (per body index).
+enum { kFlagConstrained = 1, kFlagDynamicConstrained = 2, kFlagConstrainedKinematic = 4 };
+
+// Device-side equivalent of the merged constrained-body set of PrepareConstraintIntegrationResponsibilities
+// (Solver_Solve.cs:1198-1207,1378-1381): every body referenced as dynamic gets integration inside the solver.
+__global__ void mark_constrained_kernel(const int* __restrict__ refs, int count, int stride, int bodies_per_constraint, unsigned* flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    for (int k = 0; k < bodies_per_constraint; ++k) {
+        int ref = refs[(size_t)k * stride + i];
+        if (ref < 0) continue;
+        // dynamic reference -> integrated inside the solver; kinematic reference -> member of Solver.ConstrainedKinematicHandles (Solver.cs:68)
+        unsigned bits = kFlagConstrained | (((unsigned)ref < kDynamicLimit) ? kFlagDynamicConstrained : kFlagConstrainedKinematic);
+        atomicOr(&flags[ref & kRefMask], bits);
+    }
+}
+__global__ void mark_kinematic_kernel(const int* __restrict__ indices, int count, unsigned* flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) atomicOr(&flags[indices[i]], (unsigned)(kFlagConstrainedKinematic | kFlagConstrained));
+}
+
+__device__ __forceinline__ void velocity_callback(const StepParams& sp, BodyVel& v) {  // Demos/DemoCallbacks.cs:100-109
+    V3 g = {sp.gx, sp.gy, sp.gz};
+    v.lin = scale(add(v.lin, g), sp.lin_damp);
+    v.ang = scale(v.ang, sp.ang_damp);
+}
+
+// Per-substep integration of every constrained body — the work the reference fuses into the first-touching constraint's
+// warm start (TypeProcessor.cs:1204-1283) plus the kinematic prepass (PoseIntegrator.cs:451-535).
+// substep 0: velocity only; substep > 0: pose, then velocity. World inverse inertia is refreshed either way.
+__global__ __launch_bounds__(256) void substep_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, int integrate_pose,
+                                                                 int integrate_velocity_for_kinematics, StepParams sp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    unsigned f = flags[i];
+    float4* base = bodies + (size_t)i * 8;
+    if (f & kFlagDynamicConstrained) {
+        float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3], i0 = base[4], i1 = base[5];
+        Q ori = {q4.x, q4.y, q4.z, q4.w};
+        V3 pos = {p4.x, p4.y, p4.z};
+        BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+        Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+        if (integrate_pose) {
+            pos = add(pos, scale(vel.lin, sp.dt));                      // TypeProcessor.cs:1217
+            ori = integrateOrientation(ori, vel.ang, sp.dt * 0.5f);     // :1240
+            base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+            base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+        }
+        Sym3 world = rotateInverseInertia(local, ori);                  // :1242 / :1262
+        velocity_callback(sp, vel);                                     // :1244 / :1273-1281
+        base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+        base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+        base[6] = make_float4(world.xx, world.yx, world.yy, world.zx);
+        base[7] = make_float4(world.zy, world.zz, i1.z, base[7].w);
+    } else if (f & kFlagConstrainedKinematic) {
+        float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
+        Q ori = {q4.x, q4.y, q4.z, q4.w};
+        V3 pos = {p4.x, p4.y, p4.z};
+        BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+        if (integrate_pose) {                                           // PoseIntegrator.cs:519-523
+            pos = add(pos, scale(vel.lin, sp.dt));
+            ori = integrateOrientation(ori, vel.ang, sp.dt * 0.5f);
+            base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+            base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+        }
+        if (integrate_velocity_for_kinematics) {                        // :524-529, :481-485
+            velocity_callback(sp, vel);
+            base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+            base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+        }
+    }
+}
+
+// PoseIntegrator.IntegrateBundlesAfterSubstepping (PoseIntegrator.cs:537-693), one lane per body.
+__global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, float dt, float substep_dt, int substep_count,
+                                                               int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, StepParams sp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float4* base = bodies + (size_t)i * 8;
+    const bool unconstrained = !(flags[i] & kFlagConstrained);
+    const float effective_dt = allow_substeps_for_unconstrained ? substep_dt : (unconstrained ? dt : substep_dt);  // :591-599
+    const float half_dt = effective_dt * 0.5f;
+    float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
+    Q ori = {q4.x, q4.y, q4.z, q4.w};
+    V3 pos = {p4.x, p4.y, p4.z};
+    BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+    if (unconstrained) {
+        float4 i0 = base[4], i1 = base[5];
+        const bool is_kinematic = i0.x == 0 && i0.y == 0 && i0.z == 0 && i0.w == 0 && i1.x == 0 && i1.y == 0 && i1.z == 0;  // Bodies.cs:326-349
+        const bool velocity_mask = integrate_velocity_for_kinematics ? true : !is_kinematic;                                // :604-616
+        const int steps = allow_substeps_for_unconstrained ? substep_count : 1;
+        for (int s = 0; s < steps; ++s) {
+            if (velocity_mask) velocity_callback(sp, vel);   // velocity -> pose for unconstrained bodies (:634-667)
+            pos = add(pos, scale(vel.lin, effective_dt));
+            ori = integrateOrientation(ori, vel.ang, half_dt);
+        }
+        if (velocity_mask) {
+            base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+            base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+        }
+    } else {
+        ori = integrateOrientation(ori, vel.ang, half_dt);   // :684-691
+        pos = add(pos, scale(vel.lin, effective_dt));
+    }
+    base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+    base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int32_t fail(int32_t code, const std::string& msg) { g_last_error = msg; return code; }
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return fail(BEPUHIP_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+using C1O = Contact<1, false>; using C2O = Contact<2, false>; using C3O = Contact<3, false>; using C4O = Contact<4, false>;
+using C1T = Contact<1, true>; using C2T = Contact<2, true>; using C3T = Contact<3, true>; using C4T = Contact<4, true>;
+struct TypeInfoH { int bodies, prestep, impulse; bool incremental; };
+static bool type_info(int id, TypeInfoH& t) {
+#define TI(T) { t = {T::bodies, T::prestepFloats, T::impulseFloats, T::incremental}; return true; }
+    switch (id) {
+        case kContact1OneBody: TI(C1O) case kContact2OneBody: TI(C2O)
+        case kContact3OneBody: TI(C3O) case kContact4OneBody: TI(C4O)
+        case kContact1: TI(C1T) case kContact2: TI(C2T)
+        case kContact3: TI(C3T) case kContact4: TI(C4T)
+        case kBallSocket: TI(BallSocket) case kAngularHinge: TI(AngularHinge) case kSwingLimit: TI(SwingLimit)
+        case kTwistServo: TI(TwistServo) case kTwistLimit: TI(TwistLimit) case kAngularMotor: TI(AngularMotor)
+        case kSwivelHinge: TI(SwivelHinge) case kHinge: TI(Hinge)
+    }
+#undef TI
+    return false;
+}
+
+struct HostTypeBatch {
+    int batch, type_id, count, stride;
+    TypeInfoH info;
+    size_t refs_off, prestep_off, accum_off;  // offsets (in 4-byte words) into the constraint slab
+    std::vector<int32_t> refs_soa;
+    std::vector<float> prestep_soa, accum_soa;  // host staging until end_constraints
+};
+
+struct GraphKey {
+    std::vector<int> iterations;
+    float dt;
+    bepuhip_integrator integ;
+    bool operator<(const GraphKey& o) const {
+        if (iterations != o.iterations) return iterations < o.iterations;
+        if (dt != o.dt) return dt < o.dt;
+        return memcmp(&integ, &o.integ, sizeof(integ)) < 0;
+    }
+};
+
+struct bepuhip_ctx {
+    int device = 0, W = 8, flags = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    float4* d_bodies = nullptr;
+    float4* d_bodies0 = nullptr;  // pristine snapshot for reset_state
+    unsigned* d_flags = nullptr;
+    int body_count = 0, body_capacity = 0;
+    int* d_kin = nullptr;
+    int kin_count = 0;
+    std::vector<int32_t> kin_indices;
+    // constraints
+    bool building = false, built = false;
+    int batch_count = 0;
+    std::vector<HostTypeBatch> tbs;
+    std::vector<int> batch_begin;        // tbs index of each batch's first type batch (size batch_count+1)
+    std::vector<int> batch_blocks;       // grid size per batch
+    uint32_t* d_slab = nullptr;          // all refs/prestep/accum
+    uint32_t* d_slab0 = nullptr;         // pristine snapshot
+    size_t slab_words = 0;
+    DevTypeBatch* d_tbs = nullptr;       // per (batch) descriptors, solve/warm-start grids
+    DevTypeBatch* d_inc_tbs = nullptr;   // incremental-update grid (contacts of all batches)
+    int inc_tb_count = 0, inc_blocks = 0;
+    int64_t total_constraints = 0;
+    // measurement
+    float last_ms = 0;
+    int64_t last_constraint_iterations = 0;
+    bool profiling = false;
+    float prof_ms[5] = {0, 0, 0, 0, 0};
+    int prof_launches[5] = {0, 0, 0, 0, 0};
+    std::map<GraphKey, hipGraphExec_t> graphs;
+};
+
+static void free_constraints(bepuhip_ctx* c) {
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+    if (c->d_slab) hipFree(c->d_slab);
+    if (c->d_slab0) hipFree(c->d_slab0);
+    if (c->d_tbs) hipFree(c->d_tbs);
+    if (c->d_inc_tbs) hipFree(c->d_inc_tbs);
+    c->d_slab = c->d_slab0 = nullptr;
+    c->d_tbs = c->d_inc_tbs = nullptr;
+    c->tbs.clear();
+    c->built = false;
+}
+
+extern "C" {
+
+const char* bepuhip_last_error(void) { return g_last_error.c_str(); }
+
+int32_t bepuhip_type_info(int32_t type_id, int32_t* bodies, int32_t* prestep_floats, int32_t* impulse_floats) {
+    TypeInfoH t;
+    if (!type_info(type_id, t)) return fail(BEPUHIP_E_UNSUPPORTED, "unknown constraint type id " + std::to_string(type_id));
+    if (bodies) *bodies = t.bodies;
+    if (prestep_floats) *prestep_floats = t.prestep;
+    if (impulse_floats) *impulse_floats = t.impulse;
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx) {
+    if (!config || !out_ctx) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    if (config->bundle_width != 4 && config->bundle_width != 8 && config->bundle_width != 16)
+        return fail(BEPUHIP_E_INVALID_ARGUMENT, "bundle_width must be 4, 8 or 16");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(BEPUHIP_E_DEVICE, "no HIP device available (the bepuhip product path has no CPU fallback)");
+    if (config->device_ordinal < 0 || config->device_ordinal >= n) return fail(BEPUHIP_E_INVALID_ARGUMENT, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(config->device_ordinal));
+    bepuhip_ctx* c = new bepuhip_ctx();
+    c->device = config->device_ordinal;
+    c->W = config->bundle_width;
+    c->flags = config->flags;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev_start));
+    HIP_TRY(hipEventCreate(&c->ev_stop));
+    *out_ctx = c;
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_destroy(bepuhip_ctx* c) {
+    if (!c) return BEPUHIP_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_constraints(c);
+    if (c->d_bodies) hipFree(c->d_bodies);
+    if (c->d_bodies0) hipFree(c->d_bodies0);
+    if (c->d_flags) hipFree(c->d_flags);
+    if (c->d_kin) hipFree(c->d_kin);
+    hipEventDestroy(c->ev_start);
+    hipEventDestroy(c->ev_stop);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return BEPUHIP_OK;
+}
+
+static int32_t rebuild_flags(bepuhip_ctx* c) {
+    if (!c->d_flags || c->body_count == 0) return BEPUHIP_OK;
+    HIP_TRY(hipMemsetAsync(c->d_flags, 0, (size_t)c->body_count * 4, c->stream));
+    if (c->built) {
+        for (auto& tb : c->tbs) {
+            if (tb.count == 0) continue;
+            int blocks = (tb.count + 255) / 256;
+            hipLaunchKernelGGL(mark_constrained_kernel, dim3(blocks), dim3(256), 0, c->stream, (const int*)(c->d_slab + tb.refs_off), tb.count, tb.stride, tb.info.bodies, c->d_flags);
+        }
+    }
+    if (c->kin_count > 0) {
+        hipLaunchKernelGGL(mark_kinematic_kernel, dim3((c->kin_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_kin, c->kin_count, c->d_flags);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_set_bodies(bepuhip_ctx* c, const void* aos, int32_t count) {
+    if (!c || (!aos && count > 0) || count < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad bodies argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (count > c->body_capacity) {
+        if (c->d_bodies) hipFree(c->d_bodies);
+        if (c->d_bodies0) hipFree(c->d_bodies0);
+        if (c->d_flags) hipFree(c->d_flags);
+        c->d_bodies = c->d_bodies0 = nullptr; c->d_flags = nullptr;
+        HIP_TRY(hipMalloc((void**)&c->d_bodies, (size_t)count * 128));
+        HIP_TRY(hipMalloc((void**)&c->d_bodies0, (size_t)count * 128));
+        HIP_TRY(hipMalloc((void**)&c->d_flags, (size_t)count * 4));
+        c->body_capacity = count;
+    }
+    const bool count_changed = count != c->body_count;
+    c->body_count = count;
+    if (count > 0) {
+        HIP_TRY(hipMemcpyAsync(c->d_bodies, aos, (size_t)count * 128, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_bodies0, c->d_bodies, (size_t)count * 128, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (count_changed) return rebuild_flags(c);
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_begin_constraints(bepuhip_ctx* c, int32_t batch_count, int32_t fallback_batch_threshold) {
+    if (!c || batch_count < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad batch count");
+    if (batch_count > fallback_batch_threshold)
+        return fail(BEPUHIP_E_UNSUPPORTED, "a sequential fallback batch exists (batch_count > FallbackBatchThreshold); use simulation.Solve");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStreamSynchronize(c->stream);
+    free_constraints(c);
+    c->batch_count = batch_count;
+    c->building = true;
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type_id, int32_t count, const int32_t* refs, const float* prestep, const float* accum) {
+    if (!c || !c->building) return fail(BEPUHIP_E_STATE, "set_type_batch outside begin/end");
+    if (batch_index < 0 || batch_index >= c->batch_count || count < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad batch index or count");
+    if (!c->tbs.empty() && batch_index < c->tbs.back().batch) return fail(BEPUHIP_E_INVALID_ARGUMENT, "type batches must be supplied in batch order");
+    if (count > 0 && (!refs || !prestep || !accum)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null buffer");
+    HostTypeBatch tb;
+    if (!type_info(type_id, tb.info)) return fail(BEPUHIP_E_UNSUPPORTED, "unknown constraint type id " + std::to_string(type_id));
+    tb.batch = batch_index; tb.type_id = type_id; tb.count = count;
+    tb.stride = ((count + 63) / 64) * 64;
+    const int W = c->W;
+    const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
+    tb.refs_soa.assign((size_t)nb * tb.stride, -1);
+    tb.prestep_soa.assign((size_t)pf * tb.stride, 0.0f);
+    tb.accum_soa.assign((size_t)imf * tb.stride, 0.0f);
+    for (int i = 0; i < count; ++i) {  // AOSOA -> SoA (BundleIndexing.cs:50-60, TypeProcessor.cs:269-279)
+        const size_t bundle = (size_t)(i / W), lane = (size_t)(i % W);
+        for (int k = 0; k < nb; ++k) {
+            int32_t r = refs[bundle * nb * W + (size_t)k * W + lane];
+            if (r < 0) return fail(BEPUHIP_E_UNSUPPORTED, "empty (-1) body reference inside a type batch: sequential fallback layout is not supported");
+            tb.refs_soa[(size_t)k * tb.stride + i] = r;
+        }
+        for (int f = 0; f < pf; ++f) tb.prestep_soa[(size_t)f * tb.stride + i] = prestep[bundle * pf * W + (size_t)f * W + lane];
+        for (int f = 0; f < imf; ++f) tb.accum_soa[(size_t)f * tb.stride + i] = accum[bundle * imf * W + (size_t)f * W + lane];
+    }
+    c->tbs.push_back(std::move(tb));
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
+    if (!c || !c->building) return fail(BEPUHIP_E_STATE, "end_constraints without begin");
+    HIP_TRY(hipSetDevice(c->device));
+    c->building = false;
+    size_t words = 0;
+    c->total_constraints = 0;
+    for (auto& tb : c->tbs) {
+        tb.refs_off = words; words += tb.refs_soa.size();
+        tb.prestep_off = words; words += tb.prestep_soa.size();
+        tb.accum_off = words; words += tb.accum_soa.size();
+        c->total_constraints += tb.count;
+    }
+    c->slab_words = words;
+    if (words > 0) {
+        HIP_TRY(hipMalloc((void**)&c->d_slab, words * 4));
+        HIP_TRY(hipMalloc((void**)&c->d_slab0, words * 4));
+        std::vector<uint32_t> host(words);
+        for (auto& tb : c->tbs) {
+            if (!tb.refs_soa.empty()) memcpy(&host[tb.refs_off], tb.refs_soa.data(), tb.refs_soa.size() * 4);
+            if (!tb.prestep_soa.empty()) memcpy(&host[tb.prestep_off], tb.prestep_soa.data(), tb.prestep_soa.size() * 4);
+            if (!tb.accum_soa.empty()) memcpy(&host[tb.accum_off], tb.accum_soa.data(), tb.accum_soa.size() * 4);
+            std::vector<int32_t>().swap(tb.refs_soa);
+            std::vector<float>().swap(tb.prestep_soa);
+            std::vector<float>().swap(tb.accum_soa);
+        }
+        HIP_TRY(hipMemcpy(c->d_slab, host.data(), words * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_slab0, c->d_slab, words * 4, hipMemcpyDeviceToDevice));
+    }
+    // Descriptors: per batch grid layout.
+    c->batch_begin.assign(c->batch_count + 1, 0);
+    c->batch_blocks.assign(c->batch_count, 0);
+    std::vector<DevTypeBatch> descs(c->tbs.size()), inc;
+    {
+        size_t t = 0;
+        for (int b = 0; b < c->batch_count; ++b) {
+            c->batch_begin[b] = (int)t;
+            int blocks = 0;
+            while (t < c->tbs.size() && c->tbs[t].batch == b) {
+                auto& tb = c->tbs[t];
+                DevTypeBatch d;
+                d.type_id = tb.type_id; d.count = tb.count; d.stride = tb.stride; d.block_begin = blocks;
+                d.refs = (int*)(c->d_slab + tb.refs_off);
+                d.prestep = (float*)(c->d_slab + tb.prestep_off);
+                d.accum = (float*)(c->d_slab + tb.accum_off);
+                descs[t] = d;
+                blocks += (tb.count + kBlock - 1) / kBlock;
+                ++t;
+            }
+            c->batch_blocks[b] = blocks;
+        }
+        c->batch_begin[c->batch_count] = (int)t;
+    }
+    c->inc_blocks = 0;
+    for (size_t t = 0; t < c->tbs.size(); ++t) {
+        if (!c->tbs[t].info.incremental || c->tbs[t].count == 0) continue;
+        DevTypeBatch d = descs[t];
+        d.block_begin = c->inc_blocks;
+        c->inc_blocks += (c->tbs[t].count + kBlock - 1) / kBlock;
+        inc.push_back(d);
+    }
+    c->inc_tb_count = (int)inc.size();
+    if (!descs.empty()) {
+        HIP_TRY(hipMalloc((void**)&c->d_tbs, descs.size() * sizeof(DevTypeBatch)));
+        HIP_TRY(hipMemcpy(c->d_tbs, descs.data(), descs.size() * sizeof(DevTypeBatch), hipMemcpyHostToDevice));
+    }
+    if (!inc.empty()) {
+        HIP_TRY(hipMalloc((void**)&c->d_inc_tbs, inc.size() * sizeof(DevTypeBatch)));
+        HIP_TRY(hipMemcpy(c->d_inc_tbs, inc.data(), inc.size() * sizeof(DevTypeBatch), hipMemcpyHostToDevice));
+    }
+    c->built = true;
+    return rebuild_flags(c);
+}
+
+int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* c, const int32_t* indices, int32_t count) {
+    if (!c || count < 0 || (count > 0 && !indices)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad kinematic list");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->d_kin) { hipFree(c->d_kin); c->d_kin = nullptr; }
+    c->kin_count = count;
+    c->kin_indices.assign(indices, indices + count);
+    for (int i = 0; i < count; ++i)
+        if (indices[i] < 0 || indices[i] >= c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "kinematic body index out of range (call set_bodies first)");
+    if (count > 0) {
+        HIP_TRY(hipMalloc((void**)&c->d_kin, (size_t)count * 4));
+        HIP_TRY(hipMemcpy(c->d_kin, indices, (size_t)count * 4, hipMemcpyHostToDevice));
+    }
+    return rebuild_flags(c);
+}
+
+struct Timed {
+    bepuhip_ctx* c; int family; hipEvent_t a = nullptr, b = nullptr;
+    Timed(bepuhip_ctx* c_, int f) : c(c_), family(f) {
+        if (c->profiling) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+    }
+    ~Timed() {
+        if (c->profiling) {
+            hipEventRecord(b, c->stream); hipEventSynchronize(b);
+            float ms = 0; hipEventElapsedTime(&ms, a, b);
+            c->prof_ms[family] += ms; c->prof_launches[family] += 1;
+            hipEventDestroy(a); hipEventDestroy(b);
+        }
+    }
+};
+
+static StepParams make_params(const bepuhip_integrator* in, float dt_for_callbacks, float dt, float inv_dt) {
+    // DemoPoseIntegratorCallbacks.PrepareForIntegration (Demos/DemoCallbacks.cs:79-86)
+    StepParams sp;
+    float l = 1 - in->linear_damping, a = 1 - in->angular_damping;
+    l = l < 0 ? 0 : (l > 1 ? 1 : l);
+    a = a < 0 ? 0 : (a > 1 ? 1 : a);
+    sp.lin_damp = powf(l, dt_for_callbacks);
+    sp.ang_damp = powf(a, dt_for_callbacks);
+    sp.gx = in->gravity[0] * dt_for_callbacks; sp.gy = in->gravity[1] * dt_for_callbacks; sp.gz = in->gravity[2] * dt_for_callbacks;
+    sp.dt = dt; sp.inv_dt = inv_dt;
+    return sp;
+}
+
+// Enqueue every kernel of one Simulation.Solve on the context's stream (Solver_Solve.cs:1415-1479 + PoseIntegrator.cs:707-726).
+static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t* iterations, const bepuhip_integrator* in) {
+    const float substep_dt = dt / substeps;          // Solver_Solve.cs:1417
+    const float inv_dt = 1.0f / substep_dt;          // :1421
+    const StepParams sp = make_params(in, substep_dt, substep_dt, inv_dt);
+    const int body_blocks = (c->body_count + 255) / 256;
+    for (int s = 0; s < substeps; ++s) {
+        if (s > 0 && c->inc_blocks > 0) {             // :1427-1439 (all batches in one grid: it reads velocities and writes only prestep depths)
+            Timed t(c, 0);
+            hipLaunchKernelGGL(batch_kernel<kStageIncremental>, dim3(c->inc_blocks), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_inc_tbs, 0, c->inc_tb_count, c->d_bodies, substep_dt, inv_dt);
+        }
+        if (body_blocks > 0) {                        // :1440-1445 + the integration half of GatherAndIntegrate
+            Timed t(c, 1);
+            hipLaunchKernelGGL(substep_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, s > 0 ? 1 : 0,
+                               in->integrate_velocity_for_kinematics, sp);
+        }
+        for (int b = 0; b < c->batch_count; ++b) {    // :1447-1463
+            if (c->batch_blocks[b] == 0) continue;
+            Timed t(c, 2);
+            hipLaunchKernelGGL(batch_kernel<kStageWarmStart>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
+                               c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);
+        }
+        for (int it = 0; it < iterations[s]; ++it) {  // :1464-1476
+            for (int b = 0; b < c->batch_count; ++b) {
+                if (c->batch_blocks[b] == 0) continue;
+                Timed t(c, 3);
+                hipLaunchKernelGGL(batch_kernel<kStageSolve>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
+                                   c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);
+            }
+        }
+    }
+    if (body_blocks > 0) {                            // PoseIntegrator.cs:707-726
+        const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
+        const StepParams fsp = make_params(in, vdt, vdt, 1.0f / vdt);
+        Timed t(c, 4);
+        hipLaunchKernelGGL(final_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, dt, substep_dt, substeps,
+                           in->allow_substeps_for_unconstrained, in->integrate_velocity_for_kinematics, fsp);
+    }
+}
+
+static int32_t validate_solve(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in) {
+    if (!c || !in || !iterations) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    if (!(dt > 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Timestep duration must be positive.");                  // Simulation.cs:318-319
+    if (substeps < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Substep count must be positive.");                    // SolveDescription.cs:42-47
+    for (int s = 0; s < substeps; ++s)
+        if (iterations[s] < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Velocity iteration count must be positive.");
+    if (in->angular_integration_mode != 0) return fail(BEPUHIP_E_UNSUPPORTED, "only AngularIntegrationMode.Nonconserving is supported");
+    if (c->building) return fail(BEPUHIP_E_STATE, "solve between begin_constraints and end_constraints");
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in) {
+    int32_t st = validate_solve(c, dt, substeps, iterations, in);
+    if (st != BEPUHIP_OK) return st;
+    HIP_TRY(hipSetDevice(c->device));
+    int64_t iters = 0;
+    for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
+    c->last_constraint_iterations = iters;
+    if (c->profiling) { for (int i = 0; i < 5; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; } }
+    HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+    const bool use_graph = !(c->flags & BEPUHIP_FLAG_NO_GRAPH) && !c->profiling;
+    if (use_graph) {
+        GraphKey key;
+        key.iterations.assign(iterations, iterations + substeps);
+        key.dt = dt; key.integ = *in;
+        auto it = c->graphs.find(key);
+        if (it == c->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            enqueue_solve(c, dt, substeps, iterations, in);
+            HIP_TRY(hipStreamEndCapture(c->stream, &graph));
+            hipGraphExec_t exec = nullptr;
+            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            hipGraphDestroy(graph);
+            it = c->graphs.emplace(key, exec).first;
+            // the event recorded before capture began is still first in stream order
+        }
+        HIP_TRY(hipGraphLaunch(it->second, c->stream));
+    } else {
+        enqueue_solve(c, dt, substeps, iterations, in);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_sync(bepuhip_ctx* c) {
+    if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) c->last_ms = ms;
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_solve(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in) {
+    int32_t st = bepuhip_solve_async(c, dt, substeps, iterations, in);
+    if (st != BEPUHIP_OK) return st;
+    return bepuhip_sync(c);
+}
+
+int32_t bepuhip_get_bodies(bepuhip_ctx* c, void* out, int32_t count) {
+    if (!c || !out || count < 0 || count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad get_bodies argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->d_bodies, (size_t)count * 128, hipMemcpyDeviceToHost));
+    return BEPUHIP_OK;
+}
+
+static HostTypeBatch* find_tb(bepuhip_ctx* c, int batch, int type_id) {
+    for (auto& tb : c->tbs) if (tb.batch == batch && tb.type_id == type_id) return &tb;
+    return nullptr;
+}
+static int32_t download_aosoa(bepuhip_ctx* c, HostTypeBatch* tb, size_t off, int fields, float* out) {
+    if (tb->count == 0) return BEPUHIP_OK;
+    std::vector<float> soa((size_t)fields * tb->stride);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(soa.data(), c->d_slab + off, soa.size() * 4, hipMemcpyDeviceToHost));
+    const int W = c->W;
+    for (int i = 0; i < tb->count; ++i) {
+        const size_t bundle = (size_t)(i / W), lane = (size_t)(i % W);
+        for (int f = 0; f < fields; ++f) out[bundle * fields * W + (size_t)f * W + lane] = soa[(size_t)f * tb->stride + i];
+    }
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_get_accumulated_impulses(bepuhip_ctx* c, int32_t batch, int32_t type_id, float* out) {
+    if (!c || !out || !c->built) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad argument or no constraints");
+    HIP_TRY(hipSetDevice(c->device));
+    HostTypeBatch* tb = find_tb(c, batch, type_id);
+    if (!tb) return fail(BEPUHIP_E_INVALID_ARGUMENT, "no such type batch");
+    return download_aosoa(c, tb, tb->accum_off, tb->info.impulse, out);
+}
+int32_t bepuhip_get_prestep(bepuhip_ctx* c, int32_t batch, int32_t type_id, float* out) {
+    if (!c || !out || !c->built) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad argument or no constraints");
+    HIP_TRY(hipSetDevice(c->device));
+    HostTypeBatch* tb = find_tb(c, batch, type_id);
+    if (!tb) return fail(BEPUHIP_E_INVALID_ARGUMENT, "no such type batch");
+    return download_aosoa(c, tb, tb->prestep_off, tb->info.prestep, out);
+}
+
+int32_t bepuhip_get_constrained_flags(bepuhip_ctx* c, uint8_t* out, int32_t count) {
+    if (!c || !out || count < 0 || count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<unsigned> f((size_t)count);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (count > 0) HIP_TRY(hipMemcpy(f.data(), c->d_flags, (size_t)count * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; ++i) out[i] = (uint8_t)(f[i] & 3u);
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_last_solve_ms(bepuhip_ctx* c, float* ms) {
+    if (!c || !ms) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    *ms = c->last_ms;
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_set_profiling(bepuhip_ctx* c, int32_t enabled) {
+    if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
+    c->profiling = enabled != 0;
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_get_profile(bepuhip_ctx* c, int32_t family, float* ms, int32_t* launches) {
+    if (!c || family < 0 || family > 4) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad family");
+    if (ms) *ms = c->prof_ms[family];
+    if (launches) *launches = c->prof_launches[family];
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_last_constraint_iterations(bepuhip_ctx* c, int64_t* out) {
+    if (!c || !out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    *out = c->last_constraint_iterations;
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_get_stream(bepuhip_ctx* c, void** out) {
+    if (!c || !out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    *out = (void*)c->stream;
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_reset_state(bepuhip_ctx* c) {
+    if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->body_count > 0) HIP_TRY(hipMemcpyAsync(c->d_bodies, c->d_bodies0, (size_t)c->body_count * 128, hipMemcpyDeviceToDevice, c->stream));
+    if (c->slab_words > 0) HIP_TRY(hipMemcpyAsync(c->d_slab, c->d_slab0, c->slab_words * 4, hipMemcpyDeviceToDevice, c->stream));
+    return BEPUHIP_OK;
+}
+
+}  // extern "C"

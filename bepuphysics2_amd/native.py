@@ -1,0 +1,234 @@
+"""ctypes binding of the C ABI in include/bepuhip.h (libbepuhip.so) and the host-side mirror of the reference's
+``Simulation.Solve`` call sequence (BepuPhysics/Simulation.cs:278-290) on top of it.
+
+There is no CPU fallback: if the HIP extension or a GPU is missing, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .scene import PoseIntegratorCallbacks, Scene, SolveDescription, TYPE_TABLE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbepuhip.so")
+
+BEPUHIP_OK = 0
+BEPUHIP_E_INVALID_ARGUMENT = -1
+BEPUHIP_E_UNSUPPORTED = -2
+BEPUHIP_E_DEVICE = -3
+BEPUHIP_E_STATE = -4
+BEPUHIP_FLAG_NO_GRAPH = 1
+
+# Every symbol include/bepuhip.h declares (checked by the CPU test-suite against the header).
+EXPORTED_SYMBOLS = [
+    "bepuhip_last_error", "bepuhip_create", "bepuhip_destroy", "bepuhip_set_bodies", "bepuhip_begin_constraints",
+    "bepuhip_set_type_batch", "bepuhip_end_constraints", "bepuhip_set_constrained_kinematics", "bepuhip_solve",
+    "bepuhip_get_bodies", "bepuhip_get_accumulated_impulses", "bepuhip_get_prestep", "bepuhip_get_constrained_flags",
+    "bepuhip_last_solve_ms", "bepuhip_set_profiling", "bepuhip_get_profile", "bepuhip_last_constraint_iterations",
+    "bepuhip_get_stream", "bepuhip_solve_async", "bepuhip_sync", "bepuhip_reset_state", "bepuhip_type_info",
+]
+
+
+class BepuHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"bepuhip error {code}: {message}")
+        self.code = code
+
+
+class UnsupportedError(BepuHipError):
+    """BEPUHIP_E_UNSUPPORTED: the caller should fall back to the reference's own simulation.Solve."""
+
+
+class Config(C.Structure):
+    _fields_ = [("device_ordinal", C.c_int32), ("bundle_width", C.c_int32), ("flags", C.c_int32)]
+
+
+class Integrator(C.Structure):
+    _fields_ = [("gravity", C.c_float * 3), ("linear_damping", C.c_float), ("angular_damping", C.c_float),
+                ("angular_integration_mode", C.c_int32), ("allow_substeps_for_unconstrained", C.c_int32),
+                ("integrate_velocity_for_kinematics", C.c_int32)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """Load libbepuhip.so (built in-tree by __graft_entry__.build()). Raises if it is missing — no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    lib.bepuhip_last_error.restype = C.c_char_p
+    lib.bepuhip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.bepuhip_destroy.argtypes = [vp]
+    lib.bepuhip_set_bodies.argtypes = [vp, vp, i32]
+    lib.bepuhip_begin_constraints.argtypes = [vp, i32, i32]
+    lib.bepuhip_set_type_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    lib.bepuhip_end_constraints.argtypes = [vp]
+    lib.bepuhip_set_constrained_kinematics.argtypes = [vp, vp, i32]
+    lib.bepuhip_solve.argtypes = [vp, f32, i32, vp, C.POINTER(Integrator)]
+    lib.bepuhip_solve_async.argtypes = [vp, f32, i32, vp, C.POINTER(Integrator)]
+    lib.bepuhip_sync.argtypes = [vp]
+    lib.bepuhip_get_bodies.argtypes = [vp, vp, i32]
+    lib.bepuhip_get_accumulated_impulses.argtypes = [vp, i32, i32, vp]
+    lib.bepuhip_get_prestep.argtypes = [vp, i32, i32, vp]
+    lib.bepuhip_get_constrained_flags.argtypes = [vp, vp, i32]
+    lib.bepuhip_last_solve_ms.argtypes = [vp, C.POINTER(f32)]
+    lib.bepuhip_set_profiling.argtypes = [vp, i32]
+    lib.bepuhip_get_profile.argtypes = [vp, i32, C.POINTER(f32), C.POINTER(i32)]
+    lib.bepuhip_last_constraint_iterations.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.bepuhip_get_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.bepuhip_reset_state.argtypes = [vp]
+    lib.bepuhip_type_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    for name in EXPORTED_SYMBOLS:
+        if name != "bepuhip_last_error":
+            getattr(lib, name).restype = i32
+    _lib = lib
+    return lib
+
+
+def _check(lib, status: int):
+    if status == BEPUHIP_OK:
+        return
+    msg = lib.bepuhip_last_error().decode("utf-8", "replace")
+    if status == BEPUHIP_E_UNSUPPORTED:
+        raise UnsupportedError(status, msg)
+    if status == BEPUHIP_E_INVALID_ARGUMENT:
+        raise ValueError(msg)  # the reference throws ArgumentException here (Simulation.cs:318-319, SolveDescription.cs:42-47)
+    raise BepuHipError(status, msg)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
+
+
+def make_integrator(cb: PoseIntegratorCallbacks) -> Integrator:
+    integ = Integrator()
+    integ.gravity[0], integ.gravity[1], integ.gravity[2] = [float(x) for x in cb.gravity]
+    integ.linear_damping = float(cb.linear_damping)
+    integ.angular_damping = float(cb.angular_damping)
+    integ.angular_integration_mode = 0
+    integ.allow_substeps_for_unconstrained = int(bool(cb.allow_substeps_for_unconstrained_bodies))
+    integ.integrate_velocity_for_kinematics = int(bool(cb.integrate_velocity_for_kinematics))
+    return integ
+
+
+class HipSolver:
+    """Device mirror of one Simulation's solver state; ``solve`` replaces ``Simulation.Solve`` (Simulation.cs:278-290)."""
+
+    PROFILE_FAMILIES = ("incremental", "integrate", "warmstart", "solve", "final")
+
+    def __init__(self, device: int = 0, bundle_width: int = 8, use_graph: bool = True):
+        self.lib = load_library()
+        self.ctx = C.c_void_p()
+        cfg = Config(device, bundle_width, 0 if use_graph else BEPUHIP_FLAG_NO_GRAPH)
+        _check(self.lib, self.lib.bepuhip_create(C.byref(cfg), C.byref(self.ctx)))
+        self.bundle_width = bundle_width
+        self._scene_meta = None
+
+    def close(self):
+        if self.ctx:
+            self.lib.bepuhip_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- upload ----
+    def set_bodies(self, bodies: np.ndarray):
+        bodies = np.ascontiguousarray(bodies, dtype=np.float32)
+        assert bodies.ndim == 2 and bodies.shape[1] == 32
+        _check(self.lib, self.lib.bepuhip_set_bodies(self.ctx, _ptr(bodies), bodies.shape[0]))
+
+    def set_constraints(self, scene: Scene, fallback_batch_threshold: int = 64):
+        _check(self.lib, self.lib.bepuhip_begin_constraints(self.ctx, len(scene.batches), fallback_batch_threshold))
+        for bi, batch in enumerate(scene.batches):
+            for tb in batch:
+                _check(self.lib, self.lib.bepuhip_set_type_batch(self.ctx, bi, tb.type_id, tb.count, _ptr(tb.body_refs), _ptr(tb.prestep), _ptr(tb.accumulated)))
+        _check(self.lib, self.lib.bepuhip_end_constraints(self.ctx))
+
+    def upload(self, scene: Scene, fallback_batch_threshold: int = 64):
+        assert scene.bundle_width == self.bundle_width
+        self.set_bodies(scene.bodies)
+        self.set_constraints(scene, fallback_batch_threshold)
+        kin = np.ascontiguousarray(scene.constrained_kinematic_indices(), dtype=np.int32)
+        _check(self.lib, self.lib.bepuhip_set_constrained_kinematics(self.ctx, _ptr(kin), kin.size))
+        self._scene_meta = [(bi, tb.type_id, tb.count) for bi, b in enumerate(scene.batches) for tb in b]
+
+    # ---- solve ----
+    def solve(self, dt: float, solve_description: SolveDescription, callbacks: PoseIntegratorCallbacks, asynchronous: bool = False):
+        its = np.ascontiguousarray(solve_description.iterations(), dtype=np.int32)
+        integ = make_integrator(callbacks)
+        fn = self.lib.bepuhip_solve_async if asynchronous else self.lib.bepuhip_solve
+        _check(self.lib, fn(self.ctx, float(dt), int(solve_description.substep_count), _ptr(its), C.byref(integ)))
+
+    def sync(self):
+        _check(self.lib, self.lib.bepuhip_sync(self.ctx))
+
+    def reset_state(self):
+        _check(self.lib, self.lib.bepuhip_reset_state(self.ctx))
+
+    # ---- download ----
+    def get_bodies(self, count: int) -> np.ndarray:
+        out = np.empty((count, 32), dtype=np.float32)
+        _check(self.lib, self.lib.bepuhip_get_bodies(self.ctx, _ptr(out), count))
+        return out
+
+    def download(self, scene: Scene):
+        """Write device state back into ``scene``'s buffers (bodies, accumulated impulses, prestep)."""
+        scene.bodies[...] = self.get_bodies(scene.body_count)
+        for bi, batch in enumerate(scene.batches):
+            for tb in batch:
+                if tb.count == 0:
+                    continue
+                _check(self.lib, self.lib.bepuhip_get_accumulated_impulses(self.ctx, bi, tb.type_id, _ptr(tb.accumulated)))
+                _check(self.lib, self.lib.bepuhip_get_prestep(self.ctx, bi, tb.type_id, _ptr(tb.prestep)))
+
+    def constrained_flags(self, count: int) -> np.ndarray:
+        out = np.zeros(count, dtype=np.uint8)
+        _check(self.lib, self.lib.bepuhip_get_constrained_flags(self.ctx, _ptr(out), count))
+        return out
+
+    # ---- measurement ----
+    def last_solve_ms(self) -> float:
+        v = C.c_float()
+        _check(self.lib, self.lib.bepuhip_last_solve_ms(self.ctx, C.byref(v)))
+        return float(v.value)
+
+    def last_constraint_iterations(self) -> int:
+        v = C.c_int64()
+        _check(self.lib, self.lib.bepuhip_last_constraint_iterations(self.ctx, C.byref(v)))
+        return int(v.value)
+
+    def set_profiling(self, enabled: bool):
+        _check(self.lib, self.lib.bepuhip_set_profiling(self.ctx, int(enabled)))
+
+    def profile(self) -> dict:
+        out = {}
+        for i, name in enumerate(self.PROFILE_FAMILIES):
+            ms, n = C.c_float(), C.c_int32()
+            _check(self.lib, self.lib.bepuhip_get_profile(self.ctx, i, C.byref(ms), C.byref(n)))
+            out[name] = (float(ms.value), int(n.value))
+        return out
+
+    def stream_handle(self) -> int:
+        v = C.c_void_p()
+        _check(self.lib, self.lib.bepuhip_get_stream(self.ctx, C.byref(v)))
+        return int(v.value or 0)
+
+
+def type_info(type_id: int):
+    lib = load_library()
+    b, p, i = C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib, lib.bepuhip_type_info(type_id, C.byref(b), C.byref(p), C.byref(i)))
+    return b.value, p.value, i.value

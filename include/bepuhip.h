@@ -1,0 +1,115 @@
+/* bepuhip — C ABI of the MI355X-native constraint solver + pose integrator (libbepuhip.so).
+ *
+ * Drop-in boundary for ONE reference path: the body of `Simulation.Solve(dt, dispatcher)`
+ * (BepuPhysics/Simulation.cs:278-290), i.e.
+ *     Solver.PrepareConstraintIntegrationResponsibilities   BepuPhysics/Solver_Solve.cs:1072
+ *     Solver.Solve(dt, dispatcher)                          BepuPhysics/Solver_Solve.cs:1415
+ *     PoseIntegrator.IntegrateAfterSubstepping              BepuPhysics/PoseIntegrator.cs:707
+ *     Solver.DisposeConstraintIntegrationResponsibilities   BepuPhysics/Solver_Solve.cs:1389
+ * The reference has no FFI; a `HipTimestepper : ITimestepper` (BepuPhysics/ITimestepper.cs:60-79) binds these
+ * entry points with DllImport and calls them in place of `simulation.Solve`.
+ *
+ * Conventions: every function returns int32 status (0 = OK, <0 = error, see BEPUHIP_E_*); no exceptions cross;
+ * `bepuhip_last_error()` returns a thread-local message. Host buffers are the reference's own unmanaged,
+ * 128-byte aligned BufferPool allocations (BepuUtilities/Memory/BufferPool.cs:42,83); the library COPIES on set_*
+ * and owns all device memory. A context is not thread-safe; `bepuhip_solve` is synchronous at return
+ * (one HIP stream inside, no host sync between stages). Plain pointers and sizes only.
+ */
+#ifndef BEPUHIP_H
+#define BEPUHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEPUHIP_OK 0
+#define BEPUHIP_E_INVALID_ARGUMENT (-1) /* reference throws ArgumentException (Simulation.cs:318-319, SolveDescription.cs:42-47) */
+#define BEPUHIP_E_UNSUPPORTED (-2)      /* unknown type id, fallback batch present, ...: caller should fall back to simulation.Solve */
+#define BEPUHIP_E_DEVICE (-3)           /* HIP runtime failure */
+#define BEPUHIP_E_STATE (-4)            /* calls out of order */
+
+typedef struct bepuhip_ctx bepuhip_ctx;
+
+typedef struct bepuhip_config {
+    int32_t device_ordinal; /* HIP device to use */
+    int32_t bundle_width;   /* Vector<float>.Count of the host process that lays out AOSOA buffers: 4, 8 or 16 (BepuUtilities/BundleIndexing.cs:50-60) */
+    int32_t flags;          /* BEPUHIP_FLAG_* */
+} bepuhip_config;
+#define BEPUHIP_FLAG_NO_GRAPH 1 /* launch kernels eagerly instead of replaying a captured hipGraph */
+
+/* IPoseIntegratorCallbacks as data: only the DemoPoseIntegratorCallbacks shape can cross the ABI
+ * (Demos/DemoCallbacks.cs:20-109; BepuPhysics/PoseIntegrator.cs:42-94). PrepareForIntegration(dt) is evaluated
+ * natively: linearDampingDt = powf(clamp(1-LinearDamping,0,1), dt) etc. (DemoCallbacks.cs:79-86). */
+typedef struct bepuhip_integrator {
+    float gravity[3];
+    float linear_damping;
+    float angular_damping;
+    int32_t angular_integration_mode;             /* 0 = Nonconserving (only mode supported; others -> BEPUHIP_E_UNSUPPORTED) */
+    int32_t allow_substeps_for_unconstrained;     /* AllowSubstepsForUnconstrainedBodies */
+    int32_t integrate_velocity_for_kinematics;    /* IntegrateVelocityForKinematics */
+} bepuhip_integrator;
+
+const char* bepuhip_last_error(void);
+int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx);
+int32_t bepuhip_destroy(bepuhip_ctx* ctx);
+
+/* Replaces nothing in the reference by itself: mirrors Bodies.ActiveSet.DynamicsState (BepuPhysics/BodySet.cs:41),
+ * `count` BodyDynamics structs, 128-byte stride (BepuPhysics/BodyProperties.cs:318-338). */
+int32_t bepuhip_set_bodies(bepuhip_ctx* ctx, const void* body_dynamics_aos, int32_t count);
+
+/* Mirrors Solver.ActiveSet.Batches[*].TypeBatches[*] (BepuPhysics/Constraints/TypeBatch.cs:10-19,
+ * BepuPhysics/ConstraintBatch.cs:14-49). Call begin, then one set_type_batch per (batch, type batch) in the
+ * reference's order, then end. Buffers are the TypeBatch's BodyReferences / PrestepData / AccumulatedImpulses in
+ * AOSOA layout for config.bundle_width (BepuPhysics/Constraints/TypeProcessor.cs:139-148,269-279). Body references carry
+ * the reference's encoding: low 30 bits index, bit 30 kinematic, -1 empty lane (BepuPhysics/Bodies_GatherScatter.cs:107-139).
+ * batch_count > FallbackBatchThreshold (a sequential fallback batch exists, BepuPhysics/Solver.cs:1878-1884) -> UNSUPPORTED. */
+int32_t bepuhip_begin_constraints(bepuhip_ctx* ctx, int32_t batch_count, int32_t fallback_batch_threshold);
+int32_t bepuhip_set_type_batch(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t constraint_count,
+                               const int32_t* body_references_aosoa, const float* prestep_aosoa, const float* accumulated_impulses_aosoa);
+int32_t bepuhip_end_constraints(bepuhip_ctx* ctx);
+
+/* Solver.ConstrainedKinematicHandles (BepuPhysics/Solver.cs:68) resolved to body indices by the caller
+ * (handleToLocation[handle].Index, BepuPhysics/PoseIntegrator.cs:467). */
+int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* ctx, const int32_t* body_indices, int32_t count);
+
+/* Replaces the body of Simulation.Solve (BepuPhysics/Simulation.cs:278-290): integration-responsibility prepass
+ * (derived on device from the body references), the substep loop (BepuPhysics/Solver_Solve.cs:1415-1479) and
+ * IntegrateAfterSubstepping (BepuPhysics/PoseIntegrator.cs:707). velocity_iterations[s] is
+ * GetVelocityIterationCountForSubstepIndex(s) (BepuPhysics/Solver_Solve.cs:743-751). dt <= 0, substep_count < 1
+ * or an iteration count < 1 -> INVALID_ARGUMENT. */
+int32_t bepuhip_solve(bepuhip_ctx* ctx, float dt, int32_t substep_count, const int32_t* velocity_iterations, const bepuhip_integrator* integrator);
+
+/* Read back what the reference would find in its own buffers after Simulation.Solve returns. */
+int32_t bepuhip_get_bodies(bepuhip_ctx* ctx, void* body_dynamics_aos_out, int32_t count);
+int32_t bepuhip_get_accumulated_impulses(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, float* accumulated_impulses_aosoa_out);
+int32_t bepuhip_get_prestep(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, float* prestep_aosoa_out); /* contact depths change in substeps > 0 (PenetrationLimit.cs:42) */
+
+/* Diagnostics / measurement (no reference counterpart; SimulationProfiler equivalent, BepuPhysics/SimulationProfiler.cs:9-74). */
+/* mergedConstrainedBodyHandles as computed on device, one byte per body INDEX: bit0 = referenced by any constraint,
+ * bit1 = referenced as dynamic. For parity tests of the a2 prepass (BepuPhysics/Solver_Solve.cs:1198-1207,1378-1381). */
+int32_t bepuhip_get_constrained_flags(bepuhip_ctx* ctx, uint8_t* flags_out, int32_t count);
+/* Duration of the last bepuhip_solve in milliseconds, measured with HIP events on the context's stream. */
+int32_t bepuhip_last_solve_ms(bepuhip_ctx* ctx, float* ms_out);
+/* Per-kernel-family accumulated duration (ms) and launch count of the last solve when profiling is enabled. */
+int32_t bepuhip_set_profiling(bepuhip_ctx* ctx, int32_t enabled);
+int32_t bepuhip_get_profile(bepuhip_ctx* ctx, int32_t family /*0 incremental,1 integrate,2 warmstart,3 solve,4 final*/, float* ms_out, int32_t* launches_out);
+/* Constraint-iterations executed by the last solve: sum over substeps of constraints * (1 + velocity_iterations[s]). */
+int32_t bepuhip_last_constraint_iterations(bepuhip_ctx* ctx, int64_t* out);
+/* The native HIP stream handle (hipStream_t) the context launches on, for callers that time with their own HIP events. */
+int32_t bepuhip_get_stream(bepuhip_ctx* ctx, void** stream_out);
+/* Asynchronous variant for benchmarking with inputs resident in HBM: enqueue a solve, return immediately; bepuhip_sync waits. */
+int32_t bepuhip_solve_async(bepuhip_ctx* ctx, float dt, int32_t substep_count, const int32_t* velocity_iterations, const bepuhip_integrator* integrator);
+int32_t bepuhip_sync(bepuhip_ctx* ctx);
+/* Restore device state (bodies, prestep, accumulated impulses) to what the last set_* calls uploaded, without a host copy
+ * (device-to-device from a pristine snapshot taken at end_constraints / set_bodies). Lets a benchmark time identical steps. */
+int32_t bepuhip_reset_state(bepuhip_ctx* ctx);
+
+/* Static type table: bodies per constraint, prestep floats per lane, accumulated-impulse floats per lane
+ * (sizeof(TPrestepData)/sizeof(Vector<float>) etc., BepuPhysics/Constraints/TypeProcessor.cs:247). Returns UNSUPPORTED for unknown ids. */
+int32_t bepuhip_type_info(int32_t type_id, int32_t* bodies_per_constraint, int32_t* prestep_floats, int32_t* impulse_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEPUHIP_H */

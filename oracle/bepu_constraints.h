@@ -1,0 +1,879 @@
+// TEST INFRASTRUCTURE — CPU oracle, constraint functions. PARITY UNPINNED (see bepu_math.h header).
+//
+// One lane of each reference constraint function (WarmStart / Solve / IncrementallyUpdateForSubstep),
+// restated scalar with the reference's exact operation order. `p` is the lane's prestep data as a flat
+// float array in the reference struct's field order; `a` is the lane's accumulated impulses likewise.
+#pragma once
+#include "bepu_math.h"
+
+namespace bo {
+
+// Type ids: BepuPhysics/Constraints/Contact/ContactConvexTypes.cs:338..1523 (one-body N -> N-1, two-body N -> 3+N),
+// BepuPhysics/Constraints/*.cs BatchTypeId constants.
+enum TypeId {
+    kContact1OneBody = 0, kContact2OneBody = 1, kContact3OneBody = 2, kContact4OneBody = 3,
+    kContact1 = 4, kContact2 = 5, kContact3 = 6, kContact4 = 7,
+    kBallSocket = 22, kAngularHinge = 23, kSwingLimit = 25, kTwistServo = 26, kTwistLimit = 27,
+    kAngularMotor = 30, kSwivelHinge = 46, kHinge = 47,
+};
+
+// ======================================================================================
+// Convex contact manifolds, N = 1..4 contacts, one or two bodies.
+// Prestep layout (ContactConvexTypes.cs:1418-1430 / .tt:174-187): N x {OffsetA xyz, Depth}, [OffsetB xyz], Normal xyz,
+// {FrictionCoefficient, AngularFrequency, TwiceDampingRatio, MaximumRecoveryVelocity}.
+// Accumulated impulses (:11-99): Tangent xy, Penetration0..N-1, Twist.
+// ======================================================================================
+template <int N, bool TwoBody>
+struct Contact {
+    static constexpr int bodies = TwoBody ? 2 : 1;
+    static constexpr int prestepFloats = 4 * N + (TwoBody ? 10 : 7);
+    static constexpr int impulseFloats = N + 3;
+    static constexpr int typeId = TwoBody ? 3 + N : N - 1;
+    static constexpr bool incremental = true;
+
+    static V3 offsetA(const float* p, int i) { return {p[4 * i], p[4 * i + 1], p[4 * i + 2]}; }
+    static float& depth(float* p, int i) { return p[4 * i + 3]; }
+    static V3 offsetB(const float* p) { return {p[4 * N], p[4 * N + 1], p[4 * N + 2]}; }
+    static constexpr int nOff = 4 * N + (TwoBody ? 3 : 0);
+    static V3 normal(const float* p) { return {p[nOff], p[nOff + 1], p[nOff + 2]}; }
+    static float friction(const float* p) { return p[nOff + 3]; }
+    static float springFreq(const float* p) { return p[nOff + 4]; }
+    static float springDamp(const float* p) { return p[nOff + 5]; }
+    static float maxRecovery(const float* p) { return p[nOff + 6]; }
+
+    // FrictionHelpers.ComputeFrictionCenter, ContactConvexTypes.cs:121-196.
+    static V3 frictionCenter(float* p) {
+        float w[N];
+        float weightSum = 0;
+        for (int i = 0; i < N; ++i) w[i] = sel(depth(p, i) < 0.0f, 0.0f, 1.0f);
+        if (N == 2) weightSum = w[0] + w[1];
+        if (N == 3) weightSum = w[0] + w[1] + w[2];
+        if (N == 4) weightSum = w[0] + w[1] + w[2] + w[3];
+        bool useFallback = weightSum == 0.0f;
+        weightSum = sel(useFallback, (float)N, weightSum);
+        float inverseWeightSum = 1.0f / weightSum;
+        V3 c[N];
+        for (int i = 0; i < N; ++i) {
+            w[i] = sel(useFallback, inverseWeightSum, w[i] * inverseWeightSum);
+            c[i] = scale(offsetA(p, i), w[i]);
+        }
+        if (N == 2) return add(c[0], c[1]);
+        if (N == 3) return add(add(c[0], c[1]), c[2]);
+        return add(add(c[0], c[1]), add(c[2], c[N - 1]));  // N==4: (a0+a1)+(a2+a3)
+    }
+
+    // ---- PenetrationLimit.cs / PenetrationLimitOneBody.cs ----
+    static void penApply(const Inertia& iA, const Inertia& iB, V3 n, V3 angularA, V3 angularB, float csi, BodyVel& vA, BodyVel& vB) {
+        // PenetrationLimit.cs:46-66 (two-body), PenetrationLimitOneBody.cs ApplyImpulse (one-body)
+        float linearVelocityChangeA = csi * iA.invMass;
+        V3 corrALin = scale(n, linearVelocityChangeA);
+        V3 corrAngImpA = scale(angularA, csi);
+        V3 corrAAng = transform(corrAngImpA, iA.t);
+        if (TwoBody) {
+            float linearVelocityChangeB = csi * iB.invMass;
+            V3 corrBLin = scale(n, linearVelocityChangeB);
+            V3 corrAngImpB = scale(angularB, csi);
+            V3 corrBAng = transform(corrAngImpB, iB.t);
+            vA.lin = add(vA.lin, corrALin);
+            vA.ang = add(vA.ang, corrAAng);
+            vB.lin = sub(vB.lin, corrBLin);
+            vB.ang = add(vB.ang, corrBAng);
+        } else {
+            vA.lin = add(vA.lin, corrALin);
+            vA.ang = add(vA.ang, corrAAng);
+        }
+    }
+    static void penWarmStart(const Inertia& iA, const Inertia& iB, V3 n, V3 offA, V3 offB, float acc, BodyVel& vA, BodyVel& vB) {
+        // PenetrationLimit.cs:69-76
+        V3 angularA = cross(offA, n);
+        V3 angularB = TwoBody ? cross(n, offB) : V3{0, 0, 0};
+        penApply(iA, iB, n, angularA, angularB, acc, vA, vB);
+    }
+    static void penSolve(const Inertia& iA, const Inertia& iB, V3 n, V3 offA, V3 offB, float dep, float posErrToVel, float effMassCFMScale,
+                         float maxRecoveryVelocity, float inverseDt, float softnessImpulseScale, float& acc, BodyVel& vA, BodyVel& vB) {
+        // PenetrationLimit.cs:79-131; PenetrationLimitOneBody.cs Solve
+        V3 angularA = cross(offA, n);
+        V3 angularB = TwoBody ? cross(n, offB) : V3{0, 0, 0};
+        float angularA0 = vectorSandwich(angularA, iA.t);
+        float effectiveMass;
+        if (TwoBody) {
+            float angularB0 = vectorSandwich(angularB, iB.t);
+            float linear = iA.invMass + iB.invMass;
+            effectiveMass = effMassCFMScale / (linear + angularA0 + angularB0);
+        } else {
+            effectiveMass = effMassCFMScale / (iA.invMass + angularA0);
+        }
+        float biasVelocity = vmin(dep * inverseDt, vmin(dep * posErrToVel, maxRecoveryVelocity));
+        // ComputeCorrectiveImpulse, PenetrationLimit.cs:9-26
+        float csvaLinear = dot(vA.lin, n);
+        float csvaAngular = dot(vA.ang, angularA);
+        float negatedCSI;
+        if (TwoBody) {
+            float negatedCSVBLinear = dot(vB.lin, n);
+            float csvbAngular = dot(vB.ang, angularB);
+            negatedCSI = acc * softnessImpulseScale + (csvaLinear - negatedCSVBLinear + csvaAngular + csvbAngular - biasVelocity) * effectiveMass;
+        } else {
+            negatedCSI = acc * softnessImpulseScale + (csvaLinear + csvaAngular - biasVelocity) * effectiveMass;
+        }
+        float previousAccumulated = acc;
+        acc = vmax(0.0f, acc - negatedCSI);
+        float correctiveCSI = acc - previousAccumulated;
+        penApply(iA, iB, n, angularA, angularB, correctiveCSI, vA, vB);
+    }
+
+    // ---- TangentFriction.cs / TangentFrictionOneBody.cs ----
+    struct TJ { M23 linearA, angularA, angularB; };
+    static TJ tangentJacobians(V3 tX, V3 tY, V3 offA, V3 offB) {  // TangentFriction.cs:16-50
+        TJ j;
+        j.linearA.X = tX; j.linearA.Y = tY;
+        j.angularA.X = cross(offA, tX); j.angularA.Y = cross(offA, tY);
+        if (TwoBody) { j.angularB.X = cross(tX, offB); j.angularB.Y = cross(tY, offB); }
+        else { j.angularB.X = {0, 0, 0}; j.angularB.Y = {0, 0, 0}; }
+        return j;
+    }
+    static void tangentApply(const TJ& j, const Inertia& iA, const Inertia& iB, V2 csi, BodyVel& vA, BodyVel& vB) {  // :53-69
+        V3 linearImpulseA = transform(csi, j.linearA);
+        V3 angularImpulseA = transform(csi, j.angularA);
+        V3 corrALin = scale(linearImpulseA, iA.invMass);
+        V3 corrAAng = transform(angularImpulseA, iA.t);
+        if (TwoBody) {
+            V3 angularImpulseB = transform(csi, j.angularB);
+            V3 corrBLin = scale(linearImpulseA, iB.invMass);
+            V3 corrBAng = transform(angularImpulseB, iB.t);
+            vA.lin = add(vA.lin, corrALin);
+            vA.ang = add(vA.ang, corrAAng);
+            vB.lin = sub(vB.lin, corrBLin);
+            vB.ang = add(vB.ang, corrBAng);
+        } else {
+            vA.lin = add(vA.lin, corrALin);
+            vA.ang = add(vA.ang, corrAAng);
+        }
+    }
+    static void tangentSolve(V3 tX, V3 tY, V3 offA, V3 offB, const Inertia& iA, const Inertia& iB, float maximumImpulse, V2& acc, BodyVel& vA, BodyVel& vB) {
+        // TangentFriction.cs:117-137; TangentFrictionOneBody.cs Solve
+        TJ j = tangentJacobians(tX, tY, offA, offB);
+        Sym2 inverseEffectiveMass;
+        if (TwoBody) {
+            Sym2 linearContributionA = sandwichScale(j.linearA, iA.invMass);
+            Sym2 linearContributionB = sandwichScale(j.linearA, iB.invMass);
+            Sym2 angularContributionA = matrixSandwich(j.angularA, iA.t);
+            Sym2 angularContributionB = matrixSandwich(j.angularB, iB.t);
+            Sym2 linear = add(linearContributionA, linearContributionB);
+            Sym2 angular = add(angularContributionA, angularContributionB);
+            inverseEffectiveMass = add(linear, angular);
+        } else {
+            Sym2 linearContributionA = sandwichScale(j.linearA, iA.invMass);
+            Sym2 angularContributionA = matrixSandwich(j.angularA, iA.t);
+            inverseEffectiveMass = add(linearContributionA, angularContributionA);
+        }
+        Sym2 effectiveMass = invert(inverseEffectiveMass);
+        // ComputeCorrectiveImpulse, TangentFriction.cs:72-101 / OneBody variant
+        V2 previousAccumulated = acc;
+        if (TwoBody) {
+            V2 csvaLinear = transformByTranspose(vA.lin, j.linearA);
+            V2 csvaAngular = transformByTranspose(vA.ang, j.angularA);
+            V2 csvbLinear = transformByTranspose(vB.lin, j.linearA);
+            V2 csvbAngular = transformByTranspose(vB.ang, j.angularB);
+            V2 csvLinear = sub(csvbLinear, csvaLinear);
+            V2 csvAngular = add(csvaAngular, csvbAngular);
+            V2 csv = sub(csvLinear, csvAngular);
+            V2 csi = transform(csv, effectiveMass);
+            acc = add(acc, csi);
+        } else {
+            V2 csvaLinear = transformByTranspose(vA.lin, j.linearA);
+            V2 csvaAngular = transformByTranspose(vA.ang, j.angularA);
+            V2 csv = add(csvaLinear, csvaAngular);
+            V2 negativeCSI = transform(csv, effectiveMass);
+            acc = sub(acc, negativeCSI);
+        }
+        float accumulatedMagnitude = length(acc);
+        float sc = vmin(1.0f, maximumImpulse / vmax(1e-16f, accumulatedMagnitude));
+        acc = scale(acc, sc);
+        V2 correctiveCSI = sub(acc, previousAccumulated);
+        tangentApply(j, iA, iB, correctiveCSI, vA, vB);
+    }
+
+    // ---- TwistFriction.cs / TwistFrictionOneBody.cs ----
+    static void twistApply(V3 angularJacobianA, const Inertia& iA, const Inertia& iB, float csi, BodyVel& vA, BodyVel& vB) {  // :10-19
+        V3 worldCorrectiveImpulseA = scale(angularJacobianA, csi);
+        V3 worldCorrectiveVelocityA = transform(worldCorrectiveImpulseA, iA.t);
+        if (TwoBody) {
+            V3 worldCorrectiveVelocityB = transform(worldCorrectiveImpulseA, iB.t);
+            vA.ang = add(vA.ang, worldCorrectiveVelocityA);
+            vB.ang = sub(vB.ang, worldCorrectiveVelocityB);
+        } else {
+            vA.ang = add(vA.ang, worldCorrectiveVelocityA);
+        }
+    }
+    static void twistSolve(V3 angularJacobianA, const Inertia& iA, const Inertia& iB, float maximumImpulse, float& acc, BodyVel& vA, BodyVel& vB) {  // :46-71
+        float angularA = vectorSandwich(angularJacobianA, iA.t);
+        float inverseEffectiveMass = angularA;
+        if (TwoBody) {
+            float angularB = vectorSandwich(angularJacobianA, iB.t);
+            inverseEffectiveMass = angularA + angularB;
+        }
+        bool inverseIsZero = 0.0f == inverseEffectiveMass;
+        float effectiveMass = sel(inverseIsZero, 0.0f, 1.0f / inverseEffectiveMass);
+        // ComputeCorrectiveImpulse :22-36
+        float csvA = dot(vA.ang, angularJacobianA);
+        float negatedCSI;
+        if (TwoBody) {
+            float negatedCSVB = dot(vB.ang, angularJacobianA);
+            negatedCSI = (csvA - negatedCSVB) * effectiveMass;
+        } else {
+            negatedCSI = csvA * effectiveMass;
+        }
+        float previousAccumulated = acc;
+        acc = vmin(maximumImpulse, vmax(-maximumImpulse, acc - negatedCSI));
+        float correctiveCSI = acc - previousAccumulated;
+        twistApply(angularJacobianA, iA, iB, correctiveCSI, vA, vB);
+    }
+
+    // ---- ContactNFunctions (ContactConvexTypes.cs:1461-1514, template .tt:220-289) ----
+    static void incrementalUpdate(float dt, const BodyVel& vA, const BodyVel& vB, float* p) {
+        // PenetrationLimit.UpdatePenetrationDepth, PenetrationLimit.cs:29-43; OneBody: PenetrationLimitOneBody.cs
+        V3 n = normal(p);
+        for (int i = 0; i < N; ++i) {
+            V3 contactOffsetA = offsetA(p, i);
+            V3 wxra = cross(vA.ang, contactOffsetA);
+            V3 contactVelocityA = add(wxra, vA.lin);
+            float estimatedDepthChangeVelocity;
+            if (TwoBody) {
+                V3 contactOffsetB = sub(contactOffsetA, offsetB(p));
+                V3 wxrb = cross(vB.ang, contactOffsetB);
+                V3 contactVelocityB = add(wxrb, vB.lin);
+                V3 contactVelocityDifference = sub(contactVelocityA, contactVelocityB);
+                estimatedDepthChangeVelocity = dot(n, contactVelocityDifference);
+            } else {
+                estimatedDepthChangeVelocity = dot(n, contactVelocityA);
+            }
+            depth(p, i) = depth(p, i) - estimatedDepthChangeVelocity * dt;
+        }
+    }
+    static void warmStart(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {
+        V3 n = normal(p);
+        V3 x, z;
+        buildOrthonormalBasis(n, x, z);
+        V3 centerA = (N > 1) ? frictionCenter(p) : offsetA(p, 0);
+        V3 centerB = TwoBody ? sub(centerA, offsetB(p)) : V3{0, 0, 0};
+        TJ j = tangentJacobians(x, z, centerA, centerB);
+        tangentApply(j, iA, iB, V2{a[0], a[1]}, vA, vB);
+        for (int i = 0; i < N; ++i) {
+            V3 oA = offsetA(p, i);
+            V3 oB = TwoBody ? sub(oA, offsetB(p)) : V3{0, 0, 0};
+            penWarmStart(iA, iB, n, oA, oB, a[2 + i], vA, vB);
+        }
+        twistApply(n, iA, iB, a[2 + N], vA, vB);
+    }
+    static void solve(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB) {
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(springFreq(p), springDamp(p), dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        V3 n = normal(p);
+        for (int i = 0; i < N; ++i) {
+            V3 oA = offsetA(p, i);
+            V3 oB = TwoBody ? sub(oA, offsetB(p)) : V3{0, 0, 0};
+            penSolve(iA, iB, n, oA, oB, depth(p, i), posErrToVel, effMassCFMScale, maxRecovery(p), inverseDt, softnessImpulseScale, a[2 + i], vA, vB);
+        }
+        V3 x, z;
+        buildOrthonormalBasis(n, x, z);
+        float premultipliedFrictionCoefficient = (N > 1) ? (1.0f / (float)N) * friction(p) : friction(p);
+        float penSum = a[2];
+        for (int i = 1; i < N; ++i) penSum = penSum + a[2 + i];
+        float maximumTangentImpulse = premultipliedFrictionCoefficient * penSum;
+        V3 centerA = (N > 1) ? frictionCenter(p) : offsetA(p, 0);
+        V3 centerB = TwoBody ? sub(centerA, offsetB(p)) : V3{0, 0, 0};
+        V2 tangent{a[0], a[1]};
+        tangentSolve(x, z, centerA, centerB, iA, iB, maximumTangentImpulse, tangent, vA, vB);
+        a[0] = tangent.x; a[1] = tangent.y;
+        float maximumTwistImpulse;
+        if (N == 1) {
+            maximumTwistImpulse = friction(p) * a[2] * vmax(0.0f, depth(p, 0));
+        } else {
+            float s = a[2] * distance(centerA, offsetA(p, 0));
+            for (int i = 1; i < N; ++i) s = s + a[2 + i] * distance(centerA, offsetA(p, i));
+            maximumTwistImpulse = premultipliedFrictionCoefficient * s;
+        }
+        twistSolve(n, iA, iB, maximumTwistImpulse, a[2 + N], vA, vB);
+    }
+};
+
+// ======================================================================================
+// BallSocket — BepuPhysics/Constraints/BallSocket.cs:60-103, BallSocketShared.cs:19-135.
+// Prestep: LocalOffsetA xyz, LocalOffsetB xyz, {AngularFrequency, TwiceDampingRatio}. Impulses: xyz.
+// ======================================================================================
+struct BallSocketShared {
+    static Sym3 computeEffectiveMass(const Inertia& iA, const Inertia& iB, V3 offsetA, V3 offsetB, float effectiveMassCFMScale) {  // :19-46
+        Sym3 inverseEffectiveMass = skewSandwich(offsetA, iA.t);
+        Sym3 angularBContribution = skewSandwich(offsetB, iB.t);
+        inverseEffectiveMass = add(inverseEffectiveMass, angularBContribution);
+        float linearContribution = iA.invMass + iB.invMass;
+        inverseEffectiveMass.xx += linearContribution;
+        inverseEffectiveMass.yy += linearContribution;
+        inverseEffectiveMass.zz += linearContribution;
+        Sym3 effectiveMass = invert(inverseEffectiveMass);
+        return scale(effectiveMass, effectiveMassCFMScale);
+    }
+    static void applyImpulse(BodyVel& vA, BodyVel& vB, V3 offsetA, V3 offsetB, const Inertia& iA, const Inertia& iB, V3 csi) {  // :49-66
+        V3 wsi = cross(offsetA, csi);
+        V3 change = transform(wsi, iA.t);
+        vA.ang = add(vA.ang, change);
+        change = scale(csi, iA.invMass);
+        vA.lin = add(vA.lin, change);
+        wsi = cross(csi, offsetB);
+        change = transform(wsi, iB.t);
+        vB.ang = add(vB.ang, change);
+        change = scale(csi, iB.invMass);
+        vB.lin = sub(vB.lin, change);
+    }
+    static V3 computeCorrectiveImpulse(const BodyVel& vA, const BodyVel& vB, V3 offsetA, V3 offsetB, V3 biasVelocity, const Sym3& effectiveMass,
+                                       float softnessImpulseScale, V3 accumulatedImpulse) {  // :69-98
+        V3 csv = sub(vA.lin, vB.lin);
+        V3 angularCSV = cross(vA.ang, offsetA);
+        csv = add(csv, angularCSV);
+        angularCSV = cross(offsetB, vB.ang);
+        csv = add(csv, angularCSV);
+        csv = sub(biasVelocity, csv);
+        V3 correctiveImpulse = transform(csv, effectiveMass);
+        V3 softness = scale(accumulatedImpulse, softnessImpulseScale);
+        return sub(correctiveImpulse, softness);
+    }
+};
+struct BallSocket {
+    static constexpr int bodies = 2, prestepFloats = 8, impulseFloats = 3, typeId = kBallSocket;
+    static constexpr bool incremental = false;
+    static void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    static void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :68-74
+        V3 offsetA = transform(V3{p[0], p[1], p[2]}, oA);
+        V3 offsetB = transform(V3{p[3], p[4], p[5]}, oB);
+        BallSocketShared::applyImpulse(vA, vB, offsetA, offsetB, iA, iB, V3{a[0], a[1], a[2]});
+    }
+    static void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :76-91
+        V3 offsetA = transform(V3{p[0], p[1], p[2]}, oA);
+        V3 offsetB = transform(V3{p[3], p[4], p[5]}, oB);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[6], p[7], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        Sym3 effectiveMass = BallSocketShared::computeEffectiveMass(iA, iB, offsetA, offsetB, effMassCFMScale);
+        V3 ab = sub(pB, pA);
+        V3 anchorB = add(ab, offsetB);
+        V3 error = sub(anchorB, offsetA);
+        V3 biasVelocity = scale(error, posErrToVel);
+        // BallSocketShared.Solve :101-108
+        V3 acc{a[0], a[1], a[2]};
+        V3 correctiveImpulse = BallSocketShared::computeCorrectiveImpulse(vA, vB, offsetA, offsetB, biasVelocity, effectiveMass, softnessImpulseScale, acc);
+        acc = add(acc, correctiveImpulse);
+        a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
+        BallSocketShared::applyImpulse(vA, vB, offsetA, offsetB, iA, iB, correctiveImpulse);
+    }
+};
+
+// ======================================================================================
+// AngularHinge — BepuPhysics/Constraints/AngularHinge.cs:52-228.
+// Prestep: LocalHingeAxisA xyz, LocalHingeAxisB xyz, spring{freq, 2*damp}. Impulses: xy.
+// ======================================================================================
+struct AngularHinge {
+    static constexpr int bodies = 2, prestepFloats = 8, impulseFloats = 2, typeId = kAngularHinge;
+    static constexpr bool incremental = false;
+    static void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    static V2 getErrorAngles(V3 hingeAxisA, V3 hingeAxisB, const M23& jacobianA) {  // :74-111
+        float hingeAxisBDotX = dot(hingeAxisB, jacobianA.X);
+        float hingeAxisBDotY = dot(hingeAxisB, jacobianA.Y);
+        V3 toRemoveX = scale(jacobianA.X, hingeAxisBDotX);
+        V3 toRemoveY = scale(jacobianA.Y, hingeAxisBDotY);
+        V3 hingeAxisBOnPlaneX = sub(hingeAxisB, toRemoveX);
+        V3 hingeAxisBOnPlaneY = sub(hingeAxisB, toRemoveY);
+        float xLength = length(hingeAxisBOnPlaneX);
+        float yLength = length(hingeAxisBOnPlaneY);
+        float scaleX = 1.0f / xLength;
+        float scaleY = 1.0f / yLength;
+        hingeAxisBOnPlaneX = scale(hingeAxisBOnPlaneX, scaleX);
+        hingeAxisBOnPlaneY = scale(hingeAxisBOnPlaneY, scaleY);
+        const float epsilon = 1e-7f;
+        bool useFallbackX = xLength < epsilon;
+        bool useFallbackY = yLength < epsilon;
+        hingeAxisBOnPlaneX = sel3(useFallbackX, hingeAxisA, hingeAxisBOnPlaneX);
+        hingeAxisBOnPlaneY = sel3(useFallbackY, hingeAxisA, hingeAxisBOnPlaneY);
+        float hbxha = dot(hingeAxisBOnPlaneX, hingeAxisA);
+        float hbyha = dot(hingeAxisBOnPlaneY, hingeAxisA);
+        V2 errorAngles;
+        errorAngles.x = bacos(hbxha);
+        errorAngles.y = bacos(hbyha);
+        float hbxay = dot(hingeAxisBOnPlaneX, jacobianA.Y);
+        float hbyax = dot(hingeAxisBOnPlaneY, jacobianA.X);
+        errorAngles.x = sel(hbxay < 0.0f, errorAngles.x, -errorAngles.x);
+        errorAngles.y = sel(hbyax < 0.0f, -errorAngles.y, errorAngles.y);
+        return errorAngles;
+    }
+    static void applyImpulse(const M23& impulseToVelocityA, const M23& negatedImpulseToVelocityB, V2 csi, V3& angA, V3& angB) {  // :114-120
+        V3 velocityChangeA = transform(csi, impulseToVelocityA);
+        angA = add(angA, velocityChangeA);
+        V3 negatedVelocityChangeB = transform(csi, negatedImpulseToVelocityB);
+        angB = sub(angB, negatedVelocityChangeB);
+    }
+    static void computeJacobians(V3 localHingeAxisA, Q orientationA, V3& hingeAxisA, M23& jacobianA) {  // :123-130
+        V3 localAX, localAY;
+        buildOrthonormalBasis(localHingeAxisA, localAX, localAY);
+        M3 orientationMatrixA = createFromQuaternion(orientationA);
+        hingeAxisA = transform(localHingeAxisA, orientationMatrixA);
+        jacobianA.X = transform(localAX, orientationMatrixA);
+        jacobianA.Y = transform(localAY, orientationMatrixA);
+    }
+    static void warmStart(V3, Q oA, const Inertia& iA, V3, Q, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :132-138
+        V3 hingeAxisA; M23 jacobianA;
+        computeJacobians(V3{p[0], p[1], p[2]}, oA, hingeAxisA, jacobianA);
+        M23 impulseToVelocityA = multiply(jacobianA, iA.t);
+        M23 negatedImpulseToVelocityB = multiply(jacobianA, iB.t);
+        applyImpulse(impulseToVelocityA, negatedImpulseToVelocityB, V2{a[0], a[1]}, vA.ang, vB.ang);
+    }
+    static void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :140-217
+        V3 hingeAxisA; M23 jacobianA;
+        computeJacobians(V3{p[0], p[1], p[2]}, oA, hingeAxisA, jacobianA);
+        V3 hingeAxisB = transform(V3{p[3], p[4], p[5]}, oB);
+        M23 impulseToVelocityA = multiply(jacobianA, iA.t);
+        M23 negatedImpulseToVelocityB = multiply(jacobianA, iB.t);
+        Sym2 angularA = completeMatrixSandwich2(impulseToVelocityA, jacobianA);
+        Sym2 angularB = completeMatrixSandwich2(negatedImpulseToVelocityB, jacobianA);
+        Sym2 inverseEffectiveMass = add(angularA, angularB);
+        Sym2 effectiveMass = invert(inverseEffectiveMass);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[6], p[7], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        V2 errorAngle = getErrorAngles(hingeAxisA, hingeAxisB, jacobianA);
+        V2 biasVelocity = scale(errorAngle, -posErrToVel);
+        V2 biasImpulse = transform(biasVelocity, effectiveMass);
+        V3 difference = sub(vA.ang, vB.ang);
+        V2 csv = transformByTranspose(difference, jacobianA);
+        V2 csi = transform(csv, effectiveMass);
+        csi = scale(csi, effMassCFMScale);
+        V2 acc{a[0], a[1]};
+        V2 softnessContribution = scale(acc, softnessImpulseScale);
+        csi = add(softnessContribution, csi);
+        csi = sub(biasImpulse, csi);
+        acc = add(acc, csi);
+        a[0] = acc.x; a[1] = acc.y;
+        applyImpulse(impulseToVelocityA, negatedImpulseToVelocityB, csi, vA.ang, vB.ang);
+    }
+};
+
+// ======================================================================================
+// SwingLimit — BepuPhysics/Constraints/SwingLimit.cs:84-171; InequalityHelpers.cs:15-20.
+// Prestep: AxisLocalA xyz, AxisLocalB xyz, MinimumDot, spring{freq, 2*damp}. Impulse: scalar.
+// ======================================================================================
+static inline void clampPositive(float& accumulatedImpulse, float& impulse) {  // InequalityHelpers.cs:15-20
+    float previous = accumulatedImpulse;
+    accumulatedImpulse = vmax(0.0f, accumulatedImpulse + impulse);
+    impulse = accumulatedImpulse - previous;
+}
+// Shared 1-DOF angular impulse application: SwingLimit.cs:95-101 == TwistServo.cs:161-167.
+static inline void applyAngularImpulse1(V3 impulseToVelocityA, V3 negatedImpulseToVelocityB, float csi, V3& angA, V3& angB) {
+    V3 velocityChangeA = scale(impulseToVelocityA, csi);
+    angA = add(angA, velocityChangeA);
+    V3 negatedVelocityChangeB = scale(negatedImpulseToVelocityB, csi);
+    angB = sub(angB, negatedVelocityChangeB);
+}
+struct SwingLimit {
+    static constexpr int bodies = 2, prestepFloats = 9, impulseFloats = 1, typeId = kSwingLimit;
+    static constexpr bool incremental = false;
+    static void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    static void computeJacobian(V3 axisLocalA, V3 axisLocalB, Q oA, Q oB, V3& axisA, V3& axisB, V3& jacobianA) {  // :104-113
+        axisA = transform(axisLocalA, oA);
+        axisB = transform(axisLocalB, oB);
+        jacobianA = cross(axisA, axisB);
+        V3 fallbackJacobian = findPerpendicular(axisA);
+        float jacobianLengthSquared = dot(jacobianA, jacobianA);
+        bool useFallback = jacobianLengthSquared < 1e-7f;
+        jacobianA = sel3(useFallback, fallbackJacobian, jacobianA);
+    }
+    static void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :114-120
+        V3 axisA, axisB, jacobianA;
+        computeJacobian(V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, oA, oB, axisA, axisB, jacobianA);
+        V3 impulseToVelocityA = transform(jacobianA, iA.t);
+        V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
+        applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
+    }
+    static void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :122-163
+        V3 axisA, axisB, jacobianA;
+        computeJacobian(V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, oA, oB, axisA, axisB, jacobianA);
+        V3 impulseToVelocityA = transform(jacobianA, iA.t);
+        V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
+        float angularContributionA = dot(impulseToVelocityA, jacobianA);
+        float angularContributionB = dot(negatedImpulseToVelocityB, jacobianA);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[7], p[8], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        float effectiveMass = effMassCFMScale / (angularContributionA + angularContributionB);
+        float axisDot = dot(axisA, axisB);
+        float error = axisDot - p[6];
+        float biasVelocity = -vmin(error * inverseDt, error * posErrToVel);
+        V3 difference = sub(vA.ang, vB.ang);
+        float csv = dot(difference, jacobianA);
+        float csi = effectiveMass * (biasVelocity - csv) - a[0] * softnessImpulseScale;
+        clampPositive(a[0], csi);
+        applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, csi, vA.ang, vB.ang);
+    }
+};
+
+// ======================================================================================
+// TwistServo / TwistLimit — BepuPhysics/Constraints/TwistServo.cs:77-228, TwistLimit.cs:77-141.
+// TwistServo prestep: LocalBasisA xyzw, LocalBasisB xyzw, TargetAngle, spring{2}, servo{MaximumSpeed, BaseSpeed, MaximumForce}.
+// TwistLimit prestep: LocalBasisA xyzw, LocalBasisB xyzw, MinimumAngle, MaximumAngle, spring{2}. Impulse: scalar.
+// ======================================================================================
+struct TwistShared {
+    static void computeJacobianFull(Q oA, Q oB, Q localBasisA, Q localBasisB, V3& basisBX, V3& basisBZ, M3& basisA, V3& jacobianA) {  // TwistServo.cs:89-114
+        Q basisQuaternionA = concatenate(localBasisA, oA);
+        Q basisQuaternionB = concatenate(localBasisB, oB);
+        transformUnitXZ(basisQuaternionB, basisBX, basisBZ);
+        basisA = createFromQuaternion(basisQuaternionA);
+        jacobianA = add(basisA.Z, basisBZ);
+        float len = length(jacobianA);
+        jacobianA = scale(jacobianA, 1.0f / len);
+        jacobianA = sel3(len < 1e-10f, basisA.Z, jacobianA);
+    }
+    static void computeJacobianOnly(Q oA, Q oB, Q localBasisA, Q localBasisB, V3& jacobianA) {  // TwistServo.cs:170-182
+        Q basisQuaternionA = concatenate(localBasisA, oA);
+        Q basisQuaternionB = concatenate(localBasisB, oB);
+        V3 basisAZ = transformUnitZ(basisQuaternionA);
+        V3 basisBZ = transformUnitZ(basisQuaternionB);
+        jacobianA = add(basisAZ, basisBZ);
+        float len = length(jacobianA);
+        jacobianA = scale(jacobianA, 1.0f / len);
+        jacobianA = sel3(len < 1e-10f, basisAZ, jacobianA);
+    }
+    static float computeCurrentAngle(V3 basisBX, V3 basisBZ, const M3& basisA) {  // TwistServo.cs:117-128
+        Q aligningRotation = quaternionBetweenNormalizedVectors(basisBZ, basisA.Z);
+        V3 alignedBasisBX = transform(basisBX, aligningRotation);
+        float x = dot(alignedBasisBX, basisA.X);
+        float y = dot(alignedBasisBX, basisA.Y);
+        float absAngle = bacos(x);
+        return sel(y < 0.0f, -absAngle, absAngle);
+    }
+    static void computeEffectiveMass(float dt, float springFreq, float springDamp, const Sym3& invA, const Sym3& invB, V3 jacobianA,
+                                     V3& impulseToVelocityA, V3& negatedImpulseToVelocityB, float& posErrToVel, float& softnessImpulseScale,
+                                     float& effectiveMass, V3& velocityToImpulseA) {  // TwistServo.cs:131-158
+        impulseToVelocityA = transform(jacobianA, invA);
+        negatedImpulseToVelocityB = transform(jacobianA, invB);
+        float angularA = dot(impulseToVelocityA, jacobianA);
+        float angularB = dot(negatedImpulseToVelocityB, jacobianA);
+        float unsoftenedInverseEffectiveMass = angularA + angularB;
+        float effMassCFMScale;
+        computeSpringiness(springFreq, springDamp, dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        effectiveMass = effMassCFMScale / unsoftenedInverseEffectiveMass;
+        velocityToImpulseA = scale(jacobianA, effectiveMass);
+    }
+};
+struct TwistServo {
+    static constexpr int bodies = 2, prestepFloats = 14, impulseFloats = 1, typeId = kTwistServo;
+    static constexpr bool incremental = false;
+    static void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    static void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :184-190
+        V3 jacobianA;
+        TwistShared::computeJacobianOnly(oA, oB, Q{p[0], p[1], p[2], p[3]}, Q{p[4], p[5], p[6], p[7]}, jacobianA);
+        V3 impulseToVelocityA = transform(jacobianA, iA.t);
+        V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
+        applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
+    }
+    static void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :192-222
+        V3 basisBX, basisBZ, jacobianA; M3 basisA;
+        TwistShared::computeJacobianFull(oA, oB, Q{p[0], p[1], p[2], p[3]}, Q{p[4], p[5], p[6], p[7]}, basisBX, basisBZ, basisA, jacobianA);
+        V3 impulseToVelocityA, negatedImpulseToVelocityB, velocityToImpulseA;
+        float posErrToVel, softnessImpulseScale, effectiveMass;
+        TwistShared::computeEffectiveMass(dt, p[9], p[10], iA.t, iB.t, jacobianA, impulseToVelocityA, negatedImpulseToVelocityB,
+                                          posErrToVel, softnessImpulseScale, effectiveMass, velocityToImpulseA);
+        float angle = TwistShared::computeCurrentAngle(basisBX, basisBZ, basisA);
+        float error = signedAngleDifference(p[8], angle);
+        // ServoSettingsWide.ComputeClampedBiasVelocity (scalar-error form), ServoSettings.cs:75-85
+        float maximumSpeed = p[11], baseSpeedSetting = p[12], maximumForce = p[13];
+        float baseSpeed = vmin(baseSpeedSetting, vabs(error) * inverseDt);
+        float biasVelocity = error * posErrToVel;
+        float clampedBiasVelocity = sel(biasVelocity < 0.0f,
+                                        vmax(-maximumSpeed, vmin(-baseSpeed, biasVelocity)),
+                                        vmin(maximumSpeed, vmax(baseSpeed, biasVelocity)));
+        float maximumImpulse = maximumForce * dt;
+        float biasImpulse = clampedBiasVelocity * effectiveMass;
+        V3 netVelocity = sub(vA.ang, vB.ang);
+        float csiVelocityComponent = dot(netVelocity, velocityToImpulseA);
+        float csi = biasImpulse - a[0] * softnessImpulseScale - csiVelocityComponent;
+        float previousAccumulatedImpulse = a[0];
+        a[0] = vmin(vmax(a[0] + csi, -maximumImpulse), maximumImpulse);
+        csi = a[0] - previousAccumulatedImpulse;
+        applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, csi, vA.ang, vB.ang);
+    }
+};
+struct TwistLimit {
+    static constexpr int bodies = 2, prestepFloats = 12, impulseFloats = 1, typeId = kTwistLimit;
+    static constexpr bool incremental = false;
+    static void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    static void computeJacobian(Q oA, Q oB, Q localBasisA, Q localBasisB, float minimumAngle, float maximumAngle, float& error, V3& jacobianA) {  // :88-103
+        V3 basisBX, basisBZ; M3 basisA;
+        TwistShared::computeJacobianFull(oA, oB, localBasisA, localBasisB, basisBX, basisBZ, basisA, jacobianA);
+        float angle = TwistShared::computeCurrentAngle(basisBX, basisBZ, basisA);
+        float minError = signedAngleDifference(minimumAngle, angle);
+        float maxError = signedAngleDifference(maximumAngle, angle);
+        bool useMin = vabs(minError) < vabs(maxError);
+        error = sel(useMin, -minError, maxError);
+        V3 negatedJacobianA = neg(jacobianA);
+        jacobianA = sel3(useMin, negatedJacobianA, jacobianA);
+    }
+    static void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :104-110
+        float error; V3 jacobianA;
+        computeJacobian(oA, oB, Q{p[0], p[1], p[2], p[3]}, Q{p[4], p[5], p[6], p[7]}, p[8], p[9], error, jacobianA);
+        V3 impulseToVelocityA = transform(jacobianA, iA.t);
+        V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
+        applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
+    }
+    static void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :112-131
+        float error; V3 jacobianA;
+        computeJacobian(oA, oB, Q{p[0], p[1], p[2], p[3]}, Q{p[4], p[5], p[6], p[7]}, p[8], p[9], error, jacobianA);
+        V3 impulseToVelocityA, negatedImpulseToVelocityB, velocityToImpulseA;
+        float posErrToVel, softnessImpulseScale, effectiveMass;
+        TwistShared::computeEffectiveMass(dt, p[10], p[11], iA.t, iB.t, jacobianA, impulseToVelocityA, negatedImpulseToVelocityB,
+                                          posErrToVel, softnessImpulseScale, effectiveMass, velocityToImpulseA);
+        float biasVelocity = sel(error < 0.0f, error * inverseDt, error * posErrToVel);
+        float biasImpulse = biasVelocity * effectiveMass;
+        V3 netVelocity = sub(vA.ang, vB.ang);
+        float csiVelocityComponent = dot(netVelocity, velocityToImpulseA);
+        float csi = biasImpulse - a[0] * softnessImpulseScale - csiVelocityComponent;
+        clampPositive(a[0], csi);
+        applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, csi, vA.ang, vB.ang);
+    }
+};
+
+// ======================================================================================
+// AngularMotor — BepuPhysics/Constraints/AngularMotor.cs:55-97; AngularServo.cs:73-79 (ApplyImpulse);
+// MotorSettings.cs:70-99 (ComputeSoftness); ServoSettings.cs:167-178 (ClampImpulse, Vector3Wide).
+// Prestep: TargetVelocityLocalA xyz, {MaximumForce, Damping}. Impulses: xyz.
+// ======================================================================================
+struct AngularMotor {
+    static constexpr int bodies = 2, prestepFloats = 5, impulseFloats = 3, typeId = kAngularMotor;
+    static constexpr bool incremental = false;
+    static void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    static void applyImpulse(V3& angA, V3& angB, const Sym3& impulseToVelocityA, const Sym3& negatedImpulseToVelocityB, V3 csi) {  // AngularServo.cs:73-79
+        V3 velocityChangeA = transform(csi, impulseToVelocityA);
+        angA = add(angA, velocityChangeA);
+        V3 negatedVelocityChangeB = transform(csi, negatedImpulseToVelocityB);
+        angB = sub(angB, negatedVelocityChangeB);
+    }
+    static void warmStart(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float*, float* a, BodyVel& vA, BodyVel& vB) {  // :63-66
+        applyImpulse(vA.ang, vB.ang, iA.t, iB.t, V3{a[0], a[1], a[2]});
+    }
+    static void solve(V3, Q oA, const Inertia& iA, V3, Q, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :68-90
+        // MotorSettingsWide.ComputeSoftness, MotorSettings.cs:70-99
+        float dtd = dt * p[4];
+        float maximumImpulse = p[3] * dt;
+        float softnessImpulseScale = 1.0f / (dtd + 1.0f);
+        float effectiveMassCFMScale = dtd * softnessImpulseScale;
+        Sym3 unsoftenedInverseEffectiveMass = add(iA.t, iB.t);
+        Sym3 unsoftenedEffectiveMass = invert(unsoftenedInverseEffectiveMass);
+        V3 biasVelocity = transform(V3{p[0], p[1], p[2]}, oA);
+        V3 csv = sub(vA.ang, vB.ang);
+        csv = sub(biasVelocity, csv);
+        V3 csi = transform(csv, unsoftenedEffectiveMass);
+        csi = scale(csi, effectiveMassCFMScale);
+        V3 acc{a[0], a[1], a[2]};
+        V3 softnessComponent = scale(acc, softnessImpulseScale);
+        csi = sub(csi, softnessComponent);
+        // ServoSettingsWide.ClampImpulse(Vector3Wide), ServoSettings.cs:167-178
+        V3 previousAccumulatedImpulse = acc;
+        acc = add(acc, csi);
+        float impulseMagnitude = length(acc);
+        float impulseScale = sel(vabs(impulseMagnitude) < 1e-10f, 1.0f, vmin(maximumImpulse / impulseMagnitude, 1.0f));
+        acc = scale(acc, impulseScale);
+        csi = sub(acc, previousAccumulatedImpulse);
+        a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
+        applyImpulse(vA.ang, vB.ang, iA.t, iB.t, csi);
+    }
+};
+
+// ======================================================================================
+// SwivelHinge — BepuPhysics/Constraints/SwivelHinge.cs:74-218 (4x4 effective mass).
+// Prestep: LocalOffsetA, LocalSwivelAxisA, LocalOffsetB, LocalHingeAxisB (xyz each), spring{2}. Impulses: xyzw.
+// ======================================================================================
+struct SwivelHinge {
+    static constexpr int bodies = 2, prestepFloats = 14, impulseFloats = 4, typeId = kSwivelHinge;
+    static constexpr bool incremental = false;
+    static void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    static void applyImpulse(V3 offsetA, V3 offsetB, V3 swivelHingeJacobian, const Inertia& iA, const Inertia& iB, V4 csi, BodyVel& vA, BodyVel& vB) {  // :86-105
+        V3 ballSocketCSI{csi.x, csi.y, csi.z};
+        V3 linearChangeA = scale(ballSocketCSI, iA.invMass);
+        vA.lin = add(vA.lin, linearChangeA);
+        V3 ballSocketAngularImpulseA = cross(offsetA, ballSocketCSI);
+        V3 swivelHingeAngularImpulseA = scale(swivelHingeJacobian, csi.w);
+        V3 angularImpulseA = add(ballSocketAngularImpulseA, swivelHingeAngularImpulseA);
+        V3 angularChangeA = transform(angularImpulseA, iA.t);
+        vA.ang = add(vA.ang, angularChangeA);
+        V3 negatedLinearChangeB = scale(ballSocketCSI, iB.invMass);
+        vB.lin = sub(vB.lin, negatedLinearChangeB);
+        V3 ballSocketAngularImpulseB = cross(ballSocketCSI, offsetB);
+        V3 angularImpulseB = sub(ballSocketAngularImpulseB, swivelHingeAngularImpulseA);
+        V3 angularChangeB = transform(angularImpulseB, iB.t);
+        vB.ang = add(vB.ang, angularChangeB);
+    }
+    static void computeJacobian(const float* p, Q oA, Q oB, V3& swivelAxis, V3& hingeAxis, V3& offsetA, V3& offsetB, V3& swivelHingeJacobian) {  // :108-122
+        M3 orientationMatrixA = createFromQuaternion(oA);
+        M3 orientationMatrixB = createFromQuaternion(oB);
+        offsetA = transform(V3{p[0], p[1], p[2]}, orientationMatrixA);
+        swivelAxis = transform(V3{p[3], p[4], p[5]}, orientationMatrixA);
+        offsetB = transform(V3{p[6], p[7], p[8]}, orientationMatrixB);
+        hingeAxis = transform(V3{p[9], p[10], p[11]}, orientationMatrixB);
+        swivelHingeJacobian = cross(swivelAxis, hingeAxis);
+        float lenSq = lengthSquared(swivelHingeJacobian);
+        bool useFallbackJacobian = lenSq < 1e-3f;
+        swivelHingeJacobian = sel3(useFallbackJacobian, hingeAxis, swivelHingeJacobian);
+    }
+    static void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :124-129
+        V3 swivelAxis, hingeAxis, offsetA, offsetB, jac;
+        computeJacobian(p, oA, oB, swivelAxis, hingeAxis, offsetA, offsetB, jac);
+        applyImpulse(offsetA, offsetB, jac, iA, iB, V4{a[0], a[1], a[2], a[3]}, vA, vB);
+    }
+    static void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :131-208
+        V3 swivelAxis, hingeAxis, offsetA, offsetB, jac;
+        computeJacobian(p, oA, oB, swivelAxis, hingeAxis, offsetA, offsetB, jac);
+        Sym3 ballSocketContributionAngularA = skewSandwich(offsetA, iA.t);
+        Sym3 ballSocketContributionAngularB = skewSandwich(offsetB, iB.t);
+        Sym3 upperLeft = add(ballSocketContributionAngularA, ballSocketContributionAngularB);
+        float linearContribution = iA.invMass + iB.invMass;
+        upperLeft.xx += linearContribution;
+        upperLeft.yy += linearContribution;
+        upperLeft.zz += linearContribution;
+        V3 swivelHingeInertiaA = transform(jac, iA.t);
+        V3 swivelHingeInertiaB = transform(jac, iB.t);
+        float swivelHingeContributionAngularA = dot(swivelHingeInertiaA, jac);
+        float swivelHingeContributionAngularB = dot(swivelHingeInertiaB, jac);
+        Sym4 inverseEffectiveMass;
+        inverseEffectiveMass.xx = upperLeft.xx; inverseEffectiveMass.yx = upperLeft.yx; inverseEffectiveMass.yy = upperLeft.yy;
+        inverseEffectiveMass.zx = upperLeft.zx; inverseEffectiveMass.zy = upperLeft.zy; inverseEffectiveMass.zz = upperLeft.zz;
+        inverseEffectiveMass.ww = swivelHingeContributionAngularA + swivelHingeContributionAngularB;
+        V3 offDiagonalContributionA = cross(swivelHingeInertiaA, offsetA);
+        V3 offDiagonalContributionB = cross(swivelHingeInertiaB, offsetB);
+        V3 upperRight = add(offDiagonalContributionA, offDiagonalContributionB);
+        inverseEffectiveMass.wx = upperRight.x; inverseEffectiveMass.wy = upperRight.y; inverseEffectiveMass.wz = upperRight.z;
+        Sym4 effectiveMass = invert(inverseEffectiveMass);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[12], p[13], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        V3 anchorB = add(sub(pB, pA), offsetB);
+        V3 ballSocketError = sub(anchorB, offsetA);
+        V4 biasVelocity;
+        biasVelocity.x = ballSocketError.x * posErrToVel;
+        biasVelocity.y = ballSocketError.y * posErrToVel;
+        biasVelocity.z = ballSocketError.z * posErrToVel;
+        float error = dot(hingeAxis, swivelAxis);
+        biasVelocity.w = posErrToVel * -error;
+        V3 ballSocketAngularCSVA = cross(vA.ang, offsetA);
+        float swivelHingeCSVA = dot(jac, vA.ang);
+        V3 ballSocketAngularCSVB = cross(offsetB, vB.ang);
+        float negatedSwivelHingeCSVB = dot(jac, vB.ang);
+        V3 ballSocketAngularCSV = add(ballSocketAngularCSVA, ballSocketAngularCSVB);
+        V3 ballSocketLinearCSV = sub(vA.lin, vB.lin);
+        V4 csv;
+        csv.x = ballSocketAngularCSV.x + ballSocketLinearCSV.x;
+        csv.y = ballSocketAngularCSV.y + ballSocketLinearCSV.y;
+        csv.z = ballSocketAngularCSV.z + ballSocketLinearCSV.z;
+        csv.w = swivelHingeCSVA - negatedSwivelHingeCSVB;
+        csv = V4{biasVelocity.x - csv.x, biasVelocity.y - csv.y, biasVelocity.z - csv.z, biasVelocity.w - csv.w};
+        V4 csi = transform(csv, effectiveMass);
+        csi = V4{csi.x * effMassCFMScale, csi.y * effMassCFMScale, csi.z * effMassCFMScale, csi.w * effMassCFMScale};
+        V4 soft{a[0] * softnessImpulseScale, a[1] * softnessImpulseScale, a[2] * softnessImpulseScale, a[3] * softnessImpulseScale};
+        csi = V4{csi.x - soft.x, csi.y - soft.y, csi.z - soft.z, csi.w - soft.w};
+        a[0] = a[0] + csi.x; a[1] = a[1] + csi.y; a[2] = a[2] + csi.z; a[3] = a[3] + csi.w;
+        applyImpulse(offsetA, offsetB, jac, iA, iB, csi, vA, vB);
+    }
+};
+
+// ======================================================================================
+// Hinge — BepuPhysics/Constraints/Hinge.cs:74-226 (5x5 effective mass via Schur complement).
+// Prestep: LocalOffsetA, LocalHingeAxisA, LocalOffsetB, LocalHingeAxisB (xyz each), spring{2}.
+// Impulses: BallSocket xyz, Hinge xy.
+// ======================================================================================
+struct Hinge {
+    static constexpr int bodies = 2, prestepFloats = 14, impulseFloats = 5, typeId = kHinge;
+    static constexpr bool incremental = false;
+    static void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    static void applyImpulse(V3 offsetA, V3 offsetB, const M23& hingeJacobian, const Inertia& iA, const Inertia& iB, V3 csiBall, V2 csiHinge, BodyVel& vA, BodyVel& vB) {  // :91-110
+        V3 linearChangeA = scale(csiBall, iA.invMass);
+        vA.lin = add(vA.lin, linearChangeA);
+        V3 ballSocketAngularImpulseA = cross(offsetA, csiBall);
+        V3 hingeAngularImpulseA = transform(csiHinge, hingeJacobian);
+        V3 angularImpulseA = add(ballSocketAngularImpulseA, hingeAngularImpulseA);
+        V3 angularChangeA = transform(angularImpulseA, iA.t);
+        vA.ang = add(vA.ang, angularChangeA);
+        V3 negatedLinearChangeB = scale(csiBall, iB.invMass);
+        vB.lin = sub(vB.lin, negatedLinearChangeB);
+        V3 ballSocketAngularImpulseB = cross(csiBall, offsetB);
+        V3 angularImpulseB = sub(ballSocketAngularImpulseB, hingeAngularImpulseA);
+        V3 angularChangeB = transform(angularImpulseB, iB.t);
+        vB.ang = add(vB.ang, angularChangeB);
+    }
+    static void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :112-122
+        M3 orientationMatrixA = createFromQuaternion(oA);
+        V3 offsetA = transform(V3{p[0], p[1], p[2]}, orientationMatrixA);
+        V3 offsetB = transform(V3{p[6], p[7], p[8]}, oB);
+        V3 localAX, localAY;
+        buildOrthonormalBasis(V3{p[3], p[4], p[5]}, localAX, localAY);
+        M23 hingeJacobian;
+        hingeJacobian.X = transform(localAX, orientationMatrixA);
+        hingeJacobian.Y = transform(localAY, orientationMatrixA);
+        applyImpulse(offsetA, offsetB, hingeJacobian, iA, iB, V3{a[0], a[1], a[2]}, V2{a[3], a[4]}, vA, vB);
+    }
+    static void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :124-216
+        M3 orientationMatrixA = createFromQuaternion(oA);
+        M3 orientationMatrixB = createFromQuaternion(oB);
+        V3 offsetA = transform(V3{p[0], p[1], p[2]}, orientationMatrixA);
+        V3 hingeAxisA = transform(V3{p[3], p[4], p[5]}, orientationMatrixA);
+        V3 offsetB = transform(V3{p[6], p[7], p[8]}, orientationMatrixB);
+        V3 hingeAxisB = transform(V3{p[9], p[10], p[11]}, orientationMatrixB);
+        V3 localAX, localAY;
+        buildOrthonormalBasis(V3{p[3], p[4], p[5]}, localAX, localAY);
+        M23 hingeJacobian;
+        hingeJacobian.X = transform(localAX, orientationMatrixA);
+        hingeJacobian.Y = transform(localAY, orientationMatrixA);
+        Sym3 ballSocketContributionAngularA = skewSandwich(offsetA, iA.t);
+        Sym3 ballSocketContributionAngularB = skewSandwich(offsetB, iB.t);
+        Sym3 mA = add(ballSocketContributionAngularA, ballSocketContributionAngularB);
+        float linearContribution = iA.invMass + iB.invMass;
+        mA.xx += linearContribution;
+        mA.yy += linearContribution;
+        mA.zz += linearContribution;
+        M23 hingeInertiaA = multiply(hingeJacobian, iA.t);
+        M23 hingeInertiaB = multiply(hingeJacobian, iB.t);
+        Sym2 hingeContributionAngularA = completeMatrixSandwich2(hingeInertiaA, hingeJacobian);
+        Sym2 hingeContributionAngularB = completeMatrixSandwich2(hingeInertiaB, hingeJacobian);
+        Sym2 mD = add(hingeContributionAngularA, hingeContributionAngularB);
+        V3 offDiagonalContributionAX = cross(hingeInertiaA.X, offsetA);
+        V3 offDiagonalContributionAY = cross(hingeInertiaA.Y, offsetA);
+        V3 offDiagonalContributionBX = cross(hingeInertiaB.X, offsetB);
+        V3 offDiagonalContributionBY = cross(hingeInertiaB.Y, offsetB);
+        M23 mB;
+        mB.X = add(offDiagonalContributionAX, offDiagonalContributionBX);
+        mB.Y = add(offDiagonalContributionAY, offDiagonalContributionBY);
+        Sym5 effectiveMass = invert5(mA, mB, mD);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[12], p[13], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        V3 anchorB = add(sub(pB, pA), offsetB);
+        V3 ballSocketError = sub(anchorB, offsetA);
+        V3 ballSocketBiasVelocity = scale(ballSocketError, posErrToVel);
+        V2 errorAngles = AngularHinge::getErrorAngles(hingeAxisA, hingeAxisB, hingeJacobian);
+        V2 hingeBiasVelocity = scale(errorAngles, -posErrToVel);
+        V3 ballSocketAngularCSVA = cross(vA.ang, offsetA);
+        V2 hingeCSVA = transformByTranspose(vA.ang, hingeJacobian);
+        V3 ballSocketAngularCSVB = cross(offsetB, vB.ang);
+        V2 negatedHingeCSVB = transformByTranspose(vB.ang, hingeJacobian);
+        V3 ballSocketAngularCSV = add(ballSocketAngularCSVA, ballSocketAngularCSVB);
+        V3 ballSocketLinearCSV = sub(vA.lin, vB.lin);
+        V3 ballSocketCSV = add(ballSocketAngularCSV, ballSocketLinearCSV);
+        ballSocketCSV = sub(ballSocketBiasVelocity, ballSocketCSV);
+        V2 hingeCSV = sub(hingeCSVA, negatedHingeCSVB);
+        hingeCSV = sub(hingeBiasVelocity, hingeCSV);
+        V3 csiBall; V2 csiHinge;
+        transform5(ballSocketCSV, hingeCSV, effectiveMass, csiBall, csiHinge);
+        csiBall = scale(csiBall, effMassCFMScale);
+        csiHinge = scale(csiHinge, effMassCFMScale);
+        V3 accBall{a[0], a[1], a[2]}; V2 accHinge{a[3], a[4]};
+        V3 ballSocketSoftnessContribution = scale(accBall, softnessImpulseScale);
+        csiBall = sub(csiBall, ballSocketSoftnessContribution);
+        V2 hingeSoftnessContribution = scale(accHinge, softnessImpulseScale);
+        csiHinge = sub(csiHinge, hingeSoftnessContribution);
+        accBall = add(accBall, csiBall);
+        accHinge = add(accHinge, csiHinge);
+        a[0] = accBall.x; a[1] = accBall.y; a[2] = accBall.z; a[3] = accHinge.x; a[4] = accHinge.y;
+        applyImpulse(offsetA, offsetB, hingeJacobian, iA, iB, csiBall, csiHinge, vA, vB);
+    }
+};
+
+}  // namespace bo

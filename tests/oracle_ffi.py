@@ -1,0 +1,134 @@
+"""ctypes wrapper of oracle/libbepu_oracle.so — TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py's cpu_baseline leg)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(REPO, "oracle")
+
+
+class OracleTypeBatch(C.Structure):
+    _fields_ = [("type_id", C.c_int32), ("constraint_count", C.c_int32), ("body_refs", C.c_void_p), ("prestep", C.c_void_p), ("accumulated", C.c_void_p)]
+
+
+class OracleParams(C.Structure):
+    _fields_ = [("dt", C.c_float), ("substep_count", C.c_int32), ("velocity_iterations", C.c_void_p), ("gravity", C.c_float * 3),
+                ("linear_damping", C.c_float), ("angular_damping", C.c_float), ("allow_substeps_for_unconstrained", C.c_int32),
+                ("integrate_velocity_for_kinematics", C.c_int32), ("threads", C.c_int32)]
+
+
+class OracleScene(C.Structure):
+    _fields_ = [("bodies", C.c_void_p), ("body_count", C.c_int32), ("index_to_handle", C.c_void_p), ("handle_to_index", C.c_void_p),
+                ("handle_capacity", C.c_int32), ("batch_count", C.c_int32), ("type_batch_counts", C.c_void_p), ("type_batches", C.c_void_p),
+                ("constrained_kinematic_handles", C.c_void_p), ("constrained_kinematic_count", C.c_int32), ("bundle_width", C.c_int32)]
+
+
+_libs = {}
+
+
+def load(fast: bool = False) -> C.CDLL:
+    name = "libbepu_oracle_fast.so" if fast else "libbepu_oracle.so"
+    if name in _libs:
+        return _libs[name]
+    path = os.path.join(ORACLE_DIR, name)
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s"], cwd=ORACLE_DIR)
+    lib = C.CDLL(path)
+    lib.oracle_solve.argtypes = [C.POINTER(OracleScene), C.POINTER(OracleParams)]
+    lib.oracle_solve.restype = C.c_int
+    lib.oracle_prepare_flags.argtypes = [C.POINTER(OracleScene), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.oracle_prepare_flags.restype = C.c_int
+    lib.oracle_constraint_iterate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int]
+    lib.oracle_constraint_iterate.restype = C.c_int
+    lib.oracle_math_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.oracle_type_info.argtypes = [C.c_int] + [C.POINTER(C.c_int)] * 4
+    lib.oracle_type_info.restype = C.c_int
+    _libs[name] = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
+
+
+class _Marshalled:
+    """Keeps numpy buffers alive while the C structs point into them."""
+
+    def __init__(self, scene):
+        self.scene = scene
+        tbs = [tb for b in scene.batches for tb in b]
+        self.tb_array = (OracleTypeBatch * max(len(tbs), 1))()
+        for i, tb in enumerate(tbs):
+            self.tb_array[i] = OracleTypeBatch(tb.type_id, tb.count, _p(tb.body_refs), _p(tb.prestep), _p(tb.accumulated))
+        self.counts = np.asarray([len(b) for b in scene.batches], dtype=np.int32)
+        self.kin = np.ascontiguousarray(scene.constrained_kinematic_handles, dtype=np.int32)
+        self.i2h = np.ascontiguousarray(scene.index_to_handle, dtype=np.int32)
+        self.h2i = np.ascontiguousarray(scene.handle_to_index, dtype=np.int32)
+        s = OracleScene()
+        s.bodies = _p(scene.bodies)
+        s.body_count = scene.body_count
+        s.index_to_handle = _p(self.i2h)
+        s.handle_to_index = _p(self.h2i)
+        s.handle_capacity = int(self.h2i.size)
+        s.batch_count = len(scene.batches)
+        s.type_batch_counts = _p(self.counts)
+        s.type_batches = C.cast(self.tb_array, C.c_void_p)
+        s.constrained_kinematic_handles = _p(self.kin)
+        s.constrained_kinematic_count = int(self.kin.size)
+        s.bundle_width = scene.bundle_width
+        self.c = s
+
+
+def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool = False):
+    """Run the oracle's Simulation.Solve restatement IN PLACE on ``scene``'s buffers."""
+    lib = load(fast)
+    assert scene.bodies.flags["C_CONTIGUOUS"] and scene.bodies.dtype == np.float32
+    m = _Marshalled(scene)
+    its = np.ascontiguousarray(solve_description.iterations(), dtype=np.int32)
+    p = OracleParams()
+    p.dt = float(dt)
+    p.substep_count = int(solve_description.substep_count)
+    p.velocity_iterations = _p(its)
+    p.gravity[0], p.gravity[1], p.gravity[2] = [float(x) for x in callbacks.gravity]
+    p.linear_damping = float(callbacks.linear_damping)
+    p.angular_damping = float(callbacks.angular_damping)
+    p.allow_substeps_for_unconstrained = int(bool(callbacks.allow_substeps_for_unconstrained_bodies))
+    p.integrate_velocity_for_kinematics = int(bool(callbacks.integrate_velocity_for_kinematics))
+    p.threads = int(threads)
+    rc = lib.oracle_solve(C.byref(m.c), C.byref(p))
+    if rc != 0:
+        raise RuntimeError(f"oracle_solve failed: {rc}")
+
+
+def prepare_flags(scene):
+    """Returns (merged handle bitset uint64[], flags uint64[] concatenated, coarse uint8[] per flattened type batch)."""
+    lib = load()
+    m = _Marshalled(scene)
+    words = (int(m.h2i.size) + 63) // 64 or 1
+    merged = np.zeros(words, dtype=np.uint64)
+    cap = sum(((tb.count + 63) // 64) * tb.bodies for b in scene.batches[1:] for tb in b) + 1
+    flags = np.zeros(cap, dtype=np.uint64)
+    coarse = np.zeros(max(sum(len(b) for b in scene.batches), 1), dtype=np.uint8)
+    rc = lib.oracle_prepare_flags(C.byref(m.c), _p(merged), _p(flags), cap, _p(coarse))
+    if rc != 0:
+        raise RuntimeError(f"oracle_prepare_flags failed: {rc}")
+    return merged, flags[:cap - 1], coarse
+
+
+def constraint_iterate(type_id, body_a, body_b, prestep, accumulated, dt, iterations):
+    lib = load()
+    rc = lib.oracle_constraint_iterate(type_id, _p(body_a), _p(body_b), _p(prestep), _p(accumulated), float(dt), int(iterations))
+    if rc != 0:
+        raise RuntimeError(f"oracle_constraint_iterate failed: {rc}")
+
+
+def math_probe(x):
+    lib = load()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    s, c, a = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+    lib.oracle_math_probe(_p(x), x.size, _p(s), _p(c), _p(a))
+    return s, c, a

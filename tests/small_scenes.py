@@ -1,0 +1,148 @@
+"""Seeded small-scene generators for the parity tests (pure numpy + the Python SceneBuilder mirror)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from bepuphysics2_amd.scene import TYPE_TABLE, Scene, SceneBuilder, make_body
+
+TWO_PI = 6.283185307179586
+FLOAT_MAX = float(np.finfo(np.float32).max)
+
+
+def unit(rng, n=3):
+    v = rng.normal(size=n)
+    return (v / np.linalg.norm(v)).astype(np.float32)
+
+
+def rand_quat(rng, spread=1.0):
+    q = rng.normal(size=4) * np.array([spread, spread, spread, 1.0])
+    return (q / np.linalg.norm(q)).astype(np.float32)
+
+
+def spring(frequency, damping_ratio):
+    # SpringSettings(frequency, dampingRatio): AngularFrequency = f * TwoPi, TwiceDampingRatio = 2 * zeta (SpringSettings.cs:73-78)
+    return [np.float32(frequency) * np.float32(TWO_PI), np.float32(damping_ratio) * np.float32(2)]
+
+
+def random_dynamic_body(rng, position, speed=0.5):
+    inv_mass = 1.0 / rng.uniform(1.0, 5.0)
+    d = rng.uniform(0.5, 3.0, size=3) * inv_mass
+    # diagonal local inverse inertia plus a small symmetric off-diagonal part (still positive definite)
+    off = rng.uniform(-0.05, 0.05, size=3) * inv_mass
+    inertia = (d[0], off[0], d[1], off[1], off[2], d[2])
+    return make_body(position=position, orientation=rand_quat(rng), linear=rng.uniform(-speed, speed, 3), angular=rng.uniform(-speed, speed, 3),
+                     inverse_inertia=inertia, inverse_mass=inv_mass)
+
+
+def kinematic_body(rng, position, angular=(0, 0, 0.25)):
+    return make_body(position=position, orientation=rand_quat(rng), linear=(0, 0, 0), angular=angular, inverse_inertia=(0,) * 6, inverse_mass=0.0)
+
+
+def contact_prestep(rng, n, two_body, pos_a, pos_b=None, friction=1.0, freq=30.0, max_recovery=2.0):
+    """ContactN[OneBody]PrestepData lane (ContactConvexTypes.cs:1418-1430)."""
+    lane = []
+    normal = unit(rng)
+    for _ in range(n):
+        lane += list(rng.uniform(-0.5, 0.5, 3).astype(np.float32)) + [np.float32(rng.uniform(-0.01, 0.02))]
+    if two_body:
+        lane += list((np.asarray(pos_b, np.float32) - np.asarray(pos_a, np.float32)))
+    lane += list(normal)
+    lane += [np.float32(friction)] + spring(freq, 1.0) + [np.float32(max_recovery)]
+    return lane
+
+
+def joint_prestep(rng, type_id):
+    name = TYPE_TABLE[type_id][3]
+    sp = spring(15.0, 1.0)
+    if name == "BallSocket":
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + sp
+    if name == "AngularHinge":
+        return list(unit(rng)) + list(unit(rng)) + sp
+    if name == "SwingLimit":
+        return list(unit(rng)) + list(unit(rng)) + [math.cos(rng.uniform(0.2, 2.5))] + sp
+    if name == "TwistServo":
+        servo = [FLOAT_MAX, 0.0, FLOAT_MAX] if rng.random() < 0.5 else [rng.uniform(1, 5), rng.uniform(0, 0.5), rng.uniform(10, 1000)]
+        return list(rand_quat(rng)) + list(rand_quat(rng)) + [rng.uniform(-0.5, 0.5)] + sp + servo
+    if name == "TwistLimit":
+        a = rng.uniform(0.1, 1.5)
+        return list(rand_quat(rng)) + list(rand_quat(rng)) + [-a, a] + sp
+    if name == "AngularMotor":
+        settings = [FLOAT_MAX, 1.0 / 0.01] if rng.random() < 0.5 else [rng.uniform(1, 100), rng.uniform(1, 200)]
+        return list(rng.uniform(-0.2, 0.2, 3)) + settings
+    if name in ("SwivelHinge", "Hinge"):
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + sp
+    raise KeyError(name)
+
+
+def prestep_for(rng, type_id, pos_a, pos_b):
+    nb, _, _, name = TYPE_TABLE[type_id]
+    if name.startswith("Contact"):
+        n = int(name[7])
+        return contact_prestep(rng, n, nb == 2, pos_a, pos_b)
+    return joint_prestep(rng, type_id)
+
+
+def random_graph_scene(seed, body_count, constraint_count, type_ids, kinematic_fraction=0.05, unconstrained_extra=3, warm=True) -> Scene:
+    """Random constraint graph over random bodies: exercises batching, kinematic references, every given type."""
+    rng = np.random.default_rng(seed)
+    sb = SceneBuilder()
+    positions = rng.uniform(-3, 3, size=(body_count + unconstrained_extra, 3)).astype(np.float32)
+    for i in range(body_count + unconstrained_extra):
+        if i < body_count and rng.random() < kinematic_fraction:
+            sb.add_body(kinematic_body(rng, positions[i]))
+        else:
+            sb.add_body(random_dynamic_body(rng, positions[i]))
+    added = 0
+    while added < constraint_count:
+        t = int(type_ids[rng.integers(len(type_ids))])
+        nb = TYPE_TABLE[t][0]
+        hs = list(rng.choice(body_count, size=nb, replace=False))
+        if all(sb.is_kinematic(h) for h in hs):
+            continue
+        pa = positions[hs[0]]
+        pb = positions[hs[1]] if nb == 2 else None
+        sb.add_constraint(t, hs, prestep_for(rng, t, pa, pb))
+        added += 1
+    scene = sb.build()
+    if warm:  # nonzero warm-start impulses, as a running simulation would have
+        for b in scene.batches:
+            for tb in b:
+                lanes = rng.uniform(0.0, 0.05, size=(tb.count, tb.impulse_floats)).astype(np.float32)
+                from bepuphysics2_amd.scene import to_aosoa
+                tb.accumulated[...] = to_aosoa(lanes, scene.bundle_width)
+    return scene
+
+
+def box_stack_scene(levels=3, per_level=4) -> Scene:
+    """Small analytic box pyramid: Contact4 two-body between rows, Contact4OneBody against the ground (PyramidDemo geometry, Demos/Demos/PyramidDemo.cs:26-47)."""
+    sb = SceneBuilder()
+    mat = [np.float32(1.0)] + spring(30.0, 1.0) + [np.float32(2.0)]
+    rows = []
+    for r in range(levels):
+        n = per_level - r
+        row = []
+        for c in range(n):
+            x = -n / 2.0 + c + 0.5 * 0
+            inv = (6.0, 0, 6.0, 0, 0, 6.0)  # unit cube mass 1: inverse inertia 1/(m/6)
+            row.append(sb.add_body(make_body(position=(x + 0.5 * r, r + 0.5, 0), inverse_inertia=inv, inverse_mass=1.0)))
+        rows.append(row)
+    for h in rows[0]:  # ground contacts
+        lane = []
+        for dx, dz in ((-0.5, -0.5), (0.5, -0.5), (-0.5, 0.5), (0.5, 0.5)):
+            lane += [dx, -0.5, dz, 0.0]
+        lane += [0, 1, 0] + mat
+        sb.add_constraint(3, [h], lane)
+    for r in range(1, levels):
+        for c, h in enumerate(rows[r]):
+            for below in (rows[r - 1][c], rows[r - 1][c + 1]):
+                pa = sb._bodies[h][4:7]
+                pb = sb._bodies[below][4:7]
+                x0, x1 = max(pa[0], pb[0]) - 0.5, min(pa[0], pb[0]) + 0.5
+                lane = []
+                for x, z in ((x0, -0.5), (x1, -0.5), (x0, 0.5), (x1, 0.5)):
+                    lane += [x - pa[0], -0.5, z, 0.0]
+                lane += list(pb - pa) + [0, 1, 0] + mat
+                sb.add_constraint(7, [h, below], lane)
+    return sb.build()
