@@ -1,0 +1,411 @@
+// Host-side mirror (C++) of the reference's managed surface for the solver hot path — see bepu_host.h for the file:line map.
+#include "bepu_host.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "bepuhip.h"
+
+namespace bepu {
+
+MotorSettings::MotorSettings(float maximumForce, float softness)  // MotorSettings.cs:19,44-48
+    : MaximumForce(maximumForce), Damping(softness <= 0 ? 3.402823466e+38f : 1.0f / softness) {}
+
+bool GetTypeInfo(int typeId, TypeInfo& info) {
+    // sizeof(TPrestepData)/sizeof(Vector<float>), sizeof(TAccumulatedImpulse)/sizeof(Vector<float>) (TypeProcessor.cs:247);
+    // ids: ContactConvexTypes.cs (one-body N -> N-1, two-body N -> 3+N), BatchTypeId constants of the joint types.
+    switch (typeId) {
+        case 0: info = {1, 11, 4, true}; return true;
+        case 1: info = {1, 15, 5, true}; return true;
+        case 2: info = {1, 19, 6, true}; return true;
+        case 3: info = {1, 23, 7, true}; return true;
+        case 4: info = {2, 14, 4, true}; return true;
+        case 5: info = {2, 18, 5, true}; return true;
+        case 6: info = {2, 22, 6, true}; return true;
+        case 7: info = {2, 26, 7, true}; return true;
+        case 22: info = {2, 8, 3, false}; return true;   // BallSocket
+        case 23: info = {2, 8, 2, false}; return true;   // AngularHinge
+        case 25: info = {2, 9, 1, false}; return true;   // SwingLimit
+        case 26: info = {2, 14, 1, false}; return true;  // TwistServo
+        case 27: info = {2, 12, 1, false}; return true;  // TwistLimit
+        case 30: info = {2, 5, 3, false}; return true;   // AngularMotor
+        case 46: info = {2, 14, 4, false}; return true;  // SwivelHinge
+        case 47: info = {2, 14, 5, false}; return true;  // Hinge
+    }
+    return false;
+}
+
+// ---- Bodies ----
+int32_t Bodies::Add(const BodyDescription& d) {  // BodySet.cs:83-134
+    BodyDynamics b;
+    std::memset(&b, 0, sizeof(b));
+    b.f[0] = d.Pose.Orientation.X; b.f[1] = d.Pose.Orientation.Y; b.f[2] = d.Pose.Orientation.Z; b.f[3] = d.Pose.Orientation.W;
+    b.f[4] = d.Pose.Position.X; b.f[5] = d.Pose.Position.Y; b.f[6] = d.Pose.Position.Z;
+    b.f[8] = d.Velocity.Linear.X; b.f[9] = d.Velocity.Linear.Y; b.f[10] = d.Velocity.Linear.Z;
+    b.f[12] = d.Velocity.Angular.X; b.f[13] = d.Velocity.Angular.Y; b.f[14] = d.Velocity.Angular.Z;
+    const Symmetric3x3& t = d.LocalInertia.InverseInertiaTensor;
+    b.f[16] = t.XX; b.f[17] = t.YX; b.f[18] = t.YY; b.f[19] = t.ZX; b.f[20] = t.ZY; b.f[21] = t.ZZ; b.f[22] = d.LocalInertia.InverseMass;
+    // World inertia slot is zeroed: valid for kinematics forever, refreshed by the solver for dynamics (BodySet.cs:131-134).
+    int32_t handle = (int32_t)HandleToIndex.size();
+    HandleToIndex.push_back((int32_t)DynamicsState.size());
+    IndexToHandle.push_back(handle);
+    DynamicsState.push_back(b);
+    return handle;
+}
+bool Bodies::IsKinematic(int index) const {  // Bodies.cs:326-349
+    const float* f = DynamicsState[index].f;
+    for (int i = 16; i < 23; ++i)
+        if (f[i] != 0) return false;
+    return true;
+}
+
+// ---- TypeBatch / ConstraintBatch ----
+int TypeBatch::Allocate(int constraintHandle, const int32_t* encodedBodyIndices) {  // TypeProcessor.cs:314-334
+    const int W = kBundleWidth;
+    int index = ConstraintCount++;
+    if (ConstraintCount > (int)IndexToHandle.size()) IndexToHandle.resize(ConstraintCount);
+    IndexToHandle[index] = constraintHandle;
+    int bundles = BundleCount();
+    if ((size_t)bundles * Info.bodies * W > BodyReferences.size()) {
+        size_t nb = std::max<size_t>((size_t)bundles * 2, 4);
+        BodyReferences.resize(nb * Info.bodies * W, -1);  // trailing lanes of the last bundle hold -1 (TypeProcessor.cs:287-298)
+        PrestepData.resize(nb * Info.prestepFloats * W, 0.0f);
+        AccumulatedImpulses.resize(nb * Info.impulseFloats * W, 0.0f);
+    }
+    int bundle = index / W, lane = index % W;
+    for (int k = 0; k < Info.bodies; ++k) BodyReferences[(size_t)bundle * Info.bodies * W + (size_t)k * W + lane] = encodedBodyIndices[k];
+    return index;
+}
+TypeBatch& ConstraintBatch::GetOrCreateTypeBatch(int typeId) {  // ConstraintBatch.cs:60-90
+    auto it = TypeIndexToTypeBatchIndex.find(typeId);
+    if (it != TypeIndexToTypeBatchIndex.end()) return TypeBatches[it->second];
+    TypeIndexToTypeBatchIndex[typeId] = (int)TypeBatches.size();
+    TypeBatches.emplace_back();
+    TypeBatch& tb = TypeBatches.back();
+    tb.TypeId = typeId;
+    GetTypeInfo(typeId, tb.Info);
+    return tb;
+}
+
+// ---- SolveDescription ----
+SolveDescription::SolveDescription(int velocityIterationCount, int substepCount, int fallbackBatchThreshold)
+    : VelocityIterationCount(velocityIterationCount), SubstepCount(substepCount), FallbackBatchThreshold(fallbackBatchThreshold) {
+    // SolveDescription.cs:42-47: ArgumentException
+    if (substepCount < 1) throw std::invalid_argument("Substep count must be positive.");
+    if (velocityIterationCount < 1) throw std::invalid_argument("Velocity iteration count must be positive.");
+    if (fallbackBatchThreshold < 1) throw std::invalid_argument("Fallback batch threshold must be positive.");
+}
+std::vector<int32_t> SolveDescription::ResolveIterations() const {  // Solver_Solve.cs:743-751
+    std::vector<int32_t> out(SubstepCount);
+    for (int s = 0; s < SubstepCount; ++s) {
+        int n = VelocityIterationCount;
+        if (VelocityIterationScheduler) {
+            int scheduled = VelocityIterationScheduler(s);
+            if (scheduled >= 1) n = scheduled;
+        }
+        out[s] = n;
+    }
+    return out;
+}
+
+// ---- Solver ----
+int Solver::Add(const int32_t* bodyHandles, int bodyCount, int typeId, const float* prestepLane) {  // Solver.cs:1182-1199
+    TypeInfo info;
+    if (!GetTypeInfo(typeId, info)) throw std::invalid_argument("unknown constraint type id");
+    if (bodyCount != info.bodies) throw std::invalid_argument("body count does not match constraint type");
+    int32_t encoded[4], blocking[4];
+    int blockingCount = 0;
+    for (int i = 0; i < bodyCount; ++i) {  // GetBlockingBodyHandles, Solver.cs:1058-1078: kinematics never block
+        int index = bodies.HandleToIndex[bodyHandles[i]];
+        if (bodies.IsKinematic(index)) {
+            encoded[i] = index | kKinematicMask;
+            if ((size_t)bodyHandles[i] >= kinematicConstrained.size()) kinematicConstrained.resize(bodyHandles[i] + 1, 0);
+            if (!kinematicConstrained[bodyHandles[i]]) {
+                kinematicConstrained[bodyHandles[i]] = 1;
+                ConstrainedKinematicHandles.push_back(bodyHandles[i]);
+            }
+        } else {
+            encoded[i] = index;
+            blocking[blockingCount++] = bodyHandles[i];
+        }
+    }
+    for (int b = 0; b <= (int)Batches.size(); ++b) {
+        if (b == (int)Batches.size()) {  // AllocateNewConstraintBatch, Solver.cs:1080-1091
+            if (b >= kFallbackBatchThreshold) throw std::runtime_error("sequential fallback batch is not supported by this mirror");
+            Batches.emplace_back();
+            batchReferencedHandles.emplace_back();
+        } else {
+            bool fits = true;  // IndexSet.CanFit, IndexSet.cs:70-80
+            for (int i = 0; i < blockingCount; ++i)
+                if (batchReferencedHandles[b].Contains(blocking[i])) { fits = false; break; }
+            if (!fits) continue;
+        }
+        int handle = (int)HandleToConstraint.size();
+        TypeBatch& tb = Batches[b].GetOrCreateTypeBatch(typeId);
+        int index = tb.Allocate(handle, encoded);
+        for (int i = 0; i < blockingCount; ++i) batchReferencedHandles[b].Set(blocking[i]);
+        // ApplyDescription: write the lane (GetOffsetInstance/GetFirst, BepuUtilities/GatherScatter.cs)
+        const int W = kBundleWidth;
+        float* lane = tb.PrestepData.data() + (size_t)(index / W) * info.prestepFloats * W + (index % W);
+        for (int f = 0; f < info.prestepFloats; ++f) lane[(size_t)f * W] = prestepLane[f];
+        HandleToConstraint.push_back({b, typeId, index});
+        return handle;
+    }
+    return -1;
+}
+
+void Solver::ValidateBatches() const {
+    for (size_t b = 0; b < Batches.size(); ++b) {
+        std::vector<uint8_t> seen(bodies.Count(), 0);
+        for (const TypeBatch& tb : Batches[b].TypeBatches) {
+            const int W = kBundleWidth;
+            for (int i = 0; i < tb.ConstraintCount; ++i)
+                for (int k = 0; k < tb.Info.bodies; ++k) {
+                    int32_t ref = tb.BodyReferences[(size_t)(i / W) * tb.Info.bodies * W + (size_t)k * W + (i % W)];
+                    if ((uint32_t)ref < (uint32_t)kKinematicMask) {
+                        if (seen[ref]) throw std::logic_error("dynamic body referenced twice in a non-fallback batch");
+                        seen[ref] = 1;
+                    }
+                }
+        }
+    }
+}
+
+Solver::IntegrationResponsibilities Solver::PrepareConstraintIntegrationResponsibilities() const {  // Solver_Solve.cs:1072-1388
+    IntegrationResponsibilities r;
+    const int W = kBundleWidth;
+    const int batchCount = (int)Batches.size();
+    if (batchCount == 0) return r;
+    size_t words = (bodies.HandleToIndex.size() + 64) / 64;  // (HighestPossiblyClaimedId + 64) / 64
+    r.integrationFlags.resize(batchCount);
+    r.coarseBatchIntegrationResponsibilities.resize(batchCount);
+    IndexSet& merged = r.mergedConstrainedBodyHandles;
+    merged.Flags.assign(words, 0);
+    for (size_t w = 0; w < std::min(words, batchReferencedHandles[0].Flags.size()); ++w) merged.Flags[w] = batchReferencedHandles[0].Flags[w];
+    IndexSet firstObserved;
+    for (int b = 1; b < batchCount; ++b) {
+        const IndexSet& batchHandles = batchReferencedHandles[b];
+        firstObserved.Flags.assign(words, 0);
+        size_t n = std::min(words, batchHandles.Flags.size());
+        for (size_t w = 0; w < n; ++w) {  // :1198-1207
+            uint64_t mergeBundle = merged.Flags[w], batchBundle = batchHandles.Flags[w];
+            merged.Flags[w] = mergeBundle | batchBundle;
+            firstObserved.Flags[w] = ~mergeBundle & batchBundle;
+        }
+        const ConstraintBatch& batch = Batches[b];
+        r.integrationFlags[b].resize(batch.TypeBatches.size());
+        r.coarseBatchIntegrationResponsibilities[b].assign(batch.TypeBatches.size(), 0);
+        for (size_t t = 0; t < batch.TypeBatches.size(); ++t) {  // ComputeIntegrationResponsibilitiesForConstraintRegion, :951-1044
+            const TypeBatch& tb = batch.TypeBatches[t];
+            auto& flagsForTypeBatch = r.integrationFlags[b][t];
+            flagsForTypeBatch.resize(tb.Info.bodies);
+            size_t flagWords = ((size_t)tb.ConstraintCount + 63) / 64;
+            for (auto& s : flagsForTypeBatch) s.Flags.assign(std::max<size_t>(flagWords, 1), 0);
+            uint64_t mergedFlagBundles = 0;
+            for (int i = 0; i < tb.ConstraintCount; ++i) {
+                for (int k = 0; k < tb.Info.bodies; ++k) {
+                    int bodyIndex = tb.BodyReferences[(size_t)(i / W) * tb.Info.bodies * W + (size_t)k * W + (i % W)] & kBodyReferenceMask;
+                    int bodyHandle = bodies.IndexToHandle[bodyIndex];
+                    if (firstObserved.Contains(bodyHandle)) {
+                        flagsForTypeBatch[k].Flags[i >> 6] |= 1ull << (i & 63);
+                        mergedFlagBundles |= 1;
+                    }
+                }
+            }
+            r.coarseBatchIntegrationResponsibilities[b][t] = mergedFlagBundles != 0;
+        }
+    }
+    for (int32_t h : ConstrainedKinematicHandles) merged.Set(h);  // :1378-1381
+    return r;
+}
+
+// ---- Simulation ----
+void Simulation::Timestep(float dt) {  // Simulation.cs:316-326
+    if (!(dt > 0)) throw std::invalid_argument("Timestep duration must be positive.");
+    if (!timestepper) throw std::logic_error("no timestepper (this mirror has no CPU solver: attach a HipTimestepper)");
+    timestepper->Timestep(*this, dt);
+}
+
+// ---- HipTimestepper: DefaultTimestepper.Timestep (DefaultTimestepper.cs:28-43) with simulation.Solve replaced by the C ABI ----
+struct HipApi {
+    void* lib = nullptr;
+#define DECL(name) decltype(&::name) name = nullptr;
+    DECL(bepuhip_last_error) DECL(bepuhip_create) DECL(bepuhip_destroy) DECL(bepuhip_set_bodies) DECL(bepuhip_begin_constraints)
+    DECL(bepuhip_set_type_batch) DECL(bepuhip_end_constraints) DECL(bepuhip_set_constrained_kinematics) DECL(bepuhip_solve)
+    DECL(bepuhip_get_bodies) DECL(bepuhip_get_accumulated_impulses) DECL(bepuhip_get_prestep)
+#undef DECL
+    bool load(const char* path, std::string& err) {
+        lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { err = dlerror(); return false; }
+#define LOAD(name) name = (decltype(name))dlsym(lib, #name); if (!name) { err = std::string("missing symbol ") + #name; return false; }
+        LOAD(bepuhip_last_error) LOAD(bepuhip_create) LOAD(bepuhip_destroy) LOAD(bepuhip_set_bodies) LOAD(bepuhip_begin_constraints)
+        LOAD(bepuhip_set_type_batch) LOAD(bepuhip_end_constraints) LOAD(bepuhip_set_constrained_kinematics) LOAD(bepuhip_solve)
+        LOAD(bepuhip_get_bodies) LOAD(bepuhip_get_accumulated_impulses) LOAD(bepuhip_get_prestep)
+#undef LOAD
+        return true;
+    }
+};
+
+class HipTimestepper : public ITimestepper {
+public:
+    HipApi api;
+    bepuhip_ctx* ctx = nullptr;
+    size_t uploadedConstraintCount = (size_t)-1;
+    HipTimestepper(const char* libraryPath, int device) {
+        std::string err;
+        if (!api.load(libraryPath, err)) throw std::runtime_error("cannot load libbepuhip: " + err);
+        bepuhip_config cfg{device, kBundleWidth, 0};
+        if (api.bepuhip_create(&cfg, &ctx) != BEPUHIP_OK) throw std::runtime_error(std::string("bepuhip_create: ") + api.bepuhip_last_error());
+    }
+    ~HipTimestepper() override { if (ctx) api.bepuhip_destroy(ctx); }
+    void check(int32_t status) {
+        if (status == BEPUHIP_OK) return;
+        std::string msg = api.bepuhip_last_error();
+        if (status == BEPUHIP_E_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+        throw std::runtime_error(msg);  // the C# shim converts these into InvalidOperationException / falls back on UNSUPPORTED
+    }
+    void Timestep(Simulation& sim, float dt) override {
+        // simulation.Sleep / PredictBoundingBoxes / CollisionDetection (DefaultTimestepper.cs:30-37) are out of scope: no-ops here.
+        // ---- simulation.Solve(dt) replaced (DefaultTimestepper.cs:39) ----
+        Solver& solver = sim.solver;
+        // Topology is re-uploaded only when it changed (v1: detected by constraint count); bodies are host-authoritative every frame.
+        check(api.bepuhip_set_bodies(ctx, sim.bodies.DynamicsState.data(), sim.bodies.Count()));
+        if (uploadedConstraintCount != (size_t)solver.ConstraintCount()) {
+            check(api.bepuhip_begin_constraints(ctx, (int)solver.Batches.size(), sim.solveDescription.FallbackBatchThreshold));
+            for (size_t b = 0; b < solver.Batches.size(); ++b)
+                for (const TypeBatch& tb : solver.Batches[b].TypeBatches)
+                    check(api.bepuhip_set_type_batch(ctx, (int)b, tb.TypeId, tb.ConstraintCount, tb.BodyReferences.data(), tb.PrestepData.data(), tb.AccumulatedImpulses.data()));
+            check(api.bepuhip_end_constraints(ctx));
+            std::vector<int32_t> kin;
+            for (int32_t h : solver.ConstrainedKinematicHandles) kin.push_back(sim.bodies.HandleToIndex[h]);
+            check(api.bepuhip_set_constrained_kinematics(ctx, kin.data(), (int)kin.size()));
+            uploadedConstraintCount = (size_t)solver.ConstraintCount();
+        }
+        std::vector<int32_t> iterations = sim.solveDescription.ResolveIterations();
+        bepuhip_integrator in{};
+        in.gravity[0] = sim.callbacks.Gravity.X; in.gravity[1] = sim.callbacks.Gravity.Y; in.gravity[2] = sim.callbacks.Gravity.Z;
+        in.linear_damping = sim.callbacks.LinearDamping; in.angular_damping = sim.callbacks.AngularDamping;
+        in.angular_integration_mode = 0;
+        in.allow_substeps_for_unconstrained = sim.callbacks.AllowSubstepsForUnconstrainedBodies;
+        in.integrate_velocity_for_kinematics = sim.callbacks.IntegrateVelocityForKinematics;
+        check(api.bepuhip_solve(ctx, dt, sim.solveDescription.SubstepCount, iterations.data(), &in));
+        check(api.bepuhip_get_bodies(ctx, sim.bodies.DynamicsState.data(), sim.bodies.Count()));
+        for (size_t b = 0; b < solver.Batches.size(); ++b)
+            for (TypeBatch& tb : solver.Batches[b].TypeBatches) {
+                if (tb.ConstraintCount == 0) continue;
+                check(api.bepuhip_get_accumulated_impulses(ctx, (int)b, tb.TypeId, tb.AccumulatedImpulses.data()));
+                if (tb.Info.incremental) check(api.bepuhip_get_prestep(ctx, (int)b, tb.TypeId, tb.PrestepData.data()));
+            }
+        // simulation.IncrementallyOptimizeDataStructures (DefaultTimestepper.cs:42): out of scope.
+    }
+};
+
+}  // namespace bepu
+
+// ------------------------------------------------------------------------------------------------
+// C exports for Python (ctypes): scene construction, export of the reference-layout buffers, HipTimestepper.
+// ------------------------------------------------------------------------------------------------
+using namespace bepu;
+
+namespace bepu { Simulation* BuildScene(const char* name, int64_t a, int64_t b, int64_t c, uint32_t seed); }
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char* bepuhost_last_error() { return g_err.c_str(); }
+
+void* bepuhost_simulation_create(const float* gravity, float linearDamping, float angularDamping, int velocityIterations, int substeps) {
+    try {
+        PoseIntegratorCallbacks cb;
+        cb.Gravity = {gravity[0], gravity[1], gravity[2]};
+        cb.LinearDamping = linearDamping; cb.AngularDamping = angularDamping;
+        return new Simulation(cb, SolveDescription(velocityIterations, substeps));
+    } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void* bepuhost_scene_create(const char* name, int64_t a, int64_t b, int64_t c, uint32_t seed) {
+    try { return BuildScene(name, a, b, c, seed); } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void bepuhost_simulation_destroy(void* s) {
+    Simulation* sim = (Simulation*)s;
+    if (sim) { delete sim->timestepper; delete sim; }
+}
+int32_t bepuhost_add_body(void* s, const float* pose7, const float* velocity6, const float* inertia7) {
+    BodyDescription d;
+    d.Pose.Position = {pose7[0], pose7[1], pose7[2]};
+    d.Pose.Orientation = {pose7[3], pose7[4], pose7[5], pose7[6]};
+    d.Velocity.Linear = {velocity6[0], velocity6[1], velocity6[2]};
+    d.Velocity.Angular = {velocity6[3], velocity6[4], velocity6[5]};
+    d.LocalInertia.InverseInertiaTensor = {inertia7[0], inertia7[1], inertia7[2], inertia7[3], inertia7[4], inertia7[5]};
+    d.LocalInertia.InverseMass = inertia7[6];
+    return ((Simulation*)s)->bodies.Add(d);
+}
+int32_t bepuhost_add_constraint(void* s, int typeId, const int32_t* bodyHandles, int bodyCount, const float* prestepLane) {
+    try { return ((Simulation*)s)->solver.Add(bodyHandles, bodyCount, typeId, prestepLane); } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int32_t bepuhost_validate(void* s) {
+    try { ((Simulation*)s)->solver.ValidateBatches(); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int32_t bepuhost_body_count(void* s) { return ((Simulation*)s)->bodies.Count(); }
+float* bepuhost_bodies_ptr(void* s) { return ((Simulation*)s)->bodies.DynamicsState.data()->f; }
+const int32_t* bepuhost_index_to_handle(void* s) { return ((Simulation*)s)->bodies.IndexToHandle.data(); }
+const int32_t* bepuhost_handle_to_index(void* s) { return ((Simulation*)s)->bodies.HandleToIndex.data(); }
+int32_t bepuhost_handle_capacity(void* s) { return (int32_t)((Simulation*)s)->bodies.HandleToIndex.size(); }
+int32_t bepuhost_constraint_count(void* s) { return ((Simulation*)s)->solver.ConstraintCount(); }
+int32_t bepuhost_batch_count(void* s) { return (int32_t)((Simulation*)s)->solver.Batches.size(); }
+int32_t bepuhost_type_batch_count(void* s, int b) { return (int32_t)((Simulation*)s)->solver.Batches[b].TypeBatches.size(); }
+struct bepuhost_type_batch_view { int32_t type_id, count, bodies, prestep_floats, impulse_floats, bundle_count; int32_t* refs; float* prestep; float* accumulated; };
+void bepuhost_type_batch(void* s, int b, int t, bepuhost_type_batch_view* out) {
+    TypeBatch& tb = ((Simulation*)s)->solver.Batches[b].TypeBatches[t];
+    *out = {tb.TypeId, tb.ConstraintCount, tb.Info.bodies, tb.Info.prestepFloats, tb.Info.impulseFloats, tb.BundleCount(), tb.BodyReferences.data(), tb.PrestepData.data(), tb.AccumulatedImpulses.data()};
+}
+int32_t bepuhost_kinematic_count(void* s) { return (int32_t)((Simulation*)s)->solver.ConstrainedKinematicHandles.size(); }
+const int32_t* bepuhost_kinematic_handles(void* s) { return ((Simulation*)s)->solver.ConstrainedKinematicHandles.data(); }
+void bepuhost_solve_description(void* s, int32_t* velocityIterations, int32_t* substeps) {
+    *velocityIterations = ((Simulation*)s)->solveDescription.VelocityIterationCount;
+    *substeps = ((Simulation*)s)->solveDescription.SubstepCount;
+}
+
+// Prepass export for parity tests against the oracle: same packing as oracle_prepare_flags.
+int32_t bepuhost_prepare_flags(void* s, uint64_t* outMerged, int64_t mergedCapacity, uint64_t* outFlags, int64_t flagsCapacity, uint8_t* outCoarse) {
+    Simulation* sim = (Simulation*)s;
+    auto r = sim->solver.PrepareConstraintIntegrationResponsibilities();
+    for (int64_t w = 0; w < mergedCapacity; ++w) outMerged[w] = (size_t)w < r.mergedConstrainedBodyHandles.Flags.size() ? r.mergedConstrainedBodyHandles.Flags[w] : 0;
+    int64_t o = 0;
+    size_t flat = 0;
+    for (size_t b = 0; b < sim->solver.Batches.size(); ++b) {
+        for (size_t t = 0; t < sim->solver.Batches[b].TypeBatches.size(); ++t, ++flat) {
+            outCoarse[flat] = b == 0 ? 0 : r.coarseBatchIntegrationResponsibilities[b][t];
+            if (b == 0) continue;
+            int64_t words = (sim->solver.Batches[b].TypeBatches[t].ConstraintCount + 63) / 64;
+            for (auto& slot : r.integrationFlags[b][t]) {
+                if (o + words > flagsCapacity) return -1;
+                for (int64_t w = 0; w < words; ++w) outFlags[o + w] = slot.Flags[w];
+                o += words;
+            }
+        }
+    }
+    return 0;
+}
+
+// Attach a HipTimestepper (ITimestepper) bound to libbepuhip at `libraryPath` and run Simulation.Timestep(dt).
+int32_t bepuhost_attach_hip_timestepper(void* s, const char* libraryPath, int device) {
+    try {
+        Simulation* sim = (Simulation*)s;
+        delete sim->timestepper;
+        sim->timestepper = nullptr;
+        sim->timestepper = new HipTimestepper(libraryPath, device);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int32_t bepuhost_timestep(void* s, float dt) {
+    try { ((Simulation*)s)->Timestep(dt); return 0; }
+    catch (const std::invalid_argument& e) { g_err = e.what(); return -1; }
+    catch (const std::exception& e) { g_err = e.what(); return -2; }
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+"""ctypes binding of the C++ host mirror (host/libbepuhost.so): Bodies / Solver.Add / batch colouring / scene recipes /
+HipTimestepper. The buffers it exposes are in the reference's own layouts (AoS BodyDynamics, AOSOA type batches, W=8)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import numpy as np
+
+from .scene import Scene, SolveDescription, TypeBatchData
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "host", "libbepuhost.so")
+_lib: Optional[C.CDLL] = None
+
+
+class TypeBatchView(C.Structure):
+    _fields_ = [("type_id", C.c_int32), ("count", C.c_int32), ("bodies", C.c_int32), ("prestep_floats", C.c_int32), ("impulse_floats", C.c_int32),
+                ("bundle_count", C.c_int32), ("refs", C.POINTER(C.c_int32)), ("prestep", C.POINTER(C.c_float)), ("accumulated", C.POINTER(C.c_float))]
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: run __graft_entry__.build() first")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.bepuhost_last_error.restype = C.c_char_p
+    lib.bepuhost_simulation_create.restype = vp
+    lib.bepuhost_simulation_create.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int, C.c_int]
+    lib.bepuhost_scene_create.restype = vp
+    lib.bepuhost_scene_create.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_uint32]
+    lib.bepuhost_simulation_destroy.argtypes = [vp]
+    lib.bepuhost_add_body.argtypes = [vp, vp, vp, vp]
+    lib.bepuhost_add_body.restype = i32
+    lib.bepuhost_add_constraint.argtypes = [vp, C.c_int, vp, C.c_int, vp]
+    lib.bepuhost_add_constraint.restype = i32
+    lib.bepuhost_validate.argtypes = [vp]
+    for name in ("body_count", "handle_capacity", "constraint_count", "batch_count", "kinematic_count"):
+        getattr(lib, "bepuhost_" + name).argtypes = [vp]
+        getattr(lib, "bepuhost_" + name).restype = i32
+    lib.bepuhost_type_batch_count.argtypes = [vp, C.c_int]
+    lib.bepuhost_type_batch_count.restype = i32
+    lib.bepuhost_bodies_ptr.argtypes = [vp]
+    lib.bepuhost_bodies_ptr.restype = C.POINTER(C.c_float)
+    for name in ("index_to_handle", "handle_to_index", "kinematic_handles"):
+        getattr(lib, "bepuhost_" + name).argtypes = [vp]
+        getattr(lib, "bepuhost_" + name).restype = C.POINTER(C.c_int32)
+    lib.bepuhost_type_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(TypeBatchView)]
+    lib.bepuhost_solve_description.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.bepuhost_prepare_flags.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, vp]
+    lib.bepuhost_prepare_flags.restype = i32
+    lib.bepuhost_attach_hip_timestepper.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.bepuhost_attach_hip_timestepper.restype = i32
+    lib.bepuhost_timestep.argtypes = [vp, C.c_float]
+    lib.bepuhost_timestep.restype = i32
+    _lib = lib
+    return lib
+
+
+def _err(lib) -> str:
+    return lib.bepuhost_last_error().decode("utf-8", "replace")
+
+
+def _np_from(ptr, count, dtype):
+    if count == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True)
+
+
+class HostSimulation:
+    """Owns a C++ ``bepu::Simulation`` (Simulation.cs:106-326 mirror)."""
+
+    def __init__(self, handle, lib):
+        self.lib, self.h = lib, handle
+
+    @classmethod
+    def create(cls, gravity=(0, -10, 0), linear_damping=0.03, angular_damping=0.03, velocity_iterations=1, substeps=1) -> "HostSimulation":
+        lib = load_library()
+        g = (C.c_float * 3)(*gravity)
+        h = lib.bepuhost_simulation_create(g, linear_damping, angular_damping, velocity_iterations, substeps)
+        if not h:
+            raise ValueError(_err(lib))  # SolveDescription validation (SolveDescription.cs:42-47)
+        return cls(h, lib)
+
+    @classmethod
+    def scene(cls, name: str, a: int = 0, b: int = 0, c: int = 0, seed: int = 5) -> "HostSimulation":
+        lib = load_library()
+        h = lib.bepuhost_scene_create(name.encode(), a, b, c, seed)
+        if not h:
+            raise ValueError(_err(lib))
+        return cls(h, lib)
+
+    def close(self):
+        if self.h:
+            self.lib.bepuhost_simulation_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_body(self, position, orientation, linear, angular, inverse_inertia, inverse_mass) -> int:
+        pose = np.asarray(list(position) + list(orientation), dtype=np.float32)
+        vel = np.asarray(list(linear) + list(angular), dtype=np.float32)
+        inertia = np.asarray(list(inverse_inertia) + [inverse_mass], dtype=np.float32)
+        return self.lib.bepuhost_add_body(self.h, pose.ctypes.data, vel.ctypes.data, inertia.ctypes.data)
+
+    def add_constraint(self, type_id: int, body_handles, prestep_lane) -> int:
+        hs = np.asarray(body_handles, dtype=np.int32)
+        lane = np.asarray(prestep_lane, dtype=np.float32)
+        r = self.lib.bepuhost_add_constraint(self.h, type_id, hs.ctypes.data, hs.size, lane.ctypes.data)
+        if r < 0:
+            raise ValueError(_err(self.lib))
+        return r
+
+    def validate(self):
+        if self.lib.bepuhost_validate(self.h) != 0:
+            raise AssertionError(_err(self.lib))
+
+    def solve_description(self) -> SolveDescription:
+        it, ss = C.c_int32(), C.c_int32()
+        self.lib.bepuhost_solve_description(self.h, C.byref(it), C.byref(ss))
+        return SolveDescription(it.value, ss.value)
+
+    def export(self) -> Scene:
+        """Copy the simulation's buffers (reference layouts) into a Scene."""
+        lib, h = self.lib, self.h
+        n = lib.bepuhost_body_count(h)
+        bodies = _np_from(lib.bepuhost_bodies_ptr(h), n * 32, np.float32).reshape(n, 32)
+        i2h = _np_from(lib.bepuhost_index_to_handle(h), n, np.int32)
+        h2i = _np_from(lib.bepuhost_handle_to_index(h), lib.bepuhost_handle_capacity(h), np.int32)
+        batches: List[List[TypeBatchData]] = []
+        for b in range(lib.bepuhost_batch_count(h)):
+            tbs = []
+            for t in range(lib.bepuhost_type_batch_count(h, b)):
+                v = TypeBatchView()
+                lib.bepuhost_type_batch(h, b, t, C.byref(v))
+                w = 8
+                tbs.append(TypeBatchData(v.type_id, v.count, _np_from(v.refs, v.bundle_count * v.bodies * w, np.int32),
+                                         _np_from(v.prestep, v.bundle_count * v.prestep_floats * w, np.float32),
+                                         _np_from(v.accumulated, v.bundle_count * v.impulse_floats * w, np.float32)))
+            batches.append(tbs)
+        kin = _np_from(lib.bepuhost_kinematic_handles(h), lib.bepuhost_kinematic_count(h), np.int32)
+        return Scene(bodies, i2h, h2i, batches, kin, 8)
+
+    def prepare_flags(self, scene: Scene):
+        words = (int(scene.handle_to_index.size) + 63) // 64 or 1
+        merged = np.zeros(words, dtype=np.uint64)
+        cap = sum(((tb.count + 63) // 64) * tb.bodies for b in scene.batches[1:] for tb in b) + 1
+        flags = np.zeros(cap, dtype=np.uint64)
+        coarse = np.zeros(max(sum(len(b) for b in scene.batches), 1), dtype=np.uint8)
+        if self.lib.bepuhost_prepare_flags(self.h, merged.ctypes.data, words, flags.ctypes.data, cap, coarse.ctypes.data) != 0:
+            raise RuntimeError("prepare_flags capacity")
+        return merged, flags[:cap - 1], coarse
+
+    def attach_hip_timestepper(self, device: int = 0):
+        from .native import LIB_PATH as HIP_LIB
+        if self.lib.bepuhost_attach_hip_timestepper(self.h, HIP_LIB.encode(), device) != 0:
+            raise RuntimeError(_err(self.lib))
+
+    def timestep(self, dt: float):
+        r = self.lib.bepuhost_timestep(self.h, dt)
+        if r == -1:
+            raise ValueError(_err(self.lib))  # ArgumentException (Simulation.cs:318-319)
+        if r != 0:
+            raise RuntimeError(_err(self.lib))

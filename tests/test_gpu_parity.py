@@ -52,3 +52,20 @@ def test_mixed_types_multi_frame(hip_solver_factory):
     m = pu.compare_scenes(ref, got)
     _check(m)
     assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+
+@pytest.mark.parametrize("name,a,frames", [("pyramid", 3, 2), ("pile", 8000, 2), ("ragdoll_tube", 500, 2)])
+def test_reference_scene_recipes(hip_solver_factory, name, a, frames):
+    """Scenes built by the C++ host mirror in the reference's insertion order (greedy batch colouring), solved with each scene's own SolveDescription."""
+    from bepuphysics2_amd.hostlib import HostSimulation
+    sim = HostSimulation.scene(name, a, 1 if name == "ragdoll_tube" else 0, 0, 5)
+    sim.validate()
+    scene, sd = sim.export(), sim.solve_description()
+    sim.close()
+    cb = PoseIntegratorCallbacks()
+    solver = hip_solver_factory()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=frames, threads=4)
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=frames)
+    m = pu.compare_scenes(ref, got)
+    _check(m)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
