@@ -476,10 +476,11 @@ struct Pool {
     void workerLoop() {
         int seen = 0;
         for (;;) {
-            while (generation.load(std::memory_order_acquire) == seen) {
+            for (unsigned spins = 0; generation.load(std::memory_order_acquire) == seen; ++spins) {
                 if (quit.load()) return;
+                if (spins > 2000) std::this_thread::yield();
 #if defined(__x86_64__)
-                __builtin_ia32_pause();
+                else __builtin_ia32_pause();
 #endif
             }
             seen = generation.load(std::memory_order_acquire);
@@ -508,9 +509,10 @@ struct Pool {
         next.store(0); arrived.store(0);
         generation.fetch_add(1, std::memory_order_release);
         drain();
-        while (arrived.load(std::memory_order_acquire) < n - 1) {
+        for (unsigned spins = 0; arrived.load(std::memory_order_acquire) < n - 1; ++spins) {
+            if (spins > 2000) std::this_thread::yield();
 #if defined(__x86_64__)
-            __builtin_ia32_pause();
+            else __builtin_ia32_pause();
 #endif
         }
     }

@@ -1,0 +1,45 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/bepuhip.h declares, and fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from bepuphysics2_amd import native
+from bepuphysics2_amd.scene import TYPE_TABLE
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(REPO, "include", "bepuhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bepuhip_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(native.LIB_PATH)
+    declared = _header_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(native.EXPORTED_SYMBOLS) == declared
+
+
+def test_type_info_table():
+    for tid, (nb, pf, imf, _) in TYPE_TABLE.items():
+        assert native.type_info(tid) == (nb, pf, imf)
+    with pytest.raises(native.UnsupportedError):
+        native.type_info(34)  # Weld: not on the hot path yet
+
+
+def test_create_fails_loudly_without_gpu_or_bad_config():
+    import torch
+    lib = native.load_library()
+    ctx = C.c_void_p()
+    bad = native.Config(0, 7, 0)
+    assert lib.bepuhip_create(C.byref(bad), C.byref(ctx)) == native.BEPUHIP_E_INVALID_ARGUMENT
+    if not torch.cuda.is_available():
+        with pytest.raises(native.BepuHipError) as e:
+            native.HipSolver()
+        assert e.value.code == native.BEPUHIP_E_DEVICE and b"no CPU fallback" in lib.bepuhip_last_error()

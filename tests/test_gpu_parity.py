@@ -69,3 +69,71 @@ def test_reference_scene_recipes(hip_solver_factory, name, a, frames):
     m = pu.compare_scenes(ref, got)
     _check(m)
     assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+
+def test_hip_matches_committed_golden_vectors(hip_solver_factory):
+    """The same fixtures the CPU suite pins the oracle to (tests/golden/small_scenes.npz), now through the C ABI."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_scenes.npz"))
+    solver = hip_solver_factory()
+    sd, cb = SolveDescription(2, 8), PoseIntegratorCallbacks()
+    cols = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 13, 14]
+    for seed, types in ((1, sorted(TYPE_TABLE.keys())), (2, [0, 1, 2, 3, 4, 5, 6, 7]), (3, [22, 23, 25, 26, 27, 30, 46, 47])):
+        scene = small_scenes.random_graph_scene(seed, 120, 300, types)
+        got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+        assert np.array_equal(got.bodies[:, cols].view(np.int32), g[f"graph{seed}_bodies"][:, cols].view(np.int32))
+        imp = np.concatenate([tb.accumulated_lanes().reshape(-1) for b in got.batches for tb in b])
+        assert np.array_equal(imp.view(np.int32), g[f"graph{seed}_impulses"].view(np.int32))
+
+
+def test_integrator_modes_and_iteration_schedule(hip_solver_factory):
+    solver = hip_solver_factory()
+    scene = small_scenes.random_graph_scene(21, 300, 800, sorted(TYPE_TABLE.keys()), kinematic_fraction=0.1, unconstrained_extra=20)
+    for cb in (PoseIntegratorCallbacks(allow_substeps_for_unconstrained_bodies=True),
+               PoseIntegratorCallbacks(integrate_velocity_for_kinematics=True, gravity=(1, -9, 0.5), linear_damping=0.1, angular_damping=0.2)):
+        sd = SolveDescription(1, 3, velocity_iteration_scheduler=lambda s: [3, 0, 2][s])
+        ref = pu.run_oracle(scene, 1 / 30, sd, cb, frames=2)
+        got = pu.run_hip(solver, scene, 1 / 30, sd, cb, frames=2)
+        m = pu.compare_scenes(ref, got)
+        _check(m)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"], m
+
+
+def test_device_constrained_set_matches_oracle_prepass(hip_solver_factory):
+    import oracle_ffi
+    solver = hip_solver_factory()
+    scene = small_scenes.random_graph_scene(5, 500, 900, sorted(TYPE_TABLE.keys()), kinematic_fraction=0.1, unconstrained_extra=40)
+    solver.upload(scene)
+    flags = solver.constrained_flags(scene.body_count)
+    merged, _, _ = oracle_ffi.prepare_flags(scene)
+    bits = np.unpackbits(merged.view(np.uint8), bitorder="little")[: scene.body_count].astype(bool)
+    assert np.array_equal((flags & 1).astype(bool), bits[scene.index_to_handle])
+
+
+def test_error_behaviour_through_abi(hip_solver_factory):
+    from bepuphysics2_amd import native
+    solver = hip_solver_factory()
+    scene = small_scenes.box_stack_scene()
+    solver.upload(scene)
+    cb = PoseIntegratorCallbacks()
+    with pytest.raises(ValueError):
+        solver.solve(0.0, SolveDescription(1, 1), cb)  # ArgumentException in the reference (Simulation.cs:318-319)
+    with pytest.raises(native.UnsupportedError):
+        solver.set_constraints(scene, fallback_batch_threshold=2)  # more batches than the threshold => fallback batch exists
+
+
+def test_hip_timestepper_through_host_mirror(hip_solver_factory):
+    """C++ HipTimestepper (ITimestepper) -> C ABI -> HIP, against the oracle on the exported buffers."""
+    from bepuphysics2_amd.hostlib import HostSimulation
+    sim = HostSimulation.scene("ragdoll_tube", 30, 1, 0, 7)
+    scene, sd = sim.export(), sim.solve_description()
+    ref = pu.run_oracle(scene, 1 / 60, sd, PoseIntegratorCallbacks(), frames=3)
+    sim.attach_hip_timestepper(0)
+    for _ in range(3):
+        sim.timestep(1 / 60)
+    got = sim.export()
+    m = pu.compare_scenes(ref, got)
+    _check(m)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"], m
+    with pytest.raises(ValueError):
+        sim.timestep(-1.0)

@@ -1,0 +1,166 @@
+"""CPU tests of the oracle: the reference's documented error bounds for its trig approximations, the reference's own
+microbenchmark inputs (analytic zero answers), committed golden vectors, and physical invariants that catch sign/transcription
+errors in the jacobians (the oracle's parity with the C# is otherwise unpinned — SURVEY.md §8c)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi
+import small_scenes
+from bepuphysics2_amd.scene import TYPE_TABLE, PoseIntegratorCallbacks, SolveDescription, make_body
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_trig_error_bounds_documented_by_reference():
+    # BepuUtilities/MathHelper.cs:270,306,348: "Maximum error a little below 8e-7 (cos) / 5e-7 (sin) for -2pi..2pi", acos "< 5.17e-07".
+    x = np.linspace(-2 * np.pi, 2 * np.pi, 200001).astype(np.float32)
+    s, c, _ = oracle_ffi.math_probe(x)
+    assert np.abs(s - np.sin(x.astype(np.float64))).max() < 5.2e-7 + 2e-7  # + fp32 range-reduction noise the reference mentions
+    assert np.abs(c - np.cos(x.astype(np.float64))).max() < 8e-7 + 2e-7
+    u = np.linspace(-1, 1, 100001).astype(np.float32)
+    _, _, a = oracle_ffi.math_probe(u)
+    assert np.abs(a - np.arccos(u.astype(np.float64))).max() < 5.17e-7 + 3e-7
+    # clamping outside [-1, 1]
+    _, _, a = oracle_ffi.math_probe(np.asarray([-1.5, 1.5], np.float32))
+    assert a[0] == np.float32(np.pi) and a[1] == 0
+
+
+def test_type_table_matches_oracle():
+    import ctypes as C
+    lib = oracle_ffi.load()
+    for tid, (nb, pf, imf, name) in TYPE_TABLE.items():
+        b, p, i, inc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        assert lib.oracle_type_info(tid, C.byref(b), C.byref(p), C.byref(i), C.byref(inc)) == 0
+        assert (b.value, p.value, i.value) == (nb, pf, imf), name
+        assert bool(inc.value) == name.startswith("Contact")
+
+
+def test_reference_microbenchmark_inputs_give_exact_zero():
+    """TwoBodyConstraintBenchmarks.cs:42-117: zero velocities, zero depth/error => every velocity and impulse stays exactly 0."""
+    import golden.make_golden as mg
+    for name, type_id, lane in mg.microbench_inputs():
+        a, b, acc = mg.run_micro(type_id, lane)
+        assert not np.any(a[8:15]) and not np.any(b[8:15]) and not np.any(acc), name
+
+
+def test_golden_vectors_regression():
+    import golden.make_golden as mg
+    g = np.load(os.path.join(GOLDEN, "microbench.npz"))
+    va = np.asarray([0.3, -0.2, 0.1, 0.05, 0.4, -0.3], np.float32)
+    vb = np.asarray([-0.1, 0.25, 0.0, -0.2, 0.1, 0.15], np.float32)
+    for name, type_id, lane in mg.microbench_inputs():
+        a, b, acc = mg.run_micro(type_id, lane, va, vb, iterations=8)
+        assert np.array_equal(a.view(np.int32), g[f"microv_{name}_a"].view(np.int32))
+        assert np.array_equal(b.view(np.int32), g[f"microv_{name}_b"].view(np.int32))
+        assert np.array_equal(acc.view(np.int32), g[f"microv_{name}_acc"].view(np.int32))
+    s = np.load(os.path.join(GOLDEN, "small_scenes.npz"))
+    sd, cb = SolveDescription(2, 8), PoseIntegratorCallbacks()
+    for seed, types in ((1, sorted(TYPE_TABLE.keys())), (2, [0, 1, 2, 3, 4, 5, 6, 7]), (3, [22, 23, 25, 26, 27, 30, 46, 47])):
+        sc = small_scenes.random_graph_scene(seed, 120, 300, types)
+        for _ in range(2):
+            oracle_ffi.solve(sc, 1 / 60, sd, cb)
+        assert np.array_equal(sc.bodies.view(np.int32), s[f"graph{seed}_bodies"].view(np.int32))
+
+
+def _momentum(bodies):
+    """Linear and angular momentum (about the origin) of dynamic bodies, using the WORLD inverse inertia slots."""
+    p_tot, l_tot = np.zeros(3), np.zeros(3)
+    for b in bodies.astype(np.float64):
+        if b[30] == 0:
+            continue
+        m = 1.0 / b[30]
+        inv = np.array([[b[24], b[25], b[27]], [b[25], b[26], b[28]], [b[27], b[28], b[29]]])
+        inertia = np.linalg.inv(inv)
+        v, w, r = b[8:11], b[12:15], b[4:7]
+        p_tot += m * v
+        l_tot += np.cross(r, m * v) + inertia @ w
+    return p_tot, l_tot
+
+
+@pytest.mark.parametrize("type_id", [t for t, v in TYPE_TABLE.items() if v[0] == 2])
+def test_two_body_constraints_conserve_momentum(type_id):
+    """Each two-body constraint applies equal and opposite impulses (at a common point for contacts / ball sockets):
+    linear and angular momentum of an isolated dynamic pair are conserved by WarmStart + Solve."""
+    rng = np.random.default_rng(40 + type_id)
+    pa, pb = rng.uniform(-1, 1, 3).astype(np.float32), rng.uniform(-1, 1, 3).astype(np.float32)
+    a, b = small_scenes.random_dynamic_body(rng, pa), small_scenes.random_dynamic_body(rng, pb)
+    name = TYPE_TABLE[type_id][3]
+    for body in (a, b):  # world inertia = R^T I_local R is what a solve would have stored; use local with identity orientation for simplicity
+        body[0:4] = (0, 0, 0, 1)
+        body[24:31] = body[16:23]
+    lane = np.asarray(small_scenes.prestep_for(rng, type_id, pa, pb), np.float32)
+    if name in ("BallSocket", "SwivelHinge", "Hinge"):
+        # these act at the joint anchor: offsets are what they are; momentum about the origin is conserved only if both impulses act at one
+        # world point, which holds when anchorA == anchorB. Choose LocalOffsetB so that the anchors coincide.
+        off_a = lane[0:3]
+        off_b_index = 3 if name == "BallSocket" else 6
+        lane[off_b_index:off_b_index + 3] = (pa + off_a) - pb
+    acc = rng.uniform(0, 0.02, TYPE_TABLE[type_id][2]).astype(np.float32)
+    bodies0 = np.stack([a, b])
+    p0, l0 = _momentum(bodies0)
+    oracle_ffi.constraint_iterate(type_id, a, b, lane, acc, 1 / 60, 3)
+    p1, l1 = _momentum(np.stack([a, b]))
+    assert np.allclose(p0, p1, atol=2e-5), (name, p0, p1)
+    assert np.allclose(l0, l1, atol=5e-5), (name, l0, l1)
+
+
+def test_ball_socket_removes_anchor_velocity():
+    rng = np.random.default_rng(3)
+    a, b = small_scenes.random_dynamic_body(rng, (0, 0, 0)), small_scenes.random_dynamic_body(rng, (1, 0, 0))
+    for body in (a, b):
+        body[0:4] = (0, 0, 0, 1)
+        body[24:31] = body[16:23]
+    lane = np.asarray([0.5, 0, 0, -0.5, 0, 0, 2 * np.pi * 120, 2.0], np.float32)  # stiff, anchors coincide => zero position error
+    acc = np.zeros(3, np.float32)
+    oracle_ffi.constraint_iterate(22, a, b, lane, acc, 1 / 60, 20)
+    va = a[8:11] + np.cross(a[12:15], [0.5, 0, 0])
+    vb = b[8:11] + np.cross(b[12:15], [-0.5, 0, 0])
+    assert np.abs(va - vb).max() < 1e-3
+
+
+def test_contact_stops_approach_and_never_pulls():
+    a = make_body(position=(0, 0.5, 0), linear=(0.3, -2.0, 0.1), inverse_inertia=(6, 0, 6, 0, 0, 6))
+    a[24:31] = a[16:23]
+    lane = []
+    for dx, dz in ((-0.5, -0.5), (0.5, -0.5), (-0.5, 0.5), (0.5, 0.5)):
+        lane += [dx, -0.5, dz, 0.0]
+    lane += [0, 1, 0, 1.0, 2 * np.pi * 30, 2.0, 2.0]
+    lane = np.asarray(lane, np.float32)
+    acc = np.zeros(7, np.float32)
+    oracle_ffi.constraint_iterate(3, a, None, lane, acc, 1 / 60, 10)
+    assert a[9] > -0.05  # approach velocity along the normal removed (soft constraint: small residual)
+    assert np.all(acc[2:6] >= 0)  # penetration impulses are clamped non-negative (PenetrationLimit.cs:23)
+    assert np.hypot(acc[0], acc[1]) <= 1.0 * 0.25 * acc[2:6].sum() * 4 + 1e-6  # friction cone
+
+
+def test_threads_and_fast_build_are_bitwise_identical():
+    sc = small_scenes.random_graph_scene(9, 400, 1500, sorted(TYPE_TABLE.keys()))
+    sd, cb = SolveDescription(2, 3), PoseIntegratorCallbacks()
+    ref = sc.copy()
+    oracle_ffi.solve(ref, 1 / 60, sd, cb)
+    for threads, fast in ((4, False), (1, True), (3, True)):
+        other = sc.copy()
+        oracle_ffi.solve(other, 1 / 60, sd, cb, threads=threads, fast=fast)
+        assert np.array_equal(ref.bodies.view(np.int32), other.bodies.view(np.int32)), (threads, fast)
+
+
+def test_unconstrained_and_kinematic_integration_modes():
+    """IntegrateBundlesAfterSubstepping semantics (PoseIntegrator.cs:537-693): unconstrained bodies take one step of dt (velocity -> pose)
+    unless AllowSubstepsForUnconstrainedBodies; kinematics keep their velocity unless IntegrateVelocityForKinematics."""
+    from bepuphysics2_amd.scene import SceneBuilder
+    sb = SceneBuilder()
+    sb.add_body(make_body(position=(0, 0, 0), linear=(1, 0, 0)))
+    sb.add_body(make_body(position=(5, 0, 0), linear=(0, 1, 0), inverse_inertia=(0,) * 6, inverse_mass=0))
+    dt = np.float32(1 / 60)
+    for allow in (False, True):
+        sc = sb.build()
+        cb = PoseIntegratorCallbacks(gravity=(0, -10, 0), linear_damping=0, angular_damping=0, allow_substeps_for_unconstrained_bodies=allow)
+        oracle_ffi.solve(sc, float(dt), SolveDescription(1, 4), cb)
+        if not allow:
+            vy = np.float32(0) + np.float32(-10) * dt
+            assert sc.bodies[0, 9] == vy and sc.bodies[0, 5] == np.float32(0) + vy * dt
+        else:
+            assert abs(sc.bodies[0, 9] - (-10 / 60)) < 1e-6
+        assert sc.bodies[1, 9] == 1 and abs(sc.bodies[1, 5] - 1 / 60) < 1e-7  # kinematic: velocity untouched, pose advanced
