@@ -17,8 +17,10 @@
 // gives the argument that this is value-identical (nothing reads a body between its integration and its first constraint).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -40,18 +42,30 @@ constexpr unsigned kDynamicLimit = 1u << 30;  // Bodies_GatherScatter.cs:107-118
 constexpr int kRefMask = 0x3FFFFFFF;
 constexpr int kBlock = 64;  // one wavefront per workgroup: a batch rarely fills the chip, so spread waves over as many CUs as possible
 
-struct DevTypeBatch {
-    int type_id, count, stride, block_begin;
-    int* refs;
-    float* prestep;
-    float* accum;
-};
-
 struct StepParams {
     float dt, inv_dt;
     float gx, gy, gz;  // gravity * dt
     float lin_damp, ang_damp;
 };
+
+struct DevTypeBatch {
+    int type_id, count, stride, block_begin;
+    int* refs;
+    float* prestep;
+    float* accum;
+    int* lrefs;  // cluster path: per-slot index into the owning cluster's LDS body table (bit 30 = kinematic, never written)
+};
+
+// ---- cluster path descriptors (see cluster_kernel) ----
+struct ClusterItem { int tb, start, count, batch; };  // <= 64 consecutive constraints of one type batch, all owned by one cluster
+struct ClusterDesc { int body_begin, body_count, item_begin, item_count, batch_item_offset; };
+constexpr int kMaxClusterSubsteps = 16;
+struct ClusterParams {
+    int substeps, batch_count, integrate_velocity_for_kinematics;
+    int iters[kMaxClusterSubsteps];
+    StepParams sp;
+};
+
 
 struct DBody {
     V3 pos; Q ori; BodyVel vel; Inertia inertia;
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void batch_kernel(const DevTypeBatch* __res
 }
 
 // Body flag bits (per body index).
-enum { kFlagConstrained = 1, kFlagDynamicConstrained = 2, kFlagConstrainedKinematic = 4 };
+enum { kFlagConstrained = 1, kFlagDynamicConstrained = 2, kFlagConstrainedKinematic = 4, kFlagClustered = 8 /* dynamic body owned by a cluster_kernel workgroup */ };
 
 // Device-side equivalent of the merged constrained-body set of PrepareConstraintIntegrationResponsibilities
 // (Solver_Solve.cs:1198-1207,1378-1381): every body referenced as dynamic gets integration inside the solver.
@@ -169,15 +183,40 @@ __global__ void mark_constrained_kernel(const int* __restrict__ refs, int count,
         atomicOr(&flags[ref & kRefMask], bits);
     }
 }
-__global__ void mark_kinematic_kernel(const int* __restrict__ indices, int count, unsigned* flags) {
+__global__ void mark_indices_kernel(const int* __restrict__ indices, int count, unsigned* flags, unsigned bits) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) atomicOr(&flags[indices[i]], (unsigned)(kFlagConstrainedKinematic | kFlagConstrained));
+    if (i < count) atomicOr(&flags[indices[i] & kRefMask], bits);
 }
 
 __device__ __forceinline__ void velocity_callback(const StepParams& sp, BodyVel& v) {  // Demos/DemoCallbacks.cs:100-109
     V3 g = {sp.gx, sp.gy, sp.gz};
     v.lin = scale(add(v.lin, g), sp.lin_damp);
     v.ang = scale(v.ang, sp.ang_damp);
+}
+
+// Cluster path only: advance the constrained kinematic bodies in global memory through the in-solver substeps
+// (PoseIntegrator.cs:451-535 applied substep_count times: substep 0 velocity only, later substeps pose then velocity).
+__global__ void kinematic_substeps_kernel(float4* bodies, const int* __restrict__ indices, int count, int substeps, int integrate_velocity_for_kinematics, StepParams sp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float4* base = bodies + (size_t)(indices[i] & kRefMask) * 8;
+    float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
+    Q ori = {q4.x, q4.y, q4.z, q4.w};
+    V3 pos = {p4.x, p4.y, p4.z};
+    BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+    for (int s = 0; s < substeps; ++s) {
+        if (s > 0) {
+            pos = add(pos, scale(vel.lin, sp.dt));
+            ori = integrateOrientation(ori, vel.ang, sp.dt * 0.5f);
+        }
+        if (integrate_velocity_for_kinematics) velocity_callback(sp, vel);
+    }
+    base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+    base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+    if (integrate_velocity_for_kinematics) {
+        base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+        base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+    }
 }
 
 // Per-substep integration of every constrained body — the work the reference fuses into the first-touching constraint's
@@ -189,6 +228,7 @@ __global__ __launch_bounds__(256) void substep_integrate_kernel(float4* bodies, 
     if (i >= count) return;
     unsigned f = flags[i];
     float4* base = bodies + (size_t)i * 8;
+    if (f & kFlagClustered) return;  // integrated in LDS by the owning cluster_kernel workgroup
     if (f & kFlagDynamicConstrained) {
         float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3], i0 = base[4], i1 = base[5];
         Q ori = {q4.x, q4.y, q4.z, q4.w};
@@ -232,6 +272,7 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float4* base = bodies + (size_t)i * 8;
+    if (flags[i] & kFlagClustered) return;  // final pose already written by the owning cluster_kernel workgroup
     const bool unconstrained = !(flags[i] & kFlagConstrained);
     const float effective_dt = allow_substeps_for_unconstrained ? substep_dt : (unconstrained ? dt : substep_dt);  // :591-599
     const float half_dt = effective_dt * 0.5f;
@@ -259,6 +300,206 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
     }
     base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
     base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Cluster path: islands (connected components of the constraint graph through dynamic bodies) are independent, so a workgroup
+// that owns whole islands can run EVERY stage of EVERY substep for them with workgroup barriers only: the island's bodies live in
+// LDS for the whole frame (Bodies_GatherScatter's gather/scatter becomes ds_read_b128/ds_write_b128 on a per-workgroup body table),
+// batches still execute in the host's order (the per-body operation order — hence every result bit — is unchanged),
+// and the 100+ dependent kernel boundaries of the global schedule disappear. HBM sees each body twice per frame (load, write back)
+// plus the constraint stream.
+// LDS body record: 6 x float4 = {orientation, position, linear, angular, world inverse inertia xx..zx, {zy, zz, invMass, -}}.
+// ------------------------------------------------------------------------------------------------
+constexpr int kLdsBodyVec = 6;
+
+template <int ACCESS>
+__device__ __forceinline__ void load_body_lds(const float4* lds, int lref, DBody& b) {
+    const float4* base = lds + (lref & kRefMask) * kLdsBodyVec;
+    if (ACCESS & kOri) { float4 q = base[0]; b.ori = {q.x, q.y, q.z, q.w}; } else b.ori = {0, 0, 0, 0};
+    if (ACCESS & kPos) { float4 p = base[1]; b.pos = {p.x, p.y, p.z}; } else b.pos = {0, 0, 0};
+    if (ACCESS & kLin) { float4 l = base[2]; b.vel.lin = {l.x, l.y, l.z}; b.linw = l.w; } else { b.vel.lin = {0, 0, 0}; b.linw = 0; }
+    if (ACCESS & kAng) { float4 a = base[3]; b.vel.ang = {a.x, a.y, a.z}; b.angw = a.w; } else { b.vel.ang = {0, 0, 0}; b.angw = 0; }
+    if (ACCESS & kInertia) {
+        float4 i0 = base[4], i1 = base[5];
+        b.inertia.t = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+        b.inertia.invMass = i1.z;
+    } else { b.inertia.t = {0, 0, 0, 0, 0, 0}; b.inertia.invMass = 0; }
+}
+template <int ACCESS>
+__device__ __forceinline__ void store_velocity_lds(float4* lds, int lref, const DBody& b) {
+    if ((unsigned)lref >= kDynamicLimit) return;
+    float4* base = lds + lref * kLdsBodyVec;
+    if (ACCESS & kLin) base[2] = make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, b.linw);
+    if (ACCESS & kAng) base[3] = make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, b.angw);
+}
+
+template <class F, int STAGE>
+__device__ __forceinline__ void run_cluster_constraint(const DevTypeBatch& tb, int i, float4* lds, float dt, float inv_dt) {
+    const int stride = tb.stride;
+    const int refA = tb.lrefs[i];
+    const int refB = (F::bodies == 2) ? tb.lrefs[stride + i] : -1;
+    float p[F::prestepFloats];
+    _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = tb.prestep[(size_t)f * stride + i];
+    DBody A, B;
+    if (STAGE == kStageIncremental) {
+        load_body_lds<kAccessOnlyVelocity>(lds, refA, A);
+        if (F::bodies == 2) load_body_lds<kAccessOnlyVelocity>(lds, refB, B); else load_body_lds<0>(lds, 0, B);
+        F::incrementalUpdate(dt, A.vel, B.vel, p);
+        if constexpr (F::incremental) {
+            _Pragma("unroll") for (int cidx = 0; cidx < F::impulseFloats - 3; ++cidx) tb.prestep[(size_t)(4 * cidx + 3) * stride + i] = p[4 * cidx + 3];
+        }
+        return;
+    }
+    float a[F::impulseFloats];
+    _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = tb.accum[(size_t)f * stride + i];
+    constexpr int accA = (STAGE == kStageWarmStart) ? F::wsA : F::svA;
+    constexpr int accB = (STAGE == kStageWarmStart) ? F::wsB : F::svB;
+    load_body_lds<accA>(lds, refA, A);
+    if (F::bodies == 2) load_body_lds<accB>(lds, refB, B); else load_body_lds<0>(lds, 0, B);
+    if (STAGE == kStageWarmStart) {
+        F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel);
+    } else {
+        F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel);
+        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) tb.accum[(size_t)f * stride + i] = a[f];
+    }
+    store_velocity_lds<accA>(lds, refA, A);
+    if (F::bodies == 2) store_velocity_lds<accB>(lds, refB, B);
+}
+
+template <int STAGE>
+__device__ __forceinline__ void run_cluster_item(const DevTypeBatch& tb, int i, float4* lds, float dt, float inv_dt) {
+    switch (tb.type_id) {
+        case kContact1OneBody: run_cluster_constraint<Contact<1, false>, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kContact2OneBody: run_cluster_constraint<Contact<2, false>, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kContact3OneBody: run_cluster_constraint<Contact<3, false>, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kContact4OneBody: run_cluster_constraint<Contact<4, false>, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kContact1: run_cluster_constraint<Contact<1, true>, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kContact2: run_cluster_constraint<Contact<2, true>, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kContact3: run_cluster_constraint<Contact<3, true>, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kContact4: run_cluster_constraint<Contact<4, true>, STAGE>(tb, i, lds, dt, inv_dt); break;
+        default: break;
+    }
+    if (STAGE == kStageIncremental) return;
+    switch (tb.type_id) {
+        case kBallSocket: run_cluster_constraint<BallSocket, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kAngularHinge: run_cluster_constraint<AngularHinge, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kSwingLimit: run_cluster_constraint<SwingLimit, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kTwistServo: run_cluster_constraint<TwistServo, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kTwistLimit: run_cluster_constraint<TwistLimit, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kAngularMotor: run_cluster_constraint<AngularMotor, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kSwivelHinge: run_cluster_constraint<SwivelHinge, STAGE>(tb, i, lds, dt, inv_dt); break;
+        case kHinge: run_cluster_constraint<Hinge, STAGE>(tb, i, lds, dt, inv_dt); break;
+        default: break;
+    }
+}
+
+constexpr int kClusterThreads = 512;
+
+__global__ __launch_bounds__(kClusterThreads) void cluster_kernel(const ClusterDesc* __restrict__ clusters, const ClusterItem* __restrict__ items,
+                                                                   const int* __restrict__ batch_item_begin, const int* __restrict__ cluster_bodies,
+                                                                   const DevTypeBatch* __restrict__ tbs, float4* bodies, ClusterParams cp) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];
+    const ClusterDesc cd = clusters[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
+    const float dt = cp.sp.dt, inv_dt = cp.sp.inv_dt;
+    // Load the cluster's bodies (its islands' dynamic bodies + the kinematic bodies they reference) into LDS.
+    for (int j = tid; j < cd.body_count; j += blockDim.x) {
+        const float4* base = bodies + (size_t)(cluster_bodies[cd.body_begin + j] & kRefMask) * 8;
+        float4* r = lds + j * kLdsBodyVec;
+        r[0] = base[0]; r[1] = base[1]; r[2] = base[2]; r[3] = base[3]; r[4] = base[6]; r[5] = base[7];
+    }
+    __syncthreads();
+    const int* bib = batch_item_begin + cd.batch_item_offset;
+    for (int s = 0; s < cp.substeps; ++s) {
+        if (s > 0) {  // Solver_Solve.cs:1427-1439: contact depths advance with the pre-integration velocities
+            for (int k = cd.item_begin + wave; k < cd.item_begin + cd.item_count; k += nwaves) {
+                const ClusterItem it = items[k];
+                if (lane < it.count) run_cluster_item<kStageIncremental>(tbs[it.tb], it.start + lane, lds, dt, inv_dt);
+            }
+            __syncthreads();
+        }
+        // Integration of every constrained body of the cluster (TypeProcessor.cs:1204-1283, PoseIntegrator.cs:451-535).
+        for (int j = tid; j < cd.body_count; j += blockDim.x) {
+            const int g = cluster_bodies[cd.body_begin + j];
+            float4* r = lds + j * kLdsBodyVec;
+            float4 q4 = r[0], p4 = r[1], l4 = r[2], a4 = r[3];
+            Q ori = {q4.x, q4.y, q4.z, q4.w};
+            V3 pos = {p4.x, p4.y, p4.z};
+            BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+            if ((unsigned)g < kDynamicLimit) {
+                const float4* gb = bodies + (size_t)g * 8;
+                const float4 i0 = gb[4], i1 = gb[5];
+                Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+                if (s > 0) {
+                    pos = add(pos, scale(vel.lin, dt));
+                    ori = integrateOrientation(ori, vel.ang, dt * 0.5f);
+                    r[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+                    r[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+                }
+                Sym3 world = rotateInverseInertia(local, ori);
+                velocity_callback(cp.sp, vel);
+                r[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+                r[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+                r[4] = make_float4(world.xx, world.yx, world.yy, world.zx);
+                r[5] = make_float4(world.zy, world.zz, i1.z, r[5].w);
+            } else {  // kinematic: this cluster's private copy follows the same arithmetic as the global kinematic pass
+                if (s > 0) {
+                    pos = add(pos, scale(vel.lin, dt));
+                    ori = integrateOrientation(ori, vel.ang, dt * 0.5f);
+                    r[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+                    r[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+                }
+                if (cp.integrate_velocity_for_kinematics) {
+                    velocity_callback(cp.sp, vel);
+                    r[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+                    r[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+                }
+            }
+        }
+        __syncthreads();
+        for (int b = 0; b < cp.batch_count; ++b) {  // warm start, batches in order (Solver_Solve.cs:1447-1463)
+            const int k0 = bib[b], k1 = bib[b + 1];
+            if (k0 == k1) continue;
+            for (int k = k0 + wave; k < k1; k += nwaves) {
+                const ClusterItem it = items[k];
+                if (lane < it.count) run_cluster_item<kStageWarmStart>(tbs[it.tb], it.start + lane, lds, dt, inv_dt);
+            }
+            __syncthreads();
+        }
+        for (int iter = 0; iter < cp.iters[s]; ++iter) {  // velocity iterations (:1464-1476)
+            for (int b = 0; b < cp.batch_count; ++b) {
+                const int k0 = bib[b], k1 = bib[b + 1];
+                if (k0 == k1) continue;
+                for (int k = k0 + wave; k < k1; k += nwaves) {
+                    const ClusterItem it = items[k];
+                    if (lane < it.count) run_cluster_item<kStageSolve>(tbs[it.tb], it.start + lane, lds, dt, inv_dt);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // Trailing pose integration of constrained bodies (PoseIntegrator.cs:684-691) and write-back.
+    for (int j = tid; j < cd.body_count; j += blockDim.x) {
+        const int g = cluster_bodies[cd.body_begin + j];
+        if ((unsigned)g >= kDynamicLimit) continue;  // kinematic bodies are advanced in global memory by the body kernels
+        const float4* r = lds + j * kLdsBodyVec;
+        float4 q4 = r[0], p4 = r[1], l4 = r[2], a4 = r[3];
+        Q ori = {q4.x, q4.y, q4.z, q4.w};
+        V3 pos = {p4.x, p4.y, p4.z};
+        V3 lin = {l4.x, l4.y, l4.z}, ang = {a4.x, a4.y, a4.z};
+        ori = integrateOrientation(ori, ang, dt * 0.5f);
+        pos = add(pos, scale(lin, dt));
+        float4* gb = bodies + (size_t)g * 8;
+        gb[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+        gb[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+        gb[2] = l4;
+        gb[3] = a4;
+        gb[6] = r[4];
+        gb[7] = r[5];
+    }
 }
 
 }  // namespace
@@ -295,7 +536,14 @@ static bool type_info(int id, TypeInfoH& t) {
 struct HostTypeBatch {
     int batch, type_id, count, stride;
     TypeInfoH info;
-    size_t refs_off, prestep_off, accum_off;  // offsets (in 4-byte words) into the constraint slab
+    size_t refs_off, prestep_off, accum_off, lrefs_off;  // offsets (in 4-byte words) into the constraint slab
+    std::vector<int32_t> perm;      // cluster path: device index -> host index inside the type batch (empty = identity)
+    std::vector<int32_t> inv;       // host index -> device index (lazily built)
+    int perm_inverse(int host_index) {
+        if (inv.empty()) { inv.resize(perm.size()); for (size_t d = 0; d < perm.size(); ++d) inv[perm[d]] = (int32_t)d; }
+        return inv[host_index];
+    }
+    std::vector<int32_t> lrefs_soa; // cluster path: local (LDS) body indices
     std::vector<int32_t> refs_soa;
     std::vector<float> prestep_soa, accum_soa;  // host staging until end_constraints
 };
@@ -335,6 +583,17 @@ struct bepuhip_ctx {
     DevTypeBatch* d_inc_tbs = nullptr;   // incremental-update grid (contacts of all batches)
     int inc_tb_count = 0, inc_blocks = 0;
     int64_t total_constraints = 0;
+    // cluster path
+    bool clusters_enabled = false;
+    int cluster_count = 0, cluster_max_bodies = 0;
+    ClusterDesc* d_clusters = nullptr;
+    ClusterItem* d_items = nullptr;
+    int* d_batch_item_begin = nullptr;
+    int* d_cluster_bodies = nullptr;
+    int* d_clustered_dynamic = nullptr;
+    int clustered_dynamic_count = 0;
+    int* d_kinlist = nullptr;       // constrained kinematic body indices derived from the body references
+    int kinlist_count = 0;
     // measurement
     float last_ms = 0;
     int64_t last_constraint_iterations = 0;
@@ -351,10 +610,170 @@ static void free_constraints(bepuhip_ctx* c) {
     if (c->d_slab0) hipFree(c->d_slab0);
     if (c->d_tbs) hipFree(c->d_tbs);
     if (c->d_inc_tbs) hipFree(c->d_inc_tbs);
+    if (c->d_clusters) hipFree(c->d_clusters);
+    if (c->d_items) hipFree(c->d_items);
+    if (c->d_batch_item_begin) hipFree(c->d_batch_item_begin);
+    if (c->d_cluster_bodies) hipFree(c->d_cluster_bodies);
+    if (c->d_clustered_dynamic) hipFree(c->d_clustered_dynamic);
+    if (c->d_kinlist) hipFree(c->d_kinlist);
+    c->d_clusters = nullptr; c->d_items = nullptr; c->d_batch_item_begin = nullptr; c->d_cluster_bodies = nullptr;
+    c->d_clustered_dynamic = nullptr; c->d_kinlist = nullptr;
+    c->clusters_enabled = false; c->cluster_count = 0; c->clustered_dynamic_count = 0; c->kinlist_count = 0;
     c->d_slab = c->d_slab0 = nullptr;
     c->d_tbs = c->d_inc_tbs = nullptr;
     c->tbs.clear();
     c->built = false;
+}
+
+
+// ---- cluster planning (host, once per topology upload) ----
+// Islands = connected components through dynamic bodies (kinematic references never connect: they are read-only to the solver).
+// Whole islands are packed, in body-index order, into clusters of at most `cap` LDS-resident bodies; each type batch is
+// reordered so that every cluster's constraints are contiguous (coalesced loads per <=64-lane item).
+struct ClusterPlan {
+    bool enabled = false;
+    std::vector<ClusterDesc> clusters;
+    std::vector<ClusterItem> items;
+    std::vector<int> batch_item_begin, cluster_bodies, clustered_dynamic, kinlist;
+    int max_bodies = 0;
+};
+
+static int env_int(const char* name, int fallback) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : fallback;
+}
+
+static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
+    constexpr int kLdsBudgetBodies = 1536;  // 1536 x 96 B = 144 KiB of the 160 KiB LDS
+    int universe = 0;
+    for (auto& tb : c->tbs)
+        for (int32_t r : tb.refs_soa)
+            if (r >= 0) universe = std::max(universe, (r & kRefMask) + 1);
+    // kinematic list (Solver.ConstrainedKinematicHandles equivalent), always built
+    {
+        std::vector<uint8_t> seen(universe, 0);
+        for (auto& tb : c->tbs)
+            for (int k = 0; k < tb.info.bodies; ++k)
+                for (int i = 0; i < tb.count; ++i) {
+                    int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r >= kDynamicLimit && r >= 0 && !seen[r & kRefMask]) { seen[r & kRefMask] = 1; plan.kinlist.push_back(r & kRefMask); }
+                }
+    }
+    if ((c->flags & 2 /* BEPUHIP_FLAG_NO_CLUSTERS */) || env_int("BEPUHIP_NO_CLUSTERS", 0) || universe == 0 || c->total_constraints == 0) return;
+    std::vector<int32_t> parent(universe);
+    for (int i = 0; i < universe; ++i) parent[i] = i;
+    auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    std::vector<uint8_t> is_dyn(universe, 0);
+    for (auto& tb : c->tbs) {
+        for (int i = 0; i < tb.count; ++i) {
+            int first = -1;
+            for (int k = 0; k < tb.info.bodies; ++k) {
+                int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                if ((uint32_t)r >= kDynamicLimit) continue;
+                is_dyn[r] = 1;
+                if (first < 0) first = find(r);
+                else { int o = find(r); if (o != first) { if (o < first) std::swap(o, first); parent[o] = first; } }
+            }
+            if (first < 0) return;  // a constraint with no dynamic body: leave everything to the global path
+        }
+    }
+    // component sizes (root = smallest body index of the component)
+    std::vector<int32_t> comp_size(universe, 0);
+    int64_t total_dyn = 0;
+    for (int i = 0; i < universe; ++i) if (is_dyn[i]) { comp_size[find(i)]++; ++total_dyn; }
+    int cap = env_int("BEPUHIP_CLUSTER_BODIES", 0);
+    if (cap <= 0) {
+        // default: one resident workgroup per CU (the kernel's register budget admits one 512-thread workgroup per CU), no second round
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        int64_t target = (total_dyn + (cus * 31 / 32) - 1) / std::max(1, cus * 31 / 32);
+        cap = (int)std::min<int64_t>(std::max<int64_t>(target, 64), 1024);
+    }
+    cap = std::min(cap, kLdsBudgetBodies - 32);
+    std::vector<int32_t> cluster_of(universe, -1);  // by component root
+    int nclusters = 0, cur = 0;
+    for (int i = 0; i < universe; ++i) {
+        if (!is_dyn[i] || parent[i] != i) continue;  // roots only, ascending
+        if (comp_size[i] > cap) return;              // an island does not fit one workgroup: global path
+        if (nclusters == 0 || cur + comp_size[i] > cap) { ++nclusters; cur = 0; }
+        cluster_of[i] = nclusters - 1;
+        cur += comp_size[i];
+    }
+    // local indices: dynamics first (ascending body index), kinematics appended per cluster
+    std::vector<std::vector<int32_t>> cl_bodies(nclusters);
+    std::vector<int32_t> local_of(universe, -1);
+    for (int i = 0; i < universe; ++i)
+        if (is_dyn[i]) { int cl = cluster_of[find(i)]; local_of[i] = (int)cl_bodies[cl].size(); cl_bodies[cl].push_back(i); plan.clustered_dynamic.push_back(i); }
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> cl_kin(nclusters);  // (kinematic body, local index)
+    auto kin_local = [&](int cl, int body) {
+        for (auto& kv : cl_kin[cl]) if (kv.first == body) return kv.second;
+        int l = (int)cl_bodies[cl].size();
+        cl_bodies[cl].push_back(body | (int)kDynamicLimit);
+        cl_kin[cl].push_back({body, l});
+        return l;
+    };
+    std::vector<std::vector<ClusterItem>> cl_items(nclusters);
+    for (size_t t = 0; t < c->tbs.size(); ++t) {
+        HostTypeBatch& tb = c->tbs[t];
+        const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
+        std::vector<int32_t> cl_of_constraint(tb.count);
+        for (int i = 0; i < tb.count; ++i) {
+            int cl = -1;
+            for (int k = 0; k < nb && cl < 0; ++k) {
+                int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                if ((uint32_t)r < kDynamicLimit) cl = cluster_of[find(r)];
+            }
+            cl_of_constraint[i] = cl;
+        }
+        tb.perm.resize(tb.count);
+        for (int i = 0; i < tb.count; ++i) tb.perm[i] = i;
+        std::stable_sort(tb.perm.begin(), tb.perm.end(), [&](int a, int b) { return cl_of_constraint[a] < cl_of_constraint[b]; });
+        std::vector<int32_t> refs((size_t)nb * tb.stride, -1), lrefs((size_t)nb * tb.stride, -1);
+        std::vector<float> pre((size_t)pf * tb.stride, 0.0f), acc((size_t)imf * tb.stride, 0.0f);
+        for (int d = 0; d < tb.count; ++d) {
+            const int h = tb.perm[d], cl = cl_of_constraint[h];
+            for (int k = 0; k < nb; ++k) {
+                int32_t r = tb.refs_soa[(size_t)k * tb.stride + h];
+                refs[(size_t)k * tb.stride + d] = r;
+                lrefs[(size_t)k * tb.stride + d] = ((uint32_t)r < kDynamicLimit) ? local_of[r] : (kin_local(cl, r & kRefMask) | (int)kDynamicLimit);
+            }
+            for (int f = 0; f < pf; ++f) pre[(size_t)f * tb.stride + d] = tb.prestep_soa[(size_t)f * tb.stride + h];
+            for (int f = 0; f < imf; ++f) acc[(size_t)f * tb.stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
+        }
+        tb.refs_soa.swap(refs); tb.prestep_soa.swap(pre); tb.accum_soa.swap(acc); tb.lrefs_soa.swap(lrefs);
+        for (int d = 0; d < tb.count;) {
+            const int cl = cl_of_constraint[tb.perm[d]];
+            int e = d;
+            while (e < tb.count && cl_of_constraint[tb.perm[e]] == cl) ++e;
+            for (int s0 = d; s0 < e; s0 += 64) cl_items[cl].push_back({(int)t, s0, std::min(64, e - s0), tb.batch});
+            d = e;
+        }
+    }
+    for (int cl = 0; cl < nclusters; ++cl) {
+        if ((int)cl_bodies[cl].size() > kLdsBudgetBodies) { // too many kinematic references: undo is not worth it, fall back
+            for (auto& tb : c->tbs) { /* the permuted order is still a valid global-path layout */ tb.lrefs_soa.clear(); }
+            plan = ClusterPlan{false, {}, {}, {}, {}, {}, plan.kinlist, 0};
+            return;
+        }
+        ClusterDesc d;
+        d.body_begin = (int)plan.cluster_bodies.size();
+        d.body_count = (int)cl_bodies[cl].size();
+        plan.cluster_bodies.insert(plan.cluster_bodies.end(), cl_bodies[cl].begin(), cl_bodies[cl].end());
+        d.item_begin = (int)plan.items.size();
+        d.item_count = (int)cl_items[cl].size();
+        d.batch_item_offset = (int)plan.batch_item_begin.size();
+        // items were appended in type-batch order == batch order
+        int k = 0;
+        for (int b = 0; b <= c->batch_count; ++b) {
+            while (k < d.item_count && cl_items[cl][k].batch < b) ++k;
+            plan.batch_item_begin.push_back(d.item_begin + k);
+        }
+        plan.items.insert(plan.items.end(), cl_items[cl].begin(), cl_items[cl].end());
+        plan.clusters.push_back(d);
+        plan.max_bodies = std::max(plan.max_bodies, d.body_count);
+    }
+    plan.enabled = nclusters > 0;
 }
 
 extern "C" {
@@ -416,8 +835,12 @@ static int32_t rebuild_flags(bepuhip_ctx* c) {
             hipLaunchKernelGGL(mark_constrained_kernel, dim3(blocks), dim3(256), 0, c->stream, (const int*)(c->d_slab + tb.refs_off), tb.count, tb.stride, tb.info.bodies, c->d_flags);
         }
     }
+    if (c->built && c->clusters_enabled && c->clustered_dynamic_count > 0) {
+        hipLaunchKernelGGL(mark_indices_kernel, dim3((c->clustered_dynamic_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_clustered_dynamic,
+                           c->clustered_dynamic_count, c->d_flags, (unsigned)kFlagClustered);
+    }
     if (c->kin_count > 0) {
-        hipLaunchKernelGGL(mark_kinematic_kernel, dim3((c->kin_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_kin, c->kin_count, c->d_flags);
+        hipLaunchKernelGGL(mark_indices_kernel, dim3((c->kin_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_kin, c->kin_count, c->d_flags, (unsigned)(kFlagConstrainedKinematic | kFlagConstrained));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -494,11 +917,14 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
     c->building = false;
     size_t words = 0;
     c->total_constraints = 0;
+    for (auto& tb : c->tbs) c->total_constraints += tb.count;
+    ClusterPlan plan;
+    plan_clusters(c, plan);
     for (auto& tb : c->tbs) {
         tb.refs_off = words; words += tb.refs_soa.size();
         tb.prestep_off = words; words += tb.prestep_soa.size();
         tb.accum_off = words; words += tb.accum_soa.size();
-        c->total_constraints += tb.count;
+        tb.lrefs_off = words; words += tb.lrefs_soa.size();
     }
     c->slab_words = words;
     if (words > 0) {
@@ -509,6 +935,8 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
             if (!tb.refs_soa.empty()) memcpy(&host[tb.refs_off], tb.refs_soa.data(), tb.refs_soa.size() * 4);
             if (!tb.prestep_soa.empty()) memcpy(&host[tb.prestep_off], tb.prestep_soa.data(), tb.prestep_soa.size() * 4);
             if (!tb.accum_soa.empty()) memcpy(&host[tb.accum_off], tb.accum_soa.data(), tb.accum_soa.size() * 4);
+            if (!tb.lrefs_soa.empty()) memcpy(&host[tb.lrefs_off], tb.lrefs_soa.data(), tb.lrefs_soa.size() * 4);
+            std::vector<int32_t>().swap(tb.lrefs_soa);
             std::vector<int32_t>().swap(tb.refs_soa);
             std::vector<float>().swap(tb.prestep_soa);
             std::vector<float>().swap(tb.accum_soa);
@@ -532,6 +960,7 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
                 d.refs = (int*)(c->d_slab + tb.refs_off);
                 d.prestep = (float*)(c->d_slab + tb.prestep_off);
                 d.accum = (float*)(c->d_slab + tb.accum_off);
+                d.lrefs = plan.enabled ? (int*)(c->d_slab + tb.lrefs_off) : nullptr;
                 descs[t] = d;
                 blocks += (tb.count + kBlock - 1) / kBlock;
                 ++t;
@@ -556,6 +985,27 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
     if (!inc.empty()) {
         HIP_TRY(hipMalloc((void**)&c->d_inc_tbs, inc.size() * sizeof(DevTypeBatch)));
         HIP_TRY(hipMemcpy(c->d_inc_tbs, inc.data(), inc.size() * sizeof(DevTypeBatch), hipMemcpyHostToDevice));
+    }
+    // cluster path tables
+    auto upload_ints = [&](const void* src, size_t bytes, void** dst) -> hipError_t {
+        if (bytes == 0) return hipSuccess;
+        hipError_t e = hipMalloc(dst, bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    c->kinlist_count = (int)plan.kinlist.size();
+    HIP_TRY(upload_ints(plan.kinlist.data(), plan.kinlist.size() * 4, (void**)&c->d_kinlist));
+    c->clusters_enabled = plan.enabled;
+    if (plan.enabled) {
+        c->cluster_count = (int)plan.clusters.size();
+        c->cluster_max_bodies = plan.max_bodies;
+        c->clustered_dynamic_count = (int)plan.clustered_dynamic.size();
+        HIP_TRY(upload_ints(plan.clusters.data(), plan.clusters.size() * sizeof(ClusterDesc), (void**)&c->d_clusters));
+        HIP_TRY(upload_ints(plan.items.data(), plan.items.size() * sizeof(ClusterItem), (void**)&c->d_items));
+        HIP_TRY(upload_ints(plan.batch_item_begin.data(), plan.batch_item_begin.size() * 4, (void**)&c->d_batch_item_begin));
+        HIP_TRY(upload_ints(plan.cluster_bodies.data(), plan.cluster_bodies.size() * 4, (void**)&c->d_cluster_bodies));
+        HIP_TRY(upload_ints(plan.clustered_dynamic.data(), plan.clustered_dynamic.size() * 4, (void**)&c->d_clustered_dynamic));
+        HIP_TRY(hipFuncSetAttribute((const void*)cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     c->built = true;
     return rebuild_flags(c);
@@ -610,7 +1060,26 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
     const float inv_dt = 1.0f / substep_dt;          // :1421
     const StepParams sp = make_params(in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
-    for (int s = 0; s < substeps; ++s) {
+    const bool use_clusters = c->clusters_enabled && substeps <= kMaxClusterSubsteps;
+    if (use_clusters) {
+        // Every constraint belongs to an island small enough for one workgroup: the whole substep loop runs in ONE launch.
+        ClusterParams cp;
+        cp.substeps = substeps; cp.batch_count = c->batch_count; cp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
+        for (int s = 0; s < kMaxClusterSubsteps; ++s) cp.iters[s] = s < substeps ? iterations[s] : 0;
+        cp.sp = sp;
+        {
+            Timed t(c, 3);
+            const size_t lds_bytes = (size_t)c->cluster_max_bodies * kLdsBodyVec * sizeof(float4);
+            hipLaunchKernelGGL(cluster_kernel, dim3(c->cluster_count), dim3(std::min(kClusterThreads, std::max(64, env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads) / 64 * 64))), lds_bytes, c->stream, (const ClusterDesc*)c->d_clusters, (const ClusterItem*)c->d_items,
+                               (const int*)c->d_batch_item_begin, (const int*)c->d_cluster_bodies, (const DevTypeBatch*)c->d_tbs, c->d_bodies, cp);
+        }
+        if (c->kinlist_count > 0) {
+            Timed t(c, 1);
+            hipLaunchKernelGGL(kinematic_substeps_kernel, dim3((c->kinlist_count + 63) / 64), dim3(64), 0, c->stream, c->d_bodies, (const int*)c->d_kinlist, c->kinlist_count, substeps,
+                               in->integrate_velocity_for_kinematics, sp);
+        }
+    }
+    for (int s = 0; s < substeps && !use_clusters; ++s) {
         if (s > 0 && c->inc_blocks > 0) {             // :1427-1439 (all batches in one grid: it reads velocities and writes only prestep depths)
             Timed t(c, 0);
             hipLaunchKernelGGL(batch_kernel<kStageIncremental>, dim3(c->inc_blocks), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_inc_tbs, 0, c->inc_tb_count, c->d_bodies, substep_dt, inv_dt);
@@ -725,7 +1194,8 @@ static int32_t download_aosoa(bepuhip_ctx* c, HostTypeBatch* tb, size_t off, int
     const int W = c->W;
     for (int i = 0; i < tb->count; ++i) {
         const size_t bundle = (size_t)(i / W), lane = (size_t)(i % W);
-        for (int f = 0; f < fields; ++f) out[bundle * fields * W + (size_t)f * W + lane] = soa[(size_t)f * tb->stride + i];
+        const int d = tb->perm.empty() ? i : tb->perm_inverse(i);
+        for (int f = 0; f < fields; ++f) out[bundle * fields * W + (size_t)f * W + lane] = soa[(size_t)f * tb->stride + d];
     }
     return BEPUHIP_OK;
 }

@@ -36,7 +36,8 @@ typedef struct bepuhip_config {
     int32_t bundle_width;   /* Vector<float>.Count of the host process that lays out AOSOA buffers: 4, 8 or 16 (BepuUtilities/BundleIndexing.cs:50-60) */
     int32_t flags;          /* BEPUHIP_FLAG_* */
 } bepuhip_config;
-#define BEPUHIP_FLAG_NO_GRAPH 1 /* launch kernels eagerly instead of replaying a captured hipGraph */
+#define BEPUHIP_FLAG_NO_GRAPH 1    /* launch kernels eagerly instead of replaying a captured hipGraph */
+#define BEPUHIP_FLAG_NO_CLUSTERS 2 /* never use the island-per-workgroup (LDS-resident) schedule; always one launch per batch per stage */
 
 /* IPoseIntegratorCallbacks as data: only the DemoPoseIntegratorCallbacks shape can cross the ABI
  * (Demos/DemoCallbacks.cs:20-109; BepuPhysics/PoseIntegrator.cs:42-94). PrepareForIntegration(dt) is evaluated

@@ -146,3 +146,41 @@ def box_stack_scene(levels=3, per_level=4) -> Scene:
                 lane += list(pb - pa) + [0, 1, 0] + mat
                 sb.add_constraint(7, [h, below], lane)
     return sb.build()
+
+
+def island_scene(seed, islands, bodies_per_island, constraints_per_island, type_ids, kinematic_shared=True) -> Scene:
+    """Many small independent islands (each a random connected-ish graph) plus one kinematic body shared by all of them:
+    the shape the island-per-workgroup (cluster) schedule is built for."""
+    rng = np.random.default_rng(seed)
+    sb = SceneBuilder()
+    kin = sb.add_body(kinematic_body(rng, (0, 8, 0))) if kinematic_shared else None
+    for isl in range(islands):
+        base = rng.uniform(-20, 20, 3)
+        hs, pos = [], []
+        for _ in range(bodies_per_island):
+            p = (base + rng.uniform(-1, 1, 3)).astype(np.float32)
+            pos.append(p)
+            hs.append(sb.add_body(random_dynamic_body(rng, p)))
+        for k in range(constraints_per_island):
+            t = int(type_ids[rng.integers(len(type_ids))])
+            nb = TYPE_TABLE[t][0]
+            if nb == 1:
+                a = int(rng.integers(bodies_per_island))
+                sb.add_constraint(t, [hs[a]], prestep_for(rng, t, pos[a], None))
+            else:
+                a, b = [int(x) for x in rng.choice(bodies_per_island, size=2, replace=False)]
+                if kinematic_shared and rng.random() < 0.1:
+                    pair, pb = ([hs[a], kin], np.asarray([0, 8, 0], np.float32)) if rng.random() < 0.5 else ([kin, hs[a]], pos[a])
+                    pa = pos[a] if pair[0] == hs[a] else np.asarray([0, 8, 0], np.float32)
+                    sb.add_constraint(t, pair, prestep_for(rng, t, pa, pb))
+                else:
+                    sb.add_constraint(t, [hs[a], hs[b]], prestep_for(rng, t, pos[a], pos[b]))
+    for _ in range(5):  # a few unconstrained bodies
+        sb.add_body(random_dynamic_body(rng, rng.uniform(-5, 5, 3)))
+    scene = sb.build()
+    from bepuphysics2_amd.scene import to_aosoa
+    for b in scene.batches:
+        for tb in b:
+            lanes = rng.uniform(0.0, 0.05, size=(tb.count, tb.impulse_floats)).astype(np.float32)
+            tb.accumulated[...] = to_aosoa(lanes, scene.bundle_width)
+    return scene

@@ -137,3 +137,34 @@ def test_hip_timestepper_through_host_mirror(hip_solver_factory):
     assert m["bodies_bit_exact"] and m["impulses_bit_exact"], m
     with pytest.raises(ValueError):
         sim.timestep(-1.0)
+
+
+@pytest.mark.parametrize("use_clusters", [True, False])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_island_scenes_both_schedules(hip_solver_factory, use_clusters, seed):
+    """Independent islands: the island-per-workgroup schedule (bodies in LDS, one launch per frame) and the launch-per-batch
+    schedule must both reproduce the oracle bit for bit."""
+    solver = hip_solver_factory(use_clusters=use_clusters)
+    scene = small_scenes.island_scene(seed, islands=150, bodies_per_island=10, constraints_per_island=30, type_ids=sorted(TYPE_TABLE.keys()))
+    for sd, cb in ((SolveDescription(2, 8), PoseIntegratorCallbacks()),
+                   (SolveDescription(1, 3, velocity_iteration_scheduler=lambda s: [2, 1, 3][s]), PoseIntegratorCallbacks(integrate_velocity_for_kinematics=True, allow_substeps_for_unconstrained_bodies=True))):
+        ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=4)
+        got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+        m = pu.compare_scenes(ref, got)
+        _check(m)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+
+@pytest.mark.parametrize("use_clusters", [True, False])
+def test_ragdoll_tube_both_schedules(hip_solver_factory, use_clusters):
+    from bepuphysics2_amd.hostlib import HostSimulation
+    sim = HostSimulation.scene("ragdoll_tube", 700, 1, 0, 9)
+    scene, sd = sim.export(), sim.solve_description()
+    sim.close()
+    cb = PoseIntegratorCallbacks()
+    solver = hip_solver_factory(use_clusters=use_clusters)
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=3, threads=4)
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=3)
+    m = pu.compare_scenes(ref, got)
+    _check(m)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
