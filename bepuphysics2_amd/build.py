@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
-             "-fPIC", "-shared", "-Wno-unused-result"]
+             "-fPIC", "-shared", "-Wno-unused-result", "-Wno-unused-value", "-Wno-array-bounds"]
 
 
 def _newer(target: str, sources) -> bool:

@@ -53,12 +53,20 @@ struct DevTypeBatch {
     int* refs;
     float* prestep;
     float* accum;
-    int* lrefs;  // cluster path: per-slot index into the owning cluster's LDS body table (bit 30 = kinematic, never written)
 };
 
 // ---- cluster path descriptors (see cluster_kernel) ----
-struct ClusterItem { int tb, start, count, batch; };  // <= 64 consecutive constraints of one type batch, all owned by one cluster
-struct ClusterDesc { int body_begin, body_count, item_begin, item_count, batch_item_offset; };
+constexpr int kMaxPreds = 8;
+constexpr int kFallbackBatchLimit = 64;
+struct ClusterItem {  // <= 64 consecutive constraints of one type batch, all owned by one cluster; 64 bytes, staged in LDS
+    int type_id, count, stride, start;                // start: index of the first constraint inside the (reordered) type batch
+    unsigned lrefs_off, prestep_off, accum_off;       // word offsets into the constraint slab: lrefs[bodies][stride], prestep[pf][stride], accum[imf][stride]
+    int batch_npred;                                  // bits 0-15 batch, 16-23 predecessor count, 24 overflow (wait for all earlier batches instead)
+    unsigned short pred[kMaxPreds];                   // cluster-relative indices of the items that last touched this item's dynamic bodies
+    int tb, bodies, pf, imf;                          // host bookkeeping
+};
+static_assert(sizeof(ClusterItem) == 64, "ClusterItem is staged in LDS as four 16-byte vectors");
+struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
 constexpr int kMaxClusterSubsteps = 16;
 struct ClusterParams {
     int substeps, batch_count, integrate_velocity_for_kinematics;
@@ -305,188 +313,338 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
 
 // ------------------------------------------------------------------------------------------------
 // Cluster path: islands (connected components of the constraint graph through dynamic bodies) are independent, so a workgroup
-// that owns whole islands can run EVERY stage of EVERY substep for them with workgroup barriers only: the island's bodies live in
-// LDS for the whole frame (Bodies_GatherScatter's gather/scatter becomes ds_read_b128/ds_write_b128 on a per-workgroup body table),
-// batches still execute in the host's order (the per-body operation order — hence every result bit — is unchanged),
-// and the 100+ dependent kernel boundaries of the global schedule disappear. HBM sees each body twice per frame (load, write back)
-// plus the constraint stream.
-// LDS body record: 6 x float4 = {orientation, position, linear, angular, world inverse inertia xx..zx, {zy, zz, invMass, -}}.
+// that owns whole islands can run EVERY stage of EVERY substep for them without leaving the CU: the islands' bodies live in
+// LDS for the whole frame (Bodies_GatherScatter's gather/scatter becomes ds_read_b128/ds_write_b128 on a per-workgroup body table)
+// and the 100+ dependent kernel boundaries of the launch-per-batch schedule disappear. HBM sees each body twice per frame (load,
+// write back) plus the constraint stream.
+//
+// Inside a pass (one WarmStart or one Solve sweep over the batches) the waves do not meet at a barrier per batch. The host splits
+// every cluster's constraints into work items (<= 64 consecutive constraints of one type batch) sorted by batch, and records for
+// each item its predecessors: the items that last touched any of its dynamic bodies. Waves claim items in that order from an LDS
+// counter, issue the item's global loads (body references, prestep, accumulated impulses), THEN wait on the predecessors' LDS
+// completion flags, gather, solve, scatter, and publish their own flag. The per-body order of constraint application is exactly
+// the host's batch order (hence every result bit is unchanged), the memory latency of item t+1 hides under the math of item t
+// running on another wave, and a heavy constraint type only delays the items that really depend on it.
+// Deadlock freedom: items are claimed in a topological order and a wave holds one item at a time, so the earliest unfinished
+// item always has all its predecessors finished.
+//
+// LDS: [8 planes of float4 x ncap body slots: the BodyDynamics record, one plane per 16-byte field][work items][flags, counters].
+// Slot numbering is rotated by the host inside every group of 16 (slot = (i & ~15) | ((i + (i >> 4)) & 15)) so that the regular
+// "same joint of consecutive ragdolls" access pattern (lane stride = island size) spreads over all 16 bank slots of ds_read_b128.
 // ------------------------------------------------------------------------------------------------
-constexpr int kLdsBodyVec = 6;
+constexpr int kPlanes = 8;
+constexpr int kClusterThreads = 512;
+
+typedef __attribute__((address_space(1))) float gfloat;  // global
+typedef __attribute__((address_space(1))) int gint;
+typedef __attribute__((address_space(3))) unsigned lds_u32;  // LDS: ds_read/ds_write, lgkmcnt only (a generic pointer would poll with flat loads and drag vmcnt in)
+
+struct ClusterShared {
+    float4* planes;        // [kPlanes][ncap]
+    int ncap;
+    ClusterItem* items;
+    volatile lds_u32* flags;  // per item: epoch of the last completed pass
+    lds_u32* batch_done;      // per batch: items completed, monotonic over passes (fallback for items with too many predecessors)
+    int* lbib;                // batch -> first item of the cluster (batch_count + 1 entries)
+    lds_u32* counter;         // item claim counter, monotonic
+    unsigned* status;      // global: [0] != 0 when a wait ran out of patience (a scheduling bug, never expected); [1..7] first offender
+};
 
 template <int ACCESS>
-__device__ __forceinline__ void load_body_lds(const float4* lds, int lref, DBody& b) {
-    const float4* base = lds + (lref & kRefMask) * kLdsBodyVec;
+__device__ __forceinline__ void load_body_lds(const ClusterShared& sh, int lref, DBody& b) {
+    const float4* base = sh.planes + (lref & kRefMask);
+    const int n = sh.ncap;
     if (ACCESS & kOri) { float4 q = base[0]; b.ori = {q.x, q.y, q.z, q.w}; } else b.ori = {0, 0, 0, 0};
-    if (ACCESS & kPos) { float4 p = base[1]; b.pos = {p.x, p.y, p.z}; } else b.pos = {0, 0, 0};
-    if (ACCESS & kLin) { float4 l = base[2]; b.vel.lin = {l.x, l.y, l.z}; b.linw = l.w; } else { b.vel.lin = {0, 0, 0}; b.linw = 0; }
-    if (ACCESS & kAng) { float4 a = base[3]; b.vel.ang = {a.x, a.y, a.z}; b.angw = a.w; } else { b.vel.ang = {0, 0, 0}; b.angw = 0; }
+    if (ACCESS & kPos) { float4 p = base[n]; b.pos = {p.x, p.y, p.z}; } else b.pos = {0, 0, 0};
+    if (ACCESS & kLin) { float4 l = base[2 * n]; b.vel.lin = {l.x, l.y, l.z}; b.linw = l.w; } else { b.vel.lin = {0, 0, 0}; b.linw = 0; }
+    if (ACCESS & kAng) { float4 a = base[3 * n]; b.vel.ang = {a.x, a.y, a.z}; b.angw = a.w; } else { b.vel.ang = {0, 0, 0}; b.angw = 0; }
     if (ACCESS & kInertia) {
-        float4 i0 = base[4], i1 = base[5];
+        float4 i0 = base[6 * n], i1 = base[7 * n];
         b.inertia.t = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
         b.inertia.invMass = i1.z;
     } else { b.inertia.t = {0, 0, 0, 0, 0, 0}; b.inertia.invMass = 0; }
 }
 template <int ACCESS>
-__device__ __forceinline__ void store_velocity_lds(float4* lds, int lref, const DBody& b) {
+__device__ __forceinline__ void store_velocity_lds(const ClusterShared& sh, int lref, const DBody& b) {
     if ((unsigned)lref >= kDynamicLimit) return;
-    float4* base = lds + lref * kLdsBodyVec;
-    if (ACCESS & kLin) base[2] = make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, b.linw);
-    if (ACCESS & kAng) base[3] = make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, b.angw);
+    float4* base = sh.planes + lref;
+    if (ACCESS & kLin) base[2 * sh.ncap] = make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, b.linw);
+    if (ACCESS & kAng) base[3 * sh.ncap] = make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, b.angw);
+}
+
+
+struct ItemHeader {  // wave-uniform copy of the fields the constraint code needs (SGPRs)
+    int type_id, count, stride, start, batch, npred, overflow;
+    unsigned lrefs_off, prestep_off, accum_off;
+};
+
+__device__ __forceinline__ ItemHeader read_item(const ClusterItem* it) {
+    ItemHeader h;
+    h.type_id = __builtin_amdgcn_readfirstlane(it->type_id);
+    h.count = __builtin_amdgcn_readfirstlane(it->count);
+    h.stride = __builtin_amdgcn_readfirstlane(it->stride);
+    h.start = __builtin_amdgcn_readfirstlane(it->start);
+    h.lrefs_off = __builtin_amdgcn_readfirstlane(it->lrefs_off);
+    h.prestep_off = __builtin_amdgcn_readfirstlane(it->prestep_off);
+    h.accum_off = __builtin_amdgcn_readfirstlane(it->accum_off);
+    const int packed = __builtin_amdgcn_readfirstlane(it->batch_npred);
+    h.batch = packed & 0xFFFF; h.npred = (packed >> 16) & 0xFF; h.overflow = (packed >> 24) & 0xFF;
+    return h;
+}
+
+// Wave-level claim / publish as single opaque instructions sequences: one lane (exec = 1) touches the LDS word, the result is wave-uniform.
+// Written as inline asm so that the compiler sees no lane-0 branch next to the loop back-edge (it otherwise threads the "lane == 0"
+// publish of one iteration into the "lane == 0" claim of the next and builds a divergent loop around convergent operations).
+__device__ __forceinline__ unsigned lds_address(const volatile lds_u32* p) { return (unsigned)(__SIZE_TYPE__)p; }
+__device__ __forceinline__ unsigned claim_next(lds_u32* counter) {
+    unsigned ret;
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "ds_add_rtn_u32 %[r], %[a], %[one]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [r] "=&v"(ret), [sv] "=&s"(saved)
+        : [a] "v"(lds_address(counter)), [one] "v"(1u)
+        : "memory");
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)ret);
+}
+// The wave's LDS velocity stores must have landed before the flag does: LDS executes a wave's instructions in order, the explicit
+// wait makes that independent of the pipeline's internals.
+__device__ __forceinline__ void publish_item(volatile lds_u32* flag, lds_u32* batch_counter, unsigned epoch) {
+    unsigned long long saved;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "ds_write_b32 %[fa], %[e]\n\t"
+        "ds_add_u32 %[ba], %[one]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [sv] "=&s"(saved)
+        : [fa] "v"(lds_address(flag)), [e] "v"(epoch), [ba] "v"(lds_address(batch_counter)), [one] "v"(1u)
+        : "memory");
+}
+
+// Every spin is bounded: a wait that runs out of patience (~0.1 s) records itself in the status words and lets the wave continue, so a
+// scheduling bug turns into an error code from bepuhip_sync instead of a hung GPU.
+constexpr unsigned kSpinLimit = 1u << 21;
+__device__ __noinline__ void report_stall(unsigned* status, unsigned claims, int kind, int k, int what, unsigned want, unsigned seen) {
+    if ((threadIdx.x & 63) == 0 && atomicCAS(status, 0u, 1u) == 0u) {
+        status[1] = blockIdx.x; status[2] = (unsigned)kind; status[3] = (unsigned)k; status[4] = (unsigned)what;
+        status[5] = want; status[6] = seen; status[7] = claims;
+    }
+}
+// Block until every predecessor of the item has published `epoch` (all lanes read the same LDS word: one broadcast ds_read).
+__device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, unsigned epoch) {
+    for (int q = 0; q < h.npred; ++q) {
+        const int pred = __builtin_amdgcn_readfirstlane((int)it->pred[q]);
+        unsigned spins = 0, seen;
+        while ((seen = (unsigned)__builtin_amdgcn_readfirstlane((int)sh.flags[pred])) < epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) { report_stall(sh.status, *sh.counter, 1, k, pred, epoch, seen); break; }
+            if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
+        }
+    }
+    if (h.overflow) {  // more predecessors than the item records: wait for every item of every earlier batch
+        for (int b = 0; b < h.batch; ++b) {
+            const unsigned want = epoch * (unsigned)__builtin_amdgcn_readfirstlane(sh.lbib[b + 1] - sh.lbib[b]);
+            unsigned spins = 0, seen;
+            while ((seen = (unsigned)__builtin_amdgcn_readfirstlane((int)((volatile lds_u32*)sh.batch_done)[b])) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { report_stall(sh.status, *sh.counter, 2, k, b, want, seen); break; }
+                if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");  // nothing below may be hoisted above the polls
 }
 
 template <class F, int STAGE>
-__device__ __forceinline__ void run_cluster_constraint(const DevTypeBatch& tb, int i, float4* lds, float dt, float inv_dt) {
-    const int stride = tb.stride;
-    const int refA = tb.lrefs[i];
-    const int refB = (F::bodies == 2) ? tb.lrefs[stride + i] : -1;
+__device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
+                                                       unsigned* __restrict__ slab, float dt, float inv_dt) {
+    // Lanes beyond the item's count mirror its last constraint and never store: the whole body runs with a full exec mask,
+    // which keeps the control flow around the (wave-uniform) waits trivially structured.
+    const bool active = lane < h.count;
+    const int i = h.start + (active ? lane : h.count - 1), stride = h.stride;
+    const gint* lrefs = (const gint*)(slab + h.lrefs_off);
+    gfloat* prestep = (gfloat*)(slab + h.prestep_off);
+    gfloat* accum = (gfloat*)(slab + h.accum_off);
     float p[F::prestepFloats];
-    _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = tb.prestep[(size_t)f * stride + i];
+    float a[F::impulseFloats];
+    // issue the item's global loads first: their latency hides under the wait for the predecessors
+    const int ra = lrefs[i];
+    const int rb = (F::bodies == 2) ? lrefs[stride + i] : -1;
+    _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
+    if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
     DBody A, B;
-    if (STAGE == kStageIncremental) {
-        load_body_lds<kAccessOnlyVelocity>(lds, refA, A);
-        if (F::bodies == 2) load_body_lds<kAccessOnlyVelocity>(lds, refB, B); else load_body_lds<0>(lds, 0, B);
+    if (STAGE == kStageIncremental) {  // reads velocities, writes only this constraint's depths: no ordering inside the stage
+        load_body_lds<kAccessOnlyVelocity>(sh, ra, A);
+        if (F::bodies == 2) load_body_lds<kAccessOnlyVelocity>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
         F::incrementalUpdate(dt, A.vel, B.vel, p);
         if constexpr (F::incremental) {
-            _Pragma("unroll") for (int cidx = 0; cidx < F::impulseFloats - 3; ++cidx) tb.prestep[(size_t)(4 * cidx + 3) * stride + i] = p[4 * cidx + 3];
+            if (active) { _Pragma("unroll") for (int cidx = 0; cidx < F::impulseFloats - 3; ++cidx) prestep[(size_t)(4 * cidx + 3) * stride + i] = p[4 * cidx + 3]; }
         }
         return;
     }
-    float a[F::impulseFloats];
-    _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = tb.accum[(size_t)f * stride + i];
+    wait_predecessors(sh, it, h, k, epoch);
     constexpr int accA = (STAGE == kStageWarmStart) ? F::wsA : F::svA;
     constexpr int accB = (STAGE == kStageWarmStart) ? F::wsB : F::svB;
-    load_body_lds<accA>(lds, refA, A);
-    if (F::bodies == 2) load_body_lds<accB>(lds, refB, B); else load_body_lds<0>(lds, 0, B);
-    if (STAGE == kStageWarmStart) {
-        F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel);
-    } else {
-        F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel);
-        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) tb.accum[(size_t)f * stride + i] = a[f];
+    load_body_lds<accA>(sh, ra, A);
+    if (F::bodies == 2) load_body_lds<accB>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
+    if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel);
+    else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel);
+    store_velocity_lds<accA>(sh, active ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references)
+    if (F::bodies == 2) store_velocity_lds<accB>(sh, active ? rb : -1, B);
+    publish_item(sh.flags + k, sh.batch_done + h.batch, epoch);
+    if (STAGE == kStageSolve && active) {  // off the critical path: nothing reads the impulses before the next pass (a barrier away)
+        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) accum[(size_t)f * stride + i] = a[f];
     }
-    store_velocity_lds<accA>(lds, refA, A);
-    if (F::bodies == 2) store_velocity_lds<accB>(lds, refB, B);
 }
+
+using DC1O = Contact<1, false>; using DC2O = Contact<2, false>; using DC3O = Contact<3, false>; using DC4O = Contact<4, false>;
+using DC1T = Contact<1, true>; using DC2T = Contact<2, true>; using DC3T = Contact<3, true>; using DC4T = Contact<4, true>;
 
 template <int STAGE>
-__device__ __forceinline__ void run_cluster_item(const DevTypeBatch& tb, int i, float4* lds, float dt, float inv_dt) {
-    switch (tb.type_id) {
-        case kContact1OneBody: run_cluster_constraint<Contact<1, false>, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kContact2OneBody: run_cluster_constraint<Contact<2, false>, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kContact3OneBody: run_cluster_constraint<Contact<3, false>, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kContact4OneBody: run_cluster_constraint<Contact<4, false>, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kContact1: run_cluster_constraint<Contact<1, true>, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kContact2: run_cluster_constraint<Contact<2, true>, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kContact3: run_cluster_constraint<Contact<3, true>, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kContact4: run_cluster_constraint<Contact<4, true>, STAGE>(tb, i, lds, dt, inv_dt); break;
-        default: break;
+__device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
+                                                 unsigned* __restrict__ slab, float dt, float inv_dt) {
+#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt); break;
+    switch (h.type_id) {
+        BEPU_CASE(kContact1OneBody, DC1O) BEPU_CASE(kContact2OneBody, DC2O) BEPU_CASE(kContact3OneBody, DC3O) BEPU_CASE(kContact4OneBody, DC4O)
+        BEPU_CASE(kContact1, DC1T) BEPU_CASE(kContact2, DC2T) BEPU_CASE(kContact3, DC3T) BEPU_CASE(kContact4, DC4T)
+        default:
+            if constexpr (STAGE != kStageIncremental) {  // only contacts need incremental updates (RequiresIncrementalSubstepUpdates)
+                switch (h.type_id) {
+                    BEPU_CASE(kBallSocket, BallSocket) BEPU_CASE(kAngularHinge, AngularHinge) BEPU_CASE(kSwingLimit, SwingLimit)
+                    BEPU_CASE(kTwistServo, TwistServo) BEPU_CASE(kTwistLimit, TwistLimit) BEPU_CASE(kAngularMotor, AngularMotor)
+                    BEPU_CASE(kSwivelHinge, SwivelHinge) BEPU_CASE(kHinge, Hinge)
+                    default: break;
+                }
+            }
+            break;
     }
-    if (STAGE == kStageIncremental) return;
-    switch (tb.type_id) {
-        case kBallSocket: run_cluster_constraint<BallSocket, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kAngularHinge: run_cluster_constraint<AngularHinge, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kSwingLimit: run_cluster_constraint<SwingLimit, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kTwistServo: run_cluster_constraint<TwistServo, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kTwistLimit: run_cluster_constraint<TwistLimit, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kAngularMotor: run_cluster_constraint<AngularMotor, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kSwivelHinge: run_cluster_constraint<SwivelHinge, STAGE>(tb, i, lds, dt, inv_dt); break;
-        case kHinge: run_cluster_constraint<Hinge, STAGE>(tb, i, lds, dt, inv_dt); break;
-        default: break;
+#undef BEPU_CASE
+}
+
+// One WarmStart or Solve sweep over the cluster's batches (Solver_Solve.cs:1447-1476 for the cluster's islands).
+template <int STAGE, bool TRACE>
+__device__ __forceinline__ void run_cluster_pass(const ClusterShared& sh, int item_count, int lane, int wave, unsigned epoch, unsigned claim_base,
+                                                 unsigned* __restrict__ slab, float dt, float inv_dt, unsigned long long* trace) {
+    for (;;) {
+        const unsigned g = claim_next(sh.counter);
+        const int k = (int)(g - claim_base);
+        if (k >= item_count) break;
+        const ClusterItem* it = sh.items + k;
+        const ItemHeader h = read_item(it);
+        unsigned long long t0 = 0;
+        if (TRACE) t0 = __builtin_readcyclecounter();
+        run_cluster_item<STAGE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt);
+        if (TRACE && trace && blockIdx.x == 0 && lane == 0) {
+            unsigned long long* rec = trace + ((size_t)(epoch - 1) * item_count + k) * 4;
+            rec[0] = t0; rec[1] = __builtin_readcyclecounter(); rec[2] = (unsigned long long)wave | ((unsigned long long)h.type_id << 8) | ((unsigned long long)h.batch << 16) | ((unsigned long long)STAGE << 32);
+            rec[3] = (unsigned long long)h.count;
+        }
     }
 }
 
-constexpr int kClusterThreads = 512;
-
+template <bool TRACE>
 __global__ __launch_bounds__(kClusterThreads) void cluster_kernel(const ClusterDesc* __restrict__ clusters, const ClusterItem* __restrict__ items,
                                                                    const int* __restrict__ batch_item_begin, const int* __restrict__ cluster_bodies,
-                                                                   const DevTypeBatch* __restrict__ tbs, float4* bodies, ClusterParams cp) {
+                                                                   float4* bodies, unsigned* __restrict__ slab, ClusterParams cp, int ncap, int max_items,
+                                                                   unsigned long long* trace, unsigned* status) {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
+    ClusterShared sh;
+    sh.planes = lds;
+    sh.ncap = ncap;
+    sh.items = reinterpret_cast<ClusterItem*>(lds + kPlanes * ncap);
+    unsigned* words = reinterpret_cast<unsigned*>(lds + kPlanes * ncap + max_items * (int)(sizeof(ClusterItem) / 16));
+    sh.flags = (volatile lds_u32*)words;
+    sh.batch_done = (lds_u32*)(words + max_items);
+    sh.lbib = reinterpret_cast<int*>(words + max_items + kFallbackBatchLimit + 1);
+    sh.counter = (lds_u32*)(words + max_items + 2 * (kFallbackBatchLimit + 1) + 1);
+    sh.status = status;
     const ClusterDesc cd = clusters[blockIdx.x];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
     const float dt = cp.sp.dt, inv_dt = cp.sp.inv_dt;
-    // Load the cluster's bodies (its islands' dynamic bodies + the kinematic bodies they reference) into LDS.
-    for (int j = tid; j < cd.body_count; j += blockDim.x) {
-        const float4* base = bodies + (size_t)(cluster_bodies[cd.body_begin + j] & kRefMask) * 8;
-        float4* r = lds + j * kLdsBodyVec;
-        r[0] = base[0]; r[1] = base[1]; r[2] = base[2]; r[3] = base[3]; r[4] = base[6]; r[5] = base[7];
+    const int* slots = cluster_bodies + cd.body_begin;  // slot -> body index (bit 30: kinematic, private read-only copy; -1: unused slot)
+    // ---- stage the cluster in LDS: bodies (one plane per 16-byte field), work items, batch -> item ranges; clear the sync words ----
+    for (int j = tid; j < cd.slot_count * kPlanes; j += blockDim.x) {
+        const int slot = j >> 3, v = j & 7;
+        const int g = slots[slot];
+        lds[v * ncap + slot] = g >= 0 ? bodies[(size_t)(g & kRefMask) * 8 + v] : make_float4(0, 0, 0, 0);
     }
+    {
+        const int4* src = reinterpret_cast<const int4*>(items + cd.item_begin);
+        int4* dst = reinterpret_cast<int4*>(sh.items);
+        for (int j = tid; j < cd.item_count * (int)(sizeof(ClusterItem) / 16); j += blockDim.x) dst[j] = src[j];
+    }
+    for (int j = tid; j < max_items + kFallbackBatchLimit + 1; j += blockDim.x) words[j] = 0;  // flags + batch_done
+    for (int j = tid; j <= cp.batch_count; j += blockDim.x) sh.lbib[j] = batch_item_begin[cd.batch_item_offset + j] - cd.item_begin;
+    if (tid == 0) *sh.counter = 0;
     __syncthreads();
-    const int* bib = batch_item_begin + cd.batch_item_offset;
+
+    unsigned epoch = 0, claim_base = 0;
     for (int s = 0; s < cp.substeps; ++s) {
+        if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(&sh.status[10], (unsigned)s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (s > 0) {  // Solver_Solve.cs:1427-1439: contact depths advance with the pre-integration velocities
-            for (int k = cd.item_begin + wave; k < cd.item_begin + cd.item_count; k += nwaves) {
-                const ClusterItem it = items[k];
-                if (lane < it.count) run_cluster_item<kStageIncremental>(tbs[it.tb], it.start + lane, lds, dt, inv_dt);
+            for (int k = wave; k < cd.item_count; k += nwaves) {
+                const ClusterItem* it = sh.items + k;
+                const ItemHeader h = read_item(it);
+                if (h.type_id > kContact4) continue;
+                run_cluster_item<kStageIncremental>(sh, it, h, k, lane, 0u, slab, dt, inv_dt);
             }
             __syncthreads();
         }
-        // Integration of every constrained body of the cluster (TypeProcessor.cs:1204-1283, PoseIntegrator.cs:451-535).
-        for (int j = tid; j < cd.body_count; j += blockDim.x) {
-            const int g = cluster_bodies[cd.body_begin + j];
-            float4* r = lds + j * kLdsBodyVec;
-            float4 q4 = r[0], p4 = r[1], l4 = r[2], a4 = r[3];
+        // Integration of every constrained body of the cluster (TypeProcessor.cs:1204-1283, PoseIntegrator.cs:451-535):
+        // substep 0 velocity only, later substeps pose then velocity; world inverse inertia refreshed either way.
+        for (int j = tid; j < cd.slot_count; j += blockDim.x) {
+            const int g = slots[j];
+            if (g < 0) continue;
+            float4* r = lds + j;
+            float4 q4 = r[0], p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
             Q ori = {q4.x, q4.y, q4.z, q4.w};
             V3 pos = {p4.x, p4.y, p4.z};
             BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+            if (s > 0) {
+                pos = add(pos, scale(vel.lin, dt));
+                ori = integrateOrientation(ori, vel.ang, dt * 0.5f);
+                r[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+                r[ncap] = make_float4(pos.x, pos.y, pos.z, p4.w);
+            }
             if ((unsigned)g < kDynamicLimit) {
-                const float4* gb = bodies + (size_t)g * 8;
-                const float4 i0 = gb[4], i1 = gb[5];
+                const float4 i0 = r[4 * ncap], i1 = r[5 * ncap];
                 Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
-                if (s > 0) {
-                    pos = add(pos, scale(vel.lin, dt));
-                    ori = integrateOrientation(ori, vel.ang, dt * 0.5f);
-                    r[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
-                    r[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
-                }
                 Sym3 world = rotateInverseInertia(local, ori);
                 velocity_callback(cp.sp, vel);
-                r[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
-                r[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
-                r[4] = make_float4(world.xx, world.yx, world.yy, world.zx);
-                r[5] = make_float4(world.zy, world.zz, i1.z, r[5].w);
-            } else {  // kinematic: this cluster's private copy follows the same arithmetic as the global kinematic pass
-                if (s > 0) {
-                    pos = add(pos, scale(vel.lin, dt));
-                    ori = integrateOrientation(ori, vel.ang, dt * 0.5f);
-                    r[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
-                    r[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
-                }
-                if (cp.integrate_velocity_for_kinematics) {
-                    velocity_callback(cp.sp, vel);
-                    r[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
-                    r[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
-                }
+                r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+                r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+                r[6 * ncap] = make_float4(world.xx, world.yx, world.yy, world.zx);
+                r[7 * ncap] = make_float4(world.zy, world.zz, i1.z, r[7 * ncap].w);
+            } else if (cp.integrate_velocity_for_kinematics) {  // kinematic: private copy, same arithmetic as the global kinematic pass
+                velocity_callback(cp.sp, vel);
+                r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+                r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
             }
         }
         __syncthreads();
-        for (int b = 0; b < cp.batch_count; ++b) {  // warm start, batches in order (Solver_Solve.cs:1447-1463)
-            const int k0 = bib[b], k1 = bib[b + 1];
-            if (k0 == k1) continue;
-            for (int k = k0 + wave; k < k1; k += nwaves) {
-                const ClusterItem it = items[k];
-                if (lane < it.count) run_cluster_item<kStageWarmStart>(tbs[it.tb], it.start + lane, lds, dt, inv_dt);
-            }
+        ++epoch;
+        run_cluster_pass<kStageWarmStart, TRACE>(sh, cd.item_count, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+        claim_base += cd.item_count + nwaves;  // every wave makes exactly one failing claim per pass
+        __syncthreads();
+        for (int iter = 0; iter < cp.iters[s]; ++iter) {
+            ++epoch;
+            run_cluster_pass<kStageSolve, TRACE>(sh, cd.item_count, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+            claim_base += cd.item_count + nwaves;
             __syncthreads();
-        }
-        for (int iter = 0; iter < cp.iters[s]; ++iter) {  // velocity iterations (:1464-1476)
-            for (int b = 0; b < cp.batch_count; ++b) {
-                const int k0 = bib[b], k1 = bib[b + 1];
-                if (k0 == k1) continue;
-                for (int k = k0 + wave; k < k1; k += nwaves) {
-                    const ClusterItem it = items[k];
-                    if (lane < it.count) run_cluster_item<kStageSolve>(tbs[it.tb], it.start + lane, lds, dt, inv_dt);
-                }
-                __syncthreads();
-            }
         }
     }
     // Trailing pose integration of constrained bodies (PoseIntegrator.cs:684-691) and write-back.
-    for (int j = tid; j < cd.body_count; j += blockDim.x) {
-        const int g = cluster_bodies[cd.body_begin + j];
-        if ((unsigned)g >= kDynamicLimit) continue;  // kinematic bodies are advanced in global memory by the body kernels
-        const float4* r = lds + j * kLdsBodyVec;
-        float4 q4 = r[0], p4 = r[1], l4 = r[2], a4 = r[3];
+    for (int j = tid; j < cd.slot_count; j += blockDim.x) {
+        const int g = slots[j];
+        if ((unsigned)g >= kDynamicLimit) continue;  // unused slot, or kinematic (advanced in global memory by kinematic_substeps_kernel + the final pass)
+        const float4* r = lds + j;
+        float4 q4 = r[0], p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
         Q ori = {q4.x, q4.y, q4.z, q4.w};
         V3 pos = {p4.x, p4.y, p4.z};
         V3 lin = {l4.x, l4.y, l4.z}, ang = {a4.x, a4.y, a4.z};
@@ -497,8 +655,8 @@ __global__ __launch_bounds__(kClusterThreads) void cluster_kernel(const ClusterD
         gb[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
         gb[2] = l4;
         gb[3] = a4;
-        gb[6] = r[4];
-        gb[7] = r[5];
+        gb[6] = r[6 * ncap];
+        gb[7] = r[7 * ncap];
     }
 }
 
@@ -585,7 +743,11 @@ struct bepuhip_ctx {
     int64_t total_constraints = 0;
     // cluster path
     bool clusters_enabled = false;
-    int cluster_count = 0, cluster_max_bodies = 0;
+    int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0;
+    ClusterDesc first_cluster = {0, 0, 0, 0, 0};
+    unsigned* d_status = nullptr;  // cluster schedule watchdog words (see report_stall)
+    unsigned long long* d_trace = nullptr;  // optional per-item timeline of cluster 0 (diagnostics)
+    size_t trace_words = 0;
     ClusterDesc* d_clusters = nullptr;
     ClusterItem* d_items = nullptr;
     int* d_batch_item_begin = nullptr;
@@ -598,8 +760,8 @@ struct bepuhip_ctx {
     float last_ms = 0;
     int64_t last_constraint_iterations = 0;
     bool profiling = false;
-    float prof_ms[5] = {0, 0, 0, 0, 0};
-    int prof_launches[5] = {0, 0, 0, 0, 0};
+    float prof_ms[6] = {0, 0, 0, 0, 0, 0};
+    int prof_launches[6] = {0, 0, 0, 0, 0, 0};
     std::map<GraphKey, hipGraphExec_t> graphs;
 };
 
@@ -616,6 +778,8 @@ static void free_constraints(bepuhip_ctx* c) {
     if (c->d_cluster_bodies) hipFree(c->d_cluster_bodies);
     if (c->d_clustered_dynamic) hipFree(c->d_clustered_dynamic);
     if (c->d_kinlist) hipFree(c->d_kinlist);
+    if (c->d_trace) hipFree(c->d_trace);
+    c->d_trace = nullptr; c->trace_words = 0;
     c->d_clusters = nullptr; c->d_items = nullptr; c->d_batch_item_begin = nullptr; c->d_cluster_bodies = nullptr;
     c->d_clustered_dynamic = nullptr; c->d_kinlist = nullptr;
     c->clusters_enabled = false; c->cluster_count = 0; c->clustered_dynamic_count = 0; c->kinlist_count = 0;
@@ -629,13 +793,14 @@ static void free_constraints(bepuhip_ctx* c) {
 // ---- cluster planning (host, once per topology upload) ----
 // Islands = connected components through dynamic bodies (kinematic references never connect: they are read-only to the solver).
 // Whole islands are packed, in body-index order, into clusters of at most `cap` LDS-resident bodies; each type batch is
-// reordered so that every cluster's constraints are contiguous (coalesced loads per <=64-lane item).
+// reordered so that every cluster's constraints are contiguous (coalesced loads per <=64-lane work item), and every work item
+// records which earlier items last touched its dynamic bodies (the only ordering the solve has to respect).
 struct ClusterPlan {
     bool enabled = false;
     std::vector<ClusterDesc> clusters;
     std::vector<ClusterItem> items;
     std::vector<int> batch_item_begin, cluster_bodies, clustered_dynamic, kinlist;
-    int max_bodies = 0;
+    int max_slots = 0, max_items = 0;
 };
 
 static int env_int(const char* name, int fallback) {
@@ -643,8 +808,15 @@ static int env_int(const char* name, int fallback) {
     return v && *v ? atoi(v) : fallback;
 }
 
+constexpr size_t kLdsBudgetBytes = 160 * 1024 - 256;
+static size_t cluster_sync_words(int max_items) { return (size_t)max_items + 2 * (kFallbackBatchLimit + 1) + 2; }
+static size_t cluster_lds_bytes(int ncap, int max_items) {
+    return (size_t)kPlanes * ncap * 16 + (size_t)max_items * sizeof(ClusterItem) + (cluster_sync_words(max_items) + 3) / 4 * 16;
+}
+// Slot rotation inside every group of 16 (see the LDS layout note above cluster_kernel).
+static inline int rotated_slot(int i) { return (i & ~15) | ((i + (i >> 4)) & 15); }
+
 static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
-    constexpr int kLdsBudgetBodies = 1536;  // 1536 x 96 B = 144 KiB of the 160 KiB LDS
     int universe = 0;
     for (auto& tb : c->tbs)
         for (int32_t r : tb.refs_soa)
@@ -659,7 +831,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                     if ((uint32_t)r >= kDynamicLimit && r >= 0 && !seen[r & kRefMask]) { seen[r & kRefMask] = 1; plan.kinlist.push_back(r & kRefMask); }
                 }
     }
-    if ((c->flags & 2 /* BEPUHIP_FLAG_NO_CLUSTERS */) || env_int("BEPUHIP_NO_CLUSTERS", 0) || universe == 0 || c->total_constraints == 0) return;
+    if ((c->flags & BEPUHIP_FLAG_NO_CLUSTERS) || env_int("BEPUHIP_NO_CLUSTERS", 0) || universe == 0 || c->total_constraints == 0 || c->batch_count > kFallbackBatchLimit) return;
     std::vector<int32_t> parent(universe);
     for (int i = 0; i < universe; ++i) parent[i] = i;
     auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
@@ -680,32 +852,73 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     // component sizes (root = smallest body index of the component)
     std::vector<int32_t> comp_size(universe, 0);
     int64_t total_dyn = 0;
-    for (int i = 0; i < universe; ++i) if (is_dyn[i]) { comp_size[find(i)]++; ++total_dyn; }
+    int32_t largest = 0;
+    for (int i = 0; i < universe; ++i) if (is_dyn[i]) { largest = std::max(largest, ++comp_size[find(i)]); ++total_dyn; }
+    for (int i = 0; i < universe; ++i) if (is_dyn[i]) find(i);  // full path compression: parent[i] is the root from here on
     int cap = env_int("BEPUHIP_CLUSTER_BODIES", 0);
     if (cap <= 0) {
-        // default: one resident workgroup per CU (the kernel's register budget admits one 512-thread workgroup per CU), no second round
+        // default: one resident workgroup per CU (the kernel's LDS footprint admits one workgroup per CU), a single round
         int cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         int64_t target = (total_dyn + (cus * 31 / 32) - 1) / std::max(1, cus * 31 / 32);
-        cap = (int)std::min<int64_t>(std::max<int64_t>(target, 64), 1024);
+        cap = (int)std::min<int64_t>(std::max<int64_t>(target, 64), 1200);
     }
-    cap = std::min(cap, kLdsBudgetBodies - 32);
+    if (largest > cap) cap = largest;
+    // ---- phase A: find a cap whose clusters fit the LDS budget (no mutation yet) ----
     std::vector<int32_t> cluster_of(universe, -1);  // by component root
-    int nclusters = 0, cur = 0;
-    for (int i = 0; i < universe; ++i) {
-        if (!is_dyn[i] || parent[i] != i) continue;  // roots only, ascending
-        if (comp_size[i] > cap) return;              // an island does not fit one workgroup: global path
-        if (nclusters == 0 || cur + comp_size[i] > cap) { ++nclusters; cur = 0; }
-        cluster_of[i] = nclusters - 1;
-        cur += comp_size[i];
+    std::vector<std::vector<int32_t>> cl_of_constraint(c->tbs.size());
+    int nclusters = 0;
+    for (int attempt = 0;; ++attempt) {
+        nclusters = 0;
+        int cur = 0;
+        for (int i = 0; i < universe; ++i) {
+            if (!is_dyn[i] || parent[i] != i) continue;  // roots only, ascending
+            if (nclusters == 0 || cur + comp_size[i] > cap) { ++nclusters; cur = 0; }
+            cluster_of[i] = nclusters - 1;
+            cur += comp_size[i];
+        }
+        std::vector<int32_t> dyn_count(nclusters, 0), item_count(nclusters, 0);
+        std::vector<std::vector<int32_t>> kin_seen(nclusters);
+        for (int i = 0; i < universe; ++i) if (is_dyn[i]) dyn_count[cluster_of[parent[i]]]++;
+        std::vector<int32_t> per_cluster(nclusters);
+        for (size_t t = 0; t < c->tbs.size(); ++t) {
+            HostTypeBatch& tb = c->tbs[t];
+            cl_of_constraint[t].resize(tb.count);
+            std::fill(per_cluster.begin(), per_cluster.end(), 0);
+            for (int i = 0; i < tb.count; ++i) {
+                int cl = -1;
+                for (int k = 0; k < tb.info.bodies && cl < 0; ++k) {
+                    int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r < kDynamicLimit) cl = cluster_of[parent[r]];
+                }
+                cl_of_constraint[t][i] = cl;
+                per_cluster[cl]++;
+                for (int k = 0; k < tb.info.bodies; ++k) {
+                    int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r >= kDynamicLimit) {
+                        auto& ks = kin_seen[cl];
+                        if (std::find(ks.begin(), ks.end(), r & kRefMask) == ks.end()) ks.push_back(r & kRefMask);
+                    }
+                }
+            }
+            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (per_cluster[cl] + 63) / 64;
+        }
+        int max_slots = 0, max_items = 0;
+        for (int cl = 0; cl < nclusters; ++cl) {
+            max_slots = std::max(max_slots, (dyn_count[cl] + (int)kin_seen[cl].size() + 15) / 16 * 16);
+            max_items = std::max(max_items, item_count[cl]);
+        }
+        if (max_items < 65536 && cluster_lds_bytes(max_slots, max_items) <= kLdsBudgetBytes) break;
+        if (cap <= largest || attempt > 24) return;  // an island (plus its work items) does not fit one workgroup: global path
+        cap = std::max<int>(largest, cap * 7 / 8);
     }
-    // local indices: dynamics first (ascending body index), kinematics appended per cluster
-    std::vector<std::vector<int32_t>> cl_bodies(nclusters);
+    // ---- phase B: local slots, reordered type batches, work items with predecessor lists ----
+    std::vector<std::vector<int32_t>> cl_bodies(nclusters);  // natural local order: dynamics ascending, kinematics appended on first use
     std::vector<int32_t> local_of(universe, -1);
     for (int i = 0; i < universe; ++i)
-        if (is_dyn[i]) { int cl = cluster_of[find(i)]; local_of[i] = (int)cl_bodies[cl].size(); cl_bodies[cl].push_back(i); plan.clustered_dynamic.push_back(i); }
-    std::vector<std::vector<std::pair<int32_t, int32_t>>> cl_kin(nclusters);  // (kinematic body, local index)
+        if (is_dyn[i]) { int cl = cluster_of[parent[i]]; local_of[i] = (int)cl_bodies[cl].size(); cl_bodies[cl].push_back(i); plan.clustered_dynamic.push_back(i); }
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> cl_kin(nclusters);  // (kinematic body, natural local index)
     auto kin_local = [&](int cl, int body) {
         for (auto& kv : cl_kin[cl]) if (kv.first == body) return kv.second;
         int l = (int)cl_bodies[cl].size();
@@ -713,67 +926,87 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         cl_kin[cl].push_back({body, l});
         return l;
     };
+    std::vector<std::vector<int32_t>> last_toucher(nclusters);  // by slot: cluster-relative index of the item that last touched the (dynamic) body
+    for (int cl = 0; cl < nclusters; ++cl) last_toucher[cl].assign((cl_bodies[cl].size() + 15) / 16 * 16, -1);
     std::vector<std::vector<ClusterItem>> cl_items(nclusters);
     for (size_t t = 0; t < c->tbs.size(); ++t) {
         HostTypeBatch& tb = c->tbs[t];
         const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
-        std::vector<int32_t> cl_of_constraint(tb.count);
-        for (int i = 0; i < tb.count; ++i) {
-            int cl = -1;
-            for (int k = 0; k < nb && cl < 0; ++k) {
-                int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                if ((uint32_t)r < kDynamicLimit) cl = cluster_of[find(r)];
-            }
-            cl_of_constraint[i] = cl;
-        }
+        const std::vector<int32_t>& clc = cl_of_constraint[t];
         tb.perm.resize(tb.count);
         for (int i = 0; i < tb.count; ++i) tb.perm[i] = i;
-        std::stable_sort(tb.perm.begin(), tb.perm.end(), [&](int a, int b) { return cl_of_constraint[a] < cl_of_constraint[b]; });
+        std::stable_sort(tb.perm.begin(), tb.perm.end(), [&](int a, int b) { return clc[a] < clc[b]; });
         std::vector<int32_t> refs((size_t)nb * tb.stride, -1), lrefs((size_t)nb * tb.stride, -1);
         std::vector<float> pre((size_t)pf * tb.stride, 0.0f), acc((size_t)imf * tb.stride, 0.0f);
         for (int d = 0; d < tb.count; ++d) {
-            const int h = tb.perm[d], cl = cl_of_constraint[h];
+            const int h = tb.perm[d], cl = clc[h];
             for (int k = 0; k < nb; ++k) {
                 int32_t r = tb.refs_soa[(size_t)k * tb.stride + h];
                 refs[(size_t)k * tb.stride + d] = r;
-                lrefs[(size_t)k * tb.stride + d] = ((uint32_t)r < kDynamicLimit) ? local_of[r] : (kin_local(cl, r & kRefMask) | (int)kDynamicLimit);
+                lrefs[(size_t)k * tb.stride + d] = ((uint32_t)r < kDynamicLimit) ? rotated_slot(local_of[r]) : (rotated_slot(kin_local(cl, r & kRefMask)) | (int)kDynamicLimit);
             }
             for (int f = 0; f < pf; ++f) pre[(size_t)f * tb.stride + d] = tb.prestep_soa[(size_t)f * tb.stride + h];
             for (int f = 0; f < imf; ++f) acc[(size_t)f * tb.stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
         }
         tb.refs_soa.swap(refs); tb.prestep_soa.swap(pre); tb.accum_soa.swap(acc); tb.lrefs_soa.swap(lrefs);
         for (int d = 0; d < tb.count;) {
-            const int cl = cl_of_constraint[tb.perm[d]];
+            const int cl = clc[tb.perm[d]];
             int e = d;
-            while (e < tb.count && cl_of_constraint[tb.perm[e]] == cl) ++e;
-            for (int s0 = d; s0 < e; s0 += 64) cl_items[cl].push_back({(int)t, s0, std::min(64, e - s0), tb.batch});
+            while (e < tb.count && clc[tb.perm[e]] == cl) ++e;
+            for (int s0 = d; s0 < e; s0 += 64) {
+                ClusterItem it;
+                memset(&it, 0, sizeof(it));
+                it.type_id = tb.type_id; it.count = std::min(64, e - s0); it.stride = tb.stride; it.start = s0;
+                it.tb = (int)t; it.bodies = nb; it.pf = pf; it.imf = imf;
+                const int self = (int)cl_items[cl].size();
+                int npred = 0, overflow = 0;
+                std::vector<int32_t>& lt = last_toucher[cl];
+                for (int j = s0; j < s0 + it.count; ++j)
+                    for (int k = 0; k < nb; ++k) {
+                        const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
+                        if ((uint32_t)lr >= kDynamicLimit) continue;
+                        if ((size_t)lr >= lt.size()) lt.resize((size_t)lr + 16, -1);
+                        const int pred = lt[lr];
+                        if (pred < 0 || pred == self) continue;
+                        bool known = false;
+                        for (int q = 0; q < npred; ++q) known |= it.pred[q] == pred;
+                        if (known) continue;
+                        if (npred < kMaxPreds) it.pred[npred++] = (unsigned short)pred; else overflow = 1;
+                    }
+                for (int j = s0; j < s0 + it.count; ++j)
+                    for (int k = 0; k < nb; ++k) {
+                        const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
+                        if ((uint32_t)lr < kDynamicLimit) lt[lr] = self;
+                    }
+                if (overflow) npred = 0;
+                it.batch_npred = (tb.batch & 0xFFFF) | (npred << 16) | (overflow << 24);
+                cl_items[cl].push_back(it);
+            }
             d = e;
         }
     }
     for (int cl = 0; cl < nclusters; ++cl) {
-        if ((int)cl_bodies[cl].size() > kLdsBudgetBodies) { // too many kinematic references: undo is not worth it, fall back
-            for (auto& tb : c->tbs) { /* the permuted order is still a valid global-path layout */ tb.lrefs_soa.clear(); }
-            plan = ClusterPlan{false, {}, {}, {}, {}, {}, plan.kinlist, 0};
-            return;
-        }
         ClusterDesc d;
         d.body_begin = (int)plan.cluster_bodies.size();
-        d.body_count = (int)cl_bodies[cl].size();
-        plan.cluster_bodies.insert(plan.cluster_bodies.end(), cl_bodies[cl].begin(), cl_bodies[cl].end());
+        d.slot_count = ((int)cl_bodies[cl].size() + 15) / 16 * 16;
+        std::vector<int32_t> slots(d.slot_count, -1);
+        for (size_t i = 0; i < cl_bodies[cl].size(); ++i) slots[rotated_slot((int)i)] = cl_bodies[cl][i];
+        plan.cluster_bodies.insert(plan.cluster_bodies.end(), slots.begin(), slots.end());
         d.item_begin = (int)plan.items.size();
         d.item_count = (int)cl_items[cl].size();
         d.batch_item_offset = (int)plan.batch_item_begin.size();
         // items were appended in type-batch order == batch order
         int k = 0;
         for (int b = 0; b <= c->batch_count; ++b) {
-            while (k < d.item_count && cl_items[cl][k].batch < b) ++k;
+            while (k < d.item_count && (cl_items[cl][k].batch_npred & 0xFFFF) < b) ++k;
             plan.batch_item_begin.push_back(d.item_begin + k);
         }
         plan.items.insert(plan.items.end(), cl_items[cl].begin(), cl_items[cl].end());
         plan.clusters.push_back(d);
-        plan.max_bodies = std::max(plan.max_bodies, d.body_count);
+        plan.max_slots = std::max(plan.max_slots, d.slot_count);
+        plan.max_items = std::max(plan.max_items, d.item_count);
     }
-    plan.enabled = nclusters > 0;
+    plan.enabled = nclusters > 0 && cluster_lds_bytes(plan.max_slots, plan.max_items) <= kLdsBudgetBytes;
 }
 
 extern "C" {
@@ -805,6 +1038,8 @@ int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev_start));
     HIP_TRY(hipEventCreate(&c->ev_stop));
+    HIP_TRY(hipHostMalloc((void**)&c->d_status, 256, hipHostMallocMapped | hipHostMallocCoherent));  // host-visible while a kernel runs
+    memset(c->d_status, 0, 256);
     *out_ctx = c;
     return BEPUHIP_OK;
 }
@@ -818,6 +1053,7 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_bodies0) hipFree(c->d_bodies0);
     if (c->d_flags) hipFree(c->d_flags);
     if (c->d_kin) hipFree(c->d_kin);
+    if (c->d_status) hipHostFree(c->d_status);
     hipEventDestroy(c->ev_start);
     hipEventDestroy(c->ev_stop);
     hipStreamDestroy(c->stream);
@@ -960,7 +1196,6 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
                 d.refs = (int*)(c->d_slab + tb.refs_off);
                 d.prestep = (float*)(c->d_slab + tb.prestep_off);
                 d.accum = (float*)(c->d_slab + tb.accum_off);
-                d.lrefs = plan.enabled ? (int*)(c->d_slab + tb.lrefs_off) : nullptr;
                 descs[t] = d;
                 blocks += (tb.count + kBlock - 1) / kBlock;
                 ++t;
@@ -998,14 +1233,23 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
     c->clusters_enabled = plan.enabled;
     if (plan.enabled) {
         c->cluster_count = (int)plan.clusters.size();
-        c->cluster_max_bodies = plan.max_bodies;
+        c->cluster_max_slots = plan.max_slots;
+        c->first_cluster = plan.clusters[0];
+        c->cluster_max_items = plan.max_items;
+        for (auto& it : plan.items) {  // resolve the items' slab offsets now that the slab layout exists
+            const HostTypeBatch& tb = c->tbs[it.tb];
+            it.lrefs_off = (unsigned)tb.lrefs_off;
+            it.prestep_off = (unsigned)tb.prestep_off;
+            it.accum_off = (unsigned)tb.accum_off;
+        }
         c->clustered_dynamic_count = (int)plan.clustered_dynamic.size();
         HIP_TRY(upload_ints(plan.clusters.data(), plan.clusters.size() * sizeof(ClusterDesc), (void**)&c->d_clusters));
         HIP_TRY(upload_ints(plan.items.data(), plan.items.size() * sizeof(ClusterItem), (void**)&c->d_items));
         HIP_TRY(upload_ints(plan.batch_item_begin.data(), plan.batch_item_begin.size() * 4, (void**)&c->d_batch_item_begin));
         HIP_TRY(upload_ints(plan.cluster_bodies.data(), plan.cluster_bodies.size() * 4, (void**)&c->d_cluster_bodies));
         HIP_TRY(upload_ints(plan.clustered_dynamic.data(), plan.clustered_dynamic.size() * 4, (void**)&c->d_clustered_dynamic));
-        HIP_TRY(hipFuncSetAttribute((const void*)cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)cluster_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)cluster_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
     }
     c->built = true;
     return rebuild_flags(c);
@@ -1060,7 +1304,8 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
     const float inv_dt = 1.0f / substep_dt;          // :1421
     const StepParams sp = make_params(in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
-    const bool use_clusters = c->clusters_enabled && substeps <= kMaxClusterSubsteps;
+    const size_t lds_bytes = cluster_lds_bytes(c->cluster_max_slots, c->cluster_max_items);
+    const bool use_clusters = c->clusters_enabled && substeps <= kMaxClusterSubsteps && lds_bytes <= kLdsBudgetBytes;
     if (use_clusters) {
         // Every constraint belongs to an island small enough for one workgroup: the whole substep loop runs in ONE launch.
         ClusterParams cp;
@@ -1068,10 +1313,14 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
         for (int s = 0; s < kMaxClusterSubsteps; ++s) cp.iters[s] = s < substeps ? iterations[s] : 0;
         cp.sp = sp;
         {
-            Timed t(c, 3);
-            const size_t lds_bytes = (size_t)c->cluster_max_bodies * kLdsBodyVec * sizeof(float4);
-            hipLaunchKernelGGL(cluster_kernel, dim3(c->cluster_count), dim3(std::min(kClusterThreads, std::max(64, env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads) / 64 * 64))), lds_bytes, c->stream, (const ClusterDesc*)c->d_clusters, (const ClusterItem*)c->d_items,
-                               (const int*)c->d_batch_item_begin, (const int*)c->d_cluster_bodies, (const DevTypeBatch*)c->d_tbs, c->d_bodies, cp);
+            Timed t(c, 5);
+            const int threads = std::min(kClusterThreads, std::max(64, env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads) / 64 * 64));
+            if (c->d_trace)
+                hipLaunchKernelGGL(cluster_kernel<true>, dim3(c->cluster_count), dim3(threads), lds_bytes, c->stream, (const ClusterDesc*)c->d_clusters, (const ClusterItem*)c->d_items,
+                                   (const int*)c->d_batch_item_begin, (const int*)c->d_cluster_bodies, c->d_bodies, (unsigned*)c->d_slab, cp, c->cluster_max_slots, c->cluster_max_items, c->d_trace, c->d_status);
+            else
+                hipLaunchKernelGGL(cluster_kernel<false>, dim3(c->cluster_count), dim3(threads), lds_bytes, c->stream, (const ClusterDesc*)c->d_clusters, (const ClusterItem*)c->d_items,
+                                   (const int*)c->d_batch_item_begin, (const int*)c->d_cluster_bodies, c->d_bodies, (unsigned*)c->d_slab, cp, c->cluster_max_slots, c->cluster_max_items, (unsigned long long*)nullptr, c->d_status);
         }
         if (c->kinlist_count > 0) {
             Timed t(c, 1);
@@ -1131,7 +1380,7 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     int64_t iters = 0;
     for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
     c->last_constraint_iterations = iters;
-    if (c->profiling) { for (int i = 0; i < 5; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; } }
+    if (c->profiling) { for (int i = 0; i < 6; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; } }
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
     const bool use_graph = !(c->flags & BEPUHIP_FLAG_NO_GRAPH) && !c->profiling;
     if (use_graph) {
@@ -1165,6 +1414,16 @@ int32_t bepuhip_sync(bepuhip_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) c->last_ms = ms;
+    if (c->clusters_enabled) {
+        unsigned st[8];
+        memcpy(st, c->d_status, sizeof(st));
+        if (st[0] != 0) {
+            memset(c->d_status, 0, 256);
+            char msg[256];
+            snprintf(msg, sizeof(msg), "cluster schedule stalled: cluster %u kind %u item %u waiting on %u, wanted %u saw %u, claim counter %u", st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+            return fail(BEPUHIP_E_DEVICE, msg);
+        }
+    }
     return BEPUHIP_OK;
 }
 
@@ -1235,9 +1494,39 @@ int32_t bepuhip_set_profiling(bepuhip_ctx* c, int32_t enabled) {
     return BEPUHIP_OK;
 }
 int32_t bepuhip_get_profile(bepuhip_ctx* c, int32_t family, float* ms, int32_t* launches) {
-    if (!c || family < 0 || family > 4) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad family");
+    if (!c || family < 0 || family > 5) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad family");
     if (ms) *ms = c->prof_ms[family];
     if (launches) *launches = c->prof_launches[family];
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_set_cluster_trace(bepuhip_ctx* c, int32_t enabled) {
+    if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);  // captured launches bake the trace pointer in
+    c->graphs.clear();
+    if (c->d_trace) { hipFree(c->d_trace); c->d_trace = nullptr; c->trace_words = 0; }
+    if (enabled && c->clusters_enabled) {
+        const ClusterDesc first = c->first_cluster;
+        c->trace_words = (size_t)first.item_count * 4 * (size_t)kMaxClusterSubsteps * 8;  // up to 128 passes of cluster 0
+        HIP_TRY(hipMalloc((void**)&c->d_trace, c->trace_words * 8));
+        HIP_TRY(hipMemset(c->d_trace, 0, c->trace_words * 8));
+    }
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_get_cluster_trace(bepuhip_ctx* c, uint64_t* out, int64_t capacity_words, int32_t* items_out) {
+    if (!c || !out || !items_out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    if (!c->d_trace) return fail(BEPUHIP_E_STATE, "cluster trace is not enabled (or the scene does not use the cluster schedule)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t n = std::min<size_t>(c->trace_words, (size_t)std::max<int64_t>(capacity_words, 0));
+    HIP_TRY(hipMemcpy(out, c->d_trace, n * 8, hipMemcpyDeviceToHost));
+    *items_out = c->first_cluster.item_count;
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_debug_status(bepuhip_ctx* c, uint32_t* out16) {
+    if (!c || !out16) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    memcpy(out16, c->d_status, 64);
     return BEPUHIP_OK;
 }
 int32_t bepuhip_last_constraint_iterations(bepuhip_ctx* c, int64_t* out) {

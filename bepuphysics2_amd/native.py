@@ -14,7 +14,7 @@ import numpy as np
 from .scene import PoseIntegratorCallbacks, Scene, SolveDescription, TYPE_TABLE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbepuhip.so")
+LIB_PATH = os.environ.get("BEPUHIP_LIB") or os.path.join(_HERE, "csrc", "libbepuhip.so")  # override: A/B timing of kernel builds (tools/)
 
 BEPUHIP_OK = 0
 BEPUHIP_E_INVALID_ARGUMENT = -1
@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_get_bodies", "bepuhip_get_accumulated_impulses", "bepuhip_get_prestep", "bepuhip_get_constrained_flags",
     "bepuhip_last_solve_ms", "bepuhip_set_profiling", "bepuhip_get_profile", "bepuhip_last_constraint_iterations",
     "bepuhip_get_stream", "bepuhip_solve_async", "bepuhip_sync", "bepuhip_reset_state", "bepuhip_type_info",
+    "bepuhip_set_cluster_trace", "bepuhip_get_cluster_trace",
 ]
 
 
@@ -87,6 +88,8 @@ def load_library() -> C.CDLL:
     lib.bepuhip_last_constraint_iterations.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.bepuhip_get_stream.argtypes = [vp, C.POINTER(vp)]
     lib.bepuhip_reset_state.argtypes = [vp]
+    lib.bepuhip_set_cluster_trace.argtypes = [vp, i32]
+    lib.bepuhip_get_cluster_trace.argtypes = [vp, vp, C.c_int64, C.POINTER(i32)]
     lib.bepuhip_type_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     for name in EXPORTED_SYMBOLS:
         if name != "bepuhip_last_error":
@@ -124,7 +127,7 @@ def make_integrator(cb: PoseIntegratorCallbacks) -> Integrator:
 class HipSolver:
     """Device mirror of one Simulation's solver state; ``solve`` replaces ``Simulation.Solve`` (Simulation.cs:278-290)."""
 
-    PROFILE_FAMILIES = ("incremental", "integrate", "warmstart", "solve", "final")
+    PROFILE_FAMILIES = ("incremental", "integrate", "warmstart", "solve", "final", "cluster")
 
     def __init__(self, device: int = 0, bundle_width: int = 8, use_graph: bool = True, use_clusters: bool = True):
         self.lib = load_library()
@@ -221,6 +224,18 @@ class HipSolver:
             _check(self.lib, self.lib.bepuhip_get_profile(self.ctx, i, C.byref(ms), C.byref(n)))
             out[name] = (float(ms.value), int(n.value))
         return out
+
+    def set_cluster_trace(self, enabled: bool):
+        _check(self.lib, self.lib.bepuhip_set_cluster_trace(self.ctx, int(enabled)))
+
+    def cluster_trace(self, passes: int) -> np.ndarray:
+        """(passes, items, 4) uint64 records of the first cluster: claim clock, publish clock, wave|type<<8|batch<<16|stage<<32, count."""
+        cap = 1 << 22
+        buf = np.zeros(cap, dtype=np.uint64)
+        items = C.c_int32()
+        _check(self.lib, self.lib.bepuhip_get_cluster_trace(self.ctx, _ptr(buf), cap, C.byref(items)))
+        n = int(items.value)
+        return buf[: passes * n * 4].reshape(passes, n, 4)
 
     def stream_handle(self) -> int:
         v = C.c_void_p()

@@ -94,7 +94,13 @@ int32_t bepuhip_get_constrained_flags(bepuhip_ctx* ctx, uint8_t* flags_out, int3
 int32_t bepuhip_last_solve_ms(bepuhip_ctx* ctx, float* ms_out);
 /* Per-kernel-family accumulated duration (ms) and launch count of the last solve when profiling is enabled. */
 int32_t bepuhip_set_profiling(bepuhip_ctx* ctx, int32_t enabled);
-int32_t bepuhip_get_profile(bepuhip_ctx* ctx, int32_t family /*0 incremental,1 integrate,2 warmstart,3 solve,4 final*/, float* ms_out, int32_t* launches_out);
+int32_t bepuhip_get_profile(bepuhip_ctx* ctx, int32_t family /*0 incremental,1 integrate,2 warmstart,3 solve,4 final,5 cluster (whole substep loop in one launch)*/, float* ms_out, int32_t* launches_out);
+/* Per-work-item timeline of the FIRST cluster of the island-per-workgroup schedule (kernel tuning aid). After enabling, every solve
+ * records, for pass p (0-based: warm start / velocity iteration sweeps in execution order) and work item k, four 64-bit words at
+ * [(p * items + k) * 4]: {shader clock when the item was claimed, shader clock when it was published, wave | type_id << 8 | batch << 16 |
+ * stage << 32, constraint count}. get returns `items` so that the caller can index the records. STATE if the scene runs the launch-per-batch schedule. */
+int32_t bepuhip_set_cluster_trace(bepuhip_ctx* ctx, int32_t enabled);
+int32_t bepuhip_get_cluster_trace(bepuhip_ctx* ctx, uint64_t* words_out, int64_t capacity_words, int32_t* items_out);
 /* Constraint-iterations executed by the last solve: sum over substeps of constraints * (1 + velocity_iterations[s]). */
 int32_t bepuhip_last_constraint_iterations(bepuhip_ctx* ctx, int64_t* out);
 /* The native HIP stream handle (hipStream_t) the context launches on, for callers that time with their own HIP events. */
