@@ -90,42 +90,43 @@ struct Contact {
             vA.ang = add(vA.ang, corrAAng);
         }
     }
-    BD_FN void penWarmStart(const Inertia& iA, const Inertia& iB, V3 n, V3 offA, V3 offB, float acc, BodyVel& vA, BodyVel& vB) {
-        // PenetrationLimit.cs:69-76
-        V3 angularA = cross(offA, n);
-        V3 angularB = TwoBody ? cross(n, offB) : V3{0, 0, 0};
-        penApply(iA, iB, n, angularA, angularB, acc, vA, vB);
-    }
-    BD_FN void penSolve(const Inertia& iA, const Inertia& iB, V3 n, V3 offA, V3 offB, float dep, float posErrToVel, float effMassCFMScale,
-                         float maxRecoveryVelocity, float inverseDt, float softnessImpulseScale, float& acc, BodyVel& vA, BodyVel& vB) {
-        // PenetrationLimit.cs:79-131; PenetrationLimitOneBody.cs Solve
-        V3 angularA = cross(offA, n);
-        V3 angularB = TwoBody ? cross(n, offB) : V3{0, 0, 0};
-        float angularA0 = vectorSandwich(angularA, iA.t);
-        float effectiveMass;
+    // The velocity-independent half of every row (jacobians, effective mass, bias) is separated from the velocity-dependent half
+    // (corrective impulse, application) so that a caller can evaluate the former before the bodies' velocities are available.
+    // Every value is produced by the same operations in the same order as the reference's fused form.
+    struct PenRow { V3 angularA, angularB; float effectiveMass, biasVelocity; };
+    BD_FN PenRow penSetup(const Inertia& iA, const Inertia& iB, V3 n, V3 offA, V3 offB, float dep, float posErrToVel, float effMassCFMScale,
+                          float maxRecoveryVelocity, float inverseDt) {
+        // PenetrationLimit.cs:79-131 up to the bias velocity; PenetrationLimitOneBody.cs Solve
+        PenRow r;
+        r.angularA = cross(offA, n);
+        r.angularB = TwoBody ? cross(n, offB) : V3{0, 0, 0};
+        float angularA0 = vectorSandwich(r.angularA, iA.t);
         if (TwoBody) {
-            float angularB0 = vectorSandwich(angularB, iB.t);
+            float angularB0 = vectorSandwich(r.angularB, iB.t);
             float linear = iA.invMass + iB.invMass;
-            effectiveMass = effMassCFMScale / (linear + angularA0 + angularB0);
+            r.effectiveMass = effMassCFMScale / (linear + angularA0 + angularB0);
         } else {
-            effectiveMass = effMassCFMScale / (iA.invMass + angularA0);
+            r.effectiveMass = effMassCFMScale / (iA.invMass + angularA0);
         }
-        float biasVelocity = vmin(dep * inverseDt, vmin(dep * posErrToVel, maxRecoveryVelocity));
+        r.biasVelocity = vmin(dep * inverseDt, vmin(dep * posErrToVel, maxRecoveryVelocity));
+        return r;
+    }
+    BD_FN void penIterate(const PenRow& r, const Inertia& iA, const Inertia& iB, V3 n, float softnessImpulseScale, float& acc, BodyVel& vA, BodyVel& vB) {
         // ComputeCorrectiveImpulse, PenetrationLimit.cs:9-26
         float csvaLinear = dot(vA.lin, n);
-        float csvaAngular = dot(vA.ang, angularA);
+        float csvaAngular = dot(vA.ang, r.angularA);
         float negatedCSI;
         if (TwoBody) {
             float negatedCSVBLinear = dot(vB.lin, n);
-            float csvbAngular = dot(vB.ang, angularB);
-            negatedCSI = acc * softnessImpulseScale + (csvaLinear - negatedCSVBLinear + csvaAngular + csvbAngular - biasVelocity) * effectiveMass;
+            float csvbAngular = dot(vB.ang, r.angularB);
+            negatedCSI = acc * softnessImpulseScale + (csvaLinear - negatedCSVBLinear + csvaAngular + csvbAngular - r.biasVelocity) * r.effectiveMass;
         } else {
-            negatedCSI = acc * softnessImpulseScale + (csvaLinear + csvaAngular - biasVelocity) * effectiveMass;
+            negatedCSI = acc * softnessImpulseScale + (csvaLinear + csvaAngular - r.biasVelocity) * r.effectiveMass;
         }
         float previousAccumulated = acc;
         acc = vmax(0.0f, acc - negatedCSI);
         float correctiveCSI = acc - previousAccumulated;
-        penApply(iA, iB, n, angularA, angularB, correctiveCSI, vA, vB);
+        penApply(iA, iB, n, r.angularA, r.angularB, correctiveCSI, vA, vB);
     }
 
     // ---- TangentFriction.cs / TangentFrictionOneBody.cs ----
@@ -156,25 +157,31 @@ struct Contact {
             vA.ang = add(vA.ang, corrAAng);
         }
     }
-    BD_FN void tangentSolve(V3 tX, V3 tY, V3 offA, V3 offB, const Inertia& iA, const Inertia& iB, float maximumImpulse, V2& acc, BodyVel& vA, BodyVel& vB) {
-        // TangentFriction.cs:117-137; TangentFrictionOneBody.cs Solve
-        TJ j = tangentJacobians(tX, tY, offA, offB);
+    struct TangentSetup { TJ j; Sym2 effectiveMass; };
+    BD_FN TangentSetup tangentSetup(V3 tX, V3 tY, V3 offA, V3 offB, const Inertia& iA, const Inertia& iB) {
+        // TangentFriction.cs:117-137 up to the effective mass; TangentFrictionOneBody.cs Solve
+        TangentSetup t;
+        t.j = tangentJacobians(tX, tY, offA, offB);
         Sym2 inverseEffectiveMass;
         if (TwoBody) {
-            Sym2 linearContributionA = sandwichScale(j.linearA, iA.invMass);
-            Sym2 linearContributionB = sandwichScale(j.linearA, iB.invMass);
-            Sym2 angularContributionA = matrixSandwich(j.angularA, iA.t);
-            Sym2 angularContributionB = matrixSandwich(j.angularB, iB.t);
+            Sym2 linearContributionA = sandwichScale(t.j.linearA, iA.invMass);
+            Sym2 linearContributionB = sandwichScale(t.j.linearA, iB.invMass);
+            Sym2 angularContributionA = matrixSandwich(t.j.angularA, iA.t);
+            Sym2 angularContributionB = matrixSandwich(t.j.angularB, iB.t);
             Sym2 linear = add(linearContributionA, linearContributionB);
             Sym2 angular = add(angularContributionA, angularContributionB);
             inverseEffectiveMass = add(linear, angular);
         } else {
-            Sym2 linearContributionA = sandwichScale(j.linearA, iA.invMass);
-            Sym2 angularContributionA = matrixSandwich(j.angularA, iA.t);
+            Sym2 linearContributionA = sandwichScale(t.j.linearA, iA.invMass);
+            Sym2 angularContributionA = matrixSandwich(t.j.angularA, iA.t);
             inverseEffectiveMass = add(linearContributionA, angularContributionA);
         }
-        Sym2 effectiveMass = invert(inverseEffectiveMass);
+        t.effectiveMass = invert(inverseEffectiveMass);
+        return t;
+    }
+    BD_FN void tangentIterate(const TangentSetup& t, const Inertia& iA, const Inertia& iB, float maximumImpulse, V2& acc, BodyVel& vA, BodyVel& vB) {
         // ComputeCorrectiveImpulse, TangentFriction.cs:72-101 / OneBody variant
+        const TJ& j = t.j;
         V2 previousAccumulated = acc;
         if (TwoBody) {
             V2 csvaLinear = transformByTranspose(vA.lin, j.linearA);
@@ -184,13 +191,13 @@ struct Contact {
             V2 csvLinear = sub(csvbLinear, csvaLinear);
             V2 csvAngular = add(csvaAngular, csvbAngular);
             V2 csv = sub(csvLinear, csvAngular);
-            V2 csi = transform(csv, effectiveMass);
+            V2 csi = transform(csv, t.effectiveMass);
             acc = add(acc, csi);
         } else {
             V2 csvaLinear = transformByTranspose(vA.lin, j.linearA);
             V2 csvaAngular = transformByTranspose(vA.ang, j.angularA);
             V2 csv = add(csvaLinear, csvaAngular);
-            V2 negativeCSI = transform(csv, effectiveMass);
+            V2 negativeCSI = transform(csv, t.effectiveMass);
             acc = sub(acc, negativeCSI);
         }
         float accumulatedMagnitude = length(acc);
@@ -212,7 +219,7 @@ struct Contact {
             vA.ang = add(vA.ang, worldCorrectiveVelocityA);
         }
     }
-    BD_FN void twistSolve(V3 angularJacobianA, const Inertia& iA, const Inertia& iB, float maximumImpulse, float& acc, BodyVel& vA, BodyVel& vB) {  // :46-71
+    BD_FN float twistEffectiveMass(V3 angularJacobianA, const Inertia& iA, const Inertia& iB) {  // :46-71 up to the effective mass
         float angularA = vectorSandwich(angularJacobianA, iA.t);
         float inverseEffectiveMass = angularA;
         if (TwoBody) {
@@ -220,7 +227,9 @@ struct Contact {
             inverseEffectiveMass = angularA + angularB;
         }
         bool inverseIsZero = 0.0f == inverseEffectiveMass;
-        float effectiveMass = sel(inverseIsZero, 0.0f, 1.0f / inverseEffectiveMass);
+        return sel(inverseIsZero, 0.0f, 1.0f / inverseEffectiveMass);
+    }
+    BD_FN void twistIterate(V3 angularJacobianA, float effectiveMass, const Inertia& iA, const Inertia& iB, float maximumImpulse, float& acc, BodyVel& vA, BodyVel& vB) {
         // ComputeCorrectiveImpulse :22-36
         float csvA = dot(vA.ang, angularJacobianA);
         float negatedCSI;
@@ -257,50 +266,61 @@ struct Contact {
             depth(p, i) = depth(p, i) - estimatedDepthChangeVelocity * dt;
         }
     }
-    BD_FN void warmStart(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {
+    template <class G> BD_FN void warmStart(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {
         V3 n = normal(p);
         V3 x, z;
         buildOrthonormalBasis(n, x, z);
         V3 centerA = (N > 1) ? frictionCenter(p) : offsetA(p, 0);
         V3 centerB = TwoBody ? sub(centerA, offsetB(p)) : V3{0, 0, 0};
         TJ j = tangentJacobians(x, z, centerA, centerB);
-        tangentApply(j, iA, iB, V2{a[0], a[1]}, vA, vB);
+        V3 angularA[N], angularB[N];  // PenetrationLimit.cs:69-76 jacobians
         _Pragma("unroll") for (int i = 0; i < N; ++i) {
             V3 oA = offsetA(p, i);
             V3 oB = TwoBody ? sub(oA, offsetB(p)) : V3{0, 0, 0};
-            penWarmStart(iA, iB, n, oA, oB, a[2 + i], vA, vB);
+            angularA[i] = cross(oA, n);
+            angularB[i] = TwoBody ? cross(n, oB) : V3{0, 0, 0};
         }
+        gate(vA, vB);
+        tangentApply(j, iA, iB, V2{a[0], a[1]}, vA, vB);
+        _Pragma("unroll") for (int i = 0; i < N; ++i) penApply(iA, iB, n, angularA[i], angularB[i], a[2 + i], vA, vB);
         twistApply(n, iA, iB, a[2 + N], vA, vB);
     }
-    BD_FN void solve(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB) {
+    template <class G> BD_FN void solve(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {
         float posErrToVel, effMassCFMScale, softnessImpulseScale;
         computeSpringiness(springFreq(p), springDamp(p), dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
         V3 n = normal(p);
+        PenRow rows[N];
         _Pragma("unroll") for (int i = 0; i < N; ++i) {
             V3 oA = offsetA(p, i);
             V3 oB = TwoBody ? sub(oA, offsetB(p)) : V3{0, 0, 0};
-            penSolve(iA, iB, n, oA, oB, depth(p, i), posErrToVel, effMassCFMScale, maxRecovery(p), inverseDt, softnessImpulseScale, a[2 + i], vA, vB);
+            rows[i] = penSetup(iA, iB, n, oA, oB, depth(p, i), posErrToVel, effMassCFMScale, maxRecovery(p), inverseDt);
         }
         V3 x, z;
         buildOrthonormalBasis(n, x, z);
         float premultipliedFrictionCoefficient = (N > 1) ? (1.0f / (float)N) * friction(p) : friction(p);
+        V3 centerA = (N > 1) ? frictionCenter(p) : offsetA(p, 0);
+        V3 centerB = TwoBody ? sub(centerA, offsetB(p)) : V3{0, 0, 0};
+        TangentSetup tangentSetupData = tangentSetup(x, z, centerA, centerB, iA, iB);
+        float twistMass = twistEffectiveMass(n, iA, iB);
+        float leverArm[N];
+        if (N > 1) { _Pragma("unroll") for (int i = 0; i < N; ++i) leverArm[i] = distance(centerA, offsetA(p, i)); }
+        gate(vA, vB);
+        _Pragma("unroll") for (int i = 0; i < N; ++i) penIterate(rows[i], iA, iB, n, softnessImpulseScale, a[2 + i], vA, vB);
         float penSum = a[2];
         _Pragma("unroll") for (int i = 1; i < N; ++i) penSum = penSum + a[2 + i];
         float maximumTangentImpulse = premultipliedFrictionCoefficient * penSum;
-        V3 centerA = (N > 1) ? frictionCenter(p) : offsetA(p, 0);
-        V3 centerB = TwoBody ? sub(centerA, offsetB(p)) : V3{0, 0, 0};
         V2 tangent{a[0], a[1]};
-        tangentSolve(x, z, centerA, centerB, iA, iB, maximumTangentImpulse, tangent, vA, vB);
+        tangentIterate(tangentSetupData, iA, iB, maximumTangentImpulse, tangent, vA, vB);
         a[0] = tangent.x; a[1] = tangent.y;
         float maximumTwistImpulse;
         if (N == 1) {
             maximumTwistImpulse = friction(p) * a[2] * vmax(0.0f, depth(p, 0));
         } else {
-            float s = a[2] * distance(centerA, offsetA(p, 0));
-            _Pragma("unroll") for (int i = 1; i < N; ++i) s = s + a[2 + i] * distance(centerA, offsetA(p, i));
+            float s = a[2] * leverArm[0];
+            _Pragma("unroll") for (int i = 1; i < N; ++i) s = s + a[2 + i] * leverArm[i];
             maximumTwistImpulse = premultipliedFrictionCoefficient * s;
         }
-        twistSolve(n, iA, iB, maximumTwistImpulse, a[2 + N], vA, vB);
+        twistIterate(n, twistMass, iA, iB, maximumTwistImpulse, a[2 + N], vA, vB);
     }
 };
 
@@ -350,12 +370,13 @@ struct BallSocket {
     static constexpr bool incremental = false;
     static constexpr int wsA = kAccessNoPosition, wsB = kAccessNoPosition, svA = kAccessAll, svB = kAccessAll;  // BallSocket.cs:100-103
     BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
-    BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :68-74
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :68-74
         V3 offsetA = transform(V3{p[0], p[1], p[2]}, oA);
         V3 offsetB = transform(V3{p[3], p[4], p[5]}, oB);
+        gate(vA, vB);
         BallSocketShared::applyImpulse(vA, vB, offsetA, offsetB, iA, iB, V3{a[0], a[1], a[2]});
     }
-    BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :76-91
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :76-91
         V3 offsetA = transform(V3{p[0], p[1], p[2]}, oA);
         V3 offsetB = transform(V3{p[3], p[4], p[5]}, oB);
         float posErrToVel, effMassCFMScale, softnessImpulseScale;
@@ -365,6 +386,7 @@ struct BallSocket {
         V3 anchorB = add(ab, offsetB);
         V3 error = sub(anchorB, offsetA);
         V3 biasVelocity = scale(error, posErrToVel);
+        gate(vA, vB);
         // BallSocketShared.Solve :101-108
         V3 acc{a[0], a[1], a[2]};
         V3 correctiveImpulse = BallSocketShared::computeCorrectiveImpulse(vA, vB, offsetA, offsetB, biasVelocity, effectiveMass, softnessImpulseScale, acc);
@@ -426,14 +448,15 @@ struct AngularHinge {
         jacobianA.X = transform(localAX, orientationMatrixA);
         jacobianA.Y = transform(localAY, orientationMatrixA);
     }
-    BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :132-138
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :132-138
         V3 hingeAxisA; M23 jacobianA;
         computeJacobians(V3{p[0], p[1], p[2]}, oA, hingeAxisA, jacobianA);
         M23 impulseToVelocityA = multiply(jacobianA, iA.t);
         M23 negatedImpulseToVelocityB = multiply(jacobianA, iB.t);
+        gate(vA, vB);
         applyImpulse(impulseToVelocityA, negatedImpulseToVelocityB, V2{a[0], a[1]}, vA.ang, vB.ang);
     }
-    BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :140-217
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :140-217
         V3 hingeAxisA; M23 jacobianA;
         computeJacobians(V3{p[0], p[1], p[2]}, oA, hingeAxisA, jacobianA);
         V3 hingeAxisB = transform(V3{p[3], p[4], p[5]}, oB);
@@ -448,6 +471,7 @@ struct AngularHinge {
         V2 errorAngle = getErrorAngles(hingeAxisA, hingeAxisB, jacobianA);
         V2 biasVelocity = scale(errorAngle, -posErrToVel);
         V2 biasImpulse = transform(biasVelocity, effectiveMass);
+        gate(vA, vB);
         V3 difference = sub(vA.ang, vB.ang);
         V2 csv = transformByTranspose(difference, jacobianA);
         V2 csi = transform(csv, effectiveMass);
@@ -492,14 +516,15 @@ struct SwingLimit {
         bool useFallback = jacobianLengthSquared < 1e-7f;
         jacobianA = sel3(useFallback, fallbackJacobian, jacobianA);
     }
-    BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :114-120
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :114-120
         V3 axisA, axisB, jacobianA;
         computeJacobian(V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, oA, oB, axisA, axisB, jacobianA);
         V3 impulseToVelocityA = transform(jacobianA, iA.t);
         V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
+        gate(vA, vB);
         applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
     }
-    BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :122-163
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :122-163
         V3 axisA, axisB, jacobianA;
         computeJacobian(V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, oA, oB, axisA, axisB, jacobianA);
         V3 impulseToVelocityA = transform(jacobianA, iA.t);
@@ -512,6 +537,7 @@ struct SwingLimit {
         float axisDot = dot(axisA, axisB);
         float error = axisDot - p[6];
         float biasVelocity = -vmin(error * inverseDt, error * posErrToVel);
+        gate(vA, vB);
         V3 difference = sub(vA.ang, vB.ang);
         float csv = dot(difference, jacobianA);
         float csi = effectiveMass * (biasVelocity - csv) - a[0] * softnessImpulseScale;
@@ -573,14 +599,15 @@ struct TwistServo {
     static constexpr bool incremental = false;
     static constexpr int wsA = kAccessOnlyAngular, wsB = kAccessOnlyAngular, svA = kAccessOnlyAngular, svB = kAccessOnlyAngular;  // TwistServo.cs:224
     BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
-    BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :184-190
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :184-190
         V3 jacobianA;
         TwistShared::computeJacobianOnly(oA, oB, Q{p[0], p[1], p[2], p[3]}, Q{p[4], p[5], p[6], p[7]}, jacobianA);
         V3 impulseToVelocityA = transform(jacobianA, iA.t);
         V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
+        gate(vA, vB);
         applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
     }
-    BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :192-222
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :192-222
         V3 basisBX, basisBZ, jacobianA; M3 basisA;
         TwistShared::computeJacobianFull(oA, oB, Q{p[0], p[1], p[2], p[3]}, Q{p[4], p[5], p[6], p[7]}, basisBX, basisBZ, basisA, jacobianA);
         V3 impulseToVelocityA, negatedImpulseToVelocityB, velocityToImpulseA;
@@ -598,6 +625,7 @@ struct TwistServo {
                                         vmin(maximumSpeed, vmax(baseSpeed, biasVelocity)));
         float maximumImpulse = maximumForce * dt;
         float biasImpulse = clampedBiasVelocity * effectiveMass;
+        gate(vA, vB);
         V3 netVelocity = sub(vA.ang, vB.ang);
         float csiVelocityComponent = dot(netVelocity, velocityToImpulseA);
         float csi = biasImpulse - a[0] * softnessImpulseScale - csiVelocityComponent;
@@ -623,14 +651,15 @@ struct TwistLimit {
         V3 negatedJacobianA = neg(jacobianA);
         jacobianA = sel3(useMin, negatedJacobianA, jacobianA);
     }
-    BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :104-110
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :104-110
         float error; V3 jacobianA;
         computeJacobian(oA, oB, Q{p[0], p[1], p[2], p[3]}, Q{p[4], p[5], p[6], p[7]}, p[8], p[9], error, jacobianA);
         V3 impulseToVelocityA = transform(jacobianA, iA.t);
         V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
+        gate(vA, vB);
         applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
     }
-    BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :112-131
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :112-131
         float error; V3 jacobianA;
         computeJacobian(oA, oB, Q{p[0], p[1], p[2], p[3]}, Q{p[4], p[5], p[6], p[7]}, p[8], p[9], error, jacobianA);
         V3 impulseToVelocityA, negatedImpulseToVelocityB, velocityToImpulseA;
@@ -639,6 +668,7 @@ struct TwistLimit {
                                           posErrToVel, softnessImpulseScale, effectiveMass, velocityToImpulseA);
         float biasVelocity = sel(error < 0.0f, error * inverseDt, error * posErrToVel);
         float biasImpulse = biasVelocity * effectiveMass;
+        gate(vA, vB);
         V3 netVelocity = sub(vA.ang, vB.ang);
         float csiVelocityComponent = dot(netVelocity, velocityToImpulseA);
         float csi = biasImpulse - a[0] * softnessImpulseScale - csiVelocityComponent;
@@ -663,10 +693,11 @@ struct AngularMotor {
         V3 negatedVelocityChangeB = transform(csi, negatedImpulseToVelocityB);
         angB = sub(angB, negatedVelocityChangeB);
     }
-    BD_FN void warmStart(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float*, float* a, BodyVel& vA, BodyVel& vB) {  // :63-66
+    template <class G> BD_FN void warmStart(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float*, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :63-66
+        gate(vA, vB);
         applyImpulse(vA.ang, vB.ang, iA.t, iB.t, V3{a[0], a[1], a[2]});
     }
-    BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :68-90
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :68-90
         // MotorSettingsWide.ComputeSoftness, MotorSettings.cs:70-99
         float dtd = dt * p[4];
         float maximumImpulse = p[3] * dt;
@@ -675,6 +706,7 @@ struct AngularMotor {
         Sym3 unsoftenedInverseEffectiveMass = add(iA.t, iB.t);
         Sym3 unsoftenedEffectiveMass = invert(unsoftenedInverseEffectiveMass);
         V3 biasVelocity = transform(V3{p[0], p[1], p[2]}, oA);
+        gate(vA, vB);
         V3 csv = sub(vA.ang, vB.ang);
         csv = sub(biasVelocity, csv);
         V3 csi = transform(csv, unsoftenedEffectiveMass);
@@ -731,12 +763,13 @@ struct SwivelHinge {
         bool useFallbackJacobian = lenSq < 1e-3f;
         swivelHingeJacobian = sel3(useFallbackJacobian, hingeAxis, swivelHingeJacobian);
     }
-    BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :124-129
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :124-129
         V3 swivelAxis, hingeAxis, offsetA, offsetB, jac;
         computeJacobian(p, oA, oB, swivelAxis, hingeAxis, offsetA, offsetB, jac);
+        gate(vA, vB);
         applyImpulse(offsetA, offsetB, jac, iA, iB, V4{a[0], a[1], a[2], a[3]}, vA, vB);
     }
-    BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :131-208
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :131-208
         V3 swivelAxis, hingeAxis, offsetA, offsetB, jac;
         computeJacobian(p, oA, oB, swivelAxis, hingeAxis, offsetA, offsetB, jac);
         Sym3 ballSocketContributionAngularA = skewSandwich(offsetA, iA.t);
@@ -769,6 +802,7 @@ struct SwivelHinge {
         biasVelocity.z = ballSocketError.z * posErrToVel;
         float error = dot(hingeAxis, swivelAxis);
         biasVelocity.w = posErrToVel * -error;
+        gate(vA, vB);
         V3 ballSocketAngularCSVA = cross(vA.ang, offsetA);
         float swivelHingeCSVA = dot(jac, vA.ang);
         V3 ballSocketAngularCSVB = cross(offsetB, vB.ang);
@@ -815,7 +849,7 @@ struct Hinge {
         V3 angularChangeB = transform(angularImpulseB, iB.t);
         vB.ang = add(vB.ang, angularChangeB);
     }
-    BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :112-122
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :112-122
         M3 orientationMatrixA = createFromQuaternion(oA);
         V3 offsetA = transform(V3{p[0], p[1], p[2]}, orientationMatrixA);
         V3 offsetB = transform(V3{p[6], p[7], p[8]}, oB);
@@ -824,9 +858,10 @@ struct Hinge {
         M23 hingeJacobian;
         hingeJacobian.X = transform(localAX, orientationMatrixA);
         hingeJacobian.Y = transform(localAY, orientationMatrixA);
+        gate(vA, vB);
         applyImpulse(offsetA, offsetB, hingeJacobian, iA, iB, V3{a[0], a[1], a[2]}, V2{a[3], a[4]}, vA, vB);
     }
-    BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB) {  // :124-216
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :124-216
         M3 orientationMatrixA = createFromQuaternion(oA);
         M3 orientationMatrixB = createFromQuaternion(oB);
         V3 offsetA = transform(V3{p[0], p[1], p[2]}, orientationMatrixA);
@@ -865,6 +900,7 @@ struct Hinge {
         V3 ballSocketBiasVelocity = scale(ballSocketError, posErrToVel);
         V2 errorAngles = AngularHinge::getErrorAngles(hingeAxisA, hingeAxisB, hingeJacobian);
         V2 hingeBiasVelocity = scale(errorAngles, -posErrToVel);
+        gate(vA, vB);
         V3 ballSocketAngularCSVA = cross(vA.ang, offsetA);
         V2 hingeCSVA = transformByTranspose(vA.ang, hingeJacobian);
         V3 ballSocketAngularCSVB = cross(offsetB, vB.ang);

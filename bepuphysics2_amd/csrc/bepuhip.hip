@@ -103,6 +103,9 @@ __device__ __forceinline__ void store_velocity(float4* bodies, int ref, const DB
 }
 
 enum { kStageWarmStart = 0, kStageSolve = 1, kStageIncremental = 2 };
+// The constraint functions call their gate once, right before the first use of the bodies' velocities (everything before it depends on
+// poses, inertias and prestep data only). The launch-per-batch kernels have the velocities in registers already.
+struct NoGate { __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {} };
 
 template <class F, int STAGE>
 __device__ __forceinline__ void run_constraint(const DevTypeBatch& tb, int i, float4* bodies, float dt, float inv_dt) {
@@ -129,9 +132,9 @@ __device__ __forceinline__ void run_constraint(const DevTypeBatch& tb, int i, fl
     load_body<accA>(bodies, refA, A);
     if (F::bodies == 2) load_body<accB>(bodies, refB, B); else load_body<0>(bodies, 0, B);
     if (STAGE == kStageWarmStart) {
-        F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel);
+        F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, NoGate{});
     } else {
-        F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel);
+        F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, NoGate{});
         _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) tb.accum[(size_t)f * stride + i] = a[f];
     }
     store_velocity<accA>(bodies, refA, A);
@@ -365,6 +368,13 @@ __device__ __forceinline__ void load_body_lds(const ClusterShared& sh, int lref,
     } else { b.inertia.t = {0, 0, 0, 0, 0, 0}; b.inertia.invMass = 0; }
 }
 template <int ACCESS>
+__device__ __forceinline__ void load_velocity_lds(const ClusterShared& sh, int lref, DBody& b) {
+    const float4* base = sh.planes + (lref & kRefMask);
+    const int n = sh.ncap;
+    if (ACCESS & kLin) { float4 l = base[2 * n]; b.vel.lin = {l.x, l.y, l.z}; b.linw = l.w; }
+    if (ACCESS & kAng) { float4 a = base[3 * n]; b.vel.ang = {a.x, a.y, a.z}; b.angw = a.w; }
+}
+template <int ACCESS>
 __device__ __forceinline__ void store_velocity_lds(const ClusterShared& sh, int lref, const DBody& b) {
     if ((unsigned)lref >= kDynamicLimit) return;
     float4* base = sh.planes + lref;
@@ -487,13 +497,20 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
         }
         return;
     }
-    wait_predecessors(sh, it, h, k, epoch);
     constexpr int accA = (STAGE == kStageWarmStart) ? F::wsA : F::svA;
     constexpr int accB = (STAGE == kStageWarmStart) ? F::wsB : F::svB;
-    load_body_lds<accA>(sh, ra, A);
-    if (F::bodies == 2) load_body_lds<accB>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
-    if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel);
-    else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel);
+    // Poses and inertias only change in the integration phase (a barrier away): gather them and let the constraint do all its
+    // velocity-independent work (jacobians, effective mass, bias) BEFORE waiting for the predecessors; the gate then waits and
+    // gathers the velocities, so only the corrective-impulse tail of the constraint sits on the cluster's critical path.
+    load_body_lds<accA & ~(kLin | kAng)>(sh, ra, A);
+    if (F::bodies == 2) load_body_lds<accB & ~(kLin | kAng)>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
+    auto gate = [&](BodyVel&, BodyVel&) {
+        wait_predecessors(sh, it, h, k, epoch);
+        load_velocity_lds<accA>(sh, ra, A);
+        if (F::bodies == 2) load_velocity_lds<accB>(sh, rb, B);
+    };
+    if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, gate);
+    else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, gate);
     store_velocity_lds<accA>(sh, active ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references)
     if (F::bodies == 2) store_velocity_lds<accB>(sh, active ? rb : -1, B);
     publish_item(sh.flags + k, sh.batch_done + h.batch, epoch);

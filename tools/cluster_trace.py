@@ -1,0 +1,41 @@
+"""Per-item timeline of the first cluster of the island-per-workgroup schedule (GPU box). Kernel-tuning aid, not part of the product."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+from bepuphysics2_amd.hostlib import HostSimulation
+from bepuphysics2_amd.native import HipSolver
+from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+
+ragdolls = int(os.environ.get("RAGDOLLS", "15000"))
+sim = HostSimulation.scene("ragdoll_tube", ragdolls, 1, 0, 5)
+scene, sd = sim.export(), sim.solve_description()
+cb = PoseIntegratorCallbacks()
+s = HipSolver()
+s.upload(scene)
+for _ in range(2):
+    s.solve(1 / 60, sd, cb)
+s.set_cluster_trace(True)
+s.solve(1 / 60, sd, cb)
+passes = int((1 + sd.iterations()).sum())
+tr = s.cluster_trace(passes)
+names = {0: "C1o", 1: "C2o", 2: "C3o", 3: "C4o", 4: "C1", 5: "C2", 6: "C3", 7: "C4", 22: "Ball", 23: "AHinge", 24: "Swing", 26: "TServo", 27: "TLimit", 30: "AMotor", 46: "Swivel", 47: "Hinge"}
+t_first = int(tr[..., 0][tr[..., 0] > 0].min())
+print(f"items per pass: {tr.shape[1]}, passes: {passes}")
+for p in range(passes):
+    rec = tr[p]
+    st, en = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
+    span = int(en.max() - st.min())
+    busy = int((en - st).sum())
+    print(f"pass {p}: begins at {int(st.min()) - t_first:8d} cyc, span {span:7d} cyc, sum of item times {busy:8d} ({busy / span:.2f} waves busy incl. waits), mean item {busy / len(st):.0f}")
+print(f"frame span (first claim to last publish): {int(tr[..., 1].max()) - t_first} cyc")
+p = int(os.environ.get("PASS", "1"))
+rec = tr[p]
+order = np.argsort(rec[:, 0])
+t0 = rec[:, 0].min()
+print(f"--- pass {p} timeline (cycles from pass start): item batch type wave start dur count")
+for k in order:
+    meta = int(rec[k, 2])
+    print(f"{k:4d} b{(meta >> 16) & 0xFFFF:<3d} {names.get((meta >> 8) & 0xFF, '?'):7s} w{meta & 0xFF} {int(rec[k, 0] - t0):7d} {int(rec[k, 1] - rec[k, 0]):6d} {int(rec[k, 3]):3d}")
