@@ -70,6 +70,48 @@ def cpu_baseline(ragdolls_sample: int, seed: int, target_seconds: float = 12.0):
                       f"oracle C++ restatement -O3 -march=native, reference work-block/barrier threading, best of thread counts {candidates} on {avail} available CPUs"}
 
 
+def measure_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md's HBM section prescribes: separate
+    rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE (they do not fit one pass), counters in KiB, and the gfx950 correction (FETCH_SIZE
+    reports half of a wide coalesced read stream: doubled here; WRITE_SIZE is uncalibrated and reported as is). Returns None when rocprofv3
+    is unavailable or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    out = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="bepu_pmc_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "1", "--ragdolls", str(args.ragdolls), "--no-cpu-baseline", "--no-traffic", "--traffic-child"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            per_kernel = {}
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter:
+                        k = r["Kernel_Name"]
+                        a = per_kernel.setdefault(k, [0.0, 0])
+                        a[0] += float(r["Counter_Value"])
+                        a[1] += 1
+            shutil.rmtree(d, ignore_errors=True)
+            dom = max(per_kernel.items(), key=lambda kv: kv[1][0]) if per_kernel else None
+            if dom is None:
+                return None
+            out[counter] = {"kernel": dom[0][:80], "KiB_per_launch": dom[1][0] / dom[1][1]}
+        fetch = out["FETCH_SIZE"]["KiB_per_launch"] * 1024.0
+        write = out["WRITE_SIZE"]["KiB_per_launch"] * 1024.0
+        return {"bytes_per_launch": 2.0 * fetch + write, "fetch_bytes_raw": fetch, "fetch_bytes_gfx950_corrected": 2.0 * fetch, "write_bytes": write,
+                "kernel": out["FETCH_SIZE"]["kernel"], "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950)"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +120,8 @@ def main():
     ap.add_argument("--ragdolls", type=int, default=15000, help="ragdolls per GPU (15000 ~ 1.005M constraints)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE child runs behind roofline.traffic")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,7 +144,7 @@ def main():
     build.build_all()  # no-op when the in-tree .so files are current
     from bepuphysics2_amd.native import HipSolver
     from bepuphysics2_amd.roofline import INTEGRATE_BYTES_PER_BODY, FINAL_BYTES_PER_BODY, scene_stage_bytes
-    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks, TYPE_TABLE
 
     from bepuphysics2_amd.sharding import rank_seed
     scene, sd = build_scene(args.ragdolls, rank_seed(5, rank))  # each rank: its own independent islands
@@ -133,10 +177,13 @@ def main():
         elapsed = float(t.item())
     finite = bool(np.isfinite(solver.get_bodies(scene.body_count)).all())
 
-    # ---- roofline of the dominant kernel (batch_kernel<Solve>): instrumented pass, HIP events on the solver's own stream ----
+    # ---- roofline of the dominant kernel: instrumented pass, HIP events on the solver's own stream around every launch ----
     roofline = None
     if rank == 0:
         ws_bytes, sv_bytes, inc_bytes = scene_stage_bytes(scene)
+        its = sd.iterations()
+        step_bytes = (sv_bytes * int(its.sum()) + ws_bytes * sd.substep_count + inc_bytes * (sd.substep_count - 1)
+                      + INTEGRATE_BYTES_PER_BODY * scene.body_count * sd.substep_count + FINAL_BYTES_PER_BODY * scene.body_count)
         solver.set_profiling(True)
         prof_steps = max(3, min(10, args.steps))
         agg = {}
@@ -147,24 +194,54 @@ def main():
                 a[0] += ms
                 a[1] += n
         solver.set_profiling(False)
-        its = sd.iterations()
-        solve_passes = int(its.sum()) * prof_steps
-        ws_passes = sd.substep_count * prof_steps
-        fam = {}
-        for name, total_bytes in (("solve", sv_bytes * solve_passes), ("warmstart", ws_bytes * ws_passes)):
-            ms, n = agg[name]
-            fam[name] = {"launches": n, "avg_launch_us": 1e3 * ms / max(n, 1), "algorithmic_bytes_per_launch": total_bytes / max(n, 1),
-                         "achieved_GBs": total_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
-        dom = "solve" if agg["solve"][0] >= agg["warmstart"][0] else "warmstart"
-        roofline = {"bound": "hbm", "kernel": f"batch_kernel<{dom}>", "achieved": fam[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": fam[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
-                    "avg_launch_us": fam[dom]["avg_launch_us"], "launches": fam[dom]["launches"],
-                    "algorithmic_bytes_per_launch": fam[dom]["algorithmic_bytes_per_launch"],
-                    "families_ms_per_step": {k: v[0] / prof_steps for k, v in agg.items()}, "other": fam["warmstart" if dom == "solve" else "solve"],
-                    # whole-step view: all algorithmic bytes of a step / step time
-                    "step_algorithmic_GBs": (sv_bytes * int(its.sum()) + ws_bytes * sd.substep_count + inc_bytes * (sd.substep_count - 1)
-                                             + INTEGRATE_BYTES_PER_BODY * scene.body_count * sd.substep_count + FINAL_BYTES_PER_BODY * scene.body_count)
-                                            / (elapsed / args.steps) / 1e9}
+        families = {k: v[0] / prof_steps for k, v in agg.items()}
+        step_gbs = step_bytes / (elapsed / args.steps) / 1e9
+        if agg.get("cluster", [0.0, 0])[1] > 0:
+            # Island-per-workgroup schedule: ONE launch runs every stage of every substep, so the units one launch processes are all
+            # constraint-iterations of the step and its algorithmic bytes are the whole step's (SURVEY.md 8d figure x units).
+            ms, n = agg["cluster"]
+            avg_us = 1e3 * ms / n
+            achieved = step_bytes / (avg_us * 1e-6) / 1e9
+            cyc = solver.cluster_cycles()
+            # what the launch really has to move through HBM/MALL: every body in and out once, the constraint stream once per pass
+            stream_bytes = 2 * 128 * scene.body_count
+            for batch in scene.batches:
+                for tb in batch:
+                    _, pf, imf, _name = TYPE_TABLE[tb.type_id]
+                    nb = TYPE_TABLE[tb.type_id][0]
+                    reads = (nb + pf + imf) * 4 * (sd.substep_count + int(its.sum()))
+                    writes = imf * 4 * int(its.sum())
+                    if _name.startswith("Contact"):
+                        reads += (nb + pf) * 4 * (sd.substep_count - 1)
+                        writes += int(_name[7]) * 4 * (sd.substep_count - 1)
+                    stream_bytes += (reads + writes) * tb.count
+            roofline = {"bound": "hbm", "kernel": "cluster_kernel (whole substep loop of a step in one launch)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_us, "launches": n,
+                        "algorithmic_bytes_per_launch": step_bytes,
+                        "note": "algorithmic bytes count every body gather/scatter of every constraint (SURVEY 8d); the kernel keeps bodies in LDS, so frac may exceed "
+                                "what HBM could deliver; memory_stream_* is what the launch actually has to move",
+                        "memory_stream_bytes_per_launch": stream_bytes, "memory_stream_GBs": stream_bytes / (avg_us * 1e-6) / 1e9,
+                        "memory_stream_frac_of_peak": stream_bytes / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "cluster_shader_kcycles_mean_max": [float(cyc.mean()) / 1e3, float(cyc.max()) / 1e3] if cyc.size else None,
+                        "effective_shader_GHz": float(cyc.max()) / (avg_us * 1e3) if cyc.size else None,
+                        "families_ms_per_step": families, "step_algorithmic_GBs": step_gbs}
+        else:
+            solve_passes = int(its.sum()) * prof_steps
+            ws_passes = sd.substep_count * prof_steps
+            fam = {}
+            for name, total_bytes in (("solve", sv_bytes * solve_passes), ("warmstart", ws_bytes * ws_passes)):
+                ms, n = agg[name]
+                fam[name] = {"launches": n, "avg_launch_us": 1e3 * ms / max(n, 1), "algorithmic_bytes_per_launch": total_bytes / max(n, 1),
+                             "achieved_GBs": total_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
+            dom = "solve" if agg["solve"][0] >= agg["warmstart"][0] else "warmstart"
+            roofline = {"bound": "hbm", "kernel": f"batch_kernel<{dom}>", "achieved": fam[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": fam[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_us": fam[dom]["avg_launch_us"], "launches": fam[dom]["launches"],
+                        "algorithmic_bytes_per_launch": fam[dom]["algorithmic_bytes_per_launch"],
+                        "families_ms_per_step": families, "other": fam["warmstart" if dom == "solve" else "solve"],
+                        "step_algorithmic_GBs": step_gbs}
+        if roofline is not None and not args.no_traffic:
+            roofline["traffic"] = measure_traffic(args)
 
     baseline = None
     if rank == 0 and not args.no_cpu_baseline:

@@ -280,7 +280,7 @@ struct Contact {
             angularA[i] = cross(oA, n);
             angularB[i] = TwoBody ? cross(n, oB) : V3{0, 0, 0};
         }
-        gate(vA, vB);
+        BD_GATE(vA, vB, j, angularA, angularB);
         tangentApply(j, iA, iB, V2{a[0], a[1]}, vA, vB);
         _Pragma("unroll") for (int i = 0; i < N; ++i) penApply(iA, iB, n, angularA[i], angularB[i], a[2 + i], vA, vB);
         twistApply(n, iA, iB, a[2 + N], vA, vB);
@@ -304,7 +304,7 @@ struct Contact {
         float twistMass = twistEffectiveMass(n, iA, iB);
         float leverArm[N];
         if (N > 1) { _Pragma("unroll") for (int i = 0; i < N; ++i) leverArm[i] = distance(centerA, offsetA(p, i)); }
-        gate(vA, vB);
+        BD_GATE(vA, vB, rows, tangentSetupData, twistMass, leverArm, premultipliedFrictionCoefficient, softnessImpulseScale);
         _Pragma("unroll") for (int i = 0; i < N; ++i) penIterate(rows[i], iA, iB, n, softnessImpulseScale, a[2 + i], vA, vB);
         float penSum = a[2];
         _Pragma("unroll") for (int i = 1; i < N; ++i) penSum = penSum + a[2 + i];
@@ -373,7 +373,7 @@ struct BallSocket {
     template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :68-74
         V3 offsetA = transform(V3{p[0], p[1], p[2]}, oA);
         V3 offsetB = transform(V3{p[3], p[4], p[5]}, oB);
-        gate(vA, vB);
+        BD_GATE(vA, vB, offsetA, offsetB);
         BallSocketShared::applyImpulse(vA, vB, offsetA, offsetB, iA, iB, V3{a[0], a[1], a[2]});
     }
     template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :76-91
@@ -386,7 +386,7 @@ struct BallSocket {
         V3 anchorB = add(ab, offsetB);
         V3 error = sub(anchorB, offsetA);
         V3 biasVelocity = scale(error, posErrToVel);
-        gate(vA, vB);
+        BD_GATE(vA, vB, offsetA, offsetB, effectiveMass, biasVelocity, softnessImpulseScale);
         // BallSocketShared.Solve :101-108
         V3 acc{a[0], a[1], a[2]};
         V3 correctiveImpulse = BallSocketShared::computeCorrectiveImpulse(vA, vB, offsetA, offsetB, biasVelocity, effectiveMass, softnessImpulseScale, acc);
@@ -453,7 +453,7 @@ struct AngularHinge {
         computeJacobians(V3{p[0], p[1], p[2]}, oA, hingeAxisA, jacobianA);
         M23 impulseToVelocityA = multiply(jacobianA, iA.t);
         M23 negatedImpulseToVelocityB = multiply(jacobianA, iB.t);
-        gate(vA, vB);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB);
         applyImpulse(impulseToVelocityA, negatedImpulseToVelocityB, V2{a[0], a[1]}, vA.ang, vB.ang);
     }
     template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :140-217
@@ -471,7 +471,7 @@ struct AngularHinge {
         V2 errorAngle = getErrorAngles(hingeAxisA, hingeAxisB, jacobianA);
         V2 biasVelocity = scale(errorAngle, -posErrToVel);
         V2 biasImpulse = transform(biasVelocity, effectiveMass);
-        gate(vA, vB);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB, jacobianA, effectiveMass, biasImpulse, effMassCFMScale, softnessImpulseScale);
         V3 difference = sub(vA.ang, vB.ang);
         V2 csv = transformByTranspose(difference, jacobianA);
         V2 csi = transform(csv, effectiveMass);
@@ -521,7 +521,7 @@ struct SwingLimit {
         computeJacobian(V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, oA, oB, axisA, axisB, jacobianA);
         V3 impulseToVelocityA = transform(jacobianA, iA.t);
         V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
-        gate(vA, vB);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB);
         applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
     }
     template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :122-163
@@ -537,7 +537,7 @@ struct SwingLimit {
         float axisDot = dot(axisA, axisB);
         float error = axisDot - p[6];
         float biasVelocity = -vmin(error * inverseDt, error * posErrToVel);
-        gate(vA, vB);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB, jacobianA, effectiveMass, biasVelocity, softnessImpulseScale);
         V3 difference = sub(vA.ang, vB.ang);
         float csv = dot(difference, jacobianA);
         float csi = effectiveMass * (biasVelocity - csv) - a[0] * softnessImpulseScale;
@@ -604,7 +604,7 @@ struct TwistServo {
         TwistShared::computeJacobianOnly(oA, oB, Q{p[0], p[1], p[2], p[3]}, Q{p[4], p[5], p[6], p[7]}, jacobianA);
         V3 impulseToVelocityA = transform(jacobianA, iA.t);
         V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
-        gate(vA, vB);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB);
         applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
     }
     template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :192-222
@@ -625,7 +625,7 @@ struct TwistServo {
                                         vmin(maximumSpeed, vmax(baseSpeed, biasVelocity)));
         float maximumImpulse = maximumForce * dt;
         float biasImpulse = clampedBiasVelocity * effectiveMass;
-        gate(vA, vB);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB, velocityToImpulseA, biasImpulse, softnessImpulseScale, maximumImpulse);
         V3 netVelocity = sub(vA.ang, vB.ang);
         float csiVelocityComponent = dot(netVelocity, velocityToImpulseA);
         float csi = biasImpulse - a[0] * softnessImpulseScale - csiVelocityComponent;
@@ -656,7 +656,7 @@ struct TwistLimit {
         computeJacobian(oA, oB, Q{p[0], p[1], p[2], p[3]}, Q{p[4], p[5], p[6], p[7]}, p[8], p[9], error, jacobianA);
         V3 impulseToVelocityA = transform(jacobianA, iA.t);
         V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
-        gate(vA, vB);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB);
         applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
     }
     template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :112-131
@@ -668,7 +668,7 @@ struct TwistLimit {
                                           posErrToVel, softnessImpulseScale, effectiveMass, velocityToImpulseA);
         float biasVelocity = sel(error < 0.0f, error * inverseDt, error * posErrToVel);
         float biasImpulse = biasVelocity * effectiveMass;
-        gate(vA, vB);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB, velocityToImpulseA, biasImpulse, softnessImpulseScale);
         V3 netVelocity = sub(vA.ang, vB.ang);
         float csiVelocityComponent = dot(netVelocity, velocityToImpulseA);
         float csi = biasImpulse - a[0] * softnessImpulseScale - csiVelocityComponent;
@@ -706,7 +706,7 @@ struct AngularMotor {
         Sym3 unsoftenedInverseEffectiveMass = add(iA.t, iB.t);
         Sym3 unsoftenedEffectiveMass = invert(unsoftenedInverseEffectiveMass);
         V3 biasVelocity = transform(V3{p[0], p[1], p[2]}, oA);
-        gate(vA, vB);
+        BD_GATE(vA, vB, unsoftenedEffectiveMass, biasVelocity, effectiveMassCFMScale, softnessImpulseScale, maximumImpulse);
         V3 csv = sub(vA.ang, vB.ang);
         csv = sub(biasVelocity, csv);
         V3 csi = transform(csv, unsoftenedEffectiveMass);
@@ -766,7 +766,7 @@ struct SwivelHinge {
     template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :124-129
         V3 swivelAxis, hingeAxis, offsetA, offsetB, jac;
         computeJacobian(p, oA, oB, swivelAxis, hingeAxis, offsetA, offsetB, jac);
-        gate(vA, vB);
+        BD_GATE(vA, vB, offsetA, offsetB, jac);
         applyImpulse(offsetA, offsetB, jac, iA, iB, V4{a[0], a[1], a[2], a[3]}, vA, vB);
     }
     template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :131-208
@@ -802,7 +802,7 @@ struct SwivelHinge {
         biasVelocity.z = ballSocketError.z * posErrToVel;
         float error = dot(hingeAxis, swivelAxis);
         biasVelocity.w = posErrToVel * -error;
-        gate(vA, vB);
+        BD_GATE(vA, vB, offsetA, offsetB, jac, effectiveMass, biasVelocity, effMassCFMScale, softnessImpulseScale);
         V3 ballSocketAngularCSVA = cross(vA.ang, offsetA);
         float swivelHingeCSVA = dot(jac, vA.ang);
         V3 ballSocketAngularCSVB = cross(offsetB, vB.ang);
@@ -858,7 +858,7 @@ struct Hinge {
         M23 hingeJacobian;
         hingeJacobian.X = transform(localAX, orientationMatrixA);
         hingeJacobian.Y = transform(localAY, orientationMatrixA);
-        gate(vA, vB);
+        BD_GATE(vA, vB, offsetA, offsetB, hingeJacobian);
         applyImpulse(offsetA, offsetB, hingeJacobian, iA, iB, V3{a[0], a[1], a[2]}, V2{a[3], a[4]}, vA, vB);
     }
     template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :124-216
@@ -900,7 +900,7 @@ struct Hinge {
         V3 ballSocketBiasVelocity = scale(ballSocketError, posErrToVel);
         V2 errorAngles = AngularHinge::getErrorAngles(hingeAxisA, hingeAxisB, hingeJacobian);
         V2 hingeBiasVelocity = scale(errorAngles, -posErrToVel);
-        gate(vA, vB);
+        BD_GATE(vA, vB, offsetA, offsetB, hingeJacobian, effectiveMass, ballSocketBiasVelocity, hingeBiasVelocity, effMassCFMScale, softnessImpulseScale);
         V3 ballSocketAngularCSVA = cross(vA.ang, offsetA);
         V2 hingeCSVA = transformByTranspose(vA.ang, hingeJacobian);
         V3 ballSocketAngularCSVB = cross(offsetB, vB.ang);

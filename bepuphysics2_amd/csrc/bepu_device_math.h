@@ -3,12 +3,35 @@
 // each function so results are bit-identical to an IEEE evaluation of the C# (no FMA contraction: this translation
 // unit is compiled with -ffp-contract=off and correctly rounded fp32 divide/sqrt).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #pragma clang fp contract(off)
 #define BD_FN __device__ __forceinline__ static
 
 
 namespace bd {
+
+// pin(values...): an empty asm that "rewrites" every 32-bit word of its arguments in place. Everything the values depend on has to be
+// computed before this point and nothing that uses them can be scheduled above it, so work placed before a gate (see the constraint
+// functions) cannot be sunk past the gate's wait loop by the optimizer.
+template <class T>
+BD_FN void pin_one(T& t) {
+    static_assert(sizeof(T) % 4 == 0, "pin works on 32-bit words");
+    float* f = reinterpret_cast<float*>(&t);
+    _Pragma("unroll") for (int i = 0; i < (int)(sizeof(T) / 4); ++i) asm volatile("" : "+v"(f[i]));
+}
+template <class... Ts>
+BD_FN void pin(Ts&... ts) { (pin_one(ts), ...); }
+// BD_GATE: pass the gate; gates that wait (G::kPin) first pin the listed velocity-independent values.
+#ifndef BEPU_PIN_ENABLED
+#define BEPU_PIN_ENABLED 1
+#endif
+#define BD_GATE(vA, vB, ...)                                                         \
+    do {                                                                             \
+        if constexpr (std::remove_reference_t<G>::kPin && BEPU_PIN_ENABLED) pin(__VA_ARGS__); \
+        gate(vA, vB);                                                                \
+    } while (0)
+
 
 // Vector.Min/Max lower to minps/maxps on the reference's AVX2 hosts: "a<b?a:b" / "a>b?a:b"
 // (second operand returned on NaN) — SURVEY.md A.11.

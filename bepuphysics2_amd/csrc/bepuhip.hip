@@ -105,7 +105,10 @@ __device__ __forceinline__ void store_velocity(float4* bodies, int ref, const DB
 enum { kStageWarmStart = 0, kStageSolve = 1, kStageIncremental = 2 };
 // The constraint functions call their gate once, right before the first use of the bodies' velocities (everything before it depends on
 // poses, inertias and prestep data only). The launch-per-batch kernels have the velocities in registers already.
-struct NoGate { __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {} };
+struct NoGate {
+    static constexpr bool kPin = false;
+    __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {}
+};
 
 template <class F, int STAGE>
 __device__ __forceinline__ void run_constraint(const DevTypeBatch& tb, int i, float4* bodies, float dt, float inv_dt) {
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
 // "same joint of consecutive ragdolls" access pattern (lane stride = island size) spreads over all 16 bank slots of ds_read_b128.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPlanes = 8;
-constexpr int kClusterThreads = 512;
+constexpr int kClusterThreads = 1024;
 
 typedef __attribute__((address_space(1))) float gfloat;  // global
 typedef __attribute__((address_space(1))) int gint;
@@ -384,7 +387,7 @@ __device__ __forceinline__ void store_velocity_lds(const ClusterShared& sh, int 
 
 
 struct ItemHeader {  // wave-uniform copy of the fields the constraint code needs (SGPRs)
-    int type_id, count, stride, start, batch, npred, overflow;
+    int type_id, count, stride, start, batch, npred, overflow, bodies, pf, imf;
     unsigned lrefs_off, prestep_off, accum_off;
 };
 
@@ -399,6 +402,9 @@ __device__ __forceinline__ ItemHeader read_item(const ClusterItem* it) {
     h.accum_off = __builtin_amdgcn_readfirstlane(it->accum_off);
     const int packed = __builtin_amdgcn_readfirstlane(it->batch_npred);
     h.batch = packed & 0xFFFF; h.npred = (packed >> 16) & 0xFF; h.overflow = (packed >> 24) & 0xFF;
+    h.bodies = __builtin_amdgcn_readfirstlane(it->bodies);
+    h.pf = __builtin_amdgcn_readfirstlane(it->pf);
+    h.imf = __builtin_amdgcn_readfirstlane(it->imf);
     return h;
 }
 
@@ -470,9 +476,26 @@ __device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const
     asm volatile("" ::: "memory");  // nothing below may be hoisted above the polls
 }
 
-template <class F, int STAGE>
+struct ItemStamps { unsigned long long loaded, pre_gate, post_gate; };
+
+// The gate the cluster path hands to the constraint functions: wait for the item's predecessors, then gather the velocities.
+template <int ACC_A, int ACC_B, int BODIES, bool TRACE>
+struct ClusterGate {
+    static constexpr bool kPin = true;  // the constraint pins its velocity-independent values before calling: they are computed while the predecessors still run
+    const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; int ra, rb; DBody& A; DBody& B; ItemStamps& stamps;
+    __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {
+        if (TRACE) stamps.pre_gate = __builtin_readcyclecounter();
+        wait_predecessors(sh, it, h, k, epoch);
+        if (TRACE) stamps.post_gate = __builtin_readcyclecounter();
+        load_velocity_lds<ACC_A>(sh, ra, A);
+        if (BODIES == 2) load_velocity_lds<ACC_B>(sh, rb, B);
+    }
+};
+
+
+template <class F, int STAGE, bool TRACE>
 __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
-                                                       unsigned* __restrict__ slab, float dt, float inv_dt) {
+                                                       unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
     // Lanes beyond the item's count mirror its last constraint and never store: the whole body runs with a full exec mask,
     // which keeps the control flow around the (wave-uniform) waits trivially structured.
     const bool active = lane < h.count;
@@ -482,7 +505,7 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     gfloat* accum = (gfloat*)(slab + h.accum_off);
     float p[F::prestepFloats];
     float a[F::impulseFloats];
-    // issue the item's global loads first: their latency hides under the wait for the predecessors
+    // issue the item's global loads first: their latency hides under the velocity-independent work and the wait for the predecessors
     const int ra = lrefs[i];
     const int rb = (F::bodies == 2) ? lrefs[stride + i] : -1;
     _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
@@ -504,11 +527,8 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     // gathers the velocities, so only the corrective-impulse tail of the constraint sits on the cluster's critical path.
     load_body_lds<accA & ~(kLin | kAng)>(sh, ra, A);
     if (F::bodies == 2) load_body_lds<accB & ~(kLin | kAng)>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
-    auto gate = [&](BodyVel&, BodyVel&) {
-        wait_predecessors(sh, it, h, k, epoch);
-        load_velocity_lds<accA>(sh, ra, A);
-        if (F::bodies == 2) load_velocity_lds<accB>(sh, rb, B);
-    };
+    if (TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps.loaded = __builtin_readcyclecounter(); }
+    ClusterGate<accA, accB, F::bodies, TRACE> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps};
     if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, gate);
     else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, gate);
     store_velocity_lds<accA>(sh, active ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references)
@@ -522,10 +542,10 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
 using DC1O = Contact<1, false>; using DC2O = Contact<2, false>; using DC3O = Contact<3, false>; using DC4O = Contact<4, false>;
 using DC1T = Contact<1, true>; using DC2T = Contact<2, true>; using DC3T = Contact<3, true>; using DC4T = Contact<4, true>;
 
-template <int STAGE>
+template <int STAGE, bool TRACE>
 __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
-                                                 unsigned* __restrict__ slab, float dt, float inv_dt) {
-#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt); break;
+                                                 unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
+#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps); break;
     switch (h.type_id) {
         BEPU_CASE(kContact1OneBody, DC1O) BEPU_CASE(kContact2OneBody, DC2O) BEPU_CASE(kContact3OneBody, DC3O) BEPU_CASE(kContact4OneBody, DC4O)
         BEPU_CASE(kContact1, DC1T) BEPU_CASE(kContact2, DC2T) BEPU_CASE(kContact3, DC3T) BEPU_CASE(kContact4, DC4T)
@@ -548,27 +568,29 @@ template <int STAGE, bool TRACE>
 __device__ __forceinline__ void run_cluster_pass(const ClusterShared& sh, int item_count, int lane, int wave, unsigned epoch, unsigned claim_base,
                                                  unsigned* __restrict__ slab, float dt, float inv_dt, unsigned long long* trace) {
     for (;;) {
-        const unsigned g = claim_next(sh.counter);
-        const int k = (int)(g - claim_base);
+        const int k = (int)(claim_next(sh.counter) - claim_base);
         if (k >= item_count) break;
         const ClusterItem* it = sh.items + k;
         const ItemHeader h = read_item(it);
         unsigned long long t0 = 0;
         if (TRACE) t0 = __builtin_readcyclecounter();
-        run_cluster_item<STAGE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt);
+        ItemStamps stamps = {0, 0, 0};
+        run_cluster_item<STAGE, TRACE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps);
         if (TRACE && trace && blockIdx.x == 0 && lane == 0) {
-            unsigned long long* rec = trace + ((size_t)(epoch - 1) * item_count + k) * 4;
+            unsigned long long* rec = trace + ((size_t)(epoch - 1) * item_count + k) * 8;
+            rec[4] = stamps.loaded; rec[5] = stamps.pre_gate; rec[6] = stamps.post_gate; rec[7] = 0;
             rec[0] = t0; rec[1] = __builtin_readcyclecounter(); rec[2] = (unsigned long long)wave | ((unsigned long long)h.type_id << 8) | ((unsigned long long)h.batch << 16) | ((unsigned long long)STAGE << 32);
             rec[3] = (unsigned long long)h.count;
         }
     }
 }
 
-template <bool TRACE>
-__global__ __launch_bounds__(kClusterThreads) void cluster_kernel(const ClusterDesc* __restrict__ clusters, const ClusterItem* __restrict__ items,
+template <int THREADS, bool TRACE>
+__global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __restrict__ clusters, const ClusterItem* __restrict__ items,
                                                                    const int* __restrict__ batch_item_begin, const int* __restrict__ cluster_bodies,
                                                                    float4* bodies, unsigned* __restrict__ slab, ClusterParams cp, int ncap, int max_items,
-                                                                   unsigned long long* trace, unsigned* status) {
+                                                                   unsigned long long* trace, unsigned* status, unsigned long long* cycles) {
+    const unsigned long long kernel_t0 = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
     ClusterShared sh;
     sh.planes = lds;
@@ -609,7 +631,8 @@ __global__ __launch_bounds__(kClusterThreads) void cluster_kernel(const ClusterD
                 const ClusterItem* it = sh.items + k;
                 const ItemHeader h = read_item(it);
                 if (h.type_id > kContact4) continue;
-                run_cluster_item<kStageIncremental>(sh, it, h, k, lane, 0u, slab, dt, inv_dt);
+                ItemStamps stamps = {0, 0, 0};
+                run_cluster_item<kStageIncremental, false>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
             }
             __syncthreads();
         }
@@ -675,6 +698,7 @@ __global__ __launch_bounds__(kClusterThreads) void cluster_kernel(const ClusterD
         gb[6] = r[6 * ncap];
         gb[7] = r[7 * ncap];
     }
+    if (tid == 0) cycles[blockIdx.x] = __builtin_readcyclecounter() - kernel_t0;  // shader clocks this cluster took: a clock-frequency-independent measure
 }
 
 }  // namespace
@@ -762,6 +786,7 @@ struct bepuhip_ctx {
     bool clusters_enabled = false;
     int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0;
     ClusterDesc first_cluster = {0, 0, 0, 0, 0};
+    unsigned long long* d_cycles = nullptr;  // per cluster: shader clocks of the last cluster_kernel launch
     unsigned* d_status = nullptr;  // cluster schedule watchdog words (see report_stall)
     unsigned long long* d_trace = nullptr;  // optional per-item timeline of cluster 0 (diagnostics)
     size_t trace_words = 0;
@@ -797,6 +822,8 @@ static void free_constraints(bepuhip_ctx* c) {
     if (c->d_kinlist) hipFree(c->d_kinlist);
     if (c->d_trace) hipFree(c->d_trace);
     c->d_trace = nullptr; c->trace_words = 0;
+    if (c->d_cycles) hipFree(c->d_cycles);
+    c->d_cycles = nullptr;
     c->d_clusters = nullptr; c->d_items = nullptr; c->d_batch_item_begin = nullptr; c->d_cluster_bodies = nullptr;
     c->d_clustered_dynamic = nullptr; c->d_kinlist = nullptr;
     c->clusters_enabled = false; c->cluster_count = 0; c->clustered_dynamic_count = 0; c->kinlist_count = 0;
@@ -1251,6 +1278,8 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
     if (plan.enabled) {
         c->cluster_count = (int)plan.clusters.size();
         c->cluster_max_slots = plan.max_slots;
+        HIP_TRY(hipMalloc((void**)&c->d_cycles, plan.clusters.size() * 8));
+        HIP_TRY(hipMemset(c->d_cycles, 0, plan.clusters.size() * 8));
         c->first_cluster = plan.clusters[0];
         c->cluster_max_items = plan.max_items;
         for (auto& it : plan.items) {  // resolve the items' slab offsets now that the slab layout exists
@@ -1265,8 +1294,9 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
         HIP_TRY(upload_ints(plan.batch_item_begin.data(), plan.batch_item_begin.size() * 4, (void**)&c->d_batch_item_begin));
         HIP_TRY(upload_ints(plan.cluster_bodies.data(), plan.cluster_bodies.size() * 4, (void**)&c->d_cluster_bodies));
         HIP_TRY(upload_ints(plan.clustered_dynamic.data(), plan.clustered_dynamic.size() * 4, (void**)&c->d_clustered_dynamic));
-        HIP_TRY(hipFuncSetAttribute((const void*)cluster_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)cluster_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        for (const void* fn : {(const void*)cluster_kernel<512, false>, (const void*)cluster_kernel<512, true>, (const void*)cluster_kernel<768, false>, (const void*)cluster_kernel<768, true>,
+                               (const void*)cluster_kernel<1024, false>, (const void*)cluster_kernel<1024, true>})
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
     }
     c->built = true;
     return rebuild_flags(c);
@@ -1331,13 +1361,16 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
         cp.sp = sp;
         {
             Timed t(c, 5);
-            const int threads = std::min(kClusterThreads, std::max(64, env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads) / 64 * 64));
-            if (c->d_trace)
-                hipLaunchKernelGGL(cluster_kernel<true>, dim3(c->cluster_count), dim3(threads), lds_bytes, c->stream, (const ClusterDesc*)c->d_clusters, (const ClusterItem*)c->d_items,
-                                   (const int*)c->d_batch_item_begin, (const int*)c->d_cluster_bodies, c->d_bodies, (unsigned*)c->d_slab, cp, c->cluster_max_slots, c->cluster_max_items, c->d_trace, c->d_status);
-            else
-                hipLaunchKernelGGL(cluster_kernel<false>, dim3(c->cluster_count), dim3(threads), lds_bytes, c->stream, (const ClusterDesc*)c->d_clusters, (const ClusterItem*)c->d_items,
-                                   (const int*)c->d_batch_item_begin, (const int*)c->d_cluster_bodies, c->d_bodies, (unsigned*)c->d_slab, cp, c->cluster_max_slots, c->cluster_max_items, (unsigned long long*)nullptr, c->d_status);
+            // Waves per cluster: 16 by default (four per SIMD; 12 is as fast when memory latency is low, 8 is slower everywhere); BEPUHIP_CLUSTER_THREADS selects 512 / 768 / 1024.
+            const int req = env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
+            const int threads = req >= 1024 ? 1024 : req >= 768 ? 768 : std::max(64, std::min(512, req / 64 * 64));
+            void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
+                            (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles};
+            const bool tr = c->d_trace != nullptr;
+            const void* fn = threads == 1024 ? (tr ? (const void*)cluster_kernel<1024, true> : (const void*)cluster_kernel<1024, false>)
+                             : threads == 768 ? (tr ? (const void*)cluster_kernel<768, true> : (const void*)cluster_kernel<768, false>)
+                                              : (tr ? (const void*)cluster_kernel<512, true> : (const void*)cluster_kernel<512, false>);
+            hipLaunchKernel(fn, dim3(c->cluster_count), dim3(threads), args, lds_bytes, c->stream);
         }
         if (c->kinlist_count > 0) {
             Timed t(c, 1);
@@ -1525,7 +1558,7 @@ int32_t bepuhip_set_cluster_trace(bepuhip_ctx* c, int32_t enabled) {
     if (c->d_trace) { hipFree(c->d_trace); c->d_trace = nullptr; c->trace_words = 0; }
     if (enabled && c->clusters_enabled) {
         const ClusterDesc first = c->first_cluster;
-        c->trace_words = (size_t)first.item_count * 4 * (size_t)kMaxClusterSubsteps * 8;  // up to 128 passes of cluster 0
+        c->trace_words = (size_t)first.item_count * 8 * (size_t)kMaxClusterSubsteps * 8;  // up to 128 passes of cluster 0
         HIP_TRY(hipMalloc((void**)&c->d_trace, c->trace_words * 8));
         HIP_TRY(hipMemset(c->d_trace, 0, c->trace_words * 8));
     }
@@ -1539,6 +1572,15 @@ int32_t bepuhip_get_cluster_trace(bepuhip_ctx* c, uint64_t* out, int64_t capacit
     const size_t n = std::min<size_t>(c->trace_words, (size_t)std::max<int64_t>(capacity_words, 0));
     HIP_TRY(hipMemcpy(out, c->d_trace, n * 8, hipMemcpyDeviceToHost));
     *items_out = c->first_cluster.item_count;
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_get_cluster_cycles(bepuhip_ctx* c, uint64_t* out, int32_t capacity, int32_t* count_out) {
+    if (!c || !count_out || (capacity > 0 && !out)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    *count_out = c->clusters_enabled ? c->cluster_count : 0;
+    if (!c->clusters_enabled || capacity <= 0) return BEPUHIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->d_cycles, (size_t)std::min(capacity, c->cluster_count) * 8, hipMemcpyDeviceToHost));
     return BEPUHIP_OK;
 }
 int32_t bepuhip_debug_status(bepuhip_ctx* c, uint32_t* out16) {

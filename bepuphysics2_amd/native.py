@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_get_bodies", "bepuhip_get_accumulated_impulses", "bepuhip_get_prestep", "bepuhip_get_constrained_flags",
     "bepuhip_last_solve_ms", "bepuhip_set_profiling", "bepuhip_get_profile", "bepuhip_last_constraint_iterations",
     "bepuhip_get_stream", "bepuhip_solve_async", "bepuhip_sync", "bepuhip_reset_state", "bepuhip_type_info",
-    "bepuhip_set_cluster_trace", "bepuhip_get_cluster_trace",
+    "bepuhip_set_cluster_trace", "bepuhip_get_cluster_trace", "bepuhip_get_cluster_cycles", "bepuhip_debug_status",
 ]
 
 
@@ -89,6 +89,8 @@ def load_library() -> C.CDLL:
     lib.bepuhip_get_stream.argtypes = [vp, C.POINTER(vp)]
     lib.bepuhip_reset_state.argtypes = [vp]
     lib.bepuhip_set_cluster_trace.argtypes = [vp, i32]
+    lib.bepuhip_get_cluster_cycles.argtypes = [vp, vp, i32, C.POINTER(i32)]
+    lib.bepuhip_debug_status.argtypes = [vp, vp]
     lib.bepuhip_get_cluster_trace.argtypes = [vp, vp, C.c_int64, C.POINTER(i32)]
     lib.bepuhip_type_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     for name in EXPORTED_SYMBOLS:
@@ -225,17 +227,26 @@ class HipSolver:
             out[name] = (float(ms.value), int(n.value))
         return out
 
+    def cluster_cycles(self) -> np.ndarray:
+        """Shader clocks per cluster of the last solve (empty when the launch-per-batch schedule ran)."""
+        n = C.c_int32()
+        _check(self.lib, self.lib.bepuhip_get_cluster_cycles(self.ctx, None, 0, C.byref(n)))
+        out = np.zeros(max(int(n.value), 0), dtype=np.uint64)
+        if out.size:
+            _check(self.lib, self.lib.bepuhip_get_cluster_cycles(self.ctx, _ptr(out), out.size, C.byref(n)))
+        return out
+
     def set_cluster_trace(self, enabled: bool):
         _check(self.lib, self.lib.bepuhip_set_cluster_trace(self.ctx, int(enabled)))
 
     def cluster_trace(self, passes: int) -> np.ndarray:
-        """(passes, items, 4) uint64 records of the first cluster: claim clock, publish clock, wave|type<<8|batch<<16|stage<<32, count."""
+        """(passes, items, 8) uint64 records of the first cluster: claim clock, publish clock, wave|type<<8|batch<<16|stage<<32, count, loads landed, before wait, after wait, 0."""
         cap = 1 << 22
         buf = np.zeros(cap, dtype=np.uint64)
         items = C.c_int32()
         _check(self.lib, self.lib.bepuhip_get_cluster_trace(self.ctx, _ptr(buf), cap, C.byref(items)))
         n = int(items.value)
-        return buf[: passes * n * 4].reshape(passes, n, 4)
+        return buf[: passes * n * 8].reshape(passes, n, 8)
 
     def stream_handle(self) -> int:
         v = C.c_void_p()

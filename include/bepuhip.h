@@ -96,11 +96,17 @@ int32_t bepuhip_last_solve_ms(bepuhip_ctx* ctx, float* ms_out);
 int32_t bepuhip_set_profiling(bepuhip_ctx* ctx, int32_t enabled);
 int32_t bepuhip_get_profile(bepuhip_ctx* ctx, int32_t family /*0 incremental,1 integrate,2 warmstart,3 solve,4 final,5 cluster (whole substep loop in one launch)*/, float* ms_out, int32_t* launches_out);
 /* Per-work-item timeline of the FIRST cluster of the island-per-workgroup schedule (kernel tuning aid). After enabling, every solve
- * records, for pass p (0-based: warm start / velocity iteration sweeps in execution order) and work item k, four 64-bit words at
- * [(p * items + k) * 4]: {shader clock when the item was claimed, shader clock when it was published, wave | type_id << 8 | batch << 16 |
- * stage << 32, constraint count}. get returns `items` so that the caller can index the records. STATE if the scene runs the launch-per-batch schedule. */
+ * records, for pass p (0-based: warm start / velocity iteration sweeps in execution order) and work item k, eight 64-bit words at
+ * [(p * items + k) * 8]: {shader clock when the item was claimed, shader clock when it was published, wave | type_id << 8 | batch << 16 |
+ * stage << 32, constraint count, clock when its global loads had landed, clock before / after the wait for its predecessors, 0}. get returns `items` so that the caller can index the records. STATE if the scene runs the launch-per-batch schedule. */
 int32_t bepuhip_set_cluster_trace(bepuhip_ctx* ctx, int32_t enabled);
 int32_t bepuhip_get_cluster_trace(bepuhip_ctx* ctx, uint64_t* words_out, int64_t capacity_words, int32_t* items_out);
+/* Shader clocks each workgroup of the island-per-workgroup schedule spent in the last solve (one entry per cluster; count_out = 0 when the
+ * scene runs the launch-per-batch schedule). Independent of the clock frequency the GPU happened to run at. */
+int32_t bepuhip_get_cluster_cycles(bepuhip_ctx* ctx, uint64_t* cycles_out, int32_t capacity, int32_t* count_out);
+/* Watchdog / progress words of the island-per-workgroup schedule (16 x uint32, host-visible while a solve is running). word 0 != 0: a bounded
+ * wait gave up (reported by bepuhip_sync as DEVICE error). */
+int32_t bepuhip_debug_status(bepuhip_ctx* ctx, uint32_t* words16_out);
 /* Constraint-iterations executed by the last solve: sum over substeps of constraints * (1 + velocity_iterations[s]). */
 int32_t bepuhip_last_constraint_iterations(bepuhip_ctx* ctx, int64_t* out);
 /* The native HIP stream handle (hipStream_t) the context launches on, for callers that time with their own HIP events. */

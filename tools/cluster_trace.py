@@ -35,7 +35,7 @@ p = int(os.environ.get("PASS", "1"))
 rec = tr[p]
 order = np.argsort(rec[:, 0])
 t0 = rec[:, 0].min()
-print(f"--- pass {p} timeline (cycles from pass start): item batch type wave start dur count")
+print(f"--- pass {p} timeline (cycles from pass start): item batch type wave start dur count | loads setup wait tail")
 for k in order:
     meta = int(rec[k, 2])
-    print(f"{k:4d} b{(meta >> 16) & 0xFFFF:<3d} {names.get((meta >> 8) & 0xFF, '?'):7s} w{meta & 0xFF} {int(rec[k, 0] - t0):7d} {int(rec[k, 1] - rec[k, 0]):6d} {int(rec[k, 3]):3d}")
+    print(f"{k:4d} b{(meta >> 16) & 0xFFFF:<3d} {names.get((meta >> 8) & 0xFF, '?'):7s} w{meta & 0xFF} {int(rec[k, 0] - t0):7d} {int(rec[k, 1] - rec[k, 0]):6d} {int(rec[k, 3]):3d} | {int(rec[k, 4] - rec[k, 0]):5d} {int(rec[k, 5] - rec[k, 4]):5d} {int(rec[k, 6] - rec[k, 5]):5d} {int(rec[k, 1] - rec[k, 6]):5d}")

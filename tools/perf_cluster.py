@@ -17,13 +17,13 @@ cb = PoseIntegratorCallbacks()
 its = scene.constraint_count * int((1 + sd.iterations()).sum())
 
 
-def run(label, env, steps=20, use_clusters=True):
+def run(label, env, steps=int(os.environ.get('STEPS', '400')), use_clusters=True):
     for k in ("BEPUHIP_DEBUG", "BEPUHIP_CLUSTER_BODIES", "BEPUHIP_CLUSTER_THREADS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     s = HipSolver(use_clusters=use_clusters)
     s.upload(scene)
-    for _ in range(3):
+    for _ in range(int(os.environ.get('WARM', '200'))):  # long warm-up: the clock needs tens of milliseconds of load to ramp up
         s.solve(1 / 60, sd, cb, asynchronous=True)
     s.sync()
     t0 = time.perf_counter()
@@ -31,19 +31,22 @@ def run(label, env, steps=20, use_clusters=True):
         s.solve(1 / 60, sd, cb, asynchronous=True)
     s.sync()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    print(f"{label:50s} {ms:8.3f} ms/step  {its / ms / 1e6:8.2f} G c-it/s", flush=True)
+    cyc = s.cluster_cycles()
+    extra = f"  cluster kcycles min/mean/max {cyc.min() / 1e3:.0f}/{cyc.mean() / 1e3:.0f}/{cyc.max() / 1e3:.0f} of {cyc.size} => {cyc.max() / ms / 1e6:.2f} GHz" if cyc.size else ""
+    print(f"{label:34s} {ms:8.3f} ms/step  {its / ms / 1e6:8.2f} G c-it/s{extra}", flush=True)
     s.close()
 
 
 configs = sys.argv[1:] or ["base"]
 for cfg in configs:
-    if cfg == "base":
+    if cfg == "clusters":
+        run("clusters default", {})
+    elif cfg == "base":
         run("clusters default", {})
         run("global path (launch per batch)", {}, use_clusters=False)
-    elif cfg == "debug":
-        run("debug=1 (no math)", {"BEPUHIP_DEBUG": "1"})
-        run("debug=2 (no global constraint loads)", {"BEPUHIP_DEBUG": "2"})
-        run("debug=3 (neither)", {"BEPUHIP_DEBUG": "3"})
+    elif cfg == "waves":
+        for thr in (512, 768, 1024, 512, 768, 1024):
+            run(f"threads={thr}", {"BEPUHIP_CLUSTER_THREADS": str(thr)})
     elif cfg == "sizes":
         for cap in (256, 480, 700, 960, 1400):
             for thr in (256, 512):
