@@ -21,6 +21,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -548,8 +549,16 @@ int oracle_solve(OracleScene* scene, const OracleParams* params) {
     c.cb.prepare(*params, substepDt);                             // :1418
     const float inverseDt = 1.0f / substepDt;
 
-    std::unique_ptr<Pool> pool;
-    if (threads > 1) pool.reset(new Pool(threads));
+    // The worker pool persists across calls (bench.py's cpu_baseline solves many frames): creating hundreds of threads per frame would be timed too.
+    static std::unique_ptr<Pool> persistent;
+    static std::mutex persistentMutex;
+    std::unique_lock<std::mutex> poolLock(persistentMutex, std::defer_lock);
+    Pool* pool = nullptr;
+    if (threads > 1) {
+        poolLock.lock();
+        if (!persistent || persistent->n != threads) persistent.reset(new Pool(threads));
+        pool = persistent.get();
+    }
     std::vector<std::vector<Block>> batchBlocks(scene->batch_count);
     if (threads > 1) {
         for (int b = 0; b < scene->batch_count; ++b) {
