@@ -168,3 +168,55 @@ def test_ragdoll_tube_both_schedules(hip_solver_factory, use_clusters):
     m = pu.compare_scenes(ref, got)
     _check(m)
     assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+
+def test_full_size_ragdoll_tube_against_oracle_and_between_schedules(hip_solver_factory):
+    """BASELINE.json configs[2] at its full size (15,000 ragdolls, 1.005M constraints): the island-per-workgroup schedule against the
+    oracle (all host threads; its result does not depend on the thread count) and against the launch-per-batch schedule, bit for bit."""
+    from bepuphysics2_amd.hostlib import HostSimulation
+    sim = HostSimulation.scene("ragdoll_tube", 15000, 1, 0, 5)
+    scene, sd = sim.export(), sim.solve_description()
+    sim.close()
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=1, threads=8)
+    clusters = pu.run_hip(hip_solver_factory(use_clusters=True), scene, 1 / 60, sd, cb, frames=1)
+    batches = pu.run_hip(hip_solver_factory(use_clusters=False), scene, 1 / 60, sd, cb, frames=1)
+    for got in (clusters, batches):
+        m = pu.compare_scenes(ref, got)
+        _check(m)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    assert np.isfinite(clusters.bodies).all()
+
+
+@pytest.mark.parametrize("threads", [64, 512, 768, 1024])
+def test_cluster_schedule_wave_counts(hip_solver_factory, threads, monkeypatch):
+    """The work-item dataflow must give the same bits whatever the number of waves racing for items (1, 8, 12, 16 per workgroup)."""
+    monkeypatch.setenv("BEPUHIP_CLUSTER_THREADS", str(threads))
+    solver = hip_solver_factory(use_clusters=True, use_graph=False)
+    scene = small_scenes.island_scene(3, islands=200, bodies_per_island=12, constraints_per_island=40, type_ids=sorted(TYPE_TABLE.keys()))
+    sd, cb = SolveDescription(2, 4), PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=4)
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+    m = pu.compare_scenes(ref, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    cyc = solver.cluster_cycles()
+    assert cyc.size > 0 and (cyc > 0).all()  # the island-per-workgroup schedule really ran
+
+
+def test_cluster_trace_records_every_item(hip_solver_factory):
+    solver = hip_solver_factory(use_clusters=True)
+    scene = small_scenes.island_scene(4, islands=100, bodies_per_island=10, constraints_per_island=30, type_ids=sorted(TYPE_TABLE.keys()))
+    sd, cb = SolveDescription(1, 2), PoseIntegratorCallbacks()
+    solver.upload(scene)
+    solver.set_cluster_trace(True)
+    solver.solve(1 / 60, sd, cb)
+    passes = int((1 + sd.iterations()).sum())
+    tr = solver.cluster_trace(passes)
+    assert tr.shape[0] == passes and tr.shape[1] > 0
+    assert (tr[..., 1] > tr[..., 0]).all()          # every item of every pass was claimed and published
+    assert (tr[..., 3] > 0).all() and (tr[..., 3] <= 64).all()
+    solver.set_cluster_trace(False)
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb)
+    got = scene.copy()
+    solver.download(got)
+    assert pu.compare_scenes(ref, got)["bodies_bit_exact"]
