@@ -112,6 +112,68 @@ def measure_traffic(args):
         return {"error": str(e)[:200]}
 
 
+def run_lattice(args, rank, local_rank, world, dist, torch):
+    """configs[4]: one connected lattice, shares + ghosts + RCCL exchange (bepuphysics2_amd/lattice.py). Strong scaling: the scene is fixed."""
+    from bepuphysics2_amd import lattice
+    from bepuphysics2_amd.hostlib import HostSimulation
+    from bepuphysics2_amd.native import HipSolver
+    from bepuphysics2_amd.roofline import INTEGRATE_BYTES_PER_BODY, FINAL_BYTES_PER_BODY, scene_stage_bytes
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    sim = HostSimulation.scene("ragdoll_tube", args.ragdolls, 1, 1, 5)  # every rank builds the same scene and cuts out its share
+    scene, sd = sim.export(), sim.solve_description()
+    sim.close()
+    share = lattice.make_share(scene, lattice.owner_by_groups(scene, world, 16), rank, world)
+    cb = PoseIntegratorCallbacks()
+    solver = HipSolver(device=local_rank, use_clusters=False)
+    solver.upload(share.scene, sd.fallback_batch_threshold)
+    solver.set_boundary_bodies(share.boundary_local)
+    ex = lattice.BoundaryExchange(share, dist, device=f"cuda:{local_rank}")
+    hook = lattice.DeviceExchange(solver, share, dist, f"cuda:{local_rank}")
+    dt = 1.0 / 60.0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.solve_exchanged(dt, sd, cb, hook)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.solve_exchanged(dt, sd, cb, hook)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        its = sd.iterations()
+        units = scene.constraint_count * int((1 + its).sum()) * args.steps
+        ws_bytes, sv_bytes, inc_bytes = scene_stage_bytes(scene)
+        step_bytes = (sv_bytes * int(its.sum()) + ws_bytes * sd.substep_count + inc_bytes * (sd.substep_count - 1)
+                      + INTEGRATE_BYTES_PER_BODY * scene.body_count * sd.substep_count + FINAL_BYTES_PER_BODY * scene.body_count)
+        achieved = step_bytes / (elapsed / args.steps) / 1e9
+        print(json.dumps({
+            "metric": "constraint-iterations/sec", "value": units / elapsed, "unit": "constraint-iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "one connected ragdoll lattice (BASELINE.json configs[4]): "
+                                   f"{args.ragdolls} ragdolls, {scene.constraint_count} constraints, {scene.body_count} bodies, {len(scene.batches)} batches, "
+                                   f"{sd.substep_count} substeps x {sd.velocity_iteration_count} velocity iteration(s), dt=1/60, split into {world} share(s)",
+                       "sharding": f"bodies by ragdoll ranges, {share.boundary_total} boundary bodies, mass-split block-Jacobi exchange after every pass "
+                                   f"({int((1 + its).sum())} all-reduces of {share.boundary_total * 24} bytes per step); launch-per-batch schedule",
+                       "exchanges_per_step": int((1 + its).sum())},
+            "roofline": {"bound": "hbm", "kernel": "whole step (launch-per-batch schedule + exchanges)", "achieved": achieved, "peak": HBM_PEAK_GBS * world,
+                         "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None},
+            "cpu_baseline": None}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    solver.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +182,8 @@ def main():
     ap.add_argument("--ragdolls", type=int, default=15000, help="ragdolls per GPU (15000 ~ 1.005M constraints)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lattice", action="store_true", help="BASELINE.json configs[4]: ONE connected ragdoll lattice of --ragdolls ragdolls split across the ranks "
+                    "(strong scaling, boundary-velocity exchange after every pass) instead of the default independent islands per rank")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE child runs behind roofline.traffic")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -142,6 +206,8 @@ def main():
 
     from bepuphysics2_amd import build
     build.build_all()  # no-op when the in-tree .so files are current
+    if args.lattice:
+        return run_lattice(args, rank, local_rank, world, dist, torch)
     from bepuphysics2_amd.native import HipSolver
     from bepuphysics2_amd.roofline import INTEGRATE_BYTES_PER_BODY, FINAL_BYTES_PER_BODY, scene_stage_bytes
     from bepuphysics2_amd.scene import PoseIntegratorCallbacks, TYPE_TABLE

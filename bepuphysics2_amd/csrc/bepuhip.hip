@@ -317,6 +317,39 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
 }
 
 
+
+// ---- boundary exchange (one connected scene split across GPUs, BASELINE.json configs[4]) ----
+// A boundary body exists on several ranks (owned on one, ghost elsewhere). Between passes every holder publishes what its own constraints did to the
+// body's velocity since the last synchronisation point, the ranks sum those deltas (RCCL all-reduce, done by the caller), and every holder
+// replaces its copy with snapshot + sum: block-Jacobi across the cut, Gauss-Seidel everywhere else.
+__global__ void boundary_snapshot_kernel(const float4* __restrict__ bodies, const int* __restrict__ indices, int count, float4* __restrict__ snapshot) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float4* base = bodies + (size_t)indices[i] * 8;
+    snapshot[2 * i] = base[2];
+    snapshot[2 * i + 1] = base[3];
+}
+__global__ void boundary_deltas_kernel(const float4* __restrict__ bodies, const int* __restrict__ indices, int count, const float4* __restrict__ snapshot, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float4* base = bodies + (size_t)indices[i] * 8;
+    const float4 l = base[2], a = base[3], l0 = snapshot[2 * i], a0 = snapshot[2 * i + 1];
+    float* o = out + (size_t)i * 6;
+    o[0] = l.x - l0.x; o[1] = l.y - l0.y; o[2] = l.z - l0.z;
+    o[3] = a.x - a0.x; o[4] = a.y - a0.y; o[5] = a.z - a0.z;
+}
+__global__ void boundary_apply_kernel(float4* bodies, const int* __restrict__ indices, int count, float4* snapshot, const float* __restrict__ sums) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float4* base = bodies + (size_t)indices[i] * 8;
+    const float* d = sums + (size_t)i * 6;
+    float4 l0 = snapshot[2 * i], a0 = snapshot[2 * i + 1];
+    const float4 l = make_float4(l0.x + d[0], l0.y + d[1], l0.z + d[2], l0.w);
+    const float4 a = make_float4(a0.x + d[3], a0.y + d[4], a0.z + d[5], a0.w);
+    base[2] = l; base[3] = a;
+    snapshot[2 * i] = l; snapshot[2 * i + 1] = a;  // the next pass's deltas are relative to the synchronised value
+}
+
 // ------------------------------------------------------------------------------------------------
 // Cluster path: islands (connected components of the constraint graph through dynamic bodies) are independent, so a workgroup
 // that owns whole islands can run EVERY stage of EVERY substep for them without leaving the CU: the islands' bodies live in
@@ -786,6 +819,10 @@ struct bepuhip_ctx {
     bool clusters_enabled = false;
     int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0;
     ClusterDesc first_cluster = {0, 0, 0, 0, 0};
+    int* d_boundary = nullptr;          // boundary body indices (see bepuhip_set_boundary_bodies)
+    float4* d_boundary_snapshot = nullptr;
+    float* d_boundary_buf = nullptr;     // count * 6 floats staging for host-pointer exchanges
+    int boundary_count = 0;
     unsigned long long* d_cycles = nullptr;  // per cluster: shader clocks of the last cluster_kernel launch
     unsigned* d_status = nullptr;  // cluster schedule watchdog words (see report_stall)
     unsigned long long* d_trace = nullptr;  // optional per-item timeline of cluster 0 (diagnostics)
@@ -1098,6 +1135,9 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_flags) hipFree(c->d_flags);
     if (c->d_kin) hipFree(c->d_kin);
     if (c->d_status) hipHostFree(c->d_status);
+    if (c->d_boundary) hipFree(c->d_boundary);
+    if (c->d_boundary_snapshot) hipFree(c->d_boundary_snapshot);
+    if (c->d_boundary_buf) hipFree(c->d_boundary_buf);
     hipEventDestroy(c->ev_start);
     hipEventDestroy(c->ev_stop);
     hipStreamDestroy(c->stream);
@@ -1118,6 +1158,10 @@ static int32_t rebuild_flags(bepuhip_ctx* c) {
     if (c->built && c->clusters_enabled && c->clustered_dynamic_count > 0) {
         hipLaunchKernelGGL(mark_indices_kernel, dim3((c->clustered_dynamic_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_clustered_dynamic,
                            c->clustered_dynamic_count, c->d_flags, (unsigned)kFlagClustered);
+    }
+    if (c->boundary_count > 0) {  // held by several ranks: always integrated inside the solver, whatever this rank's share of its constraints
+        hipLaunchKernelGGL(mark_indices_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_boundary, c->boundary_count, c->d_flags,
+                           (unsigned)(kFlagConstrained | kFlagDynamicConstrained));
     }
     if (c->kin_count > 0) {
         hipLaunchKernelGGL(mark_indices_kernel, dim3((c->kin_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_kin, c->kin_count, c->d_flags, (unsigned)(kFlagConstrainedKinematic | kFlagConstrained));
@@ -1317,6 +1361,8 @@ int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* c, const int32_t* indice
     return rebuild_flags(c);
 }
 
+int32_t bepuhip_sync(bepuhip_ctx* c);
+
 struct Timed {
     bepuhip_ctx* c; int family; hipEvent_t a = nullptr, b = nullptr;
     Timed(bepuhip_ctx* c_, int f) : c(c_), family(f) {
@@ -1456,6 +1502,105 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
     return BEPUHIP_OK;
+}
+
+int32_t bepuhip_set_boundary_bodies(bepuhip_ctx* c, const int32_t* indices, int32_t count) {
+    if (!c || count < 0 || (count > 0 && !indices)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad boundary list");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < count; ++i)
+        if (indices[i] < 0 || indices[i] >= c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "boundary body index out of range (call set_bodies first)");
+    if (c->d_boundary) { hipFree(c->d_boundary); hipFree(c->d_boundary_snapshot); hipFree(c->d_boundary_buf); c->d_boundary = nullptr; c->d_boundary_snapshot = nullptr; c->d_boundary_buf = nullptr; }
+    c->boundary_count = count;
+    if (count > 0) {
+        HIP_TRY(hipMalloc((void**)&c->d_boundary, (size_t)count * 4));
+        HIP_TRY(hipMalloc((void**)&c->d_boundary_snapshot, (size_t)count * 32));
+        HIP_TRY(hipMalloc((void**)&c->d_boundary_buf, (size_t)count * 24));
+        HIP_TRY(hipMemcpy(c->d_boundary, indices, (size_t)count * 4, hipMemcpyHostToDevice));
+    }
+    return rebuild_flags(c);
+}
+
+int32_t bepuhip_boundary_deltas(bepuhip_ctx* c, float* out, int32_t out_is_device) {
+    if (!c || (c->boundary_count > 0 && !out)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    if (c->boundary_count == 0) return BEPUHIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    float* dst = out_is_device ? out : c->d_boundary_buf;
+    hipLaunchKernelGGL(boundary_deltas_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, (const int*)c->d_boundary, c->boundary_count,
+                       (const float4*)c->d_boundary_snapshot, dst);
+    HIP_TRY(hipGetLastError());
+    if (!out_is_device) HIP_TRY(hipMemcpyAsync(out, dst, (size_t)c->boundary_count * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller hands the buffer to a collective on another stream / the host next
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_boundary_apply(bepuhip_ctx* c, const float* sums, int32_t in_is_device) {
+    if (!c || (c->boundary_count > 0 && !sums)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    if (c->boundary_count == 0) return BEPUHIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const float* src = sums;
+    if (!in_is_device) {
+        HIP_TRY(hipMemcpyAsync(c->d_boundary_buf, sums, (size_t)c->boundary_count * 24, hipMemcpyHostToDevice, c->stream));
+        src = c->d_boundary_buf;
+    }
+    hipLaunchKernelGGL(boundary_apply_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, c->d_bodies, (const int*)c->d_boundary, c->boundary_count,
+                       c->d_boundary_snapshot, src);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BEPUHIP_OK;
+}
+
+// Simulation.Solve with an exchange point after every pass: the launch-per-batch schedule, eager, host-synchronised at each call-back.
+int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in, bepuhip_exchange_fn fn, void* user) {
+    int32_t st = validate_solve(c, dt, substeps, iterations, in);
+    if (st != BEPUHIP_OK) return st;
+    if (!fn) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null exchange call-back");
+    if (c->clusters_enabled) return fail(BEPUHIP_E_STATE, "solve_exchanged needs a context created with BEPUHIP_FLAG_NO_CLUSTERS (a split scene is one island per rank anyway)");
+    HIP_TRY(hipSetDevice(c->device));
+    int64_t iters = 0;
+    for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
+    c->last_constraint_iterations = iters;
+    HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+    const float substep_dt = dt / substeps, inv_dt = 1.0f / substep_dt;
+    const StepParams sp = make_params(in, substep_dt, substep_dt, inv_dt);
+    const int body_blocks = (c->body_count + 255) / 256;
+    auto exchange = [&](int s, int pass) -> int32_t {
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const int32_t r = fn(user, s, pass);
+        if (r != 0) return fail(BEPUHIP_E_STATE, "exchange call-back failed with status " + std::to_string(r));
+        return BEPUHIP_OK;
+    };
+    for (int s = 0; s < substeps; ++s) {
+        if (s > 0 && c->inc_blocks > 0)
+            hipLaunchKernelGGL(batch_kernel<kStageIncremental>, dim3(c->inc_blocks), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_inc_tbs, 0, c->inc_tb_count, c->d_bodies, substep_dt, inv_dt);
+        if (body_blocks > 0)
+            hipLaunchKernelGGL(substep_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, s > 0 ? 1 : 0,
+                               in->integrate_velocity_for_kinematics, sp);
+        if (c->boundary_count > 0)  // deltas of this substep are relative to the integrated velocities (identical on every holder)
+            hipLaunchKernelGGL(boundary_snapshot_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, (const int*)c->d_boundary, c->boundary_count,
+                               c->d_boundary_snapshot);
+        for (int b = 0; b < c->batch_count; ++b)
+            if (c->batch_blocks[b] > 0)
+                hipLaunchKernelGGL(batch_kernel<kStageWarmStart>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
+                                   c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);
+        if ((st = exchange(s, 0)) != BEPUHIP_OK) return st;
+        for (int it = 0; it < iterations[s]; ++it) {
+            for (int b = 0; b < c->batch_count; ++b)
+                if (c->batch_blocks[b] > 0)
+                    hipLaunchKernelGGL(batch_kernel<kStageSolve>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
+                                       c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);
+            if ((st = exchange(s, 1 + it)) != BEPUHIP_OK) return st;
+        }
+    }
+    if (body_blocks > 0) {
+        const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
+        const StepParams fsp = make_params(in, vdt, vdt, 1.0f / vdt);
+        hipLaunchKernelGGL(final_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, dt, substep_dt, substeps,
+                           in->allow_substeps_for_unconstrained, in->integrate_velocity_for_kinematics, fsp);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+    return bepuhip_sync(c);
 }
 
 int32_t bepuhip_sync(bepuhip_ctx* c) {

@@ -285,6 +285,11 @@ Vector3 bodyPosition(const Simulation& sim, int32_t handle) {
     return {f[4], f[5], f[6]};
 }
 
+Quaternion bodyOrientation(const Simulation& sim, int32_t handle) {
+    const float* f = sim.bodies.DynamicsState[sim.bodies.HandleToIndex[handle]].f;
+    return {f[0], f[1], f[2], f[3]};
+}
+
 // Synthetic two-body manifold between bodies a and b (what the narrow phase would have emitted).
 void addSyntheticPairContact(Simulation& sim, Rng& rng, int n, int32_t a, int32_t b, const Material& m, bool bIsFarKinematic) {
     Vector3 pa = bodyPosition(sim, a), pb = bodyPosition(sim, b);
@@ -338,10 +343,17 @@ Simulation* buildRagdollTube(int64_t ragdollCount, int64_t withContacts, int64_t
     if (lattice) {
         // config 5: one connected lattice — chain neighbouring ragdolls hand-to-hand (x) and head-to-foot (y) with ball sockets.
         SpringSettings sp(15.f, 1.f);
+        // The anchor of every link is the midpoint between the two bodies' rest positions, expressed in each body's local frame: the lattice
+        // starts (almost) at rest instead of being yanked together.
+        auto link = [&](int32_t a, int32_t b) {
+            Vector3 pa = bodyPosition(*sim, a), pb = bodyPosition(*sim, b);
+            Vector3 mid = (pa + pb) * 0.5f;
+            addBallSocket(sim->solver, a, b, transform(mid - pa, conjugate(bodyOrientation(*sim, a))), transform(mid - pb, conjugate(bodyOrientation(*sim, b))), sp);
+        };
         for (int64_t r = 0; r + 1 < (int64_t)ragdolls.size(); ++r) {
-            addBallSocket(sim->solver, ragdolls[r].hand[0], ragdolls[r + 1].hand[1], {0.1f, 0, 0}, {-0.1f, 0, 0}, sp);
+            link(ragdolls[r].hand[0], ragdolls[r + 1].hand[1]);
             int64_t up = r + (int64_t)length * height;
-            if (up < (int64_t)ragdolls.size()) addBallSocket(sim->solver, ragdolls[r].head, ragdolls[up].foot[0], {0, 0.2f, 0}, {0, -0.075f, 0}, sp);
+            if (up < (int64_t)ragdolls.size()) link(ragdolls[r].head, ragdolls[up].foot[0]);
         }
     }
     if (withContacts) {

@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_last_solve_ms", "bepuhip_set_profiling", "bepuhip_get_profile", "bepuhip_last_constraint_iterations",
     "bepuhip_get_stream", "bepuhip_solve_async", "bepuhip_sync", "bepuhip_reset_state", "bepuhip_type_info",
     "bepuhip_set_cluster_trace", "bepuhip_get_cluster_trace", "bepuhip_get_cluster_cycles", "bepuhip_debug_status",
+    "bepuhip_set_boundary_bodies", "bepuhip_boundary_deltas", "bepuhip_boundary_apply", "bepuhip_solve_exchanged",
 ]
 
 
@@ -54,6 +55,8 @@ class Integrator(C.Structure):
                 ("angular_integration_mode", C.c_int32), ("allow_substeps_for_unconstrained", C.c_int32),
                 ("integrate_velocity_for_kinematics", C.c_int32)]
 
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32)  # bepuhip_exchange_fn(user, substep, pass)
 
 _lib: Optional[C.CDLL] = None
 
@@ -89,6 +92,10 @@ def load_library() -> C.CDLL:
     lib.bepuhip_get_stream.argtypes = [vp, C.POINTER(vp)]
     lib.bepuhip_reset_state.argtypes = [vp]
     lib.bepuhip_set_cluster_trace.argtypes = [vp, i32]
+    lib.bepuhip_set_boundary_bodies.argtypes = [vp, vp, i32]
+    lib.bepuhip_boundary_deltas.argtypes = [vp, vp, i32]
+    lib.bepuhip_boundary_apply.argtypes = [vp, vp, i32]
+    lib.bepuhip_solve_exchanged.argtypes = [vp, f32, i32, vp, C.POINTER(Integrator), EXCHANGE_FN, vp]
     lib.bepuhip_get_cluster_cycles.argtypes = [vp, vp, i32, C.POINTER(i32)]
     lib.bepuhip_debug_status.argtypes = [vp, vp]
     lib.bepuhip_get_cluster_trace.argtypes = [vp, vp, C.c_int64, C.POINTER(i32)]
@@ -138,6 +145,7 @@ class HipSolver:
         _check(self.lib, self.lib.bepuhip_create(C.byref(cfg), C.byref(self.ctx)))
         self.bundle_width = bundle_width
         self._scene_meta = None
+        self._boundary_count = 0
 
     def close(self):
         if self.ctx:
@@ -177,6 +185,48 @@ class HipSolver:
         integ = make_integrator(callbacks)
         fn = self.lib.bepuhip_solve_async if asynchronous else self.lib.bepuhip_solve
         _check(self.lib, fn(self.ctx, float(dt), int(solve_description.substep_count), _ptr(its), C.byref(integ)))
+
+    # ---- one connected scene split across ranks (include/bepuhip.h, "solve_exchanged") ----
+    def set_boundary_bodies(self, local_indices: np.ndarray):
+        idx = np.ascontiguousarray(local_indices, dtype=np.int32)
+        self._boundary_count = int(idx.size)
+        _check(self.lib, self.lib.bepuhip_set_boundary_bodies(self.ctx, _ptr(idx), idx.size))
+
+    def boundary_deltas(self) -> np.ndarray:
+        out = np.zeros((self._boundary_count, 6), dtype=np.float32)
+        _check(self.lib, self.lib.bepuhip_boundary_deltas(self.ctx, _ptr(out), 0))
+        return out
+
+    def boundary_apply(self, sums: np.ndarray):
+        sums = np.ascontiguousarray(sums, dtype=np.float32)
+        assert sums.shape == (self._boundary_count, 6)
+        _check(self.lib, self.lib.bepuhip_boundary_apply(self.ctx, _ptr(sums), 0))
+
+    def boundary_deltas_device(self, device_pointer: int):
+        _check(self.lib, self.lib.bepuhip_boundary_deltas(self.ctx, C.c_void_p(device_pointer), 1))
+
+    def boundary_apply_device(self, device_pointer: int):
+        _check(self.lib, self.lib.bepuhip_boundary_apply(self.ctx, C.c_void_p(device_pointer), 1))
+
+    def solve_exchanged(self, dt: float, solve_description: SolveDescription, callbacks: PoseIntegratorCallbacks, exchange):
+        """``exchange(substep, pass)`` runs after every pass (0 = warm start, k = k-th velocity iteration); exceptions abort the solve."""
+        its = np.ascontiguousarray(solve_description.iterations(), dtype=np.int32)
+        integ = make_integrator(callbacks)
+        failure = []
+
+        def trampoline(_user, substep, pass_index):
+            try:
+                exchange(int(substep), int(pass_index))
+                return 0
+            except Exception as e:  # noqa: BLE001 - must not propagate through the C frame
+                failure.append(e)
+                return 1
+
+        fn = EXCHANGE_FN(trampoline)
+        status = self.lib.bepuhip_solve_exchanged(self.ctx, float(dt), int(solve_description.substep_count), _ptr(its), C.byref(integ), fn, None)
+        if failure:
+            raise failure[0]
+        _check(self.lib, status)
 
     def sync(self):
         _check(self.lib, self.lib.bepuhip_sync(self.ctx))

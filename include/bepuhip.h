@@ -81,6 +81,23 @@ int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* ctx, const int32_t* body
  * or an iteration count < 1 -> INVALID_ARGUMENT. */
 int32_t bepuhip_solve(bepuhip_ctx* ctx, float dt, int32_t substep_count, const int32_t* velocity_iterations, const bepuhip_integrator* integrator);
 
+/* ---- One connected scene split across GPUs (BASELINE.json configs[4]) ----
+ * The reference has no counterpart (it solves one address space); the closest hooks are Solver.SubstepStarted/SubstepEnded
+ * (BepuPhysics/Solver.cs:131-146). Each rank uploads its share: the bodies it owns plus ghost copies of remote bodies its constraints
+ * reference, and the constraints assigned to it (bepuphysics2_amd/lattice.py builds the shares). `set_boundary_bodies` lists the local
+ * indices of the bodies that exist on more than one rank, in an order all ranks agree on per body; they are always treated as constrained.
+ * `solve_exchanged` = bepuhip_solve on the launch-per-batch schedule (context created with BEPUHIP_FLAG_NO_CLUSTERS) that calls `fn`
+ * after every pass: pass 0 = warm start of substep `substep`, pass k = its k-th velocity iteration. Inside the call-back the caller
+ * reads `boundary_deltas` (6 floats per boundary body: what this rank's constraints did to linear xyz / angular xyz since the last
+ * synchronisation point), sums them over the ranks (RCCL all-reduce on the device buffer, or any host transport) and hands the sums to
+ * `boundary_apply`, which sets every copy to snapshot + sum. Block-Jacobi across the cut: results are NOT bit-identical to one GPU. */
+typedef int32_t (*bepuhip_exchange_fn)(void* user, int32_t substep, int32_t pass);
+int32_t bepuhip_set_boundary_bodies(bepuhip_ctx* ctx, const int32_t* body_indices, int32_t count);
+int32_t bepuhip_boundary_deltas(bepuhip_ctx* ctx, float* deltas_out, int32_t out_is_device_pointer);
+int32_t bepuhip_boundary_apply(bepuhip_ctx* ctx, const float* summed_deltas, int32_t in_is_device_pointer);
+int32_t bepuhip_solve_exchanged(bepuhip_ctx* ctx, float dt, int32_t substep_count, const int32_t* velocity_iterations, const bepuhip_integrator* integrator,
+                                bepuhip_exchange_fn fn, void* user);
+
 /* Read back what the reference would find in its own buffers after Simulation.Solve returns. */
 int32_t bepuhip_get_bodies(bepuhip_ctx* ctx, void* body_dynamics_aos_out, int32_t count);
 int32_t bepuhip_get_accumulated_impulses(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, float* accumulated_impulses_aosoa_out);

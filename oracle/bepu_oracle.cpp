@@ -49,6 +49,10 @@ struct OracleParams {
     int32_t allow_substeps_for_unconstrained;
     int32_t integrate_velocity_for_kinematics;
     int32_t threads;
+    // Optional: called after every pass (pass 0 = warm start of the substep, k = its k-th velocity iteration), for the split-scene tests
+    // (the CPU stand-in of bepuhip_solve_exchanged, include/bepuhip.h). Null = the reference's plain loop.
+    int32_t (*exchange)(void* user, int32_t substep, int32_t pass);
+    void* exchange_user;
 };
 struct OracleScene {
     float* bodies;  // AoS BodyDynamics, 32 floats/body (BepuPhysics/BodyProperties.cs:11-46,258-338)
@@ -592,9 +596,12 @@ int oracle_solve(OracleScene* scene, const OracleParams* params) {
             integrateKinematics(c, substepDt, false);                                                    // :1444-1445
         }
         for (int b = 0; b < scene->batch_count; ++b) runStage(kStageWarmStart, b, substepIndex);         // :1447-1463
+        if (params->exchange && params->exchange(params->exchange_user, substepIndex, 0) != 0) return -4;
         int iterations = params->velocity_iterations[substepIndex];
-        for (int it = 0; it < iterations; ++it)                                                          // :1464-1476
+        for (int it = 0; it < iterations; ++it) {                                                        // :1464-1476
             for (int b = 0; b < scene->batch_count; ++b) runStage(kStageSolve, b, substepIndex);
+            if (params->exchange && params->exchange(params->exchange_user, substepIndex, 1 + it) != 0) return -4;
+        }
     }
 
     // PoseIntegrator.IntegrateAfterSubstepping (PoseIntegrator.cs:707-726)

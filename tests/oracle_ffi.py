@@ -18,7 +18,7 @@ class OracleTypeBatch(C.Structure):
 class OracleParams(C.Structure):
     _fields_ = [("dt", C.c_float), ("substep_count", C.c_int32), ("velocity_iterations", C.c_void_p), ("gravity", C.c_float * 3),
                 ("linear_damping", C.c_float), ("angular_damping", C.c_float), ("allow_substeps_for_unconstrained", C.c_int32),
-                ("integrate_velocity_for_kinematics", C.c_int32), ("threads", C.c_int32)]
+                ("integrate_velocity_for_kinematics", C.c_int32), ("threads", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p)]
 
 
 class OracleScene(C.Structure):
@@ -83,7 +83,10 @@ class _Marshalled:
         self.c = s
 
 
-def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool = False):
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32)
+
+
+def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool = False, exchange=None):
     """Run the oracle's Simulation.Solve restatement IN PLACE on ``scene``'s buffers."""
     lib = load(fast)
     assert scene.bodies.flags["C_CONTIGUOUS"] and scene.bodies.dtype == np.float32
@@ -99,7 +102,21 @@ def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool 
     p.allow_substeps_for_unconstrained = int(bool(callbacks.allow_substeps_for_unconstrained_bodies))
     p.integrate_velocity_for_kinematics = int(bool(callbacks.integrate_velocity_for_kinematics))
     p.threads = int(threads)
+    failure = []
+    fn = None
+    if exchange is not None:  # exchange(substep, pass) after every pass: the CPU stand-in of HipSolver.solve_exchanged
+        def trampoline(_user, substep, pass_index):
+            try:
+                exchange(int(substep), int(pass_index))
+                return 0
+            except Exception as e:  # noqa: BLE001
+                failure.append(e)
+                return 1
+        fn = EXCHANGE_FN(trampoline)
+        p.exchange = C.cast(fn, C.c_void_p)
     rc = lib.oracle_solve(C.byref(m.c), C.byref(p))
+    if failure:
+        raise failure[0]
     if rc != 0:
         raise RuntimeError(f"oracle_solve failed: {rc}")
 
