@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -46,6 +47,7 @@ struct StepParams {
     float dt, inv_dt;
     float gx, gy, gz;  // gravity * dt
     float lin_damp, ang_damp;
+    int angular_mode;  // AngularIntegrationMode (PoseIntegrator.cs:20-38): 0 Nonconserving, 1 ConserveMomentum, 2 ConserveMomentumWithGyroscopicTorque
 };
 
 struct DevTypeBatch {
@@ -237,25 +239,37 @@ __global__ void kinematic_substeps_kernel(float4* bodies, const int* __restrict_
 // warm start (TypeProcessor.cs:1204-1283) plus the kinematic prepass (PoseIntegrator.cs:451-535).
 // substep 0: velocity only; substep > 0: pose, then velocity. World inverse inertia is refreshed either way.
 __global__ __launch_bounds__(256) void substep_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, int integrate_pose,
-                                                                 int integrate_velocity_for_kinematics, StepParams sp) {
+                                                                 int integrate_velocity_for_kinematics, int skip_clustered, StepParams sp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     unsigned f = flags[i];
     float4* base = bodies + (size_t)i * 8;
-    if (f & kFlagClustered) return;  // integrated in LDS by the owning cluster_kernel workgroup
+    if (skip_clustered && (f & kFlagClustered)) return;  // integrated in LDS by the owning cluster_kernel workgroup
     if (f & kFlagDynamicConstrained) {
         float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3], i0 = base[4], i1 = base[5];
         Q ori = {q4.x, q4.y, q4.z, q4.w};
         V3 pos = {p4.x, p4.y, p4.z};
         BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
         Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
-        if (integrate_pose) {
-            pos = add(pos, scale(vel.lin, sp.dt));                      // TypeProcessor.cs:1217
+        Sym3 world;
+        if (integrate_pose) {                                           // IntegratePoseAndVelocity, TypeProcessor.cs:1204-1248
+            pos = add(pos, scale(vel.lin, sp.dt));                      // :1217
+            const Q previousOrientation = ori;
             ori = integrateOrientation(ori, vel.ang, sp.dt * 0.5f);     // :1240
+            world = rotateInverseInertia(local, ori);                   // :1242
+            if (sp.angular_mode == 1) vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, world, vel.ang);                // :1224-1231
+            else if (sp.angular_mode == 2) vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, sp.dt);   // :1232-1238
             base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
             base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+        } else {                                                        // IntegrateVelocity, TypeProcessor.cs:1251-1283
+            world = rotateInverseInertia(local, ori);                   // :1262
+            if (sp.angular_mode == 1) {
+                const Q previousOrientation = integrateOrientation(ori, vel.ang, sp.dt * -0.5f);  // :1266 "integrating backwards"
+                vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, world, vel.ang);
+            } else if (sp.angular_mode == 2) {
+                vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, sp.dt);
+            }
         }
-        Sym3 world = rotateInverseInertia(local, ori);                  // :1242 / :1262
         velocity_callback(sp, vel);                                     // :1244 / :1273-1281
         base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
         base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
@@ -280,13 +294,35 @@ __global__ __launch_bounds__(256) void substep_integrate_kernel(float4* bodies, 
     }
 }
 
+// Substep 0, conserving modes only: the reference transforms the angular velocity of EVERY lane of a conditionally integrating bundle before it saves
+// the "previous velocity" it later restores non-integrating lanes to (TypeProcessor.cs:1264-1281), so a body that was integrated by an earlier batch
+// is transformed once more when it shares a bundle (slot-wise) with a body that is integrated there. The host lists those bodies per batch
+// (bundle membership depends on the host's bundle width); this kernel runs before the batch's warm start. Bodies within a batch are distinct.
+__global__ void momentum_requirk_kernel(float4* bodies, const int* __restrict__ indices, int count, StepParams sp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float4* base = bodies + (size_t)indices[i] * 8;
+    const float4 q4 = base[0], a4 = base[3], i0 = base[4], i1 = base[5];
+    const Q ori = {q4.x, q4.y, q4.z, q4.w};
+    V3 ang = {a4.x, a4.y, a4.z};
+    const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+    if (sp.angular_mode == 1) {
+        const Sym3 world = rotateInverseInertia(local, ori);
+        const Q previousOrientation = integrateOrientation(ori, ang, sp.dt * -0.5f);
+        ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, world, ang);
+    } else {
+        ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, ang, sp.dt);
+    }
+    base[3] = make_float4(ang.x, ang.y, ang.z, a4.w);
+}
+
 // PoseIntegrator.IntegrateBundlesAfterSubstepping (PoseIntegrator.cs:537-693), one lane per body.
 __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, float dt, float substep_dt, int substep_count,
-                                                               int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, StepParams sp) {
+                                                               int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, int skip_clustered, StepParams sp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float4* base = bodies + (size_t)i * 8;
-    if (flags[i] & kFlagClustered) return;  // final pose already written by the owning cluster_kernel workgroup
+    if (skip_clustered && (flags[i] & kFlagClustered)) return;  // final pose already written by the owning cluster_kernel workgroup
     const bool unconstrained = !(flags[i] & kFlagConstrained);
     const float effective_dt = allow_substeps_for_unconstrained ? substep_dt : (unconstrained ? dt : substep_dt);  // :591-599
     const float half_dt = effective_dt * 0.5f;
@@ -302,7 +338,18 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
         for (int s = 0; s < steps; ++s) {
             if (velocity_mask) velocity_callback(sp, vel);   // velocity -> pose for unconstrained bodies (:634-667)
             pos = add(pos, scale(vel.lin, effective_dt));
-            ori = integrateOrientation(ori, vel.ang, half_dt);
+            if (sp.angular_mode == 1) {                      // :649-655
+                const Q previousOrientation = ori;
+                ori = integrateOrientation(ori, vel.ang, half_dt);
+                const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+                vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, rotateInverseInertia(local, ori), vel.ang);
+            } else if (sp.angular_mode == 2) {               // :656-660
+                ori = integrateOrientation(ori, vel.ang, half_dt);
+                const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+                vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, effective_dt);
+            } else {
+                ori = integrateOrientation(ori, vel.ang, half_dt);
+            }
         }
         if (velocity_mask) {
             base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
@@ -819,6 +866,8 @@ struct bepuhip_ctx {
     bool clusters_enabled = false;
     int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0;
     ClusterDesc first_cluster = {0, 0, 0, 0, 0};
+    int* d_requirk = nullptr;            // conserving angular modes: per batch, the bodies momentum_requirk_kernel transforms in substep 0
+    std::vector<int> requirk_begin;     // batch -> offset into d_requirk (batch_count + 1 entries)
     int* d_boundary = nullptr;          // boundary body indices (see bepuhip_set_boundary_bodies)
     float4* d_boundary_snapshot = nullptr;
     float* d_boundary_buf = nullptr;     // count * 6 floats staging for host-pointer exchanges
@@ -857,6 +906,8 @@ static void free_constraints(bepuhip_ctx* c) {
     if (c->d_cluster_bodies) hipFree(c->d_cluster_bodies);
     if (c->d_clustered_dynamic) hipFree(c->d_clustered_dynamic);
     if (c->d_kinlist) hipFree(c->d_kinlist);
+    if (c->d_requirk) hipFree(c->d_requirk);
+    c->d_requirk = nullptr; c->requirk_begin.clear();
     if (c->d_trace) hipFree(c->d_trace);
     c->d_trace = nullptr; c->trace_words = 0;
     if (c->d_cycles) hipFree(c->d_cycles);
@@ -1242,6 +1293,48 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
     size_t words = 0;
     c->total_constraints = 0;
     for (auto& tb : c->tbs) c->total_constraints += tb.count;
+    // Bodies the reference re-transforms in substep 0 of the conserving angular modes (see momentum_requirk_kernel). Bundles are W consecutive
+    // constraints in the HOST's order, so this runs before the island schedule permutes the type batches.
+    {
+        int universe = 0;
+        for (auto& tb : c->tbs)
+            for (int32_t r : tb.refs_soa)
+                if (r >= 0) universe = std::max(universe, (r & kRefMask) + 1);
+        std::vector<int32_t> first_batch(universe, INT32_MAX);
+        for (auto& tb : c->tbs)
+            for (int k = 0; k < tb.info.bodies; ++k)
+                for (int i = 0; i < tb.count; ++i) {
+                    const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r < kDynamicLimit) first_batch[r] = std::min(first_batch[r], tb.batch);
+                }
+        std::vector<std::vector<int32_t>> lists(c->batch_count);
+        const int W = c->W;
+        for (auto& tb : c->tbs) {
+            if (tb.batch == 0) continue;  // batch 0 always integrates (Solver_Solve.cs:188-194): no conditional bundles
+            for (int k = 0; k < tb.info.bodies; ++k)
+                for (int b0 = 0; b0 < tb.count; b0 += W) {
+                    const int b1 = std::min(tb.count, b0 + W);
+                    bool any = false;
+                    for (int i = b0; i < b1; ++i) {
+                        const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                        any |= (uint32_t)r < kDynamicLimit && first_batch[r] == tb.batch;
+                    }
+                    if (!any) continue;
+                    for (int i = b0; i < b1; ++i) {
+                        const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                        if ((uint32_t)r < kDynamicLimit && first_batch[r] < tb.batch) lists[tb.batch].push_back(r);
+                    }
+                }
+        }
+        std::vector<int32_t> flat;
+        c->requirk_begin.assign(c->batch_count + 1, 0);
+        for (int b = 0; b < c->batch_count; ++b) { c->requirk_begin[b] = (int)flat.size(); flat.insert(flat.end(), lists[b].begin(), lists[b].end()); }
+        c->requirk_begin[c->batch_count] = (int)flat.size();
+        if (!flat.empty()) {
+            HIP_TRY(hipMalloc((void**)&c->d_requirk, flat.size() * 4));
+            HIP_TRY(hipMemcpy(c->d_requirk, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     ClusterPlan plan;
     plan_clusters(c, plan);
     for (auto& tb : c->tbs) {
@@ -1388,7 +1481,15 @@ static StepParams make_params(const bepuhip_integrator* in, float dt_for_callbac
     sp.ang_damp = powf(a, dt_for_callbacks);
     sp.gx = in->gravity[0] * dt_for_callbacks; sp.gy = in->gravity[1] * dt_for_callbacks; sp.gz = in->gravity[2] * dt_for_callbacks;
     sp.dt = dt; sp.inv_dt = inv_dt;
+    sp.angular_mode = in->angular_integration_mode;
     return sp;
+}
+
+static void enqueue_requirk(bepuhip_ctx* c, int substep, int batch, const StepParams& sp) {
+    if (substep != 0 || sp.angular_mode == 0 || c->requirk_begin.empty()) return;
+    const int n = c->requirk_begin[batch + 1] - c->requirk_begin[batch];
+    if (n > 0)
+        hipLaunchKernelGGL(momentum_requirk_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_bodies, (const int*)(c->d_requirk + c->requirk_begin[batch]), n, sp);
 }
 
 // Enqueue every kernel of one Simulation.Solve on the context's stream (Solver_Solve.cs:1415-1479 + PoseIntegrator.cs:707-726).
@@ -1398,7 +1499,9 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
     const StepParams sp = make_params(in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
     const size_t lds_bytes = cluster_lds_bytes(c->cluster_max_slots, c->cluster_max_items);
-    const bool use_clusters = c->clusters_enabled && substeps <= kMaxClusterSubsteps && lds_bytes <= kLdsBudgetBytes;
+    // The island schedule implements AngularIntegrationMode.Nonconserving; the conserving modes run the launch-per-batch schedule.
+    const bool use_clusters = c->clusters_enabled && substeps <= kMaxClusterSubsteps && lds_bytes <= kLdsBudgetBytes && in->angular_integration_mode == 0;
+    const int skip_clustered = use_clusters ? 1 : 0;
     if (use_clusters) {
         // Every constraint belongs to an island small enough for one workgroup: the whole substep loop runs in ONE launch.
         ClusterParams cp;
@@ -1432,10 +1535,11 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
         if (body_blocks > 0) {                        // :1440-1445 + the integration half of GatherAndIntegrate
             Timed t(c, 1);
             hipLaunchKernelGGL(substep_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, s > 0 ? 1 : 0,
-                               in->integrate_velocity_for_kinematics, sp);
+                               in->integrate_velocity_for_kinematics, skip_clustered, sp);
         }
         for (int b = 0; b < c->batch_count; ++b) {    // :1447-1463
             if (c->batch_blocks[b] == 0) continue;
+            enqueue_requirk(c, s, b, sp);
             Timed t(c, 2);
             hipLaunchKernelGGL(batch_kernel<kStageWarmStart>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
                                c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);
@@ -1454,7 +1558,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
         const StepParams fsp = make_params(in, vdt, vdt, 1.0f / vdt);
         Timed t(c, 4);
         hipLaunchKernelGGL(final_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, dt, substep_dt, substeps,
-                           in->allow_substeps_for_unconstrained, in->integrate_velocity_for_kinematics, fsp);
+                           in->allow_substeps_for_unconstrained, in->integrate_velocity_for_kinematics, skip_clustered, fsp);
     }
 }
 
@@ -1464,7 +1568,7 @@ static int32_t validate_solve(bepuhip_ctx* c, float dt, int32_t substeps, const 
     if (substeps < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Substep count must be positive.");                    // SolveDescription.cs:42-47
     for (int s = 0; s < substeps; ++s)
         if (iterations[s] < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Velocity iteration count must be positive.");
-    if (in->angular_integration_mode != 0) return fail(BEPUHIP_E_UNSUPPORTED, "only AngularIntegrationMode.Nonconserving is supported");
+    if (in->angular_integration_mode < 0 || in->angular_integration_mode > 2) return fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown AngularIntegrationMode");
     if (c->building) return fail(BEPUHIP_E_STATE, "solve between begin_constraints and end_constraints");
     return BEPUHIP_OK;
 }
@@ -1575,14 +1679,16 @@ int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, cons
             hipLaunchKernelGGL(batch_kernel<kStageIncremental>, dim3(c->inc_blocks), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_inc_tbs, 0, c->inc_tb_count, c->d_bodies, substep_dt, inv_dt);
         if (body_blocks > 0)
             hipLaunchKernelGGL(substep_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, s > 0 ? 1 : 0,
-                               in->integrate_velocity_for_kinematics, sp);
+                               in->integrate_velocity_for_kinematics, 0, sp);
         if (c->boundary_count > 0)  // deltas of this substep are relative to the integrated velocities (identical on every holder)
             hipLaunchKernelGGL(boundary_snapshot_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, (const int*)c->d_boundary, c->boundary_count,
                                c->d_boundary_snapshot);
         for (int b = 0; b < c->batch_count; ++b)
-            if (c->batch_blocks[b] > 0)
+            if (c->batch_blocks[b] > 0) {
+                enqueue_requirk(c, s, b, sp);
                 hipLaunchKernelGGL(batch_kernel<kStageWarmStart>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
                                    c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);
+            }
         if ((st = exchange(s, 0)) != BEPUHIP_OK) return st;
         for (int it = 0; it < iterations[s]; ++it) {
             for (int b = 0; b < c->batch_count; ++b)
@@ -1596,7 +1702,7 @@ int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, cons
         const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
         const StepParams fsp = make_params(in, vdt, vdt, 1.0f / vdt);
         hipLaunchKernelGGL(final_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, dt, substep_dt, substeps,
-                           in->allow_substeps_for_unconstrained, in->integrate_velocity_for_kinematics, fsp);
+                           in->allow_substeps_for_unconstrained, in->integrate_velocity_for_kinematics, 0, fsp);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_stop, c->stream));

@@ -127,7 +127,7 @@ def make_integrator(cb: PoseIntegratorCallbacks) -> Integrator:
     integ.gravity[0], integ.gravity[1], integ.gravity[2] = [float(x) for x in cb.gravity]
     integ.linear_damping = float(cb.linear_damping)
     integ.angular_damping = float(cb.angular_damping)
-    integ.angular_integration_mode = 0
+    integ.angular_integration_mode = int(getattr(cb, "angular_integration_mode", 0))
     integ.allow_substeps_for_unconstrained = int(bool(cb.allow_substeps_for_unconstrained_bodies))
     integ.integrate_velocity_for_kinematics = int(bool(cb.integrate_velocity_for_kinematics))
     return integ

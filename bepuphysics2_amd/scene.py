@@ -160,6 +160,7 @@ class PoseIntegratorCallbacks:
     angular_damping: float = 0.03
     allow_substeps_for_unconstrained_bodies: bool = False
     integrate_velocity_for_kinematics: bool = False
+    angular_integration_mode: int = 0  # AngularIntegrationMode: 0 Nonconserving, 1 ConserveMomentum, 2 ConserveMomentumWithGyroscopicTorque (PoseIntegrator.cs:20-38)
 
 
 def make_body(position=(0, 0, 0), orientation=(0, 0, 0, 1), linear=(0, 0, 0), angular=(0, 0, 0),

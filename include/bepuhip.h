@@ -46,7 +46,7 @@ typedef struct bepuhip_integrator {
     float gravity[3];
     float linear_damping;
     float angular_damping;
-    int32_t angular_integration_mode;             /* 0 = Nonconserving (only mode supported; others -> BEPUHIP_E_UNSUPPORTED) */
+    int32_t angular_integration_mode;             /* AngularIntegrationMode (PoseIntegrator.cs:20-38): 0 Nonconserving, 1 ConserveMomentum, 2 ConserveMomentumWithGyroscopicTorque */
     int32_t allow_substeps_for_unconstrained;     /* AllowSubstepsForUnconstrainedBodies */
     int32_t integrate_velocity_for_kinematics;    /* IntegrateVelocityForKinematics */
 } bepuhip_integrator;

@@ -454,4 +454,79 @@ static inline Sym3 rotateInverseInertia(const Sym3& local, Q orientation) {     
     return rotationSandwich(m, local);
 }
 
+// ---- momentum-conserving angular integration (BepuPhysics/PoseIntegrator.cs:176-253) ----
+static inline V3 transformByTransposed(V3 v, const M3& m) {                                        // Matrix3x3Wide.cs:127-132
+    return {v.x * m.X.x + v.y * m.X.y + v.z * m.X.z, v.x * m.Y.x + v.y * m.Y.y + v.z * m.Y.z, v.x * m.Z.x + v.y * m.Z.y + v.z * m.Z.z};
+}
+static inline M3 invert(const M3& m) {                                                             // Matrix3x3Wide.cs:142-166
+    float m11 = m.Y.y * m.Z.z - m.Z.y * m.Y.z;
+    float m21 = m.Y.z * m.Z.x - m.Z.z * m.Y.x;
+    float m31 = m.Y.x * m.Z.y - m.Z.x * m.Y.y;
+    float determinantInverse = 1.0f / (m11 * m.X.x + m21 * m.X.y + m31 * m.X.z);
+    float m12 = m.Z.y * m.X.z - m.X.y * m.Z.z;
+    float m22 = m.Z.z * m.X.x - m.X.z * m.Z.x;
+    float m32 = m.Z.x * m.X.y - m.X.x * m.Z.y;
+    float m13 = m.X.y * m.Y.z - m.Y.y * m.X.z;
+    float m23 = m.X.z * m.Y.x - m.Y.z * m.X.x;
+    float m33 = m.X.x * m.Y.y - m.Y.x * m.X.y;
+    M3 inverse;
+    inverse.X = {m11 * determinantInverse, m12 * determinantInverse, m13 * determinantInverse};
+    inverse.Y = {m21 * determinantInverse, m22 * determinantInverse, m23 * determinantInverse};
+    inverse.Z = {m31 * determinantInverse, m32 * determinantInverse, m33 * determinantInverse};
+    return inverse;
+}
+static inline M3 createCrossProduct(V3 v) {                                                        // Matrix3x3Wide.cs:169-180
+    M3 skew;
+    skew.X = {0.0f, -v.z, v.y};
+    skew.Y = {v.z, 0.0f, -v.x};
+    skew.Z = {-v.y, v.x, 0.0f};
+    return skew;
+}
+static inline M3 multiply(const M3& a, const Sym3& b) {                                            // Symmetric3x3Wide.cs:319-334
+    M3 r;
+    r.X = {a.X.x * b.xx + a.X.y * b.yx + a.X.z * b.zx, a.X.x * b.yx + a.X.y * b.yy + a.X.z * b.zy, a.X.x * b.zx + a.X.y * b.zy + a.X.z * b.zz};
+    r.Y = {a.Y.x * b.xx + a.Y.y * b.yx + a.Y.z * b.zx, a.Y.x * b.yx + a.Y.y * b.yy + a.Y.z * b.zy, a.Y.x * b.zx + a.Y.y * b.zy + a.Y.z * b.zz};
+    r.Z = {a.Z.x * b.xx + a.Z.y * b.yx + a.Z.z * b.zx, a.Z.x * b.yx + a.Z.y * b.yy + a.Z.z * b.zy, a.Z.x * b.zx + a.Z.y * b.zy + a.Z.z * b.zz};
+    return r;
+}
+static inline V3 fallbackIfInertiaIncompatible(V3 previousAngularVelocity, V3 angularVelocity) {   // PoseIntegrator.cs:179-190
+    const float infinity = __builtin_inff();
+    bool useNewVelocity = (vabs(angularVelocity.x) < infinity) && (vabs(angularVelocity.y) < infinity) && (vabs(angularVelocity.z) < infinity);
+    return sel3(useNewVelocity, angularVelocity, previousAngularVelocity);
+}
+static inline V3 integrateAngularVelocityConserveMomentum(Q previousOrientation, const Sym3& localInverseInertia, const Sym3& worldInverseInertia, V3 angularVelocity) {  // :192-207
+    M3 previousOrientationMatrix = createFromQuaternion(previousOrientation);
+    V3 localPreviousAngularVelocity = transformByTransposed(angularVelocity, previousOrientationMatrix);
+    Sym3 localInertiaTensor = invert(localInverseInertia);
+    V3 localAngularMomentum = transform(localPreviousAngularVelocity, localInertiaTensor);
+    V3 angularMomentum = transform(localAngularMomentum, previousOrientationMatrix);
+    V3 newVelocity = transform(angularMomentum, worldInverseInertia);
+    return fallbackIfInertiaIncompatible(angularVelocity, newVelocity);
+}
+static inline V3 integrateAngularVelocityConserveMomentumWithGyroscopicTorque(Q orientation, const Sym3& localInverseInertia, V3 angularVelocity, float dt) {  // :209-253
+    M3 orientationMatrix = createFromQuaternion(orientation);
+    V3 localAngularVelocity = transformByTransposed(angularVelocity, orientationMatrix);
+    Sym3 localInertiaTensor = invert(localInverseInertia);
+    V3 localAngularMomentum = transform(localAngularVelocity, localInertiaTensor);
+    V3 c = cross(localAngularMomentum, localAngularVelocity);
+    V3 residual = {dt * c.x, dt * c.y, dt * c.z};
+    M3 skewMomentum = createCrossProduct(localAngularMomentum);
+    M3 skewVelocity = createCrossProduct(localAngularVelocity);
+    M3 transformedSkewVelocity = multiply(skewVelocity, localInertiaTensor);
+    M3 changeOverDt;
+    changeOverDt.X = sub(transformedSkewVelocity.X, skewMomentum.X);
+    changeOverDt.Y = sub(transformedSkewVelocity.Y, skewMomentum.Y);
+    changeOverDt.Z = sub(transformedSkewVelocity.Z, skewMomentum.Z);
+    M3 change = {scale(changeOverDt.X, dt), scale(changeOverDt.Y, dt), scale(changeOverDt.Z, dt)};
+    M3 jacobian;                                                                          // Symmetric3x3Wide.cs:539-552 (symmetric + general)
+    jacobian.X = {localInertiaTensor.xx + change.X.x, localInertiaTensor.yx + change.X.y, localInertiaTensor.zx + change.X.z};
+    jacobian.Y = {localInertiaTensor.yx + change.Y.x, localInertiaTensor.yy + change.Y.y, localInertiaTensor.zy + change.Y.z};
+    jacobian.Z = {localInertiaTensor.zx + change.Z.x, localInertiaTensor.zy + change.Z.y, localInertiaTensor.zz + change.Z.z};
+    M3 inverseJacobian = invert(jacobian);
+    V3 newtonStep = transform(residual, inverseJacobian);
+    localAngularVelocity = sub(localAngularVelocity, newtonStep);
+    V3 newVelocity = transform(localAngularVelocity, orientationMatrix);
+    return fallbackIfInertiaIncompatible(angularVelocity, newVelocity);
+}
+
 }  // namespace bo

@@ -53,6 +53,7 @@ struct OracleParams {
     // (the CPU stand-in of bepuhip_solve_exchanged, include/bepuhip.h). Null = the reference's plain loop.
     int32_t (*exchange)(void* user, int32_t substep, int32_t pass);
     void* exchange_user;
+    int32_t angular_integration_mode;  // AngularIntegrationMode (PoseIntegrator.cs:20-38): 0 Nonconserving, 1 ConserveMomentum, 2 ConserveMomentumWithGyroscopicTorque
 };
 struct OracleScene {
     float* bodies;  // AoS BodyDynamics, 32 floats/body (BepuPhysics/BodyProperties.cs:11-46,258-338)
@@ -78,7 +79,9 @@ constexpr int32_t kBodyReferenceMask = 0x3FFFFFFF;
 struct Callbacks {  // Demos/DemoCallbacks.cs:79-109
     V3 gravityDt;
     float linearDampingDt, angularDampingDt;
+    int mode = 0;  // AngularIntegrationMode
     void prepare(const OracleParams& p, float dt) {
+        mode = p.angular_integration_mode;
         float l = 1 - p.linear_damping, a = 1 - p.angular_damping;
         l = l < 0 ? 0 : (l > 1 ? 1 : l);
         a = a < 0 ? 0 : (a > 1 ? 1 : a);
@@ -137,24 +140,45 @@ struct Ctx {
     std::vector<int> batchStart;              // index of first type batch of each batch
 };
 
-// TypeProcessor.cs:1204-1248 (Nonconserving branch), one lane.
+// TypeProcessor.cs:1204-1248, one lane.
 inline void integratePoseAndVelocity(const Callbacks& cb, const Inertia& localInertia, float dt, bool mask, BodyState& s, Inertia& outInertia) {
     V3 newPosition = add(s.pos, scale(s.vel.lin, dt));
     s.pos = sel3(mask, newPosition, s.pos);
     outInertia.invMass = localInertia.invMass;
     BodyVel previousVelocity = s.vel;
-    Q newOrientation = integrateOrientation(s.ori, s.vel.ang, dt * 0.5f);
-    s.ori = mask ? newOrientation : s.ori;
-    outInertia.t = rotateInverseInertia(localInertia.t, s.ori);
+    if (cb.mode == 1) {  // ConserveMomentum :1224-1231
+        Q previousOrientation = s.ori;
+        Q newOrientation = integrateOrientation(s.ori, s.vel.ang, dt * 0.5f);
+        s.ori = mask ? newOrientation : s.ori;
+        outInertia.t = rotateInverseInertia(localInertia.t, s.ori);
+        s.vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, localInertia.t, outInertia.t, s.vel.ang);
+    } else if (cb.mode == 2) {  // ConserveMomentumWithGyroscopicTorque :1232-1238
+        Q newOrientation = integrateOrientation(s.ori, s.vel.ang, dt * 0.5f);
+        s.ori = mask ? newOrientation : s.ori;
+        outInertia.t = rotateInverseInertia(localInertia.t, s.ori);
+        s.vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(s.ori, localInertia.t, s.vel.ang, dt);
+    } else {
+        Q newOrientation = integrateOrientation(s.ori, s.vel.ang, dt * 0.5f);
+        s.ori = mask ? newOrientation : s.ori;
+        outInertia.t = rotateInverseInertia(localInertia.t, s.ori);
+    }
     cb.integrateVelocity(s.vel);
     s.vel.lin = sel3(mask, s.vel.lin, previousVelocity.lin);
     s.vel.ang = sel3(mask, s.vel.ang, previousVelocity.ang);
 }
-// TypeProcessor.cs:1251-1283 (Nonconserving branch), one lane.
+// TypeProcessor.cs:1251-1283, one lane. NOTE (:1264-1281): in the conserving modes the angular velocity of EVERY lane of the bundle is transformed
+// before the conditional branch saves `previousVelocity`, so a lane that does not integrate here (its body was integrated by an earlier batch) still
+// leaves with a transformed angular velocity when another lane of its bundle integrates. Reproduced as is.
 template <int Mode>
-inline void integrateVelocity(const Callbacks& cb, const Inertia& localInertia, bool mask, BodyState& s, Inertia& outInertia) {
+inline void integrateVelocity(const Callbacks& cb, const Inertia& localInertia, float dt, bool mask, BodyState& s, Inertia& outInertia) {
     outInertia.invMass = localInertia.invMass;
     outInertia.t = rotateInverseInertia(localInertia.t, s.ori);
+    if (cb.mode == 1) {
+        Q previousOrientation = integrateOrientation(s.ori, s.vel.ang, dt * -0.5f);  // "integrating backwards to get a previous orientation"
+        s.vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, localInertia.t, outInertia.t, s.vel.ang);
+    } else if (cb.mode == 2) {
+        s.vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(s.ori, localInertia.t, s.vel.ang, dt);
+    }
     if (Mode == kConditional) {
         BodyVel previousVelocity = s.vel;
         cb.integrateVelocity(s.vel);
@@ -195,7 +219,7 @@ inline void gatherAndIntegrateBundle(Ctx& c, const std::vector<uint64_t>* flagsF
     for (int l = 0; l < lanes; ++l) {
         Inertia local = out[l].inertia, world;
         if (AllowPose) integratePoseAndVelocity(c.cb, local, dt, mask[l], out[l], world);
-        else integrateVelocity<Mode>(c.cb, local, mask[l], out[l], world);
+        else integrateVelocity<Mode>(c.cb, local, dt, mask[l], out[l], world);
         out[l].inertia = world;
         if (mask[l]) {
             int32_t idx = refs[l] & kBodyReferenceMask;
@@ -456,7 +480,17 @@ void integrateAfterSubstepping(Ctx& c, int start, int end) {
             for (int stepIndex = 0; stepIndex < steps; ++stepIndex) {
                 if (velocityMask) c.cb.integrateVelocity(st.vel);
                 st.pos = add(st.pos, scale(st.vel.lin, effectiveDt));
-                st.ori = integrateOrientation(st.ori, st.vel.ang, halfDt);
+                if (c.cb.mode == 1) {  // PoseIntegrator.cs:649-655
+                    Q previousOrientation = st.ori;
+                    st.ori = integrateOrientation(st.ori, st.vel.ang, halfDt);
+                    Sym3 inverseInertiaTensor = rotateInverseInertia(st.inertia.t, st.ori);
+                    st.vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, st.inertia.t, inverseInertiaTensor, st.vel.ang);
+                } else if (c.cb.mode == 2) {  // :656-660
+                    st.ori = integrateOrientation(st.ori, st.vel.ang, halfDt);
+                    st.vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(st.ori, st.inertia.t, st.vel.ang, effectiveDt);
+                } else {
+                    st.ori = integrateOrientation(st.ori, st.vel.ang, halfDt);
+                }
                 scatterPose(s.bodies, i, st.pos, st.ori);
                 if (velocityMask) scatterVelocities(s.bodies, i, st.vel);
             }

@@ -220,3 +220,24 @@ def test_cluster_trace_records_every_item(hip_solver_factory):
     got = scene.copy()
     solver.download(got)
     assert pu.compare_scenes(ref, got)["bodies_bit_exact"]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_momentum_conserving_angular_integration_modes(hip_solver_factory, mode):
+    """AngularIntegrationMode.ConserveMomentum / ConserveMomentumWithGyroscopicTorque (PoseIntegrator.cs:193-253; TypeProcessor.cs:1224-1238,1264-1271),
+    including the reference's re-transformation of already integrated bodies that share a substep-0 bundle with an integrating one: constrained,
+    kinematic and unconstrained bodies, both schedule selections (the conserving modes always run launch-per-batch), bit for bit."""
+    for scene, sd, kw in (
+        (small_scenes.random_graph_scene(31, 300, 800, sorted(TYPE_TABLE.keys()), kinematic_fraction=0.1, unconstrained_extra=20), SolveDescription(2, 4), {}),
+        (small_scenes.island_scene(5, islands=120, bodies_per_island=10, constraints_per_island=30, type_ids=sorted(TYPE_TABLE.keys())), SolveDescription(1, 3),
+         {"allow_substeps_for_unconstrained_bodies": True, "integrate_velocity_for_kinematics": True}),
+    ):
+        cb = PoseIntegratorCallbacks(angular_integration_mode=mode, **kw)
+        ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2)
+        for use_clusters in (True, False):
+            got = pu.run_hip(hip_solver_factory(use_clusters=use_clusters), scene, 1 / 60, sd, cb, frames=2)
+            m = pu.compare_scenes(ref, got)
+            _check(m)
+            assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (mode, use_clusters, m)
+    plain = pu.run_oracle(scene, 1 / 60, sd, PoseIntegratorCallbacks(**kw), frames=2)
+    assert not np.array_equal(plain.bodies, ref.bodies)  # the mode does change the answer

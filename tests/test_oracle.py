@@ -164,3 +164,89 @@ def test_unconstrained_and_kinematic_integration_modes():
         else:
             assert abs(sc.bodies[0, 9] - (-10 / 60)) < 1e-6
         assert sc.bodies[1, 9] == 1 and abs(sc.bodies[1, 5] - 1 / 60) < 1e-7  # kinematic: velocity untouched, pose advanced
+
+
+def _angular_momentum(body):
+    """World angular momentum of a BodyDynamics record: R * I_local * R^T * w, I_local = inverse of the stored local inverse inertia."""
+    x, y, z, w = [float(v) for v in body[0:4]]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    xx, yx, yy, zx, zy, zz = [float(v) for v in body[16:22]]
+    inv_local = np.array([[xx, yx, zx], [yx, yy, zy], [zx, zy, zz]])
+    return R @ np.linalg.inv(inv_local) @ R.T @ body[12:15].astype(np.float64)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_conserving_angular_modes_keep_the_momentum_of_a_free_body(mode):
+    """PoseIntegrator.cs:193-253: an unconstrained asymmetric body, no gravity, no damping. ConserveMomentum keeps R I R^T w to rounding every
+    step; the gyroscopic mode is an implicit approximation (one Newton step) and drifts slowly; Nonconserving drifts visibly."""
+    from bepuphysics2_amd.scene import SceneBuilder, make_body, PoseIntegratorCallbacks, SolveDescription
+    drift = {}
+    for m in (0, mode):
+        sb = SceneBuilder()
+        sb.add_body(make_body(position=(0, 0, 0), orientation=(0.1, 0.2, 0.3, 0.927), angular=(1.0, 2.0, 0.5), inverse_inertia=(1.0, 0.05, 0.25, 0.02, 0.03, 4.0), inverse_mass=1.0))
+        scene = sb.build()
+        q = scene.bodies[0, 0:4]
+        scene.bodies[0, 0:4] = q / np.linalg.norm(q)
+        cb = PoseIntegratorCallbacks(gravity=(0, 0, 0), linear_damping=0.0, angular_damping=0.0, angular_integration_mode=m)
+        L0 = _angular_momentum(scene.bodies[0])
+        for _ in range(60):
+            oracle_ffi.solve(scene, 1 / 60, SolveDescription(1, 1), cb)
+        drift[m] = float(np.linalg.norm(_angular_momentum(scene.bodies[0]) - L0) / np.linalg.norm(L0))
+    assert drift[0] > 0.05                       # plain integration does not conserve it
+    if mode == 1:
+        assert drift[mode] < 1e-4, drift         # exact up to rounding: w' = I_world'^-1 (R I R^T w)
+    else:
+        assert drift[mode] < drift[0] / 2, drift  # one implicit Newton step per frame: damped ("applies a damping effect", PoseIntegrator.cs:34), still far better
+
+
+def test_gyroscopic_step_matches_an_independent_transcription():
+    """One unconstrained step in ConserveMomentumWithGyroscopicTorque mode against a float64 numpy transcription of PoseIntegrator.cs:209-253 written
+    from the C# separately from oracle/bepu_math.h (row-vector convention, Matrix3x3Wide.CreateFromQuaternion rows)."""
+    from bepuphysics2_amd.scene import SceneBuilder, make_body, PoseIntegratorCallbacks, SolveDescription
+
+    def rows(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w)],
+                         [2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w)],
+                         [2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)]])
+
+    def skew(v):
+        return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+    sb = SceneBuilder()
+    sb.add_body(make_body(orientation=(0.1, 0.2, 0.3, 0.927), angular=(1.0, 2.0, 0.5), inverse_inertia=(1.0, 0.05, 0.25, 0.02, 0.03, 4.0)))
+    scene = sb.build()
+    scene.bodies[0, 0:4] /= np.linalg.norm(scene.bodies[0, 0:4])
+    b0 = scene.bodies[0].astype(np.float64).copy()
+    oracle_ffi.solve(scene, 1 / 60, SolveDescription(1, 1), PoseIntegratorCallbacks(gravity=(0, 0, 0), linear_damping=0, angular_damping=0, angular_integration_mode=2))
+    dt = float(np.float32(1 / 60))
+    q0, w = b0[0:4], b0[12:15]
+    xx, yx, yy, zx, zy, zz = b0[16:22]
+    inertia = np.linalg.inv(np.array([[xx, yx, zx], [yx, yy, zy], [zx, zy, zz]]))
+    speed = np.linalg.norm(w)
+    dq = np.array([*(w * (np.sin(speed * dt * 0.5) / speed)), np.cos(speed * dt * 0.5)])
+    a, b = q0, dq  # QuaternionWide.ConcatenateWithoutOverlap(a, b): a then b
+    q1 = np.array([a[3] * b[0] + a[0] * b[3] + a[2] * b[1] - a[1] * b[2], a[3] * b[1] + a[1] * b[3] + a[0] * b[2] - a[2] * b[0],
+                   a[3] * b[2] + a[2] * b[3] + a[1] * b[0] - a[0] * b[1], a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]])
+    q1 /= np.linalg.norm(q1)
+    m = rows(q1)
+    lw = m @ w                      # TransformByTransposed
+    momentum = lw @ inertia
+    jac = inertia + dt * (skew(lw) @ inertia - skew(momentum))
+    lw1 = lw - (dt * np.cross(momentum, lw)) @ np.linalg.inv(jac)
+    assert np.allclose(scene.bodies[0, 12:15], lw1 @ m, rtol=2e-6, atol=1e-6)
+    assert np.allclose(scene.bodies[0, 0:4], q1, rtol=0, atol=1e-6)
+
+
+def test_conserving_modes_leave_kinematic_and_locked_bodies_alone():
+    """FallbackIfInertiaIncompatible (PoseIntegrator.cs:179-190): inverting a zero inverse inertia gives inf/NaN, the previous velocity is kept."""
+    from bepuphysics2_amd.scene import SceneBuilder, make_body, PoseIntegratorCallbacks, SolveDescription
+    for mode in (1, 2):
+        sb = SceneBuilder()
+        sb.add_body(make_body(angular=(0.3, -0.2, 0.9), inverse_inertia=(0,) * 6, inverse_mass=0.0))
+        scene = sb.build()
+        oracle_ffi.solve(scene, 1 / 60, SolveDescription(1, 2), PoseIntegratorCallbacks(angular_integration_mode=mode))
+        assert np.array_equal(scene.bodies[0, 12:15], np.asarray([0.3, -0.2, 0.9], dtype=np.float32))
+        assert np.isfinite(scene.bodies).all()
