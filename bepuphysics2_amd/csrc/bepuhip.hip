@@ -58,14 +58,15 @@ struct DevTypeBatch {
 };
 
 // ---- cluster path descriptors (see cluster_kernel) ----
-constexpr int kMaxPreds = 8;
+constexpr int kMaxPreds = 6;
 constexpr int kFallbackBatchLimit = 64;
 struct ClusterItem {  // <= 64 consecutive constraints of one type batch, all owned by one cluster; 64 bytes, staged in LDS
     int type_id, count, stride, start;                // start: index of the first constraint inside the (reordered) type batch
     unsigned lrefs_off, prestep_off, accum_off;       // word offsets into the constraint slab: lrefs[bodies][stride], prestep[pf][stride], accum[imf][stride]
-    int batch_npred;                                  // bits 0-15 batch, 16-23 predecessor count, 24 overflow (wait for all earlier batches instead)
-    unsigned short pred[kMaxPreds];                   // cluster-relative indices of the items that last touched this item's dynamic bodies
-    int tb, bodies, pf, imf;                          // host bookkeeping
+    int batch_npred;                                  // bits 0-15 batch, 16-19 predecessor count, 20-23 cross-pass predecessor count, 24 / 25 overflow flags
+    unsigned short pred[kMaxPreds];                   // cluster-relative indices of the items that last touched this item's dynamic bodies (same pass)
+    unsigned short xpred[kMaxPreds];                  // for bodies this item touches FIRST in a pass: their last toucher (previous pass); may be the item itself
+    int tb, shape;                                    // host bookkeeping: type batch, bodies | prestep floats << 8 | impulse floats << 16
 };
 static_assert(sizeof(ClusterItem) == 64, "ClusterItem is staged in LDS as four 16-byte vectors");
 struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
@@ -433,6 +434,7 @@ struct ClusterShared {
     lds_u32* batch_done;      // per batch: items completed, monotonic over passes (fallback for items with too many predecessors)
     int* lbib;                // batch -> first item of the cluster (batch_count + 1 entries)
     lds_u32* counter;         // item claim counter, monotonic
+    int batch_count;
     unsigned* status;      // global: [0] != 0 when a wait ran out of patience (a scheduling bug, never expected); [1..7] first offender
 };
 
@@ -467,7 +469,7 @@ __device__ __forceinline__ void store_velocity_lds(const ClusterShared& sh, int 
 
 
 struct ItemHeader {  // wave-uniform copy of the fields the constraint code needs (SGPRs)
-    int type_id, count, stride, start, batch, npred, overflow, bodies, pf, imf;
+    int type_id, count, stride, start, batch, npred, nxpred, overflow, xoverflow;
     unsigned lrefs_off, prestep_off, accum_off;
 };
 
@@ -481,10 +483,7 @@ __device__ __forceinline__ ItemHeader read_item(const ClusterItem* it) {
     h.prestep_off = __builtin_amdgcn_readfirstlane(it->prestep_off);
     h.accum_off = __builtin_amdgcn_readfirstlane(it->accum_off);
     const int packed = __builtin_amdgcn_readfirstlane(it->batch_npred);
-    h.batch = packed & 0xFFFF; h.npred = (packed >> 16) & 0xFF; h.overflow = (packed >> 24) & 0xFF;
-    h.bodies = __builtin_amdgcn_readfirstlane(it->bodies);
-    h.pf = __builtin_amdgcn_readfirstlane(it->pf);
-    h.imf = __builtin_amdgcn_readfirstlane(it->imf);
+    h.batch = packed & 0xFFFF; h.npred = (packed >> 16) & 0xF; h.nxpred = (packed >> 20) & 0xF; h.overflow = (packed >> 24) & 1; h.xoverflow = (packed >> 25) & 1;
     return h;
 }
 
@@ -531,41 +530,50 @@ __device__ __noinline__ void report_stall(unsigned* status, unsigned claims, int
         status[5] = want; status[6] = seen; status[7] = claims;
     }
 }
-// Block until every predecessor of the item has published `epoch` (all lanes read the same LDS word: one broadcast ds_read).
+// One bounded poll loop (all lanes read the same LDS word: a broadcast ds_read).
+__device__ __forceinline__ void wait_word(const ClusterShared& sh, const volatile lds_u32* word, unsigned want, int kind, int k, int what) {
+    unsigned spins = 0, seen;
+    while ((seen = (unsigned)__builtin_amdgcn_readfirstlane((int)*word)) < want) {
+        __builtin_amdgcn_s_sleep(1);  // 64 clocks; polling back to back or sleeping twice as long measures the same
+        if (++spins > kSpinLimit) { report_stall(sh.status, *sh.counter, kind, k, what, want, seen); break; }
+        if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
+    }
+}
+// Block until every predecessor of the item has published: same-pass predecessors must have finished `epoch`; with CROSS (a Solve item: the warm start
+// pass before it is not separated by a barrier) the last touchers of the bodies this item touches first must have finished `epoch - 1`.
+template <bool CROSS>
 __device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, unsigned epoch) {
     for (int q = 0; q < h.npred; ++q) {
         const int pred = __builtin_amdgcn_readfirstlane((int)it->pred[q]);
-        unsigned spins = 0, seen;
-        while ((seen = (unsigned)__builtin_amdgcn_readfirstlane((int)sh.flags[pred])) < epoch) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit) { report_stall(sh.status, *sh.counter, 1, k, pred, epoch, seen); break; }
-            if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
+        wait_word(sh, sh.flags + pred, epoch, 1, k, pred);
+    }
+    if (CROSS) {
+        for (int q = 0; q < h.nxpred; ++q) {
+            const int pred = __builtin_amdgcn_readfirstlane((int)it->xpred[q]);
+            wait_word(sh, sh.flags + pred, epoch - 1, 3, k, pred);
         }
     }
     if (h.overflow) {  // more predecessors than the item records: wait for every item of every earlier batch
-        for (int b = 0; b < h.batch; ++b) {
-            const unsigned want = epoch * (unsigned)__builtin_amdgcn_readfirstlane(sh.lbib[b + 1] - sh.lbib[b]);
-            unsigned spins = 0, seen;
-            while ((seen = (unsigned)__builtin_amdgcn_readfirstlane((int)((volatile lds_u32*)sh.batch_done)[b])) < want) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > kSpinLimit) { report_stall(sh.status, *sh.counter, 2, k, b, want, seen); break; }
-                if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            }
-        }
+        for (int b = 0; b < h.batch; ++b)
+            wait_word(sh, (const volatile lds_u32*)sh.batch_done + b, epoch * (unsigned)__builtin_amdgcn_readfirstlane(sh.lbib[b + 1] - sh.lbib[b]), 2, k, b);
+    }
+    if (CROSS && h.xoverflow) {  // ... and for the whole previous pass
+        for (int b = 0; b < sh.batch_count; ++b)
+            wait_word(sh, (const volatile lds_u32*)sh.batch_done + b, (epoch - 1) * (unsigned)__builtin_amdgcn_readfirstlane(sh.lbib[b + 1] - sh.lbib[b]), 4, k, b);
     }
     asm volatile("" ::: "memory");  // nothing below may be hoisted above the polls
 }
 
-struct ItemStamps { unsigned long long loaded, pre_gate, post_gate; };
+struct ItemStamps { unsigned long long loaded, pre_gate, post_gate; };  // trace builds only
 
 // The gate the cluster path hands to the constraint functions: wait for the item's predecessors, then gather the velocities.
-template <int ACC_A, int ACC_B, int BODIES, bool TRACE>
+template <int ACC_A, int ACC_B, int BODIES, bool CROSS, bool TRACE>
 struct ClusterGate {
     static constexpr bool kPin = true;  // the constraint pins its velocity-independent values before calling: they are computed while the predecessors still run
     const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; int ra, rb; DBody& A; DBody& B; ItemStamps& stamps;
     __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {
         if (TRACE) stamps.pre_gate = __builtin_readcyclecounter();
-        wait_predecessors(sh, it, h, k, epoch);
+        wait_predecessors<CROSS>(sh, it, h, k, epoch);
         if (TRACE) stamps.post_gate = __builtin_readcyclecounter();
         load_velocity_lds<ACC_A>(sh, ra, A);
         if (BODIES == 2) load_velocity_lds<ACC_B>(sh, rb, B);
@@ -608,7 +616,7 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     load_body_lds<accA & ~(kLin | kAng)>(sh, ra, A);
     if (F::bodies == 2) load_body_lds<accB & ~(kLin | kAng)>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
     if (TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps.loaded = __builtin_readcyclecounter(); }
-    ClusterGate<accA, accB, F::bodies, TRACE> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps};
+    ClusterGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps};
     if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, gate);
     else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, gate);
     store_velocity_lds<accA>(sh, active ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references)
@@ -643,23 +651,33 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
 #undef BEPU_CASE
 }
 
-// One WarmStart or Solve sweep over the cluster's batches (Solver_Solve.cs:1447-1476 for the cluster's islands).
-template <int STAGE, bool TRACE>
-__device__ __forceinline__ void run_cluster_pass(const ClusterShared& sh, int item_count, int lane, int wave, unsigned epoch, unsigned claim_base,
-                                                 unsigned* __restrict__ slab, float dt, float inv_dt, unsigned long long* trace) {
+// A sweep over the cluster's batches (Solver_Solve.cs:1447-1476 for the cluster's islands): the items of a WarmStart pass (epoch `epoch`) followed,
+// when `solve_items` > 0, by the items of the first velocity iteration (epoch + 1) in ONE claim sequence. No barrier separates the two: a Solve item
+// waits for its same-pass predecessors and, for the bodies it is the first to touch, for their last toucher of the warm start (cross-pass
+// predecessors), so the head of the iteration runs while the tail of the warm start's dependency chain is still draining. The warm start does
+// not write accumulated impulses, hence nothing the iteration loads from HBM is in flight. STAGE0 = kStageSolve with solve_items = 0 runs a
+// later iteration on its own (a barrier precedes it: its impulses were stored by the previous one).
+template <int STAGE0, bool TRACE>
+__device__ __forceinline__ void run_cluster_sweep(const ClusterShared& sh, int item_count, int solve_items, int lane, int wave, unsigned epoch, unsigned claim_base,
+                                                  unsigned* __restrict__ slab, float dt, float inv_dt, unsigned long long* trace) {
     for (;;) {
-        const int k = (int)(claim_next(sh.counter) - claim_base);
-        if (k >= item_count) break;
+        const int v = (int)(claim_next(sh.counter) - claim_base);
+        if (v >= item_count + solve_items) break;
+        const bool second = v >= item_count;
+        const int k = second ? v - item_count : v;
+        const unsigned item_epoch = second ? epoch + 1 : epoch;
         const ClusterItem* it = sh.items + k;
         const ItemHeader h = read_item(it);
         unsigned long long t0 = 0;
         if (TRACE) t0 = __builtin_readcyclecounter();
         ItemStamps stamps = {0, 0, 0};
-        run_cluster_item<STAGE, TRACE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps);
+        if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+        else run_cluster_item<kStageSolve, TRACE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
         if (TRACE && trace && blockIdx.x == 0 && lane == 0) {
-            unsigned long long* rec = trace + ((size_t)(epoch - 1) * item_count + k) * 8;
+            unsigned long long* rec = trace + ((size_t)(item_epoch - 1) * item_count + k) * 8;
             rec[4] = stamps.loaded; rec[5] = stamps.pre_gate; rec[6] = stamps.post_gate; rec[7] = 0;
-            rec[0] = t0; rec[1] = __builtin_readcyclecounter(); rec[2] = (unsigned long long)wave | ((unsigned long long)h.type_id << 8) | ((unsigned long long)h.batch << 16) | ((unsigned long long)STAGE << 32);
+            rec[0] = t0; rec[1] = __builtin_readcyclecounter();
+            rec[2] = (unsigned long long)wave | ((unsigned long long)h.type_id << 8) | ((unsigned long long)h.batch << 16) | ((unsigned long long)((STAGE0 == kStageWarmStart && !second) ? kStageWarmStart : kStageSolve) << 32);
             rec[3] = (unsigned long long)h.count;
         }
     }
@@ -682,6 +700,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.lbib = reinterpret_cast<int*>(words + max_items + kFallbackBatchLimit + 1);
     sh.counter = (lds_u32*)(words + max_items + 2 * (kFallbackBatchLimit + 1) + 1);
     sh.status = status;
+    sh.batch_count = cp.batch_count;
     const ClusterDesc cd = clusters[blockIdx.x];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
@@ -749,12 +768,14 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         }
         __syncthreads();
         ++epoch;
-        run_cluster_pass<kStageWarmStart, TRACE>(sh, cd.item_count, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
-        claim_base += cd.item_count + nwaves;  // every wave makes exactly one failing claim per pass
+        const int fused = cp.iters[s] > 0 ? cd.item_count : 0;  // the first velocity iteration rides in the warm start's claim sequence
+        run_cluster_sweep<kStageWarmStart, TRACE>(sh, cd.item_count, fused, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+        claim_base += cd.item_count + fused + nwaves;  // every wave makes exactly one failing claim per sweep
+        if (fused) ++epoch;
         __syncthreads();
-        for (int iter = 0; iter < cp.iters[s]; ++iter) {
+        for (int iter = 1; iter < cp.iters[s]; ++iter) {
             ++epoch;
-            run_cluster_pass<kStageSolve, TRACE>(sh, cd.item_count, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+            run_cluster_sweep<kStageSolve, TRACE>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
             claim_base += cd.item_count + nwaves;
             __syncthreads();
         }
@@ -1061,6 +1082,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     std::vector<std::vector<int32_t>> last_toucher(nclusters);  // by slot: cluster-relative index of the item that last touched the (dynamic) body
     for (int cl = 0; cl < nclusters; ++cl) last_toucher[cl].assign((cl_bodies[cl].size() + 15) / 16 * 16, -1);
     std::vector<std::vector<ClusterItem>> cl_items(nclusters);
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> first_touch(nclusters);  // (item, slot): the item is the slot's first toucher in a pass
     for (size_t t = 0; t < c->tbs.size(); ++t) {
         HostTypeBatch& tb = c->tbs[t];
         const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
@@ -1089,7 +1111,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                 ClusterItem it;
                 memset(&it, 0, sizeof(it));
                 it.type_id = tb.type_id; it.count = std::min(64, e - s0); it.stride = tb.stride; it.start = s0;
-                it.tb = (int)t; it.bodies = nb; it.pf = pf; it.imf = imf;
+                it.tb = (int)t; it.shape = nb | (pf << 8) | (imf << 16);
                 const int self = (int)cl_items[cl].size();
                 int npred = 0, overflow = 0;
                 std::vector<int32_t>& lt = last_toucher[cl];
@@ -1099,7 +1121,8 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                         if ((uint32_t)lr >= kDynamicLimit) continue;
                         if ((size_t)lr >= lt.size()) lt.resize((size_t)lr + 16, -1);
                         const int pred = lt[lr];
-                        if (pred < 0 || pred == self) continue;
+                        if (pred < 0) { first_touch[cl].push_back({self, lr}); continue; }  // this item is the body's first toucher in a pass
+                        if (pred == self) continue;
                         bool known = false;
                         for (int q = 0; q < npred; ++q) known |= it.pred[q] == pred;
                         if (known) continue;
@@ -1115,6 +1138,20 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                 cl_items[cl].push_back(it);
             }
             d = e;
+        }
+    }
+    // Cross-pass predecessors: the last toucher (end of a pass) of every body an item touches first.
+    for (int cl = 0; cl < nclusters; ++cl) {
+        for (auto& fs : first_touch[cl]) {
+            ClusterItem& it = cl_items[cl][fs.first];
+            const int last = last_toucher[cl][fs.second];
+            int nx = (it.batch_npred >> 20) & 0xF;
+            if ((it.batch_npred >> 25) & 1) continue;
+            bool known = false;
+            for (int q = 0; q < nx; ++q) known |= it.xpred[q] == last;
+            if (known) continue;
+            if (nx < kMaxPreds) { it.xpred[nx++] = (unsigned short)last; it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (nx << 20); }
+            else it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (1 << 25);
         }
     }
     for (int cl = 0; cl < nclusters; ++cl) {
