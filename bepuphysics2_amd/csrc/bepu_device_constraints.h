@@ -19,7 +19,7 @@ enum TypeId {
     kContact1OneBody = 0, kContact2OneBody = 1, kContact3OneBody = 2, kContact4OneBody = 3,
     kContact1 = 4, kContact2 = 5, kContact3 = 6, kContact4 = 7,
     kBallSocket = 22, kAngularHinge = 23, kSwingLimit = 25, kTwistServo = 26, kTwistLimit = 27,
-    kAngularMotor = 30, kSwivelHinge = 46, kHinge = 47,
+    kAngularMotor = 30, kWeld = 31, kSwivelHinge = 46, kHinge = 47,
 };
 
 // ======================================================================================
@@ -926,5 +926,78 @@ struct Hinge {
         applyImpulse(offsetA, offsetB, hingeJacobian, iA, iB, csiBall, csiHinge, vA, vB);
     }
 };
+
+// ======================================================================================
+// Weld — BepuPhysics/Constraints/Weld.cs:70-215 (6 DOF; Symmetric6x6Wide.LDLTSolve, BepuUtilities/Symmetric6x6Wide.cs:84-129).
+// Prestep: LocalOffset xyz, LocalOrientation xyzw, spring{freq, 2*damp}. Impulses: Orientation xyz, Offset xyz.
+// ======================================================================================
+struct Weld {
+    static constexpr int bodies = 2, prestepFloats = 9, impulseFloats = 6, typeId = kWeld;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessNoPosition, wsB = kAccessNoPose, svA = kAccessAll, svB = kAccessAll;  // Weld.cs:212
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    BD_FN void applyImpulse(const Inertia& iA, const Inertia& iB, V3 offset, V3 orientationCSI, V3 offsetCSI, BodyVel& vA, BodyVel& vB) {  // :85-113
+        V3 linearChangeA = scale(offsetCSI, iA.invMass);
+        vA.lin = add(vA.lin, linearChangeA);
+        V3 offsetWorldImpulse = cross(offset, offsetCSI);
+        V3 angularImpulseA = add(offsetWorldImpulse, orientationCSI);
+        V3 angularChangeA = transform(angularImpulseA, iA.t);
+        vA.ang = add(vA.ang, angularChangeA);
+        V3 negatedLinearChangeB = scale(offsetCSI, iB.invMass);
+        vB.lin = sub(vB.lin, negatedLinearChangeB);
+        V3 negatedAngularChangeB = transform(orientationCSI, iB.t);
+        vB.ang = sub(vB.ang, negatedAngularChangeB);
+    }
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :116-121
+        V3 offset = transform(V3{p[0], p[1], p[2]}, oA);
+        BD_GATE(vA, vB, offset);
+        applyImpulse(iA, iB, offset, V3{a[0], a[1], a[2]}, V3{a[3], a[4], a[5]}, vA, vB);
+    }
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :123-204
+        V3 offset = transform(V3{p[0], p[1], p[2]}, oA);
+        Sym3 jmjtA = add(iA.t, iB.t);
+        M3 xAB = createCrossProduct(offset);
+        M3 jmjtB = multiply(iA.t, xAB);
+        Sym3 jmjtD = completeMatrixSandwichTranspose(xAB, jmjtB);
+        float diagonalAdd = iA.invMass + iB.invMass;
+        jmjtD.xx += diagonalAdd;
+        jmjtD.yy += diagonalAdd;
+        jmjtD.zz += diagonalAdd;
+        V3 positionError = sub(sub(pB, pA), offset);
+        Q targetOrientationB = concatenate(Q{p[3], p[4], p[5], p[6]}, oA);
+        Q rotationError = concatenate(conjugate(targetOrientationB), oB);
+        V3 rotationErrorAxis; float rotationErrorLength;
+        getAxisAngleFromQuaternion(rotationError, rotationErrorAxis, rotationErrorLength);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[7], p[8], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        V3 orientationBiasVelocity = scale(rotationErrorAxis, rotationErrorLength * posErrToVel);
+        V3 offsetBiasVelocity = scale(positionError, posErrToVel);
+        LDLT6 factor = ldltFactor(jmjtA, jmjtB, jmjtD);  // the factorisation half of LDLTSolve needs no velocity
+        BD_GATE(vA, vB, offset, factor, orientationBiasVelocity, offsetBiasVelocity, effMassCFMScale, softnessImpulseScale);
+        V3 orientationCSV, offsetCSV;
+        orientationCSV.x = orientationBiasVelocity.x - vA.ang.x + vB.ang.x;
+        orientationCSV.y = orientationBiasVelocity.y - vA.ang.y + vB.ang.y;
+        orientationCSV.z = orientationBiasVelocity.z - vA.ang.z + vB.ang.z;
+        offsetCSV.x = offsetBiasVelocity.x - vA.lin.x + vB.lin.x - (vA.ang.y * offset.z - vA.ang.z * offset.y);
+        offsetCSV.y = offsetBiasVelocity.y - vA.lin.y + vB.lin.y - (vA.ang.z * offset.x - vA.ang.x * offset.z);
+        offsetCSV.z = offsetBiasVelocity.z - vA.lin.z + vB.lin.z - (vA.ang.x * offset.y - vA.ang.y * offset.x);
+        V3 orientationCSI, offsetCSI;
+        ldltSubstitute(factor, orientationCSV, offsetCSV, orientationCSI, offsetCSI);
+        orientationCSI.x = orientationCSI.x * effMassCFMScale - a[0] * softnessImpulseScale;
+        orientationCSI.y = orientationCSI.y * effMassCFMScale - a[1] * softnessImpulseScale;
+        orientationCSI.z = orientationCSI.z * effMassCFMScale - a[2] * softnessImpulseScale;
+        a[0] += orientationCSI.x; a[1] += orientationCSI.y; a[2] += orientationCSI.z;
+        offsetCSI.x = offsetCSI.x * effMassCFMScale - a[3] * softnessImpulseScale;
+        offsetCSI.y = offsetCSI.y * effMassCFMScale - a[4] * softnessImpulseScale;
+        offsetCSI.z = offsetCSI.z * effMassCFMScale - a[5] * softnessImpulseScale;
+        a[3] += offsetCSI.x; a[4] += offsetCSI.y; a[5] += offsetCSI.z;
+        applyImpulse(iA, iB, offset, orientationCSI, offsetCSI, vA, vB);
+    }
+};
+
+// Every non-contact type, for the dispatch switches: X(type id, struct).
+#define BD_JOINT_TYPES(X)                                                                                                     \
+    X(kBallSocket, BallSocket) X(kAngularHinge, AngularHinge) X(kSwingLimit, SwingLimit) X(kTwistServo, TwistServo)                 \
+    X(kTwistLimit, TwistLimit) X(kAngularMotor, AngularMotor) X(kWeld, Weld) X(kSwivelHinge, SwivelHinge) X(kHinge, Hinge)
 
 }  // namespace bd

@@ -172,14 +172,9 @@ __global__ __launch_bounds__(kBlock) void batch_kernel(const DevTypeBatch* __res
     }
     if (STAGE == kStageIncremental) return;  // only contacts need incremental updates (RequiresIncrementalSubstepUpdates)
     switch (tb.type_id) {
-        case kBallSocket: run_constraint<BallSocket, STAGE>(tb, i, bodies, dt, inv_dt); break;
-        case kAngularHinge: run_constraint<AngularHinge, STAGE>(tb, i, bodies, dt, inv_dt); break;
-        case kSwingLimit: run_constraint<SwingLimit, STAGE>(tb, i, bodies, dt, inv_dt); break;
-        case kTwistServo: run_constraint<TwistServo, STAGE>(tb, i, bodies, dt, inv_dt); break;
-        case kTwistLimit: run_constraint<TwistLimit, STAGE>(tb, i, bodies, dt, inv_dt); break;
-        case kAngularMotor: run_constraint<AngularMotor, STAGE>(tb, i, bodies, dt, inv_dt); break;
-        case kSwivelHinge: run_constraint<SwivelHinge, STAGE>(tb, i, bodies, dt, inv_dt); break;
-        case kHinge: run_constraint<Hinge, STAGE>(tb, i, bodies, dt, inv_dt); break;
+#define X(ID, T) case ID: run_constraint<T, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        BD_JOINT_TYPES(X)
+#undef X
         default: break;
     }
 }
@@ -640,9 +635,7 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
         default:
             if constexpr (STAGE != kStageIncremental) {  // only contacts need incremental updates (RequiresIncrementalSubstepUpdates)
                 switch (h.type_id) {
-                    BEPU_CASE(kBallSocket, BallSocket) BEPU_CASE(kAngularHinge, AngularHinge) BEPU_CASE(kSwingLimit, SwingLimit)
-                    BEPU_CASE(kTwistServo, TwistServo) BEPU_CASE(kTwistLimit, TwistLimit) BEPU_CASE(kAngularMotor, AngularMotor)
-                    BEPU_CASE(kSwivelHinge, SwivelHinge) BEPU_CASE(kHinge, Hinge)
+                    BD_JOINT_TYPES(BEPU_CASE)
                     default: break;
                 }
             }
@@ -825,9 +818,9 @@ static bool type_info(int id, TypeInfoH& t) {
         case kContact3OneBody: TI(C3O) case kContact4OneBody: TI(C4O)
         case kContact1: TI(C1T) case kContact2: TI(C2T)
         case kContact3: TI(C3T) case kContact4: TI(C4T)
-        case kBallSocket: TI(BallSocket) case kAngularHinge: TI(AngularHinge) case kSwingLimit: TI(SwingLimit)
-        case kTwistServo: TI(TwistServo) case kTwistLimit: TI(TwistLimit) case kAngularMotor: TI(AngularMotor)
-        case kSwivelHinge: TI(SwivelHinge) case kHinge: TI(Hinge)
+#define X(ID, T) case ID: TI(T)
+        BD_JOINT_TYPES(X)
+#undef X
     }
 #undef TI
     return false;

@@ -34,6 +34,7 @@ bool GetTypeInfo(int typeId, TypeInfo& info) {
         case 27: info = {2, 12, 1, false}; return true;  // TwistLimit
         case 30: info = {2, 5, 3, false}; return true;   // AngularMotor
         case 46: info = {2, 14, 4, false}; return true;  // SwivelHinge
+        case 31: info = {2, 9, 6, false}; return true;   // Weld (Weld.cs:70-81, :224)
         case 47: info = {2, 14, 5, false}; return true;  // Hinge
     }
     return false;

@@ -20,6 +20,7 @@ ACCESS = {
     "SwingLimit": (ONLY_ANGULAR,) * 4, "TwistServo": (ONLY_ANGULAR,) * 4, "TwistLimit": (ONLY_ANGULAR,) * 4,
     "AngularMotor": (ONLY_ANGULAR_NO_POSE, ONLY_ANGULAR_NO_POSE, ONLY_ANGULAR, ONLY_ANGULAR_NO_POSE),
     "SwivelHinge": (NO_POSITION, NO_POSITION, ALL, ALL), "Hinge": (NO_POSITION, NO_POSITION, ALL, ALL),
+    "Weld": (NO_POSITION, NO_POSE, ALL, ALL),
 }
 
 

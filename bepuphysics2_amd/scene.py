@@ -25,9 +25,13 @@ TYPE_TABLE: Dict[int, tuple] = {
     0: (1, 11, 4, "Contact1OneBody"), 1: (1, 15, 5, "Contact2OneBody"), 2: (1, 19, 6, "Contact3OneBody"), 3: (1, 23, 7, "Contact4OneBody"),
     4: (2, 14, 4, "Contact1"), 5: (2, 18, 5, "Contact2"), 6: (2, 22, 6, "Contact3"), 7: (2, 26, 7, "Contact4"),
     22: (2, 8, 3, "BallSocket"), 23: (2, 8, 2, "AngularHinge"), 25: (2, 9, 1, "SwingLimit"), 26: (2, 14, 1, "TwistServo"),
-    27: (2, 12, 1, "TwistLimit"), 30: (2, 5, 3, "AngularMotor"), 46: (2, 14, 4, "SwivelHinge"), 47: (2, 14, 5, "Hinge"),
+    27: (2, 12, 1, "TwistLimit"), 30: (2, 5, 3, "AngularMotor"), 31: (2, 9, 6, "Weld"), 46: (2, 14, 4, "SwivelHinge"), 47: (2, 14, 5, "Hinge"),
 }
 TYPE_IDS_BY_NAME = {v[3]: k for k, v in TYPE_TABLE.items()}
+# The sixteen types of SURVEY.md 8(a) rows a7-a13 (the committed tests/golden/small_scenes.npz fixtures were generated from exactly these).
+HOT_PATH_TYPES = [0, 1, 2, 3, 4, 5, 6, 7, 22, 23, 25, 26, 27, 30, 46, 47]
+# 8(f) widening, one type at a time.
+WIDENED_TYPES = [t for t in sorted(TYPE_TABLE) if t not in HOT_PATH_TYPES]
 
 
 def bundle_count(count: int, w: int = BUNDLE_WIDTH) -> int:

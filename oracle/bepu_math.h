@@ -529,4 +529,83 @@ static inline V3 integrateAngularVelocityConserveMomentumWithGyroscopicTorque(Q 
     return fallbackIfInertiaIncompatible(angularVelocity, newVelocity);
 }
 
+// ---- helpers of the Weld constraint ----
+static inline Q conjugate(Q q) { return {q.x, q.y, q.z, -q.w}; }                                    // QuaternionWide.cs:546-552 (negates W)
+static inline void getAxisAngleFromQuaternion(Q q, V3& axis, float& angle) {                       // QuaternionWide.cs:227-243
+    bool shouldNegate = q.w < 0.0f;
+    axis = {sel(shouldNegate, -q.x, q.x), sel(shouldNegate, -q.y, q.y), sel(shouldNegate, -q.z, q.z)};
+    float qw = sel(shouldNegate, -q.w, q.w);
+    float axisLength = length(axis);
+    axis = scale(axis, 1.0f / axisLength);
+    bool useFallback = axisLength < 1e-14f;
+    axis = {sel(useFallback, 1.0f, axis.x), sel(useFallback, 0.0f, axis.y), sel(useFallback, 0.0f, axis.z)};
+    float halfAngle = bacos(qw);
+    angle = 2.0f * halfAngle;
+}
+static inline M3 multiply(const Sym3& a, const M3& b) {                                            // Symmetric3x3Wide.cs:343-356
+    M3 r;
+    r.X = {a.xx * b.X.x + a.yx * b.Y.x + a.zx * b.Z.x, a.xx * b.X.y + a.yx * b.Y.y + a.zx * b.Z.y, a.xx * b.X.z + a.yx * b.Y.z + a.zx * b.Z.z};
+    r.Y = {a.yx * b.X.x + a.yy * b.Y.x + a.zy * b.Z.x, a.yx * b.X.y + a.yy * b.Y.y + a.zy * b.Z.y, a.yx * b.X.z + a.yy * b.Y.z + a.zy * b.Z.z};
+    r.Z = {a.zx * b.X.x + a.zy * b.Y.x + a.zz * b.Z.x, a.zx * b.X.y + a.zy * b.Y.y + a.zz * b.Z.y, a.zx * b.X.z + a.zy * b.Y.z + a.zz * b.Z.z};
+    return r;
+}
+static inline Sym3 completeMatrixSandwichTranspose(const M3& a, const M3& b) {                     // Symmetric3x3Wide.cs:508-518
+    Sym3 r;
+    r.xx = a.X.x * b.X.x + a.Y.x * b.Y.x + a.Z.x * b.Z.x;
+    r.yx = a.X.y * b.X.x + a.Y.y * b.Y.x + a.Z.y * b.Z.x;
+    r.yy = a.X.y * b.X.y + a.Y.y * b.Y.y + a.Z.y * b.Z.y;
+    r.zx = a.X.z * b.X.x + a.Y.z * b.Y.x + a.Z.z * b.Z.x;
+    r.zy = a.X.z * b.X.y + a.Y.z * b.Y.y + a.Z.z * b.Z.y;
+    r.zz = a.X.z * b.X.z + a.Y.z * b.Y.z + a.Z.z * b.Z.z;
+    return r;
+}
+// Symmetric6x6Wide.LDLTSolve (Symmetric6x6Wide.cs:84-129) in two halves: the factorisation of [a b^T; b d] depends on the matrix only, the
+// substitution on the right-hand side; every operation and its order are the reference's.
+struct LDLT6 { float inverseD1, inverseD2, inverseD3, inverseD4, inverseD5, inverseD6, l21, l31, l41, l51, l61, l32, l42, l52, l62, l43, l53, l63, l54, l64, l65; };
+static inline LDLT6 ldltFactor(const Sym3& a, const M3& b, const Sym3& d) {
+    LDLT6 f;
+    float d1 = a.xx;
+    f.inverseD1 = 1.0f / d1;
+    f.l21 = f.inverseD1 * a.yx;
+    f.l31 = f.inverseD1 * a.zx;
+    f.l41 = f.inverseD1 * b.X.x;
+    f.l51 = f.inverseD1 * b.X.y;
+    f.l61 = f.inverseD1 * b.X.z;
+    float d2 = a.yy - f.l21 * f.l21 * d1;
+    f.inverseD2 = 1.0f / d2;
+    f.l32 = f.inverseD2 * (a.zy - f.l31 * f.l21 * d1);
+    f.l42 = f.inverseD2 * (b.Y.x - f.l41 * f.l21 * d1);
+    f.l52 = f.inverseD2 * (b.Y.y - f.l51 * f.l21 * d1);
+    f.l62 = f.inverseD2 * (b.Y.z - f.l61 * f.l21 * d1);
+    float d3 = a.zz - f.l31 * f.l31 * d1 - f.l32 * f.l32 * d2;
+    f.inverseD3 = 1.0f / d3;
+    f.l43 = f.inverseD3 * (b.Z.x - f.l41 * f.l31 * d1 - f.l42 * f.l32 * d2);
+    f.l53 = f.inverseD3 * (b.Z.y - f.l51 * f.l31 * d1 - f.l52 * f.l32 * d2);
+    f.l63 = f.inverseD3 * (b.Z.z - f.l61 * f.l31 * d1 - f.l62 * f.l32 * d2);
+    float d4 = d.xx - f.l41 * f.l41 * d1 - f.l42 * f.l42 * d2 - f.l43 * f.l43 * d3;
+    f.inverseD4 = 1.0f / d4;
+    f.l54 = f.inverseD4 * (d.yx - f.l51 * f.l41 * d1 - f.l52 * f.l42 * d2 - f.l53 * f.l43 * d3);
+    f.l64 = f.inverseD4 * (d.zx - f.l61 * f.l41 * d1 - f.l62 * f.l42 * d2 - f.l63 * f.l43 * d3);
+    float d5 = d.yy - f.l51 * f.l51 * d1 - f.l52 * f.l52 * d2 - f.l53 * f.l53 * d3 - f.l54 * f.l54 * d4;
+    f.inverseD5 = 1.0f / d5;
+    f.l65 = f.inverseD5 * (d.zy - f.l61 * f.l51 * d1 - f.l62 * f.l52 * d2 - f.l63 * f.l53 * d3 - f.l64 * f.l54 * d4);
+    float d6 = d.zz - f.l61 * f.l61 * d1 - f.l62 * f.l62 * d2 - f.l63 * f.l63 * d3 - f.l64 * f.l64 * d4 - f.l65 * f.l65 * d5;
+    f.inverseD6 = 1.0f / d6;
+    return f;
+}
+static inline void ldltSubstitute(const LDLT6& f, V3 v0, V3 v1, V3& r0, V3& r1) {
+    r0.x = v0.x;
+    r0.y = v0.y - f.l21 * r0.x;
+    r0.z = v0.z - f.l31 * r0.x - f.l32 * r0.y;
+    r1.x = v1.x - f.l41 * r0.x - f.l42 * r0.y - f.l43 * r0.z;
+    r1.y = v1.y - f.l51 * r0.x - f.l52 * r0.y - f.l53 * r0.z - f.l54 * r1.x;
+    r1.z = v1.z - f.l61 * r0.x - f.l62 * r0.y - f.l63 * r0.z - f.l64 * r1.x - f.l65 * r1.y;
+    r1.z = r1.z * f.inverseD6;
+    r1.y = r1.y * f.inverseD5 - f.l65 * r1.z;
+    r1.x = r1.x * f.inverseD4 - f.l64 * r1.z - f.l54 * r1.y;
+    r0.z = r0.z * f.inverseD3 - f.l63 * r1.z - f.l53 * r1.y - f.l43 * r1.x;
+    r0.y = r0.y * f.inverseD2 - f.l62 * r1.z - f.l52 * r1.y - f.l42 * r1.x - f.l32 * r0.z;
+    r0.x = r0.x * f.inverseD1 - f.l61 * r1.z - f.l51 * r1.y - f.l41 * r1.x - f.l31 * r0.z - f.l21 * r0.y;
+}
+
 }  // namespace bo

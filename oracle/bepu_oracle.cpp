@@ -348,9 +348,9 @@ bool typeInfo(int typeId, int& bodies, int& prestepFloats, int& impulseFloats, b
         case kContact3OneBody: TI(C3O) case kContact4OneBody: TI(C4O)
         case kContact1: TI(C1T) case kContact2: TI(C2T)
         case kContact3: TI(C3T) case kContact4: TI(C4T)
-        case kBallSocket: TI(BallSocket) case kAngularHinge: TI(AngularHinge) case kSwingLimit: TI(SwingLimit)
-        case kTwistServo: TI(TwistServo) case kTwistLimit: TI(TwistLimit) case kAngularMotor: TI(AngularMotor)
-        case kSwivelHinge: TI(SwivelHinge) case kHinge: TI(Hinge)
+#define X(ID, T) case ID: TI(T)
+        BO_JOINT_TYPES(X)
+#undef X
     }
 #undef TI
     return false;
@@ -364,9 +364,9 @@ void runBlock(Ctx& c, Stage stage, int batchIndex, int typeBatchIndex, int subst
         case kContact3OneBody: RT(C3O) case kContact4OneBody: RT(C4O)
         case kContact1: RT(C1T) case kContact2: RT(C2T)
         case kContact3: RT(C3T) case kContact4: RT(C4T)
-        case kBallSocket: RT(BallSocket) case kAngularHinge: RT(AngularHinge) case kSwingLimit: RT(SwingLimit)
-        case kTwistServo: RT(TwistServo) case kTwistLimit: RT(TwistLimit) case kAngularMotor: RT(AngularMotor)
-        case kSwivelHinge: RT(SwivelHinge) case kHinge: RT(Hinge)
+#define X(ID, T) case ID: RT(T)
+        BO_JOINT_TYPES(X)
+#undef X
     }
 #undef RT
 }
@@ -702,9 +702,9 @@ int oracle_constraint_iterate(int type_id, float* bodyA, float* bodyB, float* pr
             case kContact3OneBody: IT(C3O) case kContact4OneBody: IT(C4O)
             case kContact1: IT(C1T) case kContact2: IT(C2T)
             case kContact3: IT(C3T) case kContact4: IT(C4T)
-            case kBallSocket: IT(BallSocket) case kAngularHinge: IT(AngularHinge) case kSwingLimit: IT(SwingLimit)
-            case kTwistServo: IT(TwistServo) case kTwistLimit: IT(TwistLimit) case kAngularMotor: IT(AngularMotor)
-            case kSwivelHinge: IT(SwivelHinge) case kHinge: IT(Hinge)
+#define X(ID, T) case ID: IT(T)
+            BO_JOINT_TYPES(X)
+#undef X
         }
 #undef IT
     }

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 import oracle_ffi  # noqa: E402
 import small_scenes  # noqa: E402
-from bepuphysics2_amd.scene import TYPE_TABLE, PoseIntegratorCallbacks, SolveDescription, make_body  # noqa: E402
+from bepuphysics2_amd.scene import HOT_PATH_TYPES, TYPE_TABLE, WIDENED_TYPES, PoseIntegratorCallbacks, SolveDescription, make_body  # noqa: E402
 
 SPRING = [np.float32(20 * np.float32(np.pi)), np.float32(2)]  # AngularFrequency = 20*pi, TwiceDampingRatio = 2
 
@@ -61,7 +61,7 @@ def main():
 
     scenes = {}
     sd, cb = SolveDescription(2, 8), PoseIntegratorCallbacks()
-    for seed, types in ((1, sorted(TYPE_TABLE.keys())), (2, [0, 1, 2, 3, 4, 5, 6, 7]), (3, [22, 23, 25, 26, 27, 30, 46, 47])):
+    for seed, types in ((1, HOT_PATH_TYPES), (2, [0, 1, 2, 3, 4, 5, 6, 7]), (3, [22, 23, 25, 26, 27, 30, 46, 47])):
         sc = small_scenes.random_graph_scene(seed, 120, 300, types)
         for _ in range(2):
             oracle_ffi.solve(sc, 1 / 60, sd, cb)
@@ -72,6 +72,13 @@ def main():
         oracle_ffi.solve(st, 1 / 60, SolveDescription(4, 1), cb)
     scenes["stack_bodies"] = st.bodies
     np.savez_compressed(os.path.join(HERE, "small_scenes.npz"), **scenes)
+    widened = {}
+    for type_id in WIDENED_TYPES:  # one fixture per added type
+        sc = small_scenes.random_graph_scene(400 + type_id, 120, 300, [type_id])
+        for _ in range(2):
+            oracle_ffi.solve(sc, 1 / 60, sd, cb)
+        widened[f"type{type_id}_bodies"] = sc.bodies
+    np.savez_compressed(os.path.join(HERE, "widened_types.npz"), **widened)
     print("wrote", os.listdir(HERE))
 
 

@@ -71,6 +71,8 @@ def joint_prestep(rng, type_id):
     if name == "AngularMotor":
         settings = [FLOAT_MAX, 1.0 / 0.01] if rng.random() < 0.5 else [rng.uniform(1, 100), rng.uniform(1, 200)]
         return list(rng.uniform(-0.2, 0.2, 3)) + settings
+    if name == "Weld":
+        return list(rng.uniform(-0.5, 0.5, 3)) + list(rand_quat(rng)) + sp
     if name in ("SwivelHinge", "Hinge"):
         return list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + sp
     raise KeyError(name)

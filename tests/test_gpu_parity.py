@@ -8,7 +8,7 @@ import pytest
 
 import parity_util as pu
 import small_scenes
-from bepuphysics2_amd.scene import TYPE_TABLE, PoseIntegratorCallbacks, SolveDescription
+from bepuphysics2_amd.scene import HOT_PATH_TYPES, TYPE_TABLE, WIDENED_TYPES, PoseIntegratorCallbacks, SolveDescription
 
 pytestmark = pytest.mark.gpu
 
@@ -78,12 +78,17 @@ def test_hip_matches_committed_golden_vectors(hip_solver_factory):
     solver = hip_solver_factory()
     sd, cb = SolveDescription(2, 8), PoseIntegratorCallbacks()
     cols = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 13, 14]
-    for seed, types in ((1, sorted(TYPE_TABLE.keys())), (2, [0, 1, 2, 3, 4, 5, 6, 7]), (3, [22, 23, 25, 26, 27, 30, 46, 47])):
+    for seed, types in ((1, HOT_PATH_TYPES), (2, [0, 1, 2, 3, 4, 5, 6, 7]), (3, [22, 23, 25, 26, 27, 30, 46, 47])):
         scene = small_scenes.random_graph_scene(seed, 120, 300, types)
         got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
         assert np.array_equal(got.bodies[:, cols].view(np.int32), g[f"graph{seed}_bodies"][:, cols].view(np.int32))
         imp = np.concatenate([tb.accumulated_lanes().reshape(-1) for b in got.batches for tb in b])
         assert np.array_equal(imp.view(np.int32), g[f"graph{seed}_impulses"].view(np.int32))
+    w = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "widened_types.npz"))
+    for type_id in WIDENED_TYPES:
+        scene = small_scenes.random_graph_scene(400 + type_id, 120, 300, [type_id])
+        got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+        assert np.array_equal(got.bodies[:, cols].view(np.int32), w[f"type{type_id}_bodies"][:, cols].view(np.int32))
 
 
 def test_integrator_modes_and_iteration_schedule(hip_solver_factory):

@@ -8,7 +8,7 @@ import pytest
 
 import oracle_ffi
 import small_scenes
-from bepuphysics2_amd.scene import TYPE_TABLE, PoseIntegratorCallbacks, SolveDescription, make_body
+from bepuphysics2_amd.scene import HOT_PATH_TYPES, TYPE_TABLE, WIDENED_TYPES, PoseIntegratorCallbacks, SolveDescription, make_body
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -57,11 +57,17 @@ def test_golden_vectors_regression():
         assert np.array_equal(acc.view(np.int32), g[f"microv_{name}_acc"].view(np.int32))
     s = np.load(os.path.join(GOLDEN, "small_scenes.npz"))
     sd, cb = SolveDescription(2, 8), PoseIntegratorCallbacks()
-    for seed, types in ((1, sorted(TYPE_TABLE.keys())), (2, [0, 1, 2, 3, 4, 5, 6, 7]), (3, [22, 23, 25, 26, 27, 30, 46, 47])):
+    for seed, types in ((1, HOT_PATH_TYPES), (2, [0, 1, 2, 3, 4, 5, 6, 7]), (3, [22, 23, 25, 26, 27, 30, 46, 47])):
         sc = small_scenes.random_graph_scene(seed, 120, 300, types)
         for _ in range(2):
             oracle_ffi.solve(sc, 1 / 60, sd, cb)
         assert np.array_equal(sc.bodies.view(np.int32), s[f"graph{seed}_bodies"].view(np.int32))
+    w = np.load(os.path.join(GOLDEN, "widened_types.npz"))  # SURVEY 8(f) types, pinned the same way as they are added
+    for type_id in WIDENED_TYPES:
+        sc = small_scenes.random_graph_scene(400 + type_id, 120, 300, [type_id])
+        for _ in range(2):
+            oracle_ffi.solve(sc, 1 / 60, sd, cb)
+        assert np.array_equal(sc.bodies.view(np.int32), w[f"type{type_id}_bodies"].view(np.int32))
 
 
 def _momentum(bodies):
@@ -97,6 +103,8 @@ def test_two_body_constraints_conserve_momentum(type_id):
         off_a = lane[0:3]
         off_b_index = 3 if name == "BallSocket" else 6
         lane[off_b_index:off_b_index + 3] = (pa + off_a) - pb
+    if name == "Weld":  # its linear rows act at B's centre with lever arm LocalOffset on A (Weld.cs:87-112): one world point iff LocalOffset = pB - pA
+        lane[0:3] = pb - pa
     acc = rng.uniform(0, 0.02, TYPE_TABLE[type_id][2]).astype(np.float32)
     bodies0 = np.stack([a, b])
     p0, l0 = _momentum(bodies0)
@@ -250,3 +258,21 @@ def test_conserving_modes_leave_kinematic_and_locked_bodies_alone():
         oracle_ffi.solve(scene, 1 / 60, SolveDescription(1, 2), PoseIntegratorCallbacks(angular_integration_mode=mode))
         assert np.array_equal(scene.bodies[0, 12:15], np.asarray([0.3, -0.2, 0.9], dtype=np.float32))
         assert np.isfinite(scene.bodies).all()
+
+
+def test_weld_removes_relative_motion():
+    """Weld.cs:123-204: with zero position / orientation error the six rows drive wA - wB and vA + wA x offset - vB to zero (rigid coupling)."""
+    rng = np.random.default_rng(77)
+    pa, pb = np.asarray([0.2, -0.1, 0.3], np.float32), np.asarray([0.9, 0.4, -0.2], np.float32)
+    a, b = small_scenes.random_dynamic_body(rng, pa), small_scenes.random_dynamic_body(rng, pb)
+    for body in (a, b):
+        body[0:4] = (0, 0, 0, 1)
+        body[24:31] = body[16:23]
+    lane = np.asarray(list(pb - pa) + [0, 0, 0, 1] + small_scenes.spring(30.0, 1.0), np.float32)
+    acc = np.zeros(6, np.float32)
+    before = np.abs(a[12:15] - b[12:15]).max()
+    oracle_ffi.constraint_iterate(31, a, b, lane, acc, 1 / 60, 40)
+    assert before > 0.1  # the pair started with plenty of relative motion
+    rel_ang = a[12:15] - b[12:15]
+    rel_lin = a[8:11] + np.cross(a[12:15], pb - pa) - b[8:11]
+    assert np.abs(rel_ang).max() < 2e-3 and np.abs(rel_lin).max() < 2e-3, (rel_ang, rel_lin)

@@ -21,7 +21,7 @@ s.set_cluster_trace(True)
 s.solve(1 / 60, sd, cb)
 passes = int((1 + sd.iterations()).sum())
 tr = s.cluster_trace(passes)
-names = {0: "C1o", 1: "C2o", 2: "C3o", 3: "C4o", 4: "C1", 5: "C2", 6: "C3", 7: "C4", 22: "Ball", 23: "AHinge", 24: "Swing", 26: "TServo", 27: "TLimit", 30: "AMotor", 46: "Swivel", 47: "Hinge"}
+names = {0: "C1o", 1: "C2o", 2: "C3o", 3: "C4o", 4: "C1", 5: "C2", 6: "C3", 7: "C4", 22: "Ball", 23: "AHinge", 25: "Swing", 26: "TServo", 27: "TLimit", 30: "AMotor", 31: "Weld", 46: "Swivel", 47: "Hinge"}
 t_first = int(tr[..., 0][tr[..., 0] > 0].min())
 print(f"items per pass: {tr.shape[1]}, passes: {passes}")
 for p in range(passes):
