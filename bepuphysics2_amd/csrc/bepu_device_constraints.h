@@ -14,12 +14,14 @@ namespace bd {
 // BepuPhysics/Constraints/*.cs BatchTypeId constants.
 // Body field access bits (IBodyAccessFilter equivalents).
 enum Access { kPos = 1, kOri = 2, kLin = 4, kAng = 8, kInertia = 16,
-              kAccessAll = 31, kAccessNoPosition = 30, kAccessNoPose = 28, kAccessOnlyAngular = 26, kAccessOnlyAngularWithoutPose = 24, kAccessOnlyVelocity = 12 };
+              kAccessAll = 31, kAccessNoOrientation = 29, kAccessNoPosition = 30, kAccessNoPose = 28, kAccessOnlyAngular = 26, kAccessOnlyAngularWithoutPose = 24, kAccessOnlyVelocity = 12 };
 enum TypeId {
     kContact1OneBody = 0, kContact2OneBody = 1, kContact3OneBody = 2, kContact4OneBody = 3,
     kContact1 = 4, kContact2 = 5, kContact3 = 6, kContact4 = 7,
     kBallSocket = 22, kAngularHinge = 23, kSwingLimit = 25, kTwistServo = 26, kTwistLimit = 27,
     kAngularMotor = 30, kWeld = 31, kSwivelHinge = 46, kHinge = 47,
+    kAngularSwivelHinge = 24, kTwistMotor = 28, kAngularServo = 29, kDistanceServo = 33, kDistanceLimit = 34, kAngularAxisMotor = 41,
+    kOneBodyAngularServo = 42, kOneBodyAngularMotor = 43, kOneBodyLinearServo = 44, kOneBodyLinearMotor = 45, kBallSocketMotor = 52, kBallSocketServo = 53,
 };
 
 // ======================================================================================
@@ -995,9 +997,539 @@ struct Weld {
     }
 };
 
-// Every non-contact type, for the dispatch switches: X(type id, struct).
-#define BD_JOINT_TYPES(X)                                                                                                     \
+// ======================================================================================
+// SURVEY.md 8(f) widening — further constraint types, same template as above (velocity gate, pinned setup).
+// Left out on purpose: CenterDistanceConstraint / CenterDistanceLimit / AreaConstraint / VolumeConstraint use MathHelper.FastReciprocal
+// (BepuUtilities/MathHelper.cs:380-395 = rcpps where AVX/SSE exist): the reference's own result depends on the host CPU's
+// reciprocal approximation, so there is no single bit pattern to match.
+// ======================================================================================
+// ServoSettingsWide (BepuPhysics/Constraints/ServoSettings.cs): prestep order {MaximumSpeed, BaseSpeed, MaximumForce}.
+BD_FN void servoClampedBiasVelocity(float error, float positionErrorToVelocity, float maximumSpeed, float baseSpeedSetting, float maximumForce, float dt, float inverseDt,
+                                    float& clampedBiasVelocity, float& maximumImpulse) {  // :75-85
+    float baseSpeed = vmin(baseSpeedSetting, vabs(error) * inverseDt);
+    float biasVelocity = error * positionErrorToVelocity;
+    clampedBiasVelocity = sel(biasVelocity < 0.0f, vmax(-maximumSpeed, vmin(-baseSpeed, biasVelocity)), vmin(maximumSpeed, vmax(baseSpeed, biasVelocity)));
+    maximumImpulse = maximumForce * dt;
+}
+BD_FN void servoClampedBiasVelocity(V3 errorAxis, float errorLength, float positionErrorToBiasVelocity, float maximumSpeed, float baseSpeedSetting, float maximumForce,
+                                    float dt, float inverseDt, V3& clampedBiasVelocity, float& maximumImpulse) {  // :116-130
+    float baseSpeed = vmin(baseSpeedSetting, errorLength * inverseDt);
+    float unclampedBiasSpeed = errorLength * positionErrorToBiasVelocity;
+    float targetSpeed = vmax(baseSpeed, unclampedBiasSpeed);
+    float sc = vmin(1.0f, maximumSpeed / targetSpeed);
+    bool useFallback = targetSpeed < 1e-10f;
+    sc = sel(useFallback, 1.0f, sc);
+    clampedBiasVelocity = scale(errorAxis, sc * unclampedBiasSpeed);
+    maximumImpulse = maximumForce * dt;
+}
+BD_FN void servoClampedBiasVelocityFromError(V3 error, float positionErrorToBiasVelocity, float maximumSpeed, float baseSpeedSetting, float maximumForce,
+                                             float dt, float inverseDt, V3& clampedBiasVelocity, float& maximumImpulse) {  // :132-143
+    float errorLength = length(error);
+    V3 errorAxis = scale(error, 1.0f / errorLength);
+    bool useFallback = errorLength < 1e-10f;
+    errorAxis = {sel(useFallback, 0.0f, errorAxis.x), sel(useFallback, 0.0f, errorAxis.y), sel(useFallback, 0.0f, errorAxis.z)};
+    servoClampedBiasVelocity(errorAxis, errorLength, positionErrorToBiasVelocity, maximumSpeed, baseSpeedSetting, maximumForce, dt, inverseDt, clampedBiasVelocity, maximumImpulse);
+}
+BD_FN void servoClampImpulse(float maximumImpulse, float& accumulatedImpulse, float& csi) {  // :145-151
+    float previousImpulse = accumulatedImpulse;
+    accumulatedImpulse = vmax(-maximumImpulse, vmin(maximumImpulse, accumulatedImpulse + csi));
+    csi = accumulatedImpulse - previousImpulse;
+}
+BD_FN void servoClampImpulse(float maximumImpulse, V3& accumulatedImpulse, V3& csi) {  // :167-178
+    V3 previousAccumulatedImpulse = accumulatedImpulse;
+    accumulatedImpulse = add(accumulatedImpulse, csi);
+    float impulseMagnitude = length(accumulatedImpulse);
+    float impulseScale = sel(vabs(impulseMagnitude) < 1e-10f, 1.0f, vmin(maximumImpulse / impulseMagnitude, 1.0f));
+    accumulatedImpulse = scale(accumulatedImpulse, impulseScale);
+    csi = sub(accumulatedImpulse, previousAccumulatedImpulse);
+}
+// MotorSettingsWide.ComputeSoftness (BepuPhysics/Constraints/MotorSettings.cs:70-99): prestep order {MaximumForce, Damping}.
+BD_FN void motorSoftness(float maximumForce, float damping, float dt, float& effectiveMassCFMScale, float& softnessImpulseScale, float& maximumImpulse) {
+    float dtd = dt * damping;
+    maximumImpulse = maximumForce * dt;
+    softnessImpulseScale = 1.0f / (dtd + 1.0f);
+    effectiveMassCFMScale = dtd * softnessImpulseScale;
+}
+
+// AngularSwivelHinge — AngularSwivelHinge.cs:53-155. Prestep: LocalSwivelAxisA xyz, LocalHingeAxisB xyz, spring{2}. Impulse: scalar.
+struct AngularSwivelHinge {
+    static constexpr int bodies = 2, prestepFloats = 8, impulseFloats = 1, typeId = kAngularSwivelHinge;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessOnlyAngular, wsB = kAccessOnlyAngular, svA = kAccessOnlyAngular, svB = kAccessOnlyAngular;  // :152
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    BD_FN void computeJacobian(V3 localSwivelAxisA, V3 localHingeAxisB, Q oA, Q oB, V3& swivelAxis, V3& hingeAxis, V3& jacobianA) {  // :73-86
+        swivelAxis = transform(localSwivelAxisA, oA);
+        hingeAxis = transform(localHingeAxisB, oB);
+        jacobianA = cross(swivelAxis, hingeAxis);
+        V3 fallbackJacobian = findPerpendicular(swivelAxis);
+        float jacobianLengthSquared = dot(jacobianA, jacobianA);
+        bool useFallback = jacobianLengthSquared < 1e-3f;
+        jacobianA = sel3(useFallback, fallbackJacobian, jacobianA);
+    }
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :88-94
+        V3 swivelAxis, hingeAxis, jacobianA;
+        computeJacobian(V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, oA, oB, swivelAxis, hingeAxis, jacobianA);
+        V3 impulseToVelocityA = transform(jacobianA, iA.t);
+        V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB);
+        applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
+    }
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :96-138
+        V3 swivelAxis, hingeAxis, jacobianA;
+        computeJacobian(V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, oA, oB, swivelAxis, hingeAxis, jacobianA);
+        V3 impulseToVelocityA = transform(jacobianA, iA.t);
+        V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
+        float angularA = dot(impulseToVelocityA, jacobianA);
+        float angularB = dot(negatedImpulseToVelocityB, jacobianA);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[6], p[7], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        float effectiveMass = effMassCFMScale / (angularA + angularB);
+        float error = dot(hingeAxis, swivelAxis);
+        float biasVelocity = -(posErrToVel * error);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB, jacobianA, effectiveMass, biasVelocity, softnessImpulseScale);
+        V3 difference = sub(vA.ang, vB.ang);
+        float csv = dot(difference, jacobianA);
+        float csi = effectiveMass * (biasVelocity - csv) - a[0] * softnessImpulseScale;
+        a[0] += csi;
+        applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, csi, vA.ang, vB.ang);
+    }
+};
+
+// TwistMotor — TwistMotor.cs:45-125. Prestep: LocalAxisA xyz, LocalAxisB xyz, TargetVelocity, motor{MaximumForce, Damping}. Impulse: scalar.
+struct TwistMotor {
+    static constexpr int bodies = 2, prestepFloats = 9, impulseFloats = 1, typeId = kTwistMotor;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessOnlyAngular, wsB = kAccessOnlyAngular, svA = kAccessOnlyAngular, svB = kAccessOnlyAngular;  // :122
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    BD_FN V3 computeJacobian(Q oA, Q oB, V3 localAxisA, V3 localAxisB) {  // :59-68
+        V3 axisA = transform(localAxisA, oA);
+        V3 axisB = transform(localAxisB, oB);
+        V3 jacobianA = add(axisA, axisB);
+        float len = length(jacobianA);
+        jacobianA = scale(jacobianA, 1.0f / len);
+        return sel3(len < 1e-10f, axisA, jacobianA);
+    }
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :70-76
+        V3 jacobianA = computeJacobian(oA, oB, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]});
+        V3 impulseToVelocityA = transform(jacobianA, iA.t);
+        V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB);
+        applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
+    }
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :78-103
+        V3 jacobianA = computeJacobian(oA, oB, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]});
+        // TwistServoFunctions.ComputeEffectiveMassContributions, TwistServo.cs:132-144
+        V3 impulseToVelocityA = transform(jacobianA, iA.t);
+        V3 negatedImpulseToVelocityB = transform(jacobianA, iB.t);
+        float angularA = dot(impulseToVelocityA, jacobianA);
+        float angularB = dot(negatedImpulseToVelocityB, jacobianA);
+        float unsoftenedInverseEffectiveMass = angularA + angularB;
+        float effMassCFMScale, softnessImpulseScale, maximumImpulse;
+        motorSoftness(p[7], p[8], dt, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        float effectiveMass = effMassCFMScale / unsoftenedInverseEffectiveMass;
+        V3 velocityToImpulseA = scale(jacobianA, effectiveMass);
+        float biasImpulse = p[6] * effectiveMass;
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB, velocityToImpulseA, biasImpulse, softnessImpulseScale, maximumImpulse);
+        V3 netVelocity = sub(vA.ang, vB.ang);
+        float csiVelocityComponent = dot(netVelocity, velocityToImpulseA);
+        float csi = biasImpulse - a[0] * softnessImpulseScale - csiVelocityComponent;
+        float previousAccumulatedImpulse = a[0];
+        a[0] = vmax(vmin(a[0] + csi, maximumImpulse), -maximumImpulse);
+        csi = a[0] - previousAccumulatedImpulse;
+        applyAngularImpulse1(impulseToVelocityA, negatedImpulseToVelocityB, csi, vA.ang, vB.ang);
+    }
+};
+
+// AngularServo — AngularServo.cs:53-145. Prestep: TargetRelativeRotationLocalA xyzw, spring{2}, servo{3}. Impulses: xyz.
+struct AngularServo {
+    static constexpr int bodies = 2, prestepFloats = 9, impulseFloats = 3, typeId = kAngularServo;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessOnlyAngularWithoutPose, wsB = kAccessOnlyAngularWithoutPose, svA = kAccessOnlyAngular, svB = kAccessOnlyAngular;  // :142
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    template <class G> BD_FN void warmStart(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float*, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :100-103
+        gate(vA, vB);
+        AngularMotor::applyImpulse(vA.ang, vB.ang, iA.t, iB.t, V3{a[0], a[1], a[2]});
+    }
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :105-134
+        Q targetOrientationB = concatenate(Q{p[0], p[1], p[2], p[3]}, oA);
+        Q inverseTarget = conjugate(targetOrientationB);
+        Q errorRotation = concatenate(inverseTarget, oB);
+        V3 errorAxis; float errorLength;
+        getAxisAngleFromQuaternion(errorRotation, errorAxis, errorLength);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[4], p[5], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        Sym3 unsoftenedInverseEffectiveMass = add(iA.t, iB.t);
+        Sym3 unsoftenedEffectiveMass = invert(unsoftenedInverseEffectiveMass);
+        V3 clampedBiasVelocity; float maximumImpulse;
+        servoClampedBiasVelocity(errorAxis, errorLength, posErrToVel, p[6], p[7], p[8], dt, inverseDt, clampedBiasVelocity, maximumImpulse);
+        BD_GATE(vA, vB, unsoftenedEffectiveMass, clampedBiasVelocity, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        V3 csv = sub(vA.ang, vB.ang);
+        csv = sub(clampedBiasVelocity, csv);
+        V3 csi = transform(csv, unsoftenedEffectiveMass);
+        csi = scale(csi, effMassCFMScale);
+        V3 acc{a[0], a[1], a[2]};
+        V3 softnessComponent = scale(acc, softnessImpulseScale);
+        csi = sub(csi, softnessComponent);
+        servoClampImpulse(maximumImpulse, acc, csi);
+        a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
+        AngularMotor::applyImpulse(vA.ang, vB.ang, iA.t, iB.t, csi);
+    }
+};
+
+// DistanceServo — DistanceServo.cs:82-232. Prestep: LocalOffsetA xyz, LocalOffsetB xyz, TargetDistance, servo{3}, spring{2}. Impulse: scalar.
+struct DistanceServo {
+    static constexpr int bodies = 2, prestepFloats = 12, impulseFloats = 1, typeId = kDistanceServo;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessAll, wsB = kAccessAll, svA = kAccessAll, svB = kAccessAll;  // :229
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    BD_FN void getDistance(Q oA, V3 ab, Q oB, V3 localOffsetA, V3 localOffsetB, V3& anchorOffsetA, V3& anchorOffsetB, V3& anchorOffset, float& dist) {  // :93-102
+        anchorOffsetA = transform(localOffsetA, oA);
+        anchorOffsetB = transform(localOffsetB, oB);
+        V3 anchorB = add(anchorOffsetB, ab);
+        anchorOffset = sub(anchorB, anchorOffsetA);
+        dist = length(anchorOffset);
+    }
+    BD_FN void computeJacobian(float dist, V3 anchorOffsetA, V3 anchorOffsetB, V3& direction, V3& angularJA, V3& angularJB) {  // :104-114
+        bool needFallback = dist < 1e-9f;
+        direction = {sel(needFallback, 1.0f, direction.x), sel(needFallback, 0.0f, direction.y), sel(needFallback, 0.0f, direction.z)};
+        angularJA = cross(anchorOffsetA, direction);
+        angularJB = cross(direction, anchorOffsetB);
+    }
+    BD_FN void applyImpulse(float inverseMassA, float inverseMassB, V3 direction, V3 angularImpulseToVelocityA, V3 angularImpulseToVelocityB, float csi, BodyVel& vA, BodyVel& vB) {  // :139-154
+        V3 linearVelocityChangeA = scale(direction, csi * inverseMassA);
+        V3 angularVelocityChangeA = scale(angularImpulseToVelocityA, csi);
+        vA.lin = add(linearVelocityChangeA, vA.lin);
+        vA.ang = add(angularVelocityChangeA, vA.ang);
+        V3 negatedLinearVelocityChangeB = scale(direction, csi * inverseMassB);
+        V3 angularVelocityChangeB = scale(angularImpulseToVelocityB, csi);
+        vB.lin = sub(vB.lin, negatedLinearVelocityChangeB);
+        vB.ang = add(angularVelocityChangeB, vB.ang);
+    }
+    template <class G> BD_FN void warmStart(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :156-165
+        V3 anchorOffsetA, anchorOffsetB, anchorOffset; float dist;
+        getDistance(oA, sub(pB, pA), oB, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, anchorOffsetA, anchorOffsetB, anchorOffset, dist);
+        V3 direction = scale(anchorOffset, 1.0f / dist);
+        V3 angularJA, angularJB;
+        computeJacobian(dist, anchorOffsetA, anchorOffsetB, direction, angularJA, angularJB);
+        V3 angularImpulseToVelocityA = transform(angularJA, iA.t);
+        V3 angularImpulseToVelocityB = transform(angularJB, iB.t);
+        BD_GATE(vA, vB, direction, angularImpulseToVelocityA, angularImpulseToVelocityB);
+        applyImpulse(iA.invMass, iB.invMass, direction, angularImpulseToVelocityA, angularImpulseToVelocityB, a[0], vA, vB);
+    }
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :167-216
+        V3 anchorOffsetA, anchorOffsetB, anchorOffset; float dist;
+        getDistance(oA, sub(pB, pA), oB, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, anchorOffsetA, anchorOffsetB, anchorOffset, dist);
+        V3 direction = scale(anchorOffset, 1.0f / dist);
+        // ComputeTransforms :116-137
+        V3 angularJA, angularJB;
+        computeJacobian(dist, anchorOffsetA, anchorOffsetB, direction, angularJA, angularJB);
+        V3 angularImpulseToVelocityA = transform(angularJA, iA.t);
+        V3 angularImpulseToVelocityB = transform(angularJB, iB.t);
+        float angularContributionA = dot(angularJA, angularImpulseToVelocityA);
+        float angularContributionB = dot(angularJB, angularImpulseToVelocityB);
+        float inverseEffectiveMass = iA.invMass + iB.invMass + angularContributionA + angularContributionB;
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[10], p[11], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        float effectiveMass = effMassCFMScale / inverseEffectiveMass;
+        float error = dist - p[6];
+        float clampedBiasVelocity, maximumImpulse;
+        servoClampedBiasVelocity(error, posErrToVel, p[7], p[8], p[9], dt, inverseDt, clampedBiasVelocity, maximumImpulse);
+        BD_GATE(vA, vB, direction, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB, effectiveMass, clampedBiasVelocity, softnessImpulseScale, maximumImpulse);
+        float linearCSVA = dot(vA.lin, direction);
+        float negatedLinearCSVB = dot(vB.lin, direction);
+        float angularCSVA = dot(vA.ang, angularJA);
+        float angularCSVB = dot(vB.ang, angularJB);
+        float csi = (clampedBiasVelocity - linearCSVA - angularCSVA + negatedLinearCSVB - angularCSVB) * effectiveMass - a[0] * softnessImpulseScale;
+        servoClampImpulse(maximumImpulse, a[0], csi);
+        applyImpulse(iA.invMass, iB.invMass, direction, angularImpulseToVelocityA, angularImpulseToVelocityB, csi, vA, vB);
+    }
+};
+
+// DistanceLimit — DistanceLimit.cs:72-187. Prestep: LocalOffsetA xyz, LocalOffsetB xyz, MinimumDistance, MaximumDistance, spring{2}. Impulse: scalar.
+struct DistanceLimit {
+    static constexpr int bodies = 2, prestepFloats = 10, impulseFloats = 1, typeId = kDistanceLimit;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessAll, wsB = kAccessAll, svA = kAccessAll, svB = kAccessAll;  // :184
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    BD_FN void applyImpulse(V3 linearJacobianA, V3 angularJacobianA, V3 angularJacobianB, const Inertia& iA, const Inertia& iB, float csi, BodyVel& vA, BodyVel& vB) {  // :84-93
+        V3 impulseScaledLinearJacobian = scale(linearJacobianA, csi);
+        vA.lin = add(vA.lin, scale(impulseScaledLinearJacobian, iA.invMass));
+        vB.lin = sub(vB.lin, scale(impulseScaledLinearJacobian, iB.invMass));
+        vA.ang = add(vA.ang, transform(scale(angularJacobianA, csi), iA.t));
+        vB.ang = add(vB.ang, transform(scale(angularJacobianB, csi), iB.t));
+    }
+    BD_FN void computeJacobians(V3 localOffsetA, V3 pA, Q oA, V3 localOffsetB, V3 pB, Q oB, float minimumDistance, float maximumDistance,
+                                bool& useMinimum, float& dist, V3& direction, V3& angularJA, V3& angularJB) {  // :95-117
+        V3 offsetA = transform(localOffsetA, oA);
+        V3 offsetB = transform(localOffsetB, oB);
+        V3 anchorOffset = add(sub(offsetB, offsetA), sub(pB, pA));
+        dist = length(anchorOffset);
+        useMinimum = vabs(dist - minimumDistance) < vabs(dist - maximumDistance);
+        float sign = sel(useMinimum, -1.0f, 1.0f);
+        direction = scale(anchorOffset, sign / dist);
+        bool needFallback = dist < 1e-9f;
+        direction = {sel(needFallback, 1.0f, direction.x), sel(needFallback, 0.0f, direction.y), sel(needFallback, 0.0f, direction.z)};
+        angularJA = cross(offsetA, direction);
+        angularJB = cross(direction, offsetB);
+    }
+    template <class G> BD_FN void warmStart(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :119-124
+        bool useMinimum; float dist; V3 direction, angularJA, angularJB;
+        computeJacobians(V3{p[0], p[1], p[2]}, pA, oA, V3{p[3], p[4], p[5]}, pB, oB, p[6], p[7], useMinimum, dist, direction, angularJA, angularJB);
+        BD_GATE(vA, vB, direction, angularJA, angularJB);
+        applyImpulse(direction, angularJA, angularJB, iA, iB, a[0], vA, vB);
+    }
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :126-156
+        bool useMinimum; float dist; V3 direction, angularJA, angularJB;
+        computeJacobians(V3{p[0], p[1], p[2]}, pA, oA, V3{p[3], p[4], p[5]}, pB, oB, p[6], p[7], useMinimum, dist, direction, angularJA, angularJB);
+        float angularContributionA = vectorSandwich(angularJA, iA.t);
+        float angularContributionB = vectorSandwich(angularJB, iB.t);
+        float inverseEffectiveMass = iA.invMass + iB.invMass + angularContributionA + angularContributionB;
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[8], p[9], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        float effectiveMass = effMassCFMScale / inverseEffectiveMass;
+        float error = sel(useMinimum, p[6] - dist, dist - p[7]);
+        float biasVelocity = vmin(error * inverseDt, error * posErrToVel);  // InequalityHelpers.ComputeBiasVelocity, InequalityHelpers.cs:9-12
+        BD_GATE(vA, vB, direction, angularJA, angularJB, effectiveMass, biasVelocity, softnessImpulseScale);
+        float linearCSVA = dot(vA.lin, direction);
+        float negatedLinearCSVB = dot(vB.lin, direction);
+        float angularCSVA = dot(vA.ang, angularJA);
+        float angularCSVB = dot(vB.ang, angularJB);
+        float csv = linearCSVA - negatedLinearCSVB + angularCSVA + angularCSVB;
+        float csi = -a[0] * softnessImpulseScale - effectiveMass * (csv - biasVelocity);
+        clampPositive(a[0], csi);
+        applyImpulse(direction, angularJA, angularJB, iA, iB, csi, vA, vB);
+    }
+};
+
+// AngularAxisMotor — AngularAxisMotor.cs:43-113. Prestep: LocalAxisA xyz, TargetVelocity, motor{2}. Impulse: scalar.
+struct AngularAxisMotor {
+    static constexpr int bodies = 2, prestepFloats = 6, impulseFloats = 1, typeId = kAngularAxisMotor;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessOnlyAngular, wsB = kAccessOnlyAngularWithoutPose, svA = kAccessOnlyAngular, svB = kAccessOnlyAngular;  // :110
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    BD_FN void applyImpulse(V3 impulseToVelocityA, V3 negatedImpulseToVelocityB, float csi, V3& angA, V3& angB) {  // :56-60
+        angA = add(angA, scale(impulseToVelocityA, csi));
+        angB = sub(angB, scale(negatedImpulseToVelocityB, csi));
+    }
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :62-69
+        V3 axis = transform(V3{p[0], p[1], p[2]}, oA);
+        V3 jIA = transform(axis, iA.t);
+        V3 jIB = transform(axis, iB.t);
+        BD_GATE(vA, vB, jIA, jIB);
+        applyImpulse(jIA, jIB, a[0], vA.ang, vB.ang);
+    }
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :71-98
+        V3 jA = transform(V3{p[0], p[1], p[2]}, oA);
+        V3 jIA = transform(jA, iA.t);
+        float contributionA = dot(jA, jIA);
+        V3 jIB = transform(jA, iB.t);
+        float contributionB = dot(jA, jIB);
+        float effMassCFMScale, softnessImpulseScale, maximumImpulse;
+        motorSoftness(p[4], p[5], dt, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        float inverseEffectiveMass = contributionA + contributionB;
+        BD_GATE(vA, vB, jA, jIA, jIB, inverseEffectiveMass, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        float csi = (p[3] + dot(vB.ang, jA) - dot(vA.ang, jA)) * effMassCFMScale / inverseEffectiveMass - a[0] * softnessImpulseScale;
+        servoClampImpulse(maximumImpulse, a[0], csi);
+        applyImpulse(jIA, jIB, csi, vA.ang, vB.ang);
+    }
+};
+
+// OneBodyAngularServo — OneBodyAngularServo.cs:44-116. Prestep: TargetOrientation xyzw, spring{2}, servo{3}. Impulses: xyz.
+struct OneBodyAngularServo {
+    static constexpr int bodies = 1, prestepFloats = 9, impulseFloats = 3, typeId = kOneBodyAngularServo;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessOnlyAngular, wsB = 0, svA = kAccessOnlyAngular, svB = 0;  // :113
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    template <class G> BD_FN void warmStart(V3, Q, const Inertia& iA, V3, Q, const Inertia&, float*, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :66-69
+        gate(vA, vB);
+        vA.ang = add(vA.ang, transform(V3{a[0], a[1], a[2]}, iA.t));
+    }
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q, const Inertia&, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :71-101
+        Q inverseOrientation = conjugate(oA);
+        Q errorRotation = concatenate(inverseOrientation, Q{p[0], p[1], p[2], p[3]});
+        V3 errorAxis; float errorLength;
+        getAxisAngleFromQuaternion(errorRotation, errorAxis, errorLength);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[4], p[5], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        Sym3 effectiveMass = invert(iA.t);
+        V3 clampedBiasVelocity; float maximumImpulse;
+        servoClampedBiasVelocity(errorAxis, errorLength, posErrToVel, p[6], p[7], p[8], dt, inverseDt, clampedBiasVelocity, maximumImpulse);
+        BD_GATE(vA, vB, effectiveMass, clampedBiasVelocity, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        V3 csv = sub(clampedBiasVelocity, vA.ang);
+        V3 csi = transform(csv, effectiveMass);
+        V3 acc{a[0], a[1], a[2]};
+        csi = sub(scale(csi, effMassCFMScale), scale(acc, softnessImpulseScale));
+        servoClampImpulse(maximumImpulse, acc, csi);
+        a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
+        vA.ang = add(vA.ang, transform(csi, iA.t));
+    }
+};
+
+// OneBodyAngularMotor — OneBodyAngularMotor.cs:41-100. Prestep: TargetVelocity xyz, motor{2}. Impulses: xyz.
+struct OneBodyAngularMotor {
+    static constexpr int bodies = 1, prestepFloats = 5, impulseFloats = 3, typeId = kOneBodyAngularMotor;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessOnlyAngularWithoutPose, wsB = 0, svA = kAccessOnlyAngular, svB = 0;  // :97
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    template <class G> BD_FN void warmStart(V3, Q, const Inertia& iA, V3, Q, const Inertia&, float*, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :59-62
+        gate(vA, vB);
+        vA.ang = add(vA.ang, transform(V3{a[0], a[1], a[2]}, iA.t));
+    }
+    template <class G> BD_FN void solve(V3, Q, const Inertia& iA, V3, Q, const Inertia&, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :64-86
+        float effMassCFMScale, softnessImpulseScale, maximumImpulse;
+        motorSoftness(p[3], p[4], dt, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        Sym3 unsoftenedEffectiveMass = invert(iA.t);
+        BD_GATE(vA, vB, unsoftenedEffectiveMass, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        V3 csi = transform(sub(V3{p[0], p[1], p[2]}, vA.ang), unsoftenedEffectiveMass);
+        V3 acc{a[0], a[1], a[2]};
+        csi = sub(scale(csi, effMassCFMScale), scale(acc, softnessImpulseScale));
+        servoClampImpulse(maximumImpulse, acc, csi);
+        a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
+        vA.ang = add(vA.ang, transform(csi, iA.t));
+    }
+};
+
+// OneBodyLinearServo / OneBodyLinearMotor — OneBodyLinearServo.cs:51-152, OneBodyLinearMotor.cs:44-106.
+// Servo prestep: LocalOffset xyz, Target xyz, spring{2}, servo{3}. Motor prestep: LocalOffset xyz, TargetVelocity xyz, motor{2}. Impulses: xyz.
+struct OneBodyLinearShared {
+    BD_FN void applyImpulse(V3 offset, const Inertia& inertia, BodyVel& vA, V3 csi) {  // OneBodyLinearServo.cs:85-93
+        V3 wsi = cross(offset, csi);
+        V3 change = transform(wsi, inertia.t);
+        vA.ang = add(vA.ang, change);
+        change = scale(csi, inertia.invMass);
+        vA.lin = add(vA.lin, change);
+    }
+    BD_FN Sym3 effectiveMass(V3 offset, const Inertia& inertia) {  // :117-121 / OneBodyLinearMotor.cs:77-81
+        Sym3 inverseEffectiveMass = skewSandwich(offset, inertia.t);
+        inverseEffectiveMass.xx += inertia.invMass;
+        inverseEffectiveMass.yy += inertia.invMass;
+        inverseEffectiveMass.zz += inertia.invMass;
+        return invert(inverseEffectiveMass);
+    }
+};
+struct OneBodyLinearServo {
+    static constexpr int bodies = 1, prestepFloats = 11, impulseFloats = 3, typeId = kOneBodyLinearServo;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessAll, wsB = 0, svA = kAccessAll, svB = 0;  // :149
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q, const Inertia&, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :95-100
+        V3 offset = transform(V3{p[0], p[1], p[2]}, oA);
+        BD_GATE(vA, vB, offset);
+        OneBodyLinearShared::applyImpulse(offset, iA, vA, V3{a[0], a[1], a[2]});
+    }
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3, Q, const Inertia&, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :102-133
+        V3 offset = transform(V3{p[0], p[1], p[2]}, oA);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[6], p[7], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        V3 worldGrabPoint = add(offset, pA);
+        V3 error = sub(V3{p[3], p[4], p[5]}, worldGrabPoint);
+        V3 biasVelocity; float maximumImpulse;
+        servoClampedBiasVelocityFromError(error, posErrToVel, p[8], p[9], p[10], dt, inverseDt, biasVelocity, maximumImpulse);
+        Sym3 effectiveMass = OneBodyLinearShared::effectiveMass(offset, iA);
+        BD_GATE(vA, vB, offset, biasVelocity, effectiveMass, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        V3 csv = sub(sub(biasVelocity, cross(vA.ang, offset)), vA.lin);
+        V3 csi = transform(csv, effectiveMass);
+        V3 acc{a[0], a[1], a[2]};
+        csi = sub(scale(csi, effMassCFMScale), scale(acc, softnessImpulseScale));
+        servoClampImpulse(maximumImpulse, acc, csi);
+        a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
+        OneBodyLinearShared::applyImpulse(offset, iA, vA, csi);
+    }
+};
+struct OneBodyLinearMotor {
+    static constexpr int bodies = 1, prestepFloats = 8, impulseFloats = 3, typeId = kOneBodyLinearMotor;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessNoPosition, wsB = 0, svA = kAccessNoPosition, svB = 0;  // :103
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q, const Inertia&, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :57-61
+        V3 offset = transform(V3{p[0], p[1], p[2]}, oA);
+        BD_GATE(vA, vB, offset);
+        OneBodyLinearShared::applyImpulse(offset, iA, vA, V3{a[0], a[1], a[2]});
+    }
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q, const Inertia&, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :63-91
+        V3 offset = transform(V3{p[0], p[1], p[2]}, oA);
+        float effMassCFMScale, softnessImpulseScale, maximumImpulse;
+        motorSoftness(p[6], p[7], dt, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        Sym3 effectiveMass = OneBodyLinearShared::effectiveMass(offset, iA);
+        BD_GATE(vA, vB, offset, effectiveMass, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        V3 csv = sub(sub(V3{p[3], p[4], p[5]}, cross(vA.ang, offset)), vA.lin);
+        V3 csi = transform(csv, effectiveMass);
+        V3 acc{a[0], a[1], a[2]};
+        csi = sub(scale(csi, effMassCFMScale), scale(acc, softnessImpulseScale));
+        servoClampImpulse(maximumImpulse, acc, csi);
+        a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
+        OneBodyLinearShared::applyImpulse(offset, iA, vA, csi);
+    }
+};
+
+// BallSocketMotor / BallSocketServo — BallSocketMotor.cs:47-103, BallSocketServo.cs:48-113, BallSocketShared.cs:100-135.
+// Motor prestep: LocalOffsetB xyz, TargetVelocityLocalA xyz, motor{2}. Servo prestep: LocalOffsetA xyz, LocalOffsetB xyz, spring{2}, servo{3}. Impulses: xyz.
+struct BallSocketMotor {
+    static constexpr int bodies = 2, prestepFloats = 8, impulseFloats = 3, typeId = kBallSocketMotor;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessNoOrientation, wsB = kAccessAll, svA = kAccessAll, svB = kAccessAll;  // :100
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    template <class G> BD_FN void warmStart(V3 pA, Q, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :60-64
+        V3 targetOffsetB = transform(V3{p[0], p[1], p[2]}, oB);
+        V3 offsetA = add(sub(pB, pA), targetOffsetB);
+        BD_GATE(vA, vB, targetOffsetB, offsetA);
+        BallSocketShared::applyImpulse(vA, vB, offsetA, targetOffsetB, iA, iB, V3{a[0], a[1], a[2]});
+    }
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :66-88
+        V3 targetOffsetB = transform(V3{p[0], p[1], p[2]}, oB);
+        V3 offsetA = add(sub(pB, pA), targetOffsetB);
+        float effMassCFMScale, softnessImpulseScale, maximumImpulse;
+        motorSoftness(p[6], p[7], dt, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        Sym3 effectiveMass = BallSocketShared::computeEffectiveMass(iA, iB, offsetA, targetOffsetB, effMassCFMScale);
+        V3 biasVelocity = neg(transform(V3{p[3], p[4], p[5]}, oA));
+        BD_GATE(vA, vB, targetOffsetB, offsetA, effectiveMass, biasVelocity, softnessImpulseScale, maximumImpulse);
+        V3 acc{a[0], a[1], a[2]};  // BallSocketShared.Solve with maximum impulse, BallSocketShared.cs:118-126
+        V3 correctiveImpulse = BallSocketShared::computeCorrectiveImpulse(vA, vB, offsetA, targetOffsetB, biasVelocity, effectiveMass, softnessImpulseScale, acc);
+        servoClampImpulse(maximumImpulse, acc, correctiveImpulse);
+        a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
+        BallSocketShared::applyImpulse(vA, vB, offsetA, targetOffsetB, iA, iB, correctiveImpulse);
+    }
+};
+struct BallSocketServo {
+    static constexpr int bodies = 2, prestepFloats = 11, impulseFloats = 3, typeId = kBallSocketServo;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessNoPosition, wsB = kAccessNoPosition, svA = kAccessAll, svB = kAccessAll;  // :110
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :62-67
+        V3 offsetA = transform(V3{p[0], p[1], p[2]}, oA);
+        V3 offsetB = transform(V3{p[3], p[4], p[5]}, oB);
+        BD_GATE(vA, vB, offsetA, offsetB);
+        BallSocketShared::applyImpulse(vA, vB, offsetA, offsetB, iA, iB, V3{a[0], a[1], a[2]});
+    }
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :69-98
+        V3 offsetA = transform(V3{p[0], p[1], p[2]}, oA);
+        V3 offsetB = transform(V3{p[3], p[4], p[5]}, oB);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[6], p[7], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        Sym3 effectiveMass = BallSocketShared::computeEffectiveMass(iA, iB, offsetA, offsetB, effMassCFMScale);
+        V3 ab = sub(pB, pA);
+        V3 anchorB = add(ab, offsetB);
+        V3 error = sub(anchorB, offsetA);
+        V3 biasVelocity; float maximumImpulse;
+        servoClampedBiasVelocityFromError(error, posErrToVel, p[8], p[9], p[10], dt, inverseDt, biasVelocity, maximumImpulse);
+        BD_GATE(vA, vB, offsetA, offsetB, effectiveMass, biasVelocity, softnessImpulseScale, maximumImpulse);
+        V3 acc{a[0], a[1], a[2]};
+        V3 correctiveImpulse = BallSocketShared::computeCorrectiveImpulse(vA, vB, offsetA, offsetB, biasVelocity, effectiveMass, softnessImpulseScale, acc);
+        servoClampImpulse(maximumImpulse, acc, correctiveImpulse);
+        a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
+        BallSocketShared::applyImpulse(vA, vB, offsetA, offsetB, iA, iB, correctiveImpulse);
+    }
+};
+
+// The non-contact types for the dispatch switches, X(type id, struct): SURVEY 8(a)'s rows a8-a13, and the 8(f) widening.
+#define BD_HOT_JOINT_TYPES(X)                                                                                                       \
     X(kBallSocket, BallSocket) X(kAngularHinge, AngularHinge) X(kSwingLimit, SwingLimit) X(kTwistServo, TwistServo)                 \
-    X(kTwistLimit, TwistLimit) X(kAngularMotor, AngularMotor) X(kWeld, Weld) X(kSwivelHinge, SwivelHinge) X(kHinge, Hinge)
+    X(kTwistLimit, TwistLimit) X(kAngularMotor, AngularMotor) X(kSwivelHinge, SwivelHinge) X(kHinge, Hinge)
+#define BD_WIDENED_JOINT_TYPES(X)                                                                                                   \
+    X(kWeld, Weld) X(kAngularSwivelHinge, AngularSwivelHinge) X(kTwistMotor, TwistMotor) X(kAngularServo, AngularServo)             \
+    X(kDistanceServo, DistanceServo) X(kDistanceLimit, DistanceLimit) X(kAngularAxisMotor, AngularAxisMotor)                        \
+    X(kOneBodyAngularServo, OneBodyAngularServo) X(kOneBodyAngularMotor, OneBodyAngularMotor) X(kOneBodyLinearServo, OneBodyLinearServo) \
+    X(kOneBodyLinearMotor, OneBodyLinearMotor) X(kBallSocketMotor, BallSocketMotor) X(kBallSocketServo, BallSocketServo)
+#define BD_JOINT_TYPES(X) BD_HOT_JOINT_TYPES(X) BD_WIDENED_JOINT_TYPES(X)
 
 }  // namespace bd

@@ -625,7 +625,7 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
 using DC1O = Contact<1, false>; using DC2O = Contact<2, false>; using DC3O = Contact<3, false>; using DC4O = Contact<4, false>;
 using DC1T = Contact<1, true>; using DC2T = Contact<2, true>; using DC3T = Contact<3, true>; using DC4T = Contact<4, true>;
 
-template <int STAGE, bool TRACE>
+template <int STAGE, bool TRACE, bool WIDE>
 __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
                                                  unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
 #define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps); break;
@@ -635,8 +635,15 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
         default:
             if constexpr (STAGE != kStageIncremental) {  // only contacts need incremental updates (RequiresIncrementalSubstepUpdates)
                 switch (h.type_id) {
-                    BD_JOINT_TYPES(BEPU_CASE)
-                    default: break;
+                    BD_HOT_JOINT_TYPES(BEPU_CASE)
+                    default:
+                        if constexpr (WIDE) {  // SURVEY 8(f) types live in a second kernel variant: scenes made of the sixteen hot-path types keep the leaner one
+                            switch (h.type_id) {
+                                BD_WIDENED_JOINT_TYPES(BEPU_CASE)
+                                default: break;
+                            }
+                        }
+                        break;
                 }
             }
             break;
@@ -650,7 +657,7 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
 // predecessors), so the head of the iteration runs while the tail of the warm start's dependency chain is still draining. The warm start does
 // not write accumulated impulses, hence nothing the iteration loads from HBM is in flight. STAGE0 = kStageSolve with solve_items = 0 runs a
 // later iteration on its own (a barrier precedes it: its impulses were stored by the previous one).
-template <int STAGE0, bool TRACE>
+template <int STAGE0, bool TRACE, bool WIDE>
 __device__ __forceinline__ void run_cluster_sweep(const ClusterShared& sh, int item_count, int solve_items, int lane, int wave, unsigned epoch, unsigned claim_base,
                                                   unsigned* __restrict__ slab, float dt, float inv_dt, unsigned long long* trace) {
     for (;;) {
@@ -664,8 +671,8 @@ __device__ __forceinline__ void run_cluster_sweep(const ClusterShared& sh, int i
         unsigned long long t0 = 0;
         if (TRACE) t0 = __builtin_readcyclecounter();
         ItemStamps stamps = {0, 0, 0};
-        if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
-        else run_cluster_item<kStageSolve, TRACE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+        if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE, WIDE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+        else run_cluster_item<kStageSolve, TRACE, WIDE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
         if (TRACE && trace && blockIdx.x == 0 && lane == 0) {
             unsigned long long* rec = trace + ((size_t)(item_epoch - 1) * item_count + k) * 8;
             rec[4] = stamps.loaded; rec[5] = stamps.pre_gate; rec[6] = stamps.post_gate; rec[7] = 0;
@@ -676,7 +683,7 @@ __device__ __forceinline__ void run_cluster_sweep(const ClusterShared& sh, int i
     }
 }
 
-template <int THREADS, bool TRACE>
+template <int THREADS, bool TRACE, bool WIDE>
 __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __restrict__ clusters, const ClusterItem* __restrict__ items,
                                                                    const int* __restrict__ batch_item_begin, const int* __restrict__ cluster_bodies,
                                                                    float4* bodies, unsigned* __restrict__ slab, ClusterParams cp, int ncap, int max_items,
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 const ItemHeader h = read_item(it);
                 if (h.type_id > kContact4) continue;
                 ItemStamps stamps = {0, 0, 0};
-                run_cluster_item<kStageIncremental, false>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
+                run_cluster_item<kStageIncremental, false, false>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
             }
             __syncthreads();
         }
@@ -762,13 +769,13 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         __syncthreads();
         ++epoch;
         const int fused = cp.iters[s] > 0 ? cd.item_count : 0;  // the first velocity iteration rides in the warm start's claim sequence
-        run_cluster_sweep<kStageWarmStart, TRACE>(sh, cd.item_count, fused, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+        run_cluster_sweep<kStageWarmStart, TRACE, WIDE>(sh, cd.item_count, fused, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
         claim_base += cd.item_count + fused + nwaves;  // every wave makes exactly one failing claim per sweep
         if (fused) ++epoch;
         __syncthreads();
         for (int iter = 1; iter < cp.iters[s]; ++iter) {
             ++epoch;
-            run_cluster_sweep<kStageSolve, TRACE>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+            run_cluster_sweep<kStageSolve, TRACE, WIDE>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
             claim_base += cd.item_count + nwaves;
             __syncthreads();
         }
@@ -800,6 +807,18 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
 // ------------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------------
+// cluster_kernel instantiations: register budget (launch bounds) x trace x type set. The traced build exists for the 1024-thread budget only (a kernel
+// compiled for 1024 threads runs any smaller workgroup).
+#define BEPU_CLUSTER_VARIANTS(X) X(512, false, false) X(768, false, false) X(1024, false, false) X(1024, true, false) \
+                                 X(512, false, true) X(768, false, true) X(1024, false, true) X(1024, true, true)
+static const void* cluster_kernel_variant(int threads, bool trace, bool wide) {
+    const int budget = trace ? 1024 : (threads > 768 ? 1024 : threads > 512 ? 768 : 512);
+#define X(T, TR, W) if (budget == T && trace == TR && wide == W) return (const void*)cluster_kernel<T, TR, W>;
+    BEPU_CLUSTER_VARIANTS(X)
+#undef X
+    return (const void*)cluster_kernel<1024, false, true>;
+}
+
 static thread_local std::string g_last_error;
 static int32_t fail(int32_t code, const std::string& msg) { g_last_error = msg; return code; }
 #define HIP_TRY(expr)                                                                                         \
@@ -823,6 +842,15 @@ static bool type_info(int id, TypeInfoH& t) {
 #undef X
     }
 #undef TI
+    return false;
+}
+
+static bool is_widened_type(int id) {
+    switch (id) {
+#define X(ID, T) case ID: return true;
+        BD_WIDENED_JOINT_TYPES(X)
+#undef X
+    }
     return false;
 }
 
@@ -878,6 +906,7 @@ struct bepuhip_ctx {
     int64_t total_constraints = 0;
     // cluster path
     bool clusters_enabled = false;
+    bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
     int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0;
     ClusterDesc first_cluster = {0, 0, 0, 0, 0};
     int* d_requirk = nullptr;            // conserving angular modes: per batch, the bodies momentum_requirk_kernel transforms in substep 0
@@ -1284,6 +1313,7 @@ int32_t bepuhip_begin_constraints(bepuhip_ctx* c, int32_t batch_count, int32_t f
     hipStreamSynchronize(c->stream);
     free_constraints(c);
     c->batch_count = batch_count;
+    c->has_widened_types = false;
     c->building = true;
     return BEPUHIP_OK;
 }
@@ -1312,6 +1342,7 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
         for (int f = 0; f < pf; ++f) tb.prestep_soa[(size_t)f * tb.stride + i] = prestep[bundle * pf * W + (size_t)f * W + lane];
         for (int f = 0; f < imf; ++f) tb.accum_soa[(size_t)f * tb.stride + i] = accum[bundle * imf * W + (size_t)f * W + lane];
     }
+    c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
     c->tbs.push_back(std::move(tb));
     return BEPUHIP_OK;
 }
@@ -1461,8 +1492,9 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
         HIP_TRY(upload_ints(plan.batch_item_begin.data(), plan.batch_item_begin.size() * 4, (void**)&c->d_batch_item_begin));
         HIP_TRY(upload_ints(plan.cluster_bodies.data(), plan.cluster_bodies.size() * 4, (void**)&c->d_cluster_bodies));
         HIP_TRY(upload_ints(plan.clustered_dynamic.data(), plan.clustered_dynamic.size() * 4, (void**)&c->d_clustered_dynamic));
-        for (const void* fn : {(const void*)cluster_kernel<512, false>, (const void*)cluster_kernel<512, true>, (const void*)cluster_kernel<768, false>, (const void*)cluster_kernel<768, true>,
-                               (const void*)cluster_kernel<1024, false>, (const void*)cluster_kernel<1024, true>})
+#define X(T, TR, W) (const void*)cluster_kernel<T, TR, W>,
+        for (const void* fn : {BEPU_CLUSTER_VARIANTS(X)})
+#undef X
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
     }
     c->built = true;
@@ -1546,9 +1578,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
                             (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles};
             const bool tr = c->d_trace != nullptr;
-            const void* fn = threads == 1024 ? (tr ? (const void*)cluster_kernel<1024, true> : (const void*)cluster_kernel<1024, false>)
-                             : threads == 768 ? (tr ? (const void*)cluster_kernel<768, true> : (const void*)cluster_kernel<768, false>)
-                                              : (tr ? (const void*)cluster_kernel<512, true> : (const void*)cluster_kernel<512, false>);
+            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types);
             hipLaunchKernel(fn, dim3(c->cluster_count), dim3(threads), args, lds_bytes, c->stream);
         }
         if (c->kinlist_count > 0) {

@@ -34,7 +34,19 @@ bool GetTypeInfo(int typeId, TypeInfo& info) {
         case 27: info = {2, 12, 1, false}; return true;  // TwistLimit
         case 30: info = {2, 5, 3, false}; return true;   // AngularMotor
         case 46: info = {2, 14, 4, false}; return true;  // SwivelHinge
+        case 24: info = {2, 8, 1, false}; return true;   // AngularSwivelHinge
+        case 28: info = {2, 9, 1, false}; return true;   // TwistMotor
+        case 29: info = {2, 9, 3, false}; return true;   // AngularServo
         case 31: info = {2, 9, 6, false}; return true;   // Weld (Weld.cs:70-81, :224)
+        case 33: info = {2, 12, 1, false}; return true;  // DistanceServo
+        case 34: info = {2, 10, 1, false}; return true;  // DistanceLimit
+        case 41: info = {2, 6, 1, false}; return true;   // AngularAxisMotor
+        case 42: info = {1, 9, 3, false}; return true;   // OneBodyAngularServo
+        case 43: info = {1, 5, 3, false}; return true;   // OneBodyAngularMotor
+        case 44: info = {1, 11, 3, false}; return true;  // OneBodyLinearServo
+        case 45: info = {1, 8, 3, false}; return true;   // OneBodyLinearMotor
+        case 52: info = {2, 8, 3, false}; return true;   // BallSocketMotor
+        case 53: info = {2, 11, 3, false}; return true;  // BallSocketServo
         case 47: info = {2, 14, 5, false}; return true;  // Hinge
     }
     return false;

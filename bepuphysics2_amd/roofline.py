@@ -21,6 +21,11 @@ ACCESS = {
     "AngularMotor": (ONLY_ANGULAR_NO_POSE, ONLY_ANGULAR_NO_POSE, ONLY_ANGULAR, ONLY_ANGULAR_NO_POSE),
     "SwivelHinge": (NO_POSITION, NO_POSITION, ALL, ALL), "Hinge": (NO_POSITION, NO_POSITION, ALL, ALL),
     "Weld": (NO_POSITION, NO_POSE, ALL, ALL),
+    "AngularSwivelHinge": (ONLY_ANGULAR,) * 4, "TwistMotor": (ONLY_ANGULAR,) * 4, "AngularServo": (ONLY_ANGULAR_NO_POSE, ONLY_ANGULAR_NO_POSE, ONLY_ANGULAR, ONLY_ANGULAR),
+    "DistanceServo": (ALL,) * 4, "DistanceLimit": (ALL,) * 4, "AngularAxisMotor": (ONLY_ANGULAR, ONLY_ANGULAR_NO_POSE, ONLY_ANGULAR, ONLY_ANGULAR),
+    "OneBodyAngularServo": (ONLY_ANGULAR, 0, ONLY_ANGULAR, 0), "OneBodyAngularMotor": (ONLY_ANGULAR_NO_POSE, 0, ONLY_ANGULAR, 0),
+    "OneBodyLinearServo": (ALL, 0, ALL, 0), "OneBodyLinearMotor": (NO_POSITION, 0, NO_POSITION, 0),
+    "BallSocketMotor": (29, ALL, ALL, ALL), "BallSocketServo": (NO_POSITION, NO_POSITION, ALL, ALL),
 }
 
 

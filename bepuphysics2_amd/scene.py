@@ -26,6 +26,9 @@ TYPE_TABLE: Dict[int, tuple] = {
     4: (2, 14, 4, "Contact1"), 5: (2, 18, 5, "Contact2"), 6: (2, 22, 6, "Contact3"), 7: (2, 26, 7, "Contact4"),
     22: (2, 8, 3, "BallSocket"), 23: (2, 8, 2, "AngularHinge"), 25: (2, 9, 1, "SwingLimit"), 26: (2, 14, 1, "TwistServo"),
     27: (2, 12, 1, "TwistLimit"), 30: (2, 5, 3, "AngularMotor"), 31: (2, 9, 6, "Weld"), 46: (2, 14, 4, "SwivelHinge"), 47: (2, 14, 5, "Hinge"),
+    24: (2, 8, 1, "AngularSwivelHinge"), 28: (2, 9, 1, "TwistMotor"), 29: (2, 9, 3, "AngularServo"), 33: (2, 12, 1, "DistanceServo"), 34: (2, 10, 1, "DistanceLimit"),
+    41: (2, 6, 1, "AngularAxisMotor"), 42: (1, 9, 3, "OneBodyAngularServo"), 43: (1, 5, 3, "OneBodyAngularMotor"), 44: (1, 11, 3, "OneBodyLinearServo"),
+    45: (1, 8, 3, "OneBodyLinearMotor"), 52: (2, 8, 3, "BallSocketMotor"), 53: (2, 11, 3, "BallSocketServo"),
 }
 TYPE_IDS_BY_NAME = {v[3]: k for k, v in TYPE_TABLE.items()}
 # The sixteen types of SURVEY.md 8(a) rows a7-a13 (the committed tests/golden/small_scenes.npz fixtures were generated from exactly these).

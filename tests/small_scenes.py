@@ -71,6 +71,37 @@ def joint_prestep(rng, type_id):
     if name == "AngularMotor":
         settings = [FLOAT_MAX, 1.0 / 0.01] if rng.random() < 0.5 else [rng.uniform(1, 100), rng.uniform(1, 200)]
         return list(rng.uniform(-0.2, 0.2, 3)) + settings
+    def servo():  # ServoSettings{MaximumSpeed, BaseSpeed, MaximumForce}: unlimited half of the time, as the ragdoll's twist servos are
+        return [FLOAT_MAX, 0.0, FLOAT_MAX] if rng.random() < 0.5 else [rng.uniform(1, 5), rng.uniform(0, 0.5), rng.uniform(10, 1000)]
+
+    def motor():  # MotorSettings{MaximumForce, Damping}
+        return [FLOAT_MAX, 1.0 / 0.01] if rng.random() < 0.5 else [rng.uniform(1, 100), rng.uniform(1, 200)]
+
+    if name == "AngularSwivelHinge":
+        return list(unit(rng)) + list(unit(rng)) + sp
+    if name == "TwistMotor":
+        return list(unit(rng)) + list(unit(rng)) + [rng.uniform(-1, 1)] + motor()
+    if name == "AngularServo":
+        return list(rand_quat(rng)) + sp + servo()
+    if name == "DistanceServo":
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + [rng.uniform(0.5, 3.0)] + servo() + sp
+    if name == "DistanceLimit":
+        lo = rng.uniform(0.2, 2.0)
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + [lo, lo + rng.uniform(0.1, 2.0)] + sp
+    if name == "AngularAxisMotor":
+        return list(unit(rng)) + [rng.uniform(-1, 1)] + motor()
+    if name == "OneBodyAngularServo":
+        return list(rand_quat(rng)) + sp + servo()
+    if name == "OneBodyAngularMotor":
+        return list(rng.uniform(-1, 1, 3)) + motor()
+    if name == "OneBodyLinearServo":
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-3, 3, 3)) + sp + servo()
+    if name == "OneBodyLinearMotor":
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-1, 1, 3)) + motor()
+    if name == "BallSocketMotor":
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-1, 1, 3)) + motor()
+    if name == "BallSocketServo":
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + sp + servo()
     if name == "Weld":
         return list(rng.uniform(-0.5, 0.5, 3)) + list(rand_quat(rng)) + sp
     if name in ("SwivelHinge", "Hinge"):

@@ -30,7 +30,7 @@ def test_type_info_table():
     for tid, (nb, pf, imf, _) in TYPE_TABLE.items():
         assert native.type_info(tid) == (nb, pf, imf)
     with pytest.raises(native.UnsupportedError):
-        native.type_info(34)  # Weld: not on the hot path yet
+        native.type_info(35)  # CenterDistanceConstraint: FastReciprocal makes the reference CPU-dependent (left out, see bepu_device_constraints.h)
 
 
 def test_create_fails_loudly_without_gpu_or_bad_config():

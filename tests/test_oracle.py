@@ -97,11 +97,11 @@ def test_two_body_constraints_conserve_momentum(type_id):
         body[0:4] = (0, 0, 0, 1)
         body[24:31] = body[16:23]
     lane = np.asarray(small_scenes.prestep_for(rng, type_id, pa, pb), np.float32)
-    if name in ("BallSocket", "SwivelHinge", "Hinge"):
+    if name in ("BallSocket", "SwivelHinge", "Hinge", "BallSocketServo"):
         # these act at the joint anchor: offsets are what they are; momentum about the origin is conserved only if both impulses act at one
         # world point, which holds when anchorA == anchorB. Choose LocalOffsetB so that the anchors coincide.
         off_a = lane[0:3]
-        off_b_index = 3 if name == "BallSocket" else 6
+        off_b_index = 3 if name in ("BallSocket", "BallSocketServo") else 6
         lane[off_b_index:off_b_index + 3] = (pa + off_a) - pb
     if name == "Weld":  # its linear rows act at B's centre with lever arm LocalOffset on A (Weld.cs:87-112): one world point iff LocalOffset = pB - pA
         lane[0:3] = pb - pa
@@ -276,3 +276,65 @@ def test_weld_removes_relative_motion():
     rel_ang = a[12:15] - b[12:15]
     rel_lin = a[8:11] + np.cross(a[12:15], pb - pa) - b[8:11]
     assert np.abs(rel_ang).max() < 2e-3 and np.abs(rel_lin).max() < 2e-3, (rel_ang, rel_lin)
+
+
+def _identity_pair(rng, pa, pb):
+    a, b = small_scenes.random_dynamic_body(rng, pa), small_scenes.random_dynamic_body(rng, pb)
+    for body in (a, b):
+        body[0:4] = (0, 0, 0, 1)
+        body[24:31] = body[16:23]
+    return a, b
+
+
+def test_widened_motors_and_servos_reach_their_targets():
+    """Behavioural pins of the SURVEY 8(f) types (the oracle/device parity tests cannot catch a transcription error shared by both sides)."""
+    rng = np.random.default_rng(91)
+    strong_motor = [FLOAT_MAX, 1e6]  # MotorSettings{MaximumForce, Damping}: practically rigid
+    pa, pb = np.asarray([0, 0, 0], np.float32), np.asarray([1, 0.5, 0], np.float32)
+    zero = np.zeros(32, np.float32)
+    # OneBodyAngularMotor (43): the body's angular velocity becomes the target velocity
+    a, _ = _identity_pair(rng, pa, pb)
+    lane = np.asarray([0.3, -0.7, 0.2] + strong_motor, np.float32)
+    oracle_ffi.constraint_iterate(43, a, zero.copy(), lane, np.zeros(3, np.float32), 1 / 60, 30)
+    assert np.allclose(a[12:15], [0.3, -0.7, 0.2], atol=1e-3)
+    # OneBodyLinearMotor (45): the velocity of the grabbed point becomes the target velocity
+    a, _ = _identity_pair(rng, pa, pb)
+    off = np.asarray([0.2, 0.1, -0.3], np.float32)
+    lane = np.asarray(list(off) + [0.5, 0.1, -0.4] + strong_motor, np.float32)
+    oracle_ffi.constraint_iterate(45, a, zero.copy(), lane, np.zeros(3, np.float32), 1 / 60, 30)
+    assert np.allclose(a[8:11] + np.cross(a[12:15], off), [0.5, 0.1, -0.4], atol=1e-3)
+    # TwistMotor (28) / AngularAxisMotor (41): relative angular velocity about the axis becomes the target
+    for type_id, lane in ((28, [0, 0, 1, 0, 0, 1, 0.8] + strong_motor), (41, [0, 0, 1, 0.8] + strong_motor)):
+        a, b = _identity_pair(rng, pa, pb)
+        oracle_ffi.constraint_iterate(type_id, a, b, np.asarray(lane, np.float32), np.zeros(1, np.float32), 1 / 60, 40)
+        rel = float(a[14] - b[14])
+        assert abs(abs(rel) - 0.8) < 2e-3, (type_id, rel)  # sign conventions differ between the two (TwistMotor.cs:93 vs AngularAxisMotor.cs:91)
+    # BallSocketMotor (52): anchor velocity difference equals -R_A * target (BallSocketMotor.cs:80-81)
+    a, b = _identity_pair(rng, pa, pb)
+    lane = np.asarray([0.1, 0.2, -0.1, 0.3, 0.0, -0.2] + strong_motor, np.float32)
+    oracle_ffi.constraint_iterate(52, a, b, lane, np.zeros(3, np.float32), 1 / 60, 40)
+    off_b = lane[0:3]
+    off_a = (pb - pa) + off_b
+    rel = (a[8:11] + np.cross(a[12:15], off_a)) - (b[8:11] + np.cross(b[12:15], off_b))
+    assert np.allclose(rel, -lane[3:6], atol=2e-3), rel
+    # DistanceLimit (34): inside [min, max] with no approach velocity the inequality stays inactive
+    a, b = _identity_pair(rng, pa, pb)
+    for body in (a, b):
+        body[8:15] = 0
+    before = np.concatenate([a[8:15], b[8:15]]).copy()
+    dist = float(np.linalg.norm(pb - pa))
+    lane = np.asarray([0, 0, 0, 0, 0, 0, dist - 0.5, dist + 0.5] + small_scenes.spring(30.0, 1.0), np.float32)
+    acc = np.zeros(1, np.float32)
+    oracle_ffi.constraint_iterate(34, a, b, lane, acc, 1 / 60, 5)
+    assert acc[0] == 0 and np.array_equal(np.concatenate([a[8:15], b[8:15]]), before)
+    # DistanceServo (33): the anchors' separation speed follows the (clamped) bias velocity sign: too far apart => they approach
+    a, b = _identity_pair(rng, pa, pb)
+    for body in (a, b):
+        body[8:15] = 0
+    lane = np.asarray([0, 0, 0, 0, 0, 0, dist * 0.5, FLOAT_MAX, 0.0, FLOAT_MAX] + small_scenes.spring(30.0, 1.0), np.float32)
+    oracle_ffi.constraint_iterate(33, a, b, lane, np.zeros(1, np.float32), 1 / 60, 10)
+    direction = (pb - pa) / dist
+    assert float(np.dot(b[8:11] - a[8:11], direction)) < -0.1
+
+
+FLOAT_MAX = float(np.finfo(np.float32).max)
