@@ -22,7 +22,11 @@ enum TypeId {
     kAngularMotor = 30, kWeld = 31, kSwivelHinge = 46, kHinge = 47,
     kAngularSwivelHinge = 24, kTwistMotor = 28, kAngularServo = 29, kDistanceServo = 33, kDistanceLimit = 34, kAngularAxisMotor = 41,
     kOneBodyAngularServo = 42, kOneBodyAngularMotor = 43, kOneBodyLinearServo = 44, kOneBodyLinearMotor = 45, kBallSocketMotor = 52, kBallSocketServo = 53,
+    kPointOnLineServo = 37, kLinearAxisServo = 38, kLinearAxisMotor = 39, kLinearAxisLimit = 40, kAngularAxisGearMotor = 54,
+    kContact2NonconvexOneBody = 8, kContact3NonconvexOneBody = 9, kContact4NonconvexOneBody = 10, kContact2Nonconvex = 15, kContact3Nonconvex = 16, kContact4Nonconvex = 17,
 };
+// Contact manifolds are the types with RequiresIncrementalSubstepUpdates (their depths advance every substep).
+BD_FN bool isContactType(int id) { return id <= kContact4Nonconvex; }
 
 // ======================================================================================
 // Convex contact manifolds, N = 1..4 contacts, one or two bodies.
@@ -37,6 +41,8 @@ struct Contact {
     static constexpr int impulseFloats = N + 3;
     static constexpr int typeId = TwoBody ? 3 + N : N - 1;
     static constexpr bool incremental = true;
+    static constexpr int contacts = N;
+    static constexpr int depthRow(int c) { return 4 * c + 3; }  // the rows IncrementallyUpdateForSubstep rewrites
     // TwoBodyContactTypeProcessor / OneBodyContactTypeProcessor: AccessNoPose everywhere (TwoBodyTypeProcessor.cs:244-250).
     static constexpr int wsA = kAccessNoPose, wsB = kAccessNoPose, svA = kAccessNoPose, svB = kAccessNoPose;
 
@@ -323,6 +329,133 @@ struct Contact {
             maximumTwistImpulse = premultipliedFrictionCoefficient * s;
         }
         twistIterate(n, twistMass, iA, iB, maximumTwistImpulse, a[2 + N], vA, vB);
+    }
+};
+
+// ======================================================================================
+// Nonconvex contact manifolds, N = 2..4 contacts, one or two bodies — ContactNonconvexCommon.cs:177-299.
+// Prestep layout (ContactNonconvexTypes.cs:58-66 two-body, :161-167 one-body): {FrictionCoefficient, AngularFrequency, TwiceDampingRatio,
+// MaximumRecoveryVelocity}, [OffsetB xyz], N x {Offset xyz, Depth, Normal xyz} (NonconvexContactPrestepData, ContactNonconvexCommon.cs:11-16).
+// Accumulated impulses: N x {Tangent xy, Penetration} (NonconvexAccumulatedImpulses :171-175).
+// Every contact carries its own normal and friction: the rows are solved contact by contact, penetration then tangent (:274-283), with
+// the tangent basis of that contact's normal and maximum friction = FrictionCoefficient * that contact's penetration impulse.
+// ======================================================================================
+template <int N, bool TwoBody>
+struct NonconvexContact {
+    using R = Contact<1, TwoBody>;  // the penetration / tangent row functions are shared with the convex manifolds
+    static constexpr int bodies = TwoBody ? 2 : 1;
+    static constexpr int cOff = TwoBody ? 7 : 4;
+    static constexpr int prestepFloats = cOff + 7 * N;
+    static constexpr int impulseFloats = 3 * N;
+    static constexpr int typeId = TwoBody ? 13 + N : 6 + N;  // ContactNonconvexTypes.cs:109,192,300,385,496,583
+    static constexpr bool incremental = true;
+    static constexpr int contacts = N;
+    static constexpr int depthRow(int c) { return cOff + 7 * c + 3; }
+    static constexpr int wsA = kAccessNoPose, wsB = kAccessNoPose, svA = kAccessNoPose, svB = kAccessNoPose;  // contact type processors: TwoBodyTypeProcessor.cs:244-250
+
+    BD_FN float friction(const float* p) { return p[0]; }
+    BD_FN float springFreq(const float* p) { return p[1]; }
+    BD_FN float springDamp(const float* p) { return p[2]; }
+    BD_FN float maxRecovery(const float* p) { return p[3]; }
+    BD_FN V3 offsetB(const float* p) { return {p[4], p[5], p[6]}; }
+    BD_FN V3 offset(const float* p, int i) { return {p[cOff + 7 * i], p[cOff + 7 * i + 1], p[cOff + 7 * i + 2]}; }
+    BD_FN float& depth(float* p, int i) { return p[cOff + 7 * i + 3]; }
+    BD_FN V3 normal(const float* p, int i) { return {p[cOff + 7 * i + 4], p[cOff + 7 * i + 5], p[cOff + 7 * i + 6]}; }
+
+    BD_FN void incrementalUpdate(float dt, const BodyVel& vA, const BodyVel& vB, float* p) {  // :238-247, :289-298 -> PenetrationLimit.cs:29-43
+        _Pragma("unroll") for (int i = 0; i < N; ++i) {
+            V3 n = normal(p, i);
+            V3 contactOffsetA = offset(p, i);
+            V3 wxra = cross(vA.ang, contactOffsetA);
+            V3 contactVelocityA = add(wxra, vA.lin);
+            float estimatedDepthChangeVelocity;
+            if (TwoBody) {
+                V3 contactOffsetB = sub(contactOffsetA, offsetB(p));
+                V3 wxrb = cross(vB.ang, contactOffsetB);
+                V3 contactVelocityB = add(wxrb, vB.lin);
+                V3 contactVelocityDifference = sub(contactVelocityA, contactVelocityB);
+                estimatedDepthChangeVelocity = dot(n, contactVelocityDifference);
+            } else {
+                estimatedDepthChangeVelocity = dot(n, contactVelocityA);
+            }
+            depth(p, i) = depth(p, i) - estimatedDepthChangeVelocity * dt;
+        }
+    }
+    // A waiting gate (island schedule) wants every contact's velocity-independent rows evaluated ahead of it; the launch-per-batch kernels have
+    // nothing to wait for and keep one contact's rows live at a time instead (same values either way: the rows do not depend on velocities).
+    template <class G> BD_FN void warmStart(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :192-206, :254-270
+        if constexpr (std::remove_reference_t<G>::kPin) {
+            typename R::TJ j[N];
+            V3 angularA[N], angularB[N];
+            _Pragma("unroll") for (int i = 0; i < N; ++i) warmStartRows(p, i, j[i], angularA[i], angularB[i]);
+            BD_GATE(vA, vB, j, angularA, angularB);
+            _Pragma("unroll") for (int i = 0; i < N; ++i) {
+                R::tangentApply(j[i], iA, iB, V2{a[3 * i], a[3 * i + 1]}, vA, vB);
+                R::penApply(iA, iB, normal(p, i), angularA[i], angularB[i], a[3 * i + 2], vA, vB);
+            }
+        } else {
+            gate(vA, vB);
+            _Pragma("unroll") for (int i = 0; i < N; ++i) {
+                if (i > 0) orderAfterPreviousContact(p, i, vA, vB);
+                typename R::TJ j; V3 angularA, angularB;
+                warmStartRows(p, i, j, angularA, angularB);
+                R::tangentApply(j, iA, iB, V2{a[3 * i], a[3 * i + 1]}, vA, vB);
+                R::penApply(iA, iB, normal(p, i), angularA, angularB, a[3 * i + 2], vA, vB);
+            }
+        }
+    }
+    // Launch-per-batch kernels: keep the compiler from evaluating every contact's rows up front (it would, they are independent of the velocities, and
+    // the register count of the whole kernel follows); contact i's inputs become available only after contact i-1 has updated the velocities.
+    BD_FN void orderAfterPreviousContact(float* p, int i, BodyVel& vA, BodyVel& vB) {
+        pin(vA, vB);
+        _Pragma("unroll") for (int f = 0; f < 7; ++f) pin_one(p[cOff + 7 * i + f]);
+    }
+    BD_FN void warmStartRows(const float* p, int i, typename R::TJ& j, V3& angularA, V3& angularB) {
+        V3 n = normal(p, i);
+        V3 x, z;
+        buildOrthonormalBasis(n, x, z);
+        V3 oA = offset(p, i);
+        V3 oB = TwoBody ? sub(oA, offsetB(p)) : V3{0, 0, 0};
+        j = R::tangentJacobians(x, z, oA, oB);
+        angularA = cross(oA, n);                          // PenetrationLimit.cs:69-76
+        angularB = TwoBody ? cross(n, oB) : V3{0, 0, 0};
+    }
+    BD_FN void solveRows(const Inertia& iA, const Inertia& iB, float* p, int i, float posErrToVel, float effMassCFMScale, float inverseDt,
+                         typename R::PenRow& row, typename R::TangentSetup& tangent) {
+        V3 n = normal(p, i);
+        V3 oA = offset(p, i);
+        V3 oB = TwoBody ? sub(oA, offsetB(p)) : V3{0, 0, 0};
+        row = R::penSetup(iA, iB, n, oA, oB, depth(p, i), posErrToVel, effMassCFMScale, maxRecovery(p), inverseDt);
+        V3 x, z;
+        buildOrthonormalBasis(n, x, z);
+        tangent = R::tangentSetup(x, z, oA, oB, iA, iB);
+    }
+    BD_FN void solveContact(const typename R::PenRow& row, const typename R::TangentSetup& tangentRows, const Inertia& iA, const Inertia& iB, float* p, float* a, int i,
+                            float softnessImpulseScale, BodyVel& vA, BodyVel& vB) {
+        R::penIterate(row, iA, iB, normal(p, i), softnessImpulseScale, a[3 * i + 2], vA, vB);
+        float maximumTangentImpulse = friction(p) * a[3 * i + 2];
+        V2 tangent{a[3 * i], a[3 * i + 1]};
+        R::tangentIterate(tangentRows, iA, iB, maximumTangentImpulse, tangent, vA, vB);
+        a[3 * i] = tangent.x; a[3 * i + 1] = tangent.y;
+    }
+    template <class G> BD_FN void solve(V3, Q, const Inertia& iA, V3, Q, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :208-228, :272-285
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(springFreq(p), springDamp(p), dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        if constexpr (std::remove_reference_t<G>::kPin) {
+            typename R::PenRow rows[N];
+            typename R::TangentSetup tangents[N];
+            _Pragma("unroll") for (int i = 0; i < N; ++i) solveRows(iA, iB, p, i, posErrToVel, effMassCFMScale, inverseDt, rows[i], tangents[i]);
+            BD_GATE(vA, vB, rows, tangents, softnessImpulseScale);
+            _Pragma("unroll") for (int i = 0; i < N; ++i) solveContact(rows[i], tangents[i], iA, iB, p, a, i, softnessImpulseScale, vA, vB);
+        } else {
+            gate(vA, vB);
+            _Pragma("unroll") for (int i = 0; i < N; ++i) {
+                if (i > 0) orderAfterPreviousContact(p, i, vA, vB);
+                typename R::PenRow row; typename R::TangentSetup tangent;
+                solveRows(iA, iB, p, i, posErrToVel, effMassCFMScale, inverseDt, row, tangent);
+                solveContact(row, tangent, iA, iB, p, a, i, softnessImpulseScale, vA, vB);
+            }
+        }
     }
 };
 
@@ -1521,6 +1654,296 @@ struct BallSocketServo {
     }
 };
 
+// ---- ServoSettingsWide, two-component forms (ServoSettings.cs:87-114, :153-165) ----
+BD_FN void servoClampedBiasVelocity(V2 errorAxis, float errorLength, float positionErrorToBiasVelocity, float maximumSpeed, float baseSpeedSetting, float maximumForce,
+                                    float dt, float inverseDt, V2& clampedBiasVelocity, float& maximumImpulse) {  // :87-101
+    float baseSpeed = vmin(baseSpeedSetting, errorLength * inverseDt);
+    float unclampedBiasSpeed = errorLength * positionErrorToBiasVelocity;
+    float targetSpeed = vmax(baseSpeed, unclampedBiasSpeed);
+    float sc = vmin(1.0f, maximumSpeed / targetSpeed);
+    bool useFallback = targetSpeed < 1e-10f;
+    sc = sel(useFallback, 1.0f, sc);
+    clampedBiasVelocity = scale(errorAxis, sc * unclampedBiasSpeed);
+    maximumImpulse = maximumForce * dt;
+}
+BD_FN void servoClampedBiasVelocityFromError(V2 error, float positionErrorToBiasVelocity, float maximumSpeed, float baseSpeedSetting, float maximumForce,
+                                             float dt, float inverseDt, V2& clampedBiasVelocity, float& maximumImpulse) {  // :103-113
+    float errorLength = length(error);
+    V2 errorAxis = scale(error, 1.0f / errorLength);
+    bool useFallback = errorLength < 1e-10f;
+    errorAxis = {sel(useFallback, 0.0f, errorAxis.x), sel(useFallback, 0.0f, errorAxis.y)};
+    servoClampedBiasVelocity(errorAxis, errorLength, positionErrorToBiasVelocity, maximumSpeed, baseSpeedSetting, maximumForce, dt, inverseDt, clampedBiasVelocity, maximumImpulse);
+}
+BD_FN void servoClampImpulse(float maximumImpulse, V2& accumulatedImpulse, V2& csi) {  // :153-165
+    V2 previousImpulse = accumulatedImpulse;
+    V2 unclamped = add(accumulatedImpulse, csi);
+    float impulseMagnitude = length(unclamped);
+    float impulseScale = sel(vabs(impulseMagnitude) < 1e-10f, 1.0f, vmin(maximumImpulse / impulseMagnitude, 1.0f));
+    accumulatedImpulse = scale(unclamped, impulseScale);
+    csi = sub(accumulatedImpulse, previousImpulse);
+}
+
+// ---- Linear axis constraints: a point of B held relative to a plane attached to A (LinearAxisServo.cs:88-224 shared functions) ----
+struct LinearAxisShared {
+    BD_FN void computeJacobians(V3 ab, Q orientationA, Q orientationB, V3 localPlaneNormalA, V3 localOffsetA, V3 localOffsetB,
+                                float& planeNormalDot, V3& normal, V3& angularJA, V3& angularJB) {  // :197-212
+        M3 orientationMatrixA = createFromQuaternion(orientationA);
+        normal = transform(localPlaneNormalA, orientationMatrixA);
+        V3 anchorA = transform(localOffsetA, orientationMatrixA);
+        V3 offsetB = transform(localOffsetB, orientationB);
+        V3 anchorB = add(ab, offsetB);
+        planeNormalDot = dot(sub(anchorB, anchorA), normal);
+        V3 offsetFromAToClosestPointOnPlaneToB = sub(anchorB, scale(normal, planeNormalDot));
+        angularJA = cross(offsetFromAToClosestPointOnPlaneToB, normal);
+        angularJB = cross(normal, offsetB);
+    }
+    BD_FN void computeEffectiveMass(V3 angularJA, V3 angularJB, const Inertia& iA, const Inertia& iB, float effectiveMassCFMScale,
+                                    V3& angularImpulseToVelocityA, V3& angularImpulseToVelocityB, float& effectiveMass) {  // :214-224
+        angularImpulseToVelocityA = transform(angularJA, iA.t);
+        angularImpulseToVelocityB = transform(angularJB, iB.t);
+        float angularContributionA = dot(angularJA, angularImpulseToVelocityA);
+        float angularContributionB = dot(angularJB, angularImpulseToVelocityB);
+        effectiveMass = effectiveMassCFMScale / (iA.invMass + iB.invMass + angularContributionA + angularContributionB);
+    }
+    BD_FN void applyImpulse(V3 linearJA, V3 angularImpulseToVelocityA, V3 angularImpulseToVelocityB, const Inertia& iA, const Inertia& iB, float csi, BodyVel& vA, BodyVel& vB) {  // :186-195
+        vA.lin = add(vA.lin, scale(linearJA, csi * iA.invMass));
+        vB.lin = sub(vB.lin, scale(linearJA, csi * iB.invMass));
+        vA.ang = add(vA.ang, scale(angularImpulseToVelocityA, csi));
+        vB.ang = add(vB.ang, scale(angularImpulseToVelocityB, csi));
+    }
+    BD_FN float constraintSpaceVelocity(const BodyVel& vA, const BodyVel& vB, V3 normal, V3 angularJA, V3 angularJB) {  // :246, LinearAxisMotor.cs:99, LinearAxisLimit.cs:139
+        return dot(sub(vA.lin, vB.lin), normal) + dot(vA.ang, angularJA) + dot(vB.ang, angularJB);
+    }
+};
+
+// LinearAxisServo — LinearAxisServo.cs:78-253. Prestep: LocalOffsetA xyz, LocalOffsetB xyz, LocalPlaneNormal xyz, TargetOffset, servo{3}, spring{2}. Impulse: scalar.
+struct LinearAxisServo {
+    static constexpr int bodies = 2, prestepFloats = 15, impulseFloats = 1, typeId = kLinearAxisServo;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessAll, wsB = kAccessAll, svA = kAccessAll, svB = kAccessAll;  // :250
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    template <class G> BD_FN void warmStart(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :226-232
+        float planeNormalDot; V3 normal, angularJA, angularJB;
+        LinearAxisShared::computeJacobians(sub(pB, pA), oA, oB, V3{p[6], p[7], p[8]}, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, planeNormalDot, normal, angularJA, angularJB);
+        V3 angularImpulseToVelocityA = transform(angularJA, iA.t);
+        V3 angularImpulseToVelocityB = transform(angularJB, iB.t);
+        BD_GATE(vA, vB, normal, angularImpulseToVelocityA, angularImpulseToVelocityB);
+        LinearAxisShared::applyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, iA, iB, a[0], vA, vB);
+    }
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :234-253
+        float planeNormalDot; V3 normal, angularJA, angularJB;
+        LinearAxisShared::computeJacobians(sub(pB, pA), oA, oB, V3{p[6], p[7], p[8]}, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, planeNormalDot, normal, angularJA, angularJB);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[13], p[14], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        V3 angularImpulseToVelocityA, angularImpulseToVelocityB; float effectiveMass;
+        LinearAxisShared::computeEffectiveMass(angularJA, angularJB, iA, iB, effMassCFMScale, angularImpulseToVelocityA, angularImpulseToVelocityB, effectiveMass);
+        float biasVelocity, maximumImpulse;
+        servoClampedBiasVelocity(planeNormalDot - p[9], posErrToVel, p[10], p[11], p[12], dt, inverseDt, biasVelocity, maximumImpulse);
+        BD_GATE(vA, vB, normal, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB, effectiveMass, biasVelocity, softnessImpulseScale, maximumImpulse);
+        float csv = LinearAxisShared::constraintSpaceVelocity(vA, vB, normal, angularJA, angularJB);
+        float csi = effectiveMass * (biasVelocity - csv) - a[0] * softnessImpulseScale;
+        servoClampImpulse(maximumImpulse, a[0], csi);
+        LinearAxisShared::applyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, iA, iB, csi, vA, vB);
+    }
+};
+
+// LinearAxisMotor — LinearAxisMotor.cs:73-114. Prestep: LocalOffsetA xyz, LocalOffsetB xyz, LocalPlaneNormal xyz, TargetVelocity, motor{MaximumForce, Damping}. Impulse: scalar.
+struct LinearAxisMotor {
+    static constexpr int bodies = 2, prestepFloats = 12, impulseFloats = 1, typeId = kLinearAxisMotor;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessAll, wsB = kAccessAll, svA = kAccessAll, svB = kAccessAll;  // :112
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    template <class G> BD_FN void warmStart(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :84-90
+        float planeNormalDot; V3 normal, angularJA, angularJB;
+        LinearAxisShared::computeJacobians(sub(pB, pA), oA, oB, V3{p[6], p[7], p[8]}, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, planeNormalDot, normal, angularJA, angularJB);
+        V3 angularImpulseToVelocityA = transform(angularJA, iA.t);
+        V3 angularImpulseToVelocityB = transform(angularJB, iB.t);
+        BD_GATE(vA, vB, normal, angularImpulseToVelocityA, angularImpulseToVelocityB);
+        LinearAxisShared::applyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, iA, iB, a[0], vA, vB);
+    }
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :92-105
+        float planeNormalDot; V3 normal, angularJA, angularJB;
+        LinearAxisShared::computeJacobians(sub(pB, pA), oA, oB, V3{p[6], p[7], p[8]}, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, planeNormalDot, normal, angularJA, angularJB);
+        float effMassCFMScale, softnessImpulseScale, maximumImpulse;
+        motorSoftness(p[10], p[11], dt, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        V3 angularImpulseToVelocityA, angularImpulseToVelocityB; float effectiveMass;
+        LinearAxisShared::computeEffectiveMass(angularJA, angularJB, iA, iB, effMassCFMScale, angularImpulseToVelocityA, angularImpulseToVelocityB, effectiveMass);
+        BD_GATE(vA, vB, normal, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB, effectiveMass, softnessImpulseScale, maximumImpulse);
+        float csv = LinearAxisShared::constraintSpaceVelocity(vA, vB, normal, angularJA, angularJB);
+        float csi = effectiveMass * (-p[9] - csv) - a[0] * softnessImpulseScale;
+        servoClampImpulse(maximumImpulse, a[0], csi);
+        LinearAxisShared::applyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, iA, iB, csi, vA, vB);
+    }
+};
+
+// LinearAxisLimit — LinearAxisLimit.cs:80-156. Prestep: LocalOffsetA xyz, LocalOffsetB xyz, LocalPlaneNormal xyz, MinimumOffset, MaximumOffset, spring{2}. Impulse: scalar.
+struct LinearAxisLimit {
+    static constexpr int bodies = 2, prestepFloats = 13, impulseFloats = 1, typeId = kLinearAxisLimit;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessAll, wsB = kAccessAll, svA = kAccessAll, svB = kAccessAll;  // :153
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    BD_FN void computeJacobians(V3 ab, Q orientationA, Q orientationB, V3 localPlaneNormal, V3 localOffsetA, V3 localOffsetB, float minimumOffset, float maximumOffset,
+                                float& error, V3& normal, V3& angularJA, V3& angularJB) {  // :92-118
+        M3 orientationMatrixA = createFromQuaternion(orientationA);
+        normal = transform(localPlaneNormal, orientationMatrixA);
+        V3 anchorA = transform(localOffsetA, orientationMatrixA);
+        V3 offsetB = transform(localOffsetB, orientationB);
+        V3 anchorB = add(ab, offsetB);
+        float planeNormalDot = dot(sub(anchorB, anchorA), normal);
+        // The limit chooses the normal's sign depending on which limit is closer.
+        float minimumError = minimumOffset - planeNormalDot;
+        float maximumError = planeNormalDot - maximumOffset;
+        bool useMin = vabs(minimumError) < vabs(maximumError);
+        error = sel(useMin, minimumError, maximumError);
+        normal = {sel(useMin, -normal.x, normal.x), sel(useMin, -normal.y, normal.y), sel(useMin, -normal.z, normal.z)};
+        // as in the reference, the (possibly negated) normal is scaled by the un-negated plane distance here
+        V3 offsetFromAToClosestPointOnPlaneToB = sub(anchorB, scale(normal, planeNormalDot));
+        angularJA = cross(offsetFromAToClosestPointOnPlaneToB, normal);
+        angularJB = cross(normal, offsetB);
+    }
+    template <class G> BD_FN void warmStart(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :120-126
+        float error; V3 normal, angularJA, angularJB;
+        computeJacobians(sub(pB, pA), oA, oB, V3{p[6], p[7], p[8]}, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, p[9], p[10], error, normal, angularJA, angularJB);
+        V3 angularImpulseToVelocityA = transform(angularJA, iA.t);
+        V3 angularImpulseToVelocityB = transform(angularJB, iB.t);
+        BD_GATE(vA, vB, normal, angularImpulseToVelocityA, angularImpulseToVelocityB);
+        LinearAxisShared::applyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, iA, iB, a[0], vA, vB);
+    }
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :128-146
+        float error; V3 normal, angularJA, angularJB;
+        computeJacobians(sub(pB, pA), oA, oB, V3{p[6], p[7], p[8]}, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, p[9], p[10], error, normal, angularJA, angularJB);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[11], p[12], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        V3 angularImpulseToVelocityA, angularImpulseToVelocityB; float effectiveMass;
+        LinearAxisShared::computeEffectiveMass(angularJA, angularJB, iA, iB, effMassCFMScale, angularImpulseToVelocityA, angularImpulseToVelocityB, effectiveMass);
+        float biasVelocity = vmin(error * inverseDt, error * posErrToVel);  // InequalityHelpers.ComputeBiasVelocity, InequalityHelpers.cs:9-12
+        BD_GATE(vA, vB, normal, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB, effectiveMass, biasVelocity, softnessImpulseScale);
+        float csv = LinearAxisShared::constraintSpaceVelocity(vA, vB, normal, angularJA, angularJB);
+        float csi = effectiveMass * (biasVelocity - csv) - a[0] * softnessImpulseScale;
+        clampPositive(a[0], csi);
+        LinearAxisShared::applyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, iA, iB, csi, vA, vB);
+    }
+};
+
+// PointOnLineServo — PointOnLineServo.cs:72-198. Prestep: LocalOffsetA xyz, LocalOffsetB xyz, LocalDirection xyz, servo{3}, spring{2}. Impulses: xy.
+struct PointOnLineServo {
+    static constexpr int bodies = 2, prestepFloats = 14, impulseFloats = 2, typeId = kPointOnLineServo;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessAll, wsB = kAccessAll, svA = kAccessAll, svB = kAccessAll;  // :195
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    BD_FN void applyImpulse(BodyVel& vA, BodyVel& vB, const M23& linearJacobian, const M23& angularJacobianA, const M23& angularJacobianB, const Inertia& iA, const Inertia& iB, V2 csi) {  // :83-99
+        V3 linearImpulseA = transform(csi, linearJacobian);
+        V3 angularImpulseA = transform(csi, angularJacobianA);
+        V3 angularImpulseB = transform(csi, angularJacobianB);
+        V3 angularChangeA = transform(angularImpulseA, iA.t);
+        V3 angularChangeB = transform(angularImpulseB, iB.t);
+        V3 linearChangeA = scale(linearImpulseA, iA.invMass);
+        V3 negatedLinearChangeB = scale(linearImpulseA, iB.invMass);
+        vA.lin = add(linearChangeA, vA.lin);
+        vA.ang = add(angularChangeA, vA.ang);
+        vB.lin = sub(vB.lin, negatedLinearChangeB);
+        vB.ang = add(angularChangeB, vB.ang);
+    }
+    BD_FN void computeJacobians(V3 ab, Q orientationA, Q orientationB, V3 localDirection, V3 localOffsetA, V3 localOffsetB,
+                                V3& anchorOffset, M23& linearJacobian, M23& angularJA, M23& angularJB) {  // :102-127
+        V3 localTangentX, localTangentY;
+        buildOrthonormalBasis(localDirection, localTangentX, localTangentY);
+        M3 orientationMatrixA = createFromQuaternion(orientationA);
+        V3 anchorA = transform(localOffsetA, orientationMatrixA);
+        V3 offsetB = transform(localOffsetB, orientationB);
+        // offsetA: the closest point on the line to anchorB
+        V3 direction = transform(localDirection, orientationMatrixA);
+        V3 anchorB = add(offsetB, ab);
+        anchorOffset = sub(anchorB, anchorA);
+        float d = dot(anchorOffset, direction);
+        V3 lineStartToClosestPointOnLine = scale(direction, d);
+        V3 offsetA = add(lineStartToClosestPointOnLine, anchorA);
+        linearJacobian.X = transform(localTangentX, orientationMatrixA);
+        linearJacobian.Y = transform(localTangentY, orientationMatrixA);
+        angularJA.X = cross(offsetA, linearJacobian.X);
+        angularJA.Y = cross(offsetA, linearJacobian.Y);
+        angularJB.X = cross(linearJacobian.X, offsetB);
+        angularJB.Y = cross(linearJacobian.Y, offsetB);
+    }
+    template <class G> BD_FN void warmStart(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :128-132
+        V3 anchorOffset; M23 linearJacobian, angularJA, angularJB;
+        computeJacobians(sub(pB, pA), oA, oB, V3{p[6], p[7], p[8]}, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, anchorOffset, linearJacobian, angularJA, angularJB);
+        BD_GATE(vA, vB, linearJacobian, angularJA, angularJB);
+        applyImpulse(vA, vB, linearJacobian, angularJA, angularJB, iA, iB, V2{a[0], a[1]});
+    }
+    template <class G> BD_FN void solve(V3 pA, Q oA, const Inertia& iA, V3 pB, Q oB, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :134-187
+        V3 anchorOffset; M23 linearJacobian, angularJA, angularJB;
+        computeJacobians(sub(pB, pA), oA, oB, V3{p[6], p[7], p[8]}, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, anchorOffset, linearJacobian, angularJA, angularJB);
+        Sym2 linearContribution = sandwichScale(linearJacobian, iA.invMass + iB.invMass);
+        Sym2 angularContributionA = matrixSandwich(angularJA, iA.t);
+        Sym2 angularContributionB = matrixSandwich(angularJB, iB.t);
+        Sym2 inverseEffectiveMass = add(angularContributionA, angularContributionB);
+        inverseEffectiveMass = add(inverseEffectiveMass, linearContribution);
+        Sym2 effectiveMass = invert(inverseEffectiveMass);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[12], p[13], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        effectiveMass = {effectiveMass.xx * effMassCFMScale, effectiveMass.yx * effMassCFMScale, effectiveMass.yy * effMassCFMScale};  // Symmetric2x2Wide.Scale :31-36
+        // position error and bias velocity (independent of the velocities: evaluated ahead of the constraint space velocity)
+        V2 error = {dot(anchorOffset, linearJacobian.X), dot(anchorOffset, linearJacobian.Y)};
+        V2 biasVelocity; float maximumImpulse;
+        servoClampedBiasVelocityFromError(error, posErrToVel, p[9], p[10], p[11], dt, inverseDt, biasVelocity, maximumImpulse);
+        BD_GATE(vA, vB, linearJacobian, angularJA, angularJB, effectiveMass, biasVelocity, softnessImpulseScale, maximumImpulse);
+        V2 linearCSVA = transformByTranspose(vA.lin, linearJacobian);
+        V2 negatedLinearCSVB = transformByTranspose(vB.lin, linearJacobian);
+        V2 angularCSVA = transformByTranspose(vA.ang, angularJA);
+        V2 angularCSVB = transformByTranspose(vB.ang, angularJB);
+        V2 linearCSV = sub(linearCSVA, negatedLinearCSVB);
+        V2 angularCSV = add(angularCSVA, angularCSVB);
+        V2 csv = add(linearCSV, angularCSV);
+        csv = sub(biasVelocity, csv);
+        V2 csi = transform(csv, effectiveMass);
+        V2 softnessContribution = scale(V2{a[0], a[1]}, softnessImpulseScale);
+        csi = sub(csi, softnessContribution);
+        V2 acc{a[0], a[1]};
+        servoClampImpulse(maximumImpulse, acc, csi);
+        a[0] = acc.x; a[1] = acc.y;
+        applyImpulse(vA, vB, linearJacobian, angularJA, angularJB, iA, iB, csi);
+    }
+};
+
+// AngularAxisGearMotor — AngularAxisGearMotor.cs:63-119. Prestep: LocalAxisA xyz, VelocityScale, motor{MaximumForce, Damping}. Impulse: scalar.
+struct AngularAxisGearMotor {
+    static constexpr int bodies = 2, prestepFloats = 6, impulseFloats = 1, typeId = kAngularAxisGearMotor;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessOnlyAngular, wsB = kAccessOnlyAngularWithoutPose, svA = kAccessOnlyAngular, svB = kAccessOnlyAngularWithoutPose;  // :116
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    BD_FN void applyImpulse(V3 impulseToVelocityA, V3 negatedImpulseToVelocityB, float csi, V3& angularVelocityA, V3& angularVelocityB) {  // :73-77
+        angularVelocityA = add(angularVelocityA, scale(impulseToVelocityA, csi));
+        angularVelocityB = sub(angularVelocityB, scale(negatedImpulseToVelocityB, csi));
+    }
+    template <class G> BD_FN void warmStart(V3, Q oA, const Inertia& iA, V3, Q, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :80-87
+        V3 axis = transform(V3{p[0], p[1], p[2]}, oA);
+        V3 jA = scale(axis, p[3]);
+        V3 impulseToVelocityA = transform(jA, iA.t);
+        V3 negatedImpulseToVelocityB = transform(axis, iB.t);
+        BD_GATE(vA, vB, impulseToVelocityA, negatedImpulseToVelocityB);
+        applyImpulse(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
+    }
+    template <class G> BD_FN void solve(V3, Q oA, const Inertia& iA, V3, Q, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :90-109
+        V3 axis = transform(V3{p[0], p[1], p[2]}, oA);
+        V3 jA = scale(axis, p[3]);
+        V3 impulseToVelocityA = transform(jA, iA.t);
+        float contributionA = dot(jA, impulseToVelocityA);
+        V3 negatedImpulseToVelocityB = transform(axis, iB.t);
+        float contributionB = dot(axis, negatedImpulseToVelocityB);
+        float effMassCFMScale, softnessImpulseScale, maximumImpulse;
+        motorSoftness(p[4], p[5], dt, effMassCFMScale, softnessImpulseScale, maximumImpulse);
+        float effectiveMass = effMassCFMScale / (contributionA + contributionB);
+        BD_GATE(vA, vB, axis, jA, impulseToVelocityA, negatedImpulseToVelocityB, effectiveMass, softnessImpulseScale, maximumImpulse);
+        float unscaledCSVA = dot(vA.ang, jA);
+        float negatedCSVB = dot(vB.ang, axis);
+        float csi = (negatedCSVB - unscaledCSVA) * effectiveMass - a[0] * softnessImpulseScale;
+        servoClampImpulse(maximumImpulse, a[0], csi);
+        // The reference applies the ACCUMULATED impulse here, not the corrective one (AngularAxisGearMotor.cs:108); reproduced as is.
+        applyImpulse(impulseToVelocityA, negatedImpulseToVelocityB, a[0], vA.ang, vB.ang);
+    }
+};
+
 // The non-contact types for the dispatch switches, X(type id, struct): SURVEY 8(a)'s rows a8-a13, and the 8(f) widening.
 #define BD_HOT_JOINT_TYPES(X)                                                                                                       \
     X(kBallSocket, BallSocket) X(kAngularHinge, AngularHinge) X(kSwingLimit, SwingLimit) X(kTwistServo, TwistServo)                 \
@@ -1529,7 +1952,14 @@ struct BallSocketServo {
     X(kWeld, Weld) X(kAngularSwivelHinge, AngularSwivelHinge) X(kTwistMotor, TwistMotor) X(kAngularServo, AngularServo)             \
     X(kDistanceServo, DistanceServo) X(kDistanceLimit, DistanceLimit) X(kAngularAxisMotor, AngularAxisMotor)                        \
     X(kOneBodyAngularServo, OneBodyAngularServo) X(kOneBodyAngularMotor, OneBodyAngularMotor) X(kOneBodyLinearServo, OneBodyLinearServo) \
-    X(kOneBodyLinearMotor, OneBodyLinearMotor) X(kBallSocketMotor, BallSocketMotor) X(kBallSocketServo, BallSocketServo)
+    X(kOneBodyLinearMotor, OneBodyLinearMotor) X(kBallSocketMotor, BallSocketMotor) X(kBallSocketServo, BallSocketServo) \
+    X(kPointOnLineServo, PointOnLineServo) X(kLinearAxisServo, LinearAxisServo) X(kLinearAxisMotor, LinearAxisMotor) X(kLinearAxisLimit, LinearAxisLimit) \
+    X(kAngularAxisGearMotor, AngularAxisGearMotor)
 #define BD_JOINT_TYPES(X) BD_HOT_JOINT_TYPES(X) BD_WIDENED_JOINT_TYPES(X)
+using NC2O = NonconvexContact<2, false>; using NC3O = NonconvexContact<3, false>; using NC4O = NonconvexContact<4, false>;
+using NC2T = NonconvexContact<2, true>; using NC3T = NonconvexContact<3, true>; using NC4T = NonconvexContact<4, true>;
+#define BD_NONCONVEX_CONTACT_TYPES(X)                                                                                              \
+    X(kContact2NonconvexOneBody, NC2O) X(kContact3NonconvexOneBody, NC3O) X(kContact4NonconvexOneBody, NC4O)                       \
+    X(kContact2Nonconvex, NC2T) X(kContact3Nonconvex, NC3T) X(kContact4Nonconvex, NC4T)
 
 }  // namespace bd

@@ -125,9 +125,9 @@ __device__ __forceinline__ void run_constraint(const DevTypeBatch& tb, int i, fl
         load_body<kAccessOnlyVelocity>(bodies, refA, A);
         if (F::bodies == 2) load_body<kAccessOnlyVelocity>(bodies, refB, B); else load_body<0>(bodies, 0, B);
         F::incrementalUpdate(dt, A.vel, B.vel, p);
-        // Only the contact depths change (PenetrationLimit.cs:42): prestep rows 4*c+3, c < contact count.
+        // Only the contact depths change (PenetrationLimit.cs:42): prestep rows F::depthRow(c), c < contact count.
         if constexpr (F::incremental) {
-            _Pragma("unroll") for (int cidx = 0; cidx < F::impulseFloats - 3; ++cidx) tb.prestep[(size_t)(4 * cidx + 3) * stride + i] = p[4 * cidx + 3];
+            _Pragma("unroll") for (int cidx = 0; cidx < F::contacts; ++cidx) tb.prestep[(size_t)F::depthRow(cidx) * stride + i] = p[F::depthRow(cidx)];
         }
         return;
     }
@@ -151,7 +151,7 @@ __device__ __forceinline__ void run_constraint(const DevTypeBatch& tb, int i, fl
 // Graph colouring guarantees that no dynamic body is referenced twice inside a batch (Solver.cs:1046-1051), so no two lanes of
 // the grid write the same body and results do not depend on lane order.
 template <int STAGE>
-__global__ __launch_bounds__(kBlock) void batch_kernel(const DevTypeBatch* __restrict__ tbs, int tb_begin, int tb_count, float4* bodies, float dt, float inv_dt) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void batch_kernel(const DevTypeBatch* __restrict__ tbs, int tb_begin, int tb_count, float4* bodies, float dt, float inv_dt) {
     const int b = blockIdx.x;
     int t = tb_begin;
     for (int k = 1; k < tb_count; ++k)
@@ -168,6 +168,9 @@ __global__ __launch_bounds__(kBlock) void batch_kernel(const DevTypeBatch* __res
         case kContact2: run_constraint<Contact<2, true>, STAGE>(tb, i, bodies, dt, inv_dt); break;
         case kContact3: run_constraint<Contact<3, true>, STAGE>(tb, i, bodies, dt, inv_dt); break;
         case kContact4: run_constraint<Contact<4, true>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+#define X(ID, T) case ID: run_constraint<T, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        BD_NONCONVEX_CONTACT_TYPES(X)
+#undef X
         default: break;
     }
     if (STAGE == kStageIncremental) return;  // only contacts need incremental updates (RequiresIncrementalSubstepUpdates)
@@ -569,6 +572,7 @@ struct ClusterGate {
     __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {
         if (TRACE) stamps.pre_gate = __builtin_readcyclecounter();
         wait_predecessors<CROSS>(sh, it, h, k, epoch);
+        __builtin_amdgcn_s_setprio(3);  // from here to the publish the item is on its bodies' critical path: issue ahead of waves still preparing theirs
         if (TRACE) stamps.post_gate = __builtin_readcyclecounter();
         load_velocity_lds<ACC_A>(sh, ra, A);
         if (BODIES == 2) load_velocity_lds<ACC_B>(sh, rb, B);
@@ -599,7 +603,7 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
         if (F::bodies == 2) load_body_lds<kAccessOnlyVelocity>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
         F::incrementalUpdate(dt, A.vel, B.vel, p);
         if constexpr (F::incremental) {
-            if (active) { _Pragma("unroll") for (int cidx = 0; cidx < F::impulseFloats - 3; ++cidx) prestep[(size_t)(4 * cidx + 3) * stride + i] = p[4 * cidx + 3]; }
+            if (active) { _Pragma("unroll") for (int cidx = 0; cidx < F::contacts; ++cidx) prestep[(size_t)F::depthRow(cidx) * stride + i] = p[F::depthRow(cidx)]; }
         }
         return;
     }
@@ -617,6 +621,7 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     store_velocity_lds<accA>(sh, active ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references)
     if (F::bodies == 2) store_velocity_lds<accB>(sh, active ? rb : -1, B);
     publish_item(sh.flags + k, sh.batch_done + h.batch, epoch);
+    __builtin_amdgcn_s_setprio(0);
     if (STAGE == kStageSolve && active) {  // off the critical path: nothing reads the impulses before the next pass (a barrier away)
         _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) accum[(size_t)f * stride + i] = a[f];
     }
@@ -633,6 +638,14 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
         BEPU_CASE(kContact1OneBody, DC1O) BEPU_CASE(kContact2OneBody, DC2O) BEPU_CASE(kContact3OneBody, DC3O) BEPU_CASE(kContact4OneBody, DC4O)
         BEPU_CASE(kContact1, DC1T) BEPU_CASE(kContact2, DC2T) BEPU_CASE(kContact3, DC3T) BEPU_CASE(kContact4, DC4T)
         default:
+            if constexpr (WIDE) {
+                bool nonconvex = true;
+                switch (h.type_id) {
+                    BD_NONCONVEX_CONTACT_TYPES(BEPU_CASE)
+                    default: nonconvex = false; break;
+                }
+                if (nonconvex) break;
+            }
             if constexpr (STAGE != kStageIncremental) {  // only contacts need incremental updates (RequiresIncrementalSubstepUpdates)
                 switch (h.type_id) {
                     BD_HOT_JOINT_TYPES(BEPU_CASE)
@@ -729,9 +742,9 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
             for (int k = wave; k < cd.item_count; k += nwaves) {
                 const ClusterItem* it = sh.items + k;
                 const ItemHeader h = read_item(it);
-                if (h.type_id > kContact4) continue;
+                if (!isContactType(h.type_id)) continue;
                 ItemStamps stamps = {0, 0, 0};
-                run_cluster_item<kStageIncremental, false, false>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
+                run_cluster_item<kStageIncremental, false, WIDE>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
             }
             __syncthreads();
         }
@@ -809,9 +822,16 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
 // ------------------------------------------------------------------------------------------------
 // cluster_kernel instantiations: register budget (launch bounds) x trace x type set. The traced build exists for the 1024-thread budget only (a kernel
 // compiled for 1024 threads runs any smaller workgroup).
+#ifdef BEPUHIP_FAST_BUILD  // kernel-tuning builds (tools/): one register budget, hot-path type set only
+#define BEPU_CLUSTER_VARIANTS(X) X(1024, false, false) X(1024, true, false)
+#else
 #define BEPU_CLUSTER_VARIANTS(X) X(512, false, false) X(768, false, false) X(1024, false, false) X(1024, true, false) \
                                  X(512, false, true) X(768, false, true) X(1024, false, true) X(1024, true, true)
+#endif
 static const void* cluster_kernel_variant(int threads, bool trace, bool wide) {
+#ifdef BEPUHIP_FAST_BUILD
+    return trace ? (const void*)cluster_kernel<1024, true, false> : (const void*)cluster_kernel<1024, false, false>;
+#endif
     const int budget = trace ? 1024 : (threads > 768 ? 1024 : threads > 512 ? 768 : 512);
 #define X(T, TR, W) if (budget == T && trace == TR && wide == W) return (const void*)cluster_kernel<T, TR, W>;
     BEPU_CLUSTER_VARIANTS(X)
@@ -839,6 +859,7 @@ static bool type_info(int id, TypeInfoH& t) {
         case kContact3: TI(C3T) case kContact4: TI(C4T)
 #define X(ID, T) case ID: TI(T)
         BD_JOINT_TYPES(X)
+        BD_NONCONVEX_CONTACT_TYPES(X)
 #undef X
     }
 #undef TI
@@ -849,6 +870,7 @@ static bool is_widened_type(int id) {
     switch (id) {
 #define X(ID, T) case ID: return true;
         BD_WIDENED_JOINT_TYPES(X)
+        BD_NONCONVEX_CONTACT_TYPES(X)
 #undef X
     }
     return false;
@@ -1105,7 +1127,17 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     for (int cl = 0; cl < nclusters; ++cl) last_toucher[cl].assign((cl_bodies[cl].size() + 15) / 16 * 16, -1);
     std::vector<std::vector<ClusterItem>> cl_items(nclusters);
     std::vector<std::vector<std::pair<int32_t, int32_t>>> first_touch(nclusters);  // (item, slot): the item is the slot's first toucher in a pass
-    for (size_t t = 0; t < c->tbs.size(); ++t) {
+    // Items are claimed in list order. Inside a batch any order is legal (a batch never references a body twice); the types that move the most data per
+    // constraint go first so that their loads and velocity-independent work start as early as the claim sequence allows.
+    std::vector<size_t> visit(c->tbs.size());
+    for (size_t t = 0; t < visit.size(); ++t) visit[t] = t;
+    if (env_int("BEPUHIP_CLUSTER_ORDER", 1) != 0)
+        std::stable_sort(visit.begin(), visit.end(), [&](size_t a, size_t b) {
+            const HostTypeBatch &x = c->tbs[a], &y = c->tbs[b];
+            if (x.batch != y.batch) return x.batch < y.batch;
+            return x.info.prestep + 2 * x.info.impulse > y.info.prestep + 2 * y.info.impulse;
+        });
+    for (size_t t : visit) {
         HostTypeBatch& tb = c->tbs[t];
         const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
         const std::vector<int32_t>& clc = cl_of_constraint[t];

@@ -48,6 +48,17 @@ bool GetTypeInfo(int typeId, TypeInfo& info) {
         case 52: info = {2, 8, 3, false}; return true;   // BallSocketMotor
         case 53: info = {2, 11, 3, false}; return true;  // BallSocketServo
         case 47: info = {2, 14, 5, false}; return true;  // Hinge
+        case 8: info = {1, 18, 6, true}; return true;    // Contact2NonconvexOneBody (ContactNonconvexTypes.cs:161-167, :192)
+        case 9: info = {1, 25, 9, true}; return true;    // Contact3NonconvexOneBody
+        case 10: info = {1, 32, 12, true}; return true;  // Contact4NonconvexOneBody
+        case 15: info = {2, 21, 6, true}; return true;   // Contact2Nonconvex (ContactNonconvexTypes.cs:58-66, :109)
+        case 16: info = {2, 28, 9, true}; return true;   // Contact3Nonconvex
+        case 17: info = {2, 35, 12, true}; return true;  // Contact4Nonconvex
+        case 37: info = {2, 14, 2, false}; return true;  // PointOnLineServo
+        case 38: info = {2, 15, 1, false}; return true;  // LinearAxisServo
+        case 39: info = {2, 12, 1, false}; return true;  // LinearAxisMotor
+        case 40: info = {2, 13, 1, false}; return true;  // LinearAxisLimit
+        case 54: info = {2, 6, 1, false}; return true;   // AngularAxisGearMotor
     }
     return false;
 }

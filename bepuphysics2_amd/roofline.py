@@ -26,6 +26,8 @@ ACCESS = {
     "OneBodyAngularServo": (ONLY_ANGULAR, 0, ONLY_ANGULAR, 0), "OneBodyAngularMotor": (ONLY_ANGULAR_NO_POSE, 0, ONLY_ANGULAR, 0),
     "OneBodyLinearServo": (ALL, 0, ALL, 0), "OneBodyLinearMotor": (NO_POSITION, 0, NO_POSITION, 0),
     "BallSocketMotor": (29, ALL, ALL, ALL), "BallSocketServo": (NO_POSITION, NO_POSITION, ALL, ALL),
+    "PointOnLineServo": (ALL,) * 4, "LinearAxisServo": (ALL,) * 4, "LinearAxisMotor": (ALL,) * 4, "LinearAxisLimit": (ALL,) * 4,
+    "AngularAxisGearMotor": (ONLY_ANGULAR, ONLY_ANGULAR_NO_POSE, ONLY_ANGULAR, ONLY_ANGULAR_NO_POSE),
 }
 
 
@@ -47,7 +49,10 @@ def stage_bytes(type_id: int):
     inc = 0
     if name.startswith("Contact"):
         n = int(name[7])
-        inc = 16 * n + 12 + (12 if nb == 2 else 0) + 4 * n + r + 24 * nb
+        if "Nonconvex" in name:  # every contact carries its own normal: 28 B read + 4 B depth written per contact
+            inc = 28 * n + (12 if nb == 2 else 0) + 4 * n + r + 24 * nb
+        else:
+            inc = 16 * n + 12 + (12 if nb == 2 else 0) + 4 * n + r + 24 * nb
     return ws, sv, inc
 
 

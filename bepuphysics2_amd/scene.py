@@ -29,6 +29,10 @@ TYPE_TABLE: Dict[int, tuple] = {
     24: (2, 8, 1, "AngularSwivelHinge"), 28: (2, 9, 1, "TwistMotor"), 29: (2, 9, 3, "AngularServo"), 33: (2, 12, 1, "DistanceServo"), 34: (2, 10, 1, "DistanceLimit"),
     41: (2, 6, 1, "AngularAxisMotor"), 42: (1, 9, 3, "OneBodyAngularServo"), 43: (1, 5, 3, "OneBodyAngularMotor"), 44: (1, 11, 3, "OneBodyLinearServo"),
     45: (1, 8, 3, "OneBodyLinearMotor"), 52: (2, 8, 3, "BallSocketMotor"), 53: (2, 11, 3, "BallSocketServo"),
+    8: (1, 18, 6, "Contact2NonconvexOneBody"), 9: (1, 25, 9, "Contact3NonconvexOneBody"), 10: (1, 32, 12, "Contact4NonconvexOneBody"),
+    15: (2, 21, 6, "Contact2Nonconvex"), 16: (2, 28, 9, "Contact3Nonconvex"), 17: (2, 35, 12, "Contact4Nonconvex"),
+    37: (2, 14, 2, "PointOnLineServo"), 38: (2, 15, 1, "LinearAxisServo"), 39: (2, 12, 1, "LinearAxisMotor"), 40: (2, 13, 1, "LinearAxisLimit"),
+    54: (2, 6, 1, "AngularAxisGearMotor"),
 }
 TYPE_IDS_BY_NAME = {v[3]: k for k, v in TYPE_TABLE.items()}
 # The sixteen types of SURVEY.md 8(a) rows a7-a13 (the committed tests/golden/small_scenes.npz fixtures were generated from exactly these).

@@ -261,7 +261,7 @@ void warmStartRange(Ctx& c, const OracleTypeBatch& tb, const std::vector<std::ve
         if (F::bodies == 2) gatherAndIntegrateBundle<Mode, AllowPose>(c, flagsForTypeBatch ? &(*flagsForTypeBatch)[1] : nullptr, dt, b, refsB, W, sB);
         for (int l = 0; l < W; ++l) {
             if (b * W + l >= tb.constraint_count) break;  // padding lanes (refs == -1) produce discarded garbage in the reference; skipped here
-            float p[32], a[8];
+            float p[40], a[16];
             loadLane<F>(tb, W, b, l, p, a);
             BodyState zero;
             memset(&zero, 0, sizeof(zero));
@@ -285,7 +285,7 @@ void solveRange(Ctx& c, const OracleTypeBatch& tb, float dt, float inverseDt, in
             BodyState A, B;
             gatherState(bodies, refsA[l], true, A);
             if (F::bodies == 2) gatherState(bodies, refsB[l], true, B); else memset(&B, 0, sizeof(B));
-            float p[32], a[8];
+            float p[40], a[16];
             loadLane<F>(tb, W, b, l, p, a);
             F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inverseDt, p, a, A.vel, B.vel);
             storeAccumulated<F>(tb, W, b, l, a);
@@ -307,7 +307,7 @@ void incrementalRange(Ctx& c, const OracleTypeBatch& tb, float dt, int startBund
             BodyState A, B;
             gatherState(bodies, refsA[l], true, A);
             if (F::bodies == 2) gatherState(bodies, refsB[l], true, B); else memset(&B, 0, sizeof(B));
-            float p[32], a[8];
+            float p[40], a[16];
             loadLane<F>(tb, W, b, l, p, a);
             F::incrementalUpdate(dt, A.vel, B.vel, p);
             storePrestep<F>(tb, W, b, l, p);
@@ -350,6 +350,7 @@ bool typeInfo(int typeId, int& bodies, int& prestepFloats, int& impulseFloats, b
         case kContact3: TI(C3T) case kContact4: TI(C4T)
 #define X(ID, T) case ID: TI(T)
         BO_JOINT_TYPES(X)
+        BO_NONCONVEX_CONTACT_TYPES(X)
 #undef X
     }
 #undef TI
@@ -366,6 +367,7 @@ void runBlock(Ctx& c, Stage stage, int batchIndex, int typeBatchIndex, int subst
         case kContact3: RT(C3T) case kContact4: RT(C4T)
 #define X(ID, T) case ID: RT(T)
         BO_JOINT_TYPES(X)
+        BO_NONCONVEX_CONTACT_TYPES(X)
 #undef X
     }
 #undef RT
@@ -704,6 +706,7 @@ int oracle_constraint_iterate(int type_id, float* bodyA, float* bodyB, float* pr
             case kContact3: IT(C3T) case kContact4: IT(C4T)
 #define X(ID, T) case ID: IT(T)
             BO_JOINT_TYPES(X)
+            BO_NONCONVEX_CONTACT_TYPES(X)
 #undef X
         }
 #undef IT

@@ -53,6 +53,16 @@ def contact_prestep(rng, n, two_body, pos_a, pos_b=None, friction=1.0, freq=30.0
     return lane
 
 
+def nonconvex_contact_prestep(rng, n, two_body, pos_a, pos_b=None, friction=1.0, freq=30.0, max_recovery=2.0):
+    """ContactNNonconvex[OneBody]PrestepData lane (ContactNonconvexTypes.cs:58-66, :161-167): material, [OffsetB], n x {Offset, Depth, Normal}."""
+    lane = [np.float32(friction)] + spring(freq, 1.0) + [np.float32(max_recovery)]
+    if two_body:
+        lane += list((np.asarray(pos_b, np.float32) - np.asarray(pos_a, np.float32)))
+    for _ in range(n):
+        lane += list(rng.uniform(-0.5, 0.5, 3).astype(np.float32)) + [np.float32(rng.uniform(-0.01, 0.02))] + list(unit(rng))
+    return lane
+
+
 def joint_prestep(rng, type_id):
     name = TYPE_TABLE[type_id][3]
     sp = spring(15.0, 1.0)
@@ -102,6 +112,17 @@ def joint_prestep(rng, type_id):
         return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-1, 1, 3)) + motor()
     if name == "BallSocketServo":
         return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + sp + servo()
+    if name == "PointOnLineServo":
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + servo() + sp
+    if name == "LinearAxisServo":
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + [rng.uniform(-1, 1)] + servo() + sp
+    if name == "LinearAxisMotor":
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + [rng.uniform(-1, 1)] + motor()
+    if name == "LinearAxisLimit":
+        lo = rng.uniform(-2.0, 1.0)
+        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + [lo, lo + rng.uniform(0.1, 2.0)] + sp
+    if name == "AngularAxisGearMotor":
+        return list(unit(rng)) + [rng.uniform(0.25, 3.0)] + motor()
     if name == "Weld":
         return list(rng.uniform(-0.5, 0.5, 3)) + list(rand_quat(rng)) + sp
     if name in ("SwivelHinge", "Hinge"):
@@ -113,6 +134,8 @@ def prestep_for(rng, type_id, pos_a, pos_b):
     nb, _, _, name = TYPE_TABLE[type_id]
     if name.startswith("Contact"):
         n = int(name[7])
+        if "Nonconvex" in name:
+            return nonconvex_contact_prestep(rng, n, nb == 2, pos_a, pos_b)
         return contact_prestep(rng, n, nb == 2, pos_a, pos_b)
     return joint_prestep(rng, type_id)
 
