@@ -819,6 +819,29 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
 
 // ------------------------------------------------------------------------------------------------
 // Host side
+// Ranged in-place update of one type batch's prestep / accumulated-impulse rows from the caller's AOSOA bundles (bepuhip_update_prestep /
+// bepuhip_update_accumulated_impulses): one thread per constraint of the range, `fields` strided stores each. `device_index` maps the constraint's
+// index inside the type batch to its slot in the SoA rows (identity unless the island schedule permuted the batch); null = identity.
+__global__ __launch_bounds__(256) void scatter_bundles_kernel(const float* __restrict__ bundles, float* __restrict__ rows, const int* __restrict__ device_index,
+                                                              int first_constraint, int constraint_count, int fields, int stride, int W) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= constraint_count) return;
+    const int h = first_constraint + j;
+    const int d = device_index ? device_index[h] : h;
+    const float* src = bundles + (size_t)(j / W) * fields * W + (j % W);
+    for (int f = 0; f < fields; ++f) rows[(size_t)f * stride + d] = src[(size_t)f * W];
+}
+// The inverse, for ranged read-back (bepuhip_get_*_range).
+__global__ __launch_bounds__(256) void gather_bundles_kernel(float* __restrict__ bundles, const float* __restrict__ rows, const int* __restrict__ device_index,
+                                                             int first_constraint, int constraint_count, int fields, int stride, int W) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= constraint_count) return;
+    const int h = first_constraint + j;
+    const int d = device_index ? device_index[h] : h;
+    float* dst = bundles + (size_t)(j / W) * fields * W + (j % W);
+    for (int f = 0; f < fields; ++f) dst[(size_t)f * W] = rows[(size_t)f * stride + d];
+}
+
 // ------------------------------------------------------------------------------------------------
 // cluster_kernel instantiations: register budget (launch bounds) x trace x type set. The traced build exists for the 1024-thread budget only (a kernel
 // compiled for 1024 threads runs any smaller workgroup).
@@ -886,6 +909,7 @@ struct HostTypeBatch {
         if (inv.empty()) { inv.resize(perm.size()); for (size_t d = 0; d < perm.size(); ++d) inv[perm[d]] = (int32_t)d; }
         return inv[host_index];
     }
+    int32_t* d_device_index = nullptr;  // device copy of `inv` for the ranged update / read-back kernels (allocated on first use)
     std::vector<int32_t> lrefs_soa; // cluster path: local (LDS) body indices
     std::vector<int32_t> refs_soa;
     std::vector<float> prestep_soa, accum_soa;  // host staging until end_constraints
@@ -921,6 +945,8 @@ struct bepuhip_ctx {
     std::vector<int> batch_blocks;       // grid size per batch
     uint32_t* d_slab = nullptr;          // all refs/prestep/accum
     uint32_t* d_slab0 = nullptr;         // pristine snapshot
+    float* d_stage = nullptr;            // staging for ranged updates / read-backs (caller's AOSOA bundles)
+    size_t stage_floats = 0;
     size_t slab_words = 0;
     DevTypeBatch* d_tbs = nullptr;       // per (batch) descriptors, solve/warm-start grids
     DevTypeBatch* d_inc_tbs = nullptr;   // incremental-update grid (contacts of all batches)
@@ -982,6 +1008,7 @@ static void free_constraints(bepuhip_ctx* c) {
     c->clusters_enabled = false; c->cluster_count = 0; c->clustered_dynamic_count = 0; c->kinlist_count = 0;
     c->d_slab = c->d_slab0 = nullptr;
     c->d_tbs = c->d_inc_tbs = nullptr;
+    for (auto& tb : c->tbs) if (tb.d_device_index) hipFree(tb.d_device_index);
     c->tbs.clear();
     c->built = false;
 }
@@ -1277,6 +1304,7 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_flags) hipFree(c->d_flags);
     if (c->d_kin) hipFree(c->d_kin);
     if (c->d_status) hipHostFree(c->d_status);
+    if (c->d_stage) hipFree(c->d_stage);
     if (c->d_boundary) hipFree(c->d_boundary);
     if (c->d_boundary_snapshot) hipFree(c->d_boundary_snapshot);
     if (c->d_boundary_buf) hipFree(c->d_boundary_buf);
@@ -1864,6 +1892,105 @@ int32_t bepuhip_get_prestep(bepuhip_ctx* c, int32_t batch, int32_t type_id, floa
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb) return fail(BEPUHIP_E_INVALID_ARGUMENT, "no such type batch");
     return download_aosoa(c, tb, tb->prestep_off, tb->info.prestep, out);
+}
+
+// ---- Device-resident incremental updates: ranged rewrites of what already lives in HBM, no re-plan, no full re-upload ----
+static int32_t stage_reserve(bepuhip_ctx* c, size_t floats) {
+    if (floats <= c->stage_floats) return BEPUHIP_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_stage) hipFree(c->d_stage);
+    c->d_stage = nullptr; c->stage_floats = 0;
+    HIP_TRY(hipMalloc((void**)&c->d_stage, floats * 4));
+    c->stage_floats = floats;
+    return BEPUHIP_OK;
+}
+static int32_t device_index_of(bepuhip_ctx* c, HostTypeBatch* tb, const int** out) {
+    *out = nullptr;
+    if (tb->perm.empty()) return BEPUHIP_OK;  // launch-per-batch layout: host order
+    if (!tb->d_device_index) {
+        tb->perm_inverse(0);
+        HIP_TRY(hipMalloc((void**)&tb->d_device_index, tb->inv.size() * 4));
+        HIP_TRY(hipMemcpy(tb->d_device_index, tb->inv.data(), tb->inv.size() * 4, hipMemcpyHostToDevice));
+    }
+    *out = tb->d_device_index;
+    return BEPUHIP_OK;
+}
+static int32_t bundle_range(bepuhip_ctx* c, int batch, int type_id, int first_bundle, int bundle_count, const void* buffer, HostTypeBatch** tb_out, int* first, int* n) {
+    if (!c || !c->built) return fail(BEPUHIP_E_STATE, "no constraints uploaded");
+    if (first_bundle < 0 || bundle_count < 0 || (!buffer && bundle_count > 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad bundle range");
+    HostTypeBatch* tb = find_tb(c, batch, type_id);
+    if (!tb) return fail(BEPUHIP_E_INVALID_ARGUMENT, "no such type batch");
+    const int bundles = (tb->count + c->W - 1) / c->W;
+    if (first_bundle + bundle_count > bundles) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bundle range exceeds the type batch");
+    *tb_out = tb;
+    *first = first_bundle * c->W;
+    *n = std::min(bundle_count * c->W, tb->count - *first);  // trailing lanes of the last bundle are empty (TypeProcessor.cs:287-298)
+    return BEPUHIP_OK;
+}
+static int32_t update_rows(bepuhip_ctx* c, int batch, int type_id, int first_bundle, int bundle_count, const float* bundles, bool prestep) {
+    HostTypeBatch* tb; int first, n;
+    int32_t st = bundle_range(c, batch, type_id, first_bundle, bundle_count, bundles, &tb, &first, &n);
+    if (st != BEPUHIP_OK || n <= 0) return st;
+    HIP_TRY(hipSetDevice(c->device));
+    const int fields = prestep ? tb->info.prestep : tb->info.impulse;
+    const size_t floats = (size_t)bundle_count * fields * c->W;
+    if ((st = stage_reserve(c, floats)) != BEPUHIP_OK) return st;
+    const int* index;
+    if ((st = device_index_of(c, tb, &index)) != BEPUHIP_OK) return st;
+    HIP_TRY(hipMemcpyAsync(c->d_stage, bundles, floats * 4, hipMemcpyHostToDevice, c->stream));
+    const size_t off = prestep ? tb->prestep_off : tb->accum_off;
+    for (uint32_t* slab : {c->d_slab, c->d_slab0})  // the pristine snapshot follows, so that reset_state restores "what the set_*/update_* calls uploaded"
+        if (slab) scatter_bundles_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_stage, (float*)(slab + off), index, first, n, fields, tb->stride, c->W);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's buffer and the staging buffer are free again on return
+    return BEPUHIP_OK;
+}
+static int32_t read_rows(bepuhip_ctx* c, int batch, int type_id, int first_bundle, int bundle_count, float* bundles_out, bool prestep) {
+    HostTypeBatch* tb; int first, n;
+    int32_t st = bundle_range(c, batch, type_id, first_bundle, bundle_count, bundles_out, &tb, &first, &n);
+    if (st != BEPUHIP_OK || n <= 0) return st;
+    HIP_TRY(hipSetDevice(c->device));
+    const int fields = prestep ? tb->info.prestep : tb->info.impulse;
+    const size_t floats = (size_t)bundle_count * fields * c->W;
+    if ((st = stage_reserve(c, floats)) != BEPUHIP_OK) return st;
+    const int* index;
+    if ((st = device_index_of(c, tb, &index)) != BEPUHIP_OK) return st;
+    HIP_TRY(hipMemsetAsync(c->d_stage, 0, floats * 4, c->stream));  // empty trailing lanes read back as zero
+    const size_t off = prestep ? tb->prestep_off : tb->accum_off;
+    gather_bundles_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_stage, (const float*)(c->d_slab + off), index, first, n, fields, tb->stride, c->W);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(bundles_out, c->d_stage, floats * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_update_prestep(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* prestep_bundles) {
+    return update_rows(c, batch, type_id, first_bundle, bundle_count, prestep_bundles, true);
+}
+int32_t bepuhip_update_accumulated_impulses(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* impulse_bundles) {
+    return update_rows(c, batch, type_id, first_bundle, bundle_count, impulse_bundles, false);
+}
+int32_t bepuhip_get_prestep_range(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* prestep_bundles_out) {
+    return read_rows(c, batch, type_id, first_bundle, bundle_count, prestep_bundles_out, true);
+}
+int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* impulse_bundles_out) {
+    return read_rows(c, batch, type_id, first_bundle, bundle_count, impulse_bundles_out, false);
+}
+int32_t bepuhip_update_bodies(bepuhip_ctx* c, const void* aos, int32_t first, int32_t count) {
+    if (!c || first < 0 || count < 0 || (!aos && count > 0) || first + count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad body range");
+    if (count == 0) return BEPUHIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->d_bodies + (size_t)first * 8, aos, (size_t)count * 128, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_bodies0 + (size_t)first * 8, c->d_bodies + (size_t)first * 8, (size_t)count * 128, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_get_bodies_range(bepuhip_ctx* c, void* aos_out, int32_t first, int32_t count) {
+    if (!c || first < 0 || count < 0 || (!aos_out && count > 0) || first + count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad body range");
+    if (count == 0) return BEPUHIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(aos_out, c->d_bodies + (size_t)first * 8, (size_t)count * 128, hipMemcpyDeviceToHost));
+    return BEPUHIP_OK;
 }
 
 int32_t bepuhip_get_constrained_flags(bepuhip_ctx* c, uint8_t* out, int32_t count) {

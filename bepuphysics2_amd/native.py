@@ -33,6 +33,8 @@ EXPORTED_SYMBOLS = [
     "bepuhip_get_stream", "bepuhip_solve_async", "bepuhip_sync", "bepuhip_reset_state", "bepuhip_type_info",
     "bepuhip_set_cluster_trace", "bepuhip_get_cluster_trace", "bepuhip_get_cluster_cycles", "bepuhip_debug_status",
     "bepuhip_set_boundary_bodies", "bepuhip_boundary_deltas", "bepuhip_boundary_apply", "bepuhip_solve_exchanged",
+    "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
+    "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
 ]
 
 
@@ -100,6 +102,10 @@ def load_library() -> C.CDLL:
     lib.bepuhip_debug_status.argtypes = [vp, vp]
     lib.bepuhip_get_cluster_trace.argtypes = [vp, vp, C.c_int64, C.POINTER(i32)]
     lib.bepuhip_type_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.bepuhip_update_bodies.argtypes = [vp, vp, i32, i32]
+    lib.bepuhip_get_bodies_range.argtypes = [vp, vp, i32, i32]
+    for name in ("bepuhip_update_prestep", "bepuhip_update_accumulated_impulses", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
+        getattr(lib, name).argtypes = [vp, i32, i32, i32, i32, vp]
     for name in EXPORTED_SYMBOLS:
         if name != "bepuhip_last_error":
             getattr(lib, name).restype = i32
@@ -249,6 +255,44 @@ class HipSolver:
                     continue
                 _check(self.lib, self.lib.bepuhip_get_accumulated_impulses(self.ctx, bi, tb.type_id, _ptr(tb.accumulated)))
                 _check(self.lib, self.lib.bepuhip_get_prestep(self.ctx, bi, tb.type_id, _ptr(tb.prestep)))
+
+    # ---- ranged in-place updates / read-backs (what the narrow phase and user code rewrite between frames) ----
+    def update_bodies(self, first: int, bodies: np.ndarray):
+        b = np.ascontiguousarray(bodies, dtype=np.float32).reshape(-1, 32)
+        _check(self.lib, self.lib.bepuhip_update_bodies(self.ctx, _ptr(b), first, b.shape[0]))
+
+    def get_bodies_range(self, first: int, count: int) -> np.ndarray:
+        out = np.empty((count, 32), dtype=np.float32)
+        _check(self.lib, self.lib.bepuhip_get_bodies_range(self.ctx, _ptr(out), first, count))
+        return out
+
+    def _bundle_floats(self, type_id: int, prestep: bool) -> int:
+        return (TYPE_TABLE[type_id][1] if prestep else TYPE_TABLE[type_id][2]) * self.bundle_width
+
+    def update_prestep(self, batch_index: int, type_id: int, first_bundle: int, bundles: np.ndarray):
+        """``bundles``: the type batch's PrestepData bundles [first_bundle, first_bundle + n) exactly as the reference stores them (AOSOA)."""
+        b = np.ascontiguousarray(bundles, dtype=np.float32).reshape(-1)
+        n, rem = divmod(b.size, self._bundle_floats(type_id, True))
+        if rem:
+            raise ValueError("prestep data is not a whole number of bundles")
+        _check(self.lib, self.lib.bepuhip_update_prestep(self.ctx, batch_index, type_id, first_bundle, n, _ptr(b)))
+
+    def update_accumulated_impulses(self, batch_index: int, type_id: int, first_bundle: int, bundles: np.ndarray):
+        b = np.ascontiguousarray(bundles, dtype=np.float32).reshape(-1)
+        n, rem = divmod(b.size, self._bundle_floats(type_id, False))
+        if rem:
+            raise ValueError("impulse data is not a whole number of bundles")
+        _check(self.lib, self.lib.bepuhip_update_accumulated_impulses(self.ctx, batch_index, type_id, first_bundle, n, _ptr(b)))
+
+    def get_prestep_range(self, batch_index: int, type_id: int, first_bundle: int, bundle_count: int) -> np.ndarray:
+        out = np.empty(bundle_count * self._bundle_floats(type_id, True), dtype=np.float32)
+        _check(self.lib, self.lib.bepuhip_get_prestep_range(self.ctx, batch_index, type_id, first_bundle, bundle_count, _ptr(out)))
+        return out
+
+    def get_accumulated_impulses_range(self, batch_index: int, type_id: int, first_bundle: int, bundle_count: int) -> np.ndarray:
+        out = np.empty(bundle_count * self._bundle_floats(type_id, False), dtype=np.float32)
+        _check(self.lib, self.lib.bepuhip_get_accumulated_impulses_range(self.ctx, batch_index, type_id, first_bundle, bundle_count, _ptr(out)))
+        return out
 
     def constrained_flags(self, count: int) -> np.ndarray:
         out = np.zeros(count, dtype=np.uint8)

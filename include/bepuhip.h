@@ -103,6 +103,22 @@ int32_t bepuhip_get_bodies(bepuhip_ctx* ctx, void* body_dynamics_aos_out, int32_
 int32_t bepuhip_get_accumulated_impulses(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, float* accumulated_impulses_aosoa_out);
 int32_t bepuhip_get_prestep(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, float* prestep_aosoa_out); /* contact depths change in substeps > 0 (PenetrationLimit.cs:42) */
 
+/* ---- Device-resident incremental updates ----
+ * Between frames the reference's narrow phase rewrites the prestep data (and, for persisting pairs, redistributes the accumulated impulses) of contact
+ * constraints IN PLACE (BepuPhysics/CollisionDetection/NarrowPhaseConstraintUpdate.cs:147-207, ContactConstraintAccessor UpdateConstraintForManifold),
+ * and user code rewrites poses / velocities of individual bodies (BodyReference setters, BepuPhysics/BodyReference.cs). Neither changes body references,
+ * counts or the batch structure, so the device copy is patched by range instead of being rebuilt: `first_bundle`/`bundle_count` select whole bundles of
+ * the type batch's PrestepData / AccumulatedImpulses buffers (AOSOA for config.bundle_width, the same layout set_type_batch takes), `first`/`count` select
+ * BodyDynamics structs. The caller's bundles are copied to the device as they are; a kernel transposes them into the solver's rows (and through the island
+ * schedule's permutation). Structural changes (Solver.Add/Remove, swap-with-last moves, TypeProcessor.cs:314-334,634-731) still go through begin/set/end.
+ * The *_range getters are the matching read-backs (e.g. only the contact type batches after a solve). */
+int32_t bepuhip_update_bodies(bepuhip_ctx* ctx, const void* body_dynamics_aos, int32_t first, int32_t count);
+int32_t bepuhip_update_prestep(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* prestep_bundles);
+int32_t bepuhip_update_accumulated_impulses(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* impulse_bundles);
+int32_t bepuhip_get_bodies_range(bepuhip_ctx* ctx, void* body_dynamics_aos_out, int32_t first, int32_t count);
+int32_t bepuhip_get_prestep_range(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* prestep_bundles_out);
+int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* impulse_bundles_out);
+
 /* Diagnostics / measurement (no reference counterpart; SimulationProfiler equivalent, BepuPhysics/SimulationProfiler.cs:9-74). */
 /* mergedConstrainedBodyHandles as computed on device, one byte per body INDEX: bit0 = referenced by any constraint,
  * bit1 = referenced as dynamic. For parity tests of the a2 prepass (BepuPhysics/Solver_Solve.cs:1198-1207,1378-1381). */
