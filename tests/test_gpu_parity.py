@@ -193,6 +193,23 @@ def test_full_size_ragdoll_tube_against_oracle_and_between_schedules(hip_solver_
     assert np.isfinite(clusters.bodies).all()
 
 
+def test_full_size_pile_against_oracle(hip_solver_factory):
+    """BASELINE.json configs[1] at its full size (100,000 boxes, 295,710 Contact1-4 constraints in ONE island, 4 substeps x 2 iterations):
+    the launch-per-batch schedule (the only one a single island allows) against the oracle, bit for bit, two frames."""
+    from bepuphysics2_amd.hostlib import HostSimulation
+    sim = HostSimulation.scene("pile", 100000, 0, 0, 5)
+    scene, sd = sim.export(), sim.solve_description()
+    sim.close()
+    assert scene.constraint_count > 290000 and sd.substep_count == 4 and list(sd.iterations()) == [2, 2, 2, 2]
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=8)
+    got = pu.run_hip(hip_solver_factory(), scene, 1 / 60, sd, cb, frames=2)
+    m = pu.compare_scenes(ref, got)
+    _check(m)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    assert np.isfinite(got.bodies).all()
+
+
 @pytest.mark.parametrize("threads", [64, 512, 768, 1024])
 def test_cluster_schedule_wave_counts(hip_solver_factory, threads, monkeypatch):
     """The work-item dataflow must give the same bits whatever the number of waves racing for items (1, 8, 12, 16 per workgroup)."""
