@@ -86,7 +86,8 @@ def measure_traffic(args):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="bepu_pmc_", dir="/tmp")
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BEPU_BENCH_FORCE_DIST")}
+            env["TMPDIR"] = "/tmp"
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "3", "--warmup", "1", "--ragdolls", str(args.ragdolls), "--no-cpu-baseline", "--no-traffic", "--traffic-child"]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
@@ -196,7 +197,7 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BEPU_BENCH_FORCE_DIST") == "1":  # (the env switch lets a 1-GPU box exercise the RCCL code path)
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local_rank)
@@ -205,7 +206,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
 
     from bepuphysics2_amd import build
-    build.build_all()  # no-op when the in-tree .so files are current
+    if rank == 0:
+        build.build_all()  # no-op when the in-tree .so files are current; one rank only: the outputs are shared files
+    if dist is not None:
+        dist.barrier()
     if args.lattice:
         return run_lattice(args, rank, local_rank, world, dist, torch)
     from bepuphysics2_amd.native import HipSolver
@@ -306,11 +310,11 @@ def main():
                         "algorithmic_bytes_per_launch": fam[dom]["algorithmic_bytes_per_launch"],
                         "families_ms_per_step": families, "other": fam["warmstart" if dom == "solve" else "solve"],
                         "step_algorithmic_GBs": step_gbs}
-        if roofline is not None and not args.no_traffic:
+        if roofline is not None and not args.no_traffic and world == 1:  # the PMC child runs and the CPU baseline are N=1 legs
             roofline["traffic"] = measure_traffic(args)
 
     baseline = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         baseline = cpu_baseline(max(args.ragdolls // 8, 64), 5)
 
     if rank == 0:

@@ -33,8 +33,10 @@ def build_hip(force: bool = False) -> str:
     sources = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h"))] + [os.path.join(REPO, "include", "bepuhip.h")]
     if not force and _newer(out, sources):
         return out
-    cmd = [_hipcc()] + HIP_FLAGS + ["-o", out, os.path.join(src_dir, "bepuhip.hip")]
+    tmp = out + f".tmp{os.getpid()}"  # build aside, then rename: a concurrent reader never sees a half-written library
+    cmd = [_hipcc()] + HIP_FLAGS + ["-o", tmp, os.path.join(src_dir, "bepuhip.hip")]
     subprocess.check_call(cmd, cwd=src_dir)
+    os.replace(tmp, out)
     return out
 
 
@@ -47,8 +49,10 @@ def build_host(force: bool = False) -> str:
         return ""
     if not force and _newer(out, sources):
         return out
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-I", os.path.join(REPO, "include"), "-o", out] + cpps + ["-ldl"]
+    tmp = out + f".tmp{os.getpid()}"
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-I", os.path.join(REPO, "include"), "-o", tmp] + cpps + ["-ldl"]
     subprocess.check_call(cmd, cwd=src_dir)
+    os.replace(tmp, out)
     return out
 
 
