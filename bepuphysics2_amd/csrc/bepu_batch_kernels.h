@@ -1,0 +1,315 @@
+// Launch-per-batch schedule and the per-body kernels: batch_kernel<stage>, constrained-set marking, kinematic / substep /
+// final integration, the boundary exchange of a scene split across GPUs, and the ranged update / read-back transposes.
+#pragma once
+
+#include "bepu_kernels_common.h"
+
+namespace {
+
+template <class F, int STAGE>
+__device__ __forceinline__ void run_constraint(const DevTypeBatch& tb, int i, float4* bodies, float dt, float inv_dt) {
+    const int stride = tb.stride;
+    const int refA = tb.refs[i];
+    const int refB = (F::bodies == 2) ? tb.refs[stride + i] : -1;
+    float p[F::prestepFloats];
+    _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = tb.prestep[(size_t)f * stride + i];
+    DBody A, B;
+    if (STAGE == kStageIncremental) {
+        load_body<kAccessOnlyVelocity>(bodies, refA, A);
+        if (F::bodies == 2) load_body<kAccessOnlyVelocity>(bodies, refB, B); else load_body<0>(bodies, 0, B);
+        F::incrementalUpdate(dt, A.vel, B.vel, p);
+        // Only the contact depths change (PenetrationLimit.cs:42): prestep rows F::depthRow(c), c < contact count.
+        if constexpr (F::incremental) {
+            _Pragma("unroll") for (int cidx = 0; cidx < F::contacts; ++cidx) tb.prestep[(size_t)F::depthRow(cidx) * stride + i] = p[F::depthRow(cidx)];
+        }
+        return;
+    }
+    float a[F::impulseFloats];
+    _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = tb.accum[(size_t)f * stride + i];
+    constexpr int accA = (STAGE == kStageWarmStart) ? F::wsA : F::svA;
+    constexpr int accB = (STAGE == kStageWarmStart) ? F::wsB : F::svB;
+    load_body<accA>(bodies, refA, A);
+    if (F::bodies == 2) load_body<accB>(bodies, refB, B); else load_body<0>(bodies, 0, B);
+    if (STAGE == kStageWarmStart) {
+        F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, NoGate{});
+    } else {
+        F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, NoGate{});
+        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) tb.accum[(size_t)f * stride + i] = a[f];
+    }
+    store_velocity<accA>(bodies, refA, A);
+    if (F::bodies == 2) store_velocity<accB>(bodies, refB, B);
+}
+
+// One grid per (batch, stage): the block index selects the type batch, the type id (wave-uniform) selects the function.
+// Graph colouring guarantees that no dynamic body is referenced twice inside a batch (Solver.cs:1046-1051), so no two lanes of
+// the grid write the same body and results do not depend on lane order.
+template <int STAGE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void batch_kernel(const DevTypeBatch* __restrict__ tbs, int tb_begin, int tb_count, float4* bodies, float dt, float inv_dt) {
+    const int b = blockIdx.x;
+    int t = tb_begin;
+    for (int k = 1; k < tb_count; ++k)
+        if (b >= tbs[tb_begin + k].block_begin) t = tb_begin + k;
+    const DevTypeBatch tb = tbs[t];
+    const int i = (b - tb.block_begin) * kBlock + threadIdx.x;
+    if (i >= tb.count) return;
+    switch (tb.type_id) {
+        case kContact1OneBody: run_constraint<Contact<1, false>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact2OneBody: run_constraint<Contact<2, false>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact3OneBody: run_constraint<Contact<3, false>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact4OneBody: run_constraint<Contact<4, false>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact1: run_constraint<Contact<1, true>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact2: run_constraint<Contact<2, true>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact3: run_constraint<Contact<3, true>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        case kContact4: run_constraint<Contact<4, true>, STAGE>(tb, i, bodies, dt, inv_dt); break;
+#define X(ID, T) case ID: run_constraint<T, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        BD_NONCONVEX_CONTACT_TYPES(X)
+#undef X
+        default: break;
+    }
+    if (STAGE == kStageIncremental) return;  // only contacts need incremental updates (RequiresIncrementalSubstepUpdates)
+    switch (tb.type_id) {
+#define X(ID, T) case ID: run_constraint<T, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        BD_JOINT_TYPES(X)
+#undef X
+        default: break;
+    }
+}
+
+// Body flag bits (per body index).
+enum { kFlagConstrained = 1, kFlagDynamicConstrained = 2, kFlagConstrainedKinematic = 4, kFlagClustered = 8 /* dynamic body owned by a cluster_kernel workgroup */ };
+
+// Device-side equivalent of the merged constrained-body set of PrepareConstraintIntegrationResponsibilities
+// (Solver_Solve.cs:1198-1207,1378-1381): every body referenced as dynamic gets integration inside the solver.
+__global__ void mark_constrained_kernel(const int* __restrict__ refs, int count, int stride, int bodies_per_constraint, unsigned* flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    for (int k = 0; k < bodies_per_constraint; ++k) {
+        int ref = refs[(size_t)k * stride + i];
+        if (ref < 0) continue;
+        // dynamic reference -> integrated inside the solver; kinematic reference -> member of Solver.ConstrainedKinematicHandles (Solver.cs:68)
+        unsigned bits = kFlagConstrained | (((unsigned)ref < kDynamicLimit) ? kFlagDynamicConstrained : kFlagConstrainedKinematic);
+        atomicOr(&flags[ref & kRefMask], bits);
+    }
+}
+__global__ void mark_indices_kernel(const int* __restrict__ indices, int count, unsigned* flags, unsigned bits) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) atomicOr(&flags[indices[i] & kRefMask], bits);
+}
+
+__device__ __forceinline__ void velocity_callback(const StepParams& sp, BodyVel& v) {  // Demos/DemoCallbacks.cs:100-109
+    V3 g = {sp.gx, sp.gy, sp.gz};
+    v.lin = scale(add(v.lin, g), sp.lin_damp);
+    v.ang = scale(v.ang, sp.ang_damp);
+}
+
+// Cluster path only: advance the constrained kinematic bodies in global memory through the in-solver substeps
+// (PoseIntegrator.cs:451-535 applied substep_count times: substep 0 velocity only, later substeps pose then velocity).
+__global__ void kinematic_substeps_kernel(float4* bodies, const int* __restrict__ indices, int count, int substeps, int integrate_velocity_for_kinematics, StepParams sp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float4* base = bodies + (size_t)(indices[i] & kRefMask) * 8;
+    float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
+    Q ori = {q4.x, q4.y, q4.z, q4.w};
+    V3 pos = {p4.x, p4.y, p4.z};
+    BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+    for (int s = 0; s < substeps; ++s) {
+        if (s > 0) {
+            pos = add(pos, scale(vel.lin, sp.dt));
+            ori = integrateOrientation(ori, vel.ang, sp.dt * 0.5f);
+        }
+        if (integrate_velocity_for_kinematics) velocity_callback(sp, vel);
+    }
+    base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+    base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+    if (integrate_velocity_for_kinematics) {
+        base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+        base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+    }
+}
+
+// Per-substep integration of every constrained body — the work the reference fuses into the first-touching constraint's
+// warm start (TypeProcessor.cs:1204-1283) plus the kinematic prepass (PoseIntegrator.cs:451-535).
+// substep 0: velocity only; substep > 0: pose, then velocity. World inverse inertia is refreshed either way.
+__global__ __launch_bounds__(256) void substep_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, int integrate_pose,
+                                                                 int integrate_velocity_for_kinematics, int skip_clustered, StepParams sp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    unsigned f = flags[i];
+    float4* base = bodies + (size_t)i * 8;
+    if (skip_clustered && (f & kFlagClustered)) return;  // integrated in LDS by the owning cluster_kernel workgroup
+    if (f & kFlagDynamicConstrained) {
+        float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3], i0 = base[4], i1 = base[5];
+        Q ori = {q4.x, q4.y, q4.z, q4.w};
+        V3 pos = {p4.x, p4.y, p4.z};
+        BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+        Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+        Sym3 world;
+        if (integrate_pose) {                                           // IntegratePoseAndVelocity, TypeProcessor.cs:1204-1248
+            pos = add(pos, scale(vel.lin, sp.dt));                      // :1217
+            const Q previousOrientation = ori;
+            ori = integrateOrientation(ori, vel.ang, sp.dt * 0.5f);     // :1240
+            world = rotateInverseInertia(local, ori);                   // :1242
+            if (sp.angular_mode == 1) vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, world, vel.ang);                // :1224-1231
+            else if (sp.angular_mode == 2) vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, sp.dt);   // :1232-1238
+            base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+            base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+        } else {                                                        // IntegrateVelocity, TypeProcessor.cs:1251-1283
+            world = rotateInverseInertia(local, ori);                   // :1262
+            if (sp.angular_mode == 1) {
+                const Q previousOrientation = integrateOrientation(ori, vel.ang, sp.dt * -0.5f);  // :1266 "integrating backwards"
+                vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, world, vel.ang);
+            } else if (sp.angular_mode == 2) {
+                vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, sp.dt);
+            }
+        }
+        velocity_callback(sp, vel);                                     // :1244 / :1273-1281
+        base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+        base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+        base[6] = make_float4(world.xx, world.yx, world.yy, world.zx);
+        base[7] = make_float4(world.zy, world.zz, i1.z, base[7].w);
+    } else if (f & kFlagConstrainedKinematic) {
+        float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
+        Q ori = {q4.x, q4.y, q4.z, q4.w};
+        V3 pos = {p4.x, p4.y, p4.z};
+        BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+        if (integrate_pose) {                                           // PoseIntegrator.cs:519-523
+            pos = add(pos, scale(vel.lin, sp.dt));
+            ori = integrateOrientation(ori, vel.ang, sp.dt * 0.5f);
+            base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+            base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+        }
+        if (integrate_velocity_for_kinematics) {                        // :524-529, :481-485
+            velocity_callback(sp, vel);
+            base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+            base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+        }
+    }
+}
+
+// Substep 0, conserving modes only: the reference transforms the angular velocity of EVERY lane of a conditionally integrating bundle before it saves
+// the "previous velocity" it later restores non-integrating lanes to (TypeProcessor.cs:1264-1281), so a body that was integrated by an earlier batch
+// is transformed once more when it shares a bundle (slot-wise) with a body that is integrated there. The host lists those bodies per batch
+// (bundle membership depends on the host's bundle width); this kernel runs before the batch's warm start. Bodies within a batch are distinct.
+__global__ void momentum_requirk_kernel(float4* bodies, const int* __restrict__ indices, int count, StepParams sp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float4* base = bodies + (size_t)indices[i] * 8;
+    const float4 q4 = base[0], a4 = base[3], i0 = base[4], i1 = base[5];
+    const Q ori = {q4.x, q4.y, q4.z, q4.w};
+    V3 ang = {a4.x, a4.y, a4.z};
+    const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+    if (sp.angular_mode == 1) {
+        const Sym3 world = rotateInverseInertia(local, ori);
+        const Q previousOrientation = integrateOrientation(ori, ang, sp.dt * -0.5f);
+        ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, world, ang);
+    } else {
+        ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, ang, sp.dt);
+    }
+    base[3] = make_float4(ang.x, ang.y, ang.z, a4.w);
+}
+
+// PoseIntegrator.IntegrateBundlesAfterSubstepping (PoseIntegrator.cs:537-693), one lane per body.
+__global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, float dt, float substep_dt, int substep_count,
+                                                               int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, int skip_clustered, StepParams sp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float4* base = bodies + (size_t)i * 8;
+    if (skip_clustered && (flags[i] & kFlagClustered)) return;  // final pose already written by the owning cluster_kernel workgroup
+    const bool unconstrained = !(flags[i] & kFlagConstrained);
+    const float effective_dt = allow_substeps_for_unconstrained ? substep_dt : (unconstrained ? dt : substep_dt);  // :591-599
+    const float half_dt = effective_dt * 0.5f;
+    float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
+    Q ori = {q4.x, q4.y, q4.z, q4.w};
+    V3 pos = {p4.x, p4.y, p4.z};
+    BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+    if (unconstrained) {
+        float4 i0 = base[4], i1 = base[5];
+        const bool is_kinematic = i0.x == 0 && i0.y == 0 && i0.z == 0 && i0.w == 0 && i1.x == 0 && i1.y == 0 && i1.z == 0;  // Bodies.cs:326-349
+        const bool velocity_mask = integrate_velocity_for_kinematics ? true : !is_kinematic;                                // :604-616
+        const int steps = allow_substeps_for_unconstrained ? substep_count : 1;
+        for (int s = 0; s < steps; ++s) {
+            if (velocity_mask) velocity_callback(sp, vel);   // velocity -> pose for unconstrained bodies (:634-667)
+            pos = add(pos, scale(vel.lin, effective_dt));
+            if (sp.angular_mode == 1) {                      // :649-655
+                const Q previousOrientation = ori;
+                ori = integrateOrientation(ori, vel.ang, half_dt);
+                const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+                vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, rotateInverseInertia(local, ori), vel.ang);
+            } else if (sp.angular_mode == 2) {               // :656-660
+                ori = integrateOrientation(ori, vel.ang, half_dt);
+                const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+                vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, effective_dt);
+            } else {
+                ori = integrateOrientation(ori, vel.ang, half_dt);
+            }
+        }
+        if (velocity_mask) {
+            base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+            base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+        }
+    } else {
+        ori = integrateOrientation(ori, vel.ang, half_dt);   // :684-691
+        pos = add(pos, scale(vel.lin, effective_dt));
+    }
+    base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+    base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+}
+
+
+
+// ---- boundary exchange (one connected scene split across GPUs, BASELINE.json configs[4]) ----
+// A boundary body exists on several ranks (owned on one, ghost elsewhere). Between passes every holder publishes what its own constraints did to the
+// body's velocity since the last synchronisation point, the ranks sum those deltas (RCCL all-reduce, done by the caller), and every holder
+// replaces its copy with snapshot + sum: block-Jacobi across the cut, Gauss-Seidel everywhere else.
+__global__ void boundary_snapshot_kernel(const float4* __restrict__ bodies, const int* __restrict__ indices, int count, float4* __restrict__ snapshot) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float4* base = bodies + (size_t)indices[i] * 8;
+    snapshot[2 * i] = base[2];
+    snapshot[2 * i + 1] = base[3];
+}
+__global__ void boundary_deltas_kernel(const float4* __restrict__ bodies, const int* __restrict__ indices, int count, const float4* __restrict__ snapshot, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float4* base = bodies + (size_t)indices[i] * 8;
+    const float4 l = base[2], a = base[3], l0 = snapshot[2 * i], a0 = snapshot[2 * i + 1];
+    float* o = out + (size_t)i * 6;
+    o[0] = l.x - l0.x; o[1] = l.y - l0.y; o[2] = l.z - l0.z;
+    o[3] = a.x - a0.x; o[4] = a.y - a0.y; o[5] = a.z - a0.z;
+}
+__global__ void boundary_apply_kernel(float4* bodies, const int* __restrict__ indices, int count, float4* snapshot, const float* __restrict__ sums) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float4* base = bodies + (size_t)indices[i] * 8;
+    const float* d = sums + (size_t)i * 6;
+    float4 l0 = snapshot[2 * i], a0 = snapshot[2 * i + 1];
+    const float4 l = make_float4(l0.x + d[0], l0.y + d[1], l0.z + d[2], l0.w);
+    const float4 a = make_float4(a0.x + d[3], a0.y + d[4], a0.z + d[5], a0.w);
+    base[2] = l; base[3] = a;
+    snapshot[2 * i] = l; snapshot[2 * i + 1] = a;  // the next pass's deltas are relative to the synchronised value
+}
+
+// Ranged in-place update of one type batch's prestep / accumulated-impulse rows from the caller's AOSOA bundles (bepuhip_update_prestep /
+// bepuhip_update_accumulated_impulses): one thread per constraint of the range, `fields` strided stores each. `device_index` maps the constraint's
+// index inside the type batch to its slot in the SoA rows (identity unless the island schedule permuted the batch); null = identity.
+__global__ __launch_bounds__(256) void scatter_bundles_kernel(const float* __restrict__ bundles, float* __restrict__ rows, const int* __restrict__ device_index,
+                                                              int first_constraint, int constraint_count, int fields, int stride, int W) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= constraint_count) return;
+    const int h = first_constraint + j;
+    const int d = device_index ? device_index[h] : h;
+    const float* src = bundles + (size_t)(j / W) * fields * W + (j % W);
+    for (int f = 0; f < fields; ++f) rows[(size_t)f * stride + d] = src[(size_t)f * W];
+}
+// The inverse, for ranged read-back (bepuhip_get_*_range).
+__global__ __launch_bounds__(256) void gather_bundles_kernel(float* __restrict__ bundles, const float* __restrict__ rows, const int* __restrict__ device_index,
+                                                             int first_constraint, int constraint_count, int fields, int stride, int W) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= constraint_count) return;
+    const int h = first_constraint + j;
+    const int d = device_index ? device_index[h] : h;
+    float* dst = bundles + (size_t)(j / W) * fields * W + (j % W);
+    for (int f = 0; f < fields; ++f) dst[(size_t)f * W] = rows[(size_t)f * stride + d];
+}
+
+}  // namespace

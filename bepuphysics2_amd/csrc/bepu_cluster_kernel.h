@@ -1,0 +1,427 @@
+// Island-per-workgroup schedule: cluster_kernel and its work-item dataflow.
+#pragma once
+
+#include "bepu_kernels_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Cluster path: islands (connected components of the constraint graph through dynamic bodies) are independent, so a workgroup
+// that owns whole islands can run EVERY stage of EVERY substep for them without leaving the CU: the islands' bodies live in
+// LDS for the whole frame (Bodies_GatherScatter's gather/scatter becomes ds_read_b128/ds_write_b128 on a per-workgroup body table)
+// and the 100+ dependent kernel boundaries of the launch-per-batch schedule disappear. HBM sees each body twice per frame (load,
+// write back) plus the constraint stream.
+//
+// Inside a pass (one WarmStart or one Solve sweep over the batches) the waves do not meet at a barrier per batch. The host splits
+// every cluster's constraints into work items (<= 64 consecutive constraints of one type batch) sorted by batch, and records for
+// each item its predecessors: the items that last touched any of its dynamic bodies. Waves claim items in that order from an LDS
+// counter, issue the item's global loads (body references, prestep, accumulated impulses), THEN wait on the predecessors' LDS
+// completion flags, gather, solve, scatter, and publish their own flag. The per-body order of constraint application is exactly
+// the host's batch order (hence every result bit is unchanged), the memory latency of item t+1 hides under the math of item t
+// running on another wave, and a heavy constraint type only delays the items that really depend on it.
+// Deadlock freedom: items are claimed in a topological order and a wave holds one item at a time, so the earliest unfinished
+// item always has all its predecessors finished.
+//
+// LDS: [8 planes of float4 x ncap body slots: the BodyDynamics record, one plane per 16-byte field][work items][flags, counters].
+// Slot numbering is rotated by the host inside every group of 16 (slot = (i & ~15) | ((i + (i >> 4)) & 15)) so that the regular
+// "same joint of consecutive ragdolls" access pattern (lane stride = island size) spreads over all 16 bank slots of ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPlanes = 8;
+constexpr int kClusterThreads = 1024;
+
+typedef __attribute__((address_space(1))) float gfloat;  // global
+typedef __attribute__((address_space(1))) int gint;
+typedef __attribute__((address_space(3))) unsigned lds_u32;  // LDS: ds_read/ds_write, lgkmcnt only (a generic pointer would poll with flat loads and drag vmcnt in)
+
+struct ClusterShared {
+    float4* planes;        // [kPlanes][ncap]
+    int ncap;
+    ClusterItem* items;
+    volatile lds_u32* flags;  // per item: epoch of the last completed pass
+    lds_u32* batch_done;      // per batch: items completed, monotonic over passes (fallback for items with too many predecessors)
+    int* lbib;                // batch -> first item of the cluster (batch_count + 1 entries)
+    lds_u32* counter;         // item claim counter, monotonic
+    int batch_count;
+    unsigned* status;      // global: [0] != 0 when a wait ran out of patience (a scheduling bug, never expected); [1..7] first offender
+};
+
+template <int ACCESS>
+__device__ __forceinline__ void load_body_lds(const ClusterShared& sh, int lref, DBody& b) {
+    const float4* base = sh.planes + (lref & kRefMask);
+    const int n = sh.ncap;
+    if (ACCESS & kOri) { float4 q = base[0]; b.ori = {q.x, q.y, q.z, q.w}; } else b.ori = {0, 0, 0, 0};
+    if (ACCESS & kPos) { float4 p = base[n]; b.pos = {p.x, p.y, p.z}; } else b.pos = {0, 0, 0};
+    if (ACCESS & kLin) { float4 l = base[2 * n]; b.vel.lin = {l.x, l.y, l.z}; b.linw = l.w; } else { b.vel.lin = {0, 0, 0}; b.linw = 0; }
+    if (ACCESS & kAng) { float4 a = base[3 * n]; b.vel.ang = {a.x, a.y, a.z}; b.angw = a.w; } else { b.vel.ang = {0, 0, 0}; b.angw = 0; }
+    if (ACCESS & kInertia) {
+        float4 i0 = base[6 * n], i1 = base[7 * n];
+        b.inertia.t = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+        b.inertia.invMass = i1.z;
+    } else { b.inertia.t = {0, 0, 0, 0, 0, 0}; b.inertia.invMass = 0; }
+}
+template <int ACCESS>
+__device__ __forceinline__ void load_velocity_lds(const ClusterShared& sh, int lref, DBody& b) {
+    const float4* base = sh.planes + (lref & kRefMask);
+    const int n = sh.ncap;
+    if (ACCESS & kLin) { float4 l = base[2 * n]; b.vel.lin = {l.x, l.y, l.z}; b.linw = l.w; }
+    if (ACCESS & kAng) { float4 a = base[3 * n]; b.vel.ang = {a.x, a.y, a.z}; b.angw = a.w; }
+}
+template <int ACCESS>
+__device__ __forceinline__ void store_velocity_lds(const ClusterShared& sh, int lref, const DBody& b) {
+    if ((unsigned)lref >= kDynamicLimit) return;
+    float4* base = sh.planes + lref;
+    if (ACCESS & kLin) base[2 * sh.ncap] = make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, b.linw);
+    if (ACCESS & kAng) base[3 * sh.ncap] = make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, b.angw);
+}
+
+
+struct ItemHeader {  // wave-uniform copy of the fields the constraint code needs (SGPRs)
+    int type_id, count, stride, start, batch, npred, nxpred, overflow, xoverflow;
+    unsigned lrefs_off, prestep_off, accum_off;
+};
+
+__device__ __forceinline__ ItemHeader read_item(const ClusterItem* it) {
+    ItemHeader h;
+    h.type_id = __builtin_amdgcn_readfirstlane(it->type_id);
+    h.count = __builtin_amdgcn_readfirstlane(it->count);
+    h.stride = __builtin_amdgcn_readfirstlane(it->stride);
+    h.start = __builtin_amdgcn_readfirstlane(it->start);
+    h.lrefs_off = __builtin_amdgcn_readfirstlane(it->lrefs_off);
+    h.prestep_off = __builtin_amdgcn_readfirstlane(it->prestep_off);
+    h.accum_off = __builtin_amdgcn_readfirstlane(it->accum_off);
+    const int packed = __builtin_amdgcn_readfirstlane(it->batch_npred);
+    h.batch = packed & 0xFFFF; h.npred = (packed >> 16) & 0xF; h.nxpred = (packed >> 20) & 0xF; h.overflow = (packed >> 24) & 1; h.xoverflow = (packed >> 25) & 1;
+    return h;
+}
+
+// Wave-level claim / publish as single opaque instructions sequences: one lane (exec = 1) touches the LDS word, the result is wave-uniform.
+// Written as inline asm so that the compiler sees no lane-0 branch next to the loop back-edge (it otherwise threads the "lane == 0"
+// publish of one iteration into the "lane == 0" claim of the next and builds a divergent loop around convergent operations).
+__device__ __forceinline__ unsigned lds_address(const volatile lds_u32* p) { return (unsigned)(__SIZE_TYPE__)p; }
+__device__ __forceinline__ unsigned claim_next(lds_u32* counter) {
+    unsigned ret;
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "ds_add_rtn_u32 %[r], %[a], %[one]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [r] "=&v"(ret), [sv] "=&s"(saved)
+        : [a] "v"(lds_address(counter)), [one] "v"(1u)
+        : "memory");
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)ret);
+}
+// The wave's LDS velocity stores must have landed before the flag does: LDS executes a wave's instructions in order, the explicit
+// wait makes that independent of the pipeline's internals.
+__device__ __forceinline__ void publish_item(volatile lds_u32* flag, lds_u32* batch_counter, unsigned epoch) {
+    unsigned long long saved;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "ds_write_b32 %[fa], %[e]\n\t"
+        "ds_add_u32 %[ba], %[one]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [sv] "=&s"(saved)
+        : [fa] "v"(lds_address(flag)), [e] "v"(epoch), [ba] "v"(lds_address(batch_counter)), [one] "v"(1u)
+        : "memory");
+}
+
+// Every spin is bounded: a wait that runs out of patience (~0.1 s) records itself in the status words and lets the wave continue, so a
+// scheduling bug turns into an error code from bepuhip_sync instead of a hung GPU.
+constexpr unsigned kSpinLimit = 1u << 21;
+__device__ __noinline__ void report_stall(unsigned* status, unsigned claims, int kind, int k, int what, unsigned want, unsigned seen) {
+    if ((threadIdx.x & 63) == 0 && atomicCAS(status, 0u, 1u) == 0u) {
+        status[1] = blockIdx.x; status[2] = (unsigned)kind; status[3] = (unsigned)k; status[4] = (unsigned)what;
+        status[5] = want; status[6] = seen; status[7] = claims;
+    }
+}
+// One bounded poll loop (all lanes read the same LDS word: a broadcast ds_read).
+__device__ __forceinline__ void wait_word(const ClusterShared& sh, const volatile lds_u32* word, unsigned want, int kind, int k, int what) {
+    unsigned spins = 0, seen;
+    while ((seen = (unsigned)__builtin_amdgcn_readfirstlane((int)*word)) < want) {
+        __builtin_amdgcn_s_sleep(1);  // 64 clocks; polling back to back or sleeping twice as long measures the same
+        if (++spins > kSpinLimit) { report_stall(sh.status, *sh.counter, kind, k, what, want, seen); break; }
+        if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
+    }
+}
+// Block until every predecessor of the item has published: same-pass predecessors must have finished `epoch`; with CROSS (a Solve item: the warm start
+// pass before it is not separated by a barrier) the last touchers of the bodies this item touches first must have finished `epoch - 1`.
+template <bool CROSS>
+__device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, unsigned epoch) {
+    for (int q = 0; q < h.npred; ++q) {
+        const int pred = __builtin_amdgcn_readfirstlane((int)it->pred[q]);
+        wait_word(sh, sh.flags + pred, epoch, 1, k, pred);
+    }
+    if (CROSS) {
+        for (int q = 0; q < h.nxpred; ++q) {
+            const int pred = __builtin_amdgcn_readfirstlane((int)it->xpred[q]);
+            wait_word(sh, sh.flags + pred, epoch - 1, 3, k, pred);
+        }
+    }
+    if (h.overflow) {  // more predecessors than the item records: wait for every item of every earlier batch
+        for (int b = 0; b < h.batch; ++b)
+            wait_word(sh, (const volatile lds_u32*)sh.batch_done + b, epoch * (unsigned)__builtin_amdgcn_readfirstlane(sh.lbib[b + 1] - sh.lbib[b]), 2, k, b);
+    }
+    if (CROSS && h.xoverflow) {  // ... and for the whole previous pass
+        for (int b = 0; b < sh.batch_count; ++b)
+            wait_word(sh, (const volatile lds_u32*)sh.batch_done + b, (epoch - 1) * (unsigned)__builtin_amdgcn_readfirstlane(sh.lbib[b + 1] - sh.lbib[b]), 4, k, b);
+    }
+    asm volatile("" ::: "memory");  // nothing below may be hoisted above the polls
+}
+
+struct ItemStamps { unsigned long long loaded, pre_gate, post_gate; };  // trace builds only
+
+// The gate the cluster path hands to the constraint functions: wait for the item's predecessors, then gather the velocities.
+template <int ACC_A, int ACC_B, int BODIES, bool CROSS, bool TRACE>
+struct ClusterGate {
+    static constexpr bool kPin = true;  // the constraint pins its velocity-independent values before calling: they are computed while the predecessors still run
+    const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; int ra, rb; DBody& A; DBody& B; ItemStamps& stamps;
+    __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {
+        if (TRACE) stamps.pre_gate = __builtin_readcyclecounter();
+        wait_predecessors<CROSS>(sh, it, h, k, epoch);
+        __builtin_amdgcn_s_setprio(3);  // from here to the publish the item is on its bodies' critical path: issue ahead of waves still preparing theirs
+        if (TRACE) stamps.post_gate = __builtin_readcyclecounter();
+        load_velocity_lds<ACC_A>(sh, ra, A);
+        if (BODIES == 2) load_velocity_lds<ACC_B>(sh, rb, B);
+    }
+};
+
+
+template <class F, int STAGE, bool TRACE>
+__device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
+                                                       unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
+    // Lanes beyond the item's count mirror its last constraint and never store: the whole body runs with a full exec mask,
+    // which keeps the control flow around the (wave-uniform) waits trivially structured.
+    const bool active = lane < h.count;
+    const int i = h.start + (active ? lane : h.count - 1), stride = h.stride;
+    const gint* lrefs = (const gint*)(slab + h.lrefs_off);
+    gfloat* prestep = (gfloat*)(slab + h.prestep_off);
+    gfloat* accum = (gfloat*)(slab + h.accum_off);
+    float p[F::prestepFloats];
+    float a[F::impulseFloats];
+    // issue the item's global loads first: their latency hides under the velocity-independent work and the wait for the predecessors
+    const int ra = lrefs[i];
+    const int rb = (F::bodies == 2) ? lrefs[stride + i] : -1;
+    _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
+    if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
+    DBody A, B;
+    if (STAGE == kStageIncremental) {  // reads velocities, writes only this constraint's depths: no ordering inside the stage
+        load_body_lds<kAccessOnlyVelocity>(sh, ra, A);
+        if (F::bodies == 2) load_body_lds<kAccessOnlyVelocity>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
+        F::incrementalUpdate(dt, A.vel, B.vel, p);
+        if constexpr (F::incremental) {
+            if (active) { _Pragma("unroll") for (int cidx = 0; cidx < F::contacts; ++cidx) prestep[(size_t)F::depthRow(cidx) * stride + i] = p[F::depthRow(cidx)]; }
+        }
+        return;
+    }
+    constexpr int accA = (STAGE == kStageWarmStart) ? F::wsA : F::svA;
+    constexpr int accB = (STAGE == kStageWarmStart) ? F::wsB : F::svB;
+    // Poses and inertias only change in the integration phase (a barrier away): gather them and let the constraint do all its
+    // velocity-independent work (jacobians, effective mass, bias) BEFORE waiting for the predecessors; the gate then waits and
+    // gathers the velocities, so only the corrective-impulse tail of the constraint sits on the cluster's critical path.
+    load_body_lds<accA & ~(kLin | kAng)>(sh, ra, A);
+    if (F::bodies == 2) load_body_lds<accB & ~(kLin | kAng)>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
+    if (TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps.loaded = __builtin_readcyclecounter(); }
+    ClusterGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps};
+    if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, gate);
+    else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, gate);
+    store_velocity_lds<accA>(sh, active ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references)
+    if (F::bodies == 2) store_velocity_lds<accB>(sh, active ? rb : -1, B);
+    publish_item(sh.flags + k, sh.batch_done + h.batch, epoch);
+    __builtin_amdgcn_s_setprio(0);
+    if (STAGE == kStageSolve && active) {  // off the critical path: nothing reads the impulses before the next pass (a barrier away)
+        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) accum[(size_t)f * stride + i] = a[f];
+    }
+}
+
+using DC1O = Contact<1, false>; using DC2O = Contact<2, false>; using DC3O = Contact<3, false>; using DC4O = Contact<4, false>;
+using DC1T = Contact<1, true>; using DC2T = Contact<2, true>; using DC3T = Contact<3, true>; using DC4T = Contact<4, true>;
+
+template <int STAGE, bool TRACE, bool WIDE>
+__device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
+                                                 unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
+#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps); break;
+    switch (h.type_id) {
+        BEPU_CASE(kContact1OneBody, DC1O) BEPU_CASE(kContact2OneBody, DC2O) BEPU_CASE(kContact3OneBody, DC3O) BEPU_CASE(kContact4OneBody, DC4O)
+        BEPU_CASE(kContact1, DC1T) BEPU_CASE(kContact2, DC2T) BEPU_CASE(kContact3, DC3T) BEPU_CASE(kContact4, DC4T)
+        default:
+            if constexpr (WIDE) {
+                bool nonconvex = true;
+                switch (h.type_id) {
+                    BD_NONCONVEX_CONTACT_TYPES(BEPU_CASE)
+                    default: nonconvex = false; break;
+                }
+                if (nonconvex) break;
+            }
+            if constexpr (STAGE != kStageIncremental) {  // only contacts need incremental updates (RequiresIncrementalSubstepUpdates)
+                switch (h.type_id) {
+                    BD_HOT_JOINT_TYPES(BEPU_CASE)
+                    default:
+                        if constexpr (WIDE) {  // SURVEY 8(f) types live in a second kernel variant: scenes made of the sixteen hot-path types keep the leaner one
+                            switch (h.type_id) {
+                                BD_WIDENED_JOINT_TYPES(BEPU_CASE)
+                                default: break;
+                            }
+                        }
+                        break;
+                }
+            }
+            break;
+    }
+#undef BEPU_CASE
+}
+
+// A sweep over the cluster's batches (Solver_Solve.cs:1447-1476 for the cluster's islands): the items of a WarmStart pass (epoch `epoch`) followed,
+// when `solve_items` > 0, by the items of the first velocity iteration (epoch + 1) in ONE claim sequence. No barrier separates the two: a Solve item
+// waits for its same-pass predecessors and, for the bodies it is the first to touch, for their last toucher of the warm start (cross-pass
+// predecessors), so the head of the iteration runs while the tail of the warm start's dependency chain is still draining. The warm start does
+// not write accumulated impulses, hence nothing the iteration loads from HBM is in flight. STAGE0 = kStageSolve with solve_items = 0 runs a
+// later iteration on its own (a barrier precedes it: its impulses were stored by the previous one).
+template <int STAGE0, bool TRACE, bool WIDE>
+__device__ __forceinline__ void run_cluster_sweep(const ClusterShared& sh, int item_count, int solve_items, int lane, int wave, unsigned epoch, unsigned claim_base,
+                                                  unsigned* __restrict__ slab, float dt, float inv_dt, unsigned long long* trace) {
+    for (;;) {
+        const int v = (int)(claim_next(sh.counter) - claim_base);
+        if (v >= item_count + solve_items) break;
+        const bool second = v >= item_count;
+        const int k = second ? v - item_count : v;
+        const unsigned item_epoch = second ? epoch + 1 : epoch;
+        const ClusterItem* it = sh.items + k;
+        const ItemHeader h = read_item(it);
+        unsigned long long t0 = 0;
+        if (TRACE) t0 = __builtin_readcyclecounter();
+        ItemStamps stamps = {0, 0, 0};
+        if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE, WIDE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+        else run_cluster_item<kStageSolve, TRACE, WIDE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+        if (TRACE && trace && blockIdx.x == 0 && lane == 0) {
+            unsigned long long* rec = trace + ((size_t)(item_epoch - 1) * item_count + k) * 8;
+            rec[4] = stamps.loaded; rec[5] = stamps.pre_gate; rec[6] = stamps.post_gate; rec[7] = 0;
+            rec[0] = t0; rec[1] = __builtin_readcyclecounter();
+            rec[2] = (unsigned long long)wave | ((unsigned long long)h.type_id << 8) | ((unsigned long long)h.batch << 16) | ((unsigned long long)((STAGE0 == kStageWarmStart && !second) ? kStageWarmStart : kStageSolve) << 32);
+            rec[3] = (unsigned long long)h.count;
+        }
+    }
+}
+
+template <int THREADS, bool TRACE, bool WIDE>
+__global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __restrict__ clusters, const ClusterItem* __restrict__ items,
+                                                                   const int* __restrict__ batch_item_begin, const int* __restrict__ cluster_bodies,
+                                                                   float4* bodies, unsigned* __restrict__ slab, ClusterParams cp, int ncap, int max_items,
+                                                                   unsigned long long* trace, unsigned* status, unsigned long long* cycles) {
+    const unsigned long long kernel_t0 = __builtin_readcyclecounter();
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];
+    ClusterShared sh;
+    sh.planes = lds;
+    sh.ncap = ncap;
+    sh.items = reinterpret_cast<ClusterItem*>(lds + kPlanes * ncap);
+    unsigned* words = reinterpret_cast<unsigned*>(lds + kPlanes * ncap + max_items * (int)(sizeof(ClusterItem) / 16));
+    sh.flags = (volatile lds_u32*)words;
+    sh.batch_done = (lds_u32*)(words + max_items);
+    sh.lbib = reinterpret_cast<int*>(words + max_items + kFallbackBatchLimit + 1);
+    sh.counter = (lds_u32*)(words + max_items + 2 * (kFallbackBatchLimit + 1) + 1);
+    sh.status = status;
+    sh.batch_count = cp.batch_count;
+    const ClusterDesc cd = clusters[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
+    const float dt = cp.sp.dt, inv_dt = cp.sp.inv_dt;
+    const int* slots = cluster_bodies + cd.body_begin;  // slot -> body index (bit 30: kinematic, private read-only copy; -1: unused slot)
+    // ---- stage the cluster in LDS: bodies (one plane per 16-byte field), work items, batch -> item ranges; clear the sync words ----
+    for (int j = tid; j < cd.slot_count * kPlanes; j += blockDim.x) {
+        const int slot = j >> 3, v = j & 7;
+        const int g = slots[slot];
+        lds[v * ncap + slot] = g >= 0 ? bodies[(size_t)(g & kRefMask) * 8 + v] : make_float4(0, 0, 0, 0);
+    }
+    {
+        const int4* src = reinterpret_cast<const int4*>(items + cd.item_begin);
+        int4* dst = reinterpret_cast<int4*>(sh.items);
+        for (int j = tid; j < cd.item_count * (int)(sizeof(ClusterItem) / 16); j += blockDim.x) dst[j] = src[j];
+    }
+    for (int j = tid; j < max_items + kFallbackBatchLimit + 1; j += blockDim.x) words[j] = 0;  // flags + batch_done
+    for (int j = tid; j <= cp.batch_count; j += blockDim.x) sh.lbib[j] = batch_item_begin[cd.batch_item_offset + j] - cd.item_begin;
+    if (tid == 0) *sh.counter = 0;
+    __syncthreads();
+
+    unsigned epoch = 0, claim_base = 0;
+    for (int s = 0; s < cp.substeps; ++s) {
+        if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(&sh.status[10], (unsigned)s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (s > 0) {  // Solver_Solve.cs:1427-1439: contact depths advance with the pre-integration velocities
+            for (int k = wave; k < cd.item_count; k += nwaves) {
+                const ClusterItem* it = sh.items + k;
+                const ItemHeader h = read_item(it);
+                if (!isContactType(h.type_id)) continue;
+                ItemStamps stamps = {0, 0, 0};
+                run_cluster_item<kStageIncremental, false, WIDE>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
+            }
+            __syncthreads();
+        }
+        // Integration of every constrained body of the cluster (TypeProcessor.cs:1204-1283, PoseIntegrator.cs:451-535):
+        // substep 0 velocity only, later substeps pose then velocity; world inverse inertia refreshed either way.
+        for (int j = tid; j < cd.slot_count; j += blockDim.x) {
+            const int g = slots[j];
+            if (g < 0) continue;
+            float4* r = lds + j;
+            float4 q4 = r[0], p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
+            Q ori = {q4.x, q4.y, q4.z, q4.w};
+            V3 pos = {p4.x, p4.y, p4.z};
+            BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+            if (s > 0) {
+                pos = add(pos, scale(vel.lin, dt));
+                ori = integrateOrientation(ori, vel.ang, dt * 0.5f);
+                r[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+                r[ncap] = make_float4(pos.x, pos.y, pos.z, p4.w);
+            }
+            if ((unsigned)g < kDynamicLimit) {
+                const float4 i0 = r[4 * ncap], i1 = r[5 * ncap];
+                Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+                Sym3 world = rotateInverseInertia(local, ori);
+                velocity_callback(cp.sp, vel);
+                r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+                r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+                r[6 * ncap] = make_float4(world.xx, world.yx, world.yy, world.zx);
+                r[7 * ncap] = make_float4(world.zy, world.zz, i1.z, r[7 * ncap].w);
+            } else if (cp.integrate_velocity_for_kinematics) {  // kinematic: private copy, same arithmetic as the global kinematic pass
+                velocity_callback(cp.sp, vel);
+                r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+                r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+            }
+        }
+        __syncthreads();
+        ++epoch;
+        const int fused = cp.iters[s] > 0 ? cd.item_count : 0;  // the first velocity iteration rides in the warm start's claim sequence
+        run_cluster_sweep<kStageWarmStart, TRACE, WIDE>(sh, cd.item_count, fused, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+        claim_base += cd.item_count + fused + nwaves;  // every wave makes exactly one failing claim per sweep
+        if (fused) ++epoch;
+        __syncthreads();
+        for (int iter = 1; iter < cp.iters[s]; ++iter) {
+            ++epoch;
+            run_cluster_sweep<kStageSolve, TRACE, WIDE>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+            claim_base += cd.item_count + nwaves;
+            __syncthreads();
+        }
+    }
+    // Trailing pose integration of constrained bodies (PoseIntegrator.cs:684-691) and write-back.
+    for (int j = tid; j < cd.slot_count; j += blockDim.x) {
+        const int g = slots[j];
+        if ((unsigned)g >= kDynamicLimit) continue;  // unused slot, or kinematic (advanced in global memory by kinematic_substeps_kernel + the final pass)
+        const float4* r = lds + j;
+        float4 q4 = r[0], p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
+        Q ori = {q4.x, q4.y, q4.z, q4.w};
+        V3 pos = {p4.x, p4.y, p4.z};
+        V3 lin = {l4.x, l4.y, l4.z}, ang = {a4.x, a4.y, a4.z};
+        ori = integrateOrientation(ori, ang, dt * 0.5f);
+        pos = add(pos, scale(lin, dt));
+        float4* gb = bodies + (size_t)g * 8;
+        gb[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+        gb[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+        gb[2] = l4;
+        gb[3] = a4;
+        gb[6] = r[6 * ncap];
+        gb[7] = r[7 * ncap];
+    }
+    if (tid == 0) cycles[blockIdx.x] = __builtin_readcyclecounter() - kernel_t0;  // shader clocks this cluster took: a clock-frequency-independent measure
+}
+
+}  // namespace

@@ -1,0 +1,249 @@
+// Host-side planning of the island-per-workgroup schedule (once per topology upload).
+#pragma once
+
+#include "bepu_host_state.h"
+
+// ---- cluster planning (host, once per topology upload) ----
+// Islands = connected components through dynamic bodies (kinematic references never connect: they are read-only to the solver).
+// Whole islands are packed, in body-index order, into clusters of at most `cap` LDS-resident bodies; each type batch is
+// reordered so that every cluster's constraints are contiguous (coalesced loads per <=64-lane work item), and every work item
+// records which earlier items last touched its dynamic bodies (the only ordering the solve has to respect).
+struct ClusterPlan {
+    bool enabled = false;
+    std::vector<ClusterDesc> clusters;
+    std::vector<ClusterItem> items;
+    std::vector<int> batch_item_begin, cluster_bodies, clustered_dynamic, kinlist;
+    int max_slots = 0, max_items = 0;
+};
+
+static int env_int(const char* name, int fallback) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : fallback;
+}
+
+constexpr size_t kLdsBudgetBytes = 160 * 1024 - 256;
+static size_t cluster_sync_words(int max_items) { return (size_t)max_items + 2 * (kFallbackBatchLimit + 1) + 2; }
+static size_t cluster_lds_bytes(int ncap, int max_items) {
+    return (size_t)kPlanes * ncap * 16 + (size_t)max_items * sizeof(ClusterItem) + (cluster_sync_words(max_items) + 3) / 4 * 16;
+}
+// Slot rotation inside every group of 16 (see the LDS layout note above cluster_kernel).
+static inline int rotated_slot(int i) { return (i & ~15) | ((i + (i >> 4)) & 15); }
+
+static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
+    int universe = 0;
+    for (auto& tb : c->tbs)
+        for (int32_t r : tb.refs_soa)
+            if (r >= 0) universe = std::max(universe, (r & kRefMask) + 1);
+    // kinematic list (Solver.ConstrainedKinematicHandles equivalent), always built
+    {
+        std::vector<uint8_t> seen(universe, 0);
+        for (auto& tb : c->tbs)
+            for (int k = 0; k < tb.info.bodies; ++k)
+                for (int i = 0; i < tb.count; ++i) {
+                    int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r >= kDynamicLimit && r >= 0 && !seen[r & kRefMask]) { seen[r & kRefMask] = 1; plan.kinlist.push_back(r & kRefMask); }
+                }
+    }
+    if ((c->flags & BEPUHIP_FLAG_NO_CLUSTERS) || env_int("BEPUHIP_NO_CLUSTERS", 0) || universe == 0 || c->total_constraints == 0 || c->batch_count > kFallbackBatchLimit) return;
+    std::vector<int32_t> parent(universe);
+    for (int i = 0; i < universe; ++i) parent[i] = i;
+    auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    std::vector<uint8_t> is_dyn(universe, 0);
+    for (auto& tb : c->tbs) {
+        for (int i = 0; i < tb.count; ++i) {
+            int first = -1;
+            for (int k = 0; k < tb.info.bodies; ++k) {
+                int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                if ((uint32_t)r >= kDynamicLimit) continue;
+                is_dyn[r] = 1;
+                if (first < 0) first = find(r);
+                else { int o = find(r); if (o != first) { if (o < first) std::swap(o, first); parent[o] = first; } }
+            }
+            if (first < 0) return;  // a constraint with no dynamic body: leave everything to the global path
+        }
+    }
+    // component sizes (root = smallest body index of the component)
+    std::vector<int32_t> comp_size(universe, 0);
+    int64_t total_dyn = 0;
+    int32_t largest = 0;
+    for (int i = 0; i < universe; ++i) if (is_dyn[i]) { largest = std::max(largest, ++comp_size[find(i)]); ++total_dyn; }
+    for (int i = 0; i < universe; ++i) if (is_dyn[i]) find(i);  // full path compression: parent[i] is the root from here on
+    int cap = env_int("BEPUHIP_CLUSTER_BODIES", 0);
+    if (cap <= 0) {
+        // default: one resident workgroup per CU (the kernel's LDS footprint admits one workgroup per CU), a single round
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        int64_t target = (total_dyn + (cus * 31 / 32) - 1) / std::max(1, cus * 31 / 32);
+        cap = (int)std::min<int64_t>(std::max<int64_t>(target, 64), 1200);
+    }
+    if (largest > cap) cap = largest;
+    // ---- phase A: find a cap whose clusters fit the LDS budget (no mutation yet) ----
+    std::vector<int32_t> cluster_of(universe, -1);  // by component root
+    std::vector<std::vector<int32_t>> cl_of_constraint(c->tbs.size());
+    int nclusters = 0;
+    for (int attempt = 0;; ++attempt) {
+        nclusters = 0;
+        int cur = 0;
+        for (int i = 0; i < universe; ++i) {
+            if (!is_dyn[i] || parent[i] != i) continue;  // roots only, ascending
+            if (nclusters == 0 || cur + comp_size[i] > cap) { ++nclusters; cur = 0; }
+            cluster_of[i] = nclusters - 1;
+            cur += comp_size[i];
+        }
+        std::vector<int32_t> dyn_count(nclusters, 0), item_count(nclusters, 0);
+        std::vector<std::vector<int32_t>> kin_seen(nclusters);
+        for (int i = 0; i < universe; ++i) if (is_dyn[i]) dyn_count[cluster_of[parent[i]]]++;
+        std::vector<int32_t> per_cluster(nclusters);
+        for (size_t t = 0; t < c->tbs.size(); ++t) {
+            HostTypeBatch& tb = c->tbs[t];
+            cl_of_constraint[t].resize(tb.count);
+            std::fill(per_cluster.begin(), per_cluster.end(), 0);
+            for (int i = 0; i < tb.count; ++i) {
+                int cl = -1;
+                for (int k = 0; k < tb.info.bodies && cl < 0; ++k) {
+                    int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r < kDynamicLimit) cl = cluster_of[parent[r]];
+                }
+                cl_of_constraint[t][i] = cl;
+                per_cluster[cl]++;
+                for (int k = 0; k < tb.info.bodies; ++k) {
+                    int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r >= kDynamicLimit) {
+                        auto& ks = kin_seen[cl];
+                        if (std::find(ks.begin(), ks.end(), r & kRefMask) == ks.end()) ks.push_back(r & kRefMask);
+                    }
+                }
+            }
+            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (per_cluster[cl] + 63) / 64;
+        }
+        int max_slots = 0, max_items = 0;
+        for (int cl = 0; cl < nclusters; ++cl) {
+            max_slots = std::max(max_slots, (dyn_count[cl] + (int)kin_seen[cl].size() + 15) / 16 * 16);
+            max_items = std::max(max_items, item_count[cl]);
+        }
+        if (max_items < 65536 && cluster_lds_bytes(max_slots, max_items) <= kLdsBudgetBytes) break;
+        if (cap <= largest || attempt > 24) return;  // an island (plus its work items) does not fit one workgroup: global path
+        cap = std::max<int>(largest, cap * 7 / 8);
+    }
+    // ---- phase B: local slots, reordered type batches, work items with predecessor lists ----
+    std::vector<std::vector<int32_t>> cl_bodies(nclusters);  // natural local order: dynamics ascending, kinematics appended on first use
+    std::vector<int32_t> local_of(universe, -1);
+    for (int i = 0; i < universe; ++i)
+        if (is_dyn[i]) { int cl = cluster_of[parent[i]]; local_of[i] = (int)cl_bodies[cl].size(); cl_bodies[cl].push_back(i); plan.clustered_dynamic.push_back(i); }
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> cl_kin(nclusters);  // (kinematic body, natural local index)
+    auto kin_local = [&](int cl, int body) {
+        for (auto& kv : cl_kin[cl]) if (kv.first == body) return kv.second;
+        int l = (int)cl_bodies[cl].size();
+        cl_bodies[cl].push_back(body | (int)kDynamicLimit);
+        cl_kin[cl].push_back({body, l});
+        return l;
+    };
+    std::vector<std::vector<int32_t>> last_toucher(nclusters);  // by slot: cluster-relative index of the item that last touched the (dynamic) body
+    for (int cl = 0; cl < nclusters; ++cl) last_toucher[cl].assign((cl_bodies[cl].size() + 15) / 16 * 16, -1);
+    std::vector<std::vector<ClusterItem>> cl_items(nclusters);
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> first_touch(nclusters);  // (item, slot): the item is the slot's first toucher in a pass
+    // Items are claimed in list order. Inside a batch any order is legal (a batch never references a body twice); the types that move the most data per
+    // constraint go first so that their loads and velocity-independent work start as early as the claim sequence allows.
+    std::vector<size_t> visit(c->tbs.size());
+    for (size_t t = 0; t < visit.size(); ++t) visit[t] = t;
+    if (env_int("BEPUHIP_CLUSTER_ORDER", 1) != 0)
+        std::stable_sort(visit.begin(), visit.end(), [&](size_t a, size_t b) {
+            const HostTypeBatch &x = c->tbs[a], &y = c->tbs[b];
+            if (x.batch != y.batch) return x.batch < y.batch;
+            return x.info.prestep + 2 * x.info.impulse > y.info.prestep + 2 * y.info.impulse;
+        });
+    for (size_t t : visit) {
+        HostTypeBatch& tb = c->tbs[t];
+        const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
+        const std::vector<int32_t>& clc = cl_of_constraint[t];
+        tb.perm.resize(tb.count);
+        for (int i = 0; i < tb.count; ++i) tb.perm[i] = i;
+        std::stable_sort(tb.perm.begin(), tb.perm.end(), [&](int a, int b) { return clc[a] < clc[b]; });
+        std::vector<int32_t> refs((size_t)nb * tb.stride, -1), lrefs((size_t)nb * tb.stride, -1);
+        std::vector<float> pre((size_t)pf * tb.stride, 0.0f), acc((size_t)imf * tb.stride, 0.0f);
+        for (int d = 0; d < tb.count; ++d) {
+            const int h = tb.perm[d], cl = clc[h];
+            for (int k = 0; k < nb; ++k) {
+                int32_t r = tb.refs_soa[(size_t)k * tb.stride + h];
+                refs[(size_t)k * tb.stride + d] = r;
+                lrefs[(size_t)k * tb.stride + d] = ((uint32_t)r < kDynamicLimit) ? rotated_slot(local_of[r]) : (rotated_slot(kin_local(cl, r & kRefMask)) | (int)kDynamicLimit);
+            }
+            for (int f = 0; f < pf; ++f) pre[(size_t)f * tb.stride + d] = tb.prestep_soa[(size_t)f * tb.stride + h];
+            for (int f = 0; f < imf; ++f) acc[(size_t)f * tb.stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
+        }
+        tb.refs_soa.swap(refs); tb.prestep_soa.swap(pre); tb.accum_soa.swap(acc); tb.lrefs_soa.swap(lrefs);
+        for (int d = 0; d < tb.count;) {
+            const int cl = clc[tb.perm[d]];
+            int e = d;
+            while (e < tb.count && clc[tb.perm[e]] == cl) ++e;
+            for (int s0 = d; s0 < e; s0 += 64) {
+                ClusterItem it;
+                memset(&it, 0, sizeof(it));
+                it.type_id = tb.type_id; it.count = std::min(64, e - s0); it.stride = tb.stride; it.start = s0;
+                it.tb = (int)t; it.shape = nb | (pf << 8) | (imf << 16);
+                const int self = (int)cl_items[cl].size();
+                int npred = 0, overflow = 0;
+                std::vector<int32_t>& lt = last_toucher[cl];
+                for (int j = s0; j < s0 + it.count; ++j)
+                    for (int k = 0; k < nb; ++k) {
+                        const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
+                        if ((uint32_t)lr >= kDynamicLimit) continue;
+                        if ((size_t)lr >= lt.size()) lt.resize((size_t)lr + 16, -1);
+                        const int pred = lt[lr];
+                        if (pred < 0) { first_touch[cl].push_back({self, lr}); continue; }  // this item is the body's first toucher in a pass
+                        if (pred == self) continue;
+                        bool known = false;
+                        for (int q = 0; q < npred; ++q) known |= it.pred[q] == pred;
+                        if (known) continue;
+                        if (npred < kMaxPreds) it.pred[npred++] = (unsigned short)pred; else overflow = 1;
+                    }
+                for (int j = s0; j < s0 + it.count; ++j)
+                    for (int k = 0; k < nb; ++k) {
+                        const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
+                        if ((uint32_t)lr < kDynamicLimit) lt[lr] = self;
+                    }
+                if (overflow) npred = 0;
+                it.batch_npred = (tb.batch & 0xFFFF) | (npred << 16) | (overflow << 24);
+                cl_items[cl].push_back(it);
+            }
+            d = e;
+        }
+    }
+    // Cross-pass predecessors: the last toucher (end of a pass) of every body an item touches first.
+    for (int cl = 0; cl < nclusters; ++cl) {
+        for (auto& fs : first_touch[cl]) {
+            ClusterItem& it = cl_items[cl][fs.first];
+            const int last = last_toucher[cl][fs.second];
+            int nx = (it.batch_npred >> 20) & 0xF;
+            if ((it.batch_npred >> 25) & 1) continue;
+            bool known = false;
+            for (int q = 0; q < nx; ++q) known |= it.xpred[q] == last;
+            if (known) continue;
+            if (nx < kMaxPreds) { it.xpred[nx++] = (unsigned short)last; it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (nx << 20); }
+            else it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (1 << 25);
+        }
+    }
+    for (int cl = 0; cl < nclusters; ++cl) {
+        ClusterDesc d;
+        d.body_begin = (int)plan.cluster_bodies.size();
+        d.slot_count = ((int)cl_bodies[cl].size() + 15) / 16 * 16;
+        std::vector<int32_t> slots(d.slot_count, -1);
+        for (size_t i = 0; i < cl_bodies[cl].size(); ++i) slots[rotated_slot((int)i)] = cl_bodies[cl][i];
+        plan.cluster_bodies.insert(plan.cluster_bodies.end(), slots.begin(), slots.end());
+        d.item_begin = (int)plan.items.size();
+        d.item_count = (int)cl_items[cl].size();
+        d.batch_item_offset = (int)plan.batch_item_begin.size();
+        // items were appended in type-batch order == batch order
+        int k = 0;
+        for (int b = 0; b <= c->batch_count; ++b) {
+            while (k < d.item_count && (cl_items[cl][k].batch_npred & 0xFFFF) < b) ++k;
+            plan.batch_item_begin.push_back(d.item_begin + k);
+        }
+        plan.items.insert(plan.items.end(), cl_items[cl].begin(), cl_items[cl].end());
+        plan.clusters.push_back(d);
+        plan.max_slots = std::max(plan.max_slots, d.slot_count);
+        plan.max_items = std::max(plan.max_items, d.item_count);
+    }
+    plan.enabled = nclusters > 0 && cluster_lds_bytes(plan.max_slots, plan.max_items) <= kLdsBudgetBytes;
+}

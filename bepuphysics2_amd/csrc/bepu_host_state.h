@@ -1,0 +1,173 @@
+// Host-side state of a bepuhip context: kernel variant table, error plumbing, type table, per-type-batch bookkeeping, the context itself.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// cluster_kernel instantiations: register budget (launch bounds) x trace x type set. The traced build exists for the 1024-thread budget only (a kernel
+// compiled for 1024 threads runs any smaller workgroup).
+#ifdef BEPUHIP_FAST_BUILD  // kernel-tuning builds (tools/): one register budget, hot-path type set only
+#define BEPU_CLUSTER_VARIANTS(X) X(1024, false, false) X(1024, true, false)
+#else
+#define BEPU_CLUSTER_VARIANTS(X) X(512, false, false) X(768, false, false) X(1024, false, false) X(1024, true, false) \
+                                 X(512, false, true) X(768, false, true) X(1024, false, true) X(1024, true, true)
+#endif
+static const void* cluster_kernel_variant(int threads, bool trace, bool wide) {
+#ifdef BEPUHIP_FAST_BUILD
+    return trace ? (const void*)cluster_kernel<1024, true, false> : (const void*)cluster_kernel<1024, false, false>;
+#endif
+    const int budget = trace ? 1024 : (threads > 768 ? 1024 : threads > 512 ? 768 : 512);
+#define X(T, TR, W) if (budget == T && trace == TR && wide == W) return (const void*)cluster_kernel<T, TR, W>;
+    BEPU_CLUSTER_VARIANTS(X)
+#undef X
+    return (const void*)cluster_kernel<1024, false, true>;
+}
+
+static thread_local std::string g_last_error;
+static int32_t fail(int32_t code, const std::string& msg) { g_last_error = msg; return code; }
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return fail(BEPUHIP_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+using C1O = Contact<1, false>; using C2O = Contact<2, false>; using C3O = Contact<3, false>; using C4O = Contact<4, false>;
+using C1T = Contact<1, true>; using C2T = Contact<2, true>; using C3T = Contact<3, true>; using C4T = Contact<4, true>;
+struct TypeInfoH { int bodies, prestep, impulse; bool incremental; };
+static bool type_info(int id, TypeInfoH& t) {
+#define TI(T) { t = {T::bodies, T::prestepFloats, T::impulseFloats, T::incremental}; return true; }
+    switch (id) {
+        case kContact1OneBody: TI(C1O) case kContact2OneBody: TI(C2O)
+        case kContact3OneBody: TI(C3O) case kContact4OneBody: TI(C4O)
+        case kContact1: TI(C1T) case kContact2: TI(C2T)
+        case kContact3: TI(C3T) case kContact4: TI(C4T)
+#define X(ID, T) case ID: TI(T)
+        BD_JOINT_TYPES(X)
+        BD_NONCONVEX_CONTACT_TYPES(X)
+#undef X
+    }
+#undef TI
+    return false;
+}
+
+static bool is_widened_type(int id) {
+    switch (id) {
+#define X(ID, T) case ID: return true;
+        BD_WIDENED_JOINT_TYPES(X)
+        BD_NONCONVEX_CONTACT_TYPES(X)
+#undef X
+    }
+    return false;
+}
+
+struct HostTypeBatch {
+    int batch, type_id, count, stride;
+    TypeInfoH info;
+    size_t refs_off, prestep_off, accum_off, lrefs_off;  // offsets (in 4-byte words) into the constraint slab
+    std::vector<int32_t> perm;      // cluster path: device index -> host index inside the type batch (empty = identity)
+    std::vector<int32_t> inv;       // host index -> device index (lazily built)
+    int perm_inverse(int host_index) {
+        if (inv.empty()) { inv.resize(perm.size()); for (size_t d = 0; d < perm.size(); ++d) inv[perm[d]] = (int32_t)d; }
+        return inv[host_index];
+    }
+    int32_t* d_device_index = nullptr;  // device copy of `inv` for the ranged update / read-back kernels (allocated on first use)
+    std::vector<int32_t> lrefs_soa; // cluster path: local (LDS) body indices
+    std::vector<int32_t> refs_soa;
+    std::vector<float> prestep_soa, accum_soa;  // host staging until end_constraints
+};
+
+struct GraphKey {
+    std::vector<int> iterations;
+    float dt;
+    bepuhip_integrator integ;
+    bool operator<(const GraphKey& o) const {
+        if (iterations != o.iterations) return iterations < o.iterations;
+        if (dt != o.dt) return dt < o.dt;
+        return memcmp(&integ, &o.integ, sizeof(integ)) < 0;
+    }
+};
+
+struct bepuhip_ctx {
+    int device = 0, W = 8, flags = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    float4* d_bodies = nullptr;
+    float4* d_bodies0 = nullptr;  // pristine snapshot for reset_state
+    unsigned* d_flags = nullptr;
+    int body_count = 0, body_capacity = 0;
+    int* d_kin = nullptr;
+    int kin_count = 0;
+    std::vector<int32_t> kin_indices;
+    // constraints
+    bool building = false, built = false;
+    int batch_count = 0;
+    std::vector<HostTypeBatch> tbs;
+    std::vector<int> batch_begin;        // tbs index of each batch's first type batch (size batch_count+1)
+    std::vector<int> batch_blocks;       // grid size per batch
+    uint32_t* d_slab = nullptr;          // all refs/prestep/accum
+    uint32_t* d_slab0 = nullptr;         // pristine snapshot
+    float* d_stage = nullptr;            // staging for ranged updates / read-backs (caller's AOSOA bundles)
+    size_t stage_floats = 0;
+    size_t slab_words = 0;
+    DevTypeBatch* d_tbs = nullptr;       // per (batch) descriptors, solve/warm-start grids
+    DevTypeBatch* d_inc_tbs = nullptr;   // incremental-update grid (contacts of all batches)
+    int inc_tb_count = 0, inc_blocks = 0;
+    int64_t total_constraints = 0;
+    // cluster path
+    bool clusters_enabled = false;
+    bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
+    int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0;
+    ClusterDesc first_cluster = {0, 0, 0, 0, 0};
+    int* d_requirk = nullptr;            // conserving angular modes: per batch, the bodies momentum_requirk_kernel transforms in substep 0
+    std::vector<int> requirk_begin;     // batch -> offset into d_requirk (batch_count + 1 entries)
+    int* d_boundary = nullptr;          // boundary body indices (see bepuhip_set_boundary_bodies)
+    float4* d_boundary_snapshot = nullptr;
+    float* d_boundary_buf = nullptr;     // count * 6 floats staging for host-pointer exchanges
+    int boundary_count = 0;
+    unsigned long long* d_cycles = nullptr;  // per cluster: shader clocks of the last cluster_kernel launch
+    unsigned* d_status = nullptr;  // cluster schedule watchdog words (see report_stall)
+    unsigned long long* d_trace = nullptr;  // optional per-item timeline of cluster 0 (diagnostics)
+    size_t trace_words = 0;
+    ClusterDesc* d_clusters = nullptr;
+    ClusterItem* d_items = nullptr;
+    int* d_batch_item_begin = nullptr;
+    int* d_cluster_bodies = nullptr;
+    int* d_clustered_dynamic = nullptr;
+    int clustered_dynamic_count = 0;
+    int* d_kinlist = nullptr;       // constrained kinematic body indices derived from the body references
+    int kinlist_count = 0;
+    // measurement
+    float last_ms = 0;
+    int64_t last_constraint_iterations = 0;
+    bool profiling = false;
+    float prof_ms[6] = {0, 0, 0, 0, 0, 0};
+    int prof_launches[6] = {0, 0, 0, 0, 0, 0};
+    std::map<GraphKey, hipGraphExec_t> graphs;
+};
+
+static void free_constraints(bepuhip_ctx* c) {
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+    if (c->d_slab) hipFree(c->d_slab);
+    if (c->d_slab0) hipFree(c->d_slab0);
+    if (c->d_tbs) hipFree(c->d_tbs);
+    if (c->d_inc_tbs) hipFree(c->d_inc_tbs);
+    if (c->d_clusters) hipFree(c->d_clusters);
+    if (c->d_items) hipFree(c->d_items);
+    if (c->d_batch_item_begin) hipFree(c->d_batch_item_begin);
+    if (c->d_cluster_bodies) hipFree(c->d_cluster_bodies);
+    if (c->d_clustered_dynamic) hipFree(c->d_clustered_dynamic);
+    if (c->d_kinlist) hipFree(c->d_kinlist);
+    if (c->d_requirk) hipFree(c->d_requirk);
+    c->d_requirk = nullptr; c->requirk_begin.clear();
+    if (c->d_trace) hipFree(c->d_trace);
+    c->d_trace = nullptr; c->trace_words = 0;
+    if (c->d_cycles) hipFree(c->d_cycles);
+    c->d_cycles = nullptr;
+    c->d_clusters = nullptr; c->d_items = nullptr; c->d_batch_item_begin = nullptr; c->d_cluster_bodies = nullptr;
+    c->d_clustered_dynamic = nullptr; c->d_kinlist = nullptr;
+    c->clusters_enabled = false; c->cluster_count = 0; c->clustered_dynamic_count = 0; c->kinlist_count = 0;
+    c->d_slab = c->d_slab0 = nullptr;
+    c->d_tbs = c->d_inc_tbs = nullptr;
+    for (auto& tb : c->tbs) if (tb.d_device_index) hipFree(tb.d_device_index);
+    c->tbs.clear();
+    c->built = false;
+}

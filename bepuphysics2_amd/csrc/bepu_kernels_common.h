@@ -1,0 +1,82 @@
+// Shared device-side definitions of libbepuhip's kernels: descriptors handed to the kernels, the body record in registers, its global-memory
+// gather/scatter by access filter (Bodies_GatherScatter.cs:267-753), stage ids. Included by bepuhip.hip only (one translation unit).
+#pragma once
+
+namespace {
+
+
+constexpr unsigned kDynamicLimit = 1u << 30;  // Bodies_GatherScatter.cs:107-118
+constexpr int kRefMask = 0x3FFFFFFF;
+constexpr int kBlock = 64;  // one wavefront per workgroup: a batch rarely fills the chip, so spread waves over as many CUs as possible
+
+struct StepParams {
+    float dt, inv_dt;
+    float gx, gy, gz;  // gravity * dt
+    float lin_damp, ang_damp;
+    int angular_mode;  // AngularIntegrationMode (PoseIntegrator.cs:20-38): 0 Nonconserving, 1 ConserveMomentum, 2 ConserveMomentumWithGyroscopicTorque
+};
+
+struct DevTypeBatch {
+    int type_id, count, stride, block_begin;
+    int* refs;
+    float* prestep;
+    float* accum;
+};
+
+// ---- cluster path descriptors (see cluster_kernel) ----
+constexpr int kMaxPreds = 6;
+constexpr int kFallbackBatchLimit = 64;
+struct ClusterItem {  // <= 64 consecutive constraints of one type batch, all owned by one cluster; 64 bytes, staged in LDS
+    int type_id, count, stride, start;                // start: index of the first constraint inside the (reordered) type batch
+    unsigned lrefs_off, prestep_off, accum_off;       // word offsets into the constraint slab: lrefs[bodies][stride], prestep[pf][stride], accum[imf][stride]
+    int batch_npred;                                  // bits 0-15 batch, 16-19 predecessor count, 20-23 cross-pass predecessor count, 24 / 25 overflow flags
+    unsigned short pred[kMaxPreds];                   // cluster-relative indices of the items that last touched this item's dynamic bodies (same pass)
+    unsigned short xpred[kMaxPreds];                  // for bodies this item touches FIRST in a pass: their last toucher (previous pass); may be the item itself
+    int tb, shape;                                    // host bookkeeping: type batch, bodies | prestep floats << 8 | impulse floats << 16
+};
+static_assert(sizeof(ClusterItem) == 64, "ClusterItem is staged in LDS as four 16-byte vectors");
+struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
+constexpr int kMaxClusterSubsteps = 16;
+struct ClusterParams {
+    int substeps, batch_count, integrate_velocity_for_kinematics;
+    int iters[kMaxClusterSubsteps];
+    StepParams sp;
+};
+
+
+struct DBody {
+    V3 pos; Q ori; BodyVel vel; Inertia inertia;
+    float linw, angw;  // padding lanes of the velocity float4s, preserved on store
+};
+
+template <int ACCESS>
+__device__ __forceinline__ void load_body(const float4* __restrict__ bodies, int ref, DBody& b) {
+    const float4* base = bodies + (size_t)(ref & kRefMask) * 8;
+    if (ACCESS & kOri) { float4 q = base[0]; b.ori = {q.x, q.y, q.z, q.w}; } else b.ori = {0, 0, 0, 0};
+    if (ACCESS & kPos) { float4 p = base[1]; b.pos = {p.x, p.y, p.z}; } else b.pos = {0, 0, 0};
+    if (ACCESS & kLin) { float4 l = base[2]; b.vel.lin = {l.x, l.y, l.z}; b.linw = l.w; } else { b.vel.lin = {0, 0, 0}; b.linw = 0; }
+    if (ACCESS & kAng) { float4 a = base[3]; b.vel.ang = {a.x, a.y, a.z}; b.angw = a.w; } else { b.vel.ang = {0, 0, 0}; b.angw = 0; }
+    if (ACCESS & kInertia) {
+        float4 i0 = base[6], i1 = base[7];
+        b.inertia.t = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+        b.inertia.invMass = i1.z;
+    } else { b.inertia.t = {0, 0, 0, 0, 0, 0}; b.inertia.invMass = 0; }
+}
+// ScatterVelocities: kinematic / empty references are never written (Bodies_GatherScatter.cs:675-682,717-724).
+template <int ACCESS>
+__device__ __forceinline__ void store_velocity(float4* bodies, int ref, const DBody& b) {
+    if ((unsigned)ref >= kDynamicLimit) return;
+    float4* base = bodies + (size_t)ref * 8;
+    if (ACCESS & kLin) base[2] = make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, b.linw);
+    if (ACCESS & kAng) base[3] = make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, b.angw);
+}
+
+enum { kStageWarmStart = 0, kStageSolve = 1, kStageIncremental = 2 };
+// The constraint functions call their gate once, right before the first use of the bodies' velocities (everything before it depends on
+// poses, inertias and prestep data only). The launch-per-batch kernels have the velocities in registers already.
+struct NoGate {
+    static constexpr bool kPin = false;
+    __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {}
+};
+
+}  // namespace
