@@ -1,20 +1,5 @@
-# INTEGRATION — binding bepuphysics2 to `libbepuhip.so`
-
-The reference has no FFI on this path (`grep DllImport` over `BepuPhysics/` and `BepuUtilities/` is empty). The drop-in seam is the
-user-replaceable `ITimestepper` (`BepuPhysics/ITimestepper.cs:60-79`, installed via `Simulation.Create(..., ITimestepper)`,
-`BepuPhysics/Simulation.cs:106-107,149`): a `HipTimestepper` runs `Sleep → PredictBoundingBoxes → CollisionDetection` exactly like
-`DefaultTimestepper.Timestep` (`BepuPhysics/DefaultTimestepper.cs:28-43`) and replaces only `simulation.Solve(dt, threadDispatcher)` (`:39`,
-body at `BepuPhysics/Simulation.cs:278-290`) with calls into the C ABI declared in `include/bepuhip.h`.
-
-.NET is absent from the build image (`dotnet`, `mono` not found), so the C# below is the stub a maintainer would add — it is not
-compiled here. The same call sequence is implemented and tested in C++ (`bepuphysics2_amd/host/bepu_host.cpp`, class `HipTimestepper`,
-exercised by `tests/test_gpu_parity.py::test_hip_timestepper_through_host_mirror`) and in Python over ctypes (`bepuphysics2_amd/native.py`).
-
-## C# binding (reference side)
-
-The same text is kept as a source file in `integration/csharp/HipTimestepper.cs`.
-
-```csharp
+// Reference-side binding of libbepuhip.so: drop this file into an application that references BepuPhysics (it only uses public API) and create the
+// simulation with `new HipTimestepper()`. Same text as INTEGRATION.md; not compiled in this repository's environment (no .NET SDK here).
 using System;
 using System.Runtime.InteropServices;
 using BepuPhysics;
@@ -49,6 +34,13 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_get_bodies(IntPtr ctx, void* bodyDynamics, int count);
     [DllImport(Lib)] public static extern int bepuhip_get_accumulated_impulses(IntPtr ctx, int batchIndex, int typeId, void* accumulatedImpulses);
     [DllImport(Lib)] public static extern int bepuhip_get_prestep(IntPtr ctx, int batchIndex, int typeId, void* prestepData);
+    // ranged in-place updates / read-backs for frames whose topology did not change (INTEGRATION.md)
+    [DllImport(Lib)] public static extern int bepuhip_update_bodies(IntPtr ctx, void* bodyDynamics, int first, int count);
+    [DllImport(Lib)] public static extern int bepuhip_update_prestep(IntPtr ctx, int batchIndex, int typeId, int firstBundle, int bundleCount, void* prestepBundles);
+    [DllImport(Lib)] public static extern int bepuhip_update_accumulated_impulses(IntPtr ctx, int batchIndex, int typeId, int firstBundle, int bundleCount, void* impulseBundles);
+    [DllImport(Lib)] public static extern int bepuhip_get_bodies_range(IntPtr ctx, void* bodyDynamics, int first, int count);
+    [DllImport(Lib)] public static extern int bepuhip_get_prestep_range(IntPtr ctx, int batchIndex, int typeId, int firstBundle, int bundleCount, void* prestepBundles);
+    [DllImport(Lib)] public static extern int bepuhip_get_accumulated_impulses_range(IntPtr ctx, int batchIndex, int typeId, int firstBundle, int bundleCount, void* impulseBundles);
 }
 
 public unsafe class HipTimestepper : ITimestepper, IDisposable
@@ -137,54 +129,3 @@ public unsafe class HipTimestepper : ITimestepper, IDisposable
     }
     public void Dispose() { if (ctx != IntPtr.Zero) { BepuHip.bepuhip_destroy(ctx); ctx = IntPtr.Zero; } }
 }
-```
-
-Usage: `Simulation.Create(pool, narrowPhaseCallbacks, new DemoPoseIntegratorCallbacks(gravity), new SolveDescription(1, 4), new HipTimestepper())`.
-
-### Frames whose topology did not change: ranged updates instead of a re-upload
-
-When no constraint was added, removed or moved since the last frame (the shim can compare `Solver.ActiveSet` counts and a dirty flag set from
-`Solver.Add/Remove`), the device copy is patched instead of rebuilt: only the bundles the narrow phase rewrote
-(`NarrowPhaseConstraintUpdate.cs:147-207` rewrites prestep data and redistributes impulses of persisting pairs in place) and the bodies user code touched.
-
-```csharp
-    [DllImport(Lib)] public static extern int bepuhip_update_bodies(IntPtr ctx, void* bodyDynamics, int first, int count);
-    [DllImport(Lib)] public static extern int bepuhip_update_prestep(IntPtr ctx, int batchIndex, int typeId, int firstBundle, int bundleCount, void* prestepBundles);
-    [DllImport(Lib)] public static extern int bepuhip_update_accumulated_impulses(IntPtr ctx, int batchIndex, int typeId, int firstBundle, int bundleCount, void* impulseBundles);
-    [DllImport(Lib)] public static extern int bepuhip_get_bodies_range(IntPtr ctx, void* bodyDynamics, int first, int count);
-    [DllImport(Lib)] public static extern int bepuhip_get_prestep_range(IntPtr ctx, int batchIndex, int typeId, int firstBundle, int bundleCount, void* prestepBundles);
-    [DllImport(Lib)] public static extern int bepuhip_get_accumulated_impulses_range(IntPtr ctx, int batchIndex, int typeId, int firstBundle, int bundleCount, void* impulseBundles);
-
-    // in SolveOnDevice, topology unchanged:
-    ref var tb = ref batch.TypeBatches[t];
-    if (solver.TypeProcessors[tb.TypeId].RequiresIncrementalSubstepUpdates)   // contact type batches: rewritten by the narrow phase every frame
-    {
-        int bundles = tb.BundleCount;                                          // TypeBatch.cs:29
-        Check(BepuHip.bepuhip_update_prestep(ctx, b, tb.TypeId, 0, bundles, tb.PrestepData.Memory));
-        Check(BepuHip.bepuhip_update_accumulated_impulses(ctx, b, tb.TypeId, 0, bundles, tb.AccumulatedImpulses.Memory));
-    }
-```
-
-Pointers are the type batch's own buffers offset to the first bundle of the range (`Memory + firstBundle * bytesPerBundle`); a range is whole bundles
-because that is the unit the reference's buffers are addressed in (`BundleIndexing.cs:50-60`).
-
-## Entry point ↔ reference interface
-
-| C ABI (`include/bepuhip.h`) | replaces / mirrors (reference file:line) |
-|---|---|
-| `bepuhip_set_bodies` | `Bodies.ActiveSet.DynamicsState` — `BepuPhysics/BodySet.cs:41`, layout `BepuPhysics/BodyProperties.cs:318-338` |
-| `bepuhip_begin_constraints` / `bepuhip_set_type_batch` / `bepuhip_end_constraints` | `Solver.ActiveSet.Batches[*].TypeBatches[*]` — `BepuPhysics/Constraints/TypeBatch.cs:10-19`, AOSOA addressing `BepuUtilities/BundleIndexing.cs:50-60`, body-reference encoding `BepuPhysics/Bodies_GatherScatter.cs:107-139`, fallback detection `BepuPhysics/Solver.cs:1878-1884` |
-| `bepuhip_set_constrained_kinematics` | `Solver.ConstrainedKinematicHandles` — `BepuPhysics/Solver.cs:68`, consumed at `BepuPhysics/PoseIntegrator.cs:451-535` |
-| `bepuhip_solve` | body of `Simulation.Solve` — `BepuPhysics/Simulation.cs:278-290`: prepass `BepuPhysics/Solver_Solve.cs:1072`, substep loop `:1415-1479`, `IntegrateAfterSubstepping` `BepuPhysics/PoseIntegrator.cs:707` |
-| `bepuhip_get_bodies`, `bepuhip_get_accumulated_impulses`, `bepuhip_get_prestep` | the in-place results the reference leaves in its own buffers (poses/velocities; warm-start impulses; contact depths `PenetrationLimit.cs:42`) |
-| `bepuhip_update_bodies`, `bepuhip_update_prestep`, `bepuhip_update_accumulated_impulses`, `bepuhip_get_bodies_range`, `bepuhip_get_prestep_range`, `bepuhip_get_accumulated_impulses_range` | in-place rewrites between frames: contact constraint refresh for persisting pairs `BepuPhysics/CollisionDetection/NarrowPhaseConstraintUpdate.cs:147-207`, per-body writes through `BodyReference` (`BepuPhysics/BodyReference.cs`); ranges are whole bundles of `TypeBatch.PrestepData` / `AccumulatedImpulses` (`TypeBatch.cs:13-16`) or `BodyDynamics` structs |
-| `bepuhip_set_boundary_bodies`, `bepuhip_boundary_deltas`, `bepuhip_boundary_apply`, `bepuhip_solve_exchanged` | no counterpart (the reference solves one address space); the per-pass hook sits where `Solver.SubstepStarted/SubstepEnded` fire (`BepuPhysics/Solver.cs:131-146`, raised at `Solver_Solve.cs:1425-1478`); one connected scene split across GPUs with a boundary-velocity exchange (BASELINE.json configs[4]) |
-| `bepuhip_integrator` | `IPoseIntegratorCallbacks` as data — `BepuPhysics/PoseIntegrator.cs:42-94`, `Demos/DemoCallbacks.cs:20-109` |
-| `bepuhip_last_solve_ms`, `bepuhip_get_profile`, `bepuhip_get_cluster_cycles`, `bepuhip_set/get_cluster_trace`, `bepuhip_debug_status` | `SimulationProfiler` stage timings — `BepuPhysics/SimulationProfiler.cs:9-74`; the last three have no counterpart (per-workgroup shader clocks, per-work-item timeline and watchdog words of the island-per-workgroup schedule) |
-
-Status codes: `0` OK; `-1` invalid argument (the reference throws `ArgumentException`: `Simulation.cs:318-319`, `SolveDescription.cs:42-47`);
-`-2` unsupported input (unknown type id, sequential fallback batch, non-demo velocity callback) — the shim
-falls back to `simulation.Solve`; `-3` HIP failure (including "no GPU": there is no CPU fallback inside the library); `-4` call order.
-
-Ownership: the host owns all `BufferPool` memory; the library copies on `set_*` and owns all device memory. A context is single-threaded,
-`bepuhip_solve` is synchronous at return, `IThreadDispatcher` is ignored, `Solver.SubstepStarted/Ended` events are not raised.

@@ -3,6 +3,7 @@
 // no golden vectors for this path; this is our restatement of the C#, following the reference's
 // control flow (integration fused into the first-touching constraint's warm start, per-bundle modes) rather
 // than the product's reorganised schedule, so that it also checks the product's equivalence argument.
+// oracle/pin/ holds the kit that pins it on a machine with .NET (C# ReferenceDumper + exporter + bit-for-bit comparison).
 //
 // Restates, single-threaded (threads=1) exactly as the reference's dispatcher==null path, and optionally with the
 // reference's work-block/barrier scheme (threads>1) for use as bench.py's cpu_baseline ("port"):
