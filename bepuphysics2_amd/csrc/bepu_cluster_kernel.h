@@ -150,14 +150,29 @@ __device__ __forceinline__ void wait_word(const ClusterShared& sh, const volatil
 // pass before it is not separated by a barrier) the last touchers of the bodies this item touches first must have finished `epoch - 1`.
 template <bool CROSS>
 __device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, unsigned epoch) {
-    for (int q = 0; q < h.npred; ++q) {
-        const int pred = __builtin_amdgcn_readfirstlane((int)it->pred[q]);
-        wait_word(sh, sh.flags + pred, epoch, 1, k, pred);
-    }
-    if (CROSS) {
-        for (int q = 0; q < h.nxpred; ++q) {
-            const int pred = __builtin_amdgcn_readfirstlane((int)it->xpred[q]);
-            wait_word(sh, sh.flags + pred, epoch - 1, 3, k, pred);
+    // All listed predecessors are polled at once: lane q < 6 watches same-pass predecessor q, lane 6 + q cross-pass predecessor q (pred[] and xpred[] are
+    // adjacent in the item), every other lane a word that always passes. One LDS round trip after the last of them publishes, the wave is through —
+    // polled one after the other, each already finished predecessor would still cost its own round trip on the cluster's critical path.
+    {
+        const int lane = threadIdx.x & 63;
+        const unsigned short listed = (&it->pred[0])[lane < 2 * kMaxPreds ? lane : 0];
+        const bool same = lane < h.npred;
+        const bool cross = CROSS && lane >= kMaxPreds && lane < kMaxPreds + h.nxpred;
+        const int idx = (same || cross) ? (int)listed : k;
+        const unsigned want = same ? epoch : (cross ? epoch - 1 : 0u);
+        const volatile lds_u32* word = sh.flags + idx;
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned seen = *word;
+            const unsigned long long late = __builtin_amdgcn_ballot_w64(seen < want);
+            if (late == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) {
+                const int first = (int)__builtin_ctzll(late);
+                report_stall(sh.status, *sh.counter, first < kMaxPreds ? 1 : 3, k, __builtin_amdgcn_readlane(idx, first), __builtin_amdgcn_readlane((int)want, first), __builtin_amdgcn_readlane((int)seen, first));
+                break;
+            }
+            if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
         }
     }
     if (h.overflow) {  // more predecessors than the item records: wait for every item of every earlier batch

@@ -1,6 +1,7 @@
 // Shared device-side definitions of libbepuhip's kernels: descriptors handed to the kernels, the body record in registers, its global-memory
 // gather/scatter by access filter (Bodies_GatherScatter.cs:267-753), stage ids. Included by bepuhip.hip only (one translation unit).
 #pragma once
+#include <cstddef>
 
 namespace {
 
@@ -35,6 +36,7 @@ struct ClusterItem {  // <= 64 consecutive constraints of one type batch, all ow
     int tb, shape;                                    // host bookkeeping: type batch, bodies | prestep floats << 8 | impulse floats << 16
 };
 static_assert(sizeof(ClusterItem) == 64, "ClusterItem is staged in LDS as four 16-byte vectors");
+static_assert(offsetof(ClusterItem, xpred) == offsetof(ClusterItem, pred) + kMaxPreds * sizeof(unsigned short), "wait_predecessors indexes pred[] and xpred[] as one array");
 struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
 constexpr int kMaxClusterSubsteps = 16;
 struct ClusterParams {

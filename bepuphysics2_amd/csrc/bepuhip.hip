@@ -643,10 +643,10 @@ int32_t bepuhip_solve(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t*
 }
 
 int32_t bepuhip_get_bodies(bepuhip_ctx* c, void* out, int32_t count) {
-    if (!c || !out || count < 0 || count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad get_bodies argument");
+    if (!c || (!out && count > 0) || count < 0 || count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad get_bodies argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, c->d_bodies, (size_t)count * 128, hipMemcpyDeviceToHost));
+    if (count > 0) HIP_TRY(hipMemcpy(out, c->d_bodies, (size_t)count * 128, hipMemcpyDeviceToHost));  // an empty simulation is a valid one
     return BEPUHIP_OK;
 }
 
