@@ -165,8 +165,7 @@ __device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const
         for (;;) {
             const unsigned seen = *word;
             const unsigned long long late = __builtin_amdgcn_ballot_w64(seen < want);
-            if (late == 0) break;
-            __builtin_amdgcn_s_sleep(1);
+            if (late == 0) break;  // polled back to back: pollers run at the lowest priority, and a sleep only adds to the detection latency on the chain
             if (++spins > kSpinLimit) {
                 const int first = (int)__builtin_ctzll(late);
                 report_stall(sh.status, *sh.counter, first < kMaxPreds ? 1 : 3, k, __builtin_amdgcn_readlane(idx, first), __builtin_amdgcn_readlane((int)want, first), __builtin_amdgcn_readlane((int)seen, first));
