@@ -74,6 +74,7 @@ struct HostTypeBatch {
     std::vector<float> prestep_soa, accum_soa;  // host staging until end_constraints
 };
 
+constexpr size_t kMaxCachedGraphs = 8;
 struct GraphKey {
     std::vector<int> iterations;
     float dt;
@@ -140,7 +141,7 @@ struct bepuhip_ctx {
     bool profiling = false;
     float prof_ms[6] = {0, 0, 0, 0, 0, 0};
     int prof_launches[6] = {0, 0, 0, 0, 0, 0};
-    std::map<GraphKey, hipGraphExec_t> graphs;
+    std::map<GraphKey, hipGraphExec_t> graphs;  // captured launch sequences, one per (iteration schedule, dt, integrator); at most kMaxCachedGraphs
 };
 
 static void free_constraints(bepuhip_ctx* c) {

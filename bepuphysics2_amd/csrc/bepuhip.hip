@@ -497,6 +497,12 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
         key.dt = dt; key.integ = *in;
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
+            if (c->graphs.size() >= kMaxCachedGraphs) {  // a caller with a variable time step produces a new key every frame: keep the cache bounded
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+                c->graphs.clear();
+                HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+            }
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             enqueue_solve(c, dt, substeps, iterations, in);

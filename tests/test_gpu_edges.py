@@ -99,3 +99,20 @@ def test_batch_count_at_the_fallback_threshold(hip_solver_factory, use_clusters)
     if len(too_many.batches) > FALLBACK_BATCH_THRESHOLD:
         with pytest.raises(native.UnsupportedError):
             hip_solver_factory(use_clusters=use_clusters).upload(too_many)
+
+
+def test_variable_time_step_keeps_the_graph_cache_bounded(hip_solver_factory):
+    """Every distinct dt captures a new hipGraph; the cache is bounded (8), evicted wholesale, and results stay bit-exact across evictions."""
+    scene = small_scenes.random_graph_scene(12, 80, 200, [7, 22, 30, 47])
+    sd, cb = SolveDescription(1, 2), PoseIntegratorCallbacks()
+    solver = hip_solver_factory()
+    ref = scene.copy()
+    solver.upload(scene.copy(), sd.fallback_batch_threshold)
+    import oracle_ffi
+    for frame in range(20):
+        dt = 1 / 60 + frame * 1e-4
+        oracle_ffi.solve(ref, dt, sd, cb)
+        solver.solve(dt, sd, cb)
+    got = scene.copy()
+    solver.download(got)
+    _bit_exact(ref, got)

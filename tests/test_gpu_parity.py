@@ -193,6 +193,22 @@ def test_full_size_ragdoll_tube_against_oracle_and_between_schedules(hip_solver_
     assert np.isfinite(clusters.bodies).all()
 
 
+@pytest.mark.parametrize("use_clusters", [True, False])
+def test_long_run_stays_bit_exact(hip_solver_factory, use_clusters):
+    """Sixty consecutive frames (warm-start impulses, contact depths and poses carried on the device the whole time) against the oracle."""
+    from bepuphysics2_amd.hostlib import HostSimulation
+    sim = HostSimulation.scene("ragdoll_tube", 150, 1, 0, 3)
+    scene, sd = sim.export(), sim.solve_description()
+    sim.close()
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=60, threads=4)
+    got = pu.run_hip(hip_solver_factory(use_clusters=use_clusters), scene, 1 / 60, sd, cb, frames=60)
+    m = pu.compare_scenes(ref, got)
+    _check(m)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    assert np.isfinite(got.bodies).all() and float(np.abs(got.bodies[:, 4:7] - scene.bodies[:, 4:7]).max()) > 1e-3  # and the scene really moved
+
+
 def test_full_size_pile_against_oracle(hip_solver_factory):
     """BASELINE.json configs[1] at its full size (100,000 boxes, 295,710 Contact1-4 constraints in ONE island, 4 substeps x 2 iterations):
     the launch-per-batch schedule (the only one a single island allows) against the oracle, bit for bit, two frames."""
