@@ -6,6 +6,32 @@
 
 namespace {
 
+// Three- and four-body constraints (ThreeBodyTypeProcessor.cs / FourBodyTypeProcessor.cs): the same gather / function / scatter over F::bodies slots.
+template <class F, int STAGE>
+__device__ __forceinline__ void run_constraint_many(const DevTypeBatch& tb, int i, float4* bodies, float dt, float inv_dt) {
+    if (STAGE == kStageIncremental) return;
+    constexpr int N = F::bodies;
+    const int stride = tb.stride;
+    int refs[N];
+    _Pragma("unroll") for (int k = 0; k < N; ++k) refs[k] = tb.refs[(size_t)k * stride + i];
+    float p[F::prestepFloats], a[F::impulseFloats];
+    _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = tb.prestep[(size_t)f * stride + i];
+    _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = tb.accum[(size_t)f * stride + i];
+    DBody b[N];
+    V3 pos[N]; float inverseMass[N]; BodyVel vel[N];
+    _Pragma("unroll") for (int k = 0; k < N; ++k) {
+        load_body<F::access>(bodies, refs[k], b[k]);
+        pos[k] = b[k].pos; inverseMass[k] = b[k].inertia.invMass; vel[k] = b[k].vel;
+    }
+    if (STAGE == kStageWarmStart) {
+        F::warmStartN(pos, inverseMass, p, a, vel, NoGate{});
+    } else {
+        F::solveN(pos, inverseMass, dt, inv_dt, p, a, vel, NoGate{});
+        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) tb.accum[(size_t)f * stride + i] = a[f];
+    }
+    _Pragma("unroll") for (int k = 0; k < N; ++k) { b[k].vel = vel[k]; store_velocity<F::access>(bodies, refs[k], b[k]); }
+}
+
 template <class F, int STAGE>
 __device__ __forceinline__ void run_constraint(const DevTypeBatch& tb, int i, float4* bodies, float dt, float inv_dt) {
     const int stride = tb.stride;
@@ -70,6 +96,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     switch (tb.type_id) {
 #define X(ID, T) case ID: run_constraint<T, STAGE>(tb, i, bodies, dt, inv_dt); break;
         BD_JOINT_TYPES(X)
+#undef X
+#define X(ID, T) case ID: run_constraint_many<T, STAGE>(tb, i, bodies, dt, inv_dt); break;
+        BD_MANY_BODY_TYPES(X)
 #undef X
         default: break;
     }

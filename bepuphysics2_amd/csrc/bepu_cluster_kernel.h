@@ -203,6 +203,46 @@ struct ClusterGate {
 };
 
 
+// The gate of three- and four-body constraints: same wait, then the velocities of all N bodies.
+template <int ACCESS, int N, bool CROSS>
+struct ClusterGateMany {
+    static constexpr bool kPin = true;
+    const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; const int* refs; DBody* b;
+    __device__ __forceinline__ void many(BodyVel* vel) const {
+        wait_predecessors<CROSS>(sh, it, h, k, epoch);
+        __builtin_amdgcn_s_setprio(3);
+        _Pragma("unroll") for (int j = 0; j < N; ++j) { load_velocity_lds<ACCESS>(sh, refs[j], b[j]); vel[j] = b[j].vel; }
+    }
+};
+template <class F, int STAGE>
+__device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
+                                                            unsigned* __restrict__ slab, float dt, float inv_dt) {
+    constexpr int N = F::bodies;
+    const bool active = lane < h.count;
+    const int i = h.start + (active ? lane : h.count - 1), stride = h.stride;
+    const gint* lrefs = (const gint*)(slab + h.lrefs_off);
+    gfloat* prestep = (gfloat*)(slab + h.prestep_off);
+    gfloat* accum = (gfloat*)(slab + h.accum_off);
+    float p[F::prestepFloats], a[F::impulseFloats];
+    int refs[N];
+    _Pragma("unroll") for (int j = 0; j < N; ++j) refs[j] = lrefs[(size_t)j * stride + i];
+    _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
+    _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i];
+    DBody b[N];
+    V3 pos[N]; float inverseMass[N]; BodyVel vel[N];
+    _Pragma("unroll") for (int j = 0; j < N; ++j) {
+        load_body_lds<F::access & ~(kLin | kAng)>(sh, refs[j], b[j]);
+        pos[j] = b[j].pos; inverseMass[j] = b[j].inertia.invMass; vel[j] = b[j].vel;
+    }
+    ClusterGateMany<F::access, N, STAGE == kStageSolve> gate{sh, it, h, k, epoch, refs, b};
+    if (STAGE == kStageWarmStart) F::warmStartN(pos, inverseMass, p, a, vel, gate);
+    else F::solveN(pos, inverseMass, dt, inv_dt, p, a, vel, gate);
+    _Pragma("unroll") for (int j = 0; j < N; ++j) { b[j].vel = vel[j]; store_velocity_lds<F::access>(sh, active ? refs[j] : -1, b[j]); }
+    publish_item(sh.flags + k, sh.batch_done + h.batch, epoch);
+    __builtin_amdgcn_s_setprio(0);
+    if (STAGE == kStageSolve && active) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) accum[(size_t)f * stride + i] = a[f]; }
+}
+
 template <class F, int STAGE, bool TRACE>
 __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
                                                        unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
@@ -276,6 +316,9 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
                         if constexpr (WIDE) {  // SURVEY 8(f) types live in a second kernel variant: scenes made of the sixteen hot-path types keep the leaner one
                             switch (h.type_id) {
                                 BD_WIDENED_JOINT_TYPES(BEPU_CASE)
+#define BEPU_CASE_MANY(ID, F) case ID: run_cluster_constraint_many<F, STAGE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt); break;
+                                BD_MANY_BODY_TYPES(BEPU_CASE_MANY)
+#undef BEPU_CASE_MANY
                                 default: break;
                             }
                         }

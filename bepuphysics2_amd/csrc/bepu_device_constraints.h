@@ -14,7 +14,8 @@ namespace bd {
 // BepuPhysics/Constraints/*.cs BatchTypeId constants.
 // Body field access bits (IBodyAccessFilter equivalents).
 enum Access { kPos = 1, kOri = 2, kLin = 4, kAng = 8, kInertia = 16,
-              kAccessAll = 31, kAccessNoOrientation = 29, kAccessNoPosition = 30, kAccessNoPose = 28, kAccessOnlyAngular = 26, kAccessOnlyAngularWithoutPose = 24, kAccessOnlyVelocity = 12 };
+              kAccessAll = 31, kAccessNoOrientation = 29, kAccessNoPosition = 30, kAccessNoPose = 28, kAccessOnlyAngular = 26, kAccessOnlyAngularWithoutPose = 24, kAccessOnlyVelocity = 12,
+              kAccessOnlyLinear = 21 /* position, inverse mass (gathered with the tensor), linear velocity */ };
 enum TypeId {
     kContact1OneBody = 0, kContact2OneBody = 1, kContact3OneBody = 2, kContact4OneBody = 3,
     kContact1 = 4, kContact2 = 5, kContact3 = 6, kContact4 = 7,
@@ -23,6 +24,7 @@ enum TypeId {
     kAngularSwivelHinge = 24, kTwistMotor = 28, kAngularServo = 29, kDistanceServo = 33, kDistanceLimit = 34, kAngularAxisMotor = 41,
     kOneBodyAngularServo = 42, kOneBodyAngularMotor = 43, kOneBodyLinearServo = 44, kOneBodyLinearMotor = 45, kBallSocketMotor = 52, kBallSocketServo = 53,
     kPointOnLineServo = 37, kLinearAxisServo = 38, kLinearAxisMotor = 39, kLinearAxisLimit = 40, kAngularAxisGearMotor = 54,
+    kVolumeConstraint = 32, kCenterDistanceConstraint = 35, kAreaConstraint = 36, kCenterDistanceLimit = 55,
     kContact2NonconvexOneBody = 8, kContact3NonconvexOneBody = 9, kContact4NonconvexOneBody = 10, kContact2Nonconvex = 15, kContact3Nonconvex = 16, kContact4Nonconvex = 17,
 };
 // Contact manifolds are the types with RequiresIncrementalSubstepUpdates (their depths advance every substep).
@@ -1132,9 +1134,8 @@ struct Weld {
 
 // ======================================================================================
 // SURVEY.md 8(f) widening — further constraint types, same template as above (velocity gate, pinned setup).
-// Left out on purpose: CenterDistanceConstraint / CenterDistanceLimit / AreaConstraint / VolumeConstraint use MathHelper.FastReciprocal
-// (BepuUtilities/MathHelper.cs:380-395 = rcpps where AVX/SSE exist): the reference's own result depends on the host CPU's
-// reciprocal approximation, so there is no single bit pattern to match.
+// (CenterDistanceConstraint / CenterDistanceLimit / AreaConstraint / VolumeConstraint, which go through MathHelper.FastReciprocal*, are further below,
+// restated on that helper's portable branch.)
 // ======================================================================================
 // ServoSettingsWide (BepuPhysics/Constraints/ServoSettings.cs): prestep order {MaximumSpeed, BaseSpeed, MaximumForce}.
 BD_FN void servoClampedBiasVelocity(float error, float positionErrorToVelocity, float maximumSpeed, float baseSpeedSetting, float maximumForce, float dt, float inverseDt,
@@ -1944,6 +1945,218 @@ struct AngularAxisGearMotor {
     }
 };
 
+// ======================================================================================
+// The four types built on MathHelper.FastReciprocal / FastReciprocalSquareRoot (BepuUtilities/MathHelper.cs:380-412). On x86 hosts the reference evaluates
+// those with rcpps / rsqrtps, approximations whose bits differ between CPU vendors; everywhere else it takes the portable branch, 1 / v and 1 / sqrt(v).
+// These restate the PORTABLE branch: parity for the four types is defined against the reference on hosts without those intrinsics (the oracle does the
+// same); against an x86 run the results agree to the approximation's ~1.5e-4 relative error in the reciprocal, not bit for bit.
+// All four use AccessOnlyLinear (IBodyAccessFilter.cs:118-126): position, inverse mass and linear velocity only.
+// ======================================================================================
+BD_FN float fastReciprocal(float v) { return 1.0f / v; }                      // MathHelper.cs:392
+BD_FN float fastReciprocalSquareRoot(float v) { return 1.0f / sqrtf(v); }     // MathHelper.cs:409
+
+// CenterDistanceConstraint — CenterDistanceConstraint.cs:58-138. Prestep: TargetDistance, spring{2}. Impulse: scalar.
+struct CenterDistanceConstraint {
+    static constexpr int bodies = 2, prestepFloats = 3, impulseFloats = 1, typeId = kCenterDistanceConstraint;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessOnlyLinear, wsB = kAccessOnlyLinear, svA = kAccessOnlyLinear, svB = kAccessOnlyLinear;  // :135
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    BD_FN void applyImpulse(V3 jacobianA, float inverseMassA, float inverseMassB, float impulse, BodyVel& a, BodyVel& b) {  // :68-74
+        V3 changeA = scale(jacobianA, impulse * inverseMassA);
+        V3 negatedChangeB = scale(jacobianA, impulse * inverseMassB);
+        a.lin = add(a.lin, changeA);
+        b.lin = sub(b.lin, negatedChangeB);
+    }
+    template <class G> BD_FN void warmStart(V3 pA, Q, const Inertia& iA, V3 pB, Q, const Inertia& iB, float*, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :78-91
+        V3 ab = sub(pB, pA);
+        float lengthSq = lengthSquared(ab);
+        float inverseDistance = fastReciprocalSquareRoot(lengthSq);
+        bool useFallback = lengthSq < 1e-10f;
+        V3 jacobianA = scale(ab, inverseDistance);
+        jacobianA = {sel(useFallback, 1.0f, jacobianA.x), sel(useFallback, 0.0f, jacobianA.y), sel(useFallback, 0.0f, jacobianA.z)};
+        BD_GATE(vA, vB, jacobianA);
+        applyImpulse(jacobianA, iA.invMass, iB.invMass, a[0], vA, vB);
+    }
+    template <class G> BD_FN void solve(V3 pA, Q, const Inertia& iA, V3 pB, Q, const Inertia& iB, float dt, float, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :93-121
+        V3 ab = sub(pB, pA);
+        float dist = length(ab);
+        float inverseDistance = fastReciprocal(dist);
+        bool useFallback = dist < 1e-5f;
+        V3 jacobianA = scale(ab, inverseDistance);
+        jacobianA = {sel(useFallback, 1.0f, jacobianA.x), sel(useFallback, 0.0f, jacobianA.y), sel(useFallback, 0.0f, jacobianA.z)};
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[1], p[2], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        float effectiveMass = effMassCFMScale / (iA.invMass + iB.invMass);
+        float biasVelocity = (dist - p[0]) * posErrToVel;
+        BD_GATE(vA, vB, jacobianA, effectiveMass, biasVelocity, softnessImpulseScale);
+        float linearCSVA = dot(vA.lin, jacobianA);
+        float negatedCSVB = dot(vB.lin, jacobianA);
+        float csi = (biasVelocity - (linearCSVA - negatedCSVB)) * effectiveMass - a[0] * softnessImpulseScale;
+        a[0] = a[0] + csi;
+        applyImpulse(jacobianA, iA.invMass, iB.invMass, csi, vA, vB);
+    }
+};
+
+// CenterDistanceLimit — CenterDistanceLimit.cs:73-137. Prestep: MinimumDistance, MaximumDistance, spring{2}. Impulse: scalar.
+struct CenterDistanceLimit {
+    static constexpr int bodies = 2, prestepFloats = 4, impulseFloats = 1, typeId = kCenterDistanceLimit;
+    static constexpr bool incremental = false;
+    static constexpr int wsA = kAccessOnlyLinear, wsB = kAccessOnlyLinear, svA = kAccessOnlyLinear, svB = kAccessOnlyLinear;  // :134
+    BD_FN void incrementalUpdate(float, const BodyVel&, const BodyVel&, float*) {}
+    BD_FN void computeJacobian(float minimumDistance, float maximumDistance, V3 positionA, V3 positionB, V3& jacobianA, float& dist, bool& useMinimum) {  // :82-98
+        V3 ab = sub(positionB, positionA);
+        dist = length(ab);
+        float inverseDistance = fastReciprocal(dist);
+        bool useFallback = dist < 1e-5f;
+        jacobianA = scale(ab, inverseDistance);
+        jacobianA = {sel(useFallback, 1.0f, jacobianA.x), sel(useFallback, 0.0f, jacobianA.y), sel(useFallback, 0.0f, jacobianA.z)};
+        // closer to the minimum: calibrate for the minimum, otherwise for the maximum
+        useMinimum = vabs(dist - minimumDistance) < vabs(dist - maximumDistance);
+        jacobianA = {sel(useMinimum, -jacobianA.x, jacobianA.x), sel(useMinimum, -jacobianA.y, jacobianA.y), sel(useMinimum, -jacobianA.z, jacobianA.z)};
+    }
+    template <class G> BD_FN void warmStart(V3 pA, Q, const Inertia& iA, V3 pB, Q, const Inertia& iB, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :100-105
+        V3 jacobianA; float dist; bool useMinimum;
+        computeJacobian(p[0], p[1], pA, pB, jacobianA, dist, useMinimum);
+        BD_GATE(vA, vB, jacobianA);
+        CenterDistanceConstraint::applyImpulse(jacobianA, iA.invMass, iB.invMass, a[0], vA, vB);
+    }
+    template <class G> BD_FN void solve(V3 pA, Q, const Inertia& iA, V3 pB, Q, const Inertia& iB, float dt, float inverseDt, float* p, float* a, BodyVel& vA, BodyVel& vB, G&& gate) {  // :107-124
+        V3 jacobianA; float dist; bool useMinimum;
+        computeJacobian(p[0], p[1], pA, pB, jacobianA, dist, useMinimum);
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[2], p[3], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        float effectiveMass = effMassCFMScale / (iA.invMass + iB.invMass);
+        float error = sel(useMinimum, p[0] - dist, dist - p[1]);
+        float biasVelocity = vmin(error * inverseDt, error * posErrToVel);  // InequalityHelpers.ComputeBiasVelocity, InequalityHelpers.cs:9-12
+        BD_GATE(vA, vB, jacobianA, effectiveMass, biasVelocity, softnessImpulseScale);
+        float csv = dot(vA.lin, jacobianA) - dot(vB.lin, jacobianA);
+        float csi = -a[0] * softnessImpulseScale - effectiveMass * (csv - biasVelocity);
+        clampPositive(a[0], csi);
+        CenterDistanceConstraint::applyImpulse(jacobianA, iA.invMass, iB.invMass, csi, vA, vB);
+    }
+};
+
+// ---- Three- and four-body constraints (ThreeBodyTypeProcessor.cs / FourBodyTypeProcessor.cs): the functions take the bodies as arrays. ----
+// AreaConstraint — AreaConstraint.cs:69-202. Bodies A, B, C are the triangle's vertices. Prestep: TargetScaledArea, spring{2}. Impulse: scalar.
+struct AreaConstraint {
+    static constexpr int bodies = 3, prestepFloats = 3, impulseFloats = 1, typeId = kAreaConstraint;
+    static constexpr bool incremental = false;
+    static constexpr int access = kAccessOnlyLinear;  // every body, warm start and solve (:199)
+    BD_FN void applyImpulse(const float* inverseMass, V3 negatedJacobianA, V3 jacobianB, V3 jacobianC, float impulse, BodyVel* v) {  // :78-88
+        V3 negativeVelocityChangeA = scale(negatedJacobianA, inverseMass[0] * impulse);
+        V3 velocityChangeB = scale(jacobianB, inverseMass[1] * impulse);
+        V3 velocityChangeC = scale(jacobianC, inverseMass[2] * impulse);
+        v[0].lin = sub(v[0].lin, negativeVelocityChangeA);
+        v[1].lin = add(v[1].lin, velocityChangeB);
+        v[2].lin = add(v[2].lin, velocityChangeC);
+    }
+    BD_FN void computeJacobian(const V3* pos, float& normalLength, V3& negatedJacobianA, V3& jacobianB, V3& jacobianC,
+                               float& contributionA, float& contributionB, float& contributionC, float& inverseJacobianLength) {  // :91-139
+        V3 ab = sub(pos[1], pos[0]);
+        V3 ac = sub(pos[2], pos[0]);
+        V3 abxac = cross(ab, ac);
+        normalLength = length(abxac);
+        // parallel / antiparallel edges: no normal
+        V3 normal = scale(abxac, sel(normalLength > 1e-10f, 1.0f / normalLength, 0.0f));
+        jacobianB = cross(ac, normal);
+        jacobianC = cross(normal, ab);
+        negatedJacobianA = add(jacobianB, jacobianC);
+        contributionA = dot(negatedJacobianA, negatedJacobianA);
+        contributionB = dot(jacobianB, jacobianB);
+        contributionC = dot(jacobianC, jacobianC);
+        float jacobianLengthSquared = contributionA + contributionB + contributionC;
+        jacobianLengthSquared = vmax(1e-14f, jacobianLengthSquared);
+        inverseJacobianLength = fastReciprocalSquareRoot(jacobianLengthSquared);
+    }
+    template <class G> BD_FN void warmStartN(const V3* pos, const float* inverseMass, float*, float* a, BodyVel* v, G&& gate) {  // :141-151
+        float normalLength, cA, cB, cC, inverseJacobianLength; V3 negatedJacobianA, jacobianB, jacobianC;
+        computeJacobian(pos, normalLength, negatedJacobianA, jacobianB, jacobianC, cA, cB, cC, inverseJacobianLength);
+        float impulse = inverseJacobianLength * a[0];
+        BD_GATE_N(v, negatedJacobianA, jacobianB, jacobianC, impulse);
+        applyImpulse(inverseMass, negatedJacobianA, jacobianB, jacobianC, impulse, v);
+    }
+    template <class G> BD_FN void solveN(const V3* pos, const float* inverseMass, float dt, float, float* p, float* a, BodyVel* v, G&& gate) {  // :153-192
+        float normalLength, contributionA, contributionB, contributionC, inverseJacobianLength; V3 negatedJacobianA, jacobianB, jacobianC;
+        computeJacobian(pos, normalLength, negatedJacobianA, jacobianB, jacobianC, contributionA, contributionB, contributionC, inverseJacobianLength);
+        float inverseJacobianLengthSquared = inverseJacobianLength * inverseJacobianLength;
+        float inverseEffectiveMass = vmax(1e-14f, inverseJacobianLengthSquared * (contributionA * inverseMass[0] + contributionB * inverseMass[1] + contributionC * inverseMass[2]));
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[1], p[2], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        float effectiveMass = effMassCFMScale / inverseEffectiveMass;
+        float biasVelocity = (p[0] - normalLength) * inverseJacobianLength * posErrToVel;
+        BD_GATE_N(v, negatedJacobianA, jacobianB, jacobianC, inverseJacobianLength, effectiveMass, biasVelocity, softnessImpulseScale);
+        float negatedVelocityContributionA = dot(negatedJacobianA, v[0].lin);
+        float velocityContributionB = dot(jacobianB, v[1].lin);
+        float velocityContributionC = dot(jacobianC, v[2].lin);
+        float csv = inverseJacobianLength * (velocityContributionB + velocityContributionC - negatedVelocityContributionA);
+        float csi = (biasVelocity - csv) * effectiveMass - a[0] * softnessImpulseScale;
+        a[0] = a[0] + csi;
+        applyImpulse(inverseMass, negatedJacobianA, jacobianB, jacobianC, inverseJacobianLength * csi, v);
+    }
+};
+
+// VolumeConstraint — VolumeConstraint.cs:69-191. Bodies A, B, C, D are the tetrahedron's vertices. Prestep: TargetScaledVolume, spring{2}. Impulse: scalar.
+struct VolumeConstraint {
+    static constexpr int bodies = 4, prestepFloats = 3, impulseFloats = 1, typeId = kVolumeConstraint;
+    static constexpr bool incremental = false;
+    static constexpr int access = kAccessOnlyLinear;  // :188
+    BD_FN void applyImpulse(const float* inverseMass, V3 negatedJacobianA, V3 jacobianB, V3 jacobianC, V3 jacobianD, float impulse, BodyVel* v) {  // :78-91
+        V3 negativeVelocityChangeA = scale(negatedJacobianA, inverseMass[0] * impulse);
+        V3 velocityChangeB = scale(jacobianB, inverseMass[1] * impulse);
+        V3 velocityChangeC = scale(jacobianC, inverseMass[2] * impulse);
+        V3 velocityChangeD = scale(jacobianD, inverseMass[3] * impulse);
+        v[0].lin = sub(v[0].lin, negativeVelocityChangeA);
+        v[1].lin = add(v[1].lin, velocityChangeB);
+        v[2].lin = add(v[2].lin, velocityChangeC);
+        v[3].lin = add(v[3].lin, velocityChangeD);
+    }
+    BD_FN void computeJacobian(const V3* pos, V3& ad, V3& negatedJA, V3& jacobianB, V3& jacobianC, V3& jacobianD,
+                               float& contributionA, float& contributionB, float& contributionC, float& contributionD, float& inverseJacobianLength) {  // :94-123
+        V3 ab = sub(pos[1], pos[0]);
+        V3 ac = sub(pos[2], pos[0]);
+        ad = sub(pos[3], pos[0]);
+        jacobianB = cross(ac, ad);
+        jacobianC = cross(ad, ab);
+        jacobianD = cross(ab, ac);
+        negatedJA = add(jacobianB, jacobianC);
+        negatedJA = add(jacobianD, negatedJA);
+        contributionA = dot(negatedJA, negatedJA);
+        contributionB = dot(jacobianB, jacobianB);
+        contributionC = dot(jacobianC, jacobianC);
+        contributionD = dot(jacobianD, jacobianD);
+        float jacobianLengthSquared = contributionA + contributionB + contributionC + contributionD;
+        jacobianLengthSquared = vmax(1e-14f, jacobianLengthSquared);
+        inverseJacobianLength = fastReciprocalSquareRoot(jacobianLengthSquared);
+    }
+    template <class G> BD_FN void warmStartN(const V3* pos, const float* inverseMass, float*, float* a, BodyVel* v, G&& gate) {  // :125-129
+        V3 ad, negatedJA, jacobianB, jacobianC, jacobianD; float cA, cB, cC, cD, inverseJacobianLength;
+        computeJacobian(pos, ad, negatedJA, jacobianB, jacobianC, jacobianD, cA, cB, cC, cD, inverseJacobianLength);
+        float impulse = inverseJacobianLength * a[0];
+        BD_GATE_N(v, negatedJA, jacobianB, jacobianC, jacobianD, impulse);
+        applyImpulse(inverseMass, negatedJA, jacobianB, jacobianC, jacobianD, impulse, v);
+    }
+    template <class G> BD_FN void solveN(const V3* pos, const float* inverseMass, float dt, float, float* p, float* a, BodyVel* v, G&& gate) {  // :131-157
+        V3 ad, negatedJA, jacobianB, jacobianC, jacobianD; float contributionA, contributionB, contributionC, contributionD, inverseJacobianLength;
+        computeJacobian(pos, ad, negatedJA, jacobianB, jacobianC, jacobianD, contributionA, contributionB, contributionC, contributionD, inverseJacobianLength);
+        float inverseJacobianLengthSquared = inverseJacobianLength * inverseJacobianLength;
+        float inverseEffectiveMass = vmax(1e-14f, inverseJacobianLengthSquared * (contributionA * inverseMass[0] + contributionB * inverseMass[1] + contributionC * inverseMass[2] + contributionD * inverseMass[3]));
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(p[1], p[2], dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        float effectiveMass = effMassCFMScale / inverseEffectiveMass;
+        float volume = dot(jacobianD, ad);
+        float biasVelocity = (p[0] - volume) * inverseJacobianLength * posErrToVel;
+        BD_GATE_N(v, negatedJA, jacobianB, jacobianC, jacobianD, inverseJacobianLength, effectiveMass, biasVelocity, softnessImpulseScale);
+        float negatedVelocityContributionA = dot(negatedJA, v[0].lin);
+        float velocityContributionB = dot(jacobianB, v[1].lin);
+        float velocityContributionC = dot(jacobianC, v[2].lin);
+        float velocityContributionD = dot(jacobianD, v[3].lin);
+        float csv = inverseJacobianLength * (velocityContributionB + velocityContributionC + velocityContributionD - negatedVelocityContributionA);
+        float csi = (biasVelocity - csv) * effectiveMass - a[0] * softnessImpulseScale;
+        a[0] = a[0] + csi;
+        applyImpulse(inverseMass, negatedJA, jacobianB, jacobianC, jacobianD, inverseJacobianLength * csi, v);
+    }
+};
+
 // The non-contact types for the dispatch switches, X(type id, struct): SURVEY 8(a)'s rows a8-a13, and the 8(f) widening.
 #define BD_HOT_JOINT_TYPES(X)                                                                                                       \
     X(kBallSocket, BallSocket) X(kAngularHinge, AngularHinge) X(kSwingLimit, SwingLimit) X(kTwistServo, TwistServo)                 \
@@ -1954,8 +2167,10 @@ struct AngularAxisGearMotor {
     X(kOneBodyAngularServo, OneBodyAngularServo) X(kOneBodyAngularMotor, OneBodyAngularMotor) X(kOneBodyLinearServo, OneBodyLinearServo) \
     X(kOneBodyLinearMotor, OneBodyLinearMotor) X(kBallSocketMotor, BallSocketMotor) X(kBallSocketServo, BallSocketServo) \
     X(kPointOnLineServo, PointOnLineServo) X(kLinearAxisServo, LinearAxisServo) X(kLinearAxisMotor, LinearAxisMotor) X(kLinearAxisLimit, LinearAxisLimit) \
-    X(kAngularAxisGearMotor, AngularAxisGearMotor)
+    X(kAngularAxisGearMotor, AngularAxisGearMotor) X(kCenterDistanceConstraint, CenterDistanceConstraint) X(kCenterDistanceLimit, CenterDistanceLimit)
 #define BD_JOINT_TYPES(X) BD_HOT_JOINT_TYPES(X) BD_WIDENED_JOINT_TYPES(X)
+// constraints over three and four bodies take body arrays (warmStartN / solveN)
+#define BD_MANY_BODY_TYPES(X) X(kAreaConstraint, AreaConstraint) X(kVolumeConstraint, VolumeConstraint)
 using NC2O = NonconvexContact<2, false>; using NC3O = NonconvexContact<3, false>; using NC4O = NonconvexContact<4, false>;
 using NC2T = NonconvexContact<2, true>; using NC3T = NonconvexContact<3, true>; using NC4T = NonconvexContact<4, true>;
 #define BD_NONCONVEX_CONTACT_TYPES(X)                                                                                              \

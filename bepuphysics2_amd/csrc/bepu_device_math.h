@@ -26,6 +26,12 @@ BD_FN void pin(Ts&... ts) { (pin_one(ts), ...); }
 #ifndef BEPU_PIN_ENABLED
 #define BEPU_PIN_ENABLED 1
 #endif
+// three- and four-body constraints hand the gate their velocity array
+#define BD_GATE_N(v, ...)                                                            \
+    do {                                                                             \
+        if constexpr (std::remove_reference_t<G>::kPin && BEPU_PIN_ENABLED) pin(__VA_ARGS__); \
+        gate.many(v);                                                                \
+    } while (0)
 #define BD_GATE(vA, vB, ...)                                                         \
     do {                                                                             \
         if constexpr (std::remove_reference_t<G>::kPin && BEPU_PIN_ENABLED) pin(__VA_ARGS__); \

@@ -42,6 +42,7 @@ static bool type_info(int id, TypeInfoH& t) {
 #define X(ID, T) case ID: TI(T)
         BD_JOINT_TYPES(X)
         BD_NONCONVEX_CONTACT_TYPES(X)
+        BD_MANY_BODY_TYPES(X)
 #undef X
     }
 #undef TI
@@ -53,6 +54,7 @@ static bool is_widened_type(int id) {
 #define X(ID, T) case ID: return true;
         BD_WIDENED_JOINT_TYPES(X)
         BD_NONCONVEX_CONTACT_TYPES(X)
+        BD_MANY_BODY_TYPES(X)
 #undef X
     }
     return false;

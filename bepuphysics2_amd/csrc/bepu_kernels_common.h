@@ -79,6 +79,7 @@ enum { kStageWarmStart = 0, kStageSolve = 1, kStageIncremental = 2 };
 struct NoGate {
     static constexpr bool kPin = false;
     __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {}
+    __device__ __forceinline__ void many(BodyVel*) const {}
 };
 
 }  // namespace

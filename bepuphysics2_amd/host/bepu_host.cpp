@@ -59,6 +59,10 @@ bool GetTypeInfo(int typeId, TypeInfo& info) {
         case 39: info = {2, 12, 1, false}; return true;  // LinearAxisMotor
         case 40: info = {2, 13, 1, false}; return true;  // LinearAxisLimit
         case 54: info = {2, 6, 1, false}; return true;   // AngularAxisGearMotor
+        case 32: info = {4, 3, 1, false}; return true;   // VolumeConstraint (four bodies, FourBodyTypeProcessor.cs)
+        case 35: info = {2, 3, 1, false}; return true;   // CenterDistanceConstraint
+        case 36: info = {3, 3, 1, false}; return true;   // AreaConstraint (three bodies, ThreeBodyTypeProcessor.cs)
+        case 55: info = {2, 4, 1, false}; return true;   // CenterDistanceLimit
     }
     return false;
 }

@@ -10,7 +10,7 @@ from __future__ import annotations
 from .scene import TYPE_TABLE, Scene
 
 POS, ORI, LIN, ANG, INERTIA = 1, 2, 4, 8, 16
-ALL, NO_POSITION, NO_POSE, ONLY_ANGULAR, ONLY_ANGULAR_NO_POSE = 31, 30, 28, 26, 24
+ALL, NO_POSITION, NO_POSE, ONLY_ANGULAR, ONLY_ANGULAR_NO_POSE, ONLY_LINEAR = 31, 30, 28, 26, 24, 21
 
 # (warm-start A, warm-start B, solve A, solve B) access filters, as in the reference's TypeProcessor declarations.
 ACCESS = {
@@ -28,13 +28,18 @@ ACCESS = {
     "BallSocketMotor": (29, ALL, ALL, ALL), "BallSocketServo": (NO_POSITION, NO_POSITION, ALL, ALL),
     "PointOnLineServo": (ALL,) * 4, "LinearAxisServo": (ALL,) * 4, "LinearAxisMotor": (ALL,) * 4, "LinearAxisLimit": (ALL,) * 4,
     "AngularAxisGearMotor": (ONLY_ANGULAR, ONLY_ANGULAR_NO_POSE, ONLY_ANGULAR, ONLY_ANGULAR_NO_POSE),
+    "CenterDistanceConstraint": (ONLY_LINEAR,) * 4, "CenterDistanceLimit": (ONLY_LINEAR,) * 4,
+    "AreaConstraint": (ONLY_LINEAR,) * 4, "VolumeConstraint": (ONLY_LINEAR,) * 4,  # every body of the three / four uses the same filter
 }
 
 
 def _body_bytes(mask: int) -> int:
     read = (12 if mask & POS else 0) + (16 if mask & ORI else 0) + (12 if mask & LIN else 0) + (12 if mask & ANG else 0)
     if mask & INERTIA:
-        read += 28 if mask & LIN else 24  # angular-only filters do not need the inverse mass
+        if not mask & ANG and not mask & ORI:
+            read += 4   # AccessOnlyLinear: the inverse mass alone
+        else:
+            read += 28 if mask & LIN else 24  # angular-only filters do not need the inverse mass
     write = (12 if mask & LIN else 0) + (12 if mask & ANG else 0)
     return read + write
 
@@ -44,8 +49,8 @@ def stage_bytes(type_id: int):
     nb, pf, imf, name = TYPE_TABLE[type_id]
     acc = ACCESS["Contact"] if name.startswith("Contact") else ACCESS[name]
     p, a, r = pf * 4, imf * 4, nb * 4
-    ws = p + a + r + _body_bytes(acc[0]) + (_body_bytes(acc[1]) if nb == 2 else 0)
-    sv = p + 2 * a + r + _body_bytes(acc[2]) + (_body_bytes(acc[3]) if nb == 2 else 0)
+    ws = p + a + r + _body_bytes(acc[0]) + (_body_bytes(acc[1]) * (nb - 1) if nb >= 2 else 0)
+    sv = p + 2 * a + r + _body_bytes(acc[2]) + (_body_bytes(acc[3]) * (nb - 1) if nb >= 2 else 0)
     inc = 0
     if name.startswith("Contact"):
         n = int(name[7])

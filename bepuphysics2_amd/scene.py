@@ -33,6 +33,7 @@ TYPE_TABLE: Dict[int, tuple] = {
     15: (2, 21, 6, "Contact2Nonconvex"), 16: (2, 28, 9, "Contact3Nonconvex"), 17: (2, 35, 12, "Contact4Nonconvex"),
     37: (2, 14, 2, "PointOnLineServo"), 38: (2, 15, 1, "LinearAxisServo"), 39: (2, 12, 1, "LinearAxisMotor"), 40: (2, 13, 1, "LinearAxisLimit"),
     54: (2, 6, 1, "AngularAxisGearMotor"),
+    32: (4, 3, 1, "VolumeConstraint"), 35: (2, 3, 1, "CenterDistanceConstraint"), 36: (3, 3, 1, "AreaConstraint"), 55: (2, 4, 1, "CenterDistanceLimit"),
 }
 TYPE_IDS_BY_NAME = {v[3]: k for k, v in TYPE_TABLE.items()}
 # The sixteen types of SURVEY.md 8(a) rows a7-a13 (the committed tests/golden/small_scenes.npz fixtures were generated from exactly these).

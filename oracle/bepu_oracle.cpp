@@ -295,6 +295,50 @@ void solveRange(Ctx& c, const OracleTypeBatch& tb, float dt, float inverseDt, in
         }
     }
 }
+// Three/FourBodyTypeProcessor.WarmStart / Solve (ThreeBodyTypeProcessor.cs, FourBodyTypeProcessor.cs): the same bundle loop over F::bodies body slots;
+// every slot integrates through GatherAndIntegrate with its own flags, the constraint function takes the bodies as arrays.
+template <class F, int Mode, bool AllowPose>
+void warmStartRangeMany(Ctx& c, const OracleTypeBatch& tb, const std::vector<std::vector<uint64_t>>* flagsForTypeBatch, float dt, int startBundle, int endBundle) {
+    const int W = c.W;
+    float* bodies = c.scene->bodies;
+    BodyState st[F::bodies][kMaxW];
+    for (int b = startBundle; b < endBundle; ++b) {
+        const int32_t* refs = tb.body_refs + (size_t)b * F::bodies * W;
+        for (int k = 0; k < F::bodies; ++k)
+            gatherAndIntegrateBundle<Mode, AllowPose>(c, flagsForTypeBatch ? &(*flagsForTypeBatch)[k] : nullptr, dt, b, refs + k * W, W, st[k]);
+        for (int l = 0; l < W; ++l) {
+            if (b * W + l >= tb.constraint_count) break;
+            float p[40], a[16];
+            loadLane<F>(tb, W, b, l, p, a);
+            V3 pos[F::bodies]; float inverseMass[F::bodies]; BodyVel vel[F::bodies];
+            for (int k = 0; k < F::bodies; ++k) { pos[k] = st[k][l].pos; inverseMass[k] = st[k][l].inertia.invMass; vel[k] = st[k][l].vel; }
+            F::warmStartN(pos, inverseMass, p, a, vel);
+            for (int k = 0; k < F::bodies; ++k) scatterVelocities(bodies, refs[k * W + l], vel[k]);
+        }
+    }
+}
+template <class F>
+void solveRangeMany(Ctx& c, const OracleTypeBatch& tb, float dt, float inverseDt, int startBundle, int endBundle) {
+    const int W = c.W;
+    float* bodies = c.scene->bodies;
+    for (int b = startBundle; b < endBundle; ++b) {
+        const int32_t* refs = tb.body_refs + (size_t)b * F::bodies * W;
+        for (int l = 0; l < W; ++l) {
+            if (b * W + l >= tb.constraint_count) break;
+            V3 pos[F::bodies]; float inverseMass[F::bodies]; BodyVel vel[F::bodies];
+            for (int k = 0; k < F::bodies; ++k) {
+                BodyState s;
+                gatherState(bodies, refs[k * W + l], true, s);
+                pos[k] = s.pos; inverseMass[k] = s.inertia.invMass; vel[k] = s.vel;
+            }
+            float p[40], a[16];
+            loadLane<F>(tb, W, b, l, p, a);
+            F::solveN(pos, inverseMass, dt, inverseDt, p, a, vel);
+            storeAccumulated<F>(tb, W, b, l, a);
+            for (int k = 0; k < F::bodies; ++k) scatterVelocities(bodies, refs[k * W + l], vel[k]);
+        }
+    }
+}
 // IncrementallyUpdateForSubstep (TwoBodyTypeProcessor.cs:227-241, OneBodyTypeProcessor.cs:132-146)
 template <class F>
 void incrementalRange(Ctx& c, const OracleTypeBatch& tb, float dt, int startBundle, int endBundle) {
@@ -318,27 +362,33 @@ void incrementalRange(Ctx& c, const OracleTypeBatch& tb, float dt, int startBund
 
 enum Stage { kStageIncremental, kStageWarmStart, kStageSolve };
 
+template <class F, int Mode, bool AllowPose>
+void warmStartDispatch(Ctx& c, const OracleTypeBatch& tb, const std::vector<std::vector<uint64_t>>* flags, float dt, int startBundle, int endBundle) {
+    if constexpr (F::bodies > 2) warmStartRangeMany<F, Mode, AllowPose>(c, tb, flags, dt, startBundle, endBundle);
+    else warmStartRange<F, Mode, AllowPose>(c, tb, flags, dt, startBundle, endBundle);
+}
 template <class F>
 void runTyped(Ctx& c, Stage stage, int batchIndex, int typeBatchIndex, const OracleTypeBatch& tb, int substepIndex, float dt, float inverseDt, int startBundle, int endBundle) {
     if (stage == kStageIncremental) {
-        if (F::incremental) incrementalRange<F>(c, tb, dt, startBundle, endBundle);
+        if constexpr (F::incremental) incrementalRange<F>(c, tb, dt, startBundle, endBundle);
         return;
     }
     if (stage == kStageSolve) {
-        solveRange<F>(c, tb, dt, inverseDt, startBundle, endBundle);
+        if constexpr (F::bodies > 2) solveRangeMany<F>(c, tb, dt, inverseDt, startBundle, endBundle);
+        else solveRange<F>(c, tb, dt, inverseDt, startBundle, endBundle);
         return;
     }
     // WarmStartBlock, Solver_Solve.cs:185-210
     if (batchIndex == 0) {
-        if (substepIndex == 0) warmStartRange<F, kAlways, false>(c, tb, nullptr, dt, startBundle, endBundle);
-        else warmStartRange<F, kAlways, true>(c, tb, nullptr, dt, startBundle, endBundle);
+        if (substepIndex == 0) warmStartDispatch<F, kAlways, false>(c, tb, nullptr, dt, startBundle, endBundle);
+        else warmStartDispatch<F, kAlways, true>(c, tb, nullptr, dt, startBundle, endBundle);
     } else if (c.coarse[batchIndex][typeBatchIndex]) {
         auto* fl = &c.flags[batchIndex][typeBatchIndex];
-        if (substepIndex == 0) warmStartRange<F, kConditional, false>(c, tb, fl, dt, startBundle, endBundle);
-        else warmStartRange<F, kConditional, true>(c, tb, fl, dt, startBundle, endBundle);
+        if (substepIndex == 0) warmStartDispatch<F, kConditional, false>(c, tb, fl, dt, startBundle, endBundle);
+        else warmStartDispatch<F, kConditional, true>(c, tb, fl, dt, startBundle, endBundle);
     } else {
-        if (substepIndex == 0) warmStartRange<F, kNever, false>(c, tb, nullptr, dt, startBundle, endBundle);
-        else warmStartRange<F, kNever, true>(c, tb, nullptr, dt, startBundle, endBundle);
+        if (substepIndex == 0) warmStartDispatch<F, kNever, false>(c, tb, nullptr, dt, startBundle, endBundle);
+        else warmStartDispatch<F, kNever, true>(c, tb, nullptr, dt, startBundle, endBundle);
     }
 }
 
@@ -352,6 +402,7 @@ bool typeInfo(int typeId, int& bodies, int& prestepFloats, int& impulseFloats, b
 #define X(ID, T) case ID: TI(T)
         BO_JOINT_TYPES(X)
         BO_NONCONVEX_CONTACT_TYPES(X)
+        BO_MANY_BODY_TYPES(X)
 #undef X
     }
 #undef TI
@@ -369,6 +420,7 @@ void runBlock(Ctx& c, Stage stage, int batchIndex, int typeBatchIndex, int subst
 #define X(ID, T) case ID: RT(T)
         BO_JOINT_TYPES(X)
         BO_NONCONVEX_CONTACT_TYPES(X)
+        BO_MANY_BODY_TYPES(X)
 #undef X
     }
 #undef RT
@@ -692,7 +744,7 @@ int oracle_prepare_flags(OracleScene* scene, uint64_t* out_merged, uint64_t* out
 // bodyA/bodyB: 32-float BodyDynamics (world inertia slot used as-is); prestep/accumulated: flat lane arrays.
 int oracle_constraint_iterate(int type_id, float* bodyA, float* bodyB, float* prestep, float* accumulated, float dt, int iterations) {
     int bodies, pf, imf; bool inc;
-    if (!typeInfo(type_id, bodies, pf, imf, inc)) return -3;
+    if (!typeInfo(type_id, bodies, pf, imf, inc) || bodies > 2) return -3;  // (three- and four-body types are exercised through whole scenes)
     BodyState A, B;
     gatherState(bodyA, 0, true, A);
     if (bodies == 2) gatherState(bodyB, 0, true, B); else memset(&B, 0, sizeof(B));

@@ -123,6 +123,15 @@ def joint_prestep(rng, type_id):
         return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + [lo, lo + rng.uniform(0.1, 2.0)] + sp
     if name == "AngularAxisGearMotor":
         return list(unit(rng)) + [rng.uniform(0.25, 3.0)] + motor()
+    if name == "CenterDistanceConstraint":
+        return [rng.uniform(0.5, 3.0)] + sp
+    if name == "CenterDistanceLimit":
+        lo = rng.uniform(0.2, 2.0)
+        return [lo, lo + rng.uniform(0.1, 2.0)] + sp
+    if name == "AreaConstraint":
+        return [rng.uniform(0.5, 6.0)] + sp       # TargetScaledArea = 2 x area
+    if name == "VolumeConstraint":
+        return [rng.uniform(-6.0, 6.0)] + sp      # TargetScaledVolume = 6 x signed volume
     if name == "Weld":
         return list(rng.uniform(-0.5, 0.5, 3)) + list(rand_quat(rng)) + sp
     if name in ("SwivelHinge", "Hinge"):
@@ -158,7 +167,7 @@ def random_graph_scene(seed, body_count, constraint_count, type_ids, kinematic_f
         if all(sb.is_kinematic(h) for h in hs):
             continue
         pa = positions[hs[0]]
-        pb = positions[hs[1]] if nb == 2 else None
+        pb = positions[hs[1]] if nb >= 2 else None
         sb.add_constraint(t, hs, prestep_for(rng, t, pa, pb))
         added += 1
     scene = sb.build()
@@ -223,6 +232,11 @@ def island_scene(seed, islands, bodies_per_island, constraints_per_island, type_
             if nb == 1:
                 a = int(rng.integers(bodies_per_island))
                 sb.add_constraint(t, [hs[a]], prestep_for(rng, t, pos[a], None))
+            elif nb > 2:  # three- / four-body constraints: distinct bodies of the island, now and then with the shared kinematic body among them
+                picks = [hs[int(x)] for x in rng.choice(bodies_per_island, size=nb, replace=False)]
+                if kinematic_shared and rng.random() < 0.1:
+                    picks[int(rng.integers(nb))] = kin
+                sb.add_constraint(t, picks, prestep_for(rng, t, None, None))
             else:
                 a, b = [int(x) for x in rng.choice(bodies_per_island, size=2, replace=False)]
                 if kinematic_shared and rng.random() < 0.1:

@@ -30,7 +30,7 @@ def test_type_info_table():
     for tid, (nb, pf, imf, _) in TYPE_TABLE.items():
         assert native.type_info(tid) == (nb, pf, imf)
     with pytest.raises(native.UnsupportedError):
-        native.type_info(35)  # CenterDistanceConstraint: FastReciprocal makes the reference CPU-dependent (left out, see bepu_device_constraints.h)
+        native.type_info(11)  # ids 11-14 and 18-21 are unused by the reference (DefaultTypes.cs)
 
 
 def test_create_fails_loudly_without_gpu_or_bad_config():

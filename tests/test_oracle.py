@@ -403,4 +403,51 @@ def test_nonconvex_contacts_stop_approach_per_contact_normal():
         assert np.hypot(acc[3 * c], acc[3 * c + 1]) <= 1.0 * acc[3 * c + 2] * (1 + 1e-5) + 1e-7
 
 
+def _solve_free_bodies(positions, masses, type_id, prestep, frames=40, substeps=4):
+    """A handful of point-like dynamic bodies, one constraint over all of them, no gravity or damping: returns the scene after `frames` solves."""
+    from bepuphysics2_amd.scene import SceneBuilder
+    sb = SceneBuilder()
+    rng = np.random.default_rng(5)
+    hs = []
+    for pos, m in zip(positions, masses):
+        hs.append(sb.add_body(make_body(position=pos, linear=rng.uniform(-0.3, 0.3, 3), inverse_mass=1.0 / m)))
+    sb.add_constraint(type_id, hs, prestep)
+    scene = sb.build()
+    cb = PoseIntegratorCallbacks(gravity=(0, 0, 0), linear_damping=0.0, angular_damping=0.0)
+    start = scene.copy()
+    for _ in range(frames):
+        oracle_ffi.solve(scene, 1 / 60, SolveDescription(1, substeps), cb)
+    return start, scene
+
+
+def test_center_distance_area_and_volume_constraints_hold_their_targets():
+    """The four types restated on the portable branch of MathHelper.FastReciprocal*: the constrained quantity converges to its target and the impulses
+    (along the centre line; jacobians summing to zero) leave the total linear momentum untouched."""
+    stiff = small_scenes.spring(30.0, 1.0)
+    masses = [1.0, 2.0, 0.5, 1.5]
+
+    def momentum(sc, n):
+        return sum(m * sc.bodies[i, 8:11].astype(np.float64) for i, m in zip(range(n), masses))
+
+    # CenterDistanceConstraint (35): |pB - pA| -> TargetDistance
+    start, end = _solve_free_bodies([(0, 0, 0), (1.5, 0.2, -0.1)], masses[:2], 35, [2.0] + stiff)
+    assert abs(float(np.linalg.norm(end.bodies[1, 4:7] - end.bodies[0, 4:7])) - 2.0) < 2e-2
+    assert np.allclose(momentum(start, 2), momentum(end, 2), atol=1e-4)
+    # CenterDistanceLimit (55): outside [min, max] the pair is brought back to the nearer bound, inside nothing happens
+    start, end = _solve_free_bodies([(0, 0, 0), (3.0, 0, 0)], masses[:2], 55, [0.5, 2.0] + stiff)
+    assert float(np.linalg.norm(end.bodies[1, 4:7] - end.bodies[0, 4:7])) < 2.3
+    # AreaConstraint (36): |ab x ac| -> TargetScaledArea
+    tri = [(0, 0, 0), (1, 0, 0), (0, 1, 0)]
+    start, end = _solve_free_bodies(tri, masses[:3], 36, [2.0] + stiff)
+    a, b, c = (end.bodies[i, 4:7].astype(np.float64) for i in range(3))
+    assert abs(float(np.linalg.norm(np.cross(b - a, c - a))) - 2.0) < 5e-2
+    assert np.allclose(momentum(start, 3), momentum(end, 3), atol=1e-4)
+    # VolumeConstraint (32): dot(ab x ac, ad) -> TargetScaledVolume
+    tet = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]
+    start, end = _solve_free_bodies(tet, masses, 32, [2.5] + stiff)
+    a, b, c, d = (end.bodies[i, 4:7].astype(np.float64) for i in range(4))
+    assert abs(float(np.dot(np.cross(b - a, c - a), d - a)) - 2.5) < 8e-2
+    assert np.allclose(momentum(start, 4), momentum(end, 4), atol=1e-4)
+
+
 FLOAT_MAX = float(np.finfo(np.float32).max)

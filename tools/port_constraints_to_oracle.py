@@ -10,9 +10,9 @@ import sys
 def port(text: str) -> str:
     out = []
     for line in text.split("\n"):
-        if re.match(r"\s*static constexpr int wsA = ", line):
+        if re.match(r"\s*static constexpr int (wsA|access) = ", line):
             continue  # access filters are a device-side notion
-        if re.match(r"\s*BD_GATE\(", line) or re.match(r"\s*gate\(vA, vB\);", line):
+        if re.match(r"\s*BD_GATE(_N)?\(", line) or re.match(r"\s*gate\(vA, vB\);", line):
             continue
         line = line.replace("template <class G> BD_FN", "static").replace(", G&& gate)", ")")
         line = line.replace("BD_FN", "static inline")
