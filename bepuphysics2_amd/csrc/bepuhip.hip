@@ -420,13 +420,13 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
         cp.sp = sp;
         {
             Timed t(c, 5);
-            // Waves per cluster: 16 by default (four per SIMD; 12 is as fast when memory latency is low, 8 is slower everywhere); BEPUHIP_CLUSTER_THREADS selects 512 / 768 / 1024.
+            // Waves per cluster: 16 by default (four per SIMD; 12 is as fast when memory latency is low, 8 is slower everywhere); BEPUHIP_CLUSTER_THREADS overrides.
             const int req = env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
-            const int threads = req >= 1024 ? 1024 : req >= 768 ? 768 : std::max(64, std::min(512, req / 64 * 64));
+            const int threads = std::max(64, std::min(1024, req / 64 * 64));
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
                             (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles};
             const bool tr = c->d_trace != nullptr;
-            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types);
+            const void* fn = cluster_kernel_variant(tr, c->has_widened_types);
             hipLaunchKernel(fn, dim3(c->cluster_count), dim3(threads), args, lds_bytes, c->stream);
         }
         if (c->kinlist_count > 0) {
