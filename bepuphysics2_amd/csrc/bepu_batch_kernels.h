@@ -105,7 +105,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 }
 
 // Body flag bits (per body index).
-enum { kFlagConstrained = 1, kFlagDynamicConstrained = 2, kFlagConstrainedKinematic = 4, kFlagClustered = 8 /* dynamic body owned by a cluster_kernel workgroup */ };
+enum { kFlagConstrained = 1, kFlagDynamicConstrained = 2, kFlagConstrainedKinematic = 4, kFlagClustered = 8 /* dynamic body owned by a cluster_kernel workgroup */,
+       kFlagClusterKinematic = 16 /* constrained kinematic body of the island schedule: advanced by cluster_kernel's kinematic block */ };
 
 // Device-side equivalent of the merged constrained-body set of PrepareConstraintIntegrationResponsibilities
 // (Solver_Solve.cs:1198-1207,1378-1381): every body referenced as dynamic gets integration inside the solver.
@@ -133,10 +134,8 @@ __device__ __forceinline__ void velocity_callback(const StepParams& sp, BodyVel&
 
 // Cluster path only: advance the constrained kinematic bodies in global memory through the in-solver substeps
 // (PoseIntegrator.cs:451-535 applied substep_count times: substep 0 velocity only, later substeps pose then velocity).
-__global__ void kinematic_substeps_kernel(float4* bodies, const int* __restrict__ indices, int count, int substeps, int integrate_velocity_for_kinematics, StepParams sp) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    float4* base = bodies + (size_t)(indices[i] & kRefMask) * 8;
+__device__ __forceinline__ void kinematic_substeps_body(float4* bodies, int index, int substeps, int integrate_velocity_for_kinematics, const StepParams& sp) {
+    float4* base = bodies + (size_t)(index & kRefMask) * 8;
     float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
     Q ori = {q4.x, q4.y, q4.z, q4.w};
     V3 pos = {p4.x, p4.y, p4.z};
@@ -154,6 +153,11 @@ __global__ void kinematic_substeps_kernel(float4* bodies, const int* __restrict_
         base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
         base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
     }
+}
+__global__ void kinematic_substeps_kernel(float4* bodies, const int* __restrict__ indices, int count, int substeps, int integrate_velocity_for_kinematics, StepParams sp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    kinematic_substeps_body(bodies, indices[i], substeps, integrate_velocity_for_kinematics, sp);
 }
 
 // Per-substep integration of every constrained body — the work the reference fuses into the first-touching constraint's
@@ -238,13 +242,10 @@ __global__ void momentum_requirk_kernel(float4* bodies, const int* __restrict__ 
 }
 
 // PoseIntegrator.IntegrateBundlesAfterSubstepping (PoseIntegrator.cs:537-693), one lane per body.
-__global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, float dt, float substep_dt, int substep_count,
-                                                               int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, int skip_clustered, StepParams sp) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+__device__ __forceinline__ void final_integrate_body(float4* bodies, unsigned body_flags, int i, float dt, float substep_dt, int substep_count,
+                                                     int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, const StepParams& sp) {
     float4* base = bodies + (size_t)i * 8;
-    if (skip_clustered && (flags[i] & kFlagClustered)) return;  // final pose already written by the owning cluster_kernel workgroup
-    const bool unconstrained = !(flags[i] & kFlagConstrained);
+    const bool unconstrained = !(body_flags & kFlagConstrained);
     const float effective_dt = allow_substeps_for_unconstrained ? substep_dt : (unconstrained ? dt : substep_dt);  // :591-599
     const float half_dt = effective_dt * 0.5f;
     float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
@@ -283,7 +284,14 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
     base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
     base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
 }
-
+__global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, float dt, float substep_dt, int substep_count,
+                                                               int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, int skip_clustered, StepParams sp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const unsigned f = flags[i];
+    if (skip_clustered && (f & kFlagClustered)) return;  // final pose already written by the owning cluster_kernel workgroup
+    final_integrate_body(bodies, f, i, dt, substep_dt, substep_count, allow_substeps_for_unconstrained, integrate_velocity_for_kinematics, sp);
+}
 
 
 // ---- boundary exchange (one connected scene split across GPUs, BASELINE.json configs[4]) ----

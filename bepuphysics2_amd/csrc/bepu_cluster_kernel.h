@@ -2,6 +2,7 @@
 #pragma once
 
 #include "bepu_kernels_common.h"
+#include "bepu_batch_kernels.h"  // the per-body integration functions shared with the launch-per-batch schedule
 
 namespace {
 
@@ -366,7 +367,37 @@ template <int THREADS, bool TRACE, bool WIDE>
 __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __restrict__ clusters, const ClusterItem* __restrict__ items,
                                                                    const int* __restrict__ batch_item_begin, const int* __restrict__ cluster_bodies,
                                                                    float4* bodies, unsigned* __restrict__ slab, ClusterParams cp, int ncap, int max_items,
-                                                                   unsigned long long* trace, unsigned* status, unsigned long long* cycles) {
+                                                                   unsigned long long* trace, unsigned* status, unsigned long long* cycles, TailParams tp) {
+    if ((int)blockIdx.x >= tp.cluster_count) {
+        // ---- not a cluster: the bodies no cluster owns (IntegrateBundlesAfterSubstepping for unconstrained bodies), and, in the last workgroup, the
+        // constrained kinematic bodies. Clusters stage private copies of the kinematic bodies they reference from HBM when they start, so those are
+        // advanced only after every cluster has reported its staging done (clusters are dispatched before this workgroup: it cannot starve them).
+        const int t = (int)blockIdx.x - tp.cluster_count;
+        if (t < tp.body_blocks) {
+            const int i = t * (int)blockDim.x + (int)threadIdx.x;
+            if (i < tp.body_count) {
+                const unsigned f = tp.flags[i];
+                if (!(f & (kFlagClustered | kFlagClusterKinematic)))
+                    final_integrate_body(bodies, f, i, tp.dt, tp.substep_dt, tp.substep_count, tp.allow_substeps_for_unconstrained, tp.integrate_velocity_for_kinematics, tp.final_sp);
+            }
+            return;
+        }
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(tp.staged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tp.cluster_count) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > kSpinLimit) { report_stall(status, 0u, 5, t, tp.cluster_count, (unsigned)tp.cluster_count, __hip_atomic_load(tp.staged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); break; }
+            }
+            __hip_atomic_store(tp.staged, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch (launches of one context are stream-ordered)
+        }
+        __syncthreads();
+        for (int j = (int)threadIdx.x; j < tp.kin_count; j += (int)blockDim.x) {
+            const int index = tp.kinlist[j] & kRefMask;
+            kinematic_substeps_body(bodies, index, tp.substep_count, tp.integrate_velocity_for_kinematics, cp.sp);
+            final_integrate_body(bodies, tp.flags[index], index, tp.dt, tp.substep_dt, tp.substep_count, tp.allow_substeps_for_unconstrained, tp.integrate_velocity_for_kinematics, tp.final_sp);
+        }
+        return;
+    }
     const unsigned long long kernel_t0 = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
     ClusterShared sh;
@@ -400,6 +431,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     for (int j = tid; j <= cp.batch_count; j += blockDim.x) sh.lbib[j] = batch_item_begin[cd.batch_item_offset + j] - cd.item_begin;
     if (tid == 0) *sh.counter = 0;
     __syncthreads();
+    if (tid == 0 && tp.kin_count > 0) __hip_atomic_fetch_add(tp.staged, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // this cluster's copies of kinematic bodies are in LDS
 
     unsigned epoch = 0, claim_base = 0;
     for (int s = 0; s < cp.substeps; ++s) {

@@ -46,6 +46,16 @@ struct ClusterParams {
 };
 
 
+// The per-body work that follows the substep loop (PoseIntegrator.cs:451-535 for constrained kinematics, :537-693 for every other body), handed to
+// cluster_kernel so that a whole step is ONE launch: workgroups beyond the clusters integrate the bodies no cluster owns.
+struct TailParams {
+    const unsigned* flags; const int* kinlist; unsigned* staged;
+    int body_count, kin_count, cluster_count, body_blocks;
+    float dt, substep_dt;
+    int substep_count, allow_substeps_for_unconstrained, integrate_velocity_for_kinematics;
+    StepParams final_sp;  // PrepareForIntegration(dt or dt / substeps) of the final pass (PoseIntegrator.cs:707-726), not the substep's
+};
+
 struct DBody {
     V3 pos; Q ori; BodyVel vel; Inertia inertia;
     float linw, angw;  // padding lanes of the velocity float4s, preserved on store

@@ -77,6 +77,8 @@ int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx) {
     HIP_TRY(hipEventCreate(&c->ev_start));
     HIP_TRY(hipEventCreate(&c->ev_stop));
     HIP_TRY(hipHostMalloc((void**)&c->d_status, 256, hipHostMallocMapped | hipHostMallocCoherent));  // host-visible while a kernel runs
+    HIP_TRY(hipMalloc((void**)&c->d_staged, 4));
+    HIP_TRY(hipMemset(c->d_staged, 0, 4));
     memset(c->d_status, 0, 256);
     *out_ctx = c;
     return BEPUHIP_OK;
@@ -92,6 +94,7 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_flags) hipFree(c->d_flags);
     if (c->d_kin) hipFree(c->d_kin);
     if (c->d_status) hipHostFree(c->d_status);
+    if (c->d_staged) hipFree(c->d_staged);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->d_boundary) hipFree(c->d_boundary);
     if (c->d_boundary_snapshot) hipFree(c->d_boundary_snapshot);
@@ -116,6 +119,10 @@ static int32_t rebuild_flags(bepuhip_ctx* c) {
     if (c->built && c->clusters_enabled && c->clustered_dynamic_count > 0) {
         hipLaunchKernelGGL(mark_indices_kernel, dim3((c->clustered_dynamic_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_clustered_dynamic,
                            c->clustered_dynamic_count, c->d_flags, (unsigned)kFlagClustered);
+    }
+    if (c->built && c->clusters_enabled && c->kinlist_count > 0) {
+        hipLaunchKernelGGL(mark_indices_kernel, dim3((c->kinlist_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_kinlist, c->kinlist_count, c->d_flags,
+                           (unsigned)(kFlagClusterKinematic | kFlagConstrained));
     }
     if (c->boundary_count > 0) {  // held by several ranks: always integrated inside the solver, whatever this rank's share of its constraints
         hipLaunchKernelGGL(mark_indices_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_boundary, c->boundary_count, c->d_flags,
@@ -423,16 +430,21 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             // Waves per cluster: 16 by default (four per SIMD; 12 is as fast when memory latency is low, 8 is slower everywhere); BEPUHIP_CLUSTER_THREADS overrides.
             const int req = env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
             const int threads = std::max(64, std::min(1024, req / 64 * 64));
+            // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
+            // constrained kinematic bodies (kinematic_substeps_kernel + final_integrate_kernel of the launch-per-batch schedule, folded in).
+            TailParams tp;
+            tp.flags = c->d_flags; tp.kinlist = c->d_kinlist; tp.staged = c->d_staged;
+            tp.body_count = c->body_count; tp.kin_count = c->kinlist_count; tp.cluster_count = c->cluster_count;
+            tp.body_blocks = (c->body_count + threads - 1) / threads;
+            tp.dt = dt; tp.substep_dt = substep_dt; tp.substep_count = substeps;
+            tp.allow_substeps_for_unconstrained = in->allow_substeps_for_unconstrained; tp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
+            const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
+            tp.final_sp = make_params(in, vdt, vdt, 1.0f / vdt);
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
-                            (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles};
+                            (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp};
             const bool tr = c->d_trace != nullptr;
             const void* fn = cluster_kernel_variant(tr, c->has_widened_types);
-            hipLaunchKernel(fn, dim3(c->cluster_count), dim3(threads), args, lds_bytes, c->stream);
-        }
-        if (c->kinlist_count > 0) {
-            Timed t(c, 1);
-            hipLaunchKernelGGL(kinematic_substeps_kernel, dim3((c->kinlist_count + 63) / 64), dim3(64), 0, c->stream, c->d_bodies, (const int*)c->d_kinlist, c->kinlist_count, substeps,
-                               in->integrate_velocity_for_kinematics, sp);
+            hipLaunchKernel(fn, dim3(c->cluster_count + tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0)), dim3(threads), args, lds_bytes, c->stream);
         }
     }
     for (int s = 0; s < substeps && !use_clusters; ++s) {
@@ -461,7 +473,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             }
         }
     }
-    if (body_blocks > 0) {                            // PoseIntegrator.cs:707-726
+    if (body_blocks > 0 && !use_clusters) {           // PoseIntegrator.cs:707-726 (the island schedule's launch includes it)
         const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
         const StepParams fsp = make_params(in, vdt, vdt, 1.0f / vdt);
         Timed t(c, 4);
