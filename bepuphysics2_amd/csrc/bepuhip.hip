@@ -409,6 +409,12 @@ static void enqueue_requirk(bepuhip_ctx* c, int substep, int batch, const StepPa
         hipLaunchKernelGGL(momentum_requirk_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_bodies, (const int*)(c->d_requirk + c->requirk_begin[batch]), n, sp);
 }
 
+// The island schedule implements AngularIntegrationMode.Nonconserving; the conserving modes run the launch-per-batch schedule.
+static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
+    return c->clusters_enabled && substeps <= kMaxClusterSubsteps && cluster_lds_bytes(c->cluster_max_slots, c->cluster_max_items) <= kLdsBudgetBytes &&
+           in->angular_integration_mode == 0;
+}
+
 // Enqueue every kernel of one Simulation.Solve on the context's stream (Solver_Solve.cs:1415-1479 + PoseIntegrator.cs:707-726).
 static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t* iterations, const bepuhip_integrator* in) {
     const float substep_dt = dt / substeps;          // Solver_Solve.cs:1417
@@ -416,8 +422,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
     const StepParams sp = make_params(in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
     const size_t lds_bytes = cluster_lds_bytes(c->cluster_max_slots, c->cluster_max_items);
-    // The island schedule implements AngularIntegrationMode.Nonconserving; the conserving modes run the launch-per-batch schedule.
-    const bool use_clusters = c->clusters_enabled && substeps <= kMaxClusterSubsteps && lds_bytes <= kLdsBudgetBytes && in->angular_integration_mode == 0;
+    const bool use_clusters = island_schedule_applies(c, substeps, in);
     const int skip_clustered = use_clusters ? 1 : 0;
     if (use_clusters) {
         // Every constraint belongs to an island small enough for one workgroup: the whole substep loop runs in ONE launch.
@@ -502,7 +507,8 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     c->last_constraint_iterations = iters;
     if (c->profiling) { for (int i = 0; i < 6; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; } }
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
-    const bool use_graph = !(c->flags & BEPUHIP_FLAG_NO_GRAPH) && !c->profiling;
+    // A graph pays for the launch-per-batch schedule's 100+ launches; the island schedule is ONE kernel, which a plain launch starts sooner (6-7 us per step).
+    const bool use_graph = !(c->flags & BEPUHIP_FLAG_NO_GRAPH) && !c->profiling && !island_schedule_applies(c, substeps, in);
     if (use_graph) {
         GraphKey key;
         key.iterations.assign(iterations, iterations + substeps);

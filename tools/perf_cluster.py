@@ -17,11 +17,11 @@ cb = PoseIntegratorCallbacks()
 its = scene.constraint_count * int((1 + sd.iterations()).sum())
 
 
-def run(label, env, steps=int(os.environ.get('STEPS', '400')), use_clusters=True):
+def run(label, env, steps=int(os.environ.get('STEPS', '400')), use_clusters=True, use_graph=True):
     for k in ("BEPUHIP_DEBUG", "BEPUHIP_CLUSTER_BODIES", "BEPUHIP_CLUSTER_THREADS"):
         os.environ.pop(k, None)
     os.environ.update(env)
-    s = HipSolver(use_clusters=use_clusters)
+    s = HipSolver(use_clusters=use_clusters, use_graph=use_graph)
     s.upload(scene)
     for _ in range(int(os.environ.get('WARM', '200'))):  # long warm-up: the clock needs tens of milliseconds of load to ramp up
         s.solve(1 / 60, sd, cb, asynchronous=True)
@@ -41,6 +41,10 @@ configs = sys.argv[1:] or ["base"]
 for cfg in configs:
     if cfg == "clusters":
         run("clusters default", {})
+    elif cfg == "graph":
+        for _ in range(2):
+            run("clusters, hipGraph replay", {})
+            run("clusters, direct launch", {}, use_graph=False)
     elif cfg == "base":
         run("clusters default", {})
         run("global path (launch per batch)", {}, use_clusters=False)
