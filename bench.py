@@ -294,10 +294,11 @@ def main():
                 for tb in batch:
                     _, pf, imf, _name = TYPE_TABLE[tb.type_id]
                     nb = TYPE_TABLE[tb.type_id][0]
-                    reads = (nb + pf + imf) * 4 * (sd.substep_count + int(its.sum()))
+                    refs = (nb + 1) // 2  # the island schedule reads body references as 16-bit halves, two per word
+                    reads = (refs + pf + imf) * 4 * (sd.substep_count + int(its.sum()))
                     writes = imf * 4 * int(its.sum())
                     if _name.startswith("Contact"):
-                        reads += (nb + pf) * 4 * (sd.substep_count - 1)
+                        reads += (refs + pf) * 4 * (sd.substep_count - 1)
                         writes += int(_name[7]) * 4 * (sd.substep_count - 1)
                     stream_bytes += (reads + writes) * tb.count
             roofline = {"bound": "hbm", "kernel": "cluster_kernel (whole substep loop of a step in one launch)", "achieved": achieved, "peak": HBM_PEAK_GBS,

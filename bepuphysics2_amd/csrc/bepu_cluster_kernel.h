@@ -76,6 +76,9 @@ __device__ __forceinline__ void store_velocity_lds(const ClusterShared& sh, int 
 }
 
 
+// Local body references travel as 16-bit halves (slot | kinematic << 15); the gather / scatter helpers take the 32-bit form (slot | kinematic << 30).
+__device__ __forceinline__ int unpack_local_ref(unsigned half) { return (int)((half & 0x7FFFu) | ((half & 0x8000u) << 15)); }
+
 struct ItemHeader {  // wave-uniform copy of the fields the constraint code needs (SGPRs)
     int type_id, count, stride, start, batch, npred, nxpred, overflow, xoverflow;
     unsigned lrefs_off, prestep_off, accum_off;
@@ -226,7 +229,11 @@ __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared&
     gfloat* accum = (gfloat*)(slab + h.accum_off);
     float p[F::prestepFloats], a[F::impulseFloats];
     int refs[N];
-    _Pragma("unroll") for (int j = 0; j < N; ++j) refs[j] = lrefs[(size_t)j * stride + i];
+    _Pragma("unroll") for (int j = 0; j < N; j += 2) {
+        const unsigned w = (unsigned)lrefs[(size_t)(j / 2) * stride + i];
+        refs[j] = unpack_local_ref(w & 0xFFFFu);
+        if (j + 1 < N) refs[j + 1] = unpack_local_ref(w >> 16);
+    }
     _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
     _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i];
     DBody b[N];
@@ -257,8 +264,9 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     float p[F::prestepFloats];
     float a[F::impulseFloats];
     // issue the item's global loads first: their latency hides under the velocity-independent work and the wait for the predecessors
-    const int ra = lrefs[i];
-    const int rb = (F::bodies == 2) ? lrefs[stride + i] : -1;
+    const unsigned both = (unsigned)lrefs[i];  // two 16-bit local references per word
+    const int ra = unpack_local_ref(both & 0xFFFFu);
+    const int rb = (F::bodies == 2) ? unpack_local_ref(both >> 16) : -1;
     _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
     if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
     DBody A, B;

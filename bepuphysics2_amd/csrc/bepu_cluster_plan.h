@@ -210,6 +210,19 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
             d = e;
         }
     }
+    // The kernel reads the local references as 16-bit halves, two body slots per word (slot < 32768; bit 15 = kinematic copy): half the bytes, and one
+    // load instead of two for a two-body constraint. The 32-bit form above was only needed for the predecessor search.
+    for (auto& tb : c->tbs) {
+        const int nb = tb.info.bodies, rows = (nb + 1) / 2;
+        std::vector<int32_t> packed((size_t)rows * tb.stride, 0);
+        for (int k = 0; k < nb; ++k)
+            for (int d = 0; d < tb.count; ++d) {
+                const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + d];
+                const uint32_t half = ((uint32_t)lr & 0x7FFFu) | (((uint32_t)lr >= kDynamicLimit) ? 0x8000u : 0u);
+                packed[(size_t)(k / 2) * tb.stride + d] |= (int32_t)(half << (16 * (k & 1)));
+            }
+        tb.lrefs_soa.swap(packed);
+    }
     // Cross-pass predecessors: the last toucher (end of a pass) of every body an item touches first.
     for (int cl = 0; cl < nclusters; ++cl) {
         for (auto& fs : first_touch[cl]) {
