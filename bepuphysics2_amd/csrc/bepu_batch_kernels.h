@@ -294,6 +294,25 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
 }
 
 
+// PoseIntegrator.PredictBoundingBoxes (PoseIntegrator.cs:307-370), one lane per body: the stage before collision detection, on the bodies the solver left in HBM.
+__global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __restrict__ bodies, int count, const CollidableIn* __restrict__ collidables,
+                                                              PredictedBounds* __restrict__ out, float dt, int integrate_velocity_for_kinematics, StepParams sp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float4* base = bodies + (size_t)i * 8;
+    const float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3], i0 = base[4], i1 = base[5];
+    const Q ori = {q4.x, q4.y, q4.z, q4.w};
+    const V3 pos = {p4.x, p4.y, p4.z};
+    BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+    const bool is_kinematic = i0.x == 0 && i0.y == 0 && i0.z == 0 && i0.w == 0 && i1.x == 0 && i1.y == 0 && i1.z == 0;  // Bodies.cs:326-349
+    const float sleep_energy = lengthSquared(vel.lin) + lengthSquared(vel.ang);                                           // :329, before the callback
+    if (integrate_velocity_for_kinematics || !is_kinematic) velocity_callback(sp, vel);                                   // :318-333 (never stored)
+    const CollidableIn c = collidables[i];
+    PredictedBounds r;
+    predictBounds(pos, ori, vel, sleep_energy, dt, c, r);
+    out[i] = r;
+}
+
 // ---- boundary exchange (one connected scene split across GPUs, BASELINE.json configs[4]) ----
 // A boundary body exists on several ranks (owned on one, ghost elsewhere). Between passes every holder publishes what its own constraints did to the
 // body's velocity since the last synchronisation point, the ranks sum those deltas (RCCL all-reduce, done by the caller), and every holder

@@ -29,6 +29,7 @@
 
 #include "../../include/bepuhip.h"
 #include "bepu_device_constraints.h"
+#include "bepu_device_bounds.h"
 
 #pragma clang fp contract(off)
 
@@ -802,6 +803,32 @@ int32_t bepuhip_get_bodies_range(bepuhip_ctx* c, void* aos_out, int32_t first, i
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(aos_out, c->d_bodies + (size_t)first * 8, (size_t)count * 128, hipMemcpyDeviceToHost));
+    return BEPUHIP_OK;
+}
+
+// ---- PredictBoundingBoxes on the device ----
+static_assert(sizeof(bepuhip_collidable) == sizeof(CollidableIn) && sizeof(bepuhip_collidable) == 64, "bepuhip_collidable layout");
+static_assert(sizeof(bepuhip_predicted_bounds) == sizeof(PredictedBounds) && sizeof(bepuhip_predicted_bounds) == 32, "bepuhip_predicted_bounds layout");
+int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* c, float dt, const bepuhip_integrator* in, const bepuhip_collidable* collidables, int32_t count, bepuhip_predicted_bounds* out) {
+    if (!c || !in || count < 0 || count > c->body_count || (count > 0 && (!collidables || !out))) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad predict_bounding_boxes argument");
+    if (!(dt > 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "dt must be positive");
+    for (int i = 0; i < count; ++i)
+        if (collidables[i].shape_type < -1 || collidables[i].shape_type > 4)
+            return fail(BEPUHIP_E_UNSUPPORTED, "shape type " + std::to_string(collidables[i].shape_type) + " (convex hulls, compounds and meshes stay on the host)");
+    if (count == 0) return BEPUHIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_floats = (size_t)count * 16, out_floats = (size_t)count * 8;
+    int32_t st = stage_reserve(c, in_floats + out_floats);
+    if (st != BEPUHIP_OK) return st;
+    CollidableIn* d_in = (CollidableIn*)c->d_stage;
+    PredictedBounds* d_out = (PredictedBounds*)(c->d_stage + in_floats);
+    HIP_TRY(hipMemcpyAsync(d_in, collidables, in_floats * 4, hipMemcpyHostToDevice, c->stream));
+    const StepParams sp = make_params(in, dt, dt, 1.0f / dt);  // Callbacks.PrepareForIntegration(dt): the full frame step (PoseIntegrator.cs:372-...)
+    hipLaunchKernelGGL(predict_bounds_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, count, (const CollidableIn*)d_in, d_out, dt,
+                       in->integrate_velocity_for_kinematics, sp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out, out_floats * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return BEPUHIP_OK;
 }
 

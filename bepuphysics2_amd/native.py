@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_set_boundary_bodies", "bepuhip_boundary_deltas", "bepuhip_boundary_apply", "bepuhip_solve_exchanged",
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
+    "bepuhip_predict_bounding_boxes",
 ]
 
 
@@ -102,6 +103,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_debug_status.argtypes = [vp, vp]
     lib.bepuhip_get_cluster_trace.argtypes = [vp, vp, C.c_int64, C.POINTER(i32)]
     lib.bepuhip_type_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.bepuhip_predict_bounding_boxes.argtypes = [vp, f32, C.POINTER(Integrator), vp, i32, vp]
     lib.bepuhip_update_bodies.argtypes = [vp, vp, i32, i32]
     lib.bepuhip_get_bodies_range.argtypes = [vp, vp, i32, i32]
     for name in ("bepuhip_update_prestep", "bepuhip_update_accumulated_impulses", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
@@ -137,6 +139,14 @@ def make_integrator(cb: PoseIntegratorCallbacks) -> Integrator:
     integ.allow_substeps_for_unconstrained = int(bool(cb.allow_substeps_for_unconstrained_bodies))
     integ.integrate_velocity_for_kinematics = int(bool(cb.integrate_velocity_for_kinematics))
     return integ
+
+
+# bepuhip_collidable / bepuhip_predicted_bounds (include/bepuhip.h) as numpy record types
+COLLIDABLE_DTYPE = np.dtype([("shape_type", "<i4"), ("shape", "<f4", (9,)), ("minimum_speculative_margin", "<f4"), ("maximum_speculative_margin", "<f4"),
+                             ("allow_expansion_beyond_speculative_margin", "<i4"), ("sleep_threshold", "<f4"), ("minimum_timesteps_under_threshold", "<i4"),
+                             ("activity", "<i4")])
+PREDICTED_BOUNDS_DTYPE = np.dtype([("min", "<f4", (3,)), ("speculative_margin", "<f4"), ("max", "<f4", (3,)), ("activity", "<i4")])
+SHAPE_SPHERE, SHAPE_CAPSULE, SHAPE_BOX, SHAPE_TRIANGLE, SHAPE_CYLINDER = 0, 1, 2, 3, 4  # Sphere.Id ... Cylinder.Id
 
 
 class HipSolver:
@@ -292,6 +302,15 @@ class HipSolver:
     def get_accumulated_impulses_range(self, batch_index: int, type_id: int, first_bundle: int, bundle_count: int) -> np.ndarray:
         out = np.empty(bundle_count * self._bundle_floats(type_id, False), dtype=np.float32)
         _check(self.lib, self.lib.bepuhip_get_accumulated_impulses_range(self.ctx, batch_index, type_id, first_bundle, bundle_count, _ptr(out)))
+        return out
+
+    # ---- PredictBoundingBoxes ----
+    def predict_bounding_boxes(self, dt: float, callbacks: PoseIntegratorCallbacks, collidables: np.ndarray) -> np.ndarray:
+        """``collidables``: COLLIDABLE_DTYPE records, one per body index. Returns PREDICTED_BOUNDS_DTYPE records (PoseIntegrator.cs:307-370)."""
+        c = np.ascontiguousarray(collidables, dtype=COLLIDABLE_DTYPE)
+        out = np.zeros(c.shape[0], dtype=PREDICTED_BOUNDS_DTYPE)
+        integ = make_integrator(callbacks)
+        _check(self.lib, self.lib.bepuhip_predict_bounding_boxes(self.ctx, dt, C.byref(integ), _ptr(c), c.shape[0], _ptr(out)))
         return out
 
     def constrained_flags(self, count: int) -> np.ndarray:

@@ -119,6 +119,30 @@ int32_t bepuhip_get_bodies_range(bepuhip_ctx* ctx, void* body_dynamics_aos_out, 
 int32_t bepuhip_get_prestep_range(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* prestep_bundles_out);
 int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* impulse_bundles_out);
 
+/* ---- PredictBoundingBoxes on the device ----
+ * Replaces the per-body work of PoseIntegrator.PredictBoundingBoxes (BepuPhysics/PoseIntegrator.cs:307-370, called from Simulation.PredictBoundingBoxes,
+ * BepuPhysics/Simulation.cs:252-262) for bodies whose shape is one of the five primitive convex types: sleep candidacy from the stored velocity
+ * (UpdateSleepCandidacy :287-305), the velocity callback for the full dt on a copy, TShapeWide.GetBounds, the angular / linear expansion and the speculative
+ * margin of BoundingBoxBatcher.ExecuteConvexBatch (BepuPhysics/Collidables/BoundingBoxBatcher.cs:142-223). It reads the bodies the last set_bodies /
+ * update_bodies / solve left on the device; the caller copies min/max into the broad phase leaves (BroadPhase.GetActiveBoundsPointers) and the margin and
+ * activity back into Collidable / BodyActivity. Convex hulls, compounds and meshes (shape_type > 4) -> UNSUPPORTED: those bodies stay on the host path. */
+typedef struct bepuhip_collidable {
+    int32_t shape_type;                 /* Sphere.Id 0, Capsule.Id 1, Box.Id 2, Triangle.Id 3, Cylinder.Id 4; -1: Collidable.Shape.Exists == false */
+    float shape[9];                     /* Sphere{Radius}; Capsule{Radius, HalfLength}; Box{HalfWidth, HalfHeight, HalfLength}; Triangle{A, B, C}; Cylinder{Radius, HalfLength} */
+    float minimum_speculative_margin;   /* Collidable.MinimumSpeculativeMargin, BepuPhysics/Collidables/Collidable.cs:131 */
+    float maximum_speculative_margin;   /* :139 */
+    int32_t allow_expansion_beyond_speculative_margin;  /* Continuity.AllowExpansionBeyondSpeculativeMargin, :59 */
+    float sleep_threshold;              /* BodyActivity.SleepThreshold */
+    int32_t minimum_timesteps_under_threshold;  /* BodyActivity.MinimumTimestepsUnderThreshold */
+    int32_t activity;                   /* bits 0-7 BodyActivity.TimestepsUnderThresholdCount, bit 8 SleepCandidate (before the call) */
+} bepuhip_collidable;
+typedef struct bepuhip_predicted_bounds {
+    float min[3]; float speculative_margin;   /* Collidable.SpeculativeMargin */
+    float max[3]; int32_t activity;           /* same packing as bepuhip_collidable.activity, after UpdateSleepCandidacy */
+} bepuhip_predicted_bounds;
+int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* ctx, float dt, const bepuhip_integrator* integrator, const bepuhip_collidable* collidables, int32_t count,
+                                       bepuhip_predicted_bounds* bounds_out);
+
 /* Diagnostics / measurement (no reference counterpart; SimulationProfiler equivalent, BepuPhysics/SimulationProfiler.cs:9-74). */
 /* mergedConstrainedBodyHandles as computed on device, one byte per body INDEX: bit0 = referenced by any constraint,
  * bit1 = referenced as dynamic. For parity tests of the a2 prepass (BepuPhysics/Solver_Solve.cs:1198-1207,1378-1381). */

@@ -1,0 +1,134 @@
+// TEST INFRASTRUCTURE — CPU restatement of PoseIntegrator.PredictBoundingBoxes for one body (parity unpinned, see bepu_oracle.cpp); derived from the
+// device text with tools/port_constraints_to_oracle.py, pinned by the behavioural tests in tests/test_bounds.py.
+#pragma once
+
+#include "bepu_math.h"
+
+namespace bo {
+
+// ======================================================================================
+// PoseIntegrator.PredictBoundingBoxes for one body (PoseIntegrator.cs:287-370) with BoundingBoxBatcher.ExecuteConvexBatch (BoundingBoxBatcher.cs:142-223)
+// for the five primitive convex shapes and BoundingBoxHelpers (BoundingBoxHelpers.cs:12-61). One lane = one body.
+// ======================================================================================
+enum ShapeType { kShapeNone = -1, kShapeSphere = 0, kShapeCapsule = 1, kShapeBox = 2, kShapeTriangle = 3, kShapeCylinder = 4 };  // Sphere.Id ... Cylinder.Id
+
+static inline V3 transformUnitY(Q r) {  // QuaternionWide.cs:389-405
+    float x2 = r.x + r.x, y2 = r.y + r.y, z2 = r.z + r.z;
+    float xx2 = r.x * x2, xy2 = r.x * y2, yz2 = r.y * z2, zz2 = r.z * z2, wx2 = r.w * x2, wz2 = r.w * z2;
+    return {xy2 - wz2, 1.0f - xx2 - zz2, yz2 + wx2};
+}
+
+// TShapeWide.GetBounds: local bounds around the body's position, the largest distance of any point from it, and how far a rotation can move a point outward.
+static inline bool shapeBounds(int type, const float* s, Q orientation, float& maximumRadius, float& maximumAngularExpansion, V3& mn, V3& mx) {
+    switch (type) {
+        case kShapeSphere: {  // Sphere.cs:149-160
+            maximumRadius = 0.0f; maximumAngularExpansion = 0.0f;
+            mx = {s[0], s[0], s[0]};
+            mn = {-s[0], -s[0], -s[0]};
+            return true;
+        }
+        case kShapeCapsule: {  // Capsule.cs:226-239  {Radius, HalfLength}
+            V3 segmentOffset = transformUnitY(orientation);
+            segmentOffset = scale(segmentOffset, s[1]);
+            segmentOffset = {vabs(segmentOffset.x), vabs(segmentOffset.y), vabs(segmentOffset.z)};
+            mx = {segmentOffset.x + s[0], segmentOffset.y + s[0], segmentOffset.z + s[0]};
+            mn = {-mx.x, -mx.y, -mx.z};
+            maximumRadius = s[1] + s[0];
+            maximumAngularExpansion = s[1];
+            return true;
+        }
+        case kShapeBox: {  // Box.cs:211-222  {HalfWidth, HalfHeight, HalfLength}
+            M3 basis = createFromQuaternion(orientation);
+            mx.x = vabs(s[0] * basis.X.x) + vabs(s[1] * basis.Y.x) + vabs(s[2] * basis.Z.x);
+            mx.y = vabs(s[0] * basis.X.y) + vabs(s[1] * basis.Y.y) + vabs(s[2] * basis.Z.y);
+            mx.z = vabs(s[0] * basis.X.z) + vabs(s[1] * basis.Y.z) + vabs(s[2] * basis.Z.z);
+            mn = {-mx.x, -mx.y, -mx.z};
+            maximumRadius = sqrtf(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+            maximumAngularExpansion = maximumRadius - vmin(s[2], vmin(s[1], s[2]));  // as written in the reference: HalfLength appears twice, HalfWidth not at all (:221)
+            return true;
+        }
+        case kShapeTriangle: {  // Triangle.cs:203-221  {A, B, C}
+            M3 basis = createFromQuaternion(orientation);
+            V3 a = {s[0], s[1], s[2]}, b = {s[3], s[4], s[5]}, c = {s[6], s[7], s[8]};
+            V3 worldA = transform(a, basis), worldB = transform(b, basis), worldC = transform(c, basis);
+            mn = {vmin(worldA.x, vmin(worldB.x, worldC.x)), vmin(worldA.y, vmin(worldB.y, worldC.y)), vmin(worldA.z, vmin(worldB.z, worldC.z))};
+            mx = {vmax(worldA.x, vmax(worldB.x, worldC.x)), vmax(worldA.y, vmax(worldB.y, worldC.y)), vmax(worldA.z, vmax(worldB.z, worldC.z))};
+            maximumRadius = sqrtf(vmax(lengthSquared(a), vmax(lengthSquared(b), lengthSquared(c))));
+            maximumAngularExpansion = maximumRadius;
+            return true;
+        }
+        case kShapeCylinder: {  // Cylinder.cs:222-235  {Radius, HalfLength}
+            V3 y = transformUnitY(orientation);
+            V3 squared = {1.0f - y.x * y.x, 1.0f - y.y * y.y, 1.0f - y.z * y.z};
+            mx.x = vabs(s[1] * y.x) + sqrtf(vmax(0.0f, squared.x)) * s[0];
+            mx.y = vabs(s[1] * y.y) + sqrtf(vmax(0.0f, squared.y)) * s[0];
+            mx.z = vabs(s[1] * y.z) + sqrtf(vmax(0.0f, squared.z)) * s[0];
+            mn = {-mx.x, -mx.y, -mx.z};
+            maximumRadius = sqrtf(s[1] * s[1] + s[0] * s[0]);
+            maximumAngularExpansion = maximumRadius - vmin(s[1], s[0]);
+            return true;
+        }
+        default: return false;
+    }
+}
+
+static inline float angularBoundsExpansion(float angularSpeed, float dt, float maximumRadius, float maximumAngularExpansion) {  // BoundingBoxHelpers.cs:12-47
+    float a = vmin(angularSpeed * dt, 3.14159274f / 3.0f);
+    float a2 = a * a;
+    float a4 = a2 * a2;
+    float a6 = a4 * a2;
+    float cosAngleMinusOne = a2 * (-1.0f / 2.0f) + a4 * (1.0f / 24.0f) - a6 * (1.0f / 720.0f);
+    return vmin(maximumAngularExpansion, sqrtf(-2.0f * maximumRadius * maximumRadius * cosAngleMinusOne));
+}
+
+struct CollidableIn {  // mirrors bepuhip_collidable (include/bepuhip.h), 16 words
+    int shape_type; float shape[9];
+    float minimum_speculative_margin, maximum_speculative_margin; int allow_expansion_beyond_speculative_margin;
+    float sleep_threshold; int minimum_timesteps_under_threshold; int activity;  // activity: bits 0-7 TimestepsUnderThresholdCount, bit 8 SleepCandidate
+};
+struct PredictedBounds { float min[3]; float speculative_margin; float max[3]; int activity; };
+
+// UpdateSleepCandidacy, PoseIntegrator.cs:287-305 (the count is a byte in the reference and stops at 255).
+static inline int updateSleepCandidacy(float velocityHeuristic, float sleepThreshold, int minimumTimestepsUnderThreshold, int activity) {
+    int count = activity & 0xFF;
+    bool candidate = (activity & 0x100) != 0;
+    if (velocityHeuristic > sleepThreshold) {
+        count = 0;
+        candidate = false;
+    } else if (count < 255) {
+        ++count;
+        if (count >= minimumTimestepsUnderThreshold) candidate = true;
+    }
+    return count | (candidate ? 0x100 : 0);
+}
+
+// `velocity` is the body's velocity after the integration callback ran on it for the full dt (only used for the prediction, never stored: :331-333);
+// `sleepEnergy` was taken from the stored velocity (:329).
+static inline void predictBounds(V3 position, Q orientation, const BodyVel& velocity, float sleepEnergy, float dt, const CollidableIn& c, PredictedBounds& out) {
+    out.activity = updateSleepCandidacy(sleepEnergy, c.sleep_threshold, c.minimum_timesteps_under_threshold, c.activity);
+    float maximumRadius, maximumAngularExpansion; V3 mn, mx;
+    if (!shapeBounds(c.shape_type, c.shape, orientation, maximumRadius, maximumAngularExpansion, mn, mx)) {  // Shape.Exists == false: nothing to bound (BoundingBoxBatcher.cs:326)
+        out.min[0] = out.min[1] = out.min[2] = 0.0f; out.max[0] = out.max[1] = out.max[2] = 0.0f; out.speculative_margin = 0.0f;
+        return;
+    }
+    // BoundingBoxBatcher.cs:174-191
+    float angularExpansion = angularBoundsExpansion(length(velocity.ang), dt, maximumRadius, maximumAngularExpansion);
+    float speculativeMargin = length(velocity.lin) * dt + angularExpansion;
+    speculativeMargin = vmax(c.minimum_speculative_margin, vmin(c.maximum_speculative_margin, speculativeMargin));
+    float maximumBoundsExpansion = sel(c.allow_expansion_beyond_speculative_margin != 0, 3.402823466e+38f, speculativeMargin);
+    // BoundingBoxHelpers.GetBoundsExpansion :51-60
+    V3 linearDisplacement = scale(velocity.lin, dt);
+    V3 minExpansion = {vmin(0.0f, linearDisplacement.x), vmin(0.0f, linearDisplacement.y), vmin(0.0f, linearDisplacement.z)};
+    V3 maxExpansion = {vmax(0.0f, linearDisplacement.x), vmax(0.0f, linearDisplacement.y), vmax(0.0f, linearDisplacement.z)};
+    minExpansion = {minExpansion.x - angularExpansion, minExpansion.y - angularExpansion, minExpansion.z - angularExpansion};
+    maxExpansion = {maxExpansion.x + angularExpansion, maxExpansion.y + angularExpansion, maxExpansion.z + angularExpansion};
+    minExpansion = {vmax(-maximumBoundsExpansion, minExpansion.x), vmax(-maximumBoundsExpansion, minExpansion.y), vmax(-maximumBoundsExpansion, minExpansion.z)};
+    maxExpansion = {vmin(maximumBoundsExpansion, maxExpansion.x), vmin(maximumBoundsExpansion, maxExpansion.y), vmin(maximumBoundsExpansion, maxExpansion.z)};
+    V3 lo = add(position, add(mn, minExpansion));
+    V3 hi = add(position, add(mx, maxExpansion));
+    out.min[0] = lo.x; out.min[1] = lo.y; out.min[2] = lo.z;
+    out.max[0] = hi.x; out.max[1] = hi.y; out.max[2] = hi.z;
+    out.speculative_margin = speculativeMargin;
+}
+
+}  // namespace bo

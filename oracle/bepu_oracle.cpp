@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "bepu_constraints.h"
+#include "bepu_bounds.h"
 
 using namespace bo;
 using C1O = Contact<1, false>; using C2O = Contact<2, false>; using C3O = Contact<3, false>; using C4O = Contact<4, false>;
@@ -770,6 +771,24 @@ int oracle_constraint_iterate(int type_id, float* bodyA, float* bodyB, float* pr
 }
 
 // Scalar math probes for unit tests (MathHelper.Sin/Cos/Acos restatements).
+// PoseIntegrator.PredictBoundingBoxes (PoseIntegrator.cs:307-370) over `count` bodies: sleep candidacy from the stored velocity, the velocity callback for
+// the full dt on a copy (integration mask: non-kinematic bodies unless IntegrateVelocityForKinematics), bounds of the primitive convex shapes.
+int oracle_predict_bounding_boxes(const float* bodies, int count, const OracleParams* params, const CollidableIn* collidables, PredictedBounds* out) {
+    if (!bodies || !params || !collidables || !out || count < 0 || !(params->dt > 0)) return -1;
+    Callbacks cb;
+    cb.prepare(*params, params->dt);   // PredictBoundingBoxes(dt, ...) -> Callbacks.PrepareForIntegration(dt)
+    for (int i = 0; i < count; ++i) {
+        BodyState st;
+        gatherState(bodies, i, false, st);  // GatherState<AccessAll>(laneIndices, false, ...): local inertia
+        const bool isKinematic = st.inertia.t.xx == 0 && st.inertia.t.yx == 0 && st.inertia.t.yy == 0 && st.inertia.t.zx == 0 && st.inertia.t.zy == 0 &&
+                                 st.inertia.t.zz == 0 && st.inertia.invMass == 0;
+        const float sleepEnergy = lengthSquared(st.vel.lin) + lengthSquared(st.vel.ang);
+        if (params->integrate_velocity_for_kinematics || !isKinematic) cb.integrateVelocity(st.vel);
+        predictBounds(st.pos, st.ori, st.vel, sleepEnergy, params->dt, collidables[i], out[i]);
+    }
+    return 0;
+}
+
 void oracle_math_probe(const float* x, int n, float* out_sin, float* out_cos, float* out_acos) {
     for (int i = 0; i < n; ++i) { out_sin[i] = bsin(x[i]); out_cos[i] = bcos(x[i]); out_acos[i] = bacos(x[i]); }
 }

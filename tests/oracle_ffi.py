@@ -46,6 +46,7 @@ def load(fast: bool = False) -> C.CDLL:
     lib.oracle_constraint_iterate.restype = C.c_int
     lib.oracle_math_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.oracle_type_info.argtypes = [C.c_int] + [C.POINTER(C.c_int)] * 4
+    lib.oracle_predict_bounding_boxes.argtypes = [C.c_void_p, C.c_int, C.POINTER(OracleParams), C.c_void_p, C.c_void_p]
     lib.oracle_type_info.restype = C.c_int
     _libs[name] = lib
     return lib
@@ -120,6 +121,26 @@ def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool 
         raise failure[0]
     if rc != 0:
         raise RuntimeError(f"oracle_solve failed: {rc}")
+
+
+def predict_bounding_boxes(bodies, dt, callbacks, collidables):
+    """PoseIntegrator.PredictBoundingBoxes restated (oracle/bepu_bounds.h): returns PREDICTED_BOUNDS_DTYPE records, bodies untouched."""
+    from bepuphysics2_amd.native import COLLIDABLE_DTYPE, PREDICTED_BOUNDS_DTYPE
+    lib = load()
+    b = np.ascontiguousarray(bodies, dtype=np.float32)
+    c = np.ascontiguousarray(collidables, dtype=COLLIDABLE_DTYPE)
+    out = np.zeros(c.shape[0], dtype=PREDICTED_BOUNDS_DTYPE)
+    p = OracleParams()
+    p.dt = float(dt)
+    p.substep_count = 1
+    p.gravity[0], p.gravity[1], p.gravity[2] = [float(x) for x in callbacks.gravity]
+    p.linear_damping = float(callbacks.linear_damping)
+    p.angular_damping = float(callbacks.angular_damping)
+    p.integrate_velocity_for_kinematics = int(bool(callbacks.integrate_velocity_for_kinematics))
+    rc = lib.oracle_predict_bounding_boxes(_p(b), c.shape[0], C.byref(p), _p(c), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"oracle_predict_bounding_boxes failed: {rc}")
+    return out
 
 
 def prepare_flags(scene):
