@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
 
 
 // PoseIntegrator.PredictBoundingBoxes (PoseIntegrator.cs:307-370), one lane per body: the stage before collision detection, on the bodies the solver left in HBM.
-__global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __restrict__ bodies, int count, const CollidableIn* __restrict__ collidables,
+__global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __restrict__ bodies, int count, CollidableIn* collidables, int keep_activity,
                                                               PredictedBounds* __restrict__ out, float dt, int integrate_velocity_for_kinematics, StepParams sp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __res
     PredictedBounds r;
     predictBounds(pos, ori, vel, sleep_energy, dt, c, r);
     out[i] = r;
+    if (keep_activity) collidables[i].activity = r.activity;  // device-resident records: the sleep counters carry over to the next frame
 }
 
 // ---- boundary exchange (one connected scene split across GPUs, BASELINE.json configs[4]) ----

@@ -133,6 +133,8 @@ struct bepuhip_ctx {
     int* d_cluster_bodies = nullptr;
     int* d_clustered_dynamic = nullptr;
     int clustered_dynamic_count = 0;
+    CollidableIn* d_collidables = nullptr;  // device-resident collidable records (bepuhip_set_collidables)
+    int collidable_count = 0;
     unsigned* d_staged = nullptr;   // island schedule: clusters that have staged their bodies in the current launch (see cluster_kernel's kinematic block)
     int* d_kinlist = nullptr;       // constrained kinematic body indices derived from the body references
     int kinlist_count = 0;

@@ -96,6 +96,7 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_kin) hipFree(c->d_kin);
     if (c->d_status) hipHostFree(c->d_status);
     if (c->d_staged) hipFree(c->d_staged);
+    if (c->d_collidables) hipFree(c->d_collidables);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->d_boundary) hipFree(c->d_boundary);
     if (c->d_boundary_snapshot) hipFree(c->d_boundary_snapshot);
@@ -809,22 +810,42 @@ int32_t bepuhip_get_bodies_range(bepuhip_ctx* c, void* aos_out, int32_t first, i
 // ---- PredictBoundingBoxes on the device ----
 static_assert(sizeof(bepuhip_collidable) == sizeof(CollidableIn) && sizeof(bepuhip_collidable) == 64, "bepuhip_collidable layout");
 static_assert(sizeof(bepuhip_predicted_bounds) == sizeof(PredictedBounds) && sizeof(bepuhip_predicted_bounds) == 32, "bepuhip_predicted_bounds layout");
-int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* c, float dt, const bepuhip_integrator* in, const bepuhip_collidable* collidables, int32_t count, bepuhip_predicted_bounds* out) {
-    if (!c || !in || count < 0 || count > c->body_count || (count > 0 && (!collidables || !out))) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad predict_bounding_boxes argument");
-    if (!(dt > 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "dt must be positive");
+static int32_t check_collidables(const bepuhip_collidable* collidables, int32_t count) {
     for (int i = 0; i < count; ++i)
         if (collidables[i].shape_type < -1 || collidables[i].shape_type > 4)
             return fail(BEPUHIP_E_UNSUPPORTED, "shape type " + std::to_string(collidables[i].shape_type) + " (convex hulls, compounds and meshes stay on the host)");
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_set_collidables(bepuhip_ctx* c, const bepuhip_collidable* collidables, int32_t count) {
+    if (!c || count < 0 || (count > 0 && !collidables)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad set_collidables argument");
+    int32_t st = check_collidables(collidables, count);
+    if (st != BEPUHIP_OK) return st;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_collidables) { hipFree(c->d_collidables); c->d_collidables = nullptr; }
+    c->collidable_count = count;
+    if (count > 0) {
+        HIP_TRY(hipMalloc((void**)&c->d_collidables, (size_t)count * sizeof(CollidableIn)));
+        HIP_TRY(hipMemcpy(c->d_collidables, collidables, (size_t)count * sizeof(CollidableIn), hipMemcpyHostToDevice));
+    }
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* c, float dt, const bepuhip_integrator* in, const bepuhip_collidable* collidables, int32_t count, bepuhip_predicted_bounds* out) {
+    if (!c || !in || count < 0 || count > c->body_count || (count > 0 && !out)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad predict_bounding_boxes argument");
+    if (!(dt > 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "dt must be positive");
+    const bool resident = collidables == nullptr;
+    if (resident && count > c->collidable_count) return fail(BEPUHIP_E_STATE, "no collidables given and fewer resident ones than bodies (bepuhip_set_collidables)");
+    if (!resident) { int32_t st = check_collidables(collidables, count); if (st != BEPUHIP_OK) return st; }
     if (count == 0) return BEPUHIP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t in_floats = (size_t)count * 16, out_floats = (size_t)count * 8;
+    const size_t in_floats = resident ? 0 : (size_t)count * 16, out_floats = (size_t)count * 8;
     int32_t st = stage_reserve(c, in_floats + out_floats);
     if (st != BEPUHIP_OK) return st;
-    CollidableIn* d_in = (CollidableIn*)c->d_stage;
+    CollidableIn* d_in = resident ? c->d_collidables : (CollidableIn*)c->d_stage;
     PredictedBounds* d_out = (PredictedBounds*)(c->d_stage + in_floats);
-    HIP_TRY(hipMemcpyAsync(d_in, collidables, in_floats * 4, hipMemcpyHostToDevice, c->stream));
-    const StepParams sp = make_params(in, dt, dt, 1.0f / dt);  // Callbacks.PrepareForIntegration(dt): the full frame step (PoseIntegrator.cs:372-...)
-    hipLaunchKernelGGL(predict_bounds_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, count, (const CollidableIn*)d_in, d_out, dt,
+    if (!resident) HIP_TRY(hipMemcpyAsync(d_in, collidables, in_floats * 4, hipMemcpyHostToDevice, c->stream));
+    const StepParams sp = make_params(in, dt, dt, 1.0f / dt);  // Callbacks.PrepareForIntegration(dt): the full frame step
+    hipLaunchKernelGGL(predict_bounds_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, count, d_in, resident ? 1 : 0, d_out, dt,
                        in->integrate_velocity_for_kinematics, sp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out, out_floats * 4, hipMemcpyDeviceToHost, c->stream));

@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_set_boundary_bodies", "bepuhip_boundary_deltas", "bepuhip_boundary_apply", "bepuhip_solve_exchanged",
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
-    "bepuhip_predict_bounding_boxes",
+    "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables",
 ]
 
 
@@ -104,6 +104,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_get_cluster_trace.argtypes = [vp, vp, C.c_int64, C.POINTER(i32)]
     lib.bepuhip_type_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.bepuhip_predict_bounding_boxes.argtypes = [vp, f32, C.POINTER(Integrator), vp, i32, vp]
+    lib.bepuhip_set_collidables.argtypes = [vp, vp, i32]
     lib.bepuhip_update_bodies.argtypes = [vp, vp, i32, i32]
     lib.bepuhip_get_bodies_range.argtypes = [vp, vp, i32, i32]
     for name in ("bepuhip_update_prestep", "bepuhip_update_accumulated_impulses", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
@@ -305,11 +306,22 @@ class HipSolver:
         return out
 
     # ---- PredictBoundingBoxes ----
-    def predict_bounding_boxes(self, dt: float, callbacks: PoseIntegratorCallbacks, collidables: np.ndarray) -> np.ndarray:
-        """``collidables``: COLLIDABLE_DTYPE records, one per body index. Returns PREDICTED_BOUNDS_DTYPE records (PoseIntegrator.cs:307-370)."""
+    def set_collidables(self, collidables: np.ndarray):
+        """Keep the collidable records on the device; later ``predict_bounding_boxes(dt, cb)`` calls use (and update the sleep counters of) these."""
+        c = np.ascontiguousarray(collidables, dtype=COLLIDABLE_DTYPE)
+        _check(self.lib, self.lib.bepuhip_set_collidables(self.ctx, _ptr(c), c.shape[0]))
+        self._resident_collidables = c.shape[0]
+
+    def predict_bounding_boxes(self, dt: float, callbacks: PoseIntegratorCallbacks, collidables: Optional[np.ndarray] = None) -> np.ndarray:
+        """``collidables``: COLLIDABLE_DTYPE records, one per body index (None: the resident ones). Returns PREDICTED_BOUNDS_DTYPE records (PoseIntegrator.cs:307-370)."""
+        integ = make_integrator(callbacks)
+        if collidables is None:
+            n = getattr(self, "_resident_collidables", 0)
+            out = np.zeros(n, dtype=PREDICTED_BOUNDS_DTYPE)
+            _check(self.lib, self.lib.bepuhip_predict_bounding_boxes(self.ctx, dt, C.byref(integ), None, n, _ptr(out)))
+            return out
         c = np.ascontiguousarray(collidables, dtype=COLLIDABLE_DTYPE)
         out = np.zeros(c.shape[0], dtype=PREDICTED_BOUNDS_DTYPE)
-        integ = make_integrator(callbacks)
         _check(self.lib, self.lib.bepuhip_predict_bounding_boxes(self.ctx, dt, C.byref(integ), _ptr(c), c.shape[0], _ptr(out)))
         return out
 

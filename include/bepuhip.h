@@ -140,6 +140,9 @@ typedef struct bepuhip_predicted_bounds {
     float min[3]; float speculative_margin;   /* Collidable.SpeculativeMargin */
     float max[3]; int32_t activity;           /* same packing as bepuhip_collidable.activity, after UpdateSleepCandidacy */
 } bepuhip_predicted_bounds;
+/* `collidables` == NULL uses the records uploaded with bepuhip_set_collidables (shapes and margins rarely change): nothing but the 32-byte result per body
+ * crosses PCIe, and the sleep counters are carried on the device from call to call. */
+int32_t bepuhip_set_collidables(bepuhip_ctx* ctx, const bepuhip_collidable* collidables, int32_t count);
 int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* ctx, float dt, const bepuhip_integrator* integrator, const bepuhip_collidable* collidables, int32_t count,
                                        bepuhip_predicted_bounds* bounds_out);
 

@@ -147,6 +147,15 @@ def test_hip_predict_bounding_boxes_matches_the_oracle(hip_solver_factory):
         got = solver.predict_bounding_boxes(1 / 60, cb, coll)
         assert np.array_equal(want.view(np.int32), got.view(np.int32))
     assert np.array_equal(solver.get_bodies(n).view(np.int32)[:, :15], bodies.view(np.int32)[:, :15])  # bodies untouched
+    # device-resident records: shapes stay on the device, the sleep counters carry over from call to call exactly as the oracle's do when fed its own output
+    cb = PoseIntegratorCallbacks()
+    solver.set_collidables(coll)
+    chained = coll.copy()
+    for _ in range(3):
+        want = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, chained)
+        got = solver.predict_bounding_boxes(1 / 60, cb)
+        assert np.array_equal(want.view(np.int32), got.view(np.int32))
+        chained["activity"] = want["activity"]
     from bepuphysics2_amd import native
     bad = coll[:4].copy()
     bad["shape_type"][2] = 5  # ConvexHull.Id: stays on the host
