@@ -134,6 +134,7 @@ __device__ __forceinline__ void velocity_callback(const StepParams& sp, BodyVel&
 
 // Cluster path only: advance the constrained kinematic bodies in global memory through the in-solver substeps
 // (PoseIntegrator.cs:451-535 applied substep_count times: substep 0 velocity only, later substeps pose then velocity).
+// (the island schedule's kinematic workgroup: all substeps of a constrained kinematic body at once, PoseIntegrator.cs:451-535)
 __device__ __forceinline__ void kinematic_substeps_body(float4* bodies, int index, int substeps, int integrate_velocity_for_kinematics, const StepParams& sp) {
     float4* base = bodies + (size_t)(index & kRefMask) * 8;
     float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
@@ -153,11 +154,6 @@ __device__ __forceinline__ void kinematic_substeps_body(float4* bodies, int inde
         base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
         base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
     }
-}
-__global__ void kinematic_substeps_kernel(float4* bodies, const int* __restrict__ indices, int count, int substeps, int integrate_velocity_for_kinematics, StepParams sp) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    kinematic_substeps_body(bodies, indices[i], substeps, integrate_velocity_for_kinematics, sp);
 }
 
 // Per-substep integration of every constrained body — the work the reference fuses into the first-touching constraint's

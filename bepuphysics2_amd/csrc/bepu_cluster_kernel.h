@@ -502,7 +502,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     // Trailing pose integration of constrained bodies (PoseIntegrator.cs:684-691) and write-back.
     for (int j = tid; j < cd.slot_count; j += blockDim.x) {
         const int g = slots[j];
-        if ((unsigned)g >= kDynamicLimit) continue;  // unused slot, or kinematic (advanced in global memory by kinematic_substeps_kernel + the final pass)
+        if ((unsigned)g >= kDynamicLimit) continue;  // unused slot, or kinematic (advanced in global memory by this launch's kinematic workgroup)
         const float4* r = lds + j;
         float4 q4 = r[0], p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
         Q ori = {q4.x, q4.y, q4.z, q4.w};

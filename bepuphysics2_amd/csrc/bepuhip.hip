@@ -438,7 +438,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             const int req = env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
             const int threads = std::max(64, std::min(1024, req / 64 * 64));
             // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
-            // constrained kinematic bodies (kinematic_substeps_kernel + final_integrate_kernel of the launch-per-batch schedule, folded in).
+            // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).
             TailParams tp;
             tp.flags = c->d_flags; tp.kinlist = c->d_kinlist; tp.staged = c->d_staged;
             tp.body_count = c->body_count; tp.kin_count = c->kinlist_count; tp.cluster_count = c->cluster_count;
