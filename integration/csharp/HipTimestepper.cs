@@ -34,6 +34,9 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_get_bodies(IntPtr ctx, void* bodyDynamics, int count);
     [DllImport(Lib)] public static extern int bepuhip_get_accumulated_impulses(IntPtr ctx, int batchIndex, int typeId, void* accumulatedImpulses);
     [DllImport(Lib)] public static extern int bepuhip_get_prestep(IntPtr ctx, int batchIndex, int typeId, void* prestepData);
+    // PredictBoundingBoxes + sleep candidacy for bodies with primitive convex shapes (include/bepuhip.h: bepuhip_collidable = 64 bytes, bepuhip_predicted_bounds = 32 bytes)
+    [DllImport(Lib)] public static extern int bepuhip_set_collidables(IntPtr ctx, void* collidables, int count);
+    [DllImport(Lib)] public static extern int bepuhip_predict_bounding_boxes(IntPtr ctx, float dt, BepuHipIntegrator* integrator, void* collidablesOrNull, int count, void* boundsOut);
     // ranged in-place updates / read-backs for frames whose topology did not change (INTEGRATION.md)
     [DllImport(Lib)] public static extern int bepuhip_update_bodies(IntPtr ctx, void* bodyDynamics, int first, int count);
     [DllImport(Lib)] public static extern int bepuhip_update_prestep(IntPtr ctx, int batchIndex, int typeId, int firstBundle, int bundleCount, void* prestepBundles);
