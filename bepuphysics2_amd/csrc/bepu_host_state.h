@@ -112,6 +112,7 @@ struct bepuhip_ctx {
     DevTypeBatch* d_inc_tbs = nullptr;   // incremental-update grid (contacts of all batches)
     int inc_tb_count = 0, inc_blocks = 0;
     int64_t total_constraints = 0;
+    int referenced_bodies = 0;           // 1 + the largest body index any constraint references
     // cluster path
     bool clusters_enabled = false;
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
@@ -173,5 +174,7 @@ static void free_constraints(bepuhip_ctx* c) {
     c->d_tbs = c->d_inc_tbs = nullptr;
     for (auto& tb : c->tbs) if (tb.d_device_index) hipFree(tb.d_device_index);
     c->tbs.clear();
+    c->batch_count = 0; c->batch_begin.clear(); c->batch_blocks.clear();
+    c->inc_blocks = 0; c->inc_tb_count = 0; c->total_constraints = 0; c->slab_words = 0; c->referenced_bodies = 0;
     c->built = false;
 }

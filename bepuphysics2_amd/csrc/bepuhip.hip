@@ -61,6 +61,19 @@ int32_t bepuhip_type_info(int32_t type_id, int32_t* bodies, int32_t* prestep_flo
     return BEPUHIP_OK;
 }
 
+static int32_t create_device_objects(bepuhip_ctx* c) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev_start));
+    HIP_TRY(hipEventCreate(&c->ev_stop));
+    HIP_TRY(hipHostMalloc((void**)&c->d_status, 256, hipHostMallocMapped | hipHostMallocCoherent));  // host-visible while a kernel runs
+    HIP_TRY(hipMalloc((void**)&c->d_staged, 4));
+    HIP_TRY(hipMemset(c->d_staged, 0, 4));
+    memset(c->d_status, 0, 256);
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_destroy(bepuhip_ctx* c);
+
 int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx) {
     if (!config || !out_ctx) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
     if (config->bundle_width != 4 && config->bundle_width != 8 && config->bundle_width != 16)
@@ -74,13 +87,8 @@ int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx) {
     c->device = config->device_ordinal;
     c->W = config->bundle_width;
     c->flags = config->flags;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&c->ev_start));
-    HIP_TRY(hipEventCreate(&c->ev_stop));
-    HIP_TRY(hipHostMalloc((void**)&c->d_status, 256, hipHostMallocMapped | hipHostMallocCoherent));  // host-visible while a kernel runs
-    HIP_TRY(hipMalloc((void**)&c->d_staged, 4));
-    HIP_TRY(hipMemset(c->d_staged, 0, 4));
-    memset(c->d_status, 0, 256);
+    const int32_t st = create_device_objects(c);
+    if (st != BEPUHIP_OK) { bepuhip_destroy(c); return st; }  // the message of the failing call stays in bepuhip_last_error
     *out_ctx = c;
     return BEPUHIP_OK;
 }
@@ -88,7 +96,7 @@ int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx) {
 int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (!c) return BEPUHIP_OK;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
     free_constraints(c);
     if (c->d_bodies) hipFree(c->d_bodies);
     if (c->d_bodies0) hipFree(c->d_bodies0);
@@ -101,9 +109,9 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_boundary) hipFree(c->d_boundary);
     if (c->d_boundary_snapshot) hipFree(c->d_boundary_snapshot);
     if (c->d_boundary_buf) hipFree(c->d_boundary_buf);
-    hipEventDestroy(c->ev_start);
-    hipEventDestroy(c->ev_stop);
-    hipStreamDestroy(c->stream);
+    if (c->ev_start) hipEventDestroy(c->ev_start);
+    if (c->ev_stop) hipEventDestroy(c->ev_stop);
+    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return BEPUHIP_OK;
 }
@@ -111,18 +119,21 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
 static int32_t rebuild_flags(bepuhip_ctx* c) {
     if (!c->d_flags || c->body_count == 0) return BEPUHIP_OK;
     HIP_TRY(hipMemsetAsync(c->d_flags, 0, (size_t)c->body_count * 4, c->stream));
-    if (c->built) {
+    // Constraints that reference bodies not uploaded yet are not marked (the writes would leave d_flags); validate_solve refuses to run such a
+    // state and the set_bodies that repairs it changes the count, which brings us back here.
+    const bool marked = c->built && c->referenced_bodies <= c->body_count;
+    if (marked) {
         for (auto& tb : c->tbs) {
             if (tb.count == 0) continue;
             int blocks = (tb.count + 255) / 256;
             hipLaunchKernelGGL(mark_constrained_kernel, dim3(blocks), dim3(256), 0, c->stream, (const int*)(c->d_slab + tb.refs_off), tb.count, tb.stride, tb.info.bodies, c->d_flags);
         }
     }
-    if (c->built && c->clusters_enabled && c->clustered_dynamic_count > 0) {
+    if (marked && c->clusters_enabled && c->clustered_dynamic_count > 0) {
         hipLaunchKernelGGL(mark_indices_kernel, dim3((c->clustered_dynamic_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_clustered_dynamic,
                            c->clustered_dynamic_count, c->d_flags, (unsigned)kFlagClustered);
     }
-    if (c->built && c->clusters_enabled && c->kinlist_count > 0) {
+    if (marked && c->clusters_enabled && c->kinlist_count > 0) {
         hipLaunchKernelGGL(mark_indices_kernel, dim3((c->kinlist_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_kinlist, c->kinlist_count, c->d_flags,
                            (unsigned)(kFlagClusterKinematic | kFlagConstrained));
     }
@@ -204,10 +215,18 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
     return BEPUHIP_OK;
 }
 
+static int32_t build_constraints(bepuhip_ctx* c);
+
 int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
     if (!c || !c->building) return fail(BEPUHIP_E_STATE, "end_constraints without begin");
     HIP_TRY(hipSetDevice(c->device));
     c->building = false;
+    const int32_t st = build_constraints(c);
+    if (st != BEPUHIP_OK) free_constraints(c);  // never a half-built set: the context is back to "no constraints", the error text is kept
+    return st;
+}
+
+static int32_t build_constraints(bepuhip_ctx* c) {
     size_t words = 0;
     c->total_constraints = 0;
     for (auto& tb : c->tbs) c->total_constraints += tb.count;
@@ -218,6 +237,7 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
         for (auto& tb : c->tbs)
             for (int32_t r : tb.refs_soa)
                 if (r >= 0) universe = std::max(universe, (r & kRefMask) + 1);
+        c->referenced_bodies = universe;  // checked against the body count at solve time (validate_solve)
         std::vector<int32_t> first_batch(universe, INT32_MAX);
         for (auto& tb : c->tbs)
             for (int k = 0; k < tb.info.bodies; ++k)
@@ -360,12 +380,13 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
 
 int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* c, const int32_t* indices, int32_t count) {
     if (!c || count < 0 || (count > 0 && !indices)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad kinematic list");
+    for (int i = 0; i < count; ++i)
+        if (indices[i] < 0 || indices[i] >= c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "kinematic body index out of range (call set_bodies first)");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->d_kin) { hipFree(c->d_kin); c->d_kin = nullptr; }
     c->kin_count = count;
     c->kin_indices.assign(indices, indices + count);
-    for (int i = 0; i < count; ++i)
-        if (indices[i] < 0 || indices[i] >= c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "kinematic body index out of range (call set_bodies first)");
     if (count > 0) {
         HIP_TRY(hipMalloc((void**)&c->d_kin, (size_t)count * 4));
         HIP_TRY(hipMemcpy(c->d_kin, indices, (size_t)count * 4, hipMemcpyHostToDevice));
@@ -497,6 +518,9 @@ static int32_t validate_solve(bepuhip_ctx* c, float dt, int32_t substeps, const 
         if (iterations[s] < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Velocity iteration count must be positive.");
     if (in->angular_integration_mode < 0 || in->angular_integration_mode > 2) return fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown AngularIntegrationMode");
     if (c->building) return fail(BEPUHIP_E_STATE, "solve between begin_constraints and end_constraints");
+    if (c->built && c->referenced_bodies > c->body_count)
+        return fail(BEPUHIP_E_STATE, "a constraint references body " + std::to_string(c->referenced_bodies - 1) + " but only " + std::to_string(c->body_count) +
+                                         " bodies are uploaded (set_bodies)");
     return BEPUHIP_OK;
 }
 
@@ -735,7 +759,7 @@ static int32_t bundle_range(bepuhip_ctx* c, int batch, int type_id, int first_bu
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb) return fail(BEPUHIP_E_INVALID_ARGUMENT, "no such type batch");
     const int bundles = (tb->count + c->W - 1) / c->W;
-    if (first_bundle + bundle_count > bundles) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bundle range exceeds the type batch");
+    if ((int64_t)first_bundle + bundle_count > bundles) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bundle range exceeds the type batch");
     *tb_out = tb;
     *first = first_bundle * c->W;
     *n = std::min(bundle_count * c->W, tb->count - *first);  // trailing lanes of the last bundle are empty (TypeProcessor.cs:287-298)
@@ -790,7 +814,7 @@ int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* c, int32_t batch, in
     return read_rows(c, batch, type_id, first_bundle, bundle_count, impulse_bundles_out, false);
 }
 int32_t bepuhip_update_bodies(bepuhip_ctx* c, const void* aos, int32_t first, int32_t count) {
-    if (!c || first < 0 || count < 0 || (!aos && count > 0) || first + count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad body range");
+    if (!c || first < 0 || count < 0 || (!aos && count > 0) || (int64_t)first + count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad body range");
     if (count == 0) return BEPUHIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->d_bodies + (size_t)first * 8, aos, (size_t)count * 128, hipMemcpyHostToDevice, c->stream));
@@ -799,7 +823,7 @@ int32_t bepuhip_update_bodies(bepuhip_ctx* c, const void* aos, int32_t first, in
     return BEPUHIP_OK;
 }
 int32_t bepuhip_get_bodies_range(bepuhip_ctx* c, void* aos_out, int32_t first, int32_t count) {
-    if (!c || first < 0 || count < 0 || (!aos_out && count > 0) || first + count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad body range");
+    if (!c || first < 0 || count < 0 || (!aos_out && count > 0) || (int64_t)first + count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad body range");
     if (count == 0) return BEPUHIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -116,3 +116,27 @@ def test_variable_time_step_keeps_the_graph_cache_bounded(hip_solver_factory):
     got = scene.copy()
     solver.download(got)
     _bit_exact(ref, got)
+
+
+@pytest.mark.parametrize("use_clusters", [True, False])
+def test_inconsistent_uploads_are_refused_not_run(hip_solver_factory, use_clusters):
+    """Constraints that reference bodies the device does not hold, and a kinematic list with an index out of range, are refused with the
+    context left usable (no out-of-bounds gather on the device)."""
+    from bepuphysics2_amd import native
+    scene = small_scenes.random_graph_scene(5, 40, 90, [7, 22, 30])
+    sd, cb = SolveDescription(2, 2), PoseIntegratorCallbacks()
+    solver = hip_solver_factory(use_clusters=use_clusters)
+    solver.upload(scene.copy(), sd.fallback_batch_threshold)
+    solver.set_bodies(scene.bodies[: scene.body_count // 2])       # fewer bodies than the constraints reference
+    with pytest.raises(native.BepuHipError, match="references body"):
+        solver.solve(1 / 60, sd, cb)
+    bad = np.array([0, scene.body_count + 7], dtype=np.int32)
+    with pytest.raises(ValueError, match="out of range"):
+        native._check(solver.lib, solver.lib.bepuhip_set_constrained_kinematics(solver.ctx, native._ptr(bad), bad.size))
+    solver.upload(scene.copy(), sd.fallback_batch_threshold)        # the same context recovers
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2)
+    for _ in range(2):
+        solver.solve(1 / 60, sd, cb)
+    got = scene.copy()
+    solver.download(got)
+    _bit_exact(ref, got)
