@@ -156,9 +156,44 @@ __device__ __forceinline__ void kinematic_substeps_body(float4* bodies, int inde
     }
 }
 
+// The per-body state the integration functions work on, in registers (the kernels differ only in how they move it to and from memory).
+struct BodyRegs { Q ori; V3 pos; BodyVel vel; };
+
+// IntegratePoseAndVelocity (TypeProcessor.cs:1204-1248) / IntegrateVelocity (:1251-1283) of one constrained dynamic body; returns its refreshed world
+// inverse inertia. substep 0: velocity only; substep > 0: pose, then velocity.
+__device__ __forceinline__ Sym3 substep_integrate_dynamic(BodyRegs& b, const float4& i0, const float4& i1, int integrate_pose, const StepParams& sp) {
+    const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+    Sym3 world;
+    if (integrate_pose) {
+        b.pos = add(b.pos, scale(b.vel.lin, sp.dt));                    // :1217
+        const Q previousOrientation = b.ori;
+        b.ori = integrateOrientation(b.ori, b.vel.ang, sp.dt * 0.5f);   // :1240
+        world = rotateInverseInertia(local, b.ori);                     // :1242
+        if (sp.angular_mode == 1) b.vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, world, b.vel.ang);                // :1224-1231
+        else if (sp.angular_mode == 2) b.vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(b.ori, local, b.vel.ang, sp.dt);   // :1232-1238
+    } else {
+        world = rotateInverseInertia(local, b.ori);                     // :1262
+        if (sp.angular_mode == 1) {
+            const Q previousOrientation = integrateOrientation(b.ori, b.vel.ang, sp.dt * -0.5f);  // :1266 "integrating backwards"
+            b.vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, world, b.vel.ang);
+        } else if (sp.angular_mode == 2) {
+            b.vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(b.ori, local, b.vel.ang, sp.dt);
+        }
+    }
+    velocity_callback(sp, b.vel);                                       // :1244 / :1273-1281
+    return world;
+}
+// The kinematic prepass (PoseIntegrator.cs:451-535) of one constrained kinematic body.
+__device__ __forceinline__ void substep_integrate_kinematic(BodyRegs& b, int integrate_pose, int integrate_velocity_for_kinematics, const StepParams& sp) {
+    if (integrate_pose) {                                               // :519-523
+        b.pos = add(b.pos, scale(b.vel.lin, sp.dt));
+        b.ori = integrateOrientation(b.ori, b.vel.ang, sp.dt * 0.5f);
+    }
+    if (integrate_velocity_for_kinematics) velocity_callback(sp, b.vel);  // :524-529, :481-485
+}
+
 // Per-substep integration of every constrained body — the work the reference fuses into the first-touching constraint's
-// warm start (TypeProcessor.cs:1204-1283) plus the kinematic prepass (PoseIntegrator.cs:451-535).
-// substep 0: velocity only; substep > 0: pose, then velocity. World inverse inertia is refreshed either way.
+// warm start (TypeProcessor.cs:1204-1283) plus the kinematic prepass (PoseIntegrator.cs:451-535). World inverse inertia is refreshed either way.
 __global__ __launch_bounds__(256) void substep_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, int integrate_pose,
                                                                  int integrate_velocity_for_kinematics, int skip_clustered, StepParams sp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,51 +201,29 @@ __global__ __launch_bounds__(256) void substep_integrate_kernel(float4* bodies, 
     unsigned f = flags[i];
     float4* base = bodies + (size_t)i * 8;
     if (skip_clustered && (f & kFlagClustered)) return;  // integrated in LDS by the owning cluster_kernel workgroup
+    if (!(f & (kFlagDynamicConstrained | kFlagConstrainedKinematic))) return;
+    const float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
+    BodyRegs b = {{q4.x, q4.y, q4.z, q4.w}, {p4.x, p4.y, p4.z}, {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}}};
     if (f & kFlagDynamicConstrained) {
-        float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3], i0 = base[4], i1 = base[5];
-        Q ori = {q4.x, q4.y, q4.z, q4.w};
-        V3 pos = {p4.x, p4.y, p4.z};
-        BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
-        Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
-        Sym3 world;
-        if (integrate_pose) {                                           // IntegratePoseAndVelocity, TypeProcessor.cs:1204-1248
-            pos = add(pos, scale(vel.lin, sp.dt));                      // :1217
-            const Q previousOrientation = ori;
-            ori = integrateOrientation(ori, vel.ang, sp.dt * 0.5f);     // :1240
-            world = rotateInverseInertia(local, ori);                   // :1242
-            if (sp.angular_mode == 1) vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, world, vel.ang);                // :1224-1231
-            else if (sp.angular_mode == 2) vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, sp.dt);   // :1232-1238
-            base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
-            base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
-        } else {                                                        // IntegrateVelocity, TypeProcessor.cs:1251-1283
-            world = rotateInverseInertia(local, ori);                   // :1262
-            if (sp.angular_mode == 1) {
-                const Q previousOrientation = integrateOrientation(ori, vel.ang, sp.dt * -0.5f);  // :1266 "integrating backwards"
-                vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, world, vel.ang);
-            } else if (sp.angular_mode == 2) {
-                vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, sp.dt);
-            }
+        const float4 i0 = base[4], i1 = base[5];
+        const Sym3 world = substep_integrate_dynamic(b, i0, i1, integrate_pose, sp);
+        if (integrate_pose) {
+            base[0] = make_float4(b.ori.x, b.ori.y, b.ori.z, b.ori.w);
+            base[1] = make_float4(b.pos.x, b.pos.y, b.pos.z, p4.w);
         }
-        velocity_callback(sp, vel);                                     // :1244 / :1273-1281
-        base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
-        base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+        base[2] = make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, l4.w);
+        base[3] = make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, a4.w);
         base[6] = make_float4(world.xx, world.yx, world.yy, world.zx);
         base[7] = make_float4(world.zy, world.zz, i1.z, base[7].w);
-    } else if (f & kFlagConstrainedKinematic) {
-        float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
-        Q ori = {q4.x, q4.y, q4.z, q4.w};
-        V3 pos = {p4.x, p4.y, p4.z};
-        BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
-        if (integrate_pose) {                                           // PoseIntegrator.cs:519-523
-            pos = add(pos, scale(vel.lin, sp.dt));
-            ori = integrateOrientation(ori, vel.ang, sp.dt * 0.5f);
-            base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
-            base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+    } else {
+        substep_integrate_kinematic(b, integrate_pose, integrate_velocity_for_kinematics, sp);
+        if (integrate_pose) {
+            base[0] = make_float4(b.ori.x, b.ori.y, b.ori.z, b.ori.w);
+            base[1] = make_float4(b.pos.x, b.pos.y, b.pos.z, p4.w);
         }
-        if (integrate_velocity_for_kinematics) {                        // :524-529, :481-485
-            velocity_callback(sp, vel);
-            base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
-            base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+        if (integrate_velocity_for_kinematics) {
+            base[2] = make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, l4.w);
+            base[3] = make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, a4.w);
         }
     }
 }
@@ -237,48 +250,51 @@ __global__ void momentum_requirk_kernel(float4* bodies, const int* __restrict__ 
     base[3] = make_float4(ang.x, ang.y, ang.z, a4.w);
 }
 
-// PoseIntegrator.IntegrateBundlesAfterSubstepping (PoseIntegrator.cs:537-693), one lane per body.
-__device__ __forceinline__ void final_integrate_body(float4* bodies, unsigned body_flags, int i, float dt, float substep_dt, int substep_count,
+// PoseIntegrator.IntegrateBundlesAfterSubstepping (PoseIntegrator.cs:537-693) of one body, on registers. True = the velocity changed too.
+__device__ __forceinline__ bool final_integrate_regs(BodyRegs& b, unsigned body_flags, const float4& i0, const float4& i1, float dt, float substep_dt, int substep_count,
                                                      int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, const StepParams& sp) {
-    float4* base = bodies + (size_t)i * 8;
     const bool unconstrained = !(body_flags & kFlagConstrained);
     const float effective_dt = allow_substeps_for_unconstrained ? substep_dt : (unconstrained ? dt : substep_dt);  // :591-599
     const float half_dt = effective_dt * 0.5f;
-    float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
-    Q ori = {q4.x, q4.y, q4.z, q4.w};
-    V3 pos = {p4.x, p4.y, p4.z};
-    BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
-    if (unconstrained) {
-        float4 i0 = base[4], i1 = base[5];
-        const bool is_kinematic = i0.x == 0 && i0.y == 0 && i0.z == 0 && i0.w == 0 && i1.x == 0 && i1.y == 0 && i1.z == 0;  // Bodies.cs:326-349
-        const bool velocity_mask = integrate_velocity_for_kinematics ? true : !is_kinematic;                                // :604-616
-        const int steps = allow_substeps_for_unconstrained ? substep_count : 1;
-        for (int s = 0; s < steps; ++s) {
-            if (velocity_mask) velocity_callback(sp, vel);   // velocity -> pose for unconstrained bodies (:634-667)
-            pos = add(pos, scale(vel.lin, effective_dt));
-            if (sp.angular_mode == 1) {                      // :649-655
-                const Q previousOrientation = ori;
-                ori = integrateOrientation(ori, vel.ang, half_dt);
-                const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
-                vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, rotateInverseInertia(local, ori), vel.ang);
-            } else if (sp.angular_mode == 2) {               // :656-660
-                ori = integrateOrientation(ori, vel.ang, half_dt);
-                const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
-                vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, effective_dt);
-            } else {
-                ori = integrateOrientation(ori, vel.ang, half_dt);
-            }
-        }
-        if (velocity_mask) {
-            base[2] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
-            base[3] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
-        }
-    } else {
-        ori = integrateOrientation(ori, vel.ang, half_dt);   // :684-691
-        pos = add(pos, scale(vel.lin, effective_dt));
+    if (!unconstrained) {
+        b.ori = integrateOrientation(b.ori, b.vel.ang, half_dt);   // :684-691
+        b.pos = add(b.pos, scale(b.vel.lin, effective_dt));
+        return false;
     }
-    base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
-    base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
+    const bool is_kinematic = i0.x == 0 && i0.y == 0 && i0.z == 0 && i0.w == 0 && i1.x == 0 && i1.y == 0 && i1.z == 0;  // Bodies.cs:326-349
+    const bool velocity_mask = integrate_velocity_for_kinematics ? true : !is_kinematic;                                // :604-616
+    const int steps = allow_substeps_for_unconstrained ? substep_count : 1;
+    for (int s = 0; s < steps; ++s) {
+        if (velocity_mask) velocity_callback(sp, b.vel);   // velocity -> pose for unconstrained bodies (:634-667)
+        b.pos = add(b.pos, scale(b.vel.lin, effective_dt));
+        if (sp.angular_mode == 1) {                        // :649-655
+            const Q previousOrientation = b.ori;
+            b.ori = integrateOrientation(b.ori, b.vel.ang, half_dt);
+            const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+            b.vel.ang = integrateAngularVelocityConserveMomentum(previousOrientation, local, rotateInverseInertia(local, b.ori), b.vel.ang);
+        } else if (sp.angular_mode == 2) {                 // :656-660
+            b.ori = integrateOrientation(b.ori, b.vel.ang, half_dt);
+            const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+            b.vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(b.ori, local, b.vel.ang, effective_dt);
+        } else {
+            b.ori = integrateOrientation(b.ori, b.vel.ang, half_dt);
+        }
+    }
+    return velocity_mask;
+}
+__device__ __forceinline__ void final_integrate_body(float4* bodies, unsigned body_flags, int i, float dt, float substep_dt, int substep_count,
+                                                     int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, const StepParams& sp) {
+    float4* base = bodies + (size_t)i * 8;
+    const float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
+    float4 i0 = make_float4(0, 0, 0, 0), i1 = i0;
+    if (!(body_flags & kFlagConstrained)) { i0 = base[4]; i1 = base[5]; }
+    BodyRegs b = {{q4.x, q4.y, q4.z, q4.w}, {p4.x, p4.y, p4.z}, {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}}};
+    if (final_integrate_regs(b, body_flags, i0, i1, dt, substep_dt, substep_count, allow_substeps_for_unconstrained, integrate_velocity_for_kinematics, sp)) {
+        base[2] = make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, l4.w);
+        base[3] = make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, a4.w);
+    }
+    base[0] = make_float4(b.ori.x, b.ori.y, b.ori.z, b.ori.w);
+    base[1] = make_float4(b.pos.x, b.pos.y, b.pos.z, p4.w);
 }
 __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, float dt, float substep_dt, int substep_count,
                                                                int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, int skip_clustered, StepParams sp) {

@@ -113,6 +113,13 @@ struct bepuhip_ctx {
     int inc_tb_count = 0, inc_blocks = 0;
     int64_t total_constraints = 0;
     int referenced_bodies = 0;           // 1 + the largest body index any constraint references
+    // stream schedule (bepu_stream_kernel.h)
+    bool stream_enabled = false;
+    int stream_waves = 0;                // resident wavefronts of one cooperative launch (occupancy x CUs), found once
+    int* d_batch_begin = nullptr;        // device copies of batch_begin / batch_blocks
+    int* d_batch_blocks = nullptr;
+    unsigned* d_hops = nullptr;          // arrival counters, 16 dwords per hop
+    int hop_capacity = 0;
     // cluster path
     bool clusters_enabled = false;
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
@@ -162,6 +169,9 @@ static void free_constraints(bepuhip_ctx* c) {
     if (c->d_clustered_dynamic) hipFree(c->d_clustered_dynamic);
     if (c->d_kinlist) hipFree(c->d_kinlist);
     if (c->d_requirk) hipFree(c->d_requirk);
+    if (c->d_batch_begin) hipFree(c->d_batch_begin);
+    if (c->d_batch_blocks) hipFree(c->d_batch_blocks);
+    c->d_batch_begin = c->d_batch_blocks = nullptr; c->stream_enabled = false;
     c->d_requirk = nullptr; c->requirk_begin.clear();
     if (c->d_trace) hipFree(c->d_trace);
     c->d_trace = nullptr; c->trace_words = 0;

@@ -1,0 +1,337 @@
+// Persistent launch-per-batch schedule ("stream schedule"): the launch sequence of enqueue_solve (Solver_Solve.cs:1415-1479 + PoseIntegrator.cs:707-726)
+// executed by ONE cooperative launch of resident wavefronts. Every launch of the sequence becomes a "hop"; the device-wide ordering between two
+// hops, which the launch-per-batch schedule gets from kernel boundaries (8.7 us per dependent launch on a 100k-box pile), comes from an arrival
+// counter per hop instead.
+//
+// What makes that cheap on a part with eight L2s (tools/probes/xcd_handoff_probe.hip, profiles/r01_xcd_handoff_probe.txt): body records that cross
+// workgroups are only ever moved with agent-scope (sc1) loads and stores, which bypass the per-CU L1 and are coherent across the XCDs without any
+// release/acquire fence (no L2 write-back / invalidate: 1.5 us per hand-off instead of 4.8-5.3 us). Per-constraint data (prestep, accumulated
+// impulses) never crosses wavefronts inside a launch: block `vb` of batch `b` is run by wavefront vb % G in every hop, so plain cached accesses
+// are coherent for it by construction.
+#pragma once
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct BodyPlanes { f4 ori, pos, lin, ang, w0, w1; };  // planes 0,1,2,3,6,7 of the 128-byte body record
+
+// One asm statement per burst: the loads AND the wait, so that the compiler can never touch a destination register before its data has landed.
+__device__ __forceinline__ void sc1_load_body(const float4* base, BodyPlanes& r) {
+    asm volatile(
+        "global_load_dwordx4 %0, %6, off sc1\n\t"
+        "global_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %2, %6, off offset:32 sc1\n\t"
+        "global_load_dwordx4 %3, %6, off offset:48 sc1\n\t"
+        "global_load_dwordx4 %4, %6, off offset:96 sc1\n\t"
+        "global_load_dwordx4 %5, %6, off offset:112 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r.ori), "=&v"(r.pos), "=&v"(r.lin), "=&v"(r.ang), "=&v"(r.w0), "=&v"(r.w1)
+        : "v"(base)
+        : "memory");
+}
+__device__ __forceinline__ void sc1_load_body2(const float4* baseA, const float4* baseB, BodyPlanes& a, BodyPlanes& b) {
+    asm volatile(
+        "global_load_dwordx4 %0, %12, off sc1\n\t"
+        "global_load_dwordx4 %1, %12, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %2, %12, off offset:32 sc1\n\t"
+        "global_load_dwordx4 %3, %12, off offset:48 sc1\n\t"
+        "global_load_dwordx4 %4, %12, off offset:96 sc1\n\t"
+        "global_load_dwordx4 %5, %12, off offset:112 sc1\n\t"
+        "global_load_dwordx4 %6, %13, off sc1\n\t"
+        "global_load_dwordx4 %7, %13, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %8, %13, off offset:32 sc1\n\t"
+        "global_load_dwordx4 %9, %13, off offset:48 sc1\n\t"
+        "global_load_dwordx4 %10, %13, off offset:96 sc1\n\t"
+        "global_load_dwordx4 %11, %13, off offset:112 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a.ori), "=&v"(a.pos), "=&v"(a.lin), "=&v"(a.ang), "=&v"(a.w0), "=&v"(a.w1), "=&v"(b.ori), "=&v"(b.pos), "=&v"(b.lin), "=&v"(b.ang), "=&v"(b.w0),
+          "=&v"(b.w1)
+        : "v"(baseA), "v"(baseB)
+        : "memory");
+}
+__device__ __forceinline__ void sc1_load_velocity2(const float4* baseA, const float4* baseB, f4& linA, f4& angA, f4& linB, f4& angB) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off offset:32 sc1\n\t"
+        "global_load_dwordx4 %1, %4, off offset:48 sc1\n\t"
+        "global_load_dwordx4 %2, %5, off offset:32 sc1\n\t"
+        "global_load_dwordx4 %3, %5, off offset:48 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(linA), "=&v"(angA), "=&v"(linB), "=&v"(angB)
+        : "v"(baseA), "v"(baseB)
+        : "memory");
+}
+// (the s_nop covers the wait state a wide VMEM store needs before its data registers may be rewritten; the compiler cannot see inside the asm)
+__device__ __forceinline__ void sc1_store(float4* p, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ f4 make_f4(float x, float y, float z, float w) { f4 r = {x, y, z, w}; return r; }
+
+template <int ACCESS>
+__device__ __forceinline__ void planes_to_body(const BodyPlanes& r, DBody& b) {  // the same field selection as load_body<ACCESS>
+    if (ACCESS & kOri) b.ori = {r.ori.x, r.ori.y, r.ori.z, r.ori.w}; else b.ori = {0, 0, 0, 0};
+    if (ACCESS & kPos) b.pos = {r.pos.x, r.pos.y, r.pos.z}; else b.pos = {0, 0, 0};
+    if (ACCESS & kLin) { b.vel.lin = {r.lin.x, r.lin.y, r.lin.z}; b.linw = r.lin.w; } else { b.vel.lin = {0, 0, 0}; b.linw = 0; }
+    if (ACCESS & kAng) { b.vel.ang = {r.ang.x, r.ang.y, r.ang.z}; b.angw = r.ang.w; } else { b.vel.ang = {0, 0, 0}; b.angw = 0; }
+    if (ACCESS & kInertia) { b.inertia.t = {r.w0.x, r.w0.y, r.w0.z, r.w0.w, r.w1.x, r.w1.y}; b.inertia.invMass = r.w1.z; }
+    else { b.inertia.t = {0, 0, 0, 0, 0, 0}; b.inertia.invMass = 0; }
+}
+template <int ACCESS>
+__device__ __forceinline__ void sc1_store_velocity(float4* bodies, int ref, const DBody& b) {  // ScatterVelocities: never for kinematic references
+    if ((unsigned)ref >= kDynamicLimit) return;
+    float4* base = bodies + (size_t)ref * 8;
+    if (ACCESS & kLin) sc1_store(base + 2, make_f4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, b.linw));
+    if (ACCESS & kAng) sc1_store(base + 3, make_f4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, b.angw));
+}
+
+// ---- hop ordering ----
+constexpr int kHopLanes = 16;  // arrival counter of a hop = 16 dwords (one 64-byte line): arrivals spread over them, a waiter reads the line once per poll
+struct StreamSync {
+    unsigned* counters;  // [hops][16], zeroed before the launch
+    unsigned* status;    // host-visible watchdog words (shared with the island schedule): [0] != 0 = stalled
+    unsigned long long* trace;  // diagnostics (bepuhip_set_cluster_trace): per traced wavefront and hop, four 100 MHz stamps; null = off
+};
+constexpr int kStreamTraceWaves = 3, kStreamTraceHops = 1024;
+
+__device__ __forceinline__ unsigned wave_sum16(unsigned v) {  // sum over lanes 0..15, uniform result
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// Blocks until every block of hop `hop` has arrived. False = watchdog (another wavefront never arrived): the caller unwinds.
+__device__ __forceinline__ bool hop_wait(const StreamSync& sy, int hop, unsigned expected) {
+    if (hop < 0) return true;
+    unsigned* line = sy.counters + (size_t)hop * kHopLanes;
+    const int lane = threadIdx.x;
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned v = lane < kHopLanes ? __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (wave_sum16(v) >= expected) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 255u) == 255u) {
+            if (__hip_atomic_load(sy.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;  // somebody already gave up
+            if (spins > kSpinLimit) { report_stall(sy.status, 0u, 6, hop, 0, expected, wave_sum16(v)); return false; }  // kind 6: a hop of the stream schedule
+        }
+    }
+}
+__device__ __forceinline__ void hop_arrive(const StreamSync& sy, int hop, unsigned blocks_done) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every sc1 store of this wavefront has been acknowledged = is visible device-wide
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(sy.counters + (size_t)hop * kHopLanes + (blockIdx.x & (kHopLanes - 1)), blocks_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool type_is_incremental(int type_id) { return type_id >= kContact1OneBody && type_id <= kContact4; }  // the convex contact ids are contiguous
+
+// ---- constraint blocks ----
+// The gate is called once per block, by all 64 lanes, after the block's own rows (references, prestep, accumulated impulses: never shared) have been
+// requested and before the first body access: it is where the wavefront waits for the previous hop.
+template <class F, int STAGE, class GATE>
+__device__ __forceinline__ bool stream_constraint(const DevTypeBatch& tb, int i, float4* bodies, float dt, float inv_dt, GATE&& gate) {
+    const int stride = tb.stride;
+    const bool valid = i < tb.count;
+    const int row = valid ? i : 0;
+    const int refA = tb.refs[row];
+    const int refB = (F::bodies == 2) ? tb.refs[stride + row] : refA;
+    float p[F::prestepFloats];
+    _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = tb.prestep[(size_t)f * stride + row];
+    float a[F::impulseFloats];
+    if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = tb.accum[(size_t)f * stride + row]; }
+    const float4* baseA = bodies + (size_t)(refA & kRefMask) * 8;
+    const float4* baseB = bodies + (size_t)(refB & kRefMask) * 8;
+    if (!gate()) return false;
+    if (!valid) return true;
+    DBody A, B;
+    if (STAGE == kStageIncremental) {
+        if constexpr (F::incremental) {
+            f4 la, aa, lb, ab;
+            sc1_load_velocity2(baseA, baseB, la, aa, lb, ab);
+            A.vel = {{la.x, la.y, la.z}, {aa.x, aa.y, aa.z}};
+            if (F::bodies == 2) B.vel = {{lb.x, lb.y, lb.z}, {ab.x, ab.y, ab.z}}; else B.vel = {{0, 0, 0}, {0, 0, 0}};
+            F::incrementalUpdate(dt, A.vel, B.vel, p);
+            _Pragma("unroll") for (int cidx = 0; cidx < F::contacts; ++cidx) tb.prestep[(size_t)F::depthRow(cidx) * stride + i] = p[F::depthRow(cidx)];
+        }
+        return true;
+    }
+    constexpr int accA = (STAGE == kStageWarmStart) ? F::wsA : F::svA;
+    constexpr int accB = (STAGE == kStageWarmStart) ? F::wsB : F::svB;
+    BodyPlanes ra, rb;
+    if (F::bodies == 2) sc1_load_body2(baseA, baseB, ra, rb); else sc1_load_body(baseA, ra);
+    planes_to_body<accA>(ra, A);
+    if (F::bodies == 2) planes_to_body<accB>(rb, B); else planes_to_body<0>(ra, B);
+    if (STAGE == kStageWarmStart) {
+        F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, NoGate{});
+    } else {
+        F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, NoGate{});
+        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) tb.accum[(size_t)f * stride + i] = a[f];
+    }
+    sc1_store_velocity<accA>(bodies, refA, A);
+    if (F::bodies == 2) sc1_store_velocity<accB>(bodies, refB, B);
+    return true;
+}
+
+template <int STAGE, class GATE>
+__device__ __forceinline__ bool stream_constraint_block(const DevTypeBatch& tb, int i, float4* bodies, float dt, float inv_dt, GATE&& gate) {
+    switch (tb.type_id) {
+        case kContact1OneBody: return stream_constraint<Contact<1, false>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
+        case kContact2OneBody: return stream_constraint<Contact<2, false>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
+        case kContact3OneBody: return stream_constraint<Contact<3, false>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
+        case kContact4OneBody: return stream_constraint<Contact<4, false>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
+        case kContact1: return stream_constraint<Contact<1, true>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
+        case kContact2: return stream_constraint<Contact<2, true>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
+        case kContact3: return stream_constraint<Contact<3, true>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
+        case kContact4: return stream_constraint<Contact<4, true>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
+        default: break;
+    }
+    if (STAGE != kStageIncremental) {
+        switch (tb.type_id) {
+#define X(ID, T) case ID: return stream_constraint<T, STAGE>(tb, i, bodies, dt, inv_dt, gate);
+            BD_HOT_JOINT_TYPES(X)
+#undef X
+            default: break;
+        }
+    }
+    return gate();  // a type without work in this stage still takes part in the hop
+}
+
+// ---- body blocks: substep_integrate_kernel / final_integrate_kernel, one lane per body, on sc1 accesses ----
+__device__ __forceinline__ void stream_integrate_body(float4* bodies, unsigned f, int i, int integrate_pose, int integrate_velocity_for_kinematics, const StepParams& sp) {
+    if (!(f & (kFlagDynamicConstrained | kFlagConstrainedKinematic))) return;
+    float4* base = bodies + (size_t)i * 8;
+    const float4 i0 = base[4], i1 = base[5];  // local inverse inertia: never written
+    BodyPlanes r;
+    sc1_load_body(base, r);
+    BodyRegs b = {{r.ori.x, r.ori.y, r.ori.z, r.ori.w}, {r.pos.x, r.pos.y, r.pos.z}, {{r.lin.x, r.lin.y, r.lin.z}, {r.ang.x, r.ang.y, r.ang.z}}};
+    if (f & kFlagDynamicConstrained) {
+        const Sym3 world = substep_integrate_dynamic(b, i0, i1, integrate_pose, sp);
+        if (integrate_pose) {
+            sc1_store(base + 0, make_f4(b.ori.x, b.ori.y, b.ori.z, b.ori.w));
+            sc1_store(base + 1, make_f4(b.pos.x, b.pos.y, b.pos.z, r.pos.w));
+        }
+        sc1_store(base + 2, make_f4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, r.lin.w));
+        sc1_store(base + 3, make_f4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, r.ang.w));
+        sc1_store(base + 6, make_f4(world.xx, world.yx, world.yy, world.zx));
+        sc1_store(base + 7, make_f4(world.zy, world.zz, i1.z, r.w1.w));
+    } else {
+        substep_integrate_kinematic(b, integrate_pose, integrate_velocity_for_kinematics, sp);
+        if (integrate_pose) {
+            sc1_store(base + 0, make_f4(b.ori.x, b.ori.y, b.ori.z, b.ori.w));
+            sc1_store(base + 1, make_f4(b.pos.x, b.pos.y, b.pos.z, r.pos.w));
+        }
+        if (integrate_velocity_for_kinematics) {
+            sc1_store(base + 2, make_f4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, r.lin.w));
+            sc1_store(base + 3, make_f4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, r.ang.w));
+        }
+    }
+}
+__device__ __forceinline__ void stream_final_body(float4* bodies, unsigned f, int i, float dt, float substep_dt, int substep_count, int allow_substeps_for_unconstrained,
+                                                  int integrate_velocity_for_kinematics, const StepParams& sp) {
+    float4* base = bodies + (size_t)i * 8;
+    const float4 i0 = base[4], i1 = base[5];
+    BodyPlanes r;
+    sc1_load_body(base, r);
+    BodyRegs b = {{r.ori.x, r.ori.y, r.ori.z, r.ori.w}, {r.pos.x, r.pos.y, r.pos.z}, {{r.lin.x, r.lin.y, r.lin.z}, {r.ang.x, r.ang.y, r.ang.z}}};
+    const bool velocity_written = final_integrate_regs(b, f, i0, i1, dt, substep_dt, substep_count, allow_substeps_for_unconstrained, integrate_velocity_for_kinematics, sp);
+    if (velocity_written) {
+        sc1_store(base + 2, make_f4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, r.lin.w));
+        sc1_store(base + 3, make_f4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, r.ang.w));
+    }
+    sc1_store(base + 0, make_f4(b.ori.x, b.ori.y, b.ori.z, b.ori.w));
+    sc1_store(base + 1, make_f4(b.pos.x, b.pos.y, b.pos.z, r.pos.w));
+}
+
+constexpr int kMaxStreamSubsteps = 16;
+struct StreamParams {
+    int substeps, batch_count, body_count, integrate_velocity_for_kinematics;
+    int iters[kMaxStreamSubsteps];
+    int has_incremental;
+    float frame_dt, substep_dt, inv_substep_dt;
+    int allow_substeps_for_unconstrained;
+    StepParams sp, final_sp;
+};
+
+// One wavefront per workgroup, every workgroup resident (cooperative launch). All wavefronts walk the same hop sequence; a hop's blocks are dealt
+// round-robin (block vb -> wavefront vb % G, the same in every hop of a batch).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void stream_kernel(const DevTypeBatch* __restrict__ tbs, const int* __restrict__ batch_begin,
+                                                                                           const int* __restrict__ batch_blocks, float4* bodies,
+                                                                                           const unsigned* __restrict__ flags, StreamSync sy, StreamParams P) {
+    const int w = blockIdx.x, G = gridDim.x, lane = threadIdx.x;
+    // traced wavefronts: the first, one in the middle, the last; stamps: reached the hop, passed the gate, finished the blocks, arrived
+    const int traced = sy.trace == nullptr ? -1 : (w == 0 ? 0 : (w == G / 2 ? 1 : (w == G - 1 ? 2 : -1)));
+    auto stamp = [&](int h, int k) {
+        if (traced >= 0 && lane == 0 && h < kStreamTraceHops) sy.trace[((size_t)traced * kStreamTraceHops + h) * 4 + k] = wall_clock64();
+    };
+    int hop = 0;               // index of the hop being run; it may start once hop - 1 is complete
+    unsigned prev_blocks = 0;  // arrivals that complete hop - 1
+    bool alive = true;
+
+    // (batch b, block vb) -> type batch and first constraint, as batch_kernel resolves blockIdx
+    auto locate = [&](int b, int vb, int& i) -> DevTypeBatch {
+        const int t0 = batch_begin[b], t1 = batch_begin[b + 1];
+        int t = t0;
+        for (int k = t0 + 1; k < t1; ++k)
+            if (vb >= tbs[k].block_begin) t = k;
+        const DevTypeBatch tb = tbs[t];
+        i = (vb - tb.block_begin) * kBlock + lane;
+        return tb;
+    };
+    auto constraint_hop = [&](auto stage_tag, int b_first, int b_last) {  // the blocks of batches [b_first, b_last] as one hop
+        constexpr int STAGE = decltype(stage_tag)::value;
+        unsigned total = 0, done = 0;
+        bool waited = false;
+        stamp(hop, 0);
+        auto gate = [&]() -> bool {
+            if (!waited) { waited = true; alive = hop_wait(sy, hop - 1, prev_blocks); stamp(hop, 1); }
+            return alive;
+        };
+        for (int b = b_first; b <= b_last; ++b) {
+            const int blocks = batch_blocks[b];
+            total += (unsigned)blocks;
+            for (int vb = w; vb < blocks && alive; vb += G) {
+                int i;
+                const DevTypeBatch tb = locate(b, vb, i);
+                if (STAGE == kStageIncremental && !type_is_incremental(tb.type_id)) { ++done; continue; }
+                stream_constraint_block<STAGE>(tb, i, bodies, P.substep_dt, P.inv_substep_dt, gate);
+                ++done;
+            }
+        }
+        if (total == 0) return;
+        stamp(hop, 2);
+        if (done && alive) hop_arrive(sy, hop, done);
+        stamp(hop, 3);
+        prev_blocks = total;
+        ++hop;
+    };
+    auto body_hop = [&](auto&& per_body) {
+        const unsigned blocks = (unsigned)((P.body_count + 63) / 64);
+        if (blocks == 0) return;
+        unsigned done = 0;
+        bool waited = false;
+        stamp(hop, 0);
+        for (unsigned vb = (unsigned)w; vb < blocks && alive; vb += (unsigned)G) {
+            const int i = (int)vb * 64 + lane;
+            const unsigned f = i < P.body_count ? flags[i] : 0u;
+            if (!waited) { waited = true; alive = hop_wait(sy, hop - 1, prev_blocks); stamp(hop, 1); }
+            if (!alive) break;
+            if (i < P.body_count) per_body(i, f);
+            ++done;
+        }
+        stamp(hop, 2);
+        if (done && alive) hop_arrive(sy, hop, done);
+        stamp(hop, 3);
+        prev_blocks = blocks;
+        ++hop;
+    };
+
+    for (int s = 0; s < P.substeps && alive; ++s) {
+        if (s > 0 && P.has_incremental) constraint_hop(std::integral_constant<int, kStageIncremental>{}, 0, P.batch_count - 1);
+        body_hop([&](int i, unsigned f) { stream_integrate_body(bodies, f, i, s > 0 ? 1 : 0, P.integrate_velocity_for_kinematics, P.sp); });
+        for (int b = 0; b < P.batch_count && alive; ++b) constraint_hop(std::integral_constant<int, kStageWarmStart>{}, b, b);
+        for (int it = 0; it < P.iters[s] && alive; ++it)
+            for (int b = 0; b < P.batch_count && alive; ++b) constraint_hop(std::integral_constant<int, kStageSolve>{}, b, b);
+    }
+    if (alive)
+        body_hop([&](int i, unsigned f) {
+            stream_final_body(bodies, f, i, P.frame_dt, P.substep_dt, P.substeps, P.allow_substeps_for_unconstrained, P.integrate_velocity_for_kinematics, P.final_sp);
+        });
+}
+
+}  // namespace
