@@ -115,7 +115,7 @@ struct bepuhip_ctx {
     int referenced_bodies = 0;           // 1 + the largest body index any constraint references
     // stream schedule (bepu_stream_kernel.h)
     bool stream_enabled = false;
-    int stream_waves = 0;                // resident wavefronts of one cooperative launch (occupancy x CUs), found once
+    int stream_waves = 0;                // resident workgroups of one cooperative launch (occupancy x CUs), found once
     int* d_batch_begin = nullptr;        // device copies of batch_begin / batch_blocks
     int* d_batch_blocks = nullptr;
     unsigned* d_hops = nullptr;          // arrival counters, 16 dwords per hop

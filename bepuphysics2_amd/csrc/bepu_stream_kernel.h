@@ -15,6 +15,7 @@ namespace {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct BodyPlanes { f4 ori, pos, lin, ang, w0, w1; };  // planes 0,1,2,3,6,7 of the 128-byte body record
+__device__ __forceinline__ f4 make_f4(float x, float y, float z, float w) { f4 r = {x, y, z, w}; return r; }
 
 // One asm statement per burst: the loads AND the wait, so that the compiler can never touch a destination register before its data has landed.
 __device__ __forceinline__ void sc1_load_body(const float4* base, BodyPlanes& r) {
@@ -50,6 +51,23 @@ __device__ __forceinline__ void sc1_load_body2(const float4* baseA, const float4
         : "v"(baseA), "v"(baseB)
         : "memory");
 }
+// The planes a constraint that never reads poses needs (kAccessNoPose and its subsets: the contacts): two thirds of the requests.
+__device__ __forceinline__ void sc1_load_body2_nopose(const float4* baseA, const float4* baseB, BodyPlanes& a, BodyPlanes& b) {
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off offset:32 sc1\n\t"
+        "global_load_dwordx4 %1, %8, off offset:48 sc1\n\t"
+        "global_load_dwordx4 %2, %8, off offset:96 sc1\n\t"
+        "global_load_dwordx4 %3, %8, off offset:112 sc1\n\t"
+        "global_load_dwordx4 %4, %9, off offset:32 sc1\n\t"
+        "global_load_dwordx4 %5, %9, off offset:48 sc1\n\t"
+        "global_load_dwordx4 %6, %9, off offset:96 sc1\n\t"
+        "global_load_dwordx4 %7, %9, off offset:112 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a.lin), "=&v"(a.ang), "=&v"(a.w0), "=&v"(a.w1), "=&v"(b.lin), "=&v"(b.ang), "=&v"(b.w0), "=&v"(b.w1)
+        : "v"(baseA), "v"(baseB)
+        : "memory");
+    a.ori = a.pos = b.ori = b.pos = make_f4(0, 0, 0, 0);
+}
 __device__ __forceinline__ void sc1_load_velocity2(const float4* baseA, const float4* baseB, f4& linA, f4& angA, f4& linB, f4& angB) {
     asm volatile(
         "global_load_dwordx4 %0, %4, off offset:32 sc1\n\t"
@@ -63,7 +81,6 @@ __device__ __forceinline__ void sc1_load_velocity2(const float4* baseA, const fl
 }
 // (the s_nop covers the wait state a wide VMEM store needs before its data registers may be rewritten; the compiler cannot see inside the asm)
 __device__ __forceinline__ void sc1_store(float4* p, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ f4 make_f4(float x, float y, float z, float w) { f4 r = {x, y, z, w}; return r; }
 
 template <int ACCESS>
 __device__ __forceinline__ void planes_to_body(const BodyPlanes& r, DBody& b) {  // the same field selection as load_body<ACCESS>
@@ -99,10 +116,9 @@ __device__ __forceinline__ unsigned wave_sum16(unsigned v) {  // sum over lanes 
     return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 // Blocks until every block of hop `hop` has arrived. False = watchdog (another wavefront never arrived): the caller unwinds.
-__device__ __forceinline__ bool hop_wait(const StreamSync& sy, int hop, unsigned expected) {
+__device__ __forceinline__ bool hop_wait(const StreamSync& sy, int hop, unsigned expected, int lane) {
     if (hop < 0) return true;
     unsigned* line = sy.counters + (size_t)hop * kHopLanes;
-    const int lane = threadIdx.x;
     for (unsigned spins = 0;; ++spins) {
         const unsigned v = lane < kHopLanes ? __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         if (wave_sum16(v) >= expected) return true;
@@ -113,10 +129,9 @@ __device__ __forceinline__ bool hop_wait(const StreamSync& sy, int hop, unsigned
         }
     }
 }
-__device__ __forceinline__ void hop_arrive(const StreamSync& sy, int hop, unsigned blocks_done) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every sc1 store of this wavefront has been acknowledged = is visible device-wide
-    if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(sy.counters + (size_t)hop * kHopLanes + (blockIdx.x & (kHopLanes - 1)), blocks_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// One arrival per workgroup, after its wavefronts have drained their stores and met at the workgroup barrier.
+__device__ __forceinline__ void hop_arrive(const StreamSync& sy, int hop, unsigned blocks_done, int wg) {
+    __hip_atomic_fetch_add(sy.counters + (size_t)hop * kHopLanes + (wg & (kHopLanes - 1)), blocks_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ bool type_is_incremental(int type_id) { return type_id >= kContact1OneBody && type_id <= kContact4; }  // the convex contact ids are contiguous
@@ -154,7 +169,10 @@ __device__ __forceinline__ bool stream_constraint(const DevTypeBatch& tb, int i,
     constexpr int accA = (STAGE == kStageWarmStart) ? F::wsA : F::svA;
     constexpr int accB = (STAGE == kStageWarmStart) ? F::wsB : F::svB;
     BodyPlanes ra, rb;
-    if (F::bodies == 2) sc1_load_body2(baseA, baseB, ra, rb); else sc1_load_body(baseA, ra);
+    constexpr bool kPoseFree = ((accA | accB) & (kPos | kOri)) == 0;
+    if (F::bodies == 2 && kPoseFree) sc1_load_body2_nopose(baseA, baseB, ra, rb);
+    else if (F::bodies == 2) sc1_load_body2(baseA, baseB, ra, rb);
+    else sc1_load_body(baseA, ra);
     planes_to_body<accA>(ra, A);
     if (F::bodies == 2) planes_to_body<accB>(rb, B); else planes_to_body<0>(ra, B);
     if (STAGE == kStageWarmStart) {
@@ -248,20 +266,46 @@ struct StreamParams {
     StepParams sp, final_sp;
 };
 
-// One wavefront per workgroup, every workgroup resident (cooperative launch). All wavefronts walk the same hop sequence; a hop's blocks are dealt
-// round-robin (block vb -> wavefront vb % G, the same in every hop of a batch).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void stream_kernel(const DevTypeBatch* __restrict__ tbs, const int* __restrict__ batch_begin,
-                                                                                           const int* __restrict__ batch_blocks, float4* bodies,
-                                                                                           const unsigned* __restrict__ flags, StreamSync sy, StreamParams P) {
-    const int w = blockIdx.x, G = gridDim.x, lane = threadIdx.x;
-    // traced wavefronts: the first, one in the middle, the last; stamps: reached the hop, passed the gate, finished the blocks, arrived
-    const int traced = sy.trace == nullptr ? -1 : (w == 0 ? 0 : (w == G / 2 ? 1 : (w == G - 1 ? 2 : -1)));
+// Every workgroup resident (cooperative launch), kStreamWaves wavefronts each. All wavefronts walk the same hop sequence; a hop's blocks are dealt
+// round-robin over the workgroups first (block vb -> workgroup vb % NWG, wavefront (vb / NWG) % kStreamWaves: the same in every hop of a batch), so
+// a hop of up to NWG * kStreamWaves blocks costs every wavefront one block. Only wavefront 0 of a workgroup polls the arrival counter; the others wait
+// for it at the workgroup barrier, which keeps the number of pollers at one per CU (2048 single-wave pollers saturate the fabric).
+constexpr int kStreamWaves = 8;
+__global__ __launch_bounds__(64 * kStreamWaves) void stream_kernel(const DevTypeBatch* __restrict__ tbs, const int* __restrict__ batch_begin, const int* __restrict__ batch_blocks,
+                                                                   float4* bodies, const unsigned* __restrict__ flags, StreamSync sy, StreamParams P) {
+    __shared__ int s_alive;
+    const int wg = blockIdx.x, NWG = gridDim.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int fw = wg + NWG * wv, TW = NWG * kStreamWaves;  // this wavefront's place in the deal, and the deal's period
+    // traced workgroups (wavefront 0 of each): the first, one in the middle, the last; stamps: reached the hop, passed the gate, finished the blocks, arrived
+    const int traced = (sy.trace == nullptr || wv != 0) ? -1 : (wg == 0 ? 0 : (wg == NWG / 2 ? 1 : (wg == NWG - 1 ? 2 : -1)));
     auto stamp = [&](int h, int k) {
         if (traced >= 0 && lane == 0 && h < kStreamTraceHops) sy.trace[((size_t)traced * kStreamTraceHops + h) * 4 + k] = wall_clock64();
     };
     int hop = 0;               // index of the hop being run; it may start once hop - 1 is complete
     unsigned prev_blocks = 0;  // arrivals that complete hop - 1
     bool alive = true;
+
+    // Once per hop and wavefront of a workgroup that owns blocks of the hop: wavefront 0 waits for the previous hop, the others for wavefront 0.
+    auto gate_once = [&](bool& waited) -> bool {
+        if (waited) return alive;
+        waited = true;
+        if (wv == 0) {
+            const bool ok = hop_wait(sy, hop - 1, prev_blocks, lane);
+            if (lane == 0) s_alive = ok ? 1 : 0;
+        }
+        __syncthreads();
+        alive = s_alive != 0;
+        stamp(hop, 1);
+        return alive;
+    };
+    auto arrive = [&](unsigned wg_blocks) {
+        stamp(hop, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every sc1 store of this wavefront has been acknowledged = is visible device-wide
+        __syncthreads();                                  // ... and of the other wavefronts of the workgroup (also fences s_alive for the next hop)
+        if (wv == 0 && lane == 0) hop_arrive(sy, hop, wg_blocks, wg);
+        stamp(hop, 3);
+    };
+    auto owned = [&](int blocks) -> unsigned { return blocks > wg ? (unsigned)((blocks - wg + NWG - 1) / NWG) : 0u; };  // blocks of a grid this workgroup runs
 
     // (batch b, block vb) -> type batch and first constraint, as batch_kernel resolves blockIdx
     auto locate = [&](int b, int vb, int& i) -> DevTypeBatch {
@@ -275,55 +319,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void st
     };
     auto constraint_hop = [&](auto stage_tag, int b_first, int b_last) {  // the blocks of batches [b_first, b_last] as one hop
         constexpr int STAGE = decltype(stage_tag)::value;
-        unsigned total = 0, done = 0;
-        bool waited = false;
-        stamp(hop, 0);
-        auto gate = [&]() -> bool {
-            if (!waited) { waited = true; alive = hop_wait(sy, hop - 1, prev_blocks); stamp(hop, 1); }
-            return alive;
-        };
-        for (int b = b_first; b <= b_last; ++b) {
-            const int blocks = batch_blocks[b];
-            total += (unsigned)blocks;
-            for (int vb = w; vb < blocks && alive; vb += G) {
-                int i;
-                const DevTypeBatch tb = locate(b, vb, i);
-                if (STAGE == kStageIncremental && !type_is_incremental(tb.type_id)) { ++done; continue; }
-                stream_constraint_block<STAGE>(tb, i, bodies, P.substep_dt, P.inv_substep_dt, gate);
-                ++done;
-            }
-        }
+        unsigned total = 0, wg_blocks = 0;
+        for (int b = b_first; b <= b_last; ++b) { total += (unsigned)batch_blocks[b]; wg_blocks += owned(batch_blocks[b]); }
         if (total == 0) return;
-        stamp(hop, 2);
-        if (done && alive) hop_arrive(sy, hop, done);
-        stamp(hop, 3);
+        if (wg_blocks > 0) {
+            bool waited = false;
+            stamp(hop, 0);
+            auto gate = [&]() -> bool { return gate_once(waited); };
+            for (int b = b_first; b <= b_last && alive; ++b) {
+                const int blocks = batch_blocks[b];
+                for (int vb = fw; vb < blocks && alive; vb += TW) {
+                    int i;
+                    const DevTypeBatch tb = locate(b, vb, i);
+                    if (STAGE == kStageIncremental && !type_is_incremental(tb.type_id)) continue;
+                    stream_constraint_block<STAGE>(tb, i, bodies, P.substep_dt, P.inv_substep_dt, gate);
+                }
+            }
+            gate();  // wavefronts without a block in this hop meet the others at the barrier all the same
+            if (alive) arrive(wg_blocks);
+        }
         prev_blocks = total;
         ++hop;
     };
     auto body_hop = [&](auto&& per_body) {
-        const unsigned blocks = (unsigned)((P.body_count + 63) / 64);
+        const int blocks = (P.body_count + 63) / 64;
         if (blocks == 0) return;
-        unsigned done = 0;
-        bool waited = false;
-        stamp(hop, 0);
-        for (unsigned vb = (unsigned)w; vb < blocks && alive; vb += (unsigned)G) {
-            const int i = (int)vb * 64 + lane;
-            const unsigned f = i < P.body_count ? flags[i] : 0u;
-            if (!waited) { waited = true; alive = hop_wait(sy, hop - 1, prev_blocks); stamp(hop, 1); }
-            if (!alive) break;
-            if (i < P.body_count) per_body(i, f);
-            ++done;
+        const unsigned wg_blocks = owned(blocks);
+        if (wg_blocks > 0) {
+            bool waited = false;
+            stamp(hop, 0);
+            for (int vb = fw; vb < blocks && alive; vb += TW) {
+                const int i = vb * 64 + lane;
+                const unsigned f = i < P.body_count ? flags[i] : 0u;
+                if (!gate_once(waited)) break;
+                if (i < P.body_count) per_body(i, f);
+            }
+            gate_once(waited);
+            if (alive) arrive(wg_blocks);
         }
-        stamp(hop, 2);
-        if (done && alive) hop_arrive(sy, hop, done);
-        stamp(hop, 3);
-        prev_blocks = blocks;
+        prev_blocks = (unsigned)blocks;
         ++hop;
     };
 
+    // `alive` is uniform over the workgroup after every gate, so all its wavefronts leave the loops (and skip the barriers) together.
     for (int s = 0; s < P.substeps && alive; ++s) {
         if (s > 0 && P.has_incremental) constraint_hop(std::integral_constant<int, kStageIncremental>{}, 0, P.batch_count - 1);
-        body_hop([&](int i, unsigned f) { stream_integrate_body(bodies, f, i, s > 0 ? 1 : 0, P.integrate_velocity_for_kinematics, P.sp); });
+        if (alive) body_hop([&](int i, unsigned f) { stream_integrate_body(bodies, f, i, s > 0 ? 1 : 0, P.integrate_velocity_for_kinematics, P.sp); });
         for (int b = 0; b < P.batch_count && alive; ++b) constraint_hop(std::integral_constant<int, kStageWarmStart>{}, b, b);
         for (int it = 0; it < P.iters[s] && alive; ++it)
             for (int b = 0; b < P.batch_count && alive; ++b) constraint_hop(std::integral_constant<int, kStageSolve>{}, b, b);

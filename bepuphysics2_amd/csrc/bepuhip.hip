@@ -383,10 +383,10 @@ static int32_t build_constraints(bepuhip_ctx* c) {
     if (c->stream_enabled) {
         HIP_TRY(upload_ints(c->batch_begin.data(), c->batch_begin.size() * 4, (void**)&c->d_batch_begin));
         HIP_TRY(upload_ints(c->batch_blocks.data(), c->batch_blocks.size() * 4, (void**)&c->d_batch_blocks));
-        if (c->stream_waves == 0) {  // every wavefront of the launch must be resident: occupancy x CUs
+        if (c->stream_waves == 0) {  // every workgroup of the launch must be resident: occupancy x CUs
             int per_cu = 0;
             hipDeviceProp_t prop;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel, 64, 0));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel, 64 * kStreamWaves, 0));
             HIP_TRY(hipGetDeviceProperties(&prop, c->device));
             c->stream_waves = std::max(1, per_cu * prop.multiProcessorCount);
         }
@@ -487,7 +487,7 @@ static int32_t enqueue_stream(bepuhip_ctx* c, float dt, int substeps, const int3
     const int waves = std::max(1, std::min(c->stream_waves, env_int("BEPUHIP_STREAM_WAVES", c->stream_waves)));
     void* args[] = {(void*)&c->d_tbs, (void*)&c->d_batch_begin, (void*)&c->d_batch_blocks, (void*)&c->d_bodies, (void*)&c->d_flags, (void*)&sy, (void*)&P};
     Timed t(c, 5);
-    HIP_TRY(hipLaunchCooperativeKernel((const void*)stream_kernel, dim3(waves), dim3(64), args, 0, c->stream));
+    HIP_TRY(hipLaunchCooperativeKernel((const void*)stream_kernel, dim3(waves), dim3(64 * kStreamWaves), args, 0, c->stream));
     return BEPUHIP_OK;
 }
 
