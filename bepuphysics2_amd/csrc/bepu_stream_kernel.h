@@ -82,6 +82,53 @@ __device__ __forceinline__ void sc1_load_velocity2(const float4* baseA, const fl
 // (the s_nop covers the wait state a wide VMEM store needs before its data registers may be rewritten; the compiler cannot see inside the asm)
 __device__ __forceinline__ void sc1_store(float4* p, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 
+// ---- cooperative gather: whole 128-byte records, eight lanes per record, staged through LDS ----
+// A lane that fetches the planes of its own bodies sends one 16-byte request per plane: 8-12 uncached requests per constraint, and the request rate
+// of the fabric, not its bandwidth, is what a hop then waits for. Here eight consecutive lanes fetch the eight planes of ONE record (a single
+// 128-byte request), the wavefront's 64 or 128 records land in its LDS slice plane-major, and every lane reads the planes its constraint needs from there.
+typedef int i4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f4 lds_f4;
+constexpr int kStagePlaneStride = 129;                    // 128 record slots + one: the eight planes a lane group writes fall into different banks
+constexpr int kStageWaveF4 = 8 * kStagePlaneStride;       // one wavefront's slice, in 16-byte units
+struct StreamCtx {
+    __amdgpu_buffer_rsrc_t rsrc;  // the body array as a raw buffer: 128-bit loads with the sc1 bit, compiler-managed waits, out-of-range reads return 0
+    lds_f4* stage;                // this wavefront's LDS slice
+    int lane;
+};
+constexpr int kAuxSc1 = 16;  // cache-policy operand of the raw buffer builtins on gfx94x/gfx950: bit 0 sc0, bit 1 nt, bit 4 sc1
+
+// Byte offsets of the requests this lane sends for a block of constraints (slot j < 64: body A of lane j, slot 64 + j: body B of lane j).
+template <int NB>
+__device__ __forceinline__ void stage_offsets(int refA, int refB, int lane, int (&off)[NB * 8]) {
+    const int sub = lane >> 3, plane = lane & 7;
+    _Pragma("unroll") for (int r = 0; r < NB * 8; ++r) {
+        const int ref = __shfl(r < 8 ? refA : refB, (r & 7) * 8 + sub);
+        off[r] = (ref & kRefMask) * 128 + plane * 16;
+    }
+}
+template <int ROUNDS>
+__device__ __forceinline__ void stage_records(const StreamCtx& cx, const int (&off)[ROUNDS]) {
+    i4 v[ROUNDS];
+    _Pragma("unroll") for (int r = 0; r < ROUNDS; ++r) v[r] = __builtin_amdgcn_raw_buffer_load_b128(cx.rsrc, off[r], 0, kAuxSc1);
+    const int sub = cx.lane >> 3, plane = cx.lane & 7;
+    _Pragma("unroll") for (int r = 0; r < ROUNDS; ++r) {
+        const f4 t = {__int_as_float(v[r].x), __int_as_float(v[r].y), __int_as_float(v[r].z), __int_as_float(v[r].w)};
+        cx.stage[plane * kStagePlaneStride + r * 8 + sub] = t;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is written before any lane of this wavefront reads it (LDS serves a wavefront in order)
+    __builtin_amdgcn_wave_barrier();
+}
+template <int ACCESS>
+__device__ __forceinline__ void staged_planes(const StreamCtx& cx, int slot, BodyPlanes& r) {  // only the planes load_body<ACCESS> would gather
+    const f4 zero = make_f4(0, 0, 0, 0);
+    r.ori = (ACCESS & kOri) ? cx.stage[0 * kStagePlaneStride + slot] : zero;
+    r.pos = (ACCESS & kPos) ? cx.stage[1 * kStagePlaneStride + slot] : zero;
+    r.lin = (ACCESS & kLin) ? cx.stage[2 * kStagePlaneStride + slot] : zero;
+    r.ang = (ACCESS & kAng) ? cx.stage[3 * kStagePlaneStride + slot] : zero;
+    r.w0 = (ACCESS & kInertia) ? cx.stage[6 * kStagePlaneStride + slot] : zero;
+    r.w1 = (ACCESS & kInertia) ? cx.stage[7 * kStagePlaneStride + slot] : zero;
+}
+
 template <int ACCESS>
 __device__ __forceinline__ void planes_to_body(const BodyPlanes& r, DBody& b) {  // the same field selection as load_body<ACCESS>
     if (ACCESS & kOri) b.ori = {r.ori.x, r.ori.y, r.ori.z, r.ori.w}; else b.ori = {0, 0, 0, 0};
@@ -140,7 +187,7 @@ __device__ __forceinline__ bool type_is_incremental(int type_id) { return type_i
 // The gate is called once per block, by all 64 lanes, after the block's own rows (references, prestep, accumulated impulses: never shared) have been
 // requested and before the first body access: it is where the wavefront waits for the previous hop.
 template <class F, int STAGE, class GATE>
-__device__ __forceinline__ bool stream_constraint(const DevTypeBatch& tb, int i, float4* bodies, float dt, float inv_dt, GATE&& gate) {
+__device__ __forceinline__ bool stream_constraint(const DevTypeBatch& tb, int i, float4* bodies, const StreamCtx& cx, float dt, float inv_dt, GATE&& gate) {
     const int stride = tb.stride;
     const bool valid = i < tb.count;
     const int row = valid ? i : 0;
@@ -152,10 +199,12 @@ __device__ __forceinline__ bool stream_constraint(const DevTypeBatch& tb, int i,
     if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = tb.accum[(size_t)f * stride + row]; }
     const float4* baseA = bodies + (size_t)(refA & kRefMask) * 8;
     const float4* baseB = bodies + (size_t)(refB & kRefMask) * 8;
+    int off[F::bodies * 8];
+    if (STAGE != kStageIncremental) stage_offsets<F::bodies>(refA, refB, cx.lane, off);
     if (!gate()) return false;
-    if (!valid) return true;
     DBody A, B;
     if (STAGE == kStageIncremental) {
+        if (!valid) return true;
         if constexpr (F::incremental) {
             f4 la, aa, lb, ab;
             sc1_load_velocity2(baseA, baseB, la, aa, lb, ab);
@@ -168,13 +217,12 @@ __device__ __forceinline__ bool stream_constraint(const DevTypeBatch& tb, int i,
     }
     constexpr int accA = (STAGE == kStageWarmStart) ? F::wsA : F::svA;
     constexpr int accB = (STAGE == kStageWarmStart) ? F::wsB : F::svB;
+    stage_records<F::bodies * 8>(cx, off);  // every lane fetches for its lane group, valid constraint or not
+    if (!valid) return true;
     BodyPlanes ra, rb;
-    constexpr bool kPoseFree = ((accA | accB) & (kPos | kOri)) == 0;
-    if (F::bodies == 2 && kPoseFree) sc1_load_body2_nopose(baseA, baseB, ra, rb);
-    else if (F::bodies == 2) sc1_load_body2(baseA, baseB, ra, rb);
-    else sc1_load_body(baseA, ra);
+    staged_planes<accA>(cx, cx.lane, ra);
     planes_to_body<accA>(ra, A);
-    if (F::bodies == 2) planes_to_body<accB>(rb, B); else planes_to_body<0>(ra, B);
+    if (F::bodies == 2) { staged_planes<accB>(cx, 64 + cx.lane, rb); planes_to_body<accB>(rb, B); } else planes_to_body<0>(ra, B);
     if (STAGE == kStageWarmStart) {
         F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, NoGate{});
     } else {
@@ -187,21 +235,21 @@ __device__ __forceinline__ bool stream_constraint(const DevTypeBatch& tb, int i,
 }
 
 template <int STAGE, class GATE>
-__device__ __forceinline__ bool stream_constraint_block(const DevTypeBatch& tb, int i, float4* bodies, float dt, float inv_dt, GATE&& gate) {
+__device__ __forceinline__ bool stream_constraint_block(const DevTypeBatch& tb, int i, float4* bodies, const StreamCtx& cx, float dt, float inv_dt, GATE&& gate) {
     switch (tb.type_id) {
-        case kContact1OneBody: return stream_constraint<Contact<1, false>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
-        case kContact2OneBody: return stream_constraint<Contact<2, false>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
-        case kContact3OneBody: return stream_constraint<Contact<3, false>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
-        case kContact4OneBody: return stream_constraint<Contact<4, false>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
-        case kContact1: return stream_constraint<Contact<1, true>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
-        case kContact2: return stream_constraint<Contact<2, true>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
-        case kContact3: return stream_constraint<Contact<3, true>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
-        case kContact4: return stream_constraint<Contact<4, true>, STAGE>(tb, i, bodies, dt, inv_dt, gate);
+        case kContact1OneBody: return stream_constraint<Contact<1, false>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact2OneBody: return stream_constraint<Contact<2, false>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact3OneBody: return stream_constraint<Contact<3, false>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact4OneBody: return stream_constraint<Contact<4, false>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact1: return stream_constraint<Contact<1, true>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact2: return stream_constraint<Contact<2, true>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact3: return stream_constraint<Contact<3, true>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact4: return stream_constraint<Contact<4, true>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
         default: break;
     }
     if (STAGE != kStageIncremental) {
         switch (tb.type_id) {
-#define X(ID, T) case ID: return stream_constraint<T, STAGE>(tb, i, bodies, dt, inv_dt, gate);
+#define X(ID, T) case ID: return stream_constraint<T, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
             BD_HOT_JOINT_TYPES(X)
 #undef X
             default: break;
@@ -211,12 +259,20 @@ __device__ __forceinline__ bool stream_constraint_block(const DevTypeBatch& tb, 
 }
 
 // ---- body blocks: substep_integrate_kernel / final_integrate_kernel, one lane per body, on sc1 accesses ----
-__device__ __forceinline__ void stream_integrate_body(float4* bodies, unsigned f, int i, int integrate_pose, int integrate_velocity_for_kinematics, const StepParams& sp) {
+// The 64 records of a body block are contiguous: eight coalesced 1 KiB requests per wavefront bring them into the LDS slice (slot = body - first).
+__device__ __forceinline__ void stage_body_block(const StreamCtx& cx, int first_body) {
+    int off[8];
+    _Pragma("unroll") for (int r = 0; r < 8; ++r) off[r] = (first_body + r * 8 + (cx.lane >> 3)) * 128 + (cx.lane & 7) * 16;
+    stage_records<8>(cx, off);
+}
+__device__ __forceinline__ void stream_integrate_body(float4* bodies, const StreamCtx& cx, unsigned f, int i, int integrate_pose, int integrate_velocity_for_kinematics,
+                                                      const StepParams& sp) {
     if (!(f & (kFlagDynamicConstrained | kFlagConstrainedKinematic))) return;
     float4* base = bodies + (size_t)i * 8;
-    const float4 i0 = base[4], i1 = base[5];  // local inverse inertia: never written
+    const f4 l0 = cx.stage[4 * kStagePlaneStride + cx.lane], l1 = cx.stage[5 * kStagePlaneStride + cx.lane];  // local inverse inertia: never written
+    const float4 i0 = make_float4(l0.x, l0.y, l0.z, l0.w), i1 = make_float4(l1.x, l1.y, l1.z, l1.w);
     BodyPlanes r;
-    sc1_load_body(base, r);
+    staged_planes<kAccessAll>(cx, cx.lane, r);
     BodyRegs b = {{r.ori.x, r.ori.y, r.ori.z, r.ori.w}, {r.pos.x, r.pos.y, r.pos.z}, {{r.lin.x, r.lin.y, r.lin.z}, {r.ang.x, r.ang.y, r.ang.z}}};
     if (f & kFlagDynamicConstrained) {
         const Sym3 world = substep_integrate_dynamic(b, i0, i1, integrate_pose, sp);
@@ -240,12 +296,13 @@ __device__ __forceinline__ void stream_integrate_body(float4* bodies, unsigned f
         }
     }
 }
-__device__ __forceinline__ void stream_final_body(float4* bodies, unsigned f, int i, float dt, float substep_dt, int substep_count, int allow_substeps_for_unconstrained,
-                                                  int integrate_velocity_for_kinematics, const StepParams& sp) {
+__device__ __forceinline__ void stream_final_body(float4* bodies, const StreamCtx& cx, unsigned f, int i, float dt, float substep_dt, int substep_count,
+                                                  int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, const StepParams& sp) {
     float4* base = bodies + (size_t)i * 8;
-    const float4 i0 = base[4], i1 = base[5];
+    const f4 l0 = cx.stage[4 * kStagePlaneStride + cx.lane], l1 = cx.stage[5 * kStagePlaneStride + cx.lane];
+    const float4 i0 = make_float4(l0.x, l0.y, l0.z, l0.w), i1 = make_float4(l1.x, l1.y, l1.z, l1.w);
     BodyPlanes r;
-    sc1_load_body(base, r);
+    staged_planes<kAccessAll>(cx, cx.lane, r);
     BodyRegs b = {{r.ori.x, r.ori.y, r.ori.z, r.ori.w}, {r.pos.x, r.pos.y, r.pos.z}, {{r.lin.x, r.lin.y, r.lin.z}, {r.ang.x, r.ang.y, r.ang.z}}};
     const bool velocity_written = final_integrate_regs(b, f, i0, i1, dt, substep_dt, substep_count, allow_substeps_for_unconstrained, integrate_velocity_for_kinematics, sp);
     if (velocity_written) {
@@ -274,7 +331,12 @@ constexpr int kStreamWaves = 8;
 __global__ __launch_bounds__(64 * kStreamWaves) void stream_kernel(const DevTypeBatch* __restrict__ tbs, const int* __restrict__ batch_begin, const int* __restrict__ batch_blocks,
                                                                    float4* bodies, const unsigned* __restrict__ flags, StreamSync sy, StreamParams P) {
     __shared__ int s_alive;
+    extern __shared__ __attribute__((aligned(16))) f4 s_stage[];  // kStreamWaves slices of kStageWaveF4 (host passes the size)
     const int wg = blockIdx.x, NWG = gridDim.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    StreamCtx cx;
+    cx.rsrc = __builtin_amdgcn_make_buffer_rsrc(bodies, 0, P.body_count * 128, 0x00020000);  // gfx9 raw-buffer descriptor word 3 (32-bit data format)
+    cx.stage = (lds_f4*)s_stage + wv * kStageWaveF4;
+    cx.lane = lane;
     const int fw = wg + NWG * wv, TW = NWG * kStreamWaves;  // this wavefront's place in the deal, and the deal's period
     // traced workgroups (wavefront 0 of each): the first, one in the middle, the last; stamps: reached the hop, passed the gate, finished the blocks, arrived
     const int traced = (sy.trace == nullptr || wv != 0) ? -1 : (wg == 0 ? 0 : (wg == NWG / 2 ? 1 : (wg == NWG - 1 ? 2 : -1)));
@@ -332,7 +394,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void stream_kernel(const DevType
                     int i;
                     const DevTypeBatch tb = locate(b, vb, i);
                     if (STAGE == kStageIncremental && !type_is_incremental(tb.type_id)) continue;
-                    stream_constraint_block<STAGE>(tb, i, bodies, P.substep_dt, P.inv_substep_dt, gate);
+                    stream_constraint_block<STAGE>(tb, i, bodies, cx, P.substep_dt, P.inv_substep_dt, gate);
                 }
             }
             gate();  // wavefronts without a block in this hop meet the others at the barrier all the same
@@ -352,6 +414,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void stream_kernel(const DevType
                 const int i = vb * 64 + lane;
                 const unsigned f = i < P.body_count ? flags[i] : 0u;
                 if (!gate_once(waited)) break;
+                stage_body_block(cx, vb * 64);
                 if (i < P.body_count) per_body(i, f);
             }
             gate_once(waited);
@@ -364,14 +427,14 @@ __global__ __launch_bounds__(64 * kStreamWaves) void stream_kernel(const DevType
     // `alive` is uniform over the workgroup after every gate, so all its wavefronts leave the loops (and skip the barriers) together.
     for (int s = 0; s < P.substeps && alive; ++s) {
         if (s > 0 && P.has_incremental) constraint_hop(std::integral_constant<int, kStageIncremental>{}, 0, P.batch_count - 1);
-        if (alive) body_hop([&](int i, unsigned f) { stream_integrate_body(bodies, f, i, s > 0 ? 1 : 0, P.integrate_velocity_for_kinematics, P.sp); });
+        if (alive) body_hop([&](int i, unsigned f) { stream_integrate_body(bodies, cx, f, i, s > 0 ? 1 : 0, P.integrate_velocity_for_kinematics, P.sp); });
         for (int b = 0; b < P.batch_count && alive; ++b) constraint_hop(std::integral_constant<int, kStageWarmStart>{}, b, b);
         for (int it = 0; it < P.iters[s] && alive; ++it)
             for (int b = 0; b < P.batch_count && alive; ++b) constraint_hop(std::integral_constant<int, kStageSolve>{}, b, b);
     }
     if (alive)
         body_hop([&](int i, unsigned f) {
-            stream_final_body(bodies, f, i, P.frame_dt, P.substep_dt, P.substeps, P.allow_substeps_for_unconstrained, P.integrate_velocity_for_kinematics, P.final_sp);
+            stream_final_body(bodies, cx, f, i, P.frame_dt, P.substep_dt, P.substeps, P.allow_substeps_for_unconstrained, P.integrate_velocity_for_kinematics, P.final_sp);
         });
 }
 

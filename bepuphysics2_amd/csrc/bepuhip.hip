@@ -386,7 +386,9 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         if (c->stream_waves == 0) {  // every workgroup of the launch must be resident: occupancy x CUs
             int per_cu = 0;
             hipDeviceProp_t prop;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel, 64 * kStreamWaves, 0));
+            constexpr size_t kStreamLdsBytes = (size_t)kStreamWaves * kStageWaveF4 * 16;
+            HIP_TRY(hipFuncSetAttribute((const void*)stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStreamLdsBytes));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel, 64 * kStreamWaves, kStreamLdsBytes));
             HIP_TRY(hipGetDeviceProperties(&prop, c->device));
             c->stream_waves = std::max(1, per_cu * prop.multiProcessorCount);
         }
@@ -456,7 +458,8 @@ static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const be
 }
 // The stream schedule covers what the island schedule cannot take (an island larger than one workgroup's LDS), in the nonconserving mode.
 static bool stream_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
-    return c->stream_enabled && !island_schedule_applies(c, substeps, in) && substeps <= kMaxStreamSubsteps && in->angular_integration_mode == 0;
+    return c->stream_enabled && !island_schedule_applies(c, substeps, in) && substeps <= kMaxStreamSubsteps && in->angular_integration_mode == 0 &&
+           c->body_count <= (1 << 24);  // 32-bit byte offsets into the body buffer
 }
 
 // One cooperative launch for the whole step (bepu_stream_kernel.h); the arrival counters are cleared in stream order before it.
@@ -487,7 +490,7 @@ static int32_t enqueue_stream(bepuhip_ctx* c, float dt, int substeps, const int3
     const int waves = std::max(1, std::min(c->stream_waves, env_int("BEPUHIP_STREAM_WAVES", c->stream_waves)));
     void* args[] = {(void*)&c->d_tbs, (void*)&c->d_batch_begin, (void*)&c->d_batch_blocks, (void*)&c->d_bodies, (void*)&c->d_flags, (void*)&sy, (void*)&P};
     Timed t(c, 5);
-    HIP_TRY(hipLaunchCooperativeKernel((const void*)stream_kernel, dim3(waves), dim3(64 * kStreamWaves), args, 0, c->stream));
+    HIP_TRY(hipLaunchCooperativeKernel((const void*)stream_kernel, dim3(waves), dim3(64 * kStreamWaves), args, (size_t)kStreamWaves * kStageWaveF4 * 16, c->stream));
     return BEPUHIP_OK;
 }
 
