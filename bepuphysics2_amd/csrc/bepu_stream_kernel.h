@@ -6,7 +6,7 @@
 // What makes that cheap on a part with eight L2s (tools/probes/xcd_handoff_probe.hip, profiles/r01_xcd_handoff_probe.txt): body records that cross
 // workgroups are only ever moved with agent-scope (sc1) loads and stores, which bypass the per-CU L1 and are coherent across the XCDs without any
 // release/acquire fence (no L2 write-back / invalidate: 1.5 us per hand-off instead of 4.8-5.3 us). Per-constraint data (prestep, accumulated
-// impulses) never crosses wavefronts inside a launch: block `vb` of batch `b` is run by wavefront vb % G in every hop, so plain cached accesses
+// impulses) never crosses wavefronts inside a launch: block `vb` of batch `b` is run by the same wavefront in every hop, so plain cached accesses
 // are coherent for it by construction.
 #pragma once
 
