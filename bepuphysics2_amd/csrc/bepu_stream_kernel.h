@@ -166,6 +166,8 @@ __device__ __forceinline__ unsigned wave_sum16(unsigned v) {  // sum over lanes 
 __device__ __forceinline__ bool hop_wait(const StreamSync& sy, int hop, unsigned expected, int lane) {
     if (hop < 0) return true;
     unsigned* line = sy.counters + (size_t)hop * kHopLanes;
+    // (Polls share a memory channel with the arrivals they wait for. The poller is wavefront 0, which reaches this point after the velocity-independent
+    // half of its own block: late enough that pacing the polls, or a pause before the first one, measured no better.)
     for (unsigned spins = 0;; ++spins) {
         const unsigned v = lane < kHopLanes ? __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         if (wave_sum16(v) >= expected) return true;
@@ -186,7 +188,28 @@ __device__ __forceinline__ bool type_is_incremental(int type_id) { return type_i
 // ---- constraint blocks ----
 // The gate is called once per block, by all 64 lanes, after the block's own rows (references, prestep, accumulated impulses: never shared) have been
 // requested and before the first body access: it is where the wavefront waits for the previous hop.
-template <class F, int STAGE, class GATE>
+// The gate handed INTO a constraint function (the island schedule's idea, bepu_cluster_kernel.h): poses, inertias and everything the function derives
+// from them and from its prestep rows are computed before it is called; it waits for the previous hop and fetches the velocities, nothing else.
+// Legal whenever the previous hop was not an integration hop (poses and inertias only change there).
+template <int ACC_A, int ACC_B, int BODIES, class WAIT>
+struct StreamGate {
+    static constexpr bool kPin = true;
+    const float4* baseA; const float4* baseB; DBody& A; DBody& B; WAIT& wait; bool& ok;
+    __device__ __forceinline__ void operator()(BodyVel& vA, BodyVel& vB) const {
+        ok = wait();
+        f4 la, aa, lb, ab;
+        sc1_load_velocity2(baseA, baseB, la, aa, lb, ab);
+        if (ACC_A & kLin) { vA.lin = {la.x, la.y, la.z}; A.linw = la.w; }
+        if (ACC_A & kAng) { vA.ang = {aa.x, aa.y, aa.z}; A.angw = aa.w; }
+        if (BODIES == 2) {
+            if (ACC_B & kLin) { vB.lin = {lb.x, lb.y, lb.z}; B.linw = lb.w; }
+            if (ACC_B & kAng) { vB.ang = {ab.x, ab.y, ab.z}; B.angw = ab.w; }
+        }
+    }
+};
+
+// PRE: the block may read poses and inertias before the hop wait (see StreamGate).
+template <class F, int STAGE, bool PRE, class GATE>
 __device__ __forceinline__ bool stream_constraint(const DevTypeBatch& tb, int i, float4* bodies, const StreamCtx& cx, float dt, float inv_dt, GATE&& gate) {
     const int stride = tb.stride;
     const bool valid = i < tb.count;
@@ -201,8 +224,29 @@ __device__ __forceinline__ bool stream_constraint(const DevTypeBatch& tb, int i,
     const float4* baseB = bodies + (size_t)(refB & kRefMask) * 8;
     int off[F::bodies * 8];
     if (STAGE != kStageIncremental) stage_offsets<F::bodies>(refA, refB, cx.lane, off);
-    if (!gate()) return false;
     DBody A, B;
+    if constexpr (PRE && STAGE != kStageIncremental) {
+        constexpr int accA = (STAGE == kStageWarmStart) ? F::wsA : F::svA;
+        constexpr int accB = (STAGE == kStageWarmStart) ? F::wsB : F::svB;
+        constexpr int kStatic = ~(kLin | kAng);
+        stage_records<F::bodies * 8>(cx, off);  // the velocity planes that come along may be stale: they are not read
+        BodyPlanes ra, rb;
+        staged_planes<accA & kStatic>(cx, cx.lane, ra);
+        planes_to_body<accA & kStatic>(ra, A);
+        if (F::bodies == 2) { staged_planes<accB & kStatic>(cx, 64 + cx.lane, rb); planes_to_body<accB & kStatic>(rb, B); } else planes_to_body<0>(ra, B);
+        bool ok = true;
+        StreamGate<accA, accB, F::bodies, std::remove_reference_t<GATE>> inner{baseA, baseB, A, B, gate, ok};
+        // lanes past the end of the type batch run the function on row 0 with a full exec mask (the wait inside is wave-wide) and store nothing
+        if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, inner);
+        else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, inner);
+        if (!ok) return false;
+        if (!valid) return true;
+        if (STAGE == kStageSolve) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) tb.accum[(size_t)f * stride + i] = a[f]; }
+        sc1_store_velocity<accA>(bodies, refA, A);
+        if (F::bodies == 2) sc1_store_velocity<accB>(bodies, refB, B);
+        return true;
+    }
+    if (!gate()) return false;
     if (STAGE == kStageIncremental) {
         if (!valid) return true;
         if constexpr (F::incremental) {
@@ -234,22 +278,22 @@ __device__ __forceinline__ bool stream_constraint(const DevTypeBatch& tb, int i,
     return true;
 }
 
-template <int STAGE, class GATE>
+template <int STAGE, bool PRE, class GATE>
 __device__ __forceinline__ bool stream_constraint_block(const DevTypeBatch& tb, int i, float4* bodies, const StreamCtx& cx, float dt, float inv_dt, GATE&& gate) {
     switch (tb.type_id) {
-        case kContact1OneBody: return stream_constraint<Contact<1, false>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
-        case kContact2OneBody: return stream_constraint<Contact<2, false>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
-        case kContact3OneBody: return stream_constraint<Contact<3, false>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
-        case kContact4OneBody: return stream_constraint<Contact<4, false>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
-        case kContact1: return stream_constraint<Contact<1, true>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
-        case kContact2: return stream_constraint<Contact<2, true>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
-        case kContact3: return stream_constraint<Contact<3, true>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
-        case kContact4: return stream_constraint<Contact<4, true>, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact1OneBody: return stream_constraint<Contact<1, false>, STAGE, PRE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact2OneBody: return stream_constraint<Contact<2, false>, STAGE, PRE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact3OneBody: return stream_constraint<Contact<3, false>, STAGE, PRE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact4OneBody: return stream_constraint<Contact<4, false>, STAGE, PRE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact1: return stream_constraint<Contact<1, true>, STAGE, PRE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact2: return stream_constraint<Contact<2, true>, STAGE, PRE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact3: return stream_constraint<Contact<3, true>, STAGE, PRE>(tb, i, bodies, cx, dt, inv_dt, gate);
+        case kContact4: return stream_constraint<Contact<4, true>, STAGE, PRE>(tb, i, bodies, cx, dt, inv_dt, gate);
         default: break;
     }
     if (STAGE != kStageIncremental) {
         switch (tb.type_id) {
-#define X(ID, T) case ID: return stream_constraint<T, STAGE>(tb, i, bodies, cx, dt, inv_dt, gate);
+#define X(ID, T) case ID: return stream_constraint<T, STAGE, PRE>(tb, i, bodies, cx, dt, inv_dt, gate);
             BD_HOT_JOINT_TYPES(X)
 #undef X
             default: break;
@@ -344,6 +388,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void stream_kernel(const DevType
         if (traced >= 0 && lane == 0 && h < kStreamTraceHops) sy.trace[((size_t)traced * kStreamTraceHops + h) * 4 + k] = wall_clock64();
     };
     int hop = 0;               // index of the hop being run; it may start once hop - 1 is complete
+    bool after_body_hop = true;  // the previous hop integrated bodies (or nothing ran yet): poses and inertias may not be read before the wait
     unsigned prev_blocks = 0;  // arrivals that complete hop - 1
     bool alive = true;
 
@@ -368,6 +413,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void stream_kernel(const DevType
         stamp(hop, 3);
     };
     auto owned = [&](int blocks) -> unsigned { return blocks > wg ? (unsigned)((blocks - wg + NWG - 1) / NWG) : 0u; };  // blocks of a grid this workgroup runs
+    // (Dealing consecutive batches to consecutive wavefronts, so that the hop over all batches spreads out, was measured and dropped: wavefront 0 then
+    // owns no block in most hops, starts polling at once, and 256 such pollers delay the arrivals they wait for: 0.86 -> 1.14 ms per step.)
 
     // (batch b, block vb) -> type batch and first constraint, as batch_kernel resolves blockIdx
     auto locate = [&](int b, int vb, int& i) -> DevTypeBatch {
@@ -394,13 +441,16 @@ __global__ __launch_bounds__(64 * kStreamWaves) void stream_kernel(const DevType
                     int i;
                     const DevTypeBatch tb = locate(b, vb, i);
                     if (STAGE == kStageIncremental && !type_is_incremental(tb.type_id)) continue;
-                    stream_constraint_block<STAGE>(tb, i, bodies, cx, P.substep_dt, P.inv_substep_dt, gate);
+                    if (STAGE == kStageSolve) stream_constraint_block<STAGE, true>(tb, i, bodies, cx, P.substep_dt, P.inv_substep_dt, gate);  // never follows an integration hop
+                    else if (STAGE == kStageWarmStart && !after_body_hop) stream_constraint_block<STAGE, true>(tb, i, bodies, cx, P.substep_dt, P.inv_substep_dt, gate);
+                    else stream_constraint_block<STAGE, false>(tb, i, bodies, cx, P.substep_dt, P.inv_substep_dt, gate);
                 }
             }
             gate();  // wavefronts without a block in this hop meet the others at the barrier all the same
             if (alive) arrive(wg_blocks);
         }
         prev_blocks = total;
+        after_body_hop = false;
         ++hop;
     };
     auto body_hop = [&](auto&& per_body) {
@@ -421,6 +471,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void stream_kernel(const DevType
             if (alive) arrive(wg_blocks);
         }
         prev_blocks = (unsigned)blocks;
+        after_body_hop = true;
         ++hop;
     };
 
