@@ -3,11 +3,11 @@
 // hops, which the launch-per-batch schedule gets from kernel boundaries (8.7 us per dependent launch on a 100k-box pile), comes from an arrival
 // counter per hop instead.
 //
-// What makes that cheap on a part with eight L2s (tools/probes/xcd_handoff_probe.hip, profiles/r01_xcd_handoff_probe.txt): body records that cross
+// What makes that possible on a part with eight L2s (tools/probes/xcd_handoff_probe.hip, profiles/r01_xcd_handoff_probe.txt): body records that cross
 // workgroups are only ever moved with agent-scope (sc1) loads and stores, which bypass the per-CU L1 and are coherent across the XCDs without any
 // release/acquire fence (no L2 write-back / invalidate: 1.5 us per hand-off instead of 4.8-5.3 us). Per-constraint data (prestep, accumulated
 // impulses) never crosses wavefronts inside a launch: block `vb` of batch `b` is run by the same wavefront in every hop, so plain cached accesses
-// are coherent for it by construction.
+// are coherent for it by construction. Opt-in (BEPUHIP_FLAG_STREAM): bit-exact, 10 % slower than the graph replay on the pile.
 #pragma once
 
 namespace {
@@ -17,57 +17,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 struct BodyPlanes { f4 ori, pos, lin, ang, w0, w1; };  // planes 0,1,2,3,6,7 of the 128-byte body record
 __device__ __forceinline__ f4 make_f4(float x, float y, float z, float w) { f4 r = {x, y, z, w}; return r; }
 
-// One asm statement per burst: the loads AND the wait, so that the compiler can never touch a destination register before its data has landed.
-__device__ __forceinline__ void sc1_load_body(const float4* base, BodyPlanes& r) {
-    asm volatile(
-        "global_load_dwordx4 %0, %6, off sc1\n\t"
-        "global_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
-        "global_load_dwordx4 %2, %6, off offset:32 sc1\n\t"
-        "global_load_dwordx4 %3, %6, off offset:48 sc1\n\t"
-        "global_load_dwordx4 %4, %6, off offset:96 sc1\n\t"
-        "global_load_dwordx4 %5, %6, off offset:112 sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(r.ori), "=&v"(r.pos), "=&v"(r.lin), "=&v"(r.ang), "=&v"(r.w0), "=&v"(r.w1)
-        : "v"(base)
-        : "memory");
-}
-__device__ __forceinline__ void sc1_load_body2(const float4* baseA, const float4* baseB, BodyPlanes& a, BodyPlanes& b) {
-    asm volatile(
-        "global_load_dwordx4 %0, %12, off sc1\n\t"
-        "global_load_dwordx4 %1, %12, off offset:16 sc1\n\t"
-        "global_load_dwordx4 %2, %12, off offset:32 sc1\n\t"
-        "global_load_dwordx4 %3, %12, off offset:48 sc1\n\t"
-        "global_load_dwordx4 %4, %12, off offset:96 sc1\n\t"
-        "global_load_dwordx4 %5, %12, off offset:112 sc1\n\t"
-        "global_load_dwordx4 %6, %13, off sc1\n\t"
-        "global_load_dwordx4 %7, %13, off offset:16 sc1\n\t"
-        "global_load_dwordx4 %8, %13, off offset:32 sc1\n\t"
-        "global_load_dwordx4 %9, %13, off offset:48 sc1\n\t"
-        "global_load_dwordx4 %10, %13, off offset:96 sc1\n\t"
-        "global_load_dwordx4 %11, %13, off offset:112 sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(a.ori), "=&v"(a.pos), "=&v"(a.lin), "=&v"(a.ang), "=&v"(a.w0), "=&v"(a.w1), "=&v"(b.ori), "=&v"(b.pos), "=&v"(b.lin), "=&v"(b.ang), "=&v"(b.w0),
-          "=&v"(b.w1)
-        : "v"(baseA), "v"(baseB)
-        : "memory");
-}
-// The planes a constraint that never reads poses needs (kAccessNoPose and its subsets: the contacts): two thirds of the requests.
-__device__ __forceinline__ void sc1_load_body2_nopose(const float4* baseA, const float4* baseB, BodyPlanes& a, BodyPlanes& b) {
-    asm volatile(
-        "global_load_dwordx4 %0, %8, off offset:32 sc1\n\t"
-        "global_load_dwordx4 %1, %8, off offset:48 sc1\n\t"
-        "global_load_dwordx4 %2, %8, off offset:96 sc1\n\t"
-        "global_load_dwordx4 %3, %8, off offset:112 sc1\n\t"
-        "global_load_dwordx4 %4, %9, off offset:32 sc1\n\t"
-        "global_load_dwordx4 %5, %9, off offset:48 sc1\n\t"
-        "global_load_dwordx4 %6, %9, off offset:96 sc1\n\t"
-        "global_load_dwordx4 %7, %9, off offset:112 sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(a.lin), "=&v"(a.ang), "=&v"(a.w0), "=&v"(a.w1), "=&v"(b.lin), "=&v"(b.ang), "=&v"(b.w0), "=&v"(b.w1)
-        : "v"(baseA), "v"(baseB)
-        : "memory");
-    a.ori = a.pos = b.ori = b.pos = make_f4(0, 0, 0, 0);
-}
+// Velocities of the two bodies of a constraint, fetched by the lane that owns it. One asm statement for the loads AND the wait, so that the compiler
+// can never touch a destination register before its data has landed.
 __device__ __forceinline__ void sc1_load_velocity2(const float4* baseA, const float4* baseB, f4& linA, f4& angA, f4& linB, f4& angB) {
     asm volatile(
         "global_load_dwordx4 %0, %4, off offset:32 sc1\n\t"
