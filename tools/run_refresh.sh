@@ -2,6 +2,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
+(rocm-smi --showmemorypartition --showcomputepartition --showclocks --showmemvendor 2>&1 | grep -v '^$') > gpurun_out/final/rocm_smi.txt  # which class of box this is
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
 timeout 600 python bench.py --steps 100 --warmup 20 > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
 tail -3 gpurun_out/final/bench.err; cat gpurun_out/final/bench.json
