@@ -459,7 +459,7 @@ static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const be
 // The stream schedule covers what the island schedule cannot take (an island larger than one workgroup's LDS), in the nonconserving mode.
 static bool stream_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
     return c->stream_enabled && !island_schedule_applies(c, substeps, in) && substeps <= kMaxStreamSubsteps && in->angular_integration_mode == 0 &&
-           c->body_count <= (1 << 24);  // 32-bit byte offsets into the body buffer
+           c->body_count < (1 << 24);  // 32-bit byte offsets into the body buffer (128 B per body)
 }
 
 // One cooperative launch for the whole step (bepu_stream_kernel.h); the arrival counters are cleared in stream order before it.
