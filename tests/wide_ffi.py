@@ -1,0 +1,70 @@
+"""ctypes wrapper of oracle/wide/libbepu_wide.so — TEST INFRASTRUCTURE ONLY (tests/, bench.py's cpu_baseline leg).
+
+oracle/wide is the second, independently transcribed CPU restatement (AOSOA-8 SIMD, the reference's own shape). It takes the same
+marshalled scene as oracle_ffi (the structs are a data format) and solves IN PLACE."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import oracle_ffi
+from oracle_ffi import OracleParams, OracleScene, _Marshalled, _p
+
+WIDE_DIR = os.path.join(oracle_ffi.ORACLE_DIR, "wide")
+_libs = {}
+
+
+def load(variant: str = "") -> C.CDLL:
+    """variant: "" (-O2 checker), "fast" (-O3, bench.py's cpu_baseline), "zerominus" (Vector<T> unary minus as Zero - v, wide_vec.h)."""
+    name = f"libbepu_wide_{variant}.so" if variant else "libbepu_wide.so"
+    if name not in _libs:
+        path = os.path.join(WIDE_DIR, name)
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-s"], cwd=oracle_ffi.ORACLE_DIR)
+        lib = C.CDLL(path)
+        lib.wide_solve.argtypes = [C.POINTER(OracleScene), C.POINTER(OracleParams)]
+        lib.wide_solve.restype = C.c_int
+        lib.wide_math_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.wide_constraint_iterate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int]
+        lib.wide_constraint_iterate.restype = C.c_int
+        _libs[name] = lib
+    return _libs[name]
+
+
+def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool = False, variant: str = ""):
+    """Simulation.Solve through oracle/wide, IN PLACE on ``scene``'s buffers (bundle width must be 8)."""
+    lib = load("fast" if fast else variant)
+    assert scene.bodies.flags["C_CONTIGUOUS"] and scene.bodies.dtype == np.float32
+    m = _Marshalled(scene)
+    its = np.ascontiguousarray(solve_description.iterations(), dtype=np.int32)
+    p = OracleParams()
+    p.dt = float(dt)
+    p.substep_count = int(solve_description.substep_count)
+    p.velocity_iterations = _p(its)
+    p.gravity[0], p.gravity[1], p.gravity[2] = [float(x) for x in callbacks.gravity]
+    p.linear_damping = float(callbacks.linear_damping)
+    p.angular_damping = float(callbacks.angular_damping)
+    p.allow_substeps_for_unconstrained = int(bool(callbacks.allow_substeps_for_unconstrained_bodies))
+    p.integrate_velocity_for_kinematics = int(bool(callbacks.integrate_velocity_for_kinematics))
+    p.threads = int(threads)
+    p.angular_integration_mode = int(getattr(callbacks, "angular_integration_mode", 0))
+    rc = lib.wide_solve(C.byref(m.c), C.byref(p))
+    if rc != 0:
+        raise RuntimeError(f"wide_solve failed: {rc}")
+
+
+def math_probe(x):
+    lib = load()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    s, c, a = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+    lib.wide_math_probe(_p(x), x.size, _p(s), _p(c), _p(a))
+    return s, c, a
+
+
+def constraint_iterate(type_id, body_a, body_b, prestep, accumulated, dt, iterations):
+    rc = load().wide_constraint_iterate(type_id, _p(body_a), _p(body_b), _p(prestep), _p(accumulated), float(dt), int(iterations))
+    if rc != 0:
+        raise RuntimeError(f"wide_constraint_iterate failed: {rc}")
