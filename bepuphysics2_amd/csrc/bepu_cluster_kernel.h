@@ -361,7 +361,7 @@ __device__ __forceinline__ void run_cluster_sweep(const ClusterShared& sh, int i
         ItemStamps stamps = {0, 0, 0};
         if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE, WIDE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
         else run_cluster_item<kStageSolve, TRACE, WIDE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
-        if (TRACE && trace && blockIdx.x == 0 && lane == 0) {
+        if (TRACE && trace && blockIdx.x == 0 && lane == 0 && item_epoch - 1 < (unsigned)kClusterTracePasses) {  // iteration counts are unbounded: never write past the buffer
             unsigned long long* rec = trace + ((size_t)(item_epoch - 1) * item_count + k) * 8;
             rec[4] = stamps.loaded; rec[5] = stamps.pre_gate; rec[6] = stamps.post_gate; rec[7] = 0;
             rec[0] = t0; rec[1] = __builtin_readcyclecounter();

@@ -155,9 +155,13 @@ struct bepuhip_ctx {
     std::map<GraphKey, hipGraphExec_t> graphs;  // captured launch sequences, one per (iteration schedule, dt, integrator); at most kMaxCachedGraphs
 };
 
-static void free_constraints(bepuhip_ctx* c) {
+static void clear_graphs(bepuhip_ctx* c) {
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
+}
+
+static void free_constraints(bepuhip_ctx* c) {
+    clear_graphs(c);
     if (c->d_slab) hipFree(c->d_slab);
     if (c->d_slab0) hipFree(c->d_slab0);
     if (c->d_tbs) hipFree(c->d_tbs);

@@ -39,6 +39,7 @@ static_assert(sizeof(ClusterItem) == 64, "ClusterItem is staged in LDS as four 1
 static_assert(offsetof(ClusterItem, xpred) == offsetof(ClusterItem, pred) + kMaxPreds * sizeof(unsigned short), "wait_predecessors indexes pred[] and xpred[] as one array");
 struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
 constexpr int kMaxClusterSubsteps = 16;
+constexpr int kClusterTracePasses = kMaxClusterSubsteps * 8;  // passes (warm starts + velocity iterations) the cluster trace buffer holds; later passes are not recorded
 struct ClusterParams {
     int substeps, batch_count, integrate_velocity_for_kinematics;
     int iters[kMaxClusterSubsteps];

@@ -156,17 +156,29 @@ static int32_t rebuild_flags(bepuhip_ctx* c) {
 int32_t bepuhip_set_bodies(bepuhip_ctx* c, const void* aos, int32_t count) {
     if (!c || (!aos && count > 0) || count < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad bodies argument");
     HIP_TRY(hipSetDevice(c->device));
+    const bool count_changed = count != c->body_count;
+    if (count_changed || count > c->body_capacity) {
+        // Captured graphs bake d_bodies / d_flags / body_count / grid sizes into their kernel arguments (GraphKey holds only the schedule):
+        // any change of the body set makes every cached graph stale.
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        clear_graphs(c);
+    }
     if (count > c->body_capacity) {
         if (c->d_bodies) hipFree(c->d_bodies);
         if (c->d_bodies0) hipFree(c->d_bodies0);
         if (c->d_flags) hipFree(c->d_flags);
         c->d_bodies = c->d_bodies0 = nullptr; c->d_flags = nullptr;
-        HIP_TRY(hipMalloc((void**)&c->d_bodies, (size_t)count * 128));
-        HIP_TRY(hipMalloc((void**)&c->d_bodies0, (size_t)count * 128));
-        HIP_TRY(hipMalloc((void**)&c->d_flags, (size_t)count * 4));
+        c->body_capacity = c->body_count = 0;  // a failed allocation below leaves the context empty, not half-sized
+        void *nb = nullptr, *nb0 = nullptr, *nf = nullptr;
+        if (hipMalloc(&nb, (size_t)count * 128) != hipSuccess || hipMalloc(&nb0, (size_t)count * 128) != hipSuccess || hipMalloc(&nf, (size_t)count * 4) != hipSuccess) {
+            if (nb) hipFree(nb);
+            if (nb0) hipFree(nb0);
+            if (nf) hipFree(nf);
+            return fail(BEPUHIP_E_DEVICE, "out of device memory for " + std::to_string(count) + " bodies");
+        }
+        c->d_bodies = (decltype(c->d_bodies))nb; c->d_bodies0 = (decltype(c->d_bodies0))nb0; c->d_flags = (decltype(c->d_flags))nf;
         c->body_capacity = count;
     }
-    const bool count_changed = count != c->body_count;
     c->body_count = count;
     if (count > 0) {
         HIP_TRY(hipMemcpyAsync(c->d_bodies, aos, (size_t)count * 128, hipMemcpyHostToDevice, c->stream));
@@ -607,10 +619,22 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             enqueue_solve(c, dt, substeps, iterations, in);
-            HIP_TRY(hipStreamEndCapture(c->stream, &graph));
+            // Whatever happened while capturing, the stream must leave capture mode and the graph must not leak: a context that failed once stays usable.
+            const hipError_t launch_err = hipGetLastError();
+            const hipError_t end_err = hipStreamEndCapture(c->stream, &graph);
             hipGraphExec_t exec = nullptr;
-            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            hipGraphDestroy(graph);
+            hipError_t inst_err = hipSuccess;
+            if (launch_err == hipSuccess && end_err == hipSuccess && graph != nullptr) inst_err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (graph != nullptr) hipGraphDestroy(graph);
+            if (launch_err != hipSuccess || end_err != hipSuccess || inst_err != hipSuccess || exec == nullptr) {
+                if (exec != nullptr) hipGraphExecDestroy(exec);
+                (void)hipGetLastError();
+                HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+                enqueue_solve(c, dt, substeps, iterations, in);  // eager fallback for this call; the next call tries to capture again
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+                return BEPUHIP_OK;
+            }
             it = c->graphs.emplace(key, exec).first;
             // the event recorded before capture began is still first in stream order
         }
@@ -968,8 +992,7 @@ int32_t bepuhip_set_cluster_trace(bepuhip_ctx* c, int32_t enabled) {
     if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);  // captured launches bake the trace pointer in
-    c->graphs.clear();
+    clear_graphs(c);  // captured launches bake the trace pointer in
     if (c->d_trace) { hipFree(c->d_trace); c->d_trace = nullptr; c->trace_words = 0; }
     if (enabled && c->stream_enabled && !c->clusters_enabled) {
         c->trace_words = (size_t)kStreamTraceWaves * kStreamTraceHops * 4;  // stream schedule: four stamps per traced wavefront and hop
@@ -977,7 +1000,7 @@ int32_t bepuhip_set_cluster_trace(bepuhip_ctx* c, int32_t enabled) {
         HIP_TRY(hipMemset(c->d_trace, 0, c->trace_words * 8));
     } else if (enabled && c->clusters_enabled) {
         const ClusterDesc first = c->first_cluster;
-        c->trace_words = (size_t)first.item_count * 8 * (size_t)kMaxClusterSubsteps * 8;  // up to 128 passes of cluster 0
+        c->trace_words = (size_t)first.item_count * 8 * (size_t)kClusterTracePasses;  // up to 128 passes of cluster 0; the kernel drops later ones
         HIP_TRY(hipMalloc((void**)&c->d_trace, c->trace_words * 8));
         HIP_TRY(hipMemset(c->d_trace, 0, c->trace_words * 8));
     }

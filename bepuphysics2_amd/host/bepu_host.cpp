@@ -78,6 +78,7 @@ int32_t Bodies::Add(const BodyDescription& d) {  // BodySet.cs:83-134
     const Symmetric3x3& t = d.LocalInertia.InverseInertiaTensor;
     b.f[16] = t.XX; b.f[17] = t.YX; b.f[18] = t.YY; b.f[19] = t.ZX; b.f[20] = t.ZY; b.f[21] = t.ZZ; b.f[22] = d.LocalInertia.InverseMass;
     // World inertia slot is zeroed: valid for kinematics forever, refreshed by the solver for dynamics (BodySet.cs:131-134).
+    ++TopologyVersion;
     int32_t handle = (int32_t)HandleToIndex.size();
     HandleToIndex.push_back((int32_t)DynamicsState.size());
     IndexToHandle.push_back(handle);
@@ -145,6 +146,7 @@ int Solver::Add(const int32_t* bodyHandles, int bodyCount, int typeId, const flo
     TypeInfo info;
     if (!GetTypeInfo(typeId, info)) throw std::invalid_argument("unknown constraint type id");
     if (bodyCount != info.bodies) throw std::invalid_argument("body count does not match constraint type");
+    ++TopologyVersion;
     int32_t encoded[4], blocking[4];
     int blockingCount = 0;
     for (int i = 0; i < bodyCount; ++i) {  // GetBlockingBodyHandles, Solver.cs:1058-1078: kinematics never block
@@ -282,7 +284,7 @@ class HipTimestepper : public ITimestepper {
 public:
     HipApi api;
     bepuhip_ctx* ctx = nullptr;
-    size_t uploadedConstraintCount = (size_t)-1;
+    uint64_t uploadedSolverVersion = ~0ull, uploadedBodiesVersion = ~0ull;
     HipTimestepper(const char* libraryPath, int device) {
         std::string err;
         if (!api.load(libraryPath, err)) throw std::runtime_error("cannot load libbepuhip: " + err);
@@ -300,9 +302,10 @@ public:
         // simulation.Sleep / PredictBoundingBoxes / CollisionDetection (DefaultTimestepper.cs:30-37) are out of scope: no-ops here.
         // ---- simulation.Solve(dt) replaced (DefaultTimestepper.cs:39) ----
         Solver& solver = sim.solver;
-        // Topology is re-uploaded only when it changed (v1: detected by constraint count); bodies are host-authoritative every frame.
+        // Topology is re-uploaded only when it changed: keyed on the version counters Solver.Add / Bodies.Add bump (a count comparison would miss a
+        // remove + add, or a body move that renumbers references); bodies are host-authoritative every frame.
         check(api.bepuhip_set_bodies(ctx, sim.bodies.DynamicsState.data(), sim.bodies.Count()));
-        if (uploadedConstraintCount != (size_t)solver.ConstraintCount()) {
+        if (uploadedSolverVersion != solver.TopologyVersion || uploadedBodiesVersion != sim.bodies.TopologyVersion) {
             check(api.bepuhip_begin_constraints(ctx, (int)solver.Batches.size(), sim.solveDescription.FallbackBatchThreshold));
             for (size_t b = 0; b < solver.Batches.size(); ++b)
                 for (const TypeBatch& tb : solver.Batches[b].TypeBatches)
@@ -311,7 +314,8 @@ public:
             std::vector<int32_t> kin;
             for (int32_t h : solver.ConstrainedKinematicHandles) kin.push_back(sim.bodies.HandleToIndex[h]);
             check(api.bepuhip_set_constrained_kinematics(ctx, kin.data(), (int)kin.size()));
-            uploadedConstraintCount = (size_t)solver.ConstraintCount();
+            uploadedSolverVersion = solver.TopologyVersion;
+            uploadedBodiesVersion = sim.bodies.TopologyVersion;
         }
         std::vector<int32_t> iterations = sim.solveDescription.ResolveIterations();
         bepuhip_integrator in{};

@@ -59,6 +59,7 @@ public:
     std::vector<int32_t> IndexToHandle;
     std::vector<int32_t> HandleToIndex;
     int32_t Add(const BodyDescription& description);
+    uint64_t TopologyVersion = 0;  // bumped by every change of the body set (Add; Remove / swap-with-last moves when they exist): what a device mirror keys its uploads on
     int Count() const { return (int)DynamicsState.size(); }
     bool IsKinematic(int index) const;
 };
@@ -113,6 +114,7 @@ public:
     std::vector<int32_t> ConstrainedKinematicHandles; // Solver.cs:68
     std::vector<ConstraintLocation> HandleToConstraint;
     int ConstraintCount() const { return (int)HandleToConstraint.size(); }
+    uint64_t TopologyVersion = 0;  // bumped by every Add (and by any future Remove / body memory move): a remove + add leaves the count unchanged but not the layout
     // Solver.Add(bodyHandles, description): prestepLane holds the description's fields in prestep order (what ApplyDescription writes).
     int Add(const int32_t* bodyHandles, int bodyCount, int typeId, const float* prestepLane);
     // Integration-responsibility prepass (Solver_Solve.cs:1072-1388).

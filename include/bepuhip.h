@@ -91,8 +91,9 @@ int32_t bepuhip_solve(bepuhip_ctx* ctx, float dt, int32_t substep_count, const i
  * `solve_exchanged` = bepuhip_solve on the launch-per-batch schedule (context created with BEPUHIP_FLAG_NO_CLUSTERS) that calls `fn`
  * after every pass: pass 0 = warm start of substep `substep`, pass k = its k-th velocity iteration. Inside the call-back the caller
  * reads `boundary_deltas` (6 floats per boundary body: what this rank's constraints did to linear xyz / angular xyz since the last
- * synchronisation point), sums them over the ranks (RCCL all-reduce on the device buffer, or any host transport) and hands the sums to
- * `boundary_apply`, which sets every copy to snapshot + sum. Block-Jacobi across the cut: results are NOT bit-identical to one GPU. */
+ * synchronisation point), sums them over the ranks (RCCL all-reduce on the device buffer, or any host transport), DIVIDES each body's sum by the number of ranks that hold it
+ * (mass splitting: every copy of a body with k holders was uploaded with 1/k of its mass, so the copies' deltas are averaged; bepuphysics2_amd/lattice.py
+ * `Exchange.reduce`) and hands the result to `boundary_apply`, which sets every copy to snapshot + that value. Block-Jacobi across the cut: results are NOT bit-identical to one GPU. */
 typedef int32_t (*bepuhip_exchange_fn)(void* user, int32_t substep, int32_t pass);
 int32_t bepuhip_set_boundary_bodies(bepuhip_ctx* ctx, const int32_t* body_indices, int32_t count);
 int32_t bepuhip_boundary_deltas(bepuhip_ctx* ctx, float* deltas_out, int32_t out_is_device_pointer);

@@ -4,7 +4,7 @@ import pytest
 
 import parity_util as pu
 import small_scenes
-from bepuphysics2_amd.scene import FALLBACK_BATCH_THRESHOLD, PoseIntegratorCallbacks, SceneBuilder, SolveDescription, make_body
+from bepuphysics2_amd.scene import FALLBACK_BATCH_THRESHOLD, HOT_PATH_TYPES, PoseIntegratorCallbacks, SceneBuilder, SolveDescription, make_body
 
 pytestmark = pytest.mark.gpu
 
@@ -140,3 +140,34 @@ def test_inconsistent_uploads_are_refused_not_run(hip_solver_factory, use_cluste
     got = scene.copy()
     solver.download(got)
     _bit_exact(ref, got)
+
+
+def test_set_bodies_with_a_different_count_invalidates_captured_graphs(hip_solver_factory):
+    """a captured hipGraph bakes d_bodies / d_flags / body_count into its kernel arguments; set_bodies with another count (within
+    capacity or beyond it: the buffers are reallocated) must not replay it. Launch-per-batch schedule with graphs on."""
+    import oracle_ffi
+    sd, cb = SolveDescription(2, 3), PoseIntegratorCallbacks()
+    small = small_scenes.random_graph_scene(41, 150, 400, HOT_PATH_TYPES, unconstrained_extra=5)
+    for extra in (7, 4000):  # a few more bodies / far beyond the allocated capacity (realloc)
+        solver = hip_solver_factory(use_clusters=False)
+        solver.upload(small, sd.fallback_batch_threshold)
+        solver.solve(1 / 60, sd, cb)  # captures the graph for (iterations, dt, integrator)
+        ref = small.copy()
+        oracle_ffi.solve(ref, 1 / 60, sd, cb)  # the constraints' state after frame 1 stays on the device: mirror it
+        rng = np.random.default_rng(extra)
+        new_rows = np.stack([small_scenes.random_dynamic_body(rng, rng.uniform(-5, 5, 3)) for _ in range(extra)]).astype(np.float32)
+        first_new = small.bodies.shape[0]
+        handles = np.arange(first_new, first_new + extra, dtype=np.int32)
+        ref.bodies = np.ascontiguousarray(np.concatenate([small.bodies, new_rows]))  # the host re-sends ALL bodies (frame-0 values) plus the new ones
+        ref.index_to_handle = np.concatenate([small.index_to_handle, handles + (int(small.handle_to_index.size) - first_new)]).astype(np.int32)
+        ref.handle_to_index = np.concatenate([small.handle_to_index, handles]).astype(np.int32)
+        got = ref.copy()
+        before = got.bodies.copy()
+        oracle_ffi.solve(ref, 1 / 60, sd, cb)
+        solver.set_bodies(got.bodies)  # same constraints, same graph key -> a stale graph would be replayed against freed / short buffers
+        solver.solve(1 / 60, sd, cb)
+        solver.download(got)
+        m = pu.compare_scenes(ref, got)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"], (extra, m)
+        # the new, unconstrained bodies must have been integrated (a stale body_count would leave them untouched)
+        assert not np.array_equal(got.bodies[first_new:, 4:7], before[first_new:, 4:7])
