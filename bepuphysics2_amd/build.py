@@ -27,15 +27,40 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build_hip(force: bool = False) -> str:
+HIP_COMPILE_FLAGS = [f for f in HIP_FLAGS if f != "-shared"]
+
+
+def _hip_units(src_dir: str):
+    return sorted(f for f in os.listdir(src_dir) if f.endswith(".hip"))
+
+
+def build_hip(force: bool = False, jobs: int = 0) -> str:
+    """libbepuhip.so = bepuhip.hip (C ABI, launch-per-batch / stream / per-body kernels) + one translation unit per cluster_kernel register budget
+    (bepu_cluster_{hot,wide}_{1024,768,512}.hip). Units are compiled to objects in parallel and linked; an object is rebuilt when any source is newer."""
+    from concurrent.futures import ThreadPoolExecutor
     src_dir = os.path.join(_HERE, "csrc")
+    obj_dir = os.path.join(src_dir, "build")
     out = os.path.join(src_dir, "libbepuhip.so")
-    sources = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h"))] + [os.path.join(REPO, "include", "bepuhip.h")]
-    if not force and _newer(out, sources):
+    sources = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h", ".inc"))] + [os.path.join(REPO, "include", "bepuhip.h")]
+    units = _hip_units(src_dir)
+    objects = [os.path.join(obj_dir, u[:-4] + ".o") for u in units]
+    if not force and _newer(out, sources) and all(_newer(o, sources) for o in objects):
         return out
-    tmp = out + f".tmp{os.getpid()}"  # build aside, then rename: a concurrent reader never sees a half-written library
-    cmd = [_hipcc()] + HIP_FLAGS + ["-o", tmp, os.path.join(src_dir, "bepuhip.hip")]
-    subprocess.check_call(cmd, cwd=src_dir)
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_unit(unit_object):
+        unit, obj = unit_object
+        if not force and _newer(obj, sources):
+            return
+        tmp = obj + f".tmp{os.getpid()}"
+        subprocess.check_call([hipcc] + HIP_COMPILE_FLAGS + ["-c", "-o", tmp, os.path.join(src_dir, unit)], cwd=src_dir)
+        os.replace(tmp, obj)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 1)) as pool:
+        list(pool.map(compile_unit, zip(units, objects)))
+    tmp = out + f".tmp{os.getpid()}"  # link aside, then rename: a concurrent reader never sees a half-written library
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objects, cwd=src_dir)
     os.replace(tmp, out)
     return out
 

@@ -27,8 +27,6 @@ namespace {
 // Slot numbering is rotated by the host inside every group of 16 (slot = (i & ~15) | ((i + (i >> 4)) & 15)) so that the regular
 // "same joint of consecutive ragdolls" access pattern (lane stride = island size) spreads over all 16 bank slots of ds_read_b128.
 // ------------------------------------------------------------------------------------------------
-constexpr int kPlanes = 8;
-constexpr int kClusterThreads = 1024;
 
 typedef __attribute__((address_space(1))) float gfloat;  // global
 typedef __attribute__((address_space(1))) int gint;

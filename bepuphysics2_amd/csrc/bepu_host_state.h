@@ -2,21 +2,22 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------------
-// cluster_kernel instantiations: trace x type set, all compiled for the 1024-thread register budget (such a kernel runs any smaller workgroup;
-// separate 512- and 768-thread budgets were measured and dropped: 768 is within 3 % either way depending on the box, 512 is slower).
-#ifdef BEPUHIP_FAST_BUILD  // kernel-tuning builds (tools/): hot-path type set only
-#define BEPU_CLUSTER_VARIANTS(X) X(1024, false, false) X(1024, true, false)
-#else
-#define BEPU_CLUSTER_VARIANTS(X) X(1024, false, false) X(1024, true, false) X(1024, false, true) X(1024, true, true)
-#endif
-static const void* cluster_kernel_variant(bool trace, bool wide) {
-#ifdef BEPUHIP_FAST_BUILD
-    wide = false;
-#endif
-#define X(T, TR, W) if (trace == TR && wide == W) return (const void*)cluster_kernel<T, TR, W>;
-    BEPU_CLUSTER_VARIANTS(X)
-#undef X
-    return nullptr;
+// cluster_kernel instantiations live in their own translation units (bepu_cluster_{hot,wide}_{1024,768,512}.hip): type set x register budget, each
+// with a traced twin. A kernel compiled for N threads per workgroup gets 65536 / N VGPRs per lane (128 / 168 / 256 after the allocation granule).
+const void* bepu_cluster_kernel_hot_1024(bool trace);
+const void* bepu_cluster_kernel_hot_768(bool trace);
+const void* bepu_cluster_kernel_hot_512(bool trace);
+const void* bepu_cluster_kernel_wide_1024(bool trace);
+const void* bepu_cluster_kernel_wide_768(bool trace);
+const void* bepu_cluster_kernel_wide_512(bool trace);
+constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
+static int cluster_variant_threads(int threads) { return threads > 768 ? 1024 : (threads > 512 ? 768 : 512); }  // the smallest budget that still fits `threads`
+static const void* cluster_kernel_variant(int threads, bool trace, bool wide) {
+    switch (cluster_variant_threads(threads)) {
+        case 1024: return wide ? bepu_cluster_kernel_wide_1024(trace) : bepu_cluster_kernel_hot_1024(trace);
+        case 768: return wide ? bepu_cluster_kernel_wide_768(trace) : bepu_cluster_kernel_hot_768(trace);
+        default: return wide ? bepu_cluster_kernel_wide_512(trace) : bepu_cluster_kernel_hot_512(trace);
+    }
 }
 
 static thread_local std::string g_last_error;
@@ -113,13 +114,6 @@ struct bepuhip_ctx {
     int inc_tb_count = 0, inc_blocks = 0;
     int64_t total_constraints = 0;
     int referenced_bodies = 0;           // 1 + the largest body index any constraint references
-    // stream schedule (bepu_stream_kernel.h)
-    bool stream_enabled = false;
-    int stream_waves = 0;                // resident workgroups of one cooperative launch (occupancy x CUs), found once
-    int* d_batch_begin = nullptr;        // device copies of batch_begin / batch_blocks
-    int* d_batch_blocks = nullptr;
-    unsigned* d_hops = nullptr;          // arrival counters, 16 dwords per hop
-    int hop_capacity = 0;
     // cluster path
     bool clusters_enabled = false;
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
@@ -173,9 +167,6 @@ static void free_constraints(bepuhip_ctx* c) {
     if (c->d_clustered_dynamic) hipFree(c->d_clustered_dynamic);
     if (c->d_kinlist) hipFree(c->d_kinlist);
     if (c->d_requirk) hipFree(c->d_requirk);
-    if (c->d_batch_begin) hipFree(c->d_batch_begin);
-    if (c->d_batch_blocks) hipFree(c->d_batch_blocks);
-    c->d_batch_begin = c->d_batch_blocks = nullptr; c->stream_enabled = false;
     c->d_requirk = nullptr; c->requirk_begin.clear();
     if (c->d_trace) hipFree(c->d_trace);
     c->d_trace = nullptr; c->trace_words = 0;

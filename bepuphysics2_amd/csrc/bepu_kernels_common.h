@@ -1,5 +1,5 @@
 // Shared device-side definitions of libbepuhip's kernels: descriptors handed to the kernels, the body record in registers, its global-memory
-// gather/scatter by access filter (Bodies_GatherScatter.cs:267-753), stage ids. Included by bepuhip.hip only (one translation unit).
+// gather/scatter by access filter (Bodies_GatherScatter.cs:267-753), stage ids. Included by every translation unit of the library (everything here has internal linkage).
 #pragma once
 #include <cstddef>
 
@@ -38,6 +38,8 @@ struct ClusterItem {  // <= 64 consecutive constraints of one type batch, all ow
 static_assert(sizeof(ClusterItem) == 64, "ClusterItem is staged in LDS as four 16-byte vectors");
 static_assert(offsetof(ClusterItem, xpred) == offsetof(ClusterItem, pred) + kMaxPreds * sizeof(unsigned short), "wait_predecessors indexes pred[] and xpred[] as one array");
 struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
+constexpr int kPlanes = 8;            // LDS body table: one plane per 16-byte field of BodyDynamics
+constexpr int kClusterThreads = 1024;  // default threads per cluster workgroup
 constexpr int kMaxClusterSubsteps = 16;
 constexpr int kClusterTracePasses = kMaxClusterSubsteps * 8;  // passes (warm starts + velocity iterations) the cluster trace buffer holds; later passes are not recorded
 struct ClusterParams {

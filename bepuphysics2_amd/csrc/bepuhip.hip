@@ -36,18 +36,15 @@
 
 using namespace bd;
 
-// One translation unit, split by concern:
+// Split by concern:
 //   bepu_device_math.h / bepu_device_constraints.h  scalar-per-lane math and the constraint functions (one lane = one constraint)
 //   bepu_kernels_common.h    descriptors, the body record, gather/scatter by access filter
 //   bepu_batch_kernels.h     launch-per-batch schedule, per-body integration kernels, boundary exchange, ranged update transposes
-//   bepu_cluster_kernel.h    island-per-workgroup schedule (bodies resident in LDS, work-item dataflow)
-//   bepu_stream_kernel.h     the launch-per-batch sequence as ONE cooperative launch (arrival counters between hops, sc1 body traffic)
+//   bepu_cluster_kernel.h    island-per-workgroup schedule (bodies resident in LDS, work-item dataflow); compiled in bepu_cluster_*.hip, one unit per register budget
 //   bepu_host_state.h        context, type table, error plumbing;  bepu_cluster_plan.h  host planning of the island schedule
 //   this file                the C ABI of include/bepuhip.h: uploads, graph capture / launch sequence, read-backs
 #include "bepu_kernels_common.h"
 #include "bepu_batch_kernels.h"
-#include "bepu_cluster_kernel.h"
-#include "bepu_stream_kernel.h"
 #include "bepu_host_state.h"
 #include "bepu_cluster_plan.h"
 
@@ -109,7 +106,6 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_staged) hipFree(c->d_staged);
     if (c->d_collidables) hipFree(c->d_collidables);
     if (c->d_stage) hipFree(c->d_stage);
-    if (c->d_hops) hipFree(c->d_hops);
     if (c->d_boundary) hipFree(c->d_boundary);
     if (c->d_boundary_snapshot) hipFree(c->d_boundary_snapshot);
     if (c->d_boundary_buf) hipFree(c->d_boundary_buf);
@@ -385,25 +381,10 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         HIP_TRY(upload_ints(plan.batch_item_begin.data(), plan.batch_item_begin.size() * 4, (void**)&c->d_batch_item_begin));
         HIP_TRY(upload_ints(plan.cluster_bodies.data(), plan.cluster_bodies.size() * 4, (void**)&c->d_cluster_bodies));
         HIP_TRY(upload_ints(plan.clustered_dynamic.data(), plan.clustered_dynamic.size() * 4, (void**)&c->d_clustered_dynamic));
-#define X(T, TR, W) (const void*)cluster_kernel<T, TR, W>,
-        for (const void* fn : {BEPU_CLUSTER_VARIANTS(X)})
-#undef X
-            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
-    }
-    // Persistent form of the launch-per-batch schedule (bepu_stream_kernel.h): opt-in, for the sixteen types of SURVEY 8(a).
-    c->stream_enabled = ((c->flags & BEPUHIP_FLAG_STREAM) || env_int("BEPUHIP_STREAM", 0)) && !c->has_widened_types && c->batch_count > 0 && c->total_constraints > 0;
-    if (c->stream_enabled) {
-        HIP_TRY(upload_ints(c->batch_begin.data(), c->batch_begin.size() * 4, (void**)&c->d_batch_begin));
-        HIP_TRY(upload_ints(c->batch_blocks.data(), c->batch_blocks.size() * 4, (void**)&c->d_batch_blocks));
-        if (c->stream_waves == 0) {  // every workgroup of the launch must be resident: occupancy x CUs
-            int per_cu = 0;
-            hipDeviceProp_t prop;
-            constexpr size_t kStreamLdsBytes = (size_t)kStreamWaves * kStageWaveF4 * 16;
-            HIP_TRY(hipFuncSetAttribute((const void*)stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStreamLdsBytes));
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel, 64 * kStreamWaves, kStreamLdsBytes));
-            HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-            c->stream_waves = std::max(1, per_cu * prop.multiProcessorCount);
-        }
+        for (int threads : kClusterThreadChoices)
+            for (int tr = 0; tr < 2; ++tr)
+                for (int wide = 0; wide < 2; ++wide)
+                    HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(threads, tr != 0, wide != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
     }
     c->built = true;
     return rebuild_flags(c);
@@ -468,44 +449,6 @@ static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const be
     return c->clusters_enabled && substeps <= kMaxClusterSubsteps && cluster_lds_bytes(c->cluster_max_slots, c->cluster_max_items) <= kLdsBudgetBytes &&
            in->angular_integration_mode == 0;
 }
-// The stream schedule covers what the island schedule cannot take (an island larger than one workgroup's LDS), in the nonconserving mode.
-static bool stream_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
-    return c->stream_enabled && !island_schedule_applies(c, substeps, in) && substeps <= kMaxStreamSubsteps && in->angular_integration_mode == 0 &&
-           c->body_count < (1 << 24);  // 32-bit byte offsets into the body buffer (128 B per body)
-}
-
-// One cooperative launch for the whole step (bepu_stream_kernel.h); the arrival counters are cleared in stream order before it.
-static int32_t enqueue_stream(bepuhip_ctx* c, float dt, int substeps, const int32_t* iterations, const bepuhip_integrator* in) {
-    int batches = 0;
-    for (int b = 0; b < c->batch_count; ++b) batches += c->batch_blocks[b] > 0;
-    int hops = 1;
-    for (int s = 0; s < substeps; ++s) hops += (s > 0 && c->inc_blocks > 0 ? 1 : 0) + 1 + batches * (1 + iterations[s]);
-    if (hops > c->hop_capacity) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->d_hops) hipFree(c->d_hops);
-        c->d_hops = nullptr; c->hop_capacity = 0;
-        HIP_TRY(hipMalloc((void**)&c->d_hops, (size_t)hops * kHopLanes * 4));
-        c->hop_capacity = hops;
-    }
-    HIP_TRY(hipMemsetAsync(c->d_hops, 0, (size_t)hops * kHopLanes * 4, c->stream));
-    StreamParams P;
-    memset(&P, 0, sizeof(P));
-    P.substeps = substeps; P.batch_count = c->batch_count; P.body_count = c->body_count; P.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
-    for (int s = 0; s < substeps; ++s) P.iters[s] = iterations[s];
-    P.has_incremental = c->inc_blocks > 0;
-    P.frame_dt = dt; P.substep_dt = dt / substeps; P.inv_substep_dt = 1.0f / P.substep_dt;
-    P.allow_substeps_for_unconstrained = in->allow_substeps_for_unconstrained;
-    P.sp = make_params(in, P.substep_dt, P.substep_dt, P.inv_substep_dt);
-    const float vdt = in->allow_substeps_for_unconstrained ? P.substep_dt : dt;
-    P.final_sp = make_params(in, vdt, vdt, 1.0f / vdt);
-    StreamSync sy = {c->d_hops, c->d_status, c->d_trace};
-    const int waves = std::max(1, std::min(c->stream_waves, env_int("BEPUHIP_STREAM_WAVES", c->stream_waves)));
-    void* args[] = {(void*)&c->d_tbs, (void*)&c->d_batch_begin, (void*)&c->d_batch_blocks, (void*)&c->d_bodies, (void*)&c->d_flags, (void*)&sy, (void*)&P};
-    Timed t(c, 5);
-    HIP_TRY(hipLaunchCooperativeKernel((const void*)stream_kernel, dim3(waves), dim3(64 * kStreamWaves), args, (size_t)kStreamWaves * kStageWaveF4 * 16, c->stream));
-    return BEPUHIP_OK;
-}
-
 // Enqueue every kernel of one Simulation.Solve on the context's stream (Solver_Solve.cs:1415-1479 + PoseIntegrator.cs:707-726).
 static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t* iterations, const bepuhip_integrator* in) {
     const float substep_dt = dt / substeps;          // Solver_Solve.cs:1417
@@ -539,7 +482,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
                             (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp};
             const bool tr = c->d_trace != nullptr;
-            const void* fn = cluster_kernel_variant(tr, c->has_widened_types);
+            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types);  // the register budget that matches the workgroup size
             hipLaunchKernel(fn, dim3(c->cluster_count + tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0)), dim3(threads), args, lds_bytes, c->stream);
         }
     }
@@ -602,8 +545,7 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     if (c->profiling) { for (int i = 0; i < 6; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; } }
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
     // A graph pays for the launch-per-batch schedule's 100+ launches; the island schedule is ONE kernel, which a plain launch starts sooner (6-7 us per step).
-    const bool stream = stream_schedule_applies(c, substeps, in);
-    const bool use_graph = !(c->flags & BEPUHIP_FLAG_NO_GRAPH) && !c->profiling && !island_schedule_applies(c, substeps, in) && !stream;
+    const bool use_graph = !(c->flags & BEPUHIP_FLAG_NO_GRAPH) && !c->profiling && !island_schedule_applies(c, substeps, in);
     if (use_graph) {
         GraphKey key;
         key.iterations.assign(iterations, iterations + substeps);
@@ -639,9 +581,6 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
             // the event recorded before capture began is still first in stream order
         }
         HIP_TRY(hipGraphLaunch(it->second, c->stream));
-    } else if (stream) {
-        const int32_t st2 = enqueue_stream(c, dt, substeps, iterations, in);
-        if (st2 != BEPUHIP_OK) return st2;
     } else {
         enqueue_solve(c, dt, substeps, iterations, in);
     }
@@ -757,14 +696,13 @@ int32_t bepuhip_sync(bepuhip_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) c->last_ms = ms;
-    if (c->clusters_enabled || c->stream_enabled) {
+    if (c->clusters_enabled) {
         unsigned st[8];
         memcpy(st, c->d_status, sizeof(st));
         if (st[0] != 0) {
             memset(c->d_status, 0, 256);
             char msg[256];
-            if (st[2] == 6) snprintf(msg, sizeof(msg), "stream schedule stalled: wavefront %u waiting for hop %u, wanted %u arrivals saw %u", st[1], st[3], st[5], st[6]);
-            else snprintf(msg, sizeof(msg), "cluster schedule stalled: cluster %u kind %u item %u waiting on %u, wanted %u saw %u, claim counter %u", st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+            snprintf(msg, sizeof(msg), "cluster schedule stalled: cluster %u kind %u item %u waiting on %u, wanted %u saw %u, claim counter %u", st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
             return fail(BEPUHIP_E_DEVICE, msg);
         }
     }
@@ -994,11 +932,7 @@ int32_t bepuhip_set_cluster_trace(bepuhip_ctx* c, int32_t enabled) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     clear_graphs(c);  // captured launches bake the trace pointer in
     if (c->d_trace) { hipFree(c->d_trace); c->d_trace = nullptr; c->trace_words = 0; }
-    if (enabled && c->stream_enabled && !c->clusters_enabled) {
-        c->trace_words = (size_t)kStreamTraceWaves * kStreamTraceHops * 4;  // stream schedule: four stamps per traced wavefront and hop
-        HIP_TRY(hipMalloc((void**)&c->d_trace, c->trace_words * 8));
-        HIP_TRY(hipMemset(c->d_trace, 0, c->trace_words * 8));
-    } else if (enabled && c->clusters_enabled) {
+    if (enabled && c->clusters_enabled) {
         const ClusterDesc first = c->first_cluster;
         c->trace_words = (size_t)first.item_count * 8 * (size_t)kClusterTracePasses;  // up to 128 passes of cluster 0; the kernel drops later ones
         HIP_TRY(hipMalloc((void**)&c->d_trace, c->trace_words * 8));

@@ -23,7 +23,6 @@ BEPUHIP_E_DEVICE = -3
 BEPUHIP_E_STATE = -4
 BEPUHIP_FLAG_NO_GRAPH = 1
 BEPUHIP_FLAG_NO_CLUSTERS = 2
-BEPUHIP_FLAG_STREAM = 4
 
 # Every symbol include/bepuhip.h declares (checked by the CPU test-suite against the header).
 EXPORTED_SYMBOLS = [
@@ -156,11 +155,10 @@ class HipSolver:
 
     PROFILE_FAMILIES = ("incremental", "integrate", "warmstart", "solve", "final", "cluster")
 
-    def __init__(self, device: int = 0, bundle_width: int = 8, use_graph: bool = True, use_clusters: bool = True, use_stream: bool = False):
+    def __init__(self, device: int = 0, bundle_width: int = 8, use_graph: bool = True, use_clusters: bool = True):
         self.lib = load_library()
         self.ctx = C.c_void_p()
-        cfg = Config(device, bundle_width, (0 if use_graph else BEPUHIP_FLAG_NO_GRAPH) | (0 if use_clusters else BEPUHIP_FLAG_NO_CLUSTERS) |
-                     (BEPUHIP_FLAG_STREAM if use_stream else 0))
+        cfg = Config(device, bundle_width, (0 if use_graph else BEPUHIP_FLAG_NO_GRAPH) | (0 if use_clusters else BEPUHIP_FLAG_NO_CLUSTERS))
         _check(self.lib, self.lib.bepuhip_create(C.byref(cfg), C.byref(self.ctx)))
         self.bundle_width = bundle_width
         self._scene_meta = None
@@ -374,13 +372,6 @@ class HipSolver:
         _check(self.lib, self.lib.bepuhip_get_cluster_trace(self.ctx, _ptr(buf), cap, C.byref(items)))
         n = int(items.value)
         return buf[: passes * n * 8].reshape(passes, n, 8)
-
-    def stream_trace(self) -> np.ndarray:
-        """(3 wavefronts, 1024 hops, 4) uint64 stamps (100 MHz) of the last stream-schedule launch: reached the hop, passed the gate, blocks done, arrived."""
-        buf = np.zeros(3 * 1024 * 4, dtype=np.uint64)
-        items = C.c_int32()
-        _check(self.lib, self.lib.bepuhip_get_cluster_trace(self.ctx, _ptr(buf), buf.size, C.byref(items)))
-        return buf.reshape(3, 1024, 4)
 
     def stream_handle(self) -> int:
         v = C.c_void_p()

@@ -38,8 +38,8 @@ typedef struct bepuhip_config {
 } bepuhip_config;
 #define BEPUHIP_FLAG_NO_GRAPH 1    /* launch kernels eagerly instead of replaying a captured hipGraph */
 #define BEPUHIP_FLAG_NO_CLUSTERS 2 /* never use the island-per-workgroup (LDS-resident) schedule; always one launch per batch per stage */
-#define BEPUHIP_FLAG_STREAM 4      /* run the launch-per-batch sequence as one cooperative launch (arrival counters instead of kernel boundaries) when the
-                                      island schedule does not apply; the sixteen constraint types of the hot path, AngularIntegrationMode.Nonconserving */
+/* flag value 4 is reserved (round 1's opt-in cooperative "stream" schedule: measured slower than the graph replay on every scene, now an archived experiment
+   under tools/experiments/stream_schedule/) */
 
 /* IPoseIntegratorCallbacks as data: only the DemoPoseIntegratorCallbacks shape can cross the ABI
  * (Demos/DemoCallbacks.cs:20-109; BepuPhysics/PoseIntegrator.cs:42-94). PrepareForIntegration(dt) is evaluated

@@ -17,11 +17,11 @@ cb = PoseIntegratorCallbacks()
 its = scene.constraint_count * int((1 + sd.iterations()).sum())
 
 
-def run(label, env, steps=int(os.environ.get('STEPS', '400')), use_clusters=True, use_graph=True, use_stream=False):
+def run(label, env, steps=int(os.environ.get('STEPS', '400')), use_clusters=True, use_graph=True):
     for k in ("BEPUHIP_DEBUG", "BEPUHIP_CLUSTER_BODIES", "BEPUHIP_CLUSTER_THREADS"):
         os.environ.pop(k, None)
     os.environ.update(env)
-    s = HipSolver(use_clusters=use_clusters, use_graph=use_graph, use_stream=use_stream)
+    s = HipSolver(use_clusters=use_clusters, use_graph=use_graph)
     s.upload(scene)
     for _ in range(int(os.environ.get('WARM', '200'))):  # long warm-up: the clock needs tens of milliseconds of load to ramp up
         s.solve(1 / 60, sd, cb, asynchronous=True)
@@ -48,10 +48,6 @@ for cfg in configs:
     elif cfg == "base":
         run("clusters default", {})
         run("global path (launch per batch)", {}, use_clusters=False)
-    elif cfg == "stream":  # the ragdoll scene treated as one island: launch per batch (graph replay) against the stream schedule
-        for _ in range(2):
-            run("global path (launch per batch)", {}, use_clusters=False)
-            run("global path, stream schedule", {}, use_clusters=False, use_stream=True)
     elif cfg == "waves":
         for thr in (512, 768, 1024, 512, 768, 1024):
             run(f"threads={thr}", {"BEPUHIP_CLUSTER_THREADS": str(thr)})

@@ -18,7 +18,7 @@ its = scene.constraint_count * int((1 + sd.iterations()).sum())
 print(f"pile: {scene.body_count} bodies, {scene.constraint_count} constraints, {len(scene.batches)} batches, substeps {sd.substep_count}, iterations {list(sd.iterations())}")
 for b, batch in enumerate(scene.batches):
     print(f"  batch {b}: " + ", ".join(f"type {tb.type_id} x{tb.count}" for tb in batch))
-s = HipSolver(use_stream=os.environ.get("STREAM", "0") != "0")
+s = HipSolver()
 s.upload(scene)
 for _ in range(100):
     s.solve(1 / 60, sd, cb, asynchronous=True)
