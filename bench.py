@@ -227,8 +227,13 @@ def main():
     from bepuphysics2_amd.roofline import INTEGRATE_BYTES_PER_BODY, FINAL_BYTES_PER_BODY, scene_stage_bytes
     from bepuphysics2_amd.scene import PoseIntegratorCallbacks, TYPE_TABLE
 
-    from bepuphysics2_amd.sharding import rank_seed
-    scene, sd = build_scene(args.ragdolls, rank_seed(5, rank))  # each rank: its own independent islands
+    from bepuphysics2_amd import sharding
+    # configs[3]: ONE scene of world x ragdolls independent islands (weak scaling: the scene grows with the job), built identically on every rank and cut
+    # into whole islands per rank by the partitioner the gloo test checks (tests/test_distributed_cpu.py: union of shares == single-process, bit for bit).
+    scene, sd = build_scene(args.ragdolls * world, 5)
+    whole_constraints = scene.constraint_count
+    if world > 1 or os.environ.get("BEPU_BENCH_FORCE_DIST") == "1":
+        scene = sharding.split_scene_by_islands(scene, world, only_rank=rank)[0].scene
     cb = PoseIntegratorCallbacks()
     dt = 1.0 / 60.0
     solver = HipSolver(device=local_rank, use_graph=not args.no_graph)
@@ -354,7 +359,9 @@ def main():
             "config": {"workload": "RagdollTubeBenchmark scaled to ~1M constraints (BASELINE.json configs[2]): "
                                    f"{args.ragdolls} ragdolls/GPU, {scene.constraint_count} constraints/GPU, {scene.body_count} bodies/GPU, "
                                    f"{len(scene.batches)} batches, {sd.substep_count} substeps x {sd.velocity_iteration_count} velocity iteration(s), dt=1/60",
-                       "sharding": "independent ragdoll islands per GPU, no data-path collective" if world > 1 else "single GPU",
+                       "sharding": (f"ONE scene of {args.ragdolls * world} ragdolls ({whole_constraints} constraints) cut into whole islands per GPU by "
+                                    "sharding.split_scene_by_islands (BASELINE.json configs[3]); no data-path collective, RCCL barrier + timing reduction only")
+                                   if (world > 1 or dist is not None) else "single GPU",
                        "schedule": "island-per-workgroup: one plain kernel launch per step" if solver.cluster_cycles().size else
                                    ("launch-per-batch" + ("" if args.no_graph else ", hipGraph replay")),
                        "device_prewarm": f"{prewarm_steps} untimed solves during setup, uploaded state restored before the {args.warmup} warm-up steps",
