@@ -76,8 +76,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     for (int k = 1; k < tb_count; ++k)
         if (b >= tbs[tb_begin + k].block_begin) t = tb_begin + k;
     const DevTypeBatch tb = tbs[t];
-    const int i = (b - tb.block_begin) * kBlock + threadIdx.x;
+    int i = (b - tb.block_begin) * kBlock + threadIdx.x;
     if (i >= tb.count) return;
+    if (tb.indices) i = tb.indices[i];
     switch (tb.type_id) {
         case kContact1OneBody: run_constraint<Contact<1, false>, STAGE>(tb, i, bodies, dt, inv_dt); break;
         case kContact2OneBody: run_constraint<Contact<2, false>, STAGE>(tb, i, bodies, dt, inv_dt); break;

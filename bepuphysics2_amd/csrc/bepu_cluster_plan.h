@@ -44,7 +44,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                     if ((uint32_t)r >= kDynamicLimit && r >= 0 && !seen[r & kRefMask]) { seen[r & kRefMask] = 1; plan.kinlist.push_back(r & kRefMask); }
                 }
     }
-    if ((c->flags & BEPUHIP_FLAG_NO_CLUSTERS) || env_int("BEPUHIP_NO_CLUSTERS", 0) || universe == 0 || c->total_constraints == 0 || c->batch_count > kFallbackBatchLimit) return;
+    if ((c->flags & BEPUHIP_FLAG_NO_CLUSTERS) || env_int("BEPUHIP_NO_CLUSTERS", 0) || universe == 0 || c->total_constraints == 0 || c->batch_count > kFallbackBatchLimit || c->has_fallback) return;
     std::vector<int32_t> parent(universe);
     for (int i = 0; i < universe; ++i) parent[i] = i;
     auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };

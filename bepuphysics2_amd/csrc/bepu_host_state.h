@@ -100,10 +100,14 @@ struct bepuhip_ctx {
     std::vector<int32_t> kin_indices;
     // constraints
     bool building = false, built = false;
-    int batch_count = 0;
+    int batch_count = 0;                 // the caller's batches, a sequential fallback batch included
+    int fallback_threshold = 64;         // SolveDescription.FallbackBatchThreshold: batch index == threshold is the sequential fallback batch (Solver.cs:1878-1884)
+    bool has_fallback = false;
+    int launch_count = 0;                // launches per pass: the synchronized batches, then one per dependency level of the fallback batch
+    int* d_fallback_indices = nullptr;   // row indices of every level's launches, concatenated
     std::vector<HostTypeBatch> tbs;
-    std::vector<int> batch_begin;        // tbs index of each batch's first type batch (size batch_count+1)
-    std::vector<int> batch_blocks;       // grid size per batch
+    std::vector<int> batch_begin;        // descriptor index of each launch's first type batch (size launch_count+1)
+    std::vector<int> batch_blocks;       // grid size per launch
     uint32_t* d_slab = nullptr;          // all refs/prestep/accum
     uint32_t* d_slab0 = nullptr;         // pristine snapshot
     float* d_stage = nullptr;            // staging for ranged updates / read-backs (caller's AOSOA bundles)
@@ -156,6 +160,8 @@ static void clear_graphs(bepuhip_ctx* c) {
 
 static void free_constraints(bepuhip_ctx* c) {
     clear_graphs(c);
+    if (c->d_fallback_indices) hipFree(c->d_fallback_indices);
+    c->d_fallback_indices = nullptr; c->has_fallback = false; c->launch_count = 0;
     if (c->d_slab) hipFree(c->d_slab);
     if (c->d_slab0) hipFree(c->d_slab0);
     if (c->d_tbs) hipFree(c->d_tbs);

@@ -22,6 +22,7 @@ struct DevTypeBatch {
     int* refs;
     float* prestep;
     float* accum;
+    const int* indices;  // null: lanes [0, count) of the rows; else the `count` row indices this launch processes (one dependency level of the sequential fallback batch)
 };
 
 // ---- cluster path descriptors (see cluster_kernel) ----

@@ -187,12 +187,15 @@ int32_t bepuhip_set_bodies(bepuhip_ctx* c, const void* aos, int32_t count) {
 
 int32_t bepuhip_begin_constraints(bepuhip_ctx* c, int32_t batch_count, int32_t fallback_batch_threshold) {
     if (!c || batch_count < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad batch count");
-    if (batch_count > fallback_batch_threshold)
-        return fail(BEPUHIP_E_UNSUPPORTED, "a sequential fallback batch exists (batch_count > FallbackBatchThreshold); use simulation.Solve");
+    if (fallback_batch_threshold < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Fallback batch threshold must be positive.");  // SolveDescription.cs:48-51
+    if (batch_count > fallback_batch_threshold + 1)
+        return fail(BEPUHIP_E_INVALID_ARGUMENT, "more batches than FallbackBatchThreshold + 1 (Solver.cs:1882)");
     HIP_TRY(hipSetDevice(c->device));
     hipStreamSynchronize(c->stream);
     free_constraints(c);
     c->batch_count = batch_count;
+    c->fallback_threshold = fallback_batch_threshold;
+    c->has_fallback = batch_count > fallback_batch_threshold;  // Batches[FallbackBatchThreshold] is the sequential fallback batch
     c->has_widened_types = false;
     c->building = true;
     return BEPUHIP_OK;
@@ -216,7 +219,9 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
         const size_t bundle = (size_t)(i / W), lane = (size_t)(i % W);
         for (int k = 0; k < nb; ++k) {
             int32_t r = refs[bundle * nb * W + (size_t)k * W + lane];
-            if (r < 0) return fail(BEPUHIP_E_UNSUPPORTED, "empty (-1) body reference inside a type batch: sequential fallback layout is not supported");
+            // Empty lanes exist only inside the bundles of the sequential fallback batch (TypeProcessor.cs:451-560): every body slot of the lane is -1.
+            if (r < 0 && !(r == -1 && batch_index == c->fallback_threshold))
+                return fail(BEPUHIP_E_INVALID_ARGUMENT, "empty (-1) body reference inside a synchronized batch");
             tb.refs_soa[(size_t)k * tb.stride + i] = r;
         }
         for (int f = 0; f < pf; ++f) tb.prestep_soa[(size_t)f * tb.stride + i] = prestep[bundle * pf * W + (size_t)f * W + lane];
@@ -241,7 +246,8 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
 static int32_t build_constraints(bepuhip_ctx* c) {
     size_t words = 0;
     c->total_constraints = 0;
-    for (auto& tb : c->tbs) c->total_constraints += tb.count;
+    for (auto& tb : c->tbs)
+        for (int i = 0; i < tb.count; ++i) c->total_constraints += tb.refs_soa[i] != -1;  // a fallback type batch counts its empty lanes in `count`
     // Bodies the reference re-transforms in substep 0 of the conserving angular modes (see momentum_requirk_kernel). Bundles are W consecutive
     // constraints in the HOST's order, so this runs before the island schedule permutes the type batches.
     {
@@ -285,6 +291,9 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             HIP_TRY(hipMemcpy(c->d_requirk, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
         }
     }
+    std::vector<std::vector<int32_t>> fallback_refs;  // the fallback type batches' references (SoA rows), kept past the staging buffers for the level walk below
+    if (c->has_fallback)
+        for (auto& tb : c->tbs) if (tb.batch == c->fallback_threshold) fallback_refs.push_back(tb.refs_soa);
     ClusterPlan plan;
     plan_clusters(c, plan);
     for (auto& tb : c->tbs) {
@@ -311,39 +320,106 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         HIP_TRY(hipMemcpy(c->d_slab, host.data(), words * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_slab0, c->d_slab, words * 4, hipMemcpyDeviceToDevice));
     }
-    // Descriptors: per batch grid layout.
-    c->batch_begin.assign(c->batch_count + 1, 0);
-    c->batch_blocks.assign(c->batch_count, 0);
-    std::vector<DevTypeBatch> descs(c->tbs.size()), inc;
+    // Descriptors: per launch grid layout. Synchronized batches: one launch each, all their type batches in one grid. The sequential fallback batch
+    // (Solver_Solve.cs:546-583: bundles solved one after the other by one thread, since they may share bodies) becomes one launch per DEPENDENCY LEVEL:
+    // walking its type batches and bundles in the reference's order, a constraint's level is one more than the highest level any of its dynamic bodies
+    // was last touched at, so every body still meets its constraints in the reference's order and constraints of one level share no dynamic body.
+    // The rows stay in the caller's layout (empty lanes included: read-backs and ranged updates are unchanged); a level is a list of row indices.
+    const int sync_batches = c->has_fallback ? c->fallback_threshold : c->batch_count;
+    std::vector<std::vector<std::vector<int32_t>>> level_rows;  // [level][fallback type batch ordinal] -> rows
+    std::vector<size_t> fallback_tbs;
+    if (c->has_fallback) {
+        for (size_t t = 0; t < c->tbs.size(); ++t) if (c->tbs[t].batch == c->fallback_threshold) fallback_tbs.push_back(t);
+        std::vector<int32_t> last_level(c->referenced_bodies, -1);
+        for (size_t ord = 0; ord < fallback_tbs.size(); ++ord) {
+            const HostTypeBatch& tb = c->tbs[fallback_tbs[ord]];
+            for (int i = 0; i < tb.count; ++i) {
+                if (fallback_refs[ord][i] == -1) continue;
+                int level = 0;
+                for (int k = 0; k < tb.info.bodies; ++k) {
+                    const int32_t r = fallback_refs[ord][(size_t)k * tb.stride + i];
+                    if ((uint32_t)r < kDynamicLimit) level = std::max(level, last_level[r] + 1);  // kinematic bodies are never written: no ordering through them
+                }
+                for (int k = 0; k < tb.info.bodies; ++k) {
+                    const int32_t r = fallback_refs[ord][(size_t)k * tb.stride + i];
+                    if ((uint32_t)r < kDynamicLimit) last_level[r] = level;
+                }
+                if ((size_t)level >= level_rows.size()) level_rows.resize(level + 1, std::vector<std::vector<int32_t>>(fallback_tbs.size()));
+                level_rows[level][ord].push_back(i);
+            }
+        }
+    }
+    c->launch_count = sync_batches + (int)level_rows.size();
+    c->batch_begin.assign(c->launch_count + 1, 0);
+    c->batch_blocks.assign(c->launch_count, 0);
+    std::vector<DevTypeBatch> descs, inc;
+    std::vector<int32_t> index_pool;               // all levels' row lists + the occupied rows of every incremental fallback type batch
+    std::vector<std::pair<size_t, size_t>> desc_fixups, inc_fixups;  // (descriptor, offset of its row list in index_pool): pointers are set once the pool is on the device
+    auto base_desc = [&](const HostTypeBatch& tb) {
+        DevTypeBatch d;
+        d.type_id = tb.type_id; d.count = tb.count; d.stride = tb.stride; d.block_begin = 0;
+        d.refs = (int*)(c->d_slab + tb.refs_off);
+        d.prestep = (float*)(c->d_slab + tb.prestep_off);
+        d.accum = (float*)(c->d_slab + tb.accum_off);
+        d.indices = nullptr;
+        return d;
+    };
     {
         size_t t = 0;
-        for (int b = 0; b < c->batch_count; ++b) {
-            c->batch_begin[b] = (int)t;
+        for (int b = 0; b < sync_batches; ++b) {
+            c->batch_begin[b] = (int)descs.size();
             int blocks = 0;
             while (t < c->tbs.size() && c->tbs[t].batch == b) {
-                auto& tb = c->tbs[t];
-                DevTypeBatch d;
-                d.type_id = tb.type_id; d.count = tb.count; d.stride = tb.stride; d.block_begin = blocks;
-                d.refs = (int*)(c->d_slab + tb.refs_off);
-                d.prestep = (float*)(c->d_slab + tb.prestep_off);
-                d.accum = (float*)(c->d_slab + tb.accum_off);
-                descs[t] = d;
-                blocks += (tb.count + kBlock - 1) / kBlock;
+                DevTypeBatch d = base_desc(c->tbs[t]);
+                d.block_begin = blocks;
+                descs.push_back(d);
+                blocks += (c->tbs[t].count + kBlock - 1) / kBlock;
                 ++t;
             }
             c->batch_blocks[b] = blocks;
         }
-        c->batch_begin[c->batch_count] = (int)t;
+        for (size_t level = 0; level < level_rows.size(); ++level) {
+            const int b = sync_batches + (int)level;
+            c->batch_begin[b] = (int)descs.size();
+            int blocks = 0;
+            for (size_t ord = 0; ord < fallback_tbs.size(); ++ord) {
+                const std::vector<int32_t>& rows = level_rows[level][ord];
+                if (rows.empty()) continue;
+                DevTypeBatch d = base_desc(c->tbs[fallback_tbs[ord]]);
+                d.count = (int)rows.size(); d.block_begin = blocks;
+                desc_fixups.push_back({descs.size(), index_pool.size()});
+                index_pool.insert(index_pool.end(), rows.begin(), rows.end());
+                descs.push_back(d);
+                blocks += ((int)rows.size() + kBlock - 1) / kBlock;
+            }
+            c->batch_blocks[b] = blocks;
+        }
+        c->batch_begin[c->launch_count] = (int)descs.size();
     }
     c->inc_blocks = 0;
-    for (size_t t = 0; t < c->tbs.size(); ++t) {
-        if (!c->tbs[t].info.incremental || c->tbs[t].count == 0) continue;
-        DevTypeBatch d = descs[t];
+    for (size_t t = 0; t < c->tbs.size(); ++t) {  // the incremental contact update only writes the constraint's own depths: all batches in one grid, the fallback batch included
+        const HostTypeBatch& tb = c->tbs[t];
+        if (!tb.info.incremental || tb.count == 0) continue;
+        DevTypeBatch d = base_desc(tb);
+        if (c->has_fallback && tb.batch == c->fallback_threshold) {  // skip the empty lanes: their references are -1
+            const size_t ord = std::find(fallback_tbs.begin(), fallback_tbs.end(), t) - fallback_tbs.begin();
+            const size_t begin = index_pool.size();
+            for (int i = 0; i < tb.count; ++i) if (fallback_refs[ord][i] != -1) index_pool.push_back(i);
+            d.count = (int)(index_pool.size() - begin);
+            if (d.count == 0) continue;
+            inc_fixups.push_back({inc.size(), begin});
+        }
         d.block_begin = c->inc_blocks;
-        c->inc_blocks += (c->tbs[t].count + kBlock - 1) / kBlock;
+        c->inc_blocks += (d.count + kBlock - 1) / kBlock;
         inc.push_back(d);
     }
     c->inc_tb_count = (int)inc.size();
+    if (!index_pool.empty()) {
+        HIP_TRY(hipMalloc((void**)&c->d_fallback_indices, index_pool.size() * 4));
+        HIP_TRY(hipMemcpy(c->d_fallback_indices, index_pool.data(), index_pool.size() * 4, hipMemcpyHostToDevice));
+        for (auto& fx : desc_fixups) descs[fx.first].indices = c->d_fallback_indices + fx.second;
+        for (auto& fx : inc_fixups) inc[fx.first].indices = c->d_fallback_indices + fx.second;
+    }
     if (!descs.empty()) {
         HIP_TRY(hipMalloc((void**)&c->d_tbs, descs.size() * sizeof(DevTypeBatch)));
         HIP_TRY(hipMemcpy(c->d_tbs, descs.data(), descs.size() * sizeof(DevTypeBatch), hipMemcpyHostToDevice));
@@ -438,7 +514,7 @@ static StepParams make_params(const bepuhip_integrator* in, float dt_for_callbac
 }
 
 static void enqueue_requirk(bepuhip_ctx* c, int substep, int batch, const StepParams& sp) {
-    if (substep != 0 || sp.angular_mode == 0 || c->requirk_begin.empty()) return;
+    if (substep != 0 || sp.angular_mode == 0 || c->requirk_begin.empty() || batch >= c->batch_count) return;
     const int n = c->requirk_begin[batch + 1] - c->requirk_begin[batch];
     if (n > 0)
         hipLaunchKernelGGL(momentum_requirk_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_bodies, (const int*)(c->d_requirk + c->requirk_begin[batch]), n, sp);
@@ -496,7 +572,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             hipLaunchKernelGGL(substep_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, s > 0 ? 1 : 0,
                                in->integrate_velocity_for_kinematics, skip_clustered, sp);
         }
-        for (int b = 0; b < c->batch_count; ++b) {    // :1447-1463
+        for (int b = 0; b < c->launch_count; ++b) {   // :1447-1463 (+ the fallback batch's levels, :546-563)
             if (c->batch_blocks[b] == 0) continue;
             enqueue_requirk(c, s, b, sp);
             Timed t(c, 2);
@@ -504,7 +580,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
                                c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);
         }
         for (int it = 0; it < iterations[s]; ++it) {  // :1464-1476
-            for (int b = 0; b < c->batch_count; ++b) {
+            for (int b = 0; b < c->launch_count; ++b) {  // (+ the fallback batch's levels, :574-583)
                 if (c->batch_blocks[b] == 0) continue;
                 Timed t(c, 3);
                 hipLaunchKernelGGL(batch_kernel<kStageSolve>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
@@ -529,6 +605,8 @@ static int32_t validate_solve(bepuhip_ctx* c, float dt, int32_t substeps, const 
         if (iterations[s] < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Velocity iteration count must be positive.");
     if (in->angular_integration_mode < 0 || in->angular_integration_mode > 2) return fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown AngularIntegrationMode");
     if (c->building) return fail(BEPUHIP_E_STATE, "solve between begin_constraints and end_constraints");
+    if (c->has_fallback && in->angular_integration_mode != 0)
+        return fail(BEPUHIP_E_UNSUPPORTED, "a sequential fallback batch together with a momentum-conserving AngularIntegrationMode; use simulation.Solve");
     if (c->built && c->referenced_bodies > c->body_count)
         return fail(BEPUHIP_E_STATE, "a constraint references body " + std::to_string(c->referenced_bodies - 1) + " but only " + std::to_string(c->body_count) +
                                          " bodies are uploaded (set_bodies)");
@@ -664,7 +742,7 @@ int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, cons
         if (c->boundary_count > 0)  // deltas of this substep are relative to the integrated velocities (identical on every holder)
             hipLaunchKernelGGL(boundary_snapshot_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, (const int*)c->d_boundary, c->boundary_count,
                                c->d_boundary_snapshot);
-        for (int b = 0; b < c->batch_count; ++b)
+        for (int b = 0; b < c->launch_count; ++b)
             if (c->batch_blocks[b] > 0) {
                 enqueue_requirk(c, s, b, sp);
                 hipLaunchKernelGGL(batch_kernel<kStageWarmStart>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
@@ -672,7 +750,7 @@ int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, cons
             }
         if ((st = exchange(s, 0)) != BEPUHIP_OK) return st;
         for (int it = 0; it < iterations[s]; ++it) {
-            for (int b = 0; b < c->batch_count; ++b)
+            for (int b = 0; b < c->launch_count; ++b)
                 if (c->batch_blocks[b] > 0)
                     hipLaunchKernelGGL(batch_kernel<kStageSolve>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
                                        c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);

@@ -82,6 +82,11 @@ class TypeBatchData:
     def bodies(self) -> int:
         return TYPE_TABLE[self.type_id][0]
 
+    def occupied(self, w: int = BUNDLE_WIDTH) -> np.ndarray:
+        """bool[count]: False for the empty lanes (-1 references) a sequential-fallback type batch leaves inside its bundles (TypeProcessor.cs:451-560)."""
+        v = self.body_refs.reshape(bundle_count(self.count, w), self.bodies, w)[:, 0, :].reshape(-1)[:self.count]
+        return v != -1
+
     @property
     def prestep_floats(self) -> int:
         return TYPE_TABLE[self.type_id][1]
@@ -118,7 +123,8 @@ class Scene:
 
     @property
     def constraint_count(self) -> int:
-        return sum(tb.count for b in self.batches for tb in b)
+        """Constraints that exist: a type batch of the sequential fallback batch counts its empty lanes in `count` (ConstraintCount = highest index + 1)."""
+        return sum(int(tb.occupied(self.bundle_width).sum()) if tb.count else 0 for b in self.batches for tb in b)
 
     def copy(self) -> "Scene":
         return Scene(self.bodies.copy(), self.index_to_handle.copy(), self.handle_to_index.copy(),
@@ -131,7 +137,7 @@ class Scene:
         per_type: Dict[str, int] = {}
         for b in self.batches:
             for tb in b:
-                per_type[TYPE_TABLE[tb.type_id][3]] = per_type.get(TYPE_TABLE[tb.type_id][3], 0) + tb.count
+                per_type[TYPE_TABLE[tb.type_id][3]] = per_type.get(TYPE_TABLE[tb.type_id][3], 0) + (int(tb.occupied(self.bundle_width).sum()) if tb.count else 0)
         return f"{self.body_count} bodies, {self.constraint_count} constraints, {len(self.batches)} batches, {per_type}"
 
 
@@ -221,11 +227,11 @@ class SceneBuilder:
                 blocking.append(h)
         for bi in range(len(self._batches) + 1):  # Solver.cs:1189-1196
             if bi == len(self._batches):
-                if bi >= self.fallback_batch_threshold:
-                    raise NotImplementedError("sequential fallback batch")
                 self._batches.append({})
                 self._batch_type_order.append([])
                 self._batch_handles.append(set())
+            if bi == self.fallback_batch_threshold:
+                return self._add_to_fallback(bi, type_id, encoded, blocking, prestep_lane)
             if any(h in self._batch_handles[bi] for h in blocking):
                 continue
             tb = self._batches[bi].get(type_id)
@@ -237,6 +243,45 @@ class SceneBuilder:
             self._batch_handles[bi].update(blocking)
             return bi, len(tb["refs"]) - 1
         raise AssertionError("unreachable")
+
+    def _add_to_fallback(self, bi, type_id, encoded, blocking, prestep_lane) -> tuple:
+        """The sequential fallback batch (batch index == FallbackBatchThreshold, Solver.cs:1878-1884): bodies may repeat across its bundles, never inside one.
+        TypeProcessor.AllocateInTypeBatchForFallback (TypeProcessor.cs:451-560): put the constraint into the first probed bundle that has an empty lane and
+        references none of its bodies (AllowFallbackBundleAllocation :338-359 compares masked indices, kinematic or not); otherwise open a new bundle. Lanes
+        left empty carry -1 references. (The reference probes at most 17 bundles, hashed by handle, once a type batch has more; this mirror probes them all:
+        every layout that keeps the per-bundle invariant is a legal input of the solver.)"""
+        w = self.w
+        nb, pf, _, _ = TYPE_TABLE[type_id]
+        tb = self._batches[bi].get(type_id)
+        if tb is None:
+            tb = self._batches[bi][type_id] = {"refs": [], "prestep": []}
+            self._batch_type_order[bi].append(type_id)
+        masked = {e & BODY_REFERENCE_MASK for e in encoded}
+        refs, pre = tb["refs"], tb["prestep"]
+        target = None
+        for b0 in range(0, len(refs), w):
+            lanes = refs[b0:b0 + w]
+            if any((r & BODY_REFERENCE_MASK) in masked for lane in lanes if lane[0] != -1 for r in lane):
+                continue
+            holes = [b0 + l for l, lane in enumerate(lanes) if lane[0] == -1]
+            if holes:
+                target = holes[0]
+                break
+            if len(lanes) < w:
+                target = len(refs)
+                break
+        if target is None:  # a new bundle: its remaining lanes start out empty
+            while len(refs) % w:
+                refs.append([-1] * nb)
+                pre.append([0.0] * pf)
+            target = len(refs)
+        if target == len(refs):
+            refs.append(encoded)
+            pre.append(list(prestep_lane))
+        else:
+            refs[target], pre[target] = encoded, list(prestep_lane)
+        self._batch_handles[bi].update(blocking)
+        return bi, target
 
     def build(self) -> Scene:
         n = len(self._bodies)

@@ -24,6 +24,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "bepu_constraints.h"
@@ -56,6 +57,7 @@ struct OracleParams {
     int32_t (*exchange)(void* user, int32_t substep, int32_t pass);
     void* exchange_user;
     int32_t angular_integration_mode;  // AngularIntegrationMode (PoseIntegrator.cs:20-38): 0 Nonconserving, 1 ConserveMomentum, 2 ConserveMomentumWithGyroscopicTorque
+    int32_t fallback_batch_threshold;  // SolveDescription.FallbackBatchThreshold (SolveDescription.cs:38); 0 = the default 64. Batch index == threshold is the sequential fallback batch.
 };
 struct OracleScene {
     float* bodies;  // AoS BodyDynamics, 32 floats/body (BepuPhysics/BodyProperties.cs:11-46,258-338)
@@ -140,6 +142,7 @@ struct Ctx {
     std::vector<std::vector<char>> coarse;
     std::vector<uint64_t> mergedConstrained;  // by handle
     std::vector<int> batchStart;              // index of first type batch of each batch
+    int fallbackThreshold = 64;               // SolveDescription.FallbackBatchThreshold: batch index of the sequential fallback batch, if one exists
 };
 
 // TypeProcessor.cs:1204-1248, one lane.
@@ -468,7 +471,23 @@ void prepareIntegrationResponsibilities(Ctx& c) {
         }
         c.flags[b].resize(tbCount);
         c.coarse[b].assign(tbCount, 0);
-        for (int t = 0; t < tbCount; ++t) {  // ComputeIntegrationResponsibilitiesForConstraintRegion<IsNotFallbackBatch>
+        std::unordered_map<int, uint64_t> fallbackEarliest;  // body index -> smallest (type batch << 32 | index) among its constraints in the fallback batch
+        if (b == c.fallbackThreshold) {
+            for (int t = 0; t < tbCount; ++t) {
+                const OracleTypeBatch& tb = s.type_batches[c.batchStart[b] + t];
+                int bodies, pf, imf; bool inc;
+                typeInfo(tb.type_id, bodies, pf, imf, inc);
+                for (int i = 0; i < tb.constraint_count; ++i)
+                    for (int k = 0; k < bodies; ++k) {
+                        int32_t ref = tb.body_refs[(size_t)(i / W) * bodies * W + k * W + (i % W)];
+                        if (ref == -1) continue;
+                        uint64_t slot = ((uint64_t)t << 32) | (uint32_t)i;
+                        auto it = fallbackEarliest.find(ref & kBodyReferenceMask);
+                        if (it == fallbackEarliest.end() || slot < it->second) fallbackEarliest[ref & kBodyReferenceMask] = slot;
+                    }
+            }
+        }
+        for (int t = 0; t < tbCount; ++t) {  // ComputeIntegrationResponsibilitiesForConstraintRegion
             const OracleTypeBatch& tb = s.type_batches[c.batchStart[b] + t];
             int bodies, pf, imf; bool inc;
             typeInfo(tb.type_id, bodies, pf, imf, inc);
@@ -476,12 +495,19 @@ void prepareIntegrationResponsibilities(Ctx& c) {
             if (flagWords < 1) flagWords = 1;
             c.flags[b][t].assign(bodies, std::vector<uint64_t>(flagWords + 1, 0));
             uint64_t mergedFlagBundles = 0;
+            const bool fallback = b == c.fallbackThreshold;  // ComputeIntegrationResponsibilitiesForConstraintRegion<IsFallbackBatch>, Solver_Solve.cs:978-1020
             for (int i = 0; i < tb.constraint_count; ++i) {
                 for (int k = 0; k < bodies; ++k) {
                     int32_t ref = tb.body_refs[(size_t)(i / W) * bodies * W + k * W + (i % W)];
+                    if (fallback && ref == -1) continue;  // an empty lane of a fallback bundle (:983-986)
                     int bodyIndex = ref & kBodyReferenceMask;
                     int h = s.index_to_handle[bodyIndex];
                     if ((firstObserved[h >> 6] >> (h & 63)) & 1ull) {
+                        if (fallback) {
+                            // A body may appear in many constraints of the fallback batch: the EARLIEST slot, ordered by (type batch, index in type batch), integrates it (:1003-1019).
+                            uint64_t currentSlot = ((uint64_t)t << 32) | (uint32_t)i;
+                            if (fallbackEarliest.count(bodyIndex) == 0 || fallbackEarliest[bodyIndex] != currentSlot) continue;
+                        }
                         c.flags[b][t][k][i >> 6] |= 1ull << (i & 63);
                         mergedFlagBundles |= 1;
                     }
@@ -636,6 +662,8 @@ int oracle_solve(OracleScene* scene, const OracleParams* params) {
     const int W = c.W;
     const int threads = params->threads < 1 ? 1 : params->threads;
 
+    c.fallbackThreshold = params->fallback_batch_threshold > 0 ? params->fallback_batch_threshold : 64;
+    if (scene->batch_count > c.fallbackThreshold + 1) return -5;  // at most FallbackBatchThreshold synchronized batches + the fallback batch (Solver.cs:1878-1884)
     // Simulation.Solve: prepass -> Solve -> IntegrateAfterSubstepping (Simulation.cs:278-290)
     prepareIntegrationResponsibilities(c);
 
@@ -667,7 +695,9 @@ int oracle_solve(OracleScene* scene, const OracleParams* params) {
         }
     }
     auto runStage = [&](Stage stage, int b, int substepIndex) {
-        if (threads > 1) {
+        // The fallback batch is solved by one thread, bundle after bundle (Solver_Solve.cs:546-583): its bundles may share bodies with each other.
+        // (Its incremental contact update only writes the constraint's own depths and is dispatched like any other batch, :154-164.)
+        if (threads > 1 && !(b == c.fallbackThreshold && stage != kStageIncremental)) {
             std::function<void(const Block&)> f = [&](const Block& blk) { runBlock(c, stage, b, blk.typeBatch, substepIndex, substepDt, inverseDt, blk.start, blk.end); };
             pool->run(batchBlocks[b], f);
         } else {

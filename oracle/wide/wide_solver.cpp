@@ -15,6 +15,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "wide_contacts.h"
@@ -26,6 +27,7 @@ struct SceneTypeBatch { int32_t type_id, constraint_count; void* body_refs; void
 struct SceneParams {
     float dt; int32_t substep_count; const int32_t* velocity_iterations; float gravity[3]; float linear_damping, angular_damping;
     int32_t allow_substeps_for_unconstrained, integrate_velocity_for_kinematics, threads; void* exchange; void* exchange_user; int32_t angular_integration_mode;
+    int32_t fallback_batch_threshold;  // SolveDescription.FallbackBatchThreshold; 0 = 64
 };
 struct SceneDesc {
     float* bodies; int32_t body_count; const int32_t* index_to_handle; const int32_t* handle_to_index; int32_t handle_capacity; int32_t batch_count;
@@ -721,7 +723,7 @@ struct Solver {
     std::vector<IndexSet> batchReferencedHandles;
     int substepCount, VelocityIterationCount;
     std::vector<int> velocityIterations;  // the VelocityIterationScheduler's answers (Solver_Solve.cs:743-751)
-    static constexpr int FallbackBatchThreshold = 64;  // SolveDescription.cs:38
+    int FallbackBatchThreshold = 64;  // SolveDescription.cs:38; Batches[FallbackBatchThreshold], when it exists, is the sequential fallback batch (Solver.cs:1878-1884)
 
     // ---- integration responsibilities (:951-1388)
     std::vector<std::vector<std::vector<IndexSet>>> integrationFlags;  // [batch][typeBatch][bodyIndexInConstraint]
@@ -729,7 +731,10 @@ struct Solver {
     std::vector<IndexSet> bodiesFirstObservedInBatches;
     IndexSet mergedConstrainedBodyHandles;
 
-    bool ComputeIntegrationResponsibilitiesForConstraintRegion(int batchIndex, int typeBatchIndex, int constraintStart, int exclusiveConstraintEnd) {  // :951 (IsNotFallbackBatch)
+    // activeSet.Constraints[bodyIndex] scanned for the earliest slot in the fallback batch (:1003-1013), precomputed once per solve: body index -> (type batch << 32 | index)
+    std::unordered_map<int, uint64_t> fallbackEarliestSlot;
+    template <bool IsFallbackBatch>
+    bool ComputeIntegrationResponsibilitiesForConstraintRegion(int batchIndex, int typeBatchIndex, int constraintStart, int exclusiveConstraintEnd) {  // :951
         IndexSet& firstObservedForBatch = bodiesFirstObservedInBatches[batchIndex];
         std::vector<IndexSet>& integrationFlagsForTypeBatch = integrationFlags[batchIndex][typeBatchIndex];
         TypeBatch& typeBatch = Batches[batchIndex].TypeBatches[typeBatchIndex];
@@ -746,9 +751,25 @@ struct Solver {
                 IndexSet& integrationFlagsForBodyInConstraint = integrationFlagsForTypeBatch[bodyIndexInConstraint];
                 const int32_t* bundleStart = bundleBodyReferencesStart + bodyIndexInConstraint * W;
                 for (int bundleInnerIndex = 0; bundleInnerIndex < countInBundle; ++bundleInnerIndex) {
-                    int bodyIndex = bundleStart[bundleInnerIndex] & BodyReferenceMask;
+                    int bodyIndex;
+                    if constexpr (IsFallbackBatch) {
+                        int rawBodyIndex = bundleStart[bundleInnerIndex];
+                        if (rawBodyIndex == -1) continue;  // fallback bundles can hold empty lanes anywhere (:983-986)
+                        bodyIndex = rawBodyIndex & BodyReferenceMask;
+                    } else {
+                        bodyIndex = bundleStart[bundleInnerIndex] & BodyReferenceMask;
+                    }
                     int bodyHandle = IndexToHandle[bodyIndex];
-                    if (firstObservedForBatch.Contains(bodyHandle)) integrationFlagsForBodyInConstraint.AddUnsafely(bundleStartIndexInConstraints + bundleInnerIndex);
+                    if (firstObservedForBatch.Contains(bodyHandle)) {
+                        if constexpr (IsFallbackBatch) {
+                            // the body may appear in several constraints of this batch: the earliest slot integrates it (:1003-1019)
+                            int indexInTypeBatch = bundleStartIndexInConstraints + bundleInnerIndex;
+                            uint64_t currentSlot = ((uint64_t)typeBatchIndex << 32) | (uint32_t)indexInTypeBatch;
+                            if (currentSlot == fallbackEarliestSlot[bodyIndex]) integrationFlagsForBodyInConstraint.AddUnsafely(indexInTypeBatch);
+                        } else {
+                            integrationFlagsForBodyInConstraint.AddUnsafely(bundleStartIndexInConstraints + bundleInnerIndex);
+                        }
+                    }
                 }
             }
         }
@@ -801,6 +822,25 @@ struct Solver {
             }
             batchHasAnyIntegrationResponsibilities[batchIndex] = horizontalMerge != 0;
         }
+        const int synchronizedBatchCount = std::min(batchCount, FallbackBatchThreshold);  // GetSynchronizedBatchCount, Solver.cs:1878
+        const bool fallbackExists = batchCount > FallbackBatchThreshold;
+        fallbackEarliestSlot.clear();
+        if (fallbackExists) {
+            ConstraintBatch& batch = Batches[FallbackBatchThreshold];
+            for (int j = 0; j < (int)batch.TypeBatches.size(); ++j) {
+                TypeBatch& typeBatch = batch.TypeBatches[j];
+                int bodiesPerConstraint = TypeProcessors[typeBatch.TypeId]->BodiesPerConstraint;
+                const int32_t* refs = (const int32_t*)typeBatch.BodyReferences;
+                for (int i = 0; i < typeBatch.ConstraintCount; ++i)
+                    for (int k = 0; k < bodiesPerConstraint; ++k) {
+                        int32_t raw = refs[(i >> 3) * bodiesPerConstraint * W + k * W + (i & 7)];
+                        if (raw == -1) continue;
+                        uint64_t slot = ((uint64_t)j << 32) | (uint32_t)i;
+                        auto it = fallbackEarliestSlot.find(raw & BodyReferenceMask);
+                        if (it == fallbackEarliestSlot.end() || slot < it->second) fallbackEarliestSlot[raw & BodyReferenceMask] = slot;
+                    }
+            }
+        }
         bool useSingleThreadedPath = true;
         if (threadDispatcher != nullptr && threadDispatcher->ThreadCount() > 1) {  // :1218-1271
             struct Job { int batch, typeBatch, start, end; };
@@ -829,18 +869,26 @@ struct Solver {
                     int jobIndex;
                     while ((jobIndex = nextJob.fetch_add(1)) < (int)jobs.size()) {
                         const Job& job = jobs[jobIndex];
-                        jobAlignedIntegrationResponsibilities[jobIndex] = ComputeIntegrationResponsibilitiesForConstraintRegion(job.batch, job.typeBatch, job.start, job.end);
+                        jobAlignedIntegrationResponsibilities[jobIndex] = job.batch == FallbackBatchThreshold
+                                                                              ? ComputeIntegrationResponsibilitiesForConstraintRegion<true>(job.batch, job.typeBatch, job.start, job.end)
+                                                                              : ComputeIntegrationResponsibilitiesForConstraintRegion<false>(job.batch, job.typeBatch, job.start, job.end);
                     }
                 });
                 for (size_t i = 0; i < jobs.size(); ++i) coarseBatchIntegrationResponsibilities[jobs[i].batch][jobs[i].typeBatch] |= jobAlignedIntegrationResponsibilities[i];
             }
         }
         if (useSingleThreadedPath) {
-            for (int i = 1; i < batchCount; ++i) {
+            for (int i = 1; i < synchronizedBatchCount; ++i) {
                 if (!batchHasAnyIntegrationResponsibilities[i]) continue;
                 ConstraintBatch& batch = Batches[i];
                 for (int j = 0; j < (int)batch.TypeBatches.size(); ++j)
-                    coarseBatchIntegrationResponsibilities[i][j] = ComputeIntegrationResponsibilitiesForConstraintRegion(i, j, 0, batch.TypeBatches[j].ConstraintCount);
+                    coarseBatchIntegrationResponsibilities[i][j] = ComputeIntegrationResponsibilitiesForConstraintRegion<false>(i, j, 0, batch.TypeBatches[j].ConstraintCount);
+            }
+            if (fallbackExists && batchHasAnyIntegrationResponsibilities[FallbackBatchThreshold]) {  // :1285-1293
+                ConstraintBatch& batch = Batches[FallbackBatchThreshold];
+                for (int j = 0; j < (int)batch.TypeBatches.size(); ++j)
+                    coarseBatchIntegrationResponsibilities[FallbackBatchThreshold][j] =
+                        ComputeIntegrationResponsibilitiesForConstraintRegion<true>(FallbackBatchThreshold, j, 0, batch.TypeBatches[j].ConstraintCount);
             }
         }
         for (int handle : ConstrainedKinematicHandles) mergedConstrainedBodyHandles.AddUnsafely(handle);  // :1378
@@ -1036,6 +1084,7 @@ struct Solver {
         int incrementalUpdateWorkerStart = GetUniformlyDistributedStart(workerIndex, (int)substepContext.IncrementalUpdateBlocks.size(), workerCount, 0);
         int kinematicIntegrationWorkerStart = GetUniformlyDistributedStart(workerIndex, (int)substepContext.KinematicIntegrationBlocks.size(), workerCount, 0);
         int synchronizedBatchCount = std::min((int)Batches.size(), FallbackBatchThreshold);
+        const bool fallbackExists = (int)Batches.size() > FallbackBatchThreshold;
         std::vector<int> batchStarts(Batches.size());
         for (int batchIndex = 0; batchIndex < synchronizedBatchCount; ++batchIndex) {
             int batchOffset = batchIndex > 0 ? substepContext.ConstraintBatchBoundaries[batchIndex - 1] : 0;
@@ -1083,11 +1132,25 @@ struct Solver {
                     ++syncIndex;
                     ExecuteMainStage(warmstartStage, workerIndex, batchStarts[batchIndex], substepContext.Stages[batchIndex + 2], std::max(0, syncIndex - warmStartLookback), syncIndex);
                 }
+                if (fallbackExists) {  // :546-563: the fallback batch runs on worker 0, bundle after bundle
+                    ConstraintBatch& batch = Batches[FallbackBatchThreshold];
+                    for (int j = 0; j < (int)batch.TypeBatches.size(); ++j) {
+                        TypeBatch& typeBatch = batch.TypeBatches[j];
+                        WarmStartBlock(substepIndex != 0, 0, FallbackBatchThreshold, j, 0, typeBatch.BundleCount, typeBatch, TypeProcessors[typeBatch.TypeId].get(), Dt, InverseDt);
+                    }
+                }
                 int velocityIterationCountForSubstep = substepContext.VelocityIterationCounts[substepIndex];
                 for (int iterationIndex = 0; iterationIndex < velocityIterationCountForSubstep; ++iterationIndex) {
                     for (int batchIndex = 0; batchIndex < synchronizedBatchCount; ++batchIndex) {
                         ++syncIndex;
                         ExecuteMainStage(solveStage, workerIndex, batchStarts[batchIndex], substepContext.Stages[batchIndex + 2], std::max(0, syncIndex - synchronizedBatchCount), syncIndex);
+                    }
+                    if (fallbackExists) {  // :574-583
+                        ConstraintBatch& batch = Batches[FallbackBatchThreshold];
+                        for (int j = 0; j < (int)batch.TypeBatches.size(); ++j) {
+                            TypeBatch& typeBatch = batch.TypeBatches[j];
+                            TypeProcessors[typeBatch.TypeId]->Solve(typeBatch, bodies, Dt, InverseDt, 0, typeBatch.BundleCount);
+                        }
                     }
                 }
             }
@@ -1401,7 +1464,8 @@ static int SolveScene(SceneDesc* scene, SceneParams* params) {
         if (v < 1) return 1;
     solver.TypeProcessors.resize(64);
     solver.Batches.resize(scene->batch_count);
-    if (scene->batch_count > Solver::FallbackBatchThreshold) return 4;  // a sequential fallback batch exists (Solver.cs:1878-1884): not part of this restatement
+    solver.FallbackBatchThreshold = params->fallback_batch_threshold > 0 ? params->fallback_batch_threshold : 64;
+    if (scene->batch_count > solver.FallbackBatchThreshold + 1) return 4;  // at most FallbackBatchThreshold synchronized batches + the fallback batch
     solver.batchReferencedHandles.assign(scene->batch_count, {});
     int flat = 0;
     for (int b = 0; b < scene->batch_count; ++b) {

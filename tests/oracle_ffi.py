@@ -18,7 +18,8 @@ class OracleTypeBatch(C.Structure):
 class OracleParams(C.Structure):
     _fields_ = [("dt", C.c_float), ("substep_count", C.c_int32), ("velocity_iterations", C.c_void_p), ("gravity", C.c_float * 3),
                 ("linear_damping", C.c_float), ("angular_damping", C.c_float), ("allow_substeps_for_unconstrained", C.c_int32),
-                ("integrate_velocity_for_kinematics", C.c_int32), ("threads", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p), ("angular_integration_mode", C.c_int32)]
+                ("integrate_velocity_for_kinematics", C.c_int32), ("threads", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p), ("angular_integration_mode", C.c_int32),
+                ("fallback_batch_threshold", C.c_int32)]  # 0 = SolveDescription.DefaultFallbackBatchThreshold (64)
 
 
 class OracleScene(C.Structure):
@@ -104,6 +105,7 @@ def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool 
     p.integrate_velocity_for_kinematics = int(bool(callbacks.integrate_velocity_for_kinematics))
     p.threads = int(threads)
     p.angular_integration_mode = int(getattr(callbacks, "angular_integration_mode", 0))
+    p.fallback_batch_threshold = int(solve_description.fallback_batch_threshold)
     failure = []
     fn = None
     if exchange is not None:  # exchange(substep, pass) after every pass: the CPU stand-in of HipSolver.solve_exchanged

@@ -254,3 +254,29 @@ def island_scene(seed, islands, bodies_per_island, constraints_per_island, type_
             lanes = rng.uniform(0.0, 0.05, size=(tb.count, tb.impulse_floats)).astype(np.float32)
             tb.accumulated[...] = to_aosoa(lanes, scene.bundle_width)
     return scene
+
+
+def star_scene(seed, spokes=80, hubs=2, type_ids=(7, 22, 4, 47, 30), fallback_batch_threshold=64, extra_constraints=40) -> Scene:
+    """Hub bodies with more constraints than the batch limit: every constraint on a hub needs its own batch, so the ones beyond
+    FallbackBatchThreshold land in the sequential fallback batch (Solver.cs:1878-1884, TypeProcessor.cs:451-560). Plus a few hub-free constraints
+    between spokes and one-body contacts so that the fallback batch is not the only thing that happens."""
+    rng = np.random.default_rng(seed)
+    sb = SceneBuilder(fallback_batch_threshold=fallback_batch_threshold)
+    hub_handles = [sb.add_body(random_dynamic_body(rng, rng.uniform(-1, 1, 3))) for _ in range(hubs)]
+    spoke_handles = [sb.add_body(random_dynamic_body(rng, rng.uniform(-4, 4, 3)) if i % 9 else kinematic_body(rng, rng.uniform(-4, 4, 3))) for i in range(spokes)]
+    for i, s in enumerate(spoke_handles):
+        t = type_ids[i % len(type_ids)]
+        h = hub_handles[i % hubs]
+        pair = [h, s] if i % 3 else [s, h]
+        sb.add_constraint(t, pair, prestep_for(rng, t, sb._bodies[pair[0]][4:7], sb._bodies[pair[1]][4:7]))
+    for _ in range(extra_constraints):
+        a, b = rng.choice(len(spoke_handles), 2, replace=False)
+        ha, hb = spoke_handles[a], spoke_handles[b]
+        if sb.is_kinematic(ha) and sb.is_kinematic(hb):
+            continue
+        t = type_ids[int(rng.integers(len(type_ids)))]
+        sb.add_constraint(t, [ha, hb], prestep_for(rng, t, sb._bodies[ha][4:7], sb._bodies[hb][4:7]))
+    for s in spoke_handles[::7]:
+        if not sb.is_kinematic(s):
+            sb.add_constraint(3, [s], prestep_for(rng, 3, sb._bodies[s][4:7], None))
+    return sb.build()

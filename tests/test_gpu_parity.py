@@ -115,6 +115,14 @@ def test_device_constrained_set_matches_oracle_prepass(hip_solver_factory):
     assert np.array_equal((flags & 1).astype(bool), bits[scene.index_to_handle])
 
 
+def _unknown_type_batch(scene):
+    from bepuphysics2_amd.scene import TypeBatchData
+    tb = scene.batches[0][0]
+    fake = TypeBatchData.__new__(TypeBatchData)
+    fake.type_id, fake.count, fake.body_refs, fake.prestep, fake.accumulated = 63, tb.count, tb.body_refs, tb.prestep, tb.accumulated
+    return fake
+
+
 def test_error_behaviour_through_abi(hip_solver_factory):
     from bepuphysics2_amd import native
     solver = hip_solver_factory()
@@ -123,8 +131,11 @@ def test_error_behaviour_through_abi(hip_solver_factory):
     cb = PoseIntegratorCallbacks()
     with pytest.raises(ValueError):
         solver.solve(0.0, SolveDescription(1, 1), cb)  # ArgumentException in the reference (Simulation.cs:318-319)
+    with pytest.raises(ValueError):
+        solver.set_constraints(scene, fallback_batch_threshold=2)  # more than threshold + 1 batches cannot exist in the reference (Solver.cs:1882)
     with pytest.raises(native.UnsupportedError):
-        solver.set_constraints(scene, fallback_batch_threshold=2)  # more batches than the threshold => fallback batch exists
+        solver.set_constraints(small_scenes.random_graph_scene(1, 8, 6, [7]).__class__(scene.bodies, scene.index_to_handle, scene.handle_to_index,
+                               [[_unknown_type_batch(scene)]], scene.constrained_kinematic_handles, scene.bundle_width))  # a type id the library does not know
 
 
 def test_hip_timestepper_through_host_mirror(hip_solver_factory):

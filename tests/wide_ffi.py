@@ -51,6 +51,7 @@ def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool 
     p.integrate_velocity_for_kinematics = int(bool(callbacks.integrate_velocity_for_kinematics))
     p.threads = int(threads)
     p.angular_integration_mode = int(getattr(callbacks, "angular_integration_mode", 0))
+    p.fallback_batch_threshold = int(solve_description.fallback_batch_threshold)
     rc = lib.wide_solve(C.byref(m.c), C.byref(p))
     if rc != 0:
         raise RuntimeError(f"wide_solve failed: {rc}")
