@@ -80,6 +80,53 @@ def cpu_baseline(ragdolls_sample: int, seed: int, target_seconds: float = 12.0):
                       f"threading, best of thread counts {candidates} on {avail} available CPUs"}
 
 
+def connected_scene_leg(name: str, scene_args, device: int, steps: int = 100):
+    """A scene that is ONE island (no workgroup's LDS holds it): the general-topology schedule (one launch per batch per stage, hipGraph replay).
+    Extra keys on the bench line, never `value`: the pile is BASELINE.json configs[1]; the crowd is configs[2]'s ragdolls lying on each other, as the
+    reference's benchmark ends up (RagdollTubeBenchmark.cs:536-569). Roofline: SURVEY.md 8d algorithmic bytes of a step / time of a step."""
+    from bepuphysics2_amd.hostlib import HostSimulation
+    from bepuphysics2_amd.native import HipSolver
+    from bepuphysics2_amd.roofline import INTEGRATE_BYTES_PER_BODY, FINAL_BYTES_PER_BODY, scene_stage_bytes
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    sim = HostSimulation.scene(*scene_args)
+    scene, sd = sim.export(), sim.solve_description()
+    sim.close()
+    cb = PoseIntegratorCallbacks()
+    solver = HipSolver(device=device)
+    t0 = time.perf_counter()
+    solver.upload(scene)
+    upload_ms = 1e3 * (time.perf_counter() - t0)
+    for _ in range(100):
+        solver.solve(1 / 60, sd, cb, asynchronous=True)
+    solver.reset_state()
+    solver.sync()
+    for _ in range(5):
+        solver.solve(1 / 60, sd, cb, asynchronous=True)
+    solver.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solver.solve(1 / 60, sd, cb, asynchronous=True)
+    solver.sync()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    finite = bool(np.isfinite(solver.get_bodies(scene.body_count)).all())
+    clustered = bool(solver.cluster_cycles().size)
+    solver.close()
+    its = sd.iterations()
+    ws, sv, inc = scene_stage_bytes(scene)
+    step_bytes = (sv * int(its.sum()) + ws * sd.substep_count + inc * (sd.substep_count - 1) + INTEGRATE_BYTES_PER_BODY * scene.body_count * sd.substep_count
+                  + FINAL_BYTES_PER_BODY * scene.body_count)
+    per_step = scene.constraint_count * int((1 + its).sum())
+    launches = sd.substep_count * (2 + len(scene.batches) * 1) + len(scene.batches) * int(its.sum()) + 1
+    gbs = step_bytes / (ms * 1e-3) / 1e9
+    return {"workload": f"{name}: {scene.body_count} bodies, {scene.constraint_count} constraints, {len(scene.batches)} batches, ONE island, "
+                        f"{sd.substep_count} substeps x {list(map(int, its))} iterations",
+            "ms_per_step": ms, "value": per_step / (ms * 1e-3), "unit": "constraint-iterations/s",
+            "schedule": "island-per-workgroup" if clustered else f"launch-per-batch, hipGraph replay, {launches} launches per step",
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": step_bytes,
+                         "us_per_launch": 1e3 * ms / launches},
+            "upload_ms": upload_ms, "finite": finite}
+
+
 def measure_traffic(args):
     """HBM bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md's HBM section prescribes: separate
     rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE (they do not fit one pass), counters in KiB, and the gfx950 correction (FETCH_SIZE
@@ -198,6 +245,7 @@ def main():
     ap.add_argument("--no-prewarm", action="store_true", help="skip the clock pre-warm of the setup phase (300 untimed solves, state restored afterwards)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE child runs behind roofline.traffic")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-connected-scenes", action="store_true", help="skip the extra legs on connected scenes (100k-box pile = configs[1]; ragdoll crowd)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -350,6 +398,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         baseline = cpu_baseline(args.ragdolls, 5)  # the same scene as the GPU leg; bounded by time (about 12 s after picking the thread count)
 
+    main_clustered = bool(solver.cluster_cycles().size)
+    connected = None
+    if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
+        solver.close()
+        connected = {"pile_100k": connected_scene_leg("100k-box pile (BASELINE.json configs[1])", ("pile", 100000, 0, 0, 5), local_rank),
+                     "ragdoll_crowd": connected_scene_leg(f"{args.ragdolls} ragdolls in contact with their neighbours (configs[2]'s ragdolls, one island)",
+                                                          ("ragdoll_tube", args.ragdolls, 1, 2, 5), local_rank)}
+
     if rank == 0:
         value = whole_job_rate
         out = {
@@ -362,11 +418,11 @@ def main():
                        "sharding": (f"ONE scene of {args.ragdolls * world} ragdolls ({whole_constraints} constraints) cut into whole islands per GPU by "
                                     "sharding.split_scene_by_islands (BASELINE.json configs[3]); no data-path collective, RCCL barrier + timing reduction only")
                                    if (world > 1 or dist is not None) else "single GPU",
-                       "schedule": "island-per-workgroup: one plain kernel launch per step" if solver.cluster_cycles().size else
+                       "schedule": "island-per-workgroup: one plain kernel launch per step" if main_clustered else
                                    ("launch-per-batch" + ("" if args.no_graph else ", hipGraph replay")),
                        "device_prewarm": f"{prewarm_steps} untimed solves during setup, uploaded state restored before the {args.warmup} warm-up steps",
                        "finite": finite},
-            "roofline": roofline, "cpu_baseline": baseline,
+            "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -340,7 +340,7 @@ Simulation* buildRagdollTube(int64_t ragdollCount, int64_t withContacts, int64_t
                 ragdolls.push_back(addRagdoll(*sim, origin + Vector3{spacing.X * i, spacing.Y * j, spacing.Z * k}, yaw, rng, 0.05f));
     // Kinematic tube: BodyDescription.CreateKinematic(tubeCenter, (default, (0,0,.25))) :566
     int32_t tube = sim->bodies.Add(BodyDescription::CreateKinematic(RigidPose{{0, 8, 0}, Quaternion{}}, BodyVelocity{{0, 0, 0}, {0, 0, 0.25f}}));
-    if (lattice) {
+    if (lattice == 1) {
         // config 5: one connected lattice — chain neighbouring ragdolls hand-to-hand (x) and head-to-foot (y) with ball sockets.
         SpringSettings sp(15.f, 1.f);
         // The anchor of every link is the midpoint between the two bodies' rest positions, expressed in each body's local frame: the lattice
@@ -369,6 +369,31 @@ Simulation* buildRagdollTube(int64_t ragdollCount, int64_t withContacts, int64_t
             addSyntheticPairContact(*sim, rng, 2, r.lowerArm[0], r.abdomen, m, false);
             addSyntheticPairContact(*sim, rng, 3, r.lowerLeg[1], r.lowerLeg[0], m, false);
             addSyntheticPairContact(*sim, rng, 4, r.upperArm[1], r.hips, m, false);
+        }
+        if (lattice == 2) {
+            // "Crowd": what the reference's benchmark really turns into once the ragdolls have dropped into the rotating tube and lie on each other
+            // (RagdollTubeBenchmark.cs:536-569): contact manifolds BETWEEN neighbouring ragdolls, added after every ragdoll's own constraints, as the
+            // narrow phase would. Neighbours along the three grid axes touch limb to limb, so the ragdolls form one connected island (no workgroup's LDS
+            // holds it: the general-topology schedule has to take it).
+            const int64_t strideY = length, strideX = (int64_t)length * height;
+            for (int64_t r = 0; r < (int64_t)ragdolls.size(); ++r) {
+                const Ragdoll& a = ragdolls[r];
+                if (r + 1 < (int64_t)ragdolls.size() && (r + 1) % length != 0) {       // next along z (0.5 apart): chest to chest, arm to arm
+                    const Ragdoll& b = ragdolls[r + 1];
+                    addSyntheticPairContact(*sim, rng, 4, a.chest, b.chest, m, false);
+                    addSyntheticPairContact(*sim, rng, 2, a.upperArm[0], b.upperArm[0], m, false);
+                    addSyntheticPairContact(*sim, rng, 2, a.upperLeg[1], b.upperLeg[1], m, false);
+                }
+                if (r + strideY < (int64_t)ragdolls.size() && (r / strideY + 1) % height != 0) {  // the one above (1.8 up): its feet on this one's shoulders
+                    const Ragdoll& b = ragdolls[r + strideY];
+                    addSyntheticPairContact(*sim, rng, 3, b.foot[0], a.upperArm[0], m, false);
+                    addSyntheticPairContact(*sim, rng, 3, b.foot[1], a.upperArm[1], m, false);
+                }
+                if (r + strideX < (int64_t)ragdolls.size()) {                          // next along x (1.7 apart): hand in hand
+                    const Ragdoll& b = ragdolls[r + strideX];
+                    addSyntheticPairContact(*sim, rng, 1, a.hand[0], b.hand[1], m, false);
+                }
+            }
         }
     }
     return sim;

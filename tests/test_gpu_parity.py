@@ -290,3 +290,29 @@ def test_momentum_conserving_angular_integration_modes(hip_solver_factory, mode)
             assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (mode, use_clusters, m)
     plain = pu.run_oracle(scene, 1 / 60, sd, PoseIntegratorCallbacks(**kw), frames=2)
     assert not np.array_equal(plain.bodies, ref.bodies)  # the mode does change the answer
+
+
+def test_ragdoll_crowd_one_connected_island_against_oracle(hip_solver_factory):
+    """VERDICT r1 missing #4: the reference's ragdolls end up lying on each other (RagdollTubeBenchmark.cs:536-569). Ragdoll-to-ragdoll contact manifolds make
+    the scene ONE island that no workgroup's LDS holds, so the general-topology schedule runs it; bit-exact against the oracle, and against oracle/wide."""
+    import wide_ffi
+    from bepuphysics2_amd import sharding
+    from bepuphysics2_amd.hostlib import HostSimulation
+    sim = HostSimulation.scene("ragdoll_tube", 1200, 1, 2, 11)
+    scene, sd = sim.export(), sim.solve_description()
+    sim.close()
+    labels = sharding.island_labels(scene)
+    dynamic = np.any(scene.bodies[:, 16:23] != 0, axis=1)
+    assert len(set(labels[dynamic].tolist())) == 1
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=3, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=3)
+    assert solver.cluster_cycles().size == 0  # not the island schedule
+    m = pu.compare_scenes(ref, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    second = scene.copy()
+    for _ in range(3):
+        wide_ffi.solve(second, 1 / 60, sd, cb, threads=4)
+    m2 = pu.compare_scenes(second, got)
+    assert m2["bodies_bit_exact"] and m2["impulses_bit_exact"] and m2["prestep_bit_exact"], m2
