@@ -127,6 +127,59 @@ def connected_scene_leg(name: str, scene_args, device: int, steps: int = 100):
             "upload_ms": upload_ms, "finite": finite}
 
 
+def boundary_leg(scene, sd, cb, device: int):
+    """What a C# host pays around the resident-in-HBM rate (never `value`): a full upload (set_bodies + begin/set/end, i.e. AOSOA -> rows, cluster planning,
+    H2D), and a frame through the ABI the way HipTimestepper drives it (set_bodies, solve, get_bodies, every type batch's accumulated impulses and the contacts'
+    prestep back), plus the device-resident alternative: 1 % of the contact constraints removed and re-added through the structural calls, then a solve."""
+    from bepuphysics2_amd.native import HipSolver
+    from bepuphysics2_amd.scene import TYPE_TABLE
+    solver = HipSolver(device=device)
+    t0 = time.perf_counter()
+    solver.set_bodies(scene.bodies)
+    t1 = time.perf_counter()
+    solver.set_constraints(scene, sd.fallback_batch_threshold)
+    kin = np.ascontiguousarray(scene.constrained_kinematic_indices(), dtype=np.int32)
+    from bepuphysics2_amd.native import _check, _ptr
+    _check(solver.lib, solver.lib.bepuhip_set_constrained_kinematics(solver.ctx, _ptr(kin), kin.size))
+    t2 = time.perf_counter()
+    solver._scene_meta = None
+    out = {"set_bodies_ms": 1e3 * (t1 - t0), "end_constraints_ms": 1e3 * (t2 - t1),
+           "end_constraints_note": "begin/set_type_batch/end: AOSOA -> SoA rows, island (cluster) planning on the host, one H2D copy"}
+    work = scene.copy()
+    frames = 5
+    solver.solve(1 / 60, sd, cb)
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        solver.set_bodies(work.bodies)
+        solver.solve(1 / 60, sd, cb)
+        solver.download(work)
+    out["frame_through_abi_ms"] = 1e3 * (time.perf_counter() - t0) / frames
+    out["frame_through_abi_note"] = "set_bodies + solve + get_bodies + get_accumulated_impulses / get_prestep of every type batch (HipTimestepper's frame), host buffers pageable"
+    # structural churn: 1 % of the two-body contact constraints removed and re-added (same bodies, same prestep) per frame
+    contact = [(bi, tb) for bi, b in enumerate(scene.batches) for tb in b if TYPE_TABLE[tb.type_id][3].startswith("Contact") and tb.bodies == 2 and tb.count > 100]
+    if contact:
+        rng = np.random.default_rng(1)
+        picks = []
+        for bi, tb in contact:
+            k = max(1, tb.count // 100)
+            refs, pre = tb.refs_lanes(scene.bundle_width), tb.prestep_lanes(scene.bundle_width)
+            for i in rng.choice(tb.count - k, k, replace=False):
+                picks.append((bi, tb.type_id, int(i), refs[i].copy(), pre[i].copy()))
+        solver.remove_constraint(*picks[0][:3])  # leaves the island schedule (rows back in the caller's order): a one-off, not part of the per-frame cost
+        solver.add_constraint(picks[0][0], picks[0][1], picks[0][3], picks[0][4])
+        solver.solve(1 / 60, sd, cb)
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            for bi, t, i, refs, pre in picks:
+                solver.remove_constraint(bi, t, i)
+                solver.add_constraint(bi, t, refs, pre)
+            solver.solve(1 / 60, sd, cb)
+        out["structural_frame_ms"] = 1e3 * (time.perf_counter() - t0) / frames
+        out["structural_frame_note"] = f"{len(picks)} remove_constraint + {len(picks)} add_constraint calls (1 % of the two-body contacts) + solve on the launch-per-batch schedule"
+    solver.close()
+    return out
+
+
 def measure_traffic(args):
     """HBM bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md's HBM section prescribes: separate
     rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE (they do not fit one pass), counters in KiB, and the gfx950 correction (FETCH_SIZE
@@ -406,6 +459,10 @@ def main():
                      "ragdoll_crowd": connected_scene_leg(f"{args.ragdolls} ragdolls in contact with their neighbours (configs[2]'s ragdolls, one island)",
                                                           ("ragdoll_tube", args.ragdolls, 1, 2, 5), local_rank)}
 
+    boundary = None
+    if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
+        boundary = boundary_leg(scene, sd, cb, local_rank)
+
     if rank == 0:
         value = whole_job_rate
         out = {
@@ -422,7 +479,7 @@ def main():
                                    ("launch-per-batch" + ("" if args.no_graph else ", hipGraph replay")),
                        "device_prewarm": f"{prewarm_steps} untimed solves during setup, uploaded state restored before the {args.warmup} warm-up steps",
                        "finite": finite},
-            "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected,
+            "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "boundary": boundary,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -44,14 +44,22 @@ def build_hip(force: bool = False, jobs: int = 0) -> str:
     sources = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h", ".inc"))] + [os.path.join(REPO, "include", "bepuhip.h")]
     units = _hip_units(src_dir)
     objects = [os.path.join(obj_dir, u[:-4] + ".o") for u in units]
-    if not force and _newer(out, sources) and all(_newer(o, sources) for o in objects):
+    if not force and _newer(out, sources):
         return out
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
 
+    host_only = {"bepuhip.hip", "bepu_host_state.h", "bepu_cluster_plan.h"}  # read by bepuhip.hip alone: the cluster units do not depend on them
+    cluster_only = {"bepu_cluster_kernel.h", "bepu_cluster_variant.inc"}
+
+    def unit_sources(unit):
+        skip = cluster_only if unit == "bepuhip.hip" else host_only
+        own = os.path.join(src_dir, unit)
+        return [s for s in sources if s == own or (os.path.basename(s) not in skip and not s.endswith(".hip"))]
+
     def compile_unit(unit_object):
         unit, obj = unit_object
-        if not force and _newer(obj, sources):
+        if not force and _newer(obj, unit_sources(unit)):
             return
         tmp = obj + f".tmp{os.getpid()}"
         subprocess.check_call([hipcc] + HIP_COMPILE_FLAGS + ["-c", "-o", tmp, os.path.join(src_dir, unit)], cwd=src_dir)

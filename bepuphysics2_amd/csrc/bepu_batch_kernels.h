@@ -371,6 +371,42 @@ __global__ __launch_bounds__(256) void scatter_bundles_kernel(const float* __res
     const float* src = bundles + (size_t)(j / W) * fields * W + (j % W);
     for (int f = 0; f < fields; ++f) rows[(size_t)f * stride + d] = src[(size_t)f * W];
 }
+// ---- structural updates: the host's TypeProcessor mutations mirrored on the rows that live in HBM ----
+// kind 0: TypeProcessor.Move (TypeProcessor.cs:578-592): lane `src` copied over lane `dst` (body references, prestep, accumulated impulses) — the swap-with-last of Remove.
+// kind 1: AllocateInTypeBatch (:314-334): lane `dst` written from the payload (references, prestep), accumulated impulses cleared (GatherScatter.ClearLane :327).
+// kind 2: UpdateForBodyMemoryMove (:807): one body reference of lane `dst` (body slot `src`) replaced by the payload word.
+struct StructuralOp { unsigned refs_off, prestep_off, accum_off; int stride, nb, pf, imf, kind, src, dst; unsigned payload_off; int pad; };
+static_assert(sizeof(StructuralOp) == 48, "uploaded as raw words");
+// One workgroup per type batch: its operations run in the order the host issued them (a Move may read what an earlier append wrote), rows in parallel.
+__global__ __launch_bounds__(64) void apply_structural_ops_kernel(unsigned* __restrict__ slab, const StructuralOp* __restrict__ ops, const int* __restrict__ group_begin,
+                                                                  const unsigned* __restrict__ payload) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    for (int o = group_begin[g]; o < group_begin[g + 1]; ++o) {
+        const StructuralOp op = ops[o];
+        const int rows = op.nb + op.pf + op.imf;
+        if (op.kind == 2) {
+            if (lane == 0) slab[op.refs_off + (size_t)op.src * op.stride + op.dst] = payload[op.payload_off];
+        } else {
+            for (int r = lane; r < rows; r += 64) {
+                const size_t base = r < op.nb ? op.refs_off + (size_t)r * op.stride
+                                  : (r < op.nb + op.pf ? op.prestep_off + (size_t)(r - op.nb) * op.stride : op.accum_off + (size_t)(r - op.nb - op.pf) * op.stride);
+                unsigned v;
+                if (op.kind == 0) v = slab[base + op.src];
+                else v = r < op.nb + op.pf ? payload[op.payload_off + r] : 0u;
+                slab[base + op.dst] = v;
+            }
+        }
+        __syncthreads();  // the next operation of this type batch sees this one's stores (one workgroup, global memory)
+        __threadfence_block();
+    }
+}
+// Island schedule -> caller's order: rows[r][host index] = permuted[r][device index] (the first structural update leaves the island schedule).
+__global__ __launch_bounds__(256) void unpermute_rows_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, const int* __restrict__ device_to_host, int count, int stride, int rows) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= count) return;
+    const int h = device_to_host[d];
+    for (int r = 0; r < rows; ++r) dst[(size_t)r * stride + h] = src[(size_t)r * stride + d];
+}
 // The inverse, for ranged read-back (bepuhip_get_*_range).
 __global__ __launch_bounds__(256) void gather_bundles_kernel(float* __restrict__ bundles, const float* __restrict__ rows, const int* __restrict__ device_index,
                                                              int first_constraint, int constraint_count, int fields, int stride, int W) {

@@ -105,6 +105,12 @@ struct bepuhip_ctx {
     bool has_fallback = false;
     int launch_count = 0;                // launches per pass: the synchronized batches, then one per dependency level of the fallback batch
     int* d_fallback_indices = nullptr;   // row indices of every level's launches, concatenated
+    // structural updates queued since the last flush (bepuhip_add_constraint / remove_constraint / update_body_reference)
+    struct PendingOp { int tb; StructuralOp op; };
+    std::vector<PendingOp> pending_ops;
+    std::vector<uint32_t> pending_payload;
+    bool structure_dirty = false;        // counts changed: descriptors, constrained flags and cached graphs are stale until flush_structural
+    bool requirk_stale = false;          // the conserving angular modes' substep-0 lists describe the uploaded topology only
     std::vector<HostTypeBatch> tbs;
     std::vector<int> batch_begin;        // descriptor index of each launch's first type batch (size launch_count+1)
     std::vector<int> batch_blocks;       // grid size per launch
@@ -188,4 +194,5 @@ static void free_constraints(bepuhip_ctx* c) {
     c->batch_count = 0; c->batch_begin.clear(); c->batch_blocks.clear();
     c->inc_blocks = 0; c->inc_tb_count = 0; c->total_constraints = 0; c->slab_words = 0; c->referenced_bodies = 0;
     c->built = false;
+    c->pending_ops.clear(); c->pending_payload.clear(); c->structure_dirty = false; c->requirk_stale = false;
 }

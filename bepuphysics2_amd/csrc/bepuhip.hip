@@ -233,6 +233,7 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
 }
 
 static int32_t build_constraints(bepuhip_ctx* c);
+static int32_t flush_structural(bepuhip_ctx* c);
 
 int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
     if (!c || !c->building) return fail(BEPUHIP_E_STATE, "end_constraints without begin");
@@ -243,83 +244,11 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
     return st;
 }
 
-static int32_t build_constraints(bepuhip_ctx* c) {
-    size_t words = 0;
-    c->total_constraints = 0;
-    for (auto& tb : c->tbs)
-        for (int i = 0; i < tb.count; ++i) c->total_constraints += tb.refs_soa[i] != -1;  // a fallback type batch counts its empty lanes in `count`
-    // Bodies the reference re-transforms in substep 0 of the conserving angular modes (see momentum_requirk_kernel). Bundles are W consecutive
-    // constraints in the HOST's order, so this runs before the island schedule permutes the type batches.
-    {
-        int universe = 0;
-        for (auto& tb : c->tbs)
-            for (int32_t r : tb.refs_soa)
-                if (r >= 0) universe = std::max(universe, (r & kRefMask) + 1);
-        c->referenced_bodies = universe;  // checked against the body count at solve time (validate_solve)
-        std::vector<int32_t> first_batch(universe, INT32_MAX);
-        for (auto& tb : c->tbs)
-            for (int k = 0; k < tb.info.bodies; ++k)
-                for (int i = 0; i < tb.count; ++i) {
-                    const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                    if ((uint32_t)r < kDynamicLimit) first_batch[r] = std::min(first_batch[r], tb.batch);
-                }
-        std::vector<std::vector<int32_t>> lists(c->batch_count);
-        const int W = c->W;
-        for (auto& tb : c->tbs) {
-            if (tb.batch == 0) continue;  // batch 0 always integrates (Solver_Solve.cs:188-194): no conditional bundles
-            for (int k = 0; k < tb.info.bodies; ++k)
-                for (int b0 = 0; b0 < tb.count; b0 += W) {
-                    const int b1 = std::min(tb.count, b0 + W);
-                    bool any = false;
-                    for (int i = b0; i < b1; ++i) {
-                        const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                        any |= (uint32_t)r < kDynamicLimit && first_batch[r] == tb.batch;
-                    }
-                    if (!any) continue;
-                    for (int i = b0; i < b1; ++i) {
-                        const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                        if ((uint32_t)r < kDynamicLimit && first_batch[r] < tb.batch) lists[tb.batch].push_back(r);
-                    }
-                }
-        }
-        std::vector<int32_t> flat;
-        c->requirk_begin.assign(c->batch_count + 1, 0);
-        for (int b = 0; b < c->batch_count; ++b) { c->requirk_begin[b] = (int)flat.size(); flat.insert(flat.end(), lists[b].begin(), lists[b].end()); }
-        c->requirk_begin[c->batch_count] = (int)flat.size();
-        if (!flat.empty()) {
-            HIP_TRY(hipMalloc((void**)&c->d_requirk, flat.size() * 4));
-            HIP_TRY(hipMemcpy(c->d_requirk, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
-        }
-    }
-    std::vector<std::vector<int32_t>> fallback_refs;  // the fallback type batches' references (SoA rows), kept past the staging buffers for the level walk below
-    if (c->has_fallback)
-        for (auto& tb : c->tbs) if (tb.batch == c->fallback_threshold) fallback_refs.push_back(tb.refs_soa);
-    ClusterPlan plan;
-    plan_clusters(c, plan);
-    for (auto& tb : c->tbs) {
-        tb.refs_off = words; words += tb.refs_soa.size();
-        tb.prestep_off = words; words += tb.prestep_soa.size();
-        tb.accum_off = words; words += tb.accum_soa.size();
-        tb.lrefs_off = words; words += tb.lrefs_soa.size();
-    }
-    c->slab_words = words;
-    if (words > 0) {
-        HIP_TRY(hipMalloc((void**)&c->d_slab, words * 4));
-        HIP_TRY(hipMalloc((void**)&c->d_slab0, words * 4));
-        std::vector<uint32_t> host(words);
-        for (auto& tb : c->tbs) {
-            if (!tb.refs_soa.empty()) memcpy(&host[tb.refs_off], tb.refs_soa.data(), tb.refs_soa.size() * 4);
-            if (!tb.prestep_soa.empty()) memcpy(&host[tb.prestep_off], tb.prestep_soa.data(), tb.prestep_soa.size() * 4);
-            if (!tb.accum_soa.empty()) memcpy(&host[tb.accum_off], tb.accum_soa.data(), tb.accum_soa.size() * 4);
-            if (!tb.lrefs_soa.empty()) memcpy(&host[tb.lrefs_off], tb.lrefs_soa.data(), tb.lrefs_soa.size() * 4);
-            std::vector<int32_t>().swap(tb.lrefs_soa);
-            std::vector<int32_t>().swap(tb.refs_soa);
-            std::vector<float>().swap(tb.prestep_soa);
-            std::vector<float>().swap(tb.accum_soa);
-        }
-        HIP_TRY(hipMemcpy(c->d_slab, host.data(), words * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_slab0, c->d_slab, words * 4, hipMemcpyDeviceToDevice));
-    }
+// Launch descriptors from the type batches' current counts / strides / slab offsets (called at end_constraints and after structural updates).
+static int32_t build_descriptors(bepuhip_ctx* c, const std::vector<std::vector<int32_t>>& fallback_refs) {
+    if (c->d_tbs) { hipFree(c->d_tbs); c->d_tbs = nullptr; }
+    if (c->d_inc_tbs) { hipFree(c->d_inc_tbs); c->d_inc_tbs = nullptr; }
+    if (c->d_fallback_indices) { hipFree(c->d_fallback_indices); c->d_fallback_indices = nullptr; }
     // Descriptors: per launch grid layout. Synchronized batches: one launch each, all their type batches in one grid. The sequential fallback batch
     // (Solver_Solve.cs:546-583: bundles solved one after the other by one thread, since they may share bodies) becomes one launch per DEPENDENCY LEVEL:
     // walking its type batches and bundles in the reference's order, a constraint's level is one more than the highest level any of its dynamic bodies
@@ -428,6 +357,87 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         HIP_TRY(hipMalloc((void**)&c->d_inc_tbs, inc.size() * sizeof(DevTypeBatch)));
         HIP_TRY(hipMemcpy(c->d_inc_tbs, inc.data(), inc.size() * sizeof(DevTypeBatch), hipMemcpyHostToDevice));
     }
+    return BEPUHIP_OK;
+}
+
+static int32_t build_constraints(bepuhip_ctx* c) {
+    size_t words = 0;
+    c->total_constraints = 0;
+    for (auto& tb : c->tbs)
+        for (int i = 0; i < tb.count; ++i) c->total_constraints += tb.refs_soa[i] != -1;  // a fallback type batch counts its empty lanes in `count`
+    // Bodies the reference re-transforms in substep 0 of the conserving angular modes (see momentum_requirk_kernel). Bundles are W consecutive
+    // constraints in the HOST's order, so this runs before the island schedule permutes the type batches.
+    {
+        int universe = 0;
+        for (auto& tb : c->tbs)
+            for (int32_t r : tb.refs_soa)
+                if (r >= 0) universe = std::max(universe, (r & kRefMask) + 1);
+        c->referenced_bodies = universe;  // checked against the body count at solve time (validate_solve)
+        std::vector<int32_t> first_batch(universe, INT32_MAX);
+        for (auto& tb : c->tbs)
+            for (int k = 0; k < tb.info.bodies; ++k)
+                for (int i = 0; i < tb.count; ++i) {
+                    const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r < kDynamicLimit) first_batch[r] = std::min(first_batch[r], tb.batch);
+                }
+        std::vector<std::vector<int32_t>> lists(c->batch_count);
+        const int W = c->W;
+        for (auto& tb : c->tbs) {
+            if (tb.batch == 0) continue;  // batch 0 always integrates (Solver_Solve.cs:188-194): no conditional bundles
+            for (int k = 0; k < tb.info.bodies; ++k)
+                for (int b0 = 0; b0 < tb.count; b0 += W) {
+                    const int b1 = std::min(tb.count, b0 + W);
+                    bool any = false;
+                    for (int i = b0; i < b1; ++i) {
+                        const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                        any |= (uint32_t)r < kDynamicLimit && first_batch[r] == tb.batch;
+                    }
+                    if (!any) continue;
+                    for (int i = b0; i < b1; ++i) {
+                        const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                        if ((uint32_t)r < kDynamicLimit && first_batch[r] < tb.batch) lists[tb.batch].push_back(r);
+                    }
+                }
+        }
+        std::vector<int32_t> flat;
+        c->requirk_begin.assign(c->batch_count + 1, 0);
+        for (int b = 0; b < c->batch_count; ++b) { c->requirk_begin[b] = (int)flat.size(); flat.insert(flat.end(), lists[b].begin(), lists[b].end()); }
+        c->requirk_begin[c->batch_count] = (int)flat.size();
+        if (!flat.empty()) {
+            HIP_TRY(hipMalloc((void**)&c->d_requirk, flat.size() * 4));
+            HIP_TRY(hipMemcpy(c->d_requirk, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    std::vector<std::vector<int32_t>> fallback_refs;  // the fallback type batches' references (SoA rows), kept past the staging buffers for the level walk below
+    if (c->has_fallback)
+        for (auto& tb : c->tbs) if (tb.batch == c->fallback_threshold) fallback_refs.push_back(tb.refs_soa);
+    ClusterPlan plan;
+    plan_clusters(c, plan);
+    for (auto& tb : c->tbs) {
+        tb.refs_off = words; words += tb.refs_soa.size();
+        tb.prestep_off = words; words += tb.prestep_soa.size();
+        tb.accum_off = words; words += tb.accum_soa.size();
+        tb.lrefs_off = words; words += tb.lrefs_soa.size();
+    }
+    c->slab_words = words;
+    if (words > 0) {
+        HIP_TRY(hipMalloc((void**)&c->d_slab, words * 4));
+        HIP_TRY(hipMalloc((void**)&c->d_slab0, words * 4));
+        std::vector<uint32_t> host(words);
+        for (auto& tb : c->tbs) {
+            if (!tb.refs_soa.empty()) memcpy(&host[tb.refs_off], tb.refs_soa.data(), tb.refs_soa.size() * 4);
+            if (!tb.prestep_soa.empty()) memcpy(&host[tb.prestep_off], tb.prestep_soa.data(), tb.prestep_soa.size() * 4);
+            if (!tb.accum_soa.empty()) memcpy(&host[tb.accum_off], tb.accum_soa.data(), tb.accum_soa.size() * 4);
+            if (!tb.lrefs_soa.empty()) memcpy(&host[tb.lrefs_off], tb.lrefs_soa.data(), tb.lrefs_soa.size() * 4);
+            std::vector<int32_t>().swap(tb.lrefs_soa);
+            std::vector<int32_t>().swap(tb.refs_soa);
+            std::vector<float>().swap(tb.prestep_soa);
+            std::vector<float>().swap(tb.accum_soa);
+        }
+        HIP_TRY(hipMemcpy(c->d_slab, host.data(), words * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_slab0, c->d_slab, words * 4, hipMemcpyDeviceToDevice));
+    }
+    { const int32_t st = build_descriptors(c, fallback_refs); if (st != BEPUHIP_OK) return st; }
     // cluster path tables
     auto upload_ints = [&](const void* src, size_t bytes, void** dst) -> hipError_t {
         if (bytes == 0) return hipSuccess;
@@ -605,6 +615,8 @@ static int32_t validate_solve(bepuhip_ctx* c, float dt, int32_t substeps, const 
         if (iterations[s] < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Velocity iteration count must be positive.");
     if (in->angular_integration_mode < 0 || in->angular_integration_mode > 2) return fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown AngularIntegrationMode");
     if (c->building) return fail(BEPUHIP_E_STATE, "solve between begin_constraints and end_constraints");
+    if (c->requirk_stale && in->angular_integration_mode != 0)
+        return fail(BEPUHIP_E_UNSUPPORTED, "a momentum-conserving AngularIntegrationMode after structural updates (its substep-0 lists are built at upload): re-upload with begin/set/end");
     if (c->has_fallback && in->angular_integration_mode != 0)
         return fail(BEPUHIP_E_UNSUPPORTED, "a sequential fallback batch together with a momentum-conserving AngularIntegrationMode; use simulation.Solve");
     if (c->built && c->referenced_bodies > c->body_count)
@@ -617,6 +629,7 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     int32_t st = validate_solve(c, dt, substeps, iterations, in);
     if (st != BEPUHIP_OK) return st;
     HIP_TRY(hipSetDevice(c->device));
+    if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
     int64_t iters = 0;
     for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
     c->last_constraint_iterations = iters;
@@ -719,6 +732,7 @@ int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, cons
     if (!fn) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null exchange call-back");
     if (c->clusters_enabled) return fail(BEPUHIP_E_STATE, "solve_exchanged needs a context created with BEPUHIP_FLAG_NO_CLUSTERS (a split scene is one island per rank anyway)");
     HIP_TRY(hipSetDevice(c->device));
+    if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
     int64_t iters = 0;
     for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
     c->last_constraint_iterations = iters;
@@ -821,6 +835,7 @@ static int32_t download_aosoa(bepuhip_ctx* c, HostTypeBatch* tb, size_t off, int
 int32_t bepuhip_get_accumulated_impulses(bepuhip_ctx* c, int32_t batch, int32_t type_id, float* out) {
     if (!c || !out || !c->built) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad argument or no constraints");
     HIP_TRY(hipSetDevice(c->device));
+    { const int32_t fs = flush_structural(c); if (fs != BEPUHIP_OK) return fs; }
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb) return fail(BEPUHIP_E_INVALID_ARGUMENT, "no such type batch");
     return download_aosoa(c, tb, tb->accum_off, tb->info.impulse, out);
@@ -828,9 +843,234 @@ int32_t bepuhip_get_accumulated_impulses(bepuhip_ctx* c, int32_t batch, int32_t 
 int32_t bepuhip_get_prestep(bepuhip_ctx* c, int32_t batch, int32_t type_id, float* out) {
     if (!c || !out || !c->built) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad argument or no constraints");
     HIP_TRY(hipSetDevice(c->device));
+    { const int32_t fs = flush_structural(c); if (fs != BEPUHIP_OK) return fs; }
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb) return fail(BEPUHIP_E_INVALID_ARGUMENT, "no such type batch");
     return download_aosoa(c, tb, tb->prestep_off, tb->info.prestep, out);
+}
+
+
+// ---- Structural updates: queue, apply, re-derive ----
+static int32_t apply_pending_ops(bepuhip_ctx* c) {
+    if (c->pending_ops.empty()) return BEPUHIP_OK;
+    std::stable_sort(c->pending_ops.begin(), c->pending_ops.end(), [](const bepuhip_ctx::PendingOp& a, const bepuhip_ctx::PendingOp& b) { return a.tb < b.tb; });
+    std::vector<StructuralOp> ops;
+    std::vector<int> group_begin;
+    for (size_t i = 0; i < c->pending_ops.size(); ++i) {
+        if (i == 0 || c->pending_ops[i].tb != c->pending_ops[i - 1].tb) group_begin.push_back((int)i);
+        ops.push_back(c->pending_ops[i].op);
+    }
+    group_begin.push_back((int)ops.size());
+    const int groups = (int)group_begin.size() - 1;
+    if (c->pending_payload.empty()) c->pending_payload.push_back(0u);
+    const size_t bytes = ops.size() * sizeof(StructuralOp) + group_begin.size() * 4 + c->pending_payload.size() * 4;
+    char* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    StructuralOp* d_ops = (StructuralOp*)d;
+    int* d_groups = (int*)(d + ops.size() * sizeof(StructuralOp));
+    unsigned* d_payload = (unsigned*)(d_groups + group_begin.size());
+    HIP_TRY(hipMemcpyAsync(d_ops, ops.data(), ops.size() * sizeof(StructuralOp), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_groups, group_begin.data(), group_begin.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_payload, c->pending_payload.data(), c->pending_payload.size() * 4, hipMemcpyHostToDevice, c->stream));
+    for (uint32_t* slab : {c->d_slab, c->d_slab0})  // the snapshot follows: reset_state restores "what the set_* / update_* / structural calls produced"
+        if (slab) hipLaunchKernelGGL(apply_structural_ops_kernel, dim3(groups), dim3(64), 0, c->stream, slab, (const StructuralOp*)d_ops, (const int*)d_groups, (const unsigned*)d_payload);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(d);
+    c->pending_ops.clear();
+    c->pending_payload.clear();
+    return BEPUHIP_OK;
+}
+
+static int32_t flush_structural(bepuhip_ctx* c) {
+    int32_t st = apply_pending_ops(c);
+    if (st != BEPUHIP_OK) return st;
+    if (!c->structure_dirty) return BEPUHIP_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    clear_graphs(c);  // grids and descriptor pointers are baked into captured launches
+    c->total_constraints = 0;
+    for (auto& tb : c->tbs) c->total_constraints += tb.count;
+    if ((st = build_descriptors(c, {})) != BEPUHIP_OK) return st;
+    c->structure_dirty = false;
+    return rebuild_flags(c);
+}
+
+// Re-lays the slab (and its snapshot) out for the type batches' current `stride`s; `old` holds their previous layout. Rows are copied device to device.
+struct OldLayout { size_t refs_off, prestep_off, accum_off; int stride, count; };
+static int32_t relayout_slab(bepuhip_ctx* c, const std::vector<OldLayout>& old) {
+    size_t words = 0;
+    for (auto& tb : c->tbs) {
+        tb.refs_off = words; words += (size_t)tb.info.bodies * tb.stride;
+        tb.prestep_off = words; words += (size_t)tb.info.prestep * tb.stride;
+        tb.accum_off = words; words += (size_t)tb.info.impulse * tb.stride;
+        tb.lrefs_off = words;
+    }
+    uint32_t* fresh[2] = {nullptr, nullptr};
+    uint32_t* prev[2] = {c->d_slab, c->d_slab0};
+    for (int k = 0; k < 2 && words > 0; ++k) {
+        HIP_TRY(hipMalloc((void**)&fresh[k], words * 4));
+        HIP_TRY(hipMemsetAsync(fresh[k], 0xFF, words * 4, c->stream));  // unused lanes read as -1 references / NaN floats: never touched by a launch (count bounds them)
+        for (size_t t = 0; t < c->tbs.size(); ++t) {
+            const HostTypeBatch& tb = c->tbs[t];
+            if (t >= old.size() || old[t].count == 0 || old[t].stride == 0 || !prev[k]) continue;
+            const OldLayout& o = old[t];
+            const size_t src[3] = {o.refs_off, o.prestep_off, o.accum_off}, dst[3] = {tb.refs_off, tb.prestep_off, tb.accum_off};
+            const int rows[3] = {tb.info.bodies, tb.info.prestep, tb.info.impulse};
+            for (int r = 0; r < 3; ++r)
+                HIP_TRY(hipMemcpy2DAsync(fresh[k] + dst[r], (size_t)tb.stride * 4, prev[k] + src[r], (size_t)o.stride * 4, (size_t)o.count * 4, rows[r], hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_slab) hipFree(c->d_slab);
+    if (c->d_slab0) hipFree(c->d_slab0);
+    c->d_slab = fresh[0]; c->d_slab0 = fresh[1];
+    c->slab_words = words;
+    c->structure_dirty = true;
+    return BEPUHIP_OK;
+}
+static std::vector<OldLayout> current_layout(const bepuhip_ctx* c) {
+    std::vector<OldLayout> old;
+    for (auto& tb : c->tbs) old.push_back({tb.refs_off, tb.prestep_off, tb.accum_off, tb.stride, tb.count});
+    return old;
+}
+
+// The island schedule stores every type batch permuted by cluster; structural updates address constraints by the caller's indices. The first one
+// brings the rows back into the caller's order on the device and leaves the island schedule (planning clusters needs the whole topology).
+static int32_t leave_island_schedule(bepuhip_ctx* c) {
+    bool permuted = c->clusters_enabled;
+    for (auto& tb : c->tbs) permuted |= !tb.perm.empty();
+    if (!permuted) return BEPUHIP_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    clear_graphs(c);
+    for (int k = 0; k < 2; ++k) {
+        uint32_t*& slab = k == 0 ? c->d_slab : c->d_slab0;
+        if (!slab || c->slab_words == 0) continue;
+        uint32_t* fresh = nullptr;
+        HIP_TRY(hipMalloc((void**)&fresh, c->slab_words * 4));
+        HIP_TRY(hipMemcpyAsync(fresh, slab, c->slab_words * 4, hipMemcpyDeviceToDevice, c->stream));
+        for (auto& tb : c->tbs) {
+            if (tb.perm.empty() || tb.count == 0) continue;
+            int* d_perm = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_perm, tb.perm.size() * 4));
+            HIP_TRY(hipMemcpyAsync(d_perm, tb.perm.data(), tb.perm.size() * 4, hipMemcpyHostToDevice, c->stream));
+            const size_t offs[3] = {tb.refs_off, tb.prestep_off, tb.accum_off};
+            const int rows[3] = {tb.info.bodies, tb.info.prestep, tb.info.impulse};
+            for (int r = 0; r < 3; ++r)
+                hipLaunchKernelGGL(unpermute_rows_kernel, dim3((tb.count + 255) / 256), dim3(256), 0, c->stream, (const unsigned*)(slab + offs[r]), (unsigned*)(fresh + offs[r]), (const int*)d_perm,
+                                   tb.count, tb.stride, rows[r]);
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            hipFree(d_perm);
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(slab);
+        slab = fresh;
+    }
+    for (auto& tb : c->tbs) {
+        tb.perm.clear(); tb.inv.clear();
+        if (tb.d_device_index) { hipFree(tb.d_device_index); tb.d_device_index = nullptr; }
+    }
+    for (void** p : {(void**)&c->d_clusters, (void**)&c->d_items, (void**)&c->d_batch_item_begin, (void**)&c->d_cluster_bodies, (void**)&c->d_clustered_dynamic, (void**)&c->d_kinlist,
+                     (void**)&c->d_cycles}) {
+        if (*p) hipFree(*p);
+        *p = nullptr;
+    }
+    c->clusters_enabled = false; c->cluster_count = 0; c->clustered_dynamic_count = 0; c->kinlist_count = 0;
+    c->structure_dirty = true;
+    return BEPUHIP_OK;
+}
+
+static int32_t structural_preamble(bepuhip_ctx* c) {
+    if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
+    if (c->building) return fail(BEPUHIP_E_STATE, "structural update between begin_constraints and end_constraints");
+    if (c->has_fallback) return fail(BEPUHIP_E_UNSUPPORTED, "structural updates with a sequential fallback batch: re-upload with begin/set/end");
+    HIP_TRY(hipSetDevice(c->device));
+    return leave_island_schedule(c);
+}
+
+int32_t bepuhip_get_constraint_count(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t* out) {
+    if (!c || !out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    HostTypeBatch* tb = find_tb(c, batch, type_id);
+    *out = tb ? tb->count : 0;
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_add_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, const int32_t* refs, const float* prestep, int32_t* index_out) {
+    int32_t st = structural_preamble(c);
+    if (st != BEPUHIP_OK) return st;
+    if (batch < 0 || !refs || !prestep) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad add_constraint argument");
+    if (batch >= c->fallback_threshold) return fail(BEPUHIP_E_UNSUPPORTED, "the constraint belongs to the sequential fallback batch (batch index >= FallbackBatchThreshold)");
+    TypeInfoH info;
+    if (!type_info(type_id, info)) return fail(BEPUHIP_E_UNSUPPORTED, "unknown constraint type id " + std::to_string(type_id));
+    for (int k = 0; k < info.bodies; ++k)
+        if (refs[k] < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "empty body reference");
+    HostTypeBatch* tb = find_tb(c, batch, type_id);
+    if (!tb || tb->count == tb->stride) {  // a new type batch (ConstraintBatch.GetOrCreateTypeBatch) or a full one (InternalResize: capacity doubles, TypeProcessor.cs:317-320)
+        if ((st = apply_pending_ops(c)) != BEPUHIP_OK) return st;  // queued operations carry offsets of the layout that is about to change
+        std::vector<OldLayout> old = current_layout(c);
+        if (!tb) {
+            HostTypeBatch fresh;
+            fresh.batch = batch; fresh.type_id = type_id; fresh.count = 0; fresh.stride = 64; fresh.info = info;
+            fresh.refs_off = fresh.prestep_off = fresh.accum_off = fresh.lrefs_off = 0;
+            size_t pos = 0;
+            while (pos < c->tbs.size() && c->tbs[pos].batch <= batch) ++pos;  // type batches of a batch in creation order, batches in index order
+            c->tbs.insert(c->tbs.begin() + pos, fresh);
+            old.insert(old.begin() + pos, OldLayout{0, 0, 0, 0, 0});
+            c->batch_count = std::max(c->batch_count, batch + 1);
+            c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
+            c->built = true;
+        } else {
+            tb->stride = std::max(64, tb->stride * 2);
+        }
+        if ((st = relayout_slab(c, old)) != BEPUHIP_OK) return st;
+        tb = find_tb(c, batch, type_id);
+    }
+    bepuhip_ctx::PendingOp p;
+    p.tb = (int)(tb - c->tbs.data());
+    p.op = StructuralOp{(unsigned)tb->refs_off, (unsigned)tb->prestep_off, (unsigned)tb->accum_off, tb->stride, tb->info.bodies, tb->info.prestep, tb->info.impulse, 1, 0, tb->count,
+                        (unsigned)c->pending_payload.size(), 0};
+    for (int k = 0; k < info.bodies; ++k) {
+        c->pending_payload.push_back((uint32_t)refs[k]);
+        c->referenced_bodies = std::max(c->referenced_bodies, (refs[k] & kRefMask) + 1);
+    }
+    for (int f = 0; f < info.prestep; ++f) { uint32_t w; memcpy(&w, &prestep[f], 4); c->pending_payload.push_back(w); }
+    c->pending_ops.push_back(p);
+    if (index_out) *index_out = tb->count;
+    tb->count += 1;
+    c->structure_dirty = true; c->requirk_stale = true;
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_remove_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t index) {
+    int32_t st = structural_preamble(c);
+    if (st != BEPUHIP_OK) return st;
+    HostTypeBatch* tb = find_tb(c, batch, type_id);
+    if (!tb || index < 0 || index >= tb->count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Can only remove elements that are actually in the batch!");  // TypeProcessor.cs:636
+    const int last = tb->count - 1;
+    if (index < last) {  // TypeProcessor.cs:702-714
+        bepuhip_ctx::PendingOp p;
+        p.tb = (int)(tb - c->tbs.data());
+        p.op = StructuralOp{(unsigned)tb->refs_off, (unsigned)tb->prestep_off, (unsigned)tb->accum_off, tb->stride, tb->info.bodies, tb->info.prestep, tb->info.impulse, 0, last, index, 0u, 0};
+        c->pending_ops.push_back(p);
+    }
+    tb->count = last;
+    c->structure_dirty = true; c->requirk_stale = true;
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_update_body_reference(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t index, int32_t slot, int32_t ref) {
+    int32_t st = structural_preamble(c);
+    if (st != BEPUHIP_OK) return st;
+    HostTypeBatch* tb = find_tb(c, batch, type_id);
+    if (!tb || index < 0 || index >= tb->count || slot < 0 || slot >= tb->info.bodies || ref < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad update_body_reference argument");
+    bepuhip_ctx::PendingOp p;
+    p.tb = (int)(tb - c->tbs.data());
+    p.op = StructuralOp{(unsigned)tb->refs_off, (unsigned)tb->prestep_off, (unsigned)tb->accum_off, tb->stride, tb->info.bodies, tb->info.prestep, tb->info.impulse, 2, slot, index,
+                        (unsigned)c->pending_payload.size(), 0};
+    c->pending_payload.push_back((uint32_t)ref);
+    c->pending_ops.push_back(p);
+    c->referenced_bodies = std::max(c->referenced_bodies, (ref & kRefMask) + 1);
+    c->structure_dirty = true; c->requirk_stale = true;  // constrained flags follow the references
+    return BEPUHIP_OK;
 }
 
 // ---- Device-resident incremental updates: ranged rewrites of what already lives in HBM, no re-plan, no full re-upload ----
@@ -856,6 +1096,7 @@ static int32_t device_index_of(bepuhip_ctx* c, HostTypeBatch* tb, const int** ou
 }
 static int32_t bundle_range(bepuhip_ctx* c, int batch, int type_id, int first_bundle, int bundle_count, const void* buffer, HostTypeBatch** tb_out, int* first, int* n) {
     if (!c || !c->built) return fail(BEPUHIP_E_STATE, "no constraints uploaded");
+    { const int32_t fs = flush_structural(c); if (fs != BEPUHIP_OK) return fs; }
     if (first_bundle < 0 || bundle_count < 0 || (!buffer && bundle_count > 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad bundle range");
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb) return fail(BEPUHIP_E_INVALID_ARGUMENT, "no such type batch");
@@ -1055,6 +1296,7 @@ int32_t bepuhip_get_stream(bepuhip_ctx* c, void** out) {
 int32_t bepuhip_reset_state(bepuhip_ctx* c) {
     if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    { const int32_t fs = flush_structural(c); if (fs != BEPUHIP_OK) return fs; }
     if (c->body_count > 0) HIP_TRY(hipMemcpyAsync(c->d_bodies, c->d_bodies0, (size_t)c->body_count * 128, hipMemcpyDeviceToDevice, c->stream));
     if (c->slab_words > 0) HIP_TRY(hipMemcpyAsync(c->d_slab, c->d_slab0, c->slab_words * 4, hipMemcpyDeviceToDevice, c->stream));
     return BEPUHIP_OK;

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
     "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables",
+    "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_get_constraint_count",
 ]
 
 
@@ -109,6 +110,10 @@ def load_library() -> C.CDLL:
     lib.bepuhip_get_bodies_range.argtypes = [vp, vp, i32, i32]
     for name in ("bepuhip_update_prestep", "bepuhip_update_accumulated_impulses", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
         getattr(lib, name).argtypes = [vp, i32, i32, i32, i32, vp]
+    lib.bepuhip_add_constraint.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
+    lib.bepuhip_remove_constraint.argtypes = [vp, i32, i32, i32]
+    lib.bepuhip_update_body_reference.argtypes = [vp, i32, i32, i32, i32, i32]
+    lib.bepuhip_get_constraint_count.argtypes = [vp, i32, i32, C.POINTER(i32)]
     for name in EXPORTED_SYMBOLS:
         if name != "bepuhip_last_error":
             getattr(lib, name).restype = i32
@@ -279,6 +284,29 @@ class HipSolver:
 
     def _bundle_floats(self, type_id: int, prestep: bool) -> int:
         return (TYPE_TABLE[type_id][1] if prestep else TYPE_TABLE[type_id][2]) * self.bundle_width
+
+    # ---- structural updates: the host's TypeProcessor mutations mirrored on the device rows ----
+    def add_constraint(self, batch_index: int, type_id: int, encoded_body_references, prestep_lane) -> int:
+        """TypeProcessor.AllocateInTypeBatch (TypeProcessor.cs:314-334): append at index ConstraintCount; returns that index."""
+        refs = np.ascontiguousarray(encoded_body_references, dtype=np.int32)
+        lane = np.ascontiguousarray(prestep_lane, dtype=np.float32)
+        assert refs.size == TYPE_TABLE[type_id][0] and lane.size == TYPE_TABLE[type_id][1]
+        index = C.c_int32()
+        _check(self.lib, self.lib.bepuhip_add_constraint(self.ctx, batch_index, type_id, _ptr(refs), _ptr(lane), C.byref(index)))
+        return int(index.value)
+
+    def remove_constraint(self, batch_index: int, type_id: int, index: int):
+        """TypeProcessor.Remove, non-fallback (TypeProcessor.cs:695-717): swap-with-last."""
+        _check(self.lib, self.lib.bepuhip_remove_constraint(self.ctx, batch_index, type_id, index))
+
+    def update_body_reference(self, batch_index: int, type_id: int, index: int, body_index_in_constraint: int, encoded_body_reference: int):
+        """TypeProcessor.UpdateForBodyMemoryMove (TypeProcessor.cs:807)."""
+        _check(self.lib, self.lib.bepuhip_update_body_reference(self.ctx, batch_index, type_id, index, body_index_in_constraint, int(encoded_body_reference)))
+
+    def constraint_count(self, batch_index: int, type_id: int) -> int:
+        n = C.c_int32()
+        _check(self.lib, self.lib.bepuhip_get_constraint_count(self.ctx, batch_index, type_id, C.byref(n)))
+        return int(n.value)
 
     def update_prestep(self, batch_index: int, type_id: int, first_bundle: int, bundles: np.ndarray):
         """``bundles``: the type batch's PrestepData bundles [first_bundle, first_bundle + n) exactly as the reference stores them (AOSOA)."""

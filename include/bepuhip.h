@@ -122,6 +122,27 @@ int32_t bepuhip_get_bodies_range(bepuhip_ctx* ctx, void* body_dynamics_aos_out, 
 int32_t bepuhip_get_prestep_range(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* prestep_bundles_out);
 int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* impulse_bundles_out);
 
+/* ---- Structural updates: the narrow phase's per-frame add / remove stream without a re-upload ----
+ * The C# host calls these next to the mutation it performs on its own buffers, with the same indices:
+ *   add_constraint            Solver.Add -> AllocateInBatch -> TypeProcessor.AllocateInTypeBatch (BepuPhysics/Constraints/TypeProcessor.cs:314-334): the constraint is appended at
+ *                             index ConstraintCount of (batch_index, type_id) — a batch / type batch that does not exist yet is created (ConstraintBatch.GetOrCreateTypeBatch);
+ *                             `encoded_body_references` in the reference's encoding, `prestep_lane` = the description's fields in prestep order (what ApplyDescription writes),
+ *                             accumulated impulses start at zero (:327). *index_out = the index the reference also returns.
+ *   remove_constraint         TypeProcessor.Remove, non-fallback branch (:695-717): the last constraint of the type batch is moved into `index` (TypeProcessor.Move :578-592),
+ *                             ConstraintCount drops by one. The host patches its HandleToConstraint map as the reference does; the device has no handles.
+ *   update_body_reference     TypeProcessor.UpdateForBodyMemoryMove (:807), reached from Solver.UpdateForBodyMemoryMove (BepuPhysics/Solver.cs:1475) when Bodies.RemoveAt
+ *                             (BepuPhysics/BodySet.cs:83-110) moves the last body into a freed slot: one reference of one constraint is rewritten. The body array itself is
+ *                             re-sent with set_bodies (the host is authoritative for bodies between frames).
+ * Cost is proportional to the number of calls: they are queued and applied to the rows in HBM by one small kernel before the next solve / read-back (order preserved per
+ * type batch); rows have spare capacity and grow by doubling. The island-per-workgroup schedule needs the whole topology to plan its clusters: the first structural update
+ * moves the context to the launch-per-batch schedule (rows back in the caller's order) until the next begin/set/end upload. Not supported (UNSUPPORTED): the sequential
+ * fallback batch, and solving in a momentum-conserving AngularIntegrationMode after structural updates (its substep-0 lists are built at upload). */
+int32_t bepuhip_add_constraint(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, const int32_t* encoded_body_references, const float* prestep_lane, int32_t* index_out);
+int32_t bepuhip_remove_constraint(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index);
+int32_t bepuhip_update_body_reference(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index, int32_t body_index_in_constraint, int32_t encoded_body_reference);
+/* ConstraintCount of a type batch as the device sees it (0 if it does not exist). */
+int32_t bepuhip_get_constraint_count(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t* count_out);
+
 /* ---- PredictBoundingBoxes on the device ----
  * Replaces the per-body work of PoseIntegrator.PredictBoundingBoxes (BepuPhysics/PoseIntegrator.cs:307-370, called from Simulation.PredictBoundingBoxes,
  * BepuPhysics/Simulation.cs:252-262) for bodies whose shape is one of the five primitive convex types: sleep candidacy from the stored velocity

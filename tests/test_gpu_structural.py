@@ -1,0 +1,107 @@
+"""-m gpu: structural updates on the device: the narrow phase's per-frame add / remove stream applied to the rows in HBM
+through bepuhip_add_constraint / remove_constraint, 60 frames with ~1 % of the contacts removed and as many added per frame, bit-exact against the oracle
+solving the host mirror's export every frame — which is also what a fresh upload of that export would solve."""
+import numpy as np
+import pytest
+
+import oracle_ffi
+import parity_util as pu
+import small_scenes
+from bepuphysics2_amd.scene import PoseIntegratorCallbacks, SolveDescription
+from mutable_scene import MutableSolver
+
+pytestmark = pytest.mark.gpu
+
+CONTACT_TYPES = [4, 5, 6, 7]
+JOINT_TYPES = [22, 25, 30, 47]
+
+
+def _build(seed, bodies=260, joints=300, contacts=500):
+    rng = np.random.default_rng(seed)
+    rows = [small_scenes.random_dynamic_body(rng, rng.uniform(-6, 6, 3)) if i % 37 else small_scenes.kinematic_body(rng, rng.uniform(-6, 6, 3)) for i in range(bodies)]
+    ms = MutableSolver(np.stack(rows))
+
+    def pair():
+        while True:
+            a, b = rng.choice(bodies, 2, replace=False)
+            if not (ms.is_kinematic(a) and ms.is_kinematic(b)):
+                return int(a), int(b)
+
+    for _ in range(joints):
+        a, b = pair()
+        t = JOINT_TYPES[int(rng.integers(len(JOINT_TYPES)))]
+        ms.add(t, [a, b], small_scenes.prestep_for(rng, t, ms.bodies[a, 4:7], ms.bodies[b, 4:7]))
+    for _ in range(contacts):
+        a, b = pair()
+        t = CONTACT_TYPES[int(rng.integers(len(CONTACT_TYPES)))]
+        ms.add(t, [a, b], small_scenes.prestep_for(rng, t, ms.bodies[a, 4:7], ms.bodies[b, 4:7]))
+    return ms, rng, pair
+
+
+@pytest.mark.parametrize("use_clusters", [False, True])
+def test_sixty_frames_of_contact_churn_stay_bit_exact(hip_solver_factory, use_clusters):
+    ms, rng, pair = _build(23)
+    sd, cb = SolveDescription(1, 4), PoseIntegratorCallbacks()
+    solver = hip_solver_factory(use_clusters=use_clusters)
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+    is_contact = lambda t: t in CONTACT_TYPES  # noqa: E731
+    for frame in range(60):
+        contacts = ms.locations(is_contact)
+        churn = max(1, len(contacts) // 100)
+        # removals: chosen one at a time (every swap-with-last renumbers the type batch)
+        for _ in range(churn):
+            locs = ms.locations(is_contact)
+            bi, t, i = locs[int(rng.integers(len(locs)))]
+            ms.remove(bi, t, i)
+            solver.remove_constraint(bi, t, i)
+        for _ in range(churn):
+            a, b = pair()
+            t = CONTACT_TYPES[int(rng.integers(len(CONTACT_TYPES)))]
+            lane = small_scenes.prestep_for(rng, t, ms.bodies[a, 4:7], ms.bodies[b, 4:7])
+            bi, index, encoded = ms.add(t, [a, b], lane)
+            assert solver.add_constraint(bi, t, encoded, lane) == index
+        export = ms.to_scene()
+        for bi, tbs in enumerate(export.batches):
+            for tb in tbs:
+                assert solver.constraint_count(bi, tb.type_id) == tb.count
+        oracle_ffi.solve(export, 1 / 60, sd, cb)
+        ms.absorb(export)
+        solver.solve(1 / 60, sd, cb)
+        if frame % 12 == 11 or frame == 59:
+            got = ms.to_scene()
+            solver.download(got)
+            m = pu.compare_scenes(export, got)
+            assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (frame, m)
+    assert solver.cluster_cycles().size == 0  # structural updates leave the island schedule
+
+
+def test_new_batches_type_batches_and_capacity_growth(hip_solver_factory):
+    """A hub that collects constraint after constraint opens new batches and new type batches and overflows the 64-lane rows of existing ones."""
+    rng = np.random.default_rng(5)
+    rows = [small_scenes.random_dynamic_body(rng, rng.uniform(-3, 3, 3)) for _ in range(140)]
+    ms = MutableSolver(np.stack(rows))
+    ms.add(7, [1, 2], small_scenes.prestep_for(rng, 7, ms.bodies[1, 4:7], ms.bodies[2, 4:7]))
+    sd, cb = SolveDescription(2, 2), PoseIntegratorCallbacks()
+    solver = hip_solver_factory()
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+    for k in range(3, 40):     # hub 0: every constraint needs a batch of its own
+        t = [7, 22, 4][k % 3]
+        lane = small_scenes.prestep_for(rng, t, ms.bodies[0, 4:7], ms.bodies[k, 4:7])
+        bi, index, encoded = ms.add(t, [0, k], lane)
+        assert solver.add_constraint(bi, t, encoded, lane) == index
+    for k in range(40, 139, 2):  # disjoint pairs: all land in batch 0 and overflow its Contact4 rows (64 -> 128)
+        lane = small_scenes.prestep_for(rng, 7, ms.bodies[k, 4:7], ms.bodies[k + 1, 4:7])
+        bi, index, encoded = ms.add(7, [k, k + 1], lane)
+        assert solver.add_constraint(bi, 7, encoded, lane) == index
+    for _ in range(3):
+        export = ms.to_scene()
+        oracle_ffi.solve(export, 1 / 60, sd, cb)
+        ms.absorb(export)
+        solver.solve(1 / 60, sd, cb)
+    got = ms.to_scene()
+    solver.download(got)
+    m = pu.compare_scenes(export, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    # a body memory move: body 139 takes the slot of body 3 (BodySet.RemoveAt swap-with-last); its constraints' references are patched one by one
+    with pytest.raises(ValueError):
+        solver.remove_constraint(0, 7, 10_000)
