@@ -42,6 +42,11 @@ struct ClusterShared {
     lds_u32* counter;         // item claim counter, monotonic
     int batch_count;
     unsigned* status;      // global: [0] != 0 when a wait ran out of patience (a scheduling bug, never expected); [1..7] first offender
+    // SHARED plans only (split islands): slot -> body index | flags (LDS copy), the global shared-body tables, and where the step is:
+    const int* slot_body;
+    SharedTables st;
+    unsigned events;       // integration events every shared body has seen so far (substep index + 1 during the sweeps of a substep)
+    unsigned passes;       // passes (warm starts + velocity iterations) completed before the current one, over the whole step
 };
 
 template <int ACCESS>
@@ -75,7 +80,7 @@ __device__ __forceinline__ void store_velocity_lds(const ClusterShared& sh, int 
 
 
 // Local body references travel as 16-bit halves (slot | kinematic << 15); the gather / scatter helpers take the 32-bit form (slot | kinematic << 30).
-__device__ __forceinline__ int unpack_local_ref(unsigned half) { return (int)((half & 0x7FFFu) | ((half & 0x8000u) << 15)); }
+__device__ __forceinline__ int unpack_local_ref(unsigned half) { return (int)((half & 0x3FFFu) | ((half & 0x8000u) << 15)); }  // bit 14: kLrefShared
 
 struct ItemHeader {  // wave-uniform copy of the fields the constraint code needs (SGPRs)
     int type_id, count, stride, start, batch, npred, nxpred, overflow, xoverflow;
@@ -148,6 +153,81 @@ __device__ __forceinline__ void wait_word(const ClusterShared& sh, const volatil
         if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
     }
 }
+// ---- shared bodies (split islands): agent-scope traffic, see SharedTables ----
+// The loads wait for their data inside the asm statement (the compiler does not count an asm load in vmcnt); the stores are followed by wait_vm() where
+// an event counter is about to announce them.
+typedef float agent_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_agent_pair(const float4* p, float4& a, float4& b) {  // p[0], p[1]
+    agent_f4 x, y;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x), "=&v"(y) : "v"(p) : "memory");
+    a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w);
+}
+__device__ __forceinline__ float4 load_agent_f4(const float4* p) {
+    agent_f4 x;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
+    return make_float4(x.x, x.y, x.z, x.w);
+}
+__device__ __forceinline__ void load_agent_pose_inertia(const float4* body, float4& q, float4& pos, float4& w0, float4& w1) {  // planes 0, 1, 6, 7 of a body record
+    agent_f4 a, b, c, d;
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %4, off offset:96 sc1\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:112 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(body) : "memory");
+    q = make_float4(a.x, a.y, a.z, a.w); pos = make_float4(b.x, b.y, b.z, b.w); w0 = make_float4(c.x, c.y, c.z, c.w); w1 = make_float4(d.x, d.y, d.z, d.w);
+}
+__device__ __forceinline__ void store_agent_f4(float4* p, float4 v) {
+    agent_f4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned load_seq(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_seq(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Per-lane wait until seq[body] reaches `want` (lanes with need == false pass at once). Bounded like every other wait of this kernel.
+__device__ __forceinline__ void wait_shared_seq(const ClusterShared& sh, bool need, int body, unsigned want, int kind, int k) {
+    const unsigned* word = sh.st.seq + (need ? body : 0);
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned seen = need ? load_seq(word) : want;
+        const unsigned long long late = __builtin_amdgcn_ballot_w64(seen < want);
+        if (late == 0) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSpinLimit) {
+            const int first = (int)__builtin_ctzll(late);
+            report_stall(sh.status, *sh.counter, kind, k, __builtin_amdgcn_readlane(body, first), __builtin_amdgcn_readlane((int)want, first), __builtin_amdgcn_readlane((int)seen, first));
+            break;
+        }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
+    }
+}
+struct SharedRef {  // one body slot of one lane's constraint
+    bool shared; int body; unsigned rank, degree;
+    __device__ __forceinline__ unsigned expected(const ClusterShared& sh) const { return sh.events + degree * sh.passes + rank; }
+};
+__device__ __forceinline__ SharedRef make_shared_ref(const ClusterShared& sh, unsigned half, unsigned srank, bool active) {
+    SharedRef r;
+    r.shared = active && (half & kLrefShared) != 0 && (half & 0x8000u) == 0;
+    r.body = r.shared ? (sh.slot_body[half & 0x3FFFu] & kSlotBodyMask) : 0;
+    r.rank = srank & 0xFFu; r.degree = (srank >> 8) & 0xFFu;
+    return r;
+}
+template <int ACCESS>
+__device__ __forceinline__ void load_velocity_shared(const ClusterShared& sh, const SharedRef& r, DBody& b) {
+    if (!r.shared) return;
+    const float4* v = sh.st.vel + (size_t)r.body * 2;
+    float4 l, a;
+    if ((ACCESS & kLin) && (ACCESS & kAng)) load_agent_pair(v, l, a);
+    else if (ACCESS & kLin) l = load_agent_f4(v);
+    else if (ACCESS & kAng) a = load_agent_f4(v + 1);
+    if (ACCESS & kLin) { b.vel.lin = {l.x, l.y, l.z}; b.linw = l.w; }
+    if (ACCESS & kAng) { b.vel.ang = {a.x, a.y, a.z}; b.angw = a.w; }
+}
+template <int ACCESS>
+__device__ __forceinline__ void store_velocity_shared(const ClusterShared& sh, const SharedRef& r, const DBody& b) {
+    if (!r.shared) return;
+    float4* v = sh.st.vel + (size_t)r.body * 2;
+    if (ACCESS & kLin) store_agent_f4(v, make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, b.linw));
+    if (ACCESS & kAng) store_agent_f4(v + 1, make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, b.angw));
+}
+
 // Block until every predecessor of the item has published: same-pass predecessors must have finished `epoch`; with CROSS (a Solve item: the warm start
 // pass before it is not separated by a barrier) the last touchers of the bodies this item touches first must have finished `epoch - 1`.
 template <bool CROSS>
@@ -190,17 +270,26 @@ __device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const
 struct ItemStamps { unsigned long long loaded, pre_gate, post_gate; };  // trace builds only
 
 // The gate the cluster path hands to the constraint functions: wait for the item's predecessors, then gather the velocities.
-template <int ACC_A, int ACC_B, int BODIES, bool CROSS, bool TRACE>
+template <int ACC_A, int ACC_B, int BODIES, bool CROSS, bool TRACE, bool SHARED>
 struct ClusterGate {
     static constexpr bool kPin = true;  // the constraint pins its velocity-independent values before calling: they are computed while the predecessors still run
     const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; int ra, rb; DBody& A; DBody& B; ItemStamps& stamps;
+    const SharedRef& sa; const SharedRef& sb;
     __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {
         if (TRACE) stamps.pre_gate = __builtin_readcyclecounter();
         wait_predecessors<CROSS>(sh, it, h, k, epoch);
+        if constexpr (SHARED) {  // bodies other clusters also touch: our turn comes when the body's event counter reaches this application's number
+            wait_shared_seq(sh, sa.shared, sa.body, sa.expected(sh), 6, k);
+            if (BODIES == 2) wait_shared_seq(sh, sb.shared, sb.body, sb.expected(sh), 7, k);
+        }
         __builtin_amdgcn_s_setprio(3);  // from here to the publish the item is on its bodies' critical path: issue ahead of waves still preparing theirs
         if (TRACE) stamps.post_gate = __builtin_readcyclecounter();
         load_velocity_lds<ACC_A>(sh, ra, A);
         if (BODIES == 2) load_velocity_lds<ACC_B>(sh, rb, B);
+        if constexpr (SHARED) {
+            load_velocity_shared<ACC_A>(sh, sa, A);
+            if (BODIES == 2) load_velocity_shared<ACC_B>(sh, sb, B);
+        }
     }
 };
 
@@ -249,7 +338,7 @@ __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared&
     if (STAGE == kStageSolve && active) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) accum[(size_t)f * stride + i] = a[f]; }
 }
 
-template <class F, int STAGE, bool TRACE>
+template <class F, int STAGE, bool TRACE, bool SHARED>
 __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
                                                        unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
     // Lanes beyond the item's count mirror its last constraint and never store: the whole body runs with a full exec mask,
@@ -265,12 +354,30 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     const unsigned both = (unsigned)lrefs[i];  // two 16-bit local references per word
     const int ra = unpack_local_ref(both & 0xFFFFu);
     const int rb = (F::bodies == 2) ? unpack_local_ref(both >> 16) : -1;
+    SharedRef sa = {false, 0, 0u, 0u}, sb = {false, 0, 0u, 0u};
+    if constexpr (SHARED) {  // rank | degree << 8 of this application on each shared body: rows right behind the local references
+        const gint* srank = lrefs + (size_t)((F::bodies + 1) / 2) * stride;
+        sa = make_shared_ref(sh, both & 0xFFFFu, (unsigned)srank[i], active);
+        if (F::bodies == 2) sb = make_shared_ref(sh, both >> 16, (unsigned)srank[(size_t)stride + i], active);
+    }
     _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
     if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
     DBody A, B;
     if (STAGE == kStageIncremental) {  // reads velocities, writes only this constraint's depths: no ordering inside the stage
         load_body_lds<kAccessOnlyVelocity>(sh, ra, A);
         if (F::bodies == 2) load_body_lds<kAccessOnlyVelocity>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
+        if constexpr (SHARED) {
+            // a shared body's end-of-substep velocity is in the shared table once every application of the previous substep has happened (rank 0 of the
+            // pass that would come next); the home cluster integrates it only after all its readers have checked in on `rd`
+            SharedRef ea = sa, eb = sb;
+            ea.rank = 0; eb.rank = 0;
+            wait_shared_seq(sh, ea.shared, ea.body, ea.expected(sh), 8, k);
+            if (F::bodies == 2) wait_shared_seq(sh, eb.shared, eb.body, eb.expected(sh), 8, k);
+            load_velocity_shared<kAccessOnlyVelocity>(sh, ea, A);
+            if (F::bodies == 2) load_velocity_shared<kAccessOnlyVelocity>(sh, eb, B);
+            if (ea.shared) __hip_atomic_fetch_add(sh.st.rd + ea.body, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (F::bodies == 2 && eb.shared) __hip_atomic_fetch_add(sh.st.rd + eb.body, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         F::incrementalUpdate(dt, A.vel, B.vel, p);
         if constexpr (F::incremental) {
             if (active) { _Pragma("unroll") for (int cidx = 0; cidx < F::contacts; ++cidx) prestep[(size_t)F::depthRow(cidx) * stride + i] = p[F::depthRow(cidx)]; }
@@ -285,11 +392,20 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     load_body_lds<accA & ~(kLin | kAng)>(sh, ra, A);
     if (F::bodies == 2) load_body_lds<accB & ~(kLin | kAng)>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
     if (TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps.loaded = __builtin_readcyclecounter(); }
-    ClusterGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps};
+    ClusterGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE, SHARED> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps, sa, sb};
     if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, gate);
     else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, gate);
-    store_velocity_lds<accA>(sh, active ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references)
-    if (F::bodies == 2) store_velocity_lds<accB>(sh, active ? rb : -1, B);
+    store_velocity_lds<accA>(sh, (active && !sa.shared) ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references)
+    if (F::bodies == 2) store_velocity_lds<accB>(sh, (active && !sb.shared) ? rb : -1, B);
+    if constexpr (SHARED) {
+        if (__builtin_amdgcn_ballot_w64(sa.shared || sb.shared) != 0) {  // wave-uniform: items without shared bodies skip the memory round trip
+            store_velocity_shared<accA>(sh, sa, A);
+            if (F::bodies == 2) store_velocity_shared<accB>(sh, sb, B);
+            wait_vm();  // the velocities are in memory before the event counters say so
+            if (sa.shared) store_seq(sh.st.seq + sa.body, sa.expected(sh) + 1);
+            if (F::bodies == 2 && sb.shared) store_seq(sh.st.seq + sb.body, sb.expected(sh) + 1);
+        }
+    }
     publish_item(sh.flags + k, sh.batch_done + h.batch, epoch);
     __builtin_amdgcn_s_setprio(0);
     if (STAGE == kStageSolve && active) {  // off the critical path: nothing reads the impulses before the next pass (a barrier away)
@@ -300,10 +416,10 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
 using DC1O = Contact<1, false>; using DC2O = Contact<2, false>; using DC3O = Contact<3, false>; using DC4O = Contact<4, false>;
 using DC1T = Contact<1, true>; using DC2T = Contact<2, true>; using DC3T = Contact<3, true>; using DC4T = Contact<4, true>;
 
-template <int STAGE, bool TRACE, bool WIDE>
+template <int STAGE, bool TRACE, bool WIDE, bool SHARED>
 __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
                                                  unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
-#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps); break;
+#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE, SHARED>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps); break;
     switch (h.type_id) {
         BEPU_CASE(kContact1OneBody, DC1O) BEPU_CASE(kContact2OneBody, DC2O) BEPU_CASE(kContact3OneBody, DC3O) BEPU_CASE(kContact4OneBody, DC4O)
         BEPU_CASE(kContact1, DC1T) BEPU_CASE(kContact2, DC2T) BEPU_CASE(kContact3, DC3T) BEPU_CASE(kContact4, DC4T)
@@ -343,9 +459,10 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
 // predecessors), so the head of the iteration runs while the tail of the warm start's dependency chain is still draining. The warm start does
 // not write accumulated impulses, hence nothing the iteration loads from HBM is in flight. STAGE0 = kStageSolve with solve_items = 0 runs a
 // later iteration on its own (a barrier precedes it: its impulses were stored by the previous one).
-template <int STAGE0, bool TRACE, bool WIDE>
-__device__ __forceinline__ void run_cluster_sweep(const ClusterShared& sh, int item_count, int solve_items, int lane, int wave, unsigned epoch, unsigned claim_base,
+template <int STAGE0, bool TRACE, bool WIDE, bool SHARED>
+__device__ __forceinline__ void run_cluster_sweep(ClusterShared& sh, int item_count, int solve_items, int lane, int wave, unsigned epoch, unsigned claim_base,
                                                   unsigned* __restrict__ slab, float dt, float inv_dt, unsigned long long* trace) {
+    const unsigned pass_base = sh.passes;
     for (;;) {
         const int v = (int)(claim_next(sh.counter) - claim_base);
         if (v >= item_count + solve_items) break;
@@ -357,8 +474,9 @@ __device__ __forceinline__ void run_cluster_sweep(const ClusterShared& sh, int i
         unsigned long long t0 = 0;
         if (TRACE) t0 = __builtin_readcyclecounter();
         ItemStamps stamps = {0, 0, 0};
-        if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE, WIDE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
-        else run_cluster_item<kStageSolve, TRACE, WIDE>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+        if constexpr (SHARED) sh.passes = pass_base + (second ? 1u : 0u);  // wave-private copy: which pass of the step this item belongs to
+        if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE, WIDE, SHARED>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+        else run_cluster_item<kStageSolve, TRACE, WIDE, SHARED>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
         if (TRACE && trace && blockIdx.x == 0 && lane == 0 && item_epoch - 1 < (unsigned)kClusterTracePasses) {  // iteration counts are unbounded: never write past the buffer
             unsigned long long* rec = trace + ((size_t)(item_epoch - 1) * item_count + k) * 8;
             rec[4] = stamps.loaded; rec[5] = stamps.pre_gate; rec[6] = stamps.post_gate; rec[7] = 0;
@@ -367,13 +485,14 @@ __device__ __forceinline__ void run_cluster_sweep(const ClusterShared& sh, int i
             rec[3] = (unsigned long long)h.count;
         }
     }
+    if constexpr (SHARED) sh.passes = pass_base;
 }
 
-template <int THREADS, bool TRACE, bool WIDE>
+template <int THREADS, bool TRACE, bool WIDE, bool SHARED>
 __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __restrict__ clusters, const ClusterItem* __restrict__ items,
                                                                    const int* __restrict__ batch_item_begin, const int* __restrict__ cluster_bodies,
                                                                    float4* bodies, unsigned* __restrict__ slab, ClusterParams cp, int ncap, int max_items,
-                                                                   unsigned long long* trace, unsigned* status, unsigned long long* cycles, TailParams tp) {
+                                                                   unsigned long long* trace, unsigned* status, unsigned long long* cycles, TailParams tp, SharedTables shared_tables) {
     if ((int)blockIdx.x >= tp.cluster_count) {
         // ---- not a cluster: the bodies no cluster owns (IntegrateBundlesAfterSubstepping for unconstrained bodies), and, in the last workgroup, the
         // constrained kinematic bodies. Clusters stage private copies of the kinematic bodies they reference from HBM when they start, so those are
@@ -417,6 +536,9 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.counter = (lds_u32*)(words + max_items + 2 * (kFallbackBatchLimit + 1) + 1);
     sh.status = status;
     sh.batch_count = cp.batch_count;
+    sh.st = shared_tables; sh.events = 0; sh.passes = 0;
+    int* slot_body_lds = reinterpret_cast<int*>(words + ((cluster_sync_words(max_items) + 3) / 4) * 4);  // SHARED plans: behind the sync words
+    sh.slot_body = slot_body_lds;
     const ClusterDesc cd = clusters[blockIdx.x];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
@@ -426,7 +548,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     for (int j = tid; j < cd.slot_count * kPlanes; j += blockDim.x) {
         const int slot = j >> 3, v = j & 7;
         const int g = slots[slot];
-        lds[v * ncap + slot] = g >= 0 ? bodies[(size_t)(g & kRefMask) * 8 + v] : make_float4(0, 0, 0, 0);
+        lds[v * ncap + slot] = g >= 0 ? bodies[(size_t)(g & kSlotBodyMask) * 8 + v] : make_float4(0, 0, 0, 0);
     }
     {
         const int4* src = reinterpret_cast<const int4*>(items + cd.item_begin);
@@ -436,6 +558,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     for (int j = tid; j < max_items + kFallbackBatchLimit + 1; j += blockDim.x) words[j] = 0;  // flags + batch_done
     for (int j = tid; j <= cp.batch_count; j += blockDim.x) sh.lbib[j] = batch_item_begin[cd.batch_item_offset + j] - cd.item_begin;
     if (tid == 0) *sh.counter = 0;
+    if constexpr (SHARED) { for (int j = tid; j < cd.slot_count; j += blockDim.x) slot_body_lds[j] = slots[j]; }
     __syncthreads();
     if (tid == 0 && tp.kin_count > 0) __hip_atomic_fetch_add(tp.staged, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // this cluster's copies of kinematic bodies are in LDS
 
@@ -448,7 +571,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 const ItemHeader h = read_item(it);
                 if (!isContactType(h.type_id)) continue;
                 ItemStamps stamps = {0, 0, 0};
-                run_cluster_item<kStageIncremental, false, WIDE>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
+                run_cluster_item<kStageIncremental, false, WIDE, SHARED>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
             }
             __syncthreads();
         }
@@ -457,8 +580,23 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         for (int j = tid; j < cd.slot_count; j += blockDim.x) {
             const int g = slots[j];
             if (g < 0) continue;
+            if (SHARED && (g & kSlotGhost)) continue;  // another cluster integrates it: refreshed below
             float4* r = lds + j;
             float4 q4 = r[0], p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
+            const bool home = SHARED && (g & kSlotSharedHome) != 0;
+            const int body = g & kSlotBodyMask;
+            if (home && s > 0) {
+                // every application of the previous substep has happened (event counter) and every incremental contact update has read the velocity
+                const unsigned info = shared_tables.info[body];
+                const unsigned want_seq = (unsigned)s + (info & 0xFFu) * sh.passes, want_rd = (unsigned)s * ((info >> 8) & 0xFFFFu);
+                unsigned spins = 0;
+                while (load_seq(shared_tables.seq + body) < want_seq || load_seq(shared_tables.rd + body) < want_rd) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > kSpinLimit) { report_stall(status, *sh.counter, 9, j, body, want_seq, load_seq(shared_tables.seq + body)); break; }
+                    if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                }
+                load_agent_pair(shared_tables.vel + (size_t)body * 2, l4, a4);
+            }
             Q ori = {q4.x, q4.y, q4.z, q4.w};
             V3 pos = {p4.x, p4.y, p4.z};
             BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
@@ -468,7 +606,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 r[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
                 r[ncap] = make_float4(pos.x, pos.y, pos.z, p4.w);
             }
-            if ((unsigned)g < kDynamicLimit) {
+            if ((unsigned)(g & ~(kSlotSharedHome)) < kDynamicLimit) {
                 const float4 i0 = r[4 * ncap], i1 = r[5 * ncap];
                 Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
                 Sym3 world = rotateInverseInertia(local, ori);
@@ -477,32 +615,74 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
                 r[6 * ncap] = make_float4(world.xx, world.yx, world.yy, world.zx);
                 r[7 * ncap] = make_float4(world.zy, world.zz, i1.z, r[7 * ncap].w);
+                if (home) {  // publish: velocity into the shared table, pose and world inertia into the body record the ghosts copy from, then the event
+                    float4* gb = bodies + (size_t)body * 8;
+                    store_agent_f4(shared_tables.vel + (size_t)body * 2, r[2 * ncap]);
+                    store_agent_f4(shared_tables.vel + (size_t)body * 2 + 1, r[3 * ncap]);
+                    store_agent_f4(gb, r[0]); store_agent_f4(gb + 1, r[ncap]); store_agent_f4(gb + 6, r[6 * ncap]); store_agent_f4(gb + 7, r[7 * ncap]);
+                    wait_vm();
+                    store_seq(shared_tables.seq + body, (unsigned)s + 1u + (shared_tables.info[body] & 0xFFu) * sh.passes);
+                }
             } else if (cp.integrate_velocity_for_kinematics) {  // kinematic: private copy, same arithmetic as the global kinematic pass
                 velocity_callback(cp.sp, vel);
                 r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
                 r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
             }
         }
+        if constexpr (SHARED) {  // ghosts: pose and world inertia of this substep from their home clusters
+            for (int j = tid; j < cd.slot_count; j += blockDim.x) {
+                const int g = slots[j];
+                if (g < 0 || !(g & kSlotGhost)) continue;
+                const int body = g & kSlotBodyMask;
+                const unsigned want = (unsigned)s + 1u + (shared_tables.info[body] & 0xFFu) * sh.passes;
+                unsigned spins = 0;
+                while (load_seq(shared_tables.seq + body) < want) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > kSpinLimit) { report_stall(status, *sh.counter, 10, j, body, want, load_seq(shared_tables.seq + body)); break; }
+                    if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                }
+                const float4* gb = bodies + (size_t)body * 8;
+                float4 q, pz, w0, w1;
+                load_agent_pose_inertia(gb, q, pz, w0, w1);
+                lds[j] = q; lds[ncap + j] = pz; lds[6 * ncap + j] = w0; lds[7 * ncap + j] = w1;
+            }
+            sh.events = (unsigned)s + 1u;
+        }
         __syncthreads();
         ++epoch;
         const int fused = cp.iters[s] > 0 ? cd.item_count : 0;  // the first velocity iteration rides in the warm start's claim sequence
-        run_cluster_sweep<kStageWarmStart, TRACE, WIDE>(sh, cd.item_count, fused, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+        run_cluster_sweep<kStageWarmStart, TRACE, WIDE, SHARED>(sh, cd.item_count, fused, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
         claim_base += cd.item_count + fused + nwaves;  // every wave makes exactly one failing claim per sweep
+        sh.passes += fused ? 2u : 1u;
         if (fused) ++epoch;
         __syncthreads();
         for (int iter = 1; iter < cp.iters[s]; ++iter) {
             ++epoch;
-            run_cluster_sweep<kStageSolve, TRACE, WIDE>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+            run_cluster_sweep<kStageSolve, TRACE, WIDE, SHARED>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
             claim_base += cd.item_count + nwaves;
+            sh.passes += 1u;
             __syncthreads();
         }
     }
     // Trailing pose integration of constrained bodies (PoseIntegrator.cs:684-691) and write-back.
     for (int j = tid; j < cd.slot_count; j += blockDim.x) {
-        const int g = slots[j];
+        int g = slots[j];
+        if (SHARED && g >= 0 && (g & kSlotGhost)) continue;  // written back by its home cluster
+        const bool home = SHARED && g >= 0 && (g & kSlotSharedHome) != 0;
+        if (home) g &= kSlotBodyMask;
         if ((unsigned)g >= kDynamicLimit) continue;  // unused slot, or kinematic (advanced in global memory by this launch's kinematic workgroup)
         const float4* r = lds + j;
         float4 q4 = r[0], p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
+        if (home) {  // the last applications on a shared body may belong to other clusters: wait for the step's full event count, then take its velocity
+            const unsigned want = (unsigned)cp.substeps + (shared_tables.info[g] & 0xFFu) * sh.passes;
+            unsigned spins = 0;
+            while (load_seq(shared_tables.seq + g) < want) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > kSpinLimit) { report_stall(status, *sh.counter, 11, j, g, want, load_seq(shared_tables.seq + g)); break; }
+                if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            }
+            load_agent_pair(shared_tables.vel + (size_t)g * 2, l4, a4);
+        }
         Q ori = {q4.x, q4.y, q4.z, q4.w};
         V3 pos = {p4.x, p4.y, p4.z};
         V3 lin = {l4.x, l4.y, l4.z}, ang = {a4.x, a4.y, a4.z};

@@ -2,6 +2,7 @@
 #pragma once
 
 #include "bepu_host_state.h"
+#include <unordered_map>
 
 // ---- cluster planning (host, once per topology upload) ----
 // Islands = connected components through dynamic bodies (kinematic references never connect: they are read-only to the solver).
@@ -10,6 +11,8 @@
 // records which earlier items last touched its dynamic bodies (the only ordering the solve has to respect).
 struct ClusterPlan {
     bool enabled = false;
+    bool shared = false;                 // split islands: some dynamic bodies are referenced from more than one cluster (SharedTables)
+    std::vector<uint32_t> shared_info;   // per body index: applications per pass (d) | incremental readers (c) << 8, 0 for bodies that are not shared
     std::vector<ClusterDesc> clusters;
     std::vector<ClusterItem> items;
     std::vector<int> batch_item_begin, cluster_bodies, clustered_dynamic, kinlist;
@@ -22,12 +25,13 @@ static int env_int(const char* name, int fallback) {
 }
 
 constexpr size_t kLdsBudgetBytes = 160 * 1024 - 256;
-static size_t cluster_sync_words(int max_items) { return (size_t)max_items + 2 * (kFallbackBatchLimit + 1) + 2; }
-static size_t cluster_lds_bytes(int ncap, int max_items) {
-    return (size_t)kPlanes * ncap * 16 + (size_t)max_items * sizeof(ClusterItem) + (cluster_sync_words(max_items) + 3) / 4 * 16;
+static size_t cluster_lds_bytes(int ncap, int max_items, bool shared = false) {  // shared plans keep a slot -> body table in LDS too
+    return (size_t)kPlanes * ncap * 16 + (size_t)max_items * sizeof(ClusterItem) + (cluster_sync_words(max_items) + 3) / 4 * 16 + (shared ? ((size_t)ncap * 4 + 15) / 16 * 16 : 0);
 }
 // Slot rotation inside every group of 16 (see the LDS layout note above cluster_kernel).
 static inline int rotated_slot(int i) { return (i & ~15) | ((i + (i >> 4)) & 15); }
+
+static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe);
 
 static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     int universe = 0;
@@ -123,7 +127,10 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
             max_items = std::max(max_items, item_count[cl]);
         }
         if (max_items < 65536 && cluster_lds_bytes(max_slots, max_items) <= kLdsBudgetBytes) break;
-        if (cap <= largest || attempt > 24) return;  // an island (plus its work items) does not fit one workgroup: global path
+        if (cap <= largest || attempt > 24) {  // an island (plus its work items) does not fit one workgroup: cut it (shared bodies), or leave it to the global path
+            plan_split_clusters(c, plan, universe);
+            return;
+        }
         cap = std::max<int>(largest, cap * 7 / 8);
     }
     // ---- phase B: local slots, reordered type batches, work items with predecessor lists ----
@@ -259,4 +266,302 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         plan.max_items = std::max(plan.max_items, d.item_count);
     }
     plan.enabled = nclusters > 0 && cluster_lds_bytes(plan.max_slots, plan.max_items) <= kLdsBudgetBytes;
+}
+
+
+// ---- split-island plans ----
+// An island that no workgroup's LDS can hold is cut into clusters of neighbouring bodies (breadth-first regions of the constraint graph). A constraint runs
+// in the cluster of its first dynamic body; a dynamic body that a constraint of ANOTHER cluster references is shared: its velocity lives in a global table
+// during the sweeps and every application on it waits for the body's event counter (kernel side: SharedRef, wait_shared_seq). Everything else — private
+// bodies in LDS, work items, predecessor flags — is the island schedule's. Islands that fit are still packed whole. All clusters must be resident at once
+// (they wait for each other), so the plan is refused (global path) when it needs more clusters than the device has CUs.
+static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe) {
+    if (env_int("BEPUHIP_NO_SPLIT", 0)) return;
+    for (auto& tb : c->tbs) if (tb.info.bodies > 2) return;  // three- and four-body constraints keep to whole islands
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    // adjacency of dynamic bodies (CSR), degree d and contact degree c per body
+    std::vector<uint8_t> is_dyn(universe, 0);
+    std::vector<int32_t> deg(universe, 0), cdeg(universe, 0);
+    for (auto& tb : c->tbs)
+        for (int k = 0; k < tb.info.bodies; ++k)
+            for (int i = 0; i < tb.count; ++i) {
+                const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                if ((uint32_t)r < kDynamicLimit) { is_dyn[r] = 1; ++deg[r]; if (tb.info.incremental) ++cdeg[r]; }
+            }
+    std::vector<int64_t> adj_begin(universe + 1, 0);
+    for (auto& tb : c->tbs) {
+        if (tb.info.bodies != 2) continue;
+        for (int i = 0; i < tb.count; ++i) {
+            const int32_t a = tb.refs_soa[i], b = tb.refs_soa[(size_t)tb.stride + i];
+            if ((uint32_t)a < kDynamicLimit && (uint32_t)b < kDynamicLimit) { ++adj_begin[a + 1]; ++adj_begin[b + 1]; }
+        }
+    }
+    for (int i = 0; i < universe; ++i) adj_begin[i + 1] += adj_begin[i];
+    std::vector<int32_t> adj(adj_begin[universe]);
+    {
+        std::vector<int64_t> fill(adj_begin.begin(), adj_begin.end() - 1);
+        for (auto& tb : c->tbs) {
+            if (tb.info.bodies != 2) continue;
+            for (int i = 0; i < tb.count; ++i) {
+                const int32_t a = tb.refs_soa[i], b = tb.refs_soa[(size_t)tb.stride + i];
+                if ((uint32_t)a < kDynamicLimit && (uint32_t)b < kDynamicLimit) { adj[fill[a]++] = b; adj[fill[b]++] = a; }
+            }
+        }
+    }
+    int64_t total_dyn = 0;
+    for (int i = 0; i < universe; ++i) total_dyn += is_dyn[i];
+    if (total_dyn == 0) return;
+    for (int i = 0; i < universe; ++i) if (deg[i] > 255 || cdeg[i] > 65535) return;  // rank | degree travel as bytes
+    const int target_clusters = std::max(1, std::min(cus * 31 / 32, env_int("BEPUHIP_SPLIT_CLUSTERS", cus * 31 / 32)));
+    int region = (int)((total_dyn + target_clusters - 1) / target_clusters);
+    region = std::max(region, 32);
+    // ---- regions: grown breadth-first around a seed until they hold `region` bodies (compact balls of the constraint graph: the fewer bodies on a
+    // region's surface, the fewer are shared). The next seed is a body the last region's frontier already reached, so consecutive clusters are neighbours;
+    // a component that ends early lets the next one continue the cluster (small islands are packed together, as in the whole-island plan). ----
+    std::vector<int32_t> body_cluster(universe, -1);
+    int nclusters = 0;
+    {
+        std::vector<int32_t> queue, carry;
+        int cur = 0, scan = 0;
+        size_t carry_at = 0;
+        for (;;) {
+            int seed = -1;
+            while (carry_at < carry.size() && seed < 0) { const int v = carry[carry_at++]; if (body_cluster[v] < 0) seed = v; }
+            if (seed < 0) {
+                carry.clear(); carry_at = 0;
+                while (scan < universe && (!is_dyn[scan] || body_cluster[scan] >= 0)) ++scan;
+                if (scan == universe) break;
+                seed = scan;
+            }
+            if (nclusters == 0 || cur >= region) { ++nclusters; cur = 0; }
+            queue.clear();
+            queue.push_back(seed);
+            size_t q = 0;
+            for (; q < queue.size() && cur < region; ++q) {
+                const int u = queue[q];
+                if (body_cluster[u] >= 0) continue;
+                body_cluster[u] = nclusters - 1;
+                ++cur;
+                for (int64_t e = adj_begin[u]; e < adj_begin[u + 1]; ++e)
+                    if (body_cluster[adj[e]] < 0) queue.push_back(adj[e]);
+            }
+            if (q < queue.size()) {  // region full: what the frontier had reached seeds the next regions
+                if (carry_at > 0) { carry.erase(carry.begin(), carry.begin() + carry_at); carry_at = 0; }
+                carry.insert(carry.end(), queue.begin() + q, queue.end());
+            }
+        }
+    }
+    if (nclusters > cus) return;
+    // ---- constraints -> clusters, shared bodies, per-pass rank of every application on a shared body (type batches are in batch order) ----
+    std::vector<std::vector<int32_t>> cl_of_constraint(c->tbs.size());
+    std::vector<uint8_t> shared(universe, 0);
+    for (size_t t = 0; t < c->tbs.size(); ++t) {
+        HostTypeBatch& tb = c->tbs[t];
+        cl_of_constraint[t].resize(tb.count);
+        for (int i = 0; i < tb.count; ++i) {
+            int cl = -1;
+            for (int k = 0; k < tb.info.bodies && cl < 0; ++k) {
+                const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                if ((uint32_t)r < kDynamicLimit) cl = body_cluster[r];
+            }
+            if (cl < 0) return;  // a constraint with no dynamic body: leave everything to the global path
+            cl_of_constraint[t][i] = cl;
+            for (int k = 0; k < tb.info.bodies; ++k) {
+                const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                if ((uint32_t)r < kDynamicLimit && body_cluster[r] != cl) shared[r] = 1;
+            }
+        }
+    }
+    std::vector<std::vector<uint32_t>> srank(c->tbs.size());
+    {
+        std::vector<int32_t> next_rank(universe, 0);
+        for (size_t t = 0; t < c->tbs.size(); ++t) {  // batch order == type batch order; inside a batch a body appears at most once
+            HostTypeBatch& tb = c->tbs[t];
+            srank[t].assign((size_t)tb.info.bodies * tb.stride, 0u);
+            for (int k = 0; k < tb.info.bodies; ++k)
+                for (int i = 0; i < tb.count; ++i) {
+                    const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r < kDynamicLimit && shared[r]) srank[t][(size_t)k * tb.stride + i] = (uint32_t)next_rank[r]++ | ((uint32_t)deg[r] << 8);
+                }
+        }
+    }
+    // ---- slots: home bodies (ascending), then ghosts and kinematic copies on first use ----
+    std::vector<std::vector<int32_t>> cl_bodies(nclusters);
+    std::vector<int32_t> local_of(universe, -1);
+    for (int i = 0; i < universe; ++i)
+        if (is_dyn[i]) { const int cl = body_cluster[i]; local_of[i] = (int)cl_bodies[cl].size(); cl_bodies[cl].push_back(i | (shared[i] ? kSlotSharedHome : 0)); plan.clustered_dynamic.push_back(i); }
+    std::vector<std::unordered_map<int32_t, int32_t>> cl_extra(nclusters);  // body | kind flag -> natural local index of ghosts and kinematic copies
+    auto extra_local = [&](int cl, int tagged) {
+        auto found = cl_extra[cl].find(tagged);
+        if (found != cl_extra[cl].end()) return found->second;
+        const int l = (int)cl_bodies[cl].size();
+        cl_bodies[cl].push_back(tagged);
+        cl_extra[cl].emplace(tagged, l);
+        return l;
+    };
+    // pre-size: every cluster must fit the LDS budget with its ghosts, kinematic copies and items
+    {
+        std::vector<int32_t> item_count(nclusters, 0), per_cluster(nclusters);
+        for (size_t t = 0; t < c->tbs.size(); ++t) {
+            HostTypeBatch& tb = c->tbs[t];
+            std::fill(per_cluster.begin(), per_cluster.end(), 0);
+            for (int i = 0; i < tb.count; ++i) {
+                const int cl = cl_of_constraint[t][i];
+                per_cluster[cl]++;
+                for (int k = 0; k < tb.info.bodies; ++k) {
+                    const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r >= kDynamicLimit) extra_local(cl, (r & kRefMask) | kSlotKinematic);
+                    else if (body_cluster[r] != cl) extra_local(cl, r | kSlotGhost);
+                }
+            }
+            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (per_cluster[cl] + 63) / 64 + 1;  // + 1: private and shared constraints are itemised apart
+        }
+        int max_slots = 0, max_items = 0;
+        for (int cl = 0; cl < nclusters; ++cl) {
+            max_slots = std::max(max_slots, ((int)cl_bodies[cl].size() + 15) / 16 * 16);
+            max_items = std::max(max_items, item_count[cl]);
+        }
+        if (max_slots >= 0x4000 || max_items >= 65536 || cluster_lds_bytes(max_slots, max_items, true) > kLdsBudgetBytes) return;
+    }
+    auto slot_of = [&](int cl, int32_t r) {  // 32-bit local reference of body reference r as seen from cluster cl: slot | shared << 14 | kinematic << 30
+        if ((uint32_t)r >= kDynamicLimit) return rotated_slot(extra_local(cl, (r & kRefMask) | kSlotKinematic)) | (int)kDynamicLimit;
+        const int l = body_cluster[r] == cl ? local_of[r] : extra_local(cl, r | kSlotGhost);
+        return rotated_slot(l) | (shared[r] ? (int)kLrefShared : 0);
+    };
+    std::vector<std::vector<int32_t>> last_toucher(nclusters);
+    for (int cl = 0; cl < nclusters; ++cl) last_toucher[cl].assign((cl_bodies[cl].size() + 15) / 16 * 16 + 16, -1);
+    std::vector<std::vector<ClusterItem>> cl_items(nclusters);
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> first_touch(nclusters);
+    std::vector<size_t> visit(c->tbs.size());
+    for (size_t t = 0; t < visit.size(); ++t) visit[t] = t;
+    std::stable_sort(visit.begin(), visit.end(), [&](size_t a, size_t b) {
+        const HostTypeBatch &x = c->tbs[a], &y = c->tbs[b];
+        if (x.batch != y.batch) return x.batch < y.batch;
+        return x.info.prestep + 2 * x.info.impulse > y.info.prestep + 2 * y.info.impulse;
+    });
+    for (size_t t : visit) {
+        HostTypeBatch& tb = c->tbs[t];
+        const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
+        const std::vector<int32_t>& clc = cl_of_constraint[t];
+        // inside a cluster: constraints that touch only private bodies first (their items never leave LDS), the ones with shared bodies behind them
+        std::vector<uint8_t> touches_shared(tb.count, 0);
+        for (int i = 0; i < tb.count; ++i)
+            for (int k = 0; k < nb; ++k) {
+                const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                if ((uint32_t)r < kDynamicLimit && shared[r]) touches_shared[i] = 1;
+            }
+        tb.perm.resize(tb.count);
+        for (int i = 0; i < tb.count; ++i) tb.perm[i] = i;
+        std::stable_sort(tb.perm.begin(), tb.perm.end(), [&](int a, int b) { return clc[a] != clc[b] ? clc[a] < clc[b] : touches_shared[a] < touches_shared[b]; });
+        std::vector<int32_t> refs((size_t)nb * tb.stride, -1), lrefs((size_t)nb * tb.stride, -1);
+        std::vector<uint32_t> ranks((size_t)nb * tb.stride, 0u);
+        std::vector<float> pre((size_t)pf * tb.stride, 0.0f), acc((size_t)imf * tb.stride, 0.0f);
+        for (int d = 0; d < tb.count; ++d) {
+            const int h = tb.perm[d], cl = clc[h];
+            for (int k = 0; k < nb; ++k) {
+                const int32_t r = tb.refs_soa[(size_t)k * tb.stride + h];
+                refs[(size_t)k * tb.stride + d] = r;
+                lrefs[(size_t)k * tb.stride + d] = slot_of(cl, r);
+                ranks[(size_t)k * tb.stride + d] = srank[t][(size_t)k * tb.stride + h];
+            }
+            for (int f = 0; f < pf; ++f) pre[(size_t)f * tb.stride + d] = tb.prestep_soa[(size_t)f * tb.stride + h];
+            for (int f = 0; f < imf; ++f) acc[(size_t)f * tb.stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
+        }
+        tb.refs_soa.swap(refs); tb.prestep_soa.swap(pre); tb.accum_soa.swap(acc); tb.lrefs_soa.swap(lrefs);
+        srank[t].swap(ranks);
+        for (int d = 0; d < tb.count;) {
+            const int cl = clc[tb.perm[d]];
+            const int sh0 = touches_shared[tb.perm[d]];
+            int e = d;
+            while (e < tb.count && clc[tb.perm[e]] == cl && touches_shared[tb.perm[e]] == sh0) ++e;
+            for (int s0 = d; s0 < e; s0 += 64) {
+                ClusterItem it;
+                memset(&it, 0, sizeof(it));
+                it.type_id = tb.type_id; it.count = std::min(64, e - s0); it.stride = tb.stride; it.start = s0;
+                it.tb = (int)t; it.shape = nb | (pf << 8) | (imf << 16);
+                const int self = (int)cl_items[cl].size();
+                int npred = 0, overflow = 0;
+                std::vector<int32_t>& lt = last_toucher[cl];
+                for (int j = s0; j < s0 + it.count; ++j)
+                    for (int k = 0; k < nb; ++k) {
+                        const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
+                        if ((uint32_t)lr >= kDynamicLimit || (lr & (int)kLrefShared)) continue;  // shared bodies are ordered by their event counters, not by LDS flags
+                        const int pred = lt[lr];
+                        if (pred < 0) { first_touch[cl].push_back({self, lr}); continue; }
+                        if (pred == self) continue;
+                        bool known = false;
+                        for (int q = 0; q < npred; ++q) known |= it.pred[q] == pred;
+                        if (known) continue;
+                        if (npred < kMaxPreds) it.pred[npred++] = (unsigned short)pred; else overflow = 1;
+                    }
+                for (int j = s0; j < s0 + it.count; ++j)
+                    for (int k = 0; k < nb; ++k) {
+                        const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
+                        if ((uint32_t)lr < kDynamicLimit && !(lr & (int)kLrefShared)) lt[lr] = self;
+                    }
+                if (overflow) npred = 0;
+                it.batch_npred = (tb.batch & 0xFFFF) | (npred << 16) | (overflow << 24);
+                cl_items[cl].push_back(it);
+            }
+            d = e;
+        }
+    }
+    // 16-bit local references (slot | shared << 14 | kinematic << 15), two per word, followed by the rank rows (one word per body slot)
+    for (size_t t = 0; t < c->tbs.size(); ++t) {
+        HostTypeBatch& tb = c->tbs[t];
+        const int nb = tb.info.bodies, rows = (nb + 1) / 2;
+        std::vector<int32_t> packed((size_t)(rows + nb) * tb.stride, 0);
+        for (int k = 0; k < nb; ++k)
+            for (int d = 0; d < tb.count; ++d) {
+                const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + d];
+                const uint32_t half = ((uint32_t)lr & 0x7FFFu) | (((uint32_t)lr >= kDynamicLimit) ? 0x8000u : 0u);
+                packed[(size_t)(k / 2) * tb.stride + d] |= (int32_t)(half << (16 * (k & 1)));
+                packed[(size_t)(rows + k) * tb.stride + d] = (int32_t)srank[t][(size_t)k * tb.stride + d];
+            }
+        tb.lrefs_soa.swap(packed);
+    }
+    for (int cl = 0; cl < nclusters; ++cl) {
+        for (auto& fs : first_touch[cl]) {
+            ClusterItem& it = cl_items[cl][fs.first];
+            const int last = last_toucher[cl][fs.second];
+            int nx = (it.batch_npred >> 20) & 0xF;
+            if ((it.batch_npred >> 25) & 1) continue;
+            bool known = false;
+            for (int q = 0; q < nx; ++q) known |= it.xpred[q] == last;
+            if (known) continue;
+            if (nx < kMaxPreds) { it.xpred[nx++] = (unsigned short)last; it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (nx << 20); }
+            else it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (1 << 25);
+        }
+    }
+    int64_t shared_count = 0, ghost_slots = 0;
+    for (int cl = 0; cl < nclusters; ++cl) {
+        ClusterDesc d;
+        d.body_begin = (int)plan.cluster_bodies.size();
+        d.slot_count = ((int)cl_bodies[cl].size() + 15) / 16 * 16;
+        std::vector<int32_t> slots(d.slot_count, -1);
+        for (size_t i = 0; i < cl_bodies[cl].size(); ++i) { slots[rotated_slot((int)i)] = cl_bodies[cl][i]; ghost_slots += (cl_bodies[cl][i] & kSlotGhost) != 0; }
+        plan.cluster_bodies.insert(plan.cluster_bodies.end(), slots.begin(), slots.end());
+        d.item_begin = (int)plan.items.size();
+        d.item_count = (int)cl_items[cl].size();
+        d.batch_item_offset = (int)plan.batch_item_begin.size();
+        int k = 0;
+        for (int b = 0; b <= c->batch_count; ++b) {
+            while (k < d.item_count && (cl_items[cl][k].batch_npred & 0xFFFF) < b) ++k;
+            plan.batch_item_begin.push_back(d.item_begin + k);
+        }
+        plan.items.insert(plan.items.end(), cl_items[cl].begin(), cl_items[cl].end());
+        plan.clusters.push_back(d);
+        plan.max_slots = std::max(plan.max_slots, d.slot_count);
+        plan.max_items = std::max(plan.max_items, d.item_count);
+    }
+    plan.shared_info.assign(universe, 0u);
+    for (int i = 0; i < universe; ++i) if (shared[i]) { plan.shared_info[i] = (uint32_t)deg[i] | ((uint32_t)cdeg[i] << 8); ++shared_count; }
+    plan.shared = true;
+    plan.enabled = nclusters > 0 && plan.max_slots < 0x4000 && cluster_lds_bytes(plan.max_slots, plan.max_items, true) <= kLdsBudgetBytes;
+    if (env_int("BEPUHIP_PLAN_STATS", 0))
+        fprintf(stderr, "bepuhip split plan: %d clusters (region %d), %lld dynamic bodies, %lld shared (%.1f %%), %lld ghost slots, max slots %d, max items %d, LDS %zu B, enabled %d\n", nclusters,
+                region, (long long)total_dyn, (long long)shared_count, 100.0 * shared_count / std::max<int64_t>(total_dyn, 1), (long long)ghost_slots, plan.max_slots, plan.max_items,
+                cluster_lds_bytes(plan.max_slots, plan.max_items, true), (int)plan.enabled);
 }

@@ -10,9 +10,12 @@ const void* bepu_cluster_kernel_hot_512(bool trace);
 const void* bepu_cluster_kernel_wide_1024(bool trace);
 const void* bepu_cluster_kernel_wide_768(bool trace);
 const void* bepu_cluster_kernel_wide_512(bool trace);
+const void* bepu_cluster_kernel_hot_1024s(bool trace);   // split-island plans (shared bodies): 1024 threads only, the waits want every wave they can get
+const void* bepu_cluster_kernel_wide_1024s(bool trace);
 constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
 static int cluster_variant_threads(int threads) { return threads > 768 ? 1024 : (threads > 512 ? 768 : 512); }  // the smallest budget that still fits `threads`
-static const void* cluster_kernel_variant(int threads, bool trace, bool wide) {
+static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false) {
+    if (shared) return wide ? bepu_cluster_kernel_wide_1024s(trace) : bepu_cluster_kernel_hot_1024s(trace);
     switch (cluster_variant_threads(threads)) {
         case 1024: return wide ? bepu_cluster_kernel_wide_1024(trace) : bepu_cluster_kernel_hot_1024(trace);
         case 768: return wide ? bepu_cluster_kernel_wide_768(trace) : bepu_cluster_kernel_hot_768(trace);
@@ -126,6 +129,11 @@ struct bepuhip_ctx {
     int referenced_bodies = 0;           // 1 + the largest body index any constraint references
     // cluster path
     bool clusters_enabled = false;
+    bool clusters_shared = false;    // split-island plan: bodies shared between clusters go through the tables below
+    float4* d_shared_vel = nullptr;   // 2 x float4 per body (linear, angular): the velocity of a shared body during the sweeps
+    unsigned* d_shared_seq = nullptr; // per body: event counter, then (second half) the incremental-update reader counter; zeroed before every launch
+    unsigned* d_shared_info = nullptr;
+    size_t shared_bodies = 0;         // table length (bodies)
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
     int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0;
     ClusterDesc first_cluster = {0, 0, 0, 0, 0};
@@ -184,6 +192,10 @@ static void free_constraints(bepuhip_ctx* c) {
     c->d_trace = nullptr; c->trace_words = 0;
     if (c->d_cycles) hipFree(c->d_cycles);
     c->d_cycles = nullptr;
+    if (c->d_shared_vel) hipFree(c->d_shared_vel);
+    if (c->d_shared_seq) hipFree(c->d_shared_seq);
+    if (c->d_shared_info) hipFree(c->d_shared_info);
+    c->d_shared_vel = nullptr; c->d_shared_seq = nullptr; c->d_shared_info = nullptr; c->clusters_shared = false; c->shared_bodies = 0;
     c->d_clusters = nullptr; c->d_items = nullptr; c->d_batch_item_begin = nullptr; c->d_cluster_bodies = nullptr;
     c->d_clustered_dynamic = nullptr; c->d_kinlist = nullptr;
     c->clusters_enabled = false; c->cluster_count = 0; c->clustered_dynamic_count = 0; c->kinlist_count = 0;

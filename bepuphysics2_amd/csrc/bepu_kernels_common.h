@@ -38,7 +38,21 @@ struct ClusterItem {  // <= 64 consecutive constraints of one type batch, all ow
 };
 static_assert(sizeof(ClusterItem) == 64, "ClusterItem is staged in LDS as four 16-byte vectors");
 static_assert(offsetof(ClusterItem, xpred) == offsetof(ClusterItem, pred) + kMaxPreds * sizeof(unsigned short), "wait_predecessors indexes pred[] and xpred[] as one array");
+// LDS words behind the work items: one flag per item, two (kFallbackBatchLimit + 1)-entry tables (batch counters, batch -> first item), the claim counter.
+__host__ __device__ inline size_t cluster_sync_words(int max_items) { return (size_t)max_items + 2 * (kFallbackBatchLimit + 1) + 2; }
 struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
+// Slot table entries (cluster_bodies): body index | flags; -1 = unused slot.
+constexpr int kSlotKinematic = 1 << 30;   // private read-only copy of a kinematic body
+constexpr int kSlotGhost = 1 << 29;       // SHARED plan: pose / inertia copy of a shared body whose home is another cluster (never integrated here)
+constexpr int kSlotSharedHome = 1 << 28;  // SHARED plan: this cluster integrates the body, but its velocity lives in the global shared table during the sweeps
+constexpr int kSlotBodyMask = (1 << 28) - 1;
+// Split-island ("shared body") plans, DESIGN.md 3.4: an island too large for one workgroup's LDS is cut into clusters. A dynamic body referenced by a
+// constraint that another cluster runs is SHARED: during the sweeps its velocity lives in `vel` (2 x float4 per body index, agent-scope accesses) and
+// every application of a constraint to it is ordered by `seq[body]`, which counts the events of the step on that body: one per substep for the home
+// cluster's integration, then one per constraint application in the reference's batch order (rank r of d per pass). `rd` counts the incremental contact
+// updates that have read the body's end-of-substep velocity (the home may integrate only after all c of them). `info` = d | c << 8.
+struct SharedTables { float4* vel; unsigned* seq; unsigned* rd; const unsigned* info; };
+constexpr unsigned kLrefShared = 0x4000u;  // bit 14 of a 16-bit local reference: velocity through the shared table (bit 15 = kinematic copy, bits 0-13 slot)
 constexpr int kPlanes = 8;            // LDS body table: one plane per 16-byte field of BodyDynamics
 constexpr int kClusterThreads = 1024;  // default threads per cluster workgroup
 constexpr int kMaxClusterSubsteps = 16;

@@ -471,6 +471,17 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             for (int tr = 0; tr < 2; ++tr)
                 for (int wide = 0; wide < 2; ++wide)
                     HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(threads, tr != 0, wide != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        c->clusters_shared = plan.shared;
+        if (plan.shared) {  // split islands: velocity / event tables of the bodies more than one cluster touches (indexed by body, only the shared ones are used)
+            c->shared_bodies = plan.shared_info.size();
+            HIP_TRY(hipMalloc((void**)&c->d_shared_vel, c->shared_bodies * 2 * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&c->d_shared_seq, c->shared_bodies * 2 * sizeof(unsigned)));
+            HIP_TRY(hipMemset(c->d_shared_vel, 0, c->shared_bodies * 2 * sizeof(float4)));
+            HIP_TRY(upload_ints(plan.shared_info.data(), plan.shared_info.size() * 4, (void**)&c->d_shared_info));
+            for (int tr = 0; tr < 2; ++tr)
+                for (int wide = 0; wide < 2; ++wide)
+                    HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(1024, tr != 0, wide != 0, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        }
     }
     c->built = true;
     return rebuild_flags(c);
@@ -532,7 +543,7 @@ static void enqueue_requirk(bepuhip_ctx* c, int substep, int batch, const StepPa
 
 // The island schedule implements AngularIntegrationMode.Nonconserving; the conserving modes run the launch-per-batch schedule.
 static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
-    return c->clusters_enabled && substeps <= kMaxClusterSubsteps && cluster_lds_bytes(c->cluster_max_slots, c->cluster_max_items) <= kLdsBudgetBytes &&
+    return c->clusters_enabled && substeps <= kMaxClusterSubsteps && cluster_lds_bytes(c->cluster_max_slots, c->cluster_max_items, c->clusters_shared) <= kLdsBudgetBytes &&
            in->angular_integration_mode == 0;
 }
 // Enqueue every kernel of one Simulation.Solve on the context's stream (Solver_Solve.cs:1415-1479 + PoseIntegrator.cs:707-726).
@@ -541,7 +552,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
     const float inv_dt = 1.0f / substep_dt;          // :1421
     const StepParams sp = make_params(in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
-    const size_t lds_bytes = cluster_lds_bytes(c->cluster_max_slots, c->cluster_max_items);
+    const size_t lds_bytes = cluster_lds_bytes(c->cluster_max_slots, c->cluster_max_items, c->clusters_shared);
     const bool use_clusters = island_schedule_applies(c, substeps, in);
     const int skip_clustered = use_clusters ? 1 : 0;
     if (use_clusters) {
@@ -554,7 +565,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             Timed t(c, 5);
             // Waves per cluster: 16 by default (four per SIMD; 12 is as fast when memory latency is low, 8 is slower everywhere); BEPUHIP_CLUSTER_THREADS overrides.
             const int req = env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
-            const int threads = std::max(64, std::min(1024, req / 64 * 64));
+            const int threads = c->clusters_shared ? 1024 : std::max(64, std::min(1024, req / 64 * 64));
             // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
             // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).
             TailParams tp;
@@ -565,10 +576,12 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             tp.allow_substeps_for_unconstrained = in->allow_substeps_for_unconstrained; tp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
             const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
             tp.final_sp = make_params(in, vdt, vdt, 1.0f / vdt);
+            SharedTables st = {c->d_shared_vel, c->d_shared_seq, c->d_shared_seq + c->shared_bodies, c->d_shared_info};
+            if (c->clusters_shared) hipMemsetAsync(c->d_shared_seq, 0, c->shared_bodies * 2 * sizeof(unsigned), c->stream);  // event and reader counters start every step at zero
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
-                            (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp};
+                            (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
             const bool tr = c->d_trace != nullptr;
-            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types);  // the register budget that matches the workgroup size
+            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared);  // the register budget that matches the workgroup size
             hipLaunchKernel(fn, dim3(c->cluster_count + tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0)), dim3(threads), args, lds_bytes, c->stream);
         }
     }

@@ -280,3 +280,32 @@ def star_scene(seed, spokes=80, hubs=2, type_ids=(7, 22, 4, 47, 30), fallback_ba
         if not sb.is_kinematic(s):
             sb.add_constraint(3, [s], prestep_for(rng, 3, sb._bodies[s][4:7], None))
     return sb.build()
+
+
+def concat_scenes(a: Scene, b: Scene) -> Scene:
+    """Both scenes side by side in one simulation: b's bodies follow a's, batch k holds both scenes' batch k (a body never appears twice in a batch, because the
+    two scenes share no bodies), same-type type batches joined lane after lane."""
+    from bepuphysics2_amd.scene import TypeBatchData, to_aosoa
+    w = a.bundle_width
+    assert b.bundle_width == w
+    na, ha = a.body_count, int(a.handle_to_index.size)
+    bodies = np.concatenate([a.bodies, b.bodies])
+    i2h = np.concatenate([a.index_to_handle, b.index_to_handle + ha]).astype(np.int32)
+    h2i = np.concatenate([a.handle_to_index, np.where(b.handle_to_index >= 0, b.handle_to_index + na, b.handle_to_index)]).astype(np.int32)
+    batches = []
+    for k in range(max(len(a.batches), len(b.batches))):
+        merged = {}
+        for scene, offset in ((a, 0), (b, na)):
+            if k >= len(scene.batches):
+                continue
+            for tb in scene.batches[k]:
+                refs = tb.refs_lanes(w).copy()
+                refs = np.where(refs >= 0, refs + offset, refs)  # the kinematic flag (bit 30) rides along: indices are far below it
+                merged.setdefault(tb.type_id, []).append((refs, tb.prestep_lanes(w), tb.accumulated_lanes(w)))
+        out = []
+        for type_id, parts in merged.items():
+            refs, pre, acc = (np.concatenate([p[i] for p in parts]) for i in range(3))
+            out.append(TypeBatchData(type_id, refs.shape[0], to_aosoa(refs.astype(np.int32), w, fill=-1), to_aosoa(pre.astype(np.float32), w), to_aosoa(acc.astype(np.float32), w)))
+        batches.append(out)
+    kin = np.concatenate([a.constrained_kinematic_handles, b.constrained_kinematic_handles + ha]).astype(np.int32)
+    return Scene(bodies, i2h, h2i, batches, kin, w)

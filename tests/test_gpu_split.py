@@ -1,0 +1,96 @@
+"""-m gpu: the split-island plan of the island-per-workgroup schedule — islands no workgroup's LDS holds are cut into clusters that hand
+the bodies they share to each other through global event counters. Every case is checked bit for bit against the CPU oracle, and asserts that the split
+plan is what actually ran (cluster_cycles() is empty on the launch-per-batch schedule)."""
+import numpy as np
+import pytest
+
+import parity_util as pu
+import small_scenes
+from bepuphysics2_amd.scene import PoseIntegratorCallbacks, SolveDescription
+
+pytestmark = pytest.mark.gpu
+
+TWO_BODY_TYPES = sorted(t for t, info in small_scenes.TYPE_TABLE.items() if info[0] <= 2)  # one- and two-body joints and contact manifolds
+
+
+def _exact(m):
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+
+def _host_scene(name, a, b, c, seed):
+    from bepuphysics2_amd.hostlib import HostSimulation
+    sim = HostSimulation.scene(name, a, b, c, seed)
+    scene, sd = sim.export(), sim.solve_description()
+    sim.close()
+    return scene, sd
+
+
+@pytest.mark.parametrize("clusters", [0, 12, 31])
+def test_pile_is_split_and_bit_exact(hip_solver_factory, monkeypatch, clusters):
+    """The 8000-body pile is one island of ~8000 bodies: cut into as many clusters as the device has CUs (0 = default), or into a forced handful."""
+    if clusters:
+        monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", str(clusters))
+    scene, sd = _host_scene("pile", 8000, 0, 0, 5)
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=3, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=3)
+    assert solver.cluster_cycles().size > 1
+    _exact(pu.compare_scenes(ref, got))
+
+
+def test_ragdoll_crowd_is_split_and_bit_exact(hip_solver_factory):
+    scene, sd = _host_scene("ragdoll_tube", 1200, 1, 2, 11)
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=3, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=3)
+    assert solver.cluster_cycles().size > 1
+    _exact(pu.compare_scenes(ref, got))
+
+
+@pytest.mark.parametrize("substeps,iterations", [(1, [1]), (4, [2, 1, 3, 1]), (8, [1] * 8)])
+def test_random_two_body_graph_with_kinematics(hip_solver_factory, monkeypatch, substeps, iterations):
+    """A dense random graph (every type of two-body constraint, 5 % kinematic bodies, some bodies unconstrained) has no geometric locality at all: nearly every body is
+    shared. Few clusters are forced so that the plan fits; varying iteration schedules move the event numbering."""
+    monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "24")
+    scene = small_scenes.random_graph_scene(31 + substeps, 6000, 14000, TWO_BODY_TYPES)
+    sd = SolveDescription(1, substeps, velocity_iteration_scheduler=lambda s: iterations[s])
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+    assert solver.cluster_cycles().size > 1
+    _exact(pu.compare_scenes(ref, got))
+
+
+def test_small_islands_ride_along_with_a_large_one(hip_solver_factory, monkeypatch):
+    """Whole small islands are packed into the same clusters as the pieces of the big one; kinematic bodies are shared by several islands."""
+    monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "16")
+    big, sd = _host_scene("pile", 6000, 0, 0, 3)
+    small = small_scenes.island_scene(9, 40, 12, 30, [22, 4, 8])
+    scene = small_scenes.concat_scenes(big, small)
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+    assert solver.cluster_cycles().size > 1
+    _exact(pu.compare_scenes(ref, got))
+
+
+def test_split_plan_declines_what_it_does_not_cover(hip_solver_factory, monkeypatch):
+    """Three- and four-body constraints keep to whole islands, and BEPUHIP_NO_SPLIT turns the plan off: both land on the launch-per-batch schedule, still bit-exact."""
+    scene = small_scenes.random_graph_scene(5, 6000, 14000, sorted(small_scenes.TYPE_TABLE.keys()))
+    sd, cb = SolveDescription(2, 2), PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb)
+    assert solver.cluster_cycles().size == 0
+    _exact(pu.compare_scenes(ref, got))
+    monkeypatch.setenv("BEPUHIP_NO_SPLIT", "1")
+    scene, sd = _host_scene("pile", 8000, 0, 0, 5)
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb)
+    assert solver.cluster_cycles().size == 0
+    _exact(pu.compare_scenes(ref, got))
