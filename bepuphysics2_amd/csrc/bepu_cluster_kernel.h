@@ -180,52 +180,72 @@ __device__ __forceinline__ void store_agent_f4(float4* p, float4 v) {
 }
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned load_seq(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void store_seq(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// Per-lane wait until seq[body] reaches `want` (lanes with need == false pass at once). Bounded like every other wait of this kernel.
-__device__ __forceinline__ void wait_shared_seq(const ClusterShared& sh, bool need, int body, unsigned want, int kind, int k) {
-    const unsigned* word = sh.st.seq + (need ? body : 0);
+__device__ __forceinline__ void store_agent_pair(float4* p, float4 a, float4 b) {
+    agent_f4 x = {a.x, a.y, a.z, a.w}, y = {b.x, b.y, b.z, b.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(p), "v"(x), "v"(y) : "memory");
+}
+// A shared body's record: {linear xyz, event number} {angular xyz, event number}. The event number (the count of events of this step that have happened on
+// the body, see SharedTables) travels IN the record: the reader's poll returns the velocity together with the news that it is the one it waits for — one
+// memory round trip per hand-off instead of three (poll a counter, fetch the velocity; store, drain, bump the counter). Every event rewrites both halves
+// with the same number, so a read that mixes two events shows unequal numbers and is polled again.
+struct SharedRef {  // one body slot of one lane's constraint: the body (-1: not a shared body) and the event number its record must carry before this application
+    int body; unsigned number;
+    __device__ __forceinline__ bool shared() const { return body >= 0; }
+};
+template <bool END_OF_SUBSTEP>  // END_OF_SUBSTEP: the number every application of the passes so far has happened (what the incremental contact update waits for)
+__device__ __forceinline__ SharedRef make_shared_ref(const ClusterShared& sh, unsigned half, unsigned srank, bool active) {
+    SharedRef r;
+    const bool shared = active && (half & kLrefShared) != 0 && (half & 0x8000u) == 0;
+    r.body = shared ? (sh.slot_body[half & 0x3FFFu] & kSlotBodyMask) : -1;
+    r.number = sh.events + ((srank >> 8) & 0xFFu) * sh.passes + (END_OF_SUBSTEP ? 0u : (srank & 0xFFu));  // rank | degree << 8
+    return r;
+}
+// Per-lane: poll the records of up to two shared bodies until each shows event number >= want (both halves equal), leaving their velocities in A / B.
+// Lanes without a shared body pass at once. Bounded like every other wait of this kernel.
+template <bool TWO>
+__device__ __forceinline__ void acquire_shared(const ClusterShared& sh, const SharedRef& ra, DBody& A, const SharedRef& rb, DBody& B, int kind, int k) {
+    bool need_a = ra.shared(), need_b = TWO && rb.shared();
+    if (__builtin_amdgcn_ballot_w64(need_a || need_b) == 0) return;
+    const unsigned want_a = ra.number, want_b = rb.number;
+    const float4* pa = sh.st.vel + (size_t)(need_a ? ra.body : 0) * 2;
+    const float4* pb = sh.st.vel + (size_t)(need_b ? rb.body : 0) * 2;
     unsigned spins = 0;
     for (;;) {
-        const unsigned seen = need ? load_seq(word) : want;
-        const unsigned long long late = __builtin_amdgcn_ballot_w64(seen < want);
+        float4 l, w;
+        if (need_a) {
+            load_agent_pair(pa, l, w);
+            if (__float_as_uint(l.w) == __float_as_uint(w.w) && __float_as_uint(l.w) >= want_a) { A.vel.lin = {l.x, l.y, l.z}; A.vel.ang = {w.x, w.y, w.z}; need_a = false; }
+        }
+        if (TWO && need_b) {
+            load_agent_pair(pb, l, w);
+            if (__float_as_uint(l.w) == __float_as_uint(w.w) && __float_as_uint(l.w) >= want_b) { B.vel.lin = {l.x, l.y, l.z}; B.vel.ang = {w.x, w.y, w.z}; need_b = false; }
+        }
+        const unsigned long long late = __builtin_amdgcn_ballot_w64(need_a || need_b);
         if (late == 0) break;
-        __builtin_amdgcn_s_sleep(2);
+        for (int nap = 0; nap < sh.st.poll_sleep; ++nap) __builtin_amdgcn_s_sleep(1);
         if (++spins > kSpinLimit) {
             const int first = (int)__builtin_ctzll(late);
-            report_stall(sh.status, *sh.counter, kind, k, __builtin_amdgcn_readlane(body, first), __builtin_amdgcn_readlane((int)want, first), __builtin_amdgcn_readlane((int)seen, first));
+            report_stall(sh.status, *sh.counter, kind, k, __builtin_amdgcn_readlane(need_a ? ra.body : rb.body, first), __builtin_amdgcn_readlane((int)(need_a ? want_a : want_b), first), 0u);
             break;
         }
         if ((spins & 1023u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
     }
 }
-struct SharedRef {  // one body slot of one lane's constraint
-    bool shared; int body; unsigned rank, degree;
-    __device__ __forceinline__ unsigned expected(const ClusterShared& sh) const { return sh.events + degree * sh.passes + rank; }
-};
-__device__ __forceinline__ SharedRef make_shared_ref(const ClusterShared& sh, unsigned half, unsigned srank, bool active) {
-    SharedRef r;
-    r.shared = active && (half & kLrefShared) != 0 && (half & 0x8000u) == 0;
-    r.body = r.shared ? (sh.slot_body[half & 0x3FFFu] & kSlotBodyMask) : 0;
-    r.rank = srank & 0xFFu; r.degree = (srank >> 8) & 0xFFu;
-    return r;
+__device__ __forceinline__ void release_shared(const ClusterShared& sh, const SharedRef& r, const DBody& b) {
+    if (!r.shared()) return;
+    const float n = __uint_as_float(r.number + 1u);
+    store_agent_pair(sh.st.vel + (size_t)r.body * 2, make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, n), make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, n));
 }
-template <int ACCESS>
-__device__ __forceinline__ void load_velocity_shared(const ClusterShared& sh, const SharedRef& r, DBody& b) {
-    if (!r.shared) return;
-    const float4* v = sh.st.vel + (size_t)r.body * 2;
-    float4 l, a;
-    if ((ACCESS & kLin) && (ACCESS & kAng)) load_agent_pair(v, l, a);
-    else if (ACCESS & kLin) l = load_agent_f4(v);
-    else if (ACCESS & kAng) a = load_agent_f4(v + 1);
-    if (ACCESS & kLin) { b.vel.lin = {l.x, l.y, l.z}; b.linw = l.w; }
-    if (ACCESS & kAng) { b.vel.ang = {a.x, a.y, a.z}; b.angw = a.w; }
-}
-template <int ACCESS>
-__device__ __forceinline__ void store_velocity_shared(const ClusterShared& sh, const SharedRef& r, const DBody& b) {
-    if (!r.shared) return;
-    float4* v = sh.st.vel + (size_t)r.body * 2;
-    if (ACCESS & kLin) store_agent_f4(v, make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, b.linw));
-    if (ACCESS & kAng) store_agent_f4(v + 1, make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, b.angw));
+// One lane, one record (integration phases): wait for event number >= want, return the velocity.
+__device__ __forceinline__ void acquire_shared_one(const SharedTables& st, unsigned* status, int body, unsigned want, float4& l, float4& w, int kind, int slot) {
+    unsigned spins = 0;
+    for (;;) {
+        load_agent_pair(st.vel + (size_t)body * 2, l, w);
+        if (__float_as_uint(l.w) == __float_as_uint(w.w) && __float_as_uint(l.w) >= want) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSpinLimit) { if (atomicCAS(status, 0u, 1u) == 0u) { status[1] = blockIdx.x; status[2] = (unsigned)kind; status[3] = (unsigned)slot; status[4] = (unsigned)body; status[5] = want; status[6] = __float_as_uint(l.w); status[7] = 0; } break; }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+    }
 }
 
 // Block until every predecessor of the item has published: same-pass predecessors must have finished `epoch`; with CROSS (a Solve item: the warm start
@@ -278,18 +298,12 @@ struct ClusterGate {
     __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {
         if (TRACE) stamps.pre_gate = __builtin_readcyclecounter();
         wait_predecessors<CROSS>(sh, it, h, k, epoch);
-        if constexpr (SHARED) {  // bodies other clusters also touch: our turn comes when the body's event counter reaches this application's number
-            wait_shared_seq(sh, sa.shared, sa.body, sa.expected(sh), 6, k);
-            if (BODIES == 2) wait_shared_seq(sh, sb.shared, sb.body, sb.expected(sh), 7, k);
-        }
         __builtin_amdgcn_s_setprio(3);  // from here to the publish the item is on its bodies' critical path: issue ahead of waves still preparing theirs
-        if (TRACE) stamps.post_gate = __builtin_readcyclecounter();
         load_velocity_lds<ACC_A>(sh, ra, A);
         if (BODIES == 2) load_velocity_lds<ACC_B>(sh, rb, B);
-        if constexpr (SHARED) {
-            load_velocity_shared<ACC_A>(sh, sa, A);
-            if (BODIES == 2) load_velocity_shared<ACC_B>(sh, sb, B);
-        }
+        // bodies other clusters also touch: our turn comes when the body's record carries this application's event number (the velocity comes with it)
+        if constexpr (SHARED) acquire_shared<BODIES == 2>(sh, sa, A, sb, B, 6, k);
+        if (TRACE) stamps.post_gate = __builtin_readcyclecounter();
     }
 };
 
@@ -354,11 +368,11 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     const unsigned both = (unsigned)lrefs[i];  // two 16-bit local references per word
     const int ra = unpack_local_ref(both & 0xFFFFu);
     const int rb = (F::bodies == 2) ? unpack_local_ref(both >> 16) : -1;
-    SharedRef sa = {false, 0, 0u, 0u}, sb = {false, 0, 0u, 0u};
+    SharedRef sa = {-1, 0u}, sb = {-1, 0u};
     if constexpr (SHARED) {  // rank | degree << 8 of this application on each shared body: rows right behind the local references
         const gint* srank = lrefs + (size_t)((F::bodies + 1) / 2) * stride;
-        sa = make_shared_ref(sh, both & 0xFFFFu, (unsigned)srank[i], active);
-        if (F::bodies == 2) sb = make_shared_ref(sh, both >> 16, (unsigned)srank[(size_t)stride + i], active);
+        sa = make_shared_ref<STAGE == kStageIncremental>(sh, both & 0xFFFFu, (unsigned)srank[i], active);
+        if (F::bodies == 2) sb = make_shared_ref<STAGE == kStageIncremental>(sh, both >> 16, (unsigned)srank[(size_t)stride + i], active);
     }
     _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
     if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
@@ -369,14 +383,9 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
         if constexpr (SHARED) {
             // a shared body's end-of-substep velocity is in the shared table once every application of the previous substep has happened (rank 0 of the
             // pass that would come next); the home cluster integrates it only after all its readers have checked in on `rd`
-            SharedRef ea = sa, eb = sb;
-            ea.rank = 0; eb.rank = 0;
-            wait_shared_seq(sh, ea.shared, ea.body, ea.expected(sh), 8, k);
-            if (F::bodies == 2) wait_shared_seq(sh, eb.shared, eb.body, eb.expected(sh), 8, k);
-            load_velocity_shared<kAccessOnlyVelocity>(sh, ea, A);
-            if (F::bodies == 2) load_velocity_shared<kAccessOnlyVelocity>(sh, eb, B);
-            if (ea.shared) __hip_atomic_fetch_add(sh.st.rd + ea.body, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (F::bodies == 2 && eb.shared) __hip_atomic_fetch_add(sh.st.rd + eb.body, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acquire_shared<F::bodies == 2>(sh, sa, A, sb, B, 8, k);
+            if (sa.shared()) __hip_atomic_fetch_add(sh.st.rd + sa.body, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (F::bodies == 2 && sb.shared()) __hip_atomic_fetch_add(sh.st.rd + sb.body, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         F::incrementalUpdate(dt, A.vel, B.vel, p);
         if constexpr (F::incremental) {
@@ -395,16 +404,11 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     ClusterGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE, SHARED> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps, sa, sb};
     if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, gate);
     else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, gate);
-    store_velocity_lds<accA>(sh, (active && !sa.shared) ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references)
-    if (F::bodies == 2) store_velocity_lds<accB>(sh, (active && !sb.shared) ? rb : -1, B);
+    store_velocity_lds<accA>(sh, (active && !sa.shared()) ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references)
+    if (F::bodies == 2) store_velocity_lds<accB>(sh, (active && !sb.shared()) ? rb : -1, B);
     if constexpr (SHARED) {
-        if (__builtin_amdgcn_ballot_w64(sa.shared || sb.shared) != 0) {  // wave-uniform: items without shared bodies skip the memory round trip
-            store_velocity_shared<accA>(sh, sa, A);
-            if (F::bodies == 2) store_velocity_shared<accB>(sh, sb, B);
-            wait_vm();  // the velocities are in memory before the event counters say so
-            if (sa.shared) store_seq(sh.st.seq + sa.body, sa.expected(sh) + 1);
-            if (F::bodies == 2 && sb.shared) store_seq(sh.st.seq + sb.body, sb.expected(sh) + 1);
-        }
+        release_shared(sh, sa, A);  // velocity and "event done" in one record: the next application on the body polls exactly this
+        if (F::bodies == 2) release_shared(sh, sb, B);
     }
     publish_item(sh.flags + k, sh.batch_done + h.batch, epoch);
     __builtin_amdgcn_s_setprio(0);
@@ -589,13 +593,15 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 // every application of the previous substep has happened (event counter) and every incremental contact update has read the velocity
                 const unsigned info = shared_tables.info[body];
                 const unsigned want_seq = (unsigned)s + (info & 0xFFu) * sh.passes, want_rd = (unsigned)s * ((info >> 8) & 0xFFFFu);
+                const float lw = l4.w, aw = a4.w;
+                acquire_shared_one(shared_tables, status, body, want_seq, l4, a4, 9, j);
+                l4.w = lw; a4.w = aw;  // the record's fourth lanes carry the event number; the body's own padding stays what it was
                 unsigned spins = 0;
-                while (load_seq(shared_tables.seq + body) < want_seq || load_seq(shared_tables.rd + body) < want_rd) {
+                while (load_seq(shared_tables.rd + body) < want_rd) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > kSpinLimit) { report_stall(status, *sh.counter, 9, j, body, want_seq, load_seq(shared_tables.seq + body)); break; }
+                    if (++spins > kSpinLimit) { report_stall(status, *sh.counter, 12, j, body, want_rd, load_seq(shared_tables.rd + body)); break; }
                     if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 }
-                load_agent_pair(shared_tables.vel + (size_t)body * 2, l4, a4);
             }
             Q ori = {q4.x, q4.y, q4.z, q4.w};
             V3 pos = {p4.x, p4.y, p4.z};
@@ -615,13 +621,12 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
                 r[6 * ncap] = make_float4(world.xx, world.yx, world.yy, world.zx);
                 r[7 * ncap] = make_float4(world.zy, world.zz, i1.z, r[7 * ncap].w);
-                if (home) {  // publish: velocity into the shared table, pose and world inertia into the body record the ghosts copy from, then the event
+                if (home) {  // publish: pose and world inertia into the body record the ghosts copy from, then the velocity record with the event number
                     float4* gb = bodies + (size_t)body * 8;
-                    store_agent_f4(shared_tables.vel + (size_t)body * 2, r[2 * ncap]);
-                    store_agent_f4(shared_tables.vel + (size_t)body * 2 + 1, r[3 * ncap]);
                     store_agent_f4(gb, r[0]); store_agent_f4(gb + 1, r[ncap]); store_agent_f4(gb + 6, r[6 * ncap]); store_agent_f4(gb + 7, r[7 * ncap]);
                     wait_vm();
-                    store_seq(shared_tables.seq + body, (unsigned)s + 1u + (shared_tables.info[body] & 0xFFu) * sh.passes);
+                    const float number = __uint_as_float((unsigned)s + 1u + (shared_tables.info[body] & 0xFFu) * sh.passes);
+                    store_agent_pair(shared_tables.vel + (size_t)body * 2, make_float4(vel.lin.x, vel.lin.y, vel.lin.z, number), make_float4(vel.ang.x, vel.ang.y, vel.ang.z, number));
                 }
             } else if (cp.integrate_velocity_for_kinematics) {  // kinematic: private copy, same arithmetic as the global kinematic pass
                 velocity_callback(cp.sp, vel);
@@ -635,12 +640,8 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 if (g < 0 || !(g & kSlotGhost)) continue;
                 const int body = g & kSlotBodyMask;
                 const unsigned want = (unsigned)s + 1u + (shared_tables.info[body] & 0xFFu) * sh.passes;
-                unsigned spins = 0;
-                while (load_seq(shared_tables.seq + body) < want) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > kSpinLimit) { report_stall(status, *sh.counter, 10, j, body, want, load_seq(shared_tables.seq + body)); break; }
-                    if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                }
+                float4 unused_l, unused_w;
+                acquire_shared_one(shared_tables, status, body, want, unused_l, unused_w, 10, j);
                 const float4* gb = bodies + (size_t)body * 8;
                 float4 q, pz, w0, w1;
                 load_agent_pose_inertia(gb, q, pz, w0, w1);
@@ -675,13 +676,9 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         float4 q4 = r[0], p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
         if (home) {  // the last applications on a shared body may belong to other clusters: wait for the step's full event count, then take its velocity
             const unsigned want = (unsigned)cp.substeps + (shared_tables.info[g] & 0xFFu) * sh.passes;
-            unsigned spins = 0;
-            while (load_seq(shared_tables.seq + g) < want) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > kSpinLimit) { report_stall(status, *sh.counter, 11, j, g, want, load_seq(shared_tables.seq + g)); break; }
-                if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            }
-            load_agent_pair(shared_tables.vel + (size_t)g * 2, l4, a4);
+            const float lw = l4.w, aw = a4.w;
+            acquire_shared_one(shared_tables, status, g, want, l4, a4, 11, j);
+            l4.w = lw; a4.w = aw;
         }
         Q ori = {q4.x, q4.y, q4.z, q4.w};
         V3 pos = {p4.x, p4.y, p4.z};

@@ -272,7 +272,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
 // ---- split-island plans ----
 // An island that no workgroup's LDS can hold is cut into clusters of neighbouring bodies (breadth-first regions of the constraint graph). A constraint runs
 // in the cluster of its first dynamic body; a dynamic body that a constraint of ANOTHER cluster references is shared: its velocity lives in a global table
-// during the sweeps and every application on it waits for the body's event counter (kernel side: SharedRef, wait_shared_seq). Everything else — private
+// during the sweeps and every application on it waits for its event number in the body's record (kernel side: SharedRef, acquire_shared). Everything else — private
 // bodies in LDS, work items, predecessor flags — is the island schedule's. Islands that fit are still packed whole. All clusters must be resident at once
 // (they wait for each other), so the plan is refused (global path) when it needs more clusters than the device has CUs.
 static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe) {
@@ -445,7 +445,9 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         HostTypeBatch& tb = c->tbs[t];
         const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
         const std::vector<int32_t>& clc = cl_of_constraint[t];
-        // inside a cluster: constraints that touch only private bodies first (their items never leave LDS), the ones with shared bodies behind them
+        // inside a cluster: constraints that touch only private bodies first, the ones with shared bodies behind them. They share work items: a wave spends the
+        // same time on an item whatever its lane count, and the waves' time is what a split cluster runs out of (BEPUHIP_SPLIT_SEPARATE=1 itemises them apart).
+        const bool separate = env_int("BEPUHIP_SPLIT_SEPARATE", 0) != 0;
         std::vector<uint8_t> touches_shared(tb.count, 0);
         for (int i = 0; i < tb.count; ++i)
             for (int k = 0; k < nb; ++k) {
@@ -475,7 +477,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             const int cl = clc[tb.perm[d]];
             const int sh0 = touches_shared[tb.perm[d]];
             int e = d;
-            while (e < tb.count && clc[tb.perm[e]] == cl && touches_shared[tb.perm[e]] == sh0) ++e;
+            while (e < tb.count && clc[tb.perm[e]] == cl && (!separate || touches_shared[tb.perm[e]] == sh0)) ++e;
             for (int s0 = d; s0 < e; s0 += 64) {
                 ClusterItem it;
                 memset(&it, 0, sizeof(it));

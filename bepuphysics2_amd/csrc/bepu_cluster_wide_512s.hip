@@ -1,0 +1,5 @@
+// cluster_kernel<512, *, true, SHARED>: all 44 constraint types, split-island plans (bodies shared between clusters).
+#define BEPU_VARIANT_THREADS 512
+#define BEPU_VARIANT_WIDE 1
+#define BEPU_VARIANT_SHARED 1
+#include "bepu_cluster_variant.inc"

@@ -10,12 +10,20 @@ const void* bepu_cluster_kernel_hot_512(bool trace);
 const void* bepu_cluster_kernel_wide_1024(bool trace);
 const void* bepu_cluster_kernel_wide_768(bool trace);
 const void* bepu_cluster_kernel_wide_512(bool trace);
-const void* bepu_cluster_kernel_hot_1024s(bool trace);   // split-island plans (shared bodies): 1024 threads only, the waits want every wave they can get
+const void* bepu_cluster_kernel_hot_1024s(bool trace);   // split-island plans (shared bodies)
 const void* bepu_cluster_kernel_wide_1024s(bool trace);
+const void* bepu_cluster_kernel_hot_768s(bool trace);
+const void* bepu_cluster_kernel_wide_768s(bool trace);
+const void* bepu_cluster_kernel_hot_512s(bool trace);
+const void* bepu_cluster_kernel_wide_512s(bool trace);
 constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
 static int cluster_variant_threads(int threads) { return threads > 768 ? 1024 : (threads > 512 ? 768 : 512); }  // the smallest budget that still fits `threads`
 static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false) {
-    if (shared) return wide ? bepu_cluster_kernel_wide_1024s(trace) : bepu_cluster_kernel_hot_1024s(trace);
+    if (shared) switch (cluster_variant_threads(threads)) {
+        case 1024: return wide ? bepu_cluster_kernel_wide_1024s(trace) : bepu_cluster_kernel_hot_1024s(trace);
+        case 768: return wide ? bepu_cluster_kernel_wide_768s(trace) : bepu_cluster_kernel_hot_768s(trace);
+        default: return wide ? bepu_cluster_kernel_wide_512s(trace) : bepu_cluster_kernel_hot_512s(trace);
+    }
     switch (cluster_variant_threads(threads)) {
         case 1024: return wide ? bepu_cluster_kernel_wide_1024(trace) : bepu_cluster_kernel_hot_1024(trace);
         case 768: return wide ? bepu_cluster_kernel_wide_768(trace) : bepu_cluster_kernel_hot_768(trace);
@@ -130,8 +138,7 @@ struct bepuhip_ctx {
     // cluster path
     bool clusters_enabled = false;
     bool clusters_shared = false;    // split-island plan: bodies shared between clusters go through the tables below
-    float4* d_shared_vel = nullptr;   // 2 x float4 per body (linear, angular): the velocity of a shared body during the sweeps
-    unsigned* d_shared_seq = nullptr; // per body: event counter, then (second half) the incremental-update reader counter; zeroed before every launch
+    float4* d_shared_vel = nullptr;   // 2 x float4 per body ({linear, event number} {angular, event number}), then one reader counter per body; zeroed before every launch
     unsigned* d_shared_info = nullptr;
     size_t shared_bodies = 0;         // table length (bodies)
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
@@ -193,9 +200,8 @@ static void free_constraints(bepuhip_ctx* c) {
     if (c->d_cycles) hipFree(c->d_cycles);
     c->d_cycles = nullptr;
     if (c->d_shared_vel) hipFree(c->d_shared_vel);
-    if (c->d_shared_seq) hipFree(c->d_shared_seq);
     if (c->d_shared_info) hipFree(c->d_shared_info);
-    c->d_shared_vel = nullptr; c->d_shared_seq = nullptr; c->d_shared_info = nullptr; c->clusters_shared = false; c->shared_bodies = 0;
+    c->d_shared_vel = nullptr; c->d_shared_info = nullptr; c->clusters_shared = false; c->shared_bodies = 0;
     c->d_clusters = nullptr; c->d_items = nullptr; c->d_batch_item_begin = nullptr; c->d_cluster_bodies = nullptr;
     c->d_clustered_dynamic = nullptr; c->d_kinlist = nullptr;
     c->clusters_enabled = false; c->cluster_count = 0; c->clustered_dynamic_count = 0; c->kinlist_count = 0;

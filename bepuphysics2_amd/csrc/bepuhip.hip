@@ -474,13 +474,12 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         c->clusters_shared = plan.shared;
         if (plan.shared) {  // split islands: velocity / event tables of the bodies more than one cluster touches (indexed by body, only the shared ones are used)
             c->shared_bodies = plan.shared_info.size();
-            HIP_TRY(hipMalloc((void**)&c->d_shared_vel, c->shared_bodies * 2 * sizeof(float4)));
-            HIP_TRY(hipMalloc((void**)&c->d_shared_seq, c->shared_bodies * 2 * sizeof(unsigned)));
-            HIP_TRY(hipMemset(c->d_shared_vel, 0, c->shared_bodies * 2 * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&c->d_shared_vel, c->shared_bodies * (2 * sizeof(float4) + sizeof(unsigned))));  // records, then the reader counters
             HIP_TRY(upload_ints(plan.shared_info.data(), plan.shared_info.size() * 4, (void**)&c->d_shared_info));
-            for (int tr = 0; tr < 2; ++tr)
-                for (int wide = 0; wide < 2; ++wide)
-                    HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(1024, tr != 0, wide != 0, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+            for (int threads : kClusterThreadChoices)
+                for (int tr = 0; tr < 2; ++tr)
+                    for (int wide = 0; wide < 2; ++wide)
+                        HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(threads, tr != 0, wide != 0, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
         }
     }
     c->built = true;
@@ -565,7 +564,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             Timed t(c, 5);
             // Waves per cluster: 16 by default (four per SIMD; 12 is as fast when memory latency is low, 8 is slower everywhere); BEPUHIP_CLUSTER_THREADS overrides.
             const int req = env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
-            const int threads = c->clusters_shared ? 1024 : std::max(64, std::min(1024, req / 64 * 64));
+            const int threads = std::max(64, std::min(1024, (c->clusters_shared ? env_int("BEPUHIP_SPLIT_THREADS", kSplitClusterThreads) : req) / 64 * 64));
             // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
             // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).
             TailParams tp;
@@ -576,8 +575,8 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             tp.allow_substeps_for_unconstrained = in->allow_substeps_for_unconstrained; tp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
             const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
             tp.final_sp = make_params(in, vdt, vdt, 1.0f / vdt);
-            SharedTables st = {c->d_shared_vel, c->d_shared_seq, c->d_shared_seq + c->shared_bodies, c->d_shared_info};
-            if (c->clusters_shared) hipMemsetAsync(c->d_shared_seq, 0, c->shared_bodies * 2 * sizeof(unsigned), c->stream);  // event and reader counters start every step at zero
+            SharedTables st = {c->d_shared_vel, reinterpret_cast<unsigned*>(c->d_shared_vel + c->shared_bodies * 2), c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1)};
+            if (c->clusters_shared) hipMemsetAsync(c->d_shared_vel, 0, c->shared_bodies * (2 * sizeof(float4) + sizeof(unsigned)), c->stream);  // event numbers and reader counters start every step at zero
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
                             (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
             const bool tr = c->d_trace != nullptr;

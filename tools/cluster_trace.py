@@ -10,7 +10,10 @@ from bepuphysics2_amd.native import HipSolver
 from bepuphysics2_amd.scene import PoseIntegratorCallbacks
 
 ragdolls = int(os.environ.get("RAGDOLLS", "15000"))
-sim = HostSimulation.scene("ragdoll_tube", ragdolls, 1, 0, 5)
+if os.environ.get("SCENE", "ragdolls") == "pile":  # BASELINE.json configs[1]: one island, the split plan
+    sim = HostSimulation.scene("pile", int(os.environ.get("BOXES", "100000")), 0, 0, 5)
+else:
+    sim = HostSimulation.scene("ragdoll_tube", ragdolls, 1, 0, 5)
 scene, sd = sim.export(), sim.solve_description()
 cb = PoseIntegratorCallbacks()
 s = HipSolver()
