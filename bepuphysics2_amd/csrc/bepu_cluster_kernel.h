@@ -200,6 +200,10 @@ __device__ __forceinline__ SharedRef make_shared_ref(const ClusterShared& sh, un
     r.number = sh.events + ((srank >> 8) & 0xFFu) * sh.passes + (END_OF_SUBSTEP ? 0u : (srank & 0xFFu));  // rank | degree << 8
     return r;
 }
+// Two records per body: substep s works on record s & 1, and what reads the END of substep s - 1 (the incremental contact update, the pose integration of the
+// home cluster and of every cluster holding a ghost copy) reads record (s - 1) & 1, which nobody rewrites before substep s + 1's integration — and that
+// waits for every application of substep s, each of which comes after its own cluster's reads. So readers never have to check in anywhere.
+__device__ __forceinline__ float4* shared_record(const SharedTables& st, int body, unsigned substep) { return st.vel + ((size_t)body * 2 + (substep & 1u)) * 2; }
 // Per-lane: poll the records of up to two shared bodies until each shows event number >= want (both halves equal), leaving their velocities in A / B.
 // Lanes without a shared body pass at once. Bounded like every other wait of this kernel.
 template <bool TWO>
@@ -207,8 +211,8 @@ __device__ __forceinline__ void acquire_shared(const ClusterShared& sh, const Sh
     bool need_a = ra.shared(), need_b = TWO && rb.shared();
     if (__builtin_amdgcn_ballot_w64(need_a || need_b) == 0) return;
     const unsigned want_a = ra.number, want_b = rb.number;
-    const float4* pa = sh.st.vel + (size_t)(need_a ? ra.body : 0) * 2;
-    const float4* pb = sh.st.vel + (size_t)(need_b ? rb.body : 0) * 2;
+    const float4* pa = shared_record(sh.st, need_a ? ra.body : 0, sh.events - 1u);  // during the sweeps of substep s events == s + 1; the incremental update
+    const float4* pb = shared_record(sh.st, need_b ? rb.body : 0, sh.events - 1u);  // of substep s runs while events is still s: the record of substep s - 1
     unsigned spins = 0;
     for (;;) {
         float4 l, w;
@@ -234,13 +238,13 @@ __device__ __forceinline__ void acquire_shared(const ClusterShared& sh, const Sh
 __device__ __forceinline__ void release_shared(const ClusterShared& sh, const SharedRef& r, const DBody& b) {
     if (!r.shared()) return;
     const float n = __uint_as_float(r.number + 1u);
-    store_agent_pair(sh.st.vel + (size_t)r.body * 2, make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, n), make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, n));
+    store_agent_pair(shared_record(sh.st, r.body, sh.events - 1u), make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, n), make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, n));
 }
 // One lane, one record (integration phases): wait for event number >= want, return the velocity.
-__device__ __forceinline__ void acquire_shared_one(const SharedTables& st, unsigned* status, int body, unsigned want, float4& l, float4& w, int kind, int slot) {
+__device__ __forceinline__ void acquire_shared_one(const SharedTables& st, unsigned* status, int body, unsigned substep, unsigned want, float4& l, float4& w, int kind, int slot) {
     unsigned spins = 0;
     for (;;) {
-        load_agent_pair(st.vel + (size_t)body * 2, l, w);
+        load_agent_pair(shared_record(st, body, substep), l, w);
         if (__float_as_uint(l.w) == __float_as_uint(w.w) && __float_as_uint(l.w) >= want) break;
         __builtin_amdgcn_s_sleep(2);
         if (++spins > kSpinLimit) { if (atomicCAS(status, 0u, 1u) == 0u) { status[1] = blockIdx.x; status[2] = (unsigned)kind; status[3] = (unsigned)slot; status[4] = (unsigned)body; status[5] = want; status[6] = __float_as_uint(l.w); status[7] = 0; } break; }
@@ -381,11 +385,9 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
         load_body_lds<kAccessOnlyVelocity>(sh, ra, A);
         if (F::bodies == 2) load_body_lds<kAccessOnlyVelocity>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
         if constexpr (SHARED) {
-            // a shared body's end-of-substep velocity is in the shared table once every application of the previous substep has happened (rank 0 of the
-            // pass that would come next); the home cluster integrates it only after all its readers have checked in on `rd`
+            // a shared body's end-of-substep velocity is in its record once every application of the previous substep has happened (rank 0 of the pass that
+            // would come next)
             acquire_shared<F::bodies == 2>(sh, sa, A, sb, B, 8, k);
-            if (sa.shared()) __hip_atomic_fetch_add(sh.st.rd + sa.body, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (F::bodies == 2 && sb.shared()) __hip_atomic_fetch_add(sh.st.rd + sb.body, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         F::incrementalUpdate(dt, A.vel, B.vel, p);
         if constexpr (F::incremental) {
@@ -584,24 +586,17 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         for (int j = tid; j < cd.slot_count; j += blockDim.x) {
             const int g = slots[j];
             if (g < 0) continue;
-            if (SHARED && (g & kSlotGhost)) continue;  // another cluster integrates it: refreshed below
+            const bool ghost = SHARED && (g & kSlotGhost) != 0;  // another cluster owns the body; this one keeps its pose and world inertia current by the same arithmetic
             float4* r = lds + j;
             float4 q4 = r[0], p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
             const bool home = SHARED && (g & kSlotSharedHome) != 0;
             const int body = g & kSlotBodyMask;
-            if (home && s > 0) {
-                // every application of the previous substep has happened (event counter) and every incremental contact update has read the velocity
-                const unsigned info = shared_tables.info[body];
-                const unsigned want_seq = (unsigned)s + (info & 0xFFu) * sh.passes, want_rd = (unsigned)s * ((info >> 8) & 0xFFFFu);
+            unsigned applications = 0;  // shared bodies: applications per pass
+            if (home || ghost) applications = shared_tables.info[body] & 0xFFu;
+            if ((home || ghost) && s > 0) {  // the velocity the last substep ended with: in last substep's record once every application on the body has happened
                 const float lw = l4.w, aw = a4.w;
-                acquire_shared_one(shared_tables, status, body, want_seq, l4, a4, 9, j);
+                acquire_shared_one(shared_tables, status, body, (unsigned)s - 1u, (unsigned)s + applications * sh.passes, l4, a4, 9, j);
                 l4.w = lw; a4.w = aw;  // the record's fourth lanes carry the event number; the body's own padding stays what it was
-                unsigned spins = 0;
-                while (load_seq(shared_tables.rd + body) < want_rd) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > kSpinLimit) { report_stall(status, *sh.counter, 12, j, body, want_rd, load_seq(shared_tables.rd + body)); break; }
-                    if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                }
             }
             Q ori = {q4.x, q4.y, q4.z, q4.w};
             V3 pos = {p4.x, p4.y, p4.z};
@@ -612,21 +607,20 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 r[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
                 r[ncap] = make_float4(pos.x, pos.y, pos.z, p4.w);
             }
-            if ((unsigned)(g & ~(kSlotSharedHome)) < kDynamicLimit) {
+            if ((unsigned)(g & ~(kSlotSharedHome | kSlotGhost)) < kDynamicLimit) {
                 const float4 i0 = r[4 * ncap], i1 = r[5 * ncap];
                 Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
                 Sym3 world = rotateInverseInertia(local, ori);
-                velocity_callback(cp.sp, vel);
-                r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
-                r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
                 r[6 * ncap] = make_float4(world.xx, world.yx, world.yy, world.zx);
                 r[7 * ncap] = make_float4(world.zy, world.zz, i1.z, r[7 * ncap].w);
-                if (home) {  // publish: pose and world inertia into the body record the ghosts copy from, then the velocity record with the event number
-                    float4* gb = bodies + (size_t)body * 8;
-                    store_agent_f4(gb, r[0]); store_agent_f4(gb + 1, r[ncap]); store_agent_f4(gb + 6, r[6 * ncap]); store_agent_f4(gb + 7, r[7 * ncap]);
-                    wait_vm();
-                    const float number = __uint_as_float((unsigned)s + 1u + (shared_tables.info[body] & 0xFFu) * sh.passes);
-                    store_agent_pair(shared_tables.vel + (size_t)body * 2, make_float4(vel.lin.x, vel.lin.y, vel.lin.z, number), make_float4(vel.ang.x, vel.ang.y, vel.ang.z, number));
+                if (!ghost) {
+                    velocity_callback(cp.sp, vel);
+                    r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+                    r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+                }
+                if (home) {  // this substep's record: the integrated velocity, and "integration done" as the event number
+                    const float number = __uint_as_float((unsigned)s + 1u + applications * sh.passes);
+                    store_agent_pair(shared_record(shared_tables, body, (unsigned)s), make_float4(vel.lin.x, vel.lin.y, vel.lin.z, number), make_float4(vel.ang.x, vel.ang.y, vel.ang.z, number));
                 }
             } else if (cp.integrate_velocity_for_kinematics) {  // kinematic: private copy, same arithmetic as the global kinematic pass
                 velocity_callback(cp.sp, vel);
@@ -634,21 +628,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
             }
         }
-        if constexpr (SHARED) {  // ghosts: pose and world inertia of this substep from their home clusters
-            for (int j = tid; j < cd.slot_count; j += blockDim.x) {
-                const int g = slots[j];
-                if (g < 0 || !(g & kSlotGhost)) continue;
-                const int body = g & kSlotBodyMask;
-                const unsigned want = (unsigned)s + 1u + (shared_tables.info[body] & 0xFFu) * sh.passes;
-                float4 unused_l, unused_w;
-                acquire_shared_one(shared_tables, status, body, want, unused_l, unused_w, 10, j);
-                const float4* gb = bodies + (size_t)body * 8;
-                float4 q, pz, w0, w1;
-                load_agent_pose_inertia(gb, q, pz, w0, w1);
-                lds[j] = q; lds[ncap + j] = pz; lds[6 * ncap + j] = w0; lds[7 * ncap + j] = w1;
-            }
-            sh.events = (unsigned)s + 1u;
-        }
+        if constexpr (SHARED) sh.events = (unsigned)s + 1u;
         __syncthreads();
         ++epoch;
         const int fused = cp.iters[s] > 0 ? cd.item_count : 0;  // the first velocity iteration rides in the warm start's claim sequence
@@ -677,7 +657,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         if (home) {  // the last applications on a shared body may belong to other clusters: wait for the step's full event count, then take its velocity
             const unsigned want = (unsigned)cp.substeps + (shared_tables.info[g] & 0xFFu) * sh.passes;
             const float lw = l4.w, aw = a4.w;
-            acquire_shared_one(shared_tables, status, g, want, l4, a4, 11, j);
+            acquire_shared_one(shared_tables, status, g, (unsigned)cp.substeps - 1u, want, l4, a4, 11, j);
             l4.w = lw; a4.w = aw;
         }
         Q ori = {q4.x, q4.y, q4.z, q4.w};

@@ -12,7 +12,7 @@
 struct ClusterPlan {
     bool enabled = false;
     bool shared = false;                 // split islands: some dynamic bodies are referenced from more than one cluster (SharedTables)
-    std::vector<uint32_t> shared_info;   // per body index: applications per pass (d) | incremental readers (c) << 8, 0 for bodies that are not shared
+    std::vector<uint32_t> shared_info;   // per body index: applications per pass (d), 0 for bodies that are not shared
     std::vector<ClusterDesc> clusters;
     std::vector<ClusterItem> items;
     std::vector<int> batch_item_begin, cluster_bodies, clustered_dynamic, kinlist;
@@ -281,14 +281,14 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    // adjacency of dynamic bodies (CSR), degree d and contact degree c per body
+    // adjacency of dynamic bodies (CSR), degree d per body
     std::vector<uint8_t> is_dyn(universe, 0);
-    std::vector<int32_t> deg(universe, 0), cdeg(universe, 0);
+    std::vector<int32_t> deg(universe, 0);
     for (auto& tb : c->tbs)
         for (int k = 0; k < tb.info.bodies; ++k)
             for (int i = 0; i < tb.count; ++i) {
                 const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                if ((uint32_t)r < kDynamicLimit) { is_dyn[r] = 1; ++deg[r]; if (tb.info.incremental) ++cdeg[r]; }
+                if ((uint32_t)r < kDynamicLimit) { is_dyn[r] = 1; ++deg[r]; }
             }
     std::vector<int64_t> adj_begin(universe + 1, 0);
     for (auto& tb : c->tbs) {
@@ -313,7 +313,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     int64_t total_dyn = 0;
     for (int i = 0; i < universe; ++i) total_dyn += is_dyn[i];
     if (total_dyn == 0) return;
-    for (int i = 0; i < universe; ++i) if (deg[i] > 255 || cdeg[i] > 65535) return;  // rank | degree travel as bytes
+    for (int i = 0; i < universe; ++i) if (deg[i] > 255) return;  // rank | degree travel as bytes
     const int target_clusters = std::max(1, std::min(cus * 31 / 32, env_int("BEPUHIP_SPLIT_CLUSTERS", cus * 31 / 32)));
     int region = (int)((total_dyn + target_clusters - 1) / target_clusters);
     region = std::max(region, 32);
@@ -559,7 +559,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         plan.max_items = std::max(plan.max_items, d.item_count);
     }
     plan.shared_info.assign(universe, 0u);
-    for (int i = 0; i < universe; ++i) if (shared[i]) { plan.shared_info[i] = (uint32_t)deg[i] | ((uint32_t)cdeg[i] << 8); ++shared_count; }
+    for (int i = 0; i < universe; ++i) if (shared[i]) { plan.shared_info[i] = (uint32_t)deg[i]; ++shared_count; }
     plan.shared = true;
     plan.enabled = nclusters > 0 && plan.max_slots < 0x4000 && cluster_lds_bytes(plan.max_slots, plan.max_items, true) <= kLdsBudgetBytes;
     if (env_int("BEPUHIP_PLAN_STATS", 0))

@@ -138,7 +138,7 @@ struct bepuhip_ctx {
     // cluster path
     bool clusters_enabled = false;
     bool clusters_shared = false;    // split-island plan: bodies shared between clusters go through the tables below
-    float4* d_shared_vel = nullptr;   // 2 x float4 per body ({linear, event number} {angular, event number}), then one reader counter per body; zeroed before every launch
+    float4* d_shared_vel = nullptr;   // per body two records (substep parity) of {linear, event number} {angular, event number}; zeroed before every launch
     unsigned* d_shared_info = nullptr;
     size_t shared_bodies = 0;         // table length (bodies)
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant

@@ -47,12 +47,11 @@ constexpr int kSlotGhost = 1 << 29;       // SHARED plan: pose / inertia copy of
 constexpr int kSlotSharedHome = 1 << 28;  // SHARED plan: this cluster integrates the body, but its velocity lives in the global shared table during the sweeps
 constexpr int kSlotBodyMask = (1 << 28) - 1;
 // Split-island ("shared body") plans, DESIGN.md 3.4: an island too large for one workgroup's LDS is cut into clusters. A dynamic body referenced by a
-// constraint that another cluster runs is SHARED: during the sweeps its velocity lives in `vel` (one record of 2 x float4 per body index, agent-scope
-// accesses): {linear, n} {angular, n}, where n counts the events of the step that have happened on the body — one per substep for the home cluster's
-// integration, then one per constraint application in the reference's batch order (rank r of d per pass). An application waits for "its" n, and leaves
-// n + 1 with the velocity it wrote. `rd` counts the incremental contact updates that have read the body's end-of-substep velocity (the home may
-// integrate only after all c of them). `info` = d | c << 8. `vel` and `rd` are zeroed before every launch.
-struct SharedTables { float4* vel; unsigned* rd; const unsigned* info; int poll_sleep; };  // poll_sleep: 64-clock naps between two polls of a record
+// constraint that another cluster runs is SHARED: during the sweeps its velocity lives in `vel`, two records per body index (substep parity, see
+// shared_record), each {linear, n} {angular, n} moved with agent-scope accesses. n counts the events of the step that have happened on the body — one per
+// substep for the home cluster's integration, then one per constraint application in the reference's batch order (rank r of d per pass). An application
+// waits for "its" n and leaves n + 1 with the velocity it wrote. `info[body]` = d. `vel` is zeroed before every launch.
+struct SharedTables { float4* vel; const unsigned* info; int poll_sleep; };  // poll_sleep: 64-clock naps between two polls of a record
 constexpr unsigned kLrefShared = 0x4000u;  // bit 14 of a 16-bit local reference: velocity through the shared table (bit 15 = kinematic copy, bits 0-13 slot)
 constexpr int kPlanes = 8;            // LDS body table: one plane per 16-byte field of BodyDynamics
 constexpr int kClusterThreads = 1024;  // default threads per cluster workgroup

@@ -474,7 +474,7 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         c->clusters_shared = plan.shared;
         if (plan.shared) {  // split islands: velocity / event tables of the bodies more than one cluster touches (indexed by body, only the shared ones are used)
             c->shared_bodies = plan.shared_info.size();
-            HIP_TRY(hipMalloc((void**)&c->d_shared_vel, c->shared_bodies * (2 * sizeof(float4) + sizeof(unsigned))));  // records, then the reader counters
+            HIP_TRY(hipMalloc((void**)&c->d_shared_vel, c->shared_bodies * 4 * sizeof(float4)));  // two records (substep parity) of two float4 per body
             HIP_TRY(upload_ints(plan.shared_info.data(), plan.shared_info.size() * 4, (void**)&c->d_shared_info));
             for (int threads : kClusterThreadChoices)
                 for (int tr = 0; tr < 2; ++tr)
@@ -575,8 +575,8 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             tp.allow_substeps_for_unconstrained = in->allow_substeps_for_unconstrained; tp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
             const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
             tp.final_sp = make_params(in, vdt, vdt, 1.0f / vdt);
-            SharedTables st = {c->d_shared_vel, reinterpret_cast<unsigned*>(c->d_shared_vel + c->shared_bodies * 2), c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1)};
-            if (c->clusters_shared) hipMemsetAsync(c->d_shared_vel, 0, c->shared_bodies * (2 * sizeof(float4) + sizeof(unsigned)), c->stream);  // event numbers and reader counters start every step at zero
+            SharedTables st = {c->d_shared_vel, c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1)};
+            if (c->clusters_shared) hipMemsetAsync(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4), c->stream);  // event numbers start every step at zero
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
                             (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
             const bool tr = c->d_trace != nullptr;
