@@ -23,7 +23,8 @@ namespace {
 // Deadlock freedom: items are claimed in a topological order and a wave holds one item at a time, so the earliest unfinished
 // item always has all its predecessors finished.
 //
-// LDS: [8 planes of float4 x ncap body slots: the BodyDynamics record, one plane per 16-byte field][work items][flags, counters].
+// LDS: [6 planes of float4 x ncap body slots: the fields of the BodyDynamics record the sweeps touch (the local inertia stays in memory), one plane per
+// 16-byte field][work items][flags, counters].
 // Slot numbering is rotated by the host inside every group of 16 (slot = (i & ~15) | ((i + (i >> 4)) & 15)) so that the regular
 // "same joint of consecutive ragdolls" access pattern (lane stride = island size) spreads over all 16 bank slots of ds_read_b128.
 // ------------------------------------------------------------------------------------------------
@@ -58,7 +59,7 @@ __device__ __forceinline__ void load_body_lds(const ClusterShared& sh, int lref,
     if (ACCESS & kLin) { float4 l = base[2 * n]; b.vel.lin = {l.x, l.y, l.z}; b.linw = l.w; } else { b.vel.lin = {0, 0, 0}; b.linw = 0; }
     if (ACCESS & kAng) { float4 a = base[3 * n]; b.vel.ang = {a.x, a.y, a.z}; b.angw = a.w; } else { b.vel.ang = {0, 0, 0}; b.angw = 0; }
     if (ACCESS & kInertia) {
-        float4 i0 = base[6 * n], i1 = base[7 * n];
+        float4 i0 = base[4 * n], i1 = base[5 * n];
         b.inertia.t = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
         b.inertia.invMass = i1.z;
     } else { b.inertia.t = {0, 0, 0, 0, 0, 0}; b.inertia.invMass = 0; }
@@ -552,9 +553,9 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     const int* slots = cluster_bodies + cd.body_begin;  // slot -> body index (bit 30: kinematic, private read-only copy; -1: unused slot)
     // ---- stage the cluster in LDS: bodies (one plane per 16-byte field), work items, batch -> item ranges; clear the sync words ----
     for (int j = tid; j < cd.slot_count * kPlanes; j += blockDim.x) {
-        const int slot = j >> 3, v = j & 7;
+        const int slot = j / kPlanes, v = j - slot * kPlanes;
         const int g = slots[slot];
-        lds[v * ncap + slot] = g >= 0 ? bodies[(size_t)(g & kSlotBodyMask) * 8 + v] : make_float4(0, 0, 0, 0);
+        lds[v * ncap + slot] = g >= 0 ? bodies[(size_t)(g & kSlotBodyMask) * 8 + (v < 4 ? v : v + 2)] : make_float4(0, 0, 0, 0);  // record fields 4, 5 (local inertia) stay in memory
     }
     {
         const int4* src = reinterpret_cast<const int4*>(items + cd.item_begin);
@@ -608,11 +609,11 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 r[ncap] = make_float4(pos.x, pos.y, pos.z, p4.w);
             }
             if ((unsigned)(g & ~(kSlotSharedHome | kSlotGhost)) < kDynamicLimit) {
-                const float4 i0 = r[4 * ncap], i1 = r[5 * ncap];
+                const float4 i0 = bodies[(size_t)body * 8 + 4], i1 = bodies[(size_t)body * 8 + 5];  // local inverse inertia and mass: constant over the step, read where needed
                 Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
                 Sym3 world = rotateInverseInertia(local, ori);
-                r[6 * ncap] = make_float4(world.xx, world.yx, world.yy, world.zx);
-                r[7 * ncap] = make_float4(world.zy, world.zz, i1.z, r[7 * ncap].w);
+                r[4 * ncap] = make_float4(world.xx, world.yx, world.yy, world.zx);
+                r[5 * ncap] = make_float4(world.zy, world.zz, i1.z, r[5 * ncap].w);
                 if (!ghost) {
                     velocity_callback(cp.sp, vel);
                     r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
@@ -670,8 +671,8 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         gb[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
         gb[2] = l4;
         gb[3] = a4;
-        gb[6] = r[6 * ncap];
-        gb[7] = r[7 * ncap];
+        gb[6] = r[4 * ncap];
+        gb[7] = r[5 * ncap];
     }
     if (tid == 0) cycles[blockIdx.x] = __builtin_readcyclecounter() - kernel_t0;  // shader clocks this cluster took: a clock-frequency-independent measure
 }

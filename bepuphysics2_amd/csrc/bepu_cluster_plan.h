@@ -79,7 +79,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         int64_t target = (total_dyn + (cus * 31 / 32) - 1) / std::max(1, cus * 31 / 32);
-        cap = (int)std::min<int64_t>(std::max<int64_t>(target, 64), 1200);
+        cap = (int)std::min<int64_t>(std::max<int64_t>(target, 64), 1600);
     }
     if (largest > cap) cap = largest;
     // ---- phase A: find a cap whose clusters fit the LDS budget (no mutation yet) ----
@@ -423,7 +423,12 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             max_slots = std::max(max_slots, ((int)cl_bodies[cl].size() + 15) / 16 * 16);
             max_items = std::max(max_items, item_count[cl]);
         }
-        if (max_slots >= 0x4000 || max_items >= 65536 || cluster_lds_bytes(max_slots, max_items, true) > kLdsBudgetBytes) return;
+        if (max_slots >= 0x4000 || max_items >= 65536 || cluster_lds_bytes(max_slots, max_items, true) > kLdsBudgetBytes) {
+            if (env_int("BEPUHIP_PLAN_STATS", 0))
+                fprintf(stderr, "bepuhip split plan: declined, %d clusters (region %d) would need %d slots and %d items = %zu B of LDS per workgroup (budget %zu)\n", nclusters, region,
+                        max_slots, max_items, cluster_lds_bytes(max_slots, max_items, true), kLdsBudgetBytes);
+            return;
+        }
     }
     auto slot_of = [&](int cl, int32_t r) {  // 32-bit local reference of body reference r as seen from cluster cl: slot | shared << 14 | kinematic << 30
         if ((uint32_t)r >= kDynamicLimit) return rotated_slot(extra_local(cl, (r & kRefMask) | kSlotKinematic)) | (int)kDynamicLimit;

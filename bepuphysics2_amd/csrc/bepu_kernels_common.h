@@ -53,7 +53,7 @@ constexpr int kSlotBodyMask = (1 << 28) - 1;
 // waits for "its" n and leaves n + 1 with the velocity it wrote. `info[body]` = d. `vel` is zeroed before every launch.
 struct SharedTables { float4* vel; const unsigned* info; int poll_sleep; };  // poll_sleep: 64-clock naps between two polls of a record
 constexpr unsigned kLrefShared = 0x4000u;  // bit 14 of a 16-bit local reference: velocity through the shared table (bit 15 = kinematic copy, bits 0-13 slot)
-constexpr int kPlanes = 8;            // LDS body table: one plane per 16-byte field of BodyDynamics
+constexpr int kPlanes = 6;            // LDS body table: one plane per 16-byte field of BodyDynamics the sweeps touch (orientation, position, linear, angular, world inertia x 2)
 constexpr int kClusterThreads = 1024;  // default threads per cluster workgroup
 constexpr int kSplitClusterThreads = 512;  // split-island plans: the shared-body code needs the 256-VGPR budget to stay out of scratch (spills sit on every hand-off's critical path)
 constexpr int kMaxClusterSubsteps = 16;
