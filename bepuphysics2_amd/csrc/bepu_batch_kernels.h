@@ -338,25 +338,50 @@ __global__ void boundary_snapshot_kernel(const float4* __restrict__ bodies, cons
     snapshot[2 * i] = base[2];
     snapshot[2 * i + 1] = base[3];
 }
-__global__ void boundary_deltas_kernel(const float4* __restrict__ bodies, const int* __restrict__ indices, int count, const float4* __restrict__ snapshot, float* __restrict__ out) {
+// `exact` (BEPUHIP_EXCHANGE_PER_BATCH_EXACT): the exchange runs after every batch, where at most ONE rank has touched a given body (a batch references a body
+// once, and the shares keep the global batch indices), so instead of float differences the ranks exchange the XOR of the velocity's bit pattern with the
+// snapshot's: all but one contribution are zero, an integer sum returns the toucher's pattern exactly, and every copy becomes bit-identical to what the
+// unsplit solve holds at that point. `rows` (optional) scatters / gathers through the dense exchange buffer (row of body i = rows[i]; 6 words per row).
+__global__ void boundary_deltas_kernel(const float4* __restrict__ bodies, const int* __restrict__ indices, int count, const float4* __restrict__ snapshot, float* __restrict__ out,
+                                       const int* __restrict__ rows, int exact) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const float4* base = bodies + (size_t)indices[i] * 8;
     const float4 l = base[2], a = base[3], l0 = snapshot[2 * i], a0 = snapshot[2 * i + 1];
-    float* o = out + (size_t)i * 6;
+    float* o = out + (size_t)(rows ? rows[i] : i) * 6;
+    if (exact) {
+        unsigned* x = reinterpret_cast<unsigned*>(o);
+        x[0] = __float_as_uint(l.x) ^ __float_as_uint(l0.x); x[1] = __float_as_uint(l.y) ^ __float_as_uint(l0.y); x[2] = __float_as_uint(l.z) ^ __float_as_uint(l0.z);
+        x[3] = __float_as_uint(a.x) ^ __float_as_uint(a0.x); x[4] = __float_as_uint(a.y) ^ __float_as_uint(a0.y); x[5] = __float_as_uint(a.z) ^ __float_as_uint(a0.z);
+        return;
+    }
     o[0] = l.x - l0.x; o[1] = l.y - l0.y; o[2] = l.z - l0.z;
     o[3] = a.x - a0.x; o[4] = a.y - a0.y; o[5] = a.z - a0.z;
 }
-__global__ void boundary_apply_kernel(float4* bodies, const int* __restrict__ indices, int count, float4* snapshot, const float* __restrict__ sums) {
+// `holders` (optional, indexed like the sums): the number of ranks holding the body; the summed deltas of mass-split copies are averaged (lattice.py).
+__global__ void boundary_apply_kernel(float4* bodies, const int* __restrict__ indices, int count, float4* snapshot, const float* __restrict__ sums, const int* __restrict__ rows,
+                                      const float* __restrict__ holders, int exact) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float4* base = bodies + (size_t)indices[i] * 8;
-    const float* d = sums + (size_t)i * 6;
+    const int row = rows ? rows[i] : i;
+    const float* d = sums + (size_t)row * 6;
     float4 l0 = snapshot[2 * i], a0 = snapshot[2 * i + 1];
-    const float4 l = make_float4(l0.x + d[0], l0.y + d[1], l0.z + d[2], l0.w);
-    const float4 a = make_float4(a0.x + d[3], a0.y + d[4], a0.z + d[5], a0.w);
+    float4 l, a;
+    if (exact) {
+        const unsigned* x = reinterpret_cast<const unsigned*>(d);
+        l = make_float4(__uint_as_float(__float_as_uint(l0.x) ^ x[0]), __uint_as_float(__float_as_uint(l0.y) ^ x[1]), __uint_as_float(__float_as_uint(l0.z) ^ x[2]), l0.w);
+        a = make_float4(__uint_as_float(__float_as_uint(a0.x) ^ x[3]), __uint_as_float(__float_as_uint(a0.y) ^ x[4]), __uint_as_float(__float_as_uint(a0.z) ^ x[5]), a0.w);
+    } else if (holders) {
+        const float k = holders[row];
+        l = make_float4(l0.x + d[0] / k, l0.y + d[1] / k, l0.z + d[2] / k, l0.w);
+        a = make_float4(a0.x + d[3] / k, a0.y + d[4] / k, a0.z + d[5] / k, a0.w);
+    } else {
+        l = make_float4(l0.x + d[0], l0.y + d[1], l0.z + d[2], l0.w);
+        a = make_float4(a0.x + d[3], a0.y + d[4], a0.z + d[5], a0.w);
+    }
     base[2] = l; base[3] = a;
-    snapshot[2 * i] = l; snapshot[2 * i + 1] = a;  // the next pass's deltas are relative to the synchronised value
+    snapshot[2 * i] = l; snapshot[2 * i + 1] = a;  // the next exchange's deltas are relative to the synchronised value
 }
 
 // Ranged in-place update of one type batch's prestep / accumulated-impulse rows from the caller's AOSOA bundles (bepuhip_update_prestep /

@@ -150,6 +150,14 @@ struct bepuhip_ctx {
     float4* d_boundary_snapshot = nullptr;
     float* d_boundary_buf = nullptr;     // count * 6 floats staging for host-pointer exchanges
     int boundary_count = 0;
+    int exchange_mode = 0;               // BEPUHIP_EXCHANGE_*
+    int* d_boundary_rows = nullptr;      // on-stream exchange: row of every boundary body in the dense buffer (same row on every rank)
+    float* d_boundary_dense = nullptr;   // dense_rows x 6 words, all-reduced in place
+    float* d_boundary_holders = nullptr; // per dense row: ranks holding the body (mass-split shares), null = sums applied as they are
+    int dense_rows = 0;
+    void* comm = nullptr;                // ncclComm_t of the on-stream exchange (null: single rank, the exchange only re-bases)
+    bool comm_owned = false;
+    int comm_world = 1;
     unsigned long long* d_cycles = nullptr;  // per cluster: shader clocks of the last cluster_kernel launch
     unsigned* d_status = nullptr;  // cluster schedule watchdog words (see report_stall)
     unsigned long long* d_trace = nullptr;  // optional per-item timeline of cluster 0 (diagnostics)

@@ -23,10 +23,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <type_traits>
 #include <vector>
+
+#include <rccl/rccl.h>  // types and enums only: the library is opened at run time (bepuhip_comm_*), the solver itself does not depend on it
 
 #include "../../include/bepuhip.h"
 #include "bepu_device_constraints.h"
@@ -93,6 +96,14 @@ int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx) {
     return BEPUHIP_OK;
 }
 
+static void free_boundary_layout(bepuhip_ctx* c) {
+    if (c->d_boundary_rows) hipFree(c->d_boundary_rows);
+    if (c->d_boundary_dense) hipFree(c->d_boundary_dense);
+    if (c->d_boundary_holders) hipFree(c->d_boundary_holders);
+    c->d_boundary_rows = nullptr; c->d_boundary_dense = nullptr; c->d_boundary_holders = nullptr; c->dense_rows = 0;
+}
+static void release_comm(bepuhip_ctx* c);
+
 int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (!c) return BEPUHIP_OK;
     hipSetDevice(c->device);
@@ -109,6 +120,8 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_boundary) hipFree(c->d_boundary);
     if (c->d_boundary_snapshot) hipFree(c->d_boundary_snapshot);
     if (c->d_boundary_buf) hipFree(c->d_boundary_buf);
+    free_boundary_layout(c);
+    release_comm(c);
     if (c->ev_start) hipEventDestroy(c->ev_start);
     if (c->ev_stop) hipEventDestroy(c->ev_stop);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -698,6 +711,7 @@ int32_t bepuhip_set_boundary_bodies(bepuhip_ctx* c, const int32_t* indices, int3
     for (int i = 0; i < count; ++i)
         if (indices[i] < 0 || indices[i] >= c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "boundary body index out of range (call set_bodies first)");
     if (c->d_boundary) { hipFree(c->d_boundary); hipFree(c->d_boundary_snapshot); hipFree(c->d_boundary_buf); c->d_boundary = nullptr; c->d_boundary_snapshot = nullptr; c->d_boundary_buf = nullptr; }
+    free_boundary_layout(c);  // rows belong to a boundary list
     c->boundary_count = count;
     if (count > 0) {
         HIP_TRY(hipMalloc((void**)&c->d_boundary, (size_t)count * 4));
@@ -714,7 +728,7 @@ int32_t bepuhip_boundary_deltas(bepuhip_ctx* c, float* out, int32_t out_is_devic
     HIP_TRY(hipSetDevice(c->device));
     float* dst = out_is_device ? out : c->d_boundary_buf;
     hipLaunchKernelGGL(boundary_deltas_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, (const int*)c->d_boundary, c->boundary_count,
-                       (const float4*)c->d_boundary_snapshot, dst);
+                       (const float4*)c->d_boundary_snapshot, dst, (const int*)nullptr, c->exchange_mode == BEPUHIP_EXCHANGE_PER_BATCH_EXACT ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (!out_is_device) HIP_TRY(hipMemcpyAsync(out, dst, (size_t)c->boundary_count * 24, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // the caller hands the buffer to a collective on another stream / the host next
@@ -731,18 +745,139 @@ int32_t bepuhip_boundary_apply(bepuhip_ctx* c, const float* sums, int32_t in_is_
         src = c->d_boundary_buf;
     }
     hipLaunchKernelGGL(boundary_apply_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, c->d_bodies, (const int*)c->d_boundary, c->boundary_count,
-                       c->d_boundary_snapshot, src);
+                       c->d_boundary_snapshot, src, (const int*)nullptr, (const float*)nullptr, c->exchange_mode == BEPUHIP_EXCHANGE_PER_BATCH_EXACT ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BEPUHIP_OK;
 }
 
-// Simulation.Solve with an exchange point after every pass: the launch-per-batch schedule, eager, host-synchronised at each call-back.
-int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in, bepuhip_exchange_fn fn, void* user) {
+int32_t bepuhip_set_exchange_mode(bepuhip_ctx* c, int32_t mode) {
+    if (!c || (mode != BEPUHIP_EXCHANGE_PER_PASS_AVERAGE && mode != BEPUHIP_EXCHANGE_PER_BATCH_EXACT)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown exchange mode");
+    c->exchange_mode = mode;
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_set_boundary_layout(bepuhip_ctx* c, const int32_t* dense_rows, int32_t dense_row_count, const float* holders) {
+    if (!c || dense_row_count < 0 || (c->boundary_count > 0 && !dense_rows)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad boundary layout");
+    for (int i = 0; i < c->boundary_count; ++i)
+        if (dense_rows[i] < 0 || dense_rows[i] >= dense_row_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "dense row out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    free_boundary_layout(c);
+    c->dense_rows = dense_row_count;
+    if (dense_row_count == 0) return BEPUHIP_OK;
+    HIP_TRY(hipMalloc((void**)&c->d_boundary_dense, (size_t)dense_row_count * 24));
+    if (c->boundary_count > 0) {
+        HIP_TRY(hipMalloc((void**)&c->d_boundary_rows, (size_t)c->boundary_count * 4));
+        HIP_TRY(hipMemcpy(c->d_boundary_rows, dense_rows, (size_t)c->boundary_count * 4, hipMemcpyHostToDevice));
+    }
+    if (holders) {
+        for (int i = 0; i < dense_row_count; ++i) if (!(holders[i] >= 1.0f)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "holder count below one");
+        HIP_TRY(hipMalloc((void**)&c->d_boundary_holders, (size_t)dense_row_count * 4));
+        HIP_TRY(hipMemcpy(c->d_boundary_holders, holders, (size_t)dense_row_count * 4, hipMemcpyHostToDevice));
+    }
+    return BEPUHIP_OK;
+}
+
+// ---- RCCL, opened at run time ----
+// torch ships its own librccl; a C# host gets /opt/rocm/lib's. Opening by soname returns whichever the process already has, so there is never a second copy.
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl* rccl() {
+    static Rccl lib;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib.handle) break;
+        }
+        if (lib.handle) {
+            lib.GetUniqueId = (decltype(lib.GetUniqueId))dlsym(lib.handle, "ncclGetUniqueId");
+            lib.CommInitRank = (decltype(lib.CommInitRank))dlsym(lib.handle, "ncclCommInitRank");
+            lib.CommDestroy = (decltype(lib.CommDestroy))dlsym(lib.handle, "ncclCommDestroy");
+            lib.AllReduce = (decltype(lib.AllReduce))dlsym(lib.handle, "ncclAllReduce");
+            lib.GetErrorString = (decltype(lib.GetErrorString))dlsym(lib.handle, "ncclGetErrorString");
+            if (!lib.GetUniqueId || !lib.CommInitRank || !lib.CommDestroy || !lib.AllReduce) { dlclose(lib.handle); lib.handle = nullptr; }
+        }
+    }
+    return lib.handle ? &lib : nullptr;
+}
+static int32_t rccl_fail(const char* what, ncclResult_t r) {
+    Rccl* lib = rccl();
+    return fail(BEPUHIP_E_DEVICE, std::string(what) + ": " + (lib && lib->GetErrorString ? lib->GetErrorString(r) : "RCCL error") + " (" + std::to_string((int)r) + ")");
+}
+static void release_comm(bepuhip_ctx* c) {
+    if (c->comm && c->comm_owned) { Rccl* lib = rccl(); if (lib) lib->CommDestroy((ncclComm_t)c->comm); }
+    c->comm = nullptr; c->comm_owned = false; c->comm_world = 1;
+}
+
+int32_t bepuhip_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    Rccl* lib = rccl();
+    if (!lib) return fail(BEPUHIP_E_UNSUPPORTED, "librccl.so could not be opened (needed only for the on-stream exchange of a split scene)");
+    static_assert(sizeof(ncclUniqueId) == BEPUHIP_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    const ncclResult_t r = lib->GetUniqueId(&id);
+    if (r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
+    memcpy(id_out, &id, sizeof(id));
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_comm_init(bepuhip_ctx* c, const void* id, int32_t rank, int32_t world) {
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad communicator arguments");
+    Rccl* lib = rccl();
+    if (!lib) return fail(BEPUHIP_E_UNSUPPORTED, "librccl.so could not be opened (needed only for the on-stream exchange of a split scene)");
+    HIP_TRY(hipSetDevice(c->device));
+    release_comm(c);
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = lib->CommInitRank(&comm, world, uid, rank);
+    if (r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
+    c->comm = comm; c->comm_owned = true; c->comm_world = world;
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_comm_adopt(bepuhip_ctx* c, void* nccl_comm, int32_t world) {
+    if (!c || world < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad communicator arguments");
+    if (nccl_comm && !rccl()) return fail(BEPUHIP_E_UNSUPPORTED, "librccl.so could not be opened");
+    release_comm(c);
+    c->comm = nccl_comm; c->comm_owned = false; c->comm_world = nccl_comm ? world : 1;
+    return BEPUHIP_OK;
+}
+
+// One exchange on the solver's stream, no host involvement: deltas into the dense buffer (rows this rank does not hold stay zero), all-reduce in place, apply.
+static int32_t enqueue_exchange(bepuhip_ctx* c) {
+    if (c->dense_rows == 0) return BEPUHIP_OK;
+    const int exact = c->exchange_mode == BEPUHIP_EXCHANGE_PER_BATCH_EXACT ? 1 : 0;
+    HIP_TRY(hipMemsetAsync(c->d_boundary_dense, 0, (size_t)c->dense_rows * 24, c->stream));
+    if (c->boundary_count > 0)
+        hipLaunchKernelGGL(boundary_deltas_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, (const int*)c->d_boundary, c->boundary_count,
+                           (const float4*)c->d_boundary_snapshot, c->d_boundary_dense, (const int*)c->d_boundary_rows, exact);
+    if (c->comm) {
+        const ncclResult_t r = rccl()->AllReduce(c->d_boundary_dense, c->d_boundary_dense, (size_t)c->dense_rows * 6, exact ? ncclUint32 : ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream);
+        if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+    }
+    if (c->boundary_count > 0)
+        hipLaunchKernelGGL(boundary_apply_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, c->d_bodies, (const int*)c->d_boundary, c->boundary_count,
+                           c->d_boundary_snapshot, (const float*)c->d_boundary_dense, (const int*)c->d_boundary_rows, exact ? (const float*)nullptr : (const float*)c->d_boundary_holders, exact);
+    return BEPUHIP_OK;
+}
+
+// Simulation.Solve with exchange points: the launch-per-batch schedule, eager. `fn` != null: host-synchronised call-backs (any transport); null: the exchange
+// is enqueued on the stream (enqueue_exchange) and the host does not wait for anything before the end of the frame. BEPUHIP_EXCHANGE_PER_PASS_AVERAGE exchanges
+// after every pass, BEPUHIP_EXCHANGE_PER_BATCH_EXACT after every batch of every pass.
+static int32_t run_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in, bepuhip_exchange_fn fn, void* user) {
     int32_t st = validate_solve(c, dt, substeps, iterations, in);
     if (st != BEPUHIP_OK) return st;
-    if (!fn) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null exchange call-back");
-    if (c->clusters_enabled) return fail(BEPUHIP_E_STATE, "solve_exchanged needs a context created with BEPUHIP_FLAG_NO_CLUSTERS (a split scene is one island per rank anyway)");
+    if (c->clusters_enabled) return fail(BEPUHIP_E_STATE, "an exchanged solve needs a context created with BEPUHIP_FLAG_NO_CLUSTERS (a split scene is one island per rank anyway)");
+    if (!fn && c->boundary_count > 0 && !c->d_boundary_rows) return fail(BEPUHIP_E_STATE, "bepuhip_solve_lattice needs bepuhip_set_boundary_layout after bepuhip_set_boundary_bodies");
     HIP_TRY(hipSetDevice(c->device));
     if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
     int64_t iters = 0;
@@ -752,10 +887,12 @@ int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, cons
     const float substep_dt = dt / substeps, inv_dt = 1.0f / substep_dt;
     const StepParams sp = make_params(in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
-    auto exchange = [&](int s, int pass) -> int32_t {
+    const bool per_batch = c->exchange_mode == BEPUHIP_EXCHANGE_PER_BATCH_EXACT;
+    auto exchange = [&](int s, int pass, int launch) -> int32_t {
+        if (!fn) return enqueue_exchange(c);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
-        const int32_t r = fn(user, s, pass);
+        const int32_t r = fn(user, s, pass | ((launch + 1) << 16));
         if (r != 0) return fail(BEPUHIP_E_STATE, "exchange call-back failed with status " + std::to_string(r));
         return BEPUHIP_OK;
     };
@@ -768,19 +905,23 @@ int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, cons
         if (c->boundary_count > 0)  // deltas of this substep are relative to the integrated velocities (identical on every holder)
             hipLaunchKernelGGL(boundary_snapshot_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, (const int*)c->d_boundary, c->boundary_count,
                                c->d_boundary_snapshot);
-        for (int b = 0; b < c->launch_count; ++b)
+        for (int b = 0; b < c->launch_count; ++b) {
             if (c->batch_blocks[b] > 0) {
                 enqueue_requirk(c, s, b, sp);
                 hipLaunchKernelGGL(batch_kernel<kStageWarmStart>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
                                    c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);
             }
-        if ((st = exchange(s, 0)) != BEPUHIP_OK) return st;
+            if (per_batch && (st = exchange(s, 0, b)) != BEPUHIP_OK) return st;  // also after a batch this rank has nothing in: the ranks' collectives pair up by count
+        }
+        if (!per_batch && (st = exchange(s, 0, -1)) != BEPUHIP_OK) return st;
         for (int it = 0; it < iterations[s]; ++it) {
-            for (int b = 0; b < c->launch_count; ++b)
+            for (int b = 0; b < c->launch_count; ++b) {
                 if (c->batch_blocks[b] > 0)
                     hipLaunchKernelGGL(batch_kernel<kStageSolve>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
                                        c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);
-            if ((st = exchange(s, 1 + it)) != BEPUHIP_OK) return st;
+                if (per_batch && (st = exchange(s, 1 + it, b)) != BEPUHIP_OK) return st;
+            }
+            if (!per_batch && (st = exchange(s, 1 + it, -1)) != BEPUHIP_OK) return st;
         }
     }
     if (body_blocks > 0) {
@@ -792,6 +933,15 @@ int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, cons
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
     return bepuhip_sync(c);
+}
+
+int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in, bepuhip_exchange_fn fn, void* user) {
+    if (!fn) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null exchange call-back");
+    return run_exchanged(c, dt, substeps, iterations, in, fn, user);
+}
+
+int32_t bepuhip_solve_lattice(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in) {
+    return run_exchanged(c, dt, substeps, iterations, in, nullptr, nullptr);
 }
 
 int32_t bepuhip_sync(bepuhip_ctx* c) {

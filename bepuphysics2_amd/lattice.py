@@ -100,7 +100,8 @@ def boundary_bodies(scene: Scene, owner: np.ndarray) -> np.ndarray:
     return np.nonzero(marks)[0]
 
 
-def make_share(scene: Scene, owner: np.ndarray, rank: int, world: int) -> Share:
+def make_share(scene: Scene, owner: np.ndarray, rank: int, world: int, mass_split: bool = True) -> Share:
+    """``mass_split=False``: copies keep their full masses — the shares of the per-batch exact exchange (bepuhip.h BEPUHIP_EXCHANGE_PER_BATCH_EXACT)."""
     w = scene.bundle_width
     boundary = boundary_bodies(scene, owner)
     needed = owner == rank
@@ -138,8 +139,9 @@ def make_share(scene: Scene, owner: np.ndarray, rank: int, world: int) -> Share:
     holders = boundary_holders(scene, owner, world)[boundary].sum(axis=1).astype(np.float32)
     # mass splitting: this rank's copy of a body with k holders carries 1/k of its mass
     b_local = global_to_local[boundary][held]
-    local_scene.bodies[b_local, 16:23] *= holders[held][:, None]
-    local_scene.bodies[b_local, 24:31] *= holders[held][:, None]
+    if mass_split:
+        local_scene.bodies[b_local, 16:23] *= holders[held][:, None]
+        local_scene.bodies[b_local, 24:31] *= holders[held][:, None]
     return Share(rank, world, local_scene, local_to_global, np.arange(n_local) < owned_idx.size,
                  b_local.astype(np.int32), np.nonzero(held)[0].astype(np.int64), int(boundary.size), holders, picks)
 
@@ -190,22 +192,43 @@ class BoundaryExchange:
             dense = t.cpu().numpy()
         return self.average(dense)[self.share.boundary_slot]
 
+    def reduce_exact(self, local_patterns: np.ndarray) -> np.ndarray:
+        """Per-batch exact mode: [held boundary bodies, 6] uint32 XOR patterns (at most one rank's row is non-zero for any body) -> the summed patterns."""
+        self.calls += 1
+        if self.share.boundary_total == 0:
+            return local_patterns
+        dense = np.zeros((self.share.boundary_total, 6), dtype=np.int32)
+        dense[self.share.boundary_slot] = np.ascontiguousarray(local_patterns).view(np.int32)
+        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+            import torch
+            t = torch.from_numpy(dense)  # int32: wrap-around addition, exact with a single non-zero contribution
+            if self.device is not None:
+                t = t.to(self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            dense = t.cpu().numpy()
+        return dense[self.share.boundary_slot].view(np.uint32)
+
     def average(self, dense_sums: np.ndarray) -> np.ndarray:
         """Mass splitting: the copies solved against 1/k of the mass, so the mean of their velocity changes is the full-mass response."""
         return (dense_sums / self.share.boundary_holders[:, None]).astype(np.float32)
 
 
 def solve_share_hip(solver, share: Share, dt, solve_description, callbacks, exchange: BoundaryExchange, frames: int = 1, upload: bool = True,
-                    device_buffers: bool = False):
-    """Run ``frames`` steps of this rank's share on the GPU (HipSolver created with use_clusters=False), exchanging after every pass.
+                    device_buffers: bool = False, exact: bool = False):
+    """Run ``frames`` steps of this rank's share on the GPU (HipSolver created with use_clusters=False), exchanging after every pass — or, ``exact``, after
+    every batch (the share must then come from make_share(mass_split=False)).
     ``device_buffers``: keep the deltas in HBM and all-reduce device tensors (RCCL over xGMI on a multi-GPU node); otherwise stage through the host."""
     if upload:
         solver.upload(share.scene, solve_description.fallback_batch_threshold)
         solver.set_boundary_bodies(share.boundary_local)
-    hook = DeviceExchange(solver, share, exchange.dist, exchange.device) if device_buffers else None
+    solver.set_exchange_mode(1 if exact else 0)
+    hook = DeviceExchange(solver, share, exchange.dist, exchange.device) if device_buffers and not exact else None
 
     def host_hook(_substep, _pass):
-        solver.boundary_apply(exchange.reduce(solver.boundary_deltas()))
+        if exact:
+            solver.boundary_apply(exchange.reduce_exact(solver.boundary_deltas()))
+        else:
+            solver.boundary_apply(exchange.reduce(solver.boundary_deltas()))
 
     for _ in range(frames):
         solver.solve_exchanged(dt, solve_description, callbacks, hook if hook is not None else host_hook)
@@ -247,43 +270,88 @@ class DeviceExchange:
             self.solver.boundary_apply_device(self.local.data_ptr())
 
 
-class OracleShare:
-    """CPU stand-in (tests only): the oracle solves the share; the hook reproduces the device's snapshot / delta / apply arithmetic in float32.
-    The oracle integrates a body inside its first constraint's warm start, so the substep's snapshot is the velocity call-back applied to the
-    last synchronised velocity (the same float32 operations as Demos/DemoCallbacks.cs:100-109)."""
+def solve_share_on_stream(solver, share: Share, dt, solve_description, callbacks, frames: int = 1, upload: bool = True, exact: bool = False,
+                          unique_id: Optional[bytes] = None):
+    """The production path of a multi-GPU node: the exchange runs on the solver's stream (bepuhip_solve_lattice), RCCL all-reduce over a communicator the library
+    creates from ``unique_id`` (made by rank 0 with solver.comm_unique_id() and carried to the other ranks by the host's own transport). ``unique_id`` None: a
+    single rank, no collective."""
+    if upload:
+        solver.upload(share.scene, solve_description.fallback_batch_threshold)
+        solver.set_boundary_bodies(share.boundary_local)
+        solver.set_boundary_layout(share.boundary_slot, share.boundary_total, None if exact else share.boundary_holders)
+        if unique_id is not None:
+            solver.comm_init(unique_id, share.rank, share.world)
+    solver.set_exchange_mode(1 if exact else 0)
+    for _ in range(frames):
+        solver.solve_lattice(dt, solve_description, callbacks)
+    solver.download(share.scene)
 
-    def __init__(self, share: Share, dt: float, solve_description, callbacks, exchange: BoundaryExchange):
-        self.share, self.dt, self.sd, self.cb, self.exchange = share, dt, solve_description, callbacks, exchange
-        sub_dt = np.float32(np.float32(dt) / np.float32(solve_description.substep_count))
-        lin = np.float32(min(max(1.0 - callbacks.linear_damping, 0.0), 1.0))
-        ang = np.float32(min(max(1.0 - callbacks.angular_damping, 0.0), 1.0))
-        self.lin_damp = np.float32(np.power(lin, sub_dt, dtype=np.float32))
-        self.ang_damp = np.float32(np.power(ang, sub_dt, dtype=np.float32))
-        self.gravity_dt = (np.asarray(callbacks.gravity, dtype=np.float32) * sub_dt).astype(np.float32)
-        self.snapshot = None
 
-    def _velocities(self):
-        b = self.share.scene.bodies[self.share.boundary_local]
-        return np.concatenate([b[:, 8:11], b[:, 12:15]], axis=1).astype(np.float32)
+class ThreadExchange:
+    """All ranks of a split scene inside ONE process (one thread and one HipSolver context per rank, e.g. on a single-GPU box): the ranks meet at a barrier and
+    sum their rows in host memory. Same arithmetic as BoundaryExchange over a process group; used by bench.py's lattice leg and the GPU tests."""
 
-    def _integrated(self, v):
-        out = v.copy()
-        out[:, 0:3] = (v[:, 0:3] + self.gravity_dt) * self.lin_damp
-        out[:, 3:6] = v[:, 3:6] * self.ang_damp
+    def __init__(self, shares: List[Share]):
+        import threading
+        self.shares = shares
+        self.barrier = threading.Barrier(len(shares))
+        total = shares[0].boundary_total
+        self.dense_f = np.zeros((len(shares), max(total, 1), 6), dtype=np.float32)
+        self.dense_i = np.zeros((len(shares), max(total, 1), 6), dtype=np.int32)
+        self.calls = 0
+
+    def reduce(self, rank: int, local: np.ndarray, exact: bool) -> np.ndarray:
+        sh = self.shares[rank]
+        if rank == 0:
+            self.calls += 1
+        if sh.boundary_total == 0:
+            return local
+        buf = self.dense_i if exact else self.dense_f
+        buf[rank] = 0
+        buf[rank][sh.boundary_slot] = np.ascontiguousarray(local).view(np.int32) if exact else local
+        self.barrier.wait()
+        if exact:
+            total = buf.sum(axis=0, dtype=np.int32)  # wrap-around, exact with one non-zero contribution
+            out = total[sh.boundary_slot].view(np.uint32)
+        else:
+            total = buf[0].copy()
+            for r in range(1, len(self.shares)):  # rank order: the order a ring all-reduce is free to differ from; the tolerance of this mode covers it
+                total += buf[r]
+            out = (total / sh.boundary_holders[:, None]).astype(np.float32)[sh.boundary_slot]
+        self.barrier.wait()  # nobody overwrites its row before everyone has read the sums
         return out
 
-    def hook(self, _substep, pass_index):
-        if pass_index == 0:
-            self.snapshot = self._integrated(self.synced)
-        v = self._velocities()
-        new = self.snapshot + self.exchange.reduce(v - self.snapshot)
-        bodies = self.share.scene.bodies
-        bodies[self.share.boundary_local, 8:11] = new[:, 0:3]
-        bodies[self.share.boundary_local, 12:15] = new[:, 3:6]
-        self.snapshot = new
-        self.synced = new
 
-    def solve(self, oracle_solve, frames: int = 1, threads: int = 1):
-        for _ in range(frames):
-            self.synced = self._velocities()
-            oracle_solve(self.share.scene, self.dt, self.sd, self.cb, threads=threads, exchange=self.hook)
+def solve_shares_in_process(make_solver, shares: List[Share], dt, solve_description, callbacks, frames: int = 1, exact: bool = False) -> ThreadExchange:
+    """Solve every share of a split scene in this process, one thread per rank (ctypes releases the GIL inside the library)."""
+    import threading
+    ex = ThreadExchange(shares)
+    errors = []
+
+    def run(rank):
+        try:
+            solver = make_solver()
+            share = shares[rank]
+            solver.upload(share.scene, solve_description.fallback_batch_threshold)
+            solver.set_boundary_bodies(share.boundary_local)
+            solver.set_exchange_mode(1 if exact else 0)
+
+            def hook(_substep, _pass):
+                solver.boundary_apply(ex.reduce(rank, solver.boundary_deltas(), exact))
+
+            for _ in range(frames):
+                solver.solve_exchanged(dt, solve_description, callbacks, hook)
+            solver.download(share.scene)
+            solver.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            ex.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(len(shares))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return ex

@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_get_stream", "bepuhip_solve_async", "bepuhip_sync", "bepuhip_reset_state", "bepuhip_type_info",
     "bepuhip_set_cluster_trace", "bepuhip_get_cluster_trace", "bepuhip_get_cluster_cycles", "bepuhip_debug_status",
     "bepuhip_set_boundary_bodies", "bepuhip_boundary_deltas", "bepuhip_boundary_apply", "bepuhip_solve_exchanged",
+    "bepuhip_set_exchange_mode", "bepuhip_set_boundary_layout", "bepuhip_comm_unique_id", "bepuhip_comm_init", "bepuhip_comm_adopt", "bepuhip_solve_lattice",
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
     "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables",
@@ -60,6 +61,7 @@ class Integrator(C.Structure):
                 ("integrate_velocity_for_kinematics", C.c_int32)]
 
 
+EXCHANGE_PER_PASS_AVERAGE, EXCHANGE_PER_BATCH_EXACT = 0, 1
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32)  # bepuhip_exchange_fn(user, substep, pass)
 
 _lib: Optional[C.CDLL] = None
@@ -99,7 +101,13 @@ def load_library() -> C.CDLL:
     lib.bepuhip_set_boundary_bodies.argtypes = [vp, vp, i32]
     lib.bepuhip_boundary_deltas.argtypes = [vp, vp, i32]
     lib.bepuhip_boundary_apply.argtypes = [vp, vp, i32]
+    lib.bepuhip_set_exchange_mode.argtypes = [vp, i32]
+    lib.bepuhip_set_boundary_layout.argtypes = [vp, vp, i32, vp]
+    lib.bepuhip_comm_unique_id.argtypes = [vp]
+    lib.bepuhip_comm_init.argtypes = [vp, vp, i32, i32]
+    lib.bepuhip_comm_adopt.argtypes = [vp, vp, i32]
     lib.bepuhip_solve_exchanged.argtypes = [vp, f32, i32, vp, C.POINTER(Integrator), EXCHANGE_FN, vp]
+    lib.bepuhip_solve_lattice.argtypes = [vp, f32, i32, vp, C.POINTER(Integrator)]
     lib.bepuhip_get_cluster_cycles.argtypes = [vp, vp, i32, C.POINTER(i32)]
     lib.bepuhip_debug_status.argtypes = [vp, vp]
     lib.bepuhip_get_cluster_trace.argtypes = [vp, vp, C.c_int64, C.POINTER(i32)]
@@ -168,6 +176,7 @@ class HipSolver:
         self.bundle_width = bundle_width
         self._scene_meta = None
         self._boundary_count = 0
+        self._exchange_mode = 0
 
     def close(self):
         if self.ctx:
@@ -215,12 +224,14 @@ class HipSolver:
         _check(self.lib, self.lib.bepuhip_set_boundary_bodies(self.ctx, _ptr(idx), idx.size))
 
     def boundary_deltas(self) -> np.ndarray:
+        """[boundary bodies, 6] float32 deltas — or, in the per-batch exact mode, uint32 XOR patterns (same buffer)."""
         out = np.zeros((self._boundary_count, 6), dtype=np.float32)
         _check(self.lib, self.lib.bepuhip_boundary_deltas(self.ctx, _ptr(out), 0))
-        return out
+        return out.view(np.uint32) if self._exchange_mode == EXCHANGE_PER_BATCH_EXACT else out
 
     def boundary_apply(self, sums: np.ndarray):
-        sums = np.ascontiguousarray(sums, dtype=np.float32)
+        sums = np.ascontiguousarray(sums)
+        sums = sums.view(np.float32) if sums.dtype in (np.uint32, np.int32) else sums.astype(np.float32, copy=False)  # XOR patterns travel as they are
         assert sums.shape == (self._boundary_count, 6)
         _check(self.lib, self.lib.bepuhip_boundary_apply(self.ctx, _ptr(sums), 0))
 
@@ -230,8 +241,35 @@ class HipSolver:
     def boundary_apply_device(self, device_pointer: int):
         _check(self.lib, self.lib.bepuhip_boundary_apply(self.ctx, C.c_void_p(device_pointer), 1))
 
+    def set_exchange_mode(self, mode: int):
+        _check(self.lib, self.lib.bepuhip_set_exchange_mode(self.ctx, int(mode)))
+        self._exchange_mode = int(mode)
+
+    def set_boundary_layout(self, dense_rows: np.ndarray, dense_row_count: int, holders: Optional[np.ndarray] = None):
+        rows = np.ascontiguousarray(dense_rows, dtype=np.int32)
+        assert rows.size == self._boundary_count
+        h = None if holders is None else np.ascontiguousarray(holders, dtype=np.float32)
+        assert h is None or h.size == dense_row_count
+        _check(self.lib, self.lib.bepuhip_set_boundary_layout(self.ctx, _ptr(rows), int(dense_row_count), _ptr(h)))
+
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(self.lib, self.lib.bepuhip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        _check(self.lib, self.lib.bepuhip_comm_init(self.ctx, C.c_char_p(unique_id), int(rank), int(world)))
+
+    def solve_lattice(self, dt: float, solve_description: SolveDescription, callbacks: PoseIntegratorCallbacks):
+        """The exchanged frame with the exchange enqueued on the solver's stream (RCCL all-reduce when a communicator is set): no host synchronisation inside."""
+        its = np.ascontiguousarray(solve_description.iterations(), dtype=np.int32)
+        integ = make_integrator(callbacks)
+        _check(self.lib, self.lib.bepuhip_solve_lattice(self.ctx, float(dt), int(solve_description.substep_count), _ptr(its), C.byref(integ)))
+
     def solve_exchanged(self, dt: float, solve_description: SolveDescription, callbacks: PoseIntegratorCallbacks, exchange):
-        """``exchange(substep, pass)`` runs after every pass (0 = warm start, k = k-th velocity iteration); exceptions abort the solve."""
+        """``exchange(substep, pass)`` runs after every pass (0 = warm start, k = k-th velocity iteration) — after every batch in the per-batch exact mode, with
+        pass | (batch launch + 1) << 16; exceptions abort the solve."""
         its = np.ascontiguousarray(solve_description.iterations(), dtype=np.int32)
         integ = make_integrator(callbacks)
         failure = []

@@ -101,6 +101,35 @@ int32_t bepuhip_boundary_apply(bepuhip_ctx* ctx, const float* summed_deltas, int
 int32_t bepuhip_solve_exchanged(bepuhip_ctx* ctx, float dt, int32_t substep_count, const int32_t* velocity_iterations, const bepuhip_integrator* integrator,
                                 bepuhip_exchange_fn fn, void* user);
 
+/* Exchange modes ("keep exchange frequency configurable (per batch = exact ordering ...)").
+ *   PER_PASS_AVERAGE  the default described above: one exchange per pass, float deltas, mass-split copies averaged. Not bit-identical to one GPU.
+ *   PER_BATCH_EXACT   one exchange after EVERY batch of every pass. The shares keep the reference's batch indices, and a batch references a body at most once
+ *                     (ConstraintBatch's invariant, BepuPhysics/ConstraintBatch.cs), so between two exchanges at most ONE rank has touched any given body. The
+ *                     ranks exchange the XOR of the velocity's bit pattern with the last synchronised pattern; an unsigned integer sum over the ranks returns the
+ *                     toucher's pattern exactly, and every copy is bit-identical to the unsplit Simulation.Solve at every batch boundary. Shares are uploaded with
+ *                     FULL masses (no mass splitting). Costs batches x (1 + iterations) x substeps small collectives per frame.
+ * In PER_BATCH_EXACT mode boundary_deltas / boundary_apply move uint32 XOR patterns through the same 6-words-per-body buffers, and solve_exchanged calls `fn`
+ * after every batch with pass = pass_index | (batch_launch_index + 1) << 16. */
+#define BEPUHIP_EXCHANGE_PER_PASS_AVERAGE 0
+#define BEPUHIP_EXCHANGE_PER_BATCH_EXACT 1
+int32_t bepuhip_set_exchange_mode(bepuhip_ctx* ctx, int32_t mode);
+
+/* The same frame with the exchange ON THE SOLVER'S STREAM: no call-back, no host synchronisation before the end of the frame. Every exchange point enqueues
+ * "deltas -> dense buffer, ncclAllReduce(sum) in place, apply" behind the batch kernels (RCCL orders the collective on the stream it is given).
+ *   set_boundary_layout  after set_boundary_bodies: dense_rows[i] = row of boundary body i in the dense exchange buffer (the same row for the same body on
+ *                        every rank, dense_row_count rows of 6 words on every rank); holders[row] = number of ranks holding the body (mass-split shares of the
+ *                        PER_PASS_AVERAGE mode: the summed deltas are divided by it) or NULL.
+ *   comm_unique_id       ncclGetUniqueId on one rank; the host carries the BEPUHIP_COMM_ID_BYTES to the others by any means (the reference has no transport of its own).
+ *   comm_init            ncclCommInitRank for this context's device; collective over the ranks. comm_adopt hands over an ncclComm_t the host already owns
+ *                        (not destroyed with the context). Without a communicator solve_lattice runs a single rank: the exchange only re-bases.
+ * librccl.so is opened at run time by the first comm_* call (UNSUPPORTED if absent); nothing else in the library depends on it. */
+#define BEPUHIP_COMM_ID_BYTES 128
+int32_t bepuhip_set_boundary_layout(bepuhip_ctx* ctx, const int32_t* dense_rows, int32_t dense_row_count, const float* holders);
+int32_t bepuhip_comm_unique_id(void* id_out);
+int32_t bepuhip_comm_init(bepuhip_ctx* ctx, const void* id, int32_t rank, int32_t world);
+int32_t bepuhip_comm_adopt(bepuhip_ctx* ctx, void* nccl_comm, int32_t world);
+int32_t bepuhip_solve_lattice(bepuhip_ctx* ctx, float dt, int32_t substep_count, const int32_t* velocity_iterations, const bepuhip_integrator* integrator);
+
 /* Read back what the reference would find in its own buffers after Simulation.Solve returns. */
 int32_t bepuhip_get_bodies(bepuhip_ctx* ctx, void* body_dynamics_aos_out, int32_t count);
 int32_t bepuhip_get_accumulated_impulses(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, float* accumulated_impulses_aosoa_out);

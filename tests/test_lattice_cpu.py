@@ -55,6 +55,7 @@ def test_single_rank_share_reproduces_the_plain_oracle_bit_for_bit():
     import oracle_ffi
     from bepuphysics2_amd import lattice
     from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    from oracle_share import OracleShare
     scene, sd = _lattice_scene(12)
     cb = PoseIntegratorCallbacks()
     ref = scene.copy()
@@ -62,7 +63,7 @@ def test_single_rank_share_reproduces_the_plain_oracle_bit_for_bit():
     share = lattice.make_share(scene, lattice.owner_by_groups(scene, 1, 16), 0, 1)
     assert share.boundary_total == 0 and share.owned.sum() == scene.body_count - 1
     ex = lattice.BoundaryExchange(share)
-    lattice.OracleShare(share, 1 / 60, sd, cb, ex).solve(oracle_ffi.solve)
+    OracleShare(share, 1 / 60, sd, cb, ex).solve(oracle_ffi.solve)
     assert ex.calls == int((1 + sd.iterations()).sum())  # one exchange point per pass
     merged = lattice.merge_owned(scene, [share])
     assert np.array_equal(merged.bodies[:-1, :16].view(np.int32), ref.bodies[:-1, :16].view(np.int32))  # pose + velocity
@@ -76,10 +77,11 @@ def _worker(rank, world, port, outdir, ragdolls):
     import oracle_ffi
     from bepuphysics2_amd import lattice
     from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    from oracle_share import OracleShare
     scene, sd = _lattice_scene(ragdolls)
     share = lattice.make_share(scene, lattice.owner_by_groups(scene, world, 16), rank, world)
     ex = lattice.BoundaryExchange(share, dist)
-    lattice.OracleShare(share, 1 / 60, sd, PoseIntegratorCallbacks(), ex).solve(oracle_ffi.solve, frames=2)
+    OracleShare(share, 1 / 60, sd, PoseIntegratorCallbacks(), ex).solve(oracle_ffi.solve, frames=2)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), bodies=share.scene.bodies, l2g=share.local_to_global, owned=share.owned,
              boundary_local=share.boundary_local, boundary_slot=share.boundary_slot)
     dist.barrier()
@@ -119,3 +121,45 @@ def test_two_rank_gloo_split_lattice(tmp_path):
     interior[-1] = False
     far = np.abs(ref.bodies[:, VEL] - got[:, VEL]).max(axis=1) / scale
     assert np.median(far[interior]) < 1e-3  # away from the cut the two solves agree closely
+
+
+def _exact_worker(rank, world, port, outdir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bepuphysics2_amd import lattice
+    scene, _ = _lattice_scene(24)
+    share = lattice.make_share(scene, lattice.owner_by_groups(scene, world, 16), rank, world, mass_split=False)
+    ex = lattice.BoundaryExchange(share, dist)
+    rng = np.random.default_rng(7)  # the same stream on both ranks: a "solved" value for every dense row, and which rank touched it in this batch
+    truth = rng.integers(0, 2**32, size=(share.boundary_total, 6), dtype=np.uint64).astype(np.uint32)
+    toucher = rng.integers(0, world + 1, size=share.boundary_total)  # == world: nobody
+    snapshot = rng.integers(0, 2**32, size=(share.boundary_total, 6), dtype=np.uint64).astype(np.uint32)
+    mine = toucher[share.boundary_slot] == rank
+    local_now = snapshot[share.boundary_slot].copy()
+    local_now[mine] = truth[share.boundary_slot][mine]
+    total = ex.reduce_exact(local_now ^ snapshot[share.boundary_slot])
+    np.savez(os.path.join(outdir, f"exact{rank}.npz"), new=snapshot[share.boundary_slot] ^ total, slot=share.boundary_slot, truth=truth, toucher=toucher, snapshot=snapshot)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exact_mode_exchange_moves_the_touchers_bit_pattern_over_gloo(tmp_path):
+    """BEPUHIP_EXCHANGE_PER_BATCH_EXACT's transport: XOR patterns, integer sum. Whatever one rank wrote arrives bit for bit on every holder, rows nobody
+    touched keep their pattern (NaN payloads and negative zeros included: these are raw words)."""
+    mp.spawn(_exact_worker, args=(2, 29300 + (os.getpid() % 300), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        d = np.load(os.path.join(str(tmp_path), f"exact{rank}.npz"))
+        want = np.where((d["toucher"] < 2)[:, None], d["truth"], d["snapshot"])[d["slot"]]
+        assert d["slot"].size and np.array_equal(d["new"], want)
+
+
+def test_full_mass_shares_for_the_exact_mode():
+    from bepuphysics2_amd import lattice
+    scene, _ = _lattice_scene(12)
+    owner = lattice.owner_by_groups(scene, 2, 16)
+    split, full = lattice.make_share(scene, owner, 0, 2), lattice.make_share(scene, owner, 0, 2, mass_split=False)
+    g = full.local_to_global
+    assert np.array_equal(full.scene.bodies[:, 16:31], scene.bodies[g, 16:31])
+    b = split.boundary_local
+    assert b.size and np.allclose(split.scene.bodies[b, 22], 2 * scene.bodies[g[b], 22])
