@@ -180,6 +180,43 @@ def boundary_leg(scene, sd, cb, device: int):
     return out
 
 
+def lattice_leg(device: int, ragdolls: int = 2000, world: int = 2, frames: int = 2):
+    """configs[4]'s split at N=1: one connected lattice cut into `world` shares that all run on this GPU (one thread and one context per rank, exchange through host
+    memory), compared with the unsplit solve of the same library. Reports what each exchange mode costs in accuracy; the timings of this leg mean nothing."""
+    from bepuphysics2_amd import lattice
+    from bepuphysics2_amd.hostlib import HostSimulation
+    from bepuphysics2_amd.native import HipSolver
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    try:
+        sim = HostSimulation.scene("ragdoll_tube", ragdolls, 1, 1, 5)
+        scene, sd = sim.export(), sim.solve_description()
+        sim.close()
+        cb = PoseIntegratorCallbacks()
+        ref = scene.copy()
+        solver = HipSolver(device=device)
+        solver.upload(ref, sd.fallback_batch_threshold)
+        for _ in range(frames):
+            solver.solve(1 / 60, sd, cb)
+        solver.download(ref)
+        solver.close()
+        vel = [8, 9, 10, 12, 13, 14]
+        scale = float(np.abs(ref.bodies[:, vel]).max())
+        owner = lattice.owner_by_groups(scene, world, 16)
+        out = {"workload": f"one connected lattice of {ragdolls} ragdolls ({scene.constraint_count} constraints, {len(scene.batches)} batches) cut into {world} shares on this GPU, "
+                           f"{frames} frames, error = max over bodies of |v_split - v_unsplit| / max|v_unsplit| against the unsplit solve of the same library"}
+        for name, exact in (("per_pass_block_jacobi", False), ("per_batch_exact", True)):
+            shares = [lattice.make_share(scene, owner, r, world, mass_split=not exact) for r in range(world)]
+            ex = lattice.solve_shares_in_process(lambda: HipSolver(device=device, use_clusters=False), shares, 1 / 60, sd, cb, frames=frames, exact=exact)
+            merged = lattice.merge_owned(scene, shares)
+            per_body = np.abs(ref.bodies[:, vel] - merged.bodies[:, vel]).max(axis=1) / scale
+            out[name] = {"velocity_err_max": float(per_body.max()), "velocity_err_median": float(np.median(per_body)),
+                         "bit_identical": bool(np.array_equal(ref.bodies[:, :15].view(np.int32), merged.bodies[:, :15].view(np.int32))),
+                         "exchanges_per_frame": ex.calls // frames, "boundary_bodies": int(shares[0].boundary_total)}
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)[:300]}
+
+
 def measure_traffic(args):
     """HBM bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md's HBM section prescribes: separate
     rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE (they do not fit one pass), counters in KiB, and the gfx950 correction (FETCH_SIZE
@@ -233,13 +270,18 @@ def run_lattice(args, rank, local_rank, world, dist, torch):
     sim = HostSimulation.scene("ragdoll_tube", args.ragdolls, 1, 1, 5)  # every rank builds the same scene and cuts out its share
     scene, sd = sim.export(), sim.solve_description()
     sim.close()
-    share = lattice.make_share(scene, lattice.owner_by_groups(scene, world, 16), rank, world)
+    exact = bool(args.lattice_exact)
+    share = lattice.make_share(scene, lattice.owner_by_groups(scene, world, 16), rank, world, mass_split=not exact)
     cb = PoseIntegratorCallbacks()
     solver = HipSolver(device=local_rank, use_clusters=False)
     solver.upload(share.scene, sd.fallback_batch_threshold)
     solver.set_boundary_bodies(share.boundary_local)
-    ex = lattice.BoundaryExchange(share, dist, device=f"cuda:{local_rank}")
-    hook = lattice.DeviceExchange(solver, share, dist, f"cuda:{local_rank}")
+    solver.set_boundary_layout(share.boundary_slot, share.boundary_total, None if exact else share.boundary_holders)
+    solver.set_exchange_mode(1 if exact else 0)
+    if dist is not None:  # the library's own communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes
+        ids = [solver.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        solver.comm_init(ids[0], rank, world)
     dt = 1.0 / 60.0
 
     def barrier():
@@ -248,11 +290,11 @@ def run_lattice(args, rank, local_rank, world, dist, torch):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        solver.solve_exchanged(dt, sd, cb, hook)
+        solver.solve_lattice(dt, sd, cb)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        solver.solve_exchanged(dt, sd, cb, hook)
+        solver.solve_lattice(dt, sd, cb)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -273,9 +315,12 @@ def run_lattice(args, rank, local_rank, world, dist, torch):
             "config": {"workload": "one connected ragdoll lattice (BASELINE.json configs[4]): "
                                    f"{args.ragdolls} ragdolls, {scene.constraint_count} constraints, {scene.body_count} bodies, {len(scene.batches)} batches, "
                                    f"{sd.substep_count} substeps x {sd.velocity_iteration_count} velocity iteration(s), dt=1/60, split into {world} share(s)",
-                       "sharding": f"bodies by ragdoll ranges, {share.boundary_total} boundary bodies, mass-split block-Jacobi exchange after every pass "
-                                   f"({int((1 + its).sum())} all-reduces of {share.boundary_total * 24} bytes per step); launch-per-batch schedule",
-                       "exchanges_per_step": int((1 + its).sum())},
+                       "sharding": f"bodies by ragdoll ranges, {share.boundary_total} boundary bodies, "
+                                   + (f"exact per-batch exchange of XOR bit patterns ({int((1 + its).sum()) * len(scene.batches)} " if exact else
+                                      f"mass-split block-Jacobi exchange after every pass ({int((1 + its).sum())} ")
+                                   + f"ncclAllReduce of {share.boundary_total * 24} bytes per step, enqueued on the solver's stream by bepuhip_solve_lattice: no host "
+                                     "synchronisation inside a frame); launch-per-batch schedule",
+                       "exchanges_per_step": int((1 + its).sum()) * (len(scene.batches) if exact else 1)},
             "roofline": {"bound": "hbm", "kernel": "whole step (launch-per-batch schedule + exchanges)", "achieved": achieved, "peak": HBM_PEAK_GBS * world,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None},
             "cpu_baseline": None}))
@@ -295,6 +340,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--lattice", action="store_true", help="BASELINE.json configs[4]: ONE connected ragdoll lattice of --ragdolls ragdolls split across the ranks "
                     "(strong scaling, boundary-velocity exchange after every pass) instead of the default independent islands per rank")
+    ap.add_argument("--lattice-exact", action="store_true", help="with --lattice: the per-batch exact exchange mode (bit-identical to one GPU) instead of per-pass block-Jacobi")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the clock pre-warm of the setup phase (300 untimed solves, state restored afterwards)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE child runs behind roofline.traffic")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
@@ -460,8 +506,10 @@ def main():
                                                           ("ragdoll_tube", args.ragdolls, 1, 2, 5), local_rank)}
 
     boundary = None
+    lattice_report = None
     if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
         boundary = boundary_leg(scene, sd, cb, local_rank)
+        lattice_report = lattice_leg(local_rank)
 
     if rank == 0:
         value = whole_job_rate
@@ -479,7 +527,7 @@ def main():
                                    ("launch-per-batch" + ("" if args.no_graph else ", hipGraph replay")),
                        "device_prewarm": f"{prewarm_steps} untimed solves during setup, uploaded state restored before the {args.warmup} warm-up steps",
                        "finite": finite},
-            "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "boundary": boundary,
+            "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "boundary": boundary, "lattice": lattice_report,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -48,6 +48,7 @@ using namespace bd;
 //   this file                the C ABI of include/bepuhip.h: uploads, graph capture / launch sequence, read-backs
 #include "bepu_kernels_common.h"
 #include "bepu_batch_kernels.h"
+#include "bepu_colour_kernels.h"
 #include "bepu_host_state.h"
 #include "bepu_cluster_plan.h"
 
@@ -748,6 +749,54 @@ int32_t bepuhip_boundary_apply(bepuhip_ctx* c, const float* sums, int32_t in_is_
                        c->d_boundary_snapshot, src, (const int*)nullptr, (const float*)nullptr, c->exchange_mode == BEPUHIP_EXCHANGE_PER_BATCH_EXACT ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_colour_constraints(int32_t device, const int32_t* refs, int32_t count, int32_t body_count, int32_t order, int32_t fallback_batch_threshold, int32_t* colours_out,
+                                   int32_t* batch_count_out, int32_t* rounds_out) {
+    if (count < 0 || body_count < 0 || (count > 0 && (!refs || !colours_out)) || order < 0 || order > 1 || fallback_batch_threshold < 1 || fallback_batch_threshold > 64)
+        return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad colour_constraints argument");
+    for (int64_t i = 0; i < (int64_t)count * kColourBodies; ++i)
+        if (refs[i] != -1 && (refs[i] < 0 || (refs[i] & kRefMask) >= body_count)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "body reference out of range");
+    if (batch_count_out) *batch_count_out = 0;
+    if (rounds_out) *rounds_out = 0;
+    if (count == 0) return BEPUHIP_OK;
+    HIP_TRY(hipSetDevice(device));
+    int* d_refs = nullptr; int* d_colour = nullptr; unsigned* d_degree = nullptr; unsigned long long* d_words = nullptr; unsigned* d_remaining = nullptr;
+    auto release = [&]() { for (void* p : {(void*)d_refs, (void*)d_colour, (void*)d_degree, (void*)d_words, (void*)d_remaining}) if (p) hipFree(p); };
+    const size_t nb = (size_t)std::max(body_count, 1);
+    hipError_t e = hipMalloc((void**)&d_refs, (size_t)count * kColourBodies * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_colour, (size_t)count * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_degree, nb * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_words, ((size_t)count + 2 * nb) * 8);  // priority per constraint, best bid and used-batch mask per body
+    if (e == hipSuccess) e = hipMalloc((void**)&d_remaining, 4);
+    if (e != hipSuccess) { release(); return fail(BEPUHIP_E_DEVICE, std::string("colour_constraints: ") + hipGetErrorString(e)); }
+    unsigned long long* d_priority = d_words; unsigned long long* d_best = d_words + count; unsigned long long* d_used = d_best + nb;
+    hipMemcpy(d_refs, refs, (size_t)count * kColourBodies * 4, hipMemcpyHostToDevice);
+    hipMemset(d_colour, 0xFF, (size_t)count * 4);
+    hipMemset(d_degree, 0, nb * 4);
+    hipMemset(d_used, 0, nb * 8);
+    const dim3 grid((count + 255) / 256), block(256);
+    hipLaunchKernelGGL(colour_degree_kernel, grid, block, 0, 0, (const int*)d_refs, count, d_degree);
+    hipLaunchKernelGGL(colour_priority_kernel, grid, block, 0, 0, (const int*)d_refs, count, (const unsigned*)d_degree, order, d_priority);
+    int rounds = 0;
+    for (unsigned remaining = 1; remaining != 0; ++rounds) {
+        if (rounds > count) { release(); return fail(BEPUHIP_E_DEVICE, "colour_constraints made no progress"); }  // every round colours at least the highest bid
+        hipMemsetAsync(d_best, 0, nb * 8, 0);
+        hipMemsetAsync(d_remaining, 0, 4, 0);
+        hipLaunchKernelGGL(colour_bid_kernel, grid, block, 0, 0, (const int*)d_refs, count, (const int*)d_colour, (const unsigned long long*)d_priority, d_best);
+        hipLaunchKernelGGL(colour_pick_kernel, grid, block, 0, 0, (const int*)d_refs, count, d_colour, (const unsigned long long*)d_priority, (const unsigned long long*)d_best, d_used,
+                           fallback_batch_threshold, d_remaining);
+        e = hipMemcpy(&remaining, d_remaining, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { release(); return fail(BEPUHIP_E_DEVICE, std::string("colour_constraints: ") + hipGetErrorString(e)); }
+    }
+    e = hipMemcpy(colours_out, d_colour, (size_t)count * 4, hipMemcpyDeviceToHost);
+    release();
+    if (e != hipSuccess) return fail(BEPUHIP_E_DEVICE, std::string("colour_constraints: ") + hipGetErrorString(e));
+    int highest = -1;
+    for (int i = 0; i < count; ++i) highest = std::max(highest, colours_out[i]);
+    if (batch_count_out) *batch_count_out = highest + 1;
+    if (rounds_out) *rounds_out = rounds;
     return BEPUHIP_OK;
 }
 

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_get_stream", "bepuhip_solve_async", "bepuhip_sync", "bepuhip_reset_state", "bepuhip_type_info",
     "bepuhip_set_cluster_trace", "bepuhip_get_cluster_trace", "bepuhip_get_cluster_cycles", "bepuhip_debug_status",
     "bepuhip_set_boundary_bodies", "bepuhip_boundary_deltas", "bepuhip_boundary_apply", "bepuhip_solve_exchanged",
-    "bepuhip_set_exchange_mode", "bepuhip_set_boundary_layout", "bepuhip_comm_unique_id", "bepuhip_comm_init", "bepuhip_comm_adopt", "bepuhip_solve_lattice",
+    "bepuhip_colour_constraints", "bepuhip_set_exchange_mode", "bepuhip_set_boundary_layout", "bepuhip_comm_unique_id", "bepuhip_comm_init", "bepuhip_comm_adopt", "bepuhip_solve_lattice",
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
     "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables",
@@ -102,6 +102,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_boundary_deltas.argtypes = [vp, vp, i32]
     lib.bepuhip_boundary_apply.argtypes = [vp, vp, i32]
     lib.bepuhip_set_exchange_mode.argtypes = [vp, i32]
+    lib.bepuhip_colour_constraints.argtypes = [i32, vp, i32, i32, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
     lib.bepuhip_set_boundary_layout.argtypes = [vp, vp, i32, vp]
     lib.bepuhip_comm_unique_id.argtypes = [vp]
     lib.bepuhip_comm_init.argtypes = [vp, vp, i32, i32]

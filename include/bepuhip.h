@@ -101,6 +101,19 @@ int32_t bepuhip_boundary_apply(bepuhip_ctx* ctx, const float* summed_deltas, int
 int32_t bepuhip_solve_exchanged(bepuhip_ctx* ctx, float dt, int32_t substep_count, const int32_t* velocity_iterations, const bepuhip_integrator* integrator,
                                 bepuhip_exchange_fn fn, void* user);
 
+/* ---- Batch colouring on the device ----
+ * Bulk counterpart of the reference's incremental colouring: Solver.Add's first-fit walk over the batches (BepuPhysics/Solver.cs:984-1014, :1182-1199) and
+ * BatchCompressor's later moves into earlier batches (BepuPhysics/BatchCompressor.cs:233). `refs` = count x 4 encoded body references (-1 = unused slot; bit 30 =
+ * kinematic: never a conflict, Solver.cs:1002), in the order the constraints were added. colours_out[i] = batch index of constraint i: no two constraints of
+ * a batch share a dynamic body; a constraint none of the first `fallback_batch_threshold` (<= 64) batches can take gets fallback_batch_threshold (the sequential
+ * fallback batch, Solver.cs:1878-1884).
+ *   order 0  insertion order: exactly the batches the reference's Solver.Add produces for the same sequence of adds (first fit, earlier constraints first)
+ *   order 1  largest body degree first: the usual way to get closer to the lower bound, which is the largest number of constraints on any one dynamic body
+ * The colouring changes the order in which a body's constraints are applied, hence the solve's result: the host adopts it for its own buffers (or for the oracle in
+ * the parity tests) before uploading the type batches it implies. Stand-alone: needs no context. */
+int32_t bepuhip_colour_constraints(int32_t device, const int32_t* refs, int32_t count, int32_t body_count, int32_t order, int32_t fallback_batch_threshold,
+                                   int32_t* colours_out, int32_t* batch_count_out, int32_t* rounds_out);
+
 /* Exchange modes ("keep exchange frequency configurable (per batch = exact ordering ...)").
  *   PER_PASS_AVERAGE  the default described above: one exchange per pass, float deltas, mass-split copies averaged. Not bit-identical to one GPU.
  *   PER_BATCH_EXACT   one exchange after EVERY batch of every pass. The shares keep the reference's batch indices, and a batch references a body at most once
