@@ -23,8 +23,8 @@ namespace {
 // Deadlock freedom: items are claimed in a topological order and a wave holds one item at a time, so the earliest unfinished
 // item always has all its predecessors finished.
 //
-// LDS: [6 planes of float4 x ncap body slots: the fields of the BodyDynamics record the sweeps touch (the local inertia stays in memory), one plane per
-// 16-byte field][work items][flags, counters].
+// LDS: [6 or 8 planes of float4 x ncap body slots: the fields of the BodyDynamics record the sweeps touch, then (if the cluster leaves room) the local inertia,
+// one plane per 16-byte field][work items][flags, counters].
 // Slot numbering is rotated by the host inside every group of 16 (slot = (i & ~15) | ((i + (i >> 4)) & 15)) so that the regular
 // "same joint of consecutive ragdolls" access pattern (lane stride = island size) spreads over all 16 bank slots of ds_read_b128.
 // ------------------------------------------------------------------------------------------------
@@ -34,7 +34,7 @@ typedef __attribute__((address_space(1))) int gint;
 typedef __attribute__((address_space(3))) unsigned lds_u32;  // LDS: ds_read/ds_write, lgkmcnt only (a generic pointer would poll with flat loads and drag vmcnt in)
 
 struct ClusterShared {
-    float4* planes;        // [kPlanes][ncap]
+    float4* planes;        // [cp.planes][ncap]
     int ncap;
     ClusterItem* items;
     volatile lds_u32* flags;  // per item: epoch of the last completed pass
@@ -535,8 +535,8 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     ClusterShared sh;
     sh.planes = lds;
     sh.ncap = ncap;
-    sh.items = reinterpret_cast<ClusterItem*>(lds + kPlanes * ncap);
-    unsigned* words = reinterpret_cast<unsigned*>(lds + kPlanes * ncap + max_items * (int)(sizeof(ClusterItem) / 16));
+    sh.items = reinterpret_cast<ClusterItem*>(lds + cp.planes * ncap);
+    unsigned* words = reinterpret_cast<unsigned*>(lds + cp.planes * ncap + max_items * (int)(sizeof(ClusterItem) / 16));
     sh.flags = (volatile lds_u32*)words;
     sh.batch_done = (lds_u32*)(words + max_items);
     sh.lbib = reinterpret_cast<int*>(words + max_items + kFallbackBatchLimit + 1);
@@ -552,10 +552,10 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     const float dt = cp.sp.dt, inv_dt = cp.sp.inv_dt;
     const int* slots = cluster_bodies + cd.body_begin;  // slot -> body index (bit 30: kinematic, private read-only copy; -1: unused slot)
     // ---- stage the cluster in LDS: bodies (one plane per 16-byte field), work items, batch -> item ranges; clear the sync words ----
-    for (int j = tid; j < cd.slot_count * kPlanes; j += blockDim.x) {
-        const int slot = j / kPlanes, v = j - slot * kPlanes;
+    for (int j = tid; j < cd.slot_count * cp.planes; j += blockDim.x) {
+        const int slot = j / cp.planes, v = j - slot * cp.planes;
         const int g = slots[slot];
-        lds[v * ncap + slot] = g >= 0 ? bodies[(size_t)(g & kSlotBodyMask) * 8 + (v < 4 ? v : v + 2)] : make_float4(0, 0, 0, 0);  // record fields 4, 5 (local inertia) stay in memory
+        lds[v * ncap + slot] = g >= 0 ? bodies[(size_t)(g & kSlotBodyMask) * 8 + (v < 4 ? v : (v < 6 ? v + 2 : v - 2))] : make_float4(0, 0, 0, 0);  // planes 4, 5 = record fields 6, 7 (world inertia); planes 6, 7 (if present) = fields 4, 5 (local inertia)
     }
     {
         const int4* src = reinterpret_cast<const int4*>(items + cd.item_begin);
@@ -609,7 +609,8 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 r[ncap] = make_float4(pos.x, pos.y, pos.z, p4.w);
             }
             if ((unsigned)(g & ~(kSlotSharedHome | kSlotGhost)) < kDynamicLimit) {
-                const float4 i0 = bodies[(size_t)body * 8 + 4], i1 = bodies[(size_t)body * 8 + 5];  // local inverse inertia and mass: constant over the step, read where needed
+                // local inverse inertia and mass: constant over the step; in LDS when the cluster left room for the two planes, else read where needed
+                const float4 i0 = cp.planes == kAllPlanes ? r[6 * ncap] : bodies[(size_t)body * 8 + 4], i1 = cp.planes == kAllPlanes ? r[7 * ncap] : bodies[(size_t)body * 8 + 5];
                 Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
                 Sym3 world = rotateInverseInertia(local, ori);
                 r[4 * ncap] = make_float4(world.xx, world.yx, world.yy, world.zx);

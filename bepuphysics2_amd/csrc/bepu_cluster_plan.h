@@ -17,6 +17,7 @@ struct ClusterPlan {
     std::vector<ClusterItem> items;
     std::vector<int> batch_item_begin, cluster_bodies, clustered_dynamic, kinlist;
     int max_slots = 0, max_items = 0;
+    int planes = kAllPlanes;  // LDS planes per body slot: all eight fields when they fit, else the six the sweeps touch (the local inertia is then read from memory)
 };
 
 static int env_int(const char* name, int fallback) {
@@ -25,8 +26,8 @@ static int env_int(const char* name, int fallback) {
 }
 
 constexpr size_t kLdsBudgetBytes = 160 * 1024 - 256;
-static size_t cluster_lds_bytes(int ncap, int max_items, bool shared = false) {  // shared plans keep a slot -> body table in LDS too
-    return (size_t)kPlanes * ncap * 16 + (size_t)max_items * sizeof(ClusterItem) + (cluster_sync_words(max_items) + 3) / 4 * 16 + (shared ? ((size_t)ncap * 4 + 15) / 16 * 16 : 0);
+static size_t cluster_lds_bytes(int planes, int ncap, int max_items, bool shared = false) {  // shared plans keep a slot -> body table in LDS too
+    return (size_t)planes * ncap * 16 + (size_t)max_items * sizeof(ClusterItem) + (cluster_sync_words(max_items) + 3) / 4 * 16 + (shared ? ((size_t)ncap * 4 + 15) / 16 * 16 : 0);
 }
 // Slot rotation inside every group of 16 (see the LDS layout note above cluster_kernel).
 static inline int rotated_slot(int i) { return (i & ~15) | ((i + (i >> 4)) & 15); }
@@ -126,7 +127,8 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
             max_slots = std::max(max_slots, (dyn_count[cl] + (int)kin_seen[cl].size() + 15) / 16 * 16);
             max_items = std::max(max_items, item_count[cl]);
         }
-        if (max_items < 65536 && cluster_lds_bytes(max_slots, max_items) <= kLdsBudgetBytes) break;
+        if (max_items < 65536 && cluster_lds_bytes(plan.planes, max_slots, max_items) <= kLdsBudgetBytes) break;
+        if (plan.planes == kAllPlanes) { plan.planes = kSweepPlanes; continue; }  // leave the local inertia in memory before giving up cluster size
         if (cap <= largest || attempt > 24) {  // an island (plus its work items) does not fit one workgroup: cut it (shared bodies), or leave it to the global path
             plan_split_clusters(c, plan, universe);
             return;
@@ -265,7 +267,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         plan.max_slots = std::max(plan.max_slots, d.slot_count);
         plan.max_items = std::max(plan.max_items, d.item_count);
     }
-    plan.enabled = nclusters > 0 && cluster_lds_bytes(plan.max_slots, plan.max_items) <= kLdsBudgetBytes;
+    plan.enabled = nclusters > 0 && cluster_lds_bytes(plan.planes, plan.max_slots, plan.max_items) <= kLdsBudgetBytes;
 }
 
 
@@ -423,10 +425,11 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             max_slots = std::max(max_slots, ((int)cl_bodies[cl].size() + 15) / 16 * 16);
             max_items = std::max(max_items, item_count[cl]);
         }
-        if (max_slots >= 0x4000 || max_items >= 65536 || cluster_lds_bytes(max_slots, max_items, true) > kLdsBudgetBytes) {
+        plan.planes = cluster_lds_bytes(kAllPlanes, max_slots, max_items, true) <= kLdsBudgetBytes ? kAllPlanes : kSweepPlanes;
+        if (max_slots >= 0x4000 || max_items >= 65536 || cluster_lds_bytes(plan.planes, max_slots, max_items, true) > kLdsBudgetBytes) {
             if (env_int("BEPUHIP_PLAN_STATS", 0))
                 fprintf(stderr, "bepuhip split plan: declined, %d clusters (region %d) would need %d slots and %d items = %zu B of LDS per workgroup (budget %zu)\n", nclusters, region,
-                        max_slots, max_items, cluster_lds_bytes(max_slots, max_items, true), kLdsBudgetBytes);
+                        max_slots, max_items, cluster_lds_bytes(plan.planes, max_slots, max_items, true), kLdsBudgetBytes);
             return;
         }
     }
@@ -566,9 +569,10 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     plan.shared_info.assign(universe, 0u);
     for (int i = 0; i < universe; ++i) if (shared[i]) { plan.shared_info[i] = (uint32_t)deg[i]; ++shared_count; }
     plan.shared = true;
-    plan.enabled = nclusters > 0 && plan.max_slots < 0x4000 && cluster_lds_bytes(plan.max_slots, plan.max_items, true) <= kLdsBudgetBytes;
+    plan.planes = cluster_lds_bytes(kAllPlanes, plan.max_slots, plan.max_items, true) <= kLdsBudgetBytes ? kAllPlanes : kSweepPlanes;
+    plan.enabled = nclusters > 0 && plan.max_slots < 0x4000 && cluster_lds_bytes(plan.planes, plan.max_slots, plan.max_items, true) <= kLdsBudgetBytes;
     if (env_int("BEPUHIP_PLAN_STATS", 0))
         fprintf(stderr, "bepuhip split plan: %d clusters (region %d), %lld dynamic bodies, %lld shared (%.1f %%), %lld ghost slots, max slots %d, max items %d, LDS %zu B, enabled %d\n", nclusters,
                 region, (long long)total_dyn, (long long)shared_count, 100.0 * shared_count / std::max<int64_t>(total_dyn, 1), (long long)ghost_slots, plan.max_slots, plan.max_items,
-                cluster_lds_bytes(plan.max_slots, plan.max_items, true), (int)plan.enabled);
+                cluster_lds_bytes(plan.planes, plan.max_slots, plan.max_items, true), (int)plan.enabled);
 }

@@ -142,7 +142,7 @@ struct bepuhip_ctx {
     unsigned* d_shared_info = nullptr;
     size_t shared_bodies = 0;         // table length (bodies)
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
-    int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0;
+    int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0, cluster_planes = 8;
     ClusterDesc first_cluster = {0, 0, 0, 0, 0};
     int* d_requirk = nullptr;            // conserving angular modes: per batch, the bodies momentum_requirk_kernel transforms in substep 0
     std::vector<int> requirk_begin;     // batch -> offset into d_requirk (batch_count + 1 entries)

@@ -53,13 +53,15 @@ constexpr int kSlotBodyMask = (1 << 28) - 1;
 // waits for "its" n and leaves n + 1 with the velocity it wrote. `info[body]` = d. `vel` is zeroed before every launch.
 struct SharedTables { float4* vel; const unsigned* info; int poll_sleep; };  // poll_sleep: 64-clock naps between two polls of a record
 constexpr unsigned kLrefShared = 0x4000u;  // bit 14 of a 16-bit local reference: velocity through the shared table (bit 15 = kinematic copy, bits 0-13 slot)
-constexpr int kPlanes = 6;            // LDS body table: one plane per 16-byte field of BodyDynamics the sweeps touch (orientation, position, linear, angular, world inertia x 2)
+constexpr int kSweepPlanes = 6;       // LDS body table: one plane per 16-byte field of BodyDynamics the sweeps touch (orientation, position, linear, angular, world inertia x 2)
+constexpr int kAllPlanes = 8;         // ... plus the local inertia (read once per substep by the integration phase) when the cluster leaves room for it; otherwise that stays in memory
 constexpr int kClusterThreads = 1024;  // default threads per cluster workgroup
 constexpr int kSplitClusterThreads = 512;  // split-island plans: the shared-body code needs the 256-VGPR budget to stay out of scratch (spills sit on every hand-off's critical path)
 constexpr int kMaxClusterSubsteps = 16;
 constexpr int kClusterTracePasses = kMaxClusterSubsteps * 8;  // passes (warm starts + velocity iterations) the cluster trace buffer holds; later passes are not recorded
 struct ClusterParams {
     int substeps, batch_count, integrate_velocity_for_kinematics;
+    int planes;  // kSweepPlanes or kAllPlanes
     int iters[kMaxClusterSubsteps];
     StepParams sp;
 };

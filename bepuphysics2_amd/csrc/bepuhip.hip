@@ -465,6 +465,7 @@ static int32_t build_constraints(bepuhip_ctx* c) {
     if (plan.enabled) {
         c->cluster_count = (int)plan.clusters.size();
         c->cluster_max_slots = plan.max_slots;
+        c->cluster_planes = plan.planes;
         HIP_TRY(hipMalloc((void**)&c->d_cycles, plan.clusters.size() * 8));
         HIP_TRY(hipMemset(c->d_cycles, 0, plan.clusters.size() * 8));
         c->first_cluster = plan.clusters[0];
@@ -556,7 +557,7 @@ static void enqueue_requirk(bepuhip_ctx* c, int substep, int batch, const StepPa
 
 // The island schedule implements AngularIntegrationMode.Nonconserving; the conserving modes run the launch-per-batch schedule.
 static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
-    return c->clusters_enabled && substeps <= kMaxClusterSubsteps && cluster_lds_bytes(c->cluster_max_slots, c->cluster_max_items, c->clusters_shared) <= kLdsBudgetBytes &&
+    return c->clusters_enabled && substeps <= kMaxClusterSubsteps && cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared) <= kLdsBudgetBytes &&
            in->angular_integration_mode == 0;
 }
 // Enqueue every kernel of one Simulation.Solve on the context's stream (Solver_Solve.cs:1415-1479 + PoseIntegrator.cs:707-726).
@@ -565,13 +566,14 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
     const float inv_dt = 1.0f / substep_dt;          // :1421
     const StepParams sp = make_params(in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
-    const size_t lds_bytes = cluster_lds_bytes(c->cluster_max_slots, c->cluster_max_items, c->clusters_shared);
+    const size_t lds_bytes = cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared);
     const bool use_clusters = island_schedule_applies(c, substeps, in);
     const int skip_clustered = use_clusters ? 1 : 0;
     if (use_clusters) {
         // Every constraint belongs to an island small enough for one workgroup: the whole substep loop runs in ONE launch.
         ClusterParams cp;
         cp.substeps = substeps; cp.batch_count = c->batch_count; cp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
+        cp.planes = c->cluster_planes;
         for (int s = 0; s < kMaxClusterSubsteps; ++s) cp.iters[s] = s < substeps ? iterations[s] : 0;
         cp.sp = sp;
         {
