@@ -29,6 +29,11 @@ namespace {
 // "same joint of consecutive ragdolls" access pattern (lane stride = island size) spreads over all 16 bank slots of ds_read_b128.
 // ------------------------------------------------------------------------------------------------
 
+#ifndef BEPU_VARIANT_NT
+#define BEPU_VARIANT_NT 0
+#endif
+constexpr bool kRowsNonTemporal = BEPU_VARIANT_NT != 0;  // one- and two-body constraint rows loaded with the non-temporal hint (they stream: 70 MB per pass, no reuse)
+
 typedef __attribute__((address_space(1))) float gfloat;  // global
 typedef __attribute__((address_space(1))) int gint;
 typedef __attribute__((address_space(3))) unsigned lds_u32;  // LDS: ds_read/ds_write, lgkmcnt only (a generic pointer would poll with flat loads and drag vmcnt in)
@@ -379,8 +384,13 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
         sa = make_shared_ref<STAGE == kStageIncremental>(sh, both & 0xFFFFu, (unsigned)srank[i], active);
         if (F::bodies == 2) sb = make_shared_ref<STAGE == kStageIncremental>(sh, both >> 16, (unsigned)srank[(size_t)stride + i], active);
     }
-    _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
-    if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
+    if (kRowsNonTemporal) {  // per translation unit (BEPU_VARIANT_NT): the constraint rows are read once per pass; see the note on box classes in DESIGN.md 5
+        _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = __builtin_nontemporal_load(&prestep[(size_t)f * stride + i]);
+        if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = __builtin_nontemporal_load(&accum[(size_t)f * stride + i]); }
+    } else {
+        _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
+        if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
+    }
     DBody A, B;
     if (STAGE == kStageIncremental) {  // reads velocities, writes only this constraint's depths: no ordering inside the stage
         load_body_lds<kAccessOnlyVelocity>(sh, ra, A);

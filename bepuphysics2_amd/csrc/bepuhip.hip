@@ -123,6 +123,7 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_boundary_buf) hipFree(c->d_boundary_buf);
     free_boundary_layout(c);
     release_comm(c);
+    for (auto& pair : c->policy_events) { if (pair[0]) hipEventDestroy(pair[0]); if (pair[1]) hipEventDestroy(pair[1]); }
     if (c->ev_start) hipEventDestroy(c->ev_start);
     if (c->ev_stop) hipEventDestroy(c->ev_stop);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -486,6 +487,10 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             for (int tr = 0; tr < 2; ++tr)
                 for (int wide = 0; wide < 2; ++wide)
                     HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(threads, tr != 0, wide != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        for (int tr = 0; tr < 2; ++tr)
+            for (int wide = 0; wide < 2; ++wide)
+                HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(1024, tr != 0, wide != 0, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        c->row_policy = -1; c->policy_samples = 0;  // a new topology is measured afresh
         c->clusters_shared = plan.shared;
         if (plan.shared) {  // split islands: velocity / event tables of the bodies more than one cluster touches (indexed by body, only the shared ones are used)
             c->shared_bodies = plan.shared_info.size();
@@ -555,6 +560,27 @@ static void enqueue_requirk(bepuhip_ctx* c, int substep, int batch, const StepPa
         hipLaunchKernelGGL(momentum_requirk_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_bodies, (const int*)(c->d_requirk + c->requirk_begin[batch]), n, sp);
 }
 
+// Row-load policy (bepu_host_state.h): once kPolicySamples solves have been launched, wait for the last of them, compare the medians, keep the faster variant.
+constexpr int kPolicySamples = 12;
+static void settle_row_policy(bepuhip_ctx* c) {
+    const int pinned = env_int("BEPUHIP_ROW_POLICY", -1);
+    if (pinned == 0 || pinned == 1) { c->row_policy = pinned; return; }
+    if (!c->policy_events[0][0])
+        for (auto& pair : c->policy_events) { hipEventCreate(&pair[0]); hipEventCreate(&pair[1]); }
+    if (c->policy_samples < kPolicySamples) return;
+    hipEventSynchronize(c->policy_events[kPolicySamples - 1][1]);
+    std::vector<float> ms[2];
+    for (int i = 2; i < kPolicySamples; ++i) {  // the first pair of solves warms clocks and caches
+        float t = 0;
+        if (hipEventElapsedTime(&t, c->policy_events[i][0], c->policy_events[i][1]) == hipSuccess) ms[i & 1].push_back(t);
+    }
+    for (auto& v : ms) std::sort(v.begin(), v.end());
+    c->row_policy = (!ms[0].empty() && !ms[1].empty() && ms[1][ms[1].size() / 2] < ms[0][ms[0].size() / 2]) ? 1 : 0;
+    if (env_int("BEPUHIP_PLAN_STATS", 0))
+        fprintf(stderr, "bepuhip row policy: plain %.4f ms, non-temporal %.4f ms per launch (medians of %zu) -> %s\n", ms[0].empty() ? 0.f : ms[0][ms[0].size() / 2],
+                ms[1].empty() ? 0.f : ms[1][ms[1].size() / 2], ms[0].size(), c->row_policy ? "non-temporal" : "plain");
+}
+
 // The island schedule implements AngularIntegrationMode.Nonconserving; the conserving modes run the launch-per-batch schedule.
 static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
     return c->clusters_enabled && substeps <= kMaxClusterSubsteps && cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared) <= kLdsBudgetBytes &&
@@ -596,8 +622,18 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
                             (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
             const bool tr = c->d_trace != nullptr;
-            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared);  // the register budget that matches the workgroup size
+            const bool policy_applies = !c->clusters_shared && cluster_variant_threads(threads) == 1024;
+            int sample = -1;
+            bool nt = false;
+            if (policy_applies) {
+                if (c->row_policy < 0) settle_row_policy(c);
+                if (c->row_policy < 0) { sample = c->policy_samples++; nt = (sample & 1) != 0; }  // plain, non-temporal, plain, ... each under its own event pair
+                else nt = c->row_policy == 1;
+            }
+            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt);  // the register budget that matches the workgroup size
+            if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
             hipLaunchKernel(fn, dim3(c->cluster_count + tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0)), dim3(threads), args, lds_bytes, c->stream);
+            if (sample >= 0) hipEventRecord(c->policy_events[sample][1], c->stream);
         }
     }
     for (int s = 0; s < substeps && !use_clusters; ++s) {
