@@ -375,7 +375,7 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     float p[F::prestepFloats];
     float a[F::impulseFloats];
     // issue the item's global loads first: their latency hides under the velocity-independent work and the wait for the predecessors
-    const unsigned both = (unsigned)lrefs[i];  // two 16-bit local references per word
+    const unsigned both = kRowsNonTemporal ? (unsigned)__builtin_nontemporal_load(&lrefs[i]) : (unsigned)lrefs[i];  // two 16-bit local references per word
     const int ra = unpack_local_ref(both & 0xFFFFu);
     const int rb = (F::bodies == 2) ? unpack_local_ref(both >> 16) : -1;
     SharedRef sa = {-1, 0u}, sb = {-1, 0u};
@@ -402,7 +402,12 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
         }
         F::incrementalUpdate(dt, A.vel, B.vel, p);
         if constexpr (F::incremental) {
-            if (active) { _Pragma("unroll") for (int cidx = 0; cidx < F::contacts; ++cidx) prestep[(size_t)F::depthRow(cidx) * stride + i] = p[F::depthRow(cidx)]; }
+            if (active) {
+                _Pragma("unroll") for (int cidx = 0; cidx < F::contacts; ++cidx) {
+                    if (kRowsNonTemporal) __builtin_nontemporal_store(p[F::depthRow(cidx)], &prestep[(size_t)F::depthRow(cidx) * stride + i]);
+                    else prestep[(size_t)F::depthRow(cidx) * stride + i] = p[F::depthRow(cidx)];
+                }
+            }
         }
         return;
     }
@@ -426,7 +431,7 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     publish_item(sh.flags + k, sh.batch_done + h.batch, epoch);
     __builtin_amdgcn_s_setprio(0);
     if (STAGE == kStageSolve && active) {  // off the critical path: nothing reads the impulses before the next pass (a barrier away)
-        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) accum[(size_t)f * stride + i] = a[f];
+        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) { if (kRowsNonTemporal) __builtin_nontemporal_store(a[f], &accum[(size_t)f * stride + i]); else accum[(size_t)f * stride + i] = a[f]; }
     }
 }
 
