@@ -12,6 +12,8 @@ const void* bepu_cluster_kernel_wide_768(bool trace);
 const void* bepu_cluster_kernel_wide_512(bool trace);
 const void* bepu_cluster_kernel_hot_1024n(bool trace);   // non-temporal row loads (whole-island plans, 1024 threads)
 const void* bepu_cluster_kernel_wide_1024n(bool trace);
+const void* bepu_cluster_kernel_hot_512sn(bool trace);   // non-temporal row loads, split-island plans (512 threads)
+const void* bepu_cluster_kernel_wide_512sn(bool trace);
 const void* bepu_cluster_kernel_hot_1024s(bool trace);   // split-island plans (shared bodies)
 const void* bepu_cluster_kernel_wide_1024s(bool trace);
 const void* bepu_cluster_kernel_hot_768s(bool trace);
@@ -22,6 +24,7 @@ constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
 static int cluster_variant_threads(int threads) { return threads > 768 ? 1024 : (threads > 512 ? 768 : 512); }  // the smallest budget that still fits `threads`
 static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false) {
     if (nt && !shared && cluster_variant_threads(threads) == 1024) return wide ? bepu_cluster_kernel_wide_1024n(trace) : bepu_cluster_kernel_hot_1024n(trace);
+    if (nt && shared && cluster_variant_threads(threads) == 512) return wide ? bepu_cluster_kernel_wide_512sn(trace) : bepu_cluster_kernel_hot_512sn(trace);
     if (shared) switch (cluster_variant_threads(threads)) {
         case 1024: return wide ? bepu_cluster_kernel_wide_1024s(trace) : bepu_cluster_kernel_hot_1024s(trace);
         case 768: return wide ? bepu_cluster_kernel_wide_768s(trace) : bepu_cluster_kernel_hot_768s(trace);
@@ -140,7 +143,7 @@ struct bepuhip_ctx {
     int referenced_bodies = 0;           // 1 + the largest body index any constraint references
     // cluster path
     bool clusters_enabled = false;
-    // Row-load policy of the whole-island schedule (plain or non-temporal loads of the constraint rows). Which one is faster depends on the box: the
+    // Row-load policy of the island schedule's default workgroup sizes (plain or non-temporal accesses to the constraint rows). Which one is faster depends on the box: the
     // first solves alternate between the two — their results are bit-identical — each timed with its own event pair, then the faster one stays.
     int row_policy = -1;              // -1: still measuring; 0 plain; 1 non-temporal (BEPUHIP_ROW_POLICY=0/1 pins it)
     int policy_samples = 0;           // solves launched while measuring

@@ -488,8 +488,10 @@ static int32_t build_constraints(bepuhip_ctx* c) {
                 for (int wide = 0; wide < 2; ++wide)
                     HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(threads, tr != 0, wide != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
         for (int tr = 0; tr < 2; ++tr)
-            for (int wide = 0; wide < 2; ++wide)
+            for (int wide = 0; wide < 2; ++wide) {
                 HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(1024, tr != 0, wide != 0, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+                HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(512, tr != 0, wide != 0, true, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+            }
         c->row_policy = -1; c->policy_samples = 0;  // a new topology is measured afresh
         c->clusters_shared = plan.shared;
         if (plan.shared) {  // split islands: velocity / event tables of the bodies more than one cluster touches (indexed by body, only the shared ones are used)
@@ -622,7 +624,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
                             (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
             const bool tr = c->d_trace != nullptr;
-            const bool policy_applies = !c->clusters_shared && cluster_variant_threads(threads) == 1024;
+            const bool policy_applies = cluster_variant_threads(threads) == (c->clusters_shared ? 512 : 1024);  // the variants that exist in both row policies
             int sample = -1;
             bool nt = false;
             if (policy_applies) {
