@@ -498,6 +498,7 @@ def main():
         baseline = cpu_baseline(args.ragdolls, 5)  # the same scene as the GPU leg; bounded by time (about 12 s after picking the thread count)
 
     main_clustered = bool(solver.cluster_cycles().size)
+    row_policy = {-1: "still measuring", 0: "plain", 1: "non-temporal"}[solver.row_policy()] if main_clustered else None
     connected = None
     if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
         solver.close()
@@ -525,6 +526,7 @@ def main():
                                    if (world > 1 or dist is not None) else "single GPU",
                        "schedule": "island-per-workgroup: one plain kernel launch per step" if main_clustered else
                                    ("launch-per-batch" + ("" if args.no_graph else ", hipGraph replay")),
+                       "row_policy": row_policy and f"{row_policy} constraint-row accesses, picked from the timings of the first twelve solves after the upload (both builds bit-identical; DESIGN.md 5)",
                        "device_prewarm": f"{prewarm_steps} untimed solves during setup, uploaded state restored before the {args.warmup} warm-up steps",
                        "finite": finite},
             "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "boundary": boundary, "lattice": lattice_report,

@@ -1520,6 +1520,13 @@ int32_t bepuhip_get_cluster_trace(bepuhip_ctx* c, uint64_t* out, int64_t capacit
     *items_out = c->first_cluster.item_count;
     return BEPUHIP_OK;
 }
+int32_t bepuhip_get_row_policy(bepuhip_ctx* c, int32_t* policy_out) {
+    if (!c || !policy_out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    if (c->row_policy < 0 && c->policy_samples >= kPolicySamples) settle_row_policy(c);
+    *policy_out = c->row_policy;
+    return BEPUHIP_OK;
+}
+
 int32_t bepuhip_get_cluster_cycles(bepuhip_ctx* c, uint64_t* out, int32_t capacity, int32_t* count_out) {
     if (!c || !count_out || (capacity > 0 && !out)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
     *count_out = c->clusters_enabled ? c->cluster_count : 0;

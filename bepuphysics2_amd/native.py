@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_get_bodies", "bepuhip_get_accumulated_impulses", "bepuhip_get_prestep", "bepuhip_get_constrained_flags",
     "bepuhip_last_solve_ms", "bepuhip_set_profiling", "bepuhip_get_profile", "bepuhip_last_constraint_iterations",
     "bepuhip_get_stream", "bepuhip_solve_async", "bepuhip_sync", "bepuhip_reset_state", "bepuhip_type_info",
-    "bepuhip_set_cluster_trace", "bepuhip_get_cluster_trace", "bepuhip_get_cluster_cycles", "bepuhip_debug_status",
+    "bepuhip_set_cluster_trace", "bepuhip_get_cluster_trace", "bepuhip_get_cluster_cycles", "bepuhip_get_row_policy", "bepuhip_debug_status",
     "bepuhip_set_boundary_bodies", "bepuhip_boundary_deltas", "bepuhip_boundary_apply", "bepuhip_solve_exchanged",
     "bepuhip_colour_constraints", "bepuhip_set_exchange_mode", "bepuhip_set_boundary_layout", "bepuhip_comm_unique_id", "bepuhip_comm_init", "bepuhip_comm_adopt", "bepuhip_solve_lattice",
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
@@ -110,6 +110,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_solve_exchanged.argtypes = [vp, f32, i32, vp, C.POINTER(Integrator), EXCHANGE_FN, vp]
     lib.bepuhip_solve_lattice.argtypes = [vp, f32, i32, vp, C.POINTER(Integrator)]
     lib.bepuhip_get_cluster_cycles.argtypes = [vp, vp, i32, C.POINTER(i32)]
+    lib.bepuhip_get_row_policy.argtypes = [vp, C.POINTER(i32)]
     lib.bepuhip_debug_status.argtypes = [vp, vp]
     lib.bepuhip_get_cluster_trace.argtypes = [vp, vp, C.c_int64, C.POINTER(i32)]
     lib.bepuhip_type_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
@@ -418,6 +419,12 @@ class HipSolver:
             _check(self.lib, self.lib.bepuhip_get_profile(self.ctx, i, C.byref(ms), C.byref(n)))
             out[name] = (float(ms.value), int(n.value))
         return out
+
+    def row_policy(self) -> int:
+        """-1 still measuring, 0 plain, 1 non-temporal constraint-row accesses (island schedule; bepuhip.h)."""
+        v = C.c_int32(-1)
+        _check(self.lib, self.lib.bepuhip_get_row_policy(self.ctx, C.byref(v)))
+        return int(v.value)
 
     def cluster_cycles(self) -> np.ndarray:
         """Shader clocks per cluster of the last solve (empty when the launch-per-batch schedule ran)."""
