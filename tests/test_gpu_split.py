@@ -94,3 +94,31 @@ def test_split_plan_declines_what_it_does_not_cover(hip_solver_factory, monkeypa
     got = pu.run_hip(solver, scene, 1 / 60, sd, cb)
     assert solver.cluster_cycles().size == 0
     _exact(pu.compare_scenes(ref, got))
+
+
+@pytest.mark.parametrize("options", [dict(integrate_velocity_for_kinematics=True), dict(allow_substeps_for_unconstrained_bodies=True),
+                                     dict(gravity=(0.5, -3.0, 1.0), linear_damping=0.2, angular_damping=0.4)])
+def test_split_plan_honours_the_integrator_options(hip_solver_factory, monkeypatch, options):
+    """Kinematic bodies that move (and integrate their velocity), substepped unconstrained bodies, other gravity / damping: the split plan's integration phases
+    (home bodies, ghost copies, the folded-in kinematic and unconstrained workgroups) follow the same callbacks as the whole-island plan."""
+    monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "20")
+    scene = small_scenes.random_graph_scene(77, 5000, 12000, TWO_BODY_TYPES, kinematic_fraction=0.08, unconstrained_extra=40)
+    sd, cb = SolveDescription(2, 3), PoseIntegratorCallbacks(**options)
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+    assert solver.cluster_cycles().size > 1
+    _exact(pu.compare_scenes(ref, got))
+
+
+def test_split_plan_with_the_maximum_substep_count_and_long_iteration_schedules(hip_solver_factory, monkeypatch):
+    """Event numbers grow with substeps x passes x degree: eight substeps of up to five iterations on bodies with a dozen constraints each."""
+    monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "20")
+    scene = small_scenes.random_graph_scene(78, 3000, 16000, [22, 4, 30])
+    its = [5, 1, 3, 2, 4, 1, 1, 2]
+    sd, cb = SolveDescription(1, 8, velocity_iteration_scheduler=lambda s: its[s]), PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb)
+    assert solver.cluster_cycles().size > 1
+    _exact(pu.compare_scenes(ref, got))
