@@ -105,3 +105,38 @@ def test_new_batches_type_batches_and_capacity_growth(hip_solver_factory):
     # a body memory move: body 139 takes the slot of body 3 (BodySet.RemoveAt swap-with-last); its constraints' references are patched one by one
     with pytest.raises(ValueError):
         solver.remove_constraint(0, 7, 10_000)
+
+
+def test_structural_updates_after_frames_on_the_split_island_plan(hip_solver_factory, monkeypatch):
+    """One island too large for a workgroup: the first frames run the split-island plan (rows permuted per cluster, rank rows behind the local references), then the
+    narrow phase starts adding and removing — the context has to bring the rows back into the caller's order without losing what those frames accumulated."""
+    monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "12")
+    ms, rng, pair = _build(31, bodies=2600, joints=3000, contacts=5000)
+    sd, cb = SolveDescription(1, 4), PoseIntegratorCallbacks()
+    solver = hip_solver_factory()
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+    is_contact = lambda t: t in CONTACT_TYPES  # noqa: E731
+    for frame in range(8):
+        if frame >= 3:
+            for _ in range(20):
+                locs = ms.locations(is_contact)
+                bi, t, i = locs[int(rng.integers(len(locs)))]
+                ms.remove(bi, t, i)
+                solver.remove_constraint(bi, t, i)
+            for _ in range(20):
+                a, b = pair()
+                t = CONTACT_TYPES[int(rng.integers(len(CONTACT_TYPES)))]
+                lane = small_scenes.prestep_for(rng, t, ms.bodies[a, 4:7], ms.bodies[b, 4:7])
+                bi, index, encoded = ms.add(t, [a, b], lane)
+                assert solver.add_constraint(bi, t, encoded, lane) == index
+        export = ms.to_scene()
+        oracle_ffi.solve(export, 1 / 60, sd, cb, threads=4)
+        ms.absorb(export)
+        solver.solve(1 / 60, sd, cb)
+        if frame == 2:
+            assert solver.cluster_cycles().size > 1  # the split plan ran the first frames
+        got = ms.to_scene()
+        solver.download(got)
+        m = pu.compare_scenes(export, got)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (frame, m)
+    assert solver.cluster_cycles().size == 0
