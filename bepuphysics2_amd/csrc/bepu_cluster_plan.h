@@ -2,6 +2,8 @@
 #pragma once
 
 #include "bepu_host_state.h"
+#include <atomic>
+#include <thread>
 #include <unordered_map>
 
 // ---- cluster planning (host, once per topology upload) ----
@@ -86,6 +88,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     // ---- phase A: find a cap whose clusters fit the LDS budget (no mutation yet) ----
     std::vector<int32_t> cluster_of(universe, -1);  // by component root
     std::vector<std::vector<int32_t>> cl_of_constraint(c->tbs.size());
+    std::vector<std::vector<int32_t>> kin_lists;  // per cluster: the kinematic bodies its constraints reference (of the accepted attempt)
     int nclusters = 0;
     for (int attempt = 0;; ++attempt) {
         nclusters = 0;
@@ -97,7 +100,8 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
             cur += comp_size[i];
         }
         std::vector<int32_t> dyn_count(nclusters, 0), item_count(nclusters, 0);
-        std::vector<std::vector<int32_t>> kin_seen(nclusters);
+        std::vector<std::vector<int32_t>>& kin_seen = kin_lists;
+        kin_seen.assign(nclusters, {});
         for (int i = 0; i < universe; ++i) if (is_dyn[i]) dyn_count[cluster_of[parent[i]]]++;
         std::vector<int32_t> per_cluster(nclusters);
         for (size_t t = 0; t < c->tbs.size(); ++t) {
@@ -140,14 +144,11 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     std::vector<int32_t> local_of(universe, -1);
     for (int i = 0; i < universe; ++i)
         if (is_dyn[i]) { int cl = cluster_of[parent[i]]; local_of[i] = (int)cl_bodies[cl].size(); cl_bodies[cl].push_back(i); plan.clustered_dynamic.push_back(i); }
-    std::vector<std::vector<std::pair<int32_t, int32_t>>> cl_kin(nclusters);  // (kinematic body, natural local index)
-    auto kin_local = [&](int cl, int body) {
-        for (auto& kv : cl_kin[cl]) if (kv.first == body) return kv.second;
-        int l = (int)cl_bodies[cl].size();
-        cl_bodies[cl].push_back(body | (int)kDynamicLimit);
-        cl_kin[cl].push_back({body, l});
-        return l;
-    };
+    // Kinematic copies: slots behind the cluster's dynamic bodies, in the order phase A met them. Assigned before the rows are built so that building them
+    // (the bulk of this function's time: every prestep / impulse row of every type batch is permuted) can run on several threads.
+    std::vector<std::unordered_map<int32_t, int32_t>> cl_kin(nclusters);  // kinematic body -> natural local index
+    for (int cl = 0; cl < nclusters; ++cl)
+        for (int32_t body : kin_lists[cl]) { cl_kin[cl].emplace(body, (int)cl_bodies[cl].size()); cl_bodies[cl].push_back(body | (int)kDynamicLimit); }
     std::vector<std::vector<int32_t>> last_toucher(nclusters);  // by slot: cluster-relative index of the item that last touched the (dynamic) body
     for (int cl = 0; cl < nclusters; ++cl) last_toucher[cl].assign((cl_bodies[cl].size() + 15) / 16 * 16, -1);
     std::vector<std::vector<ClusterItem>> cl_items(nclusters);
@@ -162,26 +163,54 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
             if (x.batch != y.batch) return x.batch < y.batch;
             return x.info.prestep + 2 * x.info.impulse > y.info.prestep + 2 * y.info.impulse;
         });
+    // Rows of every type batch in cluster order (stable: inside a cluster the caller's order stays). Type batches are independent of each other here.
+    auto permute_type_batch = [&](size_t t) {
+        HostTypeBatch& tb = c->tbs[t];
+        const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
+        const std::vector<int32_t>& clc = cl_of_constraint[t];
+        std::vector<int32_t> begin(nclusters + 1, 0);  // counting sort by cluster
+        for (int i = 0; i < tb.count; ++i) ++begin[clc[i] + 1];
+        for (int cl = 0; cl < nclusters; ++cl) begin[cl + 1] += begin[cl];
+        tb.perm.resize(tb.count);
+        for (int i = 0; i < tb.count; ++i) tb.perm[begin[clc[i]]++] = i;
+        std::vector<int32_t> refs((size_t)nb * tb.stride, -1), lrefs((size_t)nb * tb.stride, -1);
+        std::vector<float> pre((size_t)pf * tb.stride, 0.0f), acc((size_t)imf * tb.stride, 0.0f);
+        for (int k = 0; k < nb; ++k) {
+            const int32_t* src = tb.refs_soa.data() + (size_t)k * tb.stride;
+            int32_t* dst = refs.data() + (size_t)k * tb.stride;
+            int32_t* ldst = lrefs.data() + (size_t)k * tb.stride;
+            for (int d = 0; d < tb.count; ++d) {
+                const int h = tb.perm[d];
+                const int32_t r = src[h];
+                dst[d] = r;
+                ldst[d] = ((uint32_t)r < kDynamicLimit) ? rotated_slot(local_of[r]) : (rotated_slot(cl_kin[clc[h]].find(r & kRefMask)->second) | (int)kDynamicLimit);
+            }
+        }
+        for (int f = 0; f < pf; ++f) {
+            const float* src = tb.prestep_soa.data() + (size_t)f * tb.stride;
+            float* dst = pre.data() + (size_t)f * tb.stride;
+            for (int d = 0; d < tb.count; ++d) dst[d] = src[tb.perm[d]];
+        }
+        for (int f = 0; f < imf; ++f) {
+            const float* src = tb.accum_soa.data() + (size_t)f * tb.stride;
+            float* dst = acc.data() + (size_t)f * tb.stride;
+            for (int d = 0; d < tb.count; ++d) dst[d] = src[tb.perm[d]];
+        }
+        tb.refs_soa.swap(refs); tb.prestep_soa.swap(pre); tb.accum_soa.swap(acc); tb.lrefs_soa.swap(lrefs);
+    };
+    {
+        const int workers = std::max(1, std::min<int>({env_int("BEPUHIP_PLAN_THREADS", 8), (int)std::thread::hardware_concurrency(), (int)c->tbs.size()}));
+        std::atomic<size_t> next{0};
+        auto work = [&]() { for (size_t t; (t = next.fetch_add(1)) < c->tbs.size();) permute_type_batch(t); };
+        std::vector<std::thread> pool;
+        for (int w = 1; w < workers; ++w) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+    }
     for (size_t t : visit) {
         HostTypeBatch& tb = c->tbs[t];
         const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
         const std::vector<int32_t>& clc = cl_of_constraint[t];
-        tb.perm.resize(tb.count);
-        for (int i = 0; i < tb.count; ++i) tb.perm[i] = i;
-        std::stable_sort(tb.perm.begin(), tb.perm.end(), [&](int a, int b) { return clc[a] < clc[b]; });
-        std::vector<int32_t> refs((size_t)nb * tb.stride, -1), lrefs((size_t)nb * tb.stride, -1);
-        std::vector<float> pre((size_t)pf * tb.stride, 0.0f), acc((size_t)imf * tb.stride, 0.0f);
-        for (int d = 0; d < tb.count; ++d) {
-            const int h = tb.perm[d], cl = clc[h];
-            for (int k = 0; k < nb; ++k) {
-                int32_t r = tb.refs_soa[(size_t)k * tb.stride + h];
-                refs[(size_t)k * tb.stride + d] = r;
-                lrefs[(size_t)k * tb.stride + d] = ((uint32_t)r < kDynamicLimit) ? rotated_slot(local_of[r]) : (rotated_slot(kin_local(cl, r & kRefMask)) | (int)kDynamicLimit);
-            }
-            for (int f = 0; f < pf; ++f) pre[(size_t)f * tb.stride + d] = tb.prestep_soa[(size_t)f * tb.stride + h];
-            for (int f = 0; f < imf; ++f) acc[(size_t)f * tb.stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
-        }
-        tb.refs_soa.swap(refs); tb.prestep_soa.swap(pre); tb.accum_soa.swap(acc); tb.lrefs_soa.swap(lrefs);
         for (int d = 0; d < tb.count;) {
             const int cl = clc[tb.perm[d]];
             int e = d;

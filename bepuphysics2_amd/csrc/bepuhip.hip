@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -376,6 +377,14 @@ static int32_t build_descriptors(bepuhip_ctx* c, const std::vector<std::vector<i
 }
 
 static int32_t build_constraints(bepuhip_ctx* c) {
+    const bool stats = env_int("BEPUHIP_PLAN_STATS", 0) != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!stats) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "bepuhip end_constraints: %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     size_t words = 0;
     c->total_constraints = 0;
     for (auto& tb : c->tbs)
@@ -426,8 +435,10 @@ static int32_t build_constraints(bepuhip_ctx* c) {
     std::vector<std::vector<int32_t>> fallback_refs;  // the fallback type batches' references (SoA rows), kept past the staging buffers for the level walk below
     if (c->has_fallback)
         for (auto& tb : c->tbs) if (tb.batch == c->fallback_threshold) fallback_refs.push_back(tb.refs_soa);
+    lap("checks, responsibility lists");
     ClusterPlan plan;
     plan_clusters(c, plan);
+    lap("cluster plan (host)");
     for (auto& tb : c->tbs) {
         tb.refs_off = words; words += tb.refs_soa.size();
         tb.prestep_off = words; words += tb.prestep_soa.size();
@@ -452,7 +463,9 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         HIP_TRY(hipMemcpy(c->d_slab, host.data(), words * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_slab0, c->d_slab, words * 4, hipMemcpyDeviceToDevice));
     }
+    lap("slab assembly + upload");
     { const int32_t st = build_descriptors(c, fallback_refs); if (st != BEPUHIP_OK) return st; }
+    lap("launch descriptors");
     // cluster path tables
     auto upload_ints = [&](const void* src, size_t bytes, void** dst) -> hipError_t {
         if (bytes == 0) return hipSuccess;
@@ -505,7 +518,10 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         }
     }
     c->built = true;
-    return rebuild_flags(c);
+    lap("plan tables upload");
+    const int32_t flags_status = rebuild_flags(c);
+    lap("body flags");
+    return flags_status;
 }
 
 int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* c, const int32_t* indices, int32_t count) {
