@@ -181,6 +181,9 @@ struct bepuhip_ctx {
     int clustered_dynamic_count = 0;
     CollidableIn* d_collidables = nullptr;  // device-resident collidable records (bepuhip_set_collidables)
     int collidable_count = 0;
+    float* d_hull_points = nullptr;  // convex hulls (bepuhip_set_convex_hulls): xyz triplets, and hull -> first point (hull_count + 1 entries)
+    int* d_hull_begin = nullptr;
+    int hull_count = 0;
     unsigned* d_staged = nullptr;   // island schedule: clusters that have staged their bodies in the current launch (see cluster_kernel's kinematic block)
     int* d_kinlist = nullptr;       // constrained kinematic body indices derived from the body references
     int kinlist_count = 0;

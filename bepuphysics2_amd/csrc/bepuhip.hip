@@ -118,6 +118,8 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_status) hipHostFree(c->d_status);
     if (c->d_staged) hipFree(c->d_staged);
     if (c->d_collidables) hipFree(c->d_collidables);
+    if (c->d_hull_points) hipFree(c->d_hull_points);
+    if (c->d_hull_begin) hipFree(c->d_hull_begin);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->d_boundary) hipFree(c->d_boundary);
     if (c->d_boundary_snapshot) hipFree(c->d_boundary_snapshot);
@@ -1443,15 +1445,40 @@ int32_t bepuhip_get_bodies_range(bepuhip_ctx* c, void* aos_out, int32_t first, i
 // ---- PredictBoundingBoxes on the device ----
 static_assert(sizeof(bepuhip_collidable) == sizeof(CollidableIn) && sizeof(bepuhip_collidable) == 64, "bepuhip_collidable layout");
 static_assert(sizeof(bepuhip_predicted_bounds) == sizeof(PredictedBounds) && sizeof(bepuhip_predicted_bounds) == 32, "bepuhip_predicted_bounds layout");
-static int32_t check_collidables(const bepuhip_collidable* collidables, int32_t count) {
-    for (int i = 0; i < count; ++i)
-        if (collidables[i].shape_type < -1 || collidables[i].shape_type > 4)
-            return fail(BEPUHIP_E_UNSUPPORTED, "shape type " + std::to_string(collidables[i].shape_type) + " (convex hulls, compounds and meshes stay on the host)");
+static int32_t check_collidables(const bepuhip_ctx* c, const bepuhip_collidable* collidables, int32_t count) {
+    for (int i = 0; i < count; ++i) {
+        if (collidables[i].shape_type < -1 || collidables[i].shape_type > 5)
+            return fail(BEPUHIP_E_UNSUPPORTED, "shape type " + std::to_string(collidables[i].shape_type) + " (compounds and meshes stay on the host)");
+        if (collidables[i].shape_type == 5) {
+            const float h = collidables[i].shape[0];
+            if (!(h >= 0) || h != (float)(int)h || (int)h >= c->hull_count)
+                return fail(BEPUHIP_E_INVALID_ARGUMENT, "convex hull index " + std::to_string(h) + " of collidable " + std::to_string(i) + " is not one of the " +
+                                                             std::to_string(c->hull_count) + " hulls of bepuhip_set_convex_hulls");
+        }
+    }
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_set_convex_hulls(bepuhip_ctx* c, const float* points, const int32_t* point_begin, int32_t hull_count) {
+    if (!c || hull_count < 0 || (hull_count > 0 && (!points || !point_begin))) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad set_convex_hulls argument");
+    for (int h = 0; h < hull_count; ++h)
+        if (point_begin[h] < 0 || point_begin[h + 1] <= point_begin[h]) return fail(BEPUHIP_E_INVALID_ARGUMENT, "hull " + std::to_string(h) + " has no points (or the offsets decrease)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_hull_points) hipFree(c->d_hull_points);
+    if (c->d_hull_begin) hipFree(c->d_hull_begin);
+    c->d_hull_points = nullptr; c->d_hull_begin = nullptr; c->hull_count = 0;
+    if (hull_count == 0) return BEPUHIP_OK;
+    const size_t total = (size_t)point_begin[hull_count];
+    HIP_TRY(hipMalloc((void**)&c->d_hull_points, total * 12));
+    HIP_TRY(hipMalloc((void**)&c->d_hull_begin, ((size_t)hull_count + 1) * 4));
+    HIP_TRY(hipMemcpy(c->d_hull_points, points, total * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_hull_begin, point_begin, ((size_t)hull_count + 1) * 4, hipMemcpyHostToDevice));
+    c->hull_count = hull_count;
     return BEPUHIP_OK;
 }
 int32_t bepuhip_set_collidables(bepuhip_ctx* c, const bepuhip_collidable* collidables, int32_t count) {
     if (!c || count < 0 || (count > 0 && !collidables)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad set_collidables argument");
-    int32_t st = check_collidables(collidables, count);
+    int32_t st = check_collidables(c, collidables, count);
     if (st != BEPUHIP_OK) return st;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1468,7 +1495,7 @@ int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* c, float dt, const bepuhip_i
     if (!(dt > 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "dt must be positive");
     const bool resident = collidables == nullptr;
     if (resident && count > c->collidable_count) return fail(BEPUHIP_E_STATE, "no collidables given and fewer resident ones than bodies (bepuhip_set_collidables)");
-    if (!resident) { int32_t st = check_collidables(collidables, count); if (st != BEPUHIP_OK) return st; }
+    if (!resident) { int32_t st = check_collidables(c, collidables, count); if (st != BEPUHIP_OK) return st; }
     if (count == 0) return BEPUHIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     const size_t in_floats = resident ? 0 : (size_t)count * 16, out_floats = (size_t)count * 8;
@@ -1479,7 +1506,7 @@ int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* c, float dt, const bepuhip_i
     if (!resident) HIP_TRY(hipMemcpyAsync(d_in, collidables, in_floats * 4, hipMemcpyHostToDevice, c->stream));
     const StepParams sp = make_params(in, dt, dt, 1.0f / dt);  // Callbacks.PrepareForIntegration(dt): the full frame step
     hipLaunchKernelGGL(predict_bounds_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, count, d_in, resident ? 1 : 0, d_out, dt,
-                       in->integrate_velocity_for_kinematics, sp);
+                       in->integrate_velocity_for_kinematics, sp, HullTable{c->d_hull_points, c->d_hull_begin, c->hull_count});
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out, out_floats * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_colour_constraints", "bepuhip_set_exchange_mode", "bepuhip_set_boundary_layout", "bepuhip_comm_unique_id", "bepuhip_comm_init", "bepuhip_comm_adopt", "bepuhip_solve_lattice",
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
-    "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables",
+    "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables", "bepuhip_set_convex_hulls",
     "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_get_constraint_count",
 ]
 
@@ -116,6 +116,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_type_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.bepuhip_predict_bounding_boxes.argtypes = [vp, f32, C.POINTER(Integrator), vp, i32, vp]
     lib.bepuhip_set_collidables.argtypes = [vp, vp, i32]
+    lib.bepuhip_set_convex_hulls.argtypes = [vp, vp, vp, i32]
     lib.bepuhip_update_bodies.argtypes = [vp, vp, i32, i32]
     lib.bepuhip_get_bodies_range.argtypes = [vp, vp, i32, i32]
     for name in ("bepuhip_update_prestep", "bepuhip_update_accumulated_impulses", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
@@ -374,6 +375,12 @@ class HipSolver:
         return out
 
     # ---- PredictBoundingBoxes ----
+    def set_convex_hulls(self, hulls):
+        """hulls: a list of float32 [n_i, 3] point sets; collidables of shape_type 5 name them by index in shape[0]."""
+        pts = np.ascontiguousarray(np.concatenate([np.asarray(h, dtype=np.float32).reshape(-1, 3) for h in hulls]) if hulls else np.zeros((0, 3), np.float32), dtype=np.float32)
+        begin = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(h) for h in hulls])]), dtype=np.int32)
+        _check(self.lib, self.lib.bepuhip_set_convex_hulls(self.ctx, _ptr(pts), _ptr(begin), len(hulls)))
+
     def set_collidables(self, collidables: np.ndarray):
         """Keep the collidable records on the device; later ``predict_bounding_boxes(dt, cb)`` calls use (and update the sleep counters of) these."""
         c = np.ascontiguousarray(collidables, dtype=COLLIDABLE_DTYPE)

@@ -191,10 +191,11 @@ int32_t bepuhip_get_constraint_count(bepuhip_ctx* ctx, int32_t batch_index, int3
  * (UpdateSleepCandidacy :287-305), the velocity callback for the full dt on a copy, TShapeWide.GetBounds, the angular / linear expansion and the speculative
  * margin of BoundingBoxBatcher.ExecuteConvexBatch (BepuPhysics/Collidables/BoundingBoxBatcher.cs:142-223). It reads the bodies the last set_bodies /
  * update_bodies / solve left on the device; the caller copies min/max into the broad phase leaves (BroadPhase.GetActiveBoundsPointers) and the margin and
- * activity back into Collidable / BodyActivity. Convex hulls, compounds and meshes (shape_type > 4) -> UNSUPPORTED: those bodies stay on the host path. */
+ * activity back into Collidable / BodyActivity. Convex hulls (ConvexHull.Id 5, ConvexHullWide.GetBounds BepuPhysics/Collidables/ConvexHull.cs:319-364) read their points from
+ * the table of bepuhip_set_convex_hulls. Compounds and meshes (shape_type > 5) -> UNSUPPORTED: those bodies stay on the host path. */
 typedef struct bepuhip_collidable {
-    int32_t shape_type;                 /* Sphere.Id 0, Capsule.Id 1, Box.Id 2, Triangle.Id 3, Cylinder.Id 4; -1: Collidable.Shape.Exists == false */
-    float shape[9];                     /* Sphere{Radius}; Capsule{Radius, HalfLength}; Box{HalfWidth, HalfHeight, HalfLength}; Triangle{A, B, C}; Cylinder{Radius, HalfLength} */
+    int32_t shape_type;                 /* Sphere.Id 0, Capsule.Id 1, Box.Id 2, Triangle.Id 3, Cylinder.Id 4, ConvexHull.Id 5; -1: Collidable.Shape.Exists == false */
+    float shape[9];                     /* Sphere{Radius}; Capsule{Radius, HalfLength}; Box{HalfWidth, HalfHeight, HalfLength}; Triangle{A, B, C}; Cylinder{Radius, HalfLength}; ConvexHull{hull index as a float} */
     float minimum_speculative_margin;   /* Collidable.MinimumSpeculativeMargin, BepuPhysics/Collidables/Collidable.cs:131 */
     float maximum_speculative_margin;   /* :139 */
     int32_t allow_expansion_beyond_speculative_margin;  /* Continuity.AllowExpansionBeyondSpeculativeMargin, :59 */
@@ -206,6 +207,9 @@ typedef struct bepuhip_predicted_bounds {
     float min[3]; float speculative_margin;   /* Collidable.SpeculativeMargin */
     float max[3]; int32_t activity;           /* same packing as bepuhip_collidable.activity, after UpdateSleepCandidacy */
 } bepuhip_predicted_bounds;
+/* Convex hull point sets, resident on the device: `points` = xyz triplets of every hull's points one hull after the other (ConvexHull.Points, BepuPhysics/Collidables/ConvexHull.cs:30, without
+ * the bundle padding: the padding lanes repeat real points, which changes no minimum or maximum), hull h owns points [point_begin[h], point_begin[h + 1]). Replaces the previous table. */
+int32_t bepuhip_set_convex_hulls(bepuhip_ctx* ctx, const float* points, const int32_t* point_begin, int32_t hull_count);
 /* `collidables` == NULL uses the records uploaded with bepuhip_set_collidables (shapes and margins rarely change): nothing but the 32-byte result per body
  * crosses PCIe, and the sleep counters are carried on the device from call to call. */
 int32_t bepuhip_set_collidables(bepuhip_ctx* ctx, const bepuhip_collidable* collidables, int32_t count);

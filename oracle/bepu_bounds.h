@@ -10,7 +10,9 @@ namespace bo {
 // PoseIntegrator.PredictBoundingBoxes for one body (PoseIntegrator.cs:287-370) with BoundingBoxBatcher.ExecuteConvexBatch (BoundingBoxBatcher.cs:142-223)
 // for the five primitive convex shapes and BoundingBoxHelpers (BoundingBoxHelpers.cs:12-61). One lane = one body.
 // ======================================================================================
-enum ShapeType { kShapeNone = -1, kShapeSphere = 0, kShapeCapsule = 1, kShapeBox = 2, kShapeTriangle = 3, kShapeCylinder = 4 };  // Sphere.Id ... Cylinder.Id
+enum ShapeType { kShapeNone = -1, kShapeSphere = 0, kShapeCapsule = 1, kShapeBox = 2, kShapeTriangle = 3, kShapeCylinder = 4, kShapeConvexHull = 5 };  // Sphere.Id ... ConvexHull.Id
+// Convex hull point sets (ConvexHull.Points without the bundle padding, which repeats real points): hull h owns points [begin[h], begin[h + 1]).
+struct HullTable { const float* points; const int* begin; int count; };
 
 static inline V3 transformUnitY(Q r) {  // QuaternionWide.cs:389-405
     float x2 = r.x + r.x, y2 = r.y + r.y, z2 = r.z + r.z;
@@ -19,7 +21,7 @@ static inline V3 transformUnitY(Q r) {  // QuaternionWide.cs:389-405
 }
 
 // TShapeWide.GetBounds: local bounds around the body's position, the largest distance of any point from it, and how far a rotation can move a point outward.
-static inline bool shapeBounds(int type, const float* s, Q orientation, float& maximumRadius, float& maximumAngularExpansion, V3& mn, V3& mx) {
+static inline bool shapeBounds(int type, const float* s, Q orientation, const HullTable& hulls, float& maximumRadius, float& maximumAngularExpansion, V3& mn, V3& mx) {
     switch (type) {
         case kShapeSphere: {  // Sphere.cs:149-160
             maximumRadius = 0.0f; maximumAngularExpansion = 0.0f;
@@ -68,6 +70,24 @@ static inline bool shapeBounds(int type, const float* s, Q orientation, float& m
             maximumAngularExpansion = maximumRadius - vmin(s[1], s[0]);
             return true;
         }
+        case kShapeConvexHull: {  // ConvexHull.cs:319-364: every point rotated, componentwise min / max; the farthest point bounds both expansions. s[0] = hull index.
+            if (!hulls.points) return false;
+            const int hull = (int)s[0];
+            M3 basis = createFromQuaternion(orientation);
+            mn = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+            mx = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+            float maximumRadiusSquared = 0.0f;
+            for (int j = hulls.begin[hull]; j < hulls.begin[hull + 1]; ++j) {
+                const V3 local = {hulls.points[3 * (size_t)j], hulls.points[3 * (size_t)j + 1], hulls.points[3 * (size_t)j + 2]};
+                const V3 p = transform(local, basis);  // Matrix3x3Wide.TransformWithoutOverlap
+                maximumRadiusSquared = vmax(lengthSquared(local), maximumRadiusSquared);
+                mn = {vmin(mn.x, p.x), vmin(mn.y, p.y), vmin(mn.z, p.z)};
+                mx = {vmax(mx.x, p.x), vmax(mx.y, p.y), vmax(mx.z, p.z)};
+            }
+            maximumRadius = sqrtf(maximumRadiusSquared);
+            maximumAngularExpansion = maximumRadius;
+            return true;
+        }
         default: return false;
     }
 }
@@ -104,10 +124,10 @@ static inline int updateSleepCandidacy(float velocityHeuristic, float sleepThres
 
 // `velocity` is the body's velocity after the integration callback ran on it for the full dt (only used for the prediction, never stored: :331-333);
 // `sleepEnergy` was taken from the stored velocity (:329).
-static inline void predictBounds(V3 position, Q orientation, const BodyVel& velocity, float sleepEnergy, float dt, const CollidableIn& c, PredictedBounds& out) {
+static inline void predictBounds(V3 position, Q orientation, const BodyVel& velocity, float sleepEnergy, float dt, const CollidableIn& c, const HullTable& hulls, PredictedBounds& out) {
     out.activity = updateSleepCandidacy(sleepEnergy, c.sleep_threshold, c.minimum_timesteps_under_threshold, c.activity);
     float maximumRadius, maximumAngularExpansion; V3 mn, mx;
-    if (!shapeBounds(c.shape_type, c.shape, orientation, maximumRadius, maximumAngularExpansion, mn, mx)) {  // Shape.Exists == false: nothing to bound (BoundingBoxBatcher.cs:326)
+    if (!shapeBounds(c.shape_type, c.shape, orientation, hulls, maximumRadius, maximumAngularExpansion, mn, mx)) {  // Shape.Exists == false: nothing to bound (BoundingBoxBatcher.cs:326)
         out.min[0] = out.min[1] = out.min[2] = 0.0f; out.max[0] = out.max[1] = out.max[2] = 0.0f; out.speculative_margin = 0.0f;
         return;
     }

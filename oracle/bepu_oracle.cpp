@@ -803,8 +803,16 @@ int oracle_constraint_iterate(int type_id, float* bodyA, float* bodyB, float* pr
 // Scalar math probes for unit tests (MathHelper.Sin/Cos/Acos restatements).
 // PoseIntegrator.PredictBoundingBoxes (PoseIntegrator.cs:307-370) over `count` bodies: sleep candidacy from the stored velocity, the velocity callback for
 // the full dt on a copy (integration mask: non-kinematic bodies unless IntegrateVelocityForKinematics), bounds of the primitive convex shapes.
+int oracle_predict_bounding_boxes_hulls(const float* bodies, int count, const OracleParams* params, const CollidableIn* collidables, PredictedBounds* out, const float* hull_points,
+                                        const int* hull_begin, int hull_count);
 int oracle_predict_bounding_boxes(const float* bodies, int count, const OracleParams* params, const CollidableIn* collidables, PredictedBounds* out) {
+    return oracle_predict_bounding_boxes_hulls(bodies, count, params, collidables, out, nullptr, nullptr, 0);
+}
+// ... with convex hulls (ConvexHull.Id = 5, ConvexHull.cs:319-364): collidable.shape[0] = hull index, hull h = points [hull_begin[h], hull_begin[h + 1]).
+int oracle_predict_bounding_boxes_hulls(const float* bodies, int count, const OracleParams* params, const CollidableIn* collidables, PredictedBounds* out, const float* hull_points,
+                                        const int* hull_begin, int hull_count) {
     if (!bodies || !params || !collidables || !out || count < 0 || !(params->dt > 0)) return -1;
+    const HullTable hulls = {hull_points, hull_begin, hull_count};
     Callbacks cb;
     cb.prepare(*params, params->dt);   // PredictBoundingBoxes(dt, ...) -> Callbacks.PrepareForIntegration(dt)
     for (int i = 0; i < count; ++i) {
@@ -814,7 +822,7 @@ int oracle_predict_bounding_boxes(const float* bodies, int count, const OraclePa
                                  st.inertia.t.zz == 0 && st.inertia.invMass == 0;
         const float sleepEnergy = lengthSquared(st.vel.lin) + lengthSquared(st.vel.ang);
         if (params->integrate_velocity_for_kinematics || !isKinematic) cb.integrateVelocity(st.vel);
-        predictBounds(st.pos, st.ori, st.vel, sleepEnergy, params->dt, collidables[i], out[i]);
+        predictBounds(st.pos, st.ori, st.vel, sleepEnergy, params->dt, collidables[i], hulls, out[i]);
     }
     return 0;
 }

@@ -125,7 +125,7 @@ def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool 
         raise RuntimeError(f"oracle_solve failed: {rc}")
 
 
-def predict_bounding_boxes(bodies, dt, callbacks, collidables):
+def predict_bounding_boxes(bodies, dt, callbacks, collidables, hulls=None):
     """PoseIntegrator.PredictBoundingBoxes restated (oracle/bepu_bounds.h): returns PREDICTED_BOUNDS_DTYPE records, bodies untouched."""
     from bepuphysics2_amd.native import COLLIDABLE_DTYPE, PREDICTED_BOUNDS_DTYPE
     lib = load()
@@ -139,7 +139,14 @@ def predict_bounding_boxes(bodies, dt, callbacks, collidables):
     p.linear_damping = float(callbacks.linear_damping)
     p.angular_damping = float(callbacks.angular_damping)
     p.integrate_velocity_for_kinematics = int(bool(callbacks.integrate_velocity_for_kinematics))
-    rc = lib.oracle_predict_bounding_boxes(_p(b), c.shape[0], C.byref(p), _p(c), _p(out))
+    if hulls:
+        pts = np.ascontiguousarray(np.concatenate([np.asarray(h, dtype=np.float32).reshape(-1, 3) for h in hulls]), dtype=np.float32)
+        begin = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(h) for h in hulls])]), dtype=np.int32)
+        lib.oracle_predict_bounding_boxes_hulls.argtypes = [C.c_void_p, C.c_int, C.POINTER(OracleParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        lib.oracle_predict_bounding_boxes_hulls.restype = C.c_int
+        rc = lib.oracle_predict_bounding_boxes_hulls(_p(b), c.shape[0], C.byref(p), _p(c), _p(out), _p(pts), _p(begin), len(hulls))
+    else:
+        rc = lib.oracle_predict_bounding_boxes(_p(b), c.shape[0], C.byref(p), _p(c), _p(out))
     if rc != 0:
         raise RuntimeError(f"oracle_predict_bounding_boxes failed: {rc}")
     return out

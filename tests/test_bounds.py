@@ -158,8 +158,73 @@ def test_hip_predict_bounding_boxes_matches_the_oracle(hip_solver_factory):
         chained["activity"] = want["activity"]
     from bepuphysics2_amd import native
     bad = coll[:4].copy()
-    bad["shape_type"][2] = 5  # ConvexHull.Id: stays on the host
+    bad["shape_type"][2] = 6  # Compound.Id: stays on the host
     with pytest.raises(native.UnsupportedError):
+        solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks(), bad)
+    bad["shape_type"][2] = 5  # ConvexHull.Id without a hull table: not a valid hull index
+    with pytest.raises(ValueError):
         solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks(), bad)
     with pytest.raises(ValueError):
         solver.predict_bounding_boxes(0.0, PoseIntegratorCallbacks(), coll[:4])
+
+
+def _random_hulls(rng, count):
+    """Point clouds standing in for ConvexHull.Points (the bounds only look at the points): 4 to 40 points each, off-centre, different sizes."""
+    return [(rng.normal(size=(int(rng.integers(4, 41)), 3)) * rng.uniform(0.2, 1.5, 3) + rng.uniform(-0.3, 0.3, 3)).astype(np.float32) for _ in range(count)]
+
+
+def _hull_collidables(rng, n, hull_count):
+    c = _random_collidables(rng, n)
+    for i in range(n):
+        if i % 3 == 0:
+            c["shape_type"][i] = 5  # ConvexHull.Id
+            c["shape"][i] = 0
+            c["shape"][i, 0] = float(rng.integers(hull_count))
+    return c
+
+
+def test_convex_hull_bounds_contain_every_rotated_point():
+    """ConvexHullWide.GetBounds (ConvexHull.cs:319-364): the box holds every point of the hull at the body's orientation and touches the extreme ones."""
+    rng = np.random.default_rng(41)
+    hulls = _random_hulls(rng, 12)
+    n = 300
+    bodies = _random_bodies(rng, n)
+    bodies[:, 8:11] = 0
+    bodies[:, 12:15] = 0  # at rest: no linear or angular expansion
+    coll = _hull_collidables(rng, n, len(hulls))
+    coll["minimum_speculative_margin"] = 0
+    cb = PoseIntegratorCallbacks(gravity=(0, 0, 0), linear_damping=0, angular_damping=0)
+    out = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, coll, hulls)
+    checked = 0
+    for i in range(n):
+        if coll["shape_type"][i] != 5:
+            continue
+        pts = hulls[int(coll["shape"][i, 0])]
+        world = np.stack([_rotate(bodies[i, 0:4], p) for p in pts])
+        lo, hi = world.min(axis=0), world.max(axis=0)
+        assert np.allclose(out["min"][i], lo + bodies[i, 4:7], atol=2e-5) and np.allclose(out["max"][i], hi + bodies[i, 4:7], atol=2e-5), i
+        checked += 1
+    assert checked > 50
+
+
+@pytest.mark.gpu
+def test_hip_convex_hull_bounds_match_the_oracle(hip_solver_factory):
+    rng = np.random.default_rng(43)
+    hulls = _random_hulls(rng, 64)
+    n = 4000
+    bodies, coll = _random_bodies(rng, n), _hull_collidables(rng, n, len(hulls))
+    solver = hip_solver_factory()
+    solver.set_bodies(bodies)
+    solver.set_convex_hulls(hulls)
+    for cb in (PoseIntegratorCallbacks(), PoseIntegratorCallbacks(gravity=(1, -9, 0.5), linear_damping=0.1, angular_damping=0.2, integrate_velocity_for_kinematics=True)):
+        want = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, coll, hulls)
+        got = solver.predict_bounding_boxes(1 / 60, cb, coll)
+        assert np.array_equal(want.view(np.int32), got.view(np.int32))
+    solver.set_collidables(coll)  # resident records + resident hull table
+    got = solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks())
+    assert np.array_equal(oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, PoseIntegratorCallbacks(), coll, hulls).view(np.int32), got.view(np.int32))
+    bad = coll[:6].copy()
+    bad["shape_type"][1] = 5
+    bad["shape"][1, 0] = len(hulls)  # one past the table
+    with pytest.raises(ValueError):
+        solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks(), bad)
