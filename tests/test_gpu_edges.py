@@ -194,3 +194,34 @@ def test_fallback_batch_limits_through_the_abi(hip_solver_factory):
     solver.upload(scene, 3)
     with pytest.raises(native.UnsupportedError):  # the conserving modes' substep-0 re-transformation is defined per bundle of a synchronized batch
         solver.solve(1 / 60, SolveDescription(1, 2, fallback_batch_threshold=3), PoseIntegratorCallbacks(angular_integration_mode=1))
+
+
+def test_row_policy_is_measured_and_never_changes_a_result(hip_solver_factory, monkeypatch):
+    """The island schedule's two row-access builds (plain / non-temporal) are bit-identical: while the first twelve solves alternate between them the
+    frames still match the oracle, the policy is settled afterwards, pinning either one gives the same bytes, and a new upload measures again."""
+    import parity_util as pu
+    scene = small_scenes.island_scene(3, 60, 14, 40, [22, 4, 30, 47, 7])
+    sd, cb = SolveDescription(1, 2), PoseIntegratorCallbacks()
+    frames = 14
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=frames)
+    results = {}
+    for pin in (None, "0", "1"):
+        if pin is None:
+            monkeypatch.delenv("BEPUHIP_ROW_POLICY", raising=False)
+        else:
+            monkeypatch.setenv("BEPUHIP_ROW_POLICY", pin)
+        solver = hip_solver_factory()
+        got = scene.copy()
+        solver.upload(got)
+        assert solver.row_policy() == -1
+        for _ in range(frames):
+            solver.solve(1 / 60, sd, cb)
+        assert solver.cluster_cycles().size >= 1
+        assert solver.row_policy() == (int(pin) if pin is not None else solver.row_policy()) and solver.row_policy() in (0, 1)
+        solver.download(got)
+        m = pu.compare_scenes(ref, got)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (pin, m)
+        results[pin] = got.bodies.copy()
+        solver.upload(scene.copy())
+        assert solver.row_policy() == -1  # a new topology is measured afresh
+    assert np.array_equal(results[None].view(np.int32), results["0"].view(np.int32)) and np.array_equal(results["0"].view(np.int32), results["1"].view(np.int32))
