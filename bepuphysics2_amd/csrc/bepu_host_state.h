@@ -145,6 +145,7 @@ struct bepuhip_ctx {
     bool clusters_enabled = false;
     // Row-load policy of the island schedule's default workgroup sizes (plain or non-temporal accesses to the constraint rows). Which one is faster depends on the box: the
     // first solves alternate between the two — their results are bit-identical — each timed with its own event pair, then the faster one stays.
+    bool graphs_cleared_by_structure = false;  // set by flush_structural, consumed by the next solve (which then launches eagerly instead of capturing)
     int row_policy = -1;              // -1: still measuring; 0 plain; 1 non-temporal (BEPUHIP_ROW_POLICY=0/1 pins it)
     int policy_samples = 0;           // solves launched while measuring
     hipEvent_t policy_events[16][2] = {};

@@ -721,11 +721,19 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
     // A graph pays for the launch-per-batch schedule's 100+ launches; the island schedule is ONE kernel, which a plain launch starts sooner (6-7 us per step).
     const bool use_graph = !(c->flags & BEPUHIP_FLAG_NO_GRAPH) && !c->profiling && !island_schedule_applies(c, substeps, in);
+    if (!use_graph) c->graphs_cleared_by_structure = false;
     if (use_graph) {
         GraphKey key;
         key.iterations.assign(iterations, iterations + substeps);
         key.dt = dt; key.integ = *in;
         auto it = c->graphs.find(key);
+        if (it == c->graphs.end() && c->graphs_cleared_by_structure) {  // topology changed since the last solve: capturing + instantiating (~1.5 ms) would not pay for itself
+            c->graphs_cleared_by_structure = false;
+            enqueue_solve(c, dt, substeps, iterations, in);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+            return BEPUHIP_OK;
+        }
         if (it == c->graphs.end()) {
             if (c->graphs.size() >= kMaxCachedGraphs) {  // a caller with a variable time step produces a new key every frame: keep the cache bounded
                 HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1157,6 +1165,7 @@ static int32_t flush_structural(bepuhip_ctx* c) {
     if (!c->structure_dirty) return BEPUHIP_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
     clear_graphs(c);  // grids and descriptor pointers are baked into captured launches
+    c->graphs_cleared_by_structure = true;  // the solve that follows launches eagerly: a graph captured now would be thrown away by the next frame's updates
     c->total_constraints = 0;
     for (auto& tb : c->tbs) c->total_constraints += tb.count;
     if ((st = build_descriptors(c, {})) != BEPUHIP_OK) return st;
