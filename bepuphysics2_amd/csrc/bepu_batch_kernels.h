@@ -425,11 +425,36 @@ __global__ __launch_bounds__(64) void apply_structural_ops_kernel(unsigned* __re
         __threadfence_block();
     }
 }
+// Structural updates that stay on the island layout (bepu_soft_updates.h): the final state of every device slot touched since the last flush. A live slot gets its
+// encoded references, its packed local references, its prestep lane and zero impulses (TypeProcessor.cs:327); a freed one gets -1 references and the dead bit.
+struct SoftSlotOp { unsigned refs_off, lrefs_off, prestep_off, accum_off; int stride, bodies, prestep, impulse, slot, live; unsigned payload; int pad; };
+__global__ __launch_bounds__(64) void apply_soft_slots_kernel(unsigned* slab, const SoftSlotOp* __restrict__ ops, int count, const unsigned* __restrict__ payload) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const SoftSlotOp op = ops[i];
+    const int lref_rows = (op.bodies + 1) / 2;
+    if (!op.live) {
+        for (int k = 0; k < op.bodies; ++k) slab[op.refs_off + (size_t)k * op.stride + op.slot] = 0xFFFFFFFFu;
+        for (int k = 0; k < lref_rows; ++k) slab[op.lrefs_off + (size_t)k * op.stride + op.slot] = k == 0 ? kLrefDead : 0u;
+        return;
+    }
+    const unsigned* p = payload + op.payload;
+    for (int k = 0; k < op.bodies; ++k) slab[op.refs_off + (size_t)k * op.stride + op.slot] = *p++;
+    for (int k = 0; k < lref_rows; ++k) slab[op.lrefs_off + (size_t)k * op.stride + op.slot] = *p++;
+    for (int f = 0; f < op.prestep; ++f) slab[op.prestep_off + (size_t)f * op.stride + op.slot] = *p++;
+    for (int f = 0; f < op.impulse; ++f) slab[op.accum_off + (size_t)f * op.stride + op.slot] = 0u;
+}
+struct IndexPatch { int* table; int index, value, pad; };
+__global__ __launch_bounds__(64) void patch_index_kernel(const IndexPatch* __restrict__ patches, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) patches[i].table[patches[i].index] = patches[i].value;
+}
 // Island schedule -> caller's order: rows[r][host index] = permuted[r][device index] (the first structural update leaves the island schedule).
 __global__ __launch_bounds__(256) void unpermute_rows_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, const int* __restrict__ device_to_host, int count, int stride, int rows) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= count) return;
     const int h = device_to_host[d];
+    if (h < 0) return;  // a free slot of the island layout
     for (int r = 0; r < rows; ++r) dst[(size_t)r * stride + h] = src[(size_t)r * stride + d];
 }
 // The inverse, for ranged read-back (bepuhip_get_*_range).

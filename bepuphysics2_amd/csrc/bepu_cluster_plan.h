@@ -19,6 +19,9 @@ struct ClusterPlan {
     std::vector<ClusterItem> items;
     std::vector<int> batch_item_begin, cluster_bodies, clustered_dynamic, kinlist;
     int max_slots = 0, max_items = 0;
+    // whole-island plans: what structural updates need to stay on the island schedule (bepu_soft_updates.h)
+    std::vector<int32_t> body_cluster, body_lref, body_degree;
+    std::vector<std::unordered_map<int32_t, int32_t>> cluster_kin;
     int planes = kAllPlanes;  // LDS planes per body slot: all eight fields when they fit, else the six the sweeps touch (the local inertia is then read from memory)
 };
 
@@ -35,6 +38,10 @@ static size_t cluster_lds_bytes(int planes, int ncap, int max_items, bool shared
 static inline int rotated_slot(int i) { return (i & ~15) | ((i + (i >> 4)) & 15); }
 
 static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe);
+// Device slots a cluster's segment of a type batch gets for `live` constraints: with BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS an eighth more (at least two), so that the
+// narrow phase's additions find room without a new plan.
+static inline int segment_slots(int live, bool reserve) { return (reserve && live > 0) ? live + std::max(2, live / 8) : live; }
+constexpr int32_t kPlanDeadLref = (int32_t)kLrefDead;  // 32-bit planning form of a free slot's local reference
 
 static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     int universe = 0;
@@ -52,6 +59,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                 }
     }
     if ((c->flags & BEPUHIP_FLAG_NO_CLUSTERS) || env_int("BEPUHIP_NO_CLUSTERS", 0) || universe == 0 || c->total_constraints == 0 || c->batch_count > kFallbackBatchLimit || c->has_fallback) return;
+    const bool reserve = (c->flags & BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS) != 0;
     std::vector<int32_t> parent(universe);
     for (int i = 0; i < universe; ++i) parent[i] = i;
     auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
@@ -124,7 +132,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                     }
                 }
             }
-            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (per_cluster[cl] + 63) / 64;
+            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (segment_slots(per_cluster[cl], reserve) + 63) / 64;
         }
         int max_slots = 0, max_items = 0;
         for (int cl = 0; cl < nclusters; ++cl) {
@@ -168,19 +176,26 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         HostTypeBatch& tb = c->tbs[t];
         const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
         const std::vector<int32_t>& clc = cl_of_constraint[t];
-        std::vector<int32_t> begin(nclusters + 1, 0);  // counting sort by cluster
-        for (int i = 0; i < tb.count; ++i) ++begin[clc[i] + 1];
-        for (int cl = 0; cl < nclusters; ++cl) begin[cl + 1] += begin[cl];
-        tb.perm.resize(tb.count);
-        for (int i = 0; i < tb.count; ++i) tb.perm[begin[clc[i]]++] = i;
-        std::vector<int32_t> refs((size_t)nb * tb.stride, -1), lrefs((size_t)nb * tb.stride, -1);
-        std::vector<float> pre((size_t)pf * tb.stride, 0.0f), acc((size_t)imf * tb.stride, 0.0f);
+        std::vector<int32_t> live(nclusters, 0);
+        for (int i = 0; i < tb.count; ++i) ++live[clc[i]];
+        tb.seg_begin.assign(nclusters + 1, 0);  // every cluster's constraints in one segment of device slots, free slots (if reserved) behind the live ones
+        for (int cl = 0; cl < nclusters; ++cl) tb.seg_begin[cl + 1] = tb.seg_begin[cl] + segment_slots(live[cl], reserve);
+        tb.slots = tb.seg_begin[nclusters];
+        const int stride = std::max(tb.stride, (tb.slots + 63) / 64 * 64);
+        std::vector<int32_t> next(tb.seg_begin.begin(), tb.seg_begin.end() - 1);
+        tb.perm.assign(tb.slots, -1);
+        for (int i = 0; i < tb.count; ++i) tb.perm[next[clc[i]]++] = i;  // counting sort by cluster: inside a cluster the caller's order stays
+        tb.inv.assign(tb.count, 0);
+        std::vector<int32_t> refs((size_t)nb * stride, -1), lrefs((size_t)nb * stride, -1);
+        std::vector<float> pre((size_t)pf * stride, 0.0f), acc((size_t)imf * stride, 0.0f);
         for (int k = 0; k < nb; ++k) {
             const int32_t* src = tb.refs_soa.data() + (size_t)k * tb.stride;
-            int32_t* dst = refs.data() + (size_t)k * tb.stride;
-            int32_t* ldst = lrefs.data() + (size_t)k * tb.stride;
-            for (int d = 0; d < tb.count; ++d) {
+            int32_t* dst = refs.data() + (size_t)k * stride;
+            int32_t* ldst = lrefs.data() + (size_t)k * stride;
+            for (int d = 0; d < tb.slots; ++d) {
                 const int h = tb.perm[d];
+                if (h < 0) { ldst[d] = k == 0 ? kPlanDeadLref : 0; continue; }
+                if (k == 0) tb.inv[h] = d;
                 const int32_t r = src[h];
                 dst[d] = r;
                 ldst[d] = ((uint32_t)r < kDynamicLimit) ? rotated_slot(local_of[r]) : (rotated_slot(cl_kin[clc[h]].find(r & kRefMask)->second) | (int)kDynamicLimit);
@@ -188,14 +203,16 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         }
         for (int f = 0; f < pf; ++f) {
             const float* src = tb.prestep_soa.data() + (size_t)f * tb.stride;
-            float* dst = pre.data() + (size_t)f * tb.stride;
-            for (int d = 0; d < tb.count; ++d) dst[d] = src[tb.perm[d]];
+            float* dst = pre.data() + (size_t)f * stride;
+            for (int d = 0; d < tb.slots; ++d) if (tb.perm[d] >= 0) dst[d] = src[tb.perm[d]];
         }
         for (int f = 0; f < imf; ++f) {
             const float* src = tb.accum_soa.data() + (size_t)f * tb.stride;
-            float* dst = acc.data() + (size_t)f * tb.stride;
-            for (int d = 0; d < tb.count; ++d) dst[d] = src[tb.perm[d]];
+            float* dst = acc.data() + (size_t)f * stride;
+            for (int d = 0; d < tb.slots; ++d) if (tb.perm[d] >= 0) dst[d] = src[tb.perm[d]];
         }
+        tb.stride = stride;
+        tb.dev_refs = refs;
         tb.refs_soa.swap(refs); tb.prestep_soa.swap(pre); tb.accum_soa.swap(acc); tb.lrefs_soa.swap(lrefs);
     };
     {
@@ -211,10 +228,9 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         HostTypeBatch& tb = c->tbs[t];
         const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
         const std::vector<int32_t>& clc = cl_of_constraint[t];
-        for (int d = 0; d < tb.count;) {
-            const int cl = clc[tb.perm[d]];
-            int e = d;
-            while (e < tb.count && clc[tb.perm[e]] == cl) ++e;
+        for (int cl = 0; cl < nclusters; ++cl) {
+            const int d = tb.seg_begin[cl], e = tb.seg_begin[cl + 1];
+            if (d == e) continue;
             for (int s0 = d; s0 < e; s0 += 64) {
                 ClusterItem it;
                 memset(&it, 0, sizeof(it));
@@ -226,7 +242,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                 for (int j = s0; j < s0 + it.count; ++j)
                     for (int k = 0; k < nb; ++k) {
                         const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
-                        if ((uint32_t)lr >= kDynamicLimit) continue;
+                        if ((uint32_t)lr >= kDynamicLimit || tb.perm[j] < 0) continue;  // kinematic copy, or a free slot
                         if ((size_t)lr >= lt.size()) lt.resize((size_t)lr + 16, -1);
                         const int pred = lt[lr];
                         if (pred < 0) { first_touch[cl].push_back({self, lr}); continue; }  // this item is the body's first toucher in a pass
@@ -239,13 +255,12 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                 for (int j = s0; j < s0 + it.count; ++j)
                     for (int k = 0; k < nb; ++k) {
                         const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
-                        if ((uint32_t)lr < kDynamicLimit) lt[lr] = self;
+                        if ((uint32_t)lr < kDynamicLimit && tb.perm[j] >= 0) lt[lr] = self;
                     }
                 if (overflow) npred = 0;
                 it.batch_npred = (tb.batch & 0xFFFF) | (npred << 16) | (overflow << 24);
                 cl_items[cl].push_back(it);
             }
-            d = e;
         }
     }
     // The kernel reads the local references as 16-bit halves, two body slots per word (slot < 32768; bit 15 = kinematic copy): half the bytes, and one
@@ -254,9 +269,9 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         const int nb = tb.info.bodies, rows = (nb + 1) / 2;
         std::vector<int32_t> packed((size_t)rows * tb.stride, 0);
         for (int k = 0; k < nb; ++k)
-            for (int d = 0; d < tb.count; ++d) {
+            for (int d = 0; d < tb.slots; ++d) {
                 const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + d];
-                const uint32_t half = ((uint32_t)lr & 0x7FFFu) | (((uint32_t)lr >= kDynamicLimit) ? 0x8000u : 0u);
+                const uint32_t half = ((uint32_t)lr & 0x7FFFu) | (((uint32_t)lr >= kDynamicLimit) ? 0x8000u : 0u);  // a free slot's first half is kLrefDead | slot 0
                 packed[(size_t)(k / 2) * tb.stride + d] |= (int32_t)(half << (16 * (k & 1)));
             }
         tb.lrefs_soa.swap(packed);
@@ -297,6 +312,21 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         plan.max_items = std::max(plan.max_items, d.item_count);
     }
     plan.enabled = nclusters > 0 && cluster_lds_bytes(plan.planes, plan.max_slots, plan.max_items) <= kLdsBudgetBytes;
+    // what structural updates need in order to stay on this plan
+    plan.body_cluster.assign(universe, -1);
+    plan.body_lref.assign(universe, -1);
+    plan.body_degree.assign(universe, 0);
+    for (int i = 0; i < universe; ++i)
+        if (is_dyn[i]) { plan.body_cluster[i] = cluster_of[parent[i]]; plan.body_lref[i] = rotated_slot(local_of[i]); }
+    for (auto& tb : c->tbs)
+        for (int k = 0; k < tb.info.bodies; ++k)
+            for (int d = 0; d < tb.slots; ++d) {
+                const int32_t r = tb.dev_refs[(size_t)k * tb.stride + d];
+                if (r >= 0 && (uint32_t)r < kDynamicLimit) ++plan.body_degree[r];
+            }
+    plan.cluster_kin.resize(nclusters);
+    for (int cl = 0; cl < nclusters; ++cl)
+        for (auto& kv : cl_kin[cl]) plan.cluster_kin[cl].emplace(kv.first, rotated_slot(kv.second));
 }
 
 

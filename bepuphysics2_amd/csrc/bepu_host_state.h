@@ -83,10 +83,17 @@ struct HostTypeBatch {
     std::vector<int32_t> perm;      // cluster path: device index -> host index inside the type batch (empty = identity)
     std::vector<int32_t> inv;       // host index -> device index (lazily built)
     int perm_inverse(int host_index) {
-        if (inv.empty()) { inv.resize(perm.size()); for (size_t d = 0; d < perm.size(); ++d) inv[perm[d]] = (int32_t)d; }
+        if (inv.empty()) { inv.resize(perm.size()); for (size_t d = 0; d < perm.size(); ++d) if (perm[d] >= 0) inv[perm[d]] = (int32_t)d; }
         return inv[host_index];
     }
     int32_t* d_device_index = nullptr;  // device copy of `inv` for the ranged update / read-back kernels (allocated on first use)
+    // Island layout, whole-island plans (bepu_soft_updates.h): the rows hold `slots` device slots — every cluster's constraints of this type batch in one segment
+    // [seg_begin[cluster], seg_begin[cluster + 1]), live ones and free ones (perm[d] == -1: reserved at planning, or left by a removal; their local references carry
+    // the dead bit). `dev_refs` mirrors the encoded body references per device slot so that a removal knows whose constraint counts it lowers.
+    int slots = 0;
+    std::vector<int32_t> seg_begin;
+    std::vector<int32_t> dev_refs;
+    int device_extent() const { return slots > 0 ? slots : count; }
     std::vector<int32_t> lrefs_soa; // cluster path: local (LDS) body indices
     std::vector<int32_t> refs_soa;
     std::vector<float> prestep_soa, accum_soa;  // host staging until end_constraints
@@ -145,6 +152,19 @@ struct bepuhip_ctx {
     bool clusters_enabled = false;
     // Row-load policy of the island schedule's default workgroup sizes (plain or non-temporal accesses to the constraint rows). Which one is faster depends on the box: the
     // first solves alternate between the two — their results are bit-identical — each timed with its own event pair, then the faster one stays.
+    // Structural updates that keep the island schedule (bepu_soft_updates.h)
+    bool soft_ok = false;                        // whole-island plan with its host mirrors in place
+    std::vector<int32_t> body_cluster, body_lref, body_degree;  // per dynamic body: its cluster (-1: none), its rotated LDS slot, its constraint count
+    std::vector<std::unordered_map<int32_t, int32_t>> cluster_kin;  // per cluster: kinematic body -> rotated LDS slot of its private copy
+    std::vector<ClusterItem> items_host;         // the plan's work items (the predecessor lists of a cluster that received a constraint are replaced by batch-level waits)
+    std::vector<ClusterDesc> clusters_host;
+    std::vector<uint8_t> cluster_degraded;
+    struct SoftSlot { bool live; std::vector<uint32_t> payload; };  // final state of a device slot touched since the last flush (payload: refs, packed local refs, prestep)
+    std::map<std::pair<int, int>, SoftSlot> soft_slots;              // (type batch ordinal, device slot)
+    std::map<std::pair<int, int>, int> soft_index;                   // (type batch ordinal, caller's index) -> device slot
+    std::vector<int32_t> soft_orphans;           // bodies whose constraint count reached zero since the last flush
+    bool soft_items_dirty = false;
+    int64_t soft_adds = 0, soft_removes = 0;     // since the upload (diagnostics)
     bool graphs_cleared_by_structure = false;  // set by flush_structural, consumed by the next solve (which then launches eagerly instead of capturing)
     int row_policy = -1;              // -1: still measuring; 0 plain; 1 non-temporal (BEPUHIP_ROW_POLICY=0/1 pins it)
     int policy_samples = 0;           // solves launched while measuring
@@ -236,4 +256,5 @@ static void free_constraints(bepuhip_ctx* c) {
     c->inc_blocks = 0; c->inc_tb_count = 0; c->total_constraints = 0; c->slab_words = 0; c->referenced_bodies = 0;
     c->built = false;
     c->pending_ops.clear(); c->pending_payload.clear(); c->structure_dirty = false; c->requirk_stale = false;
+    c->soft_ok = false; c->soft_slots.clear(); c->soft_index.clear(); c->soft_orphans.clear(); c->soft_items_dirty = false; c->items_host.clear(); c->clusters_host.clear(); c->cluster_degraded.clear();
 }

@@ -28,6 +28,7 @@
 #include <map>
 #include <string>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 #include <rccl/rccl.h>  // types and enums only: the library is opened at run time (bepuhip_comm_*), the solver itself does not depend on it
@@ -52,6 +53,7 @@ using namespace bd;
 #include "bepu_colour_kernels.h"
 #include "bepu_host_state.h"
 #include "bepu_cluster_plan.h"
+#include "bepu_soft_updates.h"
 
 extern "C" {
 
@@ -142,9 +144,10 @@ static int32_t rebuild_flags(bepuhip_ctx* c) {
     const bool marked = c->built && c->referenced_bodies <= c->body_count;
     if (marked) {
         for (auto& tb : c->tbs) {
-            if (tb.count == 0) continue;
-            int blocks = (tb.count + 255) / 256;
-            hipLaunchKernelGGL(mark_constrained_kernel, dim3(blocks), dim3(256), 0, c->stream, (const int*)(c->d_slab + tb.refs_off), tb.count, tb.stride, tb.info.bodies, c->d_flags);
+            const int extent = tb.device_extent();  // island layouts hold free slots (-1 references) between the live ones
+            if (extent == 0) continue;
+            int blocks = (extent + 255) / 256;
+            hipLaunchKernelGGL(mark_constrained_kernel, dim3(blocks), dim3(256), 0, c->stream, (const int*)(c->d_slab + tb.refs_off), extent, tb.stride, tb.info.bodies, c->d_flags);
         }
     }
     if (marked && c->clusters_enabled && c->clustered_dynamic_count > 0) {
@@ -252,6 +255,7 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
 
 static int32_t build_constraints(bepuhip_ctx* c);
 static int32_t flush_structural(bepuhip_ctx* c);
+static int32_t leave_island_schedule(bepuhip_ctx* c);
 
 int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
     if (!c || !c->building) return fail(BEPUHIP_E_STATE, "end_constraints without begin");
@@ -502,6 +506,7 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             for (int tr = 0; tr < 2; ++tr)
                 for (int wide = 0; wide < 2; ++wide)
                     HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(threads, tr != 0, wide != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        soft_setup(c, plan);
         for (int tr = 0; tr < 2; ++tr)
             for (int wide = 0; wide < 2; ++wide) {
                 HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(1024, tr != 0, wide != 0, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
@@ -714,6 +719,16 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     if (st != BEPUHIP_OK) return st;
     HIP_TRY(hipSetDevice(c->device));
     if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
+    if (c->clusters_enabled && !island_schedule_applies(c, substeps, in)) {
+        // the launch-per-batch kernels address rows [0, count): an island layout with free slots between the live ones has to be brought back into the caller's order first
+        bool gaps = false;
+        for (auto& tb : c->tbs) gaps |= tb.slots > 0 && tb.slots != tb.count;
+        for (auto& tb : c->tbs) if (tb.slots > 0 && !gaps) for (int d = 0; d < tb.count && !gaps; ++d) gaps = tb.perm[d] < 0;
+        if (gaps) {
+            if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;
+            if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
+        }
+    }
     int64_t iters = 0;
     for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
     c->last_constraint_iterations = iters;
@@ -1160,8 +1175,10 @@ static int32_t apply_pending_ops(bepuhip_ctx* c) {
 }
 
 static int32_t flush_structural(bepuhip_ctx* c) {
-    int32_t st = apply_pending_ops(c);
-    if (st != BEPUHIP_OK) return st;
+    int32_t st = BEPUHIP_OK;
+    if (c->soft_ok && !soft_bodies_still_constrained(c) && (st = leave_island_schedule(c)) != BEPUHIP_OK) return st;  // a body lost its last constraint: not this plan's scene any more
+    if ((st = flush_soft(c)) != BEPUHIP_OK) return st;
+    if ((st = apply_pending_ops(c)) != BEPUHIP_OK) return st;
     if (!c->structure_dirty) return BEPUHIP_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
     clear_graphs(c);  // grids and descriptor pointers are baked into captured launches
@@ -1218,6 +1235,8 @@ static int32_t leave_island_schedule(bepuhip_ctx* c) {
     bool permuted = c->clusters_enabled;
     for (auto& tb : c->tbs) permuted |= !tb.perm.empty();
     if (!permuted) return BEPUHIP_OK;
+    { const int32_t fs = flush_soft(c); if (fs != BEPUHIP_OK) return fs; }  // the device has to show what the caller has been told
+    c->soft_ok = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
     clear_graphs(c);
     for (int k = 0; k < 2; ++k) {
@@ -1227,15 +1246,16 @@ static int32_t leave_island_schedule(bepuhip_ctx* c) {
         HIP_TRY(hipMalloc((void**)&fresh, c->slab_words * 4));
         HIP_TRY(hipMemcpyAsync(fresh, slab, c->slab_words * 4, hipMemcpyDeviceToDevice, c->stream));
         for (auto& tb : c->tbs) {
-            if (tb.perm.empty() || tb.count == 0) continue;
+            const int extent = tb.device_extent();
+            if (tb.perm.empty() || extent == 0) continue;
             int* d_perm = nullptr;
             HIP_TRY(hipMalloc((void**)&d_perm, tb.perm.size() * 4));
             HIP_TRY(hipMemcpyAsync(d_perm, tb.perm.data(), tb.perm.size() * 4, hipMemcpyHostToDevice, c->stream));
             const size_t offs[3] = {tb.refs_off, tb.prestep_off, tb.accum_off};
             const int rows[3] = {tb.info.bodies, tb.info.prestep, tb.info.impulse};
             for (int r = 0; r < 3; ++r)
-                hipLaunchKernelGGL(unpermute_rows_kernel, dim3((tb.count + 255) / 256), dim3(256), 0, c->stream, (const unsigned*)(slab + offs[r]), (unsigned*)(fresh + offs[r]), (const int*)d_perm,
-                                   tb.count, tb.stride, rows[r]);
+                hipLaunchKernelGGL(unpermute_rows_kernel, dim3((extent + 255) / 256), dim3(256), 0, c->stream, (const unsigned*)(slab + offs[r]), (unsigned*)(fresh + offs[r]), (const int*)d_perm,
+                                   extent, tb.stride, rows[r]);
             HIP_TRY(hipStreamSynchronize(c->stream));
             hipFree(d_perm);
         }
@@ -1245,6 +1265,7 @@ static int32_t leave_island_schedule(bepuhip_ctx* c) {
     }
     for (auto& tb : c->tbs) {
         tb.perm.clear(); tb.inv.clear();
+        tb.slots = 0; tb.seg_begin.clear(); std::vector<int32_t>().swap(tb.dev_refs);
         if (tb.d_device_index) { hipFree(tb.d_device_index); tb.d_device_index = nullptr; }
     }
     for (void** p : {(void**)&c->d_clusters, (void**)&c->d_items, (void**)&c->d_batch_item_begin, (void**)&c->d_cluster_bodies, (void**)&c->d_clustered_dynamic, (void**)&c->d_kinlist,
@@ -1257,11 +1278,13 @@ static int32_t leave_island_schedule(bepuhip_ctx* c) {
     return BEPUHIP_OK;
 }
 
-static int32_t structural_preamble(bepuhip_ctx* c) {
+// `stay`: the caller will try the update on the island layout first (bepu_soft_updates.h) and leaves the island schedule itself if that is not possible.
+static int32_t structural_preamble(bepuhip_ctx* c, bool stay = false) {
     if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
     if (c->building) return fail(BEPUHIP_E_STATE, "structural update between begin_constraints and end_constraints");
     if (c->has_fallback) return fail(BEPUHIP_E_UNSUPPORTED, "structural updates with a sequential fallback batch: re-upload with begin/set/end");
     HIP_TRY(hipSetDevice(c->device));
+    if (stay && c->soft_ok) return BEPUHIP_OK;
     return leave_island_schedule(c);
 }
 
@@ -1273,7 +1296,7 @@ int32_t bepuhip_get_constraint_count(bepuhip_ctx* c, int32_t batch, int32_t type
 }
 
 int32_t bepuhip_add_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, const int32_t* refs, const float* prestep, int32_t* index_out) {
-    int32_t st = structural_preamble(c);
+    int32_t st = structural_preamble(c, true);
     if (st != BEPUHIP_OK) return st;
     if (batch < 0 || !refs || !prestep) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad add_constraint argument");
     if (batch >= c->fallback_threshold) return fail(BEPUHIP_E_UNSUPPORTED, "the constraint belongs to the sequential fallback batch (batch index >= FallbackBatchThreshold)");
@@ -1282,6 +1305,16 @@ int32_t bepuhip_add_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, c
     for (int k = 0; k < info.bodies; ++k)
         if (refs[k] < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "empty body reference");
     HostTypeBatch* tb = find_tb(c, batch, type_id);
+    if (c->soft_ok) {  // on the island layout: a free slot in the segment of the cluster the bodies live in
+        if (tb && soft_add(c, tb, refs, prestep)) {
+            if (index_out) *index_out = tb->count - 1;
+            c->requirk_stale = true;
+            return BEPUHIP_OK;
+        }
+        if (!tb) soft_refuse("the new constraint opens a type batch");
+        if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;
+        tb = find_tb(c, batch, type_id);
+    }
     if (!tb || tb->count == tb->stride) {  // a new type batch (ConstraintBatch.GetOrCreateTypeBatch) or a full one (InternalResize: capacity doubles, TypeProcessor.cs:317-320)
         if ((st = apply_pending_ops(c)) != BEPUHIP_OK) return st;  // queued operations carry offsets of the layout that is about to change
         std::vector<OldLayout> old = current_layout(c);
@@ -1319,10 +1352,15 @@ int32_t bepuhip_add_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, c
 }
 
 int32_t bepuhip_remove_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t index) {
-    int32_t st = structural_preamble(c);
+    int32_t st = structural_preamble(c, true);
     if (st != BEPUHIP_OK) return st;
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb || index < 0 || index >= tb->count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Can only remove elements that are actually in the batch!");  // TypeProcessor.cs:636
+    if (c->soft_ok) {  // on the island layout: the slot is freed where it is, the caller's indices are remapped
+        if (soft_remove(c, tb, index)) { c->requirk_stale = true; return BEPUHIP_OK; }
+        if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;
+        tb = find_tb(c, batch, type_id);
+    }
     const int last = tb->count - 1;
     if (index < last) {  // TypeProcessor.cs:702-714
         bepuhip_ctx::PendingOp p;
@@ -1366,8 +1404,8 @@ static int32_t device_index_of(bepuhip_ctx* c, HostTypeBatch* tb, const int** ou
     if (tb->perm.empty()) return BEPUHIP_OK;  // launch-per-batch layout: host order
     if (!tb->d_device_index) {
         tb->perm_inverse(0);
-        HIP_TRY(hipMalloc((void**)&tb->d_device_index, tb->inv.size() * 4));
-        HIP_TRY(hipMemcpy(tb->d_device_index, tb->inv.data(), tb->inv.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&tb->d_device_index, std::max<size_t>(tb->inv.size(), (size_t)tb->device_extent()) * 4));  // room for every index additions on the island layout can create
+        if (!tb->inv.empty()) HIP_TRY(hipMemcpy(tb->d_device_index, tb->inv.data(), tb->inv.size() * 4, hipMemcpyHostToDevice));
     }
     *out = tb->d_device_index;
     return BEPUHIP_OK;

@@ -23,6 +23,7 @@ BEPUHIP_E_DEVICE = -3
 BEPUHIP_E_STATE = -4
 BEPUHIP_FLAG_NO_GRAPH = 1
 BEPUHIP_FLAG_NO_CLUSTERS = 2
+BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS = 8  # island schedule: spare device slots per cluster segment, so that add_constraint keeps the island schedule
 
 # Every symbol include/bepuhip.h declares (checked by the CPU test-suite against the header).
 EXPORTED_SYMBOLS = [
@@ -171,10 +172,10 @@ class HipSolver:
 
     PROFILE_FAMILIES = ("incremental", "integrate", "warmstart", "solve", "final", "cluster")
 
-    def __init__(self, device: int = 0, bundle_width: int = 8, use_graph: bool = True, use_clusters: bool = True):
+    def __init__(self, device: int = 0, bundle_width: int = 8, use_graph: bool = True, use_clusters: bool = True, reserve_update_slots: bool = False):
         self.lib = load_library()
         self.ctx = C.c_void_p()
-        cfg = Config(device, bundle_width, (0 if use_graph else BEPUHIP_FLAG_NO_GRAPH) | (0 if use_clusters else BEPUHIP_FLAG_NO_CLUSTERS))
+        cfg = Config(device, bundle_width, (0 if use_graph else BEPUHIP_FLAG_NO_GRAPH) | (0 if use_clusters else BEPUHIP_FLAG_NO_CLUSTERS) | (BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS if reserve_update_slots else 0))
         _check(self.lib, self.lib.bepuhip_create(C.byref(cfg), C.byref(self.ctx)))
         self.bundle_width = bundle_width
         self._scene_meta = None

@@ -38,6 +38,8 @@ typedef struct bepuhip_config {
 } bepuhip_config;
 #define BEPUHIP_FLAG_NO_GRAPH 1    /* launch kernels eagerly instead of replaying a captured hipGraph */
 #define BEPUHIP_FLAG_NO_CLUSTERS 2 /* never use the island-per-workgroup (LDS-resident) schedule; always one launch per batch per stage */
+#define BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS 8 /* island schedule: leave an eighth more device slots (at least two) behind every cluster's constraints of every type batch, so that
+                                               bepuhip_add_constraint finds room and the context stays on the island schedule across the narrow phase's add / remove stream */
 /* flag value 4 is reserved (round 1's opt-in cooperative "stream" schedule: measured slower than the graph replay on every scene, now an archived experiment
    under tools/experiments/stream_schedule/) */
 
@@ -176,9 +178,15 @@ int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* ctx, int32_t batch_i
  *                             (BepuPhysics/BodySet.cs:83-110) moves the last body into a freed slot: one reference of one constraint is rewritten. The body array itself is
  *                             re-sent with set_bodies (the host is authoritative for bodies between frames).
  * Cost is proportional to the number of calls: they are queued and applied to the rows in HBM by one small kernel before the next solve / read-back (order preserved per
- * type batch); rows have spare capacity and grow by doubling. The island-per-workgroup schedule needs the whole topology to plan its clusters: the first structural update
- * moves the context to the launch-per-batch schedule (rows back in the caller's order) until the next begin/set/end upload. Not supported (UNSUPPORTED): the sequential
- * fallback batch, and solving in a momentum-conserving AngularIntegrationMode after structural updates (its substep-0 lists are built at upload). */
+ * type batch); rows have spare capacity and grow by doubling.
+ * On the island-per-workgroup schedule (whole islands per workgroup) the updates are applied to the island layout itself as long as they leave the plan's body sets
+ * alone: a removal frees its device slot where it is (the caller's indices are remapped: swap-with-last), an addition takes a free slot of the segment of the cluster its
+ * bodies live in — one left by a removal, or one reserved at planning with BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS — and the predecessor lists of that cluster's work items are
+ * rebuilt. What the plan cannot absorb makes the context fall back to the launch-per-batch schedule (rows back in the caller's order) until the next begin/set/end
+ * upload: an addition whose dynamic bodies are not all in one cluster, or had no constraint, or needs a kinematic body the cluster holds no copy of, or a type batch
+ * the batch does not have yet, or finds no free slot; a frame's updates that leave a body without constraints; update_body_reference; three- and four-body types;
+ * split-island plans. Results are bit-identical either way. Not supported (UNSUPPORTED): the sequential fallback batch, and solving in a momentum-conserving
+ * AngularIntegrationMode after structural updates (its substep-0 lists are built at upload). */
 int32_t bepuhip_add_constraint(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, const int32_t* encoded_body_references, const float* prestep_lane, int32_t* index_out);
 int32_t bepuhip_remove_constraint(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index);
 int32_t bepuhip_update_body_reference(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index, int32_t body_index_in_constraint, int32_t encoded_body_reference);
