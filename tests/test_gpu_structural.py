@@ -75,6 +75,16 @@ def test_sixty_frames_of_contact_churn_stay_bit_exact(hip_solver_factory, use_cl
     # whether the island schedule survived depends on where the random additions landed (see the two tests below); the results may not
 
 
+def _lanes(tb, w, prestep):
+    """Mask over an AOSOA buffer: True for the floats of occupied lanes (the trailing lanes of the last bundle hold nothing)."""
+    fields = tb.prestep_floats if prestep else tb.impulse_floats
+    bundles = (tb.count + w - 1) // w
+    mask = np.zeros((bundles, fields, w), dtype=bool)
+    idx = np.arange(tb.count)
+    mask[idx // w, :, idx % w] = True
+    return mask.reshape(-1)
+
+
 def _decode(ms, encoded):
     from bepuphysics2_amd.scene import BODY_REFERENCE_MASK
     return [int(r) & BODY_REFERENCE_MASK for r in encoded]
@@ -103,6 +113,17 @@ def test_island_schedule_survives_the_refresh_of_persisting_pairs(hip_solver_fac
         for bi, tbs in enumerate(export.batches):
             for tb in tbs:
                 assert solver.constraint_count(bi, tb.type_id) == tb.count
+        if frame % 4 == 1:
+            # the narrow phase's in-place rewrites and the ranged read-backs address constraints by the caller's indices: they have to follow the remapping
+            # (device index tables patched at the flush). Every contact type batch is rewritten with what the mirror holds — a no-op if, and only if, the map is right.
+            for bi, tbs in enumerate(export.batches):
+                for tb in tbs:
+                    if tb.type_id in CONTACT_TYPES and tb.count:
+                        bundles = (tb.count + export.bundle_width - 1) // export.bundle_width
+                        assert np.array_equal(solver.get_prestep_range(bi, tb.type_id, 0, bundles).view(np.int32)[: tb.prestep.size][_lanes(tb, export.bundle_width, True)],
+                                              tb.prestep.view(np.int32)[_lanes(tb, export.bundle_width, True)])
+                        solver.update_prestep(bi, tb.type_id, 0, tb.prestep)
+                        solver.update_accumulated_impulses(bi, tb.type_id, 0, tb.accumulated)
         oracle_ffi.solve(export, 1 / 60, sd, cb)
         ms.absorb(export)
         solver.solve(1 / 60, sd, cb)
