@@ -107,6 +107,7 @@ int TypeBatch::Allocate(int constraintHandle, const int32_t* encodedBodyIndices)
     }
     int bundle = index / W, lane = index % W;
     for (int k = 0; k < Info.bodies; ++k) BodyReferences[(size_t)bundle * Info.bodies * W + (size_t)k * W + lane] = encodedBodyIndices[k];
+    for (int f = 0; f < Info.impulseFloats; ++f) AccumulatedImpulses[(size_t)bundle * Info.impulseFloats * W + (size_t)f * W + lane] = 0.0f;  // a reused lane starts from rest (:327)
     return index;
 }
 TypeBatch& ConstraintBatch::GetOrCreateTypeBatch(int typeId) {  // ConstraintBatch.cs:60-90
@@ -183,9 +184,40 @@ int Solver::Add(const int32_t* bodyHandles, int bodyCount, int typeId, const flo
         float* lane = tb.PrestepData.data() + (size_t)(index / W) * info.prestepFloats * W + (index % W);
         for (int f = 0; f < info.prestepFloats; ++f) lane[(size_t)f * W] = prestepLane[f];
         HandleToConstraint.push_back({b, typeId, index});
+        ++liveConstraints;
+        StructuralChange change{true, b, typeId, index, {-1, -1, -1, -1}, std::vector<float>(prestepLane, prestepLane + info.prestepFloats)};
+        for (int i = 0; i < bodyCount; ++i) change.encoded[i] = encoded[i];
+        StructuralLog.push_back(std::move(change));
         return handle;
     }
     return -1;
+}
+
+void Solver::Remove(int constraintHandle) {
+    if (constraintHandle < 0 || constraintHandle >= (int)HandleToConstraint.size() || HandleToConstraint[constraintHandle].BatchIndex < 0)
+        throw std::invalid_argument("Can only remove elements that are actually in the batch!");  // TypeProcessor.cs:636
+    const ConstraintLocation loc = HandleToConstraint[constraintHandle];
+    ConstraintBatch& batch = Batches[loc.BatchIndex];
+    TypeBatch& tb = batch.TypeBatches[batch.TypeIndexToTypeBatchIndex.at(loc.TypeId)];
+    const int W = kBundleWidth, nb = tb.Info.bodies, pf = tb.Info.prestepFloats, imf = tb.Info.impulseFloats;
+    const int index = loc.IndexInTypeBatch, last = tb.ConstraintCount - 1;
+    auto ref = [&](int i, int k) -> int32_t& { return tb.BodyReferences[(size_t)(i / W) * nb * W + (size_t)k * W + (i % W)]; };
+    for (int k = 0; k < nb; ++k)  // ConstraintBatch.RemoveBodyHandlesFromBatchForConstraint (ConstraintBatch.cs:196-214): dynamic bodies only
+        if ((uint32_t)ref(index, k) < (uint32_t)kKinematicMask) batchReferencedHandles[loc.BatchIndex].Unset(bodies.IndexToHandle[ref(index, k)]);
+    if (index < last) {  // TypeProcessor.Move
+        for (int k = 0; k < nb; ++k) ref(index, k) = ref(last, k);
+        for (int f = 0; f < pf; ++f) tb.PrestepData[(size_t)(index / W) * pf * W + (size_t)f * W + (index % W)] = tb.PrestepData[(size_t)(last / W) * pf * W + (size_t)f * W + (last % W)];
+        for (int f = 0; f < imf; ++f)
+            tb.AccumulatedImpulses[(size_t)(index / W) * imf * W + (size_t)f * W + (index % W)] = tb.AccumulatedImpulses[(size_t)(last / W) * imf * W + (size_t)f * W + (last % W)];
+        tb.IndexToHandle[index] = tb.IndexToHandle[last];
+        HandleToConstraint[tb.IndexToHandle[index]].IndexInTypeBatch = index;
+    }
+    for (int k = 0; k < nb; ++k) ref(last, k) = -1;  // the vacated lane reads as empty again (TypeProcessor.cs:287-298)
+    tb.ConstraintCount = last;
+    HandleToConstraint[constraintHandle].BatchIndex = -1;
+    --liveConstraints;
+    ++TopologyVersion;
+    StructuralLog.push_back(StructuralChange{false, loc.BatchIndex, loc.TypeId, index, {-1, -1, -1, -1}, {}});
 }
 
 void Solver::ValidateBatches() const {
@@ -266,7 +298,7 @@ struct HipApi {
 #define DECL(name) decltype(&::name) name = nullptr;
     DECL(bepuhip_last_error) DECL(bepuhip_create) DECL(bepuhip_destroy) DECL(bepuhip_set_bodies) DECL(bepuhip_begin_constraints)
     DECL(bepuhip_set_type_batch) DECL(bepuhip_end_constraints) DECL(bepuhip_set_constrained_kinematics) DECL(bepuhip_solve)
-    DECL(bepuhip_get_bodies) DECL(bepuhip_get_accumulated_impulses) DECL(bepuhip_get_prestep)
+    DECL(bepuhip_get_bodies) DECL(bepuhip_get_accumulated_impulses) DECL(bepuhip_get_prestep) DECL(bepuhip_add_constraint) DECL(bepuhip_remove_constraint)
 #undef DECL
     bool load(const char* path, std::string& err) {
         lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
@@ -274,7 +306,7 @@ struct HipApi {
 #define LOAD(name) name = (decltype(name))dlsym(lib, #name); if (!name) { err = std::string("missing symbol ") + #name; return false; }
         LOAD(bepuhip_last_error) LOAD(bepuhip_create) LOAD(bepuhip_destroy) LOAD(bepuhip_set_bodies) LOAD(bepuhip_begin_constraints)
         LOAD(bepuhip_set_type_batch) LOAD(bepuhip_end_constraints) LOAD(bepuhip_set_constrained_kinematics) LOAD(bepuhip_solve)
-        LOAD(bepuhip_get_bodies) LOAD(bepuhip_get_accumulated_impulses) LOAD(bepuhip_get_prestep)
+        LOAD(bepuhip_get_bodies) LOAD(bepuhip_get_accumulated_impulses) LOAD(bepuhip_get_prestep) LOAD(bepuhip_add_constraint) LOAD(bepuhip_remove_constraint)
 #undef LOAD
         return true;
     }
@@ -285,10 +317,12 @@ public:
     HipApi api;
     bepuhip_ctx* ctx = nullptr;
     uint64_t uploadedSolverVersion = ~0ull, uploadedBodiesVersion = ~0ull;
+    int fullUploads = 0, structuralReplays = 0;
+    size_t uploadedKinematics = 0;
     HipTimestepper(const char* libraryPath, int device) {
         std::string err;
         if (!api.load(libraryPath, err)) throw std::runtime_error("cannot load libbepuhip: " + err);
-        bepuhip_config cfg{device, kBundleWidth, 0};
+        bepuhip_config cfg{device, kBundleWidth, BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS};  // a simulation adds and removes constraints between frames: plan room for them
         if (api.bepuhip_create(&cfg, &ctx) != BEPUHIP_OK) throw std::runtime_error(std::string("bepuhip_create: ") + api.bepuhip_last_error());
     }
     ~HipTimestepper() override { if (ctx) api.bepuhip_destroy(ctx); }
@@ -305,7 +339,31 @@ public:
         // Topology is re-uploaded only when it changed: keyed on the version counters Solver.Add / Bodies.Add bump (a count comparison would miss a
         // remove + add, or a body move that renumbers references); bodies are host-authoritative every frame.
         check(api.bepuhip_set_bodies(ctx, sim.bodies.DynamicsState.data(), sim.bodies.Count()));
+        // Constraint changes since the last frame: replayed through the structural calls when the log covers exactly what happened since the upload (and is short
+        // next to a re-upload); the library keeps them on the island layout where it can (include/bepuhip.h).
+        if (uploadedBodiesVersion == sim.bodies.TopologyVersion && uploadedSolverVersion != solver.TopologyVersion && solver.StructuralLogBase == uploadedSolverVersion &&
+            solver.StructuralLogBase + solver.StructuralLog.size() == solver.TopologyVersion && (int)solver.StructuralLog.size() * 8 < std::max(64, solver.ConstraintCount())) {
+            for (const Solver::StructuralChange& change : solver.StructuralLog) {
+                if (change.add) {
+                    int32_t index = -1;
+                    check(api.bepuhip_add_constraint(ctx, change.batch, change.typeId, change.encoded, change.prestep.data(), &index));
+                    if (index != change.index) throw std::logic_error("device and host disagree about the index of an added constraint");
+                } else {
+                    check(api.bepuhip_remove_constraint(ctx, change.batch, change.typeId, change.index));
+                }
+            }
+            if (solver.ConstrainedKinematicHandles.size() != uploadedKinematics) {  // an addition brought a kinematic body in
+                std::vector<int32_t> kin;
+                for (int32_t h : solver.ConstrainedKinematicHandles) kin.push_back(sim.bodies.HandleToIndex[h]);
+                check(api.bepuhip_set_constrained_kinematics(ctx, kin.data(), (int)kin.size()));
+                uploadedKinematics = kin.size();
+            }
+            uploadedSolverVersion = solver.TopologyVersion;
+            ++structuralReplays;
+        }
+        solver.ConsumeStructuralLog();
         if (uploadedSolverVersion != solver.TopologyVersion || uploadedBodiesVersion != sim.bodies.TopologyVersion) {
+            ++fullUploads;
             check(api.bepuhip_begin_constraints(ctx, (int)solver.Batches.size(), sim.solveDescription.FallbackBatchThreshold));
             for (size_t b = 0; b < solver.Batches.size(); ++b)
                 for (const TypeBatch& tb : solver.Batches[b].TypeBatches)
@@ -314,6 +372,7 @@ public:
             std::vector<int32_t> kin;
             for (int32_t h : solver.ConstrainedKinematicHandles) kin.push_back(sim.bodies.HandleToIndex[h]);
             check(api.bepuhip_set_constrained_kinematics(ctx, kin.data(), (int)kin.size()));
+            uploadedKinematics = kin.size();
             uploadedSolverVersion = solver.TopologyVersion;
             uploadedBodiesVersion = sim.bodies.TopologyVersion;
         }
@@ -379,6 +438,11 @@ int32_t bepuhost_add_body(void* s, const float* pose7, const float* velocity6, c
 int32_t bepuhost_add_constraint(void* s, int typeId, const int32_t* bodyHandles, int bodyCount, const float* prestepLane) {
     try { return ((Simulation*)s)->solver.Add(bodyHandles, bodyCount, typeId, prestepLane); } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
+int32_t bepuhost_remove_constraint(void* s, int32_t constraintHandle) {
+    try { ((Simulation*)s)->solver.Remove(constraintHandle); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+// Per type batch: the handles of its constraints in index order (TypeBatch.IndexToHandle, TypeBatch.cs:19).
+const int32_t* bepuhost_type_batch_handles(void* s, int b, int t) { return ((Simulation*)s)->solver.Batches[b].TypeBatches[t].IndexToHandle.data(); }
 int32_t bepuhost_validate(void* s) {
     try { ((Simulation*)s)->solver.ValidateBatches(); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
@@ -434,10 +498,18 @@ int32_t bepuhost_attach_hip_timestepper(void* s, const char* libraryPath, int de
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
+// How often the attached HipTimestepper re-uploaded the topology / replayed a structural log instead.
+void bepuhost_timestepper_stats(void* s, int32_t* fullUploads, int32_t* structuralReplays);
 int32_t bepuhost_timestep(void* s, float dt) {
     try { ((Simulation*)s)->Timestep(dt); return 0; }
     catch (const std::invalid_argument& e) { g_err = e.what(); return -1; }
     catch (const std::exception& e) { g_err = e.what(); return -2; }
+}
+
+void bepuhost_timestepper_stats(void* s, int32_t* fullUploads, int32_t* structuralReplays) {
+    HipTimestepper* t = dynamic_cast<HipTimestepper*>(((Simulation*)s)->timestepper);
+    *fullUploads = t ? t->fullUploads : 0;
+    *structuralReplays = t ? t->structuralReplays : 0;
 }
 
 }  // extern "C"

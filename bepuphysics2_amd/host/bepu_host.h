@@ -87,6 +87,7 @@ struct IndexSet {  // BepuUtilities/Collections/IndexSet.cs:12-120
     std::vector<uint64_t> Flags;
     bool Contains(int i) const { return (size_t)(i >> 6) < Flags.size() && ((Flags[i >> 6] >> (i & 63)) & 1ull); }
     void Set(int i) { if ((size_t)(i >> 6) >= Flags.size()) Flags.resize((i >> 6) + 1, 0); Flags[i >> 6] |= 1ull << (i & 63); }
+    void Unset(int i) { if ((size_t)(i >> 6) < Flags.size()) Flags[i >> 6] &= ~(1ull << (i & 63)); }
 };
 struct ConstraintLocation { int BatchIndex, TypeId, IndexInTypeBatch; };
 
@@ -113,10 +114,19 @@ public:
     std::vector<IndexSet> batchReferencedHandles;     // Solver.cs:33
     std::vector<int32_t> ConstrainedKinematicHandles; // Solver.cs:68
     std::vector<ConstraintLocation> HandleToConstraint;
-    int ConstraintCount() const { return (int)HandleToConstraint.size(); }
-    uint64_t TopologyVersion = 0;  // bumped by every Add (and by any future Remove / body memory move): a remove + add leaves the count unchanged but not the layout
+    int ConstraintCount() const { return liveConstraints; }
+    uint64_t TopologyVersion = 0;  // bumped by every Add / Remove: a remove + add leaves the count unchanged but not the layout
     // Solver.Add(bodyHandles, description): prestepLane holds the description's fields in prestep order (what ApplyDescription writes).
     int Add(const int32_t* bodyHandles, int bodyCount, int typeId, const float* prestepLane);
+    // Solver.Remove(handle) (Solver.cs:1528-1560 -> ConstraintBatch.Remove -> TypeProcessor.Remove, TypeProcessor.cs:634-731): the last constraint of the type batch moves
+    // into the freed index (TypeProcessor.Move :578-592), handle -> location of the moved constraint is fixed up, the batch forgets the removed constraint's dynamic bodies.
+    void Remove(int constraintHandle);
+    // What changed since a device mirror last looked, in order, in the terms of include/bepuhip.h's structural updates: a mirror whose upload was taken at
+    // StructuralLogBase replays the log instead of re-uploading (HipTimestepper) and then calls ConsumeStructuralLog.
+    struct StructuralChange { bool add; int batch, typeId, index; int32_t encoded[4]; std::vector<float> prestep; };
+    std::vector<StructuralChange> StructuralLog;
+    uint64_t StructuralLogBase = 0;  // TopologyVersion the log starts from
+    void ConsumeStructuralLog() { StructuralLog.clear(); StructuralLogBase = TopologyVersion; }
     // Integration-responsibility prepass (Solver_Solve.cs:1072-1388).
     struct IntegrationResponsibilities {
         IndexSet mergedConstrainedBodyHandles;
@@ -129,6 +139,7 @@ public:
 private:
     Bodies& bodies;
     std::vector<uint8_t> kinematicConstrained;
+    int liveConstraints = 0;
 };
 
 class Simulation;

@@ -57,6 +57,12 @@ def load_library() -> C.CDLL:
     lib.bepuhost_attach_hip_timestepper.restype = i32
     lib.bepuhost_timestep.argtypes = [vp, C.c_float]
     lib.bepuhost_timestep.restype = i32
+    lib.bepuhost_remove_constraint.argtypes = [vp, i32]
+    lib.bepuhost_remove_constraint.restype = i32
+    lib.bepuhost_type_batch_handles.argtypes = [vp, C.c_int, C.c_int]
+    lib.bepuhost_type_batch_handles.restype = C.POINTER(C.c_int32)
+    lib.bepuhost_timestepper_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.bepuhost_timestepper_stats.restype = None
     _lib = lib
     return lib
 
@@ -118,6 +124,28 @@ class HostSimulation:
         if r < 0:
             raise ValueError(_err(self.lib))
         return r
+
+    def remove_constraint(self, constraint_handle: int):
+        """Solver.Remove(handle): swap-with-last inside its type batch (TypeProcessor.cs:634-731)."""
+        if self.lib.bepuhost_remove_constraint(self.h, int(constraint_handle)) != 0:
+            raise ValueError(_err(self.lib))
+
+    def constraint_handles(self, predicate=lambda type_id: True):
+        """Handles of the live constraints whose type id satisfies ``predicate`` (TypeBatch.IndexToHandle), in batch / type batch / index order."""
+        out = []
+        for b in range(self.lib.bepuhost_batch_count(self.h)):
+            for t in range(self.lib.bepuhost_type_batch_count(self.h, b)):
+                v = TypeBatchView()
+                self.lib.bepuhost_type_batch(self.h, b, t, C.byref(v))
+                if v.count and predicate(v.type_id):
+                    out.extend(_np_from(self.lib.bepuhost_type_batch_handles(self.h, b, t), v.count, np.int32).tolist())
+        return out
+
+    def timestepper_stats(self):
+        """(full topology uploads, structural-log replays) of the attached HipTimestepper."""
+        a, b = C.c_int32(), C.c_int32()
+        self.lib.bepuhost_timestepper_stats(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def validate(self):
         if self.lib.bepuhost_validate(self.h) != 0:

@@ -266,3 +266,48 @@ def test_structural_updates_after_frames_on_the_split_island_plan(hip_solver_fac
         m = pu.compare_scenes(export, got)
         assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (frame, m)
     assert solver.cluster_cycles().size == 0
+
+
+def test_cpp_simulation_adds_and_removes_between_timesteps(hip_solver_factory):
+    """The C++ mirror end to end: Simulation + Solver.Add / Solver.Remove between Timestep calls, HipTimestepper replaying the solver's structural log through
+    bepuhip_add_constraint / remove_constraint instead of re-uploading. Ragdolls in a tube: every frame a few contacts of every ragdoll-vs-tube manifold type are
+    removed and contacts of the same bodies come back (the narrow phase's refresh); each frame's result equals the oracle's solve of that frame's export."""
+    from bepuphysics2_amd.hostlib import HostSimulation
+    sim = HostSimulation.scene("ragdoll_tube", 80, 1, 0, 9)
+    sd, cb = sim.solve_description(), PoseIntegratorCallbacks()
+    sim.attach_hip_timestepper(0)
+    rng = np.random.default_rng(4)
+    contact_ids = {t for t, info in small_scenes.TYPE_TABLE.items() if info[3].startswith("Contact") and "Nonconvex" not in info[3]}
+    for frame in range(12):
+        if frame >= 2:
+            before = sim.export()
+            handles = sim.constraint_handles(lambda t: t in contact_ids)
+            for h in rng.choice(handles, size=12, replace=False):
+                # find the constraint's lane in the export (handle -> location is the mirror's business; the test reads it back from the type batch handles)
+                found = None
+                for bi, tbs in enumerate(before.batches):
+                    for ti, tb in enumerate(tbs):
+                        if tb.type_id in contact_ids and tb.count:
+                            hs = np.ctypeslib.as_array(sim.lib.bepuhost_type_batch_handles(sim.h, bi, ti), shape=(tb.count,))
+                            hit = np.nonzero(hs == h)[0]
+                            if hit.size:
+                                found = (tb.type_id, tb.refs_lanes(8)[int(hit[0])].copy(), tb.prestep_lanes(8)[int(hit[0])].copy())
+                    if found:
+                        break
+                assert found is not None
+                type_id, refs, lane = found
+                sim.remove_constraint(int(h))
+                bodies = [int(before.index_to_handle[int(r) & 0x3FFFFFFF]) for r in refs]
+                sim.add_constraint(type_id, bodies, lane)
+                before = sim.export()
+            sim.validate()
+        export = sim.export()
+        ref = export.copy()
+        oracle_ffi.solve(ref, 1 / 60, sd, cb, threads=4)
+        sim.timestep(1 / 60)
+        got = sim.export()
+        m = pu.compare_scenes(ref, got)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (frame, m)
+    uploads, replays = sim.timestepper_stats()
+    assert uploads == 1 and replays == 10, (uploads, replays)
+    sim.close()
