@@ -367,7 +367,7 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
                                                        unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
     // Lanes beyond the item's count mirror its last constraint and never store: the whole body runs with a full exec mask,
     // which keeps the control flow around the (wave-uniform) waits trivially structured.
-    bool active = lane < h.count;
+    const bool active = lane < h.count;
     const int i = h.start + (active ? lane : h.count - 1), stride = h.stride;
     const gint* lrefs = (const gint*)(slab + h.lrefs_off);
     gfloat* prestep = (gfloat*)(slab + h.prestep_off);
@@ -376,7 +376,6 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     float a[F::impulseFloats];
     // issue the item's global loads first: their latency hides under the velocity-independent work and the wait for the predecessors
     const unsigned both = kRowsNonTemporal ? (unsigned)__builtin_nontemporal_load(&lrefs[i]) : (unsigned)lrefs[i];  // two 16-bit local references per word
-    if constexpr (!SHARED) active = active && (both & kLrefDead) == 0;  // a free device slot (bepu_soft_updates.h): computes like a trailing lane, stores nothing
     const int ra = unpack_local_ref(both & 0xFFFFu);
     const int rb = (F::bodies == 2) ? unpack_local_ref(both >> 16) : -1;
     SharedRef sa = {-1, 0u}, sb = {-1, 0u};

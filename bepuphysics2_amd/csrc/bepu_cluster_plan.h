@@ -41,7 +41,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
 // Device slots a cluster's segment of a type batch gets for `live` constraints: with BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS an eighth more (at least two), so that the
 // narrow phase's additions find room without a new plan.
 static inline int segment_slots(int live, bool reserve) { return (reserve && live > 0) ? live + std::max(2, live / 8) : live; }
-constexpr int32_t kPlanDeadLref = (int32_t)kLrefDead;  // 32-bit planning form of a free slot's local reference
+constexpr int32_t kPlanDeadLref = (int32_t)kDynamicLimit;  // 32-bit planning form of a free slot's local references: the kinematic copy in slot 0 (packs to kLrefDead)
 
 static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     int universe = 0;
@@ -194,7 +194,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
             int32_t* ldst = lrefs.data() + (size_t)k * stride;
             for (int d = 0; d < tb.slots; ++d) {
                 const int h = tb.perm[d];
-                if (h < 0) { ldst[d] = k == 0 ? kPlanDeadLref : 0; continue; }
+                if (h < 0) { ldst[d] = kPlanDeadLref; continue; }
                 if (k == 0) tb.inv[h] = d;
                 const int32_t r = src[h];
                 dst[d] = r;
@@ -271,7 +271,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         for (int k = 0; k < nb; ++k)
             for (int d = 0; d < tb.slots; ++d) {
                 const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + d];
-                const uint32_t half = ((uint32_t)lr & 0x7FFFu) | (((uint32_t)lr >= kDynamicLimit) ? 0x8000u : 0u);  // a free slot's first half is kLrefDead | slot 0
+                const uint32_t half = ((uint32_t)lr & 0x7FFFu) | (((uint32_t)lr >= kDynamicLimit) ? 0x8000u : 0u);  // a free slot packs to kLrefDead
                 packed[(size_t)(k / 2) * tb.stride + d] |= (int32_t)(half << (16 * (k & 1)));
             }
         tb.lrefs_soa.swap(packed);

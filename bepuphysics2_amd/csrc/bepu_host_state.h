@@ -88,8 +88,8 @@ struct HostTypeBatch {
     }
     int32_t* d_device_index = nullptr;  // device copy of `inv` for the ranged update / read-back kernels (allocated on first use)
     // Island layout, whole-island plans (bepu_soft_updates.h): the rows hold `slots` device slots — every cluster's constraints of this type batch in one segment
-    // [seg_begin[cluster], seg_begin[cluster + 1]), live ones and free ones (perm[d] == -1: reserved at planning, or left by a removal; their local references carry
-    // the dead bit). `dev_refs` mirrors the encoded body references per device slot so that a removal knows whose constraint counts it lowers.
+    // [seg_begin[cluster], seg_begin[cluster + 1]), live ones and free ones (perm[d] == -1: reserved at planning, or left by a removal; their local references are
+    // kLrefDead). `dev_refs` mirrors the encoded body references per device slot so that a removal knows whose constraint counts it lowers.
     int slots = 0;
     std::vector<int32_t> seg_begin;
     std::vector<int32_t> dev_refs;

@@ -52,7 +52,9 @@ constexpr int kSlotBodyMask = (1 << 28) - 1;
 // substep for the home cluster's integration, then one per constraint application in the reference's batch order (rank r of d per pass). An application
 // waits for "its" n and leaves n + 1 with the velocity it wrote. `info[body]` = d. `vel` is zeroed before every launch.
 struct SharedTables { float4* vel; const unsigned* info; int poll_sleep; };  // poll_sleep: 64-clock naps between two polls of a record
-constexpr unsigned kLrefDead = 0x4000u;    // whole-island plans: bit 14 of a constraint's FIRST 16-bit local reference marks a free device slot (reserved at planning, or left by a removal)
+constexpr unsigned kLrefDead = 0x80008000u;  // whole-island plans: the packed local references of a free device slot (reserved at planning, or left by a removal): both halves
+                                             // name the kinematic copy in slot 0 — the lane computes on whatever that holds and, like every kinematic reference, writes no body back;
+                                             // what it writes into its own rows is overwritten when the slot is taken again (no extra test in the kernel)
 constexpr unsigned kLrefShared = 0x4000u;  // bit 14 of a 16-bit local reference: velocity through the shared table (bit 15 = kinematic copy, bits 0-13 slot)
 constexpr int kSweepPlanes = 6;       // LDS body table: one plane per 16-byte field of BodyDynamics the sweeps touch (orientation, position, linear, angular, world inertia x 2)
 constexpr int kAllPlanes = 8;         // ... plus the local inertia (read once per substep by the integration phase) when the cluster leaves room for it; otherwise that stays in memory

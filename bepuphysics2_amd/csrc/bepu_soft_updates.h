@@ -2,8 +2,8 @@
 //
 // A whole-island plan lays every type batch out by cluster: one segment of device slots per cluster, live constraints first, free slots behind them (reserved with
 // BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS, or left by removals). The caller keeps addressing constraints by the reference's indices (append at ConstraintCount, swap-with-last
-// on removal: TypeProcessor.cs:314-334, 695-717); `inv` / `perm` translate them to device slots, so on the device a removal only frees a slot (its local reference gets the
-// dead bit: the lane computes like a trailing lane and stores nothing) and an addition fills a free slot of the segment of the cluster its bodies live in.
+// on removal: TypeProcessor.cs:314-334, 695-717); `inv` / `perm` translate them to device slots, so on the device a removal only frees a slot (its local references then name
+// a kinematic copy: the lane computes on, and like every kinematic reference writes no body back) and an addition fills a free slot of the segment of the cluster its bodies live in.
 // What an update may NOT change is the plan's body sets: an addition whose dynamic bodies are not all in ONE cluster (a contact between two islands that were planned
 // into different clusters, or a body that had no constraint), or that needs a kinematic body the cluster holds no copy of, or that finds no free slot, and a
 // removal that would leave a body without constraints (the reference then integrates it as an unconstrained body), make the context leave the island schedule as
