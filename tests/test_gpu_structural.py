@@ -311,3 +311,16 @@ def test_cpp_simulation_adds_and_removes_between_timesteps(hip_solver_factory):
     uploads, replays = sim.timestepper_stats()
     assert uploads == 1 and replays == 10, (uploads, replays)
     sim.close()
+
+
+def test_reserved_layout_falls_back_cleanly_when_the_island_schedule_does_not_apply(hip_solver_factory):
+    """A context planned with spare device slots is asked for more substeps than the island schedule runs (and, separately, for a momentum-conserving angular
+    mode): the launch-per-batch kernels address rows [0, count), so the rows first go back into the caller's order — results as always."""
+    scene = small_scenes.island_scene(5, 30, 12, 28, [22, 4, 30, 47, 7, 5])
+    for sd, cb in ((SolveDescription(1, 17), PoseIntegratorCallbacks()), (SolveDescription(2, 3), PoseIntegratorCallbacks(angular_integration_mode=1))):
+        ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2)
+        solver = hip_solver_factory(reserve_update_slots=True)
+        got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+        assert solver.cluster_cycles().size == 0
+        m = pu.compare_scenes(ref, got)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
