@@ -1,0 +1,256 @@
+// oracle/wide — TEST INFRASTRUCTURE. Constraint types beyond the sixteen of SURVEY.md 8(a), transcribed from the C# alone like the rest of this directory
+// (the widened set gets its second, independent reading one type at a time).
+#pragma once
+#include "wide_joints.h"
+
+namespace wide {
+
+// QuaternionWide.GetAxisAngleFromQuaternion (BepuUtilities/QuaternionWide.cs:227-243)
+static inline void GetAxisAngleFromQuaternion(const QuaternionWide& q, Vector3Wide& axis, VF& angle) {
+    VI shouldNegate = LessThan(q.W, kZero);
+    axis.X = ConditionalSelect(shouldNegate, neg(q.X), q.X);
+    axis.Y = ConditionalSelect(shouldNegate, neg(q.Y), q.Y);
+    axis.Z = ConditionalSelect(shouldNegate, neg(q.Z), q.Z);
+    VF qw = ConditionalSelect(shouldNegate, neg(q.W), q.W);
+    VF axisLength;
+    Vector3Wide::Length(axis, axisLength);
+    Vector3Wide::Scale(axis, kOne / axisLength, axis);
+    VI useFallback = LessThan(axisLength, vf(1e-14f));
+    axis.X = ConditionalSelect(useFallback, kOne, axis.X);
+    axis.Y = ConditionalSelect(useFallback, kZero, axis.Y);
+    axis.Z = ConditionalSelect(useFallback, kZero, axis.Z);
+    VF halfAngle = MathHelper::Acos(qw);
+    angle = vf(2) * halfAngle;
+}
+
+namespace ServoSettingsMore {  // the Vector3Wide overloads of ServoSettingsWide.ComputeClampedBiasVelocity (BepuPhysics/Constraints/ServoSettings.cs:116-143)
+static inline void ComputeClampedBiasVelocity(const Vector3Wide& errorAxis, const VF& errorLength, const VF& positionErrorToBiasVelocity, const ServoSettingsWide& servoSettings, float dt,
+                                              float inverseDt, Vector3Wide& clampedBiasVelocity, VF& maximumImpulse) {  // :116
+    VF baseSpeed = Min(servoSettings.BaseSpeed, errorLength * vf(inverseDt));
+    VF unclampedBiasSpeed = errorLength * positionErrorToBiasVelocity;
+    VF targetSpeed = Max(baseSpeed, unclampedBiasSpeed);
+    VF scale = Min(kOne, servoSettings.MaximumSpeed / targetSpeed);
+    VI useFallback = LessThan(targetSpeed, vf(1e-10f));
+    scale = ConditionalSelect(useFallback, kOne, scale);
+    Vector3Wide::Scale(errorAxis, scale * unclampedBiasSpeed, clampedBiasVelocity);
+    maximumImpulse = servoSettings.MaximumForce * vf(dt);
+}
+static inline void ComputeClampedBiasVelocity(const Vector3Wide& error, const VF& positionErrorToBiasVelocity, const ServoSettingsWide& servoSettings, float dt, float inverseDt,
+                                              Vector3Wide& clampedBiasVelocity, VF& maximumImpulse) {  // :132
+    VF errorLength;
+    Vector3Wide::Length(error, errorLength);
+    Vector3Wide errorAxis;
+    Vector3Wide::Scale(error, kOne / errorLength, errorAxis);
+    VI useFallback = LessThan(errorLength, vf(1e-10f));
+    errorAxis.X = ConditionalSelect(useFallback, kZero, errorAxis.X);
+    errorAxis.Y = ConditionalSelect(useFallback, kZero, errorAxis.Y);
+    errorAxis.Z = ConditionalSelect(useFallback, kZero, errorAxis.Z);
+    ComputeClampedBiasVelocity(errorAxis, errorLength, positionErrorToBiasVelocity, servoSettings, dt, inverseDt, clampedBiasVelocity, maximumImpulse);
+}
+}  // namespace ServoSettingsMore
+
+// BallSocketShared.Solve with an impulse limit (BepuPhysics/Constraints/BallSocketShared.cs:126-135)
+static inline void BallSocketSolveClamped(BodyVelocityWide& velocityA, BodyVelocityWide& velocityB, const Vector3Wide& offsetA, const Vector3Wide& offsetB, const Vector3Wide& biasVelocity,
+                                          const Symmetric3x3Wide& effectiveMass, const VF& softnessImpulseScale, const VF& maximumImpulse, Vector3Wide& accumulatedImpulse,
+                                          const BodyInertiaWide& inertiaA, const BodyInertiaWide& inertiaB) {
+    Vector3Wide correctiveImpulse;
+    BallSocketShared::ComputeCorrectiveImpulse(velocityA, velocityB, offsetA, offsetB, biasVelocity, effectiveMass, softnessImpulseScale, accumulatedImpulse, correctiveImpulse);
+    ServoSettingsWide::ClampImpulse(maximumImpulse, accumulatedImpulse, correctiveImpulse);
+    BallSocketShared::ApplyImpulse(velocityA, velocityB, offsetA, offsetB, inertiaA, inertiaB, correctiveImpulse);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- AngularServo (type id 29)
+struct AngularServoPrestepData { QuaternionWide TargetRelativeRotationLocalA; SpringSettingsWide SpringSettings; ServoSettingsWide ServoSettings; };  // AngularServo.cs:62
+struct AngularServoConstraint {  // AngularServoFunctions, AngularServo.cs:69 (its ApplyImpulse :73 is wide_joints.h's AngularServoFunctions::ApplyImpulse, which AngularMotor shares)
+    typedef AngularServoPrestepData Prestep;
+    typedef Vector3Wide Impulses;
+    static void ApplyImpulse(Vector3Wide& angularVelocityA, Vector3Wide& angularVelocityB, const Symmetric3x3Wide& impulseToVelocityA, const Symmetric3x3Wide& negatedImpulseToVelocityB,
+                             const Vector3Wide& csi) {
+        AngularServoFunctions::ApplyImpulse(angularVelocityA, angularVelocityB, impulseToVelocityA, negatedImpulseToVelocityB, csi);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :101
+        ApplyImpulse(wsvA.Angular, wsvB.Angular, inertiaA.InverseInertiaTensor, inertiaB.InverseInertiaTensor, accumulatedImpulses);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :106
+        QuaternionWide targetOrientationB, inverseTarget, errorRotation;
+        QuaternionWide::ConcatenateWithoutOverlap(prestep.TargetRelativeRotationLocalA, orientationA, targetOrientationB);
+        QuaternionWide::Conjugate(targetOrientationB, inverseTarget);
+        QuaternionWide::ConcatenateWithoutOverlap(inverseTarget, orientationB, errorRotation);
+        Vector3Wide errorAxis;
+        VF errorLength;
+        GetAxisAngleFromQuaternion(errorRotation, errorAxis, errorLength);
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        Symmetric3x3Wide unsoftenedInverseEffectiveMass, unsoftenedEffectiveMass;
+        Symmetric3x3Wide::Add(inertiaA.InverseInertiaTensor, inertiaB.InverseInertiaTensor, unsoftenedInverseEffectiveMass);
+        Symmetric3x3Wide::Invert(unsoftenedInverseEffectiveMass, unsoftenedEffectiveMass);
+        Vector3Wide clampedBiasVelocity;
+        VF maximumImpulse;
+        ServoSettingsMore::ComputeClampedBiasVelocity(errorAxis, errorLength, positionErrorToVelocity, prestep.ServoSettings, dt, inverseDt, clampedBiasVelocity, maximumImpulse);
+        Vector3Wide csv, csi, softnessComponent;
+        Vector3Wide::Subtract(wsvA.Angular, wsvB.Angular, csv);
+        Vector3Wide::Subtract(clampedBiasVelocity, csv, csv);
+        Symmetric3x3Wide::TransformWithoutOverlap(csv, unsoftenedEffectiveMass, csi);
+        csi = csi * effectiveMassCFMScale;
+        Vector3Wide::Scale(accumulatedImpulses, softnessImpulseScale, softnessComponent);
+        Vector3Wide::Subtract(csi, softnessComponent, csi);
+        ServoSettingsWide::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
+        ApplyImpulse(wsvA.Angular, wsvB.Angular, inertiaA.InverseInertiaTensor, inertiaB.InverseInertiaTensor, csi);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- TwistMotor (type id 28)
+struct TwistMotorPrestepData { Vector3Wide LocalAxisA, LocalAxisB; VF TargetVelocity; MotorSettingsWide Settings; };  // TwistMotor.cs:69
+struct TwistMotorFunctions {                                                                                        // TwistMotor.cs:77
+    typedef TwistMotorPrestepData Prestep;
+    typedef VF Impulses;
+    static void ComputeJacobian(const QuaternionWide& orientationA, const QuaternionWide& orientationB, const Vector3Wide& localAxisA, const Vector3Wide& localAxisB, Vector3Wide& jacobianA) {  // :80
+        Vector3Wide axisA, axisB;
+        QuaternionWide::TransformWithoutOverlap(localAxisA, orientationA, axisA);
+        QuaternionWide::TransformWithoutOverlap(localAxisB, orientationB, axisB);
+        Vector3Wide::Add(axisA, axisB, jacobianA);
+        VF length;
+        Vector3Wide::Length(jacobianA, length);
+        Vector3Wide::Scale(jacobianA, kOne / length, jacobianA);
+        Vector3Wide::ConditionalSelect(LessThan(length, vf(1e-10f)), axisA, jacobianA, jacobianA);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :91
+        Vector3Wide jacobianA, impulseToVelocityA, negatedImpulseToVelocityB;
+        ComputeJacobian(orientationA, orientationB, prestep.LocalAxisA, prestep.LocalAxisB, jacobianA);
+        Symmetric3x3Wide::TransformWithoutOverlap(jacobianA, inertiaA.InverseInertiaTensor, impulseToVelocityA);
+        Symmetric3x3Wide::TransformWithoutOverlap(jacobianA, inertiaB.InverseInertiaTensor, negatedImpulseToVelocityB);
+        TwistServoFunctions::ApplyImpulse(wsvA.Angular, wsvB.Angular, impulseToVelocityA, negatedImpulseToVelocityB, accumulatedImpulses);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :99
+        Vector3Wide jacobianA, impulseToVelocityA, negatedImpulseToVelocityB;
+        ComputeJacobian(orientationA, orientationB, prestep.LocalAxisA, prestep.LocalAxisB, jacobianA);
+        VF unsoftenedInverseEffectiveMass;
+        TwistServoFunctions::ComputeEffectiveMassContributions(inertiaA.InverseInertiaTensor, inertiaB.InverseInertiaTensor, jacobianA, impulseToVelocityA, negatedImpulseToVelocityB,
+                                                               unsoftenedInverseEffectiveMass);
+        VF effectiveMassCFMScale, softnessImpulseScale, maximumImpulse;
+        MotorSettingsWide::ComputeSoftness(prestep.Settings, dt, effectiveMassCFMScale, softnessImpulseScale, maximumImpulse);
+        VF effectiveMass = effectiveMassCFMScale / unsoftenedInverseEffectiveMass;
+        Vector3Wide velocityToImpulseA;
+        Vector3Wide::Scale(jacobianA, effectiveMass, velocityToImpulseA);
+        VF biasImpulse = prestep.TargetVelocity * effectiveMass;
+        Vector3Wide netVelocity;
+        Vector3Wide::Subtract(wsvA.Angular, wsvB.Angular, netVelocity);
+        VF csiVelocityComponent;
+        Vector3Wide::Dot(netVelocity, velocityToImpulseA, csiVelocityComponent);
+        VF csi = biasImpulse - accumulatedImpulses * softnessImpulseScale - csiVelocityComponent;
+        VF previousAccumulatedImpulse = accumulatedImpulses;
+        accumulatedImpulses = Max(Min(accumulatedImpulses + csi, maximumImpulse), neg(maximumImpulse));
+        csi = accumulatedImpulses - previousAccumulatedImpulse;
+        TwistServoFunctions::ApplyImpulse(wsvA.Angular, wsvB.Angular, impulseToVelocityA, negatedImpulseToVelocityB, csi);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- AngularAxisMotor (type id 41)
+struct AngularAxisMotorPrestepData { Vector3Wide LocalAxisA; VF TargetVelocity; MotorSettingsWide Settings; };  // AngularAxisMotor.cs:62
+struct AngularAxisMotorFunctions {                                                                            // AngularAxisMotor.cs:69
+    typedef AngularAxisMotorPrestepData Prestep;
+    typedef VF Impulses;
+    static void ApplyImpulse(const Vector3Wide& impulseToVelocityA, const Vector3Wide& negatedImpulseToVelocityB, const VF& csi, Vector3Wide& angularVelocityA, Vector3Wide& angularVelocityB) {  // :72
+        angularVelocityA = angularVelocityA + impulseToVelocityA * csi;
+        angularVelocityB = angularVelocityB - negatedImpulseToVelocityB * csi;
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :79
+        Vector3Wide axis, jIA, jIB;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalAxisA, orientationA, axis);
+        Symmetric3x3Wide::TransformWithoutOverlap(axis, inertiaA.InverseInertiaTensor, jIA);
+        Symmetric3x3Wide::TransformWithoutOverlap(axis, inertiaB.InverseInertiaTensor, jIB);
+        ApplyImpulse(jIA, jIB, accumulatedImpulses, wsvA.Angular, wsvB.Angular);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :88
+        Vector3Wide jA, jIA, jIB;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalAxisA, orientationA, jA);
+        Symmetric3x3Wide::TransformWithoutOverlap(jA, inertiaA.InverseInertiaTensor, jIA);
+        VF contributionA, contributionB;
+        Vector3Wide::Dot(jA, jIA, contributionA);
+        Symmetric3x3Wide::TransformWithoutOverlap(jA, inertiaB.InverseInertiaTensor, jIB);
+        Vector3Wide::Dot(jA, jIB, contributionB);
+        VF effectiveMassCFMScale, softnessImpulseScale, maximumImpulse;
+        MotorSettingsWide::ComputeSoftness(prestep.Settings, dt, effectiveMassCFMScale, softnessImpulseScale, maximumImpulse);
+        VF csi = (prestep.TargetVelocity + Vector3Wide::Dot(wsvB.Angular, jA) - Vector3Wide::Dot(wsvA.Angular, jA)) * effectiveMassCFMScale / (contributionA + contributionB) -
+                 accumulatedImpulses * softnessImpulseScale;
+        ServoSettingsWide::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
+        ApplyImpulse(jIA, jIB, csi, wsvA.Angular, wsvB.Angular);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- BallSocketMotor (type id 52)
+struct BallSocketMotorPrestepData { Vector3Wide LocalOffsetB, TargetVelocityLocalA; MotorSettingsWide Settings; };  // BallSocketMotor.cs:60
+struct BallSocketMotorFunctions {                                                                                 // BallSocketMotor.cs:67
+    typedef BallSocketMotorPrestepData Prestep;
+    typedef Vector3Wide Impulses;
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :69
+        Vector3Wide targetOffsetB;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffsetB, orientationB, targetOffsetB);
+        BallSocketShared::ApplyImpulse(wsvA, wsvB, (positionB - positionA) + targetOffsetB, targetOffsetB, inertiaA, inertiaB, accumulatedImpulses);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :75
+        Vector3Wide targetOffsetB;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffsetB, orientationB, targetOffsetB);
+        Vector3Wide offsetA = (positionB - positionA) + targetOffsetB;
+        VF effectiveMassCFMScale, softnessImpulseScale, maximumImpulse;
+        MotorSettingsWide::ComputeSoftness(prestep.Settings, dt, effectiveMassCFMScale, softnessImpulseScale, maximumImpulse);
+        Symmetric3x3Wide effectiveMass;
+        BallSocketShared::ComputeEffectiveMass(inertiaA, inertiaB, offsetA, targetOffsetB, effectiveMassCFMScale, effectiveMass);
+        Vector3Wide biasVelocity, temp;
+        QuaternionWide::TransformWithoutOverlap(prestep.TargetVelocityLocalA, orientationA, temp);  // QuaternionWide.Transform = TransformWithoutOverlap into a temporary (:283-287)
+        biasVelocity = temp;
+        Vector3Wide::Negate(biasVelocity, biasVelocity);
+        BallSocketSolveClamped(wsvA, wsvB, offsetA, targetOffsetB, biasVelocity, effectiveMass, softnessImpulseScale, maximumImpulse, accumulatedImpulses, inertiaA, inertiaB);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- BallSocketServo (type id 53)
+struct BallSocketServoPrestepData { Vector3Wide LocalOffsetA, LocalOffsetB; SpringSettingsWide SpringSettings; ServoSettingsWide ServoSettings; };  // BallSocketServo.cs:68
+struct BallSocketServoFunctions {                                                                                                                  // BallSocketServo.cs:76
+    typedef BallSocketServoPrestepData Prestep;
+    typedef Vector3Wide Impulses;
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :78
+        Vector3Wide offsetA, offsetB;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffsetA, orientationA, offsetA);
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffsetB, orientationB, offsetB);
+        BallSocketShared::ApplyImpulse(wsvA, wsvB, offsetA, offsetB, inertiaA, inertiaB, accumulatedImpulses);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :85
+        Vector3Wide offsetA, offsetB;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffsetA, orientationA, offsetA);
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffsetB, orientationB, offsetB);
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        Symmetric3x3Wide effectiveMass;
+        BallSocketShared::ComputeEffectiveMass(inertiaA, inertiaB, offsetA, offsetB, effectiveMassCFMScale, effectiveMass);
+        Vector3Wide ab = positionB - positionA;
+        Vector3Wide anchorB, error, biasVelocity;
+        Vector3Wide::Add(ab, offsetB, anchorB);
+        Vector3Wide::Subtract(anchorB, offsetA, error);
+        VF maximumImpulse;
+        ServoSettingsMore::ComputeClampedBiasVelocity(error, positionErrorToVelocity, prestep.ServoSettings, dt, inverseDt, biasVelocity, maximumImpulse);
+        BallSocketSolveClamped(wsvA, wsvB, offsetA, offsetB, biasVelocity, effectiveMass, softnessImpulseScale, maximumImpulse, accumulatedImpulses, inertiaA, inertiaB);
+    }
+};
+
+}  // namespace wide

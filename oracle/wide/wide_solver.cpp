@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "wide_contacts.h"
+#include "wide_joints_more.h"
 
 namespace wide {
 
@@ -640,6 +641,12 @@ static TypeProcessor* CreateProcessor(int typeId) {  // BepuPhysics/DefaultTypes
         case 30: return new TwoBodyTypeProcessor<NoIncremental<AngularMotorFunctions>, false, false, false, false, false>();  // AngularMotor.cs:96
         case 46: return new TwoBodyTypeProcessor<NoIncremental<SwivelHingeFunctions>, true, true, true, true, false>();       // SwivelHinge.cs:216
         case 47: return new TwoBodyTypeProcessor<NoIncremental<HingeFunctions>, true, true, true, true, false>();             // Hinge.cs:224
+        // widened set (wide_joints_more.h)
+        case 28: return new TwoBodyTypeProcessor<NoIncremental<TwistMotorFunctions>, false, false, false, false, false>();        // TwistMotor.cs:130 OnlyAngular x4
+        case 29: return new TwoBodyTypeProcessor<NoIncremental<AngularServoConstraint>, false, false, false, false, false>();      // AngularServo.cs:141 OnlyAngularWithoutPose x2, OnlyAngular x2
+        case 41: return new TwoBodyTypeProcessor<NoIncremental<AngularAxisMotorFunctions>, false, false, false, false, false>();  // AngularAxisMotor.cs:109
+        case 52: return new TwoBodyTypeProcessor<NoIncremental<BallSocketMotorFunctions>, true, true, true, true, false>();       // BallSocketMotor.cs:99 NoOrientation, All, All, All
+        case 53: return new TwoBodyTypeProcessor<NoIncremental<BallSocketServoFunctions>, true, true, true, true, false>();       // BallSocketServo.cs:109 NoPosition x2, All x2
         default: return nullptr;
     }
 }
