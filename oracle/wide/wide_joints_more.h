@@ -253,4 +253,207 @@ struct BallSocketServoFunctions {                                               
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------- AngularSwivelHinge (type id 24)
+struct AngularSwivelHingePrestepData { Vector3Wide LocalSwivelAxisA, LocalHingeAxisB; SpringSettingsWide SpringSettings; };  // AngularSwivelHinge.cs:64
+struct AngularSwivelHingeFunctions {                                                                                          // AngularSwivelHinge.cs:71
+    typedef AngularSwivelHingePrestepData Prestep;
+    typedef VF Impulses;
+    static void ApplyImpulse(const Vector3Wide& impulseToVelocityA, const Vector3Wide& negatedImpulseToVelocityB, const VF& csi, Vector3Wide& angularVelocityA, Vector3Wide& angularVelocityB) {  // :74
+        Vector3Wide velocityChangeA, negatedVelocityChangeB;
+        Vector3Wide::Scale(impulseToVelocityA, csi, velocityChangeA);
+        Vector3Wide::Add(angularVelocityA, velocityChangeA, angularVelocityA);
+        Vector3Wide::Scale(negatedImpulseToVelocityB, csi, negatedVelocityChangeB);
+        Vector3Wide::Subtract(angularVelocityB, negatedVelocityChangeB, angularVelocityB);
+    }
+    static void ComputeJacobian(const Vector3Wide& localSwivelAxisA, const Vector3Wide& localHingeAxisB, const QuaternionWide& orientationA, const QuaternionWide& orientationB,
+                                Vector3Wide& swivelAxis, Vector3Wide& hingeAxis, Vector3Wide& jacobianA) {  // :83
+        QuaternionWide::TransformWithoutOverlap(localSwivelAxisA, orientationA, swivelAxis);
+        QuaternionWide::TransformWithoutOverlap(localHingeAxisB, orientationB, hingeAxis);
+        Vector3Wide::CrossWithoutOverlap(swivelAxis, hingeAxis, jacobianA);
+        Vector3Wide fallbackJacobian;
+        Helpers::FindPerpendicular(swivelAxis, fallbackJacobian);
+        VF jacobianLengthSquared;
+        Vector3Wide::Dot(jacobianA, jacobianA, jacobianLengthSquared);
+        VI useFallback = LessThan(jacobianLengthSquared, vf(1e-3f));
+        Vector3Wide::ConditionalSelect(useFallback, fallbackJacobian, jacobianA, jacobianA);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :97
+        Vector3Wide swivelAxis, hingeAxis, jacobianA, impulseToVelocityA, negatedImpulseToVelocityB;
+        ComputeJacobian(prestep.LocalSwivelAxisA, prestep.LocalHingeAxisB, orientationA, orientationB, swivelAxis, hingeAxis, jacobianA);
+        Symmetric3x3Wide::TransformWithoutOverlap(jacobianA, inertiaA.InverseInertiaTensor, impulseToVelocityA);
+        Symmetric3x3Wide::TransformWithoutOverlap(jacobianA, inertiaB.InverseInertiaTensor, negatedImpulseToVelocityB);
+        ApplyImpulse(impulseToVelocityA, negatedImpulseToVelocityB, accumulatedImpulses, wsvA.Angular, wsvB.Angular);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :105
+        Vector3Wide swivelAxis, hingeAxis, jacobianA, impulseToVelocityA, negatedImpulseToVelocityB;
+        ComputeJacobian(prestep.LocalSwivelAxisA, prestep.LocalHingeAxisB, orientationA, orientationB, swivelAxis, hingeAxis, jacobianA);
+        Symmetric3x3Wide::TransformWithoutOverlap(jacobianA, inertiaA.InverseInertiaTensor, impulseToVelocityA);
+        Symmetric3x3Wide::TransformWithoutOverlap(jacobianA, inertiaB.InverseInertiaTensor, negatedImpulseToVelocityB);
+        VF angularA, angularB;
+        Vector3Wide::Dot(impulseToVelocityA, jacobianA, angularA);
+        Vector3Wide::Dot(negatedImpulseToVelocityB, jacobianA, angularB);
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        VF effectiveMass = effectiveMassCFMScale / (angularA + angularB);
+        VF error;
+        Vector3Wide::Dot(hingeAxis, swivelAxis, error);
+        VF biasVelocity = neg(positionErrorToVelocity * error);
+        Vector3Wide difference;
+        Vector3Wide::Subtract(wsvA.Angular, wsvB.Angular, difference);
+        VF csv;
+        Vector3Wide::Dot(difference, jacobianA, csv);
+        VF csi = effectiveMass * (biasVelocity - csv) - accumulatedImpulses * softnessImpulseScale;
+        accumulatedImpulses = accumulatedImpulses + csi;
+        ApplyImpulse(impulseToVelocityA, negatedImpulseToVelocityB, csi, wsvA.Angular, wsvB.Angular);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- AngularAxisGearMotor (type id 54)
+struct AngularAxisGearMotorPrestepData { Vector3Wide LocalAxisA; VF VelocityScale; MotorSettingsWide Settings; };  // AngularAxisGearMotor.cs:63
+struct AngularAxisGearMotorFunctions {                                                                           // AngularAxisGearMotor.cs:70
+    typedef AngularAxisGearMotorPrestepData Prestep;
+    typedef VF Impulses;
+    static void ApplyImpulse(const Vector3Wide& impulseToVelocityA, const Vector3Wide& negatedImpulseToVelocityB, const VF& csi, Vector3Wide& angularVelocityA, Vector3Wide& angularVelocityB) {  // :73
+        angularVelocityA = angularVelocityA + impulseToVelocityA * csi;
+        angularVelocityB = angularVelocityB - negatedImpulseToVelocityB * csi;
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :80
+        Vector3Wide axis, jA, impulseToVelocityA, negatedImpulseToVelocityB;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalAxisA, orientationA, axis);
+        Vector3Wide::Scale(axis, prestep.VelocityScale, jA);
+        Symmetric3x3Wide::TransformWithoutOverlap(jA, inertiaA.InverseInertiaTensor, impulseToVelocityA);
+        Symmetric3x3Wide::TransformWithoutOverlap(axis, inertiaB.InverseInertiaTensor, negatedImpulseToVelocityB);
+        ApplyImpulse(impulseToVelocityA, negatedImpulseToVelocityB, accumulatedImpulses, wsvA.Angular, wsvB.Angular);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :90
+        Vector3Wide axis, jA, impulseToVelocityA, negatedImpulseToVelocityB;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalAxisA, orientationA, axis);
+        Vector3Wide::Scale(axis, prestep.VelocityScale, jA);
+        Symmetric3x3Wide::TransformWithoutOverlap(jA, inertiaA.InverseInertiaTensor, impulseToVelocityA);
+        VF contributionA, contributionB;
+        Vector3Wide::Dot(jA, impulseToVelocityA, contributionA);
+        Symmetric3x3Wide::TransformWithoutOverlap(axis, inertiaB.InverseInertiaTensor, negatedImpulseToVelocityB);
+        Vector3Wide::Dot(axis, negatedImpulseToVelocityB, contributionB);
+        VF effectiveMassCFMScale, softnessImpulseScale, maximumImpulse;
+        MotorSettingsWide::ComputeSoftness(prestep.Settings, dt, effectiveMassCFMScale, softnessImpulseScale, maximumImpulse);
+        VF effectiveMass = effectiveMassCFMScale / (contributionA + contributionB);
+        VF unscaledCSVA, negatedCSVB;
+        Vector3Wide::Dot(wsvA.Angular, jA, unscaledCSVA);
+        Vector3Wide::Dot(wsvB.Angular, axis, negatedCSVB);
+        VF csi = (negatedCSVB - unscaledCSVA) * effectiveMass - accumulatedImpulses * softnessImpulseScale;
+        ServoSettingsWide::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
+        ApplyImpulse(impulseToVelocityA, negatedImpulseToVelocityB, accumulatedImpulses, wsvA.Angular, wsvB.Angular);  // as written in the reference (:108): the accumulated impulse, not csi
+    }
+};
+
+// MathHelper.FastReciprocal / FastReciprocalSquareRoot (BepuUtilities/MathHelper.cs:380-412): the branch every target without the x86 approximation instructions takes.
+// (On AVX hosts the reference uses vrcpps / vrsqrtps, whose low bits differ between CPU vendors; oracle/ and the device restate this portable branch too.)
+static inline VF FastReciprocal(VF v) { return kOne / v; }
+static inline VF FastReciprocalSquareRoot(VF v) { return kOne / SquareRoot(v); }
+
+// ---------------------------------------------------------------------------------------------------------------- CenterDistanceConstraint (type id 35)
+struct CenterDistancePrestepData { VF TargetDistance; SpringSettingsWide SpringSettings; };  // CenterDistanceConstraint.cs:63
+struct CenterDistanceConstraintFunctions {                                                  // CenterDistanceConstraint.cs:69
+    typedef CenterDistancePrestepData Prestep;
+    typedef VF Impulses;
+    static void ApplyImpulse(const Vector3Wide& jacobianA, const VF& inverseMassA, const VF& inverseMassB, const VF& impulse, BodyVelocityWide& a, BodyVelocityWide& b) {  // :72
+        Vector3Wide changeA, negatedChangeB;
+        Vector3Wide::Scale(jacobianA, impulse * inverseMassA, changeA);
+        Vector3Wide::Scale(jacobianA, impulse * inverseMassB, negatedChangeB);
+        Vector3Wide::Add(a.Linear, changeA, a.Linear);
+        Vector3Wide::Subtract(b.Linear, negatedChangeB, b.Linear);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :82
+        Vector3Wide ab = positionB - positionA;
+        VF lengthSquared = ab.X * ab.X + ab.Y * ab.Y + ab.Z * ab.Z;
+        VF inverseDistance = FastReciprocalSquareRoot(lengthSquared);
+        VI useFallback = LessThan(lengthSquared, vf(1e-10f));
+        Vector3Wide jacobianA;
+        Vector3Wide::Scale(ab, inverseDistance, jacobianA);
+        jacobianA.X = ConditionalSelect(useFallback, kOne, jacobianA.X);
+        jacobianA.Y = ConditionalSelect(useFallback, kZero, jacobianA.Y);
+        jacobianA.Z = ConditionalSelect(useFallback, kZero, jacobianA.Z);
+        ApplyImpulse(jacobianA, inertiaA.InverseMass, inertiaB.InverseMass, accumulatedImpulses, wsvA, wsvB);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulse,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :98
+        Vector3Wide ab = positionB - positionA;
+        VF distance = SquareRoot(ab.X * ab.X + ab.Y * ab.Y + ab.Z * ab.Z);
+        VF inverseDistance = FastReciprocal(distance);
+        VI useFallback = LessThan(distance, vf(1e-5f));
+        Vector3Wide jacobianA;
+        Vector3Wide::Scale(ab, inverseDistance, jacobianA);
+        jacobianA.X = ConditionalSelect(useFallback, kOne, jacobianA.X);
+        jacobianA.Y = ConditionalSelect(useFallback, kZero, jacobianA.Y);
+        jacobianA.Z = ConditionalSelect(useFallback, kZero, jacobianA.Z);
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        VF effectiveMass = effectiveMassCFMScale / (inertiaA.InverseMass + inertiaB.InverseMass);
+        VF biasVelocity = (distance - prestep.TargetDistance) * positionErrorToVelocity;
+        VF linearCSVA, negatedCSVB;
+        Vector3Wide::Dot(wsvA.Linear, jacobianA, linearCSVA);
+        Vector3Wide::Dot(wsvB.Linear, jacobianA, negatedCSVB);
+        VF csi = (biasVelocity - (linearCSVA - negatedCSVB)) * effectiveMass - accumulatedImpulse * softnessImpulseScale;
+        accumulatedImpulse = accumulatedImpulse + csi;
+        ApplyImpulse(jacobianA, inertiaA.InverseMass, inertiaB.InverseMass, csi, wsvA, wsvB);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- CenterDistanceLimit (type id 55)
+struct CenterDistanceLimitPrestepData { VF MinimumDistance, MaximumDistance; SpringSettingsWide SpringSettings; };  // CenterDistanceLimit.cs:71
+struct CenterDistanceLimitFunctions {                                                                              // CenterDistanceLimit.cs:78
+    typedef CenterDistanceLimitPrestepData Prestep;
+    typedef VF Impulses;
+    static void ComputeJacobian(VF minimumDistance, VF maximumDistance, const Vector3Wide& positionA, const Vector3Wide& positionB, Vector3Wide& jacobianA, VF& distance, VI& useMinimum) {  // :81
+        Vector3Wide ab = positionB - positionA;
+        distance = SquareRoot(ab.X * ab.X + ab.Y * ab.Y + ab.Z * ab.Z);
+        VF inverseDistance = FastReciprocal(distance);
+        VI useFallback = LessThan(distance, vf(1e-5f));
+        Vector3Wide::Scale(ab, inverseDistance, jacobianA);
+        jacobianA.X = ConditionalSelect(useFallback, kOne, jacobianA.X);
+        jacobianA.Y = ConditionalSelect(useFallback, kZero, jacobianA.Y);
+        jacobianA.Z = ConditionalSelect(useFallback, kZero, jacobianA.Z);
+        useMinimum = LessThan(Abs(distance - minimumDistance), Abs(distance - maximumDistance));
+        Vector3Wide negated = -jacobianA;
+        Vector3Wide::ConditionalSelect(useMinimum, negated, jacobianA, jacobianA);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :96
+        Vector3Wide jacobianA;
+        VF distance;
+        VI useMinimum;
+        ComputeJacobian(prestep.MinimumDistance, prestep.MaximumDistance, positionA, positionB, jacobianA, distance, useMinimum);
+        CenterDistanceConstraintFunctions::ApplyImpulse(jacobianA, inertiaA.InverseMass, inertiaB.InverseMass, accumulatedImpulses, wsvA, wsvB);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulse,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :102
+        Vector3Wide jacobianA;
+        VF distance;
+        VI useMinimum;
+        ComputeJacobian(prestep.MinimumDistance, prestep.MaximumDistance, positionA, positionB, jacobianA, distance, useMinimum);
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        VF effectiveMass = effectiveMassCFMScale / (inertiaA.InverseMass + inertiaB.InverseMass);
+        VF error = ConditionalSelect(useMinimum, prestep.MinimumDistance - distance, distance - prestep.MaximumDistance);
+        VF biasVelocity = Min(error * vf(inverseDt), error * positionErrorToVelocity);  // InequalityHelpers.ComputeBiasVelocity (InequalityHelpers.cs:9-12)
+        VF csv = Vector3Wide::Dot(wsvA.Linear, jacobianA) - Vector3Wide::Dot(wsvB.Linear, jacobianA);
+        VF csi = neg(accumulatedImpulse) * softnessImpulseScale - effectiveMass * (csv - biasVelocity);
+        InequalityHelpers::ClampPositive(accumulatedImpulse, csi);
+        CenterDistanceConstraintFunctions::ApplyImpulse(jacobianA, inertiaA.InverseMass, inertiaB.InverseMass, csi, wsvA, wsvB);
+    }
+};
+
 }  // namespace wide

@@ -647,6 +647,10 @@ static TypeProcessor* CreateProcessor(int typeId) {  // BepuPhysics/DefaultTypes
         case 41: return new TwoBodyTypeProcessor<NoIncremental<AngularAxisMotorFunctions>, false, false, false, false, false>();  // AngularAxisMotor.cs:109
         case 52: return new TwoBodyTypeProcessor<NoIncremental<BallSocketMotorFunctions>, true, true, true, true, false>();       // BallSocketMotor.cs:99 NoOrientation, All, All, All
         case 53: return new TwoBodyTypeProcessor<NoIncremental<BallSocketServoFunctions>, true, true, true, true, false>();       // BallSocketServo.cs:109 NoPosition x2, All x2
+        case 24: return new TwoBodyTypeProcessor<NoIncremental<AngularSwivelHingeFunctions>, false, false, false, false, false>();    // AngularSwivelHinge.cs:151 OnlyAngular x4
+        case 54: return new TwoBodyTypeProcessor<NoIncremental<AngularAxisGearMotorFunctions>, false, false, false, false, false>();  // AngularAxisGearMotor.cs:117
+        case 35: return new TwoBodyTypeProcessor<NoIncremental<CenterDistanceConstraintFunctions>, true, true, true, true, false>();  // CenterDistanceConstraint.cs:135 OnlyLinear x4 (the angular halves go back unchanged)
+        case 55: return new TwoBodyTypeProcessor<NoIncremental<CenterDistanceLimitFunctions>, true, true, true, true, false>();       // CenterDistanceLimit.cs:134
         default: return nullptr;
     }
 }
