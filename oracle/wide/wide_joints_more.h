@@ -456,4 +456,308 @@ struct CenterDistanceLimitFunctions {                                           
     }
 };
 
+namespace InequalityHelpers {  // BepuPhysics/Constraints/InequalityHelpers.cs:9-12
+static inline void ComputeBiasVelocity(VF error, VF positionErrorToVelocity, float inverseDt, VF& biasVelocity) { biasVelocity = Min(error * vf(inverseDt), error * positionErrorToVelocity); }
+}  // namespace InequalityHelpers
+
+// ---------------------------------------------------------------------------------------------------------------- DistanceServo (type id 33)
+struct DistanceServoPrestepData { Vector3Wide LocalOffsetA, LocalOffsetB; VF TargetDistance; ServoSettingsWide ServoSettings; SpringSettingsWide SpringSettings; };  // DistanceServo.cs:97
+struct DistanceServoFunctions {                                                                                                                                    // DistanceServo.cs:106
+    typedef DistanceServoPrestepData Prestep;
+    typedef VF Impulses;
+    static void GetDistance(const QuaternionWide& orientationA, const Vector3Wide& ab, const QuaternionWide& orientationB, const Vector3Wide& localOffsetA, const Vector3Wide& localOffsetB,
+                            Vector3Wide& anchorOffsetA, Vector3Wide& anchorOffsetB, Vector3Wide& anchorOffset, VF& distance) {  // :108
+        QuaternionWide::TransformWithoutOverlap(localOffsetA, orientationA, anchorOffsetA);
+        QuaternionWide::TransformWithoutOverlap(localOffsetB, orientationB, anchorOffsetB);
+        Vector3Wide anchorB;
+        Vector3Wide::Add(anchorOffsetB, ab, anchorB);
+        Vector3Wide::Subtract(anchorB, anchorOffsetA, anchorOffset);
+        Vector3Wide::Length(anchorOffset, distance);
+    }
+    static void ComputeJacobian(const VF& distance, const Vector3Wide& anchorOffsetA, const Vector3Wide& anchorOffsetB, Vector3Wide& direction, Vector3Wide& angularJA, Vector3Wide& angularJB) {  // :119
+        VI needFallback = LessThan(distance, vf(1e-9f));
+        direction.X = ConditionalSelect(needFallback, kOne, direction.X);
+        direction.Y = ConditionalSelect(needFallback, kZero, direction.Y);
+        direction.Z = ConditionalSelect(needFallback, kZero, direction.Z);
+        Vector3Wide::CrossWithoutOverlap(anchorOffsetA, direction, angularJA);
+        Vector3Wide::CrossWithoutOverlap(direction, anchorOffsetB, angularJB);
+    }
+    static void ComputeTransforms(const BodyInertiaWide& inertiaA, const BodyInertiaWide& inertiaB, const Vector3Wide& anchorOffsetA, const Vector3Wide& anchorOffsetB, const VF& distance,
+                                  Vector3Wide& direction, float dt, const SpringSettingsWide& springSettings, VF& positionErrorToVelocity, VF& softnessImpulseScale, VF& effectiveMass,
+                                  Vector3Wide& angularJA, Vector3Wide& angularJB, Vector3Wide& angularImpulseToVelocityA, Vector3Wide& angularImpulseToVelocityB) {  // :132
+        ComputeJacobian(distance, anchorOffsetA, anchorOffsetB, direction, angularJA, angularJB);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJA, inertiaA.InverseInertiaTensor, angularImpulseToVelocityA);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJB, inertiaB.InverseInertiaTensor, angularImpulseToVelocityB);
+        VF angularContributionA, angularContributionB;
+        Vector3Wide::Dot(angularJA, angularImpulseToVelocityA, angularContributionA);
+        Vector3Wide::Dot(angularJB, angularImpulseToVelocityB, angularContributionB);
+        VF inverseEffectiveMass = inertiaA.InverseMass + inertiaB.InverseMass + angularContributionA + angularContributionB;
+        VF effectiveMassCFMScale;
+        SpringSettingsWide::ComputeSpringiness(springSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        effectiveMass = effectiveMassCFMScale / inverseEffectiveMass;
+    }
+    static void ApplyImpulse(const VF& inverseMassA, const VF& inverseMassB, const Vector3Wide& direction, const Vector3Wide& angularImpulseToVelocityA,
+                             const Vector3Wide& angularImpulseToVelocityB, const VF& csi, BodyVelocityWide& velocityA, BodyVelocityWide& velocityB) {  // :173
+        Vector3Wide linearVelocityChangeA, angularVelocityChangeA, negatedLinearVelocityChangeB, angularVelocityChangeB;
+        Vector3Wide::Scale(direction, csi * inverseMassA, linearVelocityChangeA);
+        Vector3Wide::Scale(angularImpulseToVelocityA, csi, angularVelocityChangeA);
+        Vector3Wide::Add(linearVelocityChangeA, velocityA.Linear, velocityA.Linear);
+        Vector3Wide::Add(angularVelocityChangeA, velocityA.Angular, velocityA.Angular);
+        Vector3Wide::Scale(direction, csi * inverseMassB, negatedLinearVelocityChangeB);
+        Vector3Wide::Scale(angularImpulseToVelocityB, csi, angularVelocityChangeB);
+        Vector3Wide::Subtract(velocityB.Linear, negatedLinearVelocityChangeB, velocityB.Linear);
+        Vector3Wide::Add(angularVelocityChangeB, velocityB.Angular, velocityB.Angular);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :189
+        Vector3Wide anchorOffsetA, anchorOffsetB, anchorOffset, direction, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB;
+        VF distance;
+        GetDistance(orientationA, positionB - positionA, orientationB, prestep.LocalOffsetA, prestep.LocalOffsetB, anchorOffsetA, anchorOffsetB, anchorOffset, distance);
+        Vector3Wide::Scale(anchorOffset, kOne / distance, direction);
+        ComputeJacobian(distance, anchorOffsetA, anchorOffsetB, direction, angularJA, angularJB);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJA, inertiaA.InverseInertiaTensor, angularImpulseToVelocityA);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJB, inertiaB.InverseInertiaTensor, angularImpulseToVelocityB);
+        ApplyImpulse(inertiaA.InverseMass, inertiaB.InverseMass, direction, angularImpulseToVelocityA, angularImpulseToVelocityB, accumulatedImpulses, wsvA, wsvB);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :199
+        Vector3Wide anchorOffsetA, anchorOffsetB, anchorOffset, direction, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB;
+        VF distance, positionErrorToVelocity, softnessImpulseScale, effectiveMass;
+        GetDistance(orientationA, positionB - positionA, orientationB, prestep.LocalOffsetA, prestep.LocalOffsetB, anchorOffsetA, anchorOffsetB, anchorOffset, distance);
+        Vector3Wide::Scale(anchorOffset, kOne / distance, direction);
+        ComputeTransforms(inertiaA, inertiaB, anchorOffsetA, anchorOffsetB, distance, direction, dt, prestep.SpringSettings, positionErrorToVelocity, softnessImpulseScale, effectiveMass,
+                          angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB);
+        VF error = distance - prestep.TargetDistance;
+        VF clampedBiasVelocity, maximumImpulse;
+        ServoSettingsWide::ComputeClampedBiasVelocity(error, positionErrorToVelocity, prestep.ServoSettings, dt, inverseDt, clampedBiasVelocity, maximumImpulse);
+        VF linearCSVA, negatedLinearCSVB, angularCSVA, angularCSVB;
+        Vector3Wide::Dot(wsvA.Linear, direction, linearCSVA);
+        Vector3Wide::Dot(wsvB.Linear, direction, negatedLinearCSVB);
+        Vector3Wide::Dot(wsvA.Angular, angularJA, angularCSVA);
+        Vector3Wide::Dot(wsvB.Angular, angularJB, angularCSVB);
+        VF csi = (clampedBiasVelocity - linearCSVA - angularCSVA + negatedLinearCSVB - angularCSVB) * effectiveMass - accumulatedImpulses * softnessImpulseScale;
+        ServoSettingsWide::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
+        ApplyImpulse(inertiaA.InverseMass, inertiaB.InverseMass, direction, angularImpulseToVelocityA, angularImpulseToVelocityB, csi, wsvA, wsvB);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- DistanceLimit (type id 34)
+struct DistanceLimitPrestepData { Vector3Wide LocalOffsetA, LocalOffsetB; VF MinimumDistance, MaximumDistance; SpringSettingsWide SpringSettings; };  // DistanceLimit.cs:94
+struct DistanceLimitFunctions {                                                                                                                     // DistanceLimit.cs:103
+    typedef DistanceLimitPrestepData Prestep;
+    typedef VF Impulses;
+    static void ApplyImpulse(const Vector3Wide& linearJacobianA, const Vector3Wide& angularJacobianA, const Vector3Wide& angularJacobianB, const BodyInertiaWide& inertiaA,
+                             const BodyInertiaWide& inertiaB, const VF& csi, BodyVelocityWide& velocityA, BodyVelocityWide& velocityB) {  // :106
+        Vector3Wide impulseScaledLinearJacobian = linearJacobianA * csi;
+        velocityA.Linear = velocityA.Linear + impulseScaledLinearJacobian * inertiaA.InverseMass;
+        velocityB.Linear = velocityB.Linear - impulseScaledLinearJacobian * inertiaB.InverseMass;
+        velocityA.Angular = velocityA.Angular + (angularJacobianA * csi) * inertiaA.InverseInertiaTensor;
+        velocityB.Angular = velocityB.Angular + (angularJacobianB * csi) * inertiaB.InverseInertiaTensor;
+    }
+    static void ComputeJacobians(const Vector3Wide& localOffsetA, const Vector3Wide& positionA, const QuaternionWide& orientationA, const Vector3Wide& localOffsetB, const Vector3Wide& positionB,
+                                 const QuaternionWide& orientationB, const VF& minimumDistance, const VF& maximumDistance, VI& useMinimum, VF& distance, Vector3Wide& direction,
+                                 Vector3Wide& angularJA, Vector3Wide& angularJB) {  // :118
+        Vector3Wide offsetA, offsetB;
+        QuaternionWide::TransformWithoutOverlap(localOffsetA, orientationA, offsetA);
+        QuaternionWide::TransformWithoutOverlap(localOffsetB, orientationB, offsetB);
+        Vector3Wide anchorOffset = (offsetB - offsetA) + (positionB - positionA);
+        Vector3Wide::Length(anchorOffset, distance);
+        useMinimum = LessThan(Abs(distance - minimumDistance), Abs(distance - maximumDistance));
+        VF sign = ConditionalSelect(useMinimum, vf(-1.0f), kOne);
+        Vector3Wide::Scale(anchorOffset, sign / distance, direction);
+        VI needFallback = LessThan(distance, vf(1e-9f));
+        direction.X = ConditionalSelect(needFallback, kOne, direction.X);
+        direction.Y = ConditionalSelect(needFallback, kZero, direction.Y);
+        direction.Z = ConditionalSelect(needFallback, kZero, direction.Z);
+        Vector3Wide::CrossWithoutOverlap(offsetA, direction, angularJA);
+        Vector3Wide::CrossWithoutOverlap(direction, offsetB, angularJB);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :141
+        VI useMinimum;
+        VF distance;
+        Vector3Wide direction, angularJA, angularJB;
+        ComputeJacobians(prestep.LocalOffsetA, positionA, orientationA, prestep.LocalOffsetB, positionB, orientationB, prestep.MinimumDistance, prestep.MaximumDistance, useMinimum, distance,
+                         direction, angularJA, angularJB);
+        ApplyImpulse(direction, angularJA, angularJB, inertiaA, inertiaB, accumulatedImpulses, wsvA, wsvB);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :148
+        VI useMinimum;
+        VF distance;
+        Vector3Wide direction, angularJA, angularJB;
+        ComputeJacobians(prestep.LocalOffsetA, positionA, orientationA, prestep.LocalOffsetB, positionB, orientationB, prestep.MinimumDistance, prestep.MaximumDistance, useMinimum, distance,
+                         direction, angularJA, angularJB);
+        VF linearCSVA, negatedLinearCSVB, angularCSVA, angularCSVB;
+        Vector3Wide::Dot(wsvA.Linear, direction, linearCSVA);
+        Vector3Wide::Dot(wsvB.Linear, direction, negatedLinearCSVB);
+        Vector3Wide::Dot(wsvA.Angular, angularJA, angularCSVA);
+        Vector3Wide::Dot(wsvB.Angular, angularJB, angularCSVB);
+        VF csv = linearCSVA - negatedLinearCSVB + angularCSVA + angularCSVB;
+        VF angularContributionA, angularContributionB;
+        Symmetric3x3Wide::VectorSandwich(angularJA, inertiaA.InverseInertiaTensor, angularContributionA);
+        Symmetric3x3Wide::VectorSandwich(angularJB, inertiaB.InverseInertiaTensor, angularContributionB);
+        VF inverseEffectiveMass = inertiaA.InverseMass + inertiaB.InverseMass + angularContributionA + angularContributionB;
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        VF effectiveMass = effectiveMassCFMScale / inverseEffectiveMass;
+        VF error = ConditionalSelect(useMinimum, prestep.MinimumDistance - distance, distance - prestep.MaximumDistance);
+        VF biasVelocity;
+        InequalityHelpers::ComputeBiasVelocity(error, positionErrorToVelocity, inverseDt, biasVelocity);
+        VF csi = neg(accumulatedImpulses) * softnessImpulseScale - effectiveMass * (csv - biasVelocity);
+        InequalityHelpers::ClampPositive(accumulatedImpulses, csi);
+        ApplyImpulse(direction, angularJA, angularJB, inertiaA, inertiaB, csi, wsvA, wsvB);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- LinearAxisServo / Motor / Limit (type ids 38, 39, 40)
+struct LinearAxisServoPrestepData { Vector3Wide LocalOffsetA, LocalOffsetB, LocalPlaneNormal; VF TargetOffset; ServoSettingsWide ServoSettings; SpringSettingsWide SpringSettings; };  // LinearAxisServo.cs:79
+struct LinearAxisServoFunctions {                                                                                                                                                    // LinearAxisServo.cs:89
+    typedef LinearAxisServoPrestepData Prestep;
+    typedef VF Impulses;
+    static void ApplyImpulse(const Vector3Wide& linearJA, const Vector3Wide& angularImpulseToVelocityA, const Vector3Wide& angularImpulseToVelocityB, const BodyInertiaWide& inertiaA,
+                             const BodyInertiaWide& inertiaB, const VF& csi, BodyVelocityWide& velocityA, BodyVelocityWide& velocityB) {  // :183
+        velocityA.Linear = velocityA.Linear + linearJA * (csi * inertiaA.InverseMass);
+        velocityB.Linear = velocityB.Linear - linearJA * (csi * inertiaB.InverseMass);
+        velocityA.Angular = velocityA.Angular + angularImpulseToVelocityA * csi;
+        velocityB.Angular = velocityB.Angular + angularImpulseToVelocityB * csi;
+    }
+    static void ComputeJacobians(const Vector3Wide& ab, const QuaternionWide& orientationA, const QuaternionWide& orientationB, const Vector3Wide& localPlaneNormalA,
+                                 const Vector3Wide& localOffsetA, const Vector3Wide& localOffsetB, VF& planeNormalDot, Vector3Wide& normal, Vector3Wide& angularJA, Vector3Wide& angularJB) {  // :193
+        Matrix3x3Wide orientationMatrixA;
+        Matrix3x3Wide::CreateFromQuaternion(orientationA, orientationMatrixA);
+        Matrix3x3Wide::TransformWithoutOverlap(localPlaneNormalA, orientationMatrixA, normal);
+        Vector3Wide anchorA, offsetB;
+        Matrix3x3Wide::TransformWithoutOverlap(localOffsetA, orientationMatrixA, anchorA);
+        QuaternionWide::TransformWithoutOverlap(localOffsetB, orientationB, offsetB);
+        Vector3Wide anchorB = ab + offsetB;
+        Vector3Wide::Dot(anchorB - anchorA, normal, planeNormalDot);
+        Vector3Wide offsetFromAToClosetPointOnPlaneToB = anchorB - planeNormalDot * normal;
+        Vector3Wide::CrossWithoutOverlap(offsetFromAToClosetPointOnPlaneToB, normal, angularJA);
+        Vector3Wide::CrossWithoutOverlap(normal, offsetB, angularJB);
+    }
+    static void ComputeEffectiveMass(const Vector3Wide& angularJA, const Vector3Wide& angularJB, const BodyInertiaWide& inertiaA, const BodyInertiaWide& inertiaB, const VF& effectiveMassCFMScale,
+                                     Vector3Wide& angularImpulseToVelocityA, Vector3Wide& angularImpulseToVelocityB, VF& effectiveMass) {  // :210
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJA, inertiaA.InverseInertiaTensor, angularImpulseToVelocityA);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJB, inertiaB.InverseInertiaTensor, angularImpulseToVelocityB);
+        VF angularContributionA, angularContributionB;
+        Vector3Wide::Dot(angularJA, angularImpulseToVelocityA, angularContributionA);
+        Vector3Wide::Dot(angularJB, angularImpulseToVelocityB, angularContributionB);
+        effectiveMass = effectiveMassCFMScale / (inertiaA.InverseMass + inertiaB.InverseMass + angularContributionA + angularContributionB);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :222
+        VF planeNormalDot;
+        Vector3Wide normal, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB;
+        ComputeJacobians(positionB - positionA, orientationA, orientationB, prestep.LocalPlaneNormal, prestep.LocalOffsetA, prestep.LocalOffsetB, planeNormalDot, normal, angularJA, angularJB);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJA, inertiaA.InverseInertiaTensor, angularImpulseToVelocityA);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJB, inertiaB.InverseInertiaTensor, angularImpulseToVelocityB);
+        ApplyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, inertiaA, inertiaB, accumulatedImpulses, wsvA, wsvB);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :230
+        VF planeNormalDot, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale, effectiveMass, biasVelocity, maximumImpulse;
+        Vector3Wide normal, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB;
+        ComputeJacobians(positionB - positionA, orientationA, orientationB, prestep.LocalPlaneNormal, prestep.LocalOffsetA, prestep.LocalOffsetB, planeNormalDot, normal, angularJA, angularJB);
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        ComputeEffectiveMass(angularJA, angularJB, inertiaA, inertiaB, effectiveMassCFMScale, angularImpulseToVelocityA, angularImpulseToVelocityB, effectiveMass);
+        ServoSettingsWide::ComputeClampedBiasVelocity(planeNormalDot - prestep.TargetOffset, positionErrorToVelocity, prestep.ServoSettings, dt, inverseDt, biasVelocity, maximumImpulse);
+        VF csv = Vector3Wide::Dot(wsvA.Linear - wsvB.Linear, normal) + Vector3Wide::Dot(wsvA.Angular, angularJA) + Vector3Wide::Dot(wsvB.Angular, angularJB);
+        VF csi = effectiveMass * (biasVelocity - csv) - accumulatedImpulses * softnessImpulseScale;
+        ServoSettingsWide::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
+        ApplyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, inertiaA, inertiaB, csi, wsvA, wsvB);
+    }
+};
+
+struct LinearAxisMotorPrestepData { Vector3Wide LocalOffsetA, LocalOffsetB, LocalPlaneNormal; VF TargetVelocity; MotorSettingsWide Settings; };  // LinearAxisMotor.cs:73
+struct LinearAxisMotorFunctions {                                                                                                              // LinearAxisMotor.cs:82
+    typedef LinearAxisMotorPrestepData Prestep;
+    typedef VF Impulses;
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :84
+        VF planeNormalDot;
+        Vector3Wide normal, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB;
+        LinearAxisServoFunctions::ComputeJacobians(positionB - positionA, orientationA, orientationB, prestep.LocalPlaneNormal, prestep.LocalOffsetA, prestep.LocalOffsetB, planeNormalDot, normal,
+                                                   angularJA, angularJB);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJA, inertiaA.InverseInertiaTensor, angularImpulseToVelocityA);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJB, inertiaB.InverseInertiaTensor, angularImpulseToVelocityB);
+        LinearAxisServoFunctions::ApplyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, inertiaA, inertiaB, accumulatedImpulses, wsvA, wsvB);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :92
+        VF planeNormalDot, effectiveMassCFMScale, softnessImpulseScale, maximumImpulse, effectiveMass;
+        Vector3Wide normal, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB;
+        LinearAxisServoFunctions::ComputeJacobians(positionB - positionA, orientationA, orientationB, prestep.LocalPlaneNormal, prestep.LocalOffsetA, prestep.LocalOffsetB, planeNormalDot, normal,
+                                                   angularJA, angularJB);
+        MotorSettingsWide::ComputeSoftness(prestep.Settings, dt, effectiveMassCFMScale, softnessImpulseScale, maximumImpulse);
+        LinearAxisServoFunctions::ComputeEffectiveMass(angularJA, angularJB, inertiaA, inertiaB, effectiveMassCFMScale, angularImpulseToVelocityA, angularImpulseToVelocityB, effectiveMass);
+        VF csv = Vector3Wide::Dot(wsvA.Linear - wsvB.Linear, normal) + Vector3Wide::Dot(wsvA.Angular, angularJA) + Vector3Wide::Dot(wsvB.Angular, angularJB);
+        VF csi = effectiveMass * (neg(prestep.TargetVelocity) - csv) - accumulatedImpulses * softnessImpulseScale;
+        ServoSettingsWide::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
+        LinearAxisServoFunctions::ApplyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, inertiaA, inertiaB, csi, wsvA, wsvB);
+    }
+};
+
+struct LinearAxisLimitPrestepData { Vector3Wide LocalOffsetA, LocalOffsetB, LocalPlaneNormal; VF MinimumOffset, MaximumOffset; SpringSettingsWide SpringSettings; };  // LinearAxisLimit.cs:80
+struct LinearAxisLimitFunctions {                                                                                                                                   // LinearAxisLimit.cs:90
+    typedef LinearAxisLimitPrestepData Prestep;
+    typedef VF Impulses;
+    static void ComputeJacobians(const Vector3Wide& ab, const QuaternionWide& orientationA, const QuaternionWide& orientationB, const Vector3Wide& localPlaneNormal, const Vector3Wide& localOffsetA,
+                                 const Vector3Wide& localOffsetB, const VF& minimumOffset, const VF& maximumOffset, VF& error, Vector3Wide& normal, Vector3Wide& angularJA, Vector3Wide& angularJB) {  // :93
+        Matrix3x3Wide orientationMatrixA;
+        Matrix3x3Wide::CreateFromQuaternion(orientationA, orientationMatrixA);
+        Matrix3x3Wide::TransformWithoutOverlap(localPlaneNormal, orientationMatrixA, normal);
+        Vector3Wide anchorA, offsetB;
+        Matrix3x3Wide::TransformWithoutOverlap(localOffsetA, orientationMatrixA, anchorA);
+        QuaternionWide::TransformWithoutOverlap(localOffsetB, orientationB, offsetB);
+        Vector3Wide anchorB = ab + offsetB;
+        VF planeNormalDot;
+        Vector3Wide::Dot(anchorB - anchorA, normal, planeNormalDot);
+        VF minimumError = minimumOffset - planeNormalDot;
+        VF maximumError = planeNormalDot - maximumOffset;
+        VI useMin = LessThan(Abs(minimumError), Abs(maximumError));
+        error = ConditionalSelect(useMin, minimumError, maximumError);
+        normal.X = ConditionalSelect(useMin, neg(normal.X), normal.X);
+        normal.Y = ConditionalSelect(useMin, neg(normal.Y), normal.Y);
+        normal.Z = ConditionalSelect(useMin, neg(normal.Z), normal.Z);
+        Vector3Wide offsetFromAToClosetPointOnPlaneToB = anchorB - planeNormalDot * normal;
+        Vector3Wide::CrossWithoutOverlap(offsetFromAToClosetPointOnPlaneToB, normal, angularJA);
+        Vector3Wide::CrossWithoutOverlap(normal, offsetB, angularJB);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :124
+        VF error;
+        Vector3Wide normal, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB;
+        ComputeJacobians(positionB - positionA, orientationA, orientationB, prestep.LocalPlaneNormal, prestep.LocalOffsetA, prestep.LocalOffsetB, prestep.MinimumOffset, prestep.MaximumOffset, error,
+                         normal, angularJA, angularJB);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJA, inertiaA.InverseInertiaTensor, angularImpulseToVelocityA);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularJB, inertiaB.InverseInertiaTensor, angularImpulseToVelocityB);
+        LinearAxisServoFunctions::ApplyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, inertiaA, inertiaB, accumulatedImpulses, wsvA, wsvB);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :132
+        VF error, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale, effectiveMass, biasVelocity;
+        Vector3Wide normal, angularJA, angularJB, angularImpulseToVelocityA, angularImpulseToVelocityB;
+        ComputeJacobians(positionB - positionA, orientationA, orientationB, prestep.LocalPlaneNormal, prestep.LocalOffsetA, prestep.LocalOffsetB, prestep.MinimumOffset, prestep.MaximumOffset, error,
+                         normal, angularJA, angularJB);
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        LinearAxisServoFunctions::ComputeEffectiveMass(angularJA, angularJB, inertiaA, inertiaB, effectiveMassCFMScale, angularImpulseToVelocityA, angularImpulseToVelocityB, effectiveMass);
+        InequalityHelpers::ComputeBiasVelocity(error, positionErrorToVelocity, inverseDt, biasVelocity);
+        VF csv = Vector3Wide::Dot(wsvA.Linear - wsvB.Linear, normal) + Vector3Wide::Dot(wsvA.Angular, angularJA) + Vector3Wide::Dot(wsvB.Angular, angularJB);
+        VF csi = effectiveMass * (biasVelocity - csv) - accumulatedImpulses * softnessImpulseScale;
+        InequalityHelpers::ClampPositive(accumulatedImpulses, csi);
+        LinearAxisServoFunctions::ApplyImpulse(normal, angularImpulseToVelocityA, angularImpulseToVelocityB, inertiaA, inertiaB, csi, wsvA, wsvB);
+    }
+};
+
 }  // namespace wide

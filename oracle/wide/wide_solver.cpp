@@ -650,6 +650,11 @@ static TypeProcessor* CreateProcessor(int typeId) {  // BepuPhysics/DefaultTypes
         case 24: return new TwoBodyTypeProcessor<NoIncremental<AngularSwivelHingeFunctions>, false, false, false, false, false>();    // AngularSwivelHinge.cs:151 OnlyAngular x4
         case 54: return new TwoBodyTypeProcessor<NoIncremental<AngularAxisGearMotorFunctions>, false, false, false, false, false>();  // AngularAxisGearMotor.cs:117
         case 35: return new TwoBodyTypeProcessor<NoIncremental<CenterDistanceConstraintFunctions>, true, true, true, true, false>();  // CenterDistanceConstraint.cs:135 OnlyLinear x4 (the angular halves go back unchanged)
+        case 33: return new TwoBodyTypeProcessor<NoIncremental<DistanceServoFunctions>, true, true, true, true, false>();    // DistanceServo.cs:232 All x4
+        case 34: return new TwoBodyTypeProcessor<NoIncremental<DistanceLimitFunctions>, true, true, true, true, false>();    // DistanceLimit.cs:184
+        case 38: return new TwoBodyTypeProcessor<NoIncremental<LinearAxisServoFunctions>, true, true, true, true, false>();  // LinearAxisServo.cs:250
+        case 39: return new TwoBodyTypeProcessor<NoIncremental<LinearAxisMotorFunctions>, true, true, true, true, false>();  // LinearAxisMotor.cs:113
+        case 40: return new TwoBodyTypeProcessor<NoIncremental<LinearAxisLimitFunctions>, true, true, true, true, false>();  // LinearAxisLimit.cs:156
         case 55: return new TwoBodyTypeProcessor<NoIncremental<CenterDistanceLimitFunctions>, true, true, true, true, false>();       // CenterDistanceLimit.cs:134
         default: return nullptr;
     }
