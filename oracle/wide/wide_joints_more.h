@@ -760,4 +760,144 @@ struct LinearAxisLimitFunctions {                                               
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------- OneBodyAngularServo (type id 42)
+struct OneBodyAngularServoPrestepData { QuaternionWide TargetOrientation; SpringSettingsWide SpringSettings; ServoSettingsWide ServoSettings; };  // OneBodyAngularServo.cs:62
+struct OneBodyAngularServoFunctions {                                                                                                           // OneBodyAngularServo.cs:69
+    typedef OneBodyAngularServoPrestepData Prestep;
+    typedef Vector3Wide Impulses;
+    static void ApplyImpulse(const Symmetric3x3Wide& inverseInertia, const Vector3Wide& csi, Vector3Wide& angularVelocity) {  // :72
+        Vector3Wide velocityChange;
+        Symmetric3x3Wide::TransformWithoutOverlap(csi, inverseInertia, velocityChange);
+        Vector3Wide::Add(angularVelocity, velocityChange, angularVelocity);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA) {  // :79
+        ApplyImpulse(inertiaA.InverseInertiaTensor, accumulatedImpulses, wsvA.Angular);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA) {  // :85
+        QuaternionWide inverseOrientation, errorRotation;
+        QuaternionWide::Conjugate(orientationA, inverseOrientation);
+        QuaternionWide::ConcatenateWithoutOverlap(inverseOrientation, prestep.TargetOrientation, errorRotation);
+        Vector3Wide errorAxis;
+        VF errorLength;
+        GetAxisAngleFromQuaternion(errorRotation, errorAxis, errorLength);
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        Symmetric3x3Wide effectiveMass;
+        Symmetric3x3Wide::Invert(inertiaA.InverseInertiaTensor, effectiveMass);
+        Vector3Wide clampedBiasVelocity;
+        VF maximumImpulse;
+        ServoSettingsMore::ComputeClampedBiasVelocity(errorAxis, errorLength, positionErrorToVelocity, prestep.ServoSettings, dt, inverseDt, clampedBiasVelocity, maximumImpulse);
+        Vector3Wide csv = clampedBiasVelocity - wsvA.Angular;
+        Vector3Wide csi;
+        Symmetric3x3Wide::TransformWithoutOverlap(csv, effectiveMass, csi);
+        csi = csi * effectiveMassCFMScale - accumulatedImpulses * softnessImpulseScale;
+        ServoSettingsWide::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
+        ApplyImpulse(inertiaA.InverseInertiaTensor, csi, wsvA.Angular);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- OneBodyAngularMotor (type id 43)
+struct OneBodyAngularMotorPrestepData { Vector3Wide TargetVelocity; MotorSettingsWide Settings; };  // OneBodyAngularMotor.cs:55
+struct OneBodyAngularMotorFunctions {                                                              // OneBodyAngularMotor.cs:61
+    typedef OneBodyAngularMotorPrestepData Prestep;
+    typedef Vector3Wide Impulses;
+    static void ApplyImpulse(Vector3Wide& angularVelocity, const Symmetric3x3Wide& impulseToVelocity, const Vector3Wide& csi) {  // :64
+        Vector3Wide velocityChange;
+        Symmetric3x3Wide::TransformWithoutOverlap(csi, impulseToVelocity, velocityChange);
+        Vector3Wide::Add(angularVelocity, velocityChange, angularVelocity);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA) {  // :70
+        ApplyImpulse(wsvA.Angular, inertiaA.InverseInertiaTensor, accumulatedImpulses);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA) {  // :75
+        VF effectiveMassCFMScale, softnessImpulseScale, maximumImpulse;
+        MotorSettingsWide::ComputeSoftness(prestep.Settings, dt, effectiveMassCFMScale, softnessImpulseScale, maximumImpulse);
+        Symmetric3x3Wide unsoftenedEffectiveMass;
+        Symmetric3x3Wide::Invert(inertiaA.InverseInertiaTensor, unsoftenedEffectiveMass);
+        Vector3Wide csi;
+        Symmetric3x3Wide::TransformWithoutOverlap(prestep.TargetVelocity - wsvA.Angular, unsoftenedEffectiveMass, csi);
+        csi = csi * effectiveMassCFMScale - accumulatedImpulses * softnessImpulseScale;
+        ServoSettingsWide::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
+        ApplyImpulse(wsvA.Angular, inertiaA.InverseInertiaTensor, csi);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- OneBodyLinearServo (type id 44)
+struct OneBodyLinearServoPrestepData { Vector3Wide LocalOffset, Target; SpringSettingsWide SpringSettings; ServoSettingsWide ServoSettings; };  // OneBodyLinearServo.cs:66
+struct OneBodyLinearServoFunctions {                                                                                                          // OneBodyLinearServo.cs:77
+    typedef OneBodyLinearServoPrestepData Prestep;
+    typedef Vector3Wide Impulses;
+    static void ApplyImpulse(const Vector3Wide& offset, const BodyInertiaWide& inertia, BodyVelocityWide& velocityA, const Vector3Wide& csi) {  // :96
+        Vector3Wide wsi, change;
+        Vector3Wide::CrossWithoutOverlap(offset, csi, wsi);
+        Symmetric3x3Wide::TransformWithoutOverlap(wsi, inertia.InverseInertiaTensor, change);
+        Vector3Wide::Add(velocityA.Angular, change, velocityA.Angular);
+        Vector3Wide::Scale(csi, inertia.InverseMass, change);
+        Vector3Wide::Add(velocityA.Linear, change, velocityA.Linear);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA) {  // :107
+        Vector3Wide offset;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffset, orientationA, offset);
+        ApplyImpulse(offset, inertiaA, wsvA, accumulatedImpulses);
+    }
+    // The effective mass both linear one-body types share (:128-134 here, OneBodyLinearMotor.cs:84-90 there).
+    static void ComputeEffectiveMass(const Vector3Wide& offset, const BodyInertiaWide& inertiaA, Symmetric3x3Wide& effectiveMass) {
+        Symmetric3x3Wide inverseEffectiveMass;
+        Symmetric3x3Wide::SkewSandwichWithoutOverlap(offset, inertiaA.InverseInertiaTensor, inverseEffectiveMass);
+        inverseEffectiveMass.XX = inverseEffectiveMass.XX + inertiaA.InverseMass;
+        inverseEffectiveMass.YY = inverseEffectiveMass.YY + inertiaA.InverseMass;
+        inverseEffectiveMass.ZZ = inverseEffectiveMass.ZZ + inertiaA.InverseMass;
+        Symmetric3x3Wide::Invert(inverseEffectiveMass, effectiveMass);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA) {  // :114
+        Vector3Wide offset;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffset, orientationA, offset);
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        Vector3Wide worldGrabPoint, error, biasVelocity;
+        Vector3Wide::Add(offset, positionA, worldGrabPoint);
+        Vector3Wide::Subtract(prestep.Target, worldGrabPoint, error);
+        VF maximumImpulse;
+        ServoSettingsMore::ComputeClampedBiasVelocity(error, positionErrorToVelocity, prestep.ServoSettings, dt, inverseDt, biasVelocity, maximumImpulse);
+        Vector3Wide csv = biasVelocity - Vector3Wide::Cross(wsvA.Angular, offset) - wsvA.Linear;
+        Symmetric3x3Wide effectiveMass;
+        ComputeEffectiveMass(offset, inertiaA, effectiveMass);
+        Vector3Wide csi;
+        Symmetric3x3Wide::TransformWithoutOverlap(csv, effectiveMass, csi);
+        csi = csi * effectiveMassCFMScale - accumulatedImpulses * softnessImpulseScale;
+        ServoSettingsWide::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
+        ApplyImpulse(offset, inertiaA, wsvA, csi);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- OneBodyLinearMotor (type id 45)
+struct OneBodyLinearMotorPrestepData { Vector3Wide LocalOffset, TargetVelocity; MotorSettingsWide Settings; };  // OneBodyLinearMotor.cs:60
+struct OneBodyLinearMotorFunctions {                                                                          // OneBodyLinearMotor.cs:67
+    typedef OneBodyLinearMotorPrestepData Prestep;
+    typedef Vector3Wide Impulses;
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA) {  // :69
+        Vector3Wide offset;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffset, orientationA, offset);
+        OneBodyLinearServoFunctions::ApplyImpulse(offset, inertiaA, wsvA, accumulatedImpulses);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA) {  // :75
+        Vector3Wide offset;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffset, orientationA, offset);
+        VF effectiveMassCFMScale, softnessImpulseScale, maximumImpulse;
+        MotorSettingsWide::ComputeSoftness(prestep.Settings, dt, effectiveMassCFMScale, softnessImpulseScale, maximumImpulse);
+        Vector3Wide csv = prestep.TargetVelocity - Vector3Wide::Cross(wsvA.Angular, offset) - wsvA.Linear;
+        Symmetric3x3Wide effectiveMass;
+        OneBodyLinearServoFunctions::ComputeEffectiveMass(offset, inertiaA, effectiveMass);
+        Vector3Wide csi;
+        Symmetric3x3Wide::TransformWithoutOverlap(csv, effectiveMass, csi);
+        csi = csi * effectiveMassCFMScale - accumulatedImpulses * softnessImpulseScale;
+        ServoSettingsWide::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
+        OneBodyLinearServoFunctions::ApplyImpulse(offset, inertiaA, wsvA, csi);
+    }
+};
+
 }  // namespace wide

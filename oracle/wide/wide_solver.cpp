@@ -536,14 +536,14 @@ struct TwoBodyTypeProcessor : TypeProcessor {
 };
 
 // Constraints/OneBodyTypeProcessor.cs:82-146 (contacts: AccessNoPose everywhere, :149-150)
-template <typename TConstraintFunctions> struct OneBodyTypeProcessor : TypeProcessor {
+template <typename TConstraintFunctions, bool Incremental = true> struct OneBodyTypeProcessor : TypeProcessor {
     typedef typename TConstraintFunctions::Prestep TPrestepData;
     typedef typename TConstraintFunctions::Impulses TAccumulatedImpulse;
     OneBodyTypeProcessor() {
         BodiesPerConstraint = 1;
         PrestepFloats = sizeof(TPrestepData) / sizeof(VF);
         ImpulseFloats = sizeof(TAccumulatedImpulse) / sizeof(VF);
-        RequiresIncrementalSubstepUpdates = true;
+        RequiresIncrementalSubstepUpdates = Incremental;
     }
     template <BatchIntegrationMode TBatchIntegrationMode, bool TAllowPoseIntegration>
     void WarmStartImpl(TypeBatch& typeBatch, const IndexSet* integrationFlags, Bodies& bodies, PoseIntegratorCallbacks& integratorCallbacks, float dt, float inverseDt, int startBundle,
@@ -623,6 +623,10 @@ template <typename F> struct NoIncremental : F {
     static void IncrementallyUpdateForSubstep(const VF&, const BodyVelocityWide&, const BodyVelocityWide&, typename F::Prestep&) {}
 };
 
+template <typename F> struct NoIncrementalOneBody : F {
+    static void IncrementallyUpdateForSubstep(const VF&, const BodyVelocityWide&, typename F::Prestep&) {}
+};
+
 static TypeProcessor* CreateProcessor(int typeId) {  // BepuPhysics/DefaultTypes.cs:20-63 (ids) + the filter lists of each *TypeProcessor class
     switch (typeId) {
         case 0: return new OneBodyTypeProcessor<ContactOneBodyFunctions<1>>();
@@ -655,6 +659,10 @@ static TypeProcessor* CreateProcessor(int typeId) {  // BepuPhysics/DefaultTypes
         case 38: return new TwoBodyTypeProcessor<NoIncremental<LinearAxisServoFunctions>, true, true, true, true, false>();  // LinearAxisServo.cs:250
         case 39: return new TwoBodyTypeProcessor<NoIncremental<LinearAxisMotorFunctions>, true, true, true, true, false>();  // LinearAxisMotor.cs:113
         case 40: return new TwoBodyTypeProcessor<NoIncremental<LinearAxisLimitFunctions>, true, true, true, true, false>();  // LinearAxisLimit.cs:156
+        case 42: return new OneBodyTypeProcessor<NoIncrementalOneBody<OneBodyAngularServoFunctions>, false>();  // OneBodyAngularServo.cs:111 OnlyAngular x2 (the linear halves go back unchanged)
+        case 43: return new OneBodyTypeProcessor<NoIncrementalOneBody<OneBodyAngularMotorFunctions>, false>();  // OneBodyAngularMotor.cs:95
+        case 44: return new OneBodyTypeProcessor<NoIncrementalOneBody<OneBodyLinearServoFunctions>, false>();   // OneBodyLinearServo.cs:148 All x2
+        case 45: return new OneBodyTypeProcessor<NoIncrementalOneBody<OneBodyLinearMotorFunctions>, false>();   // OneBodyLinearMotor.cs:102 NoPosition x2
         case 55: return new TwoBodyTypeProcessor<NoIncremental<CenterDistanceLimitFunctions>, true, true, true, true, false>();       // CenterDistanceLimit.cs:134
         default: return nullptr;
     }
