@@ -900,4 +900,156 @@ struct OneBodyLinearMotorFunctions {                                            
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------- Weld (type id 31)
+// Symmetric3x3Wide.Multiply(symmetric, matrix) (BepuUtilities/Symmetric3x3Wide.cs:343-356)
+static inline void MultiplySymmetricByMatrix(const Symmetric3x3Wide& a, const Matrix3x3Wide& b, Matrix3x3Wide& result) {
+    result.X.X = a.XX * b.X.X + a.YX * b.Y.X + a.ZX * b.Z.X;
+    result.X.Y = a.XX * b.X.Y + a.YX * b.Y.Y + a.ZX * b.Z.Y;
+    result.X.Z = a.XX * b.X.Z + a.YX * b.Y.Z + a.ZX * b.Z.Z;
+    result.Y.X = a.YX * b.X.X + a.YY * b.Y.X + a.ZY * b.Z.X;
+    result.Y.Y = a.YX * b.X.Y + a.YY * b.Y.Y + a.ZY * b.Z.Y;
+    result.Y.Z = a.YX * b.X.Z + a.YY * b.Y.Z + a.ZY * b.Z.Z;
+    result.Z.X = a.ZX * b.X.X + a.ZY * b.Y.X + a.ZZ * b.Z.X;
+    result.Z.Y = a.ZX * b.X.Y + a.ZY * b.Y.Y + a.ZZ * b.Z.Y;
+    result.Z.Z = a.ZX * b.X.Z + a.ZY * b.Y.Z + a.ZZ * b.Z.Z;
+}
+// Symmetric3x3Wide.CompleteMatrixSandwichTranspose (Symmetric3x3Wide.cs:508-518): a^T * b, known symmetric
+static inline void CompleteMatrixSandwichTranspose(const Matrix3x3Wide& a, const Matrix3x3Wide& b, Symmetric3x3Wide& result) {
+    result.XX = a.X.X * b.X.X + a.Y.X * b.Y.X + a.Z.X * b.Z.X;
+    result.YX = a.X.Y * b.X.X + a.Y.Y * b.Y.X + a.Z.Y * b.Z.X;
+    result.YY = a.X.Y * b.X.Y + a.Y.Y * b.Y.Y + a.Z.Y * b.Z.Y;
+    result.ZX = a.X.Z * b.X.X + a.Y.Z * b.Y.X + a.Z.Z * b.Z.X;
+    result.ZY = a.X.Z * b.X.Y + a.Y.Z * b.Y.Y + a.Z.Z * b.Z.Y;
+    result.ZZ = a.X.Z * b.X.Z + a.Y.Z * b.Y.Z + a.Z.Z * b.Z.Z;
+}
+// QuaternionWide operator * (QuaternionWide.cs:530-538): same expression as ConcatenateWithoutOverlap
+static inline QuaternionWide operator*(const QuaternionWide& a, const QuaternionWide& b) {
+    QuaternionWide result;
+    result.X = a.W * b.X + a.X * b.W + a.Z * b.Y - a.Y * b.Z;
+    result.Y = a.W * b.Y + a.Y * b.W + a.X * b.Z - a.Z * b.X;
+    result.Z = a.W * b.Z + a.Z * b.W + a.Y * b.X - a.X * b.Y;
+    result.W = a.W * b.W - a.X * b.X - a.Y * b.Y - a.Z * b.Z;
+    return result;
+}
+// Symmetric6x6Wide.LDLTSolve (BepuUtilities/Symmetric6x6Wide.cs:84-129): [a b^T; b d] x = [v0; v1] by an LDL^T factorisation without pivoting
+static inline void LDLTSolve(const Vector3Wide& v0, const Vector3Wide& v1, const Symmetric3x3Wide& a, const Matrix3x3Wide& b, const Symmetric3x3Wide& d, Vector3Wide& result0, Vector3Wide& result1) {
+    VF d1 = a.XX;
+    VF inverseD1 = kOne / d1;
+    VF l21 = inverseD1 * a.YX;
+    VF l31 = inverseD1 * a.ZX;
+    VF l41 = inverseD1 * b.X.X;
+    VF l51 = inverseD1 * b.X.Y;
+    VF l61 = inverseD1 * b.X.Z;
+    VF d2 = a.YY - l21 * l21 * d1;
+    VF inverseD2 = kOne / d2;
+    VF l32 = inverseD2 * (a.ZY - l31 * l21 * d1);
+    VF l42 = inverseD2 * (b.Y.X - l41 * l21 * d1);
+    VF l52 = inverseD2 * (b.Y.Y - l51 * l21 * d1);
+    VF l62 = inverseD2 * (b.Y.Z - l61 * l21 * d1);
+    VF d3 = a.ZZ - l31 * l31 * d1 - l32 * l32 * d2;
+    VF inverseD3 = kOne / d3;
+    VF l43 = inverseD3 * (b.Z.X - l41 * l31 * d1 - l42 * l32 * d2);
+    VF l53 = inverseD3 * (b.Z.Y - l51 * l31 * d1 - l52 * l32 * d2);
+    VF l63 = inverseD3 * (b.Z.Z - l61 * l31 * d1 - l62 * l32 * d2);
+    VF d4 = d.XX - l41 * l41 * d1 - l42 * l42 * d2 - l43 * l43 * d3;
+    VF inverseD4 = kOne / d4;
+    VF l54 = inverseD4 * (d.YX - l51 * l41 * d1 - l52 * l42 * d2 - l53 * l43 * d3);
+    VF l64 = inverseD4 * (d.ZX - l61 * l41 * d1 - l62 * l42 * d2 - l63 * l43 * d3);
+    VF d5 = d.YY - l51 * l51 * d1 - l52 * l52 * d2 - l53 * l53 * d3 - l54 * l54 * d4;
+    VF inverseD5 = kOne / d5;
+    VF l65 = inverseD5 * (d.ZY - l61 * l51 * d1 - l62 * l52 * d2 - l63 * l53 * d3 - l64 * l54 * d4);
+    VF d6 = d.ZZ - l61 * l61 * d1 - l62 * l62 * d2 - l63 * l63 * d3 - l64 * l64 * d4 - l65 * l65 * d5;
+    VF inverseD6 = kOne / d6;
+    result0.X = v0.X;
+    result0.Y = v0.Y - l21 * result0.X;
+    result0.Z = v0.Z - l31 * result0.X - l32 * result0.Y;
+    result1.X = v1.X - l41 * result0.X - l42 * result0.Y - l43 * result0.Z;
+    result1.Y = v1.Y - l51 * result0.X - l52 * result0.Y - l53 * result0.Z - l54 * result1.X;
+    result1.Z = v1.Z - l61 * result0.X - l62 * result0.Y - l63 * result0.Z - l64 * result1.X - l65 * result1.Y;
+    result1.Z = result1.Z * inverseD6;
+    result1.Y = result1.Y * inverseD5 - l65 * result1.Z;
+    result1.X = result1.X * inverseD4 - l64 * result1.Z - l54 * result1.Y;
+    result0.Z = result0.Z * inverseD3 - l63 * result1.Z - l53 * result1.Y - l43 * result1.X;
+    result0.Y = result0.Y * inverseD2 - l62 * result1.Z - l52 * result1.Y - l42 * result1.X - l32 * result0.Z;
+    result0.X = result0.X * inverseD1 - l61 * result1.Z - l51 * result1.Y - l41 * result1.X - l31 * result0.Z - l21 * result0.Y;
+}
+
+struct WeldPrestepData { Vector3Wide LocalOffset; QuaternionWide LocalOrientation; SpringSettingsWide SpringSettings; };  // Weld.cs:70
+struct WeldAccumulatedImpulses { Vector3Wide Orientation, Offset; };                                                     // Weld.cs:77
+struct WeldFunctions {                                                                                                   // Weld.cs:83
+    typedef WeldPrestepData Prestep;
+    typedef WeldAccumulatedImpulses Impulses;
+    static void ApplyImpulse(const BodyInertiaWide& inertiaA, const BodyInertiaWide& inertiaB, const Vector3Wide& offset, const Vector3Wide& orientationCSI, const Vector3Wide& offsetCSI,
+                             BodyVelocityWide& velocityA, BodyVelocityWide& velocityB) {  // :86
+        Vector3Wide linearChangeA, offsetWorldImpulse, angularImpulseA, angularChangeA, negatedLinearChangeB, negatedAngularChangeB;
+        Vector3Wide::Scale(offsetCSI, inertiaA.InverseMass, linearChangeA);
+        Vector3Wide::Add(velocityA.Linear, linearChangeA, velocityA.Linear);
+        Vector3Wide::CrossWithoutOverlap(offset, offsetCSI, offsetWorldImpulse);
+        Vector3Wide::Add(offsetWorldImpulse, orientationCSI, angularImpulseA);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularImpulseA, inertiaA.InverseInertiaTensor, angularChangeA);
+        Vector3Wide::Add(velocityA.Angular, angularChangeA, velocityA.Angular);
+        Vector3Wide::Scale(offsetCSI, inertiaB.InverseMass, negatedLinearChangeB);
+        Vector3Wide::Subtract(velocityB.Linear, negatedLinearChangeB, velocityB.Linear);
+        Symmetric3x3Wide::TransformWithoutOverlap(orientationCSI, inertiaB.InverseInertiaTensor, negatedAngularChangeB);
+        Vector3Wide::Subtract(velocityB.Angular, negatedAngularChangeB, velocityB.Angular);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :116
+        Vector3Wide offset;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffset, orientationA, offset);  // QuaternionWide.Transform(in, in, out) = TransformWithoutOverlap + copy (QuaternionWide.cs:283)
+        ApplyImpulse(inertiaA, inertiaB, offset, accumulatedImpulses.Orientation, accumulatedImpulses.Offset, wsvA, wsvB);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :123
+        Vector3Wide offset;
+        QuaternionWide::TransformWithoutOverlap(prestep.LocalOffset, orientationA, offset);
+        Symmetric3x3Wide jmjtA, jmjtD;
+        Matrix3x3Wide xAB, jmjtB;
+        Symmetric3x3Wide::Add(inertiaA.InverseInertiaTensor, inertiaB.InverseInertiaTensor, jmjtA);
+        Matrix3x3Wide::CreateCrossProduct(offset, xAB);
+        MultiplySymmetricByMatrix(inertiaA.InverseInertiaTensor, xAB, jmjtB);
+        CompleteMatrixSandwichTranspose(xAB, jmjtB, jmjtD);
+        VF diagonalAdd = inertiaA.InverseMass + inertiaB.InverseMass;
+        jmjtD.XX = jmjtD.XX + diagonalAdd;
+        jmjtD.YY = jmjtD.YY + diagonalAdd;
+        jmjtD.ZZ = jmjtD.ZZ + diagonalAdd;
+        Vector3Wide positionError = positionB - positionA - offset;
+        QuaternionWide targetOrientationB = prestep.LocalOrientation * orientationA;
+        QuaternionWide conjugate, rotationError;
+        QuaternionWide::Conjugate(targetOrientationB, conjugate);  // the value-returning overload (:560) has the same body
+        QuaternionWide::ConcatenateWithoutOverlap(conjugate, orientationB, rotationError);
+        Vector3Wide rotationErrorAxis;
+        VF rotationErrorLength;
+        GetAxisAngleFromQuaternion(rotationError, rotationErrorAxis, rotationErrorLength);
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        Vector3Wide orientationBiasVelocity = rotationErrorAxis * (rotationErrorLength * positionErrorToVelocity);
+        Vector3Wide offsetBiasVelocity = positionError * positionErrorToVelocity;
+        Vector3Wide orientationCSV, offsetCSV;
+        orientationCSV.X = orientationBiasVelocity.X - wsvA.Angular.X + wsvB.Angular.X;
+        orientationCSV.Y = orientationBiasVelocity.Y - wsvA.Angular.Y + wsvB.Angular.Y;
+        orientationCSV.Z = orientationBiasVelocity.Z - wsvA.Angular.Z + wsvB.Angular.Z;
+        offsetCSV.X = offsetBiasVelocity.X - wsvA.Linear.X + wsvB.Linear.X - (wsvA.Angular.Y * offset.Z - wsvA.Angular.Z * offset.Y);
+        offsetCSV.Y = offsetBiasVelocity.Y - wsvA.Linear.Y + wsvB.Linear.Y - (wsvA.Angular.Z * offset.X - wsvA.Angular.X * offset.Z);
+        offsetCSV.Z = offsetBiasVelocity.Z - wsvA.Linear.Z + wsvB.Linear.Z - (wsvA.Angular.X * offset.Y - wsvA.Angular.Y * offset.X);
+        Vector3Wide orientationCSI, offsetCSI;
+        LDLTSolve(orientationCSV, offsetCSV, jmjtA, jmjtB, jmjtD, orientationCSI, offsetCSI);
+        orientationCSI.X = orientationCSI.X * effectiveMassCFMScale - accumulatedImpulses.Orientation.X * softnessImpulseScale;
+        orientationCSI.Y = orientationCSI.Y * effectiveMassCFMScale - accumulatedImpulses.Orientation.Y * softnessImpulseScale;
+        orientationCSI.Z = orientationCSI.Z * effectiveMassCFMScale - accumulatedImpulses.Orientation.Z * softnessImpulseScale;
+        accumulatedImpulses.Orientation.X = accumulatedImpulses.Orientation.X + orientationCSI.X;
+        accumulatedImpulses.Orientation.Y = accumulatedImpulses.Orientation.Y + orientationCSI.Y;
+        accumulatedImpulses.Orientation.Z = accumulatedImpulses.Orientation.Z + orientationCSI.Z;
+        offsetCSI.X = offsetCSI.X * effectiveMassCFMScale - accumulatedImpulses.Offset.X * softnessImpulseScale;
+        offsetCSI.Y = offsetCSI.Y * effectiveMassCFMScale - accumulatedImpulses.Offset.Y * softnessImpulseScale;
+        offsetCSI.Z = offsetCSI.Z * effectiveMassCFMScale - accumulatedImpulses.Offset.Z * softnessImpulseScale;
+        accumulatedImpulses.Offset.X = accumulatedImpulses.Offset.X + offsetCSI.X;
+        accumulatedImpulses.Offset.Y = accumulatedImpulses.Offset.Y + offsetCSI.Y;
+        accumulatedImpulses.Offset.Z = accumulatedImpulses.Offset.Z + offsetCSI.Z;
+        ApplyImpulse(inertiaA, inertiaB, offset, orientationCSI, offsetCSI, wsvA, wsvB);
+    }
+};
+
 }  // namespace wide
