@@ -1052,4 +1052,131 @@ struct WeldFunctions {                                                          
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------- PointOnLineServo (type id 37)
+namespace ServoSettingsMore {  // the Vector2Wide overloads (ServoSettings.cs:88-113, :153-164)
+static inline void ComputeClampedBiasVelocity(const Vector2Wide& errorAxis, const VF& errorLength, const VF& positionErrorToBiasVelocity, const ServoSettingsWide& servoSettings, float dt,
+                                              float inverseDt, Vector2Wide& clampedBiasVelocity, VF& maximumImpulse) {  // :88
+    VF baseSpeed = Min(servoSettings.BaseSpeed, errorLength * vf(inverseDt));
+    VF unclampedBiasSpeed = errorLength * positionErrorToBiasVelocity;
+    VF targetSpeed = Max(baseSpeed, unclampedBiasSpeed);
+    VF scale = Min(kOne, servoSettings.MaximumSpeed / targetSpeed);
+    VI useFallback = LessThan(targetSpeed, vf(1e-10f));
+    scale = ConditionalSelect(useFallback, kOne, scale);
+    Vector2Wide::Scale(errorAxis, scale * unclampedBiasSpeed, clampedBiasVelocity);
+    maximumImpulse = servoSettings.MaximumForce * vf(dt);
+}
+static inline void ComputeClampedBiasVelocity(const Vector2Wide& error, const VF& positionErrorToBiasVelocity, const ServoSettingsWide& servoSettings, float dt, float inverseDt,
+                                              Vector2Wide& clampedBiasVelocity, VF& maximumImpulse) {  // :104
+    VF errorLength;
+    Vector2Wide::Length(error, errorLength);
+    Vector2Wide errorAxis;
+    Vector2Wide::Scale(error, kOne / errorLength, errorAxis);
+    VI useFallback = LessThan(errorLength, vf(1e-10f));
+    errorAxis.X = ConditionalSelect(useFallback, kZero, errorAxis.X);
+    errorAxis.Y = ConditionalSelect(useFallback, kZero, errorAxis.Y);
+    ComputeClampedBiasVelocity(errorAxis, errorLength, positionErrorToBiasVelocity, servoSettings, dt, inverseDt, clampedBiasVelocity, maximumImpulse);
+}
+static inline void ClampImpulse(const VF& maximumImpulse, Vector2Wide& accumulatedImpulse, Vector2Wide& csi) {  // :153
+    Vector2Wide previousImpulse = accumulatedImpulse;
+    Vector2Wide unclamped;
+    Vector2Wide::Add(accumulatedImpulse, csi, unclamped);
+    VF impulseMagnitude;
+    Vector2Wide::Length(unclamped, impulseMagnitude);
+    VF impulseScale = ConditionalSelect(LessThan(Abs(impulseMagnitude), vf(1e-10f)), kOne, Min(maximumImpulse / impulseMagnitude, kOne));
+    Vector2Wide::Scale(unclamped, impulseScale, accumulatedImpulse);
+    Vector2Wide::Subtract(accumulatedImpulse, previousImpulse, csi);
+}
+}  // namespace ServoSettingsMore
+
+// (Symmetric2x2Wide.SandwichScale is in wide_contacts.h, where the friction constraint first needed it.)
+struct PointOnLineServoPrestepData { Vector3Wide LocalOffsetA, LocalOffsetB, LocalDirection; ServoSettingsWide ServoSettings; SpringSettingsWide SpringSettings; };  // PointOnLineServo.cs:73
+struct PointOnLineServoFunctions {                                                                                                                                  // PointOnLineServo.cs:82
+    typedef PointOnLineServoPrestepData Prestep;
+    typedef Vector2Wide Impulses;
+    static void ApplyImpulse(BodyVelocityWide& velocityA, BodyVelocityWide& velocityB, const Matrix2x3Wide& linearJacobian, const Matrix2x3Wide& angularJacobianA,
+                             const Matrix2x3Wide& angularJacobianB, const BodyInertiaWide& inertiaA, const BodyInertiaWide& inertiaB, Vector2Wide& csi) {  // :85
+        Vector3Wide linearImpulseA, angularImpulseA, angularImpulseB, angularChangeA, angularChangeB, linearChangeA, negatedLinearChangeB;
+        Matrix2x3Wide::Transform(csi, linearJacobian, linearImpulseA);
+        Matrix2x3Wide::Transform(csi, angularJacobianA, angularImpulseA);
+        Matrix2x3Wide::Transform(csi, angularJacobianB, angularImpulseB);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularImpulseA, inertiaA.InverseInertiaTensor, angularChangeA);
+        Symmetric3x3Wide::TransformWithoutOverlap(angularImpulseB, inertiaB.InverseInertiaTensor, angularChangeB);
+        Vector3Wide::Scale(linearImpulseA, inertiaA.InverseMass, linearChangeA);
+        Vector3Wide::Scale(linearImpulseA, inertiaB.InverseMass, negatedLinearChangeB);
+        Vector3Wide::Add(linearChangeA, velocityA.Linear, velocityA.Linear);
+        Vector3Wide::Add(angularChangeA, velocityA.Angular, velocityA.Angular);
+        Vector3Wide::Subtract(velocityB.Linear, negatedLinearChangeB, velocityB.Linear);
+        Vector3Wide::Add(angularChangeB, velocityB.Angular, velocityB.Angular);
+    }
+    static void ComputeJacobians(const Vector3Wide& ab, const QuaternionWide& orientationA, const QuaternionWide& orientationB, const Vector3Wide& localDirection, const Vector3Wide& localOffsetA,
+                                 const Vector3Wide& localOffsetB, Vector3Wide& anchorOffset, Matrix2x3Wide& linearJacobian, Matrix2x3Wide& angularJA, Matrix2x3Wide& angularJB) {  // :104
+        Vector3Wide localTangentX, localTangentY;
+        Helpers::BuildOrthonormalBasis(localDirection, localTangentX, localTangentY);
+        Matrix3x3Wide orientationMatrixA;
+        Matrix3x3Wide::CreateFromQuaternion(orientationA, orientationMatrixA);
+        Vector3Wide anchorA, offsetB, direction, anchorB, lineStartToClosestPointOnLine, offsetA;
+        Matrix3x3Wide::TransformWithoutOverlap(localOffsetA, orientationMatrixA, anchorA);
+        QuaternionWide::TransformWithoutOverlap(localOffsetB, orientationB, offsetB);
+        Matrix3x3Wide::TransformWithoutOverlap(localDirection, orientationMatrixA, direction);
+        Vector3Wide::Add(offsetB, ab, anchorB);
+        Vector3Wide::Subtract(anchorB, anchorA, anchorOffset);
+        VF d;
+        Vector3Wide::Dot(anchorOffset, direction, d);
+        Vector3Wide::Scale(direction, d, lineStartToClosestPointOnLine);
+        Vector3Wide::Add(lineStartToClosestPointOnLine, anchorA, offsetA);
+        Matrix3x3Wide::TransformWithoutOverlap(localTangentX, orientationMatrixA, linearJacobian.X);
+        Matrix3x3Wide::TransformWithoutOverlap(localTangentY, orientationMatrixA, linearJacobian.Y);
+        Vector3Wide::CrossWithoutOverlap(offsetA, linearJacobian.X, angularJA.X);
+        Vector3Wide::CrossWithoutOverlap(offsetA, linearJacobian.Y, angularJA.Y);
+        Vector3Wide::CrossWithoutOverlap(linearJacobian.X, offsetB, angularJB.X);
+        Vector3Wide::CrossWithoutOverlap(linearJacobian.Y, offsetB, angularJB.Y);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :128
+        Vector3Wide anchorOffset;
+        Matrix2x3Wide linearJacobian, angularJA, angularJB;
+        ComputeJacobians(positionB - positionA, orientationA, orientationB, prestep.LocalDirection, prestep.LocalOffsetA, prestep.LocalOffsetB, anchorOffset, linearJacobian, angularJA, angularJB);
+        ApplyImpulse(wsvA, wsvB, linearJacobian, angularJA, angularJB, inertiaA, inertiaB, accumulatedImpulses);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :134
+        Vector3Wide anchorOffset;
+        Matrix2x3Wide linearJacobian, angularJA, angularJB;
+        ComputeJacobians(positionB - positionA, orientationA, orientationB, prestep.LocalDirection, prestep.LocalOffsetA, prestep.LocalOffsetB, anchorOffset, linearJacobian, angularJA, angularJB);
+        Symmetric2x2Wide linearContribution, angularContributionA, angularContributionB, inverseEffectiveMass, effectiveMass;
+        SandwichScale(linearJacobian, inertiaA.InverseMass + inertiaB.InverseMass, linearContribution);
+        Symmetric3x3Wide::MatrixSandwich(angularJA, inertiaA.InverseInertiaTensor, angularContributionA);
+        Symmetric3x3Wide::MatrixSandwich(angularJB, inertiaB.InverseInertiaTensor, angularContributionB);
+        Symmetric2x2Wide::Add(angularContributionA, angularContributionB, inverseEffectiveMass);
+        Symmetric2x2Wide::Add(inverseEffectiveMass, linearContribution, inverseEffectiveMass);
+        Symmetric2x2Wide::InvertWithoutOverlap(inverseEffectiveMass, effectiveMass);
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        Symmetric2x2Wide::Scale(effectiveMass, effectiveMassCFMScale, effectiveMass);
+        Vector2Wide linearCSVA, negatedLinearCSVB, angularCSVA, angularCSVB, linearCSV, angularCSV, csv;
+        Matrix2x3Wide::TransformByTransposeWithoutOverlap(wsvA.Linear, linearJacobian, linearCSVA);
+        Matrix2x3Wide::TransformByTransposeWithoutOverlap(wsvB.Linear, linearJacobian, negatedLinearCSVB);
+        Matrix2x3Wide::TransformByTransposeWithoutOverlap(wsvA.Angular, angularJA, angularCSVA);
+        Matrix2x3Wide::TransformByTransposeWithoutOverlap(wsvB.Angular, angularJB, angularCSVB);
+        Vector2Wide::Subtract(linearCSVA, negatedLinearCSVB, linearCSV);
+        Vector2Wide::Add(angularCSVA, angularCSVB, angularCSV);
+        Vector2Wide::Add(linearCSV, angularCSV, csv);
+        Vector2Wide error;
+        Vector3Wide::Dot(anchorOffset, linearJacobian.X, error.X);
+        Vector3Wide::Dot(anchorOffset, linearJacobian.Y, error.Y);
+        Vector2Wide biasVelocity;
+        VF maximumImpulse;
+        ServoSettingsMore::ComputeClampedBiasVelocity(error, positionErrorToVelocity, prestep.ServoSettings, dt, inverseDt, biasVelocity, maximumImpulse);
+        Vector2Wide::Subtract(biasVelocity, csv, csv);
+        Vector2Wide csi, softnessContribution;
+        Symmetric2x2Wide::TransformWithoutOverlap(csv, effectiveMass, csi);
+        Vector2Wide::Scale(accumulatedImpulses, softnessImpulseScale, softnessContribution);
+        Vector2Wide::Subtract(csi, softnessContribution, csi);
+        ServoSettingsMore::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
+        ApplyImpulse(wsvA, wsvB, linearJacobian, angularJA, angularJB, inertiaA, inertiaB, csi);
+    }
+};
+
 }  // namespace wide

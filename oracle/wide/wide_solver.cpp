@@ -664,6 +664,7 @@ static TypeProcessor* CreateProcessor(int typeId) {  // BepuPhysics/DefaultTypes
         case 44: return new OneBodyTypeProcessor<NoIncrementalOneBody<OneBodyLinearServoFunctions>, false>();   // OneBodyLinearServo.cs:148 All x2
         case 45: return new OneBodyTypeProcessor<NoIncrementalOneBody<OneBodyLinearMotorFunctions>, false>();   // OneBodyLinearMotor.cs:102 NoPosition x2
         case 31: return new TwoBodyTypeProcessor<NoIncremental<WeldFunctions>, true, true, true, true, false>();  // Weld.cs:222 NoPosition, NoPose, All, All
+        case 37: return new TwoBodyTypeProcessor<NoIncremental<PointOnLineServoFunctions>, true, true, true, true, false>();  // PointOnLineServo.cs:195 All x4
         case 55: return new TwoBodyTypeProcessor<NoIncremental<CenterDistanceLimitFunctions>, true, true, true, true, false>();       // CenterDistanceLimit.cs:134
         default: return nullptr;
     }
