@@ -2,6 +2,7 @@
 // (the widened set gets its second, independent reading one type at a time).
 #pragma once
 #include "wide_joints.h"
+#include "wide_contacts.h"
 
 namespace wide {
 
@@ -1176,6 +1177,98 @@ struct PointOnLineServoFunctions {                                              
         Vector2Wide::Subtract(csi, softnessContribution, csi);
         ServoSettingsMore::ClampImpulse(maximumImpulse, accumulatedImpulses, csi);
         ApplyImpulse(wsvA, wsvB, linearJacobian, angularJA, angularJB, inertiaA, inertiaB, csi);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- nonconvex contact manifolds (type ids 8-10 one body, 15-17 two bodies)
+struct NonconvexContactPrestepData { Vector3Wide Offset; VF Depth; Vector3Wide Normal; };  // Contact/ContactNonconvexCommon.cs:11
+struct NonconvexAccumulatedImpulses { Vector2Wide Tangent; VF Penetration; };              // ContactNonconvexCommon.cs:165
+template <int N> struct ContactNonconvexOneBodyPrestepData { MaterialPropertiesWide MaterialProperties; NonconvexContactPrestepData Contact[N]; };              // ContactNonconvexTypes.cs:161
+template <int N> struct ContactNonconvexPrestepData { MaterialPropertiesWide MaterialProperties; Vector3Wide OffsetB; NonconvexContactPrestepData Contact[N]; };  // ContactNonconvexTypes.cs:58
+template <int N> struct ContactNonconvexAccumulatedImpulses { NonconvexAccumulatedImpulses Contact[N]; };                                                       // ContactNonconvexTypes.cs:88
+
+template <int N> struct ContactNonconvexOneBodyFunctions {  // ContactNonconvexCommon.cs:171
+    typedef ContactNonconvexOneBodyPrestepData<N> Prestep;
+    typedef ContactNonconvexAccumulatedImpulses<N> Impulses;
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA) {  // :187
+        for (int i = 0; i < N; ++i) {
+            NonconvexContactPrestepData& prestepContact = prestep.Contact[i];
+            Vector3Wide x, z;
+            Helpers::BuildOrthonormalBasis(prestepContact.Normal, x, z);
+            NonconvexAccumulatedImpulses& contactImpulse = accumulatedImpulses.Contact[i];
+            TangentFrictionOneBody::WarmStart(x, z, prestepContact.Offset, inertiaA, contactImpulse.Tangent, wsvA);
+            PenetrationLimitOneBody::WarmStart(inertiaA, prestepContact.Normal, prestepContact.Offset, contactImpulse.Penetration, wsvA);
+        }
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA) {  // :202
+        MaterialPropertiesWide& prestepMaterial = prestep.MaterialProperties;
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestepMaterial.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        VF inverseDtWide = vf(inverseDt);
+        for (int i = 0; i < N; ++i) {
+            NonconvexContactPrestepData& contact = prestep.Contact[i];
+            NonconvexAccumulatedImpulses& contactImpulse = accumulatedImpulses.Contact[i];
+            PenetrationLimitOneBody::Solve(inertiaA, contact.Normal, contact.Offset, contact.Depth, positionErrorToVelocity, effectiveMassCFMScale, prestepMaterial.MaximumRecoveryVelocity,
+                                           inverseDtWide, softnessImpulseScale, contactImpulse.Penetration, wsvA);
+            Vector3Wide x, z;
+            Helpers::BuildOrthonormalBasis(contact.Normal, x, z);
+            VF maximumTangentImpulse = prestepMaterial.FrictionCoefficient * contactImpulse.Penetration;
+            TangentFrictionOneBody::Solve(x, z, contact.Offset, inertiaA, maximumTangentImpulse, contactImpulse.Tangent, wsvA);
+        }
+    }
+    static void IncrementallyUpdateForSubstep(const VF& dt, const BodyVelocityWide& wsvA, Prestep& prestep) {  // :232
+        for (int i = 0; i < N; ++i) {
+            NonconvexContactPrestepData& prestepContact = prestep.Contact[i];
+            PenetrationLimitOneBody::UpdatePenetrationDepth(dt, prestepContact.Offset, prestepContact.Normal, wsvA, prestepContact.Depth);
+        }
+    }
+};
+
+template <int N> struct ContactNonconvexTwoBodyFunctions {  // ContactNonconvexCommon.cs:243
+    typedef ContactNonconvexPrestepData<N> Prestep;
+    typedef ContactNonconvexAccumulatedImpulses<N> Impulses;
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                          const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                          BodyVelocityWide& wsvB) {  // :248
+        Vector3Wide& prestepOffsetB = prestep.OffsetB;
+        for (int i = 0; i < N; ++i) {
+            NonconvexContactPrestepData& prestepContact = prestep.Contact[i];
+            Vector3Wide x, z, contactOffsetB;
+            Helpers::BuildOrthonormalBasis(prestepContact.Normal, x, z);
+            Vector3Wide::Subtract(prestepContact.Offset, prestepOffsetB, contactOffsetB);
+            NonconvexAccumulatedImpulses& contactImpulse = accumulatedImpulses.Contact[i];
+            TangentFriction::WarmStart(x, z, prestepContact.Offset, contactOffsetB, inertiaA, inertiaB, contactImpulse.Tangent, wsvA, wsvB);
+            PenetrationLimit::WarmStart(inertiaA, inertiaB, prestepContact.Normal, prestepContact.Offset, contactOffsetB, contactImpulse.Penetration, wsvA, wsvB);
+        }
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB,
+                      const QuaternionWide& orientationB, const BodyInertiaWide& inertiaB, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses,
+                      BodyVelocityWide& wsvA, BodyVelocityWide& wsvB) {  // :265
+        Vector3Wide& prestepOffsetB = prestep.OffsetB;
+        MaterialPropertiesWide& prestepMaterial = prestep.MaterialProperties;
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestepMaterial.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        VF inverseDtWide = vf(inverseDt);
+        for (int i = 0; i < N; ++i) {
+            NonconvexContactPrestepData& contact = prestep.Contact[i];
+            NonconvexAccumulatedImpulses& contactImpulse = accumulatedImpulses.Contact[i];
+            Vector3Wide contactOffsetB;
+            Vector3Wide::Subtract(contact.Offset, prestepOffsetB, contactOffsetB);
+            PenetrationLimit::Solve(inertiaA, inertiaB, contact.Normal, contact.Offset, contactOffsetB, contact.Depth, positionErrorToVelocity, effectiveMassCFMScale,
+                                    prestepMaterial.MaximumRecoveryVelocity, inverseDtWide, softnessImpulseScale, contactImpulse.Penetration, wsvA, wsvB);
+            Vector3Wide x, z;
+            Helpers::BuildOrthonormalBasis(contact.Normal, x, z);
+            VF maximumTangentImpulse = prestepMaterial.FrictionCoefficient * contactImpulse.Penetration;
+            TangentFriction::Solve(x, z, contact.Offset, contactOffsetB, inertiaA, inertiaB, maximumTangentImpulse, contactImpulse.Tangent, wsvA, wsvB);
+        }
+    }
+    static void IncrementallyUpdateForSubstep(const VF& dt, const BodyVelocityWide& wsvA, const BodyVelocityWide& wsvB, Prestep& prestep) {  // :290
+        Vector3Wide& prestepOffsetB = prestep.OffsetB;
+        for (int i = 0; i < N; ++i) {
+            NonconvexContactPrestepData& prestepContact = prestep.Contact[i];
+            PenetrationLimit::UpdatePenetrationDepth(dt, prestepContact.Offset, prestepOffsetB, prestepContact.Normal, wsvA, wsvB, prestepContact.Depth);
+        }
     }
 };
 

@@ -665,6 +665,12 @@ static TypeProcessor* CreateProcessor(int typeId) {  // BepuPhysics/DefaultTypes
         case 45: return new OneBodyTypeProcessor<NoIncrementalOneBody<OneBodyLinearMotorFunctions>, false>();   // OneBodyLinearMotor.cs:102 NoPosition x2
         case 31: return new TwoBodyTypeProcessor<NoIncremental<WeldFunctions>, true, true, true, true, false>();  // Weld.cs:222 NoPosition, NoPose, All, All
         case 37: return new TwoBodyTypeProcessor<NoIncremental<PointOnLineServoFunctions>, true, true, true, true, false>();  // PointOnLineServo.cs:195 All x4
+        case 8: return new OneBodyTypeProcessor<ContactNonconvexOneBodyFunctions<2>>();  // ContactNonconvexTypes.cs:187 (OneBodyContactTypeProcessor: AccessNoPose x2)
+        case 9: return new OneBodyTypeProcessor<ContactNonconvexOneBodyFunctions<3>>();
+        case 10: return new OneBodyTypeProcessor<ContactNonconvexOneBodyFunctions<4>>();
+        case 15: return new TwoBodyTypeProcessor<ContactNonconvexTwoBodyFunctions<2>, true, true, true, true, true>();  // ContactNonconvexTypes.cs:104 (TwoBodyContactTypeProcessor: AccessNoPose x4)
+        case 16: return new TwoBodyTypeProcessor<ContactNonconvexTwoBodyFunctions<3>, true, true, true, true, true>();
+        case 17: return new TwoBodyTypeProcessor<ContactNonconvexTwoBodyFunctions<4>, true, true, true, true, true>();
         case 55: return new TwoBodyTypeProcessor<NoIncremental<CenterDistanceLimitFunctions>, true, true, true, true, false>();       // CenterDistanceLimit.cs:134
         default: return nullptr;
     }
