@@ -1272,4 +1272,147 @@ template <int N> struct ContactNonconvexTwoBodyFunctions {  // ContactNonconvexC
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------- AreaConstraint (type id 36, three bodies)
+struct AreaConstraintPrestepData { VF TargetScaledArea; SpringSettingsWide SpringSettings; };  // AreaConstraint.cs:70
+struct AreaConstraintFunctions {                                                              // AreaConstraint.cs:76
+    typedef AreaConstraintPrestepData Prestep;
+    typedef VF Impulses;
+    static void ApplyImpulse(const VF& inverseMassA, const VF& inverseMassB, const VF& inverseMassC, const Vector3Wide& negatedJacobianA, const Vector3Wide& jacobianB,
+                             const Vector3Wide& jacobianC, const VF& impulse, BodyVelocityWide& velocityA, BodyVelocityWide& velocityB, BodyVelocityWide& velocityC) {  // :79
+        Vector3Wide negativeVelocityChangeA, velocityChangeB, velocityChangeC;
+        Vector3Wide::Scale(negatedJacobianA, inverseMassA * impulse, negativeVelocityChangeA);
+        Vector3Wide::Scale(jacobianB, inverseMassB * impulse, velocityChangeB);
+        Vector3Wide::Scale(jacobianC, inverseMassC * impulse, velocityChangeC);
+        Vector3Wide::Subtract(velocityA.Linear, negativeVelocityChangeA, velocityA.Linear);
+        Vector3Wide::Add(velocityB.Linear, velocityChangeB, velocityB.Linear);
+        Vector3Wide::Add(velocityC.Linear, velocityChangeC, velocityC.Linear);
+    }
+    static void ComputeJacobian(const Vector3Wide& positionA, const Vector3Wide& positionB, const Vector3Wide& positionC, VF& normalLength, Vector3Wide& negatedJacobianA, Vector3Wide& jacobianB,
+                                Vector3Wide& jacobianC, VF& contributionA, VF& contributionB, VF& contributionC, VF& inverseJacobianLength) {  // :92
+        Vector3Wide ab = positionB - positionA;
+        Vector3Wide ac = positionC - positionA;
+        Vector3Wide abxac, normal;
+        Vector3Wide::CrossWithoutOverlap(ab, ac, abxac);
+        Vector3Wide::Length(abxac, normalLength);
+        Vector3Wide::Scale(abxac, ConditionalSelect(GreaterThan(normalLength, vf(1e-10f)), kOne / normalLength, kZero), normal);
+        Vector3Wide::CrossWithoutOverlap(ac, normal, jacobianB);
+        Vector3Wide::CrossWithoutOverlap(normal, ab, jacobianC);
+        Vector3Wide::Add(jacobianB, jacobianC, negatedJacobianA);
+        Vector3Wide::Dot(negatedJacobianA, negatedJacobianA, contributionA);
+        Vector3Wide::Dot(jacobianB, jacobianB, contributionB);
+        Vector3Wide::Dot(jacobianC, jacobianC, contributionC);
+        VF jacobianLengthSquared = contributionA + contributionB + contributionC;
+        jacobianLengthSquared = Max(vf(1e-14f), jacobianLengthSquared);
+        inverseJacobianLength = FastReciprocalSquareRoot(jacobianLengthSquared);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB, const QuaternionWide& orientationB,
+                          const BodyInertiaWide& inertiaB, const Vector3Wide& positionC, const QuaternionWide& orientationC, const BodyInertiaWide& inertiaC, Prestep& prestep,
+                          Impulses& accumulatedImpulses, BodyVelocityWide& wsvA, BodyVelocityWide& wsvB, BodyVelocityWide& wsvC) {  // :140
+        VF normalLength, contributionA, contributionB, contributionC, inverseJacobianLength;
+        Vector3Wide negatedJacobianA, jacobianB, jacobianC;
+        ComputeJacobian(positionA, positionB, positionC, normalLength, negatedJacobianA, jacobianB, jacobianC, contributionA, contributionB, contributionC, inverseJacobianLength);
+        ApplyImpulse(inertiaA.InverseMass, inertiaB.InverseMass, inertiaC.InverseMass, negatedJacobianA, jacobianB, jacobianC, inverseJacobianLength * accumulatedImpulses, wsvA, wsvB, wsvC);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB, const QuaternionWide& orientationB,
+                      const BodyInertiaWide& inertiaB, const Vector3Wide& positionC, const QuaternionWide& orientationC, const BodyInertiaWide& inertiaC, float dt, float inverseDt,
+                      Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA, BodyVelocityWide& wsvB, BodyVelocityWide& wsvC) {  // :152
+        VF normalLength, contributionA, contributionB, contributionC, inverseJacobianLength;
+        Vector3Wide negatedJacobianA, jacobianB, jacobianC;
+        ComputeJacobian(positionA, positionB, positionC, normalLength, negatedJacobianA, jacobianB, jacobianC, contributionA, contributionB, contributionC, inverseJacobianLength);
+        VF inverseJacobianLengthSquared = inverseJacobianLength * inverseJacobianLength;
+        VF inverseEffectiveMass =
+            Max(vf(1e-14f), inverseJacobianLengthSquared * (contributionA * inertiaA.InverseMass + contributionB * inertiaB.InverseMass + contributionC * inertiaC.InverseMass));
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        VF effectiveMass = effectiveMassCFMScale / inverseEffectiveMass;
+        VF biasVelocity = (prestep.TargetScaledArea - normalLength) * inverseJacobianLength * positionErrorToVelocity;
+        VF negatedVelocityContributionA, velocityContributionB, velocityContributionC;
+        Vector3Wide::Dot(negatedJacobianA, wsvA.Linear, negatedVelocityContributionA);
+        Vector3Wide::Dot(jacobianB, wsvB.Linear, velocityContributionB);
+        Vector3Wide::Dot(jacobianC, wsvC.Linear, velocityContributionC);
+        VF csv = inverseJacobianLength * (velocityContributionB + velocityContributionC - negatedVelocityContributionA);
+        VF csi = (biasVelocity - csv) * effectiveMass - accumulatedImpulses * softnessImpulseScale;
+        accumulatedImpulses = accumulatedImpulses + csi;
+        ApplyImpulse(inertiaA.InverseMass, inertiaB.InverseMass, inertiaC.InverseMass, negatedJacobianA, jacobianB, jacobianC, inverseJacobianLength * csi, wsvA, wsvB, wsvC);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- VolumeConstraint (type id 32, four bodies)
+struct VolumeConstraintPrestepData { VF TargetScaledVolume; SpringSettingsWide SpringSettings; };  // VolumeConstraint.cs:70
+struct VolumeConstraintFunctions {                                                                // VolumeConstraint.cs:76
+    typedef VolumeConstraintPrestepData Prestep;
+    typedef VF Impulses;
+    static void ApplyImpulse(const VF& inverseMassA, const VF& inverseMassB, const VF& inverseMassC, const VF& inverseMassD, const Vector3Wide& negatedJacobianA, const Vector3Wide& jacobianB,
+                             const Vector3Wide& jacobianC, const Vector3Wide& jacobianD, const VF& impulse, BodyVelocityWide& velocityA, BodyVelocityWide& velocityB, BodyVelocityWide& velocityC,
+                             BodyVelocityWide& velocityD) {  // :79
+        Vector3Wide negativeVelocityChangeA, velocityChangeB, velocityChangeC, velocityChangeD;
+        Vector3Wide::Scale(negatedJacobianA, inverseMassA * impulse, negativeVelocityChangeA);
+        Vector3Wide::Scale(jacobianB, inverseMassB * impulse, velocityChangeB);
+        Vector3Wide::Scale(jacobianC, inverseMassC * impulse, velocityChangeC);
+        Vector3Wide::Scale(jacobianD, inverseMassD * impulse, velocityChangeD);
+        Vector3Wide::Subtract(velocityA.Linear, negativeVelocityChangeA, velocityA.Linear);
+        Vector3Wide::Add(velocityB.Linear, velocityChangeB, velocityB.Linear);
+        Vector3Wide::Add(velocityC.Linear, velocityChangeC, velocityC.Linear);
+        Vector3Wide::Add(velocityD.Linear, velocityChangeD, velocityD.Linear);
+    }
+    static void ComputeJacobian(const Vector3Wide& positionA, const Vector3Wide& positionB, const Vector3Wide& positionC, const Vector3Wide& positionD, Vector3Wide& ad, Vector3Wide& negatedJA,
+                                Vector3Wide& jacobianB, Vector3Wide& jacobianC, Vector3Wide& jacobianD, VF& contributionA, VF& contributionB, VF& contributionC, VF& contributionD,
+                                VF& inverseJacobianLength) {  // :95
+        Vector3Wide ab = positionB - positionA;
+        Vector3Wide ac = positionC - positionA;
+        ad = positionD - positionA;
+        Vector3Wide::CrossWithoutOverlap(ac, ad, jacobianB);
+        Vector3Wide::CrossWithoutOverlap(ad, ab, jacobianC);
+        Vector3Wide::CrossWithoutOverlap(ab, ac, jacobianD);
+        Vector3Wide::Add(jacobianB, jacobianC, negatedJA);
+        Vector3Wide::Add(jacobianD, negatedJA, negatedJA);
+        Vector3Wide::Dot(negatedJA, negatedJA, contributionA);
+        Vector3Wide::Dot(jacobianB, jacobianB, contributionB);
+        Vector3Wide::Dot(jacobianC, jacobianC, contributionC);
+        Vector3Wide::Dot(jacobianD, jacobianD, contributionD);
+        VF jacobianLengthSquared = contributionA + contributionB + contributionC + contributionD;
+        jacobianLengthSquared = Max(vf(1e-14f), jacobianLengthSquared);
+        inverseJacobianLength = FastReciprocalSquareRoot(jacobianLengthSquared);
+    }
+    static void WarmStart(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB, const QuaternionWide& orientationB,
+                          const BodyInertiaWide& inertiaB, const Vector3Wide& positionC, const QuaternionWide& orientationC, const BodyInertiaWide& inertiaC, const Vector3Wide& positionD,
+                          const QuaternionWide& orientationD, const BodyInertiaWide& inertiaD, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA, BodyVelocityWide& wsvB,
+                          BodyVelocityWide& wsvC, BodyVelocityWide& wsvD) {  // :125
+        Vector3Wide ad, negatedJA, jacobianB, jacobianC, jacobianD;
+        VF contributionA, contributionB, contributionC, contributionD, inverseJacobianLength;
+        ComputeJacobian(positionA, positionB, positionC, positionD, ad, negatedJA, jacobianB, jacobianC, jacobianD, contributionA, contributionB, contributionC, contributionD,
+                        inverseJacobianLength);
+        ApplyImpulse(inertiaA.InverseMass, inertiaB.InverseMass, inertiaC.InverseMass, inertiaD.InverseMass, negatedJA, jacobianB, jacobianC, jacobianD,
+                     inverseJacobianLength * accumulatedImpulses, wsvA, wsvB, wsvC, wsvD);
+    }
+    static void Solve(const Vector3Wide& positionA, const QuaternionWide& orientationA, const BodyInertiaWide& inertiaA, const Vector3Wide& positionB, const QuaternionWide& orientationB,
+                      const BodyInertiaWide& inertiaB, const Vector3Wide& positionC, const QuaternionWide& orientationC, const BodyInertiaWide& inertiaC, const Vector3Wide& positionD,
+                      const QuaternionWide& orientationD, const BodyInertiaWide& inertiaD, float dt, float inverseDt, Prestep& prestep, Impulses& accumulatedImpulses, BodyVelocityWide& wsvA,
+                      BodyVelocityWide& wsvB, BodyVelocityWide& wsvC, BodyVelocityWide& wsvD) {  // :133
+        Vector3Wide ad, negatedJA, jacobianB, jacobianC, jacobianD;
+        VF contributionA, contributionB, contributionC, contributionD, inverseJacobianLength;
+        ComputeJacobian(positionA, positionB, positionC, positionD, ad, negatedJA, jacobianB, jacobianC, jacobianD, contributionA, contributionB, contributionC, contributionD,
+                        inverseJacobianLength);
+        VF inverseJacobianLengthSquared = inverseJacobianLength * inverseJacobianLength;
+        VF inverseEffectiveMass = Max(vf(1e-14f), inverseJacobianLengthSquared * (contributionA * inertiaA.InverseMass + contributionB * inertiaB.InverseMass +
+                                                                                contributionC * inertiaC.InverseMass + contributionD * inertiaD.InverseMass));
+        VF positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale;
+        SpringSettingsWide::ComputeSpringiness(prestep.SpringSettings, dt, positionErrorToVelocity, effectiveMassCFMScale, softnessImpulseScale);
+        VF effectiveMass = effectiveMassCFMScale / inverseEffectiveMass;
+        VF volume;
+        Vector3Wide::Dot(jacobianD, ad, volume);
+        VF biasVelocity = (prestep.TargetScaledVolume - volume) * inverseJacobianLength * positionErrorToVelocity;
+        VF negatedVelocityContributionA, velocityContributionB, velocityContributionC, velocityContributionD;
+        Vector3Wide::Dot(negatedJA, wsvA.Linear, negatedVelocityContributionA);
+        Vector3Wide::Dot(jacobianB, wsvB.Linear, velocityContributionB);
+        Vector3Wide::Dot(jacobianC, wsvC.Linear, velocityContributionC);
+        Vector3Wide::Dot(jacobianD, wsvD.Linear, velocityContributionD);
+        VF csv = inverseJacobianLength * (velocityContributionB + velocityContributionC + velocityContributionD - negatedVelocityContributionA);
+        VF csi = (biasVelocity - csv) * effectiveMass - accumulatedImpulses * softnessImpulseScale;
+        accumulatedImpulses = accumulatedImpulses + csi;
+        ApplyImpulse(inertiaA.InverseMass, inertiaB.InverseMass, inertiaC.InverseMass, inertiaD.InverseMass, negatedJA, jacobianB, jacobianC, jacobianD, inverseJacobianLength * csi, wsvA,
+                     wsvB, wsvC, wsvD);
+    }
+};
+
 }  // namespace wide

@@ -616,6 +616,188 @@ template <typename TConstraintFunctions, bool Incremental = true> struct OneBody
         }
     }
 };
+
+// Constraints/ThreeBodyTypeProcessor.cs:83-179. Both users (AreaConstraint, and VolumeConstraint below) declare AccessOnlyLinear everywhere: the scatter writes the linear half
+// only, and since the angular half that was gathered is not touched by either constraint, writing both halves back (what this template does) leaves the same bytes.
+template <typename TConstraintFunctions> struct ThreeBodyTypeProcessor : TypeProcessor {
+    typedef typename TConstraintFunctions::Prestep TPrestepData;
+    typedef typename TConstraintFunctions::Impulses TAccumulatedImpulse;
+    struct ThreeBodyReferences { VI IndexA, IndexB, IndexC; };  // :9
+    ThreeBodyTypeProcessor() {
+        BodiesPerConstraint = 3;
+        PrestepFloats = sizeof(TPrestepData) / sizeof(VF);
+        ImpulseFloats = sizeof(TAccumulatedImpulse) / sizeof(VF);
+        RequiresIncrementalSubstepUpdates = false;  // AreaConstraint.cs:190
+    }
+    template <BatchIntegrationMode TBatchIntegrationMode, bool TAllowPoseIntegration>
+    void WarmStartImpl(TypeBatch& typeBatch, const IndexSet* integrationFlags, Bodies& bodies, PoseIntegratorCallbacks& integratorCallbacks, float dt, float inverseDt, int startBundle,
+                       int exclusiveEndBundle, int workerIndex) {  // :83
+        TPrestepData* prestepBundles = (TPrestepData*)typeBatch.PrestepData;
+        ThreeBodyReferences* bodyReferencesBundles = (ThreeBodyReferences*)typeBatch.BodyReferences;
+        TAccumulatedImpulse* accumulatedImpulsesBundles = (TAccumulatedImpulse*)typeBatch.AccumulatedImpulses;
+        for (int i = startBundle; i < exclusiveEndBundle; ++i) {
+            ThreeBodyReferences& references = bodyReferencesBundles[i];
+            Vector3Wide positionA, positionB, positionC;
+            QuaternionWide orientationA, orientationB, orientationC;
+            BodyVelocityWide wsvA, wsvB, wsvC;
+            BodyInertiaWide inertiaA, inertiaB, inertiaC;
+            GatherAndIntegrate<TBatchIntegrationMode, TAllowPoseIntegration>(bodies, integratorCallbacks, integrationFlags, 0, dt, workerIndex, i, references.IndexA, positionA, orientationA,
+                                                                             wsvA, inertiaA);
+            GatherAndIntegrate<TBatchIntegrationMode, TAllowPoseIntegration>(bodies, integratorCallbacks, integrationFlags, 1, dt, workerIndex, i, references.IndexB, positionB, orientationB,
+                                                                             wsvB, inertiaB);
+            GatherAndIntegrate<TBatchIntegrationMode, TAllowPoseIntegration>(bodies, integratorCallbacks, integrationFlags, 2, dt, workerIndex, i, references.IndexC, positionC, orientationC,
+                                                                             wsvC, inertiaC);
+            TConstraintFunctions::WarmStart(positionA, orientationA, inertiaA, positionB, orientationB, inertiaB, positionC, orientationC, inertiaC, prestepBundles[i],
+                                            accumulatedImpulsesBundles[i], wsvA, wsvB, wsvC);
+            bodies.ScatterVelocities<true, true>(wsvA, references.IndexA);
+            bodies.ScatterVelocities<true, true>(wsvB, references.IndexB);
+            bodies.ScatterVelocities<true, true>(wsvC, references.IndexC);
+        }
+    }
+    void WarmStart(BatchIntegrationMode mode, bool allowPoseIntegration, TypeBatch& typeBatch, const IndexSet* integrationFlags, Bodies& bodies, PoseIntegratorCallbacks& integratorCallbacks,
+                   float dt, float inverseDt, int startBundle, int exclusiveEndBundle, int workerIndex) override {
+        if (mode == BatchShouldAlwaysIntegrate) { WIDE_DISPATCH(BatchShouldAlwaysIntegrate) }
+        else if (mode == BatchShouldNeverIntegrate) { WIDE_DISPATCH(BatchShouldNeverIntegrate) }
+        else { WIDE_DISPATCH(BatchShouldConditionallyIntegrate) }
+    }
+    void Solve(TypeBatch& typeBatch, Bodies& bodies, float dt, float inverseDt, int startBundle, int exclusiveEndBundle) override {  // :128
+        TPrestepData* prestepBundles = (TPrestepData*)typeBatch.PrestepData;
+        ThreeBodyReferences* bodyReferencesBundles = (ThreeBodyReferences*)typeBatch.BodyReferences;
+        TAccumulatedImpulse* accumulatedImpulsesBundles = (TAccumulatedImpulse*)typeBatch.AccumulatedImpulses;
+        for (int i = startBundle; i < exclusiveEndBundle; ++i) {
+            ThreeBodyReferences& references = bodyReferencesBundles[i];
+            Vector3Wide positionA, positionB, positionC;
+            QuaternionWide orientationA, orientationB, orientationC;
+            BodyVelocityWide wsvA, wsvB, wsvC;
+            BodyInertiaWide inertiaA, inertiaB, inertiaC;
+            bodies.GatherState(references.IndexA, true, positionA, orientationA, wsvA, inertiaA);
+            bodies.GatherState(references.IndexB, true, positionB, orientationB, wsvB, inertiaB);
+            bodies.GatherState(references.IndexC, true, positionC, orientationC, wsvC, inertiaC);
+            TConstraintFunctions::Solve(positionA, orientationA, inertiaA, positionB, orientationB, inertiaB, positionC, orientationC, inertiaC, dt, inverseDt, prestepBundles[i],
+                                        accumulatedImpulsesBundles[i], wsvA, wsvB, wsvC);
+            bodies.ScatterVelocities<true, true>(wsvA, references.IndexA);
+            bodies.ScatterVelocities<true, true>(wsvB, references.IndexB);
+            bodies.ScatterVelocities<true, true>(wsvC, references.IndexC);
+        }
+    }
+    void Microbenchmark(Bodies& bodies, float* prestepLane, float* accumulatedLane, float dt, int iterations) override {
+        TPrestepData prestep;
+        TAccumulatedImpulse accumulatedImpulse;
+        BroadcastLanes(prestep, prestepLane);
+        BroadcastLanes(accumulatedImpulse, accumulatedLane);
+        Vector3Wide position[3];
+        QuaternionWide orientation[3];
+        BodyVelocityWide velocity[3];
+        BodyInertiaWide inertia[3];
+        for (int k = 0; k < 3; ++k) bodies.GatherState(vi(k), true, position[k], orientation[k], velocity[k], inertia[k]);
+        const float inverseDt = 1.0f / dt;
+        for (int i = 0; i < iterations; ++i) {
+            TConstraintFunctions::WarmStart(position[0], orientation[0], inertia[0], position[1], orientation[1], inertia[1], position[2], orientation[2], inertia[2], prestep,
+                                            accumulatedImpulse, velocity[0], velocity[1], velocity[2]);
+            TConstraintFunctions::Solve(position[0], orientation[0], inertia[0], position[1], orientation[1], inertia[1], position[2], orientation[2], inertia[2], dt, inverseDt, prestep,
+                                        accumulatedImpulse, velocity[0], velocity[1], velocity[2]);
+        }
+        for (int k = 0; k < 3; ++k) {
+            VI index = VI{k, -1, -1, -1, -1, -1, -1, -1};
+            bodies.ScatterVelocities<true, true>(velocity[k], index);
+        }
+        ReadFirstLanes(prestep, prestepLane);
+        ReadFirstLanes(accumulatedImpulse, accumulatedLane);
+    }
+};
+
+// Constraints/FourBodyTypeProcessor.cs:104-192
+template <typename TConstraintFunctions> struct FourBodyTypeProcessor : TypeProcessor {
+    typedef typename TConstraintFunctions::Prestep TPrestepData;
+    typedef typename TConstraintFunctions::Impulses TAccumulatedImpulse;
+    struct FourBodyReferences { VI IndexA, IndexB, IndexC, IndexD; };  // :12
+    FourBodyTypeProcessor() {
+        BodiesPerConstraint = 4;
+        PrestepFloats = sizeof(TPrestepData) / sizeof(VF);
+        ImpulseFloats = sizeof(TAccumulatedImpulse) / sizeof(VF);
+        RequiresIncrementalSubstepUpdates = false;  // VolumeConstraint.cs:179
+    }
+    template <BatchIntegrationMode TBatchIntegrationMode, bool TAllowPoseIntegration>
+    void WarmStartImpl(TypeBatch& typeBatch, const IndexSet* integrationFlags, Bodies& bodies, PoseIntegratorCallbacks& integratorCallbacks, float dt, float inverseDt, int startBundle,
+                       int exclusiveEndBundle, int workerIndex) {  // :104
+        TPrestepData* prestepBundles = (TPrestepData*)typeBatch.PrestepData;
+        FourBodyReferences* bodyReferencesBundles = (FourBodyReferences*)typeBatch.BodyReferences;
+        TAccumulatedImpulse* accumulatedImpulsesBundles = (TAccumulatedImpulse*)typeBatch.AccumulatedImpulses;
+        for (int i = startBundle; i < exclusiveEndBundle; ++i) {
+            FourBodyReferences& references = bodyReferencesBundles[i];
+            Vector3Wide positionA, positionB, positionC, positionD;
+            QuaternionWide orientationA, orientationB, orientationC, orientationD;
+            BodyVelocityWide wsvA, wsvB, wsvC, wsvD;
+            BodyInertiaWide inertiaA, inertiaB, inertiaC, inertiaD;
+            GatherAndIntegrate<TBatchIntegrationMode, TAllowPoseIntegration>(bodies, integratorCallbacks, integrationFlags, 0, dt, workerIndex, i, references.IndexA, positionA, orientationA,
+                                                                             wsvA, inertiaA);
+            GatherAndIntegrate<TBatchIntegrationMode, TAllowPoseIntegration>(bodies, integratorCallbacks, integrationFlags, 1, dt, workerIndex, i, references.IndexB, positionB, orientationB,
+                                                                             wsvB, inertiaB);
+            GatherAndIntegrate<TBatchIntegrationMode, TAllowPoseIntegration>(bodies, integratorCallbacks, integrationFlags, 2, dt, workerIndex, i, references.IndexC, positionC, orientationC,
+                                                                             wsvC, inertiaC);
+            GatherAndIntegrate<TBatchIntegrationMode, TAllowPoseIntegration>(bodies, integratorCallbacks, integrationFlags, 3, dt, workerIndex, i, references.IndexD, positionD, orientationD,
+                                                                             wsvD, inertiaD);
+            TConstraintFunctions::WarmStart(positionA, orientationA, inertiaA, positionB, orientationB, inertiaB, positionC, orientationC, inertiaC, positionD, orientationD, inertiaD,
+                                            prestepBundles[i], accumulatedImpulsesBundles[i], wsvA, wsvB, wsvC, wsvD);
+            bodies.ScatterVelocities<true, true>(wsvA, references.IndexA);
+            bodies.ScatterVelocities<true, true>(wsvB, references.IndexB);
+            bodies.ScatterVelocities<true, true>(wsvC, references.IndexC);
+            bodies.ScatterVelocities<true, true>(wsvD, references.IndexD);
+        }
+    }
+    void WarmStart(BatchIntegrationMode mode, bool allowPoseIntegration, TypeBatch& typeBatch, const IndexSet* integrationFlags, Bodies& bodies, PoseIntegratorCallbacks& integratorCallbacks,
+                   float dt, float inverseDt, int startBundle, int exclusiveEndBundle, int workerIndex) override {
+        if (mode == BatchShouldAlwaysIntegrate) { WIDE_DISPATCH(BatchShouldAlwaysIntegrate) }
+        else if (mode == BatchShouldNeverIntegrate) { WIDE_DISPATCH(BatchShouldNeverIntegrate) }
+        else { WIDE_DISPATCH(BatchShouldConditionallyIntegrate) }
+    }
+    void Solve(TypeBatch& typeBatch, Bodies& bodies, float dt, float inverseDt, int startBundle, int exclusiveEndBundle) override {  // :150
+        TPrestepData* prestepBundles = (TPrestepData*)typeBatch.PrestepData;
+        FourBodyReferences* bodyReferencesBundles = (FourBodyReferences*)typeBatch.BodyReferences;
+        TAccumulatedImpulse* accumulatedImpulsesBundles = (TAccumulatedImpulse*)typeBatch.AccumulatedImpulses;
+        for (int i = startBundle; i < exclusiveEndBundle; ++i) {
+            FourBodyReferences& references = bodyReferencesBundles[i];
+            Vector3Wide positionA, positionB, positionC, positionD;
+            QuaternionWide orientationA, orientationB, orientationC, orientationD;
+            BodyVelocityWide wsvA, wsvB, wsvC, wsvD;
+            BodyInertiaWide inertiaA, inertiaB, inertiaC, inertiaD;
+            bodies.GatherState(references.IndexA, true, positionA, orientationA, wsvA, inertiaA);
+            bodies.GatherState(references.IndexB, true, positionB, orientationB, wsvB, inertiaB);
+            bodies.GatherState(references.IndexC, true, positionC, orientationC, wsvC, inertiaC);
+            bodies.GatherState(references.IndexD, true, positionD, orientationD, wsvD, inertiaD);
+            TConstraintFunctions::Solve(positionA, orientationA, inertiaA, positionB, orientationB, inertiaB, positionC, orientationC, inertiaC, positionD, orientationD, inertiaD, dt, inverseDt,
+                                        prestepBundles[i], accumulatedImpulsesBundles[i], wsvA, wsvB, wsvC, wsvD);
+            bodies.ScatterVelocities<true, true>(wsvA, references.IndexA);
+            bodies.ScatterVelocities<true, true>(wsvB, references.IndexB);
+            bodies.ScatterVelocities<true, true>(wsvC, references.IndexC);
+            bodies.ScatterVelocities<true, true>(wsvD, references.IndexD);
+        }
+    }
+    void Microbenchmark(Bodies& bodies, float* prestepLane, float* accumulatedLane, float dt, int iterations) override {
+        TPrestepData prestep;
+        TAccumulatedImpulse accumulatedImpulse;
+        BroadcastLanes(prestep, prestepLane);
+        BroadcastLanes(accumulatedImpulse, accumulatedLane);
+        Vector3Wide position[4];
+        QuaternionWide orientation[4];
+        BodyVelocityWide velocity[4];
+        BodyInertiaWide inertia[4];
+        for (int k = 0; k < 4; ++k) bodies.GatherState(vi(k), true, position[k], orientation[k], velocity[k], inertia[k]);
+        const float inverseDt = 1.0f / dt;
+        for (int i = 0; i < iterations; ++i) {
+            TConstraintFunctions::WarmStart(position[0], orientation[0], inertia[0], position[1], orientation[1], inertia[1], position[2], orientation[2], inertia[2], position[3],
+                                            orientation[3], inertia[3], prestep, accumulatedImpulse, velocity[0], velocity[1], velocity[2], velocity[3]);
+            TConstraintFunctions::Solve(position[0], orientation[0], inertia[0], position[1], orientation[1], inertia[1], position[2], orientation[2], inertia[2], position[3], orientation[3],
+                                        inertia[3], dt, inverseDt, prestep, accumulatedImpulse, velocity[0], velocity[1], velocity[2], velocity[3]);
+        }
+        for (int k = 0; k < 4; ++k) {
+            VI index = VI{k, -1, -1, -1, -1, -1, -1, -1};
+            bodies.ScatterVelocities<true, true>(velocity[k], index);
+        }
+        ReadFirstLanes(prestep, prestepLane);
+        ReadFirstLanes(accumulatedImpulse, accumulatedLane);
+    }
+};
 #undef WIDE_DISPATCH
 
 // Joint function structs have no incremental update; give the two-body template a uniform call.
@@ -671,6 +853,8 @@ static TypeProcessor* CreateProcessor(int typeId) {  // BepuPhysics/DefaultTypes
         case 15: return new TwoBodyTypeProcessor<ContactNonconvexTwoBodyFunctions<2>, true, true, true, true, true>();  // ContactNonconvexTypes.cs:104 (TwoBodyContactTypeProcessor: AccessNoPose x4)
         case 16: return new TwoBodyTypeProcessor<ContactNonconvexTwoBodyFunctions<3>, true, true, true, true, true>();
         case 17: return new TwoBodyTypeProcessor<ContactNonconvexTwoBodyFunctions<4>, true, true, true, true, true>();
+        case 36: return new ThreeBodyTypeProcessor<AreaConstraintFunctions>();   // AreaConstraint.cs:199 OnlyLinear x6
+        case 32: return new FourBodyTypeProcessor<VolumeConstraintFunctions>();  // VolumeConstraint.cs:188 OnlyLinear x8
         case 55: return new TwoBodyTypeProcessor<NoIncremental<CenterDistanceLimitFunctions>, true, true, true, true, false>();       // CenterDistanceLimit.cs:134
         default: return nullptr;
     }
