@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
 
 // PoseIntegrator.PredictBoundingBoxes (PoseIntegrator.cs:307-370), one lane per body: the stage before collision detection, on the bodies the solver left in HBM.
 __global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __restrict__ bodies, int count, CollidableIn* collidables, int keep_activity,
-                                                              PredictedBounds* __restrict__ out, float dt, int integrate_velocity_for_kinematics, StepParams sp, HullTable hulls) {
+                                                              PredictedBounds* __restrict__ out, float dt, int integrate_velocity_for_kinematics, StepParams sp, ShapeTables tables) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const float4* base = bodies + (size_t)i * 8;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __res
     if (integrate_velocity_for_kinematics || !is_kinematic) velocity_callback(sp, vel);                                   // :318-333 (never stored)
     const CollidableIn c = collidables[i];
     PredictedBounds r;
-    predictBounds(pos, ori, vel, sleep_energy, dt, c, hulls, r);
+    predictBoundsOfAnyShape(pos, ori, vel, sleep_energy, dt, c, tables, r);
     out[i] = r;
     if (keep_activity) collidables[i].activity = r.activity;  // device-resident records: the sleep counters carry over to the next frame
 }

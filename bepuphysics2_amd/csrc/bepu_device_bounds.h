@@ -151,4 +151,112 @@ BD_FN void predictBounds(V3 position, Q orientation, const BodyVel& velocity, fl
     out.speculative_margin = speculativeMargin;
 }
 
+
+// ======================================================================================
+// Compounds (Compound.Id 6, BigCompound.Id 7) and meshes (Mesh.Id 8): one lane still owns one body and walks its children / triangles.
+// ======================================================================================
+enum { kShapeCompound = 6, kShapeBigCompound = 7, kShapeMesh = 8 };
+struct CompoundChildIn { int shape_type; float shape[9]; float local_position[3]; float local_orientation[4]; };  // mirrors bepuhip_compound_child
+struct ShapeTables {
+    HullTable hulls;
+    const CompoundChildIn* children; const int* child_begin; int compound_count;               // compound k: children [child_begin[k], child_begin[k + 1])
+    const float* triangles; const int* triangle_begin; const float* mesh_scales; int mesh_count;  // mesh m: 9-float triangles [triangle_begin[m], triangle_begin[m + 1]), scale xyz
+};
+
+struct Box3 { V3 lo, hi; };
+BD_FN Box3 emptyBox() { return {{3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f}}; }
+BD_FN V3 min3(V3 a, V3 b) { return {vmin(a.x, b.x), vmin(a.y, b.y), vmin(a.z, b.z)}; }  // Vector3.Min / Vector3.Max, first operand kept on ties like minps
+BD_FN V3 max3(V3 a, V3 b) { return {vmax(a.x, b.x), vmax(a.y, b.y), vmax(a.z, b.z)}; }
+BD_FN float largerMargin(float a, float b) {  // MathF.Max
+    if (a != a) return a;
+    if (b != b) return b;
+    if (a == b) return (__float_as_uint(a) >> 31) ? b : a;
+    return a > b ? a : b;
+}
+BD_FN float smallerMargin(float a, float b) {  // MathF.Min
+    if (a != a) return a;
+    if (b != b) return b;
+    if (a == b) return (__float_as_uint(a) >> 31) ? a : b;
+    return a < b ? a : b;
+}
+
+// The velocity expansion every Execute*Batch ends with, given the local box and the two radii of the shape. `wideClamp` = the Vector<float> form of the margin
+// clamp (convex batches, BoundingBoxBatcher.cs:186), otherwise the MathF form of the homogeneous compound batch (:253).
+BD_FN float expandByVelocity(const BodyVel& velocity, float dt, float maximumRadius, float maximumAngularExpansion, float minimumMargin, float maximumMargin, int allowBeyondMargin,
+                             bool wideClamp, V3 position, Box3& box) {
+    const float angular = angularBoundsExpansion(length(velocity.ang), dt, maximumRadius, maximumAngularExpansion);
+    float margin = length(velocity.lin) * dt + angular;
+    margin = wideClamp ? vmax(minimumMargin, vmin(maximumMargin, margin)) : largerMargin(minimumMargin, smallerMargin(maximumMargin, margin));
+    const float limit = allowBeyondMargin != 0 ? 3.402823466e+38f : margin;
+    const V3 swept = scale(velocity.lin, dt);
+    const V3 grow_lo = {vmax(-limit, vmin(0.0f, swept.x) - angular), vmax(-limit, vmin(0.0f, swept.y) - angular), vmax(-limit, vmin(0.0f, swept.z) - angular)};
+    const V3 grow_hi = {vmin(limit, vmax(0.0f, swept.x) + angular), vmin(limit, vmax(0.0f, swept.y) + angular), vmin(limit, vmax(0.0f, swept.z) + angular)};
+    box.lo = add(position, add(box.lo, grow_lo));
+    box.hi = add(position, add(box.hi, grow_hi));
+    return margin;
+}
+
+// Compound.AddChildBoundsToBatcher (Compound.cs:198-221) feeding ExecuteConvexBatch with CompoundChild continuations (BoundingBoxBatcher.cs:142-223, merge :203-209),
+// after ExecuteCompoundBatch reset the body's box and margin (:268-287).
+BD_FN void compoundBounds(V3 position, Q orientation, const BodyVel& velocity, float dt, const CollidableIn& c, const ShapeTables& tables, PredictedBounds& out) {
+    const int compound = (int)c.shape[0];
+    Box3 whole = emptyBox();
+    float margin = 0.0f;
+    const int last = tables.child_begin[compound + 1];
+    for (int k = tables.child_begin[compound]; k < last; ++k) {
+        const CompoundChildIn* child = tables.children + k;
+        const Q local_q = {child->local_orientation[0], child->local_orientation[1], child->local_orientation[2], child->local_orientation[3]};
+        const V3 offset = transform(V3{child->local_position[0], child->local_position[1], child->local_position[2]}, orientation);  // GetRotatedChildPose, Compound.cs:153-157
+        const Q child_q = concatenate(local_q, orientation);
+        V3 swing = cross(velocity.ang, offset);  // the child's share of the angular motion, capped at the length of its offset (:210-216; the ratio is formed in double there)
+        const float swing2 = lengthSquared(swing), offset2 = lengthSquared(offset);
+        if (swing2 > offset2) swing = scale(swing, (float)(sqrt((double)offset2) / sqrt((double)swing2)));
+        const BodyVel child_v = {add(velocity.lin, swing), velocity.ang};
+        float shape[9];
+        for (int f = 0; f < 9; ++f) shape[f] = child->shape[f];
+        float maximumRadius, maximumAngularExpansion;
+        Box3 box;
+        shapeBounds(child->shape_type, shape, child_q, tables.hulls, maximumRadius, maximumAngularExpansion, box.lo, box.hi);  // children are convex (checked at the boundary)
+        const float child_margin = expandByVelocity(child_v, dt, maximumRadius, maximumAngularExpansion, c.minimum_speculative_margin, c.maximum_speculative_margin,
+                                                    c.allow_expansion_beyond_speculative_margin, true, add(offset, position), box);
+        margin = largerMargin(margin, child_margin);
+        whole.lo = min3(whole.lo, box.lo);  // BoundingBox.CreateMerged, BoundingBox.cs:173-177
+        whole.hi = max3(whole.hi, box.hi);
+    }
+    out.min[0] = whole.lo.x; out.min[1] = whole.lo.y; out.min[2] = whole.lo.z;
+    out.max[0] = whole.hi.x; out.max[1] = whole.hi.y; out.max[2] = whole.hi.z;
+    out.speculative_margin = margin;
+}
+
+// ExecuteHomogeneousCompoundBatch (BoundingBoxBatcher.cs:225-266) over Mesh.ComputeBounds (Mesh.cs:232-255).
+BD_FN void meshBounds(V3 position, Q orientation, const BodyVel& velocity, float dt, const CollidableIn& c, const ShapeTables& tables, PredictedBounds& out) {
+    const int mesh = (int)c.shape[0];
+    const float sx = tables.mesh_scales[3 * mesh], sy = tables.mesh_scales[3 * mesh + 1], sz = tables.mesh_scales[3 * mesh + 2];
+    const M3 basis = createFromQuaternion(orientation);
+    Box3 box = emptyBox();
+    const int last = tables.triangle_begin[mesh + 1];
+    for (int t = tables.triangle_begin[mesh]; t < last; ++t) {
+        const float* v = tables.triangles + 9 * (size_t)t;
+        const V3 a = transform(V3{sx * v[0], sy * v[1], sz * v[2]}, basis), b = transform(V3{sx * v[3], sy * v[4], sz * v[5]}, basis), cc = transform(V3{sx * v[6], sy * v[7], sz * v[8]}, basis);
+        box.lo = min3(min3(a, b), min3(cc, box.lo));  // the reference's pairing: Min(Min(a, b), Min(c, min)) (:248-253)
+        box.hi = max3(max3(a, b), max3(cc, box.hi));
+    }
+    const V3 abs_lo = {vabs(box.lo.x), vabs(box.lo.y), vabs(box.lo.z)}, abs_hi = {vabs(box.hi.x), vabs(box.hi.y), vabs(box.hi.z)};
+    const float maximumRadius = length(max3(abs_lo, abs_hi));
+    const V3 inner = min3(abs_lo, abs_hi);
+    const float maximumAngularExpansion = maximumRadius - vmin(inner.x, vmin(inner.y, inner.z));
+    const float margin = expandByVelocity(velocity, dt, maximumRadius, maximumAngularExpansion, c.minimum_speculative_margin, c.maximum_speculative_margin,
+                                          c.allow_expansion_beyond_speculative_margin, false, position, box);
+    out.min[0] = box.lo.x; out.min[1] = box.lo.y; out.min[2] = box.lo.z;
+    out.max[0] = box.hi.x; out.max[1] = box.hi.y; out.max[2] = box.hi.z;
+    out.speculative_margin = margin;
+}
+
+BD_FN void predictBoundsOfAnyShape(V3 position, Q orientation, const BodyVel& velocity, float sleepEnergy, float dt, const CollidableIn& c, const ShapeTables& tables, PredictedBounds& out) {
+    if (c.shape_type < kShapeCompound) return predictBounds(position, orientation, velocity, sleepEnergy, dt, c, tables.hulls, out);
+    out.activity = updateSleepCandidacy(sleepEnergy, c.sleep_threshold, c.minimum_timesteps_under_threshold, c.activity);
+    if (c.shape_type == kShapeMesh) meshBounds(position, orientation, velocity, dt, c, tables, out);
+    else compoundBounds(position, orientation, velocity, dt, c, tables, out);
+}
+
 }  // namespace bd

@@ -205,6 +205,15 @@ struct bepuhip_ctx {
     float* d_hull_points = nullptr;  // convex hulls (bepuhip_set_convex_hulls): xyz triplets, and hull -> first point (hull_count + 1 entries)
     int* d_hull_begin = nullptr;
     int hull_count = 0;
+    CompoundChildIn* d_compound_children = nullptr;  // compounds (bepuhip_set_compounds): children of every compound one after the other, and compound -> first child
+    int* d_compound_begin = nullptr;
+    int compound_count = 0;
+    int compound_hulls_needed = 0;  // 1 + the largest hull index any compound child names (checked against the hull table at every prediction)
+    float* d_mesh_triangles = nullptr;  // meshes (bepuhip_set_meshes): 9 floats per triangle, mesh -> first triangle, xyz scale per mesh
+    int* d_mesh_begin = nullptr;
+    float* d_mesh_scales = nullptr;
+    int mesh_count = 0;
+    int resident_hulls_needed = 0, resident_compounds_needed = 0, resident_meshes_needed = 0;  // 1 + the largest table index the resident collidables name
     unsigned* d_staged = nullptr;   // island schedule: clusters that have staged their bodies in the current launch (see cluster_kernel's kinematic block)
     int* d_kinlist = nullptr;       // constrained kinematic body indices derived from the body references
     int kinlist_count = 0;

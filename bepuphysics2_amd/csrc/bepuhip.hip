@@ -122,6 +122,11 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_collidables) hipFree(c->d_collidables);
     if (c->d_hull_points) hipFree(c->d_hull_points);
     if (c->d_hull_begin) hipFree(c->d_hull_begin);
+    if (c->d_compound_children) hipFree(c->d_compound_children);
+    if (c->d_compound_begin) hipFree(c->d_compound_begin);
+    if (c->d_mesh_triangles) hipFree(c->d_mesh_triangles);
+    if (c->d_mesh_begin) hipFree(c->d_mesh_begin);
+    if (c->d_mesh_scales) hipFree(c->d_mesh_scales);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->d_boundary) hipFree(c->d_boundary);
     if (c->d_boundary_snapshot) hipFree(c->d_boundary_snapshot);
@@ -1494,8 +1499,19 @@ static_assert(sizeof(bepuhip_collidable) == sizeof(CollidableIn) && sizeof(bepuh
 static_assert(sizeof(bepuhip_predicted_bounds) == sizeof(PredictedBounds) && sizeof(bepuhip_predicted_bounds) == 32, "bepuhip_predicted_bounds layout");
 static int32_t check_collidables(const bepuhip_ctx* c, const bepuhip_collidable* collidables, int32_t count) {
     for (int i = 0; i < count; ++i) {
-        if (collidables[i].shape_type < -1 || collidables[i].shape_type > 5)
-            return fail(BEPUHIP_E_UNSUPPORTED, "shape type " + std::to_string(collidables[i].shape_type) + " (compounds and meshes stay on the host)");
+        if (collidables[i].shape_type < -1 || collidables[i].shape_type > 8)
+            return fail(BEPUHIP_E_UNSUPPORTED, "shape type " + std::to_string(collidables[i].shape_type) + " is not one of the library's nine (Sphere.Id 0 ... Mesh.Id 8)");
+        if (collidables[i].shape_type >= 6) {
+            const bool mesh = collidables[i].shape_type == 8;
+            const int table = mesh ? c->mesh_count : c->compound_count;
+            const float k = collidables[i].shape[0];
+            if (!(k >= 0) || k != (float)(int)k || (int)k >= table)
+                return fail(BEPUHIP_E_INVALID_ARGUMENT, std::string(mesh ? "mesh" : "compound") + " index " + std::to_string(k) + " of collidable " + std::to_string(i) + " is not one of the " +
+                                                             std::to_string(table) + " entries of " + (mesh ? "bepuhip_set_meshes" : "bepuhip_set_compounds"));
+            if (!mesh && c->compound_hulls_needed > c->hull_count)
+                return fail(BEPUHIP_E_INVALID_ARGUMENT, "a compound child names convex hull " + std::to_string(c->compound_hulls_needed - 1) + " but bepuhip_set_convex_hulls holds " +
+                                                             std::to_string(c->hull_count));
+        }
         if (collidables[i].shape_type == 5) {
             const float h = collidables[i].shape[0];
             if (!(h >= 0) || h != (float)(int)h || (int)h >= c->hull_count)
@@ -1523,6 +1539,59 @@ int32_t bepuhip_set_convex_hulls(bepuhip_ctx* c, const float* points, const int3
     c->hull_count = hull_count;
     return BEPUHIP_OK;
 }
+static_assert(sizeof(bepuhip_compound_child) == sizeof(CompoundChildIn) && sizeof(bepuhip_compound_child) == 68, "bepuhip_compound_child layout");
+int32_t bepuhip_set_compounds(bepuhip_ctx* c, const bepuhip_compound_child* children, const int32_t* child_begin, int32_t compound_count) {
+    if (!c || compound_count < 0 || (compound_count > 0 && (!children || !child_begin))) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad set_compounds argument");
+    int hulls_needed = 0;
+    for (int k = 0; k < compound_count; ++k) {
+        if (child_begin[k] < 0 || child_begin[k + 1] <= child_begin[k]) return fail(BEPUHIP_E_INVALID_ARGUMENT, "compound " + std::to_string(k) + " has no children (or the offsets decrease)");
+        for (int j = child_begin[k]; j < child_begin[k + 1]; ++j) {
+            const int t = children[j].shape_type;
+            if (t < 0 || t > 5) return fail(BEPUHIP_E_INVALID_ARGUMENT, "child " + std::to_string(j - child_begin[k]) + " of compound " + std::to_string(k) + " has shape type " + std::to_string(t) +
+                                                                          ": compound children are convex (Compound.cs:182)");
+            if (t == 5) {
+                const float h = children[j].shape[0];
+                if (!(h >= 0) || h != (float)(int)h) return fail(BEPUHIP_E_INVALID_ARGUMENT, "child of compound " + std::to_string(k) + " names convex hull " + std::to_string(h));
+                hulls_needed = std::max(hulls_needed, (int)h + 1);
+            }
+        }
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_compound_children) hipFree(c->d_compound_children);
+    if (c->d_compound_begin) hipFree(c->d_compound_begin);
+    c->d_compound_children = nullptr; c->d_compound_begin = nullptr; c->compound_count = 0; c->compound_hulls_needed = 0;
+    if (compound_count == 0) return BEPUHIP_OK;
+    const size_t total = (size_t)child_begin[compound_count];
+    HIP_TRY(hipMalloc((void**)&c->d_compound_children, total * sizeof(CompoundChildIn)));
+    HIP_TRY(hipMalloc((void**)&c->d_compound_begin, ((size_t)compound_count + 1) * 4));
+    HIP_TRY(hipMemcpy(c->d_compound_children, children, total * sizeof(CompoundChildIn), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_compound_begin, child_begin, ((size_t)compound_count + 1) * 4, hipMemcpyHostToDevice));
+    c->compound_count = compound_count;
+    c->compound_hulls_needed = hulls_needed;
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_set_meshes(bepuhip_ctx* c, const float* triangles, const int32_t* triangle_begin, const float* scales, int32_t mesh_count) {
+    if (!c || mesh_count < 0 || (mesh_count > 0 && (!triangles || !triangle_begin || !scales))) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad set_meshes argument");
+    for (int m = 0; m < mesh_count; ++m)
+        if (triangle_begin[m] < 0 || triangle_begin[m + 1] <= triangle_begin[m]) return fail(BEPUHIP_E_INVALID_ARGUMENT, "mesh " + std::to_string(m) + " has no triangles (or the offsets decrease)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_mesh_triangles) hipFree(c->d_mesh_triangles);
+    if (c->d_mesh_begin) hipFree(c->d_mesh_begin);
+    if (c->d_mesh_scales) hipFree(c->d_mesh_scales);
+    c->d_mesh_triangles = nullptr; c->d_mesh_begin = nullptr; c->d_mesh_scales = nullptr; c->mesh_count = 0;
+    if (mesh_count == 0) return BEPUHIP_OK;
+    const size_t total = (size_t)triangle_begin[mesh_count];
+    HIP_TRY(hipMalloc((void**)&c->d_mesh_triangles, total * 36));
+    HIP_TRY(hipMalloc((void**)&c->d_mesh_begin, ((size_t)mesh_count + 1) * 4));
+    HIP_TRY(hipMalloc((void**)&c->d_mesh_scales, (size_t)mesh_count * 12));
+    HIP_TRY(hipMemcpy(c->d_mesh_triangles, triangles, total * 36, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_mesh_begin, triangle_begin, ((size_t)mesh_count + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_mesh_scales, scales, (size_t)mesh_count * 12, hipMemcpyHostToDevice));
+    c->mesh_count = mesh_count;
+    return BEPUHIP_OK;
+}
 int32_t bepuhip_set_collidables(bepuhip_ctx* c, const bepuhip_collidable* collidables, int32_t count) {
     if (!c || count < 0 || (count > 0 && !collidables)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad set_collidables argument");
     int32_t st = check_collidables(c, collidables, count);
@@ -1531,6 +1600,13 @@ int32_t bepuhip_set_collidables(bepuhip_ctx* c, const bepuhip_collidable* collid
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->d_collidables) { hipFree(c->d_collidables); c->d_collidables = nullptr; }
     c->collidable_count = count;
+    c->resident_hulls_needed = c->resident_compounds_needed = c->resident_meshes_needed = 0;
+    for (int i = 0; i < count; ++i) {
+        const int t = collidables[i].shape_type, k = (int)collidables[i].shape[0] + 1;
+        if (t == 5) c->resident_hulls_needed = std::max(c->resident_hulls_needed, k);
+        else if (t == 6 || t == 7) c->resident_compounds_needed = std::max(c->resident_compounds_needed, k);
+        else if (t == 8) c->resident_meshes_needed = std::max(c->resident_meshes_needed, k);
+    }
     if (count > 0) {
         HIP_TRY(hipMalloc((void**)&c->d_collidables, (size_t)count * sizeof(CollidableIn)));
         HIP_TRY(hipMemcpy(c->d_collidables, collidables, (size_t)count * sizeof(CollidableIn), hipMemcpyHostToDevice));
@@ -1543,6 +1619,9 @@ int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* c, float dt, const bepuhip_i
     const bool resident = collidables == nullptr;
     if (resident && count > c->collidable_count) return fail(BEPUHIP_E_STATE, "no collidables given and fewer resident ones than bodies (bepuhip_set_collidables)");
     if (!resident) { int32_t st = check_collidables(c, collidables, count); if (st != BEPUHIP_OK) return st; }
+    if (resident && (c->resident_hulls_needed > c->hull_count || c->resident_compounds_needed > c->compound_count || c->resident_meshes_needed > c->mesh_count ||
+                     (c->resident_compounds_needed > 0 && c->compound_hulls_needed > c->hull_count)))
+        return fail(BEPUHIP_E_STATE, "the resident collidables name hulls, compounds or meshes that the shape tables no longer hold (they were replaced after bepuhip_set_collidables)");
     if (count == 0) return BEPUHIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     const size_t in_floats = resident ? 0 : (size_t)count * 16, out_floats = (size_t)count * 8;
@@ -1553,7 +1632,9 @@ int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* c, float dt, const bepuhip_i
     if (!resident) HIP_TRY(hipMemcpyAsync(d_in, collidables, in_floats * 4, hipMemcpyHostToDevice, c->stream));
     const StepParams sp = make_params(in, dt, dt, 1.0f / dt);  // Callbacks.PrepareForIntegration(dt): the full frame step
     hipLaunchKernelGGL(predict_bounds_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, count, d_in, resident ? 1 : 0, d_out, dt,
-                       in->integrate_velocity_for_kinematics, sp, HullTable{c->d_hull_points, c->d_hull_begin, c->hull_count});
+                       in->integrate_velocity_for_kinematics, sp,
+                       ShapeTables{HullTable{c->d_hull_points, c->d_hull_begin, c->hull_count}, c->d_compound_children, c->d_compound_begin, c->compound_count, c->d_mesh_triangles,
+                                   c->d_mesh_begin, c->d_mesh_scales, c->mesh_count});
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out, out_floats * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

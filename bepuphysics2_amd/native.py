@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_colour_constraints", "bepuhip_set_exchange_mode", "bepuhip_set_boundary_layout", "bepuhip_comm_unique_id", "bepuhip_comm_init", "bepuhip_comm_adopt", "bepuhip_solve_lattice",
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
-    "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables", "bepuhip_set_convex_hulls",
+    "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables", "bepuhip_set_convex_hulls", "bepuhip_set_compounds", "bepuhip_set_meshes",
     "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_get_constraint_count",
 ]
 
@@ -118,6 +118,8 @@ def load_library() -> C.CDLL:
     lib.bepuhip_predict_bounding_boxes.argtypes = [vp, f32, C.POINTER(Integrator), vp, i32, vp]
     lib.bepuhip_set_collidables.argtypes = [vp, vp, i32]
     lib.bepuhip_set_convex_hulls.argtypes = [vp, vp, vp, i32]
+    lib.bepuhip_set_compounds.argtypes = [vp, vp, vp, i32]
+    lib.bepuhip_set_meshes.argtypes = [vp, vp, vp, vp, i32]
     lib.bepuhip_update_bodies.argtypes = [vp, vp, i32, i32]
     lib.bepuhip_get_bodies_range.argtypes = [vp, vp, i32, i32]
     for name in ("bepuhip_update_prestep", "bepuhip_update_accumulated_impulses", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
@@ -165,6 +167,9 @@ COLLIDABLE_DTYPE = np.dtype([("shape_type", "<i4"), ("shape", "<f4", (9,)), ("mi
                              ("activity", "<i4")])
 PREDICTED_BOUNDS_DTYPE = np.dtype([("min", "<f4", (3,)), ("speculative_margin", "<f4"), ("max", "<f4", (3,)), ("activity", "<i4")])
 SHAPE_SPHERE, SHAPE_CAPSULE, SHAPE_BOX, SHAPE_TRIANGLE, SHAPE_CYLINDER = 0, 1, 2, 3, 4  # Sphere.Id ... Cylinder.Id
+SHAPE_CONVEX_HULL, SHAPE_COMPOUND, SHAPE_BIG_COMPOUND, SHAPE_MESH = 5, 6, 7, 8     # ConvexHull.Id ... Mesh.Id
+# bepuhip_compound_child: a convex child shape and its pose in the compound's frame (CompoundChild, BepuPhysics/Collidables/Compound.cs:13-40)
+COMPOUND_CHILD_DTYPE = np.dtype([("shape_type", "<i4"), ("shape", "<f4", (9,)), ("local_position", "<f4", (3,)), ("local_orientation", "<f4", (4,))])
 
 
 class HipSolver:
@@ -381,6 +386,20 @@ class HipSolver:
         pts = np.ascontiguousarray(np.concatenate([np.asarray(h, dtype=np.float32).reshape(-1, 3) for h in hulls]) if hulls else np.zeros((0, 3), np.float32), dtype=np.float32)
         begin = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(h) for h in hulls])]), dtype=np.int32)
         _check(self.lib, self.lib.bepuhip_set_convex_hulls(self.ctx, _ptr(pts), _ptr(begin), len(hulls)))
+
+    def set_compounds(self, compounds):
+        """compounds: a list of COMPOUND_CHILD_DTYPE arrays (the children of each Compound / BigCompound); collidables of shape_type 6 / 7 name them by index in shape[0]."""
+        kids = np.ascontiguousarray(np.concatenate([np.asarray(k, dtype=COMPOUND_CHILD_DTYPE).reshape(-1) for k in compounds]) if compounds else np.zeros(0, COMPOUND_CHILD_DTYPE),
+                                    dtype=COMPOUND_CHILD_DTYPE)
+        begin = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(k) for k in compounds])]), dtype=np.int32)
+        _check(self.lib, self.lib.bepuhip_set_compounds(self.ctx, _ptr(kids), _ptr(begin), len(compounds)))
+
+    def set_meshes(self, meshes):
+        """meshes: a list of (triangles float32 [n_i, 3, 3], scale xyz); collidables of shape_type 8 name them by index in shape[0]."""
+        tris = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.float32).reshape(-1, 9) for t, _ in meshes]) if meshes else np.zeros((0, 9), np.float32), dtype=np.float32)
+        begin = np.ascontiguousarray(np.concatenate([[0], np.cumsum([np.asarray(t).reshape(-1, 9).shape[0] for t, _ in meshes])]), dtype=np.int32)
+        scales = np.ascontiguousarray(np.asarray([s for _, s in meshes], dtype=np.float32).reshape(-1, 3))
+        _check(self.lib, self.lib.bepuhip_set_meshes(self.ctx, _ptr(tris), _ptr(begin), _ptr(scales), len(meshes)))
 
     def set_collidables(self, collidables: np.ndarray):
         """Keep the collidable records on the device; later ``predict_bounding_boxes(dt, cb)`` calls use (and update the sleep counters of) these."""

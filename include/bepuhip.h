@@ -200,10 +200,13 @@ int32_t bepuhip_get_constraint_count(bepuhip_ctx* ctx, int32_t batch_index, int3
  * margin of BoundingBoxBatcher.ExecuteConvexBatch (BepuPhysics/Collidables/BoundingBoxBatcher.cs:142-223). It reads the bodies the last set_bodies /
  * update_bodies / solve left on the device; the caller copies min/max into the broad phase leaves (BroadPhase.GetActiveBoundsPointers) and the margin and
  * activity back into Collidable / BodyActivity. Convex hulls (ConvexHull.Id 5, ConvexHullWide.GetBounds BepuPhysics/Collidables/ConvexHull.cs:319-364) read their points from
- * the table of bepuhip_set_convex_hulls. Compounds and meshes (shape_type > 5) -> UNSUPPORTED: those bodies stay on the host path. */
+ * the table of bepuhip_set_convex_hulls. Compounds (Compound.Id 6, BigCompound.Id 7) and meshes (Mesh.Id 8) name an entry of bepuhip_set_compounds / bepuhip_set_meshes in shape[0]:
+ * compounds follow BoundingBoxBatcher.ExecuteCompoundBatch (:268-287) -> Compound.AddChildBoundsToBatcher (BepuPhysics/Collidables/Compound.cs:198-221) -> ExecuteConvexBatch with
+ * CompoundChild continuations (margin = largest child margin, box = union of the child boxes, :203-209); meshes follow ExecuteHomogeneousCompoundBatch (:225-266) over
+ * Mesh.ComputeBounds (BepuPhysics/Collidables/Mesh.cs:232-255). Every shape type the reference registers is covered; anything else -> UNSUPPORTED. */
 typedef struct bepuhip_collidable {
-    int32_t shape_type;                 /* Sphere.Id 0, Capsule.Id 1, Box.Id 2, Triangle.Id 3, Cylinder.Id 4, ConvexHull.Id 5; -1: Collidable.Shape.Exists == false */
-    float shape[9];                     /* Sphere{Radius}; Capsule{Radius, HalfLength}; Box{HalfWidth, HalfHeight, HalfLength}; Triangle{A, B, C}; Cylinder{Radius, HalfLength}; ConvexHull{hull index as a float} */
+    int32_t shape_type;                 /* Sphere.Id 0, Capsule.Id 1, Box.Id 2, Triangle.Id 3, Cylinder.Id 4, ConvexHull.Id 5, Compound.Id 6, BigCompound.Id 7, Mesh.Id 8; -1: Collidable.Shape.Exists == false */
+    float shape[9];                     /* Sphere{Radius}; Capsule{Radius, HalfLength}; Box{HalfWidth, HalfHeight, HalfLength}; Triangle{A, B, C}; Cylinder{Radius, HalfLength}; ConvexHull / Compound / BigCompound / Mesh{index into its table, as a float} */
     float minimum_speculative_margin;   /* Collidable.MinimumSpeculativeMargin, BepuPhysics/Collidables/Collidable.cs:131 */
     float maximum_speculative_margin;   /* :139 */
     int32_t allow_expansion_beyond_speculative_margin;  /* Continuity.AllowExpansionBeyondSpeculativeMargin, :59 */
@@ -218,6 +221,19 @@ typedef struct bepuhip_predicted_bounds {
 /* Convex hull point sets, resident on the device: `points` = xyz triplets of every hull's points one hull after the other (ConvexHull.Points, BepuPhysics/Collidables/ConvexHull.cs:30, without
  * the bundle padding: the padding lanes repeat real points, which changes no minimum or maximum), hull h owns points [point_begin[h], point_begin[h + 1]). Replaces the previous table. */
 int32_t bepuhip_set_convex_hulls(bepuhip_ctx* ctx, const float* points, const int32_t* point_begin, int32_t hull_count);
+/* Compounds, resident on the device: compound k owns children [child_begin[k], child_begin[k + 1]) (Compound.Children / BigCompound.Children: the tree of a BigCompound plays no part in
+ * its bounds, BigCompound.cs:128-131). A child is a convex shape (types 0-5, Compound.cs:182) with its pose in the compound's frame (CompoundChild, Compound.cs:13-40); hull children name
+ * an entry of bepuhip_set_convex_hulls. Replaces the previous table. */
+typedef struct bepuhip_compound_child {
+    int32_t shape_type;          /* 0-5 */
+    float shape[9];              /* as in bepuhip_collidable */
+    float local_position[3];     /* CompoundChild.LocalPosition */
+    float local_orientation[4];  /* CompoundChild.LocalOrientation (x, y, z, w) */
+} bepuhip_compound_child;
+int32_t bepuhip_set_compounds(bepuhip_ctx* ctx, const bepuhip_compound_child* children, const int32_t* child_begin, int32_t compound_count);
+/* Meshes, resident on the device: mesh m owns triangles [triangle_begin[m], triangle_begin[m + 1]) of `triangles` (9 floats each: A, B, C in the mesh's frame, Mesh.Triangles,
+ * BepuPhysics/Collidables/Mesh.cs:45) and the scale scales[3m..3m+2] (Mesh.Scale). Replaces the previous table. */
+int32_t bepuhip_set_meshes(bepuhip_ctx* ctx, const float* triangles, const int32_t* triangle_begin, const float* scales, int32_t mesh_count);
 /* `collidables` == NULL uses the records uploaded with bepuhip_set_collidables (shapes and margins rarely change): nothing but the 32-byte result per body
  * crosses PCIe, and the sleep counters are carried on the device from call to call. */
 int32_t bepuhip_set_collidables(bepuhip_ctx* ctx, const bepuhip_collidable* collidables, int32_t count);

@@ -809,10 +809,25 @@ int oracle_predict_bounding_boxes(const float* bodies, int count, const OraclePa
     return oracle_predict_bounding_boxes_hulls(bodies, count, params, collidables, out, nullptr, nullptr, 0);
 }
 // ... with convex hulls (ConvexHull.Id = 5, ConvexHull.cs:319-364): collidable.shape[0] = hull index, hull h = points [hull_begin[h], hull_begin[h + 1]).
+int oracle_predict_bounding_boxes_shapes(const float* bodies, int count, const OracleParams* params, const CollidableIn* collidables, PredictedBounds* out, const float* hull_points,
+                                         const int* hull_begin, int hull_count, const CompoundChildIn* children, const int* child_begin, int compound_count, const float* triangles,
+                                         const int* triangle_begin, const float* mesh_scales, int mesh_count);
 int oracle_predict_bounding_boxes_hulls(const float* bodies, int count, const OracleParams* params, const CollidableIn* collidables, PredictedBounds* out, const float* hull_points,
                                         const int* hull_begin, int hull_count) {
+    return oracle_predict_bounding_boxes_shapes(bodies, count, params, collidables, out, hull_points, hull_begin, hull_count, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0);
+}
+// ... and with compounds (Compound.Id = 6, BigCompound.Id = 7: collidable.shape[0] = compound index) and meshes (Mesh.Id = 8: shape[0] = mesh index).
+int oracle_predict_bounding_boxes_shapes(const float* bodies, int count, const OracleParams* params, const CollidableIn* collidables, PredictedBounds* out, const float* hull_points,
+                                         const int* hull_begin, int hull_count, const CompoundChildIn* children, const int* child_begin, int compound_count, const float* triangles,
+                                         const int* triangle_begin, const float* mesh_scales, int mesh_count) {
     if (!bodies || !params || !collidables || !out || count < 0 || !(params->dt > 0)) return -1;
-    const HullTable hulls = {hull_points, hull_begin, hull_count};
+    const ShapeTables tables = {{hull_points, hull_begin, hull_count}, {children, child_begin, compound_count}, {triangles, triangle_begin, mesh_scales, mesh_count}};
+    for (int i = 0; i < count; ++i) {  // indices must name table entries
+        const int t = collidables[i].shape_type, k = (int)collidables[i].shape[0];
+        if ((t == kShapeCompound || t == kShapeBigCompound) && (k < 0 || k >= compound_count)) return -2;
+        if (t == kShapeMesh && (k < 0 || k >= mesh_count)) return -2;
+        if (t > kShapeMesh) return -2;
+    }
     Callbacks cb;
     cb.prepare(*params, params->dt);   // PredictBoundingBoxes(dt, ...) -> Callbacks.PrepareForIntegration(dt)
     for (int i = 0; i < count; ++i) {
@@ -822,7 +837,7 @@ int oracle_predict_bounding_boxes_hulls(const float* bodies, int count, const Or
                                  st.inertia.t.zz == 0 && st.inertia.invMass == 0;
         const float sleepEnergy = lengthSquared(st.vel.lin) + lengthSquared(st.vel.ang);
         if (params->integrate_velocity_for_kinematics || !isKinematic) cb.integrateVelocity(st.vel);
-        predictBounds(st.pos, st.ori, st.vel, sleepEnergy, params->dt, collidables[i], hulls, out[i]);
+        predictBoundsOfAnyShape(st.pos, st.ori, st.vel, sleepEnergy, params->dt, collidables[i], tables, out[i]);
     }
     return 0;
 }

@@ -2,13 +2,15 @@
 
 The oracle text of this stage is derived mechanically from the device text (tools/port_constraints_to_oracle.py), so parity pins the GPU arithmetic and
 the CPU tests below pin the transcription: the predicted box must contain the shape at its current pose and at the pose the callback-integrated velocity
-leads to, obey the speculative-margin clamp, and the sleep counters must follow PoseIntegrator.UpdateSleepCandidacy."""
+leads to, obey the speculative-margin clamp, and the sleep counters must follow PoseIntegrator.UpdateSleepCandidacy. Compounds and meshes are the exception: their oracle
+text was written from the C# on its own (every child becomes a collidable of the convex path), their device text separately (one lane walks the children)."""
 import numpy as np
 import pytest
 
 import oracle_ffi
 import small_scenes
-from bepuphysics2_amd.native import (COLLIDABLE_DTYPE, SHAPE_BOX, SHAPE_CAPSULE, SHAPE_CYLINDER, SHAPE_SPHERE, SHAPE_TRIANGLE)
+from bepuphysics2_amd.native import (COLLIDABLE_DTYPE, COMPOUND_CHILD_DTYPE, SHAPE_BIG_COMPOUND, SHAPE_BOX, SHAPE_CAPSULE, SHAPE_COMPOUND, SHAPE_CONVEX_HULL, SHAPE_CYLINDER, SHAPE_MESH,
+                                      SHAPE_SPHERE, SHAPE_TRIANGLE)
 from bepuphysics2_amd.scene import PoseIntegratorCallbacks, make_body
 
 FLOAT_MAX = float(np.finfo(np.float32).max)
@@ -158,8 +160,11 @@ def test_hip_predict_bounding_boxes_matches_the_oracle(hip_solver_factory):
         chained["activity"] = want["activity"]
     from bepuphysics2_amd import native
     bad = coll[:4].copy()
-    bad["shape_type"][2] = 6  # Compound.Id: stays on the host
+    bad["shape_type"][2] = 9  # not a shape type of the library
     with pytest.raises(native.UnsupportedError):
+        solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks(), bad)
+    bad["shape_type"][2] = 6  # Compound.Id without a compound table: not a valid index
+    with pytest.raises(ValueError):
         solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks(), bad)
     bad["shape_type"][2] = 5  # ConvexHull.Id without a hull table: not a valid hull index
     with pytest.raises(ValueError):
@@ -228,3 +233,176 @@ def test_hip_convex_hull_bounds_match_the_oracle(hip_solver_factory):
     bad["shape"][1, 0] = len(hulls)  # one past the table
     with pytest.raises(ValueError):
         solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks(), bad)
+
+
+# ---- compounds and meshes (BoundingBoxBatcher.ExecuteCompoundBatch / ExecuteHomogeneousCompoundBatch) ----
+def _random_quaternion(rng):
+    q = rng.normal(size=4)
+    return (q / np.linalg.norm(q)).astype(np.float32)
+
+
+def _random_compounds(rng, count, hull_count):
+    """Children of every convex type (hulls included), 1 to 9 per compound, scattered around the compound's origin."""
+    compounds = []
+    for _ in range(count):
+        kids = np.zeros(int(rng.integers(1, 10)), dtype=COMPOUND_CHILD_DTYPE)
+        for k in range(kids.shape[0]):
+            t = int(rng.integers(0, 6))
+            kids["shape_type"][k] = t
+            if t == SHAPE_SPHERE:
+                kids["shape"][k, 0] = rng.uniform(0.1, 0.8)
+            elif t in (SHAPE_CAPSULE, SHAPE_CYLINDER):
+                kids["shape"][k, :2] = rng.uniform(0.1, 0.8, 2)
+            elif t == SHAPE_BOX:
+                kids["shape"][k, :3] = rng.uniform(0.1, 0.8, 3)
+            elif t == SHAPE_TRIANGLE:
+                kids["shape"][k, :9] = rng.uniform(-0.8, 0.8, 9)
+            else:
+                kids["shape"][k, 0] = float(rng.integers(hull_count))
+            kids["local_position"][k] = rng.uniform(-2, 2, 3)
+            kids["local_orientation"][k] = _random_quaternion(rng)
+        compounds.append(kids)
+    return compounds
+
+
+def _random_meshes(rng, count):
+    return [((rng.normal(size=(int(rng.integers(1, 60)), 3, 3)) * rng.uniform(0.3, 2.0)).astype(np.float32), rng.uniform(0.5, 2.0, 3).astype(np.float32)) for _ in range(count)]
+
+
+def _every_shape_collidables(rng, n, hull_count, compound_count, mesh_count):
+    c = _hull_collidables(rng, n, hull_count)
+    for i in range(n):
+        r = i % 7
+        if r in (1, 2):
+            c["shape_type"][i] = SHAPE_COMPOUND if r == 1 else SHAPE_BIG_COMPOUND
+            c["shape"][i] = 0
+            c["shape"][i, 0] = float(rng.integers(compound_count))
+        elif r == 4:
+            c["shape_type"][i] = SHAPE_MESH
+            c["shape"][i] = 0
+            c["shape"][i, 0] = float(rng.integers(mesh_count))
+    return c
+
+
+def _spinning_bodies(rng, n):
+    """Some bodies spin fast enough that a compound child's angular share exceeds its offset (the capped branch of Compound.cs:213-216)."""
+    bodies = _random_bodies(rng, n)
+    bodies[::3, 12:15] *= 40
+    return bodies
+
+
+def test_compound_bounds_are_the_union_of_the_children_as_bodies_of_their_own():
+    """Compound.AddChildBoundsToBatcher: every child is bounded like a convex body at pose (parent x local) with the parent's angular velocity and the linear
+    velocity its offset picks up; the compound's box is the union, its margin the largest child margin. Checked against the oracle's own convex path fed by hand."""
+    rng = np.random.default_rng(51)
+    hulls = _random_hulls(rng, 8)
+    compounds = _random_compounds(rng, 20, len(hulls))
+    n = 120
+    bodies = _spinning_bodies(rng, n)
+    coll = _random_collidables(rng, n)
+    coll["shape_type"] = SHAPE_COMPOUND
+    coll["shape"] = 0
+    coll["shape"][:, 0] = rng.integers(len(compounds), size=n)
+    cb = PoseIntegratorCallbacks(gravity=(0, 0, 0), linear_damping=0, angular_damping=0)  # velocity callback = identity: the child velocities below are the stored ones
+    out = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, coll, hulls, compounds)
+    capped = 0
+    for i in range(n):
+        kids = compounds[int(coll["shape"][i, 0])]
+        q, pos, lin, ang = bodies[i, 0:4].astype(np.float64), bodies[i, 4:7].astype(np.float64), bodies[i, 8:11].astype(np.float64), bodies[i, 12:15].astype(np.float64)
+        lo, hi, margin = np.full(3, np.inf), np.full(3, -np.inf), 0.0
+        for kid in kids:
+            offset = _rotate(q, kid["local_position"])
+            swing = np.cross(ang, offset)
+            if swing @ swing > offset @ offset:
+                swing *= np.sqrt(offset @ offset) / np.sqrt(swing @ swing)
+                capped += 1
+            lx, ly, lz, lw = [float(v) for v in kid["local_orientation"]]
+            px, py, pz, pw = q
+            child_q = np.array([lw * px + lx * pw + lz * py - ly * pz, lw * py + ly * pw + lx * pz - lz * px, lw * pz + lz * pw + ly * px - lx * py, lw * pw - lx * px - ly * py - lz * pz])
+            one = np.zeros((1, 32), np.float32)
+            one[0, 0:4], one[0, 4:7], one[0, 8:11], one[0, 12:15] = child_q, offset + pos, lin + swing, ang
+            one[0, 16:23] = bodies[i, 16:23]
+            as_body = coll[i:i + 1].copy()
+            as_body["shape_type"], as_body["shape"] = kid["shape_type"], kid["shape"]
+            child = oracle_ffi.predict_bounding_boxes(one, 1 / 60, cb, as_body, hulls)
+            lo, hi, margin = np.minimum(lo, child["min"][0]), np.maximum(hi, child["max"][0]), max(margin, float(child["speculative_margin"][0]))
+        assert np.allclose(out["min"][i], lo, rtol=1e-5, atol=1e-5) and np.allclose(out["max"][i], hi, rtol=1e-5, atol=1e-5), i
+        assert np.isclose(out["speculative_margin"][i], margin, rtol=1e-5, atol=1e-6), i
+    assert capped > 20
+
+
+def test_mesh_bounds_contain_every_rotated_vertex_and_follow_the_box_heuristic():
+    """Mesh.ComputeBounds (Mesh.cs:232-255) + ExecuteHomogeneousCompoundBatch (:225-266): at rest the box is the extent of the scaled, rotated vertices; moving, it grows
+    by the linear sweep and by an angular expansion bounded by (largest corner distance - smallest face distance) of that box."""
+    rng = np.random.default_rng(53)
+    meshes = _random_meshes(rng, 10)
+    n = 200
+    bodies = _random_bodies(rng, n)
+    coll = _random_collidables(rng, n)
+    coll["shape_type"], coll["shape"] = SHAPE_MESH, 0
+    coll["shape"][:, 0] = rng.integers(len(meshes), size=n)
+    coll["minimum_speculative_margin"] = 0
+    coll["allow_expansion_beyond_speculative_margin"] = 1
+    cb = PoseIntegratorCallbacks(gravity=(0, 0, 0), linear_damping=0, angular_damping=0)
+    at_rest = bodies.copy()
+    at_rest[:, 8:11] = 0
+    at_rest[:, 12:15] = 0
+    still = oracle_ffi.predict_bounding_boxes(at_rest, 1 / 60, cb, coll, meshes=meshes)
+    moving = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, coll, meshes=meshes)
+    for i in range(n):
+        tris, scale = meshes[int(coll["shape"][i, 0])]
+        world = np.stack([_rotate(bodies[i, 0:4], v * scale) for v in tris.reshape(-1, 3)])
+        lo, hi = world.min(axis=0), world.max(axis=0)
+        assert np.allclose(still["min"][i], lo + bodies[i, 4:7], atol=5e-5) and np.allclose(still["max"][i], hi + bodies[i, 4:7], atol=5e-5), i
+        assert still["speculative_margin"][i] == 0
+        sweep = bodies[i, 8:11].astype(np.float64) / 60
+        corner = np.linalg.norm(np.maximum(np.abs(lo), np.abs(hi)))
+        cap = corner - np.min(np.minimum(np.abs(lo), np.abs(hi)))
+        grow_lo, grow_hi = (still["min"][i] - moving["min"][i]).astype(np.float64), (moving["max"][i] - still["max"][i]).astype(np.float64)
+        angular = grow_hi - np.maximum(sweep, 0)
+        assert np.all(grow_lo > -1e-5) and np.all(grow_hi > -1e-5)
+        assert np.allclose(angular, angular[0], atol=1e-4) and angular[0] <= cap + 1e-4, i  # one scalar angular expansion on every axis, never above the cap
+        assert np.allclose(grow_lo, angular[0] - np.minimum(sweep, 0), atol=1e-4), i
+
+
+@pytest.mark.gpu
+def test_hip_compound_and_mesh_bounds_match_the_oracle(hip_solver_factory):
+    """Every shape type the reference registers in one body set (primitives, hulls, compounds with hull children, big compounds, meshes), fast spinners included: bit-exact."""
+    rng = np.random.default_rng(57)
+    hulls, meshes = _random_hulls(rng, 32), _random_meshes(rng, 24)
+    compounds = _random_compounds(rng, 80, len(hulls))
+    n = 6000
+    bodies = _spinning_bodies(rng, n)
+    coll = _every_shape_collidables(rng, n, len(hulls), len(compounds), len(meshes))
+    assert set(np.unique(coll["shape_type"])) >= {0, 1, 2, 3, 4, 5, 6, 7, 8}
+    solver = hip_solver_factory()
+    solver.set_bodies(bodies)
+    solver.set_convex_hulls(hulls)
+    solver.set_compounds(compounds)
+    solver.set_meshes(meshes)
+    for cb in (PoseIntegratorCallbacks(), PoseIntegratorCallbacks(gravity=(1, -9, 0.5), linear_damping=0.1, angular_damping=0.2, integrate_velocity_for_kinematics=True)):
+        want = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, coll, hulls, compounds, meshes)
+        got = solver.predict_bounding_boxes(1 / 60, cb, coll)
+        assert np.array_equal(want.view(np.int32), got.view(np.int32))
+    solver.set_collidables(coll)  # resident records and tables; the sleep counters chain
+    chained = coll.copy()
+    for _ in range(2):
+        want = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, PoseIntegratorCallbacks(), chained, hulls, compounds, meshes)
+        got = solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks())
+        assert np.array_equal(want.view(np.int32), got.view(np.int32))
+        chained["activity"] = want["activity"]
+    # the boundary refuses what the tables do not hold
+    bad = coll[:8].copy()
+    bad["shape_type"][1], bad["shape"][1, 0] = SHAPE_MESH, len(meshes)
+    with pytest.raises(ValueError):
+        solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks(), bad)
+    nested = np.zeros(1, dtype=COMPOUND_CHILD_DTYPE)
+    nested["shape_type"] = SHAPE_COMPOUND  # children are convex
+    with pytest.raises(ValueError):
+        solver.set_compounds([nested])
+    solver.set_convex_hulls(hulls[:2])  # compounds name hulls the smaller table no longer has
+    with pytest.raises(ValueError):
+        solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks(), coll)
+    from bepuphysics2_amd import native
+    with pytest.raises(native.BepuHipError):
+        solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks())
