@@ -308,18 +308,26 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
 
 
 // PoseIntegrator.PredictBoundingBoxes (PoseIntegrator.cs:307-370), one lane per body: the stage before collision detection, on the bodies the solver left in HBM.
+// The reference walks the bodies in bundles of Vector<float>.Count and calls the velocity callback on a whole bundle as soon as one of its lanes is to be integrated
+// (:337-338); the demo callbacks ignore the mask and nothing masks afterwards, so a kinematic body is predicted with gravity and damping applied exactly when its
+// bundle also holds a body that integrates. A wave covers 64 consecutive bodies = whole bundles (4, 8 or 16 wide), so the bundle's "any" is a slice of a ballot.
 __global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __restrict__ bodies, int count, CollidableIn* collidables, int keep_activity,
-                                                              PredictedBounds* __restrict__ out, float dt, int integrate_velocity_for_kinematics, StepParams sp, ShapeTables tables) {
+                                                              PredictedBounds* __restrict__ out, float dt, int integrate_velocity_for_kinematics, StepParams sp, ShapeTables tables,
+                                                              int bundle_width) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const float4* base = bodies + (size_t)i * 8;
+    const bool live = i < count;
+    const float4* base = bodies + (size_t)(live ? i : 0) * 8;
     const float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3], i0 = base[4], i1 = base[5];
     const Q ori = {q4.x, q4.y, q4.z, q4.w};
     const V3 pos = {p4.x, p4.y, p4.z};
     BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
     const bool is_kinematic = i0.x == 0 && i0.y == 0 && i0.z == 0 && i0.w == 0 && i1.x == 0 && i1.y == 0 && i1.z == 0;  // Bodies.cs:326-349
-    const float sleep_energy = lengthSquared(vel.lin) + lengthSquared(vel.ang);                                           // :329, before the callback
-    if (integrate_velocity_for_kinematics || !is_kinematic) velocity_callback(sp, vel);                                   // :318-333 (never stored)
+    const float sleep_energy = lengthSquared(vel.lin) + lengthSquared(vel.ang);                                           // :334, before the callback
+    const unsigned long long integrates = __ballot(live && (integrate_velocity_for_kinematics || !is_kinematic));        // :323-331, one bit per lane of the wave
+    const int first_lane_of_bundle = (threadIdx.x & 63) & ~(bundle_width - 1);
+    const bool bundle_integrates = ((integrates >> first_lane_of_bundle) & ((1ull << bundle_width) - 1ull)) != 0;
+    if (!live) return;
+    if (bundle_integrates) velocity_callback(sp, vel);  // :337-338 (never stored)
     const CollidableIn c = collidables[i];
     PredictedBounds r;
     predictBoundsOfAnyShape(pos, ori, vel, sleep_energy, dt, c, tables, r);

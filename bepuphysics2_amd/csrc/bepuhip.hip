@@ -1634,7 +1634,8 @@ int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* c, float dt, const bepuhip_i
     hipLaunchKernelGGL(predict_bounds_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, count, d_in, resident ? 1 : 0, d_out, dt,
                        in->integrate_velocity_for_kinematics, sp,
                        ShapeTables{HullTable{c->d_hull_points, c->d_hull_begin, c->hull_count}, c->d_compound_children, c->d_compound_begin, c->compound_count, c->d_mesh_triangles,
-                                   c->d_mesh_begin, c->d_mesh_scales, c->mesh_count});
+                                   c->d_mesh_begin, c->d_mesh_scales, c->mesh_count},
+                       c->W);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out, out_floats * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -203,7 +203,9 @@ int32_t bepuhip_get_constraint_count(bepuhip_ctx* ctx, int32_t batch_index, int3
  * the table of bepuhip_set_convex_hulls. Compounds (Compound.Id 6, BigCompound.Id 7) and meshes (Mesh.Id 8) name an entry of bepuhip_set_compounds / bepuhip_set_meshes in shape[0]:
  * compounds follow BoundingBoxBatcher.ExecuteCompoundBatch (:268-287) -> Compound.AddChildBoundsToBatcher (BepuPhysics/Collidables/Compound.cs:198-221) -> ExecuteConvexBatch with
  * CompoundChild continuations (margin = largest child margin, box = union of the child boxes, :203-209); meshes follow ExecuteHomogeneousCompoundBatch (:225-266) over
- * Mesh.ComputeBounds (BepuPhysics/Collidables/Mesh.cs:232-255). Every shape type the reference registers is covered; anything else -> UNSUPPORTED. */
+ * Mesh.ComputeBounds (BepuPhysics/Collidables/Mesh.cs:232-255). Every shape type the reference registers is covered; anything else -> UNSUPPORTED.
+ * As in the reference, the velocity callback runs on whole bundles of config.bundle_width consecutive bodies as soon as one of them is to be integrated and its result is not masked
+ * (PoseIntegrator.cs:323-338, Demos/DemoCallbacks.cs:99-109): a kinematic body's box feels gravity and damping exactly when a non-kinematic body shares its bundle. */
 typedef struct bepuhip_collidable {
     int32_t shape_type;                 /* Sphere.Id 0, Capsule.Id 1, Box.Id 2, Triangle.Id 3, Cylinder.Id 4, ConvexHull.Id 5, Compound.Id 6, BigCompound.Id 7, Mesh.Id 8; -1: Collidable.Shape.Exists == false */
     float shape[9];                     /* Sphere{Radius}; Capsule{Radius, HalfLength}; Box{HalfWidth, HalfHeight, HalfLength}; Triangle{A, B, C}; Cylinder{Radius, HalfLength}; ConvexHull / Compound / BigCompound / Mesh{index into its table, as a float} */

@@ -811,16 +811,16 @@ int oracle_predict_bounding_boxes(const float* bodies, int count, const OraclePa
 // ... with convex hulls (ConvexHull.Id = 5, ConvexHull.cs:319-364): collidable.shape[0] = hull index, hull h = points [hull_begin[h], hull_begin[h + 1]).
 int oracle_predict_bounding_boxes_shapes(const float* bodies, int count, const OracleParams* params, const CollidableIn* collidables, PredictedBounds* out, const float* hull_points,
                                          const int* hull_begin, int hull_count, const CompoundChildIn* children, const int* child_begin, int compound_count, const float* triangles,
-                                         const int* triangle_begin, const float* mesh_scales, int mesh_count);
+                                         const int* triangle_begin, const float* mesh_scales, int mesh_count, int bundle_width);
 int oracle_predict_bounding_boxes_hulls(const float* bodies, int count, const OracleParams* params, const CollidableIn* collidables, PredictedBounds* out, const float* hull_points,
                                         const int* hull_begin, int hull_count) {
-    return oracle_predict_bounding_boxes_shapes(bodies, count, params, collidables, out, hull_points, hull_begin, hull_count, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0);
+    return oracle_predict_bounding_boxes_shapes(bodies, count, params, collidables, out, hull_points, hull_begin, hull_count, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 8);
 }
 // ... and with compounds (Compound.Id = 6, BigCompound.Id = 7: collidable.shape[0] = compound index) and meshes (Mesh.Id = 8: shape[0] = mesh index).
 int oracle_predict_bounding_boxes_shapes(const float* bodies, int count, const OracleParams* params, const CollidableIn* collidables, PredictedBounds* out, const float* hull_points,
                                          const int* hull_begin, int hull_count, const CompoundChildIn* children, const int* child_begin, int compound_count, const float* triangles,
-                                         const int* triangle_begin, const float* mesh_scales, int mesh_count) {
-    if (!bodies || !params || !collidables || !out || count < 0 || !(params->dt > 0)) return -1;
+                                         const int* triangle_begin, const float* mesh_scales, int mesh_count, int bundle_width) {
+    if (!bodies || !params || !collidables || !out || count < 0 || !(params->dt > 0) || (bundle_width != 4 && bundle_width != 8 && bundle_width != 16)) return -1;
     const ShapeTables tables = {{hull_points, hull_begin, hull_count}, {children, child_begin, compound_count}, {triangles, triangle_begin, mesh_scales, mesh_count}};
     for (int i = 0; i < count; ++i) {  // indices must name table entries
         const int t = collidables[i].shape_type, k = (int)collidables[i].shape[0];
@@ -830,14 +830,27 @@ int oracle_predict_bounding_boxes_shapes(const float* bodies, int count, const O
     }
     Callbacks cb;
     cb.prepare(*params, params->dt);   // PredictBoundingBoxes(dt, ...) -> Callbacks.PrepareForIntegration(dt)
-    for (int i = 0; i < count; ++i) {
-        BodyState st;
-        gatherState(bodies, i, false, st);  // GatherState<AccessAll>(laneIndices, false, ...): local inertia
-        const bool isKinematic = st.inertia.t.xx == 0 && st.inertia.t.yx == 0 && st.inertia.t.yy == 0 && st.inertia.t.zx == 0 && st.inertia.t.zy == 0 &&
-                                 st.inertia.t.zz == 0 && st.inertia.invMass == 0;
-        const float sleepEnergy = lengthSquared(st.vel.lin) + lengthSquared(st.vel.ang);
-        if (params->integrate_velocity_for_kinematics || !isKinematic) cb.integrateVelocity(st.vel);
-        predictBoundsOfAnyShape(st.pos, st.ori, st.vel, sleepEnergy, params->dt, collidables[i], tables, out[i]);
+    // PoseIntegrator.cs:315-368, bundle by bundle (bundle_width = Vector<float>.Count of the host): the callback runs on the WHOLE bundle as soon as one of its lanes
+    // is to be integrated (:337-338), and nothing masks its result afterwards — the demo callbacks ignore the mask (DemoCallbacks.cs:99-109, relying on the caller
+    // to discard inactive lanes as the interface promises, PoseIntegrator.cs:91) — so a kinematic body that shares a bundle with a dynamic one is predicted with
+    // gravity and damping applied, and one in an all-kinematic bundle is not. Restated as written.
+    for (int bundleStart = 0; bundleStart < count; bundleStart += bundle_width) {
+        const int countInBundle = count - bundleStart < bundle_width ? count - bundleStart : bundle_width;
+        BodyState lanes[16];
+        float sleepEnergy[16];
+        bool anyLaneIntegrates = false;
+        for (int lane = 0; lane < countInBundle; ++lane) {
+            BodyState& st = lanes[lane];
+            gatherState(bodies, bundleStart + lane, false, st);  // GatherState<AccessAll>(laneIndices, false, ...): local inertia
+            const bool isKinematic = st.inertia.t.xx == 0 && st.inertia.t.yx == 0 && st.inertia.t.yy == 0 && st.inertia.t.zx == 0 && st.inertia.t.zy == 0 &&
+                                     st.inertia.t.zz == 0 && st.inertia.invMass == 0;                       // Bodies.IsKinematic, Bodies.cs:326-349
+            sleepEnergy[lane] = lengthSquared(st.vel.lin) + lengthSquared(st.vel.ang);                     // :334, before the callback
+            if (params->integrate_velocity_for_kinematics || !isKinematic) anyLaneIntegrates = true;       // :323-331
+        }
+        for (int lane = 0; lane < countInBundle; ++lane) {
+            if (anyLaneIntegrates) cb.integrateVelocity(lanes[lane].vel);                                  // :337-338 (never stored)
+            predictBoundsOfAnyShape(lanes[lane].pos, lanes[lane].ori, lanes[lane].vel, sleepEnergy[lane], params->dt, collidables[bundleStart + lane], tables, out[bundleStart + lane]);
+        }
     }
     return 0;
 }

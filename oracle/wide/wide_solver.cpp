@@ -1732,8 +1732,122 @@ static int SolveScene(SceneDesc* scene, SceneParams* params) {
 
 }  // namespace wide
 
+#include "wide_bounds.h"
+
+namespace wide {
+// The records of include/bepuhip.h as plain data (the same bytes oracle_ffi hands to the scalar oracle).
+struct CollidableRecord { int32_t shape_type; float shape[9]; float minimum_speculative_margin, maximum_speculative_margin; int32_t allow_expansion_beyond_speculative_margin;
+                          float sleep_threshold; int32_t minimum_timesteps_under_threshold; int32_t activity; };
+struct PredictedRecord { float min[3]; float speculative_margin; float max[3]; int32_t activity; };
+struct CompoundChildRecord { int32_t shape_type; float shape[9]; float local_position[3]; float local_orientation[4]; };
+
+static int AddConvexShape(bounds::Shapes& shapes, int type, const float* s) {  // Shapes.Add<TShape>: the index of the shape inside its type's batch
+    using namespace bounds;
+    switch (type) {
+        case SphereId: shapes.spheres.push_back({s[0]}); return (int)shapes.spheres.size() - 1;
+        case CapsuleId: shapes.capsules.push_back({s[0], s[1]}); return (int)shapes.capsules.size() - 1;
+        case BoxId: shapes.boxes.push_back({s[0], s[1], s[2]}); return (int)shapes.boxes.size() - 1;
+        case TriangleId: shapes.triangles.push_back({{s[0], s[1], s[2]}, {s[3], s[4], s[5]}, {s[6], s[7], s[8]}}); return (int)shapes.triangles.size() - 1;
+        case CylinderId: shapes.cylinders.push_back({s[0], s[1]}); return (int)shapes.cylinders.size() - 1;
+        case ConvexHullId: return (int)s[0];
+        default: return -1;
+    }
+}
+
+static int PredictBoundingBoxesOfScene(const float* bodyStates, int count, const SceneParams* params, const CollidableRecord* collidables, PredictedRecord* out, const float* hullPoints,
+                                       const int* hullBegin, int hullCount, const CompoundChildRecord* children, const int* childBegin, int compoundCount, const float* triangles,
+                                       const int* triangleBegin, const float* meshScales, int meshCount) {
+    using namespace bounds;
+    if (!bodyStates || !params || !collidables || !out || count < 0 || !(params->dt > 0)) return -1;
+    World world;
+    for (int h = 0; h < hullCount; ++h) {  // ConvexHullHelper.CreateShape (ConvexHullHelper.cs:1050-1063): bundles of points, the last vertex repeated into the unused lanes
+        ConvexHull hull;
+        int first = hullBegin[h], lastIndex = hullBegin[h + 1] - hullBegin[h] - 1;
+        hull.Points.resize((size_t)(lastIndex + W) / W);
+        for (size_t bundleIndex = 0; bundleIndex < hull.Points.size(); ++bundleIndex)
+            for (int innerIndex = 0; innerIndex < W; ++innerIndex) {
+                int index = (int)bundleIndex * W + innerIndex;
+                if (index > lastIndex) index = lastIndex;
+                const float* point = hullPoints + 3 * (size_t)(first + index);
+                hull.Points[bundleIndex].X[innerIndex] = point[0]; hull.Points[bundleIndex].Y[innerIndex] = point[1]; hull.Points[bundleIndex].Z[innerIndex] = point[2];
+            }
+        world.shapes.hulls.push_back(std::move(hull));
+    }
+    for (int k = 0; k < compoundCount; ++k) {
+        Compound compound;
+        for (int j = childBegin[k]; j < childBegin[k + 1]; ++j) {
+            const CompoundChildRecord& record = children[j];
+            if (record.shape_type < 0 || record.shape_type > ConvexHullId) return -2;
+            CompoundChild child;
+            child.ShapeType = record.shape_type;
+            child.ShapeIndex = AddConvexShape(world.shapes, record.shape_type, record.shape);
+            if (child.ShapeType == ConvexHullId && (child.ShapeIndex < 0 || child.ShapeIndex >= hullCount)) return -2;
+            child.LocalPosition = {record.local_position[0], record.local_position[1], record.local_position[2]};
+            child.LocalOrientation = {record.local_orientation[0], record.local_orientation[1], record.local_orientation[2], record.local_orientation[3]};
+            compound.Children.push_back(child);
+        }
+        world.shapes.compounds.push_back(std::move(compound));
+    }
+    for (int m = 0; m < meshCount; ++m) {
+        Mesh mesh;
+        mesh.scale = {meshScales[3 * m], meshScales[3 * m + 1], meshScales[3 * m + 2]};
+        for (int t = triangleBegin[m]; t < triangleBegin[m + 1]; ++t) {
+            const float* v = triangles + 9 * (size_t)t;
+            mesh.Triangles.push_back({{v[0], v[1], v[2]}, {v[3], v[4], v[5]}, {v[6], v[7], v[8]}});
+        }
+        world.shapes.meshes.push_back(std::move(mesh));
+    }
+    world.collidables.resize(count);
+    world.activities.resize(count);
+    world.boundsMin.assign(count, bounds::Vector3{0, 0, 0});
+    world.boundsMax.assign(count, bounds::Vector3{0, 0, 0});
+    for (int i = 0; i < count; ++i) {
+        const CollidableRecord& record = collidables[i];
+        Collidable& collidable = world.collidables[i];
+        collidable.ShapeType = record.shape_type;
+        if (record.shape_type >= 0 && record.shape_type <= ConvexHullId) collidable.ShapeIndex = AddConvexShape(world.shapes, record.shape_type, record.shape);
+        else collidable.ShapeIndex = (int)record.shape[0];
+        const int table = record.shape_type == ConvexHullId ? hullCount : (record.shape_type == CompoundId || record.shape_type == BigCompoundId) ? compoundCount : record.shape_type == MeshId ? meshCount : -1;
+        if (record.shape_type > MeshId || (table >= 0 && (collidable.ShapeIndex < 0 || collidable.ShapeIndex >= table))) return -2;
+        collidable.MinimumSpeculativeMargin = record.minimum_speculative_margin;
+        collidable.MaximumSpeculativeMargin = record.maximum_speculative_margin;
+        collidable.SpeculativeMargin = 0;
+        collidable.AllowExpansionBeyondSpeculativeMargin = record.allow_expansion_beyond_speculative_margin != 0;
+        world.activities[i] = {record.sleep_threshold, record.minimum_timesteps_under_threshold, record.activity & 0xFF, (record.activity & 0x100) != 0};
+    }
+    Bodies bodies;
+    bodies.states = const_cast<float*>(bodyStates);  // read only here: the integrated velocities are never stored (:336)
+    bodies.count = count;
+    PoseIntegratorCallbacks callbacks;
+    callbacks.Gravity[0] = params->gravity[0]; callbacks.Gravity[1] = params->gravity[1]; callbacks.Gravity[2] = params->gravity[2];
+    callbacks.LinearDamping = params->linear_damping;
+    callbacks.AngularDamping = params->angular_damping;
+    callbacks.AngularIntegrationMode = params->angular_integration_mode;
+    callbacks.AllowSubstepsForUnconstrainedBodies = params->allow_substeps_for_unconstrained != 0;
+    callbacks.IntegrateVelocityForKinematics = params->integrate_velocity_for_kinematics != 0;
+    // PoseIntegrator.PredictBoundingBoxes(dt, pool, threadDispatcher) (:372-420), single threaded: prepare the callbacks for the full dt, one batcher, every bundle, flush.
+    callbacks.PrepareForIntegration(params->dt);
+    BoundingBoxBatcher batcher(world, params->dt);
+    PredictBoundingBoxes(bodies, callbacks, world, 0, (count + W - 1) / W, params->dt, batcher, 0);
+    batcher.Flush();
+    for (int i = 0; i < count; ++i) {
+        out[i].min[0] = world.boundsMin[i].X; out[i].min[1] = world.boundsMin[i].Y; out[i].min[2] = world.boundsMin[i].Z;
+        out[i].max[0] = world.boundsMax[i].X; out[i].max[1] = world.boundsMax[i].Y; out[i].max[2] = world.boundsMax[i].Z;
+        out[i].speculative_margin = world.collidables[i].SpeculativeMargin;
+        out[i].activity = world.activities[i].TimestepsUnderThresholdCount | (world.activities[i].SleepCandidate ? 0x100 : 0);
+    }
+    return 0;
+}
+}  // namespace wide
+
 extern "C" {
 int wide_solve(wide::SceneDesc* scene, wide::SceneParams* params) { return wide::SolveScene(scene, params); }
+int wide_predict_bounding_boxes(const float* bodies, int count, const wide::SceneParams* params, const wide::CollidableRecord* collidables, wide::PredictedRecord* out,
+                                const float* hull_points, const int* hull_begin, int hull_count, const wide::CompoundChildRecord* children, const int* child_begin, int compound_count,
+                                const float* triangles, const int* triangle_begin, const float* mesh_scales, int mesh_count) {
+    return wide::PredictBoundingBoxesOfScene(bodies, count, params, collidables, out, hull_points, hull_begin, hull_count, children, child_begin, compound_count, triangles, triangle_begin,
+                                             mesh_scales, mesh_count);
+}
 
 // Per-type probe for unit tests: `iterations` x (WarmStart; Solve) on broadcast inputs, mirroring the reference's microbenchmarks
 // (DemoBenchmarks/TwoBodyConstraintBenchmarks.cs:19-117). body_a / body_b: one 32-float BodyDynamics record each (world inertia slot used);

@@ -125,7 +125,7 @@ def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool 
         raise RuntimeError(f"oracle_solve failed: {rc}")
 
 
-def predict_bounding_boxes(bodies, dt, callbacks, collidables, hulls=None, compounds=None, meshes=None):
+def predict_bounding_boxes(bodies, dt, callbacks, collidables, hulls=None, compounds=None, meshes=None, bundle_width=8):
     """PoseIntegrator.PredictBoundingBoxes restated (oracle/bepu_bounds.h): returns PREDICTED_BOUNDS_DTYPE records, bodies untouched."""
     from bepuphysics2_amd.native import COLLIDABLE_DTYPE, PREDICTED_BOUNDS_DTYPE
     lib = load()
@@ -139,7 +139,7 @@ def predict_bounding_boxes(bodies, dt, callbacks, collidables, hulls=None, compo
     p.linear_damping = float(callbacks.linear_damping)
     p.angular_damping = float(callbacks.angular_damping)
     p.integrate_velocity_for_kinematics = int(bool(callbacks.integrate_velocity_for_kinematics))
-    if compounds or meshes:
+    if compounds or meshes or bundle_width != 8:
         from bepuphysics2_amd.native import COMPOUND_CHILD_DTYPE
         hulls, compounds, meshes = hulls or [], compounds or [], meshes or []
         pts = np.ascontiguousarray(np.concatenate([np.asarray(h, dtype=np.float32).reshape(-1, 3) for h in hulls]) if hulls else np.zeros((0, 3), np.float32), dtype=np.float32)
@@ -152,10 +152,10 @@ def predict_bounding_boxes(bodies, dt, callbacks, collidables, hulls=None, compo
         scales = np.ascontiguousarray(np.asarray([s for _, s in meshes], dtype=np.float32).reshape(-1, 3))
         fn = lib.oracle_predict_bounding_boxes_shapes
         fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(OracleParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                       C.c_void_p, C.c_int]
+                       C.c_void_p, C.c_int, C.c_int]
         fn.restype = C.c_int
         rc = fn(_p(b), c.shape[0], C.byref(p), _p(c), _p(out), _p(pts), hull_begin.ctypes.data_as(C.c_void_p), len(hulls), _p(kids), kid_begin.ctypes.data_as(C.c_void_p), len(compounds),
-                _p(tris), tri_begin.ctypes.data_as(C.c_void_p), _p(scales), len(meshes))
+                _p(tris), tri_begin.ctypes.data_as(C.c_void_p), _p(scales), len(meshes), int(bundle_width))
     elif hulls:
         pts = np.ascontiguousarray(np.concatenate([np.asarray(h, dtype=np.float32).reshape(-1, 3) for h in hulls]), dtype=np.float32)
         begin = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(h) for h in hulls])]), dtype=np.int32)

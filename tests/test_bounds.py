@@ -9,6 +9,7 @@ import pytest
 
 import oracle_ffi
 import small_scenes
+import wide_ffi
 from bepuphysics2_amd.native import (COLLIDABLE_DTYPE, COMPOUND_CHILD_DTYPE, SHAPE_BIG_COMPOUND, SHAPE_BOX, SHAPE_CAPSULE, SHAPE_COMPOUND, SHAPE_CONVEX_HULL, SHAPE_CYLINDER, SHAPE_MESH,
                                       SHAPE_SPHERE, SHAPE_TRIANGLE)
 from bepuphysics2_amd.scene import PoseIntegratorCallbacks, make_body
@@ -406,3 +407,69 @@ def test_hip_compound_and_mesh_bounds_match_the_oracle(hip_solver_factory):
     from bepuphysics2_amd import native
     with pytest.raises(native.BepuHipError):
         solver.predict_bounding_boxes(1 / 60, PoseIntegratorCallbacks())
+
+
+def test_velocity_callback_runs_on_whole_bundles_as_the_reference_writes_it():
+    """PoseIntegrator.cs:337-338 calls the callback on a bundle as soon as ONE lane is to be integrated and never masks the result; DemoCallbacks.cs:99-109 ignores
+    the mask. So a kinematic body's predicted box feels gravity exactly when a dynamic body shares its bundle of Vector<float>.Count bodies — as written, per bundle width."""
+    rng = np.random.default_rng(61)
+    n = 32
+    bodies = np.stack([small_scenes.kinematic_body(rng, rng.uniform(-5, 5, 3), angular=(0, 0, 0)) for _ in range(n)]).astype(np.float32)
+    bodies[:, 8:11] = 0
+    bodies[5] = small_scenes.random_dynamic_body(rng, (0, 0, 0), speed=0.0)  # the only dynamic body: bundle 0 for widths 8 and 16, bundle 1 for width 4
+    coll = np.zeros(n, dtype=COLLIDABLE_DTYPE)
+    coll["shape_type"], coll["shape"][:, 0] = SHAPE_SPHERE, 0.5
+    coll["maximum_speculative_margin"], coll["allow_expansion_beyond_speculative_margin"] = FLOAT_MAX, 1
+    cb = PoseIntegratorCallbacks(gravity=(0, -10, 0), linear_damping=0, angular_damping=0)
+    for width in (4, 8, 16):
+        out = oracle_ffi.predict_bounding_boxes(bodies, 0.1, cb, coll, bundle_width=width)
+        swept = np.isclose(out["max"][:, 1] - out["min"][:, 1], 1.0 + 10 * 0.1 * 0.1, atol=1e-5)  # diameter + |g| dt^2 of downward sweep
+        still = np.isclose(out["max"][:, 1] - out["min"][:, 1], 1.0, atol=1e-6)
+        in_bundle = (np.arange(n) // width) == (5 // width)
+        assert np.array_equal(swept, in_bundle) and np.array_equal(still, ~in_bundle), width
+    everyone = oracle_ffi.predict_bounding_boxes(bodies, 0.1, PoseIntegratorCallbacks(gravity=(0, -10, 0), linear_damping=0, angular_damping=0, integrate_velocity_for_kinematics=True), coll)
+    assert np.allclose(everyone["max"][:, 1] - everyone["min"][:, 1], 1.1, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [4, 8, 16])
+def test_hip_bundle_wide_velocity_callback_matches_the_oracle(hip_solver_factory, width):
+    """Kinematic bodies scattered among dynamic ones, runs of kinematic bodies longer than a bundle, a ragged last bundle: the device reads the bundle's 'any lane integrates'
+    from a wave ballot, the oracle walks bundles like the reference."""
+    rng = np.random.default_rng(63 + width)
+    n = 4099
+    bodies = _random_bodies(rng, n)
+    for start in rng.integers(0, n - 40, size=30):  # runs of kinematic bodies that cover whole bundles
+        for i in range(int(start), int(start) + int(rng.integers(3, 40))):
+            bodies[i] = small_scenes.kinematic_body(rng, rng.uniform(-5, 5, 3), angular=(0.3, -1.2, 0.4))
+    coll = _random_collidables(rng, n)
+    solver = hip_solver_factory(bundle_width=width)
+    solver.set_bodies(bodies)
+    cb = PoseIntegratorCallbacks(gravity=(1, -9, 0.5), linear_damping=0.1, angular_damping=0.2)
+    want = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, coll, bundle_width=width)
+    got = solver.predict_bounding_boxes(1 / 60, cb, coll)
+    assert np.array_equal(want.view(np.int32), got.view(np.int32))
+    per_body = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, coll, bundle_width=4 if width != 4 else 16)
+    assert not np.array_equal(want.view(np.int32), per_body.view(np.int32))  # the bundle width is visible in the result
+
+
+def test_the_two_restatements_of_predict_bounding_boxes_agree_bit_for_bit():
+    """oracle/bepu_bounds.h (one body at a time, its convex text shared with the device) against oracle/wide/wide_bounds.h (the reference's own shape, from the C# alone:
+    bundles of eight bodies, the batcher with its per-type flushes of sixteen, TShapeWide.GetBounds, merge continuations for compound children, the scalar mesh path)."""
+    rng = np.random.default_rng(71)
+    hulls, meshes = _random_hulls(rng, 24), _random_meshes(rng, 12)
+    compounds = _random_compounds(rng, 40, len(hulls))
+    n = 3003  # a ragged last bundle
+    bodies = _spinning_bodies(rng, n)
+    for start in rng.integers(0, n - 40, size=20):  # all-kinematic bundles among the mixed ones
+        for i in range(int(start), int(start) + int(rng.integers(3, 30))):
+            bodies[i] = small_scenes.kinematic_body(rng, rng.uniform(-5, 5, 3), angular=(0.3, -1.2, 0.4))
+    coll = _every_shape_collidables(rng, n, len(hulls), len(compounds), len(meshes))
+    assert set(np.unique(coll["shape_type"])) == {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8}
+    for cb in (PoseIntegratorCallbacks(), PoseIntegratorCallbacks(gravity=(1, -9, 0.5), linear_damping=0.1, angular_damping=0.2, integrate_velocity_for_kinematics=True)):
+        chained_a, chained_b = coll.copy(), coll.copy()
+        for _ in range(3):  # the sleep counters chain identically
+            a = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, chained_a, hulls, compounds, meshes)
+            b = wide_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, chained_b, hulls, compounds, meshes)
+            assert np.array_equal(a.view(np.int32), b.view(np.int32)), np.flatnonzero((a.view(np.int32).reshape(n, -1) != b.view(np.int32).reshape(n, -1)).any(axis=1))[:10]
+            chained_a["activity"], chained_b["activity"] = a["activity"], b["activity"]

@@ -69,3 +69,37 @@ def constraint_iterate(type_id, body_a, body_b, prestep, accumulated, dt, iterat
     rc = load().wide_constraint_iterate(type_id, _p(body_a), _p(body_b), _p(prestep), _p(accumulated), float(dt), int(iterations))
     if rc != 0:
         raise RuntimeError(f"wide_constraint_iterate failed: {rc}")
+
+
+def predict_bounding_boxes(bodies, dt, callbacks, collidables, hulls=None, compounds=None, meshes=None):
+    """PoseIntegrator.PredictBoundingBoxes through oracle/wide's BoundingBoxBatcher transcription (wide_bounds.h); same records as oracle_ffi.predict_bounding_boxes, bundle width 8."""
+    from bepuphysics2_amd.native import COLLIDABLE_DTYPE, COMPOUND_CHILD_DTYPE, PREDICTED_BOUNDS_DTYPE
+    lib = load()
+    hulls, compounds, meshes = hulls or [], compounds or [], meshes or []
+    b = np.ascontiguousarray(bodies, dtype=np.float32)
+    c = np.ascontiguousarray(collidables, dtype=COLLIDABLE_DTYPE)
+    out = np.zeros(c.shape[0], dtype=PREDICTED_BOUNDS_DTYPE)
+    p = OracleParams()
+    p.dt = float(dt)
+    p.substep_count = 1
+    p.gravity[0], p.gravity[1], p.gravity[2] = [float(x) for x in callbacks.gravity]
+    p.linear_damping = float(callbacks.linear_damping)
+    p.angular_damping = float(callbacks.angular_damping)
+    p.integrate_velocity_for_kinematics = int(bool(callbacks.integrate_velocity_for_kinematics))
+    pts = np.ascontiguousarray(np.concatenate([np.asarray(h, dtype=np.float32).reshape(-1, 3) for h in hulls]) if hulls else np.zeros((0, 3), np.float32), dtype=np.float32)
+    hull_begin = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(h) for h in hulls])]), dtype=np.int32)
+    kids = np.ascontiguousarray(np.concatenate([np.asarray(k, dtype=COMPOUND_CHILD_DTYPE).reshape(-1) for k in compounds]) if compounds else np.zeros(0, COMPOUND_CHILD_DTYPE),
+                                dtype=COMPOUND_CHILD_DTYPE)
+    kid_begin = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(k) for k in compounds])]), dtype=np.int32)
+    tris = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.float32).reshape(-1, 9) for t, _ in meshes]) if meshes else np.zeros((0, 9), np.float32), dtype=np.float32)
+    tri_begin = np.ascontiguousarray(np.concatenate([[0], np.cumsum([np.asarray(t).reshape(-1, 9).shape[0] for t, _ in meshes])]), dtype=np.int32)
+    scales = np.ascontiguousarray(np.asarray([s for _, s in meshes], dtype=np.float32).reshape(-1, 3))
+    fn = lib.wide_predict_bounding_boxes
+    fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(OracleParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_int]
+    fn.restype = C.c_int
+    rc = fn(_p(b), c.shape[0], C.byref(p), _p(c), _p(out), _p(pts), hull_begin.ctypes.data_as(C.c_void_p), len(hulls), _p(kids), kid_begin.ctypes.data_as(C.c_void_p), len(compounds), _p(tris),
+            tri_begin.ctypes.data_as(C.c_void_p), _p(scales), len(meshes))
+    if rc != 0:
+        raise RuntimeError(f"wide_predict_bounding_boxes failed: {rc}")
+    return out
