@@ -34,7 +34,11 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_get_bodies(IntPtr ctx, void* bodyDynamics, int count);
     [DllImport(Lib)] public static extern int bepuhip_get_accumulated_impulses(IntPtr ctx, int batchIndex, int typeId, void* accumulatedImpulses);
     [DllImport(Lib)] public static extern int bepuhip_get_prestep(IntPtr ctx, int batchIndex, int typeId, void* prestepData);
-    // PredictBoundingBoxes + sleep candidacy for bodies with primitive convex shapes (include/bepuhip.h: bepuhip_collidable = 64 bytes, bepuhip_predicted_bounds = 32 bytes)
+    // PredictBoundingBoxes + sleep candidacy for every shape type (include/bepuhip.h: bepuhip_collidable = 64 bytes, bepuhip_predicted_bounds = 32 bytes, bepuhip_compound_child = 68 bytes);
+    // hull points, compound children and mesh triangles live in device tables uploaded once, collidables name their entry in shape[0]
+    [DllImport(Lib)] public static extern int bepuhip_set_convex_hulls(IntPtr ctx, float* points, int* pointBegin, int hullCount);
+    [DllImport(Lib)] public static extern int bepuhip_set_compounds(IntPtr ctx, void* children, int* childBegin, int compoundCount);
+    [DllImport(Lib)] public static extern int bepuhip_set_meshes(IntPtr ctx, float* triangles, int* triangleBegin, float* scales, int meshCount);
     [DllImport(Lib)] public static extern int bepuhip_set_collidables(IntPtr ctx, void* collidables, int count);
     [DllImport(Lib)] public static extern int bepuhip_predict_bounding_boxes(IntPtr ctx, float dt, BepuHipIntegrator* integrator, void* collidablesOrNull, int count, void* boundsOut);
     // ranged in-place updates / read-backs for frames whose topology did not change (INTEGRATION.md)
