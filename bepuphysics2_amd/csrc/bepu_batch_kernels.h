@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
 // bundle also holds a body that integrates. A wave covers 64 consecutive bodies = whole bundles (4, 8 or 16 wide), so the bundle's "any" is a slice of a ballot.
 __global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __restrict__ bodies, int count, CollidableIn* collidables, int keep_activity,
                                                               PredictedBounds* __restrict__ out, float dt, int integrate_velocity_for_kinematics, StepParams sp, ShapeTables tables,
-                                                              int bundle_width) {
+                                                              int bundle_width, int2* heavy_queue, int* heavy_count, int heavy_threshold) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < count;
     const float4* base = bodies + (size_t)(live ? i : 0) * 8;
@@ -330,9 +330,36 @@ __global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __res
     if (bundle_integrates) velocity_callback(sp, vel);  // :337-338 (never stored)
     const CollidableIn c = collidables[i];
     PredictedBounds r;
-    predictBoundsOfAnyShape(pos, ori, vel, sleep_energy, dt, c, tables, r);
+    if (heavy_queue && isHeavyShape(c, tables, heavy_threshold)) {  // a wave of predict_heavy_bounds_kernel does the box and the margin; the sleep counters are settled here
+        r.activity = updateSleepCandidacy(sleep_energy, c.sleep_threshold, c.minimum_timesteps_under_threshold, c.activity);
+        r.min[0] = r.min[1] = r.min[2] = r.max[0] = r.max[1] = r.max[2] = r.speculative_margin = 0.0f;
+        heavy_queue[atomicAdd(heavy_count, 1)] = make_int2(i, bundle_integrates ? 1 : 0);
+    } else {
+        predictBoundsOfAnyShape(pos, ori, vel, sleep_energy, dt, c, tables, r);
+    }
     out[i] = r;
     if (keep_activity) collidables[i].activity = r.activity;  // device-resident records: the sleep counters carry over to the next frame
+}
+
+// Second pass of PredictBoundingBoxes: one wave per queued body (compound, mesh, large hull), as many waves as the grid has looping over the queue.
+__global__ __launch_bounds__(64) void predict_heavy_bounds_kernel(const float4* __restrict__ bodies, const CollidableIn* __restrict__ collidables, PredictedBounds* __restrict__ out, float dt,
+                                                                   StepParams sp, ShapeTables tables, const int2* __restrict__ heavy_queue, const int* __restrict__ heavy_count) {
+    const int queued = *heavy_count;
+    for (int q = blockIdx.x; q < queued; q += gridDim.x) {
+        const int2 item = heavy_queue[q];
+        const float4* base = bodies + (size_t)item.x * 8;
+        const float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
+        BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+        if (item.y) velocity_callback(sp, vel);
+        const CollidableIn c = collidables[item.x];
+        PredictedBounds r;
+        heavyBounds((int)threadIdx.x, V3{p4.x, p4.y, p4.z}, Q{q4.x, q4.y, q4.z, q4.w}, vel, dt, c, tables, r);
+        if (threadIdx.x == 0) {
+            PredictedBounds* o = out + item.x;
+            o->min[0] = r.min[0]; o->min[1] = r.min[1]; o->min[2] = r.min[2]; o->speculative_margin = r.speculative_margin;
+            o->max[0] = r.max[0]; o->max[1] = r.max[1]; o->max[2] = r.max[2];
+        }
+    }
 }
 
 // ---- boundary exchange (one connected scene split across GPUs, BASELINE.json configs[4]) ----

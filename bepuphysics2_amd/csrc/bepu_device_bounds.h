@@ -252,6 +252,120 @@ BD_FN void meshBounds(V3 position, Q orientation, const BodyVel& velocity, float
     out.speculative_margin = margin;
 }
 
+// ---- a whole wave on one body: compounds, meshes and large hulls (predict_heavy_bounds_kernel) ----
+// The lanes share the children / triangles / points of the body and merge what they found. The serial text above fixes which of two EQUAL candidates a
+// minimum or maximum keeps (it matters for the sign of a zero only): vmin(acc, p) keeps the later one, the mesh pairing keeps the earlier triangle and c over b
+// over a. A candidate therefore carries a key, larger = kept on ties, and the merge is the same in a lane's loop and across lanes, so the result does not depend
+// on how the work was dealt out.
+struct Keyed { float v; int k; };
+BD_FN void keepSmaller(Keyed& acc, float v, int k) { if (v < acc.v || (v == acc.v && k > acc.k)) { acc.v = v; acc.k = k; } }
+BD_FN void keepLarger(Keyed& acc, float v, int k) { if (v > acc.v || (v == acc.v && k > acc.k)) { acc.v = v; acc.k = k; } }
+struct KeyedBox {
+    Keyed lo[3], hi[3];
+    __device__ __forceinline__ void reset(int seedKey) {
+        for (int a = 0; a < 3; ++a) { lo[a] = {3.402823466e+38f, seedKey}; hi[a] = {-3.402823466e+38f, seedKey}; }
+    }
+    __device__ __forceinline__ void take(V3 lower, V3 upper, int key) {
+        keepSmaller(lo[0], lower.x, key); keepSmaller(lo[1], lower.y, key); keepSmaller(lo[2], lower.z, key);
+        keepLarger(hi[0], upper.x, key); keepLarger(hi[1], upper.y, key); keepLarger(hi[2], upper.z, key);
+    }
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ void mergeAcrossWave(KeyedBox& box) {  // butterfly over the 64 lanes; every lane ends with the wave's result
+    for (int step = 32; step > 0; step >>= 1)
+        for (int a = 0; a < 3; ++a) {
+            const float lv = __shfl_xor(box.lo[a].v, step), hv = __shfl_xor(box.hi[a].v, step);
+            const int lk = __shfl_xor(box.lo[a].k, step), hk = __shfl_xor(box.hi[a].k, step);
+            keepSmaller(box.lo[a], lv, lk);
+            keepLarger(box.hi[a], hv, hk);
+        }
+}
+__device__ __forceinline__ float largestAcrossWave(float v, bool marginRule) {
+    for (int step = 32; step > 0; step >>= 1) {
+        const float other = __shfl_xor(v, step);
+        v = marginRule ? largerMargin(v, other) : vmax(v, other);
+    }
+    return v;
+}
+// One wave, one body of shape type ConvexHull (many points), Compound, BigCompound or Mesh; `lane` = 0..63. The result is written by every lane into `out` (callers keep lane 0's).
+__device__ __forceinline__ void heavyBounds(int lane, V3 position, Q orientation, const BodyVel& velocity, float dt, const CollidableIn& c, const ShapeTables& tables, PredictedBounds& out) {
+    KeyedBox found;
+    float margin = 0.0f;
+    Box3 box;
+    const int entry = (int)c.shape[0];
+    if (c.shape_type == kShapeConvexHull) {  // shapeBounds' hull case with the points dealt to the lanes: vmin(acc, p) keeps the later point
+        found.reset(-1);
+        const M3 basis = createFromQuaternion(orientation);
+        float farthest2 = 0.0f;
+        for (int j = tables.hulls.begin[entry] + lane; j < tables.hulls.begin[entry + 1]; j += 64) {
+            const V3 local = {tables.hulls.points[3 * (size_t)j], tables.hulls.points[3 * (size_t)j + 1], tables.hulls.points[3 * (size_t)j + 2]};
+            const V3 p = transform(local, basis);
+            farthest2 = vmax(lengthSquared(local), farthest2);
+            found.take(p, p, j);
+        }
+        mergeAcrossWave(found);
+        const float maximumRadius = sqrtf(largestAcrossWave(farthest2, false));
+        box = {{found.lo[0].v, found.lo[1].v, found.lo[2].v}, {found.hi[0].v, found.hi[1].v, found.hi[2].v}};
+        margin = expandByVelocity(velocity, dt, maximumRadius, maximumRadius, c.minimum_speculative_margin, c.maximum_speculative_margin, c.allow_expansion_beyond_speculative_margin, true,
+                                  position, box);
+    } else if (c.shape_type == kShapeMesh) {  // meshBounds with the triangles dealt to the lanes: the earlier triangle is kept, within one c over b over a
+        found.reset(0x7fffffff);
+        const float sx = tables.mesh_scales[3 * entry], sy = tables.mesh_scales[3 * entry + 1], sz = tables.mesh_scales[3 * entry + 2];
+        const M3 basis = createFromQuaternion(orientation);
+        const int first = tables.triangle_begin[entry];
+        for (int t = first + lane; t < tables.triangle_begin[entry + 1]; t += 64) {
+            const float* v = tables.triangles + 9 * (size_t)t;
+            const int key = -3 * (t - first);
+            const V3 a = transform(V3{sx * v[0], sy * v[1], sz * v[2]}, basis), b = transform(V3{sx * v[3], sy * v[4], sz * v[5]}, basis), cc = transform(V3{sx * v[6], sy * v[7], sz * v[8]}, basis);
+            found.take(a, a, key);
+            found.take(b, b, key + 1);
+            found.take(cc, cc, key + 2);
+        }
+        mergeAcrossWave(found);
+        box = {{found.lo[0].v, found.lo[1].v, found.lo[2].v}, {found.hi[0].v, found.hi[1].v, found.hi[2].v}};
+        const V3 abs_lo = {vabs(box.lo.x), vabs(box.lo.y), vabs(box.lo.z)}, abs_hi = {vabs(box.hi.x), vabs(box.hi.y), vabs(box.hi.z)};
+        const float maximumRadius = length(max3(abs_lo, abs_hi));
+        const V3 inner = min3(abs_lo, abs_hi);
+        margin = expandByVelocity(velocity, dt, maximumRadius, maximumRadius - vmin(inner.x, vmin(inner.y, inner.z)), c.minimum_speculative_margin, c.maximum_speculative_margin,
+                                  c.allow_expansion_beyond_speculative_margin, false, position, box);
+    } else {  // compoundBounds with the children dealt to the lanes: vmin(acc, child) keeps the later child
+        found.reset(-1);
+        for (int k = tables.child_begin[entry] + lane; k < tables.child_begin[entry + 1]; k += 64) {
+            const CompoundChildIn* child = tables.children + k;
+            const Q local_q = {child->local_orientation[0], child->local_orientation[1], child->local_orientation[2], child->local_orientation[3]};
+            const V3 offset = transform(V3{child->local_position[0], child->local_position[1], child->local_position[2]}, orientation);
+            const Q child_q = concatenate(local_q, orientation);
+            V3 swing = cross(velocity.ang, offset);
+            const float swing2 = lengthSquared(swing), offset2 = lengthSquared(offset);
+            if (swing2 > offset2) swing = scale(swing, (float)(sqrt((double)offset2) / sqrt((double)swing2)));
+            const BodyVel child_v = {add(velocity.lin, swing), velocity.ang};
+            float shape[9];
+            for (int f = 0; f < 9; ++f) shape[f] = child->shape[f];
+            float maximumRadius, maximumAngularExpansion;
+            Box3 child_box;
+            shapeBounds(child->shape_type, shape, child_q, tables.hulls, maximumRadius, maximumAngularExpansion, child_box.lo, child_box.hi);
+            const float child_margin = expandByVelocity(child_v, dt, maximumRadius, maximumAngularExpansion, c.minimum_speculative_margin, c.maximum_speculative_margin,
+                                                        c.allow_expansion_beyond_speculative_margin, true, add(offset, position), child_box);
+            margin = largerMargin(margin, child_margin);
+            found.take(child_box.lo, child_box.hi, k);
+        }
+        mergeAcrossWave(found);
+        margin = largestAcrossWave(margin, true);
+        box = {{found.lo[0].v, found.lo[1].v, found.lo[2].v}, {found.hi[0].v, found.hi[1].v, found.hi[2].v}};
+    }
+    out.min[0] = box.lo.x; out.min[1] = box.lo.y; out.min[2] = box.lo.z;
+    out.max[0] = box.hi.x; out.max[1] = box.hi.y; out.max[2] = box.hi.z;
+    out.speculative_margin = margin;
+}
+#endif
+// Which bodies get a wave of their own: hulls, compounds and meshes with more points / children / triangles than a lane should walk alone.
+BD_FN bool isHeavyShape(const CollidableIn& c, const ShapeTables& tables, int threshold) {
+    if (c.shape_type < kShapeConvexHull) return false;
+    const int entry = (int)c.shape[0];
+    const int* begin = c.shape_type == kShapeConvexHull ? tables.hulls.begin : c.shape_type == kShapeMesh ? tables.triangle_begin : tables.child_begin;
+    return begin[entry + 1] - begin[entry] > threshold;
+}
+
 BD_FN void predictBoundsOfAnyShape(V3 position, Q orientation, const BodyVel& velocity, float sleepEnergy, float dt, const CollidableIn& c, const ShapeTables& tables, PredictedBounds& out) {
     if (c.shape_type < kShapeCompound) return predictBounds(position, orientation, velocity, sleepEnergy, dt, c, tables.hulls, out);
     out.activity = updateSleepCandidacy(sleepEnergy, c.sleep_threshold, c.minimum_timesteps_under_threshold, c.activity);

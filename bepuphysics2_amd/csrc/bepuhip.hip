@@ -1497,6 +1497,7 @@ int32_t bepuhip_get_bodies_range(bepuhip_ctx* c, void* aos_out, int32_t first, i
 // ---- PredictBoundingBoxes on the device ----
 static_assert(sizeof(bepuhip_collidable) == sizeof(CollidableIn) && sizeof(bepuhip_collidable) == 64, "bepuhip_collidable layout");
 static_assert(sizeof(bepuhip_predicted_bounds) == sizeof(PredictedBounds) && sizeof(bepuhip_predicted_bounds) == 32, "bepuhip_predicted_bounds layout");
+constexpr int kBoundsWaveThreshold = 64;  // points / children / triangles above which a body's bounds are computed by a whole wave (predict_heavy_bounds_kernel) instead of its lane
 static int32_t check_collidables(const bepuhip_ctx* c, const bepuhip_collidable* collidables, int32_t count) {
     for (int i = 0; i < count; ++i) {
         if (collidables[i].shape_type < -1 || collidables[i].shape_type > 8)
@@ -1624,19 +1625,32 @@ int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* c, float dt, const bepuhip_i
         return fail(BEPUHIP_E_STATE, "the resident collidables name hulls, compounds or meshes that the shape tables no longer hold (they were replaced after bepuhip_set_collidables)");
     if (count == 0) return BEPUHIP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t in_floats = resident ? 0 : (size_t)count * 16, out_floats = (size_t)count * 8;
-    int32_t st = stage_reserve(c, in_floats + out_floats);
+    // bodies that get a wave of their own (compounds, meshes, large hulls) are queued by the per-body kernel: {body, bundle integrates} pairs behind a counter
+    const bool heavy_pass = (c->compound_count > 0 || c->mesh_count > 0 || c->hull_count > 0) && !getenv("BEPUHIP_BOUNDS_ONE_LANE");
+    const size_t in_floats = resident ? 0 : (size_t)count * 16, out_floats = (size_t)count * 8, queue_floats = heavy_pass ? (size_t)count * 2 + 4 : 0;
+    int32_t st = stage_reserve(c, in_floats + out_floats + queue_floats);
     if (st != BEPUHIP_OK) return st;
     CollidableIn* d_in = resident ? c->d_collidables : (CollidableIn*)c->d_stage;
     PredictedBounds* d_out = (PredictedBounds*)(c->d_stage + in_floats);
+    int* d_heavy_count = heavy_pass ? (int*)(c->d_stage + in_floats + out_floats) : nullptr;
+    int2* d_heavy_queue = heavy_pass ? (int2*)(c->d_stage + in_floats + out_floats + 4) : nullptr;
+    if (heavy_pass) HIP_TRY(hipMemsetAsync(d_heavy_count, 0, 4, c->stream));
     if (!resident) HIP_TRY(hipMemcpyAsync(d_in, collidables, in_floats * 4, hipMemcpyHostToDevice, c->stream));
     const StepParams sp = make_params(in, dt, dt, 1.0f / dt);  // Callbacks.PrepareForIntegration(dt): the full frame step
     hipLaunchKernelGGL(predict_bounds_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, count, d_in, resident ? 1 : 0, d_out, dt,
                        in->integrate_velocity_for_kinematics, sp,
                        ShapeTables{HullTable{c->d_hull_points, c->d_hull_begin, c->hull_count}, c->d_compound_children, c->d_compound_begin, c->compound_count, c->d_mesh_triangles,
                                    c->d_mesh_begin, c->d_mesh_scales, c->mesh_count},
-                       c->W);
+                       c->W, d_heavy_queue, d_heavy_count, getenv("BEPUHIP_BOUNDS_WAVE_THRESHOLD") ? atoi(getenv("BEPUHIP_BOUNDS_WAVE_THRESHOLD")) : kBoundsWaveThreshold);
     HIP_TRY(hipGetLastError());
+    if (heavy_pass) {
+        const int waves = std::min(count, 4096);  // 16 single-wave workgroups on each of the 256 CUs; they loop over the queue
+        hipLaunchKernelGGL(predict_heavy_bounds_kernel, dim3(waves), dim3(64), 0, c->stream, (const float4*)c->d_bodies, (const CollidableIn*)d_in, d_out, dt, sp,
+                           ShapeTables{HullTable{c->d_hull_points, c->d_hull_begin, c->hull_count}, c->d_compound_children, c->d_compound_begin, c->compound_count, c->d_mesh_triangles,
+                                       c->d_mesh_begin, c->d_mesh_scales, c->mesh_count},
+                           (const int2*)d_heavy_queue, (const int*)d_heavy_count);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMemcpyAsync(out, d_out, out_floats * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BEPUHIP_OK;

@@ -473,3 +473,57 @@ def test_the_two_restatements_of_predict_bounding_boxes_agree_bit_for_bit():
             b = wide_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, chained_b, hulls, compounds, meshes)
             assert np.array_equal(a.view(np.int32), b.view(np.int32)), np.flatnonzero((a.view(np.int32).reshape(n, -1) != b.view(np.int32).reshape(n, -1)).any(axis=1))[:10]
             chained_a["activity"], chained_b["activity"] = a["activity"], b["activity"]
+
+
+@pytest.mark.gpu
+def test_hip_wave_per_body_pass_matches_the_oracle_on_large_shapes_and_on_ties(hip_solver_factory, monkeypatch):
+    """Compounds, meshes and hulls with more entries than a wave has lanes (several strides of the wave-per-body pass), and axis-aligned bodies whose rotated
+    coordinates are exact zeros of both signs: which of two equal candidates a minimum keeps decides the sign of a zero, and the wave merge must keep the one the
+    serial reading keeps. The one-lane-per-body path (BEPUHIP_BOUNDS_ONE_LANE) must give the same bits."""
+    rng = np.random.default_rng(67)
+    hulls = _random_hulls(rng, 6) + [(rng.normal(size=(k, 3)) * 1.3).astype(np.float32) for k in (49, 64, 65, 300)]
+    big = np.zeros(700, dtype=COMPOUND_CHILD_DTYPE)
+    big["shape_type"] = rng.integers(0, 5, size=700)
+    big["shape"][:, :9] = rng.uniform(0.1, 0.6, (700, 9))
+    big["local_position"] = rng.uniform(-6, 6, (700, 3))
+    big["local_orientation"] = np.stack([_random_quaternion(rng) for _ in range(700)])
+    flat = np.zeros(70, dtype=COMPOUND_CHILD_DTYPE)  # boxes on a grid in the plane y = 0, unrotated: child boxes share faces, so maxima tie exactly
+    flat["shape_type"], flat["shape"][:, :3] = SHAPE_BOX, 0.5
+    flat["local_position"][:, 0], flat["local_position"][:, 2] = np.arange(70) % 10 - 4.5, np.arange(70) // 10 - 3.0
+    flat["local_orientation"][:, 3] = 1
+    compounds = _random_compounds(rng, 12, len(hulls)) + [big, flat]
+    grid = np.array([[[x, 0, z], [x + 1, 0, z], [x, 0, z + 1]] for x in range(-8, 8) for z in range(-8, 8)], np.float32)  # 256 coplanar triangles through the origin
+    meshes = _random_meshes(rng, 6) + [((rng.normal(size=(2000, 3, 3))).astype(np.float32), np.ones(3, np.float32)), (grid, np.array([1, 1, 1], np.float32)),
+                                       (grid, np.array([-1, 1, -0.5], np.float32))]
+    n = 900
+    bodies = _spinning_bodies(rng, n)
+    axis_aligned = [(0, 0, 0, 1), (1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0.70710677, 0, 0, 0.70710677), (0, -0.70710677, 0, 0.70710677)]
+    for i in range(0, n, 2):
+        bodies[i, 0:4] = axis_aligned[(i // 2) % len(axis_aligned)]
+        if i % 4 == 0:
+            bodies[i, 4:7] = 0
+            bodies[i, 8:11] = 0
+            bodies[i, 12:15] = 0
+    coll = _every_shape_collidables(rng, n, len(hulls), len(compounds), len(meshes))
+    for i in range(n):  # make sure the special entries are used, on axis-aligned and on tumbling bodies
+        t = coll["shape_type"][i]
+        if t == SHAPE_CONVEX_HULL:
+            coll["shape"][i, 0] = len(hulls) - 1 - (i % 4)
+        elif t in (SHAPE_COMPOUND, SHAPE_BIG_COMPOUND) and i % 3:
+            coll["shape"][i, 0] = len(compounds) - 1 - (i % 2)
+        elif t == SHAPE_MESH and i % 3:
+            coll["shape"][i, 0] = len(meshes) - 1 - (i % 3)
+    cb = PoseIntegratorCallbacks(gravity=(0, -9, 0), linear_damping=0.1, angular_damping=0.2)
+    want = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, coll, hulls, compounds, meshes)
+    assert (want.view(np.int32).reshape(n, 8)[:, [0, 1, 2, 4, 5, 6]] == 0).any()  # exact zeros reach the result (the final position + (box + expansion) turns -0 into +0 unless all three are -0)
+    for one_lane in (False, True):
+        if one_lane:
+            monkeypatch.setenv("BEPUHIP_BOUNDS_ONE_LANE", "1")
+        solver = hip_solver_factory()
+        solver.set_bodies(bodies)
+        solver.set_convex_hulls(hulls)
+        solver.set_compounds(compounds)
+        solver.set_meshes(meshes)
+        got = solver.predict_bounding_boxes(1 / 60, cb, coll)
+        bad = np.flatnonzero((want.view(np.int32).reshape(n, 8) != got.view(np.int32).reshape(n, 8)).any(axis=1))
+        assert bad.size == 0, (one_lane, bad[:10], coll["shape_type"][bad[:10]], want[bad[:3]], got[bad[:3]])
