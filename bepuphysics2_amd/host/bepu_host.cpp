@@ -352,7 +352,7 @@ public:
                     check(api.bepuhip_remove_constraint(ctx, change.batch, change.typeId, change.index));
                 }
             }
-            if (solver.ConstrainedKinematicHandles.size() != uploadedKinematics) {  // an addition brought a kinematic body in
+            {  // additions bring kinematic bodies into Solver.ConstrainedKinematicHandles, removals take them out (the count alone does not tell: one of each leaves it unchanged)
                 std::vector<int32_t> kin;
                 for (int32_t h : solver.ConstrainedKinematicHandles) kin.push_back(sim.bodies.HandleToIndex[h]);
                 check(api.bepuhip_set_constrained_kinematics(ctx, kin.data(), (int)kin.size()));
