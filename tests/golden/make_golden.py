@@ -79,8 +79,37 @@ def main():
             oracle_ffi.solve(sc, 1 / 60, sd, cb)
         widened[f"type{type_id}_bodies"] = sc.bodies
     np.savez_compressed(os.path.join(HERE, "widened_types.npz"), **widened)
+    bounds()
     print("wrote", os.listdir(HERE))
 
 
+def bounds_inputs():
+    """The seeded body set of the PredictBoundingBoxes fixture: all nine shape types, fast spinners, runs of kinematic bodies, a ragged last bundle."""
+    import test_bounds as tb
+    rng = np.random.default_rng(101)
+    hulls, meshes = tb._random_hulls(rng, 10), tb._random_meshes(rng, 6)
+    compounds = tb._random_compounds(rng, 14, len(hulls))
+    n = 603
+    bodies = tb._spinning_bodies(rng, n)
+    for start in (40, 200, 413):
+        for i in range(start, start + 19):
+            bodies[i] = small_scenes.kinematic_body(rng, rng.uniform(-5, 5, 3), angular=(0.3, -1.2, 0.4))
+    coll = tb._every_shape_collidables(rng, n, len(hulls), len(compounds), len(meshes))
+    return bodies, coll, hulls, compounds, meshes
+
+
+def bounds():
+    bodies, coll, hulls, compounds, meshes = bounds_inputs()
+    out = {}
+    for name, cb in (("default", PoseIntegratorCallbacks()),
+                     ("kinematics_integrated", PoseIntegratorCallbacks(gravity=(1, -9, 0.5), linear_damping=0.1, angular_damping=0.2, integrate_velocity_for_kinematics=True))):
+        r = oracle_ffi.predict_bounding_boxes(bodies, 1 / 60, cb, coll, hulls, compounds, meshes)
+        out[name] = r.view(np.int32).reshape(-1, 8)
+    np.savez_compressed(os.path.join(HERE, "bounds.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--bounds-only" in sys.argv:
+        bounds()
+    else:
+        main()

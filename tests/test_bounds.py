@@ -527,3 +527,37 @@ def test_hip_wave_per_body_pass_matches_the_oracle_on_large_shapes_and_on_ties(h
         got = solver.predict_bounding_boxes(1 / 60, cb, coll)
         bad = np.flatnonzero((want.view(np.int32).reshape(n, 8) != got.view(np.int32).reshape(n, 8)).any(axis=1))
         assert bad.size == 0, (one_lane, bad[:10], coll["shape_type"][bad[:10]], want[bad[:3]], got[bad[:3]])
+
+
+def test_both_restatements_reproduce_the_committed_bounds_fixture():
+    """tests/golden/bounds.npz (tests/golden/make_golden.py): a regression pin of the stage on all nine shape types — the reference holds no vectors for it."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    bodies, coll, hulls, compounds, meshes = make_golden.bounds_inputs()
+    golden = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bounds.npz"))
+    for name, cb in (("default", PoseIntegratorCallbacks()),
+                     ("kinematics_integrated", PoseIntegratorCallbacks(gravity=(1, -9, 0.5), linear_damping=0.1, angular_damping=0.2, integrate_velocity_for_kinematics=True))):
+        for restatement in (oracle_ffi, wide_ffi):
+            got = restatement.predict_bounding_boxes(bodies, 1 / 60, cb, coll, hulls, compounds, meshes)
+            assert np.array_equal(got.view(np.int32).reshape(-1, 8), golden[name]), (name, restatement.__name__)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_the_committed_bounds_fixture(hip_solver_factory):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    bodies, coll, hulls, compounds, meshes = make_golden.bounds_inputs()
+    golden = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bounds.npz"))
+    solver = hip_solver_factory()
+    solver.set_bodies(bodies)
+    solver.set_convex_hulls(hulls)
+    solver.set_compounds(compounds)
+    solver.set_meshes(meshes)
+    for name, cb in (("default", PoseIntegratorCallbacks()),
+                     ("kinematics_integrated", PoseIntegratorCallbacks(gravity=(1, -9, 0.5), linear_damping=0.1, angular_damping=0.2, integrate_velocity_for_kinematics=True))):
+        got = solver.predict_bounding_boxes(1 / 60, cb, coll)
+        assert np.array_equal(got.view(np.int32).reshape(-1, 8), golden[name]), name
