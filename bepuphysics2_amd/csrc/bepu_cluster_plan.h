@@ -418,6 +418,36 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     // ---- constraints -> clusters, shared bodies, per-pass rank of every application on a shared body (type batches are in batch order) ----
     std::vector<std::vector<int32_t>> cl_of_constraint(c->tbs.size());
     std::vector<uint8_t> shared(universe, 0);
+    // Which side runs a constraint that crosses the cut decides which of its two bodies becomes shared. Default: the first dynamic body's cluster runs it. With
+    // BEPUHIP_SPLIT_COVER=1 (experimental, off by default) the shared bodies are a greedy vertex cover of the cut constraints instead — the body with the most
+    // crossing constraints first — and a crossing constraint runs on the side of its body that is NOT in the cover (either side when both are): fewer distinct
+    // shared bodies for the same cut.
+    std::vector<uint8_t> in_cover;
+    if (env_int("BEPUHIP_SPLIT_COVER", 0)) {
+        std::vector<int32_t> crossing(universe, 0);
+        auto for_each_crossing = [&](auto&& fn) {
+            for (auto& tb : c->tbs) {
+                if (tb.info.bodies != 2) continue;
+                for (int i = 0; i < tb.count; ++i) {
+                    const int32_t a = tb.refs_soa[i], b = tb.refs_soa[(size_t)tb.stride + i];
+                    if ((uint32_t)a < kDynamicLimit && (uint32_t)b < kDynamicLimit && body_cluster[a] != body_cluster[b]) fn(a, b);
+                }
+            }
+        };
+        for_each_crossing([&](int32_t a, int32_t b) { ++crossing[a]; ++crossing[b]; });
+        std::vector<int32_t> order;
+        for (int v = 0; v < universe; ++v) if (crossing[v] > 0) order.push_back(v);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return crossing[x] > crossing[y]; });
+        // greedy cover in one sweep: a body enters the cover if one of its crossing constraints is still uncovered (its other body is not in the cover yet)
+        std::vector<std::vector<int32_t>> across(universe);
+        for_each_crossing([&](int32_t a, int32_t b) { across[a].push_back(b); across[b].push_back(a); });
+        in_cover.assign(universe, 0);
+        for (int32_t v : order) {
+            bool uncovered = false;
+            for (int32_t u : across[v]) uncovered |= !in_cover[u];
+            in_cover[v] = uncovered;
+        }
+    }
     for (size_t t = 0; t < c->tbs.size(); ++t) {
         HostTypeBatch& tb = c->tbs[t];
         cl_of_constraint[t].resize(tb.count);
@@ -426,6 +456,10 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             for (int k = 0; k < tb.info.bodies && cl < 0; ++k) {
                 const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
                 if ((uint32_t)r < kDynamicLimit) cl = body_cluster[r];
+            }
+            if (!in_cover.empty() && tb.info.bodies == 2) {
+                const int32_t a = tb.refs_soa[i], b = tb.refs_soa[(size_t)tb.stride + i];
+                if ((uint32_t)a < kDynamicLimit && (uint32_t)b < kDynamicLimit && body_cluster[a] != body_cluster[b] && in_cover[a] && !in_cover[b]) cl = body_cluster[b];
             }
             if (cl < 0) return;  // a constraint with no dynamic body: leave everything to the global path
             cl_of_constraint[t][i] = cl;
