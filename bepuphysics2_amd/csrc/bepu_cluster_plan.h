@@ -415,6 +415,37 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         }
     }
     if (nclusters > cus) return;
+    // Experimental, off by default (BEPUHIP_SPLIT_REFINE = sweeps): smooth the regions' surfaces. A body moves to the neighbouring region that holds more of its
+    // constraint partners than its own does (ties stay), as long as no region leaves [7/8, 9/8] of the target size: fewer crossing constraints for the same regions.
+    if (const int sweeps = env_int("BEPUHIP_SPLIT_REFINE", 0)) {
+        std::vector<int32_t> size(nclusters, 0);
+        for (int v = 0; v < universe; ++v) if (body_cluster[v] >= 0) ++size[body_cluster[v]];
+        const int lo = region * 7 / 8, hi = region * 9 / 8;
+        std::vector<int32_t> seen_cluster, seen_count;
+        for (int sweep = 0; sweep < sweeps; ++sweep) {
+            int moved = 0;
+            for (int v = 0; v < universe; ++v) {
+                const int own = body_cluster[v];
+                if (own < 0 || adj_begin[v] == adj_begin[v + 1]) continue;
+                seen_cluster.clear(); seen_count.clear();
+                int own_count = 0;
+                for (int64_t e = adj_begin[v]; e < adj_begin[v + 1]; ++e) {
+                    const int cl = body_cluster[adj[e]];
+                    if (cl == own) { ++own_count; continue; }
+                    size_t k = 0;
+                    while (k < seen_cluster.size() && seen_cluster[k] != cl) ++k;
+                    if (k == seen_cluster.size()) { seen_cluster.push_back(cl); seen_count.push_back(0); }
+                    ++seen_count[k];
+                }
+                int best = -1, best_count = own_count;
+                for (size_t k = 0; k < seen_cluster.size(); ++k)
+                    if (seen_count[k] > best_count && size[seen_cluster[k]] < hi) { best = seen_cluster[k]; best_count = seen_count[k]; }
+                if (best < 0 || size[own] <= lo) continue;
+                body_cluster[v] = best; --size[own]; ++size[best]; ++moved;
+            }
+            if (moved == 0) break;
+        }
+    }
     // ---- constraints -> clusters, shared bodies, per-pass rank of every application on a shared body (type batches are in batch order) ----
     std::vector<std::vector<int32_t>> cl_of_constraint(c->tbs.size());
     std::vector<uint8_t> shared(universe, 0);
