@@ -22,6 +22,63 @@ static uint64_t fnv(uint64_t h, const void* p, size_t n) {
 }
 template <class T> static uint64_t fnv_vec(uint64_t h, const std::vector<T>& v) { return v.empty() ? h : fnv(h, v.data(), v.size() * sizeof(T)); }
 
+// A coarse timing model of one pass over a plan (PLAN_SIMULATE=1), to compare cuts offline: every cluster has WAVES waves that claim its items in order; a claimed item spends
+// LOAD clocks on its row loads and velocity-independent work, then waits for its predecessors inside the cluster (LDS flags) and, per shared body, for the previous
+// application on that body (rank order = batch order; HANDOFF clocks more when that ran in another cluster), then spends APPLY clocks and frees its wave. Every dependency
+// points to a lower batch, so one sweep over the batches in order settles all times.
+static void simulate(bepuhip_ctx* c, const ClusterPlan& plan) {
+    auto knob = [](const char* name, double fallback) { const char* v = getenv(name); return v ? atof(v) : fallback; };
+    const int waves = (int)knob("SIM_WAVES", 8);
+    const double load = knob("SIM_LOAD", 6000), apply = knob("SIM_APPLY", 4000), handoff = knob("SIM_HANDOFF", 3300), passes = knob("SIM_PASSES", 12), ghz = knob("SIM_GHZ", 2.2);
+    const size_t ncl = plan.clusters.size();
+    std::vector<std::vector<double>> wave_free(ncl, std::vector<double>(waves, 0.0)), finish(ncl);
+    std::vector<double> last_claim(ncl, 0.0);
+    std::vector<size_t> cursor(ncl, 0);
+    std::vector<double> body_finish(plan.shared_info.size(), 0.0);
+    std::vector<int32_t> body_cluster(plan.shared_info.size(), -1);
+    for (size_t cl = 0; cl < ncl; ++cl) finish[cl].assign(plan.clusters[cl].item_count, 0.0);
+    double makespan = 0, waited = 0, waited_remote = 0;
+    size_t items = 0;
+    for (int batch = 0; batch < c->batch_count; ++batch)
+        for (size_t cl = 0; cl < ncl; ++cl) {
+            const ClusterDesc& cd = plan.clusters[cl];
+            while (cursor[cl] < (size_t)cd.item_count && (plan.items[cd.item_begin + cursor[cl]].batch_npred & 0xFFFF) == batch) {
+                const size_t k = cursor[cl]++;
+                const ClusterItem& it = plan.items[cd.item_begin + k];
+                const HostTypeBatch& tb = c->tbs[it.tb];
+                auto w = std::min_element(wave_free[cl].begin(), wave_free[cl].end());
+                const double claim = std::max(*w, last_claim[cl]);
+                last_claim[cl] = claim;
+                double gate = claim + load, local_wait = gate;
+                const int npred = (it.batch_npred >> 16) & 0xF;
+                if ((it.batch_npred >> 24) & 1) { for (size_t q = 0; q < k; ++q) if ((plan.items[cd.item_begin + q].batch_npred & 0xFFFF) < batch) gate = std::max(gate, finish[cl][q]); }
+                else for (int q = 0; q < npred; ++q) gate = std::max(gate, finish[cl][it.pred[q]]);
+                local_wait = gate;
+                for (int j = it.start; j < it.start + it.count; ++j)
+                    for (int b = 0; b < tb.info.bodies; ++b) {
+                        const int32_t r = tb.refs_soa[(size_t)b * tb.stride + j];
+                        if (r < 0 || (uint32_t)r >= kDynamicLimit || (size_t)r >= plan.shared_info.size() || plan.shared_info[r] == 0) continue;
+                        if (body_cluster[r] >= 0) gate = std::max(gate, body_finish[r] + (body_cluster[r] != (int)cl ? handoff : 0.0));
+                    }
+                waited += gate - (claim + load);
+                waited_remote += gate - local_wait;
+                const double done = gate + apply;
+                for (int j = it.start; j < it.start + it.count; ++j)
+                    for (int b = 0; b < tb.info.bodies; ++b) {
+                        const int32_t r = tb.refs_soa[(size_t)b * tb.stride + j];
+                        if (r < 0 || (uint32_t)r >= kDynamicLimit || (size_t)r >= plan.shared_info.size() || plan.shared_info[r] == 0) continue;
+                        body_finish[r] = done; body_cluster[r] = (int)cl;
+                    }
+                finish[cl][k] = done;
+                *w = done;
+                makespan = std::max(makespan, done);
+                ++items;
+            }
+        }
+    printf("model: one pass %.0f clocks, x %.0f passes at %.1f GHz = %.3f ms | mean wait per item %.0f clocks, of which for another cluster %.0f\n", makespan, passes, ghz,
+           makespan * passes / (ghz * 1e6), waited / items, waited_remote / items);
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: plan_harness scene.bin [repeats]\n"); return 2; }
     const int repeats = argc > 2 ? atoi(argv[2]) : 1;
@@ -70,6 +127,7 @@ int main(int argc, char** argv) {
         printf("rows %.2f ms, plan %.2f ms | enabled %d shared %d clusters %zu items %zu (max %d per cluster) max slots %d planes %d shared bodies %zu | digest %016llx\n",
                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), (int)plan.enabled, (int)plan.shared, plan.clusters.size(),
                plan.items.size(), plan.max_items, plan.max_slots, plan.planes, shared, (unsigned long long)h);
+        if (getenv("PLAN_SIMULATE") && plan.enabled) simulate(c, plan);
         delete c;
     }
     return 0;
