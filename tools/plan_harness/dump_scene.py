@@ -13,7 +13,7 @@ if kind == "graph":
     scene = small_scenes.random_graph_scene(7, size or 6000, (size or 6000) * 2, sorted(t for t, i in small_scenes.TYPE_TABLE.items() if i[0] <= 2))
 else:
     from bepuphysics2_amd.hostlib import HostSimulation
-    args = {"pile": ("pile", size or 100000, 0, 0, 5), "ragdoll_tube": ("ragdoll_tube", size or 15000, 0, 0, 11), "crowd": ("ragdoll_tube", size or 15000, 1, 2, 11)}[kind]
+    args = {"pile": ("pile", size or 100000, 0, 0, 5), "ragdoll_tube": ("ragdoll_tube", size or 15000, 1, 0, 1), "crowd": ("ragdoll_tube", size or 15000, 1, 2, 11)}[kind]
     scene = HostSimulation.scene(*args).export()
 tbs = [(bi, tb) for bi, b in enumerate(scene.batches) for tb in b]
 with open(out, "wb") as f:
