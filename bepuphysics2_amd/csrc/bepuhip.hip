@@ -241,17 +241,24 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
     tb.refs_soa.assign((size_t)nb * tb.stride, -1);
     tb.prestep_soa.assign((size_t)pf * tb.stride, 0.0f);
     tb.accum_soa.assign((size_t)imf * tb.stride, 0.0f);
-    for (int i = 0; i < count; ++i) {  // AOSOA -> SoA (BundleIndexing.cs:50-60, TypeProcessor.cs:269-279)
-        const size_t bundle = (size_t)(i / W), lane = (size_t)(i % W);
+    // AOSOA -> SoA (BundleIndexing.cs:50-60, TypeProcessor.cs:269-279): a bundle holds W consecutive constraints of every field, so field f of bundle b is W
+    // consecutive words on both sides — copied as such (the last bundle only up to `count`).
+    const bool fallback_batch = batch_index == c->fallback_threshold;
+    for (int b0 = 0; b0 < count; b0 += W) {
+        const size_t bundle = (size_t)(b0 / W);
+        const int lanes = std::min(W, count - b0);
         for (int k = 0; k < nb; ++k) {
-            int32_t r = refs[bundle * nb * W + (size_t)k * W + lane];
-            // Empty lanes exist only inside the bundles of the sequential fallback batch (TypeProcessor.cs:451-560): every body slot of the lane is -1.
-            if (r < 0 && !(r == -1 && batch_index == c->fallback_threshold))
-                return fail(BEPUHIP_E_INVALID_ARGUMENT, "empty (-1) body reference inside a synchronized batch");
-            tb.refs_soa[(size_t)k * tb.stride + i] = r;
+            const int32_t* src = refs + bundle * nb * W + (size_t)k * W;
+            int32_t* dst = tb.refs_soa.data() + (size_t)k * tb.stride + b0;
+            for (int lane = 0; lane < lanes; ++lane) {
+                const int32_t r = src[lane];
+                // Empty lanes exist only inside the bundles of the sequential fallback batch (TypeProcessor.cs:451-560): every body slot of the lane is -1.
+                if (r < 0 && !(r == -1 && fallback_batch)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "empty (-1) body reference inside a synchronized batch");
+                dst[lane] = r;
+            }
         }
-        for (int f = 0; f < pf; ++f) tb.prestep_soa[(size_t)f * tb.stride + i] = prestep[bundle * pf * W + (size_t)f * W + lane];
-        for (int f = 0; f < imf; ++f) tb.accum_soa[(size_t)f * tb.stride + i] = accum[bundle * imf * W + (size_t)f * W + lane];
+        for (int f = 0; f < pf; ++f) memcpy(tb.prestep_soa.data() + (size_t)f * tb.stride + b0, prestep + bundle * pf * W + (size_t)f * W, (size_t)lanes * 4);
+        for (int f = 0; f < imf; ++f) memcpy(tb.accum_soa.data() + (size_t)f * tb.stride + b0, accum + bundle * imf * W + (size_t)f * W, (size_t)lanes * 4);
     }
     c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
     c->tbs.push_back(std::move(tb));
