@@ -467,7 +467,7 @@ static int32_t build_constraints(bepuhip_ctx* c) {
     if (words > 0) {
         HIP_TRY(hipMalloc((void**)&c->d_slab, words * 4));
         HIP_TRY(hipMalloc((void**)&c->d_slab0, words * 4));
-        std::vector<uint32_t> host(words);
+        std::unique_ptr<uint32_t[]> host(new uint32_t[words]);  // not zeroed: the four rows of every type batch tile [0, words) exactly (offsets assigned above from the same sizes)
         for (auto& tb : c->tbs) {
             if (!tb.refs_soa.empty()) memcpy(&host[tb.refs_off], tb.refs_soa.data(), tb.refs_soa.size() * 4);
             if (!tb.prestep_soa.empty()) memcpy(&host[tb.prestep_off], tb.prestep_soa.data(), tb.prestep_soa.size() * 4);
@@ -478,7 +478,7 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             std::vector<float>().swap(tb.prestep_soa);
             std::vector<float>().swap(tb.accum_soa);
         }
-        HIP_TRY(hipMemcpy(c->d_slab, host.data(), words * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_slab, host.get(), words * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_slab0, c->d_slab, words * 4, hipMemcpyDeviceToDevice));
     }
     lap("slab assembly + upload");
