@@ -1,0 +1,63 @@
+"""The host-side planner of bepuhip_end_constraints without a device (tools/plan_harness): its output is deterministic, independent of the number of planning threads,
+and the experimental cut switches do what they say. The harness includes the library's own translation unit, so this is the product's planner, not a copy."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS_DIR = os.path.join(REPO, "tools", "plan_harness")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("plan_harness")
+    exe = str(out / "plan_harness")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result", "-Wno-unused-value", "-Wno-array-bounds",
+                           "-I", os.path.join(REPO, "include"), "-o", exe, os.path.join(HARNESS_DIR, "plan_harness.hip")])
+    scenes = {}
+    for kind, size in (("pile", 9000), ("ragdoll_tube", 500), ("graph", 800)):
+        path = str(out / f"{kind}.bin")
+        subprocess.check_call([sys.executable, os.path.join(HARNESS_DIR, "dump_scene.py"), kind, path, str(size)], stdout=subprocess.DEVNULL)
+        scenes[kind] = path
+    return exe, scenes
+
+
+def _run(exe, scene, flags=0, **env):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    out = subprocess.check_output([exe, scene, "1", str(flags)], env=e, stderr=subprocess.STDOUT).decode()
+    line = [l for l in out.splitlines() if "digest" in l][-1]
+    m = re.search(r"enabled (\d) shared (\d) clusters (\d+) items (\d+) .*shared bodies (\d+) \| digest ([0-9a-f]+)", line)
+    return {"enabled": int(m.group(1)), "shared": int(m.group(2)), "clusters": int(m.group(3)), "items": int(m.group(4)), "shared_bodies": int(m.group(5)), "digest": m.group(6)}
+
+
+def test_plan_is_deterministic_and_independent_of_the_planning_threads(harness):
+    exe, scenes = harness
+    for kind, path in scenes.items():
+        for flags in (0, 8):  # 8 = BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS
+            runs = [_run(exe, path, flags, BEPUHIP_PLAN_THREADS=threads) for threads in (1, 3, 8, 8)]
+            assert len({r["digest"] for r in runs}) == 1, (kind, flags, runs)
+            assert runs[0]["enabled"] == 1, (kind, flags, runs[0])
+    assert _run(exe, scenes["ragdoll_tube"], 0)["digest"] != _run(exe, scenes["ragdoll_tube"], 8)["digest"]  # reserved slots change a whole-island layout ...
+    assert _run(exe, scenes["pile"], 0)["digest"] == _run(exe, scenes["pile"], 8)["digest"]  # ... and are not planned for split islands (their updates leave the schedule)
+
+
+def test_one_connected_pile_is_cut_and_the_cut_switches_reduce_the_shared_bodies(harness):
+    exe, scenes = harness
+    default = _run(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24)
+    assert default["shared"] == 1 and default["clusters"] > 1 and default["shared_bodies"] > 0
+    cover = _run(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24, BEPUHIP_SPLIT_COVER=1)
+    refined = _run(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24, BEPUHIP_SPLIT_COVER=1, BEPUHIP_SPLIT_REFINE=2)
+    assert cover["enabled"] == refined["enabled"] == 1
+    assert refined["shared_bodies"] <= cover["shared_bodies"] < default["shared_bodies"]
+    assert _run(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24, BEPUHIP_SPLIT_COVER=0, BEPUHIP_SPLIT_REFINE=0)["digest"] == default["digest"]  # off = the default plan
+    assert _run(exe, scenes["pile"], BEPUHIP_NO_SPLIT=1)["enabled"] == 0  # the launch-per-batch schedule takes the scene
+    whole = _run(exe, scenes["ragdoll_tube"])
+    assert whole["shared"] == 0 and whole["shared_bodies"] == 0  # islands that fit are never cut
