@@ -61,3 +61,31 @@ def test_one_connected_pile_is_cut_and_the_cut_switches_reduce_the_shared_bodies
     assert _run(exe, scenes["pile"], BEPUHIP_NO_SPLIT=1)["enabled"] == 0  # the launch-per-batch schedule takes the scene
     whole = _run(exe, scenes["ragdoll_tube"])
     assert whole["shared"] == 0 and whole["shared_bodies"] == 0  # islands that fit are never cut
+
+
+def _validate(exe, scene, flags=0, **env):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    e["PLAN_VALIDATE"] = "1"
+    r = subprocess.run([exe, scene, "1", str(flags)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert "validate:" in out, out  # the plan was enabled and checked
+    return r.returncode, out
+
+
+def test_plans_keep_the_invariants_the_device_relies_on(harness):
+    """Checked from the plan's output alone: every live row in exactly one item of its batch, local references and slot tables agree with the global references, a body at most
+    once per batch and cluster, predecessors from earlier batches, and for split plans one home per shared body, ghost slots elsewhere, ranks 0..d-1 in batch order with the
+    right degree — for the default plans, the reserved-slot layout and the experimental cuts. Three deliberate corruptions are noticed."""
+    exe, scenes = harness
+    for kind, path in scenes.items():
+        for flags in (0, 8):
+            rc, out = _validate(exe, path, flags)
+            assert rc == 0, (kind, flags, out)
+    for env in (dict(BEPUHIP_SPLIT_CLUSTERS=24), dict(BEPUHIP_SPLIT_CLUSTERS=24, BEPUHIP_SPLIT_COVER=1), dict(BEPUHIP_SPLIT_CLUSTERS=40, BEPUHIP_SPLIT_COVER=1, BEPUHIP_SPLIT_REFINE=3),
+                dict(BEPUHIP_SPLIT_CLUSTERS=24, BEPUHIP_SPLIT_SEPARATE=1)):
+        rc, out = _validate(exe, scenes["pile"], **env)
+        assert rc == 0, (env, out)
+    for mutation in (1, 2, 3):
+        rc, out = _validate(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24, PLAN_MUTATE=mutation)
+        assert rc == 3 and "plan violation" in out, (mutation, out)

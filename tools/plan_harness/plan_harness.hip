@@ -79,6 +79,97 @@ static void simulate(bepuhip_ctx* c, const ClusterPlan& plan) {
            makespan * passes / (ghz * 1e6), waited / items, waited_remote / items);
 }
 
+// PLAN_VALIDATE=1: invariants the device relies on, checked from the plan's OUTPUT alone (the rows, the packed local references, the rank rows, the slot tables, the items).
+// Returns the number of violations (printed, first few).
+static int validate(bepuhip_ctx* c, const ClusterPlan& plan) {
+    int bad = 0;
+    auto fail = [&](const char* what, long a, long b, long d) { if (bad++ < 12) fprintf(stderr, "plan violation: %s (%ld, %ld, %ld)\n", what, a, b, d); };
+    const size_t universe = plan.shared ? plan.shared_info.size() : (size_t)c->referenced_bodies;
+    // every live row of every type batch is covered by exactly one item, and that item belongs to the row's batch
+    std::vector<std::vector<uint8_t>> covered(c->tbs.size());
+    for (size_t t = 0; t < c->tbs.size(); ++t) covered[t].assign((size_t)std::max(c->tbs[t].slots, c->tbs[t].count), 0);
+    struct Application { int batch, cluster, rank, degree; };
+    std::vector<std::vector<Application>> applications(plan.shared ? universe : 0);
+    for (size_t cl = 0; cl < plan.clusters.size(); ++cl) {
+        const ClusterDesc& cd = plan.clusters[cl];
+        const int32_t* slots = plan.cluster_bodies.data() + cd.body_begin;
+        int previous_batch = -1;
+        std::vector<int> last_batch_of_slot(cd.slot_count, -1);
+        for (int k = 0; k < cd.item_count; ++k) {
+            const ClusterItem& it = plan.items[cd.item_begin + k];
+            const HostTypeBatch& tb = c->tbs[it.tb];
+            const int batch = it.batch_npred & 0xFFFF, nb = tb.info.bodies, rows = (nb + 1) / 2;
+            if (batch < previous_batch) fail("items out of batch order", (long)cl, k, batch);
+            previous_batch = batch;
+            if (batch != tb.batch || it.type_id != tb.type_id || it.stride != tb.stride || it.count < 1 || it.count > 64) fail("item header", (long)cl, k, it.tb);
+            const int npred = (it.batch_npred >> 16) & 0xF, nxpred = (it.batch_npred >> 20) & 0xF;
+            for (int q = 0; q < npred; ++q)
+                if (it.pred[q] >= k || (plan.items[cd.item_begin + it.pred[q]].batch_npred & 0xFFFF) >= batch) fail("predecessor is not an earlier batch's item", (long)cl, k, it.pred[q]);
+            for (int q = 0; q < nxpred; ++q) if (it.xpred[q] >= cd.item_count) fail("cross-pass predecessor out of range", (long)cl, k, it.xpred[q]);
+            for (int j = it.start; j < it.start + it.count; ++j) {
+                if ((size_t)j >= covered[it.tb].size()) { fail("item row out of range", (long)cl, k, j); continue; }
+                if (covered[it.tb][j]++) fail("row covered twice", it.tb, j, 0);
+                const bool live = tb.perm.empty() || (j < (int)tb.perm.size() && tb.perm[j] >= 0);
+                for (int b = 0; b < nb; ++b) {
+                    const uint32_t word = (uint32_t)tb.lrefs_soa[(size_t)(b / 2) * tb.stride + j];
+                    const uint32_t half = (word >> (16 * (b & 1))) & 0xFFFFu;
+                    const int32_t r = tb.refs_soa[(size_t)b * tb.stride + j];
+                    if (!live) { if (half != 0x8000u) fail("free slot is not the dead reference", it.tb, j, (long)half); continue; }
+                    const int slot = (int)(half & 0x3FFFu);
+                    const bool kinematic = (half & 0x8000u) != 0, shared_ref = (half & kLrefShared) != 0;
+                    if (slot >= cd.slot_count) { fail("local reference beyond the cluster's slots", (long)cl, k, slot); continue; }
+                    const int32_t entry = slots[slot];
+                    if (entry < 0 || (entry & kSlotBodyMask) != (r & kRefMask)) fail("slot table and global reference disagree", (long)cl, slot, r & kRefMask);
+                    if (kinematic != ((uint32_t)r >= kDynamicLimit) || kinematic != ((entry & kSlotKinematic) != 0)) fail("kinematic marking", (long)cl, slot, r);
+                    if (kinematic) continue;
+                    if (last_batch_of_slot[slot] == batch) fail("a body twice in one batch of a cluster", (long)cl, slot, batch);
+                    last_batch_of_slot[slot] = batch;
+                    if (plan.shared) {
+                        const bool is_shared = plan.shared_info[r] != 0;
+                        if (shared_ref != is_shared) fail("shared bit of a local reference", (long)cl, r, (long)half);
+                        if (((entry & kSlotGhost) != 0) != (is_shared && true && !(entry & kSlotSharedHome)) && is_shared) fail("ghost / home marking of a shared body's slot", (long)cl, r, entry);
+                        if (!is_shared && (entry & (kSlotGhost | kSlotSharedHome))) fail("private body marked ghost or shared home", (long)cl, r, entry);
+                        if (is_shared) {
+                            const uint32_t rank_word = (uint32_t)tb.lrefs_soa[(size_t)(rows + b) * tb.stride + j];
+                            applications[r].push_back({batch, (int)cl, (int)(rank_word & 0xFFu), (int)(rank_word >> 8)});
+                        }
+                    }
+                }
+            }
+        }
+    }
+    for (size_t t = 0; t < c->tbs.size(); ++t) {
+        const HostTypeBatch& tb = c->tbs[t];
+        for (int j = 0; j < (int)covered[t].size(); ++j) {
+            const bool live = tb.perm.empty() ? j < tb.count : (j < (int)tb.perm.size() && tb.perm[j] >= 0);
+            if (live && !covered[t][j]) fail("live row without an item", (long)t, j, 0);
+        }
+    }
+    if (plan.shared) {
+        std::vector<int> homes(universe, 0);
+        for (size_t cl = 0; cl < plan.clusters.size(); ++cl) {
+            const ClusterDesc& cd = plan.clusters[cl];
+            for (int s = 0; s < cd.slot_count; ++s) {
+                const int32_t entry = plan.cluster_bodies[cd.body_begin + s];
+                if (entry >= 0 && !(entry & (kSlotKinematic | kSlotGhost))) ++homes[entry & kSlotBodyMask];
+            }
+        }
+        for (size_t r = 0; r < universe; ++r) {
+            auto& apps = applications[r];
+            if (plan.shared_info[r] == 0) { if (!apps.empty()) fail("applications recorded for a private body", (long)r, 0, 0); continue; }
+            if (homes[r] != 1) fail("a shared body needs exactly one home", (long)r, homes[r], 0);
+            if (apps.size() != plan.shared_info[r]) fail("degree of a shared body", (long)r, (long)apps.size(), (long)plan.shared_info[r]);
+            std::sort(apps.begin(), apps.end(), [](const Application& x, const Application& y) { return x.rank < y.rank; });
+            for (size_t q = 0; q < apps.size(); ++q) {
+                if (apps[q].rank != (int)q || apps[q].degree != (int)apps.size()) fail("rank / degree of an application", (long)r, apps[q].rank, apps[q].degree);
+                if (q > 0 && apps[q].batch <= apps[q - 1].batch) fail("ranks are not in batch order", (long)r, apps[q - 1].batch, apps[q].batch);
+            }
+        }
+    }
+    printf("validate: %d violation(s)\n", bad);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: plan_harness scene.bin [repeats]\n"); return 2; }
     const int repeats = argc > 2 ? atoi(argv[2]) : 1;
@@ -128,6 +219,17 @@ int main(int argc, char** argv) {
                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), (int)plan.enabled, (int)plan.shared, plan.clusters.size(),
                plan.items.size(), plan.max_items, plan.max_slots, plan.planes, shared, (unsigned long long)h);
         if (getenv("PLAN_SIMULATE") && plan.enabled) simulate(c, plan);
+        if (const char* mutate = getenv("PLAN_MUTATE")) {  // the validator must notice: 1 = a local reference points at the neighbouring slot, 2 = an item loses a row, 3 = a rank is bumped
+            const int kind = atoi(mutate);
+            for (auto& tb : c->tbs) {
+                if (tb.count == 0 || tb.lrefs_soa.empty()) continue;
+                if (kind == 1) tb.lrefs_soa[0] ^= 1;
+                if (kind == 3 && plan.shared) { const int rows = (tb.info.bodies + 1) / 2; for (int j = 0; j < tb.count; ++j) if (tb.lrefs_soa[(size_t)rows * tb.stride + j] >> 8) { tb.lrefs_soa[(size_t)rows * tb.stride + j] += 1; break; } }
+                break;
+            }
+            if (kind == 2 && !plan.items.empty()) plan.items[0].count -= plan.items[0].count > 1 ? 1 : 0;
+        }
+        if (getenv("PLAN_VALIDATE") && plan.enabled && validate(c, plan) != 0) return 3;
         delete c;
     }
     return 0;
