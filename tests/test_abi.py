@@ -43,3 +43,13 @@ def test_create_fails_loudly_without_gpu_or_bad_config():
         with pytest.raises(native.BepuHipError) as e:
             native.HipSolver()
         assert e.value.code == native.BEPUHIP_E_DEVICE and b"no CPU fallback" in lib.bepuhip_last_error()
+
+
+def test_every_entry_point_is_mapped_to_the_reference_in_the_integration_notes():
+    """INTEGRATION.md's table names, for every function include/bepuhip.h declares, the reference interface it replaces (or says there is none)."""
+    import re
+    header = open(os.path.join(REPO, "include", "bepuhip.h")).read()
+    notes = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(bepuhip_[a-z_0-9]+)\s*\(", header)))
+    assert len(names) > 40
+    assert [n for n in names if n not in notes] == []
