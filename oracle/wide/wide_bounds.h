@@ -1,4 +1,4 @@
-// oracle/wide — TEST INFRASTRUCTURE. PoseIntegrator.PredictBoundingBoxes with the BoundingBoxBatcher, transcribed from the C# alone like the rest of this directory
+// oracle/wide — TEST INFRASTRUCTURE (parity unpinned: no run of the reference behind it). PoseIntegrator.PredictBoundingBoxes with the BoundingBoxBatcher, transcribed from the C# alone like the rest of this directory
 // (no text shared with oracle/bepu_bounds.h or the device's bepu_device_bounds.h): bodies walked in bundles of Vector<float>.Count, the velocity callback on the bundle,
 // collidables accumulated per shape type and flushed sixteen at a time, TShapeWide.GetBounds on eight shapes at once, compound children re-entering the batcher as convex
 // shapes with a merge continuation, meshes through the scalar path. Included by wide_solver.cpp after Bodies and PoseIntegratorCallbacks.

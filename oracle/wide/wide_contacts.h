@@ -1,4 +1,4 @@
-// oracle/wide — TEST INFRASTRUCTURE. Convex contact constraints, transcribed bundle-for-bundle from
+// oracle/wide — TEST INFRASTRUCTURE (parity unpinned, see wide_vec.h). Convex contact constraints, transcribed bundle-for-bundle from
 // BepuPhysics/Constraints/Contact/*.cs. The reference generates Contact2/3/4 from a T4 template (ContactConvexTypes.tt); here the same
 // template is a C++ template over the contact count, with the reference's own special cases kept: Contact1 (no friction centre, no 1/N,
 // twist lever arm = depth, ContactConvexTypes.cs:303-328,952-979) and the per-count ComputeFrictionCenter overloads (:124-196).

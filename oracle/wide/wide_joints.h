@@ -1,4 +1,4 @@
-// oracle/wide — TEST INFRASTRUCTURE. The joint constraint functions of SURVEY.md 8(a) rows a8-a13, transcribed bundle-for-bundle from
+// oracle/wide — TEST INFRASTRUCTURE (parity unpinned, see wide_vec.h). The joint constraint functions of SURVEY.md 8(a) rows a8-a13, transcribed bundle-for-bundle from
 // BepuPhysics/Constraints/*.cs (file:line cited per function). Statement order and association follow the C#.
 #pragma once
 #include "wide_math.h"

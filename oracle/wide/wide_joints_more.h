@@ -1,4 +1,4 @@
-// oracle/wide — TEST INFRASTRUCTURE. Constraint types beyond the sixteen of SURVEY.md 8(a), transcribed from the C# alone like the rest of this directory
+// oracle/wide — TEST INFRASTRUCTURE (parity unpinned: no run of the reference behind it). Constraint types beyond the sixteen of SURVEY.md 8(a), transcribed from the C# alone like the rest of this directory
 // (the widened set gets its second, independent reading one type at a time).
 #pragma once
 #include "wide_joints.h"

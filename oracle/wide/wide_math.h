@@ -1,4 +1,4 @@
-// oracle/wide — TEST INFRASTRUCTURE. BepuUtilities' *Wide math, transcribed bundle-for-bundle from the C# (file:line cited per type).
+// oracle/wide — TEST INFRASTRUCTURE (parity unpinned, see wide_vec.h). BepuUtilities' *Wide math, transcribed bundle-for-bundle from the C# (file:line cited per type).
 // `in` parameters are const references and `out`/`ref` parameters references, so argument aliasing behaves as in the C#.
 #pragma once
 #include "wide_vec.h"

@@ -1,4 +1,4 @@
-// oracle/wide — TEST INFRASTRUCTURE (checker + bench.py's cpu_baseline leg); nothing under bepuphysics2_amd/ may use it.
+// oracle/wide — TEST INFRASTRUCTURE (checker + bench.py's cpu_baseline leg); nothing under bepuphysics2_amd/ may use it. Parity unpinned (see wide_vec.h).
 //
 // The reference's CPU solver path restated in its own shape: AOSOA bundles of Vector<float>.Count = 8 lanes, AVX 8x8 transposes for the body
 // gather/scatter (BepuPhysics/Bodies_GatherScatter.cs:267-753), integration fused into the first warm start that touches a body through the

@@ -1,4 +1,5 @@
-// oracle/wide — TEST INFRASTRUCTURE (checker + cpu_baseline leg of bench.py), never part of the product path.
+// oracle/wide — TEST INFRASTRUCTURE (checker + cpu_baseline leg of bench.py), never part of the product path. PARITY UNPINNED like oracle/: the reference cannot be
+// built or run here and holds no golden vectors for this path; what this directory adds is a second, independent reading.
 //
 // A second, independent CPU restatement of the reference's solver hot path, transcribed from the C# ONLY (it shares no text with
 // oracle/bepu_*.h or the device headers; whoever edits this directory should keep it that way — its value is that a misreading of
