@@ -37,50 +37,106 @@ def build_scene(ragdolls: int, seed: int):
     return scene, sd
 
 
-def cpu_baseline(ragdolls_sample: int, seed: int, target_seconds: float = 12.0):
+def cpu_baseline(ragdolls_sample: int, seed: int, target_seconds: float = 14.0):
     """cpu_baseline leg: oracle/wide — the reference's CPU path restated in its own shape (AOSOA bundles of 8 lanes, AVX2 8x8
     transposed gather/scatter, fused first-touch integration, the work-block / claim / sync-stage scheduler of Solver_Solve.cs:297-946) — on the
-    host cores, bounded sample of the same workload. kind "port-simd8": a C++ port, not the RyuJIT binary (no .NET in the image)."""
+    host cores, bounded sample of the same workload. kind "port-simd8": a C++ port, not the RyuJIT binary (no .NET in the image).
+
+    The scene lives in a persistent session (oracle/wide/wide_solver.cpp `Session`): 128-byte aligned buffers owned by the library, the batches' handle sets built
+    once — as the reference holds a simulation between frames (BufferPool.cs:42, Solver.cs:1046-1051). The timed region is exactly Simulation.Solve
+    (Simulation.cs:278-290): PrepareConstraintIntegrationResponsibilities + Solve + IntegrateAfterSubstepping. No marshalling, no copies, no rebuilds inside it."""
     import wide_ffi
     from bepuphysics2_amd.scene import PoseIntegratorCallbacks
     scene, sd = build_scene(ragdolls_sample, seed)
     cb = PoseIntegratorCallbacks()
     per_frame = scene.constraint_count * int((1 + sd.iterations()).sum())
-    # Pick the thread count that is fastest on this host (the sync-stage-per-batch scheme stops scaling well before 256 threads).
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    candidates = sorted({c for c in (1, 4, 8, 16, 32, 48, 64, 96, 128, 192, avail) if c <= avail and (c >= 8 or avail < 8)})
-    best, best_t, single = candidates[0], float("inf"), None
-    for c in [1] + [c for c in candidates if c != 1]:
-        probe = scene.copy()
-        wide_ffi.solve(probe, 1 / 60, sd, cb, threads=c, fast=True)  # untimed: the worker pool starts, pages are touched
-        t = float("inf")
-        for _ in range(2):
-            t0 = time.perf_counter()
-            wide_ffi.solve(probe, 1 / 60, sd, cb, threads=c, fast=True)
-            t = min(t, time.perf_counter() - t0)
-        if c == 1:
-            single = per_frame / t
-            if 1 not in candidates:
-                continue
-        if t < best_t:
-            best, best_t = c, t
-        if t > 2 * best_t:
-            break
-    cores = best
+    session = wide_ffi.Session(scene, 1 / 60, sd, cb, fast=True)
+    curve = []
+    budget_each = target_seconds / 8.0
+    for c in [c for c in (1, 8, 16, 32, 64, 128) if c <= avail] or [1]:
+        session.solve(1, c)  # untimed: the worker pool starts, pages are touched
+        frames, t0, phases = 0, time.perf_counter(), [0.0, 0.0, 0.0]
+        while True:
+            ph = session.solve(1, c)
+            phases = [a + b for a, b in zip(phases, ph)]
+            frames += 1
+            el = time.perf_counter() - t0
+            if (el >= budget_each and frames >= 2) or frames >= 200:
+                break
+        curve.append({"threads": c, "value": per_frame * frames / el, "ms_per_frame": 1e3 * el / frames,
+                      "phase_ms": {"prepare_integration_responsibilities": 1e3 * phases[0] / frames, "solve": 1e3 * phases[1] / frames,
+                                   "integrate_after_substepping": 1e3 * phases[2] / frames}})
+    single = curve[0]["value"]
+    for e in curve:
+        e["parallel_efficiency"] = e["value"] / (single * e["threads"])
+    best = max(curve, key=lambda e: e["value"])
+    # the reported figure: a longer run at the best thread count
     frames, t0 = 0, time.perf_counter()
     while True:
-        wide_ffi.solve(scene, 1 / 60, sd, cb, threads=cores, fast=True)
+        session.solve(1, best["threads"])
         frames += 1
         el = time.perf_counter() - t0
-        if el >= target_seconds or frames >= 400:
+        if el >= target_seconds / 4.0 or frames >= 400:
             break
-    return {"value": per_frame * frames / el, "unit": "constraint-iterations/s", "cores": cores, "kind": "port-simd8", "single_thread_value": single,
-            "sample": f"{ragdolls_sample} ragdolls ({scene.constraint_count} constraints), {frames} frames, 4 substeps x 1 iteration, "
-                      f"oracle/wide (C++ AOSOA-8 AVX2 transcription of the reference's CPU path, -O3 -mavx2, no FMA contraction), reference work-block/sync-stage "
-                      f"threading, best of thread counts {candidates} on {avail} available CPUs"}
+    session.close()
+    return {"value": max(per_frame * frames / el, best["value"]), "unit": "constraint-iterations/s", "cores": best["threads"], "kind": "port-simd8",
+            "single_thread_value": single, "thread_curve": curve, "host_cpus_available": avail,
+            "timed_region": "PrepareConstraintIntegrationResponsibilities + Solve + IntegrateAfterSubstepping on a persistent session (aligned library-owned buffers, "
+                            "handle sets built at creation): Simulation.cs:278-290, nothing else",
+            "sample": f"{ragdolls_sample} ragdolls ({scene.constraint_count} constraints), {frames} frames at {best['threads']} threads after a 1/8/16/32/64/128-thread curve, "
+                      f"4 substeps x 1 iteration, oracle/wide (C++ AOSOA-8 AVX2 transcription of the reference's CPU path, -O3 -mavx2, no FMA contraction), reference "
+                      f"work-block/sync-stage threading, {avail} CPUs available"}
 
 
-def connected_scene_leg(name: str, scene_args, device: int, steps: int = 100):
+def connected_scene_args(key: str, ragdolls: int):
+    return {"pile": ("pile", 100000, 0, 0, 5), "crowd": ("ragdoll_tube", ragdolls, 1, 2, 5)}[key]
+
+
+def hbm_roofline(kernel: str, launch_us: float, traffic_bytes, algorithmic_bytes: float, stream_bytes=None, **extra):
+    """The `roofline` object of the bench line. `frac` is a bandwidth fraction and nothing else: HBM bytes the PMC counters saw per launch (`traffic`) / launch time /
+    peak — at most 1 by construction. The SURVEY 8d algorithmic figure (every body gather/scatter of every constraint counted as if it went to HBM) rides beside it
+    under algorithmic_*: the island schedules serve body gathers from LDS, so that figure can exceed the peak and is NOT a bandwidth fraction. Without counters
+    (N > 1, --no-traffic, no rocprofv3) `achieved` falls back to the compulsory-stream model and says so in `basis`."""
+    seconds = launch_us * 1e-6
+    basis = "pmc"
+    moved = traffic_bytes
+    if not moved:
+        moved, basis = stream_bytes, "memory_stream_model (no PMC counters in this run)"
+    achieved = moved / seconds / 1e9 if moved else None
+    out = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
+           "traffic": traffic_bytes, "basis": basis, "avg_launch_us": launch_us,
+           "algorithmic_bytes_per_launch": algorithmic_bytes, "algorithmic_GBs": algorithmic_bytes / seconds / 1e9,
+           "algorithmic_frac_of_peak": algorithmic_bytes / seconds / 1e9 / HBM_PEAK_GBS,
+           "algorithmic_note": "SURVEY 8d bytes (per-type figures x constraint-iterations + integration passes); counts body gathers the island schedules serve from LDS, "
+                               "so it may exceed the HBM peak — reported for comparison with the survey, not as a bandwidth fraction"}
+    if stream_bytes:
+        out["memory_stream_bytes_per_launch"] = stream_bytes
+        out["memory_stream_GBs"] = stream_bytes / seconds / 1e9
+        out["traffic_over_compulsory_stream"] = traffic_bytes / stream_bytes if traffic_bytes else None
+    out.update(extra)
+    return out
+
+
+def compulsory_stream_bytes(scene, sd):
+    """What a whole-step launch of the island schedule has to move through HBM at least: every body in and out once, the constraint rows once per pass."""
+    from bepuphysics2_amd.scene import TYPE_TABLE
+    its = sd.iterations()
+    stream_bytes = 2 * 128 * scene.body_count
+    for batch in scene.batches:
+        for tb in batch:
+            nb, pf, imf, _name = TYPE_TABLE[tb.type_id]
+            refs = (nb + 1) // 2  # the island schedule reads body references as 16-bit halves, two per word
+            reads = (refs + pf + imf) * 4 * (sd.substep_count + int(its.sum()))
+            writes = imf * 4 * int(its.sum())
+            if _name.startswith("Contact"):
+                reads += (refs + pf) * 4 * (sd.substep_count - 1)
+                writes += int(_name[7]) * 4 * (sd.substep_count - 1)
+            stream_bytes += (reads + writes) * tb.count
+    return stream_bytes
+
+
+def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, steps: int = 100, traffic_args=None):
     """A scene that is ONE island (no workgroup's LDS holds it): the general-topology schedule (one launch per batch per stage, hipGraph replay).
     Extra keys on the bench line, never `value`: the pile is BASELINE.json configs[1]; the crowd is configs[2]'s ragdolls lying on each other, as the
     reference's benchmark ends up (RagdollTubeBenchmark.cs:536-569). Roofline: SURVEY.md 8d algorithmic bytes of a step / time of a step."""
@@ -88,7 +144,7 @@ def connected_scene_leg(name: str, scene_args, device: int, steps: int = 100):
     from bepuphysics2_amd.native import HipSolver
     from bepuphysics2_amd.roofline import INTEGRATE_BYTES_PER_BODY, FINAL_BYTES_PER_BODY, scene_stage_bytes
     from bepuphysics2_amd.scene import PoseIntegratorCallbacks
-    sim = HostSimulation.scene(*scene_args)
+    sim = HostSimulation.scene(*connected_scene_args(scene_key, ragdolls))
     scene, sd = sim.export(), sim.solve_description()
     sim.close()
     cb = PoseIntegratorCallbacks()
@@ -117,13 +173,15 @@ def connected_scene_leg(name: str, scene_args, device: int, steps: int = 100):
                   + FINAL_BYTES_PER_BODY * scene.body_count)
     per_step = scene.constraint_count * int((1 + its).sum())
     launches = sd.substep_count * (2 + len(scene.batches) * 1) + len(scene.batches) * int(its.sum()) + 1
-    gbs = step_bytes / (ms * 1e-3) / 1e9
+    detail = measure_traffic(traffic_args, scene_key) if (traffic_args is not None and clustered) else None
+    traffic = detail.get("bytes_per_launch") if isinstance(detail, dict) else None
     return {"workload": f"{name}: {scene.body_count} bodies, {scene.constraint_count} constraints, {len(scene.batches)} batches, ONE island, "
                         f"{sd.substep_count} substeps x {list(map(int, its))} iterations",
             "ms_per_step": ms, "value": per_step / (ms * 1e-3), "unit": "constraint-iterations/s",
-            "schedule": "island-per-workgroup" if clustered else f"launch-per-batch, hipGraph replay, {launches} launches per step",
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": step_bytes,
-                         "us_per_launch": 1e3 * ms / launches},
+            "schedule": "island-per-workgroup, split-island plan (one launch per step)" if clustered else f"launch-per-batch, hipGraph replay, {launches} launches per step",
+            "roofline": hbm_roofline("cluster_kernel<...,SHARED> (whole step in one launch)" if clustered else "whole step (launch-per-batch)", 1e3 * ms if clustered else 1e3 * ms,
+                                     traffic, step_bytes, compulsory_stream_bytes(scene, sd) if clustered else None, traffic_detail=detail,
+                                     launch_time_basis="wall time per step (one launch per step)" if clustered else f"whole step, {launches} launches"),
             "upload_ms": upload_ms, "finite": finite}
 
 
@@ -229,7 +287,7 @@ def lattice_leg(device: int, ragdolls: int = 2000, world: int = 2, frames: int =
         return {"error": str(e)[:300]}
 
 
-def measure_traffic(args):
+def measure_traffic(args, scene_key: str = "main"):
     """HBM bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md's HBM section prescribes: separate
     rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE (they do not fit one pass), counters in KiB, and the gfx950 correction (FETCH_SIZE
     reports half of a wide coalesced read stream: doubled here; WRITE_SIZE is uncalibrated and reported as is). Returns None when rocprofv3
@@ -248,7 +306,7 @@ def measure_traffic(args):
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BEPU_BENCH_FORCE_DIST")}
             env["TMPDIR"] = "/tmp"
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "3", "--warmup", "1", "--ragdolls", str(args.ragdolls), "--no-cpu-baseline", "--no-traffic", "--no-prewarm", "--traffic-child"]
+                   "--steps", "3", "--warmup", "1", "--ragdolls", str(args.ragdolls), "--no-cpu-baseline", "--no-traffic", "--no-prewarm", "--traffic-child", scene_key]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             per_kernel = {}
@@ -270,6 +328,26 @@ def measure_traffic(args):
                 "kernel": out["FETCH_SIZE"]["kernel"], "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950)"}
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)[:200]}
+
+
+def traffic_child(args, device: int):
+    """What the rocprofv3 --pmc passes of measure_traffic run: a few solves of one scene, nothing else (no torch, no timing)."""
+    from bepuphysics2_amd.hostlib import HostSimulation
+    from bepuphysics2_amd.native import HipSolver
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    if args.traffic_child == "main":
+        scene, sd = build_scene(args.ragdolls, 5)
+    else:
+        sim = HostSimulation.scene(*connected_scene_args(args.traffic_child, args.ragdolls))
+        scene, sd = sim.export(), sim.solve_description()
+        sim.close()
+    solver = HipSolver(device=device)
+    solver.upload(scene)
+    cb = PoseIntegratorCallbacks()
+    for _ in range(args.warmup + args.steps):
+        solver.solve(1.0 / 60.0, sd, cb, asynchronous=True)
+    solver.sync()
+    solver.close()
 
 
 def run_lattice(args, rank, local_rank, world, dist, torch):
@@ -355,7 +433,7 @@ def main():
     ap.add_argument("--lattice-exact", action="store_true", help="with --lattice: the per-batch exact exchange mode (bit-identical to one GPU) instead of per-pass block-Jacobi")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the clock pre-warm of the setup phase (300 untimed solves, state restored afterwards)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE child runs behind roofline.traffic")
-    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--traffic-child", default=None, choices=["main", "pile", "crowd"], help=argparse.SUPPRESS)
     ap.add_argument("--no-connected-scenes", action="store_true", help="skip the extra legs on connected scenes (100k-box pile = configs[1]; ragdoll crowd)")
     args = ap.parse_args()
 
@@ -364,6 +442,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+
+    if args.traffic_child:
+        return traffic_child(args, local_rank)
 
     import torch
     dist = None
@@ -459,31 +540,14 @@ def main():
             # constraint-iterations of the step and its algorithmic bytes are the whole step's (SURVEY.md 8d figure x units).
             ms, n = agg["cluster"]
             avg_us = 1e3 * ms / n
-            achieved = step_bytes / (avg_us * 1e-6) / 1e9
             cyc = solver.cluster_cycles()
-            # what the launch really has to move through HBM/MALL: every body in and out once, the constraint stream once per pass
-            stream_bytes = 2 * 128 * scene.body_count
-            for batch in scene.batches:
-                for tb in batch:
-                    _, pf, imf, _name = TYPE_TABLE[tb.type_id]
-                    nb = TYPE_TABLE[tb.type_id][0]
-                    refs = (nb + 1) // 2  # the island schedule reads body references as 16-bit halves, two per word
-                    reads = (refs + pf + imf) * 4 * (sd.substep_count + int(its.sum()))
-                    writes = imf * 4 * int(its.sum())
-                    if _name.startswith("Contact"):
-                        reads += (refs + pf) * 4 * (sd.substep_count - 1)
-                        writes += int(_name[7]) * 4 * (sd.substep_count - 1)
-                    stream_bytes += (reads + writes) * tb.count
-            roofline = {"bound": "hbm", "kernel": "cluster_kernel (whole substep loop of a step in one launch)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_us, "launches": n,
-                        "algorithmic_bytes_per_launch": step_bytes,
-                        "note": "algorithmic bytes count every body gather/scatter of every constraint (SURVEY 8d); the kernel keeps bodies in LDS, so frac may exceed "
-                                "what HBM could deliver; memory_stream_* is what the launch actually has to move",
-                        "memory_stream_bytes_per_launch": stream_bytes, "memory_stream_GBs": stream_bytes / (avg_us * 1e-6) / 1e9,
-                        "memory_stream_frac_of_peak": stream_bytes / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                        "cluster_shader_kcycles_mean_max": [float(cyc.mean()) / 1e3, float(cyc.max()) / 1e3] if cyc.size else None,
-                        "effective_shader_GHz": float(cyc.max()) / (avg_us * 1e3) if cyc.size else None,
-                        "families_ms_per_step": families, "step_algorithmic_GBs": step_gbs}
+            detail = measure_traffic(args) if (not args.no_traffic and world == 1) else None  # the PMC child runs are an N=1 leg
+            traffic = detail.get("bytes_per_launch") if isinstance(detail, dict) else None
+            roofline = hbm_roofline("cluster_kernel (whole substep loop of a step in one launch)", avg_us, traffic, step_bytes, compulsory_stream_bytes(scene, sd),
+                                    launches=n, traffic_detail=detail,
+                                    cluster_shader_kcycles_mean_max=[float(cyc.mean()) / 1e3, float(cyc.max()) / 1e3] if cyc.size else None,
+                                    effective_shader_GHz=float(cyc.max()) / (avg_us * 1e3) if cyc.size else None,
+                                    families_ms_per_step=families, step_algorithmic_GBs=step_gbs)
         else:
             solve_passes = int(its.sum()) * prof_steps
             ws_passes = sd.substep_count * prof_steps
@@ -499,11 +563,15 @@ def main():
                         "algorithmic_bytes_per_launch": fam[dom]["algorithmic_bytes_per_launch"],
                         "families_ms_per_step": families, "other": fam["warmstart" if dom == "solve" else "solve"],
                         "step_algorithmic_GBs": step_gbs}
-        if roofline is not None and not args.no_traffic and world == 1:  # the PMC child runs and the CPU baseline are N=1 legs
+        if roofline is not None and "traffic_detail" not in roofline and not args.no_traffic and world == 1:  # launch-per-batch: counters of the dominant batch kernel
             detail = measure_traffic(args)
-            # `traffic` is the number the contract asks for (HBM bytes per launch of the dominant kernel, PMC counters); how it was obtained rides beside it
             roofline["traffic"] = detail.get("bytes_per_launch") if isinstance(detail, dict) else None
             roofline["traffic_detail"] = detail
+            if roofline["traffic"]:  # same rule as the island schedule: frac is the counters' bandwidth fraction, the algorithmic figure keeps its own keys
+                roofline["algorithmic_GBs"], roofline["algorithmic_frac_of_peak"] = roofline["achieved"], roofline["frac"]
+                roofline["achieved"] = roofline["traffic"] / (roofline["avg_launch_us"] * 1e-6) / 1e9
+                roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+                roofline["basis"] = "pmc"
 
     baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -514,9 +582,10 @@ def main():
     connected = None
     if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
         solver.close()
-        connected = {"pile_100k": connected_scene_leg("100k-box pile (BASELINE.json configs[1])", ("pile", 100000, 0, 0, 5), local_rank),
+        targs = None if args.no_traffic else args
+        connected = {"pile_100k": connected_scene_leg("100k-box pile (BASELINE.json configs[1])", "pile", args.ragdolls, local_rank, traffic_args=targs),
                      "ragdoll_crowd": connected_scene_leg(f"{args.ragdolls} ragdolls in contact with their neighbours (configs[2]'s ragdolls, one island)",
-                                                          ("ragdoll_tube", args.ragdolls, 1, 2, 5), local_rank)}
+                                                          "crowd", args.ragdolls, local_rank, traffic_args=targs)}
 
     boundary = None
     lattice_report = None

@@ -7,6 +7,7 @@
 //
 // C ABI: wide_solve(scene, params) — same marshalling structs as tests/oracle_ffi.py builds (a data format, not shared code).
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -919,6 +920,21 @@ class ThreadDispatcher {
     bool stop_ = false;
 };
 
+// BepuPhysics/LocalSpinWait.cs:20-48: workers spin 1, 2, 4 pauses, then yield their time slice on every further poll ("being pretty aggressive about yielding
+// produces the best results"); the main thread never yields (Solver_Solve.cs:386-398, Thread.SpinWait(3)).
+struct LocalSpinWait {
+    int WaitCount = 0;
+    static constexpr int YieldThreshold = 3;
+    void SpinOnce() {
+        if (WaitCount >= YieldThreshold) {
+            std::this_thread::yield();
+        } else {
+            for (int i = 0; i < (1 << WaitCount); ++i) _mm_pause();
+            ++WaitCount;
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------------------ the solver (Solver_Solve.cs)
 struct ConstraintBatch { std::vector<TypeBatch> TypeBatches; };
 
@@ -1275,7 +1291,7 @@ struct Solver {
             substepContext.SyncIndex.store(syncIndex, std::memory_order_release);
             ExecuteWorkerStage(stageFunction, workerIndex, workerStart, stage.WorkBlockStartIndex, stage.Claims, stage.ClaimCount, previousSyncIndex, syncIndex,
                                substepContext.CompletedWorkBlockCount);
-            while (substepContext.CompletedWorkBlockCount.load(std::memory_order_acquire) != availableBlocksCount) _mm_pause();
+            while (substepContext.CompletedWorkBlockCount.load(std::memory_order_acquire) != availableBlocksCount) { _mm_pause(); _mm_pause(); _mm_pause(); }  // Thread.SpinWait(3), :395-398
             substepContext.CompletedWorkBlockCount.store(0, std::memory_order_relaxed);
         }
     }
@@ -1377,7 +1393,8 @@ struct Solver {
             int substepIndex = 0;
             for (;;) {
                 int syncIndex;
-                while (latestCompletedSyncIndex == (syncIndex = substepContext.SyncIndex.load(std::memory_order_acquire))) _mm_pause();
+                LocalSpinWait spinWait;
+                while (latestCompletedSyncIndex == (syncIndex = substepContext.SyncIndex.load(std::memory_order_acquire))) spinWait.SpinOnce();  // :599-605
                 if (syncIndex == INT32_MIN) break;
                 int syncStepsSinceLast = syncIndex - latestCompletedSyncIndex;
                 syncIndexInSubstep += syncStepsSinceLast;
@@ -1636,9 +1653,9 @@ struct Solver {
     }
 };
 
-static void* AlignedCopy(const void* src, size_t bytes) {
+static void* AlignedCopy(const void* src, size_t bytes) {  // BufferPool blocks are 128-byte aligned (BepuUtilities/Memory/BufferPool.cs:42)
     void* p = nullptr;
-    if (posix_memalign(&p, 64, bytes ? bytes : 64) != 0) return nullptr;
+    if (posix_memalign(&p, 128, bytes ? bytes : 128) != 0) return nullptr;
     std::memcpy(p, src, bytes);
     return p;
 }
@@ -1646,26 +1663,28 @@ static void* AlignedCopy(const void* src, size_t bytes) {
 static std::mutex g_dispatcherMutex;
 static std::unique_ptr<ThreadDispatcher> g_dispatcher;
 
-static int SolveScene(SceneDesc* scene, SceneParams* params) {
-    if (scene->bundle_width != W) return 2;       // this restatement is the AVX2 host shape only; results do not depend on the width (lanes are independent)
+// A scene held the way the reference holds it between frames: bodies and type batches in 128-byte aligned memory the session owns (BufferPool.cs:42,83 — the
+// reference's buffers are always aligned and never marshalled), batchReferencedHandles maintained with the constraint set (Solver.cs:1046-1051: updated on Add /
+// Remove, not rebuilt per frame). Built once by wide_session_create; wide_session_solve then runs exactly what Simulation.Solve runs (Simulation.cs:278-290):
+// PrepareConstraintIntegrationResponsibilities, Solve, IntegrateAfterSubstepping — nothing else, so that it can be timed as the reference's frame would be.
+struct Session {
+    Solver solver;
+    struct Owned { void* aligned; void* original; size_t bytes; };
+    std::vector<Owned> owned;                       // [0] = bodies, then per type batch: references, prestep, accumulated impulses
+    std::vector<int32_t> indexToHandle, handleToIndex;
+    ~Session() {
+        for (auto& o : owned) free(o.aligned);
+    }
+    void* Own(void* p, size_t bytes) {
+        void* a = AlignedCopy(p, bytes);
+        owned.push_back({a, p, bytes});
+        return a;
+    }
+};
+
+static int ApplyParams(Solver& solver, const SceneParams* params) {
     if (params->exchange != nullptr) return 3;    // the split-lattice exchange hook belongs to oracle/, not here
     if (params->dt <= 0 || params->substep_count < 1) return 1;
-    Solver solver;
-    // BufferPool memory is 128-byte aligned in the reference (BepuUtilities/Memory/BufferPool.cs:42); numpy makes no such promise. Work on aligned copies when needed.
-    struct Staged { void* aligned; void* original; size_t bytes; };
-    std::vector<Staged> staged;
-    auto stage = [&](void* p, size_t bytes) -> void* {
-        if (p == nullptr || bytes == 0) return p;
-        if (((uintptr_t)p & 31) == 0) return p;
-        void* a = AlignedCopy(p, bytes);
-        staged.push_back({a, p, bytes});
-        return a;
-    };
-    solver.bodies.states = (float*)stage(scene->bodies, (size_t)scene->body_count * 128);
-    solver.bodies.count = scene->body_count;
-    solver.IndexToHandle = scene->index_to_handle;
-    solver.HandleToIndex = scene->handle_to_index;
-    solver.HandleCapacity = scene->handle_capacity;
     solver.Callbacks.Gravity[0] = params->gravity[0];
     solver.Callbacks.Gravity[1] = params->gravity[1];
     solver.Callbacks.Gravity[2] = params->gravity[2];
@@ -1678,9 +1697,24 @@ static int SolveScene(SceneDesc* scene, SceneParams* params) {
     solver.velocityIterations.assign(params->velocity_iterations, params->velocity_iterations + params->substep_count);
     for (int v : solver.velocityIterations)
         if (v < 1) return 1;
+    solver.FallbackBatchThreshold = params->fallback_batch_threshold > 0 ? params->fallback_batch_threshold : 64;
+    return 0;
+}
+
+static int CreateSession(SceneDesc* scene, SceneParams* params, std::unique_ptr<Session>& out) {
+    if (scene->bundle_width != W) return 2;       // this restatement is the AVX2 host shape only; results do not depend on the width (lanes are independent)
+    std::unique_ptr<Session> session(new Session);
+    Solver& solver = session->solver;
+    if (int status = ApplyParams(solver, params)) return status;
+    solver.bodies.states = (float*)session->Own(scene->bodies, (size_t)scene->body_count * 128);
+    solver.bodies.count = scene->body_count;
+    session->indexToHandle.assign(scene->index_to_handle, scene->index_to_handle + scene->body_count);
+    session->handleToIndex.assign(scene->handle_to_index, scene->handle_to_index + scene->handle_capacity);
+    solver.IndexToHandle = session->indexToHandle.data();
+    solver.HandleToIndex = session->handleToIndex.data();
+    solver.HandleCapacity = scene->handle_capacity;
     solver.TypeProcessors.resize(64);
     solver.Batches.resize(scene->batch_count);
-    solver.FallbackBatchThreshold = params->fallback_batch_threshold > 0 ? params->fallback_batch_threshold : 64;
     if (scene->batch_count > solver.FallbackBatchThreshold + 1) return 4;  // at most FallbackBatchThreshold synchronized batches + the fallback batch
     solver.batchReferencedHandles.assign(scene->batch_count, {});
     int flat = 0;
@@ -1696,9 +1730,9 @@ static int SolveScene(SceneDesc* scene, SceneParams* params) {
             typeBatch.TypeId = s.type_id;
             typeBatch.ConstraintCount = s.constraint_count;
             typeBatch.BundleCount = Solver::GetBundleCount(s.constraint_count);
-            typeBatch.BodyReferences = (VI*)stage(s.body_refs, (size_t)typeBatch.BundleCount * processor->BodiesPerConstraint * 32);
-            typeBatch.PrestepData = (VF*)stage(s.prestep, (size_t)typeBatch.BundleCount * processor->PrestepFloats * 32);
-            typeBatch.AccumulatedImpulses = (VF*)stage(s.accumulated, (size_t)typeBatch.BundleCount * processor->ImpulseFloats * 32);
+            typeBatch.BodyReferences = (VI*)session->Own(s.body_refs, (size_t)typeBatch.BundleCount * processor->BodiesPerConstraint * 32);
+            typeBatch.PrestepData = (VF*)session->Own(s.prestep, (size_t)typeBatch.BundleCount * processor->PrestepFloats * 32);
+            typeBatch.AccumulatedImpulses = (VF*)session->Own(s.accumulated, (size_t)typeBatch.BundleCount * processor->ImpulseFloats * 32);
             // batchReferencedHandles (Solver.cs:1046-1051): the handles of the DYNAMIC bodies each batch references.
             const int32_t* refs = (const int32_t*)typeBatch.BodyReferences;
             for (int c = 0; c < s.constraint_count; ++c)
@@ -1710,23 +1744,48 @@ static int SolveScene(SceneDesc* scene, SceneParams* params) {
         }
     }
     solver.ConstrainedKinematicHandles.assign(scene->constrained_kinematic_handles, scene->constrained_kinematic_handles + scene->constrained_kinematic_count);
+    out = std::move(session);
+    return 0;
+}
 
+// Simulation.Solve (Simulation.cs:278-290), `frames` times on the session's state. phase_seconds (optional, 3 doubles): the time spent in each of the three calls.
+static int SolveSession(Session& session, float dt, int threads, int frames, double* phaseSeconds) {
+    Solver& solver = session.solver;
+    if (!(dt > 0) || frames < 0) return 1;
     ThreadDispatcher* dispatcher = nullptr;
     std::unique_lock<std::mutex> dispatcherLock(g_dispatcherMutex, std::defer_lock);
-    if (params->threads > 1) {
+    if (threads > 1) {
         dispatcherLock.lock();
-        if (!g_dispatcher || g_dispatcher->ThreadCount() != params->threads) g_dispatcher.reset(new ThreadDispatcher(params->threads));
+        if (!g_dispatcher || g_dispatcher->ThreadCount() != threads) g_dispatcher.reset(new ThreadDispatcher(threads));
         dispatcher = g_dispatcher.get();
     }
-    // Simulation.Solve (Simulation.cs:278-290)
-    solver.PrepareConstraintIntegrationResponsibilities(dispatcher);
-    solver.Solve(params->dt, dispatcher);
-    solver.IntegrateAfterSubstepping(params->dt, solver.substepCount, dispatcher);
-
-    for (auto& s : staged) {
-        std::memcpy(s.original, s.aligned, s.bytes);
-        free(s.aligned);
+    using Clock = std::chrono::steady_clock;
+    double phases[3] = {0, 0, 0};
+    for (int frame = 0; frame < frames; ++frame) {
+        auto t0 = Clock::now();
+        solver.PrepareConstraintIntegrationResponsibilities(dispatcher);
+        auto t1 = Clock::now();
+        solver.Solve(dt, dispatcher);
+        auto t2 = Clock::now();
+        solver.IntegrateAfterSubstepping(dt, solver.substepCount, dispatcher);
+        auto t3 = Clock::now();
+        phases[0] += std::chrono::duration<double>(t1 - t0).count();
+        phases[1] += std::chrono::duration<double>(t2 - t1).count();
+        phases[2] += std::chrono::duration<double>(t3 - t2).count();
     }
+    if (phaseSeconds) { phaseSeconds[0] = phases[0]; phaseSeconds[1] = phases[1]; phaseSeconds[2] = phases[2]; }
+    return 0;
+}
+
+static void ReadSession(Session& session) {  // the session's state back into the buffers it was created from
+    for (auto& o : session.owned) std::memcpy(o.original, o.aligned, o.bytes);
+}
+
+static int SolveScene(SceneDesc* scene, SceneParams* params) {
+    std::unique_ptr<Session> session;
+    if (int status = CreateSession(scene, params, session)) return status;
+    if (int status = SolveSession(*session, params->dt, params->threads, 1, nullptr)) return status;
+    ReadSession(*session);
     return 0;
 }
 
@@ -1842,6 +1901,22 @@ static int PredictBoundingBoxesOfScene(const float* bodyStates, int count, const
 
 extern "C" {
 int wide_solve(wide::SceneDesc* scene, wide::SceneParams* params) { return wide::SolveScene(scene, params); }
+// The persistent form (what bench.py's cpu_baseline times): create once, solve frames in place, read back, destroy.
+void* wide_session_create(wide::SceneDesc* scene, wide::SceneParams* params, int* status) {
+    std::unique_ptr<wide::Session> session;
+    int s = wide::CreateSession(scene, params, session);
+    if (status) *status = s;
+    return s == 0 ? session.release() : nullptr;
+}
+int wide_session_solve(void* session, float dt, int threads, int frames, double* phase_seconds) {
+    return session ? wide::SolveSession(*(wide::Session*)session, dt, threads, frames, phase_seconds) : -1;
+}
+int wide_session_read(void* session) {
+    if (!session) return -1;
+    wide::ReadSession(*(wide::Session*)session);
+    return 0;
+}
+void wide_session_destroy(void* session) { delete (wide::Session*)session; }
 int wide_predict_bounding_boxes(const float* bodies, int count, const wide::SceneParams* params, const wide::CollidableRecord* collidables, wide::PredictedRecord* out,
                                 const float* hull_points, const int* hull_begin, int hull_count, const wide::CompoundChildRecord* children, const int* child_begin, int compound_count,
                                 const float* triangles, const int* triangle_begin, const float* mesh_scales, int mesh_count) {

@@ -27,6 +27,14 @@ def load(variant: str = "") -> C.CDLL:
         lib = C.CDLL(path)
         lib.wide_solve.argtypes = [C.POINTER(OracleScene), C.POINTER(OracleParams)]
         lib.wide_solve.restype = C.c_int
+        lib.wide_session_create.argtypes = [C.POINTER(OracleScene), C.POINTER(OracleParams), C.POINTER(C.c_int)]
+        lib.wide_session_create.restype = C.c_void_p
+        lib.wide_session_solve.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        lib.wide_session_solve.restype = C.c_int
+        lib.wide_session_read.argtypes = [C.c_void_p]
+        lib.wide_session_read.restype = C.c_int
+        lib.wide_session_destroy.argtypes = [C.c_void_p]
+        lib.wide_session_destroy.restype = None
         lib.wide_math_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.wide_constraint_iterate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int]
         lib.wide_constraint_iterate.restype = C.c_int
@@ -34,11 +42,7 @@ def load(variant: str = "") -> C.CDLL:
     return _libs[name]
 
 
-def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool = False, variant: str = ""):
-    """Simulation.Solve through oracle/wide, IN PLACE on ``scene``'s buffers (bundle width must be 8)."""
-    lib = load("fast" if fast else variant)
-    assert scene.bodies.flags["C_CONTIGUOUS"] and scene.bodies.dtype == np.float32
-    m = _Marshalled(scene)
+def _params(dt, solve_description, callbacks, threads):
     its = np.ascontiguousarray(solve_description.iterations(), dtype=np.int32)
     p = OracleParams()
     p.dt = float(dt)
@@ -52,9 +56,53 @@ def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool 
     p.threads = int(threads)
     p.angular_integration_mode = int(getattr(callbacks, "angular_integration_mode", 0))
     p.fallback_batch_threshold = int(solve_description.fallback_batch_threshold)
+    return p, its
+
+
+def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool = False, variant: str = ""):
+    """Simulation.Solve through oracle/wide, IN PLACE on ``scene``'s buffers (bundle width must be 8)."""
+    lib = load("fast" if fast else variant)
+    assert scene.bodies.flags["C_CONTIGUOUS"] and scene.bodies.dtype == np.float32
+    m = _Marshalled(scene)
+    p, _its = _params(dt, solve_description, callbacks, threads)
     rc = lib.wide_solve(C.byref(m.c), C.byref(p))
     if rc != 0:
         raise RuntimeError(f"wide_solve failed: {rc}")
+
+
+class Session:
+    """The scene held as the reference holds it between frames (oracle/wide/wide_solver.cpp `Session`): aligned buffers owned by the library, batch handle sets built once.
+    ``solve(frames, threads)`` runs Simulation.Solve's three calls and nothing else; ``read()`` copies the state back into ``scene``'s buffers."""
+
+    def __init__(self, scene, dt, solve_description, callbacks, fast: bool = False, variant: str = ""):
+        self.lib = load("fast" if fast else variant)
+        assert scene.bodies.flags["C_CONTIGUOUS"] and scene.bodies.dtype == np.float32
+        self._m = _Marshalled(scene)  # keeps the caller's buffers alive: read() writes into them
+        self.dt = float(dt)
+        p, self._its = _params(dt, solve_description, callbacks, 1)
+        status = C.c_int(0)
+        self.handle = self.lib.wide_session_create(C.byref(self._m.c), C.byref(p), C.byref(status))
+        if not self.handle:
+            raise RuntimeError(f"wide_session_create failed: {status.value}")
+
+    def solve(self, frames: int = 1, threads: int = 1):
+        """Returns the seconds spent in (PrepareConstraintIntegrationResponsibilities, Solve, IntegrateAfterSubstepping) over the frames."""
+        phases = (C.c_double * 3)()
+        rc = self.lib.wide_session_solve(self.handle, self.dt, int(threads), int(frames), phases)
+        if rc != 0:
+            raise RuntimeError(f"wide_session_solve failed: {rc}")
+        return tuple(phases)
+
+    def read(self):
+        self.lib.wide_session_read(self.handle)
+
+    def close(self):
+        if self.handle:
+            self.lib.wide_session_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
 
 
 def math_probe(x):
