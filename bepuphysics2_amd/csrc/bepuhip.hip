@@ -903,20 +903,27 @@ int32_t bepuhip_set_boundary_layout(bepuhip_ctx* c, const int32_t* dense_rows, i
     if (!c || dense_row_count < 0 || (c->boundary_count > 0 && !dense_rows)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad boundary layout");
     for (int i = 0; i < c->boundary_count; ++i)
         if (dense_rows[i] < 0 || dense_rows[i] >= dense_row_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "dense row out of range");
+    if (holders)
+        for (int i = 0; i < dense_row_count; ++i) if (!(holders[i] >= 1.0f)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "holder count below one");
+    // everything is validated before the context is touched; from here on a failure leaves NO layout (never a partial one: rows without holders would let the
+    // averaged mode apply un-averaged sums)
     HIP_TRY(hipSetDevice(c->device));
     free_boundary_layout(c);
-    c->dense_rows = dense_row_count;
     if (dense_row_count == 0) return BEPUHIP_OK;
-    HIP_TRY(hipMalloc((void**)&c->d_boundary_dense, (size_t)dense_row_count * 24));
-    if (c->boundary_count > 0) {
-        HIP_TRY(hipMalloc((void**)&c->d_boundary_rows, (size_t)c->boundary_count * 4));
-        HIP_TRY(hipMemcpy(c->d_boundary_rows, dense_rows, (size_t)c->boundary_count * 4, hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc((void**)&c->d_boundary_dense, (size_t)dense_row_count * 24);
+    if (e == hipSuccess && c->boundary_count > 0) {
+        e = hipMalloc((void**)&c->d_boundary_rows, (size_t)c->boundary_count * 4);
+        if (e == hipSuccess) e = hipMemcpy(c->d_boundary_rows, dense_rows, (size_t)c->boundary_count * 4, hipMemcpyHostToDevice);
     }
-    if (holders) {
-        for (int i = 0; i < dense_row_count; ++i) if (!(holders[i] >= 1.0f)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "holder count below one");
-        HIP_TRY(hipMalloc((void**)&c->d_boundary_holders, (size_t)dense_row_count * 4));
-        HIP_TRY(hipMemcpy(c->d_boundary_holders, holders, (size_t)dense_row_count * 4, hipMemcpyHostToDevice));
+    if (e == hipSuccess && holders) {
+        e = hipMalloc((void**)&c->d_boundary_holders, (size_t)dense_row_count * 4);
+        if (e == hipSuccess) e = hipMemcpy(c->d_boundary_holders, holders, (size_t)dense_row_count * 4, hipMemcpyHostToDevice);
     }
+    if (e != hipSuccess) {
+        free_boundary_layout(c);
+        return fail(BEPUHIP_E_DEVICE, std::string("set_boundary_layout: ") + hipGetErrorString(e));
+    }
+    c->dense_rows = dense_row_count;
     return BEPUHIP_OK;
 }
 
@@ -1019,6 +1026,10 @@ static int32_t run_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const i
     int32_t st = validate_solve(c, dt, substeps, iterations, in);
     if (st != BEPUHIP_OK) return st;
     if (c->clusters_enabled) return fail(BEPUHIP_E_STATE, "an exchanged solve needs a context created with BEPUHIP_FLAG_NO_CLUSTERS (a split scene is one island per rank anyway)");
+    // The fallback batch runs as one launch per dependency level of THIS share: the ranks would disagree on the number of exchange points (a hang in RCCL or in the
+    // host barrier) and, in the exact mode, on who touched a body since the last exchange (its level numbering is rank-local). Shares keep the global batch indices,
+    // so a scene whose colouring reaches the fallback threshold has to be recoloured (bepuhip_colour_constraints) or solved unsplit.
+    if (c->has_fallback) return fail(BEPUHIP_E_UNSUPPORTED, "an exchanged solve of a share that contains a sequential fallback batch: the exchange points of the ranks would not pair up");
     if (!fn && c->boundary_count > 0 && !c->d_boundary_rows) return fail(BEPUHIP_E_STATE, "bepuhip_solve_lattice needs bepuhip_set_boundary_layout after bepuhip_set_boundary_bodies");
     HIP_TRY(hipSetDevice(c->device));
     if ((st = flush_structural(c)) != BEPUHIP_OK) return st;

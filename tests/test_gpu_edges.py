@@ -196,6 +196,22 @@ def test_fallback_batch_limits_through_the_abi(hip_solver_factory):
         solver.solve(1 / 60, SolveDescription(1, 2, fallback_batch_threshold=3), PoseIntegratorCallbacks(angular_integration_mode=1))
 
 
+def test_exchanged_solve_refuses_a_share_with_a_fallback_batch(hip_solver_factory):
+    """the fallback batch runs as rank-local dependency levels, so the ranks of a split scene would issue different numbers of exchanges (a hang) and
+    the exact mode's one-toucher-per-exchange premise would not hold. The library refuses instead of running it."""
+    from bepuphysics2_amd import native
+    scene = small_scenes.star_scene(4, spokes=25, hubs=2, fallback_batch_threshold=3)
+    sd, cb = SolveDescription(1, 2, fallback_batch_threshold=3), PoseIntegratorCallbacks()
+    solver = hip_solver_factory(use_clusters=False)
+    solver.upload(scene.copy(), 3)
+    solver.set_boundary_bodies(np.zeros(0, dtype=np.int32))
+    calls = []
+    with pytest.raises(native.UnsupportedError):
+        solver.solve_exchanged(1 / 60, sd, cb, lambda s_, p_: calls.append((s_, p_)))
+    assert not calls
+    solver.solve(1 / 60, sd, cb)  # the plain solve of the same context still runs it (dependency levels)
+
+
 def test_row_policy_is_measured_and_never_changes_a_result(hip_solver_factory, monkeypatch):
     """The island schedule's two row-access builds (plain / non-temporal) are bit-identical: while the first twelve solves alternate between them the
     frames still match the oracle, the policy is settled afterwards, pinning either one gives the same bytes, and a new upload measures again."""

@@ -221,8 +221,9 @@ def test_long_run_stays_bit_exact(hip_solver_factory, use_clusters):
 
 
 def test_full_size_pile_against_oracle(hip_solver_factory):
-    """BASELINE.json configs[1] at its full size (100,000 boxes, 295,710 Contact1-4 constraints in ONE island, 4 substeps x 2 iterations):
-    the launch-per-batch schedule (the only one a single island allows) against the oracle, bit for bit, two frames."""
+    """BASELINE.json configs[1] at its full size (100,000 boxes, 295,710 Contact1-4 constraints in ONE island, 4 substeps x 2 iterations), exactly the scene of
+    bench.py's pile_100k leg: the split-island plan (DESIGN.md 3.4 — asserted: more than one cluster ran it, so a plan that silently declined cannot pass on the
+    launch-per-batch schedule) against the oracle, bit for bit, two frames."""
     from bepuphysics2_amd.hostlib import HostSimulation
     sim = HostSimulation.scene("pile", 100000, 0, 0, 5)
     scene, sd = sim.export(), sim.solve_description()
@@ -230,7 +231,28 @@ def test_full_size_pile_against_oracle(hip_solver_factory):
     assert scene.constraint_count > 290000 and sd.substep_count == 4 and list(sd.iterations()) == [2, 2, 2, 2]
     cb = PoseIntegratorCallbacks()
     ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=8)
-    got = pu.run_hip(hip_solver_factory(), scene, 1 / 60, sd, cb, frames=2)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+    assert solver.cluster_cycles().size > 1, "the full-size pile must run on the split-island plan it is benchmarked on"
+    m = pu.compare_scenes(ref, got)
+    _check(m)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    assert np.isfinite(got.bodies).all()
+
+
+def test_full_size_crowd_against_oracle(hip_solver_factory):
+    """The ragdoll_crowd leg of bench.py at its full size — 15,000 ragdolls with ragdoll-to-ragdoll contact manifolds (contacts mode 2, seed 5): ONE island of
+    240,000 bodies and 1.09 M constraints, 18 batches, 4 substeps x 1 iteration — on the split-island plan (asserted) against the threaded oracle, bit for bit."""
+    from bepuphysics2_amd.hostlib import HostSimulation
+    sim = HostSimulation.scene("ragdoll_tube", 15000, 1, 2, 5)
+    scene, sd = sim.export(), sim.solve_description()
+    sim.close()
+    assert scene.constraint_count > 1_050_000 and scene.body_count > 240_000
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=8)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+    assert solver.cluster_cycles().size > 1, "the full-size crowd must run on the split-island plan it is benchmarked on"
     m = pu.compare_scenes(ref, got)
     _check(m)
     assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
