@@ -56,7 +56,7 @@ def cpu_baseline(ragdolls_sample: int, seed: int, target_seconds: float = 14.0):
     budget_each = target_seconds / 8.0
     for c in [c for c in (1, 8, 16, 32, 64, 128) if c <= avail] or [1]:
         session.solve(1, c)  # untimed: the worker pool starts, pages are touched
-        frames, t0, phases = 0, time.perf_counter(), [0.0, 0.0, 0.0]
+        frames, t0, phases = 0, time.perf_counter(), [0.0, 0.0, 0.0, 0.0]
         while True:
             ph = session.solve(1, c)
             phases = [a + b for a, b in zip(phases, ph)]
@@ -66,10 +66,15 @@ def cpu_baseline(ragdolls_sample: int, seed: int, target_seconds: float = 14.0):
                 break
         curve.append({"threads": c, "value": per_frame * frames / el, "ms_per_frame": 1e3 * el / frames,
                       "phase_ms": {"prepare_integration_responsibilities": 1e3 * phases[0] / frames, "solve": 1e3 * phases[1] / frames,
-                                   "integrate_after_substepping": 1e3 * phases[2] / frames}})
+                                   "integrate_after_substepping": 1e3 * phases[2] / frames},
+                      "solve_work_ms_summed_over_workers": 1e3 * phases[3] / frames})
     single = curve[0]["value"]
     for e in curve:
         e["parallel_efficiency"] = e["value"] / (single * e["threads"])
+        # where the efficiency goes: the share of threads x Solve time the workers spend inside work blocks (the rest is waiting at the 2 + batches x passes sync
+        # stages of every substep), and how much longer the same work blocks take than on one thread (shared memory bandwidth, cache-line traffic on the bodies)
+        e["solve_worker_busy_fraction"] = e["solve_work_ms_summed_over_workers"] / (e["threads"] * e["phase_ms"]["solve"])
+        e["solve_work_inflation_vs_one_thread"] = e["solve_work_ms_summed_over_workers"] / curve[0]["solve_work_ms_summed_over_workers"]
     best = max(curve, key=lambda e: e["value"])
     # the reported figure: a longer run at the best thread count
     frames, t0 = 0, time.perf_counter()

@@ -1256,16 +1256,22 @@ struct Solver {
         int HighestVelocityIterationCount;
     } substepContext;
 
+    // Not in the reference: time-stamp-counter ticks every worker spent INSIDE work blocks (one slot per cache line). bench.py's cpu_baseline reports the busy fraction
+    // (sum / (threads x wall)) and the inflation of the work itself against one thread next to the thread curve: what the sync stages cost and what memory contention costs.
+    std::vector<uint64_t> workerWorkTicks;
     template <typename TStageFunction>
     void ExecuteWorkerStage(TStageFunction& stageFunction, int workerIndex, int workerStart, int availableBlocksStartIndex, std::atomic<int>* claims, int claimCount, int previousSyncIndex,
                             int syncIndex, std::atomic<int>& completedWorkBlocks) {  // :297
         if (workerStart == -1) return;
         int workBlockIndex = workerStart;
         int locallyCompletedCount = 0;
+        uint64_t ticks = 0;
         for (;;) {
             int expected = previousSyncIndex;
             if (!claims[workBlockIndex].compare_exchange_strong(expected, syncIndex)) break;
+            uint64_t t0 = __rdtsc();
             stageFunction(availableBlocksStartIndex + workBlockIndex, workerIndex);
+            ticks += __rdtsc() - t0;
             ++locallyCompletedCount;
             ++workBlockIndex;
             if (workBlockIndex >= claimCount) workBlockIndex = 0;
@@ -1275,10 +1281,13 @@ struct Solver {
             if (workBlockIndex < 0) workBlockIndex = claimCount - 1;
             int expected = previousSyncIndex;
             if (!claims[workBlockIndex].compare_exchange_strong(expected, syncIndex)) break;
+            uint64_t t0 = __rdtsc();
             stageFunction(availableBlocksStartIndex + workBlockIndex, workerIndex);
+            ticks += __rdtsc() - t0;
             ++locallyCompletedCount;
             workBlockIndex--;
         }
+        workerWorkTicks[(size_t)workerIndex * 8] += ticks;
         completedWorkBlocks.fetch_add(locallyCompletedCount);
     }
     template <typename TStageFunction>
@@ -1286,7 +1295,9 @@ struct Solver {
         int availableBlocksCount = stage.ClaimCount;
         if (availableBlocksCount == 0) return;
         if (availableBlocksCount == 1) {
+            uint64_t t0 = __rdtsc();
             stageFunction(stage.WorkBlockStartIndex, workerIndex);
+            workerWorkTicks[(size_t)workerIndex * 8] += __rdtsc() - t0;
         } else {
             substepContext.SyncIndex.store(syncIndex, std::memory_order_release);
             ExecuteWorkerStage(stageFunction, workerIndex, workerStart, stage.WorkBlockStartIndex, stage.Claims, stage.ClaimCount, previousSyncIndex, syncIndex,
@@ -1483,6 +1494,7 @@ struct Solver {
 
     void ExecuteMultithreaded(float dt, ThreadDispatcher& threadDispatcher) {  // :753
         int workerCount = substepContext.WorkerCount = threadDispatcher.ThreadCount();
+        workerWorkTicks.assign((size_t)workerCount * 8, 0);
         substepContext.Dt = dt;
         substepContext.InverseDt = 1.0f / dt;
         substepContext.VelocityIterationCounts.resize(substepCount);
@@ -1748,7 +1760,8 @@ static int CreateSession(SceneDesc* scene, SceneParams* params, std::unique_ptr<
     return 0;
 }
 
-// Simulation.Solve (Simulation.cs:278-290), `frames` times on the session's state. phase_seconds (optional, 3 doubles): the time spent in each of the three calls.
+// Simulation.Solve (Simulation.cs:278-290), `frames` times on the session's state. phase_seconds (optional, 4 doubles): the time spent in each of the three calls, and
+// the seconds all workers together spent inside Solve's work blocks (the rest of threads x Solve time is waiting at sync stages).
 static int SolveSession(Session& session, float dt, int threads, int frames, double* phaseSeconds) {
     Solver& solver = session.solver;
     if (!(dt > 0) || frames < 0) return 1;
@@ -1760,20 +1773,29 @@ static int SolveSession(Session& session, float dt, int threads, int frames, dou
         dispatcher = g_dispatcher.get();
     }
     using Clock = std::chrono::steady_clock;
-    double phases[3] = {0, 0, 0};
+    double phases[4] = {0, 0, 0, 0};
     for (int frame = 0; frame < frames; ++frame) {
         auto t0 = Clock::now();
         solver.PrepareConstraintIntegrationResponsibilities(dispatcher);
         auto t1 = Clock::now();
+        uint64_t tick1 = __rdtsc();
         solver.Solve(dt, dispatcher);
+        uint64_t tick2 = __rdtsc();
         auto t2 = Clock::now();
+        if (dispatcher && tick2 > tick1) {  // seconds the workers spent inside work blocks, summed over workers (ticks converted with this Solve's own wall time)
+            uint64_t sum = 0;
+            for (size_t w = 0; w < solver.workerWorkTicks.size(); w += 8) sum += solver.workerWorkTicks[w];
+            phases[3] += (double)sum * std::chrono::duration<double>(t2 - t1).count() / (double)(tick2 - tick1);
+        } else {
+            phases[3] += std::chrono::duration<double>(t2 - t1).count();
+        }
         solver.IntegrateAfterSubstepping(dt, solver.substepCount, dispatcher);
         auto t3 = Clock::now();
         phases[0] += std::chrono::duration<double>(t1 - t0).count();
         phases[1] += std::chrono::duration<double>(t2 - t1).count();
         phases[2] += std::chrono::duration<double>(t3 - t2).count();
     }
-    if (phaseSeconds) { phaseSeconds[0] = phases[0]; phaseSeconds[1] = phases[1]; phaseSeconds[2] = phases[2]; }
+    if (phaseSeconds) { phaseSeconds[0] = phases[0]; phaseSeconds[1] = phases[1]; phaseSeconds[2] = phases[2]; phaseSeconds[3] = phases[3]; }
     return 0;
 }
 

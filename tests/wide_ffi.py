@@ -86,8 +86,9 @@ class Session:
             raise RuntimeError(f"wide_session_create failed: {status.value}")
 
     def solve(self, frames: int = 1, threads: int = 1):
-        """Returns the seconds spent in (PrepareConstraintIntegrationResponsibilities, Solve, IntegrateAfterSubstepping) over the frames."""
-        phases = (C.c_double * 3)()
+        """Returns the seconds spent in (PrepareConstraintIntegrationResponsibilities, Solve, IntegrateAfterSubstepping) over the frames, and the seconds all
+        workers together spent inside Solve's work blocks."""
+        phases = (C.c_double * 4)()
         rc = self.lib.wide_session_solve(self.handle, self.dt, int(threads), int(frames), phases)
         if rc != 0:
             raise RuntimeError(f"wide_session_solve failed: {rc}")
