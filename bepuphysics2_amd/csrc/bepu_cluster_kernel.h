@@ -53,6 +53,9 @@ struct ClusterShared {
     SharedTables st;
     unsigned events;       // integration events every shared body has seen so far (substep index + 1 during the sweeps of a substep)
     unsigned passes;       // passes (warm starts + velocity iterations) completed before the current one, over the whole step
+    int code_touch;        // see touch_code_ahead
+    unsigned scratch_row;  // LDS byte address of the 256-byte row that swallows the code-touch reads
+    unsigned slot_addr;    // PREFETCH: LDS byte address of this wave's row-prefetch slot
 };
 
 template <int ACCESS>
@@ -203,7 +206,7 @@ __device__ __forceinline__ SharedRef make_shared_ref(const ClusterShared& sh, un
     SharedRef r;
     const bool shared = active && (half & kLrefShared) != 0 && (half & 0x8000u) == 0;
     r.body = shared ? (sh.slot_body[half & 0x3FFFu] & kSlotBodyMask) : -1;
-    r.number = sh.events + ((srank >> 8) & 0xFFu) * sh.passes + (END_OF_SUBSTEP ? 0u : (srank & 0xFFu));  // rank | degree << 8
+    r.number = sh.st.base + sh.events + ((srank >> 8) & 0xFFu) * sh.passes + (END_OF_SUBSTEP ? 0u : (srank & 0xFFu));  // rank | degree << 8
     return r;
 }
 // Two records per body: substep s works on record s & 1, and what reads the END of substep s - 1 (the incremental contact update, the pose integration of the
@@ -297,6 +300,52 @@ __device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const
     asm volatile("" ::: "memory");  // nothing below may be hoisted above the polls
 }
 
+// LDS-DMA: every lane's dword at `gsrc` lands at LDS byte address lds_dst + 4 * lane (lds_dst wave-uniform), no VGPR involved; counted in vmcnt like any load.
+// hipcc does not know about it: whoever reads the destination waits (wait_vm) first.
+__device__ __forceinline__ void glds_dword(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// Instruction fetch is what separates the pool's two box classes: a work item runs 4-10 KB of straight-line code once, and an instruction-cache
+// miss that also misses L2 (the constraint rows stream through it) costs several times more on the slow class. L2 is shared by code and data, so a wave can fetch
+// its own upcoming code as DATA: one LDS-DMA read per 8 KB span, lane l reading the 128-byte line l of the span that starts at the current PC, issued right
+// behind the item's row loads. The bytes go to a scratch row nobody reads; what matters is that the lines are on their way into L2 — all at once — before the
+// instruction fetcher asks for them one after the other. Off (0 spans) unless ClusterParams.code_touch says otherwise (BEPUHIP_CODE_TOUCH).
+__device__ __forceinline__ void touch_code_ahead(const ClusterShared& sh, int lane) {
+    if (sh.code_touch == 0) return;
+    unsigned long long pc;
+    asm volatile("s_getpc_b64 %0" : "=s"(pc));
+    for (int span = 0; span < sh.code_touch; ++span) glds_dword((const char*)pc + (size_t)span * 8192 + (size_t)lane * 128, (unsigned)__builtin_amdgcn_readfirstlane((int)sh.scratch_row));
+}
+
+// PREFETCH variants: a wave claims one work item ahead and lets LDS-DMA bring that item's rows (local references, shared-body ranks, prestep, accumulated impulses:
+// `rows` x 256 B, lanes beyond the item's count mirror its last constraint) into the wave's own LDS slot while it works on the current item, whose rows it has
+// just moved from the same slot into registers. The row loads (about a third of an item's time on a split-island plan) leave the dependency chain.
+// A wave now holds two claims, the one it works on and a later one: claims are still handed out and started per wave in ascending (topological) order, so the
+// earliest unfinished item is always somebody's CURRENT item with all predecessors finished — the deadlock-freedom argument of the schedule is unchanged.
+struct RowAhead {
+    lds_u32* counter; unsigned claim_base; int total, item_count; const ClusterItem* items; unsigned slot_addr; int next;
+    template <bool SHARED>
+    __device__ __forceinline__ void advance(unsigned* __restrict__ slab, int lane) {
+        next = (int)(claim_next(counter) - claim_base);
+        if (next >= total) return;
+        const ClusterItem* it = items + (next >= item_count ? next - item_count : next);
+        const int count = __builtin_amdgcn_readfirstlane(it->count), stride = __builtin_amdgcn_readfirstlane(it->stride), start = __builtin_amdgcn_readfirstlane(it->start);
+        const int shape = __builtin_amdgcn_readfirstlane(it->shape);
+        const unsigned lrefs_off = __builtin_amdgcn_readfirstlane(it->lrefs_off), prestep_off = __builtin_amdgcn_readfirstlane(it->prestep_off), accum_off = __builtin_amdgcn_readfirstlane(it->accum_off);
+        const int nb = shape & 0xFF, pf = (shape >> 8) & 0xFF, imf = (shape >> 16) & 0xFF;
+        const int i = start + (lane < count ? lane : count - 1);
+        unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)slot_addr);
+        const unsigned* g = slab + lrefs_off + i;
+        const int nref = (nb + 1) / 2 + (SHARED ? nb : 0);  // the rank rows of a split plan sit right behind the local references
+        for (int r = 0; r < nref; ++r, dst += 256) glds_dword(g + (size_t)r * stride, dst);
+        g = slab + prestep_off + i;
+        for (int f = 0; f < pf; ++f, dst += 256) glds_dword(g + (size_t)f * stride, dst);
+        g = slab + accum_off + i;
+        for (int f = 0; f < imf; ++f, dst += 256) glds_dword(g + (size_t)f * stride, dst);
+    }
+};
+
 struct ItemStamps { unsigned long long loaded, pre_gate, post_gate; };  // trace builds only
 
 // The gate the cluster path hands to the constraint functions: wait for the item's predecessors, then gather the velocities.
@@ -362,9 +411,9 @@ __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared&
     if (STAGE == kStageSolve && active) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) accum[(size_t)f * stride + i] = a[f]; }
 }
 
-template <class F, int STAGE, bool TRACE, bool SHARED>
+template <class F, int STAGE, bool TRACE, bool SHARED, bool PREFETCH>
 __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
-                                                       unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
+                                                       unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps, RowAhead& ahead) {
     // Lanes beyond the item's count mirror its last constraint and never store: the whole body runs with a full exec mask,
     // which keeps the control flow around the (wave-uniform) waits trivially structured.
     const bool active = lane < h.count;
@@ -374,22 +423,43 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     gfloat* accum = (gfloat*)(slab + h.accum_off);
     float p[F::prestepFloats];
     float a[F::impulseFloats];
-    // issue the item's global loads first: their latency hides under the velocity-independent work and the wait for the predecessors
-    const unsigned both = kRowsNonTemporal ? (unsigned)__builtin_nontemporal_load(&lrefs[i]) : (unsigned)lrefs[i];  // two 16-bit local references per word
+    unsigned both;  // two 16-bit local references per word
+    unsigned rank_a = 0u, rank_b = 0u;  // SHARED: rank | degree << 8 of this application on each shared body (rows right behind the local references)
+    if constexpr (PREFETCH && STAGE != kStageIncremental) {
+        // The rows are in this wave's LDS slot: its own LDS-DMA reads, issued while it worked on its previous item (RowAhead::advance). Move them into registers,
+        // then claim the next item and send ITS rows on their way into the same slot.
+        constexpr int kRefRows = (F::bodies + 1) / 2, kFirstPrestep = kRefRows + (SHARED ? F::bodies : 0);
+        wait_vm();
+        const lds_u32* row = (const lds_u32*)(__SIZE_TYPE__)sh.slot_addr + lane;
+        both = row[0];
+        if constexpr (SHARED) { rank_a = row[64 * kRefRows]; if (F::bodies == 2) rank_b = row[64 * (kRefRows + 1)]; }
+        _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = __uint_as_float(row[64 * (kFirstPrestep + f)]);
+        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = __uint_as_float(row[64 * (kFirstPrestep + F::prestepFloats + f)]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every row is in registers before the slot is written again
+        ahead.advance<SHARED>(slab, lane);
+    } else {
+        // issue the item's global loads first: their latency hides under the velocity-independent work and the wait for the predecessors
+        both = kRowsNonTemporal ? (unsigned)__builtin_nontemporal_load(&lrefs[i]) : (unsigned)lrefs[i];
+        if constexpr (SHARED) {
+            const gint* srank = lrefs + (size_t)((F::bodies + 1) / 2) * stride;
+            rank_a = (unsigned)srank[i];
+            if (F::bodies == 2) rank_b = (unsigned)srank[(size_t)stride + i];
+        }
+        if (kRowsNonTemporal) {  // per translation unit (BEPU_VARIANT_NT): the constraint rows are read once per pass; see the note on box classes in DESIGN.md 5
+            _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = __builtin_nontemporal_load(&prestep[(size_t)f * stride + i]);
+            if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = __builtin_nontemporal_load(&accum[(size_t)f * stride + i]); }
+        } else {
+            _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
+            if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
+        }
+    }
+    if (STAGE != kStageIncremental) touch_code_ahead(sh, lane);
     const int ra = unpack_local_ref(both & 0xFFFFu);
     const int rb = (F::bodies == 2) ? unpack_local_ref(both >> 16) : -1;
     SharedRef sa = {-1, 0u}, sb = {-1, 0u};
-    if constexpr (SHARED) {  // rank | degree << 8 of this application on each shared body: rows right behind the local references
-        const gint* srank = lrefs + (size_t)((F::bodies + 1) / 2) * stride;
-        sa = make_shared_ref<STAGE == kStageIncremental>(sh, both & 0xFFFFu, (unsigned)srank[i], active);
-        if (F::bodies == 2) sb = make_shared_ref<STAGE == kStageIncremental>(sh, both >> 16, (unsigned)srank[(size_t)stride + i], active);
-    }
-    if (kRowsNonTemporal) {  // per translation unit (BEPU_VARIANT_NT): the constraint rows are read once per pass; see the note on box classes in DESIGN.md 5
-        _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = __builtin_nontemporal_load(&prestep[(size_t)f * stride + i]);
-        if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = __builtin_nontemporal_load(&accum[(size_t)f * stride + i]); }
-    } else {
-        _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
-        if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
+    if constexpr (SHARED) {
+        sa = make_shared_ref<STAGE == kStageIncremental>(sh, both & 0xFFFFu, rank_a, active);
+        if (F::bodies == 2) sb = make_shared_ref<STAGE == kStageIncremental>(sh, both >> 16, rank_b, active);
     }
     DBody A, B;
     if (STAGE == kStageIncremental) {  // reads velocities, writes only this constraint's depths: no ordering inside the stage
@@ -438,10 +508,10 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
 using DC1O = Contact<1, false>; using DC2O = Contact<2, false>; using DC3O = Contact<3, false>; using DC4O = Contact<4, false>;
 using DC1T = Contact<1, true>; using DC2T = Contact<2, true>; using DC3T = Contact<3, true>; using DC4T = Contact<4, true>;
 
-template <int STAGE, bool TRACE, bool WIDE, bool SHARED>
+template <int STAGE, bool TRACE, bool WIDE, bool SHARED, bool PREFETCH>
 __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
-                                                 unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
-#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE, SHARED>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps); break;
+                                                 unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps, RowAhead& ahead) {
+#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE, SHARED, PREFETCH>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps, ahead); break;
     switch (h.type_id) {
         BEPU_CASE(kContact1OneBody, DC1O) BEPU_CASE(kContact2OneBody, DC2O) BEPU_CASE(kContact3OneBody, DC3O) BEPU_CASE(kContact4OneBody, DC4O)
         BEPU_CASE(kContact1, DC1T) BEPU_CASE(kContact2, DC2T) BEPU_CASE(kContact3, DC3T) BEPU_CASE(kContact4, DC4T)
@@ -481,13 +551,16 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
 // predecessors), so the head of the iteration runs while the tail of the warm start's dependency chain is still draining. The warm start does
 // not write accumulated impulses, hence nothing the iteration loads from HBM is in flight. STAGE0 = kStageSolve with solve_items = 0 runs a
 // later iteration on its own (a barrier precedes it: its impulses were stored by the previous one).
-template <int STAGE0, bool TRACE, bool WIDE, bool SHARED>
+template <int STAGE0, bool TRACE, bool WIDE, bool SHARED, bool PREFETCH>
 __device__ __forceinline__ void run_cluster_sweep(ClusterShared& sh, int item_count, int solve_items, int lane, int wave, unsigned epoch, unsigned claim_base,
                                                   unsigned* __restrict__ slab, float dt, float inv_dt, unsigned long long* trace) {
     const unsigned pass_base = sh.passes;
-    for (;;) {
-        const int v = (int)(claim_next(sh.counter) - claim_base);
-        if (v >= item_count + solve_items) break;
+    const int total = item_count + solve_items;
+    RowAhead ahead = {sh.counter, claim_base, total, item_count, sh.items, sh.slot_addr, 0};
+    int v;
+    if constexpr (PREFETCH) { ahead.advance<SHARED>(slab, lane); v = ahead.next; }  // the sweep's first claim: its rows start their way into the slot
+    else v = (int)(claim_next(sh.counter) - claim_base);
+    while (v < total) {
         const bool second = v >= item_count;
         const int k = second ? v - item_count : v;
         const unsigned item_epoch = second ? epoch + 1 : epoch;
@@ -497,8 +570,9 @@ __device__ __forceinline__ void run_cluster_sweep(ClusterShared& sh, int item_co
         if (TRACE) t0 = __builtin_readcyclecounter();
         ItemStamps stamps = {0, 0, 0};
         if constexpr (SHARED) sh.passes = pass_base + (second ? 1u : 0u);  // wave-private copy: which pass of the step this item belongs to
-        if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE, WIDE, SHARED>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
-        else run_cluster_item<kStageSolve, TRACE, WIDE, SHARED>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+        if constexpr (PREFETCH) ahead.next = -1;
+        if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE, WIDE, SHARED, PREFETCH>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps, ahead);
+        else run_cluster_item<kStageSolve, TRACE, WIDE, SHARED, PREFETCH>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps, ahead);
         if (TRACE && trace && blockIdx.x == 0 && lane == 0 && item_epoch - 1 < (unsigned)kClusterTracePasses) {  // iteration counts are unbounded: never write past the buffer
             unsigned long long* rec = trace + ((size_t)(item_epoch - 1) * item_count + k) * 8;
             rec[4] = stamps.loaded; rec[5] = stamps.pre_gate; rec[6] = stamps.post_gate; rec[7] = 0;
@@ -506,20 +580,28 @@ __device__ __forceinline__ void run_cluster_sweep(ClusterShared& sh, int item_co
             rec[2] = (unsigned long long)wave | ((unsigned long long)h.type_id << 8) | ((unsigned long long)h.batch << 16) | ((unsigned long long)((STAGE0 == kStageWarmStart && !second) ? kStageWarmStart : kStageSolve) << 32);
             rec[3] = (unsigned long long)h.count;
         }
+        if constexpr (PREFETCH) {
+            // an item whose code path does not take its rows from the slot (three- and four-body types, an unknown type id) has not claimed ahead either
+            if (__builtin_amdgcn_readfirstlane(ahead.next) == -1) { wait_vm(); ahead.advance<SHARED>(slab, lane); }
+            v = ahead.next;
+        } else {
+            v = (int)(claim_next(sh.counter) - claim_base);
+        }
     }
     if constexpr (SHARED) sh.passes = pass_base;
 }
 
-template <int THREADS, bool TRACE, bool WIDE, bool SHARED>
+template <int THREADS, bool TRACE, bool WIDE, bool SHARED, bool PREFETCH>
 __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __restrict__ clusters, const ClusterItem* __restrict__ items,
                                                                    const int* __restrict__ batch_item_begin, const int* __restrict__ cluster_bodies,
                                                                    float4* bodies, unsigned* __restrict__ slab, ClusterParams cp, int ncap, int max_items,
                                                                    unsigned long long* trace, unsigned* status, unsigned long long* cycles, TailParams tp, SharedTables shared_tables) {
-    if ((int)blockIdx.x >= tp.cluster_count) {
+    if ((int)blockIdx.x + tp.block_offset >= tp.cluster_count) {
         // ---- not a cluster: the bodies no cluster owns (IntegrateBundlesAfterSubstepping for unconstrained bodies), and, in the last workgroup, the
         // constrained kinematic bodies. Clusters stage private copies of the kinematic bodies they reference from HBM when they start, so those are
-        // advanced only after every cluster has reported its staging done (clusters are dispatched before this workgroup: it cannot starve them).
-        const int t = (int)blockIdx.x - tp.cluster_count;
+        // advanced only after every cluster has reported its staging done (clusters are dispatched before this workgroup: it cannot starve them; with
+        // tp.block_offset > 0 these workgroups are a launch of their own behind the clusters' on the same stream).
+        const int t = (int)blockIdx.x + tp.block_offset - tp.cluster_count;
         if (t < tp.body_blocks) {
             const int i = t * (int)blockDim.x + (int)threadIdx.x;
             if (i < tp.body_count) {
@@ -561,6 +643,9 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.st = shared_tables; sh.events = 0; sh.passes = 0;
     int* slot_body_lds = reinterpret_cast<int*>(words + ((cluster_sync_words(max_items) + 3) / 4) * 4);  // SHARED plans: behind the sync words
     sh.slot_body = slot_body_lds;
+    sh.code_touch = cp.code_touch;
+    sh.scratch_row = lds_address((const volatile lds_u32*)lds) + (unsigned)cluster_lds_core_bytes(cp.planes, ncap, max_items, SHARED);
+    sh.slot_addr = sh.scratch_row + (unsigned)kLdsScratchRowBytes + (unsigned)(threadIdx.x >> 6) * (unsigned)cp.prefetch_rows * 256u;
     const ClusterDesc cd = clusters[blockIdx.x];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
@@ -593,7 +678,8 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 const ItemHeader h = read_item(it);
                 if (!isContactType(h.type_id)) continue;
                 ItemStamps stamps = {0, 0, 0};
-                run_cluster_item<kStageIncremental, false, WIDE, SHARED>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
+                RowAhead none = {};
+                run_cluster_item<kStageIncremental, false, WIDE, SHARED, false>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps, none);
             }
             __syncthreads();
         }
@@ -611,7 +697,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
             if (home || ghost) applications = shared_tables.info[body] & 0xFFu;
             if ((home || ghost) && s > 0) {  // the velocity the last substep ended with: in last substep's record once every application on the body has happened
                 const float lw = l4.w, aw = a4.w;
-                acquire_shared_one(shared_tables, status, body, (unsigned)s - 1u, (unsigned)s + applications * sh.passes, l4, a4, 9, j);
+                acquire_shared_one(shared_tables, status, body, (unsigned)s - 1u, shared_tables.base + (unsigned)s + applications * sh.passes, l4, a4, 9, j);
                 l4.w = lw; a4.w = aw;  // the record's fourth lanes carry the event number; the body's own padding stays what it was
             }
             Q ori = {q4.x, q4.y, q4.z, q4.w};
@@ -636,7 +722,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                     r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
                 }
                 if (home) {  // this substep's record: the integrated velocity, and "integration done" as the event number
-                    const float number = __uint_as_float((unsigned)s + 1u + applications * sh.passes);
+                    const float number = __uint_as_float(shared_tables.base + (unsigned)s + 1u + applications * sh.passes);
                     store_agent_pair(shared_record(shared_tables, body, (unsigned)s), make_float4(vel.lin.x, vel.lin.y, vel.lin.z, number), make_float4(vel.ang.x, vel.ang.y, vel.ang.z, number));
                 }
             } else if (cp.integrate_velocity_for_kinematics) {  // kinematic: private copy, same arithmetic as the global kinematic pass
@@ -649,14 +735,14 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         __syncthreads();
         ++epoch;
         const int fused = cp.iters[s] > 0 ? cd.item_count : 0;  // the first velocity iteration rides in the warm start's claim sequence
-        run_cluster_sweep<kStageWarmStart, TRACE, WIDE, SHARED>(sh, cd.item_count, fused, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+        run_cluster_sweep<kStageWarmStart, TRACE, WIDE, SHARED, PREFETCH>(sh, cd.item_count, fused, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
         claim_base += cd.item_count + fused + nwaves;  // every wave makes exactly one failing claim per sweep
         sh.passes += fused ? 2u : 1u;
         if (fused) ++epoch;
         __syncthreads();
         for (int iter = 1; iter < cp.iters[s]; ++iter) {
             ++epoch;
-            run_cluster_sweep<kStageSolve, TRACE, WIDE, SHARED>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+            run_cluster_sweep<kStageSolve, TRACE, WIDE, SHARED, PREFETCH>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
             claim_base += cd.item_count + nwaves;
             sh.passes += 1u;
             __syncthreads();
@@ -672,7 +758,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         const float4* r = lds + j;
         float4 q4 = r[0], p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
         if (home) {  // the last applications on a shared body may belong to other clusters: wait for the step's full event count, then take its velocity
-            const unsigned want = (unsigned)cp.substeps + (shared_tables.info[g] & 0xFFu) * sh.passes;
+            const unsigned want = shared_tables.base + (unsigned)cp.substeps + (shared_tables.info[g] & 0xFFu) * sh.passes;
             const float lw = l4.w, aw = a4.w;
             acquire_shared_one(shared_tables, status, g, (unsigned)cp.substeps - 1u, want, l4, a4, 11, j);
             l4.w = lw; a4.w = aw;

@@ -30,10 +30,7 @@ static int env_int(const char* name, int fallback) {
     return v && *v ? atoi(v) : fallback;
 }
 
-constexpr size_t kLdsBudgetBytes = 160 * 1024 - 256;
-static size_t cluster_lds_bytes(int planes, int ncap, int max_items, bool shared = false) {  // shared plans keep a slot -> body table in LDS too
-    return (size_t)planes * ncap * 16 + (size_t)max_items * sizeof(ClusterItem) + (cluster_sync_words(max_items) + 3) / 4 * 16 + (shared ? ((size_t)ncap * 4 + 15) / 16 * 16 : 0);
-}
+constexpr size_t kLdsBudgetBytes = 160 * 1024;  // cluster_lds_bytes (bepu_kernels_common.h) counts everything a workgroup asks for, the scratch row included
 // Slot rotation inside every group of 16 (see the LDS layout note above cluster_kernel).
 static inline int rotated_slot(int i) { return (i & ~15) | ((i + (i >> 4)) & 15); }
 

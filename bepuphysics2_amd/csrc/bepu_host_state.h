@@ -20,9 +20,12 @@ const void* bepu_cluster_kernel_hot_768s(bool trace);
 const void* bepu_cluster_kernel_wide_768s(bool trace);
 const void* bepu_cluster_kernel_hot_512s(bool trace);
 const void* bepu_cluster_kernel_wide_512s(bool trace);
+const void* bepu_cluster_kernel_hot_512sp(bool trace);   // split-island plans with the next item's rows prefetched into LDS (RowAhead)
+const void* bepu_cluster_kernel_wide_512sp(bool trace);
 constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
 static int cluster_variant_threads(int threads) { return threads > 768 ? 1024 : (threads > 512 ? 768 : 512); }  // the smallest budget that still fits `threads`
-static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false) {
+static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false, bool prefetch = false) {
+    if (prefetch && shared && cluster_variant_threads(threads) == 512) return wide ? bepu_cluster_kernel_wide_512sp(trace) : bepu_cluster_kernel_hot_512sp(trace);
     if (nt && !shared && cluster_variant_threads(threads) == 1024) return wide ? bepu_cluster_kernel_wide_1024n(trace) : bepu_cluster_kernel_hot_1024n(trace);
     if (nt && shared && cluster_variant_threads(threads) == 512) return wide ? bepu_cluster_kernel_wide_512sn(trace) : bepu_cluster_kernel_hot_512sn(trace);
     if (shared) switch (cluster_variant_threads(threads)) {
@@ -170,9 +173,11 @@ struct bepuhip_ctx {
     int policy_samples = 0;           // solves launched while measuring
     hipEvent_t policy_events[16][2] = {};
     bool clusters_shared = false;    // split-island plan: bodies shared between clusters go through the tables below
-    float4* d_shared_vel = nullptr;   // per body two records (substep parity) of {linear, event number} {angular, event number}; zeroed before every launch
+    float4* d_shared_vel = nullptr;   // per body two records (substep parity) of {linear, event number} {angular, event number}
     unsigned* d_shared_info = nullptr;
     size_t shared_bodies = 0;         // table length (bodies)
+    unsigned shared_epoch = 0;        // event numbers of the next step start here (SharedTables.base): the records are cleared once, not per step
+    int cluster_item_rows = 0;        // most 256-byte rows (references, ranks, prestep, impulses) any work item of the plan reads: the size of a row-prefetch slot
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
     int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0, cluster_planes = 8;
     ClusterDesc first_cluster = {0, 0, 0, 0, 0};

@@ -41,6 +41,15 @@ static_assert(offsetof(ClusterItem, xpred) == offsetof(ClusterItem, pred) + kMax
 // LDS words behind the work items: one flag per item, two (kFallbackBatchLimit + 1)-entry tables (batch counters, batch -> first item), the claim counter.
 __host__ __device__ inline size_t cluster_sync_words(int max_items) { return (size_t)max_items + 2 * (kFallbackBatchLimit + 1) + 2; }
 struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
+// LDS of a cluster workgroup: [planes x ncap float4 body table][work items][sync words][SHARED: slot -> body table][one scratch row of 256 B: the destination of the
+// LDS-DMA reads that only exist to pull code into L2 (touch_code_ahead)][row-prefetch slots: one per wave, prefetch_rows x 256 B each (PREFETCH variants)].
+__host__ __device__ inline size_t cluster_lds_core_bytes(int planes, int ncap, int max_items, bool shared) {
+    return (size_t)planes * ncap * 16 + (size_t)max_items * sizeof(ClusterItem) + (cluster_sync_words(max_items) + 3) / 4 * 16 + (shared ? ((size_t)ncap * 4 + 15) / 16 * 16 : 0);
+}
+constexpr size_t kLdsScratchRowBytes = 256;
+__host__ __device__ inline size_t cluster_lds_bytes(int planes, int ncap, int max_items, bool shared = false, int prefetch_rows = 0, int waves = 0) {
+    return cluster_lds_core_bytes(planes, ncap, max_items, shared) + kLdsScratchRowBytes + (size_t)prefetch_rows * waves * 256;
+}
 // Slot table entries (cluster_bodies): body index | flags; -1 = unused slot.
 constexpr int kSlotKinematic = 1 << 30;   // private read-only copy of a kinematic body
 constexpr int kSlotGhost = 1 << 29;       // SHARED plan: pose / inertia copy of a shared body whose home is another cluster (never integrated here)
@@ -50,8 +59,10 @@ constexpr int kSlotBodyMask = (1 << 28) - 1;
 // constraint that another cluster runs is SHARED: during the sweeps its velocity lives in `vel`, two records per body index (substep parity, see
 // shared_record), each {linear, n} {angular, n} moved with agent-scope accesses. n counts the events of the step that have happened on the body — one per
 // substep for the home cluster's integration, then one per constraint application in the reference's batch order (rank r of d per pass). An application
-// waits for "its" n and leaves n + 1 with the velocity it wrote. `info[body]` = d. `vel` is zeroed before every launch.
-struct SharedTables { float4* vel; const unsigned* info; int poll_sleep; };  // poll_sleep: 64-clock naps between two polls of a record
+// waits for "its" n and leaves n + 1 with the velocity it wrote. `info[body]` = d.
+// Event numbers of one step start at `base`: the host advances it by more than any body's events per step (substeps + 255 x passes + 2, kept even so that the
+// record parity of a substep does not depend on it), so whatever the previous step left in the records reads as "not yet" and nothing has to be cleared between steps.
+struct SharedTables { float4* vel; const unsigned* info; int poll_sleep; unsigned base; };  // poll_sleep: 64-clock naps between two polls of a record
 constexpr unsigned kLrefDead = 0x80008000u;  // whole-island plans: the packed local references of a free device slot (reserved at planning, or left by a removal): both halves
                                              // name the kinematic copy in slot 0 — the lane computes on whatever that holds and, like every kinematic reference, writes no body back;
                                              // what it writes into its own rows is overwritten when the slot is taken again (no extra test in the kernel)
@@ -65,6 +76,8 @@ constexpr int kClusterTracePasses = kMaxClusterSubsteps * 8;  // passes (warm st
 struct ClusterParams {
     int substeps, batch_count, integrate_velocity_for_kinematics;
     int planes;  // kSweepPlanes or kAllPlanes
+    int code_touch;     // 8 KB spans of its own upcoming code a wave pulls into L2 at the start of every work item (0: off), see touch_code_ahead
+    int prefetch_rows;  // PREFETCH variants: rows (256 B each) of a wave's row-prefetch slot in LDS
     int iters[kMaxClusterSubsteps];
     StepParams sp;
 };
@@ -75,6 +88,7 @@ struct ClusterParams {
 struct TailParams {
     const unsigned* flags; const int* kinlist; unsigned* staged;
     int body_count, kin_count, cluster_count, body_blocks;
+    int block_offset;  // added to blockIdx.x: the tail workgroups of a split plan are a launch of their own (the clusters' launch is cooperative: exactly the clusters)
     float dt, substep_dt;
     int substep_count, allow_substeps_for_unconstrained, integrate_velocity_for_kinematics;
     StepParams final_sp;  // PrepareForIntegration(dt or dt / substeps) of the final pass (PoseIntegrator.cs:707-726), not the substep's

@@ -508,6 +508,11 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             it.prestep_off = (unsigned)tb.prestep_off;
             it.accum_off = (unsigned)tb.accum_off;
         }
+        c->cluster_item_rows = 0;
+        for (auto& it : plan.items) {
+            const int nb = it.shape & 0xFF, pf = (it.shape >> 8) & 0xFF, imf = (it.shape >> 16) & 0xFF;
+            c->cluster_item_rows = std::max(c->cluster_item_rows, (nb + 1) / 2 + (plan.shared ? nb : 0) + pf + imf);
+        }
         c->clustered_dynamic_count = (int)plan.clustered_dynamic.size();
         HIP_TRY(upload_ints(plan.clusters.data(), plan.clusters.size() * sizeof(ClusterDesc), (void**)&c->d_clusters));
         HIP_TRY(upload_ints(plan.items.data(), plan.items.size() * sizeof(ClusterItem), (void**)&c->d_items));
@@ -529,6 +534,11 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         if (plan.shared) {  // split islands: velocity / event tables of the bodies more than one cluster touches (indexed by body, only the shared ones are used)
             c->shared_bodies = plan.shared_info.size();
             HIP_TRY(hipMalloc((void**)&c->d_shared_vel, c->shared_bodies * 4 * sizeof(float4)));  // two records (substep parity) of two float4 per body
+            HIP_TRY(hipMemset(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4)));         // cleared here, then never again: every step's event numbers start above the last step's
+            c->shared_epoch = 0;
+            for (int tr = 0; tr < 2; ++tr)
+                for (int wide = 0; wide < 2; ++wide)
+                    HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(512, tr != 0, wide != 0, true, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
             HIP_TRY(upload_ints(plan.shared_info.data(), plan.shared_info.size() * 4, (void**)&c->d_shared_info));
             for (int threads : kClusterThreadChoices)
                 for (int tr = 0; tr < 2; ++tr)
@@ -642,24 +652,43 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
         {
             Timed t(c, 5);
             // Waves per cluster: 16 by default (four per SIMD; 12 is as fast when memory latency is low, 8 is slower everywhere); BEPUHIP_CLUSTER_THREADS overrides.
-            const int req = env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
+            // Scenes with SURVEY 8(f) types take the 512-thread build: at 128 VGPRs per wave the widened types spill hundreds of registers.
+            const int req = env_int("BEPUHIP_CLUSTER_THREADS", c->has_widened_types ? kSplitClusterThreads : kClusterThreads);
             const int threads = std::max(64, std::min(1024, (c->clusters_shared ? env_int("BEPUHIP_SPLIT_THREADS", kSplitClusterThreads) : req) / 64 * 64));
+            // Split plans at 512 threads: the next work item's rows travel into LDS while the current one runs, if the wave slots fit behind the bodies.
+            const bool prefetch = c->clusters_shared && cluster_variant_threads(threads) == 512 && env_int("BEPUHIP_PREFETCH", 1) != 0 && c->cluster_item_rows > 0 &&
+                                  cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, true, c->cluster_item_rows, threads / 64) <= kLdsBudgetBytes;
+            cp.code_touch = std::max(0, std::min(4, env_int("BEPUHIP_CODE_TOUCH", 0)));
+            cp.prefetch_rows = prefetch ? c->cluster_item_rows : 0;
+            const size_t launch_lds = prefetch ? cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, true, c->cluster_item_rows, threads / 64) : lds_bytes;
             // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
             // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).
             TailParams tp;
             tp.flags = c->d_flags; tp.kinlist = c->d_kinlist; tp.staged = c->d_staged;
             tp.body_count = c->body_count; tp.kin_count = c->kinlist_count; tp.cluster_count = c->cluster_count;
             tp.body_blocks = (c->body_count + threads - 1) / threads;
+            tp.block_offset = 0;
             tp.dt = dt; tp.substep_dt = substep_dt; tp.substep_count = substeps;
             tp.allow_substeps_for_unconstrained = in->allow_substeps_for_unconstrained; tp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
             const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
             tp.final_sp = make_params(in, vdt, vdt, 1.0f / vdt);
-            SharedTables st = {c->d_shared_vel, c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1)};
-            if (c->clusters_shared) hipMemsetAsync(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4), c->stream);  // event numbers start every step at zero
+            SharedTables st = {c->d_shared_vel, c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1), 0u};
+            if (c->clusters_shared) {
+                // Event numbers of this step: [base, base + span). A body sees at most substeps + 255 x passes events per step; the span is kept even (record parity).
+                unsigned passes = 0;
+                for (int s = 0; s < substeps; ++s) passes += 1u + (unsigned)iterations[s];
+                const unsigned long long span = ((unsigned long long)substeps + 255ull * passes + 3ull) & ~1ull;
+                if ((unsigned long long)c->shared_epoch + 2ull * span > 0xFFFFFFFFull) {  // once in ~2 M steps: start over from cleared records
+                    hipMemsetAsync(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4), c->stream);
+                    c->shared_epoch = 0;
+                }
+                st.base = c->shared_epoch;
+                c->shared_epoch += (unsigned)span;
+            }
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
                             (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
             const bool tr = c->d_trace != nullptr;
-            const bool policy_applies = cluster_variant_threads(threads) == (c->clusters_shared ? 512 : 1024);  // the variants that exist in both row policies
+            const bool policy_applies = !prefetch && cluster_variant_threads(threads) == (c->clusters_shared ? 512 : 1024);  // the variants that exist in both row policies
             int sample = -1;
             bool nt = false;
             if (policy_applies) {
@@ -667,9 +696,24 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
                 if (c->row_policy < 0) { sample = c->policy_samples++; nt = (sample & 1) != 0; }  // plain, non-temporal, plain, ... each under its own event pair
                 else nt = c->row_policy == 1;
             }
-            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt);  // the register budget that matches the workgroup size
+            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, prefetch);  // the register budget that matches the workgroup size
             if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
-            hipLaunchKernel(fn, dim3(c->cluster_count + tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0)), dim3(threads), args, lds_bytes, c->stream);
+            const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
+            bool launched = false;
+            if (c->clusters_shared && env_int("BEPUHIP_COOPERATIVE", 1) != 0) {
+                // The clusters of a split plan wait for each other: they must all be resident at once. A cooperative launch of exactly the clusters makes the runtime
+                // guarantee that (or refuse), whatever else runs on the device; the per-body tail follows as an ordinary launch of the same kernel.
+                if (hipLaunchCooperativeKernel(fn, dim3(c->cluster_count), dim3(threads), args, (unsigned)launch_lds, c->stream) == hipSuccess) {
+                    launched = true;
+                    if (tail_blocks > 0) {
+                        tp.block_offset = c->cluster_count;
+                        hipLaunchKernel(fn, dim3(tail_blocks), dim3(threads), args, 0, c->stream);
+                    }
+                } else {
+                    (void)hipGetLastError();  // e.g. hipErrorCooperativeLaunchTooLarge: fall back to the plain launch below
+                }
+            }
+            if (!launched) hipLaunchKernel(fn, dim3(c->cluster_count + tail_blocks), dim3(threads), args, launch_lds, c->stream);
             if (sample >= 0) hipEventRecord(c->policy_events[sample][1], c->stream);
         }
     }

@@ -40,8 +40,8 @@ int main() {
     for (int form = 0; form < 2; ++form)
         for (unsigned off : {0u, 32768u, 60000u & ~255u, 65536u, 100000u & ~255u, 150u * 1024u}) {
             hipMemset(d_dst, 0, n * 4);
-            if (form) hipLaunchKernelGGL(probe<true>, dim3(blocks), dim3(512), 160 * 1024 - 256, 0, d_src, d_dst, off);
-            else hipLaunchKernelGGL(probe<false>, dim3(blocks), dim3(512), 160 * 1024 - 256, 0, d_src, d_dst, off);
+            if (form) hipLaunchKernelGGL(probe<true>, dim3(blocks), dim3(512), 160 * 1024, 0, d_src, d_dst, off);
+            else hipLaunchKernelGGL(probe<false>, dim3(blocks), dim3(512), 160 * 1024, 0, d_src, d_dst, off);
             hipError_t e = hipDeviceSynchronize();
             hipMemcpy(out.data(), d_dst, n * 4, hipMemcpyDeviceToHost);
             int bad = 0;
