@@ -318,9 +318,18 @@ __device__ __forceinline__ void touch_code_ahead(const ClusterShared& sh, int la
     for (int span = 0; span < sh.code_touch; ++span) glds_dword((const char*)pc + (size_t)span * 8192 + (size_t)lane * 128, (unsigned)__builtin_amdgcn_readfirstlane((int)sh.scratch_row));
 }
 
-// PREFETCH variants: a wave claims one work item ahead and lets LDS-DMA bring that item's rows (local references, shared-body ranks, prestep, accumulated impulses:
-// `rows` x 256 B, lanes beyond the item's count mirror its last constraint) into the wave's own LDS slot while it works on the current item, whose rows it has
-// just moved from the same slot into registers. The row loads (about a third of an item's time on a split-island plan) leave the dependency chain.
+__device__ __forceinline__ void glds_dwordx4(const void* gsrc, unsigned lds_dst) {  // 16 bytes per lane to lds_dst + 16 * lane; gsrc 16-byte aligned
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// PREFETCH variants: a wave claims one work item ahead and lets LDS-DMA bring that item's rows (local references, shared-body ranks, prestep, accumulated impulses)
+// into the wave's own LDS slot while it works on the current item, whose rows it has just moved from the same slot into registers. The row loads (about a third of an
+// item's time on a split-island plan) leave the dependency chain.
+// What travels is, per row, the 16-byte aligned window of 68 elements around the item's (at most 64) elements: 17 chunks of 16 bytes, so that one LDS-DMA instruction
+// moves three rows (51 lanes x 16 bytes; a dword per lane would take three times the instructions, and issuing them is what the wave pays). A row lands at
+// slot + row * kPrefetchRowPitch; element e of the item is at dword (start & 3) + e of it. Windows may run a few elements past a row's end into the next row (or the
+// slab's padding): those elements are never read.
 // A wave now holds two claims, the one it works on and a later one: claims are still handed out and started per wave in ascending (topological) order, so the
 // earliest unfinished item is always somebody's CURRENT item with all predecessors finished — the deadlock-freedom argument of the schedule is unchanged.
 struct RowAhead {
@@ -330,19 +339,20 @@ struct RowAhead {
         next = (int)(claim_next(counter) - claim_base);
         if (next >= total) return;
         const ClusterItem* it = items + (next >= item_count ? next - item_count : next);
-        const int count = __builtin_amdgcn_readfirstlane(it->count), stride = __builtin_amdgcn_readfirstlane(it->stride), start = __builtin_amdgcn_readfirstlane(it->start);
+        const int stride = __builtin_amdgcn_readfirstlane(it->stride), start = __builtin_amdgcn_readfirstlane(it->start);
         const int shape = __builtin_amdgcn_readfirstlane(it->shape);
         const unsigned lrefs_off = __builtin_amdgcn_readfirstlane(it->lrefs_off), prestep_off = __builtin_amdgcn_readfirstlane(it->prestep_off), accum_off = __builtin_amdgcn_readfirstlane(it->accum_off);
         const int nb = shape & 0xFF, pf = (shape >> 8) & 0xFF, imf = (shape >> 16) & 0xFF;
-        const int i = start + (lane < count ? lane : count - 1);
-        unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)slot_addr);
-        const unsigned* g = slab + lrefs_off + i;
         const int nref = (nb + 1) / 2 + (SHARED ? nb : 0);  // the rank rows of a split plan sit right behind the local references
-        for (int r = 0; r < nref; ++r, dst += 256) glds_dword(g + (size_t)r * stride, dst);
-        g = slab + prestep_off + i;
-        for (int f = 0; f < pf; ++f, dst += 256) glds_dword(g + (size_t)f * stride, dst);
-        g = slab + accum_off + i;
-        for (int f = 0; f < imf; ++f, dst += 256) glds_dword(g + (size_t)f * stride, dst);
+        const int rows = nref + pf + imf;
+        const int sub = lane / 17, chunk = lane - sub * 17;  // this lane's row within a group of three, and its 16-byte chunk of the window
+        const unsigned* window = slab + (start & ~3) + chunk * 4;
+        const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)slot_addr);
+        for (int r0 = 0; r0 < rows; r0 += 3) {
+            const int r = r0 + sub;
+            const size_t row_words = r < nref ? (size_t)lrefs_off + (size_t)r * stride : (r < nref + pf ? (size_t)prestep_off + (size_t)(r - nref) * stride : (size_t)accum_off + (size_t)(r - nref - pf) * stride);
+            if (lane < 51 && r < rows) glds_dwordx4(window + row_words, dst0 + (unsigned)r0 * kPrefetchRowPitch);
+        }
     }
 };
 
@@ -429,12 +439,13 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
         // The rows are in this wave's LDS slot: its own LDS-DMA reads, issued while it worked on its previous item (RowAhead::advance). Move them into registers,
         // then claim the next item and send ITS rows on their way into the same slot.
         constexpr int kRefRows = (F::bodies + 1) / 2, kFirstPrestep = kRefRows + (SHARED ? F::bodies : 0);
+        constexpr int kPitch = (int)kPrefetchRowPitch / 4;
         wait_vm();
-        const lds_u32* row = (const lds_u32*)(__SIZE_TYPE__)sh.slot_addr + lane;
+        const lds_u32* row = (const lds_u32*)(__SIZE_TYPE__)sh.slot_addr + ((h.start & 3) + (active ? lane : h.count - 1));  // lanes beyond the count mirror the last constraint
         both = row[0];
-        if constexpr (SHARED) { rank_a = row[64 * kRefRows]; if (F::bodies == 2) rank_b = row[64 * (kRefRows + 1)]; }
-        _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = __uint_as_float(row[64 * (kFirstPrestep + f)]);
-        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = __uint_as_float(row[64 * (kFirstPrestep + F::prestepFloats + f)]);
+        if constexpr (SHARED) { rank_a = row[kPitch * kRefRows]; if (F::bodies == 2) rank_b = row[kPitch * (kRefRows + 1)]; }
+        _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = __uint_as_float(row[kPitch * (kFirstPrestep + f)]);
+        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = __uint_as_float(row[kPitch * (kFirstPrestep + F::prestepFloats + f)]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every row is in registers before the slot is written again
         ahead.advance<SHARED>(slab, lane);
     } else {
@@ -645,7 +656,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.slot_body = slot_body_lds;
     sh.code_touch = cp.code_touch;
     sh.scratch_row = lds_address((const volatile lds_u32*)lds) + (unsigned)cluster_lds_core_bytes(cp.planes, ncap, max_items, SHARED);
-    sh.slot_addr = sh.scratch_row + (unsigned)kLdsScratchRowBytes + (unsigned)(threadIdx.x >> 6) * (unsigned)cp.prefetch_rows * 256u;
+    sh.slot_addr = sh.scratch_row + (unsigned)kLdsScratchRowBytes + (unsigned)(threadIdx.x >> 6) * (unsigned)cp.prefetch_rows * kPrefetchRowPitch;
     const ClusterDesc cd = clusters[blockIdx.x];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;

@@ -412,9 +412,9 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         }
     }
     if (nclusters > cus) return;
-    // Experimental, off by default (BEPUHIP_SPLIT_REFINE = sweeps): smooth the regions' surfaces. A body moves to the neighbouring region that holds more of its
-    // constraint partners than its own does (ties stay), as long as no region leaves [7/8, 9/8] of the target size: fewer crossing constraints for the same regions.
-    if (const int sweeps = env_int("BEPUHIP_SPLIT_REFINE", 0)) {
+    // Smooth the regions' surfaces (BEPUHIP_SPLIT_REFINE = sweeps, default 2; 0 = off). A body moves to the neighbouring region that holds more of its constraint
+    // partners than its own does (ties stay), as long as no region leaves [7/8, 9/8] of the target size: fewer crossing constraints for the same regions.
+    if (const int sweeps = env_int("BEPUHIP_SPLIT_REFINE", 2)) {
         std::vector<int32_t> size(nclusters, 0);
         for (int v = 0; v < universe; ++v) if (body_cluster[v] >= 0) ++size[body_cluster[v]];
         const int lo = region * 7 / 8, hi = region * 9 / 8;
@@ -446,12 +446,12 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     // ---- constraints -> clusters, shared bodies, per-pass rank of every application on a shared body (type batches are in batch order) ----
     std::vector<std::vector<int32_t>> cl_of_constraint(c->tbs.size());
     std::vector<uint8_t> shared(universe, 0);
-    // Which side runs a constraint that crosses the cut decides which of its two bodies becomes shared. Default: the first dynamic body's cluster runs it. With
-    // BEPUHIP_SPLIT_COVER=1 (experimental, off by default) the shared bodies are a greedy vertex cover of the cut constraints instead — the body with the most
-    // crossing constraints first — and a crossing constraint runs on the side of its body that is NOT in the cover (either side when both are): fewer distinct
-    // shared bodies for the same cut.
+    // Which side runs a constraint that crosses the cut decides which of its two bodies becomes shared. The shared bodies are a greedy vertex cover of the cut
+    // constraints — the body with the most crossing constraints first — and a crossing constraint runs on the side of its body that is NOT in the cover (either side
+    // when both are): fewer distinct shared bodies for the same cut than letting the first dynamic body's cluster run it (BEPUHIP_SPLIT_COVER=0 restores that rule).
+    // Measured in round 3 on an MI355X (profiles/r03_split_cut_ab.txt): pile 0.437 -> 0.421 ms/step, ragdoll crowd 0.554 -> 0.518 with two refine sweeps.
     std::vector<uint8_t> in_cover;
-    if (env_int("BEPUHIP_SPLIT_COVER", 0)) {
+    if (env_int("BEPUHIP_SPLIT_COVER", 1)) {
         std::vector<int32_t> crossing(universe, 0);
         auto for_each_crossing = [&](auto&& fn) {
             for (auto& tb : c->tbs) {

@@ -23,6 +23,7 @@ const void* bepu_cluster_kernel_wide_512s(bool trace);
 const void* bepu_cluster_kernel_hot_512sp(bool trace);   // split-island plans with the next item's rows prefetched into LDS (RowAhead)
 const void* bepu_cluster_kernel_wide_512sp(bool trace);
 constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
+constexpr size_t kSlabTailPadBytes = 1024;
 static int cluster_variant_threads(int threads) { return threads > 768 ? 1024 : (threads > 512 ? 768 : 512); }  // the smallest budget that still fits `threads`
 static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false, bool prefetch = false) {
     if (prefetch && shared && cluster_variant_threads(threads) == 512) return wide ? bepu_cluster_kernel_wide_512sp(trace) : bepu_cluster_kernel_hot_512sp(trace);

@@ -465,8 +465,8 @@ static int32_t build_constraints(bepuhip_ctx* c) {
     }
     c->slab_words = words;
     if (words > 0) {
-        HIP_TRY(hipMalloc((void**)&c->d_slab, words * 4));
-        HIP_TRY(hipMalloc((void**)&c->d_slab0, words * 4));
+        HIP_TRY(hipMalloc((void**)&c->d_slab, words * 4 + kSlabTailPadBytes));  // the row-prefetch windows of the last rows may read a few elements past the end (RowAhead)
+        HIP_TRY(hipMalloc((void**)&c->d_slab0, words * 4 + kSlabTailPadBytes));
         std::unique_ptr<uint32_t[]> host(new uint32_t[words]);  // not zeroed: the four rows of every type batch tile [0, words) exactly (offsets assigned above from the same sizes)
         for (auto& tb : c->tbs) {
             if (!tb.refs_soa.empty()) memcpy(&host[tb.refs_off], tb.refs_soa.data(), tb.refs_soa.size() * 4);
@@ -700,7 +700,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
             const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
             bool launched = false;
-            if (c->clusters_shared && env_int("BEPUHIP_COOPERATIVE", 1) != 0) {
+            if (c->clusters_shared && env_int("BEPUHIP_COOPERATIVE", (c->flags & BEPUHIP_FLAG_EXCLUSIVE_DEVICE) ? 0 : 1) != 0) {
                 // The clusters of a split plan wait for each other: they must all be resident at once. A cooperative launch of exactly the clusters makes the runtime
                 // guarantee that (or refuse), whatever else runs on the device; the per-body tail follows as an ordinary launch of the same kernel.
                 if (hipLaunchCooperativeKernel(fn, dim3(c->cluster_count), dim3(threads), args, (unsigned)launch_lds, c->stream) == hipSuccess) {
@@ -1270,7 +1270,7 @@ static int32_t relayout_slab(bepuhip_ctx* c, const std::vector<OldLayout>& old) 
     uint32_t* fresh[2] = {nullptr, nullptr};
     uint32_t* prev[2] = {c->d_slab, c->d_slab0};
     for (int k = 0; k < 2 && words > 0; ++k) {
-        HIP_TRY(hipMalloc((void**)&fresh[k], words * 4));
+        HIP_TRY(hipMalloc((void**)&fresh[k], words * 4 + kSlabTailPadBytes));
         HIP_TRY(hipMemsetAsync(fresh[k], 0xFF, words * 4, c->stream));  // unused lanes read as -1 references / NaN floats: never touched by a launch (count bounds them)
         for (size_t t = 0; t < c->tbs.size(); ++t) {
             const HostTypeBatch& tb = c->tbs[t];

@@ -24,6 +24,7 @@ BEPUHIP_E_STATE = -4
 BEPUHIP_FLAG_NO_GRAPH = 1
 BEPUHIP_FLAG_NO_CLUSTERS = 2
 BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS = 8  # island schedule: spare device slots per cluster segment, so that add_constraint keeps the island schedule
+BEPUHIP_FLAG_EXCLUSIVE_DEVICE = 16  # nothing else runs on the device during a solve: split-island plans launch plainly instead of cooperatively
 
 # Every symbol include/bepuhip.h declares (checked by the CPU test-suite against the header).
 EXPORTED_SYMBOLS = [
@@ -177,10 +178,12 @@ class HipSolver:
 
     PROFILE_FAMILIES = ("incremental", "integrate", "warmstart", "solve", "final", "cluster")
 
-    def __init__(self, device: int = 0, bundle_width: int = 8, use_graph: bool = True, use_clusters: bool = True, reserve_update_slots: bool = False):
+    def __init__(self, device: int = 0, bundle_width: int = 8, use_graph: bool = True, use_clusters: bool = True, reserve_update_slots: bool = False,
+                 exclusive_device: bool = False):
         self.lib = load_library()
         self.ctx = C.c_void_p()
-        cfg = Config(device, bundle_width, (0 if use_graph else BEPUHIP_FLAG_NO_GRAPH) | (0 if use_clusters else BEPUHIP_FLAG_NO_CLUSTERS) | (BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS if reserve_update_slots else 0))
+        cfg = Config(device, bundle_width, (0 if use_graph else BEPUHIP_FLAG_NO_GRAPH) | (0 if use_clusters else BEPUHIP_FLAG_NO_CLUSTERS) | (BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS if reserve_update_slots else 0)
+                     | (BEPUHIP_FLAG_EXCLUSIVE_DEVICE if exclusive_device else 0))
         _check(self.lib, self.lib.bepuhip_create(C.byref(cfg), C.byref(self.ctx)))
         self.bundle_width = bundle_width
         self._scene_meta = None

@@ -40,6 +40,10 @@ typedef struct bepuhip_config {
 #define BEPUHIP_FLAG_NO_CLUSTERS 2 /* never use the island-per-workgroup (LDS-resident) schedule; always one launch per batch per stage */
 #define BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS 8 /* island schedule: leave an eighth more device slots (at least two) behind every cluster's constraints of every type batch, so that
                                                bepuhip_add_constraint finds room and the context stays on the island schedule across the narrow phase's add / remove stream */
+#define BEPUHIP_FLAG_EXCLUSIVE_DEVICE 16 /* the caller states that nothing else runs on the device while a solve of this context is in flight (no other context, stream or
+                                          process). The clusters of a split-island plan wait for each other inside one launch and must all be resident at once: by default
+                                          that launch is cooperative (the runtime guarantees co-residency or refuses), which costs about 25 us per step; with this flag it
+                                          is an ordinary launch. Nothing else depends on the flag. */
 /* flag value 4 is reserved (round 1's opt-in cooperative "stream" schedule: measured slower than the graph replay on every scene, now an archived experiment
    under tools/experiments/stream_schedule/) */
 
@@ -68,7 +72,8 @@ int32_t bepuhip_set_bodies(bepuhip_ctx* ctx, const void* body_dynamics_aos, int3
  * reference's order, then end. Buffers are the TypeBatch's BodyReferences / PrestepData / AccumulatedImpulses in
  * AOSOA layout for config.bundle_width (BepuPhysics/Constraints/TypeProcessor.cs:139-148,269-279). Body references carry
  * the reference's encoding: low 30 bits index, bit 30 kinematic, -1 empty lane (BepuPhysics/Bodies_GatherScatter.cs:107-139).
- * batch_count > FallbackBatchThreshold (a sequential fallback batch exists, BepuPhysics/Solver.cs:1878-1884) -> UNSUPPORTED. */
+ * batch_count == FallbackBatchThreshold + 1: the last batch is the sequential fallback batch (BepuPhysics/Solver.cs:1878-1884), accepted and solved in dependency levels
+ * (empty lanes carry -1 references); more batches than that cannot exist and are refused (INVALID_ARGUMENT). */
 int32_t bepuhip_begin_constraints(bepuhip_ctx* ctx, int32_t batch_count, int32_t fallback_batch_threshold);
 int32_t bepuhip_set_type_batch(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t constraint_count,
                                const int32_t* body_references_aosoa, const float* prestep_aosoa, const float* accumulated_impulses_aosoa);
@@ -198,7 +203,8 @@ int32_t bepuhip_get_constraint_count(bepuhip_ctx* ctx, int32_t batch_index, int3
 
 /* ---- PredictBoundingBoxes on the device ----
  * Replaces the per-body work of PoseIntegrator.PredictBoundingBoxes (BepuPhysics/PoseIntegrator.cs:307-370, called from Simulation.PredictBoundingBoxes,
- * BepuPhysics/Simulation.cs:252-262) for bodies whose shape is one of the five primitive convex types: sleep candidacy from the stored velocity
+ * BepuPhysics/Simulation.cs:252-262) for every shape type the reference registers (sphere, capsule, box, triangle, cylinder, convex hull, compound, big compound,
+ * mesh): sleep candidacy from the stored velocity
  * (UpdateSleepCandidacy :287-305), the velocity callback for the full dt on a copy, TShapeWide.GetBounds, the angular / linear expansion and the speculative
  * margin of BoundingBoxBatcher.ExecuteConvexBatch (BepuPhysics/Collidables/BoundingBoxBatcher.cs:142-223). It reads the bodies the last set_bodies /
  * update_bodies / solve left on the device; the caller copies min/max into the broad phase leaves (BroadPhase.GetActiveBoundsPointers) and the margin and

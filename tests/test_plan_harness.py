@@ -51,13 +51,13 @@ def test_plan_is_deterministic_and_independent_of_the_planning_threads(harness):
 
 def test_one_connected_pile_is_cut_and_the_cut_switches_reduce_the_shared_bodies(harness):
     exe, scenes = harness
-    default = _run(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24)
-    assert default["shared"] == 1 and default["clusters"] > 1 and default["shared_bodies"] > 0
-    cover = _run(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24, BEPUHIP_SPLIT_COVER=1)
+    first_body = _run(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24, BEPUHIP_SPLIT_COVER=0, BEPUHIP_SPLIT_REFINE=0)  # round 2's rule: the first dynamic body's cluster runs a crossing constraint
+    assert first_body["shared"] == 1 and first_body["clusters"] > 1 and first_body["shared_bodies"] > 0
+    cover = _run(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24, BEPUHIP_SPLIT_COVER=1, BEPUHIP_SPLIT_REFINE=0)
     refined = _run(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24, BEPUHIP_SPLIT_COVER=1, BEPUHIP_SPLIT_REFINE=2)
     assert cover["enabled"] == refined["enabled"] == 1
-    assert refined["shared_bodies"] <= cover["shared_bodies"] < default["shared_bodies"]
-    assert _run(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24, BEPUHIP_SPLIT_COVER=0, BEPUHIP_SPLIT_REFINE=0)["digest"] == default["digest"]  # off = the default plan
+    assert refined["shared_bodies"] <= cover["shared_bodies"] < first_body["shared_bodies"]
+    assert _run(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24)["digest"] == refined["digest"]  # the default plan since round 3: vertex cover + two refine sweeps
     assert _run(exe, scenes["pile"], BEPUHIP_NO_SPLIT=1)["enabled"] == 0  # the launch-per-batch schedule takes the scene
     whole = _run(exe, scenes["ragdoll_tube"])
     assert whole["shared"] == 0 and whole["shared_bodies"] == 0  # islands that fit are never cut
