@@ -55,7 +55,6 @@ struct ClusterShared {
     unsigned passes;       // passes (warm starts + velocity iterations) completed before the current one, over the whole step
     int code_touch;        // see touch_code_ahead
     unsigned scratch_row;  // LDS byte address of the 256-byte row that swallows the code-touch reads
-    unsigned slot_addr;    // PREFETCH: LDS byte address of this wave's row-prefetch slot
 };
 
 template <int ACCESS>
@@ -318,44 +317,6 @@ __device__ __forceinline__ void touch_code_ahead(const ClusterShared& sh, int la
     for (int span = 0; span < sh.code_touch; ++span) glds_dword((const char*)pc + (size_t)span * 8192 + (size_t)lane * 128, (unsigned)__builtin_amdgcn_readfirstlane((int)sh.scratch_row));
 }
 
-__device__ __forceinline__ void glds_dwordx4(const void* gsrc, unsigned lds_dst) {  // 16 bytes per lane to lds_dst + 16 * lane; gsrc 16-byte aligned
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-// PREFETCH variants: a wave claims one work item ahead and lets LDS-DMA bring that item's rows (local references, shared-body ranks, prestep, accumulated impulses)
-// into the wave's own LDS slot while it works on the current item, whose rows it has just moved from the same slot into registers. The row loads (about a third of an
-// item's time on a split-island plan) leave the dependency chain.
-// What travels is, per row, the 16-byte aligned window of 68 elements around the item's (at most 64) elements: 17 chunks of 16 bytes, so that one LDS-DMA instruction
-// moves three rows (51 lanes x 16 bytes; a dword per lane would take three times the instructions, and issuing them is what the wave pays). A row lands at
-// slot + row * kPrefetchRowPitch; element e of the item is at dword (start & 3) + e of it. Windows may run a few elements past a row's end into the next row (or the
-// slab's padding): those elements are never read.
-// A wave now holds two claims, the one it works on and a later one: claims are still handed out and started per wave in ascending (topological) order, so the
-// earliest unfinished item is always somebody's CURRENT item with all predecessors finished — the deadlock-freedom argument of the schedule is unchanged.
-struct RowAhead {
-    lds_u32* counter; unsigned claim_base; int total, item_count; const ClusterItem* items; unsigned slot_addr; int next;
-    template <bool SHARED>
-    __device__ __forceinline__ void advance(unsigned* __restrict__ slab, int lane) {
-        next = (int)(claim_next(counter) - claim_base);
-        if (next >= total) return;
-        const ClusterItem* it = items + (next >= item_count ? next - item_count : next);
-        const int stride = __builtin_amdgcn_readfirstlane(it->stride), start = __builtin_amdgcn_readfirstlane(it->start);
-        const int shape = __builtin_amdgcn_readfirstlane(it->shape);
-        const unsigned lrefs_off = __builtin_amdgcn_readfirstlane(it->lrefs_off), prestep_off = __builtin_amdgcn_readfirstlane(it->prestep_off), accum_off = __builtin_amdgcn_readfirstlane(it->accum_off);
-        const int nb = shape & 0xFF, pf = (shape >> 8) & 0xFF, imf = (shape >> 16) & 0xFF;
-        const int nref = (nb + 1) / 2 + (SHARED ? nb : 0);  // the rank rows of a split plan sit right behind the local references
-        const int rows = nref + pf + imf;
-        const int sub = lane / 17, chunk = lane - sub * 17;  // this lane's row within a group of three, and its 16-byte chunk of the window
-        const unsigned* window = slab + (start & ~3) + chunk * 4;
-        const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)slot_addr);
-        for (int r0 = 0; r0 < rows; r0 += 3) {
-            const int r = r0 + sub;
-            const size_t row_words = r < nref ? (size_t)lrefs_off + (size_t)r * stride : (r < nref + pf ? (size_t)prestep_off + (size_t)(r - nref) * stride : (size_t)accum_off + (size_t)(r - nref - pf) * stride);
-            if (lane < 51 && r < rows) glds_dwordx4(window + row_words, dst0 + (unsigned)r0 * kPrefetchRowPitch);
-        }
-    }
-};
-
 struct ItemStamps { unsigned long long loaded, pre_gate, post_gate; };  // trace builds only
 
 // The gate the cluster path hands to the constraint functions: wait for the item's predecessors, then gather the velocities.
@@ -421,9 +382,9 @@ __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared&
     if (STAGE == kStageSolve && active) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) accum[(size_t)f * stride + i] = a[f]; }
 }
 
-template <class F, int STAGE, bool TRACE, bool SHARED, bool PREFETCH>
+template <class F, int STAGE, bool TRACE, bool SHARED>
 __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
-                                                       unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps, RowAhead& ahead) {
+                                                       unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
     // Lanes beyond the item's count mirror its last constraint and never store: the whole body runs with a full exec mask,
     // which keeps the control flow around the (wave-uniform) waits trivially structured.
     const bool active = lane < h.count;
@@ -433,36 +394,20 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     gfloat* accum = (gfloat*)(slab + h.accum_off);
     float p[F::prestepFloats];
     float a[F::impulseFloats];
-    unsigned both;  // two 16-bit local references per word
+    // issue the item's global loads first: their latency hides under the velocity-independent work and the wait for the predecessors
+    const unsigned both = kRowsNonTemporal ? (unsigned)__builtin_nontemporal_load(&lrefs[i]) : (unsigned)lrefs[i];  // two 16-bit local references per word
     unsigned rank_a = 0u, rank_b = 0u;  // SHARED: rank | degree << 8 of this application on each shared body (rows right behind the local references)
-    if constexpr (PREFETCH && STAGE != kStageIncremental) {
-        // The rows are in this wave's LDS slot: its own LDS-DMA reads, issued while it worked on its previous item (RowAhead::advance). Move them into registers,
-        // then claim the next item and send ITS rows on their way into the same slot.
-        constexpr int kRefRows = (F::bodies + 1) / 2, kFirstPrestep = kRefRows + (SHARED ? F::bodies : 0);
-        constexpr int kPitch = (int)kPrefetchRowPitch / 4;
-        wait_vm();
-        const lds_u32* row = (const lds_u32*)(__SIZE_TYPE__)sh.slot_addr + ((h.start & 3) + (active ? lane : h.count - 1));  // lanes beyond the count mirror the last constraint
-        both = row[0];
-        if constexpr (SHARED) { rank_a = row[kPitch * kRefRows]; if (F::bodies == 2) rank_b = row[kPitch * (kRefRows + 1)]; }
-        _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = __uint_as_float(row[kPitch * (kFirstPrestep + f)]);
-        _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = __uint_as_float(row[kPitch * (kFirstPrestep + F::prestepFloats + f)]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every row is in registers before the slot is written again
-        ahead.advance<SHARED>(slab, lane);
+    if constexpr (SHARED) {
+        const gint* srank = lrefs + (size_t)((F::bodies + 1) / 2) * stride;
+        rank_a = (unsigned)srank[i];
+        if (F::bodies == 2) rank_b = (unsigned)srank[(size_t)stride + i];
+    }
+    if (kRowsNonTemporal) {  // per translation unit (BEPU_VARIANT_NT): the constraint rows are read once per pass; see the note on box classes in DESIGN.md 5
+        _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = __builtin_nontemporal_load(&prestep[(size_t)f * stride + i]);
+        if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = __builtin_nontemporal_load(&accum[(size_t)f * stride + i]); }
     } else {
-        // issue the item's global loads first: their latency hides under the velocity-independent work and the wait for the predecessors
-        both = kRowsNonTemporal ? (unsigned)__builtin_nontemporal_load(&lrefs[i]) : (unsigned)lrefs[i];
-        if constexpr (SHARED) {
-            const gint* srank = lrefs + (size_t)((F::bodies + 1) / 2) * stride;
-            rank_a = (unsigned)srank[i];
-            if (F::bodies == 2) rank_b = (unsigned)srank[(size_t)stride + i];
-        }
-        if (kRowsNonTemporal) {  // per translation unit (BEPU_VARIANT_NT): the constraint rows are read once per pass; see the note on box classes in DESIGN.md 5
-            _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = __builtin_nontemporal_load(&prestep[(size_t)f * stride + i]);
-            if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = __builtin_nontemporal_load(&accum[(size_t)f * stride + i]); }
-        } else {
-            _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
-            if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
-        }
+        _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
+        if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
     }
     if (STAGE != kStageIncremental) touch_code_ahead(sh, lane);
     const int ra = unpack_local_ref(both & 0xFFFFu);
@@ -519,10 +464,10 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
 using DC1O = Contact<1, false>; using DC2O = Contact<2, false>; using DC3O = Contact<3, false>; using DC4O = Contact<4, false>;
 using DC1T = Contact<1, true>; using DC2T = Contact<2, true>; using DC3T = Contact<3, true>; using DC4T = Contact<4, true>;
 
-template <int STAGE, bool TRACE, bool WIDE, bool SHARED, bool PREFETCH>
+template <int STAGE, bool TRACE, bool WIDE, bool SHARED>
 __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
-                                                 unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps, RowAhead& ahead) {
-#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE, SHARED, PREFETCH>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps, ahead); break;
+                                                 unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
+#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE, SHARED>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps); break;
     switch (h.type_id) {
         BEPU_CASE(kContact1OneBody, DC1O) BEPU_CASE(kContact2OneBody, DC2O) BEPU_CASE(kContact3OneBody, DC3O) BEPU_CASE(kContact4OneBody, DC4O)
         BEPU_CASE(kContact1, DC1T) BEPU_CASE(kContact2, DC2T) BEPU_CASE(kContact3, DC3T) BEPU_CASE(kContact4, DC4T)
@@ -562,16 +507,13 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
 // predecessors), so the head of the iteration runs while the tail of the warm start's dependency chain is still draining. The warm start does
 // not write accumulated impulses, hence nothing the iteration loads from HBM is in flight. STAGE0 = kStageSolve with solve_items = 0 runs a
 // later iteration on its own (a barrier precedes it: its impulses were stored by the previous one).
-template <int STAGE0, bool TRACE, bool WIDE, bool SHARED, bool PREFETCH>
+template <int STAGE0, bool TRACE, bool WIDE, bool SHARED>
 __device__ __forceinline__ void run_cluster_sweep(ClusterShared& sh, int item_count, int solve_items, int lane, int wave, unsigned epoch, unsigned claim_base,
                                                   unsigned* __restrict__ slab, float dt, float inv_dt, unsigned long long* trace) {
     const unsigned pass_base = sh.passes;
-    const int total = item_count + solve_items;
-    RowAhead ahead = {sh.counter, claim_base, total, item_count, sh.items, sh.slot_addr, 0};
-    int v;
-    if constexpr (PREFETCH) { ahead.advance<SHARED>(slab, lane); v = ahead.next; }  // the sweep's first claim: its rows start their way into the slot
-    else v = (int)(claim_next(sh.counter) - claim_base);
-    while (v < total) {
+    for (;;) {
+        const int v = (int)(claim_next(sh.counter) - claim_base);
+        if (v >= item_count + solve_items) break;
         const bool second = v >= item_count;
         const int k = second ? v - item_count : v;
         const unsigned item_epoch = second ? epoch + 1 : epoch;
@@ -581,9 +523,8 @@ __device__ __forceinline__ void run_cluster_sweep(ClusterShared& sh, int item_co
         if (TRACE) t0 = __builtin_readcyclecounter();
         ItemStamps stamps = {0, 0, 0};
         if constexpr (SHARED) sh.passes = pass_base + (second ? 1u : 0u);  // wave-private copy: which pass of the step this item belongs to
-        if constexpr (PREFETCH) ahead.next = -1;
-        if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE, WIDE, SHARED, PREFETCH>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps, ahead);
-        else run_cluster_item<kStageSolve, TRACE, WIDE, SHARED, PREFETCH>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps, ahead);
+        if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE, WIDE, SHARED>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+        else run_cluster_item<kStageSolve, TRACE, WIDE, SHARED>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
         if (TRACE && trace && blockIdx.x == 0 && lane == 0 && item_epoch - 1 < (unsigned)kClusterTracePasses) {  // iteration counts are unbounded: never write past the buffer
             unsigned long long* rec = trace + ((size_t)(item_epoch - 1) * item_count + k) * 8;
             rec[4] = stamps.loaded; rec[5] = stamps.pre_gate; rec[6] = stamps.post_gate; rec[7] = 0;
@@ -591,18 +532,11 @@ __device__ __forceinline__ void run_cluster_sweep(ClusterShared& sh, int item_co
             rec[2] = (unsigned long long)wave | ((unsigned long long)h.type_id << 8) | ((unsigned long long)h.batch << 16) | ((unsigned long long)((STAGE0 == kStageWarmStart && !second) ? kStageWarmStart : kStageSolve) << 32);
             rec[3] = (unsigned long long)h.count;
         }
-        if constexpr (PREFETCH) {
-            // an item whose code path does not take its rows from the slot (three- and four-body types, an unknown type id) has not claimed ahead either
-            if (__builtin_amdgcn_readfirstlane(ahead.next) == -1) { wait_vm(); ahead.advance<SHARED>(slab, lane); }
-            v = ahead.next;
-        } else {
-            v = (int)(claim_next(sh.counter) - claim_base);
-        }
     }
     if constexpr (SHARED) sh.passes = pass_base;
 }
 
-template <int THREADS, bool TRACE, bool WIDE, bool SHARED, bool PREFETCH>
+template <int THREADS, bool TRACE, bool WIDE, bool SHARED>
 __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __restrict__ clusters, const ClusterItem* __restrict__ items,
                                                                    const int* __restrict__ batch_item_begin, const int* __restrict__ cluster_bodies,
                                                                    float4* bodies, unsigned* __restrict__ slab, ClusterParams cp, int ncap, int max_items,
@@ -656,7 +590,6 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.slot_body = slot_body_lds;
     sh.code_touch = cp.code_touch;
     sh.scratch_row = lds_address((const volatile lds_u32*)lds) + (unsigned)cluster_lds_core_bytes(cp.planes, ncap, max_items, SHARED);
-    sh.slot_addr = sh.scratch_row + (unsigned)kLdsScratchRowBytes + (unsigned)(threadIdx.x >> 6) * (unsigned)cp.prefetch_rows * kPrefetchRowPitch;
     const ClusterDesc cd = clusters[blockIdx.x];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
@@ -689,8 +622,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 const ItemHeader h = read_item(it);
                 if (!isContactType(h.type_id)) continue;
                 ItemStamps stamps = {0, 0, 0};
-                RowAhead none = {};
-                run_cluster_item<kStageIncremental, false, WIDE, SHARED, false>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps, none);
+                run_cluster_item<kStageIncremental, false, WIDE, SHARED>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
             }
             __syncthreads();
         }
@@ -746,14 +678,14 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         __syncthreads();
         ++epoch;
         const int fused = cp.iters[s] > 0 ? cd.item_count : 0;  // the first velocity iteration rides in the warm start's claim sequence
-        run_cluster_sweep<kStageWarmStart, TRACE, WIDE, SHARED, PREFETCH>(sh, cd.item_count, fused, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+        run_cluster_sweep<kStageWarmStart, TRACE, WIDE, SHARED>(sh, cd.item_count, fused, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
         claim_base += cd.item_count + fused + nwaves;  // every wave makes exactly one failing claim per sweep
         sh.passes += fused ? 2u : 1u;
         if (fused) ++epoch;
         __syncthreads();
         for (int iter = 1; iter < cp.iters[s]; ++iter) {
             ++epoch;
-            run_cluster_sweep<kStageSolve, TRACE, WIDE, SHARED, PREFETCH>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
+            run_cluster_sweep<kStageSolve, TRACE, WIDE, SHARED>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
             claim_base += cd.item_count + nwaves;
             sh.passes += 1u;
             __syncthreads();

@@ -20,13 +20,9 @@ const void* bepu_cluster_kernel_hot_768s(bool trace);
 const void* bepu_cluster_kernel_wide_768s(bool trace);
 const void* bepu_cluster_kernel_hot_512s(bool trace);
 const void* bepu_cluster_kernel_wide_512s(bool trace);
-const void* bepu_cluster_kernel_hot_512sp(bool trace);   // split-island plans with the next item's rows prefetched into LDS (RowAhead)
-const void* bepu_cluster_kernel_wide_512sp(bool trace);
 constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
-constexpr size_t kSlabTailPadBytes = 1024;
 static int cluster_variant_threads(int threads) { return threads > 768 ? 1024 : (threads > 512 ? 768 : 512); }  // the smallest budget that still fits `threads`
-static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false, bool prefetch = false) {
-    if (prefetch && shared && cluster_variant_threads(threads) == 512) return wide ? bepu_cluster_kernel_wide_512sp(trace) : bepu_cluster_kernel_hot_512sp(trace);
+static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false) {
     if (nt && !shared && cluster_variant_threads(threads) == 1024) return wide ? bepu_cluster_kernel_wide_1024n(trace) : bepu_cluster_kernel_hot_1024n(trace);
     if (nt && shared && cluster_variant_threads(threads) == 512) return wide ? bepu_cluster_kernel_wide_512sn(trace) : bepu_cluster_kernel_hot_512sn(trace);
     if (shared) switch (cluster_variant_threads(threads)) {
@@ -178,7 +174,6 @@ struct bepuhip_ctx {
     unsigned* d_shared_info = nullptr;
     size_t shared_bodies = 0;         // table length (bodies)
     unsigned shared_epoch = 0;        // event numbers of the next step start here (SharedTables.base): the records are cleared once, not per step
-    int cluster_item_rows = 0;        // most 256-byte rows (references, ranks, prestep, impulses) any work item of the plan reads: the size of a row-prefetch slot
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
     int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0, cluster_planes = 8;
     ClusterDesc first_cluster = {0, 0, 0, 0, 0};

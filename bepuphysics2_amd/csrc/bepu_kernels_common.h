@@ -42,14 +42,13 @@ static_assert(offsetof(ClusterItem, xpred) == offsetof(ClusterItem, pred) + kMax
 __host__ __device__ inline size_t cluster_sync_words(int max_items) { return (size_t)max_items + 2 * (kFallbackBatchLimit + 1) + 2; }
 struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
 // LDS of a cluster workgroup: [planes x ncap float4 body table][work items][sync words][SHARED: slot -> body table][one scratch row of 256 B: the destination of the
-// LDS-DMA reads that only exist to pull code into L2 (touch_code_ahead)][row-prefetch slots: one per wave, prefetch_rows x kPrefetchRowPitch B each (PREFETCH variants)].
+// LDS-DMA reads that only exist to pull code into L2 (touch_code_ahead)].
 __host__ __device__ inline size_t cluster_lds_core_bytes(int planes, int ncap, int max_items, bool shared) {
     return (size_t)planes * ncap * 16 + (size_t)max_items * sizeof(ClusterItem) + (cluster_sync_words(max_items) + 3) / 4 * 16 + (shared ? ((size_t)ncap * 4 + 15) / 16 * 16 : 0);
 }
 constexpr size_t kLdsScratchRowBytes = 256;
-constexpr unsigned kPrefetchRowPitch = 272;  // bytes of one prefetched row in LDS: 17 chunks of 16 bytes = the 68-element window that holds an item's 64 elements wherever it starts (RowAhead)
-__host__ __device__ inline size_t cluster_lds_bytes(int planes, int ncap, int max_items, bool shared = false, int prefetch_rows = 0, int waves = 0) {
-    return cluster_lds_core_bytes(planes, ncap, max_items, shared) + kLdsScratchRowBytes + (size_t)prefetch_rows * waves * kPrefetchRowPitch;
+__host__ __device__ inline size_t cluster_lds_bytes(int planes, int ncap, int max_items, bool shared = false) {
+    return cluster_lds_core_bytes(planes, ncap, max_items, shared) + kLdsScratchRowBytes;
 }
 // Slot table entries (cluster_bodies): body index | flags; -1 = unused slot.
 constexpr int kSlotKinematic = 1 << 30;   // private read-only copy of a kinematic body
@@ -78,7 +77,6 @@ struct ClusterParams {
     int substeps, batch_count, integrate_velocity_for_kinematics;
     int planes;  // kSweepPlanes or kAllPlanes
     int code_touch;     // 8 KB spans of its own upcoming code a wave pulls into L2 at the start of every work item (0: off), see touch_code_ahead
-    int prefetch_rows;  // PREFETCH variants: rows (kPrefetchRowPitch bytes each) of a wave's row-prefetch slot in LDS
     int iters[kMaxClusterSubsteps];
     StepParams sp;
 };

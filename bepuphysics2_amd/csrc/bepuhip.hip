@@ -465,8 +465,8 @@ static int32_t build_constraints(bepuhip_ctx* c) {
     }
     c->slab_words = words;
     if (words > 0) {
-        HIP_TRY(hipMalloc((void**)&c->d_slab, words * 4 + kSlabTailPadBytes));  // the row-prefetch windows of the last rows may read a few elements past the end (RowAhead)
-        HIP_TRY(hipMalloc((void**)&c->d_slab0, words * 4 + kSlabTailPadBytes));
+        HIP_TRY(hipMalloc((void**)&c->d_slab, words * 4));
+        HIP_TRY(hipMalloc((void**)&c->d_slab0, words * 4));
         std::unique_ptr<uint32_t[]> host(new uint32_t[words]);  // not zeroed: the four rows of every type batch tile [0, words) exactly (offsets assigned above from the same sizes)
         for (auto& tb : c->tbs) {
             if (!tb.refs_soa.empty()) memcpy(&host[tb.refs_off], tb.refs_soa.data(), tb.refs_soa.size() * 4);
@@ -508,11 +508,6 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             it.prestep_off = (unsigned)tb.prestep_off;
             it.accum_off = (unsigned)tb.accum_off;
         }
-        c->cluster_item_rows = 0;
-        for (auto& it : plan.items) {
-            const int nb = it.shape & 0xFF, pf = (it.shape >> 8) & 0xFF, imf = (it.shape >> 16) & 0xFF;
-            c->cluster_item_rows = std::max(c->cluster_item_rows, (nb + 1) / 2 + (plan.shared ? nb : 0) + pf + imf);
-        }
         c->clustered_dynamic_count = (int)plan.clustered_dynamic.size();
         HIP_TRY(upload_ints(plan.clusters.data(), plan.clusters.size() * sizeof(ClusterDesc), (void**)&c->d_clusters));
         HIP_TRY(upload_ints(plan.items.data(), plan.items.size() * sizeof(ClusterItem), (void**)&c->d_items));
@@ -536,9 +531,6 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             HIP_TRY(hipMalloc((void**)&c->d_shared_vel, c->shared_bodies * 4 * sizeof(float4)));  // two records (substep parity) of two float4 per body
             HIP_TRY(hipMemset(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4)));         // cleared here, then never again: every step's event numbers start above the last step's
             c->shared_epoch = 0;
-            for (int tr = 0; tr < 2; ++tr)
-                for (int wide = 0; wide < 2; ++wide)
-                    HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(512, tr != 0, wide != 0, true, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
             HIP_TRY(upload_ints(plan.shared_info.data(), plan.shared_info.size() * 4, (void**)&c->d_shared_info));
             for (int threads : kClusterThreadChoices)
                 for (int tr = 0; tr < 2; ++tr)
@@ -655,12 +647,8 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             // Scenes with SURVEY 8(f) types take the 512-thread build: at 128 VGPRs per wave the widened types spill hundreds of registers.
             const int req = env_int("BEPUHIP_CLUSTER_THREADS", c->has_widened_types ? kSplitClusterThreads : kClusterThreads);
             const int threads = std::max(64, std::min(1024, (c->clusters_shared ? env_int("BEPUHIP_SPLIT_THREADS", kSplitClusterThreads) : req) / 64 * 64));
-            // Split plans at 512 threads: the next work item's rows travel into LDS while the current one runs, if the wave slots fit behind the bodies.
-            const bool prefetch = c->clusters_shared && cluster_variant_threads(threads) == 512 && env_int("BEPUHIP_PREFETCH", 1) != 0 && c->cluster_item_rows > 0 &&
-                                  cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, true, c->cluster_item_rows, threads / 64) <= kLdsBudgetBytes;
             cp.code_touch = std::max(0, std::min(4, env_int("BEPUHIP_CODE_TOUCH", 0)));
-            cp.prefetch_rows = prefetch ? c->cluster_item_rows : 0;
-            const size_t launch_lds = prefetch ? cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, true, c->cluster_item_rows, threads / 64) : lds_bytes;
+            const size_t launch_lds = lds_bytes;
             // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
             // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).
             TailParams tp;
@@ -688,7 +676,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
                             (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
             const bool tr = c->d_trace != nullptr;
-            const bool policy_applies = !prefetch && cluster_variant_threads(threads) == (c->clusters_shared ? 512 : 1024);  // the variants that exist in both row policies
+            const bool policy_applies = cluster_variant_threads(threads) == (c->clusters_shared ? 512 : 1024);  // the variants that exist in both row policies
             int sample = -1;
             bool nt = false;
             if (policy_applies) {
@@ -696,7 +684,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
                 if (c->row_policy < 0) { sample = c->policy_samples++; nt = (sample & 1) != 0; }  // plain, non-temporal, plain, ... each under its own event pair
                 else nt = c->row_policy == 1;
             }
-            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, prefetch);  // the register budget that matches the workgroup size
+            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt);  // the register budget that matches the workgroup size
             if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
             const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
             bool launched = false;
@@ -1270,7 +1258,7 @@ static int32_t relayout_slab(bepuhip_ctx* c, const std::vector<OldLayout>& old) 
     uint32_t* fresh[2] = {nullptr, nullptr};
     uint32_t* prev[2] = {c->d_slab, c->d_slab0};
     for (int k = 0; k < 2 && words > 0; ++k) {
-        HIP_TRY(hipMalloc((void**)&fresh[k], words * 4 + kSlabTailPadBytes));
+        HIP_TRY(hipMalloc((void**)&fresh[k], words * 4));
         HIP_TRY(hipMemsetAsync(fresh[k], 0xFF, words * 4, c->stream));  // unused lanes read as -1 references / NaN floats: never touched by a launch (count bounds them)
         for (size_t t = 0; t < c->tbs.size(); ++t) {
             const HostTypeBatch& tb = c->tbs[t];
