@@ -150,8 +150,8 @@ struct bepuhip_ctx {
     int referenced_bodies = 0;           // 1 + the largest body index any constraint references
     // cluster path
     bool clusters_enabled = false;
-    // Row-load policy of the island schedule's default workgroup sizes (plain or non-temporal accesses to the constraint rows). Which one is faster depends on the box: the
-    // first solves alternate between the two — their results are bit-identical — each timed with its own event pair, then the faster one stays.
+    // Launch policy of the island schedule's default workgroup sizes (plain or non-temporal accesses to the constraint rows, code touched ahead or not; settle_row_policy).
+    // Which one is faster depends on the box: the first solves cycle through the candidates — their results are bit-identical — each timed with its own event pair.
     // Structural updates that keep the island schedule (bepu_soft_updates.h)
     bool soft_ok = false;                        // whole-island plan with its host mirrors in place
     std::vector<int32_t> body_cluster, body_lref, body_degree;  // per dynamic body: its cluster (-1: none), its rotated LDS slot, its constraint count
@@ -166,8 +166,9 @@ struct bepuhip_ctx {
     bool soft_items_dirty = false;
     int64_t soft_adds = 0, soft_removes = 0;     // since the upload (diagnostics)
     bool graphs_cleared_by_structure = false;  // set by flush_structural, consumed by the next solve (which then launches eagerly instead of capturing)
-    int row_policy = -1;              // -1: still measuring; 0 plain; 1 non-temporal (BEPUHIP_ROW_POLICY=0/1 pins it)
+    int row_policy = -1;              // -1: still measuring; 0 plain rows; 1 non-temporal rows; 2 / 3 plain rows + one / two spans of code touched per item (BEPUHIP_ROW_POLICY pins it)
     int policy_samples = 0;           // solves launched while measuring
+    int policy_threads = 0;           // workgroup size the samples ran with
     hipEvent_t policy_events[16][2] = {};
     bool clusters_shared = false;    // split-island plan: bodies shared between clusters go through the tables below
     float4* d_shared_vel = nullptr;   // per body two records (substep parity) of {linear, event number} {angular, event number}

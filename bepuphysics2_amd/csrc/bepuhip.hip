@@ -26,6 +26,8 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <map>
+#include <mutex>
+#include <tuple>
 #include <string>
 #include <type_traits>
 #include <unordered_map>
@@ -599,25 +601,52 @@ static void enqueue_requirk(bepuhip_ctx* c, int substep, int batch, const StepPa
         hipLaunchKernelGGL(momentum_requirk_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_bodies, (const int*)(c->d_requirk + c->requirk_begin[batch]), n, sp);
 }
 
-// Row-load policy (bepu_host_state.h): once kPolicySamples solves have been launched, wait for the last of them, compare the medians, keep the faster variant.
-constexpr int kPolicySamples = 12;
-static void settle_row_policy(bepuhip_ctx* c) {
+// Launch policy of the island schedules (bepu_host_state.h). Candidates — all bit-identical in their results:
+//   0 plain constraint-row accesses, 1 non-temporal row accesses, 2 plain rows + one 8 KB span of code touched per work item, 3 plain rows + two spans.
+// Which one is fastest depends on the box class (on the slow class an instruction fetch that misses L2 is what costs; the touch keeps the code there).
+// The first kPolicySamples solves after an upload cycle through the candidates, each launch under its own event pair. Once the last of them has FINISHED
+// (hipEventQuery: a solve never blocks for the policy's sake) the medians are compared: the fastest candidate stays if it beats plain by more than 2 %, else plain.
+// The decision is kept per (device, plan kind, workgroup size) for the life of the process, so that hosts that upload every frame settle once.
+constexpr int kPolicyCandidates = 4, kPolicyRounds = 4, kPolicySamples = kPolicyCandidates * kPolicyRounds;
+static std::mutex g_policy_mutex;
+static std::map<std::tuple<int, int, int, int>, int> g_policy_cache;
+static std::tuple<int, int, int, int> policy_key(const bepuhip_ctx* c, int threads) { return {c->device, c->clusters_shared ? 1 : 0, c->has_widened_types ? 1 : 0, threads}; }
+static void settle_row_policy(bepuhip_ctx* c, int threads, bool may_block) {
     const int pinned = env_int("BEPUHIP_ROW_POLICY", -1);
-    if (pinned == 0 || pinned == 1) { c->row_policy = pinned; return; }
+    if (pinned >= 0 && pinned < kPolicyCandidates) { c->row_policy = pinned; return; }
+    if (env_int("BEPUHIP_POLICY_CACHE", 1) != 0 && c->policy_samples == 0) {
+        std::lock_guard<std::mutex> lock(g_policy_mutex);
+        auto found = g_policy_cache.find(policy_key(c, threads));
+        if (found != g_policy_cache.end()) { c->row_policy = found->second; return; }
+    }
     if (!c->policy_events[0][0])
         for (auto& pair : c->policy_events) { hipEventCreate(&pair[0]); hipEventCreate(&pair[1]); }
     if (c->policy_samples < kPolicySamples) return;
-    hipEventSynchronize(c->policy_events[kPolicySamples - 1][1]);
-    std::vector<float> ms[2];
-    for (int i = 2; i < kPolicySamples; ++i) {  // the first pair of solves warms clocks and caches
-        float t = 0;
-        if (hipEventElapsedTime(&t, c->policy_events[i][0], c->policy_events[i][1]) == hipSuccess) ms[i & 1].push_back(t);
+    hipEvent_t last = c->policy_events[kPolicySamples - 1][1];
+    if (may_block) hipEventSynchronize(last);
+    else if (hipEventQuery(last) != hipSuccess) { (void)hipGetLastError(); return; }  // still running: this solve launches plain and is not a sample
+    float median[kPolicyCandidates];
+    for (int cand = 0; cand < kPolicyCandidates; ++cand) {
+        std::vector<float> ms;
+        for (int round = 1; round < kPolicyRounds; ++round) {  // the first round warms clocks and caches
+            float t = 0;
+            const int i = round * kPolicyCandidates + cand;
+            if (hipEventElapsedTime(&t, c->policy_events[i][0], c->policy_events[i][1]) == hipSuccess) ms.push_back(t);
+        }
+        std::sort(ms.begin(), ms.end());
+        median[cand] = ms.empty() ? 1e30f : ms[ms.size() / 2];
     }
-    for (auto& v : ms) std::sort(v.begin(), v.end());
-    c->row_policy = (!ms[0].empty() && !ms[1].empty() && ms[1][ms[1].size() / 2] < ms[0][ms[0].size() / 2]) ? 1 : 0;
+    int best = 0;
+    for (int cand = 1; cand < kPolicyCandidates; ++cand) if (median[cand] < median[best]) best = cand;
+    if (!(median[best] < 0.98f * median[0])) best = 0;  // within the noise of plain: keep plain
+    c->row_policy = best;
+    if (env_int("BEPUHIP_POLICY_CACHE", 1) != 0) {
+        std::lock_guard<std::mutex> lock(g_policy_mutex);
+        g_policy_cache[policy_key(c, threads)] = best;
+    }
     if (env_int("BEPUHIP_PLAN_STATS", 0))
-        fprintf(stderr, "bepuhip row policy: plain %.4f ms, non-temporal %.4f ms per launch (medians of %zu) -> %s\n", ms[0].empty() ? 0.f : ms[0][ms[0].size() / 2],
-                ms[1].empty() ? 0.f : ms[1][ms[1].size() / 2], ms[0].size(), c->row_policy ? "non-temporal" : "plain");
+        fprintf(stderr, "bepuhip launch policy: plain %.4f, non-temporal rows %.4f, code touch x1 %.4f, x2 %.4f ms per launch (medians of %d) -> %d\n", median[0], median[1], median[2],
+                median[3], kPolicyRounds - 1, best);
 }
 
 // The island schedule implements AngularIntegrationMode.Nonconserving; the conserving modes run the launch-per-batch schedule.
@@ -647,7 +676,6 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             // Scenes with SURVEY 8(f) types take the 512-thread build: at 128 VGPRs per wave the widened types spill hundreds of registers.
             const int req = env_int("BEPUHIP_CLUSTER_THREADS", c->has_widened_types ? kSplitClusterThreads : kClusterThreads);
             const int threads = std::max(64, std::min(1024, (c->clusters_shared ? env_int("BEPUHIP_SPLIT_THREADS", kSplitClusterThreads) : req) / 64 * 64));
-            cp.code_touch = std::max(0, std::min(4, env_int("BEPUHIP_CODE_TOUCH", 0)));
             const size_t launch_lds = lds_bytes;
             // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
             // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).
@@ -677,13 +705,15 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
                             (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
             const bool tr = c->d_trace != nullptr;
             const bool policy_applies = cluster_variant_threads(threads) == (c->clusters_shared ? 512 : 1024);  // the variants that exist in both row policies
-            int sample = -1;
-            bool nt = false;
+            int sample = -1, candidate = 0;
             if (policy_applies) {
-                if (c->row_policy < 0) settle_row_policy(c);
-                if (c->row_policy < 0) { sample = c->policy_samples++; nt = (sample & 1) != 0; }  // plain, non-temporal, plain, ... each under its own event pair
-                else nt = c->row_policy == 1;
+                if (c->row_policy < 0) settle_row_policy(c, threads, false);
+                if (c->row_policy >= 0) candidate = c->row_policy;
+                else if (c->policy_samples < kPolicySamples) { sample = c->policy_samples++; candidate = sample % kPolicyCandidates; c->policy_threads = threads; }  // each under its own event pair
             }
+            const bool nt = candidate == 1;
+            cp.code_touch = candidate >= 2 ? candidate - 1 : 0;
+            if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(4, forced);
             const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt);  // the register budget that matches the workgroup size
             if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
             const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
@@ -1758,7 +1788,7 @@ int32_t bepuhip_get_cluster_trace(bepuhip_ctx* c, uint64_t* out, int64_t capacit
 }
 int32_t bepuhip_get_row_policy(bepuhip_ctx* c, int32_t* policy_out) {
     if (!c || !policy_out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
-    if (c->row_policy < 0 && c->policy_samples >= kPolicySamples) settle_row_policy(c);
+    if (c->row_policy < 0 && c->policy_samples >= kPolicySamples) settle_row_policy(c, c->policy_threads, true);
     *policy_out = c->row_policy;
     return BEPUHIP_OK;
 }
