@@ -54,6 +54,7 @@ struct ClusterShared {
     unsigned events;       // integration events every shared body has seen so far (substep index + 1 during the sweeps of a substep)
     unsigned passes;       // passes (warm starts + velocity iterations) completed before the current one, over the whole step
     int code_touch;        // see touch_code_ahead
+    int code_touch_gate;   // ... a second touch (spans) from the gate on, issued before the wait for the predecessors
     unsigned scratch_row;  // LDS byte address of the 256-byte row that swallows the code-touch reads
 };
 
@@ -310,11 +311,14 @@ __device__ __forceinline__ void glds_dword(const void* gsrc, unsigned lds_dst) {
 // its own upcoming code as DATA: one LDS-DMA read per 8 KB span, lane l reading the 128-byte line l of the span that starts at the current PC, issued right
 // behind the item's row loads. The bytes go to a scratch row nobody reads; what matters is that the lines are on their way into L2 — all at once — before the
 // instruction fetcher asks for them one after the other. Off (0 spans) unless ClusterParams.code_touch says otherwise (BEPUHIP_CODE_TOUCH).
-__device__ __forceinline__ void touch_code_ahead(const ClusterShared& sh, int lane) {
-    if (sh.code_touch == 0) return;
+__device__ __forceinline__ void touch_code_span(const ClusterShared& sh, int lane, int spans) {
     unsigned long long pc;
     asm volatile("s_getpc_b64 %0" : "=s"(pc));
-    for (int span = 0; span < sh.code_touch; ++span) glds_dword((const char*)pc + (size_t)span * 8192 + (size_t)lane * 128, (unsigned)__builtin_amdgcn_readfirstlane((int)sh.scratch_row));
+    for (int span = 0; span < spans; ++span) glds_dword((const char*)pc + (size_t)span * 8192 + (size_t)lane * 128, (unsigned)__builtin_amdgcn_readfirstlane((int)sh.scratch_row));
+}
+__device__ __forceinline__ void touch_code_ahead(const ClusterShared& sh, int lane) {
+    if (sh.code_touch == 0) return;
+    touch_code_span(sh, lane, sh.code_touch);
 }
 
 struct ItemStamps { unsigned long long loaded, pre_gate, post_gate; };  // trace builds only
@@ -327,6 +331,7 @@ struct ClusterGate {
     const SharedRef& sa; const SharedRef& sb;
     __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {
         if (TRACE) stamps.pre_gate = __builtin_readcyclecounter();
+        if (sh.code_touch_gate) touch_code_span(sh, threadIdx.x & 63, sh.code_touch_gate);
         wait_predecessors<CROSS>(sh, it, h, k, epoch);
         __builtin_amdgcn_s_setprio(3);  // from here to the publish the item is on its bodies' critical path: issue ahead of waves still preparing theirs
         load_velocity_lds<ACC_A>(sh, ra, A);
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.st = shared_tables; sh.events = 0; sh.passes = 0;
     int* slot_body_lds = reinterpret_cast<int*>(words + ((cluster_sync_words(max_items) + 3) / 4) * 4);  // SHARED plans: behind the sync words
     sh.slot_body = slot_body_lds;
-    sh.code_touch = cp.code_touch;
+    sh.code_touch = cp.code_touch; sh.code_touch_gate = cp.code_touch_gate;
     sh.scratch_row = lds_address((const volatile lds_u32*)lds) + (unsigned)cluster_lds_core_bytes(cp.planes, ncap, max_items, SHARED);
     const ClusterDesc cd = clusters[blockIdx.x];
     const int tid = threadIdx.x;

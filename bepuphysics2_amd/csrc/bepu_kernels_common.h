@@ -77,6 +77,7 @@ struct ClusterParams {
     int substeps, batch_count, integrate_velocity_for_kinematics;
     int planes;  // kSweepPlanes or kAllPlanes
     int code_touch;     // 8 KB spans of its own upcoming code a wave pulls into L2 at the start of every work item (0: off), see touch_code_ahead
+    int code_touch_gate;  // experimental (BEPUHIP_CODE_TOUCH_GATE): spans touched again from the gate on
     int iters[kMaxClusterSubsteps];
     StepParams sp;
 };

@@ -714,6 +714,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             const bool nt = candidate == 1;
             cp.code_touch = candidate >= 2 ? candidate - 1 : 0;
             if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(4, forced);
+            cp.code_touch_gate = std::max(0, std::min(2, env_int("BEPUHIP_CODE_TOUCH_GATE", 0)));
             const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt);  // the register budget that matches the workgroup size
             if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
             const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
