@@ -153,7 +153,7 @@ def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, s
     scene, sd = sim.export(), sim.solve_description()
     sim.close()
     cb = PoseIntegratorCallbacks()
-    solver = HipSolver(device=device)
+    solver = HipSolver(device=device, exclusive_device=True)  # this process is alone on the GPU: split plans launch plainly (BEPUHIP_FLAG_EXCLUSIVE_DEVICE) instead of cooperatively
     t0 = time.perf_counter()
     solver.upload(scene)
     upload_ms = 1e3 * (time.perf_counter() - t0)
@@ -183,7 +183,7 @@ def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, s
     return {"workload": f"{name}: {scene.body_count} bodies, {scene.constraint_count} constraints, {len(scene.batches)} batches, ONE island, "
                         f"{sd.substep_count} substeps x {list(map(int, its))} iterations",
             "ms_per_step": ms, "value": per_step / (ms * 1e-3), "unit": "constraint-iterations/s",
-            "schedule": "island-per-workgroup, split-island plan (one launch per step)" if clustered else f"launch-per-batch, hipGraph replay, {launches} launches per step",
+            "schedule": "island-per-workgroup, split-island plan (one plain launch per step: BEPUHIP_FLAG_EXCLUSIVE_DEVICE, the bench owns the device; a cooperative launch costs ~25 us more)" if clustered else f"launch-per-batch, hipGraph replay, {launches} launches per step",
             "roofline": hbm_roofline("cluster_kernel<...,SHARED> (whole step in one launch)" if clustered else "whole step (launch-per-batch)", 1e3 * ms if clustered else 1e3 * ms,
                                      traffic, step_bytes, compulsory_stream_bytes(scene, sd) if clustered else None, traffic_detail=detail,
                                      launch_time_basis="wall time per step (one launch per step)" if clustered else f"whole step, {launches} launches"),
@@ -191,33 +191,57 @@ def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, s
 
 
 def boundary_leg(scene, sd, cb, device: int):
-    """What a C# host pays around the resident-in-HBM rate (never `value`): a full upload (set_bodies + begin/set/end, i.e. AOSOA -> rows, cluster planning,
-    H2D), and a frame through the ABI the way HipTimestepper drives it (set_bodies, solve, get_bodies, every type batch's accumulated impulses and the contacts'
-    prestep back), plus the device-resident alternative: 1 % of the contact constraints removed and re-added through the structural calls, then a solve."""
-    from bepuphysics2_amd.native import HipSolver
+    """What a C# host pays around the resident-in-HBM rate (never `value`). All host buffers are registered once (BufferPool blocks are pinned memory that lives as
+    long as the simulation, BufferPool.cs:42,83) and the legs are:
+    * a full upload: set_bodies + begin/set/end (references converted and clusters planned on the host; prestep data and impulses copied as they are and transposed
+      on the device);
+    * the RESIDENT frame a HipTimestepper runs once the scene is on the device: every contact type batch's prestep data refreshed (what the narrow phase rewrites
+      every frame, NarrowPhaseConstraintUpdate.cs:147-207), solve, poses + velocities back into the host's BodyDynamics array — all asynchronous, one sync;
+    * the full round trip of round 2 for comparison (every body in, every body, impulse and prestep row back);
+    * structural churn through the add / remove calls."""
+    from bepuphysics2_amd.native import HipSolver, _check, _ptr
     from bepuphysics2_amd.scene import TYPE_TABLE
     solver = HipSolver(device=device)
+    work = scene.copy()
+    solver.register_host_memory(work.bodies)
+    for b in work.batches:
+        for tb in b:
+            if tb.count:
+                solver.register_host_memory(tb.prestep)
+                solver.register_host_memory(tb.accumulated)
+    solver.upload(work)  # untimed: the first upload also allocates the staging buffers a simulation keeps
     t0 = time.perf_counter()
-    solver.set_bodies(scene.bodies)
+    solver.set_bodies(work.bodies)
     t1 = time.perf_counter()
-    solver.set_constraints(scene, sd.fallback_batch_threshold)
+    solver.set_constraints(work, sd.fallback_batch_threshold)
     kin = np.ascontiguousarray(scene.constrained_kinematic_indices(), dtype=np.int32)
-    from bepuphysics2_amd.native import _check, _ptr
     _check(solver.lib, solver.lib.bepuhip_set_constrained_kinematics(solver.ctx, _ptr(kin), kin.size))
     t2 = time.perf_counter()
-    solver._scene_meta = None
+    solver._scene_meta = [(bi, tb.type_id, tb.count) for bi, b in enumerate(work.batches) for tb in b]
     out = {"set_bodies_ms": 1e3 * (t1 - t0), "end_constraints_ms": 1e3 * (t2 - t1),
-           "end_constraints_note": "begin/set_type_batch/end: AOSOA -> SoA rows, island (cluster) planning on the host, one H2D copy"}
-    work = scene.copy()
-    frames = 5
+           "end_constraints_note": "begin / set_type_batch x type batches / end of an upload that re-uses the context's staging buffers: body references AOSOA -> rows and island "
+                                   "(cluster) planning on the host; prestep data and impulses copied as they are (registered memory) and transposed on the device"}
+    frames = 10
+    contact_tbs = [(bi, tb) for bi, b in enumerate(work.batches) for tb in b if tb.count and TYPE_TABLE[tb.type_id][3].startswith("Contact")]
     solver.solve(1 / 60, sd, cb)
     t0 = time.perf_counter()
     for _ in range(frames):
+        for bi, tb in contact_tbs:
+            solver.update_prestep(bi, tb.type_id, 0, tb.prestep, asynchronous=True)
+        solver.solve(1 / 60, sd, cb, asynchronous=True)
+        solver.get_poses_and_velocities(work.bodies, asynchronous=True)
+        solver.sync()
+    out["frame_through_abi_ms"] = 1e3 * (time.perf_counter() - t0) / frames
+    out["frame_through_abi_note"] = (f"the resident frame: update_prestep_async of all {len(contact_tbs)} contact type batches "
+                                     f"({sum(tb.prestep.nbytes for _, tb in contact_tbs) / 1e6:.1f} MB) + solve_async + get_poses_and_velocities_async "
+                                     f"({work.bodies.shape[0] * 64 / 1e6:.1f} MB) + one sync; host buffers registered")
+    t0 = time.perf_counter()
+    for _ in range(3):
         solver.set_bodies(work.bodies)
         solver.solve(1 / 60, sd, cb)
         solver.download(work)
-    out["frame_through_abi_ms"] = 1e3 * (time.perf_counter() - t0) / frames
-    out["frame_through_abi_note"] = "set_bodies + solve + get_bodies + get_accumulated_impulses / get_prestep of every type batch (HipTimestepper's frame), host buffers pageable"
+    out["full_round_trip_frame_ms"] = 1e3 * (time.perf_counter() - t0) / 3
+    out["full_round_trip_note"] = "round 2's frame_through_abi_ms: set_bodies + solve + get_bodies + get_accumulated_impulses / get_prestep of every type batch, synchronous calls"
     # structural churn: the last 1 % of every two-body contact type batch removed and added again (same bodies, same prestep) per frame — what the narrow phase does to
     # pairs whose manifold changed. The constraint set is the same after every frame, so the frames are comparable.
     contact = [(bi, tb) for bi, b in enumerate(scene.batches) for tb in b if TYPE_TABLE[tb.type_id][3].startswith("Contact") and tb.bodies == 2 and tb.count > 100]
@@ -346,7 +370,7 @@ def traffic_child(args, device: int):
         sim = HostSimulation.scene(*connected_scene_args(args.traffic_child, args.ragdolls))
         scene, sd = sim.export(), sim.solve_description()
         sim.close()
-    solver = HipSolver(device=device)
+    solver = HipSolver(device=device, exclusive_device=True)
     solver.upload(scene)
     cb = PoseIntegratorCallbacks()
     for _ in range(args.warmup + args.steps):

@@ -86,7 +86,10 @@ struct HostTypeBatch {
         if (inv.empty()) { inv.resize(perm.size()); for (size_t d = 0; d < perm.size(); ++d) if (perm[d] >= 0) inv[perm[d]] = (int32_t)d; }
         return inv[host_index];
     }
-    int32_t* d_device_index = nullptr;  // device copy of `inv` for the ranged update / read-back kernels (allocated on first use)
+    int32_t* d_device_index = nullptr;  // device copy of `inv` for the upload, ranged update and read-back kernels: a slice of the context's index pool when built at
+    bool index_pooled = false;          // end_constraints (never freed on its own), else allocated on first use
+    const float* raw_prestep = nullptr; // the caller's AOSOA bundles as they were copied to the device by set_type_batch (ctx.raw_chunks): end_constraints transposes
+    const float* raw_accum = nullptr;   // them into the rows ON the device; the host never touches the values
     // Island layout, whole-island plans (bepu_soft_updates.h): the rows hold `slots` device slots — every cluster's constraints of this type batch in one segment
     // [seg_begin[cluster], seg_begin[cluster + 1]), live ones and free ones (perm[d] == -1: reserved at planning, or left by a removal; their local references are
     // kLrefDead). `dev_refs` mirrors the encoded body references per device slot so that a removal knows whose constraint counts it lowers.
@@ -96,7 +99,7 @@ struct HostTypeBatch {
     int device_extent() const { return slots > 0 ? slots : count; }
     std::vector<int32_t> lrefs_soa; // cluster path: local (LDS) body indices
     std::vector<int32_t> refs_soa;
-    std::vector<float> prestep_soa, accum_soa;  // host staging until end_constraints
+    std::vector<float> prestep_soa, accum_soa;  // only with ctx.host_values (the offline plan harness): host staging until the plan has permuted them
 };
 
 constexpr size_t kMaxCachedGraphs = 8;
@@ -122,6 +125,14 @@ struct bepuhip_ctx {
     int* d_kin = nullptr;
     int kin_count = 0;
     std::vector<int32_t> kin_indices;
+    // upload staging, kept across uploads
+    bool host_values = false;            // offline plan harness only (no device): set_type_batch converts the values on the host as well
+    struct RawChunk { char* ptr; size_t capacity, used; };
+    std::vector<RawChunk> raw_chunks;    // device memory the caller's prestep / impulse bundles are copied into as they are (set_type_batch)
+    int32_t* d_index_pool = nullptr;     // host index -> device slot tables of every permuted type batch (HostTypeBatch::d_device_index points into it)
+    void* h_staging = nullptr;           // pinned host buffer for what the host does build (references, local references, index tables)
+    size_t h_staging_bytes = 0;
+    std::vector<void*> registered_host;  // bepuhip_register_host_memory
     // constraints
     bool building = false, built = false;
     int batch_count = 0;                 // the caller's batches, a sequential fallback batch included
@@ -261,7 +272,9 @@ static void free_constraints(bepuhip_ctx* c) {
     c->clusters_enabled = false; c->cluster_count = 0; c->clustered_dynamic_count = 0; c->kinlist_count = 0;
     c->d_slab = c->d_slab0 = nullptr;
     c->d_tbs = c->d_inc_tbs = nullptr;
-    for (auto& tb : c->tbs) if (tb.d_device_index) hipFree(tb.d_device_index);
+    for (auto& tb : c->tbs) if (tb.d_device_index && !tb.index_pooled) hipFree(tb.d_device_index);
+    if (c->d_index_pool) hipFree(c->d_index_pool);
+    c->d_index_pool = nullptr;
     c->tbs.clear();
     c->batch_count = 0; c->batch_begin.clear(); c->batch_blocks.clear();
     c->inc_blocks = 0; c->inc_tb_count = 0; c->total_constraints = 0; c->slab_words = 0; c->referenced_bodies = 0;

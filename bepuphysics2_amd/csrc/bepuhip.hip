@@ -130,6 +130,9 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_mesh_begin) hipFree(c->d_mesh_begin);
     if (c->d_mesh_scales) hipFree(c->d_mesh_scales);
     if (c->d_stage) hipFree(c->d_stage);
+    for (auto& chunk : c->raw_chunks) if (chunk.ptr) hipFree(chunk.ptr);
+    if (c->h_staging) hipHostFree(c->h_staging);
+    for (void* p : c->registered_host) hipHostUnregister(p);
     if (c->d_boundary) hipFree(c->d_boundary);
     if (c->d_boundary_snapshot) hipFree(c->d_boundary_snapshot);
     if (c->d_boundary_buf) hipFree(c->d_boundary_buf);
@@ -226,6 +229,32 @@ int32_t bepuhip_begin_constraints(bepuhip_ctx* c, int32_t batch_count, int32_t f
     c->has_fallback = batch_count > fallback_batch_threshold;  // Batches[FallbackBatchThreshold] is the sequential fallback batch
     c->has_widened_types = false;
     c->building = true;
+    for (auto& chunk : c->raw_chunks) chunk.used = 0;
+    return BEPUHIP_OK;
+}
+
+// Device memory for the caller's bundles, in chunks that outlive the upload (a simulation uploads again and again): a bump allocator, reset by begin_constraints.
+static int32_t raw_reserve(bepuhip_ctx* c, size_t bytes, char** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (c->raw_chunks.empty() || c->raw_chunks.back().used + bytes > c->raw_chunks.back().capacity) {
+        for (auto& chunk : c->raw_chunks)  // an earlier chunk with room (after a reset the big ones come first again)
+            if (chunk.used + bytes <= chunk.capacity) { *out = chunk.ptr + chunk.used; chunk.used += bytes; return BEPUHIP_OK; }
+        bepuhip_ctx::RawChunk chunk{nullptr, std::max<size_t>(bytes, (size_t)64 << 20), 0};
+        HIP_TRY(hipMalloc((void**)&chunk.ptr, chunk.capacity));
+        c->raw_chunks.push_back(chunk);
+    }
+    auto& chunk = c->raw_chunks.back();
+    *out = chunk.ptr + chunk.used;
+    chunk.used += bytes;
+    return BEPUHIP_OK;
+}
+static int32_t staging_reserve(bepuhip_ctx* c, size_t bytes) {  // pinned host memory: H2D copies from it run at the link's rate and asynchronously
+    if (bytes <= c->h_staging_bytes) return BEPUHIP_OK;
+    if (c->h_staging) hipHostFree(c->h_staging);
+    c->h_staging = nullptr; c->h_staging_bytes = 0;
+    bytes = std::max(bytes + bytes / 4, (size_t)16 << 20);
+    HIP_TRY(hipHostMalloc(&c->h_staging, bytes, hipHostMallocDefault));
+    c->h_staging_bytes = bytes;
     return BEPUHIP_OK;
 }
 
@@ -241,10 +270,13 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
     const int W = c->W;
     const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
     tb.refs_soa.assign((size_t)nb * tb.stride, -1);
-    tb.prestep_soa.assign((size_t)pf * tb.stride, 0.0f);
-    tb.accum_soa.assign((size_t)imf * tb.stride, 0.0f);
+    if (c->host_values) {
+        tb.prestep_soa.assign((size_t)pf * tb.stride, 0.0f);
+        tb.accum_soa.assign((size_t)imf * tb.stride, 0.0f);
+    }
     // AOSOA -> SoA (BundleIndexing.cs:50-60, TypeProcessor.cs:269-279): a bundle holds W consecutive constraints of every field, so field f of bundle b is W
-    // consecutive words on both sides — copied as such (the last bundle only up to `count`).
+    // consecutive words on both sides — copied as such (the last bundle only up to `count`). The host does this for the body references only (the plan needs them);
+    // prestep data and accumulated impulses — nine tenths of the bytes — go to the device as they are and are transposed there (end_constraints).
     const bool fallback_batch = batch_index == c->fallback_threshold;
     for (int b0 = 0; b0 < count; b0 += W) {
         const size_t bundle = (size_t)(b0 / W);
@@ -259,8 +291,24 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
                 dst[lane] = r;
             }
         }
-        for (int f = 0; f < pf; ++f) memcpy(tb.prestep_soa.data() + (size_t)f * tb.stride + b0, prestep + bundle * pf * W + (size_t)f * W, (size_t)lanes * 4);
-        for (int f = 0; f < imf; ++f) memcpy(tb.accum_soa.data() + (size_t)f * tb.stride + b0, accum + bundle * imf * W + (size_t)f * W, (size_t)lanes * 4);
+        if (c->host_values) {
+            for (int f = 0; f < pf; ++f) memcpy(tb.prestep_soa.data() + (size_t)f * tb.stride + b0, prestep + bundle * pf * W + (size_t)f * W, (size_t)lanes * 4);
+            for (int f = 0; f < imf; ++f) memcpy(tb.accum_soa.data() + (size_t)f * tb.stride + b0, accum + bundle * imf * W + (size_t)f * W, (size_t)lanes * 4);
+        }
+    }
+    if (!c->host_values && count > 0) {
+        const size_t bundles = (size_t)(count + W - 1) / W;
+        for (int which = 0; which < 2; ++which) {
+            const size_t bytes = bundles * (size_t)(which == 0 ? pf : imf) * W * 4;
+            if (bytes == 0) continue;
+            char* dst = nullptr;
+            const int32_t st = raw_reserve(c, bytes, &dst);
+            if (st != BEPUHIP_OK) return st;
+            // pageable source: the call returns when the source has been read; registered (pinned) source: asynchronous — hence the header's rule that the buffers stay
+            // unchanged until end_constraints returns
+            HIP_TRY(hipMemcpyAsync(dst, which == 0 ? (const void*)prestep : (const void*)accum, bytes, hipMemcpyHostToDevice, c->stream));
+            (which == 0 ? tb.raw_prestep : tb.raw_accum) = (const float*)dst;
+        }
     }
     c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
     c->tbs.push_back(std::move(tb));
@@ -409,49 +457,14 @@ static int32_t build_constraints(bepuhip_ctx* c) {
     c->total_constraints = 0;
     for (auto& tb : c->tbs)
         for (int i = 0; i < tb.count; ++i) c->total_constraints += tb.refs_soa[i] != -1;  // a fallback type batch counts its empty lanes in `count`
-    // Bodies the reference re-transforms in substep 0 of the conserving angular modes (see momentum_requirk_kernel). Bundles are W consecutive
-    // constraints in the HOST's order, so this runs before the island schedule permutes the type batches.
     {
         int universe = 0;
         for (auto& tb : c->tbs)
             for (int32_t r : tb.refs_soa)
                 if (r >= 0) universe = std::max(universe, (r & kRefMask) + 1);
         c->referenced_bodies = universe;  // checked against the body count at solve time (validate_solve)
-        std::vector<int32_t> first_batch(universe, INT32_MAX);
-        for (auto& tb : c->tbs)
-            for (int k = 0; k < tb.info.bodies; ++k)
-                for (int i = 0; i < tb.count; ++i) {
-                    const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                    if ((uint32_t)r < kDynamicLimit) first_batch[r] = std::min(first_batch[r], tb.batch);
-                }
-        std::vector<std::vector<int32_t>> lists(c->batch_count);
-        const int W = c->W;
-        for (auto& tb : c->tbs) {
-            if (tb.batch == 0) continue;  // batch 0 always integrates (Solver_Solve.cs:188-194): no conditional bundles
-            for (int k = 0; k < tb.info.bodies; ++k)
-                for (int b0 = 0; b0 < tb.count; b0 += W) {
-                    const int b1 = std::min(tb.count, b0 + W);
-                    bool any = false;
-                    for (int i = b0; i < b1; ++i) {
-                        const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                        any |= (uint32_t)r < kDynamicLimit && first_batch[r] == tb.batch;
-                    }
-                    if (!any) continue;
-                    for (int i = b0; i < b1; ++i) {
-                        const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                        if ((uint32_t)r < kDynamicLimit && first_batch[r] < tb.batch) lists[tb.batch].push_back(r);
-                    }
-                }
-        }
-        std::vector<int32_t> flat;
-        c->requirk_begin.assign(c->batch_count + 1, 0);
-        for (int b = 0; b < c->batch_count; ++b) { c->requirk_begin[b] = (int)flat.size(); flat.insert(flat.end(), lists[b].begin(), lists[b].end()); }
-        c->requirk_begin[c->batch_count] = (int)flat.size();
-        if (!flat.empty()) {
-            HIP_TRY(hipMalloc((void**)&c->d_requirk, flat.size() * 4));
-            HIP_TRY(hipMemcpy(c->d_requirk, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
-        }
     }
+    c->requirk_stale = true;  // the conserving angular modes' substep-0 lists are built by the first solve that asks for such a mode (build_requirk_lists)
     std::vector<std::vector<int32_t>> fallback_refs;  // the fallback type batches' references (SoA rows), kept past the staging buffers for the level walk below
     if (c->has_fallback)
         for (auto& tb : c->tbs) if (tb.batch == c->fallback_threshold) fallback_refs.push_back(tb.refs_soa);
@@ -459,29 +472,64 @@ static int32_t build_constraints(bepuhip_ctx* c) {
     ClusterPlan plan;
     plan_clusters(c, plan);
     lap("cluster plan (host)");
+    // Slab layout: what the host builds (references, local references + ranks) first, in one region that travels through pinned staging in one copy; behind it the
+    // prestep and impulse rows, which the device fills itself from the caller's bundles.
     for (auto& tb : c->tbs) {
         tb.refs_off = words; words += tb.refs_soa.size();
-        tb.prestep_off = words; words += tb.prestep_soa.size();
-        tb.accum_off = words; words += tb.accum_soa.size();
         tb.lrefs_off = words; words += tb.lrefs_soa.size();
+    }
+    const size_t index_words = words;
+    for (auto& tb : c->tbs) {
+        tb.prestep_off = words; words += (size_t)tb.info.prestep * tb.stride;
+        tb.accum_off = words; words += (size_t)tb.info.impulse * tb.stride;
     }
     c->slab_words = words;
     if (words > 0) {
         HIP_TRY(hipMalloc((void**)&c->d_slab, words * 4));
         HIP_TRY(hipMalloc((void**)&c->d_slab0, words * 4));
-        std::unique_ptr<uint32_t[]> host(new uint32_t[words]);  // not zeroed: the four rows of every type batch tile [0, words) exactly (offsets assigned above from the same sizes)
+        // host index -> device slot of every permuted type batch, one pool for all of them (with room for the indices additions on an island layout can create)
+        size_t pool_words = 0;
+        for (auto& tb : c->tbs)
+            if (!tb.perm.empty()) { tb.perm_inverse(0); pool_words += std::max<size_t>(tb.inv.size(), (size_t)tb.device_extent()); }
+        { const int32_t st = staging_reserve(c, (index_words + pool_words) * 4); if (st != BEPUHIP_OK) return st; }
+        uint32_t* host = (uint32_t*)c->h_staging;
         for (auto& tb : c->tbs) {
             if (!tb.refs_soa.empty()) memcpy(&host[tb.refs_off], tb.refs_soa.data(), tb.refs_soa.size() * 4);
-            if (!tb.prestep_soa.empty()) memcpy(&host[tb.prestep_off], tb.prestep_soa.data(), tb.prestep_soa.size() * 4);
-            if (!tb.accum_soa.empty()) memcpy(&host[tb.accum_off], tb.accum_soa.data(), tb.accum_soa.size() * 4);
             if (!tb.lrefs_soa.empty()) memcpy(&host[tb.lrefs_off], tb.lrefs_soa.data(), tb.lrefs_soa.size() * 4);
             std::vector<int32_t>().swap(tb.lrefs_soa);
             std::vector<int32_t>().swap(tb.refs_soa);
-            std::vector<float>().swap(tb.prestep_soa);
-            std::vector<float>().swap(tb.accum_soa);
         }
-        HIP_TRY(hipMemcpy(c->d_slab, host.get(), words * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_slab0, c->d_slab, words * 4, hipMemcpyDeviceToDevice));
+        if (pool_words > 0) {
+            HIP_TRY(hipMalloc((void**)&c->d_index_pool, pool_words * 4));
+            size_t at = 0;
+            for (auto& tb : c->tbs) {
+                if (tb.perm.empty()) continue;
+                const size_t room = std::max<size_t>(tb.inv.size(), (size_t)tb.device_extent());
+                memcpy(&host[index_words + at], tb.inv.data(), tb.inv.size() * 4);
+                if (room > tb.inv.size()) memset(&host[index_words + at + tb.inv.size()], 0, (room - tb.inv.size()) * 4);
+                tb.d_device_index = c->d_index_pool + at;
+                tb.index_pooled = true;
+                at += room;
+            }
+            HIP_TRY(hipMemcpyAsync(c->d_index_pool, &host[index_words], pool_words * 4, hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(hipMemsetAsync(c->d_slab + index_words, 0, (words - index_words) * 4, c->stream));  // free slots and the padding behind `count` read as zeros
+        if (index_words > 0) HIP_TRY(hipMemcpyAsync(c->d_slab, host, index_words * 4, hipMemcpyHostToDevice, c->stream));
+        // AOSOA bundles -> rows, in the plan's device order, on the device (the bundles have been in HBM since set_type_batch)
+        for (auto& tb : c->tbs) {
+            if (tb.count == 0) continue;
+            const int blocks = (tb.count + 255) / 256;
+            if (tb.raw_prestep && tb.info.prestep > 0)
+                hipLaunchKernelGGL(scatter_bundles_kernel, dim3(blocks), dim3(256), 0, c->stream, tb.raw_prestep, (float*)(c->d_slab + tb.prestep_off), (const int*)tb.d_device_index, 0, tb.count,
+                                   tb.info.prestep, tb.stride, c->W);
+            if (tb.raw_accum && tb.info.impulse > 0)
+                hipLaunchKernelGGL(scatter_bundles_kernel, dim3(blocks), dim3(256), 0, c->stream, tb.raw_accum, (float*)(c->d_slab + tb.accum_off), (const int*)tb.d_device_index, 0, tb.count,
+                                   tb.info.impulse, tb.stride, c->W);
+            tb.raw_prestep = tb.raw_accum = nullptr;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->d_slab0, c->d_slab, words * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's buffers (if registered: read asynchronously) and the staging buffer are free again
     }
     lap("slab assembly + upload");
     { const int32_t st = build_descriptors(c, fallback_refs); if (st != BEPUHIP_OK) return st; }
@@ -592,6 +640,65 @@ static StepParams make_params(const bepuhip_integrator* in, float dt_for_callbac
     sp.dt = dt; sp.inv_dt = inv_dt;
     sp.angular_mode = in->angular_integration_mode;
     return sp;
+}
+
+// Bodies the reference re-transforms in substep 0 of the conserving angular modes (see momentum_requirk_kernel): lists per batch, built when a solve first asks for
+// such a mode and again after structural updates (the lists describe the topology). Bundles are W consecutive constraints in the CALLER's order, so the references
+// are read back from the device rows and brought into that order through the type batch's index tables (island layouts are permuted by cluster).
+static int32_t build_requirk_lists(bepuhip_ctx* c) {
+    if (c->d_requirk) { hipFree(c->d_requirk); c->d_requirk = nullptr; }
+    c->requirk_begin.clear();
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int W = c->W;
+    std::vector<std::vector<int32_t>> host_refs(c->tbs.size());  // [type batch][body slot * count + caller's index]
+    int universe = 0;
+    for (size_t t = 0; t < c->tbs.size(); ++t) {
+        HostTypeBatch& tb = c->tbs[t];
+        const int nb = tb.info.bodies;
+        if (tb.count == 0) continue;
+        std::vector<int32_t> rows((size_t)nb * tb.stride);
+        HIP_TRY(hipMemcpy(rows.data(), c->d_slab + tb.refs_off, rows.size() * 4, hipMemcpyDeviceToHost));
+        host_refs[t].assign((size_t)nb * tb.count, -1);
+        for (int i = 0; i < tb.count; ++i) {
+            const int d = tb.perm.empty() ? i : tb.perm_inverse(i);
+            for (int k = 0; k < nb; ++k) {
+                const int32_t r = rows[(size_t)k * tb.stride + d];
+                host_refs[t][(size_t)k * tb.count + i] = r;
+                if (r >= 0) universe = std::max(universe, (r & kRefMask) + 1);
+            }
+        }
+    }
+    std::vector<int32_t> first_batch(universe, INT32_MAX);
+    for (size_t t = 0; t < c->tbs.size(); ++t)
+        for (int32_t r : host_refs[t])
+            if ((uint32_t)r < kDynamicLimit) first_batch[r] = std::min(first_batch[r], c->tbs[t].batch);
+    std::vector<std::vector<int32_t>> lists(c->batch_count);
+    for (size_t t = 0; t < c->tbs.size(); ++t) {
+        const HostTypeBatch& tb = c->tbs[t];
+        if (tb.batch == 0 || tb.count == 0) continue;  // batch 0 always integrates (Solver_Solve.cs:188-194): no conditional bundles
+        for (int k = 0; k < tb.info.bodies; ++k) {
+            const int32_t* refs = host_refs[t].data() + (size_t)k * tb.count;
+            for (int b0 = 0; b0 < tb.count; b0 += W) {
+                const int b1 = std::min(tb.count, b0 + W);
+                bool any = false;
+                for (int i = b0; i < b1; ++i) any |= (uint32_t)refs[i] < kDynamicLimit && first_batch[refs[i]] == tb.batch;
+                if (!any) continue;
+                for (int i = b0; i < b1; ++i)
+                    if ((uint32_t)refs[i] < kDynamicLimit && first_batch[refs[i]] < tb.batch) lists[tb.batch].push_back(refs[i]);
+            }
+        }
+    }
+    std::vector<int32_t> flat;
+    c->requirk_begin.assign(c->batch_count + 1, 0);
+    for (int b = 0; b < c->batch_count; ++b) { c->requirk_begin[b] = (int)flat.size(); flat.insert(flat.end(), lists[b].begin(), lists[b].end()); }
+    c->requirk_begin[c->batch_count] = (int)flat.size();
+    if (!flat.empty()) {
+        HIP_TRY(hipMalloc((void**)&c->d_requirk, flat.size() * 4));
+        HIP_TRY(hipMemcpy(c->d_requirk, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+    }
+    c->requirk_stale = false;
+    clear_graphs(c);  // graphs captured for a conserving mode hold the old lists
+    return BEPUHIP_OK;
 }
 
 static void enqueue_requirk(bepuhip_ctx* c, int substep, int batch, const StepParams& sp) {
@@ -779,8 +886,6 @@ static int32_t validate_solve(bepuhip_ctx* c, float dt, int32_t substeps, const 
         if (iterations[s] < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Velocity iteration count must be positive.");
     if (in->angular_integration_mode < 0 || in->angular_integration_mode > 2) return fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown AngularIntegrationMode");
     if (c->building) return fail(BEPUHIP_E_STATE, "solve between begin_constraints and end_constraints");
-    if (c->requirk_stale && in->angular_integration_mode != 0)
-        return fail(BEPUHIP_E_UNSUPPORTED, "a momentum-conserving AngularIntegrationMode after structural updates (its substep-0 lists are built at upload): re-upload with begin/set/end");
     if (c->has_fallback && in->angular_integration_mode != 0)
         return fail(BEPUHIP_E_UNSUPPORTED, "a sequential fallback batch together with a momentum-conserving AngularIntegrationMode; use simulation.Solve");
     if (c->built && c->referenced_bodies > c->body_count)
@@ -804,6 +909,7 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
             if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
         }
     }
+    if (in->angular_integration_mode != 0 && c->requirk_stale && c->built && (st = build_requirk_lists(c)) != BEPUHIP_OK) return st;  // first conserving solve of this topology
     int64_t iters = 0;
     for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
     c->last_constraint_iterations = iters;
@@ -1096,6 +1202,7 @@ static int32_t run_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const i
     if (!fn && c->boundary_count > 0 && !c->d_boundary_rows) return fail(BEPUHIP_E_STATE, "bepuhip_solve_lattice needs bepuhip_set_boundary_layout after bepuhip_set_boundary_bodies");
     HIP_TRY(hipSetDevice(c->device));
     if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
+    if (in->angular_integration_mode != 0 && c->requirk_stale && c->built && (st = build_requirk_lists(c)) != BEPUHIP_OK) return st;
     int64_t iters = 0;
     for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
     c->last_constraint_iterations = iters;
@@ -1190,6 +1297,47 @@ int32_t bepuhip_get_bodies(bepuhip_ctx* c, void* out, int32_t count) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (count > 0) HIP_TRY(hipMemcpy(out, c->d_bodies, (size_t)count * 128, hipMemcpyDeviceToHost));  // an empty simulation is a valid one
+    return BEPUHIP_OK;
+}
+
+// BufferPool blocks are pinned, unmanaged memory that lives as long as the simulation (BufferPool.cs:42,83): registering them with the HIP runtime once makes every
+// copy from / to them a DMA at the link's rate and truly asynchronous (pageable memory is staged through the runtime's own buffers at a fraction of that).
+int32_t bepuhip_register_host_memory(bepuhip_ctx* c, void* memory, int64_t bytes) {
+    if (!c || !memory || bytes <= 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad host memory range");
+    HIP_TRY(hipSetDevice(c->device));
+    for (void* p : c->registered_host) if (p == memory) return BEPUHIP_OK;
+    const hipError_t e = hipHostRegister(memory, (size_t)bytes, hipHostRegisterDefault);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return BEPUHIP_OK; }
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(BEPUHIP_E_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
+    c->registered_host.push_back(memory);
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_unregister_host_memory(bepuhip_ctx* c, void* memory) {
+    if (!c || !memory) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    for (size_t i = 0; i < c->registered_host.size(); ++i)
+        if (c->registered_host[i] == memory) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipHostUnregister(memory));
+            c->registered_host.erase(c->registered_host.begin() + i);
+            return BEPUHIP_OK;
+        }
+    return fail(BEPUHIP_E_INVALID_ARGUMENT, "this memory was not registered through this context");
+}
+
+// What a host needs back after a solve: poses and velocities — the first 64 bytes of every 128-byte BodyDynamics (MotionState: orientation, position, linear,
+// angular; BodyProperties.cs:318-338). The inertia half is the host's own (local inertia) or only valid inside the frame (world inertia, BodyProperties.cs:291-297).
+// The async form is enqueued behind the solve on the context's stream; bepuhip_sync waits for it.
+int32_t bepuhip_get_poses_and_velocities_async(bepuhip_ctx* c, void* body_dynamics_aos, int32_t count) {
+    if (!c || (!body_dynamics_aos && count > 0) || count < 0 || count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad get_poses_and_velocities argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (count > 0) HIP_TRY(hipMemcpy2DAsync(body_dynamics_aos, 128, c->d_bodies, 128, 64, (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_get_poses_and_velocities(bepuhip_ctx* c, void* body_dynamics_aos, int32_t count) {
+    const int32_t st = bepuhip_get_poses_and_velocities_async(c, body_dynamics_aos, count);
+    if (st != BEPUHIP_OK) return st;
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return BEPUHIP_OK;
 }
 
@@ -1352,7 +1500,8 @@ static int32_t leave_island_schedule(bepuhip_ctx* c) {
     for (auto& tb : c->tbs) {
         tb.perm.clear(); tb.inv.clear();
         tb.slots = 0; tb.seg_begin.clear(); std::vector<int32_t>().swap(tb.dev_refs);
-        if (tb.d_device_index) { hipFree(tb.d_device_index); tb.d_device_index = nullptr; }
+        if (tb.d_device_index && !tb.index_pooled) hipFree(tb.d_device_index);
+        tb.d_device_index = nullptr; tb.index_pooled = false;
     }
     for (void** p : {(void**)&c->d_clusters, (void**)&c->d_items, (void**)&c->d_batch_item_begin, (void**)&c->d_cluster_bodies, (void**)&c->d_clustered_dynamic, (void**)&c->d_kinlist,
                      (void**)&c->d_cycles}) {
@@ -1509,7 +1658,7 @@ static int32_t bundle_range(bepuhip_ctx* c, int batch, int type_id, int first_bu
     *n = std::min(bundle_count * c->W, tb->count - *first);  // trailing lanes of the last bundle are empty (TypeProcessor.cs:287-298)
     return BEPUHIP_OK;
 }
-static int32_t update_rows(bepuhip_ctx* c, int batch, int type_id, int first_bundle, int bundle_count, const float* bundles, bool prestep) {
+static int32_t update_rows(bepuhip_ctx* c, int batch, int type_id, int first_bundle, int bundle_count, const float* bundles, bool prestep, bool wait = true) {
     HostTypeBatch* tb; int first, n;
     int32_t st = bundle_range(c, batch, type_id, first_bundle, bundle_count, bundles, &tb, &first, &n);
     if (st != BEPUHIP_OK || n <= 0) return st;
@@ -1524,7 +1673,7 @@ static int32_t update_rows(bepuhip_ctx* c, int batch, int type_id, int first_bun
     for (uint32_t* slab : {c->d_slab, c->d_slab0})  // the pristine snapshot follows, so that reset_state restores "what the set_*/update_* calls uploaded"
         if (slab) scatter_bundles_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_stage, (float*)(slab + off), index, first, n, fields, tb->stride, c->W);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's buffer and the staging buffer are free again on return
+    if (wait) HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's buffer is free again on return (the staging buffer is reused in stream order either way)
     return BEPUHIP_OK;
 }
 static int32_t read_rows(bepuhip_ctx* c, int batch, int type_id, int first_bundle, int bundle_count, float* bundles_out, bool prestep) {
@@ -1547,6 +1696,9 @@ static int32_t read_rows(bepuhip_ctx* c, int batch, int type_id, int first_bundl
 }
 int32_t bepuhip_update_prestep(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* prestep_bundles) {
     return update_rows(c, batch, type_id, first_bundle, bundle_count, prestep_bundles, true);
+}
+int32_t bepuhip_update_prestep_async(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* prestep_bundles) {
+    return update_rows(c, batch, type_id, first_bundle, bundle_count, prestep_bundles, true, false);
 }
 int32_t bepuhip_update_accumulated_impulses(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* impulse_bundles) {
     return update_rows(c, batch, type_id, first_bundle, bundle_count, impulse_bundles, false);

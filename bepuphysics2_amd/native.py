@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
     "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables", "bepuhip_set_convex_hulls", "bepuhip_set_compounds", "bepuhip_set_meshes",
     "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_get_constraint_count",
+    "bepuhip_register_host_memory", "bepuhip_unregister_host_memory", "bepuhip_get_poses_and_velocities", "bepuhip_get_poses_and_velocities_async", "bepuhip_update_prestep_async",
 ]
 
 
@@ -123,7 +124,11 @@ def load_library() -> C.CDLL:
     lib.bepuhip_set_meshes.argtypes = [vp, vp, vp, vp, i32]
     lib.bepuhip_update_bodies.argtypes = [vp, vp, i32, i32]
     lib.bepuhip_get_bodies_range.argtypes = [vp, vp, i32, i32]
-    for name in ("bepuhip_update_prestep", "bepuhip_update_accumulated_impulses", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
+    lib.bepuhip_register_host_memory.argtypes = [vp, vp, C.c_int64]
+    lib.bepuhip_unregister_host_memory.argtypes = [vp, vp]
+    lib.bepuhip_get_poses_and_velocities.argtypes = [vp, vp, i32]
+    lib.bepuhip_get_poses_and_velocities_async.argtypes = [vp, vp, i32]
+    for name in ("bepuhip_update_prestep", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
         getattr(lib, name).argtypes = [vp, i32, i32, i32, i32, vp]
     lib.bepuhip_add_constraint.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
     lib.bepuhip_remove_constraint.argtypes = [vp, i32, i32, i32]
@@ -312,6 +317,20 @@ class HipSolver:
         _check(self.lib, self.lib.bepuhip_get_bodies(self.ctx, _ptr(out), count))
         return out
 
+    def register_host_memory(self, array: np.ndarray):
+        """Pins ``array``'s buffer for the life of the context (BufferPool blocks are pinned, BufferPool.cs:42,83): copies from / to it become asynchronous DMA."""
+        assert array.flags["C_CONTIGUOUS"]
+        _check(self.lib, self.lib.bepuhip_register_host_memory(self.ctx, _ptr(array), array.nbytes))
+
+    def unregister_host_memory(self, array: np.ndarray):
+        _check(self.lib, self.lib.bepuhip_unregister_host_memory(self.ctx, _ptr(array)))
+
+    def get_poses_and_velocities(self, bodies: np.ndarray, asynchronous: bool = False):
+        """Writes the MotionState half (floats 0-15) of every BodyDynamics into ``bodies`` ((n, 32) float32, in place); the inertia half stays what it was."""
+        assert bodies.flags["C_CONTIGUOUS"] and bodies.dtype == np.float32 and bodies.ndim == 2 and bodies.shape[1] == 32
+        fn = self.lib.bepuhip_get_poses_and_velocities_async if asynchronous else self.lib.bepuhip_get_poses_and_velocities
+        _check(self.lib, fn(self.ctx, _ptr(bodies), bodies.shape[0]))
+
     def download(self, scene: Scene):
         """Write device state back into ``scene``'s buffers (bodies, accumulated impulses, prestep)."""
         scene.bodies[...] = self.get_bodies(scene.body_count)
@@ -358,13 +377,15 @@ class HipSolver:
         _check(self.lib, self.lib.bepuhip_get_constraint_count(self.ctx, batch_index, type_id, C.byref(n)))
         return int(n.value)
 
-    def update_prestep(self, batch_index: int, type_id: int, first_bundle: int, bundles: np.ndarray):
-        """``bundles``: the type batch's PrestepData bundles [first_bundle, first_bundle + n) exactly as the reference stores them (AOSOA)."""
+    def update_prestep(self, batch_index: int, type_id: int, first_bundle: int, bundles: np.ndarray, asynchronous: bool = False):
+        """``bundles``: the type batch's PrestepData bundles [first_bundle, first_bundle + n) exactly as the reference stores them (AOSOA).
+        ``asynchronous``: enqueued on the context's stream; ``bundles`` must stay unchanged (and alive) until the next ``sync``."""
         b = np.ascontiguousarray(bundles, dtype=np.float32).reshape(-1)
         n, rem = divmod(b.size, self._bundle_floats(type_id, True))
         if rem:
             raise ValueError("prestep data is not a whole number of bundles")
-        _check(self.lib, self.lib.bepuhip_update_prestep(self.ctx, batch_index, type_id, first_bundle, n, _ptr(b)))
+        fn = self.lib.bepuhip_update_prestep_async if asynchronous else self.lib.bepuhip_update_prestep
+        _check(self.lib, fn(self.ctx, batch_index, type_id, first_bundle, n, _ptr(b)))
 
     def update_accumulated_impulses(self, batch_index: int, type_id: int, first_bundle: int, bundles: np.ndarray):
         b = np.ascontiguousarray(bundles, dtype=np.float32).reshape(-1)

@@ -74,6 +74,8 @@ int32_t bepuhip_set_bodies(bepuhip_ctx* ctx, const void* body_dynamics_aos, int3
  * the reference's encoding: low 30 bits index, bit 30 kinematic, -1 empty lane (BepuPhysics/Bodies_GatherScatter.cs:107-139).
  * batch_count == FallbackBatchThreshold + 1: the last batch is the sequential fallback batch (BepuPhysics/Solver.cs:1878-1884), accepted and solved in dependency levels
  * (empty lanes carry -1 references); more batches than that cannot exist and are refused (INVALID_ARGUMENT). */
+/* The prestep and impulse buffers handed to set_type_batch are copied to the device as they are and transposed there (the host converts only the body references):
+ * they must stay unchanged until bepuhip_end_constraints returns (memory registered with bepuhip_register_host_memory is read asynchronously). */
 int32_t bepuhip_begin_constraints(bepuhip_ctx* ctx, int32_t batch_count, int32_t fallback_batch_threshold);
 int32_t bepuhip_set_type_batch(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t constraint_count,
                                const int32_t* body_references_aosoa, const float* prestep_aosoa, const float* accumulated_impulses_aosoa);
@@ -155,6 +157,15 @@ int32_t bepuhip_solve_lattice(bepuhip_ctx* ctx, float dt, int32_t substep_count,
 
 /* Read back what the reference would find in its own buffers after Simulation.Solve returns. */
 int32_t bepuhip_get_bodies(bepuhip_ctx* ctx, void* body_dynamics_aos_out, int32_t count);
+/* BufferPool blocks are pinned unmanaged memory that lives as long as the simulation (BepuUtilities/Memory/BufferPool.cs:42,83): register them once (hipHostRegister) and
+ * every set_* / update_* / get_* that names an address inside them is a DMA at the link's rate instead of a staged copy. No counterpart in the reference. */
+int32_t bepuhip_register_host_memory(bepuhip_ctx* ctx, void* memory, int64_t bytes);
+int32_t bepuhip_unregister_host_memory(bepuhip_ctx* ctx, void* memory);
+/* What the host needs back after a solve: the MotionState half of every BodyDynamics (orientation, position, linear and angular velocity: bytes 0-63 of the 128-byte
+ * struct, BepuPhysics/BodyProperties.cs:318-338) written into the caller's BodyDynamics array; the inertia half is left alone (the local inertia is the host's own, the
+ * world inertia is only valid inside the frame, BodyProperties.cs:291-297). The _async form is enqueued behind the solve on the context's stream: bepuhip_sync waits. */
+int32_t bepuhip_get_poses_and_velocities(bepuhip_ctx* ctx, void* body_dynamics_aos_out, int32_t count);
+int32_t bepuhip_get_poses_and_velocities_async(bepuhip_ctx* ctx, void* body_dynamics_aos_out, int32_t count);
 int32_t bepuhip_get_accumulated_impulses(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, float* accumulated_impulses_aosoa_out);
 int32_t bepuhip_get_prestep(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, float* prestep_aosoa_out); /* contact depths change in substeps > 0 (PenetrationLimit.cs:42) */
 
@@ -169,6 +180,9 @@ int32_t bepuhip_get_prestep(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_
  * The *_range getters are the matching read-backs (e.g. only the contact type batches after a solve). */
 int32_t bepuhip_update_bodies(bepuhip_ctx* ctx, const void* body_dynamics_aos, int32_t first, int32_t count);
 int32_t bepuhip_update_prestep(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* prestep_bundles);
+/* bepuhip_update_prestep without the wait at the end: enqueued on the context's stream (in order with the solves). With registered memory the bundles are read
+ * asynchronously: they must stay unchanged until the next bepuhip_sync (or any synchronous call). */
+int32_t bepuhip_update_prestep_async(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* prestep_bundles);
 int32_t bepuhip_update_accumulated_impulses(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* impulse_bundles);
 int32_t bepuhip_get_bodies_range(bepuhip_ctx* ctx, void* body_dynamics_aos_out, int32_t first, int32_t count);
 int32_t bepuhip_get_prestep_range(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* prestep_bundles_out);

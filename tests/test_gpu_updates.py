@@ -96,3 +96,40 @@ def test_ranged_update_argument_checks(hip_solver_factory):
         solver.update_bodies(scene.body_count - 1, np.zeros((2, 32), np.float32))
     with pytest.raises(ValueError):               # not a whole number of bundles (caught before the ABI)
         solver.update_prestep(0, 7, 0, np.zeros(26 * W + 1, np.float32))
+
+
+def test_registered_memory_async_frame_and_pose_velocity_read_back(hip_solver_factory):
+    """The resident frame a host runs: buffers registered once, contact prestep refreshed asynchronously, solve_async, poses and velocities read back
+    asynchronously into the host's BodyDynamics array, ONE sync. Equal to the synchronous calls and to the oracle; the inertia half of the host array is left alone."""
+    import oracle_ffi
+    from bepuphysics2_amd.scene import TYPE_TABLE
+    scene = small_scenes.random_graph_scene(57, 900, 2600, [4, 5, 6, 7, 22, 25, 30])
+    sd, cb = SolveDescription(1, 4), PoseIntegratorCallbacks()
+    solver = hip_solver_factory()
+    host_bodies = scene.bodies.copy()
+    solver.register_host_memory(host_bodies)
+    contact_tbs = [(bi, tb) for bi, b in enumerate(scene.batches) for tb in b if TYPE_TABLE[tb.type_id][3].startswith("Contact")]
+    for _, tb in contact_tbs:
+        solver.register_host_memory(tb.prestep)
+    solver.upload(scene)
+    ref = scene.copy()
+    rng = np.random.default_rng(3)
+    for frame in range(3):
+        for (bi, tb), (_, rtb) in zip(contact_tbs, [(bi, tb) for bi, b in enumerate(ref.batches) for tb in b if TYPE_TABLE[tb.type_id][3].startswith("Contact")]):
+            tb.prestep[...] = rtb.prestep  # what the device holds (depths advanced by the last solve) ...
+            w, pf = scene.bundle_width, tb.prestep_floats
+            lane = np.arange(tb.count)
+            tb.prestep[(lane // w) * pf * w + 3 * w + lane % w] += rng.uniform(-0.002, 0.002, tb.count).astype(np.float32)  # ... with the first contact's depth rewritten by the "narrow phase"
+            rtb.prestep[...] = tb.prestep
+            solver.update_prestep(bi, tb.type_id, 0, tb.prestep, asynchronous=True)
+        solver.solve(1 / 60, sd, cb, asynchronous=True)
+        sentinel = host_bodies[:, 16:].copy()
+        solver.get_poses_and_velocities(host_bodies, asynchronous=True)
+        solver.sync()
+        oracle_ffi.solve(ref, 1 / 60, sd, cb)
+        full = solver.get_bodies(scene.body_count)
+        assert np.array_equal(host_bodies[:, :16].view(np.int32), full[:, :16].view(np.int32))
+        assert np.array_equal(host_bodies[:, 16:].view(np.int32), sentinel.view(np.int32))  # the inertia half is the host's
+        cols = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 13, 14]
+        assert np.array_equal(ref.bodies[:, cols].view(np.int32), host_bodies[:, cols].view(np.int32)), frame
+    solver.unregister_host_memory(host_bodies)

@@ -189,7 +189,7 @@ int main(int argc, char** argv) {
     fclose(f);
     for (int rep = 0; rep < repeats; ++rep) {
         bepuhip_ctx* c = new bepuhip_ctx();
-        c->device = 0; c->W = header[0]; c->flags = argc > 3 ? atoi(argv[3]) : 0;
+        c->device = 0; c->W = header[0]; c->flags = argc > 3 ? atoi(argv[3]) : 0; c->host_values = true;  // no device here: the values are converted (and permuted by the plan) on the host, as the digest expects
         c->batch_count = header[1]; c->fallback_threshold = header[3]; c->has_fallback = header[1] > header[3]; c->building = true;
         auto t0 = std::chrono::steady_clock::now();
         for (auto& t : tbs)
