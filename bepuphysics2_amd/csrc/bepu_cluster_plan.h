@@ -3,6 +3,7 @@
 
 #include "bepu_host_state.h"
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <unordered_map>
 
@@ -40,40 +41,106 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
 static inline int segment_slots(int live, bool reserve) { return (reserve && live > 0) ? live + std::max(2, live / 8) : live; }
 constexpr int32_t kPlanDeadLref = (int32_t)kDynamicLimit;  // 32-bit planning form of a free slot's local references: the kinematic copy in slot 0 (packs to kLrefDead)
 
+// Host threads of the planner: BEPUHIP_PLAN_THREADS, default a quarter of the hardware threads between 8 and 16 (the phases are memory-bound; more only adds start-up cost).
+static int plan_workers(size_t jobs) {
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int fallback = std::max(1, std::min(16, std::max(8, hw / 4)));
+    return std::max(1, std::min<int>({env_int("BEPUHIP_PLAN_THREADS", fallback), hw > 0 ? hw : 1, (int)std::max<size_t>(jobs, 1)}));
+}
+template <class Fn>
+static void plan_parallel_for_workers(size_t jobs, Fn&& fn) {  // fn(job, worker, workers) for every job, dynamically scheduled; results must not depend on the order
+    const int workers = plan_workers(jobs);
+    std::atomic<size_t> next{0};
+    auto work = [&](int worker) { for (size_t j; (j = next.fetch_add(1)) < jobs;) fn(j, worker, workers); };
+    std::vector<std::thread> pool;
+    for (int w = 1; w < workers; ++w) pool.emplace_back(work, w);
+    work(0);
+    for (auto& th : pool) th.join();
+}
+template <class Fn>
+static void plan_parallel_for(size_t jobs, Fn&& fn) { plan_parallel_for_workers(jobs, [&](size_t j, int, int) { fn(j); }); }
+
 static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
-    int universe = 0;
-    for (auto& tb : c->tbs)
-        for (int32_t r : tb.refs_soa)
-            if (r >= 0) universe = std::max(universe, (r & kRefMask) + 1);
-    // kinematic list (Solver.ConstrainedKinematicHandles equivalent), always built
-    {
-        std::vector<uint8_t> seen(universe, 0);
+    const bool plan_stats = env_int("BEPUHIP_PLAN_STATS", 0) >= 2;
+    auto plan_t = std::chrono::steady_clock::now();
+    auto plan_lap = [&](const char* what) {
+        if (!plan_stats) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "bepuhip plan_clusters: %-34s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - plan_t).count());
+        plan_t = now;
+    };
+    int universe = c->referenced_bodies;  // end_constraints has just computed it
+    if (universe <= 0)
         for (auto& tb : c->tbs)
-            for (int k = 0; k < tb.info.bodies; ++k)
-                for (int i = 0; i < tb.count; ++i) {
-                    int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                    if ((uint32_t)r >= kDynamicLimit && r >= 0 && !seen[r & kRefMask]) { seen[r & kRefMask] = 1; plan.kinlist.push_back(r & kRefMask); }
-                }
-    }
-    if ((c->flags & BEPUHIP_FLAG_NO_CLUSTERS) || env_int("BEPUHIP_NO_CLUSTERS", 0) || universe == 0 || c->total_constraints == 0 || c->batch_count > kFallbackBatchLimit || c->has_fallback) return;
-    const bool reserve = (c->flags & BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS) != 0;
+            for (int32_t r : tb.refs_soa)
+                if (r >= 0) universe = std::max(universe, (r & kRefMask) + 1);
+    // One pass over the references on several threads: the kinematic list (Solver.ConstrainedKinematicHandles equivalent, always built; in the order the bodies first
+    // appear when the type batches are scanned body slot by body slot — kept through the position of each body's first appearance), which bodies are dynamic, and the
+    // islands as a lock-free union-find whose roots are the smallest body index of each component (so the result does not depend on the threads).
+    std::vector<uint64_t> first_seen(universe, UINT64_MAX);
+    std::vector<uint8_t> is_dyn(universe, 0);
     std::vector<int32_t> parent(universe);
     for (int i = 0; i < universe; ++i) parent[i] = i;
-    auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
-    std::vector<uint8_t> is_dyn(universe, 0);
-    for (auto& tb : c->tbs) {
-        for (int i = 0; i < tb.count; ++i) {
+    const bool want_plan = !((c->flags & BEPUHIP_FLAG_NO_CLUSTERS) || env_int("BEPUHIP_NO_CLUSTERS", 0) || universe == 0 || c->total_constraints == 0 || c->batch_count > kFallbackBatchLimit || c->has_fallback);
+    auto find_root = [&](int x) {
+        for (;;) {
+            const int p = __atomic_load_n(&parent[x], __ATOMIC_RELAXED);
+            if (p == x) return x;
+            const int gp = __atomic_load_n(&parent[p], __ATOMIC_RELAXED);
+            if (gp != p) { int expected = p; __atomic_compare_exchange_n(&parent[x], &expected, gp, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); }  // path halving
+            x = p;
+        }
+    };
+    auto unite = [&](int a, int b) {
+        for (;;) {
+            int ra = find_root(a), rb = find_root(b);
+            if (ra == rb) return;
+            if (ra < rb) std::swap(ra, rb);  // the larger root goes under the smaller one
+            int expected = ra;
+            if (__atomic_compare_exchange_n(&parent[ra], &expected, rb, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return;
+        }
+    };
+    std::atomic<int> bodiless{0};
+    plan_parallel_for_workers(c->tbs.size(), [&](size_t t, int worker, int workers) {
+        const HostTypeBatch& tb = c->tbs[t];
+        auto note_kinematic = [&](int32_t r, int k, int i) {  // earliest (type batch, body slot, index) at which the body appears
+            const uint64_t key = ((uint64_t)t << 40) | ((uint64_t)k << 32) | (uint32_t)i;
+            uint64_t seen = __atomic_load_n(&first_seen[r & kRefMask], __ATOMIC_RELAXED);
+            while (key < seen && !__atomic_compare_exchange_n(&first_seen[r & kRefMask], &seen, key, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        };
+        if (!want_plan) {
+            for (int k = 0; k < tb.info.bodies; ++k)
+                for (int i = 0; i < tb.count; ++i) {
+                    const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r >= kDynamicLimit && r >= 0) note_kinematic(r, k, i);
+                }
+            return;
+        }
+        // Type batches list their constraints in creation order, i.e. roughly by island: workers that all start at index 0 would hammer the same few parents at the
+        // same time (a ragdoll's sixteen parents share one cache line). Every worker starts its type batch at its own offset and wraps around.
+        const int offset = tb.count > 0 ? (int)((int64_t)tb.count * worker / workers) : 0;
+        for (int j = 0; j < tb.count; ++j) {
+            const int i = j + offset < tb.count ? j + offset : j + offset - tb.count;
             int first = -1;
             for (int k = 0; k < tb.info.bodies; ++k) {
-                int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                if ((uint32_t)r >= kDynamicLimit) continue;
-                is_dyn[r] = 1;
-                if (first < 0) first = find(r);
-                else { int o = find(r); if (o != first) { if (o < first) std::swap(o, first); parent[o] = first; } }
+                const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                if ((uint32_t)r >= kDynamicLimit) { if (r >= 0) note_kinematic(r, k, i); continue; }
+                if (!__atomic_load_n(&is_dyn[r], __ATOMIC_RELAXED)) __atomic_store_n(&is_dyn[r], (uint8_t)1, __ATOMIC_RELAXED);  // read-mostly: an unconditional store makes the line bounce between the threads
+                if (first < 0) first = r; else unite(first, r);
             }
-            if (first < 0) return;  // a constraint with no dynamic body: leave everything to the global path
+            if (first < 0) bodiless.store(1, std::memory_order_relaxed);  // a constraint with no dynamic body
         }
+    });
+    {
+        std::vector<std::pair<uint64_t, int32_t>> order;
+        for (int i = 0; i < universe; ++i) if (first_seen[i] != UINT64_MAX) order.push_back({first_seen[i], i});
+        std::sort(order.begin(), order.end());
+        for (auto& kv : order) plan.kinlist.push_back(kv.second);
     }
+    if (!want_plan || bodiless.load()) return;  // (a constraint with no dynamic body: leave everything to the global path)
+    const bool reserve = (c->flags & BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS) != 0;
+    auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    plan_lap("universe, kinematic list, union-find");
     // component sizes (root = smallest body index of the component)
     std::vector<int32_t> comp_size(universe, 0);
     int64_t total_dyn = 0;
@@ -108,11 +175,15 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         std::vector<std::vector<int32_t>>& kin_seen = kin_lists;
         kin_seen.assign(nclusters, {});
         for (int i = 0; i < universe; ++i) if (is_dyn[i]) dyn_count[cluster_of[parent[i]]]++;
-        std::vector<int32_t> per_cluster(nclusters);
-        for (size_t t = 0; t < c->tbs.size(); ++t) {
+        // per type batch, side by side: the cluster of every constraint, the constraints per cluster, and the (cluster, kinematic body) pairs in the order they are met;
+        // merged in type-batch order afterwards, so that the kinematic copies get the slots a serial scan would give them
+        std::vector<std::vector<int32_t>> per_cluster(c->tbs.size());
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> kin_met(c->tbs.size());
+        plan_parallel_for(c->tbs.size(), [&](size_t t) {
             HostTypeBatch& tb = c->tbs[t];
             cl_of_constraint[t].resize(tb.count);
-            std::fill(per_cluster.begin(), per_cluster.end(), 0);
+            per_cluster[t].assign(nclusters, 0);
+            auto& met = kin_met[t];
             for (int i = 0; i < tb.count; ++i) {
                 int cl = -1;
                 for (int k = 0; k < tb.info.bodies && cl < 0; ++k) {
@@ -120,16 +191,22 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                     if ((uint32_t)r < kDynamicLimit) cl = cluster_of[parent[r]];
                 }
                 cl_of_constraint[t][i] = cl;
-                per_cluster[cl]++;
+                per_cluster[t][cl]++;
                 for (int k = 0; k < tb.info.bodies; ++k) {
                     int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
                     if ((uint32_t)r >= kDynamicLimit) {
-                        auto& ks = kin_seen[cl];
-                        if (std::find(ks.begin(), ks.end(), r & kRefMask) == ks.end()) ks.push_back(r & kRefMask);
+                        const std::pair<int32_t, int32_t> pair{cl, r & kRefMask};
+                        if (met.empty() || (met.back() != pair && std::find(met.begin(), met.end(), pair) == met.end())) met.push_back(pair);
                     }
                 }
             }
-            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (segment_slots(per_cluster[cl], reserve) + 63) / 64;
+        });
+        for (size_t t = 0; t < c->tbs.size(); ++t) {
+            for (auto& pair : kin_met[t]) {
+                auto& ks = kin_seen[pair.first];
+                if (std::find(ks.begin(), ks.end(), pair.second) == ks.end()) ks.push_back(pair.second);
+            }
+            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (segment_slots(per_cluster[t][cl], reserve) + 63) / 64;
         }
         int max_slots = 0, max_items = 0;
         for (int cl = 0; cl < nclusters; ++cl) {
@@ -144,6 +221,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         }
         cap = std::max<int>(largest, cap * 7 / 8);
     }
+    plan_lap("phase A: cluster sizes");
     // ---- phase B: local slots, reordered type batches, work items with predecessor lists ----
     std::vector<std::vector<int32_t>> cl_bodies(nclusters);  // natural local order: dynamics ascending, kinematics appended on first use
     std::vector<int32_t> local_of(universe, -1);
@@ -184,7 +262,8 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         for (int i = 0; i < tb.count; ++i) tb.perm[next[clc[i]]++] = i;  // counting sort by cluster: inside a cluster the caller's order stays
         tb.inv.assign(tb.count, 0);
         std::vector<int32_t> refs((size_t)nb * stride, -1), lrefs((size_t)nb * stride, -1);
-        std::vector<float> pre((size_t)pf * stride, 0.0f), acc((size_t)imf * stride, 0.0f);
+        const bool host_values = c->host_values;  // the product leaves prestep data and impulses on the device (transposed there through `inv`); only the offline harness permutes them here
+        std::vector<float> pre(host_values ? (size_t)pf * stride : 0, 0.0f), acc(host_values ? (size_t)imf * stride : 0, 0.0f);
         for (int k = 0; k < nb; ++k) {
             const int32_t* src = tb.refs_soa.data() + (size_t)k * tb.stride;
             int32_t* dst = refs.data() + (size_t)k * stride;
@@ -198,12 +277,12 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                 ldst[d] = ((uint32_t)r < kDynamicLimit) ? rotated_slot(local_of[r]) : (rotated_slot(cl_kin[clc[h]].find(r & kRefMask)->second) | (int)kDynamicLimit);
             }
         }
-        for (int f = 0; f < pf; ++f) {
+        for (int f = 0; f < pf && host_values; ++f) {
             const float* src = tb.prestep_soa.data() + (size_t)f * tb.stride;
             float* dst = pre.data() + (size_t)f * stride;
             for (int d = 0; d < tb.slots; ++d) if (tb.perm[d] >= 0) dst[d] = src[tb.perm[d]];
         }
-        for (int f = 0; f < imf; ++f) {
+        for (int f = 0; f < imf && host_values; ++f) {
             const float* src = tb.accum_soa.data() + (size_t)f * tb.stride;
             float* dst = acc.data() + (size_t)f * stride;
             for (int d = 0; d < tb.slots; ++d) if (tb.perm[d] >= 0) dst[d] = src[tb.perm[d]];
@@ -212,20 +291,16 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         tb.dev_refs = refs;
         tb.refs_soa.swap(refs); tb.prestep_soa.swap(pre); tb.accum_soa.swap(acc); tb.lrefs_soa.swap(lrefs);
     };
-    {
-        const int workers = std::max(1, std::min<int>({env_int("BEPUHIP_PLAN_THREADS", 8), (int)std::thread::hardware_concurrency(), (int)c->tbs.size()}));
-        std::atomic<size_t> next{0};
-        auto work = [&]() { for (size_t t; (t = next.fetch_add(1)) < c->tbs.size();) permute_type_batch(t); };
-        std::vector<std::thread> pool;
-        for (int w = 1; w < workers; ++w) pool.emplace_back(work);
-        work();
-        for (auto& th : pool) th.join();
-    }
-    for (size_t t : visit) {
-        HostTypeBatch& tb = c->tbs[t];
-        const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
-        const std::vector<int32_t>& clc = cl_of_constraint[t];
-        for (int cl = 0; cl < nclusters; ++cl) {
+    plan_lap("slots, kinematic copies");
+    plan_parallel_for(c->tbs.size(), permute_type_batch);
+    plan_lap("permuted rows (threads)");
+    // Work items and their predecessor lists: a cluster's items depend on that cluster's bodies only, so the clusters are built side by side; inside a cluster the type
+    // batches are visited in the fixed order above, which is the order of its item list.
+    plan_parallel_for((size_t)nclusters, [&](size_t cluster) {
+        const int cl = (int)cluster;
+        for (size_t t : visit) {
+            HostTypeBatch& tb = c->tbs[t];
+            const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
             const int d = tb.seg_begin[cl], e = tb.seg_begin[cl + 1];
             if (d == e) continue;
             for (int s0 = d; s0 < e; s0 += 64) {
@@ -259,10 +334,12 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                 cl_items[cl].push_back(it);
             }
         }
-    }
+    });
+    plan_lap("work items, predecessor lists");
     // The kernel reads the local references as 16-bit halves, two body slots per word (slot < 32768; bit 15 = kinematic copy): half the bytes, and one
     // load instead of two for a two-body constraint. The 32-bit form above was only needed for the predecessor search.
-    for (auto& tb : c->tbs) {
+    plan_parallel_for(c->tbs.size(), [&](size_t t) {
+        HostTypeBatch& tb = c->tbs[t];
         const int nb = tb.info.bodies, rows = (nb + 1) / 2;
         std::vector<int32_t> packed((size_t)rows * tb.stride, 0);
         for (int k = 0; k < nb; ++k)
@@ -272,7 +349,8 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                 packed[(size_t)(k / 2) * tb.stride + d] |= (int32_t)(half << (16 * (k & 1)));
             }
         tb.lrefs_soa.swap(packed);
-    }
+    });
+    plan_lap("packed local references");
     // Cross-pass predecessors: the last toucher (end of a pass) of every body an item touches first.
     for (int cl = 0; cl < nclusters; ++cl) {
         for (auto& fs : first_touch[cl]) {
@@ -312,18 +390,13 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     // what structural updates need in order to stay on this plan
     plan.body_cluster.assign(universe, -1);
     plan.body_lref.assign(universe, -1);
-    plan.body_degree.assign(universe, 0);
     for (int i = 0; i < universe; ++i)
         if (is_dyn[i]) { plan.body_cluster[i] = cluster_of[parent[i]]; plan.body_lref[i] = rotated_slot(local_of[i]); }
-    for (auto& tb : c->tbs)
-        for (int k = 0; k < tb.info.bodies; ++k)
-            for (int d = 0; d < tb.slots; ++d) {
-                const int32_t r = tb.dev_refs[(size_t)k * tb.stride + d];
-                if (r >= 0 && (uint32_t)r < kDynamicLimit) ++plan.body_degree[r];
-            }
+    // (the bodies' constraint counts, which only structural updates need, are counted from dev_refs by the first of them: soft_ensure_degrees)
     plan.cluster_kin.resize(nclusters);
     for (int cl = 0; cl < nclusters; ++cl)
         for (auto& kv : cl_kin[cl]) plan.cluster_kin[cl].emplace(kv.first, rotated_slot(kv.second));
+    plan_lap("cross-pass lists, descriptors, mirrors");
 }
 
 
@@ -588,7 +661,8 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         std::stable_sort(tb.perm.begin(), tb.perm.end(), [&](int a, int b) { return clc[a] != clc[b] ? clc[a] < clc[b] : touches_shared[a] < touches_shared[b]; });
         std::vector<int32_t> refs((size_t)nb * tb.stride, -1), lrefs((size_t)nb * tb.stride, -1);
         std::vector<uint32_t> ranks((size_t)nb * tb.stride, 0u);
-        std::vector<float> pre((size_t)pf * tb.stride, 0.0f), acc((size_t)imf * tb.stride, 0.0f);
+        const bool host_values = c->host_values;
+        std::vector<float> pre(host_values ? (size_t)pf * tb.stride : 0, 0.0f), acc(host_values ? (size_t)imf * tb.stride : 0, 0.0f);
         for (int d = 0; d < tb.count; ++d) {
             const int h = tb.perm[d], cl = clc[h];
             for (int k = 0; k < nb; ++k) {
@@ -597,8 +671,8 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                 lrefs[(size_t)k * tb.stride + d] = slot_of(cl, r);
                 ranks[(size_t)k * tb.stride + d] = srank[t][(size_t)k * tb.stride + h];
             }
-            for (int f = 0; f < pf; ++f) pre[(size_t)f * tb.stride + d] = tb.prestep_soa[(size_t)f * tb.stride + h];
-            for (int f = 0; f < imf; ++f) acc[(size_t)f * tb.stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
+            for (int f = 0; f < pf && host_values; ++f) pre[(size_t)f * tb.stride + d] = tb.prestep_soa[(size_t)f * tb.stride + h];
+            for (int f = 0; f < imf && host_values; ++f) acc[(size_t)f * tb.stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
         }
         tb.refs_soa.swap(refs); tb.prestep_soa.swap(pre); tb.accum_soa.swap(acc); tb.lrefs_soa.swap(lrefs);
         srank[t].swap(ranks);

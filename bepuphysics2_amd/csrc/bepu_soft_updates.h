@@ -27,15 +27,29 @@ static void soft_setup(bepuhip_ctx* c, ClusterPlan& plan) {
     c->soft_ok = false;
     c->soft_slots.clear(); c->soft_index.clear(); c->soft_items_dirty = false; c->soft_adds = c->soft_removes = 0;
     if (!plan.enabled || plan.shared || env_int("BEPUHIP_NO_SOFT_UPDATES", 0)) return;
-    c->body_cluster.swap(plan.body_cluster); c->body_lref.swap(plan.body_lref); c->body_degree.swap(plan.body_degree); c->cluster_kin.swap(plan.cluster_kin);
+    c->body_cluster.swap(plan.body_cluster); c->body_lref.swap(plan.body_lref); c->body_degree.clear(); c->cluster_kin.swap(plan.cluster_kin);
     c->items_host = plan.items; c->clusters_host = plan.clusters;
     c->cluster_degraded.assign(plan.clusters.size(), 0);
     c->soft_ok = true;
 }
 
+// Constraint count of every dynamic body, from the device-slot mirrors of the references: counted when the first structural update arrives (an upload that is never
+// followed by one does not pay for it).
+static void soft_ensure_degrees(bepuhip_ctx* c) {
+    if (!c->body_degree.empty()) return;
+    c->body_degree.assign(c->body_cluster.size(), 0);
+    for (auto& tb : c->tbs)
+        for (int k = 0; k < tb.info.bodies; ++k)
+            for (int d = 0; d < tb.slots; ++d) {
+                const int32_t r = tb.dev_refs[(size_t)k * tb.stride + d];
+                if (r >= 0 && (uint32_t)r < kDynamicLimit && (size_t)r < c->body_degree.size()) ++c->body_degree[r];
+            }
+}
+
 // TypeProcessor.Remove on the island layout. false: not possible here (nothing was changed).
 static bool soft_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index) {
     if (!c->soft_ok || tb->slots == 0 || tb->info.bodies > 2) return soft_refuse("removal from a type batch the island layout does not manage");
+    soft_ensure_degrees(c);
     const int t = (int)(tb - c->tbs.data());
     const int d = tb->inv[index], last = tb->count - 1, dl = tb->inv[last];
     for (int k = 0; k < tb->info.bodies; ++k) {
@@ -69,6 +83,7 @@ static bool soft_bodies_still_constrained(bepuhip_ctx* c) {
 // TypeProcessor.AllocateInTypeBatch on the island layout. false: not possible here (nothing was changed).
 static bool soft_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, const float* prestep) {
     if (!c->soft_ok || tb->slots == 0 || tb->info.bodies > 2) return soft_refuse("addition to a type batch the island layout does not manage");
+    soft_ensure_degrees(c);
     const int t = (int)(tb - c->tbs.data()), nb = tb->info.bodies;
     int cl = -1;
     for (int k = 0; k < nb; ++k) {

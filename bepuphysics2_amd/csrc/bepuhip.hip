@@ -278,6 +278,8 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
     // consecutive words on both sides — copied as such (the last bundle only up to `count`). The host does this for the body references only (the plan needs them);
     // prestep data and accumulated impulses — nine tenths of the bytes — go to the device as they are and are transposed there (end_constraints).
     const bool fallback_batch = batch_index == c->fallback_threshold;
+    int highest_reference = -1;
+    int64_t live = 0;  // a fallback type batch counts its empty lanes in `count`
     for (int b0 = 0; b0 < count; b0 += W) {
         const size_t bundle = (size_t)(b0 / W);
         const int lanes = std::min(W, count - b0);
@@ -289,6 +291,8 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
                 // Empty lanes exist only inside the bundles of the sequential fallback batch (TypeProcessor.cs:451-560): every body slot of the lane is -1.
                 if (r < 0 && !(r == -1 && fallback_batch)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "empty (-1) body reference inside a synchronized batch");
                 dst[lane] = r;
+                if (r >= 0) highest_reference = std::max(highest_reference, r & kRefMask);
+                live += (k == 0 && r != -1);
             }
         }
         if (c->host_values) {
@@ -311,6 +315,8 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
         }
     }
     c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
+    c->referenced_bodies = std::max(c->referenced_bodies, highest_reference + 1);  // checked against the body count at solve time (validate_solve)
+    c->total_constraints += live;
     c->tbs.push_back(std::move(tb));
     return BEPUHIP_OK;
 }
@@ -453,17 +459,7 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         fprintf(stderr, "bepuhip end_constraints: %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    size_t words = 0;
-    c->total_constraints = 0;
-    for (auto& tb : c->tbs)
-        for (int i = 0; i < tb.count; ++i) c->total_constraints += tb.refs_soa[i] != -1;  // a fallback type batch counts its empty lanes in `count`
-    {
-        int universe = 0;
-        for (auto& tb : c->tbs)
-            for (int32_t r : tb.refs_soa)
-                if (r >= 0) universe = std::max(universe, (r & kRefMask) + 1);
-        c->referenced_bodies = universe;  // checked against the body count at solve time (validate_solve)
-    }
+    size_t words = 0;  // (total_constraints and referenced_bodies were counted while set_type_batch converted the references)
     c->requirk_stale = true;  // the conserving angular modes' substep-0 lists are built by the first solve that asks for such a mode (build_requirk_lists)
     std::vector<std::vector<int32_t>> fallback_refs;  // the fallback type batches' references (SoA rows), kept past the staging buffers for the level walk below
     if (c->has_fallback)
@@ -672,26 +668,67 @@ static int32_t build_requirk_lists(bepuhip_ctx* c) {
     for (size_t t = 0; t < c->tbs.size(); ++t)
         for (int32_t r : host_refs[t])
             if ((uint32_t)r < kDynamicLimit) first_batch[r] = std::min(first_batch[r], c->tbs[t].batch);
-    std::vector<std::vector<int32_t>> lists(c->batch_count);
+    // Lists per LAUNCH: launch b < sync_batches is batch b; the sequential fallback batch follows as one launch per dependency level (build_descriptors). There a body
+    // may sit in several bundles: the one at its earliest slot (type batch, index) integrates it if the batch is the first to see it (Solver_Solve.cs:1003-1019), every
+    // other occurrence is an ordinary non-integrating lane — re-transformed like any other when its bundle integrates somebody, right before ITS constraint runs, i.e.
+    // at that row's level (the levels are walked exactly as build_descriptors walks them).
+    const int sync_batches = c->has_fallback ? c->fallback_threshold : c->batch_count;
+    std::vector<std::vector<int32_t>> lists(std::max(c->launch_count, sync_batches));
+    std::vector<uint64_t> earliest(c->has_fallback ? universe : 0, UINT64_MAX);  // per body: its earliest (fallback type batch ordinal << 32 | index) in the fallback batch
+    std::vector<std::vector<int32_t>> row_level;                                 // per fallback type batch ordinal: the level of every row
+    if (c->has_fallback) {
+        std::vector<int32_t> last_level(universe, -1);
+        size_t ord = 0;
+        for (size_t t = 0; t < c->tbs.size(); ++t) {
+            const HostTypeBatch& tb = c->tbs[t];
+            if (tb.batch != c->fallback_threshold) continue;
+            row_level.emplace_back(tb.count, -1);
+            for (int i = 0; i < tb.count; ++i) {
+                if (tb.count == 0 || host_refs[t][i] == -1) continue;
+                int level = 0;
+                for (int k = 0; k < tb.info.bodies; ++k) {
+                    const int32_t r = host_refs[t][(size_t)k * tb.count + i];
+                    if ((uint32_t)r < kDynamicLimit) { level = std::max(level, last_level[r] + 1); earliest[r] = std::min(earliest[r], ((uint64_t)ord << 32) | (uint32_t)i); }
+                }
+                for (int k = 0; k < tb.info.bodies; ++k) {
+                    const int32_t r = host_refs[t][(size_t)k * tb.count + i];
+                    if ((uint32_t)r < kDynamicLimit) last_level[r] = level;
+                }
+                row_level.back()[i] = level;
+            }
+            ++ord;
+        }
+    }
+    size_t fallback_ord = 0;
     for (size_t t = 0; t < c->tbs.size(); ++t) {
         const HostTypeBatch& tb = c->tbs[t];
+        const bool fallback = c->has_fallback && tb.batch == c->fallback_threshold;
+        const size_t ord = fallback ? fallback_ord++ : 0;
         if (tb.batch == 0 || tb.count == 0) continue;  // batch 0 always integrates (Solver_Solve.cs:188-194): no conditional bundles
         for (int k = 0; k < tb.info.bodies; ++k) {
             const int32_t* refs = host_refs[t].data() + (size_t)k * tb.count;
+            auto integrates = [&](int i) {  // this lane is the one that integrates its body
+                const int32_t r = refs[i];
+                if ((uint32_t)r >= kDynamicLimit || first_batch[r] != tb.batch) return false;
+                return !fallback || earliest[r] == (((uint64_t)ord << 32) | (uint32_t)i);
+            };
             for (int b0 = 0; b0 < tb.count; b0 += W) {
                 const int b1 = std::min(tb.count, b0 + W);
                 bool any = false;
-                for (int i = b0; i < b1; ++i) any |= (uint32_t)refs[i] < kDynamicLimit && first_batch[refs[i]] == tb.batch;
+                for (int i = b0; i < b1; ++i) any |= integrates(i);
                 if (!any) continue;
-                for (int i = b0; i < b1; ++i)
-                    if ((uint32_t)refs[i] < kDynamicLimit && first_batch[refs[i]] < tb.batch) lists[tb.batch].push_back(refs[i]);
+                for (int i = b0; i < b1; ++i) {
+                    if ((uint32_t)refs[i] >= kDynamicLimit || integrates(i)) continue;
+                    const int launch = fallback ? sync_batches + row_level[ord][i] : tb.batch;
+                    if (launch >= 0 && (size_t)launch < lists.size()) lists[launch].push_back(refs[i]);
+                }
             }
         }
     }
     std::vector<int32_t> flat;
-    c->requirk_begin.assign(c->batch_count + 1, 0);
-    for (int b = 0; b < c->batch_count; ++b) { c->requirk_begin[b] = (int)flat.size(); flat.insert(flat.end(), lists[b].begin(), lists[b].end()); }
-    c->requirk_begin[c->batch_count] = (int)flat.size();
+    c->requirk_begin.assign(lists.size() + 1, 0);
+    for (size_t b = 0; b < lists.size(); ++b) { c->requirk_begin[b] = (int)flat.size(); flat.insert(flat.end(), lists[b].begin(), lists[b].end()); }
+    c->requirk_begin[lists.size()] = (int)flat.size();
     if (!flat.empty()) {
         HIP_TRY(hipMalloc((void**)&c->d_requirk, flat.size() * 4));
         HIP_TRY(hipMemcpy(c->d_requirk, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
@@ -702,7 +739,7 @@ static int32_t build_requirk_lists(bepuhip_ctx* c) {
 }
 
 static void enqueue_requirk(bepuhip_ctx* c, int substep, int batch, const StepParams& sp) {
-    if (substep != 0 || sp.angular_mode == 0 || c->requirk_begin.empty() || batch >= c->batch_count) return;
+    if (substep != 0 || sp.angular_mode == 0 || c->requirk_begin.empty() || batch + 1 >= (int)c->requirk_begin.size()) return;  // `batch`: launch index (a level of the fallback batch counts)
     const int n = c->requirk_begin[batch + 1] - c->requirk_begin[batch];
     if (n > 0)
         hipLaunchKernelGGL(momentum_requirk_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_bodies, (const int*)(c->d_requirk + c->requirk_begin[batch]), n, sp);
@@ -886,8 +923,6 @@ static int32_t validate_solve(bepuhip_ctx* c, float dt, int32_t substeps, const 
         if (iterations[s] < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Velocity iteration count must be positive.");
     if (in->angular_integration_mode < 0 || in->angular_integration_mode > 2) return fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown AngularIntegrationMode");
     if (c->building) return fail(BEPUHIP_E_STATE, "solve between begin_constraints and end_constraints");
-    if (c->has_fallback && in->angular_integration_mode != 0)
-        return fail(BEPUHIP_E_UNSUPPORTED, "a sequential fallback batch together with a momentum-conserving AngularIntegrationMode; use simulation.Solve");
     if (c->built && c->referenced_bodies > c->body_count)
         return fail(BEPUHIP_E_STATE, "a constraint references body " + std::to_string(c->referenced_bodies - 1) + " but only " + std::to_string(c->body_count) +
                                          " bodies are uploaded (set_bodies)");

@@ -192,8 +192,24 @@ def test_fallback_batch_limits_through_the_abi(hip_solver_factory):
     with pytest.raises(ValueError):  # more than threshold + 1 batches cannot exist (Solver.cs:1882)
         solver.set_constraints(scene, fallback_batch_threshold=2)
     solver.upload(scene, 3)
-    with pytest.raises(native.UnsupportedError):  # the conserving modes' substep-0 re-transformation is defined per bundle of a synchronized batch
-        solver.solve(1 / 60, SolveDescription(1, 2, fallback_batch_threshold=3), PoseIntegratorCallbacks(angular_integration_mode=1))
+    solver.solve(1 / 60, SolveDescription(1, 2, fallback_batch_threshold=3), PoseIntegratorCallbacks(angular_integration_mode=1))  # (round 2 refused this combination)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("threshold, spokes, hubs", [(5, 40, 2), (3, 25, 2)])
+def test_sequential_fallback_batch_with_momentum_conserving_modes(hip_solver_factory, threshold, spokes, hubs, mode):
+    """the conserving angular modes re-transform the non-integrating lanes of every conditionally integrating bundle in substep 0
+    (TypeProcessor.cs:1264-1281); in the sequential fallback batch a body may sit in several bundles, one of which (its earliest slot) integrates it. The device applies
+    the re-transformation per dependency level, right before the row it belongs to; bit for bit the oracle's bundle-after-bundle result."""
+    scene = small_scenes.star_scene(4, spokes=spokes, hubs=hubs, fallback_batch_threshold=threshold)
+    assert len(scene.batches) == threshold + 1
+    sd = SolveDescription(2, 3, fallback_batch_threshold=threshold)
+    cb = PoseIntegratorCallbacks(angular_integration_mode=mode)
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=3)
+    got = pu.run_hip(hip_solver_factory(), scene, 1 / 60, sd, cb, frames=3)
+    _bit_exact(ref, got)
+    plain = pu.run_oracle(scene, 1 / 60, sd, PoseIntegratorCallbacks(), frames=3)
+    assert not np.array_equal(plain.bodies, ref.bodies)  # the mode does change the answer
 
 
 def test_exchanged_solve_refuses_a_share_with_a_fallback_batch(hip_solver_factory):

@@ -45,7 +45,7 @@ while time.time() < t_end:
     solver = HipSolver(use_clusters=use_clusters, use_graph=bool(rng.integers(2)))
     try:
         got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=frames)
-    except UnsupportedError:  # the one documented refusal: a sequential fallback batch together with a momentum-conserving angular integration mode
+    except UnsupportedError:  # round 2 refused a sequential fallback batch together with a momentum-conserving angular mode; nothing should be refused any more
         refused += 1
         solver.close()
         continue

@@ -194,6 +194,10 @@ int main(int argc, char** argv) {
         auto t0 = std::chrono::steady_clock::now();
         for (auto& t : tbs)
             if (bepuhip_set_type_batch(c, t.batch, t.type, t.count, t.refs.data(), t.prestep.data(), t.accum.data()) != BEPUHIP_OK) { fprintf(stderr, "set_type_batch: %s\n", bepuhip_last_error()); return 1; }
+        if (getenv("PLAN_NO_VALUES")) {  // time the plan as the product runs it: prestep data and impulses stay on the device, only references are permuted here
+            for (auto& tb : c->tbs) { std::vector<float>().swap(tb.prestep_soa); std::vector<float>().swap(tb.accum_soa); }
+            c->host_values = false;
+        }
         auto t1 = std::chrono::steady_clock::now();
         int universe = 0;
         for (auto& tb : c->tbs)
