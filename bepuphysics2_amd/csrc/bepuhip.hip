@@ -1738,6 +1738,9 @@ int32_t bepuhip_update_prestep_async(bepuhip_ctx* c, int32_t batch, int32_t type
 int32_t bepuhip_update_accumulated_impulses(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* impulse_bundles) {
     return update_rows(c, batch, type_id, first_bundle, bundle_count, impulse_bundles, false);
 }
+int32_t bepuhip_update_accumulated_impulses_async(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* impulse_bundles) {
+    return update_rows(c, batch, type_id, first_bundle, bundle_count, impulse_bundles, false, false);
+}
 int32_t bepuhip_get_prestep_range(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* prestep_bundles_out) {
     return read_rows(c, batch, type_id, first_bundle, bundle_count, prestep_bundles_out, true);
 }

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
     "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables", "bepuhip_set_convex_hulls", "bepuhip_set_compounds", "bepuhip_set_meshes",
     "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_get_constraint_count",
-    "bepuhip_register_host_memory", "bepuhip_unregister_host_memory", "bepuhip_get_poses_and_velocities", "bepuhip_get_poses_and_velocities_async", "bepuhip_update_prestep_async",
+    "bepuhip_register_host_memory", "bepuhip_unregister_host_memory", "bepuhip_get_poses_and_velocities", "bepuhip_get_poses_and_velocities_async", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses_async",
 ]
 
 
@@ -128,7 +128,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_unregister_host_memory.argtypes = [vp, vp]
     lib.bepuhip_get_poses_and_velocities.argtypes = [vp, vp, i32]
     lib.bepuhip_get_poses_and_velocities_async.argtypes = [vp, vp, i32]
-    for name in ("bepuhip_update_prestep", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
+    for name in ("bepuhip_update_prestep", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses", "bepuhip_update_accumulated_impulses_async", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
         getattr(lib, name).argtypes = [vp, i32, i32, i32, i32, vp]
     lib.bepuhip_add_constraint.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
     lib.bepuhip_remove_constraint.argtypes = [vp, i32, i32, i32]
@@ -387,12 +387,13 @@ class HipSolver:
         fn = self.lib.bepuhip_update_prestep_async if asynchronous else self.lib.bepuhip_update_prestep
         _check(self.lib, fn(self.ctx, batch_index, type_id, first_bundle, n, _ptr(b)))
 
-    def update_accumulated_impulses(self, batch_index: int, type_id: int, first_bundle: int, bundles: np.ndarray):
+    def update_accumulated_impulses(self, batch_index: int, type_id: int, first_bundle: int, bundles: np.ndarray, asynchronous: bool = False):
         b = np.ascontiguousarray(bundles, dtype=np.float32).reshape(-1)
         n, rem = divmod(b.size, self._bundle_floats(type_id, False))
         if rem:
             raise ValueError("impulse data is not a whole number of bundles")
-        _check(self.lib, self.lib.bepuhip_update_accumulated_impulses(self.ctx, batch_index, type_id, first_bundle, n, _ptr(b)))
+        fn = self.lib.bepuhip_update_accumulated_impulses_async if asynchronous else self.lib.bepuhip_update_accumulated_impulses
+        _check(self.lib, fn(self.ctx, batch_index, type_id, first_bundle, n, _ptr(b)))
 
     def get_prestep_range(self, batch_index: int, type_id: int, first_bundle: int, bundle_count: int) -> np.ndarray:
         out = np.empty(bundle_count * self._bundle_floats(type_id, True), dtype=np.float32)

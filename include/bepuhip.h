@@ -180,9 +180,10 @@ int32_t bepuhip_get_prestep(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_
  * The *_range getters are the matching read-backs (e.g. only the contact type batches after a solve). */
 int32_t bepuhip_update_bodies(bepuhip_ctx* ctx, const void* body_dynamics_aos, int32_t first, int32_t count);
 int32_t bepuhip_update_prestep(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* prestep_bundles);
-/* bepuhip_update_prestep without the wait at the end: enqueued on the context's stream (in order with the solves). With registered memory the bundles are read
- * asynchronously: they must stay unchanged until the next bepuhip_sync (or any synchronous call). */
+/* bepuhip_update_prestep / _accumulated_impulses without the wait at the end: enqueued on the context's stream (in order with the solves). With registered memory the
+ * bundles are read asynchronously: they must stay unchanged until the next bepuhip_sync (or any synchronous call). */
 int32_t bepuhip_update_prestep_async(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* prestep_bundles);
+int32_t bepuhip_update_accumulated_impulses_async(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* impulse_bundles);
 int32_t bepuhip_update_accumulated_impulses(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* impulse_bundles);
 int32_t bepuhip_get_bodies_range(bepuhip_ctx* ctx, void* body_dynamics_aos_out, int32_t first, int32_t count);
 int32_t bepuhip_get_prestep_range(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* prestep_bundles_out);
@@ -292,7 +293,7 @@ int32_t bepuhip_get_row_policy(bepuhip_ctx* ctx, int32_t* policy_out);
  * wait gave up (reported by bepuhip_sync as DEVICE error). */
 int32_t bepuhip_debug_status(bepuhip_ctx* ctx, uint32_t* words16_out);
 /* Constraint-iterations executed by the last solve: sum over substeps of constraints * (1 + velocity_iterations[s]). */
-int32_t bepuhip_last_constraint_iterations(bepuhip_ctx* ctx, int64_t* out);
+int32_t bepuhip_last_constraint_iterations(bepuhip_ctx* ctx, int64_t* iterations_out);
 /* The native HIP stream handle (hipStream_t) the context launches on, for callers that time with their own HIP events. */
 int32_t bepuhip_get_stream(bepuhip_ctx* ctx, void** stream_out);
 /* Asynchronous variant for benchmarking with inputs resident in HBM: enqueue a solve, return immediately; bepuhip_sync waits. */

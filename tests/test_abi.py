@@ -53,3 +53,33 @@ def test_every_entry_point_is_mapped_to_the_reference_in_the_integration_notes()
     names = sorted(set(re.findall(r"\b(bepuhip_[a-z_0-9]+)\s*\(", header)))
     assert len(names) > 40
     assert [n for n in names if n not in notes] == []
+
+
+def test_csharp_binding_is_one_text_and_covers_every_entry_point_of_the_header():
+    """INTEGRATION.md's C# block and integration/csharp/HipTimestepper.cs used to drift apart. The block IS the file, and the file's DllImport table
+    is the one tools/gen_csharp_imports.py generates from include/bepuhip.h (every entry point, parameter for parameter)."""
+    import importlib.util
+    import re
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    source = open(os.path.join(repo, "integration", "csharp", "HipTimestepper.cs")).read()
+    doc = open(os.path.join(repo, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```csharp\n(.*?)```", doc, flags=re.S)
+    assert blocks and blocks[0] == source, "INTEGRATION.md's first csharp block must be integration/csharp/HipTimestepper.cs verbatim"
+    spec = importlib.util.spec_from_file_location("gen_csharp_imports", os.path.join(repo, "tools", "gen_csharp_imports.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    generated = gen.block()
+    assert generated in source, "the DllImport block of HipTimestepper.cs is stale: regenerate it with tools/gen_csharp_imports.py"
+    from bepuphysics2_amd import native
+    for name in native.EXPORTED_SYMBOLS:
+        assert re.search(r"extern \w+ " + name + r"\(", source), name
+    # the calls the timestepper makes exist with the arity it uses them with
+    for call, args in re.findall(r"BepuHip\.(bepuhip_\w+)\((.*?)\)\)?;", source):
+        declared = re.search(r"extern \w+ " + call + r"\((.*?)\);", source).group(1)
+        want = 0 if not declared.strip() else declared.count(",") + 1
+        depth, got, text = 0, 1 if args.strip() else 0, args
+        for ch in text:
+            depth += ch in "(<[" 
+            depth -= ch in ")>]"
+            got += ch == "," and depth == 0
+        assert got == want, (call, args, declared)
