@@ -1076,17 +1076,28 @@ int32_t bepuhip_colour_constraints(int32_t device, const int32_t* refs, int32_t 
     const dim3 grid((count + 255) / 256), block(256);
     hipLaunchKernelGGL(colour_degree_kernel, grid, block, 0, 0, (const int*)d_refs, count, d_degree);
     hipLaunchKernelGGL(colour_priority_kernel, grid, block, 0, 0, (const int*)d_refs, count, (const unsigned*)d_degree, order, d_priority);
+    // Rounds are enqueued eight at a time; the host only looks at the count of uncoloured constraints behind each group (a round after the last useful one finds
+    // nothing to do and costs two near-empty launches), so the loop runs on the device and the host reads four bytes every eight rounds.
+    constexpr int kRoundsPerCheck = 8;
+    unsigned* d_remaining_slots = nullptr;  // one counter per round of a group: [k] = constraints still uncoloured after round k
+    e = hipMalloc((void**)&d_remaining_slots, kRoundsPerCheck * 4);
+    if (e != hipSuccess) { release(); return fail(BEPUHIP_E_DEVICE, std::string("colour_constraints: ") + hipGetErrorString(e)); }
     int rounds = 0;
-    for (unsigned remaining = 1; remaining != 0; ++rounds) {
-        if (rounds > count) { release(); return fail(BEPUHIP_E_DEVICE, "colour_constraints made no progress"); }  // every round colours at least the highest bid
-        hipMemsetAsync(d_best, 0, nb * 8, 0);
-        hipMemsetAsync(d_remaining, 0, 4, 0);
-        hipLaunchKernelGGL(colour_bid_kernel, grid, block, 0, 0, (const int*)d_refs, count, (const int*)d_colour, (const unsigned long long*)d_priority, d_best);
-        hipLaunchKernelGGL(colour_pick_kernel, grid, block, 0, 0, (const int*)d_refs, count, d_colour, (const unsigned long long*)d_priority, (const unsigned long long*)d_best, d_used,
-                           fallback_batch_threshold, d_remaining);
-        e = hipMemcpy(&remaining, d_remaining, 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { release(); return fail(BEPUHIP_E_DEVICE, std::string("colour_constraints: ") + hipGetErrorString(e)); }
+    for (bool done = false; !done;) {
+        if (rounds > count + kRoundsPerCheck) { hipFree(d_remaining_slots); release(); return fail(BEPUHIP_E_DEVICE, "colour_constraints made no progress"); }  // every round colours at least the highest bid
+        hipMemsetAsync(d_remaining_slots, 0, kRoundsPerCheck * 4, 0);
+        for (int k = 0; k < kRoundsPerCheck; ++k) {
+            hipMemsetAsync(d_best, 0, nb * 8, 0);
+            hipLaunchKernelGGL(colour_bid_kernel, grid, block, 0, 0, (const int*)d_refs, count, (const int*)d_colour, (const unsigned long long*)d_priority, d_best);
+            hipLaunchKernelGGL(colour_pick_kernel, grid, block, 0, 0, (const int*)d_refs, count, d_colour, (const unsigned long long*)d_priority, (const unsigned long long*)d_best, d_used,
+                               fallback_batch_threshold, d_remaining_slots + k);
+        }
+        unsigned remaining[kRoundsPerCheck];
+        e = hipMemcpy(remaining, d_remaining_slots, sizeof(remaining), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { hipFree(d_remaining_slots); release(); return fail(BEPUHIP_E_DEVICE, std::string("colour_constraints: ") + hipGetErrorString(e)); }
+        for (int k = 0; k < kRoundsPerCheck && !done; ++k) { ++rounds; done = remaining[k] == 0; }  // rounds = the rounds that were needed
     }
+    hipFree(d_remaining_slots);
     e = hipMemcpy(colours_out, d_colour, (size_t)count * 4, hipMemcpyDeviceToHost);
     release();
     if (e != hipSuccess) return fail(BEPUHIP_E_DEVICE, std::string("colour_constraints: ") + hipGetErrorString(e));

@@ -13,6 +13,12 @@ from bepuphysics2_amd.scene import PoseIntegratorCallbacks
 sim = HostSimulation.scene("ragdoll_tube", int(os.environ.get("RAGDOLLS", "15000")), 1, int(os.environ.get("CONTACTS", "0")), 5)
 scene, sd = sim.export(), sim.solve_description()
 cb = PoseIntegratorCallbacks()
+_types, flat, _pre, _acc = colouring.flatten_constraints(scene)
+for order in (0, 1):
+    colouring.colour_constraints(flat, scene.body_count, order)  # untimed: device and library initialisation
+    t0 = time.perf_counter()
+    _colours, nbatches, nrounds = colouring.colour_constraints(flat, scene.body_count, order)
+    print(f"bepuhip_colour_constraints order {order}: {flat.shape[0]} constraints -> {nbatches} batches in {nrounds} rounds, {1e3 * (time.perf_counter() - t0):.1f} ms (native call, H2D + D2H included)")
 t0 = time.perf_counter()
 recoloured, rounds = colouring.recolour_scene(scene)
 print(f"max dynamic degree {colouring.max_dynamic_degree(scene)}; host first fit {len(scene.batches)} batches; device largest-degree-first {len(recoloured.batches)} batches "
