@@ -197,8 +197,15 @@ __device__ __forceinline__ void store_agent_pair(float4* p, float4 a, float4 b) 
 // the body, see SharedTables) travels IN the record: the reader's poll returns the velocity together with the news that it is the one it waits for — one
 // memory round trip per hand-off instead of three (poll a counter, fetch the velocity; store, drain, bump the counter). Every event rewrites both halves
 // with the same number, so a read that mixes two events shows unequal numbers and is polled again.
-struct SharedRef {  // one body slot of one lane's constraint: the body (-1: not a shared body) and the event number its record must carry before this application
-    int body; unsigned number;
+// Hand-offs that stay inside a cluster skip the record: when the application before this one on the body (rank - 1 of the same pass) ran in THIS cluster, its
+// velocity is in the cluster's LDS slot of the body (home or ghost slot) and its item is among this item's predecessors — the lane behaves like one on a private
+// body; when the application after this one runs here too, the velocity goes to the LDS slot instead of the record. The host marks both cases in the rank word
+// (kRankPredLocal / kRankSuccLocal). Event numbers are absolute, so the records that are still written carry the numbers their readers wait for. The first and the
+// last application of a pass always use the record (the end-of-substep readers and the next pass's first application poll it).
+constexpr unsigned kRankPredLocal = 1u << 16, kRankSuccLocal = 1u << 17;
+struct SharedRef {  // one body slot of one lane's constraint: the body (-1: not a shared body), the event number its record must carry before this application, and how the
+    int body; unsigned number;  // velocity arrives (poll: from the record) and leaves (publish: into the record; else through the LDS slot)
+    bool poll, publish;
     __device__ __forceinline__ bool shared() const { return body >= 0; }
 };
 template <bool END_OF_SUBSTEP>  // END_OF_SUBSTEP: the number every application of the passes so far has happened (what the incremental contact update waits for)
@@ -207,6 +214,8 @@ __device__ __forceinline__ SharedRef make_shared_ref(const ClusterShared& sh, un
     const bool shared = active && (half & kLrefShared) != 0 && (half & 0x8000u) == 0;
     r.body = shared ? (sh.slot_body[half & 0x3FFFu] & kSlotBodyMask) : -1;
     r.number = sh.st.base + sh.events + ((srank >> 8) & 0xFFu) * sh.passes + (END_OF_SUBSTEP ? 0u : (srank & 0xFFu));  // rank | degree << 8
+    r.poll = shared && (END_OF_SUBSTEP || !(srank & kRankPredLocal));
+    r.publish = shared && !(srank & kRankSuccLocal);
     return r;
 }
 // Two records per body: substep s works on record s & 1, and what reads the END of substep s - 1 (the incremental contact update, the pose integration of the
@@ -217,7 +226,7 @@ __device__ __forceinline__ float4* shared_record(const SharedTables& st, int bod
 // Lanes without a shared body pass at once. Bounded like every other wait of this kernel.
 template <bool TWO>
 __device__ __forceinline__ void acquire_shared(const ClusterShared& sh, const SharedRef& ra, DBody& A, const SharedRef& rb, DBody& B, int kind, int k) {
-    bool need_a = ra.shared(), need_b = TWO && rb.shared();
+    bool need_a = ra.poll, need_b = TWO && rb.poll;
     if (__builtin_amdgcn_ballot_w64(need_a || need_b) == 0) return;
     const unsigned want_a = ra.number, want_b = rb.number;
     const float4* pa = shared_record(sh.st, need_a ? ra.body : 0, sh.events - 1u);  // during the sweeps of substep s events == s + 1; the incremental update
@@ -245,7 +254,7 @@ __device__ __forceinline__ void acquire_shared(const ClusterShared& sh, const Sh
     }
 }
 __device__ __forceinline__ void release_shared(const ClusterShared& sh, const SharedRef& r, const DBody& b) {
-    if (!r.shared()) return;
+    if (!r.publish) return;
     const float n = __uint_as_float(r.number + 1u);
     store_agent_pair(shared_record(sh.st, r.body, sh.events - 1u), make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, n), make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, n));
 }
@@ -417,7 +426,7 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     if (STAGE != kStageIncremental) touch_code_ahead(sh, lane);
     const int ra = unpack_local_ref(both & 0xFFFFu);
     const int rb = (F::bodies == 2) ? unpack_local_ref(both >> 16) : -1;
-    SharedRef sa = {-1, 0u}, sb = {-1, 0u};
+    SharedRef sa = {-1, 0u, false, false}, sb = {-1, 0u, false, false};
     if constexpr (SHARED) {
         sa = make_shared_ref<STAGE == kStageIncremental>(sh, both & 0xFFFFu, rank_a, active);
         if (F::bodies == 2) sb = make_shared_ref<STAGE == kStageIncremental>(sh, both >> 16, rank_b, active);
@@ -453,8 +462,8 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     ClusterGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE, SHARED> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps, sa, sb};
     if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, gate);
     else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, gate);
-    store_velocity_lds<accA>(sh, (active && !sa.shared()) ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references)
-    if (F::bodies == 2) store_velocity_lds<accB>(sh, (active && !sb.shared()) ? rb : -1, B);
+    store_velocity_lds<accA>(sh, (active && !sa.publish) ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references); a shared body's velocity goes to
+    if (F::bodies == 2) store_velocity_lds<accB>(sh, (active && !sb.publish) ? rb : -1, B);  // the LDS slot only when the next application on it runs in this cluster
     if constexpr (SHARED) {
         release_shared(sh, sa, A);  // velocity and "event done" in one record: the next application on the body polls exactly this
         if (F::bodies == 2) release_shared(sh, sb, B);

@@ -570,16 +570,43 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             }
         }
     }
-    std::vector<std::vector<uint32_t>> srank(c->tbs.size());
-    {
-        std::vector<int32_t> next_rank(universe, 0);
-        for (size_t t = 0; t < c->tbs.size(); ++t) {  // batch order == type batch order; inside a batch a body appears at most once
-            HostTypeBatch& tb = c->tbs[t];
-            srank[t].assign((size_t)tb.info.bodies * tb.stride, 0u);
+    if (env_int("BEPUHIP_PLAN_STATS", 0) >= 2) {  // how many hand-offs of shared bodies stay inside one cluster (rank r and r + 1 of a pass run by the same cluster)
+        std::vector<int32_t> last_cluster(universe, -1);
+        long long applications = 0, local_pairs = 0, pairs = 0;
+        for (size_t t = 0; t < c->tbs.size(); ++t) {
+            const HostTypeBatch& tb = c->tbs[t];
             for (int k = 0; k < tb.info.bodies; ++k)
                 for (int i = 0; i < tb.count; ++i) {
                     const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                    if ((uint32_t)r < kDynamicLimit && shared[r]) srank[t][(size_t)k * tb.stride + i] = (uint32_t)next_rank[r]++ | ((uint32_t)deg[r] << 8);
+                    if ((uint32_t)r >= kDynamicLimit || !shared[r]) continue;
+                    ++applications;
+                    if (last_cluster[r] >= 0) { ++pairs; local_pairs += last_cluster[r] == cl_of_constraint[t][i]; }
+                    last_cluster[r] = cl_of_constraint[t][i];
+                }
+        }
+        fprintf(stderr, "bepuhip split plan: %lld applications on shared bodies per pass, %lld consecutive pairs of which %lld (%.1f %%) inside one cluster\n", applications, pairs, local_pairs,
+                100.0 * local_pairs / std::max(1LL, pairs));
+    }
+    // Rank words: rank | degree << 8, plus the two hand-off flags of bepu_cluster_kernel.h (kRankPredLocal / kRankSuccLocal): consecutive applications of a pass on a
+    // shared body that the SAME cluster runs pass the velocity through that cluster's LDS slot of the body instead of the record in HBM (pile: 42 % of the hand-offs,
+    // ragdoll crowd: 78 %). BEPUHIP_SPLIT_LOCAL_HANDOFF=0 turns them off.
+    constexpr uint32_t kPlanRankPredLocal = 1u << 16, kPlanRankSuccLocal = 1u << 17;
+    const bool local_handoff = env_int("BEPUHIP_SPLIT_LOCAL_HANDOFF", 1) != 0;
+    std::vector<std::vector<uint32_t>> srank(c->tbs.size());
+    {
+        std::vector<int32_t> next_rank(universe, 0), last_cluster(universe, -1);
+        std::vector<uint32_t*> last_word(universe, nullptr);
+        for (size_t t = 0; t < c->tbs.size(); ++t) srank[t].assign((size_t)c->tbs[t].info.bodies * c->tbs[t].stride, 0u);
+        for (size_t t = 0; t < c->tbs.size(); ++t) {  // batch order == type batch order; inside a batch a body appears at most once
+            HostTypeBatch& tb = c->tbs[t];
+            for (int k = 0; k < tb.info.bodies; ++k)
+                for (int i = 0; i < tb.count; ++i) {
+                    const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
+                    if ((uint32_t)r >= kDynamicLimit || !shared[r]) continue;
+                    uint32_t& word = srank[t][(size_t)k * tb.stride + i];
+                    word = (uint32_t)next_rank[r]++ | ((uint32_t)deg[r] << 8);
+                    if (local_handoff && last_word[r] != nullptr && last_cluster[r] == cl_of_constraint[t][i]) { word |= kPlanRankPredLocal; *last_word[r] |= kPlanRankSuccLocal; }
+                    last_word[r] = &word; last_cluster[r] = cl_of_constraint[t][i];
                 }
         }
     }
@@ -689,12 +716,17 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                 const int self = (int)cl_items[cl].size();
                 int npred = 0, overflow = 0;
                 std::vector<int32_t>& lt = last_toucher[cl];
+                // Shared bodies are ordered by the event numbers in their records, not by LDS flags — except where two consecutive applications run in this cluster
+                // (the rank word's hand-off flags): there the later one waits for the earlier one's item like on a private body, under the body's slot without its flag bit.
                 for (int j = s0; j < s0 + it.count; ++j)
                     for (int k = 0; k < nb; ++k) {
-                        const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
-                        if ((uint32_t)lr >= kDynamicLimit || (lr & (int)kLrefShared)) continue;  // shared bodies are ordered by their event counters, not by LDS flags
+                        int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
+                        if ((uint32_t)lr >= kDynamicLimit) continue;
+                        const bool is_shared = (lr & (int)kLrefShared) != 0;
+                        if (is_shared && !(srank[t][(size_t)k * tb.stride + j] & kPlanRankPredLocal)) continue;
+                        lr &= ~(int)kLrefShared;
                         const int pred = lt[lr];
-                        if (pred < 0) { first_touch[cl].push_back({self, lr}); continue; }
+                        if (pred < 0) { if (!is_shared) first_touch[cl].push_back({self, lr}); continue; }
                         if (pred == self) continue;
                         bool known = false;
                         for (int q = 0; q < npred; ++q) known |= it.pred[q] == pred;
@@ -704,7 +736,9 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                 for (int j = s0; j < s0 + it.count; ++j)
                     for (int k = 0; k < nb; ++k) {
                         const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
-                        if ((uint32_t)lr < kDynamicLimit && !(lr & (int)kLrefShared)) lt[lr] = self;
+                        if ((uint32_t)lr >= kDynamicLimit) continue;
+                        if (!(lr & (int)kLrefShared)) lt[lr] = self;
+                        else if (srank[t][(size_t)k * tb.stride + j] & kPlanRankSuccLocal) lt[lr & ~(int)kLrefShared] = self;
                     }
                 if (overflow) npred = 0;
                 it.batch_npred = (tb.batch & 0xFFFF) | (npred << 16) | (overflow << 24);

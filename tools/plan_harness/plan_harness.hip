@@ -88,7 +88,7 @@ static int validate(bepuhip_ctx* c, const ClusterPlan& plan) {
     // every live row of every type batch is covered by exactly one item, and that item belongs to the row's batch
     std::vector<std::vector<uint8_t>> covered(c->tbs.size());
     for (size_t t = 0; t < c->tbs.size(); ++t) covered[t].assign((size_t)std::max(c->tbs[t].slots, c->tbs[t].count), 0);
-    struct Application { int batch, cluster, rank, degree; };
+    struct Application { int batch, cluster, rank, degree; bool pred_local, succ_local; };
     std::vector<std::vector<Application>> applications(plan.shared ? universe : 0);
     for (size_t cl = 0; cl < plan.clusters.size(); ++cl) {
         const ClusterDesc& cd = plan.clusters[cl];
@@ -131,7 +131,7 @@ static int validate(bepuhip_ctx* c, const ClusterPlan& plan) {
                         if (!is_shared && (entry & (kSlotGhost | kSlotSharedHome))) fail("private body marked ghost or shared home", (long)cl, r, entry);
                         if (is_shared) {
                             const uint32_t rank_word = (uint32_t)tb.lrefs_soa[(size_t)(rows + b) * tb.stride + j];
-                            applications[r].push_back({batch, (int)cl, (int)(rank_word & 0xFFu), (int)(rank_word >> 8)});
+                            applications[r].push_back({batch, (int)cl, (int)(rank_word & 0xFFu), (int)((rank_word >> 8) & 0xFFu), (rank_word & (1u << 16)) != 0, (rank_word & (1u << 17)) != 0});
                         }
                     }
                 }
@@ -163,6 +163,11 @@ static int validate(bepuhip_ctx* c, const ClusterPlan& plan) {
             for (size_t q = 0; q < apps.size(); ++q) {
                 if (apps[q].rank != (int)q || apps[q].degree != (int)apps.size()) fail("rank / degree of an application", (long)r, apps[q].rank, apps[q].degree);
                 if (q > 0 && apps[q].batch <= apps[q - 1].batch) fail("ranks are not in batch order", (long)r, apps[q - 1].batch, apps[q].batch);
+                // the hand-off flags: set in pairs, only between consecutive applications of ONE cluster, never on the first / last application of a pass
+                const bool pair = q > 0 && apps[q].pred_local;
+                if (pair && (apps[q - 1].cluster != apps[q].cluster || !apps[q - 1].succ_local)) fail("a local hand-off whose two ends disagree", (long)r, (long)q, apps[q].cluster);
+                if (apps[q].succ_local && (q + 1 >= apps.size() || !apps[q + 1].pred_local)) fail("a local hand-off nobody receives", (long)r, (long)q, apps[q].cluster);
+                if (q == 0 && apps[q].pred_local) fail("the first application of a pass must poll the record", (long)r, 0, 0);
             }
         }
     }
