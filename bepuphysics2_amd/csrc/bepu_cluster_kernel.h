@@ -345,8 +345,14 @@ struct ClusterGate {
         __builtin_amdgcn_s_setprio(3);  // from here to the publish the item is on its bodies' critical path: issue ahead of waves still preparing theirs
         load_velocity_lds<ACC_A>(sh, ra, A);
         if (BODIES == 2) load_velocity_lds<ACC_B>(sh, rb, B);
-        // bodies other clusters also touch: our turn comes when the body's record carries this application's event number (the velocity comes with it)
-        if constexpr (SHARED) acquire_shared<BODIES == 2>(sh, sa, A, sb, B, 6, k);
+        if constexpr (SHARED) {
+            // A shared body's velocity travels whole: a type that reads only the angular half still hands the linear half on (into a record, or to the next local
+            // application), so a lane that takes the body from the LDS slot (its predecessor ran in this cluster) takes both halves.
+            if (sa.shared() && !sa.poll) load_velocity_lds<kLin | kAng>(sh, ra, A);
+            if (BODIES == 2 && sb.shared() && !sb.poll) load_velocity_lds<kLin | kAng>(sh, rb, B);
+            // bodies other clusters also touch: our turn comes when the body's record carries this application's event number (the velocity comes with it)
+            acquire_shared<BODIES == 2>(sh, sa, A, sb, B, 6, k);
+        }
         if (TRACE) stamps.post_gate = __builtin_readcyclecounter();
     }
 };
@@ -462,8 +468,14 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     ClusterGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE, SHARED> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps, sa, sb};
     if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, gate);
     else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, gate);
-    store_velocity_lds<accA>(sh, (active && !sa.publish) ? ra : -1, A);   // -1: never stored (same rule as kinematic / empty references); a shared body's velocity goes to
-    if (F::bodies == 2) store_velocity_lds<accB>(sh, (active && !sb.publish) ? rb : -1, B);  // the LDS slot only when the next application on it runs in this cluster
+    // -1: never stored (same rule as kinematic / empty references). A shared body's velocity goes to the LDS slot only when the next application on it runs in this
+    // cluster — then both halves, whatever the type's access filter (the slot has to hold what a record would).
+    store_velocity_lds<accA>(sh, (active && !sa.shared()) ? ra : -1, A);
+    if (F::bodies == 2) store_velocity_lds<accB>(sh, (active && !sb.shared()) ? rb : -1, B);
+    if constexpr (SHARED) {
+        store_velocity_lds<kLin | kAng>(sh, (sa.shared() && !sa.publish) ? ra : -1, A);
+        if (F::bodies == 2) store_velocity_lds<kLin | kAng>(sh, (sb.shared() && !sb.publish) ? rb : -1, B);
+    }
     if constexpr (SHARED) {
         release_shared(sh, sa, A);  // velocity and "event done" in one record: the next application on the body polls exactly this
         if (F::bodies == 2) release_shared(sh, sb, B);

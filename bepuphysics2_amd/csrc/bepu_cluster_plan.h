@@ -605,7 +605,9 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                     if ((uint32_t)r >= kDynamicLimit || !shared[r]) continue;
                     uint32_t& word = srank[t][(size_t)k * tb.stride + i];
                     word = (uint32_t)next_rank[r]++ | ((uint32_t)deg[r] << 8);
-                    if (local_handoff && last_word[r] != nullptr && last_cluster[r] == cl_of_constraint[t][i]) { word |= kPlanRankPredLocal; *last_word[r] |= kPlanRankSuccLocal; }
+                    const int mode = env_int("BEPUHIP_SPLIT_LOCAL_HANDOFF", 1);  // debugging: 2 = only inside the body's home cluster, 3 = only inside clusters that hold a ghost copy, 4 = only contacts
+                    const bool allowed = mode == 1 || (mode == 2 && cl_of_constraint[t][i] == body_cluster[r]) || (mode == 3 && cl_of_constraint[t][i] != body_cluster[r]) || (mode == 4 && tb.type_id < 8);
+                    if (local_handoff && allowed && last_word[r] != nullptr && last_cluster[r] == cl_of_constraint[t][i]) { word |= kPlanRankPredLocal; *last_word[r] |= kPlanRankSuccLocal; }
                     last_word[r] = &word; last_cluster[r] = cl_of_constraint[t][i];
                 }
         }
