@@ -166,6 +166,7 @@ struct bepuhip_ctx {
     // Structural updates that keep the island schedule (bepu_soft_updates.h)
     bool soft_ok = false;                        // whole-island plan with its host mirrors in place
     std::vector<int32_t> body_cluster, body_lref, body_degree;  // per dynamic body: its cluster (-1: none), its rotated LDS slot, its constraint count
+    std::vector<uint64_t> body_batches;                          // per dynamic body: bit b = a constraint of synchronized batch b references it (the batch invariant, Solver.cs:1046-1051)
     std::vector<std::unordered_map<int32_t, int32_t>> cluster_kin;  // per cluster: kinematic body -> rotated LDS slot of its private copy
     std::vector<ClusterItem> items_host;         // the plan's work items (the predecessor lists of a cluster that received a constraint are replaced by batch-level waits)
     std::vector<ClusterDesc> clusters_host;

@@ -27,7 +27,7 @@ static void soft_setup(bepuhip_ctx* c, ClusterPlan& plan) {
     c->soft_ok = false;
     c->soft_slots.clear(); c->soft_index.clear(); c->soft_items_dirty = false; c->soft_adds = c->soft_removes = 0;
     if (!plan.enabled || plan.shared || env_int("BEPUHIP_NO_SOFT_UPDATES", 0)) return;
-    c->body_cluster.swap(plan.body_cluster); c->body_lref.swap(plan.body_lref); c->body_degree.clear(); c->cluster_kin.swap(plan.cluster_kin);
+    c->body_cluster.swap(plan.body_cluster); c->body_lref.swap(plan.body_lref); c->body_degree.clear(); c->body_batches.clear(); c->cluster_kin.swap(plan.cluster_kin);
     c->items_host = plan.items; c->clusters_host = plan.clusters;
     c->cluster_degraded.assign(plan.clusters.size(), 0);
     c->soft_ok = true;
@@ -38,11 +38,12 @@ static void soft_setup(bepuhip_ctx* c, ClusterPlan& plan) {
 static void soft_ensure_degrees(bepuhip_ctx* c) {
     if (!c->body_degree.empty()) return;
     c->body_degree.assign(c->body_cluster.size(), 0);
+    c->body_batches.assign(c->body_cluster.size(), 0);
     for (auto& tb : c->tbs)
         for (int k = 0; k < tb.info.bodies; ++k)
             for (int d = 0; d < tb.slots; ++d) {
                 const int32_t r = tb.dev_refs[(size_t)k * tb.stride + d];
-                if (r >= 0 && (uint32_t)r < kDynamicLimit && (size_t)r < c->body_degree.size()) ++c->body_degree[r];
+                if (r >= 0 && (uint32_t)r < kDynamicLimit && (size_t)r < c->body_degree.size()) { ++c->body_degree[r]; if (tb.batch < 64) c->body_batches[r] |= 1ull << tb.batch; }
             }
 }
 
@@ -56,7 +57,10 @@ static bool soft_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index) {
         int32_t& r = tb->dev_refs[(size_t)k * tb->stride + d];
         // a body whose last constraint goes would have to leave the plan (the reference integrates it as an unconstrained body from then on) — unless the same
         // batch of updates gives it a constraint again (a refreshed pair): decided when the updates are flushed (soft_bodies_still_constrained)
-        if (r >= 0 && (uint32_t)r < kDynamicLimit && --c->body_degree[r] == 0) c->soft_orphans.push_back(r);
+        if (r >= 0 && (uint32_t)r < kDynamicLimit) {
+            if (tb->batch < 64) c->body_batches[r] &= ~(1ull << tb->batch);
+            if (--c->body_degree[r] == 0) c->soft_orphans.push_back(r);
+        }
         r = -1;
     }
     tb->perm[d] = -1;
@@ -81,7 +85,7 @@ static bool soft_bodies_still_constrained(bepuhip_ctx* c) {
 }
 
 // TypeProcessor.AllocateInTypeBatch on the island layout. false: not possible here (nothing was changed).
-static bool soft_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, const float* prestep) {
+static bool soft_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, const float* prestep, bool* violation) {
     if (!c->soft_ok || tb->slots == 0 || tb->info.bodies > 2) return soft_refuse("addition to a type batch the island layout does not manage");
     soft_ensure_degrees(c);
     const int t = (int)(tb - c->tbs.data()), nb = tb->info.bodies;
@@ -93,6 +97,10 @@ static bool soft_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, con
         cl = c->body_cluster[refs[k]];
     }
     if (cl < 0) return soft_refuse("the new constraint has no dynamic body");
+    // The batch invariant the whole solve rests on (Solver.cs:1046-1051, asserted by the reference in debug builds): a dynamic body appears at most once per synchronized
+    // batch. A caller that breaks it would get a silent race on the body's velocity inside one work item or launch: refused here, where the host knows the references.
+    for (int k = 0; k < nb; ++k)
+        if ((uint32_t)refs[k] < kDynamicLimit && tb->batch < 64 && (c->body_batches[refs[k]] >> tb->batch) & 1) { *violation = true; return false; }
     unsigned halves[2] = {0u, 0u};
     for (int k = 0; k < nb; ++k) {
         if ((uint32_t)refs[k] < kDynamicLimit) { halves[k] = (unsigned)c->body_lref[refs[k]]; continue; }
@@ -107,7 +115,7 @@ static bool soft_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, con
     for (int k = 0; k < nb; ++k) {
         slot.payload.push_back((uint32_t)refs[k]);
         tb->dev_refs[(size_t)k * tb->stride + d] = refs[k];
-        if ((uint32_t)refs[k] < kDynamicLimit) ++c->body_degree[refs[k]];
+        if ((uint32_t)refs[k] < kDynamicLimit) { ++c->body_degree[refs[k]]; if (tb->batch < 64) c->body_batches[refs[k]] |= 1ull << tb->batch; }
     }
     slot.payload.push_back(halves[0] | (halves[1] << 16));
     for (int f = 0; f < tb->info.prestep; ++f) { uint32_t w; memcpy(&w, &prestep[f], 4); slot.payload.push_back(w); }

@@ -1587,11 +1587,13 @@ int32_t bepuhip_add_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, c
         if (refs[k] < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "empty body reference");
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (c->soft_ok) {  // on the island layout: a free slot in the segment of the cluster the bodies live in
-        if (tb && soft_add(c, tb, refs, prestep)) {
+        bool violation = false;
+        if (tb && soft_add(c, tb, refs, prestep, &violation)) {
             if (index_out) *index_out = tb->count - 1;
             c->requirk_stale = true;
             return BEPUHIP_OK;
         }
+        if (violation) return fail(BEPUHIP_E_INVALID_ARGUMENT, "a dynamic body of the new constraint is already referenced in this batch (a body appears at most once per synchronized batch, Solver.cs:1046-1051)");
         if (!tb) soft_refuse("the new constraint opens a type batch");
         if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;
         tb = find_tb(c, batch, type_id);

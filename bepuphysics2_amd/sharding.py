@@ -21,11 +21,6 @@ def partition_islands(island_sizes: Sequence[int], world_size: int) -> List[List
     return [sorted(x) for x in out]
 
 
-def rank_seed(base_seed: int, rank: int) -> int:
-    """Weak-scaling benchmark: every rank generates its own islands from a distinct seed."""
-    return base_seed + rank
-
-
 def aggregate_throughput(dist, units_this_rank: int, elapsed_this_rank: float, device=None) -> float:
     """Whole-job units/s: total units over all ranks / max elapsed over ranks (the bench contract)."""
     import torch

@@ -210,6 +210,9 @@ int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* ctx, int32_t batch_i
  * the batch does not have yet, or finds no free slot; a frame's updates that leave a body without constraints; update_body_reference; three- and four-body types;
  * split-island plans. Results are bit-identical either way. Not supported (UNSUPPORTED): the sequential fallback batch, and solving in a momentum-conserving
  * AngularIntegrationMode after structural updates (its substep-0 lists are built at upload). */
+/* The caller places the constraint in a batch none of its dynamic bodies is in yet (Solver.cs:1046-1051, 1182-1199: the batch invariant the whole solve rests on). On the island
+ * layout the library knows every reference and refuses an addition that breaks it (INVALID_ARGUMENT); on the launch-per-batch rows the references live on the device only and
+ * the call trusts the caller, as the reference's release build does. */
 int32_t bepuhip_add_constraint(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, const int32_t* encoded_body_references, const float* prestep_lane, int32_t* index_out);
 int32_t bepuhip_remove_constraint(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index);
 int32_t bepuhip_update_body_reference(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index, int32_t body_index_in_constraint, int32_t encoded_body_reference);

@@ -106,6 +106,30 @@ def test_momentum_conserving_modes_after_structural_updates(hip_solver_factory, 
         assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (frame, m)
 
 
+def test_addition_that_breaks_the_batch_invariant_is_refused_on_the_island_layout(hip_solver_factory):
+    """a dynamic body may appear once per synchronized batch (Solver.cs:1046-1051; the reference asserts it in debug builds). On the island layout the host
+    knows every reference, so an add_constraint into a batch that already holds one of its bodies is an INVALID_ARGUMENT instead of a silent race."""
+    ms, rng, pair = _build(31, bodies=120, joints=140, contacts=200)
+    solver = hip_solver_factory(reserve_update_slots=True)
+    solver.upload(ms.to_scene())
+    locs = ms.locations(lambda t: t in CONTACT_TYPES)
+    bi, t, i = locs[0]
+    a, b = _decode(ms, ms.batches[bi][t]["refs"][i])
+    dynamic = a if not ms.is_kinematic(a) else b
+    other = next(x for x in range(ms.bodies.shape[0]) if x not in (a, b) and not ms.is_kinematic(x))
+    lane = small_scenes.prestep_for(rng, t, ms.bodies[dynamic, 4:7], ms.bodies[other, 4:7])
+    with pytest.raises(ValueError):
+        solver.add_constraint(bi, t, np.asarray([dynamic, other], dtype=np.int32), lane)  # `dynamic` already has a constraint in batch bi
+    sd, cb = SolveDescription(1, 2), PoseIntegratorCallbacks()
+    solver.solve(1 / 60, sd, cb)  # nothing was changed: the context still solves the uploaded scene
+    ref = ms.to_scene()
+    oracle_ffi.solve(ref, 1 / 60, sd, cb)
+    got = ms.to_scene()
+    solver.download(got)
+    m = pu.compare_scenes(ref, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"], m
+
+
 def _lanes(tb, w, prestep):
     """Mask over an AOSOA buffer: True for the floats of occupied lanes (the trailing lanes of the last bundle hold nothing)."""
     fields = tb.prestep_floats if prestep else tb.impulse_floats
