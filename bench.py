@@ -607,8 +607,7 @@ def main():
         baseline = cpu_baseline(args.ragdolls, 5)  # the same scene as the GPU leg; bounded by time (about 12 s after picking the thread count)
 
     main_clustered = bool(solver.cluster_cycles().size)
-    row_policy = {-1: "still measuring", 0: "plain constraint-row accesses", 1: "non-temporal constraint-row accesses", 2: "plain rows + one 8 KB span of code touched ahead per work item",
-                  3: "plain rows + two spans of code touched ahead per work item"}[solver.row_policy()] if main_clustered else None
+    row_policy = {-1: "still measuring", 0: "plain constraint-row accesses", 1: "non-temporal constraint-row accesses", 2: "plain rows + one 8 KB span of code touched ahead per work item"}[solver.row_policy()] if main_clustered else None
     connected = None
     if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
         solver.close()
@@ -637,7 +636,7 @@ def main():
                                    if (world > 1 or dist is not None) else "single GPU",
                        "schedule": "island-per-workgroup: one plain kernel launch per step" if main_clustered else
                                    ("launch-per-batch" + ("" if args.no_graph else ", hipGraph replay")),
-                       "row_policy": row_policy and f"{row_policy}, picked from the timings of the first sixteen solves after the upload (all candidates bit-identical; DESIGN.md 5)",
+                       "row_policy": row_policy and f"{row_policy}, picked from the timings of the first fifteen solves after the upload (all candidates bit-identical; DESIGN.md 5)",
                        "device_prewarm": f"{prewarm_steps} untimed solves during setup, uploaded state restored before the {args.warmup} warm-up steps",
                        "finite": finite},
             "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "boundary": boundary, "lattice": lattice_report,

@@ -178,7 +178,7 @@ struct bepuhip_ctx {
     bool soft_items_dirty = false;
     int64_t soft_adds = 0, soft_removes = 0;     // since the upload (diagnostics)
     bool graphs_cleared_by_structure = false;  // set by flush_structural, consumed by the next solve (which then launches eagerly instead of capturing)
-    int row_policy = -1;              // -1: still measuring; 0 plain rows; 1 non-temporal rows; 2 / 3 plain rows + one / two spans of code touched per item (BEPUHIP_ROW_POLICY pins it)
+    int row_policy = -1;              // -1: still measuring; 0 plain rows; 1 non-temporal rows; 2 plain rows + one span of code touched per item (BEPUHIP_ROW_POLICY pins it)
     int policy_samples = 0;           // solves launched while measuring
     int policy_threads = 0;           // workgroup size the samples ran with
     hipEvent_t policy_events[16][2] = {};

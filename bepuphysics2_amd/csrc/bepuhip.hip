@@ -746,12 +746,13 @@ static void enqueue_requirk(bepuhip_ctx* c, int substep, int batch, const StepPa
 }
 
 // Launch policy of the island schedules (bepu_host_state.h). Candidates — all bit-identical in their results:
-//   0 plain constraint-row accesses, 1 non-temporal row accesses, 2 plain rows + one 8 KB span of code touched per work item, 3 plain rows + two spans.
+//   0 plain constraint-row accesses, 1 non-temporal row accesses, 2 plain rows + one 8 KB span of code touched per work item (two spans measured no better on
+//   either box class: profiles/r03_code_touch_ab_*).
 // Which one is fastest depends on the box class (on the slow class an instruction fetch that misses L2 is what costs; the touch keeps the code there).
 // The first kPolicySamples solves after an upload cycle through the candidates, each launch under its own event pair. Once the last of them has FINISHED
 // (hipEventQuery: a solve never blocks for the policy's sake) the medians are compared: the fastest candidate stays if it beats plain by more than 2 %, else plain.
 // The decision is kept per (device, plan kind, workgroup size) for the life of the process, so that hosts that upload every frame settle once.
-constexpr int kPolicyCandidates = 4, kPolicyRounds = 4, kPolicySamples = kPolicyCandidates * kPolicyRounds;
+constexpr int kPolicyCandidates = 3, kPolicyRounds = 5, kPolicySamples = kPolicyCandidates * kPolicyRounds;
 static std::mutex g_policy_mutex;
 static std::map<std::tuple<int, int, int, int>, int> g_policy_cache;
 static std::tuple<int, int, int, int> policy_key(const bepuhip_ctx* c, int threads) { return {c->device, c->clusters_shared ? 1 : 0, c->has_widened_types ? 1 : 0, threads}; }
@@ -789,8 +790,8 @@ static void settle_row_policy(bepuhip_ctx* c, int threads, bool may_block) {
         g_policy_cache[policy_key(c, threads)] = best;
     }
     if (env_int("BEPUHIP_PLAN_STATS", 0))
-        fprintf(stderr, "bepuhip launch policy: plain %.4f, non-temporal rows %.4f, code touch x1 %.4f, x2 %.4f ms per launch (medians of %d) -> %d\n", median[0], median[1], median[2],
-                median[3], kPolicyRounds - 1, best);
+        fprintf(stderr, "bepuhip launch policy: plain %.4f, non-temporal rows %.4f, code touch %.4f ms per launch (medians of %d) -> %d\n", median[0], median[1], median[2],
+                kPolicyRounds - 1, best);
 }
 
 // The island schedule implements AngularIntegrationMode.Nonconserving; the conserving modes run the launch-per-batch schedule.
@@ -856,7 +857,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
                 else if (c->policy_samples < kPolicySamples) { sample = c->policy_samples++; candidate = sample % kPolicyCandidates; c->policy_threads = threads; }  // each under its own event pair
             }
             const bool nt = candidate == 1;
-            cp.code_touch = candidate >= 2 ? candidate - 1 : 0;
+            cp.code_touch = candidate == 2 ? 1 : 0;
             if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(4, forced);
             cp.code_touch_gate = std::max(0, std::min(2, env_int("BEPUHIP_CODE_TOUCH_GATE", 0)));
             const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt);  // the register budget that matches the workgroup size

@@ -473,7 +473,7 @@ class HipSolver:
         return out
 
     def row_policy(self) -> int:
-        """-1 still measuring, 0 plain, 1 non-temporal constraint-row accesses, 2 / 3 plain rows + one / two spans of code touched ahead (island schedule; bepuhip.h)."""
+        """-1 still measuring, 0 plain, 1 non-temporal constraint-row accesses, 2 plain rows + a span of code touched ahead (island schedule; bepuhip.h)."""
         v = C.c_int32(-1)
         _check(self.lib, self.lib.bepuhip_get_row_policy(self.ctx, C.byref(v)))
         return int(v.value)

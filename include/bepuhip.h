@@ -287,10 +287,10 @@ int32_t bepuhip_get_cluster_trace(bepuhip_ctx* ctx, uint64_t* words_out, int64_t
 /* Shader clocks each workgroup of the island-per-workgroup schedule spent in the last solve (one entry per cluster; count_out = 0 when the
  * scene runs the launch-per-batch schedule). Independent of the clock frequency the GPU happened to run at. */
 int32_t bepuhip_get_cluster_cycles(bepuhip_ctx* ctx, uint64_t* cycles_out, int32_t capacity, int32_t* count_out);
-/* Launch policy of the island-per-workgroup schedule on this device: -1 still measuring (the first sixteen solves after an upload cycle through the bit-identical
- * candidates, each timed on the stream; no solve ever waits for the measurement), 0 plain constraint-row accesses, 1 non-temporal row accesses, 2 / 3 plain rows plus one /
- * two 8 KB spans of the work item's own code pulled into L2 ahead of the instruction fetcher. The decision is remembered per device and plan shape for the life of the
- * process. BEPUHIP_ROW_POLICY=0..3 in the environment pins it. */
+/* Launch policy of the island-per-workgroup schedule on this device: -1 still measuring (the first fifteen solves after an upload cycle through the bit-identical
+ * candidates, each timed on the stream; no solve ever waits for the measurement), 0 plain constraint-row accesses, 1 non-temporal row accesses, 2 plain rows plus an
+ * 8 KB span of the work item's own code pulled into L2 ahead of the instruction fetcher. The decision is remembered per device and plan shape for the life of the
+ * process. BEPUHIP_ROW_POLICY=0..2 in the environment pins it. */
 int32_t bepuhip_get_row_policy(bepuhip_ctx* ctx, int32_t* policy_out);
 /* Watchdog / progress words of the island-per-workgroup schedule (16 x uint32, host-visible while a solve is running). word 0 != 0: a bounded
  * wait gave up (reported by bepuhip_sync as DEVICE error). */
