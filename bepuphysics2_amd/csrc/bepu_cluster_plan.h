@@ -23,6 +23,12 @@ struct ClusterPlan {
     // whole-island plans: what structural updates need to stay on the island schedule (bepu_soft_updates.h)
     std::vector<int32_t> body_cluster, body_lref, body_degree;
     std::vector<std::unordered_map<int32_t, int32_t>> cluster_kin;
+    // split plans: which bodies are shared, their constraint counts, every cluster's ghost / kinematic copies (body | kSlotGhost / kSlotKinematic -> rotated slot), the number of
+    // natural slot indices each cluster has handed out, and the order in which the type batches were turned into items
+    std::vector<uint8_t> split_shared;
+    std::vector<int32_t> split_degree, cluster_natural;
+    std::vector<std::unordered_map<int32_t, int32_t>> cluster_extra;
+    std::vector<size_t> split_visit;
     int planes = kAllPlanes;  // LDS planes per body slot: all eight fields when they fit, else the six the sweeps touch (the local inertia is then read from memory)
 };
 
@@ -627,6 +633,8 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         return l;
     };
     // pre-size: every cluster must fit the LDS budget with its ghosts, kinematic copies and items
+    const bool reserve = (c->flags & BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS) != 0;
+    int slot_reserve = 0;  // free LDS slots behind every cluster's bodies
     {
         std::vector<int32_t> item_count(nclusters, 0), per_cluster(nclusters);
         for (size_t t = 0; t < c->tbs.size(); ++t) {
@@ -641,13 +649,20 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                     else if (body_cluster[r] != cl) extra_local(cl, r | kSlotGhost);
                 }
             }
-            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (per_cluster[cl] + 63) / 64 + 1;  // + 1: private and shared constraints are itemised apart
+            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (segment_slots(per_cluster[cl], reserve) + 63) / 64 + 1;
         }
         int max_slots = 0, max_items = 0;
         for (int cl = 0; cl < nclusters; ++cl) {
             max_slots = std::max(max_slots, ((int)cl_bodies[cl].size() + 15) / 16 * 16);
             max_items = std::max(max_items, item_count[cl]);
         }
+        // Spare LDS slots for the ghost and kinematic copies structural updates may need (BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS): an eighth more, if the workgroup's LDS has the room
+        if (reserve) {
+            const int wanted = std::min(0x3FF0, (max_slots + std::max(16, max_slots / 8) + 15) / 16 * 16);
+            const int planes_now = cluster_lds_bytes(kAllPlanes, max_slots, max_items, true) <= kLdsBudgetBytes ? kAllPlanes : kSweepPlanes;
+            if (cluster_lds_bytes(planes_now, wanted, max_items, true) <= kLdsBudgetBytes) slot_reserve = wanted - max_slots;
+        }
+        max_slots += slot_reserve;
         plan.planes = cluster_lds_bytes(kAllPlanes, max_slots, max_items, true) <= kLdsBudgetBytes ? kAllPlanes : kSweepPlanes;
         if (max_slots >= 0x4000 || max_items >= 65536 || cluster_lds_bytes(plan.planes, max_slots, max_items, true) > kLdsBudgetBytes) {
             if (env_int("BEPUHIP_PLAN_STATS", 0))
@@ -662,7 +677,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         return rotated_slot(l) | (shared[r] ? (int)kLrefShared : 0);
     };
     std::vector<std::vector<int32_t>> last_toucher(nclusters);
-    for (int cl = 0; cl < nclusters; ++cl) last_toucher[cl].assign((cl_bodies[cl].size() + 15) / 16 * 16 + 16, -1);
+    for (int cl = 0; cl < nclusters; ++cl) last_toucher[cl].assign((cl_bodies[cl].size() + 15) / 16 * 16 + slot_reserve + 16, -1);
     std::vector<std::vector<ClusterItem>> cl_items(nclusters);
     std::vector<std::vector<std::pair<int32_t, int32_t>>> first_touch(nclusters);
     std::vector<size_t> visit(c->tbs.size());
@@ -672,44 +687,62 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         if (x.batch != y.batch) return x.batch < y.batch;
         return x.info.prestep + 2 * x.info.impulse > y.info.prestep + 2 * y.info.impulse;
     });
+    plan.split_visit = visit;
     for (size_t t : visit) {
         HostTypeBatch& tb = c->tbs[t];
         const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
         const std::vector<int32_t>& clc = cl_of_constraint[t];
         // inside a cluster: constraints that touch only private bodies first, the ones with shared bodies behind them. They share work items: a wave spends the
-        // same time on an item whatever its lane count, and the waves' time is what a split cluster runs out of (BEPUHIP_SPLIT_SEPARATE=1 itemises them apart).
-        const bool separate = env_int("BEPUHIP_SPLIT_SEPARATE", 0) != 0;
+        // same time on an item whatever its lane count, and the waves' time is what a split cluster runs out of.
         std::vector<uint8_t> touches_shared(tb.count, 0);
         for (int i = 0; i < tb.count; ++i)
             for (int k = 0; k < nb; ++k) {
                 const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
                 if ((uint32_t)r < kDynamicLimit && shared[r]) touches_shared[i] = 1;
             }
-        tb.perm.resize(tb.count);
-        for (int i = 0; i < tb.count; ++i) tb.perm[i] = i;
-        std::stable_sort(tb.perm.begin(), tb.perm.end(), [&](int a, int b) { return clc[a] != clc[b] ? clc[a] < clc[b] : touches_shared[a] < touches_shared[b]; });
-        std::vector<int32_t> refs((size_t)nb * tb.stride, -1), lrefs((size_t)nb * tb.stride, -1);
-        std::vector<uint32_t> ranks((size_t)nb * tb.stride, 0u);
+        // Every cluster's constraints of the type batch in one segment of device slots, live ones first (private before shared), free slots (if reserved) behind them —
+        // the layout of the whole-island plans, so that structural updates find the same structures (bepu_soft_updates.h).
+        std::vector<int32_t> order(tb.count);
+        for (int i = 0; i < tb.count; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return clc[a] != clc[b] ? clc[a] < clc[b] : touches_shared[a] < touches_shared[b]; });
+        std::vector<int32_t> live(nclusters, 0);
+        for (int i = 0; i < tb.count; ++i) ++live[clc[i]];
+        tb.seg_begin.assign(nclusters + 1, 0);
+        for (int cl = 0; cl < nclusters; ++cl) tb.seg_begin[cl + 1] = tb.seg_begin[cl] + segment_slots(live[cl], reserve);
+        tb.slots = tb.seg_begin[nclusters];
+        const int stride = std::max(tb.stride, (tb.slots + 63) / 64 * 64);
+        tb.perm.assign(tb.slots, -1);
+        {
+            std::vector<int32_t> next(tb.seg_begin.begin(), tb.seg_begin.end() - 1);
+            for (int h : order) tb.perm[next[clc[h]]++] = h;
+        }
+        tb.inv.assign(tb.count, 0);
+        std::vector<int32_t> refs((size_t)nb * stride, -1), lrefs((size_t)nb * stride, kPlanDeadLref);
+        std::vector<uint32_t> ranks((size_t)nb * stride, 0u);
         const bool host_values = c->host_values;
-        std::vector<float> pre(host_values ? (size_t)pf * tb.stride : 0, 0.0f), acc(host_values ? (size_t)imf * tb.stride : 0, 0.0f);
-        for (int d = 0; d < tb.count; ++d) {
-            const int h = tb.perm[d], cl = clc[h];
+        std::vector<float> pre(host_values ? (size_t)pf * stride : 0, 0.0f), acc(host_values ? (size_t)imf * stride : 0, 0.0f);
+        for (int d = 0; d < tb.slots; ++d) {
+            const int h = tb.perm[d];
+            if (h < 0) continue;
+            const int cl = clc[h];
+            tb.inv[h] = d;
             for (int k = 0; k < nb; ++k) {
                 const int32_t r = tb.refs_soa[(size_t)k * tb.stride + h];
-                refs[(size_t)k * tb.stride + d] = r;
-                lrefs[(size_t)k * tb.stride + d] = slot_of(cl, r);
-                ranks[(size_t)k * tb.stride + d] = srank[t][(size_t)k * tb.stride + h];
+                refs[(size_t)k * stride + d] = r;
+                lrefs[(size_t)k * stride + d] = slot_of(cl, r);
+                ranks[(size_t)k * stride + d] = srank[t][(size_t)k * tb.stride + h];
             }
-            for (int f = 0; f < pf && host_values; ++f) pre[(size_t)f * tb.stride + d] = tb.prestep_soa[(size_t)f * tb.stride + h];
-            for (int f = 0; f < imf && host_values; ++f) acc[(size_t)f * tb.stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
+            for (int f = 0; f < pf && host_values; ++f) pre[(size_t)f * stride + d] = tb.prestep_soa[(size_t)f * tb.stride + h];
+            for (int f = 0; f < imf && host_values; ++f) acc[(size_t)f * stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
         }
+        tb.stride = stride;
+        tb.dev_refs = refs;
         tb.refs_soa.swap(refs); tb.prestep_soa.swap(pre); tb.accum_soa.swap(acc); tb.lrefs_soa.swap(lrefs);
         srank[t].swap(ranks);
-        for (int d = 0; d < tb.count;) {
-            const int cl = clc[tb.perm[d]];
-            const int sh0 = touches_shared[tb.perm[d]];
-            int e = d;
-            while (e < tb.count && clc[tb.perm[e]] == cl && (!separate || touches_shared[tb.perm[e]] == sh0)) ++e;
+        tb.plan_lrefs = tb.lrefs_soa;  // 32-bit local references and rank words per device slot: what the predecessor rule reads (kept for the structural updates)
+        tb.plan_ranks = srank[t];
+        for (int cl = 0; cl < nclusters; ++cl) {
+            const int d = tb.seg_begin[cl], e = tb.seg_begin[cl + 1];
             for (int s0 = d; s0 < e; s0 += 64) {
                 ClusterItem it;
                 memset(&it, 0, sizeof(it));
@@ -723,7 +756,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                 for (int j = s0; j < s0 + it.count; ++j)
                     for (int k = 0; k < nb; ++k) {
                         int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
-                        if ((uint32_t)lr >= kDynamicLimit) continue;
+                        if ((uint32_t)lr >= kDynamicLimit || tb.perm[j] < 0) continue;  // kinematic copy, or a free slot
                         const bool is_shared = (lr & (int)kLrefShared) != 0;
                         if (is_shared && !(srank[t][(size_t)k * tb.stride + j] & kPlanRankPredLocal)) continue;
                         lr &= ~(int)kLrefShared;
@@ -738,7 +771,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                 for (int j = s0; j < s0 + it.count; ++j)
                     for (int k = 0; k < nb; ++k) {
                         const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + j];
-                        if ((uint32_t)lr >= kDynamicLimit) continue;
+                        if ((uint32_t)lr >= kDynamicLimit || tb.perm[j] < 0) continue;
                         if (!(lr & (int)kLrefShared)) lt[lr] = self;
                         else if (srank[t][(size_t)k * tb.stride + j] & kPlanRankSuccLocal) lt[lr & ~(int)kLrefShared] = self;
                     }
@@ -746,7 +779,6 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                 it.batch_npred = (tb.batch & 0xFFFF) | (npred << 16) | (overflow << 24);
                 cl_items[cl].push_back(it);
             }
-            d = e;
         }
     }
     // 16-bit local references (slot | shared << 14 | kinematic << 15), two per word, followed by the rank rows (one word per body slot)
@@ -755,12 +787,13 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         const int nb = tb.info.bodies, rows = (nb + 1) / 2;
         std::vector<int32_t> packed((size_t)(rows + nb) * tb.stride, 0);
         for (int k = 0; k < nb; ++k)
-            for (int d = 0; d < tb.count; ++d) {
+            for (int d = 0; d < tb.slots; ++d) {
                 const int32_t lr = tb.lrefs_soa[(size_t)k * tb.stride + d];
-                const uint32_t half = ((uint32_t)lr & 0x7FFFu) | (((uint32_t)lr >= kDynamicLimit) ? 0x8000u : 0u);
+                const uint32_t half = ((uint32_t)lr & 0x7FFFu) | (((uint32_t)lr >= kDynamicLimit) ? 0x8000u : 0u);  // a free slot packs to kLrefDead
                 packed[(size_t)(k / 2) * tb.stride + d] |= (int32_t)(half << (16 * (k & 1)));
                 packed[(size_t)(rows + k) * tb.stride + d] = (int32_t)srank[t][(size_t)k * tb.stride + d];
             }
+        if (nb == 1) for (int d = 0; d < tb.slots; ++d) if (tb.perm[d] < 0) packed[d] = (int32_t)kLrefDead;
         tb.lrefs_soa.swap(packed);
     }
     for (int cl = 0; cl < nclusters; ++cl) {
@@ -780,7 +813,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     for (int cl = 0; cl < nclusters; ++cl) {
         ClusterDesc d;
         d.body_begin = (int)plan.cluster_bodies.size();
-        d.slot_count = ((int)cl_bodies[cl].size() + 15) / 16 * 16;
+        d.slot_count = ((int)cl_bodies[cl].size() + 15) / 16 * 16 + slot_reserve;  // the reserve: free slots (-1) structural updates turn into ghost / kinematic copies
         std::vector<int32_t> slots(d.slot_count, -1);
         for (size_t i = 0; i < cl_bodies[cl].size(); ++i) { slots[rotated_slot((int)i)] = cl_bodies[cl][i]; ghost_slots += (cl_bodies[cl][i] & kSlotGhost) != 0; }
         plan.cluster_bodies.insert(plan.cluster_bodies.end(), slots.begin(), slots.end());
@@ -800,6 +833,18 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     plan.shared_info.assign(universe, 0u);
     for (int i = 0; i < universe; ++i) if (shared[i]) { plan.shared_info[i] = (uint32_t)deg[i]; ++shared_count; }
     plan.shared = true;
+    // what structural updates need in order to stay on this plan (bepu_soft_updates.h, split part)
+    plan.body_cluster = body_cluster;
+    plan.body_lref.assign(universe, -1);
+    for (int i = 0; i < universe; ++i) if (is_dyn[i]) plan.body_lref[i] = rotated_slot(local_of[i]);
+    plan.split_shared = shared;
+    plan.split_degree = deg;
+    plan.cluster_natural.resize(nclusters);
+    plan.cluster_extra.resize(nclusters);
+    for (int cl = 0; cl < nclusters; ++cl) {
+        plan.cluster_natural[cl] = (int32_t)cl_bodies[cl].size();
+        for (auto& kv : cl_extra[cl]) plan.cluster_extra[cl].emplace(kv.first, rotated_slot(kv.second));
+    }
     plan.planes = cluster_lds_bytes(kAllPlanes, plan.max_slots, plan.max_items, true) <= kLdsBudgetBytes ? kAllPlanes : kSweepPlanes;
     plan.enabled = nclusters > 0 && plan.max_slots < 0x4000 && cluster_lds_bytes(plan.planes, plan.max_slots, plan.max_items, true) <= kLdsBudgetBytes;
     if (env_int("BEPUHIP_PLAN_STATS", 0))

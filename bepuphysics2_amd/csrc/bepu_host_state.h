@@ -96,6 +96,8 @@ struct HostTypeBatch {
     int slots = 0;
     std::vector<int32_t> seg_begin;
     std::vector<int32_t> dev_refs;
+    std::vector<int32_t> plan_lrefs;   // split plans: 32-bit local references (slot | kLrefShared | kinematic << 30) and rank words per device slot, the inputs of
+    std::vector<uint32_t> plan_ranks;  // the predecessor rule (bepu_cluster_plan.h), kept for the structural updates
     int device_extent() const { return slots > 0 ? slots : count; }
     std::vector<int32_t> lrefs_soa; // cluster path: local (LDS) body indices
     std::vector<int32_t> refs_soa;
