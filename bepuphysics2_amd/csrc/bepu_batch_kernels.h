@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64) void apply_structural_ops_kernel(unsigned* __re
 }
 // Structural updates that stay on the island layout (bepu_soft_updates.h): the final state of every device slot touched since the last flush. A live slot gets its
 // encoded references, its packed local references, its prestep lane and zero impulses (TypeProcessor.cs:327); a freed one gets -1 references and local references that name a kinematic copy (kLrefDead).
-struct SoftSlotOp { unsigned refs_off, lrefs_off, prestep_off, accum_off; int stride, bodies, prestep, impulse, slot, live; unsigned payload; int pad; };
+struct SoftSlotOp { unsigned refs_off, lrefs_off, prestep_off, accum_off; int stride, bodies, prestep, impulse, slot, live; unsigned payload; int ranks; };  // ranks: rank words behind the local references (split plans: one per body slot)
 __global__ __launch_bounds__(64) void apply_soft_slots_kernel(unsigned* slab, const SoftSlotOp* __restrict__ ops, int count, const unsigned* __restrict__ payload) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(64) void apply_soft_slots_kernel(unsigned* slab, co
     const unsigned* p = payload + op.payload;
     for (int k = 0; k < op.bodies; ++k) slab[op.refs_off + (size_t)k * op.stride + op.slot] = *p++;
     for (int k = 0; k < lref_rows; ++k) slab[op.lrefs_off + (size_t)k * op.stride + op.slot] = *p++;
+    for (int k = 0; k < op.ranks; ++k) slab[op.lrefs_off + (size_t)(lref_rows + k) * op.stride + op.slot] = *p++;
     for (int f = 0; f < op.prestep; ++f) slab[op.prestep_off + (size_t)f * op.stride + op.slot] = *p++;
     for (int f = 0; f < op.impulse; ++f) slab[op.accum_off + (size_t)f * op.stride + op.slot] = 0u;
 }

@@ -24,9 +24,21 @@ static int soft_cluster_of_slot(const HostTypeBatch& tb, int slot) {
 }
 
 static void soft_setup(bepuhip_ctx* c, ClusterPlan& plan) {
-    c->soft_ok = false;
+    c->soft_ok = false; c->soft_split = false;
     c->soft_slots.clear(); c->soft_index.clear(); c->soft_items_dirty = false; c->soft_adds = c->soft_removes = 0;
-    if (!plan.enabled || plan.shared || env_int("BEPUHIP_NO_SOFT_UPDATES", 0)) return;
+    c->body_apps.clear(); c->split_rerank.clear(); c->split_patches.clear();
+    if (!plan.enabled || env_int("BEPUHIP_NO_SOFT_UPDATES", 0)) return;
+    if (plan.shared) {  // split-island plan: the second half of this file
+        if (env_int("BEPUHIP_NO_SPLIT_SOFT_UPDATES", 0)) return;
+        for (auto& tb : c->tbs) if (tb.info.bodies > 2) return;
+        c->body_cluster.swap(plan.body_cluster); c->body_lref.swap(plan.body_lref); c->body_degree.clear(); c->body_batches.clear();
+        c->split_shared.swap(plan.split_shared); c->cluster_extra.swap(plan.cluster_extra); c->cluster_natural.swap(plan.cluster_natural);
+        c->cluster_bodies_host = plan.cluster_bodies; c->split_visit = plan.split_visit;
+        c->items_host = plan.items; c->clusters_host = plan.clusters;
+        c->cluster_degraded.assign(plan.clusters.size(), 0);
+        c->soft_ok = true; c->soft_split = true;
+        return;
+    }
     c->body_cluster.swap(plan.body_cluster); c->body_lref.swap(plan.body_lref); c->body_degree.clear(); c->body_batches.clear(); c->cluster_kin.swap(plan.cluster_kin);
     c->items_host = plan.items; c->clusters_host = plan.clusters;
     c->cluster_degraded.assign(plan.clusters.size(), 0);
@@ -48,8 +60,11 @@ static void soft_ensure_degrees(bepuhip_ctx* c) {
 }
 
 // TypeProcessor.Remove on the island layout. false: not possible here (nothing was changed).
+static bool split_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index);
+static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, const float* prestep, bool* violation);
 static bool soft_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index) {
     if (!c->soft_ok || tb->slots == 0 || tb->info.bodies > 2) return soft_refuse("removal from a type batch the island layout does not manage");
+    if (c->soft_split) return split_remove(c, tb, index);
     soft_ensure_degrees(c);
     const int t = (int)(tb - c->tbs.data());
     const int d = tb->inv[index], last = tb->count - 1, dl = tb->inv[last];
@@ -87,6 +102,7 @@ static bool soft_bodies_still_constrained(bepuhip_ctx* c) {
 // TypeProcessor.AllocateInTypeBatch on the island layout. false: not possible here (nothing was changed).
 static bool soft_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, const float* prestep, bool* violation) {
     if (!c->soft_ok || tb->slots == 0 || tb->info.bodies > 2) return soft_refuse("addition to a type batch the island layout does not manage");
+    if (c->soft_split) return split_add(c, tb, refs, prestep, violation);
     soft_ensure_degrees(c);
     const int t = (int)(tb - c->tbs.data()), nb = tb->info.bodies;
     int cl = -1;
@@ -175,15 +191,265 @@ static void soft_rebuild_items(bepuhip_ctx* c, int cl) {
     }
 }
 
+// ======================================================================================================================================================
+// Split-island plans. The rows have the same segmented layout, so removals and additions take and free device slots exactly as above. What is
+// different: a body may be SHARED — referenced from a cluster that is not its home —, every application on a shared body carries a rank word (rank | degree << 8 |
+// hand-off flags) that orders it against the body's other applications, the other cluster holds a ghost slot of the body, and the home cluster's slot table says so.
+//  * removal: frees the slot; the shared bodies it touched are RE-RANKED at the flush (their remaining applications renumbered in batch order, hand-off flags
+//    recomputed, the degree written to shared_info).
+//  * addition: runs in the home cluster of one of its dynamic bodies (the one where the other body already has a slot, if any). A body of another cluster is
+//    referenced through a ghost slot there — an existing one, or a free LDS slot of the reserve; a body that becomes shared this way gets the shared bit on all its
+//    applications and the kSlotSharedHome flag in its home's slot table. Kinematic bodies get a private copy the same way. The touched shared bodies are re-ranked.
+//  * every cluster that holds an application of a re-ranked body has its items' predecessor lists rebuilt (the hand-off flags decide which lanes wait through LDS).
+// Refused (the context then leaves the island schedule, as before): no free row slot, no free LDS slot, a body that had no constraint, a body with 255 constraints,
+// a removal that leaves a body without constraints.
+// ======================================================================================================================================================
+constexpr uint32_t kSoftRankPredLocal = 1u << 16, kSoftRankSuccLocal = 1u << 17;
+
+static void split_ensure_mirrors(bepuhip_ctx* c) {
+    if (!c->body_apps.empty()) return;
+    const size_t universe = c->body_cluster.size();
+    c->body_apps.assign(universe, {});
+    c->body_degree.assign(universe, 0);
+    c->body_batches.assign(universe, 0);
+    for (size_t t = 0; t < c->tbs.size(); ++t) {  // type batches in index order = batch order: every body's list ends up sorted by batch
+        const HostTypeBatch& tb = c->tbs[t];
+        for (int d = 0; d < tb.slots; ++d) {
+            if (tb.perm[d] < 0) continue;
+            for (int k = 0; k < tb.info.bodies; ++k) {
+                const int32_t r = tb.dev_refs[(size_t)k * tb.stride + d];
+                if (r < 0 || (uint32_t)r >= kDynamicLimit || (size_t)r >= universe) continue;
+                c->body_apps[r].push_back({(int32_t)t, d, k});
+                ++c->body_degree[r];
+                if (tb.batch < 64) c->body_batches[r] |= 1ull << tb.batch;
+            }
+        }
+    }
+    for (auto& apps : c->body_apps) std::sort(apps.begin(), apps.end(), [](const bepuhip_ctx::SplitApp& a, const bepuhip_ctx::SplitApp& b) { return a.tb < b.tb; });
+}
+static unsigned split_packed_lrefs(const HostTypeBatch& tb, int d, int row) {  // the 16-bit halves of body slots 2 * row and 2 * row + 1 of device slot d
+    unsigned word = 0;
+    for (int k = 2 * row; k < std::min(tb.info.bodies, 2 * row + 2); ++k) {
+        const int32_t lr = tb.plan_lrefs[(size_t)k * tb.stride + d];
+        const uint32_t half = ((uint32_t)lr & 0x7FFFu) | (((uint32_t)lr >= kDynamicLimit) ? 0x8000u : 0u);
+        word |= half << (16 * (k & 1));
+    }
+    return word;
+}
+// A free natural slot index of the cluster's LDS table (rotated into the slot number the kernel uses), or -1.
+static int split_take_lds_slot(bepuhip_ctx* c, int cl, int32_t tagged_body) {
+    const ClusterDesc& cd = c->clusters_host[cl];
+    const int natural = c->cluster_natural[cl];
+    if (natural >= cd.slot_count || natural >= 0x3FF0) return -1;
+    const int slot = rotated_slot(natural);
+    if (slot >= cd.slot_count) return -1;
+    c->cluster_natural[cl] = natural + 1;
+    c->cluster_bodies_host[cd.body_begin + slot] = tagged_body;
+    c->split_patches.push_back({2, (size_t)(cd.body_begin + slot), (uint32_t)tagged_body});
+    return slot;
+}
+static void split_mark_cluster(bepuhip_ctx* c, int cl) { c->cluster_degraded[cl] = 1; c->soft_items_dirty = true; }
+
+static bool split_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index) {
+    split_ensure_mirrors(c);
+    const int t = (int)(tb - c->tbs.data());
+    const int d = tb->inv[index], last = tb->count - 1, dl = tb->inv[last];
+    for (int k = 0; k < tb->info.bodies; ++k) {
+        int32_t& r = tb->dev_refs[(size_t)k * tb->stride + d];
+        if (r >= 0 && (uint32_t)r < kDynamicLimit) {
+            auto& apps = c->body_apps[r];
+            for (size_t q = 0; q < apps.size(); ++q) if (apps[q].tb == t && apps[q].slot == d) { apps.erase(apps.begin() + q); break; }
+            if (tb->batch < 64) c->body_batches[r] &= ~(1ull << tb->batch);
+            if (--c->body_degree[r] == 0) c->soft_orphans.push_back(r);
+            if (c->split_shared[r]) c->split_rerank.insert(r);
+        }
+        r = -1;
+        tb->plan_lrefs[(size_t)k * tb->stride + d] = kPlanDeadLref;
+        tb->plan_ranks[(size_t)k * tb->stride + d] = 0u;
+    }
+    tb->perm[d] = -1;
+    c->soft_slots[{t, d}] = bepuhip_ctx::SoftSlot{false, {}};
+    if (index != last) { tb->inv[index] = dl; tb->perm[dl] = index; c->soft_index[{t, index}] = dl; }
+    c->soft_index.erase({t, last});
+    tb->inv.pop_back();
+    tb->count = last;
+    ++c->soft_removes;
+    return true;
+}
+
+static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, const float* prestep, bool* violation) {
+    split_ensure_mirrors(c);
+    const int t = (int)(tb - c->tbs.data()), nb = tb->info.bodies;
+    int homes[2] = {-1, -1};
+    for (int k = 0; k < nb; ++k) {
+        if ((uint32_t)refs[k] >= kDynamicLimit) continue;
+        if (refs[k] >= (int)c->body_cluster.size() || c->body_cluster[refs[k]] < 0) return soft_refuse("the new constraint's body had no constraints");
+        if (c->body_degree[refs[k]] >= 255) return soft_refuse("a body with 255 constraints (ranks travel as bytes)");
+        if (tb->batch < 64 && (c->body_batches[refs[k]] >> tb->batch) & 1) { *violation = true; return false; }
+        homes[k] = c->body_cluster[refs[k]];
+    }
+    // the cluster that runs it: the home of one of its dynamic bodies — the one that already holds a slot of the other, if any
+    int cl = homes[0] >= 0 ? homes[0] : homes[1];
+    if (cl < 0) return soft_refuse("the new constraint has no dynamic body");
+    if (nb == 2 && homes[0] >= 0 && homes[1] >= 0 && homes[0] != homes[1]) {
+        const bool b_in_a = c->cluster_extra[homes[0]].count(refs[1] | kSlotGhost) != 0, a_in_b = c->cluster_extra[homes[1]].count(refs[0] | kSlotGhost) != 0;
+        cl = (!b_in_a && a_in_b) ? homes[1] : homes[0];
+    }
+    int d = -1;
+    for (int s = tb->seg_begin[cl]; s < tb->seg_begin[cl + 1] && d < 0; ++s) if (tb->perm[s] < 0) d = s;
+    if (d < 0) return soft_refuse("no free device slot in the cluster's segment of the type batch");
+    // LDS slots: count what is missing before anything is taken
+    int missing = 0;
+    for (int k = 0; k < nb; ++k) {
+        const int32_t key = (uint32_t)refs[k] >= kDynamicLimit ? ((refs[k] & kRefMask) | kSlotKinematic) : (homes[k] == cl ? -1 : (refs[k] | kSlotGhost));
+        if (key >= 0 && !c->cluster_extra[cl].count(key)) ++missing;
+    }
+    if (c->cluster_natural[cl] + missing > c->clusters_host[cl].slot_count) return soft_refuse("no free LDS slot in the cluster for a ghost or kinematic copy");
+    int32_t lrefs[2] = {kPlanDeadLref, kPlanDeadLref};
+    for (int k = 0; k < nb; ++k) {
+        const int32_t r = refs[k];
+        if ((uint32_t)r >= kDynamicLimit) {
+            const int32_t key = (r & kRefMask) | kSlotKinematic;
+            auto found = c->cluster_extra[cl].find(key);
+            int slot = found != c->cluster_extra[cl].end() ? found->second : split_take_lds_slot(c, cl, key);
+            if (slot < 0) return soft_refuse("no free LDS slot in the cluster for a kinematic copy");
+            c->cluster_extra[cl][key] = slot;
+            lrefs[k] = slot | (int)kDynamicLimit;
+            continue;
+        }
+        if (homes[k] == cl) { lrefs[k] = c->body_lref[r] | (c->split_shared[r] ? (int)kLrefShared : 0); }
+        else {
+            const int32_t key = r | kSlotGhost;
+            auto found = c->cluster_extra[cl].find(key);
+            int slot = found != c->cluster_extra[cl].end() ? found->second : split_take_lds_slot(c, cl, key);
+            if (slot < 0) return soft_refuse("no free LDS slot in the cluster for a ghost copy");
+            c->cluster_extra[cl][key] = slot;
+            if (!c->split_shared[r]) {  // the body becomes shared: its home's slot table says so, every application of it carries the shared bit from now on
+                c->split_shared[r] = 1;
+                const ClusterDesc& home = c->clusters_host[homes[k]];
+                const size_t entry = (size_t)home.body_begin + (size_t)c->body_lref[r];
+                c->cluster_bodies_host[entry] |= kSlotSharedHome;
+                c->split_patches.push_back({2, entry, (uint32_t)c->cluster_bodies_host[entry]});
+                for (auto& app : c->body_apps[r]) {
+                    HostTypeBatch& other = c->tbs[app.tb];
+                    other.plan_lrefs[(size_t)app.k * other.stride + app.slot] |= (int)kLrefShared;
+                    if (!c->soft_slots.count({app.tb, app.slot}))
+                        c->split_patches.push_back({0, other.lrefs_off + (size_t)(app.k / 2) * other.stride + app.slot, split_packed_lrefs(other, app.slot, app.k / 2)});
+                }
+                split_mark_cluster(c, homes[k]);
+            }
+            lrefs[k] = slot | (int)kLrefShared;
+        }
+        if (c->split_shared[r]) c->split_rerank.insert(r);
+    }
+    bepuhip_ctx::SoftSlot slot{true, {}};  // the prestep lane; references, local references and rank words are taken from the mirrors when the updates are flushed
+    for (int f = 0; f < tb->info.prestep; ++f) { uint32_t w; memcpy(&w, &prestep[f], 4); slot.payload.push_back(w); }
+    for (int k = 0; k < nb; ++k) {
+        tb->dev_refs[(size_t)k * tb->stride + d] = refs[k];
+        tb->plan_lrefs[(size_t)k * tb->stride + d] = lrefs[k];
+        tb->plan_ranks[(size_t)k * tb->stride + d] = 0u;
+        if ((uint32_t)refs[k] < kDynamicLimit) {
+            auto& apps = c->body_apps[refs[k]];
+            auto at = std::upper_bound(apps.begin(), apps.end(), t, [](int value, const bepuhip_ctx::SplitApp& a) { return value < a.tb; });
+            apps.insert(at, {(int32_t)t, d, k});
+            ++c->body_degree[refs[k]];
+            if (tb->batch < 64) c->body_batches[refs[k]] |= 1ull << tb->batch;
+        }
+    }
+    c->soft_slots[{t, d}] = std::move(slot);
+    tb->perm[d] = tb->count;
+    tb->inv.push_back(d);
+    c->soft_index[{t, tb->count}] = d;
+    tb->count += 1;
+    split_mark_cluster(c, cl);
+    ++c->soft_adds;
+    return true;
+}
+
+// Renumber the applications of a shared body (they are kept in batch order) and write their rank words: to the mirror, and to the device unless the slot is
+// written as a whole by this flush anyway. Every cluster that holds one of them gets its predecessor lists rebuilt.
+static void split_rerank_body(bepuhip_ctx* c, int32_t body) {
+    auto& apps = c->body_apps[body];
+    const uint32_t degree = (uint32_t)apps.size();
+    const bool local_handoff = env_int("BEPUHIP_SPLIT_LOCAL_HANDOFF", 1) != 0;
+    std::vector<int> cluster(apps.size());
+    for (size_t q = 0; q < apps.size(); ++q) cluster[q] = soft_cluster_of_slot(c->tbs[apps[q].tb], apps[q].slot);
+    for (size_t q = 0; q < apps.size(); ++q) {
+        HostTypeBatch& tb = c->tbs[apps[q].tb];
+        uint32_t word = (uint32_t)q | (degree << 8);
+        if (local_handoff && q > 0 && cluster[q - 1] == cluster[q]) word |= kSoftRankPredLocal;
+        if (local_handoff && q + 1 < apps.size() && cluster[q + 1] == cluster[q]) word |= kSoftRankSuccLocal;
+        uint32_t& mirror = tb.plan_ranks[(size_t)apps[q].k * tb.stride + apps[q].slot];
+        if (mirror != word && !c->soft_slots.count({apps[q].tb, apps[q].slot}))
+            c->split_patches.push_back({0, tb.lrefs_off + (size_t)((tb.info.bodies + 1) / 2 + apps[q].k) * tb.stride + apps[q].slot, word});
+        mirror = word;
+        split_mark_cluster(c, cluster[q]);
+    }
+    c->split_patches.push_back({1, (size_t)body, degree});
+}
+
+// The predecessor lists of one cluster of a split plan: the planner's rule (plan_split_clusters) over the mirrors.
+static void split_rebuild_items(bepuhip_ctx* c, int cl) {
+    const ClusterDesc& cd = c->clusters_host[cl];
+    std::vector<int32_t> lt(cd.slot_count + 16, -1);
+    std::vector<std::pair<int32_t, int32_t>> first_touch;
+    for (int self = 0; self < cd.item_count; ++self) {
+        ClusterItem& it = c->items_host[cd.item_begin + self];
+        const HostTypeBatch& tb = c->tbs[it.tb];
+        const int nb = tb.info.bodies;
+        int npred = 0, overflow = 0;
+        memset(it.pred, 0, sizeof(it.pred)); memset(it.xpred, 0, sizeof(it.xpred));
+        for (int j = it.start; j < it.start + it.count; ++j)
+            for (int k = 0; k < nb; ++k) {
+                int32_t lr = tb.plan_lrefs[(size_t)k * tb.stride + j];
+                if ((uint32_t)lr >= kDynamicLimit || tb.perm[j] < 0) continue;
+                const bool is_shared = (lr & (int)kLrefShared) != 0;
+                if (is_shared && !(tb.plan_ranks[(size_t)k * tb.stride + j] & kSoftRankPredLocal)) continue;
+                lr &= ~(int)kLrefShared;
+                const int pred = lt[lr];
+                if (pred < 0) { if (!is_shared) first_touch.push_back({self, lr}); continue; }
+                if (pred == self) continue;
+                bool known = false;
+                for (int q = 0; q < npred; ++q) known |= it.pred[q] == pred;
+                if (known) continue;
+                if (npred < kMaxPreds) it.pred[npred++] = (unsigned short)pred; else overflow = 1;
+            }
+        for (int j = it.start; j < it.start + it.count; ++j)
+            for (int k = 0; k < nb; ++k) {
+                const int32_t lr = tb.plan_lrefs[(size_t)k * tb.stride + j];
+                if ((uint32_t)lr >= kDynamicLimit || tb.perm[j] < 0) continue;
+                if (!(lr & (int)kLrefShared)) lt[lr] = self;
+                else if (tb.plan_ranks[(size_t)k * tb.stride + j] & kSoftRankSuccLocal) lt[lr & ~(int)kLrefShared] = self;
+            }
+        if (overflow) npred = 0;
+        it.batch_npred = (it.batch_npred & 0xFFFF) | (npred << 16) | (overflow << 24);
+    }
+    for (auto& fs : first_touch) {
+        ClusterItem& it = c->items_host[cd.item_begin + fs.first];
+        const int last = lt[fs.second];
+        int nx = (it.batch_npred >> 20) & 0xF;
+        if ((it.batch_npred >> 25) & 1) continue;
+        bool known = false;
+        for (int q = 0; q < nx; ++q) known |= it.xpred[q] == last;
+        if (known) continue;
+        if (nx < kMaxPreds) { it.xpred[nx++] = (unsigned short)last; it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (nx << 20); }
+        else it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (1 << 25);
+    }
+}
+
 // Everything the soft updates changed since the last flush, onto the device (both slabs: the snapshot follows, like every other structural update).
 static int32_t flush_soft(bepuhip_ctx* c) {
-    if (c->soft_slots.empty() && c->soft_index.empty() && !c->soft_items_dirty) return BEPUHIP_OK;
+    if (c->soft_slots.empty() && c->soft_index.empty() && !c->soft_items_dirty && c->split_rerank.empty() && c->split_patches.empty()) return BEPUHIP_OK;
+    if (c->soft_split) {
+        for (int32_t body : c->split_rerank) split_rerank_body(c, body);
+        c->split_rerank.clear();
+    }
     if (c->soft_items_dirty) {  // clusters that received constraints: their items' predecessor lists, on a few host threads
         std::vector<int> dirty;
         for (size_t cl = 0; cl < c->cluster_degraded.size(); ++cl) if (c->cluster_degraded[cl]) { dirty.push_back((int)cl); c->cluster_degraded[cl] = 0; }
         const int workers = std::max(1, std::min<int>({env_int("BEPUHIP_PLAN_THREADS", 8), (int)std::thread::hardware_concurrency(), (int)dirty.size()}));
         std::atomic<size_t> next{0};
-        auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < dirty.size();) soft_rebuild_items(c, dirty[i]); };
+        auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < dirty.size();) { if (c->soft_split) split_rebuild_items(c, dirty[i]); else soft_rebuild_items(c, dirty[i]); } };
         std::vector<std::thread> pool;
         for (int w = 1; w < workers; ++w) pool.emplace_back(work);
         work();
@@ -193,8 +459,14 @@ static int32_t flush_soft(bepuhip_ctx* c) {
     std::vector<uint32_t> payload(1, 0u);
     for (auto& kv : c->soft_slots) {
         const HostTypeBatch& tb = c->tbs[kv.first.first];
+        const int d = kv.first.second;
         SoftSlotOp op{(unsigned)tb.refs_off, (unsigned)tb.lrefs_off, (unsigned)tb.prestep_off, (unsigned)tb.accum_off, tb.stride, tb.info.bodies, tb.info.prestep, tb.info.impulse,
-                      kv.first.second, kv.second.live ? 1 : 0, (unsigned)payload.size(), 0};
+                      d, kv.second.live ? 1 : 0, (unsigned)payload.size(), c->soft_split ? tb.info.bodies : 0};
+        if (c->soft_split && kv.second.live) {  // references, packed local references and rank words as the mirrors hold them now (the re-ranking above included)
+            for (int k = 0; k < tb.info.bodies; ++k) payload.push_back((uint32_t)tb.dev_refs[(size_t)k * tb.stride + d]);
+            for (int row = 0; row < (tb.info.bodies + 1) / 2; ++row) payload.push_back(split_packed_lrefs(tb, d, row));
+            for (int k = 0; k < tb.info.bodies; ++k) payload.push_back(tb.plan_ranks[(size_t)k * tb.stride + d]);
+        }
         payload.insert(payload.end(), kv.second.payload.begin(), kv.second.payload.end());
         ops.push_back(op);
     }
@@ -204,6 +476,12 @@ static int32_t flush_soft(bepuhip_ctx* c) {
         if (!tb.d_device_index) continue;  // built from `inv` on first use: nothing to patch yet
         patches.push_back(IndexPatch{tb.d_device_index, kv.first.second, kv.second, 0});
     }
+    for (auto& wp : c->split_patches) {  // single words of the split plan's tables (rank words, local references, degrees, slot table entries)
+        if (wp.table == 0) { for (uint32_t* slab : {c->d_slab, c->d_slab0}) if (slab) patches.push_back(IndexPatch{(int*)slab, (int)wp.index, (int)wp.value, 0}); }
+        else if (wp.table == 1) patches.push_back(IndexPatch{(int*)c->d_shared_info, (int)wp.index, (int)wp.value, 0});
+        else patches.push_back(IndexPatch{c->d_cluster_bodies, (int)wp.index, (int)wp.value, 0});
+    }
+    c->split_patches.clear();
     const size_t bytes = ops.size() * sizeof(SoftSlotOp) + payload.size() * 4 + patches.size() * sizeof(IndexPatch) + 64;
     char* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, bytes));

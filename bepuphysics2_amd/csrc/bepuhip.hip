@@ -1517,7 +1517,7 @@ static int32_t leave_island_schedule(bepuhip_ctx* c) {
     for (auto& tb : c->tbs) permuted |= !tb.perm.empty();
     if (!permuted) return BEPUHIP_OK;
     { const int32_t fs = flush_soft(c); if (fs != BEPUHIP_OK) return fs; }  // the device has to show what the caller has been told
-    c->soft_ok = false;
+    c->soft_ok = false; c->soft_split = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
     clear_graphs(c);
     for (int k = 0; k < 2; ++k) {

@@ -23,9 +23,15 @@ TYPES = [4, 5, 6, 7, 22, 25, 30, 47, 0, 3, 23, 46]  # two-body manifolds and joi
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
 scenes = frames_total = bad = stayed = refused = 0
+split_scenes = split_stayed = 0
 while time.time() < t_end:
-    nb = int(rng.integers(30, 400))
-    nc = int(rng.integers(40, min(900, nb * 12)))  # degrees stay mostly under the fallback threshold (additions to the fallback batch are refused by design)
+    big = rng.random() < 0.3  # one island no workgroup holds: the split-island plan (two-body types and one-body manifolds; forced cluster counts so that small scenes split too)
+    nb = int(rng.integers(1500, 3500)) if big else int(rng.integers(30, 400))
+    nc = int(rng.integers(nb * 2, nb * 4)) if big else int(rng.integers(40, min(900, nb * 12)))  # degrees stay mostly under the fallback threshold (additions to the fallback batch are refused by design)
+    if big:
+        os.environ["BEPUHIP_SPLIT_CLUSTERS"] = str(int(rng.integers(8, 32)))
+    else:
+        os.environ.pop("BEPUHIP_SPLIT_CLUSTERS", None)
     rows = [small_scenes.random_dynamic_body(rng, rng.uniform(-6, 6, 3)) if i % 23 else small_scenes.kinematic_body(rng, rng.uniform(-6, 6, 3)) for i in range(nb)]
     ms = MutableSolver(np.stack(rows))
 
@@ -83,7 +89,10 @@ while time.time() < t_end:
         refused += 1
         break
     stayed += solver.cluster_cycles().size > 0
+    split_scenes += big
+    split_stayed += big and solver.cluster_cycles().size > 1
     solver.close()
     scenes += 1
     bad += not ok
-print(f"scenes {scenes}, frames {frames_total}, still on the island schedule at the end {stayed}, ended by a refused fallback-batch addition {refused}, mismatching scenes {bad}")
+print(f"scenes {scenes} ({split_scenes} big enough for a split-island plan, {split_stayed} of them still on it at the end), frames {frames_total}, still on an island schedule at the end {stayed}, "
+      f"ended by a refused fallback-batch addition {refused}, mismatching scenes {bad}")
