@@ -45,6 +45,9 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
 // Device slots a cluster's segment of a type batch gets for `live` constraints: with BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS an eighth more (at least two), so that the
 // narrow phase's additions find room without a new plan.
 static inline int segment_slots(int live, bool reserve) { return (reserve && live > 0) ? live + std::max(2, live / 8) : live; }
+// ... and on a split-island plan: a quarter more (at least four), also in segments that hold nothing yet — additions across the cut land in whichever of the two home
+// clusters has room, and a pile's or crowd's contacts come and go everywhere.
+static inline int split_segment_slots(int live, bool reserve) { return reserve ? live + std::max(4, live / 4) : live; }
 constexpr int32_t kPlanDeadLref = (int32_t)kDynamicLimit;  // 32-bit planning form of a free slot's local references: the kinematic copy in slot 0 (packs to kLrefDead)
 
 // Host threads of the planner: BEPUHIP_PLAN_THREADS, default a quarter of the hardware threads between 8 and 16 (the phases are memory-bound; more only adds start-up cost).
@@ -649,7 +652,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                     else if (body_cluster[r] != cl) extra_local(cl, r | kSlotGhost);
                 }
             }
-            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (segment_slots(per_cluster[cl], reserve) + 63) / 64 + 1;
+            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (split_segment_slots(per_cluster[cl], reserve) + 63) / 64 + 1;
         }
         int max_slots = 0, max_items = 0;
         for (int cl = 0; cl < nclusters; ++cl) {
@@ -708,7 +711,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         std::vector<int32_t> live(nclusters, 0);
         for (int i = 0; i < tb.count; ++i) ++live[clc[i]];
         tb.seg_begin.assign(nclusters + 1, 0);
-        for (int cl = 0; cl < nclusters; ++cl) tb.seg_begin[cl + 1] = tb.seg_begin[cl] + segment_slots(live[cl], reserve);
+        for (int cl = 0; cl < nclusters; ++cl) tb.seg_begin[cl + 1] = tb.seg_begin[cl] + split_segment_slots(live[cl], reserve);
         tb.slots = tb.seg_begin[nclusters];
         const int stride = std::max(tb.stride, (tb.slots + 63) / 64 * 64);
         tb.perm.assign(tb.slots, -1);

@@ -295,8 +295,12 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
         const bool b_in_a = c->cluster_extra[homes[0]].count(refs[1] | kSlotGhost) != 0, a_in_b = c->cluster_extra[homes[1]].count(refs[0] | kSlotGhost) != 0;
         cl = (!b_in_a && a_in_b) ? homes[1] : homes[0];
     }
-    int d = -1;
-    for (int s = tb->seg_begin[cl]; s < tb->seg_begin[cl + 1] && d < 0; ++s) if (tb->perm[s] < 0) d = s;
+    auto free_slot_of = [&](int cluster) { for (int s = tb->seg_begin[cluster]; s < tb->seg_begin[cluster + 1]; ++s) if (tb->perm[s] < 0) return s; return -1; };
+    int d = free_slot_of(cl);
+    if (d < 0 && nb == 2 && homes[0] >= 0 && homes[1] >= 0 && homes[0] != homes[1]) {  // the other body's home may run it just as well
+        cl = cl == homes[0] ? homes[1] : homes[0];
+        d = free_slot_of(cl);
+    }
     if (d < 0) return soft_refuse("no free device slot in the cluster's segment of the type batch");
     // LDS slots: count what is missing before anything is taken
     int missing = 0;

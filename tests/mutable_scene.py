@@ -66,6 +66,10 @@ class MutableSolver:
         for key in ("refs", "prestep", "acc"):
             tb[key].pop()
 
+    def dynamic_degree(self, body: int) -> int:
+        """Constraints that reference the (dynamic) body: a dynamic body appears at most once per batch."""
+        return sum(1 for handles in self.batch_handles if body in handles)
+
     def locations(self, predicate=lambda type_id: True) -> List[Tuple[int, int, int]]:
         return [(bi, t, i) for bi, b in enumerate(self.batches) for t in self.type_order[bi] if predicate(t) for i in range(len(b[t]["refs"]))]
 

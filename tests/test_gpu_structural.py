@@ -306,6 +306,8 @@ def test_structural_updates_after_frames_on_the_split_island_plan(hip_solver_fac
             for _ in range(20):
                 locs = ms.locations(is_contact)
                 bi, t, i = locs[int(rng.integers(len(locs)))]
+                if reserve and any(not (r & 0x40000000) and ms.dynamic_degree(r) < 2 for r in ms.batches[bi][t]["refs"][i]):
+                    continue  # (a body that loses its last constraint leaves ANY island plan: the reference integrates it as an unconstrained body from then on)
                 ms.remove(bi, t, i)
                 solver.remove_constraint(bi, t, i)
             for _ in range(20):
