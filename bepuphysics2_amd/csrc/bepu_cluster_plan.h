@@ -1,5 +1,9 @@
 // Host-side planning of the island-per-workgroup schedule (once per topology upload).
 #pragma once
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <unistd.h>
 
 #include "bepu_host_state.h"
 #include <atomic>
@@ -56,15 +60,66 @@ static int plan_workers(size_t jobs) {
     const int fallback = std::max(1, std::min(16, std::max(8, hw / 4)));
     return std::max(1, std::min<int>({env_int("BEPUHIP_PLAN_THREADS", fallback), hw > 0 ? hw : 1, (int)std::max<size_t>(jobs, 1)}));
 }
+// The host threads themselves: started once per process and parked on a condition variable between loops (a planner run is a dozen short parallel loops, a flush of
+// structural updates two: starting sixteen threads for each costs more than most of the loops). One loop at a time; a second caller (another context planning on another
+// thread) runs its loop on threads of its own.
+struct PlanPool {
+    std::mutex owner, m;
+    std::condition_variable wake, done;
+    std::vector<std::thread> threads;
+    const std::function<void(int)>* work = nullptr;
+    uint64_t generation = 0;
+    int wanted = 0, running = 0;
+    pid_t pid = getpid();
+    void serve(int worker) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* mine = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                wake.wait(lock, [&] { return generation != seen; });
+                seen = generation;
+                if (worker < wanted) mine = work;
+            }
+            if (!mine) continue;
+            (*mine)(worker);
+            std::lock_guard<std::mutex> lock(m);
+            if (--running == 0) done.notify_one();
+        }
+    }
+    void run(int workers, const std::function<void(int)>& fn) {  // fn(0) here, fn(1 .. workers - 1) on the parked threads
+        {
+            std::lock_guard<std::mutex> lock(m);
+            if (pid != getpid()) { pid = getpid(); threads.clear(); }  // a forked child inherits the bookkeeping, not the threads
+            while ((int)threads.size() + 1 < workers) { const int id = (int)threads.size() + 1; threads.emplace_back([this, id] { serve(id); }); threads.back().detach(); }
+            work = &fn; wanted = workers; running = workers - 1; ++generation;
+        }
+        wake.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lock(m);
+        done.wait(lock, [&] { return running == 0; });
+        work = nullptr; wanted = 0;
+    }
+};
+static PlanPool& plan_pool() { static PlanPool* pool = new PlanPool(); return *pool; }  // never destroyed: its threads outlive main's statics
 template <class Fn>
 static void plan_parallel_for_workers(size_t jobs, Fn&& fn) {  // fn(job, worker, workers) for every job, dynamically scheduled; results must not depend on the order
     const int workers = plan_workers(jobs);
     std::atomic<size_t> next{0};
     auto work = [&](int worker) { for (size_t j; (j = next.fetch_add(1)) < jobs;) fn(j, worker, workers); };
-    std::vector<std::thread> pool;
-    for (int w = 1; w < workers; ++w) pool.emplace_back(work, w);
+    if (workers == 1) { work(0); return; }
+    PlanPool& pool = plan_pool();
+    static const bool parked = env_int("BEPUHIP_PLAN_POOL", 1) != 0;
+    if (parked && pool.owner.try_lock()) {
+        const std::function<void(int)> shared_work = work;
+        pool.run(workers, shared_work);
+        pool.owner.unlock();
+        return;
+    }
+    std::vector<std::thread> own;
+    for (int w = 1; w < workers; ++w) own.emplace_back(work, w);
     work(0);
-    for (auto& th : pool) th.join();
+    for (auto& th : own) th.join();
 }
 template <class Fn>
 static void plan_parallel_for(size_t jobs, Fn&& fn) { plan_parallel_for_workers(jobs, [&](size_t j, int, int) { fn(j); }); }
@@ -659,11 +714,11 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             max_slots = std::max(max_slots, ((int)cl_bodies[cl].size() + 15) / 16 * 16);
             max_items = std::max(max_items, item_count[cl]);
         }
-        // Spare LDS slots for the ghost and kinematic copies structural updates may need (BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS): an eighth more, if the workgroup's LDS has the room
+        // Spare LDS slots for the ghost and kinematic copies structural updates may need (BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS): an eighth more (at least sixteen), if the workgroup's LDS has the room
         if (reserve) {
             const int wanted = std::min(0x3FF0, (max_slots + std::max(16, max_slots / 8) + 15) / 16 * 16);
-            const int planes_now = cluster_lds_bytes(kAllPlanes, max_slots, max_items, true) <= kLdsBudgetBytes ? kAllPlanes : kSweepPlanes;
-            if (cluster_lds_bytes(planes_now, wanted, max_items, true) <= kLdsBudgetBytes) slot_reserve = wanted - max_slots;
+            // (the two planes of local inertia give way to the reserve where both do not fit: they cost one read per body and substep, a plan that is lost costs the schedule)
+            if (cluster_lds_bytes(kSweepPlanes, wanted, max_items, true) <= kLdsBudgetBytes) slot_reserve = wanted - max_slots;
         }
         max_slots += slot_reserve;
         plan.planes = cluster_lds_bytes(kAllPlanes, max_slots, max_items, true) <= kLdsBudgetBytes ? kAllPlanes : kSweepPlanes;

@@ -1,6 +1,7 @@
 // Host-side state of a bepuhip context: kernel variant table, error plumbing, type table, per-type-batch bookkeeping, the context itself.
 #pragma once
 #include <set>
+#include <unordered_set>
 
 // ------------------------------------------------------------------------------------------------
 // cluster_kernel instantiations live in their own translation units (bepu_cluster_{hot,wide}_{1024,768,512}.hip): type set x register budget, each
@@ -186,13 +187,19 @@ struct bepuhip_ctx {
     std::vector<uint8_t> split_shared;
     std::vector<std::unordered_map<int32_t, int32_t>> cluster_extra;  // per cluster: body | kSlotGhost / kSlotKinematic -> rotated LDS slot
     std::vector<int32_t> cluster_natural;                             // per cluster: natural slot indices handed out so far
+    std::vector<std::vector<int32_t>> cluster_free_slots;             // per cluster: LDS slots of ghost / kinematic copies nothing references any more
+    std::vector<std::unordered_map<int32_t, int32_t>> cluster_extra_uses;  // per cluster: references to each ghost / kinematic copy (body | kind -> count)
     std::vector<int32_t> cluster_bodies_host;                         // mirror of d_cluster_bodies
     std::vector<size_t> split_visit;                                  // order in which the type batches become a cluster's items
     struct SplitApp { int32_t tb, slot, k; };
     std::vector<std::vector<SplitApp>> body_apps;
     std::set<int32_t> split_rerank;
-    struct WordPatch { int table; size_t index; uint32_t value; };    // table: 0 constraint slab (both copies), 1 shared_info, 2 cluster_bodies
+    // A word of the split plan's device tables that differs from its host mirror until the next flush writes it (the VALUE is read from the mirror then: a slot may be
+    // freed and taken again between the change and the flush). table: 0 constraint slab (both copies; tb / slot / row name the word), 1 shared_info, 2 cluster_bodies.
+    struct WordPatch { int table; size_t index; int32_t tb, slot, row; };
     std::vector<WordPatch> split_patches;
+    double soft_call_ms = 0.0;  // BEPUHIP_PLAN_STATS >= 2: time inside the structural calls since the last flush
+    long soft_calls = 0;
     bool graphs_cleared_by_structure = false;  // set by flush_structural, consumed by the next solve (which then launches eagerly instead of capturing)
     int row_policy = -1;              // -1: still measuring; 0 plain rows; 1 non-temporal rows; 2 plain rows + one span of code touched per item (BEPUHIP_ROW_POLICY pins it)
     int policy_samples = 0;           // solves launched while measuring
@@ -297,5 +304,5 @@ static void free_constraints(bepuhip_ctx* c) {
     c->inc_blocks = 0; c->inc_tb_count = 0; c->total_constraints = 0; c->slab_words = 0; c->referenced_bodies = 0;
     c->built = false;
     c->pending_ops.clear(); c->pending_payload.clear(); c->structure_dirty = false; c->requirk_stale = false;
-    c->soft_ok = false; c->soft_split = false; c->body_apps.clear(); c->split_rerank.clear(); c->split_patches.clear(); c->soft_slots.clear(); c->soft_index.clear(); c->soft_orphans.clear(); c->soft_items_dirty = false; c->items_host.clear(); c->clusters_host.clear(); c->cluster_degraded.clear();
+    c->soft_ok = false; c->soft_split = false; c->cluster_free_slots.clear(); c->cluster_extra_uses.clear(); c->body_apps.clear(); c->split_rerank.clear(); c->split_patches.clear(); c->soft_slots.clear(); c->soft_index.clear(); c->soft_orphans.clear(); c->soft_items_dirty = false; c->items_host.clear(); c->clusters_host.clear(); c->cluster_degraded.clear();
 }

@@ -15,6 +15,15 @@
 // ("Would leave a body without constraints" is judged per flush, not per call: a pair that is removed and added again in the same frame never leaves the plan.)
 #pragma once
 
+// BEPUHIP_PLAN_STATS >= 2: the time the structural calls spend on the island layout's bookkeeping, reported with the next flush.
+struct SoftCallTimer {
+    bepuhip_ctx* c;
+    std::chrono::steady_clock::time_point begin;
+    static bool enabled() { static const bool on = env_int("BEPUHIP_PLAN_STATS", 0) >= 2; return on; }
+    explicit SoftCallTimer(bepuhip_ctx* ctx) : c(ctx) { if (enabled()) begin = std::chrono::steady_clock::now(); }
+    ~SoftCallTimer() { if (enabled()) { c->soft_call_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - begin).count(); ++c->soft_calls; } }
+};
+
 static bool soft_refuse(const char* why) {
     if (env_int("BEPUHIP_PLAN_STATS", 0)) fprintf(stderr, "bepuhip: leaving the island schedule: %s\n", why);
     return false;
@@ -226,6 +235,32 @@ static void split_ensure_mirrors(bepuhip_ctx* c) {
         }
     }
     for (auto& apps : c->body_apps) std::sort(apps.begin(), apps.end(), [](const bepuhip_ctx::SplitApp& a, const bepuhip_ctx::SplitApp& b) { return a.tb < b.tb; });
+    // how often every ghost / kinematic copy of every cluster is referenced: a copy nothing references any more gives its LDS slot back (split_release_copy)
+    c->cluster_extra_uses.assign(c->clusters_host.size(), {});
+    c->cluster_free_slots.assign(c->clusters_host.size(), {});
+    for (auto& tb : c->tbs)
+        for (int d = 0; d < tb.slots; ++d) {
+            if (tb.perm[d] < 0) continue;
+            const int cl = soft_cluster_of_slot(tb, d);
+            for (int k = 0; k < tb.info.bodies; ++k) {
+                const int32_t r = tb.dev_refs[(size_t)k * tb.stride + d];
+                if (r < 0) continue;
+                if ((uint32_t)r >= kDynamicLimit) ++c->cluster_extra_uses[cl][(r & kRefMask) | kSlotKinematic];
+                else if (c->body_cluster[r] != cl) ++c->cluster_extra_uses[cl][r | kSlotGhost];
+            }
+        }
+}
+static void split_release_copy(bepuhip_ctx* c, int cl, int32_t key) {  // one reference less to a ghost / kinematic copy; the last one frees its LDS slot
+    auto uses = c->cluster_extra_uses[cl].find(key);
+    if (uses == c->cluster_extra_uses[cl].end() || --uses->second > 0) return;
+    c->cluster_extra_uses[cl].erase(uses);
+    auto found = c->cluster_extra[cl].find(key);
+    if (found == c->cluster_extra[cl].end()) return;
+    const ClusterDesc& cd = c->clusters_host[cl];
+    c->cluster_bodies_host[cd.body_begin + found->second] = -1;
+    c->split_patches.push_back({2, (size_t)(cd.body_begin + found->second), -1, 0, 0});
+    c->cluster_free_slots[cl].push_back(found->second);
+    c->cluster_extra[cl].erase(found);
 }
 static unsigned split_packed_lrefs(const HostTypeBatch& tb, int d, int row) {  // the 16-bit halves of body slots 2 * row and 2 * row + 1 of device slot d
     unsigned word = 0;
@@ -239,13 +274,17 @@ static unsigned split_packed_lrefs(const HostTypeBatch& tb, int d, int row) {  /
 // A free natural slot index of the cluster's LDS table (rotated into the slot number the kernel uses), or -1.
 static int split_take_lds_slot(bepuhip_ctx* c, int cl, int32_t tagged_body) {
     const ClusterDesc& cd = c->clusters_host[cl];
-    const int natural = c->cluster_natural[cl];
-    if (natural >= cd.slot_count || natural >= 0x3FF0) return -1;
-    const int slot = rotated_slot(natural);
-    if (slot >= cd.slot_count) return -1;
-    c->cluster_natural[cl] = natural + 1;
+    int slot;
+    if (!c->cluster_free_slots[cl].empty()) { slot = c->cluster_free_slots[cl].back(); c->cluster_free_slots[cl].pop_back(); }
+    else {
+        const int natural = c->cluster_natural[cl];
+        if (natural >= cd.slot_count || natural >= 0x3FF0) return -1;
+        slot = rotated_slot(natural);
+        if (slot >= cd.slot_count) return -1;
+        c->cluster_natural[cl] = natural + 1;
+    }
     c->cluster_bodies_host[cd.body_begin + slot] = tagged_body;
-    c->split_patches.push_back({2, (size_t)(cd.body_begin + slot), (uint32_t)tagged_body});
+    c->split_patches.push_back({2, (size_t)(cd.body_begin + slot), -1, 0, 0});
     return slot;
 }
 static void split_mark_cluster(bepuhip_ctx* c, int cl) { c->cluster_degraded[cl] = 1; c->soft_items_dirty = true; }
@@ -254,8 +293,11 @@ static bool split_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index) {
     split_ensure_mirrors(c);
     const int t = (int)(tb - c->tbs.data());
     const int d = tb->inv[index], last = tb->count - 1, dl = tb->inv[last];
+    const int cluster_of_slot = soft_cluster_of_slot(*tb, d);
     for (int k = 0; k < tb->info.bodies; ++k) {
         int32_t& r = tb->dev_refs[(size_t)k * tb->stride + d];
+        if (r >= 0 && (uint32_t)r >= kDynamicLimit) split_release_copy(c, cluster_of_slot, (r & kRefMask) | kSlotKinematic);
+        else if (r >= 0 && c->body_cluster[r] != cluster_of_slot) split_release_copy(c, cluster_of_slot, r | kSlotGhost);
         if (r >= 0 && (uint32_t)r < kDynamicLimit) {
             auto& apps = c->body_apps[r];
             for (size_t q = 0; q < apps.size(); ++q) if (apps[q].tb == t && apps[q].slot == d) { apps.erase(apps.begin() + q); break; }
@@ -288,27 +330,61 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
         if (tb->batch < 64 && (c->body_batches[refs[k]] >> tb->batch) & 1) { *violation = true; return false; }
         homes[k] = c->body_cluster[refs[k]];
     }
-    // the cluster that runs it: the home of one of its dynamic bodies — the one that already holds a slot of the other, if any
-    int cl = homes[0] >= 0 ? homes[0] : homes[1];
-    if (cl < 0) return soft_refuse("the new constraint has no dynamic body");
+    // The cluster that runs it: one with a free device slot in its segment of the type batch and LDS slots for the copies it lacks. Tried in this order: the home of one
+    // of its dynamic bodies (the one that already holds a ghost of the other first), then any cluster that already runs a constraint of one of the bodies (it holds
+    // that body's slot or ghost; the bodies become shared if they were not), then the next clusters by number.
+    if (homes[0] < 0 && homes[1] < 0) return soft_refuse("the new constraint has no dynamic body");
+    int candidates[2 + 32], ncand = 0;
+    auto candidate = [&](int cluster) { if (cluster < 0 || ncand == 34) return; for (int q = 0; q < ncand; ++q) if (candidates[q] == cluster) return; candidates[ncand++] = cluster; };
     if (nb == 2 && homes[0] >= 0 && homes[1] >= 0 && homes[0] != homes[1]) {
         const bool b_in_a = c->cluster_extra[homes[0]].count(refs[1] | kSlotGhost) != 0, a_in_b = c->cluster_extra[homes[1]].count(refs[0] | kSlotGhost) != 0;
-        cl = (!b_in_a && a_in_b) ? homes[1] : homes[0];
+        if (!b_in_a && a_in_b) candidate(homes[1]);
     }
+    candidate(homes[0]); candidate(homes[1]);
     auto free_slot_of = [&](int cluster) { for (int s = tb->seg_begin[cluster]; s < tb->seg_begin[cluster + 1]; ++s) if (tb->perm[s] < 0) return s; return -1; };
-    int d = free_slot_of(cl);
-    if (d < 0 && nb == 2 && homes[0] >= 0 && homes[1] >= 0 && homes[0] != homes[1]) {  // the other body's home may run it just as well
-        cl = cl == homes[0] ? homes[1] : homes[0];
-        d = free_slot_of(cl);
+    auto copies_missing = [&](int cluster) {
+        int missing = 0;
+        for (int k = 0; k < nb; ++k) {
+            const int32_t key = (uint32_t)refs[k] >= kDynamicLimit ? ((refs[k] & kRefMask) | kSlotKinematic) : (homes[k] == cluster ? -1 : (refs[k] | kSlotGhost));
+            if (key >= 0 && !c->cluster_extra[cluster].count(key)) ++missing;
+        }
+        return missing;
+    };
+    auto lds_room = [&](int cluster, int missing) { return c->cluster_natural[cluster] + missing - (int)c->cluster_free_slots[cluster].size() <= c->clusters_host[cluster].slot_count; };
+    int cl = -1, d = -1;
+    bool row_room = false;
+    for (int q = 0; q < ncand && cl < 0; ++q) {
+        const int slot = free_slot_of(candidates[q]);
+        if (slot < 0) continue;
+        row_room = true;
+        if (lds_room(candidates[q], copies_missing(candidates[q]))) { cl = candidates[q]; d = slot; }
     }
-    if (d < 0) return soft_refuse("no free device slot in the cluster's segment of the type batch");
-    // LDS slots: count what is missing before anything is taken
-    int missing = 0;
-    for (int k = 0; k < nb; ++k) {
-        const int32_t key = (uint32_t)refs[k] >= kDynamicLimit ? ((refs[k] & kRefMask) | kSlotKinematic) : (homes[k] == cl ? -1 : (refs[k] | kSlotGhost));
-        if (key >= 0 && !c->cluster_extra[cl].count(key)) ++missing;
+    if (cl < 0) {
+        const int homes_only = ncand;
+        for (int k = 0; k < nb; ++k)
+            if ((uint32_t)refs[k] < kDynamicLimit)
+                for (auto& app : c->body_apps[refs[k]]) candidate(soft_cluster_of_slot(c->tbs[app.tb], app.slot));
+        for (int q = homes_only; q < ncand && cl < 0; ++q) {
+            const int slot = free_slot_of(candidates[q]);
+            if (slot < 0) continue;
+            row_room = true;
+            if (lds_room(candidates[q], copies_missing(candidates[q]))) { cl = candidates[q]; d = slot; }
+        }
     }
-    if (c->cluster_natural[cl] + missing > c->clusters_host[cl].slot_count) return soft_refuse("no free LDS slot in the cluster for a ghost or kinematic copy");
+    if (cl < 0) {  // last resort: the next clusters by number run it on ghosts of both bodies (any cluster can; it costs two shared bodies, a lost plan costs the schedule)
+        const int first = homes[0] >= 0 ? homes[0] : homes[1], nclusters = (int)c->clusters_host.size();
+        for (int step = 1; step <= std::min(nclusters - 1, 24) && cl < 0; ++step) {
+            const int cluster = (first + step) % nclusters;
+            bool tried = false;
+            for (int q = 0; q < ncand; ++q) tried |= candidates[q] == cluster;
+            if (tried) continue;
+            const int slot = free_slot_of(cluster);
+            if (slot < 0) continue;
+            row_room = true;
+            if (lds_room(cluster, copies_missing(cluster))) { cl = cluster; d = slot; }
+        }
+    }
+    if (cl < 0) return soft_refuse(row_room ? "no free LDS slot in the cluster for a ghost or kinematic copy" : "no free device slot in the cluster's segment of the type batch");
     int32_t lrefs[2] = {kPlanDeadLref, kPlanDeadLref};
     for (int k = 0; k < nb; ++k) {
         const int32_t r = refs[k];
@@ -318,6 +394,7 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
             int slot = found != c->cluster_extra[cl].end() ? found->second : split_take_lds_slot(c, cl, key);
             if (slot < 0) return soft_refuse("no free LDS slot in the cluster for a kinematic copy");
             c->cluster_extra[cl][key] = slot;
+            ++c->cluster_extra_uses[cl][key];
             lrefs[k] = slot | (int)kDynamicLimit;
             continue;
         }
@@ -328,17 +405,17 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
             int slot = found != c->cluster_extra[cl].end() ? found->second : split_take_lds_slot(c, cl, key);
             if (slot < 0) return soft_refuse("no free LDS slot in the cluster for a ghost copy");
             c->cluster_extra[cl][key] = slot;
+            ++c->cluster_extra_uses[cl][key];
             if (!c->split_shared[r]) {  // the body becomes shared: its home's slot table says so, every application of it carries the shared bit from now on
                 c->split_shared[r] = 1;
                 const ClusterDesc& home = c->clusters_host[homes[k]];
                 const size_t entry = (size_t)home.body_begin + (size_t)c->body_lref[r];
                 c->cluster_bodies_host[entry] |= kSlotSharedHome;
-                c->split_patches.push_back({2, entry, (uint32_t)c->cluster_bodies_host[entry]});
+                c->split_patches.push_back({2, entry, -1, 0, 0});
                 for (auto& app : c->body_apps[r]) {
                     HostTypeBatch& other = c->tbs[app.tb];
                     other.plan_lrefs[(size_t)app.k * other.stride + app.slot] |= (int)kLrefShared;
-                    if (!c->soft_slots.count({app.tb, app.slot}))
-                        c->split_patches.push_back({0, other.lrefs_off + (size_t)(app.k / 2) * other.stride + app.slot, split_packed_lrefs(other, app.slot, app.k / 2)});
+                    c->split_patches.push_back({0, other.lrefs_off + (size_t)(app.k / 2) * other.stride + app.slot, app.tb, app.slot, app.k / 2});
                 }
                 split_mark_cluster(c, homes[k]);
             }
@@ -372,11 +449,10 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
 
 // Renumber the applications of a shared body (they are kept in batch order) and write their rank words: to the mirror, and to the device unless the slot is
 // written as a whole by this flush anyway. Every cluster that holds one of them gets its predecessor lists rebuilt.
-static void split_rerank_body(bepuhip_ctx* c, int32_t body) {
+static void split_rerank_body(bepuhip_ctx* c, int32_t body, bool local_handoff, std::vector<bepuhip_ctx::WordPatch>& patches, std::vector<int>& touched_clusters) {
     auto& apps = c->body_apps[body];
     const uint32_t degree = (uint32_t)apps.size();
-    const bool local_handoff = env_int("BEPUHIP_SPLIT_LOCAL_HANDOFF", 1) != 0;
-    std::vector<int> cluster(apps.size());
+    int cluster[256];
     for (size_t q = 0; q < apps.size(); ++q) cluster[q] = soft_cluster_of_slot(c->tbs[apps[q].tb], apps[q].slot);
     for (size_t q = 0; q < apps.size(); ++q) {
         HostTypeBatch& tb = c->tbs[apps[q].tb];
@@ -384,12 +460,11 @@ static void split_rerank_body(bepuhip_ctx* c, int32_t body) {
         if (local_handoff && q > 0 && cluster[q - 1] == cluster[q]) word |= kSoftRankPredLocal;
         if (local_handoff && q + 1 < apps.size() && cluster[q + 1] == cluster[q]) word |= kSoftRankSuccLocal;
         uint32_t& mirror = tb.plan_ranks[(size_t)apps[q].k * tb.stride + apps[q].slot];
-        if (mirror != word && !c->soft_slots.count({apps[q].tb, apps[q].slot}))
-            c->split_patches.push_back({0, tb.lrefs_off + (size_t)((tb.info.bodies + 1) / 2 + apps[q].k) * tb.stride + apps[q].slot, word});
+        if (mirror != word) patches.push_back({0, tb.lrefs_off + (size_t)((tb.info.bodies + 1) / 2 + apps[q].k) * tb.stride + apps[q].slot, apps[q].tb, apps[q].slot, (tb.info.bodies + 1) / 2 + apps[q].k});
         mirror = word;
-        split_mark_cluster(c, cluster[q]);
+        touched_clusters.push_back(cluster[q]);
     }
-    c->split_patches.push_back({1, (size_t)body, degree});
+    patches.push_back({1, (size_t)body, -1, 0, 0});
 }
 
 // The predecessor lists of one cluster of a split plan: the planner's rule (plan_split_clusters) over the mirrors.
@@ -441,24 +516,56 @@ static void split_rebuild_items(bepuhip_ctx* c, int cl) {
     }
 }
 
+// The words of the split plan's tables the flush has to write, with the values the mirrors hold NOW: every word once (the patch kernel writes each patch from its own
+// lane), and none of a device slot the flush writes as a whole anyway.
+struct ResolvedWord { int table; size_t index; uint32_t value; };
+static std::vector<ResolvedWord> split_resolve_patches(bepuhip_ctx* c) {
+    std::vector<ResolvedWord> words;
+    std::unordered_set<uint64_t> seen;
+    for (auto& wp : c->split_patches) {
+        if (!seen.insert(((uint64_t)wp.table << 60) | (uint64_t)wp.index).second) continue;
+        if (wp.table == 0) {
+            if (c->soft_slots.count({wp.tb, wp.slot})) continue;
+            const HostTypeBatch& tb = c->tbs[wp.tb];
+            const int lref_rows = (tb.info.bodies + 1) / 2;
+            words.push_back({0, wp.index, wp.row < lref_rows ? split_packed_lrefs(tb, wp.slot, wp.row) : tb.plan_ranks[(size_t)(wp.row - lref_rows) * tb.stride + wp.slot]});
+        } else if (wp.table == 1) words.push_back({1, wp.index, (uint32_t)c->body_apps[wp.index].size()});
+        else words.push_back({2, wp.index, (uint32_t)c->cluster_bodies_host[wp.index]});
+    }
+    return words;
+}
+
 // Everything the soft updates changed since the last flush, onto the device (both slabs: the snapshot follows, like every other structural update).
-static int32_t flush_soft(bepuhip_ctx* c) {
-    if (c->soft_slots.empty() && c->soft_index.empty() && !c->soft_items_dirty && c->split_rerank.empty() && c->split_patches.empty()) return BEPUHIP_OK;
-    if (c->soft_split) {
-        for (int32_t body : c->split_rerank) split_rerank_body(c, body);
+// The host half: ranks of the shared bodies whose applications changed, predecessor lists of the clusters that received constraints (after it the mirrors describe the
+// layout the device is about to get; tools/plan_harness validates them without a device).
+static void flush_soft_host(bepuhip_ctx* c) {
+    if (c->soft_split && !c->split_rerank.empty()) {  // every body on its own: host threads, their patches and cluster marks merged afterwards
+        const std::vector<int32_t> bodies(c->split_rerank.begin(), c->split_rerank.end());
         c->split_rerank.clear();
+        const bool local_handoff = env_int("BEPUHIP_SPLIT_LOCAL_HANDOFF", 1) != 0;
+        const size_t chunk = 256, jobs = (bodies.size() + chunk - 1) / chunk;
+        std::vector<std::vector<bepuhip_ctx::WordPatch>> patches(jobs);
+        std::vector<std::vector<int>> touched(jobs);
+        plan_parallel_for(jobs, [&](size_t j) {
+            for (size_t i = j * chunk; i < std::min(bodies.size(), (j + 1) * chunk); ++i) split_rerank_body(c, bodies[i], local_handoff, patches[j], touched[j]);
+        });
+        for (size_t j = 0; j < jobs; ++j) {
+            c->split_patches.insert(c->split_patches.end(), patches[j].begin(), patches[j].end());
+            for (int cl : touched[j]) split_mark_cluster(c, cl);
+        }
     }
     if (c->soft_items_dirty) {  // clusters that received constraints: their items' predecessor lists, on a few host threads
         std::vector<int> dirty;
         for (size_t cl = 0; cl < c->cluster_degraded.size(); ++cl) if (c->cluster_degraded[cl]) { dirty.push_back((int)cl); c->cluster_degraded[cl] = 0; }
-        const int workers = std::max(1, std::min<int>({env_int("BEPUHIP_PLAN_THREADS", 8), (int)std::thread::hardware_concurrency(), (int)dirty.size()}));
-        std::atomic<size_t> next{0};
-        auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < dirty.size();) { if (c->soft_split) split_rebuild_items(c, dirty[i]); else soft_rebuild_items(c, dirty[i]); } };
-        std::vector<std::thread> pool;
-        for (int w = 1; w < workers; ++w) pool.emplace_back(work);
-        work();
-        for (auto& th : pool) th.join();
+        plan_parallel_for(dirty.size(), [&](size_t i) { if (c->soft_split) split_rebuild_items(c, dirty[i]); else soft_rebuild_items(c, dirty[i]); });
     }
+}
+static int32_t flush_soft(bepuhip_ctx* c) {
+    if (c->soft_slots.empty() && c->soft_index.empty() && !c->soft_items_dirty && c->split_rerank.empty() && c->split_patches.empty()) return BEPUHIP_OK;
+    const bool timing = env_int("BEPUHIP_PLAN_STATS", 0) >= 2;
+    const auto t_begin = std::chrono::steady_clock::now();
+    flush_soft_host(c);
+    const auto t_host = std::chrono::steady_clock::now();
     std::vector<SoftSlotOp> ops;
     std::vector<uint32_t> payload(1, 0u);
     for (auto& kv : c->soft_slots) {
@@ -480,12 +587,13 @@ static int32_t flush_soft(bepuhip_ctx* c) {
         if (!tb.d_device_index) continue;  // built from `inv` on first use: nothing to patch yet
         patches.push_back(IndexPatch{tb.d_device_index, kv.first.second, kv.second, 0});
     }
-    for (auto& wp : c->split_patches) {  // single words of the split plan's tables (rank words, local references, degrees, slot table entries)
-        if (wp.table == 0) { for (uint32_t* slab : {c->d_slab, c->d_slab0}) if (slab) patches.push_back(IndexPatch{(int*)slab, (int)wp.index, (int)wp.value, 0}); }
-        else if (wp.table == 1) patches.push_back(IndexPatch{(int*)c->d_shared_info, (int)wp.index, (int)wp.value, 0});
-        else patches.push_back(IndexPatch{c->d_cluster_bodies, (int)wp.index, (int)wp.value, 0});
+    for (auto& word : split_resolve_patches(c)) {  // single words of the split plan's tables (rank words, local references, degrees, slot table entries)
+        if (word.table == 0) { for (uint32_t* slab : {c->d_slab, c->d_slab0}) if (slab) patches.push_back(IndexPatch{(int*)slab, (int)word.index, (int)word.value, 0}); }
+        else if (word.table == 1) patches.push_back(IndexPatch{(int*)c->d_shared_info, (int)word.index, (int)word.value, 0});
+        else patches.push_back(IndexPatch{c->d_cluster_bodies, (int)word.index, (int)word.value, 0});
     }
     c->split_patches.clear();
+    const auto t_lists = std::chrono::steady_clock::now();
     const size_t bytes = ops.size() * sizeof(SoftSlotOp) + payload.size() * 4 + patches.size() * sizeof(IndexPatch) + 64;
     char* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, bytes));
@@ -503,6 +611,12 @@ static int32_t flush_soft(bepuhip_ctx* c) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     hipFree(d);
+    if (timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "bepuhip flush of structural updates: %ld calls took %.3f ms before it; ranks + predecessor lists %.3f ms, %zu slot writes + %zu word patches listed %.3f ms, device %.3f ms\n",
+                c->soft_calls, c->soft_call_ms, ms(t_begin, t_host), ops.size(), patches.size(), ms(t_host, t_lists), ms(t_lists, std::chrono::steady_clock::now()));
+        c->soft_calls = 0; c->soft_call_ms = 0.0;
+    }
     c->soft_slots.clear(); c->soft_index.clear(); c->soft_items_dirty = false;
     c->total_constraints = 0;
     for (auto& tb : c->tbs) c->total_constraints += tb.count;

@@ -1589,6 +1589,7 @@ int32_t bepuhip_add_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, c
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (c->soft_ok) {  // on the island layout: a free slot in the segment of the cluster the bodies live in
         bool violation = false;
+        SoftCallTimer timer(c);
         if (tb && soft_add(c, tb, refs, prestep, &violation)) {
             if (index_out) *index_out = tb->count - 1;
             c->requirk_stale = true;
@@ -1641,6 +1642,7 @@ int32_t bepuhip_remove_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb || index < 0 || index >= tb->count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Can only remove elements that are actually in the batch!");  // TypeProcessor.cs:636
     if (c->soft_ok) {  // on the island layout: the slot is freed where it is, the caller's indices are remapped
+        SoftCallTimer timer(c);
         if (soft_remove(c, tb, index)) { c->requirk_stale = true; return BEPUHIP_OK; }
         if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;
         tb = find_tb(c, batch, type_id);

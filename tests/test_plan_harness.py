@@ -89,3 +89,22 @@ def test_plans_keep_the_invariants_the_device_relies_on(harness):
     for mutation in (1, 2, 3):
         rc, out = _validate(exe, scenes["pile"], BEPUHIP_SPLIT_CLUSTERS=24, PLAN_MUTATE=mutation)
         assert rc == 3 and "plan violation" in out, (mutation, out)
+
+
+def test_structural_churn_keeps_a_split_plan_valid_and_its_device_image_equal_to_the_host_mirrors(harness):
+    """PLAN_CHURN (tools/plan_harness): the library's own add / remove code runs on the plan's host mirrors, frame after frame; after every frame the rows a device would hold
+    — the upload, then nothing but what the flush sends: whole slots and single words — equal the mirrors, and the mirrors still pass every plan invariant. Near pairs (what a
+    narrow phase produces) stay on the plan; pairs from all over the scene use the free LDS slots up and are REFUSED cleanly (the context then leaves the plan)."""
+    exe, scenes = harness
+    e = dict(os.environ, PLAN_VALIDATE="1", PLAN_CHURN="25", BEPUHIP_SPLIT_CLUSTERS="24")
+    r = subprocess.run([exe, scenes["pile"], "1", "8"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "25 frames" in out and "still on the plan (24 clusters)" in out, out
+    assert out.count("validate: 0 violation(s)") == 26, out  # the plan, then every frame
+    e["PLAN_CHURN_FAR"] = "1"
+    r = subprocess.run([exe, scenes["pile"], "1", "8"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "violation(s)" in out and "difference(s)" not in out, out  # valid until the refusal, if there is one
+    e.pop("PLAN_CHURN_FAR")
+    r = subprocess.run([exe, scenes["pile"], "1", "0"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)  # without reserved slots: the first new pair finds no room
+    assert r.returncode == 0 and "difference(s)" not in r.stdout.decode(), r.stdout.decode()

@@ -1,8 +1,9 @@
-"""What structural churn costs on a connected scene (GPU box; not part of the product): every frame the last 1 % of every two-body contact type batch is removed and
-as many contacts are added between bodies that were NOT partners before (body A of one removed contact with body B of the next: same batch, so the batch invariant
-holds) — pairs that straddle the clusters of the split-island plan like the narrow phase's new contacts do. Reports the frame (calls + solve) and the solve alone,
-and whether the context is still on the split plan.
-    python tools/perf_churn.py pile|crowd"""
+"""What structural churn costs on a connected scene (GPU box; not part of the product). Every frame a hundredth of every two-body contact type batch is removed (every
+hundredth constraint, another residue every frame: the churn is spread over the scene) and as many contacts come back: most between the same bodies (the narrow phase's
+refresh of a persisting pair), every NEW_PAIRS-th between the first body and a NEAR one (the nearest body index its batch does not hold yet) — a pair that may straddle
+the clusters of the split-island plan, like the narrow phase's new contacts do. tools/plan_harness runs the same churn on the plan's host mirrors without a device and
+validates the plan after every frame. Reports the frame (calls + solve) and the solve alone, and whether the context is still on the split plan.
+    python tools/perf_churn.py pile|crowd [frames]"""
 import os
 import sys
 import time
@@ -22,6 +23,7 @@ scene, sd = sim.export(), sim.solve_description()
 sim.close()
 cb = PoseIntegratorCallbacks()
 w = scene.bundle_width
+new_pairs = int(os.environ.get("NEW_PAIRS", "5"))
 for label, env in (("split plan keeps the updates", {}), ("round 2: updates leave the split plan", {"BEPUHIP_NO_SPLIT_SOFT_UPDATES": "1"})):
     for k, v in env.items():
         os.environ[k] = v
@@ -31,37 +33,76 @@ for label, env in (("split plan keeps the updates", {}), ("round 2: updates leav
         solver.solve(1 / 60, sd, cb, asynchronous=True)
     solver.sync()
     contact = [(bi, tb) for bi, b in enumerate(scene.batches) for tb in b if TYPE_TABLE[tb.type_id][3].startswith("Contact") and tb.bodies == 2 and tb.count > 200]
-    state = []  # per type batch: the lanes currently at its end: (refs, prestep)
-    for bi, tb in contact:
-        k = max(2, tb.count // 100)
-        refs, pre = tb.refs_lanes(w), tb.prestep_lanes(w)
-        state.append([bi, tb.type_id, tb.count, [(refs[i].copy(), pre[i].copy()) for i in range(tb.count - k, tb.count)]])
-    calls = sum(len(s[3]) for s in state) * 2
+    in_batch = []  # per batch: which bodies it references
+    for b in scene.batches:
+        held = np.zeros(scene.body_count + 1, dtype=bool)
+        for tb in b:
+            r = tb.refs_lanes(w)[: tb.count].reshape(-1)
+            held[r[(r >= 0) & (r < (1 << 30))]] = True
+        in_batch.append(held)
+    state = [[bi, tb.type_id, [r.copy() for r in tb.refs_lanes(w)[: tb.count]], [p.copy() for p in tb.prestep_lanes(w)[: tb.count]]] for bi, tb in contact]  # in the caller's order
+    calls = 2 * sum(len(s[2]) // 100 for s in state)
+    frame_number = [0]
 
-    def churn():
-        for s in state:
-            bi, t, count, lanes = s
-            for j in range(len(lanes)):
-                solver.remove_constraint(bi, t, count - 1 - j)
-            shifted = [(np.asarray([lanes[i][0][0], lanes[(i + 1) % len(lanes)][0][1]], dtype=np.int32), lanes[i][1]) for i in range(len(lanes))]
-            for refs, pre in shifted:
-                solver.add_constraint(bi, t, refs, pre)
-            s[3] = shifted
+    def churn():  # the frame's calls are listed first: the timed part is the library's, not this generator's
+        ops = []
+        frame = frame_number[0]
+        frame_number[0] += 1
+        for bi, t, refs, pre in state:
+            held = in_batch[bi]
+            n = len(refs) // 100
+            stride = len(refs) // n
+            first = (frame * 37) % stride
+            lanes = []
+            for i in range(n - 1, -1, -1):  # TypeProcessor.Remove: the last constraint takes the removed one's index
+                index = first + i * stride
+                lanes.append((refs[index], pre[index]))
+                ops.append((bi, t, index, None))
+                refs[index], pre[index] = refs[-1], pre[-1]
+                refs.pop(); pre.pop()
+                held[lanes[-1][0][lanes[-1][0] < (1 << 30)]] = False
+            for i, (r, p) in enumerate(lanes):
+                r = r.copy()
+                if i % new_pairs == 0 and r[0] < (1 << 30) and r[1] < (1 << 30):
+                    coming = {int(x) for q in range(i + 1, n) for x in lanes[q][0]}
+                    for step in range(1, 17):
+                        near = int(r[0]) + ((step + 1) // 2 if step & 1 else -(step // 2))
+                        if 0 <= near < scene.body_count and near != r[1] and not held[near] and near not in coming and constrained[near]:
+                            r[1] = near
+                            break
+                ops.append((bi, t, r, p))
+                refs.append(r); pre.append(p)
+                held[r[r < (1 << 30)]] = True
+        return ops
 
-    frames = 10
-    churn(); solver.solve(1 / 60, sd, cb)
-    t0 = time.perf_counter()
+    def apply(ops):
+        for bi, t, what, p in ops:
+            if p is None:
+                solver.remove_constraint(bi, t, what)
+            else:
+                solver.add_constraint(bi, t, what, p)
+
+    constrained = np.zeros(scene.body_count + 1, dtype=bool)
+    for held in in_batch:
+        constrained |= held
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    apply(churn()); solver.solve(1 / 60, sd, cb)
+    frame_ms = calls_ms = 0.0
     for _ in range(frames):
-        churn()
-        solver.solve(1 / 60, sd, cb)
-    frame_ms = 1e3 * (time.perf_counter() - t0) / frames
+        ops = churn()
+        t0 = time.perf_counter()
+        apply(ops)
+        t1 = time.perf_counter()
+        solver.solve(1 / 60, sd, cb)  # flushes the updates, then solves
+        calls_ms += 1e3 * (t1 - t0) / frames
+        frame_ms += 1e3 * (time.perf_counter() - t1) / frames
     t0 = time.perf_counter()
     for _ in range(50):
         solver.solve(1 / 60, sd, cb, asynchronous=True)
     solver.sync()
     solve_ms = 1e3 * (time.perf_counter() - t0) / 50
     finite = bool(np.isfinite(solver.get_bodies(scene.body_count)).all())
-    print(f"{name}, {label}: {calls} structural calls per frame + solve {frame_ms:.2f} ms; the solve alone afterwards {solve_ms:.4f} ms; "
+    print(f"{name}, {label}: {calls} structural calls per frame {calls_ms:.2f} ms (through ctypes), the flush + solve that follows {frame_ms:.3f} ms; the solve alone afterwards {solve_ms:.4f} ms; "
           f"clusters {solver.cluster_cycles().size}; finite {finite}", flush=True)
     solver.close()
     for k in env:

@@ -175,6 +175,109 @@ static int validate(bepuhip_ctx* c, const ClusterPlan& plan) {
     return bad;
 }
 
+// PLAN_CHURN=frames: what the narrow phase does to a plan, without a device. Every frame a hundredth of every two-body type batch is removed (every hundredth constraint, another
+// residue every frame) and as many constraints come back: most between the same bodies (a persisting pair's refresh), every PLAN_CHURN_NEW-th between the first
+// body and a NEAR one — the nearest body index the batch does not hold yet (PLAN_CHURN_FAR=1: second bodies exchanged among the removed ones instead, pairs from all over
+// the scene, which no narrow phase produces). The structural updates run on the plan's host mirrors (bepu_soft_updates.h); after every frame (1) a device image — the rows as uploaded,
+// then only what flush_soft would write: whole slots and single words — must equal the mirrors, and (2) the mirrors must still be a valid plan (validate above).
+static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
+    const int every = getenv("PLAN_CHURN_NEW") ? atoi(getenv("PLAN_CHURN_NEW")) : 5;
+    const bool far = getenv("PLAN_CHURN_FAR") != nullptr;
+    std::vector<int32_t> cluster_bodies_image = plan.cluster_bodies;
+    std::vector<unsigned> shared_info = plan.shared_info;
+    const bool shared_plan = plan.shared;
+    size_t offset = 0;
+    for (auto& tb : c->tbs) { tb.lrefs_off = offset; offset += tb.lrefs_soa.size(); }  // the word patches name slab offsets
+    std::vector<std::vector<int32_t>> refs_image(c->tbs.size()), lrefs_image(c->tbs.size());
+    for (size_t t = 0; t < c->tbs.size(); ++t) { refs_image[t] = c->tbs[t].refs_soa; lrefs_image[t] = c->tbs[t].lrefs_soa; }
+    soft_setup(c, plan);
+    if (!c->soft_ok) { printf("churn: the plan takes no structural updates\n"); return 0; }
+    long calls = 0;
+    for (int frame = 0; frame < frames; ++frame) {
+        for (size_t t = 0; t < c->tbs.size(); ++t) {
+            HostTypeBatch* tb = &c->tbs[t];
+            if (tb->info.bodies != 2 || tb->count < 100) continue;
+            const int n = tb->count / 100;
+            const int stride = tb->count / n, first = (frame * 37) % stride;  // every stride-th constraint, another residue every frame: the churn is spread over the scene
+            std::vector<std::array<int32_t, 2>> lanes;
+            for (int i = 0; i < n; ++i) { const int d = tb->inv[first + i * stride]; lanes.push_back({tb->dev_refs[d], tb->dev_refs[(size_t)tb->stride + d]}); }
+            for (int i = n - 1; i >= 0; --i, ++calls) if (!soft_remove(c, tb, first + i * stride)) { printf("churn: frame %d, removal refused\n", frame); return 0; }
+            std::vector<int> fresh;
+            for (int i = 0; i < n; i += every) fresh.push_back(i);
+            std::vector<float> prestep(tb->info.prestep, 0.25f);
+            for (int i = 0; i < n; ++i, ++calls) {
+                int32_t refs[2] = {lanes[i][0], lanes[i][1]};
+                if (i % every == 0 && far) refs[1] = lanes[fresh[(i / every + 1) % fresh.size()]][1];
+                else if (i % every == 0 && (uint32_t)refs[0] < kDynamicLimit && (uint32_t)refs[1] < kDynamicLimit) {
+                    for (int step = 1; step <= 16; ++step) {
+                        const int32_t near = refs[0] + ((step & 1) ? (step + 1) / 2 : -(step / 2));
+                        if (near < 0 || near >= (int32_t)c->body_cluster.size() || c->body_cluster[near] < 0 || near == refs[1] || (tb->batch < 64 && (c->body_batches[near] >> tb->batch) & 1)) continue;
+                        bool taken = false;  // ... by a lane of this window that is still to come back
+                        for (int q = i + 1; q < n && !taken; ++q) taken = lanes[q][0] == near || lanes[q][1] == near;
+                        if (!taken) { refs[1] = near; break; }
+                    }
+                }
+                bool violation = false;
+                if (!soft_add(c, tb, refs, prestep.data(), &violation)) {
+                    for (int k = 0; k < 2; ++k) {
+                        if ((uint32_t)refs[k] >= kDynamicLimit) continue;
+                        const int home = c->body_cluster[refs[k]];
+                        int live = 0, total = tb->seg_begin[home + 1] - tb->seg_begin[home];
+                        for (int q = tb->seg_begin[home]; q < tb->seg_begin[home + 1]; ++q) live += tb->perm[q] >= 0;
+                        fprintf(stderr, "churn: refused lane %d of %d (was %d %d): body %d of tb %zu (batch %d type %d count %d) home %d, its segment %d live of %d\n", i, n, lanes[i][0], lanes[i][1], refs[k], t, tb->batch, tb->type_id, tb->count, home, live, total);
+                    } printf("churn: frame %d, addition refused (%s): the context would leave the plan here\n", frame, violation ? "batch invariant" : "no room"); return 0; }
+            }
+        }
+        if (!soft_bodies_still_constrained(c)) { printf("churn: frame %d, a body lost its last constraint\n", frame); return 0; }
+        const auto f0 = std::chrono::steady_clock::now();
+        flush_soft_host(c);
+        if (frame < 3) fprintf(stderr, "churn: frame %d, the host half of the flush %.3f ms\n", frame, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count());
+        // what flush_soft would send, applied to the image
+        for (auto& kv : c->soft_slots) {
+            const HostTypeBatch& tb = c->tbs[kv.first.first];
+            const int d = kv.first.second, nb = tb.info.bodies, rows = (nb + 1) / 2;
+            for (int k = 0; k < nb; ++k) refs_image[kv.first.first][(size_t)k * tb.stride + d] = kv.second.live ? tb.dev_refs[(size_t)k * tb.stride + d] : -1;
+            for (int r = 0; r < rows; ++r) lrefs_image[kv.first.first][(size_t)r * tb.stride + d] = kv.second.live ? (int32_t)split_packed_lrefs(tb, d, r) : (int32_t)kLrefDead;
+            if (kv.second.live) for (int k = 0; k < nb; ++k) lrefs_image[kv.first.first][(size_t)(rows + k) * tb.stride + d] = (int32_t)tb.plan_ranks[(size_t)k * tb.stride + d];
+        }
+        for (auto& word : split_resolve_patches(c)) {
+            if (word.table == 1) { shared_info[word.index] = word.value; continue; }
+            if (word.table == 2) { cluster_bodies_image[word.index] = (int32_t)word.value; continue; }
+            size_t t = 0;
+            while (t + 1 < c->tbs.size() && c->tbs[t + 1].lrefs_off <= word.index) ++t;
+            lrefs_image[t][word.index - c->tbs[t].lrefs_off] = (int32_t)word.value;
+        }
+        c->split_patches.clear(); c->soft_slots.clear(); c->soft_index.clear(); c->soft_items_dirty = false;
+        // (1) image == mirrors
+        int differences = 0;
+        if (cluster_bodies_image != c->cluster_bodies_host) { ++differences; fprintf(stderr, "churn: frame %d, the slot table's image differs from its mirror\n", frame); }
+        for (size_t t = 0; t < c->tbs.size(); ++t) {
+            const HostTypeBatch& tb = c->tbs[t];
+            const int nb = tb.info.bodies, rows = (nb + 1) / 2;
+            for (int d = 0; d < tb.slots; ++d) {
+                const bool live = tb.perm[d] >= 0;
+                for (int k = 0; k < nb; ++k) {
+                    if (refs_image[t][(size_t)k * tb.stride + d] != tb.dev_refs[(size_t)k * tb.stride + d] && differences++ < 8) fprintf(stderr, "churn: frame %d, reference image != mirror (tb %zu slot %d body %d)\n", frame, t, d, k);
+                    if (live && shared_plan && (uint32_t)lrefs_image[t][(size_t)(rows + k) * tb.stride + d] != tb.plan_ranks[(size_t)k * tb.stride + d] && differences++ < 8)
+                        fprintf(stderr, "churn: frame %d, rank word image %x != mirror %x (tb %zu slot %d body %d)\n", frame, lrefs_image[t][(size_t)(rows + k) * tb.stride + d], tb.plan_ranks[(size_t)k * tb.stride + d], t, d, k);
+                }
+                for (int r = 0; r < rows; ++r)
+                    if ((((uint32_t)lrefs_image[t][(size_t)r * tb.stride + d] ^ split_packed_lrefs(tb, d, r)) & ((nb & 1) && r == rows - 1 ? 0xFFFFu : 0xFFFFFFFFu)) != 0 && differences++ < 8)
+                        fprintf(stderr, "churn: frame %d, local reference image %x != mirror %x (tb %zu slot %d row %d, live %d)\n", frame, lrefs_image[t][(size_t)r * tb.stride + d], split_packed_lrefs(tb, d, r), t, d, r, (int)live);
+            }
+        }
+        if (differences) { printf("churn: frame %d, %d difference(s) between the device image and the mirrors\n", frame, differences); return 4; }
+        // (2) the image is a valid plan
+        ClusterPlan now;
+        now.enabled = true; now.shared = shared_plan; now.items = c->items_host; now.clusters = c->clusters_host; now.cluster_bodies = cluster_bodies_image; now.shared_info = shared_info;
+        for (size_t t = 0; t < c->tbs.size(); ++t) { c->tbs[t].refs_soa = refs_image[t]; c->tbs[t].lrefs_soa = lrefs_image[t]; }
+        if (validate(c, now) != 0) { printf("churn: frame %d leaves an invalid plan\n", frame); return 3; }
+    }
+    size_t live_clusters = c->clusters_host.size();
+    printf("churn: %d frames, %ld structural calls, still on the plan (%zu clusters)\n", frames, calls, live_clusters);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: plan_harness scene.bin [repeats]\n"); return 2; }
     const int repeats = argc > 2 ? atoi(argv[2]) : 1;
@@ -239,6 +342,7 @@ int main(int argc, char** argv) {
             if (kind == 2 && !plan.items.empty()) plan.items[0].count -= plan.items[0].count > 1 ? 1 : 0;
         }
         if (getenv("PLAN_VALIDATE") && plan.enabled && validate(c, plan) != 0) return 3;
+        if (getenv("PLAN_CHURN") && plan.enabled) { const int verdict = churn(c, plan, atoi(getenv("PLAN_CHURN"))); if (verdict) return verdict; }
         delete c;
     }
     return 0;
