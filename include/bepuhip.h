@@ -39,7 +39,8 @@ typedef struct bepuhip_config {
 #define BEPUHIP_FLAG_NO_GRAPH 1    /* launch kernels eagerly instead of replaying a captured hipGraph */
 #define BEPUHIP_FLAG_NO_CLUSTERS 2 /* never use the island-per-workgroup (LDS-resident) schedule; always one launch per batch per stage */
 #define BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS 8 /* island schedule: leave an eighth more device slots (at least two) behind every cluster's constraints of every type batch, so that
-                                               bepuhip_add_constraint finds room and the context stays on the island schedule across the narrow phase's add / remove stream */
+                                               bepuhip_add_constraint finds room and the context stays on the island schedule across the narrow phase's add / remove stream
+                                               (split-island plans: a quarter more, at least four, and an eighth more LDS slots per cluster for ghost copies) */
 #define BEPUHIP_FLAG_EXCLUSIVE_DEVICE 16 /* the caller states that nothing else runs on the device while a solve of this context is in flight (no other context, stream or
                                           process). The clusters of a split-island plan wait for each other inside one launch and must all be resident at once: by default
                                           that launch is cooperative (the runtime guarantees co-residency or refuses), which costs about 25 us per step; with this flag it
@@ -207,9 +208,13 @@ int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* ctx, int32_t batch_i
  * bodies live in — one left by a removal, or one reserved at planning with BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS — and the predecessor lists of that cluster's work items are
  * rebuilt. What the plan cannot absorb makes the context fall back to the launch-per-batch schedule (rows back in the caller's order) until the next begin/set/end
  * upload: an addition whose dynamic bodies are not all in one cluster, or had no constraint, or needs a kinematic body the cluster holds no copy of, or a type batch
- * the batch does not have yet, or finds no free slot; a frame's updates that leave a body without constraints; update_body_reference; three- and four-body types;
- * split-island plans. Results are bit-identical either way. Not supported (UNSUPPORTED): the sequential fallback batch, and solving in a momentum-conserving
- * AngularIntegrationMode after structural updates (its substep-0 lists are built at upload). */
+ * the batch does not have yet, or finds no free slot; a frame's updates that leave a body without constraints; update_body_reference; three- and four-body types.
+ * Split-island plans (islands too large for one workgroup, cut into clusters that share bodies) take the updates as well: an addition may name bodies of two clusters (the
+ * cluster that runs it gets a ghost copy of the foreign body, which becomes a shared body if it was not), a removal gives such a copy's LDS slot back; ranks and hand-off
+ * flags of the bodies concerned are recomputed at the next solve. With BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS a split plan reserves a quarter more device slots (at least four)
+ * per cluster and type batch and an eighth more LDS slots per cluster; without it only slots freed by removals are available. When no cluster near the bodies has room the
+ * context falls back as above. Results are bit-identical either way. Not supported (UNSUPPORTED): additions to the sequential fallback batch
+ * (batch_index >= fallback_batch_threshold). */
 /* The caller places the constraint in a batch none of its dynamic bodies is in yet (Solver.cs:1046-1051, 1182-1199: the batch invariant the whole solve rests on). On the island
  * layout the library knows every reference and refuses an addition that breaks it (INVALID_ARGUMENT); on the launch-per-batch rows the references live on the device only and
  * the call trusts the caller, as the reference's release build does. */
