@@ -190,6 +190,37 @@ def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, s
             "upload_ms": upload_ms, "finite": finite}
 
 
+def widened_types_leg(ragdolls: int, device: int, steps: int = 100):
+    """The widened constraint types on the driver line (never `value`): the bench scene's ragdolls — same bodies, same constraint graph, same batches — with the seven
+    joint types other than BallSocket replaced by widened ones (synthetic.RIG_REMAP: AngularSwivelHinge, DistanceLimit, AngularServo, TwistMotor, AngularAxisMotor, Weld,
+    BallSocketServo; seeded random settings). Such a scene runs the second `cluster_kernel` variant (all 44 type ids compiled in; 512 threads per workgroup)."""
+    from bepuphysics2_amd.native import HipSolver
+    from bepuphysics2_amd.scene import TYPE_TABLE, PoseIntegratorCallbacks
+    from bepuphysics2_amd.synthetic import RIG_REMAP, rig_scene
+    scene, sd = rig_scene(ragdolls)
+    cb = PoseIntegratorCallbacks()
+    solver = HipSolver(device=device, exclusive_device=True)
+    solver.upload(scene)
+    for _ in range(60):
+        solver.solve(1 / 60, sd, cb, asynchronous=True)
+    solver.reset_state()
+    solver.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solver.solve(1 / 60, sd, cb, asynchronous=True)
+    solver.sync()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    finite = bool(np.isfinite(solver.get_bodies(scene.body_count)).all())
+    clusters = int(solver.cluster_cycles().size)
+    solver.close()
+    its = sd.iterations()
+    per_step = scene.constraint_count * int((1 + its).sum())
+    return {"workload": f"{ragdolls} ragdoll rigs: the headline's graph ({scene.constraint_count} constraints, {len(scene.batches)} batches) with "
+                        + ", ".join(f"{TYPE_TABLE[a][3]} -> {TYPE_TABLE[b][3]}" for a, b in RIG_REMAP.items()),
+            "ms_per_step": ms, "value": per_step / (ms * 1e-3), "unit": "constraint-iterations/s",
+            "schedule": f"island-per-workgroup, {clusters} clusters, widened kernel variant" if clusters else "launch-per-batch", "finite": finite}
+
+
 def boundary_leg(scene, sd, cb, device: int):
     """What a C# host pays around the resident-in-HBM rate (never `value`). All host buffers are registered once (BufferPool blocks are pinned memory that lives as
     long as the simulation, BufferPool.cs:42,83) and the legs are:
@@ -618,7 +649,9 @@ def main():
 
     boundary = None
     lattice_report = None
+    widened = None
     if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
+        widened = widened_types_leg(args.ragdolls, local_rank)
         boundary = boundary_leg(scene, sd, cb, local_rank)
         lattice_report = lattice_leg(local_rank)
 
@@ -639,7 +672,7 @@ def main():
                        "row_policy": row_policy and f"{row_policy}, picked from the timings of the first fifteen solves after the upload (all candidates bit-identical; DESIGN.md 5)",
                        "device_prewarm": f"{prewarm_steps} untimed solves during setup, uploaded state restored before the {args.warmup} warm-up steps",
                        "finite": finite},
-            "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "boundary": boundary, "lattice": lattice_report,
+            "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "widened_types": widened, "boundary": boundary, "lattice": lattice_report,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -6,24 +6,10 @@ import math
 import numpy as np
 
 from bepuphysics2_amd.scene import TYPE_TABLE, Scene, SceneBuilder, make_body
+from bepuphysics2_amd.synthetic import joint_prestep, rand_quat, spring, unit  # noqa: F401  (the generators below and the tests use them under these names)
 
 TWO_PI = 6.283185307179586
 FLOAT_MAX = float(np.finfo(np.float32).max)
-
-
-def unit(rng, n=3):
-    v = rng.normal(size=n)
-    return (v / np.linalg.norm(v)).astype(np.float32)
-
-
-def rand_quat(rng, spread=1.0):
-    q = rng.normal(size=4) * np.array([spread, spread, spread, 1.0])
-    return (q / np.linalg.norm(q)).astype(np.float32)
-
-
-def spring(frequency, damping_ratio):
-    # SpringSettings(frequency, dampingRatio): AngularFrequency = f * TwoPi, TwiceDampingRatio = 2 * zeta (SpringSettings.cs:73-78)
-    return [np.float32(frequency) * np.float32(TWO_PI), np.float32(damping_ratio) * np.float32(2)]
 
 
 def random_dynamic_body(rng, position, speed=0.5):
@@ -61,82 +47,6 @@ def nonconvex_contact_prestep(rng, n, two_body, pos_a, pos_b=None, friction=1.0,
     for _ in range(n):
         lane += list(rng.uniform(-0.5, 0.5, 3).astype(np.float32)) + [np.float32(rng.uniform(-0.01, 0.02))] + list(unit(rng))
     return lane
-
-
-def joint_prestep(rng, type_id):
-    name = TYPE_TABLE[type_id][3]
-    sp = spring(15.0, 1.0)
-    if name == "BallSocket":
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + sp
-    if name == "AngularHinge":
-        return list(unit(rng)) + list(unit(rng)) + sp
-    if name == "SwingLimit":
-        return list(unit(rng)) + list(unit(rng)) + [math.cos(rng.uniform(0.2, 2.5))] + sp
-    if name == "TwistServo":
-        servo = [FLOAT_MAX, 0.0, FLOAT_MAX] if rng.random() < 0.5 else [rng.uniform(1, 5), rng.uniform(0, 0.5), rng.uniform(10, 1000)]
-        return list(rand_quat(rng)) + list(rand_quat(rng)) + [rng.uniform(-0.5, 0.5)] + sp + servo
-    if name == "TwistLimit":
-        a = rng.uniform(0.1, 1.5)
-        return list(rand_quat(rng)) + list(rand_quat(rng)) + [-a, a] + sp
-    if name == "AngularMotor":
-        settings = [FLOAT_MAX, 1.0 / 0.01] if rng.random() < 0.5 else [rng.uniform(1, 100), rng.uniform(1, 200)]
-        return list(rng.uniform(-0.2, 0.2, 3)) + settings
-    def servo():  # ServoSettings{MaximumSpeed, BaseSpeed, MaximumForce}: unlimited half of the time, as the ragdoll's twist servos are
-        return [FLOAT_MAX, 0.0, FLOAT_MAX] if rng.random() < 0.5 else [rng.uniform(1, 5), rng.uniform(0, 0.5), rng.uniform(10, 1000)]
-
-    def motor():  # MotorSettings{MaximumForce, Damping}
-        return [FLOAT_MAX, 1.0 / 0.01] if rng.random() < 0.5 else [rng.uniform(1, 100), rng.uniform(1, 200)]
-
-    if name == "AngularSwivelHinge":
-        return list(unit(rng)) + list(unit(rng)) + sp
-    if name == "TwistMotor":
-        return list(unit(rng)) + list(unit(rng)) + [rng.uniform(-1, 1)] + motor()
-    if name == "AngularServo":
-        return list(rand_quat(rng)) + sp + servo()
-    if name == "DistanceServo":
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + [rng.uniform(0.5, 3.0)] + servo() + sp
-    if name == "DistanceLimit":
-        lo = rng.uniform(0.2, 2.0)
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + [lo, lo + rng.uniform(0.1, 2.0)] + sp
-    if name == "AngularAxisMotor":
-        return list(unit(rng)) + [rng.uniform(-1, 1)] + motor()
-    if name == "OneBodyAngularServo":
-        return list(rand_quat(rng)) + sp + servo()
-    if name == "OneBodyAngularMotor":
-        return list(rng.uniform(-1, 1, 3)) + motor()
-    if name == "OneBodyLinearServo":
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-3, 3, 3)) + sp + servo()
-    if name == "OneBodyLinearMotor":
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-1, 1, 3)) + motor()
-    if name == "BallSocketMotor":
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-1, 1, 3)) + motor()
-    if name == "BallSocketServo":
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + sp + servo()
-    if name == "PointOnLineServo":
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + servo() + sp
-    if name == "LinearAxisServo":
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + [rng.uniform(-1, 1)] + servo() + sp
-    if name == "LinearAxisMotor":
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + [rng.uniform(-1, 1)] + motor()
-    if name == "LinearAxisLimit":
-        lo = rng.uniform(-2.0, 1.0)
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + [lo, lo + rng.uniform(0.1, 2.0)] + sp
-    if name == "AngularAxisGearMotor":
-        return list(unit(rng)) + [rng.uniform(0.25, 3.0)] + motor()
-    if name == "CenterDistanceConstraint":
-        return [rng.uniform(0.5, 3.0)] + sp
-    if name == "CenterDistanceLimit":
-        lo = rng.uniform(0.2, 2.0)
-        return [lo, lo + rng.uniform(0.1, 2.0)] + sp
-    if name == "AreaConstraint":
-        return [rng.uniform(0.5, 6.0)] + sp       # TargetScaledArea = 2 x area
-    if name == "VolumeConstraint":
-        return [rng.uniform(-6.0, 6.0)] + sp      # TargetScaledVolume = 6 x signed volume
-    if name == "Weld":
-        return list(rng.uniform(-0.5, 0.5, 3)) + list(rand_quat(rng)) + sp
-    if name in ("SwivelHinge", "Hinge"):
-        return list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + list(rng.uniform(-0.4, 0.4, 3)) + list(unit(rng)) + sp
-    raise KeyError(name)
 
 
 def prestep_for(rng, type_id, pos_a, pos_b):
