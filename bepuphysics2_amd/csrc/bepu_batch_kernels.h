@@ -485,6 +485,14 @@ __global__ __launch_bounds__(64) void patch_index_kernel(const IndexPatch* __res
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) patches[i].table[patches[i].index] = patches[i].value;
 }
+// Caller's order -> island schedule, rows to rows (bepuhip_replan): permuted[r][device_index[h]] = rows[r][h]; a null index table is the identity.
+__global__ __launch_bounds__(256) void permute_rows_kernel(const unsigned* __restrict__ src, int src_stride, unsigned* __restrict__ dst, int dst_stride, const int* __restrict__ device_index,
+                                                           int count, int rows) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= count) return;
+    const int d = device_index ? device_index[h] : h;
+    for (int r = 0; r < rows; ++r) dst[(size_t)r * dst_stride + d] = src[(size_t)r * src_stride + h];
+}
 // Island schedule -> caller's order: rows[r][host index] = permuted[r][device index] (the first structural update leaves the island schedule).
 __global__ __launch_bounds__(256) void unpermute_rows_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, const int* __restrict__ device_to_host, int count, int stride, int rows) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;

@@ -92,6 +92,10 @@ struct HostTypeBatch {
     bool index_pooled = false;          // end_constraints (never freed on its own), else allocated on first use
     const float* raw_prestep = nullptr; // the caller's AOSOA bundles as they were copied to the device by set_type_batch (ctx.raw_chunks): end_constraints transposes
     const float* raw_accum = nullptr;   // them into the rows ON the device; the host never touches the values
+    // bepuhip_replan: the values are rows of the previous slab (and of its snapshot) in the caller's order instead of bundles
+    const uint32_t* old_prestep[2] = {nullptr, nullptr};
+    const uint32_t* old_accum[2] = {nullptr, nullptr};
+    int old_stride = 0;
     // Island layout, whole-island plans (bepu_soft_updates.h): the rows hold `slots` device slots — every cluster's constraints of this type batch in one segment
     // [seg_begin[cluster], seg_begin[cluster + 1]), live ones and free ones (perm[d] == -1: reserved at planning, or left by a removal; their local references are
     // kLrefDead). `dev_refs` mirrors the encoded body references per device slot so that a removal knows whose constraint counts it lowers.
@@ -254,6 +258,13 @@ struct bepuhip_ctx {
     unsigned* d_staged = nullptr;   // island schedule: clusters that have staged their bodies in the current launch (see cluster_kernel's kinematic block)
     int* d_kinlist = nullptr;       // constrained kinematic body indices derived from the body references
     int kinlist_count = 0;
+    // Structural updates on an island layout change which kinematic bodies are constrained (the list above is the plan's): how many constraints reference each of them
+    // (counted when the first update arrives), the list's host mirror, and the bodies whose count has touched zero since the last flush.
+    std::vector<int32_t> kinlist_host;
+    std::unordered_map<int32_t, int32_t> kin_uses;
+    std::vector<int32_t> kin_touched;
+    bool kin_uses_ready = false;
+    bool soft_flags_stale = false;
     // measurement
     float last_ms = 0;
     int64_t last_constraint_iterations = 0;
@@ -304,5 +315,5 @@ static void free_constraints(bepuhip_ctx* c) {
     c->inc_blocks = 0; c->inc_tb_count = 0; c->total_constraints = 0; c->slab_words = 0; c->referenced_bodies = 0;
     c->built = false;
     c->pending_ops.clear(); c->pending_payload.clear(); c->structure_dirty = false; c->requirk_stale = false;
-    c->soft_ok = false; c->soft_split = false; c->cluster_free_slots.clear(); c->cluster_extra_uses.clear(); c->body_apps.clear(); c->split_rerank.clear(); c->split_patches.clear(); c->soft_slots.clear(); c->soft_index.clear(); c->soft_orphans.clear(); c->soft_items_dirty = false; c->items_host.clear(); c->clusters_host.clear(); c->cluster_degraded.clear();
+    c->soft_ok = false; c->soft_split = false; c->kinlist_host.clear(); c->kin_uses.clear(); c->kin_touched.clear(); c->kin_uses_ready = false; c->cluster_free_slots.clear(); c->cluster_extra_uses.clear(); c->body_apps.clear(); c->split_rerank.clear(); c->split_patches.clear(); c->soft_slots.clear(); c->soft_index.clear(); c->soft_orphans.clear(); c->soft_items_dirty = false; c->items_host.clear(); c->clusters_host.clear(); c->cluster_degraded.clear();
 }

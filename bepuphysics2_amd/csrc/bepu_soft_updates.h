@@ -32,10 +32,43 @@ static int soft_cluster_of_slot(const HostTypeBatch& tb, int slot) {
     return (int)(std::upper_bound(tb.seg_begin.begin(), tb.seg_begin.end(), slot) - tb.seg_begin.begin()) - 1;
 }
 
+// Constraints per constrained kinematic body, from the device-slot mirrors of the references (first structural update of a plan).
+static void soft_ensure_kin_uses(bepuhip_ctx* c) {
+    if (c->kin_uses_ready) return;
+    c->kin_uses.clear();
+    for (auto& tb : c->tbs)
+        for (int k = 0; k < tb.info.bodies; ++k)
+            for (int d = 0; d < tb.slots; ++d) {
+                const int32_t r = tb.dev_refs[(size_t)k * tb.stride + d];
+                if (r >= 0 && (uint32_t)r >= kDynamicLimit) ++c->kin_uses[r & kRefMask];
+            }
+    c->kin_uses_ready = true;
+}
+static void soft_kinematic_reference(bepuhip_ctx* c, int32_t ref, int delta) {  // a constraint that references kinematic body `ref` comes (+1) or goes (-1)
+    if (ref < 0 || (uint32_t)ref < kDynamicLimit) return;
+    int32_t& uses = c->kin_uses[ref & kRefMask];
+    if ((delta > 0 && uses == 0) || (delta < 0 && uses == 1)) c->kin_touched.push_back(ref & kRefMask);
+    uses += delta;
+}
+// The plan's list of constrained kinematic bodies follows the counts (judged per flush, like a dynamic body's last constraint: a refreshed pair changes nothing).
+// true: the list changed (the caller re-uploads it and rebuilds the body flags).
+static bool soft_update_kinlist(bepuhip_ctx* c) {
+    bool changed = false;
+    for (int32_t body : c->kin_touched) {
+        const bool wanted = c->kin_uses[body] > 0;
+        auto at = std::find(c->kinlist_host.begin(), c->kinlist_host.end(), body);
+        if (wanted && at == c->kinlist_host.end()) { c->kinlist_host.push_back(body); changed = true; }
+        else if (!wanted && at != c->kinlist_host.end()) { *at = c->kinlist_host.back(); c->kinlist_host.pop_back(); changed = true; }
+    }
+    c->kin_touched.clear();
+    return changed;
+}
+
 static void soft_setup(bepuhip_ctx* c, ClusterPlan& plan) {
     c->soft_ok = false; c->soft_split = false;
     c->soft_slots.clear(); c->soft_index.clear(); c->soft_items_dirty = false; c->soft_adds = c->soft_removes = 0;
     c->body_apps.clear(); c->split_rerank.clear(); c->split_patches.clear();
+    c->kinlist_host = plan.kinlist; c->kin_uses.clear(); c->kin_touched.clear(); c->kin_uses_ready = false;
     if (!plan.enabled || env_int("BEPUHIP_NO_SOFT_UPDATES", 0)) return;
     if (plan.shared) {  // split-island plan: the second half of this file
         if (env_int("BEPUHIP_NO_SPLIT_SOFT_UPDATES", 0)) return;
@@ -75,10 +108,12 @@ static bool soft_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index) {
     if (!c->soft_ok || tb->slots == 0 || tb->info.bodies > 2) return soft_refuse("removal from a type batch the island layout does not manage");
     if (c->soft_split) return split_remove(c, tb, index);
     soft_ensure_degrees(c);
+    soft_ensure_kin_uses(c);
     const int t = (int)(tb - c->tbs.data());
     const int d = tb->inv[index], last = tb->count - 1, dl = tb->inv[last];
     for (int k = 0; k < tb->info.bodies; ++k) {
         int32_t& r = tb->dev_refs[(size_t)k * tb->stride + d];
+        soft_kinematic_reference(c, r, -1);
         // a body whose last constraint goes would have to leave the plan (the reference integrates it as an unconstrained body from then on) — unless the same
         // batch of updates gives it a constraint again (a refreshed pair): decided when the updates are flushed (soft_bodies_still_constrained)
         if (r >= 0 && (uint32_t)r < kDynamicLimit) {
@@ -137,9 +172,11 @@ static bool soft_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, con
     for (int s = tb->seg_begin[cl]; s < tb->seg_begin[cl + 1] && d < 0; ++s) if (tb->perm[s] < 0) d = s;
     if (d < 0) return soft_refuse("no free device slot in the cluster's segment of the type batch");
     bepuhip_ctx::SoftSlot slot{true, {}};
+    soft_ensure_kin_uses(c);
     for (int k = 0; k < nb; ++k) {
         slot.payload.push_back((uint32_t)refs[k]);
         tb->dev_refs[(size_t)k * tb->stride + d] = refs[k];
+        soft_kinematic_reference(c, refs[k], +1);
         if ((uint32_t)refs[k] < kDynamicLimit) { ++c->body_degree[refs[k]]; if (tb->batch < 64) c->body_batches[refs[k]] |= 1ull << tb->batch; }
     }
     slot.payload.push_back(halves[0] | (halves[1] << 16));
@@ -294,8 +331,10 @@ static bool split_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index) {
     const int t = (int)(tb - c->tbs.data());
     const int d = tb->inv[index], last = tb->count - 1, dl = tb->inv[last];
     const int cluster_of_slot = soft_cluster_of_slot(*tb, d);
+    soft_ensure_kin_uses(c);
     for (int k = 0; k < tb->info.bodies; ++k) {
         int32_t& r = tb->dev_refs[(size_t)k * tb->stride + d];
+        soft_kinematic_reference(c, r, -1);
         if (r >= 0 && (uint32_t)r >= kDynamicLimit) split_release_copy(c, cluster_of_slot, (r & kRefMask) | kSlotKinematic);
         else if (r >= 0 && c->body_cluster[r] != cluster_of_slot) split_release_copy(c, cluster_of_slot, r | kSlotGhost);
         if (r >= 0 && (uint32_t)r < kDynamicLimit) {
@@ -425,8 +464,10 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
     }
     bepuhip_ctx::SoftSlot slot{true, {}};  // the prestep lane; references, local references and rank words are taken from the mirrors when the updates are flushed
     for (int f = 0; f < tb->info.prestep; ++f) { uint32_t w; memcpy(&w, &prestep[f], 4); slot.payload.push_back(w); }
+    soft_ensure_kin_uses(c);
     for (int k = 0; k < nb; ++k) {
         tb->dev_refs[(size_t)k * tb->stride + d] = refs[k];
+        soft_kinematic_reference(c, refs[k], +1);
         tb->plan_lrefs[(size_t)k * tb->stride + d] = lrefs[k];
         tb->plan_ranks[(size_t)k * tb->stride + d] = 0u;
         if ((uint32_t)refs[k] < kDynamicLimit) {
@@ -560,8 +601,19 @@ static void flush_soft_host(bepuhip_ctx* c) {
         plan_parallel_for(dirty.size(), [&](size_t i) { if (c->soft_split) split_rebuild_items(c, dirty[i]); else soft_rebuild_items(c, dirty[i]); });
     }
 }
+static int32_t rebuild_flags(bepuhip_ctx* c);
 static int32_t flush_soft(bepuhip_ctx* c) {
-    if (c->soft_slots.empty() && c->soft_index.empty() && !c->soft_items_dirty && c->split_rerank.empty() && c->split_patches.empty()) return BEPUHIP_OK;
+    if (c->soft_slots.empty() && c->soft_index.empty() && !c->soft_items_dirty && c->split_rerank.empty() && c->split_patches.empty() && c->kin_touched.empty()) return BEPUHIP_OK;
+    if (soft_update_kinlist(c)) {  // a kinematic body gained its first or lost its last constraint: the kinematic workgroup's list and the body flags follow
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_kinlist) { hipFree(c->d_kinlist); c->d_kinlist = nullptr; }
+        c->kinlist_count = (int)c->kinlist_host.size();
+        if (c->kinlist_count > 0) {
+            HIP_TRY(hipMalloc((void**)&c->d_kinlist, c->kinlist_host.size() * 4));
+            HIP_TRY(hipMemcpy(c->d_kinlist, c->kinlist_host.data(), c->kinlist_host.size() * 4, hipMemcpyHostToDevice));
+        }
+        c->soft_flags_stale = true;
+    }
     const bool timing = env_int("BEPUHIP_PLAN_STATS", 0) >= 2;
     const auto t_begin = std::chrono::steady_clock::now();
     flush_soft_host(c);
@@ -620,5 +672,6 @@ static int32_t flush_soft(bepuhip_ctx* c) {
     c->soft_slots.clear(); c->soft_index.clear(); c->soft_items_dirty = false;
     c->total_constraints = 0;
     for (auto& tb : c->tbs) c->total_constraints += tb.count;
+    if (c->soft_flags_stale) { c->soft_flags_stale = false; return rebuild_flags(c); }  // after the slots have their references: the flags are derived from them
     return BEPUHIP_OK;
 }

@@ -522,9 +522,27 @@ static int32_t build_constraints(bepuhip_ctx* c) {
                 hipLaunchKernelGGL(scatter_bundles_kernel, dim3(blocks), dim3(256), 0, c->stream, tb.raw_accum, (float*)(c->d_slab + tb.accum_off), (const int*)tb.d_device_index, 0, tb.count,
                                    tb.info.impulse, tb.stride, c->W);
             tb.raw_prestep = tb.raw_accum = nullptr;
+            if (tb.old_prestep[0] && tb.info.prestep > 0)  // bepuhip_replan: rows of the previous slab, in the caller's order
+                hipLaunchKernelGGL(permute_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, tb.old_prestep[0], tb.old_stride, c->d_slab + tb.prestep_off, tb.stride, (const int*)tb.d_device_index,
+                                   tb.count, tb.info.prestep);
+            if (tb.old_accum[0] && tb.info.impulse > 0)
+                hipLaunchKernelGGL(permute_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, tb.old_accum[0], tb.old_stride, c->d_slab + tb.accum_off, tb.stride, (const int*)tb.d_device_index,
+                                   tb.count, tb.info.impulse);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(c->d_slab0, c->d_slab, words * 4, hipMemcpyDeviceToDevice, c->stream));
+        for (auto& tb : c->tbs) {  // bepuhip_replan: the snapshot keeps ITS values (what reset_state returns to), in the new layout
+            if (tb.count == 0) continue;
+            const int blocks = (tb.count + 255) / 256;
+            if (tb.old_prestep[1] && tb.info.prestep > 0)
+                hipLaunchKernelGGL(permute_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, tb.old_prestep[1], tb.old_stride, c->d_slab0 + tb.prestep_off, tb.stride, (const int*)tb.d_device_index,
+                                   tb.count, tb.info.prestep);
+            if (tb.old_accum[1] && tb.info.impulse > 0)
+                hipLaunchKernelGGL(permute_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, tb.old_accum[1], tb.old_stride, c->d_slab0 + tb.accum_off, tb.stride, (const int*)tb.d_device_index,
+                                   tb.count, tb.info.impulse);
+            tb.old_prestep[0] = tb.old_prestep[1] = tb.old_accum[0] = tb.old_accum[1] = nullptr;
+        }
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's buffers (if registered: read asynchronously) and the staging buffer are free again
     }
     lap("slab assembly + upload");
@@ -589,6 +607,64 @@ static int32_t build_constraints(bepuhip_ctx* c) {
     const int32_t flags_status = rebuild_flags(c);
     lap("body flags");
     return flags_status;
+}
+
+// A new plan for the constraints the device holds now (after structural updates the old plan could not absorb, or to refresh a plan's reserves): body references are
+// read back, the host plans as bepuhip_end_constraints does, prestep data and accumulated impulses — of the working rows and of the snapshot bepuhip_reset_state
+// returns to — move from the old rows to the new layout on the device. Nothing crosses PCIe but the references (one way) and the plan's tables (the other).
+int32_t bepuhip_replan(bepuhip_ctx* c) {
+    if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
+    if (c->building) return fail(BEPUHIP_E_STATE, "replan between begin_constraints and end_constraints");
+    if (!c->built) return fail(BEPUHIP_E_STATE, "replan without constraints (begin / set_type_batch / end first)");
+    HIP_TRY(hipSetDevice(c->device));
+    int32_t st = BEPUHIP_OK;
+    if ((st = flush_structural(c)) != BEPUHIP_OK) return st;     // everything the caller has been told is in the rows
+    if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;  // ... and the rows are in the caller's order
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<HostTypeBatch> fresh;
+    fresh.reserve(c->tbs.size());
+    for (auto& tb : c->tbs) {
+        HostTypeBatch nt;
+        nt.batch = tb.batch; nt.type_id = tb.type_id; nt.count = tb.count; nt.info = tb.info;
+        nt.stride = std::max(64, ((tb.count + 63) / 64) * 64);
+        nt.refs_off = nt.prestep_off = nt.accum_off = nt.lrefs_off = 0;
+        nt.refs_soa.assign((size_t)tb.info.bodies * nt.stride, -1);
+        for (int k = 0; k < tb.info.bodies && tb.count > 0; ++k)
+            HIP_TRY(hipMemcpy(nt.refs_soa.data() + (size_t)k * nt.stride, c->d_slab + tb.refs_off + (size_t)k * tb.stride, (size_t)tb.count * 4, hipMemcpyDeviceToHost));
+        uint32_t* const slabs[2] = {c->d_slab, c->d_slab0};
+        for (int which = 0; which < 2; ++which) {
+            nt.old_prestep[which] = slabs[which] + tb.prestep_off;
+            nt.old_accum[which] = slabs[which] + tb.accum_off;
+        }
+        nt.old_stride = tb.stride;
+        fresh.push_back(std::move(nt));
+    }
+    uint32_t* const old_slab = c->d_slab; uint32_t* const old_slab0 = c->d_slab0;
+    c->d_slab = c->d_slab0 = nullptr;  // kept past free_constraints: the new rows are filled from them
+    const int batch_count = c->batch_count;
+    const bool has_fallback = c->has_fallback;
+    free_constraints(c);
+    c->batch_count = batch_count; c->has_fallback = has_fallback;
+    c->has_widened_types = false;
+    for (auto& tb : fresh) {
+        c->has_widened_types = c->has_widened_types || is_widened_type(tb.type_id);
+        for (int32_t r : tb.refs_soa) if (r >= 0) c->referenced_bodies = std::max(c->referenced_bodies, (r & kRefMask) + 1);
+        if (has_fallback && tb.batch == c->fallback_threshold) { for (int i = 0; i < tb.count; ++i) c->total_constraints += tb.refs_soa[i] != -1; }
+        else c->total_constraints += tb.count;
+    }
+    c->tbs = std::move(fresh);
+    st = build_constraints(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(old_slab);
+    if (old_slab0) hipFree(old_slab0);
+    if (st != BEPUHIP_OK) free_constraints(c);
+    return st;
+}
+
+int32_t bepuhip_get_schedule(bepuhip_ctx* c, int32_t* schedule_out) {
+    if (!c || !schedule_out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    *schedule_out = !c->clusters_enabled ? 0 : (c->clusters_shared ? 2 : 1);
+    return BEPUHIP_OK;
 }
 
 int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* c, const int32_t* indices, int32_t count) {

@@ -155,10 +155,7 @@ int Solver::Add(const int32_t* bodyHandles, int bodyCount, int typeId, const flo
         if (bodies.IsKinematic(index)) {
             encoded[i] = index | kKinematicMask;
             if ((size_t)bodyHandles[i] >= kinematicConstrained.size()) kinematicConstrained.resize(bodyHandles[i] + 1, 0);
-            if (!kinematicConstrained[bodyHandles[i]]) {
-                kinematicConstrained[bodyHandles[i]] = 1;
-                ConstrainedKinematicHandles.push_back(bodyHandles[i]);
-            }
+            if (kinematicConstrained[bodyHandles[i]]++ == 0) ConstrainedKinematicHandles.push_back(bodyHandles[i]);  // Solver.cs:1025
         } else {
             encoded[i] = index;
             blocking[blockingCount++] = bodyHandles[i];
@@ -204,6 +201,15 @@ void Solver::Remove(int constraintHandle) {
     auto ref = [&](int i, int k) -> int32_t& { return tb.BodyReferences[(size_t)(i / W) * nb * W + (size_t)k * W + (i % W)]; };
     for (int k = 0; k < nb; ++k)  // ConstraintBatch.RemoveBodyHandlesFromBatchForConstraint (ConstraintBatch.cs:196-214): dynamic bodies only
         if ((uint32_t)ref(index, k) < (uint32_t)kKinematicMask) batchReferencedHandles[loc.BatchIndex].Unset(bodies.IndexToHandle[ref(index, k)]);
+    for (int k = 0; k < nb; ++k) {  // RemoveConstraintReferencesFromBodiesEnumerator (Solver.cs:1368-1377): a kinematic body's last constraint takes it out of the set (FastRemove)
+        if ((uint32_t)ref(index, k) < (uint32_t)kKinematicMask) continue;
+        const int32_t handle = bodies.IndexToHandle[ref(index, k) & (kKinematicMask - 1)];
+        if (--kinematicConstrained[handle] == 0) {
+            auto at = std::find(ConstrainedKinematicHandles.begin(), ConstrainedKinematicHandles.end(), handle);
+            *at = ConstrainedKinematicHandles.back();
+            ConstrainedKinematicHandles.pop_back();
+        }
+    }
     if (index < last) {  // TypeProcessor.Move
         for (int k = 0; k < nb; ++k) ref(index, k) = ref(last, k);
         for (int f = 0; f < pf; ++f) tb.PrestepData[(size_t)(index / W) * pf * W + (size_t)f * W + (index % W)] = tb.PrestepData[(size_t)(last / W) * pf * W + (size_t)f * W + (last % W)];

@@ -138,7 +138,7 @@ public:
     void ValidateBatches() const;  // "no dynamic body twice in a non-fallback batch" (Solver.cs:1046-1051)
 private:
     Bodies& bodies;
-    std::vector<uint8_t> kinematicConstrained;
+    std::vector<int32_t> kinematicConstrained;  // per body handle: constraints that reference the (kinematic) body (Bodies' constraint lists, as far as this set needs them)
     int liveConstraints = 0;
 };
 

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
     "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables", "bepuhip_set_convex_hulls", "bepuhip_set_compounds", "bepuhip_set_meshes",
-    "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_get_constraint_count",
+    "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_get_constraint_count", "bepuhip_get_schedule", "bepuhip_replan",
     "bepuhip_register_host_memory", "bepuhip_unregister_host_memory", "bepuhip_get_poses_and_velocities", "bepuhip_get_poses_and_velocities_async", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses_async",
 ]
 
@@ -134,6 +134,8 @@ def load_library() -> C.CDLL:
     lib.bepuhip_remove_constraint.argtypes = [vp, i32, i32, i32]
     lib.bepuhip_update_body_reference.argtypes = [vp, i32, i32, i32, i32, i32]
     lib.bepuhip_get_constraint_count.argtypes = [vp, i32, i32, C.POINTER(i32)]
+    lib.bepuhip_get_schedule.argtypes = [vp, C.POINTER(i32)]
+    lib.bepuhip_replan.argtypes = [vp]
     for name in EXPORTED_SYMBOLS:
         if name != "bepuhip_last_error":
             getattr(lib, name).restype = i32
@@ -376,6 +378,21 @@ class HipSolver:
         n = C.c_int32()
         _check(self.lib, self.lib.bepuhip_get_constraint_count(self.ctx, batch_index, type_id, C.byref(n)))
         return int(n.value)
+
+    def set_constrained_kinematics(self, indices: np.ndarray):
+        """Solver.ConstrainedKinematicHandles as body indices: re-sent whenever structural updates change it (Solver.cs:1025, 1368-1377)."""
+        kin = np.ascontiguousarray(indices, dtype=np.int32)
+        _check(self.lib, self.lib.bepuhip_set_constrained_kinematics(self.ctx, _ptr(kin), kin.size))
+
+    def schedule(self) -> int:
+        """0 launch-per-batch, 1 island-per-workgroup (whole islands), 2 island-per-workgroup on a split-island plan."""
+        n = C.c_int32()
+        _check(self.lib, self.lib.bepuhip_get_schedule(self.ctx, C.byref(n)))
+        return int(n.value)
+
+    def replan(self):
+        """A fresh plan for the constraints the device holds now (bepuhip_replan): values stay on the device, only the references are read back."""
+        _check(self.lib, self.lib.bepuhip_replan(self.ctx))
 
     def update_prestep(self, batch_index: int, type_id: int, first_bundle: int, bundles: np.ndarray, asynchronous: bool = False):
         """``bundles``: the type batch's PrestepData bundles [first_bundle, first_bundle + n) exactly as the reference stores them (AOSOA).

@@ -223,6 +223,16 @@ int32_t bepuhip_remove_constraint(bepuhip_ctx* ctx, int32_t batch_index, int32_t
 int32_t bepuhip_update_body_reference(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index, int32_t body_index_in_constraint, int32_t encoded_body_reference);
 /* ConstraintCount of a type batch as the device sees it (0 if it does not exist). */
 int32_t bepuhip_get_constraint_count(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t* count_out);
+/* The schedule the next solve of this context runs: 0 one launch per batch and stage (hipGraph replay), 1 island-per-workgroup with whole islands, 2 island-per-workgroup
+ * on a split-island plan. An upload picks 1 or 2 when the scene allows it; structural updates the plan cannot absorb drop the context to 0 (see above). */
+int32_t bepuhip_get_schedule(bepuhip_ctx* ctx, int32_t* schedule_out);
+/* Plans the constraints the device holds NOW afresh, as bepuhip_end_constraints would for the same type batches: for a context that structural updates have dropped to
+ * schedule 0, or to give a plan that has been absorbing updates for a long time fresh reserves. The body references are read back (the only bytes that cross PCIe besides
+ * the new plan's tables), the host plans, prestep data and accumulated impulses — of the working rows and of the snapshot bepuhip_reset_state returns to — move into the
+ * new layout on the device. Indices, counts and values as the caller knows them are unchanged; results are bit-identical with or without the call. Costs about what
+ * bepuhip_end_constraints costs without its upload (tens of milliseconds per million constraints): call it between frames when bepuhip_get_schedule reports 0, not
+ * every frame. No counterpart in the reference (its constraint batches need no plan). */
+int32_t bepuhip_replan(bepuhip_ctx* ctx);
 
 /* ---- PredictBoundingBoxes on the device ----
  * Replaces the per-body work of PoseIntegrator.PredictBoundingBoxes (BepuPhysics/PoseIntegrator.cs:307-370, called from Simulation.PredictBoundingBoxes,

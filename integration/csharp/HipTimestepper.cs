@@ -78,6 +78,8 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_remove_constraint(IntPtr ctx, int batchIndex, int typeId, int index);
     [DllImport(Lib)] public static extern int bepuhip_update_body_reference(IntPtr ctx, int batchIndex, int typeId, int index, int bodyIndexInConstraint, int encodedBodyReference);
     [DllImport(Lib)] public static extern int bepuhip_get_constraint_count(IntPtr ctx, int batchIndex, int typeId, int* countOut);
+    [DllImport(Lib)] public static extern int bepuhip_get_schedule(IntPtr ctx, int* scheduleOut);
+    [DllImport(Lib)] public static extern int bepuhip_replan(IntPtr ctx);
     [DllImport(Lib)] public static extern int bepuhip_set_convex_hulls(IntPtr ctx, float* points, int* pointBegin, int hullCount);
     [DllImport(Lib)] public static extern int bepuhip_set_compounds(IntPtr ctx, BepuHipCompoundChild* children, int* childBegin, int compoundCount);
     [DllImport(Lib)] public static extern int bepuhip_set_meshes(IntPtr ctx, float* triangles, int* triangleBegin, float* scales, int meshCount);
@@ -126,6 +128,8 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipStructureList
     bool resident;                                    // the device holds the scene as of the last solve
     struct StructuralOp { public int Kind, Batch, TypeId, Index, Slot, Reference; public int[] References; public float[] Prestep; }
     readonly List<StructuralOp> log = new List<StructuralOp>();   // what the listener saw since the last solve, in order
+    public int ReplanInterval = 30;                                // frames between two bepuhip_replan calls at most
+    int framesSinceReplan = 30;
     readonly Dictionary<IntPtr, long> registered = new Dictionary<IntPtr, long>();
     public int ReplayLimit = 65536;                   // a longer log is not cheaper than an upload
     public event TimestepperStageHandler BeforeCollisionDetection, CollisionsDetected, ConstraintsSolved; // ITimestepper.cs:62-74 (subset)
@@ -220,6 +224,12 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipStructureList
             else Check(BepuHip.bepuhip_update_body_reference(ctx, op.Batch, op.TypeId, op.Index, op.Slot, op.Reference));
         }
         log.Clear();
+        // Updates the plan could not absorb (a new type batch, a body's first or last constraint, exhausted reserves) leave the context on the launch-per-batch
+        // schedule: a fresh plan costs tens of milliseconds once, the slow schedule costs every frame from then on. Not more often than every ReplanInterval frames.
+        int schedule;
+        Check(BepuHip.bepuhip_get_schedule(ctx, &schedule));
+        if (schedule == 0 && framesSinceReplan >= ReplanInterval) { Check(BepuHip.bepuhip_replan(ctx)); framesSinceReplan = 0; }
+        else ++framesSinceReplan;
     }
 
     // What the narrow phase rewrote in place for persisting pairs since the last solve (NarrowPhaseConstraintUpdate.cs:147-207): prestep data and redistributed impulses

@@ -17,7 +17,8 @@ class MutableSolver:
         self.batches: List[Dict[int, dict]] = []          # per batch: type_id -> {"refs": [...], "prestep": [...], "acc": [...]}
         self.type_order: List[List[int]] = []             # type batches of a batch in creation order (ConstraintBatch.GetOrCreateTypeBatch)
         self.batch_handles: List[Dict[int, int]] = []     # batchReferencedHandles: dynamic body -> 1
-        self.kinematic_constrained: List[int] = []
+        self.kinematic_constrained: List[int] = []       # Solver.ConstrainedKinematicHandles (Solver.cs:68): kinematic bodies with at least one constraint
+        self.kinematic_uses: Dict[int, int] = {}
 
     def is_kinematic(self, body: int) -> bool:
         return not np.any(self.bodies[body, 16:23])
@@ -30,7 +31,8 @@ class MutableSolver:
         for b in bodies:
             if self.is_kinematic(b):
                 encoded.append(int(b) | KINEMATIC_MASK)
-                if b not in self.kinematic_constrained:
+                self.kinematic_uses[int(b)] = self.kinematic_uses.get(int(b), 0) + 1
+                if self.kinematic_uses[int(b)] == 1:
                     self.kinematic_constrained.append(int(b))
             else:
                 encoded.append(int(b))
@@ -59,6 +61,13 @@ class MutableSolver:
         for r in tb["refs"][index]:
             if not (r & KINEMATIC_MASK):
                 del self.batch_handles[batch_index][r]
+            else:  # RemoveConstraintReferencesFromBodiesEnumerator (Solver.cs:1368-1377): a kinematic body's last constraint takes it out of ConstrainedKinematicHandles (FastRemove)
+                body = int(r) & ~KINEMATIC_MASK
+                self.kinematic_uses[body] -= 1
+                if self.kinematic_uses[body] == 0:
+                    at = self.kinematic_constrained.index(body)
+                    self.kinematic_constrained[at] = self.kinematic_constrained[-1]
+                    self.kinematic_constrained.pop()
         last = len(tb["refs"]) - 1
         if index < last:
             for key in ("refs", "prestep", "acc"):

@@ -386,3 +386,135 @@ def test_reserved_layout_falls_back_cleanly_when_the_island_schedule_does_not_ap
         assert solver.cluster_cycles().size == 0
         m = pu.compare_scenes(ref, got)
         assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+
+def test_replan_puts_a_context_that_left_its_plan_back_on_the_island_schedule(hip_solver_factory):
+    """bepuhip_replan (round 3): the hub scene of the test above drops the context to launch-per-batch (new batches, new type batches, rows that grow); a re-plan reads the
+    references back, plans the constraints the device holds, permutes prestep data and accumulated impulses on the device — and the following frames run on the island
+    schedule with the same bits as the oracle. reset_state after the re-plan returns to the state of the last structural update, in the new layout."""
+    rng = np.random.default_rng(5)
+    rows = [small_scenes.random_dynamic_body(rng, rng.uniform(-3, 3, 3)) for _ in range(140)]
+    ms, pristine = MutableSolver(np.stack(rows)), MutableSolver(np.stack(rows))  # `pristine` gets every structural update and no frame: what reset_state returns to
+    for k in range(1, 139, 2):
+        lane = small_scenes.prestep_for(rng, 7, ms.bodies[k, 4:7], ms.bodies[k + 1, 4:7])
+        ms.add(7, [k, k + 1], lane); pristine.add(7, [k, k + 1], lane)
+    sd, cb = SolveDescription(2, 2), PoseIntegratorCallbacks()
+    solver = hip_solver_factory()
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+    assert solver.schedule() == 1
+
+    def frames(n):
+        for _ in range(n):
+            export = ms.to_scene()
+            oracle_ffi.solve(export, 1 / 60, sd, cb)
+            ms.absorb(export)
+            solver.solve(1 / 60, sd, cb)
+        got = ms.to_scene()
+        solver.download(got)
+        m = pu.compare_scenes(export, got)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+    frames(2)
+    for k in range(3, 40):  # hub 0 had no constraint, and every constraint on it needs a batch of its own: nothing an island plan absorbs
+        t = [7, 22, 4][k % 3]
+        lane = small_scenes.prestep_for(rng, t, ms.bodies[0, 4:7], ms.bodies[k, 4:7])
+        bi, index, encoded = ms.add(t, [0, k], lane)
+        pristine.add(t, [0, k], lane)
+        assert solver.add_constraint(bi, t, encoded, lane) == index
+    frames(2)
+    assert solver.schedule() == 0 and solver.cluster_cycles().size == 0
+    solver.replan()
+    assert solver.schedule() == 1
+    for bi, tbs in enumerate(ms.to_scene().batches):
+        for tb in tbs:
+            assert solver.constraint_count(bi, tb.type_id) == tb.count
+    before = ms.to_scene()
+    solver.download(before)  # read-backs in the caller's order see the same values through the new layout
+    m = pu.compare_scenes(ms.to_scene(), before)
+    assert m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    frames(3)
+    assert solver.cluster_cycles().size > 0
+    # a second re-plan of a context that IS on a plan (fresh reserves) changes nothing either
+    solver.replan()
+    frames(2)
+    # the snapshot moved into the new layout with its own values: uploaded bodies and rows + the structural updates, no frame
+    solver.reset_state()
+    solver.solve(1 / 60, sd, cb)
+    want = pristine.to_scene()
+    oracle_ffi.solve(want, 1 / 60, sd, cb)
+    got = pristine.to_scene()
+    solver.download(got)
+    m = pu.compare_scenes(want, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+
+def test_replan_on_a_split_island_plan_and_the_snapshot_reset_state_returns_to(hip_solver_factory, monkeypatch):
+    monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "12")
+    ms, rng, pair = _build(37, bodies=2600, joints=3000, contacts=5000)
+    sd, cb = SolveDescription(1, 4), PoseIntegratorCallbacks()
+    solver = hip_solver_factory()  # no reserved slots: the first additions across clusters leave the plan
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+    assert solver.schedule() == 2
+    for frame in range(6):
+        if frame in (1, 2):
+            for _ in range(40):
+                a, b = pair()
+                t = CONTACT_TYPES[int(rng.integers(len(CONTACT_TYPES)))]
+                lane = small_scenes.prestep_for(rng, t, ms.bodies[a, 4:7], ms.bodies[b, 4:7])
+                bi, index, encoded = ms.add(t, [a, b], lane)
+                assert solver.add_constraint(bi, t, encoded, lane) == index
+        if frame == 3:
+            assert solver.schedule() == 0
+            solver.replan()
+            assert solver.schedule() == 2
+        export = ms.to_scene()
+        oracle_ffi.solve(export, 1 / 60, sd, cb, threads=4)
+        ms.absorb(export)
+        solver.solve(1 / 60, sd, cb)
+        got = ms.to_scene()
+        solver.download(got)
+        m = pu.compare_scenes(export, got)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (frame, m)
+    assert solver.cluster_cycles().size > 1
+
+
+def test_a_kinematic_body_that_loses_and_regains_its_constraints_on_the_island_layout(hip_solver_factory):
+    """Solver.ConstrainedKinematicHandles follows the constraints (Solver.cs:1025, 1368-1377): a kinematic body whose last constraint goes is integrated as an
+    unconstrained body from then on (once per frame, not per substep), and per substep again when a constraint comes back. On the island layout the plan's own list of
+    constrained kinematic bodies has to follow (bepu_soft_updates.h, kin_uses) — the context stays on the island schedule throughout."""
+    rng = np.random.default_rng(77)
+    rows = [small_scenes.random_dynamic_body(rng, rng.uniform(-3, 3, 3)) for _ in range(60)] + [small_scenes.kinematic_body(rng, rng.uniform(-3, 3, 3), angular=(0.3, 0.1, 0.25)) for _ in range(2)]
+    ms = MutableSolver(np.stack(rows))
+    for k in range(0, 58, 2):
+        ms.add(7, [k, k + 1], small_scenes.prestep_for(rng, 7, ms.bodies[k, 4:7], ms.bodies[k + 1, 4:7]))
+    for k, kin in ((3, 60), (8, 60), (20, 61)):
+        ms.add(5, [k, kin], small_scenes.prestep_for(rng, 5, ms.bodies[k, 4:7], ms.bodies[kin, 4:7]))
+    sd, cb = SolveDescription(1, 4), PoseIntegratorCallbacks()
+    solver = hip_solver_factory(reserve_update_slots=True)
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+
+    def frames(n):
+        for _ in range(n):
+            export = ms.to_scene()
+            kin = np.ascontiguousarray(export.constrained_kinematic_indices(), dtype=np.int32)  # the caller re-sends the set when it changes
+            solver.set_constrained_kinematics(kin)
+            oracle_ffi.solve(export, 1 / 60, sd, cb)
+            ms.absorb(export)
+            solver.solve(1 / 60, sd, cb)
+            got = ms.to_scene()
+            solver.download(got)
+            m = pu.compare_scenes(export, got)
+            assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+        assert solver.schedule() == 1
+
+    frames(2)
+    loc = [(bi, t, i) for bi, t, i in ms.locations(lambda t: t == 5) if (ms.batches[bi][t]["refs"][i][1] & 0x3FFFFFFF) == 61]
+    assert len(loc) == 1
+    lane = list(ms.batches[loc[0][0]][5]["prestep"][loc[0][2]])
+    ms.remove(*loc[0])
+    solver.remove_constraint(*loc[0])
+    assert 61 not in ms.kinematic_constrained
+    frames(3)  # body 61 is an unconstrained kinematic body now
+    bi, index, encoded = ms.add(5, [20, 61], lane)
+    assert solver.add_constraint(bi, 5, encoded, lane) == index
+    frames(3)

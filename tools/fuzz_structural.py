@@ -23,7 +23,7 @@ TYPES = [4, 5, 6, 7, 22, 25, 30, 47, 0, 3, 23, 46]  # two-body manifolds and joi
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
 scenes = frames_total = bad = stayed = refused = 0
-split_scenes = split_stayed = 0
+split_scenes = split_stayed = replans = 0
 while time.time() < t_end:
     big = rng.random() < 0.3  # one island no workgroup holds: the split-island plan (two-body types and one-body manifolds; forced cluster counts so that small scenes split too)
     nb = int(rng.integers(1500, 3500)) if big else int(rng.integers(30, 400))
@@ -58,6 +58,7 @@ while time.time() < t_end:
     solver = HipSolver(use_clusters=bool(rng.random() < 0.8), reserve_update_slots=bool(rng.integers(2)))
     solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
     ok = True
+    replanned_at = []
     for frame in range(int(rng.integers(3, 12))):
       try:
           for _ in range(int(rng.integers(0, 8))):
@@ -69,6 +70,10 @@ while time.time() < t_end:
               solver.remove_constraint(bi, t, i)
           for _ in range(int(rng.integers(0, 8))):
               add_random(solver)
+          if rng.random() < 0.15:  # now and then a fresh plan for what the device holds (bepuhip_replan), whatever schedule the context is on
+              solver.replan()
+              replans += 1
+              replanned_at.append(frame)
           export = ms.to_scene()
           kin = np.ascontiguousarray(export.constrained_kinematic_indices(), dtype=np.int32)  # Solver.ConstrainedKinematicHandles changes with the constraints: the caller re-sends it
           native._check(solver.lib, solver.lib.bepuhip_set_constrained_kinematics(solver.ctx, native._ptr(kin), kin.size))
@@ -83,7 +88,8 @@ while time.time() < t_end:
               ok = False
               cols = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 13, 14]
               rows = np.flatnonzero((export.bodies[:, cols].view(np.int32) != got.bodies[:, cols].view(np.int32)).any(axis=1))
-              print("MISMATCH", nb, nc, sub, frame, m, "bodies", rows[:8], "kinematic", [ms.is_kinematic(int(r)) for r in rows[:8]], flush=True)
+              print("MISMATCH", nb, nc, sub, frame, m, "bodies", rows[:8], "kinematic", [ms.is_kinematic(int(r)) for r in rows[:8]], "in the caller's constrained-kinematic list", [int(r) in set(kin.tolist()) for r in rows[:8]],
+                    "schedule", solver.schedule(), "re-planned before frames", replanned_at, flush=True)
               break
       except UnsupportedError:  # an addition that lands in the sequential fallback batch: refused by design, the scene ends here
         refused += 1
@@ -94,5 +100,5 @@ while time.time() < t_end:
     solver.close()
     scenes += 1
     bad += not ok
-print(f"scenes {scenes} ({split_scenes} big enough for a split-island plan, {split_stayed} of them still on it at the end), frames {frames_total}, still on an island schedule at the end {stayed}, "
+print(f"re-plans {replans}; scenes {scenes} ({split_scenes} big enough for a split-island plan, {split_stayed} of them still on it at the end), frames {frames_total}, still on an island schedule at the end {stayed}, "
       f"ended by a refused fallback-batch addition {refused}, mismatching scenes {bad}")

@@ -104,6 +104,18 @@ for label, env in (("split plan keeps the updates", {}), ("round 2: updates leav
     finite = bool(np.isfinite(solver.get_bodies(scene.body_count)).all())
     print(f"{name}, {label}: {calls} structural calls per frame {calls_ms:.2f} ms (through ctypes), the flush + solve that follows {frame_ms:.3f} ms; the solve alone afterwards {solve_ms:.4f} ms; "
           f"clusters {solver.cluster_cycles().size}; finite {finite}", flush=True)
+    if solver.schedule() == 0:  # what bepuhip_replan costs and gives back
+        t0 = time.perf_counter()
+        solver.replan()
+        replan_ms = 1e3 * (time.perf_counter() - t0)
+        for _ in range(20):
+            solver.solve(1 / 60, sd, cb, asynchronous=True)
+        solver.sync()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            solver.solve(1 / 60, sd, cb, asynchronous=True)
+        solver.sync()
+        print(f"{name}: bepuhip_replan {replan_ms:.1f} ms -> schedule {solver.schedule()}, solve {1e3 * (time.perf_counter() - t0) / 50:.4f} ms", flush=True)
     solver.close()
     for k in env:
         os.environ.pop(k, None)
