@@ -358,18 +358,55 @@ struct ClusterGate {
 };
 
 
-// The gate of three- and four-body constraints: same wait, then the velocities of all N bodies.
-template <int ACCESS, int N, bool CROSS>
+// acquire_shared for the N bodies of a three- or four-body constraint.
+template <int N>
+__device__ __forceinline__ void acquire_shared_many(const ClusterShared& sh, const SharedRef* s, DBody* b, int kind, int k) {
+    bool need[N];
+    bool any = false;
+    _Pragma("unroll") for (int j = 0; j < N; ++j) { need[j] = s[j].poll; any |= need[j]; }
+    if (__builtin_amdgcn_ballot_w64(any) == 0) return;
+    unsigned spins = 0;
+    for (;;) {
+        any = false;
+        _Pragma("unroll") for (int j = 0; j < N; ++j) {
+            if (need[j]) {
+                float4 l, w;
+                load_agent_pair(shared_record(sh.st, s[j].body, sh.events - 1u), l, w);
+                if (__float_as_uint(l.w) == __float_as_uint(w.w) && __float_as_uint(l.w) >= s[j].number) { b[j].vel.lin = {l.x, l.y, l.z}; b[j].vel.ang = {w.x, w.y, w.z}; need[j] = false; }
+            }
+            any |= need[j];
+        }
+        const unsigned long long late = __builtin_amdgcn_ballot_w64(any);
+        if (late == 0) break;
+        for (int nap = 0; nap < sh.st.poll_sleep; ++nap) __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit) {
+            int body = -1; unsigned want = 0u;
+            _Pragma("unroll") for (int j = 0; j < N; ++j) if (need[j]) { body = s[j].body; want = s[j].number; }
+            const int first = (int)__builtin_ctzll(late);
+            report_stall(sh.status, *sh.counter, kind, k, __builtin_amdgcn_readlane(body, first), __builtin_amdgcn_readlane((int)want, first), 0u);
+            break;
+        }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
+    }
+}
+// The gate of three- and four-body constraints: same wait, then the velocities of all N bodies (SHARED: shared bodies as in ClusterGate — from the LDS slot when the
+// application before this one ran in this cluster, from the body's record otherwise).
+template <int ACCESS, int N, bool CROSS, bool SHARED>
 struct ClusterGateMany {
     static constexpr bool kPin = true;
-    const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; const int* refs; DBody* b;
+    const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; const int* refs; DBody* b; const SharedRef* s;
     __device__ __forceinline__ void many(BodyVel* vel) const {
         wait_predecessors<CROSS>(sh, it, h, k, epoch);
         __builtin_amdgcn_s_setprio(3);
-        _Pragma("unroll") for (int j = 0; j < N; ++j) { load_velocity_lds<ACCESS>(sh, refs[j], b[j]); vel[j] = b[j].vel; }
+        _Pragma("unroll") for (int j = 0; j < N; ++j) load_velocity_lds<ACCESS>(sh, refs[j], b[j]);
+        if constexpr (SHARED) {
+            _Pragma("unroll") for (int j = 0; j < N; ++j) if (s[j].shared() && !s[j].poll) load_velocity_lds<kLin | kAng>(sh, refs[j], b[j]);
+            acquire_shared_many<N>(sh, s, b, 6, k);
+        }
+        _Pragma("unroll") for (int j = 0; j < N; ++j) vel[j] = b[j].vel;
     }
 };
-template <class F, int STAGE>
+template <class F, int STAGE, bool SHARED>
 __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
                                                             unsigned* __restrict__ slab, float dt, float inv_dt) {
     constexpr int N = F::bodies;
@@ -380,10 +417,18 @@ __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared&
     gfloat* accum = (gfloat*)(slab + h.accum_off);
     float p[F::prestepFloats], a[F::impulseFloats];
     int refs[N];
+    SharedRef s[N];
     _Pragma("unroll") for (int j = 0; j < N; j += 2) {
         const unsigned w = (unsigned)lrefs[(size_t)(j / 2) * stride + i];
         refs[j] = unpack_local_ref(w & 0xFFFFu);
         if (j + 1 < N) refs[j + 1] = unpack_local_ref(w >> 16);
+        s[j] = SharedRef{-1, 0u, false, false};
+        if (j + 1 < N) s[j + 1] = SharedRef{-1, 0u, false, false};
+        if constexpr (SHARED) {  // rank | degree << 8 | hand-off flags of this application on each shared body: the rows right behind the local references
+            const gint* srank = lrefs + (size_t)((N + 1) / 2) * stride;
+            s[j] = make_shared_ref<false>(sh, w & 0xFFFFu, (unsigned)srank[(size_t)j * stride + i], active);
+            if (j + 1 < N) s[j + 1] = make_shared_ref<false>(sh, w >> 16, (unsigned)srank[(size_t)(j + 1) * stride + i], active);
+        }
     }
     _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
     _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i];
@@ -393,10 +438,17 @@ __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared&
         load_body_lds<F::access & ~(kLin | kAng)>(sh, refs[j], b[j]);
         pos[j] = b[j].pos; inverseMass[j] = b[j].inertia.invMass; vel[j] = b[j].vel;
     }
-    ClusterGateMany<F::access, N, STAGE == kStageSolve> gate{sh, it, h, k, epoch, refs, b};
+    ClusterGateMany<F::access, N, STAGE == kStageSolve, SHARED> gate{sh, it, h, k, epoch, refs, b, s};
     if (STAGE == kStageWarmStart) F::warmStartN(pos, inverseMass, p, a, vel, gate);
     else F::solveN(pos, inverseMass, dt, inv_dt, p, a, vel, gate);
-    _Pragma("unroll") for (int j = 0; j < N; ++j) { b[j].vel = vel[j]; store_velocity_lds<F::access>(sh, active ? refs[j] : -1, b[j]); }
+    _Pragma("unroll") for (int j = 0; j < N; ++j) {
+        b[j].vel = vel[j];
+        store_velocity_lds<F::access>(sh, (active && !s[j].shared()) ? refs[j] : -1, b[j]);
+        if constexpr (SHARED) {  // as in run_cluster_constraint: to the LDS slot when the next application runs here, into the record otherwise
+            store_velocity_lds<kLin | kAng>(sh, (s[j].shared() && !s[j].publish) ? refs[j] : -1, b[j]);
+            release_shared(sh, s[j], b[j]);
+        }
+    }
     publish_item(sh.flags + k, sh.batch_done + h.batch, epoch);
     __builtin_amdgcn_s_setprio(0);
     if (STAGE == kStageSolve && active) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) accum[(size_t)f * stride + i] = a[f]; }
@@ -513,7 +565,7 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
                         if constexpr (WIDE) {  // SURVEY 8(f) types live in a second kernel variant: scenes made of the sixteen hot-path types keep the leaner one
                             switch (h.type_id) {
                                 BD_WIDENED_JOINT_TYPES(BEPU_CASE)
-#define BEPU_CASE_MANY(ID, F) case ID: run_cluster_constraint_many<F, STAGE>(sh, it, h, k, lane, epoch, slab, dt, inv_dt); break;
+#define BEPU_CASE_MANY(ID, F) case ID: run_cluster_constraint_many<F, STAGE, SHARED>(sh, it, h, k, lane, epoch, slab, dt, inv_dt); break;
                                 BD_MANY_BODY_TYPES(BEPU_CASE_MANY)
 #undef BEPU_CASE_MANY
                                 default: break;

@@ -472,7 +472,8 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
 // (they wait for each other), so the plan is refused (global path) when it needs more clusters than the device has CUs.
 static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe) {
     if (env_int("BEPUHIP_NO_SPLIT", 0)) return;
-    for (auto& tb : c->tbs) if (tb.info.bodies > 2) return;  // three- and four-body constraints keep to whole islands
+    if (env_int("BEPUHIP_SPLIT_MANY_BODY", 1) == 0)
+        for (auto& tb : c->tbs) if (tb.info.bodies > 2) return;  // (round 2: three- and four-body constraints kept to whole islands)
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
@@ -485,25 +486,22 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                 const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
                 if ((uint32_t)r < kDynamicLimit) { is_dyn[r] = 1; ++deg[r]; }
             }
+    // (a three- or four-body constraint links its bodies in a chain: body slot k with k + 1)
+    auto for_each_edge = [&](auto&& fn) {
+        for (auto& tb : c->tbs)
+            for (int k = 0; k + 1 < tb.info.bodies; ++k)
+                for (int i = 0; i < tb.count; ++i) {
+                    const int32_t a = tb.refs_soa[(size_t)k * tb.stride + i], b = tb.refs_soa[(size_t)(k + 1) * tb.stride + i];
+                    if ((uint32_t)a < kDynamicLimit && (uint32_t)b < kDynamicLimit) fn(a, b);
+                }
+    };
     std::vector<int64_t> adj_begin(universe + 1, 0);
-    for (auto& tb : c->tbs) {
-        if (tb.info.bodies != 2) continue;
-        for (int i = 0; i < tb.count; ++i) {
-            const int32_t a = tb.refs_soa[i], b = tb.refs_soa[(size_t)tb.stride + i];
-            if ((uint32_t)a < kDynamicLimit && (uint32_t)b < kDynamicLimit) { ++adj_begin[a + 1]; ++adj_begin[b + 1]; }
-        }
-    }
+    for_each_edge([&](int32_t a, int32_t b) { ++adj_begin[a + 1]; ++adj_begin[b + 1]; });
     for (int i = 0; i < universe; ++i) adj_begin[i + 1] += adj_begin[i];
     std::vector<int32_t> adj(adj_begin[universe]);
     {
         std::vector<int64_t> fill(adj_begin.begin(), adj_begin.end() - 1);
-        for (auto& tb : c->tbs) {
-            if (tb.info.bodies != 2) continue;
-            for (int i = 0; i < tb.count; ++i) {
-                const int32_t a = tb.refs_soa[i], b = tb.refs_soa[(size_t)tb.stride + i];
-                if ((uint32_t)a < kDynamicLimit && (uint32_t)b < kDynamicLimit) { adj[fill[a]++] = b; adj[fill[b]++] = a; }
-            }
-        }
+        for_each_edge([&](int32_t a, int32_t b) { adj[fill[a]++] = b; adj[fill[b]++] = a; });
     }
     int64_t total_dyn = 0;
     for (int i = 0; i < universe; ++i) total_dyn += is_dyn[i];

@@ -23,8 +23,8 @@ t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
 n = bad = split = batch_path = refused = 0
 while time.time() < t_end:
     seed = int(rng.integers(1 << 30))
-    big = rng.random() < 0.15  # large enough for a split-island plan (two-body types only: the plan declines the others)
-    pool = TWO_BODY if big else ALL
+    big = rng.random() < 0.15  # large enough for a split-island plan (every type id since round 3: three- and four-body constraints are split too)
+    pool = ALL
     types = [int(t) for t in rng.choice(pool, size=int(rng.integers(1, 10)), replace=False)]
     nb, nc = (int(rng.integers(3000, 7000)), int(rng.integers(6000, 16000))) if big else (int(rng.integers(20, 600)), int(rng.integers(10, 2500)))
     kin = float(rng.choice([0, 0.05, 0.3]))

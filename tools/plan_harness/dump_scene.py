@@ -1,4 +1,4 @@
-"""Writes a scene in the plan harness's binary format:  python tools/plan_harness/dump_scene.py <pile|ragdoll_tube|crowd|graph> <out.bin> [size]"""
+"""Writes a scene in the plan harness's binary format:  python tools/plan_harness/dump_scene.py <pile|ragdoll_tube|crowd|graph|graph44> <out.bin> [size]"""
 import os
 import sys
 
@@ -8,7 +8,10 @@ import numpy as np
 
 kind, out = sys.argv[1], sys.argv[2]
 size = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-if kind == "graph":
+if kind == "graph44":  # every constraint type id, three- and four-body ones included
+    import small_scenes
+    scene = small_scenes.random_graph_scene(7, size or 6000, (size or 6000) * 2, sorted(small_scenes.TYPE_TABLE))
+elif kind == "graph":
     import small_scenes
     scene = small_scenes.random_graph_scene(7, size or 6000, (size or 6000) * 2, sorted(t for t, i in small_scenes.TYPE_TABLE.items() if i[0] <= 2))
 else:
