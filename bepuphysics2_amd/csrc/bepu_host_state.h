@@ -155,6 +155,7 @@ struct bepuhip_ctx {
     bool structure_dirty = false;        // counts changed: descriptors, constrained flags and cached graphs are stale until flush_structural
     bool requirk_stale = false;          // the conserving angular modes' substep-0 lists describe the uploaded topology only
     std::vector<HostTypeBatch> tbs;
+    std::unordered_map<uint64_t, int> tb_lookup;  // (batch, type id) -> ordinal in `tbs`: a cache, every hit is checked against the type batch it names
     std::vector<int> batch_begin;        // descriptor index of each launch's first type batch (size launch_count+1)
     std::vector<int> batch_blocks;       // grid size per launch
     uint32_t* d_slab = nullptr;          // all refs/prestep/accum
@@ -180,8 +181,9 @@ struct bepuhip_ctx {
     std::vector<ClusterDesc> clusters_host;
     std::vector<uint8_t> cluster_degraded;
     struct SoftSlot { bool live; std::vector<uint32_t> payload; };  // final state of a device slot touched since the last flush (payload: refs, packed local refs, prestep)
-    std::map<std::pair<int, int>, SoftSlot> soft_slots;              // (type batch ordinal, device slot)
-    std::map<std::pair<int, int>, int> soft_index;                   // (type batch ordinal, caller's index) -> device slot
+    struct PairHash { size_t operator()(const std::pair<int, int>& p) const { return std::hash<uint64_t>()(((uint64_t)(uint32_t)p.first << 32) | (uint32_t)p.second); } };
+    std::unordered_map<std::pair<int, int>, SoftSlot, PairHash> soft_slots;  // (type batch ordinal, device slot)
+    std::unordered_map<std::pair<int, int>, int, PairHash> soft_index;       // (type batch ordinal, caller's index) -> device slot
     std::vector<int32_t> soft_orphans;           // bodies whose constraint count reached zero since the last flush
     bool soft_items_dirty = false;
     int64_t soft_adds = 0, soft_removes = 0;     // since the upload (diagnostics)
@@ -197,7 +199,7 @@ struct bepuhip_ctx {
     std::vector<size_t> split_visit;                                  // order in which the type batches become a cluster's items
     struct SplitApp { int32_t tb, slot, k; };
     std::vector<std::vector<SplitApp>> body_apps;
-    std::set<int32_t> split_rerank;
+    std::unordered_set<int32_t> split_rerank;
     // A word of the split plan's device tables that differs from its host mirror until the next flush writes it (the VALUE is read from the mirror then: a slot may be
     // freed and taken again between the change and the flush). table: 0 constraint slab (both copies; tb / slot / row name the word), 1 shared_info, 2 cluster_bodies.
     struct WordPatch { int table; size_t index; int32_t tb, slot, row; };

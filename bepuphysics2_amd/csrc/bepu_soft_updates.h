@@ -172,6 +172,7 @@ static bool soft_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, con
     for (int s = tb->seg_begin[cl]; s < tb->seg_begin[cl + 1] && d < 0; ++s) if (tb->perm[s] < 0) d = s;
     if (d < 0) return soft_refuse("no free device slot in the cluster's segment of the type batch");
     bepuhip_ctx::SoftSlot slot{true, {}};
+    slot.payload.reserve(nb + 1 + tb->info.prestep);
     soft_ensure_kin_uses(c);
     for (int k = 0; k < nb; ++k) {
         slot.payload.push_back((uint32_t)refs[k]);
@@ -463,6 +464,7 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
         if (c->split_shared[r]) c->split_rerank.insert(r);
     }
     bepuhip_ctx::SoftSlot slot{true, {}};  // the prestep lane; references, local references and rank words are taken from the mirrors when the updates are flushed
+    slot.payload.reserve(tb->info.prestep);
     for (int f = 0; f < tb->info.prestep; ++f) { uint32_t w; memcpy(&w, &prestep[f], 4); slot.payload.push_back(w); }
     soft_ensure_kin_uses(c);
     for (int k = 0; k < nb; ++k) {

@@ -1465,7 +1465,11 @@ int32_t bepuhip_get_poses_and_velocities(bepuhip_ctx* c, void* body_dynamics_aos
 }
 
 static HostTypeBatch* find_tb(bepuhip_ctx* c, int batch, int type_id) {
-    for (auto& tb : c->tbs) if (tb.batch == batch && tb.type_id == type_id) return &tb;
+    const uint64_t key = ((uint64_t)(uint32_t)batch << 32) | (uint32_t)type_id;
+    auto hit = c->tb_lookup.find(key);
+    if (hit != c->tb_lookup.end() && (size_t)hit->second < c->tbs.size() && c->tbs[hit->second].batch == batch && c->tbs[hit->second].type_id == type_id) return &c->tbs[hit->second];
+    for (size_t t = 0; t < c->tbs.size(); ++t)
+        if (c->tbs[t].batch == batch && c->tbs[t].type_id == type_id) { c->tb_lookup[key] = (int)t; return &c->tbs[t]; }
     return nullptr;
 }
 static int32_t download_aosoa(bepuhip_ctx* c, HostTypeBatch* tb, size_t off, int fields, float* out) {
@@ -1641,8 +1645,8 @@ static int32_t structural_preamble(bepuhip_ctx* c, bool stay = false) {
     if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
     if (c->building) return fail(BEPUHIP_E_STATE, "structural update between begin_constraints and end_constraints");
     if (c->has_fallback) return fail(BEPUHIP_E_UNSUPPORTED, "structural updates with a sequential fallback batch: re-upload with begin/set/end");
+    if (stay && c->soft_ok) return BEPUHIP_OK;  // bookkeeping on the host only: no device call on this path (a structural call per changed contact per frame)
     HIP_TRY(hipSetDevice(c->device));
-    if (stay && c->soft_ok) return BEPUHIP_OK;
     return leave_island_schedule(c);
 }
 
@@ -1673,6 +1677,7 @@ int32_t bepuhip_add_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, c
         }
         if (violation) return fail(BEPUHIP_E_INVALID_ARGUMENT, "a dynamic body of the new constraint is already referenced in this batch (a body appears at most once per synchronized batch, Solver.cs:1046-1051)");
         if (!tb) soft_refuse("the new constraint opens a type batch");
+        HIP_TRY(hipSetDevice(c->device));
         if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;
         tb = find_tb(c, batch, type_id);
     }
@@ -1720,6 +1725,7 @@ int32_t bepuhip_remove_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id
     if (c->soft_ok) {  // on the island layout: the slot is freed where it is, the caller's indices are remapped
         SoftCallTimer timer(c);
         if (soft_remove(c, tb, index)) { c->requirk_stale = true; return BEPUHIP_OK; }
+        HIP_TRY(hipSetDevice(c->device));
         if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;
         tb = find_tb(c, batch, type_id);
     }
