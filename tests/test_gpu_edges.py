@@ -273,3 +273,30 @@ def test_launch_policy_is_measured_and_never_changes_a_result(hip_solver_factory
     second.upload(scene.copy())
     second.solve(1 / 60, sd, cb)
     assert second.row_policy() == settled
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_replan_keeps_a_sequential_fallback_batch_and_the_results(hip_solver_factory, mode):
+    """bepuhip_replan on a context whose last batch is the sequential fallback batch (empty lanes inside its bundles, dependency levels rebuilt from the references read
+    back) and, with mode 1, in a momentum-conserving angular mode (the substep-0 lists are rebuilt by the next solve): frames before + re-plan + frames after equal the
+    oracle's frames bit for bit, and read-backs in the caller's order are unchanged by the call."""
+    threshold = 5
+    scene = small_scenes.star_scene(4, spokes=40, hubs=2, fallback_batch_threshold=threshold)
+    assert len(scene.batches) == threshold + 1
+    sd, cb = SolveDescription(2, 3, fallback_batch_threshold=threshold), PoseIntegratorCallbacks(angular_integration_mode=mode)
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=4)
+    solver = hip_solver_factory()
+    got = scene.copy()
+    solver.upload(got, threshold)
+    for _ in range(2):
+        solver.solve(1 / 60, sd, cb)
+    before = scene.copy()
+    solver.download(before)
+    solver.replan()
+    after = scene.copy()
+    solver.download(after)
+    _bit_exact(before, after)
+    for _ in range(2):
+        solver.solve(1 / 60, sd, cb)
+    solver.download(got)
+    _bit_exact(ref, got)
