@@ -193,7 +193,7 @@ def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, s
 def widened_types_leg(ragdolls: int, device: int, steps: int = 100):
     """The widened constraint types on the driver line (never `value`): the bench scene's ragdolls — same bodies, same constraint graph, same batches — with the seven
     joint types other than BallSocket replaced by widened ones (synthetic.RIG_REMAP: AngularSwivelHinge, DistanceLimit, AngularServo, TwistMotor, AngularAxisMotor, Weld,
-    BallSocketServo; seeded random settings). Such a scene runs the second `cluster_kernel` variant (all 44 type ids compiled in; 512 threads per workgroup)."""
+    BallSocketServo; seeded random settings). Such a scene runs the second `cluster_kernel` variant (all 44 type ids compiled in)."""
     from bepuphysics2_amd.native import HipSolver
     from bepuphysics2_amd.scene import TYPE_TABLE, PoseIntegratorCallbacks
     from bepuphysics2_amd.synthetic import RIG_REMAP, rig_scene

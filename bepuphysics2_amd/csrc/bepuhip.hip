@@ -895,7 +895,9 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             Timed t(c, 5);
             // Waves per cluster: 16 by default (four per SIMD; 12 is as fast when memory latency is low, 8 is slower everywhere); BEPUHIP_CLUSTER_THREADS overrides.
             // Scenes with SURVEY 8(f) types take the 512-thread build: at 128 VGPRs per wave the widened types spill hundreds of registers.
-            const int req = env_int("BEPUHIP_CLUSTER_THREADS", c->has_widened_types ? kSplitClusterThreads : kClusterThreads);
+            // (the widened variant too: its 1024-thread build spills 700 VGPRs and is still the faster one — 0.222 against 0.325 ms on the bench graph with widened joints
+            // on the pool's slow class of box, 0.195 against 0.193 on the fast one, profiles/r03_s13_widened_slowbox.txt: sixteen waves hide what the scratch traffic costs)
+            const int req = env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
             const int threads = std::max(64, std::min(1024, (c->clusters_shared ? env_int("BEPUHIP_SPLIT_THREADS", kSplitClusterThreads) : req) / 64 * 64));
             const size_t launch_lds = lds_bytes;
             // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the

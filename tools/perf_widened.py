@@ -1,5 +1,5 @@
-"""Timings of scenes with the widened constraint types (GPU box; not part of the product): they run the second `cluster_kernel` variant (512 threads: its 1024-thread
-build spills 700 VGPRs).
+"""Timings of scenes with the widened constraint types (GPU box; not part of the product): they run the second `cluster_kernel` variant, by default with 1024 threads
+per workgroup like the lean one (its 1024-thread build spills 700 VGPRs and still beats the 512-thread build on the pool's slow class of box; both are timed here).
 * rigs: the bench scene's 15,000 ragdolls (same bodies, same constraint graph, same batches) with its seven joint types other than BallSocket replaced by widened ones
   (AngularSwivelHinge, DistanceLimit, AngularServo, TwistMotor, AngularAxisMotor, Weld, BallSocketServo; random settings) — type batches as long as the headline's;
 * all 44 type ids drawn at random in islands of 16 bodies with 64 constraints: 790 type batches, one or two constraints per cluster and type batch — the worst case
@@ -27,7 +27,7 @@ for label in ("rigs (the bench scene's graph, seven joint types widened)", "all 
     t0 = time.perf_counter()
     scene = rig_scene(ragdolls)[0] if label.startswith("rigs") else small_scenes.island_scene(11, islands, 16, 64, sorted(TYPE_TABLE))
     build_s = time.perf_counter() - t0
-    for threads in ("", "1024"):
+    for threads in ("", "512"):
         if threads:
             os.environ["BEPUHIP_CLUSTER_THREADS"] = threads
         solver = HipSolver(exclusive_device=True)
