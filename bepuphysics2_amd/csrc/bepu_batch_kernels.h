@@ -480,6 +480,13 @@ __global__ __launch_bounds__(64) void apply_soft_slots_kernel(unsigned* slab, co
     for (int f = 0; f < op.prestep; ++f) slab[op.prestep_off + (size_t)f * op.stride + op.slot] = *p++;
     for (int f = 0; f < op.impulse; ++f) slab[op.accum_off + (size_t)f * op.stride + op.slot] = 0u;
 }
+// Single bits of slab words (the conserving modes' marks on an island layout): set (1) or cleared (0); words that hold several marks are listed once per mark.
+struct BitMark { size_t word; unsigned mask; unsigned pad; };
+__global__ __launch_bounds__(256) void mark_bits_kernel(unsigned* slab, const BitMark* __restrict__ marks, int count, int set) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    if (set) atomicOr(&slab[marks[i].word], marks[i].mask); else atomicAnd(&slab[marks[i].word], ~marks[i].mask);
+}
 struct IndexPatch { int* table; int index, value, pad; };
 __global__ __launch_bounds__(64) void patch_index_kernel(const IndexPatch* __restrict__ patches, int count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -32,6 +32,13 @@ namespace {
 #ifndef BEPU_VARIANT_NT
 #define BEPU_VARIANT_NT 0
 #endif
+#ifndef BEPU_VARIANT_CONSERVING
+#define BEPU_VARIANT_CONSERVING 0
+#endif
+// Per translation unit: the momentum-conserving angular integration modes (PoseIntegrator.cs:193-253) compiled in. The hot variants stay as they are; a solve that asks
+// for such a mode launches the unit's twin that carries this code (the integration phase's angular step, and substep 0's second transformation of the bodies the
+// reference's conditionally integrating bundles transform twice — one bit per body slot of a constraint, set by the host, see build_requirk_lists).
+constexpr bool kConserving = BEPU_VARIANT_CONSERVING != 0;
 constexpr bool kRowsNonTemporal = BEPU_VARIANT_NT != 0;  // one- and two-body constraint rows loaded with the non-temporal hint (they stream: 70 MB per pass, no reuse)
 
 typedef __attribute__((address_space(1))) float gfloat;  // global
@@ -56,6 +63,13 @@ struct ClusterShared {
     int code_touch;        // see touch_code_ahead
     int code_touch_gate;   // ... a second touch (spans) from the gate on, issued before the wait for the predecessors
     unsigned scratch_row;  // LDS byte address of the 256-byte row that swallows the code-touch reads
+    // kConserving units only:
+    int substep;             // the substep the sweeps belong to
+    int angular_mode;        // 1 ConserveMomentum, 2 ConserveMomentumWithGyroscopicTorque
+    float substep_dt;
+    int plane_count;         // 8: the local inverse inertia is in planes 6, 7; 6: it stays in HBM
+    const int* slot_table;   // slot -> body index | flags (global)
+    const float4* bodies;
 };
 
 template <int ACCESS>
@@ -87,6 +101,34 @@ __device__ __forceinline__ void store_velocity_lds(const ClusterShared& sh, int 
     if (ACCESS & kAng) base[3 * sh.ncap] = make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, b.angw);
 }
 
+
+// Substep 0 of the conserving modes: the body's angular velocity goes through the mode's transformation once more right before this constraint's warm start
+// (momentum_requirk_kernel of the launch-per-batch schedule, applied by the lane that holds the body; TypeProcessor.cs:1264-1281).
+constexpr unsigned kLrefRequirk = 1u << 14;   // whole-island plans: in the 16-bit local reference (the bit split plans use for "shared")
+constexpr unsigned kRankRequirk = 1u << 18;   // split plans: in the rank word
+__device__ __forceinline__ V3 requirk_angular_velocity(const ClusterShared& sh, int lref, V3 ang) {
+    const int slot = lref & kRefMask;
+    const float4 q4 = sh.planes[slot];
+    float4 i0, i1;
+    if (sh.plane_count == kAllPlanes) { i0 = sh.planes[6 * sh.ncap + slot]; i1 = sh.planes[7 * sh.ncap + slot]; }
+    else { const int body = sh.slot_table[slot] & kSlotBodyMask; i0 = sh.bodies[(size_t)body * 8 + 4]; i1 = sh.bodies[(size_t)body * 8 + 5]; }
+    const Q ori = {q4.x, q4.y, q4.z, q4.w};
+    const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+    if (sh.angular_mode == 1) {
+        const Sym3 world = rotateInverseInertia(local, ori);
+        const Q previousOrientation = integrateOrientation(ori, ang, sh.substep_dt * -0.5f);
+        return integrateAngularVelocityConserveMomentum(previousOrientation, local, world, ang);
+    }
+    return integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, ang, sh.substep_dt);
+}
+
+// ... on a private body: in place in its LDS slot, whatever part of the velocity the constraint type itself reads (the lane owns the body once its predecessors are done).
+__device__ __forceinline__ void requirk_in_lds(const ClusterShared& sh, int lref) {
+    float4* angular = sh.planes + 3 * sh.ncap + (lref & kRefMask);
+    const float4 a4 = *angular;
+    const V3 ang = requirk_angular_velocity(sh, lref, {a4.x, a4.y, a4.z});
+    *angular = make_float4(ang.x, ang.y, ang.z, a4.w);
+}
 
 // Local body references travel as 16-bit halves (slot | kinematic << 15); the gather / scatter helpers take the 32-bit form (slot | kinematic << 30).
 __device__ __forceinline__ int unpack_local_ref(unsigned half) { return (int)((half & 0x3FFFu) | ((half & 0x8000u) << 15)); }  // bit 14: kLrefShared
@@ -338,11 +380,16 @@ struct ClusterGate {
     static constexpr bool kPin = true;  // the constraint pins its velocity-independent values before calling: they are computed while the predecessors still run
     const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; int ra, rb; DBody& A; DBody& B; ItemStamps& stamps;
     const SharedRef& sa; const SharedRef& sb;
+    bool requirk_a, requirk_b;  // kConserving units, warm start of substep 0
     __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {
         if (TRACE) stamps.pre_gate = __builtin_readcyclecounter();
         if (sh.code_touch_gate) touch_code_span(sh, threadIdx.x & 63, sh.code_touch_gate);
         wait_predecessors<CROSS>(sh, it, h, k, epoch);
         __builtin_amdgcn_s_setprio(3);  // from here to the publish the item is on its bodies' critical path: issue ahead of waves still preparing theirs
+        if constexpr (kConserving && !CROSS) {
+            if (requirk_a && !sa.shared()) requirk_in_lds(sh, ra);
+            if (BODIES == 2 && requirk_b && !sb.shared()) requirk_in_lds(sh, rb);
+        }
         load_velocity_lds<ACC_A>(sh, ra, A);
         if (BODIES == 2) load_velocity_lds<ACC_B>(sh, rb, B);
         if constexpr (SHARED) {
@@ -352,6 +399,10 @@ struct ClusterGate {
             if (BODIES == 2 && sb.shared() && !sb.poll) load_velocity_lds<kLin | kAng>(sh, rb, B);
             // bodies other clusters also touch: our turn comes when the body's record carries this application's event number (the velocity comes with it)
             acquire_shared<BODIES == 2>(sh, sa, A, sb, B, 6, k);
+        }
+        if constexpr (kConserving && !CROSS && SHARED) {  // a shared body's velocity is whole in A / B by now (from its record, or from the LDS slot) and leaves whole
+            if (requirk_a && sa.shared()) A.vel.ang = requirk_angular_velocity(sh, ra, A.vel.ang);
+            if (BODIES == 2 && requirk_b && sb.shared()) B.vel.ang = requirk_angular_velocity(sh, rb, B.vel.ang);
         }
         if (TRACE) stamps.post_gate = __builtin_readcyclecounter();
     }
@@ -394,14 +445,20 @@ __device__ __forceinline__ void acquire_shared_many(const ClusterShared& sh, con
 template <int ACCESS, int N, bool CROSS, bool SHARED>
 struct ClusterGateMany {
     static constexpr bool kPin = true;
-    const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; const int* refs; DBody* b; const SharedRef* s;
+    const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; const int* refs; DBody* b; const SharedRef* s; const bool* requirk;
     __device__ __forceinline__ void many(BodyVel* vel) const {
         wait_predecessors<CROSS>(sh, it, h, k, epoch);
         __builtin_amdgcn_s_setprio(3);
+        if constexpr (kConserving && !CROSS) {
+            _Pragma("unroll") for (int j = 0; j < N; ++j) if (requirk[j] && !s[j].shared()) requirk_in_lds(sh, refs[j]);
+        }
         _Pragma("unroll") for (int j = 0; j < N; ++j) load_velocity_lds<ACCESS>(sh, refs[j], b[j]);
         if constexpr (SHARED) {
             _Pragma("unroll") for (int j = 0; j < N; ++j) if (s[j].shared() && !s[j].poll) load_velocity_lds<kLin | kAng>(sh, refs[j], b[j]);
             acquire_shared_many<N>(sh, s, b, 6, k);
+        }
+        if constexpr (kConserving && !CROSS && SHARED) {
+            _Pragma("unroll") for (int j = 0; j < N; ++j) if (requirk[j] && s[j].shared()) b[j].vel.ang = requirk_angular_velocity(sh, refs[j], b[j].vel.ang);
         }
         _Pragma("unroll") for (int j = 0; j < N; ++j) vel[j] = b[j].vel;
     }
@@ -418,16 +475,26 @@ __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared&
     float p[F::prestepFloats], a[F::impulseFloats];
     int refs[N];
     SharedRef s[N];
+    bool requirk[N];
+    const bool first_warm_start = kConserving && STAGE == kStageWarmStart && sh.substep == 0;
     _Pragma("unroll") for (int j = 0; j < N; j += 2) {
         const unsigned w = (unsigned)lrefs[(size_t)(j / 2) * stride + i];
         refs[j] = unpack_local_ref(w & 0xFFFFu);
         if (j + 1 < N) refs[j + 1] = unpack_local_ref(w >> 16);
         s[j] = SharedRef{-1, 0u, false, false};
         if (j + 1 < N) s[j + 1] = SharedRef{-1, 0u, false, false};
+        requirk[j] = !SHARED && first_warm_start && active && (w & kLrefRequirk) != 0 && (w & 0x8000u) == 0;
+        if (j + 1 < N) requirk[j + 1] = !SHARED && first_warm_start && active && ((w >> 16) & kLrefRequirk) != 0 && (w & 0x80000000u) == 0;
         if constexpr (SHARED) {  // rank | degree << 8 | hand-off flags of this application on each shared body: the rows right behind the local references
             const gint* srank = lrefs + (size_t)((N + 1) / 2) * stride;
-            s[j] = make_shared_ref<false>(sh, w & 0xFFFFu, (unsigned)srank[(size_t)j * stride + i], active);
-            if (j + 1 < N) s[j + 1] = make_shared_ref<false>(sh, w >> 16, (unsigned)srank[(size_t)(j + 1) * stride + i], active);
+            const unsigned rank_j = (unsigned)srank[(size_t)j * stride + i];
+            s[j] = make_shared_ref<false>(sh, w & 0xFFFFu, rank_j, active);
+            requirk[j] = first_warm_start && active && (rank_j & kRankRequirk) != 0;
+            if (j + 1 < N) {
+                const unsigned rank_j1 = (unsigned)srank[(size_t)(j + 1) * stride + i];
+                s[j + 1] = make_shared_ref<false>(sh, w >> 16, rank_j1, active);
+                requirk[j + 1] = first_warm_start && active && (rank_j1 & kRankRequirk) != 0;
+            }
         }
     }
     _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
@@ -438,7 +505,7 @@ __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared&
         load_body_lds<F::access & ~(kLin | kAng)>(sh, refs[j], b[j]);
         pos[j] = b[j].pos; inverseMass[j] = b[j].inertia.invMass; vel[j] = b[j].vel;
     }
-    ClusterGateMany<F::access, N, STAGE == kStageSolve, SHARED> gate{sh, it, h, k, epoch, refs, b, s};
+    ClusterGateMany<F::access, N, STAGE == kStageSolve, SHARED> gate{sh, it, h, k, epoch, refs, b, s, requirk};
     if (STAGE == kStageWarmStart) F::warmStartN(pos, inverseMass, p, a, vel, gate);
     else F::solveN(pos, inverseMass, dt, inv_dt, p, a, vel, gate);
     _Pragma("unroll") for (int j = 0; j < N; ++j) {
@@ -517,7 +584,14 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     load_body_lds<accA & ~(kLin | kAng)>(sh, ra, A);
     if (F::bodies == 2) load_body_lds<accB & ~(kLin | kAng)>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
     if (TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps.loaded = __builtin_readcyclecounter(); }
-    ClusterGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE, SHARED> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps, sa, sb};
+    bool requirk_a = false, requirk_b = false;
+    if constexpr (kConserving && STAGE == kStageWarmStart) {
+        if (sh.substep == 0 && active) {
+            requirk_a = SHARED ? (rank_a & kRankRequirk) != 0 : ((both & kLrefRequirk) != 0 && (both & 0x8000u) == 0);
+            requirk_b = F::bodies == 2 && (SHARED ? (rank_b & kRankRequirk) != 0 : (((both >> 16) & kLrefRequirk) != 0 && (both & 0x80000000u) == 0));
+        }
+    }
+    ClusterGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE, SHARED> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps, sa, sb, requirk_a, requirk_b};
     if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, gate);
     else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, gate);
     // -1: never stored (same rule as kinematic / empty references). A shared body's velocity goes to the LDS slot only when the next application on it runs in this
@@ -667,12 +741,14 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     int* slot_body_lds = reinterpret_cast<int*>(words + ((cluster_sync_words(max_items) + 3) / 4) * 4);  // SHARED plans: behind the sync words
     sh.slot_body = slot_body_lds;
     sh.code_touch = cp.code_touch; sh.code_touch_gate = cp.code_touch_gate;
+    sh.substep = 0; sh.angular_mode = cp.sp.angular_mode; sh.substep_dt = cp.sp.dt; sh.plane_count = cp.planes; sh.bodies = bodies;
     sh.scratch_row = lds_address((const volatile lds_u32*)lds) + (unsigned)cluster_lds_core_bytes(cp.planes, ncap, max_items, SHARED);
     const ClusterDesc cd = clusters[blockIdx.x];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
     const float dt = cp.sp.dt, inv_dt = cp.sp.inv_dt;
     const int* slots = cluster_bodies + cd.body_begin;  // slot -> body index (bit 30: kinematic, private read-only copy; -1: unused slot)
+    sh.slot_table = slots;
     // ---- stage the cluster in LDS: bodies (one plane per 16-byte field), work items, batch -> item ranges; clear the sync words ----
     for (int j = tid; j < cd.slot_count * cp.planes; j += blockDim.x) {
         const int slot = j / cp.planes, v = j - slot * cp.planes;
@@ -737,6 +813,15 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 Sym3 world = rotateInverseInertia(local, ori);
                 r[4 * ncap] = make_float4(world.xx, world.yx, world.yy, world.zx);
                 r[5 * ncap] = make_float4(world.zy, world.zz, i1.z, r[5 * ncap].w);
+                if constexpr (kConserving) {  // substep_integrate_dynamic's angular step (TypeProcessor.cs:1224-1238, 1264-1272); a ghost's velocity belongs to its home
+                    if (!ghost) {
+                        const Q before = {q4.x, q4.y, q4.z, q4.w};  // substep > 0: the orientation the step started from; substep 0: "integrating backwards" from the current one
+                        if (cp.sp.angular_mode == 1)
+                            vel.ang = integrateAngularVelocityConserveMomentum(s > 0 ? before : integrateOrientation(ori, vel.ang, dt * -0.5f), local, world, vel.ang);
+                        else if (cp.sp.angular_mode == 2)
+                            vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, dt);
+                    }
+                }
                 if (!ghost) {
                     velocity_callback(cp.sp, vel);
                     r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
@@ -753,6 +838,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
             }
         }
         if constexpr (SHARED) sh.events = (unsigned)s + 1u;
+        sh.substep = s;
         __syncthreads();
         ++epoch;
         const int fused = cp.iters[s] > 0 ? cd.item_count : 0;  // the first velocity iteration rides in the warm start's claim sequence

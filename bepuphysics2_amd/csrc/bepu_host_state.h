@@ -22,9 +22,16 @@ const void* bepu_cluster_kernel_hot_768s(bool trace);
 const void* bepu_cluster_kernel_wide_768s(bool trace);
 const void* bepu_cluster_kernel_hot_512s(bool trace);
 const void* bepu_cluster_kernel_wide_512s(bool trace);
+const void* bepu_cluster_kernel_hot_1024c(bool trace);   // the momentum-conserving angular modes compiled in: whole-island plans at 1024 threads ...
+const void* bepu_cluster_kernel_wide_1024c(bool trace);
+const void* bepu_cluster_kernel_hot_512sc(bool trace);   // ... split-island plans at 512
+const void* bepu_cluster_kernel_wide_512sc(bool trace);
 constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
 static int cluster_variant_threads(int threads) { return threads > 768 ? 1024 : (threads > 512 ? 768 : 512); }  // the smallest budget that still fits `threads`
-static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false) {
+// The conserving units exist for the default workgroup sizes only; other sizes (BEPUHIP_CLUSTER_THREADS / BEPUHIP_SPLIT_THREADS) keep such solves on the launch-per-batch schedule.
+static bool conserving_variant_exists(int threads, bool shared) { return cluster_variant_threads(threads) == (shared ? 512 : 1024); }
+static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false, bool conserving = false) {
+    if (conserving) return shared ? (wide ? bepu_cluster_kernel_wide_512sc(trace) : bepu_cluster_kernel_hot_512sc(trace)) : (wide ? bepu_cluster_kernel_wide_1024c(trace) : bepu_cluster_kernel_hot_1024c(trace));
     if (nt && !shared && cluster_variant_threads(threads) == 1024) return wide ? bepu_cluster_kernel_wide_1024n(trace) : bepu_cluster_kernel_hot_1024n(trace);
     if (nt && shared && cluster_variant_threads(threads) == 512) return wide ? bepu_cluster_kernel_wide_512sn(trace) : bepu_cluster_kernel_hot_512sn(trace);
     if (shared) switch (cluster_variant_threads(threads)) {
@@ -266,6 +273,7 @@ struct bepuhip_ctx {
     std::unordered_map<int32_t, int32_t> kin_uses;
     std::vector<int32_t> kin_touched;
     bool kin_uses_ready = false;
+    std::vector<BitMark> requirk_marks;  // the conserving modes' bits currently set in the island layout's rows (build_requirk_lists)
     bool soft_flags_stale = false;
     // measurement
     float last_ms = 0;
@@ -296,7 +304,7 @@ static void free_constraints(bepuhip_ctx* c) {
     if (c->d_clustered_dynamic) hipFree(c->d_clustered_dynamic);
     if (c->d_kinlist) hipFree(c->d_kinlist);
     if (c->d_requirk) hipFree(c->d_requirk);
-    c->d_requirk = nullptr; c->requirk_begin.clear();
+    c->d_requirk = nullptr; c->requirk_begin.clear(); c->requirk_marks.clear();
     if (c->d_trace) hipFree(c->d_trace);
     c->d_trace = nullptr; c->trace_words = 0;
     if (c->d_cycles) hipFree(c->d_cycles);

@@ -588,6 +588,10 @@ static int32_t build_constraints(bepuhip_ctx* c) {
                 HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(1024, tr != 0, wide != 0, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
                 HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(512, tr != 0, wide != 0, true, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
             }
+        for (int wide = 0; wide < 2; ++wide) {
+            HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(1024, false, wide != 0, false, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+            HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(512, false, wide != 0, true, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        }
         c->row_policy = -1; c->policy_samples = 0;  // a new topology is measured afresh
         c->clusters_shared = plan.shared;
         if (plan.shared) {  // split islands: velocity / event tables of the bodies more than one cluster touches (indexed by body, only the shared ones are used)
@@ -775,6 +779,7 @@ static int32_t build_requirk_lists(bepuhip_ctx* c) {
             ++ord;
         }
     }
+    std::vector<BitMark> marks;
     size_t fallback_ord = 0;
     for (size_t t = 0; t < c->tbs.size(); ++t) {
         const HostTypeBatch& tb = c->tbs[t];
@@ -797,6 +802,12 @@ static int32_t build_requirk_lists(bepuhip_ctx* c) {
                     if ((uint32_t)refs[i] >= kDynamicLimit || integrates(i)) continue;
                     const int launch = fallback ? sync_batches + row_level[ord][i] : tb.batch;
                     if (launch >= 0 && (size_t)launch < lists.size()) lists[launch].push_back(refs[i]);
+                    if (c->clusters_enabled && !fallback) {  // island layouts: the lane that holds the body does it (kLrefRequirk / kRankRequirk, bepu_cluster_kernel.h)
+                        const int d = tb.perm.empty() ? i : c->tbs[t].perm_inverse(i);
+                        const int lref_rows = (tb.info.bodies + 1) / 2;
+                        if (c->clusters_shared) marks.push_back({tb.lrefs_off + (size_t)(lref_rows + k) * tb.stride + d, 1u << 18});
+                        else marks.push_back({tb.lrefs_off + (size_t)(k / 2) * tb.stride + d, (1u << 14) << (16 * (k & 1))});
+                    }
                 }
             }
         }
@@ -809,6 +820,19 @@ static int32_t build_requirk_lists(bepuhip_ctx* c) {
         HIP_TRY(hipMalloc((void**)&c->d_requirk, flat.size() * 4));
         HIP_TRY(hipMemcpy(c->d_requirk, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
     }
+    // the island layouts' bits: the old ones go (their words may belong to other constraints by now), the new ones come — in the working rows and in the snapshot
+    for (int pass = 0; pass < 2; ++pass) {
+        const std::vector<BitMark>& list = pass == 0 ? c->requirk_marks : marks;
+        if (list.empty() || !c->d_slab) continue;
+        BitMark* d_marks = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_marks, list.size() * sizeof(BitMark)));
+        HIP_TRY(hipMemcpy(d_marks, list.data(), list.size() * sizeof(BitMark), hipMemcpyHostToDevice));
+        for (uint32_t* slab : {c->d_slab, c->d_slab0})
+            if (slab) hipLaunchKernelGGL(mark_bits_kernel, dim3(((int)list.size() + 255) / 256), dim3(256), 0, c->stream, slab, (const BitMark*)d_marks, (int)list.size(), pass);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(d_marks);
+    }
+    c->requirk_marks.swap(marks);
     c->requirk_stale = false;
     clear_graphs(c);  // graphs captured for a conserving mode hold the old lists
     return BEPUHIP_OK;
@@ -870,10 +894,16 @@ static void settle_row_policy(bepuhip_ctx* c, int threads, bool may_block) {
                 kPolicyRounds - 1, best);
 }
 
-// The island schedule implements AngularIntegrationMode.Nonconserving; the conserving modes run the launch-per-batch schedule.
+// Threads per cluster workgroup: 16 waves for whole-island plans, 8 for split plans (BEPUHIP_CLUSTER_THREADS / BEPUHIP_SPLIT_THREADS override).
+static int cluster_threads(const bepuhip_ctx* c) {
+    const int req = c->clusters_shared ? env_int("BEPUHIP_SPLIT_THREADS", kSplitClusterThreads) : env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
+    return std::max(64, std::min(1024, req / 64 * 64));
+}
+// The momentum-conserving angular modes run the island schedule through the kernel units that carry their code (round 3; BEPUHIP_CONSERVING_CLUSTERS=0: launch-per-batch
+// as in round 2), which exist for the default workgroup sizes.
 static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
     return c->clusters_enabled && substeps <= kMaxClusterSubsteps && cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared) <= kLdsBudgetBytes &&
-           in->angular_integration_mode == 0;
+           (in->angular_integration_mode == 0 || (conserving_variant_exists(cluster_threads(c), c->clusters_shared) && c->d_trace == nullptr && env_int("BEPUHIP_CONSERVING_CLUSTERS", 1) != 0));
 }
 // Enqueue every kernel of one Simulation.Solve on the context's stream (Solver_Solve.cs:1415-1479 + PoseIntegrator.cs:707-726).
 static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t* iterations, const bepuhip_integrator* in) {
@@ -897,8 +927,8 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             // Scenes with SURVEY 8(f) types take the 512-thread build: at 128 VGPRs per wave the widened types spill hundreds of registers.
             // (the widened variant too: its 1024-thread build spills 700 VGPRs and is still the faster one — 0.222 against 0.325 ms on the bench graph with widened joints
             // on the pool's slow class of box, 0.195 against 0.193 on the fast one, profiles/r03_s13_widened_slowbox.txt: sixteen waves hide what the scratch traffic costs)
-            const int req = env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
-            const int threads = std::max(64, std::min(1024, (c->clusters_shared ? env_int("BEPUHIP_SPLIT_THREADS", kSplitClusterThreads) : req) / 64 * 64));
+            const int threads = cluster_threads(c);
+            const bool conserving = in->angular_integration_mode != 0;
             const size_t launch_lds = lds_bytes;
             // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
             // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).
@@ -927,18 +957,19 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
                             (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
             const bool tr = c->d_trace != nullptr;
-            const bool policy_applies = cluster_variant_threads(threads) == (c->clusters_shared ? 512 : 1024);  // the variants that exist in both row policies
+            const bool policy_applies = cluster_variant_threads(threads) == (c->clusters_shared ? 512 : 1024) && !conserving;  // the variants that exist in both row policies (a conserving solve neither measures nor follows the policy beyond the code touch)
             int sample = -1, candidate = 0;
             if (policy_applies) {
                 if (c->row_policy < 0) settle_row_policy(c, threads, false);
                 if (c->row_policy >= 0) candidate = c->row_policy;
                 else if (c->policy_samples < kPolicySamples) { sample = c->policy_samples++; candidate = sample % kPolicyCandidates; c->policy_threads = threads; }  // each under its own event pair
             }
+            if (conserving && c->row_policy == 2) candidate = 2;
             const bool nt = candidate == 1;
             cp.code_touch = candidate == 2 ? 1 : 0;
             if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(4, forced);
             cp.code_touch_gate = std::max(0, std::min(2, env_int("BEPUHIP_CODE_TOUCH_GATE", 0)));
-            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt);  // the register budget that matches the workgroup size
+            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, conserving);  // the register budget that matches the workgroup size
             if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
             const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
             bool launched = false;
@@ -1638,6 +1669,7 @@ static int32_t leave_island_schedule(bepuhip_ctx* c) {
         *p = nullptr;
     }
     c->clusters_enabled = false; c->cluster_count = 0; c->clustered_dynamic_count = 0; c->kinlist_count = 0;
+    c->requirk_marks.clear(); c->requirk_stale = true;  // (the marks lived in rows that no longer exist; the launch-per-batch lists are rebuilt by the next conserving solve)
     c->structure_dirty = true;
     return BEPUHIP_OK;
 }

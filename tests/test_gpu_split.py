@@ -94,6 +94,22 @@ def test_three_and_four_body_constraints_in_a_split_plan(hip_solver_factory, mon
     _exact(pu.compare_scenes(ref, got))
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_momentum_conserving_modes_on_a_split_plan(hip_solver_factory, monkeypatch, mode):
+    """The conserving angular modes on a split-island plan (round 3): a shared body's angular step is its home cluster's, which publishes the transformed velocity in the
+    body's record; the substep-0 re-transformation travels as bit 18 of the rank word and is applied by whichever cluster runs that application."""
+    monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "24")
+    scene = small_scenes.random_graph_scene(91, 6000, 14000, sorted(small_scenes.TYPE_TABLE.keys()), kinematic_fraction=0.05)
+    iterations = [2, 1, 1]
+    sd = SolveDescription(1, 3, velocity_iteration_scheduler=lambda s: iterations[s])
+    cb = PoseIntegratorCallbacks(angular_integration_mode=mode)
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+    assert solver.schedule() == 2 and solver.cluster_cycles().size > 1
+    _exact(pu.compare_scenes(ref, got))
+
+
 def test_split_plan_declines_what_it_does_not_cover(hip_solver_factory, monkeypatch):
     """With BEPUHIP_SPLIT_MANY_BODY=0 three- and four-body constraints keep to whole islands as in round 2, and BEPUHIP_NO_SPLIT turns the plan off: both land on the
     launch-per-batch schedule, still bit-exact."""
