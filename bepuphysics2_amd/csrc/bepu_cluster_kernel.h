@@ -39,6 +39,13 @@ namespace {
 // for such a mode launches the unit's twin that carries this code (the integration phase's angular step, and substep 0's second transformation of the bodies the
 // reference's conditionally integrating bundles transform twice — one bit per body slot of a constraint, set by the host, see build_requirk_lists).
 constexpr bool kConserving = BEPU_VARIANT_CONSERVING != 0;
+#ifndef BEPU_VARIANT_PASS
+#define BEPU_VARIANT_PASS 0
+#endif
+// Per translation unit: ONE sweep per launch — all batches of one warm start or one velocity iteration, velocities from and back to HBM — for the exchanged solves of
+// a scene split across GPUs (bepuhip_solve_exchanged / bepuhip_solve_lattice in the per-pass mode), which trade boundary velocities between the passes. Integration,
+// the incremental contact update and the final pass stay the launch-per-batch schedule's kernels there; this unit replaces its batch-after-batch launches.
+constexpr bool kPass = BEPU_VARIANT_PASS != 0;
 constexpr bool kRowsNonTemporal = BEPU_VARIANT_NT != 0;  // one- and two-body constraint rows loaded with the non-temporal hint (they stream: 70 MB per pass, no reuse)
 
 typedef __attribute__((address_space(1))) float gfloat;  // global
@@ -767,6 +774,42 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     __syncthreads();
     if (tid == 0 && tp.kin_count > 0) __hip_atomic_fetch_add(tp.staged, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // this cluster's copies of kinematic bodies are in LDS
 
+    if constexpr (kPass) {
+        // The sweep behaves like the one pass of a one-substep step: a shared body's home publishes the velocity the launch found in HBM as "integration done"
+        // (event base + 1), the applications number on from there, the home waits for all of them before it writes the body back.
+        if constexpr (SHARED) {
+            for (int j = tid; j < cd.slot_count; j += blockDim.x) {
+                const int g = slots[j];
+                if (g < 0 || !(g & kSlotSharedHome)) continue;
+                const float4 l4 = lds[2 * ncap + j], a4 = lds[3 * ncap + j];
+                const float number = __uint_as_float(shared_tables.base + 1u);
+                store_agent_pair(shared_record(shared_tables, g & kSlotBodyMask, 0u), make_float4(l4.x, l4.y, l4.z, number), make_float4(a4.x, a4.y, a4.z, number));
+            }
+            sh.events = 1u;
+        }
+        sh.substep = cp.pass_substep;
+        __syncthreads();
+        if (cp.pass_stage == kStageWarmStart) run_cluster_sweep<kStageWarmStart, false, WIDE, SHARED>(sh, cd.item_count, 0, lane, wave, 1u, 0u, slab, dt, inv_dt, nullptr);
+        else run_cluster_sweep<kStageSolve, false, WIDE, SHARED>(sh, cd.item_count, 0, lane, wave, 1u, 0u, slab, dt, inv_dt, nullptr);
+        sh.passes = 1u;
+        __syncthreads();
+        for (int j = tid; j < cd.slot_count; j += blockDim.x) {
+            int g = slots[j];
+            if (SHARED && g >= 0 && (g & kSlotGhost)) continue;
+            const bool home = SHARED && g >= 0 && (g & kSlotSharedHome) != 0;
+            if (home) g &= kSlotBodyMask;
+            if ((unsigned)g >= kDynamicLimit) continue;
+            float4 l4 = lds[2 * ncap + j], a4 = lds[3 * ncap + j];
+            if (home) {
+                const float lw = l4.w, aw = a4.w;
+                acquire_shared_one(shared_tables, status, g, 0u, shared_tables.base + 1u + (shared_tables.info[g] & 0xFFu), l4, a4, 11, j);
+                l4.w = lw; a4.w = aw;
+            }
+            float4* gb = bodies + (size_t)g * 8;
+            gb[2] = l4; gb[3] = a4;
+        }
+        return;
+    }
     unsigned epoch = 0, claim_base = 0;
     for (int s = 0; s < cp.substeps; ++s) {
         if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(&sh.status[10], (unsigned)s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -26,10 +26,17 @@ const void* bepu_cluster_kernel_hot_1024c(bool trace);   // the momentum-conserv
 const void* bepu_cluster_kernel_wide_1024c(bool trace);
 const void* bepu_cluster_kernel_hot_512sc(bool trace);   // ... split-island plans at 512
 const void* bepu_cluster_kernel_wide_512sc(bool trace);
+const void* bepu_cluster_kernel_hot_1024p(bool trace);   // one sweep per launch (exchanged solves): whole-island plans at 1024 threads ...
+const void* bepu_cluster_kernel_wide_1024p(bool trace);
+const void* bepu_cluster_kernel_hot_512sp(bool trace);   // ... split-island plans at 512
+const void* bepu_cluster_kernel_wide_512sp(bool trace);
 constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
 static int cluster_variant_threads(int threads) { return threads > 768 ? 1024 : (threads > 512 ? 768 : 512); }  // the smallest budget that still fits `threads`
 // The conserving units exist for the default workgroup sizes only; other sizes (BEPUHIP_CLUSTER_THREADS / BEPUHIP_SPLIT_THREADS) keep such solves on the launch-per-batch schedule.
 static bool conserving_variant_exists(int threads, bool shared) { return cluster_variant_threads(threads) == (shared ? 512 : 1024); }
+static const void* cluster_pass_kernel(bool wide, bool shared) {  // (for the default workgroup sizes, like the conserving units)
+    return shared ? (wide ? bepu_cluster_kernel_wide_512sp(false) : bepu_cluster_kernel_hot_512sp(false)) : (wide ? bepu_cluster_kernel_wide_1024p(false) : bepu_cluster_kernel_hot_1024p(false));
+}
 static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false, bool conserving = false) {
     if (conserving) return shared ? (wide ? bepu_cluster_kernel_wide_512sc(trace) : bepu_cluster_kernel_hot_512sc(trace)) : (wide ? bepu_cluster_kernel_wide_1024c(trace) : bepu_cluster_kernel_hot_1024c(trace));
     if (nt && !shared && cluster_variant_threads(threads) == 1024) return wide ? bepu_cluster_kernel_wide_1024n(trace) : bepu_cluster_kernel_hot_1024n(trace);

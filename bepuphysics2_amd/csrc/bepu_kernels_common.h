@@ -79,6 +79,7 @@ struct ClusterParams {
     int code_touch;     // 8 KB spans of its own upcoming code a wave pulls into L2 at the start of every work item (0: off), see touch_code_ahead
     int code_touch_gate;  // experimental (BEPUHIP_CODE_TOUCH_GATE): spans touched again from the gate on
     int iters[kMaxClusterSubsteps];
+    int pass_stage, pass_substep;  // the one-sweep-per-launch units (kPass): kStageWarmStart or kStageSolve, and the substep the sweep belongs to
     StepParams sp;
 };
 

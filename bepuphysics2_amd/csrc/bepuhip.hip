@@ -589,6 +589,8 @@ static int32_t build_constraints(bepuhip_ctx* c) {
                 HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(512, tr != 0, wide != 0, true, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
             }
         for (int wide = 0; wide < 2; ++wide) {
+            HIP_TRY(hipFuncSetAttribute(cluster_pass_kernel(wide != 0, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+            HIP_TRY(hipFuncSetAttribute(cluster_pass_kernel(wide != 0, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
             HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(1024, false, wide != 0, false, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
             HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(512, false, wide != 0, true, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
         }
@@ -894,6 +896,10 @@ static void settle_row_policy(bepuhip_ctx* c, int threads, bool may_block) {
                 kPolicyRounds - 1, best);
 }
 
+// Cooperative launches are issued by one host thread at a time: two contexts of one process launching them concurrently from two threads (the in-process lattice
+// harness) leave the runtime in a state that crashes at process exit (ROCm 7.0, observed: every test passes, then a segmentation fault in the exit handlers).
+static std::mutex g_cooperative_launch;
+
 // Threads per cluster workgroup: 16 waves for whole-island plans, 8 for split plans (BEPUHIP_CLUSTER_THREADS / BEPUHIP_SPLIT_THREADS override).
 static int cluster_threads(const bepuhip_ctx* c) {
     const int req = c->clusters_shared ? env_int("BEPUHIP_SPLIT_THREADS", kSplitClusterThreads) : env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
@@ -976,6 +982,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             if (c->clusters_shared && env_int("BEPUHIP_COOPERATIVE", (c->flags & BEPUHIP_FLAG_EXCLUSIVE_DEVICE) ? 0 : 1) != 0) {
                 // The clusters of a split plan wait for each other: they must all be resident at once. A cooperative launch of exactly the clusters makes the runtime
                 // guarantee that (or refuse), whatever else runs on the device; the per-body tail follows as an ordinary launch of the same kernel.
+                std::lock_guard<std::mutex> one_at_a_time(g_cooperative_launch);
                 if (hipLaunchCooperativeKernel(fn, dim3(c->cluster_count), dim3(threads), args, (unsigned)launch_lds, c->stream) == hipSuccess) {
                     launched = true;
                     if (tail_blocks > 0) {
@@ -1347,10 +1354,54 @@ static int32_t enqueue_exchange(bepuhip_ctx* c) {
 // Simulation.Solve with exchange points: the launch-per-batch schedule, eager. `fn` != null: host-synchronised call-backs (any transport); null: the exchange
 // is enqueued on the stream (enqueue_exchange) and the host does not wait for anything before the end of the frame. BEPUHIP_EXCHANGE_PER_PASS_AVERAGE exchanges
 // after every pass, BEPUHIP_EXCHANGE_PER_BATCH_EXACT after every batch of every pass.
+// One sweep of the island schedule as a launch of its own (the kPass units of bepu_cluster_kernel.h): all batches of one warm start or one velocity iteration.
+static void enqueue_cluster_pass(bepuhip_ctx* c, int stage, int substep, const StepParams& sp) {
+    ClusterParams cp;
+    memset(&cp, 0, sizeof(cp));
+    cp.substeps = 1; cp.batch_count = c->batch_count; cp.planes = c->cluster_planes;
+    cp.pass_stage = stage; cp.pass_substep = substep;
+    cp.sp = sp;
+    cp.code_touch = c->row_policy == 2 ? 1 : 0;
+    const int threads = cluster_threads(c);
+    TailParams tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.flags = c->d_flags; tp.staged = c->d_staged; tp.cluster_count = c->cluster_count; tp.body_count = c->body_count;
+    SharedTables st = {c->d_shared_vel, c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1), 0u};
+    if (c->clusters_shared) {  // a pass is a one-substep, one-pass step of its own as far as the event numbers go
+        const unsigned span = 260u;
+        if ((unsigned long long)c->shared_epoch + 2ull * span > 0xFFFFFFFFull) { hipMemsetAsync(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4), c->stream); c->shared_epoch = 0; }
+        st.base = c->shared_epoch;
+        c->shared_epoch += span;
+    }
+    const size_t lds_bytes = cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared);
+    void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
+                    (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
+    const void* fn = cluster_pass_kernel(c->has_widened_types, c->clusters_shared);
+    bool launched = false;
+    if (c->clusters_shared && env_int("BEPUHIP_COOPERATIVE", (c->flags & BEPUHIP_FLAG_EXCLUSIVE_DEVICE) ? 0 : 1) != 0) {
+        std::lock_guard<std::mutex> one_at_a_time(g_cooperative_launch);
+        launched = hipLaunchCooperativeKernel(fn, dim3(c->cluster_count), dim3(threads), args, (unsigned)lds_bytes, c->stream) == hipSuccess;
+        if (!launched) (void)hipGetLastError();
+    }
+    if (!launched) hipLaunchKernel(fn, dim3(c->cluster_count), dim3(threads), args, lds_bytes, c->stream);
+}
+
 static int32_t run_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in, bepuhip_exchange_fn fn, void* user) {
     int32_t st = validate_solve(c, dt, substeps, iterations, in);
     if (st != BEPUHIP_OK) return st;
-    if (c->clusters_enabled) return fail(BEPUHIP_E_STATE, "an exchanged solve needs a context created with BEPUHIP_FLAG_NO_CLUSTERS (a split scene is one island per rank anyway)");
+    // A context on an island plan runs the sweeps between two exchanges as ONE launch each (round 3): possible where the exchange comes per pass, not per batch, the
+    // angular mode is the nonconserving one and the rows hold no free slots (the integration kernels around the sweeps address rows [0, count)).
+    bool island_passes = false;
+    if (c->clusters_enabled) {
+        bool gaps = false;
+        for (auto& tb : c->tbs) gaps |= tb.slots > 0 && tb.slots != tb.count;
+        island_passes = c->exchange_mode != BEPUHIP_EXCHANGE_PER_BATCH_EXACT && in->angular_integration_mode == 0 && !gaps && env_int("BEPUHIP_EXCHANGED_CLUSTERS", 1) != 0 &&
+                        conserving_variant_exists(cluster_threads(c), c->clusters_shared) &&
+                        cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared) <= kLdsBudgetBytes;
+        if (!island_passes)
+            return fail(BEPUHIP_E_STATE, "this exchanged solve needs a context created with BEPUHIP_FLAG_NO_CLUSTERS: an island plan runs exchanged solves only with one exchange per pass, "
+                                         "the nonconserving angular mode and no reserved update slots");
+    }
     // The fallback batch runs as one launch per dependency level of THIS share: the ranks would disagree on the number of exchange points (a hang in RCCL or in the
     // host barrier) and, in the exact mode, on who touched a body since the last exchange (its level numbering is rank-local). Shares keep the global batch indices,
     // so a scene whose colouring reaches the fallback threshold has to be recoloured (bepuhip_colour_constraints) or solved unsplit.
@@ -1384,7 +1435,8 @@ static int32_t run_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const i
         if (c->boundary_count > 0)  // deltas of this substep are relative to the integrated velocities (identical on every holder)
             hipLaunchKernelGGL(boundary_snapshot_kernel, dim3((c->boundary_count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, (const int*)c->d_boundary, c->boundary_count,
                                c->d_boundary_snapshot);
-        for (int b = 0; b < c->launch_count; ++b) {
+        if (island_passes) enqueue_cluster_pass(c, kStageWarmStart, s, sp);
+        for (int b = 0; b < c->launch_count && !island_passes; ++b) {
             if (c->batch_blocks[b] > 0) {
                 enqueue_requirk(c, s, b, sp);
                 hipLaunchKernelGGL(batch_kernel<kStageWarmStart>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
@@ -1394,7 +1446,8 @@ static int32_t run_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const i
         }
         if (!per_batch && (st = exchange(s, 0, -1)) != BEPUHIP_OK) return st;
         for (int it = 0; it < iterations[s]; ++it) {
-            for (int b = 0; b < c->launch_count; ++b) {
+            if (island_passes) enqueue_cluster_pass(c, kStageSolve, s, sp);
+            for (int b = 0; b < c->launch_count && !island_passes; ++b) {
                 if (c->batch_blocks[b] > 0)
                     hipLaunchKernelGGL(batch_kernel<kStageSolve>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
                                        c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);

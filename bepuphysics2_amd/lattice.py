@@ -329,6 +329,7 @@ def solve_shares_in_process(make_solver, shares: List[Share], dt, solve_descript
     errors = []
 
     def run(rank):
+        solver = None
         try:
             solver = make_solver()
             share = shares[rank]
@@ -342,10 +343,12 @@ def solve_shares_in_process(make_solver, shares: List[Share], dt, solve_descript
             for _ in range(frames):
                 solver.solve_exchanged(dt, solve_description, callbacks, hook)
             solver.download(share.scene)
-            solver.close()
         except Exception as e:  # noqa: BLE001
             errors.append(e)
             ex.barrier.abort()
+        finally:
+            if solver is not None:
+                solver.close()
 
     threads = [threading.Thread(target=run, args=(r,)) for r in range(len(shares))]
     for t in threads:

@@ -37,8 +37,15 @@ def test_single_share_through_solve_exchanged_is_bit_exact(hip_solver_factory):
     merged = lattice.merge_owned(scene, [share])
     m = pu.compare_scenes(ref, merged)
     assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
-    with pytest.raises(Exception):  # the island schedule owns whole islands; a split scene must run the launch-per-batch schedule
-        lattice.solve_share_hip(hip_solver_factory(use_clusters=True), share, 1 / 60, sd, cb, ex)
+    # Round 3: a context on an island plan runs the exchanged solve too — every sweep between two exchanges is ONE launch of the island kernel's one-sweep unit
+    # (integration, incremental contact update and the final pass stay global kernels) — with the same bits
+    share2 = lattice.make_share(scene, lattice.owner_by_groups(scene, 1, 16), 0, 1)
+    ex2 = lattice.BoundaryExchange(share2)
+    clustered = hip_solver_factory(use_clusters=True)
+    lattice.solve_share_hip(clustered, share2, 1 / 60, sd, cb, ex2, frames=2)
+    assert clustered.schedule() in (1, 2) and ex2.calls == ex.calls
+    m = pu.compare_scenes(ref, lattice.merge_owned(scene, [share2]))
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
 
 
 def _worker(rank, world, port, outdir, ragdolls, device_buffers):
@@ -113,6 +120,42 @@ def test_exact_mode_is_bit_identical_to_the_unsplit_solve(world):
     assert m["velocity_rel_err"] <= 1e-4 and m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
     for sh in shares:  # every copy of every body a rank holds (ghosts included) ends the frame with the unsplit solve's pose and velocity
         assert np.array_equal(sh.scene.bodies[:, :15].view(np.int32), ref.bodies[sh.local_to_global, :15].view(np.int32))
+
+
+def test_block_jacobi_shares_on_island_plans_equal_the_launch_per_batch_shares(monkeypatch):
+    """Two shares of one connected lattice, per-pass averaged exchange: each share is one island its context cuts into clusters (split-island plan), every pass one
+    launch. Same exchange points, same order of applications per body: the merged result equals the launch-per-batch shares' bit for bit. The exact per-batch mode
+    needs an exchange after every batch and keeps refusing an island plan."""
+    import parity_util as pu
+    from bepuphysics2_amd import lattice
+    from bepuphysics2_amd.native import HipSolver
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "12")
+    scene, sd = _lattice_scene(480)  # 240 connected ragdolls per share: more bodies than one workgroup's LDS holds
+    cb = PoseIntegratorCallbacks()
+    owner = lattice.owner_by_groups(scene, 2, 16)
+    results, kinds = [], []
+    for use_clusters in (False, True):
+        shares = [lattice.make_share(scene, owner, r, 2) for r in range(2)]
+        plan_kinds = []
+
+        class Recording(HipSolver):
+            def upload(self, *a, **k):
+                super().upload(*a, **k)
+                plan_kinds.append(self.schedule())
+
+        def make():
+            return Recording(device=0, use_clusters=use_clusters)
+
+        lattice.solve_shares_in_process(make, shares, 1 / 60, sd, cb, frames=2)
+        results.append(lattice.merge_owned(scene, shares))
+        kinds.append(plan_kinds)
+    assert kinds[0] == [0, 0] and kinds[1] == [2, 2], kinds  # launch-per-batch shares, then split-island plans
+    m = pu.compare_scenes(results[0], results[1])
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    shares = [lattice.make_share(scene, owner, r, 2, mass_split=False) for r in range(2)]
+    with pytest.raises(Exception):
+        lattice.solve_shares_in_process(lambda: HipSolver(device=0, use_clusters=True), shares, 1 / 60, sd, cb, frames=1, exact=True)
 
 
 def test_block_jacobi_mode_in_process_reports_its_error():
