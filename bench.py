@@ -336,7 +336,8 @@ def lattice_leg(device: int, ragdolls: int = 2000, world: int = 2, frames: int =
                            f"{frames} frames, error = max over bodies of |v_split - v_unsplit| / max|v_unsplit| against the unsplit solve of the same library"}
         for name, exact in (("per_pass_block_jacobi", False), ("per_batch_exact", True)):
             shares = [lattice.make_share(scene, owner, r, world, mass_split=not exact) for r in range(world)]
-            ex = lattice.solve_shares_in_process(lambda: HipSolver(device=device, use_clusters=False), shares, 1 / 60, sd, cb, frames=frames, exact=exact)
+            # (the per-pass mode runs each share on its island plan, one launch per pass; the per-batch mode needs an exchange after every batch: launch-per-batch)
+            ex = lattice.solve_shares_in_process(lambda: HipSolver(device=device, use_clusters=not exact), shares, 1 / 60, sd, cb, frames=frames, exact=exact)
             merged = lattice.merge_owned(scene, shares)
             per_body = np.abs(ref.bodies[:, vel] - merged.bodies[:, vel]).max(axis=1) / scale
             out[name] = {"velocity_err_max": float(per_body.max()), "velocity_err_median": float(np.median(per_body)),
@@ -423,8 +424,9 @@ def run_lattice(args, rank, local_rank, world, dist, torch):
     exact = bool(args.lattice_exact)
     share = lattice.make_share(scene, lattice.owner_by_groups(scene, world, 16), rank, world, mass_split=not exact)
     cb = PoseIntegratorCallbacks()
-    solver = HipSolver(device=local_rank, use_clusters=False)
+    solver = HipSolver(device=local_rank, use_clusters=not exact and not args.lattice_no_clusters, exclusive_device=True)
     solver.upload(share.scene, sd.fallback_batch_threshold)
+    schedule = {0: "launch-per-batch schedule", 1: "island schedule, one launch per pass (whole islands)", 2: "island schedule on a split-island plan, one launch per pass"}[solver.schedule()]
     solver.set_boundary_bodies(share.boundary_local)
     solver.set_boundary_layout(share.boundary_slot, share.boundary_total, None if exact else share.boundary_holders)
     solver.set_exchange_mode(1 if exact else 0)
@@ -469,9 +471,9 @@ def run_lattice(args, rank, local_rank, world, dist, torch):
                                    + (f"exact per-batch exchange of XOR bit patterns ({int((1 + its).sum()) * len(scene.batches)} " if exact else
                                       f"mass-split block-Jacobi exchange after every pass ({int((1 + its).sum())} ")
                                    + f"ncclAllReduce of {share.boundary_total * 24} bytes per step, enqueued on the solver's stream by bepuhip_solve_lattice: no host "
-                                     "synchronisation inside a frame); launch-per-batch schedule",
+                                     f"synchronisation inside a frame); {schedule}",
                        "exchanges_per_step": int((1 + its).sum()) * (len(scene.batches) if exact else 1)},
-            "roofline": {"bound": "hbm", "kernel": "whole step (launch-per-batch schedule + exchanges)", "achieved": achieved, "peak": HBM_PEAK_GBS * world,
+            "roofline": {"bound": "hbm", "kernel": f"whole step ({schedule} + exchanges), algorithmic bytes", "achieved": achieved, "peak": HBM_PEAK_GBS * world,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None},
             "cpu_baseline": None}))
     if dist is not None:
@@ -491,6 +493,7 @@ def main():
     ap.add_argument("--lattice", action="store_true", help="BASELINE.json configs[4]: ONE connected ragdoll lattice of --ragdolls ragdolls split across the ranks "
                     "(strong scaling, boundary-velocity exchange after every pass) instead of the default independent islands per rank")
     ap.add_argument("--lattice-exact", action="store_true", help="with --lattice: the per-batch exact exchange mode (bit-identical to one GPU) instead of per-pass block-Jacobi")
+    ap.add_argument("--lattice-no-clusters", action="store_true", help="with --lattice: the launch-per-batch schedule also in the per-pass mode (round 2's path)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the clock pre-warm of the setup phase (300 untimed solves, state restored afterwards)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE child runs behind roofline.traffic")
     ap.add_argument("--traffic-child", default=None, choices=["main", "pile", "crowd"], help=argparse.SUPPRESS)

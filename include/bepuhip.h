@@ -101,7 +101,9 @@ int32_t bepuhip_solve(bepuhip_ctx* ctx, float dt, int32_t substep_count, const i
  * (BepuPhysics/Solver.cs:131-146). Each rank uploads its share: the bodies it owns plus ghost copies of remote bodies its constraints
  * reference, and the constraints assigned to it (bepuphysics2_amd/lattice.py builds the shares). `set_boundary_bodies` lists the local
  * indices of the bodies that exist on more than one rank, in an order all ranks agree on per body; they are always treated as constrained.
- * `solve_exchanged` = bepuhip_solve on the launch-per-batch schedule (context created with BEPUHIP_FLAG_NO_CLUSTERS) that calls `fn`
+ * `solve_exchanged` = bepuhip_solve with exchange points: it calls `fn` after every pass. A context created with BEPUHIP_FLAG_NO_CLUSTERS runs the launch-per-batch
+ * schedule between them; a context on an island plan runs every pass as ONE launch of the island kernel (per-pass exchange mode, nonconserving angular mode, no
+ * reserved update slots; otherwise STATE). The results are the same bits either way.
  * after every pass: pass 0 = warm start of substep `substep`, pass k = its k-th velocity iteration. Inside the call-back the caller
  * reads `boundary_deltas` (6 floats per boundary body: what this rank's constraints did to linear xyz / angular xyz since the last
  * synchronisation point), sums them over the ranks (RCCL all-reduce on the device buffer, or any host transport), DIVIDES each body's sum by the number of ranks that hold it
