@@ -1032,6 +1032,28 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
     }
 }
 
+// `referenced_bodies` only ever grows while references are patched (bepuhip_update_body_reference lowers them: the last body moved into a freed slot and the body
+// array shrank): counted again from the rows, with everything the caller has been told applied, before a solve is refused for it.
+static int32_t recount_referenced_bodies(bepuhip_ctx* c) {
+    HIP_TRY(hipSetDevice(c->device));
+    int32_t st = flush_structural(c);
+    if (st != BEPUHIP_OK) return st;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int highest = -1;
+    std::vector<int32_t> row;
+    for (auto& tb : c->tbs) {
+        const int extent = tb.device_extent();
+        if (extent == 0) continue;
+        row.resize(extent);
+        for (int k = 0; k < tb.info.bodies; ++k) {
+            HIP_TRY(hipMemcpy(row.data(), c->d_slab + tb.refs_off + (size_t)k * tb.stride, (size_t)extent * 4, hipMemcpyDeviceToHost));
+            for (int32_t r : row) if (r >= 0) highest = std::max(highest, r & kRefMask);
+        }
+    }
+    c->referenced_bodies = highest + 1;
+    return rebuild_flags(c);  // (they were skipped while the references seemed to point past the body array)
+}
+
 static int32_t validate_solve(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in) {
     if (!c || !in || !iterations) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
     if (!(dt > 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Timestep duration must be positive.");                  // Simulation.cs:318-319
@@ -1040,6 +1062,10 @@ static int32_t validate_solve(bepuhip_ctx* c, float dt, int32_t substeps, const 
         if (iterations[s] < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Velocity iteration count must be positive.");
     if (in->angular_integration_mode < 0 || in->angular_integration_mode > 2) return fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown AngularIntegrationMode");
     if (c->building) return fail(BEPUHIP_E_STATE, "solve between begin_constraints and end_constraints");
+    if (c->built && c->referenced_bodies > c->body_count) {
+        const int32_t st = recount_referenced_bodies(c);
+        if (st != BEPUHIP_OK) return st;
+    }
     if (c->built && c->referenced_bodies > c->body_count)
         return fail(BEPUHIP_E_STATE, "a constraint references body " + std::to_string(c->referenced_bodies - 1) + " but only " + std::to_string(c->body_count) +
                                          " bodies are uploaded (set_bodies)");

@@ -75,6 +75,33 @@ class MutableSolver:
         for key in ("refs", "prestep", "acc"):
             tb[key].pop()
 
+    def remove_body(self, index: int) -> List[Tuple[int, int, int, int, int]]:
+        """Bodies.RemoveAt (BepuPhysics/BodySet.cs:83-110) of a body without constraints: the last body takes its slot, and every constraint that referenced the last
+        body is patched (Solver.UpdateForBodyMemoryMove, Solver.cs:1475 -> TypeProcessor.UpdateForBodyMemoryMove, TypeProcessor.cs:807). Returns the patches as
+        (batch index, type id, index in type batch, body slot, new encoded reference) — what bepuhip_update_body_reference is called with."""
+        last = self.bodies.shape[0] - 1
+        for b in self.batches:
+            for tb in b.values():
+                assert all((int(r) & ~KINEMATIC_MASK) != index for refs in tb["refs"] for r in refs), "the removed body still has constraints"
+        patches = []
+        if index != last:
+            for bi, b in enumerate(self.batches):
+                for t in self.type_order[bi]:
+                    for i, refs in enumerate(b[t]["refs"]):
+                        for k, r in enumerate(refs):
+                            if (int(r) & ~KINEMATIC_MASK) == last:
+                                refs[k] = index | (int(r) & KINEMATIC_MASK)
+                                patches.append((bi, t, i, k, int(refs[k])))
+                if last in self.batch_handles[bi]:
+                    self.batch_handles[bi][index] = self.batch_handles[bi].pop(last)
+            if last in self.kinematic_uses:
+                self.kinematic_uses[index] = self.kinematic_uses.pop(last)
+                self.kinematic_constrained[self.kinematic_constrained.index(last)] = index
+            self.bodies[index] = self.bodies[last]
+        self.kinematic_uses.pop(last, None)
+        self.bodies = np.ascontiguousarray(self.bodies[:last])
+        return patches
+
     def dynamic_degree(self, body: int) -> int:
         """Constraints that reference the (dynamic) body: a dynamic body appears at most once per batch."""
         return sum(1 for handles in self.batch_handles if body in handles)

@@ -521,3 +521,41 @@ def test_a_kinematic_body_that_loses_and_regains_its_constraints_on_the_island_l
     bi, index, encoded = ms.add(5, [20, 61], lane)
     assert solver.add_constraint(bi, 5, encoded, lane) == index
     frames(3)
+
+
+@pytest.mark.parametrize("use_clusters", [False, True])
+def test_body_removal_moves_the_last_body_and_patches_its_references(hip_solver_factory, use_clusters):
+    """Bodies.RemoveAt (BodySet.cs:83-110): the last body takes the removed body's slot and Solver.UpdateForBodyMemoryMove patches every constraint that referenced it
+    (bepuhip_update_body_reference), the body array shrinks (bepuhip_set_bodies). Dynamic and kinematic bodies; on an island plan the patches leave the plan and
+    bepuhip_replan brings the context back. Bit-exact against the oracle solving the host mirror every frame."""
+    ms, rng, pair = _build(41, bodies=200, joints=220, contacts=380)
+    sd, cb = SolveDescription(1, 4), PoseIntegratorCallbacks()
+    solver = hip_solver_factory(use_clusters=use_clusters)
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+
+    def frames(n):
+        for _ in range(n):
+            export = ms.to_scene()
+            solver.set_constrained_kinematics(export.constrained_kinematic_indices())
+            oracle_ffi.solve(export, 1 / 60, sd, cb)
+            ms.absorb(export)
+            solver.solve(1 / 60, sd, cb)
+            got = ms.to_scene()
+            solver.download(got)
+            m = pu.compare_scenes(export, got)
+            assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+    frames(2)
+    for victim in (5, 37, 0):  # a dynamic body, a kinematic one (every 37th), and one whose slot the then-last body (whatever it is) takes
+        for bi, t, i in sorted(((bi, t, i) for bi, t, i in ms.locations() if any((int(r) & 0x3FFFFFFF) == victim for r in ms.batches[bi][t]["refs"][i])), reverse=True):
+            ms.remove(bi, t, i)
+            solver.remove_constraint(bi, t, i)
+        for bi, t, i, k, encoded in ms.remove_body(victim):
+            solver.update_body_reference(bi, t, i, k, encoded)
+        solver.set_bodies(ms.bodies)
+        frames(2)
+        if use_clusters:
+            assert solver.schedule() == 0  # (a body move is not something an island layout absorbs yet)
+            solver.replan()
+            assert solver.schedule() in (1, 2)
+            frames(1)
