@@ -280,6 +280,14 @@ struct bepuhip_ctx {
     std::unordered_map<int32_t, int32_t> kin_uses;
     std::vector<int32_t> kin_touched;
     bool kin_uses_ready = false;
+    // Bodies that join or leave a plan with their first / last constraint (bepu_soft_updates.h): the list behind kFlagClustered (device copy with spare capacity) ...
+    std::vector<int32_t> clustered_dynamic_host;
+    std::unordered_map<int32_t, int32_t> clustered_position;  // ... body -> its position in it (built on first use)
+    int clustered_dynamic_capacity = 0;
+    bool kinlist_dirty = false;                                // ... and of the constrained kinematic bodies (a kinematic body moved)
+    bool clustered_dirty = false;                              // the device copy of the list is behind its mirror
+    bool free_slots_ready = false;                             // cluster_free_slots lists every unused LDS slot of every cluster (scanned from the slot tables on first use)
+    std::unordered_map<int32_t, int32_t> body_moves;           // Bodies.RemoveAt moves seen since the last flush: old index -> new index
     std::vector<BitMark> requirk_marks;  // the conserving modes' bits currently set in the island layout's rows (build_requirk_lists)
     bool soft_flags_stale = false;
     // measurement
@@ -332,5 +340,5 @@ static void free_constraints(bepuhip_ctx* c) {
     c->inc_blocks = 0; c->inc_tb_count = 0; c->total_constraints = 0; c->slab_words = 0; c->referenced_bodies = 0;
     c->built = false;
     c->pending_ops.clear(); c->pending_payload.clear(); c->structure_dirty = false; c->requirk_stale = false;
-    c->soft_ok = false; c->soft_split = false; c->kinlist_host.clear(); c->kin_uses.clear(); c->kin_touched.clear(); c->kin_uses_ready = false; c->cluster_free_slots.clear(); c->cluster_extra_uses.clear(); c->body_apps.clear(); c->split_rerank.clear(); c->split_patches.clear(); c->soft_slots.clear(); c->soft_index.clear(); c->soft_orphans.clear(); c->soft_items_dirty = false; c->items_host.clear(); c->clusters_host.clear(); c->cluster_degraded.clear();
+    c->soft_ok = false; c->soft_split = false; c->clustered_dynamic_host.clear(); c->clustered_position.clear(); c->clustered_dynamic_capacity = 0; c->free_slots_ready = false; c->body_moves.clear(); c->kinlist_host.clear(); c->kin_uses.clear(); c->kin_touched.clear(); c->kin_uses_ready = false; c->cluster_free_slots.clear(); c->cluster_extra_uses.clear(); c->body_apps.clear(); c->split_rerank.clear(); c->split_patches.clear(); c->soft_slots.clear(); c->soft_index.clear(); c->soft_orphans.clear(); c->soft_items_dirty = false; c->items_host.clear(); c->clusters_host.clear(); c->cluster_degraded.clear();
 }

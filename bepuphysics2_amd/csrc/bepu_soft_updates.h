@@ -69,6 +69,7 @@ static void soft_setup(bepuhip_ctx* c, ClusterPlan& plan) {
     c->soft_slots.clear(); c->soft_index.clear(); c->soft_items_dirty = false; c->soft_adds = c->soft_removes = 0;
     c->body_apps.clear(); c->split_rerank.clear(); c->split_patches.clear();
     c->kinlist_host = plan.kinlist; c->kin_uses.clear(); c->kin_touched.clear(); c->kin_uses_ready = false;
+    c->free_slots_ready = false; c->cluster_free_slots.clear(); c->body_moves.clear();
     if (!plan.enabled || env_int("BEPUHIP_NO_SOFT_UPDATES", 0)) return;
     if (plan.shared) {  // split-island plan: the second half of this file
         if (env_int("BEPUHIP_NO_SPLIT_SOFT_UPDATES", 0)) return;
@@ -82,6 +83,7 @@ static void soft_setup(bepuhip_ctx* c, ClusterPlan& plan) {
         return;
     }
     c->body_cluster.swap(plan.body_cluster); c->body_lref.swap(plan.body_lref); c->body_degree.clear(); c->body_batches.clear(); c->cluster_kin.swap(plan.cluster_kin);
+    c->cluster_bodies_host = plan.cluster_bodies;
     c->items_host = plan.items; c->clusters_host = plan.clusters;
     c->cluster_degraded.assign(plan.clusters.size(), 0);
     c->soft_ok = true;
@@ -99,6 +101,77 @@ static void soft_ensure_degrees(bepuhip_ctx* c) {
                 const int32_t r = tb.dev_refs[(size_t)k * tb.stride + d];
                 if (r >= 0 && (uint32_t)r < kDynamicLimit && (size_t)r < c->body_degree.size()) { ++c->body_degree[r]; if (tb.batch < 64) c->body_batches[r] |= 1ull << tb.batch; }
             }
+}
+
+// ---- Bodies join and leave a plan with their first and last constraint (Solver.cs:1025-1030 / 1368-1377 are the reference's bookkeeping of the same events: a body
+// without constraints is integrated as an unconstrained body, once per frame) ----
+// Every unused LDS slot of every cluster, lowest natural index last (so that pop_back hands out the lowest): scanned from the slot tables' mirror on first use.
+static void soft_ensure_free_slots(bepuhip_ctx* c) {
+    if (c->free_slots_ready) return;
+    c->cluster_free_slots.assign(c->clusters_host.size(), {});
+    for (size_t cl = 0; cl < c->clusters_host.size(); ++cl) {
+        const ClusterDesc& cd = c->clusters_host[cl];
+        for (int natural = std::min(cd.slot_count, 0x3FF0) - 1; natural >= 0; --natural) {
+            const int slot = rotated_slot(natural);
+            if (slot < cd.slot_count && c->cluster_bodies_host[cd.body_begin + slot] == -1) c->cluster_free_slots[cl].push_back(slot);
+        }
+    }
+    if (c->soft_split) for (size_t cl = 0; cl < c->cluster_natural.size(); ++cl) c->cluster_natural[cl] = c->clusters_host[cl].slot_count;  // the lists hold everything now
+    c->free_slots_ready = true;
+}
+static void soft_patch_slot_table(bepuhip_ctx* c, int cl, int slot, int32_t entry) {
+    const size_t at = (size_t)c->clusters_host[cl].body_begin + slot;
+    c->cluster_bodies_host[at] = entry;
+    c->split_patches.push_back({2, at, -1, 0, 0});
+}
+static void soft_ensure_body(bepuhip_ctx* c, int32_t body) {  // the per-body tables reach `body`
+    if ((size_t)body < c->body_cluster.size()) return;
+    const size_t n = (size_t)body + 1;
+    c->body_cluster.resize(n, -1); c->body_lref.resize(n, 0);
+    if (!c->body_degree.empty()) { c->body_degree.resize(n, 0); c->body_batches.resize(n, 0); }
+    if (c->soft_split) { c->split_shared.resize(n, 0); if (!c->body_apps.empty()) c->body_apps.resize(n); }
+}
+static void soft_clustered_positions(bepuhip_ctx* c) {
+    if (!c->clustered_position.empty() || c->clustered_dynamic_host.empty()) return;
+    for (size_t i = 0; i < c->clustered_dynamic_host.size(); ++i) c->clustered_position[c->clustered_dynamic_host[i]] = (int32_t)i;
+}
+// A dynamic body without constraints gets its first one: it becomes a body of cluster `cl` (an unused LDS slot, an entry in the list behind kFlagClustered).
+static bool soft_adopt_body(bepuhip_ctx* c, int32_t body, int cl) {
+    soft_ensure_free_slots(c);
+    if (c->cluster_free_slots[cl].empty()) return soft_refuse("no free LDS slot in the cluster for a body that had no constraints");
+    if ((int)c->clustered_dynamic_host.size() >= c->clustered_dynamic_capacity) return soft_refuse("the plan's body list is full");
+    if (c->soft_split && (size_t)body >= c->shared_bodies) return soft_refuse("a body beyond the split plan's shared-body tables");
+    soft_ensure_body(c, body);
+    const int slot = c->cluster_free_slots[cl].back();
+    c->cluster_free_slots[cl].pop_back();
+    soft_patch_slot_table(c, cl, slot, body);
+    c->body_cluster[body] = cl; c->body_lref[body] = slot;
+    soft_clustered_positions(c);
+    c->clustered_position[body] = (int32_t)c->clustered_dynamic_host.size();
+    c->clustered_dynamic_host.push_back(body);
+    c->clustered_dirty = true; c->soft_flags_stale = true;
+    return true;
+}
+// ... and one that lost its last constraint (and did not get one back before the flush) leaves: its slot is free again, the tail integrates it from now on.
+static void soft_release_body(bepuhip_ctx* c, int32_t body) {
+    const int cl = c->body_cluster[body];
+    if (cl < 0) return;
+    soft_ensure_free_slots(c);
+    const int slot = c->body_lref[body] & 0x3FFF;
+    soft_patch_slot_table(c, cl, slot, -1);
+    c->cluster_free_slots[cl].push_back(slot);
+    c->body_cluster[body] = -1;
+    soft_clustered_positions(c);
+    auto at = c->clustered_position.find(body);
+    if (at != c->clustered_position.end()) {
+        const int32_t position = at->second, last = c->clustered_dynamic_host.back();
+        c->clustered_dynamic_host[position] = last;
+        c->clustered_position[last] = position;
+        c->clustered_dynamic_host.pop_back();
+        c->clustered_position.erase(body);
+    }
+    if (c->soft_split && c->split_shared[body]) { c->split_shared[body] = 0; c->split_patches.push_back({1, (size_t)body, -1, 0, 0}); }
+    c->clustered_dirty = true; c->soft_flags_stale = true;
 }
 
 // TypeProcessor.Remove on the island layout. false: not possible here (nothing was changed).
@@ -135,10 +208,15 @@ static bool soft_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index) {
     return true;
 }
 
-// True when no body lost its last constraint since the last flush (see soft_remove).
+// Bodies that lost their last constraint since the last flush and did not get one back leave the plan (soft_release_body). Always true since round 3 (BEPUHIP_SOFT_ORPHANS=0:
+// round 2's behaviour, the context leaves the island schedule instead).
 static bool soft_bodies_still_constrained(bepuhip_ctx* c) {
+    const bool release = env_int("BEPUHIP_SOFT_ORPHANS", 1) != 0;
     bool ok = true;
-    for (int32_t body : c->soft_orphans) ok &= c->body_degree[body] > 0;
+    for (int32_t body : c->soft_orphans) {
+        if (c->body_degree[body] > 0) continue;
+        if (release) soft_release_body(c, body); else ok = false;
+    }
     c->soft_orphans.clear();
     return ok || soft_refuse("a body lost its last constraint");
 }
@@ -149,14 +227,43 @@ static bool soft_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, con
     if (c->soft_split) return split_add(c, tb, refs, prestep, violation);
     soft_ensure_degrees(c);
     const int t = (int)(tb - c->tbs.data()), nb = tb->info.bodies;
-    int cl = -1;
+    int cl = -1, dynamic_bodies = 0, newcomers = 0;
     for (int k = 0; k < nb; ++k) {
         if ((uint32_t)refs[k] >= kDynamicLimit) continue;
-        if (refs[k] >= (int)c->body_cluster.size() || c->body_cluster[refs[k]] < 0) return soft_refuse("the new constraint's body had no constraints");
+        ++dynamic_bodies;
+        if (refs[k] >= (int)c->body_cluster.size() || c->body_cluster[refs[k]] < 0) { ++newcomers; continue; }  // a body without constraints so far: it joins the cluster below
         if (cl >= 0 && c->body_cluster[refs[k]] != cl) return soft_refuse("the new constraint's bodies live in two clusters");
         cl = c->body_cluster[refs[k]];
     }
-    if (cl < 0) return soft_refuse("the new constraint has no dynamic body");
+    if (dynamic_bodies == 0) return soft_refuse("the new constraint has no dynamic body");
+    if (newcomers > 0 && env_int("BEPUHIP_SOFT_ORPHANS", 1) == 0) return soft_refuse("the new constraint's body had no constraints");
+    for (int k = 0; k < nb; ++k) {
+        if ((uint32_t)refs[k] < kDynamicLimit && (size_t)refs[k] < c->body_batches.size() && tb->batch < 64 && (c->body_batches[refs[k]] >> tb->batch) & 1) { *violation = true; return false; }
+        if (nb == 2 && refs[0] == refs[1]) return soft_refuse("a constraint between a body and itself");
+    }
+    if (cl < 0) {  // only newcomers: a new island — into the first cluster that has a free device slot in this type batch and LDS slots for them
+        soft_ensure_free_slots(c);
+        for (size_t q = 0; q < c->clusters_host.size() && cl < 0; ++q) {
+            bool row = false;
+            for (int s0 = tb->seg_begin[q]; s0 < tb->seg_begin[q + 1] && !row; ++s0) row = tb->perm[s0] < 0;
+            if (row && (int)c->cluster_free_slots[q].size() >= nb + 1) cl = (int)q;
+        }
+        if (cl < 0) return soft_refuse("no cluster has room for a new island");
+    }
+    {   // room for everything before anything is taken: a device slot of the type batch, LDS slots for the newcomers and for kinematic copies the cluster lacks
+        bool row = false;
+        for (int s0 = tb->seg_begin[cl]; s0 < tb->seg_begin[cl + 1] && !row; ++s0) row = tb->perm[s0] < 0;
+        if (!row) return soft_refuse("no free device slot in the cluster's segment of the type batch");
+        int needed = newcomers;
+        for (int k = 0; k < nb; ++k) needed += (uint32_t)refs[k] >= kDynamicLimit && !c->cluster_kin[cl].count(refs[k] & kRefMask);
+        if (needed > 0) {
+            soft_ensure_free_slots(c);
+            if ((int)c->cluster_free_slots[cl].size() < needed) return soft_refuse("no free LDS slot in the cluster for a new body or kinematic copy");
+            if ((int)c->clustered_dynamic_host.size() + newcomers > c->clustered_dynamic_capacity) return soft_refuse("the plan's body list is full");
+        }
+    }
+    for (int k = 0; k < nb; ++k)
+        if ((uint32_t)refs[k] < kDynamicLimit && (refs[k] >= (int)c->body_cluster.size() || c->body_cluster[refs[k]] < 0) && !soft_adopt_body(c, refs[k], cl)) return false;
     // The batch invariant the whole solve rests on (Solver.cs:1046-1051, asserted by the reference in debug builds): a dynamic body appears at most once per synchronized
     // batch. A caller that breaks it would get a silent race on the body's velocity inside one work item or launch: refused here, where the host knows the references.
     for (int k = 0; k < nb; ++k)
@@ -165,7 +272,12 @@ static bool soft_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, con
     for (int k = 0; k < nb; ++k) {
         if ((uint32_t)refs[k] < kDynamicLimit) { halves[k] = (unsigned)c->body_lref[refs[k]]; continue; }
         auto copy = c->cluster_kin[cl].find(refs[k] & kRefMask);
-        if (copy == c->cluster_kin[cl].end()) return soft_refuse("the cluster holds no copy of the new constraint's kinematic body");
+        if (copy == c->cluster_kin[cl].end()) {  // the cluster gets a private copy of the kinematic body (room was checked above)
+            const int slot = c->cluster_free_slots[cl].back();
+            c->cluster_free_slots[cl].pop_back();
+            soft_patch_slot_table(c, cl, slot, (refs[k] & kRefMask) | kSlotKinematic);
+            copy = c->cluster_kin[cl].emplace(refs[k] & kRefMask, slot).first;
+        }
         halves[k] = (unsigned)copy->second | 0x8000u;
     }
     int d = -1;
@@ -275,7 +387,8 @@ static void split_ensure_mirrors(bepuhip_ctx* c) {
     for (auto& apps : c->body_apps) std::sort(apps.begin(), apps.end(), [](const bepuhip_ctx::SplitApp& a, const bepuhip_ctx::SplitApp& b) { return a.tb < b.tb; });
     // how often every ghost / kinematic copy of every cluster is referenced: a copy nothing references any more gives its LDS slot back (split_release_copy)
     c->cluster_extra_uses.assign(c->clusters_host.size(), {});
-    c->cluster_free_slots.assign(c->clusters_host.size(), {});
+    c->free_slots_ready = false;
+    soft_ensure_free_slots(c);
     for (auto& tb : c->tbs)
         for (int d = 0; d < tb.slots; ++d) {
             if (tb.perm[d] < 0) continue;
@@ -363,17 +476,28 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
     split_ensure_mirrors(c);
     const int t = (int)(tb - c->tbs.data()), nb = tb->info.bodies;
     int homes[2] = {-1, -1};
+    bool newcomer[2] = {false, false};  // a body without constraints so far: it becomes a body of the cluster that runs the constraint
+    int dynamic_bodies = 0, newcomers = 0;
     for (int k = 0; k < nb; ++k) {
         if ((uint32_t)refs[k] >= kDynamicLimit) continue;
-        if (refs[k] >= (int)c->body_cluster.size() || c->body_cluster[refs[k]] < 0) return soft_refuse("the new constraint's body had no constraints");
+        ++dynamic_bodies;
+        if ((size_t)refs[k] >= c->shared_bodies) return soft_refuse("a body beyond the split plan's shared-body tables");
+        soft_ensure_body(c, refs[k]);
+        if (c->body_cluster[refs[k]] < 0) {
+            if (env_int("BEPUHIP_SOFT_ORPHANS", 1) == 0) return soft_refuse("the new constraint's body had no constraints");
+            newcomer[k] = true; ++newcomers;
+            continue;
+        }
         if (c->body_degree[refs[k]] >= 255) return soft_refuse("a body with 255 constraints (ranks travel as bytes)");
         if (tb->batch < 64 && (c->body_batches[refs[k]] >> tb->batch) & 1) { *violation = true; return false; }
         homes[k] = c->body_cluster[refs[k]];
     }
+    if (nb == 2 && refs[0] == refs[1]) return soft_refuse("a constraint between a body and itself");
     // The cluster that runs it: one with a free device slot in its segment of the type batch and LDS slots for the copies it lacks. Tried in this order: the home of one
     // of its dynamic bodies (the one that already holds a ghost of the other first), then any cluster that already runs a constraint of one of the bodies (it holds
     // that body's slot or ghost; the bodies become shared if they were not), then the next clusters by number.
-    if (homes[0] < 0 && homes[1] < 0) return soft_refuse("the new constraint has no dynamic body");
+    if (dynamic_bodies == 0) return soft_refuse("the new constraint has no dynamic body");
+    if ((int)c->clustered_dynamic_host.size() + newcomers > c->clustered_dynamic_capacity) return soft_refuse("the plan's body list is full");
     int candidates[2 + 32], ncand = 0;
     auto candidate = [&](int cluster) { if (cluster < 0 || ncand == 34) return; for (int q = 0; q < ncand; ++q) if (candidates[q] == cluster) return; candidates[ncand++] = cluster; };
     if (nb == 2 && homes[0] >= 0 && homes[1] >= 0 && homes[0] != homes[1]) {
@@ -385,6 +509,7 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
     auto copies_missing = [&](int cluster) {
         int missing = 0;
         for (int k = 0; k < nb; ++k) {
+            if (newcomer[k]) { ++missing; continue; }  // its home slot, wherever the constraint runs
             const int32_t key = (uint32_t)refs[k] >= kDynamicLimit ? ((refs[k] & kRefMask) | kSlotKinematic) : (homes[k] == cluster ? -1 : (refs[k] | kSlotGhost));
             if (key >= 0 && !c->cluster_extra[cluster].count(key)) ++missing;
         }
@@ -412,8 +537,8 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
         }
     }
     if (cl < 0) {  // last resort: the next clusters by number run it on ghosts of both bodies (any cluster can; it costs two shared bodies, a lost plan costs the schedule)
-        const int first = homes[0] >= 0 ? homes[0] : homes[1], nclusters = (int)c->clusters_host.size();
-        for (int step = 1; step <= std::min(nclusters - 1, 24) && cl < 0; ++step) {
+        const int first = homes[0] >= 0 ? homes[0] : (homes[1] >= 0 ? homes[1] : 0), nclusters = (int)c->clusters_host.size();
+        for (int step = (homes[0] < 0 && homes[1] < 0) ? 0 : 1; step <= std::min(nclusters - 1, 24) && cl < 0; ++step) {  // (only newcomers: a new island, from cluster 0 on)
             const int cluster = (first + step) % nclusters;
             bool tried = false;
             for (int q = 0; q < ncand; ++q) tried |= candidates[q] == cluster;
@@ -425,6 +550,8 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
         }
     }
     if (cl < 0) return soft_refuse(row_room ? "no free LDS slot in the cluster for a ghost or kinematic copy" : "no free device slot in the cluster's segment of the type batch");
+    for (int k = 0; k < nb; ++k)
+        if (newcomer[k]) { if (!soft_adopt_body(c, refs[k], cl)) return false; homes[k] = cl; }
     int32_t lrefs[2] = {kPlanDeadLref, kPlanDeadLref};
     for (int k = 0; k < nb; ++k) {
         const int32_t r = refs[k];
@@ -605,8 +732,19 @@ static void flush_soft_host(bepuhip_ctx* c) {
 }
 static int32_t rebuild_flags(bepuhip_ctx* c);
 static int32_t flush_soft(bepuhip_ctx* c) {
-    if (c->soft_slots.empty() && c->soft_index.empty() && !c->soft_items_dirty && c->split_rerank.empty() && c->split_patches.empty() && c->kin_touched.empty()) return BEPUHIP_OK;
-    if (soft_update_kinlist(c)) {  // a kinematic body gained its first or lost its last constraint: the kinematic workgroup's list and the body flags follow
+    c->body_moves.clear();
+    if (c->soft_slots.empty() && c->soft_index.empty() && !c->soft_items_dirty && c->split_rerank.empty() && c->split_patches.empty() && c->kin_touched.empty() && !c->clustered_dirty &&
+        !c->kinlist_dirty)
+        return BEPUHIP_OK;
+    if (c->clustered_dirty) {  // bodies joined or left the plan: the list behind kFlagClustered
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (!c->clustered_dynamic_host.empty())
+            HIP_TRY(hipMemcpy(c->d_clustered_dynamic, c->clustered_dynamic_host.data(), c->clustered_dynamic_host.size() * 4, hipMemcpyHostToDevice));
+        c->clustered_dynamic_count = (int)c->clustered_dynamic_host.size();
+        c->clustered_dirty = false;
+    }
+    if (soft_update_kinlist(c) || c->kinlist_dirty) {
+        c->kinlist_dirty = false;  // a kinematic body gained its first or lost its last constraint: the kinematic workgroup's list and the body flags follow
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_kinlist) { hipFree(c->d_kinlist); c->d_kinlist = nullptr; }
         c->kinlist_count = (int)c->kinlist_host.size();

@@ -577,7 +577,14 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         HIP_TRY(upload_ints(plan.items.data(), plan.items.size() * sizeof(ClusterItem), (void**)&c->d_items));
         HIP_TRY(upload_ints(plan.batch_item_begin.data(), plan.batch_item_begin.size() * 4, (void**)&c->d_batch_item_begin));
         HIP_TRY(upload_ints(plan.cluster_bodies.data(), plan.cluster_bodies.size() * 4, (void**)&c->d_cluster_bodies));
-        HIP_TRY(upload_ints(plan.clustered_dynamic.data(), plan.clustered_dynamic.size() * 4, (void**)&c->d_clustered_dynamic));
+        {  // with room for the bodies structural updates bring into the plan (bepu_soft_updates.h: a body's first constraint)
+            c->clustered_dynamic_host = plan.clustered_dynamic;
+            c->clustered_position.clear();
+            c->clustered_dynamic_capacity = (int)plan.clustered_dynamic.size() + std::max(256, (int)plan.clustered_dynamic.size() / 16);
+            HIP_TRY(hipMalloc((void**)&c->d_clustered_dynamic, (size_t)c->clustered_dynamic_capacity * 4));
+            if (!plan.clustered_dynamic.empty())
+                HIP_TRY(hipMemcpy(c->d_clustered_dynamic, plan.clustered_dynamic.data(), plan.clustered_dynamic.size() * 4, hipMemcpyHostToDevice));
+        }
         for (int threads : kClusterThreadChoices)
             for (int tr = 0; tr < 2; ++tr)
                 for (int wide = 0; wide < 2; ++wide)
@@ -597,11 +604,14 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         c->row_policy = -1; c->policy_samples = 0;  // a new topology is measured afresh
         c->clusters_shared = plan.shared;
         if (plan.shared) {  // split islands: velocity / event tables of the bodies more than one cluster touches (indexed by body, only the shared ones are used)
-            c->shared_bodies = plan.shared_info.size();
+            // (long enough for the bodies that have no constraints yet: structural updates may bring them into the plan and share them)
+            c->shared_bodies = std::max(plan.shared_info.size(), (size_t)std::max(c->body_count, 0)) + 1024;
             HIP_TRY(hipMalloc((void**)&c->d_shared_vel, c->shared_bodies * 4 * sizeof(float4)));  // two records (substep parity) of two float4 per body
             HIP_TRY(hipMemset(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4)));         // cleared here, then never again: every step's event numbers start above the last step's
             c->shared_epoch = 0;
-            HIP_TRY(upload_ints(plan.shared_info.data(), plan.shared_info.size() * 4, (void**)&c->d_shared_info));
+            HIP_TRY(hipMalloc((void**)&c->d_shared_info, c->shared_bodies * 4));
+            HIP_TRY(hipMemset(c->d_shared_info, 0, c->shared_bodies * 4));
+            if (!plan.shared_info.empty()) HIP_TRY(hipMemcpy(c->d_shared_info, plan.shared_info.data(), plan.shared_info.size() * 4, hipMemcpyHostToDevice));
             for (int threads : kClusterThreadChoices)
                 for (int tr = 0; tr < 2; ++tr)
                     for (int wide = 0; wide < 2; ++wide)

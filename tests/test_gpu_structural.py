@@ -559,3 +559,62 @@ def test_body_removal_moves_the_last_body_and_patches_its_references(hip_solver_
             solver.replan()
             assert solver.schedule() in (1, 2)
             frames(1)
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_bodies_join_and_leave_the_plan_with_their_first_and_last_constraint(hip_solver_factory, monkeypatch, split):
+    """A body without constraints is not part of an island plan (the tail integrates it once per frame, as the reference integrates unconstrained bodies). Its first
+    constraint brings it into the cluster that runs the constraint — an unused LDS slot, an entry in the list behind kFlagClustered — and its last one takes it out again
+    (round 3; round 2 left the island schedule in both cases). Two unconstrained bodies that get a constraint between them form a new island in a cluster with room.
+    The context stays on its plan throughout; bit-exact against the oracle every frame."""
+    if split:
+        monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "12")
+    rng = np.random.default_rng(9)
+    connected = 2600 if split else 60
+    rows = [small_scenes.random_dynamic_body(rng, rng.uniform(-3, 3, 3)) for _ in range(connected + 20)]
+    ms = MutableSolver(np.stack(rows))
+    for k in range(connected - 1):
+        ms.add(7 if k % 2 else 5, [k, k + 1], small_scenes.prestep_for(rng, 7 if k % 2 else 5, ms.bodies[k, 4:7], ms.bodies[k + 1, 4:7]))
+    for _ in range(connected if split else 0):  # (a chain alone would be cut into strips with hardly any shared body)
+        a, b = (int(x) for x in rng.choice(connected, 2, replace=False))
+        ms.add(4, [a, b], small_scenes.prestep_for(rng, 4, ms.bodies[a, 4:7], ms.bodies[b, 4:7]))
+    sd, cb = SolveDescription(1, 4), PoseIntegratorCallbacks()
+    solver = hip_solver_factory(reserve_update_slots=True)
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+    want = 2 if split else 1
+    assert solver.schedule() == want
+
+    def frames(n):
+        for _ in range(n):
+            export = ms.to_scene()
+            oracle_ffi.solve(export, 1 / 60, sd, cb, threads=4)
+            ms.absorb(export)
+            solver.solve(1 / 60, sd, cb)
+            got = ms.to_scene()
+            solver.download(got)
+            m = pu.compare_scenes(export, got)
+            assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+        assert solver.schedule() == want
+
+    def add(a, b):  # a contact between a and b, of a type its batch (Solver.Add's first fit) already holds: nothing here opens a batch or a type batch
+        bi = next(i for i in range(len(ms.batches)) if a not in ms.batch_handles[i] and b not in ms.batch_handles[i])
+        t = ms.type_order[bi][0]
+        lane = small_scenes.prestep_for(rng, t, ms.bodies[a, 4:7], ms.bodies[b, 4:7])
+        bi, index, encoded = ms.add(t, [a, b], lane)
+        assert solver.add_constraint(bi, t, encoded, lane) == index
+        return bi, t, index
+
+    frames(2)
+    free = connected  # the first body without constraints
+    add(free, free + 1)                        # two newcomers: a new island
+    joined = add(0, free + 2)                  # a newcomer joins body 0's cluster
+    frames(2)
+    ms.remove(*joined); solver.remove_constraint(*joined)      # ... and leaves again
+    add(free + 1, free + 3)                    # the new island grows by another newcomer
+    frames(2)
+    for location in sorted(ms.locations(lambda t: True), reverse=True):  # the new island dissolves: three bodies leave
+        if any((int(r) & 0x3FFFFFFF) >= free for r in ms.batches[location[0]][location[1]]["refs"][location[2]]):
+            ms.remove(*location); solver.remove_constraint(*location)
+    frames(2)
+    add(free, connected - 1)                   # and one of them comes back
+    frames(2)

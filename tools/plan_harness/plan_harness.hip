@@ -192,6 +192,10 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
     for (auto& tb : c->tbs) { tb.lrefs_off = offset; offset += tb.lrefs_soa.size(); }  // the word patches name slab offsets
     std::vector<std::vector<int32_t>> refs_image(c->tbs.size()), lrefs_image(c->tbs.size());
     for (size_t t = 0; t < c->tbs.size(); ++t) { refs_image[t] = c->tbs[t].refs_soa; lrefs_image[t] = c->tbs[t].lrefs_soa; }
+    c->shared_bodies = plan.shared_info.size() + 1024;  // what build_constraints sets up on a device
+    shared_info.resize(c->shared_bodies, 0u);
+    c->clustered_dynamic_host = plan.clustered_dynamic;
+    c->clustered_dynamic_capacity = (int)plan.clustered_dynamic.size() + 256;
     soft_setup(c, plan);
     if (!c->soft_ok) { printf("churn: the plan takes no structural updates\n"); return 0; }
     long calls = 0;
