@@ -174,6 +174,96 @@ static void soft_release_body(bepuhip_ctx* c, int32_t body) {
     c->clustered_dirty = true; c->soft_flags_stale = true;
 }
 
+static void split_ensure_mirrors(bepuhip_ctx* c);
+// Bodies.RemoveAt (BodySet.cs:83-110) moved the last body into a freed slot: body `from` is body `to` from now on. It keeps its cluster, its LDS slots (home, ghosts,
+// kinematic copies), its ranks and its constraints; every table that names it by index is re-keyed, the slot tables on the device are patched. The caller patches the
+// references constraint by constraint (soft_update_reference below) and sends the body array again.
+static bool soft_move_body(bepuhip_ctx* c, int32_t from, int32_t to, bool kinematic) {
+    if (kinematic) {
+        soft_ensure_kin_uses(c);
+        if (c->kin_uses.count(to) && c->kin_uses[to] > 0) return soft_refuse("a body moved onto a kinematic body that still has constraints");
+        c->kin_uses[to] = c->kin_uses[from];
+        c->kin_uses.erase(from);
+        for (int32_t& body : c->kinlist_host) if (body == from) { body = to; c->kinlist_dirty = true; }
+        for (size_t cl = 0; cl < c->clusters_host.size(); ++cl) {
+            if (c->soft_split) {
+                auto found = c->cluster_extra[cl].find(from | kSlotKinematic);
+                if (found == c->cluster_extra[cl].end()) continue;
+                const int slot = found->second;
+                c->cluster_extra[cl].erase(found);
+                c->cluster_extra[cl][to | kSlotKinematic] = slot;
+                auto uses = c->cluster_extra_uses[cl].find(from | kSlotKinematic);
+                if (uses != c->cluster_extra_uses[cl].end()) { const int32_t n = uses->second; c->cluster_extra_uses[cl].erase(uses); c->cluster_extra_uses[cl][to | kSlotKinematic] = n; }
+                soft_patch_slot_table(c, (int)cl, slot, to | kSlotKinematic);
+            } else {
+                auto found = c->cluster_kin[cl].find(from);
+                if (found == c->cluster_kin[cl].end()) continue;
+                const int slot = found->second;
+                c->cluster_kin[cl].erase(found);
+                c->cluster_kin[cl][to] = slot;
+                soft_patch_slot_table(c, (int)cl, slot, to | kSlotKinematic);
+            }
+        }
+        c->soft_flags_stale = true;
+        return true;
+    }
+    if ((size_t)from >= c->body_cluster.size() || c->body_cluster[from] < 0) return soft_refuse("a moved body that is not part of the plan");
+    if (c->soft_split && (size_t)to >= c->shared_bodies) return soft_refuse("a body beyond the split plan's shared-body tables");
+    soft_ensure_body(c, to);
+    if (c->body_cluster[to] >= 0 && c->body_degree[to] == 0) soft_release_body(c, to);  // the removed body lost its last constraint in this same batch of updates: it leaves now
+    if (c->body_cluster[to] >= 0) return soft_refuse("a body moved onto one that still has constraints");
+    const int cl = c->body_cluster[from], slot = c->body_lref[from] & 0x3FFF;
+    c->body_cluster[to] = cl; c->body_lref[to] = c->body_lref[from]; c->body_cluster[from] = -1;
+    c->body_degree[to] = c->body_degree[from]; c->body_degree[from] = 0;
+    c->body_batches[to] = c->body_batches[from]; c->body_batches[from] = 0;
+    int32_t entry = to;
+    if (c->soft_split) {
+        c->split_shared[to] = c->split_shared[from]; c->split_shared[from] = 0;
+        c->body_apps[to].swap(c->body_apps[from]); c->body_apps[from].clear();
+        if (c->split_shared[to]) {
+            entry |= kSlotSharedHome;
+            for (size_t q = 0; q < c->clusters_host.size(); ++q) {  // its ghost copies
+                auto found = c->cluster_extra[q].find(from | kSlotGhost);
+                if (found == c->cluster_extra[q].end()) continue;
+                const int ghost_slot = found->second;
+                c->cluster_extra[q].erase(found);
+                c->cluster_extra[q][to | kSlotGhost] = ghost_slot;
+                auto uses = c->cluster_extra_uses[q].find(from | kSlotGhost);
+                if (uses != c->cluster_extra_uses[q].end()) { const int32_t n = uses->second; c->cluster_extra_uses[q].erase(uses); c->cluster_extra_uses[q][to | kSlotGhost] = n; }
+                soft_patch_slot_table(c, (int)q, ghost_slot, to | kSlotGhost);
+            }
+            c->split_patches.push_back({1, (size_t)from, -1, 0, 0});  // degrees in shared_info (read from body_apps at the flush)
+            c->split_patches.push_back({1, (size_t)to, -1, 0, 0});
+        }
+        if (c->split_rerank.erase(from)) c->split_rerank.insert(to);
+    }
+    soft_patch_slot_table(c, cl, slot, entry);
+    soft_clustered_positions(c);
+    auto at = c->clustered_position.find(from);
+    if (at != c->clustered_position.end()) { const int32_t position = at->second; c->clustered_dynamic_host[position] = to; c->clustered_position.erase(at); c->clustered_position[to] = position; }
+    for (int32_t& orphan : c->soft_orphans) if (orphan == from) orphan = to;
+    c->clustered_dirty = true; c->soft_flags_stale = true;
+    return true;
+}
+// TypeProcessor.UpdateForBodyMemoryMove (TypeProcessor.cs:807) on the island layout: one reference of one constraint follows a body that moved.
+static bool soft_update_reference(bepuhip_ctx* c, HostTypeBatch* tb, int index, int k, int32_t ref) {
+    if (!c->soft_ok || tb->slots == 0 || tb->info.bodies > 2 || env_int("BEPUHIP_SOFT_BODY_MOVES", 1) == 0) return soft_refuse("a body reference changed (a body moved in memory)");
+    if (c->soft_split) split_ensure_mirrors(c); else soft_ensure_degrees(c);
+    const int d = tb->inv[index];
+    int32_t& mirror = tb->dev_refs[(size_t)k * tb->stride + d];
+    if (mirror < 0 || ((mirror ^ ref) & ~kRefMask) != 0) return soft_refuse("a body reference changed its kind");
+    const int32_t from = mirror & kRefMask, to = ref & kRefMask;
+    if (from == to) return true;
+    auto known = c->body_moves.find(from);
+    if (known == c->body_moves.end() || known->second != to) {  // the first patch of this move brings the body's tables along
+        if (!soft_move_body(c, from, to, (uint32_t)ref >= kDynamicLimit)) return false;
+        c->body_moves[from] = to;
+    }
+    mirror = ref;
+    c->split_patches.push_back({3, tb->refs_off + (size_t)k * tb->stride + d, (int32_t)(tb - c->tbs.data()), d, k});
+    return true;
+}
+
 // TypeProcessor.Remove on the island layout. false: not possible here (nothing was changed).
 static bool split_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index);
 static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, const float* prestep, bool* violation);
@@ -699,6 +789,9 @@ static std::vector<ResolvedWord> split_resolve_patches(bepuhip_ctx* c) {
             const HostTypeBatch& tb = c->tbs[wp.tb];
             const int lref_rows = (tb.info.bodies + 1) / 2;
             words.push_back({0, wp.index, wp.row < lref_rows ? split_packed_lrefs(tb, wp.slot, wp.row) : tb.plan_ranks[(size_t)(wp.row - lref_rows) * tb.stride + wp.slot]});
+        } else if (wp.table == 3) {  // a body reference (applied after the whole-slot writes of the same flush: a slot's payload may still carry the old index)
+            const HostTypeBatch& tb = c->tbs[wp.tb];
+            words.push_back({0, wp.index, (uint32_t)tb.dev_refs[(size_t)wp.row * tb.stride + wp.slot]});
         } else if (wp.table == 1) words.push_back({1, wp.index, (uint32_t)c->body_apps[wp.index].size()});
         else words.push_back({2, wp.index, (uint32_t)c->cluster_bodies_host[wp.index]});
     }

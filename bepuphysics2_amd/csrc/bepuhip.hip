@@ -1865,10 +1865,16 @@ int32_t bepuhip_remove_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id
 }
 
 int32_t bepuhip_update_body_reference(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t index, int32_t slot, int32_t ref) {
-    int32_t st = structural_preamble(c);
+    int32_t st = structural_preamble(c, true);
     if (st != BEPUHIP_OK) return st;
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb || index < 0 || index >= tb->count || slot < 0 || slot >= tb->info.bodies || ref < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad update_body_reference argument");
+    if (c->soft_ok) {  // on the island layout: the body keeps its place in the plan under its new index
+        if (soft_update_reference(c, tb, index, slot, ref)) { c->requirk_stale = true; return BEPUHIP_OK; }
+        HIP_TRY(hipSetDevice(c->device));
+        if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;
+        tb = find_tb(c, batch, type_id);
+    }
     bepuhip_ctx::PendingOp p;
     p.tb = (int)(tb - c->tbs.data());
     p.op = StructuralOp{(unsigned)tb->refs_off, (unsigned)tb->prestep_off, (unsigned)tb->accum_off, tb->stride, tb->info.bodies, tb->info.prestep, tb->info.impulse, 2, slot, index,

@@ -209,8 +209,9 @@ int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* ctx, int32_t batch_i
  * alone: a removal frees its device slot where it is (the caller's indices are remapped: swap-with-last), an addition takes a free slot of the segment of the cluster its
  * bodies live in — one left by a removal, or one reserved at planning with BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS — and the predecessor lists of that cluster's work items are
  * rebuilt. What the plan cannot absorb makes the context fall back to the launch-per-batch schedule (rows back in the caller's order) until the next begin/set/end
- * upload: an addition whose dynamic bodies are not all in one cluster, or had no constraint, or needs a kinematic body the cluster holds no copy of, or a type batch
- * the batch does not have yet, or finds no free slot; a frame's updates that leave a body without constraints; update_body_reference; three- and four-body types.
+ * upload (or bepuhip_replan): an addition whose dynamic bodies are not all in one cluster (whole-island plans), or a type batch the batch does not have yet, or one
+ * that finds no free slot; three- and four-body types. A body without constraints joins the plan with its first constraint and leaves it with its last one (judged per
+ * solve: a pair removed and added again in the same frame changes nothing); update_body_reference keeps the moved body's place in the plan under its new index.
  * Split-island plans (islands too large for one workgroup, cut into clusters that share bodies) take the updates as well: an addition may name bodies of two clusters (the
  * cluster that runs it gets a ghost copy of the foreign body, which becomes a shared body if it was not), a removal gives such a copy's LDS slot back; ranks and hand-off
  * flags of the bodies concerned are recomputed at the next solve. With BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS a split plan reserves a quarter more device slots (at least four)

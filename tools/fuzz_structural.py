@@ -23,7 +23,7 @@ TYPES = [4, 5, 6, 7, 22, 25, 30, 47, 0, 3, 23, 46]  # two-body manifolds and joi
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
 scenes = frames_total = bad = stayed = refused = 0
-split_scenes = split_stayed = replans = 0
+split_scenes = split_stayed = replans = body_removals = 0
 while time.time() < t_end:
     big = rng.random() < 0.3  # one island no workgroup holds: the split-island plan (two-body types and one-body manifolds; forced cluster counts so that small scenes split too)
     nb = int(rng.integers(1500, 3500)) if big else int(rng.integers(30, 400))
@@ -39,7 +39,7 @@ while time.time() < t_end:
         t = TYPES[int(rng.integers(len(TYPES)))]
         one_body = small_scenes.TYPE_TABLE[t][0] == 1
         while True:
-            a, b = (int(x) for x in rng.choice(nb, 2, replace=False))
+            a, b = (int(x) for x in rng.choice(ms.bodies.shape[0], 2, replace=False))
             if one_body and not ms.is_kinematic(a):
                 bodies = [a]
                 break
@@ -70,6 +70,17 @@ while time.time() < t_end:
               solver.remove_constraint(bi, t, i)
           for _ in range(int(rng.integers(0, 8))):
               add_random(solver)
+          if rng.random() < 0.25 and ms.bodies.shape[0] > 20:  # Bodies.RemoveAt: a body loses its constraints, the last body takes its slot, its references are patched
+              victim = int(rng.integers(ms.bodies.shape[0]))
+              mine = sorted((loc for loc in ms.locations() if any((int(r) & 0x3FFFFFFF) == victim for r in ms.batches[loc[0]][loc[1]]["refs"][loc[2]])), reverse=True)
+              if len(mine) <= 12:
+                  for bi, t, i in mine:
+                      ms.remove(bi, t, i)
+                      solver.remove_constraint(bi, t, i)
+                  for bi, t, i, k, encoded in ms.remove_body(victim):
+                      solver.update_body_reference(bi, t, i, k, encoded)
+                  solver.set_bodies(ms.bodies)
+                  body_removals += 1
           if rng.random() < 0.15:  # now and then a fresh plan for what the device holds (bepuhip_replan), whatever schedule the context is on
               solver.replan()
               replans += 1
@@ -100,5 +111,5 @@ while time.time() < t_end:
     solver.close()
     scenes += 1
     bad += not ok
-print(f"re-plans {replans}; scenes {scenes} ({split_scenes} big enough for a split-island plan, {split_stayed} of them still on it at the end), frames {frames_total}, still on an island schedule at the end {stayed}, "
+print(f"re-plans {replans}, body removals {body_removals}; scenes {scenes} ({split_scenes} big enough for a split-island plan, {split_stayed} of them still on it at the end), frames {frames_total}, still on an island schedule at the end {stayed}, "
       f"ended by a refused fallback-batch addition {refused}, mismatching scenes {bad}")
