@@ -34,5 +34,6 @@ for mode in (0, 1, 2):
         bodies = solver.get_bodies(scene.body_count)
         same = "" if mode not in reference else f", bit-identical to the other schedule: {bool(np.array_equal(reference[mode].view(np.int32), bodies.view(np.int32)))}"
         reference.setdefault(mode, bodies)
-        print(f"angular mode {mode}, {'island schedule' if (mode == 0 or clusters == "1") else 'launch-per-batch (BEPUHIP_CONSERVING_CLUSTERS=0)'}: {ms:.4f} ms/step{same}", flush=True)
+        schedule = "island schedule" if (mode == 0 or clusters == "1") else "launch-per-batch (BEPUHIP_CONSERVING_CLUSTERS=0)"
+        print(f"angular mode {mode}, {schedule}: {ms:.4f} ms/step{same}", flush=True)
         solver.close()
