@@ -1791,6 +1791,7 @@ int32_t bepuhip_add_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, c
         if (refs[k] < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "empty body reference");
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (c->soft_ok) {  // on the island layout: a free slot in the segment of the cluster the bodies live in
+        for (int k = 0; k < info.bodies; ++k) c->referenced_bodies = std::max(c->referenced_bodies, (refs[k] & kRefMask) + 1);  // (a solve before the matching set_bodies is refused, validate_solve)
         bool violation = false;
         SoftCallTimer timer(c);
         if (tb && soft_add(c, tb, refs, prestep, &violation)) {
@@ -1870,6 +1871,7 @@ int32_t bepuhip_update_body_reference(bepuhip_ctx* c, int32_t batch, int32_t typ
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb || index < 0 || index >= tb->count || slot < 0 || slot >= tb->info.bodies || ref < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad update_body_reference argument");
     if (c->soft_ok) {  // on the island layout: the body keeps its place in the plan under its new index
+        c->referenced_bodies = std::max(c->referenced_bodies, (ref & kRefMask) + 1);
         if (soft_update_reference(c, tb, index, slot, ref)) { c->requirk_stale = true; return BEPUHIP_OK; }
         HIP_TRY(hipSetDevice(c->device));
         if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;
