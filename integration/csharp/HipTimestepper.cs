@@ -129,6 +129,7 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipStructureList
     struct StructuralOp { public int Kind, Batch, TypeId, Index, Slot, Reference; public int[] References; public float[] Prestep; }
     readonly List<StructuralOp> log = new List<StructuralOp>();   // what the listener saw since the last solve, in order
     public int ReplanInterval = 30;                                // frames between two bepuhip_replan calls at most
+    int residentBodyCount;                                         // Bodies.ActiveSet.Count the device's body array was last sent with
     int framesSinceReplan = 30;
     readonly Dictionary<IntPtr, long> registered = new Dictionary<IntPtr, long>();
     public int ReplayLimit = 65536;                   // a longer log is not cheaper than an upload
@@ -257,7 +258,21 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipStructureList
         ref var activeBodies = ref bodies.ActiveSet; ref var activeSet = ref solver.ActiveSet;
         if (solver.StructureListener != this) { solver.StructureListener = this; resident = false; }   // (the maintainer's field, see IHipStructureListener)
         if (!resident || log.Count > ReplayLimit) Upload(simulation);
-        else { Replay(); RefreshContacts(simulation); }
+        else
+        {
+            // Bodies.Add / RemoveAt since the last frame (a count that changed, or the reference patches of a body that moved into a freed slot): the host's array is
+            // current for every body (last frame's read-back) and authoritative for the new ones — sent whole, before the constraints that reference it
+            bool bodiesChanged = activeBodies.Count != residentBodyCount;
+            foreach (var op in log) bodiesChanged |= op.Kind == 2;
+            Replay();
+            if (bodiesChanged)
+            {
+                Register(activeBodies.DynamicsState.Memory, (long)activeBodies.DynamicsState.Length * sizeof(BodyDynamics));
+                Check(BepuHip.bepuhip_set_bodies(ctx, activeBodies.DynamicsState.Memory, activeBodies.Count));
+            }
+            RefreshContacts(simulation);
+        }
+        residentBodyCount = activeBodies.Count;
         // Solver.ConstrainedKinematicHandles changes with the constraints (Solver.cs:1025, :1374): indices only, sent every frame
         var kinematics = stackalloc int[Math.Max(1, solver.ConstrainedKinematicHandles.Count)];
         for (int i = 0; i < solver.ConstrainedKinematicHandles.Count; ++i)
