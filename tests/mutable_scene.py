@@ -94,7 +94,7 @@ class MutableSolver:
                                 patches.append((bi, t, i, k, int(refs[k])))
                 if last in self.batch_handles[bi]:
                     self.batch_handles[bi][index] = self.batch_handles[bi].pop(last)
-            if last in self.kinematic_uses:
+            if self.kinematic_uses.get(last, 0) > 0:
                 self.kinematic_uses[index] = self.kinematic_uses.pop(last)
                 self.kinematic_constrained[self.kinematic_constrained.index(last)] = index
             self.bodies[index] = self.bodies[last]

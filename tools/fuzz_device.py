@@ -20,7 +20,7 @@ ALL = sorted(TYPE_TABLE.keys())
 TWO_BODY = [t for t in ALL if TYPE_TABLE[t][0] <= 2]
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
-n = bad = split = batch_path = refused = 0
+n = bad = split = batch_path = refused = diverged = 0
 while time.time() < t_end:
     seed = int(rng.integers(1 << 30))
     big = rng.random() < 0.15  # large enough for a split-island plan (every type id since round 3: three- and four-body constraints are split too)
@@ -53,9 +53,12 @@ while time.time() < t_end:
     solver.close()
     split += big and clusters > 1
     batch_path += clusters == 0
+    if not np.isfinite(ref.bodies[:, :15]).all():  # the ORACLE's simulation diverged (random stiff constraints, gyroscopic mode): how NaN and infinity spread from there is the
+        diverged += 1                              # hardware's business (payloads, min / max of a NaN), not the solver's — nothing to compare
+        continue
     m = pu.compare_scenes(ref, got)
     n += 1
     if not (m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"]):
         bad += 1
         print("MISMATCH seed", seed, types, nb, nc, kin, sub, its, use_clusters, frames, cb, m, flush=True)
-print(f"scenes {n} (split-island plans {split}, launch-per-batch {batch_path}, refused as UNSUPPORTED {refused}), mismatches {bad}")
+print(f"scenes {n} (split-island plans {split}, launch-per-batch {batch_path}, refused as UNSUPPORTED {refused}), diverged in the oracle and not compared {diverged}, mismatches {bad}")
