@@ -792,7 +792,7 @@ static std::vector<ResolvedWord> split_resolve_patches(bepuhip_ctx* c) {
         } else if (wp.table == 3) {  // a body reference (applied after the whole-slot writes of the same flush: a slot's payload may still carry the old index)
             const HostTypeBatch& tb = c->tbs[wp.tb];
             words.push_back({0, wp.index, (uint32_t)tb.dev_refs[(size_t)wp.row * tb.stride + wp.slot]});
-        } else if (wp.table == 1) words.push_back({1, wp.index, (uint32_t)c->body_apps[wp.index].size()});
+        } else if (wp.table == 1) words.push_back({1, wp.index, c->split_shared[wp.index] ? (uint32_t)c->body_apps[wp.index].size() : 0u});  // a private body's entry is 0 (an index may change hands)
         else words.push_back({2, wp.index, (uint32_t)c->cluster_bodies_host[wp.index]});
     }
     return words;

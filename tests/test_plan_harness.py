@@ -101,6 +101,14 @@ def test_structural_churn_keeps_a_split_plan_valid_and_its_device_image_equal_to
     out = r.stdout.decode()
     assert r.returncode == 0 and "25 frames" in out and "still on the plan (24 clusters)" in out, out
     assert out.count("validate: 0 violation(s)") == 26, out  # the plan, then every frame
+    # ... and with bodies that leave the plan (all their constraints removed), bodies that move to another index (Bodies.RemoveAt: every reference patched) and bodies that
+    # join (a free index gets a constraint): soft_release_body / soft_move_body / soft_adopt_body on a split plan, shared bodies and their ghost copies included
+    e["PLAN_CHURN_BODIES"] = "1"
+    r = subprocess.run([exe, scenes["pile"], "1", "8"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "still on the plan (24 clusters)" in out and "25 bodies moved to another index, 25 bodies joined" in out, out
+    assert out.count("validate: 0 violation(s)") == 26, out
+    e.pop("PLAN_CHURN_BODIES")
     e["PLAN_CHURN_FAR"] = "1"
     r = subprocess.run([exe, scenes["pile"], "1", "8"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     out = r.stdout.decode()

@@ -189,7 +189,10 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
     std::vector<unsigned> shared_info = plan.shared_info;
     const bool shared_plan = plan.shared;
     size_t offset = 0;
-    for (auto& tb : c->tbs) { tb.lrefs_off = offset; offset += tb.lrefs_soa.size(); }  // the word patches name slab offsets
+    constexpr size_t kRefsBase = (size_t)1 << 40;  // (the references' words get addresses of their own: patches of body moves name them)
+    for (auto& tb : c->tbs) { tb.lrefs_off = offset; tb.refs_off = kRefsBase + offset; offset += std::max(tb.lrefs_soa.size(), tb.refs_soa.size()); }  // the word patches name slab offsets
+    const bool body_events = getenv("PLAN_CHURN_BODIES") != nullptr;
+    long removals = 0, moves = 0, adoptions = 0;
     std::vector<std::vector<int32_t>> refs_image(c->tbs.size()), lrefs_image(c->tbs.size());
     for (size_t t = 0; t < c->tbs.size(); ++t) { refs_image[t] = c->tbs[t].refs_soa; lrefs_image[t] = c->tbs[t].lrefs_soa; }
     c->shared_bodies = plan.shared_info.size() + 1024;  // what build_constraints sets up on a device
@@ -198,6 +201,7 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
     c->clustered_dynamic_capacity = (int)plan.clustered_dynamic.size() + 256;
     soft_setup(c, plan);
     if (!c->soft_ok) { printf("churn: the plan takes no structural updates\n"); return 0; }
+    if (!shared_plan) { printf("churn: only split-island plans are modelled here (the image of a whole-island plan has no rank rows)\n"); return 0; }
     long calls = 0;
     for (int frame = 0; frame < frames; ++frame) {
         for (size_t t = 0; t < c->tbs.size(); ++t) {
@@ -234,6 +238,63 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
                     } printf("churn: frame %d, addition refused (%s): the context would leave the plan here\n", frame, violation ? "batch invariant" : "no room"); return 0; }
             }
         }
+        if (body_events) {
+            // PLAN_CHURN_BODIES: Bodies.RemoveAt and Bodies.Add as the plan sees them. (1) a body loses all its constraints (it leaves the plan at the flush — or right away
+            // when (2) needs its index); (2) the highest body of the plan takes its index: every reference to it is patched (TypeProcessor.UpdateForBodyMemoryMove);
+            // (3) the index that became free gets a constraint with a body of the plan: it joins that body's cluster.
+            const int universe = (int)c->body_cluster.size();
+            auto references_of = [&](int32_t body, auto&& fn) {  // fn(type batch, device slot, body slot) for every live reference to `body`
+                for (size_t t = 0; t < c->tbs.size(); ++t) {
+                    HostTypeBatch& tb = c->tbs[t];
+                    for (int k = 0; k < tb.info.bodies; ++k)
+                        for (int d = 0; d < tb.slots; ++d)
+                            if (tb.perm[d] >= 0 && tb.dev_refs[(size_t)k * tb.stride + d] >= 0 && (tb.dev_refs[(size_t)k * tb.stride + d] & kRefMask) == body && (uint32_t)tb.dev_refs[(size_t)k * tb.stride + d] < kDynamicLimit)
+                                if (!fn(&tb, d, k)) return;
+                }
+            };
+            int victim = -1;
+            for (int probe = 0; probe < universe && victim < 0; ++probe) {
+                const int v = (frame * 131 + 7 + probe * 17) % universe;
+                if (c->body_cluster[v] < 0) continue;
+                int degree = 0; bool two_body_only = true;
+                references_of(v, [&](HostTypeBatch* tb, int, int) { ++degree; two_body_only &= tb->info.bodies <= 2; return true; });
+                if (degree > 0 && degree <= 8 && two_body_only) victim = v;
+            }
+            if (victim >= 0) {
+                for (;;) {  // every removal renumbers its type batch: find the next reference afresh
+                    HostTypeBatch* found = nullptr; int index = -1;
+                    references_of(victim, [&](HostTypeBatch* tb, int d, int) { found = tb; index = tb->perm[d]; return false; });
+                    if (!found) break;
+                    if (!soft_remove(c, found, index)) { printf("churn: frame %d, removal refused\n", frame); return 0; }
+                    ++calls; ++removals;
+                }
+                int last = -1;
+                for (int b = universe - 1; b >= 0 && last < 0; --b) if (b != victim && c->body_cluster[b] >= 0) last = b;
+                bool moved = last > victim;
+                if (moved) {
+                    std::vector<std::array<int64_t, 3>> patches;
+                    references_of(last, [&](HostTypeBatch* tb, int d, int k) { patches.push_back({(int64_t)(tb - c->tbs.data()), tb->perm[d], k}); return true; });
+                    for (auto& p : patches) {
+                        if (!soft_update_reference(c, &c->tbs[p[0]], (int)p[1], (int)p[2], victim)) { printf("churn: frame %d, body move refused: the context would leave the plan here\n", frame); return 0; }
+                        ++calls;
+                    }
+                    ++moves;
+                    // (3) `last` is a free index now: a constraint with a body of the plan brings it back in
+                    for (size_t t = 0; t < c->tbs.size() && moved; ++t) {
+                        HostTypeBatch* tb = &c->tbs[t];
+                        if (tb->info.bodies != 2 || tb->count == 0 || tb->batch >= 64) continue;
+                        for (int partner = victim; partner < universe; ++partner) {
+                            if (partner == last || c->body_cluster[partner] < 0 || ((c->body_batches[partner] >> tb->batch) & 1)) continue;
+                            int32_t refs[2] = {last, partner};
+                            std::vector<float> prestep(tb->info.prestep, 0.5f);
+                            bool violation = false;
+                            if (soft_add(c, tb, refs, prestep.data(), &violation)) { ++calls; ++adoptions; moved = false; }
+                            break;
+                        }
+                    }
+                }
+            }
+        }
         if (!soft_bodies_still_constrained(c)) { printf("churn: frame %d, a body lost its last constraint\n", frame); return 0; }
         const auto f0 = std::chrono::steady_clock::now();
         flush_soft_host(c);
@@ -249,6 +310,12 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
         for (auto& word : split_resolve_patches(c)) {
             if (word.table == 1) { shared_info[word.index] = word.value; continue; }
             if (word.table == 2) { cluster_bodies_image[word.index] = (int32_t)word.value; continue; }
+            if (word.index >= kRefsBase) {  // a body reference
+                size_t t = 0;
+                while (t + 1 < c->tbs.size() && c->tbs[t + 1].refs_off <= word.index) ++t;
+                refs_image[t][word.index - c->tbs[t].refs_off] = (int32_t)word.value;
+                continue;
+            }
             size_t t = 0;
             while (t + 1 < c->tbs.size() && c->tbs[t + 1].lrefs_off <= word.index) ++t;
             lrefs_image[t][word.index - c->tbs[t].lrefs_off] = (int32_t)word.value;
@@ -280,6 +347,7 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
         if (validate(c, now) != 0) { printf("churn: frame %d leaves an invalid plan\n", frame); return 3; }
     }
     size_t live_clusters = c->clusters_host.size();
+    if (body_events) printf("churn: bodies: %ld constraint removals of bodies that left, %ld bodies moved to another index, %ld bodies joined\n", removals, moves, adoptions);
     printf("churn: %d frames, %ld structural calls, still on the plan (%zu clusters)\n", frames, calls, live_clusters);
     return 0;
 }
