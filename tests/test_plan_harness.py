@@ -108,6 +108,11 @@ def test_structural_churn_keeps_a_split_plan_valid_and_its_device_image_equal_to
     out = r.stdout.decode()
     assert r.returncode == 0 and "still on the plan (24 clusters)" in out and "25 bodies moved to another index, 25 bodies joined" in out, out
     assert out.count("validate: 0 violation(s)") == 26, out
+    # the same on a whole-island plan (islands packed into clusters, no shared bodies): new pairs inside an island, bodies leaving / moving / joining
+    r = subprocess.run([exe, scenes["ragdoll_tube"], "1", "8"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "25 frames" in out and "still on the plan" in out and "25 bodies moved to another index, 25 bodies joined" in out, out
+    assert out.count("validate: 0 violation(s)") == 26, out
     e.pop("PLAN_CHURN_BODIES")
     e["PLAN_CHURN_FAR"] = "1"
     r = subprocess.run([exe, scenes["pile"], "1", "8"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

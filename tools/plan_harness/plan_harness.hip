@@ -201,7 +201,7 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
     c->clustered_dynamic_capacity = (int)plan.clustered_dynamic.size() + 256;
     soft_setup(c, plan);
     if (!c->soft_ok) { printf("churn: the plan takes no structural updates\n"); return 0; }
-    if (!shared_plan) { printf("churn: only split-island plans are modelled here (the image of a whole-island plan has no rank rows)\n"); return 0; }
+    // (a whole-island plan keeps no host mirror of its local references: its image is built from what the slot writes carry and checked by the validator alone)
     long calls = 0;
     for (int frame = 0; frame < frames; ++frame) {
         for (size_t t = 0; t < c->tbs.size(); ++t) {
@@ -222,6 +222,7 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
                     for (int step = 1; step <= 16; ++step) {
                         const int32_t near = refs[0] + ((step & 1) ? (step + 1) / 2 : -(step / 2));
                         if (near < 0 || near >= (int32_t)c->body_cluster.size() || c->body_cluster[near] < 0 || near == refs[1] || (tb->batch < 64 && (c->body_batches[near] >> tb->batch) & 1)) continue;
+                        if (!shared_plan && c->body_cluster[near] != c->body_cluster[refs[0]]) continue;  // (a whole-island plan keeps islands apart: a pair across two clusters leaves it)
                         bool taken = false;  // ... by a lane of this window that is still to come back
                         for (int q = i + 1; q < n && !taken; ++q) taken = lanes[q][0] == near || lanes[q][1] == near;
                         if (!taken) { refs[1] = near; break; }
@@ -285,6 +286,11 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
                         if (tb->info.bodies != 2 || tb->count == 0 || tb->batch >= 64) continue;
                         for (int partner = victim; partner < universe; ++partner) {
                             if (partner == last || c->body_cluster[partner] < 0 || ((c->body_batches[partner] >> tb->batch) & 1)) continue;
+                            if (!shared_plan) {  // a free device slot in the partner's cluster, or the addition (rightly) leaves the plan
+                                bool room = false;
+                                for (int q = tb->seg_begin[c->body_cluster[partner]]; q < tb->seg_begin[c->body_cluster[partner] + 1]; ++q) room |= tb->perm[q] < 0;
+                                if (!room) continue;
+                            }
                             int32_t refs[2] = {last, partner};
                             std::vector<float> prestep(tb->info.prestep, 0.5f);
                             bool violation = false;
@@ -303,6 +309,11 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
         for (auto& kv : c->soft_slots) {
             const HostTypeBatch& tb = c->tbs[kv.first.first];
             const int d = kv.first.second, nb = tb.info.bodies, rows = (nb + 1) / 2;
+            if (!shared_plan) {  // payload of a live slot: references, the packed local references, the prestep lane
+                for (int k = 0; k < nb; ++k) refs_image[kv.first.first][(size_t)k * tb.stride + d] = kv.second.live ? (int32_t)kv.second.payload[k] : -1;
+                lrefs_image[kv.first.first][d] = kv.second.live ? (int32_t)kv.second.payload[nb] : (int32_t)kLrefDead;
+                continue;
+            }
             for (int k = 0; k < nb; ++k) refs_image[kv.first.first][(size_t)k * tb.stride + d] = kv.second.live ? tb.dev_refs[(size_t)k * tb.stride + d] : -1;
             for (int r = 0; r < rows; ++r) lrefs_image[kv.first.first][(size_t)r * tb.stride + d] = kv.second.live ? (int32_t)split_packed_lrefs(tb, d, r) : (int32_t)kLrefDead;
             if (kv.second.live) for (int k = 0; k < nb; ++k) lrefs_image[kv.first.first][(size_t)(rows + k) * tb.stride + d] = (int32_t)tb.plan_ranks[(size_t)k * tb.stride + d];
@@ -334,7 +345,7 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
                     if (live && shared_plan && (uint32_t)lrefs_image[t][(size_t)(rows + k) * tb.stride + d] != tb.plan_ranks[(size_t)k * tb.stride + d] && differences++ < 8)
                         fprintf(stderr, "churn: frame %d, rank word image %x != mirror %x (tb %zu slot %d body %d)\n", frame, lrefs_image[t][(size_t)(rows + k) * tb.stride + d], tb.plan_ranks[(size_t)k * tb.stride + d], t, d, k);
                 }
-                for (int r = 0; r < rows; ++r)
+                for (int r = 0; r < rows && shared_plan; ++r)
                     if ((((uint32_t)lrefs_image[t][(size_t)r * tb.stride + d] ^ split_packed_lrefs(tb, d, r)) & ((nb & 1) && r == rows - 1 ? 0xFFFFu : 0xFFFFFFFFu)) != 0 && differences++ < 8)
                         fprintf(stderr, "churn: frame %d, local reference image %x != mirror %x (tb %zu slot %d row %d, live %d)\n", frame, lrefs_image[t][(size_t)r * tb.stride + d], split_packed_lrefs(tb, d, r), t, d, r, (int)live);
             }
