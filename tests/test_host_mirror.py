@@ -131,3 +131,37 @@ def test_timestep_rejects_nonpositive_dt_and_missing_timestepper():
         sim.timestep(0.0)  # Simulation.cs:318-319 ArgumentException
     with pytest.raises(RuntimeError):
         sim.timestep(1 / 60)  # no timestepper attached: this mirror has no CPU solver
+
+
+def test_rig_scene_keeps_the_graph_and_swaps_the_joint_types():
+    """bepuphysics2_amd.synthetic.rig_scene (bench.py's widened_types leg): the ragdoll tube's bodies, batches and constraint counts with seven joint types replaced by
+    widened ones of the same body count; the oracle solves it (finite), and the mirror's host removal of a kinematic body's last constraint takes it out of
+    Solver.ConstrainedKinematicHandles (Solver.cs:1368-1377)."""
+    import oracle_ffi
+    from bepuphysics2_amd.hostlib import HostSimulation
+    from bepuphysics2_amd.scene import TYPE_TABLE, PoseIntegratorCallbacks
+    from bepuphysics2_amd.synthetic import RIG_REMAP, rig_scene
+    sim = HostSimulation.scene("ragdoll_tube", 40, 1, 0, 5)
+    plain = sim.export()
+    sim.close()
+    rigs, sd = rig_scene(40)
+    assert rigs.body_count == plain.body_count and rigs.constraint_count == plain.constraint_count and len(rigs.batches) == len(plain.batches)
+    for a, b in zip(plain.batches, rigs.batches):
+        assert [RIG_REMAP.get(tb.type_id, tb.type_id) for tb in a] == [tb.type_id for tb in b]
+        for x, y in zip(a, b):
+            assert x.count == y.count and np.array_equal(x.body_refs, y.body_refs) and TYPE_TABLE[x.type_id][0] == TYPE_TABLE[y.type_id][0]
+    oracle_ffi.solve(rigs, 1 / 60, sd, PoseIntegratorCallbacks())
+    assert np.isfinite(rigs.bodies).all()
+    # ConstrainedKinematicHandles follows removals in the C++ host mirror
+    sim = HostSimulation.create()
+    dyn = sim.add_body((0, 0, 0), (0, 0, 0, 1), (0, 0, 0), (0, 0, 0), (1, 0, 1, 0, 0, 1), 1.0)
+    kin = sim.add_body((1, 0, 0), (0, 0, 0, 1), (0, 0, 0), (0, 0, 0.25), (0, 0, 0, 0, 0, 0), 0.0)
+    lane = [0.1] * TYPE_TABLE[22][1]
+    first = sim.add_constraint(22, [dyn, kin], lane)
+    second = sim.add_constraint(22, [dyn, kin], lane)
+    assert list(sim.export().constrained_kinematic_indices()) == [kin]
+    sim.remove_constraint(first)
+    assert list(sim.export().constrained_kinematic_indices()) == [kin]
+    sim.remove_constraint(second)
+    assert list(sim.export().constrained_kinematic_indices()) == []
+    sim.close()
