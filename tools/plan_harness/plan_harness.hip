@@ -203,7 +203,9 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
     if (!c->soft_ok) { printf("churn: the plan takes no structural updates\n"); return 0; }
     // (a whole-island plan keeps no host mirror of its local references: its image is built from what the slot writes carry and checked by the validator alone)
     long calls = 0;
+    double calls_ms = 0.0, flush_ms = 0.0;
     for (int frame = 0; frame < frames; ++frame) {
+        const auto frame_begin = std::chrono::steady_clock::now();
         for (size_t t = 0; t < c->tbs.size(); ++t) {
             HostTypeBatch* tb = &c->tbs[t];
             if (tb->info.bodies != 2 || tb->count < 100) continue;
@@ -303,7 +305,10 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
         }
         if (!soft_bodies_still_constrained(c)) { printf("churn: frame %d, a body lost its last constraint\n", frame); return 0; }
         const auto f0 = std::chrono::steady_clock::now();
+        calls_ms += std::chrono::duration<double, std::milli>(f0 - frame_begin).count();
         flush_soft_host(c);
+        std::vector<ResolvedWord> resolved_for_timing = split_resolve_patches(c);  // (the listing half of the flush, timed with it)
+        flush_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
         if (frame < 3) fprintf(stderr, "churn: frame %d, the host half of the flush %.3f ms\n", frame, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count());
         // what flush_soft would send, applied to the image
         for (auto& kv : c->soft_slots) {
@@ -358,6 +363,7 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
         if (validate(c, now) != 0) { printf("churn: frame %d leaves an invalid plan\n", frame); return 3; }
     }
     size_t live_clusters = c->clusters_host.size();
+    printf("churn: host time per frame: the structural calls (with this harness's generator) %.2f ms, ranks + predecessor lists + word list %.2f ms\n", calls_ms / frames, flush_ms / frames);
     if (body_events) printf("churn: bodies: %ld constraint removals of bodies that left, %ld bodies moved to another index, %ld bodies joined\n", removals, moves, adoptions);
     printf("churn: %d frames, %ld structural calls, still on the plan (%zu clusters)\n", frames, calls, live_clusters);
     return 0;
