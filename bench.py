@@ -190,6 +190,14 @@ def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, s
             "upload_ms": upload_ms, "finite": finite}
 
 
+def optional_leg(fn, *a, **k):
+    """An extra leg must never cost the headline its JSON line: a failure is reported in the leg's place."""
+    try:
+        return fn(*a, **k)
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def widened_types_leg(ragdolls: int, device: int, steps: int = 100):
     """The widened constraint types on the driver line (never `value`): the bench scene's ragdolls — same bodies, same constraint graph, same batches — with the seven
     joint types other than BallSocket replaced by widened ones (synthetic.RIG_REMAP: AngularSwivelHinge, DistanceLimit, AngularServo, TwistMotor, AngularAxisMotor, Weld,
@@ -638,7 +646,7 @@ def main():
 
     baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        baseline = cpu_baseline(args.ragdolls, 5)  # the same scene as the GPU leg; bounded by time (about 12 s after picking the thread count)
+        baseline = optional_leg(cpu_baseline, args.ragdolls, 5)  # the same scene as the GPU leg; bounded by time (about 12 s after picking the thread count)
 
     main_clustered = bool(solver.cluster_cycles().size)
     row_policy = {-1: "still measuring", 0: "plain constraint-row accesses", 1: "non-temporal constraint-row accesses", 2: "plain rows + one 8 KB span of code touched ahead per work item"}[solver.row_policy()] if main_clustered else None
@@ -646,16 +654,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
         solver.close()
         targs = None if args.no_traffic else args
-        connected = {"pile_100k": connected_scene_leg("100k-box pile (BASELINE.json configs[1])", "pile", args.ragdolls, local_rank, traffic_args=targs),
-                     "ragdoll_crowd": connected_scene_leg(f"{args.ragdolls} ragdolls in contact with their neighbours (configs[2]'s ragdolls, one island)",
-                                                          "crowd", args.ragdolls, local_rank, traffic_args=targs)}
+        connected = {"pile_100k": optional_leg(connected_scene_leg, "100k-box pile (BASELINE.json configs[1])", "pile", args.ragdolls, local_rank, traffic_args=targs),
+                     "ragdoll_crowd": optional_leg(connected_scene_leg, f"{args.ragdolls} ragdolls in contact with their neighbours (configs[2]'s ragdolls, one island)",
+                                                   "crowd", args.ragdolls, local_rank, traffic_args=targs)}
 
     boundary = None
     lattice_report = None
     widened = None
     if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
-        widened = widened_types_leg(args.ragdolls, local_rank)
-        boundary = boundary_leg(scene, sd, cb, local_rank)
+        widened = optional_leg(widened_types_leg, args.ragdolls, local_rank)
+        boundary = optional_leg(boundary_leg, scene, sd, cb, local_rank)
         lattice_report = lattice_leg(local_rank)
 
     if rank == 0:
