@@ -52,9 +52,11 @@ def cpu_baseline(ragdolls_sample: int, seed: int, target_seconds: float = 14.0):
     per_frame = scene.constraint_count * int((1 + sd.iterations()).sum())
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     session = wide_ffi.Session(scene, 1 / 60, sd, cb, fast=True)
+    pin = wide_ffi.pin_plan("fast")
     curve = []
-    budget_each = target_seconds / 8.0
-    for c in [c for c in (1, 8, 16, 32, 64, 128) if c <= avail] or [1]:
+    budget_each = target_seconds / 9.0
+    counts = {1, 8, 16, 32, 64, 128, pin["first_socket_physical_cores"]}  # ... and exactly one worker per physical core of the socket
+    for c in sorted(c for c in counts if 1 <= c <= avail) or [1]:
         session.solve(1, c)  # untimed: the worker pool starts, pages are touched
         frames, t0, phases = 0, time.perf_counter(), [0.0, 0.0, 0.0, 0.0]
         while True:
@@ -85,11 +87,17 @@ def cpu_baseline(ragdolls_sample: int, seed: int, target_seconds: float = 14.0):
         if el >= target_seconds / 4.0 or frames >= 400:
             break
     session.close()
+    ideal = single * max(1, pin["first_socket_physical_cores"])
     return {"value": max(per_frame * frames / el, best["value"]), "unit": "constraint-iterations/s", "cores": best["threads"], "kind": "port-simd8",
             "single_thread_value": single, "thread_curve": curve, "host_cpus_available": avail,
+            "placement": dict(pin, note="workers pinned one per physical core of ONE socket first (sibling threads next, the other socket last); the session's memory "
+                                        "first-touched by threads pinned to the same cores (oracle/wide/wide_solver.cpp: PinPlan, AlignedCopy)"),
+            "ideal_socket_bound": {"value": ideal, "unit": "constraint-iterations/s",
+                                   "note": "the single-thread figure x the physical cores of one socket: what a perfectly scaling socket would reach — the figure to "
+                                           "hold the GPU against when the measured curve is distrusted (shared host, sync stages)"},
             "timed_region": "PrepareConstraintIntegrationResponsibilities + Solve + IntegrateAfterSubstepping on a persistent session (aligned library-owned buffers, "
                             "handle sets built at creation): Simulation.cs:278-290, nothing else",
-            "sample": f"{ragdolls_sample} ragdolls ({scene.constraint_count} constraints), {frames} frames at {best['threads']} threads after a 1/8/16/32/64/128-thread curve, "
+            "sample": f"{ragdolls_sample} ragdolls ({scene.constraint_count} constraints), {frames} frames at {best['threads']} threads after a 1/8/16/32/64/128-thread curve (plus one worker per physical core of the socket), workers pinned, "
                       f"4 substeps x 1 iteration, oracle/wide (C++ AOSOA-8 AVX2 transcription of the reference's CPU path, -O3 -mavx2, no FMA contraction), reference "
                       f"work-block/sync-stage threading, {avail} CPUs available"}
 

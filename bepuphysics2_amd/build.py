@@ -34,6 +34,39 @@ def _hip_units(src_dir: str):
     return sorted(f for f in os.listdir(src_dir) if f.endswith(".hip"))
 
 
+CODE_PAD_BYTES = 4 * 8192  # kCodeTouchMaxSpans x 8 KB (bepu_kernels_common.h)
+
+
+def check_code_pad(obj: str) -> None:
+    """cluster_kernel's code touch reads up to CODE_PAD_BYTES ahead of a wave's PC as data (bepu_cluster_kernel.h, touch_code_span). Every cluster unit therefore ends
+    in that much never-executed padding, code_pad_kernel; the compiler lays functions out in instantiation order, which this checks in the built gfx950 code object:
+    the pad is the LAST function of .text, long enough, and every cluster_kernel lies before it."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    fat, co = obj + ".fat", obj + ".co"
+    try:
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"],
+                              stderr=subprocess.DEVNULL)
+        table = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "-sW", co], text=True)
+    finally:
+        for f in (fat, co):
+            if os.path.exists(f):
+                os.remove(f)
+    functions = {}
+    for line in table.splitlines():
+        cols = line.split()
+        if len(cols) >= 8 and cols[3] == "FUNC":
+            functions[cols[7]] = (int(cols[1], 16), int(cols[2]))
+    pads = [(a, n) for name, (a, n) in functions.items() if "code_pad_kernel" in name]
+    kernels = [(a, n) for name, (a, n) in functions.items() if "cluster_kernel" in name]
+    if len(pads) != 1 or not kernels:
+        raise RuntimeError(f"{obj}: expected one code_pad_kernel and at least one cluster_kernel in the gfx950 code object")
+    pad_at, pad_bytes = pads[0]
+    if pad_bytes < CODE_PAD_BYTES or any(a + n > pad_at for a, n in functions.values() if (a, n) != pads[0]):
+        raise RuntimeError(f"{obj}: code_pad_kernel ({pad_bytes} bytes at {pad_at:#x}) is not the last function of the unit or is shorter than {CODE_PAD_BYTES} bytes: "
+                           "cluster_kernel's code touch could read past the code object")
+
+
 def build_hip(force: bool = False, jobs: int = 0) -> str:
     """libbepuhip.so = bepuhip.hip (C ABI, launch-per-batch / stream / per-body kernels) + one translation unit per cluster_kernel register budget
     (bepu_cluster_{hot,wide}_{1024,768,512}.hip). Units are compiled to objects in parallel and linked; an object is rebuilt when any source is newer."""
@@ -63,6 +96,8 @@ def build_hip(force: bool = False, jobs: int = 0) -> str:
             return
         tmp = obj + f".tmp{os.getpid()}"
         subprocess.check_call([hipcc] + HIP_COMPILE_FLAGS + ["-c", "-o", tmp, os.path.join(src_dir, unit)], cwd=src_dir)
+        if unit.startswith("bepu_cluster_"):
+            check_code_pad(tmp)
         os.replace(tmp, obj)
 
     with ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 1)) as pool:

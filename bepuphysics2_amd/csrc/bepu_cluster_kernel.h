@@ -57,7 +57,6 @@ struct ClusterShared {
     int ncap;
     ClusterItem* items;
     volatile lds_u32* flags;  // per item: epoch of the last completed pass
-    lds_u32* batch_done;      // per batch: items completed, monotonic over passes (fallback for items with too many predecessors)
     int* lbib;                // batch -> first item of the cluster (batch_count + 1 entries)
     lds_u32* counter;         // item claim counter, monotonic
     int batch_count;
@@ -68,7 +67,7 @@ struct ClusterShared {
     unsigned events;       // integration events every shared body has seen so far (substep index + 1 during the sweeps of a substep)
     unsigned passes;       // passes (warm starts + velocity iterations) completed before the current one, over the whole step
     int code_touch;        // see touch_code_ahead
-    int code_touch_gate;   // ... a second touch (spans) from the gate on, issued before the wait for the predecessors
+    unsigned jitter;       // schedule fuzzing (BEPUHIP_DEBUG_JITTER, 0 = off): see jitter_nap
     unsigned scratch_row;  // LDS byte address of the 256-byte row that swallows the code-touch reads
     // kConserving units only:
     int substep;             // the substep the sweeps belong to
@@ -179,17 +178,16 @@ __device__ __forceinline__ unsigned claim_next(lds_u32* counter) {
 }
 // The wave's LDS velocity stores must have landed before the flag does: LDS executes a wave's instructions in order, the explicit
 // wait makes that independent of the pipeline's internals.
-__device__ __forceinline__ void publish_item(volatile lds_u32* flag, lds_u32* batch_counter, unsigned epoch) {
+__device__ __forceinline__ void publish_item(volatile lds_u32* flag, unsigned epoch) {
     unsigned long long saved;
     asm volatile(
         "s_waitcnt lgkmcnt(0)\n\t"
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, 1\n\t"
         "ds_write_b32 %[fa], %[e]\n\t"
-        "ds_add_u32 %[ba], %[one]\n\t"
         "s_mov_b64 exec, %[sv]"
         : [sv] "=&s"(saved)
-        : [fa] "v"(lds_address(flag)), [e] "v"(epoch), [ba] "v"(lds_address(batch_counter)), [one] "v"(1u)
+        : [fa] "v"(lds_address(flag)), [e] "v"(epoch)
         : "memory");
 }
 
@@ -200,15 +198,6 @@ __device__ __noinline__ void report_stall(unsigned* status, unsigned claims, int
     if ((threadIdx.x & 63) == 0 && atomicCAS(status, 0u, 1u) == 0u) {
         status[1] = blockIdx.x; status[2] = (unsigned)kind; status[3] = (unsigned)k; status[4] = (unsigned)what;
         status[5] = want; status[6] = seen; status[7] = claims;
-    }
-}
-// One bounded poll loop (all lanes read the same LDS word: a broadcast ds_read).
-__device__ __forceinline__ void wait_word(const ClusterShared& sh, const volatile lds_u32* word, unsigned want, int kind, int k, int what) {
-    unsigned spins = 0, seen;
-    while ((seen = (unsigned)__builtin_amdgcn_readfirstlane((int)*word)) < want) {
-        __builtin_amdgcn_s_sleep(1);  // 64 clocks; polling back to back or sleeping twice as long measures the same
-        if (++spins > kSpinLimit) { report_stall(sh.status, *sh.counter, kind, k, what, want, seen); break; }
-        if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
     }
 }
 // ---- shared bodies (split islands): agent-scope traffic, see SharedTables ----
@@ -319,6 +308,40 @@ __device__ __forceinline__ void acquire_shared_one(const SharedTables& st, unsig
     }
 }
 
+// Schedule fuzzing (a debugging aid, off unless BEPUHIP_DEBUG_JITTER names a seed): results must not depend on which wave runs which item when, and the waits of this
+// file are what guarantees it. A missing or wrong wait shows only under unusual timing — the overflow-wait race of round 3 needed a cold instruction cache, 0.2 % of the
+// runs of a warm process. With a seed every wave naps a pseudo-random time (0 - 31 x 512 clocks; one item in eight sixteen times longer) before an item waits for its
+// predecessors and again before it publishes: items start and finish in orders no natural run produces, deterministically per (seed, cluster, item, pass). The fuzzers
+// and the regression tests run with it; one wave-uniform compare per call site when it is off.
+__device__ __forceinline__ void jitter_nap(const ClusterShared& sh, unsigned salt) {
+    if (sh.jitter == 0u) return;
+    unsigned x = sh.jitter ^ (salt * 0x9E3779B9u) ^ ((unsigned)blockIdx.x * 0x85EBCA6Bu);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    x = (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+    const unsigned naps = (x & 31u) * (((x >> 5) & 7u) == 0u ? 16u : 1u);
+    for (unsigned n = 0; n < naps; ++n) __builtin_amdgcn_s_sleep(8);
+}
+// Every item [0, count) of the cluster has completed pass `want` (its flag holds the epoch of the last pass it completed): lane l watches item base + l.
+__device__ __forceinline__ void wait_items(const ClusterShared& sh, int count, unsigned want, int kind, int k) {
+    const int lane = threadIdx.x & 63;
+    for (int base = 0; base < count; base += 64) {
+        const bool mine = base + lane < count;
+        const volatile lds_u32* word = sh.flags + (mine ? base + lane : k);
+        const unsigned need = mine ? want : 0u;
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned seen = *word;
+            const unsigned long long late = __builtin_amdgcn_ballot_w64(seen < need);
+            if (late == 0) break;
+            if (++spins > kSpinLimit) {
+                const int first = (int)__builtin_ctzll(late);
+                report_stall(sh.status, *sh.counter, kind, k, base + first, want, __builtin_amdgcn_readlane((int)seen, first));
+                break;
+            }
+            if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
+        }
+    }
+}
 // Block until every predecessor of the item has published: same-pass predecessors must have finished `epoch`; with CROSS (a Solve item: the warm start
 // pass before it is not separated by a barrier) the last touchers of the bodies this item touches first must have finished `epoch - 1`.
 template <bool CROSS>
@@ -347,14 +370,14 @@ __device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const
             if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody already gave up
         }
     }
-    if (h.overflow) {  // more predecessors than the item records: wait for every item of every earlier batch
-        for (int b = 0; b < h.batch; ++b)
-            wait_word(sh, (const volatile lds_u32*)sh.batch_done + b, epoch * (unsigned)__builtin_amdgcn_readfirstlane(sh.lbib[b + 1] - sh.lbib[b]), 2, k, b);
-    }
-    if (CROSS && h.xoverflow) {  // ... and for the whole previous pass
-        for (int b = 0; b < sh.batch_count; ++b)
-            wait_word(sh, (const volatile lds_u32*)sh.batch_done + b, (epoch - 1) * (unsigned)__builtin_amdgcn_readfirstlane(sh.lbib[b + 1] - sh.lbib[b]), 4, k, b);
-    }
+    // More predecessors than the item records: wait for every item of every earlier batch (same pass), resp. for every item of the previous pass — on the items' own
+    // flags, 64 at a time. (Until round 4 these two waits counted publishes per batch — "epoch x items of the batch" — and were wrong inside a fused sweep: there the
+    // warm start (epoch e) and the first velocity iteration (e + 1) run concurrently, a Solve item of batch b may publish before a WarmStart item of batch b has, and
+    // the count then reaches e x n_b with a warm-start item still outstanding; a cross-overflow Solve item of batch 0 started on a body whose last warm-start
+    // application had not happened. Found by tools/fuzz_device.py seed 81 ordinal 91, 12 % of the runs of a cold process, 0.2 % of a warm one: it takes a wave that is
+    // slow on its first pass through a heavy type's code. The flags say which PASS an item has completed, so they cannot be confused.)
+    if (h.overflow) wait_items(sh, (int)__builtin_amdgcn_readfirstlane(sh.lbib[h.batch]), epoch, 2, k);
+    if (CROSS && h.xoverflow) wait_items(sh, (int)__builtin_amdgcn_readfirstlane(sh.lbib[sh.batch_count]), epoch - 1, 4, k);
     asm volatile("" ::: "memory");  // nothing below may be hoisted above the polls
 }
 
@@ -369,6 +392,9 @@ __device__ __forceinline__ void glds_dword(const void* gsrc, unsigned lds_dst) {
 // its own upcoming code as DATA: one LDS-DMA read per 8 KB span, lane l reading the 128-byte line l of the span that starts at the current PC, issued right
 // behind the item's row loads. The bytes go to a scratch row nobody reads; what matters is that the lines are on their way into L2 — all at once — before the
 // instruction fetcher asks for them one after the other. Off (0 spans) unless ClusterParams.code_touch says otherwise (BEPUHIP_CODE_TOUCH).
+// The read never leaves the unit's code: the bytes behind the last cluster_kernel of a translation unit are code_pad_kernel (bepu_cluster_variant.inc), kCodeTouchMaxSpans
+// spans of s_nop that are never executed — the last switch cases of the last kernel are closer than a span to the end of the kernels themselves.
+// bepuphysics2_amd/build.py checks the layout in every built unit (the pad is the unit's last function and at least that long); the host clamps the span counts.
 __device__ __forceinline__ void touch_code_span(const ClusterShared& sh, int lane, int spans) {
     unsigned long long pc;
     asm volatile("s_getpc_b64 %0" : "=s"(pc));
@@ -390,7 +416,7 @@ struct ClusterGate {
     bool requirk_a, requirk_b;  // kConserving units, warm start of substep 0
     __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {
         if (TRACE) stamps.pre_gate = __builtin_readcyclecounter();
-        if (sh.code_touch_gate) touch_code_span(sh, threadIdx.x & 63, sh.code_touch_gate);
+        jitter_nap(sh, (unsigned)k * 2u + epoch * 0x632BE5ABu);
         wait_predecessors<CROSS>(sh, it, h, k, epoch);
         __builtin_amdgcn_s_setprio(3);  // from here to the publish the item is on its bodies' critical path: issue ahead of waves still preparing theirs
         if constexpr (kConserving && !CROSS) {
@@ -454,6 +480,7 @@ struct ClusterGateMany {
     static constexpr bool kPin = true;
     const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; const int* refs; DBody* b; const SharedRef* s; const bool* requirk;
     __device__ __forceinline__ void many(BodyVel* vel) const {
+        jitter_nap(sh, (unsigned)k * 2u + epoch * 0x632BE5ABu);
         wait_predecessors<CROSS>(sh, it, h, k, epoch);
         __builtin_amdgcn_s_setprio(3);
         if constexpr (kConserving && !CROSS) {
@@ -523,7 +550,8 @@ __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared&
             release_shared(sh, s[j], b[j]);
         }
     }
-    publish_item(sh.flags + k, sh.batch_done + h.batch, epoch);
+    jitter_nap(sh, (unsigned)k * 2u + 1u + epoch * 0x632BE5ABu);
+    publish_item(sh.flags + k, epoch);
     __builtin_amdgcn_s_setprio(0);
     if (STAGE == kStageSolve && active) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) accum[(size_t)f * stride + i] = a[f]; }
 }
@@ -613,7 +641,8 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
         release_shared(sh, sa, A);  // velocity and "event done" in one record: the next application on the body polls exactly this
         if (F::bodies == 2) release_shared(sh, sb, B);
     }
-    publish_item(sh.flags + k, sh.batch_done + h.batch, epoch);
+    jitter_nap(sh, (unsigned)k * 2u + 1u + epoch * 0x632BE5ABu);
+    publish_item(sh.flags + k, epoch);
     __builtin_amdgcn_s_setprio(0);
     if (STAGE == kStageSolve && active) {  // off the critical path: nothing reads the impulses before the next pass (a barrier away)
         _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) { if (kRowsNonTemporal) __builtin_nontemporal_store(a[f], &accum[(size_t)f * stride + i]); else accum[(size_t)f * stride + i] = a[f]; }
@@ -739,15 +768,14 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.items = reinterpret_cast<ClusterItem*>(lds + cp.planes * ncap);
     unsigned* words = reinterpret_cast<unsigned*>(lds + cp.planes * ncap + max_items * (int)(sizeof(ClusterItem) / 16));
     sh.flags = (volatile lds_u32*)words;
-    sh.batch_done = (lds_u32*)(words + max_items);
-    sh.lbib = reinterpret_cast<int*>(words + max_items + kFallbackBatchLimit + 1);
-    sh.counter = (lds_u32*)(words + max_items + 2 * (kFallbackBatchLimit + 1) + 1);
+    sh.lbib = reinterpret_cast<int*>(words + max_items);
+    sh.counter = (lds_u32*)(words + max_items + (kFallbackBatchLimit + 1) + 1);
     sh.status = status;
     sh.batch_count = cp.batch_count;
     sh.st = shared_tables; sh.events = 0; sh.passes = 0;
     int* slot_body_lds = reinterpret_cast<int*>(words + ((cluster_sync_words(max_items) + 3) / 4) * 4);  // SHARED plans: behind the sync words
     sh.slot_body = slot_body_lds;
-    sh.code_touch = cp.code_touch; sh.code_touch_gate = cp.code_touch_gate;
+    sh.code_touch = cp.code_touch; sh.jitter = cp.jitter;
     sh.substep = 0; sh.angular_mode = cp.sp.angular_mode; sh.substep_dt = cp.sp.dt; sh.plane_count = cp.planes; sh.bodies = bodies;
     sh.scratch_row = lds_address((const volatile lds_u32*)lds) + (unsigned)cluster_lds_core_bytes(cp.planes, ncap, max_items, SHARED);
     const ClusterDesc cd = clusters[blockIdx.x];
@@ -767,7 +795,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         int4* dst = reinterpret_cast<int4*>(sh.items);
         for (int j = tid; j < cd.item_count * (int)(sizeof(ClusterItem) / 16); j += blockDim.x) dst[j] = src[j];
     }
-    for (int j = tid; j < max_items + kFallbackBatchLimit + 1; j += blockDim.x) words[j] = 0;  // flags + batch_done
+    for (int j = tid; j < max_items; j += blockDim.x) words[j] = 0;  // flags
     for (int j = tid; j <= cp.batch_count; j += blockDim.x) sh.lbib[j] = batch_item_begin[cd.batch_item_offset + j] - cd.item_begin;
     if (tid == 0) *sh.counter = 0;
     if constexpr (SHARED) { for (int j = tid; j < cd.slot_count; j += blockDim.x) slot_body_lds[j] = slots[j]; }

@@ -38,8 +38,8 @@ struct ClusterItem {  // <= 64 consecutive constraints of one type batch, all ow
 };
 static_assert(sizeof(ClusterItem) == 64, "ClusterItem is staged in LDS as four 16-byte vectors");
 static_assert(offsetof(ClusterItem, xpred) == offsetof(ClusterItem, pred) + kMaxPreds * sizeof(unsigned short), "wait_predecessors indexes pred[] and xpred[] as one array");
-// LDS words behind the work items: one flag per item, two (kFallbackBatchLimit + 1)-entry tables (batch counters, batch -> first item), the claim counter.
-__host__ __device__ inline size_t cluster_sync_words(int max_items) { return (size_t)max_items + 2 * (kFallbackBatchLimit + 1) + 2; }
+// LDS words behind the work items: one flag per item, the (kFallbackBatchLimit + 1)-entry table batch -> first item, the claim counter.
+__host__ __device__ inline size_t cluster_sync_words(int max_items) { return (size_t)max_items + (kFallbackBatchLimit + 1) + 2; }
 struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
 // LDS of a cluster workgroup: [planes x ncap float4 body table][work items][sync words][SHARED: slot -> body table][one scratch row of 256 B: the destination of the
 // LDS-DMA reads that only exist to pull code into L2 (touch_code_ahead)].
@@ -72,12 +72,13 @@ constexpr int kAllPlanes = 8;         // ... plus the local inertia (read once p
 constexpr int kClusterThreads = 1024;  // default threads per cluster workgroup
 constexpr int kSplitClusterThreads = 512;  // split-island plans: the shared-body code needs the 256-VGPR budget to stay out of scratch (spills sit on every hand-off's critical path)
 constexpr int kMaxClusterSubsteps = 16;
+constexpr int kCodeTouchMaxSpans = 4;  // the most 8 KB spans of code a wave may read ahead of its PC (code touch): every cluster unit ends in that much padding (code_pad_kernel)
 constexpr int kClusterTracePasses = kMaxClusterSubsteps * 8;  // passes (warm starts + velocity iterations) the cluster trace buffer holds; later passes are not recorded
 struct ClusterParams {
     int substeps, batch_count, integrate_velocity_for_kinematics;
     int planes;  // kSweepPlanes or kAllPlanes
     int code_touch;     // 8 KB spans of its own upcoming code a wave pulls into L2 at the start of every work item (0: off), see touch_code_ahead
-    int code_touch_gate;  // experimental (BEPUHIP_CODE_TOUCH_GATE): spans touched again from the gate on
+    unsigned jitter;    // schedule fuzzing seed (BEPUHIP_DEBUG_JITTER; 0 = off): pseudo-random naps around every item's wait and publish, see jitter_nap
     int iters[kMaxClusterSubsteps];
     int pass_stage, pass_substep;  // the one-sweep-per-launch units (kPass): kStageWarmStart or kStageSolve, and the substep the sweep belongs to
     StepParams sp;

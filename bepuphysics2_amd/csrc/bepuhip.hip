@@ -301,6 +301,7 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
         }
     }
     if (!c->host_values && count > 0) {
+        HIP_TRY(hipSetDevice(c->device));  // allocates and copies on the device: contexts of different GPUs may be interleaved on one thread
         const size_t bundles = (size_t)(count + W - 1) / W;
         for (int which = 0; which < 2; ++which) {
             const size_t bytes = bundles * (size_t)(which == 0 ? pf : imf) * W * 4;
@@ -906,6 +907,16 @@ static void settle_row_policy(bepuhip_ctx* c, int threads, bool may_block) {
                 kPolicyRounds - 1, best);
 }
 
+// BEPUHIP_DEBUG_JITTER=<seed>: schedule fuzzing of the island kernels (bepu_cluster_kernel.h, jitter_nap) — a different nap pattern for every launch of the process,
+// reproducible per seed as long as the launches come in the same order. 0 / unset: off.
+static unsigned debug_jitter_seed() {
+    static std::atomic<unsigned> launches{0};
+    const unsigned seed = (unsigned)env_int("BEPUHIP_DEBUG_JITTER", 0);
+    if (seed == 0u) return 0u;
+    const unsigned mixed = seed * 0x9E3779B1u + launches.fetch_add(1u) * 0x85EBCA77u;
+    return mixed ? mixed : 1u;
+}
+
 // Cooperative launches are issued by one host thread at a time: two contexts of one process launching them concurrently from two threads (the in-process lattice
 // harness) leave the runtime in a state that crashes at process exit (ROCm 7.0, observed: every test passes, then a segmentation fault in the exit handlers).
 static std::mutex g_cooperative_launch;
@@ -983,8 +994,8 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             if (conserving && c->row_policy == 2) candidate = 2;
             const bool nt = candidate == 1;
             cp.code_touch = candidate == 2 ? 1 : 0;
-            if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(4, forced);
-            cp.code_touch_gate = std::max(0, std::min(2, env_int("BEPUHIP_CODE_TOUCH_GATE", 0)));
+            if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(kCodeTouchMaxSpans, forced);  // never beyond the padding behind the unit's kernels
+            cp.jitter = debug_jitter_seed();
             const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, conserving);  // the register budget that matches the workgroup size
             if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
             const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
@@ -1398,6 +1409,7 @@ static void enqueue_cluster_pass(bepuhip_ctx* c, int stage, int substep, const S
     cp.pass_stage = stage; cp.pass_substep = substep;
     cp.sp = sp;
     cp.code_touch = c->row_policy == 2 ? 1 : 0;
+    cp.jitter = debug_jitter_seed();
     const int threads = cluster_threads(c);
     TailParams tp;
     memset(&tp, 0, sizeof(tp));
@@ -1552,7 +1564,17 @@ int32_t bepuhip_register_host_memory(bepuhip_ctx* c, void* memory, int64_t bytes
     HIP_TRY(hipSetDevice(c->device));
     for (void* p : c->registered_host) if (p == memory) return BEPUHIP_OK;
     const hipError_t e = hipHostRegister(memory, (size_t)bytes, hipHostRegisterDefault);
-    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return BEPUHIP_OK; }
+    if (e == hipErrorHostMemoryAlreadyRegistered) {
+        // Somebody else's registration (another context's, or a neighbouring sub-allocation of the same BufferPool block) overlaps this range. That is fine only when it
+        // covers the range WHOLE: a buffer pinned in part would still be read by asynchronous DMA as if it were pinned throughout. Not recorded: not ours to unpin.
+        (void)hipGetLastError();
+        hipPointerAttribute_t head{}, tail{};
+        const bool head_ok = hipPointerGetAttributes(&head, memory) == hipSuccess && head.type == hipMemoryTypeHost;
+        const bool tail_ok = hipPointerGetAttributes(&tail, (char*)memory + bytes - 1) == hipSuccess && tail.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        if (head_ok && tail_ok) return BEPUHIP_OK;
+        return fail(BEPUHIP_E_INVALID_ARGUMENT, "host range overlaps an existing registration that does not cover it: register whole allocation blocks (BufferPool blocks), not sub-ranges");
+    }
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(BEPUHIP_E_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
     c->registered_host.push_back(memory);
     return BEPUHIP_OK;

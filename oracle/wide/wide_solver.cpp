@@ -13,11 +13,16 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <set>
+#include <string>
 #include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
+
+#include <sched.h>
 
 #include "wide_contacts.h"
 #include "wide_joints_more.h"
@@ -863,10 +868,77 @@ static TypeProcessor* CreateProcessor(int typeId) {  // BepuPhysics/DefaultTypes
 
 // ------------------------------------------------------------------------------------------------------------------ a minimal IThreadDispatcher
 // BepuUtilities/ThreadDispatcher.cs: DispatchWorkers(body, maximumWorkerCount) runs body(workerIndex) on every worker (the caller is worker 0) and returns when all are done.
+// Where the workers run (the cpu_baseline leg of bench.py; VERDICT r3 weak #11: unpinned workers on a shared two-socket host scaled NEGATIVELY beyond 16 threads).
+// PinPlan lists the CPUs the process may use, ordered so that the first N entries are the best place for N workers: all on ONE socket (the one with the most
+// allowed CPUs), one hardware thread per physical core first, sibling threads after, other sockets last. Worker i is pinned to entry i (WIDE_PIN=0: no pinning).
+struct PinPlan {
+    std::vector<int> cpus;
+    int firstSocketCores = 0, firstSocketCpus = 0;
+    static int ReadInt(const std::string& path, int fallback) {
+        FILE* f = fopen(path.c_str(), "r");
+        if (!f) return fallback;
+        int v = fallback;
+        if (fscanf(f, "%d", &v) != 1) v = fallback;
+        fclose(f);
+        return v;
+    }
+    static const PinPlan& Get() {
+        static const PinPlan plan = [] {
+            PinPlan p;
+            cpu_set_t allowed;
+            CPU_ZERO(&allowed);
+            if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return p;
+            struct Cpu { int id, package, core; };
+            std::vector<Cpu> all;
+            for (int c = 0; c < CPU_SETSIZE; ++c)
+                if (CPU_ISSET(c, &allowed)) {
+                    const std::string base = "/sys/devices/system/cpu/cpu" + std::to_string(c) + "/topology/";
+                    all.push_back({c, ReadInt(base + "physical_package_id", 0), ReadInt(base + "core_id", c)});
+                }
+            std::map<int, int> perPackage;
+            for (auto& c : all) perPackage[c.package]++;
+            std::vector<int> packages;
+            for (auto& kv : perPackage) packages.push_back(kv.first);
+            std::stable_sort(packages.begin(), packages.end(), [&](int a, int b) { return perPackage[a] > perPackage[b]; });
+            for (size_t pi = 0; pi < packages.size(); ++pi) {
+                std::set<int> coresSeen;
+                std::vector<int> first, siblings;
+                for (auto& c : all)
+                    if (c.package == packages[pi]) (coresSeen.insert(c.core).second ? first : siblings).push_back(c.id);
+                p.cpus.insert(p.cpus.end(), first.begin(), first.end());
+                p.cpus.insert(p.cpus.end(), siblings.begin(), siblings.end());
+                if (pi == 0) { p.firstSocketCores = (int)first.size(); p.firstSocketCpus = (int)(first.size() + siblings.size()); }
+            }
+            return p;
+        }();
+        return plan;
+    }
+    static bool Enabled() { const char* v = getenv("WIDE_PIN"); return !(v && *v == '0'); }
+    static void PinCurrentThread(int worker) {
+        const PinPlan& plan = Get();
+        if (!Enabled() || plan.cpus.empty()) return;
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(plan.cpus[(size_t)worker % plan.cpus.size()], &one);
+        sched_setaffinity(0, sizeof(one), &one);
+    }
+};
+// The calling thread is worker 0: pinned for the duration of a call, its own affinity restored afterwards.
+struct ScopedMainPin {
+    cpu_set_t saved;
+    bool active = false;
+    explicit ScopedMainPin(bool wanted) {
+        if (!wanted || !PinPlan::Enabled() || PinPlan::Get().cpus.empty()) return;
+        active = sched_getaffinity(0, sizeof(saved), &saved) == 0;
+        if (active) PinPlan::PinCurrentThread(0);
+    }
+    ~ScopedMainPin() { if (active) sched_setaffinity(0, sizeof(saved), &saved); }
+};
+
 class ThreadDispatcher {
   public:
     explicit ThreadDispatcher(int threadCount) : threadCount_(threadCount) {
-        for (int i = 1; i < threadCount; ++i) threads_.emplace_back([this, i] { Loop(i); });
+        for (int i = 1; i < threadCount; ++i) threads_.emplace_back([this, i] { PinPlan::PinCurrentThread(i); Loop(i); });
     }
     ~ThreadDispatcher() {
         {
@@ -1665,10 +1737,25 @@ struct Solver {
     }
 };
 
+// First touch decides which NUMA node a page lives on: large buffers are copied by threads pinned to the cores the workers will run on (PinPlan: one socket), 2 MB
+// chunks dealt round-robin, so the session's memory sits on that socket, spread over its memory controllers — not wherever the caller's thread happened to run.
 static void* AlignedCopy(const void* src, size_t bytes) {  // BufferPool blocks are 128-byte aligned (BepuUtilities/Memory/BufferPool.cs:42)
     void* p = nullptr;
     if (posix_memalign(&p, 128, bytes ? bytes : 128) != 0) return nullptr;
-    std::memcpy(p, src, bytes);
+    const size_t chunk = (size_t)2 << 20;
+    const PinPlan& plan = PinPlan::Get();
+    const int touchers = (int)std::min<size_t>({(size_t)16, (size_t)std::max(1, plan.firstSocketCores), (bytes + chunk - 1) / chunk});
+    if (!PinPlan::Enabled() || touchers <= 1) {
+        std::memcpy(p, src, bytes);
+        return p;
+    }
+    std::vector<std::thread> threads;
+    for (int t = 0; t < touchers; ++t)
+        threads.emplace_back([=] {
+            PinPlan::PinCurrentThread(t);
+            for (size_t at = (size_t)t * chunk; at < bytes; at += (size_t)touchers * chunk) std::memcpy((char*)p + at, (const char*)src + at, std::min(chunk, bytes - at));
+        });
+    for (auto& th : threads) th.join();
     return p;
 }
 
@@ -1772,6 +1859,7 @@ static int SolveSession(Session& session, float dt, int threads, int frames, dou
         if (!g_dispatcher || g_dispatcher->ThreadCount() != threads) g_dispatcher.reset(new ThreadDispatcher(threads));
         dispatcher = g_dispatcher.get();
     }
+    ScopedMainPin mainPin(true);  // worker 0 (and the single-threaded path) on the plan's first core
     using Clock = std::chrono::steady_clock;
     double phases[4] = {0, 0, 0, 0};
     for (int frame = 0; frame < frames; ++frame) {
@@ -1939,6 +2027,12 @@ int wide_session_read(void* session) {
     return 0;
 }
 void wide_session_destroy(void* session) { delete (wide::Session*)session; }
+// What the pinning plan looks like on this host: out[0] CPUs the process may use, out[1] physical cores of the socket the workers start on, out[2] hardware threads of
+// that socket, out[3] 1 if pinning is on (WIDE_PIN != 0).
+void wide_pin_plan(int* out) {
+    const wide::PinPlan& plan = wide::PinPlan::Get();
+    out[0] = (int)plan.cpus.size(); out[1] = plan.firstSocketCores; out[2] = plan.firstSocketCpus; out[3] = wide::PinPlan::Enabled() ? 1 : 0;
+}
 int wide_predict_bounding_boxes(const float* bodies, int count, const wide::SceneParams* params, const wide::CollidableRecord* collidables, wide::PredictedRecord* out,
                                 const float* hull_points, const int* hull_begin, int hull_count, const wide::CompoundChildRecord* children, const int* child_begin, int compound_count,
                                 const float* triangles, const int* triangle_begin, const float* mesh_scales, int mesh_count) {

@@ -187,21 +187,28 @@ def test_ragdoll_tube_both_schedules(hip_solver_factory, use_clusters):
 
 
 def test_full_size_ragdoll_tube_against_oracle_and_between_schedules(hip_solver_factory):
-    """BASELINE.json configs[2] at its full size (15,000 ragdolls, 1.005M constraints): the island-per-workgroup schedule against the
-    oracle (all host threads; its result does not depend on the thread count) and against the launch-per-batch schedule, bit for bit."""
+    """BASELINE.json configs[2] at its full size (15,000 ragdolls, 1.005M constraints), TWELVE consecutive frames (the bench times frames 306-325 of this
+    scene; one frame said little about warm-started impulses and moved contact depths at this size): the island-per-workgroup schedule — at its natural timing and
+    under schedule fuzzing (BEPUHIP_DEBUG_JITTER) — and the launch-per-batch schedule against the oracle (all host threads; its result does not depend on the thread
+    count), bit for bit."""
+    import fuzz_util as fu
     from bepuphysics2_amd.hostlib import HostSimulation
     sim = HostSimulation.scene("ragdoll_tube", 15000, 1, 0, 5)
     scene, sd = sim.export(), sim.solve_description()
     sim.close()
     cb = PoseIntegratorCallbacks()
-    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=1, threads=8)
-    clusters = pu.run_hip(hip_solver_factory(use_clusters=True), scene, 1 / 60, sd, cb, frames=1)
-    batches = pu.run_hip(hip_solver_factory(use_clusters=False), scene, 1 / 60, sd, cb, frames=1)
-    for got in (clusters, batches):
+    frames = 12
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=frames, threads=8)
+    clusters = pu.run_hip(hip_solver_factory(use_clusters=True), scene, 1 / 60, sd, cb, frames=frames)
+    with fu.environment(BEPUHIP_DEBUG_JITTER=4242):
+        jittered = pu.run_hip(hip_solver_factory(use_clusters=True), scene, 1 / 60, sd, cb, frames=frames)
+    batches = pu.run_hip(hip_solver_factory(use_clusters=False), scene, 1 / 60, sd, cb, frames=frames)
+    for got in (clusters, jittered, batches):
         m = pu.compare_scenes(ref, got)
         _check(m)
         assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
     assert np.isfinite(clusters.bodies).all()
+    assert float(np.abs(clusters.bodies[:, 4:7] - scene.bodies[:, 4:7]).max()) > 1e-3  # the scene moved
 
 
 @pytest.mark.parametrize("use_clusters", [True, False])

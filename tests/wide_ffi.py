@@ -35,11 +35,20 @@ def load(variant: str = "") -> C.CDLL:
         lib.wide_session_read.restype = C.c_int
         lib.wide_session_destroy.argtypes = [C.c_void_p]
         lib.wide_session_destroy.restype = None
+        lib.wide_pin_plan.argtypes = [C.POINTER(C.c_int)]
+        lib.wide_pin_plan.restype = None
         lib.wide_math_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.wide_constraint_iterate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int]
         lib.wide_constraint_iterate.restype = C.c_int
         _libs[name] = lib
     return _libs[name]
+
+
+def pin_plan(variant: str = "") -> dict:
+    """Where oracle/wide puts its workers (wide_solver.cpp, PinPlan): CPUs the process may use, physical cores / hardware threads of the socket the workers fill first."""
+    out = (C.c_int * 4)()
+    load(variant).wide_pin_plan(out)
+    return {"cpus_allowed": int(out[0]), "first_socket_physical_cores": int(out[1]), "first_socket_hardware_threads": int(out[2]), "pinned": bool(out[3])}
 
 
 def _params(dt, solve_description, callbacks, threads):

@@ -1,4 +1,4 @@
-"""Writes a scene in the plan harness's binary format:  python tools/plan_harness/dump_scene.py <pile|ragdoll_tube|crowd|graph|graph44> <out.bin> [size]"""
+"""Writes a scene in the plan harness's binary format:  python tools/plan_harness/dump_scene.py <pile|ragdoll_tube|crowd|graph|graph44|fuzz:seed:ordinal> <out.bin> [size]"""
 import os
 import sys
 
@@ -8,7 +8,14 @@ import numpy as np
 
 kind, out = sys.argv[1], sys.argv[2]
 size = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-if kind == "graph44":  # every constraint type id, three- and four-body ones included
+if kind.startswith("fuzz:"):  # fuzz:<seed>:<ordinal> — the scene of a tools/fuzz_device.py ordinal
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import replay_fuzz_device as rf
+    import small_scenes
+    _, fuzz_seed, ordinal = kind.split(":")
+    p = rf.parameters(int(fuzz_seed), int(ordinal) + 1)[int(ordinal)]
+    scene = small_scenes.random_graph_scene(p["seed"], p["nb"], p["nc"], p["types"], kinematic_fraction=p["kin"])
+elif kind == "graph44":  # every constraint type id, three- and four-body ones included
     import small_scenes
     scene = small_scenes.random_graph_scene(7, size or 6000, (size or 6000) * 2, sorted(small_scenes.TYPE_TABLE))
 elif kind == "graph":

@@ -421,6 +421,28 @@ int main(int argc, char** argv) {
         printf("rows %.2f ms, plan %.2f ms | enabled %d shared %d clusters %zu items %zu (max %d per cluster) max slots %d planes %d shared bodies %zu | digest %016llx\n",
                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), (int)plan.enabled, (int)plan.shared, plan.clusters.size(),
                plan.items.size(), plan.max_items, plan.max_slots, plan.planes, shared, (unsigned long long)h);
+        if (getenv("PLAN_DUMP_ITEMS") && plan.enabled) {  // every cluster's work items with their predecessor lists and the bodies they touch
+            for (size_t cl = 0; cl < plan.clusters.size(); ++cl) {
+                const ClusterDesc& cd = plan.clusters[cl];
+                printf("cluster %zu: %d slots, %d items\n", cl, cd.slot_count, cd.item_count);
+                for (int k = 0; k < cd.item_count; ++k) {
+                    const ClusterItem& it = plan.items[cd.item_begin + k];
+                    const HostTypeBatch& tb = c->tbs[it.tb];
+                    const int np = (it.batch_npred >> 16) & 0xF, nx = (it.batch_npred >> 20) & 0xF;
+                    printf("  item %3d batch %2d type %2d count %2d%s%s pred [", k, it.batch_npred & 0xFFFF, it.type_id, it.count, ((it.batch_npred >> 24) & 1) ? " OVERFLOW" : "", ((it.batch_npred >> 25) & 1) ? " XOVERFLOW" : "");
+                    for (int q = 0; q < np; ++q) printf("%s%d", q ? " " : "", it.pred[q]);
+                    printf("] xpred [");
+                    for (int q = 0; q < nx; ++q) printf("%s%d", q ? " " : "", it.xpred[q]);
+                    printf("] bodies");
+                    for (int j = it.start; j < it.start + it.count; ++j) {
+                        printf(" (");
+                        for (int b = 0; b < tb.info.bodies; ++b) { const int32_t r = tb.dev_refs[(size_t)b * tb.stride + j]; printf("%s%d%s", b ? "," : "", r & kRefMask, (uint32_t)r >= kDynamicLimit ? "k" : ""); }
+                        printf(")");
+                    }
+                    printf("\n");
+                }
+            }
+        }
         if (getenv("PLAN_SIMULATE") && plan.enabled) simulate(c, plan);
         if (const char* mutate = getenv("PLAN_MUTATE")) {  // the validator must notice: 1 = a local reference points at the neighbouring slot, 2 = an item loses a row, 3 = a rank is bumped
             const int kind = atoi(mutate);
