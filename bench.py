@@ -193,9 +193,76 @@ def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, s
             "ms_per_step": ms, "value": per_step / (ms * 1e-3), "unit": "constraint-iterations/s",
             "schedule": "island-per-workgroup, split-island plan (one plain launch per step: BEPUHIP_FLAG_EXCLUSIVE_DEVICE, the bench owns the device; a cooperative launch costs ~25 us more)" if clustered else f"launch-per-batch, hipGraph replay, {launches} launches per step",
             "roofline": hbm_roofline("cluster_kernel<...,SHARED> (whole step in one launch)" if clustered else "whole step (launch-per-batch)", 1e3 * ms if clustered else 1e3 * ms,
-                                     traffic, step_bytes, compulsory_stream_bytes(scene, sd) if clustered else None, traffic_detail=detail,
+                                     traffic, step_bytes, compulsory_stream_bytes(scene, sd) if clustered else None, traffic_detail=detail, working_set_bytes=working_set_bytes(scene),
                                      launch_time_basis="wall time per step (one launch per step)" if clustered else f"whole step, {launches} launches"),
             "upload_ms": upload_ms, "finite": finite}
+
+
+def working_set_bytes(scene) -> int:
+    """What a step touches in HBM: every body record and every row of every type batch (references as the island schedule stores them, prestep data, impulses). To be read
+    against the 256 MiB Infinity Cache: FETCH_SIZE / WRITE_SIZE count traffic at the fabric side of L2, MALL hits included (MI355X_MICROARCH.md, HBM section)."""
+    from bepuphysics2_amd.scene import TYPE_TABLE
+    total = 128 * scene.body_count
+    for batch in scene.batches:
+        for tb in batch:
+            nb, pf, imf, _ = TYPE_TABLE[tb.type_id]
+            total += ((nb + 1) // 2 + pf + imf) * 4 * tb.count
+    return total
+
+
+def scale_sweep_leg(args, device: int, base_ragdolls: int, factors=(1, 2, 4, 8), steps: int = 20):
+    """the headline scene fits the Infinity Cache (136 MB of 256 MiB) and is one workgroup per CU. The same benchmark at 1x / 2x / 4x / 8x the ragdolls
+    (1 - 8 M constraints, up to ~1.1 GB of working set, up to eight clusters per CU run back to back): ms/step, constraint-iterations/s, clusters, clusters per CU, the
+    working set, the counters' bandwidth fraction (own PMC child runs per size) and the compulsory-stream fraction. Extra keys on the bench line, never `value`."""
+    import copy
+    import torch
+    from bepuphysics2_amd.native import HipSolver
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    cus = int(torch.cuda.get_device_properties(device).multi_processor_count)
+    cb = PoseIntegratorCallbacks()
+    out = []
+    for f in factors:
+        ragdolls = base_ragdolls * f
+        scene, sd = build_scene(ragdolls, 5)
+        solver = HipSolver(device=device)
+        t0 = time.perf_counter()
+        solver.upload(scene)
+        upload_ms = 1e3 * (time.perf_counter() - t0)
+        for _ in range(40):  # clocks, launch policy
+            solver.solve(1 / 60, sd, cb, asynchronous=True)
+        solver.reset_state()
+        solver.sync()
+        for _ in range(3):
+            solver.solve(1 / 60, sd, cb, asynchronous=True)
+        solver.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            solver.solve(1 / 60, sd, cb, asynchronous=True)
+        solver.sync()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        clusters = int(solver.cluster_cycles().size)
+        finite = bool(np.isfinite(solver.get_bodies(scene.body_count)).all())
+        solver.close()
+        per_step = scene.constraint_count * int((1 + sd.iterations()).sum())
+        stream = compulsory_stream_bytes(scene, sd)
+        entry = {"ragdolls": ragdolls, "constraints": scene.constraint_count, "bodies": scene.body_count, "ms_per_step": ms, "value": per_step / (ms * 1e-3),
+                 "unit": "constraint-iterations/s", "clusters": clusters, "clusters_per_cu": clusters / cus, "working_set_bytes": working_set_bytes(scene),
+                 "memory_stream_bytes_per_launch": stream, "memory_stream_frac_of_peak": stream / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "upload_ms": upload_ms, "finite": finite}
+        if not args.no_traffic and clusters:
+            child = copy.copy(args)
+            child.ragdolls = ragdolls
+            detail = measure_traffic(child)
+            if isinstance(detail, dict) and detail.get("bytes_per_launch"):
+                entry["traffic"] = detail["bytes_per_launch"]
+                entry["frac"] = detail["bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS  # against the wall time of a step: one launch per step
+                entry["traffic_over_compulsory_stream"] = detail["bytes_per_launch"] / stream
+            else:
+                entry["traffic"] = None
+                entry["traffic_detail"] = detail
+        out.append(entry)
+        del scene
+    return {"sizes": out, "cus": cus, "note": "same scene recipe and solve description as the headline at every size; `frac` = PMC traffic (FETCH_SIZE x 2 + WRITE_SIZE, own child "
+                                              "runs per size) / wall time of a step / 8 TB/s; a working set above 256 MiB cannot live in the Infinity Cache"}
 
 
 def optional_leg(fn, *a, **k):
@@ -514,6 +581,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE child runs behind roofline.traffic")
     ap.add_argument("--traffic-child", default=None, choices=["main", "pile", "crowd"], help=argparse.SUPPRESS)
     ap.add_argument("--no-connected-scenes", action="store_true", help="skip the extra legs on connected scenes (100k-box pile = configs[1]; ragdoll crowd)")
+    ap.add_argument("--no-scale-sweep", action="store_true", help="skip the scale_sweep leg (the headline scene at 1x / 2x / 4x / 8x the ragdolls)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -623,7 +691,9 @@ def main():
             detail = measure_traffic(args) if (not args.no_traffic and world == 1) else None  # the PMC child runs are an N=1 leg
             traffic = detail.get("bytes_per_launch") if isinstance(detail, dict) else None
             roofline = hbm_roofline("cluster_kernel (whole substep loop of a step in one launch)", avg_us, traffic, step_bytes, compulsory_stream_bytes(scene, sd),
-                                    launches=n, traffic_detail=detail,
+                                    launches=n, traffic_detail=detail, working_set_bytes=working_set_bytes(scene),
+                                    working_set_note="bodies + constraint rows; below the 256 MiB Infinity Cache FETCH_SIZE / WRITE_SIZE count fabric-side traffic that the "
+                                                     "cache may serve — see scale_sweep for sizes that leave it",
                                     cluster_shader_kcycles_mean_max=[float(cyc.mean()) / 1e3, float(cyc.max()) / 1e3] if cyc.size else None,
                                     effective_shader_GHz=float(cyc.max()) / (avg_us * 1e3) if cyc.size else None,
                                     families_ms_per_step=families, step_algorithmic_GBs=step_gbs)
@@ -669,6 +739,10 @@ def main():
     boundary = None
     lattice_report = None
     widened = None
+    sweep = None
+    if rank == 0 and world == 1 and not args.no_scale_sweep and not args.no_connected_scenes and not args.traffic_child:
+        solver.close()
+        sweep = optional_leg(scale_sweep_leg, args, local_rank, args.ragdolls)
     if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
         widened = optional_leg(widened_types_leg, args.ragdolls, local_rank)
         boundary = optional_leg(boundary_leg, scene, sd, cb, local_rank)
@@ -691,7 +765,7 @@ def main():
                        "row_policy": row_policy and f"{row_policy}, picked from the timings of the first fifteen solves after the upload (all candidates bit-identical; DESIGN.md 5)",
                        "device_prewarm": f"{prewarm_steps} untimed solves during setup, uploaded state restored before the {args.warmup} warm-up steps",
                        "finite": finite},
-            "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "widened_types": widened, "boundary": boundary, "lattice": lattice_report,
+            "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "scale_sweep": sweep, "widened_types": widened, "boundary": boundary, "lattice": lattice_report,
         }
         print(json.dumps(out))
     if dist is not None:
