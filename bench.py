@@ -374,19 +374,40 @@ def boundary_leg(scene, sd, cb, device: int):
                 for refs, pre in lanes:
                     solver.add_constraint(bi, t, refs, pre)
 
+        # the same frame as ONE bepuhip_apply_structural_ops call (round 4): the operation table is what a host builds from its own structures (the C# shim's diff)
+        rows, words, at = [], [], 0
+        for bi, t, count, lanes in picks:
+            for j in range(len(lanes)):
+                rows.append((1, bi, t, count - 1 - j, 0, 0, 0, 0))
+            for j, (refs, pre) in enumerate(lanes):
+                rows.append((0, bi, t, count - len(lanes) + j, 0, 0, at, 0))
+                words += [np.ascontiguousarray(refs, dtype=np.int32).view(np.uint32), np.ascontiguousarray(pre, dtype=np.float32).view(np.uint32)]
+                at += refs.size + pre.size
+        table, payload = np.asarray(rows, dtype=np.int32), np.concatenate(words)
+
         churn()
         solver.solve(1 / 60, sd, cb)
         t0 = time.perf_counter()
         for _ in range(frames):
             churn()
             solver.solve(1 / 60, sd, cb)
+        out["structural_frame_per_call_ms"] = 1e3 * (time.perf_counter() - t0) / frames
+        t_calls = 0.0
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            t1 = time.perf_counter()
+            solver.apply_structural_op_table(table, payload)
+            t_calls += time.perf_counter() - t1
+            solver.solve(1 / 60, sd, cb)
         out["structural_frame_ms"] = 1e3 * (time.perf_counter() - t0) / frames
+        out["structural_ops_call_ms"] = 1e3 * t_calls / frames
         t0 = time.perf_counter()
         for _ in range(frames):
             solver.solve(1 / 60, sd, cb)
         out["solve_after_structural_updates_ms"] = 1e3 * (time.perf_counter() - t0) / frames
         stayed = bool(solver.cluster_cycles().size)
-        out["structural_frame_note"] = (f"{calls} remove_constraint + {calls} add_constraint calls from Python (1 % of the two-body contacts) + solve; the context "
+        out["structural_frame_note"] = (f"{calls} removals + {calls} additions (1 % of the two-body contacts) in ONE bepuhip_apply_structural_ops call + solve "
+                                        f"(structural_ops_call_ms: the call alone; structural_frame_per_call_ms: the same frame as {2 * calls} single calls from Python, round 3's form); the context "
                                         + ("stayed on the island schedule (freed device slots reused, the predecessor lists of the touched clusters rebuilt on the host)" if stayed else
                                            "left the island schedule for the launch-per-batch one"))
     solver.close()

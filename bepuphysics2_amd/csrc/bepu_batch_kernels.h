@@ -127,10 +127,22 @@ __global__ void mark_indices_kernel(const int* __restrict__ indices, int count, 
     if (i < count) atomicOr(&flags[indices[i] & kRefMask], bits);
 }
 
-__device__ __forceinline__ void velocity_callback(const StepParams& sp, BodyVel& v) {  // Demos/DemoCallbacks.cs:100-109
-    V3 g = {sp.gx, sp.gy, sp.gz};
-    v.lin = scale(add(v.lin, g), sp.lin_damp);
-    v.ang = scale(v.ang, sp.ang_damp);
+// IPoseIntegratorCallbacks.IntegrateVelocity (PoseIntegrator.cs:91-93) for the models that cross the ABI (bepuhip_velocity_model); `position` and `body` are the
+// callback's position and bodyIndices arguments. The caller masks the result where the reference does.
+__device__ __forceinline__ void velocity_callback(const StepParams& sp, BodyVel& v, const V3& position, int body) {
+    if (sp.velocity_model == 0) {  // Demos/DemoCallbacks.cs:100-109
+        V3 g = {sp.gx, sp.gy, sp.gz};
+        v.lin = scale(add(v.lin, g), sp.lin_damp);
+        v.ang = scale(v.ang, sp.ang_damp);
+    } else if (sp.velocity_model == 1) {  // Demos/Demos/PerBodyGravityDemo.cs:87: velocity.Linear.Y += new Vector<float>(gravityValues) * dt
+        v.lin.y = v.lin.y + sp.body_gravity[body] * sp.callback_dt;
+    } else {  // Demos/Demos/PlanetDemo.cs:44-46: offset = position - centre; velocity.Linear -= gravityDt * offset / max(1, distance^3)  (Vector3Wide.cs:357-365: "/" multiplies by 1 / scalar)
+        const V3 offset = sub(position, V3{sp.cx, sp.cy, sp.cz});
+        const float distance = sqrtf(offset.x * offset.x + offset.y * offset.y + offset.z * offset.z);
+        const V3 scaled = {offset.x * sp.radial, offset.y * sp.radial, offset.z * sp.radial};
+        const float inverse = 1.0f / vmax(1.0f, distance * distance * distance);
+        v.lin = sub(v.lin, V3{scaled.x * inverse, scaled.y * inverse, scaled.z * inverse});
+    }
 }
 
 // Cluster path only: advance the constrained kinematic bodies in global memory through the in-solver substeps
@@ -147,7 +159,7 @@ __device__ __forceinline__ void kinematic_substeps_body(float4* bodies, int inde
             pos = add(pos, scale(vel.lin, sp.dt));
             ori = integrateOrientation(ori, vel.ang, sp.dt * 0.5f);
         }
-        if (integrate_velocity_for_kinematics) velocity_callback(sp, vel);
+        if (integrate_velocity_for_kinematics) velocity_callback(sp, vel, pos, index & kRefMask);
     }
     base[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
     base[1] = make_float4(pos.x, pos.y, pos.z, p4.w);
@@ -162,7 +174,7 @@ struct BodyRegs { Q ori; V3 pos; BodyVel vel; };
 
 // IntegratePoseAndVelocity (TypeProcessor.cs:1204-1248) / IntegrateVelocity (:1251-1283) of one constrained dynamic body; returns its refreshed world
 // inverse inertia. substep 0: velocity only; substep > 0: pose, then velocity.
-__device__ __forceinline__ Sym3 substep_integrate_dynamic(BodyRegs& b, const float4& i0, const float4& i1, int integrate_pose, const StepParams& sp) {
+__device__ __forceinline__ Sym3 substep_integrate_dynamic(BodyRegs& b, const float4& i0, const float4& i1, int integrate_pose, const StepParams& sp, int body) {
     const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
     Sym3 world;
     if (integrate_pose) {
@@ -181,16 +193,16 @@ __device__ __forceinline__ Sym3 substep_integrate_dynamic(BodyRegs& b, const flo
             b.vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(b.ori, local, b.vel.ang, sp.dt);
         }
     }
-    velocity_callback(sp, b.vel);                                       // :1244 / :1273-1281
+    velocity_callback(sp, b.vel, b.pos, body);                          // :1244 / :1273-1281
     return world;
 }
 // The kinematic prepass (PoseIntegrator.cs:451-535) of one constrained kinematic body.
-__device__ __forceinline__ void substep_integrate_kinematic(BodyRegs& b, int integrate_pose, int integrate_velocity_for_kinematics, const StepParams& sp) {
+__device__ __forceinline__ void substep_integrate_kinematic(BodyRegs& b, int integrate_pose, int integrate_velocity_for_kinematics, const StepParams& sp, int body) {
     if (integrate_pose) {                                               // :519-523
         b.pos = add(b.pos, scale(b.vel.lin, sp.dt));
         b.ori = integrateOrientation(b.ori, b.vel.ang, sp.dt * 0.5f);
     }
-    if (integrate_velocity_for_kinematics) velocity_callback(sp, b.vel);  // :524-529, :481-485
+    if (integrate_velocity_for_kinematics) velocity_callback(sp, b.vel, b.pos, body);  // :524-529, :481-485
 }
 
 // Per-substep integration of every constrained body — the work the reference fuses into the first-touching constraint's
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(256) void substep_integrate_kernel(float4* bodies, 
     BodyRegs b = {{q4.x, q4.y, q4.z, q4.w}, {p4.x, p4.y, p4.z}, {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}}};
     if (f & kFlagDynamicConstrained) {
         const float4 i0 = base[4], i1 = base[5];
-        const Sym3 world = substep_integrate_dynamic(b, i0, i1, integrate_pose, sp);
+        const Sym3 world = substep_integrate_dynamic(b, i0, i1, integrate_pose, sp, i);
         if (integrate_pose) {
             base[0] = make_float4(b.ori.x, b.ori.y, b.ori.z, b.ori.w);
             base[1] = make_float4(b.pos.x, b.pos.y, b.pos.z, p4.w);
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(256) void substep_integrate_kernel(float4* bodies, 
         base[6] = make_float4(world.xx, world.yx, world.yy, world.zx);
         base[7] = make_float4(world.zy, world.zz, i1.z, base[7].w);
     } else {
-        substep_integrate_kinematic(b, integrate_pose, integrate_velocity_for_kinematics, sp);
+        substep_integrate_kinematic(b, integrate_pose, integrate_velocity_for_kinematics, sp, i);
         if (integrate_pose) {
             base[0] = make_float4(b.ori.x, b.ori.y, b.ori.z, b.ori.w);
             base[1] = make_float4(b.pos.x, b.pos.y, b.pos.z, p4.w);
@@ -253,7 +265,7 @@ __global__ void momentum_requirk_kernel(float4* bodies, const int* __restrict__ 
 
 // PoseIntegrator.IntegrateBundlesAfterSubstepping (PoseIntegrator.cs:537-693) of one body, on registers. True = the velocity changed too.
 __device__ __forceinline__ bool final_integrate_regs(BodyRegs& b, unsigned body_flags, const float4& i0, const float4& i1, float dt, float substep_dt, int substep_count,
-                                                     int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, const StepParams& sp) {
+                                                     int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, const StepParams& sp, int body) {
     const bool unconstrained = !(body_flags & kFlagConstrained);
     const float effective_dt = allow_substeps_for_unconstrained ? substep_dt : (unconstrained ? dt : substep_dt);  // :591-599
     const float half_dt = effective_dt * 0.5f;
@@ -266,7 +278,7 @@ __device__ __forceinline__ bool final_integrate_regs(BodyRegs& b, unsigned body_
     const bool velocity_mask = integrate_velocity_for_kinematics ? true : !is_kinematic;                                // :604-616
     const int steps = allow_substeps_for_unconstrained ? substep_count : 1;
     for (int s = 0; s < steps; ++s) {
-        if (velocity_mask) velocity_callback(sp, b.vel);   // velocity -> pose for unconstrained bodies (:634-667)
+        if (velocity_mask) velocity_callback(sp, b.vel, b.pos, body);   // velocity -> pose for unconstrained bodies (:634-667)
         b.pos = add(b.pos, scale(b.vel.lin, effective_dt));
         if (sp.angular_mode == 1) {                        // :649-655
             const Q previousOrientation = b.ori;
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __res
     const int first_lane_of_bundle = (threadIdx.x & 63) & ~(bundle_width - 1);
     const bool bundle_integrates = ((integrates >> first_lane_of_bundle) & ((1ull << bundle_width) - 1ull)) != 0;
     if (!live) return;
-    if (bundle_integrates) velocity_callback(sp, vel);  // :337-338 (never stored)
+    if (bundle_integrates) velocity_callback(sp, vel, pos, i);  // :337-338 (never stored)
     const CollidableIn c = collidables[i];
     PredictedBounds r;
     if (heavy_queue && isHeavyShape(c, tables, heavy_threshold)) {  // a wave of predict_heavy_bounds_kernel does the box and the margin; the sleep counters are settled here
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(64) void predict_heavy_bounds_kernel(const float4* 
         const float4* base = bodies + (size_t)item.x * 8;
         const float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
         BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
-        if (item.y) velocity_callback(sp, vel);
+        if (item.y) velocity_callback(sp, vel, V3{p4.x, p4.y, p4.z}, item.x);
         const CollidableIn c = collidables[item.x];
         PredictedBounds r;
         heavyBounds((int)threadIdx.x, V3{p4.x, p4.y, p4.z}, Q{q4.x, q4.y, q4.z, q4.w}, vel, dt, c, tables, r);
@@ -435,6 +447,7 @@ __global__ __launch_bounds__(256) void scatter_bundles_kernel(const float* __res
 // kind 0: TypeProcessor.Move (TypeProcessor.cs:578-592): lane `src` copied over lane `dst` (body references, prestep, accumulated impulses) — the swap-with-last of Remove.
 // kind 1: AllocateInTypeBatch (:314-334): lane `dst` written from the payload (references, prestep), accumulated impulses cleared (GatherScatter.ClearLane :327).
 // kind 2: UpdateForBodyMemoryMove (:807): one body reference of lane `dst` (body slot `src`) replaced by the payload word.
+// kind 3: bepuhip_swap_constraints: lanes `src` and `dst` exchanged.
 struct StructuralOp { unsigned refs_off, prestep_off, accum_off; int stride, nb, pf, imf, kind, src, dst; unsigned payload_off; int pad; };
 static_assert(sizeof(StructuralOp) == 48, "uploaded as raw words");
 // One workgroup per type batch: its operations run in the order the host issued them (a Move may read what an earlier append wrote), rows in parallel.
@@ -451,8 +464,9 @@ __global__ __launch_bounds__(64) void apply_structural_ops_kernel(unsigned* __re
                 const size_t base = r < op.nb ? op.refs_off + (size_t)r * op.stride
                                   : (r < op.nb + op.pf ? op.prestep_off + (size_t)(r - op.nb) * op.stride : op.accum_off + (size_t)(r - op.nb - op.pf) * op.stride);
                 unsigned v;
-                if (op.kind == 0) v = slab[base + op.src];
+                if (op.kind == 0 || op.kind == 3) v = slab[base + op.src];
                 else v = r < op.nb + op.pf ? payload[op.payload_off + r] : 0u;
+                if (op.kind == 3) slab[base + op.src] = slab[base + op.dst];
                 slab[base + op.dst] = v;
             }
         }

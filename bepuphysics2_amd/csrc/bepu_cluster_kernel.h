@@ -180,6 +180,16 @@ __device__ __forceinline__ unsigned claim_next(lds_u32* counter) {
 // wait makes that independent of the pipeline's internals.
 __device__ __forceinline__ void publish_item(volatile lds_u32* flag, unsigned epoch) {
     unsigned long long saved;
+#ifdef BEPU_EXPERIMENT_PUBLISH_NOWAIT  // (measured in round 4, tools/experiments/variants: the LDS runs a wave's instructions in order, so the flag cannot overtake the stores)
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "ds_write_b32 %[fa], %[e]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [sv] "=&s"(saved)
+        : [fa] "v"(lds_address(flag)), [e] "v"(epoch)
+        : "memory");
+#else
     asm volatile(
         "s_waitcnt lgkmcnt(0)\n\t"
         "s_mov_b64 %[sv], exec\n\t"
@@ -189,6 +199,7 @@ __device__ __forceinline__ void publish_item(volatile lds_u32* flag, unsigned ep
         : [sv] "=&s"(saved)
         : [fa] "v"(lds_address(flag)), [e] "v"(epoch)
         : "memory");
+#endif
 }
 
 // Every spin is bounded: a wait that runs out of patience (~0.1 s) records itself in the status words and lets the wave continue, so a

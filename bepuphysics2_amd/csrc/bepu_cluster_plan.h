@@ -217,7 +217,11 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         int cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        int64_t target = (total_dyn + (cus * 31 / 32) - 1) / std::max(1, cus * 31 / 32);
+        const int per_round = std::max(1, cus * 31 / 32);
+        int64_t target = (total_dyn + per_round - 1) / per_round;
+        // More bodies than one round of workgroups holds (1,600 per workgroup): whole rounds of equal clusters. A cap of 1,600 left 345 clusters for 2 M constraints —
+        // one full round and a second one that kept 95 of the 256 CUs busy: 0.44 ms/step where two full rounds take 0.35 (profiles/r04_s4_bench_fastbox.json, scale_sweep).
+        if (target > 1600) { const int64_t rounds = (target + 1599) / 1600; target = (total_dyn + rounds * per_round - 1) / (rounds * per_round); }
         cap = (int)std::min<int64_t>(std::max<int64_t>(target, 64), 1600);
     }
     if (largest > cap) cap = largest;

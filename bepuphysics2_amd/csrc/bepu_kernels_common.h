@@ -15,6 +15,11 @@ struct StepParams {
     float gx, gy, gz;  // gravity * dt
     float lin_damp, ang_damp;
     int angular_mode;  // AngularIntegrationMode (PoseIntegrator.cs:20-38): 0 Nonconserving, 1 ConserveMomentum, 2 ConserveMomentumWithGyroscopicTorque
+    // IPoseIntegratorCallbacks.IntegrateVelocity as data (include/bepuhip.h, bepuhip_velocity_model): which of the models velocity_callback evaluates, and their parameters
+    int velocity_model;         // 0 uniform gravity + damping (the fields above), 1 per-body gravity, 2 radial gravity
+    float callback_dt;          // the dt IntegrateVelocity is called with
+    float cx, cy, cz, radial;   // radial: the planet's centre and gravityDt = dt * Gravity (PlanetDemo.cs:36-40)
+    const float* body_gravity;  // per-body: the body's gravity by body index (PerBodyGravityDemo.cs:57-88 gathers it by handle)
 };
 
 struct DevTypeBatch {

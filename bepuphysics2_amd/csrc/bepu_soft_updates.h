@@ -264,6 +264,17 @@ static bool soft_update_reference(bepuhip_ctx* c, HostTypeBatch* tb, int index, 
     return true;
 }
 
+// bepuhip_swap_constraints on an island layout (whole islands or split): the device slots keep their contents, the caller's two indices name each other's slot from now on.
+static bool soft_swap(bepuhip_ctx* c, HostTypeBatch* tb, int a, int b) {
+    if (!c->soft_ok || tb->slots == 0) return soft_refuse("a swap in a type batch the island layout does not manage");
+    const int t = (int)(tb - c->tbs.data());
+    const int da = tb->inv[a], db = tb->inv[b];
+    tb->inv[a] = db; tb->inv[b] = da;
+    tb->perm[db] = a; tb->perm[da] = b;
+    c->soft_index[{t, a}] = db; c->soft_index[{t, b}] = da;
+    return true;
+}
+
 // TypeProcessor.Remove on the island layout. false: not possible here (nothing was changed).
 static bool split_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index);
 static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, const float* prestep, bool* violation);

@@ -1910,6 +1910,55 @@ int32_t bepuhip_update_body_reference(bepuhip_ctx* c, int32_t batch, int32_t typ
     return BEPUHIP_OK;
 }
 
+// Two constraints of a type batch change places (include/bepuhip.h: what a host that diffs the reference's type batches needs besides append and swap-with-last).
+int32_t bepuhip_swap_constraints(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t a, int32_t b) {
+    int32_t st = structural_preamble(c, true);
+    if (st != BEPUHIP_OK) return st;
+    HostTypeBatch* tb = find_tb(c, batch, type_id);
+    if (!tb || a < 0 || b < 0 || a >= tb->count || b >= tb->count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad swap_constraints argument");
+    if (a == b) return BEPUHIP_OK;
+    if (c->soft_ok) {  // on an island layout the rows stay where they are: two entries of the index tables change hands
+        if (soft_swap(c, tb, a, b)) { c->requirk_stale = true; return BEPUHIP_OK; }
+        HIP_TRY(hipSetDevice(c->device));
+        if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;
+        tb = find_tb(c, batch, type_id);
+    }
+    bepuhip_ctx::PendingOp p;
+    p.tb = (int)(tb - c->tbs.data());
+    p.op = StructuralOp{(unsigned)tb->refs_off, (unsigned)tb->prestep_off, (unsigned)tb->accum_off, tb->stride, tb->info.bodies, tb->info.prestep, tb->info.impulse, 3, a, b, 0u, 0};
+    c->pending_ops.push_back(p);
+    c->structure_dirty = true; c->requirk_stale = true;
+    return BEPUHIP_OK;
+}
+
+// A frame's structural changes in one call (include/bepuhip.h), in order, each exactly as the call of the same name.
+int32_t bepuhip_apply_structural_ops(bepuhip_ctx* c, const bepuhip_structural_op* ops, int32_t count, const uint32_t* payload, int32_t payload_words, int32_t* failed_op_out) {
+    if (failed_op_out) *failed_op_out = -1;
+    if (!c || count < 0 || (count > 0 && !ops) || payload_words < 0 || (payload_words > 0 && !payload)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad apply_structural_ops argument");
+    for (int32_t i = 0; i < count; ++i) {
+        const bepuhip_structural_op& op = ops[i];
+        int32_t st = BEPUHIP_OK;
+        switch (op.kind) {
+            case 0: {
+                TypeInfoH info;
+                if (!type_info(op.type_id, info)) { st = fail(BEPUHIP_E_UNSUPPORTED, "unknown constraint type id " + std::to_string(op.type_id)); break; }
+                if (op.payload_offset < 0 || (int64_t)op.payload_offset + info.bodies + info.prestep > (int64_t)payload_words) { st = fail(BEPUHIP_E_INVALID_ARGUMENT, "an addition's payload lies outside the payload array"); break; }
+                int32_t index = -1;
+                st = bepuhip_add_constraint(c, op.batch_index, op.type_id, (const int32_t*)(payload + op.payload_offset), (const float*)(payload + op.payload_offset + info.bodies), &index);
+                if (st == BEPUHIP_OK && op.index >= 0 && index != op.index)
+                    st = fail(BEPUHIP_E_STATE, "the device's type batch is out of step with the caller's: the added constraint got index " + std::to_string(index) + ", expected " + std::to_string(op.index));
+                break;
+            }
+            case 1: st = bepuhip_remove_constraint(c, op.batch_index, op.type_id, op.index); break;
+            case 2: st = bepuhip_update_body_reference(c, op.batch_index, op.type_id, op.index, op.slot, op.reference); break;
+            case 3: st = bepuhip_swap_constraints(c, op.batch_index, op.type_id, op.index, op.slot); break;
+            default: st = fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown structural operation kind " + std::to_string(op.kind));
+        }
+        if (st != BEPUHIP_OK) { if (failed_op_out) *failed_op_out = i; return st; }
+    }
+    return BEPUHIP_OK;
+}
+
 // ---- Device-resident incremental updates: ranged rewrites of what already lives in HBM, no re-plan, no full re-upload ----
 static int32_t stage_reserve(bepuhip_ctx* c, size_t floats) {
     if (floats <= c->stage_floats) return BEPUHIP_OK;

@@ -298,6 +298,63 @@ void Simulation::Timestep(float dt) {  // Simulation.cs:316-326
     timestepper->Timestep(*this, dt);
 }
 
+// ---- The structural changes of a frame, reconstructed from the type batches themselves (C++ twin of integration/csharp/HipTimestepper.cs, DiffTypeBatch) ----
+// The reference changes a type batch in three ways — append (TypeProcessor.AllocateInTypeBatch, TypeProcessor.cs:314-334), swap-with-last removal (Remove :695-717) and
+// single body references patched when a body moves in memory (UpdateForBodyMemoryMove :807) — and from several places (Solver.Add / Remove, the narrow phase's
+// pending adds and ConstraintRemover, the sleeper, the awakener's bulk copies). A device mirror does not have to see any of them happen: constraint handles are
+// stable (TypeBatch.IndexToHandle, TypeBatch.cs:16-19), so last frame's copy of a type batch's handles and references against this frame's tells which constraints left,
+// which came and which references changed. What it does not tell is the ORDER of the removals, which decides where swap-with-last left the survivors — hence the
+// fourth operation, swap: removals (in any order) + additions (in index order) + swaps (at most one per index that still disagrees) + reference patches reproduce
+// exactly this frame's arrangement. Operations are emitted in the form bepuhip_apply_structural_ops takes.
+void DiffTypeBatch(int batch, int typeId, int bodies, int prestepFloats, const int32_t* oldHandles, int oldCount, const int32_t* oldReferences /* [oldCount][bodies] */,
+                   const int32_t* newHandles, int newCount, const int32_t* newReferencesAosoa, const float* newPrestepAosoa,
+                   std::vector<bepuhip_structural_op>& ops, std::vector<uint32_t>& payload) {
+    auto lane_ref = [&](int index, int k) { return newReferencesAosoa[(size_t)(index / kBundleWidth) * bodies * kBundleWidth + (size_t)k * kBundleWidth + index % kBundleWidth]; };
+    auto lane_prestep = [&](int index, int f) { return newPrestepAosoa[(size_t)(index / kBundleWidth) * prestepFloats * kBundleWidth + (size_t)f * kBundleWidth + index % kBundleWidth]; };
+    if (oldCount == newCount && (oldCount == 0 || std::memcmp(oldHandles, newHandles, (size_t)oldCount * 4) == 0)) {  // the common case: same constraints at the same indices
+        for (int i = 0; i < newCount; ++i)
+            for (int k = 0; k < bodies; ++k)
+                if (oldReferences[(size_t)i * bodies + k] != lane_ref(i, k)) ops.push_back({2, batch, typeId, i, k, lane_ref(i, k), 0, 0});
+        return;
+    }
+    std::unordered_map<int32_t, int32_t> newIndexOf, position, oldIndexOf;
+    newIndexOf.reserve((size_t)newCount * 2); position.reserve((size_t)oldCount * 2); oldIndexOf.reserve((size_t)oldCount * 2);
+    for (int i = 0; i < newCount; ++i) newIndexOf[newHandles[i]] = i;
+    std::vector<int32_t> list(oldHandles, oldHandles + oldCount);  // the device's type batch as the operations so far leave it
+    for (int i = 0; i < oldCount; ++i) { position[oldHandles[i]] = i; oldIndexOf[oldHandles[i]] = i; }
+    for (int i = oldCount - 1; i >= 0; --i) {  // removals, highest old index first (any order is right; this one moves the fewest survivors)
+        const int32_t handle = oldHandles[i];
+        if (newIndexOf.count(handle)) continue;
+        const int at = position[handle], last = (int)list.size() - 1;
+        ops.push_back({1, batch, typeId, at, 0, 0, 0, 0});
+        if (at != last) { list[at] = list[last]; position[list[at]] = at; }
+        list.pop_back();
+        position.erase(handle);
+    }
+    for (int i = 0; i < newCount; ++i) {  // additions, in the order of their final indices
+        const int32_t handle = newHandles[i];
+        if (oldIndexOf.count(handle)) continue;
+        ops.push_back({0, batch, typeId, (int32_t)list.size(), 0, 0, (int32_t)payload.size(), 0});
+        for (int k = 0; k < bodies; ++k) payload.push_back((uint32_t)lane_ref(i, k));
+        for (int f = 0; f < prestepFloats; ++f) { const float v = lane_prestep(i, f); uint32_t w; std::memcpy(&w, &v, 4); payload.push_back(w); }
+        position[handle] = (int32_t)list.size();
+        list.push_back(handle);
+    }
+    for (int i = 0; i < newCount; ++i) {  // the same set by now: put every index right
+        if (list[i] == newHandles[i]) continue;
+        const int j = position[newHandles[i]];
+        ops.push_back({3, batch, typeId, i, j, 0, 0, 0});
+        std::swap(list[i], list[j]);
+        position[list[i]] = i; position[list[j]] = j;
+    }
+    for (int i = 0; i < newCount; ++i) {  // survivors whose bodies moved in memory
+        auto was = oldIndexOf.find(newHandles[i]);
+        if (was == oldIndexOf.end()) continue;
+        for (int k = 0; k < bodies; ++k)
+            if (oldReferences[(size_t)was->second * bodies + k] != lane_ref(i, k)) ops.push_back({2, batch, typeId, i, k, lane_ref(i, k), 0, 0});
+    }
+}
+
 // ---- HipTimestepper: DefaultTimestepper.Timestep (DefaultTimestepper.cs:28-43) with simulation.Solve replaced by the C ABI ----
 struct HipApi {
     void* lib = nullptr;
@@ -305,6 +362,7 @@ struct HipApi {
     DECL(bepuhip_last_error) DECL(bepuhip_create) DECL(bepuhip_destroy) DECL(bepuhip_set_bodies) DECL(bepuhip_begin_constraints)
     DECL(bepuhip_set_type_batch) DECL(bepuhip_end_constraints) DECL(bepuhip_set_constrained_kinematics) DECL(bepuhip_solve)
     DECL(bepuhip_get_bodies) DECL(bepuhip_get_accumulated_impulses) DECL(bepuhip_get_prestep) DECL(bepuhip_add_constraint) DECL(bepuhip_remove_constraint)
+    DECL(bepuhip_apply_structural_ops)
 #undef DECL
     bool load(const char* path, std::string& err) {
         lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
@@ -313,6 +371,7 @@ struct HipApi {
         LOAD(bepuhip_last_error) LOAD(bepuhip_create) LOAD(bepuhip_destroy) LOAD(bepuhip_set_bodies) LOAD(bepuhip_begin_constraints)
         LOAD(bepuhip_set_type_batch) LOAD(bepuhip_end_constraints) LOAD(bepuhip_set_constrained_kinematics) LOAD(bepuhip_solve)
         LOAD(bepuhip_get_bodies) LOAD(bepuhip_get_accumulated_impulses) LOAD(bepuhip_get_prestep) LOAD(bepuhip_add_constraint) LOAD(bepuhip_remove_constraint)
+        LOAD(bepuhip_apply_structural_ops)
 #undef LOAD
         return true;
     }
@@ -323,8 +382,51 @@ public:
     HipApi api;
     bepuhip_ctx* ctx = nullptr;
     uint64_t uploadedSolverVersion = ~0ull, uploadedBodiesVersion = ~0ull;
-    int fullUploads = 0, structuralReplays = 0;
+    int fullUploads = 0, structuralReplays = 0, diffOperations = 0;
     size_t uploadedKinematics = 0;
+    // How the constraint changes of a frame reach the device: 0 = the solver's structural log (what a listener inside the reference would record), 1 = the diff of the
+    // type batches against last frame's copy (public API only: what integration/csharp/HipTimestepper.cs does by default).
+    int mode = 0;
+    struct Mirror { std::vector<int32_t> handles, references; int bodies = 0; };
+    std::unordered_map<uint64_t, Mirror> mirrors;  // (batch index << 32 | type id) -> the type batch as the device has it
+    void RememberTypeBatches(const Solver& solver) {
+        mirrors.clear();
+        for (size_t b = 0; b < solver.Batches.size(); ++b)
+            for (const TypeBatch& tb : solver.Batches[b].TypeBatches) {
+                Mirror& m = mirrors[((uint64_t)b << 32) | (uint32_t)tb.TypeId];
+                m.bodies = tb.Info.bodies;
+                m.handles.assign(tb.IndexToHandle.begin(), tb.IndexToHandle.begin() + tb.ConstraintCount);
+                m.references.resize((size_t)tb.ConstraintCount * tb.Info.bodies);
+                for (int i = 0; i < tb.ConstraintCount; ++i)
+                    for (int k = 0; k < tb.Info.bodies; ++k)
+                        m.references[(size_t)i * tb.Info.bodies + k] = tb.BodyReferences[(size_t)(i / kBundleWidth) * tb.Info.bodies * kBundleWidth + (size_t)k * kBundleWidth + i % kBundleWidth];
+            }
+    }
+    // One bepuhip_apply_structural_ops call for everything that changed in the solver's type batches since RememberTypeBatches.
+    void DiffAndApply(const Solver& solver) {
+        std::vector<bepuhip_structural_op> ops;
+        std::vector<uint32_t> payload;
+        std::unordered_map<uint64_t, bool> seen;
+        for (size_t b = 0; b < solver.Batches.size(); ++b)
+            for (const TypeBatch& tb : solver.Batches[b].TypeBatches) {
+                const uint64_t key = ((uint64_t)b << 32) | (uint32_t)tb.TypeId;
+                seen[key] = true;
+                auto found = mirrors.find(key);
+                static const Mirror empty;
+                const Mirror& was = found == mirrors.end() ? empty : found->second;
+                DiffTypeBatch((int)b, tb.TypeId, tb.Info.bodies, tb.Info.prestepFloats, was.handles.data(), (int)was.handles.size(), was.references.data(), tb.IndexToHandle.data(),
+                              tb.ConstraintCount, tb.BodyReferences.data(), tb.PrestepData.data(), ops, payload);
+            }
+        for (auto& kv : mirrors)  // a type batch that no longer exists (ConstraintBatch.RemoveTypeBatchIfEmpty): its constraints went
+            if (!seen.count(kv.first))
+                for (int i = (int)kv.second.handles.size() - 1; i >= 0; --i) ops.push_back({1, (int32_t)(kv.first >> 32), (int32_t)(uint32_t)kv.first, i, 0, 0, 0, 0});
+        diffOperations += (int)ops.size();
+        if (!ops.empty()) {
+            int32_t failed = -1;
+            if (payload.empty()) payload.push_back(0u);
+            check(api.bepuhip_apply_structural_ops(ctx, ops.data(), (int32_t)ops.size(), payload.data(), (int32_t)payload.size(), &failed));
+        }
+    }
     HipTimestepper(const char* libraryPath, int device) {
         std::string err;
         if (!api.load(libraryPath, err)) throw std::runtime_error("cannot load libbepuhip: " + err);
@@ -347,6 +449,18 @@ public:
         check(api.bepuhip_set_bodies(ctx, sim.bodies.DynamicsState.data(), sim.bodies.Count()));
         // Constraint changes since the last frame: replayed through the structural calls when the log covers exactly what happened since the upload (and is short
         // next to a re-upload); the library keeps them on the island layout where it can (include/bepuhip.h).
+        if (mode == 1 && uploadedBodiesVersion == sim.bodies.TopologyVersion && uploadedSolverVersion != ~0ull) {
+            if (uploadedSolverVersion != solver.TopologyVersion) {
+                DiffAndApply(solver);
+                RememberTypeBatches(solver);
+                std::vector<int32_t> kin;
+                for (int32_t h : solver.ConstrainedKinematicHandles) kin.push_back(sim.bodies.HandleToIndex[h]);
+                check(api.bepuhip_set_constrained_kinematics(ctx, kin.data(), (int)kin.size()));
+                uploadedKinematics = kin.size();
+                uploadedSolverVersion = solver.TopologyVersion;
+                ++structuralReplays;
+            }
+        } else
         if (uploadedBodiesVersion == sim.bodies.TopologyVersion && uploadedSolverVersion != solver.TopologyVersion && solver.StructuralLogBase == uploadedSolverVersion &&
             solver.StructuralLogBase + solver.StructuralLog.size() == solver.TopologyVersion && (int)solver.StructuralLog.size() * 8 < std::max(64, solver.ConstraintCount())) {
             for (const Solver::StructuralChange& change : solver.StructuralLog) {
@@ -381,6 +495,7 @@ public:
             uploadedKinematics = kin.size();
             uploadedSolverVersion = solver.TopologyVersion;
             uploadedBodiesVersion = sim.bodies.TopologyVersion;
+            if (mode == 1) RememberTypeBatches(solver);
         }
         std::vector<int32_t> iterations = sim.solveDescription.ResolveIterations();
         bepuhip_integrator in{};
@@ -503,6 +618,27 @@ int32_t bepuhost_attach_hip_timestepper(void* s, const char* libraryPath, int de
         sim->timestepper = new HipTimestepper(libraryPath, device);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+// 0: the attached HipTimestepper replays the solver's structural log (a listener's view); 1: it diffs the type batches against last frame's copy (public API only).
+int32_t bepuhost_timestepper_mode(void* s, int mode) {
+    HipTimestepper* t = dynamic_cast<HipTimestepper*>(((Simulation*)s)->timestepper);
+    if (!t) { g_err = "no HipTimestepper attached"; return -1; }
+    t->mode = mode;
+    return 0;
+}
+// The diff on its own, for tests that keep their own mirror of a type batch: writes at most `opCapacity` operations (8 int32 each, bepuhip_structural_op) and
+// `payloadCapacity` payload words; returns the number of operations, *payloadWords the words used, or -1 when a capacity is too small.
+int32_t bepuhost_diff_type_batch(int batch, int typeId, int bodies, int prestepFloats, const int32_t* oldHandles, int oldCount, const int32_t* oldReferences,
+                                 const int32_t* newHandles, int newCount, const int32_t* newReferencesAosoa, const float* newPrestepAosoa,
+                                 int32_t* opsOut, int opCapacity, uint32_t* payloadOut, int payloadCapacity, int32_t* payloadWords) {
+    std::vector<bepuhip_structural_op> ops;
+    std::vector<uint32_t> payload;
+    DiffTypeBatch(batch, typeId, bodies, prestepFloats, oldHandles, oldCount, oldReferences, newHandles, newCount, newReferencesAosoa, newPrestepAosoa, ops, payload);
+    if ((int)ops.size() > opCapacity || (int)payload.size() > payloadCapacity) return -1;
+    if (!ops.empty()) std::memcpy(opsOut, ops.data(), ops.size() * sizeof(bepuhip_structural_op));
+    if (!payload.empty()) std::memcpy(payloadOut, payload.data(), payload.size() * 4);
+    *payloadWords = (int32_t)payload.size();
+    return (int32_t)ops.size();
 }
 // How often the attached HipTimestepper re-uploaded the topology / replayed a structural log instead.
 void bepuhost_timestepper_stats(void* s, int32_t* fullUploads, int32_t* structuralReplays);

@@ -63,6 +63,10 @@ def load_library() -> C.CDLL:
     lib.bepuhost_type_batch_handles.restype = C.POINTER(C.c_int32)
     lib.bepuhost_timestepper_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.bepuhost_timestepper_stats.restype = None
+    lib.bepuhost_timestepper_mode.argtypes = [vp, C.c_int]
+    lib.bepuhost_timestepper_mode.restype = i32
+    lib.bepuhost_diff_type_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.POINTER(i32)]
+    lib.bepuhost_diff_type_batch.restype = i32
     _lib = lib
     return lib
 
@@ -192,9 +196,35 @@ class HostSimulation:
         if self.lib.bepuhost_attach_hip_timestepper(self.h, HIP_LIB.encode(), device) != 0:
             raise RuntimeError(_err(self.lib))
 
+    def timestepper_mode(self, mode: int):
+        """0: the attached HipTimestepper replays the solver's structural log; 1: it diffs the type batches against last frame's copy (public API only) and sends the
+        frame's changes in one bepuhip_apply_structural_ops call."""
+        if self.lib.bepuhost_timestepper_mode(self.h, int(mode)) != 0:
+            raise RuntimeError(_err(self.lib))
+
     def timestep(self, dt: float):
         r = self.lib.bepuhost_timestep(self.h, dt)
         if r == -1:
             raise ValueError(_err(self.lib))  # ArgumentException (Simulation.cs:318-319)
         if r != 0:
             raise RuntimeError(_err(self.lib))
+
+
+def diff_type_batch(batch: int, type_id: int, bodies: int, prestep_floats: int, old_handles, old_references, new_handles, new_references_aosoa, new_prestep_aosoa):
+    """The C++ twin of integration/csharp/HipTimestepper.cs's DiffTypeBatch (host/bepu_host.cpp): the operations (int32 [n, 8], bepuhip_structural_op) and payload words that
+    turn a device type batch holding `old_handles` / `old_references` ([count, bodies], encoded) into this frame's arrangement."""
+    lib = load_library()
+    old_h = np.ascontiguousarray(old_handles, dtype=np.int32)
+    old_r = np.ascontiguousarray(old_references, dtype=np.int32).reshape(-1)
+    new_h = np.ascontiguousarray(new_handles, dtype=np.int32)
+    new_r = np.ascontiguousarray(new_references_aosoa, dtype=np.int32)
+    new_p = np.ascontiguousarray(new_prestep_aosoa, dtype=np.float32)
+    capacity = 4 * (old_h.size + new_h.size) + 16
+    ops = np.zeros((capacity, 8), dtype=np.int32)
+    payload = np.zeros(max(1, new_h.size * (bodies + prestep_floats)), dtype=np.uint32)
+    words = C.c_int32()
+    n = lib.bepuhost_diff_type_batch(batch, type_id, bodies, prestep_floats, old_h.ctypes.data, old_h.size, old_r.ctypes.data, new_h.ctypes.data, new_h.size, new_r.ctypes.data,
+                                     new_p.ctypes.data, ops.ctypes.data, capacity, payload.ctypes.data, payload.size, C.byref(words))
+    if n < 0:
+        raise RuntimeError("diff_type_batch: capacity")
+    return ops[:n].copy(), payload[: max(1, words.value)].copy()

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
     "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables", "bepuhip_set_convex_hulls", "bepuhip_set_compounds", "bepuhip_set_meshes",
-    "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_get_constraint_count", "bepuhip_get_schedule", "bepuhip_replan",
+    "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_swap_constraints", "bepuhip_apply_structural_ops", "bepuhip_get_constraint_count", "bepuhip_get_schedule", "bepuhip_replan",
     "bepuhip_register_host_memory", "bepuhip_unregister_host_memory", "bepuhip_get_poses_and_velocities", "bepuhip_get_poses_and_velocities_async", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses_async",
 ]
 
@@ -133,6 +133,8 @@ def load_library() -> C.CDLL:
     lib.bepuhip_add_constraint.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
     lib.bepuhip_remove_constraint.argtypes = [vp, i32, i32, i32]
     lib.bepuhip_update_body_reference.argtypes = [vp, i32, i32, i32, i32, i32]
+    lib.bepuhip_swap_constraints.argtypes = [vp, i32, i32, i32, i32]
+    lib.bepuhip_apply_structural_ops.argtypes = [vp, vp, i32, vp, i32, C.POINTER(i32)]
     lib.bepuhip_get_constraint_count.argtypes = [vp, i32, i32, C.POINTER(i32)]
     lib.bepuhip_get_schedule.argtypes = [vp, C.POINTER(i32)]
     lib.bepuhip_replan.argtypes = [vp]
@@ -369,6 +371,45 @@ class HipSolver:
     def remove_constraint(self, batch_index: int, type_id: int, index: int):
         """TypeProcessor.Remove, non-fallback (TypeProcessor.cs:695-717): swap-with-last."""
         _check(self.lib, self.lib.bepuhip_remove_constraint(self.ctx, batch_index, type_id, index))
+
+    def swap_constraints(self, batch_index: int, type_id: int, index_a: int, index_b: int):
+        """The constraints at two indices of a type batch change places (bepuhip.h: what a host that diffs the reference's type batches needs besides append and swap-with-last)."""
+        _check(self.lib, self.lib.bepuhip_swap_constraints(self.ctx, batch_index, type_id, index_a, index_b))
+
+    def apply_structural_ops(self, ops) -> None:
+        """One call for a frame's structural changes, in order (bepuhip_apply_structural_ops). `ops`: tuples
+        ("add", batch, type_id, encoded_body_references, prestep_lane[, expected_index]) / ("remove", batch, type_id, index) /
+        ("update", batch, type_id, index, body_index_in_constraint, encoded_body_reference) / ("swap", batch, type_id, index_a, index_b)."""
+        table = np.zeros((len(ops), 8), dtype=np.int32)
+        payload = []
+        words = 0
+        for i, op in enumerate(ops):
+            kind = op[0]
+            if kind == "add":
+                refs = np.ascontiguousarray(op[3], dtype=np.int32)
+                lane = np.ascontiguousarray(op[4], dtype=np.float32)
+                assert refs.size == TYPE_TABLE[op[2]][0] and lane.size == TYPE_TABLE[op[2]][1]
+                table[i] = (0, op[1], op[2], op[5] if len(op) > 5 else -1, 0, 0, words, 0)
+                payload += [refs.view(np.uint32), lane.view(np.uint32)]
+                words += refs.size + lane.size
+            elif kind == "remove":
+                table[i] = (1, op[1], op[2], op[3], 0, 0, 0, 0)
+            elif kind == "update":
+                table[i] = (2, op[1], op[2], op[3], op[4], int(op[5]), 0, 0)
+            elif kind == "swap":
+                table[i] = (3, op[1], op[2], op[3], op[4], 0, 0, 0)
+            else:
+                raise ValueError(kind)
+        flat = np.concatenate(payload) if payload else np.zeros(1, dtype=np.uint32)
+        failed = C.c_int32(-1)
+        _check(self.lib, self.lib.bepuhip_apply_structural_ops(self.ctx, _ptr(table), len(ops), _ptr(flat), int(words), C.byref(failed)))
+
+    def apply_structural_op_table(self, table: np.ndarray, payload: np.ndarray) -> None:
+        """The same with the operation table (int32 [n, 8]: kind, batch, type id, index, slot, reference, payload offset, 0) and the payload words prepared by the caller."""
+        table = np.ascontiguousarray(table, dtype=np.int32)
+        payload = np.ascontiguousarray(payload, dtype=np.uint32)
+        failed = C.c_int32(-1)
+        _check(self.lib, self.lib.bepuhip_apply_structural_ops(self.ctx, _ptr(table), table.shape[0], _ptr(payload), payload.size, C.byref(failed)))
 
     def update_body_reference(self, batch_index: int, type_id: int, index: int, body_index_in_constraint: int, encoded_body_reference: int):
         """TypeProcessor.UpdateForBodyMemoryMove (TypeProcessor.cs:807)."""

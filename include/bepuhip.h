@@ -25,7 +25,7 @@ extern "C" {
 
 #define BEPUHIP_OK 0
 #define BEPUHIP_E_INVALID_ARGUMENT (-1) /* reference throws ArgumentException (Simulation.cs:318-319, SolveDescription.cs:42-47) */
-#define BEPUHIP_E_UNSUPPORTED (-2)      /* unknown type id, fallback batch present, ...: caller should fall back to simulation.Solve */
+#define BEPUHIP_E_UNSUPPORTED (-2)      /* unknown type id, a structural update of a scene with a sequential fallback batch, ...: caller should fall back to simulation.Solve */
 #define BEPUHIP_E_DEVICE (-3)           /* HIP runtime failure */
 #define BEPUHIP_E_STATE (-4)            /* calls out of order */
 
@@ -224,6 +224,22 @@ int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* ctx, int32_t batch_i
 int32_t bepuhip_add_constraint(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, const int32_t* encoded_body_references, const float* prestep_lane, int32_t* index_out);
 int32_t bepuhip_remove_constraint(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index);
 int32_t bepuhip_update_body_reference(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index, int32_t body_index_in_constraint, int32_t encoded_body_reference);
+/* Exchanges the constraints at two indices of a type batch (everything the device holds for them: references, prestep data, accumulated impulses). The reference has no
+ * such call — its type batches only change by append and swap-with-last — but a host that reconstructs a frame's structural changes from the type batches themselves
+ * (integration/csharp/HipTimestepper.cs: the diff of TypeBatch.IndexToHandle, TypeBatch.cs:16, against last frame's copy) knows WHICH constraints left and came, not the
+ * order the reference removed them in, and the order decides where swap-with-last leaves the survivors: removals + additions + a few swaps reproduce any arrangement. On
+ * an island layout a swap only exchanges two entries of the index tables. */
+int32_t bepuhip_swap_constraints(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index_a, int32_t index_b);
+/* One call for a frame's structural changes (2,000 - 6,000 calls per frame cost more host time than the solve; the reference batches too: ConstraintRemover.cs,
+ * NarrowPhasePendingConstraintAdds.cs). `ops` are applied in order, each exactly as the call of the same name would be:
+ *   kind 0  bepuhip_add_constraint       payload[payload_offset ...] = the encoded body references, then the prestep lane (as raw 32-bit words); `index` = the index the
+ *                                        caller expects the constraint to get (checked: STATE when the device's type batch is out of step), or -1
+ *   kind 1  bepuhip_remove_constraint    `index`
+ *   kind 2  bepuhip_update_body_reference `index`, `slot` = body index in constraint, `reference`
+ *   kind 3  bepuhip_swap_constraints     `index`, `slot` = the other index
+ * Stops at the first operation that fails: its ordinal in *failed_op_out (optional), the operations before it stay applied, the error is the failing call's. */
+typedef struct bepuhip_structural_op { int32_t kind, batch_index, type_id, index, slot, reference, payload_offset, reserved; } bepuhip_structural_op;
+int32_t bepuhip_apply_structural_ops(bepuhip_ctx* ctx, const bepuhip_structural_op* ops, int32_t count, const uint32_t* payload, int32_t payload_words, int32_t* failed_op_out);
 /* ConstraintCount of a type batch as the device sees it (0 if it does not exist). */
 int32_t bepuhip_get_constraint_count(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t* count_out);
 /* The schedule the next solve of this context runs: 0 one launch per batch and stage (hipGraph replay), 1 island-per-workgroup with whole islands, 2 island-per-workgroup

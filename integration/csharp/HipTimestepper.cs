@@ -1,7 +1,9 @@
 // Reference-side binding of libbepuhip.so (include/bepuhip.h): drop this file into an application that references BepuPhysics and create the simulation with
-// `new HipTimestepper<TCallbacks>()`. It uses public API only, plus — for frames whose constraint set changed — three listener calls a maintainer adds to the
-// reference (IHipStructureListener below; without them the shim re-uploads whenever the topology changed). INTEGRATION.md carries the same text (a test keeps the two
-// identical, and the DllImport block is generated from the header by tools/gen_csharp_imports.py); not compiled in this repository's environment (no .NET SDK here).
+// `new HipTimestepper<TCallbacks>()`. It uses public API only, on the UNPATCHED reference: the structural changes of a frame (narrow-phase adds and removes, sleeping,
+// awakening, user calls, bodies moving in memory) are reconstructed by diffing every type batch's constraint handles (TypeBatch.IndexToHandle, TypeBatch.cs:16) and body
+// references against last frame's copy, and sent to the device in one bepuhip_apply_structural_ops call. INTEGRATION.md carries the same text (a test keeps the two
+// identical, and the DllImport block is generated from the header by tools/gen_csharp_imports.py); the diff has a C++ twin that IS compiled and tested here
+// (bepuphysics2_amd/host/bepu_host.cpp DiffTypeBatch; tests/test_structural_diff.py, tests/test_gpu_structural.py) — this text itself is not (no .NET SDK in this environment).
 using System;
 using System.Collections.Generic;
 using System.Runtime.InteropServices;
@@ -21,6 +23,9 @@ unsafe struct BepuHipIntegrator
     public float LinearDamping, AngularDamping;
     public int AngularIntegrationMode, AllowSubstepsForUnconstrained, IntegrateVelocityForKinematics;
 }
+
+[StructLayout(LayoutKind.Sequential)]
+struct BepuHipStructuralOp { public int Kind, BatchIndex, TypeId, Index, Slot, Reference, PayloadOffset, Reserved; }   // bepuhip_structural_op: 0 add, 1 remove, 2 update reference, 3 swap
 
 [StructLayout(LayoutKind.Sequential)]
 unsafe struct BepuHipCollidable   // 64 bytes, bepuhip_collidable
@@ -77,6 +82,8 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_add_constraint(IntPtr ctx, int batchIndex, int typeId, int* encodedBodyReferences, float* prestepLane, int* indexOut);
     [DllImport(Lib)] public static extern int bepuhip_remove_constraint(IntPtr ctx, int batchIndex, int typeId, int index);
     [DllImport(Lib)] public static extern int bepuhip_update_body_reference(IntPtr ctx, int batchIndex, int typeId, int index, int bodyIndexInConstraint, int encodedBodyReference);
+    [DllImport(Lib)] public static extern int bepuhip_swap_constraints(IntPtr ctx, int batchIndex, int typeId, int indexA, int indexB);
+    [DllImport(Lib)] public static extern int bepuhip_apply_structural_ops(IntPtr ctx, BepuHipStructuralOp* ops, int count, uint* payload, int payloadWords, int* failedOpOut);
     [DllImport(Lib)] public static extern int bepuhip_get_constraint_count(IntPtr ctx, int batchIndex, int typeId, int* countOut);
     [DllImport(Lib)] public static extern int bepuhip_get_schedule(IntPtr ctx, int* scheduleOut);
     [DllImport(Lib)] public static extern int bepuhip_replan(IntPtr ctx);
@@ -108,31 +115,27 @@ static unsafe class BepuHip
 /// damping" (Demos/DemoCallbacks.cs:100-109 is one) implements this by returning its fields; anything else leaves the interface off and the shim uses simulation.Solve.
 public interface IHipVelocityModel { System.Numerics.Vector3 Gravity { get; } float LinearDamping { get; } float AngularDamping { get; } }
 
-/// The three places at which the reference changes a type batch between solves, as calls. A maintainer adds them to the reference (a `public IHipStructureListener
-/// StructureListener;` on Solver, invoked behind the mutation with the indices the mutation used):
-///   TypeProcessor.AllocateInTypeBatch (Constraints/TypeProcessor.cs:314-334, reached from Solver.Add)            -> ConstraintAdded
-///   TypeProcessor.Remove              (:695-717; the last constraint moves into the hole, Move :578-592)           -> ConstraintRemoved
-///   TypeProcessor.UpdateForBodyMemoryMove (:807, from Solver.UpdateForBodyMemoryMove, Solver.cs:1475)             -> BodyReferenceChanged
-/// A new ConstraintBatch or TypeBatch (Solver.cs:1182-1199, ConstraintBatch.cs:66-80) is not an update of a type batch: -> TopologyReset (the next frame uploads).
-public interface IHipStructureListener
-{
-    unsafe void ConstraintAdded(int batchIndex, int typeId, int indexInTypeBatch, int bodiesPerConstraint, int* encodedBodyReferences, int prestepFloats, float* prestepLane);
-    void ConstraintRemoved(int batchIndex, int typeId, int indexInTypeBatch);
-    void BodyReferenceChanged(int batchIndex, int typeId, int indexInTypeBatch, int bodyIndexInConstraint, int encodedBodyReference);
-    void TopologyReset();
-}
-
-public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipStructureListener, IDisposable where TCallbacks : struct, IPoseIntegratorCallbacks, IHipVelocityModel
+public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IDisposable where TCallbacks : struct, IPoseIntegratorCallbacks, IHipVelocityModel
 {
     IntPtr ctx;
     bool resident;                                    // the device holds the scene as of the last solve
-    struct StructuralOp { public int Kind, Batch, TypeId, Index, Slot, Reference; public int[] References; public float[] Prestep; }
-    readonly List<StructuralOp> log = new List<StructuralOp>();   // what the listener saw since the last solve, in order
+    // What the device holds of every type batch, keyed by (batch index, type id): the constraint handles by index (TypeBatch.IndexToHandle is public, TypeBatch.cs:16-19;
+    // handles are stable for a constraint's life, Solver.HandlePool) and the encoded body references by index. The diff against this frame's type batches IS the frame's
+    // structural change: whoever made it — NarrowPhasePendingConstraintAdds, ConstraintRemover, Solver.Add / Remove, the sleeper, IslandAwakener's bulk copies
+    // (IslandAwakener.cs:388-400, which no per-constraint hook sees), Bodies.RemoveAt's reference patches (Solver.UpdateForBodyMemoryMove, Solver.cs:1475).
+    sealed class Mirror { public int[] Handles = Array.Empty<int>(); public int[] References = Array.Empty<int>(); public int Count, Bodies; public bool Seen; }
+    readonly Dictionary<long, Mirror> mirrors = new Dictionary<long, Mirror>();
+    readonly List<BepuHipStructuralOp> ops = new List<BepuHipStructuralOp>();
+    readonly List<uint> payload = new List<uint>();
     public int ReplanInterval = 30;                                // frames between two bepuhip_replan calls at most
-    int residentBodyCount;                                         // Bodies.ActiveSet.Count the device's body array was last sent with
+    /// Every body's state is sent before every solve (bepuhip_set_bodies: one DMA from the registered DynamicsState buffer, 0.6 ms for 240,000 bodies): velocities the user
+    /// set, ApplyImpulse, teleports, inertia changes and kinematic bodies driven by writing their velocity all reach the device. A host that never writes body state
+    /// between frames may turn it off; bodies are then sent when the body count changed or a body moved in memory.
+    public bool ResendBodiesEveryFrame = true;
+    int residentBodyCount;
     int framesSinceReplan = 30;
     readonly Dictionary<IntPtr, long> registered = new Dictionary<IntPtr, long>();
-    public int ReplayLimit = 65536;                   // a longer log is not cheaper than an upload
+    public int ReplayLimit = 262144;                  // more operations than this in one frame are not cheaper than an upload
     public event TimestepperStageHandler BeforeCollisionDetection, CollisionsDetected, ConstraintsSolved; // ITimestepper.cs:62-74 (subset)
 
     public HipTimestepper(int device = 0, bool deviceIsExclusive = false)
@@ -150,19 +153,6 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipStructureList
         throw new InvalidOperationException(message);
     }
 
-    // ---- IHipStructureListener: the narrow phase's add / remove stream, recorded with the indices the reference used ----
-    public void ConstraintAdded(int batchIndex, int typeId, int indexInTypeBatch, int bodiesPerConstraint, int* encodedBodyReferences, int prestepFloats, float* prestepLane)
-    {
-        var op = new StructuralOp { Kind = 0, Batch = batchIndex, TypeId = typeId, Index = indexInTypeBatch, References = new int[bodiesPerConstraint], Prestep = new float[prestepFloats] };
-        for (int i = 0; i < bodiesPerConstraint; ++i) op.References[i] = encodedBodyReferences[i];
-        for (int i = 0; i < prestepFloats; ++i) op.Prestep[i] = prestepLane[i];
-        log.Add(op);
-    }
-    public void ConstraintRemoved(int batchIndex, int typeId, int indexInTypeBatch) { log.Add(new StructuralOp { Kind = 1, Batch = batchIndex, TypeId = typeId, Index = indexInTypeBatch }); }
-    public void BodyReferenceChanged(int batchIndex, int typeId, int indexInTypeBatch, int bodyIndexInConstraint, int encodedBodyReference)
-    { log.Add(new StructuralOp { Kind = 2, Batch = batchIndex, TypeId = typeId, Index = indexInTypeBatch, Slot = bodyIndexInConstraint, Reference = encodedBodyReference }); }
-    public void TopologyReset() { resident = false; log.Clear(); }
-
     public void Timestep(Simulation simulation, float dt, IThreadDispatcher threadDispatcher = null)
     {
         simulation.Sleep(threadDispatcher);                               // DefaultTimestepper.cs:30
@@ -176,14 +166,40 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipStructureList
         simulation.IncrementallyOptimizeDataStructures(threadDispatcher); // :42
     }
 
-    // BufferPool blocks are pinned unmanaged memory (BufferPool.cs:42,83): registered once per address, copies from / to them are asynchronous DMA from then on.
+    // Registered (pinned) host memory is read and written by asynchronous DMA. BufferPool hands out sub-allocations of large blocks (BufferPool.cs:42,83) and neighbouring
+    // buffers share pages, so ranges are registered once per address and the library refuses a range that an existing registration covers only in part
+    // (bepuhip_register_host_memory): such a buffer stays unregistered and its copies are staged by the runtime instead — slower, never wrong.
     void Register(void* memory, long bytes)
     {
         if (memory == null || bytes <= 0) return;
-        if (registered.TryGetValue((IntPtr)memory, out var known) && known >= bytes) return;
+        if (registered.TryGetValue((IntPtr)memory, out var known) && (known >= bytes || known < 0)) return;
         if (known > 0) Check(BepuHip.bepuhip_unregister_host_memory(ctx, memory));   // the buffer was resized in place
-        Check(BepuHip.bepuhip_register_host_memory(ctx, memory, bytes));
-        registered[(IntPtr)memory] = bytes;
+        registered[(IntPtr)memory] = BepuHip.bepuhip_register_host_memory(ctx, memory, bytes) == 0 ? bytes : -1;
+    }
+
+    static long Key(int batchIndex, int typeId) => ((long)batchIndex << 32) | (uint)typeId;
+    // Floats per constraint of a type's prestep data (TypeProcessor.GetBundleTypeSizes is internal; the library knows every type id: bepuhip_type_info)
+    readonly Dictionary<int, int> prestepFloats = new Dictionary<int, int>();
+    int PrestepFloats(int typeId)
+    {
+        if (prestepFloats.TryGetValue(typeId, out var known)) return known;
+        int bodiesPerConstraint, floats, impulses;
+        Check(BepuHip.bepuhip_type_info(typeId, &bodiesPerConstraint, &floats, &impulses));
+        return prestepFloats[typeId] = floats;
+    }
+
+    void Remember(int batchIndex, ref TypeBatch tb, int bodiesPerConstraint)
+    {
+        if (!mirrors.TryGetValue(Key(batchIndex, tb.TypeId), out var m)) mirrors[Key(batchIndex, tb.TypeId)] = m = new Mirror();
+        m.Bodies = bodiesPerConstraint; m.Count = tb.ConstraintCount; m.Seen = true;
+        if (m.Handles.Length < tb.ConstraintCount) { m.Handles = new int[Math.Max(tb.ConstraintCount, m.Handles.Length * 2)]; m.References = new int[m.Handles.Length * bodiesPerConstraint]; }
+        var width = System.Numerics.Vector<int>.Count;
+        var references = (int*)tb.BodyReferences.Memory;   // AOSOA: bundle, body slot, lane (TypeProcessor.cs:139-148)
+        for (int i = 0; i < tb.ConstraintCount; ++i)
+        {
+            m.Handles[i] = tb.IndexToHandle[i].Value;
+            for (int k = 0; k < bodiesPerConstraint; ++k) m.References[i * bodiesPerConstraint + k] = references[(i / width) * bodiesPerConstraint * width + k * width + i % width];
+        }
     }
 
     void Upload(Simulation simulation)
@@ -194,6 +210,7 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipStructureList
         Register(activeBodies.DynamicsState.Memory, (long)activeBodies.DynamicsState.Length * sizeof(BodyDynamics));
         Check(BepuHip.bepuhip_set_bodies(ctx, activeBodies.DynamicsState.Memory, activeBodies.Count));
         Check(BepuHip.bepuhip_begin_constraints(ctx, activeSet.Batches.Count, solver.FallbackBatchThreshold));
+        mirrors.Clear();
         for (int b = 0; b < activeSet.Batches.Count; ++b)
         {
             ref var batch = ref activeSet.Batches[b];
@@ -202,35 +219,121 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipStructureList
                 ref var tb = ref batch.TypeBatches[t];   // TypeBatch.cs:10-19; the library reads prestep data and impulses until end_constraints returns
                 Register(tb.PrestepData.Memory, tb.PrestepData.Length); Register(tb.AccumulatedImpulses.Memory, tb.AccumulatedImpulses.Length);
                 Check(BepuHip.bepuhip_set_type_batch(ctx, b, tb.TypeId, tb.ConstraintCount, (int*)tb.BodyReferences.Memory, (float*)tb.PrestepData.Memory, (float*)tb.AccumulatedImpulses.Memory));
+                Remember(b, ref tb, solver.TypeProcessors[tb.TypeId].BodiesPerConstraint);
             }
         }
         Check(BepuHip.bepuhip_end_constraints(ctx));
         resident = true;
-        log.Clear();
     }
 
-    // The constraint set changed by what the log holds: the same mutations, with the same indices, on the rows in HBM (applied by the library at the start of the solve).
-    void Replay()
+    // One type batch: the operations that turn what the device holds (the mirror) into what the host holds now. The reference changes a type batch by append
+    // (TypeProcessor.AllocateInTypeBatch, TypeProcessor.cs:314-334), swap-with-last removal (Remove :695-717) and reference patches (UpdateForBodyMemoryMove :807); the
+    // handles say which constraints left and which came, but not the ORDER of the removals, which decides where swap-with-last left the survivors — hence the swaps:
+    // removals (any order) + additions (in index order) + swaps (at most one per index that still disagrees) + reference patches reproduce this frame's arrangement.
+    // (C++ twin, compiled and tested: bepu_host.cpp DiffTypeBatch.)
+    readonly Dictionary<int, int> newIndexOf = new Dictionary<int, int>(), position = new Dictionary<int, int>(), oldIndexOf = new Dictionary<int, int>();
+    readonly List<int> list = new List<int>();
+    void DiffTypeBatch(int batchIndex, ref TypeBatch tb, int bodiesPerConstraint, int prestepFloats, Mirror was)
     {
-        foreach (var op in log)
-        {
-            if (op.Kind == 0)
-            {
-                int index;
-                fixed (int* references = op.References) fixed (float* prestep = op.Prestep)
-                    Check(BepuHip.bepuhip_add_constraint(ctx, op.Batch, op.TypeId, references, prestep, &index));
-                if (index != op.Index) throw new InvalidOperationException("the device's type batch is out of step with the host's");
-            }
-            else if (op.Kind == 1) Check(BepuHip.bepuhip_remove_constraint(ctx, op.Batch, op.TypeId, op.Index));
-            else Check(BepuHip.bepuhip_update_body_reference(ctx, op.Batch, op.TypeId, op.Index, op.Slot, op.Reference));
+        var width = System.Numerics.Vector<int>.Count;
+        var references = (int*)tb.BodyReferences.Memory; var prestep = (uint*)tb.PrestepData.Memory;
+        int Reference(int i, int k) => references[(i / width) * bodiesPerConstraint * width + k * width + i % width];
+        int newCount = tb.ConstraintCount, oldCount = was.Count;
+        bool same = newCount == oldCount;
+        for (int i = 0; same && i < newCount; ++i) same = was.Handles[i] == tb.IndexToHandle[i].Value;
+        if (same)
+        {   // the common case: the same constraints at the same indices; only references can have changed
+            for (int i = 0; i < newCount; ++i)
+                for (int k = 0; k < bodiesPerConstraint; ++k)
+                    if (was.References[i * bodiesPerConstraint + k] != Reference(i, k))
+                        ops.Add(new BepuHipStructuralOp { Kind = 2, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = i, Slot = k, Reference = Reference(i, k) });
+            return;
         }
-        log.Clear();
-        // Updates the plan could not absorb (a new type batch, a body's first or last constraint, exhausted reserves) leave the context on the launch-per-batch
-        // schedule: a fresh plan costs tens of milliseconds once, the slow schedule costs every frame from then on. Not more often than every ReplanInterval frames.
+        newIndexOf.Clear(); position.Clear(); oldIndexOf.Clear(); list.Clear();
+        for (int i = 0; i < newCount; ++i) newIndexOf[tb.IndexToHandle[i].Value] = i;
+        for (int i = 0; i < oldCount; ++i) { list.Add(was.Handles[i]); position[was.Handles[i]] = i; oldIndexOf[was.Handles[i]] = i; }
+        for (int i = oldCount - 1; i >= 0; --i)
+        {   // removals, highest old index first
+            int handle = was.Handles[i];
+            if (newIndexOf.ContainsKey(handle)) continue;
+            int at = position[handle], last = list.Count - 1;
+            ops.Add(new BepuHipStructuralOp { Kind = 1, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = at });
+            if (at != last) { list[at] = list[last]; position[list[at]] = at; }
+            list.RemoveAt(last); position.Remove(handle);
+        }
+        for (int i = 0; i < newCount; ++i)
+        {   // additions, in the order of their final indices: references, then the prestep lane, as raw words
+            int handle = tb.IndexToHandle[i].Value;
+            if (oldIndexOf.ContainsKey(handle)) continue;
+            ops.Add(new BepuHipStructuralOp { Kind = 0, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = list.Count, PayloadOffset = payload.Count });
+            for (int k = 0; k < bodiesPerConstraint; ++k) payload.Add((uint)Reference(i, k));
+            for (int f = 0; f < prestepFloats; ++f) payload.Add(prestep[(i / width) * prestepFloats * width + f * width + i % width]);
+            position[handle] = list.Count; list.Add(handle);
+        }
+        for (int i = 0; i < newCount; ++i)
+        {   // the same set by now: put every index right
+            int handle = tb.IndexToHandle[i].Value;
+            if (list[i] == handle) continue;
+            int j = position[handle];
+            ops.Add(new BepuHipStructuralOp { Kind = 3, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = i, Slot = j });
+            int moved = list[i]; list[i] = list[j]; list[j] = moved;
+            position[list[i]] = i; position[list[j]] = j;
+        }
+        for (int i = 0; i < newCount; ++i)
+        {   // survivors whose bodies moved in memory
+            if (!oldIndexOf.TryGetValue(tb.IndexToHandle[i].Value, out var old)) continue;
+            for (int k = 0; k < bodiesPerConstraint; ++k)
+                if (was.References[old * bodiesPerConstraint + k] != Reference(i, k))
+                    ops.Add(new BepuHipStructuralOp { Kind = 2, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = i, Slot = k, Reference = Reference(i, k) });
+        }
+    }
+
+    // Everything that changed in the solver's type batches since the last frame, in ONE call. Returns false when an upload is the better answer.
+    static readonly Mirror Nothing = new Mirror();
+    bool DiffAndApply(Simulation simulation, out bool referencesChanged)
+    {
+        var solver = simulation.Solver; ref var activeSet = ref solver.ActiveSet;
+        ops.Clear(); payload.Clear(); referencesChanged = false;
+        foreach (var m in mirrors.Values) m.Seen = false;
+        for (int b = 0; b < activeSet.Batches.Count; ++b)
+        {
+            ref var batch = ref activeSet.Batches[b];
+            for (int t = 0; t < batch.TypeBatches.Count; ++t)
+            {
+                ref var tb = ref batch.TypeBatches[t];
+                var processor = solver.TypeProcessors[tb.TypeId];
+                mirrors.TryGetValue(Key(b, tb.TypeId), out var was);
+                DiffTypeBatch(b, ref tb, processor.BodiesPerConstraint, PrestepFloats(tb.TypeId), was ?? Nothing);
+            }
+        }
+        foreach (var kv in mirrors)   // a type batch that no longer exists (ConstraintBatch.RemoveTypeBatchIfEmpty): its constraints went
+            if (!kv.Value.Seen && kv.Value.Count > 0)
+                for (int i = kv.Value.Count - 1; i >= 0; --i) ops.Add(new BepuHipStructuralOp { Kind = 1, BatchIndex = (int)(kv.Key >> 32), TypeId = (int)(uint)kv.Key, Index = i });
+        if (ops.Count > ReplayLimit) return false;
+        foreach (var op in ops) referencesChanged |= op.Kind == 2;
+        if (ops.Count > 0)
+        {
+            if (payload.Count == 0) payload.Add(0);
+            int failed;
+            fixed (BepuHipStructuralOp* table = System.Runtime.InteropServices.CollectionsMarshal.AsSpan(ops)) fixed (uint* words = System.Runtime.InteropServices.CollectionsMarshal.AsSpan(payload))
+                Check(BepuHip.bepuhip_apply_structural_ops(ctx, table, ops.Count, words, payload.Count, &failed));
+        }
+        // the device holds this frame's type batches now
+        var stale = new List<long>();
+        foreach (var kv in mirrors) if (!kv.Value.Seen) stale.Add(kv.Key);
+        foreach (var key in stale) mirrors.Remove(key);
+        for (int b = 0; b < activeSet.Batches.Count; ++b)
+        {
+            ref var batch = ref activeSet.Batches[b];
+            for (int t = 0; t < batch.TypeBatches.Count; ++t) { ref var tb = ref batch.TypeBatches[t]; Remember(b, ref tb, solver.TypeProcessors[tb.TypeId].BodiesPerConstraint); }
+        }
+        // Updates the plan could not absorb (a new type batch, exhausted reserves) leave the context on the launch-per-batch schedule: a fresh plan costs tens of
+        // milliseconds once, the slow schedule costs every frame from then on. Not more often than every ReplanInterval frames.
         int schedule;
         Check(BepuHip.bepuhip_get_schedule(ctx, &schedule));
         if (schedule == 0 && framesSinceReplan >= ReplanInterval) { Check(BepuHip.bepuhip_replan(ctx)); framesSinceReplan = 0; }
         else ++framesSinceReplan;
+        return true;
     }
 
     // What the narrow phase rewrote in place for persisting pairs since the last solve (NarrowPhaseConstraintUpdate.cs:147-207): prestep data and redistributed impulses
@@ -256,16 +359,13 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipStructureList
     {
         var bodies = simulation.Bodies; var solver = simulation.Solver;
         ref var activeBodies = ref bodies.ActiveSet; ref var activeSet = ref solver.ActiveSet;
-        if (solver.StructureListener != this) { solver.StructureListener = this; resident = false; }   // (the maintainer's field, see IHipStructureListener)
-        if (!resident || log.Count > ReplayLimit) Upload(simulation);
+        bool referencesChanged = false;
+        if (!resident || !DiffAndApply(simulation, out referencesChanged)) Upload(simulation);
         else
         {
-            // Bodies.Add / RemoveAt since the last frame (a count that changed, or the reference patches of a body that moved into a freed slot): the host's array is
-            // current for every body (last frame's read-back) and authoritative for the new ones — sent whole, before the constraints that reference it
-            bool bodiesChanged = activeBodies.Count != residentBodyCount;
-            foreach (var op in log) bodiesChanged |= op.Kind == 2;
-            Replay();
-            if (bodiesChanged)
+            // Bodies: the host's array is authoritative — user writes (velocities, ApplyImpulse, teleports, inertia), Bodies.Add / RemoveAt (a count that changed, a body
+            // that moved into a freed index: the reference patches above). Sent whole before the solve unless the host vouches that it never writes body state.
+            if (ResendBodiesEveryFrame || activeBodies.Count != residentBodyCount || referencesChanged)
             {
                 Register(activeBodies.DynamicsState.Memory, (long)activeBodies.DynamicsState.Length * sizeof(BodyDynamics));
                 Check(BepuHip.bepuhip_set_bodies(ctx, activeBodies.DynamicsState.Memory, activeBodies.Count));

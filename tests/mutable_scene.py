@@ -19,6 +19,7 @@ class MutableSolver:
         self.batch_handles: List[Dict[int, int]] = []     # batchReferencedHandles: dynamic body -> 1
         self.kinematic_constrained: List[int] = []       # Solver.ConstrainedKinematicHandles (Solver.cs:68): kinematic bodies with at least one constraint
         self.kinematic_uses: Dict[int, int] = {}
+        self.next_handle = 0                               # constraint handles (Solver.HandlePool): stable for a constraint's life, TypeBatch.IndexToHandle lists them by index
 
     def is_kinematic(self, body: int) -> bool:
         return not np.any(self.bodies[body, 16:23])
@@ -46,11 +47,13 @@ class MutableSolver:
                 continue
             tb = self.batches[bi].get(type_id)
             if tb is None:
-                tb = self.batches[bi][type_id] = {"refs": [], "prestep": [], "acc": []}
+                tb = self.batches[bi][type_id] = {"refs": [], "prestep": [], "acc": [], "handles": []}
                 self.type_order[bi].append(type_id)
             tb["refs"].append(encoded)
             tb["prestep"].append(np.asarray(prestep_lane, dtype=np.float32).copy())
             tb["acc"].append(np.zeros(imf, dtype=np.float32))
+            tb["handles"].append(self.next_handle)
+            self.next_handle += 1
             for h in blocking:
                 self.batch_handles[bi][h] = 1
             return bi, len(tb["refs"]) - 1, encoded
@@ -70,10 +73,26 @@ class MutableSolver:
                     self.kinematic_constrained.pop()
         last = len(tb["refs"]) - 1
         if index < last:
-            for key in ("refs", "prestep", "acc"):
+            for key in ("refs", "prestep", "acc", "handles"):
                 tb[key][index] = tb[key][last]
-        for key in ("refs", "prestep", "acc"):
+        for key in ("refs", "prestep", "acc", "handles"):
             tb[key].pop()
+
+    def swap(self, batch_index: int, type_id: int, a: int, b: int):
+        """Two constraints of a type batch change places (bepuhip_swap_constraints; the reference has no such call)."""
+        tb = self.batches[batch_index][type_id]
+        for key in ("refs", "prestep", "acc", "handles"):
+            tb[key][a], tb[key][b] = tb[key][b], tb[key][a]
+
+    def snapshot(self) -> Dict[Tuple[int, int], Tuple[np.ndarray, np.ndarray]]:
+        """What a diffing host keeps from one frame to the next: per (batch, type id) the handles by index and the encoded references by index."""
+        out = {}
+        for bi, b in enumerate(self.batches):
+            for t in self.type_order[bi]:
+                d = b[t]
+                nb = TYPE_TABLE[t][0]
+                out[(bi, t)] = (np.asarray(d["handles"], dtype=np.int32).copy(), np.asarray(d["refs"], dtype=np.int32).reshape(len(d["refs"]), nb).copy())
+        return out
 
     def remove_body(self, index: int) -> List[Tuple[int, int, int, int, int]]:
         """Bodies.RemoveAt (BepuPhysics/BodySet.cs:83-110) of a body without constraints: the last body takes its slot, and every constraint that referenced the last

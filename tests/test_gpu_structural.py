@@ -7,7 +7,7 @@ import pytest
 import oracle_ffi
 import parity_util as pu
 import small_scenes
-from bepuphysics2_amd.scene import PoseIntegratorCallbacks, SolveDescription
+from bepuphysics2_amd.scene import TYPE_TABLE, PoseIntegratorCallbacks, SolveDescription
 from mutable_scene import MutableSolver
 
 pytestmark = pytest.mark.gpu
@@ -330,14 +330,18 @@ def test_structural_updates_after_frames_on_the_split_island_plan(hip_solver_fac
         assert solver.cluster_cycles().size > 1, "structural updates with reserved slots must keep the split-island plan"
 
 
-def test_cpp_simulation_adds_and_removes_between_timesteps(hip_solver_factory):
-    """The C++ mirror end to end: Simulation + Solver.Add / Solver.Remove between Timestep calls, HipTimestepper replaying the solver's structural log through
-    bepuhip_add_constraint / remove_constraint instead of re-uploading. Ragdolls in a tube: every frame a few contacts of every ragdoll-vs-tube manifold type are
-    removed and contacts of the same bodies come back (the narrow phase's refresh); each frame's result equals the oracle's solve of that frame's export."""
+@pytest.mark.parametrize("mode", [0, 1])
+def test_cpp_simulation_adds_and_removes_between_timesteps(hip_solver_factory, mode):
+    """The C++ mirror end to end: Simulation + Solver.Add / Solver.Remove between Timestep calls, HipTimestepper bringing the device up to date without a re-upload —
+    mode 0 by replaying the solver's structural log (what a listener inside the reference would record) through bepuhip_add_constraint / remove_constraint, mode 1 by
+    diffing the type batches' handles and references against last frame's copy (public API only: TypeBatch.IndexToHandle, TypeBatch.cs:16) and sending the frame's
+    changes in ONE bepuhip_apply_structural_ops call. Ragdolls in a tube: every frame a few contacts of every ragdoll-vs-tube manifold type are removed and
+    contacts of the same bodies come back (the narrow phase's refresh); each frame's result equals the oracle's solve of that frame's export."""
     from bepuphysics2_amd.hostlib import HostSimulation
     sim = HostSimulation.scene("ragdoll_tube", 80, 1, 0, 9)
     sd, cb = sim.solve_description(), PoseIntegratorCallbacks()
     sim.attach_hip_timestepper(0)
+    sim.timestepper_mode(mode)
     rng = np.random.default_rng(4)
     contact_ids = {t for t, info in small_scenes.TYPE_TABLE.items() if info[3].startswith("Contact") and "Nonconvex" not in info[3]}
     for frame in range(12):
@@ -616,3 +620,117 @@ def test_bodies_join_and_leave_the_plan_with_their_first_and_last_constraint(hip
     frames(2)
     add(free, connected - 1)                   # and one of them comes back
     frames(2)
+
+
+def _diff_ops(before, ms):
+    """The operations that bring a device holding `before` (MutableSolver.snapshot) to the solver's present state: hostlib.diff_type_batch per type batch (the C++ twin of
+    the C# shim's diff), concatenated into one table for bepuhip_apply_structural_ops."""
+    from bepuphysics2_amd import hostlib
+    scene = ms.to_scene()
+    tables, payloads, words = [], [], 0
+    seen = set()
+    for bi, tbs in enumerate(scene.batches):
+        for tb, t in zip(tbs, ms.type_order[bi]):
+            seen.add((bi, t))
+            nb, pf, _imf, _ = TYPE_TABLE[t]
+            old_handles, old_refs = before.get((bi, t), (np.zeros(0, np.int32), np.zeros((0, nb), np.int32)))
+            handles = np.asarray(ms.batches[bi][t]["handles"], dtype=np.int32)
+            if tb.count == 0 and old_handles.size == 0:
+                continue
+            refs = tb.body_refs if tb.count else np.zeros(nb * 8, np.int32)
+            pre = tb.prestep if tb.count else np.zeros(pf * 8, np.float32)
+            ops, payload = hostlib.diff_type_batch(bi, t, nb, pf, old_handles, old_refs, handles, refs, pre)
+            if ops.shape[0]:
+                ops[ops[:, 0] == 0, 6] += words
+                used = int(np.count_nonzero(ops[:, 0] == 0)) * (nb + pf)
+                tables.append(ops); payloads.append(payload[:used]); words += used
+    for (bi, t), (old_handles, _) in before.items():
+        assert (bi, t) in seen or old_handles.size == 0
+    table = np.concatenate(tables) if tables else np.zeros((0, 8), np.int32)
+    payload = np.concatenate(payloads) if payloads and words else np.zeros(1, np.uint32)
+    return table, payload
+
+
+@pytest.mark.parametrize("layout", ["whole_islands", "split_plan", "launch_per_batch"])
+def test_a_frames_changes_reconstructed_from_the_type_batches_and_sent_in_one_call(hip_solver_factory, monkeypatch, layout):
+    """the device is kept up to date by ONE bepuhip_apply_structural_ops call per frame whose operations are not recorded but RECONSTRUCTED — the
+    diff of every type batch's constraint handles and body references against last frame's copy (what integration/csharp/HipTimestepper.cs does on the unpatched
+    reference). Frames of contact churn, of survivors rearranged (the reference removed in another order than the diff assumes: swaps), of a body removal (the last body
+    moves into the freed index: reference patches); every frame equal to the oracle solving the host mirror."""
+    rng = np.random.default_rng(23)
+    if layout == "split_plan":
+        monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "12")
+        nb, nc = 2400, 7000
+    else:
+        nb, nc = 260, 700
+    rows = [small_scenes.random_dynamic_body(rng, rng.uniform(-6, 6, 3)) if i % 19 else small_scenes.kinematic_body(rng, rng.uniform(-6, 6, 3)) for i in range(nb)]
+    ms = MutableSolver(np.stack(rows))
+    types = [4, 5, 6, 7, 22, 25, 47, 0, 3]
+
+    def add_random():
+        t = types[int(rng.integers(len(types)))]
+        one_body = TYPE_TABLE[t][0] == 1
+        while True:
+            a, b = (int(x) for x in rng.choice(ms.bodies.shape[0], 2, replace=False))
+            if one_body and not ms.is_kinematic(a):
+                bodies = [a]
+                break
+            if not one_body and not (ms.is_kinematic(a) and ms.is_kinematic(b)):
+                bodies = [a, b]
+                break
+        ms.add(t, bodies, small_scenes.prestep_for(rng, t, ms.bodies[bodies[0], 4:7], ms.bodies[bodies[-1], 4:7]))
+
+    if layout == "split_plan":  # neighbours only: one big island with a sensible cut
+        for i in range(nc):
+            a = int(rng.integers(nb - 12))
+            b = a + int(rng.integers(1, 12))
+            if ms.is_kinematic(a) and ms.is_kinematic(b):
+                continue
+            t = [4, 5, 6, 7, 22, 25, 47][int(rng.integers(7))]
+            ms.add(t, [a, b], small_scenes.prestep_for(rng, t, ms.bodies[a, 4:7], ms.bodies[b, 4:7]))
+    else:
+        for _ in range(nc):
+            add_random()
+    sd, cb = SolveDescription(2, 3), PoseIntegratorCallbacks()
+    solver = hip_solver_factory(use_clusters=layout != "launch_per_batch", reserve_update_slots=True)
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+    sent = 0
+    for frame in range(8):
+        before = ms.snapshot()
+        for _ in range(int(rng.integers(4, 14))):
+            locs = ms.locations()
+            bi, t, i = locs[int(rng.integers(len(locs)))]
+            ms.remove(bi, t, i)
+        if layout != "split_plan":
+            for _ in range(int(rng.integers(4, 14))):
+                add_random()
+        for _ in range(3):  # survivors in another arrangement than remove-then-append leaves them in
+            locs = ms.locations()
+            bi, t, i = locs[int(rng.integers(len(locs)))]
+            n = len(ms.batches[bi][t]["refs"])
+            if n > 1:
+                ms.swap(bi, t, i, int(rng.integers(n)))
+        bodies_changed = False
+        if frame in (3, 6):  # Bodies.RemoveAt: a body loses its constraints, the last body takes its index
+            victim = int(rng.integers(ms.bodies.shape[0] - 1))
+            for bi, t, i in sorted((loc for loc in ms.locations() if any((int(r) & 0x3FFFFFFF) == victim for r in ms.batches[loc[0]][loc[1]]["refs"][loc[2]])), reverse=True):
+                ms.remove(bi, t, i)
+            ms.remove_body(victim)
+            bodies_changed = True
+        table, payload = _diff_ops(before, ms)
+        sent += table.shape[0]
+        solver.apply_structural_op_table(table, payload)
+        if bodies_changed:
+            solver.set_bodies(ms.bodies)
+        export = ms.to_scene()
+        solver.set_constrained_kinematics(export.constrained_kinematic_indices())
+        oracle_ffi.solve(export, 1 / 60, sd, cb, threads=4)
+        ms.absorb(export)
+        solver.solve(1 / 60, sd, cb)
+        got = ms.to_scene()
+        solver.download(got)
+        m = pu.compare_scenes(export, got)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (layout, frame, m)
+    assert sent > 100
+    if layout == "launch_per_batch":
+        assert solver.schedule() == 0
