@@ -302,7 +302,7 @@ __device__ __forceinline__ void final_integrate_body(float4* bodies, unsigned bo
     float4 i0 = make_float4(0, 0, 0, 0), i1 = i0;
     if (!(body_flags & kFlagConstrained)) { i0 = base[4]; i1 = base[5]; }
     BodyRegs b = {{q4.x, q4.y, q4.z, q4.w}, {p4.x, p4.y, p4.z}, {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}}};
-    if (final_integrate_regs(b, body_flags, i0, i1, dt, substep_dt, substep_count, allow_substeps_for_unconstrained, integrate_velocity_for_kinematics, sp)) {
+    if (final_integrate_regs(b, body_flags, i0, i1, dt, substep_dt, substep_count, allow_substeps_for_unconstrained, integrate_velocity_for_kinematics, sp, i)) {
         base[2] = make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, l4.w);
         base[3] = make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, a4.w);
     }

@@ -177,19 +177,10 @@ __device__ __forceinline__ unsigned claim_next(lds_u32* counter) {
     return (unsigned)__builtin_amdgcn_readfirstlane((int)ret);
 }
 // The wave's LDS velocity stores must have landed before the flag does: LDS executes a wave's instructions in order, the explicit
-// wait makes that independent of the pipeline's internals.
+// wait makes that independent of the pipeline's internals. (Round 4 measured the publish WITHOUT the wait, same box, two runs each: 0.1589 / 0.1596 ms with it,
+// 0.1592 / 0.1593 without on the bench scene, 0.4177 / 0.4167 on the pile — nothing to gain; profiles/r04_s6_ab_publish_nowait.txt.)
 __device__ __forceinline__ void publish_item(volatile lds_u32* flag, unsigned epoch) {
     unsigned long long saved;
-#ifdef BEPU_EXPERIMENT_PUBLISH_NOWAIT  // (measured in round 4, tools/experiments/variants: the LDS runs a wave's instructions in order, so the flag cannot overtake the stores)
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, 1\n\t"
-        "ds_write_b32 %[fa], %[e]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [sv] "=&s"(saved)
-        : [fa] "v"(lds_address(flag)), [e] "v"(epoch)
-        : "memory");
-#else
     asm volatile(
         "s_waitcnt lgkmcnt(0)\n\t"
         "s_mov_b64 %[sv], exec\n\t"
@@ -199,7 +190,6 @@ __device__ __forceinline__ void publish_item(volatile lds_u32* flag, unsigned ep
         : [sv] "=&s"(saved)
         : [fa] "v"(lds_address(flag)), [e] "v"(epoch)
         : "memory");
-#endif
 }
 
 // Every spin is bounded: a wait that runs out of patience (~0.1 s) records itself in the status words and lets the wave continue, so a
@@ -905,7 +895,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                     }
                 }
                 if (!ghost) {
-                    velocity_callback(cp.sp, vel);
+                    velocity_callback(cp.sp, vel, pos, body);
                     r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
                     r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
                 }
@@ -914,7 +904,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                     store_agent_pair(shared_record(shared_tables, body, (unsigned)s), make_float4(vel.lin.x, vel.lin.y, vel.lin.z, number), make_float4(vel.ang.x, vel.ang.y, vel.ang.z, number));
                 }
             } else if (cp.integrate_velocity_for_kinematics) {  // kinematic: private copy, same arithmetic as the global kinematic pass
-                velocity_callback(cp.sp, vel);
+                velocity_callback(cp.sp, vel, pos, body);
                 r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
                 r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
             }

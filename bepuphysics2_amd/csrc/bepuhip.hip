@@ -120,6 +120,7 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_flags) hipFree(c->d_flags);
     if (c->d_kin) hipFree(c->d_kin);
     if (c->d_status) hipHostFree(c->d_status);
+    if (c->d_body_gravity) hipFree(c->d_body_gravity);
     if (c->d_staged) hipFree(c->d_staged);
     if (c->d_collidables) hipFree(c->d_collidables);
     if (c->d_hull_points) hipFree(c->d_hull_points);
@@ -717,9 +718,14 @@ struct Timed {
     }
 };
 
-static StepParams make_params(const bepuhip_integrator* in, float dt_for_callbacks, float dt, float inv_dt) {
+static StepParams make_params(const bepuhip_ctx* c, const bepuhip_integrator* in, float dt_for_callbacks, float dt, float inv_dt) {
     // DemoPoseIntegratorCallbacks.PrepareForIntegration (Demos/DemoCallbacks.cs:79-86)
     StepParams sp;
+    sp.velocity_model = c->velocity_model.model;  // bepuhip_set_velocity_model: which IntegrateVelocity the device evaluates
+    sp.callback_dt = dt_for_callbacks;
+    sp.cx = c->velocity_model.center[0]; sp.cy = c->velocity_model.center[1]; sp.cz = c->velocity_model.center[2];
+    sp.radial = dt_for_callbacks * c->velocity_model.gravity;  // PlanetDemo.cs:39: gravityDt = dt * Gravity
+    sp.body_gravity = c->d_body_gravity;
     float l = 1 - in->linear_damping, a = 1 - in->angular_damping;
     l = l < 0 ? 0 : (l > 1 ? 1 : l);
     a = a < 0 ? 0 : (a > 1 ? 1 : a);
@@ -936,7 +942,7 @@ static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const be
 static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t* iterations, const bepuhip_integrator* in) {
     const float substep_dt = dt / substeps;          // Solver_Solve.cs:1417
     const float inv_dt = 1.0f / substep_dt;          // :1421
-    const StepParams sp = make_params(in, substep_dt, substep_dt, inv_dt);
+    const StepParams sp = make_params(c, in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
     const size_t lds_bytes = cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared);
     const bool use_clusters = island_schedule_applies(c, substeps, in);
@@ -967,7 +973,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             tp.dt = dt; tp.substep_dt = substep_dt; tp.substep_count = substeps;
             tp.allow_substeps_for_unconstrained = in->allow_substeps_for_unconstrained; tp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
             const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
-            tp.final_sp = make_params(in, vdt, vdt, 1.0f / vdt);
+            tp.final_sp = make_params(c, in, vdt, vdt, 1.0f / vdt);
             SharedTables st = {c->d_shared_vel, c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1), 0u};
             if (c->clusters_shared) {
                 // Event numbers of this step: [base, base + span). A body sees at most substeps + 255 x passes events per step; the span is kept even (record parity).
@@ -1046,7 +1052,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
     }
     if (body_blocks > 0 && !use_clusters) {           // PoseIntegrator.cs:707-726 (the island schedule's launch includes it)
         const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
-        const StepParams fsp = make_params(in, vdt, vdt, 1.0f / vdt);
+        const StepParams fsp = make_params(c, in, vdt, vdt, 1.0f / vdt);
         Timed t(c, 4);
         hipLaunchKernelGGL(final_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, dt, substep_dt, substeps,
                            in->allow_substeps_for_unconstrained, in->integrate_velocity_for_kinematics, skip_clustered, fsp);
@@ -1083,6 +1089,8 @@ static int32_t validate_solve(bepuhip_ctx* c, float dt, int32_t substeps, const 
         if (iterations[s] < 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Velocity iteration count must be positive.");
     if (in->angular_integration_mode < 0 || in->angular_integration_mode > 2) return fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown AngularIntegrationMode");
     if (c->building) return fail(BEPUHIP_E_STATE, "solve between begin_constraints and end_constraints");
+    if (c->velocity_model.model == BEPUHIP_VELOCITY_PER_BODY_GRAVITY && c->body_gravity_count < c->body_count)
+        return fail(BEPUHIP_E_STATE, "the per-body gravity table holds " + std::to_string(c->body_gravity_count) + " values for " + std::to_string(c->body_count) + " bodies (set_velocity_model)");
     if (c->built && c->referenced_bodies > c->body_count) {
         const int32_t st = recount_referenced_bodies(c);
         if (st != BEPUHIP_OK) return st;
@@ -1463,7 +1471,7 @@ static int32_t run_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const i
     c->last_constraint_iterations = iters;
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
     const float substep_dt = dt / substeps, inv_dt = 1.0f / substep_dt;
-    const StepParams sp = make_params(in, substep_dt, substep_dt, inv_dt);
+    const StepParams sp = make_params(c, in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
     const bool per_batch = c->exchange_mode == BEPUHIP_EXCHANGE_PER_BATCH_EXACT;
     auto exchange = [&](int s, int pass, int launch) -> int32_t {
@@ -1506,7 +1514,7 @@ static int32_t run_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const i
     }
     if (body_blocks > 0) {
         const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
-        const StepParams fsp = make_params(in, vdt, vdt, 1.0f / vdt);
+        const StepParams fsp = make_params(c, in, vdt, vdt, 1.0f / vdt);
         hipLaunchKernelGGL(final_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, dt, substep_dt, substeps,
                            in->allow_substeps_for_unconstrained, in->integrate_velocity_for_kinematics, 0, fsp);
     }
@@ -1959,6 +1967,28 @@ int32_t bepuhip_apply_structural_ops(bepuhip_ctx* c, const bepuhip_structural_op
     return BEPUHIP_OK;
 }
 
+// IPoseIntegratorCallbacks.IntegrateVelocity as data (include/bepuhip.h): the model stays with the context until the next call.
+int32_t bepuhip_set_velocity_model(bepuhip_ctx* c, const bepuhip_velocity_model* model, const float* per_body_gravity, int32_t body_count) {
+    if (!c || !model) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    if (model->model < 0 || model->model > BEPUHIP_VELOCITY_RADIAL_GRAVITY) return fail(BEPUHIP_E_UNSUPPORTED, "unknown velocity model " + std::to_string(model->model) + ": keep simulation.Solve for arbitrary IntegrateVelocity code");
+    if (model->model == BEPUHIP_VELOCITY_PER_BODY_GRAVITY && (!per_body_gravity || body_count <= 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "the per-body gravity model needs one value per body");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (model->model == BEPUHIP_VELOCITY_PER_BODY_GRAVITY) {
+        if (body_count > c->body_gravity_capacity) {
+            if (c->d_body_gravity) hipFree(c->d_body_gravity);
+            c->d_body_gravity = nullptr; c->body_gravity_capacity = 0;
+            HIP_TRY(hipMalloc((void**)&c->d_body_gravity, (size_t)body_count * 4));
+            c->body_gravity_capacity = body_count;
+        }
+        HIP_TRY(hipMemcpy(c->d_body_gravity, per_body_gravity, (size_t)body_count * 4, hipMemcpyHostToDevice));
+        c->body_gravity_count = body_count;
+    }
+    c->velocity_model = *model;
+    clear_graphs(c);  // captured launch sequences carry the model in their kernel arguments
+    return BEPUHIP_OK;
+}
+
 // ---- Device-resident incremental updates: ranged rewrites of what already lives in HBM, no re-plan, no full re-upload ----
 static int32_t stage_reserve(bepuhip_ctx* c, size_t floats) {
     if (floats <= c->stage_floats) return BEPUHIP_OK;
@@ -2207,7 +2237,7 @@ int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* c, float dt, const bepuhip_i
     int2* d_heavy_queue = heavy_pass ? (int2*)(c->d_stage + in_floats + out_floats + 4) : nullptr;
     if (heavy_pass) HIP_TRY(hipMemsetAsync(d_heavy_count, 0, 4, c->stream));
     if (!resident) HIP_TRY(hipMemcpyAsync(d_in, collidables, in_floats * 4, hipMemcpyHostToDevice, c->stream));
-    const StepParams sp = make_params(in, dt, dt, 1.0f / dt);  // Callbacks.PrepareForIntegration(dt): the full frame step
+    const StepParams sp = make_params(c, in, dt, dt, 1.0f / dt);  // Callbacks.PrepareForIntegration(dt): the full frame step
     hipLaunchKernelGGL(predict_bounds_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_bodies, count, d_in, resident ? 1 : 0, d_out, dt,
                        in->integrate_velocity_for_kinematics, sp,
                        ShapeTables{HullTable{c->d_hull_points, c->d_hull_begin, c->hull_count}, c->d_compound_children, c->d_compound_begin, c->compound_count, c->d_mesh_triangles,

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
     "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables", "bepuhip_set_convex_hulls", "bepuhip_set_compounds", "bepuhip_set_meshes",
-    "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_swap_constraints", "bepuhip_apply_structural_ops", "bepuhip_get_constraint_count", "bepuhip_get_schedule", "bepuhip_replan",
+    "bepuhip_set_velocity_model", "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_swap_constraints", "bepuhip_apply_structural_ops", "bepuhip_get_constraint_count", "bepuhip_get_schedule", "bepuhip_replan",
     "bepuhip_register_host_memory", "bepuhip_unregister_host_memory", "bepuhip_get_poses_and_velocities", "bepuhip_get_poses_and_velocities_async", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses_async",
 ]
 
@@ -56,6 +56,10 @@ class UnsupportedError(BepuHipError):
 
 class Config(C.Structure):
     _fields_ = [("device_ordinal", C.c_int32), ("bundle_width", C.c_int32), ("flags", C.c_int32)]
+
+
+class VelocityModel(C.Structure):  # bepuhip_velocity_model
+    _fields_ = [("model", C.c_int32), ("center", C.c_float * 3), ("gravity", C.c_float)]
 
 
 class Integrator(C.Structure):
@@ -133,6 +137,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_add_constraint.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
     lib.bepuhip_remove_constraint.argtypes = [vp, i32, i32, i32]
     lib.bepuhip_update_body_reference.argtypes = [vp, i32, i32, i32, i32, i32]
+    lib.bepuhip_set_velocity_model.argtypes = [vp, C.POINTER(VelocityModel), vp, i32]
     lib.bepuhip_swap_constraints.argtypes = [vp, i32, i32, i32, i32]
     lib.bepuhip_apply_structural_ops.argtypes = [vp, vp, i32, vp, i32, C.POINTER(i32)]
     lib.bepuhip_get_constraint_count.argtypes = [vp, i32, i32, C.POINTER(i32)]
@@ -232,7 +237,23 @@ class HipSolver:
         self._scene_meta = [(bi, tb.type_id, tb.count) for bi, b in enumerate(scene.batches) for tb in b]
 
     # ---- solve ----
+    def set_velocity_model(self, callbacks: PoseIntegratorCallbacks):
+        """IntegrateVelocity as data (bepuhip_set_velocity_model): sent when the callbacks' model differs from what the context holds."""
+        table = getattr(callbacks, "body_gravity", None)
+        key = (int(getattr(callbacks, "velocity_model", 0)), tuple(float(x) for x in getattr(callbacks, "planet_center", (0, 0, 0))), float(getattr(callbacks, "planet_gravity", 0.0)),
+               None if table is None else np.ascontiguousarray(table, dtype=np.float32).tobytes())
+        if key == getattr(self, "_velocity_model_key", (0, (0.0, 0.0, 0.0), 0.0, None)):
+            return
+        m = VelocityModel()
+        m.model = key[0]
+        m.center[0], m.center[1], m.center[2] = key[1]
+        m.gravity = key[2]
+        values = None if table is None else np.ascontiguousarray(table, dtype=np.float32)
+        _check(self.lib, self.lib.bepuhip_set_velocity_model(self.ctx, C.byref(m), None if values is None else _ptr(values), 0 if values is None else values.size))
+        self._velocity_model_key = key
+
     def solve(self, dt: float, solve_description: SolveDescription, callbacks: PoseIntegratorCallbacks, asynchronous: bool = False):
+        self.set_velocity_model(callbacks)
         its = np.ascontiguousarray(solve_description.iterations(), dtype=np.int32)
         integ = make_integrator(callbacks)
         fn = self.lib.bepuhip_solve_async if asynchronous else self.lib.bepuhip_solve
@@ -492,6 +513,7 @@ class HipSolver:
 
     def predict_bounding_boxes(self, dt: float, callbacks: PoseIntegratorCallbacks, collidables: Optional[np.ndarray] = None) -> np.ndarray:
         """``collidables``: COLLIDABLE_DTYPE records, one per body index (None: the resident ones). Returns PREDICTED_BOUNDS_DTYPE records (PoseIntegrator.cs:307-370)."""
+        self.set_velocity_model(callbacks)
         integ = make_integrator(callbacks)
         if collidables is None:
             n = getattr(self, "_resident_collidables", 0)

@@ -172,13 +172,19 @@ class SolveDescription:
 
 @dataclass
 class PoseIntegratorCallbacks:
-    """DemoPoseIntegratorCallbacks as data (Demos/DemoCallbacks.cs:20-109)."""
+    """IPoseIntegratorCallbacks as data: the three properties, and IntegrateVelocity as one of the models that cross the C ABI (bepuhip_velocity_model):
+    0 DemoPoseIntegratorCallbacks (Demos/DemoCallbacks.cs:20-109: gravity + damping), 1 PerBodyGravityDemoCallbacks (Demos/Demos/PerBodyGravityDemo.cs:57-88:
+    ``body_gravity[i]`` added to the linear Y velocity of the body at index i), 2 PlanetaryGravityCallbacks (Demos/Demos/PlanetDemo.cs:36-47)."""
     gravity: Sequence[float] = (0.0, -10.0, 0.0)
     linear_damping: float = 0.03
     angular_damping: float = 0.03
     allow_substeps_for_unconstrained_bodies: bool = False
     integrate_velocity_for_kinematics: bool = False
     angular_integration_mode: int = 0  # AngularIntegrationMode: 0 Nonconserving, 1 ConserveMomentum, 2 ConserveMomentumWithGyroscopicTorque (PoseIntegrator.cs:20-38)
+    velocity_model: int = 0
+    planet_center: Sequence[float] = (0.0, 0.0, 0.0)
+    planet_gravity: float = 0.0
+    body_gravity: Optional[np.ndarray] = None
 
 
 def make_body(position=(0, 0, 0), orientation=(0, 0, 0, 1), linear=(0, 0, 0), angular=(0, 0, 0),

@@ -60,9 +60,29 @@ typedef struct bepuhip_integrator {
     int32_t integrate_velocity_for_kinematics;    /* IntegrateVelocityForKinematics */
 } bepuhip_integrator;
 
+/* IPoseIntegratorCallbacks.IntegrateVelocity is arbitrary code (BepuPhysics/PoseIntegrator.cs:91-93) and cannot cross a C ABI; the models the reference's own demos use can,
+ * as data. The model belongs to the context (default: uniform gravity); bepuhip_integrator keeps carrying the callbacks' three properties and, for the uniform model, gravity
+ * and damping. Every stage that calls the callback evaluates the model — the substep integration inside the solve, the kinematic prepass, IntegrateAfterSubstepping and
+ * bepuhip_predict_bounding_boxes — with the reference's position / body-index / dt arguments, bit for bit (tests/test_gpu_velocity_models.py against both oracles).
+ *   UNIFORM_GRAVITY   Demos/DemoCallbacks.cs:100-109         linear = (linear + gravity * dt) * pow(1 - linearDamping, dt); angular *= pow(1 - angularDamping, dt)
+ *   PER_BODY_GRAVITY  Demos/Demos/PerBodyGravityDemo.cs:57-88  linear.Y += gravity[body] * dt; `per_body_gravity[i]` = the value of the body at INDEX i (the demo looks it
+ *                     up by handle: BodyGravities[bodies.ActiveSet.IndexToHandle[i]]); the caller sends the table again when bodies move in memory (Bodies.RemoveAt)
+ *   RADIAL_GRAVITY    Demos/Demos/PlanetDemo.cs:36-47          offset = position - center; linear -= (dt * gravity) * offset / max(1, |offset|^3)
+ * Anything else: UNSUPPORTED (the shim keeps simulation.Solve). Solver.SubstepStarted / SubstepEnded (Solver.cs:131-146) are not raised by the device path. */
+#define BEPUHIP_VELOCITY_UNIFORM_GRAVITY 0
+#define BEPUHIP_VELOCITY_PER_BODY_GRAVITY 1
+#define BEPUHIP_VELOCITY_RADIAL_GRAVITY 2
+typedef struct bepuhip_velocity_model {
+    int32_t model;
+    float center[3]; /* RADIAL_GRAVITY: PlanetCenter */
+    float gravity;   /* RADIAL_GRAVITY: Gravity */
+} bepuhip_velocity_model;
+
 const char* bepuhip_last_error(void);
 int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx);
 int32_t bepuhip_destroy(bepuhip_ctx* ctx);
+/* per_body_gravity: `body_count` floats for PER_BODY_GRAVITY (copied), ignored otherwise. */
+int32_t bepuhip_set_velocity_model(bepuhip_ctx* ctx, const bepuhip_velocity_model* model, const float* per_body_gravity, int32_t body_count);
 
 /* Replaces nothing in the reference by itself: mirrors Bodies.ActiveSet.DynamicsState (BepuPhysics/BodySet.cs:41),
  * `count` BodyDynamics structs, 128-byte stride (BepuPhysics/BodyProperties.cs:318-338). */

@@ -25,6 +25,9 @@ unsafe struct BepuHipIntegrator
 }
 
 [StructLayout(LayoutKind.Sequential)]
+unsafe struct BepuHipVelocityModel { public int Model; public fixed float Center[3]; public float Gravity; }   // bepuhip_velocity_model: 0 uniform, 1 per body, 2 radial
+
+[StructLayout(LayoutKind.Sequential)]
 struct BepuHipStructuralOp { public int Kind, BatchIndex, TypeId, Index, Slot, Reference, PayloadOffset, Reserved; }   // bepuhip_structural_op: 0 add, 1 remove, 2 update reference, 3 swap
 
 [StructLayout(LayoutKind.Sequential)]
@@ -47,6 +50,7 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern IntPtr bepuhip_last_error();
     [DllImport(Lib)] public static extern int bepuhip_create(BepuHipConfig* config, IntPtr* outCtx);
     [DllImport(Lib)] public static extern int bepuhip_destroy(IntPtr ctx);
+    [DllImport(Lib)] public static extern int bepuhip_set_velocity_model(IntPtr ctx, BepuHipVelocityModel* model, float* perBodyGravity, int bodyCount);
     [DllImport(Lib)] public static extern int bepuhip_set_bodies(IntPtr ctx, void* bodyDynamicsAos, int count);
     [DllImport(Lib)] public static extern int bepuhip_begin_constraints(IntPtr ctx, int batchCount, int fallbackBatchThreshold);
     [DllImport(Lib)] public static extern int bepuhip_set_type_batch(IntPtr ctx, int batchIndex, int typeId, int constraintCount, int* bodyReferencesAosoa, float* prestepAosoa, float* accumulatedImpulsesAosoa);
@@ -110,12 +114,17 @@ static unsafe class BepuHip
     // ---- end of the generated block ----
 }
 
-/// What the device needs to know about a velocity callback: IPoseIntegratorCallbacks.IntegrateVelocity is arbitrary code and cannot cross a C ABI, so the
-/// callback struct states the model it implements. Any IPoseIntegratorCallbacks whose IntegrateVelocity is "velocity += gravity * dt, then exponential
-/// damping" (Demos/DemoCallbacks.cs:100-109 is one) implements this by returning its fields; anything else leaves the interface off and the shim uses simulation.Solve.
+/// What the device needs to know about a velocity callback: IPoseIntegratorCallbacks.IntegrateVelocity is arbitrary code and cannot cross a C ABI, so the callback
+/// struct states which of the library's models it implements (bepuhip_velocity_model) by carrying one of these interfaces — its fields become the getters:
+///   IHipVelocityModel        "velocity += gravity * dt, then exponential damping": Demos/DemoCallbacks.cs:100-109
+///   IHipPerBodyGravityModel  "velocity.Linear.Y += BodyGravities[handle] * dt":    Demos/Demos/PerBodyGravityDemo.cs:57-88
+///   IHipRadialGravityModel   "velocity.Linear -= dt * Gravity * offset / max(1, |offset|^3)": Demos/Demos/PlanetDemo.cs:36-47
+/// A callback struct with none of them keeps simulation.Solve (the shim falls back), as does a host that subscribes to Solver.SubstepStarted / SubstepEnded.
 public interface IHipVelocityModel { System.Numerics.Vector3 Gravity { get; } float LinearDamping { get; } float AngularDamping { get; } }
+public interface IHipPerBodyGravityModel { CollidableProperty<float> BodyGravities { get; } }
+public interface IHipRadialGravityModel { System.Numerics.Vector3 PlanetCenter { get; } float Gravity { get; } }
 
-public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IDisposable where TCallbacks : struct, IPoseIntegratorCallbacks, IHipVelocityModel
+public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IDisposable where TCallbacks : struct, IPoseIntegratorCallbacks
 {
     IntPtr ctx;
     bool resident;                                    // the device holds the scene as of the last solve
@@ -133,6 +142,7 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IDisposable where
     /// between frames may turn it off; bodies are then sent when the body count changed or a body moved in memory.
     public bool ResendBodiesEveryFrame = true;
     int residentBodyCount;
+    int sentModel; System.Numerics.Vector3 sentCenter; float sentGravity; float[] gravities = Array.Empty<float>();   // the velocity model the context holds
     int framesSinceReplan = 30;
     readonly Dictionary<IntPtr, long> registered = new Dictionary<IntPtr, long>();
     public int ReplayLimit = 262144;                  // more operations than this in one frame are not cheaper than an upload
@@ -160,7 +170,7 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IDisposable where
         BeforeCollisionDetection?.Invoke(dt, threadDispatcher);
         simulation.CollisionDetection(dt, threadDispatcher);              // :36
         CollisionsDetected?.Invoke(dt, threadDispatcher);
-        try { SolveOnDevice(simulation, dt); }                            // replaces simulation.Solve(dt, threadDispatcher) (:39)
+        try { SolveOnDevice(simulation, dt); }                            // replaces simulation.Solve(dt, threadDispatcher) (:39); NotSupportedException is thrown before anything is enqueued
         catch (NotSupportedException) { resident = false; simulation.Solve(dt, threadDispatcher); }
         ConstraintsSolved?.Invoke(dt, threadDispatcher);
         simulation.IncrementallyOptimizeDataStructures(threadDispatcher); // :42
@@ -381,12 +391,33 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IDisposable where
 
         var iterations = stackalloc int[solver.SubstepCount];
         for (int s = 0; s < solver.SubstepCount; ++s) iterations[s] = GetVelocityIterationCountForSubstepIndex(solver, s); // Solver_Solve.cs:743-751
-        var callbacks = ((PoseIntegrator<TCallbacks>)simulation.PoseIntegrator).Callbacks;  // the three IPoseIntegratorCallbacks properties (PoseIntegrator.cs:42-94) + IHipVelocityModel
-        var integ = new BepuHipIntegrator { LinearDamping = callbacks.LinearDamping, AngularDamping = callbacks.AngularDamping,
-            AngularIntegrationMode = (int)callbacks.AngularIntegrationMode,
+        var callbacks = ((PoseIntegrator<TCallbacks>)simulation.PoseIntegrator).Callbacks;  // the three IPoseIntegratorCallbacks properties (PoseIntegrator.cs:42-94) + the model interface
+        var integ = new BepuHipIntegrator { AngularIntegrationMode = (int)callbacks.AngularIntegrationMode,
             AllowSubstepsForUnconstrained = callbacks.AllowSubstepsForUnconstrainedBodies ? 1 : 0,
             IntegrateVelocityForKinematics = callbacks.IntegrateVelocityForKinematics ? 1 : 0 };
-        integ.Gravity[0] = callbacks.Gravity.X; integ.Gravity[1] = callbacks.Gravity.Y; integ.Gravity[2] = callbacks.Gravity.Z;
+        var model = new BepuHipVelocityModel();
+        object boxed = callbacks;
+        if (boxed is IHipVelocityModel uniform)
+        {
+            integ.LinearDamping = uniform.LinearDamping; integ.AngularDamping = uniform.AngularDamping;
+            integ.Gravity[0] = uniform.Gravity.X; integ.Gravity[1] = uniform.Gravity.Y; integ.Gravity[2] = uniform.Gravity.Z;
+            if (sentModel != 0) { Check(BepuHip.bepuhip_set_velocity_model(ctx, &model, null, 0)); sentModel = 0; }
+        }
+        else if (boxed is IHipPerBodyGravityModel perBody)
+        {   // the demo looks a body's value up by handle inside the callback; the device wants it by index: gathered here, once per frame (bodies move in memory)
+            model.Model = 1;
+            if (gravities.Length < activeBodies.Count) gravities = new float[Math.Max(activeBodies.Count, gravities.Length * 2)];
+            for (int i = 0; i < activeBodies.Count; ++i) gravities[i] = perBody.BodyGravities[activeBodies.IndexToHandle[i]];
+            fixed (float* table = gravities) Check(BepuHip.bepuhip_set_velocity_model(ctx, &model, table, activeBodies.Count));
+            sentModel = 1;
+        }
+        else if (boxed is IHipRadialGravityModel radial)
+        {
+            model.Model = 2; model.Center[0] = radial.PlanetCenter.X; model.Center[1] = radial.PlanetCenter.Y; model.Center[2] = radial.PlanetCenter.Z; model.Gravity = radial.Gravity;
+            if (sentModel != 2 || sentCenter != radial.PlanetCenter || sentGravity != radial.Gravity)
+            { Check(BepuHip.bepuhip_set_velocity_model(ctx, &model, null, 0)); sentModel = 2; sentCenter = radial.PlanetCenter; sentGravity = radial.Gravity; }
+        }
+        else throw new NotSupportedException("this IPoseIntegratorCallbacks states no velocity model the device knows (IHipVelocityModel, IHipPerBodyGravityModel, IHipRadialGravityModel)");
         Check(BepuHip.bepuhip_solve_async(ctx, dt, solver.SubstepCount, iterations, &integ));
 
         // Back to the host, behind the solve on the same stream: poses and velocities (the MotionState half of BodyDynamics: what collision detection and the user read),

@@ -58,6 +58,12 @@ struct OracleParams {
     void* exchange_user;
     int32_t angular_integration_mode;  // AngularIntegrationMode (PoseIntegrator.cs:20-38): 0 Nonconserving, 1 ConserveMomentum, 2 ConserveMomentumWithGyroscopicTorque
     int32_t fallback_batch_threshold;  // SolveDescription.FallbackBatchThreshold (SolveDescription.cs:38); 0 = the default 64. Batch index == threshold is the sequential fallback batch.
+    // IPoseIntegratorCallbacks.IntegrateVelocity: 0 = DemoPoseIntegratorCallbacks (Demos/DemoCallbacks.cs:100-109, the fields above), 1 = PerBodyGravityDemoCallbacks
+    // (Demos/Demos/PerBodyGravityDemo.cs:57-88; body_gravity[i] = the value of the body at index i), 2 = PlanetaryGravityCallbacks (Demos/Demos/PlanetDemo.cs:36-47)
+    int32_t velocity_model;
+    float planet_center[3];
+    float planet_gravity;
+    const float* body_gravity;
 };
 struct OracleScene {
     float* bodies;  // AoS BodyDynamics, 32 floats/body (BepuPhysics/BodyProperties.cs:11-46,258-338)
@@ -80,12 +86,20 @@ constexpr int kMaxW = 16;
 constexpr uint32_t kDynamicLimit = 1u << 30;      // Bodies_GatherScatter.cs:107-118
 constexpr int32_t kBodyReferenceMask = 0x3FFFFFFF;
 
-struct Callbacks {  // Demos/DemoCallbacks.cs:79-109
+struct Callbacks {  // Demos/DemoCallbacks.cs:79-109; PerBodyGravityDemo.cs:57-88; PlanetDemo.cs:36-47
     V3 gravityDt;
     float linearDampingDt, angularDampingDt;
     int mode = 0;  // AngularIntegrationMode
+    int model = 0;
+    V3 planetCenter;
+    float planetGravityDt = 0;
+    const float* bodyGravity = nullptr;
     void prepare(const OracleParams& p, float dt) {
         mode = p.angular_integration_mode;
+        model = p.velocity_model;
+        planetCenter = {p.planet_center[0], p.planet_center[1], p.planet_center[2]};
+        planetGravityDt = dt * p.planet_gravity;  // PlanetDemo.cs:39
+        bodyGravity = p.body_gravity;
         float l = 1 - p.linear_damping, a = 1 - p.angular_damping;
         l = l < 0 ? 0 : (l > 1 ? 1 : l);
         a = a < 0 ? 0 : (a > 1 ? 1 : a);
@@ -93,9 +107,22 @@ struct Callbacks {  // Demos/DemoCallbacks.cs:79-109
         angularDampingDt = powf(a, dt);
         gravityDt = {p.gravity[0] * dt, p.gravity[1] * dt, p.gravity[2] * dt};
     }
-    void integrateVelocity(BodyVel& v) const {
-        v.lin = scale(add(v.lin, gravityDt), linearDampingDt);
-        v.ang = scale(v.ang, angularDampingDt);
+    // IntegrateVelocity(bodyIndices, position, ..., dt, ref velocity): one lane. bodyIndex < 0 = a lane the caller masked out (its result is discarded).
+    void integrateVelocity(BodyVel& v, const V3& position, int bodyIndex, float dt) const {
+        if (model == 0) {
+            v.lin = scale(add(v.lin, gravityDt), linearDampingDt);
+            v.ang = scale(v.ang, angularDampingDt);
+        } else if (model == 1) {  // PerBodyGravityDemo.cs:87: velocity.Linear.Y += new Vector<float>(gravityValues) * dt
+            const float g = bodyIndex >= 0 ? bodyGravity[bodyIndex] : 0.0f;
+            v.lin.y = v.lin.y + g * dt;
+        } else {  // PlanetDemo.cs:44-46
+            const V3 offset = sub(position, planetCenter);
+            const float distance = sqrtf(offset.x * offset.x + offset.y * offset.y + offset.z * offset.z);
+            const V3 scaled = {offset.x * planetGravityDt, offset.y * planetGravityDt, offset.z * planetGravityDt};  // Vector<float> * Vector3Wide (Vector3Wide.cs:390-397)
+            const float cube = distance * distance * distance;
+            const float inverse = 1.0f / (1.0f > cube ? 1.0f : cube);                                                  // Vector.Max(One, d^3); "/" = multiply by One / scalar (:357-365)
+            v.lin = sub(v.lin, V3{scaled.x * inverse, scaled.y * inverse, scaled.z * inverse});
+        }
     }
 };
 
@@ -146,7 +173,7 @@ struct Ctx {
 };
 
 // TypeProcessor.cs:1204-1248, one lane.
-inline void integratePoseAndVelocity(const Callbacks& cb, const Inertia& localInertia, float dt, bool mask, BodyState& s, Inertia& outInertia) {
+inline void integratePoseAndVelocity(const Callbacks& cb, const Inertia& localInertia, float dt, bool mask, BodyState& s, Inertia& outInertia, int bodyIndex) {
     V3 newPosition = add(s.pos, scale(s.vel.lin, dt));
     s.pos = sel3(mask, newPosition, s.pos);
     outInertia.invMass = localInertia.invMass;
@@ -167,7 +194,7 @@ inline void integratePoseAndVelocity(const Callbacks& cb, const Inertia& localIn
         s.ori = mask ? newOrientation : s.ori;
         outInertia.t = rotateInverseInertia(localInertia.t, s.ori);
     }
-    cb.integrateVelocity(s.vel);
+    cb.integrateVelocity(s.vel, s.pos, bodyIndex, dt);
     s.vel.lin = sel3(mask, s.vel.lin, previousVelocity.lin);
     s.vel.ang = sel3(mask, s.vel.ang, previousVelocity.ang);
 }
@@ -175,7 +202,7 @@ inline void integratePoseAndVelocity(const Callbacks& cb, const Inertia& localIn
 // before the conditional branch saves `previousVelocity`, so a lane that does not integrate here (its body was integrated by an earlier batch) still
 // leaves with a transformed angular velocity when another lane of its bundle integrates. Reproduced as is.
 template <int Mode>
-inline void integrateVelocity(const Callbacks& cb, const Inertia& localInertia, float dt, bool mask, BodyState& s, Inertia& outInertia) {
+inline void integrateVelocity(const Callbacks& cb, const Inertia& localInertia, float dt, bool mask, BodyState& s, Inertia& outInertia, int bodyIndex) {
     outInertia.invMass = localInertia.invMass;
     outInertia.t = rotateInverseInertia(localInertia.t, s.ori);
     if (cb.mode == 1) {
@@ -186,11 +213,11 @@ inline void integrateVelocity(const Callbacks& cb, const Inertia& localInertia, 
     }
     if (Mode == kConditional) {
         BodyVel previousVelocity = s.vel;
-        cb.integrateVelocity(s.vel);
+        cb.integrateVelocity(s.vel, s.pos, bodyIndex, dt);
         s.vel.lin = sel3(mask, s.vel.lin, previousVelocity.lin);
         s.vel.ang = sel3(mask, s.vel.ang, previousVelocity.ang);
     } else {
-        cb.integrateVelocity(s.vel);
+        cb.integrateVelocity(s.vel, s.pos, bodyIndex, dt);
     }
 }
 
@@ -223,8 +250,9 @@ inline void gatherAndIntegrateBundle(Ctx& c, const std::vector<uint64_t>* flagsF
     if (!anyIntegrate) return;
     for (int l = 0; l < lanes; ++l) {
         Inertia local = out[l].inertia, world;
-        if (AllowPose) integratePoseAndVelocity(c.cb, local, dt, mask[l], out[l], world);
-        else integrateVelocity<Mode>(c.cb, local, dt, mask[l], out[l], world);
+        const int bodyIndex = mask[l] ? (refs[l] & kBodyReferenceMask) : -1;  // DecodeBodyIndices (TypeProcessor.cs:1285-1296): masked lanes carry -1
+        if (AllowPose) integratePoseAndVelocity(c.cb, local, dt, mask[l], out[l], world, bodyIndex);
+        else integrateVelocity<Mode>(c.cb, local, dt, mask[l], out[l], world, bodyIndex);
         out[l].inertia = world;
         if (mask[l]) {
             int32_t idx = refs[l] & kBodyReferenceMask;
@@ -536,7 +564,7 @@ void integrateKinematics(Ctx& c, float substepDt, bool poses) {
             scatterPose(s.bodies, idx, st.pos, st.ori);
         }
         if (c.params->integrate_velocity_for_kinematics) {
-            c.cb.integrateVelocity(st.vel);
+            c.cb.integrateVelocity(st.vel, st.pos, idx, substepDt);
             scatterVelocities(s.bodies, idx, st.vel);  // plain index: written (ScatterVelocities<AccessAll>, :485,:530)
         }
     }
@@ -560,7 +588,7 @@ void integrateAfterSubstepping(Ctx& c, int start, int end) {
         if (unconstrained) {
             int steps = p.allow_substeps_for_unconstrained ? p.substep_count : 1;
             for (int stepIndex = 0; stepIndex < steps; ++stepIndex) {
-                if (velocityMask) c.cb.integrateVelocity(st.vel);
+                if (velocityMask) c.cb.integrateVelocity(st.vel, st.pos, i, effectiveDt);
                 st.pos = add(st.pos, scale(st.vel.lin, effectiveDt));
                 if (c.cb.mode == 1) {  // PoseIntegrator.cs:649-655
                     Q previousOrientation = st.ori;
@@ -848,7 +876,7 @@ int oracle_predict_bounding_boxes_shapes(const float* bodies, int count, const O
             if (params->integrate_velocity_for_kinematics || !isKinematic) anyLaneIntegrates = true;       // :323-331
         }
         for (int lane = 0; lane < countInBundle; ++lane) {
-            if (anyLaneIntegrates) cb.integrateVelocity(lanes[lane].vel);                                  // :337-338 (never stored)
+            if (anyLaneIntegrates) cb.integrateVelocity(lanes[lane].vel, lanes[lane].pos, bundleStart + lane, params->dt);  // :337-338 (never stored)
             predictBoundsOfAnyShape(lanes[lane].pos, lanes[lane].ori, lanes[lane].vel, sleepEnergy[lane], params->dt, collidables[bundleStart + lane], tables, out[bundleStart + lane]);
         }
     }

@@ -35,6 +35,8 @@ struct SceneParams {
     float dt; int32_t substep_count; const int32_t* velocity_iterations; float gravity[3]; float linear_damping, angular_damping;
     int32_t allow_substeps_for_unconstrained, integrate_velocity_for_kinematics, threads; void* exchange; void* exchange_user; int32_t angular_integration_mode;
     int32_t fallback_batch_threshold;  // SolveDescription.FallbackBatchThreshold; 0 = 64
+    int32_t velocity_model;            // which of the reference's callback structs PoseIntegratorCallbacks below stands for (0 demo, 1 per-body gravity, 2 planet)
+    float planet_center[3]; float planet_gravity; const float* body_gravity;
 };
 struct SceneDesc {
     float* bodies; int32_t body_count; const int32_t* index_to_handle; const int32_t* handle_to_index; int32_t handle_capacity; int32_t batch_count;
@@ -178,13 +180,38 @@ struct PoseIntegratorCallbacks {
     Vector3Wide gravityWideDt;
     VF linearDampingDt, angularDampingDt;
     static float Clamp(float value, float min, float max) { return value < min ? min : (value > max ? max : value); }  // MathHelper.Clamp
+    // Three of the reference's callback structs behind one name, picked by VelocityModel: 0 DemoPoseIntegratorCallbacks (Demos/DemoCallbacks.cs:20-109),
+    // 1 PerBodyGravityDemoCallbacks (Demos/Demos/PerBodyGravityDemo.cs:20-89; BodyGravities holds the value of the body at each INDEX here — the demo's handle lookup
+    // is done by the caller), 2 PlanetaryGravityCallbacks (Demos/Demos/PlanetDemo.cs:19-48).
+    int VelocityModel = 0;
+    float PlanetCenter[3] = {0, 0, 0}, PlanetGravity = 0;
+    const float* BodyGravities = nullptr;
+    float gravityDt = 0;
     void PrepareForIntegration(float dt) {                                                                          // :79
         linearDampingDt = vf(powf(Clamp(1 - LinearDamping, 0, 1), dt));
         angularDampingDt = vf(powf(Clamp(1 - AngularDamping, 0, 1), dt));
         gravityWideDt = Vector3Wide::Broadcast(Gravity[0] * dt, Gravity[1] * dt, Gravity[2] * dt);
+        gravityDt = dt * PlanetGravity;                                                                             // PlanetDemo.cs:39
     }
     void IntegrateVelocity(const VI& bodyIndices, const Vector3Wide& position, const QuaternionWide& orientation, const BodyInertiaWide& localInertia, const VI& integrationMask,
                            int workerIndex, const VF& dt, BodyVelocityWide& velocity) const {  // :99
+        if (VelocityModel == 1) {                                                                                   // PerBodyGravityDemo.cs:57-88
+            VF gravityValues = kZero;                                                                               // stackalloc float[Vector<float>.Count]
+            for (int bundleSlotIndex = 0; bundleSlotIndex < W; ++bundleSlotIndex) {
+                const int bodyIndex = bodyIndices[bundleSlotIndex];
+                if (bodyIndex >= 0) gravityValues[bundleSlotIndex] = BodyGravities[bodyIndex];                      // BodyGravities[bodies.ActiveSet.IndexToHandle[bodyIndex]]
+            }
+            velocity.Linear.Y = velocity.Linear.Y + gravityValues * dt;                                             // velocity.Linear.Y += new Vector<float>(gravityValues) * dt
+            return;
+        }
+        if (VelocityModel == 2) {                                                                                   // PlanetDemo.cs:42-47
+            Vector3Wide offset = position - Vector3Wide::Broadcast(PlanetCenter[0], PlanetCenter[1], PlanetCenter[2]);
+            VF distance = Vector3Wide::Length(offset);
+            Vector3Wide scaled = vf(gravityDt) * offset;
+            VF inverse = kOne / Max(kOne, distance * distance * distance);                                          // Vector3Wide operator / (Vector3Wide.cs:357-365)
+            velocity.Linear = velocity.Linear - scaled * inverse;
+            return;
+        }
         velocity.Linear = (velocity.Linear + gravityWideDt) * linearDampingDt;
         velocity.Angular = velocity.Angular * angularDampingDt;
     }
@@ -1788,6 +1815,10 @@ static int ApplyParams(Solver& solver, const SceneParams* params) {
     solver.Callbacks.Gravity[1] = params->gravity[1];
     solver.Callbacks.Gravity[2] = params->gravity[2];
     solver.Callbacks.LinearDamping = params->linear_damping;
+    solver.Callbacks.VelocityModel = params->velocity_model;
+    solver.Callbacks.PlanetCenter[0] = params->planet_center[0]; solver.Callbacks.PlanetCenter[1] = params->planet_center[1]; solver.Callbacks.PlanetCenter[2] = params->planet_center[2];
+    solver.Callbacks.PlanetGravity = params->planet_gravity;
+    solver.Callbacks.BodyGravities = params->body_gravity;
     solver.Callbacks.AngularDamping = params->angular_damping;
     solver.Callbacks.AngularIntegrationMode = params->angular_integration_mode;
     solver.Callbacks.AllowSubstepsForUnconstrainedBodies = params->allow_substeps_for_unconstrained != 0;
@@ -1990,6 +2021,10 @@ static int PredictBoundingBoxesOfScene(const float* bodyStates, int count, const
     PoseIntegratorCallbacks callbacks;
     callbacks.Gravity[0] = params->gravity[0]; callbacks.Gravity[1] = params->gravity[1]; callbacks.Gravity[2] = params->gravity[2];
     callbacks.LinearDamping = params->linear_damping;
+    callbacks.VelocityModel = params->velocity_model;
+    callbacks.PlanetCenter[0] = params->planet_center[0]; callbacks.PlanetCenter[1] = params->planet_center[1]; callbacks.PlanetCenter[2] = params->planet_center[2];
+    callbacks.PlanetGravity = params->planet_gravity;
+    callbacks.BodyGravities = params->body_gravity;
     callbacks.AngularDamping = params->angular_damping;
     callbacks.AngularIntegrationMode = params->angular_integration_mode;
     callbacks.AllowSubstepsForUnconstrainedBodies = params->allow_substeps_for_unconstrained != 0;

@@ -19,7 +19,24 @@ class OracleParams(C.Structure):
     _fields_ = [("dt", C.c_float), ("substep_count", C.c_int32), ("velocity_iterations", C.c_void_p), ("gravity", C.c_float * 3),
                 ("linear_damping", C.c_float), ("angular_damping", C.c_float), ("allow_substeps_for_unconstrained", C.c_int32),
                 ("integrate_velocity_for_kinematics", C.c_int32), ("threads", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p), ("angular_integration_mode", C.c_int32),
-                ("fallback_batch_threshold", C.c_int32)]  # 0 = SolveDescription.DefaultFallbackBatchThreshold (64)
+                ("fallback_batch_threshold", C.c_int32),  # 0 = SolveDescription.DefaultFallbackBatchThreshold (64)
+                ("velocity_model", C.c_int32), ("planet_center", C.c_float * 3), ("planet_gravity", C.c_float), ("body_gravity", C.c_void_p)]  # which IntegrateVelocity (scene.PoseIntegratorCallbacks)
+
+
+def apply_velocity_model(p: "OracleParams", callbacks):
+    """The velocity model of ``callbacks`` into the oracle's parameters; returns what must stay alive while the parameters are in use."""
+    p.velocity_model = int(getattr(callbacks, "velocity_model", 0))
+    centre = getattr(callbacks, "planet_center", (0.0, 0.0, 0.0))
+    p.planet_center[0], p.planet_center[1], p.planet_center[2] = [float(x) for x in centre]
+    p.planet_gravity = float(getattr(callbacks, "planet_gravity", 0.0))
+    table = getattr(callbacks, "body_gravity", None)
+    keep = None
+    if table is not None:
+        keep = np.ascontiguousarray(table, dtype=np.float32)
+        p.body_gravity = keep.ctypes.data
+    else:
+        p.body_gravity = None
+    return keep
 
 
 class OracleScene(C.Structure):
@@ -106,6 +123,7 @@ def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool 
     p.threads = int(threads)
     p.angular_integration_mode = int(getattr(callbacks, "angular_integration_mode", 0))
     p.fallback_batch_threshold = int(solve_description.fallback_batch_threshold)
+    _gravity_table = apply_velocity_model(p, callbacks)  # noqa: F841  (kept alive until the call returns)
     failure = []
     fn = None
     if exchange is not None:  # exchange(substep, pass) after every pass: the CPU stand-in of HipSolver.solve_exchanged
@@ -139,6 +157,7 @@ def predict_bounding_boxes(bodies, dt, callbacks, collidables, hulls=None, compo
     p.linear_damping = float(callbacks.linear_damping)
     p.angular_damping = float(callbacks.angular_damping)
     p.integrate_velocity_for_kinematics = int(bool(callbacks.integrate_velocity_for_kinematics))
+    _gravity_table = apply_velocity_model(p, callbacks)  # noqa: F841
     if compounds or meshes or bundle_width != 8:
         from bepuphysics2_amd.native import COMPOUND_CHILD_DTYPE
         hulls, compounds, meshes = hulls or [], compounds or [], meshes or []

@@ -701,9 +701,15 @@ def test_a_frames_changes_reconstructed_from_the_type_batches_and_sent_in_one_ca
             locs = ms.locations()
             bi, t, i = locs[int(rng.integers(len(locs)))]
             ms.remove(bi, t, i)
-        if layout != "split_plan":
-            for _ in range(int(rng.integers(4, 14))):
+        for _ in range(int(rng.integers(4, 14))):
+            if layout != "split_plan":
                 add_random()
+                continue
+            a = int(rng.integers(ms.bodies.shape[0] - 12))  # a split plan's narrow phase: new contacts between neighbours
+            b = a + int(rng.integers(1, 12))
+            if not (ms.is_kinematic(a) and ms.is_kinematic(b)):
+                t = [4, 5, 6, 7][int(rng.integers(4))]
+                ms.add(t, [a, b], small_scenes.prestep_for(rng, t, ms.bodies[a, 4:7], ms.bodies[b, 4:7]))
         for _ in range(3):  # survivors in another arrangement than remove-then-append leaves them in
             locs = ms.locations()
             bi, t, i = locs[int(rng.integers(len(locs)))]

@@ -65,7 +65,7 @@ def _params(dt, solve_description, callbacks, threads):
     p.threads = int(threads)
     p.angular_integration_mode = int(getattr(callbacks, "angular_integration_mode", 0))
     p.fallback_batch_threshold = int(solve_description.fallback_batch_threshold)
-    return p, its
+    return p, (its, oracle_ffi.apply_velocity_model(p, callbacks))  # what the parameters point at stays alive with the second value
 
 
 def solve(scene, dt, solve_description, callbacks, threads: int = 1, fast: bool = False, variant: str = ""):
@@ -144,6 +144,7 @@ def predict_bounding_boxes(bodies, dt, callbacks, collidables, hulls=None, compo
     p.linear_damping = float(callbacks.linear_damping)
     p.angular_damping = float(callbacks.angular_damping)
     p.integrate_velocity_for_kinematics = int(bool(callbacks.integrate_velocity_for_kinematics))
+    _gravity_table = oracle_ffi.apply_velocity_model(p, callbacks)  # noqa: F841
     pts = np.ascontiguousarray(np.concatenate([np.asarray(h, dtype=np.float32).reshape(-1, 3) for h in hulls]) if hulls else np.zeros((0, 3), np.float32), dtype=np.float32)
     hull_begin = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(h) for h in hulls])]), dtype=np.int32)
     kids = np.ascontiguousarray(np.concatenate([np.asarray(k, dtype=COMPOUND_CHILD_DTYPE).reshape(-1) for k in compounds]) if compounds else np.zeros(0, COMPOUND_CHILD_DTYPE),
