@@ -76,9 +76,10 @@ constexpr int kSweepPlanes = 6;       // LDS body table: one plane per 16-byte f
 constexpr int kAllPlanes = 8;         // ... plus the local inertia (read once per substep by the integration phase) when the cluster leaves room for it; otherwise that stays in memory
 constexpr int kClusterThreads = 1024;  // default threads per cluster workgroup
 constexpr int kSplitClusterThreads = 512;  // split-island plans: the shared-body code needs the 256-VGPR budget to stay out of scratch (spills sit on every hand-off's critical path)
-constexpr int kMaxClusterSubsteps = 16;
+constexpr int kMaxClusterSubsteps = 64;  // substeps one island-kernel launch runs (SolveDescription.SubstepCount is unbounded, SolveDescription.cs:16-136; the demos use up to 8): the per-substep
+                                         // iteration counts travel in the kernel arguments. Beyond it the launch-per-batch schedule takes the step. (16 until round 4.)
 constexpr int kCodeTouchMaxSpans = 4;  // the most 8 KB spans of code a wave may read ahead of its PC (code touch): every cluster unit ends in that much padding (code_pad_kernel)
-constexpr int kClusterTracePasses = kMaxClusterSubsteps * 8;  // passes (warm starts + velocity iterations) the cluster trace buffer holds; later passes are not recorded
+constexpr int kClusterTracePasses = 128;  // passes (warm starts + velocity iterations) the cluster trace buffer holds; later passes are not recorded
 struct ClusterParams {
     int substeps, batch_count, integrate_velocity_for_kinematics;
     int planes;  // kSweepPlanes or kAllPlanes

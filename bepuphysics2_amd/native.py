@@ -206,8 +206,9 @@ class HipSolver:
 
     def close(self):
         if self.ctx:
-            self.lib.bepuhip_destroy(self.ctx)
+            self.lib.bepuhip_destroy(self.ctx)  # unregisters what is still registered ...
             self.ctx = C.c_void_p()
+        self._registered_arrays = {}            # ... only then may the buffers go
 
     def __del__(self):
         try:
@@ -346,9 +347,15 @@ class HipSolver:
         """Pins ``array``'s buffer for the life of the context (BufferPool blocks are pinned, BufferPool.cs:42,83): copies from / to it become asynchronous DMA."""
         assert array.flags["C_CONTIGUOUS"]
         _check(self.lib, self.lib.bepuhip_register_host_memory(self.ctx, _ptr(array), array.nbytes))
+        # the buffer must outlive its registration: freed memory that is still registered leaves the runtime with a stale pinned range, and whatever the allocator
+        # puts there next (a later copy's staging vector, say) is then copied "as pinned memory" — found in round 4 as an invalid-argument hipMemcpy two tests later
+        if not hasattr(self, "_registered_arrays"):
+            self._registered_arrays = {}
+        self._registered_arrays[array.ctypes.data] = array
 
     def unregister_host_memory(self, array: np.ndarray):
         _check(self.lib, self.lib.bepuhip_unregister_host_memory(self.ctx, _ptr(array)))
+        getattr(self, "_registered_arrays", {}).pop(array.ctypes.data, None)
 
     def get_poses_and_velocities(self, bodies: np.ndarray, asynchronous: bool = False):
         """Writes the MotionState half (floats 0-15) of every BodyDynamics into ``bodies`` ((n, 32) float32, in place); the inertia half stays what it was."""

@@ -300,3 +300,39 @@ def test_replan_keeps_a_sequential_fallback_batch_and_the_results(hip_solver_fac
         solver.solve(1 / 60, sd, cb)
     solver.download(got)
     _bit_exact(ref, got)
+
+
+def test_up_to_sixty_four_substeps_stay_on_the_island_schedule(hip_solver_factory):
+    """SolveDescription.SubstepCount is unbounded in the reference (SolveDescription.cs:16-136). One launch of the island kernel ran at most sixteen substeps until
+    round 4 and anything above dropped to the launch-per-batch schedule (five times slower); the per-substep iteration counts travel in the kernel arguments, now
+    for up to 64 substeps. 24 substeps with an uneven iteration schedule on a whole-island plan and on a forced split plan, asserted to have run the island kernel,
+    against the oracle; 65 substeps still work (launch-per-batch)."""
+    import os
+    scene = small_scenes.island_scene(13, islands=40, bodies_per_island=8, constraints_per_island=20, type_ids=[4, 7, 22, 23, 25, 47, 0])
+    schedule = [1 + (s % 3) for s in range(24)]
+    sd = SolveDescription(1, 24, velocity_iteration_scheduler=lambda s: schedule[s])
+    cb = PoseIntegratorCallbacks(integrate_velocity_for_kinematics=True)
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
+    assert solver.cluster_cycles().size > 0, "24 substeps must run the island kernel"
+    m = pu.compare_scenes(ref, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    big = small_scenes.random_graph_scene(31, 2500, 6000, [4, 5, 6, 7, 22, 25, 47], kinematic_fraction=0.05)
+    os.environ["BEPUHIP_SPLIT_CLUSTERS"] = "12"
+    try:
+        ref = pu.run_oracle(big, 1 / 60, sd, cb, frames=1, threads=4)
+        solver = hip_solver_factory()
+        got = pu.run_hip(solver, big, 1 / 60, sd, cb, frames=1)
+        assert solver.schedule() == 2 and solver.cluster_cycles().size > 1
+    finally:
+        os.environ.pop("BEPUHIP_SPLIT_CLUSTERS", None)
+    m = pu.compare_scenes(ref, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    sd65 = SolveDescription(1, 65)
+    ref = pu.run_oracle(scene, 1 / 60, sd65, cb, frames=1, threads=4)
+    solver = hip_solver_factory()
+    got = pu.run_hip(solver, scene, 1 / 60, sd65, cb, frames=1)
+    assert solver.cluster_cycles().size == 0
+    m = pu.compare_scenes(ref, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m

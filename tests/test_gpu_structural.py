@@ -384,7 +384,7 @@ def test_reserved_layout_falls_back_cleanly_when_the_island_schedule_does_not_ap
     behaviour — for a momentum-conserving angular mode: the launch-per-batch kernels address rows [0, count), so the rows first go back into the caller's order — results
     as always. (By default the island schedule runs the conserving modes itself: third case.)"""
     scene = small_scenes.island_scene(5, 30, 12, 28, [22, 4, 30, 47, 7, 5])
-    for sd, cb, conserving_clusters in ((SolveDescription(1, 17), PoseIntegratorCallbacks(), "1"), (SolveDescription(2, 3), PoseIntegratorCallbacks(angular_integration_mode=1), "0"),
+    for sd, cb, conserving_clusters in ((SolveDescription(1, 65), PoseIntegratorCallbacks(), "1"), (SolveDescription(2, 3), PoseIntegratorCallbacks(angular_integration_mode=1), "0"),
                                         (SolveDescription(2, 3), PoseIntegratorCallbacks(angular_integration_mode=1), "1")):
         monkeypatch.setenv("BEPUHIP_CONSERVING_CLUSTERS", conserving_clusters)
         ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2)

@@ -24,7 +24,10 @@ def test_velocity_models_on_island_scenes(hip_solver_factory, model, use_cluster
         cb = model_callbacks(model, scene, rng, **kw)
         ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=3, threads=4)
         solver = hip_solver_factory(use_clusters=use_clusters)
-        got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=3)
+        try:
+            got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=3)
+        except Exception as e:
+            raise AssertionError(f"model {model}, clusters {use_clusters}, {kw}: {e}") from e
         assert (solver.schedule() == 1) == use_clusters
         m = pu.compare_scenes(ref, got)
         assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (model, use_clusters, kw, m)
