@@ -444,9 +444,12 @@ def lattice_leg(device: int, ragdolls: int = 2000, world: int = 2, frames: int =
             ex = lattice.solve_shares_in_process(lambda: HipSolver(device=device, use_clusters=not exact), shares, 1 / 60, sd, cb, frames=frames, exact=exact)
             merged = lattice.merge_owned(scene, shares)
             per_body = np.abs(ref.bodies[:, vel] - merged.bodies[:, vel]).max(axis=1) / scale
-            out[name] = {"velocity_err_max": float(per_body.max()), "velocity_err_median": float(np.median(per_body)),
+            out[name] = {"within_north_star_tolerance": bool(float(per_body.max()) <= 1e-4),  # BASELINE.json: <= 1e-4 relative velocity error
+                         "velocity_err_max": float(per_body.max()), "velocity_err_median": float(np.median(per_body)),
                          "bit_identical": bool(np.array_equal(ref.bodies[:, :15].view(np.int32), merged.bodies[:, :15].view(np.int32))),
                          "exchanges_per_frame": ex.calls // frames, "boundary_bodies": int(shares[0].boundary_total)}
+        out["configs4_mode"] = ("per_batch_exact: the only exchange mode inside BASELINE.json's 1e-4 tolerance (bit-identical to the unsplit solve); the per-pass block-Jacobi "
+                                "mode is an approximation for hosts that can live with its error at the cut — it is NOT a configs[4] result (VERDICT r3 weak #12)")
         return out
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)[:300]}
@@ -596,7 +599,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--lattice", action="store_true", help="BASELINE.json configs[4]: ONE connected ragdoll lattice of --ragdolls ragdolls split across the ranks "
                     "(strong scaling, boundary-velocity exchange after every pass) instead of the default independent islands per rank")
-    ap.add_argument("--lattice-exact", action="store_true", help="with --lattice: the per-batch exact exchange mode (bit-identical to one GPU) instead of per-pass block-Jacobi")
+    ap.add_argument("--lattice-exact", action="store_true", help="with --lattice: the per-batch exact exchange mode (bit-identical to one GPU: the configs[4] mode) instead of the "
+                    "per-pass block-Jacobi approximation (9 %% velocity error at the cut: outside BASELINE.json's tolerance)")
     ap.add_argument("--lattice-no-clusters", action="store_true", help="with --lattice: the launch-per-batch schedule also in the per-pass mode (round 2's path)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the clock pre-warm of the setup phase (300 untimed solves, state restored afterwards)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE child runs behind roofline.traffic")

@@ -57,7 +57,7 @@ struct ClusterShared {
     int ncap;
     ClusterItem* items;
     volatile lds_u32* flags;  // per item: epoch of the last completed pass
-    int* lbib;                // batch -> first item of the cluster (batch_count + 1 entries)
+    int item_count;           // the cluster's work items per pass
     lds_u32* counter;         // item claim counter, monotonic
     int batch_count;
     unsigned* status;      // global: [0] != 0 when a wait ran out of patience (a scheduling bug, never expected); [1..7] first offender
@@ -377,8 +377,10 @@ __device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const
     // the count then reaches e x n_b with a warm-start item still outstanding; a cross-overflow Solve item of batch 0 started on a body whose last warm-start
     // application had not happened. Found by tools/fuzz_device.py seed 81 ordinal 91, 12 % of the runs of a cold process, 0.2 % of a warm one: it takes a wave that is
     // slow on its first pass through a heavy type's code. The flags say which PASS an item has completed, so they cannot be confused.)
-    if (h.overflow) wait_items(sh, (int)__builtin_amdgcn_readfirstlane(sh.lbib[h.batch]), epoch, 2, k);
-    if (CROSS && h.xoverflow) wait_items(sh, (int)__builtin_amdgcn_readfirstlane(sh.lbib[sh.batch_count]), epoch - 1, 4, k);
+    // "Every earlier batch" is waited for as "every item before this one": items are claimed in a topological order, so that is a superset of the predecessors — also
+    // for the items of the sequential fallback batch, whose predecessors may sit in their own batch (round 4: the fallback batch runs the island schedule).
+    if (h.overflow) wait_items(sh, k, epoch, 2, k);
+    if (CROSS && h.xoverflow) wait_items(sh, sh.item_count, epoch - 1, 4, k);
     asm volatile("" ::: "memory");  // nothing below may be hoisted above the polls
 }
 
@@ -769,8 +771,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.items = reinterpret_cast<ClusterItem*>(lds + cp.planes * ncap);
     unsigned* words = reinterpret_cast<unsigned*>(lds + cp.planes * ncap + max_items * (int)(sizeof(ClusterItem) / 16));
     sh.flags = (volatile lds_u32*)words;
-    sh.lbib = reinterpret_cast<int*>(words + max_items);
-    sh.counter = (lds_u32*)(words + max_items + (kFallbackBatchLimit + 1) + 1);
+    sh.counter = (lds_u32*)(words + max_items + 1);
     sh.status = status;
     sh.batch_count = cp.batch_count;
     sh.st = shared_tables; sh.events = 0; sh.passes = 0;
@@ -797,7 +798,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         for (int j = tid; j < cd.item_count * (int)(sizeof(ClusterItem) / 16); j += blockDim.x) dst[j] = src[j];
     }
     for (int j = tid; j < max_items; j += blockDim.x) words[j] = 0;  // flags
-    for (int j = tid; j <= cp.batch_count; j += blockDim.x) sh.lbib[j] = batch_item_begin[cd.batch_item_offset + j] - cd.item_begin;
+    sh.item_count = cd.item_count;
     if (tid == 0) *sh.counter = 0;
     if constexpr (SHARED) { for (int j = tid; j < cd.slot_count; j += blockDim.x) slot_body_lds[j] = slots[j]; }
     __syncthreads();

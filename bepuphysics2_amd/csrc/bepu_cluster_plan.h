@@ -124,6 +124,30 @@ static void plan_parallel_for_workers(size_t jobs, Fn&& fn) {  // fn(job, worker
 template <class Fn>
 static void plan_parallel_for(size_t jobs, Fn&& fn) { plan_parallel_for_workers(jobs, [&](size_t j, int, int) { fn(j); }); }
 
+// One work item of a sequential fallback type batch: from position `at` of `members` (constraints of one cluster, in the reference's order) as many consecutive constraints
+// as share no dynamic body, at most 64. Returns the end position. Before the rows are permuted the references are read at the caller's index, afterwards at the device
+// slot segment_begin + position (same constraints, same order).
+static size_t fallback_item_end(const HostTypeBatch& tb, const std::vector<int32_t>& members, size_t at, bool rows_are_permuted = false, int segment_begin = 0) {
+    int32_t seen[64 * 4];
+    int nseen = 0;
+    size_t end = at;
+    for (; end < members.size() && end - at < 64; ++end) {
+        const size_t row = rows_are_permuted ? (size_t)segment_begin + end : (size_t)members[end];
+        bool repeats = false;
+        for (int k = 0; k < tb.info.bodies && !repeats; ++k) {
+            const int32_t r = tb.refs_soa[(size_t)k * tb.stride + row];
+            if ((uint32_t)r >= kDynamicLimit) continue;
+            for (int q = 0; q < nseen; ++q) repeats |= seen[q] == r;
+        }
+        if (repeats) break;
+        for (int k = 0; k < tb.info.bodies; ++k) {
+            const int32_t r = tb.refs_soa[(size_t)k * tb.stride + row];
+            if ((uint32_t)r < kDynamicLimit) seen[nseen++] = r;
+        }
+    }
+    return end > at ? end : at + 1;
+}
+
 static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     const bool plan_stats = env_int("BEPUHIP_PLAN_STATS", 0) >= 2;
     auto plan_t = std::chrono::steady_clock::now();
@@ -145,7 +169,13 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     std::vector<uint8_t> is_dyn(universe, 0);
     std::vector<int32_t> parent(universe);
     for (int i = 0; i < universe; ++i) parent[i] = i;
-    const bool want_plan = !((c->flags & BEPUHIP_FLAG_NO_CLUSTERS) || env_int("BEPUHIP_NO_CLUSTERS", 0) || universe == 0 || c->total_constraints == 0 || c->batch_count > kFallbackBatchLimit || c->has_fallback);
+    // The sequential fallback batch (Solver_Solve.cs:546-583: bundles one after the other, a body may repeat ACROSS bundles) runs the island schedule too since round 4:
+    // its constraints become work items that are cut wherever a dynamic body would repeat, in the reference's order, and the predecessor lists order them like any
+    // other items — a hub body's surplus constraints form a chain of one-constraint items (whole-island plans only; BEPUHIP_FALLBACK_CLUSTERS=0: launch-per-batch levels).
+    const bool fallback_here = c->has_fallback;
+    const int fallback_batch = c->fallback_threshold;
+    const bool want_plan = !((c->flags & BEPUHIP_FLAG_NO_CLUSTERS) || env_int("BEPUHIP_NO_CLUSTERS", 0) || universe == 0 || c->total_constraints == 0 || c->batch_count > kFallbackBatchLimit + 1 ||
+                             (fallback_here && (env_int("BEPUHIP_FALLBACK_CLUSTERS", 1) == 0 || (c->flags & BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS))));
     auto find_root = [&](int x) {
         for (;;) {
             const int p = __atomic_load_n(&parent[x], __ATOMIC_RELAXED);
@@ -192,7 +222,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                 if (!__atomic_load_n(&is_dyn[r], __ATOMIC_RELAXED)) __atomic_store_n(&is_dyn[r], (uint8_t)1, __ATOMIC_RELAXED);  // read-mostly: an unconditional store makes the line bounce between the threads
                 if (first < 0) first = r; else unite(first, r);
             }
-            if (first < 0) bodiless.store(1, std::memory_order_relaxed);  // a constraint with no dynamic body
+            if (first < 0 && tb.refs_soa[i] != -1) bodiless.store(1, std::memory_order_relaxed);  // a constraint with no dynamic body (an empty lane of the fallback batch is not a constraint)
         }
     });
     {
@@ -258,11 +288,12 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                     int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
                     if ((uint32_t)r < kDynamicLimit) cl = cluster_of[parent[r]];
                 }
+                if (cl < 0) cl = i > 0 ? cl_of_constraint[t][i - 1] : 0;  // an empty lane of the fallback batch: a dead device slot next to its neighbour
                 cl_of_constraint[t][i] = cl;
                 per_cluster[t][cl]++;
                 for (int k = 0; k < tb.info.bodies; ++k) {
                     int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                    if ((uint32_t)r >= kDynamicLimit) {
+                    if (r >= 0 && (uint32_t)r >= kDynamicLimit) {
                         const std::pair<int32_t, int32_t> pair{cl, r & kRefMask};
                         if (met.empty() || (met.back() != pair && std::find(met.begin(), met.end(), pair) == met.end())) met.push_back(pair);
                     }
@@ -273,6 +304,14 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
             for (auto& pair : kin_met[t]) {
                 auto& ks = kin_seen[pair.first];
                 if (std::find(ks.begin(), ks.end(), pair.second) == ks.end()) ks.push_back(pair.second);
+            }
+            if (fallback_here && c->tbs[t].batch == fallback_batch) {  // items end where a dynamic body would repeat: counted as they will be cut (fallback_item_end)
+                const HostTypeBatch& tb = c->tbs[t];
+                std::vector<std::vector<int32_t>> members(nclusters);
+                for (int i = 0; i < tb.count; ++i) members[cl_of_constraint[t][i]].push_back(i);
+                for (int cl = 0; cl < nclusters; ++cl)
+                    for (size_t at = 0; at < members[cl].size(); ++item_count[cl]) at = fallback_item_end(tb, members[cl], at);
+                continue;
             }
             for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (segment_slots(per_cluster[t][cl], reserve) + 63) / 64;
         }
@@ -312,6 +351,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         std::stable_sort(visit.begin(), visit.end(), [&](size_t a, size_t b) {
             const HostTypeBatch &x = c->tbs[a], &y = c->tbs[b];
             if (x.batch != y.batch) return x.batch < y.batch;
+            if (fallback_here && x.batch == fallback_batch) return false;  // the sequential fallback batch: type batches in the reference's order (Solver_Solve.cs:546-583)
             return x.info.prestep + 2 * x.info.impulse > y.info.prestep + 2 * y.info.impulse;
         });
     // Rows of every type batch in cluster order (stable: inside a cluster the caller's order stays). Type batches are independent of each other here.
@@ -342,6 +382,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                 if (k == 0) tb.inv[h] = d;
                 const int32_t r = src[h];
                 dst[d] = r;
+                if (r < 0) { ldst[d] = kPlanDeadLref; continue; }  // an empty lane of the fallback batch: computes on the kinematic copy in slot 0 and writes no body, like a free slot
                 ldst[d] = ((uint32_t)r < kDynamicLimit) ? rotated_slot(local_of[r]) : (rotated_slot(cl_kin[clc[h]].find(r & kRefMask)->second) | (int)kDynamicLimit);
             }
         }
@@ -371,10 +412,14 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
             const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
             const int d = tb.seg_begin[cl], e = tb.seg_begin[cl + 1];
             if (d == e) continue;
-            for (int s0 = d; s0 < e; s0 += 64) {
+            const bool sequential = fallback_here && tb.batch == fallback_batch;
+            std::vector<int32_t> segment;  // fallback type batches: the segment's constraints by the caller's index, to cut the items exactly as phase A counted them
+            if (sequential) for (int j = d; j < e; ++j) segment.push_back(tb.perm[j]);
+            for (int s0 = d, next = d; s0 < e; s0 = next) {
+                next = sequential ? d + (int)fallback_item_end(tb, segment, (size_t)(s0 - d), /*rows_are_permuted=*/true, d) : std::min(e, s0 + 64);
                 ClusterItem it;
                 memset(&it, 0, sizeof(it));
-                it.type_id = tb.type_id; it.count = std::min(64, e - s0); it.stride = tb.stride; it.start = s0;
+                it.type_id = tb.type_id; it.count = next - s0; it.stride = tb.stride; it.start = s0;
                 it.tb = (int)t; it.shape = nb | (pf << 8) | (imf << 16);
                 const int self = (int)cl_items[cl].size();
                 int npred = 0, overflow = 0;
@@ -475,7 +520,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
 // bodies in LDS, work items, predecessor flags — is the island schedule's. Islands that fit are still packed whole. All clusters must be resident at once
 // (they wait for each other), so the plan is refused (global path) when it needs more clusters than the device has CUs.
 static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe) {
-    if (env_int("BEPUHIP_NO_SPLIT", 0)) return;
+    if (env_int("BEPUHIP_NO_SPLIT", 0) || c->has_fallback) return;  // (a body's ranks are counted per batch; the sequential fallback batch keeps to whole islands)
     if (env_int("BEPUHIP_SPLIT_MANY_BODY", 1) == 0)
         for (auto& tb : c->tbs) if (tb.info.bodies > 2) return;  // (round 2: three- and four-body constraints kept to whole islands)
     int cus = 256;

@@ -43,8 +43,8 @@ struct ClusterItem {  // <= 64 consecutive constraints of one type batch, all ow
 };
 static_assert(sizeof(ClusterItem) == 64, "ClusterItem is staged in LDS as four 16-byte vectors");
 static_assert(offsetof(ClusterItem, xpred) == offsetof(ClusterItem, pred) + kMaxPreds * sizeof(unsigned short), "wait_predecessors indexes pred[] and xpred[] as one array");
-// LDS words behind the work items: one flag per item, the (kFallbackBatchLimit + 1)-entry table batch -> first item, the claim counter.
-__host__ __device__ inline size_t cluster_sync_words(int max_items) { return (size_t)max_items + (kFallbackBatchLimit + 1) + 2; }
+// LDS words behind the work items: one flag per item, the claim counter.
+__host__ __device__ inline size_t cluster_sync_words(int max_items) { return (size_t)max_items + 2; }
 struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
 // LDS of a cluster workgroup: [planes x ncap float4 body table][work items][sync words][SHARED: slot -> body table][one scratch row of 256 B: the destination of the
 // LDS-DMA reads that only exist to pull code into L2 (touch_code_ahead)].

@@ -366,7 +366,7 @@ static int32_t build_descriptors(bepuhip_ctx* c, const std::vector<std::vector<i
                     if ((uint32_t)r < kDynamicLimit) last_level[r] = level;
                 }
                 if ((size_t)level >= level_rows.size()) level_rows.resize(level + 1, std::vector<std::vector<int32_t>>(fallback_tbs.size()));
-                level_rows[level][ord].push_back(i);
+                level_rows[level][ord].push_back(tb.perm.empty() ? i : tb.inv[i]);  // on an island layout the constraint's row is its device slot
             }
         }
     }
@@ -425,7 +425,7 @@ static int32_t build_descriptors(bepuhip_ctx* c, const std::vector<std::vector<i
         if (c->has_fallback && tb.batch == c->fallback_threshold) {  // skip the empty lanes: their references are -1
             const size_t ord = std::find(fallback_tbs.begin(), fallback_tbs.end(), t) - fallback_tbs.begin();
             const size_t begin = index_pool.size();
-            for (int i = 0; i < tb.count; ++i) if (fallback_refs[ord][i] != -1) index_pool.push_back(i);
+            for (int i = 0; i < tb.count; ++i) if (fallback_refs[ord][i] != -1) index_pool.push_back(tb.perm.empty() ? i : tb.inv[i]);
             d.count = (int)(index_pool.size() - begin);
             if (d.count == 0) continue;
             inc_fixups.push_back({inc.size(), begin});
@@ -935,7 +935,10 @@ static int cluster_threads(const bepuhip_ctx* c) {
 // The momentum-conserving angular modes run the island schedule through the kernel units that carry their code (round 3; BEPUHIP_CONSERVING_CLUSTERS=0: launch-per-batch
 // as in round 2), which exist for the default workgroup sizes.
 static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
-    return c->clusters_enabled && substeps <= kMaxClusterSubsteps && cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared) <= kLdsBudgetBytes &&
+    // (a sequential fallback batch runs the island schedule in the nonconserving mode; the conserving modes' substep-0 re-transformations of a fallback batch are lists
+    // per dependency level, which only the launch-per-batch schedule has)
+    return c->clusters_enabled && substeps <= kMaxClusterSubsteps && !(c->has_fallback && in->angular_integration_mode != 0) &&
+           cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared) <= kLdsBudgetBytes &&
            (in->angular_integration_mode == 0 || (conserving_variant_exists(cluster_threads(c), c->clusters_shared) && c->d_trace == nullptr && env_int("BEPUHIP_CONSERVING_CLUSTERS", 1) != 0));
 }
 // Enqueue every kernel of one Simulation.Solve on the context's stream (Solver_Solve.cs:1415-1479 + PoseIntegrator.cs:707-726).

@@ -178,10 +178,23 @@ def test_sequential_fallback_batch_on_the_device(hip_solver_factory, threshold, 
     scene = small_scenes.star_scene(4, spokes=spokes, hubs=hubs, fallback_batch_threshold=threshold)
     assert len(scene.batches) == threshold + 1
     sd, cb = SolveDescription(2, 4, fallback_batch_threshold=threshold), PoseIntegratorCallbacks()
-    for use_graph in (True, False):
-        ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=3)
-        got = pu.run_hip(hip_solver_factory(use_graph=use_graph), scene, 1 / 60, sd, cb, frames=3)
+    import fuzz_util as fu
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=3)
+    # round 4: the island schedule runs the fallback batch too — its constraints are work items cut wherever a dynamic body would repeat, chained by the predecessor
+    # lists (a hub's surplus constraints: a chain of one-constraint items) — at its natural timing and under schedule fuzzing
+    for jitter in (0, 77):
+        with fu.environment(BEPUHIP_DEBUG_JITTER=jitter or None):
+            solver = hip_solver_factory()
+            got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=3)
+        assert solver.cluster_cycles().size > 0, "a scene with a sequential fallback batch must run the island schedule"
         _bit_exact(ref, got)
+    # the launch-per-batch schedule's dependency levels (what ran it until round 3), with and without hipGraph
+    with fu.environment(BEPUHIP_FALLBACK_CLUSTERS=0):
+        for use_graph in (True, False):
+            solver = hip_solver_factory(use_graph=use_graph)
+            got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=3)
+            assert solver.cluster_cycles().size == 0
+            _bit_exact(ref, got)
 
 
 def test_fallback_batch_limits_through_the_abi(hip_solver_factory):
