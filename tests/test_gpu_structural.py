@@ -390,7 +390,7 @@ def test_reserved_layout_falls_back_cleanly_when_the_island_schedule_does_not_ap
         ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2)
         solver = hip_solver_factory(reserve_update_slots=True)
         got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
-        assert (solver.cluster_cycles().size == 0) == (sd.substep_count == 17 or conserving_clusters == "0")
+        assert (solver.cluster_cycles().size == 0) == (sd.substep_count == 65 or conserving_clusters == "0")
         m = pu.compare_scenes(ref, got)
         assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
 
