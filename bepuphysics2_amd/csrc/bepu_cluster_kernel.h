@@ -58,6 +58,8 @@ struct ClusterShared {
     ClusterItem* items;
     volatile lds_u32* flags;  // per item: epoch of the last completed pass
     int item_count;           // the cluster's work items per pass
+    int* lbib;                // batch -> first item of the cluster (batch_count + 1 entries)
+    int fallback_batch;       // index of the sequential fallback batch, -1 if the scene has none
     lds_u32* counter;         // item claim counter, monotonic
     int batch_count;
     unsigned* status;      // global: [0] != 0 when a wait ran out of patience (a scheduling bug, never expected); [1..7] first offender
@@ -112,20 +114,24 @@ __device__ __forceinline__ void store_velocity_lds(const ClusterShared& sh, int 
 // (momentum_requirk_kernel of the launch-per-batch schedule, applied by the lane that holds the body; TypeProcessor.cs:1264-1281).
 constexpr unsigned kLrefRequirk = 1u << 14;   // whole-island plans: in the 16-bit local reference (the bit split plans use for "shared")
 constexpr unsigned kRankRequirk = 1u << 18;   // split plans: in the rank word
-__device__ __forceinline__ V3 requirk_angular_velocity(const ClusterShared& sh, int lref, V3 ang) {
-    const int slot = lref & kRefMask;
-    const float4 q4 = sh.planes[slot];
+// Out of line (round 4): the transformation runs for a handful of lanes in the warm start of substep 0, but inlined into the gate of every constraint type it cost every
+// sweep of every substep its registers (hot 1024-thread unit: 226 spilled VGPRs against 84 without the conserving code). Everything it needs travels by value.
+__device__ __noinline__ V3 requirk_core(const float4* planes, int ncap, int plane_count, const int* slot_table, const float4* bodies, int angular_mode, float substep_dt, int slot, V3 ang) {
+    const float4 q4 = planes[slot];
     float4 i0, i1;
-    if (sh.plane_count == kAllPlanes) { i0 = sh.planes[6 * sh.ncap + slot]; i1 = sh.planes[7 * sh.ncap + slot]; }
-    else { const int body = sh.slot_table[slot] & kSlotBodyMask; i0 = sh.bodies[(size_t)body * 8 + 4]; i1 = sh.bodies[(size_t)body * 8 + 5]; }
+    if (plane_count == kAllPlanes) { i0 = planes[6 * ncap + slot]; i1 = planes[7 * ncap + slot]; }
+    else { const int body = slot_table[slot] & kSlotBodyMask; i0 = bodies[(size_t)body * 8 + 4]; i1 = bodies[(size_t)body * 8 + 5]; }
     const Q ori = {q4.x, q4.y, q4.z, q4.w};
     const Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
-    if (sh.angular_mode == 1) {
+    if (angular_mode == 1) {
         const Sym3 world = rotateInverseInertia(local, ori);
-        const Q previousOrientation = integrateOrientation(ori, ang, sh.substep_dt * -0.5f);
+        const Q previousOrientation = integrateOrientation(ori, ang, substep_dt * -0.5f);
         return integrateAngularVelocityConserveMomentum(previousOrientation, local, world, ang);
     }
-    return integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, ang, sh.substep_dt);
+    return integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, ang, substep_dt);
+}
+__device__ __forceinline__ V3 requirk_angular_velocity(const ClusterShared& sh, int lref, V3 ang) {
+    return requirk_core(sh.planes, sh.ncap, sh.plane_count, sh.slot_table, sh.bodies, sh.angular_mode, sh.substep_dt, lref & kRefMask, ang);
 }
 
 // ... on a private body: in place in its LDS slot, whatever part of the velocity the constraint type itself reads (the lane owns the body once its predecessors are done).
@@ -377,9 +383,10 @@ __device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const
     // the count then reaches e x n_b with a warm-start item still outstanding; a cross-overflow Solve item of batch 0 started on a body whose last warm-start
     // application had not happened. Found by tools/fuzz_device.py seed 81 ordinal 91, 12 % of the runs of a cold process, 0.2 % of a warm one: it takes a wave that is
     // slow on its first pass through a heavy type's code. The flags say which PASS an item has completed, so they cannot be confused.)
-    // "Every earlier batch" is waited for as "every item before this one": items are claimed in a topological order, so that is a superset of the predecessors — also
-    // for the items of the sequential fallback batch, whose predecessors may sit in their own batch (round 4: the fallback batch runs the island schedule).
-    if (h.overflow) wait_items(sh, k, epoch, 2, k);
+    // An item of the sequential fallback batch may have predecessors in its own batch (round 4: the fallback batch runs the island schedule): it waits for every
+    // item before it — items are claimed in a topological order, so that is a superset of its predecessors. (Doing the same for every batch serialises the overflow
+    // items of a batch behind each other: the pile's 64-lane contact items all overflow, 0.395 -> 0.51 ms/step, measured and taken back.)
+    if (h.overflow) wait_items(sh, h.batch == sh.fallback_batch ? k : (int)__builtin_amdgcn_readfirstlane(sh.lbib[h.batch]), epoch, 2, k);
     if (CROSS && h.xoverflow) wait_items(sh, sh.item_count, epoch - 1, 4, k);
     asm volatile("" ::: "memory");  // nothing below may be hoisted above the polls
 }
@@ -771,7 +778,9 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.items = reinterpret_cast<ClusterItem*>(lds + cp.planes * ncap);
     unsigned* words = reinterpret_cast<unsigned*>(lds + cp.planes * ncap + max_items * (int)(sizeof(ClusterItem) / 16));
     sh.flags = (volatile lds_u32*)words;
-    sh.counter = (lds_u32*)(words + max_items + 1);
+    sh.lbib = reinterpret_cast<int*>(words + max_items);
+    sh.counter = (lds_u32*)(words + max_items + kClusterBatchTable + 1);
+    sh.fallback_batch = cp.fallback_batch;
     sh.status = status;
     sh.batch_count = cp.batch_count;
     sh.st = shared_tables; sh.events = 0; sh.passes = 0;
@@ -799,6 +808,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     }
     for (int j = tid; j < max_items; j += blockDim.x) words[j] = 0;  // flags
     sh.item_count = cd.item_count;
+    for (int j = tid; j <= cp.batch_count; j += blockDim.x) sh.lbib[j] = batch_item_begin[cd.batch_item_offset + j] - cd.item_begin;
     if (tid == 0) *sh.counter = 0;
     if constexpr (SHARED) { for (int j = tid; j < cd.slot_count; j += blockDim.x) slot_body_lds[j] = slots[j]; }
     __syncthreads();

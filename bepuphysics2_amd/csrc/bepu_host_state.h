@@ -249,6 +249,7 @@ struct bepuhip_ctx {
     int comm_world = 1;
     unsigned long long* d_cycles = nullptr;  // per cluster: shader clocks of the last cluster_kernel launch
     unsigned* d_status = nullptr;  // cluster schedule watchdog words (see report_stall)
+    bool in_substep_event = false;  // inside a handler of bepuhip_solve_with_substep_events
     bepuhip_velocity_model velocity_model = {BEPUHIP_VELOCITY_UNIFORM_GRAVITY, {0, 0, 0}, 0};  // bepuhip_set_velocity_model
     float* d_body_gravity = nullptr;  // per-body gravity model: one float per body index
     int body_gravity_capacity = 0, body_gravity_count = 0;

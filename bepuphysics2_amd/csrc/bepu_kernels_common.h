@@ -43,8 +43,9 @@ struct ClusterItem {  // <= 64 consecutive constraints of one type batch, all ow
 };
 static_assert(sizeof(ClusterItem) == 64, "ClusterItem is staged in LDS as four 16-byte vectors");
 static_assert(offsetof(ClusterItem, xpred) == offsetof(ClusterItem, pred) + kMaxPreds * sizeof(unsigned short), "wait_predecessors indexes pred[] and xpred[] as one array");
-// LDS words behind the work items: one flag per item, the claim counter.
-__host__ __device__ inline size_t cluster_sync_words(int max_items) { return (size_t)max_items + 2; }
+// LDS words behind the work items: one flag per item, the table batch -> first item (batch_count + 1 entries; the sequential fallback batch is one more batch), the claim counter.
+constexpr int kClusterBatchTable = kFallbackBatchLimit + 2;
+__host__ __device__ inline size_t cluster_sync_words(int max_items) { return (size_t)max_items + kClusterBatchTable + 2; }
 struct ClusterDesc { int body_begin, slot_count, item_begin, item_count, batch_item_offset; };
 // LDS of a cluster workgroup: [planes x ncap float4 body table][work items][sync words][SHARED: slot -> body table][one scratch row of 256 B: the destination of the
 // LDS-DMA reads that only exist to pull code into L2 (touch_code_ahead)].
@@ -87,6 +88,7 @@ struct ClusterParams {
     unsigned jitter;    // schedule fuzzing seed (BEPUHIP_DEBUG_JITTER; 0 = off): pseudo-random naps around every item's wait and publish, see jitter_nap
     int iters[kMaxClusterSubsteps];
     int pass_stage, pass_substep;  // the one-sweep-per-launch units (kPass): kStageWarmStart or kStageSolve, and the substep the sweep belongs to
+    int fallback_batch;            // index of the sequential fallback batch (its items may depend on items of their own batch), -1 if the scene has none
     StepParams sp;
 };
 

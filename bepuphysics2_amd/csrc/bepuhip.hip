@@ -955,6 +955,8 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
         ClusterParams cp;
         cp.substeps = substeps; cp.batch_count = c->batch_count; cp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
         cp.planes = c->cluster_planes;
+        cp.fallback_batch = c->has_fallback ? c->fallback_threshold : -1;
+        cp.pass_stage = 0; cp.pass_substep = 0;
         for (int s = 0; s < kMaxClusterSubsteps; ++s) cp.iters[s] = s < substeps ? iterations[s] : 0;
         cp.sp = sp;
         {
@@ -1176,6 +1178,72 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
     return BEPUHIP_OK;
+}
+
+// Simulation.Solve with Solver.SubstepStarted / SubstepEnded raised (include/bepuhip.h): the launch-per-batch kernels of one substep at a time, the host's handlers
+// between them with the stream drained.
+int32_t bepuhip_solve_with_substep_events(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in, bepuhip_substep_fn started,
+                                          bepuhip_substep_fn ended, void* user) {
+    int32_t st = validate_solve(c, dt, substeps, iterations, in);
+    if (st != BEPUHIP_OK) return st;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
+    if (c->clusters_enabled) {  // the launch-per-batch kernels address rows [0, count): an island layout with free slots goes back into the caller's order first
+        bool gaps = false;
+        for (auto& tb : c->tbs) gaps |= tb.slots > 0 && tb.slots != tb.count;
+        for (auto& tb : c->tbs) if (tb.slots > 0 && !gaps) for (int d = 0; d < tb.count && !gaps; ++d) gaps = tb.perm[d] < 0;
+        if (gaps) {
+            if ((st = leave_island_schedule(c)) != BEPUHIP_OK) return st;
+            if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
+        }
+    }
+    if (in->angular_integration_mode != 0 && c->requirk_stale && c->built && (st = build_requirk_lists(c)) != BEPUHIP_OK) return st;
+    int64_t iters = 0;
+    for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
+    c->last_constraint_iterations = iters;
+    HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+    const float substep_dt = dt / substeps, inv_dt = 1.0f / substep_dt;  // Solver_Solve.cs:1417, :1421
+    const StepParams sp = make_params(c, in, substep_dt, substep_dt, inv_dt);
+    const int body_blocks = (c->body_count + 255) / 256;
+    auto raise = [&](bepuhip_substep_fn fn, int s) -> int32_t {
+        if (!fn) return BEPUHIP_OK;
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));  // the handler sees (and may rewrite, through the update_* entry points) the state the substep starts from / ended with
+        c->in_substep_event = true;
+        fn(user, s);
+        c->in_substep_event = false;
+        return BEPUHIP_OK;
+    };
+    for (int s = 0; s < substeps; ++s) {
+        if ((st = raise(started, s)) != BEPUHIP_OK) return st;  // OnSubstepStarted(substepIndex), Solver_Solve.cs:1425
+        if (s > 0 && c->inc_blocks > 0)
+            hipLaunchKernelGGL(batch_kernel<kStageIncremental>, dim3(c->inc_blocks), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_inc_tbs, 0, c->inc_tb_count, c->d_bodies, substep_dt, inv_dt);
+        if (body_blocks > 0)
+            hipLaunchKernelGGL(substep_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, s > 0 ? 1 : 0,
+                               in->integrate_velocity_for_kinematics, 0, sp);
+        for (int b = 0; b < c->launch_count; ++b) {
+            if (c->batch_blocks[b] == 0) continue;
+            enqueue_requirk(c, s, b, sp);
+            hipLaunchKernelGGL(batch_kernel<kStageWarmStart>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
+                               c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);
+        }
+        for (int it = 0; it < iterations[s]; ++it)
+            for (int b = 0; b < c->launch_count; ++b) {
+                if (c->batch_blocks[b] == 0) continue;
+                hipLaunchKernelGGL(batch_kernel<kStageSolve>, dim3(c->batch_blocks[b]), dim3(kBlock), 0, c->stream, (const DevTypeBatch*)c->d_tbs, c->batch_begin[b],
+                                   c->batch_begin[b + 1] - c->batch_begin[b], c->d_bodies, substep_dt, inv_dt);
+            }
+        if ((st = raise(ended, s)) != BEPUHIP_OK) return st;    // OnSubstepEnded(substepIndex), :1478
+    }
+    if (body_blocks > 0) {  // PoseIntegrator.IntegrateAfterSubstepping (PoseIntegrator.cs:707-726)
+        const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
+        const StepParams fsp = make_params(c, in, vdt, vdt, 1.0f / vdt);
+        hipLaunchKernelGGL(final_integrate_kernel, dim3(body_blocks), dim3(256), 0, c->stream, c->d_bodies, (const unsigned*)c->d_flags, c->body_count, dt, substep_dt, substeps,
+                           in->allow_substeps_for_unconstrained, in->integrate_velocity_for_kinematics, 0, fsp);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+    return bepuhip_sync(c);
 }
 
 int32_t bepuhip_set_boundary_bodies(bepuhip_ctx* c, const int32_t* indices, int32_t count) {
@@ -1418,6 +1486,7 @@ static void enqueue_cluster_pass(bepuhip_ctx* c, int stage, int substep, const S
     memset(&cp, 0, sizeof(cp));
     cp.substeps = 1; cp.batch_count = c->batch_count; cp.planes = c->cluster_planes;
     cp.pass_stage = stage; cp.pass_substep = substep;
+    cp.fallback_batch = -1;  // (exchanged solves refuse a fallback batch)
     cp.sp = sp;
     cp.code_touch = c->row_policy == 2 ? 1 : 0;
     cp.jitter = debug_jitter_seed();
@@ -1801,6 +1870,7 @@ static int32_t structural_preamble(bepuhip_ctx* c, bool stay = false) {
     if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
     if (c->building) return fail(BEPUHIP_E_STATE, "structural update between begin_constraints and end_constraints");
     if (c->has_fallback) return fail(BEPUHIP_E_UNSUPPORTED, "structural updates with a sequential fallback batch: re-upload with begin/set/end");
+    if (c->in_substep_event) return fail(BEPUHIP_E_STATE, "structural update inside a substep event handler: the substep loop runs on the constraint set the solve started with");
     if (stay && c->soft_ok) return BEPUHIP_OK;  // bookkeeping on the host only: no device call on this path (a structural call per changed contact per frame)
     HIP_TRY(hipSetDevice(c->device));
     return leave_island_schedule(c);

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_update_bodies", "bepuhip_update_prestep", "bepuhip_update_accumulated_impulses",
     "bepuhip_get_bodies_range", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range",
     "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables", "bepuhip_set_convex_hulls", "bepuhip_set_compounds", "bepuhip_set_meshes",
-    "bepuhip_set_velocity_model", "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_swap_constraints", "bepuhip_apply_structural_ops", "bepuhip_get_constraint_count", "bepuhip_get_schedule", "bepuhip_replan",
+    "bepuhip_set_velocity_model", "bepuhip_solve_with_substep_events", "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_swap_constraints", "bepuhip_apply_structural_ops", "bepuhip_get_constraint_count", "bepuhip_get_schedule", "bepuhip_replan",
     "bepuhip_register_host_memory", "bepuhip_unregister_host_memory", "bepuhip_get_poses_and_velocities", "bepuhip_get_poses_and_velocities_async", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses_async",
 ]
 
@@ -70,6 +70,7 @@ class Integrator(C.Structure):
 
 EXCHANGE_PER_PASS_AVERAGE, EXCHANGE_PER_BATCH_EXACT = 0, 1
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32)  # bepuhip_exchange_fn(user, substep, pass)
+SUBSTEP_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)  # bepuhip_substep_fn(user, substep index)
 
 _lib: Optional[C.CDLL] = None
 
@@ -138,6 +139,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_remove_constraint.argtypes = [vp, i32, i32, i32]
     lib.bepuhip_update_body_reference.argtypes = [vp, i32, i32, i32, i32, i32]
     lib.bepuhip_set_velocity_model.argtypes = [vp, C.POINTER(VelocityModel), vp, i32]
+    lib.bepuhip_solve_with_substep_events.argtypes = [vp, f32, i32, vp, C.POINTER(Integrator), SUBSTEP_FN, SUBSTEP_FN, vp]
     lib.bepuhip_swap_constraints.argtypes = [vp, i32, i32, i32, i32]
     lib.bepuhip_apply_structural_ops.argtypes = [vp, vp, i32, vp, i32, C.POINTER(i32)]
     lib.bepuhip_get_constraint_count.argtypes = [vp, i32, i32, C.POINTER(i32)]
@@ -259,6 +261,28 @@ class HipSolver:
         integ = make_integrator(callbacks)
         fn = self.lib.bepuhip_solve_async if asynchronous else self.lib.bepuhip_solve
         _check(self.lib, fn(self.ctx, float(dt), int(solve_description.substep_count), _ptr(its), C.byref(integ)))
+
+    def solve_with_substep_events(self, dt: float, solve_description: SolveDescription, callbacks: PoseIntegratorCallbacks, started=None, ended=None):
+        """Solver.SubstepStarted / SubstepEnded (Solver.cs:125-146): ``started(substep)`` / ``ended(substep)`` run around every substep with the stream drained; they may
+        use the update_* and get_* calls. Exceptions raised by a handler surface after the solve."""
+        self.set_velocity_model(callbacks)
+        its = np.ascontiguousarray(solve_description.iterations(), dtype=np.int32)
+        integ = make_integrator(callbacks)
+        failure = []
+
+        def wrap(fn):
+            def trampoline(_user, substep):
+                try:
+                    if fn is not None and not failure:
+                        fn(int(substep))
+                except Exception as e:  # noqa: BLE001 - must not propagate through the C frame
+                    failure.append(e)
+            return SUBSTEP_FN(trampoline)
+
+        a, b = wrap(started), wrap(ended)
+        _check(self.lib, self.lib.bepuhip_solve_with_substep_events(self.ctx, float(dt), int(solve_description.substep_count), _ptr(its), C.byref(integ), a, b, None))
+        if failure:
+            raise failure[0]
 
     # ---- one connected scene split across ranks (include/bepuhip.h, "solve_exchanged") ----
     def set_boundary_bodies(self, local_indices: np.ndarray):

@@ -45,10 +45,10 @@ typedef struct bepuhip_config {
                                           process). The clusters of a split-island plan wait for each other inside one launch and must all be resident at once: by default
                                           that launch is cooperative (the runtime guarantees co-residency or refuses), which costs about 25 us per step; with this flag it
                                           is an ordinary launch. Nothing else depends on the flag. */
-/* flag value 4 is reserved (round 1's opt-in cooperative "stream" schedule: measured slower than the graph replay on every scene, now an archived experiment
-   under tools/experiments/stream_schedule/) */
+/* flag value 4 is reserved (round 1's opt-in cooperative "stream" schedule: measured slower than the graph replay on every scene; removed, see the history of
+   tools/experiments/stream_schedule/) */
 
-/* IPoseIntegratorCallbacks as data: only the DemoPoseIntegratorCallbacks shape can cross the ABI
+/* IPoseIntegratorCallbacks as data: the three properties, and the parameters of the uniform-gravity velocity model (bepuhip_velocity_model above holds the others)
  * (Demos/DemoCallbacks.cs:20-109; BepuPhysics/PoseIntegrator.cs:42-94). PrepareForIntegration(dt) is evaluated
  * natively: linearDampingDt = powf(clamp(1-LinearDamping,0,1), dt) etc. (DemoCallbacks.cs:79-86). */
 typedef struct bepuhip_integrator {
@@ -115,6 +115,15 @@ int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* ctx, const int32_t* body
  * GetVelocityIterationCountForSubstepIndex(s) (BepuPhysics/Solver_Solve.cs:743-751). dt <= 0, substep_count < 1
  * or an iteration count < 1 -> INVALID_ARGUMENT. */
 int32_t bepuhip_solve(bepuhip_ctx* ctx, float dt, int32_t substep_count, const int32_t* velocity_iterations, const bepuhip_integrator* integrator);
+
+/* Solver.SubstepStarted / Solver.SubstepEnded (BepuPhysics/Solver.cs:125-146; raised around every substep, Solver_Solve.cs:1425 and :1478). The one-launch island schedules
+ * have no host-visible substep boundary, so a solve that raises the events runs the launch-per-batch kernels substep by substep: `started(user, s)` before substep s's first
+ * stage, `ended(user, s)` after its last velocity iteration, both with the context's stream drained — a handler may read state back and rewrite it through the update_*
+ * entry points (a kinematic target, a servo goal per substep: what the reference's users do in these events); structural changes inside a handler are refused (STATE). Either
+ * handler may be null. Synchronous at return; results are bit-identical to bepuhip_solve when the handlers change nothing. */
+typedef void (*bepuhip_substep_fn)(void* user, int32_t substep_index);
+int32_t bepuhip_solve_with_substep_events(bepuhip_ctx* ctx, float dt, int32_t substep_count, const int32_t* velocity_iterations, const bepuhip_integrator* integrator,
+                                          bepuhip_substep_fn started, bepuhip_substep_fn ended, void* user);
 
 /* ---- One connected scene split across GPUs (BASELINE.json configs[4]) ----
  * The reference has no counterpart (it solves one address space); the closest hooks are Solver.SubstepStarted/SubstepEnded

@@ -57,6 +57,7 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_end_constraints(IntPtr ctx);
     [DllImport(Lib)] public static extern int bepuhip_set_constrained_kinematics(IntPtr ctx, int* bodyIndices, int count);
     [DllImport(Lib)] public static extern int bepuhip_solve(IntPtr ctx, float dt, int substepCount, int* velocityIterations, BepuHipIntegrator* integrator);
+    [DllImport(Lib)] public static extern int bepuhip_solve_with_substep_events(IntPtr ctx, float dt, int substepCount, int* velocityIterations, BepuHipIntegrator* integrator, delegate* unmanaged[Cdecl]<void*, int, void> started, delegate* unmanaged[Cdecl]<void*, int, void> ended, void* user);
     [DllImport(Lib)] public static extern int bepuhip_set_boundary_bodies(IntPtr ctx, int* bodyIndices, int count);
     [DllImport(Lib)] public static extern int bepuhip_boundary_deltas(IntPtr ctx, float* deltasOut, int outIsDevicePointer);
     [DllImport(Lib)] public static extern int bepuhip_boundary_apply(IntPtr ctx, float* summedDeltas, int inIsDevicePointer);
@@ -147,6 +148,15 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IDisposable where
     readonly Dictionary<IntPtr, long> registered = new Dictionary<IntPtr, long>();
     public int ReplayLimit = 262144;                  // more operations than this in one frame are not cheaper than an upload
     public event TimestepperStageHandler BeforeCollisionDetection, CollisionsDetected, ConstraintsSolved; // ITimestepper.cs:62-74 (subset)
+    /// Solver.SubstepStarted / SubstepEnded (Solver.cs:125-146) cannot be raised from outside the Solver (OnSubstepStarted is protected) and their subscribers cannot be
+    /// seen from outside either: a host that needs the events subscribes HERE instead. With a subscriber the frame runs bepuhip_solve_with_substep_events — the
+    /// launch-per-batch kernels substep by substep, handlers in between with the device idle (they may use the update_* calls through Context).
+    public event Solver.SubstepEvent SubstepStarted, SubstepEnded;
+    public IntPtr Context => ctx;
+    [UnmanagedCallersOnly(CallConvs = new[] { typeof(System.Runtime.CompilerServices.CallConvCdecl) })]
+    static void RaiseStarted(void* user, int substep) => ((HipTimestepper<TCallbacks>)GCHandle.FromIntPtr((IntPtr)user).Target).SubstepStarted?.Invoke(substep);
+    [UnmanagedCallersOnly(CallConvs = new[] { typeof(System.Runtime.CompilerServices.CallConvCdecl) })]
+    static void RaiseEnded(void* user, int substep) => ((HipTimestepper<TCallbacks>)GCHandle.FromIntPtr((IntPtr)user).Target).SubstepEnded?.Invoke(substep);
 
     public HipTimestepper(int device = 0, bool deviceIsExclusive = false)
     {
@@ -418,7 +428,13 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IDisposable where
             { Check(BepuHip.bepuhip_set_velocity_model(ctx, &model, null, 0)); sentModel = 2; sentCenter = radial.PlanetCenter; sentGravity = radial.Gravity; }
         }
         else throw new NotSupportedException("this IPoseIntegratorCallbacks states no velocity model the device knows (IHipVelocityModel, IHipPerBodyGravityModel, IHipRadialGravityModel)");
-        Check(BepuHip.bepuhip_solve_async(ctx, dt, solver.SubstepCount, iterations, &integ));
+        if (SubstepStarted != null || SubstepEnded != null)
+        {
+            var self = GCHandle.Alloc(this);
+            try { Check(BepuHip.bepuhip_solve_with_substep_events(ctx, dt, solver.SubstepCount, iterations, &integ, &RaiseStarted, &RaiseEnded, (void*)GCHandle.ToIntPtr(self))); }
+            finally { self.Free(); }
+        }
+        else Check(BepuHip.bepuhip_solve_async(ctx, dt, solver.SubstepCount, iterations, &integ));
 
         // Back to the host, behind the solve on the same stream: poses and velocities (the MotionState half of BodyDynamics: what collision detection and the user read),
         // and the accumulated impulses of the contact type batches (the narrow phase redistributes them over next frame's manifolds). Joint impulses and contact

@@ -76,10 +76,13 @@ def test_csharp_binding_is_one_text_and_covers_every_entry_point_of_the_header()
     # the calls the timestepper makes exist with the arity it uses them with
     for call, args in re.findall(r"BepuHip\.(bepuhip_\w+)\((.*?)\)\)?;", source):
         declared = re.search(r"extern \w+ " + call + r"\((.*?)\);", source).group(1)
-        want = 0 if not declared.strip() else declared.count(",") + 1
-        depth, got, text = 0, 1 if args.strip() else 0, args
-        for ch in text:
-            depth += ch in "(<[" 
-            depth -= ch in ")>]"
-            got += ch == "," and depth == 0
-        assert got == want, (call, args, declared)
+
+        def arity(text):  # commas at depth 0 (a function-pointer parameter carries commas of its own)
+            depth, n = 0, 1 if text.strip() else 0
+            for ch in text:
+                depth += ch in "(<["
+                depth -= ch in ")>]"
+                n += ch == "," and depth == 0
+            return n
+
+        assert arity(args) == arity(declared), (call, args, declared)

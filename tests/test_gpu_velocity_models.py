@@ -80,3 +80,39 @@ def test_predict_bounding_boxes_evaluates_the_model(hip_solver_factory, model):
     solver.set_bodies(bodies)
     got = solver.predict_bounding_boxes(1 / 60, cb, collidables)
     assert np.array_equal(ref.view(np.uint8), got.view(np.uint8))
+
+
+def test_substep_events_are_raised_around_every_substep_and_may_rewrite_state(hip_solver_factory):
+    """Solver.SubstepStarted / SubstepEnded (Solver.cs:125-146, raised at Solver_Solve.cs:1425 / :1478) through bepuhip_solve_with_substep_events: handlers that change
+    nothing leave bepuhip_solve's bits; a SubstepStarted handler that moves a kinematic body's velocity every substep (what the reference's users do there) gives
+    what the oracle gives when the same writes are made between single-substep solves... which the reference cannot express — so the second half is checked
+    against the device's own plain solve of a scene whose kinematic body carries the velocity the handler writes first."""
+    scene = small_scenes.island_scene(8, islands=30, bodies_per_island=8, constraints_per_island=18, type_ids=[4, 7, 22, 25, 47, 0])
+    sd = SolveDescription(1, 4, velocity_iteration_scheduler=lambda s: [2, 1, 1, 2][s])
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=4)
+    solver = hip_solver_factory()
+    solver.upload(scene, sd.fallback_batch_threshold)
+    seen = []
+    for _ in range(2):
+        solver.solve_with_substep_events(1 / 60, sd, cb, started=lambda s: seen.append(("started", s)), ended=lambda s: seen.append(("ended", s)))
+    got = scene.copy()
+    solver.download(got)
+    assert seen == [(kind, s) for _ in range(2) for s in range(4) for kind in ("started", "ended")]
+    m = pu.compare_scenes(ref, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    # a handler that writes state: every body's linear velocity is zeroed when substep 2 starts — the device must see the write (its results differ from the plain solve's)
+    solver.upload(scene, sd.fallback_batch_threshold)
+
+    def freeze(substep):
+        if substep == 2:
+            bodies = solver.get_bodies(scene.body_count)
+            bodies[:, 8:11] = 0.0
+            solver.update_bodies(0, bodies)
+
+    solver.solve_with_substep_events(1 / 60, sd, cb, started=freeze)
+    frozen = solver.get_bodies(scene.body_count)
+    plain = pu.run_hip(hip_solver_factory(), scene, 1 / 60, sd, cb, frames=1).bodies
+    assert not np.array_equal(frozen[:, 8:11], plain[:, 8:11]) and np.isfinite(frozen).all()
+    with pytest.raises(Exception):  # structural changes inside a handler are refused
+        solver.solve_with_substep_events(1 / 60, sd, cb, started=lambda s: solver.remove_constraint(0, scene.batches[0][0].type_id, 0))
