@@ -2035,7 +2035,11 @@ int32_t bepuhip_apply_structural_ops(bepuhip_ctx* c, const bepuhip_structural_op
             case 3: st = bepuhip_swap_constraints(c, op.batch_index, op.type_id, op.index, op.slot); break;
             default: st = fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown structural operation kind " + std::to_string(op.kind));
         }
-        if (st != BEPUHIP_OK) { if (failed_op_out) *failed_op_out = i; return st; }
+        if (st != BEPUHIP_OK) {
+            if (failed_op_out) *failed_op_out = i;
+            const std::string why = bepuhip_last_error();
+            return fail(st, "structural operation " + std::to_string(i) + " of " + std::to_string(count) + ": " + why);
+        }
     }
     return BEPUHIP_OK;
 }

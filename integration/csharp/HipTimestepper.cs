@@ -125,7 +125,17 @@ public interface IHipVelocityModel { System.Numerics.Vector3 Gravity { get; } fl
 public interface IHipPerBodyGravityModel { CollidableProperty<float> BodyGravities { get; } }
 public interface IHipRadialGravityModel { System.Numerics.Vector3 PlanetCenter { get; } float Gravity { get; } }
 
-public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IDisposable where TCallbacks : struct, IPoseIntegratorCallbacks
+// [UnmanagedCallersOnly] methods may not live in a generic type: the native side calls these two, which hand the event to the timestepper behind the GCHandle.
+interface IHipSubstepSink { void RaiseStarted(int substep); void RaiseEnded(int substep); }
+static unsafe class HipSubstepTrampoline
+{
+    [UnmanagedCallersOnly(CallConvs = new[] { typeof(System.Runtime.CompilerServices.CallConvCdecl) })]
+    public static void Started(void* user, int substep) => ((IHipSubstepSink)GCHandle.FromIntPtr((IntPtr)user).Target).RaiseStarted(substep);
+    [UnmanagedCallersOnly(CallConvs = new[] { typeof(System.Runtime.CompilerServices.CallConvCdecl) })]
+    public static void Ended(void* user, int substep) => ((IHipSubstepSink)GCHandle.FromIntPtr((IntPtr)user).Target).RaiseEnded(substep);
+}
+
+public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, IDisposable where TCallbacks : struct, IPoseIntegratorCallbacks
 {
     IntPtr ctx;
     bool resident;                                    // the device holds the scene as of the last solve
@@ -153,10 +163,8 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IDisposable where
     /// launch-per-batch kernels substep by substep, handlers in between with the device idle (they may use the update_* calls through Context).
     public event Solver.SubstepEvent SubstepStarted, SubstepEnded;
     public IntPtr Context => ctx;
-    [UnmanagedCallersOnly(CallConvs = new[] { typeof(System.Runtime.CompilerServices.CallConvCdecl) })]
-    static void RaiseStarted(void* user, int substep) => ((HipTimestepper<TCallbacks>)GCHandle.FromIntPtr((IntPtr)user).Target).SubstepStarted?.Invoke(substep);
-    [UnmanagedCallersOnly(CallConvs = new[] { typeof(System.Runtime.CompilerServices.CallConvCdecl) })]
-    static void RaiseEnded(void* user, int substep) => ((HipTimestepper<TCallbacks>)GCHandle.FromIntPtr((IntPtr)user).Target).SubstepEnded?.Invoke(substep);
+    void IHipSubstepSink.RaiseStarted(int substep) => SubstepStarted?.Invoke(substep);
+    void IHipSubstepSink.RaiseEnded(int substep) => SubstepEnded?.Invoke(substep);
 
     public HipTimestepper(int device = 0, bool deviceIsExclusive = false)
     {
@@ -431,7 +439,7 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IDisposable where
         if (SubstepStarted != null || SubstepEnded != null)
         {
             var self = GCHandle.Alloc(this);
-            try { Check(BepuHip.bepuhip_solve_with_substep_events(ctx, dt, solver.SubstepCount, iterations, &integ, &RaiseStarted, &RaiseEnded, (void*)GCHandle.ToIntPtr(self))); }
+            try { Check(BepuHip.bepuhip_solve_with_substep_events(ctx, dt, solver.SubstepCount, iterations, &integ, &HipSubstepTrampoline.Started, &HipSubstepTrampoline.Ended, (void*)GCHandle.ToIntPtr(self))); }
             finally { self.Free(); }
         }
         else Check(BepuHip.bepuhip_solve_async(ctx, dt, solver.SubstepCount, iterations, &integ));

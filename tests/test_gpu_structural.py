@@ -740,3 +740,34 @@ def test_a_frames_changes_reconstructed_from_the_type_batches_and_sent_in_one_ca
     assert sent > 100
     if layout == "launch_per_batch":
         assert solver.schedule() == 0
+
+
+def test_batched_operations_stop_at_the_first_failure_and_say_which(hip_solver_factory):
+    """bepuhip_apply_structural_ops applies its table in order, each operation exactly as the single call: the first failure ends it, is reported with its ordinal,
+    and what came before stays applied (the device equals the oracle on the mirror that took the same operations)."""
+    rng = np.random.default_rng(2)
+    rows = [small_scenes.random_dynamic_body(rng, rng.uniform(-4, 4, 3)) for _ in range(120)]
+    ms = MutableSolver(np.stack(rows))
+    for _ in range(300):
+        a, b = (int(x) for x in rng.choice(120, 2, replace=False))
+        t = [4, 7, 22, 47][int(rng.integers(4))]
+        ms.add(t, [a, b], small_scenes.prestep_for(rng, t, ms.bodies[a, 4:7], ms.bodies[b, 4:7]))
+    sd, cb = SolveDescription(1, 2), PoseIntegratorCallbacks()
+    solver = hip_solver_factory(reserve_update_slots=True)
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+    bi, t, _ = ms.locations()[5]
+    count = len(ms.batches[bi][t]["refs"])
+    lane = small_scenes.prestep_for(rng, t, ms.bodies[0, 4:7], ms.bodies[1, 4:7])
+    with pytest.raises(Exception, match="structural operation 1 of 3"):
+        solver.apply_structural_ops([("remove", bi, t, 0), ("remove", bi, t, count + 7), ("add", bi, t, [0, 1], lane)])
+    ms.remove(bi, t, 0)  # the first operation happened, the third did not
+    assert solver.constraint_count(bi, t) == count - 1
+    solver.apply_structural_ops([("swap", bi, t, 0, 1)])
+    ms.swap(bi, t, 0, 1)
+    export = ms.to_scene()
+    oracle_ffi.solve(export, 1 / 60, sd, cb)
+    solver.solve(1 / 60, sd, cb)
+    got = ms.to_scene()
+    solver.download(got)
+    m = pu.compare_scenes(export, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m

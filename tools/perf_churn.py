@@ -75,23 +75,37 @@ for label, env in (("split plan keeps the updates", {}), ("round 2: updates leav
                 held[r[r < (1 << 30)]] = True
         return ops
 
-    def apply(ops):
+    def apply(ops):  # ONE bepuhip_apply_structural_ops call (round 4); BATCHED=0: round 3's call per operation through ctypes
+        if os.environ.get("BATCHED", "1") == "0":
+            for bi, t, what, p in ops:
+                if p is None:
+                    solver.remove_constraint(bi, t, what)
+                else:
+                    solver.add_constraint(bi, t, what, p)
+            return 0.0
+        rows, words, at = [], [], 0
         for bi, t, what, p in ops:
             if p is None:
-                solver.remove_constraint(bi, t, what)
+                rows.append((1, bi, t, what, 0, 0, 0, 0))
             else:
-                solver.add_constraint(bi, t, what, p)
+                rows.append((0, bi, t, -1, 0, 0, at, 0))
+                words += [np.ascontiguousarray(what, dtype=np.int32).view(np.uint32), np.ascontiguousarray(p, dtype=np.float32).view(np.uint32)]
+                at += what.size + p.size
+        table, payload = np.asarray(rows, dtype=np.int32), np.concatenate(words)
+        t0 = time.perf_counter()
+        solver.apply_structural_op_table(table, payload)
+        return 1e3 * (time.perf_counter() - t0)
 
     constrained = np.zeros(scene.body_count + 1, dtype=bool)
     for held in in_batch:
         constrained |= held
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     apply(churn()); solver.solve(1 / 60, sd, cb)
-    frame_ms = calls_ms = 0.0
+    frame_ms = calls_ms = call_ms = 0.0
     for _ in range(frames):
         ops = churn()
         t0 = time.perf_counter()
-        apply(ops)
+        call_ms += apply(ops) / frames
         t1 = time.perf_counter()
         solver.solve(1 / 60, sd, cb)  # flushes the updates, then solves
         calls_ms += 1e3 * (t1 - t0) / frames
@@ -102,7 +116,7 @@ for label, env in (("split plan keeps the updates", {}), ("round 2: updates leav
     solver.sync()
     solve_ms = 1e3 * (time.perf_counter() - t0) / 50
     finite = bool(np.isfinite(solver.get_bodies(scene.body_count)).all())
-    print(f"{name}, {label}: {calls} structural calls per frame {calls_ms:.2f} ms (through ctypes), the flush + solve that follows {frame_ms:.3f} ms; the solve alone afterwards {solve_ms:.4f} ms; "
+    print(f"{name}, {label}: {calls} structural operations per frame {calls_ms:.2f} ms with the table built in Python, {call_ms:.2f} ms inside the one bepuhip_apply_structural_ops call; the flush + solve that follows {frame_ms:.3f} ms; the solve alone afterwards {solve_ms:.4f} ms; "
           f"clusters {solver.cluster_cycles().size}; finite {finite}", flush=True)
     if solver.schedule() == 0:  # what bepuhip_replan costs and gives back
         t0 = time.perf_counter()
