@@ -31,7 +31,13 @@ const void* bepu_cluster_kernel_wide_1024p(bool trace);
 const void* bepu_cluster_kernel_hot_512sp(bool trace);   // ... split-island plans at 512
 const void* bepu_cluster_kernel_wide_512sp(bool trace);
 constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
-static int cluster_variant_threads(int threads) { return threads > 768 ? 1024 : (threads > 512 ? 768 : 512); }  // the smallest budget that still fits `threads`
+// The smallest register budget that still fits `threads`; BEPUHIP_CLUSTER_VARIANT (experiments) asks for a tighter one, e.g. the 1024-thread build's 128 VGPRs for
+// 512-thread workgroups, so that two of them are resident per CU.
+static int cluster_variant_threads(int threads) {
+    static const int forced = [] { const char* v = getenv("BEPUHIP_CLUSTER_VARIANT"); return v && *v ? atoi(v) : 0; }();
+    const int fit = threads > 768 ? 1024 : (threads > 512 ? 768 : 512);
+    return (forced == 1024 || forced == 768 || forced == 512) && forced >= fit ? forced : fit;
+}
 // The conserving units exist for the default workgroup sizes only; other sizes (BEPUHIP_CLUSTER_THREADS / BEPUHIP_SPLIT_THREADS) keep such solves on the launch-per-batch schedule.
 static bool conserving_variant_exists(int threads, bool shared) { return cluster_variant_threads(threads) == (shared ? 512 : 1024); }
 static const void* cluster_pass_kernel(bool wide, bool shared) {  // (for the default workgroup sizes, like the conserving units)

@@ -18,7 +18,7 @@ its = scene.constraint_count * int((1 + sd.iterations()).sum())
 
 
 def run(label, env, steps=int(os.environ.get('STEPS', '400')), use_clusters=True, use_graph=True):
-    for k in ("BEPUHIP_DEBUG", "BEPUHIP_CLUSTER_BODIES", "BEPUHIP_CLUSTER_THREADS"):
+    for k in ("BEPUHIP_DEBUG", "BEPUHIP_CLUSTER_BODIES", "BEPUHIP_CLUSTER_THREADS", "BEPUHIP_CLUSTER_VARIANT"):
         os.environ.pop(k, None)
     os.environ.update(env)
     s = HipSolver(use_clusters=use_clusters, use_graph=use_graph)
@@ -51,6 +51,18 @@ for cfg in configs:
     elif cfg == "waves":
         for thr in (512, 768, 1024, 512, 768, 1024):
             run(f"threads={thr}", {"BEPUHIP_CLUSTER_THREADS": str(thr)})
+    elif cfg == "coresident":
+        # Several smaller workgroups per CU instead of one: the register budget is the 1024-thread build's (128 VGPRs) or the 512-thread build's (170),
+        # the LDS follows the cluster size. BEPUHIP_CLUSTER_VARIANT is read once per process: one child process per line.
+        import subprocess
+        per_ragdoll = 16  # bodies of one ragdoll: clusters hold whole ragdolls
+        base = (ragdolls * per_ragdoll + 247) // 248
+        for div, thr, variant in ((1, 1024, 1024), (2, 512, 1024), (2, 512, 512), (2, 1024, 1024), (3, 384, 1024), (4, 256, 1024), (4, 256, 512), (4, 512, 1024), (8, 128, 1024), (8, 256, 1024)):
+            cap = max(per_ragdoll, (base // div + per_ragdoll - 1) // per_ragdoll * per_ragdoll)
+            env = dict(os.environ, BEPUHIP_CLUSTER_BODIES=str(cap), BEPUHIP_CLUSTER_THREADS=str(thr), BEPUHIP_CLUSTER_VARIANT=str(variant), LABEL=f"1/{div} cluster ({cap} bodies), {thr} threads, {variant} budget")
+            subprocess.call([sys.executable, os.path.abspath(__file__), "one"], env=env)
+    elif cfg == "one":
+        run(os.environ["LABEL"], {k: os.environ[k] for k in ("BEPUHIP_CLUSTER_BODIES", "BEPUHIP_CLUSTER_THREADS", "BEPUHIP_CLUSTER_VARIANT")})
     elif cfg == "sizes":
         for cap in (256, 480, 700, 960, 1400):
             for thr in (256, 512):
