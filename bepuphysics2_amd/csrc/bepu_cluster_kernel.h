@@ -238,6 +238,24 @@ __device__ __forceinline__ void store_agent_pair(float4* p, float4 a, float4 b) 
     agent_f4 x = {a.x, a.y, a.z, a.w}, y = {b.x, b.y, b.z, b.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(p), "v"(x), "v"(y) : "memory");
 }
+// Records travel as lane pairs. A lone 16-byte agent-scope access is a request of its own on the memory side (rocprofv3 tallies 64 bytes for it; two per record and
+// lane: tools/probes/write_size_probe.hip, profiles/r04_s12_write_size_probe.txt), while two neighbouring lanes that touch the two halves of ONE record with one
+// instruction make one 32-byte request. So lanes 2k and 2k + 1 serve each other: the first instruction moves the record of the pair's even lane (the even lane its
+// first half, the odd lane its second half), the second instruction the odd lane's record, and the halves change lanes through DPP (quad_perm [1,0,3,2]; every lane
+// of the wave is enabled wherever these are called: inactive lanes carry data, not a cleared EXEC bit).
+__device__ __forceinline__ int swap_neighbour(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ float swap_neighbour(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ void load_agent_two(const float4* p, const float4* q, float4& a, float4& b) {  // *p and *q, one round trip
+    agent_f4 x, y;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x), "=&v"(y) : "v"(p), "v"(q) : "memory");
+    a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w);
+}
+__device__ __forceinline__ void load_agent_four(const float4* p, const float4* q, const float4* r, const float4* t, float4& a, float4& b, float4& c, float4& d) {
+    agent_f4 x, y, z, u;
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(u) : "v"(p), "v"(q), "v"(r), "v"(t) : "memory");
+    a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w); c = make_float4(z.x, z.y, z.z, z.w); d = make_float4(u.x, u.y, u.z, u.w);
+}
 // A shared body's record: {linear xyz, event number} {angular xyz, event number}. The event number (the count of events of this step that have happened on
 // the body, see SharedTables) travels IN the record: the reader's poll returns the velocity together with the news that it is the one it waits for — one
 // memory round trip per hand-off instead of three (poll a counter, fetch the velocity; store, drain, bump the counter). Every event rewrites both halves
@@ -269,23 +287,40 @@ __device__ __forceinline__ SharedRef make_shared_ref(const ClusterShared& sh, un
 __device__ __forceinline__ float4* shared_record(const SharedTables& st, int body, unsigned substep) { return st.vel + ((size_t)body * 2 + (substep & 1u)) * 2; }
 // Per-lane: poll the records of up to two shared bodies until each shows event number >= want (both halves equal), leaving their velocities in A / B.
 // Lanes without a shared body pass at once. Bounded like every other wait of this kernel.
+// Where the two accesses of a lane go when the pair serves `body` (this lane's) and the neighbour's: first the record of the pair's even lane, then the odd lane's;
+// an even lane touches first halves, an odd lane second halves.
+__device__ __forceinline__ void pair_addresses(const SharedTables& st, int body, unsigned substep, bool odd, float4*& first, float4*& second) {
+    const int theirs = swap_neighbour(body);
+    first = shared_record(st, odd ? theirs : body, substep) + (odd ? 1 : 0);
+    second = shared_record(st, odd ? body : theirs, substep) + (odd ? 1 : 0);
+}
+// ... and what came back: the lane's own record is the half it loaded itself plus the half its neighbour loaded for it.
+__device__ __forceinline__ void pair_route(bool odd, const float4& first, const float4& second, float4& l, float4& w) {
+    const float4 send = odd ? first : second;
+    const float4 got = make_float4(swap_neighbour(send.x), swap_neighbour(send.y), swap_neighbour(send.z), swap_neighbour(send.w));
+    l = odd ? got : first; w = odd ? second : got;
+}
 template <bool TWO>
 __device__ __forceinline__ void acquire_shared(const ClusterShared& sh, const SharedRef& ra, DBody& A, const SharedRef& rb, DBody& B, int kind, int k) {
     bool need_a = ra.poll, need_b = TWO && rb.poll;
     if (__builtin_amdgcn_ballot_w64(need_a || need_b) == 0) return;
+    const bool odd = (threadIdx.x & 1u) != 0u;
     const unsigned want_a = ra.number, want_b = rb.number;
-    const float4* pa = shared_record(sh.st, need_a ? ra.body : 0, sh.events - 1u);  // during the sweeps of substep s events == s + 1; the incremental update
-    const float4* pb = shared_record(sh.st, need_b ? rb.body : 0, sh.events - 1u);  // of substep s runs while events is still s: the record of substep s - 1
+    const unsigned record = sh.events - 1u;  // during the sweeps of substep s events == s + 1; the incremental update of substep s runs while events is still s: the record of substep s - 1
     unsigned spins = 0;
     for (;;) {
-        float4 l, w;
-        if (need_a) {
-            load_agent_pair(pa, l, w);
-            if (__float_as_uint(l.w) == __float_as_uint(w.w) && __float_as_uint(l.w) >= want_a) { A.vel.lin = {l.x, l.y, l.z}; A.vel.ang = {w.x, w.y, w.z}; need_a = false; }
-        }
-        if (TWO && need_b) {
-            load_agent_pair(pb, l, w);
-            if (__float_as_uint(l.w) == __float_as_uint(w.w) && __float_as_uint(l.w) >= want_b) { B.vel.lin = {l.x, l.y, l.z}; B.vel.ang = {w.x, w.y, w.z}; need_b = false; }
+        // (a lane that has what it waits for keeps loading for its neighbour; with nothing to load for either, record 0: one request for all such lanes)
+        float4 *a1, *a2, *b1, *b2, xa1, xa2, xb1, xb2, l, w;
+        pair_addresses(sh.st, need_a ? ra.body : 0, record, odd, a1, a2);
+        if (TWO) {
+            pair_addresses(sh.st, need_b ? rb.body : 0, record, odd, b1, b2);
+            load_agent_four(a1, a2, b1, b2, xa1, xa2, xb1, xb2);
+        } else load_agent_two(a1, a2, xa1, xa2);
+        pair_route(odd, xa1, xa2, l, w);
+        if (need_a && __float_as_uint(l.w) == __float_as_uint(w.w) && __float_as_uint(l.w) >= want_a) { A.vel.lin = {l.x, l.y, l.z}; A.vel.ang = {w.x, w.y, w.z}; need_a = false; }
+        if (TWO) {
+            pair_route(odd, xb1, xb2, l, w);
+            if (need_b && __float_as_uint(l.w) == __float_as_uint(w.w) && __float_as_uint(l.w) >= want_b) { B.vel.lin = {l.x, l.y, l.z}; B.vel.ang = {w.x, w.y, w.z}; need_b = false; }
         }
         const unsigned long long late = __builtin_amdgcn_ballot_w64(need_a || need_b);
         if (late == 0) break;
@@ -299,9 +334,17 @@ __device__ __forceinline__ void acquire_shared(const ClusterShared& sh, const Sh
     }
 }
 __device__ __forceinline__ void release_shared(const ClusterShared& sh, const SharedRef& r, const DBody& b) {
-    if (!r.publish) return;
-    const float n = __uint_as_float(r.number + 1u);
-    store_agent_pair(shared_record(sh.st, r.body, sh.events - 1u), make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, n), make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, n));
+    if (__builtin_amdgcn_ballot_w64(r.publish) == 0) return;
+    const bool odd = (threadIdx.x & 1u) != 0u;
+    const int mine = r.publish ? r.body : -1, theirs = swap_neighbour(mine);
+    const float n = __uint_as_float(r.number + 1u), their_n = swap_neighbour(n);
+    // an even lane hands the angular half of its record to its odd neighbour, an odd lane the linear half of its record to its even neighbour
+    const float gx = swap_neighbour(odd ? b.vel.lin.x : b.vel.ang.x), gy = swap_neighbour(odd ? b.vel.lin.y : b.vel.ang.y), gz = swap_neighbour(odd ? b.vel.lin.z : b.vel.ang.z);
+    const int first_body = odd ? theirs : mine, second_body = odd ? mine : theirs;  // the record of the pair's even lane, then the odd lane's
+    const float4 first = odd ? make_float4(gx, gy, gz, their_n) : make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, n);
+    const float4 second = odd ? make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, n) : make_float4(gx, gy, gz, their_n);
+    if (first_body >= 0) store_agent_f4(shared_record(sh.st, first_body, sh.events - 1u) + (odd ? 1 : 0), first);
+    if (second_body >= 0) store_agent_f4(shared_record(sh.st, second_body, sh.events - 1u) + (odd ? 1 : 0), second);
 }
 // One lane, one record (integration phases): wait for event number >= want, return the velocity.
 __device__ __forceinline__ void acquire_shared_one(const SharedTables& st, unsigned* status, int body, unsigned substep, unsigned want, float4& l, float4& w, int kind, int slot) {
