@@ -228,15 +228,20 @@ __device__ __forceinline__ void load_agent_pose_inertia(const float4* body, floa
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(body) : "memory");
     q = make_float4(a.x, a.y, a.z, a.w); pos = make_float4(b.x, b.y, b.z, b.w); w0 = make_float4(c.x, c.y, c.z, c.w); w1 = make_float4(d.x, d.y, d.z, d.w);
 }
+// The compiler's hazard recognizer does not look inside an asm statement. A VMEM store of more than 64 bits reads its data registers after it has issued: gfx940+
+// wants two wait states before a VALU instruction may overwrite them (LLVM's GCNHazardRecognizer inserts them behind its own stores), so the asm stores carry an
+// `s_nop 1` themselves. Without it the instruction after the statement can change the record's first word before the store has read it: round 4's paired records
+// happened to be followed, one scalar instruction later, by a `v_cndmask v0, 0, 1` — the crowd test read 0.0 / 1.0 velocities out of records
+// (tools/probes/pair_pingpong_probe.hip shows the same with a store followed by a `v_add_f32` on its first data register: a quarter of all accepted records wrong).
 __device__ __forceinline__ void store_agent_f4(float4* p, float4 v) {
     agent_f4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned load_seq(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_agent_pair(float4* p, float4 a, float4 b) {
     agent_f4 x = {a.x, a.y, a.z, a.w}, y = {b.x, b.y, b.z, b.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(p), "v"(x), "v"(y) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1" ::"v"(p), "v"(x), "v"(y) : "memory");
 }
 // Records travel as lane pairs. A lone 16-byte agent-scope access is a request of its own on the memory side (rocprofv3 tallies 64 bytes for it; two per record and
 // lane: tools/probes/write_size_probe.hip, profiles/r04_s12_write_size_probe.txt), while two neighbouring lanes that touch the two halves of ONE record with one
