@@ -128,6 +128,9 @@ def hbm_roofline(kernel: str, launch_us: float, traffic_bytes, algorithmic_bytes
         out["memory_stream_GBs"] = stream_bytes / seconds / 1e9
         out["traffic_over_compulsory_stream"] = traffic_bytes / stream_bytes if traffic_bytes else None
     out.update(extra)
+    issue = (extra.get("traffic_detail") or {}).get("issue") if isinstance(extra.get("traffic_detail"), dict) else None
+    if issue:  # the other ceiling, from the same run's SQ counters: the share of the chip's VALU issue cycles the launch used (`frac` stays the bandwidth fraction)
+        out["valu_busy"] = issue["valu_busy"]
     return out
 
 
@@ -469,31 +472,49 @@ def measure_traffic(args, scene_key: str = "main"):
         return None
     out = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        dominant = None
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE")):
             d = tempfile.mkdtemp(prefix="bepu_pmc_", dir="/tmp")
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BEPU_BENCH_FORCE_DIST")}
             env["TMPDIR"] = "/tmp"
-            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+            cmd = ["rocprofv3", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "3", "--warmup", "1", "--ragdolls", str(args.ragdolls), "--no-cpu-baseline", "--no-traffic", "--no-prewarm", "--traffic-child", scene_key]
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            done = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=counters[0] != "SQ_ACTIVE_INST_VALU")
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             per_kernel = {}
             for f in files:
                 for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == counter:
-                        k = r["Kernel_Name"]
-                        a = per_kernel.setdefault(k, [0.0, 0])
+                    if r["Counter_Name"] in counters:
+                        a = per_kernel.setdefault((r["Kernel_Name"], r["Counter_Name"]), [0.0, 0])
                         a[0] += float(r["Counter_Value"])
                         a[1] += 1
             shutil.rmtree(d, ignore_errors=True)
+            if counters[0] == "SQ_ACTIVE_INST_VALU":  # what the instruction issue looks like next to the bytes (optional: a failed pass leaves the traffic figures standing)
+                sq = {c: per_kernel[(dominant, c)][0] / per_kernel[(dominant, c)][1] for c in counters if (dominant, c) in per_kernel}
+                if done.returncode == 0 and len(sq) == len(counters):
+                    out["SQ"] = sq
+                continue
             dom = max(per_kernel.items(), key=lambda kv: kv[1][0]) if per_kernel else None
             if dom is None:
                 return None
-            out[counter] = {"kernel": dom[0][:80], "KiB_per_launch": dom[1][0] / dom[1][1]}
+            dominant = dominant or dom[0][0]
+            out[counters[0]] = {"kernel": dom[0][0][:80], "KiB_per_launch": dom[1][0] / dom[1][1]}
         fetch = out["FETCH_SIZE"]["KiB_per_launch"] * 1024.0
         write = out["WRITE_SIZE"]["KiB_per_launch"] * 1024.0
-        return {"bytes_per_launch": 2.0 * fetch + write, "fetch_bytes_raw": fetch, "fetch_bytes_gfx950_corrected": 2.0 * fetch, "write_bytes": write,
-                "kernel": out["FETCH_SIZE"]["kernel"], "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950)"}
+        result = {"bytes_per_launch": 2.0 * fetch + write, "fetch_bytes_raw": fetch, "fetch_bytes_gfx950_corrected": 2.0 * fetch, "write_bytes": write,
+                  "kernel": out["FETCH_SIZE"]["kernel"], "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950); WRITE_SIZE as reported "
+                  "(calibrated on this kernel's stores, profiles/r04_s12_write_size_probe.txt: exact for coalesced rows and for records written as lane pairs, 64 B per lone 16-byte store)"}
+        if "SQ" in out:
+            # All four are sums over the chip: SQ_* in quad-cycles over all waves, GRBM_GUI_ACTIVE in cycles over the 8 XCDs (value / 8 / launch time = the shader clock).
+            import torch
+            xcds, simds = 8, 4 * torch.cuda.get_device_properties(0).multi_processor_count
+            sq = out["SQ"]
+            simd_quad_cycles = sq["GRBM_GUI_ACTIVE"] / xcds / 4.0 * simds
+            result["issue"] = {"valu_busy": sq["SQ_ACTIVE_INST_VALU"] / simd_quad_cycles, "waves_per_simd": sq["SQ_WAVE_CYCLES"] / simd_quad_cycles,
+                               "wave_time_waiting": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], "cycles_per_launch": sq["GRBM_GUI_ACTIVE"] / xcds,
+                               "method": "rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE (own pass); valu_busy = VALU-issuing quad-cycles of all "
+                                         "waves / quad-cycles the chip's SIMDs offer during the launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs)"}
+        return result
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)[:200]}
 

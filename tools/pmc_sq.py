@@ -1,6 +1,6 @@
 """What bounds a kernel when it is not bytes: the SQ counters of the dominant kernel of a command (GPU box). Two rocprofv3 --pmc passes (8 SQ slots each, no tracing
 alongside), averaged per launch, and the fractions MI355X_MICROARCH.md's PMC section defines: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles),
-VALU busy = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x GRBM_GUI_ACTIVE). Usage: python tools/pmc_sq.py [--kernel SUBSTRING] -- <command ...>"""
+VALU busy = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x GRBM_GUI_ACTIVE / 8 XCDs). Usage: python tools/pmc_sq.py [--kernel SUBSTRING] -- <command ...>"""
 import csv
 import glob
 import os
@@ -43,10 +43,11 @@ cus = int(os.environ.get("CUS", "256"))
 gui = values.get("GRBM_GUI_ACTIVE", 0.0)
 wave = values.get("SQ_WAVE_CYCLES", 0.0)
 if gui and wave:
-    simd_quads = gui / 4.0 * cus * 4  # quad-cycles all SIMDs of the chip offer during the launch
+    xcds = int(os.environ.get("XCDS", "8"))
+    simd_quads = gui / xcds / 4.0 * cus * 4  # quad-cycles all SIMDs of the chip offer during the launch (GRBM_GUI_ACTIVE is summed over the XCDs: value / 8 / launch time = the shader clock)
     print(f"  waves resident per SIMD (SQ_WAVE_CYCLES / SIMD quad-cycles)      {wave / simd_quads:.2f}")
     for name in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
         if name in values:
             print(f"  {name} / SQ_WAVE_CYCLES {values[name] / wave:6.3f}    per SIMD: {values[name] / simd_quads:6.3f} of its cycles")
     if "SQ_INSTS_VALU" in values:
-        print(f"  VALU instructions per launch {values['SQ_INSTS_VALU']:.0f}; x 4 cycles / (SIMDs x cycles) = {values['SQ_INSTS_VALU'] * 4 / (gui * cus * 4):.3f} of the chip's VALU issue slots ({cus} CUs)")
+        print(f"  VALU instructions per launch {values['SQ_INSTS_VALU']:.0f}; x 4 cycles / (SIMDs x cycles) = {values['SQ_INSTS_VALU'] * 4 / (gui / xcds * cus * 4):.3f} of the chip's VALU issue slots ({cus} CUs)")
