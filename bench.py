@@ -503,7 +503,8 @@ def measure_traffic(args, scene_key: str = "main"):
         write = out["WRITE_SIZE"]["KiB_per_launch"] * 1024.0
         result = {"bytes_per_launch": 2.0 * fetch + write, "fetch_bytes_raw": fetch, "fetch_bytes_gfx950_corrected": 2.0 * fetch, "write_bytes": write,
                   "kernel": out["FETCH_SIZE"]["kernel"], "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950); WRITE_SIZE as reported "
-                  "(calibrated on this kernel's stores, profiles/r04_s12_write_size_probe.txt: exact for coalesced rows and for records written as lane pairs, 64 B per lone 16-byte store)"}
+                  "(calibrated on this kernel's stores, profiles/r04_s12_write_size_probe.txt: exact for coalesced rows and for records written as lane pairs, 64 B per lone 16-byte store; r04_s18_access_size_probe.txt: a record poll is one 64-byte request, "
+                  "which the x2 books at 128 — on split plans `traffic` therefore overstates what crosses the fabric by the polls' raw bytes)"}
         if "SQ" in out:
             # All four are sums over the chip: SQ_* in quad-cycles over all waves, GRBM_GUI_ACTIVE in cycles over the 8 XCDs (value / 8 / launch time = the shader clock).
             import torch
