@@ -86,3 +86,33 @@ def test_csharp_binding_is_one_text_and_covers_every_entry_point_of_the_header()
             return n
 
         assert arity(args) == arity(declared), (call, args, declared)
+
+
+def test_asm_stores_carry_their_own_wait_states():
+    """A VMEM store of more than 64 bits reads its data registers after it has issued; gfx940+ wants two wait states before a VALU instruction overwrites them, and the
+    compiler's hazard recognizer does not look inside asm statements (paired records turned into garbage until the stores got an `s_nop 1`). Every asm
+    statement of the kernels that stores 96 or 128 bits must therefore end in `s_nop 1` (or more) behind its last store."""
+    import re
+    csrc = os.path.join(REPO, "bepuphysics2_amd", "csrc")
+    wide_store = re.compile(r"(global|buffer|flat|scratch)_store_dwordx[34]")
+    found = 0
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".h", ".hip", ".inc")):
+            continue
+        text = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r"asm\s+volatile\s*\(", text):
+            depth, end = 0, m.end() - 1
+            for end in range(m.end() - 1, len(text)):  # the statement's closing parenthesis
+                depth += text[end] == "("
+                depth -= text[end] == ")"
+                if depth == 0:
+                    break
+            statement = text[m.start():end]
+            stores = list(wide_store.finditer(statement))
+            if not stores:
+                continue
+            found += 1
+            tail = statement[stores[-1].end():]
+            nop = re.search(r"s_nop\s+(\d+)", tail)
+            assert nop and int(nop.group(1)) >= 1, f"{name}: an asm store of more than 64 bits without two wait states behind it: {statement[:160]!r}"
+    assert found >= 2  # store_agent_f4, store_agent_pair
