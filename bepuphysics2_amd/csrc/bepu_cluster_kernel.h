@@ -69,7 +69,6 @@ struct ClusterShared {
     unsigned events;       // integration events every shared body has seen so far (substep index + 1 during the sweeps of a substep)
     unsigned passes;       // passes (warm starts + velocity iterations) completed before the current one, over the whole step
     int code_touch;        // see touch_code_ahead
-    int row_touch;         // see touch_next_rows
     unsigned jitter;       // schedule fuzzing (BEPUHIP_DEBUG_JITTER, 0 = off): see jitter_nap
     unsigned scratch_row;  // LDS byte address of the 256-byte row that swallows the code-touch reads
     // kConserving units only:
@@ -748,63 +747,6 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
 #undef BEPU_CASE
 }
 
-// Row touch (round 4): the rows of a work item come from the memory side once per pass (a scene's rows do not fit the XCD's L2), and the first items of a sweep
-// — and the contact items of the incremental update that precedes a substep's sweeps — pay that latency with nothing to hide it behind: every wave of the cluster has
-// just left a barrier. A wave that has run out of items at the end of a sweep therefore asks for the rows it is likely to want next while it waits for the chain's tail:
-// one LDS-DMA instruction per item in which lane l reads a dword of the l-th 128-byte line of the item's rows (plane l / 2, first or second half of the item's lanes);
-// the dwords land in the scratch row nobody reads, the lines in L2. Nothing waits for it (the barriers of this kernel wait for LDS, not for vector memory), no result
-// depends on it. BEPUHIP_ROW_TOUCH=0 turns it off.
-template <bool WIDE>
-__device__ __forceinline__ void item_row_counts(int type_id, int& bodies, int& prestep_floats, int& impulse_floats) {
-    bodies = 0; prestep_floats = 0; impulse_floats = 0;
-#define BEPU_CASE(ID, F) case ID: bodies = F::bodies; prestep_floats = F::prestepFloats; impulse_floats = F::impulseFloats; break;
-    switch (type_id) {
-        BEPU_CASE(kContact1OneBody, DC1O) BEPU_CASE(kContact2OneBody, DC2O) BEPU_CASE(kContact3OneBody, DC3O) BEPU_CASE(kContact4OneBody, DC4O)
-        BEPU_CASE(kContact1, DC1T) BEPU_CASE(kContact2, DC2T) BEPU_CASE(kContact3, DC3T) BEPU_CASE(kContact4, DC4T)
-        BD_HOT_JOINT_TYPES(BEPU_CASE)
-        default:
-            if constexpr (WIDE) {
-                switch (type_id) {
-                    BD_NONCONVEX_CONTACT_TYPES(BEPU_CASE)
-                    BD_WIDENED_JOINT_TYPES(BEPU_CASE)
-                    BD_MANY_BODY_TYPES(BEPU_CASE)
-                    default: break;
-                }
-            }
-            break;
-    }
-#undef BEPU_CASE
-}
-template <bool WIDE, bool SHARED>
-__device__ __forceinline__ void touch_item_rows(const ClusterShared& sh, const ItemHeader& h, int lane, const unsigned* slab, bool with_impulses) {
-    int nb, pf, imf;
-    item_row_counts<WIDE>(h.type_id, nb, pf, imf);
-    const int lref_rows = (nb + 1) / 2 + (SHARED ? nb : 0);  // local references two per word; split plans: a rank word per body behind them
-    const int planes = lref_rows + pf + (with_impulses ? imf : 0);
-    const unsigned scratch = (unsigned)__builtin_amdgcn_readfirstlane((int)sh.scratch_row);
-    for (int base = 0; base < 2 * planes; base += 64) {
-        const int line = base + lane, plane = line >> 1, half = line & 1;
-        if (plane < planes && half * 32 < h.count) {
-            const unsigned row = plane < lref_rows ? h.lrefs_off + (unsigned)plane * (unsigned)h.stride
-                               : plane < lref_rows + pf ? h.prestep_off + (unsigned)(plane - lref_rows) * (unsigned)h.stride
-                                                        : h.accum_off + (unsigned)(plane - lref_rows - pf) * (unsigned)h.stride;
-            glds_dword(slab + row + (unsigned)h.start + (unsigned)(half * 32), scratch);
-        }
-    }
-}
-// What a wave asks for when a sweep has no more items for it: the item of the next sweep it would claim if the waves claimed in order (`with_impulses`), and, when the
-// next thing is a substep boundary, the contact items whose depths it will update there (prestep rows only).
-template <bool WIDE, bool SHARED>
-__device__ __forceinline__ void touch_next_rows(const ClusterShared& sh, int item_count, int lane, int wave, int nwaves, const unsigned* slab, bool substep_boundary) {
-    if (!sh.row_touch) return;
-    if (substep_boundary)
-        for (int k = wave; k < item_count; k += nwaves) {
-            const ItemHeader h = read_item(sh.items + k);
-            if (isContactType(h.type_id)) touch_item_rows<WIDE, SHARED>(sh, h, lane, slab, false);
-        }
-    if (wave < item_count) touch_item_rows<WIDE, SHARED>(sh, read_item(sh.items + wave), lane, slab, true);
-}
-
 // A sweep over the cluster's batches (Solver_Solve.cs:1447-1476 for the cluster's islands): the items of a WarmStart pass (epoch `epoch`) followed,
 // when `solve_items` > 0, by the items of the first velocity iteration (epoch + 1) in ONE claim sequence. No barrier separates the two: a Solve item
 // waits for its same-pass predecessors and, for the bodies it is the first to touch, for their last toucher of the warm start (cross-pass
@@ -892,7 +834,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.st = shared_tables; sh.events = 0; sh.passes = 0;
     int* slot_body_lds = reinterpret_cast<int*>(words + ((cluster_sync_words(max_items) + 3) / 4) * 4);  // SHARED plans: behind the sync words
     sh.slot_body = slot_body_lds;
-    sh.code_touch = cp.code_touch; sh.jitter = cp.jitter; sh.row_touch = cp.row_touch;
+    sh.code_touch = cp.code_touch; sh.jitter = cp.jitter;
     sh.substep = 0; sh.angular_mode = cp.sp.angular_mode; sh.substep_dt = cp.sp.dt; sh.plane_count = cp.planes; sh.bodies = bodies;
     sh.scratch_row = lds_address((const volatile lds_u32*)lds) + (unsigned)cluster_lds_core_bytes(cp.planes, ncap, max_items, SHARED);
     const ClusterDesc cd = clusters[blockIdx.x];
@@ -1035,14 +977,12 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         claim_base += cd.item_count + fused + nwaves;  // every wave makes exactly one failing claim per sweep
         sh.passes += fused ? 2u : 1u;
         if (fused) ++epoch;
-        if (cp.iters[s] > 1 || s + 1 < cp.substeps) touch_next_rows<WIDE, SHARED>(sh, cd.item_count, lane, wave, nwaves, slab, cp.iters[s] <= 1);
         __syncthreads();
         for (int iter = 1; iter < cp.iters[s]; ++iter) {
             ++epoch;
             run_cluster_sweep<kStageSolve, TRACE, WIDE, SHARED>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
             claim_base += cd.item_count + nwaves;
             sh.passes += 1u;
-            if (iter + 1 < cp.iters[s] || s + 1 < cp.substeps) touch_next_rows<WIDE, SHARED>(sh, cd.item_count, lane, wave, nwaves, slab, iter + 1 >= cp.iters[s]);
             __syncthreads();
         }
     }

@@ -86,7 +86,6 @@ struct ClusterParams {
     int planes;  // kSweepPlanes or kAllPlanes
     int code_touch;     // 8 KB spans of its own upcoming code a wave pulls into L2 at the start of every work item (0: off), see touch_code_ahead
     unsigned jitter;    // schedule fuzzing seed (BEPUHIP_DEBUG_JITTER; 0 = off): pseudo-random naps around every item's wait and publish, see jitter_nap
-    int row_touch;      // a wave without items left asks for the rows it will want after the coming barrier (0: off, BEPUHIP_ROW_TOUCH), see touch_next_rows
     int iters[kMaxClusterSubsteps];
     int pass_stage, pass_substep;  // the one-sweep-per-launch units (kPass): kStageWarmStart or kStageSolve, and the substep the sweep belongs to
     int fallback_batch;            // index of the sequential fallback batch (its items may depend on items of their own batch), -1 if the scene has none

@@ -1007,7 +1007,6 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             cp.code_touch = candidate == 2 ? 1 : 0;
             if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(kCodeTouchMaxSpans, forced);  // never beyond the padding behind the unit's kernels
             cp.jitter = debug_jitter_seed();
-            cp.row_touch = env_int("BEPUHIP_ROW_TOUCH", 1);
             const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, conserving);  // the register budget that matches the workgroup size
             if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
             const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
