@@ -526,6 +526,14 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const bool split_stats = env_int("BEPUHIP_PLAN_STATS", 0) >= 2;
+    auto split_t0 = std::chrono::steady_clock::now();
+    auto split_lap = [&](const char* what) {
+        if (!split_stats) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "bepuhip plan_split_clusters: %-44s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - split_t0).count());
+        split_t0 = now;
+    };
     // adjacency of dynamic bodies (CSR), degree d per body
     std::vector<uint8_t> is_dyn(universe, 0);
     std::vector<int32_t> deg(universe, 0);
@@ -596,6 +604,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         }
     }
     if (nclusters > cus) return;
+    split_lap("adjacency, regions");
     // Smooth the regions' surfaces (BEPUHIP_SPLIT_REFINE = sweeps, default 2; 0 = off). A body moves to the neighbouring region that holds more of its constraint
     // partners than its own does (ties stay), as long as no region leaves [7/8, 9/8] of the target size: fewer crossing constraints for the same regions.
     if (const int sweeps = env_int("BEPUHIP_SPLIT_REFINE", 2)) {
@@ -627,6 +636,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             if (moved == 0) break;
         }
     }
+    split_lap("refine sweeps");
     // ---- constraints -> clusters, shared bodies, per-pass rank of every application on a shared body (type batches are in batch order) ----
     std::vector<std::vector<int32_t>> cl_of_constraint(c->tbs.size());
     std::vector<uint8_t> shared(universe, 0);
@@ -651,12 +661,14 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         for (int v = 0; v < universe; ++v) if (crossing[v] > 0) order.push_back(v);
         std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return crossing[x] > crossing[y]; });
         // greedy cover in one sweep: a body enters the cover if one of its crossing constraints is still uncovered (its other body is not in the cover yet)
-        std::vector<std::vector<int32_t>> across(universe);
-        for_each_crossing([&](int32_t a, int32_t b) { across[a].push_back(b); across[b].push_back(a); });
+        std::vector<int32_t> across_begin(universe + 1, 0);  // the other bodies of every body's crossing constraints (CSR)
+        for (int v = 0; v < universe; ++v) across_begin[v + 1] = across_begin[v] + crossing[v];
+        std::vector<int32_t> across(across_begin[universe]), fill(across_begin.begin(), across_begin.end() - 1);
+        for_each_crossing([&](int32_t a, int32_t b) { across[fill[a]++] = b; across[fill[b]++] = a; });
         in_cover.assign(universe, 0);
         for (int32_t v : order) {
             bool uncovered = false;
-            for (int32_t u : across[v]) uncovered |= !in_cover[u];
+            for (int32_t e = across_begin[v]; e < across_begin[v + 1]; ++e) uncovered |= !in_cover[across[e]];
             in_cover[v] = uncovered;
         }
     }
@@ -681,6 +693,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             }
         }
     }
+    split_lap("vertex cover, constraints -> clusters");
     if (env_int("BEPUHIP_PLAN_STATS", 0) >= 2) {  // how many hand-offs of shared bodies stay inside one cluster (rank r and r + 1 of a pass run by the same cluster)
         std::vector<int32_t> last_cluster(universe, -1);
         long long applications = 0, local_pairs = 0, pairs = 0;
@@ -702,7 +715,9 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     // shared body that the SAME cluster runs pass the velocity through that cluster's LDS slot of the body instead of the record in HBM (pile: 42 % of the hand-offs,
     // ragdoll crowd: 78 %). BEPUHIP_SPLIT_LOCAL_HANDOFF=0 turns them off.
     constexpr uint32_t kPlanRankPredLocal = 1u << 16, kPlanRankSuccLocal = 1u << 17;
-    const bool local_handoff = env_int("BEPUHIP_SPLIT_LOCAL_HANDOFF", 1) != 0;
+    const int handoff_mode = env_int("BEPUHIP_SPLIT_LOCAL_HANDOFF", 1);  // debugging: 2 = only inside the body's home cluster, 3 = only inside clusters that hold a ghost copy, 4 = only contacts
+    const bool local_handoff = handoff_mode != 0;
+    split_lap("(statistics)");
     std::vector<std::vector<uint32_t>> srank(c->tbs.size());
     {
         std::vector<int32_t> next_rank(universe, 0), last_cluster(universe, -1);
@@ -716,13 +731,14 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                     if ((uint32_t)r >= kDynamicLimit || !shared[r]) continue;
                     uint32_t& word = srank[t][(size_t)k * tb.stride + i];
                     word = (uint32_t)next_rank[r]++ | ((uint32_t)deg[r] << 8);
-                    const int mode = env_int("BEPUHIP_SPLIT_LOCAL_HANDOFF", 1);  // debugging: 2 = only inside the body's home cluster, 3 = only inside clusters that hold a ghost copy, 4 = only contacts
+                    const int mode = handoff_mode;
                     const bool allowed = mode == 1 || (mode == 2 && cl_of_constraint[t][i] == body_cluster[r]) || (mode == 3 && cl_of_constraint[t][i] != body_cluster[r]) || (mode == 4 && tb.type_id < 8);
                     if (local_handoff && allowed && last_word[r] != nullptr && last_cluster[r] == cl_of_constraint[t][i]) { word |= kPlanRankPredLocal; *last_word[r] |= kPlanRankSuccLocal; }
                     last_word[r] = &word; last_cluster[r] = cl_of_constraint[t][i];
                 }
         }
     }
+    split_lap("rank words");
     // ---- slots: home bodies (ascending), then ghosts and kinematic copies on first use ----
     std::vector<std::vector<int32_t>> cl_bodies(nclusters);
     std::vector<int32_t> local_of(universe, -1);
@@ -776,9 +792,12 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             return;
         }
     }
+    split_lap("slots, ghost and kinematic copies, sizes");
+    // (the pre-size pass above has met every (cluster, copy) pair: from here on the tables are only read, from several threads)
+    auto extra_known = [&](int cl, int tagged) { return cl_extra[cl].find(tagged)->second; };
     auto slot_of = [&](int cl, int32_t r) {  // 32-bit local reference of body reference r as seen from cluster cl: slot | shared << 14 | kinematic << 30
-        if ((uint32_t)r >= kDynamicLimit) return rotated_slot(extra_local(cl, (r & kRefMask) | kSlotKinematic)) | (int)kDynamicLimit;
-        const int l = body_cluster[r] == cl ? local_of[r] : extra_local(cl, r | kSlotGhost);
+        if ((uint32_t)r >= kDynamicLimit) return rotated_slot(extra_known(cl, (r & kRefMask) | kSlotKinematic)) | (int)kDynamicLimit;
+        const int l = body_cluster[r] == cl ? local_of[r] : extra_known(cl, r | kSlotGhost);
         return rotated_slot(l) | (shared[r] ? (int)kLrefShared : 0);
     };
     std::vector<std::vector<int32_t>> last_toucher(nclusters);
@@ -793,60 +812,82 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         return x.info.prestep + 2 * x.info.impulse > y.info.prestep + 2 * y.info.impulse;
     });
     plan.split_visit = visit;
-    for (size_t t : visit) {
+    // Every type batch's rows in their segmented order. Three steps so that one large type batch does not keep the other threads waiting: the order of every type
+    // batch (a counting sort: cluster by cluster, private before shared, otherwise in the caller's order), the rows in chunks of slots, the swaps.
+    struct RowJob { std::vector<int32_t> refs, lrefs; std::vector<uint32_t> ranks; std::vector<float> pre, acc; int stride = 0; };
+    std::vector<RowJob> row_jobs(c->tbs.size());
+    const bool host_values = c->host_values;
+    plan_parallel_for(c->tbs.size(), [&](size_t t) {
         HostTypeBatch& tb = c->tbs[t];
         const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
         const std::vector<int32_t>& clc = cl_of_constraint[t];
         // inside a cluster: constraints that touch only private bodies first, the ones with shared bodies behind them. They share work items: a wave spends the
         // same time on an item whatever its lane count, and the waves' time is what a split cluster runs out of.
         std::vector<uint8_t> touches_shared(tb.count, 0);
-        for (int i = 0; i < tb.count; ++i)
-            for (int k = 0; k < nb; ++k) {
+        for (int k = 0; k < nb; ++k)
+            for (int i = 0; i < tb.count; ++i) {
                 const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
                 if ((uint32_t)r < kDynamicLimit && shared[r]) touches_shared[i] = 1;
             }
         // Every cluster's constraints of the type batch in one segment of device slots, live ones first (private before shared), free slots (if reserved) behind them —
         // the layout of the whole-island plans, so that structural updates find the same structures (bepu_soft_updates.h).
-        std::vector<int32_t> order(tb.count);
-        for (int i = 0; i < tb.count; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return clc[a] != clc[b] ? clc[a] < clc[b] : touches_shared[a] < touches_shared[b]; });
-        std::vector<int32_t> live(nclusters, 0);
-        for (int i = 0; i < tb.count; ++i) ++live[clc[i]];
+        std::vector<int32_t> live(nclusters, 0), private_live(nclusters, 0);
+        for (int i = 0; i < tb.count; ++i) { ++live[clc[i]]; private_live[clc[i]] += !touches_shared[i]; }
         tb.seg_begin.assign(nclusters + 1, 0);
         for (int cl = 0; cl < nclusters; ++cl) tb.seg_begin[cl + 1] = tb.seg_begin[cl] + split_segment_slots(live[cl], reserve);
         tb.slots = tb.seg_begin[nclusters];
-        const int stride = std::max(tb.stride, (tb.slots + 63) / 64 * 64);
+        RowJob& job = row_jobs[t];
+        job.stride = std::max(tb.stride, (tb.slots + 63) / 64 * 64);
         tb.perm.assign(tb.slots, -1);
         {
-            std::vector<int32_t> next(tb.seg_begin.begin(), tb.seg_begin.end() - 1);
-            for (int h : order) tb.perm[next[clc[h]]++] = h;
+            std::vector<int32_t> next_private(tb.seg_begin.begin(), tb.seg_begin.end() - 1), next_shared(nclusters);
+            for (int cl = 0; cl < nclusters; ++cl) next_shared[cl] = tb.seg_begin[cl] + private_live[cl];
+            for (int i = 0; i < tb.count; ++i) tb.perm[(touches_shared[i] ? next_shared : next_private)[clc[i]]++] = i;
         }
         tb.inv.assign(tb.count, 0);
-        std::vector<int32_t> refs((size_t)nb * stride, -1), lrefs((size_t)nb * stride, kPlanDeadLref);
-        std::vector<uint32_t> ranks((size_t)nb * stride, 0u);
-        const bool host_values = c->host_values;
-        std::vector<float> pre(host_values ? (size_t)pf * stride : 0, 0.0f), acc(host_values ? (size_t)imf * stride : 0, 0.0f);
-        for (int d = 0; d < tb.slots; ++d) {
+        job.refs.assign((size_t)nb * job.stride, -1); job.lrefs.assign((size_t)nb * job.stride, kPlanDeadLref); job.ranks.assign((size_t)nb * job.stride, 0u);
+        job.pre.assign(host_values ? (size_t)pf * job.stride : 0, 0.0f); job.acc.assign(host_values ? (size_t)imf * job.stride : 0, 0.0f);
+    });
+    constexpr int kRowChunk = 8192;
+    std::vector<std::pair<int32_t, int32_t>> row_chunks;  // (type batch, first slot)
+    for (size_t t = 0; t < c->tbs.size(); ++t) for (int d = 0; d < c->tbs[t].slots; d += kRowChunk) row_chunks.push_back({(int32_t)t, d});
+    plan_parallel_for(row_chunks.size(), [&](size_t chunk) {
+        const size_t t = (size_t)row_chunks[chunk].first;
+        HostTypeBatch& tb = c->tbs[t];
+        RowJob& job = row_jobs[t];
+        const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse, stride = job.stride;
+        const std::vector<int32_t>& clc = cl_of_constraint[t];
+        for (int d = row_chunks[chunk].second; d < std::min(tb.slots, row_chunks[chunk].second + kRowChunk); ++d) {
             const int h = tb.perm[d];
             if (h < 0) continue;
             const int cl = clc[h];
             tb.inv[h] = d;
             for (int k = 0; k < nb; ++k) {
                 const int32_t r = tb.refs_soa[(size_t)k * tb.stride + h];
-                refs[(size_t)k * stride + d] = r;
-                lrefs[(size_t)k * stride + d] = slot_of(cl, r);
-                ranks[(size_t)k * stride + d] = srank[t][(size_t)k * tb.stride + h];
+                job.refs[(size_t)k * stride + d] = r;
+                job.lrefs[(size_t)k * stride + d] = slot_of(cl, r);
+                job.ranks[(size_t)k * stride + d] = srank[t][(size_t)k * tb.stride + h];
             }
-            for (int f = 0; f < pf && host_values; ++f) pre[(size_t)f * stride + d] = tb.prestep_soa[(size_t)f * tb.stride + h];
-            for (int f = 0; f < imf && host_values; ++f) acc[(size_t)f * stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
+            for (int f = 0; f < pf && host_values; ++f) job.pre[(size_t)f * stride + d] = tb.prestep_soa[(size_t)f * tb.stride + h];
+            for (int f = 0; f < imf && host_values; ++f) job.acc[(size_t)f * stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
         }
-        tb.stride = stride;
-        tb.dev_refs = refs;
-        tb.refs_soa.swap(refs); tb.prestep_soa.swap(pre); tb.accum_soa.swap(acc); tb.lrefs_soa.swap(lrefs);
-        srank[t].swap(ranks);
+    });
+    plan_parallel_for(c->tbs.size(), [&](size_t t) {
+        HostTypeBatch& tb = c->tbs[t];
+        RowJob& job = row_jobs[t];
+        tb.stride = job.stride;
+        tb.dev_refs = job.refs;
+        tb.refs_soa.swap(job.refs); tb.prestep_soa.swap(job.pre); tb.accum_soa.swap(job.acc); tb.lrefs_soa.swap(job.lrefs);
+        srank[t].swap(job.ranks);
         tb.plan_lrefs = tb.lrefs_soa;  // 32-bit local references and rank words per device slot: what the predecessor rule reads (kept for the structural updates)
         tb.plan_ranks = srank[t];
-        for (int cl = 0; cl < nclusters; ++cl) {
+    });
+    split_lap("permuted rows (threads)");
+    plan_parallel_for((size_t)nclusters, [&](size_t cluster) {  // every cluster's work items with their predecessor lists, type batches in claim order
+        const int cl = (int)cluster;
+        for (size_t t : visit) {
+            HostTypeBatch& tb = c->tbs[t];
+            const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
             const int d = tb.seg_begin[cl], e = tb.seg_begin[cl + 1];
             for (int s0 = d; s0 < e; s0 += 64) {
                 ClusterItem it;
@@ -885,9 +926,10 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                 cl_items[cl].push_back(it);
             }
         }
-    }
+    });
+    split_lap("work items, predecessor lists (threads)");
     // 16-bit local references (slot | shared << 14 | kinematic << 15), two per word, followed by the rank rows (one word per body slot)
-    for (size_t t = 0; t < c->tbs.size(); ++t) {
+    plan_parallel_for(c->tbs.size(), [&](size_t t) {
         HostTypeBatch& tb = c->tbs[t];
         const int nb = tb.info.bodies, rows = (nb + 1) / 2;
         std::vector<int32_t> packed((size_t)(rows + nb) * tb.stride, 0);
@@ -900,7 +942,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             }
         if (nb == 1) for (int d = 0; d < tb.slots; ++d) if (tb.perm[d] < 0) packed[d] = (int32_t)kLrefDead;
         tb.lrefs_soa.swap(packed);
-    }
+    });
     for (int cl = 0; cl < nclusters; ++cl) {
         for (auto& fs : first_touch[cl]) {
             ClusterItem& it = cl_items[cl][fs.first];
@@ -914,6 +956,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             else it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (1 << 25);
         }
     }
+    split_lap("packed local references, cross-pass lists");
     int64_t shared_count = 0, ghost_slots = 0;
     for (int cl = 0; cl < nclusters; ++cl) {
         ClusterDesc d;
@@ -950,6 +993,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         plan.cluster_natural[cl] = (int32_t)cl_bodies[cl].size();
         for (auto& kv : cl_extra[cl]) plan.cluster_extra[cl].emplace(kv.first, rotated_slot(kv.second));
     }
+    split_lap("descriptors, mirrors");
     plan.planes = cluster_lds_bytes(kAllPlanes, plan.max_slots, plan.max_items, true) <= kLdsBudgetBytes ? kAllPlanes : kSweepPlanes;
     plan.enabled = nclusters > 0 && plan.max_slots < 0x4000 && cluster_lds_bytes(plan.planes, plan.max_slots, plan.max_items, true) <= kLdsBudgetBytes;
     if (env_int("BEPUHIP_PLAN_STATS", 0))
