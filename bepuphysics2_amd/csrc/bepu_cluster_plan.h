@@ -672,7 +672,8 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             in_cover[v] = uncovered;
         }
     }
-    for (size_t t = 0; t < c->tbs.size(); ++t) {
+    std::atomic<int> bodiless{0};
+    plan_parallel_for(c->tbs.size(), [&](size_t t) {  // (several type batches may mark the same body shared: the same byte, the same value)
         HostTypeBatch& tb = c->tbs[t];
         cl_of_constraint[t].resize(tb.count);
         for (int i = 0; i < tb.count; ++i) {
@@ -685,14 +686,15 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                 const int32_t a = tb.refs_soa[i], b = tb.refs_soa[(size_t)tb.stride + i];
                 if ((uint32_t)a < kDynamicLimit && (uint32_t)b < kDynamicLimit && body_cluster[a] != body_cluster[b] && in_cover[a] && !in_cover[b]) cl = body_cluster[b];
             }
-            if (cl < 0) return;  // a constraint with no dynamic body: leave everything to the global path
+            if (cl < 0) { bodiless.store(1, std::memory_order_relaxed); cl = 0; }
             cl_of_constraint[t][i] = cl;
             for (int k = 0; k < tb.info.bodies; ++k) {
                 const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                if ((uint32_t)r < kDynamicLimit && body_cluster[r] != cl) shared[r] = 1;
+                if ((uint32_t)r < kDynamicLimit && body_cluster[r] != cl) __atomic_store_n(&shared[r], (uint8_t)1, __ATOMIC_RELAXED);
             }
         }
-    }
+    });
+    if (bodiless.load()) return;  // a constraint with no dynamic body: leave everything to the global path
     split_lap("vertex cover, constraints -> clusters");
     if (env_int("BEPUHIP_PLAN_STATS", 0) >= 2) {  // how many hand-offs of shared bodies stay inside one cluster (rank r and r + 1 of a pass run by the same cluster)
         std::vector<int32_t> last_cluster(universe, -1);
@@ -757,21 +759,30 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     const bool reserve = (c->flags & BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS) != 0;
     int slot_reserve = 0;  // free LDS slots behind every cluster's bodies
     {
-        std::vector<int32_t> item_count(nclusters, 0), per_cluster(nclusters);
-        for (size_t t = 0; t < c->tbs.size(); ++t) {
-            HostTypeBatch& tb = c->tbs[t];
-            std::fill(per_cluster.begin(), per_cluster.end(), 0);
+        // A copy gets its natural index when the cluster first meets it, type batches in order, constraints in order. The references that need a copy are listed per
+        // type batch on the plan threads, strung together per cluster in that order, and every cluster then numbers its own (the hash tables are the expensive part).
+        std::vector<int32_t> item_count(nclusters, 0);
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> wanted(c->tbs.size());  // (cluster, tagged body) in the order a serial scan meets them
+        std::vector<std::vector<int32_t>> per_cluster(c->tbs.size());
+        plan_parallel_for(c->tbs.size(), [&](size_t t) {
+            const HostTypeBatch& tb = c->tbs[t];
+            per_cluster[t].assign(nclusters, 0);
             for (int i = 0; i < tb.count; ++i) {
                 const int cl = cl_of_constraint[t][i];
-                per_cluster[cl]++;
+                per_cluster[t][cl]++;
                 for (int k = 0; k < tb.info.bodies; ++k) {
                     const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                    if ((uint32_t)r >= kDynamicLimit) extra_local(cl, (r & kRefMask) | kSlotKinematic);
-                    else if (body_cluster[r] != cl) extra_local(cl, r | kSlotGhost);
+                    if ((uint32_t)r >= kDynamicLimit) wanted[t].push_back({cl, (r & kRefMask) | kSlotKinematic});
+                    else if (body_cluster[r] != cl) wanted[t].push_back({cl, r | kSlotGhost});
                 }
             }
-            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (split_segment_slots(per_cluster[cl], reserve) + 63) / 64 + 1;
+        });
+        std::vector<std::vector<int32_t>> met(nclusters);
+        for (size_t t = 0; t < c->tbs.size(); ++t) {
+            for (auto& pair : wanted[t]) met[pair.first].push_back(pair.second);
+            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (split_segment_slots(per_cluster[t][cl], reserve) + 63) / 64 + 1;
         }
+        plan_parallel_for((size_t)nclusters, [&](size_t cl) { for (int32_t tagged : met[cl]) extra_local((int)cl, tagged); });
         int max_slots = 0, max_items = 0;
         for (int cl = 0; cl < nclusters; ++cl) {
             max_slots = std::max(max_slots, ((int)cl_bodies[cl].size() + 15) / 16 * 16);
@@ -848,6 +859,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         job.refs.assign((size_t)nb * job.stride, -1); job.lrefs.assign((size_t)nb * job.stride, kPlanDeadLref); job.ranks.assign((size_t)nb * job.stride, 0u);
         job.pre.assign(host_values ? (size_t)pf * job.stride : 0, 0.0f); job.acc.assign(host_values ? (size_t)imf * job.stride : 0, 0.0f);
     });
+    split_lap("row order (threads)");
     constexpr int kRowChunk = 8192;
     std::vector<std::pair<int32_t, int32_t>> row_chunks;  // (type batch, first slot)
     for (size_t t = 0; t < c->tbs.size(); ++t) for (int d = 0; d < c->tbs[t].slots; d += kRowChunk) row_chunks.push_back({(int32_t)t, d});
@@ -872,6 +884,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             for (int f = 0; f < imf && host_values; ++f) job.acc[(size_t)f * stride + d] = tb.accum_soa[(size_t)f * tb.stride + h];
         }
     });
+    split_lap("rows in chunks (threads)");
     plan_parallel_for(c->tbs.size(), [&](size_t t) {
         HostTypeBatch& tb = c->tbs[t];
         RowJob& job = row_jobs[t];
@@ -882,7 +895,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         tb.plan_lrefs = tb.lrefs_soa;  // 32-bit local references and rank words per device slot: what the predecessor rule reads (kept for the structural updates)
         tb.plan_ranks = srank[t];
     });
-    split_lap("permuted rows (threads)");
+    split_lap("row swaps, mirrors (threads)");
     plan_parallel_for((size_t)nclusters, [&](size_t cluster) {  // every cluster's work items with their predecessor lists, type batches in claim order
         const int cl = (int)cluster;
         for (size_t t : visit) {
