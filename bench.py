@@ -477,19 +477,23 @@ def measure_traffic(args, scene_key: str = "main"):
             d = tempfile.mkdtemp(prefix="bepu_pmc_", dir="/tmp")
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BEPU_BENCH_FORCE_DIST")}
             env["TMPDIR"] = "/tmp"
+            sq_pass = counters[0] == "SQ_ACTIVE_INST_VALU"  # cycle counters want the launches of a settled launch policy and warm caches: the last five of thirty
             cmd = ["rocprofv3", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "3", "--warmup", "1", "--ragdolls", str(args.ragdolls), "--no-cpu-baseline", "--no-traffic", "--no-prewarm", "--traffic-child", scene_key]
-            done = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=counters[0] != "SQ_ACTIVE_INST_VALU")
+                   "--steps", "5" if sq_pass else "3", "--warmup", "25" if sq_pass else "1", "--ragdolls", str(args.ragdolls), "--no-cpu-baseline", "--no-traffic", "--no-prewarm",
+                   "--traffic-child", scene_key]
+            done = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=not sq_pass)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             per_kernel = {}
-            for f in files:
-                for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] in counters:
-                        a = per_kernel.setdefault((r["Kernel_Name"], r["Counter_Name"]), [0.0, 0])
-                        a[0] += float(r["Counter_Value"])
-                        a[1] += 1
+            rows = [r for f in files for r in csv.DictReader(open(f)) if r["Counter_Name"] in counters]
+            if sq_pass and dominant:  # the last five step launches only
+                ids = sorted({int(r["Dispatch_Id"]) for r in rows if r["Kernel_Name"] == dominant})[-5:]
+                rows = [r for r in rows if r["Kernel_Name"] == dominant and int(r["Dispatch_Id"]) in ids]
+            for r in rows:
+                a = per_kernel.setdefault((r["Kernel_Name"], r["Counter_Name"]), [0.0, 0])
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
             shutil.rmtree(d, ignore_errors=True)
-            if counters[0] == "SQ_ACTIVE_INST_VALU":  # what the instruction issue looks like next to the bytes (optional: a failed pass leaves the traffic figures standing)
+            if sq_pass:  # what the instruction issue looks like next to the bytes (optional: a failed pass leaves the traffic figures standing)
                 sq = {c: per_kernel[(dominant, c)][0] / per_kernel[(dominant, c)][1] for c in counters if (dominant, c) in per_kernel}
                 if done.returncode == 0 and len(sq) == len(counters):
                     out["SQ"] = sq
@@ -534,7 +538,9 @@ def traffic_child(args, device: int):
     solver = HipSolver(device=device, exclusive_device=True)
     solver.upload(scene)
     cb = PoseIntegratorCallbacks()
-    for _ in range(args.warmup + args.steps):
+    for _ in range(args.warmup):  # synchronous: the launch policy settles on completed samples (a queue of thirty asynchronous solves would run out before the first one ends)
+        solver.solve(1.0 / 60.0, sd, cb)
+    for _ in range(args.steps):
         solver.solve(1.0 / 60.0, sd, cb, asynchronous=True)
     solver.sync()
     solver.close()
