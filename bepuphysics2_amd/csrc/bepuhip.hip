@@ -1004,7 +1004,9 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
             }
             if (conserving && c->row_policy == 2) candidate = 2;
             const bool nt = candidate == 1;
-            cp.code_touch = candidate == 2 ? 1 : 0;
+            // (split plans take two spans: their work items run more code — pile 0.3795 -> 0.3695 ms, crowd 0.3976 -> 0.3899 on a slow-class box, the whole-island
+            // kernel 0.1875 -> 0.1897 with two; profiles/r04_s30_code_touch_spans_slowbox.txt)
+            cp.code_touch = candidate == 2 ? (c->clusters_shared ? 2 : 1) : 0;
             if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(kCodeTouchMaxSpans, forced);  // never beyond the padding behind the unit's kernels
             cp.jitter = debug_jitter_seed();
             const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, conserving);  // the register budget that matches the workgroup size
@@ -1488,7 +1490,7 @@ static void enqueue_cluster_pass(bepuhip_ctx* c, int stage, int substep, const S
     cp.pass_stage = stage; cp.pass_substep = substep;
     cp.fallback_batch = -1;  // (exchanged solves refuse a fallback batch)
     cp.sp = sp;
-    cp.code_touch = c->row_policy == 2 ? 1 : 0;
+    cp.code_touch = c->row_policy == 2 ? (c->clusters_shared ? 2 : 1) : 0;
     cp.jitter = debug_jitter_seed();
     const int threads = cluster_threads(c);
     TailParams tp;
