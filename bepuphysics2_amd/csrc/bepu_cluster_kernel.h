@@ -616,7 +616,7 @@ __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared&
 
 template <class F, int STAGE, bool TRACE, bool SHARED>
 __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
-                                                       unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps, bool barrier_behind_row_loads = false) {
+                                                       unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
     // Lanes beyond the item's count mirror its last constraint and never store: the whole body runs with a full exec mask,
     // which keeps the control flow around the (wave-uniform) waits trivially structured.
     const bool active = lane < h.count;
@@ -651,9 +651,6 @@ __device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, 
     }
     DBody A, B;
     if (STAGE == kStageIncremental) {  // reads velocities, writes only this constraint's depths: no ordering inside the stage
-        // The wave's first item of the stage is started BEFORE the barrier that ends the last sweep of the previous substep: its rows are on their way while the wave
-        // waits for the chain's tail (the barriers of this kernel wait for LDS, not for vector memory); the velocities are read behind the barrier.
-        if (barrier_behind_row_loads) __syncthreads();
         load_body_lds<kAccessOnlyVelocity>(sh, ra, A);
         if (F::bodies == 2) load_body_lds<kAccessOnlyVelocity>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
         if constexpr (SHARED) {
@@ -715,8 +712,8 @@ using DC1T = Contact<1, true>; using DC2T = Contact<2, true>; using DC3T = Conta
 
 template <int STAGE, bool TRACE, bool WIDE, bool SHARED>
 __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
-                                                 unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps, bool barrier_behind_row_loads = false) {
-#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE, SHARED>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps, barrier_behind_row_loads); break;
+                                                 unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
+#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE, SHARED>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps); break;
     switch (h.type_id) {
         BEPU_CASE(kContact1OneBody, DC1O) BEPU_CASE(kContact2OneBody, DC2O) BEPU_CASE(kContact3OneBody, DC3O) BEPU_CASE(kContact4OneBody, DC4O)
         BEPU_CASE(kContact1, DC1T) BEPU_CASE(kContact2, DC2T) BEPU_CASE(kContact3, DC3T) BEPU_CASE(kContact4, DC4T)
@@ -904,7 +901,16 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     unsigned epoch = 0, claim_base = 0;
     for (int s = 0; s < cp.substeps; ++s) {
         if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(&sh.status[10], (unsigned)s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        // (s > 0: the contact depths have advanced with the pre-integration velocities behind the previous substep's sweeps, below)
+        if (s > 0) {  // Solver_Solve.cs:1427-1439: contact depths advance with the pre-integration velocities
+            for (int k = wave; k < cd.item_count; k += nwaves) {
+                const ClusterItem* it = sh.items + k;
+                const ItemHeader h = read_item(it);
+                if (!isContactType(h.type_id)) continue;
+                ItemStamps stamps = {0, 0, 0};
+                run_cluster_item<kStageIncremental, false, WIDE, SHARED>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
+            }
+            __syncthreads();
+        }
         // Integration of every constrained body of the cluster (TypeProcessor.cs:1204-1283, PoseIntegrator.cs:451-535):
         // substep 0 velocity only, later substeps pose then velocity; world inverse inertia refreshed either way.
         for (int j = tid; j < cd.slot_count; j += blockDim.x) {
@@ -971,29 +977,13 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         claim_base += cd.item_count + fused + nwaves;  // every wave makes exactly one failing claim per sweep
         sh.passes += fused ? 2u : 1u;
         if (fused) ++epoch;
-        // The barrier that ends a sweep. Behind the substep's LAST sweep it sits inside the next substep's incremental contact update (Solver_Solve.cs:1427-1439:
-        // contact depths advance with the pre-integration velocities), between the row loads and the velocity reads of the wave's first contact item.
-        auto end_of_sweep = [&](bool last_of_substep) {
-            if (!last_of_substep || s + 1 >= cp.substeps) { __syncthreads(); return; }
-            bool synced = false;
-            for (int k = wave; k < cd.item_count; k += nwaves) {
-                const ClusterItem* it = sh.items + k;
-                const ItemHeader h = read_item(it);
-                if (!isContactType(h.type_id)) continue;
-                ItemStamps stamps = {0, 0, 0};
-                run_cluster_item<kStageIncremental, false, WIDE, SHARED>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps, !synced);
-                synced = true;
-            }
-            if (!synced) __syncthreads();
-            __syncthreads();  // the depths are where the warm start reads them, the velocities may be integrated
-        };
-        end_of_sweep(cp.iters[s] <= 1);
+        __syncthreads();
         for (int iter = 1; iter < cp.iters[s]; ++iter) {
             ++epoch;
             run_cluster_sweep<kStageSolve, TRACE, WIDE, SHARED>(sh, cd.item_count, 0, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
             claim_base += cd.item_count + nwaves;
             sh.passes += 1u;
-            end_of_sweep(iter + 1 >= cp.iters[s]);
+            __syncthreads();
         }
     }
     // Trailing pose integration of constrained bodies (PoseIntegrator.cs:684-691) and write-back.
