@@ -28,6 +28,100 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 
 
+def cpu_quota():
+    """The CPU time this process may use per period, from the cgroup (v2 cpu.max, v1 cpu.cfs_quota_us): a container with 256 visible CPUs and a quota of 8 runs at most
+    8 threads' worth of work however many it starts. Returns (cpus or None when unlimited, where it was read)."""
+    for path, v2 in (("/sys/fs/cgroup/cpu.max", True), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", False), ("/sys/fs/cgroup/cpu,cpuacct/cpu.cfs_quota_us", False)):
+        try:
+            text = open(path).read().split()
+            if v2:
+                return (None if text[0] == "max" else float(text[0]) / float(text[1])), path
+            quota = float(text[0])
+            period = float(open(path.replace("cfs_quota_us", "cfs_period_us")).read().split()[0])
+            return (None if quota <= 0 else quota / period), path
+        except (OSError, ValueError, IndexError):
+            continue
+    return None, None
+
+
+def compact_line(out, full_path):
+    """The ONE line the driver keeps (its record holds an 8 KB tail): every number, none of the prose. The long form — notes, methods, thread curves, per-size
+    details — goes to `full_path`. Headline keys first; pile and crowd ride inside `roofline` as well so that a cut tail still shows them (VERDICT r4 next #9)."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+    def r4(x):
+        return float(f"{x:.4g}") if isinstance(x, float) else x
+
+    def rnd(d):
+        if isinstance(d, dict):
+            return {k: rnd(v) for k, v in d.items()}
+        if isinstance(d, list):
+            return [rnd(v) for v in d]
+        return r4(d)
+
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = dict(out["config"])
+    if cfg.get("row_policy"):
+        cfg["row_policy"] = cfg["row_policy"].split(",")[0]
+    line["config"] = cfg
+    roof = out.get("roofline")
+    if isinstance(roof, dict):
+        keep = pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "basis", "avg_launch_us", "launches", "algorithmic_bytes_per_launch", "algorithmic_GBs",
+                           "algorithmic_frac_of_peak", "memory_stream_bytes_per_launch", "memory_stream_GBs", "traffic_over_compulsory_stream", "working_set_bytes", "valu_busy",
+                           "effective_shader_GHz", "step_algorithmic_GBs"))
+        issue = (roof.get("traffic_detail") or {}).get("issue") if isinstance(roof.get("traffic_detail"), dict) else None
+        if issue:
+            keep["waves_per_simd"], keep["wave_time_waiting"] = issue.get("waves_per_simd"), issue.get("wave_time_waiting")
+        for short, key in (("pile", "pile_100k"), ("crowd", "ragdoll_crowd")):
+            leg = (out.get("connected_scenes") or {}).get(key)
+            if isinstance(leg, dict) and "ms_per_step" in leg:
+                lr = leg.get("roofline") or {}
+                keep[f"{short}_ms"], keep[f"{short}_frac"] = leg["ms_per_step"], lr.get("frac")
+                keep[f"{short}_traffic_over_stream"], keep[f"{short}_valu_busy"] = lr.get("traffic_over_compulsory_stream"), lr.get("valu_busy")
+        line["roofline"] = rnd(keep)
+    else:
+        line["roofline"] = roof
+    base = out.get("cpu_baseline")
+    if isinstance(base, dict) and "value" in base:
+        keep = pick(base, ("value", "unit", "cores", "kind", "single_thread_value", "host_cpus_available", "cpu_quota", "gpu_over_cpu", "gpu_over_ideal_socket"))
+        keep["ideal_socket_bound"] = (base.get("ideal_socket_bound") or {}).get("value")
+        keep["thread_curve"] = [[e["threads"], r4(float(e["value"]))] for e in base.get("thread_curve", [])]
+        keep["sample"] = base.get("sample", "")[:160]
+        line["cpu_baseline"] = rnd(keep)
+    else:
+        line["cpu_baseline"] = base
+    conn = out.get("connected_scenes")
+    if isinstance(conn, dict):
+        line["connected_scenes"] = {}
+        for key, leg in conn.items():
+            if isinstance(leg, dict) and "ms_per_step" in leg:
+                lr = leg.get("roofline") or {}
+                line["connected_scenes"][key] = rnd(dict(pick(leg, ("ms_per_step", "value", "upload_ms", "finite")), frac=lr.get("frac"), traffic=lr.get("traffic"),
+                                                       traffic_over_compulsory_stream=lr.get("traffic_over_compulsory_stream"), valu_busy=lr.get("valu_busy"),
+                                                       island_schedule=str(leg.get("schedule", "")).startswith("island")))
+            else:
+                line["connected_scenes"][key] = leg
+    sweep = out.get("scale_sweep")
+    if isinstance(sweep, dict) and "sizes" in sweep:
+        line["scale_sweep"] = rnd([pick(e, ("constraints", "ms_per_step", "value", "frac", "working_set_bytes", "clusters_per_cu")) for e in sweep["sizes"]])
+    elif sweep is not None:
+        line["scale_sweep"] = sweep
+    wid = out.get("widened_types")
+    line["widened_types"] = rnd(pick(wid, ("ms_per_step", "value", "finite", "error"))) if isinstance(wid, dict) else wid
+    bnd = out.get("boundary")
+    line["boundary"] = rnd({k: v for k, v in bnd.items() if not isinstance(v, str) or k == "error"}) if isinstance(bnd, dict) else bnd
+    lat = out.get("lattice")
+    if isinstance(lat, dict):
+        line["lattice"] = rnd({k: (pick(v, ("within_north_star_tolerance", "velocity_err_max", "bit_identical", "exchanges_per_frame")) if isinstance(v, dict) else v)
+                               for k, v in lat.items() if k in ("per_pass_block_jacobi", "per_batch_exact", "error", "exact_split_plan")})
+    for extra in ("all_types", "frame"):
+        if extra in out:
+            line[extra] = rnd(out[extra])
+    line["full_report"] = full_path
+    return line
+
+
 def build_scene(ragdolls: int, seed: int):
     from bepuphysics2_amd.hostlib import HostSimulation
     sim = HostSimulation.scene("ragdoll_tube", ragdolls, 1, 0, seed)
@@ -55,7 +149,10 @@ def cpu_baseline(ragdolls_sample: int, seed: int, target_seconds: float = 14.0):
     pin = wide_ffi.pin_plan("fast")
     curve = []
     budget_each = target_seconds / 9.0
+    quota, quota_path = cpu_quota()
     counts = {1, 8, 16, 32, 64, 128, pin["first_socket_physical_cores"]}  # ... and exactly one worker per physical core of the socket
+    if quota:  # ... and exactly the cgroup's CPU quota, when there is one
+        counts.add(max(1, int(quota)))
     for c in sorted(c for c in counts if 1 <= c <= avail) or [1]:
         session.solve(1, c)  # untimed: the worker pool starts, pages are touched
         frames, t0, phases = 0, time.perf_counter(), [0.0, 0.0, 0.0, 0.0]
@@ -90,7 +187,10 @@ def cpu_baseline(ragdolls_sample: int, seed: int, target_seconds: float = 14.0):
     ideal = single * max(1, pin["first_socket_physical_cores"])
     return {"value": max(per_frame * frames / el, best["value"]), "unit": "constraint-iterations/s", "cores": best["threads"], "kind": "port-simd8",
             "single_thread_value": single, "thread_curve": curve, "host_cpus_available": avail,
-            "placement": dict(pin, note="workers pinned one per physical core of ONE socket first (sibling threads next, the other socket last); the session's memory "
+            "cpu_quota": quota, "cpu_quota_source": quota_path or "no cgroup cpu controller file found",
+            "cpu_quota_note": "cgroup CPU quota in CPUs (None = unlimited): threads beyond it share the quota's time slices, which is what a curve that peaks at the quota and "
+                              "falls beyond it looks like; `cores` is the thread count of the best MEASURED point, the ideal-socket bound is the figure that does not depend on it",
+            "placement": dict(pin, cgroup_cpu_quota=quota, note="workers pinned one per physical core of ONE socket first (sibling threads next, the other socket last); the session's memory "
                                         "first-touched by threads pinned to the same cores (oracle/wide/wide_solver.cpp: PinPlan, AlignedCopy)"),
             "ideal_socket_bound": {"value": ideal, "unit": "constraint-iterations/s",
                                    "note": "the single-thread figure x the physical cores of one socket: what a perfectly scaling socket would reach — the figure to "
@@ -213,7 +313,7 @@ def working_set_bytes(scene) -> int:
     return total
 
 
-def scale_sweep_leg(args, device: int, base_ragdolls: int, factors=(1, 2, 4, 8), steps: int = 20):
+def scale_sweep_leg(args, device: int, base_ragdolls: int, factors=(1, 2, 4, 8), steps: int = 50):
     """the headline scene fits the Infinity Cache (136 MB of 256 MiB) and is one workgroup per CU. The same benchmark at 1x / 2x / 4x / 8x the ragdolls
     (1 - 8 M constraints, up to ~1.1 GB of working set, up to eight clusters per CU run back to back): ms/step, constraint-iterations/s, clusters, clusters per CU, the
     working set, the counters' bandwidth fraction (own PMC child runs per size) and the compulsory-stream fraction. Extra keys on the bench line, never `value`."""
@@ -231,11 +331,11 @@ def scale_sweep_leg(args, device: int, base_ragdolls: int, factors=(1, 2, 4, 8),
         t0 = time.perf_counter()
         solver.upload(scene)
         upload_ms = 1e3 * (time.perf_counter() - t0)
-        for _ in range(40):  # clocks, launch policy
+        for _ in range(300):  # the headline's pre-warm (clocks, launch policy): the sweep's 1x point is the headline's scene and has to agree with it
             solver.solve(1 / 60, sd, cb, asynchronous=True)
         solver.reset_state()
         solver.sync()
-        for _ in range(3):
+        for _ in range(5):
             solver.solve(1 / 60, sd, cb, asynchronous=True)
         solver.sync()
         t0 = time.perf_counter()
@@ -634,6 +734,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE child runs behind roofline.traffic")
     ap.add_argument("--traffic-child", default=None, choices=["main", "pile", "crowd"], help=argparse.SUPPRESS)
     ap.add_argument("--no-connected-scenes", action="store_true", help="skip the extra legs on connected scenes (100k-box pile = configs[1]; ragdoll crowd)")
+    ap.add_argument("--full-report", default=None, help="where the long form of the bench line goes (default gpurun_out/bench_full.json); stdout carries the compact line")
     ap.add_argument("--no-scale-sweep", action="store_true", help="skip the scale_sweep leg (the headline scene at 1x / 2x / 4x / 8x the ragdolls)")
     args = ap.parse_args()
 
@@ -820,7 +921,18 @@ def main():
                        "finite": finite},
             "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "scale_sweep": sweep, "widened_types": widened, "boundary": boundary, "lattice": lattice_report,
         }
-        print(json.dumps(out))
+        if isinstance(baseline, dict) and baseline.get("value"):
+            baseline["gpu_over_cpu"] = value / baseline["value"]
+            if (baseline.get("ideal_socket_bound") or {}).get("value"):
+                baseline["gpu_over_ideal_socket"] = value / baseline["ideal_socket_bound"]["value"]  # the figure to hold against north_star's >= 10x
+        full_path = args.full_report or os.path.join(REPO, "gpurun_out", "bench_full.json")
+        try:
+            os.makedirs(os.path.dirname(full_path), exist_ok=True)
+            with open(full_path, "w") as f:
+                json.dump(out, f)
+        except OSError:
+            full_path = None
+        print(json.dumps(compact_line(out, full_path)))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

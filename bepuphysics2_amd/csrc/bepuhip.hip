@@ -1649,12 +1649,18 @@ int32_t bepuhip_register_host_memory(bepuhip_ctx* c, void* memory, int64_t bytes
     if (e == hipErrorHostMemoryAlreadyRegistered) {
         // Somebody else's registration (another context's, or a neighbouring sub-allocation of the same BufferPool block) overlaps this range. That is fine only when it
         // covers the range WHOLE: a buffer pinned in part would still be read by asynchronous DMA as if it were pinned throughout. Not recorded: not ours to unpin.
+        // Every page is asked for: two neighbouring registrations with an unpinned hole between them have a pinned first and last byte. Rare path, once per
+        // buffer: a microsecond per page.
         (void)hipGetLastError();
-        hipPointerAttribute_t head{}, tail{};
-        const bool head_ok = hipPointerGetAttributes(&head, memory) == hipSuccess && head.type == hipMemoryTypeHost;
-        const bool tail_ok = hipPointerGetAttributes(&tail, (char*)memory + bytes - 1) == hipSuccess && tail.type == hipMemoryTypeHost;
+        bool covered = true;
+        const uintptr_t first_page = (uintptr_t)memory & ~(uintptr_t)4095, last_byte = (uintptr_t)memory + (uintptr_t)bytes - 1;
+        for (uintptr_t page = first_page; covered && page <= last_byte; page += 4096) {
+            hipPointerAttribute_t at{};
+            const void* probe = (const void*)(page < (uintptr_t)memory ? (uintptr_t)memory : page);
+            covered = hipPointerGetAttributes(&at, probe) == hipSuccess && at.type == hipMemoryTypeHost;
+        }
         (void)hipGetLastError();
-        if (head_ok && tail_ok) return BEPUHIP_OK;
+        if (covered) return BEPUHIP_OK;
         return fail(BEPUHIP_E_INVALID_ARGUMENT, "host range overlaps an existing registration that does not cover it: register whole allocation blocks (BufferPool blocks), not sub-ranges");
     }
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(BEPUHIP_E_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
@@ -2297,6 +2303,8 @@ int32_t bepuhip_set_collidables(bepuhip_ctx* c, const bepuhip_collidable* collid
 int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* c, float dt, const bepuhip_integrator* in, const bepuhip_collidable* collidables, int32_t count, bepuhip_predicted_bounds* out) {
     if (!c || !in || count < 0 || count > c->body_count || (count > 0 && !out)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad predict_bounding_boxes argument");
     if (!(dt > 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "dt must be positive");
+    if (c->velocity_model.model == BEPUHIP_VELOCITY_PER_BODY_GRAVITY && c->body_gravity_count < count)  // the kernels read gravity[body] for every body they bound
+        return fail(BEPUHIP_E_STATE, "the per-body gravity table holds " + std::to_string(c->body_gravity_count) + " values for " + std::to_string(count) + " bodies (set_velocity_model)");
     const bool resident = collidables == nullptr;
     if (resident && count > c->collidable_count) return fail(BEPUHIP_E_STATE, "no collidables given and fewer resident ones than bodies (bepuhip_set_collidables)");
     if (!resident) { int32_t st = check_collidables(c, collidables, count); if (st != BEPUHIP_OK) return st; }

@@ -68,7 +68,8 @@ typedef struct bepuhip_integrator {
  *   PER_BODY_GRAVITY  Demos/Demos/PerBodyGravityDemo.cs:57-88  linear.Y += gravity[body] * dt; `per_body_gravity[i]` = the value of the body at INDEX i (the demo looks it
  *                     up by handle: BodyGravities[bodies.ActiveSet.IndexToHandle[i]]); the caller sends the table again when bodies move in memory (Bodies.RemoveAt)
  *   RADIAL_GRAVITY    Demos/Demos/PlanetDemo.cs:36-47          offset = position - center; linear -= (dt * gravity) * offset / max(1, |offset|^3)
- * Anything else: UNSUPPORTED (the shim keeps simulation.Solve). Solver.SubstepStarted / SubstepEnded (Solver.cs:131-146) are not raised by the device path. */
+ * Anything else: UNSUPPORTED (the shim keeps simulation.Solve). Solver.SubstepStarted / SubstepEnded (Solver.cs:131-146) are raised by
+ * bepuhip_solve_with_substep_events only (below); the other solve entry points have no host-visible substep boundary. */
 #define BEPUHIP_VELOCITY_UNIFORM_GRAVITY 0
 #define BEPUHIP_VELOCITY_PER_BODY_GRAVITY 1
 #define BEPUHIP_VELOCITY_RADIAL_GRAVITY 2
