@@ -438,20 +438,56 @@ def boundary_leg(scene, sd, cb, device: int):
     out = {"set_bodies_ms": 1e3 * (t1 - t0), "end_constraints_ms": 1e3 * (t2 - t1),
            "end_constraints_note": "begin / set_type_batch x type batches / end of an upload that re-uses the context's staging buffers: body references AOSOA -> rows and island "
                                    "(cluster) planning on the host; prestep data and impulses copied as they are (registered memory) and transposed on the device"}
-    frames = 10
+    frames = 20
+    from bepuphysics2_amd import native as nat
     contact_tbs = [(bi, tb) for bi, b in enumerate(work.batches) for tb in b if tb.count and TYPE_TABLE[tb.type_id][3].startswith("Contact")]
+    joint_tbs = [(bi, tb) for bi, b in enumerate(work.batches) for tb in b if tb.count and not TYPE_TABLE[tb.type_id][3].startswith("Contact")]
+    # the frame's tables, prepared once (a host keeps them between frames as long as the type batches' buffers stay where they are)
+    prestep_in = solver.row_transfer_table([(nat.ROWS_UPDATE_PRESTEP, bi, tb.type_id, 0, tb.prestep.reshape(-1)) for bi, tb in contact_tbs])
+    keep = [solver._transfer_keepalive]
+    shim_in = solver.row_transfer_table([(kind, bi, tb.type_id, 0, (tb.prestep if kind == nat.ROWS_UPDATE_PRESTEP else tb.accumulated).reshape(-1))
+                                         for bi, tb in contact_tbs for kind in (nat.ROWS_UPDATE_PRESTEP, nat.ROWS_UPDATE_IMPULSES)])
+    keep.append(solver._transfer_keepalive)
+    shim_out = solver.row_transfer_table([(nat.ROWS_GET_IMPULSES, bi, tb.type_id, 0, tb.accumulated.reshape(-1)) for bi, tb in contact_tbs + joint_tbs])
+    keep.append(solver._transfer_keepalive)
     solver.solve(1 / 60, sd, cb)
-    t0 = time.perf_counter()
-    for _ in range(frames):
-        for bi, tb in contact_tbs:
-            solver.update_prestep(bi, tb.type_id, 0, tb.prestep, asynchronous=True)
+
+    def timed(fn, n=frames):
+        fn()
+        solver.sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+            solver.sync()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    def frame():
+        solver.transfer_rows(prestep_in)
         solver.solve(1 / 60, sd, cb, asynchronous=True)
         solver.get_poses_and_velocities(work.bodies, asynchronous=True)
-        solver.sync()
-    out["frame_through_abi_ms"] = 1e3 * (time.perf_counter() - t0) / frames
-    out["frame_through_abi_note"] = (f"the resident frame: update_prestep_async of all {len(contact_tbs)} contact type batches "
-                                     f"({sum(tb.prestep.nbytes for _, tb in contact_tbs) / 1e6:.1f} MB) + solve_async + get_poses_and_velocities_async "
-                                     f"({work.bodies.shape[0] * 64 / 1e6:.1f} MB) + one sync; host buffers registered")
+
+    def shim_frame():
+        solver.set_bodies(work.bodies)
+        solver.transfer_rows(shim_in)
+        solver.solve(1 / 60, sd, cb, asynchronous=True)
+        solver.get_poses_and_velocities(work.bodies, asynchronous=True)
+        solver.transfer_rows(shim_out)
+
+    out["frame_through_abi_ms"] = timed(frame)
+    out["frame_stages_ms"] = {"contact_prestep_in": timed(lambda: solver.transfer_rows(prestep_in)),
+                              "solve": timed(lambda: solver.solve(1 / 60, sd, cb, asynchronous=True)),
+                              "poses_and_velocities_out": timed(lambda: solver.get_poses_and_velocities(work.bodies, asynchronous=True)),
+                              "empty_sync": timed(lambda: None)}
+    out["frame_through_abi_note"] = (f"the resident frame: ONE bepuhip_transfer_rows_async for all {len(contact_tbs)} contact type batches' prestep data "
+                                     f"({sum(tb.prestep.nbytes for _, tb in contact_tbs) / 1e6:.1f} MB, read from the registered host buffers by the transposing kernel itself) + solve_async + "
+                                     f"get_poses_and_velocities_async ({work.bodies.shape[0] * 64 / 1e6:.1f} MB, written into the host's BodyDynamics array by a kernel) + one sync; "
+                                     "frame_stages_ms: each stage on its own, with its own sync (round 4, one copy + two launches per type batch and a strided 2-D copy: 2.8-2.9 ms)")
+    out["shim_frame_ms"] = timed(shim_frame)
+    out["shim_frame_stages_ms"] = {"set_bodies": timed(lambda: solver.set_bodies(work.bodies)), "contact_prestep_and_impulses_in": timed(lambda: solver.transfer_rows(shim_in)),
+                                   "all_impulses_out": timed(lambda: solver.transfer_rows(shim_out))}
+    out["shim_frame_note"] = (f"what integration/csharp/HipTimestepper.cs moves by default every frame: every body in ({work.bodies.nbytes / 1e6:.1f} MB), the contacts' prestep data and "
+                              f"impulses in, solve, poses and velocities out, the accumulated impulses of ALL {len(contact_tbs) + len(joint_tbs)} type batches out "
+                              f"({sum(tb.accumulated.nbytes for _, tb in contact_tbs + joint_tbs) / 1e6:.1f} MB); the host-side diff and comparison are not in it")
     t0 = time.perf_counter()
     for _ in range(3):
         solver.set_bodies(work.bodies)

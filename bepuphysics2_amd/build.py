@@ -69,7 +69,7 @@ def check_code_pad(obj: str) -> None:
 
 def build_hip(force: bool = False, jobs: int = 0) -> str:
     """libbepuhip.so = bepuhip.hip (C ABI, launch-per-batch / stream / per-body kernels) + one translation unit per cluster_kernel register budget
-    (bepu_cluster_{hot,wide}_{1024,768,512}.hip). Units are compiled to objects in parallel and linked; an object is rebuilt when any source is newer."""
+    (bepu_cluster_{hot,wide}_{1024,512}[s|n|c|p].hip). Units are compiled to objects in parallel and linked; an object is rebuilt when any source is newer."""
     from concurrent.futures import ThreadPoolExecutor
     src_dir = os.path.join(_HERE, "csrc")
     obj_dir = os.path.join(src_dir, "build")
@@ -82,7 +82,8 @@ def build_hip(force: bool = False, jobs: int = 0) -> str:
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
 
-    host_only = {"bepuhip.hip", "bepu_host_state.h", "bepu_cluster_plan.h"}  # read by bepuhip.hip alone: the cluster units do not depend on them
+    # read by bepuhip.hip alone: the cluster units do not depend on them (nor on the public header: they see none of its types)
+    host_only = {"bepuhip.hip", "bepu_host_state.h", "bepu_cluster_plan.h", "bepu_soft_updates.h", "bepu_transfer_kernels.h", "bepu_colour_kernels.h", "bepuhip.h"}
     cluster_only = {"bepu_cluster_kernel.h", "bepu_cluster_variant.inc"}
 
     def unit_sources(unit):

@@ -111,6 +111,7 @@ enum { kFlagConstrained = 1, kFlagDynamicConstrained = 2, kFlagConstrainedKinema
 
 // Device-side equivalent of the merged constrained-body set of PrepareConstraintIntegrationResponsibilities
 // (Solver_Solve.cs:1198-1207,1378-1381): every body referenced as dynamic gets integration inside the solver.
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ void mark_constrained_kernel(const int* __restrict__ refs, int count, int stride, int bodies_per_constraint, unsigned* flags) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -122,10 +123,13 @@ __global__ void mark_constrained_kernel(const int* __restrict__ refs, int count,
         atomicOr(&flags[ref & kRefMask], bits);
     }
 }
+#endif
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ void mark_indices_kernel(const int* __restrict__ indices, int count, unsigned* flags, unsigned bits) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) atomicOr(&flags[indices[i] & kRefMask], bits);
 }
+#endif
 
 // IPoseIntegratorCallbacks.IntegrateVelocity (PoseIntegrator.cs:91-93) for the models that cross the ABI (bepuhip_velocity_model); `position` and `body` are the
 // callback's position and bodyIndices arguments. The caller masks the result where the reference does.
@@ -207,6 +211,7 @@ __device__ __forceinline__ void substep_integrate_kinematic(BodyRegs& b, int int
 
 // Per-substep integration of every constrained body — the work the reference fuses into the first-touching constraint's
 // warm start (TypeProcessor.cs:1204-1283) plus the kinematic prepass (PoseIntegrator.cs:451-535). World inverse inertia is refreshed either way.
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(256) void substep_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, int integrate_pose,
                                                                  int integrate_velocity_for_kinematics, int skip_clustered, StepParams sp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -240,11 +245,13 @@ __global__ __launch_bounds__(256) void substep_integrate_kernel(float4* bodies, 
         }
     }
 }
+#endif
 
 // Substep 0, conserving modes only: the reference transforms the angular velocity of EVERY lane of a conditionally integrating bundle before it saves
 // the "previous velocity" it later restores non-integrating lanes to (TypeProcessor.cs:1264-1281), so a body that was integrated by an earlier batch
 // is transformed once more when it shares a bundle (slot-wise) with a body that is integrated there. The host lists those bodies per batch
 // (bundle membership depends on the host's bundle width); this kernel runs before the batch's warm start. Bodies within a batch are distinct.
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ void momentum_requirk_kernel(float4* bodies, const int* __restrict__ indices, int count, StepParams sp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -262,6 +269,7 @@ __global__ void momentum_requirk_kernel(float4* bodies, const int* __restrict__ 
     }
     base[3] = make_float4(ang.x, ang.y, ang.z, a4.w);
 }
+#endif
 
 // PoseIntegrator.IntegrateBundlesAfterSubstepping (PoseIntegrator.cs:537-693) of one body, on registers. True = the velocity changed too.
 __device__ __forceinline__ bool final_integrate_regs(BodyRegs& b, unsigned body_flags, const float4& i0, const float4& i1, float dt, float substep_dt, int substep_count,
@@ -309,6 +317,7 @@ __device__ __forceinline__ void final_integrate_body(float4* bodies, unsigned bo
     base[0] = make_float4(b.ori.x, b.ori.y, b.ori.z, b.ori.w);
     base[1] = make_float4(b.pos.x, b.pos.y, b.pos.z, p4.w);
 }
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, const unsigned* __restrict__ flags, int count, float dt, float substep_dt, int substep_count,
                                                                int allow_substeps_for_unconstrained, int integrate_velocity_for_kinematics, int skip_clustered, StepParams sp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -317,12 +326,14 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(float4* bodies, co
     if (skip_clustered && (f & kFlagClustered)) return;  // final pose already written by the owning cluster_kernel workgroup
     final_integrate_body(bodies, f, i, dt, substep_dt, substep_count, allow_substeps_for_unconstrained, integrate_velocity_for_kinematics, sp);
 }
+#endif
 
 
 // PoseIntegrator.PredictBoundingBoxes (PoseIntegrator.cs:307-370), one lane per body: the stage before collision detection, on the bodies the solver left in HBM.
 // The reference walks the bodies in bundles of Vector<float>.Count and calls the velocity callback on a whole bundle as soon as one of its lanes is to be integrated
 // (:337-338); the demo callbacks ignore the mask and nothing masks afterwards, so a kinematic body is predicted with gravity and damping applied exactly when its
 // bundle also holds a body that integrates. A wave covers 64 consecutive bodies = whole bundles (4, 8 or 16 wide), so the bundle's "any" is a slice of a ballot.
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __restrict__ bodies, int count, CollidableIn* collidables, int keep_activity,
                                                               PredictedBounds* __restrict__ out, float dt, int integrate_velocity_for_kinematics, StepParams sp, ShapeTables tables,
                                                               int bundle_width, int2* heavy_queue, int* heavy_count, int heavy_threshold) {
@@ -352,8 +363,10 @@ __global__ __launch_bounds__(256) void predict_bounds_kernel(const float4* __res
     out[i] = r;
     if (keep_activity) collidables[i].activity = r.activity;  // device-resident records: the sleep counters carry over to the next frame
 }
+#endif
 
 // Second pass of PredictBoundingBoxes: one wave per queued body (compound, mesh, large hull), as many waves as the grid has looping over the queue.
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(64) void predict_heavy_bounds_kernel(const float4* __restrict__ bodies, const CollidableIn* __restrict__ collidables, PredictedBounds* __restrict__ out, float dt,
                                                                    StepParams sp, ShapeTables tables, const int2* __restrict__ heavy_queue, const int* __restrict__ heavy_count) {
     const int queued = *heavy_count;
@@ -373,11 +386,13 @@ __global__ __launch_bounds__(64) void predict_heavy_bounds_kernel(const float4* 
         }
     }
 }
+#endif
 
 // ---- boundary exchange (one connected scene split across GPUs, BASELINE.json configs[4]) ----
 // A boundary body exists on several ranks (owned on one, ghost elsewhere). Between passes every holder publishes what its own constraints did to the
 // body's velocity since the last synchronisation point, the ranks sum those deltas (RCCL all-reduce, done by the caller), and every holder
 // replaces its copy with snapshot + sum: block-Jacobi across the cut, Gauss-Seidel everywhere else.
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ void boundary_snapshot_kernel(const float4* __restrict__ bodies, const int* __restrict__ indices, int count, float4* __restrict__ snapshot) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -385,10 +400,12 @@ __global__ void boundary_snapshot_kernel(const float4* __restrict__ bodies, cons
     snapshot[2 * i] = base[2];
     snapshot[2 * i + 1] = base[3];
 }
+#endif
 // `exact` (BEPUHIP_EXCHANGE_PER_BATCH_EXACT): the exchange runs after every batch, where at most ONE rank has touched a given body (a batch references a body
 // once, and the shares keep the global batch indices), so instead of float differences the ranks exchange the XOR of the velocity's bit pattern with the
 // snapshot's: all but one contribution are zero, an integer sum returns the toucher's pattern exactly, and every copy becomes bit-identical to what the
 // unsplit solve holds at that point. `rows` (optional) scatters / gathers through the dense exchange buffer (row of body i = rows[i]; 6 words per row).
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ void boundary_deltas_kernel(const float4* __restrict__ bodies, const int* __restrict__ indices, int count, const float4* __restrict__ snapshot, float* __restrict__ out,
                                        const int* __restrict__ rows, int exact) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -405,7 +422,9 @@ __global__ void boundary_deltas_kernel(const float4* __restrict__ bodies, const 
     o[0] = l.x - l0.x; o[1] = l.y - l0.y; o[2] = l.z - l0.z;
     o[3] = a.x - a0.x; o[4] = a.y - a0.y; o[5] = a.z - a0.z;
 }
+#endif
 // `holders` (optional, indexed like the sums): the number of ranks holding the body; the summed deltas of mass-split copies are averaged (lattice.py).
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ void boundary_apply_kernel(float4* bodies, const int* __restrict__ indices, int count, float4* snapshot, const float* __restrict__ sums, const int* __restrict__ rows,
                                       const float* __restrict__ holders, int exact) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,10 +449,12 @@ __global__ void boundary_apply_kernel(float4* bodies, const int* __restrict__ in
     base[2] = l; base[3] = a;
     snapshot[2 * i] = l; snapshot[2 * i + 1] = a;  // the next exchange's deltas are relative to the synchronised value
 }
+#endif
 
 // Ranged in-place update of one type batch's prestep / accumulated-impulse rows from the caller's AOSOA bundles (bepuhip_update_prestep /
 // bepuhip_update_accumulated_impulses): one thread per constraint of the range, `fields` strided stores each. `device_index` maps the constraint's
 // index inside the type batch to its slot in the SoA rows (identity unless the island schedule permuted the batch); null = identity.
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(256) void scatter_bundles_kernel(const float* __restrict__ bundles, float* __restrict__ rows, const int* __restrict__ device_index,
                                                               int first_constraint, int constraint_count, int fields, int stride, int W) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,6 +464,7 @@ __global__ __launch_bounds__(256) void scatter_bundles_kernel(const float* __res
     const float* src = bundles + (size_t)(j / W) * fields * W + (j % W);
     for (int f = 0; f < fields; ++f) rows[(size_t)f * stride + d] = src[(size_t)f * W];
 }
+#endif
 // ---- structural updates: the host's TypeProcessor mutations mirrored on the rows that live in HBM ----
 // kind 0: TypeProcessor.Move (TypeProcessor.cs:578-592): lane `src` copied over lane `dst` (body references, prestep, accumulated impulses) — the swap-with-last of Remove.
 // kind 1: AllocateInTypeBatch (:314-334): lane `dst` written from the payload (references, prestep), accumulated impulses cleared (GatherScatter.ClearLane :327).
@@ -451,6 +473,7 @@ __global__ __launch_bounds__(256) void scatter_bundles_kernel(const float* __res
 struct StructuralOp { unsigned refs_off, prestep_off, accum_off; int stride, nb, pf, imf, kind, src, dst; unsigned payload_off; int pad; };
 static_assert(sizeof(StructuralOp) == 48, "uploaded as raw words");
 // One workgroup per type batch: its operations run in the order the host issued them (a Move may read what an earlier append wrote), rows in parallel.
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(64) void apply_structural_ops_kernel(unsigned* __restrict__ slab, const StructuralOp* __restrict__ ops, const int* __restrict__ group_begin,
                                                                   const unsigned* __restrict__ payload) {
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -474,9 +497,11 @@ __global__ __launch_bounds__(64) void apply_structural_ops_kernel(unsigned* __re
         __threadfence_block();
     }
 }
+#endif
 // Structural updates that stay on the island layout (bepu_soft_updates.h): the final state of every device slot touched since the last flush. A live slot gets its
 // encoded references, its packed local references, its prestep lane and zero impulses (TypeProcessor.cs:327); a freed one gets -1 references and local references that name a kinematic copy (kLrefDead).
 struct SoftSlotOp { unsigned refs_off, lrefs_off, prestep_off, accum_off; int stride, bodies, prestep, impulse, slot, live; unsigned payload; int ranks; };  // ranks: rank words behind the local references (split plans: one per body slot)
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(64) void apply_soft_slots_kernel(unsigned* slab, const SoftSlotOp* __restrict__ ops, int count, const unsigned* __restrict__ payload) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -494,19 +519,25 @@ __global__ __launch_bounds__(64) void apply_soft_slots_kernel(unsigned* slab, co
     for (int f = 0; f < op.prestep; ++f) slab[op.prestep_off + (size_t)f * op.stride + op.slot] = *p++;
     for (int f = 0; f < op.impulse; ++f) slab[op.accum_off + (size_t)f * op.stride + op.slot] = 0u;
 }
+#endif
 // Single bits of slab words (the conserving modes' marks on an island layout): set (1) or cleared (0); words that hold several marks are listed once per mark.
 struct BitMark { size_t word; unsigned mask; unsigned pad; };
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(256) void mark_bits_kernel(unsigned* slab, const BitMark* __restrict__ marks, int count, int set) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     if (set) atomicOr(&slab[marks[i].word], marks[i].mask); else atomicAnd(&slab[marks[i].word], ~marks[i].mask);
 }
+#endif
 struct IndexPatch { int* table; int index, value, pad; };
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(64) void patch_index_kernel(const IndexPatch* __restrict__ patches, int count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) patches[i].table[patches[i].index] = patches[i].value;
 }
+#endif
 // Caller's order -> island schedule, rows to rows (bepuhip_replan): permuted[r][device_index[h]] = rows[r][h]; a null index table is the identity.
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(256) void permute_rows_kernel(const unsigned* __restrict__ src, int src_stride, unsigned* __restrict__ dst, int dst_stride, const int* __restrict__ device_index,
                                                            int count, int rows) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -514,7 +545,9 @@ __global__ __launch_bounds__(256) void permute_rows_kernel(const unsigned* __res
     const int d = device_index ? device_index[h] : h;
     for (int r = 0; r < rows; ++r) dst[(size_t)r * dst_stride + d] = src[(size_t)r * src_stride + h];
 }
+#endif
 // Island schedule -> caller's order: rows[r][host index] = permuted[r][device index] (the first structural update leaves the island schedule).
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(256) void unpermute_rows_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, const int* __restrict__ device_to_host, int count, int stride, int rows) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= count) return;
@@ -522,7 +555,9 @@ __global__ __launch_bounds__(256) void unpermute_rows_kernel(const unsigned* __r
     if (h < 0) return;  // a free slot of the island layout
     for (int r = 0; r < rows; ++r) dst[(size_t)r * stride + h] = src[(size_t)r * stride + d];
 }
+#endif
 // The inverse, for ranged read-back (bepuhip_get_*_range).
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
 __global__ __launch_bounds__(256) void gather_bundles_kernel(float* __restrict__ bundles, const float* __restrict__ rows, const int* __restrict__ device_index,
                                                              int first_constraint, int constraint_count, int fields, int stride, int W) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -532,5 +567,6 @@ __global__ __launch_bounds__(256) void gather_bundles_kernel(float* __restrict__
     float* dst = bundles + (size_t)(j / W) * fields * W + (j % W);
     for (int f = 0; f < fields; ++f) dst[(size_t)f * W] = rows[(size_t)f * stride + d];
 }
+#endif
 
 }  // namespace

@@ -207,6 +207,21 @@ __device__ __noinline__ void report_stall(unsigned* status, unsigned claims, int
         status[5] = want; status[6] = seen; status[7] = claims;
     }
 }
+// Schedule fuzzing (a debugging aid, off unless BEPUHIP_DEBUG_JITTER names a seed): results must not depend on which wave runs which item when, and the waits of this
+// file are what guarantees it. A missing or wrong wait shows only under unusual timing — the overflow-wait race of round 3 needed a cold instruction cache, 0.2 % of the
+// runs of a warm process. With a seed every wave naps a pseudo-random time (0 - 31 x 512 clocks; one item in eight sixteen times longer) before an item waits for its
+// predecessors and again before it publishes: items start and finish in orders no natural run produces, deterministically per (seed, cluster, item, pass). The fuzzers
+// and the regression tests run with it; one wave-uniform compare per call site when it is off. Round 5: the cross-workgroup record protocol naps too — before a wave
+// starts polling its shared bodies' records (acquire_shared / acquire_shared_many) and before it publishes a record (release_shared): hand-offs between clusters then
+// happen in orders and at distances in time no natural run produces, which is what a missing wait or a torn record would need to show.
+__device__ __forceinline__ void jitter_nap(const ClusterShared& sh, unsigned salt) {
+    if (sh.jitter == 0u) return;
+    unsigned x = sh.jitter ^ (salt * 0x9E3779B9u) ^ ((unsigned)blockIdx.x * 0x85EBCA6Bu);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    x = (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+    const unsigned naps = (x & 31u) * (((x >> 5) & 7u) == 0u ? 16u : 1u);
+    for (unsigned n = 0; n < naps; ++n) __builtin_amdgcn_s_sleep(8);
+}
 // ---- shared bodies (split islands): agent-scope traffic, see SharedTables ----
 // The loads wait for their data inside the asm statement (the compiler does not count an asm load in vmcnt); the stores are followed by wait_vm() where
 // an event counter is about to announce them.
@@ -309,6 +324,7 @@ template <bool TWO>
 __device__ __forceinline__ void acquire_shared(const ClusterShared& sh, const SharedRef& ra, DBody& A, const SharedRef& rb, DBody& B, int kind, int k) {
     bool need_a = ra.poll, need_b = TWO && rb.poll;
     if (__builtin_amdgcn_ballot_w64(need_a || need_b) == 0) return;
+    jitter_nap(sh, (unsigned)k * 2u + 0x51u + sh.passes * 0x2545F491u);
     const bool odd = (threadIdx.x & 1u) != 0u;
     const unsigned want_a = ra.number, want_b = rb.number;
     const unsigned record = sh.events - 1u;  // during the sweeps of substep s events == s + 1; the incremental update of substep s runs while events is still s: the record of substep s - 1
@@ -340,6 +356,7 @@ __device__ __forceinline__ void acquire_shared(const ClusterShared& sh, const Sh
 }
 __device__ __forceinline__ void release_shared(const ClusterShared& sh, const SharedRef& r, const DBody& b) {
     if (__builtin_amdgcn_ballot_w64(r.publish) == 0) return;
+    jitter_nap(sh, (unsigned)__builtin_amdgcn_readfirstlane((int)r.number) * 0x9E3779B1u + 0xA7u);
     const bool odd = (threadIdx.x & 1u) != 0u;
     const int mine = r.publish ? r.body : -1, theirs = swap_neighbour(mine);
     const float n = __uint_as_float(r.number + 1u), their_n = swap_neighbour(n);
@@ -363,19 +380,6 @@ __device__ __forceinline__ void acquire_shared_one(const SharedTables& st, unsig
     }
 }
 
-// Schedule fuzzing (a debugging aid, off unless BEPUHIP_DEBUG_JITTER names a seed): results must not depend on which wave runs which item when, and the waits of this
-// file are what guarantees it. A missing or wrong wait shows only under unusual timing — the overflow-wait race of round 3 needed a cold instruction cache, 0.2 % of the
-// runs of a warm process. With a seed every wave naps a pseudo-random time (0 - 31 x 512 clocks; one item in eight sixteen times longer) before an item waits for its
-// predecessors and again before it publishes: items start and finish in orders no natural run produces, deterministically per (seed, cluster, item, pass). The fuzzers
-// and the regression tests run with it; one wave-uniform compare per call site when it is off.
-__device__ __forceinline__ void jitter_nap(const ClusterShared& sh, unsigned salt) {
-    if (sh.jitter == 0u) return;
-    unsigned x = sh.jitter ^ (salt * 0x9E3779B9u) ^ ((unsigned)blockIdx.x * 0x85EBCA6Bu);
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    x = (unsigned)__builtin_amdgcn_readfirstlane((int)x);
-    const unsigned naps = (x & 31u) * (((x >> 5) & 7u) == 0u ? 16u : 1u);
-    for (unsigned n = 0; n < naps; ++n) __builtin_amdgcn_s_sleep(8);
-}
 // Every item [0, count) of the cluster has completed pass `want` (its flag holds the epoch of the last pass it completed): lane l watches item base + l.
 __device__ __forceinline__ void wait_items(const ClusterShared& sh, int count, unsigned want, int kind, int k) {
     const int lane = threadIdx.x & 63;
@@ -507,6 +511,7 @@ __device__ __forceinline__ void acquire_shared_many(const ClusterShared& sh, con
     bool any = false;
     _Pragma("unroll") for (int j = 0; j < N; ++j) { need[j] = s[j].poll; any |= need[j]; }
     if (__builtin_amdgcn_ballot_w64(any) == 0) return;
+    jitter_nap(sh, (unsigned)k * 2u + 0x53u + sh.passes * 0x2545F491u);
     unsigned spins = 0;
     for (;;) {
         any = false;
@@ -614,8 +619,11 @@ __device__ __forceinline__ void run_cluster_constraint_many(const ClusterShared&
     if (STAGE == kStageSolve && active) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) accum[(size_t)f * stride + i] = a[f]; }
 }
 
+#ifndef BEPU_ITEM_INLINE
+#define BEPU_ITEM_INLINE __forceinline__
+#endif
 template <class F, int STAGE, bool TRACE, bool SHARED>
-__device__ __forceinline__ void run_cluster_constraint(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
+__device__ BEPU_ITEM_INLINE void run_cluster_constraint(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
                                                        unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
     // Lanes beyond the item's count mirror its last constraint and never store: the whole body runs with a full exec mask,
     // which keeps the control flow around the (wave-uniform) waits trivially structured.

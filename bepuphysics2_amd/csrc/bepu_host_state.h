@@ -7,10 +7,8 @@
 // cluster_kernel instantiations live in their own translation units (bepu_cluster_{hot,wide}_{1024,768,512}.hip): type set x register budget, each
 // with a traced twin. A kernel compiled for N threads per workgroup gets 65536 / N VGPRs per lane (128 / 168 / 256 after the allocation granule).
 const void* bepu_cluster_kernel_hot_1024(bool trace);
-const void* bepu_cluster_kernel_hot_768(bool trace);
 const void* bepu_cluster_kernel_hot_512(bool trace);
 const void* bepu_cluster_kernel_wide_1024(bool trace);
-const void* bepu_cluster_kernel_wide_768(bool trace);
 const void* bepu_cluster_kernel_wide_512(bool trace);
 const void* bepu_cluster_kernel_hot_1024n(bool trace);   // non-temporal row loads (whole-island plans, 1024 threads)
 const void* bepu_cluster_kernel_wide_1024n(bool trace);
@@ -18,8 +16,6 @@ const void* bepu_cluster_kernel_hot_512sn(bool trace);   // non-temporal row loa
 const void* bepu_cluster_kernel_wide_512sn(bool trace);
 const void* bepu_cluster_kernel_hot_1024s(bool trace);   // split-island plans (shared bodies)
 const void* bepu_cluster_kernel_wide_1024s(bool trace);
-const void* bepu_cluster_kernel_hot_768s(bool trace);
-const void* bepu_cluster_kernel_wide_768s(bool trace);
 const void* bepu_cluster_kernel_hot_512s(bool trace);
 const void* bepu_cluster_kernel_wide_512s(bool trace);
 const void* bepu_cluster_kernel_hot_1024c(bool trace);   // the momentum-conserving angular modes compiled in: whole-island plans at 1024 threads ...
@@ -35,8 +31,8 @@ constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
 // 512-thread workgroups, so that two of them are resident per CU.
 static int cluster_variant_threads(int threads) {
     static const int forced = [] { const char* v = getenv("BEPUHIP_CLUSTER_VARIANT"); return v && *v ? atoi(v) : 0; }();
-    const int fit = threads > 768 ? 1024 : (threads > 512 ? 768 : 512);
-    return (forced == 1024 || forced == 768 || forced == 512) && forced >= fit ? forced : fit;
+    const int fit = threads > 512 ? 1024 : 512;  // (round 5: the 768-thread units, a developer knob that never won a measurement, are gone: 21 translation units instead of 25)
+    return (forced == 1024 || forced == 512) && forced >= fit ? forced : fit;
 }
 // The conserving units exist for the default workgroup sizes only; other sizes (BEPUHIP_CLUSTER_THREADS / BEPUHIP_SPLIT_THREADS) keep such solves on the launch-per-batch schedule.
 static bool conserving_variant_exists(int threads, bool shared) { return cluster_variant_threads(threads) == (shared ? 512 : 1024); }
@@ -45,16 +41,15 @@ static const void* cluster_pass_kernel(bool wide, bool shared) {  // (for the de
 }
 static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false, bool conserving = false) {
     if (conserving) return shared ? (wide ? bepu_cluster_kernel_wide_512sc(trace) : bepu_cluster_kernel_hot_512sc(trace)) : (wide ? bepu_cluster_kernel_wide_1024c(trace) : bepu_cluster_kernel_hot_1024c(trace));
-    if (nt && !shared && cluster_variant_threads(threads) == 1024) return wide ? bepu_cluster_kernel_wide_1024n(trace) : bepu_cluster_kernel_hot_1024n(trace);
-    if (nt && shared && cluster_variant_threads(threads) == 512) return wide ? bepu_cluster_kernel_wide_512sn(trace) : bepu_cluster_kernel_hot_512sn(trace);
+    // (the non-temporal units carry no traced twin: a traced solve runs the plain-row unit of the same size — same results, the timeline of the default policy)
+    if (nt && !trace && !shared && cluster_variant_threads(threads) == 1024) return wide ? bepu_cluster_kernel_wide_1024n(false) : bepu_cluster_kernel_hot_1024n(false);
+    if (nt && !trace && shared && cluster_variant_threads(threads) == 512) return wide ? bepu_cluster_kernel_wide_512sn(false) : bepu_cluster_kernel_hot_512sn(false);
     if (shared) switch (cluster_variant_threads(threads)) {
         case 1024: return wide ? bepu_cluster_kernel_wide_1024s(trace) : bepu_cluster_kernel_hot_1024s(trace);
-        case 768: return wide ? bepu_cluster_kernel_wide_768s(trace) : bepu_cluster_kernel_hot_768s(trace);
         default: return wide ? bepu_cluster_kernel_wide_512s(trace) : bepu_cluster_kernel_hot_512s(trace);
     }
     switch (cluster_variant_threads(threads)) {
         case 1024: return wide ? bepu_cluster_kernel_wide_1024(trace) : bepu_cluster_kernel_hot_1024(trace);
-        case 768: return wide ? bepu_cluster_kernel_wide_768(trace) : bepu_cluster_kernel_hot_768(trace);
         default: return wide ? bepu_cluster_kernel_wide_512(trace) : bepu_cluster_kernel_hot_512(trace);
     }
 }
@@ -161,6 +156,7 @@ struct bepuhip_ctx {
     void* h_staging = nullptr;           // pinned host buffer for what the host does build (references, local references, index tables)
     size_t h_staging_bytes = 0;
     std::vector<void*> registered_host;  // bepuhip_register_host_memory
+    std::vector<size_t> registered_bytes;  // ... and how far each registration reaches (ranges inside one are read and written by kernels directly: mapped_pointer)
     // constraints
     bool building = false, built = false;
     int batch_count = 0;                 // the caller's batches, a sequential fallback batch included
@@ -182,6 +178,8 @@ struct bepuhip_ctx {
     uint32_t* d_slab0 = nullptr;         // pristine snapshot
     float* d_stage = nullptr;            // staging for ranged updates / read-backs (caller's AOSOA bundles)
     size_t stage_floats = 0;
+    char* h_desc_ring = nullptr;         // pinned: descriptor tables of bepuhip_transfer_rows_async calls that have not been synchronised yet (bump-allocated, reset by bepuhip_sync)
+    size_t desc_ring_bytes = 0, desc_ring_used = 0;
     size_t slab_words = 0;
     DevTypeBatch* d_tbs = nullptr;       // per (batch) descriptors, solve/warm-start grids
     DevTypeBatch* d_inc_tbs = nullptr;   // incremental-update grid (contacts of all batches)

@@ -52,6 +52,7 @@ using namespace bd;
 //   this file                the C ABI of include/bepuhip.h: uploads, graph capture / launch sequence, read-backs
 #include "bepu_kernels_common.h"
 #include "bepu_batch_kernels.h"
+#include "bepu_transfer_kernels.h"
 #include "bepu_colour_kernels.h"
 #include "bepu_host_state.h"
 #include "bepu_cluster_plan.h"
@@ -131,6 +132,7 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_mesh_begin) hipFree(c->d_mesh_begin);
     if (c->d_mesh_scales) hipFree(c->d_mesh_scales);
     if (c->d_stage) hipFree(c->d_stage);
+    if (c->h_desc_ring) hipHostFree(c->h_desc_ring);
     for (auto& chunk : c->raw_chunks) if (chunk.ptr) hipFree(chunk.ptr);
     if (c->h_staging) hipHostFree(c->h_staging);
     for (void* p : c->registered_host) hipHostUnregister(p);
@@ -1612,6 +1614,7 @@ int32_t bepuhip_sync(bepuhip_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) c->last_ms = ms;
+    c->desc_ring_used = 0;  // every transfer_rows descriptor table has been consumed
     if (c->clusters_enabled) {
         unsigned st[8];
         memcpy(st, c->d_status, sizeof(st));
@@ -1665,6 +1668,7 @@ int32_t bepuhip_register_host_memory(bepuhip_ctx* c, void* memory, int64_t bytes
     }
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(BEPUHIP_E_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
     c->registered_host.push_back(memory);
+    c->registered_bytes.push_back((size_t)bytes);
     return BEPUHIP_OK;
 }
 int32_t bepuhip_unregister_host_memory(bepuhip_ctx* c, void* memory) {
@@ -1675,9 +1679,32 @@ int32_t bepuhip_unregister_host_memory(bepuhip_ctx* c, void* memory) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipHostUnregister(memory));
             c->registered_host.erase(c->registered_host.begin() + i);
+            c->registered_bytes.erase(c->registered_bytes.begin() + i);
             return BEPUHIP_OK;
         }
     return fail(BEPUHIP_E_INVALID_ARGUMENT, "this memory was not registered through this context");
+}
+
+// Host memory this context registered is mapped into the device's address space: a kernel reads and writes it directly over the link — one launch where a copy per
+// type batch (or a strided 2-D copy, which the runtime runs at a fifth of the link's rate: tools/probes/pcie_frame_probe.hip, profiles/r05_s1_pcie_frame_probe.txt)
+// would be needed. nullptr: the range is not wholly inside one of OUR registrations (pageable memory, somebody else's registration): the caller stages.
+static void* mapped_pointer(bepuhip_ctx* c, const void* host, size_t bytes) {
+    if (!host || bytes == 0 || env_int("BEPUHIP_NO_ZERO_COPY", 0)) return nullptr;
+    for (size_t i = 0; i < c->registered_host.size(); ++i) {
+        const char* base = (const char*)c->registered_host[i];
+        if ((const char*)host < base || (const char*)host + bytes > base + c->registered_bytes[i]) continue;
+        void* device = nullptr;
+        if (hipHostGetDevicePointer(&device, c->registered_host[i], 0) != hipSuccess || !device) { (void)hipGetLastError(); return nullptr; }
+        return (char*)device + ((const char*)host - base);
+    }
+    return nullptr;
+}
+// MotionState halves of `count` BodyDynamics records straight into the host's array: lane quartets move one body's four float4 (64 of every 128 bytes).
+__global__ __launch_bounds__(256) void poses_out_kernel(const float4* __restrict__ bodies, float4* __restrict__ host, int count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)count * 4) return;
+    const size_t at = (i >> 2) * 8 + (i & 3);
+    host[at] = bodies[at];
 }
 
 // What a host needs back after a solve: poses and velocities — the first 64 bytes of every 128-byte BodyDynamics (MotionState: orientation, position, linear,
@@ -1686,7 +1713,13 @@ int32_t bepuhip_unregister_host_memory(bepuhip_ctx* c, void* memory) {
 int32_t bepuhip_get_poses_and_velocities_async(bepuhip_ctx* c, void* body_dynamics_aos, int32_t count) {
     if (!c || (!body_dynamics_aos && count > 0) || count < 0 || count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad get_poses_and_velocities argument");
     HIP_TRY(hipSetDevice(c->device));
-    if (count > 0) HIP_TRY(hipMemcpy2DAsync(body_dynamics_aos, 128, c->d_bodies, 128, 64, (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    if (count == 0) return BEPUHIP_OK;
+    if (void* mapped = mapped_pointer(c, body_dynamics_aos, (size_t)count * 128)) {  // 15 MB in 0.34 ms; the 2-D copy below takes 1.4 ms
+        poses_out_kernel<<<(unsigned)(((size_t)count * 4 + 255) / 256), 256, 0, c->stream>>>((const float4*)c->d_bodies, (float4*)mapped, count);
+        HIP_TRY(hipGetLastError());
+        return BEPUHIP_OK;
+    }
+    HIP_TRY(hipMemcpy2DAsync(body_dynamics_aos, 128, c->d_bodies, 128, 64, (size_t)count, hipMemcpyDeviceToHost, c->stream));
     return BEPUHIP_OK;
 }
 int32_t bepuhip_get_poses_and_velocities(bepuhip_ctx* c, void* body_dynamics_aos, int32_t count) {
@@ -2095,73 +2128,121 @@ static int32_t device_index_of(bepuhip_ctx* c, HostTypeBatch* tb, const int** ou
     *out = tb->d_device_index;
     return BEPUHIP_OK;
 }
-static int32_t bundle_range(bepuhip_ctx* c, int batch, int type_id, int first_bundle, int bundle_count, const void* buffer, HostTypeBatch** tb_out, int* first, int* n) {
-    if (!c || !c->built) return fail(BEPUHIP_E_STATE, "no constraints uploaded");
+// A frame's row traffic in one call (include/bepuhip.h). Consecutive items of one direction form a run: a run of updates is N host-to-device copies into the staging
+// buffer and ONE scatter launch (two with the snapshot), a run of gets ONE gather launch and N device-to-host copies — where the single calls cost two or three stream
+// operations per type batch each (96 type batches on the bench scene). Everything is enqueued on the context's stream; the staging buffer is reused in stream order.
+static int32_t transfer_run(bepuhip_ctx* c, const bepuhip_row_transfer* items, int count) {
+    const bool update = items[0].kind == BEPUHIP_ROWS_UPDATE_PRESTEP || items[0].kind == BEPUHIP_ROWS_UPDATE_IMPULSES;
+    std::vector<RowTransferDesc> descs;
+    struct Copy { size_t stage_off, floats; void* host; };
+    std::vector<Copy> copies;  // the items that go through the staging buffer (host memory this context has not registered)
+    size_t staged_floats = 0;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const bepuhip_row_transfer& it = items[i];
+        HostTypeBatch* tb = find_tb(c, it.batch_index, it.type_id);
+        if (!tb) return fail(BEPUHIP_E_INVALID_ARGUMENT, "transfer_rows item " + std::to_string(i) + ": no such type batch");
+        const int bundles = (tb->count + c->W - 1) / c->W;
+        const int first_bundle = it.first_bundle, bundle_count = it.bundle_count < 0 ? bundles - first_bundle : it.bundle_count;
+        if (first_bundle < 0 || bundle_count < 0 || (int64_t)first_bundle + bundle_count > bundles || (!it.bundles && bundle_count > 0))
+            return fail(BEPUHIP_E_INVALID_ARGUMENT, "transfer_rows item " + std::to_string(i) + ": bundle range exceeds the type batch");
+        const int first = first_bundle * c->W, n = std::min(bundle_count * c->W, tb->count - first);
+        if (n <= 0) continue;
+        const bool prestep = it.kind == BEPUHIP_ROWS_UPDATE_PRESTEP || it.kind == BEPUHIP_ROWS_GET_PRESTEP;
+        const int fields = prestep ? tb->info.prestep : tb->info.impulse;
+        const int* index;
+        int32_t st = device_index_of(c, tb, &index);
+        if (st != BEPUHIP_OK) return st;
+        const size_t floats = (size_t)bundle_count * fields * c->W;
+        float* mapped = ((uintptr_t)it.bundles & 15u) ? nullptr : (float*)mapped_pointer(c, it.bundles, floats * 4);  // the kernel moves 16-byte quads
+        if (!mapped) { copies.push_back(Copy{staged_floats, floats, it.bundles}); staged_floats += (floats + 3) / 4 * 4; }
+        // (a staged item's pointer is filled in below, once the staging buffer has its final address)
+        descs.push_back(RowTransferDesc{mapped, prestep ? tb->prestep_off : tb->accum_off, index, first, n, fields, tb->stride, blocks, mapped ? 0 : (int)copies.size()});
+        blocks += (int)((floats / 4 + 255) / 256);  // a thread moves four consecutive floats of the bundles: four lanes of one field
+    }
+    if (descs.empty()) return BEPUHIP_OK;
+    const size_t table_bytes = descs.size() * sizeof(RowTransferDesc), table_floats = (table_bytes + 3) / 4;
+    int32_t st = stage_reserve(c, staged_floats + table_floats + 64);
+    if (st != BEPUHIP_OK) return st;
+    for (RowTransferDesc& d : descs) if (d.staged) d.bundles = c->d_stage + copies[d.staged - 1].stage_off;
+    // the descriptor table travels through pinned memory that stays untouched until the next bepuhip_sync (the copy is asynchronous)
+    if (c->desc_ring_used + table_bytes > c->desc_ring_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->desc_ring_used = 0;
+        if (table_bytes > c->desc_ring_bytes) {
+            if (c->h_desc_ring) hipHostFree(c->h_desc_ring);
+            c->h_desc_ring = nullptr; c->desc_ring_bytes = 0;
+            const size_t want = std::max<size_t>(table_bytes * 2, 1u << 18);
+            HIP_TRY(hipHostMalloc((void**)&c->h_desc_ring, want, hipHostMallocDefault));
+            c->desc_ring_bytes = want;
+        }
+    }
+    char* slot = c->h_desc_ring + c->desc_ring_used;
+    c->desc_ring_used += (table_bytes + 63) / 64 * 64;
+    memcpy(slot, descs.data(), table_bytes);
+    float* d_table = c->d_stage + ((staged_floats + 15) / 16) * 16;
+    HIP_TRY(hipMemcpyAsync(d_table, slot, table_bytes, hipMemcpyHostToDevice, c->stream));
+    if (update) {
+        for (const Copy& copy : copies) HIP_TRY(hipMemcpyAsync(c->d_stage + copy.stage_off, copy.host, copy.floats * 4, hipMemcpyHostToDevice, c->stream));
+        for (uint32_t* slab : {c->d_slab, c->d_slab0})  // the pristine snapshot follows, as with every update_* call
+            if (slab) transfer_rows_kernel<true><<<blocks, 256, 0, c->stream>>>((const RowTransferDesc*)d_table, (int)descs.size(), (float*)slab, c->W);
+        HIP_TRY(hipGetLastError());
+    } else {
+        transfer_rows_kernel<false><<<blocks, 256, 0, c->stream>>>((const RowTransferDesc*)d_table, (int)descs.size(), (float*)c->d_slab, c->W);
+        HIP_TRY(hipGetLastError());
+        for (const Copy& copy : copies) HIP_TRY(hipMemcpyAsync(copy.host, c->d_stage + copy.stage_off, copy.floats * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_transfer_rows_async(bepuhip_ctx* c, const bepuhip_row_transfer* items, int32_t count) {
+    if (!c || count < 0 || (count > 0 && !items)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad transfer_rows argument");
+    if (!c->built) return fail(BEPUHIP_E_STATE, "no constraints uploaded");
+    if (count == 0) return BEPUHIP_OK;
+    for (int i = 0; i < count; ++i)
+        if (items[i].kind < BEPUHIP_ROWS_UPDATE_PRESTEP || items[i].kind > BEPUHIP_ROWS_GET_IMPULSES) return fail(BEPUHIP_E_INVALID_ARGUMENT, "transfer_rows item " + std::to_string(i) + ": unknown kind");
+    HIP_TRY(hipSetDevice(c->device));
     { const int32_t fs = flush_structural(c); if (fs != BEPUHIP_OK) return fs; }
-    if (first_bundle < 0 || bundle_count < 0 || (!buffer && bundle_count > 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad bundle range");
-    HostTypeBatch* tb = find_tb(c, batch, type_id);
-    if (!tb) return fail(BEPUHIP_E_INVALID_ARGUMENT, "no such type batch");
-    const int bundles = (tb->count + c->W - 1) / c->W;
-    if ((int64_t)first_bundle + bundle_count > bundles) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bundle range exceeds the type batch");
-    *tb_out = tb;
-    *first = first_bundle * c->W;
-    *n = std::min(bundle_count * c->W, tb->count - *first);  // trailing lanes of the last bundle are empty (TypeProcessor.cs:287-298)
+    int begin = 0;
+    while (begin < count) {
+        const bool update = items[begin].kind <= BEPUHIP_ROWS_UPDATE_IMPULSES;
+        int end = begin + 1;
+        while (end < count && (items[end].kind <= BEPUHIP_ROWS_UPDATE_IMPULSES) == update) ++end;
+        const int32_t st = transfer_run(c, items + begin, end - begin);
+        if (st != BEPUHIP_OK) return st;
+        begin = end;
+    }
     return BEPUHIP_OK;
 }
-static int32_t update_rows(bepuhip_ctx* c, int batch, int type_id, int first_bundle, int bundle_count, const float* bundles, bool prestep, bool wait = true) {
-    HostTypeBatch* tb; int first, n;
-    int32_t st = bundle_range(c, batch, type_id, first_bundle, bundle_count, bundles, &tb, &first, &n);
-    if (st != BEPUHIP_OK || n <= 0) return st;
-    HIP_TRY(hipSetDevice(c->device));
-    const int fields = prestep ? tb->info.prestep : tb->info.impulse;
-    const size_t floats = (size_t)bundle_count * fields * c->W;
-    if ((st = stage_reserve(c, floats)) != BEPUHIP_OK) return st;
-    const int* index;
-    if ((st = device_index_of(c, tb, &index)) != BEPUHIP_OK) return st;
-    HIP_TRY(hipMemcpyAsync(c->d_stage, bundles, floats * 4, hipMemcpyHostToDevice, c->stream));
-    const size_t off = prestep ? tb->prestep_off : tb->accum_off;
-    for (uint32_t* slab : {c->d_slab, c->d_slab0})  // the pristine snapshot follows, so that reset_state restores "what the set_*/update_* calls uploaded"
-        if (slab) scatter_bundles_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_stage, (float*)(slab + off), index, first, n, fields, tb->stride, c->W);
-    HIP_TRY(hipGetLastError());
-    if (wait) HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's buffer is free again on return (the staging buffer is reused in stream order either way)
-    return BEPUHIP_OK;
-}
-static int32_t read_rows(bepuhip_ctx* c, int batch, int type_id, int first_bundle, int bundle_count, float* bundles_out, bool prestep) {
-    HostTypeBatch* tb; int first, n;
-    int32_t st = bundle_range(c, batch, type_id, first_bundle, bundle_count, bundles_out, &tb, &first, &n);
-    if (st != BEPUHIP_OK || n <= 0) return st;
-    HIP_TRY(hipSetDevice(c->device));
-    const int fields = prestep ? tb->info.prestep : tb->info.impulse;
-    const size_t floats = (size_t)bundle_count * fields * c->W;
-    if ((st = stage_reserve(c, floats)) != BEPUHIP_OK) return st;
-    const int* index;
-    if ((st = device_index_of(c, tb, &index)) != BEPUHIP_OK) return st;
-    HIP_TRY(hipMemsetAsync(c->d_stage, 0, floats * 4, c->stream));  // empty trailing lanes read back as zero
-    const size_t off = prestep ? tb->prestep_off : tb->accum_off;
-    gather_bundles_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_stage, (const float*)(c->d_slab + off), index, first, n, fields, tb->stride, c->W);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(bundles_out, c->d_stage, floats * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+
+// The single ranged calls are one-item transfers (synchronous unless _async).
+static int32_t transfer_one(bepuhip_ctx* c, int kind, int batch, int type_id, int first_bundle, int bundle_count, const void* bundles, bool wait) {
+    if (!c || !c->built) return fail(BEPUHIP_E_STATE, "no constraints uploaded");
+    if (first_bundle < 0 || bundle_count < 0 || (!bundles && bundle_count > 0)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad bundle range");
+    const bepuhip_row_transfer item{kind, batch, type_id, first_bundle, bundle_count, 0, const_cast<void*>(bundles)};
+    const int32_t st = bepuhip_transfer_rows_async(c, &item, 1);
+    if (st != BEPUHIP_OK) return st;
+    if (wait) HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's buffer is free again on return
     return BEPUHIP_OK;
 }
 int32_t bepuhip_update_prestep(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* prestep_bundles) {
-    return update_rows(c, batch, type_id, first_bundle, bundle_count, prestep_bundles, true);
+    return transfer_one(c, BEPUHIP_ROWS_UPDATE_PRESTEP, batch, type_id, first_bundle, bundle_count, prestep_bundles, true);
 }
 int32_t bepuhip_update_prestep_async(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* prestep_bundles) {
-    return update_rows(c, batch, type_id, first_bundle, bundle_count, prestep_bundles, true, false);
+    return transfer_one(c, BEPUHIP_ROWS_UPDATE_PRESTEP, batch, type_id, first_bundle, bundle_count, prestep_bundles, false);
 }
 int32_t bepuhip_update_accumulated_impulses(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* impulse_bundles) {
-    return update_rows(c, batch, type_id, first_bundle, bundle_count, impulse_bundles, false);
+    return transfer_one(c, BEPUHIP_ROWS_UPDATE_IMPULSES, batch, type_id, first_bundle, bundle_count, impulse_bundles, true);
 }
 int32_t bepuhip_update_accumulated_impulses_async(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, const float* impulse_bundles) {
-    return update_rows(c, batch, type_id, first_bundle, bundle_count, impulse_bundles, false, false);
+    return transfer_one(c, BEPUHIP_ROWS_UPDATE_IMPULSES, batch, type_id, first_bundle, bundle_count, impulse_bundles, false);
 }
 int32_t bepuhip_get_prestep_range(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* prestep_bundles_out) {
-    return read_rows(c, batch, type_id, first_bundle, bundle_count, prestep_bundles_out, true);
+    return transfer_one(c, BEPUHIP_ROWS_GET_PRESTEP, batch, type_id, first_bundle, bundle_count, prestep_bundles_out, true);
 }
 int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* impulse_bundles_out) {
-    return read_rows(c, batch, type_id, first_bundle, bundle_count, impulse_bundles_out, false);
+    return transfer_one(c, BEPUHIP_ROWS_GET_IMPULSES, batch, type_id, first_bundle, bundle_count, impulse_bundles_out, true);
 }
+
 int32_t bepuhip_update_bodies(bepuhip_ctx* c, const void* aos, int32_t first, int32_t count) {
     if (!c || first < 0 || count < 0 || (!aos && count > 0) || (int64_t)first + count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad body range");
     if (count == 0) return BEPUHIP_OK;

@@ -172,7 +172,9 @@ int Solver::Add(const int32_t* bodyHandles, int bodyCount, int typeId, const flo
                 if (batchReferencedHandles[b].Contains(blocking[i])) { fits = false; break; }
             if (!fits) continue;
         }
-        int handle = (int)HandleToConstraint.size();
+        int handle;
+        if (!HandlePool.empty()) { handle = HandlePool.back(); HandlePool.pop_back(); }  // IdPool.Take: the most recently returned id first
+        else { handle = (int)HandleToConstraint.size(); HandleToConstraint.push_back({-1, 0, 0}); }
         TypeBatch& tb = Batches[b].GetOrCreateTypeBatch(typeId);
         int index = tb.Allocate(handle, encoded);
         for (int i = 0; i < blockingCount; ++i) batchReferencedHandles[b].Set(blocking[i]);
@@ -180,7 +182,7 @@ int Solver::Add(const int32_t* bodyHandles, int bodyCount, int typeId, const flo
         const int W = kBundleWidth;
         float* lane = tb.PrestepData.data() + (size_t)(index / W) * info.prestepFloats * W + (index % W);
         for (int f = 0; f < info.prestepFloats; ++f) lane[(size_t)f * W] = prestepLane[f];
-        HandleToConstraint.push_back({b, typeId, index});
+        HandleToConstraint[handle] = {b, typeId, index};
         ++liveConstraints;
         StructuralChange change{true, b, typeId, index, {-1, -1, -1, -1}, std::vector<float>(prestepLane, prestepLane + info.prestepFloats)};
         for (int i = 0; i < bodyCount; ++i) change.encoded[i] = encoded[i];
@@ -221,9 +223,37 @@ void Solver::Remove(int constraintHandle) {
     for (int k = 0; k < nb; ++k) ref(last, k) = -1;  // the vacated lane reads as empty again (TypeProcessor.cs:287-298)
     tb.ConstraintCount = last;
     HandleToConstraint[constraintHandle].BatchIndex = -1;
+    HandlePool.push_back(constraintHandle);
     --liveConstraints;
     ++TopologyVersion;
     StructuralLog.push_back(StructuralChange{false, loc.BatchIndex, loc.TypeId, index, {-1, -1, -1, -1}, {}});
+}
+
+static TypeBatch& LocateTypeBatch(Solver& solver, int constraintHandle, int& index) {
+    if (constraintHandle < 0 || constraintHandle >= (int)solver.HandleToConstraint.size() || solver.HandleToConstraint[constraintHandle].BatchIndex < 0)
+        throw std::invalid_argument("the constraint handle does not name a live constraint");
+    const ConstraintLocation loc = solver.HandleToConstraint[constraintHandle];
+    ConstraintBatch& batch = solver.Batches[loc.BatchIndex];
+    index = loc.IndexInTypeBatch;
+    return batch.TypeBatches[batch.TypeIndexToTypeBatchIndex.at(loc.TypeId)];
+}
+void Solver::ApplyDescription(int constraintHandle, const float* prestepLane) {  // Solver.cs:1162-1185 -> TDescription.ApplyDescription (GetOffsetInstance / GetFirst writes)
+    int index;
+    TypeBatch& tb = LocateTypeBatch(*this, constraintHandle, index);
+    const int W = kBundleWidth, pf = tb.Info.prestepFloats;
+    for (int f = 0; f < pf; ++f) tb.PrestepData[(size_t)(index / W) * pf * W + (size_t)f * W + (index % W)] = prestepLane[f];
+}
+void Solver::SetAccumulatedImpulses(int constraintHandle, const float* impulseLane) {
+    int index;
+    TypeBatch& tb = LocateTypeBatch(*this, constraintHandle, index);
+    const int W = kBundleWidth, imf = tb.Info.impulseFloats;
+    for (int f = 0; f < imf; ++f) tb.AccumulatedImpulses[(size_t)(index / W) * imf * W + (size_t)f * W + (index % W)] = impulseLane[f];
+}
+void Solver::GetAccumulatedImpulses(int constraintHandle, float* impulseLane) const {
+    int index;
+    const TypeBatch& tb = LocateTypeBatch(const_cast<Solver&>(*this), constraintHandle, index);
+    const int W = kBundleWidth, imf = tb.Info.impulseFloats;
+    for (int f = 0; f < imf; ++f) impulseLane[f] = tb.AccumulatedImpulses[(size_t)(index / W) * imf * W + (size_t)f * W + (index % W)];
 }
 
 void Solver::ValidateBatches() const {
@@ -306,39 +336,60 @@ void Simulation::Timestep(float dt) {  // Simulation.cs:316-326
 // which came and which references changed. What it does not tell is the ORDER of the removals, which decides where swap-with-last left the survivors — hence the
 // fourth operation, swap: removals (in any order) + additions (in index order) + swaps (at most one per index that still disagrees) + reference patches reproduce
 // exactly this frame's arrangement. Operations are emitted in the form bepuhip_apply_structural_ops takes.
+// Identity: a constraint is the same constraint as last frame's when its handle AND the handles of its bodies are the same. The constraint handle alone is not enough:
+// Solver.HandlePool hands a freed handle out again last-in-first-out (IdPool.Take), so Solver.Remove(h) followed by Solver.Add(...) in one frame returns h for a different
+// constraint — possibly at the same index of the same type batch. `oldBodyHandles` / `newBodyHandles` ([count][bodies], Bodies.ActiveSet.IndexToHandle of every
+// reference) tell the two apart; a reused handle becomes a removal plus an addition. A body that only moved in memory keeps its handle: that is the reference patch.
+// Removals go to `removals`, everything else to `ops`: the caller sends EVERY type batch's removals before any addition (a constraint that replaces another one on the same
+// bodies in the same batch — a hinge swapped for a weld — would otherwise arrive while its bodies still look taken: the island layout checks the batch invariant).
+// `survivorOldIndex` (optional, newCount entries): for every constraint of the new arrangement the index it had last frame, or -1 when it is new — what the caller needs to
+// carry its copy of the device's prestep data and impulses along.
 void DiffTypeBatch(int batch, int typeId, int bodies, int prestepFloats, const int32_t* oldHandles, int oldCount, const int32_t* oldReferences /* [oldCount][bodies] */,
-                   const int32_t* newHandles, int newCount, const int32_t* newReferencesAosoa, const float* newPrestepAosoa,
-                   std::vector<bepuhip_structural_op>& ops, std::vector<uint32_t>& payload) {
+                   const int32_t* oldBodyHandles /* [oldCount][bodies] or null */, const int32_t* newHandles, int newCount, const int32_t* newReferencesAosoa,
+                   const int32_t* newBodyHandles /* [newCount][bodies] or null */, const float* newPrestepAosoa, std::vector<bepuhip_structural_op>& removals,
+                   std::vector<bepuhip_structural_op>& ops, std::vector<uint32_t>& payload, std::vector<int32_t>* survivorOldIndex) {
     auto lane_ref = [&](int index, int k) { return newReferencesAosoa[(size_t)(index / kBundleWidth) * bodies * kBundleWidth + (size_t)k * kBundleWidth + index % kBundleWidth]; };
     auto lane_prestep = [&](int index, int f) { return newPrestepAosoa[(size_t)(index / kBundleWidth) * prestepFloats * kBundleWidth + (size_t)f * kBundleWidth + index % kBundleWidth]; };
-    if (oldCount == newCount && (oldCount == 0 || std::memcmp(oldHandles, newHandles, (size_t)oldCount * 4) == 0)) {  // the common case: same constraints at the same indices
-        for (int i = 0; i < newCount; ++i)
+    const bool identities = oldBodyHandles && newBodyHandles;
+    if (survivorOldIndex) survivorOldIndex->assign((size_t)newCount, -1);
+    if (oldCount == newCount && (oldCount == 0 || std::memcmp(oldHandles, newHandles, (size_t)oldCount * 4) == 0) &&
+        (!identities || oldCount == 0 || std::memcmp(oldBodyHandles, newBodyHandles, (size_t)oldCount * bodies * 4) == 0)) {  // the common case: same constraints at the same indices
+        for (int i = 0; i < newCount; ++i) {
+            if (survivorOldIndex) (*survivorOldIndex)[i] = i;
             for (int k = 0; k < bodies; ++k)
                 if (oldReferences[(size_t)i * bodies + k] != lane_ref(i, k)) ops.push_back({2, batch, typeId, i, k, lane_ref(i, k), 0, 0});
+        }
         return;
     }
-    std::unordered_map<int32_t, int32_t> newIndexOf, position, oldIndexOf;
+    std::unordered_map<int64_t, int32_t> newIndexOf, position, oldIndexOf;
     newIndexOf.reserve((size_t)newCount * 2); position.reserve((size_t)oldCount * 2); oldIndexOf.reserve((size_t)oldCount * 2);
     for (int i = 0; i < newCount; ++i) newIndexOf[newHandles[i]] = i;
-    std::vector<int32_t> list(oldHandles, oldHandles + oldCount);  // the device's type batch as the operations so far leave it
-    for (int i = 0; i < oldCount; ++i) { position[oldHandles[i]] = i; oldIndexOf[oldHandles[i]] = i; }
+    // keys: the handle — except for an old constraint whose handle names a DIFFERENT constraint now (other bodies): it gets a key no new constraint has
+    std::vector<int64_t> list((size_t)oldCount);  // the device's type batch as the operations so far leave it
+    for (int j = 0; j < oldCount; ++j) {
+        int64_t key = oldHandles[j];
+        auto now = newIndexOf.find(key);
+        if (identities && now != newIndexOf.end() && std::memcmp(oldBodyHandles + (size_t)j * bodies, newBodyHandles + (size_t)now->second * bodies, (size_t)bodies * 4) != 0) key = -1 - key;
+        list[j] = key; position[key] = j; oldIndexOf[key] = j;
+    }
+    const std::vector<int64_t> oldKeys = list;
     for (int i = oldCount - 1; i >= 0; --i) {  // removals, highest old index first (any order is right; this one moves the fewest survivors)
-        const int32_t handle = oldHandles[i];
-        if (newIndexOf.count(handle)) continue;
-        const int at = position[handle], last = (int)list.size() - 1;
-        ops.push_back({1, batch, typeId, at, 0, 0, 0, 0});
+        const int64_t key = oldKeys[i];
+        if (key >= 0 && newIndexOf.count(key)) continue;
+        const int at = position[key], last = (int)list.size() - 1;
+        removals.push_back({1, batch, typeId, at, 0, 0, 0, 0});
         if (at != last) { list[at] = list[last]; position[list[at]] = at; }
         list.pop_back();
-        position.erase(handle);
+        position.erase(key);
     }
     for (int i = 0; i < newCount; ++i) {  // additions, in the order of their final indices
-        const int32_t handle = newHandles[i];
-        if (oldIndexOf.count(handle)) continue;
+        const int64_t key = newHandles[i];
+        if (oldIndexOf.count(key)) continue;
         ops.push_back({0, batch, typeId, (int32_t)list.size(), 0, 0, (int32_t)payload.size(), 0});
         for (int k = 0; k < bodies; ++k) payload.push_back((uint32_t)lane_ref(i, k));
         for (int f = 0; f < prestepFloats; ++f) { const float v = lane_prestep(i, f); uint32_t w; std::memcpy(&w, &v, 4); payload.push_back(w); }
-        position[handle] = (int32_t)list.size();
-        list.push_back(handle);
+        position[key] = (int32_t)list.size();
+        list.push_back(key);
     }
     for (int i = 0; i < newCount; ++i) {  // the same set by now: put every index right
         if (list[i] == newHandles[i]) continue;
@@ -350,6 +401,7 @@ void DiffTypeBatch(int batch, int typeId, int bodies, int prestepFloats, const i
     for (int i = 0; i < newCount; ++i) {  // survivors whose bodies moved in memory
         auto was = oldIndexOf.find(newHandles[i]);
         if (was == oldIndexOf.end()) continue;
+        if (survivorOldIndex) (*survivorOldIndex)[i] = was->second;
         for (int k = 0; k < bodies; ++k)
             if (oldReferences[(size_t)was->second * bodies + k] != lane_ref(i, k)) ops.push_back({2, batch, typeId, i, k, lane_ref(i, k), 0, 0});
     }
@@ -358,20 +410,18 @@ void DiffTypeBatch(int batch, int typeId, int bodies, int prestepFloats, const i
 // ---- HipTimestepper: DefaultTimestepper.Timestep (DefaultTimestepper.cs:28-43) with simulation.Solve replaced by the C ABI ----
 struct HipApi {
     void* lib = nullptr;
+#define BEPU_API(X) X(bepuhip_last_error) X(bepuhip_create) X(bepuhip_destroy) X(bepuhip_set_bodies) X(bepuhip_begin_constraints) X(bepuhip_set_type_batch) X(bepuhip_end_constraints) \
+    X(bepuhip_set_constrained_kinematics) X(bepuhip_solve) X(bepuhip_get_bodies) X(bepuhip_get_accumulated_impulses) X(bepuhip_get_prestep) X(bepuhip_add_constraint) \
+    X(bepuhip_remove_constraint) X(bepuhip_apply_structural_ops) X(bepuhip_transfer_rows_async) X(bepuhip_solve_async) X(bepuhip_sync) X(bepuhip_get_poses_and_velocities_async) \
+    X(bepuhip_register_host_memory) X(bepuhip_unregister_host_memory) X(bepuhip_get_schedule) X(bepuhip_replan)
 #define DECL(name) decltype(&::name) name = nullptr;
-    DECL(bepuhip_last_error) DECL(bepuhip_create) DECL(bepuhip_destroy) DECL(bepuhip_set_bodies) DECL(bepuhip_begin_constraints)
-    DECL(bepuhip_set_type_batch) DECL(bepuhip_end_constraints) DECL(bepuhip_set_constrained_kinematics) DECL(bepuhip_solve)
-    DECL(bepuhip_get_bodies) DECL(bepuhip_get_accumulated_impulses) DECL(bepuhip_get_prestep) DECL(bepuhip_add_constraint) DECL(bepuhip_remove_constraint)
-    DECL(bepuhip_apply_structural_ops)
+    BEPU_API(DECL)
 #undef DECL
     bool load(const char* path, std::string& err) {
         lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
         if (!lib) { err = dlerror(); return false; }
 #define LOAD(name) name = (decltype(name))dlsym(lib, #name); if (!name) { err = std::string("missing symbol ") + #name; return false; }
-        LOAD(bepuhip_last_error) LOAD(bepuhip_create) LOAD(bepuhip_destroy) LOAD(bepuhip_set_bodies) LOAD(bepuhip_begin_constraints)
-        LOAD(bepuhip_set_type_batch) LOAD(bepuhip_end_constraints) LOAD(bepuhip_set_constrained_kinematics) LOAD(bepuhip_solve)
-        LOAD(bepuhip_get_bodies) LOAD(bepuhip_get_accumulated_impulses) LOAD(bepuhip_get_prestep) LOAD(bepuhip_add_constraint) LOAD(bepuhip_remove_constraint)
-        LOAD(bepuhip_apply_structural_ops)
+        BEPU_API(LOAD)
 #undef LOAD
         return true;
     }
@@ -383,48 +433,99 @@ public:
     bepuhip_ctx* ctx = nullptr;
     uint64_t uploadedSolverVersion = ~0ull, uploadedBodiesVersion = ~0ull;
     int fullUploads = 0, structuralReplays = 0, diffOperations = 0;
+    int64_t refreshedBundles = 0;  // bundles of non-contact prestep data / impulses the resident frame found changed on the host and sent
     size_t uploadedKinematics = 0;
-    // How the constraint changes of a frame reach the device: 0 = the solver's structural log (what a listener inside the reference would record), 1 = the diff of the
-    // type batches against last frame's copy (public API only: what integration/csharp/HipTimestepper.cs does by default).
+    // How the constraint changes of a frame reach the device:
+    //   0  the solver's structural log (what a listener inside the reference would record);
+    //   1  the diff of the type batches against last frame's copy (public API only), everything read back synchronously every frame (round 4);
+    //   2  the RESIDENT frame integration/csharp/HipTimestepper.cs runs (round 5): the diff in two phases, the device's prestep data and impulses shadowed on the host so
+    //      that what the host rewrote in place since the last frame — Solver.ApplyDescription on motors and servos (Tank.cs:100,139, SimpleCar.cs:25), impulses the awakener
+    //      restored, a handle the pool handed out again — is found by comparison and sent by bundle range; poses, velocities and ALL accumulated impulses back
+    //      asynchronously behind the solve, one sync per frame.
     int mode = 0;
-    struct Mirror { std::vector<int32_t> handles, references; int bodies = 0; };
+    bool readBackContactDepths = false;  // mode 2: also fetch the contact type batches' prestep data (the depths substeps > 0 advanced): a narrow phase rewrites them anyway; tests compare them
+    struct Mirror {
+        std::vector<int32_t> handles, references, bodyHandles;
+        std::vector<float> prestep, impulses;  // mode 2: what the device holds, in the type batch's own AOSOA layout (non-contact type batches)
+        int bodies = 0; bool contact = false;
+    };
     std::unordered_map<uint64_t, Mirror> mirrors;  // (batch index << 32 | type id) -> the type batch as the device has it
-    void RememberTypeBatches(const Solver& solver) {
+    std::vector<void*> registered;
+    void Register(void* memory, size_t bytes) {  // BufferPool blocks are pinned for the simulation's life; this mirror's std::vectors move when they grow: re-registered when they do
+        if (!memory || bytes == 0) return;
+        if (api.bepuhip_register_host_memory(ctx, memory, (int64_t)bytes) == BEPUHIP_OK) registered.push_back(memory);
+    }
+    void UnregisterAll() { for (void* p : registered) api.bepuhip_unregister_host_memory(ctx, p); registered.clear(); }
+    static void Remember(Mirror& m, const TypeBatch& tb, const Bodies& bodies) {
+        m.bodies = tb.Info.bodies; m.contact = tb.Info.incremental;
+        m.handles.assign(tb.IndexToHandle.begin(), tb.IndexToHandle.begin() + tb.ConstraintCount);
+        m.references.resize((size_t)tb.ConstraintCount * tb.Info.bodies);
+        m.bodyHandles.resize(m.references.size());
+        for (int i = 0; i < tb.ConstraintCount; ++i)
+            for (int k = 0; k < tb.Info.bodies; ++k) {
+                const int32_t ref = tb.BodyReferences[(size_t)(i / kBundleWidth) * tb.Info.bodies * kBundleWidth + (size_t)k * kBundleWidth + i % kBundleWidth];
+                m.references[(size_t)i * tb.Info.bodies + k] = ref;
+                m.bodyHandles[(size_t)i * tb.Info.bodies + k] = bodies.IndexToHandle[ref & kBodyReferenceMask];
+            }
+    }
+    void RememberTypeBatches(const Solver& solver, const Bodies& bodies, bool shadows) {
         mirrors.clear();
         for (size_t b = 0; b < solver.Batches.size(); ++b)
             for (const TypeBatch& tb : solver.Batches[b].TypeBatches) {
                 Mirror& m = mirrors[((uint64_t)b << 32) | (uint32_t)tb.TypeId];
-                m.bodies = tb.Info.bodies;
-                m.handles.assign(tb.IndexToHandle.begin(), tb.IndexToHandle.begin() + tb.ConstraintCount);
-                m.references.resize((size_t)tb.ConstraintCount * tb.Info.bodies);
-                for (int i = 0; i < tb.ConstraintCount; ++i)
-                    for (int k = 0; k < tb.Info.bodies; ++k)
-                        m.references[(size_t)i * tb.Info.bodies + k] = tb.BodyReferences[(size_t)(i / kBundleWidth) * tb.Info.bodies * kBundleWidth + (size_t)k * kBundleWidth + i % kBundleWidth];
+                Remember(m, tb, bodies);
+                if (shadows && !m.contact) {
+                    m.prestep.assign(tb.PrestepData.begin(), tb.PrestepData.begin() + (size_t)tb.BundleCount() * tb.Info.prestepFloats * kBundleWidth);
+                    m.impulses.assign(tb.AccumulatedImpulses.begin(), tb.AccumulatedImpulses.begin() + (size_t)tb.BundleCount() * tb.Info.impulseFloats * kBundleWidth);
+                }
             }
     }
-    // One bepuhip_apply_structural_ops call for everything that changed in the solver's type batches since RememberTypeBatches.
-    void DiffAndApply(const Solver& solver) {
-        std::vector<bepuhip_structural_op> ops;
+    // Everything that changed in the solver's type batches since RememberTypeBatches, in ONE bepuhip_apply_structural_ops call: every type batch's removals first (the ones
+    // of type batches that no longer exist included), then additions, swaps and reference patches. With `shadows` the mirrors' copies of the device's prestep data and
+    // impulses follow the constraints to their new indices (a new constraint: the prestep lane it was added with, zero impulses — what the device now holds).
+    void DiffAndApply(const Solver& solver, const Bodies& bodies, bool shadows) {
+        std::vector<bepuhip_structural_op> removals, ops;
         std::vector<uint32_t> payload;
         std::unordered_map<uint64_t, bool> seen;
+        std::vector<int32_t> newBodyHandles, survivor;
         for (size_t b = 0; b < solver.Batches.size(); ++b)
             for (const TypeBatch& tb : solver.Batches[b].TypeBatches) {
                 const uint64_t key = ((uint64_t)b << 32) | (uint32_t)tb.TypeId;
                 seen[key] = true;
-                auto found = mirrors.find(key);
-                static const Mirror empty;
-                const Mirror& was = found == mirrors.end() ? empty : found->second;
-                DiffTypeBatch((int)b, tb.TypeId, tb.Info.bodies, tb.Info.prestepFloats, was.handles.data(), (int)was.handles.size(), was.references.data(), tb.IndexToHandle.data(),
-                              tb.ConstraintCount, tb.BodyReferences.data(), tb.PrestepData.data(), ops, payload);
+                Mirror& was = mirrors[key];
+                const int nb = tb.Info.bodies, W = kBundleWidth;
+                newBodyHandles.resize((size_t)tb.ConstraintCount * nb);
+                for (int i = 0; i < tb.ConstraintCount; ++i)
+                    for (int k = 0; k < nb; ++k)
+                        newBodyHandles[(size_t)i * nb + k] = bodies.IndexToHandle[tb.BodyReferences[(size_t)(i / W) * nb * W + (size_t)k * W + i % W] & kBodyReferenceMask];
+                const size_t before = removals.size() + ops.size();
+                DiffTypeBatch((int)b, tb.TypeId, nb, tb.Info.prestepFloats, was.handles.data(), (int)was.handles.size(), was.references.data(), was.bodyHandles.data(), tb.IndexToHandle.data(),
+                              tb.ConstraintCount, tb.BodyReferences.data(), newBodyHandles.data(), tb.PrestepData.data(), removals, ops, payload, &survivor);
+                if (shadows && !tb.Info.incremental && (removals.size() + ops.size() != before || was.handles.size() != (size_t)tb.ConstraintCount)) {
+                    const int pf = tb.Info.prestepFloats, imf = tb.Info.impulseFloats;
+                    std::vector<float> prestep((size_t)tb.BundleCount() * pf * W, 0.0f), impulses((size_t)tb.BundleCount() * imf * W, 0.0f);
+                    for (int i = 0; i < tb.ConstraintCount; ++i) {
+                        const int old = survivor[i];
+                        for (int f = 0; f < pf; ++f)
+                            prestep[(size_t)(i / W) * pf * W + (size_t)f * W + i % W] = old >= 0 ? was.prestep[(size_t)(old / W) * pf * W + (size_t)f * W + old % W]
+                                                                                                 : tb.PrestepData[(size_t)(i / W) * pf * W + (size_t)f * W + i % W];
+                        if (old >= 0) for (int f = 0; f < imf; ++f) impulses[(size_t)(i / W) * imf * W + (size_t)f * W + i % W] = was.impulses[(size_t)(old / W) * imf * W + (size_t)f * W + old % W];
+                    }
+                    was.prestep.swap(prestep); was.impulses.swap(impulses);
+                }
+                Remember(was, tb, bodies);
             }
-        for (auto& kv : mirrors)  // a type batch that no longer exists (ConstraintBatch.RemoveTypeBatchIfEmpty): its constraints went
-            if (!seen.count(kv.first))
-                for (int i = (int)kv.second.handles.size() - 1; i >= 0; --i) ops.push_back({1, (int32_t)(kv.first >> 32), (int32_t)(uint32_t)kv.first, i, 0, 0, 0, 0});
-        diffOperations += (int)ops.size();
-        if (!ops.empty()) {
+        for (auto it = mirrors.begin(); it != mirrors.end();) {  // a type batch that no longer exists (ConstraintBatch.RemoveTypeBatchIfEmpty): its constraints went
+            if (seen.count(it->first)) { ++it; continue; }
+            for (int i = (int)it->second.handles.size() - 1; i >= 0; --i) removals.push_back({1, (int32_t)(it->first >> 32), (int32_t)(uint32_t)it->first, i, 0, 0, 0, 0});
+            it = mirrors.erase(it);
+        }
+        diffOperations += (int)(removals.size() + ops.size());
+        removals.insert(removals.end(), ops.begin(), ops.end());
+        if (!removals.empty()) {
             int32_t failed = -1;
             if (payload.empty()) payload.push_back(0u);
-            check(api.bepuhip_apply_structural_ops(ctx, ops.data(), (int32_t)ops.size(), payload.data(), (int32_t)payload.size(), &failed));
+            check(api.bepuhip_apply_structural_ops(ctx, removals.data(), (int32_t)removals.size(), payload.data(), (int32_t)payload.size(), &failed));
         }
     }
     HipTimestepper(const char* libraryPath, int device) {
@@ -433,16 +534,106 @@ public:
         bepuhip_config cfg{device, kBundleWidth, BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS};  // a simulation adds and removes constraints between frames: plan room for them
         if (api.bepuhip_create(&cfg, &ctx) != BEPUHIP_OK) throw std::runtime_error(std::string("bepuhip_create: ") + api.bepuhip_last_error());
     }
-    ~HipTimestepper() override { if (ctx) api.bepuhip_destroy(ctx); }
+    ~HipTimestepper() override { if (ctx) { UnregisterAll(); api.bepuhip_destroy(ctx); } }
     void check(int32_t status) {
         if (status == BEPUHIP_OK) return;
         std::string msg = api.bepuhip_last_error();
         if (status == BEPUHIP_E_INVALID_ARGUMENT) throw std::invalid_argument(msg);
         throw std::runtime_error(msg);  // the C# shim converts these into InvalidOperationException / falls back on UNSUPPORTED
     }
+    void SendKinematics(Simulation& sim) {
+        std::vector<int32_t> kin;
+        for (int32_t h : sim.solver.ConstrainedKinematicHandles) kin.push_back(sim.bodies.HandleToIndex[h]);
+        check(api.bepuhip_set_constrained_kinematics(ctx, kin.data(), (int)kin.size()));
+        uploadedKinematics = kin.size();
+    }
+    void Upload(Simulation& sim) {
+        Solver& solver = sim.solver;
+        ++fullUploads;
+        check(api.bepuhip_begin_constraints(ctx, (int)solver.Batches.size(), sim.solveDescription.FallbackBatchThreshold));
+        for (size_t b = 0; b < solver.Batches.size(); ++b)
+            for (const TypeBatch& tb : solver.Batches[b].TypeBatches)
+                check(api.bepuhip_set_type_batch(ctx, (int)b, tb.TypeId, tb.ConstraintCount, tb.BodyReferences.data(), tb.PrestepData.data(), tb.AccumulatedImpulses.data()));
+        check(api.bepuhip_end_constraints(ctx));
+        SendKinematics(sim);
+        uploadedSolverVersion = solver.TopologyVersion;
+        uploadedBodiesVersion = sim.bodies.TopologyVersion;
+        if (mode >= 1) RememberTypeBatches(solver, sim.bodies, mode == 2);
+    }
+    bepuhip_integrator Integrator(const Simulation& sim) const {
+        bepuhip_integrator in{};
+        in.gravity[0] = sim.callbacks.Gravity.X; in.gravity[1] = sim.callbacks.Gravity.Y; in.gravity[2] = sim.callbacks.Gravity.Z;
+        in.linear_damping = sim.callbacks.LinearDamping; in.angular_damping = sim.callbacks.AngularDamping;
+        in.angular_integration_mode = 0;
+        in.allow_substeps_for_unconstrained = sim.callbacks.AllowSubstepsForUnconstrainedBodies;
+        in.integrate_velocity_for_kinematics = sim.callbacks.IntegrateVelocityForKinematics;
+        return in;
+    }
+    // ---- mode 2: the resident frame ----
+    // Bundles of a non-contact type batch whose host copy differs from what the device holds (the shadow), as ranges; the shadow takes the host's values.
+    static void ChangedRanges(const float* host, float* shadow, int bundles, int floatsPerBundle, std::vector<std::pair<int, int>>& ranges) {
+        ranges.clear();
+        for (int b = 0; b < bundles; ++b) {
+            const size_t at = (size_t)b * floatsPerBundle;
+            if (std::memcmp(host + at, shadow + at, (size_t)floatsPerBundle * 4) == 0) continue;
+            std::memcpy(shadow + at, host + at, (size_t)floatsPerBundle * 4);
+            if (!ranges.empty() && ranges.back().first + ranges.back().second == b) ++ranges.back().second; else ranges.push_back({b, 1});
+        }
+    }
+    void ResidentFrame(Simulation& sim, float dt) {
+        Solver& solver = sim.solver;
+        if (uploadedSolverVersion == ~0ull || uploadedBodiesVersion != sim.bodies.TopologyVersion) {
+            check(api.bepuhip_set_bodies(ctx, sim.bodies.DynamicsState.data(), sim.bodies.Count()));
+            Upload(sim);
+        } else {
+            DiffAndApply(solver, sim.bodies, true);  // every frame, like the C# shim: the reference has no version counter to ask
+            if (uploadedSolverVersion != solver.TopologyVersion) { ++structuralReplays; uploadedSolverVersion = solver.TopologyVersion; }
+            check(api.bepuhip_set_bodies(ctx, sim.bodies.DynamicsState.data(), sim.bodies.Count()));  // the host's array is authoritative (ResendBodiesEveryFrame)
+            SendKinematics(sim);
+            int32_t schedule = 0;
+            check(api.bepuhip_get_schedule(ctx, &schedule));
+            if (schedule == 0 && ++framesOffPlan >= replanInterval) { check(api.bepuhip_replan(ctx)); framesOffPlan = 0; }
+        }
+        solver.ConsumeStructuralLog();
+        // what the host rewrote in place since the last frame
+        std::vector<bepuhip_row_transfer> in, out;
+        std::vector<std::pair<int, int>> ranges;
+        for (size_t b = 0; b < solver.Batches.size(); ++b)
+            for (TypeBatch& tb : solver.Batches[b].TypeBatches) {
+                if (tb.ConstraintCount == 0) continue;
+                const int pfb = tb.Info.prestepFloats * kBundleWidth, ifb = tb.Info.impulseFloats * kBundleWidth;
+                if (tb.Info.incremental) {  // contacts: the narrow phase rewrites all of them (NarrowPhaseConstraintUpdate.cs:147-207)
+                    in.push_back({BEPUHIP_ROWS_UPDATE_PRESTEP, (int32_t)b, tb.TypeId, 0, -1, 0, tb.PrestepData.data()});
+                    in.push_back({BEPUHIP_ROWS_UPDATE_IMPULSES, (int32_t)b, tb.TypeId, 0, -1, 0, tb.AccumulatedImpulses.data()});
+                    if (readBackContactDepths) out.push_back({BEPUHIP_ROWS_GET_PRESTEP, (int32_t)b, tb.TypeId, 0, -1, 0, tb.PrestepData.data()});
+                } else {
+                    Mirror& m = mirrors[((uint64_t)b << 32) | (uint32_t)tb.TypeId];
+                    ChangedRanges(tb.PrestepData.data(), m.prestep.data(), tb.BundleCount(), pfb, ranges);
+                    for (auto& r : ranges) { in.push_back({BEPUHIP_ROWS_UPDATE_PRESTEP, (int32_t)b, tb.TypeId, r.first, r.second, 0, tb.PrestepData.data() + (size_t)r.first * pfb}); refreshedBundles += r.second; }
+                    ChangedRanges(tb.AccumulatedImpulses.data(), m.impulses.data(), tb.BundleCount(), ifb, ranges);
+                    for (auto& r : ranges) { in.push_back({BEPUHIP_ROWS_UPDATE_IMPULSES, (int32_t)b, tb.TypeId, r.first, r.second, 0, tb.AccumulatedImpulses.data() + (size_t)r.first * ifb}); refreshedBundles += r.second; }
+                }
+                out.push_back({BEPUHIP_ROWS_GET_IMPULSES, (int32_t)b, tb.TypeId, 0, -1, 0, tb.AccumulatedImpulses.data()});
+            }
+        if (!in.empty()) check(api.bepuhip_transfer_rows_async(ctx, in.data(), (int32_t)in.size()));
+        std::vector<int32_t> iterations = sim.solveDescription.ResolveIterations();
+        bepuhip_integrator integ = Integrator(sim);
+        check(api.bepuhip_solve_async(ctx, dt, sim.solveDescription.SubstepCount, iterations.data(), &integ));
+        check(api.bepuhip_get_poses_and_velocities_async(ctx, sim.bodies.DynamicsState.data(), sim.bodies.Count()));
+        if (!out.empty()) check(api.bepuhip_transfer_rows_async(ctx, out.data(), (int32_t)out.size()));
+        check(api.bepuhip_sync(ctx));
+        for (size_t b = 0; b < solver.Batches.size(); ++b)  // the device's impulses are the host's again: the shadows follow
+            for (TypeBatch& tb : solver.Batches[b].TypeBatches) {
+                if (tb.ConstraintCount == 0 || tb.Info.incremental) continue;
+                Mirror& m = mirrors[((uint64_t)b << 32) | (uint32_t)tb.TypeId];
+                std::memcpy(m.impulses.data(), tb.AccumulatedImpulses.data(), m.impulses.size() * 4);
+            }
+    }
+    int framesOffPlan = 0, replanInterval = 30;
     void Timestep(Simulation& sim, float dt) override {
         // simulation.Sleep / PredictBoundingBoxes / CollisionDetection (DefaultTimestepper.cs:30-37) are out of scope: no-ops here.
         // ---- simulation.Solve(dt) replaced (DefaultTimestepper.cs:39) ----
+        if (mode == 2) return ResidentFrame(sim, dt);
         Solver& solver = sim.solver;
         // Topology is re-uploaded only when it changed: keyed on the version counters Solver.Add / Bodies.Add bump (a count comparison would miss a
         // remove + add, or a body move that renumbers references); bodies are host-authoritative every frame.
@@ -451,12 +642,8 @@ public:
         // next to a re-upload); the library keeps them on the island layout where it can (include/bepuhip.h).
         if (mode == 1 && uploadedBodiesVersion == sim.bodies.TopologyVersion && uploadedSolverVersion != ~0ull) {
             if (uploadedSolverVersion != solver.TopologyVersion) {
-                DiffAndApply(solver);
-                RememberTypeBatches(solver);
-                std::vector<int32_t> kin;
-                for (int32_t h : solver.ConstrainedKinematicHandles) kin.push_back(sim.bodies.HandleToIndex[h]);
-                check(api.bepuhip_set_constrained_kinematics(ctx, kin.data(), (int)kin.size()));
-                uploadedKinematics = kin.size();
+                DiffAndApply(solver, sim.bodies, false);
+                SendKinematics(sim);
                 uploadedSolverVersion = solver.TopologyVersion;
                 ++structuralReplays;
             }
@@ -472,38 +659,14 @@ public:
                     check(api.bepuhip_remove_constraint(ctx, change.batch, change.typeId, change.index));
                 }
             }
-            {  // additions bring kinematic bodies into Solver.ConstrainedKinematicHandles, removals take them out (the count alone does not tell: one of each leaves it unchanged)
-                std::vector<int32_t> kin;
-                for (int32_t h : solver.ConstrainedKinematicHandles) kin.push_back(sim.bodies.HandleToIndex[h]);
-                check(api.bepuhip_set_constrained_kinematics(ctx, kin.data(), (int)kin.size()));
-                uploadedKinematics = kin.size();
-            }
+            SendKinematics(sim);  // additions bring kinematic bodies into Solver.ConstrainedKinematicHandles, removals take them out (the count alone does not tell: one of each leaves it unchanged)
             uploadedSolverVersion = solver.TopologyVersion;
             ++structuralReplays;
         }
         solver.ConsumeStructuralLog();
-        if (uploadedSolverVersion != solver.TopologyVersion || uploadedBodiesVersion != sim.bodies.TopologyVersion) {
-            ++fullUploads;
-            check(api.bepuhip_begin_constraints(ctx, (int)solver.Batches.size(), sim.solveDescription.FallbackBatchThreshold));
-            for (size_t b = 0; b < solver.Batches.size(); ++b)
-                for (const TypeBatch& tb : solver.Batches[b].TypeBatches)
-                    check(api.bepuhip_set_type_batch(ctx, (int)b, tb.TypeId, tb.ConstraintCount, tb.BodyReferences.data(), tb.PrestepData.data(), tb.AccumulatedImpulses.data()));
-            check(api.bepuhip_end_constraints(ctx));
-            std::vector<int32_t> kin;
-            for (int32_t h : solver.ConstrainedKinematicHandles) kin.push_back(sim.bodies.HandleToIndex[h]);
-            check(api.bepuhip_set_constrained_kinematics(ctx, kin.data(), (int)kin.size()));
-            uploadedKinematics = kin.size();
-            uploadedSolverVersion = solver.TopologyVersion;
-            uploadedBodiesVersion = sim.bodies.TopologyVersion;
-            if (mode == 1) RememberTypeBatches(solver);
-        }
+        if (uploadedSolverVersion != solver.TopologyVersion || uploadedBodiesVersion != sim.bodies.TopologyVersion) Upload(sim);
         std::vector<int32_t> iterations = sim.solveDescription.ResolveIterations();
-        bepuhip_integrator in{};
-        in.gravity[0] = sim.callbacks.Gravity.X; in.gravity[1] = sim.callbacks.Gravity.Y; in.gravity[2] = sim.callbacks.Gravity.Z;
-        in.linear_damping = sim.callbacks.LinearDamping; in.angular_damping = sim.callbacks.AngularDamping;
-        in.angular_integration_mode = 0;
-        in.allow_substeps_for_unconstrained = sim.callbacks.AllowSubstepsForUnconstrainedBodies;
-        in.integrate_velocity_for_kinematics = sim.callbacks.IntegrateVelocityForKinematics;
+        bepuhip_integrator in = Integrator(sim);
         check(api.bepuhip_solve(ctx, dt, sim.solveDescription.SubstepCount, iterations.data(), &in));
         check(api.bepuhip_get_bodies(ctx, sim.bodies.DynamicsState.data(), sim.bodies.Count()));
         for (size_t b = 0; b < solver.Batches.size(); ++b)
@@ -561,6 +724,20 @@ int32_t bepuhost_add_constraint(void* s, int typeId, const int32_t* bodyHandles,
 }
 int32_t bepuhost_remove_constraint(void* s, int32_t constraintHandle) {
     try { ((Simulation*)s)->solver.Remove(constraintHandle); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int32_t bepuhost_apply_description(void* s, int32_t constraintHandle, const float* prestepLane) {
+    try { ((Simulation*)s)->solver.ApplyDescription(constraintHandle, prestepLane); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int32_t bepuhost_set_accumulated_impulses(void* s, int32_t constraintHandle, const float* impulseLane) {
+    try { ((Simulation*)s)->solver.SetAccumulatedImpulses(constraintHandle, impulseLane); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+// (batch index, type id, index in type batch) of a live constraint; -1 when the handle names none.
+int32_t bepuhost_constraint_location(void* s, int32_t constraintHandle, int32_t* out3) {
+    const Solver& solver = ((Simulation*)s)->solver;
+    if (constraintHandle < 0 || constraintHandle >= (int)solver.HandleToConstraint.size() || solver.HandleToConstraint[constraintHandle].BatchIndex < 0) return -1;
+    const ConstraintLocation& loc = solver.HandleToConstraint[constraintHandle];
+    out3[0] = loc.BatchIndex; out3[1] = loc.TypeId; out3[2] = loc.IndexInTypeBatch;
+    return 0;
 }
 // Per type batch: the handles of its constraints in index order (TypeBatch.IndexToHandle, TypeBatch.cs:19).
 const int32_t* bepuhost_type_batch_handles(void* s, int b, int t) { return ((Simulation*)s)->solver.Batches[b].TypeBatches[t].IndexToHandle.data(); }
@@ -631,12 +808,32 @@ int32_t bepuhost_timestepper_mode(void* s, int mode) {
 int32_t bepuhost_diff_type_batch(int batch, int typeId, int bodies, int prestepFloats, const int32_t* oldHandles, int oldCount, const int32_t* oldReferences,
                                  const int32_t* newHandles, int newCount, const int32_t* newReferencesAosoa, const float* newPrestepAosoa,
                                  int32_t* opsOut, int opCapacity, uint32_t* payloadOut, int payloadCapacity, int32_t* payloadWords) {
-    std::vector<bepuhip_structural_op> ops;
+    std::vector<bepuhip_structural_op> ops, rest;
     std::vector<uint32_t> payload;
-    DiffTypeBatch(batch, typeId, bodies, prestepFloats, oldHandles, oldCount, oldReferences, newHandles, newCount, newReferencesAosoa, newPrestepAosoa, ops, payload);
+    DiffTypeBatch(batch, typeId, bodies, prestepFloats, oldHandles, oldCount, oldReferences, nullptr, newHandles, newCount, newReferencesAosoa, nullptr, newPrestepAosoa, ops, rest, payload, nullptr);
+    ops.insert(ops.end(), rest.begin(), rest.end());  // one type batch on its own: its removals, then the rest
     if ((int)ops.size() > opCapacity || (int)payload.size() > payloadCapacity) return -1;
     if (!ops.empty()) std::memcpy(opsOut, ops.data(), ops.size() * sizeof(bepuhip_structural_op));
     if (!payload.empty()) std::memcpy(payloadOut, payload.data(), payload.size() * 4);
+    *payloadWords = (int32_t)payload.size();
+    return (int32_t)ops.size();
+}
+// ... with the constraints' identities (constraint handle + the handles of its bodies, see DiffTypeBatch): a handle the pool handed out again for another constraint is a
+// removal plus an addition. survivorOut (optional, newCount entries): last frame's index of every constraint of the new arrangement, -1 for a new one. The removals come first.
+int32_t bepuhost_diff_type_batch_identities(int batch, int typeId, int bodies, int prestepFloats, const int32_t* oldHandles, int oldCount, const int32_t* oldReferences,
+                                            const int32_t* oldBodyHandles, const int32_t* newHandles, int newCount, const int32_t* newReferencesAosoa, const int32_t* newBodyHandles,
+                                            const float* newPrestepAosoa, int32_t* opsOut, int opCapacity, uint32_t* payloadOut, int payloadCapacity, int32_t* payloadWords,
+                                            int32_t* survivorOut) {
+    std::vector<bepuhip_structural_op> ops, rest;
+    std::vector<uint32_t> payload;
+    std::vector<int32_t> survivor;
+    DiffTypeBatch(batch, typeId, bodies, prestepFloats, oldHandles, oldCount, oldReferences, oldBodyHandles, newHandles, newCount, newReferencesAosoa, newBodyHandles, newPrestepAosoa, ops,
+                  rest, payload, &survivor);
+    ops.insert(ops.end(), rest.begin(), rest.end());
+    if ((int)ops.size() > opCapacity || (int)payload.size() > payloadCapacity) return -1;
+    if (!ops.empty()) std::memcpy(opsOut, ops.data(), ops.size() * sizeof(bepuhip_structural_op));
+    if (!payload.empty()) std::memcpy(payloadOut, payload.data(), payload.size() * 4);
+    if (survivorOut && newCount > 0) std::memcpy(survivorOut, survivor.data(), (size_t)newCount * 4);
     *payloadWords = (int32_t)payload.size();
     return (int32_t)ops.size();
 }
@@ -652,6 +849,22 @@ void bepuhost_timestepper_stats(void* s, int32_t* fullUploads, int32_t* structur
     HipTimestepper* t = dynamic_cast<HipTimestepper*>(((Simulation*)s)->timestepper);
     *fullUploads = t ? t->fullUploads : 0;
     *structuralReplays = t ? t->structuralReplays : 0;
+}
+// The resident frame's counters: structural operations the diffs emitted, bundles of joint prestep data / impulses found changed on the host and sent, the schedule the
+// context is on (bepuhip_get_schedule).
+int32_t bepuhost_resident_stats(void* s, int64_t* out3) {
+    HipTimestepper* t = dynamic_cast<HipTimestepper*>(((Simulation*)s)->timestepper);
+    if (!t) { g_err = "no HipTimestepper attached"; return -1; }
+    int32_t schedule = -1;
+    t->api.bepuhip_get_schedule(t->ctx, &schedule);
+    out3[0] = t->diffOperations; out3[1] = t->refreshedBundles; out3[2] = schedule;
+    return 0;
+}
+int32_t bepuhost_timestepper_read_back_contact_depths(void* s, int on) {
+    HipTimestepper* t = dynamic_cast<HipTimestepper*>(((Simulation*)s)->timestepper);
+    if (!t) { g_err = "no HipTimestepper attached"; return -1; }
+    t->readBackContactDepths = on != 0;
+    return 0;
 }
 
 }  // extern "C"

@@ -118,6 +118,13 @@ public:
     uint64_t TopologyVersion = 0;  // bumped by every Add / Remove: a remove + add leaves the count unchanged but not the layout
     // Solver.Add(bodyHandles, description): prestepLane holds the description's fields in prestep order (what ApplyDescription writes).
     int Add(const int32_t* bodyHandles, int bodyCount, int typeId, const float* prestepLane);
+    // Solver.ApplyDescription(handle, description) (Solver.cs:1162-1185): the description's fields written over the constraint's prestep lane, in place — what
+    // Demos/Demos/Tanks/Tank.cs:100,139 and Cars/SimpleCar.cs:25 do every frame to their motors and servos. Nothing else changes; nobody is told.
+    void ApplyDescription(int constraintHandle, const float* prestepLane);
+    // The constraint's accumulated impulses, read and written in place (Solver.GetAccumulatedImpulses / the awakener's bulk copies that restore them, IslandAwakener.cs:388-400).
+    void SetAccumulatedImpulses(int constraintHandle, const float* impulseLane);
+    void GetAccumulatedImpulses(int constraintHandle, float* impulseLane) const;
+    std::vector<int32_t> HandlePool;  // freed constraint handles, reused last-in-first-out like the reference's IdPool.Take (Solver.HandlePool): a Remove followed by an Add returns the same handle
     // Solver.Remove(handle) (Solver.cs:1528-1560 -> ConstraintBatch.Remove -> TypeProcessor.Remove, TypeProcessor.cs:634-731): the last constraint of the type batch moves
     // into the freed index (TypeProcessor.Move :578-592), handle -> location of the moved constraint is fixed up, the batch forgets the removed constraint's dynamic bodies.
     void Remove(int constraintHandle);

@@ -65,8 +65,20 @@ def load_library() -> C.CDLL:
     lib.bepuhost_timestepper_stats.restype = None
     lib.bepuhost_timestepper_mode.argtypes = [vp, C.c_int]
     lib.bepuhost_timestepper_mode.restype = i32
+    lib.bepuhost_apply_description.argtypes = [vp, i32, vp]
+    lib.bepuhost_apply_description.restype = i32
+    lib.bepuhost_set_accumulated_impulses.argtypes = [vp, i32, vp]
+    lib.bepuhost_set_accumulated_impulses.restype = i32
+    lib.bepuhost_constraint_location.argtypes = [vp, i32, vp]
+    lib.bepuhost_constraint_location.restype = i32
+    lib.bepuhost_resident_stats.argtypes = [vp, vp]
+    lib.bepuhost_resident_stats.restype = i32
+    lib.bepuhost_timestepper_read_back_contact_depths.argtypes = [vp, C.c_int]
+    lib.bepuhost_timestepper_read_back_contact_depths.restype = i32
     lib.bepuhost_diff_type_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.POINTER(i32)]
     lib.bepuhost_diff_type_batch.restype = i32
+    lib.bepuhost_diff_type_batch_identities.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.POINTER(i32), vp]
+    lib.bepuhost_diff_type_batch_identities.restype = i32
     _lib = lib
     return lib
 
@@ -134,6 +146,36 @@ class HostSimulation:
         if self.lib.bepuhost_remove_constraint(self.h, int(constraint_handle)) != 0:
             raise ValueError(_err(self.lib))
 
+    def apply_description(self, constraint_handle: int, prestep_lane):
+        """Solver.ApplyDescription(handle, description) (Solver.cs:1162-1185): the description's fields over the constraint's prestep lane, in place."""
+        lane = np.ascontiguousarray(prestep_lane, dtype=np.float32)
+        if self.lib.bepuhost_apply_description(self.h, int(constraint_handle), lane.ctypes.data) != 0:
+            raise ValueError(_err(self.lib))
+
+    def set_accumulated_impulses(self, constraint_handle: int, impulse_lane):
+        """The constraint's accumulated impulses written in place (what IslandAwakener.cs:388-400 does when it restores a sleeping island's constraints)."""
+        lane = np.ascontiguousarray(impulse_lane, dtype=np.float32)
+        if self.lib.bepuhost_set_accumulated_impulses(self.h, int(constraint_handle), lane.ctypes.data) != 0:
+            raise ValueError(_err(self.lib))
+
+    def constraint_location(self, constraint_handle: int):
+        """(batch index, type id, index in type batch) of a live constraint (Solver.HandleToConstraint), or None."""
+        out = (C.c_int32 * 3)()
+        if self.lib.bepuhost_constraint_location(self.h, int(constraint_handle), out) != 0:
+            return None
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def resident_stats(self):
+        """(structural operations the attached HipTimestepper's diffs emitted, bundles of joint prestep data / impulses it found changed and sent, the context's schedule)."""
+        out = (C.c_int64 * 3)()
+        if self.lib.bepuhost_resident_stats(self.h, out) != 0:
+            raise RuntimeError(_err(self.lib))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def read_back_contact_depths(self, on: bool = True):
+        if self.lib.bepuhost_timestepper_read_back_contact_depths(self.h, int(on)) != 0:
+            raise RuntimeError(_err(self.lib))
+
     def constraint_handles(self, predicate=lambda type_id: True):
         """Handles of the live constraints whose type id satisfies ``predicate`` (TypeBatch.IndexToHandle), in batch / type batch / index order."""
         out = []
@@ -198,7 +240,9 @@ class HostSimulation:
 
     def timestepper_mode(self, mode: int):
         """0: the attached HipTimestepper replays the solver's structural log; 1: it diffs the type batches against last frame's copy (public API only) and sends the
-        frame's changes in one bepuhip_apply_structural_ops call."""
+        frame's changes in one bepuhip_apply_structural_ops call; 2: the resident frame of integration/csharp/HipTimestepper.cs — the diff in two phases, what the host
+        rewrote in place (Solver.ApplyDescription, restored impulses, reused handles) found by comparison against a shadow of the device's rows and sent by bundle range,
+        everything back asynchronously behind the solve."""
         if self.lib.bepuhost_timestepper_mode(self.h, int(mode)) != 0:
             raise RuntimeError(_err(self.lib))
 
@@ -228,3 +272,28 @@ def diff_type_batch(batch: int, type_id: int, bodies: int, prestep_floats: int, 
     if n < 0:
         raise RuntimeError("diff_type_batch: capacity")
     return ops[:n].copy(), payload[: max(1, words.value)].copy()
+
+
+def diff_type_batch_identities(batch: int, type_id: int, bodies: int, prestep_floats: int, old_handles, old_references, old_body_handles, new_handles, new_references_aosoa,
+                               new_body_handles, new_prestep_aosoa):
+    """diff_type_batch with the constraints' identities (constraint handle + body handles): also returns, per constraint of the new arrangement, its index in the old one
+    (-1: new). A constraint handle that names another constraint now (Solver.HandlePool reuses handles) comes out as a removal plus an addition."""
+    lib = load_library()
+    old_h = np.ascontiguousarray(old_handles, dtype=np.int32)
+    old_r = np.ascontiguousarray(old_references, dtype=np.int32).reshape(-1)
+    old_b = np.ascontiguousarray(old_body_handles, dtype=np.int32).reshape(-1)
+    new_h = np.ascontiguousarray(new_handles, dtype=np.int32)
+    new_r = np.ascontiguousarray(new_references_aosoa, dtype=np.int32)
+    new_b = np.ascontiguousarray(new_body_handles, dtype=np.int32).reshape(-1)
+    new_p = np.ascontiguousarray(new_prestep_aosoa, dtype=np.float32)
+    capacity = 4 * (old_h.size + new_h.size) + 16
+    ops = np.zeros((capacity, 8), dtype=np.int32)
+    payload = np.zeros(max(1, new_h.size * (bodies + prestep_floats)), dtype=np.uint32)
+    survivor = np.full(max(1, new_h.size), -1, dtype=np.int32)
+    words = C.c_int32()
+    n = lib.bepuhost_diff_type_batch_identities(batch, type_id, bodies, prestep_floats, old_h.ctypes.data, old_h.size, old_r.ctypes.data, old_b.ctypes.data, new_h.ctypes.data, new_h.size,
+                                                new_r.ctypes.data, new_b.ctypes.data, new_p.ctypes.data, ops.ctypes.data, capacity, payload.ctypes.data, payload.size, C.byref(words),
+                                                survivor.ctypes.data)
+    if n < 0:
+        raise RuntimeError("diff_type_batch: capacity")
+    return ops[:n].copy(), payload[: max(1, words.value)].copy(), survivor[: new_h.size].copy()

@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_predict_bounding_boxes", "bepuhip_set_collidables", "bepuhip_set_convex_hulls", "bepuhip_set_compounds", "bepuhip_set_meshes",
     "bepuhip_set_velocity_model", "bepuhip_solve_with_substep_events", "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_swap_constraints", "bepuhip_apply_structural_ops", "bepuhip_get_constraint_count", "bepuhip_get_schedule", "bepuhip_replan",
     "bepuhip_register_host_memory", "bepuhip_unregister_host_memory", "bepuhip_get_poses_and_velocities", "bepuhip_get_poses_and_velocities_async", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses_async",
+    "bepuhip_transfer_rows_async",
 ]
 
 
@@ -60,6 +61,14 @@ class Config(C.Structure):
 
 class VelocityModel(C.Structure):  # bepuhip_velocity_model
     _fields_ = [("model", C.c_int32), ("center", C.c_float * 3), ("gravity", C.c_float)]
+
+
+class RowTransfer(C.Structure):  # bepuhip_row_transfer
+    _fields_ = [("kind", C.c_int32), ("batch_index", C.c_int32), ("type_id", C.c_int32), ("first_bundle", C.c_int32), ("bundle_count", C.c_int32), ("reserved", C.c_int32),
+                ("bundles", C.c_void_p)]
+
+
+ROWS_UPDATE_PRESTEP, ROWS_UPDATE_IMPULSES, ROWS_GET_PRESTEP, ROWS_GET_IMPULSES = 0, 1, 2, 3
 
 
 class Integrator(C.Structure):
@@ -135,6 +144,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_get_poses_and_velocities_async.argtypes = [vp, vp, i32]
     for name in ("bepuhip_update_prestep", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses", "bepuhip_update_accumulated_impulses_async", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
         getattr(lib, name).argtypes = [vp, i32, i32, i32, i32, vp]
+    lib.bepuhip_transfer_rows_async.argtypes = [vp, vp, i32]
     lib.bepuhip_add_constraint.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
     lib.bepuhip_remove_constraint.argtypes = [vp, i32, i32, i32]
     lib.bepuhip_update_body_reference.argtypes = [vp, i32, i32, i32, i32, i32]
@@ -504,6 +514,24 @@ class HipSolver:
             raise ValueError("impulse data is not a whole number of bundles")
         fn = self.lib.bepuhip_update_accumulated_impulses_async if asynchronous else self.lib.bepuhip_update_accumulated_impulses
         _check(self.lib, fn(self.ctx, batch_index, type_id, first_bundle, n, _ptr(b)))
+
+    def transfer_rows(self, items):
+        """bepuhip_transfer_rows_async: ``items`` = (kind, batch index, type id, first bundle, float32 array of whole bundles) tuples — or a prepared ``RowTransfer`` array from
+        ``row_transfer_table`` — enqueued in order on the context's stream. UPDATE kinds read the arrays, GET kinds write them (in place: they must be C-contiguous float32);
+        nothing may touch them before the next ``sync``."""
+        table = items if isinstance(items, C.Array) else self.row_transfer_table(items)
+        _check(self.lib, self.lib.bepuhip_transfer_rows_async(self.ctx, table, len(table)))
+
+    def row_transfer_table(self, items):
+        table = (RowTransfer * len(items))()
+        for slot, (kind, batch_index, type_id, first_bundle, bundles) in zip(table, items):
+            assert bundles.flags["C_CONTIGUOUS"] and bundles.dtype == np.float32
+            n, rem = divmod(bundles.size, self._bundle_floats(type_id, kind in (ROWS_UPDATE_PRESTEP, ROWS_GET_PRESTEP)))
+            if rem:
+                raise ValueError("not a whole number of bundles")
+            slot.kind, slot.batch_index, slot.type_id, slot.first_bundle, slot.bundle_count, slot.bundles = kind, batch_index, type_id, first_bundle, n, bundles.ctypes.data
+        self._transfer_keepalive = [it[4] for it in items]
+        return table
 
     def get_prestep_range(self, batch_index: int, type_id: int, first_bundle: int, bundle_count: int) -> np.ndarray:
         out = np.empty(bundle_count * self._bundle_floats(type_id, True), dtype=np.float32)

@@ -222,6 +222,29 @@ int32_t bepuhip_get_bodies_range(bepuhip_ctx* ctx, void* body_dynamics_aos_out, 
 int32_t bepuhip_get_prestep_range(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* prestep_bundles_out);
 int32_t bepuhip_get_accumulated_impulses_range(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t first_bundle, int32_t bundle_count, float* impulse_bundles_out);
 
+/* A frame's row traffic in ONE call. A resident host sends what changed in its type batches' buffers and fetches what the solve changed:
+ *   - the prestep data and redistributed impulses the narrow phase rewrote for every contact type batch (NarrowPhaseConstraintUpdate.cs:147-207),
+ *   - the prestep bundles of joints / motors / servos whose description the user rewrote between frames — Solver.ApplyDescription (BepuPhysics/Solver.cs:1162-1185) writes
+ *     into TypeBatch.PrestepData in place and tells nobody: Demos/Demos/Tanks/Tank.cs:100,139,142 and Demos/Demos/Cars/SimpleCar.cs:25 do it every frame — and accumulated
+ *     impulses the host set (IslandAwakener.cs:388-400 restores them with its bulk copies; Solver.Add zeroes them, TypeProcessor.cs:327),
+ *   - and, behind the solve, the accumulated impulses back into the host's buffers (contacts: the narrow phase redistributes them; joints: Solver.GetDescription /
+ *     GetAccumulatedImpulses, the sleeper's copies IslandSleeper.cs:174-260 and the awakener read them).
+ * `items` are enqueued on the context's stream in order, each exactly as the ranged call of the same kind (whole bundles of the caller's AOSOA buffers; the UPDATE kinds
+ * also patch the snapshot bepuhip_reset_state returns to). Nothing waits: the host buffers — read or written by DMA when they are registered — must stay untouched until the
+ * next bepuhip_sync (or any synchronous call). A GET enqueued behind bepuhip_solve_async returns that solve's results. Descriptor tables and staging live in the context. */
+#define BEPUHIP_ROWS_UPDATE_PRESTEP 0
+#define BEPUHIP_ROWS_UPDATE_IMPULSES 1
+#define BEPUHIP_ROWS_GET_PRESTEP 2
+#define BEPUHIP_ROWS_GET_IMPULSES 3
+typedef struct bepuhip_row_transfer {
+    int32_t kind;          /* BEPUHIP_ROWS_* */
+    int32_t batch_index, type_id;
+    int32_t first_bundle, bundle_count;  /* whole bundles of config.bundle_width constraints; bundle_count < 0: from first_bundle to the type batch's last bundle */
+    int32_t reserved;
+    void* bundles;         /* UPDATE: read; GET: written. Points at bundle `first_bundle`'s first float (not at the buffer's start) */
+} bepuhip_row_transfer;
+int32_t bepuhip_transfer_rows_async(bepuhip_ctx* ctx, const bepuhip_row_transfer* items, int32_t count);
+
 /* ---- Structural updates: the narrow phase's per-frame add / remove stream without a re-upload ----
  * The C# host calls these next to the mutation it performs on its own buffers, with the same indices:
  *   add_constraint            Solver.Add -> AllocateInBatch -> TypeProcessor.AllocateInTypeBatch (BepuPhysics/Constraints/TypeProcessor.cs:314-334): the constraint is appended at

@@ -1,7 +1,10 @@
 // Reference-side binding of libbepuhip.so (include/bepuhip.h): drop this file into an application that references BepuPhysics and create the simulation with
 // `new HipTimestepper<TCallbacks>()`. It uses public API only, on the UNPATCHED reference: the structural changes of a frame (narrow-phase adds and removes, sleeping,
 // awakening, user calls, bodies moving in memory) are reconstructed by diffing every type batch's constraint handles (TypeBatch.IndexToHandle, TypeBatch.cs:16) and body
-// references against last frame's copy, and sent to the device in one bepuhip_apply_structural_ops call. INTEGRATION.md carries the same text (a test keeps the two
+// references against last frame's copy, and sent to the device in one bepuhip_apply_structural_ops call; what the host rewrote IN PLACE since the last frame — Solver.ApplyDescription
+// on motors and servos (Demos/Demos/Tanks/Tank.cs:100,139; Cars/SimpleCar.cs:25), impulses the awakener restored, a constraint handle the pool handed out again — is found by
+// comparing the type batches' buffers with a shadow of what the device holds and sent by bundle range (bepuhip_transfer_rows_async); poses, velocities and ALL accumulated
+// impulses come back behind the solve. INTEGRATION.md carries the same text (a test keeps the two
 // identical, and the DllImport block is generated from the header by tools/gen_csharp_imports.py); the diff has a C++ twin that IS compiled and tested here
 // (bepuphysics2_amd/host/bepu_host.cpp DiffTypeBatch; tests/test_structural_diff.py, tests/test_gpu_structural.py) — this text itself is not (no .NET SDK in this environment).
 using System;
@@ -29,6 +32,9 @@ unsafe struct BepuHipVelocityModel { public int Model; public fixed float Center
 
 [StructLayout(LayoutKind.Sequential)]
 struct BepuHipStructuralOp { public int Kind, BatchIndex, TypeId, Index, Slot, Reference, PayloadOffset, Reserved; }   // bepuhip_structural_op: 0 add, 1 remove, 2 update reference, 3 swap
+
+[StructLayout(LayoutKind.Sequential)]
+unsafe struct BepuHipRowTransfer { public int Kind, BatchIndex, TypeId, FirstBundle, BundleCount, Reserved; public void* Bundles; }   // bepuhip_row_transfer: 0 / 1 update prestep / impulses, 2 / 3 get
 
 [StructLayout(LayoutKind.Sequential)]
 unsafe struct BepuHipCollidable   // 64 bytes, bepuhip_collidable
@@ -84,6 +90,7 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_get_bodies_range(IntPtr ctx, void* bodyDynamicsAosOut, int first, int count);
     [DllImport(Lib)] public static extern int bepuhip_get_prestep_range(IntPtr ctx, int batchIndex, int typeId, int firstBundle, int bundleCount, float* prestepBundlesOut);
     [DllImport(Lib)] public static extern int bepuhip_get_accumulated_impulses_range(IntPtr ctx, int batchIndex, int typeId, int firstBundle, int bundleCount, float* impulseBundlesOut);
+    [DllImport(Lib)] public static extern int bepuhip_transfer_rows_async(IntPtr ctx, BepuHipRowTransfer* items, int count);
     [DllImport(Lib)] public static extern int bepuhip_add_constraint(IntPtr ctx, int batchIndex, int typeId, int* encodedBodyReferences, float* prestepLane, int* indexOut);
     [DllImport(Lib)] public static extern int bepuhip_remove_constraint(IntPtr ctx, int batchIndex, int typeId, int index);
     [DllImport(Lib)] public static extern int bepuhip_update_body_reference(IntPtr ctx, int batchIndex, int typeId, int index, int bodyIndexInConstraint, int encodedBodyReference);
@@ -143,9 +150,29 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, 
     // handles are stable for a constraint's life, Solver.HandlePool) and the encoded body references by index. The diff against this frame's type batches IS the frame's
     // structural change: whoever made it — NarrowPhasePendingConstraintAdds, ConstraintRemover, Solver.Add / Remove, the sleeper, IslandAwakener's bulk copies
     // (IslandAwakener.cs:388-400, which no per-constraint hook sees), Bodies.RemoveAt's reference patches (Solver.UpdateForBodyMemoryMove, Solver.cs:1475).
-    sealed class Mirror { public int[] Handles = Array.Empty<int>(); public int[] References = Array.Empty<int>(); public int Count, Bodies; public bool Seen; }
+    // A constraint's identity is its handle AND the handles of its bodies: Solver.HandlePool hands a freed handle out again last-in-first-out (IdPool.Take), so Solver.Remove(h)
+    // followed by Solver.Add(...) in one frame returns h for a different constraint, possibly at the same index of the same type batch. BodyHandles tells the two apart.
+    // Prestep / Impulses (non-contact type batches): what the DEVICE holds, in the type batch's own AOSOA layout — compared with the host's buffers every frame.
+    sealed class Mirror
+    {
+        public int[] Handles = Array.Empty<int>(), References = Array.Empty<int>(), BodyHandles = Array.Empty<int>();
+        public float[] Prestep = Array.Empty<float>(), Impulses = Array.Empty<float>();
+        public int Count, Bodies, PrestepFloats, ImpulseFloats; public bool Seen, Contact;
+    }
     readonly Dictionary<long, Mirror> mirrors = new Dictionary<long, Mirror>();
-    readonly List<BepuHipStructuralOp> ops = new List<BepuHipStructuralOp>();
+    readonly List<BepuHipStructuralOp> ops = new List<BepuHipStructuralOp>(), removals = new List<BepuHipStructuralOp>();
+    readonly List<BepuHipRowTransfer> rowsIn = new List<BepuHipRowTransfer>(), rowsOut = new List<BepuHipRowTransfer>();
+    /// Every frame the prestep data and accumulated impulses of every NON-contact type batch are compared, bundle by bundle, with what the device holds, and the bundles that
+    /// differ are sent: Solver.ApplyDescription (Solver.cs:1162-1185) writes into TypeBatch.PrestepData in place and raises no event. About 1 ms per 40 MB of joint data on a
+    /// few threads. A host that tells the shim what it rewrote (MarkDirty) may turn the comparison off.
+    public bool CompareJointData = true;
+    /// Accumulated impulses of the joints come back every frame (behind the solve, with the contacts' impulses): Solver.GetDescription / GetAccumulatedImpulses, the sleeper's
+    /// copies (IslandSleeper.cs:174-260) and the awakener's restores (IslandAwakener.cs:388-400) then see this frame's values. 7 MB for 870,000 joints. A host that never sleeps
+    /// islands and never reads joint impulses may turn it off; FetchJointImpulses() brings them on demand.
+    public bool ReadBackJointImpulses = true;
+    readonly HashSet<int> dirtyConstraints = new HashSet<int>();
+    /// Tells the shim that the constraint's description (or its accumulated impulses) was rewritten since the last frame — only needed with CompareJointData off.
+    public void MarkDirty(ConstraintHandle handle) => dirtyConstraints.Add(handle.Value);
     readonly List<uint> payload = new List<uint>();
     public int ReplanInterval = 30;                                // frames between two bepuhip_replan calls at most
     /// Every body's state is sent before every solve (bepuhip_set_bodies: one DMA from the registered DynamicsState buffer, 0.6 ms for 240,000 bodies): velocities the user
@@ -216,17 +243,45 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, 
         return prestepFloats[typeId] = floats;
     }
 
-    void Remember(int batchIndex, ref TypeBatch tb, int bodiesPerConstraint)
+    int ImpulseFloats(int typeId)
+    {
+        int bodiesPerConstraint, floats, impulses;
+        Check(BepuHip.bepuhip_type_info(typeId, &bodiesPerConstraint, &floats, &impulses));
+        return impulses;
+    }
+    static int Lane(int index, int field, int fields, int width) => (index / width) * fields * width + field * width + index % width;   // AOSOA: bundle, field, lane (TypeProcessor.cs:139-148)
+
+    // Last frame's copy of a type batch: handles, references, the body handles behind the references; with `shadows` also the device's prestep data and impulses.
+    void Remember(Simulation simulation, int batchIndex, ref TypeBatch tb, int bodiesPerConstraint, bool shadows)
     {
         if (!mirrors.TryGetValue(Key(batchIndex, tb.TypeId), out var m)) mirrors[Key(batchIndex, tb.TypeId)] = m = new Mirror();
-        m.Bodies = bodiesPerConstraint; m.Count = tb.ConstraintCount; m.Seen = true;
-        if (m.Handles.Length < tb.ConstraintCount) { m.Handles = new int[Math.Max(tb.ConstraintCount, m.Handles.Length * 2)]; m.References = new int[m.Handles.Length * bodiesPerConstraint]; }
+        m.Bodies = bodiesPerConstraint; m.Count = tb.ConstraintCount; m.Seen = true; m.Contact = NarrowPhase.IsContactConstraintType(tb.TypeId);
+        m.PrestepFloats = PrestepFloats(tb.TypeId); m.ImpulseFloats = ImpulseFloats(tb.TypeId);
+        if (m.Handles.Length < tb.ConstraintCount)
+        {
+            m.Handles = new int[Math.Max(tb.ConstraintCount, m.Handles.Length * 2)];
+            m.References = new int[m.Handles.Length * bodiesPerConstraint]; m.BodyHandles = new int[m.Handles.Length * bodiesPerConstraint];
+        }
         var width = System.Numerics.Vector<int>.Count;
-        var references = (int*)tb.BodyReferences.Memory;   // AOSOA: bundle, body slot, lane (TypeProcessor.cs:139-148)
+        var references = (int*)tb.BodyReferences.Memory;
+        ref var activeBodies = ref simulation.Bodies.ActiveSet;
         for (int i = 0; i < tb.ConstraintCount; ++i)
         {
             m.Handles[i] = tb.IndexToHandle[i].Value;
-            for (int k = 0; k < bodiesPerConstraint; ++k) m.References[i * bodiesPerConstraint + k] = references[(i / width) * bodiesPerConstraint * width + k * width + i % width];
+            for (int k = 0; k < bodiesPerConstraint; ++k)
+            {
+                var reference = references[Lane(i, k, bodiesPerConstraint, width)];
+                m.References[i * bodiesPerConstraint + k] = reference;
+                m.BodyHandles[i * bodiesPerConstraint + k] = activeBodies.IndexToHandle[reference & Bodies.BodyReferenceMask].Value;
+            }
+        }
+        if (shadows && !m.Contact)
+        {   // the device holds exactly the host's bundles right now (an upload)
+            int prestepFloats = tb.BundleCount * m.PrestepFloats * width, impulseFloats = tb.BundleCount * m.ImpulseFloats * width;
+            if (m.Prestep.Length < prestepFloats) m.Prestep = new float[prestepFloats * 2];
+            if (m.Impulses.Length < impulseFloats) m.Impulses = new float[impulseFloats * 2];
+            new Span<float>(tb.PrestepData.Memory, prestepFloats).CopyTo(m.Prestep);
+            new Span<float>(tb.AccumulatedImpulses.Memory, impulseFloats).CopyTo(m.Impulses);
         }
     }
 
@@ -247,7 +302,7 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, 
                 ref var tb = ref batch.TypeBatches[t];   // TypeBatch.cs:10-19; the library reads prestep data and impulses until end_constraints returns
                 Register(tb.PrestepData.Memory, tb.PrestepData.Length); Register(tb.AccumulatedImpulses.Memory, tb.AccumulatedImpulses.Length);
                 Check(BepuHip.bepuhip_set_type_batch(ctx, b, tb.TypeId, tb.ConstraintCount, (int*)tb.BodyReferences.Memory, (float*)tb.PrestepData.Memory, (float*)tb.AccumulatedImpulses.Memory));
-                Remember(b, ref tb, solver.TypeProcessors[tb.TypeId].BodiesPerConstraint);
+                Remember(simulation, b, ref tb, solver.TypeProcessors[tb.TypeId].BodiesPerConstraint, true);
             }
         }
         Check(BepuHip.bepuhip_end_constraints(ctx));
@@ -256,72 +311,115 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, 
 
     // One type batch: the operations that turn what the device holds (the mirror) into what the host holds now. The reference changes a type batch by append
     // (TypeProcessor.AllocateInTypeBatch, TypeProcessor.cs:314-334), swap-with-last removal (Remove :695-717) and reference patches (UpdateForBodyMemoryMove :807); the
-    // handles say which constraints left and which came, but not the ORDER of the removals, which decides where swap-with-last left the survivors — hence the swaps:
-    // removals (any order) + additions (in index order) + swaps (at most one per index that still disagrees) + reference patches reproduce this frame's arrangement.
-    // (C++ twin, compiled and tested: bepu_host.cpp DiffTypeBatch.)
-    readonly Dictionary<int, int> newIndexOf = new Dictionary<int, int>(), position = new Dictionary<int, int>(), oldIndexOf = new Dictionary<int, int>();
-    readonly List<int> list = new List<int>();
-    void DiffTypeBatch(int batchIndex, ref TypeBatch tb, int bodiesPerConstraint, int prestepFloats, Mirror was)
+    // identities (constraint handle + body handles) say which constraints left and which came, but not the ORDER of the removals, which decides where swap-with-last left
+    // the survivors — hence the swaps: removals (any order) + additions (in index order) + swaps (at most one per index that still disagrees) + reference patches
+    // reproduce this frame's arrangement. Removals go to `removals`: DiffAndApply sends EVERY type batch's removals before any addition — a constraint that replaces
+    // another one on the same bodies in the same batch (a hinge swapped for a weld) would otherwise arrive while its bodies still look taken (the island layout checks the
+    // batch invariant). survivor[i] = last frame's index of the constraint now at index i, -1 for a new one. (C++ twin, compiled and tested: bepu_host.cpp DiffTypeBatch;
+    // tests/test_structural_diff.py.)
+    readonly Dictionary<long, int> newIndexOf = new Dictionary<long, int>(), position = new Dictionary<long, int>(), oldIndexOf = new Dictionary<long, int>();
+    readonly List<long> list = new List<long>(), oldKeys = new List<long>();
+    int[] survivor = Array.Empty<int>(), nowBodyHandles = Array.Empty<int>();
+    bool DiffTypeBatch(Simulation simulation, int batchIndex, ref TypeBatch tb, int bodiesPerConstraint, int prestepFloats, Mirror was)
     {
         var width = System.Numerics.Vector<int>.Count;
         var references = (int*)tb.BodyReferences.Memory; var prestep = (uint*)tb.PrestepData.Memory;
-        int Reference(int i, int k) => references[(i / width) * bodiesPerConstraint * width + k * width + i % width];
+        ref var activeBodies = ref simulation.Bodies.ActiveSet;
         int newCount = tb.ConstraintCount, oldCount = was.Count;
+        if (survivor.Length < newCount) survivor = new int[newCount * 2];
+        if (nowBodyHandles.Length < newCount * bodiesPerConstraint) nowBodyHandles = new int[newCount * bodiesPerConstraint * 2];
+        for (int i = 0; i < newCount; ++i)
+            for (int k = 0; k < bodiesPerConstraint; ++k)
+                nowBodyHandles[i * bodiesPerConstraint + k] = activeBodies.IndexToHandle[references[Lane(i, k, bodiesPerConstraint, width)] & Bodies.BodyReferenceMask].Value;
         bool same = newCount == oldCount;
-        for (int i = 0; same && i < newCount; ++i) same = was.Handles[i] == tb.IndexToHandle[i].Value;
-        if (same)
-        {   // the common case: the same constraints at the same indices; only references can have changed
-            for (int i = 0; i < newCount; ++i)
-                for (int k = 0; k < bodiesPerConstraint; ++k)
-                    if (was.References[i * bodiesPerConstraint + k] != Reference(i, k))
-                        ops.Add(new BepuHipStructuralOp { Kind = 2, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = i, Slot = k, Reference = Reference(i, k) });
-            return;
+        for (int i = 0; same && i < newCount; ++i)
+        {
+            same = was.Handles[i] == tb.IndexToHandle[i].Value;
+            for (int k = 0; same && k < bodiesPerConstraint; ++k) same = was.BodyHandles[i * bodiesPerConstraint + k] == nowBodyHandles[i * bodiesPerConstraint + k];
         }
-        newIndexOf.Clear(); position.Clear(); oldIndexOf.Clear(); list.Clear();
-        for (int i = 0; i < newCount; ++i) newIndexOf[tb.IndexToHandle[i].Value] = i;
-        for (int i = 0; i < oldCount; ++i) { list.Add(was.Handles[i]); position[was.Handles[i]] = i; oldIndexOf[was.Handles[i]] = i; }
+        int before = ops.Count + removals.Count;
+        if (same)
+        {   // the common case: the same constraints at the same indices; only references can have changed (bodies that moved in memory)
+            for (int i = 0; i < newCount; ++i)
+            {
+                survivor[i] = i;
+                for (int k = 0; k < bodiesPerConstraint; ++k)
+                    if (was.References[i * bodiesPerConstraint + k] != references[Lane(i, k, bodiesPerConstraint, width)])
+                        ops.Add(new BepuHipStructuralOp { Kind = 2, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = i, Slot = k, Reference = references[Lane(i, k, bodiesPerConstraint, width)] });
+            }
+            return ops.Count + removals.Count != before;
+        }
+        newIndexOf.Clear(); position.Clear(); oldIndexOf.Clear(); list.Clear(); oldKeys.Clear();
+        for (int i = 0; i < newCount; ++i) { newIndexOf[tb.IndexToHandle[i].Value] = i; survivor[i] = -1; }
+        for (int j = 0; j < oldCount; ++j)
+        {   // keys: the handle — except for an old constraint whose handle names a DIFFERENT constraint now (other bodies): it gets a key no new constraint has
+            long key = was.Handles[j];
+            if (newIndexOf.TryGetValue(key, out var now))
+                for (int k = 0; k < bodiesPerConstraint; ++k)
+                    if (was.BodyHandles[j * bodiesPerConstraint + k] != nowBodyHandles[now * bodiesPerConstraint + k]) { key = -1 - key; break; }
+            list.Add(key); oldKeys.Add(key); position[key] = j; oldIndexOf[key] = j;
+        }
         for (int i = oldCount - 1; i >= 0; --i)
         {   // removals, highest old index first
-            int handle = was.Handles[i];
-            if (newIndexOf.ContainsKey(handle)) continue;
-            int at = position[handle], last = list.Count - 1;
-            ops.Add(new BepuHipStructuralOp { Kind = 1, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = at });
+            long key = oldKeys[i];
+            if (key >= 0 && newIndexOf.ContainsKey(key)) continue;
+            int at = position[key], last = list.Count - 1;
+            removals.Add(new BepuHipStructuralOp { Kind = 1, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = at });
             if (at != last) { list[at] = list[last]; position[list[at]] = at; }
-            list.RemoveAt(last); position.Remove(handle);
+            list.RemoveAt(last); position.Remove(key);
         }
         for (int i = 0; i < newCount; ++i)
         {   // additions, in the order of their final indices: references, then the prestep lane, as raw words
-            int handle = tb.IndexToHandle[i].Value;
-            if (oldIndexOf.ContainsKey(handle)) continue;
+            long key = tb.IndexToHandle[i].Value;
+            if (oldIndexOf.ContainsKey(key)) continue;
             ops.Add(new BepuHipStructuralOp { Kind = 0, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = list.Count, PayloadOffset = payload.Count });
-            for (int k = 0; k < bodiesPerConstraint; ++k) payload.Add((uint)Reference(i, k));
-            for (int f = 0; f < prestepFloats; ++f) payload.Add(prestep[(i / width) * prestepFloats * width + f * width + i % width]);
-            position[handle] = list.Count; list.Add(handle);
+            for (int k = 0; k < bodiesPerConstraint; ++k) payload.Add((uint)references[Lane(i, k, bodiesPerConstraint, width)]);
+            for (int f = 0; f < prestepFloats; ++f) payload.Add(prestep[Lane(i, f, prestepFloats, width)]);
+            position[key] = list.Count; list.Add(key);
         }
         for (int i = 0; i < newCount; ++i)
         {   // the same set by now: put every index right
-            int handle = tb.IndexToHandle[i].Value;
-            if (list[i] == handle) continue;
-            int j = position[handle];
+            long key = tb.IndexToHandle[i].Value;
+            if (list[i] == key) continue;
+            int j = position[key];
             ops.Add(new BepuHipStructuralOp { Kind = 3, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = i, Slot = j });
-            int moved = list[i]; list[i] = list[j]; list[j] = moved;
+            long moved = list[i]; list[i] = list[j]; list[j] = moved;
             position[list[i]] = i; position[list[j]] = j;
         }
         for (int i = 0; i < newCount; ++i)
-        {   // survivors whose bodies moved in memory
+        {   // survivors: where they were, and whether their bodies moved in memory
             if (!oldIndexOf.TryGetValue(tb.IndexToHandle[i].Value, out var old)) continue;
+            survivor[i] = old;
             for (int k = 0; k < bodiesPerConstraint; ++k)
-                if (was.References[old * bodiesPerConstraint + k] != Reference(i, k))
-                    ops.Add(new BepuHipStructuralOp { Kind = 2, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = i, Slot = k, Reference = Reference(i, k) });
+                if (was.References[old * bodiesPerConstraint + k] != references[Lane(i, k, bodiesPerConstraint, width)])
+                    ops.Add(new BepuHipStructuralOp { Kind = 2, BatchIndex = batchIndex, TypeId = tb.TypeId, Index = i, Slot = k, Reference = references[Lane(i, k, bodiesPerConstraint, width)] });
         }
+        return true;
+    }
+
+    // The shadow of a type batch whose arrangement changed: every constraint's copy of the device's prestep data and impulses follows it to its new index; a new
+    // constraint holds, on the device, the prestep lane it was added with and zero impulses (TypeProcessor.cs:327) — the comparison of the frame then finds and sends
+    // whatever the host holds beyond that (the awakener restores impulses with its bulk copies, IslandAwakener.cs:388-400).
+    void CarryShadow(ref TypeBatch tb, Mirror was)
+    {
+        var width = System.Numerics.Vector<int>.Count;
+        int pf = was.PrestepFloats, imf = was.ImpulseFloats, newCount = tb.ConstraintCount;
+        var prestep = new float[Math.Max(1, tb.BundleCount) * pf * width * 2]; var impulses = new float[Math.Max(1, tb.BundleCount) * imf * width * 2];
+        var hostPrestep = (float*)tb.PrestepData.Memory;
+        for (int i = 0; i < newCount; ++i)
+        {
+            int old = survivor[i];
+            for (int f = 0; f < pf; ++f) prestep[Lane(i, f, pf, width)] = old >= 0 ? was.Prestep[Lane(old, f, pf, width)] : hostPrestep[Lane(i, f, pf, width)];
+            if (old >= 0) for (int f = 0; f < imf; ++f) impulses[Lane(i, f, imf, width)] = was.Impulses[Lane(old, f, imf, width)];
+        }
+        was.Prestep = prestep; was.Impulses = impulses;
     }
 
     // Everything that changed in the solver's type batches since the last frame, in ONE call. Returns false when an upload is the better answer.
-    static readonly Mirror Nothing = new Mirror();
     bool DiffAndApply(Simulation simulation, out bool referencesChanged)
     {
         var solver = simulation.Solver; ref var activeSet = ref solver.ActiveSet;
-        ops.Clear(); payload.Clear(); referencesChanged = false;
+        ops.Clear(); removals.Clear(); payload.Clear(); referencesChanged = false;
         foreach (var m in mirrors.Values) m.Seen = false;
         for (int b = 0; b < activeSet.Batches.Count; ++b)
         {
@@ -330,30 +428,32 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, 
             {
                 ref var tb = ref batch.TypeBatches[t];
                 var processor = solver.TypeProcessors[tb.TypeId];
-                mirrors.TryGetValue(Key(b, tb.TypeId), out var was);
-                DiffTypeBatch(b, ref tb, processor.BodiesPerConstraint, PrestepFloats(tb.TypeId), was ?? Nothing);
+                if (!mirrors.TryGetValue(Key(b, tb.TypeId), out var was))
+                {
+                    mirrors[Key(b, tb.TypeId)] = was = new Mirror { PrestepFloats = PrestepFloats(tb.TypeId), ImpulseFloats = ImpulseFloats(tb.TypeId), Contact = NarrowPhase.IsContactConstraintType(tb.TypeId) };
+                }
+                bool changed = DiffTypeBatch(simulation, b, ref tb, processor.BodiesPerConstraint, was.PrestepFloats, was);
+                if (changed && !was.Contact) CarryShadow(ref tb, was);
+                Remember(simulation, b, ref tb, processor.BodiesPerConstraint, false);   // the device holds this arrangement once the operations below are applied
             }
         }
+        var gone = new List<long>();
         foreach (var kv in mirrors)   // a type batch that no longer exists (ConstraintBatch.RemoveTypeBatchIfEmpty): its constraints went
-            if (!kv.Value.Seen && kv.Value.Count > 0)
-                for (int i = kv.Value.Count - 1; i >= 0; --i) ops.Add(new BepuHipStructuralOp { Kind = 1, BatchIndex = (int)(kv.Key >> 32), TypeId = (int)(uint)kv.Key, Index = i });
-        if (ops.Count > ReplayLimit) return false;
+            if (!kv.Value.Seen)
+            {
+                for (int i = kv.Value.Count - 1; i >= 0; --i) removals.Add(new BepuHipStructuralOp { Kind = 1, BatchIndex = (int)(kv.Key >> 32), TypeId = (int)(uint)kv.Key, Index = i });
+                gone.Add(kv.Key);
+            }
+        foreach (var key in gone) mirrors.Remove(key);
+        if (ops.Count + removals.Count > ReplayLimit) return false;   // (the caller uploads, which rebuilds every mirror)
         foreach (var op in ops) referencesChanged |= op.Kind == 2;
-        if (ops.Count > 0)
+        if (ops.Count + removals.Count > 0)
         {
+            removals.AddRange(ops);   // phase one: every removal of every type batch; phase two: additions, swaps, reference patches
             if (payload.Count == 0) payload.Add(0);
             int failed;
-            fixed (BepuHipStructuralOp* table = System.Runtime.InteropServices.CollectionsMarshal.AsSpan(ops)) fixed (uint* words = System.Runtime.InteropServices.CollectionsMarshal.AsSpan(payload))
-                Check(BepuHip.bepuhip_apply_structural_ops(ctx, table, ops.Count, words, payload.Count, &failed));
-        }
-        // the device holds this frame's type batches now
-        var stale = new List<long>();
-        foreach (var kv in mirrors) if (!kv.Value.Seen) stale.Add(kv.Key);
-        foreach (var key in stale) mirrors.Remove(key);
-        for (int b = 0; b < activeSet.Batches.Count; ++b)
-        {
-            ref var batch = ref activeSet.Batches[b];
-            for (int t = 0; t < batch.TypeBatches.Count; ++t) { ref var tb = ref batch.TypeBatches[t]; Remember(b, ref tb, solver.TypeProcessors[tb.TypeId].BodiesPerConstraint); }
+            fixed (BepuHipStructuralOp* table = System.Runtime.InteropServices.CollectionsMarshal.AsSpan(removals)) fixed (uint* words = System.Runtime.InteropServices.CollectionsMarshal.AsSpan(payload))
+                Check(BepuHip.bepuhip_apply_structural_ops(ctx, table, removals.Count, words, payload.Count, &failed));
         }
         // Updates the plan could not absorb (a new type batch, exhausted reserves) leave the context on the launch-per-batch schedule: a fresh plan costs tens of
         // milliseconds once, the slow schedule costs every frame from then on. Not more often than every ReplanInterval frames.
@@ -364,23 +464,107 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, 
         return true;
     }
 
-    // What the narrow phase rewrote in place for persisting pairs since the last solve (NarrowPhaseConstraintUpdate.cs:147-207): prestep data and redistributed impulses
-    // of the contact type batches. Enqueued; the buffers are not touched again before the sync at the end of SolveOnDevice.
-    void RefreshContacts(Simulation simulation)
+    // What the host rewrote IN PLACE since the last solve, and what the solve will change, as two bepuhip_transfer_rows_async tables (rowsIn before the solve, rowsOut behind it):
+    //  * contact type batches whole — the narrow phase rewrites prestep data and redistributed impulses of every persisting pair (NarrowPhaseConstraintUpdate.cs:147-207);
+    //  * every other type batch: the bundles whose prestep data or impulses differ from the shadow (Solver.ApplyDescription on a motor or servo, Tank.cs:100,139,
+    //    SimpleCar.cs:25; impulses the awakener restored; a handle the pool handed out again for a new joint) — compared on the thread pool, one type batch per task;
+    //  * back: accumulated impulses of the contacts always, of the joints with ReadBackJointImpulses.
+    // The buffers are not touched again before the sync at the end of SolveOnDevice.
+    sealed class Range { public int Batch, TypeId, First, Count; public bool Prestep; }
+    void CollectRowTraffic(Simulation simulation)
     {
         ref var activeSet = ref simulation.Solver.ActiveSet;
+        rowsIn.Clear(); rowsOut.Clear();
+        var width = System.Numerics.Vector<int>.Count;
+        var work = new List<(int batch, int typeBatch)>();
         for (int b = 0; b < activeSet.Batches.Count; ++b)
         {
             ref var batch = ref activeSet.Batches[b];
             for (int t = 0; t < batch.TypeBatches.Count; ++t)
             {
                 ref var tb = ref batch.TypeBatches[t];
-                if (!NarrowPhase.IsContactConstraintType(tb.TypeId) || tb.ConstraintCount == 0) continue;
+                if (tb.ConstraintCount == 0) continue;
                 Register(tb.PrestepData.Memory, tb.PrestepData.Length); Register(tb.AccumulatedImpulses.Memory, tb.AccumulatedImpulses.Length);
-                Check(BepuHip.bepuhip_update_prestep_async(ctx, b, tb.TypeId, 0, tb.BundleCount, (float*)tb.PrestepData.Memory));
-                Check(BepuHip.bepuhip_update_accumulated_impulses_async(ctx, b, tb.TypeId, 0, tb.BundleCount, (float*)tb.AccumulatedImpulses.Memory));
+                bool contact = NarrowPhase.IsContactConstraintType(tb.TypeId);
+                if (contact)
+                {
+                    rowsIn.Add(new BepuHipRowTransfer { Kind = 0, BatchIndex = b, TypeId = tb.TypeId, FirstBundle = 0, BundleCount = -1, Bundles = tb.PrestepData.Memory });
+                    rowsIn.Add(new BepuHipRowTransfer { Kind = 1, BatchIndex = b, TypeId = tb.TypeId, FirstBundle = 0, BundleCount = -1, Bundles = tb.AccumulatedImpulses.Memory });
+                }
+                else work.Add((b, t));
+                if (contact || ReadBackJointImpulses)
+                    rowsOut.Add(new BepuHipRowTransfer { Kind = 3, BatchIndex = b, TypeId = tb.TypeId, FirstBundle = 0, BundleCount = -1, Bundles = tb.AccumulatedImpulses.Memory });
             }
         }
+        var found = new List<Range>[work.Count];
+        var solver = simulation.Solver;
+        System.Threading.Tasks.Parallel.For(0, work.Count, w =>
+        {
+            ref var tb = ref solver.ActiveSet.Batches[work[w].batch].TypeBatches[work[w].typeBatch];
+            var m = mirrors[Key(work[w].batch, tb.TypeId)];
+            var ranges = found[w] = new List<Range>();
+            for (int pass = 0; pass < 2; ++pass)
+            {
+                int floatsPerBundle = (pass == 0 ? m.PrestepFloats : m.ImpulseFloats) * width;
+                var host = new Span<float>(pass == 0 ? tb.PrestepData.Memory : tb.AccumulatedImpulses.Memory, tb.BundleCount * floatsPerBundle);
+                var shadow = new Span<float>(pass == 0 ? m.Prestep : m.Impulses, 0, tb.BundleCount * floatsPerBundle);
+                for (int bundle = 0; bundle < tb.BundleCount; ++bundle)
+                {
+                    bool dirty = false;
+                    if (CompareJointData) dirty = !System.Runtime.InteropServices.MemoryMarshal.AsBytes(host.Slice(bundle * floatsPerBundle, floatsPerBundle)).SequenceEqual(System.Runtime.InteropServices.MemoryMarshal.AsBytes(shadow.Slice(bundle * floatsPerBundle, floatsPerBundle)));
+                    else for (int lane = 0; lane < width && bundle * width + lane < tb.ConstraintCount; ++lane) dirty |= dirtyConstraints.Contains(tb.IndexToHandle[bundle * width + lane].Value);
+                    if (!dirty) continue;
+                    host.Slice(bundle * floatsPerBundle, floatsPerBundle).CopyTo(shadow.Slice(bundle * floatsPerBundle, floatsPerBundle));
+                    if (ranges.Count > 0 && ranges[^1].Prestep == (pass == 0) && ranges[^1].First + ranges[^1].Count == bundle) ++ranges[^1].Count;
+                    else ranges.Add(new Range { Batch = work[w].batch, TypeId = tb.TypeId, First = bundle, Count = 1, Prestep = pass == 0 });
+                }
+            }
+        });
+        for (int w = 0; w < work.Count; ++w)
+        {
+            ref var tb = ref activeSet.Batches[work[w].batch].TypeBatches[work[w].typeBatch];
+            var m = mirrors[Key(work[w].batch, tb.TypeId)];
+            foreach (var r in found[w])
+                rowsIn.Add(new BepuHipRowTransfer { Kind = r.Prestep ? 0 : 1, BatchIndex = r.Batch, TypeId = r.TypeId, FirstBundle = r.First, BundleCount = r.Count,
+                    Bundles = r.Prestep ? (float*)tb.PrestepData.Memory + (long)r.First * m.PrestepFloats * width : (float*)tb.AccumulatedImpulses.Memory + (long)r.First * m.ImpulseFloats * width });
+        }
+        dirtyConstraints.Clear();
+    }
+    void Transfer(List<BepuHipRowTransfer> rows)
+    {
+        if (rows.Count == 0) return;
+        fixed (BepuHipRowTransfer* table = System.Runtime.InteropServices.CollectionsMarshal.AsSpan(rows)) Check(BepuHip.bepuhip_transfer_rows_async(ctx, table, rows.Count));
+    }
+    /// With ReadBackJointImpulses off: the joints' accumulated impulses now (before Solver.GetDescription on a joint, before the sleeper looks at an island).
+    public void FetchJointImpulses(Simulation simulation)
+    {
+        bool keep = ReadBackJointImpulses; ReadBackJointImpulses = true;
+        rowsOut.Clear();
+        ref var activeSet = ref simulation.Solver.ActiveSet;
+        for (int b = 0; b < activeSet.Batches.Count; ++b)
+            for (int t = 0; t < activeSet.Batches[b].TypeBatches.Count; ++t)
+            {
+                ref var tb = ref activeSet.Batches[b].TypeBatches[t];
+                if (tb.ConstraintCount > 0 && !NarrowPhase.IsContactConstraintType(tb.TypeId))
+                    rowsOut.Add(new BepuHipRowTransfer { Kind = 3, BatchIndex = b, TypeId = tb.TypeId, FirstBundle = 0, BundleCount = -1, Bundles = tb.AccumulatedImpulses.Memory });
+            }
+        Transfer(rowsOut); Check(BepuHip.bepuhip_sync(ctx)); AdoptImpulses(simulation);
+        ReadBackJointImpulses = keep;
+    }
+    // The joints' impulses the device just wrote into the host's buffers are what the device holds: the shadows follow.
+    void AdoptImpulses(Simulation simulation)
+    {
+        if (!ReadBackJointImpulses) return;
+        var width = System.Numerics.Vector<int>.Count;
+        ref var activeSet = ref simulation.Solver.ActiveSet;
+        for (int b = 0; b < activeSet.Batches.Count; ++b)
+            for (int t = 0; t < activeSet.Batches[b].TypeBatches.Count; ++t)
+            {
+                ref var tb = ref activeSet.Batches[b].TypeBatches[t];
+                if (tb.ConstraintCount == 0 || NarrowPhase.IsContactConstraintType(tb.TypeId)) continue;
+                var m = mirrors[Key(b, tb.TypeId)];
+                new Span<float>(tb.AccumulatedImpulses.Memory, tb.BundleCount * m.ImpulseFloats * width).CopyTo(m.Impulses);
+            }
     }
 
     void SolveOnDevice(Simulation simulation, float dt)
@@ -398,8 +582,9 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, 
                 Register(activeBodies.DynamicsState.Memory, (long)activeBodies.DynamicsState.Length * sizeof(BodyDynamics));
                 Check(BepuHip.bepuhip_set_bodies(ctx, activeBodies.DynamicsState.Memory, activeBodies.Count));
             }
-            RefreshContacts(simulation);
         }
+        CollectRowTraffic(simulation);
+        Transfer(rowsIn);
         residentBodyCount = activeBodies.Count;
         // Solver.ConstrainedKinematicHandles changes with the constraints (Solver.cs:1025, :1374): indices only, sent every frame
         var kinematics = stackalloc int[Math.Max(1, solver.ConstrainedKinematicHandles.Count)];
@@ -444,21 +629,14 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, 
         }
         else Check(BepuHip.bepuhip_solve_async(ctx, dt, solver.SubstepCount, iterations, &integ));
 
-        // Back to the host, behind the solve on the same stream: poses and velocities (the MotionState half of BodyDynamics: what collision detection and the user read),
-        // and the accumulated impulses of the contact type batches (the narrow phase redistributes them over next frame's manifolds). Joint impulses and contact
-        // depths stay on the device; bepuhip_get_accumulated_impulses / bepuhip_get_prestep fetch them for a host that wants to look.
+        // Back to the host, behind the solve on the same stream: poses and velocities (the MotionState half of BodyDynamics: what collision detection and the user read)
+        // and the accumulated impulses (contacts: the narrow phase redistributes them over next frame's manifolds; joints: Solver.GetDescription, the sleeper, the
+        // awakener) — one kernel each that writes straight into the registered host buffers. Contact depths stay on the device (the narrow phase rewrites them);
+        // bepuhip_get_prestep fetches them for a host that wants to look.
         Check(BepuHip.bepuhip_get_poses_and_velocities_async(ctx, activeBodies.DynamicsState.Memory, activeBodies.Count));
+        Transfer(rowsOut);
         Check(BepuHip.bepuhip_sync(ctx));
-        for (int b = 0; b < activeSet.Batches.Count; ++b)
-        {
-            ref var batch = ref activeSet.Batches[b];
-            for (int t = 0; t < batch.TypeBatches.Count; ++t)
-            {
-                ref var tb = ref batch.TypeBatches[t];
-                if (NarrowPhase.IsContactConstraintType(tb.TypeId) && tb.ConstraintCount > 0)
-                    Check(BepuHip.bepuhip_get_accumulated_impulses(ctx, b, tb.TypeId, (float*)tb.AccumulatedImpulses.Memory));
-            }
-        }
+        AdoptImpulses(simulation);
     }
     static int GetVelocityIterationCountForSubstepIndex(Solver solver, int substepIndex)
     {

@@ -44,3 +44,37 @@ class OracleShare:
         for _ in range(frames):
             self.synced = self._velocities()
             oracle_solve(self.share.scene, self.dt, self.sd, self.cb, threads=threads, exchange=self.hook)
+
+
+def solve_oracle_shares_in_process(shares, dt, solve_description, callbacks, frames: int = 1, threads: int = 1):
+    """The CPU lattice: every share through OracleShare, one thread per rank, the per-pass averaged exchange through the same ThreadExchange the in-process GPU harness
+    uses (same rank order of the sum, same division by the holders). What tests/test_gpu_lattice.py holds the device's block-Jacobi shares against."""
+    import threading
+
+    import oracle_ffi
+    from bepuphysics2_amd.lattice import ThreadExchange
+    ex = ThreadExchange(shares)
+    errors = []
+
+    class RankExchange:
+        def __init__(self, rank):
+            self.rank = rank
+
+        def reduce(self, local):
+            return ex.reduce(self.rank, np.ascontiguousarray(local, dtype=np.float32), False)
+
+    def run(rank):
+        try:
+            OracleShare(shares[rank], dt, solve_description, callbacks, RankExchange(rank)).solve(oracle_ffi.solve, frames=frames, threads=threads)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            ex.barrier.abort()
+
+    workers = [threading.Thread(target=run, args=(r,)) for r in range(len(shares))]
+    for t in workers:
+        t.start()
+    for t in workers:
+        t.join()
+    if errors:
+        raise errors[0]
+    return ex

@@ -158,6 +158,41 @@ def test_block_jacobi_shares_on_island_plans_equal_the_launch_per_batch_shares(m
         lattice.solve_shares_in_process(lambda: HipSolver(device=0, use_clusters=True), shares, 1 / 60, sd, cb, frames=1, exact=True)
 
 
+def test_block_jacobi_shares_equal_the_cpu_lattice(monkeypatch):
+    """the test above compares the device with itself. Here the per-pass averaged mode has an oracle: the CPU lattice — every share solved by the
+    oracle with the same exchange points, the same snapshot / delta / apply arithmetic and the same in-process exchange (tests/oracle_share.py, checked against the
+    two-process gloo run in tests/test_lattice_cpu.py). Two shares on launch-per-batch rows, on whole-island plans and on split-island plans: every copy of every body
+    equals the CPU lattice's bit for bit."""
+    import parity_util as pu
+    from bepuphysics2_amd import lattice
+    from bepuphysics2_amd.native import HipSolver
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    from oracle_share import solve_oracle_shares_in_process
+    scene, sd = _lattice_scene(96)
+    cb = PoseIntegratorCallbacks()
+    owner = lattice.owner_by_groups(scene, 2, 16)
+    want = [lattice.make_share(scene, owner, r, 2) for r in range(2)]
+    solve_oracle_shares_in_process(want, 1 / 60, sd, cb, frames=2, threads=2)
+    for use_clusters, split in ((False, False), (True, False), (True, True)):
+        if split:
+            monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "6")
+            monkeypatch.setenv("BEPUHIP_CLUSTER_BODIES", "200")  # no workgroup holds a share's island: split-island plans
+        shares = [lattice.make_share(scene, owner, r, 2) for r in range(2)]
+        kinds = []
+
+        class Recording(HipSolver):
+            def upload(self, *a, **k):
+                super().upload(*a, **k)
+                kinds.append(self.schedule())
+
+        lattice.solve_shares_in_process(lambda: Recording(device=0, use_clusters=use_clusters), shares, 1 / 60, sd, cb, frames=2)
+        assert kinds == [2 if split else (1 if use_clusters else 0)] * 2, (use_clusters, split, kinds)
+        for got, ref in zip(shares, want):
+            assert np.array_equal(got.scene.bodies[:, :15].view(np.int32), ref.scene.bodies[:, :15].view(np.int32)), (use_clusters, split)
+        m = pu.compare_scenes(lattice.merge_owned(scene, want), lattice.merge_owned(scene, shares))
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (use_clusters, split, m)
+
+
 def test_block_jacobi_mode_in_process_reports_its_error():
     """The per-pass averaged mode through the same in-process harness bench.py's lattice leg uses: a few percent at the cut, close agreement away from it."""
     import parity_util as pu

@@ -58,6 +58,28 @@ def test_device_fuzz_slice(seed, first, count):
     assert compared >= count * 3 // 4 and island >= count // 2 and split >= 2, (compared, island, split)  # the slice really covers the island schedules
 
 
+@pytest.mark.parametrize("seed", [515, 2026])
+def test_split_plan_fuzz_slice_under_jitter(seed):
+    """the slices above only hold the split-island scenes their generator happens to draw (two or three each). Here the twelve first BIG scenes of a
+    seed's sequence — forced split plans over random subsets of all 44 type ids, conserving modes, kinematic fractions — every one under schedule fuzzing, which since
+    round 5 also naps in front of the shared-record polls (acquire_shared / acquire_shared_many) and in front of every record publish (release_shared): the
+    cross-workgroup hand-off protocol under timing no natural run produces. Every compared scene bit-identical to the oracle."""
+    params = [p for p in fu.device_scene_parameters(seed, 400) if p["big"]][:12]
+    assert len(params) == 12
+    compared, wrong, split = 0, [], 0
+    for ordinal, p in enumerate(params):
+        p = dict(p, use_clusters=True)
+        verdict, (schedule, policy, clusters) = fu.check_device_scene(p, jitter=(seed * 7919 + ordinal) | 1)
+        split += schedule == 2 and clusters > 1
+        if verdict == "diverged":
+            continue
+        compared += 1
+        if verdict == "mismatch":
+            wrong.append((ordinal, fu.describe(p)))
+    assert not wrong, wrong
+    assert split >= 10 and compared >= 8, (split, compared)
+
+
 @pytest.mark.parametrize("seed,count", [(61, 24), (7, 24)])
 def test_structural_fuzz_slice(seed, count):
     """`count` scenes of tools/fuzz_structural.py's generator: random add / remove / body-removal / re-plan streams, every frame equal to the oracle solving the host mirror."""

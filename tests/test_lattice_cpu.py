@@ -163,3 +163,22 @@ def test_full_mass_shares_for_the_exact_mode():
     assert np.array_equal(full.scene.bodies[:, 16:31], scene.bodies[g, 16:31])
     b = split.boundary_local
     assert b.size and np.allclose(split.scene.bodies[b, 22], 2 * scene.bodies[g[b], 22])
+
+
+def test_oracle_shares_in_threads_equal_the_gloo_processes(tmp_path):
+    """The in-process CPU lattice (oracle_share.solve_oracle_shares_in_process: one thread per rank, ThreadExchange) is the oracle tests/test_gpu_lattice.py holds the device's
+    block-Jacobi shares against; here it is checked against the two-process gloo run of the same shares: same sums, same bits."""
+    from bepuphysics2_amd import lattice
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    from oracle_share import solve_oracle_shares_in_process
+    ragdolls = 24
+    port = 29100 + (os.getpid() % 300)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), ragdolls), nprocs=2, join=True)
+    scene, sd = _lattice_scene(ragdolls)
+    owner = lattice.owner_by_groups(scene, 2, 16)
+    shares = [lattice.make_share(scene, owner, r, 2) for r in range(2)]
+    ex = solve_oracle_shares_in_process(shares, 1 / 60, sd, PoseIntegratorCallbacks(), frames=2)
+    assert ex.calls == 2 * int((1 + sd.iterations()).sum())
+    for rank, sh in enumerate(shares):
+        d = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+        assert np.array_equal(sh.scene.bodies[:, :15].view(np.int32), d["bodies"][:, :15].view(np.int32)), rank
