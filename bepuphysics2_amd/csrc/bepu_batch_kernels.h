@@ -69,8 +69,11 @@ __device__ __forceinline__ void run_constraint(const DevTypeBatch& tb, int i, fl
 // One grid per (batch, stage): the block index selects the type batch, the type id (wave-uniform) selects the function.
 // Graph colouring guarantees that no dynamic body is referenced twice inside a batch (Solver.cs:1046-1051), so no two lanes of
 // the grid write the same body and results do not depend on lane order.
+// Register budget (round 5): two waves per SIMD are asked for instead of three — the Solve instantiation then has 218 VGPRs and no scratch (at three:
+// 168 VGPRs, 55 spilled, 192 B of scratch, four rounds running). A launch of this schedule is a few hundred lanes per CU (the pile: 50,000 constraints over 256 CUs), bound
+// by its four dependent memory round trips, so occupancy above two waves buys nothing and the scratch reloads sat inside the dependent chain.
 template <int STAGE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void batch_kernel(const DevTypeBatch* __restrict__ tbs, int tb_begin, int tb_count, float4* bodies, float dt, float inv_dt) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void batch_kernel(const DevTypeBatch* __restrict__ tbs, int tb_begin, int tb_count, float4* bodies, float dt, float inv_dt) {
     const int b = blockIdx.x;
     int t = tb_begin;
     for (int k = 1; k < tb_count; ++k)

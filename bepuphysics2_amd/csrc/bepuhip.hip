@@ -2184,11 +2184,11 @@ static int32_t transfer_run(bepuhip_ctx* c, const bepuhip_row_transfer* items, i
     HIP_TRY(hipMemcpyAsync(d_table, slot, table_bytes, hipMemcpyHostToDevice, c->stream));
     if (update) {
         for (const Copy& copy : copies) HIP_TRY(hipMemcpyAsync(c->d_stage + copy.stage_off, copy.host, copy.floats * 4, hipMemcpyHostToDevice, c->stream));
-        for (uint32_t* slab : {c->d_slab, c->d_slab0})  // the pristine snapshot follows, as with every update_* call
-            if (slab) transfer_rows_kernel<true><<<blocks, 256, 0, c->stream>>>((const RowTransferDesc*)d_table, (int)descs.size(), (float*)slab, c->W);
+        // (the pristine snapshot follows, as with every update_* call: same launch, the bundles cross the link once)
+        transfer_rows_kernel<true><<<blocks, 256, 0, c->stream>>>((const RowTransferDesc*)d_table, (int)descs.size(), (float*)c->d_slab, (float*)c->d_slab0, c->W);
         HIP_TRY(hipGetLastError());
     } else {
-        transfer_rows_kernel<false><<<blocks, 256, 0, c->stream>>>((const RowTransferDesc*)d_table, (int)descs.size(), (float*)c->d_slab, c->W);
+        transfer_rows_kernel<false><<<blocks, 256, 0, c->stream>>>((const RowTransferDesc*)d_table, (int)descs.size(), (float*)c->d_slab, nullptr, c->W);
         HIP_TRY(hipGetLastError());
         for (const Copy& copy : copies) HIP_TRY(hipMemcpyAsync(copy.host, c->d_stage + copy.stage_off, copy.floats * 4, hipMemcpyDeviceToHost, c->stream));
     }

@@ -172,7 +172,7 @@ def test_block_jacobi_shares_equal_the_cpu_lattice(monkeypatch):
     cb = PoseIntegratorCallbacks()
     owner = lattice.owner_by_groups(scene, 2, 16)
     want = [lattice.make_share(scene, owner, r, 2) for r in range(2)]
-    solve_oracle_shares_in_process(want, 1 / 60, sd, cb, frames=2, threads=2)
+    solve_oracle_shares_in_process(want, 1 / 60, sd, cb, frames=2)  # (one oracle thread per share: the exchange hook is a Python call-back, and the oracle's own worker threads spinning next to two of those starve each other of the GIL)
     for use_clusters, split in ((False, False), (True, False), (True, True)):
         if split:
             monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "6")

@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 TWIST_SERVO, ANGULAR_MOTOR, BALL_SOCKET, SWING_LIMIT = 26, 30, 22, 25
 NAMES = {info[3]: t for t, info in TYPE_TABLE.items()}
+REQUIRE_RESTORED_IMPULSES = True  # (a dry run of the test's host side without a device, where nothing ever accumulates, turns this off)
 
 
 def constraints_of(sim, export, predicate):
@@ -94,7 +95,7 @@ def test_resident_frame_follows_descriptions_sleeping_islands_and_reused_handles
             for t, b, lane, acc in asleep:
                 h = sim.add_constraint(t, b, lane)
                 sim.set_accumulated_impulses(h, acc)
-            assert any(np.any(acc != 0) for _, _, _, acc in asleep), "the sleeping joints had accumulated impulses to restore"
+            assert not REQUIRE_RESTORED_IMPULSES or any(np.any(acc != 0) for _, _, _, acc in asleep), "the sleeping joints had accumulated impulses to restore"
             what.append(f"{len(asleep)} constraints awake")
         if frame in (6, 11):  # the LAST ball socket of a type batch removed and another ball socket added: same handle (the pool is LIFO), same type batch, same index
             sockets = constraints_of(sim, export, lambda t, b: t == BALL_SOCKET)
