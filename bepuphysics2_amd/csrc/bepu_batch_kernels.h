@@ -155,14 +155,14 @@ __device__ __forceinline__ void velocity_callback(const StepParams& sp, BodyVel&
 // Cluster path only: advance the constrained kinematic bodies in global memory through the in-solver substeps
 // (PoseIntegrator.cs:451-535 applied substep_count times: substep 0 velocity only, later substeps pose then velocity).
 // (the island schedule's kinematic workgroup: all substeps of a constrained kinematic body at once, PoseIntegrator.cs:451-535)
-__device__ __forceinline__ void kinematic_substeps_body(float4* bodies, int index, int substeps, int integrate_velocity_for_kinematics, const StepParams& sp) {
+__device__ __forceinline__ void kinematic_substeps_body(float4* bodies, int index, int substeps, int integrate_velocity_for_kinematics, const StepParams& sp, int substep_base = 0) {
     float4* base = bodies + (size_t)(index & kRefMask) * 8;
     float4 q4 = base[0], p4 = base[1], l4 = base[2], a4 = base[3];
     Q ori = {q4.x, q4.y, q4.z, q4.w};
     V3 pos = {p4.x, p4.y, p4.z};
     BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
     for (int s = 0; s < substeps; ++s) {
-        if (s > 0) {
+        if (substep_base + s > 0) {  // (a chained step's later launches start past the step's first substep)
             pos = add(pos, scale(vel.lin, sp.dt));
             ori = integrateOrientation(ori, vel.ang, sp.dt * 0.5f);
         }

@@ -297,7 +297,9 @@ __device__ __forceinline__ SharedRef make_shared_ref(const ClusterShared& sh, un
     const bool shared = active && (half & kLrefShared) != 0 && (half & 0x8000u) == 0;
     r.body = shared ? (sh.slot_body[half & 0x3FFFu] & kSlotBodyMask) : -1;
     r.number = sh.st.base + sh.events + ((srank >> 8) & 0xFFu) * sh.passes + (END_OF_SUBSTEP ? 0u : (srank & 0xFFu));  // rank | degree << 8
-    r.poll = shared && (END_OF_SUBSTEP || !(srank & kRankPredLocal));
+    // (END_OF_SUBSTEP in a launch's first substep — a chained step's later launch — has no record to poll: every slot, ghost copies included, was staged from HBM with
+    // the velocity the previous launch's home cluster wrote back)
+    r.poll = shared && (END_OF_SUBSTEP ? sh.events > 0u : !(srank & kRankPredLocal));
     r.publish = shared && !(srank & kRankSuccLocal);
     return r;
 }
@@ -802,6 +804,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         // tp.block_offset > 0 these workgroups are a launch of their own behind the clusters' on the same stream).
         const int t = (int)blockIdx.x + tp.block_offset - tp.cluster_count;
         if (t < tp.body_blocks) {
+            if (!tp.final_launch) return;  // IntegrateAfterSubstepping belongs to the step's last launch
             const int i = t * (int)blockDim.x + (int)threadIdx.x;
             if (i < tp.body_count) {
                 const unsigned f = tp.flags[i];
@@ -821,8 +824,8 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         __syncthreads();
         for (int j = (int)threadIdx.x; j < tp.kin_count; j += (int)blockDim.x) {
             const int index = tp.kinlist[j] & kRefMask;
-            kinematic_substeps_body(bodies, index, tp.substep_count, tp.integrate_velocity_for_kinematics, cp.sp);
-            final_integrate_body(bodies, tp.flags[index], index, tp.dt, tp.substep_dt, tp.substep_count, tp.allow_substeps_for_unconstrained, tp.integrate_velocity_for_kinematics, tp.final_sp);
+            kinematic_substeps_body(bodies, index, tp.launch_substeps, tp.integrate_velocity_for_kinematics, cp.sp, tp.substep_base);
+            if (tp.final_launch) final_integrate_body(bodies, tp.flags[index], index, tp.dt, tp.substep_dt, tp.substep_count, tp.allow_substeps_for_unconstrained, tp.integrate_velocity_for_kinematics, tp.final_sp);
         }
         return;
     }
@@ -908,8 +911,9 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     }
     unsigned epoch = 0, claim_base = 0;
     for (int s = 0; s < cp.substeps; ++s) {
-        if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(&sh.status[10], (unsigned)s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (s > 0) {  // Solver_Solve.cs:1427-1439: contact depths advance with the pre-integration velocities
+        const int gs = cp.substep_base + s;  // the substep's index in the STEP (a chained step: this launch starts at substep_base); `s` counts this launch's substeps (records, events)
+        if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(&sh.status[10], (unsigned)gs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (gs > 0) {  // Solver_Solve.cs:1427-1439: contact depths advance with the pre-integration velocities
             for (int k = wave; k < cd.item_count; k += nwaves) {
                 const ClusterItem* it = sh.items + k;
                 const ItemHeader h = read_item(it);
@@ -939,7 +943,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
             Q ori = {q4.x, q4.y, q4.z, q4.w};
             V3 pos = {p4.x, p4.y, p4.z};
             BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
-            if (s > 0) {
+            if (gs > 0) {
                 pos = add(pos, scale(vel.lin, dt));
                 ori = integrateOrientation(ori, vel.ang, dt * 0.5f);
                 r[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
@@ -956,7 +960,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                     if (!ghost) {
                         const Q before = {q4.x, q4.y, q4.z, q4.w};  // substep > 0: the orientation the step started from; substep 0: "integrating backwards" from the current one
                         if (cp.sp.angular_mode == 1)
-                            vel.ang = integrateAngularVelocityConserveMomentum(s > 0 ? before : integrateOrientation(ori, vel.ang, dt * -0.5f), local, world, vel.ang);
+                            vel.ang = integrateAngularVelocityConserveMomentum(gs > 0 ? before : integrateOrientation(ori, vel.ang, dt * -0.5f), local, world, vel.ang);
                         else if (cp.sp.angular_mode == 2)
                             vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, dt);
                     }
@@ -977,7 +981,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
             }
         }
         if constexpr (SHARED) sh.events = (unsigned)s + 1u;
-        sh.substep = s;
+        sh.substep = gs;
         __syncthreads();
         ++epoch;
         const int fused = cp.iters[s] > 0 ? cd.item_count : 0;  // the first velocity iteration rides in the warm start's claim sequence
@@ -1012,8 +1016,10 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
         Q ori = {q4.x, q4.y, q4.z, q4.w};
         V3 pos = {p4.x, p4.y, p4.z};
         V3 lin = {l4.x, l4.y, l4.z}, ang = {a4.x, a4.y, a4.z};
-        ori = integrateOrientation(ori, ang, dt * 0.5f);
-        pos = add(pos, scale(lin, dt));
+        if (cp.final_launch) {  // (a chained step's earlier launches leave the pose of their last substep: the next launch's first substep integrates it on)
+            ori = integrateOrientation(ori, ang, dt * 0.5f);
+            pos = add(pos, scale(lin, dt));
+        }
         float4* gb = bodies + (size_t)g * 8;
         gb[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
         gb[1] = make_float4(pos.x, pos.y, pos.z, p4.w);

@@ -255,6 +255,8 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         cap = (int)std::min<int64_t>(std::max<int64_t>(target, 64), 1600);
     }
     if (largest > cap) cap = largest;
+    // (tests: BEPUHIP_FORCE_SPLIT=<bodies> cuts the scene's islands as if no workgroup held an island of that many bodies, so that small scenes reach the split-island kernels)
+    if (const int force = env_int("BEPUHIP_FORCE_SPLIT", 0); force > 0 && largest >= force) { plan_split_clusters(c, plan, universe); return; }
     // ---- phase A: find a cap whose clusters fit the LDS budget (no mutation yet) ----
     std::vector<int32_t> cluster_of(universe, -1);  // by component root
     std::vector<std::vector<int32_t>> cl_of_constraint(c->tbs.size());

@@ -89,6 +89,10 @@ struct ClusterParams {
     int iters[kMaxClusterSubsteps];
     int pass_stage, pass_substep;  // the one-sweep-per-launch units (kPass): kStageWarmStart or kStageSolve, and the substep the sweep belongs to
     int fallback_batch;            // index of the sequential fallback batch (its items may depend on items of their own batch), -1 if the scene has none
+    // A step may be a CHAIN of launches (round 5): more than kMaxClusterSubsteps substeps, or one substep per launch when the host raises Solver.SubstepStarted / SubstepEnded
+    // between them. A launch runs substeps [substep_base, substep_base + substeps) of the step: "substep 0" rules (velocity only, no incremental contact update, the
+    // conserving modes' backwards half-step and re-transformations) apply to the STEP's first substep only, and only the step's last launch integrates the trailing pose.
+    int substep_base, final_launch;
     StepParams sp;
 };
 
@@ -101,6 +105,7 @@ struct TailParams {
     int block_offset;  // added to blockIdx.x: the tail workgroups of a split plan are a launch of their own (the clusters' launch is cooperative: exactly the clusters)
     float dt, substep_dt;
     int substep_count, allow_substeps_for_unconstrained, integrate_velocity_for_kinematics;
+    int substep_base, launch_substeps, final_launch;  // a chained step (ClusterParams): the constrained kinematic bodies advance by this launch's substeps; IntegrateAfterSubstepping runs in the last launch only
     StepParams final_sp;  // PrepareForIntegration(dt or dt / substeps) of the final pass (PoseIntegrator.cs:707-726), not the substep's
 };
 

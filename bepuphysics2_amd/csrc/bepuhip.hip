@@ -939,99 +939,115 @@ static int cluster_threads(const bepuhip_ctx* c) {
 static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
     // (a sequential fallback batch runs the island schedule in the nonconserving mode; the conserving modes' substep-0 re-transformations of a fallback batch are lists
     // per dependency level, which only the launch-per-batch schedule has)
-    return c->clusters_enabled && substeps <= kMaxClusterSubsteps && !(c->has_fallback && in->angular_integration_mode != 0) &&
+    // (round 5: any number of substeps — a step of more than kMaxClusterSubsteps is a chain of launches, enqueue_island_launches)
+    (void)substeps;
+    return c->clusters_enabled && !(c->has_fallback && in->angular_integration_mode != 0) &&
            cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared) <= kLdsBudgetBytes &&
            (in->angular_integration_mode == 0 || (conserving_variant_exists(cluster_threads(c), c->clusters_shared) && c->d_trace == nullptr && env_int("BEPUHIP_CONSERVING_CLUSTERS", 1) != 0));
 }
+// The island schedule's launch for substeps [base, base + count) of a step of `substeps` substeps (the whole step when that is one launch: the usual case). A step is a
+// CHAIN of such launches when it has more substeps than a launch's arguments carry (kMaxClusterSubsteps), or when the host wants to be called between substeps
+// (bepuhip_solve_with_substep_events: one substep per launch). Between two launches of a chain the bodies are in HBM with the pose of the last substep run and their
+// velocities; "first substep of the step" rules and the trailing pose integration follow the STEP (ClusterParams.substep_base / final_launch).
+static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int base, int count, const int32_t* iterations, const bepuhip_integrator* in, const StepParams& sp) {
+    const float substep_dt = dt / substeps;
+    const size_t lds_bytes = cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared);
+    const bool whole_step = base == 0 && count == substeps;
+    ClusterParams cp;
+    cp.substeps = count; cp.batch_count = c->batch_count; cp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
+    cp.planes = c->cluster_planes;
+    cp.fallback_batch = c->has_fallback ? c->fallback_threshold : -1;
+    cp.pass_stage = 0; cp.pass_substep = 0;
+    cp.substep_base = base; cp.final_launch = base + count == substeps ? 1 : 0;
+    for (int s = 0; s < kMaxClusterSubsteps; ++s) cp.iters[s] = s < count ? iterations[base + s] : 0;
+    cp.sp = sp;
+    {
+        Timed t(c, 5);
+        // Waves per cluster: 16 by default (four per SIMD; 12 is as fast when memory latency is low, 8 is slower everywhere); BEPUHIP_CLUSTER_THREADS overrides.
+        // Scenes with SURVEY 8(f) types take the 512-thread build: at 128 VGPRs per wave the widened types spill hundreds of registers.
+        // (the widened variant too: its 1024-thread build spills 700 VGPRs and is still the faster one — 0.222 against 0.325 ms on the bench graph with widened joints
+        // on the pool's slow class of box, 0.195 against 0.193 on the fast one, profiles/r03_s13_widened_slowbox.txt: sixteen waves hide what the scratch traffic costs)
+        const int threads = cluster_threads(c);
+        const bool conserving = in->angular_integration_mode != 0;
+        const size_t launch_lds = lds_bytes;
+        // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
+        // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).
+        TailParams tp;
+        tp.flags = c->d_flags; tp.kinlist = c->d_kinlist; tp.staged = c->d_staged;
+        tp.body_count = c->body_count; tp.kin_count = c->kinlist_count; tp.cluster_count = c->cluster_count;
+        tp.body_blocks = cp.final_launch ? (c->body_count + threads - 1) / threads : 0;  // IntegrateAfterSubstepping of the bodies no cluster owns: the step's last launch
+        tp.block_offset = 0;
+        tp.dt = dt; tp.substep_dt = substep_dt; tp.substep_count = substeps;
+        tp.substep_base = base; tp.launch_substeps = count; tp.final_launch = cp.final_launch;
+        tp.allow_substeps_for_unconstrained = in->allow_substeps_for_unconstrained; tp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
+        const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
+        tp.final_sp = make_params(c, in, vdt, vdt, 1.0f / vdt);
+        SharedTables st = {c->d_shared_vel, c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1), 0u};
+        if (c->clusters_shared) {
+            // Event numbers of this launch: [base, base + span). A body sees at most substeps + 255 x passes events per launch; the span is kept even (record parity).
+            unsigned passes = 0;
+            for (int s = 0; s < count; ++s) passes += 1u + (unsigned)iterations[base + s];
+            const unsigned long long span = ((unsigned long long)count + 255ull * passes + 3ull) & ~1ull;
+            if ((unsigned long long)c->shared_epoch + 2ull * span > 0xFFFFFFFFull) {  // once in ~2 M steps: start over from cleared records
+                hipMemsetAsync(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4), c->stream);
+                c->shared_epoch = 0;
+            }
+            st.base = c->shared_epoch;
+            c->shared_epoch += (unsigned)span;
+        }
+        void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
+                        (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
+        const bool tr = c->d_trace != nullptr;
+        const bool policy_applies = cluster_variant_threads(threads) == (c->clusters_shared ? 512 : 1024) && !conserving;  // the variants that exist in both row policies (a conserving solve neither measures nor follows the policy beyond the code touch)
+        int sample = -1, candidate = 0;
+        if (policy_applies) {
+            if (c->row_policy < 0) settle_row_policy(c, threads, false);
+            if (c->row_policy >= 0) candidate = c->row_policy;
+            else if (whole_step && c->policy_samples < kPolicySamples) { sample = c->policy_samples++; candidate = sample % kPolicyCandidates; c->policy_threads = threads; }  // each under its own event pair (whole steps only: a link of a chain is not what the policy is for)
+        }
+        if (conserving && c->row_policy == 2) candidate = 2;
+        const bool nt = candidate == 1;
+        // (split plans take two spans: their work items run more code — pile 0.3795 -> 0.3695 ms, crowd 0.3976 -> 0.3899 on a slow-class box, the whole-island
+        // kernel 0.1875 -> 0.1897 with two; profiles/r04_s30_code_touch_spans_slowbox.txt)
+        cp.code_touch = candidate == 2 ? (c->clusters_shared ? 2 : 1) : 0;
+        if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(kCodeTouchMaxSpans, forced);  // never beyond the padding behind the unit's kernels
+        cp.jitter = debug_jitter_seed();
+        const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, conserving);  // the register budget that matches the workgroup size
+        if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
+        const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
+        bool launched = false;
+        if (c->clusters_shared && env_int("BEPUHIP_COOPERATIVE", (c->flags & BEPUHIP_FLAG_EXCLUSIVE_DEVICE) ? 0 : 1) != 0) {
+            // The clusters of a split plan wait for each other: they must all be resident at once. A cooperative launch of exactly the clusters makes the runtime
+            // guarantee that (or refuse), whatever else runs on the device; the per-body tail follows as an ordinary launch of the same kernel.
+            std::lock_guard<std::mutex> one_at_a_time(g_cooperative_launch);
+            if (hipLaunchCooperativeKernel(fn, dim3(c->cluster_count), dim3(threads), args, (unsigned)launch_lds, c->stream) == hipSuccess) {
+                launched = true;
+                if (tail_blocks > 0) {
+                    tp.block_offset = c->cluster_count;
+                    hipLaunchKernel(fn, dim3(tail_blocks), dim3(threads), args, 0, c->stream);
+                }
+            } else {
+                (void)hipGetLastError();  // e.g. hipErrorCooperativeLaunchTooLarge: fall back to the plain launch below
+            }
+        }
+        if (!launched) hipLaunchKernel(fn, dim3(c->cluster_count + tail_blocks), dim3(threads), args, launch_lds, c->stream);
+        if (sample >= 0) hipEventRecord(c->policy_events[sample][1], c->stream);
+    }
+}
+
 // Enqueue every kernel of one Simulation.Solve on the context's stream (Solver_Solve.cs:1415-1479 + PoseIntegrator.cs:707-726).
 static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t* iterations, const bepuhip_integrator* in) {
     const float substep_dt = dt / substeps;          // Solver_Solve.cs:1417
     const float inv_dt = 1.0f / substep_dt;          // :1421
     const StepParams sp = make_params(c, in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
-    const size_t lds_bytes = cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared);
     const bool use_clusters = island_schedule_applies(c, substeps, in);
     const int skip_clustered = use_clusters ? 1 : 0;
     if (use_clusters) {
-        // Every constraint belongs to an island small enough for one workgroup: the whole substep loop runs in ONE launch.
-        ClusterParams cp;
-        cp.substeps = substeps; cp.batch_count = c->batch_count; cp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
-        cp.planes = c->cluster_planes;
-        cp.fallback_batch = c->has_fallback ? c->fallback_threshold : -1;
-        cp.pass_stage = 0; cp.pass_substep = 0;
-        for (int s = 0; s < kMaxClusterSubsteps; ++s) cp.iters[s] = s < substeps ? iterations[s] : 0;
-        cp.sp = sp;
-        {
-            Timed t(c, 5);
-            // Waves per cluster: 16 by default (four per SIMD; 12 is as fast when memory latency is low, 8 is slower everywhere); BEPUHIP_CLUSTER_THREADS overrides.
-            // Scenes with SURVEY 8(f) types take the 512-thread build: at 128 VGPRs per wave the widened types spill hundreds of registers.
-            // (the widened variant too: its 1024-thread build spills 700 VGPRs and is still the faster one — 0.222 against 0.325 ms on the bench graph with widened joints
-            // on the pool's slow class of box, 0.195 against 0.193 on the fast one, profiles/r03_s13_widened_slowbox.txt: sixteen waves hide what the scratch traffic costs)
-            const int threads = cluster_threads(c);
-            const bool conserving = in->angular_integration_mode != 0;
-            const size_t launch_lds = lds_bytes;
-            // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
-            // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).
-            TailParams tp;
-            tp.flags = c->d_flags; tp.kinlist = c->d_kinlist; tp.staged = c->d_staged;
-            tp.body_count = c->body_count; tp.kin_count = c->kinlist_count; tp.cluster_count = c->cluster_count;
-            tp.body_blocks = (c->body_count + threads - 1) / threads;
-            tp.block_offset = 0;
-            tp.dt = dt; tp.substep_dt = substep_dt; tp.substep_count = substeps;
-            tp.allow_substeps_for_unconstrained = in->allow_substeps_for_unconstrained; tp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
-            const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
-            tp.final_sp = make_params(c, in, vdt, vdt, 1.0f / vdt);
-            SharedTables st = {c->d_shared_vel, c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1), 0u};
-            if (c->clusters_shared) {
-                // Event numbers of this step: [base, base + span). A body sees at most substeps + 255 x passes events per step; the span is kept even (record parity).
-                unsigned passes = 0;
-                for (int s = 0; s < substeps; ++s) passes += 1u + (unsigned)iterations[s];
-                const unsigned long long span = ((unsigned long long)substeps + 255ull * passes + 3ull) & ~1ull;
-                if ((unsigned long long)c->shared_epoch + 2ull * span > 0xFFFFFFFFull) {  // once in ~2 M steps: start over from cleared records
-                    hipMemsetAsync(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4), c->stream);
-                    c->shared_epoch = 0;
-                }
-                st.base = c->shared_epoch;
-                c->shared_epoch += (unsigned)span;
-            }
-            void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
-                            (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
-            const bool tr = c->d_trace != nullptr;
-            const bool policy_applies = cluster_variant_threads(threads) == (c->clusters_shared ? 512 : 1024) && !conserving;  // the variants that exist in both row policies (a conserving solve neither measures nor follows the policy beyond the code touch)
-            int sample = -1, candidate = 0;
-            if (policy_applies) {
-                if (c->row_policy < 0) settle_row_policy(c, threads, false);
-                if (c->row_policy >= 0) candidate = c->row_policy;
-                else if (c->policy_samples < kPolicySamples) { sample = c->policy_samples++; candidate = sample % kPolicyCandidates; c->policy_threads = threads; }  // each under its own event pair
-            }
-            if (conserving && c->row_policy == 2) candidate = 2;
-            const bool nt = candidate == 1;
-            // (split plans take two spans: their work items run more code — pile 0.3795 -> 0.3695 ms, crowd 0.3976 -> 0.3899 on a slow-class box, the whole-island
-            // kernel 0.1875 -> 0.1897 with two; profiles/r04_s30_code_touch_spans_slowbox.txt)
-            cp.code_touch = candidate == 2 ? (c->clusters_shared ? 2 : 1) : 0;
-            if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(kCodeTouchMaxSpans, forced);  // never beyond the padding behind the unit's kernels
-            cp.jitter = debug_jitter_seed();
-            const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, conserving);  // the register budget that matches the workgroup size
-            if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
-            const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
-            bool launched = false;
-            if (c->clusters_shared && env_int("BEPUHIP_COOPERATIVE", (c->flags & BEPUHIP_FLAG_EXCLUSIVE_DEVICE) ? 0 : 1) != 0) {
-                // The clusters of a split plan wait for each other: they must all be resident at once. A cooperative launch of exactly the clusters makes the runtime
-                // guarantee that (or refuse), whatever else runs on the device; the per-body tail follows as an ordinary launch of the same kernel.
-                std::lock_guard<std::mutex> one_at_a_time(g_cooperative_launch);
-                if (hipLaunchCooperativeKernel(fn, dim3(c->cluster_count), dim3(threads), args, (unsigned)launch_lds, c->stream) == hipSuccess) {
-                    launched = true;
-                    if (tail_blocks > 0) {
-                        tp.block_offset = c->cluster_count;
-                        hipLaunchKernel(fn, dim3(tail_blocks), dim3(threads), args, 0, c->stream);
-                    }
-                } else {
-                    (void)hipGetLastError();  // e.g. hipErrorCooperativeLaunchTooLarge: fall back to the plain launch below
-                }
-            }
-            if (!launched) hipLaunchKernel(fn, dim3(c->cluster_count + tail_blocks), dim3(threads), args, launch_lds, c->stream);
-            if (sample >= 0) hipEventRecord(c->policy_events[sample][1], c->stream);
-        }
+        // Every constraint belongs to an island a workgroup holds (or to a cluster of a cut island): the whole substep loop runs in ONE launch — or, past
+        // kMaxClusterSubsteps substeps (SolveDescription.SubstepCount is unbounded in the reference, SolveDescription.cs:16-136), in a chain of them.
+        for (int base = 0; base < substeps; base += kMaxClusterSubsteps)
+            enqueue_island_launch(c, dt, substeps, base, std::min(kMaxClusterSubsteps, substeps - base), iterations, in, sp);
     }
     for (int s = 0; s < substeps && !use_clusters; ++s) {
         if (s > 0 && c->inc_blocks > 0) {             // :1427-1439 (all batches in one grid: it reads velocities and writes only prestep depths)
@@ -1192,7 +1208,10 @@ int32_t bepuhip_solve_with_substep_events(bepuhip_ctx* c, float dt, int32_t subs
     if (st != BEPUHIP_OK) return st;
     HIP_TRY(hipSetDevice(c->device));
     if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
-    if (c->clusters_enabled) {  // the launch-per-batch kernels address rows [0, count): an island layout with free slots goes back into the caller's order first
+    // Round 5: a context on an island plan raises the events BETWEEN launches of the island kernel — one substep per launch (enqueue_island_launch), the bodies in HBM
+    // with the substep's pose and velocities while the handler runs, so that what it rewrites through the update_* entry points is what the next launch stages.
+    const bool islands = island_schedule_applies(c, substeps, in) && env_int("BEPUHIP_EVENT_CLUSTERS", 1) != 0;
+    if (c->clusters_enabled && !islands) {  // the launch-per-batch kernels address rows [0, count): an island layout with free slots goes back into the caller's order first
         bool gaps = false;
         for (auto& tb : c->tbs) gaps |= tb.slots > 0 && tb.slots != tb.count;
         for (auto& tb : c->tbs) if (tb.slots > 0 && !gaps) for (int d = 0; d < tb.count && !gaps; ++d) gaps = tb.perm[d] < 0;
@@ -1218,6 +1237,17 @@ int32_t bepuhip_solve_with_substep_events(bepuhip_ctx* c, float dt, int32_t subs
         c->in_substep_event = false;
         return BEPUHIP_OK;
     };
+    for (int s = 0; s < substeps && islands; ++s) {
+        if ((st = raise(started, s)) != BEPUHIP_OK) return st;  // OnSubstepStarted(substepIndex), Solver_Solve.cs:1425
+        if (!island_schedule_applies(c, substeps, in)) return fail(BEPUHIP_E_STATE, "a substep event handler made the context leave its island plan");
+        enqueue_island_launch(c, dt, substeps, s, 1, iterations, in, sp);
+        if ((st = raise(ended, s)) != BEPUHIP_OK) return st;    // OnSubstepEnded(substepIndex), :1478
+    }
+    if (islands) {
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+        return bepuhip_sync(c);
+    }
     for (int s = 0; s < substeps; ++s) {
         if ((st = raise(started, s)) != BEPUHIP_OK) return st;  // OnSubstepStarted(substepIndex), Solver_Solve.cs:1425
         if (s > 0 && c->inc_blocks > 0)

@@ -483,7 +483,9 @@ public:
     // Everything that changed in the solver's type batches since RememberTypeBatches, in ONE bepuhip_apply_structural_ops call: every type batch's removals first (the ones
     // of type batches that no longer exist included), then additions, swaps and reference patches. With `shadows` the mirrors' copies of the device's prestep data and
     // impulses follow the constraints to their new indices (a new constraint: the prestep lane it was added with, zero impulses — what the device now holds).
+    std::vector<std::pair<int, int>> changedTypeBatches;  // (batch, type id) whose arrangement the last DiffAndApply changed
     void DiffAndApply(const Solver& solver, const Bodies& bodies, bool shadows) {
+        changedTypeBatches.clear();
         std::vector<bepuhip_structural_op> removals, ops;
         std::vector<uint32_t> payload;
         std::unordered_map<uint64_t, bool> seen;
@@ -501,6 +503,7 @@ public:
                 const size_t before = removals.size() + ops.size();
                 DiffTypeBatch((int)b, tb.TypeId, nb, tb.Info.prestepFloats, was.handles.data(), (int)was.handles.size(), was.references.data(), was.bodyHandles.data(), tb.IndexToHandle.data(),
                               tb.ConstraintCount, tb.BodyReferences.data(), newBodyHandles.data(), tb.PrestepData.data(), removals, ops, payload, &survivor);
+                if (removals.size() + ops.size() != before || was.handles.size() != (size_t)tb.ConstraintCount) changedTypeBatches.push_back({(int)b, tb.TypeId});
                 if (shadows && !tb.Info.incremental && (removals.size() + ops.size() != before || was.handles.size() != (size_t)tb.ConstraintCount)) {
                     const int pf = tb.Info.prestepFloats, imf = tb.Info.impulseFloats;
                     std::vector<float> prestep((size_t)tb.BundleCount() * pf * W, 0.0f), impulses((size_t)tb.BundleCount() * imf * W, 0.0f);
@@ -643,6 +646,18 @@ public:
         if (mode == 1 && uploadedBodiesVersion == sim.bodies.TopologyVersion && uploadedSolverVersion != ~0ull) {
             if (uploadedSolverVersion != solver.TopologyVersion) {
                 DiffAndApply(solver, sim.bodies, false);
+                // A constraint that kept its handle AND its bodies is the same constraint to the diff — also when it was removed and added again in this frame (the pool
+                // hands the handle back): the device then still holds the old one's impulses where the host's start from zero (TypeProcessor.cs:327). This mode reads
+                // everything back every frame, so the host's buffers are the truth: the type batches whose arrangement changed are sent whole.
+                std::vector<bepuhip_row_transfer> rows;
+                for (auto& key : changedTypeBatches) {
+                    const ConstraintBatch& batch = solver.Batches[key.first];
+                    const TypeBatch& tb = batch.TypeBatches[batch.TypeIndexToTypeBatchIndex.at(key.second)];
+                    if (tb.ConstraintCount == 0) continue;
+                    rows.push_back({BEPUHIP_ROWS_UPDATE_PRESTEP, key.first, key.second, 0, -1, 0, const_cast<float*>(tb.PrestepData.data())});
+                    rows.push_back({BEPUHIP_ROWS_UPDATE_IMPULSES, key.first, key.second, 0, -1, 0, const_cast<float*>(tb.AccumulatedImpulses.data())});
+                }
+                if (!rows.empty()) { check(api.bepuhip_transfer_rows_async(ctx, rows.data(), (int32_t)rows.size())); check(api.bepuhip_sync(ctx)); }
                 SendKinematics(sim);
                 uploadedSolverVersion = solver.TopologyVersion;
                 ++structuralReplays;
@@ -858,6 +873,12 @@ int32_t bepuhost_resident_stats(void* s, int64_t* out3) {
     int32_t schedule = -1;
     t->api.bepuhip_get_schedule(t->ctx, &schedule);
     out3[0] = t->diffOperations; out3[1] = t->refreshedBundles; out3[2] = schedule;
+    return 0;
+}
+int32_t bepuhost_timestepper_replan_interval(void* s, int frames) {
+    HipTimestepper* t = dynamic_cast<HipTimestepper*>(((Simulation*)s)->timestepper);
+    if (!t) { g_err = "no HipTimestepper attached"; return -1; }
+    t->replanInterval = frames;
     return 0;
 }
 int32_t bepuhost_timestepper_read_back_contact_depths(void* s, int on) {

@@ -73,6 +73,8 @@ def load_library() -> C.CDLL:
     lib.bepuhost_constraint_location.restype = i32
     lib.bepuhost_resident_stats.argtypes = [vp, vp]
     lib.bepuhost_resident_stats.restype = i32
+    lib.bepuhost_timestepper_replan_interval.argtypes = [vp, C.c_int]
+    lib.bepuhost_timestepper_replan_interval.restype = i32
     lib.bepuhost_timestepper_read_back_contact_depths.argtypes = [vp, C.c_int]
     lib.bepuhost_timestepper_read_back_contact_depths.restype = i32
     lib.bepuhost_diff_type_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.POINTER(i32)]
@@ -171,6 +173,11 @@ class HostSimulation:
         if self.lib.bepuhost_resident_stats(self.h, out) != 0:
             raise RuntimeError(_err(self.lib))
         return int(out[0]), int(out[1]), int(out[2])
+
+    def replan_interval(self, frames: int):
+        """Frames a context may spend off its island plan (structural updates the plan could not absorb) before the attached HipTimestepper calls bepuhip_replan (default 30)."""
+        if self.lib.bepuhost_timestepper_replan_interval(self.h, int(frames)) != 0:
+            raise RuntimeError(_err(self.lib))
 
     def read_back_contact_depths(self, on: bool = True):
         if self.lib.bepuhost_timestepper_read_back_contact_depths(self.h, int(on)) != 0:

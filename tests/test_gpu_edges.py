@@ -319,7 +319,7 @@ def test_up_to_sixty_four_substeps_stay_on_the_island_schedule(hip_solver_factor
     """SolveDescription.SubstepCount is unbounded in the reference (SolveDescription.cs:16-136). One launch of the island kernel ran at most sixteen substeps until
     round 4 and anything above dropped to the launch-per-batch schedule (five times slower); the per-substep iteration counts travel in the kernel arguments, now
     for up to 64 substeps. 24 substeps with an uneven iteration schedule on a whole-island plan and on a forced split plan, asserted to have run the island kernel,
-    against the oracle; 65 substeps still work (launch-per-batch)."""
+    against the oracle; more than 64 substeps: a chain of island launches (round 5)."""
     import os
     scene = small_scenes.island_scene(13, islands=40, bodies_per_island=8, constraints_per_island=20, type_ids=[4, 7, 22, 23, 25, 47, 0])
     schedule = [1 + (s % 3) for s in range(24)]
@@ -342,9 +342,20 @@ def test_up_to_sixty_four_substeps_stay_on_the_island_schedule(hip_solver_factor
         os.environ.pop("BEPUHIP_SPLIT_CLUSTERS", None)
     m = pu.compare_scenes(ref, got)
     assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
-    sd65 = SolveDescription(1, 65)
-    ref = pu.run_oracle(scene, 1 / 60, sd65, cb, frames=1, threads=4)
-    solver = hip_solver_factory()
-    got = pu.run_hip(solver, scene, 1 / 60, sd65, cb, frames=1)  # (launch-per-batch on the plan's permuted rows: the plan stays for solves it can run)
-    m = pu.compare_scenes(ref, got)
-    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    # Round 5: past 64 substeps a step is a CHAIN of island launches (64 + 1 here, 64 + 64 + 2 below) — the bodies go through HBM between the links, "first substep" rules
+    # and the trailing pose integration follow the step, not the launch. Whole-island plan and forced split plan, conserving mode included.
+    for count, mode, split in ((65, 0, False), (130, 1, False), (67, 0, True)):
+        sdn = SolveDescription(1, count, velocity_iteration_scheduler=lambda s: 1 + (s % 2))
+        cbn = PoseIntegratorCallbacks(integrate_velocity_for_kinematics=True, angular_integration_mode=mode)
+        subject = big if split else scene
+        ref = pu.run_oracle(subject, 1 / 60, sdn, cbn, frames=1, threads=4)
+        if split:
+            os.environ["BEPUHIP_SPLIT_CLUSTERS"] = "12"
+        try:
+            solver = hip_solver_factory()
+            got = pu.run_hip(solver, subject, 1 / 60, sdn, cbn, frames=1)
+            assert solver.schedule() == (2 if split else 1) and solver.cluster_cycles().size > 0, (count, mode, split)
+        finally:
+            os.environ.pop("BEPUHIP_SPLIT_CLUSTERS", None)
+        m = pu.compare_scenes(ref, got)
+        assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (count, mode, split, m)

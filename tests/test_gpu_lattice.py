@@ -176,7 +176,7 @@ def test_block_jacobi_shares_equal_the_cpu_lattice(monkeypatch):
     for use_clusters, split in ((False, False), (True, False), (True, True)):
         if split:
             monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "6")
-            monkeypatch.setenv("BEPUHIP_CLUSTER_BODIES", "200")  # no workgroup holds a share's island: split-island plans
+            monkeypatch.setenv("BEPUHIP_FORCE_SPLIT", "64")  # a share's island is cut although a workgroup could hold it: split-island plans
         shares = [lattice.make_share(scene, owner, r, 2) for r in range(2)]
         kinds = []
 

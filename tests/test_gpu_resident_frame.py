@@ -56,6 +56,7 @@ def test_resident_frame_follows_descriptions_sleeping_islands_and_reused_handles
     from bepuphysics2_amd.hostlib import HostSimulation
     if layout == "split":
         monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "12")
+        monkeypatch.setenv("BEPUHIP_FORCE_SPLIT", "64")  # the crowd's one island is cut although a workgroup could hold it
     if layout == "islands":
         monkeypatch.setenv("BEPUHIP_CLUSTER_BODIES", "256")  # three clusters of sixteen ragdolls
     if layout == "batches":
@@ -64,12 +65,14 @@ def test_resident_frame_follows_descriptions_sleeping_islands_and_reused_handles
     sd, cb = sim.solve_description(), PoseIntegratorCallbacks()
     sim.attach_hip_timestepper(0)
     sim.timestepper_mode(2)
+    sim.replan_interval(1)  # a frame whose changes the plan cannot absorb (a NEW type batch in a batch: frame 7) costs one frame on launch-per-batch rows, then a re-plan
     sim.read_back_contact_depths(True)  # the test has no narrow phase that would rewrite them: the host keeps the device's depths, as the oracle's input expects
     rng = np.random.default_rng(11)
     body_of_ragdoll = lambda r: set(range(16 * r, 16 * r + 16))  # body handles == creation order: 16 per ragdoll
     asleep = []          # (type id, body handles, prestep lane, impulse lane) of the sleeping island's constraints
     sleepers = {3, 4, 5}
     expected_schedule = {"islands": 1, "split": 2, "batches": 0}[layout]
+    schedules = []
     for frame in range(14):
         export = sim.export()
         what = []
@@ -121,8 +124,9 @@ def test_resident_frame_follows_descriptions_sleeping_islands_and_reused_handles
         sim.validate()
         check_frame(sim, sd, cb, frame, what)
         ops, refreshed, schedule = sim.resident_stats()
-        if layout != "batches" or frame < 4:
-            assert schedule == expected_schedule, (frame, what, schedule)
+        schedules.append(schedule)
+        if frame != 7:  # (the angular motor of frame 7 opens a type batch its batch did not have: no plan absorbs that; bepuhip_replan puts the context back a frame later)
+            assert schedule == expected_schedule, (frame, what, schedules)
     uploads, _ = sim.timestepper_stats()
     ops, refreshed, schedule = sim.resident_stats()
     assert uploads == 1, "the scene stayed resident: one upload, everything else through the diff and the ranged transfers"
@@ -143,12 +147,24 @@ def test_transfer_rows_matches_the_single_calls_and_registered_memory(hip_solver
         solver = hip_solver_factory(device=0)
         work = scene.copy()
         if registered:
-            for b in work.batches:
-                for tb in b:
-                    if tb.count:
-                        solver.register_host_memory(tb.prestep)
-                        solver.register_host_memory(tb.accumulated)
-            solver.register_host_memory(work.bodies)
+            # As the reference holds them: every type batch's buffers are sub-allocations of ONE large block (BufferPool.cs:42,83), and the block is what gets registered —
+            # hundreds of separately registered heap arrays would share pages with their unregistered neighbours, which no DMA engine forgives.
+            tbs = [tb for b in work.batches for tb in b if tb.count]
+            floats = sum((a.size + 31) // 32 * 32 for tb in tbs for a in (tb.prestep, tb.accumulated)) + work.bodies.size + 4096
+            raw = np.zeros(floats + 1024, dtype=np.float32)
+            skip = (-raw.ctypes.data % 4096) // 4
+            block = raw[skip:skip + floats]
+            at = 0
+            def carve(a):
+                nonlocal at
+                view = block[at:at + a.size].reshape(a.shape)
+                view[...] = a
+                at += (a.size + 31) // 32 * 32  # 128-byte aligned, like the pool's buffers
+                return view
+            for tb in tbs:
+                tb.prestep, tb.accumulated = carve(tb.prestep), carve(tb.accumulated)
+            work.bodies = carve(work.bodies)
+            solver.register_host_memory(block)
         solver.upload(work)
         rng = np.random.default_rng(3)
         items = []

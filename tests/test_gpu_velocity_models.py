@@ -82,17 +82,28 @@ def test_predict_bounding_boxes_evaluates_the_model(hip_solver_factory, model):
     assert np.array_equal(ref.view(np.uint8), got.view(np.uint8))
 
 
-def test_substep_events_are_raised_around_every_substep_and_may_rewrite_state(hip_solver_factory):
+@pytest.mark.parametrize("schedule", ["islands", "split", "batches"])
+def test_substep_events_are_raised_around_every_substep_and_may_rewrite_state(hip_solver_factory, monkeypatch, schedule):
     """Solver.SubstepStarted / SubstepEnded (Solver.cs:125-146, raised at Solver_Solve.cs:1425 / :1478) through bepuhip_solve_with_substep_events: handlers that change
     nothing leave bepuhip_solve's bits; a SubstepStarted handler that moves a kinematic body's velocity every substep (what the reference's users do there) gives
     what the oracle gives when the same writes are made between single-substep solves... which the reference cannot express — so the second half is checked
     against the device's own plain solve of a scene whose kinematic body carries the velocity the handler writes first."""
-    scene = small_scenes.island_scene(8, islands=30, bodies_per_island=8, constraints_per_island=18, type_ids=[4, 7, 22, 25, 47, 0])
+    # Round 5: a context on an island plan raises the events between launches of the island kernel, one substep per launch (whole-island and split plans);
+    # BEPUHIP_EVENT_CLUSTERS=0 keeps round 4's launch-per-batch form covered.
+    if schedule == "batches":
+        monkeypatch.setenv("BEPUHIP_EVENT_CLUSTERS", "0")
+    if schedule == "split":
+        monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "8")
+        monkeypatch.setenv("BEPUHIP_FORCE_SPLIT", "64")
+        scene = small_scenes.random_graph_scene(17, 1200, 3000, [4, 5, 7, 22, 25, 47, 0], kinematic_fraction=0.05)
+    else:
+        scene = small_scenes.island_scene(8, islands=30, bodies_per_island=8, constraints_per_island=18, type_ids=[4, 7, 22, 25, 47, 0])
     sd = SolveDescription(1, 4, velocity_iteration_scheduler=lambda s: [2, 1, 1, 2][s])
-    cb = PoseIntegratorCallbacks()
+    cb = PoseIntegratorCallbacks(integrate_velocity_for_kinematics=schedule == "split")
     ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=4)
     solver = hip_solver_factory()
     solver.upload(scene, sd.fallback_batch_threshold)
+    assert solver.schedule() == {"islands": 1, "split": 2, "batches": 1}[schedule]
     seen = []
     for _ in range(2):
         solver.solve_with_substep_events(1 / 60, sd, cb, started=lambda s: seen.append(("started", s)), ended=lambda s: seen.append(("ended", s)))
