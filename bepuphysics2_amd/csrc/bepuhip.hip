@@ -1644,6 +1644,7 @@ int32_t bepuhip_sync(bepuhip_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) c->last_ms = ms;
+    else (void)hipGetLastError();  // no solve has been enqueued yet (the events were never recorded): not an error of THIS call — and it must not stay behind as the thread's last error, where the next launch check would find it (round 5: a sync between an upload's row transfers and the first solve made the following transfer fail with "invalid resource handle")
     c->desc_ring_used = 0;  // every transfer_rows descriptor table has been consumed
     if (c->clusters_enabled) {
         unsigned st[8];
