@@ -252,6 +252,11 @@ __device__ __forceinline__ void store_agent_f4(float4* p, float4 v) {
     agent_f4 x = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
+// ... and the same record into the other devices' copies of the table (SharedTables.peer): system scope, the data leaves over the fabric.
+__device__ __forceinline__ void store_system_f4(float4* p, float4 v) {
+    agent_f4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned load_seq(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_agent_pair(float4* p, float4 a, float4 b) {
@@ -307,6 +312,17 @@ __device__ __forceinline__ SharedRef make_shared_ref(const ClusterShared& sh, un
 // home cluster and of every cluster holding a ghost copy) reads record (s - 1) & 1, which nobody rewrites before substep s + 1's integration — and that
 // waits for every application of substep s, each of which comes after its own cluster's reads. So readers never have to check in anywhere.
 __device__ __forceinline__ float4* shared_record(const SharedTables& st, int body, unsigned substep) { return st.vel + ((size_t)body * 2 + (substep & 1u)) * 2; }
+// A record half (16 bytes at `at`, a pointer into the device's own table) into every copy of the table: the own one with an agent-scope store, the peers' at the same offset.
+__device__ __forceinline__ void publish_record_f4(const SharedTables& st, float4* at, float4 v) {
+    store_agent_f4(at, v);
+    const int peers = __builtin_amdgcn_readfirstlane(st.peers);
+    for (int q = 0; q < peers; ++q) store_system_f4(st.peer[q] + (at - st.vel), v);
+}
+__device__ __forceinline__ void publish_record_pair(const SharedTables& st, float4* at, float4 a, float4 b) {
+    store_agent_pair(at, a, b);
+    const int peers = __builtin_amdgcn_readfirstlane(st.peers);
+    for (int q = 0; q < peers; ++q) { store_system_f4(st.peer[q] + (at - st.vel), a); store_system_f4(st.peer[q] + (at - st.vel) + 1, b); }
+}
 // Per-lane: poll the records of up to two shared bodies until each shows event number >= want (both halves equal), leaving their velocities in A / B.
 // Lanes without a shared body pass at once. Bounded like every other wait of this kernel.
 // Where the two accesses of a lane go when the pair serves `body` (this lane's) and the neighbour's: first the record of the pair's even lane, then the odd lane's;
@@ -367,8 +383,8 @@ __device__ __forceinline__ void release_shared(const ClusterShared& sh, const Sh
     const int first_body = odd ? theirs : mine, second_body = odd ? mine : theirs;  // the record of the pair's even lane, then the odd lane's
     const float4 first = odd ? make_float4(gx, gy, gz, their_n) : make_float4(b.vel.lin.x, b.vel.lin.y, b.vel.lin.z, n);
     const float4 second = odd ? make_float4(b.vel.ang.x, b.vel.ang.y, b.vel.ang.z, n) : make_float4(gx, gy, gz, their_n);
-    if (first_body >= 0) store_agent_f4(shared_record(sh.st, first_body, sh.events - 1u) + (odd ? 1 : 0), first);
-    if (second_body >= 0) store_agent_f4(shared_record(sh.st, second_body, sh.events - 1u) + (odd ? 1 : 0), second);
+    if (first_body >= 0) publish_record_f4(sh.st, shared_record(sh.st, first_body, sh.events - 1u) + (odd ? 1 : 0), first);
+    if (second_body >= 0) publish_record_f4(sh.st, shared_record(sh.st, second_body, sh.events - 1u) + (odd ? 1 : 0), second);
 }
 // One lane, one record (integration phases): wait for event number >= want, return the velocity.
 __device__ __forceinline__ void acquire_shared_one(const SharedTables& st, unsigned* status, int body, unsigned substep, unsigned want, float4& l, float4& w, int kind, int slot) {
@@ -882,7 +898,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 if (g < 0 || !(g & kSlotSharedHome)) continue;
                 const float4 l4 = lds[2 * ncap + j], a4 = lds[3 * ncap + j];
                 const float number = __uint_as_float(shared_tables.base + 1u);
-                store_agent_pair(shared_record(shared_tables, g & kSlotBodyMask, 0u), make_float4(l4.x, l4.y, l4.z, number), make_float4(a4.x, a4.y, a4.z, number));
+                publish_record_pair(shared_tables, shared_record(shared_tables, g & kSlotBodyMask, 0u), make_float4(l4.x, l4.y, l4.z, number), make_float4(a4.x, a4.y, a4.z, number));
             }
             sh.events = 1u;
         }
@@ -972,7 +988,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 }
                 if (home) {  // this substep's record: the integrated velocity, and "integration done" as the event number
                     const float number = __uint_as_float(shared_tables.base + (unsigned)s + 1u + applications * sh.passes);
-                    store_agent_pair(shared_record(shared_tables, body, (unsigned)s), make_float4(vel.lin.x, vel.lin.y, vel.lin.z, number), make_float4(vel.ang.x, vel.ang.y, vel.ang.z, number));
+                    publish_record_pair(shared_tables, shared_record(shared_tables, body, (unsigned)s), make_float4(vel.lin.x, vel.lin.y, vel.lin.z, number), make_float4(vel.ang.x, vel.ang.y, vel.ang.z, number));
                 }
             } else if (cp.integrate_velocity_for_kinematics) {  // kinematic: private copy, same arithmetic as the global kinematic pass
                 velocity_callback(cp.sp, vel, pos, body);

@@ -68,7 +68,11 @@ constexpr int kSlotBodyMask = (1 << 28) - 1;
 // waits for "its" n and leaves n + 1 with the velocity it wrote. `info[body]` = d.
 // Event numbers of one step start at `base`: the host advances it by more than any body's events per step (substeps + 255 x passes + 2, kept even so that the
 // record parity of a substep does not depend on it), so whatever the previous step left in the records reads as "not yet" and nothing has to be cleared between steps.
-struct SharedTables { float4* vel; const unsigned* info; int poll_sleep; unsigned base; };  // poll_sleep: 64-clock naps between two polls of a record
+// One scene on several devices (round 5, bepuhip_set_device_group): every device plans the SAME clusters and runs a contiguous range of them; each keeps its own copy
+// of the record table, which its clusters poll, and every record is written to ALL copies — `peers` more tables in the other devices' memory (`peer[]`), with
+// system-scope stores: a hand-off that crosses devices is the same one-way push it is between two clusters of one device. peers == 0: one device, nothing changes.
+constexpr int kMaxPeers = 7;
+struct SharedTables { float4* vel; const unsigned* info; int poll_sleep; unsigned base; int peers; float4* const* peer; };  // poll_sleep: 64-clock naps between two polls of a record; peer: device array of `peers` table pointers
 constexpr unsigned kLrefDead = 0x80008000u;  // whole-island plans: the packed local references of a free device slot (reserved at planning, or left by a removal): both halves
                                              // name the kinematic copy in slot 0 — the lane computes on whatever that holds and, like every kinematic reference, writes no body back;
                                              // what it writes into its own rows is overwritten when the slot is taken again (no extra test in the kernel)

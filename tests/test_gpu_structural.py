@@ -380,9 +380,9 @@ def test_cpp_simulation_adds_and_removes_between_timesteps(hip_solver_factory, m
 
 
 def test_reserved_layout_falls_back_cleanly_when_the_island_schedule_does_not_apply(hip_solver_factory, monkeypatch):
-    """A context planned with spare device slots is asked for more substeps than the island schedule runs, and — with BEPUHIP_CONSERVING_CLUSTERS=0, round 2's
-    behaviour — for a momentum-conserving angular mode: the launch-per-batch kernels address rows [0, count), so the rows first go back into the caller's order — results
-    as always. (By default the island schedule runs the conserving modes itself: third case.)"""
+    """A context planned with spare device slots is asked — with BEPUHIP_CONSERVING_CLUSTERS=0, round 2's behaviour — for a momentum-conserving angular mode: the
+    launch-per-batch kernels address rows [0, count), so the rows first go back into the caller's order — results as always. (By default the island schedule runs the
+    conserving modes itself: third case; and more substeps than one launch carries are a chain of island launches since round 5: first case, no fall-back any more.)"""
     scene = small_scenes.island_scene(5, 30, 12, 28, [22, 4, 30, 47, 7, 5])
     for sd, cb, conserving_clusters in ((SolveDescription(1, 65), PoseIntegratorCallbacks(), "1"), (SolveDescription(2, 3), PoseIntegratorCallbacks(angular_integration_mode=1), "0"),
                                         (SolveDescription(2, 3), PoseIntegratorCallbacks(angular_integration_mode=1), "1")):
@@ -390,7 +390,7 @@ def test_reserved_layout_falls_back_cleanly_when_the_island_schedule_does_not_ap
         ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2)
         solver = hip_solver_factory(reserve_update_slots=True)
         got = pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2)
-        assert (solver.cluster_cycles().size == 0) == (sd.substep_count == 65 or conserving_clusters == "0")
+        assert (solver.cluster_cycles().size == 0) == (conserving_clusters == "0")
         m = pu.compare_scenes(ref, got)
         assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
 
