@@ -247,7 +247,7 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         int cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        const int per_round = std::max(1, cus * 31 / 32);
+        const int per_round = std::max(1, cus * 31 / 32) * std::max(1, c->group_world);  // (a device group: every device gets a full round of clusters)
         int64_t target = (total_dyn + per_round - 1) / per_round;
         // More bodies than one round of workgroups holds (1,600 per workgroup): whole rounds of equal clusters. A cap of 1,600 left 345 clusters for 2 M constraints —
         // one full round and a second one that kept 95 of the 256 CUs busy: 0.44 ms/step where two full rounds take 0.35 (profiles/r04_s4_bench_fastbox.json, scale_sweep).
@@ -566,7 +566,10 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     for (int i = 0; i < universe; ++i) total_dyn += is_dyn[i];
     if (total_dyn == 0) return;
     for (int i = 0; i < universe; ++i) if (deg[i] > 255) return;  // rank | degree travel as bytes
-    const int target_clusters = std::max(1, std::min(cus * 31 / 32, env_int("BEPUHIP_SPLIT_CLUSTERS", cus * 31 / 32)));
+    // (a device group, bepuhip_set_device_group: the clusters of ALL devices are planned here, identically on every device; each runs a contiguous range of them and
+    // only that range has to be resident on it)
+    const int group = std::max(1, c->group_world);
+    const int target_clusters = std::max(1, std::min(cus * 31 / 32 * group, env_int("BEPUHIP_SPLIT_CLUSTERS", cus * 31 / 32 * group)));
     int region = (int)((total_dyn + target_clusters - 1) / target_clusters);
     region = std::max(region, 32);
     // ---- regions: grown breadth-first around a seed until they hold `region` bodies (compact balls of the constraint graph: the fewer bodies on a
@@ -605,7 +608,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             }
         }
     }
-    if (nclusters > cus) return;
+    if ((nclusters + group - 1) / group > cus) return;
     split_lap("adjacency, regions");
     // Smooth the regions' surfaces (BEPUHIP_SPLIT_REFINE = sweeps, default 2; 0 = off). A body moves to the neighbouring region that holds more of its constraint
     // partners than its own does (ties stay), as long as no region leaves [7/8, 9/8] of the target size: fewer crossing constraints for the same regions.

@@ -229,6 +229,17 @@ struct bepuhip_ctx {
     int policy_samples = 0;           // solves launched while measuring
     int policy_threads = 0;           // workgroup size the samples ran with
     hipEvent_t policy_events[16][2] = {};
+    // One scene on several devices (bepuhip_set_device_group): this context plans `group_world` x the clusters one device holds and runs the contiguous range
+    // [cluster_first, cluster_first + cluster_local) of them; its record table is one of `group_world` copies, the addresses of the other copies are in d_peer_table.
+    int group_world = 1, group_rank = 0;
+    int cluster_first = 0, cluster_local = 0;
+    std::vector<int32_t> group_body_cluster;  // body -> cluster of the plan (group_world > 1: which device owns a body at the end of a step)
+    std::vector<void*> peer_records;          // the record tables of the other devices, by peer ordinal (rank order, this rank left out)
+    std::vector<void*> peer_opened;           // ... those opened from an IPC handle by this context (closed with it)
+    float4** d_peer_table = nullptr;
+    uint32_t* d_owned_dense = nullptr;        // bepuhip_sync_owned_bodies: 16 words per body
+    uint8_t* d_owned_mask = nullptr;
+    int owned_mask_bodies = 0;
     bool clusters_shared = false;    // split-island plan: bodies shared between clusters go through the tables below
     float4* d_shared_vel = nullptr;   // per body two records (substep parity) of {linear, event number} {angular, event number}
     unsigned* d_shared_info = nullptr;

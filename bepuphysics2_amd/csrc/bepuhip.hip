@@ -133,6 +133,10 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_mesh_scales) hipFree(c->d_mesh_scales);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->h_desc_ring) hipHostFree(c->h_desc_ring);
+    for (void* opened : c->peer_opened) hipIpcCloseMemHandle(opened);
+    if (c->d_peer_table) hipFree(c->d_peer_table);
+    if (c->d_owned_dense) hipFree(c->d_owned_dense);
+    if (c->d_owned_mask) hipFree(c->d_owned_mask);
     for (auto& chunk : c->raw_chunks) if (chunk.ptr) hipFree(chunk.ptr);
     if (c->h_staging) hipHostFree(c->h_staging);
     for (void* p : c->registered_host) hipHostUnregister(p);
@@ -593,6 +597,11 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             for (int tr = 0; tr < 2; ++tr)
                 for (int wide = 0; wide < 2; ++wide)
                     HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(threads, tr != 0, wide != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        c->group_body_cluster.clear();
+        if (c->group_world > 1) c->group_body_cluster = plan.body_cluster;  // (before soft_setup takes the vector: which device owns a body at the end of a step)
+        c->owned_mask_bodies = 0;  // (the device copy of the ownership mask follows the plan)
+        c->cluster_first = (int)((int64_t)plan.clusters.size() * c->group_rank / c->group_world);
+        c->cluster_local = (int)((int64_t)plan.clusters.size() * (c->group_rank + 1) / c->group_world) - c->cluster_first;
         soft_setup(c, plan);
         for (int tr = 0; tr < 2; ++tr)
             for (int wide = 0; wide < 2; ++wide) {
@@ -972,9 +981,14 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
         const size_t launch_lds = lds_bytes;
         // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
         // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).
+        // (a device group: this context's contiguous range of the plan's clusters; cluster descriptors name items, slots and rows by their absolute positions, so the
+        // range is just an offset into the descriptor and cycle arrays)
+        const int local_clusters = c->group_world > 1 ? c->cluster_local : c->cluster_count;
+        const ClusterDesc* d_my_clusters = c->d_clusters + (c->group_world > 1 ? c->cluster_first : 0);
+        unsigned long long* d_my_cycles = c->d_cycles + (c->group_world > 1 ? c->cluster_first : 0);
         TailParams tp;
         tp.flags = c->d_flags; tp.kinlist = c->d_kinlist; tp.staged = c->d_staged;
-        tp.body_count = c->body_count; tp.kin_count = c->kinlist_count; tp.cluster_count = c->cluster_count;
+        tp.body_count = c->body_count; tp.kin_count = c->kinlist_count; tp.cluster_count = local_clusters;
         tp.body_blocks = cp.final_launch ? (c->body_count + threads - 1) / threads : 0;  // IntegrateAfterSubstepping of the bodies no cluster owns: the step's last launch
         tp.block_offset = 0;
         tp.dt = dt; tp.substep_dt = substep_dt; tp.substep_count = substeps;
@@ -982,7 +996,7 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
         tp.allow_substeps_for_unconstrained = in->allow_substeps_for_unconstrained; tp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
         const float vdt = in->allow_substeps_for_unconstrained ? substep_dt : dt;
         tp.final_sp = make_params(c, in, vdt, vdt, 1.0f / vdt);
-        SharedTables st = {c->d_shared_vel, c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1), 0u};
+        SharedTables st = {c->d_shared_vel, c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1), 0u, (int)c->peer_records.size(), c->d_peer_table};
         if (c->clusters_shared) {
             // Event numbers of this launch: [base, base + span). A body sees at most substeps + 255 x passes events per launch; the span is kept even (record parity).
             unsigned passes = 0;
@@ -995,8 +1009,8 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
             st.base = c->shared_epoch;
             c->shared_epoch += (unsigned)span;
         }
-        void* args[] = {(void*)&c->d_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
-                        (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&c->d_cycles, (void*)&tp, (void*)&st};
+        void* args[] = {(void*)&d_my_clusters, (void*)&c->d_items, (void*)&c->d_batch_item_begin, (void*)&c->d_cluster_bodies, (void*)&c->d_bodies, (void*)&c->d_slab,
+                        (void*)&cp, (void*)&c->cluster_max_slots, (void*)&c->cluster_max_items, (void*)&c->d_trace, (void*)&c->d_status, (void*)&d_my_cycles, (void*)&tp, (void*)&st};
         const bool tr = c->d_trace != nullptr;
         const bool policy_applies = cluster_variant_threads(threads) == (c->clusters_shared ? 512 : 1024) && !conserving;  // the variants that exist in both row policies (a conserving solve neither measures nor follows the policy beyond the code touch)
         int sample = -1, candidate = 0;
@@ -1020,17 +1034,17 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
             // The clusters of a split plan wait for each other: they must all be resident at once. A cooperative launch of exactly the clusters makes the runtime
             // guarantee that (or refuse), whatever else runs on the device; the per-body tail follows as an ordinary launch of the same kernel.
             std::lock_guard<std::mutex> one_at_a_time(g_cooperative_launch);
-            if (hipLaunchCooperativeKernel(fn, dim3(c->cluster_count), dim3(threads), args, (unsigned)launch_lds, c->stream) == hipSuccess) {
+            if (hipLaunchCooperativeKernel(fn, dim3(local_clusters), dim3(threads), args, (unsigned)launch_lds, c->stream) == hipSuccess) {
                 launched = true;
                 if (tail_blocks > 0) {
-                    tp.block_offset = c->cluster_count;
+                    tp.block_offset = local_clusters;
                     hipLaunchKernel(fn, dim3(tail_blocks), dim3(threads), args, 0, c->stream);
                 }
             } else {
                 (void)hipGetLastError();  // e.g. hipErrorCooperativeLaunchTooLarge: fall back to the plain launch below
             }
         }
-        if (!launched) hipLaunchKernel(fn, dim3(c->cluster_count + tail_blocks), dim3(threads), args, launch_lds, c->stream);
+        if (!launched) hipLaunchKernel(fn, dim3(local_clusters + tail_blocks), dim3(threads), args, launch_lds, c->stream);
         if (sample >= 0) hipEventRecord(c->policy_events[sample][1], c->stream);
     }
 }
@@ -1528,7 +1542,7 @@ static void enqueue_cluster_pass(bepuhip_ctx* c, int stage, int substep, const S
     TailParams tp;
     memset(&tp, 0, sizeof(tp));
     tp.flags = c->d_flags; tp.staged = c->d_staged; tp.cluster_count = c->cluster_count; tp.body_count = c->body_count;
-    SharedTables st = {c->d_shared_vel, c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1), 0u};
+    SharedTables st = {c->d_shared_vel, c->d_shared_info, env_int("BEPUHIP_SHARED_POLL", 1), 0u, 0, nullptr};
     if (c->clusters_shared) {  // a pass is a one-substep, one-pass step of its own as far as the event numbers go
         const unsigned span = 260u;
         if ((unsigned long long)c->shared_epoch + 2ull * span > 0xFFFFFFFFull) { hipMemsetAsync(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4), c->stream); c->shared_epoch = 0; }
@@ -1636,6 +1650,125 @@ int32_t bepuhip_solve_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, cons
 
 int32_t bepuhip_solve_lattice(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in) {
     return run_exchanged(c, dt, substeps, iterations, in, nullptr, nullptr);
+}
+
+// ---- One scene on several devices, exact (include/bepuhip.h: device groups) ----
+static HostTypeBatch* find_tb(bepuhip_ctx* c, int batch, int type_id);
+int32_t bepuhip_set_device_group(bepuhip_ctx* c, int32_t world, int32_t rank) {
+    if (!c || world < 1 || world > kMaxPeers + 1 || rank < 0 || rank >= world) return fail(BEPUHIP_E_INVALID_ARGUMENT, "a device group has 1 to 8 members and ranks 0 .. world - 1");
+    if (c->building) return fail(BEPUHIP_E_STATE, "set_device_group between begin_constraints and end_constraints");
+    if (c->built && (world != c->group_world || rank != c->group_rank)) return fail(BEPUHIP_E_STATE, "the constraints were planned for another device group: call set_device_group before begin_constraints");
+    c->group_world = world; c->group_rank = rank;
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_get_shared_records(bepuhip_ctx* c, void** records_out, int64_t* bytes_out) {
+    if (!c || !records_out || !bytes_out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    *records_out = c->clusters_shared ? (void*)c->d_shared_vel : nullptr;  // (a plan without shared bodies — whole islands only — has no records to exchange)
+    *bytes_out = c->clusters_shared ? (int64_t)(c->shared_bodies * 4 * sizeof(float4)) : 0;
+    return BEPUHIP_OK;
+}
+static int32_t upload_peer_table(bepuhip_ctx* c) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->d_peer_table) HIP_TRY(hipMalloc((void**)&c->d_peer_table, kMaxPeers * sizeof(void*)));
+    if (!c->peer_records.empty()) HIP_TRY(hipMemcpy(c->d_peer_table, c->peer_records.data(), c->peer_records.size() * sizeof(void*), hipMemcpyHostToDevice));
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_set_peer_records(bepuhip_ctx* c, int32_t peer, void* records) {
+    if (!c || peer < 0 || peer >= c->group_world - 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "a group of N devices has N - 1 peers (ordinals 0 .. N - 2)");
+    if ((int)c->peer_records.size() <= peer) c->peer_records.resize(peer + 1, nullptr);
+    c->peer_records[peer] = records;
+    for (void* p : c->peer_records) if (!p) return BEPUHIP_OK;  // incomplete: the table is uploaded with the last entry
+    if ((int)c->peer_records.size() != c->group_world - 1) return BEPUHIP_OK;
+    return upload_peer_table(c);
+}
+int32_t bepuhip_export_shared_records(bepuhip_ctx* c, void* ipc_handle_out) {
+    if (!c || !ipc_handle_out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == BEPUHIP_IPC_HANDLE_BYTES, "IPC handle size");
+    if (!c->clusters_shared) { memset(ipc_handle_out, 0, BEPUHIP_IPC_HANDLE_BYTES); return BEPUHIP_OK; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipIpcMemHandle_t handle;
+    HIP_TRY(hipIpcGetMemHandle(&handle, c->d_shared_vel));
+    memcpy(ipc_handle_out, &handle, sizeof(handle));
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_import_peer_records(bepuhip_ctx* c, int32_t peer, const void* ipc_handle) {
+    if (!c || !ipc_handle) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipIpcMemHandle_t handle;
+    memcpy(&handle, ipc_handle, sizeof(handle));
+    void* opened = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&opened, handle, hipIpcMemLazyEnablePeerAccess));
+    c->peer_opened.push_back(opened);
+    return bepuhip_set_peer_records(c, peer, opened);
+}
+// 1 for the bodies whose state this context leaves final at the end of a solve: the bodies of its own clusters, and — on rank 0 — the bodies of no cluster
+// (unconstrained and kinematic ones: every device integrates them identically, one speaks for all).
+static void owned_body_mask(const bepuhip_ctx* c, std::vector<uint8_t>& mask, int count) {
+    mask.assign((size_t)count, 0);
+    for (int i = 0; i < count; ++i) {
+        const int cl = (size_t)i < c->group_body_cluster.size() ? c->group_body_cluster[i] : -1;
+        mask[i] = cl < 0 ? (c->group_rank == 0) : (cl >= c->cluster_first && cl < c->cluster_first + c->cluster_local);
+    }
+}
+int32_t bepuhip_get_owned_bodies(bepuhip_ctx* c, uint8_t* mask_out, int32_t count) {
+    if (!c || (!mask_out && count > 0) || count < 0 || count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad get_owned_bodies argument");
+    if (c->group_world <= 1 || !c->clusters_enabled) { if (count > 0) memset(mask_out, 1, (size_t)count); return BEPUHIP_OK; }
+    std::vector<uint8_t> mask;
+    owned_body_mask(c, mask, count);
+    if (count > 0) memcpy(mask_out, mask.data(), (size_t)count);
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_get_owned_constraints(bepuhip_ctx* c, int32_t batch, int32_t type_id, uint8_t* mask_out) {
+    if (!c || !mask_out || !c->built) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad argument or no constraints");
+    HostTypeBatch* tb = find_tb(c, batch, type_id);
+    if (!tb) return fail(BEPUHIP_E_INVALID_ARGUMENT, "no such type batch");
+    if (c->group_world <= 1 || !c->clusters_enabled || tb->seg_begin.empty()) { if (tb->count > 0) memset(mask_out, 1, (size_t)tb->count); return BEPUHIP_OK; }
+    for (int i = 0; i < tb->count; ++i) {  // the constraint's device slot lies in the segment of the cluster that runs it
+        const int d = tb->perm_inverse(i);
+        const int cl = (int)(std::upper_bound(tb->seg_begin.begin(), tb->seg_begin.end(), d) - tb->seg_begin.begin()) - 1;
+        mask_out[i] = cl >= c->cluster_first && cl < c->cluster_first + c->cluster_local;
+    }
+    return BEPUHIP_OK;
+}
+// The end-of-step exchange of a device group on the solver's stream: every device contributes the MotionState halves of the bodies it owns (zeros elsewhere), one
+// unsigned-integer all-reduce returns every owner's bit patterns exactly, and every device writes what it does not own. One collective per step.
+__global__ __launch_bounds__(256) void owned_pack_kernel(const float4* __restrict__ bodies, const uint8_t* __restrict__ owned, uint4* __restrict__ dense, int count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)count * 4) return;
+    const float4 v = bodies[(i >> 2) * 8 + (i & 3)];
+    dense[i] = owned[i >> 2] ? make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)) : make_uint4(0u, 0u, 0u, 0u);
+}
+__global__ __launch_bounds__(256) void owned_unpack_kernel(float4* __restrict__ bodies, const uint8_t* __restrict__ owned, const uint4* __restrict__ dense, int count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)count * 4 || owned[i >> 2]) return;
+    const uint4 v = dense[i];
+    bodies[(i >> 2) * 8 + (i & 3)] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+int32_t bepuhip_sync_owned_bodies(bepuhip_ctx* c) {
+    if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
+    if (c->group_world <= 1 || c->body_count == 0) return BEPUHIP_OK;
+    if (!c->comm) return fail(BEPUHIP_E_STATE, "a device group exchanges its bodies over the context's communicator (bepuhip_comm_init / comm_adopt)");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->owned_mask_bodies != c->body_count) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_owned_mask) hipFree(c->d_owned_mask);
+        if (c->d_owned_dense) hipFree(c->d_owned_dense);
+        c->d_owned_mask = nullptr; c->d_owned_dense = nullptr; c->owned_mask_bodies = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_owned_mask, (size_t)c->body_count));
+        HIP_TRY(hipMalloc((void**)&c->d_owned_dense, (size_t)c->body_count * 64));
+        std::vector<uint8_t> mask;
+        owned_body_mask(c, mask, c->body_count);
+        HIP_TRY(hipMemcpy(c->d_owned_mask, mask.data(), mask.size(), hipMemcpyHostToDevice));
+        c->owned_mask_bodies = c->body_count;
+    }
+    const unsigned blocks = (unsigned)(((size_t)c->body_count * 4 + 255) / 256);
+    owned_pack_kernel<<<blocks, 256, 0, c->stream>>>((const float4*)c->d_bodies, c->d_owned_mask, (uint4*)c->d_owned_dense, c->body_count);
+    const ncclResult_t r = rccl()->AllReduce(c->d_owned_dense, c->d_owned_dense, (size_t)c->body_count * 16, ncclUint32, ncclSum, (ncclComm_t)c->comm, c->stream);
+    if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+    owned_unpack_kernel<<<blocks, 256, 0, c->stream>>>(c->d_bodies, c->d_owned_mask, (const uint4*)c->d_owned_dense, c->body_count);
+    HIP_TRY(hipGetLastError());
+    return BEPUHIP_OK;
 }
 
 int32_t bepuhip_sync(bepuhip_ctx* c) {

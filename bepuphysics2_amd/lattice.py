@@ -358,3 +358,79 @@ def solve_shares_in_process(make_solver, shares: List[Share], dt, solve_descript
     if errors:
         raise errors[0]
     return ex
+
+
+# ---- device groups (round 5): the exact mode on the island schedule ----
+def solve_group_in_process(make_solver, scene: Scene, world: int, dt, solve_description, callbacks, frames: int = 1) -> Scene:
+    """One connected scene solved by a GROUP of ``world`` contexts in this process (one thread each; e.g. all on a single-GPU box): every member uploads the whole scene,
+    plans the same clusters (bepuhip_set_device_group) and runs its range of them; shared bodies cross from member to member through the event-numbered records every
+    member pushes into every other member's table — no exchange point inside a step. After every frame the members' owned bodies are merged on the host (on a multi-GPU
+    node: bepuhip_sync_owned_bodies, one all-reduce) and every member starts the next frame from the merged bodies. Returns the merged scene: bodies from their owners,
+    every constraint's impulses and prestep data from the member whose cluster runs it. Bit-identical to the unsplit solve."""
+    import threading
+    barrier = threading.Barrier(world)
+    records = [0] * world
+    merged_bodies = scene.bodies.copy()
+    results = [None] * world
+    errors = []
+
+    def run(rank):
+        solver = None
+        try:
+            solver = make_solver()
+            mine = scene.copy()
+            solver.set_device_group(world, rank)
+            solver.upload(mine, solve_description.fallback_batch_threshold)
+            records[rank] = solver.shared_records()[0]
+            barrier.wait()  # every member has planned and cleared its record table
+            peers = [records[r] for r in range(world) if r != rank]
+            if all(peers):
+                for k, pointer in enumerate(peers):
+                    solver.set_peer_records(k, pointer)
+            owned = solver.owned_bodies(mine.body_count)
+            barrier.wait()
+            for frame in range(frames):
+                if frame > 0:
+                    solver.set_bodies(merged_bodies)
+                    barrier.wait()  # (nobody overwrites the merged array before everybody has read it)
+                solver.solve(dt, solve_description, callbacks)
+                got = solver.get_bodies(mine.body_count)
+                barrier.wait()
+                merged_bodies[owned] = got[owned]
+                barrier.wait()
+            solver.download(mine)
+            masks = {(bi, tb.type_id): solver.owned_constraints(bi, tb.type_id, tb.count) for bi, b in enumerate(mine.batches) for tb in b if tb.count}
+            results[rank] = (mine, owned, masks, solver.schedule(), int(solver.cluster_cycles().size))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            barrier.abort()
+        finally:
+            if solver is not None:
+                solver.close()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    out = scene.copy()
+    covered = np.zeros(scene.body_count, dtype=int)
+    for mine, owned, masks, _, _ in results:
+        out.bodies[owned] = mine.bodies[owned]
+        covered += owned
+        for bi, b in enumerate(mine.batches):
+            for ti, tb in enumerate(b):
+                if not tb.count:
+                    continue
+                lanes = masks[(bi, tb.type_id)]
+                target = out.batches[bi][ti]
+                w = scene.bundle_width
+                for src, dst, fields in ((tb.accumulated, target.accumulated, tb.impulse_floats), (tb.prestep, target.prestep, tb.prestep_floats)):
+                    s3, d3 = src.reshape(-1, fields, w), dst.reshape(-1, fields, w)
+                    idx = np.nonzero(lanes)[0]
+                    d3[idx // w, :, idx % w] = s3[idx // w, :, idx % w]
+    assert (covered == 1).all(), "every body is owned by exactly one member of the group"
+    out.group_info = [(r[3], r[4]) for r in results]
+    return out

@@ -42,6 +42,8 @@ EXPORTED_SYMBOLS = [
     "bepuhip_set_velocity_model", "bepuhip_solve_with_substep_events", "bepuhip_add_constraint", "bepuhip_remove_constraint", "bepuhip_update_body_reference", "bepuhip_swap_constraints", "bepuhip_apply_structural_ops", "bepuhip_get_constraint_count", "bepuhip_get_schedule", "bepuhip_replan",
     "bepuhip_register_host_memory", "bepuhip_unregister_host_memory", "bepuhip_get_poses_and_velocities", "bepuhip_get_poses_and_velocities_async", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses_async",
     "bepuhip_transfer_rows_async",
+    "bepuhip_set_device_group", "bepuhip_get_shared_records", "bepuhip_set_peer_records", "bepuhip_export_shared_records", "bepuhip_import_peer_records",
+    "bepuhip_get_owned_bodies", "bepuhip_get_owned_constraints", "bepuhip_sync_owned_bodies",
 ]
 
 
@@ -145,6 +147,14 @@ def load_library() -> C.CDLL:
     for name in ("bepuhip_update_prestep", "bepuhip_update_prestep_async", "bepuhip_update_accumulated_impulses", "bepuhip_update_accumulated_impulses_async", "bepuhip_get_prestep_range", "bepuhip_get_accumulated_impulses_range"):
         getattr(lib, name).argtypes = [vp, i32, i32, i32, i32, vp]
     lib.bepuhip_transfer_rows_async.argtypes = [vp, vp, i32]
+    lib.bepuhip_set_device_group.argtypes = [vp, i32, i32]
+    lib.bepuhip_get_shared_records.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
+    lib.bepuhip_set_peer_records.argtypes = [vp, i32, vp]
+    lib.bepuhip_export_shared_records.argtypes = [vp, vp]
+    lib.bepuhip_import_peer_records.argtypes = [vp, i32, vp]
+    lib.bepuhip_get_owned_bodies.argtypes = [vp, vp, i32]
+    lib.bepuhip_get_owned_constraints.argtypes = [vp, i32, i32, vp]
+    lib.bepuhip_sync_owned_bodies.argtypes = [vp]
     lib.bepuhip_add_constraint.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
     lib.bepuhip_remove_constraint.argtypes = [vp, i32, i32, i32]
     lib.bepuhip_update_body_reference.argtypes = [vp, i32, i32, i32, i32, i32]
@@ -514,6 +524,42 @@ class HipSolver:
             raise ValueError("impulse data is not a whole number of bundles")
         fn = self.lib.bepuhip_update_accumulated_impulses_async if asynchronous else self.lib.bepuhip_update_accumulated_impulses
         _check(self.lib, fn(self.ctx, batch_index, type_id, first_bundle, n, _ptr(b)))
+
+    # ---- device groups: one connected scene on several devices, exact (include/bepuhip.h) ----
+    def set_device_group(self, world: int, rank: int):
+        """Before ``upload``: the plan holds ``world`` devices' worth of clusters and this context runs range ``rank`` of them."""
+        _check(self.lib, self.lib.bepuhip_set_device_group(self.ctx, world, rank))
+
+    def shared_records(self):
+        """(device pointer, bytes) of this context's copy of the record table; (0, 0) when the plan has no shared bodies."""
+        ptr, size = C.c_void_p(), C.c_int64()
+        _check(self.lib, self.lib.bepuhip_get_shared_records(self.ctx, C.byref(ptr), C.byref(size)))
+        return int(ptr.value or 0), int(size.value)
+
+    def set_peer_records(self, peer: int, pointer: int):
+        _check(self.lib, self.lib.bepuhip_set_peer_records(self.ctx, peer, C.c_void_p(pointer)))
+
+    def export_shared_records(self) -> bytes:
+        handle = (C.c_ubyte * 64)()
+        _check(self.lib, self.lib.bepuhip_export_shared_records(self.ctx, handle))
+        return bytes(handle)
+
+    def import_peer_records(self, peer: int, handle: bytes):
+        buf = (C.c_ubyte * 64).from_buffer_copy(handle)
+        _check(self.lib, self.lib.bepuhip_import_peer_records(self.ctx, peer, buf))
+
+    def owned_bodies(self, count: int) -> np.ndarray:
+        mask = np.zeros(count, dtype=np.uint8)
+        _check(self.lib, self.lib.bepuhip_get_owned_bodies(self.ctx, _ptr(mask), count))
+        return mask.astype(bool)
+
+    def owned_constraints(self, batch_index: int, type_id: int, count: int) -> np.ndarray:
+        mask = np.zeros(max(count, 1), dtype=np.uint8)
+        _check(self.lib, self.lib.bepuhip_get_owned_constraints(self.ctx, batch_index, type_id, _ptr(mask)))
+        return mask[:count].astype(bool)
+
+    def sync_owned_bodies(self):
+        _check(self.lib, self.lib.bepuhip_sync_owned_bodies(self.ctx))
 
     def transfer_rows(self, items):
         """bepuhip_transfer_rows_async: ``items`` = (kind, batch index, type id, first bundle, float32 array of whole bundles) tuples — or a prepared ``RowTransfer`` array from

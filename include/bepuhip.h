@@ -188,6 +188,34 @@ int32_t bepuhip_comm_init(bepuhip_ctx* ctx, const void* id, int32_t rank, int32_
 int32_t bepuhip_comm_adopt(bepuhip_ctx* ctx, void* nccl_comm, int32_t world);
 int32_t bepuhip_solve_lattice(bepuhip_ctx* ctx, float dt, int32_t substep_count, const int32_t* velocity_iterations, const bepuhip_integrator* integrator);
 
+/* ---- One connected scene on several GPUs, EXACT, on the island schedule (round 5; BASELINE.json configs[4]) ----
+ * The split-island plan already hands bodies from cluster to cluster through event-numbered records; a device group lets the clusters of ONE plan run on
+ * several devices. Every member uploads the SAME scene (bodies and type batches: the reference has one address space, every device mirrors it) after
+ *   set_device_group(world, rank)   before begin_constraints: the plan holds `world` devices' worth of clusters — the same plan on every member, the planner is
+ *                                   deterministic — and this context launches the contiguous range `rank` of them;
+ * and then tells the others where its copy of the record table lives (every record is written to ALL copies — a one-way push over the fabric, system-scope stores —
+ * and polled only in the device's own memory):
+ *   get_shared_records / set_peer_records          members that share an address space (several contexts in one process: the single-GPU tests)
+ *   export_shared_records / import_peer_records    members in different processes: a hipIpcMemHandle_t (BEPUHIP_IPC_HANDLE_BYTES) carried by any host transport
+ * `peer` is the ordinal among the OTHER members in rank order (0 .. world - 2). All members have to have finished their uploads before any of them solves (a host
+ * barrier), and all of them make the same sequence of solve calls (the records' event numbers advance with them). Inside a step there is no collective at all: the
+ * order of constraint applications per body is the batch order, exactly as on one device, so the results are bit-identical to the unsplit Simulation.Solve. After the
+ * step every member holds the final state of the bodies its clusters own (and of the bodies of no cluster, which all members integrate alike):
+ *   get_owned_bodies / get_owned_constraints   which bodies / which constraints of a type batch this member's results are final for (a host that merges by hand);
+ *   sync_owned_bodies                         ONE unsigned-integer all-reduce of the MotionState halves on the context's stream and communicator (bepuhip_comm_init):
+ *                                             owners contribute their bit patterns, everybody else zeros, every member ends the step with every body — the one
+ *                                             collective of a frame (136 in the per-batch exact mode of bepuhip_solve_lattice).
+ * Structural updates, bepuhip_replan and the momentum-conserving modes work as on one device as long as every member makes the same calls. */
+#define BEPUHIP_IPC_HANDLE_BYTES 64
+int32_t bepuhip_set_device_group(bepuhip_ctx* ctx, int32_t world, int32_t rank);
+int32_t bepuhip_get_shared_records(bepuhip_ctx* ctx, void** records_out, int64_t* bytes_out);
+int32_t bepuhip_set_peer_records(bepuhip_ctx* ctx, int32_t peer, void* records);
+int32_t bepuhip_export_shared_records(bepuhip_ctx* ctx, void* ipc_handle_out);
+int32_t bepuhip_import_peer_records(bepuhip_ctx* ctx, int32_t peer, const void* ipc_handle);
+int32_t bepuhip_get_owned_bodies(bepuhip_ctx* ctx, uint8_t* mask_out, int32_t count);
+int32_t bepuhip_get_owned_constraints(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, uint8_t* mask_out);
+int32_t bepuhip_sync_owned_bodies(bepuhip_ctx* ctx);
+
 /* Read back what the reference would find in its own buffers after Simulation.Solve returns. */
 int32_t bepuhip_get_bodies(bepuhip_ctx* ctx, void* body_dynamics_aos_out, int32_t count);
 /* BufferPool blocks are pinned unmanaged memory that lives as long as the simulation (BepuUtilities/Memory/BufferPool.cs:42,83): register them once (hipHostRegister) and

@@ -75,6 +75,14 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_comm_init(IntPtr ctx, void* id, int rank, int world);
     [DllImport(Lib)] public static extern int bepuhip_comm_adopt(IntPtr ctx, void* ncclComm, int world);
     [DllImport(Lib)] public static extern int bepuhip_solve_lattice(IntPtr ctx, float dt, int substepCount, int* velocityIterations, BepuHipIntegrator* integrator);
+    [DllImport(Lib)] public static extern int bepuhip_set_device_group(IntPtr ctx, int world, int rank);
+    [DllImport(Lib)] public static extern int bepuhip_get_shared_records(IntPtr ctx, void** recordsOut, long* bytesOut);
+    [DllImport(Lib)] public static extern int bepuhip_set_peer_records(IntPtr ctx, int peer, void* records);
+    [DllImport(Lib)] public static extern int bepuhip_export_shared_records(IntPtr ctx, void* ipcHandleOut);
+    [DllImport(Lib)] public static extern int bepuhip_import_peer_records(IntPtr ctx, int peer, void* ipcHandle);
+    [DllImport(Lib)] public static extern int bepuhip_get_owned_bodies(IntPtr ctx, byte* maskOut, int count);
+    [DllImport(Lib)] public static extern int bepuhip_get_owned_constraints(IntPtr ctx, int batchIndex, int typeId, byte* maskOut);
+    [DllImport(Lib)] public static extern int bepuhip_sync_owned_bodies(IntPtr ctx);
     [DllImport(Lib)] public static extern int bepuhip_get_bodies(IntPtr ctx, void* bodyDynamicsAosOut, int count);
     [DllImport(Lib)] public static extern int bepuhip_register_host_memory(IntPtr ctx, void* memory, long bytes);
     [DllImport(Lib)] public static extern int bepuhip_unregister_host_memory(IntPtr ctx, void* memory);

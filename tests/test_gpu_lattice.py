@@ -237,3 +237,33 @@ def test_on_stream_exchange_single_rank_through_rccl(hip_solver_factory, exact):
         assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
     else:  # snapshot + (v - snapshot) rounds in the last place at every exchange, and two frames of a stiff scene amplify that: not a bit-exact transport even with one holder
         assert m["velocity_rel_err"] <= 2e-3, m
+
+
+@pytest.mark.parametrize("world,plan", [(2, "split"), (3, "split"), (2, "islands")])
+def test_device_group_is_bit_identical_to_the_unsplit_solve(monkeypatch, world, plan):
+    """Round 5: the EXACT mode on the island schedule. A group of contexts (bepuhip_set_device_group; here all on this box's one GPU, one thread
+    each) plans the same clusters and every member runs its range of them in ONE launch per step; a body shared by clusters of different members is handed over through
+    the split-island plan's event-numbered records, which every member pushes into every other member's table (system-scope stores) and polls in its own — no exchange
+    point inside a step, one merge of the owned bodies per frame. The order of constraint applications per body is the batch order on any number of members: bodies,
+    impulses and contact depths equal the unsplit oracle bit for bit. `islands`: independent islands on whole-island plans (configs[3]'s case needs no records)."""
+    import parity_util as pu
+    from bepuphysics2_amd import lattice
+    from bepuphysics2_amd.hostlib import HostSimulation
+    from bepuphysics2_amd.native import HipSolver
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    if plan == "split":
+        monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "12")
+        monkeypatch.setenv("BEPUHIP_FORCE_SPLIT", "64")
+        scene, sd = _lattice_scene(120)
+    else:
+        monkeypatch.setenv("BEPUHIP_CLUSTER_BODIES", "160")
+        sim = HostSimulation.scene("ragdoll_tube", 90, 1, 0, 5)
+        scene, sd = sim.export(), sim.solve_description()
+        sim.close()
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=3, threads=4)
+    merged = lattice.solve_group_in_process(lambda: HipSolver(device=0, exclusive_device=True), scene, world, 1 / 60, sd, cb, frames=3)
+    schedules = [info[0] for info in merged.group_info]
+    assert schedules == [2 if plan == "split" else 1] * world, merged.group_info
+    m = pu.compare_scenes(ref, merged)
+    assert m["velocity_rel_err"] <= 1e-4 and m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
