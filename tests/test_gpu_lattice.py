@@ -267,3 +267,28 @@ def test_device_group_is_bit_identical_to_the_unsplit_solve(monkeypatch, world, 
     assert schedules == [2 if plan == "split" else 1] * world, merged.group_info
     m = pu.compare_scenes(ref, merged)
     assert m["velocity_rel_err"] <= 1e-4 and m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+
+def test_owned_body_exchange_packs_contributes_and_unpacks(hip_solver_factory, monkeypatch):
+    """bepuhip_sync_owned_bodies' mechanics on this box's single GPU: member 0 of a group of two with a ONE-rank communicator (RCCL admits one rank per device). The
+    all-reduce then returns what member 0 contributed — its owned bodies' MotionState bit patterns, zeros for the rest — and the unpack writes the sums into the bodies
+    member 0 does not own: owned bodies keep their bits, the others read back as zeros, the inertia halves are untouched. (With the second member's contribution the
+    zeros are its patterns: the in-process group test above covers the values, this one the kernels and the collective on the stream.)"""
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "12")
+    monkeypatch.setenv("BEPUHIP_FORCE_SPLIT", "64")
+    scene, sd = _lattice_scene(60)
+    solver = hip_solver_factory(exclusive_device=True)
+    solver.set_device_group(2, 0)
+    solver.upload(scene, sd.fallback_batch_threshold)
+    assert solver.schedule() == 2
+    owned = solver.owned_bodies(scene.body_count)
+    assert 0 < owned.sum() < scene.body_count and owned[-1], "member 0 owns its clusters' bodies and the kinematic tube (a body of no cluster)"
+    solver.comm_init(solver.comm_unique_id(), 0, 1)
+    before = solver.get_bodies(scene.body_count)
+    solver.sync_owned_bodies()
+    solver.sync()
+    after = solver.get_bodies(scene.body_count)
+    assert np.array_equal(after[owned].view(np.int32), before[owned].view(np.int32))
+    assert np.array_equal(after[~owned][:, 16:].view(np.int32), before[~owned][:, 16:].view(np.int32))
+    assert not after[~owned][:, :16].any() and before[~owned][:, :16].any()
