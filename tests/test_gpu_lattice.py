@@ -292,3 +292,76 @@ def test_owned_body_exchange_packs_contributes_and_unpacks(hip_solver_factory, m
     assert np.array_equal(after[owned].view(np.int32), before[owned].view(np.int32))
     assert np.array_equal(after[~owned][:, 16:].view(np.int32), before[~owned][:, 16:].view(np.int32))
     assert not after[~owned][:, :16].any() and before[~owned][:, :16].any()
+
+
+def _group_worker(rank, world, port, outdir, ragdolls, frames):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["BEPUHIP_SPLIT_CLUSTERS"], os.environ["BEPUHIP_FORCE_SPLIT"] = "12", "64"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch
+    from bepuphysics2_amd.native import HipSolver
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    scene, sd = _lattice_scene(ragdolls)
+    solver = HipSolver(device=0, exclusive_device=True)
+    solver.set_device_group(world, rank)
+    solver.upload(scene, sd.fallback_batch_threshold)
+    handles = [None] * world
+    dist.all_gather_object(handles, solver.export_shared_records())  # hipIpcMemHandle_t: the other PROCESS maps this member's record table
+    for k, r in enumerate(r for r in range(world) if r != rank):
+        solver.import_peer_records(k, handles[r])
+    owned = solver.owned_bodies(scene.body_count)
+    dist.barrier()
+    cb = PoseIntegratorCallbacks()
+    for frame in range(frames):
+        solver.solve(1 / 60, sd, cb)
+        got = solver.get_bodies(scene.body_count)
+        patterns = np.where(owned[:, None], got[:, :16].view(np.int32), 0).astype(np.int32)
+        t = torch.from_numpy(patterns)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)  # what bepuhip_sync_owned_bodies does with RCCL on a multi-GPU node
+        got[:, :16] = t.numpy().view(np.float32)
+        solver.set_bodies(got)
+        dist.barrier()
+    solver.download(scene)
+    scene.bodies[:, :16] = got[:, :16]
+    masks = {f"{bi}_{tb.type_id}": solver.owned_constraints(bi, tb.type_id, tb.count) for bi, b in enumerate(scene.batches) for tb in b if tb.count}
+    np.savez(os.path.join(outdir, f"group{rank}.npz"), bodies=scene.bodies, schedule=solver.schedule(), **{"mask_" + k: v for k, v in masks.items()},
+             **{f"acc_{bi}_{tb.type_id}": tb.accumulated for bi, b in enumerate(scene.batches) for tb in b if tb.count},
+             **{f"pre_{bi}_{tb.type_id}": tb.prestep for bi, b in enumerate(scene.batches) for tb in b if tb.count})
+    solver.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_device_group_across_two_processes_with_ipc_record_tables(tmp_path):
+    """The device group as a multi-GPU node runs it, minus the second GPU: two PROCESSES (gloo between them), each with its own HIP context on this box's one device,
+    each mapping the other's record table through a hipIpcMemHandle_t (bepuhip_export_shared_records / import_peer_records) — records written by one process are polled
+    by the kernels of the other — and the end-of-frame merge of the owned bodies as an integer all-reduce. Three frames, bit-identical to the unsplit oracle."""
+    import parity_util as pu
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    ragdolls, frames = 96, 3
+    port = 29850 + (os.getpid() % 100)
+    mp.spawn(_group_worker, args=(2, port, str(tmp_path), ragdolls, frames), nprocs=2, join=True)
+    scene, sd = _lattice_scene(ragdolls)
+    ref = pu.run_oracle(scene, 1 / 60, sd, PoseIntegratorCallbacks(), frames=frames, threads=4)
+    merged = scene.copy()
+    parts = [np.load(os.path.join(str(tmp_path), f"group{r}.npz")) for r in range(2)]
+    assert [int(p["schedule"]) for p in parts] == [2, 2]
+    assert np.array_equal(parts[0]["bodies"][:, :16].view(np.int32), parts[1]["bodies"][:, :16].view(np.int32)), "both members end the frame with every body"
+    merged.bodies[:, :16] = parts[0]["bodies"][:, :16]
+    w = scene.bundle_width
+    for bi, b in enumerate(merged.batches):
+        for tb in b:
+            if not tb.count:
+                continue
+            covered = np.zeros(tb.count, dtype=int)
+            for p in parts:
+                lanes = np.nonzero(p[f"mask_{bi}_{tb.type_id}"])[0]
+                covered[lanes] += 1
+                for name, dst, fields in (("acc", tb.accumulated, tb.impulse_floats), ("pre", tb.prestep, tb.prestep_floats)):
+                    src = p[f"{name}_{bi}_{tb.type_id}"].reshape(-1, fields, w)
+                    dst.reshape(-1, fields, w)[lanes // w, :, lanes % w] = src[lanes // w, :, lanes % w]
+            assert (covered == 1).all()
+    m = pu.compare_scenes(ref, merged)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
