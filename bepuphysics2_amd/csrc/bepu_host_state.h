@@ -237,6 +237,8 @@ struct bepuhip_ctx {
     std::vector<void*> peer_records;          // the record tables of the other devices, by peer ordinal (rank order, this rank left out)
     std::vector<void*> peer_opened;           // ... those opened from an IPC handle by this context (closed with it)
     float4** d_peer_table = nullptr;
+    float4* group_records = nullptr;          // the record table of a group member: allocated once (for group_records_bodies bodies), reused by every later plan that fits
+    size_t group_records_bodies = 0;
     uint32_t* d_owned_dense = nullptr;        // bepuhip_sync_owned_bodies: 16 words per body
     uint8_t* d_owned_mask = nullptr;
     int owned_mask_bodies = 0;
@@ -343,7 +345,8 @@ static void free_constraints(bepuhip_ctx* c) {
     c->d_trace = nullptr; c->trace_words = 0;
     if (c->d_cycles) hipFree(c->d_cycles);
     c->d_cycles = nullptr;
-    if (c->d_shared_vel) hipFree(c->d_shared_vel);
+    // (a device group's record table is mapped by the other members: it keeps its address across uploads and re-plans — group_records below — and dies with the context)
+    if (c->d_shared_vel && c->d_shared_vel != c->group_records) hipFree(c->d_shared_vel);
     if (c->d_shared_info) hipFree(c->d_shared_info);
     c->d_shared_vel = nullptr; c->d_shared_info = nullptr; c->clusters_shared = false; c->shared_bodies = 0;
     c->d_clusters = nullptr; c->d_items = nullptr; c->d_batch_item_begin = nullptr; c->d_cluster_bodies = nullptr;

@@ -134,6 +134,7 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_stage) hipFree(c->d_stage);
     if (c->h_desc_ring) hipHostFree(c->h_desc_ring);
     for (void* opened : c->peer_opened) hipIpcCloseMemHandle(opened);
+    if (c->group_records) hipFree(c->group_records);
     if (c->d_peer_table) hipFree(c->d_peer_table);
     if (c->d_owned_dense) hipFree(c->d_owned_dense);
     if (c->d_owned_mask) hipFree(c->d_owned_mask);
@@ -619,7 +620,19 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         if (plan.shared) {  // split islands: velocity / event tables of the bodies more than one cluster touches (indexed by body, only the shared ones are used)
             // (long enough for the bodies that have no constraints yet: structural updates may bring them into the plan and share them)
             c->shared_bodies = std::max(plan.shared_info.size(), (size_t)std::max(c->body_count, 0)) + 1024;
-            HIP_TRY(hipMalloc((void**)&c->d_shared_vel, c->shared_bodies * 4 * sizeof(float4)));  // two records (substep parity) of two float4 per body
+            if (c->group_world > 1) {
+                // The other members of a device group hold this table's address (bepuhip_set_peer_records / import_peer_records) and push records into it: it must not move
+                // when this member uploads again or re-plans. Allocated once, with room to grow; a scene that outgrows it gets a new table, and the header says what the
+                // members have to do then (exchange the tables again).
+                if (c->group_records && c->group_records_bodies < c->shared_bodies) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->group_records); c->group_records = nullptr; c->group_records_bodies = 0; }
+                if (!c->group_records) {
+                    c->group_records_bodies = c->shared_bodies + c->shared_bodies / 4;
+                    HIP_TRY(hipMalloc((void**)&c->group_records, c->group_records_bodies * 4 * sizeof(float4)));
+                }
+                c->d_shared_vel = c->group_records;
+            } else {
+                HIP_TRY(hipMalloc((void**)&c->d_shared_vel, c->shared_bodies * 4 * sizeof(float4)));  // two records (substep parity) of two float4 per body
+            }
             HIP_TRY(hipMemset(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4)));         // cleared here, then never again: every step's event numbers start above the last step's
             c->shared_epoch = 0;
             HIP_TRY(hipMalloc((void**)&c->d_shared_info, c->shared_bodies * 4));

@@ -205,7 +205,10 @@ int32_t bepuhip_solve_lattice(bepuhip_ctx* ctx, float dt, int32_t substep_count,
  *   sync_owned_bodies                         ONE unsigned-integer all-reduce of the MotionState halves on the context's stream and communicator (bepuhip_comm_init):
  *                                             owners contribute their bit patterns, everybody else zeros, every member ends the step with every body — the one
  *                                             collective of a frame (136 in the per-batch exact mode of bepuhip_solve_lattice).
- * Structural updates, bepuhip_replan and the momentum-conserving modes work as on one device as long as every member makes the same calls. */
+ * Structural updates, bepuhip_replan and the momentum-conserving modes work as on one device as long as every member makes the same calls. A member's table keeps its
+ * address across its own uploads and re-plans (the peers' mappings stay valid) unless the scene outgrows it by more than a quarter: get_shared_records then returns a new
+ * address and the members exchange tables again, behind a host barrier — as after any upload, since every member clears its table when it plans. (Event numbers wrap after
+ * about two million steps of a context; a group re-uploads before that.) */
 #define BEPUHIP_IPC_HANDLE_BYTES 64
 int32_t bepuhip_set_device_group(bepuhip_ctx* ctx, int32_t world, int32_t rank);
 int32_t bepuhip_get_shared_records(bepuhip_ctx* ctx, void** records_out, int64_t* bytes_out);

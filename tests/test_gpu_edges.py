@@ -359,3 +359,37 @@ def test_up_to_sixty_four_substeps_stay_on_the_island_schedule(hip_solver_factor
             os.environ.pop("BEPUHIP_SPLIT_CLUSTERS", None)
         m = pu.compare_scenes(ref, got)
         assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (count, mode, split, m)
+
+
+def test_no_reference_legal_solve_description_falls_back_to_launch_per_batch(hip_solver_factory):
+    """after an upload, which schedule runs a solve must not depend on the SolveDescription or the callbacks' switches. Every combination of substep
+    count (1, 5, 70: a chain of launches), uneven iteration schedule, angular integration mode, the two integrator switches and the velocity model — and the substep
+    events — is run with profiling on: the launches are the island kernel's, none is a per-batch warm start or solve. (The one exception the library documents, a
+    sequential fallback batch together with a momentum-conserving mode, is asserted as such)"""
+    import itertools
+    scene = small_scenes.island_scene(21, islands=60, bodies_per_island=9, constraints_per_island=22, type_ids=[4, 5, 7, 22, 23, 25, 27, 30, 47, 0, 3])
+    solver = hip_solver_factory()
+    solver.upload(scene)
+    solver.set_profiling(True)
+    combos = 0
+    for substeps, mode, allow, kin in itertools.product((1, 5, 70), (0, 1, 2), (False, True), (False, True)):
+        sd = SolveDescription(1, substeps, velocity_iteration_scheduler=lambda s: 1 + (s % 3))
+        cb = PoseIntegratorCallbacks(angular_integration_mode=mode, allow_substeps_for_unconstrained_bodies=allow, integrate_velocity_for_kinematics=kin)
+        solver.solve(1 / 60, sd, cb)
+        prof = solver.profile()
+        assert prof["cluster"][1] >= 1 and prof["warmstart"][1] == 0 and prof["solve"][1] == 0 and prof["integrate"][1] == 0, (substeps, mode, allow, kin, prof)
+        assert prof["cluster"][1] == (substeps + 63) // 64
+        combos += 1
+    assert combos == 36 and solver.schedule() == 1
+    solver.set_profiling(False)
+    seen = []
+    solver.solve_with_substep_events(1 / 60, SolveDescription(2, 3), PoseIntegratorCallbacks(), started=lambda s: seen.append(s))
+    assert seen == [0, 1, 2] and solver.schedule() == 1
+    # the documented exception: a sequential fallback batch under a conserving mode
+    star = small_scenes.star_scene(5, spokes=40, hubs=2, fallback_batch_threshold=5)
+    s2 = hip_solver_factory()
+    s2.upload(star, 5)
+    s2.set_profiling(True)
+    for mode, island in ((0, True), (1, False)):
+        s2.solve(1 / 60, SolveDescription(1, 2, fallback_batch_threshold=5), PoseIntegratorCallbacks(angular_integration_mode=mode))
+        assert (s2.profile()["cluster"][1] > 0) == island, (mode, s2.profile())
