@@ -733,6 +733,198 @@ __device__ BEPU_ITEM_INLINE void run_cluster_constraint(const ClusterShared& sh,
     }
 }
 
+// ---- merged manifold items (round 5; split plans only) ----
+// A pile cluster's batch holds four or five convex manifold type batches (Contact1..4, one or two bodies) with 10 - 60 constraints each: typed work items run at
+// 13 - 64 lanes, and a wave spends the same time on an item whatever its lane count — wave time is what a split cluster runs out of. The planner
+// therefore GROUPS typed items of one batch and one family (two-body Contact1..4, or the one-body four) whose lane counts sum to at most 64: the group's first item
+// (the leader, ClusterItem.shape bits 24-25 = members behind it) is followed by its members (bit 26) in the item array. Nothing else about the items changes — every
+// member keeps its rows, its predecessor lists and its flag, so structural updates rebuild the lists as before. The wave that claims the leader runs ALL the group's
+// constraints as one item: lane l takes its rows from the typed item its lane range falls in, with that type's contact count (ContactFused, per-lane count); it waits
+// for the predecessors of every item of the group and publishes every item's flag. A wave that claims a member goes on to its next claim.
+constexpr int kTraceFusedType = 0x80;  // the type column of a fused group in the cluster trace (| 1: two bodies)
+
+// wait_predecessors for the up to four items of a group at once: lanes [12 s, 12 s + 12) watch the listed predecessors of item s (pred[] then xpred[]).
+// What the wave needs from the items' headers comes by value: `npred` / `nxpred` are the counts of the item THIS lane's twelve belong to (0 beyond the group).
+template <bool CROSS>
+__device__ __forceinline__ void wait_predecessors_fused(const ClusterShared& sh, const ClusterItem* it, int members, int npred, int nxpred, bool overflow, bool xoverflow, int batch, int k, unsigned epoch) {
+    {
+        const int lane = threadIdx.x & 63;
+        const int s = (lane >= 12) + (lane >= 24) + (lane >= 36), q = lane - 12 * s;
+        const bool present = lane < 48 && s <= members;
+        const unsigned short listed = (&(it + (present ? s : 0))->pred[0])[present ? q : 0];
+        const bool same = present && q < npred;
+        const bool cross = CROSS && present && q >= kMaxPreds && q < kMaxPreds + nxpred;
+        const int idx = (same || cross) ? (int)listed : k;
+        const unsigned want = same ? epoch : (cross ? epoch - 1 : 0u);
+        const volatile lds_u32* word = sh.flags + idx;
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned seen = *word;
+            const unsigned long long late = __builtin_amdgcn_ballot_w64(seen < want);
+            if (late == 0) break;
+            if (++spins > kSpinLimit) {
+                const int first = (int)__builtin_ctzll(late);
+                report_stall(sh.status, *sh.counter, 12, k, __builtin_amdgcn_readlane(idx, first), __builtin_amdgcn_readlane((int)want, first), __builtin_amdgcn_readlane((int)seen, first));
+                break;
+            }
+            if ((spins & 4095u) == 0 && __hip_atomic_load(sh.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        }
+    }
+    // overflow waits as in wait_predecessors, once for the group (its items share a batch; the sequential fallback batch is never grouped)
+    if (overflow) wait_items(sh, (int)__builtin_amdgcn_readfirstlane(sh.lbib[batch]), epoch, 2, k);
+    if (CROSS && xoverflow) wait_items(sh, sh.item_count, epoch - 1, 4, k);
+    asm volatile("" ::: "memory");
+}
+// publish_item for `n` consecutive items: lane s < n writes flag s.
+__device__ __forceinline__ void publish_items(volatile lds_u32* flag, int n, unsigned epoch) {
+    unsigned long long saved;
+    const unsigned long long mask = (1ull << n) - 1ull;
+    const unsigned address = lds_address(flag) + 4u * (threadIdx.x & 63u);
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m]\n\t"
+        "ds_write_b32 %[fa], %[e]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [sv] "=&s"(saved)
+        : [fa] "v"(address), [e] "v"(epoch), [m] "s"(mask)
+        : "memory");
+}
+template <int ACC_A, int ACC_B, int BODIES, bool CROSS, bool TRACE, bool SHARED>
+struct FusedGate {
+    static constexpr bool kPin = true;
+    const ClusterShared& sh; const ClusterItem* it; int members, npred, nxpred; bool overflow, xoverflow; int batch; int k; unsigned epoch; int ra, rb; DBody& A; DBody& B; ItemStamps& stamps;
+    const SharedRef& sa; const SharedRef& sb;
+    bool requirk_a, requirk_b;
+    __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {
+        if (TRACE) stamps.pre_gate = __builtin_readcyclecounter();
+        jitter_nap(sh, (unsigned)k * 2u + epoch * 0x632BE5ABu);
+        wait_predecessors_fused<CROSS>(sh, it, members, npred, nxpred, overflow, xoverflow, batch, k, epoch);
+        __builtin_amdgcn_s_setprio(3);
+        if constexpr (kConserving && !CROSS) {
+            if (requirk_a && !sa.shared()) requirk_in_lds(sh, ra);
+            if (BODIES == 2 && requirk_b && !sb.shared()) requirk_in_lds(sh, rb);
+        }
+        load_velocity_lds<ACC_A>(sh, ra, A);
+        if (BODIES == 2) load_velocity_lds<ACC_B>(sh, rb, B);
+        if constexpr (SHARED) {
+            if (sa.shared() && !sa.poll) load_velocity_lds<kLin | kAng>(sh, ra, A);
+            if (BODIES == 2 && sb.shared() && !sb.poll) load_velocity_lds<kLin | kAng>(sh, rb, B);
+            acquire_shared<BODIES == 2>(sh, sa, A, sb, B, 6, k);
+        }
+        if constexpr (kConserving && !CROSS && SHARED) {
+            if (requirk_a && sa.shared()) A.vel.ang = requirk_angular_velocity(sh, ra, A.vel.ang);
+            if (BODIES == 2 && requirk_b && sb.shared()) B.vel.ang = requirk_angular_velocity(sh, rb, B.vel.ang);
+        }
+        if (TRACE) stamps.post_gate = __builtin_readcyclecounter();
+    }
+};
+
+__device__ __forceinline__ float load_row(const gfloat* p) { return kRowsNonTemporal ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ int load_row(const gint* p) { return kRowsNonTemporal ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void store_row(gfloat* p, float v) { if (kRowsNonTemporal) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// The group's work item: run_cluster_constraint with per-lane rows. `h0` is the leader's header, `members` the items behind it (1..3).
+template <bool TWO, int STAGE, bool TRACE, bool SHARED>
+__device__ __forceinline__ int run_cluster_fused(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h0, int members, int k, int lane, unsigned epoch,
+                                                  unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
+    using F = ContactFused<TWO>;
+    // the members' headers (wave-uniform; an absent member reads the leader's and counts no lanes)
+    const ItemHeader h1 = read_item(it + (members >= 1 ? 1 : 0)), h2 = read_item(it + (members >= 2 ? 2 : 0)), h3 = read_item(it + (members >= 3 ? 3 : 0));
+    const int c1 = members >= 1 ? h1.count : 0, c2 = members >= 2 ? h2.count : 0, c3 = members >= 3 ? h3.count : 0;
+    const int off1 = h0.count, off2 = off1 + c1, off3 = off2 + c2, total = off3 + c3;
+    const bool active = lane < total;
+    const int l = active ? lane : total - 1;  // lanes beyond the group mirror its last constraint and never store
+    const int sub = (l >= off1) + (l >= off2) + (l >= off3);
+#define BEPU_PICK(field) (sub == 0 ? h0.field : (sub == 1 ? h1.field : (sub == 2 ? h2.field : h3.field)))
+    const int stride = BEPU_PICK(stride);
+    const int i = BEPU_PICK(start) + (l - (sub == 0 ? 0 : (sub == 1 ? off1 : (sub == 2 ? off2 : off3))));
+    const int count = (BEPU_PICK(type_id) & 3) + 1;  // one-body Contact N is type N - 1, two-body Contact N type 3 + N
+    const gint* lrefs = (const gint*)(slab + BEPU_PICK(lrefs_off)) + i;
+    gfloat* prestep = (gfloat*)(slab + BEPU_PICK(prestep_off)) + i;
+    gfloat* accum = (gfloat*)(slab + BEPU_PICK(accum_off)) + i;
+#undef BEPU_PICK
+    // for the gate: the predecessor counts of the item whose lists this lane's twelve watch, the group's overflow flags
+    const int watch = (lane >= 12) + (lane >= 24) + (lane >= 36);
+    const int watch_npred = watch == 0 ? h0.npred : (watch == 1 ? h1.npred : (watch == 2 ? h2.npred : h3.npred));
+    const int watch_nxpred = watch == 0 ? h0.nxpred : (watch == 1 ? h1.nxpred : (watch == 2 ? h2.nxpred : h3.nxpred));
+    const bool group_overflow = h0.overflow != 0 || (members >= 1 && h1.overflow != 0) || (members >= 2 && h2.overflow != 0) || (members >= 3 && h3.overflow != 0);
+    const bool group_xoverflow = h0.xoverflow != 0 || (members >= 1 && h1.xoverflow != 0) || (members >= 2 && h2.xoverflow != 0) || (members >= 3 && h3.xoverflow != 0);
+    float p[F::prestepFloats], a[F::impulseFloats];
+    const unsigned both = (unsigned)load_row(lrefs);
+    unsigned rank_a = 0u, rank_b = 0u;
+    if constexpr (SHARED) {
+        const gint* srank = lrefs + (size_t)((F::bodies + 1) / 2) * stride;
+        rank_a = (unsigned)srank[0];
+        if (F::bodies == 2) rank_b = (unsigned)srank[(size_t)stride];
+    }
+    // the lane's rows in Contact4's layout: contact c at p[4c..4c+3] (absent contacts: zero, never used), the common block (its rows follow the lane's own contacts)
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) p[4 * c + r] = 0.0f;
+        if (c < count) { _Pragma("unroll") for (int r = 0; r < 4; ++r) p[4 * c + r] = load_row(&prestep[(size_t)(4 * c + r) * stride]); }
+    }
+    {
+        const gfloat* common = prestep + (size_t)(4 * count) * stride;
+        _Pragma("unroll") for (int f = 0; f < F::commonFloats; ++f) p[16 + f] = load_row(&common[(size_t)f * stride]);
+    }
+    if (STAGE != kStageIncremental) {
+        a[0] = load_row(&accum[0]); a[1] = load_row(&accum[(size_t)stride]);
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) { a[2 + c] = 0.0f; if (c < count) a[2 + c] = load_row(&accum[(size_t)(2 + c) * stride]); }
+        a[6] = load_row(&accum[(size_t)(2 + count) * stride]);
+    }
+    if (STAGE != kStageIncremental) touch_code_ahead(sh, lane);
+    const int ra = unpack_local_ref(both & 0xFFFFu);
+    const int rb = (F::bodies == 2) ? unpack_local_ref(both >> 16) : -1;
+    SharedRef sa = {-1, 0u, false, false}, sb = {-1, 0u, false, false};
+    if constexpr (SHARED) {
+        sa = make_shared_ref<STAGE == kStageIncremental>(sh, both & 0xFFFFu, rank_a, active);
+        if (F::bodies == 2) sb = make_shared_ref<STAGE == kStageIncremental>(sh, both >> 16, rank_b, active);
+    }
+    DBody A, B;
+    if (STAGE == kStageIncremental) {
+        load_body_lds<kAccessOnlyVelocity>(sh, ra, A);
+        if (F::bodies == 2) load_body_lds<kAccessOnlyVelocity>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
+        if constexpr (SHARED) acquire_shared<F::bodies == 2>(sh, sa, A, sb, B, 8, k);
+        F::incrementalUpdate(dt, A.vel, B.vel, p, count);
+        if (active) {
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) { if (c < count) store_row(&prestep[(size_t)(4 * c + 3) * stride], p[4 * c + 3]); }
+        }
+        return total;
+    }
+    constexpr int accA = (STAGE == kStageWarmStart) ? F::wsA : F::svA;
+    constexpr int accB = (STAGE == kStageWarmStart) ? F::wsB : F::svB;
+    load_body_lds<accA & ~(kLin | kAng)>(sh, ra, A);
+    if (F::bodies == 2) load_body_lds<accB & ~(kLin | kAng)>(sh, rb, B); else load_body_lds<0>(sh, 0, B);
+    if (TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps.loaded = __builtin_readcyclecounter(); }
+    bool requirk_a = false, requirk_b = false;
+    if constexpr (kConserving && STAGE == kStageWarmStart) {
+        if (sh.substep == 0 && active) {
+            requirk_a = SHARED ? (rank_a & kRankRequirk) != 0 : ((both & kLrefRequirk) != 0 && (both & 0x8000u) == 0);
+            requirk_b = F::bodies == 2 && (SHARED ? (rank_b & kRankRequirk) != 0 : (((both >> 16) & kLrefRequirk) != 0 && (both & 0x80000000u) == 0));
+        }
+    }
+    FusedGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE, SHARED> gate{sh, it, members, watch_npred, watch_nxpred, group_overflow, group_xoverflow, h0.batch, k, epoch, ra, rb, A, B, stamps, sa, sb, requirk_a, requirk_b};
+    if (STAGE == kStageWarmStart) F::warmStart(A.inertia, B.inertia, p, a, count, A.vel, B.vel, gate);
+    else F::solve(A.inertia, B.inertia, dt, inv_dt, p, a, count, A.vel, B.vel, gate);
+    store_velocity_lds<accA>(sh, (active && !sa.shared()) ? ra : -1, A);
+    if (F::bodies == 2) store_velocity_lds<accB>(sh, (active && !sb.shared()) ? rb : -1, B);
+    if constexpr (SHARED) {
+        store_velocity_lds<kLin | kAng>(sh, (sa.shared() && !sa.publish) ? ra : -1, A);
+        if (F::bodies == 2) store_velocity_lds<kLin | kAng>(sh, (sb.shared() && !sb.publish) ? rb : -1, B);
+        release_shared(sh, sa, A);
+        if (F::bodies == 2) release_shared(sh, sb, B);
+    }
+    jitter_nap(sh, (unsigned)k * 2u + 1u + epoch * 0x632BE5ABu);
+    publish_items(sh.flags + k, members + 1, epoch);
+    __builtin_amdgcn_s_setprio(0);
+    if (STAGE == kStageSolve && active) {
+        store_row(&accum[0], a[0]); store_row(&accum[(size_t)stride], a[1]);
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) { if (c < count) store_row(&accum[(size_t)(2 + c) * stride], a[2 + c]); }
+        store_row(&accum[(size_t)(2 + count) * stride], a[6]);
+    }
+    return total;
+}
+
 using DC1O = Contact<1, false>; using DC2O = Contact<2, false>; using DC3O = Contact<3, false>; using DC4O = Contact<4, false>;
 using DC1T = Contact<1, true>; using DC2T = Contact<2, true>; using DC3T = Contact<3, true>; using DC4T = Contact<4, true>;
 
@@ -795,14 +987,34 @@ __device__ __forceinline__ void run_cluster_sweep(ClusterShared& sh, int item_co
         if (TRACE) t0 = __builtin_readcyclecounter();
         ItemStamps stamps = {0, 0, 0};
         if constexpr (SHARED) sh.passes = pass_base + (second ? 1u : 0u);  // wave-private copy: which pass of the step this item belongs to
-        if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE, WIDE, SHARED>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
-        else run_cluster_item<kStageSolve, TRACE, WIDE, SHARED>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+        int traced_type = h.type_id, traced_count = h.count;
+        bool typed = true;
+        if constexpr (SHARED) {  // merged manifold items: the leader's wave runs the group, a member is not an item of its own
+            const int fuse = __builtin_amdgcn_readfirstlane(it->shape) >> kItemFuseShift;
+            if (fuse & kItemFuseMember) continue;
+            if (fuse & 3) {
+                typed = false;
+                const bool two = h.type_id >= kContact1;
+                traced_type = kTraceFusedType | (two ? 1 : 0);
+                if (STAGE0 == kStageWarmStart && !second) {
+                    if (two) traced_count = run_cluster_fused<true, kStageWarmStart, TRACE, SHARED>(sh, it, h, fuse & 3, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+                    else traced_count = run_cluster_fused<false, kStageWarmStart, TRACE, SHARED>(sh, it, h, fuse & 3, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+                } else {
+                    if (two) traced_count = run_cluster_fused<true, kStageSolve, TRACE, SHARED>(sh, it, h, fuse & 3, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+                    else traced_count = run_cluster_fused<false, kStageSolve, TRACE, SHARED>(sh, it, h, fuse & 3, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+                }
+            }
+        }
+        if (typed) {
+            if (STAGE0 == kStageWarmStart && !second) run_cluster_item<kStageWarmStart, TRACE, WIDE, SHARED>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+            else run_cluster_item<kStageSolve, TRACE, WIDE, SHARED>(sh, it, h, k, lane, item_epoch, slab, dt, inv_dt, stamps);
+        }
         if (TRACE && trace && blockIdx.x == 0 && lane == 0 && item_epoch - 1 < (unsigned)kClusterTracePasses) {  // iteration counts are unbounded: never write past the buffer
             unsigned long long* rec = trace + ((size_t)(item_epoch - 1) * item_count + k) * 8;
             rec[4] = stamps.loaded; rec[5] = stamps.pre_gate; rec[6] = stamps.post_gate; rec[7] = 0;
             rec[0] = t0; rec[1] = __builtin_readcyclecounter();
-            rec[2] = (unsigned long long)wave | ((unsigned long long)h.type_id << 8) | ((unsigned long long)h.batch << 16) | ((unsigned long long)((STAGE0 == kStageWarmStart && !second) ? kStageWarmStart : kStageSolve) << 32);
-            rec[3] = (unsigned long long)h.count;
+            rec[2] = (unsigned long long)wave | ((unsigned long long)traced_type << 8) | ((unsigned long long)h.batch << 16) | ((unsigned long long)((STAGE0 == kStageWarmStart && !second) ? kStageWarmStart : kStageSolve) << 32);
+            rec[3] = (unsigned long long)traced_count;
         }
     }
     if constexpr (SHARED) sh.passes = pass_base;
@@ -935,6 +1147,15 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 const ItemHeader h = read_item(it);
                 if (!isContactType(h.type_id)) continue;
                 ItemStamps stamps = {0, 0, 0};
+                if constexpr (SHARED) {
+                    const int fuse = __builtin_amdgcn_readfirstlane(it->shape) >> kItemFuseShift;
+                    if (fuse & kItemFuseMember) continue;
+                    if (fuse & 3) {
+                        if (h.type_id >= kContact1) run_cluster_fused<true, kStageIncremental, false, SHARED>(sh, it, h, fuse & 3, k, lane, 0u, slab, dt, inv_dt, stamps);
+                        else run_cluster_fused<false, kStageIncremental, false, SHARED>(sh, it, h, fuse & 3, k, lane, 0u, slab, dt, inv_dt, stamps);
+                        continue;
+                    }
+                }
                 run_cluster_item<kStageIncremental, false, WIDE, SHARED>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
             }
             __syncthreads();

@@ -901,17 +901,75 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         tb.plan_ranks = srank[t];
     });
     split_lap("row swaps, mirrors (threads)");
+    // Merged manifold items (round 5; bepu_cluster_kernel.h, run_cluster_fused): inside a batch, typed items of one convex manifold family (two-body Contact1..4,
+    // or the one-body four) that do not fill a wave are grouped, lane counts summing to at most 64, at most four to a group — first fit over the items in
+    // descending lane count. A group's items sit next to each other in the item array, leader first (shape bits 24-25: members behind it; bit 26: a member), at the
+    // place of the group's first item; everything else keeps its claim order. BEPUHIP_FUSE_ITEMS=0 plans without groups (for A/Bs on one box).
+    const bool fuse_items = env_int("BEPUHIP_FUSE_ITEMS", 1) != 0;
+    struct ItemEntry { size_t t; int s0, count, fuse; };
+    auto group_entries = [&](std::vector<ItemEntry>& entries) {
+        std::vector<ItemEntry> out;
+        out.reserve(entries.size());
+        for (size_t b0 = 0; b0 < entries.size();) {
+            size_t b1 = b0;
+            while (b1 < entries.size() && c->tbs[entries[b1].t].batch == c->tbs[entries[b0].t].batch) ++b1;
+            std::vector<int> group_of(b1 - b0, -1);  // entry -> group
+            std::vector<std::vector<size_t>> groups;
+            for (int family = 0; family < 2; ++family) {
+                std::vector<size_t> partial;
+                for (size_t e = b0; e < b1; ++e) {
+                    const int type = c->tbs[entries[e].t].type_id;
+                    if (type >= family * 4 && type < family * 4 + 4 && entries[e].count < 64) partial.push_back(e);
+                }
+                std::stable_sort(partial.begin(), partial.end(), [&](size_t x, size_t y) { return entries[x].count > entries[y].count; });
+                std::vector<std::vector<size_t>> bins;
+                std::vector<int> lanes;
+                for (size_t e : partial) {
+                    size_t at = 0;
+                    while (at < bins.size() && (lanes[at] + entries[e].count > 64 || bins[at].size() >= 4)) ++at;
+                    if (at == bins.size()) { bins.emplace_back(); lanes.push_back(0); }
+                    bins[at].push_back(e); lanes[at] += entries[e].count;
+                }
+                for (auto& bin : bins) {
+                    if (bin.size() < 2) continue;
+                    std::sort(bin.begin(), bin.end());  // claim order inside the group: the heavier type leads
+                    for (size_t e : bin) group_of[e - b0] = (int)groups.size();
+                    groups.push_back(bin);
+                }
+            }
+            for (size_t e = b0; e < b1; ++e) {
+                const int g = group_of[e - b0];
+                if (g < 0) { out.push_back(entries[e]); continue; }
+                if (groups[g][0] != e) continue;  // emitted with its leader
+                for (size_t m = 0; m < groups[g].size(); ++m) {
+                    ItemEntry member = entries[groups[g][m]];
+                    member.fuse = m == 0 ? (int)groups[g].size() - 1 : 4;
+                    out.push_back(member);
+                }
+            }
+            b0 = b1;
+        }
+        entries.swap(out);
+    };
     plan_parallel_for((size_t)nclusters, [&](size_t cluster) {  // every cluster's work items with their predecessor lists, type batches in claim order
         const int cl = (int)cluster;
+        std::vector<ItemEntry> entries;
         for (size_t t : visit) {
+            const HostTypeBatch& tb = c->tbs[t];
+            const int d = tb.seg_begin[cl], e = tb.seg_begin[cl + 1];
+            for (int s0 = d; s0 < e; s0 += 64) entries.push_back({t, s0, std::min(64, e - s0), 0});
+        }
+        if (fuse_items) group_entries(entries);
+        for (const ItemEntry& entry : entries) {
+            const size_t t = entry.t;
             HostTypeBatch& tb = c->tbs[t];
             const int nb = tb.info.bodies, pf = tb.info.prestep, imf = tb.info.impulse;
-            const int d = tb.seg_begin[cl], e = tb.seg_begin[cl + 1];
-            for (int s0 = d; s0 < e; s0 += 64) {
+            {
+                const int s0 = entry.s0;
                 ClusterItem it;
                 memset(&it, 0, sizeof(it));
-                it.type_id = tb.type_id; it.count = std::min(64, e - s0); it.stride = tb.stride; it.start = s0;
-                it.tb = (int)t; it.shape = nb | (pf << 8) | (imf << 16);
+                it.type_id = tb.type_id; it.count = entry.count; it.stride = tb.stride; it.start = s0;
+                it.tb = (int)t; it.shape = nb | (pf << 8) | (imf << 16) | (entry.fuse << 24);
                 const int self = (int)cl_items[cl].size();
                 int npred = 0, overflow = 0;
                 std::vector<int32_t>& lt = last_toucher[cl];

@@ -335,6 +335,129 @@ struct Contact {
 };
 
 // ======================================================================================
+// One manifold function for a PER-LANE contact count (round 5, the merged manifold work item of the island schedule: lanes of Contact1..4 type batches of one
+// batch share a wave). The reference generates Contact1..4 from one template (ContactConvexTypes.tt; ContactConvexTypes.cs:901-1514 are its four expansions):
+// the row functions are the same, what depends on N is how many penetration rows there are, how the friction centre is summed and two constants. `p` and `a`
+// are held in Contact4's layout (contact c at p[4c..4c+3], the common block at 16.., penetration impulses at a[2..5], twist at a[6]); `count` is the lane's N.
+// Every lane evaluates, operation for operation, what Contact<count, TwoBody> evaluates: rows beyond the lane's count are skipped under the lane mask, sums
+// that the template writes per N are selected per lane, never re-associated. (tests/test_contact_fused_host.py checks the bits on the host for all four counts.)
+// ======================================================================================
+template <bool TwoBody>
+struct ContactFused {
+    using C = Contact<4, TwoBody>;
+    static constexpr int bodies = TwoBody ? 2 : 1;
+    static constexpr int prestepFloats = C::prestepFloats;
+    static constexpr int impulseFloats = C::impulseFloats;
+    static constexpr int commonFloats = TwoBody ? 10 : 7;  // [OffsetB], Normal, material: the rows behind the contacts
+    static constexpr int wsA = kAccessNoPose, wsB = kAccessNoPose, svA = kAccessNoPose, svB = kAccessNoPose;
+    using PenRow = typename C::PenRow;
+    using TJ = typename C::TJ;
+    using TangentSetup = typename C::TangentSetup;
+
+    // FrictionHelpers.ComputeFrictionCenter for count = 2, 3, 4 (Contact<N>::frictionCenter above, per lane).
+    BD_FN V3 frictionCenter(float* p, int count) {
+        float w[4];
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) w[i] = (i < count) ? sel(C::depth(p, i) < 0.0f, 0.0f, 1.0f) : 0.0f;
+        float weightSum = w[0] + w[1] + w[2] + w[3];  // left to right: the weights are 0 or 1, adding the absent ones' +0 changes no bit
+        bool useFallback = weightSum == 0.0f;
+        weightSum = sel(useFallback, (float)count, weightSum);
+        float inverseWeightSum = 1.0f / weightSum;
+        V3 c[4];
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {
+            w[i] = sel(useFallback, inverseWeightSum, w[i] * inverseWeightSum);
+            c[i] = scale(C::offsetA(p, i), w[i]);
+        }
+        const V3 s01 = add(c[0], c[1]);
+        const V3 s23 = add(c[2], c[3]);
+        const V3 tail = sel3(count == 4, s23, c[2]);  // N == 4: (c0 + c1) + (c2 + c3); N == 3: (c0 + c1) + c2
+        const V3 three = add(s01, tail);
+        return sel3(count == 2, s01, three);
+    }
+    BD_FN V3 centerOf(float* p, int count) {
+        const V3 many = frictionCenter(p, count);
+        return sel3(count > 1, many, C::offsetA(p, 0));
+    }
+    BD_FN void incrementalUpdate(float dt, const BodyVel& vA, const BodyVel& vB, float* p, int count) {
+        V3 n = C::normal(p);
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {
+            if (i < count) {
+                V3 contactOffsetA = C::offsetA(p, i);
+                V3 wxra = cross(vA.ang, contactOffsetA);
+                V3 contactVelocityA = add(wxra, vA.lin);
+                float estimatedDepthChangeVelocity;
+                if (TwoBody) {
+                    V3 contactOffsetB = sub(contactOffsetA, C::offsetB(p));
+                    V3 wxrb = cross(vB.ang, contactOffsetB);
+                    V3 contactVelocityB = add(wxrb, vB.lin);
+                    V3 contactVelocityDifference = sub(contactVelocityA, contactVelocityB);
+                    estimatedDepthChangeVelocity = dot(n, contactVelocityDifference);
+                } else {
+                    estimatedDepthChangeVelocity = dot(n, contactVelocityA);
+                }
+                C::depth(p, i) = C::depth(p, i) - estimatedDepthChangeVelocity * dt;
+            }
+        }
+    }
+    template <class G> BD_FN void warmStart(const Inertia& iA, const Inertia& iB, float* p, float* a, int count, BodyVel& vA, BodyVel& vB, G&& gate) {
+        V3 n = C::normal(p);
+        V3 x, z;
+        buildOrthonormalBasis(n, x, z);
+        V3 centerA = centerOf(p, count);
+        V3 centerB = TwoBody ? sub(centerA, C::offsetB(p)) : V3{0, 0, 0};
+        TJ j = C::tangentJacobians(x, z, centerA, centerB);
+        V3 angularA[4], angularB[4];
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {
+            V3 oA = C::offsetA(p, i);
+            V3 oB = TwoBody ? sub(oA, C::offsetB(p)) : V3{0, 0, 0};
+            angularA[i] = cross(oA, n);
+            angularB[i] = TwoBody ? cross(n, oB) : V3{0, 0, 0};
+        }
+        BD_GATE(vA, vB, j, angularA, angularB);
+        C::tangentApply(j, iA, iB, V2{a[0], a[1]}, vA, vB);
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { if (i < count) C::penApply(iA, iB, n, angularA[i], angularB[i], a[2 + i], vA, vB); }
+        C::twistApply(n, iA, iB, a[6], vA, vB);
+    }
+    template <class G> BD_FN void solve(const Inertia& iA, const Inertia& iB, float dt, float inverseDt, float* p, float* a, int count, BodyVel& vA, BodyVel& vB, G&& gate) {
+        float posErrToVel, effMassCFMScale, softnessImpulseScale;
+        computeSpringiness(C::springFreq(p), C::springDamp(p), dt, posErrToVel, effMassCFMScale, softnessImpulseScale);
+        V3 n = C::normal(p);
+        PenRow rows[4];
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {
+            rows[i] = PenRow{{0, 0, 0}, {0, 0, 0}, 0.0f, 0.0f};
+            if (i < count) {
+                V3 oA = C::offsetA(p, i);
+                V3 oB = TwoBody ? sub(oA, C::offsetB(p)) : V3{0, 0, 0};
+                rows[i] = C::penSetup(iA, iB, n, oA, oB, C::depth(p, i), posErrToVel, effMassCFMScale, C::maxRecovery(p), inverseDt);
+            }
+        }
+        V3 x, z;
+        buildOrthonormalBasis(n, x, z);
+        // (1.0f / (float)N) * friction with N = 1 is friction itself, bit for bit: one expression serves all four counts
+        const float inverseCount = count == 1 ? 1.0f : (count == 2 ? (1.0f / 2.0f) : (count == 3 ? (1.0f / 3.0f) : (1.0f / 4.0f)));
+        float premultipliedFrictionCoefficient = inverseCount * C::friction(p);
+        V3 centerA = centerOf(p, count);
+        V3 centerB = TwoBody ? sub(centerA, C::offsetB(p)) : V3{0, 0, 0};
+        TangentSetup tangentSetupData = C::tangentSetup(x, z, centerA, centerB, iA, iB);
+        float twistMass = C::twistEffectiveMass(n, iA, iB);
+        float leverArm[4];
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) leverArm[i] = (i < count) ? distance(centerA, C::offsetA(p, i)) : 0.0f;
+        BD_GATE(vA, vB, rows, tangentSetupData, twistMass, leverArm, premultipliedFrictionCoefficient, softnessImpulseScale);
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { if (i < count) C::penIterate(rows[i], iA, iB, n, softnessImpulseScale, a[2 + i], vA, vB); }
+        float penSum = a[2];
+        _Pragma("unroll") for (int i = 1; i < 4; ++i) penSum = (i < count) ? penSum + a[2 + i] : penSum;
+        float maximumTangentImpulse = premultipliedFrictionCoefficient * penSum;
+        V2 tangent{a[0], a[1]};
+        C::tangentIterate(tangentSetupData, iA, iB, maximumTangentImpulse, tangent, vA, vB);
+        a[0] = tangent.x; a[1] = tangent.y;
+        const float single = C::friction(p) * a[2] * vmax(0.0f, C::depth(p, 0));  // N == 1
+        float s = a[2] * leverArm[0];
+        _Pragma("unroll") for (int i = 1; i < 4; ++i) s = (i < count) ? s + a[2 + i] * leverArm[i] : s;
+        const float maximumTwistImpulse = count == 1 ? single : premultipliedFrictionCoefficient * s;
+        C::twistIterate(n, twistMass, iA, iB, maximumTwistImpulse, a[6], vA, vB);
+    }
+};
+
+// ======================================================================================
 // Nonconvex contact manifolds, N = 2..4 contacts, one or two bodies — ContactNonconvexCommon.cs:177-299.
 // Prestep layout (ContactNonconvexTypes.cs:58-66 two-body, :161-167 one-body): {FrictionCoefficient, AngularFrequency, TwiceDampingRatio,
 // MaximumRecoveryVelocity}, [OffsetB xyz], N x {Offset xyz, Depth, Normal xyz} (NonconvexContactPrestepData, ContactNonconvexCommon.cs:11-16).

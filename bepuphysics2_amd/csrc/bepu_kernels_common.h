@@ -39,8 +39,12 @@ struct ClusterItem {  // <= 64 consecutive constraints of one type batch, all ow
     int batch_npred;                                  // bits 0-15 batch, 16-19 predecessor count, 20-23 cross-pass predecessor count, 24 / 25 overflow flags
     unsigned short pred[kMaxPreds];                   // cluster-relative indices of the items that last touched this item's dynamic bodies (same pass)
     unsigned short xpred[kMaxPreds];                  // for bodies this item touches FIRST in a pass: their last toucher (previous pass); may be the item itself
-    int tb, shape;                                    // host bookkeeping: type batch, bodies | prestep floats << 8 | impulse floats << 16
+    int tb, shape;                                    // host bookkeeping: type batch, bodies | prestep floats << 8 | impulse floats << 16; bits 24-26 of shape: merged manifold groups (below)
 };
+// Merged manifold items (split plans, bepu_cluster_kernel.h run_cluster_fused): (shape >> kItemFuseShift) & 3 = the members that follow a group's leader in the item
+// array, & kItemFuseMember = this item is a member (run by its leader's wave). Structural updates never touch these bits: an item's lane range is fixed at planning.
+constexpr int kItemFuseShift = 24;
+constexpr int kItemFuseMember = 4;
 static_assert(sizeof(ClusterItem) == 64, "ClusterItem is staged in LDS as four 16-byte vectors");
 static_assert(offsetof(ClusterItem, xpred) == offsetof(ClusterItem, pred) + kMaxPreds * sizeof(unsigned short), "wait_predecessors indexes pred[] and xpred[] as one array");
 // LDS words behind the work items: one flag per item, the table batch -> first item (batch_count + 1 entries; the sequential fallback batch is one more batch), the claim counter.

@@ -24,11 +24,13 @@ s.set_cluster_trace(True)
 s.solve(1 / 60, sd, cb)
 passes = int((1 + sd.iterations()).sum())
 tr = s.cluster_trace(passes)
-names = {0: "C1o", 1: "C2o", 2: "C3o", 3: "C4o", 4: "C1", 5: "C2", 6: "C3", 7: "C4", 22: "Ball", 23: "AHinge", 25: "Swing", 26: "TServo", 27: "TLimit", 30: "AMotor", 31: "Weld", 46: "Swivel", 47: "Hinge"}
+# 0x80 / 0x81: a merged manifold group (one-body / two-body Contact1..4 lanes of one batch in one wave); its members leave no record of their own
+names = {0x80: "CMo", 0x81: "CM", 0: "C1o", 1: "C2o", 2: "C3o", 3: "C4o", 4: "C1", 5: "C2", 6: "C3", 7: "C4", 22: "Ball", 23: "AHinge", 25: "Swing", 26: "TServo", 27: "TLimit", 30: "AMotor", 31: "Weld", 46: "Swivel", 47: "Hinge"}
 t_first = int(tr[..., 0][tr[..., 0] > 0].min())
-print(f"items per pass: {tr.shape[1]}, passes: {passes}")
+print(f"items per pass: {tr.shape[1]} ({int((tr[0][:, 0] > 0).sum())} claimed as items of their own), passes: {passes}")
 for p in range(passes):
     rec = tr[p]
+    rec = rec[rec[:, 0] > 0]
     st, en = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
     span = int(en.max() - st.min())
     busy = int((en - st).sum())
@@ -36,8 +38,8 @@ for p in range(passes):
 print(f"frame span (first claim to last publish): {int(tr[..., 1].max()) - t_first} cyc")
 p = int(os.environ.get("PASS", "1"))
 rec = tr[p]
-order = np.argsort(rec[:, 0])
-t0 = rec[:, 0].min()
+order = [k for k in np.argsort(rec[:, 0]) if rec[k, 0] > 0]
+t0 = rec[rec[:, 0] > 0][:, 0].min()
 print(f"--- pass {p} timeline (cycles from pass start): item batch type wave start dur count | loads setup wait tail")
 for k in order:
     meta = int(rec[k, 2])

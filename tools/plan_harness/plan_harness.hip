@@ -6,6 +6,8 @@
 #include "../../bepuphysics2_amd/csrc/bepuhip.hip"
 
 #include <cstdio>
+#include <map>
+#include <tuple>
 
 // the cluster_kernel variants live in their own translation units; nothing is launched here
 #define BEPU_STUB(name) const void* name(bool) { return nullptr; }
@@ -47,31 +49,44 @@ static void simulate(bepuhip_ctx* c, const ClusterPlan& plan) {
             while (cursor[cl] < (size_t)cd.item_count && (plan.items[cd.item_begin + cursor[cl]].batch_npred & 0xFFFF) == batch) {
                 const size_t k = cursor[cl]++;
                 const ClusterItem& it = plan.items[cd.item_begin + k];
-                const HostTypeBatch& tb = c->tbs[it.tb];
+                const int fuse = (it.shape >> kItemFuseShift) & 7;
+                if (fuse & kItemFuseMember) continue;  // run by its leader (merged manifold groups): no wave, no loads of its own
+                const size_t group = 1 + (size_t)(fuse & 3);
                 auto w = std::min_element(wave_free[cl].begin(), wave_free[cl].end());
                 const double claim = std::max(*w, last_claim[cl]);
                 last_claim[cl] = claim;
                 double gate = claim + load, local_wait = gate;
-                const int npred = (it.batch_npred >> 16) & 0xF;
-                if ((it.batch_npred >> 24) & 1) { for (size_t q = 0; q < k; ++q) if ((plan.items[cd.item_begin + q].batch_npred & 0xFFFF) < batch) gate = std::max(gate, finish[cl][q]); }
-                else for (int q = 0; q < npred; ++q) gate = std::max(gate, finish[cl][it.pred[q]]);
+                for (size_t m = 0; m < group; ++m) {
+                    const ClusterItem& mi = plan.items[cd.item_begin + k + m];
+                    const int npred = (mi.batch_npred >> 16) & 0xF;
+                    if ((mi.batch_npred >> 24) & 1) { for (size_t q = 0; q < k; ++q) if ((plan.items[cd.item_begin + q].batch_npred & 0xFFFF) < batch) gate = std::max(gate, finish[cl][q]); }
+                    else for (int q = 0; q < npred; ++q) gate = std::max(gate, finish[cl][mi.pred[q]]);
+                }
                 local_wait = gate;
-                for (int j = it.start; j < it.start + it.count; ++j)
-                    for (int b = 0; b < tb.info.bodies; ++b) {
-                        const int32_t r = tb.refs_soa[(size_t)b * tb.stride + j];
-                        if (r < 0 || (uint32_t)r >= kDynamicLimit || (size_t)r >= plan.shared_info.size() || plan.shared_info[r] == 0) continue;
-                        if (body_cluster[r] >= 0) gate = std::max(gate, body_finish[r] + (body_cluster[r] != (int)cl ? handoff : 0.0));
-                    }
+                for (size_t m = 0; m < group; ++m) {
+                    const ClusterItem& mi = plan.items[cd.item_begin + k + m];
+                    const HostTypeBatch& tb = c->tbs[mi.tb];
+                    for (int j = mi.start; j < mi.start + mi.count; ++j)
+                        for (int b = 0; b < tb.info.bodies; ++b) {
+                            const int32_t r = tb.refs_soa[(size_t)b * tb.stride + j];
+                            if (r < 0 || (uint32_t)r >= kDynamicLimit || (size_t)r >= plan.shared_info.size() || plan.shared_info[r] == 0) continue;
+                            if (body_cluster[r] >= 0) gate = std::max(gate, body_finish[r] + (body_cluster[r] != (int)cl ? handoff : 0.0));
+                        }
+                }
                 waited += gate - (claim + load);
                 waited_remote += gate - local_wait;
                 const double done = gate + apply;
-                for (int j = it.start; j < it.start + it.count; ++j)
-                    for (int b = 0; b < tb.info.bodies; ++b) {
-                        const int32_t r = tb.refs_soa[(size_t)b * tb.stride + j];
-                        if (r < 0 || (uint32_t)r >= kDynamicLimit || (size_t)r >= plan.shared_info.size() || plan.shared_info[r] == 0) continue;
-                        body_finish[r] = done; body_cluster[r] = (int)cl;
-                    }
-                finish[cl][k] = done;
+                for (size_t m = 0; m < group; ++m) {
+                    const ClusterItem& mi = plan.items[cd.item_begin + k + m];
+                    const HostTypeBatch& tb = c->tbs[mi.tb];
+                    for (int j = mi.start; j < mi.start + mi.count; ++j)
+                        for (int b = 0; b < tb.info.bodies; ++b) {
+                            const int32_t r = tb.refs_soa[(size_t)b * tb.stride + j];
+                            if (r < 0 || (uint32_t)r >= kDynamicLimit || (size_t)r >= plan.shared_info.size() || plan.shared_info[r] == 0) continue;
+                            body_finish[r] = done; body_cluster[r] = (int)cl;
+                        }
+                    finish[cl][k + m] = done;
+                }
                 *w = done;
                 makespan = std::max(makespan, done);
                 ++items;
@@ -97,10 +112,27 @@ static int validate(bepuhip_ctx* c, const ClusterPlan& plan) {
         const int32_t* slots = plan.cluster_bodies.data() + cd.body_begin;
         int previous_batch = -1;
         std::vector<int> last_batch_of_slot(cd.slot_count, -1);
+        int members_due = 0, group_lanes = 0, group_family = -1, group_batch = -1;  // merged manifold groups (kItemFuseShift): a leader, then exactly its members
         for (int k = 0; k < cd.item_count; ++k) {
             const ClusterItem& it = plan.items[cd.item_begin + k];
             const HostTypeBatch& tb = c->tbs[it.tb];
             const int batch = it.batch_npred & 0xFFFF, nb = tb.info.bodies, rows = (nb + 1) / 2;
+            {
+                const int fuse = (it.shape >> kItemFuseShift) & 7;
+                const bool member = (fuse & kItemFuseMember) != 0;
+                if (member != (members_due > 0)) fail("group member without a leader, or a leader short of members", (long)cl, k, fuse);
+                if (member) {
+                    --members_due; group_lanes += it.count;
+                    if (fuse & 3) fail("a member that leads", (long)cl, k, fuse);
+                    if (it.type_id > 7 || it.type_id / 4 != group_family || batch != group_batch) fail("group member of another family or batch", (long)cl, k, it.type_id);
+                    if (group_lanes > 64) fail("a group with more than 64 lanes", (long)cl, k, group_lanes);
+                } else if (fuse & 3) {
+                    if (!plan.shared) fail("a group outside a split plan", (long)cl, k, fuse);
+                    if (it.type_id > 7) fail("a group led by a type that is no convex manifold", (long)cl, k, it.type_id);
+                    members_due = fuse & 3; group_lanes = it.count; group_family = it.type_id / 4; group_batch = batch;
+                }
+                if (k + 1 == cd.item_count && members_due > 0) fail("a group runs past the cluster's items", (long)cl, k, members_due);
+            }
             if (batch < previous_batch) fail("items out of batch order", (long)cl, k, batch);
             previous_batch = batch;
             if (batch != tb.batch || it.type_id != tb.type_id || it.stride != tb.stride || it.count < 1 || it.count > 64) fail("item header", (long)cl, k, it.tb);
@@ -421,6 +453,24 @@ int main(int argc, char** argv) {
         printf("rows %.2f ms, plan %.2f ms | enabled %d shared %d clusters %zu items %zu (max %d per cluster) max slots %d planes %d shared bodies %zu | digest %016llx\n",
                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), (int)plan.enabled, (int)plan.shared, plan.clusters.size(),
                plan.items.size(), plan.max_items, plan.max_slots, plan.planes, shared, (unsigned long long)h);
+        {
+            size_t leaders = 0, members = 0;
+            for (auto& it : plan.items) { const int fuse = (it.shape >> kItemFuseShift) & 7; leaders += (fuse & 3) != 0; members += (fuse & kItemFuseMember) != 0; }
+            {   // the floor: every (cluster, batch, family)'s lanes cut into waves of 64
+                std::map<std::tuple<int, int, int>, int> lanes;
+                size_t other = 0;
+                for (size_t cl = 0; cl < plan.clusters.size(); ++cl)
+                    for (int k = 0; k < plan.clusters[cl].item_count; ++k) {
+                        const ClusterItem& it = plan.items[plan.clusters[cl].item_begin + k];
+                        if (it.type_id > 7) { ++other; continue; }
+                        lanes[{(int)cl, it.batch_npred & 0xFFFF, it.type_id / 4}] += it.count;
+                    }
+                size_t floor_items = other;
+                for (auto& kv : lanes) floor_items += (kv.second + 63) / 64;
+                printf("lane floor: %zu claimable items per pass if every family's lanes of a batch were cut into full waves\n", floor_items);
+            }
+            if (leaders) printf("merged manifold groups: %zu groups take %zu typed items: %zu claimable items per pass instead of %zu\n", leaders, leaders + members, plan.items.size() - members, plan.items.size());
+        }
         if (getenv("PLAN_DUMP_ITEMS") && plan.enabled) {  // every cluster's work items with their predecessor lists and the bodies they touch
             for (size_t cl = 0; cl < plan.clusters.size(); ++cl) {
                 const ClusterDesc& cd = plan.clusters[cl];
