@@ -120,6 +120,10 @@ struct HostTypeBatch {
     std::vector<int32_t> plan_lrefs;   // split plans: 32-bit local references (slot | kLrefShared | kinematic << 30) and rank words per device slot, the inputs of
     std::vector<uint32_t> plan_ranks;  // the predecessor rule (bepu_cluster_plan.h), kept for the structural updates
     int device_extent() const { return slots > 0 ? slots : count; }
+    // structural updates since the last flush (bepu_soft_updates.h): device slot -> its record in ctx.soft_records (-1: untouched; sized on first use), and the
+    // caller's indices whose device slot changed (the device copy of `inv` is patched from `inv` itself at the flush)
+    std::vector<int32_t> soft_record_of;
+    std::vector<int32_t> soft_dirty_indices;
     std::vector<int32_t> lrefs_soa; // cluster path: local (LDS) body indices
     std::vector<int32_t> refs_soa;
     std::vector<float> prestep_soa, accum_soa;  // only with ctx.host_values (the offline plan harness): host staging until the plan has permuted them
@@ -198,10 +202,16 @@ struct bepuhip_ctx {
     std::vector<ClusterItem> items_host;         // the plan's work items (the predecessor lists of a cluster that received a constraint are replaced by batch-level waits)
     std::vector<ClusterDesc> clusters_host;
     std::vector<uint8_t> cluster_degraded;
-    struct SoftSlot { bool live; std::vector<uint32_t> payload; };  // final state of a device slot touched since the last flush (payload: refs, packed local refs, prestep)
-    struct PairHash { size_t operator()(const std::pair<int, int>& p) const { return std::hash<uint64_t>()(((uint64_t)(uint32_t)p.first << 32) | (uint32_t)p.second); } };
-    std::unordered_map<std::pair<int, int>, SoftSlot, PairHash> soft_slots;  // (type batch ordinal, device slot)
-    std::unordered_map<std::pair<int, int>, int, PairHash> soft_index;       // (type batch ordinal, caller's index) -> device slot
+    // Final state of every device slot touched since the last flush: flat tables (round 5; hash maps keyed by (type batch, slot) with a vector per entry until then:
+    // two node allocations per operation). A slot touched again overwrites its record; the payload words (whole-island plans: references, packed local references,
+    // prestep lane; split plans: the prestep lane) live in one pool.
+    struct SoftSlotRecord { int32_t tb, slot; uint32_t live, payload_at, payload_words; };
+    std::vector<SoftSlotRecord> soft_records;
+    std::vector<uint32_t> soft_payload;
+    bool soft_index_dirty = false;               // some type batch has entries in soft_dirty_indices
+    // The flush's transfer: one pinned staging buffer, one device buffer, both kept (round 5; a hipMalloc / hipFree pair and three pageable copies per flush until then)
+    char* h_flush = nullptr; char* d_flush = nullptr;
+    size_t h_flush_bytes = 0, d_flush_bytes = 0;
     std::vector<int32_t> soft_orphans;           // bodies whose constraint count reached zero since the last flush
     bool soft_items_dirty = false;
     int64_t soft_adds = 0, soft_removes = 0;     // since the upload (diagnostics)
@@ -217,7 +227,8 @@ struct bepuhip_ctx {
     std::vector<size_t> split_visit;                                  // order in which the type batches become a cluster's items
     struct SplitApp { int32_t tb, slot, k; };
     std::vector<std::vector<SplitApp>> body_apps;
-    std::unordered_set<int32_t> split_rerank;
+    std::vector<uint8_t> split_rerank_flag;      // shared bodies whose applications changed since the last flush: re-ranked there (flag by body, and the list of flagged bodies)
+    std::vector<int32_t> split_rerank_list;
     // A word of the split plan's device tables that differs from its host mirror until the next flush writes it (the VALUE is read from the mirror then: a slot may be
     // freed and taken again between the change and the flush). table: 0 constraint slab (both copies; tb / slot / row name the word), 1 shared_info, 2 cluster_bodies.
     struct WordPatch { int table; size_t index; int32_t tb, slot, row; };
@@ -362,5 +373,5 @@ static void free_constraints(bepuhip_ctx* c) {
     c->inc_blocks = 0; c->inc_tb_count = 0; c->total_constraints = 0; c->slab_words = 0; c->referenced_bodies = 0;
     c->built = false;
     c->pending_ops.clear(); c->pending_payload.clear(); c->structure_dirty = false; c->requirk_stale = false;
-    c->soft_ok = false; c->soft_split = false; c->clustered_dynamic_host.clear(); c->clustered_position.clear(); c->clustered_dynamic_capacity = 0; c->free_slots_ready = false; c->body_moves.clear(); c->kinlist_host.clear(); c->kin_uses.clear(); c->kin_touched.clear(); c->kin_uses_ready = false; c->cluster_free_slots.clear(); c->cluster_extra_uses.clear(); c->body_apps.clear(); c->split_rerank.clear(); c->split_patches.clear(); c->soft_slots.clear(); c->soft_index.clear(); c->soft_orphans.clear(); c->soft_items_dirty = false; c->items_host.clear(); c->clusters_host.clear(); c->cluster_degraded.clear();
+    c->soft_ok = false; c->soft_split = false; c->clustered_dynamic_host.clear(); c->clustered_position.clear(); c->clustered_dynamic_capacity = 0; c->free_slots_ready = false; c->body_moves.clear(); c->kinlist_host.clear(); c->kin_uses.clear(); c->kin_touched.clear(); c->kin_uses_ready = false; c->cluster_free_slots.clear(); c->cluster_extra_uses.clear(); c->body_apps.clear(); c->split_rerank_flag.clear(); c->split_rerank_list.clear(); c->split_patches.clear(); c->soft_records.clear(); c->soft_payload.clear(); c->soft_index_dirty = false; c->soft_orphans.clear(); c->soft_items_dirty = false; c->items_host.clear(); c->clusters_host.clear(); c->cluster_degraded.clear();
 }

@@ -64,10 +64,84 @@ static bool soft_update_kinlist(bepuhip_ctx* c) {
     return changed;
 }
 
+// ---- what the structural calls note for the next flush (flat tables, see bepuhip_ctx::SoftSlotRecord) ----
+static void soft_note_slot(bepuhip_ctx* c, int t, int d, bool live, const uint32_t* words, size_t count) {
+    HostTypeBatch& tb = c->tbs[t];
+    if (tb.soft_record_of.size() < (size_t)tb.slots) tb.soft_record_of.assign((size_t)tb.slots, -1);
+    int32_t& at = tb.soft_record_of[d];
+    if (at < 0) { at = (int32_t)c->soft_records.size(); c->soft_records.push_back({t, d, 0u, 0u, 0u}); }
+    bepuhip_ctx::SoftSlotRecord& record = c->soft_records[at];
+    record.live = live ? 1u : 0u; record.payload_at = (uint32_t)c->soft_payload.size(); record.payload_words = (uint32_t)count;
+    c->soft_payload.insert(c->soft_payload.end(), words, words + count);
+}
+static bool soft_slot_noted(const bepuhip_ctx* c, int t, int d) {
+    const HostTypeBatch& tb = c->tbs[t];
+    return (size_t)d < tb.soft_record_of.size() && tb.soft_record_of[d] >= 0;
+}
+static void soft_note_index(bepuhip_ctx* c, HostTypeBatch* tb, int index) { tb->soft_dirty_indices.push_back(index); c->soft_index_dirty = true; }
+static void soft_clear_notes(bepuhip_ctx* c) {
+    for (auto& record : c->soft_records) c->tbs[record.tb].soft_record_of[record.slot] = -1;
+    c->soft_records.clear(); c->soft_payload.clear();
+    if (c->soft_index_dirty) { for (auto& tb : c->tbs) tb.soft_dirty_indices.clear(); c->soft_index_dirty = false; }
+}
+static void split_note_rerank(bepuhip_ctx* c, int32_t body) {
+    if (c->split_rerank_flag.size() <= (size_t)body) c->split_rerank_flag.resize((size_t)body + 1, 0);
+    if (!c->split_rerank_flag[body]) { c->split_rerank_flag[body] = 1; c->split_rerank_list.push_back(body); }
+}
+
+// ---- prefetching for a table of operations (bepuhip_apply_structural_ops) ----
+// A frame's structural operations are spread over the scene (every hundredth contact of a pile): each one touches twenty-odd cache lines of mirrors no earlier one
+// touched — the caller's index -> device slot, the slot's references / local references / rank words, its bodies' cluster, degree, batch mask, application list —
+// and the chain index -> slot -> body -> list is serial. With the whole table in hand the lines of the operations ahead are asked for while the current one runs,
+// one link of the chain per stage. Hints only: everything is bounds-checked against the state of the moment, nothing is dereferenced that a later operation may free.
+static inline void soft_prefetch_line(const void* p) { __builtin_prefetch(p, 0, 1); }
+static inline void soft_prefetch_body(const bepuhip_ctx* c, int32_t r) {
+    if (r < 0 || (uint32_t)r >= kDynamicLimit || (size_t)r >= c->body_cluster.size()) return;
+    soft_prefetch_line(&c->body_cluster[r]); soft_prefetch_line(&c->body_lref[r]);
+    if ((size_t)r < c->body_degree.size()) { soft_prefetch_line(&c->body_degree[r]); soft_prefetch_line(&c->body_batches[r]); }
+    if ((size_t)r < c->split_shared.size()) soft_prefetch_line(&c->split_shared[r]);
+    if ((size_t)r < c->body_apps.size()) soft_prefetch_line(&c->body_apps[r]);
+}
+static inline void soft_prefetch_remove(const bepuhip_ctx* c, const HostTypeBatch* tb, int index, int stage) {
+    if (!tb || tb->slots == 0 || index < 0 || (size_t)index >= tb->inv.size()) return;
+    if (stage == 0) { soft_prefetch_line(&tb->inv[index]); return; }
+    const int d = tb->inv[index];
+    if (d < 0 || d >= tb->slots) return;
+    if (stage == 1) {
+        soft_prefetch_line(&tb->perm[d]);
+        if ((size_t)d < tb->soft_record_of.size()) soft_prefetch_line(&tb->soft_record_of[d]);
+        for (int k = 0; k < tb->info.bodies; ++k) {
+            soft_prefetch_line(&tb->dev_refs[(size_t)k * tb->stride + d]);
+            if (!tb->plan_lrefs.empty()) { soft_prefetch_line(&tb->plan_lrefs[(size_t)k * tb->stride + d]); soft_prefetch_line(&tb->plan_ranks[(size_t)k * tb->stride + d]); }
+        }
+        return;
+    }
+    for (int k = 0; k < tb->info.bodies; ++k) {
+        const int32_t r = tb->dev_refs[(size_t)k * tb->stride + d];
+        soft_prefetch_body(c, r);
+        if (stage == 3 && r >= 0 && (uint32_t)r < kDynamicLimit && (size_t)r < c->body_apps.size() && !c->body_apps[r].empty()) soft_prefetch_line(c->body_apps[r].data());
+    }
+}
+static inline void soft_prefetch_add(const bepuhip_ctx* c, const HostTypeBatch* tb, const int32_t* refs, int stage) {
+    if (!tb || tb->slots == 0) return;
+    for (int k = 0; k < tb->info.bodies; ++k) {
+        const int32_t r = refs[k];
+        if (stage == 0) { soft_prefetch_body(c, r); continue; }
+        if (r < 0 || (uint32_t)r >= kDynamicLimit || (size_t)r >= c->body_cluster.size()) continue;
+        if ((size_t)r < c->body_apps.size() && !c->body_apps[r].empty()) soft_prefetch_line(c->body_apps[r].data());
+        const int cl = c->body_cluster[r];
+        if (cl < 0 || (size_t)cl + 1 >= tb->seg_begin.size()) continue;
+        // the cluster's segment of the type batch: where the free slot is looked for (live slots first, free ones behind them: the tail of the segment)
+        const int begin = tb->seg_begin[cl], end = tb->seg_begin[cl + 1];
+        for (int at = begin; at < end; at += 16) soft_prefetch_line(&tb->perm[at]);
+    }
+}
+
 static void soft_setup(bepuhip_ctx* c, ClusterPlan& plan) {
     c->soft_ok = false; c->soft_split = false;
-    c->soft_slots.clear(); c->soft_index.clear(); c->soft_items_dirty = false; c->soft_adds = c->soft_removes = 0;
-    c->body_apps.clear(); c->split_rerank.clear(); c->split_patches.clear();
+    c->soft_records.clear(); c->soft_payload.clear(); c->soft_index_dirty = false; c->soft_items_dirty = false; c->soft_adds = c->soft_removes = 0;
+    for (auto& tb : c->tbs) { tb.soft_record_of.clear(); tb.soft_dirty_indices.clear(); }
+    c->body_apps.clear(); c->split_rerank_flag.clear(); c->split_rerank_list.clear(); c->split_patches.clear();
     c->kinlist_host = plan.kinlist; c->kin_uses.clear(); c->kin_touched.clear(); c->kin_uses_ready = false;
     c->free_slots_ready = false; c->cluster_free_slots.clear(); c->body_moves.clear();
     if (!plan.enabled || env_int("BEPUHIP_NO_SOFT_UPDATES", 0)) return;
@@ -235,7 +309,7 @@ static bool soft_move_body(bepuhip_ctx* c, int32_t from, int32_t to, bool kinema
             c->split_patches.push_back({1, (size_t)from, -1, 0, 0});  // degrees in shared_info (read from body_apps at the flush)
             c->split_patches.push_back({1, (size_t)to, -1, 0, 0});
         }
-        if (c->split_rerank.erase(from)) c->split_rerank.insert(to);
+        if ((size_t)from < c->split_rerank_flag.size() && c->split_rerank_flag[from]) { c->split_rerank_flag[from] = 0; split_note_rerank(c, to); }  // (the list keeps `from`: skipped at the flush, its flag is down)
     }
     soft_patch_slot_table(c, cl, slot, entry);
     soft_clustered_positions(c);
@@ -271,7 +345,7 @@ static bool soft_swap(bepuhip_ctx* c, HostTypeBatch* tb, int a, int b) {
     const int da = tb->inv[a], db = tb->inv[b];
     tb->inv[a] = db; tb->inv[b] = da;
     tb->perm[db] = a; tb->perm[da] = b;
-    c->soft_index[{t, a}] = db; c->soft_index[{t, b}] = da;
+    soft_note_index(c, tb, a); soft_note_index(c, tb, b);
     return true;
 }
 
@@ -297,12 +371,11 @@ static bool soft_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index) {
         r = -1;
     }
     tb->perm[d] = -1;
-    c->soft_slots[{t, d}] = bepuhip_ctx::SoftSlot{false, {}};
+    soft_note_slot(c, t, d, false, nullptr, 0);
     if (index != last) {  // TypeProcessor.Move (:578-592): the last constraint takes the removed one's index; on the device it stays where it is
         tb->inv[index] = dl; tb->perm[dl] = index;
-        c->soft_index[{t, index}] = dl;
+        soft_note_index(c, tb, index);
     }
-    c->soft_index.erase({t, last});
     tb->inv.pop_back();
     tb->count = last;
     ++c->soft_removes;
@@ -384,21 +457,21 @@ static bool soft_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, con
     int d = -1;
     for (int s = tb->seg_begin[cl]; s < tb->seg_begin[cl + 1] && d < 0; ++s) if (tb->perm[s] < 0) d = s;
     if (d < 0) return soft_refuse("no free device slot in the cluster's segment of the type batch");
-    bepuhip_ctx::SoftSlot slot{true, {}};
-    slot.payload.reserve(nb + 1 + tb->info.prestep);
+    uint32_t words[2 + 1 + 64];  // references, the packed local references, the prestep lane (the widest type, Contact4Nonconvex, has 35 prestep floats)
+    size_t nwords = 0;
     soft_ensure_kin_uses(c);
     for (int k = 0; k < nb; ++k) {
-        slot.payload.push_back((uint32_t)refs[k]);
+        words[nwords++] = (uint32_t)refs[k];
         tb->dev_refs[(size_t)k * tb->stride + d] = refs[k];
         soft_kinematic_reference(c, refs[k], +1);
         if ((uint32_t)refs[k] < kDynamicLimit) { ++c->body_degree[refs[k]]; if (tb->batch < 64) c->body_batches[refs[k]] |= 1ull << tb->batch; }
     }
-    slot.payload.push_back(halves[0] | (halves[1] << 16));
-    for (int f = 0; f < tb->info.prestep; ++f) { uint32_t w; memcpy(&w, &prestep[f], 4); slot.payload.push_back(w); }
-    c->soft_slots[{t, d}] = std::move(slot);
+    words[nwords++] = halves[0] | (halves[1] << 16);
+    for (int f = 0; f < tb->info.prestep; ++f) { uint32_t w; memcpy(&w, &prestep[f], 4); words[nwords++] = w; }
+    soft_note_slot(c, t, d, true, words, nwords);
     tb->perm[d] = tb->count;
     tb->inv.push_back(d);
-    c->soft_index[{t, tb->count}] = d;
+    soft_note_index(c, tb, tb->count);
     tb->count += 1;
     c->cluster_degraded[cl] = 1;  // its predecessor lists no longer describe it: rebuilt when the updates are flushed (soft_rebuild_items)
     c->soft_items_dirty = true;
@@ -557,16 +630,15 @@ static bool split_remove(bepuhip_ctx* c, HostTypeBatch* tb, int index) {
             for (size_t q = 0; q < apps.size(); ++q) if (apps[q].tb == t && apps[q].slot == d) { apps.erase(apps.begin() + q); break; }
             if (tb->batch < 64) c->body_batches[r] &= ~(1ull << tb->batch);
             if (--c->body_degree[r] == 0) c->soft_orphans.push_back(r);
-            if (c->split_shared[r]) c->split_rerank.insert(r);
+            if (c->split_shared[r]) split_note_rerank(c, r);
         }
         r = -1;
         tb->plan_lrefs[(size_t)k * tb->stride + d] = kPlanDeadLref;
         tb->plan_ranks[(size_t)k * tb->stride + d] = 0u;
     }
     tb->perm[d] = -1;
-    c->soft_slots[{t, d}] = bepuhip_ctx::SoftSlot{false, {}};
-    if (index != last) { tb->inv[index] = dl; tb->perm[dl] = index; c->soft_index[{t, index}] = dl; }
-    c->soft_index.erase({t, last});
+    soft_note_slot(c, t, d, false, nullptr, 0);
+    if (index != last) { tb->inv[index] = dl; tb->perm[dl] = index; soft_note_index(c, tb, index); }
     tb->inv.pop_back();
     tb->count = last;
     ++c->soft_removes;
@@ -689,11 +761,11 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
             }
             lrefs[k] = slot | (int)kLrefShared;
         }
-        if (c->split_shared[r]) c->split_rerank.insert(r);
+        if (c->split_shared[r]) split_note_rerank(c, r);
     }
-    bepuhip_ctx::SoftSlot slot{true, {}};  // the prestep lane; references, local references and rank words are taken from the mirrors when the updates are flushed
-    slot.payload.reserve(tb->info.prestep);
-    for (int f = 0; f < tb->info.prestep; ++f) { uint32_t w; memcpy(&w, &prestep[f], 4); slot.payload.push_back(w); }
+    // the prestep lane; references, local references and rank words are taken from the mirrors when the updates are flushed
+    static_assert(sizeof(float) == sizeof(uint32_t), "the prestep lane is noted as words");
+    soft_note_slot(c, t, d, true, reinterpret_cast<const uint32_t*>(prestep), (size_t)tb->info.prestep);
     soft_ensure_kin_uses(c);
     for (int k = 0; k < nb; ++k) {
         tb->dev_refs[(size_t)k * tb->stride + d] = refs[k];
@@ -708,10 +780,9 @@ static bool split_add(bepuhip_ctx* c, HostTypeBatch* tb, const int32_t* refs, co
             if (tb->batch < 64) c->body_batches[refs[k]] |= 1ull << tb->batch;
         }
     }
-    c->soft_slots[{t, d}] = std::move(slot);
     tb->perm[d] = tb->count;
     tb->inv.push_back(d);
-    c->soft_index[{t, tb->count}] = d;
+    soft_note_index(c, tb, tb->count);
     tb->count += 1;
     split_mark_cluster(c, cl);
     ++c->soft_adds;
@@ -792,11 +863,21 @@ static void split_rebuild_items(bepuhip_ctx* c, int cl) {
 struct ResolvedWord { int table; size_t index; uint32_t value; };
 static std::vector<ResolvedWord> split_resolve_patches(bepuhip_ctx* c) {
     std::vector<ResolvedWord> words;
-    std::unordered_set<uint64_t> seen;
+    words.reserve(c->split_patches.size());
+    // every word once: an open-addressing set over the patch keys (a node-based set allocated per patch: a third of the listing's time on the pile's churn)
+    size_t capacity = 64;
+    while (capacity < c->split_patches.size() * 2) capacity *= 2;
+    std::vector<uint64_t> seen(capacity, ~0ull);
+    auto first_time = [&](uint64_t key) {
+        size_t at = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & (capacity - 1);
+        while (seen[at] != ~0ull) { if (seen[at] == key) return false; at = (at + 1) & (capacity - 1); }
+        seen[at] = key;
+        return true;
+    };
     for (auto& wp : c->split_patches) {
-        if (!seen.insert(((uint64_t)wp.table << 60) | (uint64_t)wp.index).second) continue;
+        if (!first_time(((uint64_t)wp.table << 60) | (uint64_t)wp.index)) continue;
         if (wp.table == 0) {
-            if (c->soft_slots.count({wp.tb, wp.slot})) continue;
+            if (soft_slot_noted(c, wp.tb, wp.slot)) continue;
             const HostTypeBatch& tb = c->tbs[wp.tb];
             const int lref_rows = (tb.info.bodies + 1) / 2;
             words.push_back({0, wp.index, wp.row < lref_rows ? split_packed_lrefs(tb, wp.slot, wp.row) : tb.plan_ranks[(size_t)(wp.row - lref_rows) * tb.stride + wp.slot]});
@@ -813,9 +894,11 @@ static std::vector<ResolvedWord> split_resolve_patches(bepuhip_ctx* c) {
 // The host half: ranks of the shared bodies whose applications changed, predecessor lists of the clusters that received constraints (after it the mirrors describe the
 // layout the device is about to get; tools/plan_harness validates them without a device).
 static void flush_soft_host(bepuhip_ctx* c) {
-    if (c->soft_split && !c->split_rerank.empty()) {  // every body on its own: host threads, their patches and cluster marks merged afterwards
-        const std::vector<int32_t> bodies(c->split_rerank.begin(), c->split_rerank.end());
-        c->split_rerank.clear();
+    if (c->soft_split && !c->split_rerank_list.empty()) {  // every body on its own: host threads, their patches and cluster marks merged afterwards
+        std::vector<int32_t> bodies;
+        bodies.reserve(c->split_rerank_list.size());
+        for (int32_t body : c->split_rerank_list) if (c->split_rerank_flag[body]) { c->split_rerank_flag[body] = 0; bodies.push_back(body); }  // (a moved body's old index stays listed with its flag down)
+        c->split_rerank_list.clear();
         const bool local_handoff = env_int("BEPUHIP_SPLIT_LOCAL_HANDOFF", 1) != 0;
         const size_t chunk = 256, jobs = (bodies.size() + chunk - 1) / chunk;
         std::vector<std::vector<bepuhip_ctx::WordPatch>> patches(jobs);
@@ -837,7 +920,7 @@ static void flush_soft_host(bepuhip_ctx* c) {
 static int32_t rebuild_flags(bepuhip_ctx* c);
 static int32_t flush_soft(bepuhip_ctx* c) {
     c->body_moves.clear();
-    if (c->soft_slots.empty() && c->soft_index.empty() && !c->soft_items_dirty && c->split_rerank.empty() && c->split_patches.empty() && c->kin_touched.empty() && !c->clustered_dirty &&
+    if (c->soft_records.empty() && !c->soft_index_dirty && !c->soft_items_dirty && c->split_rerank_list.empty() && c->split_patches.empty() && c->kin_touched.empty() && !c->clustered_dirty &&
         !c->kinlist_dirty)
         return BEPUHIP_OK;
     if (c->clustered_dirty) {  // bodies joined or left the plan: the list behind kFlagClustered
@@ -864,25 +947,27 @@ static int32_t flush_soft(bepuhip_ctx* c) {
     const auto t_host = std::chrono::steady_clock::now();
     std::vector<SoftSlotOp> ops;
     std::vector<uint32_t> payload(1, 0u);
-    for (auto& kv : c->soft_slots) {
-        const HostTypeBatch& tb = c->tbs[kv.first.first];
-        const int d = kv.first.second;
+    ops.reserve(c->soft_records.size());
+    payload.reserve(c->soft_payload.size() + c->soft_records.size() * 6 + 1);
+    for (const auto& record : c->soft_records) {
+        const HostTypeBatch& tb = c->tbs[record.tb];
+        const int d = record.slot;
         SoftSlotOp op{(unsigned)tb.refs_off, (unsigned)tb.lrefs_off, (unsigned)tb.prestep_off, (unsigned)tb.accum_off, tb.stride, tb.info.bodies, tb.info.prestep, tb.info.impulse,
-                      d, kv.second.live ? 1 : 0, (unsigned)payload.size(), c->soft_split ? tb.info.bodies : 0};
-        if (c->soft_split && kv.second.live) {  // references, packed local references and rank words as the mirrors hold them now (the re-ranking above included)
+                      d, (int)record.live, (unsigned)payload.size(), c->soft_split ? tb.info.bodies : 0};
+        if (c->soft_split && record.live) {  // references, packed local references and rank words as the mirrors hold them now (the re-ranking above included)
             for (int k = 0; k < tb.info.bodies; ++k) payload.push_back((uint32_t)tb.dev_refs[(size_t)k * tb.stride + d]);
             for (int row = 0; row < (tb.info.bodies + 1) / 2; ++row) payload.push_back(split_packed_lrefs(tb, d, row));
             for (int k = 0; k < tb.info.bodies; ++k) payload.push_back(tb.plan_ranks[(size_t)k * tb.stride + d]);
         }
-        payload.insert(payload.end(), kv.second.payload.begin(), kv.second.payload.end());
+        if (record.live) payload.insert(payload.end(), c->soft_payload.begin() + record.payload_at, c->soft_payload.begin() + record.payload_at + record.payload_words);
         ops.push_back(op);
     }
     std::vector<IndexPatch> patches;
-    for (auto& kv : c->soft_index) {
-        HostTypeBatch& tb = c->tbs[kv.first.first];
-        if (!tb.d_device_index) continue;  // built from `inv` on first use: nothing to patch yet
-        patches.push_back(IndexPatch{tb.d_device_index, kv.first.second, kv.second, 0});
-    }
+    if (c->soft_index_dirty)
+        for (auto& tb : c->tbs) {  // the caller's indices whose device slot changed: the device copy of `inv` follows `inv` (an index beyond the count was removed since)
+            if (!tb.d_device_index) continue;  // built from `inv` on first use: nothing to patch yet
+            for (int32_t index : tb.soft_dirty_indices) if (index < tb.count) patches.push_back(IndexPatch{tb.d_device_index, index, tb.inv[index], 0});
+        }
     for (auto& word : split_resolve_patches(c)) {  // single words of the split plan's tables (rank words, local references, degrees, slot table entries)
         if (word.table == 0) { for (uint32_t* slab : {c->d_slab, c->d_slab0}) if (slab) patches.push_back(IndexPatch{(int*)slab, (int)word.index, (int)word.value, 0}); }
         else if (word.table == 1) patches.push_back(IndexPatch{(int*)c->d_shared_info, (int)word.index, (int)word.value, 0});
@@ -890,30 +975,44 @@ static int32_t flush_soft(bepuhip_ctx* c) {
     }
     c->split_patches.clear();
     const auto t_lists = std::chrono::steady_clock::now();
-    const size_t bytes = ops.size() * sizeof(SoftSlotOp) + payload.size() * 4 + patches.size() * sizeof(IndexPatch) + 64;
-    char* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, bytes));
+    // One transfer: [slot operations][word patches][payload][the work items, if their lists changed], built in pinned memory, one copy, the kernels behind it.
+    const size_t ops_bytes = ops.size() * sizeof(SoftSlotOp), patch_bytes = patches.size() * sizeof(IndexPatch), payload_bytes = payload.size() * 4;
+    const size_t items_bytes = c->soft_items_dirty ? c->items_host.size() * sizeof(ClusterItem) : 0;
+    const size_t table_bytes = (ops_bytes + patch_bytes + payload_bytes + 63) / 64 * 64, bytes = table_bytes + items_bytes;
+    if (bytes > c->h_flush_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->h_flush) hipHostFree(c->h_flush);
+        if (c->d_flush) hipFree(c->d_flush);
+        c->h_flush = nullptr; c->d_flush = nullptr; c->h_flush_bytes = c->d_flush_bytes = 0;
+        const size_t room = std::max(bytes + bytes / 2, (size_t)1 << 20);
+        HIP_TRY(hipHostMalloc((void**)&c->h_flush, room, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void**)&c->d_flush, room));
+        c->h_flush_bytes = c->d_flush_bytes = room;
+    }
+    char* h = c->h_flush;
+    char* d = c->d_flush;
+    if (ops_bytes) memcpy(h, ops.data(), ops_bytes);
+    if (patch_bytes) memcpy(h + ops_bytes, patches.data(), patch_bytes);
+    memcpy(h + ops_bytes + patch_bytes, payload.data(), payload_bytes);
+    if (items_bytes) memcpy(h + table_bytes, c->items_host.data(), items_bytes);
     SoftSlotOp* d_ops = (SoftSlotOp*)d;
-    IndexPatch* d_patches = (IndexPatch*)(d + ops.size() * sizeof(SoftSlotOp));
-    unsigned* d_payload = (unsigned*)(d + ops.size() * sizeof(SoftSlotOp) + patches.size() * sizeof(IndexPatch));
-    if (!ops.empty()) HIP_TRY(hipMemcpyAsync(d_ops, ops.data(), ops.size() * sizeof(SoftSlotOp), hipMemcpyHostToDevice, c->stream));
-    if (!patches.empty()) HIP_TRY(hipMemcpyAsync(d_patches, patches.data(), patches.size() * sizeof(IndexPatch), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_payload, payload.data(), payload.size() * 4, hipMemcpyHostToDevice, c->stream));
+    IndexPatch* d_patches = (IndexPatch*)(d + ops_bytes);
+    unsigned* d_payload = (unsigned*)(d + ops_bytes + patch_bytes);
+    HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
     if (!ops.empty())
         for (uint32_t* slab : {c->d_slab, c->d_slab0})
             if (slab) hipLaunchKernelGGL(apply_soft_slots_kernel, dim3(((int)ops.size() + 63) / 64), dim3(64), 0, c->stream, slab, (const SoftSlotOp*)d_ops, (int)ops.size(), (const unsigned*)d_payload);
     if (!patches.empty()) hipLaunchKernelGGL(patch_index_kernel, dim3(((int)patches.size() + 63) / 64), dim3(64), 0, c->stream, (const IndexPatch*)d_patches, (int)patches.size());
-    if (c->soft_items_dirty) HIP_TRY(hipMemcpyAsync(c->d_items, c->items_host.data(), c->items_host.size() * sizeof(ClusterItem), hipMemcpyHostToDevice, c->stream));
+    if (items_bytes) HIP_TRY(hipMemcpyAsync(c->d_items, d + table_bytes, items_bytes, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    hipFree(d);
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the staging buffer is the next flush's too (and the caller's next structural calls change the mirrors this flush read)
     if (timing) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "bepuhip flush of structural updates: %ld calls took %.3f ms before it; ranks + predecessor lists %.3f ms, %zu slot writes + %zu word patches listed %.3f ms, device %.3f ms\n",
                 c->soft_calls, c->soft_call_ms, ms(t_begin, t_host), ops.size(), patches.size(), ms(t_host, t_lists), ms(t_lists, std::chrono::steady_clock::now()));
         c->soft_calls = 0; c->soft_call_ms = 0.0;
     }
-    c->soft_slots.clear(); c->soft_index.clear(); c->soft_items_dirty = false;
+    soft_clear_notes(c); c->soft_items_dirty = false;
     c->total_constraints = 0;
     for (auto& tb : c->tbs) c->total_constraints += tb.count;
     if (c->soft_flags_stale) { c->soft_flags_stale = false; return rebuild_flags(c); }  // after the slots have their references: the flags are derived from them

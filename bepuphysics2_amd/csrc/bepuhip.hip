@@ -140,6 +140,8 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_owned_mask) hipFree(c->d_owned_mask);
     for (auto& chunk : c->raw_chunks) if (chunk.ptr) hipFree(chunk.ptr);
     if (c->h_staging) hipHostFree(c->h_staging);
+    if (c->h_flush) hipHostFree(c->h_flush);
+    if (c->d_flush) hipFree(c->d_flush);
     for (void* p : c->registered_host) hipHostUnregister(p);
     if (c->d_boundary) hipFree(c->d_boundary);
     if (c->d_boundary_snapshot) hipFree(c->d_boundary_snapshot);
@@ -2234,8 +2236,25 @@ int32_t bepuhip_swap_constraints(bepuhip_ctx* c, int32_t batch, int32_t type_id,
 int32_t bepuhip_apply_structural_ops(bepuhip_ctx* c, const bepuhip_structural_op* ops, int32_t count, const uint32_t* payload, int32_t payload_words, int32_t* failed_op_out) {
     if (failed_op_out) *failed_op_out = -1;
     if (!c || count < 0 || (count > 0 && !ops) || payload_words < 0 || (payload_words > 0 && !payload)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad apply_structural_ops argument");
+    // On an island layout the bookkeeping of one operation is twenty-odd cache lines nothing before it touched (bepu_soft_updates.h, soft_prefetch_*): the lines of the
+    // operations ahead are asked for while the current one runs. Hints only: the type batch is looked up afresh (one entry cached: operations come in runs of a type batch).
+    struct { int batch = -1, type_id = -1; const HostTypeBatch* base = nullptr; HostTypeBatch* tb = nullptr; } ahead_cache;
+    auto prefetch_ahead = [&](int32_t at, int stage) {
+        if (at >= count || !c->soft_ok) return;
+        const bepuhip_structural_op& op = ops[at];
+        if (op.kind != 0 && op.kind != 1) return;
+        if (ahead_cache.batch != op.batch_index || ahead_cache.type_id != op.type_id || ahead_cache.base != c->tbs.data()) {
+            ahead_cache.batch = op.batch_index; ahead_cache.type_id = op.type_id; ahead_cache.base = c->tbs.data(); ahead_cache.tb = find_tb(c, op.batch_index, op.type_id);
+        }
+        HostTypeBatch* tb = ahead_cache.tb;
+        if (!tb) return;
+        if (op.kind == 1) { soft_prefetch_remove(c, tb, op.index, stage); return; }
+        if (stage >= 2 || op.payload_offset < 0 || (int64_t)op.payload_offset + tb->info.bodies > (int64_t)payload_words) return;
+        soft_prefetch_add(c, tb, (const int32_t*)(payload + op.payload_offset), stage);
+    };
     for (int32_t i = 0; i < count; ++i) {
         const bepuhip_structural_op& op = ops[i];
+        prefetch_ahead(i + 12, 0); prefetch_ahead(i + 8, 1); prefetch_ahead(i + 5, 2); prefetch_ahead(i + 2, 3);
         int32_t st = BEPUHIP_OK;
         switch (op.kind) {
             case 0: {

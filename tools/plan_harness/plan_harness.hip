@@ -235,7 +235,8 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
     if (!c->soft_ok) { printf("churn: the plan takes no structural updates\n"); return 0; }
     // (a whole-island plan keeps no host mirror of its local references: its image is built from what the slot writes carry and checked by the validator alone)
     long calls = 0;
-    double calls_ms = 0.0, flush_ms = 0.0;
+    double calls_ms = 0.0, flush_ms = 0.0, library_ms = 0.0, resolve_ms = 0.0;  // library_ms: inside soft_remove / soft_add alone (the generator's own searches left out)
+    auto timed = [&](auto&& call) { const auto a = std::chrono::steady_clock::now(); const bool ok = call(); library_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); return ok; };
     for (int frame = 0; frame < frames; ++frame) {
         const auto frame_begin = std::chrono::steady_clock::now();
         for (size_t t = 0; t < c->tbs.size(); ++t) {
@@ -245,7 +246,15 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
             const int stride = tb->count / n, first = (frame * 37) % stride;  // every stride-th constraint, another residue every frame: the churn is spread over the scene
             std::vector<std::array<int32_t, 2>> lanes;
             for (int i = 0; i < n; ++i) { const int d = tb->inv[first + i * stride]; lanes.push_back({tb->dev_refs[d], tb->dev_refs[(size_t)tb->stride + d]}); }
-            for (int i = n - 1; i >= 0; --i, ++calls) if (!soft_remove(c, tb, first + i * stride)) { printf("churn: frame %d, removal refused\n", frame); return 0; }
+            const bool prefetching = getenv("PLAN_CHURN_NO_PREFETCH") == nullptr;  // what bepuhip_apply_structural_ops does with a table of operations
+            for (int i = n - 1; i >= 0; --i, ++calls) if (!timed([&] {
+                    if (prefetching) {
+                        if (i >= 12) soft_prefetch_remove(c, tb, first + (i - 12) * stride, 0);
+                        if (i >= 8) soft_prefetch_remove(c, tb, first + (i - 8) * stride, 1);
+                        if (i >= 5) soft_prefetch_remove(c, tb, first + (i - 5) * stride, 2);
+                        if (i >= 2) soft_prefetch_remove(c, tb, first + (i - 2) * stride, 3);
+                    }
+                    return soft_remove(c, tb, first + i * stride); })) { printf("churn: frame %d, removal refused\n", frame); return 0; }
             std::vector<int> fresh;
             for (int i = 0; i < n; i += every) fresh.push_back(i);
             std::vector<float> prestep(tb->info.prestep, 0.25f);
@@ -263,7 +272,12 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
                     }
                 }
                 bool violation = false;
-                if (!soft_add(c, tb, refs, prestep.data(), &violation)) {
+                if (!timed([&] {
+                        if (prefetching) {  // (the harness decides a lane's second body late: it prefetches for the pair as removed, which most additions are)
+                            if (i + 8 < n) { const int32_t ahead[2] = {lanes[i + 8][0], lanes[i + 8][1]}; soft_prefetch_add(c, tb, ahead, 0); }
+                            if (i + 4 < n) { const int32_t ahead[2] = {lanes[i + 4][0], lanes[i + 4][1]}; soft_prefetch_add(c, tb, ahead, 1); }
+                        }
+                        return soft_add(c, tb, refs, prestep.data(), &violation); })) {
                     for (int k = 0; k < 2; ++k) {
                         if ((uint32_t)refs[k] >= kDynamicLimit) continue;
                         const int home = c->body_cluster[refs[k]];
@@ -339,21 +353,24 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
         const auto f0 = std::chrono::steady_clock::now();
         calls_ms += std::chrono::duration<double, std::milli>(f0 - frame_begin).count();
         flush_soft_host(c);
+        const auto f1 = std::chrono::steady_clock::now();
         std::vector<ResolvedWord> resolved_for_timing = split_resolve_patches(c);  // (the listing half of the flush, timed with it)
         flush_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
+        resolve_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f1).count();
         if (frame < 3) fprintf(stderr, "churn: frame %d, the host half of the flush %.3f ms\n", frame, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count());
         // what flush_soft would send, applied to the image
-        for (auto& kv : c->soft_slots) {
-            const HostTypeBatch& tb = c->tbs[kv.first.first];
-            const int d = kv.first.second, nb = tb.info.bodies, rows = (nb + 1) / 2;
+        for (const auto& record : c->soft_records) {
+            const HostTypeBatch& tb = c->tbs[record.tb];
+            const int d = record.slot, nb = tb.info.bodies, rows = (nb + 1) / 2;
+            const uint32_t* words = c->soft_payload.data() + record.payload_at;
             if (!shared_plan) {  // payload of a live slot: references, the packed local references, the prestep lane
-                for (int k = 0; k < nb; ++k) refs_image[kv.first.first][(size_t)k * tb.stride + d] = kv.second.live ? (int32_t)kv.second.payload[k] : -1;
-                lrefs_image[kv.first.first][d] = kv.second.live ? (int32_t)kv.second.payload[nb] : (int32_t)kLrefDead;
+                for (int k = 0; k < nb; ++k) refs_image[record.tb][(size_t)k * tb.stride + d] = record.live ? (int32_t)words[k] : -1;
+                lrefs_image[record.tb][d] = record.live ? (int32_t)words[nb] : (int32_t)kLrefDead;
                 continue;
             }
-            for (int k = 0; k < nb; ++k) refs_image[kv.first.first][(size_t)k * tb.stride + d] = kv.second.live ? tb.dev_refs[(size_t)k * tb.stride + d] : -1;
-            for (int r = 0; r < rows; ++r) lrefs_image[kv.first.first][(size_t)r * tb.stride + d] = kv.second.live ? (int32_t)split_packed_lrefs(tb, d, r) : (int32_t)kLrefDead;
-            if (kv.second.live) for (int k = 0; k < nb; ++k) lrefs_image[kv.first.first][(size_t)(rows + k) * tb.stride + d] = (int32_t)tb.plan_ranks[(size_t)k * tb.stride + d];
+            for (int k = 0; k < nb; ++k) refs_image[record.tb][(size_t)k * tb.stride + d] = record.live ? tb.dev_refs[(size_t)k * tb.stride + d] : -1;
+            for (int r = 0; r < rows; ++r) lrefs_image[record.tb][(size_t)r * tb.stride + d] = record.live ? (int32_t)split_packed_lrefs(tb, d, r) : (int32_t)kLrefDead;
+            if (record.live) for (int k = 0; k < nb; ++k) lrefs_image[record.tb][(size_t)(rows + k) * tb.stride + d] = (int32_t)tb.plan_ranks[(size_t)k * tb.stride + d];
         }
         for (auto& word : split_resolve_patches(c)) {
             if (word.table == 1) { shared_info[word.index] = word.value; continue; }
@@ -368,7 +385,7 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
             while (t + 1 < c->tbs.size() && c->tbs[t + 1].lrefs_off <= word.index) ++t;
             lrefs_image[t][word.index - c->tbs[t].lrefs_off] = (int32_t)word.value;
         }
-        c->split_patches.clear(); c->soft_slots.clear(); c->soft_index.clear(); c->soft_items_dirty = false;
+        c->split_patches.clear(); soft_clear_notes(c); c->soft_items_dirty = false;
         // (1) image == mirrors
         int differences = 0;
         if (cluster_bodies_image != c->cluster_bodies_host) { ++differences; fprintf(stderr, "churn: frame %d, the slot table's image differs from its mirror\n", frame); }
@@ -395,7 +412,7 @@ static int churn(bepuhip_ctx* c, ClusterPlan& plan, int frames) {
         if (validate(c, now) != 0) { printf("churn: frame %d leaves an invalid plan\n", frame); return 3; }
     }
     size_t live_clusters = c->clusters_host.size();
-    printf("churn: host time per frame: the structural calls (with this harness's generator) %.2f ms, ranks + predecessor lists + word list %.2f ms\n", calls_ms / frames, flush_ms / frames);
+    printf("churn: host time per frame: the structural calls (with this harness's generator) %.2f ms, of which inside soft_remove / soft_add %.2f ms; ranks + predecessor lists + word list %.2f ms (the word list alone %.2f)\n", calls_ms / frames, library_ms / frames, flush_ms / frames, resolve_ms / frames);
     if (body_events) printf("churn: bodies: %ld constraint removals of bodies that left, %ld bodies moved to another index, %ld bodies joined\n", removals, moves, adoptions);
     printf("churn: %d frames, %ld structural calls, still on the plan (%zu clusters)\n", frames, calls, live_clusters);
     return 0;
