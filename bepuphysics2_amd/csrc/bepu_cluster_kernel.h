@@ -487,14 +487,29 @@ __device__ __forceinline__ void touch_code_ahead(const ClusterShared& sh, int la
 
 struct ItemStamps { unsigned long long loaded, pre_gate, post_gate; };  // trace builds only
 
+// Types whose Solve fetches its tangent and twist impulses at the gate (F::lateImpulses: Contact<N, true>, N >= 2, in the 128-VGPR units).
+template <class F, class = void> struct LateImpulses { static constexpr bool value = false; };
+template <class F> struct LateImpulses<F, std::void_t<decltype(F::lateImpulses)>> { static constexpr bool value = F::lateImpulses; };
+__device__ __forceinline__ int fresh_lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }  // not threadIdx.x & 63: nothing the compiler can keep live from earlier
+
 // The gate the cluster path hands to the constraint functions: wait for the item's predecessors, then gather the velocities.
-template <int ACC_A, int ACC_B, int BODIES, bool CROSS, bool TRACE, bool SHARED>
+template <int ACC_A, int ACC_B, int BODIES, bool CROSS, bool TRACE, bool SHARED, int LATE_TWIST_ROW = -1>
 struct ClusterGate {
     static constexpr bool kPin = true;  // the constraint pins its velocity-independent values before calling: they are computed while the predecessors still run
+    static constexpr bool kLateImpulses = LATE_TWIST_ROW >= 0;  // the type's tangent (rows 0, 1) and twist (row LATE_TWIST_ROW) impulses are fetched here, not with the rows
     const ClusterShared& sh; const ClusterItem* it; const ItemHeader& h; int k; unsigned epoch; int ra, rb; DBody& A; DBody& B; ItemStamps& stamps;
     const SharedRef& sa; const SharedRef& sb;
     bool requirk_a, requirk_b;  // kConserving units, warm start of substep 0
+    const unsigned* slab; float* late;  // kLateImpulses: the constraint slab, and where the three values go
+    __device__ __forceinline__ float lateImpulse(int which) const { return late[which]; }
     __device__ __forceinline__ void operator()(BodyVel&, BodyVel&) const {
+        if constexpr (kLateImpulses) {  // asked for now, used behind the penetration rows: the round trip runs under the wait below
+            const int lane = fresh_lane_id();
+            const gfloat* rows = (const gfloat*)(slab + h.accum_off) + (h.start + (lane < h.count ? lane : h.count - 1));
+            late[0] = kRowsNonTemporal ? __builtin_nontemporal_load(&rows[0]) : rows[0];
+            late[1] = kRowsNonTemporal ? __builtin_nontemporal_load(&rows[(size_t)h.stride]) : rows[(size_t)h.stride];
+            late[2] = kRowsNonTemporal ? __builtin_nontemporal_load(&rows[(size_t)LATE_TWIST_ROW * h.stride]) : rows[(size_t)LATE_TWIST_ROW * h.stride];
+        }
         if (TRACE) stamps.pre_gate = __builtin_readcyclecounter();
         jitter_nap(sh, (unsigned)k * 2u + epoch * 0x632BE5ABu);
         wait_predecessors<CROSS>(sh, it, h, k, epoch);
@@ -660,12 +675,15 @@ __device__ BEPU_ITEM_INLINE void run_cluster_constraint(const ClusterShared& sh,
         rank_a = (unsigned)srank[i];
         if (F::bodies == 2) rank_b = (unsigned)srank[(size_t)stride + i];
     }
+    constexpr bool late = LateImpulses<F>::value && STAGE == kStageSolve && !SHARED;  // tangent and twist impulses at the gate (ClusterGate): rows 0, 1 and the last one
+    auto with_the_rows = [](int f) { return !late || (f >= 2 && f < F::impulseFloats - 1); };
+    if (late) { a[0] = a[1] = a[F::impulseFloats - 1] = 0.0f; }
     if (kRowsNonTemporal) {  // per translation unit (BEPU_VARIANT_NT): the constraint rows are read once per pass; see the note on box classes in DESIGN.md 5
         _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = __builtin_nontemporal_load(&prestep[(size_t)f * stride + i]);
-        if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = __builtin_nontemporal_load(&accum[(size_t)f * stride + i]); }
+        if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) if (with_the_rows(f)) a[f] = __builtin_nontemporal_load(&accum[(size_t)f * stride + i]); }
     } else {
         _Pragma("unroll") for (int f = 0; f < F::prestepFloats; ++f) p[f] = prestep[(size_t)f * stride + i];
-        if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) a[f] = accum[(size_t)f * stride + i]; }
+        if (STAGE != kStageIncremental) { _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) if (with_the_rows(f)) a[f] = accum[(size_t)f * stride + i]; }
     }
     if (STAGE != kStageIncremental) touch_code_ahead(sh, lane);
     const int ra = unpack_local_ref(both & 0xFFFFu);
@@ -710,7 +728,8 @@ __device__ BEPU_ITEM_INLINE void run_cluster_constraint(const ClusterShared& sh,
             requirk_b = F::bodies == 2 && (SHARED ? (rank_b & kRankRequirk) != 0 : (((both >> 16) & kLrefRequirk) != 0 && (both & 0x80000000u) == 0));
         }
     }
-    ClusterGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE, SHARED> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps, sa, sb, requirk_a, requirk_b};
+    float late_impulses[3] = {0.0f, 0.0f, 0.0f};
+    ClusterGate<accA, accB, F::bodies, STAGE == kStageSolve, TRACE, SHARED, late ? F::impulseFloats - 1 : -1> gate{sh, it, h, k, epoch, ra, rb, A, B, stamps, sa, sb, requirk_a, requirk_b, slab, late_impulses};
     if (STAGE == kStageWarmStart) F::warmStart(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, p, a, A.vel, B.vel, gate);
     else F::solve(A.pos, A.ori, A.inertia, B.pos, B.ori, B.inertia, dt, inv_dt, p, a, A.vel, B.vel, gate);
     // -1: never stored (same rule as kinematic / empty references). A shared body's velocity goes to the LDS slot only when the next application on it runs in this
@@ -728,7 +747,13 @@ __device__ BEPU_ITEM_INLINE void run_cluster_constraint(const ClusterShared& sh,
     jitter_nap(sh, (unsigned)k * 2u + 1u + epoch * 0x632BE5ABu);
     publish_item(sh.flags + k, epoch);
     __builtin_amdgcn_s_setprio(0);
-    if (STAGE == kStageSolve && active) {  // off the critical path: nothing reads the impulses before the next pass (a barrier away)
+    if constexpr (late) {  // ... from wave-uniform values and the lane id again: the row pointer is not carried through the tail either
+        const int lane_now = fresh_lane_id();
+        if (lane_now < h.count) {
+            gfloat* rows = (gfloat*)(slab + h.accum_off) + (h.start + lane_now);
+            _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) { if (kRowsNonTemporal) __builtin_nontemporal_store(a[f], &rows[(size_t)f * h.stride]); else rows[(size_t)f * h.stride] = a[f]; }
+        }
+    } else if (STAGE == kStageSolve && active) {  // off the critical path: nothing reads the impulses before the next pass (a barrier away)
         _Pragma("unroll") for (int f = 0; f < F::impulseFloats; ++f) { if (kRowsNonTemporal) __builtin_nontemporal_store(a[f], &accum[(size_t)f * stride + i]); else accum[(size_t)f * stride + i] = a[f]; }
     }
 }

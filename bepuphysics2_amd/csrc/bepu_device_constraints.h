@@ -36,8 +36,23 @@ BD_FN bool isContactType(int id) { return id <= kContact4Nonconvex; }
 // {FrictionCoefficient, AngularFrequency, TwiceDampingRatio, MaximumRecoveryVelocity}.
 // Accumulated impulses (:11-99): Tangent xy, Penetration0..N-1, Twist.
 // ======================================================================================
+#ifndef BEPU_LEAN_TANGENT
+#define BEPU_LEAN_TANGENT 0
+#endif
+#ifndef BEPU_LATE_IMPULSES
+#define BEPU_LATE_IMPULSES 0  // 1 (the 128-VGPR cluster units, bepu_cluster_variant.inc): see Contact::lateImpulses
+#endif
+// Gates that can fetch an accumulated impulse when the tail asks for it say so (ClusterGate in the 128-VGPR units); every other gate:
+template <class G, class = void> struct GateFetchesImpulses { static constexpr bool value = false; };
+template <class G> struct GateFetchesImpulses<G, std::void_t<decltype(G::kLateImpulses)>> { static constexpr bool value = G::kLateImpulses; };
 template <int N, bool TwoBody>
 struct Contact {
+    // A two-body manifold with two to four contacts does not fit a 128-register wave: the compiler spills across the gate and reloads in the velocity-dependent tail —
+    // in the committed round-4 build the twist impulse and the second body's local reference, each a memory round trip on the cluster's dependency chain
+    // (profiles/r05_s16_headline_trace*.txt: the Contact4 item that ends every pass of the bench scene spends 7.5 k clocks in its tail with 128 registers, 2.3 k with
+    // 256). The tangent and twist impulses are first used behind all penetration rows: such a type's Solve leaves them in memory until the gate, which asks for them
+    // under the wait for the predecessors (address from wave-uniform values and the lane id: nothing of it is live in front of the gate).
+    static constexpr bool lateImpulses = BEPU_LATE_IMPULSES != 0 && TwoBody && N >= 2;
     static constexpr int bodies = TwoBody ? 2 : 1;
     static constexpr int prestepFloats = 4 * N + (TwoBody ? 10 : 7);
     static constexpr int impulseFloats = N + 3;
@@ -314,12 +329,20 @@ struct Contact {
         float twistMass = twistEffectiveMass(n, iA, iB);
         float leverArm[N];
         if (N > 1) { _Pragma("unroll") for (int i = 0; i < N; ++i) leverArm[i] = distance(centerA, offsetA(p, i)); }
-        BD_GATE(vA, vB, rows, tangentSetupData, twistMass, leverArm, premultipliedFrictionCoefficient, softnessImpulseScale);
+        constexpr bool leanTangent = lateImpulses && GateFetchesImpulses<std::remove_reference_t<G>>::value && BEPU_LEAN_TANGENT;
+        if constexpr (leanTangent) {
+            BD_GATE(vA, vB, rows, x, z, centerA, centerB, tangentSetupData.effectiveMass, twistMass, leverArm, premultipliedFrictionCoefficient, softnessImpulseScale);
+        } else {
+            BD_GATE(vA, vB, rows, tangentSetupData, twistMass, leverArm, premultipliedFrictionCoefficient, softnessImpulseScale);
+        }
         _Pragma("unroll") for (int i = 0; i < N; ++i) penIterate(rows[i], iA, iB, n, softnessImpulseScale, a[2 + i], vA, vB);
         float penSum = a[2];
         _Pragma("unroll") for (int i = 1; i < N; ++i) penSum = penSum + a[2 + i];
         float maximumTangentImpulse = premultipliedFrictionCoefficient * penSum;
+        if constexpr (leanTangent) { pin(x, z, centerA, centerB); tangentSetupData.j = tangentJacobians(x, z, centerA, centerB); }
+        constexpr bool fetched = lateImpulses && GateFetchesImpulses<std::remove_reference_t<G>>::value;  // then a[0], a[1], a[2 + N] arrive through the gate
         V2 tangent{a[0], a[1]};
+        if constexpr (fetched) tangent = V2{gate.lateImpulse(0), gate.lateImpulse(1)};
         tangentIterate(tangentSetupData, iA, iB, maximumTangentImpulse, tangent, vA, vB);
         a[0] = tangent.x; a[1] = tangent.y;
         float maximumTwistImpulse;
@@ -330,6 +353,7 @@ struct Contact {
             _Pragma("unroll") for (int i = 1; i < N; ++i) s = s + a[2 + i] * leverArm[i];
             maximumTwistImpulse = premultipliedFrictionCoefficient * s;
         }
+        if constexpr (fetched) a[2 + N] = gate.lateImpulse(2);
         twistIterate(n, twistMass, iA, iB, maximumTwistImpulse, a[2 + N], vA, vB);
     }
 };
