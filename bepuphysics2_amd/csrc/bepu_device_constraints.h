@@ -36,9 +36,6 @@ BD_FN bool isContactType(int id) { return id <= kContact4Nonconvex; }
 // {FrictionCoefficient, AngularFrequency, TwiceDampingRatio, MaximumRecoveryVelocity}.
 // Accumulated impulses (:11-99): Tangent xy, Penetration0..N-1, Twist.
 // ======================================================================================
-#ifndef BEPU_LEAN_TANGENT
-#define BEPU_LEAN_TANGENT 0
-#endif
 #ifndef BEPU_LATE_IMPULSES
 #define BEPU_LATE_IMPULSES 0  // 1 (the 128-VGPR cluster units, bepu_cluster_variant.inc): see Contact::lateImpulses
 #endif
@@ -329,17 +326,11 @@ struct Contact {
         float twistMass = twistEffectiveMass(n, iA, iB);
         float leverArm[N];
         if (N > 1) { _Pragma("unroll") for (int i = 0; i < N; ++i) leverArm[i] = distance(centerA, offsetA(p, i)); }
-        constexpr bool leanTangent = lateImpulses && GateFetchesImpulses<std::remove_reference_t<G>>::value && BEPU_LEAN_TANGENT;
-        if constexpr (leanTangent) {
-            BD_GATE(vA, vB, rows, x, z, centerA, centerB, tangentSetupData.effectiveMass, twistMass, leverArm, premultipliedFrictionCoefficient, softnessImpulseScale);
-        } else {
-            BD_GATE(vA, vB, rows, tangentSetupData, twistMass, leverArm, premultipliedFrictionCoefficient, softnessImpulseScale);
-        }
+        BD_GATE(vA, vB, rows, tangentSetupData, twistMass, leverArm, premultipliedFrictionCoefficient, softnessImpulseScale);
         _Pragma("unroll") for (int i = 0; i < N; ++i) penIterate(rows[i], iA, iB, n, softnessImpulseScale, a[2 + i], vA, vB);
         float penSum = a[2];
         _Pragma("unroll") for (int i = 1; i < N; ++i) penSum = penSum + a[2 + i];
         float maximumTangentImpulse = premultipliedFrictionCoefficient * penSum;
-        if constexpr (leanTangent) { pin(x, z, centerA, centerB); tangentSetupData.j = tangentJacobians(x, z, centerA, centerB); }
         constexpr bool fetched = lateImpulses && GateFetchesImpulses<std::remove_reference_t<G>>::value;  // then a[0], a[1], a[2 + N] arrive through the gate
         V2 tangent{a[0], a[1]};
         if constexpr (fetched) tangent = V2{gate.lateImpulse(0), gate.lateImpulse(1)};
