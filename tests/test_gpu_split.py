@@ -158,3 +158,38 @@ def test_split_plan_with_the_maximum_substep_count_and_long_iteration_schedules(
     got = pu.run_hip(solver, scene, 1 / 60, sd, cb)
     assert solver.cluster_cycles().size > 1
     _exact(pu.compare_scenes(ref, got))
+
+
+def test_merged_manifold_groups_run_and_change_no_bit(hip_solver_factory, monkeypatch):
+    """Split plans run Contact1-4 lanes of one batch in one wave (merged manifold work items). The pile planned with and without the groups gives the
+    same bits — and the oracle's —, and the per-item timeline of the first cluster shows that groups were claimed (type column 0x80 / 0x81, more than 64 >= lanes > any
+    typed partial item) in one case and none in the other."""
+    monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "12")
+    scene, sd = _host_scene("pile", 8000, 0, 0, 5)
+    cb = PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=2, threads=4)
+    passes = int((1 + sd.iterations()).sum())
+    results, groups = [], []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("BEPUHIP_FUSE_ITEMS", fuse)  # read when the plan is made
+        solver = hip_solver_factory()
+        got = scene.copy()
+        solver.upload(got)
+        solver.solve(1 / 60, sd, cb)
+        solver.set_cluster_trace(True)
+        solver.solve(1 / 60, sd, cb)
+        trace = solver.cluster_trace(passes)
+        solver.set_cluster_trace(False)
+        solver.download(got)
+        assert solver.cluster_cycles().size > 1
+        claimed = trace[0][trace[0][:, 0] > 0]
+        types = (claimed[:, 2].astype(np.int64) >> 8) & 0xFF
+        groups.append(int((types >= 0x80).sum()))
+        if fuse == "1":
+            assert groups[-1] > 0 and len(claimed) < trace.shape[1], (groups, len(claimed), trace.shape)  # members leave no record of their own
+            assert int(claimed[types >= 0x80][:, 3].max()) <= 64
+        else:
+            assert groups[-1] == 0 and len(claimed) == trace.shape[1], (groups, len(claimed), trace.shape)
+        results.append(got)
+        _exact(pu.compare_scenes(ref, got))
+    assert np.array_equal(results[0].bodies.view(np.int32), results[1].bodies.view(np.int32))
