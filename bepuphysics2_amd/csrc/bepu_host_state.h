@@ -18,6 +18,7 @@ const void* bepu_cluster_kernel_hot_1024s(bool trace);   // split-island plans (
 const void* bepu_cluster_kernel_wide_1024s(bool trace);
 const void* bepu_cluster_kernel_hot_512s(bool trace);
 const void* bepu_cluster_kernel_wide_512s(bool trace);
+const void* bepu_cluster_kernel_hot_768s(bool trace);    // split-island plans at 768 threads (twelve waves, 168 VGPRs): plans with many work items per cluster (round 5)
 const void* bepu_cluster_kernel_hot_1024c(bool trace);   // the momentum-conserving angular modes compiled in: whole-island plans at 1024 threads ...
 const void* bepu_cluster_kernel_wide_1024c(bool trace);
 const void* bepu_cluster_kernel_hot_512sc(bool trace);   // ... split-island plans at 512
@@ -44,6 +45,7 @@ static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bo
     // (the non-temporal units carry no traced twin: a traced solve runs the plain-row unit of the same size — same results, the timeline of the default policy)
     if (nt && !trace && !shared && cluster_variant_threads(threads) == 1024) return wide ? bepu_cluster_kernel_wide_1024n(false) : bepu_cluster_kernel_hot_1024n(false);
     if (nt && !trace && shared && cluster_variant_threads(threads) == 512) return wide ? bepu_cluster_kernel_wide_512sn(false) : bepu_cluster_kernel_hot_512sn(false);
+    if (shared && !wide && !nt && threads > 512 && threads <= 768) return bepu_cluster_kernel_hot_768s(trace);
     if (shared) switch (cluster_variant_threads(threads)) {
         case 1024: return wide ? bepu_cluster_kernel_wide_1024s(trace) : bepu_cluster_kernel_hot_1024s(trace);
         default: return wide ? bepu_cluster_kernel_wide_512s(trace) : bepu_cluster_kernel_hot_512s(trace);
@@ -254,6 +256,7 @@ struct bepuhip_ctx {
     uint8_t* d_owned_mask = nullptr;
     int owned_mask_bodies = 0;
     bool clusters_shared = false;    // split-island plan: bodies shared between clusters go through the tables below
+    bool split_twelve_waves = false; // ... whose clusters hand out enough work items per pass to be short of wave time: 768 threads per cluster instead of 512 (enqueue_island_launch)
     float4* d_shared_vel = nullptr;   // per body two records (substep parity) of {linear, event number} {angular, event number}
     unsigned* d_shared_info = nullptr;
     size_t shared_bodies = 0;         // table length (bodies)

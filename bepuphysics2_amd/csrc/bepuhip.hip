@@ -600,6 +600,7 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             for (int tr = 0; tr < 2; ++tr)
                 for (int wide = 0; wide < 2; ++wide)
                     HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(threads, tr != 0, wide != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        for (int tr = 0; tr < 2; ++tr) HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(768, tr != 0, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
         c->group_body_cluster.clear();
         if (c->group_world > 1) c->group_body_cluster = plan.body_cluster;  // (before soft_setup takes the vector: which device owns a body at the end of a step)
         c->owned_mask_bodies = 0;  // (the device copy of the ownership mask follows the plan)
@@ -619,6 +620,12 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         }
         c->row_policy = -1; c->policy_samples = 0;  // a new topology is measured afresh
         c->clusters_shared = plan.shared;
+        {   // Twelve waves instead of eight for split plans that are short of wave time (enqueue_island_launch): judged by the work items a cluster hands out per pass
+            size_t claimable = 0;
+            for (auto& it : plan.items) claimable += ((it.shape >> kItemFuseShift) & kItemFuseMember) == 0;
+            const double per_cluster = plan.clusters.empty() ? 0.0 : (double)claimable / (double)plan.clusters.size();
+            c->split_twelve_waves = plan.shared && getenv("BEPUHIP_SPLIT_THREADS") == nullptr && per_cluster >= (double)env_int("BEPUHIP_SPLIT_TWELVE_WAVES_ITEMS", 56);
+        }
         if (plan.shared) {  // split islands: velocity / event tables of the bodies more than one cluster touches (indexed by body, only the shared ones are used)
             // (long enough for the bodies that have no constraints yet: structural updates may bring them into the plan and share them)
             c->shared_bodies = std::max(plan.shared_info.size(), (size_t)std::max(c->body_count, 0)) + 1024;
@@ -991,8 +998,13 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
         // Scenes with SURVEY 8(f) types take the 512-thread build: at 128 VGPRs per wave the widened types spill hundreds of registers.
         // (the widened variant too: its 1024-thread build spills 700 VGPRs and is still the faster one — 0.222 against 0.325 ms on the bench graph with widened joints
         // on the pool's slow class of box, 0.195 against 0.193 on the fast one, profiles/r03_s13_widened_slowbox.txt: sixteen waves hide what the scratch traffic costs)
-        const int threads = cluster_threads(c);
+        int threads = cluster_threads(c);
         const bool conserving = in->angular_integration_mode != 0;
+        // Split plans with many work items per cluster (the ragdoll crowd: 77 - 96 per pass on eight waves, every wave busy, no item waiting for more than its flag's
+        // round trip: profiles/r05_s20_crowd_trace.txt) run twelve waves per cluster: the 768-thread unit has 168 VGPRs per wave and, since the manifolds' tails were
+        // looked at ("spills on the chain"), no reload in a joint's tail — crowd 0.3784 -> 0.3490 ms same box. Plans with few, heavy items (the pile:
+        // 22 - 33 per pass, on its chain of batch steps) lose 5 % there and keep eight waves. Hot types, nonconserving mode: the units that exist at 768 threads.
+        if (c->split_twelve_waves && c->clusters_shared && threads == kSplitClusterThreads && !conserving && !c->has_widened_types) threads = 768;
         const size_t launch_lds = lds_bytes;
         // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
         // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).

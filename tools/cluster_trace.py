@@ -12,6 +12,8 @@ from bepuphysics2_amd.scene import PoseIntegratorCallbacks
 ragdolls = int(os.environ.get("RAGDOLLS", "15000"))
 if os.environ.get("SCENE", "ragdolls") == "pile":  # BASELINE.json configs[1]: one island, the split plan
     sim = HostSimulation.scene("pile", int(os.environ.get("BOXES", "100000")), 0, 0, 5)
+elif os.environ.get("SCENE") == "crowd":  # the ragdolls lying on each other: one island of 240,000 bodies, the split plan with joints and contacts
+    sim = HostSimulation.scene("ragdoll_tube", ragdolls, 1, 2, 5)
 else:
     sim = HostSimulation.scene("ragdoll_tube", ragdolls, 1, 0, 5)
 scene, sd = sim.export(), sim.solve_description()
