@@ -32,7 +32,7 @@ constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
 // 512-thread workgroups, so that two of them are resident per CU.
 static int cluster_variant_threads(int threads) {
     static const int forced = [] { const char* v = getenv("BEPUHIP_CLUSTER_VARIANT"); return v && *v ? atoi(v) : 0; }();
-    const int fit = threads > 512 ? 1024 : 512;  // (round 5: the 768-thread units, a developer knob that never won a measurement, are gone: 21 translation units instead of 25)
+    const int fit = threads > 512 ? 1024 : 512;  // (round 5: the 768-thread units of round 2 are gone but one — bepu_cluster_hot_768s, the split plans' twelve-wave unit, picked in cluster_kernel_variant)
     return (forced == 1024 || forced == 512) && forced >= fit ? forced : fit;
 }
 // The conserving units exist for the default workgroup sizes only; other sizes (BEPUHIP_CLUSTER_THREADS / BEPUHIP_SPLIT_THREADS) keep such solves on the launch-per-batch schedule.
