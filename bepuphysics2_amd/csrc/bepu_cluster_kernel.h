@@ -164,6 +164,25 @@ __device__ __forceinline__ ItemHeader read_item(const ClusterItem* it) {
     return h;
 }
 
+// The lane id from v_mbcnt instead of threadIdx.x & 63: nothing the compiler could have kept live (or spilled) from earlier — for addresses that are only needed
+// behind a gate (ClusterGate's late impulses).
+__device__ __forceinline__ int fresh_lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// ... and as an asm statement, which the compiler can neither hoist nor share: the builtins are pure, and the 168-VGPR split unit evaluated them once at kernel entry,
+// spilled the result and reloaded it from scratch in front of the merged items' flag publish — a memory round trip between a finished item and its waiters.
+__device__ __forceinline__ int opaque_lane_id() {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+}
+
+// The lane id the gates use. Split units take the opaque form: their waits sit behind thousands of clocks of shared-body code, and a lane id carried from kernel entry is
+// what the 168-VGPR unit spilled and reloaded in front of a poll. The whole-island units keep the plain form (their code is validated as it is).
+#if defined(BEPU_VARIANT_SHARED) && BEPU_VARIANT_SHARED
+__device__ __forceinline__ int gate_lane_id() { return opaque_lane_id(); }
+#else
+__device__ __forceinline__ int gate_lane_id() { return (int)(threadIdx.x & 63); }
+#endif
+
 // Wave-level claim / publish as single opaque instructions sequences: one lane (exec = 1) touches the LDS word, the result is wave-uniform.
 // Written as inline asm so that the compiler sees no lane-0 branch next to the loop back-edge (it otherwise threads the "lane == 0"
 // publish of one iteration into the "lane == 0" claim of the next and builds a divergent loop around convergent operations).
@@ -400,7 +419,7 @@ __device__ __forceinline__ void acquire_shared_one(const SharedTables& st, unsig
 
 // Every item [0, count) of the cluster has completed pass `want` (its flag holds the epoch of the last pass it completed): lane l watches item base + l.
 __device__ __forceinline__ void wait_items(const ClusterShared& sh, int count, unsigned want, int kind, int k) {
-    const int lane = threadIdx.x & 63;
+    const int lane = gate_lane_id();
     for (int base = 0; base < count; base += 64) {
         const bool mine = base + lane < count;
         const volatile lds_u32* word = sh.flags + (mine ? base + lane : k);
@@ -427,7 +446,7 @@ __device__ __forceinline__ void wait_predecessors(const ClusterShared& sh, const
     // adjacent in the item), every other lane a word that always passes. One LDS round trip after the last of them publishes, the wave is through —
     // polled one after the other, each already finished predecessor would still cost its own round trip on the cluster's critical path.
     {
-        const int lane = threadIdx.x & 63;
+        const int lane = gate_lane_id();
         const unsigned short listed = (&it->pred[0])[lane < 2 * kMaxPreds ? lane : 0];
         const bool same = lane < h.npred;
         const bool cross = CROSS && lane >= kMaxPreds && lane < kMaxPreds + h.nxpred;
@@ -490,7 +509,6 @@ struct ItemStamps { unsigned long long loaded, pre_gate, post_gate; };  // trace
 // Types whose Solve fetches its tangent and twist impulses at the gate (F::lateImpulses: Contact<N, true>, N >= 2, in the 128-VGPR units).
 template <class F, class = void> struct LateImpulses { static constexpr bool value = false; };
 template <class F> struct LateImpulses<F, std::void_t<decltype(F::lateImpulses)>> { static constexpr bool value = F::lateImpulses; };
-__device__ __forceinline__ int fresh_lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }  // not threadIdx.x & 63: nothing the compiler can keep live from earlier
 
 // The gate the cluster path hands to the constraint functions: wait for the item's predecessors, then gather the velocities.
 template <int ACC_A, int ACC_B, int BODIES, bool CROSS, bool TRACE, bool SHARED, int LATE_TWIST_ROW = -1>
@@ -773,7 +791,7 @@ constexpr int kTraceFusedType = 0x80;  // the type column of a fused group in th
 template <bool CROSS>
 __device__ __forceinline__ void wait_predecessors_fused(const ClusterShared& sh, const ClusterItem* it, int members, int npred, int nxpred, bool overflow, bool xoverflow, int batch, int k, unsigned epoch) {
     {
-        const int lane = threadIdx.x & 63;
+        const int lane = gate_lane_id();
         const int s = (lane >= 12) + (lane >= 24) + (lane >= 36), q = lane - 12 * s;
         const bool present = lane < 48 && s <= members;
         const unsigned short listed = (&(it + (present ? s : 0))->pred[0])[present ? q : 0];
@@ -804,7 +822,7 @@ __device__ __forceinline__ void wait_predecessors_fused(const ClusterShared& sh,
 __device__ __forceinline__ void publish_items(volatile lds_u32* flag, int n, unsigned epoch) {
     unsigned long long saved;
     const unsigned long long mask = (1ull << n) - 1ull;
-    const unsigned address = lds_address(flag) + 4u * (threadIdx.x & 63u);
+    const unsigned address = lds_address(flag) + 4u * (unsigned)opaque_lane_id();
     asm volatile(
         "s_waitcnt lgkmcnt(0)\n\t"
         "s_mov_b64 %[sv], exec\n\t"
@@ -997,12 +1015,16 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
 // not write accumulated impulses, hence nothing the iteration loads from HBM is in flight. STAGE0 = kStageSolve with solve_items = 0 runs a
 // later iteration on its own (a barrier precedes it: its impulses were stored by the previous one).
 template <int STAGE0, bool TRACE, bool WIDE, bool SHARED>
-__device__ __forceinline__ void run_cluster_sweep(ClusterShared& sh, int item_count, int solve_items, int lane, int wave, unsigned epoch, unsigned claim_base,
+__device__ __forceinline__ void run_cluster_sweep(ClusterShared& sh, int item_count, int solve_items, int kernel_lane, int wave, unsigned epoch, unsigned claim_base,
                                                   unsigned* __restrict__ slab, float dt, float inv_dt, unsigned long long* trace) {
     const unsigned pass_base = sh.passes;
     for (;;) {
         const int v = (int)(claim_next(sh.counter) - claim_base);
         if (v >= item_count + solve_items) break;
+        // Split units: the lane id is made afresh for every item. Carried from kernel entry it is a value the 168-VGPR unit keeps in scratch and reloads at the top of
+        // every item — a memory round trip before the item's row loads are even issued (one scratch_load in every type's path in front of the gate, read in the
+        // disassembly; every item of a plan that is short of wave time pays it).
+        const int lane = SHARED ? gate_lane_id() : kernel_lane;
         const bool second = v >= item_count;
         const int k = second ? v - item_count : v;
         const unsigned item_epoch = second ? epoch + 1 : epoch;
@@ -1172,6 +1194,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 const ItemHeader h = read_item(it);
                 if (!isContactType(h.type_id)) continue;
                 ItemStamps stamps = {0, 0, 0};
+                const int lane = SHARED ? gate_lane_id() : (tid & 63);  // (split units: afresh per item, see run_cluster_sweep)
                 if constexpr (SHARED) {
                     const int fuse = __builtin_amdgcn_readfirstlane(it->shape) >> kItemFuseShift;
                     if (fuse & kItemFuseMember) continue;
