@@ -187,6 +187,9 @@ struct bepuhip_ctx {
     char* h_desc_ring = nullptr;         // pinned: descriptor tables of bepuhip_transfer_rows_async calls that have not been synchronised yet (bump-allocated, reset by bepuhip_sync)
     size_t desc_ring_bytes = 0, desc_ring_used = 0;
     size_t slab_words = 0;
+    size_t slab_alloc_words = 0;           // what d_slab / d_slab0 were allocated with (>= slab_words: a re-upload takes the previous upload's pair back when it fits)
+    uint32_t* spare_slab[2] = {nullptr, nullptr};  // the pair free_constraints set aside for the next upload (two 87 MB hipMalloc / hipFree pairs per upload of the bench scene otherwise)
+    size_t spare_slab_words = 0;
     DevTypeBatch* d_tbs = nullptr;       // per (batch) descriptors, solve/warm-start grids
     DevTypeBatch* d_inc_tbs = nullptr;   // incremental-update grid (contacts of all batches)
     int inc_tb_count = 0, inc_blocks = 0;
@@ -343,8 +346,13 @@ static void free_constraints(bepuhip_ctx* c) {
     clear_graphs(c);
     if (c->d_fallback_indices) hipFree(c->d_fallback_indices);
     c->d_fallback_indices = nullptr; c->has_fallback = false; c->launch_count = 0;
-    if (c->d_slab) hipFree(c->d_slab);
-    if (c->d_slab0) hipFree(c->d_slab0);
+    if (c->d_slab && c->d_slab0 && !c->spare_slab[0] && c->slab_alloc_words > 0) {  // kept for the next upload (build_constraints)
+        c->spare_slab[0] = c->d_slab; c->spare_slab[1] = c->d_slab0; c->spare_slab_words = c->slab_alloc_words;
+    } else {
+        if (c->d_slab) hipFree(c->d_slab);
+        if (c->d_slab0) hipFree(c->d_slab0);
+    }
+    c->slab_alloc_words = 0;
     if (c->d_tbs) hipFree(c->d_tbs);
     if (c->d_inc_tbs) hipFree(c->d_inc_tbs);
     if (c->d_clusters) hipFree(c->d_clusters);

@@ -140,6 +140,7 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_owned_mask) hipFree(c->d_owned_mask);
     for (auto& chunk : c->raw_chunks) if (chunk.ptr) hipFree(chunk.ptr);
     if (c->h_staging) hipHostFree(c->h_staging);
+    for (uint32_t* spare : c->spare_slab) if (spare) hipFree(spare);
     if (c->h_flush) hipHostFree(c->h_flush);
     if (c->d_flush) hipFree(c->d_flush);
     for (void* p : c->registered_host) hipHostUnregister(p);
@@ -492,20 +493,29 @@ static int32_t build_constraints(bepuhip_ctx* c) {
     }
     c->slab_words = words;
     if (words > 0) {
-        HIP_TRY(hipMalloc((void**)&c->d_slab, words * 4));
-        HIP_TRY(hipMalloc((void**)&c->d_slab0, words * 4));
+        if (c->spare_slab[0] && c->spare_slab_words >= words) {  // the previous upload's pair (free_constraints): everything below rewrites what it reads
+            c->d_slab = c->spare_slab[0]; c->d_slab0 = c->spare_slab[1]; c->slab_alloc_words = c->spare_slab_words;
+            c->spare_slab[0] = c->spare_slab[1] = nullptr; c->spare_slab_words = 0;
+        } else {
+            for (uint32_t*& spare : c->spare_slab) { if (spare) hipFree(spare); spare = nullptr; }
+            c->spare_slab_words = 0;
+            HIP_TRY(hipMalloc((void**)&c->d_slab, words * 4));
+            HIP_TRY(hipMalloc((void**)&c->d_slab0, words * 4));
+            c->slab_alloc_words = words;
+        }
         // host index -> device slot of every permuted type batch, one pool for all of them (with room for the indices additions on an island layout can create)
         size_t pool_words = 0;
         for (auto& tb : c->tbs)
             if (!tb.perm.empty()) { tb.perm_inverse(0); pool_words += std::max<size_t>(tb.inv.size(), (size_t)tb.device_extent()); }
         { const int32_t st = staging_reserve(c, (index_words + pool_words) * 4); if (st != BEPUHIP_OK) return st; }
         uint32_t* host = (uint32_t*)c->h_staging;
-        for (auto& tb : c->tbs) {
+        plan_parallel_for(c->tbs.size(), [&](size_t t) {  // (12 MB for the bench scene: on the plan threads, not one after the other)
+            HostTypeBatch& tb = c->tbs[t];
             if (!tb.refs_soa.empty()) memcpy(&host[tb.refs_off], tb.refs_soa.data(), tb.refs_soa.size() * 4);
             if (!tb.lrefs_soa.empty()) memcpy(&host[tb.lrefs_off], tb.lrefs_soa.data(), tb.lrefs_soa.size() * 4);
             std::vector<int32_t>().swap(tb.lrefs_soa);
             std::vector<int32_t>().swap(tb.refs_soa);
-        }
+        });
         if (pool_words > 0) {
             HIP_TRY(hipMalloc((void**)&c->d_index_pool, pool_words * 4));
             size_t at = 0;
@@ -2036,7 +2046,7 @@ static int32_t relayout_slab(bepuhip_ctx* c, const std::vector<OldLayout>& old) 
     if (c->d_slab) hipFree(c->d_slab);
     if (c->d_slab0) hipFree(c->d_slab0);
     c->d_slab = fresh[0]; c->d_slab0 = fresh[1];
-    c->slab_words = words;
+    c->slab_words = words; c->slab_alloc_words = words;
     c->structure_dirty = true;
     return BEPUHIP_OK;
 }
