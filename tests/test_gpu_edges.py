@@ -393,3 +393,17 @@ def test_no_reference_legal_solve_description_falls_back_to_launch_per_batch(hip
     for mode, island in ((0, True), (1, False)):
         s2.solve(1 / 60, SolveDescription(1, 2, fallback_batch_threshold=5), PoseIntegratorCallbacks(angular_integration_mode=mode))
         assert (s2.profile()["cluster"][1] > 0) == island, (mode, s2.profile())
+
+
+def test_reuploads_on_one_context_take_the_slab_pair_back(hip_solver_factory):
+    """A context keeps the pair of constraint slabs of its previous upload for the next one (round 5: two large allocations less per upload). Uploading a small scene,
+    a larger one (the pair is too small: replaced) and the small one again (the pair is larger than needed: reused, every word the kernels read rewritten) must each give
+    the oracle's bits — on both schedules."""
+    sd, cb = SolveDescription(2, 3), PoseIntegratorCallbacks()
+    small = small_scenes.random_graph_scene(71, 300, 900, sorted(HOT_PATH_TYPES))
+    large = small_scenes.random_graph_scene(72, 1500, 6000, sorted(HOT_PATH_TYPES))
+    refs = {id(s): pu.run_oracle(s, 1 / 60, sd, cb, frames=2) for s in (small, large)}
+    for use_clusters in (True, False):
+        solver = hip_solver_factory(use_clusters=use_clusters)
+        for scene in (small, large, small, small):
+            _bit_exact(refs[id(scene)], pu.run_hip(solver, scene, 1 / 60, sd, cb, frames=2))
