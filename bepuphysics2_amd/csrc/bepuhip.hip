@@ -864,7 +864,8 @@ static int32_t build_requirk_lists(bepuhip_ctx* c) {
                     if ((uint32_t)refs[i] >= kDynamicLimit || integrates(i)) continue;
                     const int launch = fallback ? sync_batches + row_level[ord][i] : tb.batch;
                     if (launch >= 0 && (size_t)launch < lists.size()) lists[launch].push_back(refs[i]);
-                    if (c->clusters_enabled && !fallback) {  // island layouts: the lane that holds the body does it (kLrefRequirk / kRankRequirk, bepu_cluster_kernel.h)
+                    if (c->clusters_enabled) {  // island layouts: the lane that holds the body does it (kLrefRequirk / kRankRequirk, bepu_cluster_kernel.h) — the sequential
+                        // fallback batch's lanes too (round 5): its items wait for every earlier item of their batch, so "right before ITS constraint runs" is the lane's own gate
                         const int d = tb.perm.empty() ? i : c->tbs[t].perm_inverse(i);
                         const int lref_rows = (tb.info.bodies + 1) / 2;
                         if (c->clusters_shared) marks.push_back({tb.lrefs_off + (size_t)(lref_rows + k) * tb.stride + d, 1u << 18});
@@ -978,11 +979,11 @@ static int cluster_threads(const bepuhip_ctx* c) {
 // The momentum-conserving angular modes run the island schedule through the kernel units that carry their code (round 3; BEPUHIP_CONSERVING_CLUSTERS=0: launch-per-batch
 // as in round 2), which exist for the default workgroup sizes.
 static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
-    // (a sequential fallback batch runs the island schedule in the nonconserving mode; the conserving modes' substep-0 re-transformations of a fallback batch are lists
-    // per dependency level, which only the launch-per-batch schedule has)
+    // (round 5: a sequential fallback batch runs the island schedule under the conserving modes as well — the substep-0 re-transformation of a non-integrating lane is a
+    // bit on that lane like in every other batch, build_requirk_lists; BEPUHIP_FALLBACK_CONSERVING_CLUSTERS=0: the per-level lists of the launch-per-batch schedule)
     // (round 5: any number of substeps — a step of more than kMaxClusterSubsteps is a chain of launches, enqueue_island_launches)
     (void)substeps;
-    return c->clusters_enabled && !(c->has_fallback && in->angular_integration_mode != 0) &&
+    return c->clusters_enabled && !(c->has_fallback && in->angular_integration_mode != 0 && env_int("BEPUHIP_FALLBACK_CONSERVING_CLUSTERS", 1) == 0) &&
            cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared) <= kLdsBudgetBytes &&
            (in->angular_integration_mode == 0 || (conserving_variant_exists(cluster_threads(c), c->clusters_shared) && c->d_trace == nullptr && env_int("BEPUHIP_CONSERVING_CLUSTERS", 1) != 0));
 }
