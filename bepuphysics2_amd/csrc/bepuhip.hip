@@ -2013,7 +2013,17 @@ static int32_t flush_structural(bepuhip_ctx* c) {
     c->graphs_cleared_by_structure = true;  // the solve that follows launches eagerly: a graph captured now would be thrown away by the next frame's updates
     c->total_constraints = 0;
     for (auto& tb : c->tbs) c->total_constraints += tb.count;
-    if ((st = build_descriptors(c, {})) != BEPUHIP_OK) return st;
+    // (a sequential fallback batch: its dependency levels are rebuilt from its references as the device holds them — rows in the caller's order here: a context
+    // with a fallback batch leaves the island schedule for its first structural update, structural_preamble)
+    std::vector<std::vector<int32_t>> fallback_refs;
+    if (c->has_fallback)
+        for (auto& tb : c->tbs) {
+            if (tb.batch != c->fallback_threshold) continue;
+            std::vector<int32_t> rows((size_t)tb.info.bodies * tb.stride, -1);
+            if (!rows.empty() && c->d_slab) HIP_TRY(hipMemcpy(rows.data(), c->d_slab + tb.refs_off, rows.size() * 4, hipMemcpyDeviceToHost));
+            fallback_refs.push_back(std::move(rows));
+        }
+    if ((st = build_descriptors(c, fallback_refs)) != BEPUHIP_OK) return st;
     c->structure_dirty = false;
     return rebuild_flags(c);
 }
@@ -2112,9 +2122,11 @@ static int32_t leave_island_schedule(bepuhip_ctx* c) {
 static int32_t structural_preamble(bepuhip_ctx* c, bool stay = false) {
     if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
     if (c->building) return fail(BEPUHIP_E_STATE, "structural update between begin_constraints and end_constraints");
-    if (c->has_fallback) return fail(BEPUHIP_E_UNSUPPORTED, "structural updates with a sequential fallback batch: re-upload with begin/set/end");
     if (c->in_substep_event) return fail(BEPUHIP_E_STATE, "structural update inside a substep event handler: the substep loop runs on the constraint set the solve started with");
-    if (stay && c->soft_ok) return BEPUHIP_OK;  // bookkeeping on the host only: no device call on this path (a structural call per changed contact per frame)
+    // A sequential fallback batch (round 5; UNSUPPORTED until then): constraints of the synchronized batches come and go on the launch-per-batch rows — the context leaves
+    // its island layout for the first such update —, the fallback batch's own rows stay as uploaded (additions to it and removals from it are refused by the calls below;
+    // its references may be patched when a body moves in memory: the dependency levels are rebuilt at the flush, flush_structural).
+    if (stay && c->soft_ok && !c->has_fallback) return BEPUHIP_OK;  // bookkeeping on the host only: no device call on this path (a structural call per changed contact per frame)
     HIP_TRY(hipSetDevice(c->device));
     return leave_island_schedule(c);
 }
@@ -2192,6 +2204,8 @@ int32_t bepuhip_remove_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id
     if (st != BEPUHIP_OK) return st;
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb || index < 0 || index >= tb->count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Can only remove elements that are actually in the batch!");  // TypeProcessor.cs:636
+    if (c->has_fallback && batch >= c->fallback_threshold)  // (TypeProcessor.cs:695-731 has a fallback branch: it compacts bundles around the hole; here: re-upload)
+        return fail(BEPUHIP_E_UNSUPPORTED, "removal from the sequential fallback batch (batch index >= FallbackBatchThreshold): re-upload with begin/set/end");
     if (c->soft_ok) {  // on the island layout: the slot is freed where it is, the caller's indices are remapped
         SoftCallTimer timer(c);
         if (soft_remove(c, tb, index)) { c->requirk_stale = true; return BEPUHIP_OK; }
@@ -2241,6 +2255,7 @@ int32_t bepuhip_swap_constraints(bepuhip_ctx* c, int32_t batch, int32_t type_id,
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb || a < 0 || b < 0 || a >= tb->count || b >= tb->count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad swap_constraints argument");
     if (a == b) return BEPUHIP_OK;
+    if (c->has_fallback && batch >= c->fallback_threshold) return fail(BEPUHIP_E_UNSUPPORTED, "a swap inside the sequential fallback batch would change the order its bundles are solved in: re-upload with begin/set/end");
     if (c->soft_ok) {  // on an island layout the rows stay where they are: two entries of the index tables change hands
         if (soft_swap(c, tb, a, b)) { c->requirk_stale = true; return BEPUHIP_OK; }
         HIP_TRY(hipSetDevice(c->device));

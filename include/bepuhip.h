@@ -25,7 +25,7 @@ extern "C" {
 
 #define BEPUHIP_OK 0
 #define BEPUHIP_E_INVALID_ARGUMENT (-1) /* reference throws ArgumentException (Simulation.cs:318-319, SolveDescription.cs:42-47) */
-#define BEPUHIP_E_UNSUPPORTED (-2)      /* unknown type id, a structural update of a scene with a sequential fallback batch, ...: caller should fall back to simulation.Solve */
+#define BEPUHIP_E_UNSUPPORTED (-2)      /* unknown type id, an addition to / removal from the sequential fallback batch itself, ...: caller should fall back to simulation.Solve */
 #define BEPUHIP_E_DEVICE (-3)           /* HIP runtime failure */
 #define BEPUHIP_E_STATE (-4)            /* calls out of order */
 
@@ -300,8 +300,10 @@ int32_t bepuhip_transfer_rows_async(bepuhip_ctx* ctx, const bepuhip_row_transfer
  * cluster that runs it gets a ghost copy of the foreign body, which becomes a shared body if it was not), a removal gives such a copy's LDS slot back; ranks and hand-off
  * flags of the bodies concerned are recomputed at the next solve. With BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS a split plan reserves a quarter more device slots (at least four)
  * per cluster and type batch and an eighth more LDS slots per cluster; without it only slots freed by removals are available. When no cluster near the bodies has room the
- * context falls back as above. Results are bit-identical either way. Not supported (UNSUPPORTED): additions to the sequential fallback batch
- * (batch_index >= fallback_batch_threshold). */
+ * context falls back as above. Results are bit-identical either way. A scene with a sequential fallback batch takes structural updates of its synchronized batches
+ * on the launch-per-batch rows (the context leaves its island layout for the first one; bepuhip_replan brings it back) and patches of the fallback batch's references
+ * when a body moves in memory; not supported (UNSUPPORTED): additions to the sequential fallback batch, removals from it and swaps inside it
+ * (batch_index >= fallback_batch_threshold; the reference's fallback branch of Remove, TypeProcessor.cs:695-731, compacts bundles around the hole) — re-upload. */
 /* The caller places the constraint in a batch none of its dynamic bodies is in yet (Solver.cs:1046-1051, 1182-1199: the batch invariant the whole solve rests on). On the island
  * layout the library knows every reference and refuses an addition that breaks it (INVALID_ARGUMENT); on the launch-per-batch rows the references live on the device only and
  * the call trusts the caller, as the reference's release build does. */
