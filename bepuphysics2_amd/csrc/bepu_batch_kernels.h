@@ -114,15 +114,25 @@ enum { kFlagConstrained = 1, kFlagDynamicConstrained = 2, kFlagConstrainedKinema
 
 // Device-side equivalent of the merged constrained-body set of PrepareConstraintIntegrationResponsibilities
 // (Solver_Solve.cs:1198-1207,1378-1381): every body referenced as dynamic gets integration inside the solver.
-#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy
-__global__ void mark_constrained_kernel(const int* __restrict__ refs, int count, int stride, int bodies_per_constraint, unsigned* flags) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    for (int k = 0; k < bodies_per_constraint; ++k) {
-        int ref = refs[(size_t)k * stride + i];
+#ifndef BEPU_CLUSTER_UNIT  // launched by bepuhip.hip only: the cluster units do not carry a copy. A group of type batches per launch: refs_off in words from the slab's base,
+// blocks of 256 constraints numbered through the group; a dynamic reference -> integrated inside the solver, a kinematic one -> member of Solver.ConstrainedKinematicHandles (Solver.cs:68)
+constexpr int kMarkGroupEntries = 96;
+struct MarkGroup {
+    struct Entry { unsigned long long refs_off; int extent, stride, bodies, block_begin; };
+    int count, blocks;
+    Entry entries[kMarkGroupEntries];
+};
+__global__ void mark_constrained_group_kernel(const int* __restrict__ slab, const MarkGroup group, unsigned* flags) {
+    int entry = 0;
+    while (entry + 1 < group.count && group.entries[entry + 1].block_begin <= (int)blockIdx.x) ++entry;
+    const MarkGroup::Entry e = group.entries[entry];
+    const int i = ((int)blockIdx.x - e.block_begin) * (int)blockDim.x + (int)threadIdx.x;
+    if (i >= e.extent) return;
+    const int* refs = slab + e.refs_off;
+    for (int k = 0; k < e.bodies; ++k) {
+        const int ref = refs[(size_t)k * e.stride + i];
         if (ref < 0) continue;
-        // dynamic reference -> integrated inside the solver; kinematic reference -> member of Solver.ConstrainedKinematicHandles (Solver.cs:68)
-        unsigned bits = kFlagConstrained | (((unsigned)ref < kDynamicLimit) ? kFlagDynamicConstrained : kFlagConstrainedKinematic);
+        const unsigned bits = kFlagConstrained | (((unsigned)ref < kDynamicLimit) ? kFlagDynamicConstrained : kFlagConstrainedKinematic);
         atomicOr(&flags[ref & kRefMask], bits);
     }
 }

@@ -4,6 +4,9 @@
 #include <functional>
 #include <mutex>
 #include <unistd.h>
+#include <pthread.h>
+#include <sched.h>
+#include <memory>
 
 #include "bepu_host_state.h"
 #include <atomic>
@@ -60,6 +63,66 @@ static int plan_workers(size_t jobs) {
     const int fallback = std::max(1, std::min(16, std::max(8, hw / 4)));
     return std::max(1, std::min<int>({env_int("BEPUHIP_PLAN_THREADS", fallback), hw > 0 ? hw : 1, (int)std::max<size_t>(jobs, 1)}));
 }
+// Where the parked threads run. The planner's loops hand cache lines back and forth (the union-find's parents, the per-cluster lists): on a two-socket host with sixteen
+// L3 domains the scheduler spreads sixteen fresh threads over all of them, and every hand-over is a trip across the fabric — the same loops run a quarter faster when
+// the threads share a last-level cache (end_constraints of the bench scene under `taskset -c 0-7`: 12.4 ms against 14.5, profiles/r05_s27_upload_probe_before.txt). The
+// threads are therefore kept on the logical CPUs that share an L3 with the CPU the first caller runs on, plus neighbouring L3 domains of the same package until there
+// is a CPU per thread — never outside the caller's own affinity mask; nothing is pinned when the topology cannot be read or BEPUHIP_PLAN_PIN=0. The caller's thread is
+// left alone.
+static bool plan_read_cpu_list(const char* path, cpu_set_t& out) {
+    CPU_ZERO(&out);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char text[4096];
+    const bool got = fgets(text, sizeof(text), f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    for (char* at = text; *at && *at != '\n';) {  // "0-7,128-135"
+        char* end = nullptr;
+        const long a = strtol(at, &end, 10);
+        if (end == at) return false;
+        long b = a;
+        if (*end == '-') { at = end + 1; b = strtol(at, &end, 10); if (end == at) return false; }
+        for (long cpu = a; cpu <= b && cpu < CPU_SETSIZE; ++cpu) if (cpu >= 0) CPU_SET((int)cpu, &out);
+        at = (*end == ',') ? end + 1 : end;
+        if (*end != ',' && *end != '\n' && *end != 0) return false;
+    }
+    return CPU_COUNT(&out) > 0;
+}
+static bool plan_home_cpus(int threads, cpu_set_t& home) {
+    CPU_ZERO(&home);
+    if (env_int("BEPUHIP_PLAN_PIN", 1) == 0) return false;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    const int here = sched_getcpu();
+    if (here < 0 || !CPU_ISSET(here, &allowed)) return false;
+    auto l3_of = [](int cpu, cpu_set_t& set) {
+        char path[128];
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+        return plan_read_cpu_list(path, set);
+    };
+    auto package_of = [](int cpu) {
+        char path[128];
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/physical_package_id", cpu);
+        int id = -1;
+        if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &id) != 1) id = -1; fclose(f); }
+        return id;
+    };
+    cpu_set_t domain;
+    if (!l3_of(here, domain)) return false;
+    CPU_AND(&home, &domain, &allowed);
+    const int package = package_of(here);
+    for (int step = 1; step < CPU_SETSIZE && CPU_COUNT(&home) < threads && package >= 0; ++step)
+        for (int cpu : {here + step, here - step}) {
+            if (cpu < 0 || cpu >= CPU_SETSIZE || !CPU_ISSET(cpu, &allowed) || CPU_ISSET(cpu, &home) || CPU_COUNT(&home) >= threads) continue;
+            if (package_of(cpu) != package || !l3_of(cpu, domain)) continue;
+            cpu_set_t more;
+            CPU_AND(&more, &domain, &allowed);
+            CPU_OR(&home, &home, &more);
+        }
+    return CPU_COUNT(&home) > 0;
+}
+
 // The host threads themselves: started once per process and parked on a condition variable between loops (a planner run is a dozen short parallel loops, a flush of
 // structural updates two: starting sixteen threads for each costs more than most of the loops). One loop at a time; a second caller (another context planning on another
 // thread) runs its loop on threads of its own.
@@ -71,6 +134,8 @@ struct PlanPool {
     uint64_t generation = 0;
     int wanted = 0, running = 0;
     pid_t pid = getpid();
+    bool placed = false, pinned = false;
+    cpu_set_t home;
     void serve(int worker) {
         uint64_t seen = 0;
         for (;;) {
@@ -90,8 +155,14 @@ struct PlanPool {
     void run(int workers, const std::function<void(int)>& fn) {  // fn(0) here, fn(1 .. workers - 1) on the parked threads
         {
             std::lock_guard<std::mutex> lock(m);
-            if (pid != getpid()) { pid = getpid(); threads.clear(); }  // a forked child inherits the bookkeeping, not the threads
-            while ((int)threads.size() + 1 < workers) { const int id = (int)threads.size() + 1; threads.emplace_back([this, id] { serve(id); }); threads.back().detach(); }
+            if (pid != getpid()) { pid = getpid(); threads.clear(); placed = false; }  // a forked child inherits the bookkeeping, not the threads
+            if ((int)threads.size() + 1 < workers && !placed) { placed = true; pinned = plan_home_cpus(std::max(workers, plan_workers((size_t)1 << 20)), home); }
+            while ((int)threads.size() + 1 < workers) {
+                const int id = (int)threads.size() + 1;
+                threads.emplace_back([this, id] { serve(id); });
+                if (pinned) pthread_setaffinity_np(threads.back().native_handle(), sizeof(home), &home);  // (refused: the thread runs where the scheduler puts it)
+                threads.back().detach();
+            }
             work = &fn; wanted = workers; running = workers - 1; ++generation;
         }
         wake.notify_all();
@@ -123,6 +194,14 @@ static void plan_parallel_for_workers(size_t jobs, Fn&& fn) {  // fn(job, worker
 }
 template <class Fn>
 static void plan_parallel_for(size_t jobs, Fn&& fn) { plan_parallel_for_workers(jobs, [&](size_t j, int, int) { fn(j); }); }
+template <class Fn>
+static void plan_parallel_ranges(size_t n, size_t grain, Fn&& fn) {  // fn(begin, end) over [0, n) in pieces of `grain`
+    plan_parallel_for((n + grain - 1) / grain, [&](size_t j) { fn(j * grain, std::min(n, (j + 1) * grain)); });
+}
+// A piece of a type batch: the planner's loops over all constraints run over pieces of at most kPlanPiece constraints, so that the threads share the work evenly whatever
+// the sizes of the type batches are (the headline scene: 32 type batches of 7,500 to 90,000 constraints on 16 threads).
+constexpr int kPlanPiece = 16384;
+struct PlanPiece { int32_t t, begin, end; };
 
 // One work item of a sequential fallback type batch: from position `at` of `members` (constraints of one cluster, in the reference's order) as many consecutive constraints
 // as share no dynamic body, at most 64. Returns the end position. Before the rows are permuted the references are read at the caller's index, afterwards at the device
@@ -165,10 +244,14 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     // One pass over the references on several threads: the kinematic list (Solver.ConstrainedKinematicHandles equivalent, always built; in the order the bodies first
     // appear when the type batches are scanned body slot by body slot — kept through the position of each body's first appearance), which bodies are dynamic, and the
     // islands as a lock-free union-find whose roots are the smallest body index of each component (so the result does not depend on the threads).
-    std::vector<uint64_t> first_seen(universe, UINT64_MAX);
-    std::vector<uint8_t> is_dyn(universe, 0);
-    std::vector<int32_t> parent(universe);
-    for (int i = 0; i < universe; ++i) parent[i] = i;
+    // (arrays the threads fill: allocated raw and first touched in parallel — zero-filling a fresh vector of this size on one thread is page faults, a millisecond of them)
+    std::unique_ptr<uint64_t[]> first_seen(new uint64_t[universe]);
+    std::unique_ptr<uint8_t[]> is_dyn(new uint8_t[universe]);
+    std::unique_ptr<int32_t[]> parent_store(new int32_t[universe]);
+    int32_t* parent = parent_store.get();
+    plan_parallel_ranges((size_t)universe, 32768, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) { first_seen[i] = UINT64_MAX; is_dyn[i] = 0; parent[i] = (int32_t)i; }
+    });
     // The sequential fallback batch (Solver_Solve.cs:546-583: bundles one after the other, a body may repeat ACROSS bundles) runs the island schedule too since round 4:
     // its constraints become work items that are cut wherever a dynamic body would repeat, in the reference's order, and the predecessor lists order them like any
     // other items — a hub body's surplus constraints form a chain of one-constraint items (whole-island plans only; BEPUHIP_FALLBACK_CLUSTERS=0: launch-per-batch levels).
@@ -195,7 +278,13 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         }
     };
     std::atomic<int> bodiless{0};
-    plan_parallel_for_workers(c->tbs.size(), [&](size_t t, int worker, int workers) {
+    std::vector<PlanPiece> pieces;  // (a fallback type batch stays in one piece: an empty lane takes its cluster from the lane before it)
+    for (size_t t = 0; t < c->tbs.size(); ++t) {
+        const int count = c->tbs[t].count, step = (fallback_here && c->tbs[t].batch == fallback_batch) ? std::max(count, 1) : kPlanPiece;
+        for (int b = 0; b < count; b += step) pieces.push_back({(int32_t)t, b, std::min(count, b + step)});
+    }
+    plan_parallel_for(pieces.size(), [&](size_t piece) {
+        const size_t t = (size_t)pieces[piece].t;
         const HostTypeBatch& tb = c->tbs[t];
         auto note_kinematic = [&](int32_t r, int k, int i) {  // earliest (type batch, body slot, index) at which the body appears
             const uint64_t key = ((uint64_t)t << 40) | ((uint64_t)k << 32) | (uint32_t)i;
@@ -204,17 +293,16 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
         };
         if (!want_plan) {
             for (int k = 0; k < tb.info.bodies; ++k)
-                for (int i = 0; i < tb.count; ++i) {
+                for (int i = pieces[piece].begin; i < pieces[piece].end; ++i) {
                     const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
                     if ((uint32_t)r >= kDynamicLimit && r >= 0) note_kinematic(r, k, i);
                 }
             return;
         }
-        // Type batches list their constraints in creation order, i.e. roughly by island: workers that all start at index 0 would hammer the same few parents at the
-        // same time (a ragdoll's sixteen parents share one cache line). Every worker starts its type batch at its own offset and wraps around.
-        const int offset = tb.count > 0 ? (int)((int64_t)tb.count * worker / workers) : 0;
-        for (int j = 0; j < tb.count; ++j) {
-            const int i = j + offset < tb.count ? j + offset : j + offset - tb.count;
+        // Type batches list their constraints in creation order, i.e. roughly by island: threads that walk different type batches at the same relative position would
+        // hammer the same few parents at the same time (a ragdoll's sixteen parents share one cache line). The pieces are handed out type batch by type batch, which
+        // puts the threads at different positions.
+        for (int i = pieces[piece].begin; i < pieces[piece].end; ++i) {
             int first = -1;
             for (int k = 0; k < tb.info.bodies; ++k) {
                 const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
@@ -233,14 +321,23 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     }
     if (!want_plan || bodiless.load()) return;  // (a constraint with no dynamic body: leave everything to the global path)
     const bool reserve = (c->flags & BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS) != 0;
-    auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
     plan_lap("universe, kinematic list, union-find");
-    // component sizes (root = smallest body index of the component)
+    // Every body's root (the smallest body index of its component), looked up side by side without writing — the unions are over, the paths are short — and from here
+    // on parent[i] IS the root; then the component sizes.
+    {
+        std::unique_ptr<int32_t[]> root_store(new int32_t[universe]);
+        int32_t* const root = root_store.get();
+        const int32_t* const up = parent;
+        plan_parallel_ranges((size_t)universe, 32768, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) { int32_t x = (int32_t)i; while (up[x] != x) x = up[x]; root[i] = x; }
+        });
+        parent_store.swap(root_store);
+    }
+    parent = parent_store.get();
     std::vector<int32_t> comp_size(universe, 0);
     int64_t total_dyn = 0;
     int32_t largest = 0;
-    for (int i = 0; i < universe; ++i) if (is_dyn[i]) { largest = std::max(largest, ++comp_size[find(i)]); ++total_dyn; }
-    for (int i = 0; i < universe; ++i) if (is_dyn[i]) find(i);  // full path compression: parent[i] is the root from here on
+    for (int i = 0; i < universe; ++i) if (is_dyn[i]) { largest = std::max(largest, ++comp_size[parent[i]]); ++total_dyn; }
     int cap = env_int("BEPUHIP_CLUSTER_BODIES", 0);
     if (cap <= 0) {
         // default: one resident workgroup per CU (the kernel's LDS footprint admits one workgroup per CU), a single round
@@ -258,41 +355,49 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     // (tests: BEPUHIP_FORCE_SPLIT=<bodies> cuts the scene's islands as if no workgroup held an island of that many bodies, so that small scenes reach the split-island kernels)
     if (const int force = env_int("BEPUHIP_FORCE_SPLIT", 0); force > 0 && largest >= force) { plan_split_clusters(c, plan, universe); return; }
     // ---- phase A: find a cap whose clusters fit the LDS budget (no mutation yet) ----
-    std::vector<int32_t> cluster_of(universe, -1);  // by component root
+    std::vector<int32_t> cluster_of(universe, -1);  // every dynamic body's cluster: its component's
     std::vector<std::vector<int32_t>> cl_of_constraint(c->tbs.size());
+    plan_parallel_for(c->tbs.size(), [&](size_t t) { cl_of_constraint[t].resize(c->tbs[t].count); });
     std::vector<std::vector<int32_t>> kin_lists;  // per cluster: the kinematic bodies its constraints reference (of the accepted attempt)
     int nclusters = 0;
+    std::vector<int32_t> dyn_count;
     for (int attempt = 0;; ++attempt) {
         nclusters = 0;
         int cur = 0;
-        for (int i = 0; i < universe; ++i) {
-            if (!is_dyn[i] || parent[i] != i) continue;  // roots only, ascending
-            if (nclusters == 0 || cur + comp_size[i] > cap) { ++nclusters; cur = 0; }
-            cluster_of[i] = nclusters - 1;
-            cur += comp_size[i];
+        dyn_count.clear();
+        for (int i = 0; i < universe; ++i) {  // (a root is the smallest index of its component: it has its cluster before its bodies ask for it)
+            if (!is_dyn[i]) continue;
+            if (parent[i] == i) {  // roots, ascending: components are packed in that order
+                if (nclusters == 0 || cur + comp_size[i] > cap) { ++nclusters; cur = 0; dyn_count.push_back(0); }
+                cluster_of[i] = nclusters - 1;
+                cur += comp_size[i];
+            } else {
+                cluster_of[i] = cluster_of[parent[i]];
+            }
+            ++dyn_count[cluster_of[i]];
         }
-        std::vector<int32_t> dyn_count(nclusters, 0), item_count(nclusters, 0);
+        std::vector<int32_t> item_count(nclusters, 0);
         std::vector<std::vector<int32_t>>& kin_seen = kin_lists;
         kin_seen.assign(nclusters, {});
-        for (int i = 0; i < universe; ++i) if (is_dyn[i]) dyn_count[cluster_of[parent[i]]]++;
-        // per type batch, side by side: the cluster of every constraint, the constraints per cluster, and the (cluster, kinematic body) pairs in the order they are met;
-        // merged in type-batch order afterwards, so that the kinematic copies get the slots a serial scan would give them
-        std::vector<std::vector<int32_t>> per_cluster(c->tbs.size());
-        std::vector<std::vector<std::pair<int32_t, int32_t>>> kin_met(c->tbs.size());
-        plan_parallel_for(c->tbs.size(), [&](size_t t) {
-            HostTypeBatch& tb = c->tbs[t];
-            cl_of_constraint[t].resize(tb.count);
-            per_cluster[t].assign(nclusters, 0);
-            auto& met = kin_met[t];
-            for (int i = 0; i < tb.count; ++i) {
+        // per piece of a type batch, side by side: the cluster of every constraint, the constraints per cluster, and the (cluster, kinematic body) pairs in the order they
+        // are met; merged in type-batch order afterwards, so that the kinematic copies get the slots a serial scan would give them
+        std::vector<std::vector<int32_t>> per_cluster(c->tbs.size()), piece_clusters(pieces.size());
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> kin_met(pieces.size());
+        plan_parallel_for(pieces.size(), [&](size_t piece) {
+            const size_t t = (size_t)pieces[piece].t;
+            const HostTypeBatch& tb = c->tbs[t];
+            std::vector<int32_t>& counts = piece_clusters[piece];
+            counts.assign(nclusters, 0);
+            auto& met = kin_met[piece];
+            for (int i = pieces[piece].begin; i < pieces[piece].end; ++i) {
                 int cl = -1;
                 for (int k = 0; k < tb.info.bodies && cl < 0; ++k) {
                     int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                    if ((uint32_t)r < kDynamicLimit) cl = cluster_of[parent[r]];
+                    if ((uint32_t)r < kDynamicLimit) cl = cluster_of[r];
                 }
                 if (cl < 0) cl = i > 0 ? cl_of_constraint[t][i - 1] : 0;  // an empty lane of the fallback batch: a dead device slot next to its neighbour
                 cl_of_constraint[t][i] = cl;
-                per_cluster[t][cl]++;
+                counts[cl]++;
                 for (int k = 0; k < tb.info.bodies; ++k) {
                     int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
                     if (r >= 0 && (uint32_t)r >= kDynamicLimit) {
@@ -302,11 +407,16 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
                 }
             }
         });
-        for (size_t t = 0; t < c->tbs.size(); ++t) {
-            for (auto& pair : kin_met[t]) {
+        for (size_t t = 0; t < c->tbs.size(); ++t) per_cluster[t].assign(nclusters, 0);
+        for (size_t piece = 0; piece < pieces.size(); ++piece) {  // (in type-batch order, a type batch's pieces in index order)
+            std::vector<int32_t>& sum = per_cluster[pieces[piece].t];
+            for (int cl = 0; cl < nclusters; ++cl) sum[cl] += piece_clusters[piece][cl];
+            for (auto& pair : kin_met[piece]) {
                 auto& ks = kin_seen[pair.first];
                 if (std::find(ks.begin(), ks.end(), pair.second) == ks.end()) ks.push_back(pair.second);
             }
+        }
+        for (size_t t = 0; t < c->tbs.size(); ++t) {
             if (fallback_here && c->tbs[t].batch == fallback_batch) {  // items end where a dynamic body would repeat: counted as they will be cut (fallback_item_end)
                 const HostTypeBatch& tb = c->tbs[t];
                 std::vector<std::vector<int32_t>> members(nclusters);
@@ -334,8 +444,10 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     // ---- phase B: local slots, reordered type batches, work items with predecessor lists ----
     std::vector<std::vector<int32_t>> cl_bodies(nclusters);  // natural local order: dynamics ascending, kinematics appended on first use
     std::vector<int32_t> local_of(universe, -1);
+    for (int cl = 0; cl < nclusters; ++cl) cl_bodies[cl].reserve((size_t)dyn_count[cl] + kin_lists[cl].size());
+    plan.clustered_dynamic.reserve(plan.clustered_dynamic.size() + (size_t)total_dyn);
     for (int i = 0; i < universe; ++i)
-        if (is_dyn[i]) { int cl = cluster_of[parent[i]]; local_of[i] = (int)cl_bodies[cl].size(); cl_bodies[cl].push_back(i); plan.clustered_dynamic.push_back(i); }
+        if (is_dyn[i]) { int cl = cluster_of[i]; local_of[i] = (int)cl_bodies[cl].size(); cl_bodies[cl].push_back(i); plan.clustered_dynamic.push_back(i); }
     // Kinematic copies: slots behind the cluster's dynamic bodies, in the order phase A met them. Assigned before the rows are built so that building them
     // (the bulk of this function's time: every prestep / impulse row of every type batch is permuted) can run on several threads.
     std::vector<std::unordered_map<int32_t, int32_t>> cl_kin(nclusters);  // kinematic body -> natural local index
@@ -467,7 +579,8 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     });
     plan_lap("packed local references");
     // Cross-pass predecessors: the last toucher (end of a pass) of every body an item touches first.
-    for (int cl = 0; cl < nclusters; ++cl) {
+    plan_parallel_for((size_t)nclusters, [&](size_t cluster) {
+        const int cl = (int)cluster;
         for (auto& fs : first_touch[cl]) {
             ClusterItem& it = cl_items[cl][fs.first];
             const int last = last_toucher[cl][fs.second];
@@ -479,6 +592,14 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
             if (nx < kMaxPreds) { it.xpred[nx++] = (unsigned short)last; it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (nx << 20); }
             else it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (1 << 25);
         }
+    });
+    {
+        size_t slots = 0, items = 0;
+        for (int cl = 0; cl < nclusters; ++cl) { slots += (cl_bodies[cl].size() + 15) / 16 * 16; items += cl_items[cl].size(); }
+        plan.cluster_bodies.reserve(plan.cluster_bodies.size() + slots);
+        plan.items.reserve(plan.items.size() + items);
+        plan.batch_item_begin.reserve(plan.batch_item_begin.size() + (size_t)nclusters * (c->batch_count + 1));
+        plan.clusters.reserve(plan.clusters.size() + nclusters);
     }
     for (int cl = 0; cl < nclusters; ++cl) {
         ClusterDesc d;
@@ -503,10 +624,9 @@ static void plan_clusters(bepuhip_ctx* c, ClusterPlan& plan) {
     }
     plan.enabled = nclusters > 0 && cluster_lds_bytes(plan.planes, plan.max_slots, plan.max_items) <= kLdsBudgetBytes;
     // what structural updates need in order to stay on this plan
-    plan.body_cluster.assign(universe, -1);
-    plan.body_lref.assign(universe, -1);
-    for (int i = 0; i < universe; ++i)
-        if (is_dyn[i]) { plan.body_cluster[i] = cluster_of[parent[i]]; plan.body_lref[i] = rotated_slot(local_of[i]); }
+    plan.body_cluster.swap(cluster_of);  // (-1 for every body that is not dynamic here)
+    plan_parallel_ranges((size_t)universe, 32768, [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) if (local_of[i] >= 0) local_of[i] = rotated_slot(local_of[i]); });
+    plan.body_lref.swap(local_of);
     // (the bodies' constraint counts, which only structural updates need, are counted from dev_refs by the first of them: soft_ensure_degrees)
     plan.cluster_kin.resize(nclusters);
     for (int cl = 0; cl < nclusters; ++cl)

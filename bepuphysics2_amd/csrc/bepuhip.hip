@@ -163,13 +163,22 @@ static int32_t rebuild_flags(bepuhip_ctx* c) {
     // Constraints that reference bodies not uploaded yet are not marked (the writes would leave d_flags); validate_solve refuses to run such a
     // state and the set_bodies that repairs it changes the count, which brings us back here.
     const bool marked = c->built && c->referenced_bodies <= c->body_count;
-    if (marked) {
+    if (marked) {  // up to kMarkGroupEntries type batches per launch, their descriptions in the kernel's arguments (one launch per type batch was a third of a millisecond of launches)
+        MarkGroup group;
+        group.count = 0; group.blocks = 0;
+        auto launch = [&]() {
+            if (group.count > 0) hipLaunchKernelGGL(mark_constrained_group_kernel, dim3(group.blocks), dim3(256), 0, c->stream, (const int*)c->d_slab, group, c->d_flags);
+            group.count = 0; group.blocks = 0;
+        };
         for (auto& tb : c->tbs) {
             const int extent = tb.device_extent();  // island layouts hold free slots (-1 references) between the live ones
             if (extent == 0) continue;
-            int blocks = (extent + 255) / 256;
-            hipLaunchKernelGGL(mark_constrained_kernel, dim3(blocks), dim3(256), 0, c->stream, (const int*)(c->d_slab + tb.refs_off), extent, tb.stride, tb.info.bodies, c->d_flags);
+            MarkGroup::Entry& e = group.entries[group.count++];
+            e.refs_off = (unsigned long long)tb.refs_off; e.extent = extent; e.stride = tb.stride; e.bodies = tb.info.bodies; e.block_begin = group.blocks;
+            group.blocks += (extent + 255) / 256;
+            if (group.count == kMarkGroupEntries) launch();
         }
+        launch();
     }
     if (marked && c->clusters_enabled && c->clustered_dynamic_count > 0) {
         hipLaunchKernelGGL(mark_indices_kernel, dim3((c->clustered_dynamic_count + 255) / 256), dim3(256), 0, c->stream, (const int*)c->d_clustered_dynamic,
@@ -291,7 +300,36 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
     const bool fallback_batch = batch_index == c->fallback_threshold;
     int highest_reference = -1;
     int64_t live = 0;  // a fallback type batch counts its empty lanes in `count`
-    for (int b0 = 0; b0 < count; b0 += W) {
+    // A synchronized batch has no empty lanes: its references are copied bundle row by bundle row with the checks folded into an OR and a maximum (loops the compiler
+    // turns into vector code — this conversion is two of the upload's milliseconds otherwise); the lane-by-lane loop below is the fallback batch's.
+    const int plain_bundles = (fallback_batch || c->host_values) ? 0 : count / W;
+    if (plain_bundles > 0) {
+        int32_t any = 0, highest = 0;
+        auto rows_of = [&](auto width) {
+            constexpr int kW = decltype(width)::value;
+            for (int bundle = 0; bundle < plain_bundles; ++bundle)
+                for (int k = 0; k < nb; ++k) {
+                    const int32_t* src = refs + ((size_t)bundle * nb + k) * kW;
+                    int32_t* dst = tb.refs_soa.data() + (size_t)k * tb.stride + (size_t)bundle * kW;
+                    for (int lane = 0; lane < kW; ++lane) { const int32_t r = src[lane]; dst[lane] = r; any |= r; highest = std::max(highest, r & kRefMask); }
+                }
+        };
+        if (W == 8) rows_of(std::integral_constant<int, 8>());
+        else if (W == 16) rows_of(std::integral_constant<int, 16>());
+        else if (W == 4) rows_of(std::integral_constant<int, 4>());
+        else {
+            for (int bundle = 0; bundle < plain_bundles; ++bundle)
+                for (int k = 0; k < nb; ++k)
+                    for (int lane = 0; lane < W; ++lane) {
+                        const int32_t r = refs[((size_t)bundle * nb + k) * W + lane];
+                        tb.refs_soa[(size_t)k * tb.stride + (size_t)bundle * W + lane] = r; any |= r; highest = std::max(highest, r & kRefMask);
+                    }
+        }
+        if (any < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "empty (-1) body reference inside a synchronized batch");
+        highest_reference = highest;
+        live = (int64_t)plain_bundles * W;
+    }
+    for (int b0 = plain_bundles * W; b0 < count; b0 += W) {
         const size_t bundle = (size_t)(b0 / W);
         const int lanes = std::min(W, count - b0);
         for (int k = 0; k < nb; ++k) {
@@ -732,6 +770,9 @@ int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* c, const int32_t* indice
     if (!c || count < 0 || (count > 0 && !indices)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad kinematic list");
     for (int i = 0; i < count; ++i)
         if (indices[i] < 0 || indices[i] >= c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "kinematic body index out of range (call set_bodies first)");
+    // The list the context already holds (a host that uploads its constraints again hands the same Solver.ConstrainedKinematicHandles over): every call that changes what
+    // the flags depend on rebuilds them with the list it finds here, so they are current.
+    if (count == c->kin_count && (count == 0 || memcmp(indices, c->kin_indices.data(), (size_t)count * 4) == 0)) return BEPUHIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->d_kin) { hipFree(c->d_kin); c->d_kin = nullptr; }
