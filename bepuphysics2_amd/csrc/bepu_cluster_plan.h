@@ -656,7 +656,9 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         fprintf(stderr, "bepuhip plan_split_clusters: %-44s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - split_t0).count());
         split_t0 = now;
     };
-    // adjacency of dynamic bodies (CSR), degree d per body
+    // adjacency of dynamic bodies (CSR), degree d per body. One thread: on the hosts this was measured on, an owner-computes build (every thread walks all references and
+    // fills its own bodies' lists, so that the lists keep the serial order) and atomic counts LOSE to this loop — 11.4 against 8.2 ms for the crowd — the tables fit the
+    // cache of one core and sixteen walks over all references do not.
     std::vector<uint8_t> is_dyn(universe, 0);
     std::vector<int32_t> deg(universe, 0);
     for (auto& tb : c->tbs)
@@ -677,7 +679,8 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     std::vector<int64_t> adj_begin(universe + 1, 0);
     for_each_edge([&](int32_t a, int32_t b) { ++adj_begin[a + 1]; ++adj_begin[b + 1]; });
     for (int i = 0; i < universe; ++i) adj_begin[i + 1] += adj_begin[i];
-    std::vector<int32_t> adj(adj_begin[universe]);
+    std::unique_ptr<int32_t[]> adj_store(new int32_t[std::max<int64_t>(adj_begin[universe], 1)]);  // (every entry is written below)
+    int32_t* const adj = adj_store.get();
     {
         std::vector<int64_t> fill(adj_begin.begin(), adj_begin.end() - 1);
         for_each_edge([&](int32_t a, int32_t b) { adj[fill[a]++] = b; adj[fill[b]++] = a; });
@@ -772,24 +775,31 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     std::vector<uint8_t> in_cover;
     if (env_int("BEPUHIP_SPLIT_COVER", 1)) {
         std::vector<int32_t> crossing(universe, 0);
+        std::vector<PlanPiece> pieces;  // two-body type batches in pieces: the counts are sums, and the cover only asks WHETHER a body's crossing constraints are covered
+        for (size_t t = 0; t < c->tbs.size(); ++t)
+            if (c->tbs[t].info.bodies == 2)
+                for (int b = 0; b < c->tbs[t].count; b += kPlanPiece) pieces.push_back({(int32_t)t, b, std::min(c->tbs[t].count, b + kPlanPiece)});
         auto for_each_crossing = [&](auto&& fn) {
-            for (auto& tb : c->tbs) {
-                if (tb.info.bodies != 2) continue;
-                for (int i = 0; i < tb.count; ++i) {
+            plan_parallel_for(pieces.size(), [&](size_t piece) {
+                const HostTypeBatch& tb = c->tbs[pieces[piece].t];
+                for (int i = pieces[piece].begin; i < pieces[piece].end; ++i) {
                     const int32_t a = tb.refs_soa[i], b = tb.refs_soa[(size_t)tb.stride + i];
                     if ((uint32_t)a < kDynamicLimit && (uint32_t)b < kDynamicLimit && body_cluster[a] != body_cluster[b]) fn(a, b);
                 }
-            }
+            });
         };
-        for_each_crossing([&](int32_t a, int32_t b) { ++crossing[a]; ++crossing[b]; });
+        for_each_crossing([&](int32_t a, int32_t b) { __atomic_fetch_add(&crossing[a], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&crossing[b], 1, __ATOMIC_RELAXED); });
         std::vector<int32_t> order;
         for (int v = 0; v < universe; ++v) if (crossing[v] > 0) order.push_back(v);
         std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return crossing[x] > crossing[y]; });
         // greedy cover in one sweep: a body enters the cover if one of its crossing constraints is still uncovered (its other body is not in the cover yet)
-        std::vector<int32_t> across_begin(universe + 1, 0);  // the other bodies of every body's crossing constraints (CSR)
+        std::vector<int32_t> across_begin(universe + 1, 0);  // the other bodies of every body's crossing constraints (CSR; a body's entries in no particular order)
         for (int v = 0; v < universe; ++v) across_begin[v + 1] = across_begin[v] + crossing[v];
         std::vector<int32_t> across(across_begin[universe]), fill(across_begin.begin(), across_begin.end() - 1);
-        for_each_crossing([&](int32_t a, int32_t b) { across[fill[a]++] = b; across[fill[b]++] = a; });
+        for_each_crossing([&](int32_t a, int32_t b) {
+            across[__atomic_fetch_add(&fill[a], 1, __ATOMIC_RELAXED)] = b;
+            across[__atomic_fetch_add(&fill[b], 1, __ATOMIC_RELAXED)] = a;
+        });
         in_cover.assign(universe, 0);
         for (int32_t v : order) {
             bool uncovered = false;
@@ -798,10 +808,14 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         }
     }
     std::atomic<int> bodiless{0};
-    plan_parallel_for(c->tbs.size(), [&](size_t t) {  // (several type batches may mark the same body shared: the same byte, the same value)
+    std::vector<PlanPiece> all_pieces;
+    for (size_t t = 0; t < c->tbs.size(); ++t)
+        for (int b = 0; b < c->tbs[t].count; b += kPlanPiece) all_pieces.push_back({(int32_t)t, b, std::min(c->tbs[t].count, b + kPlanPiece)});
+    plan_parallel_for(c->tbs.size(), [&](size_t t) { cl_of_constraint[t].resize(c->tbs[t].count); });
+    plan_parallel_for(all_pieces.size(), [&](size_t piece) {  // (several constraints may mark the same body shared: the same byte, the same value)
+        const size_t t = (size_t)all_pieces[piece].t;
         HostTypeBatch& tb = c->tbs[t];
-        cl_of_constraint[t].resize(tb.count);
-        for (int i = 0; i < tb.count; ++i) {
+        for (int i = all_pieces[piece].begin; i < all_pieces[piece].end; ++i) {
             int cl = -1;
             for (int k = 0; k < tb.info.bodies && cl < 0; ++k) {
                 const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
@@ -849,11 +863,21 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     {
         std::vector<int32_t> next_rank(universe, 0), last_cluster(universe, -1);
         std::vector<uint32_t*> last_word(universe, nullptr);
-        for (size_t t = 0; t < c->tbs.size(); ++t) srank[t].assign((size_t)c->tbs[t].info.bodies * c->tbs[t].stride, 0u);
-        for (size_t t = 0; t < c->tbs.size(); ++t) {  // batch order == type batch order; inside a batch a body appears at most once
+        plan_parallel_for(c->tbs.size(), [&](size_t t) { srank[t].assign((size_t)c->tbs[t].info.bodies * c->tbs[t].stride, 0u); });
+        // Batch order == type batch order, and inside a batch a body appears at most once: the batches one after the other, every batch's constraints side by side
+        // (what a constraint reads and writes here belongs to its own bodies).
+        std::vector<PlanPiece> pieces;
+        for (size_t t0 = 0; t0 < c->tbs.size();) {
+            size_t t1 = t0;
+            pieces.clear();
+            for (; t1 < c->tbs.size() && c->tbs[t1].batch == c->tbs[t0].batch; ++t1)
+                for (int b = 0; b < c->tbs[t1].count; b += kPlanPiece) pieces.push_back({(int32_t)t1, b, std::min(c->tbs[t1].count, b + kPlanPiece)});
+            t0 = t1;
+            plan_parallel_for(pieces.size(), [&](size_t piece) {
+            const size_t t = (size_t)pieces[piece].t;
             HostTypeBatch& tb = c->tbs[t];
             for (int k = 0; k < tb.info.bodies; ++k)
-                for (int i = 0; i < tb.count; ++i) {
+                for (int i = pieces[piece].begin; i < pieces[piece].end; ++i) {
                     const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
                     if ((uint32_t)r >= kDynamicLimit || !shared[r]) continue;
                     uint32_t& word = srank[t][(size_t)k * tb.stride + i];
@@ -863,12 +887,19 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
                     if (local_handoff && allowed && last_word[r] != nullptr && last_cluster[r] == cl_of_constraint[t][i]) { word |= kPlanRankPredLocal; *last_word[r] |= kPlanRankSuccLocal; }
                     last_word[r] = &word; last_cluster[r] = cl_of_constraint[t][i];
                 }
+            });
         }
     }
     split_lap("rank words");
     // ---- slots: home bodies (ascending), then ghosts and kinematic copies on first use ----
     std::vector<std::vector<int32_t>> cl_bodies(nclusters);
     std::vector<int32_t> local_of(universe, -1);
+    {
+        std::vector<int32_t> homes(nclusters, 0);
+        for (int i = 0; i < universe; ++i) if (is_dyn[i]) ++homes[body_cluster[i]];
+        for (int cl = 0; cl < nclusters; ++cl) cl_bodies[cl].reserve((size_t)homes[cl] + homes[cl] / 2 + 16);  // (room for the ghosts and kinematic copies that follow)
+        plan.clustered_dynamic.reserve(plan.clustered_dynamic.size() + (size_t)total_dyn);
+    }
     for (int i = 0; i < universe; ++i)
         if (is_dyn[i]) { const int cl = body_cluster[i]; local_of[i] = (int)cl_bodies[cl].size(); cl_bodies[cl].push_back(i | (shared[i] ? kSlotSharedHome : 0)); plan.clustered_dynamic.push_back(i); }
     std::vector<std::unordered_map<int32_t, int32_t>> cl_extra(nclusters);  // body | kind flag -> natural local index of ghosts and kinematic copies
@@ -887,26 +918,32 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         // A copy gets its natural index when the cluster first meets it, type batches in order, constraints in order. The references that need a copy are listed per
         // type batch on the plan threads, strung together per cluster in that order, and every cluster then numbers its own (the hash tables are the expensive part).
         std::vector<int32_t> item_count(nclusters, 0);
-        std::vector<std::vector<std::pair<int32_t, int32_t>>> wanted(c->tbs.size());  // (cluster, tagged body) in the order a serial scan meets them
-        std::vector<std::vector<int32_t>> per_cluster(c->tbs.size());
-        plan_parallel_for(c->tbs.size(), [&](size_t t) {
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> wanted(all_pieces.size());  // (cluster, tagged body) in the order a serial scan meets them, piece by piece
+        std::vector<std::vector<int32_t>> per_cluster(c->tbs.size()), piece_clusters(all_pieces.size());
+        plan_parallel_for(all_pieces.size(), [&](size_t piece) {
+            const size_t t = (size_t)all_pieces[piece].t;
             const HostTypeBatch& tb = c->tbs[t];
-            per_cluster[t].assign(nclusters, 0);
-            for (int i = 0; i < tb.count; ++i) {
+            std::vector<int32_t>& counts = piece_clusters[piece];
+            counts.assign(nclusters, 0);
+            for (int i = all_pieces[piece].begin; i < all_pieces[piece].end; ++i) {
                 const int cl = cl_of_constraint[t][i];
-                per_cluster[t][cl]++;
+                counts[cl]++;
                 for (int k = 0; k < tb.info.bodies; ++k) {
                     const int32_t r = tb.refs_soa[(size_t)k * tb.stride + i];
-                    if ((uint32_t)r >= kDynamicLimit) wanted[t].push_back({cl, (r & kRefMask) | kSlotKinematic});
-                    else if (body_cluster[r] != cl) wanted[t].push_back({cl, r | kSlotGhost});
+                    if ((uint32_t)r >= kDynamicLimit) wanted[piece].push_back({cl, (r & kRefMask) | kSlotKinematic});
+                    else if (body_cluster[r] != cl) wanted[piece].push_back({cl, r | kSlotGhost});
                 }
             }
         });
         std::vector<std::vector<int32_t>> met(nclusters);
-        for (size_t t = 0; t < c->tbs.size(); ++t) {
-            for (auto& pair : wanted[t]) met[pair.first].push_back(pair.second);
-            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (split_segment_slots(per_cluster[t][cl], reserve) + 63) / 64 + 1;
+        for (size_t t = 0; t < c->tbs.size(); ++t) per_cluster[t].assign(nclusters, 0);
+        for (size_t piece = 0; piece < all_pieces.size(); ++piece) {  // (type batches in order, a type batch's pieces in order)
+            for (auto& pair : wanted[piece]) met[pair.first].push_back(pair.second);
+            std::vector<int32_t>& sum = per_cluster[all_pieces[piece].t];
+            for (int cl = 0; cl < nclusters; ++cl) sum[cl] += piece_clusters[piece][cl];
         }
+        for (size_t t = 0; t < c->tbs.size(); ++t)
+            for (int cl = 0; cl < nclusters; ++cl) item_count[cl] += (split_segment_slots(per_cluster[t][cl], reserve) + 63) / 64 + 1;
         plan_parallel_for((size_t)nclusters, [&](size_t cl) { for (int32_t tagged : met[cl]) extra_local((int)cl, tagged); });
         int max_slots = 0, max_items = 0;
         for (int cl = 0; cl < nclusters; ++cl) {
@@ -1139,7 +1176,8 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         if (nb == 1) for (int d = 0; d < tb.slots; ++d) if (tb.perm[d] < 0) packed[d] = (int32_t)kLrefDead;
         tb.lrefs_soa.swap(packed);
     });
-    for (int cl = 0; cl < nclusters; ++cl) {
+    plan_parallel_for((size_t)nclusters, [&](size_t cluster) {
+        const int cl = (int)cluster;
         for (auto& fs : first_touch[cl]) {
             ClusterItem& it = cl_items[cl][fs.first];
             const int last = last_toucher[cl][fs.second];
@@ -1151,9 +1189,17 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             if (nx < kMaxPreds) { it.xpred[nx++] = (unsigned short)last; it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (nx << 20); }
             else it.batch_npred = (it.batch_npred & ~(0xF << 20)) | (1 << 25);
         }
-    }
+    });
     split_lap("packed local references, cross-pass lists");
     int64_t shared_count = 0, ghost_slots = 0;
+    {
+        size_t slots = 0, items = 0;
+        for (int cl = 0; cl < nclusters; ++cl) { slots += (cl_bodies[cl].size() + 15) / 16 * 16 + (size_t)slot_reserve; items += cl_items[cl].size(); }
+        plan.cluster_bodies.reserve(plan.cluster_bodies.size() + slots);
+        plan.items.reserve(plan.items.size() + items);
+        plan.batch_item_begin.reserve(plan.batch_item_begin.size() + (size_t)nclusters * (c->batch_count + 1));
+        plan.clusters.reserve(plan.clusters.size() + nclusters);
+    }
     for (int cl = 0; cl < nclusters; ++cl) {
         ClusterDesc d;
         d.body_begin = (int)plan.cluster_bodies.size();
@@ -1177,18 +1223,18 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     plan.shared_info.assign(universe, 0u);
     for (int i = 0; i < universe; ++i) if (shared[i]) { plan.shared_info[i] = (uint32_t)deg[i]; ++shared_count; }
     plan.shared = true;
-    // what structural updates need in order to stay on this plan (bepu_soft_updates.h, split part)
-    plan.body_cluster = body_cluster;
-    plan.body_lref.assign(universe, -1);
-    for (int i = 0; i < universe; ++i) if (is_dyn[i]) plan.body_lref[i] = rotated_slot(local_of[i]);
-    plan.split_shared = shared;
-    plan.split_degree = deg;
+    // what structural updates need in order to stay on this plan (bepu_soft_updates.h, split part); the planner's own tables are handed over, not copied
+    plan_parallel_ranges((size_t)universe, 32768, [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) if (local_of[i] >= 0) local_of[i] = rotated_slot(local_of[i]); });
+    plan.body_lref.swap(local_of);  // (-1 for every body that is not dynamic here)
+    plan.body_cluster.swap(body_cluster);
+    plan.split_shared.swap(shared);
+    plan.split_degree.swap(deg);
     plan.cluster_natural.resize(nclusters);
     plan.cluster_extra.resize(nclusters);
-    for (int cl = 0; cl < nclusters; ++cl) {
+    plan_parallel_for((size_t)nclusters, [&](size_t cl) {
         plan.cluster_natural[cl] = (int32_t)cl_bodies[cl].size();
         for (auto& kv : cl_extra[cl]) plan.cluster_extra[cl].emplace(kv.first, rotated_slot(kv.second));
-    }
+    });
     split_lap("descriptors, mirrors");
     plan.planes = cluster_lds_bytes(kAllPlanes, plan.max_slots, plan.max_items, true) <= kLdsBudgetBytes ? kAllPlanes : kSweepPlanes;
     plan.enabled = nclusters > 0 && plan.max_slots < 0x4000 && cluster_lds_bytes(plan.planes, plan.max_slots, plan.max_items, true) <= kLdsBudgetBytes;
