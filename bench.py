@@ -376,6 +376,58 @@ def optional_leg(fn, *a, **k):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+EXTRA_LEGS = ("pile", "crowd", "sweep", "widened", "boundary", "lattice")
+
+
+def run_extra_leg(name: str, args, device: int):
+    """One extra leg by name, in this process (the child side of `leg_in_child`)."""
+    from bepuphysics2_amd.scene import PoseIntegratorCallbacks
+    targs = None if args.no_traffic else args
+    if name == "pile":
+        return connected_scene_leg("100k-box pile (BASELINE.json configs[1])", "pile", args.ragdolls, device, traffic_args=targs)
+    if name == "crowd":
+        return connected_scene_leg(f"{args.ragdolls} ragdolls in contact with their neighbours (configs[2]'s ragdolls, one island)", "crowd", args.ragdolls, device, traffic_args=targs)
+    if name == "sweep":
+        return scale_sweep_leg(args, device, args.ragdolls)
+    if name == "widened":
+        return widened_types_leg(args.ragdolls, device)
+    if name == "boundary":
+        scene, sd = build_scene(args.ragdolls, 5)
+        return boundary_leg(scene, sd, PoseIntegratorCallbacks(), device)
+    if name == "lattice":
+        return lattice_leg(device)
+    raise ValueError(name)
+
+
+def leg_in_child(name: str, args, device: int, timeout: float = 900.0):
+    """An extra leg in a process of its own: `optional_leg` catches exceptions, but a leg that takes the PROCESS down (a device fault aborts it) would take the
+    headline's JSON line with it — seen once in round 5 (`profiles/r05_s30_bench_fault.txt`: a memory access fault inside the lattice leg, after 205 GPU tests had
+    passed on the same library; eight repeats of that leg alone ran clean). The parent has closed its context by then: the child is alone on the GPU, as the legs were
+    when they ran in-process. What comes back is the leg's report, or the way the child ended."""
+    import subprocess
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix=f"bepu_leg_{name}_", suffix=".json", dir="/tmp")
+    os.close(fd)
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg-child", name, "--leg-out", path, "--ragdolls", str(args.ragdolls)] + (["--no-traffic"] if args.no_traffic else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BEPU_BENCH_FORCE_DIST")}
+    env["BEPU_BENCH_LEG_DEVICE"] = str(device)
+    try:
+        done = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+        try:
+            with open(path) as f:
+                return json.load(f)
+        except (OSError, ValueError):
+            tail = [ln for ln in done.stderr.decode(errors="replace").splitlines() if ln.strip() and "RCCL" not in ln and "ibrccl" not in ln][-2:]
+            return {"error": f"leg '{name}' ended with exit code {done.returncode} and no report: " + " | ".join(tail)[:300]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"leg '{name}' did not finish within {timeout:.0f} s"}
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
 def widened_types_leg(ragdolls: int, device: int, steps: int = 100):
     """The widened constraint types on the driver line (never `value`): the bench scene's ragdolls — same bodies, same constraint graph, same batches — with the seven
     joint types other than BallSocket replaced by widened ones (synthetic.RIG_REMAP: AngularSwivelHinge, DistanceLimit, AngularServo, TwistMotor, AngularAxisMotor, Weld,
@@ -880,6 +932,9 @@ def main():
     ap.add_argument("--no-connected-scenes", action="store_true", help="skip the extra legs on connected scenes (100k-box pile = configs[1]; ragdoll crowd)")
     ap.add_argument("--full-report", default=None, help="where the long form of the bench line goes (default gpurun_out/bench_full.json); stdout carries the compact line")
     ap.add_argument("--no-scale-sweep", action="store_true", help="skip the scale_sweep leg (the headline scene at 1x / 2x / 4x / 8x the ragdolls)")
+    ap.add_argument("--legs-in-process", action="store_true", help="run the extra legs in this process instead of one child process each (a leg that aborts then takes the JSON line with it)")
+    ap.add_argument("--leg-child", default=None, choices=list(EXTRA_LEGS), help=argparse.SUPPRESS)
+    ap.add_argument("--leg-out", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -890,6 +945,17 @@ def main():
 
     if args.traffic_child:
         return traffic_child(args, local_rank)
+    if args.leg_child:
+        import torch
+        if not torch.cuda.is_available():  # (also brings torch's device state up before the library's, the order the parent process has: the counters' pass asks torch for the CU count)
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        torch.cuda.init()
+        from bepuphysics2_amd import build
+        build.build_all()
+        report = optional_leg(run_extra_leg, args.leg_child, args, int(os.environ.get("BEPU_BENCH_LEG_DEVICE", "0")))
+        with open(args.leg_out, "w") as f:
+            json.dump(report, f)
+        return
 
     import torch
     dist = None
@@ -1027,12 +1093,12 @@ def main():
     main_clustered = bool(solver.cluster_cycles().size)
     row_policy = {-1: "still measuring", 0: "plain constraint-row accesses", 1: "non-temporal constraint-row accesses", 2: "plain rows + one 8 KB span of code touched ahead per work item"}[solver.row_policy()] if main_clustered else None
     connected = None
+    def extra(name):  # (every extra leg in a process of its own unless --legs-in-process: leg_in_child)
+        return optional_leg(run_extra_leg, name, args, local_rank) if args.legs_in_process else leg_in_child(name, args, local_rank)
+
     if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
         solver.close()
-        targs = None if args.no_traffic else args
-        connected = {"pile_100k": optional_leg(connected_scene_leg, "100k-box pile (BASELINE.json configs[1])", "pile", args.ragdolls, local_rank, traffic_args=targs),
-                     "ragdoll_crowd": optional_leg(connected_scene_leg, f"{args.ragdolls} ragdolls in contact with their neighbours (configs[2]'s ragdolls, one island)",
-                                                   "crowd", args.ragdolls, local_rank, traffic_args=targs)}
+        connected = {"pile_100k": extra("pile"), "ragdoll_crowd": extra("crowd")}
 
     boundary = None
     lattice_report = None
@@ -1040,11 +1106,11 @@ def main():
     sweep = None
     if rank == 0 and world == 1 and not args.no_scale_sweep and not args.no_connected_scenes and not args.traffic_child:
         solver.close()
-        sweep = optional_leg(scale_sweep_leg, args, local_rank, args.ragdolls)
+        sweep = extra("sweep")
     if rank == 0 and world == 1 and not args.no_connected_scenes and not args.traffic_child:
-        widened = optional_leg(widened_types_leg, args.ragdolls, local_rank)
-        boundary = optional_leg(boundary_leg, scene, sd, cb, local_rank)
-        lattice_report = lattice_leg(local_rank)
+        widened = extra("widened")
+        boundary = extra("boundary")
+        lattice_report = extra("lattice")
 
     if rank == 0:
         value = whole_job_rate
