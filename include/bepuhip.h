@@ -107,7 +107,8 @@ int32_t bepuhip_end_constraints(bepuhip_ctx* ctx);
  * (handleToLocation[handle].Index, BepuPhysics/PoseIntegrator.cs:467). The reference keeps that set current inside Solver.Add / Solver.Remove (BepuPhysics/Solver.cs:1025, :1374);
  * here it is the caller's: after bepuhip_add_constraint / bepuhip_remove_constraint calls that gave a kinematic body its first constraint or took its last, send the list again before the
  * next solve (it is cheap: indices only). A kinematic body is integrated per substep inside the solve when it is on the list and once after it when it is not (PoseIntegrator.cs:451-535, :707)
- * — the two differ in the last bits of the pose. */
+ * — the two differ in the last bits of the pose. A call with the list the context already holds returns at once (a host that uploads its constraints again every
+ * frame hands the same list over every frame). */
 int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* ctx, const int32_t* body_indices, int32_t count);
 
 /* Replaces the body of Simulation.Solve (BepuPhysics/Simulation.cs:278-290): integration-responsibility prepass
