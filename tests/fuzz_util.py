@@ -131,11 +131,14 @@ def check_device_scene(p, jitter: int = 0):
 STRUCTURAL_TYPES = [4, 5, 6, 7, 22, 25, 30, 47, 0, 3, 23, 46]  # two-body manifolds and joints, one-body manifolds
 
 
-def run_structural_scene(rng, jitter: int = 0) -> dict:
+def run_structural_scene(rng, jitter: int = 0, touch_environment: bool = True, oracle_lock=None) -> dict:
     """One random scene of joints and contact manifolds; every frame a random number of removals (swap-with-last) and additions (random pairs, random types — inside an
     island, across islands, into new batches or type batches, onto reserved slots or not), now and then a body removal (Bodies.RemoveAt's move of the last body) or a
     re-plan, with and without BEPUHIP_FLAG_RESERVE_UPDATE_SLOTS, on both schedules; the device follows through the structural entry points and is compared with the
-    oracle solving the host mirror, bit for bit, after every frame. Returns the scene's statistics ('ok': no frame differed)."""
+    oracle solving the host mirror, bit for bit, after every frame. Returns the scene's statistics ('ok': no frame differed).
+    ``touch_environment`` False (tests/soak_util.py: several of these at once on threads of one process): the developer switches are left alone — setenv beside another
+    thread's getenv is a race of its own; ``oracle_lock``: held around the checker's calls."""
+    import contextlib
     from mutable_scene import MutableSolver
     stats = {"ok": True, "frames": 0, "refused": 0, "replans": 0, "body_removals": 0, "report": ""}
     big = rng.random() < 0.3  # one island no workgroup holds: the split-island plan (forced cluster counts so that small scenes split too)
@@ -165,7 +168,7 @@ def run_structural_scene(rng, jitter: int = 0) -> dict:
         add_random()
     sub = int(rng.integers(1, 5))
     sd, cb = SolveDescription(int(rng.integers(1, 4)), sub), PoseIntegratorCallbacks()
-    with environment(BEPUHIP_SPLIT_CLUSTERS=split, BEPUHIP_DEBUG_JITTER=jitter or None):
+    with (environment(BEPUHIP_SPLIT_CLUSTERS=split, BEPUHIP_DEBUG_JITTER=jitter or None) if touch_environment else contextlib.nullcontext()):
         solver = HipSolver(use_clusters=bool(rng.random() < 0.8), reserve_update_slots=bool(rng.integers(2)))
         try:
             solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
@@ -199,7 +202,8 @@ def run_structural_scene(rng, jitter: int = 0) -> dict:
                     export = ms.to_scene()
                     kin = np.ascontiguousarray(export.constrained_kinematic_indices(), dtype=np.int32)  # Solver.ConstrainedKinematicHandles changes with the constraints: the caller re-sends it
                     native._check(solver.lib, solver.lib.bepuhip_set_constrained_kinematics(solver.ctx, native._ptr(kin), kin.size))
-                    oracle_ffi.solve(export, 1 / 60, sd, cb)
+                    with (oracle_lock or contextlib.nullcontext()):
+                        oracle_ffi.solve(export, 1 / 60, sd, cb)
                     ms.absorb(export)
                     solver.solve(1 / 60, sd, cb)
                     got = ms.to_scene()
