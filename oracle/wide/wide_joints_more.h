@@ -355,10 +355,18 @@ struct AngularAxisGearMotorFunctions {                                          
     }
 };
 
-// MathHelper.FastReciprocal / FastReciprocalSquareRoot (BepuUtilities/MathHelper.cs:380-412): the branch every target without the x86 approximation instructions takes.
-// (On AVX hosts the reference uses vrcpps / vrsqrtps, whose low bits differ between CPU vendors; oracle/ and the device restate this portable branch too.)
+// MathHelper.FastReciprocal / FastReciprocalSquareRoot (BepuUtilities/MathHelper.cs:380-412). Default: the branch every target without the x86 approximation
+// instructions takes (`Vector<float>.One / v`, :392 and :409) — what oracle/ and the device restate too.
+// -DWIDE_FAST_RECIPROCAL_X86: the branch an AVX host takes (`Avx.Reciprocal` :384, `Avx.ReciprocalSqrt` :401 = vrcpps / vrsqrtps, the very instructions; relative
+// error <= 1.5 * 2^-12, low bits vendor-specific). Built as wide/libbepu_wide_rcpx86.so and used ONLY to measure how far the portable branch (= the device) is from
+// what the reference computes on the x86 host beside the GPU (tests/test_fast_reciprocal.py) — it is not a parity checker for the device.
+#ifdef WIDE_FAST_RECIPROCAL_X86
+static inline VF FastReciprocal(VF v) { return (VF)_mm256_rcp_ps((__m256)v); }
+static inline VF FastReciprocalSquareRoot(VF v) { return (VF)_mm256_rsqrt_ps((__m256)v); }
+#else
 static inline VF FastReciprocal(VF v) { return kOne / v; }
 static inline VF FastReciprocalSquareRoot(VF v) { return kOne / SquareRoot(v); }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------- CenterDistanceConstraint (type id 35)
 struct CenterDistancePrestepData { VF TargetDistance; SpringSettingsWide SpringSettings; };  // CenterDistanceConstraint.cs:63

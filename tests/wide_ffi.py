@@ -18,7 +18,8 @@ _libs = {}
 
 
 def load(variant: str = "") -> C.CDLL:
-    """variant: "" (-O2 checker), "fast" (-O3, bench.py's cpu_baseline), "zerominus" (Vector<T> unary minus as Zero - v, wide_vec.h)."""
+    """variant: "" (-O2 checker), "fast" (-O3, bench.py's cpu_baseline), "zerominus" (Vector<T> unary minus as Zero - v, wide_vec.h),
+    "rcpx86" (MathHelper.FastReciprocal[SquareRoot] as vrcpps / vrsqrtps: the reference's branch on an AVX host, wide_joints_more.h)."""
     name = f"libbepu_wide_{variant}.so" if variant else "libbepu_wide.so"
     if name not in _libs:
         path = os.path.join(WIDE_DIR, name)
