@@ -251,7 +251,8 @@ struct bepuhip_ctx {
     int cluster_first = 0, cluster_local = 0;
     std::vector<int32_t> group_body_cluster;  // body -> cluster of the plan (group_world > 1: which device owns a body at the end of a step)
     std::vector<void*> peer_records;          // the record tables of the other devices, by peer ordinal (rank order, this rank left out)
-    std::vector<void*> peer_opened;           // ... those opened from an IPC handle by this context (closed with it)
+    std::vector<void*> peer_opened;           // ... those opened from an IPC handle by this context, by peer ordinal (closed with it, or when the peer's table is imported again)
+    std::vector<uint8_t> peer_on_this_device; // by peer ordinal: the table lies in THIS device's memory (members of a group sharing one device: a test configuration, see group_queue_check)
     float4** d_peer_table = nullptr;
     float4* group_records = nullptr;          // the record table of a group member: allocated once (for group_records_bodies bodies), reused by every later plan that fits
     size_t group_records_bodies = 0;
@@ -336,6 +337,19 @@ struct bepuhip_ctx {
     int prof_launches[6] = {0, 0, 0, 0, 0, 0};
     std::map<GraphKey, hipGraphExec_t> graphs;  // captured launch sequences, one per (iteration schedule, dt, integrator); at most kMaxCachedGraphs
 };
+
+// Every copy and fill of the library runs on the context's own (non-blocking) stream — never on the legacy stream. A legacy-stream call (hipMemcpy, hipMemset) made on one
+// host thread while ANOTHER thread of the process has a stream in capture fails with hipErrorStreamCaptureImplicit and invalidates that thread's capture, whatever the
+// capture mode and although the streams are non-blocking (ROCm 7.2; found by tests/test_gpu_soak.py: two contexts on two threads, one capturing its launch-per-batch
+// graph while the other uploads); the legacy stream is also not ordered with a non-blocking stream, so a fill issued on it is not ordered with the kernels that follow
+// on the context's stream. copy_sync returns when the bytes have arrived (pageable or registered host memory alike).
+static hipError_t copy_sync(bepuhip_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (bytes == 0) return hipSuccess;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
+}
+static hipError_t fill_async(bepuhip_ctx* c, void* dst, int value, size_t bytes) { return bytes == 0 ? hipSuccess : hipMemsetAsync(dst, value, bytes, c->stream); }
+
 
 static void clear_graphs(bepuhip_ctx* c) {
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);

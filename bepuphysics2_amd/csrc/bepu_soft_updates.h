@@ -220,6 +220,7 @@ static bool soft_adopt_body(bepuhip_ctx* c, int32_t body, int cl) {
     c->cluster_free_slots[cl].pop_back();
     soft_patch_slot_table(c, cl, slot, body);
     c->body_cluster[body] = cl; c->body_lref[body] = slot;
+    c->owned_mask_bodies = 0;  // device groups: which member owns the body at the end of a step follows its cluster (owned_body_mask reads the live table)
     soft_clustered_positions(c);
     c->clustered_position[body] = (int32_t)c->clustered_dynamic_host.size();
     c->clustered_dynamic_host.push_back(body);
@@ -235,6 +236,7 @@ static void soft_release_body(bepuhip_ctx* c, int32_t body) {
     soft_patch_slot_table(c, cl, slot, -1);
     c->cluster_free_slots[cl].push_back(slot);
     c->body_cluster[body] = -1;
+    c->owned_mask_bodies = 0;  // device groups: which member owns the body at the end of a step follows its cluster (owned_body_mask reads the live table)
     soft_clustered_positions(c);
     auto at = c->clustered_position.find(body);
     if (at != c->clustered_position.end()) {
@@ -288,6 +290,7 @@ static bool soft_move_body(bepuhip_ctx* c, int32_t from, int32_t to, bool kinema
     if (c->body_cluster[to] >= 0) return soft_refuse("a body moved onto one that still has constraints");
     const int cl = c->body_cluster[from], slot = c->body_lref[from] & 0x3FFF;
     c->body_cluster[to] = cl; c->body_lref[to] = c->body_lref[from]; c->body_cluster[from] = -1;
+    c->owned_mask_bodies = 0;  // device groups: which member owns the body at the end of a step follows its cluster (owned_body_mask reads the live table)
     c->body_degree[to] = c->body_degree[from]; c->body_degree[from] = 0;
     c->body_batches[to] = c->body_batches[from]; c->body_batches[from] = 0;
     int32_t entry = to;
@@ -926,7 +929,7 @@ static int32_t flush_soft(bepuhip_ctx* c) {
     if (c->clustered_dirty) {  // bodies joined or left the plan: the list behind kFlagClustered
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (!c->clustered_dynamic_host.empty())
-            HIP_TRY(hipMemcpy(c->d_clustered_dynamic, c->clustered_dynamic_host.data(), c->clustered_dynamic_host.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(copy_sync(c, c->d_clustered_dynamic, c->clustered_dynamic_host.data(), c->clustered_dynamic_host.size() * 4, hipMemcpyHostToDevice));
         c->clustered_dynamic_count = (int)c->clustered_dynamic_host.size();
         c->clustered_dirty = false;
     }
@@ -937,7 +940,7 @@ static int32_t flush_soft(bepuhip_ctx* c) {
         c->kinlist_count = (int)c->kinlist_host.size();
         if (c->kinlist_count > 0) {
             HIP_TRY(hipMalloc((void**)&c->d_kinlist, c->kinlist_host.size() * 4));
-            HIP_TRY(hipMemcpy(c->d_kinlist, c->kinlist_host.data(), c->kinlist_host.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(copy_sync(c, c->d_kinlist, c->kinlist_host.data(), c->kinlist_host.size() * 4, hipMemcpyHostToDevice));
         }
         c->soft_flags_stale = true;
     }

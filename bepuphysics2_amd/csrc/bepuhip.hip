@@ -77,12 +77,16 @@ static int32_t create_device_objects(bepuhip_ctx* c) {
     HIP_TRY(hipEventCreate(&c->ev_stop));
     HIP_TRY(hipHostMalloc((void**)&c->d_status, 256, hipHostMallocMapped | hipHostMallocCoherent));  // host-visible while a kernel runs
     HIP_TRY(hipMalloc((void**)&c->d_staged, 4));
-    HIP_TRY(hipMemset(c->d_staged, 0, 4));
+    HIP_TRY(fill_async(c, c->d_staged, 0, 4));
     memset(c->d_status, 0, 256);
     return BEPUHIP_OK;
 }
 
 int32_t bepuhip_destroy(bepuhip_ctx* c);
+
+// Live contexts per device (each holds one stream): what group_queue_check counts.
+constexpr int kMaxCountedDevices = 64;
+static std::atomic<int> g_live_contexts[kMaxCountedDevices];
 
 int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx) {
     if (!config || !out_ctx) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
@@ -98,6 +102,7 @@ int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx) {
     c->W = config->bundle_width;
     c->flags = config->flags;
     const int32_t st = create_device_objects(c);
+    if (c->device < kMaxCountedDevices) g_live_contexts[c->device].fetch_add(1);
     if (st != BEPUHIP_OK) { bepuhip_destroy(c); return st; }  // the message of the failing call stays in bepuhip_last_error
     *out_ctx = c;
     return BEPUHIP_OK;
@@ -114,6 +119,7 @@ static void release_comm(bepuhip_ctx* c);
 int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (!c) return BEPUHIP_OK;
     hipSetDevice(c->device);
+    if (c->device < kMaxCountedDevices) g_live_contexts[c->device].fetch_sub(1);
     if (c->stream) hipStreamSynchronize(c->stream);
     free_constraints(c);
     if (c->d_bodies) hipFree(c->d_bodies);
@@ -133,7 +139,7 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_mesh_scales) hipFree(c->d_mesh_scales);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->h_desc_ring) hipHostFree(c->h_desc_ring);
-    for (void* opened : c->peer_opened) hipIpcCloseMemHandle(opened);
+    for (void* opened : c->peer_opened) if (opened) hipIpcCloseMemHandle(opened);
     if (c->group_records) hipFree(c->group_records);
     if (c->d_peer_table) hipFree(c->d_peer_table);
     if (c->d_owned_dense) hipFree(c->d_owned_dense);
@@ -373,6 +379,7 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
 
 static int32_t build_constraints(bepuhip_ctx* c);
 static int32_t flush_structural(bepuhip_ctx* c);
+static int32_t group_queue_check(const bepuhip_ctx* c);
 static int32_t leave_island_schedule(bepuhip_ctx* c);
 
 int32_t bepuhip_end_constraints(bepuhip_ctx* c) {
@@ -485,17 +492,17 @@ static int32_t build_descriptors(bepuhip_ctx* c, const std::vector<std::vector<i
     c->inc_tb_count = (int)inc.size();
     if (!index_pool.empty()) {
         HIP_TRY(hipMalloc((void**)&c->d_fallback_indices, index_pool.size() * 4));
-        HIP_TRY(hipMemcpy(c->d_fallback_indices, index_pool.data(), index_pool.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, c->d_fallback_indices, index_pool.data(), index_pool.size() * 4, hipMemcpyHostToDevice));
         for (auto& fx : desc_fixups) descs[fx.first].indices = c->d_fallback_indices + fx.second;
         for (auto& fx : inc_fixups) inc[fx.first].indices = c->d_fallback_indices + fx.second;
     }
     if (!descs.empty()) {
         HIP_TRY(hipMalloc((void**)&c->d_tbs, descs.size() * sizeof(DevTypeBatch)));
-        HIP_TRY(hipMemcpy(c->d_tbs, descs.data(), descs.size() * sizeof(DevTypeBatch), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, c->d_tbs, descs.data(), descs.size() * sizeof(DevTypeBatch), hipMemcpyHostToDevice));
     }
     if (!inc.empty()) {
         HIP_TRY(hipMalloc((void**)&c->d_inc_tbs, inc.size() * sizeof(DevTypeBatch)));
-        HIP_TRY(hipMemcpy(c->d_inc_tbs, inc.data(), inc.size() * sizeof(DevTypeBatch), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, c->d_inc_tbs, inc.data(), inc.size() * sizeof(DevTypeBatch), hipMemcpyHostToDevice));
     }
     return BEPUHIP_OK;
 }
@@ -612,7 +619,7 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         if (bytes == 0) return hipSuccess;
         hipError_t e = hipMalloc(dst, bytes);
         if (e != hipSuccess) return e;
-        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return copy_sync(c, *dst, src, bytes, hipMemcpyHostToDevice);
     };
     c->kinlist_count = (int)plan.kinlist.size();
     HIP_TRY(upload_ints(plan.kinlist.data(), plan.kinlist.size() * 4, (void**)&c->d_kinlist));
@@ -622,7 +629,7 @@ static int32_t build_constraints(bepuhip_ctx* c) {
         c->cluster_max_slots = plan.max_slots;
         c->cluster_planes = plan.planes;
         HIP_TRY(hipMalloc((void**)&c->d_cycles, plan.clusters.size() * 8));
-        HIP_TRY(hipMemset(c->d_cycles, 0, plan.clusters.size() * 8));
+        HIP_TRY(fill_async(c, c->d_cycles, 0, plan.clusters.size() * 8));
         c->first_cluster = plan.clusters[0];
         c->cluster_max_items = plan.max_items;
         for (auto& it : plan.items) {  // resolve the items' slab offsets now that the slab layout exists
@@ -642,7 +649,7 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             c->clustered_dynamic_capacity = (int)plan.clustered_dynamic.size() + std::max(256, (int)plan.clustered_dynamic.size() / 16);
             HIP_TRY(hipMalloc((void**)&c->d_clustered_dynamic, (size_t)c->clustered_dynamic_capacity * 4));
             if (!plan.clustered_dynamic.empty())
-                HIP_TRY(hipMemcpy(c->d_clustered_dynamic, plan.clustered_dynamic.data(), plan.clustered_dynamic.size() * 4, hipMemcpyHostToDevice));
+                HIP_TRY(copy_sync(c, c->d_clustered_dynamic, plan.clustered_dynamic.data(), plan.clustered_dynamic.size() * 4, hipMemcpyHostToDevice));
         }
         for (int threads : kClusterThreadChoices)
             for (int tr = 0; tr < 2; ++tr)
@@ -690,11 +697,11 @@ static int32_t build_constraints(bepuhip_ctx* c) {
             } else {
                 HIP_TRY(hipMalloc((void**)&c->d_shared_vel, c->shared_bodies * 4 * sizeof(float4)));  // two records (substep parity) of two float4 per body
             }
-            HIP_TRY(hipMemset(c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4)));         // cleared here, then never again: every step's event numbers start above the last step's
+            HIP_TRY(fill_async(c, c->d_shared_vel, 0, c->shared_bodies * 4 * sizeof(float4)));         // cleared here, then never again: every step's event numbers start above the last step's
             c->shared_epoch = 0;
             HIP_TRY(hipMalloc((void**)&c->d_shared_info, c->shared_bodies * 4));
-            HIP_TRY(hipMemset(c->d_shared_info, 0, c->shared_bodies * 4));
-            if (!plan.shared_info.empty()) HIP_TRY(hipMemcpy(c->d_shared_info, plan.shared_info.data(), plan.shared_info.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(fill_async(c, c->d_shared_info, 0, c->shared_bodies * 4));
+            if (!plan.shared_info.empty()) HIP_TRY(copy_sync(c, c->d_shared_info, plan.shared_info.data(), plan.shared_info.size() * 4, hipMemcpyHostToDevice));
             for (int threads : kClusterThreadChoices)
                 for (int tr = 0; tr < 2; ++tr)
                     for (int wide = 0; wide < 2; ++wide)
@@ -729,7 +736,7 @@ int32_t bepuhip_replan(bepuhip_ctx* c) {
         nt.refs_off = nt.prestep_off = nt.accum_off = nt.lrefs_off = 0;
         nt.refs_soa.assign((size_t)tb.info.bodies * nt.stride, -1);
         for (int k = 0; k < tb.info.bodies && tb.count > 0; ++k)
-            HIP_TRY(hipMemcpy(nt.refs_soa.data() + (size_t)k * nt.stride, c->d_slab + tb.refs_off + (size_t)k * tb.stride, (size_t)tb.count * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(copy_sync(c, nt.refs_soa.data() + (size_t)k * nt.stride, c->d_slab + tb.refs_off + (size_t)k * tb.stride, (size_t)tb.count * 4, hipMemcpyDeviceToHost));
         uint32_t* const slabs[2] = {c->d_slab, c->d_slab0};
         for (int which = 0; which < 2; ++which) {
             nt.old_prestep[which] = slabs[which] + tb.prestep_off;
@@ -780,7 +787,7 @@ int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* c, const int32_t* indice
     c->kin_indices.assign(indices, indices + count);
     if (count > 0) {
         HIP_TRY(hipMalloc((void**)&c->d_kin, (size_t)count * 4));
-        HIP_TRY(hipMemcpy(c->d_kin, indices, (size_t)count * 4, hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, c->d_kin, indices, (size_t)count * 4, hipMemcpyHostToDevice));
     }
     return rebuild_flags(c);
 }
@@ -836,7 +843,7 @@ static int32_t build_requirk_lists(bepuhip_ctx* c) {
         const int nb = tb.info.bodies;
         if (tb.count == 0) continue;
         std::vector<int32_t> rows((size_t)nb * tb.stride);
-        HIP_TRY(hipMemcpy(rows.data(), c->d_slab + tb.refs_off, rows.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(c, rows.data(), c->d_slab + tb.refs_off, rows.size() * 4, hipMemcpyDeviceToHost));
         host_refs[t].assign((size_t)nb * tb.count, -1);
         for (int i = 0; i < tb.count; ++i) {
             const int d = tb.perm.empty() ? i : tb.perm_inverse(i);
@@ -922,7 +929,7 @@ static int32_t build_requirk_lists(bepuhip_ctx* c) {
     c->requirk_begin[lists.size()] = (int)flat.size();
     if (!flat.empty()) {
         HIP_TRY(hipMalloc((void**)&c->d_requirk, flat.size() * 4));
-        HIP_TRY(hipMemcpy(c->d_requirk, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, c->d_requirk, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
     }
     // the island layouts' bits: the old ones go (their words may belong to other constraints by now), the new ones come — in the working rows and in the snapshot
     for (int pass = 0; pass < 2; ++pass) {
@@ -930,7 +937,7 @@ static int32_t build_requirk_lists(bepuhip_ctx* c) {
         if (list.empty() || !c->d_slab) continue;
         BitMark* d_marks = nullptr;
         HIP_TRY(hipMalloc((void**)&d_marks, list.size() * sizeof(BitMark)));
-        HIP_TRY(hipMemcpy(d_marks, list.data(), list.size() * sizeof(BitMark), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, d_marks, list.data(), list.size() * sizeof(BitMark), hipMemcpyHostToDevice));
         for (uint32_t* slab : {c->d_slab, c->d_slab0})
             if (slab) hipLaunchKernelGGL(mark_bits_kernel, dim3(((int)list.size() + 255) / 256), dim3(256), 0, c->stream, slab, (const BitMark*)d_marks, (int)list.size(), pass);
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1019,11 +1026,15 @@ static int cluster_threads(const bepuhip_ctx* c) {
 }
 // The momentum-conserving angular modes run the island schedule through the kernel units that carry their code (round 3; BEPUHIP_CONSERVING_CLUSTERS=0: launch-per-batch
 // as in round 2), which exist for the default workgroup sizes.
+static bool group_chain_hazard(const bepuhip_ctx* c, int launches) { return c->group_world > 1 && c->clusters_shared && launches > 1; }
 static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const bepuhip_integrator* in) {
     // (round 5: a sequential fallback batch runs the island schedule under the conserving modes as well — the substep-0 re-transformation of a non-integrating lane is a
     // bit on that lane like in every other batch, build_requirk_lists; BEPUHIP_FALLBACK_CONSERVING_CLUSTERS=0: the per-level lists of the launch-per-batch schedule)
     // (round 5: any number of substeps — a step of more than kMaxClusterSubsteps is a chain of launches, enqueue_island_launches)
-    (void)substeps;
+    // (round 6, ADVICE r5: NOT in a device group on a split plan — between two launches of a chain every slot, ghost copies included, is staged again from THIS device's
+    // HBM, and a ghost's home cluster may have run on another device: such a step runs the launch-per-batch schedule, on every member over the whole scene — identical
+    // results on all of them, so the owners' merge is unaffected)
+    if (group_chain_hazard(c, (substeps + kMaxClusterSubsteps - 1) / kMaxClusterSubsteps)) return false;
     return c->clusters_enabled && !(c->has_fallback && in->angular_integration_mode != 0 && env_int("BEPUHIP_FALLBACK_CONSERVING_CLUSTERS", 1) == 0) &&
            cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared) <= kLdsBudgetBytes &&
            (in->angular_integration_mode == 0 || (conserving_variant_exists(cluster_threads(c), c->clusters_shared) && c->d_trace == nullptr && env_int("BEPUHIP_CONSERVING_CLUSTERS", 1) != 0));
@@ -1191,7 +1202,7 @@ static int32_t recount_referenced_bodies(bepuhip_ctx* c) {
         if (extent == 0) continue;
         row.resize(extent);
         for (int k = 0; k < tb.info.bodies; ++k) {
-            HIP_TRY(hipMemcpy(row.data(), c->d_slab + tb.refs_off + (size_t)k * tb.stride, (size_t)extent * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(copy_sync(c, row.data(), c->d_slab + tb.refs_off + (size_t)k * tb.stride, (size_t)extent * 4, hipMemcpyDeviceToHost));
             for (int32_t r : row) if (r >= 0) highest = std::max(highest, r & kRefMask);
         }
     }
@@ -1223,6 +1234,7 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     int32_t st = validate_solve(c, dt, substeps, iterations, in);
     if (st != BEPUHIP_OK) return st;
     HIP_TRY(hipSetDevice(c->device));
+    if ((st = group_queue_check(c)) != BEPUHIP_OK) return st;
     if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
     if (c->clusters_enabled && !island_schedule_applies(c, substeps, in)) {
         // the launch-per-batch kernels address rows [0, count): an island layout with free slots between the live ones has to be brought back into the caller's order first
@@ -1274,7 +1286,11 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
             if (graph != nullptr) hipGraphDestroy(graph);
             if (launch_err != hipSuccess || end_err != hipSuccess || inst_err != hipSuccess || exec == nullptr) {
                 if (exec != nullptr) hipGraphExecDestroy(exec);
-                (void)hipGetLastError();
+                // A capture can be invalidated from outside the library (another thread's legacy-stream call, ROCm 7.2: bepu_host_state.h, copy_sync): make sure the
+                // stream has left capture mode and no error of the dead capture is left behind for the eager launches to trip over.
+                hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(c->stream, &status) == hipSuccess && status != hipStreamCaptureStatusNone) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(c->stream, &dead); if (dead) hipGraphDestroy(dead); }
+                for (int k = 0; k < 4 && hipGetLastError() != hipSuccess; ++k) {}
                 HIP_TRY(hipEventRecord(c->ev_start, c->stream));
                 enqueue_solve(c, dt, substeps, iterations, in);  // eager fallback for this call; the next call tries to capture again
                 HIP_TRY(hipGetLastError());
@@ -1303,7 +1319,7 @@ int32_t bepuhip_solve_with_substep_events(bepuhip_ctx* c, float dt, int32_t subs
     if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
     // Round 5: a context on an island plan raises the events BETWEEN launches of the island kernel — one substep per launch (enqueue_island_launch), the bodies in HBM
     // with the substep's pose and velocities while the handler runs, so that what it rewrites through the update_* entry points is what the next launch stages.
-    const bool islands = island_schedule_applies(c, substeps, in) && env_int("BEPUHIP_EVENT_CLUSTERS", 1) != 0;
+    const bool islands = island_schedule_applies(c, substeps, in) && env_int("BEPUHIP_EVENT_CLUSTERS", 1) != 0 && !group_chain_hazard(c, substeps);  // (one launch per substep: a chain)
     if (c->clusters_enabled && !islands) {  // the launch-per-batch kernels address rows [0, count): an island layout with free slots goes back into the caller's order first
         bool gaps = false;
         for (auto& tb : c->tbs) gaps |= tb.slots > 0 && tb.slots != tb.count;
@@ -1385,7 +1401,7 @@ int32_t bepuhip_set_boundary_bodies(bepuhip_ctx* c, const int32_t* indices, int3
         HIP_TRY(hipMalloc((void**)&c->d_boundary, (size_t)count * 4));
         HIP_TRY(hipMalloc((void**)&c->d_boundary_snapshot, (size_t)count * 32));
         HIP_TRY(hipMalloc((void**)&c->d_boundary_buf, (size_t)count * 24));
-        HIP_TRY(hipMemcpy(c->d_boundary, indices, (size_t)count * 4, hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, c->d_boundary, indices, (size_t)count * 4, hipMemcpyHostToDevice));
     }
     return rebuild_flags(c);
 }
@@ -1430,7 +1446,9 @@ int32_t bepuhip_colour_constraints(int32_t device, const int32_t* refs, int32_t 
     if (count == 0) return BEPUHIP_OK;
     HIP_TRY(hipSetDevice(device));
     int* d_refs = nullptr; int* d_colour = nullptr; unsigned* d_degree = nullptr; unsigned long long* d_words = nullptr; unsigned* d_remaining = nullptr;
-    auto release = [&]() { for (void* p : {(void*)d_refs, (void*)d_colour, (void*)d_degree, (void*)d_words, (void*)d_remaining}) if (p) hipFree(p); };
+    hipStream_t stream = nullptr;  // a stream of its own, non-blocking: nothing of the library runs on the legacy stream (bepu_host_state.h, copy_sync)
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    auto release = [&]() { hipStreamSynchronize(stream); for (void* p : {(void*)d_refs, (void*)d_colour, (void*)d_degree, (void*)d_words, (void*)d_remaining}) if (p) hipFree(p); hipStreamDestroy(stream); };
     const size_t nb = (size_t)std::max(body_count, 1);
     hipError_t e = hipMalloc((void**)&d_refs, (size_t)count * kColourBodies * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&d_colour, (size_t)count * 4);
@@ -1439,13 +1457,13 @@ int32_t bepuhip_colour_constraints(int32_t device, const int32_t* refs, int32_t 
     if (e == hipSuccess) e = hipMalloc((void**)&d_remaining, 4);
     if (e != hipSuccess) { release(); return fail(BEPUHIP_E_DEVICE, std::string("colour_constraints: ") + hipGetErrorString(e)); }
     unsigned long long* d_priority = d_words; unsigned long long* d_best = d_words + count; unsigned long long* d_used = d_best + nb;
-    hipMemcpy(d_refs, refs, (size_t)count * kColourBodies * 4, hipMemcpyHostToDevice);
-    hipMemset(d_colour, 0xFF, (size_t)count * 4);
-    hipMemset(d_degree, 0, nb * 4);
-    hipMemset(d_used, 0, nb * 8);
+    hipMemcpyAsync(d_refs, refs, (size_t)count * kColourBodies * 4, hipMemcpyHostToDevice, stream);
+    hipMemsetAsync(d_colour, 0xFF, (size_t)count * 4, stream);
+    hipMemsetAsync(d_degree, 0, nb * 4, stream);
+    hipMemsetAsync(d_used, 0, nb * 8, stream);
     const dim3 grid((count + 255) / 256), block(256);
-    hipLaunchKernelGGL(colour_degree_kernel, grid, block, 0, 0, (const int*)d_refs, count, d_degree);
-    hipLaunchKernelGGL(colour_priority_kernel, grid, block, 0, 0, (const int*)d_refs, count, (const unsigned*)d_degree, order, d_priority);
+    hipLaunchKernelGGL(colour_degree_kernel, grid, block, 0, stream, (const int*)d_refs, count, d_degree);
+    hipLaunchKernelGGL(colour_priority_kernel, grid, block, 0, stream, (const int*)d_refs, count, (const unsigned*)d_degree, order, d_priority);
     // Rounds are enqueued eight at a time; the host only looks at the count of uncoloured constraints behind each group (a round after the last useful one finds
     // nothing to do and costs two near-empty launches), so the loop runs on the device and the host reads four bytes every eight rounds.
     constexpr int kRoundsPerCheck = 8;
@@ -1455,20 +1473,22 @@ int32_t bepuhip_colour_constraints(int32_t device, const int32_t* refs, int32_t 
     int rounds = 0;
     for (bool done = false; !done;) {
         if (rounds > count + kRoundsPerCheck) { hipFree(d_remaining_slots); release(); return fail(BEPUHIP_E_DEVICE, "colour_constraints made no progress"); }  // every round colours at least the highest bid
-        hipMemsetAsync(d_remaining_slots, 0, kRoundsPerCheck * 4, 0);
+        hipMemsetAsync(d_remaining_slots, 0, kRoundsPerCheck * 4, stream);
         for (int k = 0; k < kRoundsPerCheck; ++k) {
-            hipMemsetAsync(d_best, 0, nb * 8, 0);
-            hipLaunchKernelGGL(colour_bid_kernel, grid, block, 0, 0, (const int*)d_refs, count, (const int*)d_colour, (const unsigned long long*)d_priority, d_best);
-            hipLaunchKernelGGL(colour_pick_kernel, grid, block, 0, 0, (const int*)d_refs, count, d_colour, (const unsigned long long*)d_priority, (const unsigned long long*)d_best, d_used,
+            hipMemsetAsync(d_best, 0, nb * 8, stream);
+            hipLaunchKernelGGL(colour_bid_kernel, grid, block, 0, stream, (const int*)d_refs, count, (const int*)d_colour, (const unsigned long long*)d_priority, d_best);
+            hipLaunchKernelGGL(colour_pick_kernel, grid, block, 0, stream, (const int*)d_refs, count, d_colour, (const unsigned long long*)d_priority, (const unsigned long long*)d_best, d_used,
                                fallback_batch_threshold, d_remaining_slots + k);
         }
         unsigned remaining[kRoundsPerCheck];
-        e = hipMemcpy(remaining, d_remaining_slots, sizeof(remaining), hipMemcpyDeviceToHost);
+        e = hipMemcpyAsync(remaining, d_remaining_slots, sizeof(remaining), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) { hipFree(d_remaining_slots); release(); return fail(BEPUHIP_E_DEVICE, std::string("colour_constraints: ") + hipGetErrorString(e)); }
         for (int k = 0; k < kRoundsPerCheck && !done; ++k) { ++rounds; done = remaining[k] == 0; }  // rounds = the rounds that were needed
     }
     hipFree(d_remaining_slots);
-    e = hipMemcpy(colours_out, d_colour, (size_t)count * 4, hipMemcpyDeviceToHost);
+    e = hipMemcpyAsync(colours_out, d_colour, (size_t)count * 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
     release();
     if (e != hipSuccess) return fail(BEPUHIP_E_DEVICE, std::string("colour_constraints: ") + hipGetErrorString(e));
     int highest = -1;
@@ -1498,11 +1518,11 @@ int32_t bepuhip_set_boundary_layout(bepuhip_ctx* c, const int32_t* dense_rows, i
     hipError_t e = hipMalloc((void**)&c->d_boundary_dense, (size_t)dense_row_count * 24);
     if (e == hipSuccess && c->boundary_count > 0) {
         e = hipMalloc((void**)&c->d_boundary_rows, (size_t)c->boundary_count * 4);
-        if (e == hipSuccess) e = hipMemcpy(c->d_boundary_rows, dense_rows, (size_t)c->boundary_count * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = copy_sync(c, c->d_boundary_rows, dense_rows, (size_t)c->boundary_count * 4, hipMemcpyHostToDevice);
     }
     if (e == hipSuccess && holders) {
         e = hipMalloc((void**)&c->d_boundary_holders, (size_t)dense_row_count * 4);
-        if (e == hipSuccess) e = hipMemcpy(c->d_boundary_holders, holders, (size_t)dense_row_count * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = copy_sync(c, c->d_boundary_holders, holders, (size_t)dense_row_count * 4, hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) {
         free_boundary_layout(c);
@@ -1750,16 +1770,38 @@ static int32_t upload_peer_table(bepuhip_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!c->d_peer_table) HIP_TRY(hipMalloc((void**)&c->d_peer_table, kMaxPeers * sizeof(void*)));
-    if (!c->peer_records.empty()) HIP_TRY(hipMemcpy(c->d_peer_table, c->peer_records.data(), c->peer_records.size() * sizeof(void*), hipMemcpyHostToDevice));
+    if (!c->peer_records.empty()) HIP_TRY(copy_sync(c, c->d_peer_table, c->peer_records.data(), c->peer_records.size() * sizeof(void*), hipMemcpyHostToDevice));
     return BEPUHIP_OK;
 }
 int32_t bepuhip_set_peer_records(bepuhip_ctx* c, int32_t peer, void* records) {
     if (!c || peer < 0 || peer >= c->group_world - 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "a group of N devices has N - 1 peers (ordinals 0 .. N - 2)");
     if ((int)c->peer_records.size() <= peer) c->peer_records.resize(peer + 1, nullptr);
     c->peer_records[peer] = records;
+    if ((int)c->peer_on_this_device.size() <= peer) c->peer_on_this_device.resize(peer + 1, 0);
+    hipPointerAttribute_t where;
+    c->peer_on_this_device[peer] = records && hipPointerGetAttributes(&where, records) == hipSuccess && where.device == c->device ? 1 : 0;
+    (void)hipGetLastError();
     for (void* p : c->peer_records) if (!p) return BEPUHIP_OK;  // incomplete: the table is uploaded with the last entry
     if ((int)c->peer_records.size() != c->group_world - 1) return BEPUHIP_OK;
     return upload_peer_table(c);
+}
+// Members of a device group wait for each other INSIDE their kernels, so their kernels must run at the same time. One member per device (the deployment) has a device's
+// queues to itself. Members that share a device (a test configuration: this pool has single-GPU boxes) depend on the runtime giving each of their streams a hardware queue
+// of its own: ROCm multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues per device, the null stream included, and two members whose
+// streams share a queue run one after the other — each waits for the other's records until the watchdog words report a stall (found by tests/test_gpu_soak.py: two members
+// beside two idle contexts). Refused up front instead: more live contexts on the device than hardware queues left.
+static int32_t group_queue_check(const bepuhip_ctx* c) {
+    if (c->group_world <= 1 || !c->clusters_shared || c->device >= kMaxCountedDevices || env_int("BEPUHIP_GROUP_QUEUE_CHECK", 1) == 0) return BEPUHIP_OK;
+    bool shares_device = false;
+    for (uint8_t same : c->peer_on_this_device) shares_device |= same != 0;
+    if (!shares_device) return BEPUHIP_OK;
+    static const int hw_queues = std::max(1, env_int("GPU_MAX_HW_QUEUES", 4));
+    const int live = g_live_contexts[c->device].load();
+    if (live + 1 > hw_queues)
+        return fail(BEPUHIP_E_STATE, "device group members share device " + std::to_string(c->device) + " with " + std::to_string(live) + " live contexts, but the runtime has " + std::to_string(hw_queues) +
+                    " hardware queues per device (null stream included): members whose streams share a queue cannot run at the same time. Destroy idle contexts, or start the process "
+                    "with GPU_MAX_HW_QUEUES=" + std::to_string(live + 1) + " or more (one member per device needs neither)");
+    return BEPUHIP_OK;
 }
 int32_t bepuhip_export_shared_records(bepuhip_ctx* c, void* ipc_handle_out) {
     if (!c || !ipc_handle_out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
@@ -1773,12 +1815,16 @@ int32_t bepuhip_export_shared_records(bepuhip_ctx* c, void* ipc_handle_out) {
 }
 int32_t bepuhip_import_peer_records(bepuhip_ctx* c, int32_t peer, const void* ipc_handle) {
     if (!c || !ipc_handle) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    if (peer < 0 || peer >= c->group_world - 1) return fail(BEPUHIP_E_INVALID_ARGUMENT, "a group of N devices has N - 1 peers (ordinals 0 .. N - 2)");
     HIP_TRY(hipSetDevice(c->device));
     hipIpcMemHandle_t handle;
     memcpy(&handle, ipc_handle, sizeof(handle));
     void* opened = nullptr;
     HIP_TRY(hipIpcOpenMemHandle(&opened, handle, hipIpcMemLazyEnablePeerAccess));
-    c->peer_opened.push_back(opened);
+    // A peer whose scene outgrew its table frees it and exports a new one (the header's re-exchange): the mapping of the old table is closed here, not at destroy
+    if ((int)c->peer_opened.size() <= peer) c->peer_opened.resize(peer + 1, nullptr);
+    if (c->peer_opened[peer] && c->peer_opened[peer] != opened) { HIP_TRY(hipStreamSynchronize(c->stream)); hipIpcCloseMemHandle(c->peer_opened[peer]); }
+    c->peer_opened[peer] = opened;
     return bepuhip_set_peer_records(c, peer, opened);
 }
 // 1 for the bodies whose state this context leaves final at the end of a solve: the bodies of its own clusters, and — on rank 0 — the bodies of no cluster
@@ -1786,7 +1832,10 @@ int32_t bepuhip_import_peer_records(bepuhip_ctx* c, int32_t peer, const void* ip
 static void owned_body_mask(const bepuhip_ctx* c, std::vector<uint8_t>& mask, int count) {
     mask.assign((size_t)count, 0);
     for (int i = 0; i < count; ++i) {
-        const int cl = (size_t)i < c->group_body_cluster.size() ? c->group_body_cluster[i] : -1;
+        // the LIVE body -> cluster table when the context keeps one (structural updates move bodies between clusters, bring them into the plan and take them out:
+        // bepu_soft_updates.h), else the upload's snapshot — such a context leaves the island schedule at its first structural update
+        const std::vector<int32_t>& body_cluster = c->soft_ok ? c->body_cluster : c->group_body_cluster;
+        const int cl = (size_t)i < body_cluster.size() ? body_cluster[i] : -1;
         mask[i] = cl < 0 ? (c->group_rank == 0) : (cl >= c->cluster_first && cl < c->cluster_first + c->cluster_local);
     }
 }
@@ -1838,7 +1887,7 @@ int32_t bepuhip_sync_owned_bodies(bepuhip_ctx* c) {
         HIP_TRY(hipMalloc((void**)&c->d_owned_dense, (size_t)c->body_count * 64));
         std::vector<uint8_t> mask;
         owned_body_mask(c, mask, c->body_count);
-        HIP_TRY(hipMemcpy(c->d_owned_mask, mask.data(), mask.size(), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, c->d_owned_mask, mask.data(), mask.size(), hipMemcpyHostToDevice));
         c->owned_mask_bodies = c->body_count;
     }
     const unsigned blocks = (unsigned)(((size_t)c->body_count * 4 + 255) / 256);
@@ -1881,7 +1930,7 @@ int32_t bepuhip_get_bodies(bepuhip_ctx* c, void* out, int32_t count) {
     if (!c || (!out && count > 0) || count < 0 || count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad get_bodies argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (count > 0) HIP_TRY(hipMemcpy(out, c->d_bodies, (size_t)count * 128, hipMemcpyDeviceToHost));  // an empty simulation is a valid one
+    if (count > 0) HIP_TRY(copy_sync(c, out, c->d_bodies, (size_t)count * 128, hipMemcpyDeviceToHost));  // an empty simulation is a valid one
     return BEPUHIP_OK;
 }
 
@@ -1984,7 +2033,7 @@ static int32_t download_aosoa(bepuhip_ctx* c, HostTypeBatch* tb, size_t off, int
     if (tb->count == 0) return BEPUHIP_OK;
     std::vector<float> soa((size_t)fields * tb->stride);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(soa.data(), c->d_slab + off, soa.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(c, soa.data(), c->d_slab + off, soa.size() * 4, hipMemcpyDeviceToHost));
     const int W = c->W;
     for (int i = 0; i < tb->count; ++i) {
         const size_t bundle = (size_t)(i / W), lane = (size_t)(i % W);
@@ -2061,7 +2110,7 @@ static int32_t flush_structural(bepuhip_ctx* c) {
         for (auto& tb : c->tbs) {
             if (tb.batch != c->fallback_threshold) continue;
             std::vector<int32_t> rows((size_t)tb.info.bodies * tb.stride, -1);
-            if (!rows.empty() && c->d_slab) HIP_TRY(hipMemcpy(rows.data(), c->d_slab + tb.refs_off, rows.size() * 4, hipMemcpyDeviceToHost));
+            if (!rows.empty() && c->d_slab) HIP_TRY(copy_sync(c, rows.data(), c->d_slab + tb.refs_off, rows.size() * 4, hipMemcpyDeviceToHost));
             fallback_refs.push_back(std::move(rows));
         }
     if ((st = build_descriptors(c, fallback_refs)) != BEPUHIP_OK) return st;
@@ -2374,7 +2423,7 @@ int32_t bepuhip_set_velocity_model(bepuhip_ctx* c, const bepuhip_velocity_model*
             HIP_TRY(hipMalloc((void**)&c->d_body_gravity, (size_t)body_count * 4));
             c->body_gravity_capacity = body_count;
         }
-        HIP_TRY(hipMemcpy(c->d_body_gravity, per_body_gravity, (size_t)body_count * 4, hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, c->d_body_gravity, per_body_gravity, (size_t)body_count * 4, hipMemcpyHostToDevice));
         c->body_gravity_count = body_count;
     }
     c->velocity_model = *model;
@@ -2398,7 +2447,7 @@ static int32_t device_index_of(bepuhip_ctx* c, HostTypeBatch* tb, const int** ou
     if (!tb->d_device_index) {
         tb->perm_inverse(0);
         HIP_TRY(hipMalloc((void**)&tb->d_device_index, std::max<size_t>(tb->inv.size(), (size_t)tb->device_extent()) * 4));  // room for every index additions on the island layout can create
-        if (!tb->inv.empty()) HIP_TRY(hipMemcpy(tb->d_device_index, tb->inv.data(), tb->inv.size() * 4, hipMemcpyHostToDevice));
+        if (!tb->inv.empty()) HIP_TRY(copy_sync(c, tb->d_device_index, tb->inv.data(), tb->inv.size() * 4, hipMemcpyHostToDevice));
     }
     *out = tb->d_device_index;
     return BEPUHIP_OK;
@@ -2532,7 +2581,7 @@ int32_t bepuhip_get_bodies_range(bepuhip_ctx* c, void* aos_out, int32_t first, i
     if (count == 0) return BEPUHIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(aos_out, c->d_bodies + (size_t)first * 8, (size_t)count * 128, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(c, aos_out, c->d_bodies + (size_t)first * 8, (size_t)count * 128, hipMemcpyDeviceToHost));
     return BEPUHIP_OK;
 }
 
@@ -2577,8 +2626,8 @@ int32_t bepuhip_set_convex_hulls(bepuhip_ctx* c, const float* points, const int3
     const size_t total = (size_t)point_begin[hull_count];
     HIP_TRY(hipMalloc((void**)&c->d_hull_points, total * 12));
     HIP_TRY(hipMalloc((void**)&c->d_hull_begin, ((size_t)hull_count + 1) * 4));
-    HIP_TRY(hipMemcpy(c->d_hull_points, points, total * 12, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_hull_begin, point_begin, ((size_t)hull_count + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(c, c->d_hull_points, points, total * 12, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(c, c->d_hull_begin, point_begin, ((size_t)hull_count + 1) * 4, hipMemcpyHostToDevice));
     c->hull_count = hull_count;
     return BEPUHIP_OK;
 }
@@ -2608,8 +2657,8 @@ int32_t bepuhip_set_compounds(bepuhip_ctx* c, const bepuhip_compound_child* chil
     const size_t total = (size_t)child_begin[compound_count];
     HIP_TRY(hipMalloc((void**)&c->d_compound_children, total * sizeof(CompoundChildIn)));
     HIP_TRY(hipMalloc((void**)&c->d_compound_begin, ((size_t)compound_count + 1) * 4));
-    HIP_TRY(hipMemcpy(c->d_compound_children, children, total * sizeof(CompoundChildIn), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_compound_begin, child_begin, ((size_t)compound_count + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(c, c->d_compound_children, children, total * sizeof(CompoundChildIn), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(c, c->d_compound_begin, child_begin, ((size_t)compound_count + 1) * 4, hipMemcpyHostToDevice));
     c->compound_count = compound_count;
     c->compound_hulls_needed = hulls_needed;
     return BEPUHIP_OK;
@@ -2629,9 +2678,9 @@ int32_t bepuhip_set_meshes(bepuhip_ctx* c, const float* triangles, const int32_t
     HIP_TRY(hipMalloc((void**)&c->d_mesh_triangles, total * 36));
     HIP_TRY(hipMalloc((void**)&c->d_mesh_begin, ((size_t)mesh_count + 1) * 4));
     HIP_TRY(hipMalloc((void**)&c->d_mesh_scales, (size_t)mesh_count * 12));
-    HIP_TRY(hipMemcpy(c->d_mesh_triangles, triangles, total * 36, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_mesh_begin, triangle_begin, ((size_t)mesh_count + 1) * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_mesh_scales, scales, (size_t)mesh_count * 12, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(c, c->d_mesh_triangles, triangles, total * 36, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(c, c->d_mesh_begin, triangle_begin, ((size_t)mesh_count + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(c, c->d_mesh_scales, scales, (size_t)mesh_count * 12, hipMemcpyHostToDevice));
     c->mesh_count = mesh_count;
     return BEPUHIP_OK;
 }
@@ -2652,7 +2701,7 @@ int32_t bepuhip_set_collidables(bepuhip_ctx* c, const bepuhip_collidable* collid
     }
     if (count > 0) {
         HIP_TRY(hipMalloc((void**)&c->d_collidables, (size_t)count * sizeof(CollidableIn)));
-        HIP_TRY(hipMemcpy(c->d_collidables, collidables, (size_t)count * sizeof(CollidableIn), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, c->d_collidables, collidables, (size_t)count * sizeof(CollidableIn), hipMemcpyHostToDevice));
     }
     return BEPUHIP_OK;
 }
@@ -2705,7 +2754,7 @@ int32_t bepuhip_get_constrained_flags(bepuhip_ctx* c, uint8_t* out, int32_t coun
     HIP_TRY(hipSetDevice(c->device));
     std::vector<unsigned> f((size_t)count);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (count > 0) HIP_TRY(hipMemcpy(f.data(), c->d_flags, (size_t)count * 4, hipMemcpyDeviceToHost));
+    if (count > 0) HIP_TRY(copy_sync(c, f.data(), c->d_flags, (size_t)count * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < count; ++i) out[i] = (uint8_t)(f[i] & 3u);
     return BEPUHIP_OK;
 }
@@ -2736,7 +2785,7 @@ int32_t bepuhip_set_cluster_trace(bepuhip_ctx* c, int32_t enabled) {
         const ClusterDesc first = c->first_cluster;
         c->trace_words = (size_t)first.item_count * 8 * (size_t)kClusterTracePasses;  // up to 128 passes of cluster 0; the kernel drops later ones
         HIP_TRY(hipMalloc((void**)&c->d_trace, c->trace_words * 8));
-        HIP_TRY(hipMemset(c->d_trace, 0, c->trace_words * 8));
+        HIP_TRY(fill_async(c, c->d_trace, 0, c->trace_words * 8));
     }
     return BEPUHIP_OK;
 }
@@ -2746,7 +2795,7 @@ int32_t bepuhip_get_cluster_trace(bepuhip_ctx* c, uint64_t* out, int64_t capacit
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const size_t n = std::min<size_t>(c->trace_words, (size_t)std::max<int64_t>(capacity_words, 0));
-    HIP_TRY(hipMemcpy(out, c->d_trace, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(c, out, c->d_trace, n * 8, hipMemcpyDeviceToHost));
     *items_out = c->first_cluster.item_count;
     return BEPUHIP_OK;
 }
@@ -2763,7 +2812,7 @@ int32_t bepuhip_get_cluster_cycles(bepuhip_ctx* c, uint64_t* out, int32_t capaci
     if (!c->clusters_enabled || capacity <= 0) return BEPUHIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, c->d_cycles, (size_t)std::min(capacity, c->cluster_count) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(c, out, c->d_cycles, (size_t)std::min(capacity, c->cluster_count) * 8, hipMemcpyDeviceToHost));
     return BEPUHIP_OK;
 }
 int32_t bepuhip_debug_status(bepuhip_ctx* c, uint32_t* out16) {

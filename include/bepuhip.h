@@ -209,7 +209,14 @@ int32_t bepuhip_solve_lattice(bepuhip_ctx* ctx, float dt, int32_t substep_count,
  * Structural updates, bepuhip_replan and the momentum-conserving modes work as on one device as long as every member makes the same calls. A member's table keeps its
  * address across its own uploads and re-plans (the peers' mappings stay valid) unless the scene outgrows it by more than a quarter: get_shared_records then returns a new
  * address and the members exchange tables again, behind a host barrier — as after any upload, since every member clears its table when it plans. (Event numbers wrap after
- * about two million steps of a context; a group re-uploads before that.) */
+ * about two million steps of a context; a group re-uploads before that.)
+ * Round 6: (1) ownership follows structural updates — a body that joins, leaves or changes its cluster is owned by the member that runs its cluster from the next solve on
+ * (get_owned_bodies / sync_owned_bodies read the live body -> cluster table); (2) a step that needs a CHAIN of island launches — more than 64 substeps, or
+ * bepuhip_solve_with_substep_events — runs the launch-per-batch schedule in a group (every member over the whole scene, identical results; the owners' merge is unchanged):
+ * between two launches of a chain a cluster stages its ghost copies from its own device's memory, where another device's results have not arrived; (3) importing a peer's
+ * table again closes the mapping of the old one; (4) members that SHARE a device (the single-GPU tests; never a deployment) need a hardware queue each — the runtime
+ * multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4, null stream included) queues per device, and two members on one queue wait for each other until the
+ * watchdog reports a stall: a solve is refused with BEPUHIP_E_STATE when more contexts of this library are alive on the device than queues are left. */
 #define BEPUHIP_IPC_HANDLE_BYTES 64
 int32_t bepuhip_set_device_group(bepuhip_ctx* ctx, int32_t world, int32_t rank);
 int32_t bepuhip_get_shared_records(bepuhip_ctx* ctx, void** records_out, int64_t* bytes_out);

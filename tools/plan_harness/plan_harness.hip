@@ -435,6 +435,12 @@ int main(int argc, char** argv) {
         if (fread(t.refs.data(), 4, h[3], f) != (size_t)h[3] || fread(t.prestep.data(), 4, h[4], f) != (size_t)h[4] || fread(t.accum.data(), 4, h[5], f) != (size_t)h[5]) return 2;
     }
     fclose(f);
+    // PLAN_THREADS=N (round 6, the sanitizer runs: hipcc -fsanitize=thread / address -fno-gpu-sanitize): N host threads run the repeats at the same time, each on contexts of
+    // its own — two contexts planning at once contend for the parked plan pool exactly as two uploading threads of one process do (the second caller gets threads of its own).
+    const int harness_threads = getenv("PLAN_THREADS") ? std::max(1, atoi(getenv("PLAN_THREADS"))) : 1;
+    std::atomic<int> verdict_all{0};
+    std::mutex print_lock;
+    auto run_repeats = [&](int harness_thread) -> int {
     for (int rep = 0; rep < repeats; ++rep) {
         bepuhip_ctx* c = new bepuhip_ctx();
         c->device = 0; c->W = header[0]; c->flags = argc > 3 ? atoi(argv[3]) : 0; c->host_values = true;  // no device here: the values are converted (and permuted by the plan) on the host, as the digest expects
@@ -522,8 +528,14 @@ int main(int argc, char** argv) {
             if (kind == 2 && !plan.items.empty()) plan.items[0].count -= plan.items[0].count > 1 ? 1 : 0;
         }
         if (getenv("PLAN_VALIDATE") && plan.enabled && validate(c, plan) != 0) return 3;
-        if (getenv("PLAN_CHURN") && plan.enabled) { const int verdict = churn(c, plan, atoi(getenv("PLAN_CHURN"))); if (verdict) return verdict; }
+        if (getenv("PLAN_CHURN") && plan.enabled) { const int verdict = churn(c, plan, atoi(getenv("PLAN_CHURN")) + harness_thread); if (verdict) return verdict; }
         delete c;
     }
     return 0;
+    };
+    if (harness_threads == 1) return run_repeats(0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < harness_threads; ++t) pool.emplace_back([&, t] { const int v = run_repeats(t); if (v) verdict_all.store(v); });
+    for (auto& th : pool) th.join();
+    return verdict_all.load();
 }
