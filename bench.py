@@ -16,6 +16,7 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -118,6 +119,11 @@ def compact_line(out, full_path):
     for extra in ("all_types", "frame"):
         if extra in out:
             line[extra] = rnd(out[extra])
+    grp = out.get("lattice_device_group")  # N > 1: BASELINE.json configs[4] (one connected lattice over the N devices, exact) beside configs[3]
+    if isinstance(grp, dict):
+        line["lattice_device_group"] = rnd(dict(pick(grp, ("value", "ms_per_step", "scaling", "n_gpus", "error")), **pick(grp.get("config") or {}, ("exchanges_per_step", "finite", "schedule_is_island"))))
+    if out.get("self_checks"):
+        line["self_checks"] = out["self_checks"]
     line["full_report"] = full_path
     return line
 
@@ -753,7 +759,7 @@ def traffic_child(args, device: int):
     solver.close()
 
 
-def run_lattice_group(args, rank, local_rank, world, dist, torch, scene, sd):
+def run_lattice_group(args, rank, local_rank, world, dist, torch, scene, sd, standalone=True):
     """configs[4], exact, on the island schedule (round 5): a device group (bepuhip_set_device_group). Every rank uploads the whole lattice, plans the same clusters and runs
     its range of them in ONE launch per step; shared bodies cross ranks through the split plan's records, pushed into every rank's table over the fabric; one all-reduce of
     the owned bodies per step. Strong scaling: the scene is fixed."""
@@ -765,6 +771,7 @@ def run_lattice_group(args, rank, local_rank, world, dist, torch, scene, sd):
     solver.set_device_group(world, rank)
     solver.upload(scene, sd.fallback_batch_threshold)
     schedule = {0: "launch-per-batch schedule", 1: "island schedule (whole islands), one launch per step", 2: "island schedule on a split-island plan, one launch per step"}[solver.schedule()]
+    line = None
     if dist is not None and world > 1:
         handles = [None] * world
         dist.all_gather_object(handles, solver.export_shared_records())  # hipIpcMemHandle_t of every rank's record table
@@ -811,7 +818,7 @@ def run_lattice_group(args, rank, local_rank, world, dist, torch, scene, sd):
         step_bytes = (sv_bytes * int(its.sum()) + ws_bytes * sd.substep_count + inc_bytes * (sd.substep_count - 1)
                       + INTEGRATE_BYTES_PER_BODY * scene.body_count * sd.substep_count + FINAL_BYTES_PER_BODY * scene.body_count)
         achieved = step_bytes / (elapsed / args.steps) / 1e9
-        print(json.dumps({
+        line = ({
             "metric": "constraint-iterations/sec", "value": units / elapsed, "unit": "constraint-iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -825,11 +832,16 @@ def run_lattice_group(args, rank, local_rank, world, dist, torch, scene, sd):
                        "device_prewarm": f"{prewarm_steps} untimed steps during setup, uploaded state restored before the {args.warmup} warm-up steps"},
             "roofline": {"bound": "hbm", "kernel": f"whole step ({schedule}), algorithmic bytes", "achieved": achieved, "peak": HBM_PEAK_GBS * world,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None},
-            "cpu_baseline": None}))
+            "cpu_baseline": None})
+        line["config"]["schedule_is_island"] = solver.schedule() == 2  # (False: the plan did not fit — more clusters per device than CUs, or LDS — and the group ran launch-per-batch)
+        if standalone:
+            print(json.dumps(line))
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        if standalone:
+            dist.destroy_process_group()
     solver.close()
+    return line if rank == 0 else None
 
 
 def run_lattice(args, rank, local_rank, world, dist, torch):
@@ -911,6 +923,44 @@ def run_lattice(args, rank, local_rank, world, dist, torch):
     solver.close()
 
 
+def launch_plan(gpus: int, env: dict, device_count: int, argv: list):
+    """What `python bench.py --gpus N` does about its ranks (it used to run ONE rank and print n_gpus 1 when N > 1 and no launcher had set WORLD_SIZE).
+    ("run", None): this process is a rank (N = 1, or started by torchrun with WORLD_SIZE = N) | ("spawn", command): no launcher — start the N ranks ourselves, the way the
+    driver does | ("error", text): a world that does not match, or more ranks than devices. Pure: tested on the CPU (tests/test_bench_launcher.py)."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    if gpus < 1:
+        return "error", f"--gpus {gpus}: at least one GPU"
+    if "WORLD_SIZE" in env and world != gpus:
+        return "error", f"--gpus {gpus} != WORLD_SIZE {world}: the launcher and the flag must agree"
+    if gpus == 1 or "WORLD_SIZE" in env:
+        return "run", None
+    if device_count < gpus:
+        return "error", f"--gpus {gpus} but this node shows {device_count} GPU(s): one rank per GPU (RCCL admits one rank per device)"
+    port = env.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+    return "spawn", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", port,
+                     os.path.abspath(__file__)] + list(argv)
+
+
+def multi_gpu_self_checks(torch, dist, world: int, local_rank: int) -> dict:
+    """Start-up checks of an N > 1 run, with errors that say what is wrong instead of a hang inside the first collective: every pair of devices can reach each other
+    (the device group's records are pushed into the peers' memory), the communicator has as many ranks as the job, one device per rank."""
+    report = {"world": world, "devices_visible": int(torch.cuda.device_count())}
+    if dist.get_world_size() != world:
+        raise SystemExit(f"process group of {dist.get_world_size()} ranks for --gpus {world}")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} visible device(s): RCCL admits one rank per device")
+    unreachable = [(a, b) for a in range(world) for b in range(world) if a != b and not torch.cuda.can_device_access_peer(a, b)]
+    report["peer_access_all_pairs"] = not unreachable
+    if unreachable:
+        raise SystemExit(f"devices without peer access: {unreachable[:8]} - the device group pushes records into its peers' memory over xGMI")
+    probe = torch.ones(1, device=f"cuda:{local_rank}")
+    dist.all_reduce(probe)
+    if int(probe.item()) != world:
+        raise SystemExit(f"all-reduce of ones over {world} ranks returned {probe.item()}")
+    report["all_reduce_of_ones"] = int(probe.item())
+    return report
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -937,11 +987,19 @@ def main():
     ap.add_argument("--leg-out", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if not (args.traffic_child or args.leg_child):
+        device_count = 0
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            import torch
+            device_count = torch.cuda.device_count()
+        action, detail = launch_plan(args.gpus, dict(os.environ), device_count, sys.argv[1:])
+        if action == "error":
+            raise SystemExit(f"bench.py: {detail}")
+        if action == "spawn":  # (never an N = 1 line for an N > 1 request)
+            raise SystemExit(subprocess.call(detail, env=dict(os.environ, MASTER_ADDR="127.0.0.1")))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
 
     if args.traffic_child:
         return traffic_child(args, local_rank)
@@ -959,11 +1017,13 @@ def main():
 
     import torch
     dist = None
+    self_checks = None
     if world > 1 or os.environ.get("BEPU_BENCH_FORCE_DIST") == "1":  # (the env switch lets a 1-GPU box exercise the RCCL code path)
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        self_checks = multi_gpu_self_checks(torch, dist, world, local_rank) if world > 1 else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
 
@@ -1112,6 +1172,20 @@ def main():
         boundary = extra("boundary")
         lattice_report = extra("lattice")
 
+    lattice_group = None
+    if world > 1 and dist is not None and not args.no_connected_scenes:
+        # BASELINE.json configs[4] beside configs[3] on ONE line at N > 1 (VERDICT r5 next #7b): the same number of ragdolls as one rank's share, as ONE connected lattice
+        # split over the N devices as a device group (exact mode). Strong scaling inside this leg: its own ms_per_step, and the N = 1 figure of the same lattice is the
+        # `lattice.device_group_single_rank_ms` of an N = 1 run.
+        solver.close()
+        from bepuphysics2_amd.hostlib import HostSimulation
+        sim = HostSimulation.scene("ragdoll_tube", args.ragdolls, 1, 1, 5)
+        lattice_scene, lattice_sd = sim.export(), sim.solve_description()
+        sim.close()
+        try:
+            lattice_group = run_lattice_group(args, rank, local_rank, world, dist, torch, lattice_scene, lattice_sd, standalone=False)
+        except Exception as e:  # noqa: BLE001 — the headline line survives a leg that fails; the failure is on the line
+            lattice_group = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         value = whole_job_rate
         out = {
@@ -1130,6 +1204,7 @@ def main():
                        "device_prewarm": f"{prewarm_steps} untimed solves during setup, uploaded state restored before the {args.warmup} warm-up steps",
                        "finite": finite},
             "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "scale_sweep": sweep, "widened_types": widened, "boundary": boundary, "lattice": lattice_report,
+            "lattice_device_group": lattice_group, "self_checks": self_checks,
         }
         if isinstance(baseline, dict) and baseline.get("value"):
             baseline["gpu_over_cpu"] = value / baseline["value"]

@@ -47,6 +47,15 @@ constexpr bool kConserving = BEPU_VARIANT_CONSERVING != 0;
 // the incremental contact update and the final pass stay the launch-per-batch schedule's kernels there; this unit replaces its batch-after-batch launches.
 constexpr bool kPass = BEPU_VARIANT_PASS != 0;
 constexpr bool kRowsNonTemporal = BEPU_VARIANT_NT != 0;  // one- and two-body constraint rows loaded with the non-temporal hint (they stream: 70 MB per pass, no reuse)
+#ifndef BEPU_VARIANT_CONTACTS
+#define BEPU_VARIANT_CONTACTS 0
+#endif
+// Per translation unit (round 6): the TYPE SET the unit is compiled for. The reference registers one TypeProcessor per constraint type and a batch only ever runs the
+// processors of the types it holds (DefaultTypes.cs:18-63, TypeBatch dispatch in Solver_Solve.cs); a cluster_kernel holds the code of every type of its family, and a
+// scene made of convex contact manifolds alone (Contact1-4, one- and two-body: type ids 0-7 — box stacks, piles, BASELINE.json configs[0] and configs[1]) dragged the
+// eight hot joint types along: code it never executes, in an instruction cache it does not fit, under a register budget the joints set. The contacts family carries the
+// eight manifolds (typed and merged items) and nothing else; the launcher picks it when no other type id is present (bepu_host_state.h, cluster_kernel_variant).
+constexpr bool kContactsOnly = BEPU_VARIANT_CONTACTS != 0;
 
 typedef __attribute__((address_space(1))) float gfloat;  // global
 typedef __attribute__((address_space(1))) int gint;
@@ -987,7 +996,7 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
                 }
                 if (nonconvex) break;
             }
-            if constexpr (STAGE != kStageIncremental) {  // only contacts need incremental updates (RequiresIncrementalSubstepUpdates)
+            if constexpr (STAGE != kStageIncremental && !kContactsOnly) {  // only contacts need incremental updates (RequiresIncrementalSubstepUpdates)
                 switch (h.type_id) {
                     BD_HOT_JOINT_TYPES(BEPU_CASE)
                     default:

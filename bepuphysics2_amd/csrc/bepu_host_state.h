@@ -27,6 +27,9 @@ const void* bepu_cluster_kernel_hot_1024p(bool trace);   // one sweep per launch
 const void* bepu_cluster_kernel_wide_1024p(bool trace);
 const void* bepu_cluster_kernel_hot_512sp(bool trace);   // ... split-island plans at 512
 const void* bepu_cluster_kernel_wide_512sp(bool trace);
+const void* bepu_cluster_kernel_contacts_512s(bool trace);  // round 6: the contacts family (type ids 0-7 only): split plans at eight waves ...
+const void* bepu_cluster_kernel_contacts_768s(bool trace);  // ... at twelve
+const void* bepu_cluster_kernel_contacts_1024(bool trace);  // ... whole-island plans
 constexpr int kClusterThreadChoices[3] = {1024, 768, 512};
 // The smallest register budget that still fits `threads`; BEPUHIP_CLUSTER_VARIANT (experiments) asks for a tighter one, e.g. the 1024-thread build's 128 VGPRs for
 // 512-thread workgroups, so that two of them are resident per CU.
@@ -40,7 +43,21 @@ static bool conserving_variant_exists(int threads, bool shared) { return cluster
 static const void* cluster_pass_kernel(bool wide, bool shared) {  // (for the default workgroup sizes, like the conserving units)
     return shared ? (wide ? bepu_cluster_kernel_wide_512sp(false) : bepu_cluster_kernel_hot_512sp(false)) : (wide ? bepu_cluster_kernel_wide_1024p(false) : bepu_cluster_kernel_hot_1024p(false));
 }
-static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false, bool conserving = false) {
+// Type-set families (round 6): kFamilyContacts = nothing but convex contact manifolds (type ids 0-7), kFamilyHot = SURVEY 8(a)'s sixteen, kFamilyWide = all 44. A family
+// that has no unit for a (threads, policy, mode) combination runs the next larger family's: same bits by construction (a unit differs from its superset only in the
+// switch cases it leaves out), asserted by tests/test_gpu_type_families.py.
+enum { kFamilyContacts = 0, kFamilyHot = 1, kFamilyWide = 2 };
+static bool contacts_family_enabled() { const char* v = getenv("BEPUHIP_CONTACTS_FAMILY"); return v == nullptr || atoi(v) != 0; }  // (developer switch, read per launch: tools/ab_scene.py compares the families on one box)
+static const void* contacts_kernel_variant(int threads, bool trace, bool shared) {
+    if (shared && threads > 512 && threads <= 768) return bepu_cluster_kernel_contacts_768s(trace);
+    if (shared && cluster_variant_threads(threads) == 512) return bepu_cluster_kernel_contacts_512s(trace);
+    if (!shared && cluster_variant_threads(threads) == 1024) return bepu_cluster_kernel_contacts_1024(trace);
+    return nullptr;
+}
+static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bool shared = false, bool nt = false, bool conserving = false, bool contacts_only = false) {
+    if (contacts_only && !wide && !nt && !conserving && contacts_family_enabled()) {
+        if (const void* fn = contacts_kernel_variant(threads, trace, shared)) return fn;
+    }
     if (conserving) return shared ? (wide ? bepu_cluster_kernel_wide_512sc(trace) : bepu_cluster_kernel_hot_512sc(trace)) : (wide ? bepu_cluster_kernel_wide_1024c(trace) : bepu_cluster_kernel_hot_1024c(trace));
     // (the non-temporal units carry no traced twin: a traced solve runs the plain-row unit of the same size — same results, the timeline of the default policy)
     if (nt && !trace && !shared && cluster_variant_threads(threads) == 1024) return wide ? bepu_cluster_kernel_wide_1024n(false) : bepu_cluster_kernel_hot_1024n(false);
@@ -266,6 +283,7 @@ struct bepuhip_ctx {
     size_t shared_bodies = 0;         // table length (bodies)
     unsigned shared_epoch = 0;        // event numbers of the next step start here (SharedTables.base): the records are cleared once, not per step
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
+    bool has_joint_types = false;    // any type that is not a convex contact manifold (type id > 7): without one, the contacts family's units run the scene (round 6)
     int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0, cluster_planes = 8;
     ClusterDesc first_cluster = {0, 0, 0, 0, 0};
     int* d_requirk = nullptr;            // conserving angular modes: per batch, the bodies momentum_requirk_kernel transforms in substep 0

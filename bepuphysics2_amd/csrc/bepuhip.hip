@@ -253,7 +253,7 @@ int32_t bepuhip_begin_constraints(bepuhip_ctx* c, int32_t batch_count, int32_t f
     c->batch_count = batch_count;
     c->fallback_threshold = fallback_batch_threshold;
     c->has_fallback = batch_count > fallback_batch_threshold;  // Batches[FallbackBatchThreshold] is the sequential fallback batch
-    c->has_widened_types = false;
+    c->has_widened_types = false; c->has_joint_types = false;
     c->building = true;
     for (auto& chunk : c->raw_chunks) chunk.used = 0;
     return BEPUHIP_OK;
@@ -371,6 +371,7 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
         }
     }
     c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
+    c->has_joint_types = c->has_joint_types || type_id > kContact4;
     c->referenced_bodies = std::max(c->referenced_bodies, highest_reference + 1);  // checked against the body count at solve time (validate_solve)
     c->total_constraints += live;
     c->tbs.push_back(std::move(tb));
@@ -656,6 +657,9 @@ static int32_t build_constraints(bepuhip_ctx* c) {
                 for (int wide = 0; wide < 2; ++wide)
                     HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(threads, tr != 0, wide != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
         for (int tr = 0; tr < 2; ++tr) HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(768, tr != 0, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        for (int tr = 0; tr < 2; ++tr)
+            for (const void* fn : {bepu_cluster_kernel_contacts_512s(tr != 0), bepu_cluster_kernel_contacts_768s(tr != 0), bepu_cluster_kernel_contacts_1024(tr != 0)})
+                HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
         c->group_body_cluster.clear();
         if (c->group_world > 1) c->group_body_cluster = plan.body_cluster;  // (before soft_setup takes the vector: which device owns a body at the end of a step)
         c->owned_mask_bodies = 0;  // (the device copy of the ownership mask follows the plan)
@@ -751,9 +755,10 @@ int32_t bepuhip_replan(bepuhip_ctx* c) {
     const bool has_fallback = c->has_fallback;
     free_constraints(c);
     c->batch_count = batch_count; c->has_fallback = has_fallback;
-    c->has_widened_types = false;
+    c->has_widened_types = false; c->has_joint_types = false;
     for (auto& tb : fresh) {
         c->has_widened_types = c->has_widened_types || is_widened_type(tb.type_id);
+        c->has_joint_types = c->has_joint_types || tb.type_id > kContact4;
         for (int32_t r : tb.refs_soa) if (r >= 0) c->referenced_bodies = std::max(c->referenced_bodies, (r & kRefMask) + 1);
         if (has_fallback && tb.batch == c->fallback_threshold) { for (int i = 0; i < tb.count; ++i) c->total_constraints += tb.refs_soa[i] != -1; }
         else c->total_constraints += tb.count;
@@ -966,7 +971,7 @@ static void enqueue_requirk(bepuhip_ctx* c, int substep, int batch, const StepPa
 constexpr int kPolicyCandidates = 3, kPolicyRounds = 5, kPolicySamples = kPolicyCandidates * kPolicyRounds;
 static std::mutex g_policy_mutex;
 static std::map<std::tuple<int, int, int, int>, int> g_policy_cache;
-static std::tuple<int, int, int, int> policy_key(const bepuhip_ctx* c, int threads) { return {c->device, c->clusters_shared ? 1 : 0, c->has_widened_types ? 1 : 0, threads}; }
+static std::tuple<int, int, int, int> policy_key(const bepuhip_ctx* c, int threads) { return {c->device, c->clusters_shared ? 1 : 0, c->has_widened_types ? 2 : (c->has_joint_types ? 1 : 0), threads}; }  // (the type-set family: each has its own units)
 static void settle_row_policy(bepuhip_ctx* c, int threads, bool may_block) {
     const int pinned = env_int("BEPUHIP_ROW_POLICY", -1);
     if (pinned >= 0 && pinned < kPolicyCandidates) { c->row_policy = pinned; return; }
@@ -1116,7 +1121,7 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
         cp.code_touch = candidate == 2 ? (c->clusters_shared ? 2 : 1) : 0;
         if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(kCodeTouchMaxSpans, forced);  // never beyond the padding behind the unit's kernels
         cp.jitter = debug_jitter_seed();
-        const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, conserving);  // the register budget that matches the workgroup size
+        const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, conserving, !c->has_joint_types);  // the register budget that matches the workgroup size, the type set that matches the scene
         if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
         const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
         bool launched = false;
@@ -2266,6 +2271,7 @@ int32_t bepuhip_add_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, c
             old.insert(old.begin() + pos, OldLayout{0, 0, 0, 0, 0});
             c->batch_count = std::max(c->batch_count, batch + 1);
             c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
+            c->has_joint_types = c->has_joint_types || type_id > kContact4;
             c->built = true;
         } else {
             tb->stride = std::max(64, tb->stride * 2);

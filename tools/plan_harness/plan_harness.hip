@@ -17,6 +17,7 @@ BEPU_STUB(bepu_cluster_kernel_hot_1024n) BEPU_STUB(bepu_cluster_kernel_wide_1024
 BEPU_STUB(bepu_cluster_kernel_hot_1024s) BEPU_STUB(bepu_cluster_kernel_wide_1024s)
 BEPU_STUB(bepu_cluster_kernel_hot_512s) BEPU_STUB(bepu_cluster_kernel_wide_512s) BEPU_STUB(bepu_cluster_kernel_hot_768s)
 BEPU_STUB(bepu_cluster_kernel_hot_1024p) BEPU_STUB(bepu_cluster_kernel_wide_1024p) BEPU_STUB(bepu_cluster_kernel_hot_512sp) BEPU_STUB(bepu_cluster_kernel_wide_512sp)
+BEPU_STUB(bepu_cluster_kernel_contacts_512s) BEPU_STUB(bepu_cluster_kernel_contacts_768s) BEPU_STUB(bepu_cluster_kernel_contacts_1024)
 BEPU_STUB(bepu_cluster_kernel_hot_1024c) BEPU_STUB(bepu_cluster_kernel_wide_1024c) BEPU_STUB(bepu_cluster_kernel_hot_512sc) BEPU_STUB(bepu_cluster_kernel_wide_512sc)
 
 static uint64_t fnv(uint64_t h, const void* p, size_t n) {
