@@ -283,6 +283,7 @@ struct bepuhip_ctx {
     size_t shared_bodies = 0;         // table length (bodies)
     unsigned shared_epoch = 0;        // event numbers of the next step start here (SharedTables.base): the records are cleared once, not per step
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
+    int last_kernel_family = -1;     // bepuhip_get_kernel_family: the family of the last island launch
     bool has_joint_types = false;    // any type that is not a convex contact manifold (type id > 7): without one, the contacts family's units run the scene (round 6)
     int cluster_count = 0, cluster_max_slots = 0, cluster_max_items = 0, cluster_total_items = 0, cluster_planes = 8;
     ClusterDesc first_cluster = {0, 0, 0, 0, 0};

@@ -253,7 +253,7 @@ int32_t bepuhip_begin_constraints(bepuhip_ctx* c, int32_t batch_count, int32_t f
     c->batch_count = batch_count;
     c->fallback_threshold = fallback_batch_threshold;
     c->has_fallback = batch_count > fallback_batch_threshold;  // Batches[FallbackBatchThreshold] is the sequential fallback batch
-    c->has_widened_types = false; c->has_joint_types = false;
+    c->has_widened_types = false; c->has_joint_types = false; c->last_kernel_family = -1;
     c->building = true;
     for (auto& chunk : c->raw_chunks) chunk.used = 0;
     return BEPUHIP_OK;
@@ -755,7 +755,7 @@ int32_t bepuhip_replan(bepuhip_ctx* c) {
     const bool has_fallback = c->has_fallback;
     free_constraints(c);
     c->batch_count = batch_count; c->has_fallback = has_fallback;
-    c->has_widened_types = false; c->has_joint_types = false;
+    c->has_widened_types = false; c->has_joint_types = false; c->last_kernel_family = -1;
     for (auto& tb : fresh) {
         c->has_widened_types = c->has_widened_types || is_widened_type(tb.type_id);
         c->has_joint_types = c->has_joint_types || tb.type_id > kContact4;
@@ -775,6 +775,12 @@ int32_t bepuhip_replan(bepuhip_ctx* c) {
 int32_t bepuhip_get_schedule(bepuhip_ctx* c, int32_t* schedule_out) {
     if (!c || !schedule_out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
     *schedule_out = !c->clusters_enabled ? 0 : (c->clusters_shared ? 2 : 1);
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_get_kernel_family(bepuhip_ctx* c, int32_t* family_out) {
+    if (!c || !family_out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    *family_out = c->last_kernel_family;
     return BEPUHIP_OK;
 }
 
@@ -1122,6 +1128,7 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
         if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(kCodeTouchMaxSpans, forced);  // never beyond the padding behind the unit's kernels
         cp.jitter = debug_jitter_seed();
         const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, conserving, !c->has_joint_types);  // the register budget that matches the workgroup size, the type set that matches the scene
+        c->last_kernel_family = c->has_widened_types ? kFamilyWide : ((!c->has_joint_types && contacts_family_enabled() && !nt && !conserving && fn == contacts_kernel_variant(threads, tr, c->clusters_shared)) ? kFamilyContacts : kFamilyHot);
         if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
         const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
         bool launched = false;

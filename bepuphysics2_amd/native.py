@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_transfer_rows_async",
     "bepuhip_set_device_group", "bepuhip_get_shared_records", "bepuhip_set_peer_records", "bepuhip_export_shared_records", "bepuhip_import_peer_records",
     "bepuhip_get_owned_bodies", "bepuhip_get_owned_constraints", "bepuhip_sync_owned_bodies",
+    "bepuhip_get_kernel_family",
 ]
 
 
@@ -164,6 +165,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_apply_structural_ops.argtypes = [vp, vp, i32, vp, i32, C.POINTER(i32)]
     lib.bepuhip_get_constraint_count.argtypes = [vp, i32, i32, C.POINTER(i32)]
     lib.bepuhip_get_schedule.argtypes = [vp, C.POINTER(i32)]
+    lib.bepuhip_get_kernel_family.argtypes = [vp, C.POINTER(i32)]
     lib.bepuhip_replan.argtypes = [vp]
     for name in EXPORTED_SYMBOLS:
         if name != "bepuhip_last_error":
@@ -501,6 +503,12 @@ class HipSolver:
         """0 launch-per-batch, 1 island-per-workgroup (whole islands), 2 island-per-workgroup on a split-island plan."""
         n = C.c_int32()
         _check(self.lib, self.lib.bepuhip_get_schedule(self.ctx, C.byref(n)))
+        return int(n.value)
+
+    def kernel_family(self) -> int:
+        """The type-set family of the last island launch: 0 contacts only, 1 the sixteen hot-path types, 2 all 44; -1 none yet (bepuhip_get_kernel_family)."""
+        n = C.c_int32()
+        _check(self.lib, self.lib.bepuhip_get_kernel_family(self.ctx, C.byref(n)))
         return int(n.value)
 
     def replan(self):

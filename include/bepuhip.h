@@ -339,6 +339,11 @@ int32_t bepuhip_get_constraint_count(bepuhip_ctx* ctx, int32_t batch_index, int3
 /* The schedule the next solve of this context runs: 0 one launch per batch and stage (hipGraph replay), 1 island-per-workgroup with whole islands, 2 island-per-workgroup
  * on a split-island plan. An upload picks 1 or 2 when the scene allows it; structural updates the plan cannot absorb drop the context to 0 (see above). */
 int32_t bepuhip_get_schedule(bepuhip_ctx* ctx, int32_t* schedule_out);
+/* Which type-set family of the island kernel ran the context's LAST island launch (round 6): 0 the contacts family (nothing but convex contact manifolds, type ids 0-7:
+ * box stacks and piles), 1 the sixteen hot-path types of SURVEY.md 8(a), 2 all 44 types; -1 when the context has not launched an island kernel yet (or runs the
+ * launch-per-batch schedule, whose kernels carry every type). The reference's counterpart is its per-type registration: a batch runs the TypeProcessors of the types it
+ * holds and nothing else (BepuPhysics/DefaultTypes.cs:18-63). A family is picked per launch from the type ids present; results do not depend on it. */
+int32_t bepuhip_get_kernel_family(bepuhip_ctx* ctx, int32_t* family_out);
 /* Plans the constraints the device holds NOW afresh, as bepuhip_end_constraints would for the same type batches: for a context that structural updates have dropped to
  * schedule 0, or to give a plan that has been absorbing updates for a long time fresh reserves. The body references are read back (the only bytes that cross PCIe besides
  * the new plan's tables), the host plans, prestep data and accumulated impulses — of the working rows and of the snapshot bepuhip_reset_state returns to — move into the

@@ -106,6 +106,7 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_apply_structural_ops(IntPtr ctx, BepuHipStructuralOp* ops, int count, uint* payload, int payloadWords, int* failedOpOut);
     [DllImport(Lib)] public static extern int bepuhip_get_constraint_count(IntPtr ctx, int batchIndex, int typeId, int* countOut);
     [DllImport(Lib)] public static extern int bepuhip_get_schedule(IntPtr ctx, int* scheduleOut);
+    [DllImport(Lib)] public static extern int bepuhip_get_kernel_family(IntPtr ctx, int* familyOut);
     [DllImport(Lib)] public static extern int bepuhip_replan(IntPtr ctx);
     [DllImport(Lib)] public static extern int bepuhip_set_convex_hulls(IntPtr ctx, float* points, int* pointBegin, int hullCount);
     [DllImport(Lib)] public static extern int bepuhip_set_compounds(IntPtr ctx, BepuHipCompoundChild* children, int* childBegin, int compoundCount);
