@@ -278,6 +278,7 @@ def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, s
         solver.solve(1 / 60, sd, cb, asynchronous=True)
     solver.reset_state()
     solver.sync()
+    quiet_gc()  # (a full collection of Python's garbage collector inside the timed loop would be a third of its time)
     for _ in range(5):
         solver.solve(1 / 60, sd, cb, asynchronous=True)
     solver.sync()
@@ -341,6 +342,7 @@ def scale_sweep_leg(args, device: int, base_ragdolls: int, factors=(1, 2, 4, 8),
             solver.solve(1 / 60, sd, cb, asynchronous=True)
         solver.reset_state()
         solver.sync()
+        quiet_gc()
         for _ in range(5):
             solver.solve(1 / 60, sd, cb, asynchronous=True)
         solver.sync()
@@ -449,6 +451,7 @@ def widened_types_leg(ragdolls: int, device: int, steps: int = 100):
         solver.solve(1 / 60, sd, cb, asynchronous=True)
     solver.reset_state()
     solver.sync()
+    quiet_gc()
     t0 = time.perf_counter()
     for _ in range(steps):
         solver.solve(1 / 60, sd, cb, asynchronous=True)
@@ -516,6 +519,7 @@ def boundary_leg(scene, sd, cb, device: int):
     def timed(fn, n=frames):
         fn()
         solver.sync()
+        quiet_gc()
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
@@ -793,7 +797,10 @@ def run_lattice_group(args, rank, local_rank, world, dist, torch, scene, sd, sta
         solver.solve(dt, sd, cb, asynchronous=True)
         solver.sync_owned_bodies()
 
-    prewarm_steps = 0 if args.no_prewarm else 300  # clocks and launch policy, as in the headline run: the first tens of solves of a process run at a third of the settled rate
+    # (round 6: 30 steps for the clocks and the launch policy's fifteen samples — the first ten steps of a context run 8-15 % slow; the 300 of round 5 were there for a
+    # "cold-start anomaly" that was Python's garbage collector: quiet_gc)
+    prewarm_steps = 0 if args.no_prewarm else 30
+    quiet_gc()
     for _ in range(prewarm_steps):
         step()
     if prewarm_steps:
@@ -876,7 +883,8 @@ def run_lattice(args, rank, local_rank, world, dist, torch):
             dist.barrier()
         torch.cuda.synchronize()
 
-    prewarm_steps = 0 if args.no_prewarm else 300
+    prewarm_steps = 0 if args.no_prewarm else 30  # (see run_lattice_group)
+    quiet_gc()
     for _ in range(prewarm_steps):
         solver.solve_lattice(dt, sd, cb)
     if prewarm_steps:
@@ -921,6 +929,16 @@ def run_lattice(args, rank, local_rank, world, dist, torch):
         dist.barrier()
         dist.destroy_process_group()
     solver.close()
+
+
+def quiet_gc():
+    """Before a timed region: one full collection now, and everything alive moved to the permanent generation. CPython's cyclic collector runs a full collection every few
+    thousand container allocations; with torch imported that is a 35 ms pause on the host — which, landing inside a timed loop of 50 asynchronous 0.25 ms steps, was round
+    5's "cold-start anomaly" (the first sixty lattice steps at a third of the settled rate: profiles/r06_s6_cold_start_is_python_gc.txt). The device and the library never
+    see it; a C# host has no such collector on this path (the solve is one P/Invoke)."""
+    import gc
+    gc.collect()
+    gc.freeze()
 
 
 def launch_plan(gpus: int, env: dict, device_count: int, argv: list):
@@ -1054,6 +1072,7 @@ def main():
     # value (2.0 -> 2.2 GHz here). Run the same solve for a while, then restore the uploaded state device-to-device, so that the W warm-up steps and the K
     # timed steps below start from exactly the scene that was uploaded, on a device that is already clocked as it would be in a running simulation.
     prewarm_steps = 0 if args.no_prewarm else 300
+    quiet_gc()  # (no full collection of Python's garbage collector inside the timed region: quiet_gc)
     for _ in range(prewarm_steps):
         solver.solve(dt, sd, cb, asynchronous=True)
     if prewarm_steps:

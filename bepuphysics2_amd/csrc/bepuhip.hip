@@ -1159,6 +1159,7 @@ static void enqueue_solve(bepuhip_ctx* c, float dt, int substeps, const int32_t*
     const int body_blocks = (c->body_count + 255) / 256;
     const bool use_clusters = island_schedule_applies(c, substeps, in);
     const int skip_clustered = use_clusters ? 1 : 0;
+    if (!use_clusters) c->last_kernel_family = -1;  // (the launch-per-batch kernels carry every type: bepuhip_get_kernel_family)
     if (use_clusters) {
         // Every constraint belongs to an island a workgroup holds (or to a cluster of a cut island): the whole substep loop runs in ONE launch — or, past
         // kMaxClusterSubsteps substeps (SolveDescription.SubstepCount is unbounded in the reference, SolveDescription.cs:16-136), in a chain of them.
@@ -1242,12 +1243,29 @@ static int32_t validate_solve(bepuhip_ctx* c, float dt, int32_t substeps, const 
     return BEPUHIP_OK;
 }
 
+// BEPUHIP_SOLVE_STATS=1 (developer switch): a solve call that takes more than 2 ms on the HOST says where (a launch is ~10 us; round 6's hunt for the 37 ms call)
+struct SolveLaps {
+    const bool on = env_int("BEPUHIP_SOLVE_STATS", 0) != 0;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    std::string text;
+    void lap(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[96];
+        snprintf(buf, sizeof(buf), " %s %.3f", what, std::chrono::duration<double, std::milli>(now - last).count());
+        text += buf; last = now;
+    }
+    ~SolveLaps() { if (on && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 2.0) fprintf(stderr, "bepuhip solve call, ms:%s\n", text.c_str()); }
+};
 int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const int32_t* iterations, const bepuhip_integrator* in) {
+    SolveLaps laps;
     int32_t st = validate_solve(c, dt, substeps, iterations, in);
     if (st != BEPUHIP_OK) return st;
+    laps.lap("validate");
     HIP_TRY(hipSetDevice(c->device));
     if ((st = group_queue_check(c)) != BEPUHIP_OK) return st;
     if ((st = flush_structural(c)) != BEPUHIP_OK) return st;
+    laps.lap("flush");
     if (c->clusters_enabled && !island_schedule_applies(c, substeps, in)) {
         // the launch-per-batch kernels address rows [0, count): an island layout with free slots between the live ones has to be brought back into the caller's order first
         bool gaps = false;
@@ -1263,7 +1281,9 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
     c->last_constraint_iterations = iters;
     if (c->profiling) { for (int i = 0; i < 6; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; } }
+    laps.lap("checks");
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+    laps.lap("event record");
     // A graph pays for the launch-per-batch schedule's 100+ launches; the island schedule is ONE kernel, which a plain launch starts sooner (6-7 us per step).
     const bool use_graph = !(c->flags & BEPUHIP_FLAG_NO_GRAPH) && !c->profiling && !island_schedule_applies(c, substeps, in);
     if (!use_graph) c->graphs_cleared_by_structure = false;
@@ -1316,8 +1336,10 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     } else {
         enqueue_solve(c, dt, substeps, iterations, in);
     }
+    laps.lap("enqueue");
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+    laps.lap("stop event");
     return BEPUHIP_OK;
 }
 

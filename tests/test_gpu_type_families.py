@@ -88,4 +88,5 @@ def test_the_family_follows_structural_updates(hip_solver_factory):
         solver.download(got)
         _exact(export, got)
     assert families[0][1] == 0 and families[1][1] == 0
-    assert all(f != 0 for s, f in families[2:]), families  # the hot family on the island schedule, or -1's successor: launch-per-batch keeps the last island launch's value
+    # with the joint: the hot family if the island plan absorbed the new type batch, none (-1) if the context went to the launch-per-batch schedule, whose kernels carry every type
+    assert all((s == 0 and f == -1) or (s != 0 and f == 1) for s, f in families[2:]), families
