@@ -483,6 +483,8 @@ __global__ __launch_bounds__(256) void scatter_bundles_kernel(const float* __res
 // kind 1: AllocateInTypeBatch (:314-334): lane `dst` written from the payload (references, prestep), accumulated impulses cleared (GatherScatter.ClearLane :327).
 // kind 2: UpdateForBodyMemoryMove (:807): one body reference of lane `dst` (body slot `src`) replaced by the payload word.
 // kind 3: bepuhip_swap_constraints: lanes `src` and `dst` exchanged.
+// kind 4 (round 6, the sequential fallback batch): the references of `src` lanes from lane `dst` on become -1 (RemoveBodyReferencesLane :301-311; a new bundle's lanes :287-296).
+// kind 5 (round 6): `pad` lanes of EVERY row copied from lane `src` on to lane `dst` on — the last bundle moved into an emptied one (TypeProcessor.cs:660-667).
 struct StructuralOp { unsigned refs_off, prestep_off, accum_off; int stride, nb, pf, imf, kind, src, dst; unsigned payload_off; int pad; };
 static_assert(sizeof(StructuralOp) == 48, "uploaded as raw words");
 // One workgroup per type batch: its operations run in the order the host issued them (a Move may read what an earlier append wrote), rows in parallel.
@@ -495,6 +497,15 @@ __global__ __launch_bounds__(64) void apply_structural_ops_kernel(unsigned* __re
         const int rows = op.nb + op.pf + op.imf;
         if (op.kind == 2) {
             if (lane == 0) slab[op.refs_off + (size_t)op.src * op.stride + op.dst] = payload[op.payload_off];
+        } else if (op.kind == 4) {
+            for (int e = lane; e < op.nb * op.src; e += 64) slab[op.refs_off + (size_t)(e / op.src) * op.stride + op.dst + (e % op.src)] = 0xFFFFFFFFu;
+        } else if (op.kind == 5) {
+            for (int e = lane; e < rows * op.pad; e += 64) {
+                const int r = e / op.pad, l = e % op.pad;
+                const size_t base = r < op.nb ? op.refs_off + (size_t)r * op.stride
+                                  : (r < op.nb + op.pf ? op.prestep_off + (size_t)(r - op.nb) * op.stride : op.accum_off + (size_t)(r - op.nb - op.pf) * op.stride);
+                slab[base + op.dst + l] = slab[base + op.src + l];
+            }
         } else {
             for (int r = lane; r < rows; r += 64) {
                 const size_t base = r < op.nb ? op.refs_off + (size_t)r * op.stride

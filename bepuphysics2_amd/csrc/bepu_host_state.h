@@ -116,6 +116,7 @@ struct HostTypeBatch {
     int batch, type_id, count, stride;
     TypeInfoH info;
     size_t refs_off, prestep_off, accum_off, lrefs_off;  // offsets (in 4-byte words) into the constraint slab
+    std::vector<uint8_t> occupied;  // type batches of the sequential fallback batch: lane i of the caller's layout holds a constraint (empty lanes carry -1 references, TypeProcessor.cs:451-571)
     std::vector<int32_t> perm;      // cluster path: device index -> host index inside the type batch (empty = identity)
     std::vector<int32_t> inv;       // host index -> device index (lazily built)
     int perm_inverse(int host_index) {

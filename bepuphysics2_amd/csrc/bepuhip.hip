@@ -370,6 +370,7 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
             (which == 0 ? tb.raw_prestep : tb.raw_accum) = (const float*)dst;
         }
     }
+    if (fallback_batch) { tb.occupied.resize((size_t)count); for (int i = 0; i < count; ++i) tb.occupied[i] = tb.refs_soa[i] != -1; }  // (structural updates of the fallback batch keep it current)
     c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
     c->has_joint_types = c->has_joint_types || type_id > kContact4;
     c->referenced_bodies = std::max(c->referenced_bodies, highest_reference + 1);  // checked against the body count at solve time (validate_solve)
@@ -747,6 +748,7 @@ int32_t bepuhip_replan(bepuhip_ctx* c) {
             nt.old_accum[which] = slabs[which] + tb.accum_off;
         }
         nt.old_stride = tb.stride;
+        nt.occupied = tb.occupied;
         fresh.push_back(std::move(nt));
     }
     uint32_t* const old_slab = c->d_slab; uint32_t* const old_slab0 = c->d_slab0;
@@ -2136,7 +2138,10 @@ static int32_t flush_structural(bepuhip_ctx* c) {
     clear_graphs(c);  // grids and descriptor pointers are baked into captured launches
     c->graphs_cleared_by_structure = true;  // the solve that follows launches eagerly: a graph captured now would be thrown away by the next frame's updates
     c->total_constraints = 0;
-    for (auto& tb : c->tbs) c->total_constraints += tb.count;
+    for (auto& tb : c->tbs) {  // (a type batch of the sequential fallback batch counts its empty lanes in `count`)
+        if (c->has_fallback && tb.batch == c->fallback_threshold && !tb.occupied.empty()) { for (int i = 0; i < tb.count && (size_t)i < tb.occupied.size(); ++i) c->total_constraints += tb.occupied[i]; }
+        else c->total_constraints += tb.count;
+    }
     // (a sequential fallback batch: its dependency levels are rebuilt from its references as the device holds them — rows in the caller's order here: a context
     // with a fallback batch leaves the island schedule for its first structural update, structural_preamble)
     std::vector<std::vector<int32_t>> fallback_refs;
@@ -2262,11 +2267,105 @@ int32_t bepuhip_get_constraint_count(bepuhip_ctx* c, int32_t batch, int32_t type
     return BEPUHIP_OK;
 }
 
+// ---- The sequential fallback batch's own additions and removals (round 6; TypeProcessor.cs:451-571, :633-694), on the launch-per-batch rows: the rows are in the caller's
+// layout there, empty lanes included, and the dependency levels the batch is solved in are rebuilt from the references at the flush (flush_structural). ----
+static void queue_fallback_op(bepuhip_ctx* c, HostTypeBatch* tb, int kind, int src, int dst, int lanes) {
+    bepuhip_ctx::PendingOp p;
+    p.tb = (int)(tb - c->tbs.data());
+    p.op = StructuralOp{(unsigned)tb->refs_off, (unsigned)tb->prestep_off, (unsigned)tb->accum_off, tb->stride, tb->info.bodies, tb->info.prestep, tb->info.impulse, kind, src, dst, 0u, lanes};
+    c->pending_ops.push_back(p);
+}
+static int32_t remove_from_fallback(bepuhip_ctx* c, HostTypeBatch* tb, int index) {
+    // (structural_preamble has brought the rows into the caller's order: a context with a fallback batch leaves its island layout for any structural update)
+    if (tb->occupied.size() < (size_t)tb->count) tb->occupied.resize((size_t)tb->count, 0);
+    if (!tb->occupied[index]) return fail(BEPUHIP_E_INVALID_ARGUMENT, "the lane of the sequential fallback batch is empty already");
+    const int W = c->W;
+    queue_fallback_op(c, tb, 4, 1, index, 0);  // RemoveBodyReferencesLane (:301-311)
+    tb->occupied[index] = 0;
+    const int bundle = index / W;
+    bool empty = true;
+    for (int i = bundle * W; i < std::min(tb->count, (bundle + 1) * W); ++i) empty = empty && !tb->occupied[i];
+    if (empty) {  // :650-681
+        int last_bundle = (tb->count + W - 1) / W - 1;
+        if (bundle != last_bundle) {  // the last bundle's prestep data, accumulated impulses and references overwrite the dead bundle's (whole bundles: its empty lanes too)
+            queue_fallback_op(c, tb, 5, last_bundle * W, bundle * W, W);
+            queue_fallback_op(c, tb, 4, W, last_bundle * W, 0);  // (the reference leaves the moved-from bundle's references behind ConstraintCount and clears them when a new bundle is opened there; cleared now)
+            if (tb->occupied.size() < (size_t)(last_bundle + 1) * W) tb->occupied.resize((size_t)(last_bundle + 1) * W, 0);
+            for (int l = 0; l < W; ++l) { tb->occupied[(size_t)bundle * W + l] = tb->occupied[(size_t)last_bundle * W + l]; tb->occupied[(size_t)last_bundle * W + l] = 0; }
+            --last_bundle;
+        }
+        int inner = 0;  // BundleIndexing.GetLastSetLaneCount of the new last bundle's occupied lanes
+        if (last_bundle >= 0) for (int l = 0; l < W; ++l) if ((size_t)last_bundle * W + l < tb->occupied.size() && tb->occupied[(size_t)last_bundle * W + l]) inner = l + 1;
+        tb->count = std::max(0, last_bundle * W + inner);
+        tb->occupied.resize((size_t)tb->count);
+    }
+    c->structure_dirty = true; c->requirk_stale = true;
+    return BEPUHIP_OK;
+}
+
+int32_t bepuhip_add_constraint_at(bepuhip_ctx* c, int32_t batch, int32_t type_id, int32_t index, const int32_t* refs, const float* prestep) {
+    int32_t st = structural_preamble(c, false);
+    if (st != BEPUHIP_OK) return st;
+    if (!refs || !prestep || index < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad add_constraint_at argument");
+    if (batch != c->fallback_threshold) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bepuhip_add_constraint_at places constraints of the sequential fallback batch (batch index == FallbackBatchThreshold); synchronized batches append: bepuhip_add_constraint");
+    TypeInfoH info;
+    if (!type_info(type_id, info)) return fail(BEPUHIP_E_UNSUPPORTED, "unknown constraint type id " + std::to_string(type_id));
+    for (int k = 0; k < info.bodies; ++k)
+        if (refs[k] < 0) return fail(BEPUHIP_E_INVALID_ARGUMENT, "empty body reference");
+    const int W = c->W;
+    HostTypeBatch* tb = find_tb(c, batch, type_id);
+    const int count = tb ? tb->count : 0;
+    const int bundles = (count + W - 1) / W;
+    if (tb && tb->occupied.size() < (size_t)count) tb->occupied.resize((size_t)count, 0);
+    const bool into_hole = index < bundles * W && (index >= count || !tb->occupied[index]);
+    const bool new_bundle = index == bundles * W;
+    if (!into_hole && !new_bundle)
+        return fail(BEPUHIP_E_INVALID_ARGUMENT, "index " + std::to_string(index) + " is neither an empty lane of one of the type batch's " + std::to_string(bundles) + " bundles nor lane 0 of a new one (TypeProcessor.cs:451-571)");
+    if (!tb || index >= tb->stride) {  // a new type batch, or rows that have to grow (InternalResize: capacity doubles)
+        if ((st = apply_pending_ops(c)) != BEPUHIP_OK) return st;
+        std::vector<OldLayout> old = current_layout(c);
+        if (!tb) {
+            HostTypeBatch fresh;
+            fresh.batch = batch; fresh.type_id = type_id; fresh.count = 0; fresh.stride = 64; fresh.info = info;
+            fresh.refs_off = fresh.prestep_off = fresh.accum_off = fresh.lrefs_off = 0;
+            size_t pos = 0;
+            while (pos < c->tbs.size() && c->tbs[pos].batch <= batch) ++pos;
+            c->tbs.insert(c->tbs.begin() + pos, fresh);
+            old.insert(old.begin() + pos, OldLayout{0, 0, 0, 0, 0});
+            c->batch_count = std::max(c->batch_count, batch + 1);
+            c->has_fallback = true;  // (Batches[FallbackBatchThreshold] exists from now on)
+            c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
+            c->has_joint_types = c->has_joint_types || type_id > kContact4;
+            c->built = true;
+        } else {
+            while (index >= tb->stride) tb->stride = std::max(64, tb->stride * 2);
+        }
+        if ((st = relayout_slab(c, old)) != BEPUHIP_OK) return st;
+        tb = find_tb(c, batch, type_id);
+    }
+    if (new_bundle) queue_fallback_op(c, tb, 4, W, index, 0);  // AddBodyReferencesLane with innerIndex 0 (:287-296): the bundle's lanes start empty
+    bepuhip_ctx::PendingOp p;
+    p.tb = (int)(tb - c->tbs.data());
+    p.op = StructuralOp{(unsigned)tb->refs_off, (unsigned)tb->prestep_off, (unsigned)tb->accum_off, tb->stride, tb->info.bodies, tb->info.prestep, tb->info.impulse, 1, 0, index,
+                        (unsigned)c->pending_payload.size(), 0};
+    for (int k = 0; k < info.bodies; ++k) {
+        c->pending_payload.push_back((uint32_t)refs[k]);
+        c->referenced_bodies = std::max(c->referenced_bodies, (refs[k] & kRefMask) + 1);
+    }
+    for (int f = 0; f < info.prestep; ++f) { uint32_t w; memcpy(&w, &prestep[f], 4); c->pending_payload.push_back(w); }
+    c->pending_ops.push_back(p);
+    tb->count = std::max(tb->count, index + 1);
+    tb->occupied.resize((size_t)tb->count, 0);
+    tb->occupied[index] = 1;
+    c->structure_dirty = true; c->requirk_stale = true;
+    return BEPUHIP_OK;
+}
+
 int32_t bepuhip_add_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id, const int32_t* refs, const float* prestep, int32_t* index_out) {
     int32_t st = structural_preamble(c, true);
     if (st != BEPUHIP_OK) return st;
     if (batch < 0 || !refs || !prestep) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad add_constraint argument");
-    if (batch >= c->fallback_threshold) return fail(BEPUHIP_E_UNSUPPORTED, "the constraint belongs to the sequential fallback batch (batch index >= FallbackBatchThreshold)");
+    if (batch >= c->fallback_threshold) return fail(BEPUHIP_E_UNSUPPORTED, "the constraint belongs to the sequential fallback batch (batch index >= FallbackBatchThreshold): its lane is the reference's choice, bepuhip_add_constraint_at");
     TypeInfoH info;
     if (!type_info(type_id, info)) return fail(BEPUHIP_E_UNSUPPORTED, "unknown constraint type id " + std::to_string(type_id));
     for (int k = 0; k < info.bodies; ++k)
@@ -2329,8 +2428,7 @@ int32_t bepuhip_remove_constraint(bepuhip_ctx* c, int32_t batch, int32_t type_id
     if (st != BEPUHIP_OK) return st;
     HostTypeBatch* tb = find_tb(c, batch, type_id);
     if (!tb || index < 0 || index >= tb->count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "Can only remove elements that are actually in the batch!");  // TypeProcessor.cs:636
-    if (c->has_fallback && batch >= c->fallback_threshold)  // (TypeProcessor.cs:695-731 has a fallback branch: it compacts bundles around the hole; here: re-upload)
-        return fail(BEPUHIP_E_UNSUPPORTED, "removal from the sequential fallback batch (batch index >= FallbackBatchThreshold): re-upload with begin/set/end");
+    if (c->has_fallback && batch >= c->fallback_threshold) return remove_from_fallback(c, tb, index);
     if (c->soft_ok) {  // on the island layout: the slot is freed where it is, the caller's indices are remapped
         SoftCallTimer timer(c);
         if (soft_remove(c, tb, index)) { c->requirk_stale = true; return BEPUHIP_OK; }
@@ -2433,6 +2531,13 @@ int32_t bepuhip_apply_structural_ops(bepuhip_ctx* c, const bepuhip_structural_op
             case 1: st = bepuhip_remove_constraint(c, op.batch_index, op.type_id, op.index); break;
             case 2: st = bepuhip_update_body_reference(c, op.batch_index, op.type_id, op.index, op.slot, op.reference); break;
             case 3: st = bepuhip_swap_constraints(c, op.batch_index, op.type_id, op.index, op.slot); break;
+            case 4: {
+                TypeInfoH info;
+                if (!type_info(op.type_id, info)) { st = fail(BEPUHIP_E_UNSUPPORTED, "unknown constraint type id " + std::to_string(op.type_id)); break; }
+                if (op.payload_offset < 0 || (int64_t)op.payload_offset + info.bodies + info.prestep > (int64_t)payload_words) { st = fail(BEPUHIP_E_INVALID_ARGUMENT, "an addition's payload lies outside the payload array"); break; }
+                st = bepuhip_add_constraint_at(c, op.batch_index, op.type_id, op.index, (const int32_t*)(payload + op.payload_offset), (const float*)(payload + op.payload_offset + info.bodies));
+                break;
+            }
             default: st = fail(BEPUHIP_E_INVALID_ARGUMENT, "unknown structural operation kind " + std::to_string(op.kind));
         }
         if (st != BEPUHIP_OK) {

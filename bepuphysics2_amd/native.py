@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_transfer_rows_async",
     "bepuhip_set_device_group", "bepuhip_get_shared_records", "bepuhip_set_peer_records", "bepuhip_export_shared_records", "bepuhip_import_peer_records",
     "bepuhip_get_owned_bodies", "bepuhip_get_owned_constraints", "bepuhip_sync_owned_bodies",
-    "bepuhip_get_kernel_family",
+    "bepuhip_get_kernel_family", "bepuhip_add_constraint_at",
 ]
 
 
@@ -157,6 +157,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_get_owned_constraints.argtypes = [vp, i32, i32, vp]
     lib.bepuhip_sync_owned_bodies.argtypes = [vp]
     lib.bepuhip_add_constraint.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
+    lib.bepuhip_add_constraint_at.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.bepuhip_remove_constraint.argtypes = [vp, i32, i32, i32]
     lib.bepuhip_update_body_reference.argtypes = [vp, i32, i32, i32, i32, i32]
     lib.bepuhip_set_velocity_model.argtypes = [vp, C.POINTER(VelocityModel), vp, i32]
@@ -441,6 +442,13 @@ class HipSolver:
         index = C.c_int32()
         _check(self.lib, self.lib.bepuhip_add_constraint(self.ctx, batch_index, type_id, _ptr(refs), _ptr(lane), C.byref(index)))
         return int(index.value)
+
+    def add_constraint_at(self, batch_index: int, type_id: int, index: int, encoded_body_references, prestep_lane):
+        """An addition to the sequential fallback batch at the lane the reference's allocation chose (bepuhip_add_constraint_at)."""
+        refs = np.ascontiguousarray(encoded_body_references, dtype=np.int32)
+        lane = np.ascontiguousarray(prestep_lane, dtype=np.float32)
+        assert refs.size == TYPE_TABLE[type_id][0] and lane.size == TYPE_TABLE[type_id][1]
+        _check(self.lib, self.lib.bepuhip_add_constraint_at(self.ctx, int(batch_index), int(type_id), int(index), _ptr(refs), _ptr(lane)))
 
     def remove_constraint(self, batch_index: int, type_id: int, index: int):
         """TypeProcessor.Remove, non-fallback (TypeProcessor.cs:695-717): swap-with-last."""

@@ -25,7 +25,7 @@ extern "C" {
 
 #define BEPUHIP_OK 0
 #define BEPUHIP_E_INVALID_ARGUMENT (-1) /* reference throws ArgumentException (Simulation.cs:318-319, SolveDescription.cs:42-47) */
-#define BEPUHIP_E_UNSUPPORTED (-2)      /* unknown type id, an addition to / removal from the sequential fallback batch itself, ...: caller should fall back to simulation.Solve */
+#define BEPUHIP_E_UNSUPPORTED (-2)      /* unknown type id, a swap inside the sequential fallback batch, ...: caller should fall back to simulation.Solve */
 #define BEPUHIP_E_DEVICE (-3)           /* HIP runtime failure */
 #define BEPUHIP_E_STATE (-4)            /* calls out of order */
 
@@ -310,13 +310,23 @@ int32_t bepuhip_transfer_rows_async(bepuhip_ctx* ctx, const bepuhip_row_transfer
  * per cluster and type batch and an eighth more LDS slots per cluster; without it only slots freed by removals are available. When no cluster near the bodies has room the
  * context falls back as above. Results are bit-identical either way. A scene with a sequential fallback batch takes structural updates of its synchronized batches
  * on the launch-per-batch rows (the context leaves its island layout for the first one; bepuhip_replan brings it back) and patches of the fallback batch's references
- * when a body moves in memory; not supported (UNSUPPORTED): additions to the sequential fallback batch, removals from it and swaps inside it
- * (batch_index >= fallback_batch_threshold; the reference's fallback branch of Remove, TypeProcessor.cs:695-731, compacts bundles around the hole) — re-upload. */
+ * when a body moves in memory. Round 6: the sequential fallback batch itself takes additions and removals on those rows — bepuhip_add_constraint_at places a constraint
+ * in the lane the reference's allocation chose (TypeProcessor.AllocateInTypeBatchForFallback, TypeProcessor.cs:451-571: an empty lane of a probed bundle that holds none
+ * of its bodies, else lane 0 of a new bundle — the probe order depends on the constraint's handle, which stays the host's business), bepuhip_remove_constraint on a
+ * fallback type batch follows the reference's fallback branch of Remove (TypeProcessor.cs:633-694: the lane's references become -1; a bundle that is empty afterwards is
+ * overwritten by the LAST bundle, whose constraints move down by whole bundles; ConstraintCount = last bundle x width + its highest occupied lane + 1) and
+ * bepuhip_get_constraint_count reports the same ConstraintCount. The dependency levels the fallback batch is solved in are rebuilt at the next solve. Still UNSUPPORTED:
+ * swaps inside the fallback batch (they would change the order its bundles are solved in; the reference has no such operation). */
 /* The caller places the constraint in a batch none of its dynamic bodies is in yet (Solver.cs:1046-1051, 1182-1199: the batch invariant the whole solve rests on). On the island
  * layout the library knows every reference and refuses an addition that breaks it (INVALID_ARGUMENT); on the launch-per-batch rows the references live on the device only and
  * the call trusts the caller, as the reference's release build does. */
 int32_t bepuhip_add_constraint(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, const int32_t* encoded_body_references, const float* prestep_lane, int32_t* index_out);
 int32_t bepuhip_remove_constraint(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index);
+/* An addition to the sequential fallback batch (batch_index == FallbackBatchThreshold) at the index the reference's TypeProcessor.AllocateInTypeBatchForFallback returned
+ * (TypeProcessor.cs:451-571): either an empty lane of an existing bundle (index < bundles x width, lane empty) or lane 0 of a new bundle (index == bundles x width) —
+ * anything else is INVALID_ARGUMENT. The constraint's accumulated impulses are cleared (:546), the other lanes of a new bundle start empty (:287-296). A scene without a
+ * fallback batch gets one with the first such call. */
+int32_t bepuhip_add_constraint_at(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index, const int32_t* encoded_body_references, const float* prestep_lane);
 int32_t bepuhip_update_body_reference(bepuhip_ctx* ctx, int32_t batch_index, int32_t type_id, int32_t index, int32_t body_index_in_constraint, int32_t encoded_body_reference);
 /* Exchanges the constraints at two indices of a type batch (everything the device holds for them: references, prestep data, accumulated impulses). The reference has no
  * such call — its type batches only change by append and swap-with-last — but a host that reconstructs a frame's structural changes from the type batches themselves
@@ -331,6 +341,7 @@ int32_t bepuhip_swap_constraints(bepuhip_ctx* ctx, int32_t batch_index, int32_t 
  *   kind 1  bepuhip_remove_constraint    `index`
  *   kind 2  bepuhip_update_body_reference `index`, `slot` = body index in constraint, `reference`
  *   kind 3  bepuhip_swap_constraints     `index`, `slot` = the other index
+ *   kind 4  bepuhip_add_constraint_at    payload as kind 0; `index` = the lane the reference's fallback allocation chose
  * Stops at the first operation that fails: its ordinal in *failed_op_out (optional), the operations before it stay applied, the error is the failing call's. */
 typedef struct bepuhip_structural_op { int32_t kind, batch_index, type_id, index, slot, reference, payload_offset, reserved; } bepuhip_structural_op;
 int32_t bepuhip_apply_structural_ops(bepuhip_ctx* ctx, const bepuhip_structural_op* ops, int32_t count, const uint32_t* payload, int32_t payload_words, int32_t* failed_op_out);

@@ -101,6 +101,7 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_transfer_rows_async(IntPtr ctx, BepuHipRowTransfer* items, int count);
     [DllImport(Lib)] public static extern int bepuhip_add_constraint(IntPtr ctx, int batchIndex, int typeId, int* encodedBodyReferences, float* prestepLane, int* indexOut);
     [DllImport(Lib)] public static extern int bepuhip_remove_constraint(IntPtr ctx, int batchIndex, int typeId, int index);
+    [DllImport(Lib)] public static extern int bepuhip_add_constraint_at(IntPtr ctx, int batchIndex, int typeId, int index, int* encodedBodyReferences, float* prestepLane);
     [DllImport(Lib)] public static extern int bepuhip_update_body_reference(IntPtr ctx, int batchIndex, int typeId, int index, int bodyIndexInConstraint, int encodedBodyReference);
     [DllImport(Lib)] public static extern int bepuhip_swap_constraints(IntPtr ctx, int batchIndex, int typeId, int indexA, int indexB);
     [DllImport(Lib)] public static extern int bepuhip_apply_structural_ops(IntPtr ctx, BepuHipStructuralOp* ops, int count, uint* payload, int payloadWords, int* failedOpOut);

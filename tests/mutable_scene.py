@@ -11,9 +11,11 @@ from bepuphysics2_amd.scene import BUNDLE_WIDTH, KINEMATIC_MASK, TYPE_TABLE, Sce
 
 
 class MutableSolver:
-    def __init__(self, bodies: np.ndarray, bundle_width: int = BUNDLE_WIDTH):
+    def __init__(self, bodies: np.ndarray, bundle_width: int = BUNDLE_WIDTH, fallback_batch_threshold: int = 64):
         self.bodies = np.ascontiguousarray(bodies, dtype=np.float32).copy()
         self.w = bundle_width
+        self.fallback_batch_threshold = fallback_batch_threshold  # SolveDescription.FallbackBatchThreshold: Batches[threshold] is the sequential fallback batch (Solver.cs:1878-1884)
+        self.free_handles: List[int] = []                  # Solver.HandlePool is last-in-first-out (IdPool)
         self.batches: List[Dict[int, dict]] = []          # per batch: type_id -> {"refs": [...], "prestep": [...], "acc": [...]}
         self.type_order: List[List[int]] = []             # type batches of a batch in creation order (ConstraintBatch.GetOrCreateTypeBatch)
         self.batch_handles: List[Dict[int, int]] = []     # batchReferencedHandles: dynamic body -> 1
@@ -43,6 +45,8 @@ class MutableSolver:
                 self.batches.append({})
                 self.type_order.append([])
                 self.batch_handles.append({})
+            if bi == self.fallback_batch_threshold:
+                return self._add_to_fallback(bi, type_id, encoded, blocking, prestep_lane)
             if any(h in self.batch_handles[bi] for h in blocking):
                 continue
             tb = self.batches[bi].get(type_id)
@@ -52,15 +56,139 @@ class MutableSolver:
             tb["refs"].append(encoded)
             tb["prestep"].append(np.asarray(prestep_lane, dtype=np.float32).copy())
             tb["acc"].append(np.zeros(imf, dtype=np.float32))
-            tb["handles"].append(self.next_handle)
-            self.next_handle += 1
+            tb["handles"].append(self._take_handle())
             for h in blocking:
                 self.batch_handles[bi][h] = 1
             return bi, len(tb["refs"]) - 1, encoded
         raise AssertionError("unreachable")
 
+    # ---- the sequential fallback batch (round 6): the reference's own allocation and removal rules ----
+    @staticmethod
+    def rehash(value: int) -> int:
+        """HashHelper.Rehash (BepuUtilities/Collections/QuickDictionary.cs:20-41) as a 32-bit signed int."""
+        u = (value * 982451653) & 0xFFFFFFFF
+        rot = lambda x, k: ((x << k) | (x >> (32 - k))) & 0xFFFFFFFF  # noqa: E731
+        r = rot(u, 6) ^ rot(u, 13) ^ rot(u, 25)
+        return r - (1 << 32) if r & 0x80000000 else r
+
+    def _take_handle(self) -> int:
+        """A handle nothing has had before. (The reference's pool is last-in-first-out; this mirror identifies bodies by index, and a diffing host needs the BODY handles to tell
+        "a reused constraint handle" from "a constraint whose body moved in memory" — tests/test_structural_diff.py and the C++ twin, which have them, cover the reuse.)"""
+        self.next_handle += 1
+        return self.next_handle - 1
+
+    def _add_to_fallback(self, bi, type_id, encoded, blocking, prestep_lane):
+        """TypeProcessor.AllocateInTypeBatchForFallback (TypeProcessor.cs:451-571): probe bundles for one that holds none of the constraint's bodies (masked indices:
+        kinematic references never block, :338-359) and has an empty lane — all of them while the type batch has at most 17 bundles, else the last one and sixteen more
+        chosen from the constraint's handle (HashHelper.Rehash) — and take its first empty lane; no such bundle: lane 0 of a new bundle. Empty lanes carry -1 references and a
+        handle of -1; ConstraintCount is the highest index + 1."""
+        w = self.w
+        nb, pf, imf, _ = TYPE_TABLE[type_id]
+        tb = self.batches[bi].get(type_id)
+        if tb is None:
+            tb = self.batches[bi][type_id] = {"refs": [], "prestep": [], "acc": [], "handles": []}
+            self.type_order[bi].append(type_id)
+        handle = self._take_handle()
+        refs = tb["refs"]
+        count = len(refs)
+        bundles = (count + w - 1) // w
+        masked = [e & ~KINEMATIC_MASK for e in encoded]  # (the broadcast indices have the kinematic flag stripped; the bundle's own references keep theirs: a kinematic never matches)
+
+        def probe(b):
+            lanes = refs[b * w:(b + 1) * w]
+            for lane in lanes:
+                if lane[0] != -1 and any(r in masked for r in lane):
+                    return None
+            for l in range(w):  # the first lane that holds -1 (lanes beyond ConstraintCount in the last bundle are -1 too)
+                if b * w + l >= count or lanes[l][0] == -1:
+                    return b * w + l
+            return None
+
+        target = None
+        if bundles <= 17:
+            for b in range(bundles):
+                target = probe(b)
+                if target is not None:
+                    break
+        else:
+            last = bundles - 1
+            target = probe(last)
+            if target is None:
+                nxt = (self.rehash(handle) & 0x7FFFFFFF) % last
+                jump = bundles // 16
+                remainder = last - jump * 16
+                for k in range(16):
+                    target = probe(nxt)
+                    if target is not None:
+                        break
+                    nxt += jump
+                    if k < remainder:
+                        nxt += 1
+                    if nxt >= bundles:
+                        nxt -= bundles
+        if target is None:
+            target = bundles * w
+        while len(refs) <= target:
+            refs.append([-1] * nb)
+            tb["prestep"].append(np.zeros(pf, dtype=np.float32))
+            tb["acc"].append(np.zeros(imf, dtype=np.float32))
+            tb["handles"].append(-1)
+        refs[target] = list(encoded)
+        tb["prestep"][target] = np.asarray(prestep_lane, dtype=np.float32).copy()
+        tb["acc"][target] = np.zeros(imf, dtype=np.float32)
+        tb["handles"][target] = handle
+        for h in blocking:  # (the fallback batch's referenced handles count constraints per body; here: presence)
+            self.batch_handles[bi][h] = self.batch_handles[bi].get(h, 0) + 1
+        return bi, target, encoded
+
+    def _remove_from_fallback(self, batch_index: int, type_id: int, index: int):
+        """TypeProcessor.Remove with isFallback (TypeProcessor.cs:633-694)."""
+        w = self.w
+        tb = self.batches[batch_index][type_id]
+        nb = TYPE_TABLE[type_id][0]
+        assert tb["refs"][index][0] != -1
+        self.free_handles.append(tb["handles"][index])
+        tb["handles"][index] = -1
+        tb["refs"][index] = [-1] * nb
+        count = len(tb["refs"])
+        bundle = index // w
+        if all(lane[0] == -1 for lane in tb["refs"][bundle * w:(bundle + 1) * w]):
+            last_bundle = (count + w - 1) // w - 1
+            if bundle != last_bundle:  # the last bundle's memory overwrites the dead bundle's, lanes beyond ConstraintCount included (they are empty)
+                nb_, pf_, imf_, _ = TYPE_TABLE[type_id]
+                pads = {"refs": lambda: [-1] * nb_, "prestep": lambda: np.zeros(pf_, dtype=np.float32), "acc": lambda: np.zeros(imf_, dtype=np.float32), "handles": lambda: -1}
+                for key in ("refs", "prestep", "acc", "handles"):
+                    src = list(tb[key][last_bundle * w:(last_bundle + 1) * w])
+                    while len(src) < w:
+                        src.append(pads[key]())
+                    tb[key][bundle * w:(bundle + 1) * w] = src
+                last_bundle -= 1
+            inner = 0
+            if last_bundle >= 0:
+                for l, lane in enumerate(tb["refs"][last_bundle * w:(last_bundle + 1) * w]):
+                    if lane[0] != -1:
+                        inner = l + 1
+            new_count = max(0, last_bundle * w + inner)
+            for key in ("refs", "prestep", "acc", "handles"):
+                del tb[key][new_count:]
+
     def remove(self, batch_index: int, type_id: int, index: int):
         tb = self.batches[batch_index][type_id]
+        if batch_index == self.fallback_batch_threshold:
+            for r in tb["refs"][index]:
+                if not (r & KINEMATIC_MASK):
+                    self.batch_handles[batch_index][r] -= 1
+                    if self.batch_handles[batch_index][r] == 0:
+                        del self.batch_handles[batch_index][r]
+                else:
+                    body = int(r) & ~KINEMATIC_MASK
+                    self.kinematic_uses[body] -= 1
+                    if self.kinematic_uses[body] == 0:
+                        at = self.kinematic_constrained.index(body)
+                        self.kinematic_constrained[at] = self.kinematic_constrained[-1]
+                        self.kinematic_constrained.pop()
+            self._remove_from_fallback(batch_index, type_id, index)
+            return
         for r in tb["refs"][index]:
             if not (r & KINEMATIC_MASK):
                 del self.batch_handles[batch_index][r]
@@ -71,6 +199,7 @@ class MutableSolver:
                     at = self.kinematic_constrained.index(body)
                     self.kinematic_constrained[at] = self.kinematic_constrained[-1]
                     self.kinematic_constrained.pop()
+        self.free_handles.append(tb["handles"][index])
         last = len(tb["refs"]) - 1
         if index < last:
             for key in ("refs", "prestep", "acc", "handles"):
@@ -126,7 +255,7 @@ class MutableSolver:
         return sum(1 for handles in self.batch_handles if body in handles)
 
     def locations(self, predicate=lambda type_id: True) -> List[Tuple[int, int, int]]:
-        return [(bi, t, i) for bi, b in enumerate(self.batches) for t in self.type_order[bi] if predicate(t) for i in range(len(b[t]["refs"]))]
+        return [(bi, t, i) for bi, b in enumerate(self.batches) for t in self.type_order[bi] if predicate(t) for i in range(len(b[t]["refs"])) if b[t]["refs"][i][0] != -1]
 
     def to_scene(self) -> Scene:
         batches = []
