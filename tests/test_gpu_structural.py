@@ -901,10 +901,9 @@ def test_the_sequential_fallback_batch_itself_takes_additions_and_removals(hip_s
         assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], (frame, m)
     assert grew_past_17 and emptied, (grew_past_17, emptied)
     # a lane that is not the reference's to give is refused
-    from bepuphysics2_amd.native import BepuHipError
     t = next(t for t, tb in ms.batches[threshold].items() if len(tb["refs"]) > 0)
     occupied = next(i for i, lane in enumerate(ms.batches[threshold][t]["refs"]) if lane[0] != -1)
-    with pytest.raises(BepuHipError):
+    with pytest.raises(ValueError):  # BEPUHIP_E_INVALID_ARGUMENT
         solver.add_constraint_at(threshold, t, occupied, ms.batches[threshold][t]["refs"][occupied], ms.batches[threshold][t]["prestep"][occupied])
-    with pytest.raises(BepuHipError):
+    with pytest.raises(ValueError):  # BEPUHIP_E_INVALID_ARGUMENT
         solver.add_constraint_at(threshold, t, len(ms.batches[threshold][t]["refs"]) + 3 * ms.w, ms.batches[threshold][t]["refs"][occupied], ms.batches[threshold][t]["prestep"][occupied])
