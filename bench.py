@@ -109,7 +109,7 @@ def compact_line(out, full_path):
     elif sweep is not None:
         line["scale_sweep"] = sweep
     wid = out.get("widened_types")
-    line["widened_types"] = rnd(pick(wid, ("ms_per_step", "value", "finite", "error"))) if isinstance(wid, dict) else wid
+    line["widened_types"] = rnd(pick(wid, ("ms_per_step", "value", "finite", "error", "all_types_ms", "all_types_value", "all_types_finite", "all_types_error"))) if isinstance(wid, dict) else wid
     bnd = out.get("boundary")
     line["boundary"] = rnd({k: v for k, v in bnd.items() if not isinstance(v, str) or k == "error"}) if isinstance(bnd, dict) else bnd
     lat = out.get("lattice")
@@ -462,10 +462,40 @@ def widened_types_leg(ragdolls: int, device: int, steps: int = 100):
     solver.close()
     its = sd.iterations()
     per_step = scene.constraint_count * int((1 + its).sum())
-    return {"workload": f"{ragdolls} ragdoll rigs: the headline's graph ({scene.constraint_count} constraints, {len(scene.batches)} batches) with "
-                        + ", ".join(f"{TYPE_TABLE[a][3]} -> {TYPE_TABLE[b][3]}" for a, b in RIG_REMAP.items()),
-            "ms_per_step": ms, "value": per_step / (ms * 1e-3), "unit": "constraint-iterations/s",
-            "schedule": f"island-per-workgroup, {clusters} clusters, widened kernel variant" if clusters else "launch-per-batch", "finite": finite}
+    out = {"workload": f"{ragdolls} ragdoll rigs: the headline's graph ({scene.constraint_count} constraints, {len(scene.batches)} batches) with "
+                       + ", ".join(f"{TYPE_TABLE[a][3]} -> {TYPE_TABLE[b][3]}" for a, b in RIG_REMAP.items()),
+           "ms_per_step": ms, "value": per_step / (ms * 1e-3), "unit": "constraint-iterations/s",
+           "schedule": f"island-per-workgroup, {clusters} clusters, widened kernel variant" if clusters else "launch-per-batch", "finite": finite,
+           # (static, measured on the CPU: profiles/r06_fast_reciprocal_gap.txt, tests/test_fast_reciprocal.py)
+           "x86_fast_reciprocal_gap": "CenterDistanceConstraint / CenterDistanceLimit 0.6-1.3e-4, AreaConstraint / VolumeConstraint ~1e-5 relative velocity error after 8 substeps against "
+                                      "vrcpps / vrsqrtps (the reference's MathHelper.FastReciprocal on an AVX host); every other type bit-identical to both oracles"}
+    # The worst case of the work-item design, every round: all 44 type ids drawn at random in 4,000 islands of 16 bodies with 64 constraints — 790 type
+    # batches, one or two constraints per cluster and type batch, i.e. ~1.3 of 64 lanes busy per work item and ~6,300 work items per cluster and step.
+    try:
+        import small_scenes  # (test infrastructure: the generator of tools/perf_widened.py)
+        from bepuphysics2_amd.scene import SolveDescription
+        everything = small_scenes.island_scene(11, 4000, 16, 64, sorted(TYPE_TABLE))
+        sd44 = SolveDescription(1, 4)
+        solver = HipSolver(device=device, exclusive_device=True)
+        solver.upload(everything)
+        for _ in range(40):
+            solver.solve(1 / 60, sd44, cb, asynchronous=True)
+        solver.reset_state()
+        solver.sync()
+        quiet_gc()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            solver.solve(1 / 60, sd44, cb, asynchronous=True)
+        solver.sync()
+        ms44 = 1e3 * (time.perf_counter() - t0) / 50
+        out["all_types_ms"] = ms44
+        out["all_types_value"] = everything.constraint_count * int((1 + sd44.iterations()).sum()) / (ms44 * 1e-3)
+        out["all_types_workload"] = f"all 44 type ids at random: {everything.body_count} bodies, {everything.constraint_count} constraints, {len(everything.batches)} batches, {int(solver.cluster_cycles().size)} clusters"
+        out["all_types_finite"] = bool(np.isfinite(solver.get_bodies(everything.body_count)).all())
+        solver.close()
+    except Exception as e:  # noqa: BLE001
+        out["all_types_error"] = f"{type(e).__name__}: {e}"[:200]
+    return out
 
 
 def boundary_leg(scene, sd, cb, device: int):

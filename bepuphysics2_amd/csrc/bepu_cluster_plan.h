@@ -172,7 +172,17 @@ struct PlanPool {
         work = nullptr; wanted = 0;
     }
 };
-static PlanPool& plan_pool() { static PlanPool* pool = new PlanPool(); return *pool; }  // never destroyed: its threads outlive main's statics
+// Never destroyed: its threads outlive main's statics. A forked child gets a pool of its own: the parent's mutexes may have been held by threads that do not
+// exist in the child, where locking them again would never return; the old object is abandoned, not freed (its condition variables may be mid-wait in the copy).
+static PlanPool*& plan_pool_slot() { static PlanPool* pool = nullptr; return pool; }
+static PlanPool& plan_pool() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        plan_pool_slot() = new PlanPool();
+        pthread_atfork(nullptr, nullptr, [] { plan_pool_slot() = new PlanPool(); });
+    });
+    return *plan_pool_slot();
+}
 template <class Fn>
 static void plan_parallel_for_workers(size_t jobs, Fn&& fn) {  // fn(job, worker, workers) for every job, dynamically scheduled; results must not depend on the order
     const int workers = plan_workers(jobs);

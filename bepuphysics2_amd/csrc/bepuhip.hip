@@ -2042,7 +2042,9 @@ int32_t bepuhip_get_poses_and_velocities_async(bepuhip_ctx* c, void* body_dynami
     if (!c || (!body_dynamics_aos && count > 0) || count < 0 || count > c->body_count) return fail(BEPUHIP_E_INVALID_ARGUMENT, "bad get_poses_and_velocities argument");
     HIP_TRY(hipSetDevice(c->device));
     if (count == 0) return BEPUHIP_OK;
-    if (void* mapped = mapped_pointer(c, body_dynamics_aos, (size_t)count * 128)) {  // 15 MB in 0.34 ms; the 2-D copy below takes 1.4 ms
+    // (16-byte stores: a registered buffer that is not 16-byte aligned takes the 2-D copy — ADVICE r5; BodyDynamics arrays of the reference's BufferPool are)
+    void* mapped = ((uintptr_t)body_dynamics_aos & 15) == 0 ? mapped_pointer(c, body_dynamics_aos, (size_t)count * 128) : nullptr;
+    if (mapped) {  // 15 MB in 0.34 ms; the 2-D copy below takes 1.4 ms
         poses_out_kernel<<<(unsigned)(((size_t)count * 4 + 255) / 256), 256, 0, c->stream>>>((const float4*)c->d_bodies, (float4*)mapped, count);
         HIP_TRY(hipGetLastError());
         return BEPUHIP_OK;
