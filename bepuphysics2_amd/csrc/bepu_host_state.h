@@ -274,6 +274,7 @@ struct bepuhip_ctx {
     float4** d_peer_table = nullptr;
     float4* group_records = nullptr;          // the record table of a group member: allocated once (for group_records_bodies bodies), reused by every later plan that fits
     size_t group_records_bodies = 0;
+    bool group_records_on_host = false;       // BEPUHIP_GROUP_FAKE_REMOTE=1: the table lives in fine-grained host memory (see free_group_records)
     uint32_t* d_owned_dense = nullptr;        // bepuhip_sync_owned_bodies: 16 words per body
     uint8_t* d_owned_mask = nullptr;
     int owned_mask_bodies = 0;

@@ -116,6 +116,12 @@ static void free_boundary_layout(bepuhip_ctx* c) {
 }
 static void release_comm(bepuhip_ctx* c);
 
+static void free_group_records(bepuhip_ctx* c) {
+    if (!c->group_records) return;
+    if (c->group_records_on_host) hipHostFree(c->group_records); else hipFree(c->group_records);
+    c->group_records = nullptr; c->group_records_bodies = 0; c->group_records_on_host = false;
+}
+
 int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (!c) return BEPUHIP_OK;
     hipSetDevice(c->device);
@@ -140,7 +146,7 @@ int32_t bepuhip_destroy(bepuhip_ctx* c) {
     if (c->d_stage) hipFree(c->d_stage);
     if (c->h_desc_ring) hipHostFree(c->h_desc_ring);
     for (void* opened : c->peer_opened) if (opened) hipIpcCloseMemHandle(opened);
-    if (c->group_records) hipFree(c->group_records);
+    free_group_records(c);
     if (c->d_peer_table) hipFree(c->d_peer_table);
     if (c->d_owned_dense) hipFree(c->d_owned_dense);
     if (c->d_owned_mask) hipFree(c->d_owned_mask);
@@ -693,10 +699,25 @@ static int32_t build_constraints(bepuhip_ctx* c) {
                 // The other members of a device group hold this table's address (bepuhip_set_peer_records / import_peer_records) and push records into it: it must not move
                 // when this member uploads again or re-plans. Allocated once, with room to grow; a scene that outgrows it gets a new table, and the header says what the
                 // members have to do then (exchange the tables again).
-                if (c->group_records && c->group_records_bodies < c->shared_bodies) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->group_records); c->group_records = nullptr; c->group_records_bodies = 0; }
+                if (c->group_records && c->group_records_bodies < c->shared_bodies) { HIP_TRY(hipStreamSynchronize(c->stream)); free_group_records(c); }
                 if (!c->group_records) {
                     c->group_records_bodies = c->shared_bodies + c->shared_bodies / 4;
-                    HIP_TRY(hipMalloc((void**)&c->group_records, c->group_records_bodies * 4 * sizeof(float4)));
+                    const size_t bytes = c->group_records_bodies * 4 * sizeof(float4);
+                    if (env_int("BEPUHIP_GROUP_FAKE_REMOTE", 0) != 0) {
+                        // A developer switch for boxes with ONE GPU (VERDICT r5 next #7d): the table in fine-grained, host-coherent memory instead of this device's HBM. Members
+                        // that share the device then exchange records through memory that is remote to all of them — the peers' system-scope stores and the owner's agent-scope
+                        // polls travel over the host link and have to be coherent there, instead of meeting in the local L2 / HBM where any scope works. Slow, and exactly the
+                        // path (minus xGMI) that two devices take.
+                        void* host = nullptr;
+                        HIP_TRY(hipHostMalloc(&host, bytes, hipHostMallocCoherent | hipHostMallocMapped));
+                        void* mapped = nullptr;
+                        HIP_TRY(hipHostGetDevicePointer(&mapped, host, 0));
+                        c->group_records = (float4*)mapped;
+                        c->group_records_on_host = true;
+                    } else {
+                        HIP_TRY(hipMalloc((void**)&c->group_records, bytes));
+                        c->group_records_on_host = false;
+                    }
                 }
                 c->d_shared_vel = c->group_records;
             } else {
@@ -1815,7 +1836,7 @@ int32_t bepuhip_set_peer_records(bepuhip_ctx* c, int32_t peer, void* records) {
     c->peer_records[peer] = records;
     if ((int)c->peer_on_this_device.size() <= peer) c->peer_on_this_device.resize(peer + 1, 0);
     hipPointerAttribute_t where;
-    c->peer_on_this_device[peer] = records && hipPointerGetAttributes(&where, records) == hipSuccess && where.device == c->device ? 1 : 0;
+    c->peer_on_this_device[peer] = records && hipPointerGetAttributes(&where, records) == hipSuccess && (where.device == c->device || where.type == hipMemoryTypeHost) ? 1 : 0;  // (a table in host memory: BEPUHIP_GROUP_FAKE_REMOTE, members of one device)
     (void)hipGetLastError();
     for (void* p : c->peer_records) if (!p) return BEPUHIP_OK;  // incomplete: the table is uploaded with the last entry
     if ((int)c->peer_records.size() != c->group_world - 1) return BEPUHIP_OK;

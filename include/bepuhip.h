@@ -216,7 +216,9 @@ int32_t bepuhip_solve_lattice(bepuhip_ctx* ctx, float dt, int32_t substep_count,
  * between two launches of a chain a cluster stages its ghost copies from its own device's memory, where another device's results have not arrived; (3) importing a peer's
  * table again closes the mapping of the old one; (4) members that SHARE a device (the single-GPU tests; never a deployment) need a hardware queue each — the runtime
  * multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4, null stream included) queues per device, and two members on one queue wait for each other until the
- * watchdog reports a stall: a solve is refused with BEPUHIP_E_STATE when more contexts of this library are alive on the device than queues are left. */
+ * watchdog reports a stall: a solve is refused with BEPUHIP_E_STATE when more contexts of this library are alive on the device than queues are left. A developer switch for
+ * such boxes, BEPUHIP_GROUP_FAKE_REMOTE=1 (read at upload): the member's table is allocated in fine-grained host-coherent memory instead of its HBM, so that the peers'
+ * system-scope pushes and the owner's polls cross the host link instead of meeting in local memory (in-process members only: such a table has no IPC handle). */
 #define BEPUHIP_IPC_HANDLE_BYTES 64
 int32_t bepuhip_set_device_group(bepuhip_ctx* ctx, int32_t world, int32_t rank);
 int32_t bepuhip_get_shared_records(bepuhip_ctx* ctx, void** records_out, int64_t* bytes_out);

@@ -146,7 +146,11 @@ def run_structural_scene(rng, jitter: int = 0, touch_environment: bool = True, o
     nc = int(rng.integers(nb * 2, nb * 4)) if big else int(rng.integers(40, min(900, nb * 12)))  # degrees stay mostly under the fallback threshold (additions to the fallback batch are refused by design)
     split = str(int(rng.integers(8, 32))) if big else None
     rows = [small_scenes.random_dynamic_body(rng, rng.uniform(-6, 6, 3)) if i % 23 else small_scenes.kinematic_body(rng, rng.uniform(-6, 6, 3)) for i in range(nb)]
-    ms = MutableSolver(np.stack(rows))
+    # Round 6: one small scene in five has a LOW FallbackBatchThreshold, so that bodies of higher degree push constraints into the sequential fallback batch and the stream
+    # of additions and removals reaches it (bepuhip_add_constraint_at, the fallback branch of Remove: hashed probing, emptied bundles overwritten by the last one)
+    threshold = int(rng.integers(3, 7)) if (not big and rng.random() < 0.2) else 64
+    stats["fallback_threshold"] = threshold
+    ms = MutableSolver(np.stack(rows), fallback_batch_threshold=threshold)
 
     def add_random(solver=None):
         t = STRUCTURAL_TYPES[int(rng.integers(len(STRUCTURAL_TYPES)))]
@@ -162,12 +166,15 @@ def run_structural_scene(rng, jitter: int = 0, touch_environment: bool = True, o
         lane = small_scenes.prestep_for(rng, t, ms.bodies[bodies[0], 4:7], ms.bodies[bodies[-1], 4:7])
         bi, index, encoded = ms.add(t, bodies, lane)
         if solver is not None:
-            assert solver.add_constraint(bi, t, encoded, lane) == index
+            if bi == threshold:
+                solver.add_constraint_at(bi, t, index, encoded, lane)
+            else:
+                assert solver.add_constraint(bi, t, encoded, lane) == index
 
     for _ in range(nc):
         add_random()
     sub = int(rng.integers(1, 5))
-    sd, cb = SolveDescription(int(rng.integers(1, 4)), sub), PoseIntegratorCallbacks()
+    sd, cb = SolveDescription(int(rng.integers(1, 4)), sub, fallback_batch_threshold=threshold), PoseIntegratorCallbacks()
     with (environment(BEPUHIP_SPLIT_CLUSTERS=split, BEPUHIP_DEBUG_JITTER=jitter or None) if touch_environment else contextlib.nullcontext()):
         solver = HipSolver(use_clusters=bool(rng.random() < 0.8), reserve_update_slots=bool(rng.integers(2)))
         try:
