@@ -55,3 +55,30 @@ def compare_scenes(ref, got, rel_tol=1e-4):
     out["prestep_bit_exact"] = pre_exact
     out["impulses_max_ulp"] = imp_ulp
     return out
+
+
+def compare_scenes_with_nans(ref, got):
+    """compare_scenes for scenes that are MEANT to hold NaN / infinity: a word is NaN in both or in neither, and every word that is not NaN is bit-equal.
+    Which NaN it is (sign, payload) is the hardware's business — x86 makes the negative 'real indefinite' out of inf - inf, gfx950 the positive one — where it appears is not:
+    that is decided by the order of the operands of Vector.Min / Max (minps / maxps return the SECOND operand when either is NaN) and by the comparisons' outcomes on NaN.
+    Bodies (padding floats ignored), accumulated impulses and prestep rows; returns the NaN word counts so that a caller can insist the scene really held some."""
+    cols = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 13, 14]
+
+    def same(a, b):
+        na, nb = np.isnan(a), np.isnan(b)
+        return bool(np.array_equal(na, nb)) and bool(np.array_equal(a.view(np.int32)[~na], b.view(np.int32)[~nb])), int(na.sum())
+
+    out = {}
+    out["bodies_same"], out["body_nans"] = same(np.ascontiguousarray(ref.bodies[:, cols]), np.ascontiguousarray(got.bodies[:, cols]))
+    out["body_infinities"] = int(np.isinf(ref.bodies[:, cols]).sum())
+    imp, pre, nans = True, True, 0
+    for br, bg in zip(ref.batches, got.batches):
+        for tr, tg in zip(br, bg):
+            assert tr.type_id == tg.type_id and tr.count == tg.count
+            occupied = tr.occupied(ref.bundle_width)
+            ok, n = same(np.ascontiguousarray(tr.accumulated_lanes(ref.bundle_width)[occupied]), np.ascontiguousarray(tg.accumulated_lanes(got.bundle_width)[occupied]))
+            imp &= ok; nans += n
+            ok, n = same(np.ascontiguousarray(tr.prestep_lanes(ref.bundle_width)[occupied]), np.ascontiguousarray(tg.prestep_lanes(got.bundle_width)[occupied]))
+            pre &= ok; nans += n
+    out["impulses_same"], out["prestep_same"], out["constraint_nans"] = imp, pre, nans
+    return out
