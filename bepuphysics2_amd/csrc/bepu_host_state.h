@@ -161,8 +161,11 @@ struct GraphKey {
     }
 };
 
+struct ReplanJob;  // bepuhip.hip
 struct bepuhip_ctx {
     int device = 0, W = 8, flags = 0;
+    ReplanJob* replan_job = nullptr;  // bepuhip_replan_begin ... _commit: the planning thread, its shadow of the type batches, the log of structural calls since
+    bool replan_replaying = false;    // ... the commit is feeding that log back through the public calls: they do not log themselves again
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     float4* d_bodies = nullptr;

@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_set_device_group", "bepuhip_get_shared_records", "bepuhip_set_peer_records", "bepuhip_export_shared_records", "bepuhip_import_peer_records",
     "bepuhip_get_owned_bodies", "bepuhip_get_owned_constraints", "bepuhip_sync_owned_bodies",
     "bepuhip_get_kernel_family", "bepuhip_add_constraint_at",
+    "bepuhip_replan_begin", "bepuhip_replan_poll", "bepuhip_replan_commit", "bepuhip_replan_cancel",
 ]
 
 
@@ -168,6 +169,10 @@ def load_library() -> C.CDLL:
     lib.bepuhip_get_schedule.argtypes = [vp, C.POINTER(i32)]
     lib.bepuhip_get_kernel_family.argtypes = [vp, C.POINTER(i32)]
     lib.bepuhip_replan.argtypes = [vp]
+    lib.bepuhip_replan_begin.argtypes = [vp]
+    lib.bepuhip_replan_poll.argtypes = [vp, C.POINTER(i32)]
+    lib.bepuhip_replan_commit.argtypes = [vp, i32, C.POINTER(i32)]
+    lib.bepuhip_replan_cancel.argtypes = [vp]
     for name in EXPORTED_SYMBOLS:
         if name != "bepuhip_last_error":
             getattr(lib, name).restype = i32
@@ -522,6 +527,25 @@ class HipSolver:
     def replan(self):
         """A fresh plan for the constraints the device holds now (bepuhip_replan): values stay on the device, only the references are read back."""
         _check(self.lib, self.lib.bepuhip_replan(self.ctx))
+
+    def replan_begin(self):
+        """bepuhip_replan_begin: the references are read back, a host thread plans them; the frames go on (on the launch-per-batch schedule) until replan_commit."""
+        _check(self.lib, self.lib.bepuhip_replan_begin(self.ctx))
+
+    def replan_state(self) -> int:
+        """0 no re-plan in flight, 1 planning, 2 ready to commit."""
+        state = C.c_int32(0)
+        _check(self.lib, self.lib.bepuhip_replan_poll(self.ctx, C.byref(state)))
+        return int(state.value)
+
+    def replan_commit(self, wait: bool = False) -> bool:
+        """bepuhip_replan_commit: True when the new plan is the context's now (False: still planning and `wait` was not asked for)."""
+        committed = C.c_int32(0)
+        _check(self.lib, self.lib.bepuhip_replan_commit(self.ctx, 1 if wait else 0, C.byref(committed)))
+        return bool(committed.value)
+
+    def replan_cancel(self):
+        _check(self.lib, self.lib.bepuhip_replan_cancel(self.ctx))
 
     def update_prestep(self, batch_index: int, type_id: int, first_bundle: int, bundles: np.ndarray, asynchronous: bool = False):
         """``bundles``: the type batch's PrestepData bundles [first_bundle, first_bundle + n) exactly as the reference stores them (AOSOA).

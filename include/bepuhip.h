@@ -364,6 +364,27 @@ int32_t bepuhip_get_kernel_family(bepuhip_ctx* ctx, int32_t* family_out);
  * bepuhip_end_constraints costs without its upload (tens of milliseconds per million constraints): call it between frames when bepuhip_get_schedule reports 0, not
  * every frame. No counterpart in the reference (its constraint batches need no plan). */
 int32_t bepuhip_replan(bepuhip_ctx* ctx);
+/* bepuhip_replan with the planning OFF the caller's thread (round 6): the host planner is what the call costs (20-36 ms for the 100k-box pile or the 1M-constraint
+ * tube), and a frame loop cannot stop for it.
+ *   bepuhip_replan_begin   reads the body references back (about a millisecond per million constraints) and starts a host thread that plans them; returns at once. From
+ *                          here to the commit the context runs the launch-per-batch schedule (a context still on an island layout leaves it here). Everything stays
+ *                          legal in between — solves, ranged updates, read-backs, structural updates (each successful structural call is also written to the job's log).
+ *   bepuhip_replan_poll    *state_out = 0 no job, 1 planning, 2 the plan is ready.
+ *   bepuhip_replan_commit  `wait` = 0: returns at once with *committed_out = 0 while the worker is still planning; otherwise (or with `wait` != 0, after waiting for it)
+ *                          the context becomes what it was at begin on the new plan, the logged structural operations are applied to that plan in order through the
+ *                          public entry points — the plan absorbs them exactly as it would have frame by frame; an operation it cannot absorb leaves the context on the
+ *                          launch-per-batch schedule, where it was anyway — and prestep data and accumulated impulses of every constraint alive now (working rows and
+ *                          the bepuhip_reset_state snapshot) move into the new layout on the device. *committed_out = 1. Costs the caller's thread the upload of the
+ *                          plan's tables and the replay (a few milliseconds), not the planning. Indices, counts and values as the caller knows them are unchanged;
+ *                          results are bit-identical with or without the calls.
+ *   bepuhip_replan_cancel  drops a job (waits for its worker); bepuhip_begin_constraints, bepuhip_replan and bepuhip_destroy do the same.
+ * One job per context at a time (STATE otherwise); not for members of a device group (UNSUPPORTED: they re-plan together with bepuhip_replan). No counterpart in the
+ * reference (its constraint batches need no plan; the nearest thing is the deferred batch compression, BepuPhysics/BatchCompressor.cs:15-45 — analysis spread over
+ * frames and "performed asynchronously ... hidden behind other stages", applied between frames: Simulation.cs:302-304). */
+int32_t bepuhip_replan_begin(bepuhip_ctx* ctx);
+int32_t bepuhip_replan_poll(bepuhip_ctx* ctx, int32_t* state_out);
+int32_t bepuhip_replan_commit(bepuhip_ctx* ctx, int32_t wait, int32_t* committed_out);
+int32_t bepuhip_replan_cancel(bepuhip_ctx* ctx);
 
 /* ---- PredictBoundingBoxes on the device ----
  * Replaces the per-body work of PoseIntegrator.PredictBoundingBoxes (BepuPhysics/PoseIntegrator.cs:307-370, called from Simulation.PredictBoundingBoxes,

@@ -109,6 +109,10 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_get_schedule(IntPtr ctx, int* scheduleOut);
     [DllImport(Lib)] public static extern int bepuhip_get_kernel_family(IntPtr ctx, int* familyOut);
     [DllImport(Lib)] public static extern int bepuhip_replan(IntPtr ctx);
+    [DllImport(Lib)] public static extern int bepuhip_replan_begin(IntPtr ctx);
+    [DllImport(Lib)] public static extern int bepuhip_replan_poll(IntPtr ctx, int* stateOut);
+    [DllImport(Lib)] public static extern int bepuhip_replan_commit(IntPtr ctx, int wait, int* committedOut);
+    [DllImport(Lib)] public static extern int bepuhip_replan_cancel(IntPtr ctx);
     [DllImport(Lib)] public static extern int bepuhip_set_convex_hulls(IntPtr ctx, float* points, int* pointBegin, int hullCount);
     [DllImport(Lib)] public static extern int bepuhip_set_compounds(IntPtr ctx, BepuHipCompoundChild* children, int* childBegin, int compoundCount);
     [DllImport(Lib)] public static extern int bepuhip_set_meshes(IntPtr ctx, float* triangles, int* triangleBegin, float* scales, int meshCount);
@@ -185,6 +189,9 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, 
     public void MarkDirty(ConstraintHandle handle) => dirtyConstraints.Add(handle.Value);
     readonly List<uint> payload = new List<uint>();
     public int ReplanInterval = 30;                                // frames between two bepuhip_replan calls at most
+    /// The re-plan's host planner (20-36 ms for a million constraints) on a thread of the library's own (bepuhip_replan_begin / _commit) instead of inside Timestep.
+    public bool ReplanInBackground = true;
+    bool replanInFlight;
     /// Every body's state is sent before every solve (bepuhip_set_bodies: one DMA from the registered DynamicsState buffer, 0.6 ms for 240,000 bodies): velocities the user
     /// set, ApplyImpulse, teleports, inertia changes and kinematic bodies driven by writing their velocity all reach the device. A host that never writes body state
     /// between frames may turn it off; bodies are then sent when the body count changed or a body moved in memory.
@@ -302,6 +309,7 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, 
         // Bodies.ActiveSet.DynamicsState: 128-byte BodyDynamics (BodySet.cs:41)
         Register(activeBodies.DynamicsState.Memory, (long)activeBodies.DynamicsState.Length * sizeof(BodyDynamics));
         Check(BepuHip.bepuhip_set_bodies(ctx, activeBodies.DynamicsState.Memory, activeBodies.Count));
+        replanInFlight = false;   // (an upload drops a re-plan in the making: it described the constraints this upload replaces)
         Check(BepuHip.bepuhip_begin_constraints(ctx, activeSet.Batches.Count, solver.FallbackBatchThreshold));
         mirrors.Clear();
         for (int b = 0; b < activeSet.Batches.Count; ++b)
@@ -469,7 +477,17 @@ public unsafe class HipTimestepper<TCallbacks> : ITimestepper, IHipSubstepSink, 
         // milliseconds once, the slow schedule costs every frame from then on. Not more often than every ReplanInterval frames.
         int schedule;
         Check(BepuHip.bepuhip_get_schedule(ctx, &schedule));
-        if (schedule == 0 && framesSinceReplan >= ReplanInterval) { Check(BepuHip.bepuhip_replan(ctx)); framesSinceReplan = 0; }
+        if (replanInFlight)
+        {   // the worker plans beside the frames; when it is done the commit costs this thread the tables' upload and the replay of the operations since, not the planning
+            int committed;
+            Check(BepuHip.bepuhip_replan_commit(ctx, 0, &committed));
+            if (committed != 0) { replanInFlight = false; framesSinceReplan = 0; }
+        }
+        else if (schedule == 0 && framesSinceReplan >= ReplanInterval)
+        {
+            if (ReplanInBackground) { Check(BepuHip.bepuhip_replan_begin(ctx)); replanInFlight = true; }
+            else { Check(BepuHip.bepuhip_replan(ctx)); framesSinceReplan = 0; }
+        }
         else ++framesSinceReplan;
         return true;
     }

@@ -140,7 +140,7 @@ def run_structural_scene(rng, jitter: int = 0, touch_environment: bool = True, o
     thread's getenv is a race of its own; ``oracle_lock``: held around the checker's calls."""
     import contextlib
     from mutable_scene import MutableSolver
-    stats = {"ok": True, "frames": 0, "refused": 0, "replans": 0, "body_removals": 0, "report": ""}
+    stats = {"ok": True, "frames": 0, "refused": 0, "replans": 0, "background_replans": 0, "body_removals": 0, "report": ""}
     big = rng.random() < 0.3  # one island no workgroup holds: the split-island plan (forced cluster counts so that small scenes split too)
     nb = int(rng.integers(1500, 3500)) if big else int(rng.integers(30, 400))
     nc = int(rng.integers(nb * 2, nb * 4)) if big else int(rng.integers(40, min(900, nb * 12)))  # degrees stay mostly under the fallback threshold (additions to the fallback batch are refused by design)
@@ -180,7 +180,9 @@ def run_structural_scene(rng, jitter: int = 0, touch_environment: bool = True, o
         try:
             solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
             replanned_at = []
-            for frame in range(int(rng.integers(3, 12))):
+            in_flight = False
+            frames = int(rng.integers(3, 12))
+            for frame in range(frames):
                 try:
                     for _ in range(int(rng.integers(0, 8))):
                         locs = ms.locations()
@@ -202,10 +204,20 @@ def run_structural_scene(rng, jitter: int = 0, touch_environment: bool = True, o
                                 solver.update_body_reference(bi, t, i, k, encoded)
                             solver.set_bodies(ms.bodies)
                             stats["body_removals"] += 1
-                    if rng.random() < 0.15:  # now and then a fresh plan for what the device holds (bepuhip_replan), whatever schedule the context is on
+                    event = rng.random()
+                    if in_flight:  # round 6: a re-plan in the background (bepuhip_replan_begin): committed some frames later, with or without waiting for the worker — the operations of the frames in between are replayed onto the new plan
+                        if frame == frames - 1 or event < 0.5:
+                            if solver.replan_commit(wait=bool(frame == frames - 1 or rng.integers(2))):
+                                in_flight = False
+                                stats["background_replans"] += 1
+                                replanned_at.append(-frame)
+                    elif event < 0.15:  # now and then a fresh plan for what the device holds (bepuhip_replan), whatever schedule the context is on
                         solver.replan()
                         stats["replans"] += 1
                         replanned_at.append(frame)
+                    elif event < 0.30 and frame < frames - 1:
+                        solver.replan_begin()
+                        in_flight = True
                     export = ms.to_scene()
                     kin = np.ascontiguousarray(export.constrained_kinematic_indices(), dtype=np.int32)  # Solver.ConstrainedKinematicHandles changes with the constraints: the caller re-sends it
                     native._check(solver.lib, solver.lib.bepuhip_set_constrained_kinematics(solver.ctx, native._ptr(kin), kin.size))
@@ -222,7 +234,7 @@ def run_structural_scene(rng, jitter: int = 0, touch_environment: bool = True, o
                         cols = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 13, 14]
                         rows = np.flatnonzero((export.bodies[:, cols].view(np.int32) != got.bodies[:, cols].view(np.int32)).any(axis=1))
                         stats["report"] = (f"MISMATCH bodies {nb} constraints {nc} substeps {sub} frame {frame} {m} bodies {rows[:8]} kinematic {[ms.is_kinematic(int(r)) for r in rows[:8]]} "
-                                           f"in the caller's constrained-kinematic list {[int(r) in set(kin.tolist()) for r in rows[:8]]} schedule {solver.schedule()} re-planned before frames {replanned_at}")
+                                           f"in the caller's constrained-kinematic list {[int(r) in set(kin.tolist()) for r in rows[:8]]} schedule {solver.schedule()} re-planned before frames {replanned_at} (negative: background commit)")
                         break
                 except UnsupportedError:  # an addition that lands in the sequential fallback batch: refused by design, the scene ends here
                     stats["refused"] += 1

@@ -907,3 +907,175 @@ def test_the_sequential_fallback_batch_itself_takes_additions_and_removals(hip_s
         solver.add_constraint_at(threshold, t, occupied, ms.batches[threshold][t]["refs"][occupied], ms.batches[threshold][t]["prestep"][occupied])
     with pytest.raises(ValueError):  # BEPUHIP_E_INVALID_ARGUMENT
         solver.add_constraint_at(threshold, t, len(ms.batches[threshold][t]["refs"]) + 3 * ms.w, ms.batches[threshold][t]["refs"][occupied], ms.batches[threshold][t]["prestep"][occupied])
+
+
+def _churn(ms, rng, pair, solver, removals, additions, keep_degree=True):
+    """`removals` random contact removals and `additions` random contact additions, on the mirror and on the device."""
+    is_contact = lambda t: t in CONTACT_TYPES  # noqa: E731
+    for _ in range(removals):
+        locs = ms.locations(is_contact)
+        bi, t, i = locs[int(rng.integers(len(locs)))]
+        if keep_degree and any(not (r & 0x40000000) and ms.dynamic_degree(r) < 2 for r in ms.batches[bi][t]["refs"][i]):
+            continue  # (a body that loses its last constraint leaves any island plan)
+        ms.remove(bi, t, i)
+        solver.remove_constraint(bi, t, i)
+    for _ in range(additions):
+        a, b = pair()
+        t = CONTACT_TYPES[int(rng.integers(len(CONTACT_TYPES)))]
+        lane = small_scenes.prestep_for(rng, t, ms.bodies[a, 4:7], ms.bodies[b, 4:7])
+        bi, index, encoded = ms.add(t, [a, b], lane)
+        assert solver.add_constraint(bi, t, encoded, lane) == index
+
+
+def _frame(ms, solver, sd, cb, threads=1):
+    export = ms.to_scene()
+    oracle_ffi.solve(export, 1 / 60, sd, cb, threads=threads)
+    ms.absorb(export)
+    solver.solve(1 / 60, sd, cb)
+    got = ms.to_scene()
+    solver.download(got)
+    m = pu.compare_scenes(export, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+
+@pytest.mark.parametrize("churn_in_flight", [0, 25])
+def test_background_replan_with_structural_updates_in_flight_on_a_split_plan(hip_solver_factory, monkeypatch, churn_in_flight):
+    """bepuhip_replan_begin / _commit (round 6, VERDICT r5 next #6a): the planner runs on a host thread of the library while the frames go on — here four frames on the
+    launch-per-batch rows, each with `churn_in_flight` removals and additions of random contact pairs (most of them across clusters) — and the commit adopts the plan made
+    for the constraints of the snapshot, replays the logged operations onto it through the public entry points (reserved slots: the plan absorbs them and the context is on
+    the split-island schedule afterwards) and moves the CURRENT prestep data and accumulated impulses — what the frames in between produced — into the new layout. Every
+    frame before, between and after is bit-exact against the oracle solving the host mirror; read-backs in the caller's order see the same values through the new layout;
+    reset_state returns to uploaded values + structural updates, as it does after bepuhip_replan."""
+    monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "12")
+    ms, rng, pair = _build(41, bodies=2600, joints=3000, contacts=5000)
+    sd, cb = SolveDescription(1, 4), PoseIntegratorCallbacks()
+    solver = hip_solver_factory(reserve_update_slots=True)
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+    assert solver.schedule() == 2 and solver.replan_state() == 0
+    _frame(ms, solver, sd, cb, 4)
+    solver.replan_begin()
+    assert solver.schedule() == 0, "from begin to commit the context runs the rows in the caller's order"
+    with pytest.raises(native_error()) as e:
+        solver.replan_begin()
+    assert e.value.code == native_codes().BEPUHIP_E_STATE
+    for _ in range(4):
+        _churn(ms, rng, pair, solver, churn_in_flight, churn_in_flight)
+        _frame(ms, solver, sd, cb, 4)
+    assert solver.replan_state() in (1, 2)
+    assert solver.replan_commit(wait=True)
+    assert solver.replan_state() == 0
+    assert solver.schedule() == 2, "the new plan (with its reserves) took the operations of the frames in between"
+    for bi, tbs in enumerate(ms.to_scene().batches):
+        for tb in tbs:
+            assert solver.constraint_count(bi, tb.type_id) == tb.count
+    before = ms.to_scene()
+    solver.download(before)
+    m = pu.compare_scenes(ms.to_scene(), before)
+    assert m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    for _ in range(3):
+        _churn(ms, rng, pair, solver, 10, 10)
+        _frame(ms, solver, sd, cb, 4)
+    assert solver.schedule() == 2 and solver.cluster_cycles().size > 1
+    with pytest.raises(native_error()) as e:
+        solver.replan_commit(wait=True)  # nothing in flight
+    assert e.value.code == native_codes().BEPUHIP_E_STATE
+
+
+def native_error():
+    from bepuphysics2_amd.native import BepuHipError
+    return BepuHipError
+
+
+def native_codes():
+    from bepuphysics2_amd import native
+    return native
+
+
+def test_background_replan_on_a_whole_island_plan_and_what_reset_state_returns_to(hip_solver_factory):
+    """The hub scene of test_replan_puts_a_context_that_left_its_plan_back_on_the_island_schedule, re-planned in the background: between begin and commit the hub gets more
+    constraints (new batches, rows that grow), some are removed again, two frames are solved. After the commit the context is on the whole-island schedule, the frames stay
+    bit-exact, and reset_state returns to the uploaded values plus every structural update — the snapshot moved into the new layout with ITS values."""
+    rng = np.random.default_rng(6)
+    rows = [small_scenes.random_dynamic_body(rng, rng.uniform(-3, 3, 3)) for _ in range(140)]
+    ms, pristine = MutableSolver(np.stack(rows)), MutableSolver(np.stack(rows))
+    for k in range(1, 139, 2):
+        lane = small_scenes.prestep_for(rng, 7, ms.bodies[k, 4:7], ms.bodies[k + 1, 4:7])
+        ms.add(7, [k, k + 1], lane); pristine.add(7, [k, k + 1], lane)
+    sd, cb = SolveDescription(2, 2), PoseIntegratorCallbacks()
+    solver = hip_solver_factory(reserve_update_slots=True)
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+    assert solver.schedule() == 1
+
+    def hub(k):
+        t = [7, 22, 4][k % 3]
+        lane = small_scenes.prestep_for(rng, t, ms.bodies[0, 4:7], ms.bodies[k, 4:7])
+        bi, index, encoded = ms.add(t, [0, k], lane)
+        pristine.add(t, [0, k], lane)
+        assert solver.add_constraint(bi, t, encoded, lane) == index
+
+    _frame(ms, solver, sd, cb)
+    for k in range(3, 30):
+        hub(k)
+    _frame(ms, solver, sd, cb)
+    assert solver.schedule() == 0
+    solver.replan_begin()
+    for k in range(30, 36):  # the log: additions that open batches the snapshot did not have ...
+        hub(k)
+    _frame(ms, solver, sd, cb)
+    for bi, t, i in sorted(ms.locations(lambda t: t == 22), reverse=True)[:4]:  # ... and removals (swap-with-last) of constraints the snapshot did have
+        ms.remove(bi, t, i); pristine.remove(bi, t, i)
+        solver.remove_constraint(bi, t, i)
+    _frame(ms, solver, sd, cb)
+    assert solver.replan_commit(wait=True)
+    # (the replayed additions open batches and type batches: no plan absorbs that, the context is back on the rows — with everything intact)
+    for bi, tbs in enumerate(ms.to_scene().batches):
+        for tb in tbs:
+            assert solver.constraint_count(bi, tb.type_id) == tb.count
+    _frame(ms, solver, sd, cb)
+    solver.replan_begin()  # nothing happens in flight this time: the commit is bepuhip_replan with the planning elsewhere
+    _frame(ms, solver, sd, cb)
+    assert solver.replan_commit(wait=True)
+    assert solver.schedule() == 1
+    _frame(ms, solver, sd, cb)
+    _frame(ms, solver, sd, cb)
+    assert solver.cluster_cycles().size > 0
+    solver.reset_state()
+    solver.solve(1 / 60, sd, cb)
+    want = pristine.to_scene()
+    oracle_ffi.solve(want, 1 / 60, sd, cb)
+    got = pristine.to_scene()
+    solver.download(got)
+    m = pu.compare_scenes(want, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+
+
+def test_background_replan_is_dropped_by_an_upload_a_replan_or_the_end_of_the_context(hip_solver_factory):
+    """A job describes the constraints it was begun for: bepuhip_begin_constraints, bepuhip_replan and bepuhip_destroy drop it (waiting for its worker), bepuhip_replan_cancel
+    does so on request; a commit without a job is STATE. Polling without waiting never blocks and reports 0 / 1 / 2."""
+    ms, rng, pair = _build(43, bodies=400, joints=500, contacts=900)
+    sd, cb = SolveDescription(1, 2), PoseIntegratorCallbacks()
+    solver = hip_solver_factory(reserve_update_slots=True)
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)
+    _frame(ms, solver, sd, cb)
+    solver.replan_begin()
+    solver.upload(ms.to_scene(), sd.fallback_batch_threshold)  # drops the job
+    assert solver.replan_state() == 0
+    _frame(ms, solver, sd, cb)
+    solver.replan_begin()
+    solver.replan()  # the synchronous call drops it too
+    assert solver.replan_state() == 0
+    _frame(ms, solver, sd, cb)
+    solver.replan_begin()
+    solver.replan_cancel()
+    assert solver.replan_state() == 0
+    _frame(ms, solver, sd, cb)
+    solver.replan_begin()
+    polls = 0
+    while not solver.replan_commit(wait=False):  # frames go on until the worker is done
+        _churn(ms, rng, pair, solver, 3, 3)
+        _frame(ms, solver, sd, cb)
+        polls += 1
+        assert polls < 2000
+    assert solver.schedule() >= 1
+    _frame(ms, solver, sd, cb)
+    solver.replan_begin()  # ... and a context that is destroyed with a job in flight waits for the worker and frees it (hip_solver_factory closes the solver)
