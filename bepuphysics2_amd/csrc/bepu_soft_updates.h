@@ -163,6 +163,29 @@ static void soft_setup(bepuhip_ctx* c, ClusterPlan& plan) {
     c->soft_ok = true;
 }
 
+// The mirrors the first structural update of a plan builds lazily (constraint counts, free LDS slots, kinematic uses; on a split plan every body's applications:
+// 26 ms for the 100k-box pile), built NOW: by the worker of a background re-plan (bepuhip_replan_begin), whose commit replays a frame's worth of operations at once.
+static void soft_ensure_degrees(bepuhip_ctx* c);
+static void soft_ensure_free_slots(bepuhip_ctx* c);
+static void split_ensure_mirrors(bepuhip_ctx* c);
+static void soft_warm(bepuhip_ctx* c) {
+    if (!c->soft_ok) return;
+    soft_ensure_kin_uses(c);
+    if (c->soft_split) split_ensure_mirrors(c);
+    else { soft_ensure_degrees(c); soft_ensure_free_slots(c); }
+}
+// Everything soft_setup and the lazy builders fill, moved from the context it was prepared on (the shadow of a background re-plan; its type batches — which carry the
+// per-type-batch half of the state — travel separately) to the context that will run it.
+static void soft_move_state(bepuhip_ctx* to, bepuhip_ctx* from) {
+#define MV(f) to->f = std::move(from->f)
+    MV(soft_ok); MV(soft_split); MV(soft_records); MV(soft_payload); MV(soft_index_dirty); MV(soft_items_dirty); MV(soft_adds); MV(soft_removes);
+    MV(body_apps); MV(split_rerank_flag); MV(split_rerank_list); MV(split_patches); MV(kinlist_host); MV(kin_uses); MV(kin_touched); MV(kin_uses_ready);
+    MV(free_slots_ready); MV(cluster_free_slots); MV(body_moves); MV(body_cluster); MV(body_lref); MV(body_degree); MV(body_batches); MV(cluster_kin);
+    MV(split_shared); MV(cluster_extra); MV(cluster_natural); MV(cluster_extra_uses); MV(cluster_bodies_host); MV(split_visit); MV(items_host); MV(clusters_host);
+    MV(cluster_degraded); MV(soft_orphans);
+#undef MV
+}
+
 // Constraint count of every dynamic body, from the device-slot mirrors of the references: counted when the first structural update arrives (an upload that is never
 // followed by one does not pay for it).
 static void soft_ensure_degrees(bepuhip_ctx* c) {

@@ -410,7 +410,7 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
     return BEPUHIP_OK;
 }
 
-static int32_t build_constraints(bepuhip_ctx* c, ClusterPlan* planned = nullptr, std::vector<std::vector<int32_t>>* planned_fallback_refs = nullptr);
+static int32_t build_constraints(bepuhip_ctx* c, ClusterPlan* planned = nullptr, std::vector<std::vector<int32_t>>* planned_fallback_refs = nullptr, bepuhip_ctx* soft_from = nullptr);
 static int32_t flush_structural(bepuhip_ctx* c);
 static HostTypeBatch* find_tb(bepuhip_ctx* c, int batch, int type_id);
 static int32_t device_index_of(bepuhip_ctx* c, HostTypeBatch* tb, const int** out);
@@ -544,8 +544,9 @@ static int32_t build_descriptors(bepuhip_ctx* c, const std::vector<std::vector<i
 }
 
 // `planned`: the plan was computed beforehand for exactly these type batches (bepuhip_replan_commit: by the job's worker thread, on the shadow the type batches were
-// moved out of) — with it the fallback type batches' references as they were before the planner permuted them.
-static int32_t build_constraints(bepuhip_ctx* c, ClusterPlan* planned, std::vector<std::vector<int32_t>>* planned_fallback_refs) {
+// moved out of) — with it the fallback type batches' references as they were before the planner permuted them, and the context (that shadow) on which soft_setup has
+// run for the plan already, lazily built mirrors included.
+static int32_t build_constraints(bepuhip_ctx* c, ClusterPlan* planned, std::vector<std::vector<int32_t>>* planned_fallback_refs, bepuhip_ctx* soft_from) {
     const bool stats = env_int("BEPUHIP_PLAN_STATS", 0) != 0;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -678,6 +679,7 @@ static int32_t build_constraints(bepuhip_ctx* c, ClusterPlan* planned, std::vect
             it.prestep_off = (unsigned)tb.prestep_off;
             it.accum_off = (unsigned)tb.accum_off;
         }
+        if (soft_from && soft_from->soft_ok) soft_from->items_host = plan.items;  // (the mirror soft_setup took on the worker's thread predates the slab layout)
         c->clustered_dynamic_count = (int)plan.clustered_dynamic.size();
         HIP_TRY(upload_ints(plan.clusters.data(), plan.clusters.size() * sizeof(ClusterDesc), (void**)&c->d_clusters));
         HIP_TRY(upload_ints(plan.items.data(), plan.items.size() * sizeof(ClusterItem), (void**)&c->d_items));
@@ -704,7 +706,7 @@ static int32_t build_constraints(bepuhip_ctx* c, ClusterPlan* planned, std::vect
         c->owned_mask_bodies = 0;  // (the device copy of the ownership mask follows the plan)
         c->cluster_first = (int)((int64_t)plan.clusters.size() * c->group_rank / c->group_world);
         c->cluster_local = (int)((int64_t)plan.clusters.size() * (c->group_rank + 1) / c->group_world) - c->cluster_first;
-        soft_setup(c, plan);
+        if (soft_from) soft_move_state(c, soft_from); else soft_setup(c, plan);
         for (int tr = 0; tr < 2; ++tr)
             for (int wide = 0; wide < 2; ++wide) {
                 HIP_TRY(hipFuncSetAttribute(cluster_kernel_variant(1024, tr != 0, wide != 0, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
@@ -932,6 +934,10 @@ int32_t bepuhip_replan_begin(bepuhip_ctx* c) {
     ReplanJob* raw = job.release();
     raw->worker = std::thread([raw] {
         plan_clusters(&raw->shadow, raw->plan);
+        if (raw->plan.enabled) {  // what build_constraints would do with the plan's host half at the commit — and what the first structural update would build lazily
+            soft_setup(&raw->shadow, raw->plan);
+            soft_warm(&raw->shadow);
+        }
         raw->plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - raw->started).count();
         raw->done.store(1, std::memory_order_release);
     });
@@ -976,7 +982,7 @@ int32_t bepuhip_replan_commit(bepuhip_ctx* c, int32_t wait, int32_t* committed_o
     // (1) the context as it was when the job began, on the plan the worker made for it (values: none yet)
     adopt_type_batches(c, std::move(job->shadow.tbs), job->batch_count, job->has_fallback);
     c->referenced_bodies = job->shadow.referenced_bodies; c->total_constraints = job->shadow.total_constraints;  // (counted before the planner permuted the references)
-    st = build_constraints(c, &job->plan, &job->fallback_refs);
+    st = build_constraints(c, &job->plan, &job->fallback_refs, job->plan.enabled ? &job->shadow : nullptr);
     const auto t1 = std::chrono::steady_clock::now();
     // (2) the frames' structural operations, through the public entry points
     int32_t failed = -1;

@@ -119,6 +119,8 @@ for label, env in (("split plan keeps the updates", {}), ("round 2: updates leav
     print(f"{name}, {label}: {calls} structural operations per frame {calls_ms:.2f} ms with the table built in Python, {call_ms:.2f} ms inside the one bepuhip_apply_structural_ops call; the flush + solve that follows {frame_ms:.3f} ms; the solve alone afterwards {solve_ms:.4f} ms; "
           f"clusters {solver.cluster_cycles().size}; finite {finite}", flush=True)
     if solver.schedule() == 0:  # what a re-plan costs and gives back: in the background with the churn going on (round 6), then bepuhip_replan itself
+        for k in env:  # (the developer switch that made the updates leave the plan is off again: the new plan takes the operations of the frames in between)
+            os.environ.pop(k, None)
         t0 = time.perf_counter()
         solver.replan_begin()
         begin_ms = 1e3 * (time.perf_counter() - t0)
