@@ -58,10 +58,15 @@ static inline int split_segment_slots(int live, bool reserve) { return reserve ?
 constexpr int32_t kPlanDeadLref = (int32_t)kDynamicLimit;  // 32-bit planning form of a free slot's local references: the kinematic copy in slot 0 (packs to kLrefDead)
 
 // Host threads of the planner: BEPUHIP_PLAN_THREADS, default a quarter of the hardware threads between 8 and 16 (the phases are memory-bound; more only adds start-up cost).
+// (round 6) The worker of a background re-plan (bepuhip_replan_begin) plans BESIDE the frames: it takes BEPUHIP_REPLAN_THREADS threads (default 4) from a pool of its own
+// — sixteen planner threads next to the caller's own flush loops oversubscribe a sixteen-CPU quota and the frames in between pay for it (crowd: 18 ms frames).
+static thread_local int tl_plan_thread_cap = 0;
 static int plan_workers(size_t jobs) {
     const int hw = (int)std::thread::hardware_concurrency();
     const int fallback = std::max(1, std::min(16, std::max(8, hw / 4)));
-    return std::max(1, std::min<int>({env_int("BEPUHIP_PLAN_THREADS", fallback), hw > 0 ? hw : 1, (int)std::max<size_t>(jobs, 1)}));
+    int wanted = env_int("BEPUHIP_PLAN_THREADS", fallback);
+    if (tl_plan_thread_cap > 0) wanted = std::min(wanted, tl_plan_thread_cap);
+    return std::max(1, std::min<int>({wanted, hw > 0 ? hw : 1, (int)std::max<size_t>(jobs, 1)}));
 }
 // Where the parked threads run. The planner's loops hand cache lines back and forth (the union-find's parents, the per-cluster lists): on a two-socket host with sixteen
 // L3 domains the scheduler spreads sixteen fresh threads over all of them, and every hand-over is a trip across the fabric — the same loops run a quarter faster when
@@ -174,14 +179,14 @@ struct PlanPool {
 };
 // Never destroyed: its threads outlive main's statics. A forked child gets a pool of its own: the parent's mutexes may have been held by threads that do not
 // exist in the child, where locking them again would never return; the old object is abandoned, not freed (its condition variables may be mid-wait in the copy).
-static PlanPool*& plan_pool_slot() { static PlanPool* pool = nullptr; return pool; }
+static PlanPool*& plan_pool_slot(int which = 0) { static PlanPool* pool[2] = {nullptr, nullptr}; return pool[which]; }  // [1]: the background re-plan workers' pool
 static PlanPool& plan_pool() {
     static std::once_flag once;
     std::call_once(once, [] {
-        plan_pool_slot() = new PlanPool();
-        pthread_atfork(nullptr, nullptr, [] { plan_pool_slot() = new PlanPool(); });
+        plan_pool_slot(0) = new PlanPool(); plan_pool_slot(1) = new PlanPool();
+        pthread_atfork(nullptr, nullptr, [] { plan_pool_slot(0) = new PlanPool(); plan_pool_slot(1) = new PlanPool(); });
     });
-    return *plan_pool_slot();
+    return *plan_pool_slot(tl_plan_thread_cap > 0 ? 1 : 0);
 }
 template <class Fn>
 static void plan_parallel_for_workers(size_t jobs, Fn&& fn) {  // fn(job, worker, workers) for every job, dynamically scheduled; results must not depend on the order

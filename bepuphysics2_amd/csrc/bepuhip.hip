@@ -933,6 +933,7 @@ int32_t bepuhip_replan_begin(bepuhip_ctx* c) {
     job->started = std::chrono::steady_clock::now();
     ReplanJob* raw = job.release();
     raw->worker = std::thread([raw] {
+        tl_plan_thread_cap = std::max(1, env_int("BEPUHIP_REPLAN_THREADS", 4));  // beside the frames, not instead of them (bepu_cluster_plan.h)
         plan_clusters(&raw->shadow, raw->plan);
         if (raw->plan.enabled) {  // what build_constraints would do with the plan's host half at the commit — and what the first structural update would build lazily
             soft_setup(&raw->shadow, raw->plan);
