@@ -644,6 +644,30 @@ def boundary_leg(scene, sd, cb, device: int):
                                         f"(structural_ops_call_ms: the call alone; structural_frame_per_call_ms: the same frame as {2 * calls} single calls from Python, round 3's form); the context "
                                         + ("stayed on the island schedule (freed device slots reused, the predecessor lists of the touched clusters rebuilt on the host)" if stayed else
                                            "left the island schedule for the launch-per-batch one"))
+        # a re-plan beside the frames (round 6, bepuhip_replan_begin / _commit) against bepuhip_replan: what each costs the thread that runs the frames
+        t0 = time.perf_counter()
+        solver.replan()
+        out["replan_sync_ms"] = 1e3 * (time.perf_counter() - t0)
+        solver.solve(1 / 60, sd, cb)
+        t0 = time.perf_counter()
+        solver.replan_begin()
+        out["replan_begin_ms"] = 1e3 * (time.perf_counter() - t0)
+        in_flight = 0
+        while True:
+            t0 = time.perf_counter()
+            committed = solver.replan_commit(wait=in_flight >= 200)
+            commit_ms = 1e3 * (time.perf_counter() - t0)
+            if committed:
+                break
+            solver.apply_structural_op_table(table, payload)
+            solver.solve(1 / 60, sd, cb)
+            in_flight += 1
+        out["replan_commit_ms"] = commit_ms
+        out["replan_blocking_ms"] = out["replan_begin_ms"] + commit_ms
+        out["replan_frames_in_flight"] = in_flight
+        out["replan_schedule_after"] = solver.schedule()
+        out["replan_note"] = (f"bepuhip_replan blocks the caller for the host planner (replan_sync_ms); begin + commit block it for the snapshot, the tables' upload and the replay of the "
+                              f"{in_flight} x {2 * calls} structural operations of the frames solved while the worker planned (replan_blocking_ms)")
     solver.close()
     return out
 
