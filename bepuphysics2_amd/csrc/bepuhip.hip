@@ -2481,29 +2481,43 @@ static int32_t leave_island_schedule(bepuhip_ctx* c) {
     c->soft_ok = false; c->soft_split = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
     clear_graphs(c);
-    for (int k = 0; k < 2; ++k) {
-        uint32_t*& slab = k == 0 ? c->d_slab : c->d_slab0;
-        if (!slab || c->slab_words == 0) continue;
-        uint32_t* fresh = nullptr;
-        HIP_TRY(hipMalloc((void**)&fresh, c->slab_words * 4));
-        HIP_TRY(hipMemcpyAsync(fresh, slab, c->slab_words * 4, hipMemcpyDeviceToDevice, c->stream));
-        for (auto& tb : c->tbs) {
-            const int extent = tb.device_extent();
-            if (tb.perm.empty() || extent == 0) continue;
-            int* d_perm = nullptr;
-            HIP_TRY(hipMalloc((void**)&d_perm, tb.perm.size() * 4));
-            HIP_TRY(hipMemcpyAsync(d_perm, tb.perm.data(), tb.perm.size() * 4, hipMemcpyHostToDevice, c->stream));
-            const size_t offs[3] = {tb.refs_off, tb.prestep_off, tb.accum_off};
-            const int rows[3] = {tb.info.bodies, tb.info.prestep, tb.info.impulse};
-            for (int r = 0; r < 3; ++r)
-                hipLaunchKernelGGL(unpermute_rows_kernel, dim3((extent + 255) / 256), dim3(256), 0, c->stream, (const unsigned*)(slab + offs[r]), (unsigned*)(fresh + offs[r]), (const int*)d_perm,
-                                   extent, tb.stride, rows[r]);
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            hipFree(d_perm);
+    {   // every permuted type batch's device slot -> caller's index table in ONE device buffer, sent once (round 6; a hipMalloc, a copy and a wait per type batch and slab until
+        // then: 9 ms for the headline scene's 32 type batches, on the caller's thread in front of a structural frame or a bepuhip_replan_begin)
+        size_t perm_words = 0;
+        for (auto& tb : c->tbs) if (!tb.perm.empty() && tb.device_extent() > 0) perm_words += tb.perm.size();
+        int* d_perms = nullptr;
+        if (perm_words > 0) {
+            { const int32_t st = staging_reserve(c, perm_words * 4); if (st != BEPUHIP_OK) return st; }
+            int32_t* staged = (int32_t*)c->h_staging;
+            size_t at = 0;
+            for (auto& tb : c->tbs) if (!tb.perm.empty() && tb.device_extent() > 0) { memcpy(staged + at, tb.perm.data(), tb.perm.size() * 4); at += tb.perm.size(); }
+            HIP_TRY(hipMalloc((void**)&d_perms, perm_words * 4));
+            HIP_TRY(hipMemcpyAsync(d_perms, staged, perm_words * 4, hipMemcpyHostToDevice, c->stream));
         }
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        hipFree(slab);
-        slab = fresh;
+        for (int k = 0; k < 2; ++k) {
+            uint32_t*& slab = k == 0 ? c->d_slab : c->d_slab0;
+            if (!slab || c->slab_words == 0) continue;
+            uint32_t* fresh = nullptr;
+            HIP_TRY(hipMalloc((void**)&fresh, c->slab_words * 4));
+            HIP_TRY(hipMemcpyAsync(fresh, slab, c->slab_words * 4, hipMemcpyDeviceToDevice, c->stream));
+            size_t at = 0;
+            for (auto& tb : c->tbs) {
+                const int extent = tb.device_extent();
+                if (tb.perm.empty() || extent == 0) continue;
+                const size_t offs[3] = {tb.refs_off, tb.prestep_off, tb.accum_off};
+                const int rows[3] = {tb.info.bodies, tb.info.prestep, tb.info.impulse};
+                for (int r = 0; r < 3; ++r)
+                    if (rows[r] > 0)
+                        hipLaunchKernelGGL(unpermute_rows_kernel, dim3((extent + 255) / 256), dim3(256), 0, c->stream, (const unsigned*)(slab + offs[r]), (unsigned*)(fresh + offs[r]), (const int*)(d_perms + at),
+                                           extent, tb.stride, rows[r]);
+                at += tb.perm.size();
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            hipFree(slab);
+            slab = fresh;
+        }
+        if (d_perms) hipFree(d_perms);
     }
     for (auto& tb : c->tbs) {
         tb.perm.clear(); tb.inv.clear();
