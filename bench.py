@@ -45,6 +45,15 @@ def cpu_quota():
     return None, None
 
 
+def specialise(solver):
+    """Setup, untimed: the island kernel compiled for exactly the scene's constraint types (bepuhip_specialise_units; the units of the BASELINE.json scenes are prebuilt by
+    __graft_entry__.build() into csrc/units/ and load in milliseconds, anything else is a 40-60 s hipcc run on a thread of the library — waited for here, like any JIT
+    warm-up). BENCH_SPECIALISE=0 keeps the prebuilt families. Returns the state (2 = loaded)."""
+    if os.environ.get("BENCH_SPECIALISE", "1") == "0":
+        return -1
+    return solver.specialise_units(wait=True)
+
+
 def compact_line(out, full_path):
     """The ONE line the driver keeps (its record holds an 8 KB tail): every number, none of the prose. The long form — notes, methods, thread curves, per-size
     details — goes to `full_path`. Headline keys first; pile and crowd ride inside `roofline` as well so that a cut tail still shows them (VERDICT r4 next #9)."""
@@ -274,6 +283,7 @@ def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, s
     t0 = time.perf_counter()
     solver.upload(scene)
     upload_ms = 1e3 * (time.perf_counter() - t0)
+    unit_state = specialise(solver)
     for _ in range(100):
         solver.solve(1 / 60, sd, cb, asynchronous=True)
     solver.reset_state()
@@ -288,6 +298,7 @@ def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, s
     solver.sync()
     ms = 1e3 * (time.perf_counter() - t0) / steps
     finite = bool(np.isfinite(solver.get_bodies(scene.body_count)).all())
+    solver_family = solver.kernel_family()
     clustered = bool(solver.cluster_cycles().size)
     solver.close()
     its = sd.iterations()
@@ -305,7 +316,7 @@ def connected_scene_leg(name: str, scene_key: str, ragdolls: int, device: int, s
             "roofline": hbm_roofline("cluster_kernel<...,SHARED> (whole step in one launch)" if clustered else "whole step (launch-per-batch)", 1e3 * ms if clustered else 1e3 * ms,
                                      traffic, step_bytes, compulsory_stream_bytes(scene, sd) if clustered else None, traffic_detail=detail, working_set_bytes=working_set_bytes(scene),
                                      launch_time_basis="wall time per step (one launch per step)" if clustered else f"whole step, {launches} launches"),
-            "upload_ms": upload_ms, "finite": finite}
+            "upload_ms": upload_ms, "finite": finite, "kernel_family": solver_family, "unit_state": unit_state}
 
 
 def working_set_bytes(scene) -> int:
@@ -338,6 +349,7 @@ def scale_sweep_leg(args, device: int, base_ragdolls: int, factors=(1, 2, 4, 8),
         t0 = time.perf_counter()
         solver.upload(scene)
         upload_ms = 1e3 * (time.perf_counter() - t0)
+        specialise(solver)
         for _ in range(300):  # the headline's pre-warm (clocks, launch policy): the sweep's 1x point is the headline's scene and has to agree with it
             solver.solve(1 / 60, sd, cb, asynchronous=True)
         solver.reset_state()
@@ -447,6 +459,7 @@ def widened_types_leg(ragdolls: int, device: int, steps: int = 100):
     cb = PoseIntegratorCallbacks()
     solver = HipSolver(device=device, exclusive_device=True)
     solver.upload(scene)
+    specialise(solver)
     for _ in range(60):
         solver.solve(1 / 60, sd, cb, asynchronous=True)
     solver.reset_state()
@@ -1121,6 +1134,7 @@ def main():
     dt = 1.0 / 60.0
     solver = HipSolver(device=local_rank, use_graph=not args.no_graph)
     solver.upload(scene)  # inputs resident in HBM before the timed region starts
+    unit_state = specialise(solver)  # (setup: the island kernel for exactly this scene's twelve constraint types, prebuilt into csrc/units/)
     per_step_iterations = scene.constraint_count * int((1 + sd.iterations()).sum())
     # Part of the setup, disclosed in config.device_prewarm: the shader clock of an idle MI355X takes tens of milliseconds of load to reach its sustained
     # value (2.0 -> 2.2 GHz here). Run the same solve for a while, then restore the uploaded state device-to-device, so that the W warm-up steps and the K
@@ -1155,6 +1169,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     finite = bool(np.isfinite(solver.get_bodies(scene.body_count)).all())
+    kernel_family = solver.kernel_family()
 
     # ---- roofline of the dominant kernel: instrumented pass, HIP events on the solver's own stream around every launch ----
     roofline = None
@@ -1275,6 +1290,8 @@ def main():
                                    ("launch-per-batch" + ("" if args.no_graph else ", hipGraph replay")),
                        "row_policy": row_policy and f"{row_policy}, picked from the timings of the first fifteen solves after the upload (all candidates bit-identical; DESIGN.md 5)",
                        "device_prewarm": f"{prewarm_steps} untimed solves during setup, uploaded state restored before the {args.warmup} warm-up steps",
+                       "kernel_family": {-1: "none (launch-per-batch)", 0: "contacts family (8 types)", 1: "hot family (16 types)", 2: "wide family (44 types)",
+                                         3: "a unit compiled for exactly the scene's constraint types (bepuhip_specialise_units; prebuilt by build() into csrc/units/)"}.get(kernel_family, str(kernel_family)),
                        "finite": finite},
             "roofline": roofline, "cpu_baseline": baseline, "connected_scenes": connected, "scale_sweep": sweep, "widened_types": widened, "boundary": boundary, "lattice": lattice_report,
             "lattice_device_group": lattice_group, "self_checks": self_checks,

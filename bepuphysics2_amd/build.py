@@ -125,6 +125,42 @@ def build_host(force: bool = False) -> str:
     return out
 
 
+# Units of the island kernel for the exact type sets of the BASELINE.json scenes (bepu_unit_cache.h): compiled by the library's own bepuhip_prebuild_unit into
+# csrc/units/, where a context that asks for its unit (bepuhip_specialise_units) finds it without a compiler run. (type mask, threads budget, split plan, what it is)
+BASELINE_UNITS = [
+    (0xC0004E4000F8, 1024, 0, "configs[2] / [3]: the ragdoll tube (12 of the 16 hot types), whole-island plans"),
+    (0xF8, 512, 1, "configs[1]: the 100k-box pile (Contact1-4 two-body + Contact4 one-body), split plan at eight waves"),
+    (0x20C204FFC000FF, 1024, 0, "bench.py's widened_types leg: the sixteen hot types + seven widened joint types, whole-island plans"),
+]
+
+
+def build_units(jobs: int = 0) -> list:
+    """The BASELINE_UNITS, in parallel (a unit is a 40-60 s hipcc run; found in the cache when the sources have not changed). Objects of other source states are removed."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+    lib = ctypes.CDLL(os.path.join(_HERE, "csrc", "libbepuhip.so"))
+    lib.bepuhip_prebuild_unit.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]
+    lib.bepuhip_last_error.restype = ctypes.c_char_p
+
+    def one(unit):
+        mask, budget, split, what = unit
+        path = ctypes.create_string_buffer(1024)
+        status = lib.bepuhip_prebuild_unit(mask, budget, split, path, 1024)
+        if status != 0:
+            raise RuntimeError(f"unit for {what}: {lib.bepuhip_last_error().decode()}")
+        return path.value.decode()
+
+    with ThreadPoolExecutor(max_workers=jobs or len(BASELINE_UNITS)) as pool:
+        paths = list(pool.map(one, BASELINE_UNITS))
+    units_dir = os.path.join(_HERE, "csrc", "units")
+    if os.path.isdir(units_dir) and paths:
+        current = os.path.basename(paths[0]).split("_")[1]  # unit_<sources hash>_m<mask>_t<budget>[s].so
+        for name in os.listdir(units_dir):
+            if name.startswith("unit_") and name.split("_")[1] != current:
+                os.remove(os.path.join(units_dir, name))
+    return paths
+
+
 def build_oracle() -> None:
     """Compile oracle/'s C++ restatement (test infrastructure; building the checker is not using it)."""
     subprocess.check_call(["make", "-s"], cwd=os.path.join(REPO, "oracle"))
@@ -132,5 +168,6 @@ def build_oracle() -> None:
 
 def build_all(force: bool = False) -> None:
     build_hip(force)
+    build_units()
     build_host(force)
     build_oracle()

@@ -56,6 +56,15 @@ constexpr bool kRowsNonTemporal = BEPU_VARIANT_NT != 0;  // one- and two-body co
 // eight hot joint types along: code it never executes, in an instruction cache it does not fit, under a register budget the joints set. The contacts family carries the
 // eight manifolds (typed and merged items) and nothing else; the launcher picks it when no other type id is present (bepu_host_state.h, cluster_kernel_variant).
 constexpr bool kContactsOnly = BEPU_VARIANT_CONTACTS != 0;
+#ifndef BEPU_VARIANT_TYPE_MASK
+#define BEPU_VARIANT_TYPE_MASK 0xFFFFFFFFFFFFFFFFull
+#endif
+// Per translation unit (round 6, last session): bit t set = the unit carries the code of constraint type id t (all of its family by default). A unit compiled for the exact
+// type set of a scene — bepuhip_specialise_units: hipcc at run time, in the background, cached on disk — differs from its family's unit only in the switch cases it leaves
+// out: same bits by construction. Why bother: the headline scene (sixteen hot types) runs 9 % slower on the all-44 unit than on the hot one (0.1697 against 0.1555 ms,
+// profiles/r06_s22_ab_family_headline.txt) — the extra types' code costs the shared types registers and scheduling even when it never runs.
+constexpr unsigned long long kTypeMask = BEPU_VARIANT_TYPE_MASK;
+constexpr bool type_compiled(int id) { return id >= 0 && id < 64 && ((kTypeMask >> id) & 1ull) != 0; }
 
 typedef __attribute__((address_space(1))) float gfloat;  // global
 typedef __attribute__((address_space(1))) int gint;
@@ -983,7 +992,7 @@ using DC1T = Contact<1, true>; using DC2T = Contact<2, true>; using DC3T = Conta
 template <int STAGE, bool TRACE, bool WIDE, bool SHARED>
 __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const ClusterItem* it, const ItemHeader& h, int k, int lane, unsigned epoch,
                                                  unsigned* __restrict__ slab, float dt, float inv_dt, ItemStamps& stamps) {
-#define BEPU_CASE(ID, F) case ID: run_cluster_constraint<F, STAGE, TRACE, SHARED>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps); break;
+#define BEPU_CASE(ID, F) case ID: if constexpr (type_compiled(ID)) run_cluster_constraint<F, STAGE, TRACE, SHARED>(sh, it, h, k, lane, epoch, slab, dt, inv_dt, stamps); break;
     switch (h.type_id) {
         BEPU_CASE(kContact1OneBody, DC1O) BEPU_CASE(kContact2OneBody, DC2O) BEPU_CASE(kContact3OneBody, DC3O) BEPU_CASE(kContact4OneBody, DC4O)
         BEPU_CASE(kContact1, DC1T) BEPU_CASE(kContact2, DC2T) BEPU_CASE(kContact3, DC3T) BEPU_CASE(kContact4, DC4T)
@@ -1003,7 +1012,7 @@ __device__ __forceinline__ void run_cluster_item(const ClusterShared& sh, const 
                         if constexpr (WIDE) {  // SURVEY 8(f) types live in a second kernel variant: scenes made of the sixteen hot-path types keep the leaner one
                             switch (h.type_id) {
                                 BD_WIDENED_JOINT_TYPES(BEPU_CASE)
-#define BEPU_CASE_MANY(ID, F) case ID: run_cluster_constraint_many<F, STAGE, SHARED>(sh, it, h, k, lane, epoch, slab, dt, inv_dt); break;
+#define BEPU_CASE_MANY(ID, F) case ID: if constexpr (type_compiled(ID)) run_cluster_constraint_many<F, STAGE, SHARED>(sh, it, h, k, lane, epoch, slab, dt, inv_dt); break;
                                 BD_MANY_BODY_TYPES(BEPU_CASE_MANY)
 #undef BEPU_CASE_MANY
                                 default: break;

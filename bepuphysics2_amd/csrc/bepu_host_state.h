@@ -46,7 +46,7 @@ static const void* cluster_pass_kernel(bool wide, bool shared) {  // (for the de
 // Type-set families (round 6): kFamilyContacts = nothing but convex contact manifolds (type ids 0-7), kFamilyHot = SURVEY 8(a)'s sixteen, kFamilyWide = all 44. A family
 // that has no unit for a (threads, policy, mode) combination runs the next larger family's: same bits by construction (a unit differs from its superset only in the
 // switch cases it leaves out), asserted by tests/test_gpu_type_families.py.
-enum { kFamilyContacts = 0, kFamilyHot = 1, kFamilyWide = 2 };
+enum { kFamilyContacts = 0, kFamilyHot = 1, kFamilyWide = 2, kFamilySpecial = 3 };
 static bool contacts_family_enabled() { const char* v = getenv("BEPUHIP_CONTACTS_FAMILY"); return v == nullptr || atoi(v) != 0; }  // (developer switch, read per launch: tools/ab_scene.py compares the families on one box)
 static const void* contacts_kernel_variant(int threads, bool trace, bool shared) {
     if (shared && threads > 512 && threads <= 768) return bepu_cluster_kernel_contacts_768s(trace);
@@ -162,6 +162,7 @@ struct GraphKey {
 };
 
 struct ReplanJob;  // bepuhip.hip
+struct SpecialUnit;  // bepu_unit_cache.h
 struct bepuhip_ctx {
     int device = 0, W = 8, flags = 0;
     ReplanJob* replan_job = nullptr;  // bepuhip_replan_begin ... _commit: the planning thread, its shadow of the type batches, the log of structural calls since
@@ -287,6 +288,12 @@ struct bepuhip_ctx {
     unsigned* d_shared_info = nullptr;
     size_t shared_bodies = 0;         // table length (bodies)
     unsigned shared_epoch = 0;        // event numbers of the next step start here (SharedTables.base): the records are cleared once, not per step
+    unsigned long long type_mask = 0;  // bit t: a type batch of constraint type id t has been uploaded or added (never cleared by removals: a superset of the types present)
+    SpecialUnit* special_unit = nullptr;  // bepuhip_specialise_units: the cluster_kernel unit compiled for exactly `special_mask` / `special_budget` / `special_shared` (bepu_unit_cache.h)
+    unsigned long long special_mask = 0;
+    int special_budget = 0;
+    bool special_shared = false;
+    bool specialise_auto = false;     // BEPUHIP_SPECIALISE=1 (or bepuhip_specialise_units once): every plan asks for its unit; launches use it once it is loaded
     bool has_widened_types = false;  // any type outside SURVEY 8(a)'s sixteen: selects the wider cluster_kernel variant
     int last_kernel_family = -1;     // bepuhip_get_kernel_family: the family of the last island launch
     bool has_joint_types = false;    // any type that is not a convex contact manifold (type id > 7): without one, the contacts family's units run the scene (round 6)

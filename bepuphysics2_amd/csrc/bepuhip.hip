@@ -32,6 +32,9 @@
 #include <type_traits>
 #include <unordered_map>
 #include <vector>
+#include <atomic>
+#include <memory>
+#include <thread>
 
 #include <rccl/rccl.h>  // types and enums only: the library is opened at run time (bepuhip_comm_*), the solver itself does not depend on it
 
@@ -57,6 +60,7 @@ using namespace bd;
 #include "bepu_host_state.h"
 #include "bepu_cluster_plan.h"
 #include "bepu_soft_updates.h"
+#include "bepu_unit_cache.h"
 
 #include <atomic>
 #include <memory>
@@ -124,6 +128,7 @@ int32_t bepuhip_create(const bepuhip_config* config, bepuhip_ctx** out_ctx) {
     c->device = config->device_ordinal;
     c->W = config->bundle_width;
     c->flags = config->flags;
+    c->specialise_auto = env_int("BEPUHIP_SPECIALISE", 0) != 0;
     const int32_t st = create_device_objects(c);
     if (c->device < kMaxCountedDevices) g_live_contexts[c->device].fetch_add(1);
     if (st != BEPUHIP_OK) { bepuhip_destroy(c); return st; }  // the message of the failing call stays in bepuhip_last_error
@@ -284,7 +289,7 @@ int32_t bepuhip_begin_constraints(bepuhip_ctx* c, int32_t batch_count, int32_t f
     c->batch_count = batch_count;
     c->fallback_threshold = fallback_batch_threshold;
     c->has_fallback = batch_count > fallback_batch_threshold;  // Batches[FallbackBatchThreshold] is the sequential fallback batch
-    c->has_widened_types = false; c->has_joint_types = false; c->last_kernel_family = -1;
+    c->has_widened_types = false; c->has_joint_types = false; c->last_kernel_family = -1; c->type_mask = 0;
     c->building = true;
     for (auto& chunk : c->raw_chunks) chunk.used = 0;
     return BEPUHIP_OK;
@@ -402,7 +407,7 @@ int32_t bepuhip_set_type_batch(bepuhip_ctx* c, int32_t batch_index, int32_t type
         }
     }
     if (fallback_batch) { tb.occupied.resize((size_t)count); for (int i = 0; i < count; ++i) tb.occupied[i] = tb.refs_soa[i] != -1; }  // (structural updates of the fallback batch keep it current)
-    c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
+    c->has_widened_types = c->has_widened_types || is_widened_type(type_id); if (count > 0) c->type_mask |= 1ull << (type_id & 63);
     c->has_joint_types = c->has_joint_types || type_id > kContact4;
     c->referenced_bodies = std::max(c->referenced_bodies, highest_reference + 1);  // checked against the body count at solve time (validate_solve)
     c->total_constraints += live;
@@ -820,11 +825,12 @@ static int32_t snapshot_type_batches(bepuhip_ctx* c, const uint32_t* slab, const
 // What begin_constraints / set_type_batch would have counted for these type batches.
 static void adopt_type_batches(bepuhip_ctx* c, std::vector<HostTypeBatch>&& fresh, int batch_count, bool has_fallback) {
     c->batch_count = batch_count; c->has_fallback = has_fallback;
-    c->has_widened_types = false; c->has_joint_types = false; c->last_kernel_family = -1;
+    c->has_widened_types = false; c->has_joint_types = false; c->last_kernel_family = -1; c->type_mask = 0;
     c->referenced_bodies = 0; c->total_constraints = 0;
     for (auto& tb : fresh) {
         c->has_widened_types = c->has_widened_types || is_widened_type(tb.type_id);
         c->has_joint_types = c->has_joint_types || tb.type_id > kContact4;
+        c->type_mask |= 1ull << (tb.type_id & 63);
         for (int32_t r : tb.refs_soa) if (r >= 0) c->referenced_bodies = std::max(c->referenced_bodies, (r & kRefMask) + 1);
         if (has_fallback && tb.batch == c->fallback_threshold) { for (int i = 0; i < tb.count; ++i) c->total_constraints += tb.refs_soa[i] != -1; }
         else c->total_constraints += tb.count;
@@ -1056,6 +1062,37 @@ int32_t bepuhip_get_schedule(bepuhip_ctx* c, int32_t* schedule_out) {
 int32_t bepuhip_get_kernel_family(bepuhip_ctx* c, int32_t* family_out) {
     if (!c || !family_out) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
     *family_out = c->last_kernel_family;
+    return BEPUHIP_OK;
+}
+
+static UnitKey special_key(const bepuhip_ctx* c, int threads);
+static void special_request(bepuhip_ctx* c, const UnitKey& key);
+static int island_launch_threads(const bepuhip_ctx* c, bool conserving);
+// The island kernel compiled for exactly this context's constraint types (include/bepuhip.h; bepu_unit_cache.h).
+int32_t bepuhip_specialise_units(bepuhip_ctx* c, int32_t wait, int32_t* state_out) {
+    if (state_out) *state_out = kUnitUnavailable;
+    if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
+    if (c->building) return fail(BEPUHIP_E_STATE, "specialise_units between begin_constraints and end_constraints");
+    c->specialise_auto = true;  // from here on every plan of this context asks for its unit
+    if (!c->built || !c->clusters_enabled || c->type_mask == 0) return BEPUHIP_OK;  // nothing to specialise yet (or the launch-per-batch schedule, whose kernels are not per family)
+    HIP_TRY(hipSetDevice(c->device));
+    special_request(c, special_key(c, island_launch_threads(c, false)));
+    if (wait) unit_wait(c->special_unit);
+    const int state = c->special_unit->state.load(std::memory_order_acquire);
+    if (state_out) *state_out = state;
+    if (wait && state == kUnitFailed) return fail(BEPUHIP_E_DEVICE, "specialise_units: " + c->special_unit->why);
+    return BEPUHIP_OK;
+}
+
+// The same object without a context or a device: found in the unit cache or compiled into it, now, on the caller's thread (bepuphysics2_amd/build.py prebuilds the
+// units of the BASELINE.json scenes with it, so that they travel with the tree).
+int32_t bepuhip_prebuild_unit(uint64_t type_mask, int32_t threads_budget, int32_t split_plan, char* path_out, int32_t path_capacity) {
+    if (type_mask == 0 || (threads_budget != 1024 && threads_budget != 768 && threads_budget != 512)) return fail(BEPUHIP_E_INVALID_ARGUMENT, "prebuild_unit: an empty type mask, or a budget other than 1024 / 768 / 512 threads");
+    for (int t = 0; t < 64; ++t) { TypeInfoH info; if (((type_mask >> t) & 1ull) && !type_info(t, info)) return fail(BEPUHIP_E_UNSUPPORTED, "prebuild_unit: unknown constraint type id " + std::to_string(t)); }
+    std::string why;
+    const std::string path = unit_obtain(UnitKey{(unsigned long long)type_mask, threads_budget, split_plan != 0}, why);
+    if (path.empty()) return fail(BEPUHIP_E_UNSUPPORTED, "prebuild_unit: " + why);
+    if (path_out && path_capacity > 0) { strncpy(path_out, path.c_str(), (size_t)path_capacity - 1); path_out[path_capacity - 1] = 0; }
     return BEPUHIP_OK;
 }
 
@@ -1329,6 +1366,20 @@ static bool island_schedule_applies(const bepuhip_ctx* c, int substeps, const be
 // CHAIN of such launches when it has more substeps than a launch's arguments carry (kMaxClusterSubsteps), or when the host wants to be called between substeps
 // (bepuhip_solve_with_substep_events: one substep per launch). Between two launches of a chain the bodies are in HBM with the pose of the last substep run and their
 // velocities; "first substep of the step" rules and the trailing pose integration follow the STEP (ClusterParams.substep_base / final_launch).
+// The specialised unit a launch of `threads` threads per cluster would use: the context's type set, the register budget of the workgroup size, the plan kind.
+static UnitKey special_key(const bepuhip_ctx* c, int threads) {
+    const int budget = c->clusters_shared ? (threads <= 512 ? 512 : (threads <= 768 ? 768 : 1024)) : cluster_variant_threads(threads);
+    return UnitKey{c->type_mask, budget, c->clusters_shared};
+}
+static void special_request(bepuhip_ctx* c, const UnitKey& key) {
+    c->special_unit = unit_request(key, c->device, kLdsBudgetBytes);
+    c->special_mask = key.mask; c->special_budget = key.budget; c->special_shared = key.shared;
+}
+static int island_launch_threads(const bepuhip_ctx* c, bool conserving) {
+    int threads = cluster_threads(c);
+    if (c->split_twelve_waves && c->clusters_shared && threads == kSplitClusterThreads && !conserving && !c->has_widened_types) threads = 768;
+    return threads;
+}
 static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int base, int count, const int32_t* iterations, const bepuhip_integrator* in, const StepParams& sp) {
     const float substep_dt = dt / substeps;
     const size_t lds_bytes = cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared);
@@ -1347,13 +1398,12 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
         // Scenes with SURVEY 8(f) types take the 512-thread build: at 128 VGPRs per wave the widened types spill hundreds of registers.
         // (the widened variant too: its 1024-thread build spills 700 VGPRs and is still the faster one — 0.222 against 0.325 ms on the bench graph with widened joints
         // on the pool's slow class of box, 0.195 against 0.193 on the fast one, profiles/r03_s13_widened_slowbox.txt: sixteen waves hide what the scratch traffic costs)
-        int threads = cluster_threads(c);
         const bool conserving = in->angular_integration_mode != 0;
+        int threads = island_launch_threads(c, conserving);
         // Split plans with many work items per cluster (the ragdoll crowd: 77 - 96 per pass on eight waves, every wave busy, no item waiting for more than its flag's
         // round trip: profiles/r05_s20_crowd_trace.txt) run twelve waves per cluster: the 768-thread unit has 168 VGPRs per wave and, since the manifolds' tails were
         // looked at ("spills on the chain"), no reload in a joint's tail — crowd 0.3784 -> 0.3490 ms same box. Plans with few, heavy items (the pile:
         // 22 - 33 per pass, on its chain of batch steps) lose 5 % there and keep eight waves. Hot types, nonconserving mode: the units that exist at 768 threads.
-        if (c->split_twelve_waves && c->clusters_shared && threads == kSplitClusterThreads && !conserving && !c->has_widened_types) threads = 768;
         const size_t launch_lds = lds_bytes;
         // One launch per step: workgroups [0, clusters) run the islands, the next `body_blocks` integrate the bodies no cluster owns, the last one the
         // constrained kinematic bodies (the per-substep kinematic prepass and the final pass, folded in).
@@ -1402,8 +1452,19 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
         cp.code_touch = candidate == 2 ? (c->clusters_shared ? 2 : 1) : 0;
         if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(kCodeTouchMaxSpans, forced);  // never beyond the padding behind the unit's kernels
         cp.jitter = debug_jitter_seed();
-        const void* fn = cluster_kernel_variant(threads, tr, c->has_widened_types, c->clusters_shared, nt, conserving, !c->has_joint_types);  // the register budget that matches the workgroup size, the type set that matches the scene
-        c->last_kernel_family = c->has_widened_types ? kFamilyWide : ((!c->has_joint_types && contacts_family_enabled() && !nt && !conserving && fn == contacts_kernel_variant(threads, tr, c->clusters_shared)) ? kFamilyContacts : kFamilyHot);
+        // (BEPUHIP_FORCE_WIDE_FAMILY=1, a developer switch: the all-44 unit for a scene that does not need it — what a family's extra code costs the types both carry, tools/ab_scene.py)
+        const bool wide_family = c->has_widened_types || env_int("BEPUHIP_FORCE_WIDE_FAMILY", 0) != 0;
+        const void* fn = cluster_kernel_variant(threads, tr, wide_family, c->clusters_shared, nt, conserving, !c->has_joint_types && !wide_family);  // the register budget that matches the workgroup size, the type set that matches the scene
+        c->last_kernel_family = wide_family ? kFamilyWide : ((!c->has_joint_types && contacts_family_enabled() && !nt && !conserving && fn == contacts_kernel_variant(threads, tr, c->clusters_shared)) ? kFamilyContacts : kFamilyHot);
+        // A unit compiled for exactly this scene's type set (bepu_unit_cache.h), once it is loaded: the plain-row kernel of the same register budget, nothing else differs.
+        if (!nt && !conserving && !env_int("BEPUHIP_FORCE_WIDE_FAMILY", 0)) {
+            const UnitKey want = special_key(c, threads);
+            if (c->specialise_auto && (!c->special_unit || c->special_mask != want.mask || c->special_budget != want.budget || c->special_shared != want.shared)) special_request(c, want);
+            if (c->special_unit && c->special_mask == want.mask && c->special_budget == want.budget && c->special_shared == want.shared && c->special_unit->state.load(std::memory_order_acquire) == kUnitLoaded) {
+                fn = tr ? c->special_unit->traced : c->special_unit->kernel;
+                c->last_kernel_family = kFamilySpecial;
+            }
+        }
         if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
         const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
         bool launched = false;
@@ -2623,7 +2684,7 @@ static int32_t add_constraint_at_impl(bepuhip_ctx* c, int32_t batch, int32_t typ
             old.insert(old.begin() + pos, OldLayout{0, 0, 0, 0, 0});
             c->batch_count = std::max(c->batch_count, batch + 1);
             c->has_fallback = true;  // (Batches[FallbackBatchThreshold] exists from now on)
-            c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
+            c->has_widened_types = c->has_widened_types || is_widened_type(type_id); c->type_mask |= 1ull << (type_id & 63);
             c->has_joint_types = c->has_joint_types || type_id > kContact4;
             c->built = true;
         } else {
@@ -2687,7 +2748,7 @@ static int32_t add_constraint_impl(bepuhip_ctx* c, int32_t batch, int32_t type_i
             c->tbs.insert(c->tbs.begin() + pos, fresh);
             old.insert(old.begin() + pos, OldLayout{0, 0, 0, 0, 0});
             c->batch_count = std::max(c->batch_count, batch + 1);
-            c->has_widened_types = c->has_widened_types || is_widened_type(type_id);
+            c->has_widened_types = c->has_widened_types || is_widened_type(type_id); c->type_mask |= 1ull << (type_id & 63);
             c->has_joint_types = c->has_joint_types || type_id > kContact4;
             c->built = true;
         } else {

@@ -46,6 +46,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_get_owned_bodies", "bepuhip_get_owned_constraints", "bepuhip_sync_owned_bodies",
     "bepuhip_get_kernel_family", "bepuhip_add_constraint_at",
     "bepuhip_replan_begin", "bepuhip_replan_poll", "bepuhip_replan_commit", "bepuhip_replan_cancel",
+    "bepuhip_specialise_units", "bepuhip_prebuild_unit",
 ]
 
 
@@ -173,6 +174,8 @@ def load_library() -> C.CDLL:
     lib.bepuhip_replan_poll.argtypes = [vp, C.POINTER(i32)]
     lib.bepuhip_replan_commit.argtypes = [vp, i32, C.POINTER(i32)]
     lib.bepuhip_replan_cancel.argtypes = [vp]
+    lib.bepuhip_specialise_units.argtypes = [vp, i32, C.POINTER(i32)]
+    lib.bepuhip_prebuild_unit.argtypes = [C.c_uint64, i32, i32, C.c_char_p, i32]
     for name in EXPORTED_SYMBOLS:
         if name != "bepuhip_last_error":
             getattr(lib, name).restype = i32
@@ -519,10 +522,17 @@ class HipSolver:
         return int(n.value)
 
     def kernel_family(self) -> int:
-        """The type-set family of the last island launch: 0 contacts only, 1 the sixteen hot-path types, 2 all 44; -1 none yet (bepuhip_get_kernel_family)."""
+        """The type-set family of the last island launch: 0 contacts only, 1 the sixteen hot-path types, 2 all 44, 3 a unit compiled for the context's exact types; -1 none yet (bepuhip_get_kernel_family)."""
         n = C.c_int32()
         _check(self.lib, self.lib.bepuhip_get_kernel_family(self.ctx, C.byref(n)))
         return int(n.value)
+
+    def specialise_units(self, wait: bool = False) -> int:
+        """bepuhip_specialise_units: the island kernel compiled for exactly this context's constraint types (found in the unit cache, or compiled by hipcc on a thread of the
+        library). Returns 0 unavailable, 1 compiling, 2 loaded, 3 the compiler failed."""
+        state = C.c_int32(0)
+        _check(self.lib, self.lib.bepuhip_specialise_units(self.ctx, 1 if wait else 0, C.byref(state)))
+        return int(state.value)
 
     def replan(self):
         """A fresh plan for the constraints the device holds now (bepuhip_replan): values stay on the device, only the references are read back."""

@@ -353,10 +353,26 @@ int32_t bepuhip_get_constraint_count(bepuhip_ctx* ctx, int32_t batch_index, int3
  * on a split-island plan. An upload picks 1 or 2 when the scene allows it; structural updates the plan cannot absorb drop the context to 0 (see above). */
 int32_t bepuhip_get_schedule(bepuhip_ctx* ctx, int32_t* schedule_out);
 /* Which type-set family of the island kernel ran the context's LAST island launch (round 6): 0 the contacts family (nothing but convex contact manifolds, type ids 0-7:
- * box stacks and piles), 1 the sixteen hot-path types of SURVEY.md 8(a), 2 all 44 types; -1 when the context has not launched an island kernel yet (or runs the
+ * box stacks and piles), 1 the sixteen hot-path types of SURVEY.md 8(a), 2 all 44 types, 3 a unit compiled for exactly the context's types (bepuhip_specialise_units); -1 when the context has not launched an island kernel yet (or runs the
  * launch-per-batch schedule, whose kernels carry every type). The reference's counterpart is its per-type registration: a batch runs the TypeProcessors of the types it
  * holds and nothing else (BepuPhysics/DefaultTypes.cs:18-63). A family is picked per launch from the type ids present; results do not depend on it. */
 int32_t bepuhip_get_kernel_family(bepuhip_ctx* ctx, int32_t* family_out);
+/* The island kernel compiled for EXACTLY the constraint types this context holds (round 6; family 3 of bepuhip_get_kernel_family). A prebuilt family's unit carries the
+ * code of every type of the family, and code a scene never runs still costs the types it does run registers and scheduling: the all-44 unit at 1024 threads spills 681
+ * VGPRs where a unit for the sixteen hot types + seven joint types of the second set spills 43, and the headline scene is 9 % slower on the all-44 unit than on the hot
+ * one. bepuhip_specialise_units asks for the unit of the context's current plan: the library's own kernel sources (they ship next to the library) compiled by hipcc as a
+ * child process on a host thread of the library, with the type set as a compile-time mask, into a shared object in the unit cache ($BEPUHIP_UNIT_CACHE, else units/ next
+ * to the library, else ~/.cache/bepuhip/units; the file name carries a hash of the sources), loaded when it is ready. Until then — and on a host without hipcc and
+ * without a cached object — launches run the nearest prebuilt family; afterwards the plain-row launches of the context run the unit. Same bits by construction (a unit
+ * differs from its family's only in the switch cases it leaves out). `wait` != 0 blocks until the object is loaded or known to be unavailable (about 40 s for a unit
+ * that has to be compiled, milliseconds for a cached one). *state_out: 0 unavailable (no plan, no compiler, no sources), 1 compiling, 2 loaded, 3 the compiler failed.
+ * After the call every later plan of the context (uploads with other types, re-plans) asks for its unit by itself; BEPUHIP_SPECIALISE=1 in the environment does the same
+ * for every context from its creation. Reference counterpart: one TypeProcessor per registered type, a batch runs those of the types it holds and nothing else
+ * (BepuPhysics/DefaultTypes.cs:18-63, Solver.cs Register). */
+int32_t bepuhip_specialise_units(bepuhip_ctx* ctx, int32_t wait, int32_t* state_out);
+/* The same object without a context or a device, on the caller's thread: found in the unit cache or compiled into it now — for build scripts that ship the units of
+ * known scenes with the library (`type_mask`: bit t = constraint type id t; `threads_budget` 1024 for whole-island plans, 512 or 768 for split plans). */
+int32_t bepuhip_prebuild_unit(uint64_t type_mask, int32_t threads_budget, int32_t split_plan, char* path_out, int32_t path_capacity);
 /* Plans the constraints the device holds NOW afresh, as bepuhip_end_constraints would for the same type batches: for a context that structural updates have dropped to
  * schedule 0, or to give a plan that has been absorbing updates for a long time fresh reserves. The body references are read back (the only bytes that cross PCIe besides
  * the new plan's tables), the host plans, prestep data and accumulated impulses — of the working rows and of the snapshot bepuhip_reset_state returns to — move into the

@@ -90,3 +90,49 @@ def test_the_family_follows_structural_updates(hip_solver_factory):
     assert families[0][1] == 0 and families[1][1] == 0
     # with the joint: the hot family if the island plan absorbed the new type batch, none (-1) if the context went to the launch-per-batch schedule, whose kernels carry every type
     assert all((s == 0 and f == -1) or (s != 0 and f == 1) for s, f in families[2:]), families
+
+
+@pytest.mark.parametrize("plan", ["whole_islands", "split"])
+def test_a_unit_compiled_for_the_scenes_exact_types_runs_the_same_bits(hip_solver_factory, monkeypatch, tmp_path, plan):
+    """bepuhip_specialise_units (round 6): the island kernel compiled — by hipcc on this box, from the library's own sources, on a thread of the library —
+    for exactly the scene's types (two manifolds, BallSocket, and Weld and AngularServo of the widened set: the wide family's scene), cached in BEPUHIP_UNIT_CACHE. Before the
+    unit is there the scene runs the all-44 family (2), afterwards the unit (family 3): every frame bit-exact against the oracle either way, and both contexts end with the
+    same bits. A second context finds the object in the cache (no compiler run); another type set is another unit."""
+    monkeypatch.setenv("BEPUHIP_UNIT_CACHE", str(tmp_path))
+    types = [4, 7, 22, 31, 29]
+    if plan == "split":
+        monkeypatch.setenv("BEPUHIP_SPLIT_CLUSTERS", "14")
+        monkeypatch.setenv("BEPUHIP_FORCE_SPLIT", "64")
+        scene = small_scenes.random_graph_scene(41, 2500, 7000, types)
+    else:
+        scene = small_scenes.island_scene(42, islands=60, bodies_per_island=14, constraints_per_island=40, type_ids=types)
+    sd, cb = SolveDescription(2, 4), PoseIntegratorCallbacks()
+    ref = pu.run_oracle(scene, 1 / 60, sd, cb, frames=4, threads=4)
+    family = hip_solver_factory()
+    got_family = pu.run_hip(family, scene, 1 / 60, sd, cb, frames=4)
+    assert family.schedule() == (2 if plan == "split" else 1) and family.kernel_family() == 2
+    _exact(ref, got_family)
+    solver = hip_solver_factory()
+    work = scene.copy()
+    solver.upload(work, sd.fallback_batch_threshold)
+    solver.solve(1 / 60, sd, cb)  # the unit is not there yet: the family's
+    assert solver.kernel_family() == 2
+    assert solver.specialise_units(wait=True) == 2, "hipcc is part of the image: the unit compiles"
+    objects = sorted(p.name for p in tmp_path.iterdir() if p.suffix == ".so")
+    assert len(objects) == 1 and objects[0].endswith("t512s.so" if plan == "split" else "t1024.so"), objects
+    for _ in range(3):
+        solver.solve(1 / 60, sd, cb)
+    assert solver.kernel_family() == 3
+    solver.download(work)
+    _exact(ref, work)
+    assert np.array_equal(work.bodies.view(np.int32), got_family.bodies.view(np.int32))
+    again = hip_solver_factory()  # a second context: the cache has the object, and the registry of this process the loaded unit
+    assert again.specialise_units(wait=True) == 0, "nothing uploaded yet: nothing to specialise"
+    got_again = scene.copy()
+    again.upload(got_again, sd.fallback_batch_threshold)  # ... but the context asks by itself from now on
+    for _ in range(4):
+        again.solve(1 / 60, sd, cb)
+    assert again.specialise_units(wait=True) == 2 and again.kernel_family() in (2, 3)
+    again.download(got_again)
+    _exact(ref, got_again)
+    assert sorted(p.name for p in tmp_path.iterdir() if p.suffix == ".so") == objects

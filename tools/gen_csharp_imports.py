@@ -11,7 +11,7 @@ TYPES = [
     (r"^const bepuhip_structural_op\*$", "BepuHipStructuralOp*"), (r"^const bepuhip_velocity_model\*$", "BepuHipVelocityModel*"), (r"^const bepuhip_row_transfer\*$", "BepuHipRowTransfer*"),
     (r"^bepuhip_exchange_fn$", "delegate* unmanaged[Cdecl]<void*, int, int, int>"), (r"^bepuhip_substep_fn$", "delegate* unmanaged[Cdecl]<void*, int, void>"),
     (r"^(const )?int32_t\*$", "int*"), (r"^(const )?float\*$", "float*"), (r"^(const )?void\*$", "void*"), (r"^void\*\*$", "void**"), (r"^uint8_t\*$", "byte*"),
-    (r"^(const )?uint32_t\*$", "uint*"), (r"^uint64_t\*$", "ulong*"), (r"^int64_t\*$", "long*"), (r"^int32_t$", "int"), (r"^int64_t$", "long"), (r"^float$", "float"),
+    (r"^(const )?uint32_t\*$", "uint*"), (r"^uint64_t\*$", "ulong*"), (r"^int64_t\*$", "long*"), (r"^int32_t$", "int"), (r"^int64_t$", "long"), (r"^uint64_t$", "ulong"), (r"^char\*$", "byte*"), (r"^float$", "float"),
 ]
 
 
