@@ -129,6 +129,7 @@ def build_host(force: bool = False) -> str:
 # csrc/units/, where a context that asks for its unit (bepuhip_specialise_units) finds it without a compiler run. (type mask, threads budget, split plan, what it is)
 BASELINE_UNITS = [
     (0xC0004E4000F8, 1024, 0, "configs[2] / [3]: the ragdoll tube (12 of the 16 hot types), whole-island plans"),
+    (0xC0004E4000F8, 768, 1, "bench.py's connected ragdoll crowd: the same types on a split plan at twelve waves (no gain measured: prebuilt so that the bench's setup never waits for a compiler)"),
     (0xF8, 512, 1, "configs[1]: the 100k-box pile (Contact1-4 two-body + Contact4 one-body), split plan at eight waves"),
     (0x20C204FFC000FF, 1024, 0, "bench.py's widened_types leg: the sixteen hot types + seven widened joint types, whole-island plans"),
 ]

@@ -1457,7 +1457,8 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
         const void* fn = cluster_kernel_variant(threads, tr, wide_family, c->clusters_shared, nt, conserving, !c->has_joint_types && !wide_family);  // the register budget that matches the workgroup size, the type set that matches the scene
         c->last_kernel_family = wide_family ? kFamilyWide : ((!c->has_joint_types && contacts_family_enabled() && !nt && !conserving && fn == contacts_kernel_variant(threads, tr, c->clusters_shared)) ? kFamilyContacts : kFamilyHot);
         // A unit compiled for exactly this scene's type set (bepu_unit_cache.h), once it is loaded: the plain-row kernel of the same register budget, nothing else differs.
-        if (!nt && !conserving && !env_int("BEPUHIP_FORCE_WIDE_FAMILY", 0)) {
+        // (not with the code touch: that policy reads up to 32 KB ahead of a wave's PC as data and relies on the padding build.py verifies behind a prebuilt unit's kernels)
+        if (!nt && !conserving && cp.code_touch == 0 && !env_int("BEPUHIP_FORCE_WIDE_FAMILY", 0)) {
             const UnitKey want = special_key(c, threads);
             if (c->specialise_auto && (!c->special_unit || c->special_mask != want.mask || c->special_budget != want.budget || c->special_shared != want.shared)) special_request(c, want);
             if (c->special_unit && c->special_mask == want.mask && c->special_budget == want.budget && c->special_shared == want.shared && c->special_unit->state.load(std::memory_order_acquire) == kUnitLoaded) {
