@@ -14,9 +14,7 @@ const void* bepu_cluster_kernel_hot_1024n(bool trace);   // non-temporal row loa
 const void* bepu_cluster_kernel_wide_1024n(bool trace);
 const void* bepu_cluster_kernel_hot_512sn(bool trace);   // non-temporal row loads, split-island plans (512 threads)
 const void* bepu_cluster_kernel_wide_512sn(bool trace);
-const void* bepu_cluster_kernel_hot_1024s(bool trace);   // split-island plans (shared bodies)
-const void* bepu_cluster_kernel_wide_1024s(bool trace);
-const void* bepu_cluster_kernel_hot_512s(bool trace);
+const void* bepu_cluster_kernel_hot_512s(bool trace);    // split-island plans (shared bodies); the 1024-thread split units (372 / 3,437 spilled VGPRs, 1.3 MB: experiments only) are gone since round 6
 const void* bepu_cluster_kernel_wide_512s(bool trace);
 const void* bepu_cluster_kernel_hot_768s(bool trace);    // split-island plans at 768 threads (twelve waves, 168 VGPRs): plans with many work items per cluster (round 5)
 const void* bepu_cluster_kernel_hot_1024c(bool trace);   // the momentum-conserving angular modes compiled in: whole-island plans at 1024 threads ...
@@ -63,10 +61,7 @@ static const void* cluster_kernel_variant(int threads, bool trace, bool wide, bo
     if (nt && !trace && !shared && cluster_variant_threads(threads) == 1024) return wide ? bepu_cluster_kernel_wide_1024n(false) : bepu_cluster_kernel_hot_1024n(false);
     if (nt && !trace && shared && cluster_variant_threads(threads) == 512) return wide ? bepu_cluster_kernel_wide_512sn(false) : bepu_cluster_kernel_hot_512sn(false);
     if (shared && !wide && !nt && threads > 512 && threads <= 768) return bepu_cluster_kernel_hot_768s(trace);
-    if (shared) switch (cluster_variant_threads(threads)) {
-        case 1024: return wide ? bepu_cluster_kernel_wide_1024s(trace) : bepu_cluster_kernel_hot_1024s(trace);
-        default: return wide ? bepu_cluster_kernel_wide_512s(trace) : bepu_cluster_kernel_hot_512s(trace);
-    }
+    if (shared) return wide ? bepu_cluster_kernel_wide_512s(trace) : bepu_cluster_kernel_hot_512s(trace);  // (cluster_threads keeps a split plan's workgroups within what these are compiled for)
     switch (cluster_variant_threads(threads)) {
         case 1024: return wide ? bepu_cluster_kernel_wide_1024(trace) : bepu_cluster_kernel_hot_1024(trace);
         default: return wide ? bepu_cluster_kernel_wide_512(trace) : bepu_cluster_kernel_hot_512(trace);
