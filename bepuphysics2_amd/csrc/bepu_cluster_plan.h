@@ -1002,7 +1002,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     plan.split_visit = visit;
     // Every type batch's rows in their segmented order. Three steps so that one large type batch does not keep the other threads waiting: the order of every type
     // batch (a counting sort: cluster by cluster, private before shared, otherwise in the caller's order), the rows in chunks of slots, the swaps.
-    struct RowJob { std::vector<int32_t> refs, lrefs; std::vector<uint32_t> ranks; std::vector<float> pre, acc; int stride = 0; };
+    struct RowJob { std::vector<int32_t> refs, lrefs; std::vector<uint32_t> ranks; std::vector<float> pre, acc; int stride = 0; std::vector<int32_t> private_live; };
     std::vector<RowJob> row_jobs(c->tbs.size());
     const bool host_values = c->host_values;
     plan_parallel_for(c->tbs.size(), [&](size_t t) {
@@ -1033,6 +1033,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
             for (int i = 0; i < tb.count; ++i) tb.perm[(touches_shared[i] ? next_shared : next_private)[clc[i]]++] = i;
         }
         tb.inv.assign(tb.count, 0);
+        job.private_live = private_live;
         job.refs.assign((size_t)nb * job.stride, -1); job.lrefs.assign((size_t)nb * job.stride, kPlanDeadLref); job.ranks.assign((size_t)nb * job.stride, 0u);
         job.pre.assign(host_values ? (size_t)pf * job.stride : 0, 0.0f); job.acc.assign(host_values ? (size_t)imf * job.stride : 0, 0.0f);
     });
@@ -1078,6 +1079,7 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
     // descending lane count. A group's items sit next to each other in the item array, leader first (shape bits 24-25: members behind it; bit 26: a member), at the
     // place of the group's first item; everything else keeps its claim order. BEPUHIP_FUSE_ITEMS=0 plans without groups (for A/Bs on one box).
     const bool fuse_items = env_int("BEPUHIP_FUSE_ITEMS", 1) != 0;
+    const bool boundary_items = env_int("BEPUHIP_SPLIT_BOUNDARY_ITEMS", 0) != 0;
     struct ItemEntry { size_t t; int s0, count, fuse; };
     auto group_entries = [&](std::vector<ItemEntry>& entries) {
         std::vector<ItemEntry> out;
@@ -1129,7 +1131,12 @@ static void plan_split_clusters(bepuhip_ctx* c, ClusterPlan& plan, int universe)
         for (size_t t : visit) {
             const HostTypeBatch& tb = c->tbs[t];
             const int d = tb.seg_begin[cl], e = tb.seg_begin[cl + 1];
-            for (int s0 = d; s0 < e; s0 += 64) entries.push_back({t, s0, std::min(64, e - s0), 0});
+            // BEPUHIP_SPLIT_BOUNDARY_ITEMS=1 (an experiment of round 6): the segment's constraints on private bodies and the ones that touch a shared body in items of
+            // their own — an item waits for the slowest of its lanes, and a lane behind a record that another cluster has yet to publish holds up the sixty-three
+            // that only needed the LDS, and through them whatever comes next on THEIR bodies; more items per pass is what it costs.
+            const int boundary = boundary_items ? std::min(e, d + row_jobs[t].private_live[cl]) : d;
+            for (int s0 = d; s0 < boundary; s0 += 64) entries.push_back({t, s0, std::min(64, boundary - s0), 0});
+            for (int s0 = boundary; s0 < e; s0 += 64) entries.push_back({t, s0, std::min(64, e - s0), 0});
         }
         if (fuse_items) group_entries(entries);
         for (const ItemEntry& entry : entries) {
