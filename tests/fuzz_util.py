@@ -91,8 +91,17 @@ def run_device(p, scene, sd, env=None, jitter: int = 0):
     with environment(**switches):
         solver = HipSolver(use_clusters=p["use_clusters"], use_graph=p["use_graph"])
         try:
-            got = pu.run_hip(solver, scene, 1 / 60, sd, p["cb"], frames=p["frames"])
-            info = (solver.schedule(), solver.row_policy(), int(solver.cluster_cycles().size))
+            if os.environ.get("FUZZ_SPECIALISE") == "1":  # the scene on the unit compiled for exactly its types (bepuhip_specialise_units, waited for: seconds to a minute per new type set)
+                got = scene.copy()
+                solver.upload(got, sd.fallback_batch_threshold)
+                solver.specialise_units(wait=True)
+                for _ in range(p["frames"]):
+                    solver.solve(1 / 60, sd, p["cb"])
+                solver.download(got)
+                info = (solver.schedule(), solver.row_policy(), int(solver.cluster_cycles().size), solver.kernel_family())
+            else:
+                got = pu.run_hip(solver, scene, 1 / 60, sd, p["cb"], frames=p["frames"])
+                info = (solver.schedule(), solver.row_policy(), int(solver.cluster_cycles().size))
         finally:
             solver.close()
     return got, info

@@ -18,7 +18,7 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
 log = open(sys.argv[3], "a") if len(sys.argv) > 3 else None
 params = fu.device_scene_parameters(seed, 20000)
-n = bad = split = batch_path = refused = diverged = jittered = 0
+n = bad = split = batch_path = refused = diverged = jittered = special = 0
 for ordinal, p in enumerate(params):
     if time.time() >= t_end:
         break
@@ -26,7 +26,9 @@ for ordinal, p in enumerate(params):
     if log:
         log.write(f"ordinal {ordinal} jitter {jitter}: {fu.describe(p)}\n"); log.flush(); os.fsync(log.fileno())
     try:
-        verdict, (schedule, policy, clusters) = fu.check_device_scene(p, jitter=jitter)
+        verdict, info = fu.check_device_scene(p, jitter=jitter)
+        schedule, policy, clusters = info[:3]
+        special += len(info) > 3 and info[3] == 3  # FUZZ_SPECIALISE=1: the scene ran the unit compiled for exactly its types
     except UnsupportedError:  # round 2 refused a sequential fallback batch together with a momentum-conserving angular mode; nothing should be refused any more
         refused += 1
         continue
@@ -40,5 +42,5 @@ for ordinal, p in enumerate(params):
     if verdict == "mismatch":
         bad += 1
         print(f"MISMATCH seed {seed} ordinal {ordinal} jitter {jitter}: {fu.describe(p)} schedule/policy/clusters {(schedule, policy, clusters)}", flush=True)
-print(f"scenes {n} (split-island plans {split}, launch-per-batch {batch_path}, island schedule under jitter {jittered}, refused as UNSUPPORTED {refused}), "
+print((f"on units compiled for the scene's exact types {special}; " if os.environ.get("FUZZ_SPECIALISE") == "1" else "") + f"scenes {n} (split-island plans {split}, launch-per-batch {batch_path}, island schedule under jitter {jittered}, refused as UNSUPPORTED {refused}), "
       f"diverged in the oracle and not compared {diverged}, mismatches {bad}")
