@@ -41,6 +41,13 @@ def test_each_type_random_graph(hip_solver_factory, type_id):
     m = pu.compare_scenes(ref, got)
     _check(m)
     assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], m
+    # ... and against the SECOND reading directly (VERDICT r5 weak #1b: for 22 joint types oracle/'s constraint text is derived from the device's own, so device == oracle/
+    # pins the GPU arithmetic there, not the transcription; oracle/wide is transcribed from the C# alone, in the C#'s AOSOA shape)
+    import wide_ffi
+    second = scene.copy()
+    wide_ffi.solve(second, 1 / 60, sd, cb)
+    m = pu.compare_scenes(second, got)
+    assert m["bodies_bit_exact"] and m["impulses_bit_exact"] and m["prestep_bit_exact"], ("device vs oracle/wide", m)
 
 
 def test_mixed_types_multi_frame(hip_solver_factory):
