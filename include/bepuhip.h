@@ -397,6 +397,8 @@ int32_t bepuhip_replan(bepuhip_ctx* ctx);
  * One job per context at a time (STATE otherwise); not for members of a device group (UNSUPPORTED: they re-plan together with bepuhip_replan). No counterpart in the
  * reference (its constraint batches need no plan; the nearest thing is the deferred batch compression, BepuPhysics/BatchCompressor.cs:15-45 — analysis spread over
  * frames and "performed asynchronously ... hidden behind other stages", applied between frames: Simulation.cs:302-304). */
+/* Threads: the planning worker (and the compile worker of bepuhip_specialise_units) read the library's BEPUHIP_* developer switches with getenv like every other part of
+ * the library; a host that changes its environment (setenv / putenv) must not do so while such a worker may be running — the usual rule for getenv in a threaded process. */
 int32_t bepuhip_replan_begin(bepuhip_ctx* ctx);
 int32_t bepuhip_replan_poll(bepuhip_ctx* ctx, int32_t* state_out);
 int32_t bepuhip_replan_commit(bepuhip_ctx* ctx, int32_t wait, int32_t* committed_out);
