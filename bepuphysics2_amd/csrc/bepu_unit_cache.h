@@ -14,6 +14,8 @@
 #include <sys/wait.h>
 #include <unistd.h>
 #include <fcntl.h>
+#include <signal.h>
+#include <condition_variable>
 
 extern char** environ;
 
@@ -109,8 +111,22 @@ static std::vector<std::string> unit_compile_command(const UnitKey& key, const s
     argv.push_back("-o"); argv.push_back(out);
     return argv;
 }
+// At most BEPUHIP_UNIT_COMPILERS (default 2) compiler processes of this library at a time: a host that creates contexts for many type sets at once (a test suite, a
+// fuzzer with BEPUHIP_SPECIALISE=1) must not find dozens of hipcc runs — a gigabyte and a core each — beside its simulation.
+// The process is ending (atexit): compiler children are told to stop, workers do not load anything any more and are waited for — a worker that is still inside dlopen or
+// the HIP runtime while the runtime's own exit handlers run is a crash at exit.
+static std::atomic<bool> g_units_shutdown{false};
+static std::mutex g_unit_children_mutex;
+static std::vector<pid_t>& unit_children() { static auto* pids = new std::vector<pid_t>(); return *pids; }
+struct UnitCompilerSlots {
+    std::mutex m; std::condition_variable cv; int running = 0;
+    void enter() { std::unique_lock<std::mutex> lock(m); const int most = std::max(1, env_int("BEPUHIP_UNIT_COMPILERS", 2)); cv.wait(lock, [&] { return running < most; }); ++running; }
+    void leave() { { std::lock_guard<std::mutex> lock(m); --running; } cv.notify_one(); }
+};
+static UnitCompilerSlots& unit_compiler_slots() { static auto* slots = new UnitCompilerSlots(); return *slots; }
 // Runs the compiler as a child process (stdout / stderr into `log`); true when it exited with 0.
 static bool unit_run(const std::vector<std::string>& argv, const std::string& log) {
+    struct Slot { Slot() { unit_compiler_slots().enter(); } ~Slot() { unit_compiler_slots().leave(); } } slot;
     std::vector<char*> raw;
     for (auto& a : argv) raw.push_back(const_cast<char*>(a.c_str()));
     raw.push_back(nullptr);
@@ -119,12 +135,16 @@ static bool unit_run(const std::vector<std::string>& argv, const std::string& lo
     posix_spawn_file_actions_addopen(&actions, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     posix_spawn_file_actions_adddup2(&actions, 1, 2);
     pid_t pid = 0;
+    if (g_units_shutdown.load()) { posix_spawn_file_actions_destroy(&actions); return false; }
     const int rc = posix_spawn(&pid, raw[0], &actions, nullptr, raw.data(), environ);
     posix_spawn_file_actions_destroy(&actions);
     if (rc != 0) return false;
+    { std::lock_guard<std::mutex> lock(g_unit_children_mutex); unit_children().push_back(pid); }
+    if (g_units_shutdown.load()) kill(pid, SIGTERM);
     int status = 0;
     while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
-    return WIFEXITED(status) && WEXITSTATUS(status) == 0;
+    { std::lock_guard<std::mutex> lock(g_unit_children_mutex); auto& pids = unit_children(); pids.erase(std::remove(pids.begin(), pids.end(), pid), pids.end()); }
+    return WIFEXITED(status) && WEXITSTATUS(status) == 0 && !g_units_shutdown.load();
 }
 // The object of `key` as a file: found in one of the cache directories, or compiled into the first writable one. Empty + `why` when neither is possible.
 static std::string unit_obtain(const UnitKey& key, std::string& why, bool* compiled_now = nullptr) {
@@ -152,6 +172,17 @@ static SpecialUnit* unit_request(const UnitKey& key, int device, size_t lds_byte
     const std::string name = unit_file_name(key) + "@" + std::to_string(device);
     auto found = unit_registry().find(name);
     if (found != unit_registry().end()) return found->second;
+    static const bool at_exit_registered = [] {
+        atexit([] {
+            g_units_shutdown.store(true);
+            { std::lock_guard<std::mutex> lock(g_unit_children_mutex); for (pid_t pid : unit_children()) kill(pid, SIGTERM); }
+            std::vector<SpecialUnit*> units;
+            { std::lock_guard<std::mutex> lock(g_units_mutex); for (auto& kv : unit_registry()) units.push_back(kv.second); }
+            for (SpecialUnit* u : units) { std::lock_guard<std::mutex> lock(u->join_mutex); if (u->worker.joinable()) u->worker.join(); }
+        });
+        return true;
+    }();
+    (void)at_exit_registered;
     SpecialUnit* unit = new SpecialUnit();
     unit_registry()[name] = unit;
     unit->worker = std::thread([unit, key, device, lds_bytes] {
@@ -159,7 +190,8 @@ static SpecialUnit* unit_request(const UnitKey& key, int device, size_t lds_byte
         std::string why;
         const std::string path = unit_obtain(key, why, &unit->compiled_now);
         int state = kUnitFailed;
-        if (path.empty()) state = (why.find("hipcc failed") != std::string::npos) ? kUnitFailed : kUnitUnavailable;
+        if (g_units_shutdown.load()) { state = kUnitUnavailable; why = "the process is ending"; }
+        else if (path.empty()) state = (why.find("hipcc failed") != std::string::npos) ? kUnitFailed : kUnitUnavailable;
         else if (void* dl = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL)) {
             typedef const void* (*Entry)(bool);
             if (Entry entry = (Entry)dlsym(dl, "bepu_special_unit")) {

@@ -17,6 +17,7 @@ def plain_rows(monkeypatch):
     """The launch policy's first fifteen solves cycle through its candidates, and the non-temporal-rows candidate exists in the hot and wide families only (a contacts
     scene runs the hot unit for those launches: the next larger family, same bits): pinned to plain rows, so that every launch of these tests is the family under test."""
     monkeypatch.setenv("BEPUHIP_ROW_POLICY", "0")
+    monkeypatch.setenv("BEPUHIP_SPECIALISE", "0")  # (a suite run under BEPUHIP_SPECIALISE=1 would give every context of these tests its own unit: family 3 before the tests ask for it)
 
 
 def _exact(ref, got):
