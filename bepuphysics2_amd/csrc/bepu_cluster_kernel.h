@@ -1140,7 +1140,11 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.slot_body = slot_body_lds;
     sh.code_touch = cp.code_touch; sh.jitter = cp.jitter;
     sh.substep = 0; sh.angular_mode = cp.sp.angular_mode; sh.substep_dt = cp.sp.dt; sh.plane_count = cp.planes; sh.bodies = bodies;
-    sh.scratch_row = lds_address((const volatile lds_u32*)lds) + (unsigned)cluster_lds_core_bytes(cp.planes, ncap, max_items, SHARED);
+    // The slot -> body table in LDS: always on split plans; on whole-island plans when the launcher found the room (ClusterParams.slot_table_in_lds, round 6) — every
+    // integration phase and the write-back start from a body's slot entry, and read from global memory that is a full memory latency in front of each of them
+    // (profiles/r06_s36_*: the pose half of the integration takes 8 k clocks whether sixteen or eight waves run it).
+    const bool slot_table = SHARED || cp.slot_table_in_lds != 0;
+    sh.scratch_row = lds_address((const volatile lds_u32*)lds) + (unsigned)cluster_lds_core_bytes(cp.planes, ncap, max_items, slot_table);
     const ClusterDesc cd = clusters[blockIdx.x];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
@@ -1162,7 +1166,8 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     sh.item_count = cd.item_count;
     for (int j = tid; j <= cp.batch_count; j += blockDim.x) sh.lbib[j] = batch_item_begin[cd.batch_item_offset + j] - cd.item_begin;
     if (tid == 0) *sh.counter = 0;
-    if constexpr (SHARED) { for (int j = tid; j < cd.slot_count; j += blockDim.x) slot_body_lds[j] = slots[j]; }
+    if (slot_table) { for (int j = tid; j < cd.slot_count; j += blockDim.x) slot_body_lds[j] = slots[j]; }
+    auto slot_entry = [&](int j) { return slot_table ? slot_body_lds[j] : slots[j]; };
     __syncthreads();
     if (tid == 0 && tp.kin_count > 0) __hip_atomic_fetch_add(tp.staged, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // this cluster's copies of kinematic bodies are in LDS
 
@@ -1206,7 +1211,12 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     for (int s = 0; s < cp.substeps; ++s) {
         const int gs = cp.substep_base + s;  // the substep's index in the STEP (a chained step: this launch starts at substep_base); `s` counts this launch's substeps (records, events)
         if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(&sh.status[10], (unsigned)gs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (gs > 0) {  // Solver_Solve.cs:1427-1439: contact depths advance with the pre-integration velocities
+        // (trace builds: where the time between two sweeps goes — pass slot kClusterTracePasses - 16 + s holds, per wave, the clock at the top of the substep,
+        // behind the incremental contact update's barrier and behind the integration's barrier; tools/cluster_trace.py prints them)
+        unsigned long long* phase = (TRACE && trace && blockIdx.x == 0 && lane == 0 && s < 16 && nwaves * 4 <= cd.item_count * 8) ? trace + (size_t)(kClusterTracePasses - 16 + s) * cd.item_count * 8 + wave * 4 : nullptr;
+        if (phase) phase[0] = __builtin_readcyclecounter();
+        // Solver_Solve.cs:1427-1439: contact depths advance with the pre-integration velocities — the incremental update of the contact items, one item per wave at a time.
+        auto incremental_items = [&]() {
             for (int k = wave; k < cd.item_count; k += nwaves) {
                 const ClusterItem* it = sh.items + k;
                 const ItemHeader h = read_item(it);
@@ -1224,68 +1234,104 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
                 }
                 run_cluster_item<kStageIncremental, false, WIDE, SHARED>(sh, it, h, k, lane, 0u, slab, dt, inv_dt, stamps);
             }
-            __syncthreads();
-        }
+        };
         // Integration of every constrained body of the cluster (TypeProcessor.cs:1204-1283, PoseIntegrator.cs:451-535):
         // substep 0 velocity only, later substeps pose then velocity; world inverse inertia refreshed either way.
-        for (int j = tid; j < cd.slot_count; j += blockDim.x) {
-            const int g = slots[j];
-            if (g < 0) continue;
-            const bool ghost = SHARED && (g & kSlotGhost) != 0;  // another cluster owns the body; this one keeps its pose and world inertia current by the same arithmetic
-            float4* r = lds + j;
-            float4 q4 = r[0], p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
-            const bool home = SHARED && (g & kSlotSharedHome) != 0;
-            const int body = g & kSlotBodyMask;
-            unsigned applications = 0;  // shared bodies: applications per pass
-            if (home || ghost) applications = shared_tables.info[body] & 0xFFu;
-            if ((home || ghost) && s > 0) {  // the velocity the last substep ended with: in last substep's record once every application on the body has happened
-                const float lw = l4.w, aw = a4.w;
-                acquire_shared_one(shared_tables, status, body, (unsigned)s - 1u, shared_tables.base + (unsigned)s + applications * sh.passes, l4, a4, 9, j);
-                l4.w = lw; a4.w = aw;  // the record's fourth lanes carry the event number; the body's own padding stays what it was
-            }
-            Q ori = {q4.x, q4.y, q4.z, q4.w};
-            V3 pos = {p4.x, p4.y, p4.z};
-            BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
-            if (gs > 0) {
-                pos = add(pos, scale(vel.lin, dt));
-                ori = integrateOrientation(ori, vel.ang, dt * 0.5f);
-                r[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
-                r[ncap] = make_float4(pos.x, pos.y, pos.z, p4.w);
-            }
-            if ((unsigned)(g & ~(kSlotSharedHome | kSlotGhost)) < kDynamicLimit) {
-                // local inverse inertia and mass: constant over the step; in LDS when the cluster left room for the two planes, else read where needed
-                const float4 i0 = cp.planes == kAllPlanes ? r[6 * ncap] : bodies[(size_t)body * 8 + 4], i1 = cp.planes == kAllPlanes ? r[7 * ncap] : bodies[(size_t)body * 8 + 5];
-                Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
-                Sym3 world = rotateInverseInertia(local, ori);
-                r[4 * ncap] = make_float4(world.xx, world.yx, world.yy, world.zx);
-                r[5 * ncap] = make_float4(world.zy, world.zz, i1.z, r[5 * ncap].w);
-                if constexpr (kConserving) {  // substep_integrate_dynamic's angular step (TypeProcessor.cs:1224-1238, 1264-1272); a ghost's velocity belongs to its home
-                    if (!ghost) {
-                        const Q before = {q4.x, q4.y, q4.z, q4.w};  // substep > 0: the orientation the step started from; substep 0: "integrating backwards" from the current one
-                        if (cp.sp.angular_mode == 1)
-                            vel.ang = integrateAngularVelocityConserveMomentum(gs > 0 ? before : integrateOrientation(ori, vel.ang, dt * -0.5f), local, world, vel.ang);
-                        else if (cp.sp.angular_mode == 2)
-                            vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, dt);
-                    }
+        // PART 0: all of it. PART 1: the pose half (pose, world inverse inertia; a shared body's end-of-substep velocity moves from its record into the home's LDS slot).
+        // PART 2: the velocity half (IntegrateVelocity, the home's "integration done" record). Same arithmetic per body in the same order whichever way it is cut.
+        auto integrate_bodies = [&](auto part_tag) {
+            constexpr int PART = decltype(part_tag)::value;
+            for (int j0 = tid; j0 < cd.slot_count; j0 += blockDim.x) {
+                // (opaque: the planes' LDS addresses of slot j are otherwise computed once per launch, in front of the substep loop, and kept in scratch by the 128-VGPR
+                // units — every integration phase then starts with a chain of scratch loads, each a memory round trip; recomputed here they cost a few integer instructions)
+                int j = j0;
+                asm volatile("" : "+v"(j));
+                const int g = slot_entry(j);
+                if (g < 0) continue;
+                const bool ghost = SHARED && (g & kSlotGhost) != 0;  // another cluster owns the body; this one keeps its pose and world inertia current by the same arithmetic
+                if (PART == 2 && ghost) continue;
+                float4* r = lds + j;
+                const bool home = SHARED && (g & kSlotSharedHome) != 0;
+                const int body = g & kSlotBodyMask;
+                const bool dynamic = (unsigned)(g & ~(kSlotSharedHome | kSlotGhost)) < kDynamicLimit;
+                if (PART == 2 && !dynamic && !cp.integrate_velocity_for_kinematics) continue;
+                float4 q4 = make_float4(0, 0, 0, 1), p4 = r[ncap], l4 = r[2 * ncap], a4 = r[3 * ncap];
+                if (PART != 2) q4 = r[0];
+                unsigned applications = 0;  // shared bodies: applications per pass
+                if (home || ghost) applications = shared_tables.info[body] & 0xFFu;
+                if (PART != 2 && (home || ghost) && s > 0) {  // the velocity the last substep ended with: in last substep's record once every application on the body has happened
+                    const float lw = l4.w, aw = a4.w;
+                    acquire_shared_one(shared_tables, status, body, (unsigned)s - 1u, shared_tables.base + (unsigned)s + applications * sh.passes, l4, a4, 9, j);
+                    l4.w = lw; a4.w = aw;  // the record's fourth lanes carry the event number; the body's own padding stays what it was
+                    if (PART == 1 && home) { r[2 * ncap] = l4; r[3 * ncap] = a4; }  // (the velocity half finds it there)
                 }
-                if (!ghost) {
+                Q ori = {q4.x, q4.y, q4.z, q4.w};
+                V3 pos = {p4.x, p4.y, p4.z};
+                BodyVel vel = {{l4.x, l4.y, l4.z}, {a4.x, a4.y, a4.z}};
+                if (PART != 2 && gs > 0) {
+                    pos = add(pos, scale(vel.lin, dt));
+                    ori = integrateOrientation(ori, vel.ang, dt * 0.5f);
+                    r[0] = make_float4(ori.x, ori.y, ori.z, ori.w);
+                    r[ncap] = make_float4(pos.x, pos.y, pos.z, p4.w);
+                }
+                if (dynamic) {
+                    if constexpr (PART != 2) {
+                        // local inverse inertia and mass: constant over the step; in LDS when the cluster left room for the two planes, else read where needed
+                        const float4 i0 = cp.planes == kAllPlanes ? r[6 * ncap] : bodies[(size_t)body * 8 + 4], i1 = cp.planes == kAllPlanes ? r[7 * ncap] : bodies[(size_t)body * 8 + 5];
+                        Sym3 local = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y};
+                        Sym3 world = rotateInverseInertia(local, ori);
+                        r[4 * ncap] = make_float4(world.xx, world.yx, world.yy, world.zx);
+                        r[5 * ncap] = make_float4(world.zy, world.zz, i1.z, r[5 * ncap].w);
+                        if constexpr (kConserving) {  // substep_integrate_dynamic's angular step (TypeProcessor.cs:1224-1238, 1264-1272); a ghost's velocity belongs to its home
+                            static_assert(PART == 0, "the conserving modes integrate a body in one piece (the angular step reads the orientation the substep started from)");
+                            if (!ghost) {
+                                const Q before = {q4.x, q4.y, q4.z, q4.w};  // substep > 0: the orientation the step started from; substep 0: "integrating backwards" from the current one
+                                if (cp.sp.angular_mode == 1)
+                                    vel.ang = integrateAngularVelocityConserveMomentum(gs > 0 ? before : integrateOrientation(ori, vel.ang, dt * -0.5f), local, world, vel.ang);
+                                else if (cp.sp.angular_mode == 2)
+                                    vel.ang = integrateAngularVelocityConserveMomentumWithGyroscopicTorque(ori, local, vel.ang, dt);
+                            }
+                        }
+                    }
+                    if constexpr (PART != 1) {
+                        if (!ghost) {
+                            velocity_callback(cp.sp, vel, pos, body);
+                            r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
+                            r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
+                        }
+                        if (home) {  // this substep's record: the integrated velocity, and "integration done" as the event number
+                            const float number = __uint_as_float(shared_tables.base + (unsigned)s + 1u + applications * sh.passes);
+                            publish_record_pair(shared_tables, shared_record(shared_tables, body, (unsigned)s), make_float4(vel.lin.x, vel.lin.y, vel.lin.z, number), make_float4(vel.ang.x, vel.ang.y, vel.ang.z, number));
+                        }
+                    }
+                } else if (PART != 1 && cp.integrate_velocity_for_kinematics) {  // kinematic: private copy, same arithmetic as the global kinematic pass
                     velocity_callback(cp.sp, vel, pos, body);
                     r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
                     r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
                 }
-                if (home) {  // this substep's record: the integrated velocity, and "integration done" as the event number
-                    const float number = __uint_as_float(shared_tables.base + (unsigned)s + 1u + applications * sh.passes);
-                    publish_record_pair(shared_tables, shared_record(shared_tables, body, (unsigned)s), make_float4(vel.lin.x, vel.lin.y, vel.lin.z, number), make_float4(vel.ang.x, vel.ang.y, vel.ang.z, number));
-                }
-            } else if (cp.integrate_velocity_for_kinematics) {  // kinematic: private copy, same arithmetic as the global kinematic pass
-                velocity_callback(cp.sp, vel, pos, body);
-                r[2 * ncap] = make_float4(vel.lin.x, vel.lin.y, vel.lin.z, l4.w);
-                r[3 * ncap] = make_float4(vel.ang.x, vel.ang.y, vel.ang.z, a4.w);
             }
+        };
+        // Between two substeps (round 6): the contact items' incremental update waits for memory (its rows: 2 - 4 k clocks per item, profiles/r06_s35_*), the pose half of
+        // the integration is arithmetic (about 500 instructions per body), and neither touches what the other writes — the update reads velocities and writes depth rows,
+        // the pose half reads velocities and writes poses and inertias. So half the waves of every SIMD take their bodies' pose half first and their contact items second,
+        // the other half the other way round: one's arithmetic under the other's loads. The velocity half (IntegrateVelocity: a few instructions) waits behind a barrier
+        // for every update to have read the velocities it is about to change. The conserving modes' angular step needs the body in one piece: old order there.
+        const bool halves = !kConserving && gs > 0 && cp.split_integration != 0;  // (wave-uniform, the same for every wave of the workgroup: the barriers below are taken by all or none)
+        const bool pose_first = halves && ((wave >> 2) & 1) != 0;  // waves w, w + 4, ... share a SIMD: every SIMD gets both kinds
+        if (pose_first) integrate_bodies(std::integral_constant<int, kConserving ? 0 : 1>{});
+        if (gs > 0) {
+            incremental_items();
+            if (phase) phase[3] = __builtin_readcyclecounter();  // this wave's incremental items are done
         }
+        if (halves && !pose_first) integrate_bodies(std::integral_constant<int, kConserving ? 0 : 1>{});
+        if (gs > 0) __syncthreads();
+        if (phase) phase[1] = __builtin_readcyclecounter();
+        if (halves) integrate_bodies(std::integral_constant<int, kConserving ? 0 : 2>{});
+        else integrate_bodies(std::integral_constant<int, 0>{});
         if constexpr (SHARED) sh.events = (unsigned)s + 1u;
         sh.substep = gs;
         __syncthreads();
+        if (phase) phase[2] = __builtin_readcyclecounter();
         ++epoch;
         const int fused = cp.iters[s] > 0 ? cd.item_count : 0;  // the first velocity iteration rides in the warm start's claim sequence
         run_cluster_sweep<kStageWarmStart, TRACE, WIDE, SHARED>(sh, cd.item_count, fused, lane, wave, epoch, claim_base, slab, dt, inv_dt, trace);
@@ -1303,7 +1349,7 @@ __global__ __launch_bounds__(THREADS) void cluster_kernel(const ClusterDesc* __r
     }
     // Trailing pose integration of constrained bodies (PoseIntegrator.cs:684-691) and write-back.
     for (int j = tid; j < cd.slot_count; j += blockDim.x) {
-        int g = slots[j];
+        int g = slot_entry(j);
         if (SHARED && g >= 0 && (g & kSlotGhost)) continue;  // written back by its home cluster
         const bool home = SHARED && g >= 0 && (g & kSlotSharedHome) != 0;
         if (home) g &= kSlotBodyMask;

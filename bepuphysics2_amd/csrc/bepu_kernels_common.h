@@ -93,6 +93,8 @@ struct ClusterParams {
     int substeps, batch_count, integrate_velocity_for_kinematics;
     int planes;  // kSweepPlanes or kAllPlanes
     int code_touch;     // 8 KB spans of its own upcoming code a wave pulls into L2 at the start of every work item (0: off), see touch_code_ahead
+    int split_integration;  // between two substeps the pose half of the integration runs beside the contact items' incremental update, the velocity half behind a barrier (cluster_kernel; 0: one piece, behind the update)
+    int slot_table_in_lds;  // whole-island plans: the launch asked for LDS room for the slot -> body table behind the sync words (split plans always have it)
     unsigned jitter;    // schedule fuzzing seed (BEPUHIP_DEBUG_JITTER; 0 = off): pseudo-random naps around every item's wait and publish, see jitter_nap
     int iters[kMaxClusterSubsteps];
     int pass_stage, pass_substep;  // the one-sweep-per-launch units (kPass): kStageWarmStart or kStageSolve, and the substep the sweep belongs to

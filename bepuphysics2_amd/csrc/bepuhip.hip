@@ -1385,7 +1385,9 @@ static int island_launch_threads(const bepuhip_ctx* c, bool conserving) {
 }
 static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int base, int count, const int32_t* iterations, const bepuhip_integrator* in, const StepParams& sp) {
     const float substep_dt = dt / substeps;
-    const size_t lds_bytes = cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, c->clusters_shared);
+    // (whole-island plans: the slot -> body table goes to LDS too when the workgroup has the room for it; the planner never counts on it)
+    const bool slot_table = c->clusters_shared || (env_int("BEPUHIP_SLOT_TABLE_IN_LDS", 1) != 0 && cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, true) <= kLdsBudgetBytes);
+    const size_t lds_bytes = cluster_lds_bytes(c->cluster_planes, c->cluster_max_slots, c->cluster_max_items, slot_table);
     const bool whole_step = base == 0 && count == substeps;
     ClusterParams cp;
     cp.substeps = count; cp.batch_count = c->batch_count; cp.integrate_velocity_for_kinematics = in->integrate_velocity_for_kinematics;
@@ -1455,6 +1457,10 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
         cp.code_touch = candidate == 2 ? (c->clusters_shared ? 2 : 1) : 0;
         if (const int forced = env_int("BEPUHIP_CODE_TOUCH", -1); forced >= 0) cp.code_touch = std::min(kCodeTouchMaxSpans, forced);  // never beyond the padding behind the unit's kernels
         cp.jitter = debug_jitter_seed();
+        // (split plans: every item is a contact item or nearly so and their incremental update waits for memory — crowd 0.3425 -> 0.3373 ms, pile 0.3424 -> 0.3398 with the
+        // halves; whole-island plans: the boundary is arithmetic either way, 0.1563 / 0.1564 ms on the headline — profiles/r06_s38_ab_slot_table_halves.txt)
+        cp.split_integration = env_int("BEPUHIP_SPLIT_INTEGRATION", c->clusters_shared ? 1 : 0);
+        cp.slot_table_in_lds = slot_table && !c->clusters_shared;
         // (BEPUHIP_FORCE_WIDE_FAMILY=1, a developer switch: the all-44 unit for a scene that does not need it — what a family's extra code costs the types both carry, tools/ab_scene.py)
         const bool wide_family = c->has_widened_types || env_int("BEPUHIP_FORCE_WIDE_FAMILY", 0) != 0;
         const void* fn = cluster_kernel_variant(threads, tr, wide_family, c->clusters_shared, nt, conserving, !c->has_joint_types && !wide_family);  // the register budget that matches the workgroup size, the type set that matches the scene

@@ -38,6 +38,13 @@ for p in range(passes):
     busy = int((en - st).sum())
     print(f"pass {p}: begins at {int(st.min()) - t_first:8d} cyc, span {span:7d} cyc, sum of item times {busy:8d} ({busy / span:.2f} waves busy incl. waits), mean item {busy / len(st):.0f}")
 print(f"frame span (first claim to last publish): {int(tr[..., 1].max()) - t_first} cyc")
+if os.environ.get("PHASES"):  # between the sweeps: per wave the clock at the top of a substep, after its incremental items, behind that barrier, behind the integration's barrier
+    full = s.cluster_trace(128)
+    waves = int(os.environ.get("PHASES"))
+    for sub in range(int(sd.substep_count)):
+        ph = full[128 - 16 + sub].reshape(-1)[: waves * 4].reshape(waves, 4).astype(np.int64)
+        top, mid, end, own = ph[:, 0], ph[:, 1], ph[:, 2], ph[:, 3]
+        print(f"substep {sub}: top of substep {int(top.min()) - t_first:8d} .. {int(top.max()) - t_first:8d} | incremental items done (per wave, 0 = none) {[int(x - top.min()) if x else 0 for x in own]} | barrier behind them {int(mid.max() - top.min()):6d} | integration + barrier {int(end.max() - mid.max()):6d} cyc")
 p = int(os.environ.get("PASS", "1"))
 rec = tr[p]
 order = [k for k in np.argsort(rec[:, 0]) if rec[k, 0] > 0]
