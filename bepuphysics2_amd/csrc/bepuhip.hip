@@ -1347,7 +1347,8 @@ static int cluster_threads(const bepuhip_ctx* c) {
     const int req = c->clusters_shared ? env_int("BEPUHIP_SPLIT_THREADS", kSplitClusterThreads) : env_int("BEPUHIP_CLUSTER_THREADS", kClusterThreads);
     // (split plans: the units that exist are compiled for 512 threads — and 768 for the hot and contacts families; the 1024-thread split units spilled 372 - 3,437 VGPRs,
     // were never a default and are no longer built)
-    const int most = c->clusters_shared ? (c->has_widened_types ? 512 : 768) : 1024;
+    // (BEPUHIP_SPLIT_ALLOW_1024=1, experiments: sixteen waves on a split plan — only a unit compiled for the scene's exact types exists for that, bepuhip_specialise_units first)
+    const int most = c->clusters_shared ? (c->has_widened_types ? 512 : (env_int("BEPUHIP_SPLIT_ALLOW_1024", 0) ? 1024 : 768)) : 1024;
     return std::max(64, std::min(most, req / 64 * 64));
 }
 // The momentum-conserving angular modes run the island schedule through the kernel units that carry their code (round 3; BEPUHIP_CONSERVING_CLUSTERS=0: launch-per-batch

@@ -41,6 +41,8 @@ def main():
         try:
             s = HipSolver()
             s.upload(scene)
+            if os.environ.get("AB_SPECIALISE"):  # the unit compiled for exactly the scene's types (and this configuration's workgroup size), waited for
+                print(f"  ({label}: specialise_units -> {s.specialise_units(wait=True)})", flush=True)
             for _ in range(100):
                 s.solve(1 / 60, sd, cb, asynchronous=True)
             s.sync()
