@@ -70,7 +70,7 @@ static std::string unit_cache_dir(std::vector<std::string>* read_dirs = nullptr)
 // What a unit is compiled from, hashed: an object of another source state is never loaded.
 static const char* const kUnitSources[] = {"bepu_cluster_variant.inc", "bepu_cluster_kernel.h", "bepu_kernels_common.h", "bepu_batch_kernels.h", "bepu_device_constraints.h", "bepu_device_math.h", "bepu_device_bounds.h"};
 // The flags of bepuphysics2_amd/build.py (HIP_COMPILE_FLAGS; tests/test_unit_cache.py compares the two lists)
-static const char* const kUnitFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-result", "-Wno-unused-value", "-Wno-array-bounds"};
+static const char* const kUnitFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Xarch_device", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-result", "-Wno-unused-value", "-Wno-array-bounds"};
 static uint64_t unit_sources_hash() {
     static const uint64_t hash = [] {
         uint64_t h = 1469598103934665603ull;

@@ -5,7 +5,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "bepuphysics2_amd", "csrc")
 unit, extra = sys.argv[1], sys.argv[2:]
 obj = tempfile.mktemp(suffix=".o")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Xarch_device", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
        "-Wno-array-bounds", "-c", "-o", obj, unit, "-Rpass-analysis=kernel-resource-usage"] + extra
 err = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True).stderr
 cur = None
