@@ -137,7 +137,7 @@ def compact_line(out, full_path):
             line[extra] = rnd(out[extra])
     grp = out.get("lattice_device_group")  # N > 1: BASELINE.json configs[4] (one connected lattice over the N devices, exact) beside configs[3]
     if isinstance(grp, dict):
-        line["lattice_device_group"] = rnd(dict(pick(grp, ("value", "ms_per_step", "scaling", "n_gpus", "error")), **pick(grp.get("config") or {}, ("exchanges_per_step", "finite", "schedule_is_island"))))
+        line["lattice_device_group"] = rnd(dict(pick(grp, ("value", "ms_per_step", "scaling", "n_gpus", "error", "ranks")), **pick(grp.get("config") or {}, ("exchanges_per_step", "finite", "schedule_is_island"))))
     if out.get("self_checks"):
         line["self_checks"] = out["self_checks"]
     line["full_report"] = full_path
@@ -918,7 +918,7 @@ def run_lattice_group(args, rank, local_rank, world, dist, torch, scene, sd, sta
             "cpu_baseline": None})
         line["config"]["schedule_is_island"] = solver.schedule() == 2  # (False: the plan did not fit — more clusters per device than CUs, or LDS — and the group ran launch-per-batch)
         if standalone:
-            print(json.dumps(line))
+            emit_line(line)
     if dist is not None:
         dist.barrier()
         if standalone:
@@ -985,7 +985,7 @@ def run_lattice(args, rank, local_rank, world, dist, torch):
         step_bytes = (sv_bytes * int(its.sum()) + ws_bytes * sd.substep_count + inc_bytes * (sd.substep_count - 1)
                       + INTEGRATE_BYTES_PER_BODY * scene.body_count * sd.substep_count + FINAL_BYTES_PER_BODY * scene.body_count)
         achieved = step_bytes / (elapsed / args.steps) / 1e9
-        print(json.dumps({
+        emit_line({
             "metric": "constraint-iterations/sec", "value": units / elapsed, "unit": "constraint-iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -1000,11 +1000,81 @@ def run_lattice(args, rank, local_rank, world, dist, torch):
                        "exchanges_per_step": int((1 + its).sum()) * (len(scene.batches) if exact else 1)},
             "roofline": {"bound": "hbm", "kernel": f"whole step ({schedule} + exchanges), algorithmic bytes", "achieved": achieved, "peak": HBM_PEAK_GBS * world,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None},
-            "cpu_baseline": None}))
+            "cpu_baseline": None})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     solver.close()
+
+
+def lattice_group_command(args, world: int):
+    """The command line of one rank of the configs[4] leg (a standalone `--lattice --lattice-exact` run: run_lattice_group prints its own line on rank 0). Pure."""
+    return [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--lattice", "--lattice-exact", "--steps", str(args.steps), "--warmup", str(args.warmup),
+            "--ragdolls", str(args.ragdolls)] + (["--no-prewarm"] if args.no_prewarm else [])
+
+
+def lattice_group_in_children(args, rank: int, local_rank: int, world: int, dist, timeout: float = 420.0):
+    """The device-group leg of an N > 1 run, one child process per rank (same isolation as `leg_in_child`): rank 0 picks a free port, every rank starts
+    `bench.py --lattice --lattice-exact` with its own RANK / LOCAL_RANK and that port, waits for it (bounded), and rank 0 reads the child's JSON line. The parents keep
+    their process group idle meanwhile and meet at a barrier afterwards. Returns the leg's line on rank 0 (or how the children ended), None elsewhere."""
+    import socket
+    port = [None]
+    if rank == 0:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port[0] = sock.getsockname()[1]
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]))
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+              "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "BEPU_BENCH_GROUP_LEG"):
+        env.pop(k, None)  # (the children are a job of their own: nothing of the launcher's store or agent)
+    if world == 1:
+        env["BEPU_BENCH_FORCE_DIST"] = "1"  # (the one-GPU rehearsal of this path: BEPU_BENCH_GROUP_LEG=1)
+    report = None
+    try:
+        done = subprocess.run(lattice_group_command(args, world), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+        status = {"rank": rank, "exit_code": done.returncode}
+        if rank == 0:
+            lines = [ln for ln in done.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            try:
+                report = json.loads(lines[-1]) if lines else None
+            except ValueError:
+                report = None
+        if done.returncode != 0 or (rank == 0 and report is None):
+            status["stderr_tail"] = " | ".join([ln for ln in done.stderr.decode(errors="replace").splitlines() if ln.strip()][-2:])[:300]
+    except subprocess.TimeoutExpired:
+        status = {"rank": rank, "error": f"child did not finish within {timeout:.0f} s (killed)"}
+    statuses = [None] * world
+    dist.all_gather_object(statuses, status)
+    if rank != 0:
+        return None
+    failed = [st for st in statuses if st.get("exit_code", 1) != 0]
+    if report is None or failed:
+        return {"error": "the device-group leg did not complete on every rank", "ranks": failed or statuses, "partial": report}
+    return report
+
+
+_LINE_FD = None
+
+
+def claim_stdout():
+    """ONE JSON line on stdout and nothing else: RCCL prints a five-line version banner on the C library's stdout when its first communicator comes up (seen after the
+    JSON line in a pipe: C stdio flushes at exit), and whatever else a library of the process writes there would land beside the line too. From here on file descriptor 1
+    of this process (and of what it starts) is stderr; `emit_line` writes the line to the descriptor stdout used to be."""
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(obj):
+    text = (json.dumps(obj) + "\n").encode()
+    if _LINE_FD is None:
+        sys.stdout.write(text.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_LINE_FD, text)
 
 
 def quiet_gc():
@@ -1094,6 +1164,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not (args.traffic_child or args.leg_child):
+        claim_stdout()  # (every rank: only rank 0 ever emits, and only the line)
 
     if args.traffic_child:
         return traffic_child(args, local_rank)
@@ -1270,19 +1342,14 @@ def main():
         lattice_report = extra("lattice")
 
     lattice_group = None
-    if world > 1 and dist is not None and not args.no_connected_scenes:
+    if dist is not None and (world > 1 or os.environ.get("BEPU_BENCH_GROUP_LEG") == "1") and not args.no_connected_scenes:
         # BASELINE.json configs[4] beside configs[3] on ONE line at N > 1 (VERDICT r5 next #7b): the same number of ragdolls as one rank's share, as ONE connected lattice
         # split over the N devices as a device group (exact mode). Strong scaling inside this leg: its own ms_per_step, and the N = 1 figure of the same lattice is the
-        # `lattice.device_group_single_rank_ms` of an N = 1 run.
+        # `lattice.device_group_single_rank_ms` of an N = 1 run. The device group has never run on more than one GPU (the pool has single-GPU boxes), so the leg runs the
+        # way the N = 1 legs do — every rank starts a child of its own, the children meet on a rendezvous of their own — and a child that aborts or hangs costs the
+        # leg's report, not the headline's line (lattice_group_in_children).
         solver.close()
-        from bepuphysics2_amd.hostlib import HostSimulation
-        sim = HostSimulation.scene("ragdoll_tube", args.ragdolls, 1, 1, 5)
-        lattice_scene, lattice_sd = sim.export(), sim.solve_description()
-        sim.close()
-        try:
-            lattice_group = run_lattice_group(args, rank, local_rank, world, dist, torch, lattice_scene, lattice_sd, standalone=False)
-        except Exception as e:  # noqa: BLE001 — the headline line survives a leg that fails; the failure is on the line
-            lattice_group = {"error": f"{type(e).__name__}: {e}"[:300]}
+        lattice_group = lattice_group_in_children(args, rank, local_rank, world, dist)
     if rank == 0:
         value = whole_job_rate
         out = {
@@ -1316,7 +1383,7 @@ def main():
                 json.dump(out, f)
         except OSError:
             full_path = None
-        print(json.dumps(compact_line(out, full_path)))
+        emit_line(compact_line(out, full_path))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
