@@ -357,6 +357,7 @@ struct bepuhip_ctx {
     bool soft_flags_stale = false;
     // measurement
     float last_ms = 0;
+    bool solve_timing = false, solve_timed = false, last_ms_valid = false;  // bepuhip_set_solve_timing: events around a solve only when asked for (solve_event)
     int64_t last_constraint_iterations = 0;
     bool profiling = false;
     float prof_ms[6] = {0, 0, 0, 0, 0, 0};

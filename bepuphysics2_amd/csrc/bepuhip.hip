@@ -16,6 +16,7 @@
 // Integration is hoisted out of the first-touching constraint's warm start into the per-substep body kernel; SURVEY.md A.2
 // gives the argument that this is value-identical (nothing reads a body between its integration and its first constraint).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1117,14 +1118,18 @@ int32_t bepuhip_set_constrained_kinematics(bepuhip_ctx* c, const int32_t* indice
 
 int32_t bepuhip_sync(bepuhip_ctx* c);
 
+// (`attached`: the one launch inside the scope takes the two events itself — hipExtLaunchKernel(..., a, b, 0): they carry the kernel's own start and end, what a kernel
+// trace shows for it. Events recorded on the stream around a launch are marker packets in front of and behind it and add their own few microseconds to what they
+// bracket: 54.3 us for a 50 us kernel where the attached pair says 51.6, tools/probes/launch_gap_probe.hip.)
 struct Timed {
-    bepuhip_ctx* c; int family; hipEvent_t a = nullptr, b = nullptr;
-    Timed(bepuhip_ctx* c_, int f) : c(c_), family(f) {
-        if (c->profiling) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+    bepuhip_ctx* c; int family; hipEvent_t a = nullptr, b = nullptr; bool attached = false;
+    Timed(bepuhip_ctx* c_, int f, bool attach = false) : c(c_), family(f), attached(attach && c_->profiling) {
+        if (c->profiling) { hipEventCreate(&a); hipEventCreate(&b); if (!attached) hipEventRecord(a, c->stream); }
     }
     ~Timed() {
         if (c->profiling) {
-            hipEventRecord(b, c->stream); hipEventSynchronize(b);
+            if (!attached) hipEventRecord(b, c->stream);
+            hipEventSynchronize(b);
             float ms = 0; hipEventElapsedTime(&ms, a, b);
             c->prof_ms[family] += ms; c->prof_launches[family] += 1;
             hipEventDestroy(a); hipEventDestroy(b);
@@ -1379,6 +1384,15 @@ static void special_request(bepuhip_ctx* c, const UnitKey& key) {
     c->special_unit = unit_request(key, c->device, kLdsBudgetBytes);
     c->special_mask = key.mask; c->special_budget = key.budget; c->special_shared = key.shared;
 }
+// The events behind bepuhip_last_solve_ms. Off unless bepuhip_set_solve_timing asked for them (round 6, last session): an event recorded on a stream is a marker packet of
+// its own with a completion signal, and one in front of and one behind the launch put 7 us between two back-to-back solves of the island schedule — 11 us from the end of
+// one launch to the start of the next where two plain launches of the same shape take 2.3 (tools/probes/launch_gap_probe.hip, profiles/r06_s54_launch_gap_probe.txt:
+// hipExtLaunchKernel's own event pair costs 4.4). A solve that is not timed enqueues its kernels and nothing else.
+static hipError_t solve_event(bepuhip_ctx* c, bool start) {
+    if (start) c->solve_timed = c->solve_timing;
+    if (!c->solve_timed) return hipSuccess;
+    return hipEventRecord(start ? c->ev_start : c->ev_stop, c->stream);
+}
 static int island_launch_threads(const bepuhip_ctx* c, bool conserving) {
     int threads = cluster_threads(c);
     if (c->split_twelve_waves && c->clusters_shared && threads == kSplitClusterThreads && !conserving && !c->has_widened_types) threads = 768;
@@ -1399,7 +1413,8 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
     for (int s = 0; s < kMaxClusterSubsteps; ++s) cp.iters[s] = s < count ? iterations[base + s] : 0;
     cp.sp = sp;
     {
-        Timed t(c, 5);
+        const bool cooperative = c->clusters_shared && env_int("BEPUHIP_COOPERATIVE", (c->flags & BEPUHIP_FLAG_EXCLUSIVE_DEVICE) ? 0 : 1) != 0;
+        Timed t(c, 5, !cooperative);  // (a plain launch carries its own event pair when the context is profiling)
         // Waves per cluster: 16 by default (four per SIMD; 12 is as fast when memory latency is low, 8 is slower everywhere); BEPUHIP_CLUSTER_THREADS overrides.
         // Scenes with SURVEY 8(f) types take the 512-thread build: at 128 VGPRs per wave the widened types spill hundreds of registers.
         // (the widened variant too: its 1024-thread build spills 700 VGPRs and is still the faster one — 0.222 against 0.325 ms on the bench graph with widened joints
@@ -1421,7 +1436,10 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
         TailParams tp;
         tp.flags = c->d_flags; tp.kinlist = c->d_kinlist; tp.staged = c->d_staged;
         tp.body_count = c->body_count; tp.kin_count = c->kinlist_count; tp.cluster_count = local_clusters;
-        tp.body_blocks = cp.final_launch ? (c->body_count + threads - 1) / threads : 0;  // IntegrateAfterSubstepping of the bodies no cluster owns: the step's last launch
+        // IntegrateAfterSubstepping of the bodies no cluster owns: the step's last launch — unless the plan owns every body (the list behind kFlagClustered is a set: as long as
+        // the body count, no index is left for these workgroups; a pile of boxes in contact: 196 workgroups that read a flag and leave, a launch of their own on the cooperative path)
+        const bool every_body_clustered = c->clustered_dynamic_count == c->body_count && !c->clustered_dirty && c->group_world <= 1;
+        tp.body_blocks = cp.final_launch && !every_body_clustered ? (c->body_count + threads - 1) / threads : 0;
         tp.block_offset = 0;
         tp.dt = dt; tp.substep_dt = substep_dt; tp.substep_count = substeps;
         tp.substep_base = base; tp.launch_substeps = count; tp.final_launch = cp.final_launch;
@@ -1479,7 +1497,7 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
         if (sample >= 0) hipEventRecord(c->policy_events[sample][0], c->stream);
         const int tail_blocks = tp.body_blocks + (c->kinlist_count > 0 ? 1 : 0);
         bool launched = false;
-        if (c->clusters_shared && env_int("BEPUHIP_COOPERATIVE", (c->flags & BEPUHIP_FLAG_EXCLUSIVE_DEVICE) ? 0 : 1) != 0) {
+        if (cooperative) {
             // The clusters of a split plan wait for each other: they must all be resident at once. A cooperative launch of exactly the clusters makes the runtime
             // guarantee that (or refuse), whatever else runs on the device; the per-body tail follows as an ordinary launch of the same kernel.
             std::lock_guard<std::mutex> one_at_a_time(g_cooperative_launch);
@@ -1493,7 +1511,10 @@ static void enqueue_island_launch(bepuhip_ctx* c, float dt, int substeps, int ba
                 (void)hipGetLastError();  // e.g. hipErrorCooperativeLaunchTooLarge: fall back to the plain launch below
             }
         }
-        if (!launched) hipLaunchKernel(fn, dim3(local_clusters + tail_blocks), dim3(threads), args, launch_lds, c->stream);
+        if (!launched) {
+            if (t.attached) hipExtLaunchKernel(fn, dim3(local_clusters + tail_blocks), dim3(threads), args, launch_lds, c->stream, t.a, t.b, 0);
+            else hipLaunchKernel(fn, dim3(local_clusters + tail_blocks), dim3(threads), args, launch_lds, c->stream);
+        }
         if (sample >= 0) hipEventRecord(c->policy_events[sample][1], c->stream);
     }
 }
@@ -1629,7 +1650,7 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     c->last_constraint_iterations = iters;
     if (c->profiling) { for (int i = 0; i < 6; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; } }
     laps.lap("checks");
-    HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+    HIP_TRY(solve_event(c, true));
     laps.lap("event record");
     // A graph pays for the launch-per-batch schedule's 100+ launches; the island schedule is ONE kernel, which a plain launch starts sooner (6-7 us per step).
     const bool use_graph = !(c->flags & BEPUHIP_FLAG_NO_GRAPH) && !c->profiling && !island_schedule_applies(c, substeps, in);
@@ -1643,7 +1664,7 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
             c->graphs_cleared_by_structure = false;
             enqueue_solve(c, dt, substeps, iterations, in);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+            HIP_TRY(solve_event(c, false));
             return BEPUHIP_OK;
         }
         if (it == c->graphs.end()) {
@@ -1651,7 +1672,7 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
                 c->graphs.clear();
-                HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+                HIP_TRY(solve_event(c, true));
             }
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -1670,10 +1691,10 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
                 hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
                 if (hipStreamIsCapturing(c->stream, &status) == hipSuccess && status != hipStreamCaptureStatusNone) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(c->stream, &dead); if (dead) hipGraphDestroy(dead); }
                 for (int k = 0; k < 4 && hipGetLastError() != hipSuccess; ++k) {}
-                HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+                HIP_TRY(solve_event(c, true));
                 enqueue_solve(c, dt, substeps, iterations, in);  // eager fallback for this call; the next call tries to capture again
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+                HIP_TRY(solve_event(c, false));
                 return BEPUHIP_OK;
             }
             it = c->graphs.emplace(key, exec).first;
@@ -1685,7 +1706,7 @@ int32_t bepuhip_solve_async(bepuhip_ctx* c, float dt, int32_t substeps, const in
     }
     laps.lap("enqueue");
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+    HIP_TRY(solve_event(c, false));
     laps.lap("stop event");
     return BEPUHIP_OK;
 }
@@ -1714,7 +1735,7 @@ int32_t bepuhip_solve_with_substep_events(bepuhip_ctx* c, float dt, int32_t subs
     int64_t iters = 0;
     for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
     c->last_constraint_iterations = iters;
-    HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+    HIP_TRY(solve_event(c, true));
     const float substep_dt = dt / substeps, inv_dt = 1.0f / substep_dt;  // Solver_Solve.cs:1417, :1421
     const StepParams sp = make_params(c, in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
@@ -1735,7 +1756,7 @@ int32_t bepuhip_solve_with_substep_events(bepuhip_ctx* c, float dt, int32_t subs
     }
     if (islands) {
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+        HIP_TRY(solve_event(c, false));
         return bepuhip_sync(c);
     }
     for (int s = 0; s < substeps; ++s) {
@@ -1766,7 +1787,7 @@ int32_t bepuhip_solve_with_substep_events(bepuhip_ctx* c, float dt, int32_t subs
                            in->allow_substeps_for_unconstrained, in->integrate_velocity_for_kinematics, 0, fsp);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+    HIP_TRY(solve_event(c, false));
     return bepuhip_sync(c);
 }
 
@@ -2069,7 +2090,7 @@ static int32_t run_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const i
     int64_t iters = 0;
     for (int s = 0; s < substeps; ++s) iters += c->total_constraints * (int64_t)(1 + iterations[s]);
     c->last_constraint_iterations = iters;
-    HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+    HIP_TRY(solve_event(c, true));
     const float substep_dt = dt / substeps, inv_dt = 1.0f / substep_dt;
     const StepParams sp = make_params(c, in, substep_dt, substep_dt, inv_dt);
     const int body_blocks = (c->body_count + 255) / 256;
@@ -2119,7 +2140,7 @@ static int32_t run_exchanged(bepuhip_ctx* c, float dt, int32_t substeps, const i
                            in->allow_substeps_for_unconstrained, in->integrate_velocity_for_kinematics, 0, fsp);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+    HIP_TRY(solve_event(c, false));
     return bepuhip_sync(c);
 }
 
@@ -2285,7 +2306,8 @@ int32_t bepuhip_sync(bepuhip_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0;
-    if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) c->last_ms = ms;
+    if (!c->solve_timed) {}  // (bepuhip_set_solve_timing is off: no events were recorded)
+    else if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) { c->last_ms = ms; c->last_ms_valid = true; }
     else (void)hipGetLastError();  // no solve has been enqueued yet (the events were never recorded): not an error of THIS call — and it must not stay behind as the thread's last error, where the next launch check would find it (round 5: a sync between an upload's row transfers and the first solve made the following transfer fail with "invalid resource handle")
     c->desc_ring_used = 0;  // every transfer_rows descriptor table has been consumed
     if (c->clusters_enabled) {
@@ -3291,7 +3313,14 @@ int32_t bepuhip_get_constrained_flags(bepuhip_ctx* c, uint8_t* out, int32_t coun
 
 int32_t bepuhip_last_solve_ms(bepuhip_ctx* c, float* ms) {
     if (!c || !ms) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null argument");
+    if (!c->last_ms_valid) return fail(BEPUHIP_E_STATE, "no timed solve has completed: bepuhip_set_solve_timing(ctx, 1), solve, bepuhip_sync");
     *ms = c->last_ms;
+    return BEPUHIP_OK;
+}
+int32_t bepuhip_set_solve_timing(bepuhip_ctx* c, int32_t enabled) {
+    if (!c) return fail(BEPUHIP_E_INVALID_ARGUMENT, "null context");
+    c->solve_timing = enabled != 0;
+    if (!c->solve_timing) c->last_ms_valid = false;
     return BEPUHIP_OK;
 }
 int32_t bepuhip_set_profiling(bepuhip_ctx* c, int32_t enabled) {

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "bepuhip_last_error", "bepuhip_create", "bepuhip_destroy", "bepuhip_set_bodies", "bepuhip_begin_constraints",
     "bepuhip_set_type_batch", "bepuhip_end_constraints", "bepuhip_set_constrained_kinematics", "bepuhip_solve",
     "bepuhip_get_bodies", "bepuhip_get_accumulated_impulses", "bepuhip_get_prestep", "bepuhip_get_constrained_flags",
-    "bepuhip_last_solve_ms", "bepuhip_set_profiling", "bepuhip_get_profile", "bepuhip_last_constraint_iterations",
+    "bepuhip_last_solve_ms", "bepuhip_set_solve_timing", "bepuhip_set_profiling", "bepuhip_get_profile", "bepuhip_last_constraint_iterations",
     "bepuhip_get_stream", "bepuhip_solve_async", "bepuhip_sync", "bepuhip_reset_state", "bepuhip_type_info",
     "bepuhip_set_cluster_trace", "bepuhip_get_cluster_trace", "bepuhip_get_cluster_cycles", "bepuhip_get_row_policy", "bepuhip_debug_status",
     "bepuhip_set_boundary_bodies", "bepuhip_boundary_deltas", "bepuhip_boundary_apply", "bepuhip_solve_exchanged",
@@ -114,6 +114,7 @@ def load_library() -> C.CDLL:
     lib.bepuhip_get_prestep.argtypes = [vp, i32, i32, vp]
     lib.bepuhip_get_constrained_flags.argtypes = [vp, vp, i32]
     lib.bepuhip_last_solve_ms.argtypes = [vp, C.POINTER(f32)]
+    lib.bepuhip_set_solve_timing.argtypes = [vp, i32]
     lib.bepuhip_set_profiling.argtypes = [vp, i32]
     lib.bepuhip_get_profile.argtypes = [vp, i32, C.POINTER(f32), C.POINTER(i32)]
     lib.bepuhip_last_constraint_iterations.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -686,6 +687,10 @@ class HipSolver:
         return out
 
     # ---- measurement ----
+    def set_solve_timing(self, enabled: bool) -> None:
+        """HIP events around every solve from now on (bepuhip_last_solve_ms); off by default: they cost two marker packets per solve."""
+        _check(self.lib, self.lib.bepuhip_set_solve_timing(self.ctx, 1 if enabled else 0))
+
     def last_solve_ms(self) -> float:
         v = C.c_float()
         _check(self.lib, self.lib.bepuhip_last_solve_ms(self.ctx, C.byref(v)))

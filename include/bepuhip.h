@@ -458,7 +458,10 @@ int32_t bepuhip_predict_bounding_boxes(bepuhip_ctx* ctx, float dt, const bepuhip
 /* mergedConstrainedBodyHandles as computed on device, one byte per body INDEX: bit0 = referenced by any constraint,
  * bit1 = referenced as dynamic. For parity tests of the a2 prepass (BepuPhysics/Solver_Solve.cs:1198-1207,1378-1381). */
 int32_t bepuhip_get_constrained_flags(bepuhip_ctx* ctx, uint8_t* flags_out, int32_t count);
-/* Duration of the last bepuhip_solve in milliseconds, measured with HIP events on the context's stream. */
+/* Duration of the last bepuhip_solve in milliseconds, measured with HIP events on the context's stream — for the solves enqueued after
+ * bepuhip_set_solve_timing(ctx, 1) and completed by bepuhip_sync; STATE otherwise. Off by default: the two events put 7 us between two
+ * back-to-back solves (a marker packet each), 5 % of the headline scene's step. */
+int32_t bepuhip_set_solve_timing(bepuhip_ctx* ctx, int32_t enabled);
 int32_t bepuhip_last_solve_ms(bepuhip_ctx* ctx, float* ms_out);
 /* Per-kernel-family accumulated duration (ms) and launch count of the last solve when profiling is enabled. */
 int32_t bepuhip_set_profiling(bepuhip_ctx* ctx, int32_t enabled);

@@ -121,6 +121,7 @@ static unsafe class BepuHip
     [DllImport(Lib)] public static extern int bepuhip_set_collidables(IntPtr ctx, BepuHipCollidable* collidables, int count);
     [DllImport(Lib)] public static extern int bepuhip_predict_bounding_boxes(IntPtr ctx, float dt, BepuHipIntegrator* integrator, BepuHipCollidable* collidables, int count, BepuHipPredictedBounds* boundsOut);
     [DllImport(Lib)] public static extern int bepuhip_get_constrained_flags(IntPtr ctx, byte* flagsOut, int count);
+    [DllImport(Lib)] public static extern int bepuhip_set_solve_timing(IntPtr ctx, int enabled);
     [DllImport(Lib)] public static extern int bepuhip_last_solve_ms(IntPtr ctx, float* msOut);
     [DllImport(Lib)] public static extern int bepuhip_set_profiling(IntPtr ctx, int enabled);
     [DllImport(Lib)] public static extern int bepuhip_get_profile(IntPtr ctx, int family, float* msOut, int* launchesOut);

@@ -434,3 +434,38 @@ def test_nan_and_infinity_stop_where_minps_stops_them(hip_solver_factory, use_cl
         m = pu.compare_scenes_with_nans(ref, got)
         assert m["bodies_same"] and m["impulses_same"] and m["prestep_same"], m
         assert m["body_nans"] > 0 and m["body_nans"] < 13 * scene.body_count, "some words are NaN, and the NaN did not simply take the whole scene"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_clusters", [True, False])
+def test_solve_timing_is_asked_for_and_changes_no_bit(hip_solver_factory, use_clusters):
+    """bepuhip_last_solve_ms's events are recorded only after bepuhip_set_solve_timing(ctx, 1) (two marker packets per solve otherwise sit between back-to-back solves: 7 us
+    of the headline's 143): STATE until a timed solve has completed, a duration afterwards, the same bits with and without, back-to-back asynchronous solves included."""
+    from bepuphysics2_amd import native
+    scene = small_scenes.random_graph_scene(31, 120, 320, [7, 22, 30, 47], kinematic_fraction=0.05)
+    sd, cb = SolveDescription(3, 1), PoseIntegratorCallbacks()
+    import oracle_ffi
+    ref = scene.copy()
+    for _ in range(6):
+        oracle_ffi.solve(ref, 1 / 60, sd, cb)
+    results = []
+    for timed in (False, True):
+        solver = hip_solver_factory(use_clusters=use_clusters)
+        solver.upload(scene.copy(), sd.fallback_batch_threshold)
+        with pytest.raises(native.BepuHipError) as e:
+            solver.last_solve_ms()
+        assert e.value.code == native.BEPUHIP_E_STATE
+        if timed:
+            solver.set_solve_timing(True)
+        for _ in range(6):
+            solver.solve(1 / 60, sd, cb, asynchronous=True)
+        solver.sync()
+        if timed:
+            assert 0.0 < solver.last_solve_ms() < 1000.0
+            solver.set_solve_timing(False)
+        with pytest.raises(native.BepuHipError):
+            solver.last_solve_ms()
+        got = scene.copy()
+        solver.download(got)
+        _bit_exact(ref, got)
+        results.append(got)
