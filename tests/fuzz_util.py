@@ -242,7 +242,18 @@ def run_structural_scene(rng, jitter: int = 0, touch_environment: bool = True, o
                         stats["ok"] = False
                         cols = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 13, 14]
                         rows = np.flatnonzero((export.bodies[:, cols].view(np.int32) != got.bodies[:, cols].view(np.int32)).any(axis=1))
-                        stats["report"] = (f"MISMATCH bodies {nb} constraints {nc} substeps {sub} frame {frame} {m} bodies {rows[:8]} kinematic {[ms.is_kinematic(int(r)) for r in rows[:8]]} "
+                        detail = []  # which rows differ: (batch, type id, count, lanes whose impulses / prestep differ, the first such lane's values on either side)
+                        for bi, (br, bg) in enumerate(zip(export.batches, got.batches)):
+                            for tr, tg in zip(br, bg):
+                                occupied = tr.occupied(export.bundle_width)
+                                for what, ar, ag in (("impulses", tr.accumulated_lanes(export.bundle_width)[occupied], tg.accumulated_lanes(got.bundle_width)[occupied]),
+                                                     ("prestep", tr.prestep_lanes(export.bundle_width)[occupied], tg.prestep_lanes(got.bundle_width)[occupied])):
+                                    lanes = np.flatnonzero((np.ascontiguousarray(ar).view(np.int32) != np.ascontiguousarray(ag).view(np.int32)).any(axis=1)) if ar.size else np.zeros(0, np.int64)
+                                    if lanes.size and len(detail) < 4:
+                                        k = int(lanes[0])
+                                        detail.append(f"batch {bi} type {tr.type_id} count {tr.count} {what}: {lanes.size} lanes (first {lanes[:6].tolist()}), lane {k} oracle {np.round(ar[k], 5).tolist()} device {np.round(ag[k], 5).tolist()} "
+                                                      f"bodies {tr.refs_lanes(export.bundle_width)[occupied][k].tolist()}")
+                        stats["report"] = (" | ".join(detail) + " || " if detail else "") + (f"MISMATCH bodies {nb} constraints {nc} substeps {sub} frame {frame} {m} bodies {rows[:8]} kinematic {[ms.is_kinematic(int(r)) for r in rows[:8]]} "
                                            f"in the caller's constrained-kinematic list {[int(r) in set(kin.tolist()) for r in rows[:8]]} schedule {solver.schedule()} re-planned before frames {replanned_at} (negative: background commit)")
                         break
                 except UnsupportedError:  # an addition that lands in the sequential fallback batch: refused by design, the scene ends here
