@@ -114,9 +114,12 @@ struct HostTypeBatch {
     std::vector<uint8_t> occupied;  // type batches of the sequential fallback batch: lane i of the caller's layout holds a constraint (empty lanes carry -1 references, TypeProcessor.cs:451-571)
     std::vector<int32_t> perm;      // cluster path: device index -> host index inside the type batch (empty = identity)
     std::vector<int32_t> inv;       // host index -> device index (lazily built)
+    // (`inv` has `count` entries, never `perm.size()`: on an island layout with reserved slots perm is longer than the type batch, and a type batch that was EMPTY when a plan
+    // was built got a table of `slots` zeros here — the next addition appended its slot behind them and index 0 pointed at device slot 0, a dead one: the constraint was
+    // solved where it was, read back and updated from somewhere else. Found by tools/fuzz_structural.py 6802, scene 490, in round 6's last hour; tests/test_gpu_schedule_fuzz.py replays it.)
     int perm_inverse(int host_index) {
-        if (inv.empty()) { inv.resize(perm.size()); for (size_t d = 0; d < perm.size(); ++d) if (perm[d] >= 0) inv[perm[d]] = (int32_t)d; }
-        return inv[host_index];
+        if (inv.empty() && count > 0) { inv.assign((size_t)count, 0); for (size_t d = 0; d < perm.size(); ++d) if (perm[d] >= 0 && perm[d] < count) inv[perm[d]] = (int32_t)d; }
+        return (size_t)host_index < inv.size() ? inv[host_index] : 0;
     }
     int32_t* d_device_index = nullptr;  // device copy of `inv` for the upload, ranged update and read-back kernels: a slice of the context's index pool when built at
     bool index_pooled = false;          // end_constraints (never freed on its own), else allocated on first use

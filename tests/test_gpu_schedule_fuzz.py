@@ -90,3 +90,21 @@ def test_structural_fuzz_slice(seed, count):
         assert stats["ok"], (scene, stats["report"])
         frames += stats["frames"]
     assert frames >= 3 * count
+
+
+def test_an_addition_into_a_type_batch_that_was_empty_when_the_plan_was_built_reads_back_from_its_own_slot():
+    """tools/fuzz_structural.py 6802, scene 490 (the generator's state in front of it: tests/golden/fuzz_structural_6802_490_state.json): a Contact3 type batch loses its only
+    constraint, the context re-plans with the type batch empty (reserved slots only), the next frame adds a constraint to it. The host index -> device slot table of an
+    EMPTY type batch used to be built with one entry per device slot instead of none, so the addition's entry landed behind `slots` zeros and index 0 pointed at device slot 0:
+    the constraint was solved in its own slot and read back (and ranged-updated) from a dead one — zero prestep data, NaN impulses, bodies bit-exact as long as the contact
+    stayed inactive. HostTypeBatch::perm_inverse now sizes the table by the type batch."""
+    import json
+    import os
+    import numpy as np
+    import fuzz_util as fu
+    state = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_structural_6802_490_state.json")))
+    rng = np.random.default_rng(0)
+    rng.bit_generator.state = state
+    stats = fu.run_structural_scene(rng, jitter=0)
+    assert stats["ok"], stats["report"]
+    assert stats["replans"] >= 1 and stats["big"]
